@@ -1,0 +1,428 @@
+"""ctypes/numpy front-end of the CPU ORACLE (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The product package (gorse_amd) never does.
+
+`Oracle` wraps oracle/liboracle.so (our C restatement, gorse_oracle.c).
+`Ref` wraps oracle/_ref/libgorse_ref.so (the reference's own SIMD C kernels,
+compiled from /root/reference by oracle/Makefile) and is None-safe: on a host
+without AVX512 or without the prebuilt file, `load_ref()` returns None.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ISA_GO, ISA_AVX, ISA_AVX512 = 0, 1, 2
+METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
+M_NDCG, M_PRECISION, M_RECALL, M_HR, M_MAP, M_MRR = range(6)
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_i32p)
+
+
+def _i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(_i64p)
+
+
+def build(force=False):
+    """Compile liboracle.so (always possible) and _ref (only where /root/reference exists)."""
+    so = os.path.join(HERE, "liboracle.so")
+    src = os.path.join(HERE, "gorse_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE], stdout=subprocess.DEVNULL)
+    ref = os.path.join(HERE, "_ref", "libgorse_ref.so")
+    if os.path.isdir("/root/reference/common/floats/src") and (force or not os.path.exists(ref)):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        L = C.CDLL(os.path.join(HERE, "liboracle.so"))
+        self.L = L
+        L.orc_dot.restype = C.c_float
+        L.orc_dot.argtypes = [_f32p, _f32p, C.c_int64]
+        L.orc_euclidean.restype = C.c_float
+        L.orc_euclidean.argtypes = [_f32p, _f32p, C.c_int64]
+        L.orc_bf16_euclidean.restype = C.c_float
+        L.orc_bf16_euclidean.argtypes = [_u16p, _u16p, C.c_int64]
+        L.orc_exp.restype = C.c_float
+        L.orc_exp.argtypes = [C.c_float]
+        L.orc_exp_restated.restype = C.c_float
+        L.orc_exp_restated.argtypes = [C.c_float]
+        L.orc_distance.restype = C.c_float
+        L.orc_distance.argtypes = [C.c_int, _f32p, _f32p, C.c_int64]
+        L.orc_metric.restype = C.c_float
+        L.orc_metric.argtypes = [C.c_int, _i32p, C.c_int64, _i32p, C.c_int64]
+        L.orc_bpr_apply_triplets.restype = C.c_double
+        L.orc_bpr_apply_triplets.argtypes = [_f32p, _f32p, C.c_int64, _i32p, _i32p, _i32p, C.c_int64, C.c_float,
+                                             C.c_float]
+        L.orc_bpr_epoch_sampled.restype = C.c_double
+        L.orc_bpr_epoch_sampled.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _i32p,
+                                            C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_float, C.c_float]
+        L.orc_bpr_sample.restype = None
+        L.orc_bpr_sample.argtypes = [C.c_int64, C.c_int64, _i64p, _i32p, _i32p, C.c_uint64, C.c_uint64, C.c_int64,
+                                     C.c_int64, _i32p, _i32p, _i32p]
+        L.orc_als_epoch.restype = None
+        L.orc_als_epoch.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _i64p, _i32p,
+                                    C.c_float, C.c_float]
+        L.orc_mf_score.restype = None
+        L.orc_mf_score.argtypes = [_f32p, _f32p, C.c_int64, _i32p, _i32p, C.c_int64, _f32p]
+        L.orc_mf_rank.restype = None
+        L.orc_mf_rank.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i32p, _i64p, _i32p, C.c_int, _i32p, _i32p]
+        L.orc_evaluate.restype = None
+        L.orc_evaluate.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, _i64p, _i32p, _i64p, _i32p, C.c_int, _i32p,
+                                   C.c_int, _f32p]
+        L.orc_topk_filter.restype = C.c_int
+        L.orc_topk_filter.argtypes = [C.c_int, C.c_int64, _i32p, _f32p, _i32p, _f32p]
+        L.orc_pq_sort.restype = C.c_int
+        L.orc_pq_sort.argtypes = [C.c_int, C.c_int64, _i32p, _f32p, _i32p, _f32p]
+        L.orc_bruteforce_select.restype = C.c_int
+        L.orc_bruteforce_select.argtypes = [C.c_int64, _f32p, C.c_int64, C.c_int, C.c_int, _i32p, _f32p]
+        L.orc_bruteforce_search_index.restype = C.c_int
+        L.orc_bruteforce_search_index.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                                  _i32p, _f32p]
+        L.orc_bruteforce_search_vector.restype = C.c_int
+        L.orc_bruteforce_search_vector.argtypes = [_f32p, C.c_int64, C.c_int64, C.c_int, _f32p, C.c_int, C.c_int,
+                                                   _i32p, _f32p]
+        L.orc_philox4x32_10.restype = None
+        L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        L.orc_mm.restype = None
+        L.orc_mm.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _f32p, C.c_int64, _f32p, C.c_int64,
+                             _f32p, C.c_int64]
+
+    # ---- configuration -------------------------------------------------
+    def set_isa(self, isa):
+        self.L.orc_set_isa(int(isa))
+
+    def set_exp(self, mode):
+        self.L.orc_set_exp(int(mode))
+
+    # ---- floats --------------------------------------------------------
+    def dot(self, a, b):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        assert a.size == b.size
+        return float(np.float32(self.L.orc_dot(pa, pb, a.size)))
+
+    def euclidean(self, a, b):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        return float(np.float32(self.L.orc_euclidean(pa, pb, a.size)))
+
+    def _vec(self, name, *args):
+        getattr(self.L, name)(*args)
+
+    def mul_const_add(self, a, c, dst):
+        a, pa = _f32(a)
+        dst = np.array(dst, dtype=np.float32)
+        self.L.orc_mul_const_add.argtypes = [_f32p, C.c_float, _f32p, C.c_int64]
+        self.L.orc_mul_const_add(pa, c, dst.ctypes.data_as(_f32p), a.size)
+        return dst
+
+    def mul_const_add_to(self, a, b, c):
+        a, pa = _f32(a)
+        c, pc = _f32(c)
+        dst = np.zeros_like(a)
+        self.L.orc_mul_const_add_to.argtypes = [_f32p, C.c_float, _f32p, _f32p, C.c_int64]
+        self.L.orc_mul_const_add_to(pa, b, pc, dst.ctypes.data_as(_f32p), a.size)
+        return dst
+
+    def mul_const_to(self, a, b):
+        a, pa = _f32(a)
+        dst = np.zeros_like(a)
+        self.L.orc_mul_const_to.argtypes = [_f32p, C.c_float, _f32p, C.c_int64]
+        self.L.orc_mul_const_to(pa, b, dst.ctypes.data_as(_f32p), a.size)
+        return dst
+
+    def sub_to(self, a, b):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        dst = np.zeros_like(a)
+        self.L.orc_sub_to.argtypes = [_f32p, _f32p, _f32p, C.c_int64]
+        self.L.orc_sub_to(pa, pb, dst.ctypes.data_as(_f32p), a.size)
+        return dst
+
+    def mm(self, transA, transB, m, n, k, a, lda, b, ldb, c, ldc):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        c = np.array(c, dtype=np.float32)
+        self.L.orc_mm(int(transA), int(transB), m, n, k, pa, lda, pb, ldb, c.ctypes.data_as(_f32p), ldc)
+        return c
+
+    # ---- bf16 ----------------------------------------------------------
+    def bf16_from_f32(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        out = np.zeros(a.shape, dtype=np.uint16)
+        self.L.orc_bf16_from_f32.argtypes = [_f32p, _u16p, C.c_int64]
+        self.L.orc_bf16_from_f32(a.ctypes.data_as(_f32p), out.ctypes.data_as(_u16p), a.size)
+        return out
+
+    def bf16_to_f32(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint16)
+        out = np.zeros(a.shape, dtype=np.float32)
+        self.L.orc_bf16_to_f32.argtypes = [_u16p, _f32p, C.c_int64]
+        self.L.orc_bf16_to_f32(a.ctypes.data_as(_u16p), out.ctypes.data_as(_f32p), a.size)
+        return out
+
+    def bf16_euclidean(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint16)
+        b = np.ascontiguousarray(b, dtype=np.uint16)
+        return float(np.float32(self.L.orc_bf16_euclidean(a.ctypes.data_as(_u16p), b.ctypes.data_as(_u16p), a.size)))
+
+    # ---- heaps ---------------------------------------------------------
+    def topk_filter(self, k, items, weights):
+        items, pi = _i32(items)
+        weights, pw = _f32(weights)
+        oi = np.zeros(max(k, 1), dtype=np.int32)
+        ow = np.zeros(max(k, 1), dtype=np.float32)
+        n = self.L.orc_topk_filter(k, items.size, pi, pw, oi.ctypes.data_as(_i32p), ow.ctypes.data_as(_f32p))
+        return oi[:n].copy(), ow[:n].copy()
+
+    def pq_sort(self, desc, items, weights):
+        items, pi = _i32(items)
+        weights, pw = _f32(weights)
+        oi = np.zeros(items.size + 1, dtype=np.int32)
+        ow = np.zeros(items.size + 1, dtype=np.float32)
+        n = self.L.orc_pq_sort(int(desc), items.size, pi, pw, oi.ctypes.data_as(_i32p), ow.ctypes.data_as(_f32p))
+        return oi[:n].copy(), ow[:n].copy()
+
+    def bruteforce_select(self, dist, skip, k, prune0=False):
+        dist, pd = _f32(dist)
+        oi = np.zeros(k + 1, dtype=np.int32)
+        ow = np.zeros(k + 1, dtype=np.float32)
+        n = self.L.orc_bruteforce_select(dist.size, pd, skip, k, int(prune0), oi.ctypes.data_as(_i32p),
+                                         ow.ctypes.data_as(_f32p))
+        return oi[:n].copy(), ow[:n].copy()
+
+    def search_index(self, X, metric, q, k, prune0=False):
+        X, px = _f32(X)
+        n, d = X.shape
+        oi = np.zeros(k + 1, dtype=np.int32)
+        ow = np.zeros(k + 1, dtype=np.float32)
+        cnt = self.L.orc_bruteforce_search_index(px, n, d, metric, q, k, int(prune0), oi.ctypes.data_as(_i32p),
+                                                 ow.ctypes.data_as(_f32p))
+        if cnt < 0:
+            raise IndexError("index out of range: %d" % q)
+        return oi[:cnt].copy(), ow[:cnt].copy()
+
+    def search_vector(self, X, metric, qv, k, prune0=False):
+        X, px = _f32(X)
+        qv, pq = _f32(qv)
+        n, d = X.shape
+        oi = np.zeros(k + 1, dtype=np.int32)
+        ow = np.zeros(k + 1, dtype=np.float32)
+        cnt = self.L.orc_bruteforce_search_vector(px, n, d, metric, pq, k, int(prune0), oi.ctypes.data_as(_i32p),
+                                                  ow.ctypes.data_as(_f32p))
+        return oi[:cnt].copy(), ow[:cnt].copy()
+
+    def distance(self, metric, a, b):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        return float(np.float32(self.L.orc_distance(metric, pa, pb, a.size)))
+
+    # ---- rng / sampling --------------------------------------------------
+    def philox(self, ctr, key):
+        ctr = np.ascontiguousarray(ctr, dtype=np.uint32)
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        out = np.zeros(4, dtype=np.uint32)
+        self.L.orc_philox4x32_10(ctr.ctypes.data_as(_u32p), key.ctypes.data_as(_u32p), out.ctypes.data_as(_u32p))
+        return out
+
+    def bpr_sample(self, U, I, indptr, indices, n, seed, epoch, sample_base=0, sorted_indices=None):
+        indptr, pp = _i64(indptr)
+        indices, pi = _i32(indices)
+        if sorted_indices is None:
+            sorted_indices = sort_rows(indptr, indices)
+        sorted_indices, ps = _i32(sorted_indices)
+        u = np.zeros(n, dtype=np.int32)
+        i = np.zeros(n, dtype=np.int32)
+        j = np.zeros(n, dtype=np.int32)
+        self.L.orc_bpr_sample(U, I, pp, pi, ps, seed, epoch, sample_base, n, u.ctypes.data_as(_i32p),
+                              i.ctypes.data_as(_i32p), j.ctypes.data_as(_i32p))
+        return u, i, j
+
+    # ---- BPR / ALS -------------------------------------------------------
+    def bpr_apply_triplets(self, P, Q, u, i, j, lr, reg):
+        """Sequential (Jobs=1) SGD over the triplet stream; returns new (P, Q, cost)."""
+        P = np.array(P, dtype=np.float32, order="C")
+        Q = np.array(Q, dtype=np.float32, order="C")
+        u, pu = _i32(u)
+        i, pi = _i32(i)
+        j, pj = _i32(j)
+        cost = self.L.orc_bpr_apply_triplets(P.ctypes.data_as(_f32p), Q.ctypes.data_as(_f32p), P.shape[1], pu, pi, pj,
+                                             u.size, lr, reg)
+        return P, Q, cost
+
+    def bpr_epoch_sampled(self, P, Q, indptr, indices, sorted_indices, seed, epoch, sample_base, n, lr, reg):
+        """In-place epoch (P, Q must be C-contiguous float32); used by tests and the cpu_baseline leg."""
+        assert P.dtype == np.float32 and Q.dtype == np.float32 and P.flags.c_contiguous and Q.flags.c_contiguous
+        indptr, pp = _i64(indptr)
+        indices, pi = _i32(indices)
+        sorted_indices, ps = _i32(sorted_indices)
+        return self.L.orc_bpr_epoch_sampled(P.ctypes.data_as(_f32p), Q.ctypes.data_as(_f32p), P.shape[0], Q.shape[0],
+                                            P.shape[1], pp, pi, ps, seed, epoch, sample_base, n, lr, reg)
+
+    def als_epoch(self, P, Q, uptr, uidx, iptr, iidx, w, reg):
+        P = np.array(P, dtype=np.float32, order="C")
+        Q = np.array(Q, dtype=np.float32, order="C")
+        uptr, a = _i64(uptr)
+        uidx, b = _i32(uidx)
+        iptr, c = _i64(iptr)
+        iidx, d = _i32(iidx)
+        self.L.orc_als_epoch(P.ctypes.data_as(_f32p), Q.ctypes.data_as(_f32p), P.shape[0], Q.shape[0], P.shape[1], a,
+                             b, c, d, w, reg)
+        return P, Q
+
+    # ---- predict / evaluate ------------------------------------------------
+    def mf_score(self, P, Q, u, i):
+        P, pP = _f32(P)
+        Q, pQ = _f32(Q)
+        u, pu = _i32(u)
+        i, pi = _i32(i)
+        out = np.zeros(u.size, dtype=np.float32)
+        self.L.orc_mf_score(pP, pQ, P.shape[1], pu, pi, u.size, out.ctypes.data_as(_f32p))
+        return out
+
+    def mf_rank(self, P, Q, users, cand_ptr, cand, topk):
+        P, pP = _f32(P)
+        Q, pQ = _f32(Q)
+        users, pu = _i32(users)
+        cand_ptr, pp = _i64(cand_ptr)
+        cand, pc = _i32(cand)
+        rank = np.full((users.size, topk), -1, dtype=np.int32)
+        rlen = np.zeros(users.size, dtype=np.int32)
+        self.L.orc_mf_rank(pP, pQ, P.shape[1], users.size, pu, pp, pc, topk, rank.ctypes.data_as(_i32p),
+                           rlen.ctypes.data_as(_i32p))
+        return rank, rlen
+
+    def metric(self, m, target, rank):
+        target, pt = _i32(target)
+        rank, pr = _i32(rank)
+        return float(np.float32(self.L.orc_metric(m, pt, target.size, pr, rank.size)))
+
+    def evaluate(self, P, Q, test_ptr, test_idx, neg_ptr, neg_idx, topk, metrics=(M_NDCG, M_PRECISION, M_RECALL)):
+        P, pP = _f32(P)
+        Q, pQ = _f32(Q)
+        test_ptr, a = _i64(test_ptr)
+        test_idx, b = _i32(test_idx)
+        neg_ptr, c = _i64(neg_ptr)
+        neg_idx, d = _i32(neg_idx)
+        metrics, pm = _i32(list(metrics))
+        out = np.zeros(metrics.size, dtype=np.float32)
+        self.L.orc_evaluate(pP, pQ, P.shape[1], P.shape[0], a, b, c, d, topk, pm, metrics.size,
+                            out.ctypes.data_as(_f32p))
+        return out
+
+
+def sort_rows(indptr, indices):
+    """Each CSR row sorted ascending (membership structure of the BPR negative sampler)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int32)
+    rows = np.repeat(np.arange(indptr.size - 1, dtype=np.int64), np.diff(indptr))
+    order = np.lexsort((indices, rows))
+    return np.ascontiguousarray(indices[order])
+
+
+class Ref:
+    """The reference's own C kernels (oracle/_ref/libgorse_ref.so)."""
+
+    def __init__(self, path):
+        L = C.CDLL(path)
+        self.L = L
+        for isa in ("_mm512", "_mm256"):
+            getattr(L, isa + "_dot").restype = C.c_float
+            getattr(L, isa + "_dot").argtypes = [_f32p, _f32p, C.c_int64]
+            getattr(L, isa + "_euclidean").restype = C.c_float
+            getattr(L, isa + "_euclidean").argtypes = [_f32p, _f32p, C.c_int64]
+            getattr(L, isa + "_euclidean_bf16").restype = C.c_float
+            getattr(L, isa + "_euclidean_bf16").argtypes = [_u16p, _u16p, C.c_int64]
+            getattr(L, isa + "_mul_const_add").argtypes = [_f32p, _f32p, _f32p, C.c_int64]
+            getattr(L, isa + "_mul_const_add_to").argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int64]
+            getattr(L, isa + "_mul_const_to").argtypes = [_f32p, _f32p, _f32p, C.c_int64]
+            getattr(L, isa + "_sub_to").argtypes = [_f32p, _f32p, _f32p, C.c_int64]
+            getattr(L, isa + "_mm").argtypes = [C.c_bool, C.c_bool, C.c_int64, C.c_int64, C.c_int64, _f32p, C.c_int64,
+                                                _f32p, C.c_int64, _f32p, C.c_int64]
+
+    @staticmethod
+    def _p(isa):
+        return "_mm512" if isa == ISA_AVX512 else "_mm256"
+
+    def dot(self, isa, a, b):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        return float(np.float32(getattr(self.L, self._p(isa) + "_dot")(pa, pb, a.size)))
+
+    def euclidean(self, isa, a, b):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        return float(np.float32(getattr(self.L, self._p(isa) + "_euclidean")(pa, pb, a.size)))
+
+    def euclidean_bf16(self, isa, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint16)
+        b = np.ascontiguousarray(b, dtype=np.uint16)
+        return float(np.float32(getattr(self.L, self._p(isa) + "_euclidean_bf16")(
+            a.ctypes.data_as(_u16p), b.ctypes.data_as(_u16p), a.size)))
+
+    def mul_const_add(self, isa, a, c, dst):
+        a, pa = _f32(a)
+        dst = np.array(dst, dtype=np.float32)
+        cc = C.c_float(c)
+        getattr(self.L, self._p(isa) + "_mul_const_add")(pa, C.cast(C.byref(cc), _f32p), dst.ctypes.data_as(_f32p),
+                                                         a.size)
+        return dst
+
+    def mul_const_add_to(self, isa, a, b, c):
+        a, pa = _f32(a)
+        c, pc = _f32(c)
+        dst = np.zeros_like(a)
+        bb = C.c_float(b)
+        getattr(self.L, self._p(isa) + "_mul_const_add_to")(pa, C.cast(C.byref(bb), _f32p), pc,
+                                                            dst.ctypes.data_as(_f32p), a.size)
+        return dst
+
+    def mm(self, isa, transA, transB, m, n, k, a, lda, b, ldb, c, ldc):
+        a, pa = _f32(a)
+        b, pb = _f32(b)
+        c = np.array(c, dtype=np.float32)
+        getattr(self.L, self._p(isa) + "_mm")(bool(transA), bool(transB), m, n, k, pa, lda, pb, ldb,
+                                              c.ctypes.data_as(_f32p), ldc)
+        return c
+
+
+def _cpu_has(flag):
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return flag in line.split()
+    except OSError:
+        pass
+    return False
+
+
+def load_ref():
+    """The compiled reference kernels, or None (file absent / host lacks AVX512F+FMA)."""
+    path = os.path.join(HERE, "_ref", "libgorse_ref.so")
+    if not os.path.exists(path):
+        return None
+    if not (_cpu_has("avx512f") and _cpu_has("avx512bw") and _cpu_has("fma") and _cpu_has("avx2")):
+        return None
+    return Ref(path)

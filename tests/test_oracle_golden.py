@@ -1,0 +1,207 @@
+"""Pin the CPU oracle: (1) the reference's own known-answer tests, (2) bit-equality
+with the reference's SIMD C kernels (committed fixture + live oracle/_ref when present),
+(3) published Philox4x32-10 known-answer vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KATS = json.load(open(os.path.join(GOLD, "reference_kats.json")))
+ALL_ISA = [orc.ISA_GO, orc.ISA_AVX, orc.ISA_AVX512]
+
+
+@pytest.fixture(autouse=True)
+def _reset(oracle):
+    oracle.set_isa(orc.ISA_AVX512)
+    oracle.set_exp(0)
+    yield
+    oracle.set_isa(orc.ISA_AVX512)
+    oracle.set_exp(0)
+
+
+@pytest.mark.parametrize("isa", ALL_ISA)
+def test_floats_kats(oracle, isa):
+    # common/floats/floats_test.go:58-179 -- integers, so every ISA path is exact
+    oracle.set_isa(isa)
+    f = KATS["floats"]
+    assert oracle.mul_const_to(f["mul_const_to"]["a"], f["mul_const_to"]["c"]).tolist() == f["mul_const_to"]["out"]
+    k = f["mul_const_add"]
+    assert oracle.mul_const_add(k["a"], k["c"], k["dst"]).tolist() == k["out"]
+    k = f["mul_const_add_to"]
+    assert oracle.mul_const_add_to(k["a"], k["b"], k["c"]).tolist() == k["out"]
+    k = f["sub_to"]
+    assert oracle.sub_to(k["a"], k["b"]).tolist() == k["out"]
+    assert oracle.dot(f["dot"]["a"], f["dot"]["b"]) == f["dot"]["out"]
+    assert np.float32(oracle.euclidean(f["euclidean"]["a"], f["euclidean"]["b"])) == np.float32(f["euclidean"]["out"])
+
+
+@pytest.mark.parametrize("isa", ALL_ISA)
+def test_mm_kats(oracle, isa):
+    # floats_test.go:279-301, 425-447
+    oracle.set_isa(isa)
+    mm = KATS["floats"]["mm"]
+    for c in mm["cases"]:
+        out = oracle.mm(c["transA"], c["transB"], c["m"], c["n"], c["k"], mm["a"], c["lda"], mm["b"], c["ldb"],
+                        np.zeros(8, np.float32), c["ldc"])
+        assert out.tolist() == c["out"]
+
+
+@pytest.mark.parametrize("isa", ALL_ISA)
+def test_bfloats_kats(oracle, isa):
+    # common/bfloats/bfloats_test.go:23-28 ; truncation bfloats.go:24-30
+    oracle.set_isa(isa)
+    k = KATS["bfloats"]["euclidean"]
+    a = oracle.bf16_from_f32(k["a"])
+    b = oracle.bf16_from_f32(k["b"])
+    assert np.float32(oracle.bf16_euclidean(a, b)) == np.float32(k["out"])
+    x = np.array([0.1, 0.2, 0.3, -1.7, 3.1415927], np.float32)
+    assert oracle.bf16_from_f32(x).tolist() == (x.view(np.uint32) >> 16).tolist()
+    assert oracle.bf16_to_f32(oracle.bf16_from_f32(x)).view(np.uint32).tolist() == \
+        ((x.view(np.uint32) >> 16) << 16).tolist()
+
+
+def test_heap_kats(oracle):
+    # common/heap/filter_test.go:22-45, pq_test.go:28-61
+    for k in KATS["heap"]["topk_filter"]:
+        v, w = oracle.topk_filter(k["k"], k["items"], k["weights"])
+        assert v.tolist() == k["values"] and w.tolist() == k["out_weights"]
+    pq = KATS["heap"]["priority_queue"]
+    e = pq["elements"]
+    v, w = oracle.pq_sort(False, e, e)
+    assert v.tolist() == pq["asc"] and w.tolist() == pq["asc"]
+    v, w = oracle.pq_sort(True, e, e)
+    assert v.tolist() == pq["desc"]
+
+
+def test_metric_kats(oracle):
+    # model/cf/evaluator_test.go:33-74
+    m = KATS["metrics"]
+    ids = {"ndcg": orc.M_NDCG, "precision": orc.M_PRECISION, "recall": orc.M_RECALL, "hr": orc.M_HR,
+           "map": orc.M_MAP, "mrr": orc.M_MRR}
+    for c in m["cases"]:
+        assert abs(oracle.metric(ids[c["metric"]], c["target"], m["rank"]) - c["out"]) < m["epsilon"]
+
+
+def test_evaluate_kat(oracle):
+    # model/cf/evaluator_test.go:137-171: mock scores expressed as rank-1 factors is impossible,
+    # so run Rank/Precision through the same TopKFilter path on the mock's score table.
+    e = KATS["evaluate"]
+    total = np.float32(0)
+    for u in range(4):
+        test_items = [i for i in range(16) if i // 4 == u]
+        negs = [i for i in range(16) if i // 4 != u]       # SampleUserNegatives with n >= range
+        cand = test_items + negs
+        score = [1.0 if i in e["positive"][u] else (-1.0 if i in e["negative"][u] else 0.0) for i in cand]
+        rank, _ = oracle.topk_filter(e["topk"], cand, score)
+        total += np.float32(oracle.metric(orc.M_PRECISION, test_items, rank))
+    assert np.float32(total * np.float32(1 / np.float32(4))) == np.float32(e["precision"])
+
+
+def test_mf_items_search_kat(oracle):
+    # logics/cf_test.go:26-58 with distance = -floats.Dot (logics/cf.go:32-34)
+    k = KATS["mf_items_search"]
+    X = np.array(k["vectors"], np.float32)
+    idx, dist = oracle.search_vector(X, orc.METRIC_NEG_DOT, k["query"], k["k"])
+    got = [[k["ids"][i], float(-d)] for i, d in zip(idx, dist)]
+    assert got == k["out"]
+
+
+def _check_fixture(oracle, getter):
+    z = np.load(os.path.join(GOLD, "ref_simd_vectors.npz"))
+    off = 0
+    for t, n in enumerate(z["lengths"]):
+        n = int(n)
+        a, b, c = z["a"][off:off + n], z["b"][off:off + n], z["c"][off:off + n]
+        s = float(z["s"][t])
+        exp = getter(z, t, off, n)
+        for isa, keys in ((orc.ISA_AVX512, ("dot512", "euc512", "bfeuc512", "mca512")),
+                          (orc.ISA_AVX, ("dot256", "euc256", "bfeuc256", "mca256"))):
+            oracle.set_isa(isa)
+            if n > 0:
+                assert np.float32(oracle.dot(a, b)).view(np.uint32) == exp[keys[0]].view(np.uint32), (n, isa)
+                assert np.float32(oracle.euclidean(a, b)).view(np.uint32) == exp[keys[1]].view(np.uint32), (n, isa)
+                ab = (a.view(np.uint32) >> 16).astype(np.uint16)
+                bb = (b.view(np.uint32) >> 16).astype(np.uint16)
+                assert np.float32(oracle.bf16_euclidean(ab, bb)).view(np.uint32) == exp[keys[2]].view(np.uint32), (n, isa)
+            assert np.array_equal(oracle.mul_const_add(a, s, c).view(np.uint32), exp[keys[3]].view(np.uint32)), (n, isa)
+        oracle.set_isa(orc.ISA_AVX512)
+        assert np.array_equal(oracle.mul_const_add_to(a, s, c).view(np.uint32), exp["mcat512"].view(np.uint32))
+        off += n
+
+
+def test_bit_equal_to_reference_kernels_fixture(oracle):
+    """Oracle == the reference's compiled C kernels, bit for bit (fixture made by
+    scripts/gen_golden_ref_vectors.py from /root/reference)."""
+    def getter(z, t, off, n):
+        d = {k: z[k][t] for k in ("dot512", "dot256", "euc512", "euc256", "bfeuc512", "bfeuc256")}
+        d["mca512"] = z["mca512"][off:off + n]
+        d["mca256"] = z["mca256"][off:off + n]
+        d["mcat512"] = z["mcat512"][off:off + n]
+        return d
+    _check_fixture(oracle, getter)
+
+
+def test_mm_bit_equal_fixture(oracle):
+    z = np.load(os.path.join(GOLD, "ref_simd_vectors.npz"))
+    oa = ob = oc = 0
+    for (m, n, k, tA, tB) in z["mm_shapes"]:
+        m, n, k = int(m), int(n), int(k)
+        a = z["mm_a"][oa:oa + m * k]
+        b = z["mm_b"][ob:ob + n * k]
+        c0 = z["mm_c0"][oc:oc + m * n]
+        lda = m if tA else k
+        ldb = k if tB else n
+        for isa, key in ((orc.ISA_AVX512, "mm_c512"), (orc.ISA_AVX, "mm_c256")):
+            oracle.set_isa(isa)
+            got = oracle.mm(tA, tB, m, n, k, a, lda, b, ldb, c0, n)
+            assert np.array_equal(got.view(np.uint32), z[key][oc:oc + m * n].view(np.uint32)), (m, n, k, tA, tB, isa)
+        oa += m * k
+        ob += n * k
+        oc += m * n
+
+
+def test_bit_equal_to_live_reference_kernels(oracle, ref):
+    """Same check against oracle/_ref run live, on fresh random data."""
+    if ref is None:
+        pytest.skip("oracle/_ref/libgorse_ref.so absent or host lacks AVX512")
+    rng = np.random.default_rng(7)
+    for n in list(range(1, 140)) + [255, 256, 257]:
+        a = rng.standard_normal(n).astype(np.float32)
+        b = rng.standard_normal(n).astype(np.float32)
+        for isa in (orc.ISA_AVX, orc.ISA_AVX512):
+            oracle.set_isa(isa)
+            assert np.float32(oracle.dot(a, b)).view(np.uint32) == np.float32(ref.dot(isa, a, b)).view(np.uint32)
+            assert np.float32(oracle.euclidean(a, b)).view(np.uint32) == \
+                np.float32(ref.euclidean(isa, a, b)).view(np.uint32)
+
+
+def test_simd_equals_scalar_on_integers(oracle):
+    # the reference's SIMDTestSuite (floats_test.go:307-423): every ISA == pure Go on small integers
+    a = np.arange(20, dtype=np.float32)
+    b = np.arange(20, dtype=np.float32) * 2
+    outs = []
+    for isa in ALL_ISA:
+        oracle.set_isa(isa)
+        outs.append((oracle.dot(a, b), oracle.euclidean(a, b), oracle.mul_const_add(a, 2.0, b).tolist()))
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_philox_kat(oracle):
+    # Random123 kat_vectors, philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11)
+    assert oracle.philox([0, 0, 0, 0], [0, 0]).tolist() == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle.philox([0xffffffff] * 4, [0xffffffff] * 2).tolist() == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]).tolist() == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_exp_restated_close_to_libm(oracle):
+    xs = np.linspace(-20, 20, 4001).astype(np.float32)
+    for x in xs:
+        r = oracle.L.orc_exp_restated(float(x))
+        e = np.exp(np.float64(x))
+        assert abs(r - e) <= 2e-7 * e
