@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR positive-samples/s (and item x item top-k pairs/s) on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  A "step" is one BPR epoch = CountFeedback()
+SGD samples over one rank's resident dataset (model/cf/model.go:446-494).  Rank 0 prints ONE
+JSON line.
+
+Workloads (BASELINE.json configs):
+  ml1m   (default) C2: S-ml1m shape 6040 x 3706 x 994,169, nFactors 64, fp32.  With N ranks every
+         rank trains its own S-ml1m-shaped USER SHARD against the shared item matrix (weak scaling:
+         N*6040 users), Q replicated, one all-reduce of the item-factor delta per epoch over RCCL.
+  c3     C3 shard: 125,000 users x 200,000 items x 12.5M feedbacks per rank, nFactors 128 (at N = 8
+         this is exactly the 1M x 200K x 100M configuration).
+Timed region: inputs resident in HBM, barrier + device sync on both sides, MAX over ranks.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: libgorse_hip then binds to the HIP runtime torch already loaded)
+import torch.distributed as dist  # noqa: E402
+
+from gorse_amd import capi, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k"])
+    ap.add_argument("--mode", type=int, default=capi.BPR_HOGWILD_ATOMIC)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_data(workload, rank):
+    if workload == "ml1m":
+        data = synth.synth_cf(6040, 3706, 994169, seed=42 + 1000 * rank, min_len=19, n_neg=99, with_test=False)
+        return data, 64, "S-ml1m 6040x3706x994169 per rank (C2), nFactors=64"
+    if workload == "ml100k":
+        data = synth.synth_cf(943, 1682, 99057, seed=42 + 1000 * rank, min_len=19, n_neg=99, with_test=False)
+        return data, 16, "S-ml100k 943x1682x99057 per rank (C1), nFactors=16"
+    data = synth.s_big_shard(rank=rank, world=8)
+    return data, 128, "S-big shard 125000x200000x12.5M per rank (C3/8), nFactors=128"
+
+
+def cpu_baseline(data, d, lr, reg, seconds):
+    """The oracle's BPR epoch (kind 'port': our C restatement of model.go:446-494, auto-vectorised
+    build) timed on this host: Hogwild over T threads sharing P, Q -- like parallel.Parallel with
+    Jobs = T but without the per-sample channel hop, so an upper bound for the Go path."""
+    from oracle import oracle as orc
+    orc.build()
+    fast = os.path.join("/tmp", "liboracle_fast_%d.so" % os.getuid())
+    src = os.path.join(ROOT, "oracle", "gorse_oracle.c")
+    if not os.path.exists(fast) or os.path.getmtime(fast) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu11", "-fPIC", "-shared", "-o", fast, src, "-lm"])
+    L = ctypes.CDLL(fast)
+    f32p, i32p, i64p = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+    L.orc_bpr_epoch_sampled.restype = ctypes.c_double
+    L.orc_bpr_epoch_sampled.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, i64p, i32p, i32p,
+                                        ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_float, ctypes.c_float]
+    P, Q = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
+    srt = orc.sort_rows(data.uptr, data.uidx)
+    uptr = np.ascontiguousarray(data.uptr, np.int64)
+    uidx = np.ascontiguousarray(data.uidx, np.int32)
+    threads = min(os.cpu_count() or 1, 32)
+
+    def run(n_per_thread, epoch):
+        def work(t):
+            L.orc_bpr_epoch_sampled(P.ctypes.data_as(f32p), Q.ctypes.data_as(f32p), data.U, data.I, d,
+                                    uptr.ctypes.data_as(i64p), uidx.ctypes.data_as(i32p), srt.ctypes.data_as(i32p), 1,
+                                    epoch, t * n_per_thread, n_per_thread, lr, reg)
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
+
+    probe = 50_000
+    dt = run(probe, 0)
+    rate = probe * threads / dt
+    n = int(max(probe, min(rate * seconds / threads, 50_000_000)))
+    dt = run(n, 1)
+    return {"value": n * threads / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d samples (%d per thread x %d Hogwild threads) of the same workload, %.1f s; "
+                      "oracle/gorse_oracle.c built -O3 -march=native" % (n * threads, n, threads, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+    torch.cuda.set_device(local)
+
+    data, d, desc = make_data(args.workload, rank)
+    lr, reg = 0.05, 0.01
+    n_samples = data.n_train
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, device=local)
+    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, seed=1)  # same Q on every rank
+    if world > 1:
+        P0 = synth.init_factors(data.U, 1, d, 0.0, 0.001, seed=100 + rank)[0]
+    mf.set_factors(P0, Q0)
+    xbuf = None
+    if world > 1:
+        xbuf = torch.empty(data.I * d, dtype=torch.float32, device="cuda")
+        mf.item_sync_mark()
+        mf.synchronize()
+
+    def step(epoch):
+        mf.bpr_epoch_enqueue(n_samples, lr, reg, 2024, epoch, sample_base=rank * (1 << 40), mode=args.mode)
+        if world > 1:  # exchange step: Q <- Q_sync + sum over ranks of (Q - Q_sync)
+            mf.item_delta_export(xbuf.data_ptr())
+            dist.all_reduce(xbuf)
+            torch.cuda.synchronize()
+            mf.item_delta_import(xbuf.data_ptr())
+
+    def fence():
+        mf.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w + 1)
+    fence()
+    mf.set_profiling(True)
+    mf.reset_profile()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s + 1)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    launches, upd_ms = mf.get_profile(capi.PROF_BPR_UPDATE)
+    s_launches, smp_ms = mf.get_profile(capi.PROF_BPR_SAMPLE)
+    mf.set_profiling(False)
+    P, Q = mf.get_factors()
+    finite = bool(np.isfinite(P).all() and np.isfinite(Q).all())
+
+    if rank == 0:
+        bytes_per_sample = 6 * d * 4 + 12  # three rows read + three written + indices
+        samples_per_launch = args.steps * n_samples / max(launches, 1)
+        avg_ms = upd_ms / max(launches, 1)
+        achieved = samples_per_launch * bytes_per_sample / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "BPR positive-samples/sec (whole job, N GPUs)",
+            "value": world * n_samples * args.steps / dt,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "samples_per_step_per_gpu": n_samples, "lr": lr, "reg": reg,
+                       "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode],
+                       "parallelism": "users sharded x%d, item factors replicated, 1 all-reduce(I*d fp32)/epoch" % world
+                       if world > 1 else "single GPU", "factors_finite": finite},
+            "roofline": {"bound": "hbm", "kernel": "bpr_update_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": avg_ms,
+                         "launches": launches, "sampler_avg_ms": smp_ms / max(s_launches, 1),
+                         "note": "working set %.1f MB" % ((data.U + data.I) * d * 4 / 1e6)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(data, d, lr, reg, args.cpu_seconds)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,290 @@
+"""ctypes binding of the C ABI in include/gorse_hip.h (libgorse_hip.so).
+
+This is plumbing: every entry point of the header is declared here with its exact
+signature, plus thin numpy-friendly wrappers (`MF`, `TopK`).  There is NO CPU fallback:
+if the shared library is missing, or no gfx950 device is visible when a handle is
+created, the call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgorse_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE, ERR_RANGE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
+BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY = 0, 1, 2
+DTYPE_F32, DTYPE_BF16 = 0, 1
+METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
+PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM = 0, 1, 2, 3
+PROF_TOPK_SCORE, PROF_TOPK_RESCORE = 0, 1
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/gorse_hip.h one to one
+SIGNATURES = {
+    "gorse_hip_abi_version": (C.c_int32, []),
+    "gorse_hip_last_error": (C.c_char_p, []),
+    "gorse_hip_device_count": (C.c_int32, [_i32p]),
+    "gorse_mf_create": (C.c_int32, [C.POINTER(_vp), C.c_int32, C.c_int64, C.c_int64, C.c_int32, _i64p, _i32p, _i64p, _i32p]),
+    "gorse_mf_destroy": (C.c_int32, [_vp]),
+    "gorse_mf_set_factors": (C.c_int32, [_vp, _f32p, _f32p]),
+    "gorse_mf_get_factors": (C.c_int32, [_vp, _f32p, _f32p]),
+    "gorse_mf_score": (C.c_int32, [_vp, _i32p, _i32p, C.c_int64, _f32p]),
+    "gorse_mf_rank": (C.c_int32, [_vp, C.c_int64, _i32p, _i64p, _i32p, C.c_int32, _i32p, _i32p]),
+    "gorse_bpr_epoch": (C.c_int32, [_vp, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
+                                    _i32p, _f64p]),
+    "gorse_bpr_epoch_enqueue": (C.c_int32, [_vp, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int64,
+                                            C.c_int32]),
+    "gorse_bpr_sample_triplets": (C.c_int32, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
+    "gorse_bpr_apply_triplets": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float, C.c_int32]),
+    "gorse_als_epoch": (C.c_int32, [_vp, C.c_float, C.c_float, _i32p]),
+    "gorse_mf_item_sync_mark": (C.c_int32, [_vp]),
+    "gorse_mf_item_delta_export": (C.c_int32, [_vp, _vp]),
+    "gorse_mf_item_delta_import": (C.c_int32, [_vp, _vp]),
+    "gorse_mf_device_ptrs": (C.c_int32, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "gorse_mf_synchronize": (C.c_int32, [_vp]),
+    "gorse_mf_set_profiling": (C.c_int32, [_vp, C.c_int32]),
+    "gorse_mf_get_profile": (C.c_int32, [_vp, C.c_int32, _i64p, _f64p]),
+    "gorse_mf_reset_profile": (C.c_int32, [_vp]),
+    "gorse_topk_create": (C.c_int32, [C.POINTER(_vp), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    "gorse_topk_destroy": (C.c_int32, [_vp]),
+    "gorse_topk_search_index": (C.c_int32, [_vp, _i64p, C.c_int64, C.c_int32, C.c_int32, _i32p, _f32p, _i32p]),
+    "gorse_topk_search_vector": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, _i32p, _f32p, _i32p]),
+    "gorse_topk_all_pairs": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int32, _i32p, _f32p]),
+    "gorse_topk_synchronize": (C.c_int32, [_vp]),
+    "gorse_topk_set_profiling": (C.c_int32, [_vp, C.c_int32]),
+    "gorse_topk_get_profile": (C.c_int32, [_vp, C.c_int32, _i64p, _f64p]),
+    "gorse_topk_last_stats": (C.c_int32, [_vp, _i64p, _i64p]),
+    "gorse_hip_sgemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_int32,
+                                    _f32p, C.c_int32, _f32p, C.c_int32]),
+    "gorse_hip_test_set_exact_exp": (None, [C.c_int32]),
+}
+
+
+class GorseHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libgorse_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libgorse_hip.so (once). Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP extension is mandatory; there is no CPU path)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise GorseHipError(rc, lib().gorse_hip_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int32(0)
+    rc = lib().gorse_hip_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class MF:
+    """One gorse_mf handle (one model resident on one GPU)."""
+
+    def __init__(self, U, I, d, user_indptr, user_indices, item_indptr=None, item_indices=None, device=0):
+        self.U, self.I, self.d = int(U), int(I), int(d)
+        up, ui = _arr(user_indptr, np.int64), _arr(user_indices, np.int32)
+        if up.size != self.U + 1:
+            raise GorseHipError(ERR_INVALID, "user_indptr must have U+1 entries")
+        ip = _arr(item_indptr, np.int64) if item_indptr is not None else None
+        ii = _arr(item_indices, np.int32) if item_indices is not None else None
+        self.h = _vp()
+        check(lib().gorse_mf_create(C.byref(self.h), device, self.U, self.I, self.d, _p(up, _i64p), _p(ui, _i32p),
+                                    _p(ip, _i64p), _p(ii, _i32p)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gorse_mf_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_factors(self, P=None, Q=None):
+        P = _arr(P, np.float32) if P is not None else None
+        Q = _arr(Q, np.float32) if Q is not None else None
+        if P is not None and P.shape != (self.U, self.d):
+            raise GorseHipError(ERR_INVALID, "P must be U x d")
+        if Q is not None and Q.shape != (self.I, self.d):
+            raise GorseHipError(ERR_INVALID, "Q must be I x d")
+        check(lib().gorse_mf_set_factors(self.h, _p(P, _f32p), _p(Q, _f32p)))
+
+    def get_factors(self):
+        P = np.empty((self.U, self.d), np.float32)
+        Q = np.empty((self.I, self.d), np.float32)
+        check(lib().gorse_mf_get_factors(self.h, _p(P, _f32p), _p(Q, _f32p)))
+        return P, Q
+
+    def score(self, u, i):
+        u, i = _arr(u, np.int32), _arr(i, np.int32)
+        out = np.empty(u.size, np.float32)
+        check(lib().gorse_mf_score(self.h, _p(u, _i32p), _p(i, _i32p), u.size, _p(out, _f32p)))
+        return out
+
+    def rank(self, users, cand_indptr, cand, topk):
+        users, cand_indptr, cand = _arr(users, np.int32), _arr(cand_indptr, np.int64), _arr(cand, np.int32)
+        rank = np.empty((users.size, topk), np.int32)
+        rlen = np.empty(users.size, np.int32)
+        check(lib().gorse_mf_rank(self.h, users.size, _p(users, _i32p), _p(cand_indptr, _i64p), _p(cand, _i32p), topk,
+                                  _p(rank, _i32p), _p(rlen, _i32p)))
+        return rank, rlen
+
+    def bpr_epoch(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_ATOMIC, want_loss=False,
+                  cancel=None):
+        loss = C.c_double(0)
+        cp = _p(cancel, _i32p) if cancel is not None else None
+        check(lib().gorse_bpr_epoch(self.h, n_samples, lr, reg, seed, epoch, sample_base, mode, cp,
+                                    C.byref(loss) if want_loss else None))
+        return loss.value
+
+    def bpr_epoch_enqueue(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_ATOMIC):
+        check(lib().gorse_bpr_epoch_enqueue(self.h, n_samples, lr, reg, seed, epoch, sample_base, mode))
+
+    def bpr_sample_triplets(self, n, seed, epoch, sample_base=0):
+        u = np.empty(n, np.int32)
+        i = np.empty(n, np.int32)
+        j = np.empty(n, np.int32)
+        check(lib().gorse_bpr_sample_triplets(self.h, n, seed, epoch, sample_base, _p(u, _i32p), _p(i, _i32p),
+                                              _p(j, _i32p)))
+        return u, i, j
+
+    def bpr_apply_triplets(self, u, i, j, lr, reg, mode):
+        u, i, j = _arr(u, np.int32), _arr(i, np.int32), _arr(j, np.int32)
+        if not (u.size == i.size == j.size):
+            raise GorseHipError(ERR_INVALID, "triplet arrays differ in length")
+        check(lib().gorse_bpr_apply_triplets(self.h, _p(u, _i32p), _p(i, _i32p), _p(j, _i32p), u.size, lr, reg, mode))
+
+    def als_epoch(self, weight, reg, cancel=None):
+        cp = _p(cancel, _i32p) if cancel is not None else None
+        check(lib().gorse_als_epoch(self.h, weight, reg, cp))
+
+    def item_sync_mark(self):
+        check(lib().gorse_mf_item_sync_mark(self.h))
+
+    def item_delta_export(self, dev_ptr):
+        check(lib().gorse_mf_item_delta_export(self.h, _vp(dev_ptr)))
+
+    def item_delta_import(self, dev_ptr):
+        check(lib().gorse_mf_item_delta_import(self.h, _vp(dev_ptr)))
+
+    def device_ptrs(self):
+        P, Q = _vp(), _vp()
+        check(lib().gorse_mf_device_ptrs(self.h, C.byref(P), C.byref(Q)))
+        return P.value, Q.value
+
+    def synchronize(self):
+        check(lib().gorse_mf_synchronize(self.h))
+
+    def set_profiling(self, on):
+        check(lib().gorse_mf_set_profiling(self.h, int(bool(on))))
+
+    def reset_profile(self):
+        check(lib().gorse_mf_reset_profile(self.h))
+
+    def get_profile(self, cls):
+        n, ms = C.c_int64(0), C.c_double(0)
+        check(lib().gorse_mf_get_profile(self.h, cls, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+class TopK:
+    """One gorse_topk handle (exact brute-force index resident on one GPU)."""
+
+    def __init__(self, X, metric, dtype=DTYPE_F32, device=0):
+        X = _arr(X, np.uint16 if dtype == DTYPE_BF16 else np.float32)
+        if X.ndim != 2:
+            raise GorseHipError(ERR_INVALID, "X must be N x d")
+        self.N, self.d = X.shape
+        self.dtype, self.metric = dtype, metric
+        self.h = _vp()
+        check(lib().gorse_topk_create(C.byref(self.h), device, self.N, self.d, dtype, metric, X.ctypes.data_as(_vp)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gorse_topk_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _out(self, nq, k):
+        return np.empty((nq, k), np.int32), np.empty((nq, k), np.float32), np.empty(nq, np.int32)
+
+    def search_index(self, q, k, prune0=False):
+        q = _arr(np.atleast_1d(q), np.int64)
+        idx, dist, cnt = self._out(q.size, k)
+        check(lib().gorse_topk_search_index(self.h, _p(q, _i64p), q.size, k, int(prune0), _p(idx, _i32p),
+                                            _p(dist, _f32p), _p(cnt, _i32p)))
+        return idx, dist, cnt
+
+    def search_vector(self, qv, k, prune0=False):
+        qv = _arr(np.atleast_2d(qv), np.uint16 if self.dtype == DTYPE_BF16 else np.float32)
+        if qv.shape[1] != self.d:
+            raise GorseHipError(ERR_INVALID, "query dimension mismatch")
+        idx, dist, cnt = self._out(qv.shape[0], k)
+        check(lib().gorse_topk_search_vector(self.h, qv.ctypes.data_as(_vp), qv.shape[0], k, int(prune0),
+                                             _p(idx, _i32p), _p(dist, _f32p), _p(cnt, _i32p)))
+        return idx, dist, cnt
+
+    def all_pairs(self, k, q_begin=0, q_end=None, fetch=True):
+        q_end = self.N if q_end is None else q_end
+        nq = q_end - q_begin
+        idx = np.empty((nq, k), np.int32) if fetch else None
+        dist = np.empty((nq, k), np.float32) if fetch else None
+        check(lib().gorse_topk_all_pairs(self.h, q_begin, q_end, k, _p(idx, _i32p), _p(dist, _f32p)))
+        return idx, dist
+
+    def synchronize(self):
+        check(lib().gorse_topk_synchronize(self.h))
+
+    def set_profiling(self, on):
+        check(lib().gorse_topk_set_profiling(self.h, int(bool(on))))
+
+    def get_profile(self, cls):
+        n, ms = C.c_int64(0), C.c_double(0)
+        check(lib().gorse_topk_get_profile(self.h, cls, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def last_stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().gorse_topk_last_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+def sgemm(transA, transB, m, n, k, a, lda, b, ldb, c, ldc, device=0):
+    a, b = _arr(a, np.float32), _arr(b, np.float32)
+    c = np.array(c, dtype=np.float32, order="C")
+    check(lib().gorse_hip_sgemm(device, int(transA), int(transB), m, n, k, _p(a, _f32p), lda, _p(b, _f32p), ldb,
+                                _p(c, _f32p), ldc))
+    return c

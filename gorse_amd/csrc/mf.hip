@@ -1,0 +1,446 @@
+// mf.hip -- gorse_mf lifetime, factor transfer, internalPredict (score), Rank, exchange helpers.
+// Reference: model/cf/model.go:118-203 (BaseMatrixFactorization), evaluator.go:162-169 (Rank),
+// common/heap/filter.go:23-59 (TopKFilter).
+#include <algorithm>
+
+#include "goheap.hpp"
+#include "mf_internal.hpp"
+
+using namespace gorse;
+
+extern "C" int32_t gorse_hip_abi_version(void) { return GORSE_HIP_ABI_VERSION; }
+extern "C" const char *gorse_hip_last_error(void) { return last_error().c_str(); }
+extern "C" int32_t gorse_hip_device_count(int32_t *n) {
+    if (!n) return fail(GORSE_ERR_INVALID, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(GORSE_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return GORSE_OK;
+}
+
+namespace {
+
+// each CSR row sorted ascending, on the host (one-off at create time)
+void sort_rows(const int64_t *ptr, const int32_t *idx, int64_t rows, std::vector<int32_t> &out) {
+    out.assign(idx, idx + ptr[rows]);
+    for (int64_t r = 0; r < rows; r++) {
+        int32_t *b = out.data() + ptr[r], *e = out.data() + ptr[r + 1];
+        // rows are short on average; insertion sort for tiny rows, std::sort otherwise
+        if (e - b > 1) std::sort(b, e);
+    }
+}
+
+int32_t validate_csr(const char *name, const int64_t *ptr, const int32_t *idx, int64_t rows, int64_t cols) {
+    if (ptr[0] != 0) return fail(GORSE_ERR_INVALID, "%s_indptr[0] != 0", name);
+    for (int64_t r = 0; r < rows; r++)
+        if (ptr[r + 1] < ptr[r]) return fail(GORSE_ERR_INVALID, "%s_indptr not monotone at row %lld", name, (long long)r);
+    for (int64_t t = 0; t < ptr[rows]; t++)
+        if (idx[t] < 0 || idx[t] >= cols)
+            return fail(GORSE_ERR_INVALID, "%s_indices[%lld] = %d out of range [0,%lld)", name, (long long)t, idx[t],
+                        (long long)cols);
+    return GORSE_OK;
+}
+
+// ---- internalPredict ---------------------------------------------------------------------
+template <int NC>
+__global__ __launch_bounds__(kBlock) void mf_score_kernel(const float *__restrict__ P, const float *__restrict__ Q,
+                                                          const int32_t *__restrict__ us,
+                                                          const int32_t *__restrict__ is, int64_t n, int d,
+                                                          float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int gib = threadIdx.x / kGroup;
+    const int64_t group = (int64_t)blockIdx.x * kGroupsPerBlock + gib;
+    const int64_t ngroups = (int64_t)gridDim.x * kGroupsPerBlock;
+    const VecShape vs(d);
+    for (int64_t t = group; t < n; t += ngroups) {
+        const int u = us[t], i = is[t];
+        float r = 0.0f;
+        if (u >= 0 && i >= 0) {
+            const float *pu = P + (int64_t)u * d, *qi = Q + (int64_t)i * d;
+            if constexpr (NC > 0) {
+                float a[NC], b[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    a[c] = pu[16 * c + lane];
+                    b[c] = qi[16 * c + lane];
+                }
+                r = dot512_regs<NC>(a, b);
+            } else {
+                float *sa = smem + (size_t)gib * 2 * d, *sb = sa + d;
+                for (int e = lane; e < d; e += kGroup) {
+                    sa[e] = pu[e];
+                    sb[e] = qi[e];
+                }
+                __builtin_amdgcn_wave_barrier();
+                r = dot512_lds(sa, sb, vs, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) out[t] = r;
+    }
+}
+
+// ---- heap.TopKFilter per user over precomputed scores ------------------------------------------
+__global__ void mf_rank_kernel(const int64_t *__restrict__ cand_ptr, const int32_t *__restrict__ cand,
+                               const float *__restrict__ score, int64_t n_users, int topk, int32_t *heap_v,
+                               float *heap_w, int32_t *__restrict__ rank_out, int32_t *__restrict__ rank_len) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_users) return;
+    GoHeap<false> h(heap_v + t * (topk + 1), heap_w + t * (topk + 1));
+    for (int64_t c = cand_ptr[t]; c < cand_ptr[t + 1]; c++) {
+        h.push(cand[c], score[c]);
+        if (h.n > topk) h.pop();
+    }
+    const int cnt = h.n;
+    rank_len[t] = cnt;
+    for (int k = 0; k < topk; k++) rank_out[t * topk + k] = -1;
+    for (int k = cnt - 1; k >= 0; k--) {
+        h.pop();  // root moved to position h.n
+        rank_out[t * topk + k] = h.v[h.n];
+    }
+}
+
+__global__ void expand_users_kernel(const int64_t *__restrict__ cand_ptr, const int32_t *__restrict__ users,
+                                    int64_t n_users, int32_t *__restrict__ pair_u) {
+    int64_t t = blockIdx.x;
+    for (; t < n_users; t += gridDim.x)
+        for (int64_t c = cand_ptr[t] + threadIdx.x; c < cand_ptr[t + 1]; c += blockDim.x) pair_u[c] = users[t];
+}
+
+__global__ void delta_export_kernel(const float4 *__restrict__ q, const float4 *__restrict__ qs, float4 *__restrict__ dst,
+                                    int64_t n4) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = q[t], b = qs[t];
+        dst[t] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+    }
+}
+__global__ void delta_import_kernel(float4 *__restrict__ q, float4 *__restrict__ qs, const float4 *__restrict__ src,
+                                    int64_t n4) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (int64_t)gridDim.x * blockDim.x) {
+        float4 b = qs[t], s = src[t];
+        float4 r = make_float4(b.x + s.x, b.y + s.y, b.z + s.z, b.w + s.w);
+        q[t] = r;
+        qs[t] = r;
+    }
+}
+__global__ void delta_export_tail(const float *q, const float *qs, float *dst, int64_t begin, int64_t n) {
+    int64_t t = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = q[t] - qs[t];
+}
+__global__ void delta_import_tail(float *q, float *qs, const float *src, int64_t begin, int64_t n) {
+    int64_t t = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float r = qs[t] + src[t];
+        q[t] = r;
+        qs[t] = r;
+    }
+}
+
+}  // namespace
+
+namespace gorse {
+
+int32_t mf_sync_streams(gorse_mf *h) {
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream2));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+// score launcher shared with the rank path (device pointers)
+int32_t mf_score_device(gorse_mf *h, const int32_t *us, const int32_t *is, int64_t n, float *out) {
+    if (n == 0) return GORSE_OK;
+    const int d = h->d;
+    int64_t blocks = ceil_div(n, kGroupsPerBlock);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    dim3 grid((unsigned)blocks), block(kBlock);
+    if (d == 16)
+        mf_score_kernel<1><<<grid, block, 0, h->stream>>>(h->P.p, h->Q.p, us, is, n, d, out);
+    else if (d == 32)
+        mf_score_kernel<2><<<grid, block, 0, h->stream>>>(h->P.p, h->Q.p, us, is, n, d, out);
+    else if (d == 64)
+        mf_score_kernel<4><<<grid, block, 0, h->stream>>>(h->P.p, h->Q.p, us, is, n, d, out);
+    else if (d == 128)
+        mf_score_kernel<8><<<grid, block, 0, h->stream>>>(h->P.p, h->Q.p, us, is, n, d, out);
+    else
+        mf_score_kernel<0><<<grid, block, (size_t)kGroupsPerBlock * 2 * d * sizeof(float), h->stream>>>(
+            h->P.p, h->Q.p, us, is, n, d, out);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+}  // namespace gorse
+
+extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, int64_t I, int32_t d,
+                                   const int64_t *user_indptr, const int32_t *user_indices,
+                                   const int64_t *item_indptr, const int32_t *item_indices) {
+    if (!out) return fail(GORSE_ERR_INVALID, "handle pointer is NULL");
+    *out = nullptr;
+    if (U <= 0 || I <= 0 || d <= 0) return fail(GORSE_ERR_INVALID, "U, I, d must be positive (got %lld, %lld, %d)",
+                                                 (long long)U, (long long)I, d);
+    if (U > INT32_MAX || I > INT32_MAX) return fail(GORSE_ERR_INVALID, "U and I must fit int32 (dataset indices are int32)");
+    if (d > 2048) return fail(GORSE_ERR_INVALID, "nFactors %d > 2048 unsupported", d);
+    if (!user_indptr || !user_indices) return fail(GORSE_ERR_INVALID, "user CSR is NULL");
+    if ((item_indptr == nullptr) != (item_indices == nullptr))
+        return fail(GORSE_ERR_INVALID, "item_indptr and item_indices must both be given or both NULL");
+    GORSE_TRY(validate_csr("user", user_indptr, user_indices, U, I));
+    if (item_indptr) GORSE_TRY(validate_csr("item", item_indptr, item_indices, I, U));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
+    if (device < 0 || device >= ndev) return fail(GORSE_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    gorse_mf *h = new (std::nothrow) gorse_mf();
+    if (!h) return fail(GORSE_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->U = U;
+    h->I = I;
+    h->d = d;
+    h->nnz = user_indptr[U];
+    h->has_item_csr = item_indptr != nullptr;
+    for (int64_t r = 0; r < U; r++) h->max_user_row = std::max(h->max_user_row, user_indptr[r + 1] - user_indptr[r]);
+    if (item_indptr)
+        for (int64_t r = 0; r < I; r++) h->max_item_row = std::max(h->max_item_row, item_indptr[r + 1] - item_indptr[r]);
+    int32_t rc = [&]() -> int32_t {
+        GORSE_TRY(h->use());
+        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
+            GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
+        }
+        GORSE_TRY(h->P.alloc((size_t)U * d));
+        GORSE_TRY(h->Q.alloc((size_t)I * d));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->P.p, 0, (size_t)U * d * sizeof(float), h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->Q.p, 0, (size_t)I * d * sizeof(float), h->stream));
+        GORSE_TRY(h->uptr.alloc((size_t)U + 1));
+        GORSE_TRY(h->uidx.alloc((size_t)h->nnz));
+        GORSE_TRY(h->uidx_sorted.alloc((size_t)h->nnz));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->uptr.p, user_indptr, (size_t)(U + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                                       h->stream));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->uidx.p, user_indices, (size_t)h->nnz * sizeof(int32_t), hipMemcpyHostToDevice,
+                                       h->stream));
+        std::vector<int32_t> sorted;
+        sort_rows(user_indptr, user_indices, U, sorted);
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->uidx_sorted.p, sorted.data(), (size_t)h->nnz * sizeof(int32_t),
+                                       hipMemcpyHostToDevice, h->stream));
+        if (h->has_item_csr) {
+            int64_t innz = item_indptr[I];
+            GORSE_TRY(h->iptr.alloc((size_t)I + 1));
+            GORSE_TRY(h->iidx.alloc((size_t)innz));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->iptr.p, item_indptr, (size_t)(I + 1) * sizeof(int64_t),
+                                           hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->iidx.p, item_indices, (size_t)innz * sizeof(int32_t), hipMemcpyHostToDevice,
+                                           h->stream));
+        }
+        GORSE_TRY(h->loss.alloc(1));
+        GORSE_TRY(h->fail_count.alloc(1));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->fail_count.p, 0, sizeof(int32_t), h->stream));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // host staging vectors go out of scope
+        return GORSE_OK;
+    }();
+    if (rc != GORSE_OK) {
+        std::string keep = last_error();
+        gorse_mf_destroy(h);
+        last_error() = keep;
+        return rc;
+    }
+    *out = h;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_destroy(gorse_mf *h) {
+    if (!h) return GORSE_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (int b = 0; b < 2; b++) {
+        if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
+        if (h->ev_consumed[b]) (void)hipEventDestroy(h->ev_consumed[b]);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    delete h;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_set_factors(gorse_mf *h, const float *P, const float *Q) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    if (P) GORSE_HIP_CHECK(hipMemcpyAsync(h->P.p, P, (size_t)h->U * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (Q) GORSE_HIP_CHECK(hipMemcpyAsync(h->Q.p, Q, (size_t)h->I * h->d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_get_factors(gorse_mf *h, float *P, float *Q) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    if (P) GORSE_HIP_CHECK(hipMemcpyAsync(P, h->P.p, (size_t)h->U * h->d * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (Q) GORSE_HIP_CHECK(hipMemcpyAsync(Q, h->Q.p, (size_t)h->I * h->d * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_score(gorse_mf *h, const int32_t *u, const int32_t *items, int64_t n, float *out) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (n < 0 || (n > 0 && (!u || !items || !out))) return fail(GORSE_ERR_INVALID, "bad arguments");
+    if (n == 0) return GORSE_OK;
+    for (int64_t t = 0; t < n; t++)
+        if (u[t] >= h->U || items[t] >= h->I)
+            return fail(GORSE_ERR_RANGE, "pair %lld (%d,%d) out of range", (long long)t, u[t], items[t]);
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    size_t bytes = (size_t)n * (2 * sizeof(int32_t) + sizeof(float));
+    GORSE_TRY(h->stage.ensure(bytes));
+    int32_t *du = (int32_t *)h->stage.p, *di = du + n;
+    float *dout = (float *)(di + n);
+    GORSE_HIP_CHECK(hipMemcpyAsync(du, u, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(di, items, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    GORSE_TRY(mf_score_device(h, du, di, n, dout));
+    GORSE_HIP_CHECK(hipMemcpyAsync(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_rank(gorse_mf *h, int64_t n_users, const int32_t *users, const int64_t *cand_indptr,
+                                 const int32_t *cand, int32_t topk, int32_t *rank_out, int32_t *rank_len) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (n_users < 0 || topk <= 0) return fail(GORSE_ERR_INVALID, "n_users < 0 or topk <= 0");
+    if (n_users == 0) return GORSE_OK;
+    if (!users || !cand_indptr || !rank_out || !rank_len) return fail(GORSE_ERR_INVALID, "NULL argument");
+    const int64_t nc = cand_indptr[n_users];
+    if (cand_indptr[0] != 0 || nc < 0 || (nc > 0 && !cand)) return fail(GORSE_ERR_INVALID, "bad candidate CSR");
+    for (int64_t t = 0; t < n_users; t++) {
+        if (users[t] < 0 || users[t] >= h->U) return fail(GORSE_ERR_RANGE, "user %d out of range", users[t]);
+        if (cand_indptr[t + 1] < cand_indptr[t]) return fail(GORSE_ERR_INVALID, "cand_indptr not monotone");
+    }
+    for (int64_t c = 0; c < nc; c++)
+        if (cand[c] < 0 || cand[c] >= h->I) return fail(GORSE_ERR_RANGE, "candidate %d out of range", cand[c]);
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    // staging layout: cand_ptr | users | cand | pair_u | score | heap_v | heap_w | rank | len
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    size_t o_ptr = carve((size_t)(n_users + 1) * 8), o_users = carve((size_t)n_users * 4), o_cand = carve((size_t)nc * 4),
+           o_pu = carve((size_t)nc * 4), o_score = carve((size_t)nc * 4), o_hv = carve((size_t)n_users * (topk + 1) * 4),
+           o_hw = carve((size_t)n_users * (topk + 1) * 4), o_rank = carve((size_t)n_users * topk * 4),
+           o_len = carve((size_t)n_users * 4);
+    GORSE_TRY(h->stage.ensure(off));
+    char *base = h->stage.p;
+    int64_t *d_ptr = (int64_t *)(base + o_ptr);
+    int32_t *d_users = (int32_t *)(base + o_users), *d_cand = (int32_t *)(base + o_cand), *d_pu = (int32_t *)(base + o_pu);
+    float *d_score = (float *)(base + o_score);
+    int32_t *d_hv = (int32_t *)(base + o_hv);
+    float *d_hw = (float *)(base + o_hw);
+    int32_t *d_rank = (int32_t *)(base + o_rank), *d_len = (int32_t *)(base + o_len);
+    GORSE_HIP_CHECK(hipMemcpyAsync(d_ptr, cand_indptr, (size_t)(n_users + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(d_users, users, (size_t)n_users * 4, hipMemcpyHostToDevice, h->stream));
+    if (nc > 0) {
+        GORSE_HIP_CHECK(hipMemcpyAsync(d_cand, cand, (size_t)nc * 4, hipMemcpyHostToDevice, h->stream));
+        int64_t eb = n_users < 4096 ? n_users : 4096;
+        expand_users_kernel<<<dim3((unsigned)eb), dim3(64), 0, h->stream>>>(d_ptr, d_users, n_users, d_pu);
+        GORSE_HIP_CHECK(hipGetLastError());
+        GORSE_TRY(mf_score_device(h, d_pu, d_cand, nc, d_score));
+    }
+    mf_rank_kernel<<<dim3((unsigned)ceil_div(n_users, 64)), dim3(64), 0, h->stream>>>(d_ptr, d_cand, d_score, n_users, topk,
+                                                                                     d_hv, d_hw, d_rank, d_len);
+    GORSE_HIP_CHECK(hipGetLastError());
+    GORSE_HIP_CHECK(hipMemcpyAsync(rank_out, d_rank, (size_t)n_users * topk * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(rank_len, d_len, (size_t)n_users * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+// ---- multi-GPU exchange ---------------------------------------------------------------------
+extern "C" int32_t gorse_mf_item_sync_mark(gorse_mf *h) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_TRY(h->Qsync.ensure((size_t)h->I * h->d));
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->Qsync.p, h->Q.p, (size_t)h->I * h->d * sizeof(float), hipMemcpyDeviceToDevice,
+                                   h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_item_delta_export(gorse_mf *h, float *dst) {
+    if (!h || !dst) return fail(GORSE_ERR_INVALID, "NULL argument");
+    if (!h->Qsync.p) return fail(GORSE_ERR_INVALID, "gorse_mf_item_sync_mark was never called");
+    GORSE_TRY(h->use());
+    const int64_t n = h->I * (int64_t)h->d, n4 = (((uintptr_t)dst & 15) == 0) ? n / 4 : 0;
+    if (n4 > 0) {
+        int64_t blocks = std::min<int64_t>(ceil_div(n4, 256), 2048);
+        delta_export_kernel<<<dim3((unsigned)blocks), dim3(256), 0, h->stream>>>((const float4 *)h->Q.p,
+                                                                                 (const float4 *)h->Qsync.p, (float4 *)dst, n4);
+    }
+    if (n4 * 4 < n)
+        delta_export_tail<<<dim3((unsigned)ceil_div(n - n4 * 4, 256)), dim3(256), 0, h->stream>>>(h->Q.p, h->Qsync.p, dst,
+                                                                                                 n4 * 4, n);
+    GORSE_HIP_CHECK(hipGetLastError());
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the caller's collective runs on its own stream
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_item_delta_import(gorse_mf *h, const float *src) {
+    if (!h || !src) return fail(GORSE_ERR_INVALID, "NULL argument");
+    if (!h->Qsync.p) return fail(GORSE_ERR_INVALID, "gorse_mf_item_sync_mark was never called");
+    GORSE_TRY(h->use());
+    const int64_t n = h->I * (int64_t)h->d, n4 = (((uintptr_t)src & 15) == 0) ? n / 4 : 0;
+    if (n4 > 0) {
+        int64_t blocks = std::min<int64_t>(ceil_div(n4, 256), 2048);
+        delta_import_kernel<<<dim3((unsigned)blocks), dim3(256), 0, h->stream>>>((float4 *)h->Q.p, (float4 *)h->Qsync.p,
+                                                                                 (const float4 *)src, n4);
+    }
+    if (n4 * 4 < n)
+        delta_import_tail<<<dim3((unsigned)ceil_div(n - n4 * 4, 256)), dim3(256), 0, h->stream>>>(h->Q.p, h->Qsync.p, src,
+                                                                                                 n4 * 4, n);
+    GORSE_HIP_CHECK(hipGetLastError());
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_device_ptrs(gorse_mf *h, float **P, float **Q) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (P) *P = h->P.p;
+    if (Q) *Q = h->Q.p;
+    return GORSE_OK;
+}
+
+// ---- stream / measurement -----------------------------------------------------------------------
+extern "C" int32_t gorse_mf_synchronize(gorse_mf *h) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    return mf_sync_streams(h);
+}
+extern "C" int32_t gorse_mf_set_profiling(gorse_mf *h, int32_t on) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    h->prof.resolve();
+    h->prof.on = on != 0;
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_mf_get_profile(gorse_mf *h, int32_t cls, int64_t *launches, double *total_ms) {
+    if (!h || cls < 0 || cls >= GORSE_PROF_NCLASSES) return fail(GORSE_ERR_INVALID, "bad kernel class");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    h->prof.resolve();
+    if (launches) *launches = h->prof.launches[cls];
+    if (total_ms) *total_ms = h->prof.ms[cls];
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_mf_reset_profile(gorse_mf *h) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    h->prof.reset();
+    return GORSE_OK;
+}

@@ -1,0 +1,42 @@
+// mf_internal.hpp -- the gorse_mf handle: everything one model keeps resident in HBM.
+#pragma once
+#include "cf_device.hpp"
+
+struct gorse_mf {
+    int device = 0;
+    int64_t U = 0, I = 0, nnz = 0;
+    int64_t max_user_row = 0, max_item_row = 0;  // longest feedback rows
+    int d = 0;
+    bool has_item_csr = false;
+    hipStream_t stream = nullptr;   // update kernels, copies
+    hipStream_t stream2 = nullptr;  // sampler running ahead of the update kernels
+    hipEvent_t ev_sampled[2] = {nullptr, nullptr};
+    hipEvent_t ev_consumed[2] = {nullptr, nullptr};
+    // factors, row-major, row stride d (rows 16-byte aligned whenever d % 4 == 0)
+    gorse::DevBuf<float> P, Q, Qsync;
+    // dataset.CFSplit user->items (stored order + row-sorted copy) and item->users
+    gorse::DevBuf<int64_t> uptr, iptr;
+    gorse::DevBuf<int32_t> uidx, uidx_sorted, iidx;
+    // BPR triplet chunk buffers (double-buffered: sampler fills one while the other is applied)
+    gorse::DevBuf<int32_t> trip[2];
+    size_t trip_cap = 0;  // samples per buffer
+    gorse::DevBuf<int32_t> order;  // sequential mode: samples sorted by dependency level
+    gorse::DevBuf<double> loss;
+    gorse::DevBuf<int32_t> fail_count;
+    // ALS scratch
+    gorse::DevBuf<float> gram, gram_partial, als_scratch;
+    // generic staging
+    gorse::DevBuf<char> stage;
+    gorse::KernelProfile prof{GORSE_PROF_NCLASSES};
+
+    int32_t use() const {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return gorse::fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return GORSE_OK;
+    }
+};
+
+namespace gorse {
+// implemented in bpr.hip / als.hip, used across files
+int32_t mf_sync_streams(gorse_mf *h);
+}

@@ -1,0 +1,370 @@
+// topk.hip -- exact nearest-neighbour search (ann.Index / ann.Bruteforce) on gfx950.
+// Reference: common/ann/ann.go:21-25, common/ann/bruteforce.go:24-83, common/heap/pq.go.
+//
+// Path A (this file, always exact, any d / dtype / metric): score one block of queries against
+// all N stored vectors in the reference's own arithmetic order (one 16-lane group per pair, the
+// query block resident in LDS), then run the reference's heap selection.  The selection is the
+// literal container/heap procedure (goheap.hpp), so ties come out exactly as in Go.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "cf_device.hpp"
+#include "goheap.hpp"
+
+using namespace gorse;
+
+struct gorse_topk {
+    int device = 0;
+    int64_t N = 0;
+    int d = 0, dtype = 0, metric = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<float> X;       // N x d fp32 (bf16 inputs are expanded by <<16, bfloats.go:32-38)
+    DevBuf<uint16_t> Xb;   // N x d bf16 as given (kept for the MFMA path)
+    DevBuf<float> norm2;   // floats.Dot(x, x) per stored vector (cosine)
+    DevBuf<float> qbuf, qnorm, dist;
+    DevBuf<int64_t> qidx;
+    DevBuf<int32_t> out_idx, out_cnt, heap_v;
+    DevBuf<float> out_dist, heap_w;
+    KernelProfile prof{2};
+    int64_t n_fallback = 0, n_tie = 0;
+    int32_t use() const {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return GORSE_OK;
+    }
+};
+
+namespace {
+
+__global__ void expand_bf16_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, int64_t n) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = __uint_as_float((uint32_t)in[t] << 16);
+}
+
+// floats.Euclidean (squared part) in AVX512 order for rows staged in LDS: floats_avx512.c:374-441
+__device__ __forceinline__ float euclid512_lds(const float *a, const float *b, const VecShape &vs, int lane) {
+    float acc = 0.0f;
+    for (int c = 0; c < vs.nfull; c++) {
+        float v = a[16 * c + lane] - b[16 * c + lane];
+        v = v * v;
+        acc = c == 0 ? v : v + acc;
+    }
+    float sum = group_tree16(acc);
+    if (vs.has8) {
+        int e = vs.nfull * 16 + (lane & 7);
+        float v = a[e] - b[e];
+        sum += group_tree8(v * v);
+    }
+    for (int e = vs.tail0; e < vs.d; e++) {
+        float v = a[e] - b[e];
+        sum = fmaf(v, v, sum);
+    }
+    return sqrtf(sum);
+}
+
+// norm2[i] = floats.Dot(x_i, x_i)
+__global__ __launch_bounds__(kBlock) void norm2_kernel(const float *__restrict__ X, int64_t n, int d,
+                                                       float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & (kGroup - 1), gib = threadIdx.x / kGroup;
+    const VecShape vs(d);
+    float *sa = smem + (size_t)gib * d;
+    for (int64_t t = (int64_t)blockIdx.x * kGroupsPerBlock + gib; t < n; t += (int64_t)gridDim.x * kGroupsPerBlock) {
+        for (int e = lane; e < d; e += kGroup) sa[e] = X[t * d + e];
+        __builtin_amdgcn_wave_barrier();
+        float r = dot512_lds(sa, sa, vs, lane);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) out[t] = r;
+    }
+}
+
+// dist[qb][i] for one query (blockIdx.y) against candidates i; the query row sits in LDS
+__global__ __launch_bounds__(kBlock) void dist_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+                                                      const float *__restrict__ Qv, const float *__restrict__ qnorm2,
+                                                      int64_t N, int d, int metric, float *__restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & (kGroup - 1), gib = threadIdx.x / kGroup;
+    const VecShape vs(d);
+    float *sq = smem;                             // d
+    float *sx = smem + d + (size_t)gib * d;       // per-group candidate row
+    const int64_t q = blockIdx.y;
+    for (int e = threadIdx.x; e < d; e += blockDim.x) sq[e] = Qv[q * d + e];
+    __syncthreads();
+    const float qq = metric == GORSE_METRIC_COSINE ? qnorm2[q] : 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * kGroupsPerBlock + gib; i < N; i += (int64_t)gridDim.x * kGroupsPerBlock) {
+        for (int e = lane; e < d; e += kGroup) sx[e] = X[i * d + e];
+        __builtin_amdgcn_wave_barrier();
+        float r;
+        if (metric == GORSE_METRIC_EUCLIDEAN) {
+            r = euclid512_lds(sq, sx, vs, lane);
+        } else {
+            float ab = dot512_lds(sq, sx, vs, lane);
+            if (metric == GORSE_METRIC_NEG_DOT)
+                r = -ab;
+            else
+                r = 1.0f - ab / (sqrtf(qq) * sqrtf(norm2[i]));
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) dist[q * N + i] = r;
+    }
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ X, const float *__restrict__ norm2,
+                                   const int64_t *__restrict__ qidx, int d, float *__restrict__ Qv,
+                                   float *__restrict__ qn) {
+    const int64_t q = blockIdx.x;
+    const int64_t src = qidx[q];
+    for (int e = threadIdx.x; e < d; e += blockDim.x) Qv[q * d + e] = X[src * d + e];
+    if (threadIdx.x == 0 && norm2) qn[q] = norm2[src];
+}
+
+// Bruteforce selection (bruteforce.go:45-62 / 67-82), one thread per query, literal heaps.
+__global__ void select_kernel(const float *__restrict__ dist, const int64_t *__restrict__ qidx, int64_t nq, int64_t N,
+                              int k, int prune0, int32_t *heap_v, float *heap_w, int32_t *__restrict__ out_idx,
+                              float *__restrict__ out_dist, int32_t *__restrict__ out_cnt) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int64_t skip = qidx ? qidx[q] : -1;
+    int32_t *hv = heap_v + q * 2 * (k + 1);
+    float *hw = heap_w + q * 2 * (k + 1);
+    GoHeap<true> mx(hv, hw);
+    const float *dq = dist + q * N;
+    for (int64_t i = 0; i < N; i++) {
+        if (i == skip) continue;
+        mx.push((int32_t)i, dq[i]);
+        if (mx.n > k) mx.pop();
+    }
+    GoHeap<false> mn(hv + (k + 1), hw + (k + 1));  // Reverse(): re-push in array order
+    for (int t = 0; t < mx.n; t++) mn.push(hv[t], hw[t]);
+    int cnt = 0;
+    while (mn.n > 0) {
+        mn.pop();
+        const int32_t v = mn.v[mn.n];
+        const float w = mn.w[mn.n];
+        if (!prune0 || w > 0) {
+            out_idx[q * k + cnt] = v;
+            out_dist[q * k + cnt] = w;
+            cnt++;
+        }
+    }
+    out_cnt[q] = cnt;
+    for (int t = cnt; t < k; t++) {
+        out_idx[q * k + t] = -1;
+        out_dist[q * k + t] = __int_as_float(0x7f800000);
+    }
+}
+
+constexpr int64_t kDistBudget = (int64_t)1 << 28;  // floats in the distance slab (1 GiB)
+
+// queries already on the device in h->qbuf (nq x d, fp32) [+ h->qnorm]; qidx_dev = exclude list or null
+int32_t search_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int k, int prune0, int32_t *idx_out,
+                     float *dist_out, int32_t *cnt_out) {
+    const int d = h->d;
+    GORSE_TRY(h->dist.ensure((size_t)nq * h->N));
+    GORSE_TRY(h->heap_v.ensure((size_t)nq * 2 * (k + 1)));
+    GORSE_TRY(h->heap_w.ensure((size_t)nq * 2 * (k + 1)));
+    GORSE_TRY(h->out_idx.ensure((size_t)nq * k));
+    GORSE_TRY(h->out_dist.ensure((size_t)nq * k));
+    GORSE_TRY(h->out_cnt.ensure((size_t)nq));
+    int64_t bx = std::min<int64_t>(ceil_div(h->N, kGroupsPerBlock), 1024);
+    int tok = h->prof.begin(GORSE_PROF_TOPK_SCORE, h->stream);
+    dist_kernel<<<dim3((unsigned)bx, (unsigned)nq), dim3(kBlock), (size_t)(1 + kGroupsPerBlock) * d * sizeof(float),
+                  h->stream>>>(h->X.p, h->norm2.p, h->qbuf.p, h->qnorm.p, h->N, d, h->metric, h->dist.p);
+    GORSE_HIP_CHECK(hipGetLastError());
+    h->prof.end(tok, h->stream);
+    tok = h->prof.begin(GORSE_PROF_TOPK_RESCORE, h->stream);
+    select_kernel<<<dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, h->stream>>>(h->dist.p, qidx_dev, nq, h->N, k, prune0,
+                                                                              h->heap_v.p, h->heap_w.p, h->out_idx.p,
+                                                                              h->out_dist.p, h->out_cnt.p);
+    GORSE_HIP_CHECK(hipGetLastError());
+    h->prof.end(tok, h->stream);
+    if (idx_out) GORSE_HIP_CHECK(hipMemcpyAsync(idx_out, h->out_idx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+    if (dist_out) GORSE_HIP_CHECK(hipMemcpyAsync(dist_out, h->out_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
+    if (cnt_out) GORSE_HIP_CHECK(hipMemcpyAsync(cnt_out, h->out_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+int64_t block_queries(const gorse_topk *h) {
+    int64_t b = kDistBudget / std::max<int64_t>(h->N, 1);
+    return std::max<int64_t>(1, std::min<int64_t>(b, 65535));
+}
+
+int32_t compute_norms(gorse_topk *h, const float *V, int64_t n, float *out) {
+    int64_t bx = std::min<int64_t>(ceil_div(n, kGroupsPerBlock), 4096);
+    norm2_kernel<<<dim3((unsigned)bx), dim3(kBlock), (size_t)kGroupsPerBlock * h->d * sizeof(float), h->stream>>>(V, n, h->d,
+                                                                                                                out);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t gorse_topk_create(gorse_topk **out, int32_t device, int64_t N, int32_t d, int32_t dtype,
+                                     int32_t metric, const void *X) {
+    if (!out) return fail(GORSE_ERR_INVALID, "handle pointer is NULL");
+    *out = nullptr;
+    if (N <= 0 || d <= 0 || !X) return fail(GORSE_ERR_INVALID, "N, d must be positive and X non-NULL");
+    if (N > INT32_MAX) return fail(GORSE_ERR_INVALID, "N must fit int32");
+    if (d > 4096) return fail(GORSE_ERR_INVALID, "d %d > 4096 unsupported", d);
+    if (dtype != GORSE_DTYPE_F32 && dtype != GORSE_DTYPE_BF16) return fail(GORSE_ERR_INVALID, "unknown dtype %d", dtype);
+    if (metric < 0 || metric > 2) return fail(GORSE_ERR_INVALID, "unknown metric %d", metric);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
+    if (device < 0 || device >= ndev) return fail(GORSE_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    gorse_topk *h = new (std::nothrow) gorse_topk();
+    if (!h) return fail(GORSE_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->N = N;
+    h->d = d;
+    h->dtype = dtype;
+    h->metric = metric;
+    int32_t rc = [&]() -> int32_t {
+        GORSE_TRY(h->use());
+        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        GORSE_TRY(h->X.alloc((size_t)N * d));
+        if (dtype == GORSE_DTYPE_BF16) {
+            GORSE_TRY(h->Xb.alloc((size_t)N * d));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->Xb.p, X, (size_t)N * d * 2, hipMemcpyHostToDevice, h->stream));
+            expand_bf16_kernel<<<dim3(2048), dim3(256), 0, h->stream>>>(h->Xb.p, h->X.p, N * (int64_t)d);
+            GORSE_HIP_CHECK(hipGetLastError());
+        } else {
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->X.p, X, (size_t)N * d * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        GORSE_TRY(h->norm2.alloc((size_t)N));
+        GORSE_TRY(compute_norms(h, h->X.p, N, h->norm2.p));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        return GORSE_OK;
+    }();
+    if (rc != GORSE_OK) {
+        std::string keep = last_error();
+        gorse_topk_destroy(h);
+        last_error() = keep;
+        return rc;
+    }
+    *out = h;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_destroy(gorse_topk *h) {
+    if (!h) return GORSE_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_search_index(gorse_topk *h, const int64_t *q, int64_t nq, int32_t k, int32_t prune0,
+                                           int32_t *idx_out, float *dist_out, int32_t *count_out) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (nq < 0 || k <= 0 || (nq > 0 && !q)) return fail(GORSE_ERR_INVALID, "bad arguments");
+    for (int64_t t = 0; t < nq; t++)
+        if (q[t] < 0 || q[t] >= h->N) return fail(GORSE_ERR_RANGE, "index out of range: %lld", (long long)q[t]);
+    if (nq == 0) return GORSE_OK;
+    GORSE_TRY(h->use());
+    const int64_t bq = block_queries(h);
+    GORSE_TRY(h->qidx.ensure((size_t)std::min(bq, nq)));
+    GORSE_TRY(h->qbuf.ensure((size_t)std::min(bq, nq) * h->d));
+    GORSE_TRY(h->qnorm.ensure((size_t)std::min(bq, nq)));
+    for (int64_t q0 = 0; q0 < nq; q0 += bq) {
+        const int64_t m = std::min(bq, nq - q0);
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->qidx.p, q + q0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+        gather_rows_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->X.p, h->norm2.p, h->qidx.p, h->d, h->qbuf.p,
+                                                                         h->qnorm.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        GORSE_TRY(search_block(h, m, h->qidx.p, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
+                               dist_out ? dist_out + q0 * k : nullptr, count_out ? count_out + q0 : nullptr));
+    }
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_search_vector(gorse_topk *h, const void *qv, int64_t nq, int32_t k, int32_t prune0,
+                                            int32_t *idx_out, float *dist_out, int32_t *count_out) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (nq < 0 || k <= 0 || (nq > 0 && !qv)) return fail(GORSE_ERR_INVALID, "bad arguments");
+    if (nq == 0) return GORSE_OK;
+    GORSE_TRY(h->use());
+    const int64_t bq = block_queries(h);
+    const int64_t mb = std::min(bq, nq);
+    GORSE_TRY(h->qbuf.ensure((size_t)mb * h->d));
+    GORSE_TRY(h->qnorm.ensure((size_t)mb));
+    DevBuf<uint16_t> qb16;
+    if (h->dtype == GORSE_DTYPE_BF16) GORSE_TRY(qb16.alloc((size_t)mb * h->d));
+    for (int64_t q0 = 0; q0 < nq; q0 += bq) {
+        const int64_t m = std::min(bq, nq - q0);
+        if (h->dtype == GORSE_DTYPE_BF16) {
+            GORSE_HIP_CHECK(hipMemcpyAsync(qb16.p, (const uint16_t *)qv + q0 * h->d, (size_t)m * h->d * 2,
+                                           hipMemcpyHostToDevice, h->stream));
+            expand_bf16_kernel<<<dim3(256), dim3(256), 0, h->stream>>>(qb16.p, h->qbuf.p, m * (int64_t)h->d);
+            GORSE_HIP_CHECK(hipGetLastError());
+        } else {
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->qbuf.p, (const float *)qv + q0 * h->d, (size_t)m * h->d * 4,
+                                           hipMemcpyHostToDevice, h->stream));
+        }
+        if (h->metric == GORSE_METRIC_COSINE) GORSE_TRY(compute_norms(h, h->qbuf.p, m, h->qnorm.p));
+        GORSE_TRY(search_block(h, m, nullptr, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
+                               dist_out ? dist_out + q0 * k : nullptr, count_out ? count_out + q0 : nullptr));
+    }
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t *idx_out,
+                                        float *dist_out) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (q_begin < 0 || q_end > h->N || q_begin > q_end || k <= 0) return fail(GORSE_ERR_RANGE, "bad query range");
+    const int64_t nq = q_end - q_begin;
+    if (nq == 0) return GORSE_OK;
+    GORSE_TRY(h->use());
+    const int64_t bq = block_queries(h);
+    const int64_t mb = std::min(bq, nq);
+    GORSE_TRY(h->qidx.ensure((size_t)mb));
+    GORSE_TRY(h->qbuf.ensure((size_t)mb * h->d));
+    GORSE_TRY(h->qnorm.ensure((size_t)mb));
+    std::vector<int64_t> ids((size_t)mb);
+    for (int64_t q0 = 0; q0 < nq; q0 += bq) {
+        const int64_t m = std::min(bq, nq - q0);
+        for (int64_t t = 0; t < m; t++) ids[t] = q_begin + q0 + t;
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->qidx.p, ids.data(), (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+        gather_rows_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->X.p, h->norm2.p, h->qidx.p, h->d, h->qbuf.p,
+                                                                         h->qnorm.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        GORSE_TRY(search_block(h, m, h->qidx.p, k, 0, idx_out ? idx_out + q0 * k : nullptr,
+                               dist_out ? dist_out + q0 * k : nullptr, nullptr));
+    }
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_synchronize(gorse_topk *h) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_topk_set_profiling(gorse_topk *h, int32_t on) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->prof.resolve();
+    h->prof.on = on != 0;
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_topk_get_profile(gorse_topk *h, int32_t cls, int64_t *launches, double *total_ms) {
+    if (!h || cls < 0 || cls >= 2) return fail(GORSE_ERR_INVALID, "bad kernel class");
+    GORSE_TRY(h->use());
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->prof.resolve();
+    if (launches) *launches = h->prof.launches[cls];
+    if (total_ms) *total_ms = h->prof.ms[cls];
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int64_t *n_tie_resolved) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (n_fallback) *n_fallback = h->n_fallback;
+    if (n_tie_resolved) *n_tie_resolved = h->n_tie;
+    return GORSE_OK;
+}

@@ -1,0 +1,191 @@
+/*
+ * gorse_hip.h -- C ABI of libgorse_hip.so, the MI355X (gfx950) implementation of
+ * Gorse's collaborative-filtering training and exact embedding top-k hot path.
+ *
+ * This is the drop-in boundary: exactly what a cgo file built with
+ * `//go:build cgo && hip` inside the reference's packages model/cf, common/ann and
+ * common/floats would bind (see INTEGRATION.md for the Go stubs).  The reference has
+ * no FFI for this path today; its precedent is the cgo BLAS binding
+ * common/blas/blas_openblas.go:19-26 (pointer to the first element of a flat Go
+ * slice, synchronous call, nothing retained) and build-tag twins such as
+ * model/ctr/fm.go vs fm_xla.go.  The same conventions hold here:
+ *
+ *   - plain C, no C++/torch types; every pointer marked "host" is caller-owned host
+ *     memory that is only read/written for the duration of the call (never retained,
+ *     so Go's cgo pointer rules are met); pointers marked "device" are HIP device
+ *     addresses on the handle's device;
+ *   - every function returns int32: 0 = ok, <0 = error (gorse_hip_last_error() gives a
+ *     thread-local message).  Where the reference panics (slice length mismatch) or
+ *     returns an error (ann.Bruteforce.SearchIndex out of range) the matching code is
+ *     returned and nothing is modified;
+ *   - one handle = one GPU (one process per GPU; multi-GPU = several processes, each
+ *     with its own handle, exchanging the item-factor delta through the
+ *     gorse_mf_item_delta_* calls and an all-reduce done by the caller, RCCL in
+ *     production);
+ *   - calls on one handle must be serialised by the caller (the Go side holds a mutex,
+ *     as logics/vector_writer.go does); different handles are independent;
+ *   - long calls poll a caller-supplied cancel flag between kernel launches, the
+ *     equivalent of ctx.Err() checks in common/parallel/parallel.go:36-38.
+ */
+#ifndef GORSE_HIP_H
+#define GORSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GORSE_HIP_ABI_VERSION 1
+
+/* return codes */
+#define GORSE_OK 0
+#define GORSE_ERR_INVALID (-1)   /* bad argument (a Go panic in the reference, e.g. floats.go:96-99) */
+#define GORSE_ERR_HIP (-2)       /* HIP runtime / launch failure */
+#define GORSE_ERR_CANCELLED (-3) /* cancel flag observed: ctx.Err() != nil, model/cf/model.go:490-493 */
+#define GORSE_ERR_NO_DEVICE (-4) /* no usable gfx950 device */
+#define GORSE_ERR_RANGE (-5)     /* "index out of range", common/ann/bruteforce.go:41-43 */
+#define GORSE_ERR_NOMEM (-6)
+
+/* BPR update schedules (gorse_bpr_epoch / gorse_bpr_apply_triplets `mode`) */
+#define GORSE_BPR_HOGWILD_ATOMIC 0 /* all samples of a chunk in flight, fp32 atomics: no lost updates   */
+#define GORSE_BPR_SEQUENTIAL 1     /* dependency-levelled: bit-faithful to the reference with Jobs = 1  */
+#define GORSE_BPR_HOGWILD_RACY 2   /* write-through load/fma/store, lost updates like the CPU Hogwild   */
+
+/* top-k element types and metrics */
+#define GORSE_DTYPE_F32 0
+#define GORSE_DTYPE_BF16 1      /* uint16 = upper half of the fp32 word, common/bfloats/bfloats.go:24-30 */
+#define GORSE_METRIC_NEG_DOT 0  /* distance = -floats.Dot        (logics/cf.go:32-34)                     */
+#define GORSE_METRIC_EUCLIDEAN 1 /* distance = floats.Euclidean  (common/ann/ann_test.go)                  */
+#define GORSE_METRIC_COSINE 2   /* distance = 1 - a.b/(|a||b|)   (storage/vectors/database.go:29-33)      */
+
+typedef struct gorse_mf gorse_mf;     /* one matrix-factorisation model resident on one GPU */
+typedef struct gorse_topk gorse_topk; /* one exact nearest-neighbour index resident on one GPU */
+
+/* ---- library ------------------------------------------------------------------- */
+int32_t gorse_hip_abi_version(void);
+const char *gorse_hip_last_error(void);
+int32_t gorse_hip_device_count(int32_t *n);
+
+/* ---- cf.MatrixFactorization state (model/cf/model.go:118-127) ------------------------
+ * U users, I items, d = nFactors.  user_indptr[U+1] / user_indices[nnz] are
+ * dataset.CFSplit.GetUserFeedback() flattened IN STORED ORDER (dataset/dataset.go:231-240);
+ * item_indptr / item_indices are GetItemFeedback() likewise and may be NULL when only BPR
+ * is run.  The library keeps its own device copies (plus a row-sorted copy of the user
+ * rows for the negative sampler's membership test, model.go:461-468). */
+int32_t gorse_mf_create(gorse_mf **h, int32_t device, int64_t U, int64_t I, int32_t d,
+                        const int64_t *user_indptr /*host*/, const int32_t *user_indices /*host*/,
+                        const int64_t *item_indptr /*host or NULL*/, const int32_t *item_indices /*host or NULL*/);
+int32_t gorse_mf_destroy(gorse_mf *h);
+
+/* BaseMatrixFactorization.UserFactor / ItemFactor as flat row-major U*d / I*d float32.
+ * Either pointer may be NULL to skip that matrix. (Init draws stay on the Go side:
+ * model/cf/model.go:532-540, common/util/random.go:45-60.) */
+int32_t gorse_mf_set_factors(gorse_mf *h, const float *P /*host*/, const float *Q /*host*/);
+int32_t gorse_mf_get_factors(gorse_mf *h, float *P /*host*/, float *Q /*host*/);
+
+/* internalPredict for n (user, item) index pairs, model/cf/model.go:195-203:
+ * out[t] = floats.Dot(UserFactor[u[t]], ItemFactor[items[t]]) in the reference's AVX512
+ * operation order, 0 when either index is negative. */
+int32_t gorse_mf_score(gorse_mf *h, const int32_t *u /*host*/, const int32_t *items /*host*/, int64_t n,
+                       float *out /*host*/);
+
+/* cf.Rank for many users at once, model/cf/evaluator.go:162-169: user users[t] ranks the
+ * candidates cand[cand_indptr[t] .. cand_indptr[t+1]) through heap.TopKFilter(topk)
+ * (common/heap/filter.go:23-59, Go container/heap tie behaviour).  rank_out is
+ * n_users*topk, padded with -1; rank_len[t] = number of valid entries. */
+int32_t gorse_mf_rank(gorse_mf *h, int64_t n_users, const int32_t *users /*host*/, const int64_t *cand_indptr /*host*/,
+                      const int32_t *cand /*host*/, int32_t topk, int32_t *rank_out /*host*/, int32_t *rank_len /*host*/);
+
+/* ---- BPR, model/cf/model.go:446-494 ------------------------------------------------------
+ * One call = n_samples SGD steps (the reference does CountFeedback() per epoch).
+ * Sampling (model.go:449-468) runs on the device from a counter-based Philox4x32-10 stream
+ * keyed by (seed, epoch, sample_base + sample index) and consumed through Go's Int31n
+ * algorithm; gorse_bpr_sample_triplets returns exactly the triplets an epoch call with the
+ * same (seed, epoch, sample_base) applies, so a caller (or a test) can replay them.
+ * loss_out (may be NULL) receives sum log1p(exp(-diff)), the reference's unused `cost`. */
+int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
+                        int64_t sample_base, int32_t mode, const volatile int32_t *cancel /*host or NULL*/,
+                        double *loss_out /*host or NULL*/);
+/* Same, but only enqueues the work on the handle's stream (hogwild modes only). */
+int32_t gorse_bpr_epoch_enqueue(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
+                                int64_t sample_base, int32_t mode);
+int32_t gorse_bpr_sample_triplets(gorse_mf *h, int64_t n, uint64_t seed, uint64_t epoch, int64_t sample_base,
+                                  int32_t *u /*host*/, int32_t *i /*host*/, int32_t *j /*host*/);
+/* Apply a host-supplied triplet stream (test hook and replay path). Triplets with a
+ * negative index are skipped. */
+int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u /*host*/, const int32_t *i /*host*/,
+                                 const int32_t *j /*host*/, int64_t n, float lr, float reg, int32_t mode);
+
+/* ---- ALS (eALS), model/cf/model.go:641-738 ------------------------------------------------
+ * One call = one epoch: S = sum q q^T over items with feedback, user sweep, S = sum p p^T
+ * over users with feedback, item sweep.  Needs item_indptr/item_indices. */
+int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const volatile int32_t *cancel /*host or NULL*/);
+
+/* ---- multi-GPU exchange (one process per GPU; Q replicated, users sharded) ------------------
+ * mark:   Q_sync <- Q
+ * export: dst[I*d] <- Q - Q_sync                 (device buffer owned by the caller)
+ * import: Q <- Q_sync + src ; Q_sync <- Q        (src = all-reduced sum of every rank's export) */
+int32_t gorse_mf_item_sync_mark(gorse_mf *h);
+int32_t gorse_mf_item_delta_export(gorse_mf *h, float *dst /*device*/);
+int32_t gorse_mf_item_delta_import(gorse_mf *h, const float *src /*device*/);
+/* Raw device addresses of the resident factor matrices (row-major U*d, I*d). */
+int32_t gorse_mf_device_ptrs(gorse_mf *h, float **P /*out: device*/, float **Q /*out: device*/);
+
+/* ---- stream / measurement ---------------------------------------------------------------------
+ * All work of a handle runs on the handle's own HIP stream(s).  Profiling mode brackets every
+ * launch of the dominant kernels with hipEvents on the stream they run on and accumulates
+ * (count, milliseconds) per kernel class; bench.py reads these for the roofline line. */
+int32_t gorse_mf_synchronize(gorse_mf *h);
+int32_t gorse_mf_set_profiling(gorse_mf *h, int32_t on);
+#define GORSE_PROF_BPR_UPDATE 0
+#define GORSE_PROF_BPR_SAMPLE 1
+#define GORSE_PROF_ALS_SWEEP 2
+#define GORSE_PROF_ALS_GRAM 3
+#define GORSE_PROF_NCLASSES 4
+int32_t gorse_mf_get_profile(gorse_mf *h, int32_t kernel_class, int64_t *launches, double *total_ms);
+int32_t gorse_mf_reset_profile(gorse_mf *h);
+
+/* ---- exact top-k: ann.Index / ann.Bruteforce, common/ann/ann.go:21-25, bruteforce.go:24-83 ----
+ * X is N x d row-major, float32 or bf16 (uint16).  Search results follow the reference
+ * exactly: the k smallest distances kept in a max-heap (pq.go), Reverse(), popped ascending;
+ * ties resolved as Go's container/heap resolves them; prune0 drops results with distance <= 0.
+ * idx_out / dist_out are nq*k, padded with -1 / +inf; count_out[t] = valid entries. */
+int32_t gorse_topk_create(gorse_topk **h, int32_t device, int64_t N, int32_t d, int32_t dtype, int32_t metric,
+                          const void *X /*host*/);
+int32_t gorse_topk_destroy(gorse_topk *h);
+/* Bruteforce.SearchIndex for nq stored vectors q[t] (the vector itself is excluded, i != q). */
+int32_t gorse_topk_search_index(gorse_topk *h, const int64_t *q /*host*/, int64_t nq, int32_t k, int32_t prune0,
+                                int32_t *idx_out /*host*/, float *dist_out /*host*/, int32_t *count_out /*host*/);
+/* Bruteforce.SearchVector for nq query vectors (nq x d, same dtype as the index). */
+int32_t gorse_topk_search_vector(gorse_topk *h, const void *qv /*host*/, int64_t nq, int32_t k, int32_t prune0,
+                                 int32_t *idx_out /*host*/, float *dist_out /*host*/, int32_t *count_out /*host*/);
+/* SearchIndex for every stored vector q in [q_begin, q_end): the item-to-item bulk build.
+ * Results stay on the device unless host pointers are given (either may be NULL). */
+int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t *idx_out /*host or NULL*/,
+                             float *dist_out /*host or NULL*/);
+int32_t gorse_topk_synchronize(gorse_topk *h);
+#define GORSE_PROF_TOPK_SCORE 0
+#define GORSE_PROF_TOPK_RESCORE 1
+int32_t gorse_topk_set_profiling(gorse_topk *h, int32_t on);
+int32_t gorse_topk_get_profile(gorse_topk *h, int32_t kernel_class, int64_t *launches, double *total_ms);
+/* statistics of the last all_pairs / search call: queries that took the exact fallback path */
+int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int64_t *n_tie_resolved);
+
+/* ---- floats.MM / blas.SGEMM, common/floats/floats.go:241, mm.go:19-49 ------------------------
+ * Row-major C(m x n) = op(A) op(B) with the reference's own semantics: the NN, TN and TT
+ * cases ACCUMULATE into C, the NT case overwrites it (mm.go:20-48, floats_avx512.c:443-480). */
+int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k,
+                        const float *a /*host*/, int32_t lda, const float *b /*host*/, int32_t ldb, float *c /*host*/,
+                        int32_t ldc);
+
+/* ---- test hook -------------------------------------------------------------------------
+ * exp flavour used by the GORSE_BPR_SEQUENTIAL schedule: 0 = device expf (default),
+ * 1 = the float32 FreeBSD/math32 scheme restated in oracle/gorse_oracle.c (orc_exp_restated),
+ * which makes device and oracle factors comparable bit for bit. */
+void gorse_hip_test_set_exact_exp(int32_t mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GORSE_HIP_H */

@@ -1,0 +1,322 @@
+"""GPU parity tests (run on the MI355X box): HIP path through the C ABI vs the CPU oracle.
+
+Bars: bit-exact for integer/index work (sampled triplets, rank lists,
+scores in the reference's AVX512 operation order); BPR factors under the same (sequential)
+schedule bit-exact with the restated exp and <= 1e-4 relative with libm exp; ALS factors
+<= 1e-4 relative; Hogwild schedules: NDCG@10 within +-0.01 of the sequential oracle.
+"""
+import numpy as np
+import pytest
+
+from gorse_amd import capi, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-6)))
+
+
+@pytest.fixture(scope="module")
+def small():
+    return synth.synth_cf(300, 200, 6000, seed=7, min_len=3, n_neg=50)
+
+
+@pytest.fixture(autouse=True)
+def _reset(oracle):
+    oracle.set_isa(orc.ISA_AVX512)
+    oracle.set_exp(0)
+    capi.lib().gorse_hip_test_set_exact_exp(0)
+    yield
+    oracle.set_isa(orc.ISA_AVX512)
+    oracle.set_exp(0)
+    capi.lib().gorse_hip_test_set_exact_exp(0)
+
+
+def make_mf(data, d, seed=3, std=0.1, with_items=True):
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, data.iptr if with_items else None,
+                 data.iidx if with_items else None)
+    P, Q = synth.init_factors(data.U, data.I, d, 0.0, std, seed)
+    mf.set_factors(P, Q)
+    return mf, P, Q
+
+
+def test_device_present_and_abi():
+    assert capi.lib().gorse_hip_abi_version() == 1
+    assert capi.device_count() >= 1
+
+
+@pytest.mark.parametrize("d", [16, 64, 128, 8, 10, 24, 50, 100])
+def test_score_bit_exact(oracle, small, d):
+    # internalPredict == floats.Dot, model/cf/model.go:195-203 (model_test.go:60-62 asserts equality)
+    mf, P, Q = make_mf(small, d)
+    rng = np.random.default_rng(1)
+    u = rng.integers(0, small.U, 5000).astype(np.int32)
+    i = rng.integers(0, small.I, 5000).astype(np.int32)
+    u[:3] = -1  # unknown user -> 0
+    got = mf.score(u, i)
+    exp = oracle.mf_score(P, Q, u, i)
+    assert np.array_equal(bits(got), bits(exp))
+    P2, Q2 = mf.get_factors()
+    assert np.array_equal(bits(P2), bits(P)) and np.array_equal(bits(Q2), bits(Q))
+
+
+def test_sampler_matches_oracle(oracle, small):
+    # model/cf/model.go:449-468 through the shared Philox stream: integer-exact
+    mf, _, _ = make_mf(small, 16, with_items=False)
+    for (seed, epoch, base, n) in [(1, 0, 0, 20000), (0xDEADBEEFCAFE, 7, 123456789012, 5000)]:
+        gu, gi, gj = mf.bpr_sample_triplets(n, seed, epoch, base)
+        eu, ei, ej = oracle.bpr_sample(small.U, small.I, small.uptr, small.uidx, n, seed, epoch, base)
+        assert np.array_equal(gu, eu) and np.array_equal(gi, ei) and np.array_equal(gj, ej)
+    # semantics: positive is one of the user's items, negative is not
+    for t in range(200):
+        row = small.uidx[small.uptr[gu[t]]:small.uptr[gu[t] + 1]]
+        assert gi[t] in row and gj[t] not in row
+
+
+def test_sampler_users_without_feedback(oracle):
+    # users with no feedback are re-drawn (model.go:452-458); ragged/empty rows
+    U, I = 50, 40
+    lens = np.zeros(U, np.int64)
+    lens[::3] = 5
+    uptr = np.zeros(U + 1, np.int64)
+    np.cumsum(lens, out=uptr[1:])
+    rng = np.random.default_rng(3)
+    uidx = np.concatenate([rng.permutation(I)[:5] for _ in range(int((lens > 0).sum()))]).astype(np.int32)
+    mf = capi.MF(U, I, 16, uptr, uidx)
+    gu, gi, gj = mf.bpr_sample_triplets(4000, 5, 1)
+    eu, ei, ej = oracle.bpr_sample(U, I, uptr, uidx, 4000, 5, 1)
+    assert np.array_equal(gu, eu) and np.array_equal(gi, ei) and np.array_equal(gj, ej)
+    assert (lens[gu] > 0).all()
+
+
+@pytest.mark.parametrize("d", [16, 64, 128, 8, 10, 24, 50])
+def test_bpr_sequential_bit_exact(oracle, small, d):
+    """Same triplet stream, sequential schedule: device factors == oracle factors, bit for bit
+    (exp restated identically on both sides)."""
+    mf, P, Q = make_mf(small, d, std=0.3)
+    u, i, j = oracle.bpr_sample(small.U, small.I, small.uptr, small.uidx, 8000, 11, 0)
+    oracle.set_exp(1)
+    capi.lib().gorse_hip_test_set_exact_exp(1)
+    eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
+    mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_SEQUENTIAL)
+    gP, gQ = mf.get_factors()
+    assert np.array_equal(bits(gP), bits(eP))
+    assert np.array_equal(bits(gQ), bits(eQ))
+
+
+def test_bpr_sequential_libm_exp_within_tolerance(oracle, small):
+    # against the oracle with libm expf: factor values within 1e-4 relative (north_star)
+    d = 64
+    mf, P, Q = make_mf(small, d, std=0.3)
+    u, i, j = oracle.bpr_sample(small.U, small.I, small.uptr, small.uidx, 8000, 12, 0)
+    eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
+    mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_SEQUENTIAL)
+    gP, gQ = mf.get_factors()
+    assert rel_err(gP, eP) < 1e-4 and rel_err(gQ, eQ) < 1e-4
+
+
+def test_bpr_sequential_epoch_equals_replay(oracle, small):
+    # gorse_bpr_epoch(mode=sequential) == oracle applied to the stream gorse_bpr_sample_triplets reports
+    d = 32
+    mf, P, Q = make_mf(small, d, std=0.2)
+    oracle.set_exp(1)
+    capi.lib().gorse_hip_test_set_exact_exp(1)
+    n = small.n_train
+    u, i, j = mf.bpr_sample_triplets(n, 99, 3)
+    loss = mf.bpr_epoch(n, 0.05, 0.01, 99, 3, mode=capi.BPR_SEQUENTIAL, want_loss=True)
+    eP, eQ, cost = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
+    gP, gQ = mf.get_factors()
+    assert np.array_equal(bits(gP), bits(eP)) and np.array_equal(bits(gQ), bits(eQ))
+    assert abs(loss - cost) < 1e-3 * abs(cost)
+
+
+def test_bpr_skips_negative_triplets_and_same_item(oracle, small):
+    d = 16
+    mf, P, Q = make_mf(small, d, std=0.3)
+    u = np.array([0, -1, 2, 3, 3], np.int32)
+    i = np.array([1, 2, -1, 5, 7], np.int32)
+    j = np.array([2, 3, 4, 5, 9], np.int32)  # sample 3 has i == j (hand-made stream)
+    oracle.set_exp(1)
+    capi.lib().gorse_hip_test_set_exact_exp(1)
+    eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
+    mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_SEQUENTIAL)
+    gP, gQ = mf.get_factors()
+    assert np.array_equal(bits(gP), bits(eP)) and np.array_equal(bits(gQ), bits(eQ))
+
+
+@pytest.mark.parametrize("mode", [capi.BPR_HOGWILD_ATOMIC, capi.BPR_HOGWILD_RACY])
+@pytest.mark.parametrize("d", [16, 64, 128, 24])
+def test_bpr_hogwild_conflict_free_batch(oracle, small, mode, d):
+    """One batch whose triplets touch pairwise distinct rows: every schedule must agree with the
+    sequential oracle (only rounding of the final add differs in atomic mode)."""
+    mf, P, Q = make_mf(small, d, std=0.3)
+    rng = np.random.default_rng(5)
+    n = 60
+    u = rng.permutation(small.U)[:n].astype(np.int32)
+    items = rng.permutation(small.I)[:2 * n].astype(np.int32)
+    i, j = items[:n], items[n:]
+    eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
+    mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, mode)
+    gP, gQ = mf.get_factors()
+    assert rel_err(gP, eP) < 2e-5 and rel_err(gQ, eQ) < 2e-5
+    # untouched rows are untouched
+    mask = np.ones(small.U, bool)
+    mask[u] = False
+    assert np.array_equal(bits(gP[mask]), bits(P[mask]))
+
+
+def test_bpr_atomic_no_lost_updates(small):
+    """All samples hit the same (u, i, j): with atomics every update must land (sum of deltas)."""
+    d = 16
+    mf, P, Q = make_mf(small, d, std=0.3)
+    n = 4096
+    u = np.zeros(n, np.int32)
+    i = np.full(n, 1, np.int32)
+    j = np.full(n, 2, np.int32)
+    lr, reg = 1e-4, 0.0
+    mf.bpr_apply_triplets(u, i, j, lr, reg, capi.BPR_HOGWILD_ATOMIC)
+    gP, gQ = mf.get_factors()
+    # with reg = 0 and a tiny lr the gradient is ~constant: Q[1] moves by ~ n*lr*grad*p
+    diff = float(P[0] @ Q[1] - P[0] @ Q[2])
+    grad = 1.0 / (1.0 + np.exp(diff))
+    expect = Q[1] + n * lr * grad * P[0]
+    assert rel_err(gQ[1], expect) < 2e-2
+    assert np.abs(gQ[1] - Q[1]).max() > 0.5 * np.abs(expect - Q[1]).max()
+
+
+def test_rank_exact(oracle, small):
+    # cf.Rank / TopKFilter: index-exact, ties included (scores quantised to force ties)
+    d = 16
+    mf, P, Q = make_mf(small, d)
+    Pq = np.round(P * 4) / 4
+    Qq = np.round(Q * 4) / 4
+    mf.set_factors(Pq, Qq)
+    users, cptr, cand = small.candidates()
+    for topk in (1, 10, 37):
+        got, glen = mf.rank(users, cptr, cand, topk)
+        exp, elen = oracle.mf_rank(Pq, Qq, users, cptr, cand, topk)
+        assert np.array_equal(glen, elen)
+        assert np.array_equal(got, exp)
+
+
+def evaluate_ndcg(oracle, data, P, Q, topk=10):
+    return oracle.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, topk)
+
+
+def test_evaluate_through_device_rank(oracle, small):
+    # Evaluate (evaluator.go:35-72): device rank lists + host metrics == oracle Evaluate exactly
+    d = 32
+    mf, P, Q = make_mf(small, d)
+    users, cptr, cand = small.candidates()
+    rank, rlen = mf.rank(users, cptr, cand, 10)
+    sums = np.zeros(3, np.float32)
+    for t, u in enumerate(users):
+        tgt = small.test_idx[small.test_ptr[u]:small.test_ptr[u + 1]]
+        for m, mid in enumerate((orc.M_NDCG, orc.M_PRECISION, orc.M_RECALL)):
+            sums[m] += np.float32(oracle.metric(mid, tgt, rank[t, :rlen[t]]))
+    got = sums * np.float32(1 / np.float32(users.size))
+    exp = evaluate_ndcg(oracle, small, P, Q)
+    assert np.array_equal(bits(got), bits(exp))
+
+
+@pytest.mark.parametrize("mode", [capi.BPR_HOGWILD_ATOMIC, capi.BPR_HOGWILD_RACY])
+def test_bpr_hogwild_ndcg_parity_ml100k(oracle, mode):
+    """Statistical parity with the reference's sequential semantics (model_test.go:35-48 style):
+    S-ml100k, nFactors 16, lr .05, reg .01, 10 epochs; NDCG@10 within +-0.01 of the CPU oracle."""
+    data = synth.s_ml100k()
+    d, lr, reg, epochs = 16, 0.05, 0.01, 10
+    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
+    # oracle: sequential epochs on the same sampler stream
+    P, Q = P0.copy(), Q0.copy()
+    srt = orc.sort_rows(data.uptr, data.uidx)
+    for ep in range(1, epochs + 1):
+        oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, 2024, ep, 0, data.n_train, lr, reg)
+    ref = evaluate_ndcg(oracle, data, P, Q)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P0, Q0)
+    for ep in range(1, epochs + 1):
+        mf.bpr_epoch(data.n_train, lr, reg, 2024, ep, mode=mode)
+    gP, gQ = mf.get_factors()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+    got = evaluate_ndcg(oracle, data, gP, gQ)
+    print("NDCG oracle %.4f device(mode %d) %.4f" % (ref[0], mode, got[0]))
+    assert ref[0] > 0.15  # the model learned something
+    assert abs(float(got[0]) - float(ref[0])) < 0.01
+
+
+@pytest.mark.parametrize("d", [16, 64, 24])
+def test_als_epoch_parity(oracle, small, d):
+    # ALS is deterministic w.r.t. Jobs: <= 1e-4 relative after 3 epochs
+    mf, P, Q = make_mf(small, d, std=0.1)
+    eP, eQ = P, Q
+    for _ in range(3):
+        eP, eQ = oracle.als_epoch(eP, eQ, small.uptr, small.uidx, small.iptr, small.iidx, 0.05, 0.015)
+        mf.als_epoch(0.05, 0.015)
+    gP, gQ = mf.get_factors()
+    assert np.isfinite(gP).all()
+    scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
+
+
+def test_als_needs_item_csr(small):
+    mf, _, _ = make_mf(small, 16, with_items=False)
+    with pytest.raises(capi.GorseHipError) as e:
+        mf.als_epoch(0.05, 0.015)
+    assert e.value.code == capi.ERR_INVALID
+
+
+def test_als_heavy_rows(oracle):
+    # rows longer than the LDS staging caps (global-scratch path)
+    data = synth.synth_cf(40, 6000, 60000, seed=9, min_len=3, max_frac=0.9, n_neg=10)
+    d = 16
+    mf, P, Q = make_mf(data, d, std=0.1)
+    eP, eQ = oracle.als_epoch(P, Q, data.uptr, data.uidx, data.iptr, data.iidx, 0.05, 0.015)
+    mf.als_epoch(0.05, 0.015)
+    gP, gQ = mf.get_factors()
+    scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
+
+
+def test_multi_gpu_exchange_calls(small):
+    # Q <- Q_sync + sum of deltas: with one rank the round trip is the identity on Q
+    import torch
+    d = 32
+    mf, P, Q = make_mf(small, d, std=0.3)
+    mf.item_sync_mark()
+    mf.bpr_epoch(small.n_train, 0.05, 0.01, 5, 1)
+    _, Q1 = mf.get_factors()
+    buf = torch.empty(small.I * d, dtype=torch.float32, device="cuda")
+    mf.item_delta_export(buf.data_ptr())
+    delta = buf.cpu().numpy().reshape(small.I, d)
+    assert np.allclose(delta, Q1 - Q, atol=1e-6)
+    buf.mul_(2.0)  # pretend a second rank produced the same delta
+    mf.item_delta_import(buf.data_ptr())
+    _, Q2 = mf.get_factors()
+    assert np.allclose(Q2, Q + 2 * delta, atol=1e-5)
+
+
+def test_error_paths(small):
+    with pytest.raises(capi.GorseHipError):
+        capi.MF(10, 10, 0, np.zeros(11, np.int64), np.zeros(0, np.int32))
+    bad = small.uidx.copy()
+    bad[0] = small.I + 5
+    with pytest.raises(capi.GorseHipError):
+        capi.MF(small.U, small.I, 8, small.uptr, bad)
+    mf, _, _ = make_mf(small, 16, with_items=False)
+    with pytest.raises(capi.GorseHipError) as e:
+        mf.score(np.array([small.U + 1], np.int32), np.array([0], np.int32))
+    assert e.value.code == capi.ERR_RANGE
+    with pytest.raises(capi.GorseHipError):
+        mf.bpr_epoch(10, 0.05, 0.01, 1, 1, mode=9)
+    cancel = np.ones(1, np.int32)
+    with pytest.raises(capi.GorseHipError) as e:
+        mf.bpr_epoch(small.n_train, 0.05, 0.01, 1, 1, cancel=cancel)
+    assert e.value.code == capi.ERR_CANCELLED
