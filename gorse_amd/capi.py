@@ -64,6 +64,7 @@ SIGNATURES = {
     "gorse_hip_sgemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_int32,
                                     _f32p, C.c_int32, _f32p, C.c_int32]),
     "gorse_hip_test_set_exact_exp": (None, [C.c_int32]),
+    "gorse_hip_test_set_variant": (None, [C.c_int32]),
 }
 
 

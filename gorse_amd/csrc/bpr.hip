@@ -15,6 +15,7 @@ using namespace gorse;
 
 namespace {
 
+int g_variant = 0;  // probe-only ablation bits (1 plain loads, 2/4/8 skip P/Qi/Qj writes)
 constexpr int MODE_ATOMIC = GORSE_BPR_HOGWILD_ATOMIC;
 constexpr int MODE_EXACT = GORSE_BPR_SEQUENTIAL;
 constexpr int MODE_RACY = GORSE_BPR_HOGWILD_RACY;
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(int32_t U, int32_t I, c
 
 // ---- memory access flavours ------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ float load_row(const float *p) {
-    if constexpr (MODE == MODE_EXACT)
+__device__ __forceinline__ float load_row(const float *p, int variant = 0) {
+    if (MODE == MODE_EXACT || (variant & 1))
         return *p;
     else  // agent-scope load: served by L2 (never stale for written-back data), bypasses the CU's L1
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -104,7 +105,7 @@ __device__ __forceinline__ float bpr_exp(float x, int exp_mode) {
 // one element of the three updates of model.go:473-488 (operation order of SURVEY.md A2)
 template <int MODE>
 __device__ __forceinline__ void update_elem(float *pu, float *qi, float *qj, int e, float p, float a, float b, float grad,
-                                            float nreg, float lr, bool fused, bool same_item) {
+                                            float nreg, float lr, bool fused, bool same_item, int variant = 0) {
     float t1 = p * grad;
     t1 = fused ? fmaf(a, nreg, t1) : a * nreg + t1;
     float t2 = p * (-grad);
@@ -120,9 +121,9 @@ __device__ __forceinline__ void update_elem(float *pu, float *qi, float *qj, int
         qj[e] = fused ? fmaf(t2, lr, base) : t2 * lr + base;
         pu[e] = fused ? fmaf(t3, lr, p) : t3 * lr + p;
     } else {
-        apply<MODE>(qi + e, a, t1, lr, fused);
-        apply<MODE>(qj + e, b, t2, lr, fused);
-        apply<MODE>(pu + e, p, t3, lr, fused);
+        if (!(variant & 4)) apply<MODE>(qi + e, a, t1, lr, fused);
+        if (!(variant & 8)) apply<MODE>(qj + e, b, t2, lr, fused);
+        if (!(variant & 2)) apply<MODE>(pu + e, p, t3, lr, fused);
     }
 }
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
                                                             const int32_t *__restrict__ js,
                                                             const int32_t *__restrict__ order, int64_t begin,
                                                             int64_t end, int d, float lr, float reg, int exp_mode,
-                                                            double *loss) {
+                                                            double *loss, int variant) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & (kGroup - 1);
     const int gib = threadIdx.x / kGroup;
@@ -150,9 +151,9 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
             float p[NC], a[NC], b[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                p[c] = load_row<MODE>(pu + 16 * c + lane);
-                a[c] = load_row<MODE>(qi + 16 * c + lane);
-                b[c] = load_row<MODE>(qj + 16 * c + lane);
+                p[c] = load_row<MODE>(pu + 16 * c + lane, variant);
+                a[c] = load_row<MODE>(qi + 16 * c + lane, variant);
+                b[c] = load_row<MODE>(qj + 16 * c + lane, variant);
             }
             const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
             const float ex = bpr_exp(-diff, exp_mode);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
             if (loss && lane == 0) my_loss += (double)log1pf(ex);
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                update_elem<MODE>(pu, qi, qj, 16 * c + lane, p[c], a[c], b[c], grad, nreg, lr, true, i == j);
+                update_elem<MODE>(pu, qi, qj, 16 * c + lane, p[c], a[c], b[c], grad, nreg, lr, true, i == j, variant);
         } else {
             float *sp = smem + (size_t)gib * 3 * d, *sa = sp + d, *sb = sa + d;
             for (int e = lane; e < d; e += kGroup) {
@@ -194,7 +195,7 @@ int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, co
     dim3 grid((unsigned)blocks), block(kBlock);
 #define LAUNCH(NC, SH)                                                                                               \
     bpr_update_kernel<NC, MODE><<<grid, block, SH, st>>>(h->P.p, h->Q.p, us, is, js, order, begin, end, d, lr, reg, \
-                                                         exp_mode, loss)
+                                                         exp_mode, loss, g_variant)
     if (d == 16)
         LAUNCH(1, 0);
     else if (d == 32)
@@ -362,6 +363,7 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
 }  // namespace
 
 extern "C" void gorse_hip_test_set_exact_exp(int32_t mode) { g_exp_mode_exact = mode; }
+extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
 
 extern "C" int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
                                    int64_t sample_base, int32_t mode, const volatile int32_t *cancel, double *loss_out) {

@@ -184,6 +184,10 @@ int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t 
  * 1 = the float32 FreeBSD/math32 scheme restated in oracle/gorse_oracle.c (orc_exp_restated),
  * which makes device and oracle factors comparable bit for bit. */
 void gorse_hip_test_set_exact_exp(int32_t mode);
+/* probe-only ablation of the Hogwild update kernel (bit 0: plain instead of L1-bypassing loads;
+ * bits 1/2/3: skip the writes to P / Q[i] / Q[j]).  Used by scripts/gpu_probe_*.py to attribute time;
+ * 0 (the default) is the only value the product ever runs with. */
+void gorse_hip_test_set_variant(int32_t variant);
 
 #ifdef __cplusplus
 }
