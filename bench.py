@@ -31,6 +31,7 @@ import torch  # noqa: E402  (first: libgorse_hip then binds to the HIP runtime t
 import torch.distributed as dist  # noqa: E402
 
 from gorse_amd import capi, synth  # noqa: E402
+from gorse_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
@@ -126,19 +127,13 @@ def main():
     if world > 1:
         P0 = synth.init_factors(data.U, 1, d, 0.0, 0.001, seed=100 + rank)[0]
     mf.set_factors(P0, Q0)
-    xbuf = None
+    engine = gdist.HipEngine(mf, args.mode)
+    comm = gdist.TorchComm() if world > 1 else None
     if world > 1:
-        xbuf = torch.empty(data.I * d, dtype=torch.float32, device="cuda")
-        mf.item_sync_mark()
-        mf.synchronize()
+        engine.enable_exchange()
 
-    def step(epoch):
-        mf.bpr_epoch_enqueue(n_samples, lr, reg, 2024, epoch, sample_base=rank * (1 << 40), mode=args.mode)
-        if world > 1:  # exchange step: Q <- Q_sync + sum over ranks of (Q - Q_sync)
-            mf.item_delta_export(xbuf.data_ptr())
-            dist.all_reduce(xbuf)
-            torch.cuda.synchronize()
-            mf.item_delta_import(xbuf.data_ptr())
+    def step(epoch):  # gorse_amd.dist.run_epoch is the function the gloo CPU tests exercise
+        gdist.run_epoch(engine, comm, n_samples, lr, reg, 2024, epoch, rank * (1 << 40))
 
     def fence():
         mf.synchronize()

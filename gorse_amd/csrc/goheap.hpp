@@ -8,9 +8,13 @@
 //               if !less(j,i) break; swap(i,j); i=j
 //   Push = append, up(n-1).   Pop = swap(0,n-1), down(0,n-1), take last.
 #pragma once
-#include <hip/hip_runtime.h>
-
 #include <cstdint>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GORSE_HD __host__ __device__
+#else
+#define GORSE_HD
+#endif
 
 namespace gorse {
 
@@ -19,9 +23,9 @@ struct GoHeap {
     int32_t *v;
     float *w;
     int n;
-    __host__ __device__ GoHeap(int32_t *v_, float *w_) : v(v_), w(w_), n(0) {}
-    __host__ __device__ bool less(int i, int j) const { return DESC ? w[i] > w[j] : w[i] < w[j]; }
-    __host__ __device__ void swap(int i, int j) {
+    GORSE_HD GoHeap(int32_t *v_, float *w_) : v(v_), w(w_), n(0) {}
+    GORSE_HD bool less(int i, int j) const { return DESC ? w[i] > w[j] : w[i] < w[j]; }
+    GORSE_HD void swap(int i, int j) {
         int32_t tv = v[i];
         v[i] = v[j];
         v[j] = tv;
@@ -29,7 +33,7 @@ struct GoHeap {
         w[i] = w[j];
         w[j] = tw;
     }
-    __host__ __device__ void up(int j) {
+    GORSE_HD void up(int j) {
         for (;;) {
             int i = (j - 1) / 2;
             if (i == j || !less(j, i)) break;
@@ -37,7 +41,7 @@ struct GoHeap {
             j = i;
         }
     }
-    __host__ __device__ void down(int i0, int m) {
+    GORSE_HD void down(int i0, int m) {
         int i = i0;
         for (;;) {
             int j1 = 2 * i + 1;
@@ -49,14 +53,14 @@ struct GoHeap {
             i = j;
         }
     }
-    __host__ __device__ void push(int32_t val, float wt) {
+    GORSE_HD void push(int32_t val, float wt) {
         v[n] = val;
         w[n] = wt;
         n++;
         up(n - 1);
     }
     // removes the root; it is left at position n (just past the new end)
-    __host__ __device__ void pop() {
+    GORSE_HD void pop() {
         int m = n - 1;
         swap(0, m);
         down(0, m);

@@ -1,0 +1,88 @@
+"""Multi-GPU BPR: one process per GPU, users sharded by contiguous row range, item factors replicated.
+
+The reference trains in one process; sharding is this implementation's own
+(SURVEY.md 8e).  Per epoch every rank runs its share of the SGD samples against its own replica of Q
+and the ranks then exchange the ONE thing they share:
+
+    Q  <-  Q_sync + sum over ranks of (Q_rank - Q_sync)          (all-reduce of I*d fp32 over RCCL)
+
+`run_epoch` is backend-agnostic: `engine` is anything with epoch()/export_delta()/import_delta()
+(gorse_amd.dist.HipEngine on a GPU; the CPU tests inject an oracle-backed engine and run the very
+same function over gloo with world_size 2).
+"""
+import numpy as np
+
+
+def shard_range(n_rows, rank, world):
+    """Contiguous row range [lo, hi) owned by `rank` (remainder rows go to the first ranks)."""
+    base, rem = divmod(int(n_rows), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def samples_for_rank(n_total, users_with_feedback_local, users_with_feedback_total):
+    """The reference draws the user uniformly among users with feedback (model/cf/model.go:452-458),
+    so a shard's expected share of an epoch's CountFeedback() samples is its share of such users."""
+    if users_with_feedback_total == 0:
+        return 0
+    return int(round(n_total * users_with_feedback_local / users_with_feedback_total))
+
+
+def shard_csr(indptr, indices, lo, hi):
+    """Rows [lo, hi) of a CSR, re-based to start at 0."""
+    indptr = np.asarray(indptr, np.int64)
+    p = indptr[lo:hi + 1] - indptr[lo]
+    return np.ascontiguousarray(p), np.ascontiguousarray(np.asarray(indices)[indptr[lo]:indptr[hi]])
+
+
+def run_epoch(engine, comm, n_samples, lr, reg, seed, epoch, sample_base):
+    """One data-parallel BPR epoch + the item-factor exchange.  comm: object with all_reduce_sum(tensor)
+    (None for a single rank)."""
+    engine.epoch(n_samples, lr, reg, seed, epoch, sample_base)
+    if comm is not None and comm.world > 1:
+        delta = engine.export_delta()
+        comm.all_reduce_sum(delta)
+        engine.import_delta(delta)
+
+
+class TorchComm:
+    """torch.distributed plumbing (backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' in the CPU tests)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def all_reduce_sum(self, tensor):
+        self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+
+class HipEngine:
+    """A gorse_mf handle + a torch CUDA buffer that carries the item-factor delta through RCCL."""
+
+    def __init__(self, mf, mode):
+        import torch
+        self.torch = torch
+        self.mf, self.mode = mf, mode
+        self.xbuf = None
+
+    def enable_exchange(self):
+        self.xbuf = self.torch.empty(self.mf.I * self.mf.d, dtype=self.torch.float32, device="cuda")
+        self.mf.item_sync_mark()
+        self.mf.synchronize()
+
+    def epoch(self, n_samples, lr, reg, seed, epoch, sample_base):
+        self.mf.bpr_epoch_enqueue(n_samples, lr, reg, seed, epoch, sample_base=sample_base, mode=self.mode)
+
+    def export_delta(self):
+        self.mf.item_delta_export(self.xbuf.data_ptr())  # synchronises the library's stream
+        return self.xbuf
+
+    def import_delta(self, delta):
+        self.torch.cuda.synchronize()  # the collective ran on torch's stream
+        self.mf.item_delta_import(delta.data_ptr())

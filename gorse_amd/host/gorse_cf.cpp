@@ -1,0 +1,326 @@
+// gorse_cf.cpp -- implementation of the host mirror (see gorse_cf.hpp).  Numeric work goes through
+// the C ABI only; this file is the C++ twin of what model/cf/bpr_hip.go / als_hip.go would contain.
+#include "gorse_cf.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+namespace gorse {
+namespace cf {
+
+namespace {
+void flatten(const std::vector<std::vector<int32_t>> &rows, size_t nrows, std::vector<int64_t> &ptr,
+             std::vector<int32_t> &idx) {
+    ptr.assign(nrows + 1, 0);
+    for (size_t r = 0; r < nrows; r++) ptr[r + 1] = ptr[r] + (r < rows.size() ? (int64_t)rows[r].size() : 0);
+    idx.resize((size_t)ptr[nrows]);
+    for (size_t r = 0; r < nrows && r < rows.size(); r++) std::copy(rows[r].begin(), rows[r].end(), idx.begin() + ptr[r]);
+}
+std::string fmt(const char *f, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, f);
+    vsnprintf(buf, sizeof(buf), f, ap);
+    va_end(ap);
+    return buf;
+}
+// protobuf varint / LatentFactor{1: string id, 2: packed float data}
+void put_varint(std::ostream &w, uint64_t v) {
+    while (v >= 0x80) {
+        w.put((char)(v | 0x80));
+        v >>= 7;
+    }
+    w.put((char)v);
+}
+uint64_t get_varint(std::istream &r) {
+    uint64_t v = 0;
+    int shift = 0;
+    for (;;) {
+        int c = r.get();
+        if (c < 0) throw std::runtime_error("unexpected EOF");
+        v |= (uint64_t)(c & 0x7f) << shift;
+        if (!(c & 0x80)) break;
+        shift += 7;
+    }
+    return v;
+}
+size_t varint_len(uint64_t v) {
+    size_t n = 1;
+    while (v >= 0x80) {
+        v >>= 7;
+        n++;
+    }
+    return n;
+}
+void write_latent(std::ostream &w, const std::string &id, const float *data, int d) {
+    size_t body = 0;
+    if (!id.empty()) body += 1 + varint_len(id.size()) + id.size();
+    if (d > 0) body += 1 + varint_len((uint64_t)d * 4) + (size_t)d * 4;
+    put_varint(w, body);  // pbutil.WriteDelimited
+    if (!id.empty()) {
+        w.put(0x0A);
+        put_varint(w, id.size());
+        w.write(id.data(), (std::streamsize)id.size());
+    }
+    if (d > 0) {
+        w.put(0x12);
+        put_varint(w, (uint64_t)d * 4);
+        w.write((const char *)data, (std::streamsize)d * 4);
+    }
+}
+void read_latent(std::istream &r, std::string &id, std::vector<float> &data) {
+    uint64_t body = get_varint(r);
+    std::string buf((size_t)body, '\0');
+    r.read(&buf[0], (std::streamsize)body);
+    if ((uint64_t)r.gcount() != body) throw std::runtime_error("unexpected EOF");
+    std::istringstream s(buf);
+    id.clear();
+    data.clear();
+    while (s.peek() != EOF) {
+        uint64_t tag = get_varint(s);
+        if (tag == 0x0A) {
+            uint64_t n = get_varint(s);
+            id.resize((size_t)n);
+            s.read(&id[0], (std::streamsize)n);
+        } else if (tag == 0x12) {
+            uint64_t n = get_varint(s);
+            data.resize((size_t)n / 4);
+            s.read((char *)data.data(), (std::streamsize)n);
+        } else if (tag == 0x15) {  // unpacked float
+            float f;
+            s.read((char *)&f, 4);
+            data.push_back(f);
+        } else {
+            throw std::runtime_error("unknown LatentFactor field");
+        }
+    }
+}
+template <typename T>
+void put_le(std::ostream &w, T v) {
+    w.write((const char *)&v, sizeof(T));
+}
+template <typename T>
+T get_le(std::istream &r) {
+    T v;
+    r.read((char *)&v, sizeof(T));
+    if (r.gcount() != (std::streamsize)sizeof(T)) throw std::runtime_error("unexpected EOF");
+    return v;
+}
+}  // namespace
+
+void MatrixFactorization::Init(const dataset::Dataset &trainSet) {
+    UserIndex = trainSet.GetUserDict();
+    ItemIndex = trainSet.GetItemDict();
+    const auto &uf = trainSet.GetUserFeedback();
+    const auto &itf = trainSet.GetItemFeedback();
+    UserPredictable.assign((size_t)trainSet.CountUsers(), false);
+    for (size_t u = 0; u < UserPredictable.size(); u++) UserPredictable[u] = u < uf.size() && !uf[u].empty();
+    ItemPredictable.assign((size_t)trainSet.CountItems(), false);
+    for (size_t i = 0; i < ItemPredictable.size(); i++) ItemPredictable[i] = i < itf.size() && !itf[i].empty();
+}
+
+void MatrixFactorization::create_handle(const dataset::Dataset &trainSet, bool with_items, int device) {
+    release();
+    device_ = device;
+    std::vector<int64_t> uptr, iptr;
+    std::vector<int32_t> uidx, iidx;
+    flatten(trainSet.GetUserFeedback(), (size_t)trainSet.CountUsers(), uptr, uidx);
+    if (with_items) flatten(trainSet.GetItemFeedback(), (size_t)trainSet.CountItems(), iptr, iidx);
+    check(gorse_mf_create(&h_, device, trainSet.CountUsers(), trainSet.CountItems(), nFactors_, uptr.data(), uidx.data(),
+                          with_items ? iptr.data() : nullptr, with_items ? iidx.data() : nullptr));
+    check(gorse_mf_set_factors(h_, UserFactor.data(), ItemFactor.data()));
+}
+
+void MatrixFactorization::ensure_resident() {
+    if (h_) return;
+    if (Invalid()) throw std::runtime_error("model is not fitted");
+    // a model restored by Unmarshal has factors but no dataset: an empty feedback structure is enough for scoring
+    const int64_t U = (int64_t)(UserFactor.size() / (size_t)nFactors_), I = (int64_t)(ItemFactor.size() / (size_t)nFactors_);
+    std::vector<int64_t> uptr((size_t)U + 1, 0);
+    int32_t dummy = 0;
+    check(gorse_mf_create(&h_, device_, U, I, nFactors_, uptr.data(), &dummy, nullptr, nullptr));
+    check(gorse_mf_set_factors(h_, UserFactor.data(), ItemFactor.data()));
+}
+
+std::vector<float> Evaluate(MatrixFactorization &estimator, dataset::Dataset &testSet, dataset::Dataset &trainSet, int topK,
+                            int numCandidates, int nJobs, const std::vector<Metric> &scorers) {
+    (void)nJobs;  // the device ranks every user at once; sums are taken in user order (== nJobs 1)
+    const auto &negatives = testSet.SampleUserNegatives(trainSet, numCandidates);
+    const auto &tf = testSet.GetUserFeedback();
+    std::vector<int32_t> users;
+    std::vector<std::vector<int32_t>> cands;
+    std::vector<TargetSet> targets;
+    for (int u = 0; u < testSet.CountUsers(); u++) {
+        if ((size_t)u >= tf.size()) break;
+        TargetSet t(tf[(size_t)u].begin(), tf[(size_t)u].end());
+        if (t.empty()) continue;
+        std::vector<int32_t> c(tf[(size_t)u]);
+        if ((size_t)u < negatives.size()) c.insert(c.end(), negatives[(size_t)u].begin(), negatives[(size_t)u].end());
+        users.push_back(u);
+        cands.push_back(std::move(c));
+        targets.push_back(std::move(t));
+    }
+    std::vector<float> sum(scorers.size(), 0.0f);
+    float count = 0;
+    if (!users.empty()) {
+        auto ranks = estimator.RankMany(users, cands, topK);
+        for (size_t t = 0; t < users.size(); t++) {
+            count++;
+            for (size_t m = 0; m < scorers.size(); m++) sum[m] += scorers[m](targets[t], ranks[t]);
+        }
+    }
+    const float inv = 1 / count;
+    for (auto &s : sum) s *= inv;  // floats.MulConst(sum, 1/count)
+    return sum;
+}
+
+Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Dataset &trainSet, dataset::Dataset &valSet,
+                                    const FitConfig &config, const std::function<int32_t(int)> &run_epoch) {
+    auto log = [&](const std::string &s) {
+        if (config.Log) config.Log(s);
+    };
+    const std::vector<Metric> metrics{NDCG, Precision, Recall};
+    auto score = Evaluate(*this, valSet, trainSet, config.TopK, config.Candidates, config.Jobs, metrics);
+    std::vector<std::pair<int, float>> scores{{0, score[0]}};
+    log(fmt("fit %s 0/%d NDCG@%d=%g Precision@%d=%g Recall@%d=%g", tag, nEpochs, config.TopK, score[0], config.TopK, score[1],
+            config.TopK, score[2]));
+    for (int epoch = 1; epoch <= nEpochs; epoch++) {
+        int32_t rc = run_epoch(epoch);
+        if (rc == GORSE_ERR_CANCELLED) {  // "fit bpr canceled" -> Score{} (model.go:490-493)
+            log(fmt("fit %s canceled epoch=%d", tag, epoch));
+            pull_factors();
+            return Score{};
+        }
+        check(rc);
+        if (epoch % config.Verbose == 0 || epoch == nEpochs) {
+            score = Evaluate(*this, valSet, trainSet, config.TopK, config.Candidates, config.Jobs, metrics);
+            scores.emplace_back(epoch, score[0]);
+            log(fmt("fit %s %d/%d NDCG@%d=%g Precision@%d=%g Recall@%d=%g", tag, epoch, nEpochs, config.TopK, score[0],
+                    config.TopK, score[1], config.TopK, score[2]));
+            if (config.Patience > 0 && epoch > config.Patience) {
+                // lo.MaxBy with strict > : the FIRST maximum
+                auto best = scores[0];
+                for (auto &s : scores)
+                    if (s.second > best.second) best = s;
+                if (best.first <= epoch - config.Patience) {
+                    log(fmt("early stopping best_epoch=%d best_NDCG=%g patience=%d", best.first, best.second, config.Patience));
+                    break;
+                }
+            }
+        }
+        if (config.OnEpoch) config.OnEpoch(epoch);
+    }
+    pull_factors();  // the reference's [][]float32 rows, before Marshal / GetUserFactor are used
+    log(fmt("fit %s complete NDCG@%d=%g", tag, config.TopK, score[0]));
+    return Score{score[0], score[1], score[2]};
+}
+
+Score BPR::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitConfig &config) {
+    // Init (model.go:532-540): users first, then items
+    GetRandomGenerator().NormalMatrix(trainSet.CountUsers(), nFactors_, initMean, initStdDev, UserFactor);
+    GetRandomGenerator().NormalMatrix(trainSet.CountItems(), nFactors_, initMean, initStdDev, ItemFactor);
+    Init(trainSet);
+    create_handle(trainSet, false, config.Device);
+    // per-Fit sampler seed, as rng[i] = NewRandomGenerator(bpr.GetRandomGenerator().Int63()) (model.go:420-423)
+    const uint64_t seed = (uint64_t)GetRandomGenerator().Int63();
+    // Jobs <= 1: parallel.Parallel runs the samples strictly in order (parallel.go:34-43) -> sequential
+    // schedule; Jobs > 1: Hogwild workers -> the atomic Hogwild schedule.
+    const int mode = config.Jobs <= 1 ? GORSE_BPR_SEQUENTIAL : GORSE_BPR_HOGWILD_ATOMIC;
+    const int64_t n = trainSet.CountFeedback();
+    return fit_loop("bpr", nEpochs, trainSet, valSet, config, [&](int epoch) {
+        return gorse_bpr_epoch(h_, n, lr, reg, seed, (uint64_t)epoch, 0, mode, config.Cancel, nullptr);
+    });
+}
+
+Score ALS::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitConfig &config) {
+    GetRandomGenerator().NormalMatrix(trainSet.CountUsers(), nFactors_, initMean, initStdDev, UserFactor);
+    GetRandomGenerator().NormalMatrix(trainSet.CountItems(), nFactors_, initMean, initStdDev, ItemFactor);
+    Init(trainSet);
+    create_handle(trainSet, true, config.Device);
+    return fit_loop("als", nEpochs, trainSet, valSet, config,
+                    [&](int) { return gorse_als_epoch(h_, weight, reg, config.Cancel); });
+}
+
+void MatrixFactorization::Marshal(std::ostream &w) const {
+    put_le<int32_t>(w, (int32_t)Params.size());
+    for (auto &kv : Params) {
+        put_le<int32_t>(w, (int32_t)kv.first.size());
+        w.write(kv.first.data(), (std::streamsize)kv.first.size());
+        put_le<double>(w, kv.second);
+    }
+    int64_t cnt = 0;
+    for (int32_t u = 0; u < UserIndex->Count(); u++) cnt += IsUserPredictable(u);
+    put_le<int64_t>(w, cnt);
+    std::string id;
+    for (int32_t u = 0; u < UserIndex->Count(); u++)
+        if (IsUserPredictable(u)) {
+            UserIndex->String(u, id);
+            write_latent(w, id, GetUserFactor(u), nFactors_);
+        }
+    cnt = 0;
+    for (int32_t i = 0; i < ItemIndex->Count(); i++) cnt += IsItemPredictable(i);
+    put_le<int64_t>(w, cnt);
+    for (int32_t i = 0; i < ItemIndex->Count(); i++)
+        if (IsItemPredictable(i)) {
+            ItemIndex->String(i, id);
+            write_latent(w, id, GetItemFactor(i), nFactors_);
+        }
+}
+
+void MatrixFactorization::Unmarshal(std::istream &r) {
+    release();
+    model::Params p;
+    int32_t np = get_le<int32_t>(r);
+    for (int32_t k = 0; k < np; k++) {
+        int32_t len = get_le<int32_t>(r);
+        std::string name((size_t)len, '\0');
+        r.read(&name[0], len);
+        p[name] = get_le<double>(r);
+    }
+    SetParams(p);
+    auto read_side = [&](std::shared_ptr<dataset::FreqDict> &dict, std::vector<bool> &pred, std::vector<float> &fac) {
+        int64_t cnt = get_le<int64_t>(r);
+        dict = std::make_shared<dataset::FreqDict>();
+        pred.assign((size_t)cnt, false);
+        fac.assign((size_t)cnt * (size_t)nFactors_, 0.0f);
+        std::string id;
+        std::vector<float> data;
+        for (int64_t k = 0; k < cnt; k++) {
+            read_latent(r, id, data);
+            int32_t idx = dict->Add(id);
+            pred[(size_t)idx] = true;
+            if ((int)data.size() != nFactors_) throw std::runtime_error("latent factor length mismatch");
+            std::copy(data.begin(), data.end(), fac.begin() + (ptrdiff_t)((size_t)idx * (size_t)nFactors_));
+        }
+    };
+    read_side(UserIndex, UserPredictable, UserFactor);
+    read_side(ItemIndex, ItemPredictable, ItemFactor);
+}
+
+void MarshalModel(std::ostream &w, const MatrixFactorization &m) {
+    std::string name = m.Name();  // encoding.WriteString: LE int32 length + bytes
+    put_le<int32_t>(w, (int32_t)name.size());
+    w.write(name.data(), (std::streamsize)name.size());
+    m.Marshal(w);
+}
+
+std::unique_ptr<MatrixFactorization> UnmarshalModel(std::istream &r) {
+    int32_t len = get_le<int32_t>(r);
+    std::string name((size_t)len, '\0');
+    r.read(&name[0], len);
+    std::unique_ptr<MatrixFactorization> m;
+    if (name == "bpr")
+        m.reset(new BPR());
+    else if (name == "als")
+        m.reset(new ALS());
+    else
+        throw std::runtime_error("unknown model " + name);
+    m->Unmarshal(r);
+    return m;
+}
+
+}  // namespace cf
+}  // namespace gorse

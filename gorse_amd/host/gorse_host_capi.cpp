@@ -1,0 +1,220 @@
+// gorse_host_capi.cpp -- flat C entry points over the C++ host mirror, so that the parity tests
+// (pytest + ctypes) can drive gorse::cf::BPR / ALS / Evaluate / ann::Bruteforce / heap::* exactly as
+// the reference's Go tests drive their Go twins.  Test/binding plumbing only.
+#include <cstring>
+#include <sstream>
+
+#include "gorse_cf.hpp"
+
+using namespace gorse;
+
+namespace {
+thread_local std::string g_err;
+template <typename F>
+int32_t guard(F &&f) {
+    try {
+        f();
+        return 0;
+    } catch (const HipError &e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::out_of_range &e) {
+        g_err = e.what();
+        return GORSE_ERR_RANGE;
+    } catch (const std::invalid_argument &e) {
+        g_err = e.what();
+        return GORSE_ERR_INVALID;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return -100;
+    }
+}
+struct FitLog {
+    std::string text;
+};
+}  // namespace
+
+extern "C" {
+const char *gh_last_error() { return g_err.c_str(); }
+
+// ---- dataset ---------------------------------------------------------------------------------
+void *gh_dataset_new() { return new dataset::Dataset(); }
+void *gh_dataset_new_shared(void *other) { return new dataset::Dataset(*(dataset::Dataset *)other, true); }
+void gh_dataset_free(void *d) { delete (dataset::Dataset *)d; }
+void gh_dataset_add_feedback(void *d, const int32_t *u, const int32_t *i, int64_t n) {
+    auto *ds = (dataset::Dataset *)d;
+    for (int64_t t = 0; t < n; t++) ds->AddFeedbackIndexed(u[t], i[t]);
+}
+void gh_dataset_add_feedback_str(void *d, const char *user, const char *item) {
+    ((dataset::Dataset *)d)->AddFeedback(user, item);
+}
+void gh_dataset_add_user(void *d, const char *user) { ((dataset::Dataset *)d)->AddUser(user); }
+void gh_dataset_add_item(void *d, const char *item) { ((dataset::Dataset *)d)->AddItem(item); }
+void gh_dataset_set_negatives(void *d, int32_t user, const int32_t *neg, int32_t n) {
+    ((dataset::Dataset *)d)->SetNegatives(user, std::vector<int32_t>(neg, neg + n));
+}
+int32_t gh_dataset_count_users(void *d) { return ((dataset::Dataset *)d)->CountUsers(); }
+int32_t gh_dataset_count_items(void *d) { return ((dataset::Dataset *)d)->CountItems(); }
+int32_t gh_dataset_count_feedback(void *d) { return ((dataset::Dataset *)d)->CountFeedback(); }
+
+// ---- models ------------------------------------------------------------------------------------
+static model::Params make_params(const char **names, const double *vals, int32_t n) {
+    model::Params p;
+    for (int32_t k = 0; k < n; k++) p[names[k]] = vals[k];
+    return p;
+}
+void *gh_bpr_new(const char **names, const double *vals, int32_t n) { return new cf::BPR(make_params(names, vals, n)); }
+void *gh_als_new(const char **names, const double *vals, int32_t n) { return new cf::ALS(make_params(names, vals, n)); }
+void gh_model_free(void *m) { delete (cf::MatrixFactorization *)m; }
+const char *gh_model_name(void *m) { return ((cf::MatrixFactorization *)m)->Name(); }
+
+// Fit(ctx, trainSet, valSet, config) -> Score.  log_out receives the zap-style log lines.
+int32_t gh_model_fit(void *m, void *train, void *val, int32_t jobs, int32_t verbose, int32_t candidates, int32_t topk,
+                     int32_t patience, const volatile int32_t *cancel, float *score3, int32_t *epochs_done, char *log_out,
+                     int64_t log_cap) {
+    return guard([&] {
+        cf::FitConfig c;
+        c.Jobs = jobs, c.Verbose = verbose, c.Candidates = candidates, c.TopK = topk, c.Patience = patience, c.Cancel = cancel;
+        int done = 0;
+        std::string logs;
+        c.OnEpoch = [&](int) { done++; };
+        c.Log = [&](const std::string &s) { logs += s + "\n"; };
+        cf::Score s = ((cf::MatrixFactorization *)m)->Fit(*(dataset::Dataset *)train, *(dataset::Dataset *)val, c);
+        score3[0] = s.NDCG, score3[1] = s.Precision, score3[2] = s.Recall;
+        if (epochs_done) *epochs_done = done;
+        if (log_out && log_cap > 0) {
+            size_t n = std::min<size_t>((size_t)log_cap - 1, logs.size());
+            memcpy(log_out, logs.data(), n);
+            log_out[n] = 0;
+        }
+    });
+}
+int32_t gh_model_predict(void *m, const char *user, const char *item, float *out) {
+    return guard([&] { *out = ((cf::MatrixFactorization *)m)->Predict(user, item); });
+}
+int32_t gh_model_internal_predict(void *m, int32_t u, int32_t i, float *out) {
+    return guard([&] { *out = ((cf::MatrixFactorization *)m)->internalPredict(u, i); });
+}
+int32_t gh_model_n_factors(void *m) { return ((cf::MatrixFactorization *)m)->NFactors(); }
+int32_t gh_model_count_users(void *m) {
+    auto *mf = (cf::MatrixFactorization *)m;
+    return mf->UserIndex ? mf->UserIndex->Count() : -1;
+}
+int32_t gh_model_count_items(void *m) {
+    auto *mf = (cf::MatrixFactorization *)m;
+    return mf->ItemIndex ? mf->ItemIndex->Count() : -1;
+}
+int32_t gh_model_user_index(void *m, const char *id) {
+    auto *mf = (cf::MatrixFactorization *)m;
+    return mf->UserIndex ? mf->UserIndex->Id(id) : -1;
+}
+int32_t gh_model_item_index(void *m, const char *id) {
+    auto *mf = (cf::MatrixFactorization *)m;
+    return mf->ItemIndex ? mf->ItemIndex->Id(id) : -1;
+}
+void gh_model_get_user_factor(void *m, int32_t u, float *out) {
+    auto *mf = (cf::MatrixFactorization *)m;
+    memcpy(out, mf->GetUserFactor(u), (size_t)mf->NFactors() * 4);
+}
+void gh_model_get_item_factor(void *m, int32_t i, float *out) {
+    auto *mf = (cf::MatrixFactorization *)m;
+    memcpy(out, mf->GetItemFactor(i), (size_t)mf->NFactors() * 4);
+}
+int32_t gh_model_is_user_predictable(void *m, int32_t u) { return ((cf::MatrixFactorization *)m)->IsUserPredictable(u); }
+int32_t gh_model_is_item_predictable(void *m, int32_t i) { return ((cf::MatrixFactorization *)m)->IsItemPredictable(i); }
+void gh_model_clear(void *m) { ((cf::MatrixFactorization *)m)->Clear(); }
+int32_t gh_model_invalid(void *m) { return ((cf::MatrixFactorization *)m)->Invalid(); }
+// MarshalModel into a caller buffer; returns bytes needed
+int64_t gh_model_marshal(void *m, char *buf, int64_t cap) {
+    std::ostringstream o;
+    cf::MarshalModel(o, *(cf::MatrixFactorization *)m);
+    const std::string &s = o.str();
+    if (buf && cap >= (int64_t)s.size()) memcpy(buf, s.data(), s.size());
+    return (int64_t)s.size();
+}
+void *gh_model_unmarshal(const char *buf, int64_t n) {
+    void *r = nullptr;
+    guard([&] {
+        std::istringstream i(std::string(buf, (size_t)n));
+        r = cf::UnmarshalModel(i).release();
+    });
+    return r;
+}
+// test helper: a model whose factors are given (ids "0".."n-1"), the equivalent of Unmarshal
+int32_t gh_model_load_factors(void *m, int32_t U, int32_t I, const float *P, const float *Q) {
+    return guard([&] {
+        auto *mf = (cf::MatrixFactorization *)m;
+        mf->Clear();
+        const int d = mf->NFactors();
+        mf->UserIndex = std::make_shared<dataset::FreqDict>();
+        mf->ItemIndex = std::make_shared<dataset::FreqDict>();
+        for (int32_t u = 0; u < U; u++) mf->UserIndex->Add(std::to_string(u));
+        for (int32_t i = 0; i < I; i++) mf->ItemIndex->Add(std::to_string(i));
+        mf->UserPredictable.assign((size_t)U, true);
+        mf->ItemPredictable.assign((size_t)I, true);
+        mf->UserFactor.assign(P, P + (size_t)U * (size_t)d);
+        mf->ItemFactor.assign(Q, Q + (size_t)I * (size_t)d);
+    });
+}
+// Evaluate(estimator, testSet, trainSet, topK, numCandidates, nJobs, metrics...); metric ids 0..5
+int32_t gh_evaluate(void *m, void *test, void *train, int32_t topk, int32_t candidates, int32_t jobs, const int32_t *metric_ids,
+                    int32_t n_metrics, float *out) {
+    return guard([&] {
+        static const cf::Metric table[] = {cf::NDCG, cf::Precision, cf::Recall, cf::HR, cf::MAP, cf::MRR};
+        std::vector<cf::Metric> ms;
+        for (int32_t k = 0; k < n_metrics; k++) ms.push_back(table[metric_ids[k]]);
+        auto r = cf::Evaluate(*(cf::MatrixFactorization *)m, *(dataset::Dataset *)test, *(dataset::Dataset *)train, topk,
+                              candidates, jobs, ms);
+        for (int32_t k = 0; k < n_metrics; k++) out[k] = r[(size_t)k];
+    });
+}
+float gh_metric(int32_t id, const int32_t *target, int32_t nt, const int32_t *rank, int32_t nr) {
+    static const cf::Metric table[] = {cf::NDCG, cf::Precision, cf::Recall, cf::HR, cf::MAP, cf::MRR};
+    return table[id](cf::TargetSet(target, target + nt), std::vector<int32_t>(rank, rank + nr));
+}
+
+// ---- heap ----------------------------------------------------------------------------------------
+int32_t gh_topk_filter(int32_t k, const int32_t *items, const float *weights, int32_t n, int32_t *out_items, float *out_w) {
+    heap::TopKFilter f(k);
+    for (int32_t t = 0; t < n; t++) f.Push(items[t], weights[t]);
+    auto r = f.PopAll();
+    for (size_t t = 0; t < r.size(); t++) out_items[t] = r[t].Value, out_w[t] = r[t].Weight;
+    return (int32_t)r.size();
+}
+int32_t gh_pq_drain(int32_t desc, int32_t reverse, const int32_t *items, const float *weights, int32_t n, int32_t *out_items,
+                    float *out_w) {
+    int32_t cnt = 0;
+    int32_t rc = guard([&] {
+        heap::PriorityQueue pq(desc != 0);
+        for (int32_t t = 0; t < n; t++) pq.Push(items[t], weights[t]);
+        heap::PriorityQueue q = reverse ? pq.Reverse() : pq.Clone();
+        while (q.Len() > 0) {
+            auto e = q.Pop();
+            out_items[cnt] = e.first, out_w[cnt] = e.second, cnt++;
+        }
+    });
+    return rc < 0 ? rc : cnt;
+}
+
+// ---- ann.Bruteforce ---------------------------------------------------------------------------------
+void *gh_bruteforce_new(int32_t metric) { return new ann::Bruteforce(metric); }
+void gh_bruteforce_free(void *b) { delete (ann::Bruteforce *)b; }
+int32_t gh_bruteforce_add(void *b, const float *v, int32_t d, int32_t *ret) {
+    return guard([&] { *ret = ((ann::Bruteforce *)b)->Add(std::vector<float>(v, v + d)); });
+}
+int32_t gh_bruteforce_search_index(void *b, int32_t q, int32_t k, int32_t prune0, int32_t *idx, float *dist, int32_t *cnt) {
+    return guard([&] {
+        auto r = ((ann::Bruteforce *)b)->SearchIndex(q, k, prune0 != 0);
+        *cnt = (int32_t)r.size();
+        for (size_t t = 0; t < r.size(); t++) idx[t] = r[t].first, dist[t] = r[t].second;
+    });
+}
+int32_t gh_bruteforce_search_vector(void *b, const float *q, int32_t d, int32_t k, int32_t prune0, int32_t *idx, float *dist,
+                                    int32_t *cnt) {
+    return guard([&] {
+        auto r = ((ann::Bruteforce *)b)->SearchVector(std::vector<float>(q, q + d), k, prune0 != 0);
+        *cnt = (int32_t)r.size();
+        for (size_t t = 0; t < r.size(); t++) idx[t] = r[t].first, dist[t] = r[t].second;
+    });
+}
+}  // extern "C"

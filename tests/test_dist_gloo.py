@@ -1,0 +1,108 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  The sharding / exchange logic (gorse_amd.dist) is the
+code bench.py runs on GPUs; here the per-rank compute engine is the CPU oracle (tests may use it), and the
+result must equal a single-process emulation of the same schedule, exactly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gorse_amd import dist as gdist  # noqa: E402
+from gorse_amd import synth  # noqa: E402
+
+
+class OracleEngine:
+    """CPU stand-in for HipEngine: the oracle's sequential BPR epoch on this rank's user shard."""
+
+    def __init__(self, P, Q, uptr, uidx):
+        from oracle import oracle as orc
+        self.o = orc.Oracle()
+        self.P, self.Q = P.copy(), Q.copy()
+        self.Qsync = Q.copy()
+        self.uptr, self.uidx = uptr, uidx
+        self.srt = orc.sort_rows(uptr, uidx)
+
+    def epoch(self, n, lr, reg, seed, epoch, base):
+        self.o.bpr_epoch_sampled(self.P, self.Q, self.uptr, self.uidx, self.srt, seed, epoch, base, n, lr, reg)
+
+    def export_delta(self):
+        return torch.from_numpy((self.Q - self.Qsync).ravel().copy())
+
+    def import_delta(self, delta):
+        self.Q = (self.Qsync + delta.numpy().reshape(self.Q.shape)).astype(np.float32)
+        self.Qsync = self.Q.copy()
+
+
+def _problem():
+    data = synth.synth_cf(120, 80, 2400, seed=3, min_len=3, with_test=False)
+    P, Q = synth.init_factors(data.U, data.I, 16, 0.0, 0.1, 1)
+    return data, P, Q
+
+
+def _rank_inputs(data, P, rank, world):
+    lo, hi = gdist.shard_range(data.U, rank, world)
+    uptr, uidx = gdist.shard_csr(data.uptr, data.uidx, lo, hi)
+    active = int((np.diff(uptr) > 0).sum())
+    total_active = int((np.diff(data.uptr) > 0).sum())
+    n = gdist.samples_for_rank(data.n_train, active, total_active)
+    return lo, hi, uptr, uidx, n
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data, P, Q = _problem()
+    lo, hi, uptr, uidx, n = _rank_inputs(data, P, rank, world)
+    eng = OracleEngine(P[lo:hi], Q, uptr, uidx)
+    comm = gdist.TorchComm()
+    for ep in range(1, 4):
+        gdist.run_epoch(eng, comm, n, 0.05, 0.01, 11, ep, rank * (1 << 40))
+    np.save(os.path.join(out, "P%d.npy" % rank), eng.P)
+    np.save(os.path.join(out, "Q%d.npy" % rank), eng.Q)
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_rows():
+    for n in (1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            spans = [gdist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_two_rank_bpr_matches_single_process_emulation(tmp_path):
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    # emulation: both shards run from the same Q, deltas are summed, per epoch
+    data, P, Q = _problem()
+    engines = []
+    for r in range(world):
+        lo, hi, uptr, uidx, n = _rank_inputs(data, P, r, world)
+        engines.append((OracleEngine(P[lo:hi], Q, uptr, uidx), n))
+    for ep in range(1, 4):
+        deltas = []
+        for r, (e, n) in enumerate(engines):
+            e.epoch(n, 0.05, 0.01, 11, ep, r * (1 << 40))
+            deltas.append(e.export_delta())
+        total = deltas[0] + deltas[1]
+        for e, _ in engines:
+            e.import_delta(total.clone())
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("P%d.npy" % r)), engines[r][0].P)
+        assert np.array_equal(np.load(tmp_path / ("Q%d.npy" % r)), engines[r][0].Q)
+    # every rank ends with the same replica of Q
+    assert np.array_equal(np.load(tmp_path / "Q0.npy"), np.load(tmp_path / "Q1.npy"))
+    assert not np.array_equal(np.load(tmp_path / "Q0.npy"), Q)

@@ -1,0 +1,156 @@
+"""GPU tests of the C++ host mirror, written after the reference's own tests:
+model/cf/model_test.go (TestBPR_MovieLens / TestCCD_MovieLens), evaluator_test.go (TestEvaluate),
+common/ann/ann_test.go and logics/cf_test.go.  MovieLens is not available offline, so S-ml100k /
+S-ml1m-shaped synthetic data stands in and the accuracy bar is the CPU oracle's NDCG +-0.01."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gorse_amd import capi, cf, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+fitConfig = None
+
+
+def new_fit_config(jobs=8):
+    return cf.NewFitConfig().SetVerbose(1).SetJobs(jobs)
+
+
+def assert_model_contract(m, train_data, oracle):
+    """model_test.go:50-76: Predict == internalPredict == floats.Dot of the stored factors,
+    predictable flags, marshal round trip, Clear / Invalid."""
+    oracle.set_isa(orc.ISA_AVX512)
+    assert m.Predict("1", "1") == m.internalPredict(1, 1)
+    uf, itf = m.GetUserFactor(1), m.GetItemFactor(1)
+    assert np.float32(m.internalPredict(1, 1)) == np.float32(oracle.dot(uf, itf))   # assert.Equal(floats.Dot(...))
+    assert m.Predict("no-such-user", "1") == 0.0                                     # unknown id -> 0
+    assert m.IsUserPredictable(1) and m.IsItemPredictable(1)
+    assert not m.IsUserPredictable(train_data.U + 5) and not m.IsItemPredictable(-1)
+    buf = cf.MarshalModel(m)
+    m2 = cf.UnmarshalModel(buf)
+    assert m2.Name() == m.Name()
+    assert m2.Predict("1", "1") == m.Predict("1", "1")
+    assert np.array_equal(m2.GetUserFactor(m2.UserIndex("1")), uf)
+    assert not m.Invalid()
+    m.Clear()
+    assert m.Invalid()
+
+
+def oracle_bpr_ndcg(oracle, data, d, lr, reg, epochs, std, seed=3):
+    P, Q = synth.init_factors(data.U, data.I, d, 0.0, std, seed)
+    srt = orc.sort_rows(data.uptr, data.uidx)
+    for ep in range(1, epochs + 1):
+        oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, 77, ep, 0, data.n_train, lr, reg)
+    return float(oracle.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)[0])
+
+
+def test_bpr_fit_like_TestBPR_MovieLens(oracle):
+    # model_test.go:35-48 hyper-parameters (nFactors 8, reg .01, lr .05, 30 epochs, init N(0, .001))
+    data = synth.s_ml100k()
+    train, test = cf.datasets_from_synth(data)
+    m = cf.NewBPR({"NFactors": 8, "Reg": 0.01, "Lr": 0.05, "NEpochs": 30, "InitMean": 0, "InitStdDev": 0.001})
+    score = m.Fit(train, test, new_fit_config())
+    ref = oracle_bpr_ndcg(oracle, data, 8, 0.05, 0.01, 30, 0.001)
+    print("BPR NDCG device %.4f oracle %.4f" % (score.NDCG, ref))
+    assert abs(score.NDCG - ref) < 0.01
+    assert m.epochs_done == 30 and "fit bpr 30/30" in m.log
+    assert_model_contract(m, data, oracle)
+
+
+def test_bpr_fit_jobs1_is_the_sequential_schedule(oracle):
+    # Jobs = 1 -> strictly sequential SGD (parallel.go:34-43); NDCG must agree with the oracle run
+    data = synth.synth_cf(300, 200, 6000, seed=7, min_len=3, n_neg=50)
+    train, test = cf.datasets_from_synth(data)
+    m = cf.NewBPR({"NFactors": 16, "NEpochs": 5, "InitStdDev": 0.01})
+    s1 = m.Fit(train, test, cf.NewFitConfig().SetVerbose(1).SetJobs(1))
+    s2 = cf.NewBPR({"NFactors": 16, "NEpochs": 5, "InitStdDev": 0.01}).Fit(train, test, cf.NewFitConfig().SetVerbose(1).SetJobs(1))
+    assert s1.NDCG == s2.NDCG and s1.Recall == s2.Recall  # deterministic
+
+
+def test_als_fit_like_TestCCD_MovieLens(oracle):
+    # model_test.go:93-104 (nFactors 8, reg .015, alpha .05, 30 epochs); ALS is deterministic w.r.t. Jobs
+    data = synth.s_ml100k()
+    train, test = cf.datasets_from_synth(data)
+    m = cf.NewALS({"NFactors": 8, "Reg": 0.015, "NEpochs": 10, "Alpha": 0.05})
+    score = m.Fit(train, test, new_fit_config())
+    P, Q = synth.init_factors(data.U, data.I, 8, 0.0, 0.1, 5)
+    for _ in range(10):
+        P, Q = oracle.als_epoch(P, Q, data.uptr, data.uidx, data.iptr, data.iidx, 0.05, 0.015)
+    ref = float(oracle.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)[0])
+    print("ALS NDCG device %.4f oracle %.4f" % (score.NDCG, ref))
+    assert abs(score.NDCG - ref) < 0.01
+    assert_model_contract(m, data, oracle)
+
+
+def test_early_stopping_and_cancel():
+    data = synth.synth_cf(300, 200, 6000, seed=7, min_len=3, n_neg=50)
+    train, test = cf.datasets_from_synth(data)
+    m = cf.NewBPR({"NFactors": 16, "NEpochs": 60, "Lr": 0.05})
+    m.Fit(train, test, cf.NewFitConfig().SetVerbose(1).SetJobs(4).SetPatience(3))
+    assert m.epochs_done < 60 and "early stopping" in m.log  # model.go:508-517
+    cfg = cf.NewFitConfig().SetJobs(4)
+    cfg.cancel = np.ones(1, np.int32)
+    s = cf.NewBPR({"NFactors": 16, "NEpochs": 5}).Fit(train, test, cfg)
+    assert (s.NDCG, s.Precision, s.Recall) == (0.0, 0.0, 0.0)  # ctx cancelled -> Score{} (model.go:490-493)
+
+
+def test_evaluate_like_TestEvaluate():
+    # evaluator_test.go:137-171: the mock's +1/-1/0 scores realised as factors (p_u = e_u, q_i[u] = score)
+    e = KATS["evaluate"]
+    train, test = cf.Dataset(), None
+    for i in range(4):
+        train.AddUser(i)
+    test = cf.Dataset()
+    for i in range(4):
+        test.AddUser(i // 4)
+    for i in range(16):
+        test.AddItem(i)
+        test.AddFeedback(i // 4, i)
+    assert (test.CountFeedback(), test.CountUsers(), test.CountItems()) == (16, 4, 16)
+    P = np.eye(4, 16, dtype=np.float32)
+    Q = np.zeros((16, 16), np.float32)
+    for u in range(4):
+        for i in e["positive"][u]:
+            Q[i, u] = 1
+        for i in e["negative"][u]:
+            Q[i, u] = -1
+    m = cf.NewBPR({"NFactors": 16})
+    m.load_factors(P, Q)
+    s = cf.Evaluate(m, test, train, 4, test.CountItems(), 4, cf.Precision)
+    assert len(s) == 1 and np.float32(s[0]) == np.float32(e["precision"])
+
+
+def test_evaluate_equals_oracle(oracle):
+    data = synth.synth_cf(300, 200, 6000, seed=7, min_len=3, n_neg=50)
+    train, test = cf.datasets_from_synth(data)
+    P, Q = synth.init_factors(data.U, data.I, 32, 0, 0.1, 4)
+    m = cf.NewBPR({"NFactors": 32})
+    m.load_factors(P, Q)
+    got = cf.Evaluate(m, test, train, 10, 100, 1, cf.NDCG, cf.Precision, cf.Recall)
+    exp = oracle.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_bruteforce_index_like_ann_tests(oracle):
+    # common/ann/ann.go:21-25 contract; logics/cf_test.go:26-58 golden
+    k = KATS["mf_items_search"]
+    b = cf.Bruteforce(capi.METRIC_NEG_DOT)
+    for n, v in enumerate(k["vectors"]):
+        assert b.Add(v) == n + 1  # Bruteforce.Add returns len(vectors) (bruteforce.go:34-37)
+    got = b.SearchVector(k["query"], k["k"], False)
+    assert [[k["ids"][i], -s] for i, s in got] == k["out"]
+    with pytest.raises(cf.HostError) as e:  # "index out of range" (bruteforce.go:41-43)
+        b.SearchIndex(5, 2, False)
+    assert e.value.code == capi.ERR_RANGE
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((300, 24)).astype(np.float32)
+    b = cf.Bruteforce(capi.METRIC_EUCLIDEAN)
+    for v in X:
+        b.Add(v)
+    for q in (0, 17, 299):
+        ei, ed = oracle.search_index(X, orc.METRIC_EUCLIDEAN, q, 10)
+        assert b.SearchIndex(q, 10, False) == [(int(a), float(c)) for a, c in zip(ei, ed)]
