@@ -17,7 +17,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE, ERR_RANGE, ERR_NOMEM = 0
 BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
-PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM = 0, 1, 2, 3
+PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM, PROF_BPR_SORT = 0, 1, 2, 3, 4
 PROF_TOPK_SCORE, PROF_TOPK_RESCORE = 0, 1
 
 _f32p = C.POINTER(C.c_float)
@@ -65,6 +65,7 @@ SIGNATURES = {
                                     _f32p, C.c_int32, _f32p, C.c_int32]),
     "gorse_hip_test_set_exact_exp": (None, [C.c_int32]),
     "gorse_hip_test_set_variant": (None, [C.c_int32]),
+    "gorse_hip_test_item_sort": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),
 }
 
 
@@ -186,6 +187,13 @@ class MF:
         if not (u.size == i.size == j.size):
             raise GorseHipError(ERR_INVALID, "triplet arrays differ in length")
         check(lib().gorse_bpr_apply_triplets(self.h, _p(u, _i32p), _p(i, _i32p), _p(j, _i32p), u.size, lr, reg, mode))
+
+    def test_item_sort(self, u, i, j):
+        u, i, j = _arr(u, np.int32), _arr(i, np.int32), _arr(j, np.int32)
+        su, si, sj = np.empty_like(u), np.empty_like(i), np.empty_like(j)
+        check(lib().gorse_hip_test_item_sort(self.h, _p(u, _i32p), _p(i, _i32p), _p(j, _i32p), u.size, _p(su, _i32p),
+                                             _p(si, _i32p), _p(sj, _i32p)))
+        return su, si, sj
 
     def als_epoch(self, weight, reg, cancel=None):
         cp = _p(cancel, _i32p) if cancel is not None else None

@@ -1,11 +1,19 @@
 // bpr.hip -- BPR training step on gfx950.  Reference: model/cf/model.go:446-494.
 //
-// Two kernels per chunk of samples:
-//   bpr_sample_kernel : model.go:449-468 -- one thread per sample draws (u, i, j) from a
-//                       counter-based Philox stream; runs AHEAD on its own stream.
-//   bpr_update_kernel : model.go:469-488 -- one 16-lane group per sample gathers the three
-//                       factor rows (64-byte contiguous segments per load), two AVX512-order dot
-//                       products by DPP rotate-adds, sigmoid, and three scaled row updates.
+// Kernels per chunk of samples:
+//   bpr_sample_kernel      : model.go:449-468 -- one thread per sample draws (u, i, j) from a
+//                            counter-based Philox stream; runs AHEAD on its own stream.
+//   bpr_rank/scan/scatter  : counting sort of the chunk's triplets by positive item i (the order in
+//                            which a Hogwild epoch applies its samples is free: parallel.go:44-68).
+//   bpr_update_runs_kernel : model.go:469-488 -- one 16-lane group walks a block of consecutive
+//                            SORTED samples; the positive item's row q_i stays in registers across a
+//                            run of equal i (sequential SGD on q_i inside the run, ONE atomic flush of
+//                            its delta per run), p_u and q_j are gathered per sample (64-byte contiguous
+//                            segments per load) and updated with fp32 atomics.  Popularity-skewed
+//                            positive items therefore never serialise on one L2 channel.
+//   bpr_update_kernel      : the per-sample form (one group per sample, three rows updated in place):
+//                            the sequential parity schedule, the racy diagnostic, and the round-1
+//                            atomic schedule kept for A/B probes.
 // HBM-bound: algorithmic bytes per sample = 6*d*4 (three rows read + three written) + 12 (indices).
 #include <algorithm>
 
@@ -182,6 +190,281 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
     if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
 }
 
+
+// ---- item-run schedule: counting sort by positive item ------------------------------------------
+// Counters are privatised kSortCopies ways (copy = bits 8.. of the sample index) so that the
+// returning atomics of a very popular item do not form one serial chain on a single address.
+constexpr int kSortCopies = 16;
+constexpr int kScanTile = 2048;  // elements per workgroup of the scan (256 threads x 8)
+
+__device__ __forceinline__ int64_t sort_bucket(int32_t i, int32_t I, int64_t s) {
+    const int32_t key = i < 0 ? I : i;  // skipped samples sort behind every item
+    return (int64_t)key * kSortCopies + ((s >> 8) & (kSortCopies - 1));
+}
+
+__global__ __launch_bounds__(256) void bpr_rank_kernel(const int32_t *__restrict__ is, int64_t n, int32_t I,
+                                                       int32_t *__restrict__ bucket, int32_t *__restrict__ rank) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x)
+        rank[s] = atomicAdd(&bucket[sort_bucket(is[s], I, s)], 1);
+}
+
+// exclusive scan of data[0..m) in place, three launches: tile sums, scan of the tile sums, tile rescans
+__device__ __forceinline__ int32_t block_exclusive_scan_256(int32_t v, int32_t *lds, int32_t *total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[wid] = x;
+    __syncthreads();
+    int32_t base = 0;
+    for (int w = 0; w < wid; w++) base += lds[w];
+    if (total) *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(256) void scan_tile_sums_kernel(const int32_t *__restrict__ data, int64_t m,
+                                                             int32_t *__restrict__ sums) {
+    __shared__ int32_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 8;
+    int32_t v = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if (base + e < m) v += data[base + e];
+    int32_t total;
+    (void)block_exclusive_scan_256(v, lds, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void scan_sums_kernel(int32_t *__restrict__ sums, int64_t nt) {
+    __shared__ int32_t lds[4];
+    int32_t carry = 0;
+    for (int64_t t0 = 0; t0 < nt; t0 += 256) {
+        const int64_t t = t0 + threadIdx.x;
+        const int32_t v = t < nt ? sums[t] : 0;
+        int32_t total;
+        const int32_t ex = block_exclusive_scan_256(v, lds, &total);
+        if (t < nt) sums[t] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(int32_t *__restrict__ data, int64_t m,
+                                                         const int32_t *__restrict__ sums) {
+    __shared__ int32_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 8;
+    int32_t x[8], v = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        x[e] = base + e < m ? data[base + e] : 0;
+        v += x[e];
+    }
+    int32_t run = sums[blockIdx.x] + block_exclusive_scan_256(v, lds, nullptr);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        if (base + e < m) data[base + e] = run;
+        run += x[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_scatter_kernel(const int32_t *__restrict__ us, const int32_t *__restrict__ is,
+                                                          const int32_t *__restrict__ js, int64_t n, int32_t I,
+                                                          const int32_t *__restrict__ bucket,
+                                                          const int32_t *__restrict__ rank, int32_t *__restrict__ su,
+                                                          int32_t *__restrict__ si, int32_t *__restrict__ sj) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t i = is[s];
+        const int64_t pos = (int64_t)bucket[sort_bucket(i, I, s)] + rank[s];
+        su[pos] = us[s];
+        si[pos] = i;
+        sj[pos] = js[s];
+    }
+}
+
+// ---- item-run update ------------------------------------------------------------------------------
+// A group owns `batches` x 16 consecutive positions of the item-sorted triplet arrays.  The indices of
+// one batch are loaded coalesced (lane l holds position base + l) and broadcast inside the 16-lane row.
+template <int NC>
+__global__ __launch_bounds__(kBlock) void bpr_update_runs_kernel(float *P, float *Q, const int32_t *__restrict__ su,
+                                                                 const int32_t *__restrict__ si,
+                                                                 const int32_t *__restrict__ sj, int64_t n, int batches,
+                                                                 int d, float lr, float reg, double *loss,
+                                                                 int variant) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int gib = threadIdx.x / kGroup;
+    const int64_t group = (int64_t)blockIdx.x * kGroupsPerBlock + gib;
+    const int64_t ngroups = (int64_t)gridDim.x * kGroupsPerBlock;
+    const int64_t span = (int64_t)batches * kGroup;
+    const VecShape vs(d);
+    const float nreg = -reg;
+    double my_loss = 0.0;
+    // generic-d path: q_i | q_i at load time | p_u | q_j per group in LDS
+    float *sa = smem + (size_t)gib * 4 * d, *sa0 = sa + d, *sp = sa0 + d, *sb = sp + d;
+    for (int64_t base = group * span; base < n; base += ngroups * span) {
+        int cur = -1;
+        float a[NC > 0 ? NC : 1], a0[NC > 0 ? NC : 1];
+        for (int bt = 0; bt < batches; bt++) {
+            const int64_t pos0 = base + (int64_t)bt * kGroup;
+            if (pos0 >= n) break;
+            const int cntv = n - pos0 < kGroup ? (int)(n - pos0) : kGroup;
+            int mu = -1, mi = -1, mj = -1;
+            if (lane < cntv) {
+                mu = su[pos0 + lane];
+                mi = si[pos0 + lane];
+                mj = sj[pos0 + lane];
+            }
+            for (int t = 0; t < cntv; t++) {
+                const int u = __shfl(mu, t, kGroup), i = __shfl(mi, t, kGroup), j = __shfl(mj, t, kGroup);
+                if ((u | i | j) < 0) continue;
+                float *pu = P + (int64_t)u * d, *qj = Q + (int64_t)j * d;
+                if (i != cur) {
+                    if (cur >= 0 && !(variant & 4)) {  // flush the finished run: Q[cur] += (q - q at load time)
+                        float *qc = Q + (int64_t)cur * d;
+                        if constexpr (NC > 0) {
+#pragma unroll
+                            for (int c = 0; c < NC; c++)
+                                __hip_atomic_fetch_add(qc + 16 * c + lane, a[c] - a0[c], __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            for (int e = lane; e < d; e += kGroup)
+                                __hip_atomic_fetch_add(qc + e, sa[e] - sa0[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    const float *qi = Q + (int64_t)i * d;
+                    if constexpr (NC > 0) {
+#pragma unroll
+                        for (int c = 0; c < NC; c++) a0[c] = a[c] = load_row<MODE_ATOMIC>(qi + 16 * c + lane, variant);
+                    } else {
+                        for (int e = lane; e < d; e += kGroup) sa0[e] = sa[e] = load_row<MODE_ATOMIC>(qi + e, variant);
+                    }
+                    cur = i;
+                }
+                if constexpr (NC > 0) {
+                    float p[NC], b[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane, variant);
+                        b[c] = load_row<MODE_ATOMIC>(qj + 16 * c + lane, variant);
+                    }
+                    const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
+                    const float ex = expf(-diff);
+                    const float grad = ex / (1.0f + ex);
+                    if (loss && lane == 0) my_loss += (double)log1pf(ex);
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const int e = 16 * c + lane;
+                        float t1 = fmaf(a[c], nreg, p[c] * grad);
+                        float t2 = fmaf(b[c], nreg, p[c] * (-grad));
+                        float t3 = fmaf(p[c], nreg, (a[c] - b[c]) * grad);
+                        a[c] = fmaf(t1, lr, a[c]);
+                        if (!(variant & 8)) __hip_atomic_fetch_add(qj + e, t2 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!(variant & 2)) __hip_atomic_fetch_add(pu + e, t3 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    for (int e = lane; e < d; e += kGroup) {
+                        sp[e] = load_row<MODE_ATOMIC>(pu + e);
+                        sb[e] = load_row<MODE_ATOMIC>(qj + e);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const float diff = dot512_lds(sp, sa, vs, lane) - dot512_lds(sp, sb, vs, lane);
+                    const float ex = expf(-diff);
+                    const float grad = ex / (1.0f + ex);
+                    if (loss && lane == 0) my_loss += (double)log1pf(ex);
+                    __builtin_amdgcn_wave_barrier();
+                    for (int e = lane; e < d; e += kGroup) {
+                        const float pe = sp[e], ae = sa[e], be = sb[e];
+                        float t1 = fmaf(ae, nreg, pe * grad);
+                        float t2 = fmaf(be, nreg, pe * (-grad));
+                        float t3 = fmaf(pe, nreg, (ae - be) * grad);
+                        sa[e] = fmaf(t1, lr, ae);
+                        __hip_atomic_fetch_add(qj + e, t2 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(pu + e, t3 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (cur >= 0 && !(variant & 4)) {
+            float *qc = Q + (int64_t)cur * d;
+            if constexpr (NC > 0) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    __hip_atomic_fetch_add(qc + 16 * c + lane, a[c] - a0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                for (int e = lane; e < d; e += kGroup)
+                    __hip_atomic_fetch_add(qc + e, sa[e] - sa0[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
+}
+
+int32_t exclusive_scan_i32(int32_t *data, int64_t m, int32_t *tmp, hipStream_t st) {
+    const int64_t nt = ceil_div(m, kScanTile);
+    scan_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, st>>>(data, m, tmp);
+    scan_sums_kernel<<<dim3(1), dim3(256), 0, st>>>(tmp, nt);
+    scan_apply_kernel<<<dim3((unsigned)nt), dim3(256), 0, st>>>(data, m, tmp);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+// counting sort of the chunk in `trip` (us | is | js, stride cap) into `sorted` (su | si | sj, stride cap)
+int32_t launch_item_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int64_t n, size_t cap, hipStream_t st) {
+    const int64_t m = (h->I + 1) * kSortCopies;
+    GORSE_HIP_CHECK(hipMemsetAsync(h->bucket.p, 0, (size_t)m * sizeof(int32_t), st));
+    const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
+    bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip + cap, n, (int32_t)h->I, h->bucket.p, h->rank.p);
+    GORSE_TRY(exclusive_scan_i32(h->bucket.p, m, h->scan_tmp.p, st));
+    bpr_scatter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, trip + cap, trip + 2 * cap, n, (int32_t)h->I,
+                                                                    h->bucket.p, h->rank.p, sorted, sorted + cap,
+                                                                    sorted + 2 * cap);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+// samples per group block (a multiple of 16): long enough that a popular item's run amortises its
+// flush, short enough that the chunk still spreads over every CU
+int run_batches(int64_t n) {
+    const int ov = (g_variant >> 8) & 15;
+    if (ov > 0) return std::max(1, (1 << ov) / kGroup);
+    const int64_t groups_wanted = 256 * 32 * 4;  // one full residency of 16-lane groups
+    int b = 1;
+    while (b < 4 && ceil_div(n, (int64_t)b * 2 * kGroup) >= groups_wanted) b *= 2;
+    return b;
+}
+
+int32_t launch_update_runs(gorse_mf *h, const int32_t *sorted, size_t cap, int64_t n, float lr, float reg, double *loss,
+                           hipStream_t st) {
+    if (n <= 0) return GORSE_OK;
+    const int d = h->d;
+    const int batches = run_batches(n);
+    int64_t blocks = ceil_div(ceil_div(n, (int64_t)batches * kGroup), kGroupsPerBlock);
+    const int64_t cap_blocks = 256 * 16;
+    if (blocks > cap_blocks) blocks = cap_blocks;
+    dim3 grid((unsigned)blocks), block(kBlock);
+#define LAUNCH(NC, SH)                                                                                          \
+    bpr_update_runs_kernel<NC><<<grid, block, SH, st>>>(h->P.p, h->Q.p, sorted, sorted + cap, sorted + 2 * cap, n, \
+                                                        batches, d, lr, reg, loss, g_variant)
+    if (d == 16)
+        LAUNCH(1, 0);
+    else if (d == 32)
+        LAUNCH(2, 0);
+    else if (d == 64)
+        LAUNCH(4, 0);
+    else if (d == 128)
+        LAUNCH(8, 0);
+    else
+        LAUNCH(0, (size_t)kGroupsPerBlock * 4 * d * sizeof(float));
+#undef LAUNCH
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
 template <int MODE>
 int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, const int32_t *js, const int32_t *order,
                            int64_t begin, int64_t end, float lr, float reg, int exp_mode, double *loss,
@@ -241,6 +524,11 @@ int32_t ensure_trip(gorse_mf *h, int64_t want) {
     if (cap <= h->trip_cap) return GORSE_OK;
     GORSE_TRY(mf_sync_streams(h));
     for (int b = 0; b < 2; b++) GORSE_TRY(h->trip[b].alloc(cap * 3));
+    for (int b = 0; b < 2; b++) GORSE_TRY(h->sorted[b].alloc(cap * 3));
+    GORSE_TRY(h->rank.alloc(cap));
+    const int64_t m = (h->I + 1) * kSortCopies;
+    GORSE_TRY(h->bucket.ensure((size_t)m));
+    GORSE_TRY(h->scan_tmp.ensure((size_t)ceil_div(m, kScanTile)));
     h->trip_cap = cap;
     return GORSE_OK;
 }
@@ -326,31 +614,40 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
                                      lr, reg, g_exp_mode_exact, cancel, d_loss));
         }
     } else {
-        // two-stream pipeline: stream2 samples chunk c+1 while stream applies chunk c
+        // two-stream pipeline: stream2 samples (and item-sorts) chunk c+1 while stream applies chunk c; the
+        // buffer parity runs on across calls so that back-to-back enqueued epochs overlap as well
+        const bool runs = mode == MODE_ATOMIC && !(g_variant & 16);
         int64_t c = 0;
         for (int64_t s0 = 0; s0 < n_samples; s0 += cap, c++) {
-            const int b = (int)(c & 1);
+            const int b = (int)(h->chunk_seq & 1);
+            h->chunk_seq++;
             const int64_t m = std::min(cap, n_samples - s0);
             if (cancel && *cancel) {
                 GORSE_TRY(mf_sync_streams(h));
                 return fail(GORSE_ERR_CANCELLED, "cancelled");
             }
             int32_t *tb = h->trip[b].p;
-            if (c >= 2) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_consumed[b], 0));
+            // a never-recorded event is complete: the first two chunks of a handle do not wait
+            GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_consumed[b], 0));
             int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, h->stream2);
             GORSE_TRY(launch_sampler(h, seed, epoch, base + s0, m, tb, (size_t)cap, h->stream2));
             h->prof.end(tok, h->stream2);
+            if (runs) {
+                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
+                GORSE_TRY(launch_item_sort(h, tb, h->sorted[b].p, m, (size_t)cap, h->stream2));
+                h->prof.end(tok, h->stream2);
+            }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
             tok = h->prof.begin(GORSE_PROF_BPR_UPDATE, h->stream);
-            GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, d_loss, h->stream));
+            if (runs)
+                GORSE_TRY(launch_update_runs(h, h->sorted[b].p, (size_t)cap, m, lr, reg, d_loss, h->stream));
+            else
+                GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, d_loss, h->stream));
             h->prof.end(tok, h->stream);
             GORSE_HIP_CHECK(hipEventRecord(h->ev_consumed[b], h->stream));
             if (cancel && (c & 7) == 7) GORSE_TRY(mf_sync_streams(h));
         }
-        // the next call's sampler must not overwrite a buffer still being applied
-        GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_consumed[0], 0));
-        if (c >= 2) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_consumed[1], 0));
     }
     if (sync || loss_out) {
         if (loss_out)
@@ -364,6 +661,30 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
 
 extern "C" void gorse_hip_test_set_exact_exp(int32_t mode) { g_exp_mode_exact = mode; }
 extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
+
+// test hook: the counting sort of the item-run schedule on a host-supplied chunk
+extern "C" int32_t gorse_hip_test_item_sort(gorse_mf *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t n,
+                                            int32_t *su, int32_t *si, int32_t *sj) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (n <= 0 || !u || !i || !j || !su || !si || !sj) return fail(GORSE_ERR_INVALID, "bad arguments");
+    for (int64_t s = 0; s < n; s++)
+        if (i[s] >= h->I) return fail(GORSE_ERR_RANGE, "item %d out of range", i[s]);
+    GORSE_TRY(h->use());
+    GORSE_TRY(ensure_trip(h, n));
+    if ((size_t)n > h->trip_cap) return fail(GORSE_ERR_INVALID, "n exceeds one chunk (%zu)", h->trip_cap);
+    GORSE_TRY(mf_sync_streams(h));
+    const size_t cap = h->trip_cap;
+    int32_t *tb = h->trip[0].p, *sb = h->sorted[0].p;
+    GORSE_HIP_CHECK(hipMemcpyAsync(tb, u, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(tb + cap, i, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(tb + 2 * cap, j, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    GORSE_TRY(launch_item_sort(h, tb, sb, n, cap, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(su, sb, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(si, sb + cap, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(sj, sb + 2 * cap, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
 
 extern "C" int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
                                    int64_t sample_base, int32_t mode, const volatile int32_t *cancel, double *loss_out) {
@@ -419,6 +740,10 @@ extern "C" int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u, const
         if (mode == MODE_EXACT) {
             GORSE_TRY(run_sequential(h, tb, tb + cap, tb + 2 * cap, u + s0, i + s0, j + s0, m, lr, reg, g_exp_mode_exact,
                                      nullptr, nullptr));
+        } else if (mode == MODE_ATOMIC && !(g_variant & 16)) {
+            GORSE_TRY(launch_item_sort(h, tb, h->sorted[0].p, m, (size_t)cap, h->stream));
+            GORSE_TRY(launch_update_runs(h, h->sorted[0].p, (size_t)cap, m, lr, reg, nullptr, h->stream));
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         } else {
             GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, nullptr, h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));

@@ -20,6 +20,12 @@ struct gorse_mf {
     // BPR triplet chunk buffers (double-buffered: sampler fills one while the other is applied)
     gorse::DevBuf<int32_t> trip[2];
     size_t trip_cap = 0;  // samples per buffer
+    // item-run schedule (bpr.hip): the chunk's triplets counting-sorted by positive item
+    gorse::DevBuf<int32_t> sorted[2];  // su | si | sj, each trip_cap long
+    gorse::DevBuf<int32_t> rank;       // arrival rank of a sample inside its (item, copy) bucket
+    gorse::DevBuf<int32_t> bucket;     // (I+1) * kSortCopies counters -> exclusive offsets after the scan
+    gorse::DevBuf<int32_t> scan_tmp;   // per-tile sums of the scan
+    int64_t chunk_seq = 0;             // chunks enqueued so far: buffer = chunk_seq & 1, across calls
     gorse::DevBuf<int32_t> order;  // sequential mode: samples sorted by dependency level
     gorse::DevBuf<double> loss;
     gorse::DevBuf<int32_t> fail_count;

@@ -48,7 +48,8 @@ extern "C" {
 #define GORSE_ERR_NOMEM (-6)
 
 /* BPR update schedules (gorse_bpr_epoch / gorse_bpr_apply_triplets `mode`) */
-#define GORSE_BPR_HOGWILD_ATOMIC 0 /* all samples of a chunk in flight, fp32 atomics: no lost updates   */
+#define GORSE_BPR_HOGWILD_ATOMIC 0 /* all samples of a chunk in flight, item-run privatised + fp32 atomics:  *
+                                    * no lost updates (production schedule, Jobs > 1)                       */
 #define GORSE_BPR_SEQUENTIAL 1     /* dependency-levelled: bit-faithful to the reference with Jobs = 1  */
 #define GORSE_BPR_HOGWILD_RACY 2   /* write-through load/fma/store, lost updates like the CPU Hogwild   */
 
@@ -142,7 +143,8 @@ int32_t gorse_mf_set_profiling(gorse_mf *h, int32_t on);
 #define GORSE_PROF_BPR_SAMPLE 1
 #define GORSE_PROF_ALS_SWEEP 2
 #define GORSE_PROF_ALS_GRAM 3
-#define GORSE_PROF_NCLASSES 4
+#define GORSE_PROF_BPR_SORT 4 /* counting sort of a chunk's triplets by positive item (rank + scan + scatter) */
+#define GORSE_PROF_NCLASSES 5
 int32_t gorse_mf_get_profile(gorse_mf *h, int32_t kernel_class, int64_t *launches, double *total_ms);
 int32_t gorse_mf_reset_profile(gorse_mf *h);
 
@@ -185,9 +187,16 @@ int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t 
  * which makes device and oracle factors comparable bit for bit. */
 void gorse_hip_test_set_exact_exp(int32_t mode);
 /* probe-only ablation of the Hogwild update kernel (bit 0: plain instead of L1-bypassing loads;
- * bits 1/2/3: skip the writes to P / Q[i] / Q[j]).  Used by scripts/gpu_probe_*.py to attribute time;
- * 0 (the default) is the only value the product ever runs with. */
+ * bits 1/2/3: skip the writes to P / Q[i] / Q[j]; bit 4: the round-1 per-sample kernel without the
+ * item-run sort; bits 8..11: log2 of the run-block length override, 0 = automatic).  Used by
+ * scripts/gpu_probe_*.py to attribute time; 0 (the default) is the only value the product ever runs with. */
 void gorse_hip_test_set_variant(int32_t variant);
+/* the counting sort by positive item that precedes the item-run update kernel, on a host-supplied
+ * chunk (n <= one chunk = 4M samples): su/si/sj receive the triplets in the order the kernel walks them
+ * (ascending i, skipped samples last). */
+int32_t gorse_hip_test_item_sort(gorse_mf *h, const int32_t *u /*host*/, const int32_t *i /*host*/,
+                                 const int32_t *j /*host*/, int64_t n, int32_t *su /*host*/, int32_t *si /*host*/,
+                                 int32_t *sj /*host*/);
 
 #ifdef __cplusplus
 }

@@ -198,6 +198,57 @@ def test_bpr_atomic_no_lost_updates(small):
         assert np.abs(moved - expect).max() < 0.02 * np.abs(expect).max()
 
 
+@pytest.mark.parametrize("n,I", [(1, 5), (17, 3), (5000, 200), (300000, 3706), (1 << 20, 50)])
+def test_item_sort_is_a_sorted_permutation(n, I):
+    """Counting sort in front of the item-run kernel: output is a permutation of the input triplets,
+    ascending in the positive item, skipped samples (negative index) last."""
+    uptr = np.arange(65, dtype=np.int64)  # 64 users with one feedback each
+    mf = capi.MF(64, I, 16, uptr, (np.arange(64) % I).astype(np.int32))
+    rng = np.random.default_rng(n)
+    w = 1.0 / np.arange(1, I + 1)  # Zipf: one very popular item
+    i = rng.choice(I, size=n, p=w / w.sum()).astype(np.int32)
+    u = rng.integers(0, 64, n).astype(np.int32)
+    j = rng.integers(0, I, n).astype(np.int32)
+    skip = rng.random(n) < 0.01
+    u[skip] = -1
+    i[skip] = -1
+    j[skip] = -1
+    su, si, sj = mf.test_item_sort(u, i, j)
+    key = np.where(si < 0, I, si)
+    assert np.all(np.diff(key.astype(np.int64)) >= 0)
+    def canon(a, b, c):
+        t = np.stack([a, b, c], axis=1)
+        return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+    assert np.array_equal(canon(u, i, j), canon(su, si, sj))
+
+
+def test_bpr_atomic_item_runs_vs_sequential(oracle, small):
+    """Runs of equal positive items (the register-resident q_i path): users and negatives pairwise
+    distinct and never equal to a positive item, so the only order dependence is the order INSIDE a run,
+    a second-order effect in lr.  Every update must land: compare with the sequential oracle."""
+    d = 64
+    mf, P, Q = make_mf(small, d, std=0.3)
+    rng = np.random.default_rng(11)
+    items = rng.permutation(small.I)
+    pos, neg = items[:6], items[6:6 + 150]
+    u = rng.permutation(small.U)[:150].astype(np.int32)
+    i = pos[rng.integers(0, 6, 150)].astype(np.int32)
+    i[:40] = pos[0]  # one long run spanning several 16-sample batches
+    j = neg.astype(np.int32)
+    lr, reg = 0.01, 0.01
+    eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, lr, reg)
+    mf.bpr_apply_triplets(u, i, j, lr, reg, capi.BPR_HOGWILD_ATOMIC)
+    gP, gQ = mf.get_factors()
+    # displacement of every touched row agrees with the sequential result to second order in lr
+    for got, exp, base in ((gP, eP, P), (gQ, eQ, Q)):
+        moved = np.abs(exp - base).max(axis=1) > 0
+        num = np.abs((got - base) - (exp - base))[moved].max()
+        den = np.abs(exp - base)[moved].max()
+        assert num < 0.02 * den
+        assert np.array_equal(bits(got[~moved]), bits(base[~moved]))
+
+
 def test_rank_exact(oracle, small):
     # cf.Rank / TopKFilter: index-exact, ties included (scores quantised to force ties)
     d = 16
