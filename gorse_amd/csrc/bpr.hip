@@ -135,18 +135,71 @@ __device__ __forceinline__ void update_elem(float *pu, float *qi, float *qj, int
     }
 }
 
+// Hot-row replicas (GORSE_BPR_HOGWILD_ATOMIC only).  Device-scope atomics and L1-bypassing loads are
+// served memory-side, line by line, in order: a row that a popularity-skewed epoch keeps hitting builds a
+// deep atomic queue, and every gather of that row -- and the retirement of every wave that updated it --
+// waits in it (measured: positive-item atomics redirected away from the rows being read = 2.0x, spread
+// over 8 rows each = 2.7x on S-ml1m; profiles/r01_b_probe_rep.txt).  So the positive-item update of a HOT
+// item (share of the training feedback >= 1/2048, chosen at create time) lands in one of kHotReplicas
+// private rows picked by the group id, and FOLDER workgroups of the same launch keep draining the
+// replicas into the real rows with one combined atomic per element and pass.  Q stays the only source of
+// truth for every reader; a hot row's update becomes visible one folder pass (tens of microseconds) late,
+// the same order as the latency of the atomics themselves.  A fold kernel after the launch leaves every
+// replica zero, so nothing outside bpr.hip ever sees them.
+constexpr int kHotReplicas = 8;
+constexpr int kFolderBlocks = 32;
+
+struct HotRows {
+    const int32_t *slot;   // I entries: replica slot of an item, or -1
+    const int32_t *items;  // n_hot entries: item of a slot
+    float *rep;            // n_hot x kHotReplicas x d, all zero outside an update launch
+    int32_t *done;         // worker workgroups that have finished (zeroed before the launch)
+    int n_hot;
+};
+
+// one folder pass: (slot, element) pairs strided over the folder threads
+__device__ __forceinline__ void fold_pass(const HotRows &hot, float *Q, int d, int64_t tid, int64_t nthreads) {
+    const int64_t work = (int64_t)hot.n_hot * d;
+    for (int64_t w = tid; w < work; w += nthreads) {
+        const int64_t slot = w / d;
+        const int e = (int)(w - slot * d);
+        float *r0 = hot.rep + slot * kHotReplicas * d + e;
+        float v[kHotReplicas];
+#pragma unroll
+        for (int r = 0; r < kHotReplicas; r++)
+            v[r] = __hip_atomic_exchange(r0 + (int64_t)r * d, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < kHotReplicas; r++) sum += v[r];
+        if (sum != 0.0f)
+            __hip_atomic_fetch_add(Q + (int64_t)hot.items[slot] * d + e, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int NC, int MODE>
 __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, const int32_t *__restrict__ us,
                                                             const int32_t *__restrict__ is,
                                                             const int32_t *__restrict__ js,
                                                             const int32_t *__restrict__ order, int64_t begin,
                                                             int64_t end, int d, float lr, float reg, int exp_mode,
-                                                            double *loss, int variant) {
+                                                            double *loss, int variant, HotRows hot, int folders) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (MODE == MODE_ATOMIC && (int)blockIdx.x < folders) {
+        // folder workgroups: drain the replicas until every worker workgroup has finished.  Nobody waits
+        // for a folder, and the pass count is bounded, so an early exit only leaves more to the fold kernel.
+        const int workers = (int)gridDim.x - folders;
+        const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
+        for (int pass = 0; pass < (1 << 16); pass++) {
+            fold_pass(hot, Q, d, tid, nthreads);
+            if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        return;
+    }
     const int lane = threadIdx.x & (kGroup - 1);
     const int gib = threadIdx.x / kGroup;
-    const int64_t group = (int64_t)blockIdx.x * kGroupsPerBlock + gib;
-    const int64_t ngroups = (int64_t)gridDim.x * kGroupsPerBlock;
+    const int64_t group = (int64_t)((int)blockIdx.x - folders) * kGroupsPerBlock + gib;
+    const int64_t ngroups = (int64_t)((int)gridDim.x - folders) * kGroupsPerBlock;
     const VecShape vs(d);
     const float nreg = -reg;
     double my_loss = 0.0;
@@ -155,6 +208,11 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
         const int u = us[t], i = is[t], j = js[t];
         if ((u | i | j) < 0) continue;
         float *pu = P + (int64_t)u * d, *qi = Q + (int64_t)i * d, *qj = Q + (int64_t)j * d;
+        float *qiw = qi;  // where the positive item's update lands
+        if (MODE == MODE_ATOMIC && hot.n_hot > 0) {
+            const int slot = hot.slot[i];
+            if (slot >= 0) qiw = hot.rep + ((int64_t)slot * kHotReplicas + (group & (kHotReplicas - 1))) * d;
+        }
         if constexpr (NC > 0) {
             float p[NC], a[NC], b[NC];
 #pragma unroll
@@ -169,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
             if (loss && lane == 0) my_loss += (double)log1pf(ex);
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                update_elem<MODE>(pu, qi, qj, 16 * c + lane, p[c], a[c], b[c], grad, nreg, lr, true, i == j, variant);
+                update_elem<MODE>(pu, qiw, qj, 16 * c + lane, p[c], a[c], b[c], grad, nreg, lr, true, i == j, variant);
         } else {
             float *sp = smem + (size_t)gib * 3 * d, *sa = sp + d, *sb = sa + d;
             for (int e = lane; e < d; e += kGroup) {
@@ -183,29 +241,53 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
             const float grad = ex / (1.0f + ex);
             if (loss && lane == 0) my_loss += (double)log1pf(ex);
             for (int e = lane; e < d; e += kGroup)
-                update_elem<MODE>(pu, qi, qj, e, sp[e], sa[e], sb[e], grad, nreg, lr, !vs.unfused(e), i == j);
+                update_elem<MODE>(pu, qiw, qj, e, sp[e], sa[e], sb[e], grad, nreg, lr, !vs.unfused(e), i == j);
             __builtin_amdgcn_wave_barrier();
         }
     }
     if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
+    if (MODE == MODE_ATOMIC && folders > 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
+// after an update launch: Q[item] += sum of its replicas, replicas <- 0 (nothing else runs on the stream)
+__global__ __launch_bounds__(256) void bpr_fold_kernel(HotRows hot, float *Q, int d) {
+    const int64_t work = (int64_t)hot.n_hot * d;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < work; w += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t slot = w / d;
+        const int e = (int)(w - slot * d);
+        float *r0 = hot.rep + slot * kHotReplicas * d + e;
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < kHotReplicas; r++) {
+            sum += r0[(int64_t)r * d];
+            r0[(int64_t)r * d] = 0.0f;
+        }
+        if (sum != 0.0f) Q[(int64_t)hot.items[slot] * d + e] += sum;
+    }
+}
 
-// ---- item-run schedule: counting sort by positive item ------------------------------------------
-// Counters are privatised kSortCopies ways (copy = bits 8.. of the sample index) so that the
-// returning atomics of a very popular item do not form one serial chain on a single address.
-constexpr int kSortCopies = 16;
+// ---- item-run schedule: counting sort by (window, positive item) ---------------------------------
+// The chunk is cut into WINDOWS of `window` consecutive samples (sampler order) and each window is
+// sorted by its positive item.  The update kernel walks the sorted array front to back with a fixed
+// number of resident groups, so what runs concurrently is a slice of ONE window (two at a seam):
+// a popular item gets at most share_i * window updates from one stale view of its row, the same
+// staleness bound the per-sample kernel had from its residency, while inside a window every run of
+// equal items is applied sequentially in registers.  (Sorting the whole chunk by item would apply all
+// of an item's updates of the epoch at once from one stale view: measured divergence on S-ml1m.)
 constexpr int kScanTile = 2048;  // elements per workgroup of the scan (256 threads x 8)
 
-__device__ __forceinline__ int64_t sort_bucket(int32_t i, int32_t I, int64_t s) {
-    const int32_t key = i < 0 ? I : i;  // skipped samples sort behind every item
-    return (int64_t)key * kSortCopies + ((s >> 8) & (kSortCopies - 1));
+__device__ __forceinline__ int64_t sort_bucket(int32_t i, int32_t I, int64_t s, int wshift) {
+    const int32_t key = i < 0 ? I : i;  // skipped samples sort behind every item of their window
+    return (s >> wshift) * ((int64_t)I + 1) + key;
 }
 
-__global__ __launch_bounds__(256) void bpr_rank_kernel(const int32_t *__restrict__ is, int64_t n, int32_t I,
+__global__ __launch_bounds__(256) void bpr_rank_kernel(const int32_t *__restrict__ is, int64_t n, int32_t I, int wshift,
                                                        int32_t *__restrict__ bucket, int32_t *__restrict__ rank) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x)
-        rank[s] = atomicAdd(&bucket[sort_bucket(is[s], I, s)], 1);
+        rank[s] = atomicAdd(&bucket[sort_bucket(is[s], I, s, wshift)], 1);
 }
 
 // exclusive scan of data[0..m) in place, three launches: tile sums, scan of the tile sums, tile rescans
@@ -272,12 +354,12 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(int32_t *__restrict__ d
 
 __global__ __launch_bounds__(256) void bpr_scatter_kernel(const int32_t *__restrict__ us, const int32_t *__restrict__ is,
                                                           const int32_t *__restrict__ js, int64_t n, int32_t I,
-                                                          const int32_t *__restrict__ bucket,
+                                                          int wshift, const int32_t *__restrict__ bucket,
                                                           const int32_t *__restrict__ rank, int32_t *__restrict__ su,
                                                           int32_t *__restrict__ si, int32_t *__restrict__ sj) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         const int32_t i = is[s];
-        const int64_t pos = (int64_t)bucket[sort_bucket(i, I, s)] + rank[s];
+        const int64_t pos = (int64_t)bucket[sort_bucket(i, I, s, wshift)] + rank[s];
         su[pos] = us[s];
         si[pos] = i;
         sj[pos] = js[s];
@@ -285,12 +367,12 @@ __global__ __launch_bounds__(256) void bpr_scatter_kernel(const int32_t *__restr
 }
 
 // ---- item-run update ------------------------------------------------------------------------------
-// A group owns `batches` x 16 consecutive positions of the item-sorted triplet arrays.  The indices of
+// A group owns `blk` consecutive positions of the item-sorted triplet arrays at a time.  The indices of
 // one batch are loaded coalesced (lane l holds position base + l) and broadcast inside the 16-lane row.
 template <int NC>
 __global__ __launch_bounds__(kBlock) void bpr_update_runs_kernel(float *P, float *Q, const int32_t *__restrict__ su,
                                                                  const int32_t *__restrict__ si,
-                                                                 const int32_t *__restrict__ sj, int64_t n, int batches,
+                                                                 const int32_t *__restrict__ sj, int64_t n, int blk,
                                                                  int d, float lr, float reg, double *loss,
                                                                  int variant) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -298,7 +380,9 @@ __global__ __launch_bounds__(kBlock) void bpr_update_runs_kernel(float *P, float
     const int gib = threadIdx.x / kGroup;
     const int64_t group = (int64_t)blockIdx.x * kGroupsPerBlock + gib;
     const int64_t ngroups = (int64_t)gridDim.x * kGroupsPerBlock;
-    const int64_t span = (int64_t)batches * kGroup;
+    const int64_t span = blk;                              // consecutive sorted positions per group block
+    const int batches = blk < kGroup ? 1 : blk / kGroup;  // index loads: up to 16 positions at a time
+    const int per = blk < kGroup ? blk : kGroup;
     const VecShape vs(d);
     const float nreg = -reg;
     double my_loss = 0.0;
@@ -310,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_runs_kernel(float *P, float
         for (int bt = 0; bt < batches; bt++) {
             const int64_t pos0 = base + (int64_t)bt * kGroup;
             if (pos0 >= n) break;
-            const int cntv = n - pos0 < kGroup ? (int)(n - pos0) : kGroup;
+            const int cntv = n - pos0 < per ? (int)(n - pos0) : per;
             int mu = -1, mi = -1, mj = -1;
             if (lane < cntv) {
                 mu = su[pos0 + lane];
@@ -413,43 +497,58 @@ int32_t exclusive_scan_i32(int32_t *data, int64_t m, int32_t *tmp, hipStream_t s
     return GORSE_OK;
 }
 
+// log2 of the sort window: the staleness bound of the schedule (see above).  32768 samples matches the
+// residency-bounded window of the per-sample kernel (8192 resident waves x 4 samples).
+int window_shift() {
+    const int ov = (g_variant >> 12) & 31;
+    return ov > 0 ? ov : 15;
+}
+int64_t sort_buckets(const gorse_mf *h, int64_t n) { return ceil_div(n, (int64_t)1 << window_shift()) * (h->I + 1); }
+
 // counting sort of the chunk in `trip` (us | is | js, stride cap) into `sorted` (su | si | sj, stride cap)
 int32_t launch_item_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int64_t n, size_t cap, hipStream_t st) {
-    const int64_t m = (h->I + 1) * kSortCopies;
+    const int wshift = window_shift();
+    const int64_t m = sort_buckets(h, n);
+    if ((size_t)m > h->bucket.n) return fail(GORSE_ERR_INVALID, "sort bucket array too small");
     GORSE_HIP_CHECK(hipMemsetAsync(h->bucket.p, 0, (size_t)m * sizeof(int32_t), st));
     const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
-    bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip + cap, n, (int32_t)h->I, h->bucket.p, h->rank.p);
+    bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip + cap, n, (int32_t)h->I, wshift, h->bucket.p,
+                                                                 h->rank.p);
     GORSE_TRY(exclusive_scan_i32(h->bucket.p, m, h->scan_tmp.p, st));
     bpr_scatter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, trip + cap, trip + 2 * cap, n, (int32_t)h->I,
-                                                                    h->bucket.p, h->rank.p, sorted, sorted + cap,
+                                                                    wshift, h->bucket.p, h->rank.p, sorted, sorted + cap,
                                                                     sorted + 2 * cap);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 
-// samples per group block (a multiple of 16): long enough that a popular item's run amortises its
-// flush, short enough that the chunk still spreads over every CU
-int run_batches(int64_t n) {
+// Positions per group block and resident workgroups.  Their product (x 16 groups) is the SPAN of sorted
+// positions being applied concurrently: every group sees its positive row only as of its block start, so
+// a popular item receives up to share_i * span updates computed from views that miss each other.  32768
+// (block 4 x 8192 groups) reproduces the bound the per-sample kernel had from residency; measured on
+// S-ml1m (lr 0.05): span 131072 diverges, 32768 matches the sequential oracle's NDCG.
+int run_block() {
     const int ov = (g_variant >> 8) & 15;
-    if (ov > 0) return std::max(1, (1 << ov) / kGroup);
-    const int64_t groups_wanted = 256 * 32 * 4;  // one full residency of 16-lane groups
-    int b = 1;
-    while (b < 4 && ceil_div(n, (int64_t)b * 2 * kGroup) >= groups_wanted) b *= 2;
-    return b;
+    return ov > 0 ? 1 << (ov - 1) : 4;
+}
+int64_t run_workgroups() {
+    const int ov = (g_variant >> 20) & 15;
+    return ov > 0 ? (int64_t)1 << ov : 512;
 }
 
 int32_t launch_update_runs(gorse_mf *h, const int32_t *sorted, size_t cap, int64_t n, float lr, float reg, double *loss,
                            hipStream_t st) {
     if (n <= 0) return GORSE_OK;
     const int d = h->d;
-    const int batches = run_batches(n);
-    int64_t blocks = ceil_div(ceil_div(n, (int64_t)batches * kGroup), kGroupsPerBlock);
-    const int64_t cap_blocks = 256 * 16;
+    const int blk = run_block();
+    int64_t blocks = ceil_div(ceil_div(n, (int64_t)blk), kGroupsPerBlock);
+    // every workgroup is resident from the start (2 per CU), so the array is walked front to back
+    const int64_t cap_blocks = run_workgroups();
     if (blocks > cap_blocks) blocks = cap_blocks;
     dim3 grid((unsigned)blocks), block(kBlock);
 #define LAUNCH(NC, SH)                                                                                          \
     bpr_update_runs_kernel<NC><<<grid, block, SH, st>>>(h->P.p, h->Q.p, sorted, sorted + cap, sorted + 2 * cap, n, \
-                                                        batches, d, lr, reg, loss, g_variant)
+                                                        blk, d, lr, reg, loss, g_variant)
     if (d == 16)
         LAUNCH(1, 0);
     else if (d == 32)
@@ -475,10 +574,18 @@ int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, co
     int64_t blocks = ceil_div(n, kGroupsPerBlock);
     const int64_t cap = 256 * 16;  // 16 workgroups of 4 waves per CU: grid-stride beyond that
     if (blocks > cap) blocks = cap;
+    HotRows hot{h->hot_slot.p, h->hot_items.p, h->hot_rep.p, h->hot_done.p, 0};
+    int folders = 0;
+    if (MODE == MODE_ATOMIC && h->n_hot > 0 && !(g_variant & 32)) {
+        hot.n_hot = h->n_hot;
+        folders = kFolderBlocks;
+        GORSE_HIP_CHECK(hipMemsetAsync(h->hot_done.p, 0, sizeof(int32_t), st));
+    }
+    blocks += folders;
     dim3 grid((unsigned)blocks), block(kBlock);
 #define LAUNCH(NC, SH)                                                                                               \
     bpr_update_kernel<NC, MODE><<<grid, block, SH, st>>>(h->P.p, h->Q.p, us, is, js, order, begin, end, d, lr, reg, \
-                                                         exp_mode, loss, g_variant)
+                                                         exp_mode, loss, g_variant, hot, folders)
     if (d == 16)
         LAUNCH(1, 0);
     else if (d == 32)
@@ -491,6 +598,12 @@ int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, co
         LAUNCH(0, (size_t)kGroupsPerBlock * 3 * d * sizeof(float));
 #undef LAUNCH
     GORSE_HIP_CHECK(hipGetLastError());
+    if (folders > 0) {
+        static_assert(kHotReplicas == 8, "gorse_mf_create sizes hot_rep for 8 replicas");
+        const int64_t fb = std::min<int64_t>(ceil_div((int64_t)hot.n_hot * d, 256), 512);
+        bpr_fold_kernel<<<dim3((unsigned)fb), dim3(256), 0, st>>>(hot, h->Q.p, d);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
     return GORSE_OK;
 }
 
@@ -526,10 +639,17 @@ int32_t ensure_trip(gorse_mf *h, int64_t want) {
     for (int b = 0; b < 2; b++) GORSE_TRY(h->trip[b].alloc(cap * 3));
     for (int b = 0; b < 2; b++) GORSE_TRY(h->sorted[b].alloc(cap * 3));
     GORSE_TRY(h->rank.alloc(cap));
-    const int64_t m = (h->I + 1) * kSortCopies;
-    GORSE_TRY(h->bucket.ensure((size_t)m));
-    GORSE_TRY(h->scan_tmp.ensure((size_t)ceil_div(m, kScanTile)));
     h->trip_cap = cap;
+    return GORSE_OK;
+}
+
+// counters of the counting sort: one per (window, item) of a full chunk
+int32_t ensure_sort(gorse_mf *h) {
+    const int64_t m = sort_buckets(h, (int64_t)h->trip_cap);
+    if ((size_t)m <= h->bucket.n) return GORSE_OK;
+    GORSE_TRY(mf_sync_streams(h));
+    GORSE_TRY(h->bucket.alloc((size_t)m));
+    GORSE_TRY(h->scan_tmp.alloc((size_t)ceil_div(m, kScanTile)));
     return GORSE_OK;
 }
 
@@ -616,7 +736,8 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
     } else {
         // two-stream pipeline: stream2 samples (and item-sorts) chunk c+1 while stream applies chunk c; the
         // buffer parity runs on across calls so that back-to-back enqueued epochs overlap as well
-        const bool runs = mode == MODE_ATOMIC && !(g_variant & 16);
+        const bool runs = mode == MODE_ATOMIC && (g_variant & 64);
+        if (runs) GORSE_TRY(ensure_sort(h));
         int64_t c = 0;
         for (int64_t s0 = 0; s0 < n_samples; s0 += cap, c++) {
             const int b = (int)(h->chunk_seq & 1);
@@ -673,6 +794,7 @@ extern "C" int32_t gorse_hip_test_item_sort(gorse_mf *h, const int32_t *u, const
     GORSE_TRY(ensure_trip(h, n));
     if ((size_t)n > h->trip_cap) return fail(GORSE_ERR_INVALID, "n exceeds one chunk (%zu)", h->trip_cap);
     GORSE_TRY(mf_sync_streams(h));
+    GORSE_TRY(ensure_sort(h));
     const size_t cap = h->trip_cap;
     int32_t *tb = h->trip[0].p, *sb = h->sorted[0].p;
     GORSE_HIP_CHECK(hipMemcpyAsync(tb, u, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -740,7 +862,8 @@ extern "C" int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u, const
         if (mode == MODE_EXACT) {
             GORSE_TRY(run_sequential(h, tb, tb + cap, tb + 2 * cap, u + s0, i + s0, j + s0, m, lr, reg, g_exp_mode_exact,
                                      nullptr, nullptr));
-        } else if (mode == MODE_ATOMIC && !(g_variant & 16)) {
+        } else if (mode == MODE_ATOMIC && (g_variant & 64)) {
+            GORSE_TRY(ensure_sort(h));
             GORSE_TRY(launch_item_sort(h, tb, h->sorted[0].p, m, (size_t)cap, h->stream));
             GORSE_TRY(launch_update_runs(h, h->sorted[0].p, (size_t)cap, m, lr, reg, nullptr, h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));

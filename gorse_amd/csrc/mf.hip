@@ -236,6 +236,35 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_HIP_CHECK(hipMemcpyAsync(h->iidx.p, item_indices, (size_t)innz * sizeof(int32_t), hipMemcpyHostToDevice,
                                            h->stream));
         }
+        {   // hot items: share of the training feedback >= 1/2048, at most 1024 of them (bpr.hip, HotRows)
+            std::vector<int64_t> cnt((size_t)I, 0);
+            for (int64_t t = 0; t < h->nnz; t++) cnt[user_indices[t]]++;
+            const int64_t thr = std::max<int64_t>(2, (h->nnz + 2047) / 2048);
+            std::vector<int32_t> hot;
+            for (int64_t i = 0; i < I; i++)
+                if (cnt[i] >= thr) hot.push_back((int32_t)i);
+            if (hot.size() > 1024) {
+                std::nth_element(hot.begin(), hot.begin() + 1024, hot.end(),
+                                 [&](int32_t a, int32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; });
+                hot.resize(1024);
+                std::sort(hot.begin(), hot.end());
+            }
+            std::vector<int32_t> slot((size_t)I, -1);
+            for (size_t k = 0; k < hot.size(); k++) slot[hot[k]] = (int32_t)k;
+            h->n_hot = (int)hot.size();
+            GORSE_TRY(h->hot_slot.alloc((size_t)I));
+            GORSE_TRY(h->hot_items.alloc(hot.size()));
+            GORSE_TRY(h->hot_rep.alloc(hot.size() * 8 * (size_t)d));
+            GORSE_TRY(h->hot_done.alloc(1));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->hot_slot.p, slot.data(), (size_t)I * sizeof(int32_t), hipMemcpyHostToDevice,
+                                           h->stream));
+            if (!hot.empty())
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->hot_items.p, hot.data(), hot.size() * sizeof(int32_t),
+                                               hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->hot_rep.p, 0, std::max<size_t>(1, hot.size() * 8 * (size_t)d) * sizeof(float),
+                                           h->stream));
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // slot / hot are host temporaries
+        }
         GORSE_TRY(h->loss.alloc(1));
         GORSE_TRY(h->fail_count.alloc(1));
         GORSE_HIP_CHECK(hipMemsetAsync(h->fail_count.p, 0, sizeof(int32_t), h->stream));

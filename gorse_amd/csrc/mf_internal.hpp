@@ -26,6 +26,10 @@ struct gorse_mf {
     gorse::DevBuf<int32_t> bucket;     // (I+1) * kSortCopies counters -> exclusive offsets after the scan
     gorse::DevBuf<int32_t> scan_tmp;   // per-tile sums of the scan
     int64_t chunk_seq = 0;             // chunks enqueued so far: buffer = chunk_seq & 1, across calls
+    // hot-row replicas of the Hogwild schedule (bpr.hip): popular items' positive updates land here
+    gorse::DevBuf<int32_t> hot_slot, hot_items, hot_done;
+    gorse::DevBuf<float> hot_rep;
+    int n_hot = 0;
     gorse::DevBuf<int32_t> order;  // sequential mode: samples sorted by dependency level
     gorse::DevBuf<double> loss;
     gorse::DevBuf<int32_t> fail_count;

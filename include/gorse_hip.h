@@ -186,14 +186,16 @@ int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t 
  * 1 = the float32 FreeBSD/math32 scheme restated in oracle/gorse_oracle.c (orc_exp_restated),
  * which makes device and oracle factors comparable bit for bit. */
 void gorse_hip_test_set_exact_exp(int32_t mode);
-/* probe-only ablation of the Hogwild update kernel (bit 0: plain instead of L1-bypassing loads;
- * bits 1/2/3: skip the writes to P / Q[i] / Q[j]; bit 4: the round-1 per-sample kernel without the
- * item-run sort; bits 8..11: log2 of the run-block length override, 0 = automatic).  Used by
- * scripts/gpu_probe_*.py to attribute time; 0 (the default) is the only value the product ever runs with. */
+/* probe-only switches of the Hogwild update path (bit 0: plain instead of L1-bypassing loads; bits 1/2/3:
+ * skip the writes to P / Q[i] / Q[j]; bit 5: no hot-row replicas = the round-1 kernel; bit 6: the
+ * experimental item-run schedule (window-sorted triplets, q_i register-resident across a run), with bits
+ * 8..11: 1 + log2 of its run-block length, bits 12..16: log2 of its sort window, bits 20..23: log2 of its
+ * resident workgroup count).  Used by scripts/gpu_probe_*.py to attribute time; 0 (the default) is the only
+ * value the product ever runs with. */
 void gorse_hip_test_set_variant(int32_t variant);
 /* the counting sort by positive item that precedes the item-run update kernel, on a host-supplied
  * chunk (n <= one chunk = 4M samples): su/si/sj receive the triplets in the order the kernel walks them
- * (ascending i, skipped samples last). */
+ * (per window of 32768 consecutive samples: ascending i, skipped samples last). */
 int32_t gorse_hip_test_item_sort(gorse_mf *h, const int32_t *u /*host*/, const int32_t *i /*host*/,
                                  const int32_t *j /*host*/, int64_t n, int32_t *su /*host*/, int32_t *si /*host*/,
                                  int32_t *sj /*host*/);
