@@ -34,6 +34,7 @@ from gorse_amd import capi, synth  # noqa: E402
 from gorse_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
 
 
 def parse():
@@ -41,7 +42,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k"])
+    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k", "topk"])
+    ap.add_argument("--no-topk", action="store_true", help="skip the item x item top-k leg of the default run")
+    ap.add_argument("--topk-n", type=int, default=1_000_000)
+    ap.add_argument("--topk-steps", type=int, default=2)
     ap.add_argument("--mode", type=int, default=capi.BPR_HOGWILD_ATOMIC)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -104,6 +108,97 @@ def cpu_baseline(data, d, lr, reg, seconds):
                       "oracle/gorse_oracle.c built -O3 -march=native" % (n * threads, n, threads, dt)}
 
 
+def topk_cpu_baseline(Xe, k, seconds, idx_gpu, dist_gpu, q_begin):
+    """ann.Bruteforce.SearchIndex restated (oracle, kind 'port') on a few query rows, one query per host thread;
+    the rows double as a bit-exact check of the GPU result."""
+    from oracle import oracle as orc
+    o = orc.Oracle()
+    o.set_isa(orc.ISA_AVX512)
+    N = Xe.shape[0]
+    threads = min(os.cpu_count() or 1, 32)
+    t0 = time.perf_counter()
+    o.search_index(Xe, orc.METRIC_COSINE, q_begin, k)
+    one = max(time.perf_counter() - t0, 1e-3)
+    per_thread = max(1, min(int(seconds / one), 64))
+    qs = [q_begin + 97 * t for t in range(threads * per_thread)]
+    res = [None] * len(qs)
+
+    def work(t):
+        for r in range(t, len(qs), threads):
+            res[r] = o.search_index(Xe, orc.METRIC_COSINE, qs[r], k)
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    ok = 0
+    for q, (ei, ed) in zip(qs, res):
+        r = q - q_begin
+        if r < idx_gpu.shape[0]:
+            same = np.array_equal(idx_gpu[r, :ei.size], ei) and np.array_equal(dist_gpu[r, :ei.size].view(np.uint32), ed.view(np.uint32))
+            assert same, "GPU top-k row %d differs from the oracle" % q
+            ok += 1
+    return {"value": len(qs) * (N - 1) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "%d full queries (each against all %d vectors, d=%d) on %d threads, %.1f s; %d of them compared "
+                      "bit for bit with the GPU rows" % (len(qs), N, Xe.shape[1], threads, dt, ok)}
+
+
+def bench_topk(args, world, rank, local, fence):
+    """BASELINE config C4: item-to-item cosine top-100 over N x 128 bf16 embeddings; query rows sharded over ranks,
+    X replicated, no collective.  A step = one all-pairs pass over this rank's query shard; the
+    N x k indices + distances stay in HBM (timed region: embeddings resident -> results resident)."""
+    N, d, k = args.topk_n, 128, 100
+    Xb, Xe = synth.s_emb(N, d, 44)
+    t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16, device=local)
+    q0, q1 = rank * N // world, (rank + 1) * N // world
+    t.all_pairs(k, q0, min(q1, q0 + 8192), fetch=False)  # warm-up: allocations, code objects
+    fence()
+    t.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.topk_steps):
+        t.all_pairs(k, q0, q1, fetch=False)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    launches, sweep_ms = t.get_profile(capi.PROF_TOPK_SWEEP)
+    r_launches, resc_ms = t.get_profile(capi.PROF_TOPK_SELECT)
+    t.set_profiling(False)
+    n_fb = t.last_stats()[0]
+    if rank != 0:
+        return None
+    pairs_step = (q1 - q0) * (N - 1)
+    flops_launch = 2.0 * d * (q1 - q0) * N * args.topk_steps / max(launches, 1)  # SURVEY 8(d): 2*d flop per scored pair
+    avg_ms = sweep_ms / max(launches, 1)
+    achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "item x item cosine top-%d pairs/sec (whole job, N GPUs)" % k,
+        "value": world * pairs_step * args.topk_steps / dt, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.topk_steps, "ms_per_step": dt / args.topk_steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "S-emb %dx%d bf16, cosine, k=%d (C4), query rows sharded x%d" % (N, d, k, world),
+                   "queries_per_step_per_gpu": q1 - q0, "fallback_queries": n_fb},
+        "roofline": {"bound": "mfma", "kernel": "topk_sweep_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                     "algorithmic_flop_per_pair": 2 * d, "avg_launch_ms": avg_ms, "launches": launches,
+                     "rescore_avg_ms": resc_ms / max(r_launches, 1)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            m = min(q1 - q0, 65536)
+            idx, dst = t.all_pairs(k, q0, q0 + m)
+            out["cpu_baseline"] = topk_cpu_baseline(Xe, k, args.cpu_seconds, idx, dst, q0)
+        except AssertionError:
+            raise
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +213,23 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
     torch.cuda.set_device(local)
+
+    def fence0():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.workload == "topk":
+        out = bench_topk(args, world, rank, local, fence0)
+        if rank == 0:
+            out["warmup"] = 1
+            out["vs_baseline"] = None
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     data, d, desc = make_data(args.workload, rank)
     lr, reg = 0.05, 0.01
@@ -191,6 +303,18 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+    topk = None
+    if args.workload == "ml1m" and not args.no_topk:  # BASELINE.json's metric has two halves; the second one
+        del mf
+        try:
+            topk = bench_topk(args, world, rank, local, fence0)
+        except AssertionError:
+            raise
+        except Exception as e:
+            topk = {"metric": "item x item cosine top-100 pairs/sec", "value": None, "error": repr(e)}
+    if rank == 0:
+        if topk is not None:
+            out["topk"] = topk
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,7 +1,8 @@
 // topk.hip -- exact nearest-neighbour search (ann.Index / ann.Bruteforce) on gfx950.
 // Reference: common/ann/ann.go:21-25, common/ann/bruteforce.go:24-83, common/heap/pq.go.
 //
-// Path A (this file, always exact, any d / dtype / metric): score one block of queries against
+// Path A (this file, always exact, any d / dtype / metric; the arbiter for every query path B of
+// topk_mfma.hip cannot decide): score one block of queries against
 // all N stored vectors in the reference's own arithmetic order (one 16-lane group per pair, the
 // query block resident in LDS), then run the reference's heap selection.  The selection is the
 // literal container/heap procedure (goheap.hpp), so ties come out exactly as in Go.
@@ -9,31 +10,10 @@
 #include <cmath>
 #include <limits>
 
-#include "cf_device.hpp"
 #include "goheap.hpp"
+#include "topk_internal.hpp"
 
 using namespace gorse;
-
-struct gorse_topk {
-    int device = 0;
-    int64_t N = 0;
-    int d = 0, dtype = 0, metric = 0;
-    hipStream_t stream = nullptr;
-    DevBuf<float> X;       // N x d fp32 (bf16 inputs are expanded by <<16, bfloats.go:32-38)
-    DevBuf<uint16_t> Xb;   // N x d bf16 as given (kept for the MFMA path)
-    DevBuf<float> norm2;   // floats.Dot(x, x) per stored vector (cosine)
-    DevBuf<float> qbuf, qnorm, dist;
-    DevBuf<int64_t> qidx;
-    DevBuf<int32_t> out_idx, out_cnt, heap_v;
-    DevBuf<float> out_dist, heap_w;
-    KernelProfile prof{2};
-    int64_t n_fallback = 0, n_tie = 0;
-    int32_t use() const {
-        hipError_t e = hipSetDevice(device);
-        if (e != hipSuccess) return fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
-        return GORSE_OK;
-    }
-};
 
 namespace {
 
@@ -157,8 +137,12 @@ __global__ void select_kernel(const float *__restrict__ dist, const int64_t *__r
 
 constexpr int64_t kDistBudget = (int64_t)1 << 28;  // floats in the distance slab (1 GiB)
 
+}  // namespace
+
+namespace gorse {
+
 // queries already on the device in h->qbuf (nq x d, fp32) [+ h->qnorm]; qidx_dev = exclude list or null
-int32_t search_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int k, int prune0, int32_t *idx_out,
+int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int k, int prune0, int32_t *idx_out,
                      float *dist_out, int32_t *cnt_out) {
     const int d = h->d;
     GORSE_TRY(h->dist.ensure((size_t)nq * h->N));
@@ -186,12 +170,12 @@ int32_t search_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int k, 
     return GORSE_OK;
 }
 
-int64_t block_queries(const gorse_topk *h) {
+int64_t topk_scan_block_queries(const gorse_topk *h) {
     int64_t b = kDistBudget / std::max<int64_t>(h->N, 1);
     return std::max<int64_t>(1, std::min<int64_t>(b, 65535));
 }
 
-int32_t compute_norms(gorse_topk *h, const float *V, int64_t n, float *out) {
+int32_t topk_compute_norms(gorse_topk *h, const float *V, int64_t n, float *out) {
     int64_t bx = std::min<int64_t>(ceil_div(n, kGroupsPerBlock), 4096);
     norm2_kernel<<<dim3((unsigned)bx), dim3(kBlock), (size_t)kGroupsPerBlock * h->d * sizeof(float), h->stream>>>(V, n, h->d,
                                                                                                                 out);
@@ -199,7 +183,7 @@ int32_t compute_norms(gorse_topk *h, const float *V, int64_t n, float *out) {
     return GORSE_OK;
 }
 
-}  // namespace
+}  // namespace gorse
 
 extern "C" int32_t gorse_topk_create(gorse_topk **out, int32_t device, int64_t N, int32_t d, int32_t dtype,
                                      int32_t metric, const void *X) {
@@ -234,8 +218,9 @@ extern "C" int32_t gorse_topk_create(gorse_topk **out, int32_t device, int64_t N
             GORSE_HIP_CHECK(hipMemcpyAsync(h->X.p, X, (size_t)N * d * 4, hipMemcpyHostToDevice, h->stream));
         }
         GORSE_TRY(h->norm2.alloc((size_t)N));
-        GORSE_TRY(compute_norms(h, h->X.p, N, h->norm2.p));
+        GORSE_TRY(topk_compute_norms(h, h->X.p, N, h->norm2.p));
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        GORSE_TRY(topk_mfma_prepare(h));  // path B operands (dot / cosine, d within the register budget)
         return GORSE_OK;
     }();
     if (rc != GORSE_OK) {
@@ -267,7 +252,9 @@ extern "C" int32_t gorse_topk_search_index(gorse_topk *h, const int64_t *q, int6
         if (q[t] < 0 || q[t] >= h->N) return fail(GORSE_ERR_RANGE, "index out of range: %lld", (long long)q[t]);
     if (nq == 0) return GORSE_OK;
     GORSE_TRY(h->use());
-    const int64_t bq = block_queries(h);
+    h->n_fallback = 0;
+    if (topk_mfma_usable(h, nq, k)) return topk_mfma_search(h, q, -1, nullptr, nq, k, prune0, idx_out, dist_out, count_out);
+    const int64_t bq = topk_scan_block_queries(h);
     GORSE_TRY(h->qidx.ensure((size_t)std::min(bq, nq)));
     GORSE_TRY(h->qbuf.ensure((size_t)std::min(bq, nq) * h->d));
     GORSE_TRY(h->qnorm.ensure((size_t)std::min(bq, nq)));
@@ -277,7 +264,7 @@ extern "C" int32_t gorse_topk_search_index(gorse_topk *h, const int64_t *q, int6
         gather_rows_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->X.p, h->norm2.p, h->qidx.p, h->d, h->qbuf.p,
                                                                          h->qnorm.p);
         GORSE_HIP_CHECK(hipGetLastError());
-        GORSE_TRY(search_block(h, m, h->qidx.p, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
+        GORSE_TRY(topk_scan_block(h, m, h->qidx.p, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
                                dist_out ? dist_out + q0 * k : nullptr, count_out ? count_out + q0 : nullptr));
     }
     return GORSE_OK;
@@ -289,7 +276,22 @@ extern "C" int32_t gorse_topk_search_vector(gorse_topk *h, const void *qv, int64
     if (nq < 0 || k <= 0 || (nq > 0 && !qv)) return fail(GORSE_ERR_INVALID, "bad arguments");
     if (nq == 0) return GORSE_OK;
     GORSE_TRY(h->use());
-    const int64_t bq = block_queries(h);
+    h->n_fallback = 0;
+    if (topk_mfma_usable(h, nq, k)) {  // all query vectors to the device as fp32, then path B
+        GORSE_TRY(h->qf32.ensure((size_t)nq * h->d));
+        if (h->dtype == GORSE_DTYPE_BF16) {
+            DevBuf<uint16_t> q16;
+            GORSE_TRY(q16.alloc((size_t)nq * h->d));
+            GORSE_HIP_CHECK(hipMemcpyAsync(q16.p, qv, (size_t)nq * h->d * 2, hipMemcpyHostToDevice, h->stream));
+            expand_bf16_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(q16.p, h->qf32.p, nq * (int64_t)h->d);
+            GORSE_HIP_CHECK(hipGetLastError());
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        } else {
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->qf32.p, qv, (size_t)nq * h->d * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        return topk_mfma_search(h, nullptr, -1, h->qf32.p, nq, k, prune0, idx_out, dist_out, count_out);
+    }
+    const int64_t bq = topk_scan_block_queries(h);
     const int64_t mb = std::min(bq, nq);
     GORSE_TRY(h->qbuf.ensure((size_t)mb * h->d));
     GORSE_TRY(h->qnorm.ensure((size_t)mb));
@@ -306,8 +308,8 @@ extern "C" int32_t gorse_topk_search_vector(gorse_topk *h, const void *qv, int64
             GORSE_HIP_CHECK(hipMemcpyAsync(h->qbuf.p, (const float *)qv + q0 * h->d, (size_t)m * h->d * 4,
                                            hipMemcpyHostToDevice, h->stream));
         }
-        if (h->metric == GORSE_METRIC_COSINE) GORSE_TRY(compute_norms(h, h->qbuf.p, m, h->qnorm.p));
-        GORSE_TRY(search_block(h, m, nullptr, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
+        if (h->metric == GORSE_METRIC_COSINE) GORSE_TRY(topk_compute_norms(h, h->qbuf.p, m, h->qnorm.p));
+        GORSE_TRY(topk_scan_block(h, m, nullptr, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
                                dist_out ? dist_out + q0 * k : nullptr, count_out ? count_out + q0 : nullptr));
     }
     return GORSE_OK;
@@ -320,7 +322,9 @@ extern "C" int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t 
     const int64_t nq = q_end - q_begin;
     if (nq == 0) return GORSE_OK;
     GORSE_TRY(h->use());
-    const int64_t bq = block_queries(h);
+    h->n_fallback = 0;
+    if (topk_mfma_usable(h, nq, k)) return topk_mfma_search(h, nullptr, q_begin, nullptr, nq, k, 0, idx_out, dist_out, nullptr);
+    const int64_t bq = topk_scan_block_queries(h);
     const int64_t mb = std::min(bq, nq);
     GORSE_TRY(h->qidx.ensure((size_t)mb));
     GORSE_TRY(h->qbuf.ensure((size_t)mb * h->d));
@@ -333,7 +337,7 @@ extern "C" int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t 
         gather_rows_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->X.p, h->norm2.p, h->qidx.p, h->d, h->qbuf.p,
                                                                          h->qnorm.p);
         GORSE_HIP_CHECK(hipGetLastError());
-        GORSE_TRY(search_block(h, m, h->qidx.p, k, 0, idx_out ? idx_out + q0 * k : nullptr,
+        GORSE_TRY(topk_scan_block(h, m, h->qidx.p, k, 0, idx_out ? idx_out + q0 * k : nullptr,
                                dist_out ? dist_out + q0 * k : nullptr, nullptr));
     }
     return GORSE_OK;
@@ -354,7 +358,7 @@ extern "C" int32_t gorse_topk_set_profiling(gorse_topk *h, int32_t on) {
     return GORSE_OK;
 }
 extern "C" int32_t gorse_topk_get_profile(gorse_topk *h, int32_t cls, int64_t *launches, double *total_ms) {
-    if (!h || cls < 0 || cls >= 2) return fail(GORSE_ERR_INVALID, "bad kernel class");
+    if (!h || cls < 0 || cls >= GORSE_PROF_TOPK_NCLASSES) return fail(GORSE_ERR_INVALID, "bad kernel class");
     GORSE_TRY(h->use());
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->prof.resolve();
@@ -368,3 +372,6 @@ extern "C" int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int
     if (n_tie_resolved) *n_tie_resolved = h->n_tie;
     return GORSE_OK;
 }
+
+// test hook: 0 = automatic path choice, 1 = path A only (literal scan), 2 = path B whenever its operands exist
+extern "C" void gorse_hip_test_set_topk_path(int32_t path) { gorse::g_topk_force_path = path; }

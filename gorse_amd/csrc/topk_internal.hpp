@@ -1,0 +1,61 @@
+// topk_internal.hpp -- the gorse_topk handle shared by topk.hip (path A: exact VALU scan + literal
+// heaps) and topk_mfma.hip (path B: bf16 MFMA candidate sweep + exact rescoring).
+#pragma once
+#include "cf_device.hpp"
+
+#define GORSE_PROF_TOPK_NCLASSES 4
+
+struct gorse_topk {
+    int device = 0;
+    int64_t N = 0;
+    int d = 0, dtype = 0, metric = 0;
+    hipStream_t stream = nullptr;
+    gorse::DevBuf<float> X;       // N x d fp32 (bf16 inputs are expanded by <<16, bfloats.go:32-38)
+    gorse::DevBuf<uint16_t> Xb;   // N x d bf16 as given
+    gorse::DevBuf<float> norm2;   // floats.Dot(x, x) per stored vector
+    gorse::DevBuf<float> qbuf, qnorm, dist;
+    gorse::DevBuf<int64_t> qidx;
+    gorse::DevBuf<int32_t> out_idx, out_cnt, heap_v;
+    gorse::DevBuf<float> out_dist, heap_w;
+    // ---- path B (topk_mfma.hip) ----
+    bool mfma_ok = false;          // operands built and the data admits a rigorous error bound
+    int kp = 0;                    // k-steps of 16 of the MFMA operands (KPAD = 16 * kp)
+    float err_coef = 0.0f;         // |approx - reference| <= err_coef * |q| * |x| (dot of the operands)
+    float max_norm = 0.0f;         // max_i sqrt(norm2[i])
+    gorse::DevBuf<uint16_t> opA_own, opB_own;  // bf16 operand matrices N x KPAD (candidate / query roles)
+    const uint16_t *opA = nullptr, *opB = nullptr;  // may alias Xb
+    gorse::DevBuf<float> rscale;   // cosine: 1 / sqrt(norm2[i])
+    gorse::DevBuf<uint16_t> opQ;   // query operands of the current chunk when they are not rows of opB
+    gorse::DevBuf<float> qn2, qmargin, qf32;
+    gorse::DevBuf<int64_t> qid;
+    gorse::DevBuf<uint2> cbuf;     // per query: kCap (approx key, candidate index) entries
+    gorse::DevBuf<int32_t> ccnt;
+    gorse::DevBuf<uint8_t> cflag;
+    gorse::DevBuf<int32_t> res_idx, res_cnt;
+    gorse::DevBuf<float> res_dist;
+    gorse::KernelProfile prof{GORSE_PROF_TOPK_NCLASSES};
+    int64_t n_fallback = 0, n_tie = 0;
+    int32_t use() const {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return gorse::fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return GORSE_OK;
+    }
+};
+
+namespace gorse {
+// topk.hip
+int32_t topk_compute_norms(gorse_topk *h, const float *V, int64_t n, float *out);
+// path A on queries whose fp32 rows sit in h->qbuf (nq x d) [+ h->qnorm]; qidx_dev = exclusion ids or null.
+// Results land in h->out_idx / out_dist / out_cnt and, where given, in the host arrays.
+int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int k, int prune0, int32_t *idx_out,
+                        float *dist_out, int32_t *cnt_out);
+int64_t topk_scan_block_queries(const gorse_topk *h);
+// topk_mfma.hip
+int32_t topk_mfma_prepare(gorse_topk *h);  // at create: operands, scales, error bound
+// Queries: stored vectors qid_host[0..nq) (exclude_self) or, when qid_host is NULL and qv_dev is given, nq fp32
+// query vectors already on the device.  Host outputs may be NULL.
+int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev,
+                         int64_t nq, int k, int prune0, int32_t *idx_out, float *dist_out, int32_t *cnt_out);
+bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k);
+extern int g_topk_force_path;  // 0 auto, 1 path A only, 2 path B whenever it is usable
+}  // namespace gorse

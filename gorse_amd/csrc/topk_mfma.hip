@@ -1,0 +1,709 @@
+// topk_mfma.hip -- path B of the exact top-k: a bf16 MFMA candidate sweep followed by exact rescoring.
+// Reference semantics: common/ann/bruteforce.go:39-83 (keep the k smallest distances, return them ascending),
+// distances computed by floats.Dot in AVX512 order (common/floats/src/floats_avx512.c:306-367).
+//
+// The reference scores all N vectors per query one pair at a time.  Here the N x nq score matrix is produced
+// by v_mfma_f32_32x32x16_bf16 tiles and never leaves the CU: every wave keeps the operands of its 32*NCB queries
+// in registers for the whole sweep, candidate rows stream through LDS, and the epilogue only compares the 16
+// scores a lane holds (all of ONE query: the C layout puts a query per column) against that query's running
+// filter threshold.  Scores that pass are appended to a small per-query candidate list in HBM; when a list
+// fills, its wave raises the threshold to (K-th best approximate score so far) - margin and compacts the list.
+//
+// Exactness: |approx - reference| <= delta_q for every pair of one query (delta_q from a forward error bound
+// of both summation orders, see topk_mfma_prepare).  Any vector whose reference score is among the K best has an
+// approximate score >= (final K-th best approximate score) - 2*delta_q >= every threshold used during the sweep,
+// so it is in the list.  The list is then rescored in the reference's own arithmetic order and ranked; a query
+// whose K+1 best exact distances are not all distinct (where the reference's result depends on container/heap
+// mechanics), whose list overflowed, or that saw a NaN is handed to path A (topk.hip), which replays the
+// reference's heaps literally.  Results are therefore identical to path A's, ties included.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "topk_internal.hpp"
+
+using namespace gorse;
+
+namespace gorse {
+int g_topk_force_path = 0;
+}
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTR = 64;        // candidate rows per LDS tile (two 32-row MFMA blocks)
+constexpr int kWaves = 8;      // waves per workgroup, two per SIMD
+constexpr int kThreads = kWaves * 64;
+constexpr int kCap = 512;      // candidate-list capacity per query
+constexpr int kEPL = kCap / 64;
+constexpr int kCompactAt = kCap - 64;   // compact a list once it holds more than this (a block adds <= 32)
+constexpr int kOverflowAt = kCap - 128; // a compaction that keeps more than this cannot make progress
+constexpr int kMaxKth = 256;
+constexpr int64_t kChunkQ = (int64_t)1 << 20;
+
+__device__ __forceinline__ uint32_t fkey(float x) {  // order-preserving float -> uint
+    uint32_t b = __float_as_uint(x);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ int lane_rank(uint64_t m) {  // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+}
+
+struct SweepParams {
+    const uint16_t *A;     // candidate operands, N x KPAD bf16
+    const uint16_t *B;     // query operands, nq x KPAD bf16
+    const float *rscale;   // per-candidate score scale (cosine) or null
+    const float *qmargin;  // per-query 2*delta_q
+    uint2 *cbuf;           // nq x kCap (key, index)
+    int32_t *ccnt;         // nq
+    uint8_t *cflag;        // nq: 1 = hand to path A
+    int64_t N, nq;
+    int kth;
+};
+
+// One wave raises the filter threshold of local query ql and compacts its list.
+__device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s_cnt, float *s_f, const float *s_mg,
+                                              uint8_t *flag) {
+    const int lane = threadIdx.x & 63;
+    const int n = s_cnt[ql];
+    uint32_t key[kEPL], idx[kEPL];
+#pragma unroll
+    for (int j = 0; j < kEPL; j++) {
+        const int e = j * 64 + lane;
+        unsigned long long v = 0;  // key 0 = never counted below (trial >= 1)
+        if (e < n)
+            v = __hip_atomic_load(reinterpret_cast<unsigned long long *>(qb + e), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+        key[j] = (uint32_t)v;
+        idx[j] = (uint32_t)(v >> 32);
+    }
+    float newf = -__builtin_inff();
+    if (n >= kth) {  // K-th largest key by bisection on the 32 key bits
+        uint32_t prefix = 0;
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t trial = prefix | (1u << b);
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < kEPL; j++) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(key[j] >= trial));
+            if (c >= kth) prefix = trial;
+        }
+        newf = fkey_inv(prefix) - s_mg[ql];
+    }
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < kEPL; j++) {
+        const bool keep = (j * 64 + lane < n) && (fkey_inv(key[j]) >= newf);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) qb[base + lane_rank(m)] = make_uint2(key[j], idx[j]);
+        base += __builtin_popcountll(m);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        s_cnt[ql] = base;
+        s_f[ql] = newf;
+        if (base > kOverflowAt) {  // ties / a margin too wide for the list: stop collecting, path A decides
+            s_f[ql] = __builtin_inff();
+            *flag = 1;
+        }
+    }
+}
+
+template <int KP, int NCB, bool SCALE>
+__global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) {
+    constexpr int KPAD = KP * 16;
+    constexpr int ROWB = KPAD * 2 + 16;  // +16 B: consecutive rows start 4 banks apart, ds_read_b128 conflict-free
+    constexpr int QW = 32 * NCB;
+    constexpr int BQ = QW * kWaves;
+    constexpr int CHUNKS = kTR * KP * 2;  // 16-byte pieces per tile
+    constexpr int CPT = (CHUNKS + kThreads - 1) / kThreads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *s_tile = smem;
+    float *s_rs = reinterpret_cast<float *>(smem + 2 * kTR * ROWB);
+    int *s_cnt = reinterpret_cast<int *>(s_rs + 2 * kTR);
+    float *s_f = reinterpret_cast<float *>(s_cnt + BQ);
+    float *s_mg = s_f + BQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t wgq0 = (int64_t)blockIdx.x * BQ;
+    for (int t = tid; t < BQ; t += kThreads) {
+        const int64_t q = wgq0 + t;
+        s_cnt[t] = 0;
+        s_f[t] = q < p.nq ? -__builtin_inff() : __builtin_inff();
+        s_mg[t] = q < p.nq ? p.qmargin[q] : 0.0f;
+    }
+    // query operands: resident in registers for the whole sweep
+    bf16x8 bfrag[NCB][KP];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        int64_t q = wgq0 + w * QW + cb * 32 + (lane & 31);
+        if (q >= p.nq) q = p.nq - 1;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.B + q * KPAD) + (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < KP; ks++) {
+            uint4 v = src[ks * 2];
+            bfrag[cb][ks] = *reinterpret_cast<bf16x8 *>(&v);
+        }
+    }
+
+    uint4 pre[CPT];
+    float pre_rs = 0.0f;
+    auto load_tile = [&](int64_t t) {
+        const int64_t base_row = t * kTR;
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int ch = tid + c * kThreads;
+            if (ch < CHUNKS) {
+                const int row = ch / (KP * 2), cc = ch % (KP * 2);
+                const int64_t grow = base_row + row;
+                pre[c] = grow < p.N ? reinterpret_cast<const uint4 *>(p.A + grow * KPAD)[cc] : make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (SCALE && tid < kTR) pre_rs = base_row + tid < p.N ? p.rscale[base_row + tid] : 0.0f;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            const int ch = tid + c * kThreads;
+            if (ch < CHUNKS) {
+                const int row = ch / (KP * 2), cc = ch % (KP * 2);
+                *reinterpret_cast<uint4 *>(s_tile + (size_t)buf * kTR * ROWB + row * ROWB + cc * 16) = pre[c];
+            }
+        }
+        if (SCALE && tid < kTR) s_rs[buf * kTR + tid] = pre_rs;
+    };
+
+    const int64_t NT = (p.N + kTR - 1) / kTR;
+    load_tile(0);
+    store_tile(0);
+    if (NT > 1) load_tile(1);
+    __syncthreads();
+
+    float fth[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) fth[cb] = s_f[w * QW + cb * 32 + (lane & 31)];
+
+    for (int64_t t = 0; t < NT; t++) {
+        const int buf = (int)(t & 1);
+        if (t + 1 < NT) store_tile(buf ^ 1);  // rows of tile t+1 (loaded during tile t-1)
+        if (t + 2 < NT) load_tile(t + 2);
+        const unsigned char *tb = s_tile + (size_t)buf * kTR * ROWB;
+        const int64_t base_row = t * kTR;
+        const int valid = (int)std::min<int64_t>(kTR, p.N - base_row);
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+            f32x16 acc[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[cb][r] = 0.0f;
+            const unsigned char *rowp = tb + (rb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+            // candidate fragments: up to 8 k-steps of ds_read_b128 in flight ahead of the MFMAs that use them
+            constexpr int PF = KP < 8 ? KP : 8;
+#pragma unroll
+            for (int k0 = 0; k0 < KP; k0 += PF) {
+                bf16x8 a[PF];
+#pragma unroll
+                for (int j = 0; j < PF; j++)
+                    if (k0 + j < KP) a[j] = *reinterpret_cast<const bf16x8 *>(rowp + (k0 + j) * 32);
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead: hipcc otherwise sinks each next to its MFMA
+#pragma unroll
+                for (int j = 0; j < PF; j++)
+                    if (k0 + j < KP) {
+#pragma unroll
+                        for (int cb = 0; cb < NCB; cb++)
+                            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bfrag[cb][k0 + j], acc[cb], 0, 0, 0);
+                    }
+            }
+            // C layout: lane holds column (= query) lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                if (SCALE) {
+                    const float4 *r4 = reinterpret_cast<const float4 *>(s_rs + buf * kTR + rb * 32);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const float4 s = r4[2 * g + (lane >> 5)];
+                        acc[cb][4 * g + 0] *= s.x;
+                        acc[cb][4 * g + 1] *= s.y;
+                        acc[cb][4 * g + 2] *= s.z;
+                        acc[cb][4 * g + 3] *= s.w;
+                    }
+                }
+                if (valid < kTR) {  // last tile: rows past N never qualify
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (row >= valid) acc[cb][r] = -__builtin_inff();
+                    }
+                }
+                float m = acc[cb][0];
+#pragma unroll
+                for (int r = 1; r < 16; r++) m = fmaxf(m, acc[cb][r]);
+                if (__builtin_amdgcn_ballot_w64(m >= fth[cb]) != 0) {
+                    const int ql = w * QW + cb * 32 + (lane & 31);
+                    const int64_t qg = wgq0 + ql;
+                    uint2 *qb = p.cbuf + qg * kCap;
+                    const float f = fth[cb];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const bool hit = acc[cb][r] >= f && qg < p.nq;
+                        if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+                            if (hit) {
+                                const int slot = atomicAdd(&s_cnt[ql], 1);
+                                const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                                qb[slot] = make_uint2(fkey(acc[cb][r]), row);
+                            }
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    uint64_t need = __builtin_amdgcn_ballot_w64(s_cnt[ql] > kCompactAt) & 0xffffffffull;
+                    while (need) {
+                        const int l = __builtin_ctzll(need);
+                        need &= need - 1;
+                        const int qlc = w * QW + cb * 32 + l;
+                        compact_query(p.cbuf + (wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg, p.cflag + wgq0 + qlc);
+                    }
+                    fth[cb] = s_f[ql];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // final threshold + compaction of every list this wave owns
+    for (int l = 0; l < QW; l++) {
+        const int ql = w * QW + l;
+        const int64_t qg = wgq0 + ql;
+        if (qg >= p.nq) break;
+        if (s_f[ql] == __builtin_inff()) continue;  // flagged
+        compact_query(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg);
+        if (lane == 0) p.ccnt[qg] = s_cnt[ql];
+    }
+}
+
+// ---- exact rescoring + ranking of one query's candidate list ------------------------------------------
+struct RescoreParams {
+    const float *X;        // N x d fp32 stored vectors
+    const float *norm2;    // N
+    const float *Qf;       // nq x d fp32 query vectors, or null (queries are stored vectors)
+    const float *qn2;      // nq query norms (cosine)
+    const int64_t *qid;    // stored-vector id per query, or null
+    int64_t q0;            // used when qid == null and Qf == null: id = q0 + t
+    const uint2 *cbuf;
+    const int32_t *ccnt;
+    uint8_t *cflag;
+    int d, metric, k, prune0;
+    int64_t expect;        // min(k, number of admissible vectors)
+    int32_t *out_idx;
+    float *out_dist;
+    int32_t *out_cnt;
+};
+
+__global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int d = p.d;
+    float *sq = smem_f;                          // d
+    float *sx = sq + d;                          // kGroupsPerBlock * d
+    float *s_e = sx + (size_t)kGroupsPerBlock * d;  // kCap
+    int *s_i = reinterpret_cast<int *>(s_e + kCap);  // kCap
+    int *s_misc = s_i + kCap;                    // [0] nonpositive in top-k, [1] flag
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
+    const int k = p.k;
+    if (p.cflag[t]) return;  // path A fills this row
+    const int n = p.ccnt[t];
+    const int64_t self = p.Qf ? -1 : (p.qid ? p.qid[t] : p.q0 + t);
+    const float *qrow = p.Qf ? p.Qf + t * d : p.X + self * d;
+    for (int e = tid; e < d; e += kBlock) sq[e] = qrow[e];
+    if (tid < 2) s_misc[tid] = 0;
+    __syncthreads();
+    const VecShape vs(d);
+    const float qq = p.metric == GORSE_METRIC_COSINE ? p.qn2[t] : 0.0f;
+    const uint2 *cb = p.cbuf + t * kCap;
+    for (int c = gib; c < n; c += kGroupsPerBlock) {
+        const int64_t i = cb[c].y;
+        float *row = sx + (size_t)gib * d;
+        for (int e = lane; e < d; e += kGroup) row[e] = p.X[i * d + e];
+        __builtin_amdgcn_wave_barrier();
+        const float ab = dot512_lds(sq, row, vs, lane);
+        __builtin_amdgcn_wave_barrier();
+        float r;
+        if (p.metric == GORSE_METRIC_NEG_DOT)
+            r = -ab;
+        else
+            r = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+        if (lane == 0) {
+            s_e[c] = r;
+            s_i[c] = (int)i;
+        }
+    }
+    __syncthreads();
+    // rank every candidate among the admissible ones; flag ties that reach the top k+1
+    bool bad = false;
+    int my_rank[kCap / kBlock];
+#pragma unroll
+    for (int s = 0; s < kCap / kBlock; s++) {
+        const int c = tid + s * kBlock;
+        my_rank[s] = -1;
+        if (c >= n || s_i[c] == self) continue;
+        const float e = s_e[c];
+        if (e != e) {
+            bad = true;
+            continue;
+        }
+        int rank = 0;
+        bool tie = false;
+        for (int c2 = 0; c2 < n; c2++) {
+            if (c2 == c || s_i[c2] == self) continue;
+            const float e2 = s_e[c2];
+            rank += (e2 < e) || (e2 == e && c2 < c);
+            tie |= (e2 == e);
+        }
+        if (tie && rank <= k) bad = true;
+        my_rank[s] = rank;
+        if (rank < k && p.prune0 && !(e > 0)) atomicAdd(&s_misc[0], 1);
+    }
+    if (bad) s_misc[1] = 1;
+    __syncthreads();
+    int admissible = n;
+    for (int c2 = 0; c2 < n; c2++)
+        if (s_i[c2] == self) admissible--;
+    const int top = admissible < k ? admissible : k;
+    if (s_misc[1] || top < p.expect) {  // ties, NaN, or a list that cannot hold the answer: path A
+        if (tid == 0) p.cflag[t] = 1;
+        return;
+    }
+    const int dropped = s_misc[0];  // prune0: the non-positive distances are the smallest, i.e. the first ones
+#pragma unroll
+    for (int s = 0; s < kCap / kBlock; s++) {
+        const int c = tid + s * kBlock;
+        const int rank = my_rank[s];
+        if (rank < 0 || rank >= k) continue;
+        const float e = s_e[c];
+        if (p.prune0 && !(e > 0)) continue;
+        p.out_idx[t * k + rank - dropped] = s_i[c];
+        p.out_dist[t * k + rank - dropped] = e;
+    }
+    const int cnt = top - dropped;
+    for (int r = cnt + tid; r < k; r += kBlock) {
+        p.out_idx[t * k + r] = -1;
+        p.out_dist[t * k + r] = __builtin_inff();
+    }
+    if (tid == 0) p.out_cnt[t] = cnt;
+}
+
+// ---- operand construction ------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bf16_rne(float x) {
+    uint32_t b = __float_as_uint(x);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+__device__ __forceinline__ float bf16_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// fp32 rows -> [hi | lo | hi] (role 0, candidates) or [hi | hi | lo] (role 1, queries), zero padded to kpad:
+// sum over the operand = hi.hi + lo.hi + hi.lo, the three leading terms of the split product.
+__global__ void split_f32_kernel(const float *__restrict__ X, int64_t n, int d, int kpad, int role,
+                                 uint16_t *__restrict__ out) {
+    const int64_t total = n * kpad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / kpad;
+        const int e = (int)(t % kpad);
+        uint16_t v = 0;
+        if (e < 3 * d) {
+            const int part = e / d, j = e % d;
+            const float x = X[row * d + j];
+            const uint16_t hi = bf16_rne(x);
+            const bool want_lo = role == 0 ? part == 1 : part == 2;
+            v = want_lo ? bf16_rne(x - bf16_f32(hi)) : hi;
+        }
+        out[t] = v;
+    }
+}
+// bf16 rows (or fp32 rows that hold bf16 values exactly) -> zero padded bf16 operand rows
+__global__ void pad_bf16_kernel(const uint16_t *__restrict__ Xb, const float *__restrict__ Xf, int64_t n, int d,
+                                int kpad, uint16_t *__restrict__ out) {
+    const int64_t total = n * kpad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / kpad;
+        const int e = (int)(t % kpad);
+        uint16_t v = 0;
+        if (e < d) v = Xb ? Xb[row * d + e] : (uint16_t)(__float_as_uint(Xf[row * d + e]) >> 16);
+        out[t] = v;
+    }
+}
+__global__ void rscale_kernel(const float *__restrict__ norm2, int64_t n, float *__restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = 1.0f / sqrtf(norm2[t]);
+}
+// gather operand rows / norms of stored vectors for an id list
+__global__ void gather_queries_kernel(const uint16_t *__restrict__ opB, const float *__restrict__ norm2,
+                                      const int64_t *__restrict__ qid, int64_t nq, int kpad,
+                                      uint16_t *__restrict__ opQ, float *__restrict__ qn2) {
+    const int64_t t = blockIdx.x;
+    const int64_t src = qid[t];
+    const uint4 *s = reinterpret_cast<const uint4 *>(opB + src * kpad);
+    uint4 *o = reinterpret_cast<uint4 *>(opQ + t * kpad);
+    for (int e = threadIdx.x; e < kpad / 8; e += blockDim.x) o[e] = s[e];
+    if (threadIdx.x == 0) qn2[t] = norm2[src];
+}
+__global__ void margin_kernel(const float *__restrict__ qn2, int64_t nq, float coef, float other,
+                              float *__restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = 2.0f * coef * sqrtf(qn2[t]) * other * 1.001f + 1e-30f;
+}
+
+const int kSupportedKP[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+
+template <int KP, int NCB>
+int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale) {
+    constexpr int BQ = 32 * NCB * kWaves;
+    constexpr int ROWB = KP * 32 + 16;
+    const size_t lds = (size_t)2 * kTR * ROWB + 2 * kTR * 4 + (size_t)3 * BQ * 4;
+    const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
+    if (scale) {
+        GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        topk_sweep_kernel<KP, NCB, true><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
+    } else {
+        GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        topk_sweep_kernel<KP, NCB, false><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
+    }
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool scale) {
+    switch (h->kp) {
+        case 1: return launch_sweep<1, 2>(h, p, scale);
+        case 2: return launch_sweep<2, 2>(h, p, scale);
+        case 3: return launch_sweep<3, 2>(h, p, scale);
+        case 4: return launch_sweep<4, 2>(h, p, scale);
+        case 6: return launch_sweep<6, 2>(h, p, scale);
+        case 8: return launch_sweep<8, 2>(h, p, scale);
+        case 12: return scale ? launch_sweep<12, 1>(h, p, scale) : launch_sweep<12, 2>(h, p, scale);
+        case 16: return launch_sweep<16, 1>(h, p, scale);
+        case 24: return launch_sweep<24, 1>(h, p, scale);
+    }
+    return fail(GORSE_ERR_INVALID, "unsupported operand depth %d", h->kp);
+}
+
+}  // namespace
+
+namespace gorse {
+
+bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k) {
+    if (!h->mfma_ok || g_topk_force_path == 1) return false;
+    if (k + 1 > kMaxKth) return false;
+    return g_topk_force_path == 2 || nq >= 64;
+}
+
+int32_t topk_mfma_prepare(gorse_topk *h) {
+    h->mfma_ok = false;
+    if (h->metric != GORSE_METRIC_NEG_DOT && h->metric != GORSE_METRIC_COSINE) return GORSE_OK;
+    const int64_t N = h->N;
+    const int d = h->d;
+    const bool bf = h->dtype == GORSE_DTYPE_BF16;
+    const int need = (int)ceil_div(bf ? d : 3 * (int64_t)d, 16);
+    int kp = 0;
+    for (int c : kSupportedKP)
+        if (c >= need) {
+            kp = c;
+            break;
+        }
+    if (kp == 0) return GORSE_OK;  // too deep for register-resident query operands: path A
+    // the error bound needs finite norms (and non-zero ones for cosine, whose reference distance is then NaN)
+    std::vector<float> n2((size_t)N);
+    GORSE_HIP_CHECK(hipMemcpyAsync(n2.data(), h->norm2.p, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    float mx = 0.0f;
+    for (float v : n2) {
+        if (!(v == v) || std::isinf(v)) return GORSE_OK;
+        if (h->metric == GORSE_METRIC_COSINE && !(v > 0.0f)) return GORSE_OK;
+        mx = std::max(mx, v);
+    }
+    h->max_norm = std::sqrt(mx) * 1.0001f;
+    h->kp = kp;
+    const int kpad = kp * 16;
+    // forward error of two different summation orders of the same K' exact products (the reference's fp32
+    // chain, gamma <= K' u, and the MFMA's, gamma <= 2 K' u allowing truncating adders), plus the fp32 roundings
+    // of the cosine formula; fp32 inputs add the dropped lo.lo / residual terms of the RNE split (3 * 2^-16).
+    const double u = std::ldexp(1.0, -24);
+    double coef = bf ? (3.0 * d + 64.0) * u : (9.0 * d + 64.0) * u + 3.2 * std::ldexp(1.0, -16);
+    coef += 16.0 * u;
+    h->err_coef = (float)(coef * 1.01);
+    if (bf && d == kpad) {
+        h->opA = h->opB = h->Xb.p;
+    } else {
+        GORSE_TRY(h->opA_own.alloc((size_t)N * kpad));
+        if (bf) {
+            pad_bf16_kernel<<<dim3(2048), dim3(256), 0, h->stream>>>(h->Xb.p, nullptr, N, d, kpad, h->opA_own.p);
+            h->opA = h->opB = h->opA_own.p;
+        } else {
+            GORSE_TRY(h->opB_own.alloc((size_t)N * kpad));
+            split_f32_kernel<<<dim3(2048), dim3(256), 0, h->stream>>>(h->X.p, N, d, kpad, 0, h->opA_own.p);
+            split_f32_kernel<<<dim3(2048), dim3(256), 0, h->stream>>>(h->X.p, N, d, kpad, 1, h->opB_own.p);
+            h->opA = h->opA_own.p;
+            h->opB = h->opB_own.p;
+        }
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    if (h->metric == GORSE_METRIC_COSINE) {
+        GORSE_TRY(h->rscale.alloc((size_t)N));
+        rscale_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->norm2.p, N, h->rscale.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->mfma_ok = true;
+    return GORSE_OK;
+}
+
+int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev,
+                         int64_t nq, int k, int prune0, int32_t *idx_out, float *dist_out, int32_t *cnt_out) {
+    const int d = h->d, kpad = h->kp * 16;
+    const bool by_vector = qv_dev != nullptr;
+    const bool contiguous = !by_vector && qid_host == nullptr;
+    const bool exclude_self = !by_vector;
+    const int kth = k + (exclude_self ? 1 : 0);
+    const int64_t admissible = h->N - (exclude_self ? 1 : 0);
+    const int64_t expect = std::min<int64_t>(k, admissible);
+    const bool scale = h->metric == GORSE_METRIC_COSINE;
+    const float other = scale ? 1.0f : h->max_norm;
+    const int64_t mb = std::min(nq, kChunkQ);
+    GORSE_TRY(h->cbuf.ensure((size_t)mb * kCap));
+    GORSE_TRY(h->ccnt.ensure((size_t)mb));
+    GORSE_TRY(h->cflag.ensure((size_t)mb));
+    GORSE_TRY(h->qmargin.ensure((size_t)mb));
+    GORSE_TRY(h->res_idx.ensure((size_t)mb * k));
+    GORSE_TRY(h->res_dist.ensure((size_t)mb * k));
+    GORSE_TRY(h->res_cnt.ensure((size_t)mb));
+    if (!contiguous) {
+        GORSE_TRY(h->opQ.ensure((size_t)mb * kpad));
+        GORSE_TRY(h->qn2.ensure((size_t)mb));
+    }
+    if (qid_host) GORSE_TRY(h->qid.ensure((size_t)mb));
+    h->n_fallback = 0;
+    std::vector<uint8_t> flags((size_t)mb);
+    for (int64_t c0 = 0; c0 < nq; c0 += kChunkQ) {
+        const int64_t m = std::min(kChunkQ, nq - c0);
+        const uint16_t *Bop;
+        const float *qn2;
+        const float *Qf = nullptr;
+        if (contiguous) {
+            Bop = h->opB + (q_contig_begin + c0) * kpad;
+            qn2 = h->norm2.p + q_contig_begin + c0;
+        } else if (qid_host) {
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->qid.p, qid_host + c0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+            gather_queries_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->opB, h->norm2.p, h->qid.p, m, kpad,
+                                                                                h->opQ.p, h->qn2.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+            Bop = h->opQ.p;
+            qn2 = h->qn2.p;
+        } else {
+            Qf = qv_dev + c0 * d;
+            if (h->dtype == GORSE_DTYPE_BF16)
+                pad_bf16_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(nullptr, Qf, m, d, kpad, h->opQ.p);
+            else
+                split_f32_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(Qf, m, d, kpad, 1, h->opQ.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+            GORSE_TRY(topk_compute_norms(h, Qf, m, h->qn2.p));
+            Bop = h->opQ.p;
+            qn2 = h->qn2.p;
+        }
+        margin_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
+            qn2, m, h->err_coef, other, h->qmargin.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
+        SweepParams sp;
+        sp.A = h->opA;
+        sp.B = Bop;
+        sp.rscale = scale ? h->rscale.p : nullptr;
+        sp.qmargin = h->qmargin.p;
+        sp.cbuf = h->cbuf.p;
+        sp.ccnt = h->ccnt.p;
+        sp.cflag = h->cflag.p;
+        sp.N = h->N;
+        sp.nq = m;
+        sp.kth = kth;
+        int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
+        GORSE_TRY(dispatch_sweep(h, sp, scale));
+        h->prof.end(tok, h->stream);
+        RescoreParams rp;
+        rp.X = h->X.p;
+        rp.norm2 = h->norm2.p;
+        rp.Qf = Qf;
+        rp.qn2 = qn2;
+        rp.qid = qid_host ? h->qid.p : nullptr;
+        rp.q0 = q_contig_begin + c0;
+        rp.cbuf = h->cbuf.p;
+        rp.ccnt = h->ccnt.p;
+        rp.cflag = h->cflag.p;
+        rp.d = d;
+        rp.metric = h->metric;
+        rp.k = k;
+        rp.prune0 = prune0;
+        rp.expect = expect;
+        rp.out_idx = h->res_idx.p;
+        rp.out_dist = h->res_dist.p;
+        rp.out_cnt = h->res_cnt.p;
+        const size_t lds = ((size_t)(1 + kGroupsPerBlock) * d + 2 * kCap + 4) * 4;
+        tok = h->prof.begin(GORSE_PROF_TOPK_SELECT, h->stream);
+        topk_rescore_kernel<<<dim3((unsigned)m), dim3(kBlock), lds, h->stream>>>(rp);
+        GORSE_HIP_CHECK(hipGetLastError());
+        h->prof.end(tok, h->stream);
+        if (idx_out)
+            GORSE_HIP_CHECK(hipMemcpyAsync(idx_out + c0 * k, h->res_idx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
+        if (dist_out)
+            GORSE_HIP_CHECK(hipMemcpyAsync(dist_out + c0 * k, h->res_dist.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
+        if (cnt_out)
+            GORSE_HIP_CHECK(hipMemcpyAsync(cnt_out + c0, h->res_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        // queries the MFMA path could not decide: replay the reference literally (path A)
+        std::vector<int64_t> fb;
+        for (int64_t t = 0; t < m; t++)
+            if (flags[t]) fb.push_back(t);
+        if (fb.empty()) continue;
+        h->n_fallback += (int64_t)fb.size();
+        const int64_t bq = topk_scan_block_queries(h);
+        std::vector<int64_t> ids((size_t)std::min<int64_t>(bq, (int64_t)fb.size()));
+        std::vector<int32_t> ti((size_t)ids.size() * k), tc(ids.size());
+        std::vector<float> td((size_t)ids.size() * k);
+        GORSE_TRY(h->qbuf.ensure(ids.size() * (size_t)d));
+        GORSE_TRY(h->qnorm.ensure(ids.size()));
+        GORSE_TRY(h->qidx.ensure(ids.size()));
+        for (size_t f0 = 0; f0 < fb.size(); f0 += (size_t)bq) {
+            const int64_t fm = std::min<int64_t>(bq, (int64_t)(fb.size() - f0));
+            for (int64_t r = 0; r < fm; r++) {
+                const int64_t t = fb[f0 + r];
+                const float *src = by_vector ? Qf + t * d : h->X.p + (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t) * d;
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->qbuf.p + r * d, src, (size_t)d * 4, hipMemcpyDeviceToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->qnorm.p + r, qn2 + t, 4, hipMemcpyDeviceToDevice, h->stream));
+                ids[r] = by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
+            }
+            const int64_t *excl = nullptr;
+            if (!by_vector) {
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->qidx.p, ids.data(), (size_t)fm * 8, hipMemcpyHostToDevice, h->stream));
+                excl = h->qidx.p;
+            }
+            GORSE_TRY(topk_scan_block(h, fm, excl, k, prune0, ti.data(), td.data(), tc.data()));
+            for (int64_t r = 0; r < fm; r++) {
+                const int64_t t = fb[f0 + r];
+                if (idx_out) std::copy(ti.begin() + r * k, ti.begin() + (r + 1) * k, idx_out + (c0 + t) * k);
+                if (dist_out) std::copy(td.begin() + r * k, td.begin() + (r + 1) * k, dist_out + (c0 + t) * k);
+                if (cnt_out) cnt_out[c0 + t] = tc[r];
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_idx.p + t * k, ti.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_dist.p + t * k, td.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_cnt.p + t, tc.data() + r, 4, hipMemcpyHostToDevice, h->stream));
+            }
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+    }
+    return GORSE_OK;
+}
+
+}  // namespace gorse

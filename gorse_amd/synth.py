@@ -177,3 +177,13 @@ def s_emb(N=1_000_000, d=128, seed=44):
     X = rng.standard_normal((N, d), dtype=np.float32)
     X /= np.sqrt((X.astype(np.float32) ** 2).sum(axis=1, keepdims=True, dtype=np.float32))
     return (X.view(np.uint32) >> 16).astype(np.uint16)
+
+
+def s_emb(N=1_000_000, d=128, seed=44):
+    """S-emb (BASELINE config C4): N x d entries N(0,1), L2-normalised in fp32, then bf16 by
+    truncation (common/bfloats/bfloats.go:24-30).  Returns (uint16 N x d, the same values expanded to fp32)."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    X /= np.sqrt(np.einsum("ij,ij->i", X, X, dtype=np.float32))[:, None]
+    Xb = (X.view(np.uint32) >> 16).astype(np.uint16)
+    return Xb, (Xb.astype(np.uint32) << 16).view(np.float32)

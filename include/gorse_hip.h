@@ -167,8 +167,10 @@ int32_t gorse_topk_search_vector(gorse_topk *h, const void *qv /*host*/, int64_t
 int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t *idx_out /*host or NULL*/,
                              float *dist_out /*host or NULL*/);
 int32_t gorse_topk_synchronize(gorse_topk *h);
-#define GORSE_PROF_TOPK_SCORE 0
-#define GORSE_PROF_TOPK_RESCORE 1
+#define GORSE_PROF_TOPK_SCORE 0   /* path A: dist_kernel (pair-at-a-time scan in the reference's order)      */
+#define GORSE_PROF_TOPK_RESCORE 1 /* path A: select_kernel (literal container/heap selection)                 */
+#define GORSE_PROF_TOPK_SWEEP 2   /* path B: topk_sweep_kernel (bf16 MFMA candidate sweep + threshold filter) */
+#define GORSE_PROF_TOPK_SELECT 3  /* path B: topk_rescore_kernel (exact rescoring + ranking of the lists)     */
 int32_t gorse_topk_set_profiling(gorse_topk *h, int32_t on);
 int32_t gorse_topk_get_profile(gorse_topk *h, int32_t kernel_class, int64_t *launches, double *total_ms);
 /* statistics of the last all_pairs / search call: queries that took the exact fallback path */
@@ -193,6 +195,10 @@ void gorse_hip_test_set_exact_exp(int32_t mode);
  * resident workgroup count).  Used by scripts/gpu_probe_*.py to attribute time; 0 (the default) is the only
  * value the product ever runs with. */
 void gorse_hip_test_set_variant(int32_t variant);
+/* top-k path choice: 0 = automatic (MFMA sweep for >= 64 queries, dot / cosine, k <= 255), 1 = always the
+ * literal scan (path A), 2 = the MFMA sweep whenever its operands exist.  Both paths return identical results;
+ * the hook exists so the parity tests can drive each one. */
+void gorse_hip_test_set_topk_path(int32_t path);
 /* the counting sort by positive item that precedes the item-run update kernel, on a host-supplied
  * chunk (n <= one chunk = 4M samples): su/si/sj receive the triplets in the order the kernel walks them
  * (per window of 32768 consecutive samples: ascending i, skipped samples last). */

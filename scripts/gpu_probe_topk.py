@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""GPU probe: time top-k path B (MFMA sweep + rescoring) on a few index shapes; prints one line per case."""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from gorse_amd import capi, synth  # noqa: E402
+
+
+def run(name, X, metric, dtype, k, q0, q1, reps=2):
+    t0 = time.perf_counter()
+    t = capi.TopK(X, metric, dtype=dtype)
+    t_create = time.perf_counter() - t0
+    t.all_pairs(k, q0, min(q1, q0 + 4096), fetch=False)
+    t.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        t.all_pairs(k, q0, q1, fetch=False)
+    dt = (time.perf_counter() - t0) / reps
+    ns, sweep = t.get_profile(capi.PROF_TOPK_SWEEP)
+    nr, resc = t.get_profile(capi.PROF_TOPK_SELECT)
+    na, scan = t.get_profile(capi.PROF_TOPK_SCORE)
+    N, d = X.shape
+    pairs = (q1 - q0) * (N - 1)
+    kd = d if dtype == capi.DTYPE_BF16 else 3 * d
+    print("%-34s N=%8d d=%4d k=%3d nq=%8d wall %8.2f ms (%.3e pairs/s) sweep %8.2f ms (%.1f TFLOP/s on %d-deep operands) "
+          "rescore %7.2f ms scan-launches %d fallback %d create %.2f s"
+          % (name, N, d, k, q1 - q0, dt * 1e3, pairs / dt, sweep / max(ns, 1), 2.0 * kd * (q1 - q0) * N / (sweep / max(ns, 1) * 1e-3) / 1e12,
+             kd, resc / max(nr, 1), na, t.last_stats()[0], t_create), flush=True)
+    t.close()
+
+
+def main():
+    capi.lib().gorse_hip_test_set_topk_path(0)
+    Xb, Xe = synth.s_emb(1_000_000, 128, 44)
+    run("C4 S-emb bf16 cosine", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000)
+    run("C4 S-emb bf16 -dot", Xb, capi.METRIC_NEG_DOT, capi.DTYPE_BF16, 100, 0, 1_000_000)
+    run("S-emb bf16 cosine 128K queries", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 131072)
+    run("S-emb bf16 cosine k=10", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 10, 0, 262144)
+    del Xb, Xe
+    rng = np.random.default_rng(3)
+    Q = (rng.standard_normal((200_000, 64)) * 0.3).astype(np.float32)
+    Q *= rng.lognormal(0, 0.5, (200_000, 1)).astype(np.float32)
+    run("item factors fp32 d=64 -dot", Q, capi.METRIC_NEG_DOT, capi.DTYPE_F32, 100, 0, 200_000)
+    Q2 = rng.standard_normal((200_000, 128)).astype(np.float32)
+    run("fp32 d=128 cosine", Q2, capi.METRIC_COSINE, capi.DTYPE_F32, 100, 0, 200_000)
+    Xs = (rng.standard_normal((100_000, 16))).astype(np.float32)
+    run("fp32 d=16 -dot", Xs, capi.METRIC_NEG_DOT, capi.DTYPE_F32, 10, 0, 100_000)
+
+
+if __name__ == "__main__":
+    main()
