@@ -174,6 +174,245 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
     }
 }
 
+
+// ---- Gram-form row solve (d <= 64) --------------------------------------------------------------
+// model.go:659-690 keeps a residual per feedback entry and re-walks the row's n entries for every one
+// of the d coordinates.  Substituting the residual, r^f_t = sum_{k != f} p_k q_tk, turns the three sums into
+//     a - b = s_f - sum_{k != f} p_k M_kf,   c + w S_ff = M_ff,   M = (1 - w) G + w S,
+//     G = sum_t q_t q_t^T,   s = sum_t q_t        (t over the row's feedback entries)
+// i.e. the same Gauss-Seidel sweep over f on a d x d system per row.  G is built by
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fmaf chain over the entries) straight from the
+// gathered rows: a half-wave reads 32 consecutive floats of one feedback row (128 B), so one MFMA
+// consumes two entries.  Same mathematics, different summation order than the reference: parity is
+// the 1e-4 relative bar of BASELINE.md (the reference's own fp32 residual recurrence is no closer to
+// the exact solution: tests/test_gpu_cf_parity.py::test_als_*).
+int g_als_long_row = 4096;  // rows longer than this are cut into chunks (test hook: gorse_hip_test_set_als_plan)
+int g_als_chunk = 4096;     // feedback entries per chunk of a long row
+int g_als_path = 0;         // 0 auto (Gram form for d <= 64), 1 force the residual sweep, 2 force the Gram form
+constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
+constexpr int kAlsWaves = 4;        // waves per workgroup of the row kernels
+constexpr int kAlsPairs = 8;        // feedback-entry pairs per pipeline stage (16 entries, 4 KB at d = 64)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum64(float v) {
+    v = group_tree16(v);  // every lane of a 16-lane row holds its row's total
+    int m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __int_as_float(m);
+    m = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    v += __int_as_float(m);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int NB>
+struct GramAcc {
+    static constexpr int NT = NB * (NB + 1) / 2;
+    f32x16 t[NT];   // upper-triangular 32x32 tiles (bi <= bj), row-major over (bi, bj)
+    float sum[NB];  // this lane's share of the column sums
+    __device__ __forceinline__ static constexpr int tile(int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
+};
+
+// one pipeline stage: kAlsPairs entry pairs of the 64-entry index batch held in `idx` (one entry per lane)
+template <int NB>
+__device__ __forceinline__ void gram_load_stage(const float *__restrict__ B, const float *__restrict__ zeros, int idx,
+                                                int first, int d, int lane, float (&fr)[kAlsPairs][NB]) {
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int j = 0; j < kAlsPairs; j++) {
+        const int r0 = __builtin_amdgcn_readlane(idx, first + 2 * j);
+        const int r1 = __builtin_amdgcn_readlane(idx, first + 2 * j + 1);
+        const int r = half ? r1 : r0;
+        const float *row = B + (int64_t)r * d;
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int e = 32 * b + col;
+            // padding lanes and entries past the row's end read a zero word instead: the select is on the
+            // ADDRESS, so every lane issues the load and no branch (with its vmcnt(0)) splits the gathers
+            const float *src = (r >= 0 && e < d) ? row + e : zeros + lane;
+            fr[j][b] = *src;
+        }
+    }
+}
+
+// G += sum over fb[0..n) of q q^T, sum += column sums; the whole wave walks one row (or one chunk of a row)
+template <int NB>
+__device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, const float *__restrict__ zeros,
+                                                const int32_t *__restrict__ fb, int n, int d, int lane,
+                                                GramAcc<NB> &g) {
+#pragma unroll
+    for (int t = 0; t < GramAcc<NB>::NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) g.t[t][r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; b++) g.sum[b] = 0.0f;
+    if (n <= 0) return;
+    const int nstages = (n + 2 * kAlsPairs - 1) / (2 * kAlsPairs);
+    constexpr int kStagesPerBatch = 64 / (2 * kAlsPairs);
+    // index batches: lane l of idx_cur holds entry 64 * batch + l (or -1 past the row's end, which makes the
+    // gathers of those entries read zeros); idx_nxt is the batch after it
+    int idx_cur = lane < n ? fb[lane] : -1;
+    int idx_nxt = 64 + lane < n ? fb[64 + lane] : -1;
+    int loaded = 0;  // stages whose gathers have been issued
+    auto issue = [&](float (&fr)[kAlsPairs][NB]) {
+        const int sb = loaded % kStagesPerBatch;
+        if (sb == 0 && loaded > 0) {
+            idx_cur = idx_nxt;
+            const int64_t nb = (int64_t)(loaded / kStagesPerBatch + 1) * 64 + lane;
+            idx_nxt = nb < n ? fb[nb] : -1;
+        }
+        gram_load_stage<NB>(B, zeros, idx_cur, sb * 2 * kAlsPairs, d, lane, fr);
+        loaded++;
+    };
+    auto consume = [&](const float (&fr)[kAlsPairs][NB]) {
+#pragma unroll
+        for (int j = 0; j < kAlsPairs; j++) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) g.sum[b] += fr[j][b];
+#pragma unroll
+            for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+                for (int bj = bi; bj < NB; bj++)
+                    g.t[GramAcc<NB>::tile(bi, bj)] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fr[j][bi], fr[j][bj], g.t[GramAcc<NB>::tile(bi, bj)], 0, 0, 0);
+        }
+    };
+    // ping-pong: the gathers of stage s + 1 are in flight while the MFMAs of stage s run.  Stages past the
+    // end are all-zero gathers (at most two per row), which keeps every load unconditional.
+    float f0[kAlsPairs][NB], f1[kAlsPairs][NB];
+    issue(f0);
+    for (int s = 0; s < nstages; s += 2) {
+        issue(f1);
+        consume(f0);
+        issue(f0);
+        consume(f1);
+    }
+}
+
+// visit every (i, j, value) of the full symmetric G held as upper-triangular tiles; C layout of the
+// 32x32 MFMA: lane holds column lane & 31, rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+template <int NB, typename F>
+__device__ __forceinline__ void gram_foreach(const GramAcc<NB> &g, int d, int lane, F &&f) {
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+        for (int bj = bi; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int j = 32 * bj + (lane & 31);
+                if (i < d && j < d) {
+                    const float v = g.t[GramAcc<NB>::tile(bi, bj)][r];
+                    f(i, j, v);
+                    if (bi != bj) f(j, i, v);
+                }
+            }
+}
+
+// column sums: lanes l and l + 32 hold the two halves of column (32 b + l & 31)
+template <int NB>
+__device__ __forceinline__ void gram_store_sums(const GramAcc<NB> &g, int d, int lane, float *dst) {
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const float other = __shfl_xor(g.sum[b], 32, 64);
+        const int e = 32 * b + (lane & 31);
+        if (lane < 32 && e < d) dst[e] = g.sum[b] + other;
+    }
+}
+
+// one Gauss-Seidel sweep over the d coordinates of row `a` against M (LDS, stride kAlsDP) and s (LDS)
+__device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss, int d, float reg,
+                                              int lane) {
+    float p = lane < d ? a[lane] : 0.0f;
+    for (int f = 0; f < d; f++) {
+        const float m = lane < d ? sM[f * kAlsDP + lane] : 0.0f;  // M is symmetric: row f = column f
+        const float tot = wave_sum64(lane == f ? 0.0f : p * m);
+        const float mff = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), f));
+        const float nf = (ss[f] - tot) / (mff + reg);
+        if (lane == f) p = nf;
+    }
+    if (lane < d) a[lane] = p;
+}
+
+// A: side being solved, B: the other side, S: d x d Gram of B over rows with feedback
+template <int NB>
+__global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__restrict__ A, const float *__restrict__ B,
+                                                                 const int64_t *__restrict__ ptr,
+                                                                 const int32_t *__restrict__ idx,
+                                                                 const float *__restrict__ S,
+                                                                 const int32_t *__restrict__ rows, int64_t n_rows, int d,
+                                                                 float w, float reg, const float *__restrict__ zeros) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *sM = smem + (size_t)wv * (64 * kAlsDP + 64);
+    float *ss = sM + 64 * kAlsDP;
+    const float one_w = 1 - w;
+    const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
+    for (int64_t t = wave; t < n_rows; t += nwaves) {
+        const int64_t u = rows[t];
+        const int64_t beg = ptr[u];
+        const int n = (int)(ptr[u + 1] - beg);
+        GramAcc<NB> g;
+        gram_accumulate<NB>(B, zeros, idx + beg, n, d, lane, g);
+        gram_foreach<NB>(g, d, lane, [&](int i, int j, float v) { sM[i * kAlsDP + j] = v; });
+        gram_store_sums<NB>(g, d, lane, ss);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < d; i++)  // M = (1 - w) G + w S, one row of M per step (S is L1/L2 resident)
+            if (lane < d) sM[i * kAlsDP + lane] = one_w * sM[i * kAlsDP + lane] + w * S[i * d + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        als_solve_row(A + u * d, sM, ss, d, reg, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// long rows, stage 1: one wave per chunk -> partial[c] = [G (d x d, full) | s (d)]
+template <int NB>
+__global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const float *__restrict__ B,
+                                                                   const int32_t *__restrict__ idx,
+                                                                   const int64_t *__restrict__ chunk_beg,
+                                                                   const int32_t *__restrict__ chunk_cnt,
+                                                                   int64_t n_chunks, int d, float *__restrict__ partial,
+                                                                   const float *__restrict__ zeros) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
+    const int64_t stride = (int64_t)d * d + d;
+    for (int64_t c = wave; c < n_chunks; c += nwaves) {
+        GramAcc<NB> g;
+        gram_accumulate<NB>(B, zeros, idx + chunk_beg[c], chunk_cnt[c], d, lane, g);
+        float *dst = partial + c * stride;
+        gram_foreach<NB>(g, d, lane, [&](int i, int j, float v) { dst[i * d + j] = v; });
+        gram_store_sums<NB>(g, d, lane, dst + (int64_t)d * d);
+    }
+}
+
+// long rows, stage 2: one workgroup per row adds the row's partials in chunk order, wave 0 solves
+__global__ __launch_bounds__(256) void als_long_solve_kernel(float *__restrict__ A, const float *__restrict__ S,
+                                                             const int32_t *__restrict__ rows,
+                                                             const int32_t *__restrict__ first,
+                                                             const int32_t *__restrict__ nch, int64_t n_rows, int d,
+                                                             float w, float reg, const float *__restrict__ partial) {
+    __shared__ float sM[64 * kAlsDP];
+    __shared__ float ss[64];
+    const float one_w = 1 - w;
+    const int64_t stride = (int64_t)d * d + d;
+    for (int64_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
+        const float *src = partial + (int64_t)first[t] * stride;
+        const int nc = nch[t];
+        for (int e = threadIdx.x; e < (int)stride; e += blockDim.x) {
+            float acc = 0.0f;
+            for (int c = 0; c < nc; c++) acc += src[(int64_t)c * stride + e];
+            if (e < d * d)
+                sM[(e / d) * kAlsDP + e % d] = one_w * acc + w * S[e];
+            else
+                ss[e - d * d] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) als_solve_row(A + (int64_t)rows[t] * d, sM, ss, d, reg, threadIdx.x);
+        __syncthreads();
+    }
+}
+
 int32_t run_gram(gorse_mf *h, const float *F, const int64_t *ptr, int64_t rows, int tok_cls) {
     const int d = h->d, dd = d * d;
     GORSE_TRY(h->gram.ensure((size_t)dd));
@@ -217,6 +456,48 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
     return GORSE_OK;
 }
 
+
+int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int64_t *ptr, const int32_t *idx, float w,
+                      float reg) {
+    const int d = h->d;
+    gorse_mf::AlsPlan &pl = h->als_plan[side];
+    const size_t lds = (size_t)kAlsWaves * (64 * kAlsDP + 64) * sizeof(float);
+    int tok = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
+    if (pl.n_short > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_short, kAlsWaves), 512);  // 2 workgroups per CU
+        if (d <= 32) {
+            GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)lds));
+            als_row_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p);
+        } else {
+            GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)lds));
+            als_row_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p);
+        }
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    if (pl.n_long > 0) {
+        GORSE_TRY(h->als_partial.ensure((size_t)pl.n_chunks * ((size_t)d * d + d)));
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_chunks, kAlsWaves), 2048);
+        if (d <= 32)
+            als_chunk_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p,
+                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p);
+        else
+            als_chunk_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p,
+                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        als_long_solve_kernel<<<dim3((unsigned)std::min<int64_t>(pl.n_long, 1024)), dim3(256), 0, h->stream>>>(
+            A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    h->prof.end(tok, h->stream);
+    return GORSE_OK;
+}
+
+bool use_gram_form(const gorse_mf *h) { return g_als_path == 2 || (g_als_path == 0 && h->d <= 64); }
+
 }  // namespace
 
 extern "C" int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const volatile int32_t *cancel) {
@@ -225,15 +506,82 @@ extern "C" int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const v
     GORSE_TRY(h->use());
     GORSE_TRY(mf_sync_streams(h));
     const int64_t max_u = h->max_user_row, max_i = h->max_item_row;
+    if (g_als_path == 2 && h->d > 64) return fail(GORSE_ERR_INVALID, "the Gram-form ALS kernels cover nFactors <= 64 (got %d)", h->d);
+    const bool gram_form = use_gram_form(h);
     if (cancel && *cancel) return fail(GORSE_ERR_CANCELLED, "cancelled");
     GORSE_TRY(run_gram(h, h->Q.p, h->iptr.p, h->I, GORSE_PROF_ALS_GRAM));                          // model.go:645-658
-    GORSE_TRY(run_sweep(h, h->P.p, h->Q.p, h->uptr.p, h->uidx.p, h->U, max_u, weight, reg));       // model.go:659-690
+    if (gram_form)
+        GORSE_TRY(run_side_gram(h, 0, h->P.p, h->Q.p, h->uptr.p, h->uidx.p, weight, reg));
+    else
+        GORSE_TRY(run_sweep(h, h->P.p, h->Q.p, h->uptr.p, h->uidx.p, h->U, max_u, weight, reg));   // model.go:659-690
     if (cancel && *cancel) {
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         return fail(GORSE_ERR_CANCELLED, "cancelled");
     }
     GORSE_TRY(run_gram(h, h->P.p, h->uptr.p, h->U, GORSE_PROF_ALS_GRAM));                          // model.go:693-706
-    GORSE_TRY(run_sweep(h, h->Q.p, h->P.p, h->iptr.p, h->iidx.p, h->I, max_i, weight, reg));       // model.go:707-738
+    if (gram_form)
+        GORSE_TRY(run_side_gram(h, 1, h->Q.p, h->P.p, h->iptr.p, h->iidx.p, weight, reg));
+    else
+        GORSE_TRY(run_sweep(h, h->Q.p, h->P.p, h->iptr.p, h->iidx.p, h->I, max_i, weight, reg));   // model.go:707-738
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     return GORSE_OK;
 }
+
+extern "C" void gorse_hip_test_set_als_path(int32_t path) { g_als_path = path; }
+// takes effect for handles created afterwards (the row plan is built in gorse_mf_create)
+extern "C" void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk) {
+    g_als_long_row = long_row > 0 ? long_row : 4096;
+    g_als_chunk = chunk > 0 ? chunk : 4096;
+}
+
+namespace gorse {
+// rows of one side -> short-row list (longest first) + chunks of the long rows; host CSR pointers only
+int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows) {
+    gorse_mf::AlsPlan &pl = h->als_plan[side];
+    if (h->als_zeros.n < 64) {
+        GORSE_TRY(h->als_zeros.alloc(64));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->als_zeros.p, 0, 64 * sizeof(float), h->stream));
+    }
+    std::vector<int32_t> shorts, lrows, lfirst, lnch, crow, ccnt;
+    std::vector<int64_t> cbeg;
+    for (int64_t r = 0; r < rows; r++) {
+        const int64_t n = ptr[r + 1] - ptr[r];
+        if (n <= g_als_long_row) {
+            shorts.push_back((int32_t)r);
+            continue;
+        }
+        lrows.push_back((int32_t)r);
+        lfirst.push_back((int32_t)crow.size());
+        int nc = 0;
+        for (int64_t b = 0; b < n; b += g_als_chunk, nc++) {
+            crow.push_back((int32_t)r);
+            cbeg.push_back(ptr[r] + b);
+            ccnt.push_back((int32_t)std::min<int64_t>(g_als_chunk, n - b));
+        }
+        lnch.push_back(nc);
+    }
+    std::stable_sort(shorts.begin(), shorts.end(),
+                     [&](int32_t a, int32_t b) { return ptr[a + 1] - ptr[a] > ptr[b + 1] - ptr[b]; });
+    pl.n_short = (int64_t)shorts.size();
+    pl.n_long = (int64_t)lrows.size();
+    pl.n_chunks = (int64_t)crow.size();
+    auto up32 = [&](DevBuf<int32_t> &b, const std::vector<int32_t> &v) -> int32_t {
+        GORSE_TRY(b.alloc(v.size()));
+        if (!v.empty())
+            GORSE_HIP_CHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        return GORSE_OK;
+    };
+    GORSE_TRY(up32(pl.short_rows, shorts));
+    GORSE_TRY(up32(pl.long_rows, lrows));
+    GORSE_TRY(up32(pl.long_first, lfirst));
+    GORSE_TRY(up32(pl.long_nch, lnch));
+    GORSE_TRY(up32(pl.chunk_row, crow));
+    GORSE_TRY(up32(pl.chunk_cnt, ccnt));
+    GORSE_TRY(pl.chunk_beg.alloc(cbeg.size()));
+    if (!cbeg.empty())
+        GORSE_HIP_CHECK(hipMemcpyAsync(pl.chunk_beg.p, cbeg.data(), cbeg.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+                                       h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // host vectors go out of scope
+    return GORSE_OK;
+}
+}  // namespace gorse

@@ -235,6 +235,8 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
                                            hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->iidx.p, item_indices, (size_t)innz * sizeof(int32_t), hipMemcpyHostToDevice,
                                            h->stream));
+            GORSE_TRY(als_build_plan(h, 0, user_indptr, U));
+            GORSE_TRY(als_build_plan(h, 1, item_indptr, I));
         }
         {   // hot items: share of the training feedback >= 1/2048, at most 1024 of them (bpr.hip, HotRows)
             std::vector<int64_t> cnt((size_t)I, 0);

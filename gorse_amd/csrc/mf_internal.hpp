@@ -35,6 +35,19 @@ struct gorse_mf {
     gorse::DevBuf<int32_t> fail_count;
     // ALS scratch
     gorse::DevBuf<float> gram, gram_partial, als_scratch;
+    // ALS row plan per side (0 = user rows, 1 = item rows), built at create time (als.hip):
+    // rows with at most kAlsLongRow feedbacks are solved by one wave each (list sorted by length,
+    // longest first); longer rows are cut into chunks whose partial Gram matrices are reduced
+    // in chunk order by the long-row solver.
+    struct AlsPlan {
+        gorse::DevBuf<int32_t> short_rows;               // n_short row ids
+        gorse::DevBuf<int32_t> chunk_row, chunk_cnt;     // n_chunks
+        gorse::DevBuf<int64_t> chunk_beg;                // n_chunks: offset into the side's indices
+        gorse::DevBuf<int32_t> long_rows, long_first, long_nch;  // n_long
+        int64_t n_short = 0, n_chunks = 0, n_long = 0;
+    } als_plan[2];
+    gorse::DevBuf<float> als_zeros;    // 64 zero words: where padding lanes of the gathers read
+    gorse::DevBuf<float> als_partial;  // n_chunks x (d*d + d) partial Gram matrices + column sums
     // generic staging
     gorse::DevBuf<char> stage;
     gorse::KernelProfile prof{GORSE_PROF_NCLASSES};
@@ -49,4 +62,5 @@ struct gorse_mf {
 namespace gorse {
 // implemented in bpr.hip / als.hip, used across files
 int32_t mf_sync_streams(gorse_mf *h);
+int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows);
 }

@@ -33,6 +33,13 @@ struct gorse_topk {
     gorse::DevBuf<uint8_t> cflag;
     gorse::DevBuf<int32_t> res_idx, res_cnt;
     gorse::DevBuf<float> res_dist;
+    // tie replay (history sweep of the flagged queries + topk_replay_kernel)
+    gorse::DevBuf<int32_t> rp_pos, rp_ccnt, rp_hcnt;
+    gorse::DevBuf<int64_t> rp_self;
+    gorse::DevBuf<uint16_t> rp_op;
+    gorse::DevBuf<float> rp_margin;
+    gorse::DevBuf<uint2> rp_cbuf, rp_hbuf;
+    gorse::DevBuf<uint8_t> rp_flag;
     gorse::KernelProfile prof{GORSE_PROF_TOPK_NCLASSES};
     int64_t n_fallback = 0, n_tie = 0;
     int32_t use() const {
@@ -57,5 +64,5 @@ int32_t topk_mfma_prepare(gorse_topk *h);  // at create: operands, scales, error
 int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev,
                          int64_t nq, int k, int prune0, int32_t *idx_out, float *dist_out, int32_t *cnt_out);
 bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k);
-extern int g_topk_force_path;  // 0 auto, 1 path A only, 2 path B whenever it is usable
+extern int g_topk_force_path;  // 0 auto, 1 path A only, 2 path B whenever it is usable, 3 = 2 without the tie replay
 }  // namespace gorse

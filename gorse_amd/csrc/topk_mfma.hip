@@ -20,6 +20,7 @@
 #include <cmath>
 #include <limits>
 
+#include "goheap.hpp"
 #include "topk_internal.hpp"
 
 using namespace gorse;
@@ -41,6 +42,9 @@ constexpr int kEPL = kCap / 64;
 constexpr int kCompactAt = kCap - 64;   // compact a list once it holds more than this (a block adds <= 32)
 constexpr int kOverflowAt = kCap - 128; // a compaction that keeps more than this cannot make progress
 constexpr int kMaxKth = 256;
+constexpr int kHistCap = 4096;          // history entries per query of the tie-replay sweep (see topk_replay_kernel)
+constexpr int kReplayCap = 8192;        // power of two >= kCap + kHistCap: entries the replay sorts
+constexpr int64_t kReplayChunk = 16384; // flagged queries per history sweep (history buffer = 512 MB)
 constexpr int64_t kChunkQ = (int64_t)1 << 20;
 
 __device__ __forceinline__ uint32_t fkey(float x) {  // order-preserving float -> uint
@@ -62,14 +66,19 @@ struct SweepParams {
     const float *qmargin;  // per-query 2*delta_q
     uint2 *cbuf;           // nq x kCap (key, index)
     int32_t *ccnt;         // nq
-    uint8_t *cflag;        // nq: 1 = hand to path A
+    uint8_t *cflag;        // nq: 1 = this path cannot decide the query
+    uint2 *hbuf;           // HIST sweeps: nq x kHistCap entries a compaction dropped, in arrival order
+    int32_t *hcnt;         // HIST sweeps: nq
     int64_t N, nq;
     int kth;
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
+// HIST: the entries the new threshold drops are appended to the query's history (hb, counter s_hc[ql]) instead of
+// being forgotten; list + history then hold every vector the reference's heap can have accepted.
+template <bool HIST>
 __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s_cnt, float *s_f, const float *s_mg,
-                                              uint8_t *flag) {
+                                              uint8_t *flag, uint2 *hb = nullptr, int *s_hc = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n = s_cnt[ql];
     uint32_t key[kEPL], idx[kEPL];
@@ -96,25 +105,38 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
         newf = fkey_inv(prefix) - s_mg[ql];
     }
     int base = 0;
+    int hbase = HIST ? s_hc[ql] : 0;
+    bool hist_full = false;
 #pragma unroll
     for (int j = 0; j < kEPL; j++) {
-        const bool keep = (j * 64 + lane < n) && (fkey_inv(key[j]) >= newf);
+        const bool valid = j * 64 + lane < n;
+        const bool keep = valid && (fkey_inv(key[j]) >= newf);
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) qb[base + lane_rank(m)] = make_uint2(key[j], idx[j]);
         base += __builtin_popcountll(m);
+        if (HIST) {
+            const uint64_t md = __builtin_amdgcn_ballot_w64(valid && !keep);
+            const int nd = __builtin_popcountll(md);
+            if (hbase + nd > kHistCap)
+                hist_full = true;
+            else if (valid && !keep)
+                hb[hbase + lane_rank(md)] = make_uint2(key[j], idx[j]);
+            if (!hist_full) hbase += nd;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
         s_cnt[ql] = base;
         s_f[ql] = newf;
-        if (base > kOverflowAt) {  // ties / a margin too wide for the list: stop collecting, path A decides
+        if (HIST) s_hc[ql] = hbase;
+        if (base > kOverflowAt || hist_full) {  // ties / a margin too wide for the list: stop collecting, path A decides
             s_f[ql] = __builtin_inff();
             *flag = 1;
         }
     }
 }
 
-template <int KP, int NCB, bool SCALE>
+template <int KP, int NCB, bool SCALE, bool HIST>
 __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) {
     constexpr int KPAD = KP * 16;
     constexpr int ROWB = KPAD * 2 + 16;  // +16 B: consecutive rows start 4 banks apart, ds_read_b128 conflict-free
@@ -128,12 +150,14 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
     int *s_cnt = reinterpret_cast<int *>(s_rs + 2 * kTR);
     float *s_f = reinterpret_cast<float *>(s_cnt + BQ);
     float *s_mg = s_f + BQ;
+    int *s_hc = reinterpret_cast<int *>(s_mg + BQ);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t wgq0 = (int64_t)blockIdx.x * BQ;
     for (int t = tid; t < BQ; t += kThreads) {
         const int64_t q = wgq0 + t;
         s_cnt[t] = 0;
+        s_hc[t] = 0;
         s_f[t] = q < p.nq ? -__builtin_inff() : __builtin_inff();
         s_mg[t] = q < p.nq ? p.qmargin[q] : 0.0f;
     }
@@ -251,7 +275,8 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                     const float f = fth[cb];
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        const bool hit = acc[cb][r] >= f && qg < p.nq;
+                        // rows past N carry -inf: they must not pass a threshold that is still -inf
+                        const bool hit = acc[cb][r] >= f && acc[cb][r] > -__builtin_inff() && qg < p.nq;
                         if (__builtin_amdgcn_ballot_w64(hit) != 0) {
                             if (hit) {
                                 const int slot = atomicAdd(&s_cnt[ql], 1);
@@ -266,7 +291,8 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                         const int l = __builtin_ctzll(need);
                         need &= need - 1;
                         const int qlc = w * QW + cb * 32 + l;
-                        compact_query(p.cbuf + (wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg, p.cflag + wgq0 + qlc);
+                        compact_query<HIST>(p.cbuf + (wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg, p.cflag + wgq0 + qlc,
+                                            HIST ? p.hbuf + (wgq0 + qlc) * kHistCap : nullptr, s_hc);
                     }
                     fth[cb] = s_f[ql];
                 }
@@ -280,8 +306,12 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
         const int64_t qg = wgq0 + ql;
         if (qg >= p.nq) break;
         if (s_f[ql] == __builtin_inff()) continue;  // flagged
-        compact_query(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg);
-        if (lane == 0) p.ccnt[qg] = s_cnt[ql];
+        compact_query<HIST>(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg,
+                            HIST ? p.hbuf + qg * kHistCap : nullptr, s_hc);
+        if (lane == 0) {
+            p.ccnt[qg] = s_cnt[ql];
+            if (HIST) p.hcnt[qg] = s_hc[ql];
+        }
     }
 }
 
@@ -396,6 +426,237 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     if (tid == 0) p.out_cnt[t] = cnt;
 }
 
+
+// ---- tie replay: the reference's heap history of one query, rebuilt from list + history ------------------------
+// The rescoring kernel hands over queries whose top k+1 exact distances are not all distinct: there the reference's
+// answer depends on the ARRANGEMENT of its heap array, i.e. on everything Bruteforce pushed (bruteforce.go:46-53:
+// Push, then Pop when the queue holds more than k).  A history sweep (HIST) has recorded, for such a query, every
+// vector whose approximate score reached the filter threshold of its time.  A vector that was NOT recorded had
+// approx < threshold = (K-th best approx among earlier vectors) - 2 delta, so at least k EARLIER vectors are strictly
+// closer in exact arithmetic: the reference pushed it to the root and popped it straight away.  Such a push/pop pair
+// (operator T below) depends only on the heap state, not on the vector -- it is the identity unless equal distances
+// sit on the path it touches, and then it permutes them with a short period (<= ~log2 k).  So the replay is: exact
+// distances for the recorded vectors (reference arithmetic), sort by index, literal container/heap Push/Pop for each
+// (goheap.hpp), and T^gap for every gap of unrecorded vectors in between, T^gap evaluated by cycle detection.
+// Queries with a NaN, an overflowed history or an undetected cycle are flagged 2 and go to path A.
+struct ReplayParams {
+    const float *X;
+    const float *norm2;
+    const float *Qf;       // by-vector queries: fp32 rows of the chunk (row pos[t]), or null
+    const float *qn2;      // query norms of the chunk (row pos[t]), cosine only
+    const int64_t *self;   // stored-vector id of the query, or -1 for by-vector queries
+    const int32_t *pos;    // row of the query in the chunk's result arrays
+    const uint2 *cbuf;
+    const int32_t *ccnt;
+    const uint2 *hbuf;
+    const int32_t *hcnt;
+    uint8_t *cflag;        // in: flags of the history sweep (non-zero: undecidable); out: 2 = undecided here
+    int64_t N;
+    int d, metric, k, prune0;
+    int32_t *out_idx;
+    float *out_dist;
+    int32_t *out_cnt;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    const int d = p.d, k = p.k;
+    int *s_idx = reinterpret_cast<int *>(smem_f);           // kReplayCap
+    float *s_dst = smem_f + kReplayCap;                      // kReplayCap
+    float *sq = s_dst + kReplayCap;                          // d
+    float *sx = sq + d;                                      // kGroupsPerBlock * d
+    int32_t *hv = reinterpret_cast<int32_t *>(sx + (size_t)kGroupsPerBlock * d);  // 2 * (k + 2)
+    float *hw = reinterpret_cast<float *>(hv + 2 * (k + 2));                      // 2 * (k + 2)
+    int32_t *snap = reinterpret_cast<int32_t *>(hw + 2 * (k + 2));                // k + 2
+    int *s_misc = snap + (k + 2);                            // [0] NaN seen
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
+    if (p.cflag[t]) return;  // the history sweep could not hold this query: path A
+    const int n1 = p.ccnt[t], n2 = p.hcnt[t], n = n1 + n2;
+    const int64_t self = p.self[t];
+    const int64_t row = p.pos[t];
+    const float *qrow = p.Qf ? p.Qf + row * d : p.X + self * d;
+    for (int e = tid; e < d; e += kBlock) sq[e] = qrow[e];
+    if (tid == 0) s_misc[0] = 0;
+    __syncthreads();
+    const VecShape vs(d);
+    const float qq = p.metric == GORSE_METRIC_COSINE ? p.qn2[row] : 0.0f;
+    const uint2 *cb = p.cbuf + t * kCap, *hb = p.hbuf + t * kHistCap;
+    for (int c = gib; c < n; c += kGroupsPerBlock) {  // exact distances, the reference's arithmetic (as topk_rescore_kernel)
+        const int64_t i = c < n1 ? cb[c].y : hb[c - n1].y;
+        float *xr = sx + (size_t)gib * d;
+        for (int e = lane; e < d; e += kGroup) xr[e] = p.X[i * d + e];
+        __builtin_amdgcn_wave_barrier();
+        const float ab = dot512_lds(sq, xr, vs, lane);
+        __builtin_amdgcn_wave_barrier();
+        float r;
+        if (p.metric == GORSE_METRIC_NEG_DOT)
+            r = -ab;
+        else
+            r = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+        if (lane == 0) {
+            s_idx[c] = (int)i;
+            s_dst[c] = r;
+            if (r != r) s_misc[0] = 1;
+        }
+    }
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int c = n + tid; c < P; c += kBlock) {
+        s_idx[c] = 0x7fffffff;
+        s_dst[c] = 0.0f;
+    }
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)  // bitonic sort by index
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = tid; e < P / 2; e += kBlock) {
+                const int a = (e / stride) * 2 * stride + (e % stride), b = a + stride;
+                const bool up = (a & size) == 0;
+                const int ia = s_idx[a], ib = s_idx[b];
+                if ((ia > ib) == up) {
+                    s_idx[a] = ib;
+                    s_idx[b] = ia;
+                    const float da = s_dst[a];
+                    s_dst[a] = s_dst[b];
+                    s_dst[b] = da;
+                }
+            }
+            __syncthreads();
+        }
+    if (tid >= 64) return;
+    // ---- wave 0: lane 0 runs the reference's heaps, all lanes snapshot / compare heap states -------------------
+    const int wl = tid;
+    GoHeap<true> mx(hv, hw);
+    int hn = 0;  // heap size, tracked by every lane
+    bool undecided = s_misc[0] != 0;
+    const float kInf = __builtin_inff();
+    auto apply_T = [&]() {  // a push that goes to the root and is popped at once
+        if (wl == 0) {
+            mx.n = hn;
+            mx.push(-1, kInf);
+            mx.pop();
+        }
+        wave_lds_sync();
+    };
+    auto take_snapshot = [&]() {
+        for (int e = wl; e < hn; e += 64) snap[e] = hv[e];
+        wave_lds_sync();
+    };
+    auto same_as_snapshot = [&]() -> bool {
+        bool diff = false;
+        for (int e = wl; e < hn; e += 64) diff |= snap[e] != hv[e];
+        return __builtin_amdgcn_ballot_w64(diff) == 0;
+    };
+    auto t_pow = [&](int64_t gap) {
+        int64_t steps = 0;
+        while (steps < gap && steps < 16) {  // fixpoint (the usual case: no equal distances on the path) or pre-period
+            take_snapshot();
+            apply_T();
+            steps++;
+            if (same_as_snapshot()) return;
+        }
+        if (steps == gap) return;
+        take_snapshot();  // inside the cycle now (or not: then the period search below fails and the query is flagged)
+        int64_t period = 0;
+        bool closed = false;
+        while (period < 64) {
+            apply_T();
+            period++;
+            steps++;
+            if (steps == gap) return;
+            if (same_as_snapshot()) {
+                closed = true;
+                break;
+            }
+        }
+        if (!closed) {
+            undecided = true;
+            return;
+        }
+        const int64_t rem = (gap - steps) % period;
+        for (int64_t r = 0; r < rem; r++) apply_T();
+    };
+    int64_t prev = -1;
+    wave_lds_sync();
+    for (int e = 0; e < n && !undecided; e++) {
+        const int64_t i = s_idx[e];
+        const float dd = s_dst[e];
+        if (i == self) continue;
+        if (i == prev) {  // cannot happen: every recorded vector lives in exactly one place
+            undecided = true;
+            break;
+        }
+        int64_t gap = i - prev - 1;
+        if (self > prev && self < i) gap--;
+        if (gap > 0) {
+            if (hn < k) {  // unrecorded vectors before the heap is full would have been accepted
+                undecided = true;
+                break;
+            }
+            t_pow(gap);
+            if (undecided) break;
+        }
+        if (wl == 0) {
+            mx.n = hn;
+            mx.push((int32_t)i, dd);
+            if (mx.n > k) mx.pop();
+        }
+        wave_lds_sync();
+        hn = hn < k ? hn + 1 : k;
+        prev = i;
+    }
+    if (!undecided) {
+        int64_t gap = p.N - 1 - prev;
+        if (self > prev) gap--;
+        if (gap > 0) {
+            if (hn < k)
+                undecided = true;
+            else
+                t_pow(gap);
+        }
+    }
+    if (wl != 0) return;
+    if (undecided) {
+        p.cflag[t] = 2;
+        return;
+    }
+    GoHeap<false> mn(hv + (k + 2), hw + (k + 2));  // Reverse(): re-push in array order (pq.go:121-128)
+    for (int e = 0; e < hn; e++) mn.push(hv[e], hw[e]);
+    int cnt = 0;
+    while (mn.n > 0) {
+        mn.pop();
+        const int32_t v = mn.v[mn.n];
+        const float w = mn.w[mn.n];
+        if (!p.prune0 || w > 0) {
+            p.out_idx[row * k + cnt] = v;
+            p.out_dist[row * k + cnt] = w;
+            cnt++;
+        }
+    }
+    p.out_cnt[row] = cnt;
+    for (int e = cnt; e < k; e++) {
+        p.out_idx[row * k + e] = -1;
+        p.out_dist[row * k + e] = kInf;
+    }
+}
+
+// rows pos[t] of a bf16 operand matrix / a float vector -> compact arrays of the flagged queries
+__global__ void gather_pos_kernel(const uint16_t *__restrict__ op, const float *__restrict__ margin,
+                                  const int32_t *__restrict__ pos, int kpad, uint16_t *__restrict__ op_out,
+                                  float *__restrict__ margin_out) {
+    const int64_t t = blockIdx.x;
+    const int64_t src = pos[t];
+    const uint4 *s = reinterpret_cast<const uint4 *>(op + src * kpad);
+    uint4 *o = reinterpret_cast<uint4 *>(op_out + t * kpad);
+    for (int e = threadIdx.x; e < kpad / 8; e += blockDim.x) o[e] = s[e];
+    if (threadIdx.x == 0) margin_out[t] = margin[src];
+}
+
 // ---- operand construction ------------------------------------------------------------------------------
 __device__ __forceinline__ uint16_t bf16_rne(float x) {
     uint32_t b = __float_as_uint(x);
@@ -458,36 +719,36 @@ __global__ void margin_kernel(const float *__restrict__ qn2, int64_t nq, float c
 
 const int kSupportedKP[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
 
-template <int KP, int NCB>
-int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale) {
+template <int KP, int NCB, bool SCALE, bool HIST>
+int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int BQ = 32 * NCB * kWaves;
     constexpr int ROWB = KP * 32 + 16;
-    const size_t lds = (size_t)2 * kTR * ROWB + 2 * kTR * 4 + (size_t)3 * BQ * 4;
+    const size_t lds = (size_t)2 * kTR * ROWB + 2 * kTR * 4 + (size_t)4 * BQ * 4;
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
-    if (scale) {
-        GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        topk_sweep_kernel<KP, NCB, true><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
-    } else {
-        GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        topk_sweep_kernel<KP, NCB, false><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
-    }
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    topk_sweep_kernel<KP, NCB, SCALE, HIST><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 
-int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool scale) {
+template <int KP, int NCB>
+int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
+    if (scale) return hist ? launch_sweep_one<KP, NCB, true, true>(h, p) : launch_sweep_one<KP, NCB, true, false>(h, p);
+    return hist ? launch_sweep_one<KP, NCB, false, true>(h, p) : launch_sweep_one<KP, NCB, false, false>(h, p);
+}
+
+int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
     switch (h->kp) {
-        case 1: return launch_sweep<1, 2>(h, p, scale);
-        case 2: return launch_sweep<2, 2>(h, p, scale);
-        case 3: return launch_sweep<3, 2>(h, p, scale);
-        case 4: return launch_sweep<4, 2>(h, p, scale);
-        case 6: return launch_sweep<6, 2>(h, p, scale);
-        case 8: return launch_sweep<8, 2>(h, p, scale);
-        case 12: return scale ? launch_sweep<12, 1>(h, p, scale) : launch_sweep<12, 2>(h, p, scale);
-        case 16: return launch_sweep<16, 1>(h, p, scale);
-        case 24: return launch_sweep<24, 1>(h, p, scale);
+        case 1: return launch_sweep<1, 2>(h, p, scale, hist);
+        case 2: return launch_sweep<2, 2>(h, p, scale, hist);
+        case 3: return launch_sweep<3, 2>(h, p, scale, hist);
+        case 4: return launch_sweep<4, 2>(h, p, scale, hist);
+        case 6: return launch_sweep<6, 2>(h, p, scale, hist);
+        case 8: return launch_sweep<8, 2>(h, p, scale, hist);
+        case 12: return scale ? launch_sweep<12, 1>(h, p, scale, hist) : launch_sweep<12, 2>(h, p, scale, hist);
+        case 16: return launch_sweep<16, 1>(h, p, scale, hist);
+        case 24: return launch_sweep<24, 1>(h, p, scale, hist);
     }
     return fail(GORSE_ERR_INVALID, "unsupported operand depth %d", h->kp);
 }
@@ -499,7 +760,7 @@ namespace gorse {
 bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k) {
     if (!h->mfma_ok || g_topk_force_path == 1) return false;
     if (k + 1 > kMaxKth) return false;
-    return g_topk_force_path == 2 || nq >= 64;
+    return g_topk_force_path >= 2 || nq >= 64;
 }
 
 int32_t topk_mfma_prepare(gorse_topk *h) {
@@ -587,6 +848,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     }
     if (qid_host) GORSE_TRY(h->qid.ensure((size_t)mb));
     h->n_fallback = 0;
+    h->n_tie = 0;
     std::vector<uint8_t> flags((size_t)mb);
     for (int64_t c0 = 0; c0 < nq; c0 += kChunkQ) {
         const int64_t m = std::min(kChunkQ, nq - c0);
@@ -626,11 +888,13 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.cbuf = h->cbuf.p;
         sp.ccnt = h->ccnt.p;
         sp.cflag = h->cflag.p;
+        sp.hbuf = nullptr;
+        sp.hcnt = nullptr;
         sp.N = h->N;
         sp.nq = m;
         sp.kth = kth;
         int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
-        GORSE_TRY(dispatch_sweep(h, sp, scale));
+        GORSE_TRY(dispatch_sweep(h, sp, scale, false));
         h->prof.end(tok, h->stream);
         RescoreParams rp;
         rp.X = h->X.p;
@@ -655,53 +919,139 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         topk_rescore_kernel<<<dim3((unsigned)m), dim3(kBlock), lds, h->stream>>>(rp);
         GORSE_HIP_CHECK(hipGetLastError());
         h->prof.end(tok, h->stream);
+        GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        std::vector<int64_t> fb;  // queries the sweep + rescoring could not decide (ties in the top k+1, NaN, overflow)
+        for (int64_t t = 0; t < m; t++)
+            if (flags[t]) fb.push_back(t);
+        auto stored_id = [&](int64_t t) -> int64_t {
+            return by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
+        };
+        // stage 2: history sweep + literal heap replay (topk_replay_kernel) for the flagged queries
+        std::vector<int64_t> rest;
+        if (!fb.empty() && g_topk_force_path != 3) {
+            std::vector<int32_t> pos;
+            std::vector<int64_t> selfs;
+            std::vector<uint8_t> f2;
+            for (size_t f0 = 0; f0 < fb.size(); f0 += (size_t)kReplayChunk) {
+                const int64_t m2 = std::min<int64_t>(kReplayChunk, (int64_t)(fb.size() - f0));
+                pos.resize((size_t)m2);
+                selfs.resize((size_t)m2);
+                for (int64_t r = 0; r < m2; r++) {
+                    pos[r] = (int32_t)fb[f0 + r];
+                    selfs[r] = stored_id(fb[f0 + r]);
+                }
+                GORSE_TRY(h->rp_pos.ensure((size_t)m2));
+                GORSE_TRY(h->rp_self.ensure((size_t)m2));
+                GORSE_TRY(h->rp_op.ensure((size_t)m2 * kpad));
+                GORSE_TRY(h->rp_margin.ensure((size_t)m2));
+                GORSE_TRY(h->rp_cbuf.ensure((size_t)m2 * kCap));
+                GORSE_TRY(h->rp_hbuf.ensure((size_t)m2 * kHistCap));
+                GORSE_TRY(h->rp_ccnt.ensure((size_t)m2));
+                GORSE_TRY(h->rp_hcnt.ensure((size_t)m2));
+                GORSE_TRY(h->rp_flag.ensure((size_t)m2));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_pos.p, pos.data(), (size_t)m2 * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_self.p, selfs.data(), (size_t)m2 * 8, hipMemcpyHostToDevice, h->stream));
+                gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, h->rp_pos.p, kpad,
+                                                                                 h->rp_op.p, h->rp_margin.p);
+                GORSE_HIP_CHECK(hipGetLastError());
+                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, (size_t)m2, h->stream));
+                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_hcnt.p, 0, (size_t)m2 * 4, h->stream));
+                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, (size_t)m2 * 4, h->stream));
+                SweepParams hp = sp;
+                hp.B = h->rp_op.p;
+                hp.qmargin = h->rp_margin.p;
+                hp.cbuf = h->rp_cbuf.p;
+                hp.ccnt = h->rp_ccnt.p;
+                hp.cflag = h->rp_flag.p;
+                hp.hbuf = h->rp_hbuf.p;
+                hp.hcnt = h->rp_hcnt.p;
+                hp.nq = m2;
+                tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
+                GORSE_TRY(dispatch_sweep(h, hp, scale, true));
+                h->prof.end(tok, h->stream);
+                ReplayParams pp;
+                pp.X = h->X.p;
+                pp.norm2 = h->norm2.p;
+                pp.Qf = Qf;
+                pp.qn2 = qn2;
+                pp.self = h->rp_self.p;
+                pp.pos = h->rp_pos.p;
+                pp.cbuf = h->rp_cbuf.p;
+                pp.ccnt = h->rp_ccnt.p;
+                pp.hbuf = h->rp_hbuf.p;
+                pp.hcnt = h->rp_hcnt.p;
+                pp.cflag = h->rp_flag.p;
+                pp.N = h->N;
+                pp.d = d;
+                pp.metric = h->metric;
+                pp.k = k;
+                pp.prune0 = prune0;
+                pp.out_idx = h->res_idx.p;
+                pp.out_dist = h->res_dist.p;
+                pp.out_cnt = h->res_cnt.p;
+                const size_t rlds = ((size_t)2 * kReplayCap + (size_t)(1 + kGroupsPerBlock) * d + 5 * (size_t)(k + 2) + 4) * 4;
+                GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_replay_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+                tok = h->prof.begin(GORSE_PROF_TOPK_SELECT, h->stream);
+                topk_replay_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
+                GORSE_HIP_CHECK(hipGetLastError());
+                h->prof.end(tok, h->stream);
+                f2.resize((size_t)m2);
+                GORSE_HIP_CHECK(hipMemcpyAsync(f2.data(), h->rp_flag.p, (size_t)m2, hipMemcpyDeviceToHost, h->stream));
+                GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+                for (int64_t r = 0; r < m2; r++) {
+                    if (f2[r])
+                        rest.push_back(fb[f0 + r]);
+                    else
+                        h->n_tie++;
+                }
+            }
+        } else {
+            rest = fb;
+        }
+        // stage 3: whatever is left replays the reference literally over all N vectors (path A); its rows go into
+        // the chunk's device result arrays like everybody else's
+        if (!rest.empty()) {
+            h->n_fallback += (int64_t)rest.size();
+            const int64_t bq = topk_scan_block_queries(h);
+            std::vector<int64_t> ids((size_t)std::min<int64_t>(bq, (int64_t)rest.size()));
+            std::vector<int32_t> ti((size_t)ids.size() * k), tc(ids.size());
+            std::vector<float> td((size_t)ids.size() * k);
+            GORSE_TRY(h->qbuf.ensure(ids.size() * (size_t)d));
+            GORSE_TRY(h->qnorm.ensure(ids.size()));
+            GORSE_TRY(h->qidx.ensure(ids.size()));
+            for (size_t f0 = 0; f0 < rest.size(); f0 += (size_t)bq) {
+                const int64_t fm = std::min<int64_t>(bq, (int64_t)(rest.size() - f0));
+                for (int64_t r = 0; r < fm; r++) {
+                    const int64_t t = rest[f0 + r];
+                    ids[r] = stored_id(t);
+                    const float *src = by_vector ? Qf + t * d : h->X.p + ids[r] * d;
+                    GORSE_HIP_CHECK(hipMemcpyAsync(h->qbuf.p + r * d, src, (size_t)d * 4, hipMemcpyDeviceToDevice, h->stream));
+                    GORSE_HIP_CHECK(hipMemcpyAsync(h->qnorm.p + r, qn2 + t, 4, hipMemcpyDeviceToDevice, h->stream));
+                }
+                const int64_t *excl = nullptr;
+                if (!by_vector) {
+                    GORSE_HIP_CHECK(hipMemcpyAsync(h->qidx.p, ids.data(), (size_t)fm * 8, hipMemcpyHostToDevice, h->stream));
+                    excl = h->qidx.p;
+                }
+                GORSE_TRY(topk_scan_block(h, fm, excl, k, prune0, ti.data(), td.data(), tc.data()));
+                for (int64_t r = 0; r < fm; r++) {
+                    const int64_t t = rest[f0 + r];
+                    GORSE_HIP_CHECK(hipMemcpyAsync(h->res_idx.p + t * k, ti.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
+                    GORSE_HIP_CHECK(hipMemcpyAsync(h->res_dist.p + t * k, td.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
+                    GORSE_HIP_CHECK(hipMemcpyAsync(h->res_cnt.p + t, tc.data() + r, 4, hipMemcpyHostToDevice, h->stream));
+                }
+                GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+            }
+        }
         if (idx_out)
             GORSE_HIP_CHECK(hipMemcpyAsync(idx_out + c0 * k, h->res_idx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
         if (dist_out)
             GORSE_HIP_CHECK(hipMemcpyAsync(dist_out + c0 * k, h->res_dist.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
         if (cnt_out)
             GORSE_HIP_CHECK(hipMemcpyAsync(cnt_out + c0, h->res_cnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
-        GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-        // queries the MFMA path could not decide: replay the reference literally (path A)
-        std::vector<int64_t> fb;
-        for (int64_t t = 0; t < m; t++)
-            if (flags[t]) fb.push_back(t);
-        if (fb.empty()) continue;
-        h->n_fallback += (int64_t)fb.size();
-        const int64_t bq = topk_scan_block_queries(h);
-        std::vector<int64_t> ids((size_t)std::min<int64_t>(bq, (int64_t)fb.size()));
-        std::vector<int32_t> ti((size_t)ids.size() * k), tc(ids.size());
-        std::vector<float> td((size_t)ids.size() * k);
-        GORSE_TRY(h->qbuf.ensure(ids.size() * (size_t)d));
-        GORSE_TRY(h->qnorm.ensure(ids.size()));
-        GORSE_TRY(h->qidx.ensure(ids.size()));
-        for (size_t f0 = 0; f0 < fb.size(); f0 += (size_t)bq) {
-            const int64_t fm = std::min<int64_t>(bq, (int64_t)(fb.size() - f0));
-            for (int64_t r = 0; r < fm; r++) {
-                const int64_t t = fb[f0 + r];
-                const float *src = by_vector ? Qf + t * d : h->X.p + (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t) * d;
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->qbuf.p + r * d, src, (size_t)d * 4, hipMemcpyDeviceToDevice, h->stream));
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->qnorm.p + r, qn2 + t, 4, hipMemcpyDeviceToDevice, h->stream));
-                ids[r] = by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
-            }
-            const int64_t *excl = nullptr;
-            if (!by_vector) {
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->qidx.p, ids.data(), (size_t)fm * 8, hipMemcpyHostToDevice, h->stream));
-                excl = h->qidx.p;
-            }
-            GORSE_TRY(topk_scan_block(h, fm, excl, k, prune0, ti.data(), td.data(), tc.data()));
-            for (int64_t r = 0; r < fm; r++) {
-                const int64_t t = fb[f0 + r];
-                if (idx_out) std::copy(ti.begin() + r * k, ti.begin() + (r + 1) * k, idx_out + (c0 + t) * k);
-                if (dist_out) std::copy(td.begin() + r * k, td.begin() + (r + 1) * k, dist_out + (c0 + t) * k);
-                if (cnt_out) cnt_out[c0 + t] = tc[r];
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_idx.p + t * k, ti.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_dist.p + t * k, td.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_cnt.p + t, tc.data() + r, 4, hipMemcpyHostToDevice, h->stream));
-            }
-            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-        }
     }
     return GORSE_OK;
 }

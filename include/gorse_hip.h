@@ -199,6 +199,14 @@ void gorse_hip_test_set_variant(int32_t variant);
  * literal scan (path A), 2 = the MFMA sweep whenever its operands exist.  Both paths return identical results;
  * the hook exists so the parity tests can drive each one. */
 void gorse_hip_test_set_topk_path(int32_t path);
+/* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
+ * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
+ * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */
+void gorse_hip_test_set_als_path(int32_t path);
+/* thresholds of the Gram-form row plan, for handles created AFTERWARDS: rows longer than long_row feedbacks
+ * are cut into chunks of `chunk` entries (defaults 4096 / 4096; <= 0 restores a default).  Lets small test
+ * inputs exercise the long-row path. */
+void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk);
 /* the counting sort by positive item that precedes the item-run update kernel, on a host-supplied
  * chunk (n <= one chunk = 4M samples): su/si/sj receive the triplets in the order the kernel walks them
  * (per window of 32768 consecutive samples: ascending i, skipped samples last). */

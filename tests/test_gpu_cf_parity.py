@@ -327,9 +327,21 @@ def test_bpr_racy_schedule_is_diagnostic_only(oracle):
     assert got <= ref + 0.01
 
 
-@pytest.mark.parametrize("d", [16, 64, 24])
-def test_als_epoch_parity(oracle, small, d):
+@pytest.fixture
+def als_paths():
+    """restores the automatic ALS row-solve choice and the default row plan after a test"""
+    yield
+    capi.lib().gorse_hip_test_set_als_path(0)
+    capi.lib().gorse_hip_test_set_als_plan(0, 0)
+
+
+# path 1 = the reference's residual recurrence (als_sweep_kernel), path 2 = the Gram form on the fp32 MFMA
+# (als_row_kernel / als_chunk_kernel + als_long_solve_kernel); 0 = what the product picks
+@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("d", [16, 64, 24, 40, 7])
+def test_als_epoch_parity(oracle, small, d, path, als_paths):
     # ALS is deterministic w.r.t. Jobs (SURVEY.md A3): <= 1e-4 relative after 3 epochs
+    capi.lib().gorse_hip_test_set_als_path(path)
     mf, P, Q = make_mf(small, d, std=0.1)
     eP, eQ = P, Q
     for _ in range(3):
@@ -341,6 +353,60 @@ def test_als_epoch_parity(oracle, small, d):
     assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
+def test_als_gram_form_rejects_wide_factors(small, als_paths):
+    capi.lib().gorse_hip_test_set_als_path(2)
+    mf, _, _ = make_mf(small, 96, std=0.1)
+    with pytest.raises(capi.GorseHipError) as e:
+        mf.als_epoch(0.05, 0.015)
+    assert e.value.code == capi.ERR_INVALID
+    capi.lib().gorse_hip_test_set_als_path(0)
+    mf.als_epoch(0.05, 0.015)  # automatic choice: residual sweep for nFactors > 64
+
+
+@pytest.mark.parametrize("long_row,chunk", [(16, 16), (40, 13), (0, 0)])
+@pytest.mark.parametrize("d", [16, 64, 33])
+def test_als_long_rows_chunked(oracle, d, long_row, chunk, als_paths):
+    # long-row path of the Gram form: partial Gram matrices per chunk, reduced in chunk order.  Small plan
+    # thresholds push most rows of a small input through it; (0, 0) = the default plan on heavy rows
+    capi.lib().gorse_hip_test_set_als_path(2)
+    capi.lib().gorse_hip_test_set_als_plan(long_row, chunk)
+    data = synth.synth_cf(60, 5000, 50000, seed=11, min_len=3, max_frac=0.9, n_neg=10)
+    mf, P, Q = make_mf(data, d, std=0.1)
+    eP, eQ = P, Q
+    for _ in range(2):
+        eP, eQ = oracle.als_epoch(eP, eQ, data.uptr, data.uidx, data.iptr, data.iidx, 0.05, 0.015)
+        mf.als_epoch(0.05, 0.015)
+    gP, gQ = mf.get_factors()
+    scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
+
+
+def test_als_rows_without_feedback(oracle, als_paths):
+    # users / items with no feedback still get p_f = -b / (w S_ff + reg) (model.go:672-684 with empty sums)
+    rng = np.random.default_rng(3)
+    U, I, d = 50, 40, 16
+    rows = [np.sort(rng.choice(I - 5, rng.integers(0, 6), replace=False)).astype(np.int32) if u % 3 else
+            np.zeros(0, np.int32) for u in range(U)]
+    uptr = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
+    uidx = np.concatenate(rows).astype(np.int32)
+    cols = [[] for _ in range(I)]
+    for u, r in enumerate(rows):
+        for i in r:
+            cols[i].append(u)
+    iptr = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int64)
+    iidx = np.array([u for c in cols for u in c], np.int32)
+    P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 5)
+    for path in (1, 2):
+        capi.lib().gorse_hip_test_set_als_path(path)
+        mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx)
+        mf.set_factors(P, Q)
+        eP, eQ = oracle.als_epoch(P, Q, uptr, uidx, iptr, iidx, 0.05, 0.015)
+        mf.als_epoch(0.05, 0.015)
+        gP, gQ = mf.get_factors()
+        scale = max(np.abs(eP).max(), np.abs(eQ).max())
+        assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
+
+
 def test_als_needs_item_csr(small):
     mf, _, _ = make_mf(small, 16, with_items=False)
     with pytest.raises(capi.GorseHipError) as e:
@@ -348,8 +414,11 @@ def test_als_needs_item_csr(small):
     assert e.value.code == capi.ERR_INVALID
 
 
-def test_als_heavy_rows(oracle):
-    # rows longer than the LDS staging caps (global-scratch path)
+@pytest.mark.parametrize("path", [1, 2])
+def test_als_heavy_rows(oracle, path, als_paths):
+    # rows longer than the LDS staging caps (global-scratch path of the residual sweep; multi-batch
+    # accumulation of the Gram form)
+    capi.lib().gorse_hip_test_set_als_path(path)
     data = synth.synth_cf(40, 6000, 60000, seed=9, min_len=3, max_frac=0.9, n_neg=10)
     d = 16
     mf, P, Q = make_mf(data, d, std=0.1)

@@ -68,9 +68,12 @@ def test_all_pairs_matches_oracle(oracle, metric, dtype, d, k):
     assert np.array_equal(ia, idx[:600]) and np.array_equal(bits(da), bits(dist[:600]))
 
 
-def test_ties_go_to_the_scan(oracle):
+@pytest.mark.parametrize("path", [2, 3])
+def test_ties_inside_the_top_k(oracle, path):
     # small-integer vectors: most queries have equal distances inside their top k+1, where the reference's answer
-    # is decided by container/heap mechanics -> path B must flag them and the literal replay must decide
+    # is decided by container/heap mechanics.  path 2: the history sweep + literal heap replay (topk_replay_kernel)
+    # decides them; path 3: the replay is switched off and the literal scan over all N vectors (path A) must
+    capi.lib().gorse_hip_test_set_topk_path(path)
     rng = np.random.default_rng(4)
     N, d, k = 900, 8, 15
     X = rng.integers(-2, 3, (N, d)).astype(np.float32)
@@ -87,7 +90,34 @@ def test_ties_go_to_the_scan(oracle):
                 assert cnt[r] == ei.size, (metric, prune0, q)
                 assert np.array_equal(idx[r, :cnt[r]], ei), (metric, prune0, q)
                 assert np.array_equal(bits(dist[r, :cnt[r]]), bits(ed))
-        assert t.last_stats()[0] > 0
+        n_scan, n_replay = t.last_stats()
+        if path == 2:
+            assert n_replay > 0 and n_scan <= 20, (n_scan, n_replay)
+        else:
+            assert n_scan > 0 and n_replay == 0
+
+
+@pytest.mark.parametrize("N,d,k,lo,hi", [(6000, 8, 15, -3, 4), (20000, 6, 40, -4, 5), (3000, 4, 100, -2, 3)])
+def test_tie_replay_long_history(oracle, N, d, k, lo, hi):
+    # many compactions (N >> list capacity) and plenty of equal distances: the replay has to bridge long gaps of
+    # unrecorded vectors with T^gap while equal weights sit in the heap (cycle detection), for every query
+    rng = np.random.default_rng(N + k)
+    X = rng.integers(lo, hi, (N, d)).astype(np.float32)
+    t = capi.TopK(X, capi.METRIC_NEG_DOT)
+    qs = rng.choice(N, 300, replace=False)
+    idx, dist, cnt = t.search_index(qs, k)
+    n_scan, n_replay = t.last_stats()
+    for r, q in enumerate(qs):
+        ei, ed = oracle.search_index(X, capi.METRIC_NEG_DOT, int(q), k)
+        assert cnt[r] == ei.size and np.array_equal(idx[r, :cnt[r]], ei), (q, n_scan, n_replay)
+        assert np.array_equal(bits(dist[r, :cnt[r]]), bits(ed))
+    assert n_replay > 0
+    # search by vector: no self exclusion, same machinery
+    qv = X[qs[:60]] + 0.0
+    i2, d2, c2 = t.search_vector(qv, k)
+    for r in range(60):
+        ei, ed = oracle.search_vector(X, capi.METRIC_NEG_DOT, qv[r], k)
+        assert c2[r] == ei.size and np.array_equal(i2[r, :c2[r]], ei) and np.array_equal(bits(d2[r, :c2[r]]), bits(ed))
 
 
 def test_duplicates_and_overflowing_lists(oracle):

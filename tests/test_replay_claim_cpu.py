@@ -1,0 +1,168 @@
+"""The claim behind topk_replay_kernel (gorse_amd/csrc/topk_mfma.hip), checked on the CPU with Go's container/heap
+rules restated in pure Python (same rules as gorse_amd/csrc/goheap.hpp / common/heap/pq.go):
+
+  Bruteforce's queue (bruteforce.go:46-53: Push, then Pop once it holds more than k) ends in the same heap ARRAY
+  when only a superset of the accepted vectors is pushed literally and every run of `gap` strictly-rejected vectors in
+  between is replaced by T^gap, T = "push +inf, pop" -- T being evaluated by cycle detection, because with equal
+  weights in the heap it is a permutation with a short period rather than the identity.
+"""
+import heapq
+
+import numpy as np
+
+INF = float("inf")
+
+
+class GoMaxHeap:  # heap.NewPriorityQueue(true): less(i, j) = w[i] > w[j]
+    def __init__(self):
+        self.v, self.w = [], []
+
+    def less(self, i, j):
+        return self.w[i] > self.w[j]
+
+    def swap(self, i, j):
+        self.v[i], self.v[j] = self.v[j], self.v[i]
+        self.w[i], self.w[j] = self.w[j], self.w[i]
+
+    def up(self, j):
+        while True:
+            i = (j - 1) // 2
+            if j == 0 or i == j or not self.less(j, i):
+                break
+            self.swap(i, j)
+            j = i
+
+    def down(self, i, n):
+        while True:
+            j1 = 2 * i + 1
+            if j1 >= n:
+                break
+            j = j1
+            if j1 + 1 < n and self.less(j1 + 1, j1):
+                j = j1 + 1
+            if not self.less(j, i):
+                break
+            self.swap(i, j)
+            i = j
+
+    def push(self, v, w):
+        self.v.append(v)
+        self.w.append(w)
+        self.up(len(self.v) - 1)
+
+    def pop(self):
+        n = len(self.v) - 1
+        self.swap(0, n)
+        self.down(0, n)
+        self.v.pop()
+        self.w.pop()
+
+
+def literal(dist, k):
+    h = GoMaxHeap()
+    for i, x in enumerate(dist):
+        h.push(i, x)
+        if len(h.v) > k:
+            h.pop()
+    return list(h.v)
+
+
+def t_pow(h, gap):
+    """exactly the control flow of t_pow in topk_replay_kernel"""
+    def apply():
+        h.push(-1, INF)
+        h.pop()
+    steps = 0
+    while steps < gap and steps < 16:
+        snap = list(h.v)
+        apply()
+        steps += 1
+        if h.v == snap:
+            return True
+    if steps == gap:
+        return True
+    snap = list(h.v)
+    period, closed = 0, False
+    while period < 64:
+        apply()
+        period += 1
+        steps += 1
+        if steps == gap:
+            return True
+        if h.v == snap:
+            closed = True
+            break
+    if not closed:
+        return False
+    for _ in range((gap - steps) % period):
+        apply()
+    return True
+
+
+def replay(dist, k, recorded):
+    h = GoMaxHeap()
+    prev = -1
+    for i in list(recorded) + [len(dist)]:
+        gap = i - prev - 1
+        if gap > 0:
+            assert len(h.v) == k
+            if not t_pow(h, gap):
+                return None
+        if i < len(dist):
+            h.push(i, dist[i])
+            if len(h.v) > k:
+                h.pop()
+        prev = i
+    return list(h.v)
+
+
+def test_replay_with_gaps_equals_the_literal_heap():
+    rng = np.random.default_rng(1)
+    undecided = 0
+    for trial in range(250):
+        n = int(rng.integers(50, 3000))
+        k = int(rng.integers(1, 60))
+        levels = int(rng.integers(2, 80))  # few distinct weights: ties everywhere
+        dist = [float(x) for x in rng.integers(0, levels, n)]
+        # superset of the accepted pushes: d_i <= running k-th smallest, plus a few strictly rejected ones
+        rec, best = [], []
+        for i, x in enumerate(dist):
+            if len(best) < k or x <= -best[0]:
+                rec.append(i)
+            elif rng.random() < 0.03:
+                rec.append(i)
+            if len(best) < k:
+                heapq.heappush(best, -x)
+            elif x < -best[0]:
+                heapq.heapreplace(best, -x)
+        got = replay(dist, k, rec)
+        if got is None:
+            undecided += 1
+            continue
+        assert got == literal(dist, k), (trial, n, k, levels)
+    assert undecided <= 2  # the kernel hands such queries to the literal scan
+
+
+def test_t_is_a_short_cycle():
+    # pre-period and period of T stay far below the bounds the kernel searches (16 and 64)
+    rng = np.random.default_rng(5)
+    worst_pre = worst_per = 0
+    for trial in range(400):
+        k = int(rng.integers(1, 200))
+        levels = int(rng.integers(1, 12))
+        h = GoMaxHeap()
+        for i in range(k + int(rng.integers(0, 200))):
+            h.push(i, float(rng.integers(0, levels)))
+            if len(h.v) > k:
+                h.pop()
+        if len(h.v) < k:
+            continue
+        seen, t = {}, 0
+        while tuple(h.v) not in seen:
+            seen[tuple(h.v)] = t
+            h.push(-1, INF)
+            h.pop()
+            t += 1
+        worst_pre = max(worst_pre, seen[tuple(h.v)])
+        worst_per = max(worst_per, t - seen[tuple(h.v)])
+    assert worst_pre <= 12 and worst_per <= 32, (worst_pre, worst_per)
