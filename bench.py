@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-topk", action="store_true", help="skip the item x item top-k leg of the default run")
     ap.add_argument("--topk-n", type=int, default=1_000_000)
     ap.add_argument("--topk-steps", type=int, default=2)
+    ap.add_argument("--topk-budget", type=float, default=60.0, help="seconds the timed top-k steps may take (see bench_topk)")
     ap.add_argument("--mode", type=int, default=capi.BPR_HOGWILD_ATOMIC)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -155,6 +156,18 @@ def bench_topk(args, world, rank, local, fence):
     q0, q1 = rank * N // world, (rank + 1) * N // world
     t.all_pairs(k, q0, min(q1, q0 + 8192), fetch=False)  # warm-up: allocations, code objects
     fence()
+    # keep the default run bounded: if a 16K-query pass predicts more than --topk-budget seconds for the timed
+    # steps, time a prefix of the query rows instead (all N stored vectors are still scanned per query; the
+    # pairs/s figure is over the rows actually processed and config.queries_per_step_per_gpu says how many)
+    probe_q = min(q1 - q0, 16384)
+    t0 = time.perf_counter()
+    t.all_pairs(k, q0, q0 + probe_q, fetch=False)
+    fence()
+    per_query = (time.perf_counter() - t0) / probe_q
+    full = q1 - q0
+    if per_query * full * args.topk_steps > args.topk_budget:
+        q1 = q0 + max(probe_q, int(args.topk_budget / args.topk_steps / per_query) // 8192 * 8192)
+        q1 = min(q1, q0 + full)
     t.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.topk_steps):
@@ -168,7 +181,7 @@ def bench_topk(args, world, rank, local, fence):
     launches, sweep_ms = t.get_profile(capi.PROF_TOPK_SWEEP)
     r_launches, resc_ms = t.get_profile(capi.PROF_TOPK_SELECT)
     t.set_profiling(False)
-    n_fb = t.last_stats()[0]
+    n_fb, n_tie = t.last_stats()
     if rank != 0:
         return None
     pairs_step = (q1 - q0) * (N - 1)
@@ -181,7 +194,8 @@ def bench_topk(args, world, rank, local, fence):
         "n_gpus": world, "steps": args.topk_steps, "ms_per_step": dt / args.topk_steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "S-emb %dx%d bf16, cosine, k=%d (C4), query rows sharded x%d" % (N, d, k, world),
-                   "queries_per_step_per_gpu": q1 - q0, "fallback_queries": n_fb},
+                   "queries_per_step_per_gpu": q1 - q0, "all_query_rows": q1 - q0 == full,
+                   "tie_replayed_queries": n_tie, "scan_fallback_queries": n_fb},
         "roofline": {"bound": "mfma", "kernel": "topk_sweep_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                      "algorithmic_flop_per_pair": 2 * d, "avg_launch_ms": avg_ms, "launches": launches,

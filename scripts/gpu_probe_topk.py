@@ -26,15 +26,19 @@ def run(name, X, metric, dtype, k, q0, q1, reps=2):
     pairs = (q1 - q0) * (N - 1)
     kd = d if dtype == capi.DTYPE_BF16 else 3 * d
     print("%-34s N=%8d d=%4d k=%3d nq=%8d wall %8.2f ms (%.3e pairs/s) sweep %8.2f ms (%.1f TFLOP/s on %d-deep operands) "
-          "rescore %7.2f ms scan-launches %d fallback %d create %.2f s"
-          % (name, N, d, k, q1 - q0, dt * 1e3, pairs / dt, sweep / max(ns, 1), 2.0 * kd * (q1 - q0) * N / (sweep / max(ns, 1) * 1e-3) / 1e12,
-             kd, resc / max(nr, 1), na, t.last_stats()[0], t_create), flush=True)
+          "rescore+replay %7.2f ms (%d launches) scan-launches %d scan-fallback %d tie-replayed %d create %.2f s"
+          % (name, N, d, k, q1 - q0, dt * 1e3, pairs / dt, sweep / reps, 2.0 * kd * (q1 - q0) * N / (sweep / reps * 1e-3) / 1e12,
+             kd, resc / reps, nr, na, t.last_stats()[0], t.last_stats()[1], t_create), flush=True)
     t.close()
 
 
 def main():
     capi.lib().gorse_hip_test_set_topk_path(0)
     Xb, Xe = synth.s_emb(1_000_000, 128, 44)
+    if len(sys.argv) > 1 and sys.argv[1] == "c4":  # one bounded case: a quarter of the query rows, then all of them
+        run("C4 S-emb bf16 cosine 256K q", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
+        run("C4 S-emb bf16 cosine", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
+        return
     run("C4 S-emb bf16 cosine", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000)
     run("C4 S-emb bf16 -dot", Xb, capi.METRIC_NEG_DOT, capi.DTYPE_BF16, 100, 0, 1_000_000)
     run("S-emb bf16 cosine 128K queries", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 131072)
