@@ -44,6 +44,10 @@ SIGNATURES = {
     "gorse_bpr_sample_triplets": (C.c_int32, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
     "gorse_bpr_apply_triplets": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float, C.c_int32]),
     "gorse_als_epoch": (C.c_int32, [_vp, C.c_float, C.c_float, _i32p]),
+    "gorse_als_set_ranges": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "gorse_als_half_epoch": (C.c_int32, [_vp, C.c_int32, C.c_float, C.c_float]),
+    "gorse_mf_rows_export": (C.c_int32, [_vp, C.c_int32, C.c_int64, C.c_int64, _vp]),
+    "gorse_mf_rows_import": (C.c_int32, [_vp, C.c_int32, C.c_int64, C.c_int64, _vp]),
     "gorse_mf_item_sync_mark": (C.c_int32, [_vp]),
     "gorse_mf_item_delta_export": (C.c_int32, [_vp, _vp]),
     "gorse_mf_item_delta_import": (C.c_int32, [_vp, _vp]),
@@ -204,6 +208,18 @@ class MF:
 
     def item_sync_mark(self):
         check(lib().gorse_mf_item_sync_mark(self.h))
+
+    def als_set_ranges(self, u_begin, u_end, i_begin, i_end):
+        check(lib().gorse_als_set_ranges(self.h, u_begin, u_end, i_begin, i_end))
+
+    def als_half_epoch(self, side, weight, reg):
+        check(lib().gorse_als_half_epoch(self.h, side, weight, reg))
+
+    def rows_export(self, side, begin, end, dev_ptr):
+        check(lib().gorse_mf_rows_export(self.h, side, begin, end, _vp(dev_ptr)))
+
+    def rows_import(self, side, begin, end, dev_ptr):
+        check(lib().gorse_mf_rows_import(self.h, side, begin, end, _vp(dev_ptr)))
 
     def item_delta_export(self, dev_ptr):
         check(lib().gorse_mf_item_delta_export(self.h, _vp(dev_ptr)))

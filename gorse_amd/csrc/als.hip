@@ -55,11 +55,12 @@ __global__ __launch_bounds__(256) void als_gram_partial_kernel(const float *__re
     }
 }
 
-__global__ void als_gram_reduce_kernel(const float *__restrict__ partial, int nparts, int dd, float *__restrict__ S) {
+__global__ void als_gram_reduce_kernel(const float *__restrict__ partial, int nparts, int dd, float *__restrict__ S,
+                                       int64_t stride) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= dd) return;
     float s = 0.0f;
-    for (int g = 0; g < nparts; g++) s += partial[(size_t)g * dd + e];  // fixed order: deterministic
+    for (int g = 0; g < nparts; g++) s += partial[(size_t)g * stride + e];  // fixed order: deterministic
     S[e] = s;
 }
 
@@ -106,8 +107,9 @@ __device__ __forceinline__ void block_sum3(float &a, float &b, float &c, float *
 __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                         const int64_t *__restrict__ ptr,
                                                         const int32_t *__restrict__ idx, const float *__restrict__ S,
-                                                        int64_t rows, int d, float w, float reg, int pred_cap,
-                                                        int q_cap, float *__restrict__ scratch, int64_t scratch_stride) {
+                                                        int64_t row_begin, int64_t rows, int d, float w, float reg,
+                                                        int pred_cap, int q_cap, float *__restrict__ scratch,
+                                                        int64_t scratch_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sp = smem;                      // d          current row of A
     float *red = sp + ((d + 3) & ~3);      // 12
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
     const VecShape vs(d);
     const float one_w = 1 - w;
     float *gpred = scratch + (size_t)blockIdx.x * scratch_stride;
-    for (int64_t u = blockIdx.x; u < rows; u += gridDim.x) {
+    for (int64_t u = row_begin + blockIdx.x; u < rows; u += gridDim.x) {  // rows = end of the row range
         const int64_t beg = ptr[u];
         const int n = (int)(ptr[u + 1] - beg);
         const int32_t *fb = idx + beg;
@@ -424,7 +426,7 @@ int32_t run_gram(gorse_mf *h, const float *F, const int64_t *ptr, int64_t rows, 
             F, ptr, rows, d, h->gram_partial.p);
         GORSE_HIP_CHECK(hipGetLastError());
         als_gram_reduce_kernel<<<dim3((unsigned)ceil_div(dd, 256)), dim3(256), 0, h->stream>>>(h->gram_partial.p, nparts,
-                                                                                              dd, h->gram.p);
+                                                                                              dd, h->gram.p, dd);
     } else {
         als_gram_naive_kernel<<<dim3((unsigned)ceil_div(dd, 256)), dim3(256), 0, h->stream>>>(F, ptr, rows, d, h->gram.p);
     }
@@ -433,8 +435,8 @@ int32_t run_gram(gorse_mf *h, const float *F, const int64_t *ptr, int64_t rows, 
     return GORSE_OK;
 }
 
-int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, const int32_t *idx, int64_t rows,
-                  int64_t max_row, float w, float reg) {
+int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, const int32_t *idx, int64_t row_begin,
+                  int64_t row_end, int64_t max_row, float w, float reg) {
     const int d = h->d;
     const size_t fixed = ((size_t)((d + 3) & ~3) + 12 + 2 * (size_t)kGroupsPerBlock * d) * sizeof(float);
     const size_t budget = 64 * 1024;
@@ -443,14 +445,15 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
     if (fixed + (size_t)pred_cap * 4 < budget) q_cap = (int)((budget - fixed - (size_t)pred_cap * 4) / ((size_t)(d + 1) * 4));
     while (fixed + (size_t)pred_cap * 4 + (size_t)q_cap * (d + 1) * 4 > 150 * 1024 && pred_cap > 256) pred_cap /= 2;
     const size_t shmem = fixed + (size_t)pred_cap * 4 + (size_t)q_cap * (d + 1) * 4;
-    int blocks = (int)std::min<int64_t>(rows, 256 * 8);
+    if (row_end <= row_begin) return GORSE_OK;
+    int blocks = (int)std::min<int64_t>(row_end - row_begin, 256 * 8);
     const int64_t stride = max_row > pred_cap ? max_row : 1;
     GORSE_TRY(h->als_scratch.ensure((size_t)blocks * stride));
     GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)shmem));
     int tok = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
-    als_sweep_kernel<<<dim3(blocks), dim3(256), shmem, h->stream>>>(A, B, ptr, idx, h->gram.p, rows, d, w, reg, pred_cap,
-                                                                   q_cap, h->als_scratch.p, stride);
+    als_sweep_kernel<<<dim3(blocks), dim3(256), shmem, h->stream>>>(A, B, ptr, idx, h->gram.p, row_begin, row_end, d, w, reg,
+                                                                   pred_cap, q_cap, h->als_scratch.p, stride);
     GORSE_HIP_CHECK(hipGetLastError());
     h->prof.end(tok, h->stream);
     return GORSE_OK;
@@ -496,33 +499,126 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
     return GORSE_OK;
 }
 
+// S = sum over the rows of F with feedback of x x^T on the fp32 MFMA: the rows-with-feedback list of `side` is the
+// "feedback list", cut into chunks; partial Gram matrices are added in chunk order (deterministic, bitwise symmetric)
+int32_t run_gram_mfma(gorse_mf *h, const float *F, int side) {
+    const int d = h->d, dd = d * d;
+    gorse_mf::AlsPlan &pl = h->als_plan[side];
+    GORSE_TRY(h->gram.ensure((size_t)dd));
+    int tok = h->prof.begin(GORSE_PROF_ALS_GRAM, h->stream);
+    if (pl.n_gchunks == 0) {
+        GORSE_HIP_CHECK(hipMemsetAsync(h->gram.p, 0, (size_t)dd * sizeof(float), h->stream));
+    } else {
+        const int64_t stride = (int64_t)dd + d;
+        GORSE_TRY(h->gram_partial.ensure((size_t)pl.n_gchunks * stride));
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_gchunks, kAlsWaves), 2048);
+        if (d <= 32)
+            als_chunk_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p,
+                                                                                   pl.n_gchunks, d, h->gram_partial.p,
+                                                                                   h->als_zeros.p);
+        else
+            als_chunk_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p,
+                                                                                   pl.n_gchunks, d, h->gram_partial.p,
+                                                                                   h->als_zeros.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        als_gram_reduce_kernel<<<dim3((unsigned)ceil_div(dd, 256)), dim3(256), 0, h->stream>>>(
+            h->gram_partial.p, (int)pl.n_gchunks, dd, h->gram.p, stride);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    h->prof.end(tok, h->stream);
+    return GORSE_OK;
+}
+
 bool use_gram_form(const gorse_mf *h) { return g_als_path == 2 || (g_als_path == 0 && h->d <= 64); }
 
 }  // namespace
 
-extern "C" int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const volatile int32_t *cancel) {
+namespace {
+// one half of model.go:641-738: S over ALL rows (with feedback) of the other side, then the coordinate sweep of this
+// handle's row range of `side` (0: user factors from item factors, 1: item factors from user factors)
+int32_t half_epoch(gorse_mf *h, int side, float weight, float reg) {
+    const bool gram_form = use_gram_form(h);
+    float *A = side == 0 ? h->P.p : h->Q.p;
+    const float *B = side == 0 ? h->Q.p : h->P.p;
+    const int64_t *ptr = side == 0 ? h->uptr.p : h->iptr.p;
+    const int32_t *idx = side == 0 ? h->uidx.p : h->iidx.p;
+    if (gram_form) {
+        GORSE_TRY(run_gram_mfma(h, B, 1 - side));
+        GORSE_TRY(run_side_gram(h, side, A, B, ptr, idx, weight, reg));
+    } else {
+        GORSE_TRY(run_gram(h, B, side == 0 ? h->iptr.p : h->uptr.p, side == 0 ? h->I : h->U, GORSE_PROF_ALS_GRAM));
+        GORSE_TRY(run_sweep(h, A, B, ptr, idx, h->als_lo[side], h->als_hi[side],
+                            side == 0 ? h->max_user_row : h->max_item_row, weight, reg));
+    }
+    return GORSE_OK;
+}
+int32_t als_check(gorse_mf *h) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
     if (!h->has_item_csr) return fail(GORSE_ERR_INVALID, "ALS needs the item feedback CSR (item_indptr/item_indices)");
+    if (g_als_path == 2 && h->d > 64) return fail(GORSE_ERR_INVALID, "the Gram-form ALS kernels cover nFactors <= 64 (got %d)", h->d);
+    return GORSE_OK;
+}
+}  // namespace
+
+extern "C" int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const volatile int32_t *cancel) {
+    GORSE_TRY(als_check(h));
     GORSE_TRY(h->use());
     GORSE_TRY(mf_sync_streams(h));
-    const int64_t max_u = h->max_user_row, max_i = h->max_item_row;
-    if (g_als_path == 2 && h->d > 64) return fail(GORSE_ERR_INVALID, "the Gram-form ALS kernels cover nFactors <= 64 (got %d)", h->d);
-    const bool gram_form = use_gram_form(h);
     if (cancel && *cancel) return fail(GORSE_ERR_CANCELLED, "cancelled");
-    GORSE_TRY(run_gram(h, h->Q.p, h->iptr.p, h->I, GORSE_PROF_ALS_GRAM));                          // model.go:645-658
-    if (gram_form)
-        GORSE_TRY(run_side_gram(h, 0, h->P.p, h->Q.p, h->uptr.p, h->uidx.p, weight, reg));
-    else
-        GORSE_TRY(run_sweep(h, h->P.p, h->Q.p, h->uptr.p, h->uidx.p, h->U, max_u, weight, reg));   // model.go:659-690
+    GORSE_TRY(half_epoch(h, 0, weight, reg));  // model.go:645-690
     if (cancel && *cancel) {
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         return fail(GORSE_ERR_CANCELLED, "cancelled");
     }
-    GORSE_TRY(run_gram(h, h->P.p, h->uptr.p, h->U, GORSE_PROF_ALS_GRAM));                          // model.go:693-706
-    if (gram_form)
-        GORSE_TRY(run_side_gram(h, 1, h->Q.p, h->P.p, h->iptr.p, h->iidx.p, weight, reg));
-    else
-        GORSE_TRY(run_sweep(h, h->Q.p, h->P.p, h->iptr.p, h->iidx.p, h->I, max_i, weight, reg));   // model.go:707-738
+    GORSE_TRY(half_epoch(h, 1, weight, reg));  // model.go:693-738
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_als_half_epoch(gorse_mf *h, int32_t side, float weight, float reg) {
+    GORSE_TRY(als_check(h));
+    if (side != 0 && side != 1) return fail(GORSE_ERR_INVALID, "side must be 0 (users) or 1 (items)");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    GORSE_TRY(half_epoch(h, side, weight, reg));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_als_set_ranges(gorse_mf *h, int64_t u_begin, int64_t u_end, int64_t i_begin, int64_t i_end) {
+    GORSE_TRY(als_check(h));
+    if (u_begin < 0 || u_end > h->U || u_begin > u_end || i_begin < 0 || i_end > h->I || i_begin > i_end)
+        return fail(GORSE_ERR_RANGE, "bad row ranges [%lld,%lld) x [%lld,%lld)", (long long)u_begin, (long long)u_end,
+                    (long long)i_begin, (long long)i_end);
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_sync_streams(h));
+    h->als_lo[0] = u_begin;
+    h->als_hi[0] = u_end;
+    h->als_lo[1] = i_begin;
+    h->als_hi[1] = i_end;
+    GORSE_TRY(als_build_plan(h, 0, h->h_uptr.data(), h->U, u_begin, u_end));
+    GORSE_TRY(als_build_plan(h, 1, h->h_iptr.data(), h->I, i_begin, i_end));
+    return GORSE_OK;
+}
+
+// factor rows [begin, end) of one side <-> a caller-owned device buffer (the blocks an all-gather moves)
+extern "C" int32_t gorse_mf_rows_export(gorse_mf *h, int32_t side, int64_t begin, int64_t end, float *dst) {
+    if (!h || !dst) return fail(GORSE_ERR_INVALID, "NULL argument");
+    const int64_t rows = side == 0 ? h->U : h->I;
+    if ((side != 0 && side != 1) || begin < 0 || end > rows || begin > end) return fail(GORSE_ERR_RANGE, "bad row range");
+    GORSE_TRY(h->use());
+    const float *src = (side == 0 ? h->P.p : h->Q.p) + begin * h->d;
+    GORSE_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)(end - begin) * h->d * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_mf_rows_import(gorse_mf *h, int32_t side, int64_t begin, int64_t end, const float *src) {
+    if (!h || !src) return fail(GORSE_ERR_INVALID, "NULL argument");
+    const int64_t rows = side == 0 ? h->U : h->I;
+    if ((side != 0 && side != 1) || begin < 0 || end > rows || begin > end) return fail(GORSE_ERR_RANGE, "bad row range");
+    GORSE_TRY(h->use());
+    float *dst = (side == 0 ? h->P.p : h->Q.p) + begin * h->d;
+    GORSE_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)(end - begin) * h->d * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     return GORSE_OK;
 }
@@ -536,7 +632,7 @@ extern "C" void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk) {
 
 namespace gorse {
 // rows of one side -> short-row list (longest first) + chunks of the long rows; host CSR pointers only
-int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows) {
+int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, int64_t lo, int64_t hi) {
     gorse_mf::AlsPlan &pl = h->als_plan[side];
     if (h->als_zeros.n < 64) {
         GORSE_TRY(h->als_zeros.alloc(64));
@@ -544,7 +640,7 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows) 
     }
     std::vector<int32_t> shorts, lrows, lfirst, lnch, crow, ccnt;
     std::vector<int64_t> cbeg;
-    for (int64_t r = 0; r < rows; r++) {
+    for (int64_t r = lo; r < hi; r++) {  // the rows this handle solves; the Gram list below covers ALL rows
         const int64_t n = ptr[r + 1] - ptr[r];
         if (n <= g_als_long_row) {
             shorts.push_back((int32_t)r);
@@ -560,6 +656,17 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows) 
         }
         lnch.push_back(nc);
     }
+    std::vector<int32_t> fbr, gcnt;
+    std::vector<int64_t> gbeg;
+    for (int64_t r = 0; r < rows; r++)
+        if (ptr[r + 1] > ptr[r]) fbr.push_back((int32_t)r);
+    constexpr int64_t kGramChunk = 1024;
+    for (int64_t b = 0; b < (int64_t)fbr.size(); b += kGramChunk) {
+        gbeg.push_back(b);
+        gcnt.push_back((int32_t)std::min<int64_t>(kGramChunk, (int64_t)fbr.size() - b));
+    }
+    pl.n_fb_rows = (int64_t)fbr.size();
+    pl.n_gchunks = (int64_t)gbeg.size();
     std::stable_sort(shorts.begin(), shorts.end(),
                      [&](int32_t a, int32_t b) { return ptr[a + 1] - ptr[a] > ptr[b + 1] - ptr[b]; });
     pl.n_short = (int64_t)shorts.size();
@@ -577,6 +684,12 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows) 
     GORSE_TRY(up32(pl.long_nch, lnch));
     GORSE_TRY(up32(pl.chunk_row, crow));
     GORSE_TRY(up32(pl.chunk_cnt, ccnt));
+    GORSE_TRY(up32(pl.fb_rows, fbr));
+    GORSE_TRY(up32(pl.g_cnt, gcnt));
+    GORSE_TRY(pl.g_beg.alloc(gbeg.size()));
+    if (!gbeg.empty())
+        GORSE_HIP_CHECK(hipMemcpyAsync(pl.g_beg.p, gbeg.data(), gbeg.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+                                       h->stream));
     GORSE_TRY(pl.chunk_beg.alloc(cbeg.size()));
     if (!cbeg.empty())
         GORSE_HIP_CHECK(hipMemcpyAsync(pl.chunk_beg.p, cbeg.data(), cbeg.size() * sizeof(int64_t), hipMemcpyHostToDevice,

@@ -235,8 +235,12 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
                                            hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->iidx.p, item_indices, (size_t)innz * sizeof(int32_t), hipMemcpyHostToDevice,
                                            h->stream));
-            GORSE_TRY(als_build_plan(h, 0, user_indptr, U));
-            GORSE_TRY(als_build_plan(h, 1, item_indptr, I));
+            h->h_uptr.assign(user_indptr, user_indptr + U + 1);
+            h->h_iptr.assign(item_indptr, item_indptr + I + 1);
+            h->als_hi[0] = U;
+            h->als_hi[1] = I;
+            GORSE_TRY(als_build_plan(h, 0, user_indptr, U, 0, U));
+            GORSE_TRY(als_build_plan(h, 1, item_indptr, I, 0, I));
         }
         {   // hot items: share of the training feedback >= 1/2048, at most 1024 of them (bpr.hip, HotRows)
             std::vector<int64_t> cnt((size_t)I, 0);

@@ -44,8 +44,13 @@ struct gorse_mf {
         gorse::DevBuf<int32_t> chunk_row, chunk_cnt;     // n_chunks
         gorse::DevBuf<int64_t> chunk_beg;                // n_chunks: offset into the side's indices
         gorse::DevBuf<int32_t> long_rows, long_first, long_nch;  // n_long
-        int64_t n_short = 0, n_chunks = 0, n_long = 0;
+        // rows with feedback (the rows S = sum x x^T runs over, model.go:645-658), cut into Gram chunks
+        gorse::DevBuf<int32_t> fb_rows, g_cnt;
+        gorse::DevBuf<int64_t> g_beg;
+        int64_t n_short = 0, n_chunks = 0, n_long = 0, n_fb_rows = 0, n_gchunks = 0;
     } als_plan[2];
+    std::vector<int64_t> h_uptr, h_iptr;      // host copies of the CSR row pointers (row plans are rebuilt from them)
+    int64_t als_lo[2] = {0, 0}, als_hi[2] = {0, 0};  // row range of each side this handle solves (gorse_als_set_ranges)
     gorse::DevBuf<float> als_zeros;    // 64 zero words: where padding lanes of the gathers read
     gorse::DevBuf<float> als_partial;  // n_chunks x (d*d + d) partial Gram matrices + column sums
     // generic staging
@@ -62,5 +67,5 @@ struct gorse_mf {
 namespace gorse {
 // implemented in bpr.hip / als.hip, used across files
 int32_t mf_sync_streams(gorse_mf *h);
-int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows);
+int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, int64_t lo, int64_t hi);
 }

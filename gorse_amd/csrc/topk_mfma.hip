@@ -582,6 +582,7 @@ __global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
         for (int64_t r = 0; r < rem; r++) apply_T();
     };
     int64_t prev = -1;
+    int64_t pend = 0;  // T applications owed: unrecorded vectors + recorded ones that are strictly worse than the root
     wave_lds_sync();
     for (int e = 0; e < n && !undecided; e++) {
         const int64_t i = s_idx[e];
@@ -593,12 +594,19 @@ __global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
         }
         int64_t gap = i - prev - 1;
         if (self > prev && self < i) gap--;
-        if (gap > 0) {
-            if (hn < k) {  // unrecorded vectors before the heap is full would have been accepted
-                undecided = true;
-                break;
-            }
-            t_pow(gap);
+        if (gap > 0 && hn < k) {  // unrecorded vectors before the heap is full would have been accepted
+            undecided = true;
+            break;
+        }
+        pend += gap;
+        prev = i;
+        if (hn == k && dd > hw[0]) {  // goes to the root and is popped at once: one more T
+            pend++;
+            continue;
+        }
+        if (pend > 0) {
+            t_pow(pend);
+            pend = 0;
             if (undecided) break;
         }
         if (wl == 0) {
@@ -608,17 +616,13 @@ __global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
         }
         wave_lds_sync();
         hn = hn < k ? hn + 1 : k;
-        prev = i;
     }
     if (!undecided) {
         int64_t gap = p.N - 1 - prev;
         if (self > prev) gap--;
-        if (gap > 0) {
-            if (hn < k)
-                undecided = true;
-            else
-                t_pow(gap);
-        }
+        if (gap > 0 && hn < k) undecided = true;
+        pend += gap;
+        if (!undecided && pend > 0) t_pow(pend);
     }
     if (wl != 0) return;
     if (undecided) {

@@ -45,6 +45,25 @@ def run_epoch(engine, comm, n_samples, lr, reg, seed, epoch, sample_base):
         engine.import_delta(delta)
 
 
+def block_rows(n_rows, world):
+    """Rows of the largest shard: the slot size of the equal-sized blocks an all-gather moves."""
+    return shard_range(n_rows, 0, world)[1]
+
+
+def run_als_epoch(engine, comm, weight, reg):
+    """One row-sharded ALS epoch: every rank holds both factor matrices and the whole dataset,
+    solves its own user rows, the ranks all-gather the user row blocks, then the same for the item rows.  The
+    d x d Gram matrices are recomputed locally from the gathered (identical) replicas, so the only exchange is the
+    two all-gathers: (U + I) * d fp32 per epoch.  engine: half(side), export_block(side) -> tensor of
+    block_rows * d, import_blocks(side, gathered tensor of world * block_rows * d)."""
+    for side in (0, 1):  # model.go:645-690, then :693-738
+        engine.half(side, weight, reg)
+        if comm is not None and comm.world > 1:
+            mine = engine.export_block(side)
+            gathered = comm.all_gather(mine)
+            engine.import_blocks(side, gathered)
+
+
 class TorchComm:
     """torch.distributed plumbing (backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' in the CPU tests)."""
 
@@ -56,6 +75,13 @@ class TorchComm:
 
     def all_reduce_sum(self, tensor):
         self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
+
+    def all_gather(self, tensor):
+        """concatenation over ranks of equal-sized 1-D tensors"""
+        import torch
+        out = torch.empty(self.world * tensor.numel(), dtype=tensor.dtype, device=tensor.device)
+        self.dist.all_gather_into_tensor(out, tensor)
+        return out
 
     def barrier(self):
         if self.world > 1:
@@ -86,3 +112,35 @@ class HipEngine:
     def import_delta(self, delta):
         self.torch.cuda.synchronize()  # the collective ran on torch's stream
         self.mf.item_delta_import(delta.data_ptr())
+
+
+class HipAlsEngine:
+    """A gorse_mf handle restricted to this rank's row ranges + torch CUDA buffers for the all-gathers."""
+
+    def __init__(self, mf, rank, world):
+        import torch
+        self.torch = torch
+        self.mf, self.rank, self.world = mf, rank, world
+        self.rows = (mf.U, mf.I)
+        self.range = [shard_range(n, rank, world) for n in self.rows]
+        mf.als_set_ranges(self.range[0][0], self.range[0][1], self.range[1][0], self.range[1][1])
+        self.block = [block_rows(n, world) for n in self.rows]
+        self.buf = [torch.zeros(b * mf.d, dtype=torch.float32, device="cuda") for b in self.block] if world > 1 else None
+
+    def half(self, side, weight, reg):
+        self.mf.als_half_epoch(side, weight, reg)
+
+    def export_block(self, side):
+        lo, hi = self.range[side]
+        self.mf.rows_export(side, lo, hi, self.buf[side].data_ptr())  # synchronises the library's stream
+        return self.buf[side]
+
+    def import_blocks(self, side, gathered):
+        self.torch.cuda.synchronize()  # the collective ran on torch's stream
+        d, b = self.mf.d, self.block[side]
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            lo, hi = shard_range(self.rows[side], r, self.world)
+            if hi > lo:
+                self.mf.rows_import(side, lo, hi, gathered.data_ptr() + r * b * d * 4)

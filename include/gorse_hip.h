@@ -122,6 +122,17 @@ int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u /*host*/, const i
  * One call = one epoch: S = sum q q^T over items with feedback, user sweep, S = sum p p^T
  * over users with feedback, item sweep.  Needs item_indptr/item_indices. */
 int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const volatile int32_t *cancel /*host or NULL*/);
+/* Row-sharded ALS (one process per GPU): every process holds the whole dataset and both factor
+ * matrices, solves only user rows [u_begin,u_end) and item rows [i_begin,i_end) (rows are independent inside a
+ * half-sweep: model.go:659, 707 hand them to parallel.Parallel), and the caller all-gathers the row blocks after
+ * each half.  set_ranges rebuilds the row plans (default after create: all rows); half_epoch(side) = S over ALL
+ * rows of the other side + the sweep of the owned rows of `side` (0 = users, model.go:645-690; 1 = items,
+ * :693-738); gorse_als_epoch = half 0 then half 1 on the current ranges. */
+int32_t gorse_als_set_ranges(gorse_mf *h, int64_t u_begin, int64_t u_end, int64_t i_begin, int64_t i_end);
+int32_t gorse_als_half_epoch(gorse_mf *h, int32_t side, float weight, float reg);
+/* factor rows [begin,end) of side 0 (P) / 1 (Q) -> / <- a device buffer owned by the caller */
+int32_t gorse_mf_rows_export(gorse_mf *h, int32_t side, int64_t begin, int64_t end, float *dst /*device*/);
+int32_t gorse_mf_rows_import(gorse_mf *h, int32_t side, int64_t begin, int64_t end, const float *src /*device*/);
 
 /* ---- multi-GPU exchange (one process per GPU; Q replicated, users sharded) ------------------
  * mark:   Q_sync <- Q

@@ -80,6 +80,9 @@ class Oracle:
         L.orc_bpr_sample.restype = None
         L.orc_bpr_sample.argtypes = [C.c_int64, C.c_int64, _i64p, _i32p, _i32p, C.c_uint64, C.c_uint64, C.c_int64,
                                      C.c_int64, _i32p, _i32p, _i32p]
+        L.orc_als_half_range.restype = None
+        L.orc_als_half_range.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _i64p, C.c_float,
+                                         C.c_float, C.c_int64, C.c_int64]
         L.orc_als_epoch.restype = None
         L.orc_als_epoch.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _i64p, _i32p,
                                     C.c_float, C.c_float]
@@ -290,6 +293,17 @@ class Oracle:
         self.L.orc_als_epoch(P.ctypes.data_as(_f32p), Q.ctypes.data_as(_f32p), P.shape[0], Q.shape[0], P.shape[1], a,
                              b, c, d, w, reg)
         return P, Q
+
+    def als_half_range(self, A, B, ptr, idx, bptr, w, reg, row_begin, row_end):
+        """rows [row_begin, row_end) of A solved in place against B (model.go:659-690 / 707-738)"""
+        assert A.dtype == np.float32 and A.flags.c_contiguous
+        B, pB = _f32(B)
+        ptr, a = _i64(ptr)
+        idx, b = _i32(idx)
+        bptr, c = _i64(bptr)
+        self.L.orc_als_half_range(A.ctypes.data_as(_f32p), pB, A.shape[0], B.shape[0], A.shape[1], a, b, c, w, reg,
+                                  row_begin, row_end)
+        return A
 
     # ---- predict / evaluate ------------------------------------------------
     def mf_score(self, P, Q, u, i):

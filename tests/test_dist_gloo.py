@@ -106,3 +106,74 @@ def test_two_rank_bpr_matches_single_process_emulation(tmp_path):
     # every rank ends with the same replica of Q
     assert np.array_equal(np.load(tmp_path / "Q0.npy"), np.load(tmp_path / "Q1.npy"))
     assert not np.array_equal(np.load(tmp_path / "Q0.npy"), Q)
+
+
+# ---- row-sharded ALS (gorse_amd.dist.run_als_epoch) -----------------------------------------------------------
+class OracleAlsEngine:
+    """CPU stand-in for HipAlsEngine: the oracle's half-sweep on this rank's row ranges, full replicas of P and Q."""
+
+    def __init__(self, data, P, Q, rank, world):
+        from oracle import oracle as orc
+        self.o = orc.Oracle()
+        self.data, self.rank, self.world = data, rank, world
+        self.F = [P.copy(), Q.copy()]
+        self.rows = (data.U, data.I)
+        self.range = [gdist.shard_range(n, rank, world) for n in self.rows]
+        self.block = [gdist.block_rows(n, world) for n in self.rows]
+
+    def half(self, side, weight, reg):
+        d = self.data
+        ptr, idx, bptr = (d.uptr, d.uidx, d.iptr) if side == 0 else (d.iptr, d.iidx, d.uptr)
+        lo, hi = self.range[side]
+        self.o.als_half_range(self.F[side], self.F[1 - side], ptr, idx, bptr, weight, reg, lo, hi)
+
+    def export_block(self, side):
+        lo, hi = self.range[side]
+        buf = np.zeros((self.block[side], self.F[side].shape[1]), np.float32)
+        buf[:hi - lo] = self.F[side][lo:hi]
+        return torch.from_numpy(buf.ravel())
+
+    def import_blocks(self, side, gathered):
+        g = gathered.numpy().reshape(self.world, self.block[side], -1)
+        for r in range(self.world):
+            lo, hi = gdist.shard_range(self.rows[side], r, self.world)
+            if r != self.rank:
+                self.F[side][lo:hi] = g[r, :hi - lo]
+
+
+def _als_problem():
+    data = synth.synth_cf(101, 67, 1500, seed=5, min_len=2, with_test=False)  # odd sizes: uneven shards
+    P, Q = synth.init_factors(data.U, data.I, 16, 0.0, 0.1, 2)
+    return data, P, Q
+
+
+def _als_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data, P, Q = _als_problem()
+    eng = OracleAlsEngine(data, P, Q, rank, world)
+    comm = gdist.TorchComm()
+    for _ in range(3):
+        gdist.run_als_epoch(eng, comm, 0.05, 0.015)
+    np.save(os.path.join(out, "alsP%d.npy" % rank), eng.F[0])
+    np.save(os.path.join(out, "alsQ%d.npy" % rank), eng.F[1])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_als_equals_the_single_process_epoch(tmp_path, world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_als_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as orc
+    o = orc.Oracle()
+    data, P, Q = _als_problem()
+    eP, eQ = P, Q
+    for _ in range(3):
+        eP, eQ = o.als_epoch(eP, eQ, data.uptr, data.uidx, data.iptr, data.iidx, 0.05, 0.015)
+    for r in range(world):  # rows are independent inside a half-sweep: sharding changes nothing, bit for bit
+        assert np.array_equal(np.load(tmp_path / ("alsP%d.npy" % r)), eP)
+        assert np.array_equal(np.load(tmp_path / ("alsQ%d.npy" % r)), eQ)

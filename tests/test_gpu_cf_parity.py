@@ -407,6 +407,47 @@ def test_als_rows_without_feedback(oracle, als_paths):
         assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
+@pytest.mark.parametrize("path,d", [(2, 64), (2, 16), (1, 24), (1, 96)])
+def test_als_row_sharded_equals_the_full_epoch(small, path, d, als_paths):
+    # three "ranks" on one GPU, each a handle restricted to its row ranges (gorse_als_set_ranges);
+    # after every half-sweep the row blocks travel through device buffers (gorse_mf_rows_export / _import), the way
+    # gorse_amd.dist.HipAlsEngine moves them through an RCCL all-gather.  Rows are independent inside a half-sweep,
+    # so the result equals the unsharded epoch bit for bit.
+    import torch
+    from gorse_amd import dist as gdist
+    capi.lib().gorse_hip_test_set_als_path(path)
+    capi.lib().gorse_hip_test_set_als_plan(48, 20)  # some long rows in every shard
+    world = 3
+    full, P, Q = make_mf(small, d, std=0.1)
+    shards = []
+    for r in range(world):
+        mf = capi.MF(small.U, small.I, d, small.uptr, small.uidx, small.iptr, small.iidx)
+        mf.set_factors(P, Q)
+        ur, ir = gdist.shard_range(small.U, r, world), gdist.shard_range(small.I, r, world)
+        mf.als_set_ranges(ur[0], ur[1], ir[0], ir[1])
+        shards.append((mf, (ur, ir)))
+    rows = (small.U, small.I)
+    for _ in range(2):
+        full.als_epoch(0.05, 0.015)
+        for side in (0, 1):
+            for mf, _ in shards:
+                mf.als_half_epoch(side, 0.05, 0.015)
+            for r, (src, rng_) in enumerate(shards):  # "all-gather": every block to every other handle
+                lo, hi = rng_[side]
+                buf = torch.empty((hi - lo) * d, dtype=torch.float32, device="cuda")
+                src.rows_export(side, lo, hi, buf.data_ptr())
+                torch.cuda.synchronize()
+                for r2, (dst, _) in enumerate(shards):
+                    if r2 != r:
+                        dst.rows_import(side, lo, hi, buf.data_ptr())
+    fP, fQ = full.get_factors()
+    for mf, _ in shards:
+        gP, gQ = mf.get_factors()
+        assert np.array_equal(bits(gP), bits(fP)) and np.array_equal(bits(gQ), bits(fQ))
+    with pytest.raises(capi.GorseHipError):
+        shards[0][0].als_set_ranges(0, rows[0] + 1, 0, rows[1])
+
+
 def test_als_needs_item_csr(small):
     mf, _, _ = make_mf(small, 16, with_items=False)
     with pytest.raises(capi.GorseHipError) as e:

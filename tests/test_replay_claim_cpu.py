@@ -100,19 +100,30 @@ def t_pow(h, gap):
 
 
 def replay(dist, k, recorded):
+    """the control flow of topk_replay_kernel: unrecorded vectors and recorded ones that are strictly worse than
+    the root are T applications, batched until the next vector the heap really takes"""
     h = GoMaxHeap()
-    prev = -1
+    prev, pend = -1, 0
     for i in list(recorded) + [len(dist)]:
         gap = i - prev - 1
         if gap > 0:
             assert len(h.v) == k
-            if not t_pow(h, gap):
-                return None
-        if i < len(dist):
-            h.push(i, dist[i])
-            if len(h.v) > k:
-                h.pop()
+        pend += gap
         prev = i
+        if i == len(dist):
+            break
+        if len(h.v) == k and dist[i] > h.w[0]:
+            pend += 1
+            continue
+        if pend > 0:
+            if not t_pow(h, pend):
+                return None
+            pend = 0
+        h.push(i, dist[i])
+        if len(h.v) > k:
+            h.pop()
+    if pend > 0 and not t_pow(h, pend):
+        return None
     return list(h.v)
 
 
