@@ -12,6 +12,9 @@ Workloads (BASELINE.json configs):
          N*6040 users), Q replicated, one all-reduce of the item-factor delta per epoch over RCCL.
   c3     C3 shard: 125,000 users x 200,000 items x 12.5M feedbacks per rank, nFactors 128 (at N = 8
          this is exactly the 1M x 200K x 100M configuration).
+  topk   C4 alone: item x item cosine top-100 over 1M x 128 bf16 (the default run appends it as "topk").
+  als    C5: eALS 500K x 100K x 50M feedbacks, nFactors 64; rows sharded over the ranks (strong scaling), two
+         all-gathers of factor row blocks per epoch.
 Timed region: inputs resident in HBM, barrier + device sync on both sides, MAX over ranks.
 """
 import argparse
@@ -42,7 +45,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k", "topk"])
+    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k", "topk", "als"])
+    ap.add_argument("--als-scale", type=float, default=1.0, help="shrink S-als (users, items, feedbacks) by this factor")
     ap.add_argument("--no-topk", action="store_true", help="skip the item x item top-k leg of the default run")
     ap.add_argument("--topk-n", type=int, default=1_000_000)
     ap.add_argument("--topk-steps", type=int, default=2)
@@ -213,6 +217,101 @@ def bench_topk(args, world, rank, local, fence):
     return out
 
 
+def als_cpu_baseline(uptr, uidx, iptr, P, Q, w, reg, seconds):
+    """The oracle's half-sweep (kind 'port', model.go:659-690) on a prefix of the user rows, T host threads each on
+    its own row range (rows are independent: what parallel.Parallel does); the serial d x d Gram pass every call
+    repeats is timed separately and subtracted."""
+    from oracle import oracle as orc
+    o = orc.Oracle()
+    threads = min(os.cpu_count() or 1, 32)
+    A = P.copy()
+    t0 = time.perf_counter()
+    o.als_half_range(A, Q, uptr, uidx, iptr, w, reg, 0, 0)
+    t_gram = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    o.als_half_range(A, Q, uptr, uidx, iptr, w, reg, 0, 64)
+    per_entry = max(time.perf_counter() - t0 - t_gram, 1e-6) / max(int(uptr[64]), 1)
+    rows = int(np.searchsorted(uptr, min(int(uptr[-1]), int(seconds * threads / per_entry)), side="right")) - 1
+    rows = max(threads, min(rows, uptr.size - 1))
+    cuts = [rows * t // threads for t in range(threads + 1)]
+
+    def work(t):
+        o.als_half_range(A, Q, uptr, uidx, iptr, w, reg, cuts[t], cuts[t + 1])
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = max(time.perf_counter() - t0 - t_gram, 1e-6)
+    n = int(uptr[rows])
+    return {"value": n / (2.0 * dt), "unit": "entries/s", "cores": threads, "kind": "port",
+            "sample": "user half-sweep over rows [0,%d) = %d feedback entries on %d threads, %.1f s after subtracting the "
+                      "serial Gram pass (%.2f s, repeated per call); an epoch walks every entry twice (user + item "
+                      "half-sweep), hence entries / (2 x time)" % (rows, n, threads, dt, t_gram)}
+
+
+def bench_als(args, world, rank, local, fence):
+    """BASELINE config C5: eALS, nFactors 64.  Every rank holds the dataset and both factor matrices and solves its
+    row ranges (gorse_amd.dist.run_als_epoch); a step = one epoch = 2 half-sweeps + 2 all-gathers."""
+    sc = args.als_scale
+    U, I, nnz, d = int(500_000 * sc), int(100_000 * sc), int(50_000_000 * sc), 64
+    w, reg = 0.001, 0.06
+    uptr, uidx, iptr, iidx = synth.s_als(U, I, nnz, 45)
+    n = int(uptr[-1])
+    mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx, device=local)
+    P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.1, seed=1)
+    mf.set_factors(P0, Q0)
+    eng = gdist.HipAlsEngine(mf, rank, world)
+    comm = gdist.TorchComm() if world > 1 else None
+    for _ in range(max(args.warmup, 1)):
+        gdist.run_als_epoch(eng, comm, w, reg)
+    mf.synchronize()
+    fence()
+    mf.set_profiling(True)
+    mf.reset_profile()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gdist.run_als_epoch(eng, comm, w, reg)
+    mf.synchronize()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    ns, sweep_ms = mf.get_profile(capi.PROF_ALS_SWEEP)
+    ng, gram_ms = mf.get_profile(capi.PROF_ALS_GRAM)
+    mf.set_profiling(False)
+    P, Q = mf.get_factors()
+    if rank != 0:
+        return None
+    (u0, u1), (i0, i1) = eng.range
+    own = int(uptr[u1] - uptr[u0]) + int(iptr[i1] - iptr[i0])  # gathered rows of this rank's two half-sweeps
+    algo = own * d * 4.0 + 2.0 * ((u1 - u0) + (i1 - i0)) * d * 4  # SURVEY 8(d): gathers + factor rows read/written
+    per_epoch_ms = (sweep_ms + gram_ms) / max(args.steps, 1)
+    achieved = algo / (per_epoch_ms * 1e-3) / 1e9 if per_epoch_ms > 0 else 0.0
+    out = {
+        "metric": "ALS feedback entries/sec (nnz per epoch x epochs / time, whole job, N GPUs)",
+        "value": n * args.steps / dt, "unit": "entries/s", "n_gpus": world, "steps": args.steps,
+        "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "S-als %dx%dx%d (C5%s), nFactors=%d, weight=%g reg=%g" % (U, I, n, "" if sc == 1.0 else " x%g" % sc, d, w, reg),
+                   "parallelism": "rows sharded x%d, factors replicated, 2 all-gathers((U+I)*d fp32)/epoch" % world
+                   if world > 1 else "single GPU", "factors_finite": bool(np.isfinite(P).all() and np.isfinite(Q).all())},
+        "roofline": {"bound": "hbm", "kernel": "als_row_kernel + als_chunk_kernel (+ S Gram)", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_epoch": algo, "avg_launch_ms": per_epoch_ms, "launches": ns,
+                     "sweeps_ms_per_epoch": sweep_ms / max(args.steps, 1), "gram_ms_per_epoch": gram_ms / max(args.steps, 1)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = als_cpu_baseline(uptr, uidx, iptr, P0, Q0, w, reg, args.cpu_seconds)
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "entries/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -234,11 +333,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.workload == "topk":
-        out = bench_topk(args, world, rank, local, fence0)
+    if args.workload in ("topk", "als"):
+        if args.workload == "als":
+            out = bench_als(args, world, rank, local, fence0)
+        else:
+            out = bench_topk(args, world, rank, local, fence0)
+            if rank == 0:
+                out["warmup"] = 1
+                out["vs_baseline"] = None
         if rank == 0:
-            out["warmup"] = 1
-            out["vs_baseline"] = None
             print(json.dumps(out), flush=True)
         if world > 1:
             dist.barrier()

@@ -172,14 +172,6 @@ def init_factors(U, I, d, mean, std, seed):
 
 
 def s_emb(N=1_000_000, d=128, seed=44):
-    """S-emb (C4): N(0,1) entries, L2-normalised in fp32, then bf16-truncated (bfloats.go:24-30)."""
-    rng = np.random.default_rng(seed)
-    X = rng.standard_normal((N, d), dtype=np.float32)
-    X /= np.sqrt((X.astype(np.float32) ** 2).sum(axis=1, keepdims=True, dtype=np.float32))
-    return (X.view(np.uint32) >> 16).astype(np.uint16)
-
-
-def s_emb(N=1_000_000, d=128, seed=44):
     """S-emb (BASELINE config C4): N x d entries N(0,1), L2-normalised in fp32, then bf16 by
     truncation (common/bfloats/bfloats.go:24-30).  Returns (uint16 N x d, the same values expanded to fp32)."""
     rng = np.random.default_rng(seed)
@@ -187,3 +179,27 @@ def s_emb(N=1_000_000, d=128, seed=44):
     X /= np.sqrt(np.einsum("ij,ij->i", X, X, dtype=np.float32))[:, None]
     Xb = (X.view(np.uint32) >> 16).astype(np.uint16)
     return Xb, (Xb.astype(np.uint32) << 16).view(np.float32)
+
+
+def s_als(U=500_000, I=100_000, nnz=50_000_000, seed=45, zipf_s=1.0):
+    """S-als (BASELINE config C5; nnz is this repo's assumption, BASELINE gives none): log-normal user
+    activity (min 1), Zipf(1.0) item popularity over a random permutation, drawn with replacement -- a pair may
+    repeat inside a row, which the ALS kernels treat as two feedback entries (timing input, not a parity fixture).
+    Returns (uptr, uidx, iptr, iidx): user-major and item-major CSR of the same entries."""
+    rng = np.random.default_rng(seed)
+    act = rng.lognormal(0.0, 1.0, U)
+    lens = np.maximum(1, np.floor(act / act.sum() * nnz)).astype(np.int64)
+    uptr = np.zeros(U + 1, np.int64)
+    np.cumsum(lens, out=uptr[1:])
+    n = int(uptr[-1])
+    w = 1.0 / np.power(np.arange(1, I + 1, dtype=np.float64), zipf_s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    perm = rng.permutation(I).astype(np.int32)
+    uidx = perm[np.minimum(np.searchsorted(cdf, rng.random(n)), I - 1)].astype(np.int32)
+    rows = np.repeat(np.arange(U, dtype=np.int32), lens)
+    order = np.argsort(uidx, kind="stable")
+    iidx = rows[order].astype(np.int32)
+    iptr = np.zeros(I + 1, np.int64)
+    np.cumsum(np.bincount(uidx, minlength=I), out=iptr[1:])
+    return uptr, uidx, iptr, iidx

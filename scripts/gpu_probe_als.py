@@ -11,30 +11,9 @@ sys.path.insert(0, ".")
 from gorse_amd import capi, synth  # noqa: E402
 
 
-def fast_cf(U, I, nnz, seed, zipf=1.0):
-    """log-normal user activity, Zipf item popularity, duplicates inside a row allowed (timing only)"""
-    rng = np.random.default_rng(seed)
-    act = rng.lognormal(0.0, 1.0, U)
-    lens = np.maximum(1, np.floor(act / act.sum() * nnz)).astype(np.int64)
-    uptr = np.zeros(U + 1, np.int64)
-    np.cumsum(lens, out=uptr[1:])
-    n = int(uptr[-1])
-    w = 1.0 / np.power(np.arange(1, I + 1, dtype=np.float64), zipf)
-    cdf = np.cumsum(w)
-    cdf /= cdf[-1]
-    perm = rng.permutation(I).astype(np.int32)
-    uidx = perm[np.minimum(np.searchsorted(cdf, rng.random(n)), I - 1)]
-    rows = np.repeat(np.arange(U, dtype=np.int32), lens)
-    order = np.argsort(uidx, kind="stable")
-    iidx = rows[order]
-    iptr = np.zeros(I + 1, np.int64)
-    np.cumsum(np.bincount(uidx, minlength=I), out=iptr[1:])
-    return uptr, uidx.astype(np.int32), iptr, iidx.astype(np.int32)
-
-
 def run(name, U, I, nnz, d, paths, reps=3):
     t0 = time.perf_counter()
-    uptr, uidx, iptr, iidx = fast_cf(U, I, nnz, 45)
+    uptr, uidx, iptr, iidx = synth.s_als(U, I, nnz, 45)
     gen = time.perf_counter() - t0
     n = int(uptr[-1])
     P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 1)
