@@ -40,6 +40,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the last committed PMC passes (profiles/traffic.json, written
+    by scripts/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this very command).
+    bench.py cannot collect counters on itself; it reports the recorded figure and says where it came from."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[workload]
+        f, w = rec.get("fetch_bytes_per_launch"), rec.get("write_bytes_per_launch")
+        if f is None or w is None:
+            return None, None
+        return f + w, "profiles/traffic.json[%s]: FETCH_SIZE %.0f MB + WRITE_SIZE %.0f MB per launch; %s" % (
+            workload, f / 1e6, w / 1e6, rec.get("how", ""))
+    except Exception:
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +199,8 @@ def bench_topk(args, world, rank, local, fence):
     dt = float(tt.item())
     launches, sweep_ms = t.get_profile(capi.PROF_TOPK_SWEEP)
     r_launches, resc_ms = t.get_profile(capi.PROF_TOPK_SELECT)
+    h_launches, hist_ms = t.get_profile(capi.PROF_TOPK_HIST)
+    p_launches, replay_ms = t.get_profile(capi.PROF_TOPK_REPLAY)
     t.set_profiling(False)
     n_fb, n_tie = t.last_stats()
     if rank != 0:
@@ -203,8 +220,12 @@ def bench_topk(args, world, rank, local, fence):
         "roofline": {"bound": "mfma", "kernel": "topk_sweep_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                      "algorithmic_flop_per_pair": 2 * d, "avg_launch_ms": avg_ms, "launches": launches,
-                     "rescore_avg_ms": resc_ms / max(r_launches, 1)},
+                     "rescore_avg_ms": resc_ms / max(r_launches, 1),
+                     "tie_history_sweep_ms_per_step": hist_ms / max(args.topk_steps, 1),
+                     "tie_replay_ms_per_step": replay_ms / max(args.topk_steps, 1)},
     }
+    if N == 1_000_000 and q1 - q0 == N:
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("topk")
     if world == 1 and not args.no_cpu_baseline:
         try:
             m = min(q1 - q0, 65536)
@@ -414,6 +435,8 @@ def main():
                          "launches": launches, "sampler_avg_ms": smp_ms / max(s_launches, 1),
                          "note": "working set %.1f MB" % ((data.U + data.I) * d * 4 / 1e6)},
         }
+        if args.workload == "ml1m" and args.mode == capi.BPR_HOGWILD_ATOMIC:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ml1m")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(data, d, lr, reg, args.cpu_seconds)

@@ -18,7 +18,7 @@ BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
 PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM, PROF_BPR_SORT = 0, 1, 2, 3, 4
-PROF_TOPK_SCORE, PROF_TOPK_RESCORE, PROF_TOPK_SWEEP, PROF_TOPK_SELECT = 0, 1, 2, 3
+PROF_TOPK_SCORE, PROF_TOPK_RESCORE, PROF_TOPK_SWEEP, PROF_TOPK_SELECT, PROF_TOPK_HIST, PROF_TOPK_REPLAY = 0, 1, 2, 3, 4, 5
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)

@@ -16,6 +16,8 @@
 //                            atomic schedule kept for A/B probes.
 // HBM-bound: algorithmic bytes per sample = 6*d*4 (three rows read + three written) + 12 (indices).
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "mf_internal.hpp"
 
@@ -366,6 +368,22 @@ __global__ __launch_bounds__(256) void bpr_scatter_kernel(const int32_t *__restr
     }
 }
 
+
+// scatter by an arbitrary key array (one window): keys < 0 sort behind every real key
+__global__ __launch_bounds__(256) void bpr_scatter_by_kernel(const int32_t *__restrict__ key, const int32_t *__restrict__ us,
+                                                             const int32_t *__restrict__ is, const int32_t *__restrict__ js,
+                                                             int64_t n, int32_t K, const int32_t *__restrict__ bucket,
+                                                             const int32_t *__restrict__ rank, int32_t *__restrict__ su,
+                                                             int32_t *__restrict__ si, int32_t *__restrict__ sj) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t kk = key[s] < 0 ? K : key[s];
+        const int64_t pos = (int64_t)bucket[kk] + rank[s];
+        su[pos] = us[s];
+        si[pos] = is[s];
+        sj[pos] = js[s];
+    }
+}
+
 // ---- item-run update ------------------------------------------------------------------------------
 // A group owns `blk` consecutive positions of the item-sorted triplet arrays at a time.  The indices of
 // one batch are loaded coalesced (lane l holds position base + l) and broadcast inside the 16-lane row.
@@ -488,6 +506,92 @@ __global__ __launch_bounds__(kBlock) void bpr_update_runs_kernel(float *P, float
     if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
 }
 
+
+// ---- user-run schedule ---------------------------------------------------------------------------
+// The chunk's triplets are counting-sorted by USER (the order in which a Hogwild epoch applies its samples is free:
+// parallel.go:44-68) and one 16-lane group walks ALL samples of one user: p_u is loaded once, updated in registers
+// sample after sample -- exact sequential SGD on the user side, no lost or delayed update -- and stored once, so a
+// third of the fp32 atomics (the unit this kernel is bound by: ~1 dword/clk per L2 channel) and a third of the
+// gathers disappear.  q_i / q_j are gathered one sample ahead of the arithmetic and updated with atomics exactly as
+// in bpr_update_kernel (hot positive items through the replicas).  Users are drawn uniformly (model.go:452-458), so
+// the runs are Poisson(N / U)-sized: balanced without any work splitting.
+template <int NC>
+__global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float *Q, const int32_t *__restrict__ si,
+                                                                 const int32_t *__restrict__ sj,
+                                                                 const int32_t *__restrict__ off, int32_t U, int d,
+                                                                 float lr, float reg, int exp_mode, double *loss,
+                                                                 HotRows hot, int folders) {
+    if ((int)blockIdx.x < folders) {
+        const int workers = (int)gridDim.x - folders;
+        const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
+        for (int pass = 0; pass < (1 << 16); pass++) {
+            fold_pass(hot, Q, d, tid, nthreads);
+            if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        return;
+    }
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int gib = threadIdx.x / kGroup;
+    const int64_t group = (int64_t)((int)blockIdx.x - folders) * kGroupsPerBlock + gib;
+    const int64_t ngroups = (int64_t)((int)gridDim.x - folders) * kGroupsPerBlock;
+    const float nreg = -reg;
+    double my_loss = 0.0;
+    for (int64_t u = group; u < U; u += ngroups) {
+        const int beg = off[u], end = off[u + 1];
+        if (beg >= end) continue;
+        float *pu = P + u * d;
+        float p[NC], a[NC], b[NC], an[NC], bn[NC];
+        int i = si[beg], j = sj[beg];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
+            a[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i * d + 16 * c + lane);
+            b[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j * d + 16 * c + lane);
+        }
+        for (int s = beg; s < end; s++) {
+            const int sn = s + 1 < end ? s + 1 : s;  // the last iteration re-reads its own rows (result unused)
+            const int in = si[sn], jn = sj[sn];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                an[c] = load_row<MODE_ATOMIC>(Q + (int64_t)in * d + 16 * c + lane);
+                bn[c] = load_row<MODE_ATOMIC>(Q + (int64_t)jn * d + 16 * c + lane);
+            }
+            float *qi = Q + (int64_t)i * d, *qj = Q + (int64_t)j * d;
+            if (hot.n_hot > 0) {
+                const int slot = hot.slot[i];
+                if (slot >= 0) qi = hot.rep + ((int64_t)slot * kHotReplicas + (group & (kHotReplicas - 1))) * d;
+            }
+            const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
+            const float ex = bpr_exp(-diff, exp_mode);
+            const float grad = ex / (1.0f + ex);
+            if (loss && lane == 0) my_loss += (double)log1pf(ex);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int e = 16 * c + lane;
+                const float t1 = fmaf(a[c], nreg, p[c] * grad);
+                const float t2 = fmaf(b[c], nreg, p[c] * (-grad));
+                const float t3 = fmaf(p[c], nreg, (a[c] - b[c]) * grad);
+                __hip_atomic_fetch_add(qi + e, t1 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(qj + e, t2 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p[c] = fmaf(t3, lr, p[c]);
+                a[c] = an[c];
+                b[c] = bn[c];
+            }
+            i = in;
+            j = jn;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++)  // the only writer of this row in the launch
+            __hip_atomic_store(pu + 16 * c + lane, p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
+    if (folders > 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 int32_t exclusive_scan_i32(int32_t *data, int64_t m, int32_t *tmp, hipStream_t st) {
     const int64_t nt = ceil_div(m, kScanTile);
     scan_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, st>>>(data, m, tmp);
@@ -561,6 +665,71 @@ int32_t launch_update_runs(gorse_mf *h, const int32_t *sorted, size_t cap, int64
         LAUNCH(0, (size_t)kGroupsPerBlock * 4 * d * sizeof(float));
 #undef LAUNCH
     GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+
+// counting sort of the chunk by user: `sorted` receives su | si | sj, h->bucket[0..U] the run offsets
+int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int64_t n, size_t cap, hipStream_t st) {
+    const int64_t m = h->U + 2;  // one counter per user + one for skipped samples (sorted last) + the end offset
+    GORSE_HIP_CHECK(hipMemsetAsync(h->bucket.p, 0, (size_t)m * sizeof(int32_t), st));
+    const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
+    // one window (shift 62): key = user, skipped samples (u < 0) get key U
+    // test hook (variant bit 29): one thread ranks the samples in stream order -> every run keeps the stream's order
+    if (g_variant & (1 << 29))
+        bpr_rank_kernel<<<dim3(1), dim3(1), 0, st>>>(trip, n, (int32_t)h->U, 62, h->bucket.p, h->rank.p);
+    else
+        bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, n, (int32_t)h->U, 62, h->bucket.p, h->rank.p);
+    GORSE_TRY(exclusive_scan_i32(h->bucket.p, m, h->scan_tmp.p, st));
+    bpr_scatter_by_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, trip, trip + cap, trip + 2 * cap, n,
+                                                                       (int32_t)h->U, h->bucket.p, h->rank.p, sorted,
+                                                                       sorted + cap, sorted + 2 * cap);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+int32_t ensure_user_sort(gorse_mf *h) {
+    const int64_t m = h->U + 2;
+    if ((size_t)m <= h->bucket.n) return GORSE_OK;  // invariant: scan_tmp covers ceil(bucket.n / kScanTile) tiles
+    GORSE_TRY(mf_sync_streams(h));
+    GORSE_TRY(h->bucket.alloc((size_t)m));
+    GORSE_TRY(h->scan_tmp.alloc((size_t)ceil_div(m, kScanTile)));
+    return GORSE_OK;
+}
+bool user_runs_supported(const gorse_mf *h) { return h->d == 16 || h->d == 32 || h->d == 64 || h->d == 128; }
+
+int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, size_t cap, float lr, float reg, int exp_mode,
+                            double *loss, hipStream_t st) {
+    const int d = h->d;
+    int64_t blocks = ceil_div(h->U, kGroupsPerBlock);
+    const int64_t capb = 256 * 16;
+    if (blocks > capb) blocks = capb;
+    HotRows hot{h->hot_slot.p, h->hot_items.p, h->hot_rep.p, h->hot_done.p, 0};
+    int folders = 0;
+    if (h->n_hot > 0 && !(g_variant & 32)) {
+        hot.n_hot = h->n_hot;
+        folders = kFolderBlocks;
+        GORSE_HIP_CHECK(hipMemsetAsync(h->hot_done.p, 0, sizeof(int32_t), st));
+    }
+    blocks += folders;
+    dim3 grid((unsigned)blocks), block(kBlock);
+#define LAUNCH(NC)                                                                                                     \
+    bpr_update_user_kernel<NC><<<grid, block, 0, st>>>(h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, h->bucket.p,    \
+                                                       (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders)
+    if (d == 16)
+        LAUNCH(1);
+    else if (d == 32)
+        LAUNCH(2);
+    else if (d == 64)
+        LAUNCH(4);
+    else
+        LAUNCH(8);
+#undef LAUNCH
+    GORSE_HIP_CHECK(hipGetLastError());
+    if (folders > 0) {
+        const int64_t fb = std::min<int64_t>(ceil_div((int64_t)hot.n_hot * d, 256), 512);
+        bpr_fold_kernel<<<dim3((unsigned)fb), dim3(256), 0, st>>>(hot, h->Q.p, d);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
     return GORSE_OK;
 }
 
@@ -700,6 +869,20 @@ int32_t run_sequential(gorse_mf *h, const int32_t *d_us, const int32_t *d_is, co
     return GORSE_OK;
 }
 
+// Hogwild schedule: 1 = user runs (bpr_update_user_kernel), 0 = per-sample groups (bpr_update_kernel).  The
+// environment variable GORSE_BPR_SCHEDULE = "users" | "samples" overrides the compiled default (read once);
+// the probe bits of gorse_hip_test_set_variant override both.
+int g_user_runs = 0;
+bool user_runs_default() {
+    static const int v = [] {
+        const char *e = getenv("GORSE_BPR_SCHEDULE");
+        if (e && !strcmp(e, "users")) return 1;
+        if (e && !strcmp(e, "samples")) return 0;
+        return g_user_runs;
+    }();
+    return v != 0;
+}
+bool user_runs_enabled() { return (g_variant & 128) ? true : ((g_variant & (1 << 28)) ? false : user_runs_default()); }
 int g_exp_mode_exact = 0;  // exp flavour of the sequential schedule; tests flip it to 1 for bit parity
 
 int32_t check_mode(int mode) {
@@ -737,7 +920,9 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
         // two-stream pipeline: stream2 samples (and item-sorts) chunk c+1 while stream applies chunk c; the
         // buffer parity runs on across calls so that back-to-back enqueued epochs overlap as well
         const bool runs = mode == MODE_ATOMIC && (g_variant & 64);
+        const bool uruns = mode == MODE_ATOMIC && !runs && user_runs_enabled() && user_runs_supported(h);
         if (runs) GORSE_TRY(ensure_sort(h));
+        if (uruns) GORSE_TRY(ensure_user_sort(h));
         int64_t c = 0;
         for (int64_t s0 = 0; s0 < n_samples; s0 += cap, c++) {
             const int b = (int)(h->chunk_seq & 1);
@@ -760,8 +945,15 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
+            if (uruns) {  // the run offsets live in ONE bucket array: the sort runs on the update stream, in order
+                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream);
+                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, m, (size_t)cap, h->stream));
+                h->prof.end(tok, h->stream);
+            }
             tok = h->prof.begin(GORSE_PROF_BPR_UPDATE, h->stream);
-            if (runs)
+            if (uruns)
+                GORSE_TRY(launch_update_users(h, h->sorted[b].p, (size_t)cap, lr, reg, g_exp_mode_exact, d_loss, h->stream));
+            else if (runs)
                 GORSE_TRY(launch_update_runs(h, h->sorted[b].p, (size_t)cap, m, lr, reg, d_loss, h->stream));
             else
                 GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, d_loss, h->stream));
@@ -862,6 +1054,11 @@ extern "C" int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u, const
         if (mode == MODE_EXACT) {
             GORSE_TRY(run_sequential(h, tb, tb + cap, tb + 2 * cap, u + s0, i + s0, j + s0, m, lr, reg, g_exp_mode_exact,
                                      nullptr, nullptr));
+        } else if (mode == MODE_ATOMIC && !(g_variant & 64) && user_runs_enabled() && user_runs_supported(h)) {
+            GORSE_TRY(ensure_user_sort(h));
+            GORSE_TRY(launch_user_sort(h, tb, h->sorted[0].p, m, (size_t)cap, h->stream));
+            GORSE_TRY(launch_update_users(h, h->sorted[0].p, (size_t)cap, lr, reg, g_exp_mode_exact, nullptr, h->stream));
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         } else if (mode == MODE_ATOMIC && (g_variant & 64)) {
             GORSE_TRY(ensure_sort(h));
             GORSE_TRY(launch_item_sort(h, tb, h->sorted[0].p, m, (size_t)cap, h->stream));

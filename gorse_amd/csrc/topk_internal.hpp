@@ -3,7 +3,7 @@
 #pragma once
 #include "cf_device.hpp"
 
-#define GORSE_PROF_TOPK_NCLASSES 4
+#define GORSE_PROF_TOPK_NCLASSES 6
 
 struct gorse_topk {
     int device = 0;

@@ -971,7 +971,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 hp.hbuf = h->rp_hbuf.p;
                 hp.hcnt = h->rp_hcnt.p;
                 hp.nq = m2;
-                tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
+                tok = h->prof.begin(GORSE_PROF_TOPK_HIST, h->stream);
                 GORSE_TRY(dispatch_sweep(h, hp, scale, true));
                 h->prof.end(tok, h->stream);
                 ReplayParams pp;
@@ -997,7 +997,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 const size_t rlds = ((size_t)2 * kReplayCap + (size_t)(1 + kGroupsPerBlock) * d + 5 * (size_t)(k + 2) + 4) * 4;
                 GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_replay_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-                tok = h->prof.begin(GORSE_PROF_TOPK_SELECT, h->stream);
+                tok = h->prof.begin(GORSE_PROF_TOPK_REPLAY, h->stream);
                 topk_replay_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
                 GORSE_HIP_CHECK(hipGetLastError());
                 h->prof.end(tok, h->stream);

@@ -182,6 +182,8 @@ int32_t gorse_topk_synchronize(gorse_topk *h);
 #define GORSE_PROF_TOPK_RESCORE 1 /* path A: select_kernel (literal container/heap selection)                 */
 #define GORSE_PROF_TOPK_SWEEP 2   /* path B: topk_sweep_kernel (bf16 MFMA candidate sweep + threshold filter) */
 #define GORSE_PROF_TOPK_SELECT 3  /* path B: topk_rescore_kernel (exact rescoring + ranking of the lists)     */
+#define GORSE_PROF_TOPK_HIST 4    /* path B: history sweep of the queries with ties in their top k+1           */
+#define GORSE_PROF_TOPK_REPLAY 5  /* path B: topk_replay_kernel (literal heap replay of those queries)         */
 int32_t gorse_topk_set_profiling(gorse_topk *h, int32_t on);
 int32_t gorse_topk_get_profile(gorse_topk *h, int32_t kernel_class, int64_t *launches, double *total_ms);
 /* statistics of the last all_pairs / search call: queries that took the exact fallback path */
@@ -203,8 +205,10 @@ void gorse_hip_test_set_exact_exp(int32_t mode);
  * skip the writes to P / Q[i] / Q[j]; bit 5: no hot-row replicas = the round-1 kernel; bit 6: the
  * experimental item-run schedule (window-sorted triplets, q_i register-resident across a run), with bits
  * 8..11: 1 + log2 of its run-block length, bits 12..16: log2 of its sort window, bits 20..23: log2 of its
- * resident workgroup count).  Used by scripts/gpu_probe_*.py to attribute time; 0 (the default) is the only
- * value the product ever runs with. */
+ * resident workgroup count); bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
+ * register-resident over a user's samples), bit 28: force the per-sample schedule, bit 29: the user sort ranks
+ * samples in stream order (single thread; makes a run's order deterministic for the parity test).  Used by
+ * scripts/gpu_probe_*.py and the tests; 0 (the default) is the only value the product ever runs with. */
 void gorse_hip_test_set_variant(int32_t variant);
 /* top-k path choice: 0 = automatic (MFMA sweep for >= 64 queries, dot / cosine, k <= 255), 1 = always the
  * literal scan (path A), 2 = the MFMA sweep whenever its operands exist.  Both paths return identical results;

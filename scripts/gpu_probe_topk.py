@@ -22,13 +22,15 @@ def run(name, X, metric, dtype, k, q0, q1, reps=2):
     ns, sweep = t.get_profile(capi.PROF_TOPK_SWEEP)
     nr, resc = t.get_profile(capi.PROF_TOPK_SELECT)
     na, scan = t.get_profile(capi.PROF_TOPK_SCORE)
+    nh, hist = t.get_profile(capi.PROF_TOPK_HIST)
+    npl, repl = t.get_profile(capi.PROF_TOPK_REPLAY)
     N, d = X.shape
     pairs = (q1 - q0) * (N - 1)
     kd = d if dtype == capi.DTYPE_BF16 else 3 * d
     print("%-34s N=%8d d=%4d k=%3d nq=%8d wall %8.2f ms (%.3e pairs/s) sweep %8.2f ms (%.1f TFLOP/s on %d-deep operands) "
-          "rescore+replay %7.2f ms (%d launches) scan-launches %d scan-fallback %d tie-replayed %d create %.2f s"
+          "rescore %7.2f ms (%d launches) tie-history-sweep %7.2f ms tie-replay %7.2f ms scan-launches %d scan-fallback %d tie-replayed %d create %.2f s"
           % (name, N, d, k, q1 - q0, dt * 1e3, pairs / dt, sweep / reps, 2.0 * kd * (q1 - q0) * N / (sweep / reps * 1e-3) / 1e12,
-             kd, resc / reps, nr, na, t.last_stats()[0], t.last_stats()[1], t_create), flush=True)
+             kd, resc / reps, nr, hist / reps, repl / reps, na, t.last_stats()[0], t.last_stats()[1], t_create), flush=True)
     t.close()
 
 

@@ -289,7 +289,7 @@ def test_evaluate_through_device_rank(oracle, small):
     assert np.array_equal(bits(got), bits(exp))
 
 
-def _ndcg_run(oracle, mode):
+def _ndcg_run(oracle, mode, variant=0):
     data = synth.s_ml100k()
     d, lr, reg, epochs = 16, 0.05, 0.01, 10
     P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
@@ -300,8 +300,12 @@ def _ndcg_run(oracle, mode):
     ref = evaluate_ndcg(oracle, data, P, Q)
     mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
     mf.set_factors(P0, Q0)
-    for ep in range(1, epochs + 1):
-        mf.bpr_epoch(data.n_train, lr, reg, 2024, ep, mode=mode)
+    capi.lib().gorse_hip_test_set_variant(variant)
+    try:
+        for ep in range(1, epochs + 1):
+            mf.bpr_epoch(data.n_train, lr, reg, 2024, ep, mode=mode)
+    finally:
+        capi.lib().gorse_hip_test_set_variant(0)
     gP, gQ = mf.get_factors()
     assert np.isfinite(gP).all() and np.isfinite(gQ).all()
     got = evaluate_ndcg(oracle, data, gP, gQ)
@@ -316,6 +320,57 @@ def test_bpr_hogwild_ndcg_parity_ml100k(oracle):
     ref, got = _ndcg_run(oracle, capi.BPR_HOGWILD_ATOMIC)
     assert ref > 0.15  # the model learned something
     assert abs(got - ref) < 0.01
+
+
+VARIANT_USER_RUNS, VARIANT_PER_SAMPLE, VARIANT_STABLE_RANK = 128, 1 << 28, 1 << 29
+
+
+@pytest.mark.parametrize("variant", [VARIANT_USER_RUNS, VARIANT_PER_SAMPLE])
+def test_bpr_hogwild_schedules_ndcg_parity(oracle, variant):
+    """Both Hogwild schedules -- user runs (p_u register-resident over all samples of a user, bpr_update_user_kernel)
+    and per-sample groups (bpr_update_kernel) -- against the sequential oracle, whichever one is the default."""
+    ref, got = _ndcg_run(oracle, capi.BPR_HOGWILD_ATOMIC, variant)
+    assert abs(got - ref) < 0.01
+
+
+@pytest.mark.parametrize("d", [16, 64, 128])
+def test_bpr_user_runs_equal_the_sequential_result_when_items_are_disjoint(oracle, d):
+    """The user-run schedule in a case with a unique answer: every item row is touched by ONE sample, users repeat
+    a lot, and the test hook ranks the samples in stream order.  Then every p_u sees exactly the sequential history
+    (bit-exact with the restated exp), and every item row gets its single update from that same p_u (the atomic add
+    rounds q + (t * lr) in two steps where the sequential code uses one fma: <= 1 ulp)."""
+    oracle.set_exp(1)
+    capi.lib().gorse_hip_test_set_exact_exp(1)
+    rng = np.random.default_rng(d)
+    U, I, n = 37, 3000, 1400
+    # dataset only sets up the handle; a few items are "hot" (count >= 2) so that their positive updates take the
+    # replica route of the kernel
+    rows = [rng.choice(40, 3, replace=False).astype(np.int32) for _ in range(U)]
+    uptr = np.arange(0, 3 * U + 1, 3, dtype=np.int64)
+    uidx = np.concatenate(rows)
+    items = rng.permutation(I)[:2 * n].astype(np.int32)
+    items[:30] = rng.permutation(40)[:30]  # positives among the dataset's (possibly hot) items, still all distinct
+    items[30:] = rng.permutation(np.arange(40, I))[:2 * n - 30]
+    u = rng.integers(0, U, n).astype(np.int32)
+    i, j = items[:n].copy(), items[n:].copy()
+    u[5] = -1  # a skipped sample (sampler failure marker) sorts behind every user
+    P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 9)
+    mf = capi.MF(U, I, d, uptr, uidx)
+    mf.set_factors(P, Q)
+    capi.lib().gorse_hip_test_set_variant(VARIANT_USER_RUNS | VARIANT_STABLE_RANK)
+    try:
+        mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_HOGWILD_ATOMIC)
+    finally:
+        capi.lib().gorse_hip_test_set_variant(0)
+    keep = u >= 0
+    eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u[keep], i[keep], j[keep], 0.05, 0.01)
+    gP, gQ = mf.get_factors()
+    assert np.array_equal(bits(gP), bits(eP))
+    assert rel_err(gQ, eQ) < 1e-6
+    touched = np.zeros(I, bool)
+    touched[i[keep]] = True
+    touched[j[keep]] = True
+    assert np.array_equal(bits(gQ[~touched]), bits(Q[~touched]))  # nothing else moved
 
 
 def test_bpr_racy_schedule_is_diagnostic_only(oracle):
