@@ -70,6 +70,7 @@ SIGNATURES = {
     "gorse_hip_test_set_exact_exp": (None, [C.c_int32]),
     "gorse_hip_test_set_variant": (None, [C.c_int32]),
     "gorse_hip_test_set_topk_path": (None, [C.c_int32]),
+    "gorse_hip_test_set_topk_variant": (None, [C.c_int32]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
     "gorse_hip_test_item_sort": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),

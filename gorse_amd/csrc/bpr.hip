@@ -670,35 +670,40 @@ int32_t launch_update_runs(gorse_mf *h, const int32_t *sorted, size_t cap, int64
 
 
 // counting sort of the chunk by user: `sorted` receives su | si | sj, h->bucket[0..U] the run offsets
-int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int64_t n, size_t cap, hipStream_t st) {
+int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int32_t *bucket, int64_t n, size_t cap,
+                         hipStream_t st) {
     const int64_t m = h->U + 2;  // one counter per user + one for skipped samples (sorted last) + the end offset
-    GORSE_HIP_CHECK(hipMemsetAsync(h->bucket.p, 0, (size_t)m * sizeof(int32_t), st));
+    GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)m * sizeof(int32_t), st));
     const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
     // one window (shift 62): key = user, skipped samples (u < 0) get key U
     // test hook (variant bit 29): one thread ranks the samples in stream order -> every run keeps the stream's order
     if (g_variant & (1 << 29))
-        bpr_rank_kernel<<<dim3(1), dim3(1), 0, st>>>(trip, n, (int32_t)h->U, 62, h->bucket.p, h->rank.p);
+        bpr_rank_kernel<<<dim3(1), dim3(1), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, h->rank.p);
     else
-        bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, n, (int32_t)h->U, 62, h->bucket.p, h->rank.p);
-    GORSE_TRY(exclusive_scan_i32(h->bucket.p, m, h->scan_tmp.p, st));
+        bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, h->rank.p);
+    GORSE_TRY(exclusive_scan_i32(bucket, m, h->scan_tmp.p, st));
     bpr_scatter_by_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, trip, trip + cap, trip + 2 * cap, n,
-                                                                       (int32_t)h->U, h->bucket.p, h->rank.p, sorted,
+                                                                       (int32_t)h->U, bucket, h->rank.p, sorted,
                                                                        sorted + cap, sorted + 2 * cap);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 int32_t ensure_user_sort(gorse_mf *h) {
     const int64_t m = h->U + 2;
-    if ((size_t)m <= h->bucket.n) return GORSE_OK;  // invariant: scan_tmp covers ceil(bucket.n / kScanTile) tiles
+    if ((size_t)m <= h->ubucket[0].n && h->scan_tmp.n >= (size_t)ceil_div(m, kScanTile)) return GORSE_OK;
     GORSE_TRY(mf_sync_streams(h));
-    GORSE_TRY(h->bucket.alloc((size_t)m));
-    GORSE_TRY(h->scan_tmp.alloc((size_t)ceil_div(m, kScanTile)));
+    for (int b = 0; b < 2; b++) GORSE_TRY(h->ubucket[b].alloc((size_t)m));
+    if (h->scan_tmp.n < (size_t)ceil_div(m, kScanTile)) GORSE_TRY(h->scan_tmp.alloc((size_t)ceil_div(m, kScanTile)));
     return GORSE_OK;
 }
-bool user_runs_supported(const gorse_mf *h) { return h->d == 16 || h->d == 32 || h->d == 64 || h->d == 128; }
+// user runs need enough users to fill the chip with one 16-lane group each (4096 groups = one wave per SIMD) and a
+// register-resident factor width; otherwise the per-sample schedule is the faster one (S-ml100k: 943 users)
+bool user_runs_supported(const gorse_mf *h) {
+    return (h->d == 16 || h->d == 32 || h->d == 64 || h->d == 128) && (h->U >= 4096 || (g_variant & 128));
+}
 
-int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, size_t cap, float lr, float reg, int exp_mode,
-                            double *loss, hipStream_t st) {
+int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *bucket, size_t cap, float lr, float reg,
+                            int exp_mode, double *loss, hipStream_t st) {
     const int d = h->d;
     int64_t blocks = ceil_div(h->U, kGroupsPerBlock);
     const int64_t capb = 256 * 16;
@@ -713,7 +718,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, size_t cap, floa
     blocks += folders;
     dim3 grid((unsigned)blocks), block(kBlock);
 #define LAUNCH(NC)                                                                                                     \
-    bpr_update_user_kernel<NC><<<grid, block, 0, st>>>(h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, h->bucket.p,    \
+    bpr_update_user_kernel<NC><<<grid, block, 0, st>>>(h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket,         \
                                                        (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders)
     if (d == 16)
         LAUNCH(1);
@@ -872,7 +877,7 @@ int32_t run_sequential(gorse_mf *h, const int32_t *d_us, const int32_t *d_is, co
 // Hogwild schedule: 1 = user runs (bpr_update_user_kernel), 0 = per-sample groups (bpr_update_kernel).  The
 // environment variable GORSE_BPR_SCHEDULE = "users" | "samples" overrides the compiled default (read once);
 // the probe bits of gorse_hip_test_set_variant override both.
-int g_user_runs = 0;
+int g_user_runs = 1;
 bool user_runs_default() {
     static const int v = [] {
         const char *e = getenv("GORSE_BPR_SCHEDULE");
@@ -943,16 +948,16 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
                 GORSE_TRY(launch_item_sort(h, tb, h->sorted[b].p, m, (size_t)cap, h->stream2));
                 h->prof.end(tok, h->stream2);
             }
+            if (uruns) {  // runs ahead on the sampler stream like the sampler itself; offsets are per triplet buffer
+                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
+                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, m, (size_t)cap, h->stream2));
+                h->prof.end(tok, h->stream2);
+            }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
-            if (uruns) {  // the run offsets live in ONE bucket array: the sort runs on the update stream, in order
-                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream);
-                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, m, (size_t)cap, h->stream));
-                h->prof.end(tok, h->stream);
-            }
             tok = h->prof.begin(GORSE_PROF_BPR_UPDATE, h->stream);
             if (uruns)
-                GORSE_TRY(launch_update_users(h, h->sorted[b].p, (size_t)cap, lr, reg, g_exp_mode_exact, d_loss, h->stream));
+                GORSE_TRY(launch_update_users(h, h->sorted[b].p, h->ubucket[b].p, (size_t)cap, lr, reg, g_exp_mode_exact, d_loss, h->stream));
             else if (runs)
                 GORSE_TRY(launch_update_runs(h, h->sorted[b].p, (size_t)cap, m, lr, reg, d_loss, h->stream));
             else
@@ -1056,8 +1061,9 @@ extern "C" int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u, const
                                      nullptr, nullptr));
         } else if (mode == MODE_ATOMIC && !(g_variant & 64) && user_runs_enabled() && user_runs_supported(h)) {
             GORSE_TRY(ensure_user_sort(h));
-            GORSE_TRY(launch_user_sort(h, tb, h->sorted[0].p, m, (size_t)cap, h->stream));
-            GORSE_TRY(launch_update_users(h, h->sorted[0].p, (size_t)cap, lr, reg, g_exp_mode_exact, nullptr, h->stream));
+            GORSE_TRY(launch_user_sort(h, tb, h->sorted[0].p, h->ubucket[0].p, m, (size_t)cap, h->stream));
+            GORSE_TRY(launch_update_users(h, h->sorted[0].p, h->ubucket[0].p, (size_t)cap, lr, reg, g_exp_mode_exact, nullptr,
+                                          h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         } else if (mode == MODE_ATOMIC && (g_variant & 64)) {
             GORSE_TRY(ensure_sort(h));

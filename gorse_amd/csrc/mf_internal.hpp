@@ -24,6 +24,7 @@ struct gorse_mf {
     gorse::DevBuf<int32_t> sorted[2];  // su | si | sj, each trip_cap long
     gorse::DevBuf<int32_t> rank;       // arrival rank of a sample inside its (item, copy) bucket
     gorse::DevBuf<int32_t> bucket;     // (I+1) * kSortCopies counters -> exclusive offsets after the scan
+    gorse::DevBuf<int32_t> ubucket[2]; // user-run schedule: U + 2 run offsets per triplet buffer (sorted on stream2)
     gorse::DevBuf<int32_t> scan_tmp;   // per-tile sums of the scan
     int64_t chunk_seq = 0;             // chunks enqueued so far: buffer = chunk_seq & 1, across calls
     // hot-row replicas of the Hogwild schedule (bpr.hip): popular items' positive updates land here

@@ -375,3 +375,4 @@ extern "C" int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int
 
 // test hook: 0 = automatic path choice, 1 = path A only (literal scan), 2 = path B whenever its operands exist
 extern "C" void gorse_hip_test_set_topk_path(int32_t path) { gorse::g_topk_force_path = path; }
+extern "C" void gorse_hip_test_set_topk_variant(int32_t v) { gorse::g_topk_variant = v; }

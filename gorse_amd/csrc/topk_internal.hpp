@@ -22,6 +22,7 @@ struct gorse_topk {
     int kp = 0;                    // k-steps of 16 of the MFMA operands (KPAD = 16 * kp)
     float err_coef = 0.0f;         // |approx - reference| <= err_coef * |q| * |x| (dot of the operands)
     float max_norm = 0.0f;         // max_i sqrt(norm2[i])
+    bool coarse_ok = false;        // cosine with nearly equal norms: block-level scale bound in the sweep
     gorse::DevBuf<uint16_t> opA_own, opB_own;  // bf16 operand matrices N x KPAD (candidate / query roles)
     const uint16_t *opA = nullptr, *opB = nullptr;  // may alias Xb
     gorse::DevBuf<float> rscale;   // cosine: 1 / sqrt(norm2[i])
@@ -64,5 +65,6 @@ int32_t topk_mfma_prepare(gorse_topk *h);  // at create: operands, scales, error
 int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev,
                          int64_t nq, int k, int prune0, int32_t *idx_out, float *dist_out, int32_t *cnt_out);
 bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k);
+extern int g_topk_variant;     // probe switches of the sweep (tile rows, coarse scale test)
 extern int g_topk_force_path;  // 0 auto, 1 path A only, 2 path B whenever it is usable, 3 = 2 without the tie replay
 }  // namespace gorse

@@ -27,6 +27,7 @@ using namespace gorse;
 
 namespace gorse {
 int g_topk_force_path = 0;
+int g_topk_variant = 0;  // probe switches: bit 0 = 64-row tiles, bit 1 = 128-row tiles, bit 2 / 3 = coarse scale test off / on
 }
 
 namespace {
@@ -34,7 +35,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTR = 64;        // candidate rows per LDS tile (two 32-row MFMA blocks)
+constexpr int kMaxRB = 4;      // a tile holds RB 32-row MFMA blocks (RB = 2 or 4: 64 or 128 candidate rows per barrier)
 constexpr int kWaves = 8;      // waves per workgroup, two per SIMD
 constexpr int kThreads = kWaves * 64;
 constexpr int kCap = 512;      // candidate-list capacity per query
@@ -59,6 +60,9 @@ __device__ __forceinline__ int lane_rank(uint64_t m) {  // set bits of m below t
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
+constexpr int kDefaultRowsPerTile = 64;
+inline int topk_rows_per_tile() { return (g_topk_variant & 1) ? 64 : ((g_topk_variant & 2) ? 128 : kDefaultRowsPerTile); }
+
 struct SweepParams {
     const uint16_t *A;     // candidate operands, N x KPAD bf16
     const uint16_t *B;     // query operands, nq x KPAD bf16
@@ -71,6 +75,7 @@ struct SweepParams {
     int32_t *hcnt;         // HIST sweeps: nq
     int64_t N, nq;
     int kth;
+    int coarse;            // cosine: reject a 32-row block on max(raw score) x (block's extreme row scale) first
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
@@ -81,6 +86,7 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
                                               uint8_t *flag, uint2 *hb = nullptr, int *s_hc = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n = s_cnt[ql];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2 before they are re-read
     uint32_t key[kEPL], idx[kEPL];
 #pragma unroll
     for (int j = 0; j < kEPL; j++) {
@@ -136,8 +142,9 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
     }
 }
 
-template <int KP, int NCB, bool SCALE, bool HIST>
+template <int KP, int NCB, bool SCALE, bool HIST, int RB>
 __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) {
+    constexpr int kTR = 32 * RB;
     constexpr int KPAD = KP * 16;
     constexpr int ROWB = KPAD * 2 + 16;  // +16 B: consecutive rows start 4 banks apart, ds_read_b128 conflict-free
     constexpr int QW = 32 * NCB;
@@ -147,7 +154,8 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_tile = smem;
     float *s_rs = reinterpret_cast<float *>(smem + 2 * kTR * ROWB);
-    int *s_cnt = reinterpret_cast<int *>(s_rs + 2 * kTR);
+    float *s_bmm = s_rs + 2 * kTR;  // per buffer and 32-row block: (min, max) row scale
+    int *s_cnt = reinterpret_cast<int *>(s_bmm + 2 * 2 * kMaxRB);
     float *s_f = reinterpret_cast<float *>(s_cnt + BQ);
     float *s_mg = s_f + BQ;
     int *s_hc = reinterpret_cast<int *>(s_mg + BQ);
@@ -199,7 +207,20 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                 *reinterpret_cast<uint4 *>(s_tile + (size_t)buf * kTR * ROWB + row * ROWB + cc * 16) = pre[c];
             }
         }
-        if (SCALE && tid < kTR) s_rs[buf * kTR + tid] = pre_rs;
+        if (SCALE && tid < kTR) {
+            s_rs[buf * kTR + tid] = pre_rs;
+            // (min, max) of the 32 scales of this row block; rows past N carry 0 and never qualify anyway
+            float mn = pre_rs > 0.0f ? pre_rs : __builtin_inff(), mx = pre_rs;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                mn = fminf(mn, __shfl_xor(mn, o, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            }
+            if ((tid & 31) == 0) {
+                s_bmm[(buf * kMaxRB + (tid >> 5)) * 2 + 0] = mn;
+                s_bmm[(buf * kMaxRB + (tid >> 5)) * 2 + 1] = mx;
+            }
+        }
     };
 
     const int64_t NT = (p.N + kTR - 1) / kTR;
@@ -220,7 +241,7 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
         const int64_t base_row = t * kTR;
         const int valid = (int)std::min<int64_t>(kTR, p.N - base_row);
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++) {
+        for (int rb = 0; rb < RB; rb++) {
             f32x16 acc[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++)
@@ -247,7 +268,8 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
             // C layout: lane holds column (= query) lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
-                if (SCALE) {
+                const bool coarse = SCALE && p.coarse;
+                auto scale_rows = [&]() {
                     const float4 *r4 = reinterpret_cast<const float4 *>(s_rs + buf * kTR + rb * 32);
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
@@ -257,7 +279,8 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                         acc[cb][4 * g + 2] *= s.z;
                         acc[cb][4 * g + 3] *= s.w;
                     }
-                }
+                };
+                if (SCALE && !coarse) scale_rows();
                 if (valid < kTR) {  // last tile: rows past N never qualify
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
@@ -268,7 +291,12 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                 float m = acc[cb][0];
 #pragma unroll
                 for (int r = 1; r < 16; r++) m = fmaxf(m, acc[cb][r]);
+                if (coarse) {  // an upper bound of every scaled score of the block: scales are positive
+                    const float mn = s_bmm[(buf * kMaxRB + rb) * 2 + 0], mx = s_bmm[(buf * kMaxRB + rb) * 2 + 1];
+                    m = m * (m >= 0.0f ? mx : mn);
+                }
                 if (__builtin_amdgcn_ballot_w64(m >= fth[cb]) != 0) {
+                    if (coarse) scale_rows();
                     const int ql = w * QW + cb * 32 + (lane & 31);
                     const int64_t qg = wgq0 + ql;
                     uint2 *qb = p.cbuf + qg * kCap;
@@ -285,7 +313,6 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                             }
                         }
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     uint64_t need = __builtin_amdgcn_ballot_w64(s_cnt[ql] > kCompactAt) & 0xffffffffull;
                     while (need) {
                         const int l = __builtin_ctzll(need);
@@ -723,23 +750,31 @@ __global__ void margin_kernel(const float *__restrict__ qn2, int64_t nq, float c
 
 const int kSupportedKP[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
 
-template <int KP, int NCB, bool SCALE, bool HIST>
+template <int KP, int NCB, bool SCALE, bool HIST, int RB>
 int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int BQ = 32 * NCB * kWaves;
     constexpr int ROWB = KP * 32 + 16;
-    const size_t lds = (size_t)2 * kTR * ROWB + 2 * kTR * 4 + (size_t)4 * BQ * 4;
+    constexpr int TR = 32 * RB;
+    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)4 * BQ * 4;
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST>),
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<KP, NCB, SCALE, HIST><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
+    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 
 template <int KP, int NCB>
 int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
-    if (scale) return hist ? launch_sweep_one<KP, NCB, true, true>(h, p) : launch_sweep_one<KP, NCB, true, false>(h, p);
-    return hist ? launch_sweep_one<KP, NCB, false, true>(h, p) : launch_sweep_one<KP, NCB, false, false>(h, p);
+    // 128-row tiles (one barrier per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
+    // queries keeps the 64-row form
+    const bool wide = !hist && KP <= 12 && topk_rows_per_tile() == 128;
+    if (wide) {
+        if constexpr (KP <= 12)
+            return scale ? launch_sweep_one<KP, NCB, true, false, 4>(h, p) : launch_sweep_one<KP, NCB, false, false, 4>(h, p);
+    }
+    if (scale) return hist ? launch_sweep_one<KP, NCB, true, true, 2>(h, p) : launch_sweep_one<KP, NCB, true, false, 2>(h, p);
+    return hist ? launch_sweep_one<KP, NCB, false, true, 2>(h, p) : launch_sweep_one<KP, NCB, false, false, 2>(h, p);
 }
 
 int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
@@ -792,6 +827,11 @@ int32_t topk_mfma_prepare(gorse_topk *h) {
         mx = std::max(mx, v);
     }
     h->max_norm = std::sqrt(mx) * 1.0001f;
+    {   // cosine: row scales within 2 % of each other -> the block-level bound loses nothing (topk_sweep_kernel)
+        float mn2 = std::numeric_limits<float>::infinity();
+        for (float v : n2) mn2 = std::min(mn2, v);
+        h->coarse_ok = h->metric == GORSE_METRIC_COSINE && mn2 > 0.0f && std::sqrt(mx / mn2) <= 1.02f;
+    }
     h->kp = kp;
     const int kpad = kp * 16;
     // forward error of two different summation orders of the same K' exact products (the reference's fp32
@@ -894,6 +934,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.cflag = h->cflag.p;
         sp.hbuf = nullptr;
         sp.hcnt = nullptr;
+        sp.coarse = (g_topk_variant & 4) ? 0 : ((g_topk_variant & 8) ? 1 : (h->coarse_ok ? 1 : 0));
         sp.N = h->N;
         sp.nq = m;
         sp.kth = kth;

@@ -214,6 +214,10 @@ void gorse_hip_test_set_variant(int32_t variant);
  * literal scan (path A), 2 = the MFMA sweep whenever its operands exist.  Both paths return identical results;
  * the hook exists so the parity tests can drive each one. */
 void gorse_hip_test_set_topk_path(int32_t path);
+/* probe switches of the MFMA sweep: bit 0 = 64 candidate rows per LDS tile, bit 1 = 128 (default: what the library
+ * ships with), bit 2 / bit 3 = block-level row-scale bound of the cosine sweep off / on (default: on when all norms
+ * are within 2 % of each other).  Results never depend on them. */
+void gorse_hip_test_set_topk_variant(int32_t variant);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */

@@ -53,23 +53,23 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python "$ROOT/scripts/pmc_traffic.py" ml1m bpr_update_kernel "$(find "$OUT/pmc_${TAG}_FETCH_SIZE" -name '*_results.db' | head -1)" \
     "$(find "$OUT/pmc_${TAG}_WRITE_SIZE" -name '*_results.db' | head -1)" "$OUT/${TAG}_traffic.json"
+cd "$ROOT"
+timeout 240 python bench.py --workload c3 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_c3.json" 2> "$OUT/${TAG}_bench_c3.err"
+echo "bench c3 exit $?"; tail -c 1500 "$OUT/${TAG}_bench_c3.json"
+timeout 240 python bench.py --workload als --steps 2 --warmup 1 > "$OUT/${TAG}_bench_als.json" 2> "$OUT/${TAG}_bench_als.err"
+echo "bench als exit $?"; tail -c 1800 "$OUT/${TAG}_bench_als.json"; tail -2 "$OUT/${TAG}_bench_als.err"
+cd /tmp
 # top-k sweep: one SQ pass (MFMA busy, wave cycles, stall buckets, LDS conflicts) and the two HBM passes
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_${TAG}_topk_SQ" -o bench -- python "$ROOT/bench.py" --workload topk --topk-steps 1 --no-cpu-baseline > /dev/null 2> "$OUT/${TAG}_pmc_topk_SQ.err"
 DB=$(find "$OUT/pmc_${TAG}_topk_SQ" -name '*_results.db' | head -1)
 python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmc_topk_SQ.txt" 2>&1
 grep -h "topk_sweep" "$OUT/${TAG}_pmc_topk_SQ.txt" | cut -c1-60,91-170 | head -12
-for C in FETCH_SIZE WRITE_SIZE; do
+for C in FETCH_SIZE; do
     timeout 120 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_${TAG}_topk_$C" -o bench -- python "$ROOT/bench.py" --workload topk --topk-steps 1 --no-cpu-baseline \
         > /dev/null 2> "$OUT/${TAG}_pmc_topk_$C.err"
     DB=$(find "$OUT/pmc_${TAG}_topk_$C" -name '*_results.db' | head -1)
     python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmc_topk_$C.txt" 2>&1
 done
-python "$ROOT/scripts/pmc_traffic.py" topk topk_sweep_kernel "$(find "$OUT/pmc_${TAG}_topk_FETCH_SIZE" -name '*_results.db' | head -1)" \
-    "$(find "$OUT/pmc_${TAG}_topk_WRITE_SIZE" -name '*_results.db' | head -1)" "$OUT/${TAG}_traffic.json"
 cd "$ROOT"
-timeout 240 python bench.py --workload c3 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_c3.json" 2> "$OUT/${TAG}_bench_c3.err"
-echo "bench c3 exit $?"; tail -c 1500 "$OUT/${TAG}_bench_c3.json"
-timeout 240 python bench.py --workload als --steps 3 --warmup 1 > "$OUT/${TAG}_bench_als.json" 2> "$OUT/${TAG}_bench_als.err"
-echo "bench als exit $?"; tail -c 1800 "$OUT/${TAG}_bench_als.json"; tail -2 "$OUT/${TAG}_bench_als.err"
 rm -rf "$OUT"/prof_${TAG} "$OUT"/pmc_${TAG}_*   # databases are large; the summaries are what we keep

@@ -31,6 +31,35 @@ def _paths(oracle):
     capi.lib().gorse_hip_test_set_topk_path(2)
     yield
     capi.lib().gorse_hip_test_set_topk_path(0)
+    capi.lib().gorse_hip_test_set_topk_variant(0)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 1 | 4, 1 | 8, 2 | 4, 2 | 8])
+@pytest.mark.parametrize("dtype,d,N", [(capi.DTYPE_BF16, 128, 4321), (capi.DTYPE_F32, 40, 3000), (capi.DTYPE_BF16, 64, 130)])
+def test_sweep_variants_return_the_same_rows(oracle, variant, dtype, d, N):
+    # tile height (64 / 128 candidate rows per barrier) and the block-level row-scale bound of the cosine sweep are
+    # performance switches: every combination must reproduce the reference's rows, also with skewed norms (where the
+    # library itself would not pick the bound) and with a last tile that is mostly past N
+    rng = np.random.default_rng(d + N)
+    Xf = rng.standard_normal((N, d)).astype(np.float32)
+    Xf *= rng.uniform(0.3, 2.5, (N, 1)).astype(np.float32)
+    Xf[::7] *= -1.0
+    X = to_bf16(Xf) if dtype == capi.DTYPE_BF16 else Xf
+    Xe = from_bf16(X) if dtype == capi.DTYPE_BF16 else Xf
+    capi.lib().gorse_hip_test_set_topk_variant(variant)
+    k = 25
+    for metric in (capi.METRIC_COSINE, capi.METRIC_NEG_DOT):
+        t = capi.TopK(X, metric, dtype=dtype)
+        idx, dist = t.all_pairs(k)
+        qs = np.arange(0, N, 37)
+        check_rows(oracle, Xe, metric, qs, k, idx[qs], dist[qs])
+        qv = rng.standard_normal((70, d)).astype(np.float32)
+        qv = to_bf16(qv) if dtype == capi.DTYPE_BF16 else qv
+        qe = from_bf16(qv) if dtype == capi.DTYPE_BF16 else qv
+        i2, d2, c2 = t.search_vector(qv, k)
+        for r in range(0, 70, 9):
+            ei, ed = oracle.search_vector(Xe, metric, qe[r], k)
+            assert c2[r] == ei.size and np.array_equal(i2[r, :c2[r]], ei) and np.array_equal(bits(d2[r, :c2[r]]), bits(ed))
 
 
 def check_rows(oracle, Xe, metric, qs, k, idx, dist, prune0=False):
