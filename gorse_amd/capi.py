@@ -71,6 +71,7 @@ SIGNATURES = {
     "gorse_hip_test_set_variant": (None, [C.c_int32]),
     "gorse_hip_test_set_topk_path": (None, [C.c_int32]),
     "gorse_hip_test_set_topk_variant": (None, [C.c_int32]),
+    "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
     "gorse_hip_test_item_sort": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),
@@ -304,6 +305,11 @@ class TopK:
         n, ms = C.c_int64(0), C.c_double(0)
         check(lib().gorse_topk_get_profile(self.h, cls, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def sweep_profile(self):
+        out = (C.c_uint64 * 12)()
+        check(lib().gorse_hip_test_get_sweep_profile(self.h, out))
+        return [int(x) for x in out]
 
     def last_stats(self):
         a, b = C.c_int64(0), C.c_int64(0)

@@ -41,6 +41,7 @@ struct gorse_topk {
     gorse::DevBuf<float> rp_margin;
     gorse::DevBuf<uint2> rp_cbuf, rp_hbuf;
     gorse::DevBuf<uint8_t> rp_flag;
+    gorse::DevBuf<unsigned long long> sweep_prof;  // probe: phase counters of the instrumented sweep
     gorse::KernelProfile prof{GORSE_PROF_TOPK_NCLASSES};
     int64_t n_fallback = 0, n_tie = 0;
     int32_t use() const {

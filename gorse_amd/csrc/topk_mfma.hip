@@ -76,6 +76,7 @@ struct SweepParams {
     int64_t N, nq;
     int kth;
     int coarse;            // cosine: reject a 32-row block on max(raw score) x (block's extreme row scale) first
+    unsigned long long *prof;  // PROF instantiations: 8 cycle / event counters summed over all waves
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
@@ -85,14 +86,19 @@ template <bool HIST>
 __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s_cnt, float *s_f, const float *s_mg,
                                               uint8_t *flag, uint2 *hb = nullptr, int *s_hc = nullptr) {
     const int lane = threadIdx.x & 63;
-    const int n = s_cnt[ql];
+    // the list is two interleaved sub-lists: even slots belong to the lane holding rows 0-3, 8-11, ... of the query's
+    // column (lane < 32), odd slots to its partner (lane >= 32); each appends at its own counter (slot 2 * c + half)
+    const int n_lo = s_cnt[2 * ql], n_hi = s_cnt[2 * ql + 1];
+    const int n = n_lo + n_hi;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2 before they are re-read
     uint32_t key[kEPL], idx[kEPL];
+    bool valid[kEPL];
 #pragma unroll
     for (int j = 0; j < kEPL; j++) {
         const int e = j * 64 + lane;
+        valid[j] = (e & 1) ? (e >> 1) < n_hi : (e >> 1) < n_lo;
         unsigned long long v = 0;  // key 0 = never counted below (trial >= 1)
-        if (e < n)
+        if (valid[j])
             v = __hip_atomic_load(reinterpret_cast<unsigned long long *>(qb + e), __ATOMIC_RELAXED,
                                   __HIP_MEMORY_SCOPE_AGENT);
         key[j] = (uint32_t)v;
@@ -115,24 +121,24 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
     bool hist_full = false;
 #pragma unroll
     for (int j = 0; j < kEPL; j++) {
-        const bool valid = j * 64 + lane < n;
-        const bool keep = valid && (fkey_inv(key[j]) >= newf);
+        const bool keep = valid[j] && (fkey_inv(key[j]) >= newf);
         const uint64_t m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) qb[base + lane_rank(m)] = make_uint2(key[j], idx[j]);
+        if (keep) qb[base + lane_rank(m)] = make_uint2(key[j], idx[j]);  // survivors packed into slots 0 .. base-1
         base += __builtin_popcountll(m);
         if (HIST) {
-            const uint64_t md = __builtin_amdgcn_ballot_w64(valid && !keep);
+            const uint64_t md = __builtin_amdgcn_ballot_w64(valid[j] && !keep);
             const int nd = __builtin_popcountll(md);
             if (hbase + nd > kHistCap)
                 hist_full = true;
-            else if (valid && !keep)
+            else if (valid[j] && !keep)
                 hb[hbase + lane_rank(md)] = make_uint2(key[j], idx[j]);
             if (!hist_full) hbase += nd;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-        s_cnt[ql] = base;
+        s_cnt[2 * ql] = (base + 1) >> 1;  // slots 0 .. base-1 read as the two interleaved sub-lists again
+        s_cnt[2 * ql + 1] = base >> 1;
         s_f[ql] = newf;
         if (HIST) s_hc[ql] = hbase;
         if (base > kOverflowAt || hist_full) {  // ties / a margin too wide for the list: stop collecting, path A decides
@@ -142,9 +148,15 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
     }
 }
 
-template <int KP, int NCB, bool SCALE, bool HIST, int RB>
+// PROF (probe only): s_memtime stamps around the phases of the tile loop, summed over the waves into p.prof:
+// [0] tile store + prefetch issue, [1] MFMA + epilogues (slow paths included), [2] slow paths alone, [3] barrier wait,
+// [4] row blocks examined, [5] row blocks that took the slow path, [6] whole kernel, [7] waves
+template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool PROF = false>
 __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) {
     constexpr int kTR = 32 * RB;
+    unsigned long long c_store = 0, c_comp = 0, c_slow = 0, c_bar = 0, n_blk = 0, n_slow = 0, t_begin = 0, ts = 0;
+    unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, n_hits = 0;  // slow path: count + exchange | appends | compaction
+    if (PROF) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int KPAD = KP * 16;
     constexpr int ROWB = KPAD * 2 + 16;  // +16 B: consecutive rows start 4 banks apart, ds_read_b128 conflict-free
     constexpr int QW = 32 * NCB;
@@ -155,8 +167,8 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
     unsigned char *s_tile = smem;
     float *s_rs = reinterpret_cast<float *>(smem + 2 * kTR * ROWB);
     float *s_bmm = s_rs + 2 * kTR;  // per buffer and 32-row block: (min, max) row scale
-    int *s_cnt = reinterpret_cast<int *>(s_bmm + 2 * 2 * kMaxRB);
-    float *s_f = reinterpret_cast<float *>(s_cnt + BQ);
+    int *s_cnt = reinterpret_cast<int *>(s_bmm + 2 * 2 * kMaxRB);  // 2 per query: the interleaved sub-list lengths
+    float *s_f = reinterpret_cast<float *>(s_cnt + 2 * BQ);
     float *s_mg = s_f + BQ;
     int *s_hc = reinterpret_cast<int *>(s_mg + BQ);
 
@@ -164,7 +176,8 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
     const int64_t wgq0 = (int64_t)blockIdx.x * BQ;
     for (int t = tid; t < BQ; t += kThreads) {
         const int64_t q = wgq0 + t;
-        s_cnt[t] = 0;
+        s_cnt[2 * t] = 0;
+        s_cnt[2 * t + 1] = 0;
         s_hc[t] = 0;
         s_f[t] = q < p.nq ? -__builtin_inff() : __builtin_inff();
         s_mg[t] = q < p.nq ? p.qmargin[q] : 0.0f;
@@ -230,13 +243,23 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
     __syncthreads();
 
     float fth[NCB];
+    int cnt[NCB];  // length of this lane's sub-list of its query (mirrored in s_cnt around a compaction)
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb++) fth[cb] = s_f[w * QW + cb * 32 + (lane & 31)];
+    for (int cb = 0; cb < NCB; cb++) {
+        fth[cb] = s_f[w * QW + cb * 32 + (lane & 31)];
+        cnt[cb] = 0;
+    }
 
     for (int64_t t = 0; t < NT; t++) {
         const int buf = (int)(t & 1);
+        if (PROF) ts = __builtin_amdgcn_s_memtime();
         if (t + 1 < NT) store_tile(buf ^ 1);  // rows of tile t+1 (loaded during tile t-1)
         if (t + 2 < NT) load_tile(t + 2);
+        if (PROF) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            c_store += now - ts;
+            ts = now;
+        }
         const unsigned char *tb = s_tile + (size_t)buf * kTR * ROWB;
         const int64_t base_row = t * kTR;
         const int valid = (int)std::min<int64_t>(kTR, p.N - base_row);
@@ -281,11 +304,11 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                     }
                 };
                 if (SCALE && !coarse) scale_rows();
-                if (valid < kTR) {  // last tile: rows past N never qualify
+                if (valid < kTR) {  // last tile: rows past N never qualify (NaN fails every >=, fmaxf skips it)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (row >= valid) acc[cb][r] = -__builtin_inff();
+                        if (row >= valid) acc[cb][r] = __builtin_nanf("");
                     }
                 }
                 float m = acc[cb][0];
@@ -295,39 +318,92 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                     const float mn = s_bmm[(buf * kMaxRB + rb) * 2 + 0], mx = s_bmm[(buf * kMaxRB + rb) * 2 + 1];
                     m = m * (m >= 0.0f ? mx : mn);
                 }
+                if (PROF) n_blk++;
                 if (__builtin_amdgcn_ballot_w64(m >= fth[cb]) != 0) {
+                    unsigned long long tsl = 0;
+                    if (PROF) {
+                        tsl = __builtin_amdgcn_s_memtime();
+                        n_slow++;
+                    }
                     if (coarse) scale_rows();
                     const int ql = w * QW + cb * 32 + (lane & 31);
                     const int64_t qg = wgq0 + ql;
                     uint2 *qb = p.cbuf + qg * kCap;
                     const float f = fth[cb];
+                    // One pass, one compare per score: every lane appends to ITS OWN sub-list of the query (even /
+                    // odd slots, see compact_query), so no slot exchange between the two lanes of a query and no
+                    // counting pass are needed.  f is +inf for lanes past nq and for flagged queries; rows past N are
+                    // NaN.  (Measured before this form: ~2600 cycles per candidate block, VALU-issue bound next to
+                    // the sibling wave's MFMAs -- profiles/r01_i_probe_topk_prof.txt.)
+                    unsigned long long tq = 0;
+                    if (PROF) {
+                        tq = __builtin_amdgcn_s_memtime();
+                        c_s1 += tq - tsl;
+                    }
+                    uint2 *mine = qb + (lane >> 5);
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        // rows past N carry -inf: they must not pass a threshold that is still -inf
-                        const bool hit = acc[cb][r] >= f && acc[cb][r] > -__builtin_inff() && qg < p.nq;
-                        if (__builtin_amdgcn_ballot_w64(hit) != 0) {
-                            if (hit) {
-                                const int slot = atomicAdd(&s_cnt[ql], 1);
-                                const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                                qb[slot] = make_uint2(fkey(acc[cb][r]), row);
-                            }
+                        if (acc[cb][r] >= f) {
+                            const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                            mine[2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
+                            cnt[cb]++;
                         }
                     }
-                    uint64_t need = __builtin_amdgcn_ballot_w64(s_cnt[ql] > kCompactAt) & 0xffffffffull;
-                    while (need) {
-                        const int l = __builtin_ctzll(need);
-                        need &= need - 1;
-                        const int qlc = w * QW + cb * 32 + l;
-                        compact_query<HIST>(p.cbuf + (wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg, p.cflag + wgq0 + qlc,
-                                            HIST ? p.hbuf + (wgq0 + qlc) * kHistCap : nullptr, s_hc);
+                    if (PROF) {
+                        const unsigned long long now = __builtin_amdgcn_s_memtime();
+                        c_s2 += now - tq;
+                        tq = now;
+                        n_hits++;
                     }
-                    fth[cb] = s_f[ql];
+                    uint64_t need = __builtin_amdgcn_ballot_w64(cnt[cb] > kCompactAt / 2);
+                    if (need) {
+                        s_cnt[2 * ql + (lane >> 5)] = cnt[cb];
+                        need = (need | (need >> 32)) & 0xffffffffull;  // either sub-list of a query
+                        do {
+                            const int l = __builtin_ctzll(need);
+                            need &= need - 1;
+                            const int qlc = w * QW + cb * 32 + l;
+                            compact_query<HIST>(p.cbuf + (wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg,
+                                                p.cflag + wgq0 + qlc, HIST ? p.hbuf + (wgq0 + qlc) * kHistCap : nullptr, s_hc);
+                        } while (need);
+                        cnt[cb] = s_cnt[2 * ql + (lane >> 5)];
+                        fth[cb] = s_f[ql];
+                    }
+                    if (PROF) {
+                        const unsigned long long now = __builtin_amdgcn_s_memtime();
+                        c_s3 += now - tq;
+                        c_slow += now - tsl;
+                    }
                 }
             }
         }
+        if (PROF) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            c_comp += now - ts;
+            ts = now;
+        }
         __syncthreads();
+        if (PROF) c_bar += __builtin_amdgcn_s_memtime() - ts;
+    }
+    if (PROF && lane == 0) {
+        atomicAdd(p.prof + 0, c_store);
+        atomicAdd(p.prof + 1, c_comp);
+        atomicAdd(p.prof + 2, c_slow);
+        atomicAdd(p.prof + 3, c_bar);
+        atomicAdd(p.prof + 4, n_blk);
+        atomicAdd(p.prof + 5, n_slow);
+        atomicAdd(p.prof + 6, (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+        atomicAdd(p.prof + 7, 1ull);
+        atomicAdd(p.prof + 8, c_s1);
+        atomicAdd(p.prof + 9, c_s2);
+        atomicAdd(p.prof + 10, c_s3);
+        atomicAdd(p.prof + 11, n_hits);
     }
     // final threshold + compaction of every list this wave owns
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) s_cnt[2 * (w * QW + cb * 32 + (lane & 31)) + (lane >> 5)] = cnt[cb];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int l = 0; l < QW; l++) {
         const int ql = w * QW + l;
         const int64_t qg = wgq0 + ql;
@@ -336,7 +412,7 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
         compact_query<HIST>(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg,
                             HIST ? p.hbuf + qg * kHistCap : nullptr, s_hc);
         if (lane == 0) {
-            p.ccnt[qg] = s_cnt[ql];
+            p.ccnt[qg] = s_cnt[2 * ql] + s_cnt[2 * ql + 1];  // packed by the final compaction: slots 0 .. count-1
             if (HIST) p.hcnt[qg] = s_hc[ql];
         }
     }
@@ -755,11 +831,22 @@ int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int BQ = 32 * NCB * kWaves;
     constexpr int ROWB = KP * 32 + 16;
     constexpr int TR = 32 * RB;
-    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)4 * BQ * 4;
+    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4;
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     topk_sweep_kernel<KP, NCB, SCALE, HIST, RB><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+template <int RB>
+int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {
+    constexpr int BQ = 32 * 2 * kWaves, ROWB = 8 * 32 + 16, TR = 32 * RB;
+    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4;
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, true, false, RB, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    topk_sweep_kernel<8, 2, true, false, RB, true><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -769,6 +856,10 @@ int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist)
     // 128-row tiles (one barrier per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
     // queries keeps the 64-row form
     const bool wide = !hist && KP <= 12 && topk_rows_per_tile() == 128;
+    if constexpr (KP == 8 && NCB == 2) {
+        if ((g_topk_variant & 16) && scale && !hist && p.prof)  // instrumented twin of the C4 sweep (probe only)
+            return wide ? launch_sweep_prof<4>(h, p) : launch_sweep_prof<2>(h, p);
+    }
     if (wide) {
         if constexpr (KP <= 12)
             return scale ? launch_sweep_one<KP, NCB, true, false, 4>(h, p) : launch_sweep_one<KP, NCB, false, false, 4>(h, p);
@@ -935,6 +1026,12 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.hbuf = nullptr;
         sp.hcnt = nullptr;
         sp.coarse = (g_topk_variant & 4) ? 0 : ((g_topk_variant & 8) ? 1 : (h->coarse_ok ? 1 : 0));
+        sp.prof = nullptr;
+        if (g_topk_variant & 16) {
+            GORSE_TRY(h->sweep_prof.ensure(12));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->sweep_prof.p, 0, 12 * sizeof(unsigned long long), h->stream));
+            sp.prof = h->sweep_prof.p;
+        }
         sp.N = h->N;
         sp.nq = m;
         sp.kth = kth;

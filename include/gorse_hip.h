@@ -218,6 +218,12 @@ void gorse_hip_test_set_topk_path(int32_t path);
  * ships with), bit 2 / bit 3 = block-level row-scale bound of the cosine sweep off / on (default: on when all norms
  * are within 2 % of each other).  Results never depend on them. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
+/* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its twelve
+ * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the
+ * candidate paths inside [1], [3] barrier wait, then [4] row blocks examined, [5] row blocks with a candidate, [6]
+ * kernel ticks, [7] waves, and the candidate path split into [8] count + exchange, [9] appends, [10] compaction
+ * check / compaction, with [11] lanes that appended. */
+int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */

@@ -41,6 +41,26 @@ def main():
         run("C4 S-emb bf16 cosine 256K q", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
         run("C4 S-emb bf16 cosine", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "prof":  # phase counters of the instrumented sweep twin (s_memtime ticks)
+        for v, label in [(16 | 1, "64-row tiles"), (16 | 2, "128-row tiles")]:
+            capi.lib().gorse_hip_test_set_topk_variant(v)
+            t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
+            for nq in (131072,):
+                t0 = time.perf_counter()
+                t.all_pairs(100, 0, nq, fetch=False)
+                dt = time.perf_counter() - t0
+                c = t.sweep_profile()
+                waves = max(c[7], 1)
+                tot = c[6] / waves
+                print("%-14s nq=%8d wall %8.2f ms | per wave: kernel %.3e ticks = store+prefetch %.1f%% + mfma/epilogue %.1f%% "
+                      "(slow paths %.1f%%) + barrier wait %.1f%% | row blocks %d, with a candidate %.1f%%, slow path %.0f ticks each "
+                      "= count+exchange %.0f + appends %.0f + compaction %.0f; appending lanes per slow block %.2f"
+                      % (label, nq, dt * 1e3, tot, 100.0 * c[0] / c[6], 100.0 * c[1] / c[6], 100.0 * c[2] / c[6],
+                         100.0 * c[3] / c[6], c[4], 100.0 * c[5] / max(c[4], 1), c[2] / max(c[5], 1), c[8] / max(c[5], 1),
+                         c[9] / max(c[5], 1), c[10] / max(c[5], 1), c[11] / max(c[5], 1)), flush=True)
+            t.close()
+        capi.lib().gorse_hip_test_set_topk_variant(0)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":  # tile height x block-level scale bound, C4 shape
         for v, label in [(1 | 4, "64 rows, exact scale"), (1 | 8, "64 rows, block bound"), (2 | 4, "128 rows, exact scale"),
                          (2 | 8, "128 rows, block bound")]:
