@@ -408,6 +408,8 @@ def main():
     dt = float(tt.item())
     launches, upd_ms = mf.get_profile(capi.PROF_BPR_UPDATE)
     s_launches, smp_ms = mf.get_profile(capi.PROF_BPR_SAMPLE)
+    o_launches, sort_ms = mf.get_profile(capi.PROF_BPR_SORT)
+    user_runs = args.mode == capi.BPR_HOGWILD_ATOMIC and mf.bpr_user_runs()
     mf.set_profiling(False)
     P, Q = mf.get_factors()
     finite = bool(np.isfinite(P).all() and np.isfinite(Q).all())
@@ -426,17 +428,21 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "samples_per_step_per_gpu": n_samples, "lr": lr, "reg": reg,
-                       "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode],
+                       "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode]
+                       + (", user runs (triplets counting-sorted by user, p_u register-resident)" if user_runs else
+                          (", one group per sample" if args.mode == capi.BPR_HOGWILD_ATOMIC else "")),
                        "parallelism": "users sharded x%d, item factors replicated, 1 all-reduce(I*d fp32)/epoch" % world
                        if world > 1 else "single GPU", "factors_finite": finite},
-            "roofline": {"bound": "hbm", "kernel": "bpr_update_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "bpr_update_user_kernel" if user_runs else "bpr_update_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": avg_ms,
                          "launches": launches, "sampler_avg_ms": smp_ms / max(s_launches, 1),
+                         "user_sort_avg_ms": sort_ms / max(o_launches, 1) if o_launches else 0.0,
                          "note": "working set %.1f MB" % ((data.U + data.I) * d * 4 / 1e6)},
         }
         if args.workload == "ml1m" and args.mode == capi.BPR_HOGWILD_ATOMIC:
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ml1m")
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ml1m_users" if user_runs else "ml1m")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(data, d, lr, reg, args.cpu_seconds)

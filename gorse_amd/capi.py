@@ -43,6 +43,7 @@ SIGNATURES = {
                                             C.c_int32]),
     "gorse_bpr_sample_triplets": (C.c_int32, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
     "gorse_bpr_apply_triplets": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float, C.c_int32]),
+    "gorse_mf_bpr_schedule": (C.c_int32, [_vp, _i32p]),
     "gorse_als_epoch": (C.c_int32, [_vp, C.c_float, C.c_float, _i32p]),
     "gorse_als_set_ranges": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "gorse_als_half_epoch": (C.c_int32, [_vp, C.c_int32, C.c_float, C.c_float]),
@@ -210,6 +211,11 @@ class MF:
 
     def item_sync_mark(self):
         check(lib().gorse_mf_item_sync_mark(self.h))
+
+    def bpr_user_runs(self):
+        v = C.c_int32(0)
+        check(lib().gorse_mf_bpr_schedule(self.h, C.byref(v)))
+        return bool(v.value)
 
     def als_set_ranges(self, u_begin, u_end, i_begin, i_end):
         check(lib().gorse_als_set_ranges(self.h, u_begin, u_end, i_begin, i_end))

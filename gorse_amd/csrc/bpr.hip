@@ -948,13 +948,17 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
                 GORSE_TRY(launch_item_sort(h, tb, h->sorted[b].p, m, (size_t)cap, h->stream2));
                 h->prof.end(tok, h->stream2);
             }
-            if (uruns) {  // runs ahead on the sampler stream like the sampler itself; offsets are per triplet buffer
-                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
-                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, m, (size_t)cap, h->stream2));
-                h->prof.end(tok, h->stream2);
-            }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
+            if (uruns) {
+                // The sort runs on the update stream, between two update launches.  Running it ahead on the sampler
+                // stream was measured and is slower: its atomics and scattered writes then compete with the update
+                // kernel for the same L2 atomic units (S-ml1m: update 0.60 -> 0.81 ms, profiles/r01_f_probe_bpr_users.txt
+                // vs r01_e_probe_bpr_users.txt).
+                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream);
+                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, m, (size_t)cap, h->stream));
+                h->prof.end(tok, h->stream);
+            }
             tok = h->prof.begin(GORSE_PROF_BPR_UPDATE, h->stream);
             if (uruns)
                 GORSE_TRY(launch_update_users(h, h->sorted[b].p, h->ubucket[b].p, (size_t)cap, lr, reg, g_exp_mode_exact, d_loss, h->stream));
@@ -978,6 +982,12 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
 }  // namespace
 
 extern "C" void gorse_hip_test_set_exact_exp(int32_t mode) { g_exp_mode_exact = mode; }
+
+extern "C" int32_t gorse_mf_bpr_schedule(gorse_mf *h, int32_t *user_runs) {
+    if (!h || !user_runs) return fail(GORSE_ERR_INVALID, "NULL argument");
+    *user_runs = (!(g_variant & 64) && user_runs_enabled() && user_runs_supported(h)) ? 1 : 0;
+    return GORSE_OK;
+}
 extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
 
 // test hook: the counting sort of the item-run schedule on a host-supplied chunk

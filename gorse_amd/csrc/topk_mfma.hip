@@ -36,7 +36,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxRB = 4;      // a tile holds RB 32-row MFMA blocks (RB = 2 or 4: 64 or 128 candidate rows per barrier)
-constexpr int kWaves = 8;      // waves per workgroup, two per SIMD
+constexpr int kWavesMain = 8;  // waves per workgroup of the main sweep, two per SIMD
+// the history sweep serves the few queries with ties: small workgroups (2 waves = 64 * NCB queries) spread them over
+// many CUs instead of a handful of 8-wave workgroups; deep operands keep more waves (the tile prefetch registers of a
+// thread grow as the workgroup shrinks)
+constexpr int sweep_waves(bool hist, int kp) { return !hist ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
+constexpr int kWaves = kWavesMain;
 constexpr int kThreads = kWaves * 64;
 constexpr int kCap = 512;      // candidate-list capacity per query
 constexpr int kEPL = kCap / 64;
@@ -75,6 +80,7 @@ struct SweepParams {
     int32_t *hcnt;         // HIST sweeps: nq
     int64_t N, nq;
     int kth;
+    int compact_at;        // a sub-list longer than this triggers the compaction of its query (<= kCompactAt / 2)
     int coarse;            // cosine: reject a 32-row block on max(raw score) x (block's extreme row scale) first
     unsigned long long *prof;  // PROF instantiations: 8 cycle / event counters summed over all waves
 };
@@ -105,9 +111,12 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
         idx[j] = (uint32_t)(v >> 32);
     }
     float newf = -__builtin_inff();
-    if (n >= kth) {  // K-th largest key by bisection on the 32 key bits
+    if (n >= kth) {
+        // a lower bound of the K-th largest key: bisection on the 16 leading key bits (sign, exponent, 7 mantissa
+        // bits), the rest left at zero.  Any bound <= the true K-th best keeps the exactness argument; the 2^-7
+        // relative slack keeps a few more entries and halves the cost of a compaction.
         uint32_t prefix = 0;
-        for (int b = 31; b >= 0; --b) {
+        for (int b = 31; b >= 16; --b) {
             const uint32_t trial = prefix | (1u << b);
             int c = 0;
 #pragma unroll
@@ -152,7 +161,9 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
 // [0] tile store + prefetch issue, [1] MFMA + epilogues (slow paths included), [2] slow paths alone, [3] barrier wait,
 // [4] row blocks examined, [5] row blocks that took the slow path, [6] whole kernel, [7] waves
 template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool PROF = false>
-__global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) {
+__global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kernel(SweepParams p) {
+    constexpr int kWaves = sweep_waves(HIST, KP);
+    constexpr int kThreads = kWaves * 64;
     constexpr int kTR = 32 * RB;
     unsigned long long c_store = 0, c_comp = 0, c_slow = 0, c_bar = 0, n_blk = 0, n_slow = 0, t_begin = 0, ts = 0;
     unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, n_hits = 0;  // slow path: count + exchange | appends | compaction
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(kThreads, 2) void topk_sweep_kernel(SweepParams p) 
                         tq = now;
                         n_hits++;
                     }
-                    uint64_t need = __builtin_amdgcn_ballot_w64(cnt[cb] > kCompactAt / 2);
+                    uint64_t need = __builtin_amdgcn_ballot_w64(cnt[cb] > p.compact_at);
                     if (need) {
                         s_cnt[2 * ql + (lane >> 5)] = cnt[cb];
                         need = (need | (need >> 32)) & 0xffffffffull;  // either sub-list of a query
@@ -828,14 +839,15 @@ const int kSupportedKP[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
 
 template <int KP, int NCB, bool SCALE, bool HIST, int RB>
 int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
-    constexpr int BQ = 32 * NCB * kWaves;
+    constexpr int WV = sweep_waves(HIST, KP);
+    constexpr int BQ = 32 * NCB * WV;
     constexpr int ROWB = KP * 32 + 16;
     constexpr int TR = 32 * RB;
     const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4;
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB><<<dim3(grid), dim3(kThreads), lds, h->stream>>>(p);
+    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB><<<dim3(grid), dim3(WV * 64), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -855,13 +867,13 @@ template <int KP, int NCB>
 int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
     // 128-row tiles (one barrier per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
     // queries keeps the 64-row form
-    const bool wide = !hist && KP <= 12 && topk_rows_per_tile() == 128;
+    const bool wide = !hist && KP <= 8 && topk_rows_per_tile() == 128;
     if constexpr (KP == 8 && NCB == 2) {
         if ((g_topk_variant & 16) && scale && !hist && p.prof)  // instrumented twin of the C4 sweep (probe only)
             return wide ? launch_sweep_prof<4>(h, p) : launch_sweep_prof<2>(h, p);
     }
     if (wide) {
-        if constexpr (KP <= 12)
+        if constexpr (KP <= 8)
             return scale ? launch_sweep_one<KP, NCB, true, false, 4>(h, p) : launch_sweep_one<KP, NCB, false, false, 4>(h, p);
     }
     if (scale) return hist ? launch_sweep_one<KP, NCB, true, true, 2>(h, p) : launch_sweep_one<KP, NCB, true, false, 2>(h, p);
@@ -876,7 +888,7 @@ int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool his
         case 4: return launch_sweep<4, 2>(h, p, scale, hist);
         case 6: return launch_sweep<6, 2>(h, p, scale, hist);
         case 8: return launch_sweep<8, 2>(h, p, scale, hist);
-        case 12: return scale ? launch_sweep<12, 1>(h, p, scale, hist) : launch_sweep<12, 2>(h, p, scale, hist);
+        case 12: return launch_sweep<12, 1>(h, p, scale, hist);  // 2 column blocks would spill
         case 16: return launch_sweep<16, 1>(h, p, scale, hist);
         case 24: return launch_sweep<24, 1>(h, p, scale, hist);
     }
@@ -1026,6 +1038,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.hbuf = nullptr;
         sp.hcnt = nullptr;
         sp.coarse = (g_topk_variant & 4) ? 0 : ((g_topk_variant & 8) ? 1 : (h->coarse_ok ? 1 : 0));
+        sp.compact_at = (g_topk_variant & 32) ? 128 : ((g_topk_variant & 64) ? 96 : kCompactAt / 2);
         sp.prof = nullptr;
         if (g_topk_variant & 16) {
             GORSE_TRY(h->sweep_prof.ensure(12));

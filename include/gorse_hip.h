@@ -111,6 +111,12 @@ int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uin
 /* Same, but only enqueues the work on the handle's stream (hogwild modes only). */
 int32_t gorse_bpr_epoch_enqueue(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
                                 int64_t sample_base, int32_t mode);
+/* Which form of the GORSE_BPR_HOGWILD_ATOMIC schedule this handle runs: 1 = user runs (the chunk's triplets are
+ * counting-sorted by user and one 16-lane group applies all samples of a user with p_u in registers; chosen when
+ * there are >= 4096 users and nFactors is 16/32/64/128), 0 = one group per sample.  Both apply exactly the triplets
+ * gorse_bpr_sample_triplets returns, in a different (Hogwild-legal) order; GORSE_BPR_SCHEDULE=users|samples in the
+ * environment overrides the choice. */
+int32_t gorse_mf_bpr_schedule(gorse_mf *h, int32_t *user_runs /*out*/);
 int32_t gorse_bpr_sample_triplets(gorse_mf *h, int64_t n, uint64_t seed, uint64_t epoch, int64_t sample_base,
                                   int32_t *u /*host*/, int32_t *i /*host*/, int32_t *j /*host*/);
 /* Apply a host-supplied triplet stream (test hook and replay path). Triplets with a
@@ -216,7 +222,8 @@ void gorse_hip_test_set_variant(int32_t variant);
 void gorse_hip_test_set_topk_path(int32_t path);
 /* probe switches of the MFMA sweep: bit 0 = 64 candidate rows per LDS tile, bit 1 = 128 (default: what the library
  * ships with), bit 2 / bit 3 = block-level row-scale bound of the cosine sweep off / on (default: on when all norms
- * are within 2 % of each other).  Results never depend on them. */
+ * are within 2 % of each other), bit 4 = the instrumented twin (see below), bit 5 / bit 6 = compact a candidate list
+ * when one of its two sub-lists exceeds 128 / 96 entries (default 224).  Results never depend on them. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
 /* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its twelve
  * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the

@@ -62,12 +62,12 @@ def main():
         capi.lib().gorse_hip_test_set_topk_variant(0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "variants":  # tile height x block-level scale bound, C4 shape
-        for v, label in [(1 | 4, "64 rows, exact scale"), (1 | 8, "64 rows, block bound"), (2 | 4, "128 rows, exact scale"),
-                         (2 | 8, "128 rows, block bound")]:
+        for v, label in [(1 | 4, "64 rows, exact scale"), (1 | 8, "64 rows, block bound"), (2 | 8, "128 rows, block bound"),
+                         (1 | 8 | 32, "64 rows, compact at 2x128"), (1 | 8 | 64, "64 rows, compact at 2x96")]:
             capi.lib().gorse_hip_test_set_topk_variant(v)
             run("C4 256K q: " + label, Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
-        capi.lib().gorse_hip_test_set_topk_variant(2 | 8)
-        run("C4 1M q: 128 rows, block bound", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
+        capi.lib().gorse_hip_test_set_topk_variant(1 | 8 | 32)
+        run("C4 1M q: 64 rows, compact at 2x128", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
         capi.lib().gorse_hip_test_set_topk_variant(0)
         run("C4 1M q: library default", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
         return

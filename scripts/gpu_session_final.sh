@@ -9,36 +9,18 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout 420 python -m pytest tests -q -m gpu > "$OUT/${TAG}_pytest_gpu.log" 2>&1
 echo "pytest gpu exit $?"; tail -3 "$OUT/${TAG}_pytest_gpu.log"
-# schedule choice by rule: user runs become the session's (and then the compiled) default iff they are >= 10 % faster on
-# S-ml1m end to end AND within 0.01 NDCG@10 of the sequential oracle on both S-ml1m and S-ml100k
 timeout 400 python scripts/gpu_probe_users.py > "$OUT/${TAG}_probe_bpr_users.txt" 2>&1
 echo "probe users exit $?"; cat "$OUT/${TAG}_probe_bpr_users.txt"
-SCHED=$(python - "$OUT/${TAG}_probe_bpr_users.txt" <<'PY'
-import re, sys
-ref, rate, ndcg = {}, {}, {}
-for line in open(sys.argv[1]):
-    m = re.match(r"(\S+)\s+sequential CPU oracle: NDCG@10 ([0-9.]+)", line)
-    if m:
-        ref[m.group(1)] = float(m.group(2))
-    m = re.match(r"(\S+)\s+d=\s*\d+ (.*?)\s+update .* wall/epoch [0-9.]+ ms \(([0-9.e+]+) samples/s\) finite=True NDCG ([0-9.na]+)", line)
-    if m:
-        rate[(m.group(1), m.group(2).strip())] = float(m.group(3))
-        ndcg[(m.group(1), m.group(2).strip())] = float(m.group(4))
-ok = False
-try:
-    u, s = "user runs + replicas", "per-sample groups + replicas"
-    ok = (rate[("ml1m", u)] >= 1.1 * rate[("ml1m", s)] and abs(ndcg[("ml1m", u)] - ref["ml1m"]) < 0.01
-          and abs(ndcg[("ml100k", u)] - ref["ml100k"]) < 0.01)
-except Exception:
-    ok = False
-print("users" if ok else "samples")
-PY
-)
-echo "schedule for this session: $SCHED"
-export GORSE_BPR_SCHEDULE=$SCHED
-echo "$SCHED" > "$OUT/${TAG}_schedule.txt"
 timeout 300 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "bench exit $?"; tail -c 2500 "$OUT/${TAG}_bench.json"; tail -2 "$OUT/${TAG}_bench.err"
+python - "$OUT/${TAG}_bench.json" > "$OUT/${TAG}_trafkey.txt" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("ml1m_users" if "user runs" in d["config"]["schedule"] else "ml1m")
+except Exception:
+    print("ml1m")
+PY
 cd /tmp
 timeout 240 rocprofv3 --kernel-trace --stats -d "$OUT/prof_${TAG}" -o bench -- python "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err"
@@ -51,7 +33,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
     DB=$(find "$OUT/pmc_${TAG}_$C" -name '*_results.db' | head -1)
     python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmc_bpr_$C.txt" 2>&1
 done
-python "$ROOT/scripts/pmc_traffic.py" ml1m bpr_update_kernel "$(find "$OUT/pmc_${TAG}_FETCH_SIZE" -name '*_results.db' | head -1)" \
+python "$ROOT/scripts/pmc_traffic.py" "$(cat "$OUT/${TAG}_trafkey.txt")" bpr_update "$(find "$OUT/pmc_${TAG}_FETCH_SIZE" -name '*_results.db' | head -1)" \
     "$(find "$OUT/pmc_${TAG}_WRITE_SIZE" -name '*_results.db' | head -1)" "$OUT/${TAG}_traffic.json"
 cd "$ROOT"
 timeout 240 python bench.py --workload c3 --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/${TAG}_bench_c3.json" 2> "$OUT/${TAG}_bench_c3.err"
