@@ -34,13 +34,15 @@ struct gorse_topk {
     gorse::DevBuf<uint8_t> cflag;
     gorse::DevBuf<int32_t> res_idx, res_cnt;
     gorse::DevBuf<float> res_dist;
-    // tie replay (history sweep of the flagged queries + topk_replay_kernel)
+    // tie replay (history sweep of the flagged queries + topk_tie_sort_kernel + topk_tie_replay_kernel)
     gorse::DevBuf<int32_t> rp_pos, rp_ccnt, rp_hcnt;
     gorse::DevBuf<int64_t> rp_self;
     gorse::DevBuf<uint16_t> rp_op;
     gorse::DevBuf<float> rp_margin;
     gorse::DevBuf<uint2> rp_cbuf, rp_hbuf;
     gorse::DevBuf<uint8_t> rp_flag;
+    gorse::DevBuf<int32_t> rp_sidx, rp_scount;
+    gorse::DevBuf<float> rp_sdst;
     gorse::DevBuf<unsigned long long> sweep_prof;  // probe: phase counters of the instrumented sweep
     gorse::KernelProfile prof{GORSE_PROF_TOPK_NCLASSES};
     int64_t n_fallback = 0, n_tie = 0;

@@ -20,7 +20,6 @@
 #include <cmath>
 #include <limits>
 
-#include "goheap.hpp"
 #include "topk_internal.hpp"
 
 using namespace gorse;
@@ -48,7 +47,7 @@ constexpr int kEPL = kCap / 64;
 constexpr int kCompactAt = kCap - 64;   // compact a list once it holds more than this (a block adds <= 32)
 constexpr int kOverflowAt = kCap - 128; // a compaction that keeps more than this cannot make progress
 constexpr int kMaxKth = 256;
-constexpr int kHistCap = 4096;          // history entries per query of the tie-replay sweep (see topk_replay_kernel)
+constexpr int kHistCap = 4096;          // history entries per query of the tie-replay sweep (see topk_tie_replay_kernel)
 constexpr int kReplayCap = 8192;        // power of two >= kCap + kHistCap: entries the replay sorts
 constexpr int64_t kReplayChunk = 16384; // flagged queries per history sweep (history buffer = 512 MB)
 constexpr int64_t kChunkQ = (int64_t)1 << 20;
@@ -570,24 +569,21 @@ struct ReplayParams {
     int32_t *out_idx;
     float *out_dist;
     int32_t *out_cnt;
+    int32_t *sidx;         // per query kReplayCap recorded vector ids, ascending (stage 1 -> stage 2)
+    float *sdst;           // their exact distances
+    int32_t *scount;       // how many, or -1 when a distance is NaN
 };
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-__global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
+// stage 1 of the tie path: exact distances (the reference's arithmetic) of one query's recorded vectors, sorted by
+// index; one workgroup per query, everything parallel.  Output: sidx / sdst (kReplayCap slots per query), scount.
+__global__ __launch_bounds__(kBlock) void topk_tie_sort_kernel(ReplayParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    const int d = p.d, k = p.k;
+    const int d = p.d;
     int *s_idx = reinterpret_cast<int *>(smem_f);           // kReplayCap
     float *s_dst = smem_f + kReplayCap;                      // kReplayCap
     float *sq = s_dst + kReplayCap;                          // d
     float *sx = sq + d;                                      // kGroupsPerBlock * d
-    int32_t *hv = reinterpret_cast<int32_t *>(sx + (size_t)kGroupsPerBlock * d);  // 2 * (k + 2)
-    float *hw = reinterpret_cast<float *>(hv + 2 * (k + 2));                      // 2 * (k + 2)
-    int32_t *snap = reinterpret_cast<int32_t *>(hw + 2 * (k + 2));                // k + 2
-    int *s_misc = snap + (k + 2);                            // [0] NaN seen
+    int *s_misc = reinterpret_cast<int *>(sx + (size_t)kGroupsPerBlock * d);  // [0] NaN seen
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
     if (p.cflag[t]) return;  // the history sweep could not hold this query: path A
@@ -601,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
     const VecShape vs(d);
     const float qq = p.metric == GORSE_METRIC_COSINE ? p.qn2[row] : 0.0f;
     const uint2 *cb = p.cbuf + t * kCap, *hb = p.hbuf + t * kHistCap;
-    for (int c = gib; c < n; c += kGroupsPerBlock) {  // exact distances, the reference's arithmetic (as topk_rescore_kernel)
+    for (int c = gib; c < n; c += kGroupsPerBlock) {  // exact distances, as topk_rescore_kernel
         const int64_t i = c < n1 ? cb[c].y : hb[c - n1].y;
         float *xr = sx + (size_t)gib * d;
         for (int e = lane; e < d; e += kGroup) xr[e] = p.X[i * d + e];
@@ -642,40 +638,134 @@ __global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
             }
             __syncthreads();
         }
-    if (tid >= 64) return;
-    // ---- wave 0: lane 0 runs the reference's heaps, all lanes snapshot / compare heap states -------------------
-    const int wl = tid;
-    GoHeap<true> mx(hv, hw);
-    int hn = 0;  // heap size, tracked by every lane
-    bool undecided = s_misc[0] != 0;
-    const float kInf = __builtin_inff();
-    auto apply_T = [&]() {  // a push that goes to the root and is popped at once
-        if (wl == 0) {
-            mx.n = hn;
-            mx.push(-1, kInf);
-            mx.pop();
+    for (int c = tid; c < n; c += kBlock) {
+        p.sidx[t * kReplayCap + c] = s_idx[c];
+        p.sdst[t * kReplayCap + c] = s_dst[c];
+    }
+    if (tid == 0) p.scount[t] = s_misc[0] ? -1 : n;  // -1: a NaN distance (the reference panics on it): path A
+}
+
+// The reference's heap as a wave-uniform register structure: entry j lives in lane j & 63 of register j >> 6
+// (capacity 256 = kMaxKth), every index and weight the sift rules look at is a scalar (v_readlane / v_writelane), so a
+// Push or Pop costs no LDS or memory round trip.  The sift loops are the hole form of container/heap's swap loops
+// (goheap.hpp): the moving element is compared with the same neighbours and ends in the same slot, and every other
+// element is moved exactly as the swaps would move it.
+template <bool DESC>
+struct RegHeap {
+    int w[4], v[4];  // weights (float bits) and values
+    int n;
+    __device__ __forceinline__ RegHeap() : n(0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) w[r] = v[r] = 0;
+    }
+    __device__ __forceinline__ static bool less(float a, float b) { return DESC ? a > b : a < b; }
+    __device__ __forceinline__ float getw(int j) const {
+        const int l = j & 63;
+        int x;
+        switch (j >> 6) {
+        case 0: x = __builtin_amdgcn_readlane(w[0], l); break;
+        case 1: x = __builtin_amdgcn_readlane(w[1], l); break;
+        case 2: x = __builtin_amdgcn_readlane(w[2], l); break;
+        default: x = __builtin_amdgcn_readlane(w[3], l); break;
         }
-        wave_lds_sync();
-    };
-    auto take_snapshot = [&]() {
-        for (int e = wl; e < hn; e += 64) snap[e] = hv[e];
-        wave_lds_sync();
-    };
-    auto same_as_snapshot = [&]() -> bool {
+        return __int_as_float(x);
+    }
+    __device__ __forceinline__ int getv(int j) const {
+        const int l = j & 63;
+        switch (j >> 6) {
+        case 0: return __builtin_amdgcn_readlane(v[0], l);
+        case 1: return __builtin_amdgcn_readlane(v[1], l);
+        case 2: return __builtin_amdgcn_readlane(v[2], l);
+        default: return __builtin_amdgcn_readlane(v[3], l);
+        }
+    }
+    __device__ __forceinline__ void set(int j, float wt, int val) {
+        const bool me = (int)(threadIdx.x & 63) == (j & 63);
+        const int wb = __float_as_int(wt);
+        switch (j >> 6) {
+        case 0: w[0] = me ? wb : w[0]; v[0] = me ? val : v[0]; break;
+        case 1: w[1] = me ? wb : w[1]; v[1] = me ? val : v[1]; break;
+        case 2: w[2] = me ? wb : w[2]; v[2] = me ? val : v[2]; break;
+        default: w[3] = me ? wb : w[3]; v[3] = me ? val : v[3]; break;
+        }
+    }
+    __device__ __forceinline__ void push(int val, float wt) {  // heap.Push: append, up(n - 1)
+        int j = n++;
+        while (j > 0) {
+            const int i = (j - 1) / 2;
+            const float wi = getw(i);
+            if (!less(wt, wi)) break;
+            set(j, wi, getv(i));
+            j = i;
+        }
+        set(j, wt, val);
+    }
+    // heap.Pop: swap(0, n - 1), down(0, n - 1), take the last; returns the removed root
+    __device__ __forceinline__ void pop(int &val, float &wt) {
+        val = getv(0);
+        wt = getw(0);
+        const int m = --n;  // the last element (index m) moves to the root and sifts down over m elements
+        if (m == 0) return;
+        const float wl = getw(m);
+        const int vl = getv(m);
+        int i = 0;
+        for (;;) {
+            const int j1 = 2 * i + 1;
+            if (j1 >= m) break;
+            int j = j1;
+            float wj = getw(j1);
+            if (j1 + 1 < m) {
+                const float w2 = getw(j1 + 1);
+                if (less(w2, wj)) {
+                    j = j1 + 1;
+                    wj = w2;
+                }
+            }
+            if (!less(wj, wl)) break;
+            set(i, wj, getv(j));
+            i = j;
+        }
+        set(i, wl, vl);
+    }
+    // every lane: do the first n values equal those of `o`?
+    __device__ __forceinline__ bool same_values(const RegHeap &o, int lane) const {
         bool diff = false;
-        for (int e = wl; e < hn; e += 64) diff |= snap[e] != hv[e];
+#pragma unroll
+        for (int r = 0; r < 4; r++) diff |= (lane + 64 * r < n) && v[r] != o.v[r];
         return __builtin_amdgcn_ballot_w64(diff) == 0;
+    }
+};
+
+// stage 2 of the tie path: one WAVE per query replays the reference's heap over the sorted entries (see the comment
+// above ReplayParams); four queries per workgroup, no LDS.
+__global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, int64_t nq) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= nq) return;
+    if (p.cflag[t]) return;
+    const int n = p.scount[t];
+    const int k = p.k;
+    const int64_t self = p.self[t];
+    const int64_t row = p.pos[t];
+    bool undecided = n < 0;
+    const float kInf = __builtin_inff();
+    RegHeap<true> mx;
+    auto apply_T = [&]() {  // a push that goes to the root and is popped at once
+        int dv;
+        float dw;
+        mx.push(-1, kInf);
+        mx.pop(dv, dw);
     };
     auto t_pow = [&](int64_t gap) {
         int64_t steps = 0;
         while (steps < gap && steps < 16) {  // fixpoint (the usual case: no equal distances on the path) or pre-period
-            take_snapshot();
+            const RegHeap<true> snap = mx;
             apply_T();
             steps++;
-            if (same_as_snapshot()) return;
+            if (mx.same_values(snap, lane)) return;
         }
         if (steps == gap) return;
-        take_snapshot();  // inside the cycle now (or not: then the period search below fails and the query is flagged)
+        const RegHeap<true> snap = mx;  // inside the cycle now (or not: then the period search fails, query flagged)
         int64_t period = 0;
         bool closed = false;
         while (period < 64) {
@@ -683,7 +773,7 @@ __global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
             period++;
             steps++;
             if (steps == gap) return;
-            if (same_as_snapshot()) {
+            if (mx.same_values(snap, lane)) {
                 closed = true;
                 break;
             }
@@ -695,69 +785,76 @@ __global__ __launch_bounds__(kBlock) void topk_replay_kernel(ReplayParams p) {
         const int64_t rem = (gap - steps) % period;
         for (int64_t r = 0; r < rem; r++) apply_T();
     };
+    const int32_t *sidx = p.sidx + t * kReplayCap;
+    const float *sdst = p.sdst + t * kReplayCap;
     int64_t prev = -1;
     int64_t pend = 0;  // T applications owed: unrecorded vectors + recorded ones that are strictly worse than the root
-    wave_lds_sync();
-    for (int e = 0; e < n && !undecided; e++) {
-        const int64_t i = s_idx[e];
-        const float dd = s_dst[e];
-        if (i == self) continue;
-        if (i == prev) {  // cannot happen: every recorded vector lives in exactly one place
-            undecided = true;
-            break;
-        }
-        int64_t gap = i - prev - 1;
-        if (self > prev && self < i) gap--;
-        if (gap > 0 && hn < k) {  // unrecorded vectors before the heap is full would have been accepted
-            undecided = true;
-            break;
-        }
-        pend += gap;
-        prev = i;
-        if (hn == k && dd > hw[0]) {  // goes to the root and is popped at once: one more T
-            pend++;
-            continue;
-        }
-        if (pend > 0) {
-            t_pow(pend);
-            pend = 0;
-            if (undecided) break;
-        }
-        if (wl == 0) {
-            mx.n = hn;
+    for (int e0 = 0; e0 < n && !undecided; e0 += 64) {
+        const int bi = e0 + lane < n ? sidx[e0 + lane] : 0;
+        const int bd = e0 + lane < n ? __float_as_int(sdst[e0 + lane]) : 0;
+        const int cntb = n - e0 < 64 ? n - e0 : 64;
+        for (int j = 0; j < cntb && !undecided; j++) {
+            const int64_t i = __builtin_amdgcn_readlane(bi, j);
+            const float dd = __int_as_float(__builtin_amdgcn_readlane(bd, j));
+            if (i == self) continue;
+            if (i == prev) {  // cannot happen: every recorded vector lives in exactly one place
+                undecided = true;
+                break;
+            }
+            int64_t gap = i - prev - 1;
+            if (self > prev && self < i) gap--;
+            if (gap > 0 && mx.n < k) {  // unrecorded vectors before the heap is full would have been accepted
+                undecided = true;
+                break;
+            }
+            pend += gap;
+            prev = i;
+            if (mx.n == k && dd > mx.getw(0)) {  // goes to the root and is popped at once: one more T
+                pend++;
+                continue;
+            }
+            if (pend > 0) {
+                t_pow(pend);
+                pend = 0;
+                if (undecided) break;
+            }
             mx.push((int32_t)i, dd);
-            if (mx.n > k) mx.pop();
+            if (mx.n > k) {
+                int dv;
+                float dw;
+                mx.pop(dv, dw);
+            }
         }
-        wave_lds_sync();
-        hn = hn < k ? hn + 1 : k;
     }
     if (!undecided) {
         int64_t gap = p.N - 1 - prev;
         if (self > prev) gap--;
-        if (gap > 0 && hn < k) undecided = true;
+        if (gap > 0 && mx.n < k) undecided = true;
         pend += gap;
         if (!undecided && pend > 0) t_pow(pend);
     }
-    if (wl != 0) return;
     if (undecided) {
-        p.cflag[t] = 2;
+        if (lane == 0) p.cflag[t] = 2;
         return;
     }
-    GoHeap<false> mn(hv + (k + 2), hw + (k + 2));  // Reverse(): re-push in array order (pq.go:121-128)
-    for (int e = 0; e < hn; e++) mn.push(hv[e], hw[e]);
+    RegHeap<false> mn;  // Reverse(): re-push in array order (pq.go:121-128)
+    const int hn = mx.n;
+    for (int e = 0; e < hn; e++) mn.push(mx.getv(e), mx.getw(e));
     int cnt = 0;
     while (mn.n > 0) {
-        mn.pop();
-        const int32_t v = mn.v[mn.n];
-        const float w = mn.w[mn.n];
+        int v;
+        float w;
+        mn.pop(v, w);
         if (!p.prune0 || w > 0) {
-            p.out_idx[row * k + cnt] = v;
-            p.out_dist[row * k + cnt] = w;
+            if (lane == 0) {
+                p.out_idx[row * k + cnt] = v;
+                p.out_dist[row * k + cnt] = w;
+            }
             cnt++;
         }
     }
-    p.out_cnt[row] = cnt;
-    for (int e = cnt; e < k; e++) {
+    if (lane == 0) p.out_cnt[row] = cnt;
+    for (int e = cnt + lane; e < k; e += 64) {
         p.out_idx[row * k + e] = -1;
         p.out_dist[row * k + e] = kInf;
     }
@@ -1082,7 +1179,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         auto stored_id = [&](int64_t t) -> int64_t {
             return by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
         };
-        // stage 2: history sweep + literal heap replay (topk_replay_kernel) for the flagged queries
+        // stage 2: history sweep + literal heap replay (topk_tie_sort_kernel, topk_tie_replay_kernel) for the flagged queries
         std::vector<int64_t> rest;
         if (!fb.empty() && g_topk_force_path != 3) {
             std::vector<int32_t> pos;
@@ -1145,11 +1242,19 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 pp.out_idx = h->res_idx.p;
                 pp.out_dist = h->res_dist.p;
                 pp.out_cnt = h->res_cnt.p;
-                const size_t rlds = ((size_t)2 * kReplayCap + (size_t)(1 + kGroupsPerBlock) * d + 5 * (size_t)(k + 2) + 4) * 4;
-                GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_replay_kernel),
+                GORSE_TRY(h->rp_sidx.ensure((size_t)m2 * kReplayCap));
+                GORSE_TRY(h->rp_sdst.ensure((size_t)m2 * kReplayCap));
+                GORSE_TRY(h->rp_scount.ensure((size_t)m2));
+                pp.sidx = h->rp_sidx.p;
+                pp.sdst = h->rp_sdst.p;
+                pp.scount = h->rp_scount.p;
+                const size_t rlds = ((size_t)2 * kReplayCap + (size_t)(1 + kGroupsPerBlock) * d + 4) * 4;
+                GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_tie_sort_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
                 tok = h->prof.begin(GORSE_PROF_TOPK_REPLAY, h->stream);
-                topk_replay_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
+                topk_tie_sort_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
+                GORSE_HIP_CHECK(hipGetLastError());
+                topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2);
                 GORSE_HIP_CHECK(hipGetLastError());
                 h->prof.end(tok, h->stream);
                 f2.resize((size_t)m2);

@@ -189,7 +189,7 @@ int32_t gorse_topk_synchronize(gorse_topk *h);
 #define GORSE_PROF_TOPK_SWEEP 2   /* path B: topk_sweep_kernel (bf16 MFMA candidate sweep + threshold filter) */
 #define GORSE_PROF_TOPK_SELECT 3  /* path B: topk_rescore_kernel (exact rescoring + ranking of the lists)     */
 #define GORSE_PROF_TOPK_HIST 4    /* path B: history sweep of the queries with ties in their top k+1           */
-#define GORSE_PROF_TOPK_REPLAY 5  /* path B: topk_replay_kernel (literal heap replay of those queries)         */
+#define GORSE_PROF_TOPK_REPLAY 5  /* path B: topk_tie_sort_kernel + topk_tie_replay_kernel (literal heap replay) */
 int32_t gorse_topk_set_profiling(gorse_topk *h, int32_t on);
 int32_t gorse_topk_get_profile(gorse_topk *h, int32_t kernel_class, int64_t *launches, double *total_ms);
 /* statistics of the last all_pairs / search call: queries that took the exact fallback path */

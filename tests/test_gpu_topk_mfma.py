@@ -100,7 +100,7 @@ def test_all_pairs_matches_oracle(oracle, metric, dtype, d, k):
 @pytest.mark.parametrize("path", [2, 3])
 def test_ties_inside_the_top_k(oracle, path):
     # small-integer vectors: most queries have equal distances inside their top k+1, where the reference's answer
-    # is decided by container/heap mechanics.  path 2: the history sweep + literal heap replay (topk_replay_kernel)
+    # is decided by container/heap mechanics.  path 2: the history sweep + literal heap replay (topk_tie_replay_kernel)
     # decides them; path 3: the replay is switched off and the literal scan over all N vectors (path A) must
     capi.lib().gorse_hip_test_set_topk_path(path)
     rng = np.random.default_rng(4)

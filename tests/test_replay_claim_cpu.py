@@ -1,4 +1,4 @@
-"""The claim behind topk_replay_kernel (gorse_amd/csrc/topk_mfma.hip), checked on the CPU with Go's container/heap
+"""The claim behind topk_tie_replay_kernel (gorse_amd/csrc/topk_mfma.hip), checked on the CPU with Go's container/heap
 rules restated in pure Python (same rules as gorse_amd/csrc/goheap.hpp / common/heap/pq.go):
 
   Bruteforce's queue (bruteforce.go:46-53: Push, then Pop once it holds more than k) ends in the same heap ARRAY
@@ -68,7 +68,7 @@ def literal(dist, k):
 
 
 def t_pow(h, gap):
-    """exactly the control flow of t_pow in topk_replay_kernel"""
+    """exactly the control flow of t_pow in topk_tie_replay_kernel"""
     def apply():
         h.push(-1, INF)
         h.pop()
@@ -100,7 +100,7 @@ def t_pow(h, gap):
 
 
 def replay(dist, k, recorded):
-    """the control flow of topk_replay_kernel: unrecorded vectors and recorded ones that are strictly worse than
+    """the control flow of topk_tie_replay_kernel: unrecorded vectors and recorded ones that are strictly worse than
     the root are T applications, batched until the next vector the heap really takes"""
     h = GoMaxHeap()
     prev, pend = -1, 0
