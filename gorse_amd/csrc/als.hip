@@ -402,8 +402,18 @@ __global__ __launch_bounds__(256) void als_long_solve_kernel(float *__restrict__
         const float *src = partial + (int64_t)first[t] * stride;
         const int nc = nch[t];
         for (int e = threadIdx.x; e < (int)stride; e += blockDim.x) {
-            float acc = 0.0f;
-            for (int c = 0; c < nc; c++) acc += src[(int64_t)c * stride + e];
+            // chunk order, four independent chains (chunks c = 0, 1, 2, 3 mod 4) so that four loads are in flight;
+            // the grouping is fixed, hence deterministic and the same whichever process solves the row
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            int c = 0;
+            for (; c + 3 < nc; c += 4) {
+                a0 += src[(int64_t)c * stride + e];
+                a1 += src[(int64_t)(c + 1) * stride + e];
+                a2 += src[(int64_t)(c + 2) * stride + e];
+                a3 += src[(int64_t)(c + 3) * stride + e];
+            }
+            for (; c < nc; c++) a0 += src[(int64_t)c * stride + e];
+            const float acc = (a0 + a1) + (a2 + a3);
             if (e < d * d)
                 sM[(e / d) * kAlsDP + e % d] = one_w * acc + w * S[e];
             else
@@ -648,11 +658,14 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, 
         }
         lrows.push_back((int32_t)r);
         lfirst.push_back((int32_t)crow.size());
+        // at most 256 chunks per row (the long-row solver adds a row's partials one after the other): very long
+        // rows get proportionally longer chunks, in multiples of one pipeline stage (16 entries)
+        const int64_t chunk = std::max<int64_t>(g_als_chunk, (ceil_div(n, 256) + 15) / 16 * 16);
         int nc = 0;
-        for (int64_t b = 0; b < n; b += g_als_chunk, nc++) {
+        for (int64_t b = 0; b < n; b += chunk, nc++) {
             crow.push_back((int32_t)r);
             cbeg.push_back(ptr[r] + b);
-            ccnt.push_back((int32_t)std::min<int64_t>(g_als_chunk, n - b));
+            ccnt.push_back((int32_t)std::min<int64_t>(chunk, n - b));
         }
         lnch.push_back(nc);
     }

@@ -41,6 +41,12 @@ echo "bench c3 exit $?"; tail -c 1500 "$OUT/${TAG}_bench_c3.json"
 timeout 240 python bench.py --workload als --steps 2 --warmup 1 > "$OUT/${TAG}_bench_als.json" 2> "$OUT/${TAG}_bench_als.err"
 echo "bench als exit $?"; tail -c 1800 "$OUT/${TAG}_bench_als.json"; tail -2 "$OUT/${TAG}_bench_als.err"
 cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT/prof_${TAG}_als" -o bench -- python "$ROOT/bench.py" --workload als --steps 2 --warmup 1 --no-cpu-baseline \
+    > "$OUT/${TAG}_bench_als_under_rocprof.json" 2> "$OUT/${TAG}_rocprof_als.err"
+python "$ROOT/scripts/rocpd_summary.py" "$(find "$OUT/prof_${TAG}_als" -name '*_results.db' | head -1)" > "$OUT/${TAG}_kernel_stats_als.txt" 2>&1
+head -10 "$OUT/${TAG}_kernel_stats_als.txt" | cut -c1-170
+cd "$ROOT"
+cd /tmp
 # top-k sweep: one SQ pass (MFMA busy, wave cycles, stall buckets, LDS conflicts) and the two HBM passes
 timeout 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_${TAG}_topk_SQ" -o bench -- python "$ROOT/bench.py" --workload topk --topk-steps 1 --no-cpu-baseline > /dev/null 2> "$OUT/${TAG}_pmc_topk_SQ.err"
@@ -54,4 +60,4 @@ for C in FETCH_SIZE; do
     python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmc_topk_$C.txt" 2>&1
 done
 cd "$ROOT"
-rm -rf "$OUT"/prof_${TAG} "$OUT"/pmc_${TAG}_*   # databases are large; the summaries are what we keep
+rm -rf "$OUT"/prof_${TAG} "$OUT"/prof_${TAG}_als "$OUT"/pmc_${TAG}_*   # databases are large; the summaries are what we keep
