@@ -75,6 +75,7 @@ SIGNATURES = {
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
+    "gorse_hip_test_als_profile": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_item_sort": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),
 }
 
@@ -216,6 +217,11 @@ class MF:
         v = C.c_int32(0)
         check(lib().gorse_mf_bpr_schedule(self.h, C.byref(v)))
         return bool(v.value)
+
+    def als_profile(self, enable, fetch=False):
+        out = (C.c_uint64 * 16)() if fetch else None
+        check(lib().gorse_hip_test_als_profile(self.h, int(enable), out))
+        return [int(x) for x in out] if fetch else None
 
     def als_set_ranges(self, u_begin, u_end, i_begin, i_end):
         check(lib().gorse_als_set_ranges(self.h, u_begin, u_end, i_begin, i_end))

@@ -290,23 +290,22 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
     }
 }
 
-// visit every (i, j, value) of the full symmetric G held as upper-triangular tiles; C layout of the
-// 32x32 MFMA: lane holds column lane & 31, rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+// visit every value of the full symmetric G held as upper-triangular tiles; C layout of the 32x32 MFMA: lane holds
+// column lane & 31, rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The callback gets the COMPILE-TIME parts (ci, cj)
+// of the coordinates: i = ci + 4 * (lane >> 5), j = cj + (lane & 31); `mirror` says the value is being handed over a
+// second time for the transposed position (j, i) of an off-diagonal tile.
 template <int NB, typename F>
-__device__ __forceinline__ void gram_foreach(const GramAcc<NB> &g, int d, int lane, F &&f) {
+__device__ __forceinline__ void gram_foreach(const GramAcc<NB> &g, F &&f) {
 #pragma unroll
     for (int bi = 0; bi < NB; bi++)
 #pragma unroll
         for (int bj = bi; bj < NB; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int j = 32 * bj + (lane & 31);
-                if (i < d && j < d) {
-                    const float v = g.t[GramAcc<NB>::tile(bi, bj)][r];
-                    f(i, j, v);
-                    if (bi != bj) f(j, i, v);
-                }
+                const int ci = 32 * bi + (r & 3) + 8 * (r >> 2), cj = 32 * bj;
+                const float v = g.t[GramAcc<NB>::tile(bi, bj)][r];
+                f(ci, cj, v, false);
+                if (bi != bj) f(ci, cj, v, true);
             }
 }
 
@@ -322,15 +321,49 @@ __device__ __forceinline__ void gram_store_sums(const GramAcc<NB> &g, int d, int
 }
 
 // one Gauss-Seidel sweep over the d coordinates of row `a` against M (LDS, stride kAlsDP) and s (LDS)
-__device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss, int d, float reg,
+// One Gauss-Seidel sweep over the d coordinates of row `a`, M held in registers: lane k keeps column k of the
+// symmetric M (= row k), so step f needs M[f][k] = mcol[f] -- a register picked by the unrolled loop index -- and the
+// only cross-lane traffic is the wave sum and two v_readlane.  (The first version re-read M from LDS every step: 475
+// cycles per step, latency bound; profiles/r01_n_probe_als_prof.txt.)
+//   FORM: mcol[i] = (1 - w) * G[i][lane] + w * S[i][lane] from the raw Gram in LDS and S in global memory (L1-resident);
+//   !FORM: sM already holds M.
+template <int DMAX, bool FORM>
+__device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss,
+                                              const float *__restrict__ S, int d, float one_w, float w, float reg,
                                               int lane) {
+    float mcol[DMAX];
+    if (FORM) {  // an opaque zero offset per call: keeps the 64 loads of S inside the row loop instead of 64 registers
+        int z;   // hoisted across the whole kernel (they are L1 hits; the registers are needed by the accumulation)
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+        S += z;
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < DMAX; i0 += 16) {  // 16 columns' worth of loads in flight at a time (register pressure)
+#pragma unroll
+        for (int i = i0; i < i0 + 16; i++) {
+            float m = 0.0f;
+            if (i < d && lane < d) {
+                m = sM[i * kAlsDP + lane];
+                if (FORM) m = one_w * m + w * S[i * d + lane];
+            }
+            mcol[i] = m;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     float p = lane < d ? a[lane] : 0.0f;
-    for (int f = 0; f < d; f++) {
-        const float m = lane < d ? sM[f * kAlsDP + lane] : 0.0f;  // M is symmetric: row f = column f
-        const float tot = wave_sum64(lane == f ? 0.0f : p * m);
-        const float mff = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), f));
-        const float nf = (ss[f] - tot) / (mff + reg);
-        if (lane == f) p = nf;
+    const int sreg = __float_as_int(lane < d ? ss[lane] : 0.0f);
+#pragma unroll
+    for (int f = 0; f < DMAX; f++) {
+        if (f < d) {  // uniform; no break, so that the loop unrolls and mcol[f] is a register
+            const float m = mcol[f];
+            const float tot = wave_sum64(lane == f ? 0.0f : p * m);
+            const float mff = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), f));
+            const float sf = __int_as_float(__builtin_amdgcn_readlane(sreg, f));
+            // v_rcp_f32 (1 ulp) instead of the 12-instruction IEEE division: this chain is what every step waits for,
+            // and the parity bar of ALS is 1e-4 relative (the summation order already differs from the reference's)
+            const float nf = (sf - tot) * __builtin_amdgcn_rcpf(mff + reg);
+            if (lane == f) p = nf;
+        }
     }
     if (lane < d) a[lane] = p;
 }
@@ -342,9 +375,14 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
                                                                  const int32_t *__restrict__ idx,
                                                                  const float *__restrict__ S,
                                                                  const int32_t *__restrict__ rows, int64_t n_rows, int d,
-                                                                 float w, float reg, const float *__restrict__ zeros) {
+                                                                 float w, float reg, const float *__restrict__ zeros,
+                                                                 unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // probe only (prof != null): s_memtime ticks per wave in [0] Gram accumulation, [1] M to LDS, [2] solve; [3] rows,
+    // [4] feedback entries, [5] kernel ticks, [6] waves
+    unsigned long long c_acc = 0, c_m = 0, c_solve = 0, c_rows = 0, c_ent = 0, t_begin = 0;
+    if (prof) t_begin = __builtin_amdgcn_s_memtime();
     float *sM = smem + (size_t)wv * (64 * kAlsDP + 64);
     float *ss = sM + 64 * kAlsDP;
     const float one_w = 1 - w;
@@ -354,17 +392,50 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
         const int64_t beg = ptr[u];
         const int n = (int)(ptr[u + 1] - beg);
         GramAcc<NB> g;
+        unsigned long long t0 = 0;
+        if (prof) t0 = __builtin_amdgcn_s_memtime();
         gram_accumulate<NB>(B, zeros, idx + beg, n, d, lane, g);
-        gram_foreach<NB>(g, d, lane, [&](int i, int j, float v) { sM[i * kAlsDP + j] = v; });
+        if (prof) {
+            // the accumulators are only complete once they are read: touch one so that the stamp waits for the MFMAs
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime() + (__float_as_int(g.t[0][0]) & 0);
+            c_acc += t1 - t0;
+            t0 = t1;
+        }
+        {   // rows / columns past d are zeros of the padded gathers: stored unconditionally (sM is 64 x kAlsDP), with
+            // immediate offsets from two lane-dependent bases
+            float *direct = sM + 4 * (lane >> 5) * kAlsDP + (lane & 31);
+            float *mirror = sM + (lane & 31) * kAlsDP + 4 * (lane >> 5);
+            gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
+                if (mir)
+                    mirror[cj * kAlsDP + ci] = v;
+                else
+                    direct[ci * kAlsDP + cj] = v;
+            });
+        }
         gram_store_sums<NB>(g, d, lane, ss);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < d; i++)  // M = (1 - w) G + w S, one row of M per step (S is L1/L2 resident)
-            if (lane < d) sM[i * kAlsDP + lane] = one_w * sM[i * kAlsDP + lane] + w * S[i * d + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (prof) {
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            c_m += t1 - t0;
+            t0 = t1;
+        }
+        als_solve_row<32 * NB, true>(A + u * d, sM, ss, S, d, one_w, w, reg, lane);
         __builtin_amdgcn_wave_barrier();
-        als_solve_row(A + u * d, sM, ss, d, reg, lane);
-        __builtin_amdgcn_wave_barrier();
+        if (prof) {
+            c_solve += __builtin_amdgcn_s_memtime() - t0;
+            c_rows++;
+            c_ent += n;
+        }
+    }
+    if (prof && lane == 0) {
+        atomicAdd(prof + 0, c_acc);
+        atomicAdd(prof + 1, c_m);
+        atomicAdd(prof + 2, c_solve);
+        atomicAdd(prof + 3, c_rows);
+        atomicAdd(prof + 4, c_ent);
+        atomicAdd(prof + 5, (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+        atomicAdd(prof + 6, 1ull);
     }
 }
 
@@ -383,7 +454,10 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
         GramAcc<NB> g;
         gram_accumulate<NB>(B, zeros, idx + chunk_beg[c], chunk_cnt[c], d, lane, g);
         float *dst = partial + c * stride;
-        gram_foreach<NB>(g, d, lane, [&](int i, int j, float v) { dst[i * d + j] = v; });
+        gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
+            const int i = ci + 4 * (lane >> 5), j = cj + (lane & 31);
+            if (i < d && j < d) dst[mir ? j * d + i : i * d + j] = v;
+        });
         gram_store_sums<NB>(g, d, lane, dst + (int64_t)d * d);
     }
 }
@@ -420,7 +494,7 @@ __global__ __launch_bounds__(256) void als_long_solve_kernel(float *__restrict__
                 ss[e - d * d] = acc;
         }
         __syncthreads();
-        if (threadIdx.x < 64) als_solve_row(A + (int64_t)rows[t] * d, sM, ss, d, reg, threadIdx.x);
+        if (threadIdx.x < 64) als_solve_row<64, false>(A + (int64_t)rows[t] * d, sM, ss, S, d, one_w, w, reg, threadIdx.x);
         __syncthreads();
     }
 }
@@ -470,11 +544,19 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
 }
 
 
+// probe: 8 counters per side in h->als_prof when the hook is on
+bool g_als_prof = false;
+unsigned long long *als_prof_slot(gorse_mf *h, int side) { return g_als_prof && h->als_prof.n >= 16 ? h->als_prof.p + 8 * side : nullptr; }
+
 int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int64_t *ptr, const int32_t *idx, float w,
                       float reg) {
     const int d = h->d;
     gorse_mf::AlsPlan &pl = h->als_plan[side];
     const size_t lds = (size_t)kAlsWaves * (64 * kAlsDP + 64) * sizeof(float);
+    if (g_als_prof) {
+        GORSE_TRY(h->als_prof.ensure(16));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->als_prof.p + 8 * side, 0, 8 * sizeof(unsigned long long), h->stream));
+    }
     int tok = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
     if (pl.n_short > 0) {
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_short, kAlsWaves), 512);  // 2 workgroups per CU
@@ -482,12 +564,12 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
             als_row_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p);
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side));
         } else {
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
             als_row_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p);
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side));
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }
@@ -634,6 +716,17 @@ extern "C" int32_t gorse_mf_rows_import(gorse_mf *h, int32_t side, int64_t begin
 }
 
 extern "C" void gorse_hip_test_set_als_path(int32_t path) { g_als_path = path; }
+// probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
+extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    g_als_prof = enable != 0;
+    if (!out16) return GORSE_OK;
+    if (h->als_prof.n < 16) return fail(GORSE_ERR_INVALID, "no profiled ALS sweep has run on this handle");
+    GORSE_TRY(h->use());
+    GORSE_HIP_CHECK(hipMemcpyAsync(out16, h->als_prof.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
 // takes effect for handles created afterwards (the row plan is built in gorse_mf_create)
 extern "C" void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk) {
     g_als_long_row = long_row > 0 ? long_row : 4096;

@@ -52,6 +52,7 @@ struct gorse_mf {
     } als_plan[2];
     std::vector<int64_t> h_uptr, h_iptr;      // host copies of the CSR row pointers (row plans are rebuilt from them)
     int64_t als_lo[2] = {0, 0}, als_hi[2] = {0, 0};  // row range of each side this handle solves (gorse_als_set_ranges)
+    gorse::DevBuf<unsigned long long> als_prof;  // probe: phase counters of als_row_kernel (gorse_hip_test_als_profile)
     gorse::DevBuf<float> als_zeros;    // 64 zero words: where padding lanes of the gathers read
     gorse::DevBuf<float> als_partial;  // n_chunks x (d*d + d) partial Gram matrices + column sums
     // generic staging

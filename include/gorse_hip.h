@@ -239,6 +239,10 @@ void gorse_hip_test_set_als_path(int32_t path);
  * are cut into chunks of `chunk` entries (defaults 4096 / 4096; <= 0 restores a default).  Lets small test
  * inputs exercise the long-row path. */
 void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk);
+/* probe: enable != 0 makes als_row_kernel stamp its phases with s_memtime; out16 (may be NULL) receives, for the last
+ * user half-sweep and then the last item half-sweep, ticks summed over the waves in [0] Gram accumulation (gathers +
+ * MFMA), [1] M to LDS, [2] the d-step solve, then [3] rows, [4] feedback entries, [5] kernel ticks, [6] waves, [7] 0. */
+int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16 /*host or NULL*/);
 /* the counting sort by positive item that precedes the item-run update kernel, on a host-supplied
  * chunk (n <= one chunk = 4M samples): su/si/sj receive the triplets in the order the kernel walks them
  * (per window of 32768 consecutive samples: ascending i, skipped samples last). */

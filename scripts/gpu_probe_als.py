@@ -48,7 +48,38 @@ def run(name, U, I, nnz, d, paths, reps=3):
     capi.lib().gorse_hip_test_set_als_path(0)
 
 
+def prof(name, U, I, nnz, d):
+    """phase counters of als_row_kernel (s_memtime) on one epoch"""
+    uptr, uidx, iptr, iidx = synth.s_als(U, I, nnz, 45)
+    P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 1)
+    mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx)
+    mf.set_factors(P, Q)
+    mf.als_epoch(0.001, 0.06)
+    mf.als_profile(True)
+    t0 = time.perf_counter()
+    mf.als_epoch(0.001, 0.06)
+    dt = time.perf_counter() - t0
+    c = mf.als_profile(False, fetch=True)
+    mf.als_epoch(0.001, 0.06)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        mf.als_epoch(0.001, 0.06)
+    plain = (time.perf_counter() - t0) / 3
+    print("%-18s epoch without stamps %.2f ms" % (name, plain * 1e3), flush=True)
+    for side, label in ((0, "user rows"), (1, "item rows (short)")):
+        a, m, s, rows, ent, tot, waves = c[8 * side:8 * side + 7]
+        waves = max(waves, 1)
+        print("%-18s %-18s rows %8d entries %10d | per wave: kernel %.3e ticks = accumulate %.1f%% + M to LDS %.1f%% + solve %.1f%% "
+              "| per row: accumulate %.0f, M %.0f, solve %.0f ticks; %.1f entries per row (epoch with stamps %.2f ms)"
+              % (name, label, rows, ent, tot / waves, 100.0 * a / max(tot, 1), 100.0 * m / max(tot, 1), 100.0 * s / max(tot, 1),
+                 a / max(rows, 1), m / max(rows, 1), s / max(rows, 1), ent / max(rows, 1), dt * 1e3), flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "prof":
+        prof("C5 d=64", 500_000, 100_000, 50_000_000, 64)
+        prof("C5 shard d=16", 125_000, 100_000, 12_500_000, 16)
+        return
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     run("small 20Kx10Kx1M", 20_000, 10_000, 1_000_000, 64, (1, 2))
     run("C5 shard/4 d=64", 125_000, 100_000, 12_500_000, 64, (2,) if quick else (1, 2), reps=2)

@@ -468,7 +468,6 @@ def test_als_row_sharded_equals_the_full_epoch(small, path, d, als_paths):
     # after every half-sweep the row blocks travel through device buffers (gorse_mf_rows_export / _import), the way
     # gorse_amd.dist.HipAlsEngine moves them through an RCCL all-gather.  Rows are independent inside a half-sweep,
     # so the result equals the unsharded epoch bit for bit.
-    import torch
     from gorse_amd import dist as gdist
     capi.lib().gorse_hip_test_set_als_path(path)
     capi.lib().gorse_hip_test_set_als_plan(48, 20)  # some long rows in every shard
@@ -481,6 +480,9 @@ def test_als_row_sharded_equals_the_full_epoch(small, path, d, als_paths):
         ur, ir = gdist.shard_range(small.U, r, world), gdist.shard_range(small.I, r, world)
         mf.als_set_ranges(ur[0], ur[1], ir[0], ir[1])
         shards.append((mf, (ur, ir)))
+    # the "wire": device memory of a handle that takes no part in the computation (its user-factor matrix)
+    wire = capi.MF(small.U, small.I, d, small.uptr, small.uidx)
+    wire_ptr = wire.device_ptrs()[0]
     rows = (small.U, small.I)
     for _ in range(2):
         full.als_epoch(0.05, 0.015)
@@ -489,12 +491,11 @@ def test_als_row_sharded_equals_the_full_epoch(small, path, d, als_paths):
                 mf.als_half_epoch(side, 0.05, 0.015)
             for r, (src, rng_) in enumerate(shards):  # "all-gather": every block to every other handle
                 lo, hi = rng_[side]
-                buf = torch.empty((hi - lo) * d, dtype=torch.float32, device="cuda")
-                src.rows_export(side, lo, hi, buf.data_ptr())
-                torch.cuda.synchronize()
+                assert (hi - lo) <= small.U  # fits the wire buffer (U x d floats)
+                src.rows_export(side, lo, hi, wire_ptr)
                 for r2, (dst, _) in enumerate(shards):
                     if r2 != r:
-                        dst.rows_import(side, lo, hi, buf.data_ptr())
+                        dst.rows_import(side, lo, hi, wire_ptr)
     fP, fQ = full.get_factors()
     for mf, _ in shards:
         gP, gQ = mf.get_factors()
