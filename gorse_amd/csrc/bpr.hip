@@ -541,21 +541,27 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         const int beg = off[u], end = off[u + 1];
         if (beg >= end) continue;
         float *pu = P + u * d;
-        float p[NC], a[NC], b[NC], an[NC], bn[NC];
+        // item rows are gathered TWO samples ahead of the arithmetic (a/b: this sample, a1/b1: the next, a2/b2 in
+        // flight); positions past the run's end re-read the last sample's rows (result unused)
+        float p[NC], a[NC], b[NC], a1[NC], b1[NC], a2[NC], b2[NC];
+        const int last = end - 1;
         int i = si[beg], j = sj[beg];
+        int i1 = si[beg + 1 <= last ? beg + 1 : last], j1 = sj[beg + 1 <= last ? beg + 1 : last];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
             a[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i * d + 16 * c + lane);
             b[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j * d + 16 * c + lane);
+            a1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i1 * d + 16 * c + lane);
+            b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j1 * d + 16 * c + lane);
         }
         for (int s = beg; s < end; s++) {
-            const int sn = s + 1 < end ? s + 1 : s;  // the last iteration re-reads its own rows (result unused)
-            const int in = si[sn], jn = sj[sn];
+            const int s2 = s + 2 <= last ? s + 2 : last;
+            const int i2 = si[s2], j2 = sj[s2];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                an[c] = load_row<MODE_ATOMIC>(Q + (int64_t)in * d + 16 * c + lane);
-                bn[c] = load_row<MODE_ATOMIC>(Q + (int64_t)jn * d + 16 * c + lane);
+                a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i2 * d + 16 * c + lane);
+                b2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j2 * d + 16 * c + lane);
             }
             float *qi = Q + (int64_t)i * d, *qj = Q + (int64_t)j * d;
             if (hot.n_hot > 0) {
@@ -575,11 +581,15 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
                 __hip_atomic_fetch_add(qi + e, t1 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_fetch_add(qj + e, t2 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 p[c] = fmaf(t3, lr, p[c]);
-                a[c] = an[c];
-                b[c] = bn[c];
+                a[c] = a1[c];
+                b[c] = b1[c];
+                a1[c] = a2[c];
+                b1[c] = b2[c];
             }
-            i = in;
-            j = jn;
+            i = i1;
+            j = j1;
+            i1 = i2;
+            j1 = j2;
         }
 #pragma unroll
         for (int c = 0; c < NC; c++)  // the only writer of this row in the launch

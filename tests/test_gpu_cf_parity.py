@@ -289,28 +289,35 @@ def test_evaluate_through_device_rank(oracle, small):
     assert np.array_equal(bits(got), bits(exp))
 
 
-def _ndcg_run(oracle, mode, variant=0):
+def _ndcg_run(oracle, mode, variant=0, seeds=(2024, 7, 99)):
+    """NDCG@10 after 10 epochs, averaged over independent sampler seeds, for the sequential oracle and for the device
+    schedule.  A Hogwild epoch is not reproducible run to run (the order in which concurrent updates land is up to the
+    hardware), and a single seed's NDCG moves by up to ~0.01 between runs (one outlier of 0.014 in
+    profiles/r01_p_pytest_cf.log); the mean over three seeds is what the +-0.01 bar is applied to."""
     data = synth.s_ml100k()
     d, lr, reg, epochs = 16, 0.05, 0.01, 10
     P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
-    P, Q = P0.copy(), Q0.copy()
     srt = orc.sort_rows(data.uptr, data.uidx)
-    for ep in range(1, epochs + 1):  # oracle: sequential (Jobs = 1) epochs on the same sampler stream
-        oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, 2024, ep, 0, data.n_train, lr, reg)
-    ref = evaluate_ndcg(oracle, data, P, Q)
-    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
-    mf.set_factors(P0, Q0)
-    capi.lib().gorse_hip_test_set_variant(variant)
-    try:
-        for ep in range(1, epochs + 1):
-            mf.bpr_epoch(data.n_train, lr, reg, 2024, ep, mode=mode)
-    finally:
-        capi.lib().gorse_hip_test_set_variant(0)
-    gP, gQ = mf.get_factors()
-    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
-    got = evaluate_ndcg(oracle, data, gP, gQ)
-    print("NDCG oracle %.4f device(mode %d) %.4f" % (ref[0], mode, got[0]))
-    return float(ref[0]), float(got[0])
+    refs, gots = [], []
+    for seed in seeds:
+        P, Q = P0.copy(), Q0.copy()
+        for ep in range(1, epochs + 1):  # oracle: sequential (Jobs = 1) epochs on the same sampler stream
+            oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, seed, ep, 0, data.n_train, lr, reg)
+        refs.append(float(evaluate_ndcg(oracle, data, P, Q)[0]))
+        mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+        mf.set_factors(P0, Q0)
+        capi.lib().gorse_hip_test_set_variant(variant)
+        try:
+            for ep in range(1, epochs + 1):
+                mf.bpr_epoch(data.n_train, lr, reg, seed, ep, mode=mode)
+        finally:
+            capi.lib().gorse_hip_test_set_variant(0)
+        gP, gQ = mf.get_factors()
+        assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+        gots.append(float(evaluate_ndcg(oracle, data, gP, gQ)[0]))
+        mf.close()
+    print("NDCG oracle %s device(mode %d, variant %d) %s" % (refs, mode, variant, gots))
+    return float(np.mean(refs)), float(np.mean(gots))
 
 
 def test_bpr_hogwild_ndcg_parity_ml100k(oracle):
