@@ -64,6 +64,21 @@ def run_als_epoch(engine, comm, weight, reg):
             engine.import_blocks(side, gathered)
 
 
+def evaluate_sharded(engine, comm, topk, metrics=("ndcg", "precision", "recall")):
+    """Evaluate (model/cf/evaluator.go:35-72) over user shards: every rank is one parallel.Parallel worker with its
+    partial sums (partSum[workerId]) and partial count, the partials are added across ranks (one all-reduce of
+    len(metrics) + 1 floats) and scaled by 1 / count -- the reference's own reduction, with ranks for workers.
+    engine.eval_partial(topk, metrics) -> (float32 sums, float32 count) over the users this rank owns."""
+    sums, count = engine.eval_partial(topk, metrics)
+    t = np.array([float(x) for x in sums] + [float(count)], np.float32)
+    if comm is not None and comm.world > 1:
+        import torch
+        tt = torch.from_numpy(t).to(getattr(engine, "device", "cpu"))
+        comm.all_reduce_sum(tt)
+        t = tt.cpu().numpy()
+    return (t[:-1] * np.float32(1.0) / t[-1]).astype(np.float32) if t[-1] > 0 else np.full(len(metrics), np.nan, np.float32)
+
+
 class TorchComm:
     """torch.distributed plumbing (backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' in the CPU tests)."""
 
@@ -92,12 +107,13 @@ class HipEngine:
     """A gorse_mf handle + a torch CUDA buffer that carries the item-factor delta through RCCL."""
 
     def __init__(self, mf, mode):
-        import torch
-        self.torch = torch
         self.mf, self.mode = mf, mode
         self.xbuf = None
+        self.torch = None  # imported only when a collective is needed (single-GPU use never touches torch)
 
     def enable_exchange(self):
+        import torch
+        self.torch = torch
         self.xbuf = self.torch.empty(self.mf.I * self.mf.d, dtype=self.torch.float32, device="cuda")
         self.mf.item_sync_mark()
         self.mf.synchronize()
@@ -108,6 +124,20 @@ class HipEngine:
     def export_delta(self):
         self.mf.item_delta_export(self.xbuf.data_ptr())  # synchronises the library's stream
         return self.xbuf
+
+    def set_eval(self, test_ptr, test_idx, neg_ptr, neg_idx):
+        """test split of THIS rank's users (local user ids): positives + sampled negatives per user"""
+        self.device = "cuda"
+        self.eval_split = (np.asarray(test_ptr, np.int64), np.asarray(test_idx, np.int32),
+                           np.asarray(neg_ptr, np.int64), np.asarray(neg_idx, np.int32))
+
+    def eval_partial(self, topk, metrics):
+        from . import metrics as M
+        test_ptr, test_idx, neg_ptr, neg_idx = self.eval_split
+        users = np.nonzero(np.diff(test_ptr) > 0)[0].astype(np.int32)
+        cptr, cidx = M.candidates(test_ptr, test_idx, neg_ptr, neg_idx, users)
+        rank, rlen = self.mf.rank(users, cptr, cidx, topk)  # Rank + heap.TopKFilter on the device
+        return M.partial_sums(rank, rlen, users, test_ptr, test_idx, metrics)
 
     def import_delta(self, delta):
         self.torch.cuda.synchronize()  # the collective ran on torch's stream

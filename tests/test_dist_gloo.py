@@ -177,3 +177,59 @@ def test_row_sharded_als_equals_the_single_process_epoch(tmp_path, world):
     for r in range(world):  # rows are independent inside a half-sweep: sharding changes nothing, bit for bit
         assert np.array_equal(np.load(tmp_path / ("alsP%d.npy" % r)), eP)
         assert np.array_equal(np.load(tmp_path / ("alsQ%d.npy" % r)), eQ)
+
+
+# ---- sharded Evaluate (gorse_amd.dist.evaluate_sharded) ---------------------------------------------------------
+class OracleEvalEngine:
+    """CPU stand-in for HipEngine.eval_partial: rank lists from the oracle's Rank, metric arithmetic and partial sums from
+    gorse_amd.metrics (the code the GPU path runs on the host)."""
+
+    def __init__(self, P_local, Q, test_ptr, test_idx, neg_ptr, neg_idx):
+        from oracle import oracle as orc
+        self.o = orc.Oracle()
+        self.P, self.Q = P_local, Q
+        self.split = (test_ptr, test_idx, neg_ptr, neg_idx)
+
+    def eval_partial(self, topk, metrics):
+        from gorse_amd import metrics as M
+        test_ptr, test_idx, neg_ptr, neg_idx = self.split
+        users = np.nonzero(np.diff(test_ptr) > 0)[0].astype(np.int32)
+        cptr, cidx = M.candidates(test_ptr, test_idx, neg_ptr, neg_idx, users)
+        rank, rlen = self.o.mf_rank(self.P, self.Q, users, cptr, cidx, topk)
+        return M.partial_sums(rank, rlen, users, test_ptr, test_idx, metrics)
+
+
+def _eval_problem():
+    data = synth.synth_cf(151, 90, 3000, seed=8, min_len=3, n_neg=30)
+    P, Q = synth.init_factors(data.U, data.I, 16, 0.0, 0.3, 6)
+    return data, P, Q
+
+
+def _eval_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data, P, Q = _eval_problem()
+    lo, hi = gdist.shard_range(data.U, rank, world)
+    tp, ti = gdist.shard_csr(data.test_ptr, data.test_idx, lo, hi)
+    npr, ni = gdist.shard_csr(data.neg_ptr, data.neg_idx, lo, hi)
+    eng = OracleEvalEngine(P[lo:hi], Q, tp, ti, npr, ni)
+    score = gdist.evaluate_sharded(eng, gdist.TorchComm(), 10)
+    np.save(os.path.join(out, "eval%d.npy" % rank), score)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_evaluate_equals_evaluate(tmp_path, world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_eval_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as orc
+    data, P, Q = _eval_problem()
+    ref = orc.Oracle().evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)
+    for r in range(world):  # every rank holds the same NDCG / Precision / Recall; worker-partial sums as in the reference
+        got = np.load(tmp_path / ("eval%d.npy" % r))
+        assert np.allclose(got, ref, atol=2e-6), (got, ref)
+    assert np.array_equal(np.load(tmp_path / "eval0.npy"), np.load(tmp_path / ("eval%d.npy" % (world - 1))))

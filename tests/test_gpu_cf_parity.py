@@ -380,6 +380,22 @@ def test_bpr_user_runs_equal_the_sequential_result_when_items_are_disjoint(oracl
     assert np.array_equal(bits(gQ[~touched]), bits(Q[~touched]))  # nothing else moved
 
 
+def test_evaluate_on_device_ranks_equals_the_oracle(oracle):
+    """gorse_amd.dist.evaluate_sharded on one rank: Rank + TopKFilter on the device (gorse_mf_rank), metric arithmetic
+    and worker-partial sums on the host (gorse_amd.metrics) = Evaluate (evaluator.go:35-72)."""
+    from gorse_amd import dist as gdist
+    data = synth.s_ml100k()
+    d = 16
+    P, Q = synth.init_factors(data.U, data.I, d, 0.0, 0.3, 5)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P, Q)
+    eng = gdist.HipEngine(mf, capi.BPR_HOGWILD_ATOMIC)
+    eng.set_eval(data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx)
+    got = gdist.evaluate_sharded(eng, None, 10)
+    ref = oracle.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)
+    assert np.allclose(got, ref, atol=2e-6), (got, ref)
+
+
 def test_bpr_racy_schedule_is_diagnostic_only(oracle):
     """GORSE_BPR_HOGWILD_RACY (load / fma / write-through store) loses concurrent updates when
     ~10^5 samples are in flight; it exists to price the atomics and is never used by Fit.  It must
