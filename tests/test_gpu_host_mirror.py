@@ -40,11 +40,11 @@ def assert_model_contract(m, train_data, oracle):
     assert m.Invalid()
 
 
-def oracle_bpr_ndcg(oracle, data, d, lr, reg, epochs, std, seed=3):
+def oracle_bpr_ndcg(oracle, data, d, lr, reg, epochs, std, seed=3, sampler_seed=77):
     P, Q = synth.init_factors(data.U, data.I, d, 0.0, std, seed)
     srt = orc.sort_rows(data.uptr, data.uidx)
     for ep in range(1, epochs + 1):
-        oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, 77, ep, 0, data.n_train, lr, reg)
+        oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, sampler_seed, ep, 0, data.n_train, lr, reg)
     return float(oracle.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)[0])
 
 
@@ -52,11 +52,17 @@ def test_bpr_fit_like_TestBPR_MovieLens(oracle):
     # model_test.go:35-48 hyper-parameters (nFactors 8, reg .01, lr .05, 30 epochs, init N(0, .001))
     data = synth.s_ml100k()
     train, test = cf.datasets_from_synth(data)
-    m = cf.NewBPR({"NFactors": 8, "Reg": 0.01, "Lr": 0.05, "NEpochs": 30, "InitMean": 0, "InitStdDev": 0.001})
-    score = m.Fit(train, test, new_fit_config())
-    ref = oracle_bpr_ndcg(oracle, data, 8, 0.05, 0.01, 30, 0.001)
-    print("BPR NDCG device %.4f oracle %.4f" % (score.NDCG, ref))
-    assert abs(score.NDCG - ref) < 0.01
+    # a Hogwild fit is not reproducible run to run (see tests/test_gpu_cf_parity.py::_ndcg_run): the bar is applied to
+    # the mean over two fits with different RandomState, like the reference's own test compares with a constant
+    scores = []
+    for state in (0, 1):
+        m = cf.NewBPR({"NFactors": 8, "Reg": 0.01, "Lr": 0.05, "NEpochs": 30, "InitMean": 0, "InitStdDev": 0.001,
+                       "RandomState": state})
+        score = m.Fit(train, test, new_fit_config())
+        scores.append(score.NDCG)
+    refs = [oracle_bpr_ndcg(oracle, data, 8, 0.05, 0.01, 30, 0.001, seed=3 + r, sampler_seed=77 + r) for r in range(2)]
+    print("BPR NDCG device %s oracle %s" % (scores, refs))
+    assert abs(float(np.mean(scores)) - float(np.mean(refs))) < 0.01
     assert m.epochs_done == 30 and "fit bpr 30/30" in m.log
     assert_model_contract(m, data, oracle)
 
