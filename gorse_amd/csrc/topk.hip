@@ -22,27 +22,6 @@ __global__ void expand_bf16_kernel(const uint16_t *__restrict__ in, float *__res
         out[t] = __uint_as_float((uint32_t)in[t] << 16);
 }
 
-// floats.Euclidean (squared part) in AVX512 order for rows staged in LDS: floats_avx512.c:374-441
-__device__ __forceinline__ float euclid512_lds(const float *a, const float *b, const VecShape &vs, int lane) {
-    float acc = 0.0f;
-    for (int c = 0; c < vs.nfull; c++) {
-        float v = a[16 * c + lane] - b[16 * c + lane];
-        v = v * v;
-        acc = c == 0 ? v : v + acc;
-    }
-    float sum = group_tree16(acc);
-    if (vs.has8) {
-        int e = vs.nfull * 16 + (lane & 7);
-        float v = a[e] - b[e];
-        sum += group_tree8(v * v);
-    }
-    for (int e = vs.tail0; e < vs.d; e++) {
-        float v = a[e] - b[e];
-        sum = fmaf(v, v, sum);
-    }
-    return sqrtf(sum);
-}
-
 // norm2[i] = floats.Dot(x_i, x_i)
 __global__ __launch_bounds__(kBlock) void norm2_kernel(const float *__restrict__ X, int64_t n, int d,
                                                        float *__restrict__ out) {

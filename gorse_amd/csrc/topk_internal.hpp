@@ -54,6 +54,27 @@ struct gorse_topk {
 };
 
 namespace gorse {
+// floats.Euclidean (squared part) in AVX512 order for rows staged in LDS: floats_avx512.c:374-441
+__device__ __forceinline__ float euclid512_lds(const float *a, const float *b, const VecShape &vs, int lane) {
+    float acc = 0.0f;
+    for (int c = 0; c < vs.nfull; c++) {
+        float v = a[16 * c + lane] - b[16 * c + lane];
+        v = v * v;
+        acc = c == 0 ? v : v + acc;
+    }
+    float sum = group_tree16(acc);
+    if (vs.has8) {
+        int e = vs.nfull * 16 + (lane & 7);
+        float v = a[e] - b[e];
+        sum += group_tree8(v * v);
+    }
+    for (int e = vs.tail0; e < vs.d; e++) {
+        float v = a[e] - b[e];
+        sum = fmaf(v, v, sum);
+    }
+    return sqrtf(sum);
+}
+
 // topk.hip
 int32_t topk_compute_norms(gorse_topk *h, const float *V, int64_t n, float *out);
 // path A on queries whose fp32 rows sit in h->qbuf (nq x d) [+ h->qnorm]; qidx_dev = exclusion ids or null.

@@ -81,6 +81,7 @@ struct SweepParams {
     int kth;
     int compact_at;        // a sub-list longer than this triggers the compaction of its query (<= kCompactAt / 2)
     int coarse;            // cosine: reject a 32-row block on max(raw score) x (block's extreme row scale) first
+    int bias;              // Euclidean: the per-candidate value (-|x|^2 / 2) is ADDED to the score instead of multiplied
     unsigned long long *prof;  // PROF instantiations: 8 cycle / event counters summed over all waves
 };
 
@@ -307,10 +308,17 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const float4 s = r4[2 * g + (lane >> 5)];
-                        acc[cb][4 * g + 0] *= s.x;
-                        acc[cb][4 * g + 1] *= s.y;
-                        acc[cb][4 * g + 2] *= s.z;
-                        acc[cb][4 * g + 3] *= s.w;
+                        if (p.bias) {  // q.x - |x|^2 / 2 = (|q|^2 - |q - x|^2) / 2: same order as the distance
+                            acc[cb][4 * g + 0] += s.x;
+                            acc[cb][4 * g + 1] += s.y;
+                            acc[cb][4 * g + 2] += s.z;
+                            acc[cb][4 * g + 3] += s.w;
+                        } else {
+                            acc[cb][4 * g + 0] *= s.x;
+                            acc[cb][4 * g + 1] *= s.y;
+                            acc[cb][4 * g + 2] *= s.z;
+                            acc[cb][4 * g + 3] *= s.w;
+                        }
                     }
                 };
                 if (SCALE && !coarse) scale_rows();
@@ -472,13 +480,17 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
         float *row = sx + (size_t)gib * d;
         for (int e = lane; e < d; e += kGroup) row[e] = p.X[i * d + e];
         __builtin_amdgcn_wave_barrier();
-        const float ab = dot512_lds(sq, row, vs, lane);
-        __builtin_amdgcn_wave_barrier();
         float r;
-        if (p.metric == GORSE_METRIC_NEG_DOT)
-            r = -ab;
-        else
-            r = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+        if (p.metric == GORSE_METRIC_EUCLIDEAN) {
+            r = euclid512_lds(sq, row, vs, lane);
+        } else {
+            const float ab = dot512_lds(sq, row, vs, lane);
+            if (p.metric == GORSE_METRIC_NEG_DOT)
+                r = -ab;
+            else
+                r = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+        }
+        __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             s_e[c] = r;
             s_i[c] = (int)i;
@@ -602,13 +614,17 @@ __global__ __launch_bounds__(kBlock) void topk_tie_sort_kernel(ReplayParams p) {
         float *xr = sx + (size_t)gib * d;
         for (int e = lane; e < d; e += kGroup) xr[e] = p.X[i * d + e];
         __builtin_amdgcn_wave_barrier();
-        const float ab = dot512_lds(sq, xr, vs, lane);
-        __builtin_amdgcn_wave_barrier();
         float r;
-        if (p.metric == GORSE_METRIC_NEG_DOT)
-            r = -ab;
-        else
-            r = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+        if (p.metric == GORSE_METRIC_EUCLIDEAN) {
+            r = euclid512_lds(sq, xr, vs, lane);
+        } else {
+            const float ab = dot512_lds(sq, xr, vs, lane);
+            if (p.metric == GORSE_METRIC_NEG_DOT)
+                r = -ab;
+            else
+                r = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+        }
+        __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             s_idx[c] = (int)i;
             s_dst[c] = r;
@@ -926,6 +942,22 @@ __global__ void gather_queries_kernel(const uint16_t *__restrict__ opB, const fl
     for (int e = threadIdx.x; e < kpad / 8; e += blockDim.x) o[e] = s[e];
     if (threadIdx.x == 0) qn2[t] = norm2[src];
 }
+// Euclidean: score = q.x - |x|^2 / 2 stands for (|q|^2 - d^2) / 2 with d = the reference's floats.Euclidean.  Its error
+// against that quantity: the dot product's (coef |q| |x|), the fp32 norm in the bias (d u |x|^2 / 2) and the
+// reference's own rounding of the sum of squares and the square root ((d + 8) u (|q| + |x|)^2 / 2); margin = 2 x that.
+__global__ void margin_euclid_kernel(const float *__restrict__ qn2, int64_t nq, float coef, float xmax, float du,
+                                     float *__restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq; t += (int64_t)gridDim.x * blockDim.x) {
+        const float qn = sqrtf(qn2[t]);
+        const float u = 5.9604645e-8f;  // 2^-24; the + 4u also covers the rounding of the bias addition itself
+        const float delta = coef * qn * xmax + 0.5f * (du + 4.0f * u) * xmax * xmax + 0.5f * (du + 8.0f * u) * (qn + xmax) * (qn + xmax);
+        out[t] = 2.0f * delta * 1.01f + 1e-30f;
+    }
+}
+__global__ void bias_kernel(const float *__restrict__ norm2, int64_t n, float *__restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        out[t] = -0.5f * norm2[t];
+}
 __global__ void margin_kernel(const float *__restrict__ qn2, int64_t nq, float coef, float other,
                               float *__restrict__ out) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq; t += (int64_t)gridDim.x * blockDim.x)
@@ -1004,7 +1036,8 @@ bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k) {
 
 int32_t topk_mfma_prepare(gorse_topk *h) {
     h->mfma_ok = false;
-    if (h->metric != GORSE_METRIC_NEG_DOT && h->metric != GORSE_METRIC_COSINE) return GORSE_OK;
+    if (h->metric != GORSE_METRIC_NEG_DOT && h->metric != GORSE_METRIC_COSINE && h->metric != GORSE_METRIC_EUCLIDEAN)
+        return GORSE_OK;
     const int64_t N = h->N;
     const int d = h->d;
     const bool bf = h->dtype == GORSE_DTYPE_BF16;
@@ -1057,6 +1090,11 @@ int32_t topk_mfma_prepare(gorse_topk *h) {
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }
+    if (h->metric == GORSE_METRIC_EUCLIDEAN) {  // per-candidate bias -|x|^2 / 2 in the slot the cosine scale uses
+        GORSE_TRY(h->rscale.alloc((size_t)N));
+        bias_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->norm2.p, N, h->rscale.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
     if (h->metric == GORSE_METRIC_COSINE) {
         GORSE_TRY(h->rscale.alloc((size_t)N));
         rscale_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->norm2.p, N, h->rscale.p);
@@ -1076,8 +1114,9 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     const int kth = k + (exclude_self ? 1 : 0);
     const int64_t admissible = h->N - (exclude_self ? 1 : 0);
     const int64_t expect = std::min<int64_t>(k, admissible);
-    const bool scale = h->metric == GORSE_METRIC_COSINE;
-    const float other = scale ? 1.0f : h->max_norm;
+    const bool euclid = h->metric == GORSE_METRIC_EUCLIDEAN;
+    const bool scale = h->metric == GORSE_METRIC_COSINE || euclid;  // a per-candidate value enters the epilogue
+    const float other = h->metric == GORSE_METRIC_COSINE ? 1.0f : h->max_norm;
     const int64_t mb = std::min(nq, kChunkQ);
     GORSE_TRY(h->cbuf.ensure((size_t)mb * kCap));
     GORSE_TRY(h->ccnt.ensure((size_t)mb));
@@ -1120,8 +1159,12 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             Bop = h->opQ.p;
             qn2 = h->qn2.p;
         }
-        margin_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
-            qn2, m, h->err_coef, other, h->qmargin.p);
+        if (euclid)
+            margin_euclid_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
+                qn2, m, h->err_coef, h->max_norm, (float)(d * 5.9604645e-8), h->qmargin.p);
+        else
+            margin_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
+                qn2, m, h->err_coef, other, h->qmargin.p);
         GORSE_HIP_CHECK(hipGetLastError());
         GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
         SweepParams sp;
@@ -1134,7 +1177,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.cflag = h->cflag.p;
         sp.hbuf = nullptr;
         sp.hcnt = nullptr;
-        sp.coarse = (g_topk_variant & 4) ? 0 : ((g_topk_variant & 8) ? 1 : (h->coarse_ok ? 1 : 0));
+        sp.coarse = euclid ? 0 : ((g_topk_variant & 4) ? 0 : ((g_topk_variant & 8) ? 1 : (h->coarse_ok ? 1 : 0)));
+        sp.bias = euclid ? 1 : 0;
         sp.compact_at = (g_topk_variant & 32) ? 128 : ((g_topk_variant & 64) ? 96 : kCompactAt / 2);
         sp.prof = nullptr;
         if (g_topk_variant & 16) {
