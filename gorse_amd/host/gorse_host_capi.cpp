@@ -5,6 +5,7 @@
 #include <sstream>
 
 #include "gorse_cf.hpp"
+#include "gorse_vectors.hpp"
 
 using namespace gorse;
 
@@ -18,6 +19,15 @@ int32_t guard(F &&f) {
     } catch (const HipError &e) {
         g_err = e.what();
         return e.code;
+    } catch (const storage::ErrNotFound &e) {
+        g_err = e.what();
+        return -201;
+    } catch (const storage::ErrAlreadyExists &e) {
+        g_err = e.what();
+        return -202;
+    } catch (const storage::ErrNotSupported &e) {
+        g_err = e.what();
+        return -203;
     } catch (const std::out_of_range &e) {
         g_err = e.what();
         return GORSE_ERR_RANGE;
@@ -216,5 +226,158 @@ int32_t gh_bruteforce_search_vector(void *b, const float *q, int32_t d, int32_t 
         *cnt = (int32_t)r.size();
         for (size_t t = 0; t < r.size(); t++) idx[t] = r[t].first, dist[t] = r[t].second;
     });
+}
+
+// ---- vectors.Database ("hip://") ----------------------------------------------------------------------
+// Vectors cross the boundary one field at a time through a thread-local staging list: *_stage_* fill it before
+// AddVectors, GetVectors / QueryVectors leave their results in it for the gh_vdb_result_* readers.
+namespace {
+typedef int32_t (*gh_search_cb)(const float *X, int64_t n, int32_t d, int32_t metric, const float *Q, int64_t nq, int32_t k,
+                                int32_t *idx, float *dist, int32_t *cnt);
+struct CallbackSearcher : vectors::Searcher {  // the CPU test-suite's checker (an exact search built on the oracle)
+    gh_search_cb cb;
+    explicit CallbackSearcher(gh_search_cb c) : cb(c) {}
+    void invalidate(const std::string &) override {}
+    void search(const std::string &, const float *X, int64_t n, int d, int metric, const float *Q, int64_t nq, int k,
+                int32_t *idx, float *dist, int32_t *cnt) override {
+        if (cb(X, n, d, metric, Q, nq, k, idx, dist, cnt) != 0) throw std::runtime_error("search callback failed");
+    }
+};
+struct VdbHandle {
+    std::shared_ptr<vectors::HipDatabase> db;
+};
+thread_local std::vector<vectors::ScoredVector> g_stage;
+thread_local std::vector<int64_t> g_stage_split;  // batch queries: result t is g_stage[split[t] .. split[t+1])
+std::vector<std::string> split_lines(const char *s) {
+    std::vector<std::string> out;
+    if (!s || !*s) return out;
+    std::string cur;
+    for (const char *p = s;; p++) {
+        if (*p == '\n' || *p == 0) {
+            out.push_back(cur);
+            cur.clear();
+            if (*p == 0) break;
+        } else {
+            cur.push_back(*p);
+        }
+    }
+    return out;
+}
+vectors::HipDatabase &vdb(void *h) { return *((VdbHandle *)h)->db; }
+}  // namespace
+
+void *gh_vdb_open(const char *url) {
+    void *out = nullptr;
+    guard([&] { out = new VdbHandle{vectors::Open(url)}; });
+    return out;
+}
+void *gh_vdb_open_with_searcher(gh_search_cb cb) {
+    return new VdbHandle{std::make_shared<vectors::HipDatabase>(std::make_shared<CallbackSearcher>(cb))};
+}
+void gh_vdb_free(void *h) { delete (VdbHandle *)h; }
+int32_t gh_vdb_close(void *h) { return guard([&] { vdb(h).Close(); }); }
+int32_t gh_vdb_add_collection(void *h, const char *name, int32_t dim, int32_t distance, const char *qtype, int32_t bits) {
+    return guard([&] {
+        vectors::VectorConfig cfg;
+        cfg.Type = qtype ? qtype : "";
+        cfg.Bits = bits;
+        vdb(h).AddCollection(name, dim, (vectors::Distance)distance, cfg);
+    });
+}
+int32_t gh_vdb_delete_collection(void *h, const char *name) { return guard([&] { vdb(h).DeleteCollection(name); }); }
+int32_t gh_vdb_describe(void *h, const char *name, int32_t *dim, int32_t *distance, int32_t *bits) {
+    return guard([&] {
+        auto info = vdb(h).DescribeCollection(name);
+        *dim = info.Dimension;
+        *distance = (int32_t)info.Dist;
+        *bits = info.Config.Bits;
+    });
+}
+// '\n'-joined names into buf (NUL-terminated); returns the length needed or a negative error
+int64_t gh_vdb_list(void *h, char *buf, int64_t cap) {
+    std::string joined;
+    int32_t rc = guard([&] {
+        for (auto &n : vdb(h).ListCollections()) joined += (joined.empty() ? "" : "\n") + n;
+    });
+    if (rc != 0) return rc;
+    if ((int64_t)joined.size() + 1 <= cap) std::memcpy(buf, joined.c_str(), joined.size() + 1);
+    return (int64_t)joined.size() + 1;
+}
+int64_t gh_vdb_count(void *h, const char *name) {
+    int64_t n = 0;
+    int32_t rc = guard([&] { n = vdb(h).CountVectors(name); });
+    return rc != 0 ? rc : n;
+}
+void gh_vdb_stage_clear() {
+    g_stage.clear();
+    g_stage_split.clear();
+}
+void gh_vdb_stage_vector(const char *id, const float *values, int32_t n_values, const uint32_t *indices, int32_t n_indices,
+                         int32_t hidden, const char *categories, int64_t timestamp_ms) {
+    vectors::ScoredVector v;
+    v.Id = id;
+    v.Values.assign(values, values + n_values);
+    if (n_indices > 0) v.Indices.assign(indices, indices + n_indices);
+    v.IsHidden = hidden != 0;
+    v.Categories = split_lines(categories);
+    v.TimestampMs = timestamp_ms;
+    g_stage.push_back(std::move(v));
+}
+int32_t gh_vdb_add_staged(void *h, const char *name) {
+    return guard([&] {
+        std::vector<vectors::Vector> vs(g_stage.begin(), g_stage.end());
+        g_stage.clear();
+        vdb(h).AddVectors(name, vs);
+    });
+}
+int32_t gh_vdb_get(void *h, const char *name, const char *ids) {
+    return guard([&] {
+        gh_vdb_stage_clear();
+        for (auto &v : vdb(h).GetVectors(name, split_lines(ids))) {
+            vectors::ScoredVector s;
+            static_cast<vectors::Vector &>(s) = v;
+            g_stage.push_back(std::move(s));
+        }
+    });
+}
+int32_t gh_vdb_delete_vectors(void *h, const char *name, int64_t timestamp_ms) {
+    return guard([&] { vdb(h).DeleteVectors(name, timestamp_ms); });
+}
+// the query is the LAST staged vector (Values, or Indices for the sparse refusal); results replace the staging list
+int32_t gh_vdb_query_staged(void *h, const char *name, const char *categories, int32_t topk) {
+    return guard([&] {
+        if (g_stage.empty()) throw std::invalid_argument("no staged query vector");
+        vectors::Vector q = g_stage.back();
+        gh_vdb_stage_clear();
+        g_stage = vdb(h).QueryVectors(name, q, split_lines(categories), topk);
+    });
+}
+int32_t gh_vdb_query_batch(void *h, const char *name, const float *Q, int64_t nq, int32_t d, const char *categories,
+                           int32_t topk) {
+    return guard([&] {
+        gh_vdb_stage_clear();
+        auto res = vdb(h).QueryVectorsBatch(name, std::vector<float>(Q, Q + nq * d), nq, split_lines(categories), topk);
+        g_stage_split.push_back(0);
+        for (auto &r : res) {
+            for (auto &v : r) g_stage.push_back(std::move(v));
+            g_stage_split.push_back((int64_t)g_stage.size());
+        }
+    });
+}
+int64_t gh_vdb_result_count() { return (int64_t)g_stage.size(); }
+int64_t gh_vdb_result_split(int64_t t) { return t >= 0 && t < (int64_t)g_stage_split.size() ? g_stage_split[(size_t)t] : -1; }
+const char *gh_vdb_result_id(int64_t r) { return g_stage[(size_t)r].Id.c_str(); }
+float gh_vdb_result_score(int64_t r) { return g_stage[(size_t)r].Score; }
+int32_t gh_vdb_result_hidden(int64_t r) { return g_stage[(size_t)r].IsHidden ? 1 : 0; }
+int64_t gh_vdb_result_timestamp(int64_t r) { return g_stage[(size_t)r].TimestampMs; }
+int32_t gh_vdb_result_dim(int64_t r) { return (int32_t)g_stage[(size_t)r].Values.size(); }
+void gh_vdb_result_values(int64_t r, float *out) {
+    std::copy(g_stage[(size_t)r].Values.begin(), g_stage[(size_t)r].Values.end(), out);
+}
+int64_t gh_vdb_result_categories(int64_t r, char *buf, int64_t cap) {
+    std::string joined;
+    for (auto &c : g_stage[(size_t)r].Categories) joined += (joined.empty() ? "" : "\n") + c;
+    if ((int64_t)joined.size() + 1 <= cap) std::memcpy(buf, joined.c_str(), joined.size() + 1);
+    return (int64_t)joined.size() + 1;
 }
 }  // extern "C"

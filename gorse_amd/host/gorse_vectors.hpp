@@ -1,0 +1,328 @@
+// gorse_vectors.hpp -- C++ twin of the reference's vectors.Database interface (storage/vectors/database.go:107-120)
+// with a backend for the "hip://" prefix: collections of DENSE vectors whose similarity search is the exact GPU top-k
+// of libgorse_hip (gorse_topk_*), i.e. what storage/vectors/hip.go would contain behind `//go:build cgo && hip` and
+// `vectors.Register([]string{"hip://"}, creator)` (database.go:155-175).
+//
+// Semantics follow the reference's own backend for dense collections (storage/vectors/xvec.go):
+//   * AddVectors upserts by Id (xvec.go:301-327); GetVectors returns the found vectors in the order of the requested
+//     ids, duplicates and misses dropped (database.go:136-153 orderVectors); DeleteVectors removes everything with
+//     Timestamp < cutoff at millisecond resolution (xvec.go:371-377).
+//   * QueryVectors (xvec.go:379-446): hidden vectors never match; `categories` is CONTAIN_ALL; topK <= 0 -> empty;
+//     Score is "higher = more similar": the inner product for Dot, the NEGATED distance for Euclidean and Cosine
+//     (xvec.go:425-427).  The query vector itself is not excluded (database_test.go:146-153).
+//   * Search is EXACT here (the reference's DiskANN index is approximate: rank order on the reference's test inputs is
+//     the pinned behaviour, numeric scores are not -- SURVEY.md 8c).  Distances are the reference's own functions:
+//     -floats.Dot, floats.Euclidean, 1 - cos (gorse_hip.h GORSE_METRIC_*).
+//   * Filters are applied after an over-fetched exact search: k' = topK + slack vectors are fetched, filtered, and k'
+//     grows until topK admissible vectors are found or the collection is exhausted, so the answer is the exact top-K of
+//     the admissible set.
+//   * Sparse collections (dimension 0, `Indices`) and quantized collections are ErrNotSupported: the sparse dot is
+//     SURVEY.md 8f item 2, not built.
+// Errors are the reference's sentinels (storage/errors.go:20-24) as exception types; all methods are serialised by one
+// mutex per database (the reference requires goroutine safety; a GPU handle must be used by one caller at a time).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/gorse_hip.h"
+
+namespace gorse {
+namespace storage {
+struct ErrNotFound : std::runtime_error { using std::runtime_error::runtime_error; };        // errors.go:20
+struct ErrNotSupported : std::runtime_error { using std::runtime_error::runtime_error; };    // errors.go:23
+struct ErrAlreadyExists : std::runtime_error { using std::runtime_error::runtime_error; };   // errors.go:24
+}  // namespace storage
+
+namespace vectors {
+
+enum Distance { Cosine = 0, Euclidean = 1, Dot = 2 };  // database.go:29-33
+
+struct VectorConfig {   // database.go:75-80
+    std::string Type;   // "" | sq | pq | rq
+    int Bits = 0;
+};
+struct CollectionInfo {  // database.go:83-88
+    std::string Name;
+    int Dimension = 0;
+    Distance Dist = Cosine;
+    VectorConfig Config;
+};
+struct Vector {  // database.go:90-97
+    std::string Id;
+    std::vector<float> Values;
+    std::vector<uint32_t> Indices;
+    bool IsHidden = false;
+    std::vector<std::string> Categories;
+    int64_t TimestampMs = 0;  // time.Time at the millisecond resolution the backends store
+};
+struct ScoredVector : Vector {  // database.go:100-103
+    float Score = 0;
+};
+
+// Exact k-nearest search of one query over a dense row-major matrix; the default implementation is the GPU
+// (HipSearcher), the CPU test-suite injects a checker built on the oracle.
+struct Searcher {
+    virtual ~Searcher() = default;
+    // X changed since the last call (rows added / removed): drop any cached index of this collection
+    virtual void invalidate(const std::string &collection) = 0;
+    // for each of the nq queries (row-major Q): the k smallest distances, ascending, into idx / dist (nq x k) and how
+    // many of them into cnt (nq)
+    virtual void search(const std::string &collection, const float *X, int64_t n, int d, int metric, const float *Q,
+                        int64_t nq, int k, int32_t *idx, float *dist, int32_t *cnt) = 0;
+};
+
+// One gorse_topk handle per collection, rebuilt lazily after a change (like BruteforceHIP.sync in INTEGRATION.md).
+class HipSearcher : public Searcher {
+public:
+    explicit HipSearcher(int device = 0) : device_(device) {}
+    ~HipSearcher() override {
+        for (auto &kv : handles_) gorse_topk_destroy(kv.second);
+    }
+    void invalidate(const std::string &collection) override {
+        auto it = handles_.find(collection);
+        if (it != handles_.end()) {
+            gorse_topk_destroy(it->second);
+            handles_.erase(it);
+        }
+    }
+    void search(const std::string &collection, const float *X, int64_t n, int d, int metric, const float *Q, int64_t nq,
+                int k, int32_t *idx, float *dist, int32_t *cnt) override {
+        gorse_topk *&h = handles_[collection];
+        if (!h) {
+            if (gorse_topk_create(&h, device_, n, d, GORSE_DTYPE_F32, metric, X) != GORSE_OK) {
+                handles_.erase(collection);
+                throw std::runtime_error(std::string("gorse_topk_create: ") + gorse_hip_last_error());
+            }
+        }
+        // one call for all queries: >= 64 of them run on the MFMA path of the library, fewer on its literal scan
+        if (gorse_topk_search_vector(h, Q, nq, k, 0, idx, dist, cnt) != GORSE_OK)
+            throw std::runtime_error(std::string("gorse_topk_search_vector: ") + gorse_hip_last_error());
+    }
+
+private:
+    int device_;
+    std::map<std::string, gorse_topk *> handles_;
+};
+
+class HipDatabase {
+public:
+    explicit HipDatabase(std::shared_ptr<Searcher> searcher = nullptr)
+        : searcher_(searcher ? std::move(searcher) : std::make_shared<HipSearcher>()) {}
+
+    void Init() {}
+    void Optimize(const std::string &) {}
+    void Close() {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto &kv : collections_) searcher_->invalidate(kv.first);
+        closed_ = true;
+    }
+
+    std::vector<std::string> ListCollections() {
+        std::lock_guard<std::mutex> g(mu_);
+        check_open();
+        std::vector<std::string> names;
+        for (auto &kv : collections_) names.push_back(kv.first);
+        return names;  // std::map: sorted, like the sorted listing of the file-backed backends
+    }
+    CollectionInfo DescribeCollection(const std::string &name) {
+        std::lock_guard<std::mutex> g(mu_);
+        return coll(name).info;
+    }
+    void AddCollection(const std::string &name, int dimensions, Distance distance, const VectorConfig &config = {}) {
+        std::lock_guard<std::mutex> g(mu_);
+        check_open();
+        if (dimensions < 0) throw std::invalid_argument("invalid vector dimension " + std::to_string(dimensions));
+        if (!config.Type.empty()) throw storage::ErrNotSupported("quantization type " + config.Type + " for hip not supported");
+        if (dimensions == 0) throw storage::ErrNotSupported("sparse vectors for hip not supported");
+        if (distance != Cosine && distance != Euclidean && distance != Dot) throw storage::ErrNotSupported("distance method not supported");
+        if (collections_.count(name)) throw storage::ErrAlreadyExists("collection " + name + " already exists");
+        Collection c;
+        c.info.Name = name;
+        c.info.Dimension = dimensions;
+        c.info.Dist = distance;
+        c.info.Config = config;
+        collections_.emplace(name, std::move(c));
+    }
+    void DeleteCollection(const std::string &name) {
+        std::lock_guard<std::mutex> g(mu_);
+        check_open();
+        if (!collections_.erase(name)) throw storage::ErrNotFound("collection " + name + ": not found");
+        searcher_->invalidate(name);
+    }
+    int64_t CountVectors(const std::string &name) {
+        std::lock_guard<std::mutex> g(mu_);
+        return (int64_t)coll(name).rows.size();
+    }
+    void AddVectors(const std::string &name, const std::vector<Vector> &vs) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (vs.empty()) return;
+        Collection &c = coll(name);
+        for (const Vector &v : vs) {  // validate everything before touching the collection (xvec.go:318-321)
+            if (!v.Indices.empty()) throw storage::ErrNotSupported("sparse vectors for hip not supported");
+            if ((int)v.Values.size() != c.info.Dimension)
+                throw std::invalid_argument("vector " + v.Id + " has dimension " + std::to_string(v.Values.size()) +
+                                            ", collection " + name + " has " + std::to_string(c.info.Dimension));
+        }
+        for (const Vector &v : vs) {
+            auto it = c.by_id.find(v.Id);
+            if (it == c.by_id.end()) {
+                c.by_id[v.Id] = c.rows.size();
+                c.rows.push_back(v);
+                c.data.insert(c.data.end(), v.Values.begin(), v.Values.end());
+            } else {  // upsert
+                c.rows[it->second] = v;
+                std::copy(v.Values.begin(), v.Values.end(), c.data.begin() + it->second * c.info.Dimension);
+            }
+        }
+        searcher_->invalidate(name);
+    }
+    std::vector<Vector> GetVectors(const std::string &name, const std::vector<std::string> &ids) {
+        std::lock_guard<std::mutex> g(mu_);
+        Collection &c = coll(name);
+        std::vector<Vector> out;
+        std::map<std::string, bool> seen;
+        for (const std::string &id : ids) {
+            if (seen.count(id)) continue;
+            seen[id] = true;
+            auto it = c.by_id.find(id);
+            if (it != c.by_id.end()) out.push_back(c.rows[it->second]);
+        }
+        return out;
+    }
+    void DeleteVectors(const std::string &name, int64_t timestamp_ms) {
+        std::lock_guard<std::mutex> g(mu_);
+        Collection &c = coll(name);
+        std::vector<Vector> keep;
+        for (Vector &v : c.rows)
+            if (!(v.TimestampMs < timestamp_ms)) keep.push_back(std::move(v));
+        if (keep.size() == c.rows.size()) {
+            c.rows = std::move(keep);
+            return;
+        }
+        c.rows = std::move(keep);
+        c.by_id.clear();
+        c.data.clear();
+        for (size_t r = 0; r < c.rows.size(); r++) {
+            c.by_id[c.rows[r].Id] = r;
+            c.data.insert(c.data.end(), c.rows[r].Values.begin(), c.rows[r].Values.end());
+        }
+        searcher_->invalidate(name);
+    }
+    std::vector<ScoredVector> QueryVectors(const std::string &name, const Vector &q, const std::vector<std::string> &categories,
+                                           int topK) {
+        if (!q.Indices.empty()) throw storage::ErrNotSupported("sparse queries for hip not supported");
+        auto r = QueryVectorsBatch(name, q.Values, 1, categories, topK);
+        return r.empty() ? std::vector<ScoredVector>() : std::move(r[0]);
+    }
+    // The bulk form: nq dense queries (row-major) against one collection with one filter, in ONE
+    // device search per over-fetch round -- what replaces the per-user QueryVectors loop of worker/pipeline.go:403-448.
+    std::vector<std::vector<ScoredVector>> QueryVectorsBatch(const std::string &name, const std::vector<float> &queries,
+                                                             int64_t nq, const std::vector<std::string> &categories,
+                                                             int topK) {
+        std::lock_guard<std::mutex> g(mu_);
+        Collection &c = coll(name);
+        std::vector<std::vector<ScoredVector>> out((size_t)std::max<int64_t>(nq, 0));
+        if (topK <= 0 || nq <= 0) return out;
+        const int d = c.info.Dimension;
+        if ((int64_t)queries.size() != nq * d)
+            throw std::invalid_argument("query has dimension " + std::to_string(nq ? queries.size() / nq : 0) + ", collection " +
+                                        name + " has " + std::to_string(d));
+        const int64_t n = (int64_t)c.rows.size();
+        if (n == 0) return out;
+        const int metric = c.info.Dist == Dot ? GORSE_METRIC_NEG_DOT : (c.info.Dist == Euclidean ? GORSE_METRIC_EUCLIDEAN : GORSE_METRIC_COSINE);
+        std::vector<char> ok((size_t)n);
+        for (int64_t r = 0; r < n; r++) {
+            const Vector &v = c.rows[(size_t)r];
+            bool a = !v.IsHidden;
+            for (const std::string &cat : categories)
+                a = a && std::find(v.Categories.begin(), v.Categories.end(), cat) != v.Categories.end();
+            ok[(size_t)r] = a;
+        }
+        // queries still short of topK admissible vectors are searched again with a 4x larger k
+        std::vector<int64_t> todo((size_t)nq);
+        for (int64_t t = 0; t < nq; t++) todo[(size_t)t] = t;
+        int64_t k = std::min<int64_t>(n, std::max<int64_t>(2 * (int64_t)topK, (int64_t)topK + 32));
+        std::vector<float> Q;
+        std::vector<int32_t> idx, cnt;
+        std::vector<float> dist;
+        while (!todo.empty()) {
+            const int64_t m = (int64_t)todo.size();
+            const float *qp = queries.data();
+            if (m != nq) {
+                Q.resize((size_t)m * d);
+                for (int64_t t = 0; t < m; t++)
+                    std::copy(queries.begin() + todo[(size_t)t] * d, queries.begin() + (todo[(size_t)t] + 1) * d, Q.begin() + t * d);
+                qp = Q.data();
+            }
+            idx.assign((size_t)(m * k), -1);
+            dist.assign((size_t)(m * k), 0.0f);
+            cnt.assign((size_t)m, 0);
+            searcher_->search(name, c.data.data(), n, d, metric, qp, m, (int)k, idx.data(), dist.data(), cnt.data());
+            std::vector<int64_t> again;
+            for (int64_t t = 0; t < m; t++) {
+                std::vector<ScoredVector> &res = out[(size_t)todo[(size_t)t]];
+                res.clear();
+                for (int e = 0; e < cnt[(size_t)t] && (int)res.size() < topK; e++) {
+                    const int32_t r = idx[(size_t)(t * k + e)];
+                    if (!ok[(size_t)r]) continue;
+                    ScoredVector s;
+                    static_cast<Vector &>(s) = c.rows[(size_t)r];
+                    s.Score = -dist[(size_t)(t * k + e)];  // Dot: a.b; Euclidean / Cosine: negated distance (xvec.go:425-427)
+                    res.push_back(std::move(s));
+                }
+                if ((int)res.size() < topK && k < n) again.push_back(todo[(size_t)t]);
+            }
+            if (k >= n) break;
+            todo.swap(again);
+            k = std::min<int64_t>(n, k * 4);
+        }
+        return out;
+    }
+
+private:
+    struct Collection {
+        CollectionInfo info;
+        std::vector<Vector> rows;               // insertion order; row r of `data`
+        std::vector<float> data;                // rows x Dimension, row-major: what the searcher indexes
+        std::map<std::string, size_t> by_id;
+    };
+    void check_open() const {
+        if (closed_) throw std::runtime_error("hip vector database is closed");
+    }
+    Collection &coll(const std::string &name) {
+        check_open();
+        auto it = collections_.find(name);
+        if (it == collections_.end()) throw storage::ErrNotFound("collection " + name + ": not found");
+        return it->second;
+    }
+    std::mutex mu_;
+    bool closed_ = false;
+    std::shared_ptr<Searcher> searcher_;
+    std::map<std::string, Collection> collections_;
+};
+
+// vectors.Register / vectors.Open (database.go:155-175): creators by URL prefix
+using Creator = std::function<std::shared_ptr<HipDatabase>(const std::string &path, const std::string &tablePrefix)>;
+inline std::map<std::string, Creator> &creators() {
+    static std::map<std::string, Creator> c = {
+        {"hip://", [](const std::string &, const std::string &) { return std::make_shared<HipDatabase>(); }}};
+    return c;
+}
+inline void Register(const std::vector<std::string> &prefixes, Creator creator) {
+    for (const std::string &p : prefixes) creators()[p] = creator;
+}
+inline std::shared_ptr<HipDatabase> Open(const std::string &path, const std::string &tablePrefix = "") {
+    for (auto &kv : creators())
+        if (path.compare(0, kv.first.size(), kv.first) == 0) return kv.second(path, tablePrefix);
+    throw std::runtime_error("Unknown database: " + path);
+}
+
+}  // namespace vectors
+}  // namespace gorse

@@ -1,0 +1,231 @@
+"""Python face of the C++ twin of vectors.Database (gorse_amd/host/gorse_vectors.hpp; storage/vectors/database.go:107-120)
+so that the parity tests read like storage/vectors/database_test.go.  `Open("hip://")` searches on the MI355X through
+libgorse_hip; `Database(searcher=...)` takes a search callback instead (the CPU test-suite injects a checker built on
+the oracle there -- the product path never does)."""
+import ctypes as C
+import datetime as dt
+
+import numpy as np
+
+from . import cf
+
+Cosine, Euclidean, Dot = 0, 1, 2  # database.go:29-33
+
+
+class ErrNotFound(RuntimeError):  # storage/errors.go:20
+    pass
+
+
+class ErrAlreadyExists(RuntimeError):  # storage/errors.go:24
+    pass
+
+
+class ErrNotSupported(RuntimeError):  # storage/errors.go:23
+    pass
+
+
+_ERR = {-201: ErrNotFound, -202: ErrAlreadyExists, -203: ErrNotSupported}
+_INVALID = -1  # GORSE_ERR_INVALID (std::invalid_argument in the C++ twin)
+SEARCH_CB = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int64,
+                        C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int32))
+_H = None
+
+
+def _host():
+    global _H
+    if _H is None:
+        H = cf.host()
+        H.gh_vdb_open.restype = C.c_void_p
+        H.gh_vdb_open.argtypes = [C.c_char_p]
+        H.gh_vdb_open_with_searcher.restype = C.c_void_p
+        H.gh_vdb_open_with_searcher.argtypes = [SEARCH_CB]
+        H.gh_vdb_free.argtypes = [C.c_void_p]
+        for n, args in (("gh_vdb_close", [C.c_void_p]),
+                        ("gh_vdb_add_collection", [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]),
+                        ("gh_vdb_delete_collection", [C.c_void_p, C.c_char_p]),
+                        ("gh_vdb_describe", [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+                        ("gh_vdb_add_staged", [C.c_void_p, C.c_char_p]),
+                        ("gh_vdb_get", [C.c_void_p, C.c_char_p, C.c_char_p]),
+                        ("gh_vdb_delete_vectors", [C.c_void_p, C.c_char_p, C.c_int64]),
+                        ("gh_vdb_query_staged", [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]),
+                        ("gh_vdb_query_batch", [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_char_p, C.c_int32])):
+            getattr(H, n).restype = C.c_int32
+            getattr(H, n).argtypes = args
+        H.gh_vdb_list.restype = C.c_int64
+        H.gh_vdb_list.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        H.gh_vdb_count.restype = C.c_int64
+        H.gh_vdb_count.argtypes = [C.c_void_p, C.c_char_p]
+        H.gh_vdb_stage_vector.restype = None
+        H.gh_vdb_stage_vector.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_uint32), C.c_int32,
+                                          C.c_int32, C.c_char_p, C.c_int64]
+        H.gh_vdb_stage_clear.restype = None
+        H.gh_vdb_result_count.restype = C.c_int64
+        H.gh_vdb_result_split.restype = C.c_int64
+        H.gh_vdb_result_split.argtypes = [C.c_int64]
+        H.gh_vdb_result_id.restype = C.c_char_p
+        H.gh_vdb_result_id.argtypes = [C.c_int64]
+        H.gh_vdb_result_score.restype = C.c_float
+        H.gh_vdb_result_score.argtypes = [C.c_int64]
+        H.gh_vdb_result_hidden.argtypes = [C.c_int64]
+        H.gh_vdb_result_timestamp.restype = C.c_int64
+        H.gh_vdb_result_timestamp.argtypes = [C.c_int64]
+        H.gh_vdb_result_dim.argtypes = [C.c_int64]
+        H.gh_vdb_result_values.restype = None
+        H.gh_vdb_result_values.argtypes = [C.c_int64, C.POINTER(C.c_float)]
+        H.gh_vdb_result_categories.restype = C.c_int64
+        H.gh_vdb_result_categories.argtypes = [C.c_int64, C.c_char_p, C.c_int64]
+        _H = H
+    return _H
+
+
+def _ck(rc):
+    if rc < 0:
+        msg = _host().gh_last_error().decode()
+        raise _ERR.get(int(rc), ValueError if rc == _INVALID else RuntimeError)(msg)
+    return rc
+
+
+def _ms(t):
+    if t is None:
+        return 0
+    if isinstance(t, dt.datetime):
+        if t.tzinfo is None:
+            t = t.replace(tzinfo=dt.timezone.utc)
+        return int(round(t.timestamp() * 1000))
+    return int(t)
+
+
+class Vector:
+    """vectors.Vector (database.go:90-97); Timestamp in milliseconds since the epoch (what the backends store)."""
+
+    def __init__(self, Id="", Values=(), Indices=(), IsHidden=False, Categories=(), Timestamp=0):
+        self.Id, self.Values, self.Indices = Id, [float(np.float32(v)) for v in Values], [int(i) for i in Indices]
+        self.IsHidden, self.Categories, self.Timestamp = bool(IsHidden), list(Categories), _ms(Timestamp)
+
+    def __eq__(self, o):
+        return (self.Id, self.Values, self.Indices, self.IsHidden, self.Categories, self.Timestamp) == \
+               (o.Id, o.Values, o.Indices, o.IsHidden, o.Categories, o.Timestamp)
+
+    def __repr__(self):
+        return "Vector(%r, %r, hidden=%r, cats=%r, ts=%r)" % (self.Id, self.Values, self.IsHidden, self.Categories, self.Timestamp)
+
+
+class ScoredVector(Vector):
+    Score = 0.0
+
+
+class Database:
+    """vectors.Database.  Methods and error behaviour follow database.go:107-120 / xvec.go."""
+
+    def __init__(self, url="hip://", searcher=None):
+        H = _host()
+        if searcher is not None:
+            self._cb = SEARCH_CB(searcher)  # keep the thunk alive
+            self.h = C.c_void_p(H.gh_vdb_open_with_searcher(self._cb))
+        else:
+            p = H.gh_vdb_open(url.encode())
+            if not p:
+                raise RuntimeError(H.gh_last_error().decode())
+            self.h = C.c_void_p(p)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _host().gh_vdb_free(self.h)
+            self.h = None
+
+    def Init(self):
+        return None
+
+    def Optimize(self, name):
+        return None
+
+    def Close(self):
+        _ck(_host().gh_vdb_close(self.h))
+
+    def ListCollections(self):
+        H = _host()
+        n = _ck(H.gh_vdb_list(self.h, None, 0))
+        buf = C.create_string_buffer(int(n))
+        _ck(H.gh_vdb_list(self.h, buf, n))
+        s = buf.value.decode()
+        return s.split("\n") if s else []
+
+    def DescribeCollection(self, name):
+        d, dist, bits = C.c_int32(), C.c_int32(), C.c_int32()
+        _ck(_host().gh_vdb_describe(self.h, name.encode(), C.byref(d), C.byref(dist), C.byref(bits)))
+        return {"Name": name, "Dimension": d.value, "Distance": dist.value, "Type": "", "Bits": bits.value}
+
+    def AddCollection(self, name, dimensions, distance, quantization="", bits=0):
+        _ck(_host().gh_vdb_add_collection(self.h, name.encode(), dimensions, distance, quantization.encode(), bits))
+
+    def DeleteCollection(self, name):
+        _ck(_host().gh_vdb_delete_collection(self.h, name.encode()))
+
+    def CountVectors(self, name):
+        return int(_ck(_host().gh_vdb_count(self.h, name.encode())))
+
+    @staticmethod
+    def _stage(v):
+        vals = np.ascontiguousarray(v.Values, np.float32)
+        ind = np.ascontiguousarray(v.Indices, np.uint32)
+        _host().gh_vdb_stage_vector(v.Id.encode(), vals.ctypes.data_as(C.POINTER(C.c_float)), vals.size,
+                                    ind.ctypes.data_as(C.POINTER(C.c_uint32)), ind.size, int(v.IsHidden),
+                                    "\n".join(v.Categories).encode(), v.Timestamp)
+
+    @staticmethod
+    def _results(scored):
+        H = _host()
+        out = []
+        for r in range(int(H.gh_vdb_result_count())):
+            v = ScoredVector() if scored else Vector()
+            v.Id = H.gh_vdb_result_id(r).decode()
+            vals = np.empty(H.gh_vdb_result_dim(r), np.float32)
+            H.gh_vdb_result_values(r, vals.ctypes.data_as(C.POINTER(C.c_float)))
+            v.Values = [float(x) for x in vals]
+            v.IsHidden = bool(H.gh_vdb_result_hidden(r))
+            n = H.gh_vdb_result_categories(r, None, 0)
+            buf = C.create_string_buffer(int(n))
+            H.gh_vdb_result_categories(r, buf, n)
+            s = buf.value.decode()
+            v.Categories = s.split("\n") if s else []
+            v.Timestamp = int(H.gh_vdb_result_timestamp(r))
+            if scored:
+                v.Score = float(H.gh_vdb_result_score(r))
+            out.append(v)
+        return out
+
+    def AddVectors(self, name, vectors):
+        H = _host()
+        H.gh_vdb_stage_clear()
+        for v in vectors:
+            self._stage(v)
+        _ck(H.gh_vdb_add_staged(self.h, name.encode()))
+
+    def GetVectors(self, name, ids):
+        _ck(_host().gh_vdb_get(self.h, name.encode(), "\n".join(ids or []).encode()))
+        return self._results(False)
+
+    def DeleteVectors(self, name, timestamp):
+        _ck(_host().gh_vdb_delete_vectors(self.h, name.encode(), _ms(timestamp)))
+
+    def QueryVectors(self, name, q, categories, topK):
+        H = _host()
+        H.gh_vdb_stage_clear()
+        self._stage(q)
+        _ck(H.gh_vdb_query_staged(self.h, name.encode(), "\n".join(categories or []).encode(), topK))
+        return self._results(True)
+
+    def QueryVectorsBatch(self, name, Q, categories, topK):
+        """Bulk form: rows of Q are dense queries; one device search per over-fetch round (gorse_vectors.hpp)."""
+        H = _host()
+        Q = np.ascontiguousarray(Q, np.float32)
+        _ck(H.gh_vdb_query_batch(self.h, name.encode(), Q.ctypes.data_as(C.POINTER(C.c_float)), Q.shape[0], Q.shape[1],
+                                 "\n".join(categories or []).encode(), topK))
+        flat = self._results(True)
+        cuts = [int(H.gh_vdb_result_split(t)) for t in range(Q.shape[0] + 1)]
+        return [flat[cuts[t]:cuts[t + 1]] for t in range(Q.shape[0])]
+
+
+def Open(path, tablePrefix=""):
+    """vectors.Open (database.go:167-175): creators by URL prefix; 'hip://' is the one registered here."""
+    return Database(url=path)

@@ -1,0 +1,28 @@
+"""The reference's vectors.Database test-suite (tests/vectors_suite.py) on the MI355X: `vectors.Open("hip://")`, every
+search an exact gorse_topk search on the device (literal scan for single queries, MFMA sweep for the bulk form)."""
+import numpy as np
+import pytest
+
+import vectors_suite as S
+from gorse_amd import vectors as V
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def db():
+    return V.Open("hip://")
+
+
+@pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.sparse, S.hidden, S.dot, S.delete_vectors,
+                                  S.upsert_and_close], ids=lambda f: f.__name__)
+def test_reference_suite(db, case):
+    case(db)
+
+
+@pytest.mark.parametrize("distance,name,metric", [(V.Dot, "dot", orc.METRIC_NEG_DOT), (V.Euclidean, "l2", orc.METRIC_EUCLIDEAN),
+                                                  (V.Cosine, "cos", orc.METRIC_COSINE)])
+def test_exact_filtered_topk(db, oracle, distance, name, metric):
+    oracle.set_isa(orc.ISA_AVX512)
+    S.exact_filtered_topk(db, distance, name, lambda X, q: np.array([oracle.distance(metric, q, x) for x in X], np.float32))

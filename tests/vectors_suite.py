@@ -1,0 +1,152 @@
+"""The reference's vectors.Database test-suite (storage/vectors/database_test.go:33-330), transcribed; the two test
+modules run it against the C++ twin with the GPU searcher (test_gpu_vectors_db.py) and with an exact CPU checker built on
+the oracle (test_vectors_db_cpu.py).  defaultVectorSize and the vectors are the reference's."""
+import numpy as np
+import pytest
+
+from gorse_amd import vectors as V
+
+defaultVectorSize = 4  # database_test.go: vectors of 4 floats ({1,0,0,0}, {0.9,0.1,0,0}, ...)
+
+
+def vec(*xs):
+    v = [0.0] * defaultVectorSize
+    for i, x in enumerate(xs):
+        v[i] = x
+    return v
+
+
+def collections(db):  # TestCollections (database_test.go:38-84)
+    assert db.ListCollections() == []
+    db.AddCollection("test", defaultVectorSize, V.Cosine)
+    with pytest.raises(V.ErrAlreadyExists):
+        db.AddCollection("test", defaultVectorSize, V.Cosine)
+    info = db.DescribeCollection("test")
+    assert info["Name"] == "test" and info["Dimension"] == defaultVectorSize and info["Distance"] == V.Cosine
+    assert info["Type"] == "" and info["Bits"] == 0
+    assert db.ListCollections() == ["test"]
+    db.DeleteCollection("test")
+    with pytest.raises(V.ErrNotFound):
+        db.DescribeCollection("test")
+    assert db.ListCollections() == []
+    with pytest.raises(V.ErrNotFound):
+        db.DeleteCollection("non-existent")
+
+
+def vectors(db):  # TestVectors (database_test.go:86-153)
+    db.AddCollection("test", defaultVectorSize, V.Cosine)
+    assert db.CountVectors("test") == 0
+    a, b = vec(1), vec(0.9, 0.1)
+    db.AddVectors("test", [V.Vector("a", a, Categories=["cat-a", "common"]), V.Vector("b", b, Categories=["cat-b", "common"])])
+    assert db.CountVectors("test") == 2
+    r = db.QueryVectors("test", V.Vector(Values=a), ["cat-a"], 10)
+    assert [x.Id for x in r] == ["a"] and r[0].Categories
+    r = db.QueryVectors("test", V.Vector(Values=a), ["common"], 10)
+    assert [x.Id for x in r] == ["a", "b"] and r[0].Score > r[1].Score and all(x.Categories for x in r)
+    r = db.QueryVectors("test", V.Vector(Values=a), ["cat-a", "common"], 10)
+    assert [x.Id for x in r] == ["a"]
+    r = db.QueryVectors("test", V.Vector(Values=a), None, 1)
+    assert r and all(x.Categories for x in r)
+    q = db.GetVectors("test", ["a"])
+    assert len(q) == 1
+    r = db.QueryVectors("test", q[0], None, 10)  # the query vector itself is not excluded
+    assert [x.Id for x in r] == ["a", "b"]
+    assert db.QueryVectors("test", V.Vector(Values=a), None, 0) == []  # topK <= 0 (xvec.go:380-382)
+    with pytest.raises(V.ErrNotFound):
+        db.QueryVectors("nope", V.Vector(Values=a), None, 3)
+
+
+def get_vectors(db):  # TestGetVectors (database_test.go:155-190)
+    db.AddCollection("test", defaultVectorSize, V.Cosine)
+    ta = 1_790_000_000_123
+    va = V.Vector("a", [1, 0, 0, 0], Categories=["cat-a", "common"], Timestamp=ta)
+    vb = V.Vector("b", [0, 1, 0, 0], IsHidden=True, Categories=["cat-b", "common"], Timestamp=ta + 1000)
+    db.AddVectors("test", [va, vb])
+    assert db.GetVectors("test", ["b", "missing", "a", "b"]) == [vb, va]
+    assert db.GetVectors("test", None) == []
+
+
+def sparse(db):  # TestSparse (database_test.go:192-243): sparse collections are the reference's Flat index; not built here
+    with pytest.raises(V.ErrNotSupported):
+        db.AddCollection("test_sparse", 0, V.Dot)
+    db.AddCollection("dense", defaultVectorSize, V.Dot)
+    with pytest.raises(V.ErrNotSupported):
+        db.AddVectors("dense", [V.Vector("old", [1, 1], Indices=[1, 100])])
+    with pytest.raises(V.ErrNotSupported):
+        db.QueryVectors("dense", V.Vector(Values=[1, 2], Indices=[1, 100]), None, 10)
+    with pytest.raises(V.ErrNotSupported):  # quantized collections (database_test.go:332-420) neither
+        db.AddCollection("q", defaultVectorSize, V.Cosine, quantization="sq", bits=8)
+
+
+def hidden(db):  # TestHidden (database_test.go:245-279)
+    db.AddCollection("test_hidden", defaultVectorSize, V.Cosine)
+    query = [1, 0, 0, 0]
+    db.AddVectors("test_hidden", [V.Vector("visible", [0.9, 0.1, 0, 0], Categories=["common", "quo'te"]),
+                                  V.Vector("hidden", query, IsHidden=True, Categories=["common", "quo'te"])])
+    assert db.CountVectors("test_hidden") == 2
+    for cats in (None, ["common"], ["quo'te"]):
+        r = db.QueryVectors("test_hidden", V.Vector(Values=query), cats, 10)
+        assert [x.Id for x in r] == ["visible"]
+
+
+def dot(db):  # TestDot (database_test.go:281-300)
+    db.AddCollection("test_dot", defaultVectorSize, V.Dot)
+    db.AddVectors("test_dot", [V.Vector("a", [2, 0, 0, 0]), V.Vector("b", [1, 1, 0, 0])])
+    r = db.QueryVectors("test_dot", V.Vector(Values=[1, 0, 0, 0]), None, 2)
+    assert [x.Id for x in r] == ["a", "b"] and r[0].Score > r[1].Score
+    assert r[0].Score == 2.0 and r[1].Score == 1.0  # Dot: the score IS the inner product
+
+
+def delete_vectors(db):  # TestDeleteVectors (database_test.go:302-330)
+    db.AddCollection("test", defaultVectorSize, V.Cosine)
+    cutoff = 1_790_000_000_000
+    db.AddVectors("test", [V.Vector("old", vec(1), Categories=["common"], Timestamp=cutoff - 3_600_000),
+                           V.Vector("new", vec(0.9, 0.1), Categories=["common"], Timestamp=cutoff)])
+    db.DeleteVectors("test", cutoff)
+    assert db.CountVectors("test") == 1
+    r = db.QueryVectors("test", V.Vector(Values=vec(1)), ["common"], 10)
+    assert [x.Id for x in r] == ["new"]
+
+
+def upsert_and_close(db):  # xvec.go:301-327 (Upsert), :166-185 (closed database)
+    db.AddCollection("c", defaultVectorSize, V.Euclidean)
+    db.AddVectors("c", [V.Vector("a", [1, 0, 0, 0]), V.Vector("b", [0, 1, 0, 0])])
+    db.AddVectors("c", [V.Vector("a", [0, 0, 1, 0], Categories=["x"])])  # same Id: replaced, not appended
+    assert db.CountVectors("c") == 2
+    assert db.GetVectors("c", ["a"])[0].Values == [0, 0, 1, 0]
+    r = db.QueryVectors("c", V.Vector(Values=[0, 0, 1, 0]), None, 2)
+    assert [x.Id for x in r] == ["a", "b"] and r[0].Score == 0.0 and abs(r[1].Score + np.sqrt(2)) < 1e-6  # negated distance
+    with pytest.raises(ValueError):
+        db.AddVectors("c", [V.Vector("bad", [1, 2, 3])])  # wrong dimension: nothing is added
+    assert db.CountVectors("c") == 2
+    db.Close()
+    with pytest.raises(RuntimeError):
+        db.CountVectors("c")
+
+
+def exact_filtered_topk(db, distance, metric_name, brute):
+    """Over-fetch + filter = the exact top-K of the admissible set, one query at a time and in bulk."""
+    rng = np.random.default_rng(distance + 7)
+    n, d, topk = 700, 24, 12
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    cats = [["a"] if r % 3 == 0 else (["a", "b"] if r % 3 == 1 else ["c"]) for r in range(n)]
+    hid = rng.random(n) < 0.4  # many hidden vectors: the first fetch is not enough for most queries
+    db.AddCollection(metric_name, d, distance)
+    db.AddVectors(metric_name, [V.Vector("v%d" % r, X[r], IsHidden=bool(hid[r]), Categories=cats[r]) for r in range(n)])
+    Q = rng.standard_normal((70, d)).astype(np.float32)
+    for want in (None, ["a"], ["a", "b"], ["zzz"]):
+        ok = np.array([not hid[r] and all(c in cats[r] for c in (want or [])) for r in range(n)])
+        bulk = db.QueryVectorsBatch(metric_name, Q, want, topk)
+        for t in range(Q.shape[0]):
+            dist = brute(X, Q[t])
+            order = [r for r in np.argsort(dist, kind="stable") if ok[r]][:topk]
+            got = bulk[t]
+            assert len(got) == len(order)
+            # equal distances may come in either order: compare as (distance, id) with the distances exact
+            assert [np.float32(-g.Score) for g in got] == [np.float32(dist[r]) for r in order], (metric_name, want, t)
+            assert sorted(g.Id for g in got) == sorted("v%d" % r for r in order) or \
+                len(set(np.float32(dist[r]) for r in order)) < len(order)
+            assert not any(g.IsHidden for g in got)
+            if t < 5:
+                one = db.QueryVectors(metric_name, V.Vector(Values=Q[t]), want, topk)
+                assert [(g.Id, g.Score) for g in one] == [(g.Id, g.Score) for g in got]
