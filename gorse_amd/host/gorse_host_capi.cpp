@@ -380,4 +380,47 @@ int64_t gh_vdb_result_categories(int64_t r, char *buf, int64_t cap) {
     if ((int64_t)joined.size() + 1 <= cap) std::memcpy(buf, joined.c_str(), joined.size() + 1);
     return (int64_t)joined.size() + 1;
 }
+
+// ---- logics: embedding item-to-item / user-to-user over a vectors.Database ----------------------------------
+void *gh_vwriter_new(void *h, const char *collection, int32_t distance, int64_t timestamp_ms, int32_t batch) {
+    return new logics::VectorWriter(((VdbHandle *)h)->db, collection, (vectors::Distance)distance, timestamp_ms, batch);
+}
+void gh_vwriter_free(void *w) { delete (logics::VectorWriter *)w; }
+// the vector to add is the LAST staged one
+int32_t gh_vwriter_add_staged(void *w) {
+    return guard([&] {
+        if (g_stage.empty()) throw std::invalid_argument("no staged vector");
+        vectors::Vector v = g_stage.back();
+        gh_vdb_stage_clear();
+        ((logics::VectorWriter *)w)->Add(v);
+    });
+}
+int32_t gh_vwriter_clean(void *w) { return guard([&] { ((logics::VectorWriter *)w)->Clean(); }); }
+// results: staged as ScoredVector with Score = the cache.Score value (double narrowed for transport is NOT wanted: see
+// gh_logics_result_score)
+namespace {
+thread_local std::vector<double> g_scores;
+void stage_scores(const std::vector<std::vector<logics::Score>> &res) {
+    gh_vdb_stage_clear();
+    g_scores.clear();
+    g_stage_split.push_back(0);
+    for (auto &r : res) {
+        for (auto &sc : r) {
+            vectors::ScoredVector v;
+            v.Id = sc.Id;
+            v.Categories = sc.Categories;
+            g_stage.push_back(std::move(v));
+            g_scores.push_back(sc.Value);
+        }
+        g_stage_split.push_back((int64_t)g_stage.size());
+    }
+}
+}  // namespace
+int32_t gh_logics_query_similar(void *h, const char *collection, const char *id, const char *categories, int32_t n) {
+    return guard([&] { stage_scores({logics::QuerySimilar(vdb(h), collection, id, split_lines(categories), n)}); });
+}
+int32_t gh_logics_query_similar_bulk(void *h, const char *collection, const char *ids, const char *categories, int32_t n) {
+    return guard([&] { stage_scores(logics::QuerySimilarBulk(vdb(h), collection, split_lines(ids), split_lines(categories), n)); });
+}
+double gh_logics_result_score(int64_t r) { return g_scores[(size_t)r]; }
 }  // extern "C"

@@ -324,5 +324,137 @@ inline std::shared_ptr<HipDatabase> Open(const std::string &path, const std::str
     throw std::runtime_error("Unknown database: " + path);
 }
 
+inline std::string ItemToItemCollection(const std::string &name) { return "item_to_item_" + name; }   // database.go:56-58
+inline std::string UserToUserCollection(const std::string &name) { return "user_to_user_" + name; }   // database.go:60-62
+
 }  // namespace vectors
+
+// ---- logics: the dense ("embedding") similarity recommenders over a vectors.Database ----------------------------------
+// logics/vector_writer.go:33-190 (VectorWriter), logics/item_to_item.go:50-152 (QueryItemToItem, embeddingItemToItem),
+// logics/user_to_user.go:50-152 (the same with users).  The sparse kinds (tags / users / auto: IDF-weighted sparse dot) are
+// SURVEY.md 8f item 2 and not built.
+namespace logics {
+
+struct Score {  // cache.Score as QueryItemToItem fills it (item_to_item.go:81)
+    std::string Id;
+    double Value = 0;
+    std::vector<std::string> Categories;
+};
+
+class VectorWriter {  // dense writer: collection validation + batched AddVectors (vector_writer.go:35-190)
+public:
+    VectorWriter(std::shared_ptr<vectors::HipDatabase> client, std::string collection, vectors::Distance distance,
+                 int64_t timestamp_ms, int batchSize = 0)
+        : client_(std::move(client)), collection_(std::move(collection)), distance_(distance), timestamp_(timestamp_ms),
+          batch_(batchSize > 0 ? batchSize : 1024) {}
+    void Add(const vectors::Vector &v) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!v.Indices.empty() || v.Values.empty()) return;  // vector_writer.go:92-96: silently skipped
+        buffer_.push_back(v);
+        if ((int)buffer_.size() >= batch_) flush();
+    }
+    void Clean() {  // flush, then drop what an earlier refresh left behind (vector_writer.go:104-114)
+        std::lock_guard<std::mutex> g(mu_);
+        flush();
+        try {
+            client_->DeleteVectors(collection_, timestamp_);
+        } catch (const storage::ErrNotFound &) {
+        }
+    }
+
+private:
+    void flush() {
+        if (buffer_.empty()) return;
+        if (dimension_ < 0) {  // the most frequent dimension of the first batch, first seen wins ties (:153-166)
+            std::map<size_t, int> counts;
+            for (auto &v : buffer_) counts[v.Values.size()]++;
+            size_t dim = buffer_[0].Values.size();
+            for (auto &v : buffer_)
+                if (counts[v.Values.size()] > counts[dim]) dim = v.Values.size();
+            dimension_ = (int)dim;
+        }
+        std::vector<vectors::Vector> ok;
+        for (auto &v : buffer_)
+            if ((int)v.Values.size() == dimension_) ok.push_back(v);  // others are logged and dropped (:169-180)
+        buffer_.clear();
+        ensure_collection();
+        client_->AddVectors(collection_, ok);
+    }
+    void ensure_collection() {  // vector_writer.go:116-147: recreate when dimension / distance / config differ
+        if (exists_) return;
+        bool have = false;
+        try {
+            auto info = client_->DescribeCollection(collection_);
+            have = true;
+            if (info.Dimension != dimension_ || info.Dist != distance_ || !info.Config.Type.empty() || info.Config.Bits != 0) {
+                try {
+                    client_->DeleteCollection(collection_);
+                } catch (const storage::ErrNotFound &) {
+                }
+                have = false;
+            }
+        } catch (const storage::ErrNotFound &) {
+        }
+        if (!have) client_->AddCollection(collection_, dimension_, distance_);
+        exists_ = true;
+    }
+    std::shared_ptr<vectors::HipDatabase> client_;
+    std::string collection_;
+    vectors::Distance distance_;
+    int64_t timestamp_;
+    int batch_;
+    std::mutex mu_;
+    int dimension_ = -1;
+    bool exists_ = false;
+    std::vector<vectors::Vector> buffer_;
+};
+
+// neighbour list -> scores, the loop of item_to_item.go:72-86 for the embedding type (distance Euclidean, scale 1):
+// the item itself is skipped, score = 1 / (1 - Score) = 1 / (1 + distance), at most n entries
+inline std::vector<Score> embedding_scores(const std::vector<vectors::ScoredVector> &neighbors, const std::string &self, int n) {
+    std::vector<Score> out;
+    for (const auto &nb : neighbors) {
+        if (nb.Id == self) continue;
+        Score s;
+        s.Id = nb.Id;
+        s.Value = 1.0 / (1.0 - (double)nb.Score);
+        s.Categories = nb.Categories;
+        out.push_back(std::move(s));
+        if ((int)out.size() == n) break;
+    }
+    return out;
+}
+
+// QueryItemToItem / QueryUserToUser for Type == "embedding" (item_to_item.go:50-88): GetVectors(id), QueryVectors(n + 1)
+inline std::vector<Score> QuerySimilar(vectors::HipDatabase &client, const std::string &collection, const std::string &id,
+                                       const std::vector<std::string> &categories, int n) {
+    auto queries = client.GetVectors(collection, {id});
+    if (queries.empty()) return {};
+    return embedding_scores(client.QueryVectors(collection, queries[0], categories, n + 1), id, n);
+}
+
+// The same for many ids with ONE bulk search (vectors::HipDatabase::QueryVectorsBatch): the refresh loop of
+// master/tasks.go:930-962 / worker/pipeline.go:403-448 asks for every item's neighbours, which is the all-pairs top-k.
+inline std::vector<std::vector<Score>> QuerySimilarBulk(vectors::HipDatabase &client, const std::string &collection,
+                                                        const std::vector<std::string> &ids,
+                                                        const std::vector<std::string> &categories, int n) {
+    std::vector<std::vector<Score>> out(ids.size());
+    std::vector<float> Q;
+    std::vector<size_t> which;
+    int d = 0;
+    for (size_t t = 0; t < ids.size(); t++) {
+        auto v = client.GetVectors(collection, {ids[t]});
+        if (v.empty()) continue;  // unknown id: empty list, like the nil of item_to_item.go:56-58
+        d = (int)v[0].Values.size();
+        Q.insert(Q.end(), v[0].Values.begin(), v[0].Values.end());
+        which.push_back(t);
+    }
+    if (which.empty()) return out;
+    auto res = client.QueryVectorsBatch(collection, Q, (int64_t)which.size(), categories, n + 1);
+    (void)d;
+    for (size_t r = 0; r < which.size(); r++) out[which[r]] = embedding_scores(res[r], ids[which[r]], n);
+    return out;
+}
+
+}  // namespace logics
 }  // namespace gorse

@@ -229,3 +229,86 @@ class Database:
 def Open(path, tablePrefix=""):
     """vectors.Open (database.go:167-175): creators by URL prefix; 'hip://' is the one registered here."""
     return Database(url=path)
+
+
+# ---- logics: embedding item-to-item / user-to-user (logics/item_to_item.go, user_to_user.go, vector_writer.go) ----------
+def ItemToItemCollection(name):
+    return "item_to_item_" + name  # database.go:56-58
+
+
+def UserToUserCollection(name):
+    return "user_to_user_" + name  # database.go:60-62
+
+
+def _logics_host():
+    H = _host()
+    if not getattr(H, "_logics_ready", False):
+        H.gh_vwriter_new.restype = C.c_void_p
+        H.gh_vwriter_new.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int32]
+        H.gh_vwriter_free.argtypes = [C.c_void_p]
+        H.gh_vwriter_add_staged.argtypes = [C.c_void_p]
+        H.gh_vwriter_clean.argtypes = [C.c_void_p]
+        H.gh_logics_query_similar.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
+        H.gh_logics_query_similar_bulk.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
+        H.gh_logics_result_score.restype = C.c_double
+        H.gh_logics_result_score.argtypes = [C.c_int64]
+        H._logics_ready = True
+    return H
+
+
+class Score:
+    """cache.Score as QueryItemToItem fills it"""
+
+    def __init__(self, Id, Score, Categories):
+        self.Id, self.Score, self.Categories = Id, Score, Categories
+
+
+class EmbeddingItemToItem:
+    """embeddingItemToItem (logics/item_to_item.go:122-152) = a dense VectorWriter with distance Euclidean.  `Add` takes
+    the already extracted embedding (the expr column evaluation of the reference is configuration plumbing)."""
+
+    def __init__(self, name, timestamp, client, batch_size=0, collection=None):
+        self.client, self.timestamp = client, _ms(timestamp)
+        self.collection = collection or ItemToItemCollection(name)
+        self.w = C.c_void_p(_logics_host().gh_vwriter_new(client.h, self.collection.encode(), Euclidean, self.timestamp, batch_size))
+
+    def __del__(self):
+        if getattr(self, "w", None):
+            _logics_host().gh_vwriter_free(self.w)
+            self.w = None
+
+    def Add(self, item_id, embedding, is_hidden=False, categories=()):
+        if embedding is None or isinstance(embedding, str) or len(embedding) == 0:
+            return None  # ExtractItemEmbedding failed / empty (item_to_item.go:137-141): nothing is written
+        H = _logics_host()
+        H.gh_vdb_stage_clear()
+        Database._stage(Vector(item_id, embedding, IsHidden=is_hidden, Categories=categories, Timestamp=self.timestamp))
+        _ck(H.gh_vwriter_add_staged(self.w))
+
+    def Clean(self):
+        _ck(_logics_host().gh_vwriter_clean(self.w))
+
+
+def _scores():
+    H = _logics_host()
+    out = []
+    for r, v in enumerate(Database._results(False)):
+        out.append(Score(v.Id, float(H.gh_logics_result_score(r)), v.Categories))
+    return out
+
+
+def QuerySimilar(client, collection, item_id, categories, n):
+    """QueryItemToItem / QueryUserToUser for the embedding type (item_to_item.go:50-88)"""
+    _ck(_logics_host().gh_logics_query_similar(client.h, collection.encode(), item_id.encode(),
+                                                "\n".join(categories or []).encode(), n))
+    return _scores()
+
+
+def QuerySimilarBulk(client, collection, ids, categories, n):
+    """every id's neighbours with one bulk device search (gorse_vectors.hpp logics::QuerySimilarBulk)"""
+    H = _logics_host()
+    _ck(H.gh_logics_query_similar_bulk(client.h, collection.encode(), "\n".join(ids).encode(),
+                                       "\n".join(categories or []).encode(), n))
+    flat = _scores()
+    cuts = [int(H.gh_vdb_result_split(t)) for t in range(len(ids) + 1)]
+    return [flat[cuts[t]:cuts[t + 1]] for t in range(len(ids))]

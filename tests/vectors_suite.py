@@ -150,3 +150,58 @@ def exact_filtered_topk(db, distance, metric_name, brute):
             if t < 5:
                 one = db.QueryVectors(metric_name, V.Vector(Values=Q[t]), want, topk)
                 assert [(g.Id, g.Score) for g in one] == [(g.Id, g.Score) for g in got]
+
+
+# ---- logics/item_to_item_test.go ------------------------------------------------------------------------------------
+def item_to_item_column(db):  # TestColumnFunc (item_to_item_test.go:46-115): what reaches the vector database
+    i2i = V.EmbeddingItemToItem("column", 1_790_000_000_000, db)
+    coll = V.ItemToItemCollection("column")
+    i2i.Add("1", [0.1, 0.2, 0.3])
+    i2i.Clean()
+    assert db.CountVectors(coll) == 1
+    i2i.Add("2", [0.1, 0.2, 0.3], is_hidden=True)  # hidden items are stored (and never returned)
+    i2i.Clean()
+    assert db.CountVectors(coll) == 2
+    i2i.Add("1", [0.1, 0.2])  # dimension does not match: dropped
+    i2i.Clean()
+    assert db.CountVectors(coll) == 2
+    i2i.Add("1", "hello")  # type does not match
+    i2i.Clean()
+    assert db.CountVectors(coll) == 2
+    i2i.Add("2", None)  # column does not exist
+    i2i.Clean()
+    assert db.CountVectors(coll) == 2
+
+
+def item_to_item_embedding(db):  # TestEmbedding (item_to_item_test.go:117-141)
+    i2i = V.EmbeddingItemToItem("embedding", 1_790_000_000_000, db)
+    for i in range(100):
+        f = np.float32(i)
+        i2i.Add(str(i), [np.float32(0.1) * f, np.float32(0.2) * f, np.float32(0.3) * f])
+    i2i.Clean()
+    coll = V.ItemToItemCollection("embedding")
+    scores = V.QuerySimilar(db, coll, "0", None, 10)
+    assert [s.Id for s in scores] == [str(i) for i in range(1, 11)]
+    assert all(0 < s.Score < 1 for s in scores) and scores[0].Score > scores[-1].Score  # 1 / (1 + distance)
+    assert V.QuerySimilar(db, coll, "no-such-item", None, 10) == []
+    bulk = V.QuerySimilarBulk(db, coll, [str(i) for i in range(100)] + ["missing"], None, 5)
+    assert bulk[-1] == [] and len(bulk) == 101
+    for i in (0, 1, 50, 99):
+        one = V.QuerySimilar(db, coll, str(i), None, 5)
+        assert [(s.Id, s.Score) for s in bulk[i]] == [(s.Id, s.Score) for s in one]
+    assert [s.Id for s in bulk[50]][:2] in (["49", "51"], ["51", "49"])
+
+
+def item_to_item_clean(db):  # TestClean (item_to_item_test.go:143-170): Clean drops what an earlier refresh left behind
+    ts = 1_790_000_000_000
+    coll = V.ItemToItemCollection("cleanup")
+    db.AddCollection(coll, 2, V.Euclidean)
+    db.AddVectors(coll, [V.Vector("stale", [0, 0], Timestamp=ts - 3_600_000), V.Vector("fresh", [1, 1], Timestamp=ts)])
+    i2i = V.EmbeddingItemToItem("cleanup", ts, db)
+    i2i.Clean()
+    assert db.CountVectors(coll) == 1 and db.GetVectors(coll, ["stale", "fresh"])[0].Id == "fresh"
+    # a collection with another dimension is recreated by the writer (vector_writer.go:127-137)
+    i2i3 = V.EmbeddingItemToItem("cleanup", ts + 1, db)
+    i2i3.Add("x", [1, 2, 3])
+    i2i3.Clean()
+    assert db.DescribeCollection(coll)["Dimension"] == 3 and db.CountVectors(coll) == 1
