@@ -205,3 +205,26 @@ def item_to_item_clean(db):  # TestClean (item_to_item_test.go:143-170): Clean d
     i2i3.Add("x", [1, 2, 3])
     i2i3.Clean()
     assert db.DescribeCollection(coll)["Dimension"] == 3 and db.CountVectors(coll) == 1
+
+
+# ---- logics/user_to_user_test.go (the embedding kind is the same writer and query over the user_to_user_* collection) --
+def user_to_user_embedding(db):  # TestEmbedding (user_to_user_test.go:48-71)
+    coll = V.UserToUserCollection("embedding")
+    u2u = V.EmbeddingItemToItem("embedding", 1_790_000_000_000, db, collection=coll)
+    for i in range(100):
+        f = np.float32(i)
+        u2u.Add(str(i), [np.float32(0.1) * f, np.float32(0.2) * f, np.float32(0.3) * f])
+    u2u.Clean()
+    scores = V.QuerySimilar(db, coll, "0", None, 10)
+    assert [s.Id for s in scores] == [str(i) for i in range(1, 11)]
+
+
+def user_to_user_clean(db):  # TestClean (user_to_user_test.go:73-93)
+    ts = 1_790_000_000_000
+    coll = V.UserToUserCollection("cleanup")
+    db.AddCollection(coll, 2, V.Euclidean)
+    db.AddVectors(coll, [V.Vector("stale", [0, 0], Timestamp=ts - 3_600_000), V.Vector("current", [1, 0], Timestamp=ts)])
+    w = V.EmbeddingItemToItem("cleanup", ts, db, collection=coll)
+    w.Add("new", [2, 0])
+    w.Clean()
+    assert [v.Id for v in db.GetVectors(coll, ["stale", "current", "new"])] == ["current", "new"]
