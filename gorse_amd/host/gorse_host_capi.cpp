@@ -423,4 +423,28 @@ int32_t gh_logics_query_similar_bulk(void *h, const char *collection, const char
     return guard([&] { stage_scores(logics::QuerySimilarBulk(vdb(h), collection, split_lines(ids), split_lines(categories), n)); });
 }
 double gh_logics_result_score(int64_t r) { return g_scores[(size_t)r]; }
+
+// users: Q is n_users x d; excludes: one '\n'-joined id list per user, users separated by '\x1e' (record separator)
+int32_t gh_logics_cf_recommend_bulk(void *h, const char *collection, const float *Q, int64_t n_users, int32_t d,
+                                    const char *excludes, int32_t cache_size) {
+    return guard([&] {
+        std::vector<logics::UserQuery> users((size_t)n_users);
+        std::vector<std::string> per_user;
+        std::string cur;
+        for (const char *p = excludes ? excludes : "";; p++) {
+            if (*p == '\x1e' || *p == 0) {
+                per_user.push_back(cur);
+                cur.clear();
+                if (*p == 0) break;
+            } else {
+                cur.push_back(*p);
+            }
+        }
+        for (int64_t t = 0; t < n_users; t++) {
+            users[(size_t)t].Embedding.assign(Q + t * d, Q + (t + 1) * d);
+            if ((size_t)t < per_user.size()) users[(size_t)t].Exclude = split_lines(per_user[(size_t)t].c_str());
+        }
+        stage_scores(logics::CollaborativeRecommendBulk(vdb(h), collection, users, cache_size));
+    });
+}
 }  // extern "C"

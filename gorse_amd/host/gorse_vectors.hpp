@@ -456,5 +456,40 @@ inline std::vector<std::vector<Score>> QuerySimilarBulk(vectors::HipDatabase &cl
     return out;
 }
 
+// worker/pipeline.go:403-425 (updateCollaborativeRecommend) for MANY users at once: the reference asks the vector
+// database for CacheSize + |excludeSet| neighbours of the user's embedding in the collaborative_filtering_<id> collection
+// (distance Dot, filled by master/tasks.go:930-962) and drops the excluded ids.  Here all users go through one bulk
+// search with k = CacheSize + the largest exclude set; each user's list is the first CacheSize + |exclude_u| entries of
+// its row with the excluded ids dropped -- the per-user result of the reference (ties at a cut may order differently).
+struct UserQuery {
+    std::vector<float> Embedding;
+    std::vector<std::string> Exclude;
+};
+inline std::vector<std::vector<Score>> CollaborativeRecommendBulk(vectors::HipDatabase &client, const std::string &collection,
+                                                                  const std::vector<UserQuery> &users, int cacheSize) {
+    std::vector<std::vector<Score>> out(users.size());
+    if (users.empty()) return out;
+    size_t max_ex = 0;
+    std::vector<float> Q;
+    for (const auto &u : users) {
+        max_ex = std::max(max_ex, u.Exclude.size());
+        Q.insert(Q.end(), u.Embedding.begin(), u.Embedding.end());
+    }
+    auto res = client.QueryVectorsBatch(collection, Q, (int64_t)users.size(), {}, cacheSize + (int)max_ex);
+    for (size_t t = 0; t < users.size(); t++) {
+        const size_t take = (size_t)cacheSize + users[t].Exclude.size();
+        for (size_t e = 0; e < res[t].size() && e < take; e++) {
+            const auto &v = res[t][e];
+            if (std::find(users[t].Exclude.begin(), users[t].Exclude.end(), v.Id) != users[t].Exclude.end()) continue;
+            Score sc;
+            sc.Id = v.Id;
+            sc.Value = (double)v.Score;
+            sc.Categories = v.Categories;
+            out[t].push_back(std::move(sc));
+        }
+    }
+    return out;
+}
+
 }  // namespace logics
 }  // namespace gorse

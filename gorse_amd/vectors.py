@@ -250,6 +250,8 @@ def _logics_host():
         H.gh_vwriter_clean.argtypes = [C.c_void_p]
         H.gh_logics_query_similar.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
         H.gh_logics_query_similar_bulk.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
+        H.gh_logics_cf_recommend_bulk.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_char_p,
+                                                  C.c_int32]
         H.gh_logics_result_score.restype = C.c_double
         H.gh_logics_result_score.argtypes = [C.c_int64]
         H._logics_ready = True
@@ -312,3 +314,20 @@ def QuerySimilarBulk(client, collection, ids, categories, n):
     flat = _scores()
     cuts = [int(H.gh_vdb_result_split(t)) for t in range(len(ids) + 1)]
     return [flat[cuts[t]:cuts[t + 1]] for t in range(len(ids))]
+
+
+def CollaborativeFilteringCollection(model_id):
+    return "collaborative_filtering_%d" % model_id  # database.go:52-54
+
+
+def CollaborativeRecommendBulk(client, collection, embeddings, excludes, cache_size):
+    """updateCollaborativeRecommend (worker/pipeline.go:403-425) for many users with one bulk device search; excludes[t] =
+    the ids user t has already seen.  Returns one Score list per user."""
+    H = _logics_host()
+    Q = np.ascontiguousarray(embeddings, np.float32)
+    ex = "\x1e".join("\n".join(e) for e in excludes)
+    _ck(H.gh_logics_cf_recommend_bulk(client.h, collection.encode(), Q.ctypes.data_as(C.POINTER(C.c_float)), Q.shape[0],
+                                      Q.shape[1], ex.encode(), cache_size))
+    flat = _scores()
+    cuts = [int(H.gh_vdb_result_split(t)) for t in range(Q.shape[0] + 1)]
+    return [flat[cuts[t]:cuts[t + 1]] for t in range(Q.shape[0])]

@@ -27,7 +27,7 @@ def db(oracle):
 
 @pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.sparse, S.hidden, S.dot, S.delete_vectors,
                                   S.upsert_and_close, S.item_to_item_column, S.item_to_item_embedding, S.item_to_item_clean,
-                                  S.user_to_user_embedding, S.user_to_user_clean],
+                                  S.user_to_user_embedding, S.user_to_user_clean, S.collaborative_recommend],
                          ids=lambda f: f.__name__)
 def test_reference_suite(db, case):
     case(db)

@@ -228,3 +228,29 @@ def user_to_user_clean(db):  # TestClean (user_to_user_test.go:73-93)
     w.Add("new", [2, 0])
     w.Clean()
     assert [v.Id for v in db.GetVectors(coll, ["stale", "current", "new"])] == ["current", "new"]
+
+
+# ---- master/tasks.go:930-962 + worker/pipeline.go:403-425: item factors in a Dot collection, per-user recommendations ----
+def collaborative_recommend(db):
+    rng = np.random.default_rng(12)
+    n_items, n_users, d, cache_size = 400, 90, 16, 10
+    Qf = (rng.standard_normal((n_items, d)) * 0.3).astype(np.float32)
+    P = (rng.standard_normal((n_users, d)) * 0.3).astype(np.float32)
+    coll = V.CollaborativeFilteringCollection(1790000000000)
+    db.AddCollection(coll, d, V.Dot)
+    for start in range(0, n_items, 128):  # batches, as the master's index loop
+        db.AddVectors(coll, [V.Vector("i%d" % i, Qf[i], IsHidden=(i % 17 == 0), Categories=["c%d" % (i % 3)])
+                             for i in range(start, min(start + 128, n_items))])
+    excludes = [["i%d" % i for i in rng.choice(n_items, int(rng.integers(0, 25)), replace=False)] for _ in range(n_users)]
+    bulk = V.CollaborativeRecommendBulk(db, coll, P, excludes, cache_size)
+    assert len(bulk) == n_users
+    for u in range(n_users):
+        # the reference's per-user form: QueryVectors(CacheSize + |exclude|), then drop the excluded ids
+        ref = [v for v in db.QueryVectors(coll, V.Vector(Values=P[u]), None, cache_size + len(excludes[u])) if v.Id not in excludes[u]]
+        assert [s.Id for s in bulk[u]] == [v.Id for v in ref], u
+        assert [np.float32(s.Score) for s in bulk[u]] == [np.float32(v.Score) for v in ref]
+        assert len(bulk[u]) >= cache_size and not any(s.Id in excludes[u] for s in bulk[u])
+        assert all(int(s.Id[1:]) % 17 != 0 for s in bulk[u])  # hidden items never recommended
+        # scores are the inner products (Dot), best first
+        want = sorted((float(np.float32(np.dot(P[u].astype(np.float64), Qf[int(s.Id[1:])].astype(np.float64)))) for s in bulk[u]), reverse=True)
+        assert np.allclose([s.Score for s in bulk[u]], want, rtol=1e-5, atol=1e-6)
