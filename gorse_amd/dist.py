@@ -106,15 +106,20 @@ class TorchComm:
 class HipEngine:
     """A gorse_mf handle + a torch CUDA buffer that carries the item-factor delta through RCCL."""
 
-    def __init__(self, mf, mode):
+    def __init__(self, mf, mode, device="cuda"):
         self.mf, self.mode = mf, mode
         self.xbuf = None
         self.torch = None  # imported only when a collective is needed (single-GPU use never touches torch)
+        self.device = device  # where the exchange buffers live ("cpu" only in the gloo tests, with a stand-in handle)
+
+    def _sync(self):
+        if self.device != "cpu":
+            self.torch.cuda.synchronize()
 
     def enable_exchange(self):
         import torch
         self.torch = torch
-        self.xbuf = self.torch.empty(self.mf.I * self.mf.d, dtype=self.torch.float32, device="cuda")
+        self.xbuf = self.torch.empty(self.mf.I * self.mf.d, dtype=self.torch.float32, device=self.device)
         self.mf.item_sync_mark()
         self.mf.synchronize()
 
@@ -127,7 +132,6 @@ class HipEngine:
 
     def set_eval(self, test_ptr, test_idx, neg_ptr, neg_idx):
         """test split of THIS rank's users (local user ids): positives + sampled negatives per user"""
-        self.device = "cuda"
         self.eval_split = (np.asarray(test_ptr, np.int64), np.asarray(test_idx, np.int32),
                            np.asarray(neg_ptr, np.int64), np.asarray(neg_idx, np.int32))
 
@@ -140,22 +144,23 @@ class HipEngine:
         return M.partial_sums(rank, rlen, users, test_ptr, test_idx, metrics)
 
     def import_delta(self, delta):
-        self.torch.cuda.synchronize()  # the collective ran on torch's stream
+        self._sync()  # the collective ran on torch's stream
         self.mf.item_delta_import(delta.data_ptr())
 
 
 class HipAlsEngine:
     """A gorse_mf handle restricted to this rank's row ranges + torch CUDA buffers for the all-gathers."""
 
-    def __init__(self, mf, rank, world):
+    def __init__(self, mf, rank, world, device="cuda"):
         import torch
         self.torch = torch
+        self.device = device
         self.mf, self.rank, self.world = mf, rank, world
         self.rows = (mf.U, mf.I)
         self.range = [shard_range(n, rank, world) for n in self.rows]
         mf.als_set_ranges(self.range[0][0], self.range[0][1], self.range[1][0], self.range[1][1])
         self.block = [block_rows(n, world) for n in self.rows]
-        self.buf = [torch.zeros(b * mf.d, dtype=torch.float32, device="cuda") for b in self.block] if world > 1 else None
+        self.buf = [torch.zeros(b * mf.d, dtype=torch.float32, device=device) for b in self.block] if world > 1 else None
 
     def half(self, side, weight, reg):
         self.mf.als_half_epoch(side, weight, reg)
@@ -166,7 +171,8 @@ class HipAlsEngine:
         return self.buf[side]
 
     def import_blocks(self, side, gathered):
-        self.torch.cuda.synchronize()  # the collective ran on torch's stream
+        if self.device != "cpu":
+            self.torch.cuda.synchronize()  # the collective ran on torch's stream
         d, b = self.mf.d, self.block[side]
         for r in range(self.world):
             if r == self.rank:

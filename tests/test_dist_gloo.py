@@ -233,3 +233,116 @@ def test_sharded_evaluate_equals_evaluate(tmp_path, world):
         got = np.load(tmp_path / ("eval%d.npy" % r))
         assert np.allclose(got, ref, atol=2e-6), (got, ref)
     assert np.array_equal(np.load(tmp_path / "eval0.npy"), np.load(tmp_path / ("eval%d.npy" % (world - 1))))
+
+
+# ---- the GPU engines themselves (HipEngine / HipAlsEngine) over gloo, with a stand-in for the gorse_mf handle ----------
+class StandInMF:
+    """Implements the gorse_mf calls the engines make (capi.MF's method names and pointer conventions) with the oracle
+    as the compute and host memory as "device" memory, so that the engines' own code -- ranges, block sizes, buffer
+    offsets, call order -- runs under gloo exactly as it runs under RCCL."""
+
+    def __init__(self, data, P, Q):
+        import ctypes
+        from oracle import oracle as orc
+        self.ct, self.o = ctypes, orc.Oracle()
+        self.data = data
+        self.U, self.I, self.d = P.shape[0], Q.shape[0], P.shape[1]
+        self.F = [np.ascontiguousarray(P.copy()), np.ascontiguousarray(Q.copy())]
+        self.Qsync = None
+        self.ranges = [(0, self.U), (0, self.I)]
+        self.srt = orc.sort_rows(data.uptr, data.uidx) if data is not None else None
+
+    def _view(self, ptr, n):
+        return np.ctypeslib.as_array(self.ct.cast(ptr, self.ct.POINTER(self.ct.c_float)), (n,))
+
+    # ALS
+    def als_set_ranges(self, u0, u1, i0, i1):
+        self.ranges = [(u0, u1), (i0, i1)]
+
+    def als_half_epoch(self, side, w, reg):
+        d = self.data
+        ptr, idx, bptr = (d.uptr, d.uidx, d.iptr) if side == 0 else (d.iptr, d.iidx, d.uptr)
+        self.o.als_half_range(self.F[side], self.F[1 - side], ptr, idx, bptr, w, reg, *self.ranges[side])
+
+    def rows_export(self, side, lo, hi, ptr):
+        self._view(ptr, (hi - lo) * self.d)[:] = self.F[side][lo:hi].ravel()
+
+    def rows_import(self, side, lo, hi, ptr):
+        self.F[side][lo:hi] = self._view(ptr, (hi - lo) * self.d).reshape(hi - lo, self.d)
+
+    # BPR
+    def bpr_epoch_enqueue(self, n, lr, reg, seed, epoch, sample_base=0, mode=0):
+        self.o.bpr_epoch_sampled(self.F[0], self.F[1], self.data.uptr, self.data.uidx, self.srt, seed, epoch, sample_base, n, lr, reg)
+
+    def item_sync_mark(self):
+        self.Qsync = self.F[1].copy()
+
+    def synchronize(self):
+        pass
+
+    def item_delta_export(self, ptr):
+        self._view(ptr, self.I * self.d)[:] = (self.F[1] - self.Qsync).ravel()
+
+    def item_delta_import(self, ptr):
+        self.F[1] = (self.Qsync + self._view(ptr, self.I * self.d).reshape(self.I, self.d)).astype(np.float32)
+        self.Qsync = self.F[1].copy()
+
+
+def _hip_engines_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = gdist.TorchComm()
+    # ALS through HipAlsEngine
+    data, P, Q = _als_problem()
+    eng = gdist.HipAlsEngine(StandInMF(data, P, Q), rank, world, device="cpu")
+    for _ in range(2):
+        gdist.run_als_epoch(eng, comm, 0.05, 0.015)
+    np.save(os.path.join(out, "hP%d.npy" % rank), eng.mf.F[0])
+    np.save(os.path.join(out, "hQ%d.npy" % rank), eng.mf.F[1])
+    # BPR through HipEngine
+    data, P, Q = _problem()
+    lo, hi, uptr, uidx, n = _rank_inputs(data, P, rank, world)
+    import types
+    shard = types.SimpleNamespace(uptr=uptr, uidx=uidx)
+    beng = gdist.HipEngine(StandInMF(shard, P[lo:hi], Q), 0, device="cpu")
+    beng.enable_exchange()
+    for ep in range(1, 3):
+        gdist.run_epoch(beng, comm, n, 0.05, 0.01, 11, ep, rank * (1 << 40))
+    np.save(os.path.join(out, "bP%d.npy" % rank), beng.mf.F[0])
+    np.save(os.path.join(out, "bQ%d.npy" % rank), beng.mf.F[1])
+    dist.destroy_process_group()
+
+
+def test_hip_engines_over_gloo_with_a_stand_in_handle(tmp_path):
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_hip_engines_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as orc
+    o = orc.Oracle()
+    data, P, Q = _als_problem()
+    eP, eQ = P, Q
+    for _ in range(2):
+        eP, eQ = o.als_epoch(eP, eQ, data.uptr, data.uidx, data.iptr, data.iidx, 0.05, 0.015)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("hP%d.npy" % r)), eP) and np.array_equal(np.load(tmp_path / ("hQ%d.npy" % r)), eQ)
+    # BPR: the same emulation as test_two_rank_bpr_matches_single_process_emulation, two epochs
+    data, P, Q = _problem()
+    engines = []
+    for r in range(world):
+        lo, hi, uptr, uidx, n = _rank_inputs(data, P, r, world)
+        engines.append((OracleEngine(P[lo:hi], Q, uptr, uidx), n))
+    for ep in range(1, 3):
+        deltas = []
+        for r, (e, n) in enumerate(engines):
+            e.epoch(n, 0.05, 0.01, 11, ep, r * (1 << 40))
+            deltas.append(e.export_delta())
+        total = deltas[0] + deltas[1]
+        for e, _ in engines:
+            e.import_delta(total.clone())
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("bP%d.npy" % r)), engines[r][0].P)
+        assert np.array_equal(np.load(tmp_path / ("bQ%d.npy" % r)), engines[r][0].Q)
