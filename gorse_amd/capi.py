@@ -1,7 +1,7 @@
 """ctypes binding of the C ABI in include/gorse_hip.h (libgorse_hip.so).
 
 This is plumbing: every entry point of the header is declared here with its exact
-signature, plus thin numpy-friendly wrappers (`MF`, `TopK`).  There is NO CPU fallback:
+signature, plus thin numpy-friendly wrappers (`MF`, `TopK`, `Sparse`).  There is NO CPU fallback:
 if the shared library is missing, or no gfx950 device is visible when a handle is
 created, the call raises.
 """
@@ -66,6 +66,15 @@ SIGNATURES = {
     "gorse_topk_set_profiling": (C.c_int32, [_vp, C.c_int32]),
     "gorse_topk_get_profile": (C.c_int32, [_vp, C.c_int32, _i64p, _f64p]),
     "gorse_topk_last_stats": (C.c_int32, [_vp, _i64p, _i64p]),
+    "gorse_sparse_create": (C.c_int32, [C.POINTER(_vp), C.c_int32, C.c_int64, _i64p, _vp, _f32p]),
+    "gorse_sparse_destroy": (C.c_int32, [_vp]),
+    "gorse_sparse_set_mask": (C.c_int32, [_vp, _vp]),
+    "gorse_sparse_search": (C.c_int32, [_vp, C.c_int64, _i64p, _vp, _f32p, _i64p, C.c_int32, _i32p, _f32p, _i32p]),
+    "gorse_sparse_all_pairs": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _i32p, _f32p, _i32p]),
+    "gorse_sparse_synchronize": (C.c_int32, [_vp]),
+    "gorse_sparse_set_profiling": (C.c_int32, [_vp, C.c_int32]),
+    "gorse_sparse_get_profile": (C.c_int32, [_vp, _i64p, _f64p]),
+    "gorse_sparse_last_stats": (C.c_int32, [_vp, _i64p, _i64p]),
     "gorse_hip_sgemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_int32,
                                     _f32p, C.c_int32, _f32p, C.c_int32]),
     "gorse_hip_test_set_exact_exp": (None, [C.c_int32]),
@@ -326,6 +335,69 @@ class TopK:
     def last_stats(self):
         a, b = C.c_int64(0), C.c_int64(0)
         check(lib().gorse_topk_last_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+class Sparse:
+    """One gorse_sparse handle: N sparse vectors (CSR, strictly ascending indices per row) resident on one GPU."""
+
+    def __init__(self, indptr, indices, values, device=0):
+        self.indptr = _arr(indptr, np.int64)
+        self.indices = _arr(indices, np.uint32)
+        self.values = _arr(values, np.float32)
+        self.N = self.indptr.size - 1
+        self.h = _vp()
+        check(lib().gorse_sparse_create(C.byref(self.h), device, self.N, _p(self.indptr, _i64p),
+                                        self.indices.ctypes.data_as(_vp), _p(self.values, _f32p)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gorse_sparse_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_mask(self, admissible=None):
+        m = None if admissible is None else _arr(admissible, np.uint8)
+        if m is not None and m.size != self.N:
+            raise GorseHipError(ERR_INVALID, "mask must have N entries")
+        check(lib().gorse_sparse_set_mask(self.h, None if m is None else m.ctypes.data_as(_vp)))
+
+    def search(self, q_indptr, q_indices, q_values, k, exclude=None):
+        qp = _arr(q_indptr, np.int64)
+        qi = _arr(q_indices, np.uint32)
+        qv = _arr(q_values, np.float32)
+        nq = qp.size - 1
+        ex = None if exclude is None else _arr(exclude, np.int64)
+        idx, sc, cnt = np.empty((nq, k), np.int32), np.empty((nq, k), np.float32), np.empty(nq, np.int32)
+        check(lib().gorse_sparse_search(self.h, nq, _p(qp, _i64p), qi.ctypes.data_as(_vp), _p(qv, _f32p), _p(ex, _i64p), k,
+                                        _p(idx, _i32p), _p(sc, _f32p), _p(cnt, _i32p)))
+        return idx, sc, cnt
+
+    def all_pairs(self, k, q_begin=0, q_end=None, exclude_self=True, fetch=True):
+        q_end = self.N if q_end is None else q_end
+        nq = q_end - q_begin
+        idx = np.empty((nq, k), np.int32) if fetch else None
+        sc = np.empty((nq, k), np.float32) if fetch else None
+        cnt = np.empty(nq, np.int32) if fetch else None
+        check(lib().gorse_sparse_all_pairs(self.h, q_begin, q_end, k, int(bool(exclude_self)), _p(idx, _i32p),
+                                           _p(sc, _f32p), _p(cnt, _i32p)))
+        return idx, sc, cnt
+
+    def synchronize(self):
+        check(lib().gorse_sparse_synchronize(self.h))
+
+    def set_profiling(self, on):
+        check(lib().gorse_sparse_set_profiling(self.h, int(bool(on))))
+
+    def get_profile(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        check(lib().gorse_sparse_get_profile(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def last_stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib().gorse_sparse_last_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
 

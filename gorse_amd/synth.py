@@ -203,3 +203,29 @@ def s_als(U=500_000, I=100_000, nnz=50_000_000, seed=45, zipf_s=1.0):
     iptr = np.zeros(I + 1, np.int64)
     np.cumsum(np.bincount(uidx, minlength=I), out=iptr[1:])
     return uptr, uidx, iptr, iidx
+
+
+def idf_vectors(ptr, idx, n_other):
+    """The sparse vectors of the "users" item-to-item / "items" user-to-user recommenders for the rows of one CSR
+    side (logics/item_to_item.go:209-220, user_to_user.go:201-212): row r = its feedback ids ascending
+    (slices.Sort), value sqrt(idf[id]) with idf[id] = log(1 + n_rows / freq(id)) in float32
+    (dataset/dataset.go:160-180: GetUserIDF divides the ITEM count by the user's frequency and vice versa; here the
+    rows are the counted side), ids with idf <= 0 dropped (vector_writer.go:200-208).
+    ptr/idx: row -> ids CSR (e.g. CFData.iptr/iidx = item -> users); n_other = number of distinct ids.
+    Returns (indptr int64, indices uint32, values float32)."""
+    ptr = np.asarray(ptr, np.int64)
+    idx = np.asarray(idx, np.int64)
+    n_rows = ptr.size - 1
+    freq = np.bincount(idx, minlength=n_other).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        idf = np.log((np.float32(1) + np.float32(n_rows) / freq).astype(np.float64)).astype(np.float32)
+    val_of = np.sqrt(idf.astype(np.float64)).astype(np.float32)
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(ptr))
+    order = np.lexsort((idx, rows))
+    rows, ids = rows[order], idx[order]
+    keep = idf[ids] > 0
+    keep[1:] &= ~((rows[1:] == rows[:-1]) & (ids[1:] == ids[:-1]))  # a set: duplicates once
+    rows, ids = rows[keep], ids[keep]
+    out_ptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum(np.bincount(rows, minlength=n_rows), out=out_ptr[1:])
+    return out_ptr, np.ascontiguousarray(ids.astype(np.uint32)), np.ascontiguousarray(val_of[ids])

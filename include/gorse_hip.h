@@ -195,6 +195,43 @@ int32_t gorse_topk_get_profile(gorse_topk *h, int32_t kernel_class, int64_t *lau
 /* statistics of the last all_pairs / search call: queries that took the exact fallback path */
 int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int64_t *n_tie_resolved);
 
+/* ---- exact sparse top-k: the sparse collections of vectors.Database --------------------------------
+ * storage/vectors/database.go:90-97 (Vector.Indices / Values), xvec.go:241-247 (dimension 0 = sparse, distance Dot
+ * only, Flat = exact index), filled by the IDF item-to-item / user-to-user writers of logics/vector_writer.go:192-209
+ * (ascending ids, value sqrt(idf)) and queried by logics/item_to_item.go:50-88.
+ * N stored vectors as CSR: indptr[N+1], indices[nnz] STRICTLY ASCENDING inside a row, values[nnz].
+ * Score of (query, row) = sum over the common indices, in ascending index order, of q_value * x_value, each product
+ * and each addition rounded to float32 (no fused multiply-add).  A row is a hit when it shares at least one index
+ * with the query (TestSparse, database_test.go:217-224: the disjoint vector is not returned).  Results per query:
+ * the k hits with the largest score, descending; equal scores in ascending row order (the reference's Flat index is a
+ * third-party module whose tie order no test pins); -0 counts as +0.  idx_out / score_out are nq*k padded with
+ * -1 / -inf, count_out[t] = number of valid entries. */
+typedef struct gorse_sparse gorse_sparse;
+int32_t gorse_sparse_create(gorse_sparse **h, int32_t device, int64_t N, const int64_t *indptr /*host*/,
+                            const uint32_t *indices /*host*/, const float *values /*host*/);
+int32_t gorse_sparse_destroy(gorse_sparse *h);
+/* admissible[r] == 0 removes row r from every later result (IsHidden / the categories CONTAIN_ALL filter of
+ * xvec.go:379-446 evaluated by the caller); NULL = all rows admissible (the default). */
+int32_t gorse_sparse_set_mask(gorse_sparse *h, const uint8_t *admissible /*host, N bytes, or NULL*/);
+/* nq query vectors as CSR (same ordering rule as the stored rows; indices the index never saw match nothing).
+ * exclude[t] (array may be NULL, entries may be -1) is a stored row left out of query t's result. */
+int32_t gorse_sparse_search(gorse_sparse *h, int64_t nq, const int64_t *q_indptr /*host*/,
+                            const uint32_t *q_indices /*host*/, const float *q_values /*host*/,
+                            const int64_t *exclude /*host or NULL*/, int32_t k, int32_t *idx_out /*host*/,
+                            float *score_out /*host*/, int32_t *count_out /*host*/);
+/* every stored row q in [q_begin, q_end) as a query (the item-to-item / user-to-user refresh): exclude_self != 0
+ * leaves row q out of its own result.  Host pointers may be NULL (results stay on the device). */
+int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t exclude_self,
+                               int32_t *idx_out /*host or NULL*/, float *score_out /*host or NULL*/,
+                               int32_t *count_out /*host or NULL*/);
+int32_t gorse_sparse_synchronize(gorse_sparse *h);
+/* measurement: hipEvent pairs around sparse_query_kernel on the handle's stream, and the work of the last call:
+ * postings = sum over its queries and their indices of the posting-list lengths (= multiply-adds performed; the
+ * kernel reads 8 bytes per posting), hits = rows that shared an index with their query. */
+int32_t gorse_sparse_set_profiling(gorse_sparse *h, int32_t on);
+int32_t gorse_sparse_get_profile(gorse_sparse *h, int64_t *launches, double *total_ms);
+int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, int64_t *hits);
+
 /* ---- floats.MM / blas.SGEMM, common/floats/floats.go:241, mm.go:19-49 ------------------------
  * Row-major C(m x n) = op(A) op(B) with the reference's own semantics: the NN, TN and TT
  * cases ACCUMULATE into C, the NT case overwrites it (mm.go:20-48, floats_avx512.c:443-480). */

@@ -107,6 +107,14 @@ class Oracle:
                                                    _i32p, _f32p]
         L.orc_philox4x32_10.restype = None
         L.orc_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
+        _u8p = C.POINTER(C.c_uint8)
+        L.orc_sparse_dot.restype = C.c_int64
+        L.orc_sparse_dot.argtypes = [_u32p, _f32p, C.c_int64, _u32p, _f32p, C.c_int64, _f32p]
+        L.orc_sparse_search.restype = C.c_int
+        L.orc_sparse_search.argtypes = [C.c_int64, _i64p, _u32p, _f32p, _u32p, _f32p, C.c_int64, C.c_int64, _u8p,
+                                        C.c_int, _i32p, _f32p]
+        L.orc_idf.restype = None
+        L.orc_idf.argtypes = [_i32p, C.c_int64, C.c_int64, _f32p]
         L.orc_mm.restype = None
         L.orc_mm.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _f32p, C.c_int64, _f32p, C.c_int64,
                              _f32p, C.c_int64]
@@ -235,6 +243,41 @@ class Oracle:
         cnt = self.L.orc_bruteforce_search_vector(px, n, d, metric, pq, k, int(prune0), oi.ctypes.data_as(_i32p),
                                                   ow.ctypes.data_as(_f32p))
         return oi[:cnt].copy(), ow[:cnt].copy()
+
+    # ---- sparse collections (vectors.Database, dimension 0 / Dot) -------------------------
+    def sparse_dot(self, ia, va, ib, vb):
+        ia = np.ascontiguousarray(ia, dtype=np.uint32)
+        ib = np.ascontiguousarray(ib, dtype=np.uint32)
+        va, pva = _f32(va)
+        vb, pvb = _f32(vb)
+        out = np.zeros(1, dtype=np.float32)
+        common = self.L.orc_sparse_dot(ia.ctypes.data_as(_u32p), pva, ia.size, ib.ctypes.data_as(_u32p), pvb, ib.size,
+                                       out.ctypes.data_as(_f32p))
+        return int(common), out[0]
+
+    def sparse_search(self, indptr, indices, values, q_idx, q_val, k, exclude=-1, admissible=None):
+        """One query against the CSR rows: (row indices, scores) of the k best hits, best first."""
+        indptr, pp = _i64(indptr)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        values, pv = _f32(values)
+        q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32)
+        q_val, pqv = _f32(q_val)
+        pm = None
+        if admissible is not None:
+            admissible = np.ascontiguousarray(admissible, dtype=np.uint8)
+            pm = admissible.ctypes.data_as(C.POINTER(C.c_uint8))
+        oi = np.zeros(k + 1, dtype=np.int32)
+        ow = np.zeros(k + 1, dtype=np.float32)
+        cnt = self.L.orc_sparse_search(indptr.size - 1, pp, indices.ctypes.data_as(_u32p), pv,
+                                       q_idx.ctypes.data_as(_u32p), pqv, q_idx.size, int(exclude), pm, k,
+                                       oi.ctypes.data_as(_i32p), ow.ctypes.data_as(_f32p))
+        return oi[:cnt].copy(), ow[:cnt].copy()
+
+    def idf(self, freq, total):
+        freq, pf = _i32(freq)
+        out = np.zeros(freq.size, dtype=np.float32)
+        self.L.orc_idf(pf, freq.size, int(total), out.ctypes.data_as(_f32p))
+        return out
 
     def distance(self, metric, a, b):
         a, pa = _f32(a)

@@ -1,0 +1,144 @@
+"""GPU parity: exact top-k over sparse vectors (the sparse collections of vectors.Database: storage/vectors/
+database.go:90-97, xvec.go:241-247; filled by the IDF writers of logics/vector_writer.go:192-209) through the C ABI
+(gorse_sparse_*), against the oracle's merge-order sparse dot: rows, score bits, counts and padding."""
+import numpy as np
+import pytest
+
+from gorse_amd import capi, synth
+from sparse_cases import check_against_oracle as check, random_csr, rows_of, tie_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_all_pairs_equals_oracle(oracle):
+    rng = np.random.default_rng(100)
+    ptr, idx, val = random_csr(rng, 600, 400, 0, 30)
+    s = capi.Sparse(ptr, idx, val)
+    for k in (7, 64, 100):
+        got = s.all_pairs(k)
+        check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(600)), list(range(600)))
+    # statistics of the last call: multiply-adds = posting-list lengths summed over the queries' indices
+    lens = np.bincount(idx, minlength=400)
+    postings, hits = s.last_stats()
+    assert postings == int(lens[idx].sum())
+    got = s.all_pairs(5, q_begin=590, q_end=597, exclude_self=False)
+    check(oracle, ptr, idx, val, 5, got, rows_of(ptr, idx, val, range(590, 597)), [-1] * 7)
+
+
+@pytest.mark.parametrize("k", [3, 10, 64, 65, 200, 513, 1024])
+def test_many_hits_overflow_the_ranking_buffer(oracle, k):
+    """far more hits than the 2*KP slots of the LDS buffer, negative scores included"""
+    rng = np.random.default_rng(7)
+    ptr, idx, val = random_csr(rng, 5000, 30, 3, 12, neg=True)
+    qp, qi, qv = random_csr(rng, 9, 30, 8, 20, neg=True)
+    s = capi.Sparse(ptr, idx, val)
+    got = s.search(qp, qi, qv, k)
+    check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(9)), [-1] * 9)
+
+
+def test_ties_zero_scores_mask_and_exclude(oracle):
+    ptr, idx, val, (qp, qi, qv), mask, excl = tie_case()
+    s = capi.Sparse(ptr, idx, val)
+    s.set_mask(mask)
+    got = s.search(qp, qi, qv, 20, exclude=excl)
+    check(oracle, ptr, idx, val, 20, got, rows_of(qp, qi, qv, range(3)), list(excl), mask)
+    assert list(got[0][0, :got[2][0]]) == [3, 1, 4, 7, 8]
+    assert not np.signbit(got[1][0, 2:5]).any()
+    s.set_mask(None)
+    got = s.search(qp, qi, qv, 20, exclude=excl)
+    check(oracle, ptr, idx, val, 20, got, rows_of(qp, qi, qv, range(3)), list(excl), None)
+
+
+def test_test_sparse_of_the_reference():
+    """storage/vectors/database_test.go:198-224 (TestSparse): the query {1: 1, 100: 2} finds "match" (1*1 + 2*2 = 5) then
+    "old" (1*1 + 2*1 = 3); "other" shares no index and is not returned"""
+    ptr = np.array([0, 2, 4, 6], np.int64)
+    idx = np.array([1, 100, 1, 100, 2, 200], np.uint32)
+    val = np.array([1, 1, 1, 2, 1, 2], np.float32)
+    s = capi.Sparse(ptr, idx, val)
+    i, sc, cnt = s.search(np.array([0, 2], np.int64), np.array([1, 100], np.uint32), np.array([1, 2], np.float32), 10)
+    assert cnt[0] == 2 and list(i[0, :2]) == [1, 0] and list(sc[0, :2]) == [5.0, 3.0]
+
+
+def test_scratch_reuse_across_calls(oracle):
+    """the per-workgroup accumulators and stamps are never cleared between queries or calls"""
+    rng = np.random.default_rng(11)
+    ptr, idx, val = random_csr(rng, 3000, 200, 1, 8, zipf=True)
+    s = capi.Sparse(ptr, idx, val)
+    first = s.all_pairs(9)
+    qp, qi, qv = random_csr(rng, 40, 260, 1, 12)
+    mid = s.search(qp, qi, qv, 30)
+    check(oracle, ptr, idx, val, 30, mid, rows_of(qp, qi, qv, range(40)), [-1] * 40)
+    again = s.all_pairs(9)
+    for a, b in zip(first, again):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    sample = list(range(0, 3000, 97))
+    check(oracle, ptr, idx, val, 9, [x[sample] for x in again], rows_of(ptr, idx, val, sample), sample)
+
+
+def test_users_item_to_item_ml100k_shape(oracle):
+    """the "users" item-to-item vectors (item -> its users ascending, value sqrt(idf(user))) of an S-ml100k-shaped
+    dataset: sampled rows against the oracle, every row through the properties that need no oracle"""
+    data = synth.s_ml100k()
+    ptr, idx, val = synth.idf_vectors(data.iptr, data.iidx, data.U)
+    k = 100
+    s = capi.Sparse(ptr, idx, val)
+    s.set_profiling(True)
+    out_idx, out_sc, out_cnt = s.all_pairs(k)
+    launches, ms = s.get_profile()
+    assert launches == 1 and ms > 0
+    sample = list(range(0, data.I, 41))
+    check(oracle, ptr, idx, val, k, (out_idx[sample], out_sc[sample], out_cnt[sample]), rows_of(ptr, idx, val, sample), sample)
+    properties(ptr, out_idx, out_sc, out_cnt, k)
+
+
+def properties(ptr, out_idx, out_sc, out_cnt, k):
+    N = out_idx.shape[0]
+    valid = np.arange(k)[None, :] < out_cnt[:, None]
+    assert (out_idx[valid] >= 0).all() and (out_idx[~valid] == -1).all() and np.isneginf(out_sc[~valid]).all()
+    assert not (out_idx == np.arange(N)[:, None]).any()  # exclude_self
+    # descending scores, equal scores in ascending row order
+    a, b = out_sc[:, :-1], out_sc[:, 1:]
+    both = valid[:, 1:]
+    assert (a[both] >= b[both]).all()
+    eq = both & (a == b)
+    assert (out_idx[:, :-1][eq] < out_idx[:, 1:][eq]).all()
+    # the sparse dot is symmetric bit for bit (same common indices, same order, commutative products): whenever j is
+    # in i's list and i in j's, the two scores agree
+    pos = {}
+    for i in range(N):
+        for t in range(out_cnt[i]):
+            pos[(i, int(out_idx[i, t]))] = out_sc[i, t]
+    checked = 0
+    for (i, j), sc in pos.items():
+        other = pos.get((j, i))
+        if other is not None:
+            assert np.float32(sc).view(np.uint32) == np.float32(other).view(np.uint32)
+            checked += 1
+    assert checked > N
+    # rows without entries have no hits
+    empty = np.diff(ptr) == 0
+    assert (out_cnt[empty] == 0).all()
+
+
+def test_argument_errors():
+    ptr = np.array([0, 2, 3], np.int64)
+    idx = np.array([1, 5, 2], np.uint32)
+    val = np.ones(3, np.float32)
+    s = capi.Sparse(ptr, idx, val)
+    q = (np.array([0, 2], np.int64), np.array([5, 1], np.uint32), np.ones(2, np.float32))
+    with pytest.raises(capi.GorseHipError) as e:  # query indices not ascending
+        s.search(*q, 3)
+    assert e.value.code == capi.ERR_INVALID
+    q = (np.array([0, 2], np.int64), np.array([1, 5], np.uint32), np.ones(2, np.float32))
+    with pytest.raises(capi.GorseHipError) as e:
+        s.search(*q, 1025)
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.GorseHipError) as e:
+        s.search(*q, 3, exclude=[2])
+    assert e.value.code == capi.ERR_RANGE
+    with pytest.raises(capi.GorseHipError) as e:
+        s.all_pairs(3, q_begin=1, q_end=5)
+    assert e.value.code == capi.ERR_RANGE
+    i, sc, cnt = s.search(*q, 3, exclude=[0])
+    assert cnt[0] == 0  # row 1 = {2} shares nothing, row 0 is excluded

@@ -205,3 +205,52 @@ def test_exp_restated_close_to_libm(oracle):
         r = oracle.L.orc_exp_restated(float(x))
         e = np.exp(np.float64(x))
         assert abs(r - e) <= 2e-7 * e
+
+
+# ---- sparse collections: what the reference's tests pin (rank order on distinct scores, disjoint vectors left out) ----
+def test_sparse_search_reference_test_sparse(oracle):
+    # storage/vectors/database_test.go:198-224: old {1:1,100:1}, match {1:1,100:2}, other {2:1,200:2}; query {1:1,100:2}
+    ptr = np.array([0, 2, 4, 6], np.int64)
+    idx = np.array([1, 100, 1, 100, 2, 200], np.uint32)
+    val = np.array([1, 1, 1, 2, 1, 2], np.float32)
+    i, s = oracle.sparse_search(ptr, idx, val, [1, 100], [1, 2], 10)
+    assert i.tolist() == [1, 0] and s.tolist() == [5.0, 3.0]  # "match" first, "other" (no common index) not returned
+
+
+def _nested(n_items, idf):
+    """item_to_item_test.go:244-270 (TestUsers): item i has feedback from users 1 .. 100-i; every idf = 1"""
+    rows = [np.arange(1, n_items - i + 1) for i in range(n_items)]
+    ptr = np.array([0] + list(np.cumsum([r.size for r in rows])), np.int64)
+    idx = np.concatenate(rows).astype(np.uint32)
+    val = np.sqrt(np.asarray(idf, np.float64)[idx]).astype(np.float32)  # vector_writer.go:206
+    return ptr, idx, val
+
+
+def test_sparse_search_reference_test_users_rank_order(oracle):
+    ptr, idx, val = _nested(100, np.ones(101))
+    i, s = oracle.sparse_search(ptr, idx, val, idx[ptr[0]:ptr[1]], val[ptr[0]:ptr[1]], 11)
+    # QueryItemToItem asks for n + 1 neighbours and drops the item itself: "1" .. "10" (item_to_item_test.go:266-270)
+    assert i.tolist() == list(range(0, 11)) and s.tolist() == [float(100 - t) for t in range(11)]
+
+
+def test_sparse_dot_order_and_ties(oracle):
+    common, s = oracle.sparse_dot([1, 3, 9], [1.0, 2.0, 3.0], [3, 9, 11], [0.5, 2.0, 7.0])
+    assert common == 2 and s == np.float32(7.0)
+    # float32 accumulation in ascending index order: (1e8 + 1) - 1e8 is 0 in that order, not 1
+    common, s = oracle.sparse_dot([0, 1, 2], [1e8, 1.0, -1e8], [0, 1, 2], [1.0, 1.0, 1.0])
+    assert common == 3 and s == 0.0
+    # equal scores come back in ascending row order; a cancelled (+-0) hit is still a hit and is +0
+    ptr = np.array([0, 1, 2, 4], np.int64)
+    idx = np.array([5, 5, 5, 6], np.uint32)
+    val = np.array([2.0, 2.0, 1.0, -1.0], np.float32)
+    i, sc = oracle.sparse_search(ptr, idx, val, [5, 6], [1.0, 1.0], 5)
+    assert i.tolist() == [0, 1, 2] and sc.tolist() == [2.0, 2.0, 0.0] and not np.signbit(sc[2])
+    i, sc = oracle.sparse_search(ptr, idx, val, [5, 6], [1.0, 1.0], 5, exclude=0, admissible=[1, 0, 1])
+    assert i.tolist() == [2]
+
+
+def test_idf_formula(oracle):
+    # dataset/dataset.go:160-166: math32.Log(1 + float32(n) / float32(freq))
+    out = oracle.idf([1, 2, 50, 100], 100)
+    exp = [np.float32(np.log(np.float64(np.float32(1) + np.float32(100) / np.float32(f)))) for f in (1, 2, 50, 100)]
+    assert out.tolist() == exp
