@@ -88,6 +88,21 @@ class Dataset:
     def CountFeedback(self):
         return host().gh_dataset_count_feedback(self.p)
 
+    def _idf(self, side, n):
+        H = host()
+        H.gh_dataset_idf.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_int32]
+        out = np.zeros(max(n, 1), np.float32)
+        m = H.gh_dataset_idf(self.p, side, out.ctypes.data_as(C.POINTER(C.c_float)), out.size)
+        return out[:m].copy()
+
+    def GetUserIDF(self):
+        """dataset/dataset.go:160-166: log(1 + #items / freq(user)), the weights of the "users" item-to-item vectors"""
+        return self._idf(0, self.CountUsers())
+
+    def GetItemIDF(self):
+        """dataset/dataset.go:174-180: log(1 + #users / freq(item)), the weights of the "items" user-to-user vectors"""
+        return self._idf(1, self.CountItems())
+
 
 def datasets_from_synth(data):
     """(train, test) Datasets from a gorse_amd.synth.CFData, in the NCF built-in layout

@@ -24,6 +24,7 @@ struct gorse_sparse {
     DevBuf<float> r_val, p_val;
     DevBuf<uint8_t> mask;
     bool has_mask = false;
+    int64_t n_admissible = 0;  // rows with mask != 0 (N without a mask)
     // per-workgroup scratch (slots x N each); stamps are never reused for a slot until the wrap-around clear
     DevBuf<float> acc;
     DevBuf<uint32_t> stamp;
@@ -92,6 +93,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
     a.q_ptr = qp, a.q_idx = qi, a.q_val = qv, a.q_first = q_first, a.nq = nq;
     a.exclude = excl_dev, a.exclude_self = exclude_self;
     a.mask = h->has_mask ? h->mask.p : nullptr;
+    a.n_admissible = h->has_mask ? h->n_admissible : h->N;
     a.N = h->N;
     a.acc = h->acc.p, a.stamp = h->stamp.p, a.touched = h->touched.p;
     a.serial_base = h->serial;
@@ -201,6 +203,8 @@ extern "C" int32_t gorse_sparse_set_mask(gorse_sparse *h, const uint8_t *admissi
     GORSE_TRY(h->mask.ensure((size_t)h->N));
     GORSE_HIP_CHECK(hipMemcpyAsync(h->mask.p, admissible, (size_t)h->N, hipMemcpyHostToDevice, h->stream));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->n_admissible = 0;
+    for (int64_t r = 0; r < h->N; r++) h->n_admissible += admissible[r] != 0;
     h->has_mask = true;
     return GORSE_OK;
 }

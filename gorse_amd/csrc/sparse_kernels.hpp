@@ -14,6 +14,9 @@
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
 // well-defined answer whatever order the lanes append in.  Keys above the running threshold go to an LDS buffer of
 // 2*KP entries; when it overflows it is bitonic-sorted, cut to KP entries and the threshold becomes the k-th key.
+// The reference ranks ALL admissible documents (one sharing no index scores 0), cuts to topK and THEN drops Score == 0
+// (xvec.go:419-421), so zero-score documents use up slots: only the non-zero rows are ranked here, and the number of
+// results follows from the counts of positive / negative rows and the number of admissible rows (see `written`).
 //
 // Only constructs that tests/emu/hip_emu.hpp can also run on the CPU are used here (threadIdx/blockIdx, static
 // __shared__, __syncthreads, __syncthreads_or, integer atomicAdd): the kernel's control flow is exercised without a GPU
@@ -40,6 +43,7 @@ struct QueryArgs {
     const int64_t *exclude;  // per query: a stored row left out of its result (-1 = none); may be null
     int exclude_self;        // all pairs: query t is stored row q_first + t, left out of its own result
     const uint8_t *mask;     // admissible[row] or null
+    int64_t n_admissible;    // number of admissible rows (N without a mask)
     int64_t N;
     // scratch, N entries per workgroup each
     float *acc;
@@ -53,11 +57,24 @@ struct QueryArgs {
     unsigned long long *stat;  // [0] += postings walked, [1] += rows hit
 };
 
-__device__ inline unsigned long long make_key(float score, int32_t row) {
+constexpr uint32_t kZeroOrd = 0x80000000u;  // ordered bits of +0
+// order-preserving bits of a score: larger float <=> larger unsigned; -0 counts as +0
+__device__ inline uint32_t score_ord(float score) {
     uint32_t u = __float_as_uint(score);
-    if ((u << 1) == 0) u = 0;  // -0 -> +0
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
+    if ((u << 1) == 0) u = 0;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline unsigned long long make_key(uint32_t ord, int32_t row) {
+    return ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
+}
+// results the reference returns (xvec.go:379-446): it ranks every admissible document, cuts to k, drops Score == 0.
+// pos / neg = admissible rows scoring above / below zero, adm = admissible rows; the rest score zero.
+__device__ inline int written(long long pos, long long neg, long long adm, int k) {
+    if (pos >= k) return k;
+    const long long zeros = adm - pos - neg;
+    long long n = pos;
+    if (pos + zeros < k) n += neg < k - pos - zeros ? neg : k - pos - zeros;
+    return (int)n;
 }
 __device__ inline float key_score(unsigned long long key) {
     uint32_t u = (uint32_t)(key >> 32);
@@ -94,6 +111,7 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
     __shared__ unsigned long long s_thr;  // keys <= s_thr cannot be among the k best
     __shared__ int s_cnt;                 // rows touched by the current query
     __shared__ int s_bcnt;                // slots handed out in s_buf
+    __shared__ int s_pos, s_neg;          // admissible rows of the current query scoring above / below zero
     const int tid = threadIdx.x, nt = blockDim.x;
     float *acc = a.acc + (int64_t)blockIdx.x * a.N;
     uint32_t *stamp = a.stamp + (int64_t)blockIdx.x * a.N;
@@ -105,6 +123,8 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
             s_cnt = 0;
             s_bcnt = 0;
             s_thr = 0;
+            s_pos = 0;
+            s_neg = 0;
         }
         __syncthreads();
         // ---- accumulate: one posting list per query index, ascending ----
@@ -134,12 +154,20 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
         // ---- rank the touched rows ----
         const int T = s_cnt;
         const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? qr : (int64_t)-1);
+        int my_pos = 0, my_neg = 0;
         for (int base = 0; base < T; base += nt) {
             unsigned long long key = 0;  // 0 is below every real key
             const int i = base + tid;
             if (i < T) {
                 const int32_t row = touched[i];
-                if ((int64_t)row != ex && (!a.mask || a.mask[row])) key = make_key(acc[row], row);
+                if ((int64_t)row != ex && (!a.mask || a.mask[row])) {
+                    const uint32_t ord = score_ord(acc[row]);
+                    if (ord != kZeroOrd) {  // a zero score is dropped by the reference's wrapper
+                        key = make_key(ord, row);
+                        my_pos += ord > kZeroOrd;
+                        my_neg += ord < kZeroOrd;
+                    }
+                }
             }
             bool want = key > s_thr;
             while (true) {
@@ -164,15 +192,17 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
                 want = want && key > s_thr;
             }
         }
+        if (my_pos) atomicAdd(&s_pos, my_pos);
+        if (my_neg) atomicAdd(&s_neg, my_neg);
         __syncthreads();
         const int n = s_bcnt;  // <= CAP: an overflow is always followed by the cut to KP
-        int cnt = 0;
         if (n > 0) {
             for (int i = n + tid; i < CAP; i += nt) s_buf[i] = 0;
             __syncthreads();
-            sort_desc<CAP>(s_buf, tid, nt);
-            cnt = n < a.k ? n : a.k;
+            sort_desc<CAP>(s_buf, tid, nt);  // positive scores first, then the negative ones
         }
+        const bool ex_counts = ex >= 0 && ex < a.N && (!a.mask || a.mask[ex]);
+        const int cnt = written(s_pos, s_neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
         for (int i = tid; i < a.k; i += nt) {
             const unsigned long long key = i < cnt ? s_buf[i] : 0;
             a.out_idx[t * a.k + i] = i < cnt ? key_row(key) : -1;

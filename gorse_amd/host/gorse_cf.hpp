@@ -329,6 +329,11 @@ class Dataset {
         const_cast<Dataset *>(this)->itemFeedback_.resize((size_t)CountItems());
         return itemFeedback_;
     }
+    // GetUserIDF / GetItemIDF (dataset.go:160-180): idf = math32.Log(1 + float32(#other side) / float32(freq)); the
+    // weights of the sparse "users" item-to-item and "items" user-to-user vectors (logics/vector_writer.go:192-209).
+    // math32.Log (chewxy/math32 v1.11.1) restated as the float64 logarithm narrowed to float32.
+    std::vector<float> GetUserIDF() const { return idf(*userDict_, CountItems()); }
+    std::vector<float> GetItemIDF() const { return idf(*itemDict_, CountUsers()); }
     void SetNegatives(int32_t user, std::vector<int32_t> negs) {
         if (negatives_.size() < (size_t)CountUsers()) negatives_.resize((size_t)CountUsers());
         negatives_[(size_t)user] = std::move(negs);
@@ -353,6 +358,12 @@ class Dataset {
     }
 
    private:
+    static std::vector<float> idf(const FreqDict &dict, int other) {
+        std::vector<float> out((size_t)dict.Count());
+        for (int32_t t = 0; t < dict.Count(); t++)
+            out[(size_t)t] = (float)std::log((double)(1.0f + (float)other / (float)dict.Freq(t)));
+        return out;
+    }
     std::shared_ptr<FreqDict> userDict_, itemDict_;
     std::vector<std::vector<int32_t>> userFeedback_, itemFeedback_, negatives_;
     int numFeedback_ = 0;

@@ -66,6 +66,12 @@ void gh_dataset_set_negatives(void *d, int32_t user, const int32_t *neg, int32_t
 int32_t gh_dataset_count_users(void *d) { return ((dataset::Dataset *)d)->CountUsers(); }
 int32_t gh_dataset_count_items(void *d) { return ((dataset::Dataset *)d)->CountItems(); }
 int32_t gh_dataset_count_feedback(void *d) { return ((dataset::Dataset *)d)->CountFeedback(); }
+// GetUserIDF (side 0) / GetItemIDF (side 1) into out[CountUsers() / CountItems() of the dictionary]
+int32_t gh_dataset_idf(void *d, int32_t side, float *out, int32_t cap) {
+    auto v = side == 0 ? ((dataset::Dataset *)d)->GetUserIDF() : ((dataset::Dataset *)d)->GetItemIDF();
+    for (size_t t = 0; t < v.size() && (int32_t)t < cap; t++) out[t] = v[t];
+    return (int32_t)v.size();
+}
 
 // ---- models ------------------------------------------------------------------------------------
 static model::Params make_params(const char **names, const double *vals, int32_t n) {
@@ -243,6 +249,20 @@ struct CallbackSearcher : vectors::Searcher {  // the CPU test-suite's checker (
         if (cb(X, n, d, metric, Q, nq, k, idx, dist, cnt) != 0) throw std::runtime_error("search callback failed");
     }
 };
+typedef int32_t (*gh_sparse_search_cb)(int64_t n, const int64_t *indptr, const uint32_t *indices, const float *values,
+                                       const uint8_t *admissible, int64_t nq, const int64_t *q_indptr, const uint32_t *q_indices,
+                                       const float *q_values, int32_t k, int32_t *idx, float *score, int32_t *cnt);
+struct CallbackSparseSearcher : vectors::SparseSearcher {  // the CPU test-suite's checker for sparse collections
+    gh_sparse_search_cb cb;
+    explicit CallbackSparseSearcher(gh_sparse_search_cb c) : cb(c) {}
+    void invalidate(const std::string &) override {}
+    void search(const std::string &, int64_t n, const int64_t *indptr, const uint32_t *indices, const float *values,
+                const uint8_t *admissible, int64_t nq, const int64_t *q_indptr, const uint32_t *q_indices, const float *q_values,
+                int k, int32_t *idx, float *score, int32_t *cnt) override {
+        if (cb(n, indptr, indices, values, admissible, nq, q_indptr, q_indices, q_values, k, idx, score, cnt) != 0)
+            throw std::runtime_error("sparse search callback failed");
+    }
+};
 struct VdbHandle {
     std::shared_ptr<vectors::HipDatabase> db;
 };
@@ -273,6 +293,13 @@ void *gh_vdb_open(const char *url) {
 }
 void *gh_vdb_open_with_searcher(gh_search_cb cb) {
     return new VdbHandle{std::make_shared<vectors::HipDatabase>(std::make_shared<CallbackSearcher>(cb))};
+}
+void *gh_vdb_open_with_searchers(gh_search_cb cb, gh_sparse_search_cb scb) {
+    std::shared_ptr<vectors::Searcher> dense;
+    std::shared_ptr<vectors::SparseSearcher> sparse;
+    if (cb) dense = std::make_shared<CallbackSearcher>(cb);
+    if (scb) sparse = std::make_shared<CallbackSparseSearcher>(scb);
+    return new VdbHandle{std::make_shared<vectors::HipDatabase>(dense, sparse)};
 }
 void gh_vdb_free(void *h) { delete (VdbHandle *)h; }
 int32_t gh_vdb_close(void *h) { return guard([&] { vdb(h).Close(); }); }
@@ -343,7 +370,7 @@ int32_t gh_vdb_get(void *h, const char *name, const char *ids) {
 int32_t gh_vdb_delete_vectors(void *h, const char *name, int64_t timestamp_ms) {
     return guard([&] { vdb(h).DeleteVectors(name, timestamp_ms); });
 }
-// the query is the LAST staged vector (Values, or Indices for the sparse refusal); results replace the staging list
+// the query is the LAST staged vector (dense Values, or Indices + Values for a sparse collection); results replace the staging list
 int32_t gh_vdb_query_staged(void *h, const char *name, const char *categories, int32_t topk) {
     return guard([&] {
         if (g_stage.empty()) throw std::invalid_argument("no staged query vector");
@@ -363,6 +390,23 @@ int32_t gh_vdb_query_batch(void *h, const char *name, const float *Q, int64_t nq
             g_stage_split.push_back((int64_t)g_stage.size());
         }
     });
+}
+// every staged vector is one sparse query; results replace the staging list, split per query
+int32_t gh_vdb_query_sparse_staged(void *h, const char *name, const char *categories, int32_t topk) {
+    return guard([&] {
+        std::vector<vectors::Vector> qs(g_stage.begin(), g_stage.end());
+        gh_vdb_stage_clear();
+        auto res = vdb(h).QuerySparseBatch(name, qs, split_lines(categories), topk);
+        g_stage_split.push_back(0);
+        for (auto &r : res) {
+            for (auto &v : r) g_stage.push_back(std::move(v));
+            g_stage_split.push_back((int64_t)g_stage.size());
+        }
+    });
+}
+int32_t gh_vdb_result_nnz(int64_t r) { return (int32_t)g_stage[(size_t)r].Indices.size(); }
+void gh_vdb_result_indices(int64_t r, uint32_t *out) {
+    std::copy(g_stage[(size_t)r].Indices.begin(), g_stage[(size_t)r].Indices.end(), out);
 }
 int64_t gh_vdb_result_count() { return (int64_t)g_stage.size(); }
 int64_t gh_vdb_result_split(int64_t t) { return t >= 0 && t < (int64_t)g_stage_split.size() ? g_stage_split[(size_t)t] : -1; }
@@ -385,7 +429,27 @@ int64_t gh_vdb_result_categories(int64_t r, char *buf, int64_t cap) {
 void *gh_vwriter_new(void *h, const char *collection, int32_t distance, int64_t timestamp_ms, int32_t batch) {
     return new logics::VectorWriter(((VdbHandle *)h)->db, collection, (vectors::Distance)distance, timestamp_ms, batch);
 }
+void *gh_vwriter_new_sparse(void *h, const char *collection, int64_t timestamp_ms, int32_t batch) {  // distance Dot
+    return new logics::VectorWriter(((VdbHandle *)h)->db, collection, vectors::Dot, timestamp_ms, batch, true);
+}
 void gh_vwriter_free(void *w) { delete (logics::VectorWriter *)w; }
+// stage the vector a sparse kind writes for one item / user: kind 0 = tags, 1 = feedback (users / items), 2 = auto
+void gh_logics_stage_kind_vector(int32_t kind, const char *id, int32_t hidden, const char *categories, int64_t timestamp_ms,
+                                 const int32_t *tags, int32_t n_tags, const float *tags_idf, int32_t n_tags_idf,
+                                 const int32_t *feedback, int32_t n_feedback, const float *fb_idf, int32_t n_fb_idf) {
+    vectors::Vector meta;
+    meta.Id = id;
+    meta.IsHidden = hidden != 0;
+    meta.Categories = split_lines(categories);
+    meta.TimestampMs = timestamp_ms;
+    std::vector<int32_t> t(tags, tags + n_tags), f(feedback, feedback + n_feedback);
+    std::vector<float> ti(tags_idf, tags_idf + n_tags_idf), fi(fb_idf, fb_idf + n_fb_idf);
+    vectors::ScoredVector v;
+    static_cast<vectors::Vector &>(v) = kind == 0   ? logics::tagsVector(meta, t, ti)
+                                        : kind == 1 ? logics::feedbackVector(meta, f, fi)
+                                                    : logics::autoVector(meta, t, ti, f, fi);
+    g_stage.push_back(std::move(v));
+}
 // the vector to add is the LAST staged one
 int32_t gh_vwriter_add_staged(void *w) {
     return guard([&] {
@@ -421,6 +485,16 @@ int32_t gh_logics_query_similar(void *h, const char *collection, const char *id,
 }
 int32_t gh_logics_query_similar_bulk(void *h, const char *collection, const char *ids, const char *categories, int32_t n) {
     return guard([&] { stage_scores(logics::QuerySimilarBulk(vdb(h), collection, split_lines(ids), split_lines(categories), n)); });
+}
+int32_t gh_logics_query_similar_typed(void *h, const char *collection, const char *type, const char *id, const char *categories,
+                                      int32_t n) {
+    return guard([&] { stage_scores({logics::QuerySimilarTyped(vdb(h), collection, type, id, split_lines(categories), n)}); });
+}
+int32_t gh_logics_query_similar_typed_bulk(void *h, const char *collection, const char *type, const char *ids,
+                                           const char *categories, int32_t n) {
+    return guard([&] {
+        stage_scores(logics::QuerySimilarTypedBulk(vdb(h), collection, type, split_lines(ids), split_lines(categories), n));
+    });
 }
 double gh_logics_result_score(int64_t r) { return g_scores[(size_t)r]; }
 

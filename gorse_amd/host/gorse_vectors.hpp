@@ -16,12 +16,17 @@
 //   * Filters are applied after an over-fetched exact search: k' = topK + slack vectors are fetched, filtered, and k'
 //     grows until topK admissible vectors are found or the collection is exhausted, so the answer is the exact top-K of
 //     the admissible set.
-//   * Sparse collections (dimension 0, `Indices`) and quantized collections are ErrNotSupported: the sparse dot is
-//     SURVEY.md 8f item 2, not built.
+//   * Sparse collections (dimension 0, `Indices`; distance Dot only, xvec.go:241-247) are searched by the exact sparse
+//     top-k of libgorse_hip (gorse_sparse_*): every admissible vector ranked by its inner product, cut to topK, the
+//     zero scores dropped (xvec.go:419-421).  The hidden / categories filter goes to the device as an admissibility mask,
+//     so there are no over-fetch rounds.  Vectors are stored as given (GetVectors returns them unchanged) and indexed
+//     with their entries sorted by index; a repeated index is rejected.
+//   * Quantized collections are ErrNotSupported.
 // Errors are the reference's sentinels (storage/errors.go:20-24) as exception types; all methods are serialised by one
 // mutex per database (the reference requires goroutine safety; a GPU handle must be used by one caller at a time).
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -111,16 +116,62 @@ private:
     std::map<std::string, gorse_topk *> handles_;
 };
 
+// Exact top-k of sparse queries over sparse rows (CSR, indices strictly ascending per row), rows with admissible[r] == 0
+// left out: the reference's QueryVectors on a sparse collection.  Default = the GPU, the CPU test-suite injects the oracle.
+struct SparseSearcher {
+    virtual ~SparseSearcher() = default;
+    virtual void invalidate(const std::string &collection) = 0;
+    virtual void search(const std::string &collection, int64_t n, const int64_t *indptr, const uint32_t *indices,
+                        const float *values, const uint8_t *admissible, int64_t nq, const int64_t *q_indptr,
+                        const uint32_t *q_indices, const float *q_values, int k, int32_t *idx, float *score,
+                        int32_t *cnt) = 0;
+};
+
+class HipSparseSearcher : public SparseSearcher {  // one gorse_sparse handle per collection, rebuilt after a change
+public:
+    explicit HipSparseSearcher(int device = 0) : device_(device) {}
+    ~HipSparseSearcher() override {
+        for (auto &kv : handles_) gorse_sparse_destroy(kv.second);
+    }
+    void invalidate(const std::string &collection) override {
+        auto it = handles_.find(collection);
+        if (it != handles_.end()) {
+            gorse_sparse_destroy(it->second);
+            handles_.erase(it);
+        }
+    }
+    void search(const std::string &collection, int64_t n, const int64_t *indptr, const uint32_t *indices, const float *values,
+                const uint8_t *admissible, int64_t nq, const int64_t *q_indptr, const uint32_t *q_indices,
+                const float *q_values, int k, int32_t *idx, float *score, int32_t *cnt) override {
+        gorse_sparse *&h = handles_[collection];
+        if (!h) {
+            if (gorse_sparse_create(&h, device_, n, indptr, indices, values) != GORSE_OK) {
+                handles_.erase(collection);
+                throw std::runtime_error(std::string("gorse_sparse_create: ") + gorse_hip_last_error());
+            }
+        }
+        if (gorse_sparse_set_mask(h, admissible) != GORSE_OK)
+            throw std::runtime_error(std::string("gorse_sparse_set_mask: ") + gorse_hip_last_error());
+        if (gorse_sparse_search(h, nq, q_indptr, q_indices, q_values, nullptr, k, idx, score, cnt) != GORSE_OK)
+            throw std::runtime_error(std::string("gorse_sparse_search: ") + gorse_hip_last_error());
+    }
+
+private:
+    int device_;
+    std::map<std::string, gorse_sparse *> handles_;
+};
+
 class HipDatabase {
 public:
-    explicit HipDatabase(std::shared_ptr<Searcher> searcher = nullptr)
-        : searcher_(searcher ? std::move(searcher) : std::make_shared<HipSearcher>()) {}
+    explicit HipDatabase(std::shared_ptr<Searcher> searcher = nullptr, std::shared_ptr<SparseSearcher> sparse = nullptr)
+        : searcher_(searcher ? std::move(searcher) : std::make_shared<HipSearcher>()),
+          sparse_(sparse ? std::move(sparse) : std::make_shared<HipSparseSearcher>()) {}
 
     void Init() {}
     void Optimize(const std::string &) {}
     void Close() {
         std::lock_guard<std::mutex> g(mu_);
-        for (auto &kv : collections_) searcher_->invalidate(kv.first);
+        for (auto &kv : collections_) drop_index(kv.first);
         closed_ = true;
     }
 
@@ -140,8 +191,9 @@ public:
         check_open();
         if (dimensions < 0) throw std::invalid_argument("invalid vector dimension " + std::to_string(dimensions));
         if (!config.Type.empty()) throw storage::ErrNotSupported("quantization type " + config.Type + " for hip not supported");
-        if (dimensions == 0) throw storage::ErrNotSupported("sparse vectors for hip not supported");
         if (distance != Cosine && distance != Euclidean && distance != Dot) throw storage::ErrNotSupported("distance method not supported");
+        if (dimensions == 0 && distance != Dot)  // xvec.go:243-245
+            throw storage::ErrNotSupported("distance method for sparse vector not supported");
         if (collections_.count(name)) throw storage::ErrAlreadyExists("collection " + name + " already exists");
         Collection c;
         c.info.Name = name;
@@ -154,7 +206,7 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         check_open();
         if (!collections_.erase(name)) throw storage::ErrNotFound("collection " + name + ": not found");
-        searcher_->invalidate(name);
+        drop_index(name);
     }
     int64_t CountVectors(const std::string &name) {
         std::lock_guard<std::mutex> g(mu_);
@@ -164,24 +216,34 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         if (vs.empty()) return;
         Collection &c = coll(name);
+        const bool sparse = c.info.Dimension == 0;
         for (const Vector &v : vs) {  // validate everything before touching the collection (xvec.go:318-321)
-            if (!v.Indices.empty()) throw storage::ErrNotSupported("sparse vectors for hip not supported");
-            if ((int)v.Values.size() != c.info.Dimension)
+            if (sparse) {
+                if (v.Indices.empty() || v.Indices.size() != v.Values.size())
+                    throw std::invalid_argument("vector " + v.Id + " is not a sparse vector (Indices and Values of one length)");
+                std::vector<uint32_t> sorted(v.Indices);
+                std::sort(sorted.begin(), sorted.end());
+                if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+                    throw std::invalid_argument("vector " + v.Id + " repeats an index");
+            } else if (!v.Indices.empty() || (int)v.Values.size() != c.info.Dimension) {
                 throw std::invalid_argument("vector " + v.Id + " has dimension " + std::to_string(v.Values.size()) +
-                                            ", collection " + name + " has " + std::to_string(c.info.Dimension));
+                                            (v.Indices.empty() ? "" : " (sparse)") + ", collection " + name + " has " +
+                                            std::to_string(c.info.Dimension));
+            }
         }
         for (const Vector &v : vs) {
             auto it = c.by_id.find(v.Id);
             if (it == c.by_id.end()) {
                 c.by_id[v.Id] = c.rows.size();
                 c.rows.push_back(v);
-                c.data.insert(c.data.end(), v.Values.begin(), v.Values.end());
+                if (!sparse) c.data.insert(c.data.end(), v.Values.begin(), v.Values.end());
             } else {  // upsert
                 c.rows[it->second] = v;
-                std::copy(v.Values.begin(), v.Values.end(), c.data.begin() + it->second * c.info.Dimension);
+                if (!sparse) std::copy(v.Values.begin(), v.Values.end(), c.data.begin() + it->second * c.info.Dimension);
             }
         }
-        searcher_->invalidate(name);
+        c.csr_valid = false;
+        drop_index(name);
     }
     std::vector<Vector> GetVectors(const std::string &name, const std::vector<std::string> &ids) {
         std::lock_guard<std::mutex> g(mu_);
@@ -211,15 +273,68 @@ public:
         c.data.clear();
         for (size_t r = 0; r < c.rows.size(); r++) {
             c.by_id[c.rows[r].Id] = r;
-            c.data.insert(c.data.end(), c.rows[r].Values.begin(), c.rows[r].Values.end());
+            if (c.info.Dimension != 0) c.data.insert(c.data.end(), c.rows[r].Values.begin(), c.rows[r].Values.end());
         }
-        searcher_->invalidate(name);
+        c.csr_valid = false;
+        drop_index(name);
     }
     std::vector<ScoredVector> QueryVectors(const std::string &name, const Vector &q, const std::vector<std::string> &categories,
                                            int topK) {
-        if (!q.Indices.empty()) throw storage::ErrNotSupported("sparse queries for hip not supported");
+        if (!q.Indices.empty()) {
+            auto r = QuerySparseBatch(name, {q}, categories, topK);
+            return r.empty() ? std::vector<ScoredVector>() : std::move(r[0]);
+        }
         auto r = QueryVectorsBatch(name, q.Values, 1, categories, topK);
         return r.empty() ? std::vector<ScoredVector>() : std::move(r[0]);
+    }
+    // Sparse queries (Indices / Values) against a sparse collection, all in ONE device search: every admissible vector
+    // ranked by its inner product with the query, cut to topK, zero scores dropped (xvec.go:379-446).
+    std::vector<std::vector<ScoredVector>> QuerySparseBatch(const std::string &name, const std::vector<Vector> &queries,
+                                                            const std::vector<std::string> &categories, int topK) {
+        std::lock_guard<std::mutex> g(mu_);
+        Collection &c = coll(name);
+        std::vector<std::vector<ScoredVector>> out(queries.size());
+        if (topK <= 0 || queries.empty()) return out;
+        if (c.info.Dimension != 0) throw std::invalid_argument("sparse query against the dense collection " + name);
+        if (topK > 1024) throw storage::ErrNotSupported("topK > 1024 on a sparse collection for hip not supported");
+        std::vector<int64_t> qp{0};
+        std::vector<uint32_t> qi;
+        std::vector<float> qv;
+        for (const Vector &q : queries) {
+            if (q.Indices.size() != q.Values.size()) throw std::invalid_argument("sparse query: Indices and Values differ in length");
+            const size_t before = qi.size();
+            append_sorted(q, qi, qv);
+            if (std::adjacent_find(qi.begin() + (std::ptrdiff_t)before, qi.end()) != qi.end())
+                throw std::invalid_argument("sparse query repeats an index");
+            qp.push_back((int64_t)qi.size());
+        }
+        const int64_t n = (int64_t)c.rows.size();
+        if (n == 0) return out;
+        if (!c.csr_valid) {
+            c.indptr.assign(1, 0);
+            c.indices.clear();
+            c.values.clear();
+            for (const Vector &v : c.rows) {
+                append_sorted(v, c.indices, c.values);
+                c.indptr.push_back((int64_t)c.indices.size());
+            }
+            c.csr_valid = true;
+        }
+        std::vector<uint8_t> ok((size_t)n);
+        for (int64_t r = 0; r < n; r++) ok[(size_t)r] = admissible(c.rows[(size_t)r], categories);
+        const int64_t nq = (int64_t)queries.size();
+        std::vector<int32_t> idx((size_t)(nq * topK), -1), cnt((size_t)nq, 0);
+        std::vector<float> score((size_t)(nq * topK), 0.0f);
+        sparse_->search(name, n, c.indptr.data(), c.indices.data(), c.values.data(), ok.data(), nq, qp.data(), qi.data(),
+                        qv.data(), topK, idx.data(), score.data(), cnt.data());
+        for (int64_t t = 0; t < nq; t++)
+            for (int e = 0; e < cnt[(size_t)t]; e++) {
+                ScoredVector sv;
+                static_cast<Vector &>(sv) = c.rows[(size_t)idx[(size_t)(t * topK + e)]];
+                sv.Score = score[(size_t)(t * topK + e)];  // Dot: the inner product itself
+                out[(size_t)t].push_back(std::move(sv));
+            }
+        return out;
     }
     // The bulk form: nq dense queries (row-major) against one collection with one filter, in ONE
     // device search per over-fetch round -- what replaces the per-user QueryVectors loop of worker/pipeline.go:403-448.
@@ -231,6 +346,7 @@ public:
         std::vector<std::vector<ScoredVector>> out((size_t)std::max<int64_t>(nq, 0));
         if (topK <= 0 || nq <= 0) return out;
         const int d = c.info.Dimension;
+        if (d == 0) throw std::invalid_argument("dense query against the sparse collection " + name);
         if ((int64_t)queries.size() != nq * d)
             throw std::invalid_argument("query has dimension " + std::to_string(nq ? queries.size() / nq : 0) + ", collection " +
                                         name + " has " + std::to_string(d));
@@ -238,13 +354,7 @@ public:
         if (n == 0) return out;
         const int metric = c.info.Dist == Dot ? GORSE_METRIC_NEG_DOT : (c.info.Dist == Euclidean ? GORSE_METRIC_EUCLIDEAN : GORSE_METRIC_COSINE);
         std::vector<char> ok((size_t)n);
-        for (int64_t r = 0; r < n; r++) {
-            const Vector &v = c.rows[(size_t)r];
-            bool a = !v.IsHidden;
-            for (const std::string &cat : categories)
-                a = a && std::find(v.Categories.begin(), v.Categories.end(), cat) != v.Categories.end();
-            ok[(size_t)r] = a;
-        }
+        for (int64_t r = 0; r < n; r++) ok[(size_t)r] = admissible(c.rows[(size_t)r], categories);
         // queries still short of topK admissible vectors are searched again with a 4x larger k
         std::vector<int64_t> todo((size_t)nq);
         for (int64_t t = 0; t < nq; t++) todo[(size_t)t] = t;
@@ -290,9 +400,35 @@ private:
     struct Collection {
         CollectionInfo info;
         std::vector<Vector> rows;               // insertion order; row r of `data`
-        std::vector<float> data;                // rows x Dimension, row-major: what the searcher indexes
+        std::vector<float> data;                // dense: rows x Dimension, row-major: what the searcher indexes
         std::map<std::string, size_t> by_id;
+        // sparse: the rows as CSR with ascending indices, rebuilt lazily after a change
+        bool csr_valid = false;
+        std::vector<int64_t> indptr;
+        std::vector<uint32_t> indices;
+        std::vector<float> values;
     };
+    // hidden vectors never match; `categories` is CONTAIN_ALL (xvec.go:386-394)
+    static bool admissible(const Vector &v, const std::vector<std::string> &categories) {
+        bool a = !v.IsHidden;
+        for (const std::string &cat : categories)
+            a = a && std::find(v.Categories.begin(), v.Categories.end(), cat) != v.Categories.end();
+        return a;
+    }
+    // (index, value) pairs of v appended in ascending index order
+    static void append_sorted(const Vector &v, std::vector<uint32_t> &indices, std::vector<float> &values) {
+        std::vector<size_t> order(v.Indices.size());
+        for (size_t t = 0; t < order.size(); t++) order[t] = t;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return v.Indices[a] < v.Indices[b]; });
+        for (size_t t : order) {
+            indices.push_back(v.Indices[t]);
+            values.push_back(v.Values[t]);
+        }
+    }
+    void drop_index(const std::string &name) {
+        searcher_->invalidate(name);
+        sparse_->invalidate(name);
+    }
     void check_open() const {
         if (closed_) throw std::runtime_error("hip vector database is closed");
     }
@@ -305,6 +441,7 @@ private:
     std::mutex mu_;
     bool closed_ = false;
     std::shared_ptr<Searcher> searcher_;
+    std::shared_ptr<SparseSearcher> sparse_;
     std::map<std::string, Collection> collections_;
 };
 
@@ -329,10 +466,12 @@ inline std::string UserToUserCollection(const std::string &name) { return "user_
 
 }  // namespace vectors
 
-// ---- logics: the dense ("embedding") similarity recommenders over a vectors.Database ----------------------------------
-// logics/vector_writer.go:33-190 (VectorWriter), logics/item_to_item.go:50-152 (QueryItemToItem, embeddingItemToItem),
-// logics/user_to_user.go:50-152 (the same with users).  The sparse kinds (tags / users / auto: IDF-weighted sparse dot) are
-// SURVEY.md 8f item 2 and not built.
+// ---- logics: the similarity recommenders over a vectors.Database ------------------------------------------------------
+// logics/vector_writer.go:33-209 (VectorWriter, newSparseVector), logics/item_to_item.go:50-245 (QueryItemToItem and the
+// embedding / tags / users / auto kinds), logics/user_to_user.go:50-237 (the same with users: embedding / tags / items /
+// auto).  The sparse kinds store sqrt(idf)-weighted id sets in a sparse Dot collection, so that the inner product of two
+// vectors is the sum of the idf of their common ids.  Column expressions (expr programs over data.Item / data.User) are
+// the caller's: the twins take the extracted embedding / label ids.
 namespace logics {
 
 struct Score {  // cache.Score as QueryItemToItem fills it (item_to_item.go:81)
@@ -341,15 +480,19 @@ struct Score {  // cache.Score as QueryItemToItem fills it (item_to_item.go:81)
     std::vector<std::string> Categories;
 };
 
-class VectorWriter {  // dense writer: collection validation + batched AddVectors (vector_writer.go:35-190)
+class VectorWriter {  // collection validation + batched AddVectors (vector_writer.go:35-190); sparse: dimension 0
 public:
     VectorWriter(std::shared_ptr<vectors::HipDatabase> client, std::string collection, vectors::Distance distance,
-                 int64_t timestamp_ms, int batchSize = 0)
+                 int64_t timestamp_ms, int batchSize = 0, bool sparse = false)
         : client_(std::move(client)), collection_(std::move(collection)), distance_(distance), timestamp_(timestamp_ms),
-          batch_(batchSize > 0 ? batchSize : 1024) {}
+          batch_(batchSize > 0 ? batchSize : 1024), sparse_(sparse), dimension_(sparse ? 0 : -1) {}
     void Add(const vectors::Vector &v) {
         std::lock_guard<std::mutex> g(mu_);
-        if (!v.Indices.empty() || v.Values.empty()) return;  // vector_writer.go:92-96: silently skipped
+        if (sparse_) {  // vector_writer.go:88-91: silently skipped
+            if (v.Indices.empty() || v.Indices.size() != v.Values.size()) return;
+        } else if (!v.Indices.empty() || v.Values.empty()) {  // :92-96
+            return;
+        }
         buffer_.push_back(v);
         if ((int)buffer_.size() >= batch_) flush();
     }
@@ -365,6 +508,13 @@ public:
 private:
     void flush() {
         if (buffer_.empty()) return;
+        if (sparse_) {  // no dimension bookkeeping (vector_writer.go:152: only `if !w.sparse`)
+            std::vector<vectors::Vector> all;
+            all.swap(buffer_);
+            ensure_collection();
+            client_->AddVectors(collection_, all);
+            return;
+        }
         if (dimension_ < 0) {  // the most frequent dimension of the first batch, first seen wins ties (:153-166)
             std::map<size_t, int> counts;
             for (auto &v : buffer_) counts[v.Values.size()]++;
@@ -403,11 +553,48 @@ private:
     vectors::Distance distance_;
     int64_t timestamp_;
     int batch_;
+    bool sparse_;
     std::mutex mu_;
-    int dimension_ = -1;
+    int dimension_;
     bool exists_ = false;
     std::vector<vectors::Vector> buffer_;
 };
+
+// newSparseVector / appendSparseVector (vector_writer.go:192-209): ids outside the idf table or with idf <= 0 are
+// dropped, the value is float32(math.Sqrt(float64(idf))), the index is offset + id
+inline void appendSparseVector(vectors::Vector &v, const std::vector<int32_t> &ids, const std::vector<float> &idf, uint32_t offset) {
+    for (int32_t id : ids) {
+        if (id < 0 || (size_t)id >= idf.size() || !(idf[(size_t)id] > 0)) continue;
+        v.Indices.push_back(offset + (uint32_t)id);
+        v.Values.push_back((float)std::sqrt((double)idf[(size_t)id]));
+    }
+}
+// a set of label ids in ascending order: mapset + slices.Sort (item_to_item.go:187-191)
+inline std::vector<int32_t> sorted_set(std::vector<int32_t> ids) {
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    return ids;
+}
+// feedback ids in ascending order: slices.Sort (item_to_item.go:213).  A repeated id -- the reference would hand xvec a
+// vector with a repeated index, whose treatment no test pins -- is kept once.
+inline std::vector<int32_t> sorted_feedback(std::vector<int32_t> ids) { return sorted_set(std::move(ids)); }
+
+// The three sparse kinds of NewItemToItem / NewUserToUser (item_to_item.go:89-113, user_to_user.go:89-113).  `meta` carries
+// Id / IsHidden / Categories (users have neither of the last two); Timestamp is the writer's.
+inline vectors::Vector tagsVector(vectors::Vector meta, const std::vector<int32_t> &tags, const std::vector<float> &tagsIDF) {
+    appendSparseVector(meta, sorted_set(tags), tagsIDF, 0);  // tagsItemToItem.Add, item_to_item.go:179-199
+    return meta;
+}
+inline vectors::Vector feedbackVector(vectors::Vector meta, const std::vector<int32_t> &feedback, const std::vector<float> &idf) {
+    appendSparseVector(meta, sorted_feedback(feedback), idf, 0);  // usersItemToItem.Add, :212-220
+    return meta;
+}
+inline vectors::Vector autoVector(vectors::Vector meta, const std::vector<int32_t> &tags, const std::vector<float> &tagsIDF,
+                                  const std::vector<int32_t> &feedback, const std::vector<float> &feedbackIDF) {
+    appendSparseVector(meta, sorted_set(tags), tagsIDF, 0);  // autoItemToItem.Add, :232-245: feedback ids after the tags
+    appendSparseVector(meta, sorted_feedback(feedback), feedbackIDF, (uint32_t)tagsIDF.size());
+    return meta;
+}
 
 // neighbour list -> scores, the loop of item_to_item.go:72-86 for the embedding type (distance Euclidean, scale 1):
 // the item itself is skipped, score = 1 / (1 - Score) = 1 / (1 + distance), at most n entries
@@ -422,6 +609,50 @@ inline std::vector<Score> embedding_scores(const std::vector<vectors::ScoredVect
         out.push_back(std::move(s));
         if ((int)out.size() == n) break;
     }
+    return out;
+}
+
+// neighbour list -> scores for ANY kind (item_to_item.go:64-87): distance Dot unless the kind is "embedding"; the item
+// itself and, for Dot, scores <= 0 are skipped; "auto" halves the score (tags + feedback both contribute)
+inline std::vector<Score> similar_scores(const std::vector<vectors::ScoredVector> &neighbors, const std::string &type,
+                                         const std::string &self, int n) {
+    if (type == "embedding") return embedding_scores(neighbors, self, n);
+    const double scale = type == "auto" ? .5 : 1.0;
+    std::vector<Score> out;
+    for (const auto &nb : neighbors) {
+        if (nb.Id == self || nb.Score <= 0) continue;
+        Score s;
+        s.Id = nb.Id;
+        s.Value = (double)nb.Score * scale;
+        s.Categories = nb.Categories;
+        out.push_back(std::move(s));
+        if ((int)out.size() == n) break;
+    }
+    return out;
+}
+// QueryItemToItem / QueryUserToUser for any kind: GetVectors(id), QueryVectors(n + 1), similar_scores
+inline std::vector<Score> QuerySimilarTyped(vectors::HipDatabase &client, const std::string &collection, const std::string &type,
+                                            const std::string &id, const std::vector<std::string> &categories, int n) {
+    auto queries = client.GetVectors(collection, {id});
+    if (queries.empty()) return {};
+    return similar_scores(client.QueryVectors(collection, queries[0], categories, n + 1), type, id, n);
+}
+// the refresh of a sparse kind for many ids with ONE device search (HipDatabase::QuerySparseBatch)
+inline std::vector<std::vector<Score>> QuerySimilarTypedBulk(vectors::HipDatabase &client, const std::string &collection,
+                                                             const std::string &type, const std::vector<std::string> &ids,
+                                                             const std::vector<std::string> &categories, int n) {
+    std::vector<std::vector<Score>> out(ids.size());
+    std::vector<vectors::Vector> queries;
+    std::vector<size_t> which;
+    for (size_t t = 0; t < ids.size(); t++) {
+        auto v = client.GetVectors(collection, {ids[t]});
+        if (v.empty()) continue;
+        queries.push_back(std::move(v[0]));
+        which.push_back(t);
+    }
+    if (which.empty()) return out;
+    auto res = client.QuerySparseBatch(collection, queries, categories, n + 1);
+    for (size_t r = 0; r < which.size(); r++) out[which[r]] = similar_scores(res[r], type, ids[which[r]], n);
     return out;
 }
 

@@ -1,7 +1,7 @@
 """Python face of the C++ twin of vectors.Database (gorse_amd/host/gorse_vectors.hpp; storage/vectors/database.go:107-120)
 so that the parity tests read like storage/vectors/database_test.go.  `Open("hip://")` searches on the MI355X through
-libgorse_hip; `Database(searcher=...)` takes a search callback instead (the CPU test-suite injects a checker built on
-the oracle there -- the product path never does)."""
+libgorse_hip; `Database(searcher=..., sparse_searcher=...)` takes search callbacks instead (the CPU test-suite injects
+checkers built on the oracle there -- the product path never does)."""
 import ctypes as C
 import datetime as dt
 
@@ -28,6 +28,9 @@ _ERR = {-201: ErrNotFound, -202: ErrAlreadyExists, -203: ErrNotSupported}
 _INVALID = -1  # GORSE_ERR_INVALID (std::invalid_argument in the C++ twin)
 SEARCH_CB = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int64,
                         C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int32))
+SPARSE_CB = C.CFUNCTYPE(C.c_int32, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                        C.POINTER(C.c_uint8), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                        C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int32))
 _H = None
 
 
@@ -39,6 +42,8 @@ def _host():
         H.gh_vdb_open.argtypes = [C.c_char_p]
         H.gh_vdb_open_with_searcher.restype = C.c_void_p
         H.gh_vdb_open_with_searcher.argtypes = [SEARCH_CB]
+        H.gh_vdb_open_with_searchers.restype = C.c_void_p
+        H.gh_vdb_open_with_searchers.argtypes = [C.c_void_p, C.c_void_p]
         H.gh_vdb_free.argtypes = [C.c_void_p]
         for n, args in (("gh_vdb_close", [C.c_void_p]),
                         ("gh_vdb_add_collection", [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]),
@@ -48,6 +53,7 @@ def _host():
                         ("gh_vdb_get", [C.c_void_p, C.c_char_p, C.c_char_p]),
                         ("gh_vdb_delete_vectors", [C.c_void_p, C.c_char_p, C.c_int64]),
                         ("gh_vdb_query_staged", [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]),
+                        ("gh_vdb_query_sparse_staged", [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]),
                         ("gh_vdb_query_batch", [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int64, C.c_int32, C.c_char_p, C.c_int32])):
             getattr(H, n).restype = C.c_int32
             getattr(H, n).argtypes = args
@@ -72,6 +78,9 @@ def _host():
         H.gh_vdb_result_dim.argtypes = [C.c_int64]
         H.gh_vdb_result_values.restype = None
         H.gh_vdb_result_values.argtypes = [C.c_int64, C.POINTER(C.c_float)]
+        H.gh_vdb_result_nnz.argtypes = [C.c_int64]
+        H.gh_vdb_result_indices.restype = None
+        H.gh_vdb_result_indices.argtypes = [C.c_int64, C.POINTER(C.c_uint32)]
         H.gh_vdb_result_categories.restype = C.c_int64
         H.gh_vdb_result_categories.argtypes = [C.c_int64, C.c_char_p, C.c_int64]
         _H = H
@@ -117,11 +126,13 @@ class ScoredVector(Vector):
 class Database:
     """vectors.Database.  Methods and error behaviour follow database.go:107-120 / xvec.go."""
 
-    def __init__(self, url="hip://", searcher=None):
+    def __init__(self, url="hip://", searcher=None, sparse_searcher=None):
         H = _host()
-        if searcher is not None:
-            self._cb = SEARCH_CB(searcher)  # keep the thunk alive
-            self.h = C.c_void_p(H.gh_vdb_open_with_searcher(self._cb))
+        if searcher is not None or sparse_searcher is not None:
+            self._cb = SEARCH_CB(searcher) if searcher is not None else None  # keep the thunks alive
+            self._scb = SPARSE_CB(sparse_searcher) if sparse_searcher is not None else None
+            self.h = C.c_void_p(H.gh_vdb_open_with_searchers(C.cast(self._cb, C.c_void_p) if self._cb else None,
+                                                             C.cast(self._scb, C.c_void_p) if self._scb else None))
         else:
             p = H.gh_vdb_open(url.encode())
             if not p:
@@ -182,6 +193,9 @@ class Database:
             vals = np.empty(H.gh_vdb_result_dim(r), np.float32)
             H.gh_vdb_result_values(r, vals.ctypes.data_as(C.POINTER(C.c_float)))
             v.Values = [float(x) for x in vals]
+            ind = np.empty(H.gh_vdb_result_nnz(r), np.uint32)
+            H.gh_vdb_result_indices(r, ind.ctypes.data_as(C.POINTER(C.c_uint32)))
+            v.Indices = [int(x) for x in ind]
             v.IsHidden = bool(H.gh_vdb_result_hidden(r))
             n = H.gh_vdb_result_categories(r, None, 0)
             buf = C.create_string_buffer(int(n))
@@ -226,12 +240,24 @@ class Database:
         return [flat[cuts[t]:cuts[t + 1]] for t in range(Q.shape[0])]
 
 
+    def QuerySparseBatch(self, name, queries, categories, topK):
+        """Bulk form for a sparse collection: every Vector of `queries` (Indices / Values) in one device search."""
+        H = _host()
+        H.gh_vdb_stage_clear()
+        for q in queries:
+            self._stage(q)
+        _ck(H.gh_vdb_query_sparse_staged(self.h, name.encode(), "\n".join(categories or []).encode(), topK))
+        flat = self._results(True)
+        cuts = [int(H.gh_vdb_result_split(t)) for t in range(len(queries) + 1)]
+        return [flat[cuts[t]:cuts[t + 1]] for t in range(len(queries))]
+
+
 def Open(path, tablePrefix=""):
     """vectors.Open (database.go:167-175): creators by URL prefix; 'hip://' is the one registered here."""
     return Database(url=path)
 
 
-# ---- logics: embedding item-to-item / user-to-user (logics/item_to_item.go, user_to_user.go, vector_writer.go) ----------
+# ---- logics: item-to-item / user-to-user, embedding and sparse kinds (logics/item_to_item.go, user_to_user.go, vector_writer.go) ----
 def ItemToItemCollection(name):
     return "item_to_item_" + name  # database.go:56-58
 
@@ -245,6 +271,14 @@ def _logics_host():
     if not getattr(H, "_logics_ready", False):
         H.gh_vwriter_new.restype = C.c_void_p
         H.gh_vwriter_new.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int32]
+        H.gh_vwriter_new_sparse.restype = C.c_void_p
+        H.gh_vwriter_new_sparse.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int32]
+        H.gh_logics_stage_kind_vector.restype = None
+        H.gh_logics_stage_kind_vector.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int64, C.POINTER(C.c_int32),
+                                                  C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.c_int32,
+                                                  C.POINTER(C.c_float), C.c_int32]
+        H.gh_logics_query_similar_typed.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
+        H.gh_logics_query_similar_typed_bulk.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32]
         H.gh_vwriter_free.argtypes = [C.c_void_p]
         H.gh_vwriter_add_staged.argtypes = [C.c_void_p]
         H.gh_vwriter_clean.argtypes = [C.c_void_p]
@@ -289,6 +323,63 @@ class EmbeddingItemToItem:
 
     def Clean(self):
         _ck(_logics_host().gh_vwriter_clean(self.w))
+
+
+class SparseSimilarity:
+    """The sparse kinds of NewItemToItem / NewUserToUser (logics/item_to_item.go:89-113, 169-245; user_to_user.go:89-113,
+    160-237): kind "tags" (label ids, tags IDF), "users" / "items" (feedback ids, their IDF), "auto" (both, feedback ids
+    offset by len(tagsIDF)).  One class serves items and users; `Add` takes the label ids the column expression yields."""
+    KINDS = {"tags": 0, "users": 1, "items": 1, "auto": 2}
+
+    def __init__(self, kind, collection, timestamp, client, tags_idf=None, feedback_idf=None, batch_size=0):
+        if kind not in self.KINDS:
+            raise ValueError("invalid item-to-item type")  # item_to_item.go:110-112
+        if kind in ("tags", "auto") and tags_idf is None:
+            raise ValueError("tags IDF is required for %s" % kind)  # :97-99, 106-108
+        if kind in ("users", "items", "auto") and feedback_idf is None:
+            raise ValueError("%s IDF is required for %s" % ("users" if kind != "items" else "items", kind))
+        self.kind, self.collection, self.client, self.timestamp = kind, collection, client, _ms(timestamp)
+        self.tags_idf = np.ascontiguousarray(tags_idf if tags_idf is not None else [], np.float32)
+        self.fb_idf = np.ascontiguousarray(feedback_idf if feedback_idf is not None else [], np.float32)
+        self.w = C.c_void_p(_logics_host().gh_vwriter_new_sparse(client.h, collection.encode(), self.timestamp, batch_size))
+
+    def __del__(self):
+        if getattr(self, "w", None):
+            _logics_host().gh_vwriter_free(self.w)
+            self.w = None
+
+    def Add(self, id, tags=(), feedback=(), is_hidden=False, categories=()):
+        H = _logics_host()
+        t = np.ascontiguousarray(list(tags), np.int32)
+        f = np.ascontiguousarray(list(feedback), np.int32)
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        H.gh_vdb_stage_clear()
+        H.gh_logics_stage_kind_vector(self.KINDS[self.kind], str(id).encode(), int(is_hidden), "\n".join(categories).encode(),
+                                      self.timestamp, t.ctypes.data_as(ip), t.size, self.tags_idf.ctypes.data_as(fp),
+                                      self.tags_idf.size, f.ctypes.data_as(ip), f.size, self.fb_idf.ctypes.data_as(fp),
+                                      self.fb_idf.size)
+        _ck(H.gh_vwriter_add_staged(self.w))
+
+    def Clean(self):
+        _ck(_logics_host().gh_vwriter_clean(self.w))
+
+
+def QuerySimilarTyped(client, collection, kind, id, categories, n):
+    """QueryItemToItem / QueryUserToUser for any kind (item_to_item.go:50-88): Dot unless "embedding", the id itself and
+    scores <= 0 skipped, "auto" halved"""
+    _ck(_logics_host().gh_logics_query_similar_typed(client.h, collection.encode(), kind.encode(), str(id).encode(),
+                                                      "\n".join(categories or []).encode(), n))
+    return _scores()
+
+
+def QuerySimilarTypedBulk(client, collection, kind, ids, categories, n):
+    """a sparse kind's neighbours for many ids with ONE device search (logics::QuerySimilarTypedBulk)"""
+    H = _logics_host()
+    _ck(H.gh_logics_query_similar_typed_bulk(client.h, collection.encode(), kind.encode(), "\n".join(map(str, ids)).encode(),
+                                             "\n".join(categories or []).encode(), n))
+    flat = _scores()
+    cuts = [int(H.gh_vdb_result_split(t)) for t in range(len(ids) + 1)]
+    return [flat[cuts[t]:cuts[t + 1]] for t in range(len(ids))]
 
 
 def _scores():

@@ -201,11 +201,12 @@ int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int64_t *n_tie
  * (ascending ids, value sqrt(idf)) and queried by logics/item_to_item.go:50-88.
  * N stored vectors as CSR: indptr[N+1], indices[nnz] STRICTLY ASCENDING inside a row, values[nnz].
  * Score of (query, row) = sum over the common indices, in ascending index order, of q_value * x_value, each product
- * and each addition rounded to float32 (no fused multiply-add).  A row is a hit when it shares at least one index
- * with the query (TestSparse, database_test.go:217-224: the disjoint vector is not returned).  Results per query:
- * the k hits with the largest score, descending; equal scores in ascending row order (the reference's Flat index is a
- * third-party module whose tie order no test pins); -0 counts as +0.  idx_out / score_out are nq*k padded with
- * -1 / -inf, count_out[t] = number of valid entries. */
+ * and each addition rounded to float32 (no fused multiply-add); a row sharing no index scores 0.  Results per query
+ * are what QueryVectors returns (xvec.go:379-446): all admissible rows ranked by score, descending (equal scores in
+ * ascending row order: the reference's Flat index is a third-party module whose tie order no test pins), cut to k, and
+ * the rows with Score == 0 dropped AFTER the cut (xvec.go:419-421; TestSparse, database_test.go:217-224: the disjoint
+ * vector is not returned).  With positive values -- all the IDF writers produce -- that is simply the k best rows
+ * sharing an index with the query.  idx_out / score_out are nq*k padded with -1 / -inf, count_out[t] = valid entries. */
 typedef struct gorse_sparse gorse_sparse;
 int32_t gorse_sparse_create(gorse_sparse **h, int32_t device, int64_t N, const int64_t *indptr /*host*/,
                             const uint32_t *indices /*host*/, const float *values /*host*/);
@@ -214,13 +215,13 @@ int32_t gorse_sparse_destroy(gorse_sparse *h);
  * xvec.go:379-446 evaluated by the caller); NULL = all rows admissible (the default). */
 int32_t gorse_sparse_set_mask(gorse_sparse *h, const uint8_t *admissible /*host, N bytes, or NULL*/);
 /* nq query vectors as CSR (same ordering rule as the stored rows; indices the index never saw match nothing).
- * exclude[t] (array may be NULL, entries may be -1) is a stored row left out of query t's result. */
+ * exclude[t] (array may be NULL, entries may be -1) is a stored row treated as absent for query t. */
 int32_t gorse_sparse_search(gorse_sparse *h, int64_t nq, const int64_t *q_indptr /*host*/,
                             const uint32_t *q_indices /*host*/, const float *q_values /*host*/,
                             const int64_t *exclude /*host or NULL*/, int32_t k, int32_t *idx_out /*host*/,
                             float *score_out /*host*/, int32_t *count_out /*host*/);
 /* every stored row q in [q_begin, q_end) as a query (the item-to-item / user-to-user refresh): exclude_self != 0
- * leaves row q out of its own result.  Host pointers may be NULL (results stay on the device). */
+ * treats row q as absent from its own ranking.  Host pointers may be NULL (results stay on the device). */
 int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t exclude_self,
                                int32_t *idx_out /*host or NULL*/, float *score_out /*host or NULL*/,
                                int32_t *count_out /*host or NULL*/);

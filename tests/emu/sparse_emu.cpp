@@ -30,6 +30,11 @@ extern "C" int emu_sparse_search(int64_t N, const int64_t *indptr, const uint32_
     a.q_ptr = q_ptr ? q_ptr : indptr, a.q_idx = q_ptr ? q_idx : indices, a.q_val = q_ptr ? q_val : values;
     a.q_first = q_ptr ? 0 : q_first, a.nq = nq;
     a.exclude = exclude, a.exclude_self = exclude_self, a.mask = mask, a.N = N;
+    a.n_admissible = N;
+    if (mask) {
+        a.n_admissible = 0;
+        for (int64_t r = 0; r < N; r++) a.n_admissible += mask[r] != 0;
+    }
     a.acc = acc.data(), a.stamp = stamp.data(), a.touched = touched.data();
     a.k = k, a.out_idx = out_idx, a.out_score = out_score, a.out_cnt = out_cnt, a.stat = stat2;
     const uint32_t per_launch = (uint32_t)((nq + grid - 1) / grid);

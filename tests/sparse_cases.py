@@ -39,9 +39,14 @@ def check_against_oracle(o, ptr, idx, val, k, got, queries, excludes, mask=None)
         assert (out_idx[t, ei.size:] == -1).all() and np.isneginf(out_sc[t, ei.size:]).all(), t
 
 
-# rows with equal scores, products that cancel to +-0, an empty row, a row of explicit zeros
+# rows with equal scores, products that cancel to +-0, an empty row, a row of explicit zeros, negative scores
 TIE_ROWS = [([1, 4], [1.0, 1.0]), ([1, 4], [1.0, 1.0]), ([4], [2.0]), ([1, 9], [3.0, 1.0]), ([1, 4], [1.0, -1.0]),
-            ([2], [5.0]), ([], []), ([1, 4], [-1.0, 1.0]), ([4, 9], [0.0, 0.0])]
+            ([2], [5.0]), ([], []), ([1, 4], [-1.0, 1.0]), ([4, 9], [0.0, 0.0]), ([1], [-4.0]), ([1, 4], [1.0, 1.0]),
+            ([4], [-4.0])]
+# query 0 = {1: 1, 4: 1} with row 0 excluded and row 2 masked: scores 3 (row 3), 2 (rows 1 and 10: a tie, ascending row),
+# -4 (rows 9 and 11), and six zero-score rows (4, 7, 8 cancel or multiply zeros; 5, 6 share nothing) -- the reference
+# ranks all ten admissible rows, cuts to k and drops the zeros, so a negative row needs k > 3 + 5
+TIE_EXPECT = {3: [3, 1, 10], 8: [3, 1, 10], 9: [3, 1, 10, 9], 10: [3, 1, 10, 9, 11], 20: [3, 1, 10, 9, 11]}
 
 
 def tie_case():

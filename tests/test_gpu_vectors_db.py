@@ -17,9 +17,10 @@ def db():
 
 # S.collaborative_recommend (bulk recommendations for many users) was written after the round's GPU budget was spent: it
 # runs in the CPU module against the oracle-backed searcher and joins this list once it has been run on a device.
+# The sparse collections (S.SPARSE_CASES) run on the device from tests/test_gpu_vectors_sparse.py.
 
 
-@pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.sparse, S.hidden, S.dot, S.delete_vectors,
+@pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.hidden, S.dot, S.delete_vectors,
                                   S.upsert_and_close, S.item_to_item_column, S.item_to_item_embedding, S.item_to_item_clean,
                                   S.user_to_user_embedding, S.user_to_user_clean],
                          ids=lambda f: f.__name__)

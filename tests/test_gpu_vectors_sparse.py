@@ -4,8 +4,10 @@ database.go:90-97, xvec.go:241-247; filled by the IDF writers of logics/vector_w
 import numpy as np
 import pytest
 
+import vectors_suite as S
 from gorse_amd import capi, synth
-from sparse_cases import check_against_oracle as check, random_csr, rows_of, tie_case
+from gorse_amd import vectors as V
+from sparse_cases import TIE_EXPECT, check_against_oracle as check, random_csr, rows_of, tie_case
 
 pytestmark = pytest.mark.gpu
 
@@ -37,13 +39,15 @@ def test_many_hits_overflow_the_ranking_buffer(oracle, k):
 
 
 def test_ties_zero_scores_mask_and_exclude(oracle):
+    """equal scores rank by ascending row; zero scores are dropped AFTER the cut to k (xvec.go:419-421: they use up
+    slots, so negative scores appear only when every zero-score row fits too); mask / exclude"""
     ptr, idx, val, (qp, qi, qv), mask, excl = tie_case()
     s = capi.Sparse(ptr, idx, val)
     s.set_mask(mask)
-    got = s.search(qp, qi, qv, 20, exclude=excl)
-    check(oracle, ptr, idx, val, 20, got, rows_of(qp, qi, qv, range(3)), list(excl), mask)
-    assert list(got[0][0, :got[2][0]]) == [3, 1, 4, 7, 8]
-    assert not np.signbit(got[1][0, 2:5]).any()
+    for k, expect in TIE_EXPECT.items():
+        got = s.search(qp, qi, qv, k, exclude=excl)
+        check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(3)), list(excl), mask)
+        assert list(got[0][0, :got[2][0]]) == expect
     s.set_mask(None)
     got = s.search(qp, qi, qv, 20, exclude=excl)
     check(oracle, ptr, idx, val, 20, got, rows_of(qp, qi, qv, range(3)), list(excl), None)
@@ -142,3 +146,11 @@ def test_argument_errors():
     assert e.value.code == capi.ERR_RANGE
     i, sc, cnt = s.search(*q, 3, exclude=[0])
     assert cnt[0] == 0  # row 1 = {2} shares nothing, row 0 is excluded
+
+
+# ---- the same kernel behind the vectors.Database twin and the sparse similarity kinds of logics -----------------------
+@pytest.mark.parametrize("case", S.SPARSE_CASES, ids=lambda f: f.__name__)
+def test_reference_suite_sparse(case):
+    """storage/vectors/database_test.go TestSparse and logics/{item_to_item,user_to_user}_test.go TestTags / TestUsers /
+    TestItems / TestAuto (tests/vectors_suite.py) on `vectors.Open("hip://")`"""
+    case(V.Open("hip://"))

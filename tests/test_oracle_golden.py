@@ -239,14 +239,16 @@ def test_sparse_dot_order_and_ties(oracle):
     # float32 accumulation in ascending index order: (1e8 + 1) - 1e8 is 0 in that order, not 1
     common, s = oracle.sparse_dot([0, 1, 2], [1e8, 1.0, -1e8], [0, 1, 2], [1.0, 1.0, 1.0])
     assert common == 3 and s == 0.0
-    # equal scores come back in ascending row order; a cancelled (+-0) hit is still a hit and is +0
-    ptr = np.array([0, 1, 2, 4], np.int64)
-    idx = np.array([5, 5, 5, 6], np.uint32)
-    val = np.array([2.0, 2.0, 1.0, -1.0], np.float32)
-    i, sc = oracle.sparse_search(ptr, idx, val, [5, 6], [1.0, 1.0], 5)
-    assert i.tolist() == [0, 1, 2] and sc.tolist() == [2.0, 2.0, 0.0] and not np.signbit(sc[2])
-    i, sc = oracle.sparse_search(ptr, idx, val, [5, 6], [1.0, 1.0], 5, exclude=0, admissible=[1, 0, 1])
-    assert i.tolist() == [2]
+    # equal scores come back in ascending row order; a zero score (cancelled products, or no common index) takes a slot
+    # of the top k and is then dropped (xvec.go:419-421), so the negative row 3 only shows once rows 0, 1, 2, 4 fit too
+    ptr = np.array([0, 1, 2, 4, 5, 6], np.int64)
+    idx = np.array([5, 5, 5, 6, 6, 9], np.uint32)
+    val = np.array([2.0, 2.0, 1.0, -1.0, -3.0, 1.0], np.float32)
+    for k, rows in ((2, [0, 1]), (4, [0, 1]), (5, [0, 1, 3])):
+        i, sc = oracle.sparse_search(ptr, idx, val, [5, 6], [1.0, 1.0], k)
+        assert i.tolist() == rows and sc.tolist() == [2.0, 2.0, -3.0][:len(rows)]
+    i, sc = oracle.sparse_search(ptr, idx, val, [5, 6], [1.0, 1.0], 5, exclude=0, admissible=[1, 0, 1, 1, 1])
+    assert i.tolist() == [3]  # rows 2 and 4 score zero, 3 admissible rows < k
 
 
 def test_idf_formula(oracle):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from sparse_cases import check_against_oracle as check, random_csr, rows_of, tie_case
+from sparse_cases import TIE_EXPECT, check_against_oracle as check, random_csr, rows_of, tie_case
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU = os.path.join(HERE, "emu")
@@ -76,14 +76,13 @@ def test_buffer_overflow_and_cut(emu, oracle):
 
 
 def test_ties_zero_scores_mask_and_exclude(emu, oracle):
-    """equal scores rank by ascending row; a hit whose products cancel to (+-)0 is still a hit; mask / exclude"""
+    """equal scores rank by ascending row; zero scores are dropped AFTER the cut to k (they use up slots); mask / exclude"""
     ptr, idx, val, (qp, qi, qv), mask, excl = tie_case()
-    got = run_emu(emu, ptr, idx, val, 20, 3, q=(qp, qi, qv), exclude=excl, mask=mask, grid=1, block=4)
-    check(oracle, ptr, idx, val, 20, got, rows_of(qp, qi, qv, range(3)), list(excl), mask)
-    # spelled out: rows 3 (3.0) and 1 (2.0) lead; rows 4 and 7 cancel to 0 and tie with row 8 (0 * anything): 4, 7, 8
-    assert list(got[0][0, :got[2][0]]) == [3, 1, 4, 7, 8]
-    assert got[2][1] == 0 and got[2][2] == 0
-    assert not np.signbit(got[1][0, 2:5]).any()
+    for k, expect in TIE_EXPECT.items():
+        got = run_emu(emu, ptr, idx, val, k, 3, q=(qp, qi, qv), exclude=excl, mask=mask, grid=1, block=4)
+        check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(3)), list(excl), mask)
+        assert list(got[0][0, :got[2][0]]) == expect
+        assert got[2][1] == 0 and got[2][2] == 0
 
 
 def test_stamps_survive_many_queries_and_launches(emu, oracle):
@@ -155,8 +154,8 @@ def _gpu_cases():
     import test_gpu_vectors_sparse as G
     cases = []
     for name in sorted(dir(G)):
-        if not name.startswith("test_") or name == "test_argument_errors":  # argument checks live in sparse.hip
-            continue
+        if not name.startswith("test_") or name in ("test_argument_errors", "test_reference_suite_sparse"):
+            continue  # argument checks live in sparse.hip; the database suite has its own emulated run below
         if name == "test_many_hits_overflow_the_ranking_buffer":
             cases += [(name, k) for k in (3, 64, 65, 513)]
         else:
@@ -187,3 +186,20 @@ def test_no_data_race_between_barriers_under_thread_sanitizer(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert "ThreadSanitizer" not in run.stderr, run.stderr[-2000:]
     assert run.returncode == 0 and "tsan run done rc=0" in run.stdout
+
+
+# ---- the vectors.Database twin and the sparse logics kinds with the emulated kernel as their searcher -----------------
+def _suite_cases():
+    import vectors_suite as S
+    return S.SPARSE_CASES
+
+
+@pytest.mark.parametrize("case", _suite_cases(), ids=lambda f: f.__name__)
+def test_database_suite_on_the_emulated_kernel(emu, case):
+    from gorse_amd import vectors as V
+
+    def sparse_searcher(n, indptr, indices, values, admissible, nq, q_indptr, q_indices, q_values, k, idx, score, cnt):
+        p = lambda x: C.cast(x, C.c_void_p)
+        return emu.emu_sparse_search(n, p(indptr), p(indices), p(values), nq, p(q_indptr), p(q_indices), p(q_values), 0, None, 0,
+                                     p(admissible), k, 2, 8, 1, 0, p(idx), p(score), p(cnt), None)
+    case(V.Database(sparse_searcher=sparse_searcher))

@@ -1,5 +1,5 @@
-"""vectors.Database twin (gorse_amd/host/gorse_vectors.hpp) against the reference's own test-suite, with the device search
-replaced by an exact checker built on the oracle (ann.Bruteforce restated): collection / vector bookkeeping, filters,
+"""vectors.Database twin (gorse_amd/host/gorse_vectors.hpp) against the reference's own test-suite, with the device searches
+replaced by exact checkers built on the oracle (ann.Bruteforce and the sparse inner-product ranking restated): collection / vector bookkeeping, filters,
 over-fetch logic and score conventions are host code and are fully exercised here; test_gpu_vectors_db.py runs the same
 suite on the MI355X."""
 import numpy as np
@@ -22,12 +22,28 @@ def db(oracle):
             ei, ed = oracle.search_vector(Xa, metric, Qa[t], k)
             I[t, :ei.size], D[t, :ei.size], Cn[t] = ei, ed, ei.size
         return 0
-    return V.Database(searcher=searcher)
+
+    def sparse_searcher(n, indptr, indices, values, admissible, nq, q_indptr, q_indices, q_values, k, idx, score, cnt):
+        ptr = np.ctypeslib.as_array(indptr, (n + 1,)).copy()
+        nnz = int(ptr[-1])
+        ind = np.ctypeslib.as_array(indices, (max(nnz, 1),))[:nnz].copy()
+        val = np.ctypeslib.as_array(values, (max(nnz, 1),))[:nnz].copy()
+        ok = np.ctypeslib.as_array(admissible, (n,)).copy()
+        qp = np.ctypeslib.as_array(q_indptr, (nq + 1,)).copy()
+        qn = int(qp[-1])
+        qi = np.ctypeslib.as_array(q_indices, (max(qn, 1),))[:qn].copy()
+        qv = np.ctypeslib.as_array(q_values, (max(qn, 1),))[:qn].copy()
+        I, Sc, Cn = np.ctypeslib.as_array(idx, (nq, k)), np.ctypeslib.as_array(score, (nq, k)), np.ctypeslib.as_array(cnt, (nq,))
+        for t in range(nq):
+            ei, es = oracle.sparse_search(ptr, ind, val, qi[qp[t]:qp[t + 1]], qv[qp[t]:qp[t + 1]], k, admissible=ok)
+            I[t, :ei.size], Sc[t, :ei.size], Cn[t] = ei, es, ei.size
+        return 0
+    return V.Database(searcher=searcher, sparse_searcher=sparse_searcher)
 
 
-@pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.sparse, S.hidden, S.dot, S.delete_vectors,
+@pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.hidden, S.dot, S.delete_vectors,
                                   S.upsert_and_close, S.item_to_item_column, S.item_to_item_embedding, S.item_to_item_clean,
-                                  S.user_to_user_embedding, S.user_to_user_clean, S.collaborative_recommend],
+                                  S.user_to_user_embedding, S.user_to_user_clean, S.collaborative_recommend] + S.SPARSE_CASES,
                          ids=lambda f: f.__name__)
 def test_reference_suite(db, case):
     case(db)

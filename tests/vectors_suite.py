@@ -66,16 +66,63 @@ def get_vectors(db):  # TestGetVectors (database_test.go:155-190)
     assert db.GetVectors("test", None) == []
 
 
-def sparse(db):  # TestSparse (database_test.go:192-243): sparse collections are the reference's Flat index; not built here
+def sparse(db):  # TestSparse (database_test.go:187-236)
+    db.AddCollection("test_sparse", 0, V.Dot)
+    info = db.DescribeCollection("test_sparse")
+    assert info["Dimension"] == 0 and info["Distance"] == V.Dot
+    cutoff = 1_790_000_000_000
+    db.AddVectors("test_sparse", [V.Vector("old", [1, 1], Indices=[1, 100], Timestamp=cutoff - 3_600_000),
+                                  V.Vector("match", [1, 2], Indices=[1, 100], Timestamp=cutoff),
+                                  V.Vector("other", [1, 2], Indices=[2, 200], Timestamp=cutoff)])
+    assert db.CountVectors("test_sparse") == 3
+    got = db.GetVectors("test_sparse", ["match", "missing"])
+    assert len(got) == 1 and got[0].Id == "match" and got[0].Indices == [1, 100] and got[0].Values == [1, 2]
+    assert got[0].Timestamp == cutoff
+    r = db.QueryVectors("test_sparse", V.Vector(Values=[1, 2], Indices=[1, 100]), None, 10)
+    assert len(r) == 2 and r[0].Id == "match"  # "other" shares no index: Score == 0 is dropped (xvec.go:419-421)
+    assert [x.Id for x in r] == ["match", "old"] and [x.Score for x in r] == [5.0, 3.0] and r[0].Indices == [1, 100]
+    db.DeleteVectors("test_sparse", cutoff)
+    assert db.CountVectors("test_sparse") == 2
+    db.DeleteCollection("test_sparse")
+    with pytest.raises(V.ErrNotFound):
+        db.DescribeCollection("test_sparse")
+
+
+def sparse_rules(db):  # xvec.go:241-247 (sparse = Dot only), :301-327 (validation before the upsert), :386-394 (filters)
     with pytest.raises(V.ErrNotSupported):
-        db.AddCollection("test_sparse", 0, V.Dot)
-    db.AddCollection("dense", defaultVectorSize, V.Dot)
-    with pytest.raises(V.ErrNotSupported):
-        db.AddVectors("dense", [V.Vector("old", [1, 1], Indices=[1, 100])])
-    with pytest.raises(V.ErrNotSupported):
-        db.QueryVectors("dense", V.Vector(Values=[1, 2], Indices=[1, 100]), None, 10)
-    with pytest.raises(V.ErrNotSupported):  # quantized collections (database_test.go:332-420) neither
+        db.AddCollection("s", 0, V.Cosine)  # "distance method for sparse vector"
+    with pytest.raises(V.ErrNotSupported):  # quantized collections (database_test.go:332-420)
         db.AddCollection("q", defaultVectorSize, V.Cosine, quantization="sq", bits=8)
+    db.AddCollection("s", 0, V.Dot)
+    db.AddCollection("dense", defaultVectorSize, V.Dot)
+    with pytest.raises(ValueError):
+        db.AddVectors("dense", [V.Vector("x", [1, 1], Indices=[1, 100])])  # a sparse vector in a dense collection
+    with pytest.raises(ValueError):
+        db.AddVectors("s", [V.Vector("ok", [1.0], Indices=[3]), V.Vector("x", [1, 0, 0, 0])])  # dense in sparse: nothing added
+    with pytest.raises(ValueError):
+        db.AddVectors("s", [V.Vector("x", [1, 2], Indices=[7, 7])])  # repeated index
+    assert db.CountVectors("s") == 0
+    with pytest.raises(ValueError):
+        db.QueryVectors("dense", V.Vector(Values=[1, 2], Indices=[1, 100]), None, 10)
+    # entries may come in any order; hidden vectors and the categories filter; upsert; zero / negative scores
+    db.AddVectors("s", [V.Vector("a", [2, 1], Indices=[9, 4], Categories=["c", "x"]),
+                        V.Vector("b", [1, 1], Indices=[4, 9], Categories=["c"]),
+                        V.Vector("h", [5, 5], Indices=[4, 9], IsHidden=True, Categories=["c", "x"]),
+                        V.Vector("n", [-1], Indices=[4], Categories=["c"]),
+                        V.Vector("z", [1, -1], Indices=[4, 9], Categories=["c"]),
+                        V.Vector("far", [1], Indices=[1000])])
+    q = V.Vector(Values=[1, 1], Indices=[9, 4])
+    assert [(x.Id, x.Score) for x in db.QueryVectors("s", q, None, 10)] == [("a", 3.0), ("b", 2.0), ("n", -1.0)]
+    # the reference ranks all five visible vectors, cuts, THEN drops the zero scores ("z" cancels, "far" is disjoint):
+    # with topK 4 the slots after "a", "b" go to the two zeros and "n" is not returned
+    assert [x.Id for x in db.QueryVectors("s", q, None, 4)] == ["a", "b"]
+    assert [x.Id for x in db.QueryVectors("s", q, ["x"], 10)] == ["a"]
+    assert db.QueryVectors("s", q, ["nope"], 10) == [] and db.QueryVectors("s", q, None, 0) == []
+    db.AddVectors("s", [V.Vector("b", [4], Indices=[9], Categories=["c"])])  # upsert
+    assert db.CountVectors("s") == 6
+    assert [(x.Id, x.Score) for x in db.QueryVectors("s", q, None, 2)] == [("b", 4.0), ("a", 3.0)]
+    bulk = db.QuerySparseBatch("s", [q, V.Vector(Values=[1], Indices=[1000]), V.Vector(Values=[1], Indices=[77])], None, 3)
+    assert [[x.Id for x in r] for r in bulk] == [["b", "a"], ["far"], []]
 
 
 def hidden(db):  # TestHidden (database_test.go:245-279)
@@ -207,6 +254,79 @@ def item_to_item_clean(db):  # TestClean (item_to_item_test.go:143-170): Clean d
     assert db.DescribeCollection(coll)["Dimension"] == 3 and db.CountVectors(coll) == 1
 
 
+def _nested_kind(db, kind, collection, n=100):
+    """TestTags / TestUsers (item_to_item_test.go:212-270) and TestTags / TestItems (user_to_user_test.go:96-153): entity i
+    carries the ids 1 .. 100-i (as labels or as feedback), every idf is 1; the neighbours of "0" are "1" .. "10" in order"""
+    idf = np.ones(101, np.float32)
+    w = V.SparseSimilarity(kind, collection, 1_790_000_000_000, db, tags_idf=idf if kind == "tags" else None,
+                           feedback_idf=None if kind == "tags" else idf)
+    for i in range(n):
+        ids = list(range(100 - i, 0, -1))  # unsorted on purpose: the writer sorts (slices.Sort)
+        w.Add(str(i), tags=ids if kind == "tags" else (), feedback=() if kind == "tags" else ids)
+    w.Clean()
+    scores = V.QuerySimilarTyped(db, collection, kind, "0", None, 10)
+    assert [s.Id for s in scores] == [str(i) for i in range(1, 11)]
+    assert [s.Score for s in scores] == [float(100 - i) for i in range(1, 11)]  # sum of idf over the common ids
+    bulk = V.QuerySimilarTypedBulk(db, collection, kind, [str(i) for i in range(n)] + ["missing"], None, 7)
+    assert bulk[-1] == [] and len(bulk) == n + 1
+    for i in (0, 1, 37, 99):
+        one = V.QuerySimilarTyped(db, collection, kind, str(i), None, 7)
+        assert [(s.Id, s.Score) for s in bulk[i]] == [(s.Id, s.Score) for s in one]
+    assert V.QuerySimilarTyped(db, collection, kind, "no-such-id", None, 10) == []
+
+
+def item_to_item_tags(db):  # TestTags (item_to_item_test.go:212-242)
+    _nested_kind(db, "tags", V.ItemToItemCollection("tags"))
+
+
+def item_to_item_users(db):  # TestUsers (item_to_item_test.go:244-271)
+    _nested_kind(db, "users", V.ItemToItemCollection("users"))
+
+
+def _auto_kind(db, collection):
+    """TestAuto (item_to_item_test.go:273-316): even entities carry labels, odd ones feedback; both id spaces share one
+    vector (feedback ids offset by len(tagsIDF)), so even entities only match even ones, odd only odd; scores halved"""
+    idf = np.ones(101, np.float32)
+    w = V.SparseSimilarity("auto", collection, 1_790_000_000_000, db, tags_idf=idf, feedback_idf=idf)
+    for i in range(100):
+        ids = list(range(1, 100 - i + 1))
+        w.Add(str(i), tags=ids if i % 2 == 0 else (), feedback=() if i % 2 == 0 else ids)
+    w.Clean()
+    s0 = V.QuerySimilarTyped(db, collection, "auto", "0", None, 10)
+    assert [s.Id for s in s0] == [str(2 * i) for i in range(1, 11)]
+    assert [s.Score for s in s0] == [(100 - 2 * i) * .5 for i in range(1, 11)]
+    s1 = V.QuerySimilarTyped(db, collection, "auto", "1", None, 10)
+    assert [s.Id for s in s1] == [str(2 * i + 1) for i in range(1, 11)]
+    v = db.GetVectors(collection, ["1"])[0]
+    assert v.Indices[0] == 101 + 1 and len(v.Indices) == 99  # offset = len(tagsIDF)
+
+
+def item_to_item_auto(db):
+    _auto_kind(db, V.ItemToItemCollection("auto"))
+
+
+def item_to_item_sparse_hidden_and_idf(db):
+    """TestHidden's rule for a sparse kind (item_to_item_test.go:166-210: hidden items are stored, never returned), ids with
+    idf <= 0 or outside the table dropped (vector_writer.go:200-208), an item without usable ids not written (:88-91),
+    and the categories filter of QueryItemToItem"""
+    coll = V.ItemToItemCollection("users_idf")
+    idf = np.array([0.0, 4.0, 9.0, -1.0, 16.0], np.float32)  # users 0 and 3 carry no weight
+    w = V.SparseSimilarity("users", coll, 1_790_000_000_000, db, feedback_idf=idf)
+    w.Add("a", feedback=[1, 2, 4], categories=["k"])
+    w.Add("b", feedback=[4, 0, 1, 99], categories=["k"])      # 0: idf 0, 99: outside the table
+    w.Add("c", feedback=[2, 3], is_hidden=True, categories=["k"])
+    w.Add("d", feedback=[2])
+    w.Add("e", feedback=[0, 3, 7])                               # nothing usable: no vector
+    w.Clean()
+    assert db.CountVectors(coll) == 4
+    vb = db.GetVectors(coll, ["b"])[0]
+    assert vb.Indices == [1, 4] and vb.Values == [2.0, 4.0]  # sqrt(idf)
+    r = V.QuerySimilarTyped(db, coll, "users", "a", None, 10)
+    assert [(s.Id, s.Score) for s in r] == [("b", 20.0), ("d", 9.0)]  # 4 + 16, 9; "c" is hidden; "a" itself skipped
+    assert [s.Id for s in V.QuerySimilarTyped(db, coll, "users", "a", ["k"], 10)] == ["b"]
+    assert V.QuerySimilarTyped(db, coll, "users", "e", None, 10) == []
+
+
 # ---- logics/user_to_user_test.go (the embedding kind is the same writer and query over the user_to_user_* collection) --
 def user_to_user_embedding(db):  # TestEmbedding (user_to_user_test.go:48-71)
     coll = V.UserToUserCollection("embedding")
@@ -228,6 +348,22 @@ def user_to_user_clean(db):  # TestClean (user_to_user_test.go:73-93)
     w.Add("new", [2, 0])
     w.Clean()
     assert [v.Id for v in db.GetVectors(coll, ["stale", "current", "new"])] == ["current", "new"]
+
+
+def user_to_user_tags(db):  # TestTags (user_to_user_test.go:96-125)
+    _nested_kind(db, "tags", V.UserToUserCollection("tags"))
+
+
+def user_to_user_items(db):  # TestItems (user_to_user_test.go:127-153)
+    _nested_kind(db, "items", V.UserToUserCollection("items"))
+
+
+def user_to_user_auto(db):  # TestAuto (user_to_user_test.go:155-190)
+    _auto_kind(db, V.UserToUserCollection("auto"))
+
+
+SPARSE_CASES = [sparse, sparse_rules, item_to_item_tags, item_to_item_users, item_to_item_auto,
+                item_to_item_sparse_hidden_and_idf, user_to_user_tags, user_to_user_items, user_to_user_auto]
 
 
 # ---- master/tasks.go:930-962 + worker/pipeline.go:403-425: item factors in a Dot collection, per-user recommendations ----
