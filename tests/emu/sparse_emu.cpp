@@ -11,7 +11,9 @@ using namespace gorse::sparse;
 // queries: q_ptr == NULL -> the stored rows q_first .. q_first + nq (all pairs), else the given CSR rows 0 .. nq.
 // `rounds` launches are made over the same scratch (serial bases advance like in the library); the outputs hold the
 // results of the last one.  Returns 0, or -1 for an invalid input (message not kept: the tests feed valid data).
-extern "C" int emu_sparse_search(int64_t N, const int64_t *indptr, const uint32_t *indices, const float *values, int64_t nq,
+// Built with -fvisibility=hidden: the kernel template and the index builder have the same mangled names as the host stubs
+// inside libgorse_hip.so, which the test process may have loaded with RTLD_GLOBAL; only this entry point is exported.
+extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t N, const int64_t *indptr, const uint32_t *indices, const float *values, int64_t nq,
                                  const int64_t *q_ptr, const uint32_t *q_idx, const float *q_val, int64_t q_first,
                                  const int64_t *exclude, int exclude_self, const uint8_t *mask, int k, int grid, int block,
                                  int rounds, uint32_t serial_base, int32_t *out_idx, float *out_score, int32_t *out_cnt,

@@ -25,7 +25,7 @@ def emu():
             os.path.join(HERE, "..", "gorse_amd", "csrc", "sparse_kernels.hpp"),
             os.path.join(HERE, "..", "gorse_amd", "csrc", "sparse_host.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread", "-o", so,
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-pthread", "-o", so,
                                srcs[0]])
     L = C.CDLL(so)
     p = C.c_void_p
