@@ -15,6 +15,9 @@ Workloads (BASELINE.json configs):
   topk   C4 alone: item x item cosine top-100 over 1M x 128 bf16 (the default run appends it as "topk").
   als    C5: eALS 500K x 100K x 50M feedbacks, nFactors 64; rows sharded over the ranks (strong scaling), two
          all-gathers of factor row blocks per epoch.
+  i2i    SURVEY 8f item 2: the "users" item-to-item refresh = sparse all-pairs top-100 over the IDF vectors of the C3-shard
+         dataset's 200,000 items (item -> its users, value sqrt(idf)); query rows sharded over the ranks, index replicated,
+         no collective.  `--i2i-shape ml1m` uses the S-ml1m items instead.
 Timed region: inputs resident in HBM, barrier + device sync on both sides, MAX over ranks.
 """
 import argparse
@@ -60,7 +63,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k", "topk", "als"])
+    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k", "topk", "als", "i2i"])
+    ap.add_argument("--i2i-shape", default="c3", choices=["c3", "ml1m", "ml100k"])
     ap.add_argument("--als-scale", type=float, default=1.0, help="shrink S-als (users, items, feedbacks) by this factor")
     ap.add_argument("--no-topk", action="store_true", help="skip the item x item top-k leg of the default run")
     ap.add_argument("--topk-n", type=int, default=1_000_000)
@@ -242,6 +246,104 @@ def bench_topk(args, world, rank, local, fence):
     return out
 
 
+def bench_sparse(args, world, rank, local, fence):
+    """The sparse similarity refresh (logics/item_to_item.go "users" kind over a sparse Dot collection): every item's
+    top-100 neighbours by the inner product of the sqrt(idf)-weighted user sets.  A step = one all-pairs pass over this
+    rank's query rows; results stay in HBM."""
+    k = 100
+    if args.i2i_shape == "c3":
+        data, desc = synth.s_big_shard(rank=0, world=8), "S-big shard 125000 users x 200000 items x 12.5M feedbacks"
+    elif args.i2i_shape == "ml1m":
+        data, desc = synth.s_ml1m(), "S-ml1m 6040 users x 3706 items"
+    else:
+        data, desc = synth.s_ml100k(), "S-ml100k 943 users x 1682 items"
+    ptr, idx, val = synth.idf_vectors(data.iptr, data.iidx, data.U)
+    N = ptr.size - 1
+    sp = capi.Sparse(ptr, idx, val, device=local)
+    q0, q1 = rank * N // world, (rank + 1) * N // world
+    sp.all_pairs(k, q0, min(q1, q0 + 4096), fetch=False)  # warm-up: scratch allocation, code objects
+    for _ in range(max(args.warmup - 1, 0)):
+        sp.all_pairs(k, q0, q1, fetch=False)
+    fence()
+    sp.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sp.all_pairs(k, q0, q1, fetch=False)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    launches, ms = sp.get_profile()
+    postings, hits = sp.last_stats()
+    sp.set_profiling(False)
+    if rank != 0:
+        return None
+    # SURVEY 8f item 2 / DESIGN: 8 algorithmic bytes per multiply-add (the posting's row id + value); the accumulators
+    # live in a per-workgroup scratch row that is meant to stay in L2
+    avg_ms = ms / max(launches, 1)
+    achieved = postings * 8.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "sparse item x item top-%d multiply-adds/sec (postings walked, whole job, N GPUs)" % k,
+        "value": world * postings * args.steps / dt, "unit": "postings/s", "n_gpus": world, "steps": args.steps,
+        "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "users item-to-item over %s: %d sparse vectors, %d entries, k=%d, query rows sharded x%d"
+                               % (desc, N, int(ptr[-1]), k, world),
+                   "queries_per_step_per_gpu": q1 - q0, "postings_per_step_per_gpu": postings, "hit_rows_per_step_per_gpu": hits},
+        "roofline": {"bound": "hbm", "kernel": "sparse_query_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_posting": 8,
+                     "avg_launch_ms": avg_ms, "launches": launches},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = sparse_cpu_baseline(ptr, idx, val, k, args.cpu_seconds, sp, q0)
+        except AssertionError:
+            raise
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "postings/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    return out
+
+
+def sparse_cpu_baseline(ptr, idx, val, k, seconds, sp, q_begin):
+    """The oracle's sparse search (kind 'port': every stored vector merged against the query, what an exact Flat index
+    does) on a few query rows, one query per host thread; the rows double as a bit-exact check of the GPU result."""
+    from oracle import oracle as orc
+    o = orc.Oracle()
+    N = ptr.size - 1
+    threads = min(os.cpu_count() or 1, 32)
+    row = lambda r: (idx[ptr[r]:ptr[r + 1]], val[ptr[r]:ptr[r + 1]])
+    t0 = time.perf_counter()
+    o.sparse_search(ptr, idx, val, *row(q_begin), k, exclude=q_begin)
+    one = max(time.perf_counter() - t0, 1e-4)
+    per_thread = max(1, min(int(seconds / one), 256))
+    qs = [q_begin + (131 * t) % max(N - q_begin, 1) for t in range(threads * per_thread)]
+    res = [None] * len(qs)
+
+    def work(t):
+        for r in range(t, len(qs), threads):
+            res[r] = o.sparse_search(ptr, idx, val, *row(qs[r]), k, exclude=qs[r])
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    lens = np.bincount(idx, minlength=int(idx.max()) + 1 if idx.size else 1)
+    postings = int(sum(lens[row(q)[0]].sum() for q in qs))
+    for q, (ei, es) in zip(qs, res):
+        gi, gs, gc = sp.all_pairs(k, q, q + 1)
+        same = gc[0] == ei.size and np.array_equal(gi[0, :ei.size], ei) and \
+            np.array_equal(gs[0, :ei.size].view(np.uint32), es.view(np.uint32))
+        assert same, "GPU sparse top-k row %d differs from the oracle" % q
+    return {"value": postings / dt, "unit": "postings/s", "cores": threads, "kind": "port",
+            "sample": "%d queries (each merged against all %d stored vectors) on %d threads, %.1f s, counted in the same "
+                      "unit (posting-list entries an inverted index would walk for them); all of them compared bit for bit "
+                      "with the GPU rows" % (len(qs), N, threads, dt)}
+
+
 def als_cpu_baseline(uptr, uidx, iptr, P, Q, w, reg, seconds):
     """The oracle's half-sweep (kind 'port', model.go:659-690) on a prefix of the user rows, T host threads each on
     its own row range (rows are independent: what parallel.Parallel does); the serial d x d Gram pass every call
@@ -358,9 +460,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.workload in ("topk", "als"):
+    if args.workload in ("topk", "als", "i2i"):
         if args.workload == "als":
             out = bench_als(args, world, rank, local, fence0)
+        elif args.workload == "i2i":
+            out = bench_sparse(args, world, rank, local, fence0)
         else:
             out = bench_topk(args, world, rank, local, fence0)
             if rank == 0:
