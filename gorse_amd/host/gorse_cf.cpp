@@ -2,6 +2,8 @@
 // the C ABI only; this file is the C++ twin of what model/cf/bpr_hip.go / als_hip.go would contain.
 #include "gorse_cf.hpp"
 
+#include "gob.hpp"
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -245,12 +247,18 @@ Score ALS::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitCo
 }
 
 void MatrixFactorization::Marshal(std::ostream &w) const {
-    put_le<int32_t>(w, (int32_t)Params.size());
+    // encoding.WriteGob(w, baseModel.Params) (model.go:208, encoding.go:98-107): int32 byte count + the gob stream of
+    // map[ParamName]any.  The reference reads NFactors / NEpochs with GetInt (only `int` matches, params.go:86-97) and
+    // RandomState with GetInt64 (int64 or int), everything else through GetFloat32 (float32 / float64 / int).
+    gob::Entries entries;
     for (auto &kv : Params) {
-        put_le<int32_t>(w, (int32_t)kv.first.size());
-        w.write(kv.first.data(), (std::streamsize)kv.first.size());
-        put_le<double>(w, kv.second);
+        const bool integral = kv.first == model::NFactors || kv.first == model::NEpochs || kv.first == model::RandomState;
+        entries.emplace_back(kv.first, integral && kv.second == (double)(int64_t)kv.second ? gob::Value::of_int((int64_t)kv.second)
+                                                                                            : gob::Value::of_float(kv.second));
     }
+    const std::string params = gob::encode_map("Params", entries);
+    put_le<int32_t>(w, (int32_t)params.size());
+    w.write(params.data(), (std::streamsize)params.size());
     int64_t cnt = 0;
     for (int32_t u = 0; u < UserIndex->Count(); u++) cnt += IsUserPredictable(u);
     put_le<int64_t>(w, cnt);
@@ -272,14 +280,14 @@ void MatrixFactorization::Marshal(std::ostream &w) const {
 
 void MatrixFactorization::Unmarshal(std::istream &r) {
     release();
-    model::Params p;
-    int32_t np = get_le<int32_t>(r);
-    for (int32_t k = 0; k < np; k++) {
-        int32_t len = get_le<int32_t>(r);
-        std::string name((size_t)len, '\0');
-        r.read(&name[0], len);
-        p[name] = get_le<double>(r);
-    }
+    model::Params p;  // encoding.ReadGob(r, &baseModel.Params) (model.go:251)
+    const int32_t nbytes = get_le<int32_t>(r);
+    if (nbytes < 0) throw std::runtime_error("negative gob length");
+    std::string params((size_t)nbytes, '\0');
+    r.read(&params[0], nbytes);
+    if (r.gcount() != (std::streamsize)nbytes) throw std::runtime_error("unexpected EOF");
+    for (auto &kv : gob::decode_map(params))
+        if (kv.second.kind != gob::Value::String) p[kv.first] = kv.second.number();
     SetParams(p);
     auto read_side = [&](std::shared_ptr<dataset::FreqDict> &dict, std::vector<bool> &pred, std::vector<float> &fac) {
         int64_t cnt = get_le<int64_t>(r);

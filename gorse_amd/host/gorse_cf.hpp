@@ -510,9 +510,9 @@ class MatrixFactorization {
     }
     bool Invalid() const { return !UserIndex || !ItemIndex || ItemFactor.empty() || UserFactor.empty(); }
 
-    // Marshal / Unmarshal (model.go:206-292).  Layout of the reference except for the Params block,
-    // which is Go gob there (Go-only) and a count + (name, float64) list here; the LatentFactor
-    // records are byte-identical protobuf (protocol/encoding.proto:27-30, pbutil.WriteDelimited).
+    // Marshal / Unmarshal (model.go:206-292): the Params block is a gob stream of map[ParamName]any (gob.hpp: restated
+    // from the encoding/gob documentation, unpinned against a Go encoder), the counts are little-endian int64, the
+    // LatentFactor records are byte-identical protobuf (protocol/encoding.proto:27-30, pbutil.WriteDelimited).
     void Marshal(std::ostream &w) const;
     void Unmarshal(std::istream &r);
 

@@ -189,6 +189,89 @@ float gh_metric(int32_t id, const int32_t *target, int32_t nt, const int32_t *ra
     return table[id](cf::TargetSet(target, target + nt), std::vector<int32_t>(rank, rank + nr));
 }
 
+// ---- gob (test hooks of gob.hpp) and the MatrixFactorizationUsers blob --------------------------------------------------
+static int64_t copy_out(const std::string &s, char *buf, int64_t cap) {
+    if (buf && cap >= (int64_t)s.size()) memcpy(buf, s.data(), s.size());
+    return (int64_t)s.size();
+}
+int64_t gh_gob_encode_int(int64_t v, char *buf, int64_t cap) { return copy_out(gob::encode_int(v), buf, cap); }
+int64_t gh_gob_encode_string(const char *s, char *buf, int64_t cap) { return copy_out(gob::encode_string(s), buf, cap); }
+int32_t gh_gob_decode_int(const char *buf, int64_t n, int64_t *out) {
+    return guard([&] { *out = gob::decode_int(std::string(buf, (size_t)n)); });
+}
+// kinds: 0 int, 1 float64, 2 bool
+int64_t gh_gob_encode_params(const char **names, const double *vals, const int32_t *kinds, int32_t n, char *buf, int64_t cap) {
+    gob::Entries e;
+    for (int32_t k = 0; k < n; k++) {
+        gob::Value v = kinds[k] == 0 ? gob::Value::of_int((int64_t)vals[k]) : gob::Value::of_float(vals[k]);
+        if (kinds[k] == 2) v.kind = gob::Value::Bool, v.b = vals[k] != 0;
+        e.emplace_back(names[k], v);
+    }
+    return copy_out(gob::encode_map("Params", e), buf, cap);
+}
+// decoded entries as "name\tkind\tvalue" lines
+int64_t gh_gob_decode_params(const char *buf, int64_t n, char *out, int64_t cap) {
+    std::string text;
+    int32_t rc = guard([&] {
+        for (auto &kv : gob::decode_map(std::string(buf, (size_t)n))) {
+            char num[64];
+            snprintf(num, sizeof(num), "%.17g", kv.second.number());
+            text += kv.first + "\t" + std::to_string((int)kv.second.kind) + "\t" +
+                    (kv.second.kind == gob::Value::String ? kv.second.s : std::string(num)) + "\n";
+        }
+    });
+    return rc != 0 ? rc : copy_out(text, out, cap);
+}
+// the worked example of the encoding/gob documentation, type Point struct{ X, Y int } holding {22, 33}, rebuilt from the
+// primitives: the definition of type 65 (a structType with two int fields), then the value
+int64_t gh_gob_doc_example(char *buf, int64_t cap) {
+    std::string def;
+    gob::put_int(def, -65);
+    gob::put_uint(def, 3);  // wireType.StructT
+    gob::put_uint(def, 1);  // CommonType
+    gob::put_uint(def, 1);
+    gob::put_string(def, "Point");
+    gob::put_uint(def, 1);
+    gob::put_int(def, 65);
+    gob::put_uint(def, 0);
+    gob::put_uint(def, 1);  // Field
+    gob::put_uint(def, 2);  // two fieldTypes
+    for (const char *f : {"X", "Y"}) {
+        gob::put_uint(def, 1);
+        gob::put_string(def, f);
+        gob::put_uint(def, 1);
+        gob::put_int(def, gob::tInt);
+        gob::put_uint(def, 0);
+    }
+    gob::put_uint(def, 0);
+    gob::put_uint(def, 0);
+    std::string val;
+    gob::put_int(val, 65);
+    gob::put_uint(val, 1);
+    gob::put_int(val, 22);
+    gob::put_uint(val, 1);
+    gob::put_int(val, 33);
+    gob::put_uint(val, 0);
+    return copy_out(gob::message(def) + gob::message(val), buf, cap);
+}
+void *gh_mfusers_new() { return new logics::MatrixFactorizationUsers(); }
+void gh_mfusers_free(void *u) { delete (logics::MatrixFactorizationUsers *)u; }
+void gh_mfusers_add(void *u, const char *id, const float *v, int32_t d) {
+    ((logics::MatrixFactorizationUsers *)u)->Add(id, std::vector<float>(v, v + d));
+}
+int32_t gh_mfusers_get(void *u, const char *id, float *out, int32_t cap) {
+    std::vector<float> v;
+    if (!((logics::MatrixFactorizationUsers *)u)->Get(id, v)) return -1;
+    for (size_t t = 0; t < v.size() && (int32_t)t < cap; t++) out[t] = v[t];
+    return (int32_t)v.size();
+}
+int64_t gh_mfusers_marshal(void *u, char *buf, int64_t cap) {
+    return copy_out(((logics::MatrixFactorizationUsers *)u)->Marshal(), buf, cap);
+}
+int32_t gh_mfusers_unmarshal(void *u, const char *buf, int64_t n) {
+    return guard([&] { ((logics::MatrixFactorizationUsers *)u)->Unmarshal(std::string(buf, (size_t)n)); });
+}
+
 // ---- heap ----------------------------------------------------------------------------------------
 int32_t gh_topk_filter(int32_t k, const int32_t *items, const float *weights, int32_t n, int32_t *out_items, float *out_w) {
     heap::TopKFilter f(k);

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <memory>
@@ -37,6 +38,7 @@
 #include <vector>
 
 #include "../../include/gorse_hip.h"
+#include "gob.hpp"
 
 namespace gorse {
 namespace storage {
@@ -721,6 +723,67 @@ inline std::vector<std::vector<Score>> CollaborativeRecommendBulk(vectors::HipDa
     }
     return out;
 }
+
+// MatrixFactorizationUsers (logics/cf.go:122-179): user id -> embedding, and its blob: WriteGob(int64 count), then per
+// user WriteString(id) (little-endian int32 length + bytes) + WriteSlice(embedding) (int32 length + little-endian float32s).
+// The reference iterates a Go map (any order); here ids go out sorted.
+class MatrixFactorizationUsers {
+public:
+    void Add(const std::string &userId, std::vector<float> v) { embeddings_[userId] = std::move(v); }
+    bool Get(const std::string &userId, std::vector<float> &out) const {
+        auto it = embeddings_.find(userId);
+        if (it == embeddings_.end()) return false;
+        out = it->second;
+        return true;
+    }
+    size_t Count() const { return embeddings_.size(); }
+    std::string Marshal() const {
+        std::string w;
+        put_bytes(w, gob::encode_int((int64_t)embeddings_.size()));
+        for (const auto &kv : embeddings_) {
+            put_bytes(w, kv.first);
+            put_i32(w, (int32_t)kv.second.size());
+            w.append((const char *)kv.second.data(), kv.second.size() * sizeof(float));
+        }
+        return w;
+    }
+    void Unmarshal(const std::string &blob) {
+        size_t at = 0;
+        const int64_t n = gob::decode_int(get_bytes(blob, at));
+        embeddings_.clear();
+        for (int64_t k = 0; k < n; k++) {
+            std::string id = get_bytes(blob, at);
+            const int32_t len = get_i32(blob, at);
+            if (len < 0 || blob.size() - at < (size_t)len * sizeof(float)) throw std::runtime_error("unexpected EOF");
+            std::vector<float> v((size_t)len);
+            std::memcpy(v.data(), blob.data() + at, (size_t)len * sizeof(float));
+            at += (size_t)len * sizeof(float);
+            embeddings_[id] = std::move(v);
+        }
+    }
+
+private:
+    static void put_i32(std::string &w, int32_t v) { w.append((const char *)&v, 4); }
+    static void put_bytes(std::string &w, const std::string &b) {  // encoding.WriteBytes
+        put_i32(w, (int32_t)b.size());
+        w += b;
+    }
+    static int32_t get_i32(const std::string &b, size_t &at) {
+        if (b.size() - at < 4) throw std::runtime_error("unexpected EOF");
+        int32_t v;
+        std::memcpy(&v, b.data() + at, 4);
+        at += 4;
+        return v;
+    }
+    static std::string get_bytes(const std::string &b, size_t &at) {
+        const int32_t n = get_i32(b, at);
+        if (n < 0 || b.size() - at < (size_t)n) throw std::runtime_error("unexpected EOF");
+        std::string out = b.substr(at, (size_t)n);
+        at += (size_t)n;
+        return out;
+    }
+    std::map<std::string, std::vector<float>> embeddings_;
+};
 
 }  // namespace logics
 }  // namespace gorse

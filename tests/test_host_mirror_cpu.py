@@ -1,5 +1,6 @@
 """Host-side logic of the C++ mirror that needs no GPU: heap containers and ranking metrics against the
 reference's known-answer tests, dataset bookkeeping, model file framing."""
+import ctypes as C
 import json
 import os
 
@@ -62,3 +63,128 @@ def test_dataset_bookkeeping():
     assert (d.CountUsers(), d.CountItems(), d.CountFeedback()) == (3, 3, 4)
     d.AddUser("lonely")
     assert d.CountUsers() == 4 and d.CountFeedback() == 4
+
+
+# ---- model / blob formats (model/cf/model.go:206-292, common/encoding/encoding.go, logics/cf.go:122-179) ---------------
+def _buf(fn, *args):
+    H = cf.host()
+    fn.restype = C.c_int64
+    n = fn(*args, None, C.c_int64(0))
+    assert n >= 0
+    b = C.create_string_buffer(int(n))
+    fn(*args, b, C.c_int64(n))
+    return b.raw
+
+
+def test_gob_primitives_against_the_package_documentation():
+    """encoding/gob is Go's standard library (no toolchain here): the wire rules of gorse_amd/host/gob.hpp are checked
+    against the worked example of the package documentation and its statements about integers and floats"""
+    H = cf.host()
+    # "type Point struct { X, Y int }" holding {22, 33}
+    doc = bytes.fromhex("1fff810301010550 6f696e7401ff8200 0102010158010400 0101590104000000".replace(" ", "")) + \
+        bytes.fromhex("07ff82012c014200")
+    assert _buf(H.gh_gob_doc_example) == doc
+    # a top-level int: byte count, type id int (2 -> 04), the zero that precedes a non-struct value, the value
+    H.gh_gob_encode_int.argtypes = [C.c_int64, C.c_char_p, C.c_int64]
+    assert _buf(H.gh_gob_encode_int, C.c_int64(7)) == bytes.fromhex("0304000e")
+    assert _buf(H.gh_gob_encode_int, C.c_int64(-129)) == bytes.fromhex("050400fe0101")  # (^-129 << 1) | 1 = 257
+    assert _buf(H.gh_gob_encode_int, C.c_int64(256)) == bytes.fromhex("050400fe0200")   # doc: 256 is (FE 01 00) as a uint
+    H.gh_gob_encode_string.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
+    assert _buf(H.gh_gob_encode_string, b"hello") == bytes.fromhex("080c0005") + b"hello"
+    out = C.c_int64(0)
+    for v in (0, 1, -1, 63, 64, 127, 128, -128, 65, 1 << 40, -(1 << 40), (1 << 62)):
+        b = _buf(H.gh_gob_encode_int, C.c_int64(v))
+        assert H.gh_gob_decode_int(b, C.c_int64(len(b)), C.byref(out)) == 0 and out.value == v
+
+
+def _params_blob(params):
+    H = cf.host()
+    names = (C.c_char_p * len(params))(*[k.encode() for k in params])
+    vals = (C.c_double * len(params))(*[float(v[1]) for v in params.values()])
+    kinds = (C.c_int32 * len(params))(*[v[0] for v in params.values()])
+    H.gh_gob_encode_params.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_int64]
+    return _buf(H.gh_gob_encode_params, names, vals, kinds, len(params))
+
+
+def test_gob_params_map_layout_and_round_trip():
+    blob = _params_blob({"NFactors": (0, 16), "Lr": (1, 17.0)})
+    # type definition of id 65: wireType.MapT{CommonType{"Params", 65}, Key string (6), Elem interface (8)}
+    definition = bytes.fromhex("ff81040101") + b"\x06Params" + bytes.fromhex("01ff8200010c01100000")
+    assert blob[:1 + len(definition)] == bytes([len(definition)]) + definition
+    # the map: id 65, singleton marker, 2 entries; "NFactors" -> int 16; "Lr" -> float64 17.0 (doc: 17.0 is FE 31 40)
+    value = bytes.fromhex("ff820002") + b"\x08NFactors" + b"\x03int" + bytes.fromhex("04020020") + \
+        b"\x02Lr" + b"\x07float64" + bytes.fromhex("080400fe3140")
+    assert blob[1 + len(definition):] == bytes([len(value)]) + value
+    H = cf.host()
+    H.gh_gob_decode_params.restype = C.c_int64
+    H.gh_gob_decode_params.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+    n = H.gh_gob_decode_params(blob, len(blob), None, 0)
+    out = C.create_string_buffer(int(n))
+    H.gh_gob_decode_params(blob, len(blob), out, n)
+    assert out.raw.decode().splitlines() == ["NFactors\t0\t16", "Lr\t1\t17"]
+    # what a Go encoder may also send: bool values, float32 (same wire type as float64), values in any order
+    blob = _params_blob({"UseFeature": (2, 1), "Reg": (1, 0.01), "NEpochs": (0, -3)})
+    n = H.gh_gob_decode_params(blob, len(blob), None, 0)
+    out = C.create_string_buffer(int(n))
+    H.gh_gob_decode_params(blob, len(blob), out, n)
+    assert out.raw.decode().splitlines() == ["UseFeature\t2\t1", "Reg\t1\t0.01", "NEpochs\t0\t-3"]
+    assert H.gh_gob_decode_params(blob[:-3], len(blob) - 3, None, 0) < 0  # truncated stream: an error, not garbage
+
+
+def test_model_file_round_trip_and_framing():
+    """MarshalModel (model.go:320-328): name, gob Params, int64 count + LatentFactor records per side -- without a device"""
+    rng = np.random.default_rng(3)
+    P = rng.standard_normal((5, 8)).astype(np.float32)
+    Q = rng.standard_normal((7, 8)).astype(np.float32)
+    m = cf.BPR({"NFactors": 8, "NEpochs": 3, "Lr": 0.05, "Reg": 0.01, "InitStdDev": 0.001, "RandomState": 42})
+    m.load_factors(P, Q)
+    blob = cf.MarshalModel(m)
+    assert blob[:7] == b"\x03\x00\x00\x00bpr"  # encoding.WriteString
+    glen = int.from_bytes(blob[7:11], "little")
+    gob_part = blob[11:11 + glen]
+    assert gob_part[6:13] == b"\x06Params" and b"\x08NFactors\x03int\x04\x02\x00\x10" in gob_part and b"\x02Lr\x07float64" in gob_part
+    assert int.from_bytes(blob[11 + glen:19 + glen], "little") == 5  # predictable users, little-endian int64
+    # first LatentFactor record: varint length, field 1 = "0", field 2 = 8 packed floats
+    rec = blob[19 + glen:]
+    assert rec[0] == 3 + 2 + 32 and rec[1:4] == b"\x0a\x010" and rec[4:6] == b"\x12\x20" and rec[6:38] == P[0].tobytes()
+    m2 = cf.UnmarshalModel(blob)
+    assert m2.Name() == "bpr" and m2.CountUsers() == 5 and m2.CountItems() == 7 and not m2.Invalid()
+    for u in range(5):
+        assert np.array_equal(m2.GetUserFactor(u), P[u]) and m2.IsUserPredictable(u)
+    for i in range(7):
+        assert np.array_equal(m2.GetItemFactor(i), Q[i])
+    assert cf.MarshalModel(m2) == blob  # same Params (sorted names), same records
+    a = cf.ALS({"NFactors": 8, "Alpha": 0.002})
+    a.load_factors(P, Q)
+    assert cf.UnmarshalModel(cf.MarshalModel(a)).Name() == "als"
+    with pytest.raises(cf.HostError):
+        cf.UnmarshalModel(b"\x03\x00\x00\x00xyz")  # "unknown model" (model.go:349)
+
+
+def test_matrix_factorization_users_blob():
+    # logics/cf.go:122-179 and its test (cf_test.go:60-80): Add / Get / Marshal / Unmarshal
+    H = cf.host()
+    H.gh_mfusers_new.restype = C.c_void_p
+    H.gh_mfusers_add.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int32]
+    H.gh_mfusers_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int32]
+    H.gh_mfusers_marshal.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    H.gh_mfusers_unmarshal.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    H.gh_mfusers_free.argtypes = [C.c_void_p]
+    u = C.c_void_p(H.gh_mfusers_new())
+    fp = C.POINTER(C.c_float)
+    for name, v in (("b", [1, 2, 3]), ("a", [0.5, -1]), ("b", [4, 5, 6])):  # the second "b" replaces the first
+        a = np.array(v, np.float32)
+        H.gh_mfusers_add(u, name.encode(), a.ctypes.data_as(fp), a.size)
+    blob = _buf(H.gh_mfusers_marshal, u)
+    # WriteGob(int64(2)) = int32 4 + (03 04 00 04); then "a": int32 1 + 'a', int32 2, two floats; then "b"
+    exp = b"\x04\x00\x00\x00\x03\x04\x00\x04" + b"\x01\x00\x00\x00a\x02\x00\x00\x00" + np.array([0.5, -1], np.float32).tobytes() + \
+        b"\x01\x00\x00\x00b\x03\x00\x00\x00" + np.array([4, 5, 6], np.float32).tobytes()
+    assert blob == exp
+    w = C.c_void_p(H.gh_mfusers_new())
+    assert H.gh_mfusers_unmarshal(w, blob, len(blob)) == 0
+    out = np.zeros(8, np.float32)
+    assert H.gh_mfusers_get(w, b"b", out.ctypes.data_as(fp), 8) == 3 and out[:3].tolist() == [4, 5, 6]
+    assert H.gh_mfusers_get(w, b"missing", out.ctypes.data_as(fp), 8) == -1
+    assert H.gh_mfusers_unmarshal(w, blob[:-2], len(blob) - 2) != 0
+    H.gh_mfusers_free(u)
+    H.gh_mfusers_free(w)
