@@ -249,6 +249,49 @@ def NewALS(params):
     return ALS(params)
 
 
+def _search_out():
+    return C.create_string_buffer(64), C.create_string_buffer(4096), (C.c_float * 3)()
+
+
+def _search_result(type_buf, params_buf, score):
+    params = {}
+    for line in params_buf.value.decode().splitlines():
+        k, v = line.split("=")
+        params[k] = float(v)
+    return {"Type": type_buf.value.decode(), "Params": params, "Score": Score(score[0], score[1], score[2])}
+
+
+def search_mock(n_trials, seed=0):
+    """optimize_test.go's TestTPE search (mock model, NDCG = NFactors + InitMean + InitStdDev) under the random study;
+    returns (study.GetBestValue(), search.Result())"""
+    t, p, sc = _search_out()
+    best = C.c_double(0)
+    H = host()
+    H.gh_search_mock.argtypes = [C.c_int32, C.c_int64, C.POINTER(C.c_double), C.c_char_p, C.c_int64, C.c_char_p, C.c_int64,
+                                 C.POINTER(C.c_float)]
+    _ck(H.gh_search_mock(n_trials, seed, C.byref(best), t, len(t), p, len(p), sc))
+    return best.value, _search_result(t, p, sc)
+
+
+def ModelSearch(trainSet, valSet, n_trials, seed=0, jobs=1, patience=0, overrides=None, keep_resident=True, cancel=None):
+    """optimizeCollaborativeFiltering (master/tasks.go:1268-1316): BPR and ALS at their defaults (+ overrides such as
+    {"NEpochs": 20}) over n_trials random trials; the training set stays on the device across the trials when
+    keep_resident.  Returns (search.Result(), {"uploads", "reuses", "trials"})."""
+    overrides = overrides or {}
+    names = (C.c_char_p * len(overrides))(*[k.encode() for k in overrides])
+    vals = (C.c_double * len(overrides))(*[float(v) for v in overrides.values()])
+    t, p, sc = _search_out()
+    counters = (C.c_int32 * 3)()
+    H = host()
+    H.gh_model_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_char_p),
+                                  C.POINTER(C.c_double), C.c_int32, C.c_int32, _i32p, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    cptr = cancel.ctypes.data_as(_i32p) if cancel is not None else None
+    _ck(H.gh_model_search(trainSet.p, valSet.p, n_trials, seed, jobs, patience, names, vals, len(overrides), int(keep_resident),
+                          cptr, t, len(t), p, len(p), sc, counters))
+    return _search_result(t, p, sc), {"uploads": counters[0], "reuses": counters[1], "trials": counters[2]}
+
+
 def MarshalModel(m):
     n = host().gh_model_marshal(m.p, None, C.c_int64(0))
     buf = C.create_string_buffer(n)

@@ -124,9 +124,34 @@ void MatrixFactorization::Init(const dataset::Dataset &trainSet) {
     for (size_t i = 0; i < ItemPredictable.size(); i++) ItemPredictable[i] = i < itf.size() && !itf[i].empty();
 }
 
-void MatrixFactorization::create_handle(const dataset::Dataset &trainSet, bool with_items, int device) {
+void MatrixFactorization::create_handle(const dataset::Dataset &trainSet, bool with_items, int device, ResidentDataset *res) {
     release();
     device_ = device;
+    if (res) {  // borrow the resident copy when it is this very training set at this nFactors
+        const bool same = res->h && res->trainSet == (const void *)&trainSet && res->U == trainSet.CountUsers() &&
+                          res->I == trainSet.CountItems() && res->N == trainSet.CountFeedback() && res->nFactors == nFactors_ &&
+                          res->device == device && (res->with_items || !with_items);
+        if (!same) {
+            if (res->h) gorse_mf_destroy(res->h);
+            res->h = nullptr;
+            std::vector<int64_t> uptr, iptr;
+            std::vector<int32_t> uidx, iidx;
+            flatten(trainSet.GetUserFeedback(), (size_t)trainSet.CountUsers(), uptr, uidx);
+            flatten(trainSet.GetItemFeedback(), (size_t)trainSet.CountItems(), iptr, iidx);  // always: ALS may come next
+            check(gorse_mf_create(&res->h, device, trainSet.CountUsers(), trainSet.CountItems(), nFactors_, uptr.data(),
+                                  uidx.data(), iptr.data(), iidx.data()));
+            res->trainSet = (const void *)&trainSet;
+            res->U = trainSet.CountUsers(), res->I = trainSet.CountItems(), res->N = trainSet.CountFeedback();
+            res->nFactors = nFactors_, res->device = device, res->with_items = true;
+            res->uploads++;
+        } else {
+            res->reuses++;
+        }
+        h_ = res->h;
+        borrowed_ = true;
+        check(gorse_mf_set_factors(h_, UserFactor.data(), ItemFactor.data()));
+        return;
+    }
     std::vector<int64_t> uptr, iptr;
     std::vector<int32_t> uidx, iidx;
     flatten(trainSet.GetUserFeedback(), (size_t)trainSet.CountUsers(), uptr, uidx);
@@ -194,6 +219,7 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
         if (rc == GORSE_ERR_CANCELLED) {  // "fit bpr canceled" -> Score{} (model.go:490-493)
             log(fmt("fit %s canceled epoch=%d", tag, epoch));
             pull_factors();
+            if (borrowed_) release();
             return Score{};
         }
         check(rc);
@@ -216,6 +242,7 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
         if (config.OnEpoch) config.OnEpoch(epoch);
     }
     pull_factors();  // the reference's [][]float32 rows, before Marshal / GetUserFactor are used
+    if (borrowed_) release();  // a lent handle goes back: the next Fit overwrites its factors (Predict re-uploads ours)
     log(fmt("fit %s complete NDCG@%d=%g", tag, config.TopK, score[0]));
     return Score{score[0], score[1], score[2]};
 }
@@ -225,7 +252,7 @@ Score BPR::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitCo
     GetRandomGenerator().NormalMatrix(trainSet.CountUsers(), nFactors_, initMean, initStdDev, UserFactor);
     GetRandomGenerator().NormalMatrix(trainSet.CountItems(), nFactors_, initMean, initStdDev, ItemFactor);
     Init(trainSet);
-    create_handle(trainSet, false, config.Device);
+    create_handle(trainSet, false, config.Device, config.Resident);
     // per-Fit sampler seed, as rng[i] = NewRandomGenerator(bpr.GetRandomGenerator().Int63()) (model.go:420-423)
     const uint64_t seed = (uint64_t)GetRandomGenerator().Int63();
     // Jobs <= 1: parallel.Parallel runs the samples strictly in order (parallel.go:34-43) -> sequential
@@ -241,7 +268,7 @@ Score ALS::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitCo
     GetRandomGenerator().NormalMatrix(trainSet.CountUsers(), nFactors_, initMean, initStdDev, UserFactor);
     GetRandomGenerator().NormalMatrix(trainSet.CountItems(), nFactors_, initMean, initStdDev, ItemFactor);
     Init(trainSet);
-    create_handle(trainSet, true, config.Device);
+    create_handle(trainSet, true, config.Device, config.Resident);
     return fit_loop("als", nEpochs, trainSet, valSet, config,
                     [&](int) { return gorse_als_epoch(h_, weight, reg, config.Cancel); });
 }

@@ -398,6 +398,19 @@ namespace cf {
 struct Score {
     float NDCG = 0, Precision = 0, Recall = 0;
 };
+// One gorse_mf handle (dataset CSR on the device + factor matrices of a fixed nFactors) lent to successive models that fit
+// the same training set: Fit then only uploads fresh factors (gorse_mf_set_factors) instead of the whole dataset.
+struct ResidentDataset {
+    gorse_mf *h = nullptr;
+    const void *trainSet = nullptr;  // identity of the dataset::Dataset the handle was built from
+    int64_t U = 0, I = 0, N = 0;
+    int nFactors = 0, device = 0;
+    bool with_items = false;
+    int uploads = 0, reuses = 0;  // how often the dataset crossed PCIe / was found resident
+    ~ResidentDataset() {
+        if (h) gorse_mf_destroy(h);
+    }
+};
 // FitConfig (model.go:50-80) plus the two hooks a Go context / monitor span provide there.
 struct FitConfig {
     int Jobs = 1, Verbose = 10, Candidates = 100, TopK = 10, Patience = 0;
@@ -405,6 +418,9 @@ struct FitConfig {
     std::function<void(int)> OnEpoch;                 // span.Add(1)
     std::function<void(const std::string &)> Log;     // zap logger lines ("fit bpr e/E ...")
     int Device = 0;
+    // a dataset kept on the device across Fit calls (the trials of a ModelSearch, the fit periods of the
+    // master); null = every Fit uploads its own copy, as round 1 did
+    struct ResidentDataset *Resident = nullptr;
     FitConfig &SetVerbose(int v) { Verbose = v; return *this; }
     FitConfig &SetJobs(int j) { Jobs = j; return *this; }
     FitConfig &SetPatience(int p) { Patience = p; return *this; }
@@ -454,11 +470,21 @@ inline float MRR(const TargetSet &t, const std::vector<int32_t> &r) {
     return 0;
 }
 
+// goptuna.Trial (github.com/c-bata/goptuna v0.9.0, go.mod) as far as SuggestParams / ModelSearch.Objective call it
+// (model.go:397-405, 588-596; optimize.go:61-64; optimize_test.go:95-99)
+struct Trial {
+    virtual ~Trial() = default;
+    virtual std::string SuggestCategorical(const std::string &name, const std::vector<std::string> &choices) = 0;
+    virtual double SuggestLogFloat(const std::string &name, double low, double high) = 0;
+    virtual double SuggestDiscreteFloat(const std::string &name, double low, double high, double q) = 0;
+};
+
 // cf.MatrixFactorization (model.go:82-127) with its state resident on one MI355X.
 class MatrixFactorization {
    public:
     virtual ~MatrixFactorization() { release(); }
     virtual const char *Name() const = 0;
+    virtual model::Params SuggestParams(Trial &trial) = 0;  // model.Model (model/model.go): the search space of a trial
     virtual void SetParams(const model::Params &p) {
         Params = p;
         randState_ = Params.GetInt64(model::RandomState, 0);
@@ -539,12 +565,13 @@ class MatrixFactorization {
 
    protected:
     void Init(const dataset::Dataset &trainSet);  // BaseMatrixFactorization.Init, model.go:129-146
-    void create_handle(const dataset::Dataset &trainSet, bool with_items, int device);
+    void create_handle(const dataset::Dataset &trainSet, bool with_items, int device, ResidentDataset *res = nullptr);
     void ensure_resident();
     void pull_factors() { check(gorse_mf_get_factors(h_, UserFactor.data(), ItemFactor.data())); }
     void release() {
-        if (h_) gorse_mf_destroy(h_);
+        if (h_ && !borrowed_) gorse_mf_destroy(h_);  // a borrowed handle stays with its ResidentDataset
         h_ = nullptr;
+        borrowed_ = false;
     }
     util::RandomGenerator &GetRandomGenerator() { return rng_; }
     // the shared evaluate / early-stopping epoch loop of BPR.Fit and ALS.Fit (model.go:432-440, 496-518)
@@ -555,6 +582,7 @@ class MatrixFactorization {
     int64_t randState_ = 0;
     util::RandomGenerator rng_{0};
     gorse_mf *h_ = nullptr;
+    bool borrowed_ = false;
     int device_ = 0;
 };
 
@@ -577,6 +605,15 @@ class BPR : public MatrixFactorization {
         initStdDev = Params.GetFloat32(model::InitStdDev, 0.001f);
     }
     Score Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitConfig &config) override;
+    model::Params SuggestParams(Trial &trial) override {  // model.go:397-405
+        model::Params p;
+        p[model::NFactors] = 16;
+        p[model::Lr] = trial.SuggestLogFloat(model::Lr, 0.001, 0.1);
+        p[model::Reg] = trial.SuggestLogFloat(model::Reg, 0.001, 0.1);
+        p[model::InitMean] = 0;
+        p[model::InitStdDev] = trial.SuggestLogFloat(model::InitStdDev, 0.001, 0.1);
+        return p;
+    }
     int nEpochs = 100;
     float lr = 0.05f, reg = 0.01f, initMean = 0, initStdDev = 0.001f;
 };
@@ -595,8 +632,118 @@ class ALS : public MatrixFactorization {
         weight = Params.GetFloat32(model::Alpha, 0.001f);
     }
     Score Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitConfig &config) override;
+    model::Params SuggestParams(Trial &trial) override {  // model.go:588-596
+        model::Params p;
+        p[model::NFactors] = 16;
+        p[model::InitMean] = 0;
+        p[model::InitStdDev] = trial.SuggestLogFloat(model::InitStdDev, 0.001, 0.1);
+        p[model::Reg] = trial.SuggestLogFloat(model::Reg, 0.001, 0.1);
+        p[model::Alpha] = trial.SuggestLogFloat(model::Alpha, 0.001, 0.1);
+        return p;
+    }
     int nEpochs = 50;
     float reg = 0.06f, initMean = 0, initStdDev = 0.1f, weight = 0.001f;
+};
+
+// ---- hyper-parameter search: ModelSearch (optimize.go:28-85) + the study that drives it (master/tasks.go:1268-1316) ----
+using ModelCreator = std::function<std::unique_ptr<MatrixFactorization>()>;
+struct SearchResult {  // meta.Model[Score]
+    std::string Type;
+    model::Params Params;
+    Score Score_;
+};
+class ModelSearch {
+   public:
+    // trainSet / valSet may be null for models whose Fit ignores them (optimize_test.go's mock).  With keepResident the
+    // search lends ONE device copy of the training set to all its trials (every SuggestParams fixes NFactors = 16).
+    ModelSearch(std::map<std::string, ModelCreator> models, dataset::Dataset *trainSet, dataset::Dataset *valSet,
+                FitConfig config, bool keepResident = true)
+        : creators_(std::move(models)), train_(trainSet), val_(valSet), config_(std::move(config)) {
+        for (auto &kv : creators_) types_.push_back(kv.first);  // maps.Keys: any order in Go, sorted here
+        if (keepResident) config_.Resident = &resident_;
+    }
+    double Objective(Trial &trial) {  // optimize.go:61-81
+        if (creators_.empty()) throw std::runtime_error("no model to search");
+        const std::string type = trial.SuggestCategorical("Model", types_);
+        auto m = creators_.at(type)();
+        m->SetParams(m->SuggestParams(trial));
+        static dataset::Dataset none;
+        const Score score = m->Fit(train_ ? *train_ : none, val_ ? *val_ : none, config_);
+        if (score.NDCG > result_.Score_.NDCG) {
+            result_.Type = type;
+            result_.Params = m->GetParams();
+            result_.Score_ = score;
+        }
+        if (OnTrial) OnTrial();  // span.Add(1)
+        return (double)score.NDCG;
+    }
+    const SearchResult &Result() const { return result_; }
+    const ResidentDataset &Resident() const { return resident_; }
+    std::function<void()> OnTrial;
+
+   private:
+    std::map<std::string, ModelCreator> creators_;
+    std::vector<std::string> types_;
+    dataset::Dataset *train_, *val_;
+    FitConfig config_;
+    ResidentDataset resident_;  // declared after config_: destroyed first, while no model borrows it any more
+    SearchResult result_;
+};
+
+// A trial that draws every parameter independently: uniform over the choices, log-uniform, uniform over the grid
+// low, low + q, ... <= high.  This is goptuna's random sampling, which its TPE sampler also uses for its start-up trials;
+// the TPE model itself (github.com/c-bata/goptuna v0.9.0, absent from /root/reference) is not restated, and which values
+// Go's generator would draw is unpinned like every math/rand stream.
+class RandomTrial : public Trial {
+   public:
+    explicit RandomTrial(util::RandomGenerator &rng) : rng_(rng) {}
+    std::string SuggestCategorical(const std::string &name, const std::vector<std::string> &choices) override {
+        if (choices.empty()) throw std::invalid_argument("no choices for " + name);
+        return choices[(size_t)rng_.Intn((int)choices.size())];
+    }
+    double SuggestLogFloat(const std::string &name, double low, double high) override {
+        if (!(low > 0) || high < low) throw std::invalid_argument("bad log range for " + name);
+        const double v = std::exp(std::log(low) + rng_.Float64() * (std::log(high) - std::log(low)));
+        return record(name, std::min(std::max(v, low), high));
+    }
+    double SuggestDiscreteFloat(const std::string &name, double low, double high, double q) override {
+        if (!(q > 0) || high < low) throw std::invalid_argument("bad grid for " + name);
+        const int steps = (int)std::floor((high - low) / q + 1e-9) + 1;
+        return record(name, low + q * (double)rng_.Intn(steps));
+    }
+    std::map<std::string, double> Values;  // what this trial drew, by parameter name
+
+   private:
+    double record(const std::string &name, double v) {
+        Values[name] = v;
+        return v;
+    }
+    util::RandomGenerator &rng_;
+};
+
+// goptuna.CreateStudy(direction = maximize) + study.Optimize(objective, nTrials) with independent random trials
+class Study {
+   public:
+    explicit Study(int64_t seed = 0) : rng_(seed) {}
+    void Optimize(const std::function<double(Trial &)> &objective, int nTrials, const volatile int32_t *cancel = nullptr) {
+        for (int t = 0; t < nTrials; t++) {
+            if (cancel && *cancel) throw std::runtime_error("context canceled");  // study.WithContext(ctx)
+            RandomTrial trial(rng_);
+            const double v = objective(trial);
+            if (values_.empty() || v > best_) best_ = v;
+            values_.push_back(v);
+        }
+    }
+    double GetBestValue() const {
+        if (values_.empty()) throw std::runtime_error("no trials");
+        return best_;
+    }
+    const std::vector<double> &Values() const { return values_; }
+
+   private:
+    util::RandomGenerator rng_;
+    std::vector<double> values_;
+    double best_ = 0;
 };
 
 void MarshalModel(std::ostream &w, const MatrixFactorization &m);               // model.go:320-328

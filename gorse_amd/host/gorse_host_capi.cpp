@@ -189,6 +189,87 @@ float gh_metric(int32_t id, const int32_t *target, int32_t nt, const int32_t *ra
     return table[id](cf::TargetSet(target, target + nt), std::vector<int32_t>(rank, rank + nr));
 }
 
+// ---- ModelSearch (optimize.go) ---------------------------------------------------------------------------------------
+namespace {
+// optimize_test.go:29-99: a model whose Fit returns NDCG = NFactors + InitMean + InitStdDev over a 4 x 4 x 1 grid
+struct MockForSearch : cf::MatrixFactorization {
+    const char *Name() const override { return "mock"; }
+    cf::Score Fit(dataset::Dataset &, dataset::Dataset &, const cf::FitConfig &) override {
+        cf::Score s;
+        s.NDCG = Params.GetFloat32(model::NFactors, 0) + Params.GetFloat32(model::InitMean, 0) + Params.GetFloat32(model::InitStdDev, 0);
+        return s;
+    }
+    model::Params SuggestParams(cf::Trial &trial) override {
+        model::Params p;
+        p[model::NFactors] = trial.SuggestDiscreteFloat(model::NFactors, 1, 4, 1);
+        p[model::InitMean] = trial.SuggestDiscreteFloat(model::InitMean, 1, 4, 1);
+        p[model::InitStdDev] = trial.SuggestDiscreteFloat(model::InitStdDev, 4, 4, 1);
+        return p;
+    }
+};
+void report(const cf::SearchResult &r, char *type_out, int64_t type_cap, char *params_out, int64_t params_cap, float *score3) {
+    if (type_out && type_cap > (int64_t)r.Type.size()) std::memcpy(type_out, r.Type.c_str(), r.Type.size() + 1);
+    std::string text;
+    for (auto &kv : r.Params) {
+        char num[64];
+        snprintf(num, sizeof(num), "%.17g", kv.second);
+        text += kv.first + "=" + num + "\n";
+    }
+    if (params_out && params_cap > (int64_t)text.size()) std::memcpy(params_out, text.c_str(), text.size() + 1);
+    score3[0] = r.Score_.NDCG, score3[1] = r.Score_.Precision, score3[2] = r.Score_.Recall;
+}
+}  // namespace
+// TestTPE's search (optimize_test.go:101-126) with the random study; best_value = study.GetBestValue()
+int32_t gh_search_mock(int32_t n_trials, int64_t seed, double *best_value, char *type_out, int64_t type_cap, char *params_out,
+                       int64_t params_cap, float *score3) {
+    return guard([&] {
+        cf::ModelSearch search({{"mock", [] { return std::unique_ptr<cf::MatrixFactorization>(new MockForSearch()); }}}, nullptr,
+                               nullptr, cf::FitConfig(), false);
+        cf::Study study(seed);
+        study.Optimize([&](cf::Trial &t) { return search.Objective(t); }, n_trials);
+        *best_value = study.GetBestValue();
+        report(search.Result(), type_out, type_cap, params_out, params_cap, score3);
+    });
+}
+// optimizeCollaborativeFiltering (master/tasks.go:1268-1316): BPR and ALS with their default parameters (+ the overrides
+// given, e.g. NEpochs), FitConfig{Jobs, Patience}, n_trials trials; counters = {dataset uploads, resident reuses, trials run}
+int32_t gh_model_search(void *train, void *val, int32_t n_trials, int64_t seed, int32_t jobs, int32_t patience,
+                        const char **names, const double *vals, int32_t n_over, int32_t keep_resident, const volatile int32_t *cancel,
+                        char *type_out, int64_t type_cap, char *params_out, int64_t params_cap, float *score3, int32_t *counters) {
+    return guard([&] {
+        // the overrides are re-applied after SuggestParams (which replaces the whole parameter set, optimize.go:69)
+        const model::Params over = make_params(names, vals, n_over);
+        struct BPRo : cf::BPR {
+            model::Params over;
+            model::Params SuggestParams(cf::Trial &t) override {
+                model::Params p = cf::BPR::SuggestParams(t);
+                for (auto &kv : over) p[kv.first] = kv.second;
+                return p;
+            }
+        };
+        struct ALSo : cf::ALS {
+            model::Params over;
+            model::Params SuggestParams(cf::Trial &t) override {
+                model::Params p = cf::ALS::SuggestParams(t);
+                for (auto &kv : over) p[kv.first] = kv.second;
+                return p;
+            }
+        };
+        cf::FitConfig c;
+        c.SetJobs(jobs).SetPatience(patience);
+        c.Cancel = cancel;
+        cf::ModelSearch search({{"BPR", [&] { auto m = new BPRo(); m->over = over; return std::unique_ptr<cf::MatrixFactorization>(m); }},
+                                {"ALS", [&] { auto m = new ALSo(); m->over = over; return std::unique_ptr<cf::MatrixFactorization>(m); }}},
+                               (dataset::Dataset *)train, (dataset::Dataset *)val, c, keep_resident != 0);
+        int trials = 0;
+        search.OnTrial = [&] { trials++; };
+        cf::Study study(seed);
+        study.Optimize([&](cf::Trial &t) { return search.Objective(t); }, n_trials, cancel);
+        report(search.Result(), type_out, type_cap, params_out, params_cap, score3);
+        if (counters) counters[0] = search.Resident().uploads, counters[1] = search.Resident().reuses, counters[2] = trials;
+    });
+}
+
 // ---- gob (test hooks of gob.hpp) and the MatrixFactorizationUsers blob --------------------------------------------------
 static int64_t copy_out(const std::string &s, char *buf, int64_t cap) {
     if (buf && cap >= (int64_t)s.size()) memcpy(buf, s.data(), s.size());

@@ -188,3 +188,17 @@ def test_matrix_factorization_users_blob():
     assert H.gh_mfusers_unmarshal(w, blob[:-2], len(blob) - 2) != 0
     H.gh_mfusers_free(u)
     H.gh_mfusers_free(w)
+
+
+def test_model_search_on_the_mock_of_the_reference():
+    """optimize_test.go:101-126 (TestTPE): the mock's best trial is NFactors = InitMean = InitStdDev = 4 (NDCG 12).  The
+    reference finds it in 10 trials with goptuna's seeded TPE sampler (third-party, not restated); the random study here
+    needs more draws over the 4 x 4 grid, everything else -- Objective, Result, the maximize direction -- is the same"""
+    best, result = cf.search_mock(200, seed=1)
+    assert best == 12.0
+    assert result["Type"] == "mock" and result["Params"] == {"NFactors": 4.0, "InitMean": 4.0, "InitStdDev": 4.0}
+    assert (result["Score"].NDCG, result["Score"].Precision, result["Score"].Recall) == (12.0, 0.0, 0.0)
+    best1, r1 = cf.search_mock(1, seed=5)
+    assert best1 == r1["Score"].NDCG and 6.0 <= best1 <= 12.0
+    a, b = cf.search_mock(30, seed=9), cf.search_mock(30, seed=9)  # seeded: repeatable
+    assert a[0] == b[0] and a[1]["Params"] == b[1]["Params"]
