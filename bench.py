@@ -260,15 +260,17 @@ def bench_sparse(args, world, rank, local, fence):
     ptr, idx, val = synth.idf_vectors(data.iptr, data.iidx, data.U)
     N = ptr.size - 1
     sp = capi.Sparse(ptr, idx, val, device=local)
-    q0, q1 = rank * N // world, (rank + 1) * N // world
+    q0, q1 = gdist.shard_range(N, rank, world)
+    eng = gdist.HipNeighborsEngine(sp, fetch=False)
+    comm = gdist.TorchComm() if world > 1 else None
     sp.all_pairs(k, q0, min(q1, q0 + 4096), fetch=False)  # warm-up: scratch allocation, code objects
     for _ in range(max(args.warmup - 1, 0)):
-        sp.all_pairs(k, q0, q1, fetch=False)
+        gdist.refresh_neighbors_sharded(eng, comm, k, gather=False)
     fence()
     sp.set_profiling(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sp.all_pairs(k, q0, q1, fetch=False)
+    for _ in range(args.steps):  # gorse_amd.dist.refresh_neighbors_sharded is the function the gloo CPU tests exercise
+        gdist.refresh_neighbors_sharded(eng, comm, k, gather=False)
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")

@@ -79,6 +79,52 @@ def evaluate_sharded(engine, comm, topk, metrics=("ndcg", "precision", "recall")
     return (t[:-1] * np.float32(1.0) / t[-1]).astype(np.float32) if t[-1] > 0 else np.full(len(metrics), np.nan, np.float32)
 
 
+def refresh_neighbors_sharded(engine, comm, k, gather=True):
+    """The item-to-item / user-to-user refresh over row shards ("all-pairs top-k": query rows split, the
+    index replicated, no exchange inside the search): rank r answers the stored rows of its shard_range against the whole
+    index.  With `gather` the (row ids, scores, counts) blocks are all-gathered so that every rank -- the one that writes
+    the neighbour lists in particular -- holds all n_rows results; three collectives of block_rows * k (* 4 bytes) each.
+    engine.n_rows, engine.neighbors(lo, hi, k) -> (idx int32 (hi-lo) x k, score float32, cnt int32)."""
+    world = comm.world if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    lo, hi = shard_range(engine.n_rows, rank, world)
+    idx, score, cnt = engine.neighbors(lo, hi, k)
+    if world == 1 or not gather:
+        return idx, score, cnt
+    import torch
+    b = block_rows(engine.n_rows, world)
+    dev = getattr(engine, "device", "cpu")
+
+    def padded(a, fill, width):
+        out = np.full((b, width), fill, a.dtype)
+        out[:hi - lo] = a.reshape(hi - lo, width)
+        return torch.from_numpy(out.ravel()).to(dev)
+    g_idx = comm.all_gather(padded(idx, -1, k)).cpu().numpy().reshape(world, b, k)
+    g_score = comm.all_gather(padded(score, -np.inf, k)).cpu().numpy().reshape(world, b, k)
+    g_cnt = comm.all_gather(padded(cnt, 0, 1)).cpu().numpy().reshape(world, b)
+    spans = [shard_range(engine.n_rows, r, world) for r in range(world)]
+    return (np.concatenate([g_idx[r, :h - l] for r, (l, h) in enumerate(spans)]),
+            np.concatenate([g_score[r, :h - l] for r, (l, h) in enumerate(spans)]),
+            np.concatenate([g_cnt[r, :h - l] for r, (l, h) in enumerate(spans)]))
+
+
+class HipNeighborsEngine:
+    """A gorse_sparse (capi.Sparse) or gorse_topk (capi.TopK) handle as the engine of refresh_neighbors_sharded."""
+
+    def __init__(self, index, device="cuda", fetch=True):
+        self.index, self.device, self.n_rows, self.fetch = index, device, index.N, fetch
+
+    def neighbors(self, lo, hi, k):
+        if not self.fetch:  # results stay in HBM (bench.py's timed region); nothing to gather
+            self.index.all_pairs(k, lo, hi, fetch=False)
+            return None, None, None
+        res = self.index.all_pairs(k, lo, hi)
+        if len(res) == 3:  # Sparse: (idx, score, cnt)
+            return res
+        idx, dist = res    # TopK: distances ascending, padded with -1 / +inf
+        return idx, dist, (idx >= 0).sum(axis=1).astype(np.int32)
+
+
 class TorchComm:
     """torch.distributed plumbing (backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' in the CPU tests)."""
 

@@ -346,3 +346,54 @@ def test_hip_engines_over_gloo_with_a_stand_in_handle(tmp_path):
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("bP%d.npy" % r)), engines[r][0].P)
         assert np.array_equal(np.load(tmp_path / ("bQ%d.npy" % r)), engines[r][0].Q)
+
+
+# ---- the neighbour refresh (sparse item-to-item / user-to-user, dense top-k) over row shards --------------------------------
+class StandInSparse:
+    """capi.Sparse's all_pairs with the oracle as the compute (tests only)"""
+
+    def __init__(self, ptr, idx, val):
+        from oracle import oracle as orc
+        self.o, self.ptr, self.idx, self.val, self.N = orc.Oracle(), ptr, idx, val, ptr.size - 1
+
+    def all_pairs(self, k, q_begin=0, q_end=None):
+        q_end = self.N if q_end is None else q_end
+        n = q_end - q_begin
+        I, S, Cn = np.full((n, k), -1, np.int32), np.full((n, k), -np.inf, np.float32), np.zeros(n, np.int32)
+        for t, q in enumerate(range(q_begin, q_end)):
+            ei, es = self.o.sparse_search(self.ptr, self.idx, self.val, self.idx[self.ptr[q]:self.ptr[q + 1]],
+                                          self.val[self.ptr[q]:self.ptr[q + 1]], k, exclude=q)
+            I[t, :ei.size], S[t, :ei.size], Cn[t] = ei, es, ei.size
+        return I, S, Cn
+
+
+def _i2i_problem():
+    data = synth.synth_cf(400, 53, 500, seed=21, min_len=1, with_test=False)  # 53 items: shards of unequal size
+    return synth.idf_vectors(data.iptr, data.iidx, data.U)
+
+
+def _refresh_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ptr, idx, val = _i2i_problem()
+    eng = gdist.HipNeighborsEngine(StandInSparse(ptr, idx, val), device="cpu")
+    I, S, Cn = gdist.refresh_neighbors_sharded(eng, gdist.TorchComm(), 12)
+    np.savez(os.path.join(out, "nb%d.npz" % rank), I=I, S=S, Cn=Cn)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_neighbor_refresh_equals_the_single_process_result(tmp_path, world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_refresh_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ptr, idx, val = _i2i_problem()
+    I, S, Cn = StandInSparse(ptr, idx, val).all_pairs(12)
+    assert Cn.max() == 12 and Cn.min() < 12  # full and padded rows both occur
+    for r in range(world):
+        got = np.load(tmp_path / ("nb%d.npz" % r))
+        assert np.array_equal(got["I"], I) and np.array_equal(got["S"].view(np.uint32), S.view(np.uint32))
+        assert np.array_equal(got["Cn"], Cn)
