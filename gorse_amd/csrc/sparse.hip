@@ -26,8 +26,7 @@ struct gorse_sparse {
     bool has_mask = false;
     int64_t n_admissible = 0;  // rows with mask != 0 (N without a mask)
     // per-workgroup scratch (slots x N each); stamps are never reused for a slot until the wrap-around clear
-    DevBuf<float> acc;
-    DevBuf<uint32_t> stamp;
+    DevBuf<sparse::Cell> cell;
     DevBuf<int32_t> touched;
     int64_t slots = 0;
     uint32_t serial = 0;
@@ -55,10 +54,9 @@ int64_t slot_cap(int64_t N) { return std::max<int64_t>(1, std::min<int64_t>(kMax
 
 int32_t ensure_scratch(gorse_sparse *h, int64_t want) {
     if (want <= h->slots) return GORSE_OK;
-    GORSE_TRY(h->acc.alloc((size_t)want * h->N));
-    GORSE_TRY(h->stamp.alloc((size_t)want * h->N));
+    GORSE_TRY(h->cell.alloc((size_t)want * h->N));
     GORSE_TRY(h->touched.alloc((size_t)want * h->N));
-    GORSE_HIP_CHECK(hipMemsetAsync(h->stamp.p, 0, (size_t)want * h->N * sizeof(uint32_t), h->stream));
+    GORSE_HIP_CHECK(hipMemsetAsync(h->cell.p, 0, (size_t)want * h->N * sizeof(sparse::Cell), h->stream));
     h->slots = want;
     h->serial = 0;
     return GORSE_OK;
@@ -84,7 +82,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
     GORSE_TRY(h->stat.ensure(2));
     const int64_t per_slot = ceil_div(nq, grid);  // queries (= stamps) one workgroup consumes in this launch
     if ((uint64_t)h->serial + (uint64_t)per_slot >= 0xFFFFFFFFull) {
-        GORSE_HIP_CHECK(hipMemsetAsync(h->stamp.p, 0, (size_t)h->slots * h->N * sizeof(uint32_t), h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->cell.p, 0, (size_t)h->slots * h->N * sizeof(sparse::Cell), h->stream));
         h->serial = 0;
     }
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
@@ -95,7 +93,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
     a.mask = h->has_mask ? h->mask.p : nullptr;
     a.n_admissible = h->has_mask ? h->n_admissible : h->N;
     a.N = h->N;
-    a.acc = h->acc.p, a.stamp = h->stamp.p, a.touched = h->touched.p;
+    a.cell = h->cell.p, a.touched = h->touched.p;
     a.serial_base = h->serial;
     a.k = k;
     a.out_idx = h->out_idx.p, a.out_score = h->out_score.p, a.out_cnt = h->out_cnt.p;

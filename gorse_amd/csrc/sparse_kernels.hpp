@@ -5,10 +5,10 @@
 // One workgroup answers one query at a time.  The stored rows are held as POSTINGS (one list of (row, value) per
 // index); the query's indices are walked in ascending order and, for each, the workgroup's lanes stream that posting
 // list (coalesced 4-byte rows + 4-byte values = the 8 algorithmic bytes per multiply-add) and update a per-workgroup
-// accumulator `acc[row]`.  A row occurs at most once per posting list, so inside one list no two lanes touch the same
+// accumulator (the high word of `cell[row]`).  A row occurs at most once per posting list, so inside one list no two lanes touch the same
 // accumulator, and the barrier between lists makes every row's sum run in ascending index order: the float32 result
 // is the merge-order sparse dot of the oracle bit for bit, with no atomics on data.  Rows reached for the first time
-// (stamp[row] != serial of this query) are appended to a `touched` list; only those are ranked, so nothing of size N
+// (the low word of cell[row] != serial of this query) are appended to a `touched` list; only those are ranked, so nothing of size N
 // is cleared or scanned per query.
 //
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
@@ -29,6 +29,14 @@ namespace sparse {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: the per-list barrier costs a wave-local s_barrier
 
+// One scratch cell per (workgroup, stored row): low word = serial of the last query that reached the row, high word = the
+// bits of its running inner product.  Kept as ONE 64-bit integer so that a posting costs one 8-byte load and one 8-byte
+// store (as a two-field struct the compiler loads the stamp, branches, and loads the sum in a second round trip).
+using Cell = unsigned long long;
+__device__ inline uint32_t cell_stamp(Cell c) { return (uint32_t)c; }
+__device__ inline float cell_acc(Cell c) { return __uint_as_float((uint32_t)(c >> 32)); }
+__device__ inline Cell make_cell(uint32_t stamp, float acc) { return ((Cell)__float_as_uint(acc) << 32) | (Cell)stamp; }
+
 struct QueryArgs {
     // postings of the N stored rows: list of index t = p_row / p_val [p_ptr[t], p_ptr[t+1]), D lists
     const int64_t *p_ptr;
@@ -45,9 +53,9 @@ struct QueryArgs {
     const uint8_t *mask;     // admissible[row] or null
     int64_t n_admissible;    // number of admissible rows (N without a mask)
     int64_t N;
-    // scratch, N entries per workgroup each
-    float *acc;
-    uint32_t *stamp;
+    // scratch, N entries per workgroup each: (stamp, accumulator) pairs -- one 8-byte access per posting -- and the list
+    // of rows the current query has reached
+    Cell *cell;
     int32_t *touched;
     uint32_t serial_base;  // stamps of this launch are serial_base + 1 ..; never reused for a scratch slot
     int k;
@@ -113,8 +121,7 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
     __shared__ int s_bcnt;                // slots handed out in s_buf
     __shared__ int s_pos, s_neg;          // admissible rows of the current query scoring above / below zero
     const int tid = threadIdx.x, nt = blockDim.x;
-    float *acc = a.acc + (int64_t)blockIdx.x * a.N;
-    uint32_t *stamp = a.stamp + (int64_t)blockIdx.x * a.N;
+    Cell *cell = a.cell + (int64_t)blockIdx.x * a.N;
     int32_t *touched = a.touched + (int64_t)blockIdx.x * a.N;
     uint32_t serial = a.serial_base;
     for (int64_t t = blockIdx.x; t < a.nq; t += gridDim.x) {
@@ -141,13 +148,10 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
             for (int64_t p = ps + tid; p < pe; p += nt) {
                 const int32_t row = a.p_row[p];
                 const float term = __fmul_rn(qv, a.p_val[p]);
-                if (stamp[row] != serial) {
-                    stamp[row] = serial;
-                    acc[row] = __fadd_rn(0.0f, term);
-                    touched[atomicAdd(&s_cnt, 1)] = row;
-                } else {
-                    acc[row] = __fadd_rn(acc[row], term);
-                }
+                const Cell c = cell[row];
+                const bool first = cell_stamp(c) != serial;
+                cell[row] = make_cell(serial, __fadd_rn(first ? 0.0f : cell_acc(c), term));
+                if (first) touched[atomicAdd(&s_cnt, 1)] = row;
             }
             __syncthreads();
         }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
             if (i < T) {
                 const int32_t row = touched[i];
                 if ((int64_t)row != ex && (!a.mask || a.mask[row])) {
-                    const uint32_t ord = score_ord(acc[row]);
+                    const uint32_t ord = score_ord(cell_acc(cell[row]));
                     if (ord != kZeroOrd) {  // a zero score is dropped by the reference's wrapper
                         key = make_key(ord, row);
                         my_pos += ord > kZeroOrd;

@@ -24,8 +24,7 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
     if (!build_postings(N, indptr, indices, values, post).empty()) return -1;
     const int kp = pick_kp(k);
     if (!kp || grid < 1 || block < 1) return -1;
-    std::vector<float> acc((size_t)grid * N);
-    std::vector<uint32_t> stamp((size_t)grid * N, 0);
+    std::vector<Cell> cell((size_t)grid * N, 0);
     std::vector<int32_t> touched((size_t)grid * N);
     QueryArgs a;
     a.p_ptr = post.ptr.data(), a.p_row = post.row.data(), a.p_val = post.val.data(), a.D = post.D;
@@ -37,7 +36,7 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
         a.n_admissible = 0;
         for (int64_t r = 0; r < N; r++) a.n_admissible += mask[r] != 0;
     }
-    a.acc = acc.data(), a.stamp = stamp.data(), a.touched = touched.data();
+    a.cell = cell.data(), a.touched = touched.data();
     a.k = k, a.out_idx = out_idx, a.out_score = out_score, a.out_cnt = out_cnt, a.stat = stat2;
     const uint32_t per_launch = (uint32_t)((nq + grid - 1) / grid);
     for (int r = 0; r < rounds; r++) {
