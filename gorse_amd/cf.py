@@ -36,7 +36,7 @@ def host():
 
 class HostError(RuntimeError):
     def __init__(self, code):
-        super().__init__("host error %d: %s" % (code, host().gh_last_error().decode()))
+        super().__init__("host error %d: %s" % (code, host().gh_last_error().decode("utf-8", "replace")))
         self.code = code
 
 

@@ -43,11 +43,21 @@ uint64_t get_varint(std::istream &r) {
     for (;;) {
         int c = r.get();
         if (c < 0) throw std::runtime_error("unexpected EOF");
+        if (shift > 63) throw std::runtime_error("varint too long");
         v |= (uint64_t)(c & 0x7f) << shift;
         if (!(c & 0x80)) break;
         shift += 7;
     }
     return v;
+}
+// bytes left in a seekable stream (a length field of a corrupt file must not size an allocation); "unknown" = huge
+uint64_t remaining(std::istream &r) {
+    const auto at = r.tellg();
+    if (at < 0) return UINT64_MAX;
+    r.seekg(0, std::ios::end);
+    const auto end = r.tellg();
+    r.seekg(at);
+    return end < at ? 0 : (uint64_t)(end - at);
 }
 size_t varint_len(uint64_t v) {
     size_t n = 1;
@@ -75,6 +85,7 @@ void write_latent(std::ostream &w, const std::string &id, const float *data, int
 }
 void read_latent(std::istream &r, std::string &id, std::vector<float> &data) {
     uint64_t body = get_varint(r);
+    if (body > remaining(r)) throw std::runtime_error("unexpected EOF");
     std::string buf((size_t)body, '\0');
     r.read(&buf[0], (std::streamsize)body);
     if ((uint64_t)r.gcount() != body) throw std::runtime_error("unexpected EOF");
@@ -85,10 +96,12 @@ void read_latent(std::istream &r, std::string &id, std::vector<float> &data) {
         uint64_t tag = get_varint(s);
         if (tag == 0x0A) {
             uint64_t n = get_varint(s);
+            if (n > remaining(s)) throw std::runtime_error("unexpected EOF");
             id.resize((size_t)n);
             s.read(&id[0], (std::streamsize)n);
         } else if (tag == 0x12) {
             uint64_t n = get_varint(s);
+            if (n > remaining(s) || n % 4) throw std::runtime_error("bad packed float field");
             data.resize((size_t)n / 4);
             s.read((char *)data.data(), (std::streamsize)n);
         } else if (tag == 0x15) {  // unpacked float
@@ -309,7 +322,7 @@ void MatrixFactorization::Unmarshal(std::istream &r) {
     release();
     model::Params p;  // encoding.ReadGob(r, &baseModel.Params) (model.go:251)
     const int32_t nbytes = get_le<int32_t>(r);
-    if (nbytes < 0) throw std::runtime_error("negative gob length");
+    if (nbytes < 0 || (uint64_t)nbytes > remaining(r)) throw std::runtime_error("bad gob length");
     std::string params((size_t)nbytes, '\0');
     r.read(&params[0], nbytes);
     if (r.gcount() != (std::streamsize)nbytes) throw std::runtime_error("unexpected EOF");
@@ -318,6 +331,9 @@ void MatrixFactorization::Unmarshal(std::istream &r) {
     SetParams(p);
     auto read_side = [&](std::shared_ptr<dataset::FreqDict> &dict, std::vector<bool> &pred, std::vector<float> &fac) {
         int64_t cnt = get_le<int64_t>(r);
+        // a record holds its factors (4 bytes each): a count the rest of the file cannot hold is corrupt
+        if (cnt < 0 || (uint64_t)cnt > remaining(r) || nFactors_ <= 0 || (uint64_t)cnt * (uint64_t)nFactors_ > remaining(r))
+            throw std::runtime_error("latent factor count does not fit the file");
         dict = std::make_shared<dataset::FreqDict>();
         pred.assign((size_t)cnt, false);
         fac.assign((size_t)cnt * (size_t)nFactors_, 0.0f);
@@ -344,6 +360,7 @@ void MarshalModel(std::ostream &w, const MatrixFactorization &m) {
 
 std::unique_ptr<MatrixFactorization> UnmarshalModel(std::istream &r) {
     int32_t len = get_le<int32_t>(r);
+    if (len < 0 || (uint64_t)len > remaining(r)) throw std::runtime_error("bad model name length");
     std::string name((size_t)len, '\0');
     r.read(&name[0], len);
     std::unique_ptr<MatrixFactorization> m;

@@ -202,3 +202,31 @@ def test_model_search_on_the_mock_of_the_reference():
     assert best1 == r1["Score"].NDCG and 6.0 <= best1 <= 12.0
     a, b = cf.search_mock(30, seed=9), cf.search_mock(30, seed=9)  # seeded: repeatable
     assert a[0] == b[0] and a[1]["Params"] == b[1]["Params"]
+
+
+def test_corrupt_model_files_are_rejected_not_crashed_on():
+    """Unmarshal reads files other programs wrote: every truncation and a few thousand byte flips of a valid file must end
+    in an error or in a (different) model, never in a crash, a hang or an allocation by a corrupt length"""
+    rng = np.random.default_rng(17)
+    m = cf.BPR({"NFactors": 4, "NEpochs": 3, "Lr": 0.05, "RandomState": 7})
+    m.load_factors(rng.standard_normal((3, 4)).astype(np.float32), rng.standard_normal((2, 4)).astype(np.float32))
+    blob = cf.MarshalModel(m)
+    H = cf.host()
+    H.gh_gob_decode_params.restype = C.c_int64
+    H.gh_gob_decode_params.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+
+    def try_load(data):
+        try:
+            cf.UnmarshalModel(data)
+        except cf.HostError:
+            pass
+    for cut in range(len(blob)):
+        try_load(blob[:cut])
+    glen = int.from_bytes(blob[7:11], "little")
+    for _ in range(3000):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        try_load(bytes(b))
+        g = bytes(b[11:11 + glen])
+        H.gh_gob_decode_params(g, len(g), None, 0)
