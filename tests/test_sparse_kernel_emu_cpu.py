@@ -203,3 +203,24 @@ def test_database_suite_on_the_emulated_kernel(emu, case):
         return emu.emu_sparse_search(n, p(indptr), p(indices), p(values), nq, p(q_indptr), p(q_indices), p(q_values), 0, None, 0,
                                      p(admissible), k, 2, 8, 1, 0, p(idx), p(score), p(cnt), None)
     case(V.Database(sparse_searcher=sparse_searcher))
+
+
+def test_random_database_operations_on_the_emulated_kernel(emu, oracle):
+    """tests/test_vectors_db_cpu.py's random-operations test with the emulated kernel behind the sparse collection (the dense
+    one keeps the oracle-backed searcher)"""
+    import test_vectors_db_cpu as T
+    from gorse_amd import vectors as V
+
+    def dense_searcher(X, n, d, metric, Q, nq, k, idx, dist, cnt):
+        Xa, Qa = np.ctypeslib.as_array(X, (n, d)).copy(), np.ctypeslib.as_array(Q, (nq, d)).copy()
+        I, D, Cn = np.ctypeslib.as_array(idx, (nq, k)), np.ctypeslib.as_array(dist, (nq, k)), np.ctypeslib.as_array(cnt, (nq,))
+        for t in range(nq):
+            ei, ed = oracle.search_vector(Xa, metric, Qa[t], k)
+            I[t, :ei.size], D[t, :ei.size], Cn[t] = ei, ed, ei.size
+        return 0
+
+    def sparse_searcher(n, indptr, indices, values, admissible, nq, q_indptr, q_indices, q_values, k, idx, score, cnt):
+        p = lambda x: C.cast(x, C.c_void_p)
+        return emu.emu_sparse_search(n, p(indptr), p(indices), p(values), nq, p(q_indptr), p(q_indices), p(q_values), 0, None, 0,
+                                     p(admissible), k, 2, 8, 1, 0, p(idx), p(score), p(cnt), None)
+    T.test_random_operations_against_a_model_of_the_reference(V.Database(searcher=dense_searcher, sparse_searcher=sparse_searcher))

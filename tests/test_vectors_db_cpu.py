@@ -58,3 +58,73 @@ def test_exact_filtered_topk(db, oracle, distance, name, metric):
 def test_unknown_prefix():
     with pytest.raises(RuntimeError):
         V.Open("nosuch://")
+
+
+def test_random_operations_against_a_model_of_the_reference(db):
+    """A few hundred random AddVectors (inserts and upserts) / DeleteVectors / QueryVectors / QuerySparseBatch on one dense
+    and one sparse collection, next to a plain-Python model of xvec.go's semantics: upsert by Id, millisecond cut-off,
+    hidden / CONTAIN_ALL filters, Dot scores, the zero-score rule of sparse queries.  Scores are small integers, so
+    every inner product is exact whatever the summation order."""
+    rng = np.random.default_rng(2026)
+    d, dims = 6, 14
+    db.AddCollection("dense", d, V.Dot)
+    db.AddCollection("sparse", 0, V.Dot)
+    model = {"dense": {}, "sparse": {}}  # id -> Vector, insertion-ordered like the collection's rows
+    cats_pool = ["a", "b", "c"]
+
+    def rand_vec(kind, vid, ts):
+        cats = [c for c in cats_pool if rng.random() < 0.5]
+        hidden = bool(rng.random() < 0.2)
+        if kind == "dense":
+            return V.Vector(vid, rng.integers(-3, 4, d).astype(np.float32), IsHidden=hidden, Categories=cats, Timestamp=ts)
+        n = int(rng.integers(1, 6))
+        idx = rng.choice(dims, n, replace=False)  # any order
+        return V.Vector(vid, rng.integers(-2, 4, n).astype(np.float32), Indices=idx, IsHidden=hidden, Categories=cats, Timestamp=ts)
+
+    def score(kind, q, v):
+        if kind == "dense":
+            return float(np.dot(np.float64(q.Values), np.float64(v.Values)))
+        qd = dict(zip(q.Indices, q.Values))
+        return float(sum(qd[i] * x for i, x in zip(v.Indices, v.Values) if i in qd))
+
+    def expect(kind, q, cats, topk):
+        rows = [v for v in model[kind].values() if not v.IsHidden and all(c in v.Categories for c in cats)]
+        scored = sorted(((score(kind, q, v), t, v.Id) for t, v in enumerate(rows)), key=lambda x: (-x[0], x[1]))[:topk]
+        if kind == "sparse":
+            scored = [s for s in scored if s[0] != 0]  # xvec.go:419-421, after the cut
+        return scored
+
+    ts = 1_790_000_000_000
+    for step in range(260):
+        kind = "dense" if rng.random() < 0.5 else "sparse"
+        op = rng.random()
+        if op < 0.45:
+            batch = [rand_vec(kind, "v%d" % int(rng.integers(0, 60)), ts + int(rng.integers(0, 50))) for _ in range(int(rng.integers(1, 5)))]
+            db.AddVectors(kind, batch)
+            for v in batch:  # a later entry of the same batch replaces an earlier one, like successive upserts
+                model[kind][v.Id] = v
+        elif op < 0.55:
+            cut = ts + int(rng.integers(0, 50))
+            db.DeleteVectors(kind, cut)
+            model[kind] = {k: v for k, v in model[kind].items() if not v.Timestamp < cut}
+        else:
+            q = rand_vec(kind, "", 0)
+            cats = [c for c in cats_pool if rng.random() < 0.25]
+            topk = int(rng.integers(1, 12))
+            got = db.QueryVectors(kind, q, cats, topk)
+            want = expect(kind, q, cats, topk)
+            # equal scores may come in either order (unpinned in the reference): compare scores, and ids as sets per score
+            assert [g.Score for g in got] == [w[0] for w in want], (step, kind)
+            for sc in set(w[0] for w in want):
+                ids_g = {g.Id for g in got if g.Score == sc}
+                ids_w = {w[2] for w in want if w[0] == sc}
+                full = [v.Id for v in model[kind].values() if not v.IsHidden and all(c in v.Categories for c in cats)
+                        and score(kind, q, v) == sc]
+                assert ids_g == ids_w or (ids_g <= set(full) and len(ids_g) == len(ids_w)), (step, kind, sc)
+            if kind == "sparse" and rng.random() < 0.3:
+                bulk = db.QuerySparseBatch(kind, [q, q], cats, topk)
+                assert [[(g.Id, g.Score) for g in r] for r in bulk] == [[(g.Id, g.Score) for g in got]] * 2
+        assert db.CountVectors(kind) == len(model[kind])
+    for kind in model:
+        got = db.GetVectors(kind, list(model[kind]))
+        assert got == list(model[kind].values())
