@@ -160,7 +160,11 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
 // PROF (probe only): s_memtime stamps around the phases of the tile loop, summed over the waves into p.prof:
 // [0] tile store + prefetch issue, [1] MFMA + epilogues (slow paths included), [2] slow paths alone, [3] barrier wait,
 // [4] row blocks examined, [5] row blocks that took the slow path, [6] whole kernel, [7] waves
-template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool PROF = false>
+// VOTE (probe only, variant bit 7, never run on a device yet): in the candidate path every one of the 16 score rows is first
+// voted on by the whole wave and skipped when no lane holds a candidate in it (a block that takes the path has one or
+// two candidates among its 1024 scores), instead of running the 16 predicated compare + append bodies.  The appends
+// that do happen are the same, in the same per-lane order, so the lists -- and every result -- are unchanged.
+template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool PROF = false, bool VOTE = false>
 __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kernel(SweepParams p) {
     constexpr int kWaves = sweep_waves(HIST, KP);
     constexpr int kThreads = kWaves * 64;
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                     uint2 *mine = qb + (lane >> 5);
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
+                        if (VOTE && __builtin_amdgcn_ballot_w64(acc[cb][r] >= f) == 0) continue;  // wave-uniform
                         if (acc[cb][r] >= f) {
                             const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
                             mine[2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
@@ -992,6 +997,17 @@ int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {
     return GORSE_OK;
 }
 
+template <int RB>
+int32_t launch_sweep_vote(gorse_topk *h, const SweepParams &p) {  // the C4 shape with the per-row wave vote (probe only)
+    constexpr int BQ = 32 * 2 * kWaves, ROWB = 8 * 32 + 16, TR = 32 * RB;
+    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4;
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, true, false, RB, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    topk_sweep_kernel<8, 2, true, false, RB, false, true><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
 template <int KP, int NCB>
 int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
     // 128-row tiles (one barrier per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
@@ -1000,6 +1016,8 @@ int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist)
     if constexpr (KP == 8 && NCB == 2) {
         if ((g_topk_variant & 16) && scale && !hist && p.prof)  // instrumented twin of the C4 sweep (probe only)
             return wide ? launch_sweep_prof<4>(h, p) : launch_sweep_prof<2>(h, p);
+        if ((g_topk_variant & 128) && scale && !hist)  // per-row wave vote in the candidate path (probe only)
+            return wide ? launch_sweep_vote<4>(h, p) : launch_sweep_vote<2>(h, p);
     }
     if (wide) {
         if constexpr (KP <= 8)

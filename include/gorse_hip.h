@@ -261,7 +261,9 @@ void gorse_hip_test_set_topk_path(int32_t path);
 /* probe switches of the MFMA sweep: bit 0 = 64 candidate rows per LDS tile, bit 1 = 128 (default: what the library
  * ships with), bit 2 / bit 3 = block-level row-scale bound of the cosine sweep off / on (default: on when all norms
  * are within 2 % of each other), bit 4 = the instrumented twin (see below), bit 5 / bit 6 = compact a candidate list
- * when one of its two sub-lists exceeds 128 / 96 entries (default 224).  Results never depend on them. */
+ * when one of its two sub-lists exceeds 128 / 96 entries (default 224), bit 7 = the candidate path of the C4-shaped
+ * sweep votes on each score row wave-wide before touching it (written without a GPU; to be measured).  Results never
+ * depend on them. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
 /* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its twelve
  * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the

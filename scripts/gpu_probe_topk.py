@@ -68,6 +68,9 @@ def main():
             run("C4 256K q: " + label, Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
         capi.lib().gorse_hip_test_set_topk_variant(1 | 8 | 32)
         run("C4 1M q: 64 rows, compact at 2x128", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
+        capi.lib().gorse_hip_test_set_topk_variant(128)
+        run("C4 256K q: per-row wave vote in the candidate path", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
+        run("C4 1M q: per-row wave vote in the candidate path", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
         capi.lib().gorse_hip_test_set_topk_variant(0)
         run("C4 1M q: library default", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
         return
