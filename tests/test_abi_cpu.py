@@ -45,6 +45,16 @@ def test_no_device_fails_loudly():
     with pytest.raises(capi.GorseHipError) as e:
         capi.sgemm(0, 0, 2, 2, 2, np.zeros(4), 2, np.zeros(4), 2, np.zeros(4), 2)
     assert e.value.code == capi.ERR_NO_DEVICE
+    with pytest.raises(capi.GorseHipError) as e:
+        capi.Sparse(np.array([0, 2], np.int64), np.array([1, 2], np.uint32), np.ones(2, np.float32))
+    assert e.value.code == capi.ERR_NO_DEVICE
+    # the host twins above the ABI have no CPU path either: a sparse query on hip:// ends in the library's error
+    from gorse_amd import vectors as V
+    db = V.Open("hip://")
+    db.AddCollection("s", 0, V.Dot)
+    db.AddVectors("s", [V.Vector("a", [1.0], Indices=[3])])
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        db.QueryVectors("s", V.Vector(Values=[1.0], Indices=[3]), None, 1)
 
 
 def test_argument_validation_without_gpu():
@@ -54,6 +64,9 @@ def test_argument_validation_without_gpu():
     assert e.value.code == capi.ERR_INVALID
     with pytest.raises(capi.GorseHipError) as e:  # item index out of range
         capi.MF(2, 2, 8, np.array([0, 1, 2], np.int64), np.array([0, 7], np.int32))
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.GorseHipError) as e:  # sparse rows must come with strictly ascending indices
+        capi.Sparse(np.array([0, 2], np.int64), np.array([2, 2], np.uint32), np.ones(2, np.float32))
     assert e.value.code == capi.ERR_INVALID
     with pytest.raises(capi.GorseHipError) as e:  # leading dimension too small (floats.MM panics)
         capi.sgemm(0, 0, 2, 2, 2, np.zeros(4), 1, np.zeros(4), 2, np.zeros(4), 2)
