@@ -47,6 +47,8 @@ struct gorse_sparse {
 
 namespace {
 
+int g_sparse_build = 0;  // 0 = postings built on the host (default), 1 = by the device kernels (test hook, see gorse_hip.h)
+
 constexpr int64_t kScratchBudget = (int64_t)16 << 30;  // bytes of accumulator scratch (of 288 GB of HBM)
 constexpr int64_t kMaxSlots = 8192;                    // 256 CUs x 32 single-wave workgroups
 
@@ -138,9 +140,15 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
     if (device < 0 || device >= ndev) return fail(GORSE_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    const bool on_device = g_sparse_build == 1;
     sparse::Postings post;
-    const std::string why = sparse::build_postings(N, indptr, indices, values, post);
-    if (!why.empty()) return fail(GORSE_ERR_INVALID, "%s", why.c_str());
+    if (on_device) {  // only the index space is needed from the host
+        for (int64_t t = base; t < base + nnz; t++) post.D = indices[t] >= post.D ? (int64_t)indices[t] + 1 : post.D;
+        if (post.D > sparse::kMaxDims) return fail(GORSE_ERR_INVALID, "largest index %lld exceeds the supported index space", (long long)(post.D - 1));
+    } else {
+        const std::string why = sparse::build_postings(N, indptr, indices, values, post);
+        if (!why.empty()) return fail(GORSE_ERR_INVALID, "%s", why.c_str());
+    }
     gorse_sparse *h = new (std::nothrow) gorse_sparse();
     if (!h) return fail(GORSE_ERR_NOMEM, "out of host memory");
     h->device = device;
@@ -159,13 +167,32 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         GORSE_TRY(h->p_row.alloc((size_t)nnz));
         GORSE_TRY(h->p_val.alloc((size_t)nnz));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->r_ptr.p, ptr0.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        GORSE_HIP_CHECK(hipMemcpyAsync(h->p_ptr.p, post.ptr.data(), ((size_t)post.D + 1) * 8, hipMemcpyHostToDevice,
-                                       h->stream));
         if (nnz > 0) {
             GORSE_HIP_CHECK(hipMemcpyAsync(h->r_idx.p, indices + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->r_val.p, values + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->p_row.p, post.row.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->p_val.p, post.val.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
+        }
+        if (on_device) {  // counting sort of the uploaded CSR entries by index: count, scan (one workgroup), scatter
+            DevBuf<unsigned long long> cursor;
+            GORSE_TRY(cursor.alloc((size_t)post.D));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->p_ptr.p, 0, ((size_t)post.D + 1) * 8, h->stream));
+            sparse::BuildArgs b;
+            b.r_ptr = h->r_ptr.p, b.r_idx = h->r_idx.p, b.r_val = h->r_val.p;
+            b.N = N, b.nnz = nnz, b.D = post.D;
+            b.p_ptr = reinterpret_cast<unsigned long long *>(h->p_ptr.p), b.cursor = cursor.p;
+            b.p_row = h->p_row.p, b.p_val = h->p_val.p;
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, ceil_div(nnz, 256)));
+            sparse::sparse_count_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(b);
+            sparse::sparse_scan_kernel<<<dim3(1), dim3(sparse::kScanBlock), 0, h->stream>>>(b);
+            sparse::sparse_scatter_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(b);
+            GORSE_HIP_CHECK(hipGetLastError());
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // `cursor` is freed when this scope ends
+        } else {
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->p_ptr.p, post.ptr.data(), ((size_t)post.D + 1) * 8, hipMemcpyHostToDevice,
+                                           h->stream));
+            if (nnz > 0) {
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->p_row.p, post.row.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->p_val.p, post.val.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
+            }
         }
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host staging vectors die with this scope
         return GORSE_OK;
@@ -281,3 +308,5 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
     if (hits) *hits = h->last_hits;
     return GORSE_OK;
 }
+
+extern "C" void gorse_hip_test_set_sparse_build(int32_t mode) { g_sparse_build = mode; }

@@ -223,5 +223,76 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
     }
 }
 
+// ---- postings on the device (counting sort of the CSR entries by index) -------------------------------------------------
+// Not the library's default yet (sparse.hip builds the postings on the host unless gorse_hip_test_set_sparse_build(1)):
+// written without a GPU like the rest of this file, exercised through the emulation.  The order of the entries INSIDE a
+// posting list depends on the atomics' order; no result depends on it (a row occurs once per list, and a row's sum runs
+// over the lists in the query's index order).
+constexpr int kScanBlock = 1024;
+
+struct BuildArgs {
+    const int64_t *r_ptr;  // N + 1
+    const uint32_t *r_idx;
+    const float *r_val;
+    int64_t N, nnz, D;
+    unsigned long long *p_ptr;   // D + 1, zeroed before the count kernel; = the posting directory after the scan
+    unsigned long long *cursor;  // D: next free slot of every list during the scatter
+    int32_t *p_row;
+    float *p_val;
+};
+
+// p_ptr[t + 1] = number of entries with index t
+__global__ void sparse_count_kernel(BuildArgs a) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nnz; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&a.p_ptr[(int64_t)a.r_idx[e] + 1], 1ull);
+}
+
+// in-place inclusive scan of p_ptr[1 .. D] by ONE workgroup (the directory has at most 2^30 entries and is scanned once per
+// index build), then cursor[t] = p_ptr[t]: every thread sums a contiguous chunk, thread 0 scans the chunk sums, every
+// thread rewrites its chunk
+__global__ __launch_bounds__(kScanBlock) void sparse_scan_kernel(BuildArgs a) {
+    __shared__ unsigned long long s_part[kScanBlock];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t chunk = (a.D + nt - 1) / nt;
+    const int64_t lo = 1 + (int64_t)tid * chunk, hi = lo + chunk < a.D + 1 ? lo + chunk : a.D + 1;
+    unsigned long long sum = 0;
+    for (int64_t t = lo; t < hi; t++) sum += a.p_ptr[t];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < nt; t++) {
+            const unsigned long long x = s_part[t];
+            s_part[t] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    unsigned long long run = s_part[tid];
+    for (int64_t t = lo; t < hi; t++) {
+        run += a.p_ptr[t];
+        a.p_ptr[t] = run;
+    }
+    __syncthreads();  // the directory is complete (one workgroup: a barrier orders its global writes for its own reads)
+    for (int64_t t = tid; t < a.D; t += nt) a.cursor[t] = a.p_ptr[t];
+}
+
+// entry e of the CSR goes to the next free slot of its index's list; its row = the r_ptr interval that holds e
+__global__ void sparse_scatter_kernel(BuildArgs a) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = a.N;  // largest row with r_ptr[row] <= e
+        while (hi - lo > 1) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (a.r_ptr[mid] <= e)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const unsigned long long at = atomicAdd(&a.cursor[a.r_idx[e]], 1ull);
+        a.p_row[at] = (int32_t)lo;
+        a.p_val[at] = a.r_val[e];
+    }
+}
+
 }  // namespace sparse
 }  // namespace gorse

@@ -271,6 +271,11 @@ void gorse_hip_test_set_topk_variant(int32_t variant);
  * kernel ticks, [7] waves, and the candidate path split into [8] count + exchange, [9] appends, [10] compaction
  * check / compaction, with [11] lanes that appended. */
 int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/);
+/* where gorse_sparse_create builds the posting lists of a handle created AFTERWARDS: 0 = on the host (counting sort, the
+ * default this round), 1 = on the device (sparse_count_kernel / sparse_scan_kernel / sparse_scatter_kernel over the
+ * uploaded CSR).  Written without a GPU and checked through the CPU emulation only; it becomes the default once the GPU
+ * test that compares both builds has run.  Results never depend on it. */
+void gorse_hip_test_set_sparse_build(int32_t mode);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */

@@ -6,7 +6,14 @@
 #include "../../gorse_amd/csrc/sparse_host.hpp"
 #include "../../gorse_amd/csrc/sparse_kernels.hpp"
 
+#include <algorithm>
+
 using namespace gorse::sparse;
+
+static int g_device_build = 0;
+// 1: emu_sparse_search also runs the postings build kernels, checks them against the host build and lets the query kernel
+// walk the lists they produced
+extern "C" __attribute__((visibility("default"))) void emu_sparse_set_device_build(int on) { g_device_build = on; }
 
 // queries: q_ptr == NULL -> the stored rows q_first .. q_first + nq (all pairs), else the given CSR rows 0 .. nq.
 // `rounds` launches are made over the same scratch (serial bases advance like in the library); the outputs hold the
@@ -22,6 +29,36 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
     if (q_ptr && !validate_csr(nq, q_ptr, q_idx).empty()) return -1;
     Postings post;
     if (!build_postings(N, indptr, indices, values, post).empty()) return -1;
+    if (g_device_build) {  // the same postings from the three build kernels (entries of a list in any order)
+        const int64_t nnz = indptr[N] - indptr[0], D = post.D;
+        std::vector<int64_t> rp((size_t)N + 1);
+        for (int64_t r = 0; r <= N; r++) rp[(size_t)r] = indptr[r] - indptr[0];
+        std::vector<unsigned long long> pp((size_t)D + 1, 0), cursor((size_t)(D > 0 ? D : 1), 0);
+        std::vector<int32_t> prow((size_t)(nnz > 0 ? nnz : 1), -1);
+        std::vector<float> pval((size_t)(nnz > 0 ? nnz : 1), 0.0f);
+        BuildArgs b;
+        b.r_ptr = rp.data(), b.r_idx = indices + indptr[0], b.r_val = values + indptr[0];
+        b.N = N, b.nnz = nnz, b.D = D;
+        b.p_ptr = pp.data(), b.cursor = cursor.data(), b.p_row = prow.data(), b.p_val = pval.data();
+        emu::launch(3, (unsigned)block, [&] { sparse_count_kernel(b); });
+        emu::launch(1, (unsigned)(block < kScanBlock ? block : kScanBlock), [&] { sparse_scan_kernel(b); });
+        emu::launch(2, (unsigned)block, [&] { sparse_scatter_kernel(b); });
+        // same directory, every list the same SET of (row, value) as the host build
+        for (int64_t t = 0; t <= D; t++)
+            if ((int64_t)pp[(size_t)t] != post.ptr[(size_t)t]) return -2;
+        for (int64_t t = 0; t < D; t++) {
+            if ((int64_t)cursor[(size_t)t] != post.ptr[(size_t)t + 1]) return -3;
+            std::vector<std::pair<int32_t, float>> x, y;
+            for (int64_t e = post.ptr[(size_t)t]; e < post.ptr[(size_t)t + 1]; e++) {
+                x.emplace_back(post.row[(size_t)e], post.val[(size_t)e]);
+                y.emplace_back(prow[(size_t)e], pval[(size_t)e]);
+            }
+            std::sort(y.begin(), y.end());
+            if (x != y) return -4;
+        }
+        post.row.assign(prow.begin(), prow.begin() + nnz);  // the query kernel below walks the device-built lists
+        post.val.assign(pval.begin(), pval.begin() + nnz);
+    }
     const int kp = pick_kp(k);
     if (!kp || grid < 1 || block < 1) return -1;
     std::vector<Cell> cell((size_t)grid * N, 0);

@@ -12,6 +12,7 @@ extern "C" int emu_sparse_search(int64_t N, const int64_t *indptr, const uint32_
                                  const int64_t *exclude, int exclude_self, const uint8_t *mask, int k, int grid, int block,
                                  int rounds, uint32_t serial_base, int32_t *out_idx, float *out_score, int32_t *out_cnt,
                                  unsigned long long *stat2);
+extern "C" void emu_sparse_set_device_build(int on);
 
 int main() {
     std::mt19937 rng(5);
@@ -28,6 +29,7 @@ int main() {
         ptr.push_back((int64_t)idx.size());
     }
     int rc = 0;
+    emu_sparse_set_device_build(1);  // the postings build kernels run under the sanitizer too
     for (int k : {5, 70}) {  // KP = 64 (many overflows with ~690 hits per query) and KP = 128
         const int64_t nq = 24;
         std::vector<int32_t> oi((size_t)nq * k), oc((size_t)nq);

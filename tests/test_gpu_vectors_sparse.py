@@ -125,6 +125,23 @@ def properties(ptr, out_idx, out_sc, out_cnt, k):
     assert (out_cnt[empty] == 0).all()
 
 
+def test_postings_built_on_the_device_give_the_same_results(oracle):
+    """gorse_hip_test_set_sparse_build(1): count / scan / scatter kernels instead of the host's counting sort"""
+    rng = np.random.default_rng(41)
+    ptr, idx, val = random_csr(rng, 4000, 900, 0, 25, neg=True, zipf=True)
+    host = capi.Sparse(ptr, idx, val).all_pairs(20)
+    capi.lib().gorse_hip_test_set_sparse_build(1)
+    try:
+        s = capi.Sparse(ptr, idx, val)
+    finally:
+        capi.lib().gorse_hip_test_set_sparse_build(0)
+    dev = s.all_pairs(20)
+    for a, b in zip(host, dev):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+    sample = list(range(0, 4000, 131))
+    check(oracle, ptr, idx, val, 20, [x[sample] for x in dev], rows_of(ptr, idx, val, sample), sample)
+
+
 def test_argument_errors():
     ptr = np.array([0, 2, 3], np.int64)
     idx = np.array([1, 5, 2], np.uint32)

@@ -224,3 +224,19 @@ def test_random_database_operations_on_the_emulated_kernel(emu, oracle):
         return emu.emu_sparse_search(n, p(indptr), p(indices), p(values), nq, p(q_indptr), p(q_indices), p(q_values), 0, None, 0,
                                      p(admissible), k, 2, 8, 1, 0, p(idx), p(score), p(cnt), None)
     T.test_random_operations_against_a_model_of_the_reference(V.Database(searcher=dense_searcher, sparse_searcher=sparse_searcher))
+
+
+@pytest.mark.parametrize("block", [1, 7, 64])
+def test_postings_built_by_the_device_kernels(emu, oracle, block):
+    """sparse_count_kernel / sparse_scan_kernel / sparse_scatter_kernel under emulation: the same posting directory as the
+    host build, every list the same set of (row, value) entries, and queries over the device-built lists (whose entries
+    come in the atomics' order) still equal the oracle bit for bit.  Empty rows, empty lists and a single row included."""
+    rng = np.random.default_rng(40 + block)
+    emu.emu_sparse_set_device_build(1)
+    try:
+        for rows, dims, lo, hi in ((90, 37, 0, 8), (1, 5, 3, 3), (40, 300, 0, 3)):
+            ptr, idx, val = random_csr(rng, rows, dims, lo, hi, neg=True, zipf=rows > 1)
+            got = run_emu(emu, ptr, idx, val, 6, rows, exclude_self=1, grid=2, block=block)  # asserts rc == 0
+            check(oracle, ptr, idx, val, 6, got, rows_of(ptr, idx, val, range(rows)), list(range(rows)))
+    finally:
+        emu.emu_sparse_set_device_build(0)
