@@ -8,8 +8,8 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_vectors_sparse.py -q -m gpu > "$OUT/${TAG}_pytest_sparse.log" 2>&1
-echo "pytest sparse exit $?"; tail -15 "$OUT/${TAG}_pytest_sparse.log"
+timeout 300 python -m pytest tests/test_gpu_vectors_sparse.py tests/test_gpu_x_model_search.py -q -m gpu > "$OUT/${TAG}_pytest_sparse.log" 2>&1
+echo "pytest sparse + model search exit $?"; tail -15 "$OUT/${TAG}_pytest_sparse.log"
 for SHAPE in ml100k ml1m c3; do
     timeout 300 python bench.py --workload i2i --i2i-shape $SHAPE --steps 5 --warmup 2 > "$OUT/${TAG}_bench_i2i_$SHAPE.json" 2> "$OUT/${TAG}_bench_i2i_$SHAPE.err"
     echo "bench i2i $SHAPE exit $?"; tail -c 1800 "$OUT/${TAG}_bench_i2i_$SHAPE.json"; tail -2 "$OUT/${TAG}_bench_i2i_$SHAPE.err"
@@ -26,4 +26,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
     grep -h "sparse_query" "$OUT/${TAG}_pmc_i2i_$C.txt" | cut -c1-170 | head -4
 done
 cd "$ROOT"
+timeout 400 python scripts/gpu_probe_topk.py variants > "$OUT/${TAG}_probe_topk_variants.txt" 2>&1   # incl. the row-vote variant (bit 7)
+echo "probe topk variants exit $?"; tail -5 "$OUT/${TAG}_probe_topk_variants.txt" | cut -c1-220
 rm -rf "$OUT"/prof_${TAG}_i2i "$OUT"/pmc_${TAG}_i2i_*   # databases are large; the summaries are what we keep

@@ -11,7 +11,6 @@ import subprocess
 import numpy as np
 import pytest
 
-from oracle import oracle as orc
 from sparse_cases import TIE_EXPECT, check_against_oracle as check, random_csr, rows_of, tie_case
 
 HERE = os.path.dirname(os.path.abspath(__file__))
