@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_gpu_vectors_sparse.py tests/test_gpu_x_model_search.py -q -m gpu > "$OUT/${TAG}_pytest_sparse.log" 2>&1
+GORSE_GPU_ISOLATED=1 timeout 300 python -m pytest tests/test_gpu_vectors_sparse.py tests/test_gpu_x_model_search.py -q -m gpu > "$OUT/${TAG}_pytest_sparse.log" 2>&1
 echo "pytest sparse + model search exit $?"; tail -15 "$OUT/${TAG}_pytest_sparse.log"
 for SHAPE in ml100k ml1m c3; do
     timeout 300 python bench.py --workload i2i --i2i-shape $SHAPE --steps 5 --warmup 2 > "$OUT/${TAG}_bench_i2i_$SHAPE.json" 2> "$OUT/${TAG}_bench_i2i_$SHAPE.err"

@@ -8,8 +8,25 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# GPU test modules whose kernels have never run on a device (written after a round's GPU budget was spent).  A fault or a
+# hang in such a kernel would take the whole pytest process -- and with it the record of every validated test -- down, so
+# in a normal session they are skipped and tests/test_gpu_zz_isolated.py runs them in a child process with a timeout
+# (GORSE_GPU_ISOLATED=1 in the child, or by hand: GORSE_GPU_ISOLATED=1 python -m pytest tests/test_gpu_vectors_sparse.py).
+# A module leaves this list once a device session has seen it green.
+ISOLATED_GPU_MODULES = ("test_gpu_vectors_sparse.py", "test_gpu_x_model_search.py")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("GORSE_GPU_ISOLATED"):
+        return
+    skip = pytest.mark.skip(reason="never run on a device yet: runs in a child process, see tests/test_gpu_zz_isolated.py")
+    for item in items:
+        if os.path.basename(str(item.fspath)) in ISOLATED_GPU_MODULES:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")
