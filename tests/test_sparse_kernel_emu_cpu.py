@@ -172,6 +172,20 @@ def test_gpu_case_on_the_emulated_kernel(emu, oracle, monkeypatch, name, k):
     fn(**{a: args[a] for a in fn.__code__.co_varnames[:fn.__code__.co_argcount]})
 
 
+def test_no_out_of_bounds_access_under_address_sanitizer(tmp_path):
+    """the same driver under AddressSanitizer + UndefinedBehaviorSanitizer: an index past the LDS ranking buffer, the
+    scratch rows, the posting arrays or the result rows is a report"""
+    exe = str(tmp_path / "asan_sparse")
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                            "-ffp-contract=off", "-pthread", os.path.join(EMU, "tsan_main.cpp"), os.path.join(EMU, "sparse_emu.cpp"),
+                            "-o", exe], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("AddressSanitizer is not available to this g++: " + build.stderr[-200:])
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert "Sanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-2000:]
+    assert run.returncode == 0 and "tsan run done rc=0" in run.stdout
+
+
 def test_no_data_race_between_barriers_under_thread_sanitizer(tmp_path):
     """tests/emu/tsan_main.cpp: the emulated kernel under ThreadSanitizer -- two work-items reaching the same plain
     load/store without a barrier in between is a reported race (removing the barrier after a posting list gives four
