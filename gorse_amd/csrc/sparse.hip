@@ -52,7 +52,12 @@ int g_sparse_build = 0;  // 0 = postings built on the host (default), 1 = by the
 constexpr int64_t kScratchBudget = (int64_t)16 << 30;  // bytes of accumulator scratch (of 288 GB of HBM)
 constexpr int64_t kMaxSlots = 8192;                    // 256 CUs x 32 single-wave workgroups
 
-int64_t slot_cap(int64_t N) { return std::max<int64_t>(1, std::min<int64_t>(kMaxSlots, kScratchBudget / (12 * N))); }
+int64_t g_sparse_max_slots = 0;  // probe: fewer resident workgroups = a smaller live scratch footprint (0 = kMaxSlots)
+
+int64_t slot_cap(int64_t N) {
+    const int64_t most = g_sparse_max_slots > 0 ? std::min(g_sparse_max_slots, kMaxSlots) : kMaxSlots;
+    return std::max<int64_t>(1, std::min<int64_t>(most, kScratchBudget / (12 * N)));
+}
 
 int32_t ensure_scratch(gorse_sparse *h, int64_t want) {
     if (want <= h->slots) return GORSE_OK;
@@ -310,3 +315,4 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 }
 
 extern "C" void gorse_hip_test_set_sparse_build(int32_t mode) { g_sparse_build = mode; }
+extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }

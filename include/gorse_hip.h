@@ -276,6 +276,10 @@ int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/
  * uploaded CSR).  Written without a GPU and checked through the CPU emulation only; it becomes the default once the GPU
  * test that compares both builds has run.  Results never depend on it. */
 void gorse_hip_test_set_sparse_build(int32_t mode);
+/* probe: at most this many workgroups (= queries in flight, each with its 12 N bytes of scratch) per sparse launch; 0 = the
+ * library's own bound (8192, or what 16 GiB of scratch allow).  Trades occupancy against the cache footprint of the
+ * accumulators; results never depend on it. */
+void gorse_hip_test_set_sparse_slots(int64_t max_slots);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Probe of the sparse top-k (csrc/sparse*): the "users" item-to-item and "items" user-to-user refresh on three dataset
+shapes, host- vs device-built postings, and the number of queries in flight (scratch footprint vs occupancy).
+One line per case: create time, all-pairs time by hipEvents, postings/s, algorithmic GB/s (8 B per posting)."""
+import sys
+import time
+
+import numpy as np
+import torch  # noqa: F401  (loads the HIP runtime first)
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from gorse_amd import capi, synth  # noqa: E402
+
+
+def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0):
+    L = capi.lib()
+    L.gorse_hip_test_set_sparse_build(device_build)
+    L.gorse_hip_test_set_sparse_slots(slots)
+    t0 = time.perf_counter()
+    s = capi.Sparse(ptr, idx, val)
+    t_create = time.perf_counter() - t0
+    s.all_pairs(k, 0, min(s.N, 4096), fetch=False)
+    s.all_pairs(k, fetch=False)
+    s.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        s.all_pairs(k, fetch=False)
+    wall = (time.perf_counter() - t0) / reps
+    n, ms = s.get_profile()
+    postings, hits = s.last_stats()
+    per = ms / max(n, 1)
+    print("%-44s N=%8d nnz=%10d k=%3d slots=%5s build=%s create %7.3f s  all-pairs %9.3f ms (wall %9.3f)  postings %.3e  "
+          "%.3e postings/s  %8.1f GB/s algorithmic  hit rows/query %.0f"
+          % (name, s.N, int(ptr[-1]), k, slots or "max", "device" if device_build else "host", t_create, per, wall * 1e3,
+             postings, postings / (per * 1e-3), postings * 8 / (per * 1e-3) / 1e9, hits / s.N), flush=True)
+    s.close()
+    L.gorse_hip_test_set_sparse_build(0)
+    L.gorse_hip_test_set_sparse_slots(0)
+
+
+def main():
+    shapes = [("S-ml100k", synth.s_ml100k()), ("S-ml1m", synth.s_ml1m())]
+    if len(sys.argv) < 2 or sys.argv[1] != "small":
+        shapes.append(("S-big shard (C3/8)", synth.s_big_shard(rank=0, world=8)))
+    for name, data in shapes:
+        i2i = synth.idf_vectors(data.iptr, data.iidx, data.U)   # item -> users, users' IDF
+        u2u = synth.idf_vectors(data.uptr, data.uidx, data.I)   # user -> items, items' IDF
+        run(name + " users item-to-item", *i2i)
+        run(name + " users item-to-item", *i2i, device_build=1)
+        run(name + " items user-to-user", *u2u)
+        for slots in (256, 1024, 4096):
+            run(name + " users item-to-item", *i2i, slots=slots)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,8 @@ for SHAPE in ml100k ml1m c3; do
     timeout 300 python bench.py --workload i2i --i2i-shape $SHAPE --steps 5 --warmup 2 > "$OUT/${TAG}_bench_i2i_$SHAPE.json" 2> "$OUT/${TAG}_bench_i2i_$SHAPE.err"
     echo "bench i2i $SHAPE exit $?"; tail -c 1800 "$OUT/${TAG}_bench_i2i_$SHAPE.json"; tail -2 "$OUT/${TAG}_bench_i2i_$SHAPE.err"
 done
+timeout 500 python scripts/gpu_probe_sparse.py > "$OUT/${TAG}_probe_sparse.txt" 2>&1
+echo "probe sparse exit $?"; cut -c1-230 "$OUT/${TAG}_probe_sparse.txt"
 cd /tmp
 timeout 240 rocprofv3 --kernel-trace --stats -d "$OUT/prof_${TAG}_i2i" -o bench -- python "$ROOT/bench.py" --workload i2i --steps 5 --warmup 2 --no-cpu-baseline \
     > "$OUT/${TAG}_bench_i2i_under_rocprof.json" 2> "$OUT/${TAG}_rocprof_i2i.err"
