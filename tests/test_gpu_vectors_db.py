@@ -15,9 +15,10 @@ def db():
     return V.Open("hip://")
 
 
-# S.collaborative_recommend (bulk recommendations for many users) was written after the round's GPU budget was spent: it
-# runs in the CPU module against the oracle-backed searcher and joins this list once it has been run on a device.
-# The sparse collections (S.SPARSE_CASES) run on the device from tests/test_gpu_vectors_sparse.py.
+# S.collaborative_recommend (bulk recommendations for many users), S.PENDING_DENSE_CASES and the sparse collections
+# (S.SPARSE_CASES) were written after the round's GPU budget was spent: they run in the CPU module against the oracle-backed
+# searchers and, on the device, from tests/test_gpu_vectors_sparse.py (isolated in a child process until a device session
+# has seen them green); the dense ones join this list then.
 
 
 @pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.hidden, S.dot, S.delete_vectors,

@@ -166,7 +166,7 @@ def test_argument_errors():
 
 
 # ---- the same kernel behind the vectors.Database twin and the sparse similarity kinds of logics -----------------------
-@pytest.mark.parametrize("case", S.SPARSE_CASES, ids=lambda f: f.__name__)
+@pytest.mark.parametrize("case", S.SPARSE_CASES + S.PENDING_DENSE_CASES + [S.collaborative_recommend], ids=lambda f: f.__name__)
 def test_reference_suite_sparse(case):
     """storage/vectors/database_test.go TestSparse and logics/{item_to_item,user_to_user}_test.go TestTags / TestUsers /
     TestItems / TestAuto (tests/vectors_suite.py) on `vectors.Open("hip://")`"""

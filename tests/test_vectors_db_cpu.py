@@ -43,7 +43,7 @@ def db(oracle):
 
 @pytest.mark.parametrize("case", [S.collections, S.vectors, S.get_vectors, S.hidden, S.dot, S.delete_vectors,
                                   S.upsert_and_close, S.item_to_item_column, S.item_to_item_embedding, S.item_to_item_clean,
-                                  S.user_to_user_embedding, S.user_to_user_clean, S.collaborative_recommend] + S.SPARSE_CASES,
+                                  S.user_to_user_embedding, S.user_to_user_clean, S.collaborative_recommend] + S.PENDING_DENSE_CASES + S.SPARSE_CASES,
                          ids=lambda f: f.__name__)
 def test_reference_suite(db, case):
     case(db)

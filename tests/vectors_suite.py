@@ -254,6 +254,19 @@ def item_to_item_clean(db):  # TestClean (item_to_item_test.go:143-170): Clean d
     assert db.DescribeCollection(coll)["Dimension"] == 3 and db.CountVectors(coll) == 1
 
 
+def item_to_item_hidden(db):  # TestHidden (item_to_item_test.go:166-210)
+    i2i = V.EmbeddingItemToItem("hidden", 1_790_000_000_000, db)
+    i2i.Add("visible_1", [0.0, 0.0, 0.0])
+    i2i.Add("visible_2", [0.1, 0.0, 0.0])
+    i2i.Add("hidden_1", [0.05, 0.0, 0.0], is_hidden=True)
+    i2i.Clean()
+    coll = V.ItemToItemCollection("hidden")
+    hidden_scores = V.QuerySimilar(db, coll, "hidden_1", None, 2)  # a hidden item still gets neighbours, from the visible ones
+    assert len(hidden_scores) == 2 and all(s.Id != "hidden_1" for s in hidden_scores)
+    visible_scores = V.QuerySimilar(db, coll, "visible_1", None, 2)  # and is never anybody's neighbour
+    assert [s.Id for s in visible_scores] == ["visible_2"]
+
+
 def _nested_kind(db, kind, collection, n=100):
     """TestTags / TestUsers (item_to_item_test.go:212-270) and TestTags / TestItems (user_to_user_test.go:96-153): entity i
     carries the ids 1 .. 100-i (as labels or as feedback), every idf is 1; the neighbours of "0" are "1" .. "10" in order"""
@@ -362,6 +375,8 @@ def user_to_user_auto(db):  # TestAuto (user_to_user_test.go:155-190)
     _auto_kind(db, V.UserToUserCollection("auto"))
 
 
+# dense cases written after the last device session: on the CPU list now, on the device through tests/test_gpu_vectors_sparse.py
+PENDING_DENSE_CASES = [item_to_item_hidden]
 SPARSE_CASES = [sparse, sparse_rules, item_to_item_tags, item_to_item_users, item_to_item_auto,
                 item_to_item_sparse_hidden_and_idf, user_to_user_tags, user_to_user_items, user_to_user_auto]
 
