@@ -316,3 +316,8 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_build(int32_t mode) { g_sparse_build = mode; }
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
+extern "C" int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    h->serial = serial;
+    return GORSE_OK;
+}

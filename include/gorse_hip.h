@@ -280,6 +280,9 @@ void gorse_hip_test_set_sparse_build(int32_t mode);
  * library's own bound (8192, or what 16 GiB of scratch allow).  Trades occupancy against the cache footprint of the
  * accumulators; results never depend on it. */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
+/* the stamp counter of a handle (every query a workgroup answers takes the next 32-bit stamp; when the counter would wrap
+ * the library clears the scratch and starts over): lets a test put the counter just below the wrap. */
+int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */

@@ -125,6 +125,27 @@ def properties(ptr, out_idx, out_sc, out_cnt, k):
     assert (out_cnt[empty] == 0).all()
 
 
+def test_stamp_counter_wraps_by_clearing_the_scratch(oracle):
+    """every answered query takes the next 32-bit stamp of its workgroup's scratch; just below 2^32 the library clears the
+    scratch and restarts -- without the clear, cells stamped 1, 2, ... by the first call would pass for already reached"""
+    rng = np.random.default_rng(43)
+    ptr, idx, val = random_csr(rng, 700, 500, 1, 3)  # few hits per query: most cells keep the stamp of ONE earlier query
+    s = capi.Sparse(ptr, idx, val)
+    capi.lib().gorse_hip_test_set_sparse_slots(7)  # 700 queries over 7 workgroups: 100 stamps per launch
+    try:
+        first = s.all_pairs(11)
+        sample = list(range(0, 700, 13))
+        check(oracle, ptr, idx, val, 11, [x[sample] for x in first], rows_of(ptr, idx, val, sample), sample)
+        for serial in (0xFFFFFFFF - 100, 0xFFFFFFFF - 150, 0xFFFFFFFF - 99):  # wrap over cells stamped 1..100, no wrap, wrap
+            capi.check(capi.lib().gorse_hip_test_sparse_set_serial(s.h, serial))
+            again = s.all_pairs(11)
+            for a, b in zip(first, again):
+                assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
+                                      b.view(np.uint32) if b.dtype == np.float32 else b), hex(serial)
+    finally:
+        capi.lib().gorse_hip_test_set_sparse_slots(0)
+
+
 def test_postings_built_on_the_device_give_the_same_results(oracle):
     """gorse_hip_test_set_sparse_build(1): count / scan / scatter kernels instead of the host's counting sort"""
     rng = np.random.default_rng(41)
