@@ -153,8 +153,11 @@ def _gpu_cases():
     import test_gpu_vectors_sparse as G
     cases = []
     for name in sorted(dir(G)):
-        if not name.startswith("test_") or name in ("test_argument_errors", "test_reference_suite_sparse"):
-            continue  # argument checks live in sparse.hip; the database suite has its own emulated run below
+        if not name.startswith("test_") or name in ("test_argument_errors", "test_reference_suite_sparse",
+                                                    "test_stamp_counter_wraps_by_clearing_the_scratch",
+                                                    "test_postings_built_on_the_device_give_the_same_results"):
+            continue  # these drive sparse.hip itself (tests/test_sparse_fake_runtime_cpu.py runs them); the database suite
+            # has its own emulated run below
         if name == "test_many_hits_overflow_the_ranking_buffer":
             cases += [(name, k) for k in (3, 64, 65, 513)]
         else:
