@@ -273,10 +273,10 @@ def bench_sparse(args, world, rank, local, fence):
         gdist.refresh_neighbors_sharded(eng, comm, k, gather=False)
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+        dt = float(tt.item())
     launches, ms = sp.get_profile()
     postings, hits = sp.last_stats()
     sp.set_profiling(False)

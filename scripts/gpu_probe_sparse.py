@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Probe of the sparse top-k (csrc/sparse*): the "users" item-to-item and "items" user-to-user refresh on three dataset
+"""Probe of the sparse top-k (csrc/sparse*) -- `small` leaves the C3 shard out, `tiny` runs S-ml100k only: the "users" item-to-item and "items" user-to-user refresh on three dataset
 shapes, host- vs device-built postings, and the number of queries in flight (scratch footprint vs occupancy).
 One line per case: create time, all-pairs time by hipEvents, postings/s, algorithmic GB/s (8 B per posting)."""
 import sys
@@ -39,8 +39,10 @@ def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0):
 
 
 def main():
-    shapes = [("S-ml100k", synth.s_ml100k()), ("S-ml1m", synth.s_ml1m())]
-    if len(sys.argv) < 2 or sys.argv[1] != "small":
+    shapes = [("S-ml100k", synth.s_ml100k())]
+    if len(sys.argv) < 2 or sys.argv[1] != "tiny":
+        shapes.append(("S-ml1m", synth.s_ml1m()))
+    if len(sys.argv) < 2 or sys.argv[1] not in ("small", "tiny"):
         shapes.append(("S-big shard (C3/8)", synth.s_big_shard(rank=0, world=8)))
     for name, data in shapes:
         i2i = synth.idf_vectors(data.iptr, data.iidx, data.U)   # item -> users, users' IDF

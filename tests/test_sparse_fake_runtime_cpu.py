@@ -32,3 +32,28 @@ def test_gpu_sparse_tests_through_the_real_library_on_a_fake_hip_runtime():
     assert child.returncode == 0, tail
     assert " passed" in tail and "failed" not in tail and "skipped" not in tail, tail
     assert int(tail.rsplit(" passed", 1)[0].split()[-1]) >= 24, tail
+
+
+def test_bench_i2i_leg_on_the_fake_runtime():
+    """bench.py --workload i2i (S-ml100k shape, single rank) end to end on the fake runtime: the JSON object carries the
+    contract's fields, a roofline at 8 bytes per posting and the oracle baseline, whose rows are compared bit for bit with
+    the library's inside bench.py"""
+    so = os.path.join(EMU, "libfakehip.so")
+    code = ("import json, sys, types; sys.argv = ['bench.py', '--workload', 'i2i', '--i2i-shape', 'ml100k', '--steps', '2', '--warmup', '1', "
+            "'--cpu-seconds', '0.2']; import bench; args = bench.parse(); "
+            "out = bench.bench_sparse(args, 1, 0, 0, lambda: None); print('JSON ' + json.dumps(out))")
+    child = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, LD_PRELOAD=so), capture_output=True, text=True,
+                           timeout=1200)
+    assert child.returncode == 0, (child.stdout + child.stderr)[-3000:]
+    import json
+    out = json.loads([l for l in child.stdout.splitlines() if l.startswith("JSON ")][-1][5:])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["unit"] == "postings/s" and out["n_gpus"] == 1 and out["steps"] == 2 and out["vs_baseline"] is None
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "sparse_query_kernel" and r["algorithmic_bytes_per_posting"] == 8 and r["launches"] == 2
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert out["config"]["postings_per_step_per_gpu"] > 0 and out["config"]["queries_per_step_per_gpu"] == 1682
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and "compared bit for bit" in c["sample"]
