@@ -84,6 +84,7 @@ SIGNATURES = {
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_set_sparse_build": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
+    "gorse_hip_test_set_sparse_heavy": (None, [C.c_int64]),
     "gorse_hip_test_sparse_set_serial": (C.c_int32, [_vp, C.c_uint32]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),

@@ -36,6 +36,11 @@ struct gorse_sparse {
     DevBuf<float> q_val, out_score;
     DevBuf<int32_t> out_idx, out_cnt;
     DevBuf<unsigned long long> stat;
+    // heavy queries (row streaming): host copy of the stored rows' offsets (the lengths of all_pairs' queries), per-batch
+    // score / shared-index rows
+    std::vector<int64_t> r_ptr_host;
+    DevBuf<float> hscore;
+    DevBuf<uint8_t> hcommon;
     KernelProfile prof{1};
     int64_t last_postings = 0, last_hits = 0;
     int32_t use() const {
@@ -47,6 +52,7 @@ struct gorse_sparse {
 
 namespace {
 
+int64_t g_sparse_heavy_dims = 2048;  // queries with more entries than this take the row-streaming path (test hook)
 int g_sparse_build = 0;  // 0 = postings built on the host (default), 1 = by the device kernels (test hook, see gorse_hip.h)
 
 constexpr int64_t kScratchBudget = (int64_t)16 << 30;  // bytes of accumulator scratch (of 288 GB of HBM)
@@ -73,12 +79,17 @@ template <int KP>
 void launch_query(const QueryArgs &a, unsigned grid, hipStream_t s) {
     sparse::sparse_query_kernel<KP><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
 }
+template <int KP>
+void launch_heavy_rank(const sparse::HeavyArgs &a, hipStream_t s) {
+    sparse::sparse_heavy_rank_kernel<KP><<<dim3((unsigned)a.nb), dim3(sparse::kBlock), 0, s>>>(a);
+}
 
 // nq queries = CSR rows q_first .. of device arrays (qp, qi, qv); results into the handle's out_* buffers and, where
 // given, the host arrays
+// q_len_host: q_len_host[t + 1] - q_len_host[t] = number of entries of query t (host copy of the offsets)
 int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, const float *qv, int64_t q_first, int64_t nq,
-                    const int64_t *excl_dev, int exclude_self, int k, int32_t *idx_out, float *score_out,
-                    int32_t *cnt_out) {
+                    const int64_t *q_len_host, const int64_t *excl_dev, int exclude_self, int k, int32_t *idx_out,
+                    float *score_out, int32_t *cnt_out) {
     const int kp = sparse::pick_kp(k);
     if (!kp) return fail(GORSE_ERR_INVALID, "k = %d: must be in 1..1024", k);
     const int64_t grid = std::min<int64_t>(nq, slot_cap(h->N));
@@ -97,6 +108,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
     a.p_ptr = h->p_ptr.p, a.p_row = h->p_row.p, a.p_val = h->p_val.p, a.D = h->D;
     a.q_ptr = qp, a.q_idx = qi, a.q_val = qv, a.q_first = q_first, a.nq = nq;
     a.exclude = excl_dev, a.exclude_self = exclude_self;
+    a.heavy_dims = g_sparse_heavy_dims > 0 ? g_sparse_heavy_dims : INT64_MAX;
     a.mask = h->has_mask ? h->mask.p : nullptr;
     a.n_admissible = h->has_mask ? h->n_admissible : h->N;
     a.N = h->N;
@@ -114,8 +126,36 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
         case 512: launch_query<512>(a, (unsigned)grid, h->stream); break;
         default: launch_query<1024>(a, (unsigned)grid, h->stream); break;
     }
-    h->prof.end(tok, h->stream);
     GORSE_HIP_CHECK(hipGetLastError());
+    // the queries the kernel above skipped: row streaming, kHeavyBatch of them per pass over the stored rows
+    std::vector<int64_t> heavy;
+    for (int64_t t = 0; t < nq; t++)
+        if (q_len_host[t + 1] - q_len_host[t] > a.heavy_dims) heavy.push_back(t);
+    if (!heavy.empty()) {
+        GORSE_TRY(h->hscore.ensure((size_t)sparse::kHeavyBatch * h->N));
+        GORSE_TRY(h->hcommon.ensure((size_t)sparse::kHeavyBatch * h->N));
+        sparse::HeavyArgs ha;
+        ha.r_ptr = h->r_ptr.p, ha.r_idx = h->r_idx.p, ha.r_val = h->r_val.p, ha.N = h->N;
+        ha.q_ptr = qp, ha.q_idx = qi, ha.q_val = qv, ha.q_first = q_first;
+        ha.score = h->hscore.p, ha.common = h->hcommon.p;
+        ha.exclude = excl_dev, ha.exclude_self = exclude_self, ha.mask = a.mask, ha.n_admissible = a.n_admissible;
+        ha.k = k, ha.out_idx = a.out_idx, ha.out_score = a.out_score, ha.out_cnt = a.out_cnt, ha.stat = a.stat;
+        const unsigned sgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, ceil_div(h->N, 256)));
+        for (size_t at = 0; at < heavy.size(); at += sparse::kHeavyBatch) {
+            ha.nb = (int)std::min<size_t>(sparse::kHeavyBatch, heavy.size() - at);
+            for (int b = 0; b < sparse::kHeavyBatch; b++) ha.hq[b] = b < ha.nb ? heavy[at + b] : 0;
+            sparse::sparse_heavy_score_kernel<<<dim3(sgrid), dim3(256), 0, h->stream>>>(ha);
+            switch (kp) {
+                case 64: launch_heavy_rank<64>(ha, h->stream); break;
+                case 128: launch_heavy_rank<128>(ha, h->stream); break;
+                case 256: launch_heavy_rank<256>(ha, h->stream); break;
+                case 512: launch_heavy_rank<512>(ha, h->stream); break;
+                default: launch_heavy_rank<1024>(ha, h->stream); break;
+            }
+        }
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    h->prof.end(tok, h->stream);
     unsigned long long st[2] = {0, 0};
     GORSE_HIP_CHECK(hipMemcpyAsync(st, h->stat.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     if (idx_out)
@@ -163,7 +203,8 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     int32_t rc = [&]() -> int32_t {
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        std::vector<int64_t> ptr0((size_t)N + 1);
+        std::vector<int64_t> &ptr0 = h->r_ptr_host;
+        ptr0.resize((size_t)N + 1);
         for (int64_t r = 0; r <= N; r++) ptr0[(size_t)r] = indptr[r] - base;
         GORSE_TRY(h->r_ptr.alloc((size_t)N + 1));
         GORSE_TRY(h->r_idx.alloc((size_t)nnz));
@@ -269,7 +310,7 @@ extern "C" int32_t gorse_sparse_search(gorse_sparse *h, int64_t nq, const int64_
         GORSE_HIP_CHECK(hipMemcpyAsync(h->q_excl.p, exclude, (size_t)nq * 8, hipMemcpyHostToDevice, h->stream));
     }
     // run_queries ends with a stream synchronisation, which also covers the uploads from ptr0
-    return run_queries(h, h->q_ptr.p, h->q_idx.p, h->q_val.p, 0, nq, exclude ? h->q_excl.p : nullptr, 0, k, idx_out,
+    return run_queries(h, h->q_ptr.p, h->q_idx.p, h->q_val.p, 0, nq, q_indptr, exclude ? h->q_excl.p : nullptr, 0, k, idx_out,
                        score_out, count_out);
 }
 
@@ -279,8 +320,8 @@ extern "C" int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int6
     if (q_begin < 0 || q_end > h->N || q_begin > q_end || k <= 0) return fail(GORSE_ERR_RANGE, "bad query range");
     if (q_begin == q_end) return GORSE_OK;
     GORSE_TRY(h->use());
-    return run_queries(h, h->r_ptr.p, h->r_idx.p, h->r_val.p, q_begin, q_end - q_begin, nullptr, exclude_self != 0, k,
-                       idx_out, score_out, count_out);
+    return run_queries(h, h->r_ptr.p, h->r_idx.p, h->r_val.p, q_begin, q_end - q_begin, h->r_ptr_host.data() + q_begin, nullptr,
+                       exclude_self != 0, k, idx_out, score_out, count_out);
 }
 
 extern "C" int32_t gorse_sparse_synchronize(gorse_sparse *h) {
@@ -316,6 +357,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_build(int32_t mode) { g_sparse_build = mode; }
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
+extern "C" void gorse_hip_test_set_sparse_heavy(int64_t dims) { g_sparse_heavy_dims = dims; }
 extern "C" int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
     h->serial = serial;

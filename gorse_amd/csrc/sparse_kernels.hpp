@@ -50,6 +50,7 @@ struct QueryArgs {
     int64_t q_first, nq;
     const int64_t *exclude;  // per query: a stored row left out of its result (-1 = none); may be null
     int exclude_self;        // all pairs: query t is stored row q_first + t, left out of its own result
+    int64_t heavy_dims;      // queries with more entries than this are left to the row-streaming kernels below
     const uint8_t *mask;     // admissible[row] or null
     int64_t n_admissible;    // number of admissible rows (N without a mask)
     int64_t N;
@@ -112,6 +113,61 @@ __device__ inline void sort_desc(unsigned long long *b, int tid, int nt) {
     }
 }
 
+// The ranking shared by both query paths: candidates i = 0 .. count-1, key_at(i) = its 64-bit key or 0 for "not a candidate"
+// (called once per i by the lane that owns it).  Leaves the min(buffered, CAP) best keys sorted descending in s_buf and
+// returns how many are buffered (> 0 only).  s_thr / s_bcnt must be 0 on entry; needs blockDim.x <= KP (after a cut to KP
+// the CAP - KP free slots take every lane still waiting).  All lanes of the workgroup call it together.
+template <int KP, typename KeyAt>
+__device__ inline int rank_candidates(int64_t count, KeyAt key_at, int k, unsigned long long *s_buf, unsigned long long *s_thr,
+                                      int *s_bcnt, int tid, int nt) {
+    constexpr int CAP = 2 * KP;
+    for (int64_t base = 0; base < count; base += nt) {
+        const int64_t i = base + tid;
+        const unsigned long long key = i < count ? key_at(i) : 0;  // 0 is below every real key
+        bool want = key > *s_thr;
+        while (true) {
+            bool over = false;
+            if (want) {
+                const int slot = atomicAdd(s_bcnt, 1);
+                if (slot < CAP) {
+                    s_buf[slot] = key;
+                    want = false;
+                } else {
+                    over = true;
+                }
+            }
+            if (!__syncthreads_or(over ? 1 : 0)) break;  // everybody found a slot
+            // some lane drew a slot >= CAP, so slots 0..CAP-1 are all written: keep the KP best
+            sort_desc<CAP>(s_buf, tid, nt);
+            if (tid == 0) {
+                *s_bcnt = KP;
+                *s_thr = s_buf[k - 1];
+            }
+            __syncthreads();
+            want = want && key > *s_thr;
+        }
+    }
+    __syncthreads();
+    const int n = *s_bcnt;  // <= CAP: an overflow is always followed by the cut to KP
+    if (n > 0) {
+        for (int i = n + tid; i < CAP; i += nt) s_buf[i] = 0;
+        __syncthreads();
+        sort_desc<CAP>(s_buf, tid, nt);  // positive scores first, then the negative ones
+    }
+    return n;
+}
+
+// result row t from the sorted buffer: cnt entries, the rest padded
+__device__ inline void write_result(const unsigned long long *s_buf, int cnt, int k, int64_t t, int32_t *out_idx, float *out_score,
+                                    int32_t *out_cnt, int tid, int nt) {
+    for (int i = tid; i < k; i += nt) {
+        const unsigned long long key = i < cnt ? s_buf[i] : 0;
+        out_idx[t * k + i] = i < cnt ? key_row(key) : -1;
+        out_score[t * k + i] = i < cnt ? key_score(key) : __uint_as_float(0xff800000u);
+    }
+    if (tid == 0) out_cnt[t] = cnt;
+}
+
 template <int KP>
 __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
     constexpr int CAP = 2 * KP;
@@ -137,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
         // ---- accumulate: one posting list per query index, ascending ----
         const int64_t qr = a.q_first + t;
         const int64_t qs = a.q_ptr[qr], qe = a.q_ptr[qr + 1];
+        if (qe - qs > a.heavy_dims) continue;  // uniform; answered by sparse_heavy_score_kernel / sparse_heavy_rank_kernel
         unsigned long long walked = 0;
         for (int64_t e = qs; e < qe; e++) {  // every condition below is uniform over the workgroup
             const uint32_t dim = a.q_idx[e];
@@ -159,67 +216,146 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
         const int T = s_cnt;
         const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? qr : (int64_t)-1);
         int my_pos = 0, my_neg = 0;
-        for (int base = 0; base < T; base += nt) {
-            unsigned long long key = 0;  // 0 is below every real key
-            const int i = base + tid;
-            if (i < T) {
+        rank_candidates<KP>(
+            T,
+            [&](int64_t i) -> unsigned long long {
                 const int32_t row = touched[i];
-                if ((int64_t)row != ex && (!a.mask || a.mask[row])) {
-                    const uint32_t ord = score_ord(cell_acc(cell[row]));
-                    if (ord != kZeroOrd) {  // a zero score is dropped by the reference's wrapper
-                        key = make_key(ord, row);
-                        my_pos += ord > kZeroOrd;
-                        my_neg += ord < kZeroOrd;
-                    }
-                }
-            }
-            bool want = key > s_thr;
-            while (true) {
-                bool over = false;
-                if (want) {
-                    const int slot = atomicAdd(&s_bcnt, 1);
-                    if (slot < CAP) {
-                        s_buf[slot] = key;
-                        want = false;
-                    } else {
-                        over = true;
-                    }
-                }
-                if (!__syncthreads_or(over ? 1 : 0)) break;  // everybody found a slot
-                // some lane drew a slot >= CAP, so slots 0..CAP-1 are all written: keep the KP best
-                sort_desc<CAP>(s_buf, tid, nt);
-                if (tid == 0) {
-                    s_bcnt = KP;
-                    s_thr = s_buf[a.k - 1];
-                }
-                __syncthreads();
-                want = want && key > s_thr;
-            }
-        }
+                if ((int64_t)row == ex || (a.mask && !a.mask[row])) return 0;
+                const uint32_t ord = score_ord(cell_acc(cell[row]));
+                if (ord == kZeroOrd) return 0;  // a zero score is dropped by the reference's wrapper
+                my_pos += ord > kZeroOrd;
+                my_neg += ord < kZeroOrd;
+                return make_key(ord, row);
+            },
+            a.k, s_buf, &s_thr, &s_bcnt, tid, nt);
         if (my_pos) atomicAdd(&s_pos, my_pos);
         if (my_neg) atomicAdd(&s_neg, my_neg);
         __syncthreads();
-        const int n = s_bcnt;  // <= CAP: an overflow is always followed by the cut to KP
-        if (n > 0) {
-            for (int i = n + tid; i < CAP; i += nt) s_buf[i] = 0;
-            __syncthreads();
-            sort_desc<CAP>(s_buf, tid, nt);  // positive scores first, then the negative ones
-        }
         const bool ex_counts = ex >= 0 && ex < a.N && (!a.mask || a.mask[ex]);
         const int cnt = written(s_pos, s_neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
-        for (int i = tid; i < a.k; i += nt) {
-            const unsigned long long key = i < cnt ? s_buf[i] : 0;
-            a.out_idx[t * a.k + i] = i < cnt ? key_row(key) : -1;
-            a.out_score[t * a.k + i] = i < cnt ? key_score(key) : __uint_as_float(0xff800000u);
-        }
+        write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, tid, nt);
         if (tid == 0) {
-            a.out_cnt[t] = cnt;
             if (a.stat) {
                 atomicAdd(&a.stat[0], walked);
                 atomicAdd(&a.stat[1], (unsigned long long)T);
             }
         }
         __syncthreads();  // s_buf / s_cnt are reused by the next query
+    }
+}
+
+// ---- heavy queries: row streaming instead of posting lists -----------------------------------------------------------------
+// A query with very many entries (a popular item's user set under a Zipf law: tens of thousands) would walk that many
+// posting lists one after the other in sparse_query_kernel -- milliseconds on ONE wave while the rest of the launch has long
+// finished.  Such a query reaches most stored rows anyway, so it is answered the other way round: every stored row r is
+// merged against the query by ONE lane (the row's entries in ascending order, each looked up in the query's sorted index
+// list by binary search), which needs no accumulators, no barriers and no order bookkeeping -- the sum runs over the
+// common indices in ascending order by construction, the oracle's merge order.  HBM-bound on the stored CSR (read once per
+// batch of kHeavyBatch queries); the query's own arrays stay in L2.
+constexpr int kHeavyBatch = 8;
+
+struct HeavyArgs {
+    // the stored rows (CSR, indices ascending) and the queries (CSR rows q_first + t)
+    const int64_t *r_ptr;
+    const uint32_t *r_idx;
+    const float *r_val;
+    int64_t N;
+    const int64_t *q_ptr;
+    const uint32_t *q_idx;
+    const float *q_val;
+    int64_t q_first;
+    int64_t hq[kHeavyBatch];  // the heavy queries of this batch (indices t into the call's queries)
+    int nb;
+    float *score;     // nb x N: the inner product of row r with heavy query b
+    uint8_t *common;  // nb x N: 1 when they share an index
+    // ranking (sparse_heavy_rank_kernel)
+    const int64_t *exclude;
+    int exclude_self;
+    const uint8_t *mask;
+    int64_t n_admissible;
+    int k;
+    int32_t *out_idx;
+    float *out_score;
+    int32_t *out_cnt;
+    unsigned long long *stat;  // [0] += row entries looked up, [1] += rows sharing an index
+};
+
+__global__ void sparse_heavy_score_kernel(HeavyArgs a) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.N; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rs = a.r_ptr[r], re = a.r_ptr[r + 1];
+        for (int b = 0; b < a.nb; b++) {
+            const int64_t qr = a.q_first + a.hq[b];
+            const int64_t qs = a.q_ptr[qr], qe = a.q_ptr[qr + 1];
+            float sum = 0.0f;
+            bool any = false;
+            int64_t from = qs;  // both lists ascend: the search for the next entry starts behind the last match
+            for (int64_t e = rs; e < re && from < qe; e++) {
+                const uint32_t idx = a.r_idx[e];
+                int64_t lo = from, hi = qe;  // first query entry with index >= idx
+                while (lo < hi) {
+                    const int64_t mid = lo + (hi - lo) / 2;
+                    if (a.q_idx[mid] < idx)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                from = lo;
+                if (lo < qe && a.q_idx[lo] == idx) {
+                    sum = __fadd_rn(sum, __fmul_rn(a.q_val[lo], a.r_val[e]));
+                    any = true;
+                    from = lo + 1;
+                }
+            }
+            a.score[(int64_t)b * a.N + r] = sum;
+            a.common[(int64_t)b * a.N + r] = any ? 1 : 0;
+        }
+    }
+}
+
+// one workgroup per heavy query of the batch: the same ranking as sparse_query_kernel over all N rows
+template <int KP>
+__global__ __launch_bounds__(kBlock) void sparse_heavy_rank_kernel(HeavyArgs a) {
+    constexpr int CAP = 2 * KP;
+    __shared__ unsigned long long s_buf[CAP];
+    __shared__ unsigned long long s_thr;
+    __shared__ int s_bcnt, s_pos, s_neg, s_hit;
+    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    if (tid == 0) {
+        s_bcnt = 0;
+        s_thr = 0;
+        s_pos = 0;
+        s_neg = 0;
+        s_hit = 0;
+    }
+    __syncthreads();
+    const int64_t t = a.hq[b], qr = a.q_first + t;
+    const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? qr : (int64_t)-1);
+    const float *score = a.score + (int64_t)b * a.N;
+    const uint8_t *common = a.common + (int64_t)b * a.N;
+    int my_pos = 0, my_neg = 0, my_hit = 0;
+    rank_candidates<KP>(
+        a.N,
+        [&](int64_t row) -> unsigned long long {
+            if (!common[row]) return 0;
+            my_hit++;
+            if (row == ex || (a.mask && !a.mask[row])) return 0;
+            const uint32_t ord = score_ord(score[row]);
+            if (ord == kZeroOrd) return 0;
+            my_pos += ord > kZeroOrd;
+            my_neg += ord < kZeroOrd;
+            return make_key(ord, (int32_t)row);
+        },
+        a.k, s_buf, &s_thr, &s_bcnt, tid, nt);
+    if (my_pos) atomicAdd(&s_pos, my_pos);
+    if (my_neg) atomicAdd(&s_neg, my_neg);
+    if (my_hit) atomicAdd(&s_hit, my_hit);
+    __syncthreads();
+    const bool ex_counts = ex >= 0 && ex < a.N && (!a.mask || a.mask[ex]);
+    const int cnt = written(s_pos, s_neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
+    write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, tid, nt);
+    if (tid == 0 && a.stat) {
+        atomicAdd(&a.stat[0], (unsigned long long)(a.r_ptr[a.N] - a.r_ptr[0]));
+        atomicAdd(&a.stat[1], (unsigned long long)s_hit);
     }
 }
 

@@ -228,7 +228,8 @@ int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int64_t q_end, 
 int32_t gorse_sparse_synchronize(gorse_sparse *h);
 /* measurement: hipEvent pairs around sparse_query_kernel on the handle's stream, and the work of the last call:
  * postings = sum over its queries and their indices of the posting-list lengths (= multiply-adds performed; the
- * kernel reads 8 bytes per posting), hits = rows that shared an index with their query. */
+ * kernel reads 8 bytes per posting) plus, for every query that took the row-streaming path, the number of stored
+ * entries (8 bytes each as well); hits = rows that shared an index with their query. */
 int32_t gorse_sparse_set_profiling(gorse_sparse *h, int32_t on);
 int32_t gorse_sparse_get_profile(gorse_sparse *h, int64_t *launches, double *total_ms);
 int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, int64_t *hits);
@@ -280,6 +281,10 @@ void gorse_hip_test_set_sparse_build(int32_t mode);
  * library's own bound (8192, or what 16 GiB of scratch allow).  Trades occupancy against the cache footprint of the
  * accumulators; results never depend on it. */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
+/* queries with more than `dims` entries are answered by row streaming (every stored row merged against the query by one
+ * lane) instead of posting-list walks; default 2048, 0 = never.  Lets small test inputs take that path; results never
+ * depend on it. */
+void gorse_hip_test_set_sparse_heavy(int64_t dims);
 /* the stamp counter of a handle (every query a workgroup answers takes the next 32-bit stamp; when the counter would wrap
  * the library clears the scratch and starts over): lets a test put the counter just below the wrap. */
 int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial);

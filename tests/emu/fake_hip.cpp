@@ -150,5 +150,25 @@ API hipError_t hipLaunchKernel(const void *func, Dim3 grid, Dim3 block, void **a
         });
         return kSuccess;
     }
+    if (name.find("sparse_heavy_score_kernel") != std::string::npos) {
+        const HeavyArgs h = *static_cast<const HeavyArgs *>(args[0]);
+        emu::launch(grid.x < 3 ? grid.x : 3, block.x < 16 ? block.x : 16, [&] { sparse_heavy_score_kernel(h); });
+        return kSuccess;
+    }
+    if (name.find("sparse_heavy_rank_kernel") != std::string::npos) {
+        const HeavyArgs h = *static_cast<const HeavyArgs *>(args[0]);
+        const int kp = template_int(name);
+        emu::launch(grid.x, block.x, [&] {
+            switch (kp) {
+                case 64: sparse_heavy_rank_kernel<64>(h); break;
+                case 128: sparse_heavy_rank_kernel<128>(h); break;
+                case 256: sparse_heavy_rank_kernel<256>(h); break;
+                case 512: sparse_heavy_rank_kernel<512>(h); break;
+                case 1024: sparse_heavy_rank_kernel<1024>(h); break;
+                default: std::fprintf(stderr, "fake HIP runtime: unknown KP in %s\n", name.c_str()); std::abort();
+            }
+        });
+        return kSuccess;
+    }
     return g_last = kInvalidDeviceFunction;
 }

@@ -11,6 +11,8 @@
 using namespace gorse::sparse;
 
 static int g_device_build = 0;
+static int64_t g_heavy_dims = 0;  // > 0: queries with more entries go through the row-streaming kernels, as in sparse.hip
+extern "C" __attribute__((visibility("default"))) void emu_sparse_set_heavy(int64_t dims) { g_heavy_dims = dims; }
 // 1: emu_sparse_search also runs the postings build kernels, checks them against the host build and lets the query kernel
 // walk the lists they produced
 extern "C" __attribute__((visibility("default"))) void emu_sparse_set_device_build(int on) { g_device_build = on; }
@@ -68,6 +70,7 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
     a.q_ptr = q_ptr ? q_ptr : indptr, a.q_idx = q_ptr ? q_idx : indices, a.q_val = q_ptr ? q_val : values;
     a.q_first = q_ptr ? 0 : q_first, a.nq = nq;
     a.exclude = exclude, a.exclude_self = exclude_self, a.mask = mask, a.N = N;
+    a.heavy_dims = g_heavy_dims > 0 ? g_heavy_dims : INT64_MAX;
     a.n_admissible = N;
     if (mask) {
         a.n_admissible = 0;
@@ -89,6 +92,34 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
             }
         };
         emu::launch((unsigned)grid, (unsigned)block, body);
+        // the queries the kernel skipped, kHeavyBatch per pass over the stored rows (sparse.hip's run_queries)
+        std::vector<int64_t> rp((size_t)N + 1);
+        for (int64_t r2 = 0; r2 <= N; r2++) rp[(size_t)r2] = indptr[r2] - indptr[0];
+        std::vector<int64_t> heavy;
+        for (int64_t t = 0; t < nq; t++)
+            if (a.q_ptr[a.q_first + t + 1] - a.q_ptr[a.q_first + t] > a.heavy_dims) heavy.push_back(t);
+        std::vector<float> hscore((size_t)kHeavyBatch * N);
+        std::vector<uint8_t> hcommon((size_t)kHeavyBatch * N);
+        HeavyArgs ha;
+        ha.r_ptr = rp.data(), ha.r_idx = indices + indptr[0], ha.r_val = values + indptr[0], ha.N = N;
+        ha.q_ptr = a.q_ptr, ha.q_idx = a.q_idx, ha.q_val = a.q_val, ha.q_first = a.q_first;
+        ha.score = hscore.data(), ha.common = hcommon.data();
+        ha.exclude = exclude, ha.exclude_self = exclude_self, ha.mask = mask, ha.n_admissible = a.n_admissible;
+        ha.k = k, ha.out_idx = out_idx, ha.out_score = out_score, ha.out_cnt = out_cnt, ha.stat = stat2;
+        for (size_t at = 0; at < heavy.size(); at += kHeavyBatch) {
+            ha.nb = (int)(heavy.size() - at < (size_t)kHeavyBatch ? heavy.size() - at : (size_t)kHeavyBatch);
+            for (int b = 0; b < kHeavyBatch; b++) ha.hq[b] = b < ha.nb ? heavy[at + b] : 0;
+            emu::launch(2, (unsigned)block, [&] { sparse_heavy_score_kernel(ha); });
+            emu::launch((unsigned)ha.nb, (unsigned)(block < kp ? block : kp), [&] {
+                switch (kp) {
+                    case 64: sparse_heavy_rank_kernel<64>(ha); break;
+                    case 128: sparse_heavy_rank_kernel<128>(ha); break;
+                    case 256: sparse_heavy_rank_kernel<256>(ha); break;
+                    case 512: sparse_heavy_rank_kernel<512>(ha); break;
+                    default: sparse_heavy_rank_kernel<1024>(ha); break;
+                }
+            });
+        }
     }
     return 0;
 }

@@ -13,6 +13,7 @@ extern "C" int emu_sparse_search(int64_t N, const int64_t *indptr, const uint32_
                                  int rounds, uint32_t serial_base, int32_t *out_idx, float *out_score, int32_t *out_cnt,
                                  unsigned long long *stat2);
 extern "C" void emu_sparse_set_device_build(int on);
+extern "C" void emu_sparse_set_heavy(int64_t dims);
 
 int main() {
     std::mt19937 rng(5);
@@ -30,6 +31,7 @@ int main() {
     }
     int rc = 0;
     emu_sparse_set_device_build(1);  // the postings build kernels run under the sanitizer too
+    emu_sparse_set_heavy(7);         // and so do the row-streaming kernels: rows with more than 7 of the 24 indices
     for (int k : {5, 70}) {  // KP = 64 (many overflows with ~690 hits per query) and KP = 128
         const int64_t nq = 24;
         std::vector<int32_t> oi((size_t)nq * k), oc((size_t)nq);

@@ -125,6 +125,33 @@ def properties(ptr, out_idx, out_sc, out_cnt, k):
     assert (out_cnt[empty] == 0).all()
 
 
+@pytest.mark.parametrize("k", [5, 70])
+def test_heavy_queries_take_the_row_streaming_path(oracle, k):
+    """queries with more entries than the threshold (2048 by default, 6 here) are merged against every stored row by one
+    lane each instead of walking posting lists: same results, in one call together with light queries, masks, exclusions,
+    negative and cancelling scores, more than one batch of heavy queries"""
+    rng = np.random.default_rng(47)
+    ptr, idx, val = random_csr(rng, 900, 80, 0, 14, neg=True, zipf=True)
+    n_heavy = int((np.diff(ptr) > 6).sum())
+    assert n_heavy > 2 * 8 and n_heavy < 800  # several batches of heavy queries next to light ones
+    mask = (rng.random(900) < 0.8).astype(np.uint8)
+    s = capi.Sparse(ptr, idx, val)
+    capi.lib().gorse_hip_test_set_sparse_heavy(6)
+    try:
+        got = s.all_pairs(k)
+        check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(900)), list(range(900)))
+        s.set_mask(mask)
+        qp, qi, qv = random_csr(rng, 30, 95, 0, 25, neg=True)
+        excl = rng.integers(-1, 900, 30).astype(np.int64)
+        got = s.search(qp, qi, qv, k, exclude=excl)
+        check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(30)), list(excl), mask)
+    finally:
+        capi.lib().gorse_hip_test_set_sparse_heavy(2048)
+    light = s.search(qp, qi, qv, k, exclude=excl)  # the same call on posting lists only
+    for a, b in zip(got, light):
+        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+
+
 def test_stamp_counter_wraps_by_clearing_the_scratch(oracle):
     """every answered query takes the next 32-bit stamp of its workgroup's scratch; just below 2^32 the library clears the
     scratch and restarts -- without the clear, cells stamped 1, 2, ... by the first call would pass for already reached"""

@@ -155,7 +155,8 @@ def _gpu_cases():
     for name in sorted(dir(G)):
         if not name.startswith("test_") or name in ("test_argument_errors", "test_reference_suite_sparse",
                                                     "test_stamp_counter_wraps_by_clearing_the_scratch",
-                                                    "test_postings_built_on_the_device_give_the_same_results"):
+                                                    "test_postings_built_on_the_device_give_the_same_results",
+                                                    "test_heavy_queries_take_the_row_streaming_path"):
             continue  # these drive sparse.hip itself (tests/test_sparse_fake_runtime_cpu.py runs them); the database suite
             # has its own emulated run below
         if name == "test_many_hits_overflow_the_ranking_buffer":
@@ -256,3 +257,20 @@ def test_postings_built_by_the_device_kernels(emu, oracle, block):
             check(oracle, ptr, idx, val, 6, got, rows_of(ptr, idx, val, range(rows)), list(range(rows)))
     finally:
         emu.emu_sparse_set_device_build(0)
+
+
+@pytest.mark.parametrize("block", [1, 8, 64])
+def test_heavy_queries_by_row_streaming(emu, oracle, block):
+    """sparse_heavy_score_kernel + sparse_heavy_rank_kernel under emulation: queries with more than 5 entries are merged against
+    every stored row instead of walking posting lists; light and heavy queries in one call, three batches of heavy ones"""
+    rng = np.random.default_rng(60 + block)
+    ptr, idx, val = random_csr(rng, 150, 40, 0, 12, neg=True, zipf=True)
+    assert 16 < int((np.diff(ptr) > 5).sum()) < 140
+    mask = (rng.random(150) < 0.8).astype(np.uint8)
+    emu.emu_sparse_set_heavy(5)
+    try:
+        for k in (4, 70):
+            got = run_emu(emu, ptr, idx, val, k, 150, exclude_self=1, mask=mask, grid=3, block=block)
+            check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(150)), list(range(150)), mask)
+    finally:
+        emu.emu_sparse_set_heavy(0)
