@@ -26,7 +26,7 @@ _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
-# name -> (restype, argtypes); mirrors include/gorse_hip.h one to one
+# name -> (restype, argtypes); mirrors include/gorse_hip.h (the boundary) and include/gorse_hip_test.h (test hooks) one to one
 SIGNATURES = {
     "gorse_hip_abi_version": (C.c_int32, []),
     "gorse_hip_last_error": (C.c_char_p, []),

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/gorse_hip.h"
+#include "../../include/gorse_hip_test.h"
 
 namespace gorse {
 

@@ -241,72 +241,6 @@ int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t 
                         const float *a /*host*/, int32_t lda, const float *b /*host*/, int32_t ldb, float *c /*host*/,
                         int32_t ldc);
 
-/* ---- test hook -------------------------------------------------------------------------
- * exp flavour used by the GORSE_BPR_SEQUENTIAL schedule: 0 = device expf (default),
- * 1 = the float32 FreeBSD/math32 scheme restated in oracle/gorse_oracle.c (orc_exp_restated),
- * which makes device and oracle factors comparable bit for bit. */
-void gorse_hip_test_set_exact_exp(int32_t mode);
-/* probe-only switches of the Hogwild update path (bit 0: plain instead of L1-bypassing loads; bits 1/2/3:
- * skip the writes to P / Q[i] / Q[j]; bit 5: no hot-row replicas = the round-1 kernel; bit 6: the
- * experimental item-run schedule (window-sorted triplets, q_i register-resident across a run), with bits
- * 8..11: 1 + log2 of its run-block length, bits 12..16: log2 of its sort window, bits 20..23: log2 of its
- * resident workgroup count); bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
- * register-resident over a user's samples), bit 28: force the per-sample schedule, bit 29: the user sort ranks
- * samples in stream order (single thread; makes a run's order deterministic for the parity test).  Used by
- * scripts/gpu_probe_*.py and the tests; 0 (the default) is the only value the product ever runs with. */
-void gorse_hip_test_set_variant(int32_t variant);
-/* top-k path choice: 0 = automatic (MFMA sweep for >= 64 queries, any of the three metrics, k <= 255), 1 = always the
- * literal scan (path A), 2 = the MFMA sweep whenever its operands exist.  Both paths return identical results;
- * the hook exists so the parity tests can drive each one. */
-void gorse_hip_test_set_topk_path(int32_t path);
-/* probe switches of the MFMA sweep: bit 0 = 64 candidate rows per LDS tile, bit 1 = 128 (default: what the library
- * ships with), bit 2 / bit 3 = block-level row-scale bound of the cosine sweep off / on (default: on when all norms
- * are within 2 % of each other), bit 4 = the instrumented twin (see below), bit 5 / bit 6 = compact a candidate list
- * when one of its two sub-lists exceeds 128 / 96 entries (default 224), bit 7 = the candidate path of the C4-shaped
- * sweep votes on each score row wave-wide before touching it (written without a GPU; to be measured).  Results never
- * depend on them. */
-void gorse_hip_test_set_topk_variant(int32_t variant);
-/* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its twelve
- * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the
- * candidate paths inside [1], [3] barrier wait, then [4] row blocks examined, [5] row blocks with a candidate, [6]
- * kernel ticks, [7] waves, and the candidate path split into [8] count + exchange, [9] appends, [10] compaction
- * check / compaction, with [11] lanes that appended. */
-int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/);
-/* where gorse_sparse_create builds the posting lists of a handle created AFTERWARDS: 0 = on the host (counting sort, the
- * default this round), 1 = on the device (sparse_count_kernel / sparse_scan_kernel / sparse_scatter_kernel over the
- * uploaded CSR).  Written without a GPU and checked through the CPU emulation only; it becomes the default once the GPU
- * test that compares both builds has run.  Results never depend on it. */
-void gorse_hip_test_set_sparse_build(int32_t mode);
-/* probe: at most this many workgroups (= queries in flight, each with its 12 N bytes of scratch) per sparse launch; 0 = the
- * library's own bound (8192, or what 16 GiB of scratch allow).  Trades occupancy against the cache footprint of the
- * accumulators; results never depend on it. */
-void gorse_hip_test_set_sparse_slots(int64_t max_slots);
-/* queries with more than `dims` entries are answered by row streaming (every stored row merged against the query by one
- * lane) instead of posting-list walks; default 2048, 0 = never.  Lets small test inputs take that path; results never
- * depend on it. */
-void gorse_hip_test_set_sparse_heavy(int64_t dims);
-/* the stamp counter of a handle (every query a workgroup answers takes the next 32-bit stamp; when the counter would wrap
- * the library clears the scratch and starts over): lets a test put the counter just below the wrap. */
-int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial);
-/* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
- * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
- * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */
-void gorse_hip_test_set_als_path(int32_t path);
-/* thresholds of the Gram-form row plan, for handles created AFTERWARDS: rows longer than long_row feedbacks
- * are cut into chunks of `chunk` entries (defaults 4096 / 4096; <= 0 restores a default).  Lets small test
- * inputs exercise the long-row path. */
-void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk);
-/* probe: enable != 0 makes als_row_kernel stamp its phases with s_memtime; out16 (may be NULL) receives, for the last
- * user half-sweep and then the last item half-sweep, ticks summed over the waves in [0] Gram accumulation (gathers +
- * MFMA), [1] M to LDS, [2] the d-step solve, then [3] rows, [4] feedback entries, [5] kernel ticks, [6] waves, [7] 0. */
-int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16 /*host or NULL*/);
-/* the counting sort by positive item that precedes the item-run update kernel, on a host-supplied
- * chunk (n <= one chunk = 4M samples): su/si/sj receive the triplets in the order the kernel walks them
- * (per window of 32768 consecutive samples: ascending i, skipped samples last). */
-int32_t gorse_hip_test_item_sort(gorse_mf *h, const int32_t *u /*host*/, const int32_t *i /*host*/,
-                                 const int32_t *j /*host*/, int64_t n, int32_t *su /*host*/, int32_t *si /*host*/,
-                                 int32_t *sj /*host*/);
-
 #ifdef __cplusplus
 }
 #endif

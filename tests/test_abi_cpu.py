@@ -11,10 +11,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "gorse_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gorse_[a-z0-9_]+)\s*\(", src)))
+def header_functions(names=("gorse_hip.h", "gorse_hip_test.h")):
+    out = set()
+    for name in names:
+        src = open(os.path.join(ROOT, "include", name)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(gorse_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
 
 
 def test_library_builds_and_exports_every_declared_symbol():
@@ -29,6 +32,9 @@ def test_library_builds_and_exports_every_declared_symbol():
     # the ctypes table mirrors the header one to one
     assert set(capi.SIGNATURES) == set(names)
     assert capi.lib().gorse_hip_abi_version() == 1
+    # the drop-in boundary carries no test hook, the hook header nothing else
+    assert not [n for n in header_functions(("gorse_hip.h",)) if n.startswith("gorse_hip_test_")]
+    assert all(n.startswith("gorse_hip_test_") for n in header_functions(("gorse_hip_test.h",)))
 
 
 def test_no_device_fails_loudly():
