@@ -19,10 +19,10 @@ def test_unvalidated_gpu_modules_in_a_child_process():
     child = subprocess.Popen([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files, cwd=ROOT, env=env,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
     try:
-        out, _ = child.communicate(timeout=900)
+        out, _ = child.communicate(timeout=240)
     except subprocess.TimeoutExpired:
         os.killpg(child.pid, signal.SIGKILL)
         out, _ = child.communicate()
-        pytest.fail("the isolated GPU modules did not finish within 900 s (killed)\n" + (out or "")[-4000:])
+        pytest.fail("the isolated GPU modules did not finish within 240 s (killed)\n" + (out or "")[-4000:])
     print(out[-6000:])  # shown with -rP / on failure: the child's own summary
     assert child.returncode == 0, "isolated GPU modules: exit code %d\n%s" % (child.returncode, out[-6000:])
