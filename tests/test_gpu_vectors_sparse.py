@@ -152,6 +152,46 @@ def test_heavy_queries_take_the_row_streaming_path(oracle, k):
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
 
 
+def test_random_configurations(oracle):
+    """thirty random small problems, each with random k, mask, exclusions and random settings of the library's switches
+    (heavy-query threshold, queries in flight, where the postings are built): every answer equals the oracle's"""
+    rng = np.random.default_rng(2027)
+    L = capi.lib()
+    try:
+        for case in range(30):
+            rows, dims = int(rng.integers(1, 400)), int(rng.integers(1, 120))
+            hi = int(rng.integers(0, min(dims, 30) + 1))
+            ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
+            L.gorse_hip_test_set_sparse_build(int(rng.integers(0, 2)))
+            L.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 1, 3, 8, 2048])))
+            L.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
+            s = capi.Sparse(ptr, idx, val)
+            k = int(rng.choice([1, 2, 7, 64, 65, 300]))
+            mask = None
+            if rng.random() < 0.5:
+                mask = (rng.random(rows) < rng.random()).astype(np.uint8)  # anything from nearly all hidden to all visible
+                s.set_mask(mask)
+            if rng.random() < 0.5:
+                q0 = int(rng.integers(0, rows))
+                q1 = int(rng.integers(q0, rows + 1))
+                self_out = bool(rng.integers(0, 2))
+                got = s.all_pairs(k, q0, q1, exclude_self=self_out)
+                if q1 > q0:
+                    check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(q0, q1)),
+                          list(range(q0, q1)) if self_out else [-1] * (q1 - q0), mask)
+            else:
+                nq = int(rng.integers(1, 40))
+                qp, qi, qv = random_csr(rng, nq, dims + 5, 0, min(dims + 5, 40), neg=True)
+                excl = rng.integers(-1, rows, nq).astype(np.int64) if rng.random() < 0.5 else None
+                got = s.search(qp, qi, qv, k, exclude=excl)
+                check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(nq)), list(excl) if excl is not None else [-1] * nq, mask)
+            s.close()
+    finally:
+        L.gorse_hip_test_set_sparse_build(0)
+        L.gorse_hip_test_set_sparse_heavy(2048)
+        L.gorse_hip_test_set_sparse_slots(0)
+
+
 def test_stamp_counter_wraps_by_clearing_the_scratch(oracle):
     """every answered query takes the next 32-bit stamp of its workgroup's scratch; just below 2^32 the library clears the
     scratch and restarts -- without the clear, cells stamped 1, 2, ... by the first call would pass for already reached"""
