@@ -20,7 +20,7 @@ struct gorse_sparse {
     // stored rows as CSR (the queries of all_pairs) and as postings (what every query walks)
     DevBuf<int64_t> r_ptr, p_ptr;
     DevBuf<uint32_t> r_idx;
-    DevBuf<int32_t> p_row;
+    DevBuf<int32_t> p_row, orig_of;  // posting lists hold scratch ids (longest row first); orig_of maps them back
     DevBuf<float> r_val, p_val;
     DevBuf<uint8_t> mask;
     bool has_mask = false;
@@ -53,6 +53,7 @@ struct gorse_sparse {
 namespace {
 
 int64_t g_sparse_heavy_dims = 2048;  // queries with more entries than this take the row-streaming path (test hook)
+int g_sparse_hot = 0;  // probe: 512 / 1024 = that many of the longest rows keep their accumulators in LDS (0 = none)
 int g_sparse_build = 0;  // 0 = postings built on the host (default), 1 = by the device kernels (test hook, see gorse_hip.h)
 
 constexpr int64_t kScratchBudget = (int64_t)16 << 30;  // bytes of accumulator scratch (of 288 GB of HBM)
@@ -77,7 +78,12 @@ int32_t ensure_scratch(gorse_sparse *h, int64_t want) {
 
 template <int KP>
 void launch_query(const QueryArgs &a, unsigned grid, hipStream_t s) {
-    sparse::sparse_query_kernel<KP><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
+    if (g_sparse_hot == 512)
+        sparse::sparse_query_kernel<KP, 512><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
+    else if (g_sparse_hot == 1024)
+        sparse::sparse_query_kernel<KP, 1024><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
+    else
+        sparse::sparse_query_kernel<KP, 0><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
 }
 template <int KP>
 void launch_heavy_rank(const sparse::HeavyArgs &a, hipStream_t s) {
@@ -113,6 +119,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
     a.n_admissible = h->has_mask ? h->n_admissible : h->N;
     a.N = h->N;
     a.cell = h->cell.p, a.touched = h->touched.p;
+    a.orig_of = h->orig_of.p;
     a.serial_base = h->serial;
     a.k = k;
     a.out_idx = h->out_idx.p, a.out_score = h->out_score.p, a.out_cnt = h->out_cnt.p;
@@ -186,12 +193,13 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
     if (device < 0 || device >= ndev) return fail(GORSE_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
     const bool on_device = g_sparse_build == 1;
+    const sparse::RowOrder order = sparse::order_rows(N, indptr);
     sparse::Postings post;
     if (on_device) {  // only the index space is needed from the host
         for (int64_t t = base; t < base + nnz; t++) post.D = indices[t] >= post.D ? (int64_t)indices[t] + 1 : post.D;
         if (post.D > sparse::kMaxDims) return fail(GORSE_ERR_INVALID, "largest index %lld exceeds the supported index space", (long long)(post.D - 1));
     } else {
-        const std::string why = sparse::build_postings(N, indptr, indices, values, post);
+        const std::string why = sparse::build_postings(N, indptr, indices, values, post, order.new_of.data());
         if (!why.empty()) return fail(GORSE_ERR_INVALID, "%s", why.c_str());
     }
     gorse_sparse *h = new (std::nothrow) gorse_sparse();
@@ -211,6 +219,8 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         GORSE_TRY(h->r_val.alloc((size_t)nnz));
         GORSE_TRY(h->p_ptr.alloc((size_t)post.D + 1));
         GORSE_TRY(h->p_row.alloc((size_t)nnz));
+        GORSE_TRY(h->orig_of.alloc((size_t)N));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->orig_of.p, order.orig_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_TRY(h->p_val.alloc((size_t)nnz));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->r_ptr.p, ptr0.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, h->stream));
         if (nnz > 0) {
@@ -219,19 +229,22 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         }
         if (on_device) {  // counting sort of the uploaded CSR entries by index: count, scan (one workgroup), scatter
             DevBuf<unsigned long long> cursor;
+            DevBuf<int32_t> new_of;
             GORSE_TRY(cursor.alloc((size_t)post.D));
+            GORSE_TRY(new_of.alloc((size_t)N));
+            GORSE_HIP_CHECK(hipMemcpyAsync(new_of.p, order.new_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemsetAsync(h->p_ptr.p, 0, ((size_t)post.D + 1) * 8, h->stream));
             sparse::BuildArgs b;
             b.r_ptr = h->r_ptr.p, b.r_idx = h->r_idx.p, b.r_val = h->r_val.p;
             b.N = N, b.nnz = nnz, b.D = post.D;
             b.p_ptr = reinterpret_cast<unsigned long long *>(h->p_ptr.p), b.cursor = cursor.p;
-            b.p_row = h->p_row.p, b.p_val = h->p_val.p;
+            b.p_row = h->p_row.p, b.p_val = h->p_val.p, b.new_of = new_of.p;
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, ceil_div(nnz, 256)));
             sparse::sparse_count_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(b);
             sparse::sparse_scan_kernel<<<dim3(1), dim3(sparse::kScanBlock), 0, h->stream>>>(b);
             sparse::sparse_scatter_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(b);
             GORSE_HIP_CHECK(hipGetLastError());
-            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // `cursor` is freed when this scope ends
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // `cursor` and `new_of` are freed when this scope ends
         } else {
             GORSE_HIP_CHECK(hipMemcpyAsync(h->p_ptr.p, post.ptr.data(), ((size_t)post.D + 1) * 8, hipMemcpyHostToDevice,
                                            h->stream));
@@ -358,6 +371,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 extern "C" void gorse_hip_test_set_sparse_build(int32_t mode) { g_sparse_build = mode; }
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 extern "C" void gorse_hip_test_set_sparse_heavy(int64_t dims) { g_sparse_heavy_dims = dims; }
+extern "C" void gorse_hip_test_set_sparse_hot(int32_t rows) { g_sparse_hot = rows; }
 extern "C" int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
     h->serial = serial;

@@ -1,7 +1,9 @@
 // sparse_host.hpp -- host-side index construction of the sparse top-k (no HIP in here: sparse.hip uses it before the
 // upload, tests/emu/sparse_emu.cpp uses the very same code in front of the emulated kernel).
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -26,7 +28,27 @@ inline std::string validate_csr(int64_t rows, const int64_t *indptr, const uint3
     return "";
 }
 
-// Postings (the transposed CSR) by counting sort: list t holds the rows that contain index t, in ascending row order.
+// Scratch numbering of the stored rows: longest row first (ties by row).  Rows with many entries are the ones most queries
+// reach, so the first H scratch ids are where an LDS-resident slice of the accumulators pays; results, masks and
+// exclusions keep the caller's row ids (orig_of translates back).
+struct RowOrder {
+    std::vector<int32_t> new_of;   // caller's row -> scratch id
+    std::vector<int32_t> orig_of;  // scratch id -> caller's row
+};
+inline RowOrder order_rows(int64_t N, const int64_t *indptr) {
+    RowOrder o;
+    o.orig_of.resize((size_t)N);
+    o.new_of.resize((size_t)N);
+    std::iota(o.orig_of.begin(), o.orig_of.end(), 0);
+    std::stable_sort(o.orig_of.begin(), o.orig_of.end(), [&](int32_t a, int32_t b) {
+        return indptr[a + 1] - indptr[a] > indptr[b + 1] - indptr[b];
+    });
+    for (int64_t t = 0; t < N; t++) o.new_of[(size_t)o.orig_of[(size_t)t]] = (int32_t)t;
+    return o;
+}
+
+// Postings (the transposed CSR) by counting sort: list t holds the (scratch ids of the) rows that contain index t, in
+// ascending order of the caller's row ids.
 // D = largest index + 1 (0 without entries).
 struct Postings {
     int64_t D = 0;
@@ -34,8 +56,9 @@ struct Postings {
     std::vector<int32_t> row;   // nnz
     std::vector<float> val;     // nnz
 };
+// `new_of` (may be null = identity): the id stored for row r
 inline std::string build_postings(int64_t N, const int64_t *indptr, const uint32_t *indices, const float *values,
-                                  Postings &out) {
+                                  Postings &out, const int32_t *new_of = nullptr) {
     const int64_t b = N > 0 ? indptr[0] : 0, e = N > 0 ? indptr[N] : 0;
     int64_t D = 0;
     for (int64_t t = b; t < e; t++) D = indices[t] >= D ? (int64_t)indices[t] + 1 : D;
@@ -50,7 +73,7 @@ inline std::string build_postings(int64_t N, const int64_t *indptr, const uint32
     for (int64_t r = 0; r < N; r++)
         for (int64_t t = indptr[r]; t < indptr[r + 1]; t++) {
             const int64_t at = cur[indices[t]]++;
-            out.row[(size_t)at] = (int32_t)r;
+            out.row[(size_t)at] = new_of ? new_of[r] : (int32_t)r;
             out.val[(size_t)at] = values[t];
         }
     return "";

@@ -54,6 +54,9 @@ struct QueryArgs {
     const uint8_t *mask;     // admissible[row] or null
     int64_t n_admissible;    // number of admissible rows (N without a mask)
     int64_t N;
+    // posting lists and scratch use SCRATCH ids (longest stored row first, sparse_host.hpp order_rows); orig_of translates
+    // back to the caller's row ids, which masks, exclusions and results use
+    const int32_t *orig_of;
     // scratch, N entries per workgroup each: (stamp, accumulator) pairs -- one 8-byte access per posting -- and the list
     // of rows the current query has reached
     Cell *cell;
@@ -168,10 +171,13 @@ __device__ inline void write_result(const unsigned long long *s_buf, int cnt, in
     if (tid == 0) out_cnt[t] = cnt;
 }
 
-template <int KP>
+// HOT > 0 (probe, off by default): the cells of scratch ids < HOT -- the longest stored rows, which under a popularity
+// law take most of the hits -- live in LDS instead of the workgroup's global scratch row.
+template <int KP, int HOT>
 __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
     constexpr int CAP = 2 * KP;
     __shared__ unsigned long long s_buf[CAP];
+    __shared__ Cell s_hot[HOT > 0 ? HOT : 1];
     __shared__ unsigned long long s_thr;  // keys <= s_thr cannot be among the k best
     __shared__ int s_cnt;                 // rows touched by the current query
     __shared__ int s_bcnt;                // slots handed out in s_buf
@@ -180,6 +186,10 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
     Cell *cell = a.cell + (int64_t)blockIdx.x * a.N;
     int32_t *touched = a.touched + (int64_t)blockIdx.x * a.N;
     uint32_t serial = a.serial_base;
+    if (HOT > 0) {  // LDS does not survive a launch: stamp 0 = "reached by no query" (serials start at 1)
+        for (int i = tid; i < HOT; i += nt) s_hot[i] = 0;
+        __syncthreads();
+    }
     for (int64_t t = blockIdx.x; t < a.nq; t += gridDim.x) {
         serial++;
         if (tid == 0) {
@@ -205,9 +215,10 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
             for (int64_t p = ps + tid; p < pe; p += nt) {
                 const int32_t row = a.p_row[p];
                 const float term = __fmul_rn(qv, a.p_val[p]);
-                const Cell c = cell[row];
+                Cell *at = (HOT > 0 && row < HOT) ? &s_hot[row] : &cell[row];
+                const Cell c = *at;
                 const bool first = cell_stamp(c) != serial;
-                cell[row] = make_cell(serial, __fadd_rn(first ? 0.0f : cell_acc(c), term));
+                *at = make_cell(serial, __fadd_rn(first ? 0.0f : cell_acc(c), term));
                 if (first) touched[atomicAdd(&s_cnt, 1)] = row;
             }
             __syncthreads();
@@ -219,9 +230,10 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
         rank_candidates<KP>(
             T,
             [&](int64_t i) -> unsigned long long {
-                const int32_t row = touched[i];
+                const int32_t sid = touched[i];
+                const int32_t row = a.orig_of[sid];
                 if ((int64_t)row == ex || (a.mask && !a.mask[row])) return 0;
-                const uint32_t ord = score_ord(cell_acc(cell[row]));
+                const uint32_t ord = score_ord(cell_acc((HOT > 0 && sid < HOT) ? s_hot[sid] : cell[sid]));
                 if (ord == kZeroOrd) return 0;  // a zero score is dropped by the reference's wrapper
                 my_pos += ord > kZeroOrd;
                 my_neg += ord < kZeroOrd;
@@ -375,6 +387,7 @@ struct BuildArgs {
     unsigned long long *cursor;  // D: next free slot of every list during the scatter
     int32_t *p_row;
     float *p_val;
+    const int32_t *new_of;  // scratch id of every row (what the posting lists store)
 };
 
 // p_ptr[t + 1] = number of entries with index t
@@ -425,7 +438,7 @@ __global__ void sparse_scatter_kernel(BuildArgs a) {
                 hi = mid;
         }
         const unsigned long long at = atomicAdd(&a.cursor[a.r_idx[e]], 1ull);
-        a.p_row[at] = (int32_t)lo;
+        a.p_row[at] = a.new_of[lo];
         a.p_val[at] = a.r_val[e];
     }
 }

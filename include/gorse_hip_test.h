@@ -56,6 +56,10 @@ void gorse_hip_test_set_sparse_slots(int64_t max_slots);
  * lane) instead of posting-list walks; default 2048, 0 = never.  Lets small test inputs take that path; results never
  * depend on it. */
 void gorse_hip_test_set_sparse_heavy(int64_t dims);
+/* probe: 512 or 1024 = the accumulators of that many stored rows -- the longest ones, which under a popularity law take
+ * most of the hits -- live in LDS instead of the workgroup's global scratch row (fewer workgroups fit a CU in exchange);
+ * 0 = none (default).  Results never depend on it. */
+void gorse_hip_test_set_sparse_hot(int32_t rows);
 /* the stamp counter of a handle (every query a workgroup answers takes the next 32-bit stamp; when the counter would wrap
  * the library clears the scratch and starts over): lets a test put the counter just below the wrap. */
 int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial);

@@ -12,11 +12,12 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from gorse_amd import capi, synth  # noqa: E402
 
 
-def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0, heavy=2048):
+def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0, heavy=2048, hot=0):
     L = capi.lib()
     L.gorse_hip_test_set_sparse_build(device_build)
     L.gorse_hip_test_set_sparse_slots(slots)
     L.gorse_hip_test_set_sparse_heavy(heavy)
+    L.gorse_hip_test_set_sparse_hot(hot)
     t0 = time.perf_counter()
     s = capi.Sparse(ptr, idx, val)
     t_create = time.perf_counter() - t0
@@ -31,14 +32,15 @@ def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0, heavy=2048)
     postings, hits = s.last_stats()
     per = ms / max(n, 1)
     n_heavy = int((np.diff(ptr) > heavy).sum()) if heavy > 0 else 0
-    print("%-44s N=%8d nnz=%10d k=%3d slots=%5s heavy>%5d (%5d queries) build=%s create %7.3f s  all-pairs %9.3f ms (wall %9.3f)  postings %.3e  "
+    print("%-44s N=%8d nnz=%10d k=%3d slots=%5s heavy>%5d (%5d queries) hot=%4d build=%s create %7.3f s  all-pairs %9.3f ms (wall %9.3f)  postings %.3e  "
           "%.3e postings/s  %8.1f GB/s algorithmic  hit rows/query %.0f"
-          % (name, s.N, int(ptr[-1]), k, slots or "max", heavy, n_heavy, "device" if device_build else "host", t_create, per, wall * 1e3,
+          % (name, s.N, int(ptr[-1]), k, slots or "max", heavy, n_heavy, hot, "device" if device_build else "host", t_create, per, wall * 1e3,
              postings, postings / (per * 1e-3), postings * 8 / (per * 1e-3) / 1e9, hits / s.N), flush=True)
     s.close()
     L.gorse_hip_test_set_sparse_build(0)
     L.gorse_hip_test_set_sparse_slots(0)
     L.gorse_hip_test_set_sparse_heavy(2048)
+    L.gorse_hip_test_set_sparse_hot(0)
 
 
 def main():
@@ -55,6 +57,8 @@ def main():
         run(name + " items user-to-user", *u2u)
         for slots in (256, 1024, 4096):
             run(name + " users item-to-item", *i2i, slots=slots)
+        for hot in (512, 1024):  # accumulators of the longest rows in LDS
+            run(name + " users item-to-item", *i2i, hot=hot)
         for heavy in (0, 512, 8192):  # 0 = posting lists only: the longest query sets the launch time
             run(name + " users item-to-item", *i2i, heavy=heavy)
 

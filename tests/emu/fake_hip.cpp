@@ -35,8 +35,9 @@ size_t g_cfg_shmem;
 hipStream_t g_cfg_stream;
 int g_fatbin_token;
 
-int template_int(const std::string &name) {  // "...kernelILi128EEE..." -> 128
-    const size_t at = name.find("ILi");
+int template_int(const std::string &name, int which = 0) {  // "...kernelILi128ELi512EEE...": 0 -> 128, 1 -> 512
+    size_t at = name.find("ILi");
+    for (int w = 0; w < which && at != std::string::npos; w++) at = name.find("ELi", at + 1);
     return at == std::string::npos ? 0 : std::atoi(name.c_str() + at + 3);
 }
 }  // namespace
@@ -121,15 +122,16 @@ API hipError_t hipLaunchKernel(const void *func, Dim3 grid, Dim3 block, void **a
     if (grid.y != 1 || grid.z != 1 || block.y != 1 || block.z != 1) return g_last = kInvalidValue;
     if (name.find("sparse_query_kernel") != std::string::npos) {
         const QueryArgs a = *static_cast<const QueryArgs *>(args[0]);
-        const int kp = template_int(name);
+        const int kp = template_int(name, 0), hot = template_int(name, 1);
         emu::launch(grid.x, block.x, [&] {
-            switch (kp) {
-                case 64: sparse_query_kernel<64>(a); break;
-                case 128: sparse_query_kernel<128>(a); break;
-                case 256: sparse_query_kernel<256>(a); break;
-                case 512: sparse_query_kernel<512>(a); break;
-                case 1024: sparse_query_kernel<1024>(a); break;
-                default: std::fprintf(stderr, "fake HIP runtime: unknown KP in %s\n", name.c_str()); std::abort();
+            switch (kp * 10000 + hot) {
+#define Q(KP, HOT) \
+    case KP * 10000 + HOT: sparse_query_kernel<KP, HOT>(a); break;
+                Q(64, 0) Q(128, 0) Q(256, 0) Q(512, 0) Q(1024, 0)
+                Q(64, 512) Q(128, 512) Q(256, 512) Q(512, 512) Q(1024, 512)
+                Q(64, 1024) Q(128, 1024) Q(256, 1024) Q(512, 1024) Q(1024, 1024)
+#undef Q
+                default: std::fprintf(stderr, "fake HIP runtime: unknown instantiation %s\n", name.c_str()); std::abort();
             }
         });
         return kSuccess;

@@ -11,6 +11,8 @@
 using namespace gorse::sparse;
 
 static int g_device_build = 0;
+static int g_hot = 0;  // 512: the query kernel keeps the cells of the 512 longest rows in (emulated) LDS
+extern "C" __attribute__((visibility("default"))) void emu_sparse_set_hot(int rows) { g_hot = rows; }
 static int64_t g_heavy_dims = 0;  // > 0: queries with more entries go through the row-streaming kernels, as in sparse.hip
 extern "C" __attribute__((visibility("default"))) void emu_sparse_set_heavy(int64_t dims) { g_heavy_dims = dims; }
 // 1: emu_sparse_search also runs the postings build kernels, checks them against the host build and lets the query kernel
@@ -29,8 +31,9 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
                                  unsigned long long *stat2) {
     if (!validate_csr(N, indptr, indices).empty()) return -1;
     if (q_ptr && !validate_csr(nq, q_ptr, q_idx).empty()) return -1;
+    const RowOrder order = order_rows(N, indptr);
     Postings post;
-    if (!build_postings(N, indptr, indices, values, post).empty()) return -1;
+    if (!build_postings(N, indptr, indices, values, post, order.new_of.data()).empty()) return -1;
     if (g_device_build) {  // the same postings from the three build kernels (entries of a list in any order)
         const int64_t nnz = indptr[N] - indptr[0], D = post.D;
         std::vector<int64_t> rp((size_t)N + 1);
@@ -42,6 +45,7 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
         b.r_ptr = rp.data(), b.r_idx = indices + indptr[0], b.r_val = values + indptr[0];
         b.N = N, b.nnz = nnz, b.D = D;
         b.p_ptr = pp.data(), b.cursor = cursor.data(), b.p_row = prow.data(), b.p_val = pval.data();
+        b.new_of = order.new_of.data();
         emu::launch(3, (unsigned)block, [&] { sparse_count_kernel(b); });
         emu::launch(1, (unsigned)(block < kScanBlock ? block : kScanBlock), [&] { sparse_scan_kernel(b); });
         emu::launch(2, (unsigned)block, [&] { sparse_scatter_kernel(b); });
@@ -55,6 +59,7 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
                 x.emplace_back(post.row[(size_t)e], post.val[(size_t)e]);
                 y.emplace_back(prow[(size_t)e], pval[(size_t)e]);
             }
+            std::sort(x.begin(), x.end());
             std::sort(y.begin(), y.end());
             if (x != y) return -4;
         }
@@ -77,18 +82,29 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
         for (int64_t r = 0; r < N; r++) a.n_admissible += mask[r] != 0;
     }
     a.cell = cell.data(), a.touched = touched.data();
+    a.orig_of = order.orig_of.data();
     a.k = k, a.out_idx = out_idx, a.out_score = out_score, a.out_cnt = out_cnt, a.stat = stat2;
     const uint32_t per_launch = (uint32_t)((nq + grid - 1) / grid);
     for (int r = 0; r < rounds; r++) {
         if (stat2) stat2[0] = stat2[1] = 0;
         a.serial_base = serial_base + (uint32_t)r * per_launch;
         auto body = [&] {
+            if (g_hot == 512) {
+                switch (kp) {
+                    case 64: sparse_query_kernel<64, 512>(a); break;
+                    case 128: sparse_query_kernel<128, 512>(a); break;
+                    case 256: sparse_query_kernel<256, 512>(a); break;
+                    case 512: sparse_query_kernel<512, 512>(a); break;
+                    default: sparse_query_kernel<1024, 512>(a); break;
+                }
+                return;
+            }
             switch (kp) {
-                case 64: sparse_query_kernel<64>(a); break;
-                case 128: sparse_query_kernel<128>(a); break;
-                case 256: sparse_query_kernel<256>(a); break;
-                case 512: sparse_query_kernel<512>(a); break;
-                default: sparse_query_kernel<1024>(a); break;
+                case 64: sparse_query_kernel<64, 0>(a); break;
+                case 128: sparse_query_kernel<128, 0>(a); break;
+                case 256: sparse_query_kernel<256, 0>(a); break;
+                case 512: sparse_query_kernel<512, 0>(a); break;
+                default: sparse_query_kernel<1024, 0>(a); break;
             }
         };
         emu::launch((unsigned)grid, (unsigned)block, body);

@@ -154,17 +154,19 @@ def test_heavy_queries_take_the_row_streaming_path(oracle, k):
 
 def test_random_configurations(oracle):
     """thirty random small problems, each with random k, mask, exclusions and random settings of the library's switches
-    (heavy-query threshold, queries in flight, where the postings are built): every answer equals the oracle's"""
+    (heavy-query threshold, queries in flight, where the postings are built, how many rows accumulate in LDS): every answer
+    equals the oracle's"""
     rng = np.random.default_rng(2027)
     L = capi.lib()
     try:
         for case in range(30):
-            rows, dims = int(rng.integers(1, 400)), int(rng.integers(1, 120))
+            rows, dims = int(rng.integers(1, 400 if case % 3 else 1500)), int(rng.integers(1, 120))
             hi = int(rng.integers(0, min(dims, 30) + 1))
             ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
             L.gorse_hip_test_set_sparse_build(int(rng.integers(0, 2)))
             L.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 1, 3, 8, 2048])))
             L.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
+            L.gorse_hip_test_set_sparse_hot(int(rng.choice([0, 512, 1024])))
             s = capi.Sparse(ptr, idx, val)
             k = int(rng.choice([1, 2, 7, 64, 65, 300]))
             mask = None
@@ -190,6 +192,7 @@ def test_random_configurations(oracle):
         L.gorse_hip_test_set_sparse_build(0)
         L.gorse_hip_test_set_sparse_heavy(2048)
         L.gorse_hip_test_set_sparse_slots(0)
+        L.gorse_hip_test_set_sparse_hot(0)
 
 
 def test_stamp_counter_wraps_by_clearing_the_scratch(oracle):

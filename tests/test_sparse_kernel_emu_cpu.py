@@ -275,3 +275,21 @@ def test_heavy_queries_by_row_streaming(emu, oracle, block):
             check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(150)), list(range(150)), mask)
     finally:
         emu.emu_sparse_set_heavy(0)
+
+
+@pytest.mark.parametrize("block", [4, 64])
+def test_hot_rows_in_lds(emu, oracle, block):
+    """sparse_query_kernel<KP, 512>: the accumulators of the 512 longest stored rows live in LDS, the others in the global
+    scratch row; both kinds in every query, stamps carried across the queries of a workgroup and across launches"""
+    rng = np.random.default_rng(70 + block)
+    ptr, idx, val = random_csr(rng, 1300, 90, 0, 9, neg=True, zipf=True)
+    mask = (rng.random(1300) < 0.85).astype(np.uint8)
+    emu.emu_sparse_set_hot(512)
+    try:
+        got = run_emu(emu, ptr, idx, val, 9, 140, q_first=600, exclude_self=1, mask=mask, grid=3, block=block, rounds=2)
+        check(oracle, ptr, idx, val, 9, got, rows_of(ptr, idx, val, range(600, 740)), list(range(600, 740)), mask)
+        small = random_csr(rng, 40, 12, 1, 5)  # fewer rows than LDS cells
+        got = run_emu(emu, *small, 5, 40, exclude_self=0, grid=2, block=block)
+        check(oracle, *small, 5, got, rows_of(*small, range(40)), [-1] * 40)
+    finally:
+        emu.emu_sparse_set_hot(0)
