@@ -367,6 +367,24 @@ class StandInSparse:
         return I, S, Cn
 
 
+class StandInTopK:
+    """capi.TopK's all_pairs (SearchIndex for every stored vector: distances ascending, padded with -1 / +inf) with the
+    oracle as the compute (tests only)"""
+
+    def __init__(self, X, metric):
+        from oracle import oracle as orc
+        self.o, self.X, self.metric, self.N = orc.Oracle(), X, metric, X.shape[0]
+
+    def all_pairs(self, k, q_begin=0, q_end=None):
+        q_end = self.N if q_end is None else q_end
+        I = np.full((q_end - q_begin, k), -1, np.int32)
+        D = np.full((q_end - q_begin, k), np.inf, np.float32)
+        for t, q in enumerate(range(q_begin, q_end)):
+            ei, ed = self.o.search_index(self.X, self.metric, q, k)
+            I[t, :ei.size], D[t, :ei.size] = ei, ed
+        return I, D
+
+
 def _i2i_problem():
     data = synth.synth_cf(400, 53, 500, seed=21, min_len=1, with_test=False)  # 53 items: shards of unequal size
     return synth.idf_vectors(data.iptr, data.iidx, data.U)
@@ -379,7 +397,10 @@ def _refresh_worker(rank, world, port, out):
     ptr, idx, val = _i2i_problem()
     eng = gdist.HipNeighborsEngine(StandInSparse(ptr, idx, val), device="cpu")
     I, S, Cn = gdist.refresh_neighbors_sharded(eng, gdist.TorchComm(), 12)
-    np.savez(os.path.join(out, "nb%d.npz" % rank), I=I, S=S, Cn=Cn)
+    # the same refresh over a dense index (embedding item-to-item): 23 vectors, k = 30 > N - 1, so every row is padded
+    X = np.random.default_rng(5).standard_normal((23, 8)).astype(np.float32)
+    dI, dD, dC = gdist.refresh_neighbors_sharded(gdist.HipNeighborsEngine(StandInTopK(X, 1), device="cpu"), gdist.TorchComm(), 30)
+    np.savez(os.path.join(out, "nb%d.npz" % rank), I=I, S=S, Cn=Cn, dI=dI, dD=dD, dC=dC)
     dist.destroy_process_group()
 
 
@@ -397,3 +418,9 @@ def test_sharded_neighbor_refresh_equals_the_single_process_result(tmp_path, wor
         got = np.load(tmp_path / ("nb%d.npz" % r))
         assert np.array_equal(got["I"], I) and np.array_equal(got["S"].view(np.uint32), S.view(np.uint32))
         assert np.array_equal(got["Cn"], Cn)
+    X = np.random.default_rng(5).standard_normal((23, 8)).astype(np.float32)
+    dI, dD = StandInTopK(X, 1).all_pairs(30)
+    for r in range(world):
+        got = np.load(tmp_path / ("nb%d.npz" % r))
+        assert np.array_equal(got["dI"], dI) and np.array_equal(got["dD"].view(np.uint32), dD.view(np.uint32))
+        assert (got["dC"] == 22).all()
