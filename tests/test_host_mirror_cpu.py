@@ -230,3 +230,43 @@ def test_corrupt_model_files_are_rejected_not_crashed_on():
         try_load(bytes(b))
         g = bytes(b[11:11 + glen])
         H.gh_gob_decode_params(g, len(g), None, 0)
+
+
+def test_dataset_idf_like_the_reference():
+    # dataset/dataset_test.go:170-196 (TestDataset_AddFeedback): user i gives feedback to items i..9
+    d = cf.Dataset()
+    for i in range(10):
+        d.AddUser(i)
+    for i in range(10):
+        d.AddItem(i)
+    for i in range(10):
+        for j in range(i, 10):
+            d.AddFeedback(i, j)
+    user_idf, item_idf = d.GetUserIDF(), d.GetItemIDF()
+    assert user_idf.size == 10 and item_idf.size == 10
+    for i in range(10):
+        assert abs(user_idf[i] - np.log(np.float32(1) + np.float32(10) / np.float32(10 - i))) < 1e-6  # the reference asks 1e-2
+        assert abs(item_idf[i] - np.log(np.float32(1) + np.float32(10) / np.float32(i + 1))) < 1e-6
+    # the same numbers from the oracle's restatement and from the synthetic-data helper (what the GPU tests feed the kernel)
+    from oracle import oracle as orc
+    assert np.array_equal(orc.Oracle().idf([10 - i for i in range(10)], 10), user_idf)
+
+
+def test_synthetic_idf_vectors_equal_the_writer_of_the_twin():
+    """gorse_amd.synth.idf_vectors (the sparse vectors bench.py and the GPU tests feed the kernel) are what the "users"
+    item-to-item writer produces from the dataset twin's GetUserIDF: ids ascending, value float32(sqrt(float64(idf)))"""
+    from gorse_amd import synth
+    data = synth.synth_cf(60, 45, 700, seed=4, min_len=2, with_test=False)
+    train = cf.Dataset()
+    for u in range(data.U):
+        train.AddUser(u)
+    for i in range(data.I):
+        train.AddItem(i)
+    rows = np.repeat(np.arange(data.U, dtype=np.int32), np.diff(data.uptr))
+    train.add_feedback_arrays(rows, data.uidx)
+    idf = train.GetUserIDF()
+    ptr, idx, val = synth.idf_vectors(data.iptr, data.iidx, data.U)
+    for i in range(data.I):
+        users = np.sort(data.iidx[data.iptr[i]:data.iptr[i + 1]])
+        assert np.array_equal(idx[ptr[i]:ptr[i + 1]], users.astype(np.uint32))
+        assert np.array_equal(val[ptr[i]:ptr[i + 1]], np.sqrt(idf[users].astype(np.float64)).astype(np.float32))
