@@ -88,6 +88,46 @@ class Dataset:
     def CountFeedback(self):
         return host().gh_dataset_count_feedback(self.p)
 
+    @classmethod
+    def _wrap(cls, ptr):
+        d = cls.__new__(cls)
+        d.p = C.c_void_p(ptr)
+        return d
+
+    def SplitCF(self, numTestUsers, seed):
+        """dataset.go:258-318: (train, test) by user-leave-one-out; the production split is SplitCF(0, 0) (master/tasks.go:232)"""
+        a, b = C.c_void_p(), C.c_void_p()
+        H = host()
+        H.gh_dataset_split_cf.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        _ck(H.gh_dataset_split_cf(self.p, int(numTestUsers), int(seed), C.byref(a), C.byref(b)))
+        return Dataset._wrap(a.value), Dataset._wrap(b.value)
+
+    @staticmethod
+    def LoadNCF(train_text, test_text):
+        """LoadDataFromBuiltIn (dataset.go:398-490) on the contents of train.txt / test.txt"""
+        a, b = C.c_void_p(), C.c_void_p()
+        H = host()
+        H.gh_dataset_load_ncf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        _ck(H.gh_dataset_load_ncf(train_text.encode(), test_text.encode(), C.byref(a), C.byref(b)))
+        return Dataset._wrap(a.value), Dataset._wrap(b.value)
+
+    def _row(self, side, row):
+        H = host()
+        H.gh_dataset_row.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, C.c_int32]
+        n = H.gh_dataset_row(self.p, side, int(row), None, 0)
+        out = np.zeros(max(n, 1), np.int32)
+        H.gh_dataset_row(self.p, side, int(row), out.ctypes.data_as(_i32p), out.size)
+        return out[:n].tolist()
+
+    def GetUserFeedback(self):
+        return [self._row(0, u) for u in range(self.CountUsers())]
+
+    def GetItemFeedback(self):
+        return [self._row(1, i) for i in range(self.CountItems())]
+
+    def Negatives(self, user):
+        return self._row(2, user)
+
     def _idf(self, side, n):
         H = host()
         H.gh_dataset_idf.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_int32]

@@ -14,6 +14,7 @@
 //   heap::TopKFilter, heap::PriorityQueue               common/heap/filter.go, pq.go
 //   ann::Index, ann::Bruteforce                         common/ann/ann.go, bruteforce.go
 #pragma once
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <functional>
@@ -329,6 +330,89 @@ class Dataset {
         const_cast<Dataset *>(this)->itemFeedback_.resize((size_t)CountItems());
         return itemFeedback_;
     }
+    // SplitCF (dataset.go:258-318): leave-one-out per user.  numTestUsers <= 0 or >= CountUsers(): every user with feedback
+    // gives one (rng.Intn) of its items to the test set; otherwise only numTestUsers sampled users do.  The splits share
+    // this dataset's dictionaries.  (Which item / which users depends on the generator: Go's stream is not reproducible
+    // here, SURVEY.md 8c -- the structure and the counts are.)
+    std::pair<Dataset, Dataset> SplitCF(int numTestUsers, int64_t seed) const {
+        Dataset train(*this, true), test(*this, true);
+        const int U = CountUsers();
+        train.userFeedback_.resize((size_t)U), test.userFeedback_.resize((size_t)U);
+        train.itemFeedback_.resize((size_t)CountItems()), test.itemFeedback_.resize((size_t)CountItems());
+        util::RandomGenerator rng(seed);
+        const auto &uf = GetUserFeedback();
+        auto leave_one_out = [&](int32_t u) {
+            const auto &row = uf[(size_t)u];
+            if (row.empty()) return;
+            const int k = rng.Intn((int)row.size());
+            test.add_indexed(u, row[(size_t)k]);
+            for (size_t i = 0; i < row.size(); i++)
+                if ((int)i != k) train.add_indexed(u, row[i]);
+        };
+        if (numTestUsers >= U || numTestUsers <= 0) {
+            for (int32_t u = 0; u < U; u++) leave_one_out(u);
+        } else {
+            const std::vector<int32_t> testUsers = rng.SampleInt32(0, U, numTestUsers, {});
+            for (int32_t u : testUsers) leave_one_out(u);
+            const std::set<int32_t> chosen(testUsers.begin(), testUsers.end());
+            for (int32_t u = 0; u < U; u++)
+                if (!chosen.count(u))
+                    for (int32_t i : uf[(size_t)u]) train.add_indexed(u, i);
+        }
+        return {std::move(train), std::move(test)};
+    }
+    // LoadDataFromBuiltIn without the download (dataset.go:398-490): train.txt = "user<TAB>item[<TAB>...]"
+    // per line, users / items 0..max all created; test.txt = "(user,item)<TAB>neg<TAB>neg..." per line, the negatives kept
+    // per user and -- like the reference, which looks them up with itemDict.Add -- counted in the item dictionary.
+    static std::pair<Dataset, Dataset> LoadNCF(std::istream &trainFile, std::istream &testFile) {
+        Dataset train;
+        std::string line;
+        auto split = [](const std::string &l, char sep) {
+            std::vector<std::string> out(1);
+            for (char c : l)
+                if (c == sep)
+                    out.emplace_back();
+                else
+                    out.back().push_back(c);
+            return out;
+        };
+        auto parse = [](const std::string &f) {  // util.ParseInt[int32]
+            size_t used = 0;
+            long long v = 0;
+            try {
+                v = std::stoll(f, &used);
+            } catch (const std::exception &) {
+                used = 0;
+            }
+            if (f.empty() || used != f.size() || v < INT32_MIN || v > INT32_MAX) throw std::invalid_argument("invalid integer: " + f);
+            return (int32_t)v;
+        };
+        while (std::getline(trainFile, line)) {
+            const auto f = split(line, '\t');
+            if (f.size() < 2) throw std::invalid_argument("wrong format: " + line);
+            const int32_t u = parse(f[0]), i = parse(f[1]);
+            for (int32_t t = train.userDict_->Count(); t <= u; t++) train.AddUser(std::to_string(t));
+            for (int32_t t = train.itemDict_->Count(); t <= i; t++) train.AddItem(std::to_string(t));
+            train.AddFeedback(f[0], f[1]);
+        }
+        Dataset test(train, true);
+        test.negatives_.resize(train.userFeedback_.size());
+        while (std::getline(testFile, line)) {
+            const auto f = split(line, '\t');
+            const std::string &pos = f[0];
+            if (pos.size() < 2 || pos.front() != '(' || pos.back() != ')') throw std::invalid_argument("wrong format: " + line);
+            const auto pair = split(pos.substr(1, pos.size() - 2), ',');
+            if (pair.size() < 2) throw std::invalid_argument("wrong format: " + line);
+            test.AddFeedback(pair[0], pair[1]);
+            const int32_t u = parse(pair[0]);
+            if (u < 0 || (size_t)u >= test.negatives_.size()) throw std::out_of_range("index out of range: " + pair[0]);  // a Go panic
+            std::vector<int32_t> negs;
+            for (size_t t = 1; t < f.size(); t++) negs.push_back(test.itemDict_->Add(f[t]));
+            test.negatives_[(size_t)u] = std::move(negs);
+        }
+        return {std::move(train), std::move(test)};
+    }
+    const std::vector<std::vector<int32_t>> &Negatives() const { return negatives_; }
     // GetUserIDF / GetItemIDF (dataset.go:160-180): idf = math32.Log(1 + float32(#other side) / float32(freq)); the
     // weights of the sparse "users" item-to-item and "items" user-to-user vectors (logics/vector_writer.go:192-209).
     // math32.Log (chewxy/math32 v1.11.1) restated as the float64 logarithm narrowed to float32.
@@ -358,6 +442,11 @@ class Dataset {
     }
 
    private:
+    void add_indexed(int32_t u, int32_t i) {  // a feedback between existing dense indices, dictionaries untouched
+        userFeedback_[(size_t)u].push_back(i);
+        itemFeedback_[(size_t)i].push_back(u);
+        numFeedback_++;
+    }
     static std::vector<float> idf(const FreqDict &dict, int other) {
         std::vector<float> out((size_t)dict.Count());
         for (int32_t t = 0; t < dict.Count(); t++)

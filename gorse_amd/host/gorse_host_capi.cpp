@@ -66,6 +66,32 @@ void gh_dataset_set_negatives(void *d, int32_t user, const int32_t *neg, int32_t
 int32_t gh_dataset_count_users(void *d) { return ((dataset::Dataset *)d)->CountUsers(); }
 int32_t gh_dataset_count_items(void *d) { return ((dataset::Dataset *)d)->CountItems(); }
 int32_t gh_dataset_count_feedback(void *d) { return ((dataset::Dataset *)d)->CountFeedback(); }
+// SplitCF(numTestUsers, seed): two new datasets (free both)
+int32_t gh_dataset_split_cf(void *d, int32_t num_test_users, int64_t seed, void **train, void **test) {
+    return guard([&] {
+        auto pr = ((dataset::Dataset *)d)->SplitCF(num_test_users, seed);
+        *train = new dataset::Dataset(std::move(pr.first));
+        *test = new dataset::Dataset(std::move(pr.second));
+    });
+}
+// LoadDataFromBuiltIn's two files, given as text
+int32_t gh_dataset_load_ncf(const char *train_txt, const char *test_txt, void **train, void **test) {
+    return guard([&] {
+        std::istringstream a(train_txt), b(test_txt);
+        auto pr = dataset::Dataset::LoadNCF(a, b);
+        *train = new dataset::Dataset(std::move(pr.first));
+        *test = new dataset::Dataset(std::move(pr.second));
+    });
+}
+// row `row` of GetUserFeedback (side 0) / GetItemFeedback (side 1) / the stored negatives (side 2); returns its length
+int32_t gh_dataset_row(void *d, int32_t side, int32_t row, int32_t *out, int32_t cap) {
+    auto *ds = (dataset::Dataset *)d;
+    const auto &m = side == 0 ? ds->GetUserFeedback() : (side == 1 ? ds->GetItemFeedback() : ds->Negatives());
+    if (row < 0 || (size_t)row >= m.size()) return 0;
+    const auto &r = m[(size_t)row];
+    for (size_t t = 0; t < r.size() && (int32_t)t < cap; t++) out[t] = r[t];
+    return (int32_t)r.size();
+}
 // GetUserIDF (side 0) / GetItemIDF (side 1) into out[CountUsers() / CountItems() of the dictionary]
 int32_t gh_dataset_idf(void *d, int32_t side, float *out, int32_t cap) {
     auto v = side == 0 ? ((dataset::Dataset *)d)->GetUserIDF() : ((dataset::Dataset *)d)->GetItemIDF();

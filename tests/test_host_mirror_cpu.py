@@ -270,3 +270,52 @@ def test_synthetic_idf_vectors_equal_the_writer_of_the_twin():
         users = np.sort(data.iidx[data.iptr[i]:data.iptr[i + 1]])
         assert np.array_equal(idx[ptr[i]:ptr[i + 1]], users.astype(np.uint32))
         assert np.array_equal(val[ptr[i]:ptr[i + 1]], np.sqrt(idf[users].astype(np.float64)).astype(np.float32))
+
+
+def test_dataset_split_cf_like_the_reference():
+    # dataset/dataset_test.go:198-230 (TestDataset_Split): 3 users, 5 items, user i -> items i+1 .. 4
+    d = cf.Dataset()
+    for u in range(3):
+        d.AddUser("user%d" % u)
+    for i in range(5):
+        d.AddItem("item%d" % i)
+    for u in range(3):
+        for i in range(u + 1, 5):
+            d.AddFeedback("user%d" % u, "item%d" % i)
+    assert d.CountFeedback() == 9
+    train, test = d.SplitCF(0, 0)
+    assert (train.CountUsers(), train.CountItems(), train.CountFeedback()) == (3, 5, 9 - 3)
+    assert (test.CountUsers(), test.CountItems(), test.CountFeedback()) == (3, 5, 3)
+    train2, test2 = d.SplitCF(2, 0)
+    assert (train2.CountUsers(), train2.CountItems(), train2.CountFeedback()) == (3, 5, 7)
+    assert (test2.CountUsers(), test2.CountItems(), test2.CountFeedback()) == (3, 5, 2)
+    # leave-one-out: per user the two splits partition the original row; both directions stay consistent
+    full = d.GetUserFeedback()
+    for tr, te in ((train, test), (train2, test2)):
+        for u in range(3):
+            a, b = tr.GetUserFeedback()[u], te.GetUserFeedback()[u]
+            assert len(b) <= 1 and sorted(a + b) == sorted(full[u])
+        for ds in (tr, te):
+            pairs = sorted((u, i) for u, row in enumerate(ds.GetUserFeedback()) for i in row)
+            assert pairs == sorted((u, i) for i, col in enumerate(ds.GetItemFeedback()) for u in col)
+    a, b = d.SplitCF(0, 7), d.SplitCF(0, 7)  # seeded: repeatable
+    assert a[1].GetUserFeedback() == b[1].GetUserFeedback()
+
+
+def test_load_ncf_files():
+    """LoadDataFromBuiltIn's formats (dataset.go:423-490): users / items 0..max all created, one
+    held-out positive and the fixed negatives per test line, the negatives looked up with itemDict.Add (a new id extends
+    the dictionary both splits share)"""
+    train_txt = "0\t1\t5\t978300760\n0\t3\n2\t0\n2\t3\n"
+    test_txt = "(0,2)\t4\t1\n(2,1)\t3\t7\n"
+    train, test = cf.Dataset.LoadNCF(train_txt, test_txt)
+    assert (train.CountUsers(), train.CountFeedback()) == (3, 4)       # user 1 exists without feedback
+    assert train.GetUserFeedback() == [[1, 3], [], [0, 3]]
+    assert test.GetUserFeedback() == [[2], [], [1]] and test.CountFeedback() == 2
+    assert test.Negatives(0) == [4, 1] and test.Negatives(1) == [] and test.Negatives(2) == [3, 5]  # "7" is new: dense index 5
+    assert train.CountItems() == 6 and test.CountItems() == 6        # items 0..3 from train.txt, "4" and "7" from the negatives
+    for bad in ("(0,2\t4\n", "0,2)\t4\n", "(9,2)\t4\n"):
+        with pytest.raises(cf.HostError):
+            cf.Dataset.LoadNCF(train_txt, bad)
+    with pytest.raises(cf.HostError):
+        cf.Dataset.LoadNCF("0\tx\n", "")
