@@ -99,6 +99,34 @@ int32_t gh_dataset_idf(void *d, int32_t side, float *out, int32_t cap) {
     return (int32_t)v.size();
 }
 
+// ---- FreqDict / RandomGenerator (test hooks over dataset/dict.go, common/util/random.go) --------------------------------------
+void *gh_freqdict_new() { return new dataset::FreqDict(); }
+void gh_freqdict_free(void *d) { delete (dataset::FreqDict *)d; }
+int32_t gh_freqdict_add(void *d, const char *s) { return ((dataset::FreqDict *)d)->Add(s); }
+int32_t gh_freqdict_add_no_count(void *d, const char *s) { return ((dataset::FreqDict *)d)->AddNoCount(s); }
+int32_t gh_freqdict_count(void *d) { return ((dataset::FreqDict *)d)->Count(); }
+int32_t gh_freqdict_freq(void *d, int32_t id) { return ((dataset::FreqDict *)d)->Freq(id); }
+int32_t gh_freqdict_id(void *d, const char *s) { return ((dataset::FreqDict *)d)->Id(s); }
+void gh_rng_normal_matrix(int64_t seed, int64_t rows, int64_t cols, float mean, float stddev, float *out) {
+    util::RandomGenerator rng(seed);
+    std::vector<float> m;
+    rng.NormalMatrix(rows, cols, mean, stddev, m);
+    std::copy(m.begin(), m.end(), out);
+}
+// successive SampleInt32(low, high, n[i], exclude) calls on ONE generator, like random_test.go:51-59; out = concatenation
+int32_t gh_rng_sample_int32(int64_t seed, int32_t low, int32_t high, const int32_t *ns, int32_t n_calls, const int32_t *exclude,
+                            int32_t n_exclude, int32_t *out, int32_t *out_lens) {
+    util::RandomGenerator rng(seed);
+    const std::set<int32_t> ex(exclude, exclude + n_exclude);
+    int32_t at = 0;
+    for (int32_t c = 0; c < n_calls; c++) {
+        auto v = rng.SampleInt32(low, high, ns[c], ex);
+        out_lens[c] = (int32_t)v.size();
+        for (int32_t x : v) out[at++] = x;
+    }
+    return at;
+}
+
 // ---- models ------------------------------------------------------------------------------------
 static model::Params make_params(const char **names, const double *vals, int32_t n) {
     model::Params p;

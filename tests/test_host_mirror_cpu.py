@@ -319,3 +319,43 @@ def test_load_ncf_files():
             cf.Dataset.LoadNCF(train_txt, bad)
     with pytest.raises(cf.HostError):
         cf.Dataset.LoadNCF("0\tx\n", "")
+
+
+def test_freq_dict_like_the_reference():
+    # dataset/dict_test.go:25-39
+    H = cf.host()
+    H.gh_freqdict_new.restype = C.c_void_p
+    for f in ("gh_freqdict_add", "gh_freqdict_add_no_count", "gh_freqdict_id"):
+        getattr(H, f).argtypes = [C.c_void_p, C.c_char_p]
+    H.gh_freqdict_count.argtypes = [C.c_void_p]
+    H.gh_freqdict_freq.argtypes = [C.c_void_p, C.c_int32]
+    H.gh_freqdict_free.argtypes = [C.c_void_p]
+    d = C.c_void_p(H.gh_freqdict_new())
+    assert [H.gh_freqdict_add(d, s) for s in (b"a", b"b", b"b", b"c", b"c", b"c")] == [0, 1, 1, 2, 2, 2]
+    assert H.gh_freqdict_count(d) == 3
+    assert [H.gh_freqdict_freq(d, i) for i in range(3)] == [1, 2, 3]
+    assert H.gh_freqdict_id(d, b"a") == 0 and H.gh_freqdict_id(d, b"e") == -1
+    assert H.gh_freqdict_add_no_count(d, b"z") == 3 and H.gh_freqdict_freq(d, 3) == 0  # AddNoCount (dict.go)
+    H.gh_freqdict_free(d)
+
+
+def test_random_generator_like_the_reference():
+    # common/util/random_test.go:29-60: NormalMatrix moments within 0.1; SampleInt32 never returns an excluded value
+    H = cf.host()
+    H.gh_rng_normal_matrix.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    v = np.zeros(1000, np.float32)
+    H.gh_rng_normal_matrix(0, 1, 1000, 1.0, 2.0, v.ctypes.data_as(C.POINTER(C.c_float)))
+    assert abs(v.mean() - 1) <= 0.1 and abs(v.std(ddof=1) - 2) <= 0.1
+    ip = C.POINTER(C.c_int32)
+    H.gh_rng_sample_int32.argtypes = [C.c_int64, C.c_int32, C.c_int32, ip, C.c_int32, ip, C.c_int32, ip, ip]
+    ns = np.arange(1, 11, dtype=np.int32)
+    ex = np.arange(5, dtype=np.int32)
+    out, lens = np.zeros(100, np.int32), np.zeros(10, np.int32)
+    total = H.gh_rng_sample_int32(0, 0, 10, ns.ctypes.data_as(ip), 10, ex.ctypes.data_as(ip), 5, out.ctypes.data_as(ip), lens.ctypes.data_as(ip))
+    assert not set(out[:total]) & set(ex) and set(out[:total]) <= set(range(5, 10))
+    # n >= what is left: everything that is not excluded, in order (random.go:112-120); otherwise n distinct values
+    assert lens.tolist() == [1, 2, 3, 4, 5, 5, 5, 5, 5, 5]
+    at = 0
+    for n in lens:
+        assert len(set(out[at:at + n])) == n
+        at += n
