@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--i2i-shape", default="c3", choices=["c3", "ml1m", "ml100k"])
     ap.add_argument("--als-scale", type=float, default=1.0, help="shrink S-als (users, items, feedbacks) by this factor")
     ap.add_argument("--no-topk", action="store_true", help="skip the item x item top-k leg of the default run")
+    ap.add_argument("--no-i2i", action="store_true", help="skip the sparse item-to-item leg of the default single-GPU run")
+    ap.add_argument("--i2i-timeout", type=float, default=240.0, help="seconds the sparse leg's child process may take")
     ap.add_argument("--topk-n", type=int, default=1_000_000)
     ap.add_argument("--topk-steps", type=int, default=2)
     ap.add_argument("--topk-budget", type=float, default=60.0, help="seconds the timed top-k steps may take (see bench_topk)")
@@ -346,6 +348,29 @@ def sparse_cpu_baseline(ptr, idx, val, k, seconds, sp, q_begin):
                       "with the GPU rows" % (len(qs), N, threads, dt)}
 
 
+def i2i_in_a_child(args):
+    """The sparse item-to-item leg of the default run, in a CHILD process with a time limit: its kernels were
+    written after round 1's GPU budget was spent and have not run on a device, and nothing that happens to them may cost
+    the line its headline numbers.  Returns the child's JSON object, or {"error": ...}."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "i2i", "--i2i-shape", args.i2i_shape, "--steps", "3", "--warmup", "1",
+           "--cpu-seconds", str(args.cpu_seconds)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    try:
+        child = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            so, se = child.communicate(timeout=args.i2i_timeout)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(child.pid, signal.SIGKILL)
+            child.communicate()
+            return {"error": "no result within %.0f s (child killed)" % args.i2i_timeout}
+        lines = [l for l in so.splitlines() if l.startswith("{")]
+        if child.returncode != 0 or not lines:
+            return {"error": "exit code %d: %s" % (child.returncode, (se or so)[-600:])}
+        return json.loads(lines[-1])
+    except Exception as e:  # a report, never a reason to lose the line
+        return {"error": repr(e)}
+
+
 def als_cpu_baseline(uptr, uidx, iptr, P, Q, w, reg, seconds):
     """The oracle's half-sweep (kind 'port', model.go:659-690) on a prefix of the user rows, T host threads each on
     its own row range (rows are independent: what parallel.Parallel does); the serial d x d Gram pass every call
@@ -571,6 +596,8 @@ def main():
     if rank == 0:
         if topk is not None:
             out["topk"] = topk
+        if args.workload == "ml1m" and world == 1 and not args.no_i2i:
+            out["i2i"] = i2i_in_a_child(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

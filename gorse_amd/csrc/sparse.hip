@@ -52,7 +52,11 @@ struct gorse_sparse {
 
 namespace {
 
-int64_t g_sparse_heavy_dims = 2048;  // queries with more entries than this take the row-streaming path (test hook)
+// Queries with more entries than this take the row-streaming path.  A posting-list walk costs its query about a microsecond
+// per list on one wave (16K lists = a tail of ~16 ms), a row-streaming pass serves eight queries for one read of the stored
+// CSR plus a binary search per (entry, query): worth it for the handful of longest queries of a popularity-skewed
+// collection only (64 of the 200,000 items of the C3 shard exceed 16K users; 622 exceed 2K).  To be tuned on a device.
+int64_t g_sparse_heavy_dims = 16384;
 int g_sparse_hot = 0;  // probe: 512 / 1024 = that many of the longest rows keep their accumulators in LDS (0 = none)
 int g_sparse_build = 0;  // 0 = postings built on the host (default), 1 = by the device kernels (test hook, see gorse_hip.h)
 

@@ -53,7 +53,7 @@ void gorse_hip_test_set_sparse_build(int32_t mode);
  * accumulators; results never depend on it. */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
 /* queries with more than `dims` entries are answered by row streaming (every stored row merged against the query by one
- * lane) instead of posting-list walks; default 2048, 0 = never.  Lets small test inputs take that path; results never
+ * lane) instead of posting-list walks; default 16384, 0 = never.  Lets small test inputs take that path; results never
  * depend on it. */
 void gorse_hip_test_set_sparse_heavy(int64_t dims);
 /* probe: 512 or 1024 = the accumulators of that many stored rows -- the longest ones, which under a popularity law take

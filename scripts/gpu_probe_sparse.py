@@ -12,7 +12,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from gorse_amd import capi, synth  # noqa: E402
 
 
-def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0, heavy=2048, hot=0):
+def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0, heavy=16384, hot=0):
     L = capi.lib()
     L.gorse_hip_test_set_sparse_build(device_build)
     L.gorse_hip_test_set_sparse_slots(slots)
@@ -39,7 +39,7 @@ def run(name, ptr, idx, val, k=100, reps=3, slots=0, device_build=0, heavy=2048,
     s.close()
     L.gorse_hip_test_set_sparse_build(0)
     L.gorse_hip_test_set_sparse_slots(0)
-    L.gorse_hip_test_set_sparse_heavy(2048)
+    L.gorse_hip_test_set_sparse_heavy(16384)
     L.gorse_hip_test_set_sparse_hot(0)
 
 
@@ -59,7 +59,7 @@ def main():
             run(name + " users item-to-item", *i2i, slots=slots)
         for hot in (512, 1024):  # accumulators of the longest rows in LDS
             run(name + " users item-to-item", *i2i, hot=hot)
-        for heavy in (0, 512, 8192):  # 0 = posting lists only: the longest query sets the launch time
+        for heavy in (0, 2048, 8192, 65536):  # 0 = posting lists only: the longest query sets the launch time
             run(name + " users item-to-item", *i2i, heavy=heavy)
 
 

@@ -127,7 +127,7 @@ def properties(ptr, out_idx, out_sc, out_cnt, k):
 
 @pytest.mark.parametrize("k", [5, 70])
 def test_heavy_queries_take_the_row_streaming_path(oracle, k):
-    """queries with more entries than the threshold (2048 by default, 6 here) are merged against every stored row by one
+    """queries with more entries than the threshold (16384 by default, 6 here) are merged against every stored row by one
     lane each instead of walking posting lists: same results, in one call together with light queries, masks, exclusions,
     negative and cancelling scores, more than one batch of heavy queries"""
     rng = np.random.default_rng(47)
@@ -146,7 +146,7 @@ def test_heavy_queries_take_the_row_streaming_path(oracle, k):
         got = s.search(qp, qi, qv, k, exclude=excl)
         check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(30)), list(excl), mask)
     finally:
-        capi.lib().gorse_hip_test_set_sparse_heavy(2048)
+        capi.lib().gorse_hip_test_set_sparse_heavy(16384)
     light = s.search(qp, qi, qv, k, exclude=excl)  # the same call on posting lists only
     for a, b in zip(got, light):
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
@@ -164,7 +164,7 @@ def test_random_configurations(oracle):
             hi = int(rng.integers(0, min(dims, 30) + 1))
             ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
             L.gorse_hip_test_set_sparse_build(int(rng.integers(0, 2)))
-            L.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 1, 3, 8, 2048])))
+            L.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 1, 3, 8, 16384])))
             L.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
             L.gorse_hip_test_set_sparse_hot(int(rng.choice([0, 512, 1024])))
             s = capi.Sparse(ptr, idx, val)
@@ -190,7 +190,7 @@ def test_random_configurations(oracle):
             s.close()
     finally:
         L.gorse_hip_test_set_sparse_build(0)
-        L.gorse_hip_test_set_sparse_heavy(2048)
+        L.gorse_hip_test_set_sparse_heavy(16384)
         L.gorse_hip_test_set_sparse_slots(0)
         L.gorse_hip_test_set_sparse_hot(0)
 

@@ -57,3 +57,19 @@ def test_bench_i2i_leg_on_the_fake_runtime():
     assert out["config"]["postings_per_step_per_gpu"] > 0 and out["config"]["queries_per_step_per_gpu"] == 1682
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and "compared bit for bit" in c["sample"]
+
+
+def test_default_bench_keeps_its_line_whatever_the_sparse_leg_does():
+    """bench.py appends the sparse leg to the default single-GPU line from a child process: no GPU here, so the child fails
+    (or is killed at its time limit) and the parent must get an {"error": ...} object back, never an exception"""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = types.SimpleNamespace(i2i_shape="ml100k", cpu_seconds=0.1, no_cpu_baseline=True, i2i_timeout=300.0)
+    out = bench.i2i_in_a_child(args)
+    assert set(out) == {"error"} and "MI355X" in out["error"]  # "bench.py needs an MI355X (no CPU path exists)"
+    args.i2i_timeout = 0.01
+    out = bench.i2i_in_a_child(args)
+    assert set(out) == {"error"} and "killed" in out["error"]
