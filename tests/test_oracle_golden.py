@@ -256,3 +256,23 @@ def test_idf_formula(oracle):
     out = oracle.idf([1, 2, 50, 100], 100)
     exp = [np.float32(np.log(np.float64(np.float32(1) + np.float32(100) / np.float32(f)))) for f in (1, 2, 50, 100)]
     assert out.tolist() == exp
+
+
+def test_sparse_dot_both_search_strategies_equal_a_plain_sequential_sum(oracle):
+    """orc_sparse_dot merges similar-length lists and binary-searches lopsided ones: both must give the products of the
+    common indices summed in ascending index order in float32, written here as the plainest possible loop"""
+    rng = np.random.default_rng(0)
+    for _ in range(400):
+        D = int(rng.integers(1, 400))
+        na, nb = int(rng.integers(0, min(D, 300) + 1)), int(rng.integers(0, min(D, 30) + 1))
+        ia = np.sort(rng.choice(D, na, replace=False)).astype(np.uint32)
+        ib = np.sort(rng.choice(D, nb, replace=False)).astype(np.uint32)
+        va, vb = rng.standard_normal(na).astype(np.float32), rng.standard_normal(nb).astype(np.float32)
+        da, db = dict(zip(ia.tolist(), va)), dict(zip(ib.tolist(), vb))
+        s = np.float32(0)
+        common = np.intersect1d(ia, ib)
+        for t in common:
+            s = np.float32(s + np.float32(da[int(t)] * db[int(t)]))
+        for x, y in (((ia, va), (ib, vb)), ((ib, vb), (ia, va))):
+            c, got = oracle.sparse_dot(x[0], x[1], y[0], y[1])
+            assert c == common.size and np.float32(got).view(np.uint32) == s.view(np.uint32)
