@@ -89,10 +89,6 @@ void launch_query(const QueryArgs &a, unsigned grid, hipStream_t s) {
     else
         sparse::sparse_query_kernel<KP, 0><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
 }
-template <int KP>
-void launch_heavy_rank(const sparse::HeavyArgs &a, hipStream_t s) {
-    sparse::sparse_heavy_rank_kernel<KP><<<dim3((unsigned)a.nb), dim3(sparse::kBlock), 0, s>>>(a);
-}
 
 // nq queries = CSR rows q_first .. of device arrays (qp, qi, qv); results into the handle's out_* buffers and, where
 // given, the host arrays
@@ -131,8 +127,6 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
     h->serial += (uint32_t)per_slot;
     const int tok = h->prof.begin(0, h->stream);
     switch (kp) {
-        case 64: launch_query<64>(a, (unsigned)grid, h->stream); break;
-        case 128: launch_query<128>(a, (unsigned)grid, h->stream); break;
         case 256: launch_query<256>(a, (unsigned)grid, h->stream); break;
         case 512: launch_query<512>(a, (unsigned)grid, h->stream); break;
         default: launch_query<1024>(a, (unsigned)grid, h->stream); break;
@@ -156,13 +150,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
             ha.nb = (int)std::min<size_t>(sparse::kHeavyBatch, heavy.size() - at);
             for (int b = 0; b < sparse::kHeavyBatch; b++) ha.hq[b] = b < ha.nb ? heavy[at + b] : 0;
             sparse::sparse_heavy_score_kernel<<<dim3(sgrid), dim3(256), 0, h->stream>>>(ha);
-            switch (kp) {
-                case 64: launch_heavy_rank<64>(ha, h->stream); break;
-                case 128: launch_heavy_rank<128>(ha, h->stream); break;
-                case 256: launch_heavy_rank<256>(ha, h->stream); break;
-                case 512: launch_heavy_rank<512>(ha, h->stream); break;
-                default: launch_heavy_rank<1024>(ha, h->stream); break;
-            }
+            sparse::sparse_heavy_rank_kernel<<<dim3((unsigned)ha.nb), dim3(sparse::kHeavyRankBlock), 0, h->stream>>>(ha);
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }

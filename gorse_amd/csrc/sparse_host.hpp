@@ -79,9 +79,10 @@ inline std::string build_postings(int64_t N, const int64_t *indptr, const uint32
     return "";
 }
 
-// LDS ranking buffer: the smallest instantiated KP >= k (0 = k too large)
+// LDS ranking buffer of sparse_query_kernel: the smallest instantiated KP >= k (0 = k too large); 256 at least, because a
+// lane ranks four candidates between two votes of its 64-lane workgroup (sparse_kernels.hpp rank_candidates)
 inline int pick_kp(int k) {
-    for (int kp = 64; kp <= 1024; kp <<= 1)
+    for (int kp = 256; kp <= 1024; kp <<= 1)
         if (k <= kp) return kp;
     return 0;
 }

@@ -28,6 +28,8 @@ namespace gorse {
 namespace sparse {
 
 constexpr int kBlock = 64;  // one wavefront per workgroup: the per-list barrier costs a wave-local s_barrier
+constexpr int kRankUnroll = 4;   // candidates a lane of sparse_query_kernel ranks between two votes (KP >= 4 * kBlock)
+constexpr int kHeavyRankBlock = 1024;  // sparse_heavy_rank_kernel: sixteen waves stream the N rows of one heavy query
 
 // One scratch cell per (workgroup, stored row): low word = serial of the last query that reached the row, high word = the
 // bits of its running inner product.  Kept as ONE 64-bit integer so that a posting costs one 8-byte load and one 8-byte
@@ -117,37 +119,45 @@ __device__ inline void sort_desc(unsigned long long *b, int tid, int nt) {
 }
 
 // The ranking shared by both query paths: candidates i = 0 .. count-1, key_at(i) = its 64-bit key or 0 for "not a candidate"
-// (called once per i by the lane that owns it).  Leaves the min(buffered, CAP) best keys sorted descending in s_buf and
-// returns how many are buffered (> 0 only).  s_thr / s_bcnt must be 0 on entry; needs blockDim.x <= KP (after a cut to KP
-// the CAP - KP free slots take every lane still waiting).  All lanes of the workgroup call it together.
-template <int KP, typename KeyAt>
+// (called once per i by the lane that owns it).  Every lane takes U candidates between two votes of the workgroup (a vote
+// is a barrier, and a query that reaches most of 200,000 rows would otherwise pay 3000 of them on its one wave).  Leaves
+// the min(buffered, CAP) best keys sorted descending in s_buf and returns how many are buffered (> 0 only).  s_thr / s_bcnt
+// must be 0 on entry; needs U * blockDim.x <= KP (after a cut to KP the CAP - KP free slots take every candidate still
+// waiting).  All lanes of the workgroup call it together.
+template <int KP, int U, typename KeyAt>
 __device__ inline int rank_candidates(int64_t count, KeyAt key_at, int k, unsigned long long *s_buf, unsigned long long *s_thr,
                                       int *s_bcnt, int tid, int nt) {
     constexpr int CAP = 2 * KP;
-    for (int64_t base = 0; base < count; base += nt) {
-        const int64_t i = base + tid;
-        const unsigned long long key = i < count ? key_at(i) : 0;  // 0 is below every real key
-        bool want = key > *s_thr;
+    for (int64_t base = 0; base < count; base += (int64_t)nt * U) {
+        unsigned long long key[U];
+        bool want[U];
+        const unsigned long long thr = *s_thr;
+        for (int u = 0; u < U; u++) {
+            const int64_t i = base + (int64_t)u * nt + tid;
+            key[u] = i < count ? key_at(i) : 0;  // 0 is below every real key
+            want[u] = key[u] > thr;
+        }
         while (true) {
             bool over = false;
-            if (want) {
-                const int slot = atomicAdd(s_bcnt, 1);
-                if (slot < CAP) {
-                    s_buf[slot] = key;
-                    want = false;
-                } else {
-                    over = true;
+            for (int u = 0; u < U; u++)
+                if (want[u]) {
+                    const int slot = atomicAdd(s_bcnt, 1);
+                    if (slot < CAP) {
+                        s_buf[slot] = key[u];
+                        want[u] = false;
+                    } else {
+                        over = true;
+                    }
                 }
-            }
-            if (!__syncthreads_or(over ? 1 : 0)) break;  // everybody found a slot
-            // some lane drew a slot >= CAP, so slots 0..CAP-1 are all written: keep the KP best
+            if (!__syncthreads_or(over ? 1 : 0)) break;  // every candidate found a slot
+            // some candidate drew a slot >= CAP, so slots 0..CAP-1 are all written: keep the KP best
             sort_desc<CAP>(s_buf, tid, nt);
             if (tid == 0) {
                 *s_bcnt = KP;
                 *s_thr = s_buf[k - 1];
             }
             __syncthreads();
-            want = want && key > *s_thr;
+            for (int u = 0; u < U; u++) want[u] = want[u] && key[u] > *s_thr;
         }
     }
     __syncthreads();
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
         const int T = s_cnt;
         const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? qr : (int64_t)-1);
         int my_pos = 0, my_neg = 0;
-        rank_candidates<KP>(
+        rank_candidates<KP, kRankUnroll>(
             T,
             [&](int64_t i) -> unsigned long long {
                 const int32_t sid = touched[i];
@@ -324,10 +334,9 @@ __global__ void sparse_heavy_score_kernel(HeavyArgs a) {
     }
 }
 
-// one workgroup per heavy query of the batch: the same ranking as sparse_query_kernel over all N rows
-template <int KP>
-__global__ __launch_bounds__(kBlock) void sparse_heavy_rank_kernel(HeavyArgs a) {
-    constexpr int CAP = 2 * KP;
+// one workgroup of kHeavyRankBlock lanes per heavy query of the batch: the same ranking as sparse_query_kernel over all N rows
+__global__ __launch_bounds__(kHeavyRankBlock) void sparse_heavy_rank_kernel(HeavyArgs a) {
+    constexpr int KP = kHeavyRankBlock, CAP = 2 * KP;
     __shared__ unsigned long long s_buf[CAP];
     __shared__ unsigned long long s_thr;
     __shared__ int s_bcnt, s_pos, s_neg, s_hit;
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void sparse_heavy_rank_kernel(HeavyArgs a) 
     const float *score = a.score + (int64_t)b * a.N;
     const uint8_t *common = a.common + (int64_t)b * a.N;
     int my_pos = 0, my_neg = 0, my_hit = 0;
-    rank_candidates<KP>(
+    rank_candidates<KP, 1>(
         a.N,
         [&](int64_t row) -> unsigned long long {
             if (!common[row]) return 0;

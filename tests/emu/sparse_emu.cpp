@@ -91,8 +91,6 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
         auto body = [&] {
             if (g_hot == 512) {
                 switch (kp) {
-                    case 64: sparse_query_kernel<64, 512>(a); break;
-                    case 128: sparse_query_kernel<128, 512>(a); break;
                     case 256: sparse_query_kernel<256, 512>(a); break;
                     case 512: sparse_query_kernel<512, 512>(a); break;
                     default: sparse_query_kernel<1024, 512>(a); break;
@@ -100,8 +98,6 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
                 return;
             }
             switch (kp) {
-                case 64: sparse_query_kernel<64, 0>(a); break;
-                case 128: sparse_query_kernel<128, 0>(a); break;
                 case 256: sparse_query_kernel<256, 0>(a); break;
                 case 512: sparse_query_kernel<512, 0>(a); break;
                 default: sparse_query_kernel<1024, 0>(a); break;
@@ -126,15 +122,7 @@ extern "C" __attribute__((visibility("default"))) int emu_sparse_search(int64_t 
             ha.nb = (int)(heavy.size() - at < (size_t)kHeavyBatch ? heavy.size() - at : (size_t)kHeavyBatch);
             for (int b = 0; b < kHeavyBatch; b++) ha.hq[b] = b < ha.nb ? heavy[at + b] : 0;
             emu::launch(2, (unsigned)block, [&] { sparse_heavy_score_kernel(ha); });
-            emu::launch((unsigned)ha.nb, (unsigned)(block < kp ? block : kp), [&] {
-                switch (kp) {
-                    case 64: sparse_heavy_rank_kernel<64>(ha); break;
-                    case 128: sparse_heavy_rank_kernel<128>(ha); break;
-                    case 256: sparse_heavy_rank_kernel<256>(ha); break;
-                    case 512: sparse_heavy_rank_kernel<512>(ha); break;
-                    default: sparse_heavy_rank_kernel<1024>(ha); break;
-                }
-            });
+            emu::launch((unsigned)ha.nb, (unsigned)block, [&] { sparse_heavy_rank_kernel(ha); });
         }
     }
     return 0;
