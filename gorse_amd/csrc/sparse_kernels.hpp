@@ -2,14 +2,15 @@
 // vectors.Database (storage/vectors/database.go:90-97, xvec.go:241-247: Dot over Indices / Values, exact Flat index)
 // that the IDF item-to-item / user-to-user writers fill (logics/vector_writer.go:192-209).
 //
-// One workgroup answers one query at a time.  The stored rows are held as POSTINGS (one list of (row, value) per
-// index); the query's indices are walked in ascending order and, for each, the workgroup's lanes stream that posting
-// list (coalesced 4-byte rows + 4-byte values = the 8 algorithmic bytes per multiply-add) and update a per-workgroup
-// accumulator (the high word of `cell[row]`).  A row occurs at most once per posting list, so inside one list no two lanes touch the same
-// accumulator, and the barrier between lists makes every row's sum run in ascending index order: the float32 result
-// is the merge-order sparse dot of the oracle bit for bit, with no atomics on data.  Rows reached for the first time
-// (the low word of cell[row] != serial of this query) are appended to a `touched` list; only those are ranked, so nothing of size N
-// is cleared or scanned per query.
+// sparse_query_kernel: one workgroup (one wave) answers one query at a time.  The stored rows are held as POSTINGS (one
+// list of (row, value) per index); the query's indices are walked in ascending order and, for each, the lanes stream that
+// posting list (coalesced 4-byte rows + 4-byte values = the 8 algorithmic bytes per multiply-add) and update a
+// per-workgroup accumulator (the high word of `cell[row]`).  A row occurs at most once per posting list, so inside one
+// list no two lanes touch the same accumulator, and the barrier between lists makes every row's sum run in ascending
+// index order: the float32 result is the merge-order sparse dot of the oracle bit for bit, with no atomics on data.
+// Rows reached for the first time (the low word of cell[row] != serial of this query) are appended to a `touched`
+// list; only those are ranked, so nothing of size N is cleared or scanned per query.  Queries with very many entries go
+// to the row-streaming kernels further down instead (sparse_heavy_*).
 //
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
 // well-defined answer whatever order the lanes append in.  Keys above the running threshold go to an LDS buffer of
