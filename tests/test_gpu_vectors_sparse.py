@@ -233,6 +233,31 @@ def test_postings_built_on_the_device_give_the_same_results(oracle):
     check(oracle, ptr, idx, val, 20, [x[sample] for x in dev], rows_of(ptr, idx, val, sample), sample)
 
 
+def test_edge_inputs(oracle):
+    """one stored row without entries; only empty rows; indptr that does not start at 0; an index space with huge gaps; k = 1024;
+    an empty query between two others; infinities and a NaN among the values (ordered like the oracle's total order)"""
+    s = capi.Sparse(np.array([0, 0], np.int64), np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    assert s.all_pairs(3)[2].tolist() == [0]
+    assert s.search(np.array([0, 1], np.int64), np.array([5], np.uint32), np.ones(1, np.float32), 2)[2].tolist() == [0]
+    s = capi.Sparse(np.zeros(6, np.int64), np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    i, sc, c = s.all_pairs(4)
+    assert (c == 0).all() and (i == -1).all() and np.isneginf(sc).all()
+    rng = np.random.default_rng(1)
+    ptr, idx, val = random_csr(rng, 300, 50, 1, 6)
+    idx = (idx.astype(np.uint64) * 80000 + 7).astype(np.uint32)  # largest index ~ 4e6
+    s = capi.Sparse(ptr + 5, np.concatenate([np.zeros(5, np.uint32), idx]), np.concatenate([np.zeros(5, np.float32), val]))
+    check(oracle, ptr, idx, val, 1024, s.all_pairs(1024), rows_of(ptr, idx, val, range(300)), list(range(300)))
+    qp = np.array([3, 5, 5, 9], np.int64)
+    qi = np.concatenate([np.zeros(3, np.uint32), np.sort(rng.choice(idx, 2, replace=False)), np.sort(rng.choice(np.unique(idx), 4, replace=False))])
+    qv = np.ones(9, np.float32)
+    check(oracle, ptr, idx, val, 7, s.search(qp, qi.astype(np.uint32), qv, 7), [(qi[3:5], qv[3:5]), (qi[5:5], qv[5:5]), (qi[5:9], qv[5:9])], [-1] * 3)
+    ptr3, idx3 = np.array([0, 2, 3, 4], np.int64), np.array([1, 2, 1, 2], np.uint32)
+    val3 = np.array([np.inf, 1, np.nan, -np.inf], np.float32)
+    got = capi.Sparse(ptr3, idx3, val3).search(np.array([0, 2], np.int64), np.array([1, 2], np.uint32), np.ones(2, np.float32), 5)
+    check(oracle, ptr3, idx3, val3, 5, got, [(np.array([1, 2], np.uint32), np.ones(2, np.float32))], [-1])
+    assert got[0][0, :3].tolist() == [1, 0, 2]  # NaN (positive sign bit pattern) above +inf above -inf
+
+
 def test_argument_errors():
     ptr = np.array([0, 2, 3], np.int64)
     idx = np.array([1, 5, 2], np.uint32)

@@ -157,7 +157,7 @@ def _gpu_cases():
                                                     "test_stamp_counter_wraps_by_clearing_the_scratch",
                                                     "test_postings_built_on_the_device_give_the_same_results",
                                                     "test_heavy_queries_take_the_row_streaming_path",
-                                                    "test_random_configurations"):
+                                                    "test_random_configurations", "test_edge_inputs"):
             continue  # these drive sparse.hip itself (tests/test_sparse_fake_runtime_cpu.py runs them); the database suite
             # has its own emulated run below
         if name == "test_many_hits_overflow_the_ranking_buffer":
