@@ -739,4 +739,31 @@ int32_t gh_logics_cf_recommend_bulk(void *h, const char *collection, const float
         stage_scores(logics::CollaborativeRecommendBulk(vdb(h), collection, users, cache_size));
     });
 }
+// master/tasks.go:925-969: items of model `m` into collaborative_filtering_<model_id> of database `h`, users into a new
+// MatrixFactorizationUsers (returned; free with gh_mfusers_free).  hidden: one byte per item or NULL; categories: one
+// '\n'-joined list per item, items separated by '\x1e', or NULL
+void *gh_publish_cf(void *m, void *h, int64_t model_id, const uint8_t *hidden, int32_t n_hidden, const char *categories,
+                    int32_t batch) {
+    void *out = nullptr;
+    guard([&] {
+        std::vector<bool> hid(hidden, hidden + (hidden ? n_hidden : 0));
+        std::vector<std::vector<std::string>> cats;
+        if (categories) {
+            std::string cur;
+            for (const char *p = categories;; p++) {
+                if (*p == '\x1e' || *p == 0) {
+                    cats.push_back(split_lines(cur.c_str()));
+                    cur.clear();
+                    if (*p == 0) break;
+                } else {
+                    cur.push_back(*p);
+                }
+            }
+        }
+        auto users = logics::PublishCollaborativeFiltering(*(cf::MatrixFactorization *)m, vdb(h), model_id, hid, cats, batch > 0 ? batch : 1024);
+        out = new logics::MatrixFactorizationUsers(std::move(users));
+    });
+    return out;
+}
+int32_t gh_mfusers_count(void *u) { return (int32_t)((logics::MatrixFactorizationUsers *)u)->Count(); }
 }  // extern "C"

@@ -785,5 +785,41 @@ private:
     std::map<std::string, std::vector<float>> embeddings_;
 };
 
+// The publishing step of the master after a fit (master/tasks.go:925-969): the predictable items' factors go into a fresh
+// Dot collection collaborative_filtering_<modelId> (batches of batchSize, Id / IsHidden / Categories from the item table,
+// Timestamp = the model id), the predictable users' factors into the MatrixFactorizationUsers blob the workers download.
+// Model = anything with the cf.MatrixFactorization accessors (cf::BPR / cf::ALS); hidden[i] / categories[i] belong to item
+// index i (data.Item.IsHidden / .Categories; either vector may be shorter than the item count = defaults).
+template <typename Model>
+MatrixFactorizationUsers PublishCollaborativeFiltering(Model &model, vectors::HipDatabase &db, int64_t modelId,
+                                                       const std::vector<bool> &hidden,
+                                                       const std::vector<std::vector<std::string>> &categories, int batchSize = 1024) {
+    const std::string collection = "collaborative_filtering_" + std::to_string(modelId);  // database.go:52-54
+    const int d = model.NFactors();
+    const int32_t nItems = model.GetItemIndex()->Count(), nUsers = model.GetUserIndex()->Count();
+    db.AddCollection(collection, d, vectors::Dot);
+    for (int32_t start = 0; start < nItems; start += batchSize) {
+        std::vector<vectors::Vector> batch;
+        for (int32_t i = start; i < std::min<int32_t>(start + batchSize, nItems); i++) {
+            if (!model.IsItemPredictable(i)) continue;
+            vectors::Vector v;
+            model.GetItemIndex()->String(i, v.Id);
+            v.Values.assign(model.GetItemFactor(i), model.GetItemFactor(i) + d);
+            v.IsHidden = (size_t)i < hidden.size() && hidden[(size_t)i];
+            if ((size_t)i < categories.size()) v.Categories = categories[(size_t)i];
+            v.TimestampMs = modelId;
+            batch.push_back(std::move(v));
+        }
+        if (!batch.empty()) db.AddVectors(collection, batch);
+    }
+    MatrixFactorizationUsers users;
+    for (int32_t u = 0; u < nUsers; u++) {
+        std::string id;
+        if (model.GetUserIndex()->String(u, id) && model.IsUserPredictable(u))
+            users.Add(id, std::vector<float>(model.GetUserFactor(u), model.GetUserFactor(u) + d));
+    }
+    return users;
+}
+
 }  // namespace logics
 }  // namespace gorse

@@ -422,3 +422,60 @@ def CollaborativeRecommendBulk(client, collection, embeddings, excludes, cache_s
     flat = _scores()
     cuts = [int(H.gh_vdb_result_split(t)) for t in range(Q.shape[0] + 1)]
     return [flat[cuts[t]:cuts[t + 1]] for t in range(Q.shape[0])]
+
+
+class MatrixFactorizationUsers:
+    """logics.MatrixFactorizationUsers (logics/cf.go:122-179): user id -> embedding, the blob workers download"""
+
+    def __init__(self, ptr=None):
+        H = _logics_host()
+        H.gh_mfusers_new.restype = C.c_void_p
+        H.gh_mfusers_free.argtypes = [C.c_void_p]
+        H.gh_mfusers_add.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int32]
+        H.gh_mfusers_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int32]
+        H.gh_mfusers_count.argtypes = [C.c_void_p]
+        H.gh_mfusers_marshal.restype = C.c_int64
+        H.gh_mfusers_marshal.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        H.gh_mfusers_unmarshal.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        self.p = C.c_void_p(ptr if ptr is not None else H.gh_mfusers_new())
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            _logics_host().gh_mfusers_free(self.p)
+            self.p = None
+
+    def Add(self, user_id, v):
+        a = np.ascontiguousarray(v, np.float32)
+        _logics_host().gh_mfusers_add(self.p, str(user_id).encode(), a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
+
+    def Get(self, user_id, max_dim=4096):
+        out = np.zeros(max_dim, np.float32)
+        n = _logics_host().gh_mfusers_get(self.p, str(user_id).encode(), out.ctypes.data_as(C.POINTER(C.c_float)), max_dim)
+        return (out[:n].copy(), True) if n >= 0 else (None, False)
+
+    def Count(self):
+        return _logics_host().gh_mfusers_count(self.p)
+
+    def Marshal(self):
+        H = _logics_host()
+        n = H.gh_mfusers_marshal(self.p, None, 0)
+        buf = C.create_string_buffer(int(n))
+        H.gh_mfusers_marshal(self.p, buf, n)
+        return buf.raw
+
+    def Unmarshal(self, blob):
+        _ck(_logics_host().gh_mfusers_unmarshal(self.p, blob, len(blob)))
+
+
+def PublishCollaborativeFiltering(model, client, model_id, hidden=None, categories=None, batch_size=0):
+    """What the master does with a fitted model (master/tasks.go:925-969): the predictable items' factors into the Dot
+    collection collaborative_filtering_<model_id>, the predictable users' factors into a MatrixFactorizationUsers."""
+    H = _logics_host()
+    H.gh_publish_cf.restype = C.c_void_p
+    H.gh_publish_cf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
+    hid = None if hidden is None else np.ascontiguousarray(hidden, np.uint8).tobytes()
+    cats = None if categories is None else "\x1e".join("\n".join(c) for c in categories).encode()
+    ptr = H.gh_publish_cf(model.p, client.h, int(model_id), hid, 0 if hidden is None else len(hidden), cats, batch_size)
+    if not ptr:
+        raise RuntimeError(H.gh_last_error().decode("utf-8", "replace"))
+    return MatrixFactorizationUsers(ptr)

@@ -375,8 +375,40 @@ def user_to_user_auto(db):  # TestAuto (user_to_user_test.go:155-190)
     _auto_kind(db, V.UserToUserCollection("auto"))
 
 
+def publish_and_recommend(db):
+    """master/tasks.go:925-969 then worker/pipeline.go:403-425: a fitted model is published (items -> Dot collection, users ->
+    blob), a worker restores the blob and asks for every user's recommendations in one bulk search"""
+    from gorse_amd import cf
+    rng = np.random.default_rng(21)
+    U, I, d = 40, 150, 8
+    P = (rng.standard_normal((U, d)) * 0.3).astype(np.float32)
+    Q = (rng.standard_normal((I, d)) * 0.3).astype(np.float32)
+    m = cf.BPR({"NFactors": d})
+    m.load_factors(P, Q)  # ids "0".."n-1", every row predictable
+    hidden = [i % 11 == 0 for i in range(I)]
+    cats = [["c%d" % (i % 4)] for i in range(I)]
+    model_id = 1_790_000_123_456
+    users = V.PublishCollaborativeFiltering(m, db, model_id, hidden, cats, batch_size=64)
+    coll = V.CollaborativeFilteringCollection(model_id)
+    assert db.CountVectors(coll) == I and users.Count() == U
+    info = db.DescribeCollection(coll)
+    assert info["Dimension"] == d and info["Distance"] == V.Dot
+    v7 = db.GetVectors(coll, ["7", "11"])
+    assert v7[0].Values == [float(x) for x in Q[7]] and v7[0].Categories == ["c3"] and not v7[0].IsHidden and v7[1].IsHidden
+    assert v7[0].Timestamp == model_id
+    worker = V.MatrixFactorizationUsers()
+    worker.Unmarshal(users.Marshal())
+    emb = np.stack([worker.Get(str(u))[0] for u in range(U)])
+    assert np.array_equal(emb, P) and worker.Get("nobody") == (None, False)
+    rec = V.CollaborativeRecommendBulk(db, coll, emb, [[] for _ in range(U)], 5)
+    for u in range(U):
+        scores = Q.astype(np.float64) @ P[u].astype(np.float64)
+        best = [i for i in np.argsort(-scores, kind="stable") if not hidden[i]][:5]
+        assert [s.Id for s in rec[u]] == [str(i) for i in best], u
+
+
 # dense cases written after the last device session: on the CPU list now, on the device through tests/test_gpu_vectors_sparse.py
-PENDING_DENSE_CASES = [item_to_item_hidden]
+PENDING_DENSE_CASES = [item_to_item_hidden, publish_and_recommend]
 SPARSE_CASES = [sparse, sparse_rules, item_to_item_tags, item_to_item_users, item_to_item_auto,
                 item_to_item_sparse_hidden_and_idf, user_to_user_tags, user_to_user_items, user_to_user_auto]
 
