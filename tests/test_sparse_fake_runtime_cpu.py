@@ -8,6 +8,7 @@ import os
 import subprocess
 import sys
 
+import vectors_suite as S
 from conftest import ROOT
 
 EMU = os.path.join(ROOT, "tests", "emu")
@@ -26,7 +27,7 @@ def test_gpu_sparse_tests_through_the_real_library_on_a_fake_hip_runtime():
     # the dense cases of that module need the MFMA / scan kernels, which are not emulated
     child = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                             os.path.join(ROOT, "tests", "test_gpu_vectors_sparse.py"), "-k",
-                            "not item_to_item_hidden and not collaborative_recommend"],
+                            " and ".join("not " + f.__name__ for f in S.PENDING_DENSE_CASES + [S.collaborative_recommend])],
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     tail = (child.stdout + child.stderr)[-3000:]
     assert child.returncode == 0, tail
