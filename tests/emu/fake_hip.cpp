@@ -123,7 +123,9 @@ API hipError_t hipLaunchKernel(const void *func, Dim3 grid, Dim3 block, void **a
     if (name.find("sparse_query_kernel") != std::string::npos) {
         const QueryArgs a = *static_cast<const QueryArgs *>(args[0]);
         const int kp = template_int(name, 0), hot = template_int(name, 1);
-        emu::launch(grid.x, block.x, [&] {
+        // the kernel is written for any workgroup size up to KP / 4: eight OS threads per workgroup instead of the real 64
+        // lanes keep this container's cores from being oversubscribed (the 64-lane form runs in test_sparse_kernel_emu_cpu.py)
+        emu::launch(grid.x, block.x < 8 ? block.x : 8, [&] {
             switch (kp * 10000 + hot) {
 #define Q(KP, HOT) \
     case KP * 10000 + HOT: sparse_query_kernel<KP, HOT>(a); break;
@@ -159,8 +161,8 @@ API hipError_t hipLaunchKernel(const void *func, Dim3 grid, Dim3 block, void **a
     }
     if (name.find("sparse_heavy_rank_kernel") != std::string::npos) {
         const HeavyArgs h = *static_cast<const HeavyArgs *>(args[0]);
-        // the real block is 1024 lanes: 64 OS threads run the same code (any block size up to KP = 1024 is legal)
-        emu::launch(grid.x, block.x < 64 ? block.x : 64, [&] { sparse_heavy_rank_kernel(h); });
+        // the real block is 1024 lanes: 8 OS threads run the same code (any block size up to KP = 1024 is legal)
+        emu::launch(grid.x, block.x < 8 ? block.x : 8, [&] { sparse_heavy_rank_kernel(h); });
         return kSuccess;
     }
     return g_last = kInvalidDeviceFunction;
