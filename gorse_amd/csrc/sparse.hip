@@ -189,7 +189,8 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     sparse::Postings post;
     if (on_device) {  // only the index space is needed from the host
         for (int64_t t = base; t < base + nnz; t++) post.D = indices[t] >= post.D ? (int64_t)indices[t] + 1 : post.D;
-        if (post.D > sparse::kMaxDims) return fail(GORSE_ERR_INVALID, "largest index %lld exceeds the supported index space", (long long)(post.D - 1));
+        if (post.D > sparse::kMaxDims)
+            return fail(GORSE_ERR_INVALID, "largest index %lld exceeds the supported index space", (long long)(post.D - 1));
     } else {
         const std::string why = sparse::build_postings(N, indptr, indices, values, post, order.new_of.data());
         if (!why.empty()) return fail(GORSE_ERR_INVALID, "%s", why.c_str());

@@ -172,8 +172,8 @@ __device__ inline int rank_candidates(int64_t count, KeyAt key_at, int k, unsign
 }
 
 // result row t from the sorted buffer: cnt entries, the rest padded
-__device__ inline void write_result(const unsigned long long *s_buf, int cnt, int k, int64_t t, int32_t *out_idx, float *out_score,
-                                    int32_t *out_cnt, int tid, int nt) {
+__device__ inline void write_result(const unsigned long long *s_buf, int cnt, int k, int64_t t, int32_t *out_idx,
+                                    float *out_score, int32_t *out_cnt, int tid, int nt) {
     for (int i = tid; i < k; i += nt) {
         const unsigned long long key = i < cnt ? s_buf[i] : 0;
         out_idx[t * k + i] = i < cnt ? key_row(key) : -1;
