@@ -1,0 +1,89 @@
+//go:build cgo && hip
+
+package cf
+
+// #include "gorse_hip.h"
+import "C"
+
+import (
+	"context"
+	"fmt"
+	"time"
+
+	"github.com/gorse-io/gorse/common/log"
+	"github.com/gorse-io/gorse/common/monitor"
+	"github.com/gorse-io/gorse/dataset"
+	"github.com/samber/lo"
+	"go.uber.org/zap"
+)
+
+// Fit the BPR model on one MI355X.  Everything around the epoch body -- Init draws, evaluation schedule, early stopping,
+// logging, span, the returned Score -- is model.go:408-530 unchanged; the body (sampling + the SGD steps of one epoch,
+// model.go:446-494) is one gorse_bpr_epoch call.
+func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, config *FitConfig) Score {
+	log.Logger().Info("fit bpr (hip)",
+		zap.Int("train_set_size", trainSet.CountFeedback()),
+		zap.Int("test_set_size", valSet.CountFeedback()),
+		zap.Any("params", bpr.GetParams()),
+		zap.Any("config", config))
+	bpr.Init(trainSet)
+	hm, err := newHipModel(ctx, &bpr.BaseMatrixFactorization, bpr.nFactors, trainSet, false)
+	if err != nil {
+		log.Logger().Error("fit bpr: no device", zap.Error(err))
+		return Score{}
+	}
+	defer hm.close()
+	// one sampler stream per Fit, seeded like the reference's worker generators (model.go:420-423)
+	seed := uint64(bpr.GetRandomGenerator().Int63())
+	mode := C.int32_t(C.GORSE_BPR_HOGWILD_ATOMIC)
+	if config.Jobs <= 1 {
+		mode = C.GORSE_BPR_SEQUENTIAL // parallel.Parallel with one worker runs the samples strictly in order
+	}
+	evalStart := time.Now()
+	score := hm.evaluate(valSet, trainSet, config.TopK, config.Candidates, NDCG, Precision, Recall)
+	scores := []lo.Tuple2[int, float32]{{A: 0, B: score[0]}}
+	log.Logger().Debug(fmt.Sprintf("fit bpr %v/%v", 0, bpr.nEpochs),
+		zap.String("eval_time", time.Since(evalStart).String()),
+		zap.Float32(fmt.Sprintf("NDCG@%v", config.TopK), score[0]),
+		zap.Float32(fmt.Sprintf("Precision@%v", config.TopK), score[1]),
+		zap.Float32(fmt.Sprintf("Recall@%v", config.TopK), score[2]))
+	_, span := monitor.Start(ctx, "BPR.Fit", bpr.nEpochs)
+	defer span.End()
+	for epoch := 1; epoch <= bpr.nEpochs; epoch++ {
+		fitStart := time.Now()
+		rc := C.gorse_bpr_epoch(hm.h, C.int64_t(trainSet.CountFeedback()), C.float(bpr.lr), C.float(bpr.reg),
+			C.uint64_t(seed), C.uint64_t(epoch), 0, mode, hm.cancel, nil)
+		if rc == C.GORSE_ERR_CANCELLED {
+			log.Logger().Info("fit bpr canceled", zap.Int("epoch", epoch), zap.Error(ctx.Err()))
+			hm.pull()
+			return Score{}
+		} else if rc != 0 {
+			log.Logger().Error("fit bpr", zap.Error(hipError("gorse_bpr_epoch", rc)))
+			return Score{}
+		}
+		fitTime := time.Since(fitStart)
+		if epoch%config.Verbose == 0 || epoch == bpr.nEpochs {
+			evalStart = time.Now()
+			score = hm.evaluate(valSet, trainSet, config.TopK, config.Candidates, NDCG, Precision, Recall)
+			scores = append(scores, lo.Tuple2[int, float32]{A: epoch, B: score[0]})
+			log.Logger().Info(fmt.Sprintf("fit bpr %v/%v", epoch, bpr.nEpochs),
+				zap.String("fit_time", fitTime.String()),
+				zap.String("eval_time", time.Since(evalStart).String()),
+				zap.Float32(fmt.Sprintf("NDCG@%v", config.TopK), score[0]),
+				zap.Float32(fmt.Sprintf("Precision@%v", config.TopK), score[1]),
+				zap.Float32(fmt.Sprintf("Recall@%v", config.TopK), score[2]))
+			if best, stop := earlyStop(scores, epoch, config.Patience); stop {
+				log.Logger().Info("early stopping",
+					zap.Int("best_epoch", best.A), zap.Float32("best_NDCG", best.B), zap.Int("patience", config.Patience))
+				break
+			}
+		}
+		span.Add(1)
+	}
+	hm.pull() // the [][]float32 rows alias the flat arrays: Marshal / GetUserFactor / Predict see the trained factors
+	log.Logger().Info("fit bpr complete",
+		zap.Float32(fmt.Sprintf("NDCG@%v", config.TopK), score[0]),
+		zap.Float32(fmt.Sprintf("Precision@%v", config.TopK), score[1]),
+		zap.Float32(fmt.Sprintf("Recall@%v", config.TopK), score[2]))
+	return Score{NDCG: score[0], Precision: score[1], Recall: score[2]}
+}
