@@ -18,6 +18,7 @@ Workloads (BASELINE.json configs):
   i2i    SURVEY 8f item 2: the "users" item-to-item refresh = sparse all-pairs top-100 over the IDF vectors of the C3-shard
          dataset's 200,000 items (item -> its users, value sqrt(idf)); query rows sharded over the ranks, index replicated,
          no collective.  `--i2i-shape ml1m` uses the S-ml1m items instead.
+         The default single-GPU run appends this leg as "i2i", measured in a child process with a time limit.
 Timed region: inputs resident in HBM, barrier + device sync on both sides, MAX over ranks.
 """
 import argparse
