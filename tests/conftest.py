@@ -13,7 +13,8 @@ if ROOT not in sys.path:
 # in a normal session they are skipped and tests/test_gpu_zz_isolated.py runs them in a child process with a timeout
 # (GORSE_GPU_ISOLATED=1 in the child, or by hand: GORSE_GPU_ISOLATED=1 python -m pytest tests/test_gpu_vectors_sparse.py).
 # A module leaves this list once a device session has seen it green.
-ISOLATED_GPU_MODULES = ("test_gpu_vectors_sparse.py", "test_gpu_x_model_search.py", "test_gpu_y_movielens.py")
+# Round 2: the sparse, model-search and MovieLens modules ran green on the device (GPUTEST_r01 child, r02_a session) and left the list.
+ISOLATED_GPU_MODULES = ()
 
 
 def pytest_configure(config):

@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_unvalidated_gpu_modules_in_a_child_process():
+    if not ISOLATED_GPU_MODULES:
+        pytest.skip("no GPU module is waiting for its first device run")
     files = [os.path.join(ROOT, "tests", m) for m in ISOLATED_GPU_MODULES]
     env = dict(os.environ, GORSE_GPU_ISOLATED="1")
     child = subprocess.Popen([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + files, cwd=ROOT, env=env,
