@@ -285,8 +285,8 @@ def bench_sparse(args, world, rank, local, fence):
     sp.set_profiling(False)
     if rank != 0:
         return None
-    # SURVEY 8f item 2 / DESIGN: 8 algorithmic bytes per multiply-add (the posting's row id + value); the accumulators
-    # live in a per-workgroup scratch row that is meant to stay in L2
+    # SURVEY 8f item 2 / DESIGN: 8 algorithmic bytes per multiply-add (the posting's accumulator id + value); the
+    # accumulators themselves live in LDS
     avg_ms = ms / max(launches, 1)
     achieved = postings * 8.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     out = {
@@ -296,8 +296,8 @@ def bench_sparse(args, world, rank, local, fence):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "users item-to-item over %s: %d sparse vectors, %d entries, k=%d, query rows sharded x%d"
                                % (desc, N, int(ptr[-1]), k, world),
-                   "queries_per_step_per_gpu": q1 - q0, "postings_per_step_per_gpu": postings, "hit_rows_per_step_per_gpu": hits},
-        "roofline": {"bound": "hbm", "kernel": "sparse_query_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "queries_per_step_per_gpu": q1 - q0, "postings_per_step_per_gpu": postings, "nonzero_pairs_per_step_per_gpu": hits},
+        "roofline": {"bound": "hbm", "kernel": "sparse_tile_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_posting": 8,
                      "avg_launch_ms": avg_ms, "launches": launches},
     }
@@ -312,23 +312,38 @@ def bench_sparse(args, world, rank, local, fence):
 
 
 def sparse_cpu_baseline(ptr, idx, val, k, seconds, sp, q_begin):
-    """The oracle's sparse search (kind 'port': every stored vector merged against the query, what an exact Flat index
-    does) on a few query rows, one query per host thread; the rows double as a bit-exact check of the GPU result."""
+    """The oracle's INVERTED-INDEX search (kind 'port': orc_sparse_search_inverted -- posting lists walked in ascending index
+    order into per-thread accumulators, the same multiply-adds the GPU performs) on a sample of the query rows, one query per
+    host thread at a time; every sampled row doubles as a bit-exact check of the GPU result."""
     from oracle import oracle as orc
     o = orc.Oracle()
     N = ptr.size - 1
     threads = min(os.cpu_count() or 1, 32)
+    ix = o.sparse_index(ptr, idx, val)
     row = lambda r: (idx[ptr[r]:ptr[r + 1]], val[ptr[r]:ptr[r + 1]])
+    lens = np.bincount(idx, minlength=int(idx.max()) + 1 if idx.size else 1)
+    stride = 131
+    sample = [q_begin + (stride * t) % max(N - q_begin, 1) for t in range(min(N - q_begin, 1 << 16))]
+    # a probe sets the sample size: postings/s of one thread on the first 64 sampled rows
+    scratch0 = ix.scratch()
     t0 = time.perf_counter()
-    o.sparse_search(ptr, idx, val, *row(q_begin), k, exclude=q_begin)
-    one = max(time.perf_counter() - t0, 1e-4)
-    per_thread = max(1, min(int(seconds / one), 256))
-    qs = [q_begin + (131 * t) % max(N - q_begin, 1) for t in range(threads * per_thread)]
+    probe = sum(ix.search(*row(q), k, exclude=q, scratch=scratch0)[2] for q in sample[:64])
+    rate = max(probe, 1) / max(time.perf_counter() - t0, 1e-4)
+    budget, qs, acc = rate * threads * seconds, [], 0
+    for q in sample:
+        qs.append(q)
+        acc += int(lens[row(q)[0]].sum())
+        if acc >= budget:
+            break
     res = [None] * len(qs)
+    walked = [0] * threads
 
     def work(t):
+        scratch = ix.scratch()
         for r in range(t, len(qs), threads):
-            res[r] = o.sparse_search(ptr, idx, val, *row(qs[r]), k, exclude=qs[r])
+            ei, es, w = ix.search(*row(qs[r]), k, exclude=qs[r], scratch=scratch)
+            res[r] = (ei, es)
+            walked[t] += w
     ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
     t0 = time.perf_counter()
     for t in ts:
@@ -336,23 +351,22 @@ def sparse_cpu_baseline(ptr, idx, val, k, seconds, sp, q_begin):
     for t in ts:
         t.join()
     dt = time.perf_counter() - t0
-    lens = np.bincount(idx, minlength=int(idx.max()) + 1 if idx.size else 1)
-    postings = int(sum(lens[row(q)[0]].sum() for q in qs))
+    postings = int(sum(walked))
     for q, (ei, es) in zip(qs, res):
         gi, gs, gc = sp.all_pairs(k, q, q + 1)
         same = gc[0] == ei.size and np.array_equal(gi[0, :ei.size], ei) and \
             np.array_equal(gs[0, :ei.size].view(np.uint32), es.view(np.uint32))
         assert same, "GPU sparse top-k row %d differs from the oracle" % q
     return {"value": postings / dt, "unit": "postings/s", "cores": threads, "kind": "port",
-            "sample": "%d queries (each merged against all %d stored vectors) on %d threads, %.1f s, counted in the same "
-                      "unit (posting-list entries an inverted index would walk for them); all of them compared bit for bit "
-                      "with the GPU rows" % (len(qs), N, threads, dt)}
+            "sample": "%d query rows (every %dth from row %d) through the oracle's inverted-index search on %d threads, "
+                      "%d postings walked in %.1f s; all of them compared bit for bit with the GPU rows"
+                      % (len(qs), stride, q_begin, threads, postings, dt)}
 
 
 def i2i_in_a_child(args):
-    """The sparse item-to-item leg of the default run, in a CHILD process with a time limit: its kernels were
-    written after round 1's GPU budget was spent and have not run on a device, and nothing that happens to them may cost
-    the line its headline numbers.  Returns the child's JSON object, or {"error": ...}."""
+    """The sparse item-to-item leg of the default run, in a CHILD process with a time limit (its dataset is
+    the 12.5M-feedback C3 shard: generation plus the CPU baseline take tens of seconds, and nothing that happens there may
+    cost the line its headline numbers).  Returns the child's JSON object, or {"error": ...}."""
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "i2i", "--i2i-shape", args.i2i_shape, "--steps", "3", "--warmup", "1",
            "--cpu-seconds", str(args.cpu_seconds)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
     try:

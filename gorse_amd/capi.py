@@ -82,11 +82,10 @@ SIGNATURES = {
     "gorse_hip_test_set_topk_path": (None, [C.c_int32]),
     "gorse_hip_test_set_topk_variant": (None, [C.c_int32]),
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
-    "gorse_hip_test_set_sparse_build": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
-    "gorse_hip_test_set_sparse_heavy": (None, [C.c_int64]),
-    "gorse_hip_test_set_sparse_hot": (None, [C.c_int32]),
-    "gorse_hip_test_sparse_set_serial": (C.c_int32, [_vp, C.c_uint32]),
+    "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
+    "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
+    "gorse_hip_test_set_sparse_atomic": (None, [C.c_int32]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
     "gorse_hip_test_als_profile": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),

@@ -2,8 +2,8 @@
 // (storage/vectors/database.go:90-97 Vector.Indices / Values; xvec.go:241-247: dimension 0 = sparse, distance Dot,
 // Flat = exact index) that the IDF item-to-item / user-to-user writers fill (logics/vector_writer.go:192-209) and
 // QueryItemToItem / QueryUserToUser read (logics/item_to_item.go:50-88, user_to_user.go:50-88).
-// Host side of the gorse_sparse_* entry points of include/gorse_hip.h; the kernel is in sparse_kernels.hpp, the index
-// construction (CSR validation, postings) in sparse_host.hpp.
+// Host side of the gorse_sparse_* entry points of include/gorse_hip.h; the kernels are in sparse_kernels.hpp, the host
+// part of the index construction (CSR validation, row order, the list of distinct indices) in sparse_host.hpp.
 #include <algorithm>
 
 #include "common.hpp"
@@ -11,36 +11,32 @@
 #include "sparse_kernels.hpp"
 
 using namespace gorse;
-using gorse::sparse::QueryArgs;
+using gorse::sparse::TileArgs;
 
 struct gorse_sparse {
     int device = 0;
-    int64_t N = 0, nnz = 0, D = 0;
+    int64_t N = 0, nnz = 0, Dc = 0;
+    int32_t logT = 0, ntiles = 0;
     hipStream_t stream = nullptr;
-    // stored rows as CSR (the queries of all_pairs) and as postings (what every query walks)
-    DevBuf<int64_t> r_ptr, p_ptr;
-    DevBuf<uint32_t> r_idx;
-    DevBuf<int32_t> p_row, orig_of;  // posting lists hold scratch ids (longest row first); orig_of maps them back
-    DevBuf<float> r_val, p_val;
-    DevBuf<uint8_t> mask;
+    // stored rows as CSR with directory entries instead of raw indices (the queries of all_pairs), the tiled posting lists
+    DevBuf<int64_t> r_ptr;
+    DevBuf<int32_t> r_cid, orig_of, new_of;
+    DevBuf<float> r_val;
+    DevBuf<uint32_t> dims, off;
+    DevBuf<sparse::Posting> post;
+    DevBuf<uint8_t> mask_sid;
     bool has_mask = false;
     int64_t n_admissible = 0;  // rows with mask != 0 (N without a mask)
-    // per-workgroup scratch (slots x N each); stamps are never reused for a slot until the wrap-around clear
-    DevBuf<sparse::Cell> cell;
-    DevBuf<int32_t> touched;
-    int64_t slots = 0;
-    uint32_t serial = 0;
+    float stored_small = 0.0f;  // smallest non-zero |value| stored
+    sparse::RowOrder order;    // host copy: masks arrive in the caller's row order
+    std::vector<int64_t> r_ptr_host;
     // staging of one call
     DevBuf<int64_t> q_ptr, q_excl;
     DevBuf<uint32_t> q_idx;
+    DevBuf<int32_t> q_cid, out_idx, out_cnt, next, split_t, part_cnt;
     DevBuf<float> q_val, out_score;
-    DevBuf<int32_t> out_idx, out_cnt;
-    DevBuf<unsigned long long> stat;
-    // heavy queries (row streaming): host copy of the stored rows' offsets (the lengths of all_pairs' queries), per-batch
-    // score / shared-index rows
-    std::vector<int64_t> r_ptr_host;
-    DevBuf<float> hscore;
-    DevBuf<uint8_t> hcommon;
+    DevBuf<sparse::Work> work;
+    DevBuf<unsigned long long> part_keys, stat;
     KernelProfile prof{1};
     int64_t last_postings = 0, last_hits = 0;
     int32_t use() const {
@@ -52,105 +48,129 @@ struct gorse_sparse {
 
 namespace {
 
-// Queries with more entries than this take the row-streaming path.  A posting-list walk costs its query about a microsecond
-// per list on one wave (16K lists = a tail of ~16 ms), a row-streaming pass serves eight queries for one read of the stored
-// CSR plus a binary search per (entry, query): worth it for the handful of longest queries of a popularity-skewed
-// collection only (64 of the 200,000 items of the C3 shard exceed 16K users; 622 exceed 2K).  To be tuned on a device.
-int64_t g_sparse_heavy_dims = 16384;
-int g_sparse_hot = 0;  // probe: 512 / 1024 = that many of the longest rows keep their accumulators in LDS (0 = none)
-int g_sparse_build = 0;  // 0 = postings built on the host (default), 1 = by the device kernels (test hook, see gorse_hip.h)
+// probes / test hooks (include/gorse_hip_test.h); results never depend on them
+int g_sparse_tile = 0;           // rows per tile (power of two, 256 .. 16384); 0 = chosen from N
+int64_t g_sparse_split = 2048;   // queries with more entries than this are split over the 8 stripes; <= 0 = never
+int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
+int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 
-constexpr int64_t kScratchBudget = (int64_t)16 << 30;  // bytes of accumulator scratch (of 288 GB of HBM)
-constexpr int64_t kMaxSlots = 8192;                    // 256 CUs x 32 single-wave workgroups
-
-int64_t g_sparse_max_slots = 0;  // probe: fewer resident workgroups = a smaller live scratch footprint (0 = kMaxSlots)
-
-int64_t slot_cap(int64_t N) {
-    const int64_t most = g_sparse_max_slots > 0 ? std::min(g_sparse_max_slots, kMaxSlots) : kMaxSlots;
-    return std::max<int64_t>(1, std::min<int64_t>(most, kScratchBudget / (12 * N)));
-}
-
-int32_t ensure_scratch(gorse_sparse *h, int64_t want) {
-    if (want <= h->slots) return GORSE_OK;
-    GORSE_TRY(h->cell.alloc((size_t)want * h->N));
-    GORSE_TRY(h->touched.alloc((size_t)want * h->N));
-    GORSE_HIP_CHECK(hipMemsetAsync(h->cell.p, 0, (size_t)want * h->N * sizeof(sparse::Cell), h->stream));
-    h->slots = want;
-    h->serial = 0;
-    return GORSE_OK;
+int pick_log_tile(int64_t N) {
+    if (g_sparse_tile > 0) {
+        int l = 8;
+        while ((1 << l) < g_sparse_tile && l < 14) l++;
+        return l;
+    }
+    int l = 11;  // 2048 rows = 8 KB of accumulators: 13 waves per CU next to the ranking buffer
+    while (l < 14 && ((int64_t)512 << l) < N) l++;
+    return l;
 }
 
 template <int KP>
-void launch_query(const QueryArgs &a, unsigned grid, hipStream_t s) {
-    if (g_sparse_hot == 512)
-        sparse::sparse_query_kernel<KP, 512><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
-    else if (g_sparse_hot == 1024)
-        sparse::sparse_query_kernel<KP, 1024><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
-    else
-        sparse::sparse_query_kernel<KP, 0><<<dim3(grid), dim3(sparse::kBlock), 0, s>>>(a);
+int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, hipStream_t s) {
+    auto k1 = sparse::sparse_tile_kernel<KP, true>;
+    auto k0 = sparse::sparse_tile_kernel<KP, false>;
+    auto kern = atomic ? k1 : k0;
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<dim3(grid), dim3(sparse::kBlock), lds, s>>>(a);
+    return GORSE_OK;
 }
 
-// nq queries = CSR rows q_first .. of device arrays (qp, qi, qv); results into the handle's out_* buffers and, where
-// given, the host arrays
-// q_len_host: q_len_host[t + 1] - q_len_host[t] = number of entries of query t (host copy of the offsets)
-int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, const float *qv, int64_t q_first, int64_t nq,
-                    const int64_t *q_len_host, const int64_t *excl_dev, int exclude_self, int k, int32_t *idx_out,
+int32_t scan_exclusive(uint32_t *x, int64_t n, DevBuf<uint32_t> &sums, hipStream_t s) {
+    const int64_t per = (int64_t)sparse::kScanBlock * sparse::kScanPer;
+    const int64_t nb = ceil_div(n, per);
+    GORSE_TRY(sums.ensure((size_t)nb));
+    sparse::sparse_scan_sums_kernel<<<dim3((unsigned)nb), dim3(sparse::kScanBlock), 0, s>>>(x, n, sums.p);
+    sparse::sparse_scan_top_kernel<<<dim3(1), dim3(sparse::kScanBlock), 0, s>>>(sums.p, nb);
+    sparse::sparse_scan_apply_kernel<<<dim3((unsigned)nb), dim3(sparse::kScanBlock), 0, s>>>(x, n, sums.p);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+// nq queries = CSR rows q_first .. of device arrays (qp, qc, qv); results into the handle's out_* buffers and, where
+// given, the host arrays.  q_len_host[t + 1] - q_len_host[t] = number of entries of query t (host copy of the offsets);
+// q_small = smallest non-zero |value| among the queries' entries (0 = none).
+int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const float *qv, int64_t q_first, int64_t nq,
+                    const int64_t *q_len_host, const int64_t *excl_dev, int exclude_self, int k, bool atomic, int32_t *idx_out,
                     float *score_out, int32_t *cnt_out) {
     const int kp = sparse::pick_kp(k);
     if (!kp) return fail(GORSE_ERR_INVALID, "k = %d: must be in 1..1024", k);
-    const int64_t grid = std::min<int64_t>(nq, slot_cap(h->N));
-    GORSE_TRY(ensure_scratch(h, grid));
+    if (nq > INT32_MAX / (sparse::kStripes + 1)) return fail(GORSE_ERR_INVALID, "too many queries in one call");
     GORSE_TRY(h->out_idx.ensure((size_t)nq * k));
     GORSE_TRY(h->out_score.ensure((size_t)nq * k));
     GORSE_TRY(h->out_cnt.ensure((size_t)nq));
     GORSE_TRY(h->stat.ensure(2));
-    const int64_t per_slot = ceil_div(nq, grid);  // queries (= stamps) one workgroup consumes in this launch
-    if ((uint64_t)h->serial + (uint64_t)per_slot >= 0xFFFFFFFFull) {
-        GORSE_HIP_CHECK(hipMemsetAsync(h->cell.p, 0, (size_t)h->slots * h->N * sizeof(sparse::Cell), h->stream));
-        h->serial = 0;
+    GORSE_TRY(h->next.ensure(1));
+    // work items, longest first; long queries as 8 items (one per stripe)
+    std::vector<sparse::Work> work;
+    std::vector<int64_t> cost;
+    std::vector<int32_t> split_t;
+    work.reserve((size_t)nq);
+    cost.reserve((size_t)nq);
+    for (int64_t t = 0; t < nq; t++) {
+        const int64_t L = q_len_host[t + 1] - q_len_host[t];
+        if (g_sparse_split > 0 && L > g_sparse_split && h->ntiles >= sparse::kStripes) {
+            for (int s = 0; s < sparse::kStripes; s++) {
+                work.push_back(sparse::Work{(int32_t)t, s, (int32_t)split_t.size()});
+                cost.push_back(L / sparse::kStripes + 1);
+            }
+            split_t.push_back((int32_t)t);
+        } else {
+            work.push_back(sparse::Work{(int32_t)t, -1, 0});
+            cost.push_back(L);
+        }
+    }
+    {
+        std::vector<int32_t> by(work.size());
+        for (size_t i = 0; i < by.size(); i++) by[i] = (int32_t)i;
+        std::stable_sort(by.begin(), by.end(), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
+        std::vector<sparse::Work> sorted(work.size());
+        for (size_t i = 0; i < by.size(); i++) sorted[i] = work[(size_t)by[i]];
+        work.swap(sorted);
+    }
+    GORSE_TRY(h->work.ensure(work.size()));
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
+    if (!split_t.empty()) {
+        GORSE_TRY(h->split_t.ensure(split_t.size()));
+        GORSE_TRY(h->part_keys.ensure(split_t.size() * sparse::kStripes * (size_t)kp));
+        GORSE_TRY(h->part_cnt.ensure(split_t.size() * sparse::kStripes * 2));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, split_t.data(), split_t.size() * 4, hipMemcpyHostToDevice, h->stream));
     }
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
-    QueryArgs a;
-    a.p_ptr = h->p_ptr.p, a.p_row = h->p_row.p, a.p_val = h->p_val.p, a.D = h->D;
-    a.q_ptr = qp, a.q_idx = qi, a.q_val = qv, a.q_first = q_first, a.nq = nq;
+    GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sizeof(int32_t), h->stream));
+    TileArgs a;
+    a.off = h->off.p, a.post = h->post.p, a.ntiles = h->ntiles, a.logT = h->logT, a.N = h->N;
+    a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
+    a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
     a.exclude = excl_dev, a.exclude_self = exclude_self;
-    a.heavy_dims = g_sparse_heavy_dims > 0 ? g_sparse_heavy_dims : INT64_MAX;
-    a.mask = h->has_mask ? h->mask.p : nullptr;
+    a.mask_sid = h->has_mask ? h->mask_sid.p : nullptr;
     a.n_admissible = h->has_mask ? h->n_admissible : h->N;
-    a.N = h->N;
-    a.cell = h->cell.p, a.touched = h->touched.p;
-    a.orig_of = h->orig_of.p;
-    a.serial_base = h->serial;
+    a.work = h->work.p, a.n_work = (int32_t)work.size(), a.next = h->next.p;
     a.k = k;
     a.out_idx = h->out_idx.p, a.out_score = h->out_score.p, a.out_cnt = h->out_cnt.p;
+    a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
     a.stat = h->stat.p;
-    h->serial += (uint32_t)per_slot;
+    const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
+    const size_t lds = (size_t)2 * kp * 8 + ((size_t)4 << h->logT);
     const int tok = h->prof.begin(0, h->stream);
     switch (kp) {
-        case 256: launch_query<256>(a, (unsigned)grid, h->stream); break;
-        case 512: launch_query<512>(a, (unsigned)grid, h->stream); break;
-        default: launch_query<1024>(a, (unsigned)grid, h->stream); break;
+        case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;
+        case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, h->stream)); break;
+        default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, h->stream)); break;
     }
     GORSE_HIP_CHECK(hipGetLastError());
-    // the queries the kernel above skipped: row streaming, kHeavyBatch of them per pass over the stored rows
-    std::vector<int64_t> heavy;
-    for (int64_t t = 0; t < nq; t++)
-        if (q_len_host[t + 1] - q_len_host[t] > a.heavy_dims) heavy.push_back(t);
-    if (!heavy.empty()) {
-        GORSE_TRY(h->hscore.ensure((size_t)sparse::kHeavyBatch * h->N));
-        GORSE_TRY(h->hcommon.ensure((size_t)sparse::kHeavyBatch * h->N));
-        sparse::HeavyArgs ha;
-        ha.r_ptr = h->r_ptr.p, ha.r_idx = h->r_idx.p, ha.r_val = h->r_val.p, ha.N = h->N;
-        ha.q_ptr = qp, ha.q_idx = qi, ha.q_val = qv, ha.q_first = q_first;
-        ha.score = h->hscore.p, ha.common = h->hcommon.p;
-        ha.exclude = excl_dev, ha.exclude_self = exclude_self, ha.mask = a.mask, ha.n_admissible = a.n_admissible;
-        ha.k = k, ha.out_idx = a.out_idx, ha.out_score = a.out_score, ha.out_cnt = a.out_cnt, ha.stat = a.stat;
-        const unsigned sgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, ceil_div(h->N, 256)));
-        for (size_t at = 0; at < heavy.size(); at += sparse::kHeavyBatch) {
-            ha.nb = (int)std::min<size_t>(sparse::kHeavyBatch, heavy.size() - at);
-            for (int b = 0; b < sparse::kHeavyBatch; b++) ha.hq[b] = b < ha.nb ? heavy[at + b] : 0;
-            sparse::sparse_heavy_score_kernel<<<dim3(sgrid), dim3(256), 0, h->stream>>>(ha);
-            sparse::sparse_heavy_rank_kernel<<<dim3((unsigned)ha.nb), dim3(sparse::kHeavyRankBlock), 0, h->stream>>>(ha);
+    if (!split_t.empty()) {
+        sparse::MergeArgs m;
+        m.split_t = h->split_t.p, m.n_split = (int32_t)split_t.size();
+        m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
+        m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
+        m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
+        m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
+        const unsigned mg = (unsigned)std::min<size_t>(split_t.size(), 4096);
+        switch (kp) {
+            case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }
@@ -162,10 +182,18 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const uint32_t *qi, cons
     if (score_out)
         GORSE_HIP_CHECK(hipMemcpyAsync(score_out, h->out_score.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
     if (cnt_out) GORSE_HIP_CHECK(hipMemcpyAsync(cnt_out, h->out_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
-    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from `work` / `split_t`
     h->last_postings = (int64_t)st[0];
     h->last_hits = (int64_t)st[1];
     return GORSE_OK;
+}
+
+// ds_add_f32 is used when no partial sum can be subnormal: every term then is 0 or at least 2^-100 in magnitude, and a
+// non-zero difference of such terms is at least 2^-123
+bool atomic_ok(float stored_small, float query_small) {
+    if (g_sparse_atomic >= 0) return g_sparse_atomic != 0;
+    if (stored_small == 0.0f || query_small == 0.0f) return true;  // no non-zero product at all
+    return (double)stored_small * (double)query_small >= 0x1p-100;
 }
 
 }  // namespace
@@ -180,73 +208,63 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     if (!bad.empty()) return fail(GORSE_ERR_INVALID, "stored vectors: %s", bad.c_str());
     const int64_t base = indptr[0], nnz = indptr[N] - indptr[0];
     if (nnz > 0 && !values) return fail(GORSE_ERR_INVALID, "values is NULL");
+    if (nnz >= (int64_t)UINT32_MAX) return fail(GORSE_ERR_INVALID, "more than 2^32 - 2 stored entries");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
     if (device < 0 || device >= ndev) return fail(GORSE_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
-    const bool on_device = g_sparse_build == 1;
-    const sparse::RowOrder order = sparse::order_rows(N, indptr);
-    sparse::Postings post;
-    if (on_device) {  // only the index space is needed from the host
-        for (int64_t t = base; t < base + nnz; t++) post.D = indices[t] >= post.D ? (int64_t)indices[t] + 1 : post.D;
-        if (post.D > sparse::kMaxDims)
-            return fail(GORSE_ERR_INVALID, "largest index %lld exceeds the supported index space", (long long)(post.D - 1));
-    } else {
-        const std::string why = sparse::build_postings(N, indptr, indices, values, post, order.new_of.data());
-        if (!why.empty()) return fail(GORSE_ERR_INVALID, "%s", why.c_str());
-    }
     gorse_sparse *h = new (std::nothrow) gorse_sparse();
     if (!h) return fail(GORSE_ERR_NOMEM, "out of host memory");
     h->device = device;
     h->N = N;
     h->nnz = nnz;
-    h->D = post.D;
+    h->order = sparse::order_rows(N, indptr);
+    const std::vector<uint32_t> dims = sparse::distinct_indices(indices + base, nnz);
+    h->Dc = (int64_t)dims.size();
+    h->logT = pick_log_tile(N);
+    h->ntiles = (int32_t)(ceil_div(N, (int64_t)sparse::kStripes << h->logT) * sparse::kStripes);
     int32_t rc = [&]() -> int32_t {
+        const int64_t cells = h->Dc * h->ntiles;
+        if (cells >= (int64_t)1 << 33) return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d row tiles",
+                                                   (long long)h->Dc, h->ntiles);
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         std::vector<int64_t> &ptr0 = h->r_ptr_host;
         ptr0.resize((size_t)N + 1);
         for (int64_t r = 0; r <= N; r++) ptr0[(size_t)r] = indptr[r] - base;
         GORSE_TRY(h->r_ptr.alloc((size_t)N + 1));
-        GORSE_TRY(h->r_idx.alloc((size_t)nnz));
+        GORSE_TRY(h->r_cid.alloc((size_t)nnz));
         GORSE_TRY(h->r_val.alloc((size_t)nnz));
-        GORSE_TRY(h->p_ptr.alloc((size_t)post.D + 1));
-        GORSE_TRY(h->p_row.alloc((size_t)nnz));
         GORSE_TRY(h->orig_of.alloc((size_t)N));
-        GORSE_HIP_CHECK(hipMemcpyAsync(h->orig_of.p, order.orig_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
-        GORSE_TRY(h->p_val.alloc((size_t)nnz));
+        GORSE_TRY(h->new_of.alloc((size_t)N));
+        GORSE_TRY(h->dims.alloc((size_t)h->Dc));
+        GORSE_TRY(h->off.alloc((size_t)cells + 1));
+        GORSE_TRY(h->post.alloc((size_t)nnz));
+        DevBuf<uint32_t> raw, cursor, sums;
+        GORSE_TRY(raw.alloc((size_t)nnz));
+        GORSE_TRY(cursor.alloc((size_t)cells + 1));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->orig_of.p, h->order.orig_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->new_of.p, h->order.new_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->r_ptr.p, ptr0.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->off.p, 0, ((size_t)cells + 1) * 4, h->stream));
         if (nnz > 0) {
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->r_idx.p, indices + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->dims.p, dims.data(), dims.size() * 4, hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(raw.p, indices + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->r_val.p, values + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
-        }
-        if (on_device) {  // counting sort of the uploaded CSR entries by index: count, scan (one workgroup), scatter
-            DevBuf<unsigned long long> cursor;
-            DevBuf<int32_t> new_of;
-            GORSE_TRY(cursor.alloc((size_t)post.D));
-            GORSE_TRY(new_of.alloc((size_t)N));
-            GORSE_HIP_CHECK(hipMemcpyAsync(new_of.p, order.new_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
-            GORSE_HIP_CHECK(hipMemsetAsync(h->p_ptr.p, 0, ((size_t)post.D + 1) * 8, h->stream));
+            const unsigned eg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(nnz, 256)));
+            sparse::sparse_translate_kernel<<<dim3(eg), dim3(256), 0, h->stream>>>(raw.p, nnz, h->dims.p, h->Dc, h->r_cid.p);
             sparse::BuildArgs b;
-            b.r_ptr = h->r_ptr.p, b.r_idx = h->r_idx.p, b.r_val = h->r_val.p;
-            b.N = N, b.nnz = nnz, b.D = post.D;
-            b.p_ptr = reinterpret_cast<unsigned long long *>(h->p_ptr.p), b.cursor = cursor.p;
-            b.p_row = h->p_row.p, b.p_val = h->p_val.p, b.new_of = new_of.p;
-            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, ceil_div(nnz, 256)));
-            sparse::sparse_count_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(b);
-            sparse::sparse_scan_kernel<<<dim3(1), dim3(sparse::kScanBlock), 0, h->stream>>>(b);
-            sparse::sparse_scatter_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(b);
+            b.r_ptr = h->r_ptr.p, b.r_cid = h->r_cid.p, b.r_val = h->r_val.p, b.N = N, b.new_of = h->new_of.p;
+            b.ntiles = h->ntiles, b.logT = h->logT, b.cnt = h->off.p, b.post = h->post.p;
+            const unsigned rg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(N, 4)));
+            sparse::sparse_build_kernel<false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);  // counts per (index, tile)
+            GORSE_TRY(scan_exclusive(h->off.p, cells + 1, sums, h->stream));               // -> the directory
+            GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->off.p, ((size_t)cells + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
+            b.cnt = cursor.p;
+            sparse::sparse_build_kernel<true><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
             GORSE_HIP_CHECK(hipGetLastError());
-            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // `cursor` and `new_of` are freed when this scope ends
-        } else {
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->p_ptr.p, post.ptr.data(), ((size_t)post.D + 1) * 8, hipMemcpyHostToDevice,
-                                           h->stream));
-            if (nnz > 0) {
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->p_row.p, post.row.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->p_val.p, post.val.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
-            }
         }
-        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the host staging vectors die with this scope
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the temporaries die with this scope
         return GORSE_OK;
     }();
     if (rc != GORSE_OK) {
@@ -255,6 +273,7 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         last_error() = keep;
         return rc;
     }
+    h->stored_small = sparse::smallest_magnitude(values ? values + base : nullptr, nnz);
     *out = h;
     return GORSE_OK;
 }
@@ -277,11 +296,15 @@ extern "C" int32_t gorse_sparse_set_mask(gorse_sparse *h, const uint8_t *admissi
         h->has_mask = false;
         return GORSE_OK;
     }
-    GORSE_TRY(h->mask.ensure((size_t)h->N));
-    GORSE_HIP_CHECK(hipMemcpyAsync(h->mask.p, admissible, (size_t)h->N, hipMemcpyHostToDevice, h->stream));
-    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<uint8_t> by_sid((size_t)h->N);
     h->n_admissible = 0;
-    for (int64_t r = 0; r < h->N; r++) h->n_admissible += admissible[r] != 0;
+    for (int64_t s = 0; s < h->N; s++) {
+        by_sid[(size_t)s] = admissible[h->order.orig_of[(size_t)s]] != 0;
+        h->n_admissible += by_sid[(size_t)s];
+    }
+    GORSE_TRY(h->mask_sid.ensure((size_t)h->N));
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->mask_sid.p, by_sid.data(), (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->has_mask = true;
     return GORSE_OK;
 }
@@ -305,19 +328,24 @@ extern "C" int32_t gorse_sparse_search(gorse_sparse *h, int64_t nq, const int64_
     for (int64_t t = 0; t <= nq; t++) ptr0[(size_t)t] = q_indptr[t] - base;
     GORSE_TRY(h->q_ptr.ensure((size_t)nq + 1));
     GORSE_TRY(h->q_idx.ensure((size_t)qnnz));
+    GORSE_TRY(h->q_cid.ensure((size_t)qnnz));
     GORSE_TRY(h->q_val.ensure((size_t)qnnz));
     GORSE_HIP_CHECK(hipMemcpyAsync(h->q_ptr.p, ptr0.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, h->stream));
     if (qnnz > 0) {
         GORSE_HIP_CHECK(hipMemcpyAsync(h->q_idx.p, q_indices + base, (size_t)qnnz * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->q_val.p, q_values + base, (size_t)qnnz * 4, hipMemcpyHostToDevice, h->stream));
+        const unsigned eg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(qnnz, 256)));
+        sparse::sparse_translate_kernel<<<dim3(eg), dim3(256), 0, h->stream>>>(h->q_idx.p, qnnz, h->dims.p, h->Dc, h->q_cid.p);
+        GORSE_HIP_CHECK(hipGetLastError());
     }
     if (exclude) {
         GORSE_TRY(h->q_excl.ensure((size_t)nq));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->q_excl.p, exclude, (size_t)nq * 8, hipMemcpyHostToDevice, h->stream));
     }
+    const bool atomic = atomic_ok(h->stored_small, sparse::smallest_magnitude(q_values ? q_values + base : nullptr, qnnz));
     // run_queries ends with a stream synchronisation, which also covers the uploads from ptr0
-    return run_queries(h, h->q_ptr.p, h->q_idx.p, h->q_val.p, 0, nq, q_indptr, exclude ? h->q_excl.p : nullptr, 0, k, idx_out,
-                       score_out, count_out);
+    return run_queries(h, h->q_ptr.p, h->q_cid.p, h->q_val.p, 0, nq, ptr0.data(), exclude ? h->q_excl.p : nullptr, 0, k, atomic,
+                       idx_out, score_out, count_out);
 }
 
 extern "C" int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t exclude_self,
@@ -326,8 +354,8 @@ extern "C" int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int6
     if (q_begin < 0 || q_end > h->N || q_begin > q_end || k <= 0) return fail(GORSE_ERR_RANGE, "bad query range");
     if (q_begin == q_end) return GORSE_OK;
     GORSE_TRY(h->use());
-    return run_queries(h, h->r_ptr.p, h->r_idx.p, h->r_val.p, q_begin, q_end - q_begin, h->r_ptr_host.data() + q_begin, nullptr,
-                       exclude_self != 0, k, idx_out, score_out, count_out);
+    return run_queries(h, h->r_ptr.p, h->r_cid.p, h->r_val.p, q_begin, q_end - q_begin, h->r_ptr_host.data() + q_begin, nullptr,
+                       exclude_self != 0, k, atomic_ok(h->stored_small, h->stored_small), idx_out, score_out, count_out);
 }
 
 extern "C" int32_t gorse_sparse_synchronize(gorse_sparse *h) {
@@ -361,12 +389,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
     return GORSE_OK;
 }
 
-extern "C" void gorse_hip_test_set_sparse_build(int32_t mode) { g_sparse_build = mode; }
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
-extern "C" void gorse_hip_test_set_sparse_heavy(int64_t dims) { g_sparse_heavy_dims = dims; }
-extern "C" void gorse_hip_test_set_sparse_hot(int32_t rows) { g_sparse_hot = rows; }
-extern "C" int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial) {
-    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
-    h->serial = serial;
-    return GORSE_OK;
-}
+extern "C" void gorse_hip_test_set_sparse_tile(int32_t rows) { g_sparse_tile = rows; }
+extern "C" void gorse_hip_test_set_sparse_split(int64_t entries) { g_sparse_split = entries; }
+extern "C" void gorse_hip_test_set_sparse_atomic(int32_t mode) { g_sparse_atomic = mode; }

@@ -1,5 +1,5 @@
-// sparse_host.hpp -- host-side index construction of the sparse top-k (no HIP in here: sparse.hip uses it before the
-// upload, tests/emu/sparse_emu.cpp uses the very same code in front of the emulated kernel).
+// sparse_host.hpp -- host-side part of the index construction of the sparse top-k (no HIP in here): CSR validation, the
+// scratch numbering of the rows, the list of distinct indices.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -9,8 +9,6 @@
 
 namespace gorse {
 namespace sparse {
-
-constexpr int64_t kMaxDims = (int64_t)1 << 30;  // posting-list directory: 8 bytes per possible index
 
 // CSR sanity: indptr non-decreasing from a non-negative start, indices strictly ascending inside a row (what
 // slices.Sort + a set give the reference's writers, logics/item_to_item.go:187-193).  Returns "" or the complaint.
@@ -29,8 +27,8 @@ inline std::string validate_csr(int64_t rows, const int64_t *indptr, const uint3
 }
 
 // Scratch numbering of the stored rows: longest row first (ties by row).  Rows with many entries are the ones most queries
-// reach, so the first H scratch ids are where an LDS-resident slice of the accumulators pays; results, masks and
-// exclusions keep the caller's row ids (orig_of translates back).
+// reach; numbering them first puts them into the first tiles (sparse_kernels.hpp), whose accumulators are then dense.
+// Results, masks and exclusions keep the caller's row ids (orig_of translates back).
 struct RowOrder {
     std::vector<int32_t> new_of;   // caller's row -> scratch id
     std::vector<int32_t> orig_of;  // scratch id -> caller's row
@@ -47,40 +45,41 @@ inline RowOrder order_rows(int64_t N, const int64_t *indptr) {
     return o;
 }
 
-// Postings (the transposed CSR) by counting sort: list t holds the (scratch ids of the) rows that contain index t, in
-// ascending order of the caller's row ids.
-// D = largest index + 1 (0 without entries).
-struct Postings {
-    int64_t D = 0;
-    std::vector<int64_t> ptr;   // D + 1
-    std::vector<int32_t> row;   // nnz
-    std::vector<float> val;     // nnz
-};
-// `new_of` (may be null = identity): the id stored for row r
-inline std::string build_postings(int64_t N, const int64_t *indptr, const uint32_t *indices, const float *values,
-                                  Postings &out, const int32_t *new_of = nullptr) {
-    const int64_t b = N > 0 ? indptr[0] : 0, e = N > 0 ? indptr[N] : 0;
-    int64_t D = 0;
-    for (int64_t t = b; t < e; t++) D = indices[t] >= D ? (int64_t)indices[t] + 1 : D;
-    if (D > kMaxDims) return "largest index " + std::to_string(D - 1) + " exceeds the supported index space";
-    out.D = D;
-    out.ptr.assign((size_t)D + 1, 0);
-    out.row.resize((size_t)(e - b));
-    out.val.resize((size_t)(e - b));
-    for (int64_t t = b; t < e; t++) out.ptr[(size_t)indices[t] + 1]++;
-    for (int64_t t = 0; t < D; t++) out.ptr[(size_t)t + 1] += out.ptr[(size_t)t];
-    std::vector<int64_t> cur(out.ptr.begin(), out.ptr.end() - 1);
-    for (int64_t r = 0; r < N; r++)
-        for (int64_t t = indptr[r]; t < indptr[r + 1]; t++) {
-            const int64_t at = cur[indices[t]]++;
-            out.row[(size_t)at] = new_of ? new_of[r] : (int32_t)r;
-            out.val[(size_t)at] = values[t];
-        }
-    return "";
+// The sorted distinct indices of the stored entries: the posting-list directory has one row per index that occurs, so
+// the raw index space (up to 2^32) costs nothing.  A bitmap where the space is small enough, a sort otherwise.
+inline std::vector<uint32_t> distinct_indices(const uint32_t *indices, int64_t nnz) {
+    std::vector<uint32_t> out;
+    if (nnz <= 0) return out;
+    uint32_t top = 0;
+    for (int64_t t = 0; t < nnz; t++) top = indices[t] > top ? indices[t] : top;
+    if ((uint64_t)top < ((uint64_t)1 << 31)) {  // <= 256 MB of bits
+        std::vector<uint64_t> bits(((size_t)top >> 6) + 1, 0);
+        for (int64_t t = 0; t < nnz; t++) bits[indices[t] >> 6] |= (uint64_t)1 << (indices[t] & 63);
+        size_t n = 0;
+        for (uint64_t w : bits) n += (size_t)__builtin_popcountll(w);
+        out.reserve(n);
+        for (size_t w = 0; w < bits.size(); w++)
+            for (uint64_t b = bits[w]; b; b &= b - 1) out.push_back((uint32_t)((w << 6) + (size_t)__builtin_ctzll(b)));
+    } else {
+        out.assign(indices, indices + nnz);
+        std::sort(out.begin(), out.end());
+        out.erase(std::unique(out.begin(), out.end()), out.end());
+    }
+    return out;
 }
 
-// LDS ranking buffer of sparse_query_kernel: the smallest instantiated KP >= k (0 = k too large); 256 at least, because a
-// lane ranks four candidates between two votes of its 64-lane workgroup (sparse_kernels.hpp rank_candidates)
+// smallest non-zero finite |value| (0 when there is none): sparse.hip uses ds_add_f32 only where no product of a stored and a
+// query value -- hence no partial sum -- can come near the subnormal range
+inline float smallest_magnitude(const float *v, int64_t n) {
+    float m = 0.0f;
+    for (int64_t t = 0; t < n; t++) {
+        const float x = v[t] < 0 ? -v[t] : v[t];
+        if (x > 0.0f && x <= 3.4028234e38f && (m == 0.0f || x < m)) m = x;
+    }
+    return m;
+}
+
+// LDS ranking buffer of sparse_tile_kernel: the smallest instantiated KP >= k (0 = k too large)
 inline int pick_kp(int k) {
     for (int kp = 256; kp <= 1024; kp <<= 1)
         if (k <= kp) return kp;

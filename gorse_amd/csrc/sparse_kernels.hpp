@@ -2,15 +2,23 @@
 // vectors.Database (storage/vectors/database.go:90-97, xvec.go:241-247: Dot over Indices / Values, exact Flat index)
 // that the IDF item-to-item / user-to-user writers fill (logics/vector_writer.go:192-209).
 //
-// sparse_query_kernel: one workgroup (one wave) answers one query at a time.  The stored rows are held as POSTINGS (one
-// list of (row, value) per index); the query's indices are walked in ascending order and, for each, the lanes stream that
-// posting list (coalesced 4-byte rows + 4-byte values = the 8 algorithmic bytes per multiply-add) and update a
-// per-workgroup accumulator (the high word of `cell[row]`).  A row occurs at most once per posting list, so inside one
-// list no two lanes touch the same accumulator, and the barrier between lists makes every row's sum run in ascending
-// index order: the float32 result is the merge-order sparse dot of the oracle bit for bit, with no atomics on data.
-// Rows reached for the first time (the low word of cell[row] != serial of this query) are appended to a `touched`
-// list; only those are ranked, so nothing of size N is cleared or scanned per query.  Queries with very many entries go
-// to the row-streaming kernels further down instead (sparse_heavy_*).
+// Round 2 design (round 1's kernel kept its accumulators in global memory and walked one posting list per memory round
+// trip: a 16,384-entry query was a 125 ms tail on one wave and the row-streaming path of the 64 longest queries took 11.6 s
+// of the 12.6 s pass, profiles/r02_a_kernel_stats_i2i.txt):
+//
+// * The stored rows are numbered longest first (scratch ids) and cut into TILES of T rows: rows [g*8T, (g+1)*8T) form a
+//   group, the row with scratch id sid belongs to stripe sid % 8 of its group, and tile 8g + s holds stripe s of group g
+//   (interleaving spreads the popular rows evenly over the 8 tiles of a group).  The posting list of every index is stored
+//   sorted by tile, with a directory off[index][tile] of where each tile's segment starts.
+// * One wave answers one query, one tile at a time, with the tile's T accumulators in LDS: it walks the query's indices in
+//   ascending order and, for each, streams that index's segment of the tile (8 bytes per posting, coalesced) into the
+//   accumulators with ds_add_f32.  A row occurs at most once per posting list, so the lanes of one instruction never
+//   collide, and the LDS executes one wave's instructions in issue order: every accumulator receives its products in
+//   ascending index order -- the float32 merge-order sparse dot of the oracle, bit for bit -- without a single wait in the
+//   loop (the adds return nothing).  A tile's results are read back either by a linear scan of its accumulators (dense
+//   tiles) or by walking the same segments again with ds_wrxchg (sparse tiles); both leave the accumulators zero.
+// * Queries with many entries are split over the 8 stripes (8 work items, one per stripe, each ranking its own tiles);
+//   sparse_merge_kernel joins the 8 partial rankings.  Work items are drawn longest first from one counter.
 //
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
 // well-defined answer whatever order the lanes append in.  Keys above the running threshold go to an LDS buffer of
@@ -18,58 +26,66 @@
 // The reference ranks ALL admissible documents (one sharing no index scores 0), cuts to topK and THEN drops Score == 0
 // (xvec.go:419-421), so zero-score documents use up slots: only the non-zero rows are ranked here, and the number of
 // results follows from the counts of positive / negative rows and the number of admissible rows (see `written`).
-//
-// Only constructs that tests/emu/hip_emu.hpp can also run on the CPU are used here (threadIdx/blockIdx, static
-// __shared__, __syncthreads, __syncthreads_or, integer atomicAdd): the kernel's control flow is exercised without a GPU
-// by tests/test_sparse_kernel_emu_cpu.py.  That emulation is test infrastructure; the product runs this file on gfx950.
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 
 namespace gorse {
 namespace sparse {
 
-constexpr int kBlock = 64;  // one wavefront per workgroup: the per-list barrier costs a wave-local s_barrier
-constexpr int kRankUnroll = 4;   // candidates a lane of sparse_query_kernel ranks between two votes (KP >= 4 * kBlock)
-constexpr int kHeavyRankBlock = 1024;  // sparse_heavy_rank_kernel: sixteen waves stream the N rows of one heavy query
+constexpr int kBlock = 64;    // one wavefront per workgroup
+constexpr int kStripes = 8;   // tiles per row group = parts of a split query
+constexpr int kLogStripes = 3;
 
-// One scratch cell per (workgroup, stored row): low word = serial of the last query that reached the row, high word = the
-// bits of its running inner product.  Kept as ONE 64-bit integer so that a posting costs one 8-byte load and one 8-byte
-// store (as a two-field struct the compiler loads the stamp, branches, and loads the sum in a second round trip).
-using Cell = unsigned long long;
-__device__ inline uint32_t cell_stamp(Cell c) { return (uint32_t)c; }
-__device__ inline float cell_acc(Cell c) { return __uint_as_float((uint32_t)(c >> 32)); }
-__device__ inline Cell make_cell(uint32_t stamp, float acc) { return ((Cell)__float_as_uint(acc) << 32) | (Cell)stamp; }
+struct Posting {
+    int32_t loc;  // accumulator of the row inside its tile
+    float val;
+};
 
-struct QueryArgs {
-    // postings of the N stored rows: list of index t = p_row / p_val [p_ptr[t], p_ptr[t+1]), D lists
-    const int64_t *p_ptr;
-    const int32_t *p_row;
-    const float *p_val;
-    int64_t D;
-    // queries: CSR rows q_first .. q_first + nq of (q_ptr, q_idx, q_val); indices strictly ascending per row
+// scratch id <-> (tile, accumulator)
+__host__ __device__ inline int32_t tile_of(int64_t sid, int logT) {
+    return (int32_t)((sid >> (logT + kLogStripes)) << kLogStripes) + (int32_t)(sid & (kStripes - 1));
+}
+__host__ __device__ inline int32_t loc_of(int64_t sid, int logT) {
+    return (int32_t)((sid & (((int64_t)1 << (logT + kLogStripes)) - 1)) >> kLogStripes);
+}
+__host__ __device__ inline int64_t sid_of(int32_t tile, int32_t loc, int logT) {
+    return ((int64_t)(tile >> kLogStripes) << (logT + kLogStripes)) + ((int64_t)loc << kLogStripes) + (tile & (kStripes - 1));
+}
+
+struct Work {
+    int32_t t;       // query of the call
+    int32_t stripe;  // -1 = all tiles, else the tiles 8g + stripe
+    int32_t pslot;   // split queries: which block of partial rankings
+};
+
+struct TileArgs {
+    // index
+    const uint32_t *off;  // Dc * ntiles + 1: segment (c, tile) = post[off[c * ntiles + tile], off[c * ntiles + tile + 1])
+    const Posting *post;
+    int32_t ntiles, logT;
+    int64_t N;
+    const int32_t *orig_of, *new_of;  // scratch id <-> caller's row
+    // queries: CSR rows q_first .. of (q_ptr, q_cid, q_val); q_cid = directory entry of the index or -1 (never stored)
     const int64_t *q_ptr;
-    const uint32_t *q_idx;
+    const int32_t *q_cid;
     const float *q_val;
-    int64_t q_first, nq;
+    int64_t q_first;
     const int64_t *exclude;  // per query: a stored row left out of its result (-1 = none); may be null
     int exclude_self;        // all pairs: query t is stored row q_first + t, left out of its own result
-    int64_t heavy_dims;      // queries with more entries than this are left to the row-streaming kernels below
-    const uint8_t *mask;     // admissible[row] or null
-    int64_t n_admissible;    // number of admissible rows (N without a mask)
-    int64_t N;
-    // posting lists and scratch use SCRATCH ids (longest stored row first, sparse_host.hpp order_rows); orig_of translates
-    // back to the caller's row ids, which masks, exclusions and results use
-    const int32_t *orig_of;
-    // scratch, N entries per workgroup each: (stamp, accumulator) pairs -- one 8-byte access per posting -- and the list
-    // of rows the current query has reached
-    Cell *cell;
-    int32_t *touched;
-    uint32_t serial_base;  // stamps of this launch are serial_base + 1 ..; never reused for a scratch slot
+    const uint8_t *mask_sid;  // admissible[scratch id] or null
+    int64_t n_admissible;     // number of admissible rows (N without a mask)
+    const Work *work;
+    int32_t n_work;
+    int32_t *next;  // work counter
     int k;
     int32_t *out_idx;   // nq x k, padded with -1
     float *out_score;   // nq x k, padded with -inf
     int32_t *out_cnt;   // nq
-    unsigned long long *stat;  // [0] += postings walked, [1] += rows hit
+    unsigned long long *part_keys;  // per (pslot, stripe): KP keys, descending, padded with 0
+    int32_t *part_cnt;              // per (pslot, stripe): rows scoring above / below zero
+    unsigned long long *stat;       // [0] += postings walked, [1] += rows with a non-zero score
 };
 
 constexpr uint32_t kZeroOrd = 0x80000000u;  // ordered bits of +0
@@ -98,12 +114,12 @@ __device__ inline float key_score(unsigned long long key) {
 }
 __device__ inline int32_t key_row(unsigned long long key) { return (int32_t)(0xFFFFFFFFu - (uint32_t)key); }
 
-// bitonic sort of b[0..CAP) into descending order by all threads of the workgroup; ends with a barrier
+// bitonic sort of b[0..CAP) into descending order by the 64 lanes of the workgroup; ends with a barrier
 template <int CAP>
-__device__ inline void sort_desc(unsigned long long *b, int tid, int nt) {
+__device__ inline void sort_desc(unsigned long long *b, int tid) {
     for (int size = 2; size <= CAP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < CAP; i += nt) {
+            for (int i = tid; i < CAP; i += kBlock) {
                 const int j = i ^ stride;
                 if (j > i) {
                     const bool desc = (i & size) == 0;
@@ -119,338 +135,422 @@ __device__ inline void sort_desc(unsigned long long *b, int tid, int nt) {
     }
 }
 
-// The ranking shared by both query paths: candidates i = 0 .. count-1, key_at(i) = its 64-bit key or 0 for "not a candidate"
-// (called once per i by the lane that owns it).  Every lane takes U candidates between two votes of the workgroup (a vote
-// is a barrier, and a query that reaches most of 200,000 rows would otherwise pay 3000 of them on its one wave).  Leaves
-// the min(buffered, CAP) best keys sorted descending in s_buf and returns how many are buffered (> 0 only).  s_thr / s_bcnt
-// must be 0 on entry; needs U * blockDim.x <= KP (after a cut to KP the CAP - KP free slots take every candidate still
-// waiting).  All lanes of the workgroup call it together.
-template <int KP, int U, typename KeyAt>
-__device__ inline int rank_candidates(int64_t count, KeyAt key_at, int k, unsigned long long *s_buf, unsigned long long *s_thr,
-                                      int *s_bcnt, int tid, int nt) {
+__device__ inline int lanes_below(unsigned long long m, int lane) { return __popcll(m & (((unsigned long long)1 << lane) - 1)); }
+__device__ inline uint32_t lane_u32(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ inline float lane_f32(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ inline long long wave_sum(long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// The wave's ranking buffer: lanes with want hand their key in; bcnt (slots in use) and thr (keys <= thr cannot be among the
+// k best) are wave-uniform.  After an overflow the KP best keys stay, sorted.
+template <int KP>
+__device__ inline void push(unsigned long long *s_buf, int k, int &bcnt, unsigned long long &thr, unsigned long long key, bool want,
+                            int lane) {
     constexpr int CAP = 2 * KP;
-    for (int64_t base = 0; base < count; base += (int64_t)nt * U) {
-        unsigned long long key[U];
-        bool want[U];
-        const unsigned long long thr = *s_thr;
-        for (int u = 0; u < U; u++) {
-            const int64_t i = base + (int64_t)u * nt + tid;
-            key[u] = i < count ? key_at(i) : 0;  // 0 is below every real key
-            want[u] = key[u] > thr;
+    unsigned long long m = __ballot(want);
+    while (m) {
+        const int slot = bcnt + lanes_below(m, lane);
+        if (want && slot < CAP) {
+            s_buf[slot] = key;
+            want = false;
         }
-        while (true) {
-            bool over = false;
-            for (int u = 0; u < U; u++)
-                if (want[u]) {
-                    const int slot = atomicAdd(s_bcnt, 1);
-                    if (slot < CAP) {
-                        s_buf[slot] = key[u];
-                        want[u] = false;
-                    } else {
-                        over = true;
-                    }
-                }
-            if (!__syncthreads_or(over ? 1 : 0)) break;  // every candidate found a slot
-            // some candidate drew a slot >= CAP, so slots 0..CAP-1 are all written: keep the KP best
-            sort_desc<CAP>(s_buf, tid, nt);
-            if (tid == 0) {
-                *s_bcnt = KP;
-                *s_thr = s_buf[k - 1];
-            }
-            __syncthreads();
-            for (int u = 0; u < U; u++) want[u] = want[u] && key[u] > *s_thr;
+        const int total = bcnt + __popcll(m);
+        if (total <= CAP) {
+            bcnt = total;
+            break;
         }
+        __syncthreads();  // slots 0 .. CAP-1 are all written: keep the KP best
+        sort_desc<CAP>(s_buf, lane);
+        bcnt = KP;
+        thr = s_buf[k - 1];
+        want = want && key > thr;
+        m = __ballot(want);
     }
+}
+
+// sorts what the buffer holds (padding with 0) -- positive scores first, then the negative ones; all lanes together
+template <int KP>
+__device__ inline void finish(unsigned long long *s_buf, int bcnt, int lane) {
+    constexpr int CAP = 2 * KP;
     __syncthreads();
-    const int n = *s_bcnt;  // <= CAP: an overflow is always followed by the cut to KP
-    if (n > 0) {
-        for (int i = n + tid; i < CAP; i += nt) s_buf[i] = 0;
-        __syncthreads();
-        sort_desc<CAP>(s_buf, tid, nt);  // positive scores first, then the negative ones
-    }
-    return n;
+    for (int i = bcnt + lane; i < CAP; i += kBlock) s_buf[i] = 0;
+    __syncthreads();
+    if (bcnt > 0) sort_desc<CAP>(s_buf, lane);
 }
 
 // result row t from the sorted buffer: cnt entries, the rest padded
-__device__ inline void write_result(const unsigned long long *s_buf, int cnt, int k, int64_t t, int32_t *out_idx,
-                                    float *out_score, int32_t *out_cnt, int tid, int nt) {
-    for (int i = tid; i < k; i += nt) {
+__device__ inline void write_result(const unsigned long long *s_buf, int cnt, int k, int64_t t, int32_t *out_idx, float *out_score,
+                                    int32_t *out_cnt, int lane) {
+    for (int i = lane; i < k; i += kBlock) {
         const unsigned long long key = i < cnt ? s_buf[i] : 0;
         out_idx[t * k + i] = i < cnt ? key_row(key) : -1;
         out_score[t * k + i] = i < cnt ? key_score(key) : __uint_as_float(0xff800000u);
     }
-    if (tid == 0) out_cnt[t] = cnt;
+    if (lane == 0) out_cnt[t] = cnt;
 }
 
-// HOT > 0 (probe, off by default): the cells of scratch ids < HOT -- the longest stored rows, which under a popularity
-// law take most of the hits -- live in LDS instead of the workgroup's global scratch row.
-template <int KP, int HOT>
-__global__ __launch_bounds__(kBlock) void sparse_query_kernel(QueryArgs a) {
+// ATOMIC: ds_add_f32 (no return, no wait).  !ATOMIC: load / add / store by the same wave, for inputs whose partial sums
+// may be subnormal (the LDS adder's handling of those is not relied upon); same order, same bits, slower.
+template <bool ATOMIC>
+__device__ inline void acc_add(float *acc, int32_t loc, float term) {
+    if (ATOMIC) {
+        __hip_atomic_fetch_add(&acc[loc], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        volatile float *a = acc;
+        a[loc] = __fadd_rn(a[loc], term);
+    }
+}
+__device__ inline float acc_take(float *acc, int32_t loc) {
+    return __hip_atomic_exchange(&acc[loc], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One chunk (up to 64 of the query's indices, one per lane, ascending with the lane) against one tile: lane holds the
+// segment [s, e) of its index in this tile and the query's value qv.  COLLECT = false: accumulate; true: take the
+// accumulators of the segments' rows back (each row is handed to `consider` by the first posting that reaches it).
+// Returns the number of postings walked.  The first 64 postings of the NEXT segment are loaded before the current one is
+// applied (the compiler keeps loads behind the LDS atomics of the program order, so the overlap is spelled out).
+template <bool COLLECT, bool ATOMIC, typename F>
+__device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *acc, uint32_t s, uint32_t e, float qv, int lane,
+                                      F &&consider) {
+    unsigned long long m = __ballot(e > s);
+    if (!m) return 0;
+    uint32_t walked = 0;
+    int l = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    uint32_t sl = lane_u32(s, l), el = lane_u32(e, l);
+    float ql = lane_f32(qv, l);
+    Posting P{0, 0.0f};
+    if (sl + lane < el) P = post[sl + lane];
+    for (;;) {
+        const bool more = m != 0;
+        uint32_t ns = 0, ne = 0;
+        float nq = 0.0f;
+        Posting NP{0, 0.0f};
+        if (more) {
+            l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            ns = lane_u32(s, l), ne = lane_u32(e, l), nq = lane_f32(qv, l);
+            if (ns + lane < ne) NP = post[ns + lane];
+        }
+        if (COLLECT) {
+            const bool have = sl + lane < el;
+            const float x = have ? acc_take(acc, P.loc) : 0.0f;
+            consider(have, P.loc, x);
+        } else if (sl + lane < el) {
+            acc_add<ATOMIC>(acc, P.loc, __fmul_rn(ql, P.val));
+        }
+        for (uint32_t p = sl + kBlock; p < el; p += 4 * kBlock) {  // long segments: four loads in flight
+            Posting x[4];
+            bool have[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t at = p + j * kBlock + lane;
+                have[j] = at < el;
+                x[j] = Posting{0, 0.0f};
+                if (have[j]) x[j] = post[at];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (COLLECT) {
+                    if (p + j * kBlock < el) {  // uniform
+                        const float v = have[j] ? acc_take(acc, x[j].loc) : 0.0f;
+                        consider(have[j], x[j].loc, v);
+                    }
+                } else if (have[j]) {
+                    acc_add<ATOMIC>(acc, x[j].loc, __fmul_rn(ql, x[j].val));
+                }
+            }
+        }
+        walked += el - sl;
+        if (!more) break;
+        sl = ns, el = ne, ql = nq, P = NP;
+    }
+    return walked;
+}
+
+template <int KP, bool ATOMIC>
+__global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
-    __shared__ unsigned long long s_buf[CAP];
-    __shared__ Cell s_hot[HOT > 0 ? HOT : 1];
-    __shared__ unsigned long long s_thr;  // keys <= s_thr cannot be among the k best
-    __shared__ int s_cnt;                 // rows touched by the current query
-    __shared__ int s_bcnt;                // slots handed out in s_buf
-    __shared__ int s_pos, s_neg;          // admissible rows of the current query scoring above / below zero
-    const int tid = threadIdx.x, nt = blockDim.x;
-    Cell *cell = a.cell + (int64_t)blockIdx.x * a.N;
-    int32_t *touched = a.touched + (int64_t)blockIdx.x * a.N;
-    uint32_t serial = a.serial_base;
-    if (HOT > 0) {  // LDS does not survive a launch: stamp 0 = "reached by no query" (serials start at 1)
-        for (int i = tid; i < HOT; i += nt) s_hot[i] = 0;
-        __syncthreads();
-    }
-    for (int64_t t = blockIdx.x; t < a.nq; t += gridDim.x) {
-        serial++;
-        if (tid == 0) {
-            s_cnt = 0;
-            s_bcnt = 0;
-            s_thr = 0;
-            s_pos = 0;
-            s_neg = 0;
-        }
-        __syncthreads();
-        // ---- accumulate: one posting list per query index, ascending ----
-        const int64_t qr = a.q_first + t;
-        const int64_t qs = a.q_ptr[qr], qe = a.q_ptr[qr + 1];
-        if (qe - qs > a.heavy_dims) continue;  // uniform; answered by sparse_heavy_score_kernel / sparse_heavy_rank_kernel
-        unsigned long long walked = 0;
-        for (int64_t e = qs; e < qe; e++) {  // every condition below is uniform over the workgroup
-            const uint32_t dim = a.q_idx[e];
-            if ((int64_t)dim >= a.D) continue;
-            const int64_t ps = a.p_ptr[dim], pe = a.p_ptr[dim + 1];
-            if (ps == pe) continue;
-            const float qv = a.q_val[e];
-            walked += (unsigned long long)(pe - ps);
-            for (int64_t p = ps + tid; p < pe; p += nt) {
-                const int32_t row = a.p_row[p];
-                const float term = __fmul_rn(qv, a.p_val[p]);
-                Cell *at = (HOT > 0 && row < HOT) ? &s_hot[row] : &cell[row];
-                const Cell c = *at;
-                const bool first = cell_stamp(c) != serial;
-                *at = make_cell(serial, __fadd_rn(first ? 0.0f : cell_acc(c), term));
-                if (first) touched[atomicAdd(&s_cnt, 1)] = row;
-            }
-            __syncthreads();
-        }
-        // ---- rank the touched rows ----
-        const int T = s_cnt;
+    extern __shared__ __align__(16) unsigned char s_mem[];
+    const int T = 1 << a.logT;
+    unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(s_mem);
+    float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < T; i += kBlock) acc[i] = 0.0f;
+    __syncthreads();
+    for (;;) {
+        int w = 0;
+        if (lane == 0) w = atomicAdd(a.next, 1);
+        w = __builtin_amdgcn_readfirstlane(w);
+        if (w >= a.n_work) break;
+        const Work wk = a.work[w];
+        const int64_t t = wk.t, qr = a.q_first + t;
+        const int64_t qs = a.q_ptr[qr];
+        const int64_t L = a.q_ptr[qr + 1] - qs;
         const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? qr : (int64_t)-1);
-        int my_pos = 0, my_neg = 0;
-        rank_candidates<KP, kRankUnroll>(
-            T,
-            [&](int64_t i) -> unsigned long long {
-                const int32_t sid = touched[i];
-                const int32_t row = a.orig_of[sid];
-                if ((int64_t)row == ex || (a.mask && !a.mask[row])) return 0;
-                const uint32_t ord = score_ord(cell_acc((HOT > 0 && sid < HOT) ? s_hot[sid] : cell[sid]));
-                if (ord == kZeroOrd) return 0;  // a zero score is dropped by the reference's wrapper
-                my_pos += ord > kZeroOrd;
-                my_neg += ord < kZeroOrd;
-                return make_key(ord, row);
-            },
-            a.k, s_buf, &s_thr, &s_bcnt, tid, nt);
-        if (my_pos) atomicAdd(&s_pos, my_pos);
-        if (my_neg) atomicAdd(&s_neg, my_neg);
-        __syncthreads();
-        const bool ex_counts = ex >= 0 && ex < a.N && (!a.mask || a.mask[ex]);
-        const int cnt = written(s_pos, s_neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
-        write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, tid, nt);
-        if (tid == 0) {
-            if (a.stat) {
-                atomicAdd(&a.stat[0], walked);
-                atomicAdd(&a.stat[1], (unsigned long long)T);
+        const bool ex_in = ex >= 0 && ex < a.N;
+        const int64_t ex_sid = ex_in ? (int64_t)a.new_of[ex] : (int64_t)-1;
+        int bcnt = 0;
+        unsigned long long thr = 0;
+        long long my_pos = 0, my_neg = 0, my_hit = 0;
+        unsigned long long walked_q = 0;
+        const int first = wk.stripe < 0 ? 0 : wk.stripe, step = wk.stripe < 0 ? 1 : kStripes;
+        // queries of at most 64 entries keep (directory entry, value) in registers for all tiles
+        const bool small = L <= kBlock;
+        int32_t cid0 = -1;
+        float qv0 = 0.0f;
+        if (small && lane < L) {
+            cid0 = a.q_cid[qs + lane];
+            qv0 = a.q_val[qs + lane];
+        }
+        for (int tile = first; tile < a.ntiles; tile += step) {
+            auto consider = [&](bool have, int32_t loc, float x) {
+                have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
+                if (!__ballot(have)) return;
+                const int64_t sid = sid_of(tile, loc, a.logT);
+                my_hit += have;
+                have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
+                const uint32_t ord = score_ord(x);
+                my_pos += have && ord > kZeroOrd;
+                my_neg += have && ord < kZeroOrd;
+                const bool cand = have && ord >= (uint32_t)(thr >> 32);
+                if (!__ballot(cand)) return;
+                const unsigned long long key = cand ? make_key(ord, a.orig_of[sid]) : 0;
+                push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
+            };
+            auto nothing = [](bool, int32_t, float) {};
+            uint32_t walked = 0;
+            if (small) {
+                uint32_t s = 0, e = 0;
+                if (cid0 >= 0) {
+                    const uint32_t *o = a.off + (size_t)cid0 * a.ntiles + tile;
+                    s = o[0], e = o[1];
+                }
+                walked = walk_chunk<false, ATOMIC>(a.post, acc, s, e, qv0, lane, nothing);
+                if (walked == 0) continue;
+                if ((int64_t)walked * 4 < T) {
+                    walk_chunk<true, ATOMIC>(a.post, acc, s, e, qv0, lane, consider);
+                    walked_q += walked;
+                    continue;
+                }
+            } else {
+                for (int64_t c = 0; c < L; c += kBlock) {
+                    uint32_t s = 0, e = 0;
+                    float qv = 0.0f;
+                    if (c + lane < L) {
+                        const int32_t cid = a.q_cid[qs + c + lane];
+                        qv = a.q_val[qs + c + lane];
+                        if (cid >= 0) {
+                            const uint32_t *o = a.off + (size_t)cid * a.ntiles + tile;
+                            s = o[0], e = o[1];
+                        }
+                    }
+                    walked += walk_chunk<false, ATOMIC>(a.post, acc, s, e, qv, lane, nothing);
+                }
+                if (walked == 0) continue;
+                if ((int64_t)walked * 4 < T) {
+                    for (int64_t c = 0; c < L; c += kBlock) {
+                        uint32_t s = 0, e = 0;
+                        if (c + lane < L) {
+                            const int32_t cid = a.q_cid[qs + c + lane];
+                            if (cid >= 0) {
+                                const uint32_t *o = a.off + (size_t)cid * a.ntiles + tile;
+                                s = o[0], e = o[1];
+                            }
+                        }
+                        walk_chunk<true, ATOMIC>(a.post, acc, s, e, 0.0f, lane, consider);
+                    }
+                    walked_q += walked;
+                    continue;
+                }
+            }
+            walked_q += walked;
+            // dense tile: every accumulator is looked at once
+            for (int i = lane; i < T; i += kBlock) {
+                const float x = acc[i];
+                if (__float_as_uint(x) != 0) acc[i] = 0.0f;
+                consider(true, i, x);
             }
         }
-        __syncthreads();  // s_buf / s_cnt are reused by the next query
+        const long long pos = wave_sum(my_pos), neg = wave_sum(my_neg), hit = wave_sum(my_hit);
+        finish<KP>(s_buf, bcnt, lane);
+        if (wk.stripe < 0) {
+            const bool ex_counts = ex_in && (!a.mask_sid || a.mask_sid[ex_sid]);
+            const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
+            write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
+        } else {
+            const size_t part = (size_t)wk.pslot * kStripes + wk.stripe;
+            for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
+            if (lane == 0) {
+                a.part_cnt[part * 2] = (int32_t)pos;
+                a.part_cnt[part * 2 + 1] = (int32_t)neg;
+            }
+        }
+        if (lane == 0 && a.stat) {
+            atomicAdd(&a.stat[0], walked_q);
+            atomicAdd(&a.stat[1], (unsigned long long)hit);
+        }
+        __syncthreads();  // s_buf is reused by the next work item
     }
 }
 
-// ---- heavy queries: row streaming instead of posting lists -----------------------------------------------------------------
-// A query with very many entries (a popular item's user set under a Zipf law: tens of thousands) would walk that many
-// posting lists one after the other in sparse_query_kernel -- milliseconds on ONE wave while the rest of the launch has long
-// finished.  Such a query reaches most stored rows anyway, so it is answered the other way round: every stored row r is
-// merged against the query by ONE lane (the row's entries in ascending order, each looked up in the query's sorted index
-// list by binary search), which needs no accumulators, no barriers and no order bookkeeping -- the sum runs over the
-// common indices in ascending order by construction, the oracle's merge order.  HBM-bound on the stored CSR (read once per
-// batch of kHeavyBatch queries); the query's own arrays stay in L2.
-constexpr int kHeavyBatch = 8;
-
-struct HeavyArgs {
-    // the stored rows (CSR, indices ascending) and the queries (CSR rows q_first + t)
-    const int64_t *r_ptr;
-    const uint32_t *r_idx;
-    const float *r_val;
-    int64_t N;
-    const int64_t *q_ptr;
-    const uint32_t *q_idx;
-    const float *q_val;
-    int64_t q_first;
-    int64_t hq[kHeavyBatch];  // the heavy queries of this batch (indices t into the call's queries)
-    int nb;
-    float *score;     // nb x N: the inner product of row r with heavy query b
-    uint8_t *common;  // nb x N: 1 when they share an index
-    // ranking (sparse_heavy_rank_kernel)
+// the eight partial rankings of a split query -> its result row
+struct MergeArgs {
+    const int32_t *split_t;  // query of every block of partial rankings
+    int32_t n_split;
+    const unsigned long long *part_keys;
+    const int32_t *part_cnt;
+    int64_t q_first, N;
     const int64_t *exclude;
     int exclude_self;
-    const uint8_t *mask;
+    const uint8_t *mask_sid;
+    const int32_t *new_of;
     int64_t n_admissible;
     int k;
     int32_t *out_idx;
     float *out_score;
     int32_t *out_cnt;
-    unsigned long long *stat;  // [0] += row entries looked up, [1] += rows sharing an index
 };
 
-__global__ void sparse_heavy_score_kernel(HeavyArgs a) {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.N; r += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t rs = a.r_ptr[r], re = a.r_ptr[r + 1];
-        for (int b = 0; b < a.nb; b++) {
-            const int64_t qr = a.q_first + a.hq[b];
-            const int64_t qs = a.q_ptr[qr], qe = a.q_ptr[qr + 1];
-            float sum = 0.0f;
-            bool any = false;
-            int64_t from = qs;  // both lists ascend: the search for the next entry starts behind the last match
-            for (int64_t e = rs; e < re && from < qe; e++) {
-                const uint32_t idx = a.r_idx[e];
-                int64_t lo = from, hi = qe;  // first query entry with index >= idx
-                while (lo < hi) {
-                    const int64_t mid = lo + (hi - lo) / 2;
-                    if (a.q_idx[mid] < idx)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                from = lo;
-                if (lo < qe && a.q_idx[lo] == idx) {
-                    sum = __fadd_rn(sum, __fmul_rn(a.q_val[lo], a.r_val[e]));
-                    any = true;
-                    from = lo + 1;
-                }
-            }
-            a.score[(int64_t)b * a.N + r] = sum;
-            a.common[(int64_t)b * a.N + r] = any ? 1 : 0;
-        }
-    }
-}
-
-// one workgroup of kHeavyRankBlock lanes per heavy query of the batch: the same ranking as sparse_query_kernel over all N rows
-__global__ __launch_bounds__(kHeavyRankBlock) void sparse_heavy_rank_kernel(HeavyArgs a) {
-    constexpr int KP = kHeavyRankBlock, CAP = 2 * KP;
+template <int KP>
+__global__ __launch_bounds__(kBlock) void sparse_merge_kernel(MergeArgs a) {
+    constexpr int CAP = 2 * KP;
     __shared__ unsigned long long s_buf[CAP];
-    __shared__ unsigned long long s_thr;
-    __shared__ int s_bcnt, s_pos, s_neg, s_hit;
-    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
-    if (tid == 0) {
-        s_bcnt = 0;
-        s_thr = 0;
-        s_pos = 0;
-        s_neg = 0;
-        s_hit = 0;
-    }
-    __syncthreads();
-    const int64_t t = a.hq[b], qr = a.q_first + t;
-    const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? qr : (int64_t)-1);
-    const float *score = a.score + (int64_t)b * a.N;
-    const uint8_t *common = a.common + (int64_t)b * a.N;
-    int my_pos = 0, my_neg = 0, my_hit = 0;
-    rank_candidates<KP, 1>(
-        a.N,
-        [&](int64_t row) -> unsigned long long {
-            if (!common[row]) return 0;
-            my_hit++;
-            if (row == ex || (a.mask && !a.mask[row])) return 0;
-            const uint32_t ord = score_ord(score[row]);
-            if (ord == kZeroOrd) return 0;
-            my_pos += ord > kZeroOrd;
-            my_neg += ord < kZeroOrd;
-            return make_key(ord, (int32_t)row);
-        },
-        a.k, s_buf, &s_thr, &s_bcnt, tid, nt);
-    if (my_pos) atomicAdd(&s_pos, my_pos);
-    if (my_neg) atomicAdd(&s_neg, my_neg);
-    if (my_hit) atomicAdd(&s_hit, my_hit);
-    __syncthreads();
-    const bool ex_counts = ex >= 0 && ex < a.N && (!a.mask || a.mask[ex]);
-    const int cnt = written(s_pos, s_neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
-    write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, tid, nt);
-    if (tid == 0 && a.stat) {
-        atomicAdd(&a.stat[0], (unsigned long long)(a.r_ptr[a.N] - a.r_ptr[0]));
-        atomicAdd(&a.stat[1], (unsigned long long)s_hit);
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < a.n_split; b += gridDim.x) {
+        const int64_t t = a.split_t[b];
+        int bcnt = 0;
+        unsigned long long thr = 0;
+        long long pos = 0, neg = 0;
+        for (int s = 0; s < kStripes; s++) {
+            const size_t part = (size_t)b * kStripes + s;
+            pos += a.part_cnt[part * 2];
+            neg += a.part_cnt[part * 2 + 1];
+            for (int i = 0; i < KP; i += kBlock) {
+                const unsigned long long key = a.part_keys[part * KP + i + lane];
+                push<KP>(s_buf, a.k, bcnt, thr, key, key > thr, lane);
+            }
+        }
+        finish<KP>(s_buf, bcnt, lane);
+        const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? a.q_first + t : (int64_t)-1);
+        const bool ex_in = ex >= 0 && ex < a.N;
+        const bool ex_counts = ex_in && (!a.mask_sid || a.mask_sid[a.new_of[ex_in ? ex : 0]]);
+        const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
+        write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
+        __syncthreads();
     }
 }
 
-// ---- postings on the device (counting sort of the CSR entries by index) -------------------------------------------------
-// Not the library's default yet (sparse.hip builds the postings on the host unless gorse_hip_test_set_sparse_build(1)):
-// written without a GPU like the rest of this file, exercised through the emulation.  The order of the entries INSIDE a
-// posting list depends on the atomics' order; no result depends on it (a row occurs once per list, and a row's sum runs
-// over the lists in the query's index order).
-constexpr int kScanBlock = 1024;
+// ---- index construction on the device -------------------------------------------------------------------------------------
+// dims = the sorted distinct indices of the stored rows (built by the host while it validates the CSR); the directory entry
+// of an index is its position there.
+__device__ inline int32_t find_dim(const uint32_t *dims, int64_t Dc, uint32_t idx) {
+    int64_t lo = 0, hi = Dc;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (dims[mid] < idx)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo < Dc && dims[lo] == idx ? (int32_t)lo : -1;
+}
+
+__global__ void sparse_translate_kernel(const uint32_t *idx, int64_t n, const uint32_t *dims, int64_t Dc, int32_t *cid) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        cid[e] = find_dim(dims, Dc, idx[e]);
+}
 
 struct BuildArgs {
     const int64_t *r_ptr;  // N + 1
-    const uint32_t *r_idx;
+    const int32_t *r_cid;  // directory entry of every stored entry
     const float *r_val;
-    int64_t N, nnz, D;
-    unsigned long long *p_ptr;   // D + 1, zeroed before the count kernel; = the posting directory after the scan
-    unsigned long long *cursor;  // D: next free slot of every list during the scatter
-    int32_t *p_row;
-    float *p_val;
-    const int32_t *new_of;  // scratch id of every row (what the posting lists store)
+    int64_t N;
+    const int32_t *new_of;  // scratch id of every row
+    int32_t ntiles, logT;
+    uint32_t *cnt;  // Dc * ntiles (+ 1): entries per (index, tile); the cursor of the scatter pass afterwards
+    Posting *post;
 };
 
-// p_ptr[t + 1] = number of entries with index t
-__global__ void sparse_count_kernel(BuildArgs a) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nnz; e += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&a.p_ptr[(int64_t)a.r_idx[e] + 1], 1ull);
-}
-
-// in-place inclusive scan of p_ptr[1 .. D] by ONE workgroup (the directory has at most 2^30 entries and is scanned once per
-// index build), then cursor[t] = p_ptr[t]: every thread sums a contiguous chunk, thread 0 scans the chunk sums, every
-// thread rewrites its chunk
-__global__ __launch_bounds__(kScanBlock) void sparse_scan_kernel(BuildArgs a) {
-    __shared__ unsigned long long s_part[kScanBlock];
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int64_t chunk = (a.D + nt - 1) / nt;
-    const int64_t lo = 1 + (int64_t)tid * chunk, hi = lo + chunk < a.D + 1 ? lo + chunk : a.D + 1;
-    unsigned long long sum = 0;
-    for (int64_t t = lo; t < hi; t++) sum += a.p_ptr[t];
-    s_part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long run = 0;
-        for (int t = 0; t < nt; t++) {
-            const unsigned long long x = s_part[t];
-            s_part[t] = run;
-            run += x;
-        }
-    }
-    __syncthreads();
-    unsigned long long run = s_part[tid];
-    for (int64_t t = lo; t < hi; t++) {
-        run += a.p_ptr[t];
-        a.p_ptr[t] = run;
-    }
-    __syncthreads();  // the directory is complete (one workgroup: a barrier orders its global writes for its own reads)
-    for (int64_t t = tid; t < a.D; t += nt) a.cursor[t] = a.p_ptr[t];
-}
-
-// entry e of the CSR goes to the next free slot of its index's list; its row = the r_ptr interval that holds e
-__global__ void sparse_scatter_kernel(BuildArgs a) {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nnz; e += (int64_t)gridDim.x * blockDim.x) {
-        int64_t lo = 0, hi = a.N;  // largest row with r_ptr[row] <= e
-        while (hi - lo > 1) {
-            const int64_t mid = lo + (hi - lo) / 2;
-            if (a.r_ptr[mid] <= e)
-                lo = mid;
+// one wave per stored row; SCATTER = false counts the entries of every (index, tile), true places them
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void sparse_build_kernel(BuildArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < a.N; r += nwaves) {
+        const int64_t sid = a.new_of[r];
+        const int32_t tile = tile_of(sid, a.logT), loc = loc_of(sid, a.logT);
+        for (int64_t e = a.r_ptr[r] + lane; e < a.r_ptr[r + 1]; e += 64) {
+            uint32_t *c = a.cnt + (size_t)a.r_cid[e] * a.ntiles + tile;
+            if (SCATTER)
+                a.post[atomicAdd(c, 1u)] = Posting{loc, a.r_val[e]};
             else
-                hi = mid;
+                atomicAdd(c, 1u);
         }
-        const unsigned long long at = atomicAdd(&a.cursor[a.r_idx[e]], 1ull);
-        a.p_row[at] = a.new_of[lo];
-        a.p_val[at] = a.r_val[e];
     }
+}
+
+// exclusive scan of n uint32 in place, three launches: chunk sums, one workgroup over the sums, chunks again
+constexpr int kScanBlock = 1024;
+constexpr int kScanPer = 8;  // elements per thread
+__device__ inline uint32_t block_exclusive(uint32_t v, uint32_t *s_part, int tid, uint32_t *total) {
+    s_part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < kScanBlock; o <<= 1) {
+        const uint32_t x = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += x;
+        __syncthreads();
+    }
+    const uint32_t incl = s_part[tid];
+    if (total) *total = s_part[kScanBlock - 1];
+    __syncthreads();
+    return incl - v;
+}
+__global__ __launch_bounds__(kScanBlock) void sparse_scan_sums_kernel(const uint32_t *x, int64_t n, uint32_t *sums) {
+    __shared__ uint32_t s_part[kScanBlock];
+    const int tid = threadIdx.x;
+    const int64_t base = ((int64_t)blockIdx.x * kScanBlock + tid) * kScanPer;
+    uint32_t v = 0;
+    for (int j = 0; j < kScanPer; j++)
+        if (base + j < n) v += x[base + j];
+    uint32_t total;
+    block_exclusive(v, s_part, tid, &total);
+    if (tid == 0) sums[blockIdx.x] = total;
+}
+// one workgroup: exclusive scan of the nb chunk sums in place
+__global__ __launch_bounds__(kScanBlock) void sparse_scan_top_kernel(uint32_t *sums, int64_t nb) {
+    __shared__ uint32_t s_part[kScanBlock];
+    const int tid = threadIdx.x;
+    const int64_t per = (nb + kScanBlock - 1) / kScanBlock;
+    const int64_t lo = (int64_t)tid * per, hi = lo + per < nb ? lo + per : nb;
+    uint32_t v = 0;
+    for (int64_t i = lo; i < hi; i++) v += sums[i];
+    uint32_t run = block_exclusive(v, s_part, tid, nullptr);
+    for (int64_t i = lo; i < hi; i++) {
+        const uint32_t x = sums[i];
+        sums[i] = run;
+        run += x;
+    }
+}
+__global__ __launch_bounds__(kScanBlock) void sparse_scan_apply_kernel(uint32_t *x, int64_t n, const uint32_t *sums) {
+    __shared__ uint32_t s_part[kScanBlock];
+    const int tid = threadIdx.x;
+    const int64_t base = ((int64_t)blockIdx.x * kScanBlock + tid) * kScanPer;
+    uint32_t loc[kScanPer];
+    uint32_t v = 0;
+    for (int j = 0; j < kScanPer; j++) {
+        loc[j] = base + j < n ? x[base + j] : 0;
+        v += loc[j];
+    }
+    uint32_t run = sums[blockIdx.x] + block_exclusive(v, s_part, tid, nullptr);
+    for (int j = 0; j < kScanPer; j++)
+        if (base + j < n) {
+            x[base + j] = run;
+            run += loc[j];
+        }
 }
 
 }  // namespace sparse

@@ -226,10 +226,9 @@ int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int64_t q_end, 
                                int32_t *idx_out /*host or NULL*/, float *score_out /*host or NULL*/,
                                int32_t *count_out /*host or NULL*/);
 int32_t gorse_sparse_synchronize(gorse_sparse *h);
-/* measurement: hipEvent pairs around sparse_query_kernel on the handle's stream, and the work of the last call:
- * postings = sum over its queries and their indices of the posting-list lengths (= multiply-adds performed; the
- * kernel reads 8 bytes per posting) plus, for every query that took the row-streaming path, the number of stored
- * entries (8 bytes each as well); hits = rows that shared an index with their query. */
+/* measurement: hipEvent pairs around sparse_tile_kernel (+ the merge of split queries) on the handle's stream, and the
+ * work of the last call: postings = sum over its queries and their indices of the posting-list lengths (= multiply-adds
+ * performed; the kernel reads 8 bytes per posting); hits = (query, row) pairs with a non-zero inner product. */
 int32_t gorse_sparse_set_profiling(gorse_sparse *h, int32_t on);
 int32_t gorse_sparse_get_profile(gorse_sparse *h, int64_t *launches, double *total_ms);
 int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, int64_t *hits);

@@ -43,26 +43,19 @@ void gorse_hip_test_set_topk_variant(int32_t variant);
  * kernel ticks, [7] waves, and the candidate path split into [8] count + exchange, [9] appends, [10] compaction
  * check / compaction, with [11] lanes that appended. */
 int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/);
-/* where gorse_sparse_create builds the posting lists of a handle created AFTERWARDS: 0 = on the host (counting sort, the
- * default this round), 1 = on the device (sparse_count_kernel / sparse_scan_kernel / sparse_scatter_kernel over the
- * uploaded CSR).  Written without a GPU and checked through the CPU emulation only; it becomes the default once the GPU
- * test that compares both builds has run.  Results never depend on it. */
-void gorse_hip_test_set_sparse_build(int32_t mode);
-/* probe: at most this many workgroups (= queries in flight, each with its 12 N bytes of scratch) per sparse launch; 0 = the
- * library's own bound (8192, or what 16 GiB of scratch allow).  Trades occupancy against the cache footprint of the
- * accumulators; results never depend on it. */
+/* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
+ * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
-/* queries with more than `dims` entries are answered by row streaming (every stored row merged against the query by one
- * lane) instead of posting-list walks; default 16384, 0 = never.  Lets small test inputs take that path; results never
- * depend on it. */
-void gorse_hip_test_set_sparse_heavy(int64_t dims);
-/* probe: 512 or 1024 = the accumulators of that many stored rows -- the longest ones, which under a popularity law take
- * most of the hits -- live in LDS instead of the workgroup's global scratch row (fewer workgroups fit a CU in exchange);
- * 0 = none (default).  Results never depend on it. */
-void gorse_hip_test_set_sparse_hot(int32_t rows);
-/* the stamp counter of a handle (every query a workgroup answers takes the next 32-bit stamp; when the counter would wrap
- * the library clears the scratch and starts over): lets a test put the counter just below the wrap. */
-int32_t gorse_hip_test_sparse_set_serial(gorse_sparse *h, uint32_t serial);
+/* rows per accumulator tile of a handle created AFTERWARDS: a power of two in 256 .. 16384; 0 = chosen from N (2048 up to
+ * one million rows).  A tile costs 4 bytes of LDS per row. */
+void gorse_hip_test_set_sparse_tile(int32_t rows);
+/* queries with more than `entries` entries are answered by eight work items (one per row stripe) and a merge instead of one
+ * (default 2048; <= 0 = never): lets small test inputs take that path. */
+void gorse_hip_test_set_sparse_split(int64_t entries);
+/* how products reach the LDS accumulators: 1 = ds_add_f32 (no return value, no wait), 0 = load / add / store by the same
+ * wave, -1 = the library's choice (ds_add_f32 unless a product of a stored and a query value could fall below 2^-100,
+ * where partial sums may be subnormal and the LDS adder's handling of those is not relied upon). */
+void gorse_hip_test_set_sparse_atomic(int32_t mode);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */

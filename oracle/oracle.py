@@ -52,6 +52,48 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
+class SparseIndex:
+    """orc_sparse_index_*: posting lists of the stored rows; search() = orc_sparse_search_inverted (same results as
+    Oracle.sparse_search, found by walking posting lists).  scratch() makes the per-thread work arrays."""
+
+    def __init__(self, oracle, indptr, indices, values):
+        self.o = oracle
+        self.indptr, pp = _i64(indptr)
+        self.indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        self.values, pv = _f32(values)
+        self.N = self.indptr.size - 1
+        self.h = oracle.L.orc_sparse_index_build(self.N, pp, self.indices.ctypes.data_as(_u32p), pv)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.o.L.orc_sparse_index_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def scratch(self):
+        return np.zeros(self.N, np.float32), np.zeros(self.N, np.uint8), np.zeros(self.N, np.int32)
+
+    def search(self, q_idx, q_val, k, exclude=-1, admissible=None, scratch=None):
+        """(row indices, scores, postings walked)"""
+        acc, seen, touched = scratch if scratch is not None else self.scratch()
+        q_idx = np.ascontiguousarray(q_idx, dtype=np.uint32)
+        q_val, pqv = _f32(q_val)
+        pm, n_adm = None, self.N
+        if admissible is not None:
+            admissible = np.ascontiguousarray(admissible, dtype=np.uint8)
+            pm = admissible.ctypes.data_as(C.POINTER(C.c_uint8))
+            n_adm = int(np.count_nonzero(admissible))
+        oi = np.zeros(k + 1, dtype=np.int32)
+        ow = np.zeros(k + 1, dtype=np.float32)
+        walked = C.c_int64(0)
+        cnt = self.o.L.orc_sparse_search_inverted(self.h, self.N, q_idx.ctypes.data_as(_u32p), pqv, q_idx.size, int(exclude), pm,
+                                                  n_adm, k, acc.ctypes.data_as(_f32p), seen.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                  touched.ctypes.data_as(_i32p), oi.ctypes.data_as(_i32p),
+                                                  ow.ctypes.data_as(_f32p), C.byref(walked))
+        return oi[:cnt].copy(), ow[:cnt].copy(), walked.value
+
+
 class Oracle:
     def __init__(self):
         build()
@@ -113,6 +155,13 @@ class Oracle:
         L.orc_sparse_search.restype = C.c_int
         L.orc_sparse_search.argtypes = [C.c_int64, _i64p, _u32p, _f32p, _u32p, _f32p, C.c_int64, C.c_int64, _u8p,
                                         C.c_int, _i32p, _f32p]
+        L.orc_sparse_index_build.restype = C.c_void_p
+        L.orc_sparse_index_build.argtypes = [C.c_int64, _i64p, _u32p, _f32p]
+        L.orc_sparse_index_free.restype = None
+        L.orc_sparse_index_free.argtypes = [C.c_void_p]
+        L.orc_sparse_search_inverted.restype = C.c_int
+        L.orc_sparse_search_inverted.argtypes = [C.c_void_p, C.c_int64, _u32p, _f32p, C.c_int64, C.c_int64, _u8p, C.c_int64,
+                                                 C.c_int, _f32p, _u8p, _i32p, _i32p, _f32p, _i64p]
         L.orc_idf.restype = None
         L.orc_idf.argtypes = [_i32p, C.c_int64, C.c_int64, _f32p]
         L.orc_mm.restype = None
@@ -272,6 +321,10 @@ class Oracle:
                                        q_idx.ctypes.data_as(_u32p), pqv, q_idx.size, int(exclude), pm, k,
                                        oi.ctypes.data_as(_i32p), ow.ctypes.data_as(_f32p))
         return oi[:cnt].copy(), ow[:cnt].copy()
+
+    def sparse_index(self, indptr, indices, values):
+        """Inverted index over the CSR rows (the CPU baseline of bench.py's sparse leg); see SparseIndex."""
+        return SparseIndex(self, indptr, indices, values)
 
     def idf(self, freq, total):
         freq, pf = _i32(freq)

@@ -1,5 +1,4 @@
-"""Inputs and the oracle comparison shared by the sparse top-k tests (the CPU emulation of the kernel,
-tests/test_sparse_kernel_emu_cpu.py, and the GPU parity tests, tests/test_gpu_vectors_sparse.py)."""
+"""Inputs and the oracle comparison of the sparse top-k GPU parity tests (tests/test_gpu_vectors_sparse.py)."""
 import numpy as np
 
 

@@ -1,0 +1,156 @@
+"""GPU parity at the BASELINE.json configurations themselves (the sizes bench.py times), through the C ABI:
+
+  C2  S-ml1m 6040 x 3706 x 994,169, nFactors 64, the default Hogwild schedule (user runs): NDCG@10 within +-0.01 of the
+      sequential oracle (the bar of model/cf/model_test.go:35-48 is +-0.01 around its anchor), and the top-10 rank lists
+      of gorse_mf_rank on the DEVICE's factors equal the oracle's, index for index.
+  C3  one 125,000-user shard of S-big (200,000 items, 12.5M feedbacks), nFactors 128: one epoch, factors finite, NDCG@10
+      of 8192 held-out users within +-0.01 of the sequential oracle's epoch.
+  C5  S-als 500,000 x 100,000 x 50M, nFactors 64: one user half-sweep on the device, 2048 rows spread over the row-length
+      range (incl. the longest) <= 1e-4 against orc_als_half_range.
+  C4  S-emb 1,000,000 x 128 bf16, cosine, k = 100: 96 query rows of the all-pairs pass equal Bruteforce.SearchIndex restated
+      (oracle) in indices AND distance bits.
+
+The element-wise relative error |got - ref| / |ref| is printed next to the bar each ALS comparison uses (`rel_to_scale`:
+error over the largest reference magnitude, the form "1e-4 relative fp32" takes for a matrix whose small elements are
+differences of large ones)."""
+import time
+
+import numpy as np
+import pytest
+
+from gorse_amd import capi, synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def ndcg(oracle, data, P, Q):
+    return float(oracle.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)[0])
+
+
+def test_c2_ml1m_d64_user_runs_ndcg_and_rank_lists(oracle):
+    data = synth.s_ml1m()
+    d, lr, reg, epochs, seed = 64, 0.05, 0.01, 8, 2024
+    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
+    srt = orc.sort_rows(data.uptr, data.uidx)
+    P, Q = P0.copy(), Q0.copy()
+    for ep in range(1, epochs + 1):  # sequential (Jobs = 1) epochs on the shared sampler stream
+        oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, seed, ep, 0, data.n_train, lr, reg)
+    ref = ndcg(oracle, data, P, Q)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P0, Q0)
+    assert mf.bpr_user_runs()  # the schedule bench.py times at C2
+    for ep in range(1, epochs + 1):
+        mf.bpr_epoch(data.n_train, lr, reg, seed, ep, mode=capi.BPR_HOGWILD_ATOMIC)
+    gP, gQ = mf.get_factors()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+    got = ndcg(oracle, data, gP, gQ)
+    print("C2 NDCG@10 after %d epochs: sequential oracle %.4f, device user-run schedule %.4f" % (epochs, ref, got))
+    assert ref > 0.15
+    assert abs(got - ref) < 0.01
+    # Rank / TopKFilter (evaluator.go:162-169) on the device's own factors: all 6040 users x 100 candidates
+    users, cptr, cand = data.candidates()
+    rank, rlen = mf.rank(users, cptr, cand, 10)
+    erank, elen = oracle.mf_rank(gP, gQ, users, cptr, cand, 10)
+    assert np.array_equal(rlen, elen) and np.array_equal(rank, erank)
+
+
+def _held_out(data, n_users, n_neg, seed):
+    """the last stored feedback of the first n_users users with >= 2 feedbacks becomes the test positive; n_neg negatives"""
+    rng = np.random.default_rng(seed)
+    lens = np.diff(data.uptr)
+    users = np.nonzero(lens >= 2)[0][:n_users]
+    keep = np.ones(data.uidx.size, bool)
+    last = data.uptr[users + 1] - 1
+    keep[last] = False
+    rows = np.repeat(np.arange(data.U, dtype=np.int64), lens)[keep]
+    uidx = np.ascontiguousarray(data.uidx[keep])
+    uptr = np.zeros(data.U + 1, np.int64)
+    np.cumsum(np.bincount(rows, minlength=data.U), out=uptr[1:])
+    has = np.zeros(data.U, bool)
+    has[users] = True
+    test_ptr = np.zeros(data.U + 1, np.int64)
+    np.cumsum(has, out=test_ptr[1:])
+    test_idx = np.ascontiguousarray(data.uidx[last].astype(np.int32))
+    neg_ptr = np.zeros(data.U + 1, np.int64)
+    np.cumsum(np.where(has, n_neg, 0), out=neg_ptr[1:])
+    neg_idx = np.empty(users.size * n_neg, np.int32)
+    for t, u in enumerate(users):
+        posset = data.uidx[data.uptr[u]:data.uptr[u + 1]]
+        got = np.empty(0, np.int64)
+        while got.size < n_neg:
+            c = rng.integers(0, data.I, size=2 * n_neg)
+            got = np.unique(np.concatenate([got, c[~np.isin(c, posset)]]))
+        neg_idx[t * n_neg:(t + 1) * n_neg] = rng.permutation(got)[:n_neg]
+    out = synth.CFData(data.U, data.I, uptr, uidx, None, None, test_ptr, test_idx, neg_ptr, neg_idx)
+    return out
+
+
+def test_c3_shard_d128_one_epoch_ndcg(oracle):
+    full = synth.s_big_shard(rank=0, world=8)
+    data = _held_out(full, 8192, 99, 5)
+    d, lr, reg, seed = 128, 0.05, 0.01, 77
+    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P0, Q0)
+    assert mf.bpr_user_runs()
+    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_ATOMIC)
+    gP, gQ = mf.get_factors()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+    got = ndcg(oracle, data, gP, gQ)
+    srt = orc.sort_rows(data.uptr, data.uidx)
+    P, Q = P0.copy(), Q0.copy()
+    t0 = time.perf_counter()
+    oracle.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, seed, 1, 0, data.n_train, lr, reg)
+    ref = ndcg(oracle, data, P, Q)
+    base = ndcg(oracle, data, P0, Q0)
+    print("C3 shard NDCG@10 of 8192 held-out users after one epoch: sequential oracle %.4f (%.0f s), device %.4f, untrained %.4f"
+          % (ref, time.perf_counter() - t0, got, base))
+    assert ref > base + 0.02  # one epoch moved the ranking
+    assert abs(got - ref) < 0.01
+
+
+def rel_to_scale(got, ref):
+    return float(np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max())
+
+
+def elementwise_rel(got, ref):
+    ref = ref.astype(np.float64)
+    return float((np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)).max())
+
+
+def test_c5_als_user_half_sweep_rows(oracle):
+    U, I, d, w, reg = 500_000, 100_000, 64, 0.001, 0.06
+    uptr, uidx, iptr, iidx = synth.s_als(U, I, 50_000_000, 45)
+    P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.1, seed=1)
+    mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx)
+    mf.set_factors(P0, Q0)
+    mf.als_half_epoch(0, w, reg)  # every user row against Q0
+    gP, gQ = mf.get_factors()
+    assert np.array_equal(gQ.view(np.uint32), Q0.view(np.uint32))
+    assert np.isfinite(gP).all()
+    lens = np.diff(uptr)
+    by_len = np.argsort(lens, kind="stable")
+    rows = np.unique(np.concatenate([by_len[np.linspace(0, U - 1, 2040).astype(np.int64)], by_len[-8:]]))  # incl. the longest rows
+    A = np.ascontiguousarray(P0[rows])  # the sampled rows as one compact problem: one Gram pass of the oracle for all of them
+    sub_ptr = np.zeros(rows.size + 1, np.int64)
+    np.cumsum(lens[rows], out=sub_ptr[1:])
+    sub_idx = np.concatenate([uidx[uptr[r]:uptr[r + 1]] for r in rows])
+    oracle.als_half_range(A, Q0, sub_ptr, sub_idx, iptr, w, reg, 0, rows.size)
+    worst_scale = max(rel_to_scale(gP[r:r + 1], A[t:t + 1]) for t, r in enumerate(rows))
+    worst_elem = elementwise_rel(gP[rows], A)
+    print("C5 user half-sweep, %d rows (lengths %d..%d): max error / largest |ref| of the row %.2e; element-wise relative %.2e"
+          % (rows.size, lens[rows].min(), lens[rows].max(), worst_scale, worst_elem))
+    assert worst_scale < 1e-4
+
+
+def test_c4_rows_against_the_oracle(oracle):
+    Xb, Xe = synth.s_emb(1_000_000, 128, 44)
+    k = 100
+    t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
+    q0, q1 = 500_000, 500_096
+    idx, dist = t.all_pairs(k, q0, q1)
+    for r in range(q1 - q0):
+        ei, ed = oracle.search_index(Xe, orc.METRIC_COSINE, q0 + r, k)
+        assert ei.size == k and np.array_equal(idx[r], ei), "row %d: indices differ" % (q0 + r)
+        assert np.array_equal(dist[r].view(np.uint32), ed.view(np.uint32)), "row %d: distances differ" % (q0 + r)

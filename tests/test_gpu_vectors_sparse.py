@@ -65,7 +65,7 @@ def test_test_sparse_of_the_reference():
 
 
 def test_scratch_reuse_across_calls(oracle):
-    """the per-workgroup accumulators and stamps are never cleared between queries or calls"""
+    """a workgroup's LDS accumulators serve one query after the other (every read-back leaves them zero); calls repeat"""
     rng = np.random.default_rng(11)
     ptr, idx, val = random_csr(rng, 3000, 200, 1, 8, zipf=True)
     s = capi.Sparse(ptr, idx, val)
@@ -125,112 +125,109 @@ def properties(ptr, out_idx, out_sc, out_cnt, k):
     assert (out_cnt[empty] == 0).all()
 
 
-@pytest.mark.parametrize("k", [5, 70])
-def test_heavy_queries_take_the_row_streaming_path(oracle, k):
-    """queries with more entries than the threshold (16384 by default, 6 here) are merged against every stored row by one
-    lane each instead of walking posting lists: same results, in one call together with light queries, masks, exclusions,
-    negative and cancelling scores, more than one batch of heavy queries"""
-    rng = np.random.default_rng(47)
-    ptr, idx, val = random_csr(rng, 900, 80, 0, 14, neg=True, zipf=True)
-    n_heavy = int((np.diff(ptr) > 6).sum())
-    assert n_heavy > 2 * 8 and n_heavy < 800  # several batches of heavy queries next to light ones
-    mask = (rng.random(900) < 0.8).astype(np.uint8)
-    s = capi.Sparse(ptr, idx, val)
-    capi.lib().gorse_hip_test_set_sparse_heavy(6)
-    try:
-        got = s.all_pairs(k)
-        check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(900)), list(range(900)))
-        s.set_mask(mask)
-        qp, qi, qv = random_csr(rng, 30, 95, 0, 25, neg=True)
-        excl = rng.integers(-1, 900, 30).astype(np.int64)
-        got = s.search(qp, qi, qv, k, exclude=excl)
-        check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(30)), list(excl), mask)
-    finally:
-        capi.lib().gorse_hip_test_set_sparse_heavy(16384)
-    light = s.search(qp, qi, qv, k, exclude=excl)  # the same call on posting lists only
-    for a, b in zip(got, light):
+def _same(x, y):
+    for a, b in zip(x, y):
         assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
 
 
-def test_random_configurations(oracle):
-    """thirty random small problems, each with random k, mask, exclusions and random settings of the library's switches
-    (heavy-query threshold, queries in flight, where the postings are built, how many rows accumulate in LDS): every answer
-    equals the oracle's"""
-    rng = np.random.default_rng(2027)
+@pytest.fixture
+def hooks():
     L = capi.lib()
-    try:
-        for case in range(30):
-            rows, dims = int(rng.integers(1, 400 if case % 3 else 1500)), int(rng.integers(1, 120))
-            hi = int(rng.integers(0, min(dims, 30) + 1))
-            ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
-            L.gorse_hip_test_set_sparse_build(int(rng.integers(0, 2)))
-            L.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 1, 3, 8, 16384])))
-            L.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
-            L.gorse_hip_test_set_sparse_hot(int(rng.choice([0, 512, 1024])))
-            s = capi.Sparse(ptr, idx, val)
-            k = int(rng.choice([1, 2, 7, 64, 65, 300]))
-            mask = None
-            if rng.random() < 0.5:
-                mask = (rng.random(rows) < rng.random()).astype(np.uint8)  # anything from nearly all hidden to all visible
-                s.set_mask(mask)
-            if rng.random() < 0.5:
-                q0 = int(rng.integers(0, rows))
-                q1 = int(rng.integers(q0, rows + 1))
-                self_out = bool(rng.integers(0, 2))
-                got = s.all_pairs(k, q0, q1, exclude_self=self_out)
-                if q1 > q0:
-                    check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(q0, q1)),
-                          list(range(q0, q1)) if self_out else [-1] * (q1 - q0), mask)
-            else:
-                nq = int(rng.integers(1, 40))
-                qp, qi, qv = random_csr(rng, nq, dims + 5, 0, min(dims + 5, 40), neg=True)
-                excl = rng.integers(-1, rows, nq).astype(np.int64) if rng.random() < 0.5 else None
-                got = s.search(qp, qi, qv, k, exclude=excl)
-                check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(nq)), list(excl) if excl is not None else [-1] * nq, mask)
-            s.close()
-    finally:
-        L.gorse_hip_test_set_sparse_build(0)
-        L.gorse_hip_test_set_sparse_heavy(16384)
-        L.gorse_hip_test_set_sparse_slots(0)
-        L.gorse_hip_test_set_sparse_hot(0)
+    yield L
+    L.gorse_hip_test_set_sparse_slots(0)
+    L.gorse_hip_test_set_sparse_tile(0)
+    L.gorse_hip_test_set_sparse_split(2048)
+    L.gorse_hip_test_set_sparse_atomic(-1)
 
 
-def test_stamp_counter_wraps_by_clearing_the_scratch(oracle):
-    """every answered query takes the next 32-bit stamp of its workgroup's scratch; just below 2^32 the library clears the
-    scratch and restarts -- without the clear, cells stamped 1, 2, ... by the first call would pass for already reached"""
-    rng = np.random.default_rng(43)
-    ptr, idx, val = random_csr(rng, 700, 500, 1, 3)  # few hits per query: most cells keep the stamp of ONE earlier query
+@pytest.mark.parametrize("k", [5, 70, 300])
+def test_long_queries_are_split_over_the_row_stripes(oracle, k, hooks):
+    """queries with more entries than the threshold (2048 by default, 6 here) are answered by eight work items -- one per row
+    stripe, each with its own ranking -- and a merge: same results, in one call together with unsplit queries, masks,
+    exclusions, negative and cancelling scores; small tiles so that every stripe owns several tiles"""
+    rng = np.random.default_rng(47)
+    ptr, idx, val = random_csr(rng, 9000, 80, 0, 14, neg=True, zipf=True)
+    n_long = int((np.diff(ptr) > 6).sum())
+    assert n_long > 100 and n_long < 8000
+    mask = (rng.random(9000) < 0.8).astype(np.uint8)
+    hooks.gorse_hip_test_set_sparse_tile(256)
+    s = capi.Sparse(ptr, idx, val)  # 9000 rows = 5 groups of 8 tiles
+    hooks.gorse_hip_test_set_sparse_split(6)
+    sample = list(range(0, 9000, 23))
+    got = s.all_pairs(k)
+    check(oracle, ptr, idx, val, k, [x[sample] for x in got], rows_of(ptr, idx, val, sample), sample)
+    s.set_mask(mask)
+    qp, qi, qv = random_csr(rng, 30, 95, 0, 25, neg=True)
+    excl = rng.integers(-1, 9000, 30).astype(np.int64)
+    split = s.search(qp, qi, qv, k, exclude=excl)
+    check(oracle, ptr, idx, val, k, split, rows_of(qp, qi, qv, range(30)), list(excl), mask)
+    hooks.gorse_hip_test_set_sparse_split(0)
+    _same(split, s.search(qp, qi, qv, k, exclude=excl))  # the same call, one work item per query
+    s.set_mask(None)
+    _same(got, s.all_pairs(k))
+
+
+@pytest.mark.parametrize("atomic", [0, 1])
+def test_both_accumulation_forms(oracle, atomic, hooks):
+    """ds_add_f32 (fire and forget, applied in issue order) and the load / add / store form give the oracle's bits: rows hit
+    by many posting lists of one query (a popularity law over few indices), dense and sparse tiles, cancelling terms"""
+    rng = np.random.default_rng(5 + atomic)
+    ptr, idx, val = random_csr(rng, 20000, 300, 1, 40, neg=True, zipf=True)
+    hooks.gorse_hip_test_set_sparse_atomic(atomic)
+    hooks.gorse_hip_test_set_sparse_tile(512)
     s = capi.Sparse(ptr, idx, val)
-    capi.lib().gorse_hip_test_set_sparse_slots(7)  # 700 queries over 7 workgroups: 100 stamps per launch
-    try:
-        first = s.all_pairs(11)
-        sample = list(range(0, 700, 13))
-        check(oracle, ptr, idx, val, 11, [x[sample] for x in first], rows_of(ptr, idx, val, sample), sample)
-        for serial in (0xFFFFFFFF - 100, 0xFFFFFFFF - 150, 0xFFFFFFFF - 99):  # wrap over cells stamped 1..100, no wrap, wrap
-            capi.check(capi.lib().gorse_hip_test_sparse_set_serial(s.h, serial))
-            again = s.all_pairs(11)
-            for a, b in zip(first, again):
-                assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a,
-                                      b.view(np.uint32) if b.dtype == np.float32 else b), hex(serial)
-    finally:
-        capi.lib().gorse_hip_test_set_sparse_slots(0)
+    sample = list(range(0, 20000, 397))
+    got = s.all_pairs(50)
+    check(oracle, ptr, idx, val, 50, [x[sample] for x in got], rows_of(ptr, idx, val, sample), sample)
+    qp, qi, qv = random_csr(rng, 12, 300, 100, 280, neg=True)  # long queries: hundreds of lists reach the popular rows
+    check(oracle, ptr, idx, val, 20, s.search(qp, qi, qv, 20), rows_of(qp, qi, qv, range(12)), [-1] * 12)
 
 
-def test_postings_built_on_the_device_give_the_same_results(oracle):
-    """gorse_hip_test_set_sparse_build(1): count / scan / scatter kernels instead of the host's counting sort"""
-    rng = np.random.default_rng(41)
-    ptr, idx, val = random_csr(rng, 4000, 900, 0, 25, neg=True, zipf=True)
-    host = capi.Sparse(ptr, idx, val).all_pairs(20)
-    capi.lib().gorse_hip_test_set_sparse_build(1)
-    try:
+def test_tiny_values_take_the_non_atomic_form(oracle):
+    """products below 2^-100: partial sums may be subnormal; the library then accumulates by load / add / store (its own
+    choice, no hook) and the bits still equal the oracle's, subnormal results included"""
+    rng = np.random.default_rng(77)
+    ptr, idx, val = random_csr(rng, 500, 40, 1, 10, neg=True)
+    val = (val * np.float32(2.0 ** -70)).astype(np.float32)
+    s = capi.Sparse(ptr, idx, val)
+    got = s.all_pairs(30)
+    check(oracle, ptr, idx, val, 30, got, rows_of(ptr, idx, val, range(500)), list(range(500)))
+    assert (np.abs(got[1][np.isfinite(got[1])]) < 2.0 ** -126).any()  # subnormal scores were produced and ranked
+
+
+def test_random_configurations(oracle, hooks):
+    """thirty random small problems, each with random k, mask, exclusions and random settings of the library's switches
+    (tile height, split threshold, workgroups per launch, accumulation form): every answer equals the oracle's"""
+    rng = np.random.default_rng(2027)
+    for case in range(30):
+        rows, dims = int(rng.integers(1, 400 if case % 3 else 3000)), int(rng.integers(1, 120))
+        hi = int(rng.integers(0, min(dims, 30) + 1))
+        ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
+        hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 256, 512, 4096])))
+        hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 2048])))
+        hooks.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
+        hooks.gorse_hip_test_set_sparse_atomic(int(rng.choice([-1, 0, 1])))
         s = capi.Sparse(ptr, idx, val)
-    finally:
-        capi.lib().gorse_hip_test_set_sparse_build(0)
-    dev = s.all_pairs(20)
-    for a, b in zip(host, dev):
-        assert np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
-    sample = list(range(0, 4000, 131))
-    check(oracle, ptr, idx, val, 20, [x[sample] for x in dev], rows_of(ptr, idx, val, sample), sample)
+        k = int(rng.choice([1, 2, 7, 64, 65, 300]))
+        mask = None
+        if rng.random() < 0.5:
+            mask = (rng.random(rows) < rng.random()).astype(np.uint8)  # anything from nearly all hidden to all visible
+            s.set_mask(mask)
+        if rng.random() < 0.5:
+            q0 = int(rng.integers(0, rows))
+            q1 = int(rng.integers(q0, rows + 1))
+            self_out = bool(rng.integers(0, 2))
+            got = s.all_pairs(k, q0, q1, exclude_self=self_out)
+            if q1 > q0:
+                check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(q0, q1)),
+                      list(range(q0, q1)) if self_out else [-1] * (q1 - q0), mask)
+        else:
+            nq = int(rng.integers(1, 40))
+            qp, qi, qv = random_csr(rng, nq, dims + 5, 0, min(dims + 5, 40), neg=True)
+            excl = rng.integers(-1, rows, nq).astype(np.int64) if rng.random() < 0.5 else None
+            got = s.search(qp, qi, qv, k, exclude=excl)
+            check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(nq)), list(excl) if excl is not None else [-1] * nq, mask)
+        s.close()
 
 
 def test_edge_inputs(oracle):

@@ -276,3 +276,30 @@ def test_sparse_dot_both_search_strategies_equal_a_plain_sequential_sum(oracle):
         for x, y in (((ia, va), (ib, vb)), ((ib, vb), (ia, va))):
             c, got = oracle.sparse_dot(x[0], x[1], y[0], y[1])
             assert c == common.size and np.float32(got).view(np.uint32) == s.view(np.uint32)
+
+
+def test_inverted_index_search_equals_the_brute_force_search(oracle):
+    """orc_sparse_search_inverted (the CPU baseline bench.py times: posting lists + accumulators) returns what
+    orc_sparse_search (every row merged against the query) returns -- rows, score bits, counts -- with masks, exclusions,
+    cancelling and negative scores, k below and above the number of hits"""
+    from sparse_cases import random_csr, tie_case, TIE_EXPECT
+    rng = np.random.default_rng(9)
+    for case in range(12):
+        rows, dims = int(rng.integers(1, 500)), int(rng.integers(1, 60))
+        ptr, idx, val = random_csr(rng, rows, dims, 0, min(dims, 12), neg=bool(case % 2), zipf=bool(case % 3))
+        ix = oracle.sparse_index(ptr, idx, val)
+        scratch = ix.scratch()
+        mask = (rng.random(rows) < 0.7).astype(np.uint8) if case % 4 == 1 else None
+        for q in range(min(rows, 25)):
+            qi, qv = idx[ptr[q]:ptr[q + 1]], val[ptr[q]:ptr[q + 1]]
+            for k in (1, 5, 40, 600):
+                ex = q if k != 5 else -1
+                ei, es = oracle.sparse_search(ptr, idx, val, qi, qv, k, exclude=ex, admissible=mask)
+                gi, gs, walked = ix.search(qi, qv, k, exclude=ex, admissible=mask, scratch=scratch)
+                assert gi.tolist() == ei.tolist() and gs.view(np.uint32).tolist() == es.view(np.uint32).tolist()
+        assert not scratch[0].any() and not scratch[1].any()  # the scratch comes back clean
+    ptr, idx, val, (qp, qi, qv), mask, excl = tie_case()
+    ix = oracle.sparse_index(ptr, idx, val)
+    for k, expect in TIE_EXPECT.items():
+        gi, gs, walked = ix.search(qi[:2], qv[:2], k, exclude=0, admissible=mask)
+        assert gi.tolist() == expect
