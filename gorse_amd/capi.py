@@ -17,7 +17,8 @@ OK, ERR_INVALID, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE, ERR_RANGE, ERR_NOMEM = 0
 BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
 METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
-PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM, PROF_BPR_SORT = 0, 1, 2, 3, 4
+PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM, PROF_BPR_SORT, PROF_COMM = 0, 1, 2, 3, 4, 5
+COMM_ID_BYTES = 128
 PROF_TOPK_SCORE, PROF_TOPK_RESCORE, PROF_TOPK_SWEEP, PROF_TOPK_SELECT, PROF_TOPK_HIST, PROF_TOPK_REPLAY = 0, 1, 2, 3, 4, 5
 
 _f32p = C.POINTER(C.c_float)
@@ -53,6 +54,14 @@ SIGNATURES = {
     "gorse_mf_item_delta_export": (C.c_int32, [_vp, _vp]),
     "gorse_mf_item_delta_import": (C.c_int32, [_vp, _vp]),
     "gorse_mf_device_ptrs": (C.c_int32, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "gorse_comm_unique_id": (C.c_int32, [_vp]),
+    "gorse_comm_create": (C.c_int32, [C.POINTER(_vp), _vp, C.c_int32, C.c_int32, C.c_int32]),
+    "gorse_comm_create_local": (C.c_int32, [C.POINTER(_vp), _i32p, C.c_int32]),
+    "gorse_comm_destroy": (C.c_int32, [_vp]),
+    "gorse_comm_info": (C.c_int32, [_vp, _i32p, _i32p]),
+    "gorse_mf_item_allreduce": (C.c_int32, [C.POINTER(_vp), C.POINTER(_vp), C.c_int32]),
+    "gorse_mf_rows_allgather": (C.c_int32, [C.POINTER(_vp), C.POINTER(_vp), C.c_int32, C.c_int32, _i64p]),
+    "gorse_comm_allreduce_f32": (C.c_int32, [_vp, _f32p, C.c_int64]),
     "gorse_mf_synchronize": (C.c_int32, [_vp]),
     "gorse_mf_set_profiling": (C.c_int32, [_vp, C.c_int32]),
     "gorse_mf_get_profile": (C.c_int32, [_vp, C.c_int32, _i64p, _f64p]),
@@ -340,6 +349,65 @@ class TopK:
         a, b = C.c_int64(0), C.c_int64(0)
         check(lib().gorse_topk_last_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+class Comm:
+    """One rank of an RCCL communicator owned by the library (gorse_comm_*): Comm.unique_id() on rank 0, the bytes shipped
+    to every rank by the caller, Comm(id, world, rank, device) everywhere; Comm.local(devices) = all ranks in this process."""
+
+    def __init__(self, uid=None, world=1, rank=0, device=0, _handle=None):
+        if _handle is not None:
+            self.h = _handle
+        else:
+            buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+            self.h = _vp()
+            check(lib().gorse_comm_create(C.byref(self.h), C.cast(buf, _vp), world, rank, device))
+        w, r = C.c_int32(0), C.c_int32(0)
+        check(lib().gorse_comm_info(self.h, C.byref(w), C.byref(r)))
+        self.world, self.rank = w.value, r.value
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        check(lib().gorse_comm_unique_id(C.cast(buf, _vp)))
+        return bytes(buf)
+
+    @staticmethod
+    def local(devices):
+        devs = _arr(devices, np.int32)
+        out = (_vp * devs.size)()
+        check(lib().gorse_comm_create_local(out, _p(devs, _i32p), devs.size))
+        return [Comm(_handle=_vp(out[i])) for i in range(devs.size)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().gorse_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def allreduce_f32(self, values):
+        a = np.array(values, dtype=np.float32)
+        check(lib().gorse_comm_allreduce_f32(self.h, _p(a, _f32p), a.size))
+        return a
+
+
+def _pairs(mfs, comms):
+    n = len(mfs)
+    hs, cs = (_vp * n)(*[m.h for m in mfs]), (_vp * n)(*[c.h for c in comms])
+    return hs, cs, n
+
+
+def item_allreduce(mfs, comms):
+    """gorse_mf_item_allreduce over this process's (handle, communicator) pairs"""
+    hs, cs, n = _pairs(mfs, comms)
+    check(lib().gorse_mf_item_allreduce(hs, cs, n))
+
+
+def rows_allgather(mfs, comms, side, row_splits):
+    hs, cs, n = _pairs(mfs, comms)
+    sp = _arr(row_splits, np.int64)
+    check(lib().gorse_mf_rows_allgather(hs, cs, n, side, _p(sp, _i64p)))
 
 
 class Sparse:

@@ -406,10 +406,10 @@ extern "C" int32_t gorse_mf_item_sync_mark(gorse_mf *h) {
     return GORSE_OK;
 }
 
-extern "C" int32_t gorse_mf_item_delta_export(gorse_mf *h, float *dst) {
-    if (!h || !dst) return fail(GORSE_ERR_INVALID, "NULL argument");
+// the two halves of the item-factor exchange, enqueued on the handle's stream (no host synchronisation): comm.hip puts the
+// RCCL all-reduce between them on the same stream
+int32_t gorse::mf_delta_export_async(gorse_mf *h, float *dst) {
     if (!h->Qsync.p) return fail(GORSE_ERR_INVALID, "gorse_mf_item_sync_mark was never called");
-    GORSE_TRY(h->use());
     const int64_t n = h->I * (int64_t)h->d, n4 = (((uintptr_t)dst & 15) == 0) ? n / 4 : 0;
     if (n4 > 0) {
         int64_t blocks = std::min<int64_t>(ceil_div(n4, 256), 2048);
@@ -420,14 +420,11 @@ extern "C" int32_t gorse_mf_item_delta_export(gorse_mf *h, float *dst) {
         delta_export_tail<<<dim3((unsigned)ceil_div(n - n4 * 4, 256)), dim3(256), 0, h->stream>>>(h->Q.p, h->Qsync.p, dst,
                                                                                                  n4 * 4, n);
     GORSE_HIP_CHECK(hipGetLastError());
-    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the caller's collective runs on its own stream
     return GORSE_OK;
 }
 
-extern "C" int32_t gorse_mf_item_delta_import(gorse_mf *h, const float *src) {
-    if (!h || !src) return fail(GORSE_ERR_INVALID, "NULL argument");
+int32_t gorse::mf_delta_import_async(gorse_mf *h, const float *src) {
     if (!h->Qsync.p) return fail(GORSE_ERR_INVALID, "gorse_mf_item_sync_mark was never called");
-    GORSE_TRY(h->use());
     const int64_t n = h->I * (int64_t)h->d, n4 = (((uintptr_t)src & 15) == 0) ? n / 4 : 0;
     if (n4 > 0) {
         int64_t blocks = std::min<int64_t>(ceil_div(n4, 256), 2048);
@@ -438,6 +435,21 @@ extern "C" int32_t gorse_mf_item_delta_import(gorse_mf *h, const float *src) {
         delta_import_tail<<<dim3((unsigned)ceil_div(n - n4 * 4, 256)), dim3(256), 0, h->stream>>>(h->Q.p, h->Qsync.p, src,
                                                                                                  n4 * 4, n);
     GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_item_delta_export(gorse_mf *h, float *dst) {
+    if (!h || !dst) return fail(GORSE_ERR_INVALID, "NULL argument");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_delta_export_async(h, dst));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the caller's collective runs on its own stream
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_item_delta_import(gorse_mf *h, const float *src) {
+    if (!h || !src) return fail(GORSE_ERR_INVALID, "NULL argument");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_delta_import_async(h, src));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     return GORSE_OK;
 }

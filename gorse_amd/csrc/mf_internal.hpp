@@ -69,5 +69,7 @@ struct gorse_mf {
 namespace gorse {
 // implemented in bpr.hip / als.hip, used across files
 int32_t mf_sync_streams(gorse_mf *h);
+int32_t mf_delta_export_async(gorse_mf *h, float *dst);        // mf.hip: dst <- Q - Q_sync, enqueued on h->stream
+int32_t mf_delta_import_async(gorse_mf *h, const float *src);  // mf.hip: Q <- Q_sync + src; Q_sync <- Q
 int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, int64_t lo, int64_t hi);
 }

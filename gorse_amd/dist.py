@@ -37,8 +37,13 @@ def shard_csr(indptr, indices, lo, hi):
 
 def run_epoch(engine, comm, n_samples, lr, reg, seed, epoch, sample_base):
     """One data-parallel BPR epoch + the item-factor exchange.  comm: object with all_reduce_sum(tensor)
-    (None for a single rank)."""
+    (None for a single rank), or a LibComm: the exchange then is ONE library call (gorse_mf_item_allreduce: export
+    kernel, RCCL all-reduce and import kernel enqueued on the handle's stream, no host synchronisation)."""
     engine.epoch(n_samples, lr, reg, seed, epoch, sample_base)
+    if isinstance(comm, LibComm):
+        if comm.world > 1 or comm.always:
+            comm.item_allreduce(engine.mf)
+        return
     if comm is not None and comm.world > 1:
         delta = engine.export_delta()
         comm.all_reduce_sum(delta)
@@ -58,6 +63,11 @@ def run_als_epoch(engine, comm, weight, reg):
     block_rows * d, import_blocks(side, gathered tensor of world * block_rows * d)."""
     for side in (0, 1):  # model.go:645-690, then :693-738
         engine.half(side, weight, reg)
+        if isinstance(comm, LibComm):
+            if comm.world > 1 or comm.always:
+                comm.rows_allgather(engine.mf, side, [shard_range(engine.rows[side], r, comm.world)[0] for r in range(comm.world)]
+                                    + [engine.rows[side]])
+            continue
         if comm is not None and comm.world > 1:
             mine = engine.export_block(side)
             gathered = comm.all_gather(mine)
@@ -71,7 +81,10 @@ def evaluate_sharded(engine, comm, topk, metrics=("ndcg", "precision", "recall")
     engine.eval_partial(topk, metrics) -> (float32 sums, float32 count) over the users this rank owns."""
     sums, count = engine.eval_partial(topk, metrics)
     t = np.array([float(x) for x in sums] + [float(count)], np.float32)
-    if comm is not None and comm.world > 1:
+    if isinstance(comm, LibComm):
+        if comm.world > 1 or comm.always:
+            t = comm.comm.allreduce_f32(t)
+    elif comm is not None and comm.world > 1:
         import torch
         tt = torch.from_numpy(t).to(getattr(engine, "device", "cpu"))
         comm.all_reduce_sum(tt)
@@ -123,6 +136,29 @@ class HipNeighborsEngine:
             return res
         idx, dist = res    # TopK: distances ascending, padded with -1 / +inf
         return idx, dist, (idx >= 0).sum(axis=1).astype(np.int32)
+
+
+class LibComm:
+    """The library's own RCCL communicator (gorse_comm_*, csrc/comm.hip) for one process per GPU: rank 0 draws the unique
+    id, `share(bytes) -> bytes` ships it to every rank (bench.py: a torch.distributed broadcast).  `always` runs the
+    collectives at world 1 too (what the one-GPU box can test of this path)."""
+
+    def __init__(self, rank, world, device, share, always=False):
+        from . import capi
+        self.capi = capi
+        uid = capi.Comm.unique_id() if rank == 0 else bytes(capi.COMM_ID_BYTES)
+        uid = share(uid)
+        self.comm = capi.Comm(uid, world, rank, device)
+        self.world, self.rank, self.always = world, rank, always
+
+    def item_allreduce(self, mf):
+        self.capi.item_allreduce([mf], [self.comm])
+
+    def rows_allgather(self, mf, side, row_splits):
+        self.capi.rows_allgather([mf], [self.comm], side, row_splits)
+
+    def close(self):
+        self.comm.close()
 
 
 class TorchComm:

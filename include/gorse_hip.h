@@ -147,6 +147,33 @@ int32_t gorse_mf_rows_import(gorse_mf *h, int32_t side, int64_t begin, int64_t e
 int32_t gorse_mf_item_sync_mark(gorse_mf *h);
 int32_t gorse_mf_item_delta_export(gorse_mf *h, float *dst /*device*/);
 int32_t gorse_mf_item_delta_import(gorse_mf *h, const float *src /*device*/);
+/* ---- the same exchanges with RCCL behind the boundary ------------------------------------------------
+ * the reference trains in ONE process and one goroutine (master/tasks.go:879-1034), so the
+ * multi-GPU path has to be callable from there: a gorse_comm is one rank of an RCCL communicator owned by this
+ * library (librccl is dlopen'ed on first use).  Two ways to get the ranks:
+ *   one process, N GPUs  : gorse_comm_create_local(comms, devices, N)  -- one handle + one communicator per device,
+ *                          every exchange call below receives all N pairs (issued as one RCCL group);
+ *   one process per GPU  : rank 0 calls gorse_comm_unique_id and ships the 128 bytes to the others (bench.py: a
+ *                          torch.distributed broadcast; Go: whatever RPC the deployment has), every rank calls
+ *                          gorse_comm_create(id, world, rank, device) and passes its ONE (handle, communicator) pair.
+ * The collectives are enqueued on the handles' own streams between the kernels that fill and consume their buffers:
+ * an exchange synchronises nothing with the host.
+ *   gorse_mf_item_allreduce : Q <- Q_sync + sum over ranks (Q - Q_sync); Q_sync <- Q   (one all-reduce of I*d fp32;
+ *                             gorse_mf_item_sync_mark once before the first epoch)
+ *   gorse_mf_rows_allgather : after gorse_als_half_epoch(side): rank r's rows [row_splits[r], row_splits[r+1]) of P (side 0)
+ *                             or Q (side 1) reach every replica (one broadcast per owner, grouped; (U or I)*d fp32)
+ *   gorse_comm_allreduce_f32: n host floats summed over the ranks in place (metric partial sums of a sharded Evaluate) */
+typedef struct gorse_comm gorse_comm;
+#define GORSE_COMM_ID_BYTES 128
+int32_t gorse_comm_unique_id(uint8_t *id /*host, GORSE_COMM_ID_BYTES*/);
+int32_t gorse_comm_create(gorse_comm **c, const uint8_t *id /*host*/, int32_t world, int32_t rank, int32_t device);
+int32_t gorse_comm_create_local(gorse_comm **comms /*out: n*/, const int32_t *devices /*n*/, int32_t n);
+int32_t gorse_comm_destroy(gorse_comm *c);
+int32_t gorse_comm_info(gorse_comm *c, int32_t *world /*out*/, int32_t *rank /*out*/);
+int32_t gorse_mf_item_allreduce(gorse_mf *const *handles, gorse_comm *const *comms, int32_t n);
+int32_t gorse_mf_rows_allgather(gorse_mf *const *handles, gorse_comm *const *comms, int32_t n, int32_t side,
+                                const int64_t *row_splits /*host, world + 1*/);
+int32_t gorse_comm_allreduce_f32(gorse_comm *c, float *buf /*host, in place*/, int64_t n);
 /* Raw device addresses of the resident factor matrices (row-major U*d, I*d). */
 int32_t gorse_mf_device_ptrs(gorse_mf *h, float **P /*out: device*/, float **Q /*out: device*/);
 
@@ -161,7 +188,8 @@ int32_t gorse_mf_set_profiling(gorse_mf *h, int32_t on);
 #define GORSE_PROF_ALS_SWEEP 2
 #define GORSE_PROF_ALS_GRAM 3
 #define GORSE_PROF_BPR_SORT 4 /* counting sort of a chunk's triplets by positive item (rank + scan + scatter) */
-#define GORSE_PROF_NCLASSES 5
+#define GORSE_PROF_COMM 5 /* the RCCL collectives of gorse_mf_item_allreduce / gorse_mf_rows_allgather          */
+#define GORSE_PROF_NCLASSES 6
 int32_t gorse_mf_get_profile(gorse_mf *h, int32_t kernel_class, int64_t *launches, double *total_ms);
 int32_t gorse_mf_reset_profile(gorse_mf *h);
 
