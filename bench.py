@@ -64,12 +64,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="ml1m", choices=["ml1m", "c3", "ml100k", "topk", "als", "i2i"])
+    ap.add_argument("--workload", default=None, choices=["ml1m", "c3", "ml100k", "topk", "als", "i2i"],
+                    help="default: ml1m (C2) on one GPU -- the line then also carries topk (C4), c3, i2i and als objects; c3 on N > 1")
+    ap.add_argument("--comm", default="lib", choices=["lib", "torch"], help="who owns the RCCL communicator of a multi-rank run")
+    ap.add_argument("--no-extra", action="store_true", help="default single-GPU run without the c3 / i2i / als objects")
     ap.add_argument("--i2i-shape", default="c3", choices=["c3", "ml1m", "ml100k"])
     ap.add_argument("--als-scale", type=float, default=1.0, help="shrink S-als (users, items, feedbacks) by this factor")
     ap.add_argument("--no-topk", action="store_true", help="skip the item x item top-k leg of the default run")
-    ap.add_argument("--no-i2i", action="store_true", help="skip the sparse item-to-item leg of the default single-GPU run")
-    ap.add_argument("--i2i-timeout", type=float, default=240.0, help="seconds the sparse leg's child process may take")
     ap.add_argument("--topk-n", type=int, default=1_000_000)
     ap.add_argument("--topk-steps", type=int, default=2)
     ap.add_argument("--topk-budget", type=float, default=60.0, help="seconds the timed top-k steps may take (see bench_topk)")
@@ -77,6 +78,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
+
+
+def make_data_desc(workload):
+    return {"ml1m": (64, "S-ml1m 6040x3706x994169 per rank (C2), nFactors=64"),
+            "ml100k": (16, "S-ml100k 943x1682x99057 per rank (C1), nFactors=16"),
+            "c3": (128, "S-big shard 125000x200000x12.5M per rank (C3/8), nFactors=128")}[workload]
 
 
 def make_data(workload, rank):
@@ -249,12 +256,16 @@ def bench_topk(args, world, rank, local, fence):
     return out
 
 
-def bench_sparse(args, world, rank, local, fence):
+def bench_sparse(args, world, rank, local, fence, data=None, steps=None, warmup=None):
     """The sparse similarity refresh (logics/item_to_item.go "users" kind over a sparse Dot collection): every item's
     top-100 neighbours by the inner product of the sqrt(idf)-weighted user sets.  A step = one all-pairs pass over this
     rank's query rows; results stay in HBM."""
     k = 100
-    if args.i2i_shape == "c3":
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    if data is not None:
+        desc = "S-big shard 125000 users x 200000 items x 12.5M feedbacks"
+    elif args.i2i_shape == "c3":
         data, desc = synth.s_big_shard(rank=0, world=8), "S-big shard 125000 users x 200000 items x 12.5M feedbacks"
     elif args.i2i_shape == "ml1m":
         data, desc = synth.s_ml1m(), "S-ml1m 6040 users x 3706 items"
@@ -267,12 +278,12 @@ def bench_sparse(args, world, rank, local, fence):
     eng = gdist.HipNeighborsEngine(sp, fetch=False)
     comm = gdist.TorchComm() if world > 1 else None
     sp.all_pairs(k, q0, min(q1, q0 + 4096), fetch=False)  # warm-up: scratch allocation, code objects
-    for _ in range(max(args.warmup - 1, 0)):
+    for _ in range(max(warmup - 1, 0)):
         gdist.refresh_neighbors_sharded(eng, comm, k, gather=False)
     fence()
     sp.set_profiling(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):  # gorse_amd.dist.refresh_neighbors_sharded is the function the gloo CPU tests exercise
+    for _ in range(steps):  # gorse_amd.dist.refresh_neighbors_sharded is the function the gloo CPU tests exercise
         gdist.refresh_neighbors_sharded(eng, comm, k, gather=False)
     fence()
     dt = time.perf_counter() - t0
@@ -291,8 +302,8 @@ def bench_sparse(args, world, rank, local, fence):
     achieved = postings * 8.0 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     out = {
         "metric": "sparse item x item top-%d multiply-adds/sec (postings walked, whole job, N GPUs)" % k,
-        "value": world * postings * args.steps / dt, "unit": "postings/s", "n_gpus": world, "steps": args.steps,
-        "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "value": world * postings * steps / dt, "unit": "postings/s", "n_gpus": world, "steps": steps,
+        "warmup": max(warmup, 1), "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "users item-to-item over %s: %d sparse vectors, %d entries, k=%d, query rows sharded x%d"
                                % (desc, N, int(ptr[-1]), k, world),
@@ -363,29 +374,6 @@ def sparse_cpu_baseline(ptr, idx, val, k, seconds, sp, q_begin):
                       % (len(qs), stride, q_begin, threads, postings, dt)}
 
 
-def i2i_in_a_child(args):
-    """The sparse item-to-item leg of the default run, in a CHILD process with a time limit (its dataset is
-    the 12.5M-feedback C3 shard: generation plus the CPU baseline take tens of seconds, and nothing that happens there may
-    cost the line its headline numbers).  Returns the child's JSON object, or {"error": ...}."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "i2i", "--i2i-shape", args.i2i_shape, "--steps", "3", "--warmup", "1",
-           "--cpu-seconds", str(args.cpu_seconds)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
-    try:
-        child = subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-        try:
-            so, se = child.communicate(timeout=args.i2i_timeout)
-        except subprocess.TimeoutExpired:
-            import signal
-            os.killpg(child.pid, signal.SIGKILL)
-            child.communicate()
-            return {"error": "no result within %.0f s (child killed)" % args.i2i_timeout}
-        lines = [l for l in so.splitlines() if l.startswith("{")]
-        if child.returncode != 0 or not lines:
-            return {"error": "exit code %d: %s" % (child.returncode, (se or so)[-600:])}
-        return json.loads(lines[-1])
-    except Exception as e:  # a report, never a reason to lose the line
-        return {"error": repr(e)}
-
-
 def als_cpu_baseline(uptr, uidx, iptr, P, Q, w, reg, seconds):
     """The oracle's half-sweep (kind 'port', model.go:659-690) on a prefix of the user rows, T host threads each on
     its own row range (rows are independent: what parallel.Parallel does); the serial d x d Gram pass every call
@@ -420,9 +408,11 @@ def als_cpu_baseline(uptr, uidx, iptr, P, Q, w, reg, seconds):
                       "half-sweep), hence entries / (2 x time)" % (rows, n, threads, dt, t_gram)}
 
 
-def bench_als(args, world, rank, local, fence):
+def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
     """BASELINE config C5: eALS, nFactors 64.  Every rank holds the dataset and both factor matrices and solves its
     row ranges (gorse_amd.dist.run_als_epoch); a step = one epoch = 2 half-sweeps + 2 all-gathers."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     sc = args.als_scale
     U, I, nnz, d = int(500_000 * sc), int(100_000 * sc), int(50_000_000 * sc), 64
     w, reg = 0.001, 0.06
@@ -432,15 +422,15 @@ def bench_als(args, world, rank, local, fence):
     P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.1, seed=1)
     mf.set_factors(P0, Q0)
     eng = gdist.HipAlsEngine(mf, rank, world)
-    comm = gdist.TorchComm() if world > 1 else None
-    for _ in range(max(args.warmup, 1)):
+    comm, comm_label = make_comm(args, world, rank, local)
+    for _ in range(max(warmup, 1)):
         gdist.run_als_epoch(eng, comm, w, reg)
     mf.synchronize()
     fence()
     mf.set_profiling(True)
     mf.reset_profile()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         gdist.run_als_epoch(eng, comm, w, reg)
     mf.synchronize()
     fence()
@@ -458,20 +448,20 @@ def bench_als(args, world, rank, local, fence):
     (u0, u1), (i0, i1) = eng.range
     own = int(uptr[u1] - uptr[u0]) + int(iptr[i1] - iptr[i0])  # gathered rows of this rank's two half-sweeps
     algo = own * d * 4.0 + 2.0 * ((u1 - u0) + (i1 - i0)) * d * 4  # gathers + factor rows read/written
-    per_epoch_ms = (sweep_ms + gram_ms) / max(args.steps, 1)
+    per_epoch_ms = (sweep_ms + gram_ms) / max(steps, 1)
     achieved = algo / (per_epoch_ms * 1e-3) / 1e9 if per_epoch_ms > 0 else 0.0
     out = {
         "metric": "ALS feedback entries/sec (nnz per epoch x epochs / time, whole job, N GPUs)",
-        "value": n * args.steps / dt, "unit": "entries/s", "n_gpus": world, "steps": args.steps,
-        "warmup": max(args.warmup, 1), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "value": n * steps / dt, "unit": "entries/s", "n_gpus": world, "steps": steps,
+        "warmup": max(warmup, 1), "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "S-als %dx%dx%d (C5%s), nFactors=%d, weight=%g reg=%g" % (U, I, n, "" if sc == 1.0 else " x%g" % sc, d, w, reg),
-                   "parallelism": "rows sharded x%d, factors replicated, 2 all-gathers((U+I)*d fp32)/epoch" % world
+                   "parallelism": "rows sharded x%d, factors replicated, 2 all-gathers((U+I)*d fp32)/epoch over %s" % (world, comm_label)
                    if world > 1 else "single GPU", "factors_finite": bool(np.isfinite(P).all() and np.isfinite(Q).all())},
         "roofline": {"bound": "hbm", "kernel": "als_row_kernel + als_chunk_kernel (+ S Gram)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_epoch": algo, "avg_launch_ms": per_epoch_ms, "launches": ns,
-                     "sweeps_ms_per_epoch": sweep_ms / max(args.steps, 1), "gram_ms_per_epoch": gram_ms / max(args.steps, 1)},
+                     "sweeps_ms_per_epoch": sweep_ms / max(steps, 1), "gram_ms_per_epoch": gram_ms / max(steps, 1)},
     }
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -479,6 +469,137 @@ def bench_als(args, world, rank, local, fence):
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "entries/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     return out
+
+
+def make_comm(args, world, rank, local):
+    """The exchange path of a multi-rank run: the library's own RCCL communicator (csrc/comm.hip; the unique id travels from
+    rank 0 through a torch.distributed broadcast), or torch.distributed's with --comm torch / when the library's cannot be
+    set up.  Returns (comm, label)."""
+    if world == 1:
+        return None, "single GPU"
+    label = "torch.distributed nccl"
+    if args.comm == "lib":
+        lib, why = None, ""
+        try:
+            def share(uid):
+                t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+                dist.broadcast(t, src=0)
+                return bytes(t.cpu().tolist())
+            lib = gdist.LibComm(rank, world, local, share)
+        except Exception as e:  # reported in the line; the run goes on over torch.distributed
+            why = repr(e)
+        ok = torch.tensor([1.0 if lib is not None else 0.0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
+        if float(ok.item()) > 0:
+            return lib, "gorse_comm (RCCL inside libgorse_hip, collectives on the handle's stream)"
+        label = "torch.distributed nccl (gorse_comm unavailable on some rank%s)" % (": " + why if why else "")
+    return gdist.TorchComm(), label
+
+
+def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmup, data=None, with_cpu=True):
+    """One BPR leg: a step = one epoch = CountFeedback() samples over this rank's resident shard + the item-factor exchange."""
+    if data is None:
+        data, d, desc = make_data(workload, rank)
+    else:
+        d, desc = make_data_desc(workload)
+    lr, reg = 0.05, 0.01
+    n_samples = data.n_train
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, device=local)
+    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, seed=1)  # same Q on every rank
+    if world > 1:
+        P0 = synth.init_factors(data.U, 1, d, 0.0, 0.001, seed=100 + rank)[0]
+    mf.set_factors(P0, Q0)
+    engine = gdist.HipEngine(mf, args.mode)
+    if world > 1:
+        if isinstance(comm, gdist.LibComm):
+            mf.item_sync_mark()
+        else:
+            engine.enable_exchange()
+
+    def step(epoch):  # gorse_amd.dist.run_epoch is the function the gloo CPU tests exercise
+        gdist.run_epoch(engine, comm, n_samples, lr, reg, 2024, epoch, rank * (1 << 40))
+
+    def fence():
+        mf.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(warmup):
+        step(w + 1)
+    fence()
+    mf.set_profiling(True)
+    mf.reset_profile()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        step(warmup + s + 1)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    launches, upd_ms = mf.get_profile(capi.PROF_BPR_UPDATE)
+    s_launches, smp_ms = mf.get_profile(capi.PROF_BPR_SAMPLE)
+    o_launches, sort_ms = mf.get_profile(capi.PROF_BPR_SORT)
+    c_launches, comm_ms = mf.get_profile(capi.PROF_COMM)
+    user_runs = args.mode == capi.BPR_HOGWILD_ATOMIC and mf.bpr_user_runs()
+    mf.set_profiling(False)
+    P, Q = mf.get_factors()
+    finite = bool(np.isfinite(P).all() and np.isfinite(Q).all())
+    mf.close()
+    if rank != 0:
+        return None
+    bytes_per_sample = 6 * d * 4 + 12  # SURVEY.md 8(d): three rows read + three written + indices
+    samples_per_launch = steps * n_samples / max(launches, 1)
+    avg_ms = upd_ms / max(launches, 1)
+    achieved = samples_per_launch * bytes_per_sample / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "BPR positive-samples/sec (whole job, N GPUs)",
+        "value": world * n_samples * steps / dt,
+        "unit": "samples/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "samples_per_step_per_gpu": n_samples, "lr": lr, "reg": reg,
+                   "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode]
+                   + (", user runs (triplets counting-sorted by user, p_u register-resident)" if user_runs else
+                      (", one group per sample" if args.mode == capi.BPR_HOGWILD_ATOMIC else "")),
+                   "parallelism": "users sharded x%d, item factors replicated, 1 all-reduce(%.1f MB = I*d fp32)/epoch over %s"
+                   % (world, data.I * d * 4 / 1e6, comm_label) if world > 1 else "single GPU", "factors_finite": finite},
+        "roofline": {"bound": "hbm", "kernel": "bpr_update_user_kernel" if user_runs else "bpr_update_kernel",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": avg_ms,
+                     "launches": launches, "sampler_avg_ms": smp_ms / max(s_launches, 1),
+                     "user_sort_avg_ms": sort_ms / max(o_launches, 1) if o_launches else 0.0,
+                     "note": "working set %.1f MB" % ((data.U + data.I) * d * 4 / 1e6)},
+    }
+    if world > 1:
+        out["exchange"] = {"allreduce_avg_ms": comm_ms / max(c_launches, 1) if c_launches else None, "launches": c_launches,
+                           "bytes": data.I * d * 4, "path": comm_label}
+    if args.mode == capi.BPR_HOGWILD_ATOMIC and workload in ("ml1m", "c3"):
+        key = {"ml1m": "ml1m_users" if user_runs else "ml1m", "c3": "c3_users"}[workload]
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(key)
+    if world == 1 and with_cpu and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(data, d, lr, reg, args.cpu_seconds)
+        except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+    return out
+
+
+def leg(fn, what):
+    """a secondary leg of the default line: its failure costs the line that object only"""
+    try:
+        return fn()
+    except AssertionError:
+        raise  # a parity check inside a leg failed: that must not pass silently
+    except Exception as e:
+        return {"metric": what, "value": None, "error": repr(e)}
 
 
 def main():
@@ -495,6 +616,8 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
     torch.cuda.set_device(local)
+    # BASELINE.json quotes the single-GPU number on C2 (S-ml1m) and the 8-GPU number on C3: that is what N = 1 / N > 1 run
+    workload = args.workload or ("ml1m" if world == 1 else "c3")
 
     def fence0():
         torch.cuda.synchronize()
@@ -502,10 +625,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.workload in ("topk", "als", "i2i"):
-        if args.workload == "als":
+    if workload in ("topk", "als", "i2i"):
+        if workload == "als":
             out = bench_als(args, world, rank, local, fence0)
-        elif args.workload == "i2i":
+        elif workload == "i2i":
             out = bench_sparse(args, world, rank, local, fence0)
         else:
             out = bench_topk(args, world, rank, local, fence0)
@@ -519,100 +642,21 @@ def main():
             dist.destroy_process_group()
         return
 
-    data, d, desc = make_data(args.workload, rank)
-    lr, reg = 0.05, 0.01
-    n_samples = data.n_train
-    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, device=local)
-    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, seed=1)  # same Q on every rank
-    if world > 1:
-        P0 = synth.init_factors(data.U, 1, d, 0.0, 0.001, seed=100 + rank)[0]
-    mf.set_factors(P0, Q0)
-    engine = gdist.HipEngine(mf, args.mode)
-    comm = gdist.TorchComm() if world > 1 else None
-    if world > 1:
-        engine.enable_exchange()
-
-    def step(epoch):  # gorse_amd.dist.run_epoch is the function the gloo CPU tests exercise
-        gdist.run_epoch(engine, comm, n_samples, lr, reg, 2024, epoch, rank * (1 << 40))
-
-    def fence():
-        mf.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for w in range(args.warmup):
-        step(w + 1)
-    fence()
-    mf.set_profiling(True)
-    mf.reset_profile()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(args.warmup + s + 1)
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    launches, upd_ms = mf.get_profile(capi.PROF_BPR_UPDATE)
-    s_launches, smp_ms = mf.get_profile(capi.PROF_BPR_SAMPLE)
-    o_launches, sort_ms = mf.get_profile(capi.PROF_BPR_SORT)
-    user_runs = args.mode == capi.BPR_HOGWILD_ATOMIC and mf.bpr_user_runs()
-    mf.set_profiling(False)
-    P, Q = mf.get_factors()
-    finite = bool(np.isfinite(P).all() and np.isfinite(Q).all())
-
-    if rank == 0:
-        bytes_per_sample = 6 * d * 4 + 12  # three rows read + three written + indices
-        samples_per_launch = args.steps * n_samples / max(launches, 1)
-        avg_ms = upd_ms / max(launches, 1)
-        achieved = samples_per_launch * bytes_per_sample / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        out = {
-            "metric": "BPR positive-samples/sec (whole job, N GPUs)",
-            "value": world * n_samples * args.steps / dt,
-            "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "samples_per_step_per_gpu": n_samples, "lr": lr, "reg": reg,
-                       "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode]
-                       + (", user runs (triplets counting-sorted by user, p_u register-resident)" if user_runs else
-                          (", one group per sample" if args.mode == capi.BPR_HOGWILD_ATOMIC else "")),
-                       "parallelism": "users sharded x%d, item factors replicated, 1 all-reduce(I*d fp32)/epoch" % world
-                       if world > 1 else "single GPU", "factors_finite": finite},
-            "roofline": {"bound": "hbm", "kernel": "bpr_update_user_kernel" if user_runs else "bpr_update_kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": avg_ms,
-                         "launches": launches, "sampler_avg_ms": smp_ms / max(s_launches, 1),
-                         "user_sort_avg_ms": sort_ms / max(o_launches, 1) if o_launches else 0.0,
-                         "note": "working set %.1f MB" % ((data.U + data.I) * d * 4 / 1e6)},
-        }
-        if args.workload == "ml1m" and args.mode == capi.BPR_HOGWILD_ATOMIC:
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("ml1m_users" if user_runs else "ml1m")
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(data, d, lr, reg, args.cpu_seconds)
-            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
-    topk = None
-    if args.workload == "ml1m" and not args.no_topk:  # BASELINE.json's metric has two halves; the second one
-        del mf
-        try:
-            topk = bench_topk(args, world, rank, local, fence0)
-        except AssertionError:
-            raise
-        except Exception as e:
-            topk = {"metric": "item x item cosine top-100 pairs/sec", "value": None, "error": repr(e)}
-    if rank == 0:
-        if topk is not None:
+    comm, comm_label = make_comm(args, world, rank, local)
+    out = bench_bpr(args, workload, world, rank, local, comm, comm_label, args.steps, args.warmup)
+    full_line = args.workload is None and world == 1  # the default single-GPU run carries the other configurations too
+    if workload == "ml1m" and not args.no_topk:  # BASELINE.json's metric has two halves; this is the second one
+        topk = leg(lambda: bench_topk(args, world, rank, local, fence0), "item x item cosine top-100 pairs/sec")
+        if rank == 0:
             out["topk"] = topk
-        if args.workload == "ml1m" and world == 1 and not args.no_i2i:
-            out["i2i"] = i2i_in_a_child(args)
+    if full_line and not args.no_extra:
+        big = synth.s_big_shard(rank=0, world=8)
+        out["c3"] = leg(lambda: bench_bpr(args, "c3", 1, 0, local, None, "single GPU", 5, 2, data=big, with_cpu=False),
+                        "BPR positive-samples/sec, one C3 shard")
+        out["i2i"] = leg(lambda: bench_sparse(args, 1, 0, local, fence0, data=big, steps=3, warmup=1), "sparse item x item top-100")
+        del big
+        out["als"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=3, warmup=1), "ALS feedback entries/sec")
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -49,19 +49,19 @@ struct gorse_sparse {
 namespace {
 
 // probes / test hooks (include/gorse_hip_test.h); results never depend on them
-int g_sparse_tile = 0;           // rows per tile (power of two, 256 .. 16384); 0 = chosen from N
+int g_sparse_tile = 0;           // rows per tile (power of two, 64 .. 2048; a group = 8 tiles); 0 = chosen from N
 int64_t g_sparse_split = 2048;   // queries with more entries than this are split over the 8 stripes; <= 0 = never
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 
 int pick_log_tile(int64_t N) {
     if (g_sparse_tile > 0) {
-        int l = 8;
-        while ((1 << l) < g_sparse_tile && l < 14) l++;
+        int l = 6;
+        while ((1 << l) < g_sparse_tile && l < 11) l++;
         return l;
     }
-    int l = 11;  // 2048 rows = 8 KB of accumulators: 13 waves per CU next to the ranking buffer
-    while (l < 14 && ((int64_t)512 << l) < N) l++;
+    int l = 9;  // 512 rows per tile, 4096 per group: 16 KB of accumulators + 4 KB of stamps, 6 waves per CU with KP = 256
+    while (l < 11 && ((int64_t)512 << l) < N) l++;  // at most ~512 tiles per posting list
     return l;
 }
 
@@ -151,7 +151,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.stat = h->stat.p;
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
-    const size_t lds = (size_t)2 * kp * 8 + ((size_t)4 << h->logT);
+    const size_t lds = (size_t)2 * kp * 8 + ((size_t)5 * sparse::kStripes << h->logT);  // ranking buffer, accumulators, stamps
     const int tok = h->prof.begin(0, h->stream);
     switch (kp) {
         case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;

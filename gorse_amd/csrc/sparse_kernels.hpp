@@ -10,15 +10,21 @@
 //   group, the row with scratch id sid belongs to stripe sid % 8 of its group, and tile 8g + s holds stripe s of group g
 //   (interleaving spreads the popular rows evenly over the 8 tiles of a group).  The posting list of every index is stored
 //   sorted by tile, with a directory off[index][tile] of where each tile's segment starts.
-// * One wave answers one query, one tile at a time, with the tile's T accumulators in LDS: it walks the query's indices in
-//   ascending order and, for each, streams that index's segment of the tile (8 bytes per posting, coalesced) into the
-//   accumulators with ds_add_f32.  A row occurs at most once per posting list, so the lanes of one instruction never
-//   collide, and the LDS executes one wave's instructions in issue order: every accumulator receives its products in
-//   ascending index order -- the float32 merge-order sparse dot of the oracle, bit for bit -- without a single wait in the
-//   loop (the adds return nothing).  A tile's results are read back either by a linear scan of its accumulators (dense
-//   tiles) or by walking the same segments again with ds_wrxchg (sparse tiles); both leave the accumulators zero.
-// * Queries with many entries are split over the 8 stripes (8 work items, one per stripe, each ranking its own tiles);
-//   sparse_merge_kernel joins the 8 partial rankings.  Work items are drawn longest first from one counter.
+// * One wave answers one query, one row GROUP at a time (the 8 tiles of a group are adjacent in every posting list), with
+//   the group's 8T accumulators in LDS: it walks the query's indices in ascending order and, for each, streams that index's
+//   segment of the group (8 bytes per posting, coalesced) into the accumulators with ds_add_f32.  A row occurs at most once
+//   per posting list, so the lanes of one instruction never collide, and the LDS executes one wave's instructions in issue
+//   order: every accumulator receives its products in ascending index order -- the float32 merge-order sparse dot of the
+//   oracle, bit for bit -- without a single wait in the loop (the adds return nothing).  A group's results are read back
+//   either by a linear scan of its accumulators (dense groups) or by walking the same segments again with ds_wrxchg
+//   (sparse groups); both leave the accumulators zero.
+// * Outside the first groups a segment holds a posting or two, and one list per instruction would leave 60 lanes idle.
+//   There 64 lists go at once: every lane gathers the (at most 8) postings of ITS list's segment, the lanes stamp their
+//   rows in a byte-per-row tag array and read the stamps back -- a foreign stamp means two lists share a row and the order
+//   of their products matters, and only then the chunk falls back to one list at a time; otherwise all products are added
+//   by one ds_add_f32 per round.
+// * Queries with many entries are split over the 8 stripes (8 work items, one per stripe, each ranking its own tiles with T
+//   accumulators); sparse_merge_kernel joins the 8 partial rankings.  Work items are drawn longest first from one counter.
 //
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
 // well-defined answer whatever order the lanes append in.  Keys above the running threshold go to an LDS buffer of
@@ -39,19 +45,17 @@ constexpr int kStripes = 8;   // tiles per row group = parts of a split query
 constexpr int kLogStripes = 3;
 
 struct Posting {
-    int32_t loc;  // accumulator of the row inside its tile
+    int32_t loc;  // the row inside its group (scratch id mod 8T); a stripe's work item uses loc >> 3
     float val;
 };
+constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
 
 // scratch id <-> (tile, accumulator)
 __host__ __device__ inline int32_t tile_of(int64_t sid, int logT) {
     return (int32_t)((sid >> (logT + kLogStripes)) << kLogStripes) + (int32_t)(sid & (kStripes - 1));
 }
 __host__ __device__ inline int32_t loc_of(int64_t sid, int logT) {
-    return (int32_t)((sid & (((int64_t)1 << (logT + kLogStripes)) - 1)) >> kLogStripes);
-}
-__host__ __device__ inline int64_t sid_of(int32_t tile, int32_t loc, int logT) {
-    return ((int64_t)(tile >> kLogStripes) << (logT + kLogStripes)) + ((int64_t)loc << kLogStripes) + (tile & (kStripes - 1));
+    return (int32_t)(sid & (((int64_t)1 << (logT + kLogStripes)) - 1));
 }
 
 struct Work {
@@ -142,6 +146,10 @@ __device__ inline long long wave_sum(long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ inline uint32_t wave_sum_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
 
 // The wave's ranking buffer: lanes with want hand their key in; bcnt (slots in use) and thr (keys <= thr cannot be among the
 // k best) are wave-uniform.  After an overflow the KP best keys stay, sorted.
@@ -206,16 +214,50 @@ __device__ inline float acc_take(float *acc, int32_t loc) {
     return __hip_atomic_exchange(&acc[loc], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// One chunk (up to 64 of the query's indices, one per lane, ascending with the lane) against one tile: lane holds the
-// segment [s, e) of its index in this tile and the query's value qv.  COLLECT = false: accumulate; true: take the
-// accumulators of the segments' rows back (each row is handed to `consider` by the first posting that reaches it).
-// Returns the number of postings walked.  The first 64 postings of the NEXT segment are loaded before the current one is
-// applied (the compiler keeps loads behind the LDS atomics of the program order, so the overlap is spelled out).
+// One chunk (up to 64 of the query's indices, one per lane, ascending with the lane) against one group (shift 0) or one
+// stripe tile of it (shift 3): lane holds the segment [s, e) of its index there and the query's value qv; a posting's
+// accumulator is loc >> shift.  COLLECT = false: accumulate; true: take the accumulators of the segments' rows back (each
+// row is handed to `consider` by the first posting that reaches it).  Returns the number of postings walked.
 template <bool COLLECT, bool ATOMIC, typename F>
-__device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *acc, uint32_t s, uint32_t e, float qv, int lane,
-                                      F &&consider) {
-    unsigned long long m = __ballot(e > s);
+__device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *acc, volatile uint8_t *tag, int shift, uint32_t s,
+                                      uint32_t e, float qv, int lane, F &&consider) {
+    const uint32_t len = e - s;
+    unsigned long long m = __ballot(len > 0);
     if (!m) return 0;
+    if (!__ballot(len > (uint32_t)kGather)) {
+        // ---- 64 lists at once: lane-private gathers, rows stamped, one add per round unless two lists share a row ----
+        Posting P[kGather];
+#pragma unroll
+        for (int j = 0; j < kGather; j++) {
+            P[j] = Posting{0, 0.0f};
+            if ((uint32_t)j < len) P[j] = post[s + j];
+        }
+        bool clash = false;
+        if (!COLLECT) {
+#pragma unroll
+            for (int j = 0; j < kGather; j++)
+                if ((uint32_t)j < len) tag[P[j].loc >> shift] = (uint8_t)lane;
+#pragma unroll
+            for (int j = 0; j < kGather; j++)
+                if ((uint32_t)j < len) clash = clash || tag[P[j].loc >> shift] != (uint8_t)lane;
+        }
+        if (!__ballot(clash)) {
+#pragma unroll
+            for (int j = 0; j < kGather; j++) {
+                if (!__ballot((uint32_t)j < len)) break;
+                const bool have = (uint32_t)j < len;
+                if (COLLECT) {
+                    const float x = have ? acc_take(acc, P[j].loc >> shift) : 0.0f;
+                    consider(have, P[j].loc >> shift, x);
+                } else if (have) {
+                    acc_add<ATOMIC>(acc, P[j].loc >> shift, __fmul_rn(qv, P[j].val));
+                }
+            }
+            return wave_sum_u32(len);
+        }
+    }
+    // ---- one list at a time, its postings over the lanes; the first 64 postings of the NEXT segment are loaded before the
+    // current one is applied (the compiler keeps loads behind the LDS atomics of the program order) ----
     uint32_t walked = 0;
     int l = __ffsll((long long)m) - 1;
     m &= m - 1;
@@ -236,10 +278,10 @@ __device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *a
         }
         if (COLLECT) {
             const bool have = sl + lane < el;
-            const float x = have ? acc_take(acc, P.loc) : 0.0f;
-            consider(have, P.loc, x);
+            const float x = have ? acc_take(acc, P.loc >> shift) : 0.0f;
+            consider(have, P.loc >> shift, x);
         } else if (sl + lane < el) {
-            acc_add<ATOMIC>(acc, P.loc, __fmul_rn(ql, P.val));
+            acc_add<ATOMIC>(acc, P.loc >> shift, __fmul_rn(ql, P.val));
         }
         for (uint32_t p = sl + kBlock; p < el; p += 4 * kBlock) {  // long segments: four loads in flight
             Posting x[4];
@@ -255,11 +297,11 @@ __device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *a
             for (int j = 0; j < 4; j++) {
                 if (COLLECT) {
                     if (p + j * kBlock < el) {  // uniform
-                        const float v = have[j] ? acc_take(acc, x[j].loc) : 0.0f;
-                        consider(have[j], x[j].loc, v);
+                        const float v = have[j] ? acc_take(acc, x[j].loc >> shift) : 0.0f;
+                        consider(have[j], x[j].loc >> shift, v);
                     }
                 } else if (have[j]) {
-                    acc_add<ATOMIC>(acc, x[j].loc, __fmul_rn(ql, x[j].val));
+                    acc_add<ATOMIC>(acc, x[j].loc >> shift, __fmul_rn(ql, x[j].val));
                 }
             }
         }
@@ -274,12 +316,14 @@ template <int KP, bool ATOMIC>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
     extern __shared__ __align__(16) unsigned char s_mem[];
-    const int T = 1 << a.logT;
+    const int G = kStripes << a.logT;  // rows per group
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(s_mem);
     float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
+    volatile uint8_t *tag = s_mem + (size_t)CAP * 8 + (size_t)G * 4;
     const int lane = threadIdx.x;
-    for (int i = lane; i < T; i += kBlock) acc[i] = 0.0f;
+    for (int i = lane; i < G; i += kBlock) acc[i] = 0.0f;
     __syncthreads();
+    const int ngroups = a.ntiles >> kLogStripes;
     for (;;) {
         int w = 0;
         if (lane == 0) w = atomicAdd(a.next, 1);
@@ -296,8 +340,12 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         unsigned long long thr = 0;
         long long my_pos = 0, my_neg = 0, my_hit = 0;
         unsigned long long walked_q = 0;
-        const int first = wk.stripe < 0 ? 0 : wk.stripe, step = wk.stripe < 0 ? 1 : kStripes;
-        // queries of at most 64 entries keep (directory entry, value) in registers for all tiles
+        // the whole query (stripe < 0): one group = 8 adjacent tiles at a time, 8T accumulators; one stripe of a split
+        // query: tile 8g + stripe of every group, T accumulators (accumulator = loc >> 3)
+        const int shift = wk.stripe < 0 ? 0 : kLogStripes;
+        const int first = wk.stripe < 0 ? 0 : wk.stripe, width = wk.stripe < 0 ? kStripes : 1;
+        const int nacc = G >> shift;
+        // queries of at most 64 entries keep (directory entry, value) in registers for all groups
         const bool small = L <= kBlock;
         int32_t cid0 = -1;
         float qv0 = 0.0f;
@@ -305,11 +353,13 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             cid0 = a.q_cid[qs + lane];
             qv0 = a.q_val[qs + lane];
         }
-        for (int tile = first; tile < a.ntiles; tile += step) {
-            auto consider = [&](bool have, int32_t loc, float x) {
+        for (int g = 0; g < ngroups; g++) {
+            const int tile = g * kStripes + first;
+            const int64_t sid0 = (int64_t)g * G + (wk.stripe < 0 ? 0 : wk.stripe);
+            auto consider = [&](bool have, int32_t i, float x) {
                 have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
                 if (!__ballot(have)) return;
-                const int64_t sid = sid_of(tile, loc, a.logT);
+                const int64_t sid = sid0 + ((int64_t)i << shift);
                 my_hit += have;
                 have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
                 const uint32_t ord = score_ord(x);
@@ -321,54 +371,50 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
             };
             auto nothing = [](bool, int32_t, float) {};
+            auto segment = [&](int32_t cid, uint32_t &s, uint32_t &e) {
+                s = 0, e = 0;
+                if (cid >= 0) {
+                    const uint32_t *o = a.off + (size_t)cid * a.ntiles + tile;
+                    s = o[0], e = o[width];
+                }
+            };
             uint32_t walked = 0;
             if (small) {
-                uint32_t s = 0, e = 0;
-                if (cid0 >= 0) {
-                    const uint32_t *o = a.off + (size_t)cid0 * a.ntiles + tile;
-                    s = o[0], e = o[1];
-                }
-                walked = walk_chunk<false, ATOMIC>(a.post, acc, s, e, qv0, lane, nothing);
+                uint32_t s, e;
+                segment(cid0, s, e);
+                walked = walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, nothing);
                 if (walked == 0) continue;
-                if ((int64_t)walked * 4 < T) {
-                    walk_chunk<true, ATOMIC>(a.post, acc, s, e, qv0, lane, consider);
+                if ((int64_t)walked * 4 < nacc) {
+                    walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, consider);
                     walked_q += walked;
                     continue;
                 }
             } else {
                 for (int64_t c = 0; c < L; c += kBlock) {
-                    uint32_t s = 0, e = 0;
+                    uint32_t s, e;
                     float qv = 0.0f;
+                    int32_t cid = -1;
                     if (c + lane < L) {
-                        const int32_t cid = a.q_cid[qs + c + lane];
+                        cid = a.q_cid[qs + c + lane];
                         qv = a.q_val[qs + c + lane];
-                        if (cid >= 0) {
-                            const uint32_t *o = a.off + (size_t)cid * a.ntiles + tile;
-                            s = o[0], e = o[1];
-                        }
                     }
-                    walked += walk_chunk<false, ATOMIC>(a.post, acc, s, e, qv, lane, nothing);
+                    segment(cid, s, e);
+                    walked += walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv, lane, nothing);
                 }
                 if (walked == 0) continue;
-                if ((int64_t)walked * 4 < T) {
+                if ((int64_t)walked * 4 < nacc) {
                     for (int64_t c = 0; c < L; c += kBlock) {
-                        uint32_t s = 0, e = 0;
-                        if (c + lane < L) {
-                            const int32_t cid = a.q_cid[qs + c + lane];
-                            if (cid >= 0) {
-                                const uint32_t *o = a.off + (size_t)cid * a.ntiles + tile;
-                                s = o[0], e = o[1];
-                            }
-                        }
-                        walk_chunk<true, ATOMIC>(a.post, acc, s, e, 0.0f, lane, consider);
+                        uint32_t s, e;
+                        segment(c + lane < L ? a.q_cid[qs + c + lane] : -1, s, e);
+                        walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, 0.0f, lane, consider);
                     }
                     walked_q += walked;
                     continue;
                 }
             }
             walked_q += walked;
-            // dense tile: every accumulator is looked at once
-            for (int i = lane; i < T; i += kBlock) {
+            // dense: every accumulator is looked at once
+            for (int i = lane; i < nacc; i += kBlock) {
                 const float x = acc[i];
                 if (__float_as_uint(x) != 0) acc[i] = 0.0f;
                 consider(true, i, x);

@@ -46,8 +46,8 @@ int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/
 /* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
-/* rows per accumulator tile of a handle created AFTERWARDS: a power of two in 256 .. 16384; 0 = chosen from N (2048 up to
- * one million rows).  A tile costs 4 bytes of LDS per row. */
+/* rows per tile of a handle created AFTERWARDS: a power of two in 64 .. 2048; 0 = chosen from N (512 up to 256K rows).
+ * A workgroup holds the accumulators of a row group = 8 tiles: 40 bytes of LDS per tile row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);
 /* queries with more than `entries` entries are answered by eight work items (one per row stripe) and a merge instead of one
  * (default 2048; <= 0 = never): lets small test inputs take that path. */

@@ -51,7 +51,7 @@ def main():
         u2u = synth.idf_vectors(data.uptr, data.uidx, data.I)   # user -> items, items' IDF
         run(name + " users item-to-item", *i2i)
         run(name + " items user-to-user", *u2u)
-        for tile in (512, 1024, 4096):
+        for tile in (128, 256, 1024):
             run(name + " users item-to-item", *i2i, tile=tile)
         for split in (0, 256, 8192):
             run(name + " users item-to-item", *i2i, split=split)

@@ -150,8 +150,8 @@ def test_long_queries_are_split_over_the_row_stripes(oracle, k, hooks):
     n_long = int((np.diff(ptr) > 6).sum())
     assert n_long > 100 and n_long < 8000
     mask = (rng.random(9000) < 0.8).astype(np.uint8)
-    hooks.gorse_hip_test_set_sparse_tile(256)
-    s = capi.Sparse(ptr, idx, val)  # 9000 rows = 5 groups of 8 tiles
+    hooks.gorse_hip_test_set_sparse_tile(64)
+    s = capi.Sparse(ptr, idx, val)  # 9000 rows = 18 groups of 8 tiles
     hooks.gorse_hip_test_set_sparse_split(6)
     sample = list(range(0, 9000, 23))
     got = s.all_pairs(k)
@@ -174,7 +174,7 @@ def test_both_accumulation_forms(oracle, atomic, hooks):
     rng = np.random.default_rng(5 + atomic)
     ptr, idx, val = random_csr(rng, 20000, 300, 1, 40, neg=True, zipf=True)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
-    hooks.gorse_hip_test_set_sparse_tile(512)
+    hooks.gorse_hip_test_set_sparse_tile(128)
     s = capi.Sparse(ptr, idx, val)
     sample = list(range(0, 20000, 397))
     got = s.all_pairs(50)
@@ -203,7 +203,7 @@ def test_random_configurations(oracle, hooks):
         rows, dims = int(rng.integers(1, 400 if case % 3 else 3000)), int(rng.integers(1, 120))
         hi = int(rng.integers(0, min(dims, 30) + 1))
         ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
-        hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 256, 512, 4096])))
+        hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 64, 128, 2048])))
         hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 2048])))
         hooks.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
         hooks.gorse_hip_test_set_sparse_atomic(int(rng.choice([-1, 0, 1])))
