@@ -421,8 +421,8 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
     mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx, device=local)
     P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.1, seed=1)
     mf.set_factors(P0, Q0)
-    eng = gdist.HipAlsEngine(mf, rank, world)
     comm, comm_label = make_comm(args, world, rank, local)
+    eng = gdist.HipAlsEngine(mf, rank, world, staging=not isinstance(comm, gdist.LibComm))
     for _ in range(max(warmup, 1)):
         gdist.run_als_epoch(eng, comm, w, reg)
     mf.synchronize()

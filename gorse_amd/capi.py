@@ -91,6 +91,7 @@ SIGNATURES = {
     "gorse_hip_test_set_topk_path": (None, [C.c_int32]),
     "gorse_hip_test_set_topk_variant": (None, [C.c_int32]),
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
+    "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
@@ -328,6 +329,11 @@ class TopK:
         dist = np.empty((nq, k), np.float32) if fetch else None
         check(lib().gorse_topk_all_pairs(self.h, q_begin, q_end, k, _p(idx, _i32p), _p(dist, _f32p)))
         return idx, dist
+
+    def resweeps(self):
+        n = C.c_int64(0)
+        check(lib().gorse_hip_test_topk_resweeps(self.h, C.byref(n)))
+        return n.value
 
     def synchronize(self):
         check(lib().gorse_topk_synchronize(self.h))

@@ -232,29 +232,48 @@ __device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *a
             P[j] = Posting{0, 0.0f};
             if ((uint32_t)j < len) P[j] = post[s + j];
         }
-        bool clash = false;
-        if (!COLLECT) {
-#pragma unroll
-            for (int j = 0; j < kGather; j++)
-                if ((uint32_t)j < len) tag[P[j].loc >> shift] = (uint8_t)lane;
-#pragma unroll
-            for (int j = 0; j < kGather; j++)
-                if ((uint32_t)j < len) clash = clash || tag[P[j].loc >> shift] != (uint8_t)lane;
-        }
-        if (!__ballot(clash)) {
+        if (COLLECT) {
 #pragma unroll
             for (int j = 0; j < kGather; j++) {
                 if (!__ballot((uint32_t)j < len)) break;
                 const bool have = (uint32_t)j < len;
-                if (COLLECT) {
-                    const float x = have ? acc_take(acc, P[j].loc >> shift) : 0.0f;
-                    consider(have, P[j].loc >> shift, x);
-                } else if (have) {
-                    acc_add<ATOMIC>(acc, P[j].loc >> shift, __fmul_rn(qv, P[j].val));
-                }
+                const float x = have ? acc_take(acc, P[j].loc >> shift) : 0.0f;  // two lists on one row: the first taker gets it
+                consider(have, P[j].loc >> shift, x);
             }
             return wave_sum_u32(len);
         }
+        // Rounds.  Every pending lane stamps the rows of its list with its lane number and reads the stamps back; a lane that
+        // finds a foreign stamp shares a row with another pending list (it "lost" that row).  Let lim be the lowest loser:
+        // every pending lane below it won all its rows, and whoever else holds one of those rows is a loser ABOVE lim, i.e. a
+        // later list -- so the lanes below lim are applied together (their rows are distinct among themselves), then lane
+        // lim alone (all earlier lists are in), and the lanes above lim go round again.  Without sharing: one round.
+        bool pending = len > 0;
+        for (;;) {
+#pragma unroll
+            for (int j = 0; j < kGather; j++)
+                if (pending && (uint32_t)j < len) tag[P[j].loc >> shift] = (uint8_t)lane;
+            bool lost = false;
+#pragma unroll
+            for (int j = 0; j < kGather; j++)
+                if (pending && (uint32_t)j < len) lost = lost || tag[P[j].loc >> shift] != (uint8_t)lane;
+            const unsigned long long ml = __ballot(lost);
+            const int lim = ml ? __ffsll((long long)ml) - 1 : 64;
+            const bool go = pending && lane < lim;
+#pragma unroll
+            for (int j = 0; j < kGather; j++) {
+                if (!__ballot(go && (uint32_t)j < len)) break;
+                if (go && (uint32_t)j < len) acc_add<ATOMIC>(acc, P[j].loc >> shift, __fmul_rn(qv, P[j].val));
+            }
+            if (!ml) break;
+#pragma unroll
+            for (int j = 0; j < kGather; j++) {
+                if (!__ballot(lane == lim && (uint32_t)j < len)) break;
+                if (lane == lim && (uint32_t)j < len) acc_add<ATOMIC>(acc, P[j].loc >> shift, __fmul_rn(qv, P[j].val));
+            }
+            pending = pending && lane > lim;
+            if (!__ballot(pending)) break;
+        }
+        return wave_sum_u32(len);
     }
     // ---- one list at a time, its postings over the lanes; the first 64 postings of the NEXT segment are loaded before the
     // current one is applied (the compiler keeps loads behind the LDS atomics of the program order) ----

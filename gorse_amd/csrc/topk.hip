@@ -352,6 +352,13 @@ extern "C" int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int
     return GORSE_OK;
 }
 
+// probe: queries of the last search whose warm-started threshold could not be verified and that were swept again
+extern "C" int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n) {
+    if (!h || !n) return fail(GORSE_ERR_INVALID, "NULL argument");
+    *n = h->n_resweep;
+    return GORSE_OK;
+}
+
 // test hook: 0 = automatic path choice, 1 = path A only (literal scan), 2 = path B whenever its operands exist
 extern "C" void gorse_hip_test_set_topk_path(int32_t path) { gorse::g_topk_force_path = path; }
 extern "C" void gorse_hip_test_set_topk_variant(int32_t v) { gorse::g_topk_variant = v; }

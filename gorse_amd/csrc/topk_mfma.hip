@@ -83,6 +83,12 @@ struct SweepParams {
     int coarse;            // cosine: reject a 32-row block on max(raw score) x (block's extreme row scale) first
     int bias;              // Euclidean: the per-candidate value (-|x|^2 / 2) is ADDED to the score instead of multiplied
     unsigned long long *prof;  // PROF instantiations: 8 cycle / event counters summed over all waves
+    // warm start (see topk_mfma_search): a PILOT sweep walks every tile_stride-th tile with kth = a small j and writes the
+    // threshold it ends with to f_out; the main sweep starts from f0 and verifies it (compact_query: a threshold that a later
+    // K-th-best bound does not reach flags the query 2 = "sweep again from -inf")
+    const float *f0;   // nq initial thresholds or null (-inf)
+    float *f_out;      // pilot: nq final thresholds; null otherwise
+    int tile_stride;   // 1, or the pilot's sampling stride over the row tiles
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
@@ -124,6 +130,18 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
             if (c >= kth) prefix = trial;
         }
         newf = fkey_inv(prefix) - s_mg[ql];
+    }
+    if (newf < s_f[ql]) {
+        // Only a warm-started threshold can be above what the list proves (thresholds derived from the list never fall):
+        // the K-th best of everything above it is not known to clear it by the margin, so rows may have been dropped
+        // wrongly.  The query is swept again from -inf by the host (flag 2).
+        if (lane == 0) {
+            s_f[ql] = __builtin_inff();
+            s_cnt[2 * ql] = 0;  // the list is dropped: nothing of it triggers another compaction
+            s_cnt[2 * ql + 1] = 0;
+            *flag = 2;
+        }
+        return;
     }
     int base = 0;
     int hbase = HIST ? s_hc[ql] : 0;
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         s_cnt[2 * t] = 0;
         s_cnt[2 * t + 1] = 0;
         s_hc[t] = 0;
-        s_f[t] = q < p.nq ? -__builtin_inff() : __builtin_inff();
+        s_f[t] = q < p.nq ? (p.f0 ? p.f0[q] : -__builtin_inff()) : __builtin_inff();
         s_mg[t] = q < p.nq ? p.qmargin[q] : 0.0f;
     }
     // query operands: resident in registers for the whole sweep
@@ -213,8 +231,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
 
     uint4 pre[CPT];
     float pre_rs = 0.0f;
+    const int64_t stride_rows = (int64_t)p.tile_stride * kTR;  // the pilot samples every tile_stride-th tile
     auto load_tile = [&](int64_t t) {
-        const int64_t base_row = t * kTR;
+        const int64_t base_row = t * stride_rows;
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
             const int ch = tid + c * kThreads;
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         }
     };
 
-    const int64_t NT = (p.N + kTR - 1) / kTR;
+    const int64_t NT = (p.N + stride_rows - 1) / stride_rows;
     load_tile(0);
     store_tile(0);
     if (NT > 1) load_tile(1);
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
             ts = now;
         }
         const unsigned char *tb = s_tile + (size_t)buf * kTR * ROWB;
-        const int64_t base_row = t * kTR;
+        const int64_t base_row = t * stride_rows;
         const int valid = (int)std::min<int64_t>(kTR, p.N - base_row);
 #pragma unroll
         for (int rb = 0; rb < RB; rb++) {
@@ -431,12 +450,16 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         const int ql = w * QW + l;
         const int64_t qg = wgq0 + ql;
         if (qg >= p.nq) break;
-        if (s_f[ql] == __builtin_inff()) continue;  // flagged
+        if (s_f[ql] == __builtin_inff()) {  // flagged
+            if (p.f_out && lane == 0) p.f_out[qg] = -__builtin_inff();
+            continue;
+        }
         compact_query<HIST>(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg,
                             HIST ? p.hbuf + qg * kHistCap : nullptr, s_hc);
         if (lane == 0) {
             p.ccnt[qg] = s_cnt[2 * ql] + s_cnt[2 * ql + 1];  // packed by the final compaction: slots 0 .. count-1
             if (HIST) p.hcnt[qg] = s_hc[ql];
+            if (p.f_out) p.f_out[qg] = s_f[ql] == __builtin_inff() ? -__builtin_inff() : s_f[ql];
         }
     }
 }
@@ -893,6 +916,19 @@ __global__ void gather_pos_kernel(const uint16_t *__restrict__ op, const float *
     if (threadIdx.x == 0) margin_out[t] = margin[src];
 }
 
+// lists of the re-swept queries back to their places: list t of (src, src_cnt, src_flag) -> query pos[t] of the chunk
+__global__ void scatter_lists_kernel(const int32_t *__restrict__ pos, const uint2 *__restrict__ src, const int32_t *__restrict__ src_cnt,
+                                     const uint8_t *__restrict__ src_flag, uint2 *__restrict__ dst, int32_t *__restrict__ dst_cnt,
+                                     uint8_t *__restrict__ dst_flag) {
+    const int64_t t = blockIdx.x, q = pos[t];
+    const int n = src_flag[t] ? 0 : src_cnt[t];
+    for (int e = threadIdx.x; e < n; e += blockDim.x) dst[q * kCap + e] = src[t * kCap + e];
+    if (threadIdx.x == 0) {
+        dst_cnt[q] = n;
+        dst_flag[q] = src_flag[t];
+    }
+}
+
 // ---- operand construction ------------------------------------------------------------------------------
 __device__ __forceinline__ uint16_t bf16_rne(float x) {
     uint32_t b = __float_as_uint(x);
@@ -1150,6 +1186,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     if (qid_host) GORSE_TRY(h->qid.ensure((size_t)mb));
     h->n_fallback = 0;
     h->n_tie = 0;
+    h->n_resweep = 0;
     std::vector<uint8_t> flags((size_t)mb);
     for (int64_t c0 = 0; c0 < nq; c0 += kChunkQ) {
         const int64_t m = std::min(kChunkQ, nq - c0);
@@ -1207,8 +1244,59 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.N = h->N;
         sp.nq = m;
         sp.kth = kth;
+        sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1;
+        // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
+        // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
+        // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
+        // among the true kth - 1 best, that score is below the kth best of ALL rows unless X >= j -- j is chosen for a
+        // tail of ~1e-3 -- and about 16 j rows lie above it.  The main sweep starts there and VERIFIES it (compact_query
+        // flags a query whose K-th-best bound does not reach its threshold); those few queries are swept again from -inf.
+        const int pilot_stride = 16;
+        // probe / test switches: bit 8 = no warm start, bit 9 = warm start whatever N, bit 10 = a pilot kth of 2 (thresholds
+        // far too high: most queries fail the verification and are swept again)
+        const bool warm = !(g_topk_variant & 256) && kth >= 8 && (h->N >= (int64_t)1 << 17 || (g_topk_variant & 512));
         int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
+        if (warm) {
+            const double lam = (double)(kth - 1) / pilot_stride;
+            GORSE_TRY(h->f0.ensure((size_t)mb));
+            SweepParams pp = sp;
+            pp.kth = (g_topk_variant & 1024) ? 2 : (int)std::ceil(lam + 3.3 * std::sqrt(lam) + 1.5);
+            pp.tile_stride = pilot_stride;
+            pp.f_out = h->f0.p;
+            GORSE_TRY(dispatch_sweep(h, pp, scale, false));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot list that overflowed says nothing
+            sp.f0 = h->f0.p;
+        }
         GORSE_TRY(dispatch_sweep(h, sp, scale, false));
+        if (warm) {  // the queries whose warm start could not be verified: gathered, swept from -inf, lists put back
+            GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+            std::vector<int32_t> redo;
+            for (int64_t t = 0; t < m; t++)
+                if (flags[t] == 2) redo.push_back((int32_t)t);
+            h->n_resweep += (int64_t)redo.size();
+            for (size_t r0 = 0; r0 < redo.size(); r0 += (size_t)kReplayChunk) {
+                const int64_t m2 = std::min<int64_t>(kReplayChunk, (int64_t)(redo.size() - r0));
+                GORSE_TRY(h->rp_pos.ensure((size_t)m2));
+                GORSE_TRY(h->rp_op.ensure((size_t)m2 * kpad));
+                GORSE_TRY(h->rp_margin.ensure((size_t)m2));
+                GORSE_TRY(h->rp_cbuf.ensure((size_t)m2 * kCap));
+                GORSE_TRY(h->rp_ccnt.ensure((size_t)m2));
+                GORSE_TRY(h->rp_flag.ensure((size_t)m2));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_pos.p, redo.data() + r0, (size_t)m2 * 4, hipMemcpyHostToDevice, h->stream));
+                gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, h->rp_pos.p, kpad,
+                                                                                 h->rp_op.p, h->rp_margin.p);
+                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, (size_t)m2, h->stream));
+                SweepParams rp2 = sp;
+                rp2.B = h->rp_op.p, rp2.qmargin = h->rp_margin.p, rp2.cbuf = h->rp_cbuf.p, rp2.ccnt = h->rp_ccnt.p;
+                rp2.cflag = h->rp_flag.p, rp2.f0 = nullptr, rp2.nq = m2;
+                GORSE_TRY(dispatch_sweep(h, rp2, scale, false));
+                scatter_lists_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(h->rp_pos.p, h->rp_cbuf.p, h->rp_ccnt.p, h->rp_flag.p,
+                                                                                    h->cbuf.p, h->ccnt.p, h->cflag.p);
+                GORSE_HIP_CHECK(hipGetLastError());
+                GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // `redo` is read by the upload until here
+            }
+        }
         h->prof.end(tok, h->stream);
         RescoreParams rp;
         rp.X = h->X.p;
@@ -1273,6 +1361,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 GORSE_HIP_CHECK(hipMemsetAsync(h->rp_hcnt.p, 0, (size_t)m2 * 4, h->stream));
                 GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, (size_t)m2 * 4, h->stream));
                 SweepParams hp = sp;
+                hp.f0 = nullptr;  // the history sweep records what a threshold that starts at -inf would have kept
                 hp.B = h->rp_op.p;
                 hp.qmargin = h->rp_margin.p;
                 hp.cbuf = h->rp_cbuf.p;

@@ -233,16 +233,20 @@ class HipEngine:
 class HipAlsEngine:
     """A gorse_mf handle restricted to this rank's row ranges + torch CUDA buffers for the all-gathers."""
 
-    def __init__(self, mf, rank, world, device="cuda"):
-        import torch
-        self.torch = torch
+    def __init__(self, mf, rank, world, device="cuda", staging=True):
+        """staging = False: no torch buffers (the exchange runs inside the library: LibComm / gorse_mf_rows_allgather)"""
+        self.torch = None
         self.device = device
         self.mf, self.rank, self.world = mf, rank, world
         self.rows = (mf.U, mf.I)
         self.range = [shard_range(n, rank, world) for n in self.rows]
         mf.als_set_ranges(self.range[0][0], self.range[0][1], self.range[1][0], self.range[1][1])
         self.block = [block_rows(n, world) for n in self.rows]
-        self.buf = [torch.zeros(b * mf.d, dtype=torch.float32, device=device) for b in self.block] if world > 1 else None
+        self.buf = None
+        if world > 1 and staging:
+            import torch
+            self.torch = torch
+            self.buf = [torch.zeros(b * mf.d, dtype=torch.float32, device=device) for b in self.block]
 
     def half(self, side, weight, reg):
         self.mf.als_half_epoch(side, weight, reg)

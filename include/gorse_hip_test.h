@@ -37,6 +37,11 @@ void gorse_hip_test_set_topk_path(int32_t path);
  * sweep votes on each score row wave-wide before touching it (written without a GPU; to be measured).  Results never
  * depend on them. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
+/* variant bit 8 (256) switches the warm start of the sweep off (pilot sweep over every 16th row tile -> initial thresholds,
+ * verified by the main sweep; csrc/topk_mfma.hip topk_mfma_search), bit 9 (512) switches it on below its size limit of 2^17
+ * rows, bit 10 (1024) gives the pilot a kth of 2 so that most warm starts fail their verification.  This returns how many
+ * queries of the last search failed it and were swept again from -inf. */
+int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n /*out*/);
 /* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its twelve
  * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the
  * candidate paths inside [1], [3] barrier wait, then [4] row blocks examined, [5] row blocks with a candidate, [6]

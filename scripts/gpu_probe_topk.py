@@ -28,9 +28,9 @@ def run(name, X, metric, dtype, k, q0, q1, reps=2):
     pairs = (q1 - q0) * (N - 1)
     kd = d if dtype == capi.DTYPE_BF16 else 3 * d
     print("%-34s N=%8d d=%4d k=%3d nq=%8d wall %8.2f ms (%.3e pairs/s) sweep %8.2f ms (%.1f TFLOP/s on %d-deep operands) "
-          "rescore %7.2f ms (%d launches) tie-history-sweep %7.2f ms tie-replay %7.2f ms scan-launches %d scan-fallback %d tie-replayed %d create %.2f s"
+          "rescore %7.2f ms (%d launches) tie-history-sweep %7.2f ms tie-replay %7.2f ms scan-launches %d scan-fallback %d tie-replayed %d re-swept %d create %.2f s"
           % (name, N, d, k, q1 - q0, dt * 1e3, pairs / dt, sweep / reps, 2.0 * kd * (q1 - q0) * N / (sweep / reps * 1e-3) / 1e12,
-             kd, resc / reps, nr, hist / reps, repl / reps, na, t.last_stats()[0], t.last_stats()[1], t_create), flush=True)
+             kd, resc / reps, nr, hist / reps, repl / reps, na, t.last_stats()[0], t.last_stats()[1], t.resweeps(), t_create), flush=True)
     t.close()
 
 
@@ -40,6 +40,13 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "c4":  # one bounded case: a quarter of the query rows, then all of them
         run("C4 S-emb bf16 cosine 256K q", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
         run("C4 S-emb bf16 cosine", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "warm":  # the warm-started sweep against the cold one, with the re-sweep counts
+        for v, label in [(256, "cold start"), (0, "warm start"), (2, "warm start, 128-row tiles"), (2 | 256, "cold start, 128-row tiles")]:
+            capi.lib().gorse_hip_test_set_topk_variant(v)
+            run("C4 256K q: " + label, Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
+            run("C4 1M q: " + label, Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
+        capi.lib().gorse_hip_test_set_topk_variant(0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "prof":  # phase counters of the instrumented sweep twin (s_memtime ticks)
         for v, label in [(16 | 1, "64-row tiles"), (16 | 2, "128-row tiles")]:

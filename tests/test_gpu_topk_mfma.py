@@ -233,3 +233,32 @@ def test_large_index_against_the_scan():
     capi.lib().gorse_hip_test_set_topk_path(1)
     ia, da, _ = t.search_index(sample, k)
     assert np.array_equal(ia, idx[sample - q0]) and np.array_equal(bits(da), bits(dist[sample - q0]))
+
+
+WARM_OFF, WARM_ALWAYS, WARM_SABOTAGE = 256, 512, 512 | 1024
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_COSINE, capi.METRIC_NEG_DOT, capi.METRIC_EUCLIDEAN])
+@pytest.mark.parametrize("dtype,d,N,k", [(capi.DTYPE_BF16, 128, 40000, 100), (capi.DTYPE_F32, 64, 20000, 30)])
+def test_warm_started_sweep_returns_the_same_rows(oracle, metric, dtype, d, N, k):
+    """The pilot sweep (every 16th row tile, a small kth) only proposes initial thresholds; the main sweep verifies each one
+    and the host sweeps the failures again from -inf.  With the warm start forced on (it is automatic from 2^17 rows), with
+    it off, and with a pilot that proposes thresholds far too high (kth = 2: most queries must be swept again), every row
+    and every distance bit is the same -- and equal to the oracle's on a sample; rows sorted by norm make the systematic
+    sample a biased one."""
+    rng = np.random.default_rng(N + d)
+    Xf = rng.standard_normal((N, d)).astype(np.float32)
+    Xf *= np.sort(rng.uniform(0.5, 2.0, N)).astype(np.float32)[:, None]
+    Xf[100:140] = Xf[5]  # duplicates: ties in the top k of their queries
+    X = to_bf16(Xf) if dtype == capi.DTYPE_BF16 else Xf
+    Xe = from_bf16(X) if dtype == capi.DTYPE_BF16 else Xf
+    t = capi.TopK(X, metric, dtype=dtype)
+    out = {}
+    for v in (WARM_OFF, WARM_ALWAYS, WARM_SABOTAGE):
+        capi.lib().gorse_hip_test_set_topk_variant(v)
+        out[v] = t.all_pairs(k) + (t.resweeps(),)
+    assert out[WARM_OFF][2] == 0 and out[WARM_ALWAYS][2] < N // 50 and out[WARM_SABOTAGE][2] > N // 4
+    for v in (WARM_ALWAYS, WARM_SABOTAGE):
+        assert np.array_equal(out[v][0], out[WARM_OFF][0]) and np.array_equal(bits(out[v][1]), bits(out[WARM_OFF][1]))
+    qs = np.concatenate([np.arange(0, N, 1999), [5, 100, 139]])
+    check_rows(oracle, Xe, metric, qs, k, out[WARM_ALWAYS][0][qs], out[WARM_ALWAYS][1][qs])
