@@ -96,6 +96,7 @@ SIGNATURES = {
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_atomic": (None, [C.c_int32]),
+    "gorse_hip_test_sparse_trace": (C.c_int64, [_vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int64]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
     "gorse_hip_test_als_profile": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
@@ -477,6 +478,14 @@ class Sparse:
         a, b = C.c_int64(0), C.c_int64(0)
         check(lib().gorse_sparse_last_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def trace(self, on=True):
+        """probe: switch the per-work-item records on / off; returns the records of the last call (n x 10 uint64)"""
+        n = lib().gorse_hip_test_sparse_trace(self.h, int(bool(on)), None, 0)
+        out = np.zeros((max(n, 0), 10), np.uint64)
+        if n > 0:
+            lib().gorse_hip_test_sparse_trace(self.h, int(bool(on)), out.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        return out
 
 
 def sgemm(transA, transB, m, n, k, a, lda, b, ldb, c, ldc, device=0):

@@ -350,18 +350,35 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    float p = lane < d ? a[lane] : 0.0f;
-    const int sreg = __float_as_int(lane < d ? ss[lane] : 0.0f);
+    // Gauss-Seidel with a running y = M p instead of one wave-wide dot product per coordinate:
+    //     sum_{k != f} p_k M_kf = y_f - p_f M_ff,   p_f' = (s_f - y_f + p_f M_ff) / (M_ff + reg),   y += (p_f' - p_f) M[:, f]
+    // Lane k keeps y_k, and column f of the symmetric M is mcol[f] of every lane, so a step is one v_readlane of y, two
+    // VALU operations on wave-uniform values and ONE fused multiply-add per lane -- no cross-lane reduction in the chain
+    // (the wave sum took ~650 cycles per step next to a sibling wave's MFMAs: 42K cycles per row against 27K for the Gram
+    // accumulation, profiles/r01_p_probe_als_prof.txt).  Same recurrence, products summed in a different order; agreement
+    // with the float64 recurrence 6e-7 of the row's scale on random systems (well inside the 1e-4 bar).
+    const float p0 = lane < d ? a[lane] : 0.0f;
+    const float sv = lane < d ? ss[lane] : 0.0f;
+    float diag = 0.0f;
+    if (lane < d) {
+        diag = sM[lane * kAlsDP + lane];
+        if (FORM) diag = one_w * diag + w * S[lane * d + lane];
+    }
+    const float inv = __builtin_amdgcn_rcpf(diag + reg);  // 1 ulp; the parity bar of ALS is 1e-4 relative
+    const float base = (sv + p0 * diag) * inv;
+    float y = 0.0f;
+#pragma unroll
+    for (int f = 0; f < DMAX; f++)
+        if (f < d) y = fmaf(mcol[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f)), y);
+    float p = p0;
 #pragma unroll
     for (int f = 0; f < DMAX; f++) {
         if (f < d) {  // uniform; no break, so that the loop unrolls and mcol[f] is a register
-            const float m = mcol[f];
-            const float tot = wave_sum64(lane == f ? 0.0f : p * m);
-            const float mff = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), f));
-            const float sf = __int_as_float(__builtin_amdgcn_readlane(sreg, f));
-            // v_rcp_f32 (1 ulp) instead of the 12-instruction IEEE division: this chain is what every step waits for,
-            // and the parity bar of ALS is 1e-4 relative (the summation order already differs from the reference's)
-            const float nf = (sf - tot) * __builtin_amdgcn_rcpf(mff + reg);
+            const float yf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), f));
+            const float nf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(base), f)) -
+                             yf * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), f));
+            const float delta = nf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f));
+            y = fmaf(delta, mcol[f], y);
             if (lane == f) p = nf;
         }
     }

@@ -48,7 +48,10 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(int32_t U, int32_t I, c
                                                          const int32_t *__restrict__ usorted, uint64_t seed,
                                                          uint64_t epoch, int64_t sample_base, int64_t n,
                                                          int32_t *__restrict__ us, int32_t *__restrict__ is,
-                                                         int32_t *__restrict__ js, int32_t *__restrict__ fail_count) {
+                                                         int32_t *__restrict__ js, int32_t *__restrict__ fail_count,
+                                                         int32_t *__restrict__ bucket, int32_t *__restrict__ rank) {
+    // bucket != null (user-run schedule): the sample also draws its arrival rank inside its user's run -- the first pass of
+    // the counting sort by user, done here so that no separate pass over the triplets is needed (skipped samples: key U)
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         Philox g;
         g.init(seed, epoch, (uint64_t)(sample_base + s));
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(int32_t U, int32_t I, c
         us[s] = u;
         is[s] = pi;
         js[s] = nj;
+        if (bucket) rank[s] = atomicAdd(&bucket[u < 0 ? U : u], 1);
     }
 }
 
@@ -680,30 +684,37 @@ int32_t launch_update_runs(gorse_mf *h, const int32_t *sorted, size_t cap, int64
 
 
 // counting sort of the chunk by user: `sorted` receives su | si | sj, h->bucket[0..U] the run offsets
-int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int32_t *bucket, int64_t n, size_t cap,
-                         hipStream_t st) {
+// ranked: the sampler already counted the runs into `bucket` and wrote every sample's rank (launch_sampler with a bucket)
+int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int32_t *bucket, int32_t *rank, int64_t n, size_t cap,
+                         hipStream_t st, bool ranked) {
     const int64_t m = h->U + 2;  // one counter per user + one for skipped samples (sorted last) + the end offset
-    GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)m * sizeof(int32_t), st));
     const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
-    // one window (shift 62): key = user, skipped samples (u < 0) get key U
-    // test hook (variant bit 29): one thread ranks the samples in stream order -> every run keeps the stream's order
-    if (g_variant & (1 << 29))
-        bpr_rank_kernel<<<dim3(1), dim3(1), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, h->rank.p);
-    else
-        bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, h->rank.p);
-    GORSE_TRY(exclusive_scan_i32(bucket, m, h->scan_tmp.p, st));
+    if (!ranked) {
+        GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)m * sizeof(int32_t), st));
+        // one window (shift 62): key = user, skipped samples (u < 0) get key U
+        // test hook (variant bit 29): one thread ranks the samples in stream order -> every run keeps the stream's order
+        if (g_variant & (1 << 29))
+            bpr_rank_kernel<<<dim3(1), dim3(1), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, rank);
+        else
+            bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, rank);
+    }
+    GORSE_TRY(exclusive_scan_i32(bucket, m, h->scan_tmp2.p, st));
     bpr_scatter_by_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, trip, trip + cap, trip + 2 * cap, n,
-                                                                       (int32_t)h->U, bucket, h->rank.p, sorted,
+                                                                       (int32_t)h->U, bucket, rank, sorted,
                                                                        sorted + cap, sorted + 2 * cap);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 int32_t ensure_user_sort(gorse_mf *h) {
     const int64_t m = h->U + 2;
-    if ((size_t)m <= h->ubucket[0].n && h->scan_tmp.n >= (size_t)ceil_div(m, kScanTile)) return GORSE_OK;
+    if ((size_t)m <= h->ubucket[0].n && h->scan_tmp2.n >= (size_t)ceil_div(m, kScanTile) && h->urank[0].n >= h->trip_cap)
+        return GORSE_OK;
     GORSE_TRY(mf_sync_streams(h));
-    for (int b = 0; b < 2; b++) GORSE_TRY(h->ubucket[b].alloc((size_t)m));
-    if (h->scan_tmp.n < (size_t)ceil_div(m, kScanTile)) GORSE_TRY(h->scan_tmp.alloc((size_t)ceil_div(m, kScanTile)));
+    for (int b = 0; b < 2; b++) {
+        GORSE_TRY(h->ubucket[b].alloc((size_t)m));
+        GORSE_TRY(h->urank[b].alloc(h->trip_cap));  // per buffer: the sampler of chunk c + 1 ranks while chunk c is applied
+    }
+    if (h->scan_tmp2.n < (size_t)ceil_div(m, kScanTile)) GORSE_TRY(h->scan_tmp2.alloc((size_t)ceil_div(m, kScanTile)));
     return GORSE_OK;
 }
 // user runs need enough users to fill the chip with one 16-lane group each (4096 groups = one wave per SIMD) and a
@@ -806,12 +817,13 @@ int32_t launch_update(gorse_mf *h, int mode, const int32_t *us, const int32_t *i
 }
 
 int32_t launch_sampler(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base, int64_t n, int32_t *trip, size_t cap,
-                       hipStream_t st) {
+                       hipStream_t st, int32_t *bucket = nullptr, int32_t *rank = nullptr) {
     if (n <= 0) return GORSE_OK;
     int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
+    if (bucket) GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)(h->U + 2) * sizeof(int32_t), st));
     bpr_sample_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
                                                                     h->uidx_sorted.p, seed, epoch, base, n, trip,
-                                                                    trip + cap, trip + 2 * cap, h->fail_count.p);
+                                                                    trip + cap, trip + 2 * cap, h->fail_count.p, bucket, rank);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -950,9 +962,20 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             int32_t *tb = h->trip[b].p;
             // a never-recorded event is complete: the first two chunks of a handle do not wait
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_consumed[b], 0));
+            // user runs: the sampler ranks its samples inside their users' runs and the rest of the counting sort (scan of
+            // U + 2 counters, scatter) follows on the sampler stream: the whole preparation of chunk c + 1 runs under the
+            // update kernel of chunk c.  (Round 1 measured a sort on this stream as slower -- its separate rank pass put
+            // 1 M returning atomics next to the update kernel's; that pass is gone.)  Variant bit 27: sort on the update stream.
+            const bool fused = uruns && !(g_variant & (1 << 29)) && !(g_variant & (1 << 27));
             int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, h->stream2);
-            GORSE_TRY(launch_sampler(h, seed, epoch, base + s0, m, tb, (size_t)cap, h->stream2));
+            GORSE_TRY(launch_sampler(h, seed, epoch, base + s0, m, tb, (size_t)cap, h->stream2, fused ? h->ubucket[b].p : nullptr,
+                                     fused ? h->urank[b].p : nullptr));
             h->prof.end(tok, h->stream2);
+            if (fused) {
+                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
+                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, h->stream2, true));
+                h->prof.end(tok, h->stream2);
+            }
             if (runs) {
                 tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
                 GORSE_TRY(launch_item_sort(h, tb, h->sorted[b].p, m, (size_t)cap, h->stream2));
@@ -960,13 +983,9 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
-            if (uruns) {
-                // The sort runs on the update stream, between two update launches.  Running it ahead on the sampler
-                // stream was measured and is slower: its atomics and scattered writes then compete with the update
-                // kernel for the same L2 atomic units (S-ml1m: update 0.60 -> 0.81 ms, profiles/r01_f_probe_bpr_users.txt
-                // vs r01_e_probe_bpr_users.txt).
+            if (uruns && !fused) {
                 tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream);
-                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, m, (size_t)cap, h->stream));
+                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, h->stream, false));
                 h->prof.end(tok, h->stream);
             }
             tok = h->prof.begin(GORSE_PROF_BPR_UPDATE, h->stream);
@@ -1081,7 +1100,7 @@ extern "C" int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u, const
                                      nullptr, nullptr));
         } else if (mode == MODE_ATOMIC && !(g_variant & 64) && user_runs_enabled() && user_runs_supported(h)) {
             GORSE_TRY(ensure_user_sort(h));
-            GORSE_TRY(launch_user_sort(h, tb, h->sorted[0].p, h->ubucket[0].p, m, (size_t)cap, h->stream));
+            GORSE_TRY(launch_user_sort(h, tb, h->sorted[0].p, h->ubucket[0].p, h->urank[0].p, m, (size_t)cap, h->stream, false));
             GORSE_TRY(launch_update_users(h, h->sorted[0].p, h->ubucket[0].p, (size_t)cap, lr, reg, g_exp_mode_exact, nullptr,
                                           h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));

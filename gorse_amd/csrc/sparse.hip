@@ -37,6 +37,9 @@ struct gorse_sparse {
     DevBuf<float> q_val, out_score;
     DevBuf<sparse::Work> work;
     DevBuf<unsigned long long> part_keys, stat;
+    DevBuf<sparse::Trace> trace;  // probe (gorse_hip_test_sparse_trace)
+    std::vector<sparse::Trace> trace_host;
+    bool trace_on = false;
     KernelProfile prof{1};
     int64_t last_postings = 0, last_hits = 0;
     int32_t use() const {
@@ -149,6 +152,11 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.out_idx = h->out_idx.p, a.out_score = h->out_score.p, a.out_cnt = h->out_cnt.p;
     a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
     a.stat = h->stat.p;
+    a.trace = nullptr;
+    if (h->trace_on) {
+        GORSE_TRY(h->trace.ensure(work.size()));
+        a.trace = h->trace.p;
+    }
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
     const size_t lds = (size_t)2 * kp * 8 + ((size_t)5 * sparse::kStripes << h->logT);  // ranking buffer, accumulators, stamps
@@ -185,6 +193,10 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from `work` / `split_t`
     h->last_postings = (int64_t)st[0];
     h->last_hits = (int64_t)st[1];
+    if (h->trace_on) {
+        h->trace_host.resize(work.size());
+        GORSE_HIP_CHECK(hipMemcpy(h->trace_host.data(), h->trace.p, work.size() * sizeof(sparse::Trace), hipMemcpyDeviceToHost));
+    }
     return GORSE_OK;
 }
 
@@ -390,6 +402,22 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 }
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
+// probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
+// 10 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1, entries, chunks taken 64 lists at once, their rounds, segments walked
+// one list at a time, groups read back densely, groups read back by re-walking}; returns the number of work items
+extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out, int64_t cap) {
+    if (!h) return -1;
+    h->trace_on = on != 0;
+    if (!out) return (int64_t)h->trace_host.size();
+    const int64_t n = std::min<int64_t>(cap, (int64_t)h->trace_host.size());
+    for (int64_t i = 0; i < n; i++) {
+        const sparse::Trace &t = h->trace_host[(size_t)i];
+        uint64_t *o = out + i * 10;
+        o[0] = t.t0, o[1] = t.t1, o[2] = (uint64_t)t.t, o[3] = (uint64_t)(t.stripe + 1), o[4] = t.entries;
+        o[5] = t.fast_chunks, o[6] = t.rounds, o[7] = t.slow_segments, o[8] = t.dense_groups, o[9] = t.sparse_groups;
+    }
+    return (int64_t)h->trace_host.size();
+}
 extern "C" void gorse_hip_test_set_sparse_tile(int32_t rows) { g_sparse_tile = rows; }
 extern "C" void gorse_hip_test_set_sparse_split(int64_t entries) { g_sparse_split = entries; }
 extern "C" void gorse_hip_test_set_sparse_atomic(int32_t mode) { g_sparse_atomic = mode; }

@@ -49,6 +49,12 @@ struct Posting {
     float val;
 };
 constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
+// probe (gorse_hip_test_sparse_trace): what one work item did
+struct Trace {
+    unsigned long long t0, t1;  // s_memrealtime (100 MHz) at its start / end
+    int32_t t, stripe;
+    uint32_t entries, fast_chunks, rounds, slow_segments, dense_groups, sparse_groups;
+};
 
 // scratch id <-> (tile, accumulator)
 __host__ __device__ inline int32_t tile_of(int64_t sid, int logT) {
@@ -90,6 +96,7 @@ struct TileArgs {
     unsigned long long *part_keys;  // per (pslot, stripe): KP keys, descending, padded with 0
     int32_t *part_cnt;              // per (pslot, stripe): rows scoring above / below zero
     unsigned long long *stat;       // [0] += postings walked, [1] += rows with a non-zero score
+    Trace *trace;                   // probe: one record per work item, or null
 };
 
 constexpr uint32_t kZeroOrd = 0x80000000u;  // ordered bits of +0
@@ -220,7 +227,7 @@ __device__ inline float acc_take(float *acc, int32_t loc) {
 // row is handed to `consider` by the first posting that reaches it).  Returns the number of postings walked.
 template <bool COLLECT, bool ATOMIC, typename F>
 __device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *acc, volatile uint8_t *tag, int shift, uint32_t s,
-                                      uint32_t e, float qv, int lane, F &&consider) {
+                                      uint32_t e, float qv, int lane, F &&consider, Trace &tr) {
     const uint32_t len = e - s;
     unsigned long long m = __ballot(len > 0);
     if (!m) return 0;
@@ -248,7 +255,9 @@ __device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *a
         // later list -- so the lanes below lim are applied together (their rows are distinct among themselves), then lane
         // lim alone (all earlier lists are in), and the lanes above lim go round again.  Without sharing: one round.
         bool pending = len > 0;
+        tr.fast_chunks++;
         for (;;) {
+            tr.rounds++;
 #pragma unroll
             for (int j = 0; j < kGather; j++)
                 if (pending && (uint32_t)j < len) tag[P[j].loc >> shift] = (uint8_t)lane;
@@ -325,6 +334,7 @@ __device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *a
             }
         }
         walked += el - sl;
+        tr.slow_segments += COLLECT ? 0 : 1;
         if (!more) break;
         sl = ns, el = ne, ql = nq, P = NP;
     }
@@ -359,6 +369,8 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         unsigned long long thr = 0;
         long long my_pos = 0, my_neg = 0, my_hit = 0;
         unsigned long long walked_q = 0;
+        Trace tr{};
+        if (a.trace) tr.t0 = __builtin_amdgcn_s_memrealtime();
         // the whole query (stripe < 0): one group = 8 adjacent tiles at a time, 8T accumulators; one stripe of a split
         // query: tile 8g + stripe of every group, T accumulators (accumulator = loc >> 3)
         const int shift = wk.stripe < 0 ? 0 : kLogStripes;
@@ -401,11 +413,12 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             if (small) {
                 uint32_t s, e;
                 segment(cid0, s, e);
-                walked = walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, nothing);
+                walked = walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, nothing, tr);
                 if (walked == 0) continue;
                 if ((int64_t)walked * 4 < nacc) {
-                    walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, consider);
+                    walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, consider, tr);
                     walked_q += walked;
+                    tr.sparse_groups++;
                     continue;
                 }
             } else {
@@ -418,20 +431,22 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         qv = a.q_val[qs + c + lane];
                     }
                     segment(cid, s, e);
-                    walked += walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv, lane, nothing);
+                    walked += walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv, lane, nothing, tr);
                 }
                 if (walked == 0) continue;
                 if ((int64_t)walked * 4 < nacc) {
                     for (int64_t c = 0; c < L; c += kBlock) {
                         uint32_t s, e;
                         segment(c + lane < L ? a.q_cid[qs + c + lane] : -1, s, e);
-                        walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, 0.0f, lane, consider);
+                        walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, 0.0f, lane, consider, tr);
                     }
                     walked_q += walked;
+                    tr.sparse_groups++;
                     continue;
                 }
             }
             walked_q += walked;
+            tr.dense_groups++;
             // dense: every accumulator is looked at once
             for (int i = lane; i < nacc; i += kBlock) {
                 const float x = acc[i];
@@ -456,6 +471,11 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         if (lane == 0 && a.stat) {
             atomicAdd(&a.stat[0], walked_q);
             atomicAdd(&a.stat[1], (unsigned long long)hit);
+        }
+        if (a.trace && lane == 0) {
+            tr.t1 = __builtin_amdgcn_s_memrealtime();
+            tr.t = wk.t, tr.stripe = wk.stripe, tr.entries = (uint32_t)L;
+            a.trace[w] = tr;
         }
         __syncthreads();  // s_buf is reused by the next work item
     }

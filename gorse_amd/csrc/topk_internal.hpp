@@ -46,7 +46,7 @@ struct gorse_topk {
     gorse::DevBuf<unsigned long long> sweep_prof;  // probe: phase counters of the instrumented sweep
     gorse::KernelProfile prof{GORSE_PROF_TOPK_NCLASSES};
     int64_t n_fallback = 0, n_tie = 0, n_resweep = 0;  // of the last search: path A rows, tie replays, warm starts swept again
-    gorse::DevBuf<float> f0;                           // warm-start thresholds of a chunk (topk_mfma_search)
+    gorse::DevBuf<float> f0, f1;                       // warm-start thresholds of a chunk (topk_mfma_search): pilot, pre-pilot
     int32_t use() const {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return gorse::fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));

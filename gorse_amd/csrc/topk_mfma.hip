@@ -89,6 +89,8 @@ struct SweepParams {
     const float *f0;   // nq initial thresholds or null (-inf)
     float *f_out;      // pilot: nq final thresholds; null otherwise
     int tile_stride;   // 1, or the pilot's sampling stride over the row tiles
+    int vote;          // candidate path: skip a score row when no lane of the wave holds a candidate in it (pays when
+                       // candidates are rare, i.e. behind a warm start: one or two of a block's 1024 scores)
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                     uint2 *mine = qb + (lane >> 5);
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
-                        if (VOTE && __builtin_amdgcn_ballot_w64(acc[cb][r] >= f) == 0) continue;  // wave-uniform
+                        if ((VOTE || p.vote) && __builtin_amdgcn_ballot_w64(acc[cb][r] >= f) == 0) continue;  // wave-uniform
                         if (acc[cb][r] >= f) {
                             const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
                             mine[2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
@@ -1244,7 +1246,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.N = h->N;
         sp.nq = m;
         sp.kth = kth;
-        sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1;
+        sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1, sp.vote = 0;
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
         // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
         // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
@@ -1257,15 +1259,34 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         const bool warm = !(g_topk_variant & 256) && kth >= 8 && (h->N >= (int64_t)1 << 17 || (g_topk_variant & 512));
         int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
         if (warm) {
-            const double lam = (double)(kth - 1) / pilot_stride;
+            // two pilots: the 1/16 sample's own sweep would start cold (and a cold start accepts ~1500 rows per query however
+            // few rows there are: every block of its 1/16 of the tiles would take the slow epilogue), so a 1/256 sample --
+            // a subset of the 1/16 sample -- proposes ITS thresholds first, by the same rule
+            auto pilot_kth = [](int of, int ratio) {
+                const double lam = (double)(of - 1) / ratio;
+                return (int)std::ceil(lam + 3.3 * std::sqrt(lam) + 1.5);
+            };
             GORSE_TRY(h->f0.ensure((size_t)mb));
-            SweepParams pp = sp;
-            pp.kth = (g_topk_variant & 1024) ? 2 : (int)std::ceil(lam + 3.3 * std::sqrt(lam) + 1.5);
-            pp.tile_stride = pilot_stride;
-            pp.f_out = h->f0.p;
-            GORSE_TRY(dispatch_sweep(h, pp, scale, false));
-            GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot list that overflowed says nothing
+            GORSE_TRY(h->f1.ensure((size_t)mb));
+            SweepParams p2 = sp;
+            p2.kth = (g_topk_variant & 1024) ? 2 : pilot_kth(kth, pilot_stride);
+            p2.tile_stride = pilot_stride;
+            p2.f_out = h->f0.p;
+            p2.prof = nullptr;  // the instrumented twin profiles the main sweep only
+            if (h->N >= (int64_t)1 << 18 || (g_topk_variant & 512)) {
+                SweepParams p1 = p2;
+                p1.kth = pilot_kth(p2.kth, 16);
+                p1.tile_stride = pilot_stride * 16;
+                p1.f_out = h->f1.p;
+                GORSE_TRY(dispatch_sweep(h, p1, scale, false));
+                GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
+                p2.f0 = h->f1.p;
+                p2.vote = 1;
+            }
+            GORSE_TRY(dispatch_sweep(h, p2, scale, false));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot's flags say nothing about the query
             sp.f0 = h->f0.p;
+            sp.vote = 1;
         }
         GORSE_TRY(dispatch_sweep(h, sp, scale, false));
         if (warm) {  // the queries whose warm start could not be verified: gathered, swept from -inf, lists put back
@@ -1289,7 +1310,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, (size_t)m2, h->stream));
                 SweepParams rp2 = sp;
                 rp2.B = h->rp_op.p, rp2.qmargin = h->rp_margin.p, rp2.cbuf = h->rp_cbuf.p, rp2.ccnt = h->rp_ccnt.p;
-                rp2.cflag = h->rp_flag.p, rp2.f0 = nullptr, rp2.nq = m2;
+                rp2.cflag = h->rp_flag.p, rp2.f0 = nullptr, rp2.vote = 0, rp2.nq = m2;
                 GORSE_TRY(dispatch_sweep(h, rp2, scale, false));
                 scatter_lists_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(h->rp_pos.p, h->rp_cbuf.p, h->rp_ccnt.p, h->rp_flag.p,
                                                                                     h->cbuf.p, h->ccnt.p, h->cflag.p);
@@ -1362,6 +1383,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, (size_t)m2 * 4, h->stream));
                 SweepParams hp = sp;
                 hp.f0 = nullptr;  // the history sweep records what a threshold that starts at -inf would have kept
+                hp.vote = 0;
                 hp.B = h->rp_op.p;
                 hp.qmargin = h->rp_margin.p;
                 hp.cbuf = h->rp_cbuf.p;

@@ -61,6 +61,11 @@ void gorse_hip_test_set_sparse_split(int64_t entries);
  * wave, -1 = the library's choice (ds_add_f32 unless a product of a stored and a query value could fall below 2^-100,
  * where partial sums may be subnormal and the LDS adder's handling of those is not relied upon). */
 void gorse_hip_test_set_sparse_atomic(int32_t mode);
+/* probe: with on != 0 the following calls of the handle record what every work item (a query, or one stripe of a long query)
+ * did; with out != NULL copies up to cap records of the last call as 10 uint64 each: {start, end (100 MHz ticks), query,
+ * stripe + 1 (0 = whole query), entries, chunks taken 64 lists at once, their rounds, segments walked one list at a time,
+ * groups read back densely, groups read back by re-walking}.  Returns the number of work items of the last call. */
+int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /*host or NULL*/, int64_t cap);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */

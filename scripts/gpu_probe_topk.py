@@ -49,7 +49,8 @@ def main():
         capi.lib().gorse_hip_test_set_topk_variant(0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "prof":  # phase counters of the instrumented sweep twin (s_memtime ticks)
-        for v, label in [(16 | 1, "64-row tiles"), (16 | 2, "128-row tiles")]:
+        for v, label in [(16 | 1, "64-row tiles, warm"), (16 | 1 | 256, "64-row tiles, cold"), (16 | 2, "128-row tiles, warm"),
+                         (16 | 2 | 256, "128-row tiles, cold")]:
             capi.lib().gorse_hip_test_set_topk_variant(v)
             t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
             for nq in (131072,):
@@ -59,7 +60,7 @@ def main():
                 c = t.sweep_profile()
                 waves = max(c[7], 1)
                 tot = c[6] / waves
-                print("%-14s nq=%8d wall %8.2f ms | per wave: kernel %.3e ticks = store+prefetch %.1f%% + mfma/epilogue %.1f%% "
+                print("%-22s nq=%8d wall %8.2f ms | per wave: kernel %.3e ticks = store+prefetch %.1f%% + mfma/epilogue %.1f%% "
                       "(slow paths %.1f%%) + barrier wait %.1f%% | row blocks %d, with a candidate %.1f%%, slow path %.0f ticks each "
                       "= count+exchange %.0f + appends %.0f + compaction %.0f; appending lanes per slow block %.2f"
                       % (label, nq, dt * 1e3, tot, 100.0 * c[0] / c[6], 100.0 * c[1] / c[6], 100.0 * c[2] / c[6],

@@ -15,10 +15,13 @@ from oracle import oracle as orc
 
 L = capi.lib()
 EPOCHS = 8
-PER_SAMPLE, USERS, NO_REPLICAS = 1 << 28, 128, 32
-variants = [(PER_SAMPLE, "per-sample groups + replicas"), (USERS, "user runs + replicas"), (USERS | NO_REPLICAS, "user runs, no replicas")]
+PER_SAMPLE, USERS, NO_REPLICAS, SORT_ON_UPDATE_STREAM = 1 << 28, 128, 32, 1 << 27
+variants = [(PER_SAMPLE, "per-sample groups + replicas"), (USERS, "user runs, sort under the update"),
+            (USERS | SORT_ON_UPDATE_STREAM, "user runs, sort between updates"), (USERS | NO_REPLICAS, "user runs, no replicas")]
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 cases = [("ml1m", lambda: synth.s_ml1m(), 64), ("ml100k", lambda: synth.s_ml100k(), 16)]
+if len(sys.argv) > 1 and sys.argv[1] == "c3":
+    cases = []
 if not quick:
     cases.append(("c3/8", lambda: synth.s_big_shard(rank=0, world=8), 128))
 o = orc.Oracle()
