@@ -159,7 +159,8 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     }
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
-    const size_t lds = (size_t)2 * kp * 8 + ((size_t)5 * sparse::kStripes << h->logT);  // ranking buffer, accumulators, stamps
+    // ranking buffer, accumulators (4 B per group row), stamps (1 B), touched list (2 B per 4 rows)
+    const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 * sparse::kStripes << h->logT) / 2;
     const int tok = h->prof.begin(0, h->stream);
     switch (kp) {
         case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;

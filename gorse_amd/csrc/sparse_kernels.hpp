@@ -15,9 +15,11 @@
 //   segment of the group (8 bytes per posting, coalesced) into the accumulators with ds_add_f32.  A row occurs at most once
 //   per posting list, so the lanes of one instruction never collide, and the LDS executes one wave's instructions in issue
 //   order: every accumulator receives its products in ascending index order -- the float32 merge-order sparse dot of the
-//   oracle, bit for bit -- without a single wait in the loop (the adds return nothing).  A group's results are read back
-//   either by a linear scan of its accumulators (dense groups) or by walking the same segments again with ds_wrxchg
-//   (sparse groups); both leave the accumulators zero.
+//   oracle, bit for bit.  A group's results are read back either by a linear scan of its accumulators (dense groups) or
+//   from the list of rows whose accumulator was +0 before an add (sparse groups); both leave the accumulators zero.
+//   Nothing in the loop waits for memory: the (index, value) pairs, directory entries and postings of the next three
+//   visits are in flight while one is applied (an earlier version waited for each: 15 us per group and query,
+//   profiles/r02_e_probe_sparse_trace.txt).
 // * Outside the first groups a segment holds a posting or two, and one list per instruction would leave 60 lanes idle.
 //   There 64 lists go at once: every lane gathers the (at most 8) postings of ITS list's segment, the lanes stamp their
 //   rows in a byte-per-row tag array and read the stamps back -- a foreign stamp means two lists share a row and the order
@@ -206,139 +208,148 @@ __device__ inline void write_result(const unsigned long long *s_buf, int cnt, in
     if (lane == 0) out_cnt[t] = cnt;
 }
 
-// ATOMIC: ds_add_f32 (no return, no wait).  !ATOMIC: load / add / store by the same wave, for inputs whose partial sums
-// may be subnormal (the LDS adder's handling of those is not relied upon); same order, same bits, slower.
+// ATOMIC: ds_add_rtn_f32 / ds_add_f32.  !ATOMIC: load / add / store by the same wave, for inputs whose partial sums may be
+// subnormal (the LDS adder's handling of those is not relied upon); same order, same bits, slower.
+// Returns the accumulator's value BEFORE the add (exactly +0 = the row had not been reached, or its sum is back at zero).
 template <bool ATOMIC>
-__device__ inline void acc_add(float *acc, int32_t loc, float term) {
+__device__ inline float acc_add_old(float *acc, int32_t i, float term) {
+    if (ATOMIC) return __hip_atomic_fetch_add(&acc[i], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    volatile float *a = acc;
+    const float old = a[i];
+    a[i] = __fadd_rn(old, term);
+    return old;
+}
+template <bool ATOMIC>
+__device__ inline void acc_add(float *acc, int32_t i, float term) {
     if (ATOMIC) {
-        __hip_atomic_fetch_add(&acc[loc], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
         volatile float *a = acc;
-        a[loc] = __fadd_rn(a[loc], term);
+        a[i] = __fadd_rn(a[i], term);
     }
 }
-__device__ inline float acc_take(float *acc, int32_t loc) {
-    return __hip_atomic_exchange(&acc[loc], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ inline float acc_take(float *acc, int32_t i) {
+    return __hip_atomic_exchange(&acc[i], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// One chunk (up to 64 of the query's indices, one per lane, ascending with the lane) against one group (shift 0) or one
-// stripe tile of it (shift 3): lane holds the segment [s, e) of its index there and the query's value qv; a posting's
-// accumulator is loc >> shift.  COLLECT = false: accumulate; true: take the accumulators of the segments' rows back (each
-// row is handed to `consider` by the first posting that reaches it).  Returns the number of postings walked.
-template <bool COLLECT, bool ATOMIC, typename F>
-__device__ inline uint32_t walk_chunk(const Posting *__restrict__ post, float *acc, volatile uint8_t *tag, int shift, uint32_t s,
-                                      uint32_t e, float qv, int lane, F &&consider, Trace &tr) {
-    const uint32_t len = e - s;
-    unsigned long long m = __ballot(len > 0);
-    if (!m) return 0;
-    if (!__ballot(len > (uint32_t)kGather)) {
-        // ---- 64 lists at once: lane-private gathers, rows stamped, one add per round unless two lists share a row ----
-        Posting P[kGather];
-#pragma unroll
-        for (int j = 0; j < kGather; j++) {
-            P[j] = Posting{0, 0.0f};
-            if ((uint32_t)j < len) P[j] = post[s + j];
-        }
-        if (COLLECT) {
-#pragma unroll
-            for (int j = 0; j < kGather; j++) {
-                if (!__ballot((uint32_t)j < len)) break;
-                const bool have = (uint32_t)j < len;
-                const float x = have ? acc_take(acc, P[j].loc >> shift) : 0.0f;  // two lists on one row: the first taker gets it
-                consider(have, P[j].loc >> shift, x);
-            }
-            return wave_sum_u32(len);
-        }
-        // Rounds.  Every pending lane stamps the rows of its list with its lane number and reads the stamps back; a lane that
-        // finds a foreign stamp shares a row with another pending list (it "lost" that row).  Let lim be the lowest loser:
-        // every pending lane below it won all its rows, and whoever else holds one of those rows is a loser ABOVE lim, i.e. a
-        // later list -- so the lanes below lim are applied together (their rows are distinct among themselves), then lane
-        // lim alone (all earlier lists are in), and the lanes above lim go round again.  Without sharing: one round.
-        bool pending = len > 0;
-        tr.fast_chunks++;
-        for (;;) {
-            tr.rounds++;
-#pragma unroll
-            for (int j = 0; j < kGather; j++)
-                if (pending && (uint32_t)j < len) tag[P[j].loc >> shift] = (uint8_t)lane;
-            bool lost = false;
-#pragma unroll
-            for (int j = 0; j < kGather; j++)
-                if (pending && (uint32_t)j < len) lost = lost || tag[P[j].loc >> shift] != (uint8_t)lane;
-            const unsigned long long ml = __ballot(lost);
-            const int lim = ml ? __ffsll((long long)ml) - 1 : 64;
-            const bool go = pending && lane < lim;
-#pragma unroll
-            for (int j = 0; j < kGather; j++) {
-                if (!__ballot(go && (uint32_t)j < len)) break;
-                if (go && (uint32_t)j < len) acc_add<ATOMIC>(acc, P[j].loc >> shift, __fmul_rn(qv, P[j].val));
-            }
-            if (!ml) break;
-#pragma unroll
-            for (int j = 0; j < kGather; j++) {
-                if (!__ballot(lane == lim && (uint32_t)j < len)) break;
-                if (lane == lim && (uint32_t)j < len) acc_add<ATOMIC>(acc, P[j].loc >> shift, __fmul_rn(qv, P[j].val));
-            }
-            pending = pending && lane > lim;
-            if (!__ballot(pending)) break;
-        }
-        return wave_sum_u32(len);
-    }
-    // ---- one list at a time, its postings over the lanes; the first 64 postings of the NEXT segment are loaded before the
-    // current one is applied (the compiler keeps loads behind the LDS atomics of the program order) ----
-    uint32_t walked = 0;
-    int l = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    uint32_t sl = lane_u32(s, l), el = lane_u32(e, l);
-    float ql = lane_f32(qv, l);
-    Posting P{0, 0.0f};
-    if (sl + lane < el) P = post[sl + lane];
+// What a lane holds of one VISIT = (group, chunk of 64 of the query's indices): its index's directory entry and value, the
+// segment [s, e) of that index's posting list inside the group (or stripe tile), and the first kGather postings of it.  The
+// three parts are loaded one visit apart (see the pipeline in sparse_tile_kernel), so that no load is waited for.
+struct Visit {
+    int32_t cid;
+    float qv;
+    uint32_t s, e;
+    Posting P[kGather];
+};
+
+// the group's state while it accumulates
+struct GroupState {
+    uint32_t walked;  // postings applied
+    int tcnt;         // rows on the touched list
+    bool slow;        // a chunk went one list at a time: the group is read back densely
+};
+
+// 64 lists at once (every segment of the visit has at most kGather postings, already in v.P).
+// Rounds: every pending lane stamps the rows of its list with its lane number and reads the stamps back; a lane that finds a
+// foreign stamp shares a row with another pending list (it "lost" that row).  Let lim be the lowest loser: every pending lane
+// below it won all its rows, and whoever else holds one of those rows is a loser ABOVE lim, i.e. a later list -- so the lanes
+// below lim are applied together (their rows are distinct among themselves), then lane lim alone (all earlier lists are in),
+// and the lanes above lim go round again.  Without sharing: one round.
+// Rows whose accumulator was +0 before the add go on the touched list (a sum that returns to zero and is reached again is
+// listed twice; the read-back takes it once).
+template <bool ATOMIC>
+__device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_t *tag, uint16_t *touched, int tcap, int shift,
+                                     int lane, GroupState &gs, Trace &tr) {
+    const uint32_t len = v.e - v.s;
+    bool pending = len > 0;
+    tr.fast_chunks++;
     for (;;) {
-        const bool more = m != 0;
-        uint32_t ns = 0, ne = 0;
-        float nq = 0.0f;
-        Posting NP{0, 0.0f};
-        if (more) {
-            l = __ffsll((long long)m) - 1;
+        tr.rounds++;
+#pragma unroll
+        for (int j = 0; j < kGather; j++)
+            if (pending && (uint32_t)j < len) tag[v.P[j].loc >> shift] = (uint8_t)lane;
+        bool lost = false;
+#pragma unroll
+        for (int j = 0; j < kGather; j++)
+            if (pending && (uint32_t)j < len) lost = lost || tag[v.P[j].loc >> shift] != (uint8_t)lane;
+        const unsigned long long ml = __ballot(lost);
+        const int lim = ml ? __ffsll((long long)ml) - 1 : 64;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {  // the lanes below lim together, then lane lim alone
+            const bool go = pending && (pass == 0 ? lane < lim : lane == lim);
+            if (pass == 1 && !ml) break;
+#pragma unroll
+            for (int j = 0; j < kGather; j++) {
+                const bool have = go && (uint32_t)j < len;
+                const unsigned long long mh = __ballot(have);
+                if (!mh) break;
+                const int i = v.P[j].loc >> shift;
+                float old = 1.0f;
+                if (have) old = acc_add_old<ATOMIC>(acc, i, __fmul_rn(v.qv, v.P[j].val));
+                const bool first = have && __float_as_uint(old) == 0;
+                const unsigned long long mf = __ballot(first);
+                if (mf) {
+                    const int at = gs.tcnt + lanes_below(mf, lane);
+                    if (first && at < tcap) touched[at] = (uint16_t)i;
+                    gs.tcnt += __popcll(mf);
+                }
+            }
+        }
+        if (!ml) break;
+        pending = pending && lane > lim;
+        if (!__ballot(pending)) break;
+    }
+    gs.walked += wave_sum_u32(len);
+}
+
+// One list at a time, its postings over the lanes (segments longer than kGather: the popular rows' groups).  The first 64
+// postings of the next THREE segments are in flight while one is applied (the compiler keeps loads behind the LDS atomics of
+// the program order, so the look-ahead is spelled out).  No touched list: such a group is read back densely.
+template <bool ATOMIC>
+__device__ inline void apply_one_by_one(const Posting *__restrict__ post, const Visit &v, float *acc, int shift, int lane, GroupState &gs,
+                                        Trace &tr) {
+    struct Seg {
+        uint32_t sl, el;  // wave-uniform; el == sl: none
+        float ql;
+        Posting P;
+    };
+    unsigned long long m = __ballot(v.e > v.s);
+    auto next = [&](Seg &x) {
+        x.sl = 0, x.el = 0, x.ql = 0.0f;
+        x.P = Posting{0, 0.0f};
+        if (m) {
+            const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
-            ns = lane_u32(s, l), ne = lane_u32(e, l), nq = lane_f32(qv, l);
-            if (ns + lane < ne) NP = post[ns + lane];
+            x.sl = lane_u32(v.s, l), x.el = lane_u32(v.e, l), x.ql = lane_f32(v.qv, l);
+            if (x.sl + lane < x.el) x.P = post[x.sl + lane];
         }
-        if (COLLECT) {
-            const bool have = sl + lane < el;
-            const float x = have ? acc_take(acc, P.loc >> shift) : 0.0f;
-            consider(have, P.loc >> shift, x);
-        } else if (sl + lane < el) {
-            acc_add<ATOMIC>(acc, P.loc >> shift, __fmul_rn(ql, P.val));
-        }
-        for (uint32_t p = sl + kBlock; p < el; p += 4 * kBlock) {  // long segments: four loads in flight
+    };
+    Seg r0, r1, r2, r3;
+    next(r0);
+    next(r1);
+    next(r2);
+    while (r0.el > r0.sl) {
+        next(r3);
+        if (r0.sl + lane < r0.el) acc_add<ATOMIC>(acc, r0.P.loc >> shift, __fmul_rn(r0.ql, r0.P.val));
+        for (uint32_t p = r0.sl + kBlock; p < r0.el; p += 4 * kBlock) {  // long segments: four loads in flight
             Posting x[4];
             bool have[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t at = p + j * kBlock + lane;
-                have[j] = at < el;
+                have[j] = at < r0.el;
                 x[j] = Posting{0, 0.0f};
                 if (have[j]) x[j] = post[at];
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (COLLECT) {
-                    if (p + j * kBlock < el) {  // uniform
-                        const float v = have[j] ? acc_take(acc, x[j].loc >> shift) : 0.0f;
-                        consider(have[j], x[j].loc >> shift, v);
-                    }
-                } else if (have[j]) {
-                    acc_add<ATOMIC>(acc, x[j].loc >> shift, __fmul_rn(ql, x[j].val));
-                }
-            }
+            for (int j = 0; j < 4; j++)
+                if (have[j]) acc_add<ATOMIC>(acc, x[j].loc >> shift, __fmul_rn(r0.ql, x[j].val));
         }
-        walked += el - sl;
-        tr.slow_segments += COLLECT ? 0 : 1;
-        if (!more) break;
-        sl = ns, el = ne, ql = nq, P = NP;
+        gs.walked += r0.el - r0.sl;
+        tr.slow_segments++;
+        r0 = r1, r1 = r2, r2 = r3;
     }
-    return walked;
+    gs.slow = true;
 }
 
 template <int KP, bool ATOMIC>
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(s_mem);
     float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
     volatile uint8_t *tag = s_mem + (size_t)CAP * 8 + (size_t)G * 4;
+    uint16_t *touched = reinterpret_cast<uint16_t *>(s_mem + (size_t)CAP * 8 + (size_t)G * 5);  // G / 4 entries
     const int lane = threadIdx.x;
     for (int i = lane; i < G; i += kBlock) acc[i] = 0.0f;
     __syncthreads();
@@ -376,83 +388,118 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const int shift = wk.stripe < 0 ? 0 : kLogStripes;
         const int first = wk.stripe < 0 ? 0 : wk.stripe, width = wk.stripe < 0 ? kStripes : 1;
         const int nacc = G >> shift;
-        // queries of at most 64 entries keep (directory entry, value) in registers for all groups
-        const bool small = L <= kBlock;
+        const int tcap = nacc >> 2;
+        const int64_t nch = (L + kBlock - 1) / kBlock;  // chunks of 64 indices
+        const int64_t V = nch * ngroups;                // visits, group-major
+        // The pipeline: while visit v is applied, the postings of v + 1, the directory entries of v + 2 and the (index, value)
+        // pairs of v + 3 are in flight.  A query of at most 64 entries has one chunk: its pairs stay in registers.
+        const bool small = nch <= 1;
         int32_t cid0 = -1;
         float qv0 = 0.0f;
         if (small && lane < L) {
             cid0 = a.q_cid[qs + lane];
             qv0 = a.q_val[qs + lane];
         }
-        for (int g = 0; g < ngroups; g++) {
-            const int tile = g * kStripes + first;
-            const int64_t sid0 = (int64_t)g * G + (wk.stripe < 0 ? 0 : wk.stripe);
-            auto consider = [&](bool have, int32_t i, float x) {
-                have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
-                if (!__ballot(have)) return;
-                const int64_t sid = sid0 + ((int64_t)i << shift);
-                my_hit += have;
-                have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
-                const uint32_t ord = score_ord(x);
-                my_pos += have && ord > kZeroOrd;
-                my_neg += have && ord < kZeroOrd;
-                const bool cand = have && ord >= (uint32_t)(thr >> 32);
-                if (!__ballot(cand)) return;
-                const unsigned long long key = cand ? make_key(ord, a.orig_of[sid]) : 0;
-                push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
-            };
-            auto nothing = [](bool, int32_t, float) {};
-            auto segment = [&](int32_t cid, uint32_t &s, uint32_t &e) {
-                s = 0, e = 0;
-                if (cid >= 0) {
-                    const uint32_t *o = a.off + (size_t)cid * a.ntiles + tile;
-                    s = o[0], e = o[width];
-                }
-            };
-            uint32_t walked = 0;
+        // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (group, chunk) counters
+        int64_t c1 = 0, c2 = 0;
+        int g2 = 0;
+        auto stage1 = [&](int64_t v, Visit &x) {
+            x.cid = -1, x.qv = 0.0f;
+            if (v >= V) return;
             if (small) {
-                uint32_t s, e;
-                segment(cid0, s, e);
-                walked = walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, nothing, tr);
-                if (walked == 0) continue;
-                if ((int64_t)walked * 4 < nacc) {
-                    walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, qv0, lane, consider, tr);
-                    walked_q += walked;
-                    tr.sparse_groups++;
-                    continue;
-                }
-            } else {
-                for (int64_t c = 0; c < L; c += kBlock) {
-                    uint32_t s, e;
-                    float qv = 0.0f;
-                    int32_t cid = -1;
-                    if (c + lane < L) {
-                        cid = a.q_cid[qs + c + lane];
-                        qv = a.q_val[qs + c + lane];
-                    }
-                    segment(cid, s, e);
-                    walked += walk_chunk<false, ATOMIC>(a.post, acc, tag, shift, s, e, qv, lane, nothing, tr);
-                }
-                if (walked == 0) continue;
-                if ((int64_t)walked * 4 < nacc) {
-                    for (int64_t c = 0; c < L; c += kBlock) {
-                        uint32_t s, e;
-                        segment(c + lane < L ? a.q_cid[qs + c + lane] : -1, s, e);
-                        walk_chunk<true, ATOMIC>(a.post, acc, tag, shift, s, e, 0.0f, lane, consider, tr);
-                    }
-                    walked_q += walked;
-                    tr.sparse_groups++;
-                    continue;
+                x.cid = cid0, x.qv = qv0;
+                return;
+            }
+            const int64_t at = c1 * kBlock + lane;
+            if (at < L) {
+                x.cid = a.q_cid[qs + at];
+                x.qv = a.q_val[qs + at];
+            }
+            if (++c1 == nch) c1 = 0;
+        };
+        auto stage2 = [&](int64_t v, Visit &x) {
+            x.s = 0, x.e = 0;
+            if (v >= V) return;
+            if (x.cid >= 0) {
+                const uint32_t *o = a.off + (size_t)x.cid * a.ntiles + g2 * kStripes + first;
+                x.s = o[0], x.e = o[width];
+            }
+            if (++c2 == nch) {
+                c2 = 0;
+                g2++;
+            }
+        };
+        auto stage3 = [&](Visit &x) {
+            const uint32_t len = x.e - x.s;
+#pragma unroll
+            for (int j = 0; j < kGather; j++) {
+                x.P[j] = Posting{0, 0.0f};
+                if ((uint32_t)j < len) x.P[j] = a.post[x.s + j];
+            }
+        };
+        Visit v0, v1, v2, v3;
+        stage1(0, v0);
+        stage1(1, v1);
+        stage1(2, v2);
+        stage2(0, v0);
+        stage2(1, v1);
+        stage3(v0);
+        GroupState gs{0, 0, false};
+        int64_t c = 0;  // chunk of visit v inside its group
+        int g = 0;
+        for (int64_t v = 0; v < V; v++) {
+            stage1(v + 3, v3);
+            stage2(v + 2, v2);
+            stage3(v1);
+            {   // visit v
+                const uint32_t len = v0.e - v0.s;
+                if (__ballot(len > 0)) {
+                    if (!__ballot(len > (uint32_t)kGather))
+                        apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, shift, lane, gs, tr);
+                    else
+                        apply_one_by_one<ATOMIC>(a.post, v0, acc, shift, lane, gs, tr);
                 }
             }
-            walked_q += walked;
-            tr.dense_groups++;
-            // dense: every accumulator is looked at once
-            for (int i = lane; i < nacc; i += kBlock) {
-                const float x = acc[i];
-                if (__float_as_uint(x) != 0) acc[i] = 0.0f;
-                consider(true, i, x);
+            if (++c == nch) {  // the group is complete: read it back
+                if (gs.walked > 0) {
+                    const int64_t sid0 = (int64_t)g * G + (wk.stripe < 0 ? 0 : wk.stripe);
+                    auto consider = [&](bool have, int32_t i, float x) {
+                        have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
+                        if (!__ballot(have)) return;
+                        const int64_t sid = sid0 + ((int64_t)i << shift);
+                        my_hit += have;
+                        have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
+                        const uint32_t ord = score_ord(x);
+                        my_pos += have && ord > kZeroOrd;
+                        my_neg += have && ord < kZeroOrd;
+                        const bool cand = have && ord >= (uint32_t)(thr >> 32);
+                        if (!__ballot(cand)) return;
+                        const unsigned long long key = cand ? make_key(ord, a.orig_of[sid]) : 0;
+                        push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
+                    };
+                    if (gs.slow || (int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
+                        tr.dense_groups++;
+                        for (int i = lane; i < nacc; i += kBlock) {
+                            const float x = acc[i];
+                            if (__float_as_uint(x) != 0) acc[i] = 0.0f;
+                            consider(true, i, x);
+                        }
+                    } else {
+                        tr.sparse_groups++;
+                        for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {
+                            const bool have = i0 + lane < gs.tcnt;
+                            const int i = have ? (int)touched[i0 + lane] : 0;
+                            const float x = have ? acc_take(acc, i) : 0.0f;  // a row listed twice: the first taker gets it
+                            consider(have, i, x);
+                        }
+                    }
+                    walked_q += gs.walked;
+                }
+                gs = GroupState{0, 0, false};
+                c = 0;
+                g++;
             }
+            v0 = v1, v1 = v2, v2 = v3;
         }
         const long long pos = wave_sum(my_pos), neg = wave_sum(my_neg), hit = wave_sum(my_hit);
         finish<KP>(s_buf, bcnt, lane);

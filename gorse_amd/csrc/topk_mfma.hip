@@ -64,7 +64,7 @@ __device__ __forceinline__ int lane_rank(uint64_t m) {  // set bits of m below t
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
 
-constexpr int kDefaultRowsPerTile = 64;
+constexpr int kDefaultRowsPerTile = 128;  // one barrier per four MFMA row blocks: 8 % faster than 64 at C4 (profiles/r02_d_probe_topk_warm.txt)
 inline int topk_rows_per_tile() { return (g_topk_variant & 1) ? 64 : ((g_topk_variant & 2) ? 128 : kDefaultRowsPerTile); }
 
 struct SweepParams {
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     float *s_f = reinterpret_cast<float *>(s_cnt + 2 * BQ);
     float *s_mg = s_f + BQ;
     int *s_hc = reinterpret_cast<int *>(s_mg + BQ);
+    float *s_stage = reinterpret_cast<float *>(s_hc + BQ);  // 16 scores per thread: where the candidate path parks a block
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t wgq0 = (int64_t)blockIdx.x * BQ;
@@ -384,13 +385,37 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                         c_s1 += tq - tsl;
                     }
                     uint2 *mine = qb + (lane >> 5);
+                    if (VOTE) {
+                        // Candidates are rare behind a warm start (one or two of the block's 1024 scores): instead of 16
+                        // predicated compare + append bodies (whose scalar bookkeeping -- ~14 instructions and two or three
+                        // branches per score row -- was 1700 of the path's 2300 cycles, profiles/r02_e_probe_topk_prof.txt),
+                        // every lane builds the bit mask of its passing rows with branch-free VALU code, parks its 16 scores
+                        // in LDS and walks its own mask: the loop runs as often as the busiest lane has candidates.
+                        uint32_t lm = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        if ((VOTE || p.vote) && __builtin_amdgcn_ballot_w64(acc[cb][r] >= f) == 0) continue;  // wave-uniform
-                        if (acc[cb][r] >= f) {
-                            const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                            mine[2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
-                            cnt[cb]++;
+                        for (int r = 0; r < 16; r++) lm |= acc[cb][r] >= f ? (1u << r) : 0u;
+                        if (__builtin_amdgcn_ballot_w64(lm != 0) != 0) {  // the block bound can be a false alarm
+                            float *st = s_stage + (size_t)tid * 16;
+#pragma unroll
+                            for (int g = 0; g < 4; g++)
+                                *reinterpret_cast<float4 *>(st + 4 * g) =
+                                    make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
+                            while (lm) {
+                                const int r = __builtin_ctz(lm);
+                                lm &= lm - 1;
+                                const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                                mine[2 * cnt[cb]] = make_uint2(fkey(st[r]), row);
+                                cnt[cb]++;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            if (acc[cb][r] >= f) {
+                                const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                                mine[2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
+                                cnt[cb]++;
+                            }
                         }
                     }
                     if (PROF) {
@@ -1009,39 +1034,28 @@ __global__ void margin_kernel(const float *__restrict__ qn2, int64_t nq, float c
 
 const int kSupportedKP[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
 
-template <int KP, int NCB, bool SCALE, bool HIST, int RB>
+template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool VOTE = false>
 int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int WV = sweep_waves(HIST, KP);
     constexpr int BQ = 32 * NCB * WV;
     constexpr int ROWB = KP * 32 + 16;
     constexpr int TR = 32 * RB;
-    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4;
+    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4 + (size_t)WV * 64 * 16 * 4;
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB>),
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB><<<dim3(grid), dim3(WV * 64), lds, h->stream>>>(p);
+    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE><<<dim3(grid), dim3(WV * 64), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 
-template <int RB>
+template <int RB, bool VOTE>
 int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {
     constexpr int BQ = 32 * 2 * kWaves, ROWB = 8 * 32 + 16, TR = 32 * RB;
-    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4;
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, true, false, RB, true>),
+    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4 + (size_t)kWaves * 64 * 16 * 4;
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, true, false, RB, true, VOTE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<8, 2, true, false, RB, true><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
-    GORSE_HIP_CHECK(hipGetLastError());
-    return GORSE_OK;
-}
-
-template <int RB>
-int32_t launch_sweep_vote(gorse_topk *h, const SweepParams &p) {  // the C4 shape with the per-row wave vote (probe only)
-    constexpr int BQ = 32 * 2 * kWaves, ROWB = 8 * 32 + 16, TR = 32 * RB;
-    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4;
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, true, false, RB, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<8, 2, true, false, RB, false, true><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
+    topk_sweep_kernel<8, 2, true, false, RB, true, VOTE><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -1053,9 +1067,15 @@ int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist)
     const bool wide = !hist && KP <= 8 && topk_rows_per_tile() == 128;
     if constexpr (KP == 8 && NCB == 2) {
         if ((g_topk_variant & 16) && scale && !hist && p.prof)  // instrumented twin of the C4 sweep (probe only)
-            return wide ? launch_sweep_prof<4>(h, p) : launch_sweep_prof<2>(h, p);
-        if ((g_topk_variant & 128) && scale && !hist)  // per-row wave vote in the candidate path (probe only)
-            return wide ? launch_sweep_vote<4>(h, p) : launch_sweep_vote<2>(h, p);
+            return p.vote ? (wide ? launch_sweep_prof<4, true>(h, p) : launch_sweep_prof<2, true>(h, p))
+                          : (wide ? launch_sweep_prof<4, false>(h, p) : launch_sweep_prof<2, false>(h, p));
+    }
+    if (p.vote && !hist) {  // behind a warm start: the candidate path for rare candidates
+        if (wide) {
+            if constexpr (KP <= 8)
+                return scale ? launch_sweep_one<KP, NCB, true, false, 4, true>(h, p) : launch_sweep_one<KP, NCB, false, false, 4, true>(h, p);
+        }
+        return scale ? launch_sweep_one<KP, NCB, true, false, 2, true>(h, p) : launch_sweep_one<KP, NCB, false, false, 2, true>(h, p);
     }
     if (wide) {
         if constexpr (KP <= 8)
