@@ -437,7 +437,13 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
             c_m += t1 - t0;
             t0 = t1;
         }
+        // The solve is a chain of ~1100 dependent VALU operations; the sibling wave of this SIMD is meanwhile streaming fp32
+        // MFMAs, and at equal priority the arbiter lets one VALU operation through per 64-cycle MFMA (840 cycles per solve
+        // step, profiles/r02_g_probe_als_prof.txt).  At raised priority the chain issues at its own pace and the MFMA stream
+        // takes the slots in between -- it needs one issue per 64 cycles.
+        __builtin_amdgcn_s_setprio(3);
         als_solve_row<32 * NB, true>(A + u * d, sM, ss, S, d, one_w, w, reg, lane);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
         if (prof) {
             c_solve += __builtin_amdgcn_s_memtime() - t0;

@@ -89,6 +89,8 @@ struct SweepParams {
     const float *f0;   // nq initial thresholds or null (-inf)
     float *f_out;      // pilot: nq final thresholds; null otherwise
     int tile_stride;   // 1, or the pilot's sampling stride over the row tiles
+    int prio;          // candidate path at raised wave priority (s_setprio): its VALU chain competes with the sibling wave's
+                       // MFMA issue, and the wave that took the path is the one the barrier waits for
     int vote;          // candidate path: skip a score row when no lane of the wave holds a candidate in it (pays when
                        // candidates are rare, i.e. behind a warm start: one or two of a block's 1024 scores)
 };
@@ -326,6 +328,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                     }
             }
             // C layout: lane holds column (= query) lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+            if (p.prio & 2) __builtin_amdgcn_s_setprio(1);  // probe: the whole epilogue ahead of the sibling's MFMA issue
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
                 const bool coarse = SCALE && p.coarse;
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                         tsl = __builtin_amdgcn_s_memtime();
                         n_slow++;
                     }
+                    if (p.prio & 1) __builtin_amdgcn_s_setprio(3);
                     if (coarse) scale_rows();
                     const int ql = w * QW + cb * 32 + (lane & 31);
                     const int64_t qg = wgq0 + ql;
@@ -438,6 +442,12 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                         cnt[cb] = s_cnt[2 * ql + (lane >> 5)];
                         fth[cb] = s_f[ql];
                     }
+                    if (p.prio & 1) {
+                        if (p.prio & 2)
+                            __builtin_amdgcn_s_setprio(1);
+                        else
+                            __builtin_amdgcn_s_setprio(0);
+                    }
                     if (PROF) {
                         const unsigned long long now = __builtin_amdgcn_s_memtime();
                         c_s3 += now - tq;
@@ -446,6 +456,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                 }
             }
         }
+        if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
         if (PROF) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             c_comp += now - ts;
@@ -1267,6 +1278,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.nq = m;
         sp.kth = kth;
         sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1, sp.vote = 0;
+        // variant bit 11: candidate path at the default priority; bit 13: the whole epilogue at priority 1 (probe)
+        sp.prio = ((g_topk_variant & 2048) ? 0 : 1) | ((g_topk_variant & 8192) ? 2 : 0);
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
         // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
         // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
@@ -1301,12 +1314,11 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 GORSE_TRY(dispatch_sweep(h, p1, scale, false));
                 GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
                 p2.f0 = h->f1.p;
-                p2.vote = 1;
             }
             GORSE_TRY(dispatch_sweep(h, p2, scale, false));
             GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot's flags say nothing about the query
             sp.f0 = h->f0.p;
-            sp.vote = 1;
+            sp.vote = (g_topk_variant & 4096) ? 1 : 0;  // variant bit 12: lane-mask candidate path (measured slower: r02_f)
         }
         GORSE_TRY(dispatch_sweep(h, sp, scale, false));
         if (warm) {  // the queries whose warm start could not be verified: gathered, swept from -inf, lists put back

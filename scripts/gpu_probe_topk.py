@@ -5,7 +5,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from gorse_amd import capi, synth  # noqa: E402
 
 
@@ -44,6 +44,13 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] in ("onewarm", "onecold"):  # one configuration, for a kernel trace
         capi.lib().gorse_hip_test_set_topk_variant(0 if sys.argv[1] == "onewarm" else 256)
         run("C4 256K q: " + sys.argv[1], Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
+        capi.lib().gorse_hip_test_set_topk_variant(0)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "prio":  # wave priority of the candidate path / the epilogue, cold and warm
+        for v, label in [(256 | 2048, "cold, default priority"), (256, "cold, candidate path prio 3"), (256 | 8192, "cold, + epilogue prio 1"),
+                         (0, "warm, candidate path prio 3"), (8192, "warm, + epilogue prio 1"), (2048, "warm, default priority")]:
+            capi.lib().gorse_hip_test_set_topk_variant(v)
+            run("C4 256K q: " + label, Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=2)
         capi.lib().gorse_hip_test_set_topk_variant(0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "warm":  # the warm-started sweep against the cold one, with the re-sweep counts
