@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgorse_hip.so")
 OK, ERR_INVALID, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE, ERR_RANGE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY = 0, 1, 2
 DTYPE_F32, DTYPE_BF16 = 0, 1
-METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
+METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_EUCLIDEAN_BF16 = 0, 1, 2, 3
 PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM, PROF_BPR_SORT, PROF_COMM = 0, 1, 2, 3, 4, 5
 COMM_ID_BYTES = 128
 PROF_TOPK_SCORE, PROF_TOPK_RESCORE, PROF_TOPK_SWEEP, PROF_TOPK_SELECT, PROF_TOPK_HIST, PROF_TOPK_REPLAY = 0, 1, 2, 3, 4, 5
@@ -94,6 +94,7 @@ SIGNATURES = {
     "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
+    "gorse_hip_test_set_sparse_stripe_rows": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_atomic": (None, [C.c_int32]),
     "gorse_hip_test_sparse_trace": (C.c_int64, [_vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int64]),

@@ -330,7 +330,9 @@ __device__ __forceinline__ void gram_store_sums(const GramAcc<NB> &g, int d, int
 template <int DMAX, bool FORM>
 __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss,
                                               const float *__restrict__ S, int d, float one_w, float w, float reg,
-                                              int lane) {
+                                              int lane, unsigned long long *c_load = nullptr) {
+    unsigned long long t_in = 0;
+    if (c_load) t_in = __builtin_amdgcn_s_memtime();
     float mcol[DMAX];
     if (FORM) {  // an opaque zero offset per call: keeps the 64 loads of S inside the row loop instead of 64 registers
         int z;   // hoisted across the whole kernel (they are L1 hits; the registers are needed by the accumulation)
@@ -357,6 +359,7 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     // (the wave sum took ~650 cycles per step next to a sibling wave's MFMAs: 42K cycles per row against 27K for the Gram
     // accumulation, profiles/r01_p_probe_als_prof.txt).  Same recurrence, products summed in a different order; agreement
     // with the float64 recurrence 6e-7 of the row's scale on random systems (well inside the 1e-4 bar).
+    if (c_load) *c_load += __builtin_amdgcn_s_memtime() + (__float_as_int(mcol[DMAX - 1]) & 0) - t_in;  // probe: columns of M in registers
     const float p0 = lane < d ? a[lane] : 0.0f;
     const float sv = lane < d ? ss[lane] : 0.0f;
     float diag = 0.0f;
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // probe only (prof != null): s_memtime ticks per wave in [0] Gram accumulation, [1] M to LDS, [2] solve; [3] rows,
     // [4] feedback entries, [5] kernel ticks, [6] waves
-    unsigned long long c_acc = 0, c_m = 0, c_solve = 0, c_rows = 0, c_ent = 0, t_begin = 0;
+    unsigned long long c_acc = 0, c_m = 0, c_solve = 0, c_rows = 0, c_ent = 0, t_begin = 0, c_load = 0;
     if (prof) t_begin = __builtin_amdgcn_s_memtime();
     float *sM = smem + (size_t)wv * (64 * kAlsDP + 64);
     float *ss = sM + 64 * kAlsDP;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
         // step, profiles/r02_g_probe_als_prof.txt).  At raised priority the chain issues at its own pace and the MFMA stream
         // takes the slots in between -- it needs one issue per 64 cycles.
         __builtin_amdgcn_s_setprio(3);
-        als_solve_row<32 * NB, true>(A + u * d, sM, ss, S, d, one_w, w, reg, lane);
+        als_solve_row<32 * NB, true>(A + u * d, sM, ss, S, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
         if (prof) {
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
         atomicAdd(prof + 4, c_ent);
         atomicAdd(prof + 5, (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
         atomicAdd(prof + 6, 1ull);
+        atomicAdd(prof + 7, c_load);
     }
 }
 

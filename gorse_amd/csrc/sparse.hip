@@ -16,14 +16,15 @@ using gorse::sparse::TileArgs;
 struct gorse_sparse {
     int device = 0;
     int64_t N = 0, nnz = 0, Dc = 0;
-    int32_t logT = 0, ntiles = 0;
+    int32_t logG = 0, ngroups = 0;  // arrangement A: groups of G = 1 << logG consecutive scratch ids
+    int32_t logS = 0, naccB = 0;    // arrangement B: S = 1 << logS stripes (scratch id mod S) of naccB rows
     hipStream_t stream = nullptr;
     // stored rows as CSR with directory entries instead of raw indices (the queries of all_pairs), the tiled posting lists
     DevBuf<int64_t> r_ptr;
     DevBuf<int32_t> r_cid, orig_of, new_of;
     DevBuf<float> r_val;
-    DevBuf<uint32_t> dims, off;
-    DevBuf<sparse::Posting> post;
+    DevBuf<uint32_t> dims, offA, offB;
+    DevBuf<sparse::Posting> postA, postB;
     DevBuf<uint8_t> mask_sid;
     bool has_mask = false;
     int64_t n_admissible = 0;  // rows with mask != 0 (N without a mask)
@@ -34,6 +35,7 @@ struct gorse_sparse {
     DevBuf<int64_t> q_ptr, q_excl;
     DevBuf<uint32_t> q_idx;
     DevBuf<int32_t> q_cid, out_idx, out_cnt, next, split_t, part_cnt;
+    DevBuf<sparse::Work> workB;
     DevBuf<float> q_val, out_score;
     DevBuf<sparse::Work> work;
     DevBuf<unsigned long long> part_keys, stat;
@@ -52,19 +54,25 @@ struct gorse_sparse {
 namespace {
 
 // probes / test hooks (include/gorse_hip_test.h); results never depend on them
-int g_sparse_tile = 0;           // rows per tile (power of two, 64 .. 2048; a group = 8 tiles); 0 = chosen from N
-int64_t g_sparse_split = 2048;   // queries with more entries than this are split over the 8 stripes; <= 0 = never
+int g_sparse_tile = 0;           // rows per group of arrangement A (power of two, 256 .. 16384); 0 = 4096
+int64_t g_sparse_split = 2048;   // queries with more entries than this are split over the stripes of arrangement B; <= 0 = never
+int g_sparse_stripe_rows = 0;    // rows per stripe of arrangement B are at most this (power of two); 0 = 8192
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 
-int pick_log_tile(int64_t N) {
+int pick_log_group() {
+    int l = 12;  // 4096 rows: 16 KB of accumulators + 4 KB of stamps + 2 KB of touched list, 6 waves per CU with KP = 256
     if (g_sparse_tile > 0) {
-        int l = 6;
-        while ((1 << l) < g_sparse_tile && l < 11) l++;
-        return l;
+        l = 8;
+        while ((1 << l) < g_sparse_tile && l < 14) l++;
     }
-    int l = 9;  // 512 rows per tile, 4096 per group: 16 KB of accumulators + 4 KB of stamps, 6 waves per CU with KP = 256
-    while (l < 11 && ((int64_t)512 << l) < N) l++;  // at most ~512 tiles per posting list
+    return l;
+}
+// stripes of arrangement B: the fewest (a power of two, at least 2) whose row count fits the LDS budget of a stripe
+int pick_log_stripes(int64_t N) {
+    const int64_t most = g_sparse_stripe_rows > 0 ? g_sparse_stripe_rows : 8192;
+    int l = 1;
+    while (ceil_div(N, (int64_t)1 << l) > most && l < 20) l++;
     return l;
 }
 
@@ -97,80 +105,85 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
                     float *score_out, int32_t *cnt_out) {
     const int kp = sparse::pick_kp(k);
     if (!kp) return fail(GORSE_ERR_INVALID, "k = %d: must be in 1..1024", k);
-    if (nq > INT32_MAX / (sparse::kStripes + 1)) return fail(GORSE_ERR_INVALID, "too many queries in one call");
+    if (nq > (INT32_MAX >> (h->logS + 1))) return fail(GORSE_ERR_INVALID, "too many queries in one call");
     GORSE_TRY(h->out_idx.ensure((size_t)nq * k));
     GORSE_TRY(h->out_score.ensure((size_t)nq * k));
     GORSE_TRY(h->out_cnt.ensure((size_t)nq));
     GORSE_TRY(h->stat.ensure(2));
-    GORSE_TRY(h->next.ensure(1));
-    // work items, longest first; long queries as 8 items (one per stripe)
-    std::vector<sparse::Work> work;
-    std::vector<int64_t> cost;
+    // work items, longest first: a long query as one item per stripe of arrangement B (+ a merge), the others as one item
+    // over arrangement A
+    const int S = 1 << h->logS;
+    std::vector<sparse::Work> workA, workB;
     std::vector<int32_t> split_t;
-    work.reserve((size_t)nq);
-    cost.reserve((size_t)nq);
+    workA.reserve((size_t)nq);
     for (int64_t t = 0; t < nq; t++) {
         const int64_t L = q_len_host[t + 1] - q_len_host[t];
-        if (g_sparse_split > 0 && L > g_sparse_split && h->ntiles >= sparse::kStripes) {
-            for (int s = 0; s < sparse::kStripes; s++) {
-                work.push_back(sparse::Work{(int32_t)t, s, (int32_t)split_t.size()});
-                cost.push_back(L / sparse::kStripes + 1);
-            }
+        if (g_sparse_split > 0 && L > g_sparse_split) {
+            for (int s = 0; s < S; s++) workB.push_back(sparse::Work{(int32_t)t, s, (int32_t)split_t.size()});
             split_t.push_back((int32_t)t);
         } else {
-            work.push_back(sparse::Work{(int32_t)t, -1, 0});
-            cost.push_back(L);
+            workA.push_back(sparse::Work{(int32_t)t, -1, 0});
         }
     }
-    {
-        std::vector<int32_t> by(work.size());
-        for (size_t i = 0; i < by.size(); i++) by[i] = (int32_t)i;
-        std::stable_sort(by.begin(), by.end(), [&](int32_t x, int32_t y) { return cost[(size_t)x] > cost[(size_t)y]; });
-        std::vector<sparse::Work> sorted(work.size());
-        for (size_t i = 0; i < by.size(); i++) sorted[i] = work[(size_t)by[i]];
-        work.swap(sorted);
-    }
-    GORSE_TRY(h->work.ensure(work.size()));
-    GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
-    if (!split_t.empty()) {
+    auto by_length = [&](const sparse::Work &x, const sparse::Work &y) {
+        return q_len_host[x.t + 1] - q_len_host[x.t] > q_len_host[y.t + 1] - q_len_host[y.t];
+    };
+    std::stable_sort(workA.begin(), workA.end(), by_length);
+    std::stable_sort(workB.begin(), workB.end(), by_length);
+    GORSE_TRY(h->next.ensure(2));
+    GORSE_TRY(h->work.ensure(workA.size()));
+    GORSE_TRY(h->workB.ensure(workB.size()));
+    if (!workA.empty())
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, workA.data(), workA.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
+    if (!workB.empty()) {
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->workB.p, workB.data(), workB.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
         GORSE_TRY(h->split_t.ensure(split_t.size()));
-        GORSE_TRY(h->part_keys.ensure(split_t.size() * sparse::kStripes * (size_t)kp));
-        GORSE_TRY(h->part_cnt.ensure(split_t.size() * sparse::kStripes * 2));
+        GORSE_TRY(h->part_keys.ensure(split_t.size() * (size_t)S * (size_t)kp));
+        GORSE_TRY(h->part_cnt.ensure(split_t.size() * (size_t)S * 2));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, split_t.data(), split_t.size() * 4, hipMemcpyHostToDevice, h->stream));
     }
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
-    GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sizeof(int32_t), h->stream));
+    GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, 2 * sizeof(int32_t), h->stream));
     TileArgs a;
-    a.off = h->off.p, a.post = h->post.p, a.ntiles = h->ntiles, a.logT = h->logT, a.N = h->N;
+    a.offA = h->offA.p, a.postA = h->postA.p, a.ngroups = h->ngroups, a.logG = h->logG;
+    a.offB = h->offB.p, a.postB = h->postB.p, a.logS = h->logS, a.naccB = h->naccB;
+    a.N = h->N;
     a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
     a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
     a.exclude = excl_dev, a.exclude_self = exclude_self;
     a.mask_sid = h->has_mask ? h->mask_sid.p : nullptr;
     a.n_admissible = h->has_mask ? h->n_admissible : h->N;
-    a.work = h->work.p, a.n_work = (int32_t)work.size(), a.next = h->next.p;
     a.k = k;
     a.out_idx = h->out_idx.p, a.out_score = h->out_score.p, a.out_cnt = h->out_cnt.p;
     a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
     a.stat = h->stat.p;
     a.trace = nullptr;
+    const size_t n_items = workA.size() + workB.size();
     if (h->trace_on) {
-        GORSE_TRY(h->trace.ensure(work.size()));
+        GORSE_TRY(h->trace.ensure(n_items));
         a.trace = h->trace.p;
     }
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
-    // ranking buffer, accumulators (4 B per group row), stamps (1 B), touched list (2 B per 4 rows)
-    const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 * sparse::kStripes << h->logT) / 2;
+    // LDS of a workgroup: ranking buffer + per accumulator 4 B (sum) + 1 B (stamp) + 0.5 B (touched list)
+    auto lds_for = [&](int64_t nacc) { return (size_t)2 * kp * 8 + (size_t)nacc * 11 / 2; };
+    auto launch = [&](const TileArgs &x, size_t n, size_t lds) -> int32_t {
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n, slots));
+        switch (kp) {
+            case 256: return launch_tiles<256>(x, grid, lds, atomic, h->stream);
+            case 512: return launch_tiles<512>(x, grid, lds, atomic, h->stream);
+            default: return launch_tiles<1024>(x, grid, lds, atomic, h->stream);
+        }
+    };
     const int tok = h->prof.begin(0, h->stream);
-    switch (kp) {
-        case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;
-        case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, h->stream)); break;
-        default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, h->stream)); break;
-    }
-    GORSE_HIP_CHECK(hipGetLastError());
-    if (!split_t.empty()) {
+    if (!workB.empty()) {  // the stripes of the long queries first: they are the longest items of the call
+        TileArgs b = a;
+        b.work = h->workB.p, b.n_work = (int32_t)workB.size(), b.next = h->next.p + 1;
+        b.nacc_lds = (int32_t)(ceil_div(h->naccB, 64) * 64);
+        b.trace = a.trace ? a.trace + workA.size() : nullptr;
+        GORSE_TRY(launch(b, workB.size(), lds_for(b.nacc_lds)));
+        GORSE_HIP_CHECK(hipGetLastError());
         sparse::MergeArgs m;
-        m.split_t = h->split_t.p, m.n_split = (int32_t)split_t.size();
+        m.split_t = h->split_t.p, m.n_split = (int32_t)split_t.size(), m.nparts = S;
         m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
         m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
         m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
@@ -183,6 +196,12 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }
+    if (!workA.empty()) {
+        a.work = h->work.p, a.n_work = (int32_t)workA.size(), a.next = h->next.p;
+        a.nacc_lds = 1 << h->logG;
+        GORSE_TRY(launch(a, workA.size(), lds_for(a.nacc_lds)));
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
     h->prof.end(tok, h->stream);
     unsigned long long st[2] = {0, 0};
     GORSE_HIP_CHECK(hipMemcpyAsync(st, h->stat.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -191,12 +210,12 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     if (score_out)
         GORSE_HIP_CHECK(hipMemcpyAsync(score_out, h->out_score.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
     if (cnt_out) GORSE_HIP_CHECK(hipMemcpyAsync(cnt_out, h->out_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
-    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from `work` / `split_t`
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from the work lists and `split_t`
     h->last_postings = (int64_t)st[0];
     h->last_hits = (int64_t)st[1];
     if (h->trace_on) {
-        h->trace_host.resize(work.size());
-        GORSE_HIP_CHECK(hipMemcpy(h->trace_host.data(), h->trace.p, work.size() * sizeof(sparse::Trace), hipMemcpyDeviceToHost));
+        h->trace_host.resize(n_items);
+        GORSE_HIP_CHECK(hipMemcpy(h->trace_host.data(), h->trace.p, n_items * sizeof(sparse::Trace), hipMemcpyDeviceToHost));
     }
     return GORSE_OK;
 }
@@ -234,12 +253,16 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     h->order = sparse::order_rows(N, indptr);
     const std::vector<uint32_t> dims = sparse::distinct_indices(indices + base, nnz);
     h->Dc = (int64_t)dims.size();
-    h->logT = pick_log_tile(N);
-    h->ntiles = (int32_t)(ceil_div(N, (int64_t)sparse::kStripes << h->logT) * sparse::kStripes);
+    h->logG = pick_log_group();
+    h->ngroups = (int32_t)ceil_div(N, (int64_t)1 << h->logG);
+    h->logS = pick_log_stripes(N);
+    h->naccB = (int32_t)ceil_div(N, (int64_t)1 << h->logS);
     int32_t rc = [&]() -> int32_t {
-        const int64_t cells = h->Dc * h->ntiles;
-        if (cells >= (int64_t)1 << 33) return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d row tiles",
-                                                   (long long)h->Dc, h->ntiles);
+        const int64_t cellsA = h->Dc * h->ngroups, cellsB = h->Dc << h->logS;
+        if (std::max(cellsA, cellsB) >= (int64_t)1 << 33)
+            return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d row groups / %d stripes", (long long)h->Dc,
+                        h->ngroups, 1 << h->logS);
+        if (h->naccB > 65536) return fail(GORSE_ERR_INVALID, "too many rows per stripe");
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         std::vector<int64_t> &ptr0 = h->r_ptr_host;
@@ -251,30 +274,40 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         GORSE_TRY(h->orig_of.alloc((size_t)N));
         GORSE_TRY(h->new_of.alloc((size_t)N));
         GORSE_TRY(h->dims.alloc((size_t)h->Dc));
-        GORSE_TRY(h->off.alloc((size_t)cells + 1));
-        GORSE_TRY(h->post.alloc((size_t)nnz));
+        GORSE_TRY(h->offA.alloc((size_t)cellsA + 1));
+        GORSE_TRY(h->offB.alloc((size_t)cellsB + 1));
+        GORSE_TRY(h->postA.alloc((size_t)nnz));
+        GORSE_TRY(h->postB.alloc((size_t)nnz));
         DevBuf<uint32_t> raw, cursor, sums;
         GORSE_TRY(raw.alloc((size_t)nnz));
-        GORSE_TRY(cursor.alloc((size_t)cells + 1));
+        GORSE_TRY(cursor.alloc((size_t)std::max(cellsA, cellsB) + 1));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->orig_of.p, h->order.orig_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->new_of.p, h->order.new_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->r_ptr.p, ptr0.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        GORSE_HIP_CHECK(hipMemsetAsync(h->off.p, 0, ((size_t)cells + 1) * 4, h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->offA.p, 0, ((size_t)cellsA + 1) * 4, h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->offB.p, 0, ((size_t)cellsB + 1) * 4, h->stream));
         if (nnz > 0) {
             GORSE_HIP_CHECK(hipMemcpyAsync(h->dims.p, dims.data(), dims.size() * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(raw.p, indices + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->r_val.p, values + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
             const unsigned eg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(nnz, 256)));
             sparse::sparse_translate_kernel<<<dim3(eg), dim3(256), 0, h->stream>>>(raw.p, nnz, h->dims.p, h->Dc, h->r_cid.p);
+            const unsigned rg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(N, 4)));
+            // each arrangement: counts per (index, bucket) -> exclusive scan = the directory -> scatter through a cursor copy
             sparse::BuildArgs b;
             b.r_ptr = h->r_ptr.p, b.r_cid = h->r_cid.p, b.r_val = h->r_val.p, b.N = N, b.new_of = h->new_of.p;
-            b.ntiles = h->ntiles, b.logT = h->logT, b.cnt = h->off.p, b.post = h->post.p;
-            const unsigned rg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(N, 4)));
-            sparse::sparse_build_kernel<false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);  // counts per (index, tile)
-            GORSE_TRY(scan_exclusive(h->off.p, cells + 1, sums, h->stream));               // -> the directory
-            GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->off.p, ((size_t)cells + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
+            b.stride = h->ngroups, b.shift = h->logG, b.cnt = h->offA.p, b.post = h->postA.p;
+            sparse::sparse_build_kernel<false, false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
+            GORSE_TRY(scan_exclusive(h->offA.p, cellsA + 1, sums, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->offA.p, ((size_t)cellsA + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
             b.cnt = cursor.p;
-            sparse::sparse_build_kernel<true><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
+            sparse::sparse_build_kernel<true, false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
+            b.stride = 1 << h->logS, b.shift = h->logS, b.cnt = h->offB.p, b.post = h->postB.p;
+            sparse::sparse_build_kernel<false, true><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
+            GORSE_TRY(scan_exclusive(h->offB.p, cellsB + 1, sums, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->offB.p, ((size_t)cellsB + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
+            b.cnt = cursor.p;
+            sparse::sparse_build_kernel<true, true><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
             GORSE_HIP_CHECK(hipGetLastError());
         }
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the temporaries die with this scope
@@ -404,7 +437,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
-// 10 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1, entries, chunks taken 64 lists at once, their rounds, segments walked
+// 10 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1 (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
 // one list at a time, groups read back densely, groups read back by re-walking}; returns the number of work items
 extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out, int64_t cap) {
     if (!h) return -1;
@@ -414,11 +447,12 @@ extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint
     for (int64_t i = 0; i < n; i++) {
         const sparse::Trace &t = h->trace_host[(size_t)i];
         uint64_t *o = out + i * 10;
-        o[0] = t.t0, o[1] = t.t1, o[2] = (uint64_t)t.t, o[3] = (uint64_t)(t.stripe + 1), o[4] = t.entries;
+        o[0] = t.t0, o[1] = t.t1, o[2] = (uint64_t)t.t, o[3] = (uint64_t)(t.part + 1), o[4] = t.entries;
         o[5] = t.fast_chunks, o[6] = t.rounds, o[7] = t.slow_segments, o[8] = t.dense_groups, o[9] = t.sparse_groups;
     }
     return (int64_t)h->trace_host.size();
 }
 extern "C" void gorse_hip_test_set_sparse_tile(int32_t rows) { g_sparse_tile = rows; }
+extern "C" void gorse_hip_test_set_sparse_stripe_rows(int32_t rows) { g_sparse_stripe_rows = rows; }
 extern "C" void gorse_hip_test_set_sparse_split(int64_t entries) { g_sparse_split = entries; }
 extern "C" void gorse_hip_test_set_sparse_atomic(int32_t mode) { g_sparse_atomic = mode; }

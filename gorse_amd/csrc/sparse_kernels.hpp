@@ -6,31 +6,31 @@
 // trip: a 16,384-entry query was a 125 ms tail on one wave and the row-streaming path of the 64 longest queries took 11.6 s
 // of the 12.6 s pass, profiles/r02_a_kernel_stats_i2i.txt):
 //
-// * The stored rows are numbered longest first (scratch ids) and cut into TILES of T rows: rows [g*8T, (g+1)*8T) form a
-//   group, the row with scratch id sid belongs to stripe sid % 8 of its group, and tile 8g + s holds stripe s of group g
-//   (interleaving spreads the popular rows evenly over the 8 tiles of a group).  The posting list of every index is stored
-//   sorted by tile, with a directory off[index][tile] of where each tile's segment starts.
-// * One wave answers one query, one row GROUP at a time (the 8 tiles of a group are adjacent in every posting list), with
-//   the group's 8T accumulators in LDS: it walks the query's indices in ascending order and, for each, streams that index's
-//   segment of the group (8 bytes per posting, coalesced) into the accumulators with ds_add_f32.  A row occurs at most once
-//   per posting list, so the lanes of one instruction never collide, and the LDS executes one wave's instructions in issue
-//   order: every accumulator receives its products in ascending index order -- the float32 merge-order sparse dot of the
-//   oracle, bit for bit.  A group's results are read back either by a linear scan of its accumulators (dense groups) or
-//   from the list of rows whose accumulator was +0 before an add (sparse groups); both leave the accumulators zero.
-//   Nothing in the loop waits for memory: the (index, value) pairs, directory entries and postings of the next three
-//   visits are in flight while one is applied (an earlier version waited for each: 15 us per group and query,
-//   profiles/r02_e_probe_sparse_trace.txt).
-// * Outside the first groups a segment holds a posting or two, and one list per instruction would leave 60 lanes idle.
-//   There 64 lists go at once: every lane gathers the (at most 8) postings of ITS list's segment, the lanes stamp their
-//   rows in a byte-per-row tag array and read the stamps back -- a foreign stamp means two lists share a row and the order
-//   of their products matters, and only then the chunk falls back to one list at a time; otherwise all products are added
-//   by one ds_add_f32 per round.
-// * Queries with many entries are split over the 8 stripes (8 work items, one per stripe, each ranking its own tiles with T
-//   accumulators); sparse_merge_kernel joins the 8 partial rankings.  Work items are drawn longest first from one counter.
+// * The stored rows are numbered longest first (scratch ids).  ONE WAVE answers one work item with its accumulators in LDS:
+//   it walks the query's indices in ascending order and streams every index's postings (8 bytes each) into the accumulators
+//   with ds_add_f32.  A row occurs at most once per posting list, so the lanes of one instruction never collide, and the LDS
+//   executes one wave's instructions in issue order: every accumulator receives its products in ascending index order -- the
+//   float32 merge-order sparse dot of the oracle, bit for bit.
+// * The posting lists exist in two arrangements:
+//     A  sorted by row GROUP (G consecutive scratch ids, G accumulators in LDS): a query of ordinary length visits the groups
+//        one after the other, reading of every posting list the segment that falls into the group;
+//     B  sorted by row STRIPE (scratch id mod S, N / S accumulators in LDS): a LONG query is split into S work items, one per
+//        stripe, each of which walks every posting list of the query once, reading one contiguous segment of it; a merge
+//        kernel joins the S partial rankings.  (As group visits the longest query of the C3 shard took 186 ms on its own:
+//        49 groups x 1,820 chunks of scattered 8-byte reads, profiles/r02_f_probe_sparse_trace.txt.)
+// * 64 lists at once: where every list of a chunk contributes at most 8 postings, every lane gathers the postings of ITS
+//   list, the lanes stamp their rows in a byte-per-row tag array and read the stamps back -- a foreign stamp means two lists
+//   share a row and the order of their products matters; rounds of "everybody below the lowest loser, then the loser" keep
+//   that order (see apply_at_once).  Longer segments go one list at a time with their postings over the lanes.
+// * Nothing waits for memory: the (index, value) pairs, directory entries and postings of the next three visits are in flight
+//   while one is applied.
+// * A group / stripe is read back either by a scan of its accumulators (dense) or from the list of accumulators that were +0
+//   before an add (sparse); both leave the accumulators zero.
 //
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
-// well-defined answer whatever order the lanes append in.  Keys above the running threshold go to an LDS buffer of
-// 2*KP entries; when it overflows it is bitonic-sorted, cut to KP entries and the threshold becomes the k-th key.
+// well-defined answer whatever order the lanes append in.  Keys above the running threshold go to an LDS buffer of 2*KP
+// entries; when it overflows, the k-th largest key is found by bisection on the key bits (the keys sit in registers, one
+// ballot per key and bit), the keys below it are dropped and it becomes the threshold.  One sort at the end of the item.
 // The reference ranks ALL admissible documents (one sharing no index scores 0), cuts to topK and THEN drops Score == 0
 // (xvec.go:419-421), so zero-score documents use up slots: only the non-zero rows are ranked here, and the number of
 // results follows from the counts of positive / negative rows and the number of admissible rows (see `written`).
@@ -42,41 +42,36 @@
 namespace gorse {
 namespace sparse {
 
-constexpr int kBlock = 64;    // one wavefront per workgroup
-constexpr int kStripes = 8;   // tiles per row group = parts of a split query
-constexpr int kLogStripes = 3;
+constexpr int kBlock = 64;  // one wavefront per workgroup
+constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
 
 struct Posting {
-    int32_t loc;  // the row inside its group (scratch id mod 8T); a stripe's work item uses loc >> 3
+    int32_t loc;  // accumulator of the row: scratch id mod G (arrangement A) or scratch id / S (arrangement B)
     float val;
 };
-constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
+
+struct Work {
+    int32_t t;      // query of the call
+    int32_t part;   // -1 = the whole query over arrangement A, else stripe `part` of it over arrangement B
+    int32_t pslot;  // split queries: which block of partial rankings
+};
+
 // probe (gorse_hip_test_sparse_trace): what one work item did
 struct Trace {
     unsigned long long t0, t1;  // s_memrealtime (100 MHz) at its start / end
-    int32_t t, stripe;
+    int32_t t, part;
     uint32_t entries, fast_chunks, rounds, slow_segments, dense_groups, sparse_groups;
 };
 
-// scratch id <-> (tile, accumulator)
-__host__ __device__ inline int32_t tile_of(int64_t sid, int logT) {
-    return (int32_t)((sid >> (logT + kLogStripes)) << kLogStripes) + (int32_t)(sid & (kStripes - 1));
-}
-__host__ __device__ inline int32_t loc_of(int64_t sid, int logT) {
-    return (int32_t)(sid & (((int64_t)1 << (logT + kLogStripes)) - 1));
-}
-
-struct Work {
-    int32_t t;       // query of the call
-    int32_t stripe;  // -1 = all tiles, else the tiles 8g + stripe
-    int32_t pslot;   // split queries: which block of partial rankings
-};
-
 struct TileArgs {
-    // index
-    const uint32_t *off;  // Dc * ntiles + 1: segment (c, tile) = post[off[c * ntiles + tile], off[c * ntiles + tile + 1])
-    const Posting *post;
-    int32_t ntiles, logT;
+    // arrangement A: segment (c, g) = postA[offA[c * ngroups + g], offA[c * ngroups + g + 1]), rows g * G + loc
+    const uint32_t *offA;
+    const Posting *postA;
+    int32_t ngroups, logG;
+    // arrangement B: segment (c, s) = postB[offB[c * S + s], offB[c * S + s + 1]), rows loc * S + s
+    const uint32_t *offB;
+    const Posting *postB;
+    int32_t logS, naccB;  // S = 1 << logS stripes of naccB = ceil(N / S) rows
     int64_t N;
     const int32_t *orig_of, *new_of;  // scratch id <-> caller's row
     // queries: CSR rows q_first .. of (q_ptr, q_cid, q_val); q_cid = directory entry of the index or -1 (never stored)
@@ -90,7 +85,8 @@ struct TileArgs {
     int64_t n_admissible;     // number of admissible rows (N without a mask)
     const Work *work;
     int32_t n_work;
-    int32_t *next;  // work counter
+    int32_t *next;     // work counter
+    int32_t nacc_lds;  // accumulators the launch's LDS holds (G, or naccB rounded up to 64)
     int k;
     int32_t *out_idx;   // nq x k, padded with -1
     float *out_score;   // nq x k, padded with -inf
@@ -160,8 +156,47 @@ __device__ inline uint32_t wave_sum_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+// The buffer is full (CAP keys, all distinct): keep the k largest -- and, while they fit into KP slots, the keys that share
+// the k-th key's score -- and make the smallest kept key minus one the new threshold.  The keys sit in registers (CAP / 64 per
+// lane); the k-th largest is found bit by bit: a key bit is set in the answer when at least k keys are >= the trial.
+template <int KP>
+__device__ inline void cut_to_k(unsigned long long *s_buf, int k, int &bcnt, unsigned long long &thr, int lane) {
+    constexpr int CAP = 2 * KP, PER = CAP / kBlock;
+    unsigned long long key[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) key[j] = s_buf[j * kBlock + lane];
+    auto count_ge = [&](unsigned long long t) {
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) c += __popcll(__ballot(key[j] >= t));
+        return c;
+    };
+    unsigned long long kth = 0;
+    for (int b = 63; b >= 32; --b) {  // the score bits
+        const unsigned long long trial = kth | ((unsigned long long)1 << b);
+        if (count_ge(trial) >= k) kth = trial;
+    }
+    if (count_ge(kth) > KP)  // more equal scores than the buffer keeps: the row bits decide
+        for (int b = 31; b >= 0; --b) {
+            const unsigned long long trial = kth | ((unsigned long long)1 << b);
+            if (count_ge(trial) >= k) kth = trial;
+        }
+    __syncthreads();  // every lane holds its keys: the buffer can be rewritten
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const bool keep = key[j] >= kth;
+        const unsigned long long m = __ballot(keep);
+        if (keep) s_buf[base + lanes_below(m, lane)] = key[j];
+        base += __popcll(m);
+    }
+    __syncthreads();
+    bcnt = base;
+    thr = kth ? kth - 1 : 0;
+}
+
 // The wave's ranking buffer: lanes with want hand their key in; bcnt (slots in use) and thr (keys <= thr cannot be among the
-// k best) are wave-uniform.  After an overflow the KP best keys stay, sorted.
+// k best) are wave-uniform.
 template <int KP>
 __device__ inline void push(unsigned long long *s_buf, int k, int &bcnt, unsigned long long &thr, unsigned long long key, bool want,
                             int lane) {
@@ -178,10 +213,8 @@ __device__ inline void push(unsigned long long *s_buf, int k, int &bcnt, unsigne
             bcnt = total;
             break;
         }
-        __syncthreads();  // slots 0 .. CAP-1 are all written: keep the KP best
-        sort_desc<CAP>(s_buf, lane);
-        bcnt = KP;
-        thr = s_buf[k - 1];
+        __syncthreads();  // slots 0 .. CAP-1 are all written
+        cut_to_k<KP>(s_buf, k, bcnt, thr, lane);
         want = want && key > thr;
         m = __ballot(want);
     }
@@ -210,7 +243,8 @@ __device__ inline void write_result(const unsigned long long *s_buf, int cnt, in
 
 // ATOMIC: ds_add_rtn_f32 / ds_add_f32.  !ATOMIC: load / add / store by the same wave, for inputs whose partial sums may be
 // subnormal (the LDS adder's handling of those is not relied upon); same order, same bits, slower.
-// Returns the accumulator's value BEFORE the add (exactly +0 = the row had not been reached, or its sum is back at zero).
+// acc_add_old returns the accumulator's value BEFORE the add (exactly +0 = the row had not been reached, or its sum is back
+// at zero).
 template <bool ATOMIC>
 __device__ inline float acc_add_old(float *acc, int32_t i, float term) {
     if (ATOMIC) return __hip_atomic_fetch_add(&acc[i], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -232,9 +266,9 @@ __device__ inline float acc_take(float *acc, int32_t i) {
     return __hip_atomic_exchange(&acc[i], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// What a lane holds of one VISIT = (group, chunk of 64 of the query's indices): its index's directory entry and value, the
-// segment [s, e) of that index's posting list inside the group (or stripe tile), and the first kGather postings of it.  The
-// three parts are loaded one visit apart (see the pipeline in sparse_tile_kernel), so that no load is waited for.
+// What a lane holds of one VISIT = (group or stripe, chunk of 64 of the query's indices): its index's directory entry and value,
+// the segment [s, e) of that index's posting list, and the first kGather postings of it.  The three parts are loaded one visit
+// apart (see the pipeline in sparse_tile_kernel), so that no load is waited for.
 struct Visit {
     int32_t cid;
     float qv;
@@ -242,12 +276,21 @@ struct Visit {
     Posting P[kGather];
 };
 
-// the group's state while it accumulates
+// the group's / stripe's state while it accumulates
 struct GroupState {
     uint32_t walked;  // postings applied
-    int tcnt;         // rows on the touched list
-    bool slow;        // a chunk went one list at a time: the group is read back densely
+    int tcnt;         // entries of the touched list
 };
+
+// appends the accumulators of the lanes with `add` to the touched list (entries past its capacity are counted, not stored:
+// the read-back then scans the accumulators instead)
+__device__ inline void touch(uint16_t *touched, int tcap, GroupState &gs, bool add, int i, int lane) {
+    const unsigned long long m = __ballot(add);
+    if (!m) return;
+    const int at = gs.tcnt + lanes_below(m, lane);
+    if (add && at < tcap) touched[at] = (uint16_t)i;
+    gs.tcnt += __popcll(m);
+}
 
 // 64 lists at once (every segment of the visit has at most kGather postings, already in v.P).
 // Rounds: every pending lane stamps the rows of its list with its lane number and reads the stamps back; a lane that finds a
@@ -258,8 +301,8 @@ struct GroupState {
 // Rows whose accumulator was +0 before the add go on the touched list (a sum that returns to zero and is reached again is
 // listed twice; the read-back takes it once).
 template <bool ATOMIC>
-__device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_t *tag, uint16_t *touched, int tcap, int shift,
-                                     int lane, GroupState &gs, Trace &tr) {
+__device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_t *tag, uint16_t *touched, int tcap, int lane,
+                                     GroupState &gs, Trace &tr) {
     const uint32_t len = v.e - v.s;
     bool pending = len > 0;
     tr.fast_chunks++;
@@ -267,32 +310,32 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_
         tr.rounds++;
 #pragma unroll
         for (int j = 0; j < kGather; j++)
-            if (pending && (uint32_t)j < len) tag[v.P[j].loc >> shift] = (uint8_t)lane;
+            if (pending && (uint32_t)j < len) tag[v.P[j].loc] = (uint8_t)lane;
+        uint32_t stamp[kGather];
+#pragma unroll
+        for (int j = 0; j < kGather; j++) {
+            stamp[j] = (uint32_t)lane;
+            if (pending && (uint32_t)j < len) stamp[j] = tag[v.P[j].loc];
+        }
         bool lost = false;
 #pragma unroll
-        for (int j = 0; j < kGather; j++)
-            if (pending && (uint32_t)j < len) lost = lost || tag[v.P[j].loc >> shift] != (uint8_t)lane;
+        for (int j = 0; j < kGather; j++) lost = lost | (stamp[j] != (uint32_t)lane);
         const unsigned long long ml = __ballot(lost);
         const int lim = ml ? __ffsll((long long)ml) - 1 : 64;
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {  // the lanes below lim together, then lane lim alone
-            const bool go = pending && (pass == 0 ? lane < lim : lane == lim);
             if (pass == 1 && !ml) break;
+            const bool go = pending && (pass == 0 ? lane < lim : lane == lim);
+            float old[kGather];
 #pragma unroll
             for (int j = 0; j < kGather; j++) {
-                const bool have = go && (uint32_t)j < len;
-                const unsigned long long mh = __ballot(have);
-                if (!mh) break;
-                const int i = v.P[j].loc >> shift;
-                float old = 1.0f;
-                if (have) old = acc_add_old<ATOMIC>(acc, i, __fmul_rn(v.qv, v.P[j].val));
-                const bool first = have && __float_as_uint(old) == 0;
-                const unsigned long long mf = __ballot(first);
-                if (mf) {
-                    const int at = gs.tcnt + lanes_below(mf, lane);
-                    if (first && at < tcap) touched[at] = (uint16_t)i;
-                    gs.tcnt += __popcll(mf);
-                }
+                old[j] = 1.0f;
+                if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, v.P[j].loc, __fmul_rn(v.qv, v.P[j].val));
+            }
+#pragma unroll
+            for (int j = 0; j < kGather; j++) {
+                if (!__ballot(go && (uint32_t)j < len)) break;
+                touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, v.P[j].loc, lane);
             }
         }
         if (!ml) break;
@@ -302,12 +345,12 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_
     gs.walked += wave_sum_u32(len);
 }
 
-// One list at a time, its postings over the lanes (segments longer than kGather: the popular rows' groups).  The first 64
-// postings of the next THREE segments are in flight while one is applied (the compiler keeps loads behind the LDS atomics of
-// the program order, so the look-ahead is spelled out).  No touched list: such a group is read back densely.
+// One list at a time, its postings over the lanes (segments longer than kGather).  The first 64 postings of the next THREE
+// segments are in flight while one is applied (the compiler keeps loads behind the LDS atomics of the program order, so the
+// look-ahead is spelled out).  Every accumulator reached goes on the touched list (no +0 test: the add returns nothing here).
 template <bool ATOMIC>
-__device__ inline void apply_one_by_one(const Posting *__restrict__ post, const Visit &v, float *acc, int shift, int lane, GroupState &gs,
-                                        Trace &tr) {
+__device__ inline void apply_one_by_one(const Posting *__restrict__ post, const Visit &v, float *acc, uint16_t *touched, int tcap,
+                                        int lane, GroupState &gs, Trace &tr) {
     struct Seg {
         uint32_t sl, el;  // wave-uniform; el == sl: none
         float ql;
@@ -330,7 +373,11 @@ __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const 
     next(r2);
     while (r0.el > r0.sl) {
         next(r3);
-        if (r0.sl + lane < r0.el) acc_add<ATOMIC>(acc, r0.P.loc >> shift, __fmul_rn(r0.ql, r0.P.val));
+        {
+            const bool have = r0.sl + lane < r0.el;
+            if (have) acc_add<ATOMIC>(acc, r0.P.loc, __fmul_rn(r0.ql, r0.P.val));
+            touch(touched, tcap, gs, have, r0.P.loc, lane);
+        }
         for (uint32_t p = r0.sl + kBlock; p < r0.el; p += 4 * kBlock) {  // long segments: four loads in flight
             Posting x[4];
             bool have[4];
@@ -342,29 +389,29 @@ __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const 
                 if (have[j]) x[j] = post[at];
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (have[j]) acc_add<ATOMIC>(acc, x[j].loc >> shift, __fmul_rn(r0.ql, x[j].val));
+            for (int j = 0; j < 4; j++) {
+                if (have[j]) acc_add<ATOMIC>(acc, x[j].loc, __fmul_rn(r0.ql, x[j].val));
+                touch(touched, tcap, gs, have[j], x[j].loc, lane);
+            }
         }
         gs.walked += r0.el - r0.sl;
         tr.slow_segments++;
         r0 = r1, r1 = r2, r2 = r3;
     }
-    gs.slow = true;
 }
 
 template <int KP, bool ATOMIC>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
     extern __shared__ __align__(16) unsigned char s_mem[];
-    const int G = kStripes << a.logT;  // rows per group
+    const int NL = a.nacc_lds;  // accumulators in LDS, a multiple of 64
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(s_mem);
     float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
-    volatile uint8_t *tag = s_mem + (size_t)CAP * 8 + (size_t)G * 4;
-    uint16_t *touched = reinterpret_cast<uint16_t *>(s_mem + (size_t)CAP * 8 + (size_t)G * 5);  // G / 4 entries
+    volatile uint8_t *tag = s_mem + (size_t)CAP * 8 + (size_t)NL * 4;
+    uint16_t *touched = reinterpret_cast<uint16_t *>(s_mem + (size_t)CAP * 8 + (size_t)NL * 5);  // NL / 4 entries
     const int lane = threadIdx.x;
-    for (int i = lane; i < G; i += kBlock) acc[i] = 0.0f;
+    for (int i = lane; i < NL; i += kBlock) acc[i] = 0.0f;
     __syncthreads();
-    const int ngroups = a.ntiles >> kLogStripes;
     for (;;) {
         int w = 0;
         if (lane == 0) w = atomicAdd(a.next, 1);
@@ -383,14 +430,16 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         unsigned long long walked_q = 0;
         Trace tr{};
         if (a.trace) tr.t0 = __builtin_amdgcn_s_memrealtime();
-        // the whole query (stripe < 0): one group = 8 adjacent tiles at a time, 8T accumulators; one stripe of a split
-        // query: tile 8g + stripe of every group, T accumulators (accumulator = loc >> 3)
-        const int shift = wk.stripe < 0 ? 0 : kLogStripes;
-        const int first = wk.stripe < 0 ? 0 : wk.stripe, width = wk.stripe < 0 ? kStripes : 1;
-        const int nacc = G >> shift;
+        // the view of this item: arrangement A (the groups one after the other) or one stripe of arrangement B
+        const bool whole = wk.part < 0;
+        const uint32_t *off = whole ? a.offA : a.offB;
+        const Posting *post = whole ? a.postA : a.postB;
+        const int dir_stride = whole ? a.ngroups : (1 << a.logS);
+        const int nviews = whole ? a.ngroups : 1;
+        const int nacc = whole ? (1 << a.logG) : ((a.naccB + kBlock - 1) / kBlock) * kBlock;
         const int tcap = nacc >> 2;
         const int64_t nch = (L + kBlock - 1) / kBlock;  // chunks of 64 indices
-        const int64_t V = nch * ngroups;                // visits, group-major
+        const int64_t V = nch * nviews;                 // visits, view-major
         // The pipeline: while visit v is applied, the postings of v + 1, the directory entries of v + 2 and the (index, value)
         // pairs of v + 3 are in flight.  A query of at most 64 entries has one chunk: its pairs stay in registers.
         const bool small = nch <= 1;
@@ -400,9 +449,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             cid0 = a.q_cid[qs + lane];
             qv0 = a.q_val[qs + lane];
         }
-        // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (group, chunk) counters
+        // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (view, chunk) counters
         int64_t c1 = 0, c2 = 0;
-        int g2 = 0;
+        int g2 = whole ? 0 : wk.part;
         auto stage1 = [&](int64_t v, Visit &x) {
             x.cid = -1, x.qv = 0.0f;
             if (v >= V) return;
@@ -421,8 +470,8 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             x.s = 0, x.e = 0;
             if (v >= V) return;
             if (x.cid >= 0) {
-                const uint32_t *o = a.off + (size_t)x.cid * a.ntiles + g2 * kStripes + first;
-                x.s = o[0], x.e = o[width];
+                const uint32_t *o = off + (size_t)x.cid * dir_stride + g2;
+                x.s = o[0], x.e = o[1];
             }
             if (++c2 == nch) {
                 c2 = 0;
@@ -434,7 +483,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
 #pragma unroll
             for (int j = 0; j < kGather; j++) {
                 x.P[j] = Posting{0, 0.0f};
-                if ((uint32_t)j < len) x.P[j] = a.post[x.s + j];
+                if ((uint32_t)j < len) x.P[j] = post[x.s + j];
             }
         };
         Visit v0, v1, v2, v3;
@@ -444,8 +493,8 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         stage2(0, v0);
         stage2(1, v1);
         stage3(v0);
-        GroupState gs{0, 0, false};
-        int64_t c = 0;  // chunk of visit v inside its group
+        GroupState gs{0, 0};
+        int64_t c = 0;  // chunk of visit v inside its view
         int g = 0;
         for (int64_t v = 0; v < V; v++) {
             stage1(v + 3, v3);
@@ -455,18 +504,17 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 const uint32_t len = v0.e - v0.s;
                 if (__ballot(len > 0)) {
                     if (!__ballot(len > (uint32_t)kGather))
-                        apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, shift, lane, gs, tr);
+                        apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, lane, gs, tr);
                     else
-                        apply_one_by_one<ATOMIC>(a.post, v0, acc, shift, lane, gs, tr);
+                        apply_one_by_one<ATOMIC>(post, v0, acc, touched, tcap, lane, gs, tr);
                 }
             }
-            if (++c == nch) {  // the group is complete: read it back
+            if (++c == nch) {  // the view is complete: read it back
                 if (gs.walked > 0) {
-                    const int64_t sid0 = (int64_t)g * G + (wk.stripe < 0 ? 0 : wk.stripe);
                     auto consider = [&](bool have, int32_t i, float x) {
                         have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
                         if (!__ballot(have)) return;
-                        const int64_t sid = sid0 + ((int64_t)i << shift);
+                        const int64_t sid = whole ? ((int64_t)g << a.logG) + i : ((int64_t)i << a.logS) + wk.part;
                         my_hit += have;
                         have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
                         const uint32_t ord = score_ord(x);
@@ -477,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         const unsigned long long key = cand ? make_key(ord, a.orig_of[sid]) : 0;
                         push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
                     };
-                    if (gs.slow || (int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
+                    if ((int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
                         tr.dense_groups++;
                         for (int i = lane; i < nacc; i += kBlock) {
                             const float x = acc[i];
@@ -489,13 +537,13 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {
                             const bool have = i0 + lane < gs.tcnt;
                             const int i = have ? (int)touched[i0 + lane] : 0;
-                            const float x = have ? acc_take(acc, i) : 0.0f;  // a row listed twice: the first taker gets it
+                            const float x = have ? acc_take(acc, i) : 0.0f;  // an accumulator listed twice: the first taker gets it
                             consider(have, i, x);
                         }
                     }
                     walked_q += gs.walked;
                 }
-                gs = GroupState{0, 0, false};
+                gs = GroupState{0, 0};
                 c = 0;
                 g++;
             }
@@ -503,12 +551,12 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         }
         const long long pos = wave_sum(my_pos), neg = wave_sum(my_neg), hit = wave_sum(my_hit);
         finish<KP>(s_buf, bcnt, lane);
-        if (wk.stripe < 0) {
+        if (whole) {
             const bool ex_counts = ex_in && (!a.mask_sid || a.mask_sid[ex_sid]);
             const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
             write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         } else {
-            const size_t part = (size_t)wk.pslot * kStripes + wk.stripe;
+            const size_t part = ((size_t)wk.pslot << a.logS) + wk.part;
             for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
             if (lane == 0) {
                 a.part_cnt[part * 2] = (int32_t)pos;
@@ -521,17 +569,17 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         }
         if (a.trace && lane == 0) {
             tr.t1 = __builtin_amdgcn_s_memrealtime();
-            tr.t = wk.t, tr.stripe = wk.stripe, tr.entries = (uint32_t)L;
+            tr.t = wk.t, tr.part = wk.part, tr.entries = (uint32_t)L;
             a.trace[w] = tr;
         }
         __syncthreads();  // s_buf is reused by the next work item
     }
 }
 
-// the eight partial rankings of a split query -> its result row
+// the partial rankings of a split query (one per stripe) -> its result row
 struct MergeArgs {
     const int32_t *split_t;  // query of every block of partial rankings
-    int32_t n_split;
+    int32_t n_split, nparts;
     const unsigned long long *part_keys;
     const int32_t *part_cnt;
     int64_t q_first, N;
@@ -556,8 +604,8 @@ __global__ __launch_bounds__(kBlock) void sparse_merge_kernel(MergeArgs a) {
         int bcnt = 0;
         unsigned long long thr = 0;
         long long pos = 0, neg = 0;
-        for (int s = 0; s < kStripes; s++) {
-            const size_t part = (size_t)b * kStripes + s;
+        for (int s = 0; s < a.nparts; s++) {
+            const size_t part = (size_t)b * a.nparts + s;
             pos += a.part_cnt[part * 2];
             neg += a.part_cnt[part * 2 + 1];
             for (int i = 0; i < KP; i += kBlock) {
@@ -601,21 +649,24 @@ struct BuildArgs {
     const float *r_val;
     int64_t N;
     const int32_t *new_of;  // scratch id of every row
-    int32_t ntiles, logT;
-    uint32_t *cnt;  // Dc * ntiles (+ 1): entries per (index, tile); the cursor of the scatter pass afterwards
+    int32_t stride;         // directory entries per index: groups (arrangement A) or stripes (B)
+    int32_t shift;          // A: log2 G (bucket = sid >> shift, loc = sid mod G); B: log2 S (bucket = sid mod S, loc = sid >> shift)
+    uint32_t *cnt;  // Dc * stride (+ 1): entries per (index, bucket); the cursor of the scatter pass afterwards
     Posting *post;
 };
 
-// one wave per stored row; SCATTER = false counts the entries of every (index, tile), true places them
-template <bool SCATTER>
+// one wave per stored row; SCATTER = false counts the entries of every (index, bucket), true places them; BY_STRIPE = arrangement B
+template <bool SCATTER, bool BY_STRIPE>
 __global__ __launch_bounds__(256) void sparse_build_kernel(BuildArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t low = ((int64_t)1 << a.shift) - 1;
     for (int64_t r = wave; r < a.N; r += nwaves) {
         const int64_t sid = a.new_of[r];
-        const int32_t tile = tile_of(sid, a.logT), loc = loc_of(sid, a.logT);
+        const int32_t bucket = BY_STRIPE ? (int32_t)(sid & low) : (int32_t)(sid >> a.shift);
+        const int32_t loc = BY_STRIPE ? (int32_t)(sid >> a.shift) : (int32_t)(sid & low);
         for (int64_t e = a.r_ptr[r] + lane; e < a.r_ptr[r + 1]; e += 64) {
-            uint32_t *c = a.cnt + (size_t)a.r_cid[e] * a.ntiles + tile;
+            uint32_t *c = a.cnt + (size_t)a.r_cid[e] * a.stride + bucket;
             if (SCATTER)
                 a.post[atomicAdd(c, 1u)] = Posting{loc, a.r_val[e]};
             else

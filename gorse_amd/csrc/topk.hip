@@ -55,8 +55,8 @@ __global__ __launch_bounds__(kBlock) void dist_kernel(const float *__restrict__ 
         for (int e = lane; e < d; e += kGroup) sx[e] = X[i * d + e];
         __builtin_amdgcn_wave_barrier();
         float r;
-        if (metric == GORSE_METRIC_EUCLIDEAN) {
-            r = euclid512_lds(sq, sx, vs, lane);
+        if (metric == GORSE_METRIC_EUCLIDEAN || metric == kMetricEuclidBf16) {
+            r = euclid_any_lds(metric, sq, sx, vs, lane);
         } else {
             float ab = dot512_lds(sq, sx, vs, lane);
             if (metric == GORSE_METRIC_NEG_DOT)
@@ -133,7 +133,7 @@ int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int 
     int64_t bx = std::min<int64_t>(ceil_div(h->N, kGroupsPerBlock), 1024);
     int tok = h->prof.begin(GORSE_PROF_TOPK_SCORE, h->stream);
     dist_kernel<<<dim3((unsigned)bx, (unsigned)nq), dim3(kBlock), (size_t)(1 + kGroupsPerBlock) * d * sizeof(float),
-                  h->stream>>>(h->X.p, h->norm2.p, h->qbuf.p, h->qnorm.p, h->N, d, h->metric, h->dist.p);
+                  h->stream>>>(h->X.p, h->norm2.p, h->qbuf.p, h->qnorm.p, h->N, d, h->kernel_metric(), h->dist.p);
     GORSE_HIP_CHECK(hipGetLastError());
     h->prof.end(tok, h->stream);
     tok = h->prof.begin(GORSE_PROF_TOPK_RESCORE, h->stream);
@@ -172,7 +172,9 @@ extern "C" int32_t gorse_topk_create(gorse_topk **out, int32_t device, int64_t N
     if (N > INT32_MAX) return fail(GORSE_ERR_INVALID, "N must fit int32");
     if (d > 4096) return fail(GORSE_ERR_INVALID, "d %d > 4096 unsupported", d);
     if (dtype != GORSE_DTYPE_F32 && dtype != GORSE_DTYPE_BF16) return fail(GORSE_ERR_INVALID, "unknown dtype %d", dtype);
-    if (metric < 0 || metric > 2) return fail(GORSE_ERR_INVALID, "unknown metric %d", metric);
+    if (metric < 0 || metric > 3) return fail(GORSE_ERR_INVALID, "unknown metric %d", metric);
+    if (metric == GORSE_METRIC_EUCLIDEAN_BF16 && dtype != GORSE_DTYPE_BF16)
+        return fail(GORSE_ERR_INVALID, "GORSE_METRIC_EUCLIDEAN_BF16 (bfloats.Euclidean) needs a bf16 index");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
@@ -183,7 +185,8 @@ extern "C" int32_t gorse_topk_create(gorse_topk **out, int32_t device, int64_t N
     h->N = N;
     h->d = d;
     h->dtype = dtype;
-    h->metric = metric;
+    h->metric = metric == GORSE_METRIC_EUCLIDEAN_BF16 ? GORSE_METRIC_EUCLIDEAN : metric;
+    h->bf16_order = metric == GORSE_METRIC_EUCLIDEAN_BF16;
     int32_t rc = [&]() -> int32_t {
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));

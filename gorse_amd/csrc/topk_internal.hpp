@@ -45,6 +45,8 @@ struct gorse_topk {
     gorse::DevBuf<float> rp_sdst;
     gorse::DevBuf<unsigned long long> sweep_prof;  // probe: phase counters of the instrumented sweep
     gorse::KernelProfile prof{GORSE_PROF_TOPK_NCLASSES};
+    bool bf16_order = false;  // GORSE_METRIC_EUCLIDEAN_BF16: metric is kept as GORSE_METRIC_EUCLIDEAN, the distance kernels get id 3
+    int kernel_metric() const { return bf16_order ? 3 : metric; }
     int64_t n_fallback = 0, n_tie = 0, n_resweep = 0;  // of the last search: path A rows, tie replays, warm starts swept again
     gorse::DevBuf<float> f0, f1;                       // warm-start thresholds of a chunk (topk_mfma_search): pilot, pre-pilot
     int32_t use() const {
@@ -74,6 +76,33 @@ __device__ __forceinline__ float euclid512_lds(const float *a, const float *b, c
         sum = fmaf(v, v, sum);
     }
     return sqrtf(sum);
+}
+
+// bfloats.Euclidean (squared part) in the order of the reference's AVX512BW kernel (common/bfloats/src/bfloats_avx512.c:26-59 as
+// shipped in bfloats_avx512.s, restated by the oracle's orc_bf16_euclidean): rows are the bf16 values expanded by << 16;
+// sixteen partial sums with UNFUSED multiply + add, the partials added SEQUENTIALLY (a vaddss chain, not the shuffle tree of
+// floats.Euclidean), the n % 16 tail one element at a time with a fused multiply-add.
+__device__ __forceinline__ float euclid_bf16_lds(const float *a, const float *b, int d, int lane) {
+    const int nfull = d / 16;
+    float acc = 0.0f;
+    for (int c = 0; c < nfull; c++) {
+        const float v = a[16 * c + lane] - b[16 * c + lane];
+        acc = acc + v * v;  // -ffp-contract=off: two roundings, as vmulps + vaddps
+    }
+    float sum = 0.0f;
+    const int base = threadIdx.x & ~15;  // first lane of this 16-lane group inside its wave
+#pragma unroll
+    for (int l = 0; l < 16; l++) sum = sum + __shfl(acc, (base & 63) + l, 64);
+    for (int e = 16 * nfull; e < d; e++) {
+        const float v = a[e] - b[e];
+        sum = fmaf(v, v, sum);
+    }
+    return sqrtf(sum);
+}
+// the distance of `metric` (GORSE_METRIC_EUCLIDEAN or the kernels' own id 3 = bfloats order) for rows staged in LDS
+constexpr int kMetricEuclidBf16 = 3;
+__device__ __forceinline__ float euclid_any_lds(int metric, const float *a, const float *b, const VecShape &vs, int lane) {
+    return metric == kMetricEuclidBf16 ? euclid_bf16_lds(a, b, vs.d, lane) : euclid512_lds(a, b, vs, lane);
 }
 
 // topk.hip

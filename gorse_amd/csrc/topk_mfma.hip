@@ -547,8 +547,8 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
         for (int e = lane; e < d; e += kGroup) row[e] = p.X[i * d + e];
         __builtin_amdgcn_wave_barrier();
         float r;
-        if (p.metric == GORSE_METRIC_EUCLIDEAN) {
-            r = euclid512_lds(sq, row, vs, lane);
+        if (p.metric == GORSE_METRIC_EUCLIDEAN || p.metric == kMetricEuclidBf16) {
+            r = euclid_any_lds(p.metric, sq, row, vs, lane);
         } else {
             const float ab = dot512_lds(sq, row, vs, lane);
             if (p.metric == GORSE_METRIC_NEG_DOT)
@@ -681,8 +681,8 @@ __global__ __launch_bounds__(kBlock) void topk_tie_sort_kernel(ReplayParams p) {
         for (int e = lane; e < d; e += kGroup) xr[e] = p.X[i * d + e];
         __builtin_amdgcn_wave_barrier();
         float r;
-        if (p.metric == GORSE_METRIC_EUCLIDEAN) {
-            r = euclid512_lds(sq, xr, vs, lane);
+        if (p.metric == GORSE_METRIC_EUCLIDEAN || p.metric == kMetricEuclidBf16) {
+            r = euclid_any_lds(p.metric, sq, xr, vs, lane);
         } else {
             const float ab = dot512_lds(sq, xr, vs, lane);
             if (p.metric == GORSE_METRIC_NEG_DOT)
@@ -952,19 +952,6 @@ __global__ void gather_pos_kernel(const uint16_t *__restrict__ op, const float *
     uint4 *o = reinterpret_cast<uint4 *>(op_out + t * kpad);
     for (int e = threadIdx.x; e < kpad / 8; e += blockDim.x) o[e] = s[e];
     if (threadIdx.x == 0) margin_out[t] = margin[src];
-}
-
-// lists of the re-swept queries back to their places: list t of (src, src_cnt, src_flag) -> query pos[t] of the chunk
-__global__ void scatter_lists_kernel(const int32_t *__restrict__ pos, const uint2 *__restrict__ src, const int32_t *__restrict__ src_cnt,
-                                     const uint8_t *__restrict__ src_flag, uint2 *__restrict__ dst, int32_t *__restrict__ dst_cnt,
-                                     uint8_t *__restrict__ dst_flag) {
-    const int64_t t = blockIdx.x, q = pos[t];
-    const int n = src_flag[t] ? 0 : src_cnt[t];
-    for (int e = threadIdx.x; e < n; e += blockDim.x) dst[q * kCap + e] = src[t * kCap + e];
-    if (threadIdx.x == 0) {
-        dst_cnt[q] = n;
-        dst_flag[q] = src_flag[t];
-    }
 }
 
 // ---- operand construction ------------------------------------------------------------------------------
@@ -1285,7 +1272,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
         // among the true kth - 1 best, that score is below the kth best of ALL rows unless X >= j -- j is chosen for a
         // tail of ~1e-3 -- and about 16 j rows lie above it.  The main sweep starts there and VERIFIES it (compact_query
-        // flags a query whose K-th-best bound does not reach its threshold); those few queries are swept again from -inf.
+        // flags a query whose K-th-best bound does not reach its threshold); those few queries join the tie queries' stage.
         const int pilot_stride = 16;
         // probe / test switches: bit 8 = no warm start, bit 9 = warm start whatever N, bit 10 = a pilot kth of 2 (thresholds
         // far too high: most queries fail the verification and are swept again)
@@ -1321,35 +1308,9 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             sp.vote = (g_topk_variant & 4096) ? 1 : 0;  // variant bit 12: lane-mask candidate path (measured slower: r02_f)
         }
         GORSE_TRY(dispatch_sweep(h, sp, scale, false));
-        if (warm) {  // the queries whose warm start could not be verified: gathered, swept from -inf, lists put back
-            GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
-            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-            std::vector<int32_t> redo;
-            for (int64_t t = 0; t < m; t++)
-                if (flags[t] == 2) redo.push_back((int32_t)t);
-            h->n_resweep += (int64_t)redo.size();
-            for (size_t r0 = 0; r0 < redo.size(); r0 += (size_t)kReplayChunk) {
-                const int64_t m2 = std::min<int64_t>(kReplayChunk, (int64_t)(redo.size() - r0));
-                GORSE_TRY(h->rp_pos.ensure((size_t)m2));
-                GORSE_TRY(h->rp_op.ensure((size_t)m2 * kpad));
-                GORSE_TRY(h->rp_margin.ensure((size_t)m2));
-                GORSE_TRY(h->rp_cbuf.ensure((size_t)m2 * kCap));
-                GORSE_TRY(h->rp_ccnt.ensure((size_t)m2));
-                GORSE_TRY(h->rp_flag.ensure((size_t)m2));
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_pos.p, redo.data() + r0, (size_t)m2 * 4, hipMemcpyHostToDevice, h->stream));
-                gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, h->rp_pos.p, kpad,
-                                                                                 h->rp_op.p, h->rp_margin.p);
-                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, (size_t)m2, h->stream));
-                SweepParams rp2 = sp;
-                rp2.B = h->rp_op.p, rp2.qmargin = h->rp_margin.p, rp2.cbuf = h->rp_cbuf.p, rp2.ccnt = h->rp_ccnt.p;
-                rp2.cflag = h->rp_flag.p, rp2.f0 = nullptr, rp2.vote = 0, rp2.nq = m2;
-                GORSE_TRY(dispatch_sweep(h, rp2, scale, false));
-                scatter_lists_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(h->rp_pos.p, h->rp_cbuf.p, h->rp_ccnt.p, h->rp_flag.p,
-                                                                                    h->cbuf.p, h->ccnt.p, h->cflag.p);
-                GORSE_HIP_CHECK(hipGetLastError());
-                GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // `redo` is read by the upload until here
-            }
-        }
+        // The queries whose warm start failed its verification carry flag 2: topk_rescore_kernel leaves flagged queries alone
+        // and stage 2 below (history sweep from -inf + literal replay) answers them together with the tie queries -- a sweep
+        // of their own would cost one workgroup a full pass over the rows (48 ms for 86 queries, profiles/r02_h_*).
         h->prof.end(tok, h->stream);
         RescoreParams rp;
         rp.X = h->X.p;
@@ -1362,7 +1323,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         rp.ccnt = h->ccnt.p;
         rp.cflag = h->cflag.p;
         rp.d = d;
-        rp.metric = h->metric;
+        rp.metric = h->kernel_metric();
         rp.k = k;
         rp.prune0 = prune0;
         rp.expect = expect;
@@ -1378,7 +1339,10 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         std::vector<int64_t> fb;  // queries the sweep + rescoring could not decide (ties in the top k+1, NaN, overflow)
         for (int64_t t = 0; t < m; t++)
-            if (flags[t]) fb.push_back(t);
+            if (flags[t]) {
+                fb.push_back(t);
+                h->n_resweep += flags[t] == 2;
+            }
         auto stored_id = [&](int64_t t) -> int64_t {
             return by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
         };
@@ -1441,7 +1405,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 pp.cflag = h->rp_flag.p;
                 pp.N = h->N;
                 pp.d = d;
-                pp.metric = h->metric;
+                pp.metric = h->kernel_metric();
                 pp.k = k;
                 pp.prune0 = prune0;
                 pp.out_idx = h->res_idx.p;

@@ -59,6 +59,9 @@ extern "C" {
 #define GORSE_METRIC_NEG_DOT 0  /* distance = -floats.Dot        (logics/cf.go:32-34)                     */
 #define GORSE_METRIC_EUCLIDEAN 1 /* distance = floats.Euclidean  (common/ann/ann_test.go)                  */
 #define GORSE_METRIC_COSINE 2   /* distance = 1 - a.b/(|a||b|)   (storage/vectors/database.go:29-33)      */
+#define GORSE_METRIC_EUCLIDEAN_BF16 3 /* distance = bfloats.Euclidean (common/bfloats/bfloats.go:49-57; the summation order
+                                       * of src/bfloats_avx512.c:26-59: 16 unfused partials added one after the other, fused
+                                       * scalar tail); bf16 indexes only                                                    */
 
 typedef struct gorse_mf gorse_mf;     /* one matrix-factorisation model resident on one GPU */
 typedef struct gorse_topk gorse_topk; /* one exact nearest-neighbour index resident on one GPU */

@@ -51,10 +51,13 @@ int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/
 /* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
-/* rows per tile of a handle created AFTERWARDS: a power of two in 64 .. 2048; 0 = chosen from N (512 up to 256K rows).
- * A workgroup holds the accumulators of a row group = 8 tiles: 40 bytes of LDS per tile row. */
+/* rows per group of a handle created AFTERWARDS (arrangement A of the posting lists, csrc/sparse_kernels.hpp): a power of two
+ * in 256 .. 16384; 0 = 4096.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);
-/* queries with more than `entries` entries are answered by eight work items (one per row stripe) and a merge instead of one
+/* most rows per stripe of arrangement B of a handle created AFTERWARDS (power of two; 0 = 8192): the number of stripes -- and
+ * of work items a long query is split into -- follows from it. */
+void gorse_hip_test_set_sparse_stripe_rows(int32_t rows);
+/* queries with more than `entries` entries are answered by one work item per row stripe and a merge instead of one item
  * (default 2048; <= 0 = never): lets small test inputs take that path. */
 void gorse_hip_test_set_sparse_split(int64_t entries);
 /* how products reach the LDS accumulators: 1 = ds_add_f32 (no return value, no wait), 0 = load / add / store by the same

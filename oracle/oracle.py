@@ -16,7 +16,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ISA_GO, ISA_AVX, ISA_AVX512 = 0, 1, 2
-METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE = 0, 1, 2
+METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_EUCLIDEAN_BF16 = 0, 1, 2, 3
 M_NDCG, M_PRECISION, M_RECALL, M_HR, M_MAP, M_MRR = range(6)
 
 _f32p = C.POINTER(C.c_float)

@@ -67,12 +67,12 @@ def prof(name, U, I, nnz, d):
     plain = (time.perf_counter() - t0) / 3
     print("%-18s epoch without stamps %.2f ms" % (name, plain * 1e3), flush=True)
     for side, label in ((0, "user rows"), (1, "item rows (short)")):
-        a, m, s, rows, ent, tot, waves = c[8 * side:8 * side + 7]
+        a, m, s, rows, ent, tot, waves, ld = c[8 * side:8 * side + 8]
         waves = max(waves, 1)
         print("%-18s %-18s rows %8d entries %10d | per wave: kernel %.3e ticks = accumulate %.1f%% + M to LDS %.1f%% + solve %.1f%% "
-              "| per row: accumulate %.0f, M %.0f, solve %.0f ticks; %.1f entries per row (epoch with stamps %.2f ms)"
+              "| per row: accumulate %.0f, M %.0f, solve %.0f ticks (of which the columns of M into registers %.0f); %.1f entries per row (epoch with stamps %.2f ms)"
               % (name, label, rows, ent, tot / waves, 100.0 * a / max(tot, 1), 100.0 * m / max(tot, 1), 100.0 * s / max(tot, 1),
-                 a / max(rows, 1), m / max(rows, 1), s / max(rows, 1), ent / max(rows, 1), dt * 1e3), flush=True)
+                 a / max(rows, 1), m / max(rows, 1), s / max(rows, 1), ld / max(rows, 1), ent / max(rows, 1), dt * 1e3), flush=True)
 
 
 def main():

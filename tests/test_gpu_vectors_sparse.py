@@ -136,22 +136,24 @@ def hooks():
     yield L
     L.gorse_hip_test_set_sparse_slots(0)
     L.gorse_hip_test_set_sparse_tile(0)
+    L.gorse_hip_test_set_sparse_stripe_rows(0)
     L.gorse_hip_test_set_sparse_split(2048)
     L.gorse_hip_test_set_sparse_atomic(-1)
 
 
 @pytest.mark.parametrize("k", [5, 70, 300])
 def test_long_queries_are_split_over_the_row_stripes(oracle, k, hooks):
-    """queries with more entries than the threshold (2048 by default, 6 here) are answered by eight work items -- one per row
-    stripe, each with its own ranking -- and a merge: same results, in one call together with unsplit queries, masks,
-    exclusions, negative and cancelling scores; small tiles so that every stripe owns several tiles"""
+    """queries with more entries than the threshold (2048 by default, 6 here) are answered by one work item per row stripe
+    (arrangement B of the posting lists: 32 stripes here), each with its own ranking, and a merge: same results, in one call
+    together with unsplit queries (arrangement A: 36 groups of 256 rows), masks, exclusions, negative and cancelling scores"""
     rng = np.random.default_rng(47)
     ptr, idx, val = random_csr(rng, 9000, 80, 0, 14, neg=True, zipf=True)
     n_long = int((np.diff(ptr) > 6).sum())
     assert n_long > 100 and n_long < 8000
     mask = (rng.random(9000) < 0.8).astype(np.uint8)
-    hooks.gorse_hip_test_set_sparse_tile(64)
-    s = capi.Sparse(ptr, idx, val)  # 9000 rows = 18 groups of 8 tiles
+    hooks.gorse_hip_test_set_sparse_tile(256)
+    hooks.gorse_hip_test_set_sparse_stripe_rows(512)
+    s = capi.Sparse(ptr, idx, val)
     hooks.gorse_hip_test_set_sparse_split(6)
     sample = list(range(0, 9000, 23))
     got = s.all_pairs(k)
@@ -174,7 +176,9 @@ def test_both_accumulation_forms(oracle, atomic, hooks):
     rng = np.random.default_rng(5 + atomic)
     ptr, idx, val = random_csr(rng, 20000, 300, 1, 40, neg=True, zipf=True)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
-    hooks.gorse_hip_test_set_sparse_tile(128)
+    hooks.gorse_hip_test_set_sparse_tile(1024)
+    hooks.gorse_hip_test_set_sparse_stripe_rows(1024)
+    hooks.gorse_hip_test_set_sparse_split(200)
     s = capi.Sparse(ptr, idx, val)
     sample = list(range(0, 20000, 397))
     got = s.all_pairs(50)
@@ -197,13 +201,14 @@ def test_tiny_values_take_the_non_atomic_form(oracle):
 
 def test_random_configurations(oracle, hooks):
     """thirty random small problems, each with random k, mask, exclusions and random settings of the library's switches
-    (tile height, split threshold, workgroups per launch, accumulation form): every answer equals the oracle's"""
+    (group height, stripe height, split threshold, workgroups per launch, accumulation form): every answer equals the oracle's"""
     rng = np.random.default_rng(2027)
     for case in range(30):
         rows, dims = int(rng.integers(1, 400 if case % 3 else 3000)), int(rng.integers(1, 120))
         hi = int(rng.integers(0, min(dims, 30) + 1))
         ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
-        hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 64, 128, 2048])))
+        hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 256, 512, 2048])))
+        hooks.gorse_hip_test_set_sparse_stripe_rows(int(rng.choice([0, 64, 256])))
         hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 2048])))
         hooks.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
         hooks.gorse_hip_test_set_sparse_atomic(int(rng.choice([-1, 0, 1])))
