@@ -192,7 +192,9 @@ int g_als_long_row = 4096;  // rows longer than this are cut into chunks (test h
 int g_als_chunk = 4096;     // feedback entries per chunk of a long row
 int g_als_path = 0;         // 0 auto (Gram form for d <= 64), 1 force the residual sweep, 2 force the Gram form
 constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
-constexpr int kAlsWaves = 4;        // waves per workgroup of the row kernels
+constexpr int kAlsWaves = 4;        // waves per workgroup of the chunk kernels
+constexpr int kAlsRowWaves = 8;     // waves per workgroup of als_row_kernel: ONE workgroup per CU (2 waves per SIMD) so that its LDS
+                                    // holds the 8 per-wave M buffers (133 KB) next to one copy of S (16 KB)
 constexpr int kAlsPairs = 8;        // feedback-entry pairs per pipeline stage (16 entries, 4 KB at d = 64)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -390,7 +392,7 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
 
 // A: side being solved, B: the other side, S: d x d Gram of B over rows with feedback
 template <int NB>
-__global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__restrict__ A, const float *__restrict__ B,
+__global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void als_row_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                                  const int64_t *__restrict__ ptr,
                                                                  const int32_t *__restrict__ idx,
                                                                  const float *__restrict__ S,
@@ -403,10 +405,16 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
     // [4] feedback entries, [5] kernel ticks, [6] waves
     unsigned long long c_acc = 0, c_m = 0, c_solve = 0, c_rows = 0, c_ent = 0, t_begin = 0, c_load = 0;
     if (prof) t_begin = __builtin_amdgcn_s_memtime();
-    float *sM = smem + (size_t)wv * (64 * kAlsDP + 64);
+    // S (d x d, the same for every row of the half-sweep) is copied to LDS once: read from global memory inside the solve, its
+    // 64 loads per row queued behind the sibling waves' gathers -- 24.6K of the solve's 40.5K cycles per row
+    // (profiles/r02_i_probe_als_prof.txt)
+    float *sS = smem;
+    for (int e = threadIdx.x; e < d * d; e += blockDim.x) sS[e] = S[e];
+    __syncthreads();
+    float *sM = smem + (size_t)d * d + (size_t)wv * (64 * kAlsDP + 64);
     float *ss = sM + 64 * kAlsDP;
     const float one_w = 1 - w;
-    const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
+    const int64_t wave = (int64_t)blockIdx.x * kAlsRowWaves + wv, nwaves = (int64_t)gridDim.x * kAlsRowWaves;
     for (int64_t t = wave; t < n_rows; t += nwaves) {
         const int64_t u = rows[t];
         const int64_t beg = ptr[u];
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_row_kernel(float *__res
         // step, profiles/r02_g_probe_als_prof.txt).  At raised priority the chain issues at its own pace and the MFMA stream
         // takes the slots in between -- it needs one issue per 64 cycles.
         __builtin_amdgcn_s_setprio(3);
-        als_solve_row<32 * NB, true>(A + u * d, sM, ss, S, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+        als_solve_row<32 * NB, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
         if (prof) {
@@ -579,23 +587,23 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
                       float reg) {
     const int d = h->d;
     gorse_mf::AlsPlan &pl = h->als_plan[side];
-    const size_t lds = (size_t)kAlsWaves * (64 * kAlsDP + 64) * sizeof(float);
+    const size_t lds = ((size_t)d * d + (size_t)kAlsRowWaves * (64 * kAlsDP + 64)) * sizeof(float);
     if (g_als_prof) {
         GORSE_TRY(h->als_prof.ensure(16));
         GORSE_HIP_CHECK(hipMemsetAsync(h->als_prof.p + 8 * side, 0, 8 * sizeof(unsigned long long), h->stream));
     }
     int tok = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
     if (pl.n_short > 0) {
-        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_short, kAlsWaves), 512);  // 2 workgroups per CU
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_short, kAlsRowWaves), 256);  // one workgroup per CU
         if (d <= 32) {
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
-            als_row_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
+            als_row_kernel<1><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
                                                                                    pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side));
         } else {
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
-            als_row_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
+            als_row_kernel<2><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
                                                                                    pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side));
         }
         GORSE_HIP_CHECK(hipGetLastError());

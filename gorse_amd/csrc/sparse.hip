@@ -54,14 +54,15 @@ struct gorse_sparse {
 namespace {
 
 // probes / test hooks (include/gorse_hip_test.h); results never depend on them
-int g_sparse_tile = 0;           // rows per group of arrangement A (power of two, 256 .. 16384); 0 = 4096
+int g_sparse_tile = 0;           // rows per group of arrangement A (power of two, 256 .. 16384); 0 = 2048
 int64_t g_sparse_split = 2048;   // queries with more entries than this are split over the stripes of arrangement B; <= 0 = never
 int g_sparse_stripe_rows = 0;    // rows per stripe of arrangement B are at most this (power of two); 0 = 8192
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 
 int pick_log_group() {
-    int l = 12;  // 4096 rows: 16 KB of accumulators + 4 KB of stamps + 2 KB of touched list, 6 waves per CU with KP = 256
+    int l = 11;  // 2048 rows: 8 KB of accumulators + 2 KB of stamps + 1 KB of touched list, 10 waves per CU with KP = 256
+                 // (C3-shard item-to-item: 94 ms against 101 with 4096 and 122 with 8192, profiles/r02_i_probe_sparse_c3.txt)
     if (g_sparse_tile > 0) {
         l = 8;
         while ((1 << l) < g_sparse_tile && l < 14) l++;

@@ -345,7 +345,7 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_
     gs.walked += wave_sum_u32(len);
 }
 
-// One list at a time, its postings over the lanes (segments longer than kGather).  The first 64 postings of the next THREE
+// One list at a time, its postings over the lanes (segments longer than kGather).  The first 64 postings of the next SEVEN
 // segments are in flight while one is applied (the compiler keeps loads behind the LDS atomics of the program order, so the
 // look-ahead is spelled out).  Every accumulator reached goes on the touched list (no +0 test: the add returns nothing here).
 template <bool ATOMIC>
@@ -367,36 +367,46 @@ __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const 
             if (x.sl + lane < x.el) x.P = post[x.sl + lane];
         }
     };
-    Seg r0, r1, r2, r3;
-    next(r0);
-    next(r1);
-    next(r2);
-    while (r0.el > r0.sl) {
-        next(r3);
-        {
-            const bool have = r0.sl + lane < r0.el;
-            if (have) acc_add<ATOMIC>(acc, r0.P.loc, __fmul_rn(r0.ql, r0.P.val));
-            touch(touched, tcap, gs, have, r0.P.loc, lane);
-        }
-        for (uint32_t p = r0.sl + kBlock; p < r0.el; p += 4 * kBlock) {  // long segments: four loads in flight
-            Posting x[4];
-            bool have[4];
+    // a ring of kAhead segments whose first 64 postings are in flight; the loop is unrolled over the ring so that the ring
+    // slots are registers
+    constexpr int kAhead = 8;
+    Seg ring[kAhead];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t at = p + j * kBlock + lane;
-                have[j] = at < r0.el;
-                x[j] = Posting{0, 0.0f};
-                if (have[j]) x[j] = post[at];
-            }
+    for (int i = 0; i < kAhead - 1; i++) next(ring[i]);
+    bool more = ring[0].el > ring[0].sl;
+    while (more) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (have[j]) acc_add<ATOMIC>(acc, x[j].loc, __fmul_rn(r0.ql, x[j].val));
-                touch(touched, tcap, gs, have[j], x[j].loc, lane);
+        for (int slot = 0; slot < kAhead; slot++) {
+            Seg &r0 = ring[slot];
+            if (!(r0.el > r0.sl)) {
+                more = false;
+                break;
             }
+            next(ring[(slot + kAhead - 1) % kAhead]);
+            {
+                const bool have = r0.sl + lane < r0.el;
+                if (have) acc_add<ATOMIC>(acc, r0.P.loc, __fmul_rn(r0.ql, r0.P.val));
+                touch(touched, tcap, gs, have, r0.P.loc, lane);
+            }
+            for (uint32_t p = r0.sl + kBlock; p < r0.el; p += 4 * kBlock) {  // long segments: four loads in flight
+                Posting x[4];
+                bool have[4];
+    #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t at = p + j * kBlock + lane;
+                    have[j] = at < r0.el;
+                    x[j] = Posting{0, 0.0f};
+                    if (have[j]) x[j] = post[at];
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (have[j]) acc_add<ATOMIC>(acc, x[j].loc, __fmul_rn(r0.ql, x[j].val));
+                    touch(touched, tcap, gs, have[j], x[j].loc, lane);
+                }
+            }
+            gs.walked += r0.el - r0.sl;
+            tr.slow_segments++;
         }
-        gs.walked += r0.el - r0.sl;
-        tr.slow_segments++;
-        r0 = r1, r1 = r2, r2 = r3;
     }
 }
 

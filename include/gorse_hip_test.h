@@ -52,7 +52,7 @@ int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
 /* rows per group of a handle created AFTERWARDS (arrangement A of the posting lists, csrc/sparse_kernels.hpp): a power of two
- * in 256 .. 16384; 0 = 4096.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
+ * in 256 .. 16384; 0 = 2048.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);
 /* most rows per stripe of arrangement B of a handle created AFTERWARDS (power of two; 0 = 8192): the number of stripes -- and
  * of work items a long query is split into -- follows from it. */

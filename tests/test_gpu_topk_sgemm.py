@@ -159,3 +159,42 @@ def test_sgemm_larger_vs_oracle(oracle):
 def test_sgemm_errors():
     with pytest.raises(capi.GorseHipError):
         capi.sgemm(0, 0, 2, 2, 2, np.zeros(4), 1, np.zeros(4), 2, np.zeros(4), 2)  # lda too small
+
+
+@pytest.mark.parametrize("path", [1, 2])
+def test_bfloats_euclidean_order(oracle, path):
+    """GORSE_METRIC_EUCLIDEAN_BF16: the distance of a bf16 index is bfloats.Euclidean in the summation order of the reference's
+    AVX512BW kernel (common/bfloats/src/bfloats_avx512.c:26-59: 16 unfused partials added one after the other, fused scalar
+    tail) -- bit for bit against orc_bf16_euclidean (itself pinned to the reference's own kernel, tests/golden/
+    ref_simd_vectors.npz), for every vector length class (multiples of 16, tails, shorter than 16), through the literal
+    scan (path 1) and the MFMA sweep + exact rescoring (path 2); floats.Euclidean's order gives other bits for the same rows."""
+    capi.lib().gorse_hip_test_set_topk_path(path)
+    try:
+        rng = np.random.default_rng(5)
+        differs = 0
+        for d in (1, 7, 16, 17, 31, 32, 48, 64, 100, 128, 200):
+            N = 700
+            Xf = rng.standard_normal((N, d)).astype(np.float32) * rng.uniform(0.2, 3.0, (N, 1)).astype(np.float32)
+            Xb = (Xf.view(np.uint32) >> 16).astype(np.uint16)
+            Xe = (Xb.astype(np.uint32) << 16).view(np.float32)
+            t = capi.TopK(Xb, capi.METRIC_EUCLIDEAN_BF16, dtype=capi.DTYPE_BF16)
+            idx, dist = t.all_pairs(20)
+            for q in range(0, N, 53):
+                ei, ed = oracle.search_index(Xe, orc.METRIC_EUCLIDEAN_BF16, q, 20)
+                assert np.array_equal(idx[q], ei), (d, q)
+                assert np.array_equal(dist[q].view(np.uint32), ed.view(np.uint32)), (d, q)
+                for r in range(0, 20, 7):  # the oracle's distance IS bfloats.Euclidean of the two uint16 rows
+                    assert np.float32(oracle.bf16_euclidean(Xb[q], Xb[ei[r]])).view(np.uint32) == ed[r].view(np.uint32)
+            plain = capi.TopK(Xb, capi.METRIC_EUCLIDEAN, dtype=capi.DTYPE_BF16).all_pairs(20)[1]
+            differs += int((plain.view(np.uint32) != dist.view(np.uint32)).sum())
+            qv = (rng.standard_normal((9, d)).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+            i2, d2, c2 = t.search_vector(qv, 5)
+            for r in range(9):
+                ei, ed = oracle.search_vector(Xe, orc.METRIC_EUCLIDEAN_BF16, (qv[r].astype(np.uint32) << 16).view(np.float32), 5)
+                assert np.array_equal(i2[r, :c2[r]], ei) and np.array_equal(d2[r, :c2[r]].view(np.uint32), ed.view(np.uint32))
+        assert differs > 0  # the two summation orders are not the same function
+        with pytest.raises(capi.GorseHipError) as e:
+            capi.TopK(Xf, capi.METRIC_EUCLIDEAN_BF16, dtype=capi.DTYPE_F32)
+        assert e.value.code == capi.ERR_INVALID
+    finally:
+        capi.lib().gorse_hip_test_set_topk_path(0)

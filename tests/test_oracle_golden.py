@@ -303,3 +303,15 @@ def test_inverted_index_search_equals_the_brute_force_search(oracle):
     for k, expect in TIE_EXPECT.items():
         gi, gs, walked = ix.search(qi[:2], qv[:2], k, exclude=0, admissible=mask)
         assert gi.tolist() == expect
+
+
+def test_metric_3_is_bfloats_euclidean(oracle):
+    """orc_distance(3, ...) on << 16-expanded rows = orc_bf16_euclidean on the uint16 rows (the kernel that
+    tests/golden/ref_simd_vectors.npz pins to the reference's own bfloats_avx512.c)"""
+    rng = np.random.default_rng(2)
+    for n in (0, 1, 15, 16, 17, 64, 100, 200):
+        a = (rng.standard_normal(n).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        b = (rng.standard_normal(n).astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        af, bf = (a.astype(np.uint32) << 16).view(np.float32), (b.astype(np.uint32) << 16).view(np.float32)
+        assert np.float32(oracle.distance(orc.METRIC_EUCLIDEAN_BF16, af, bf)).view(np.uint32) == \
+            np.float32(oracle.bf16_euclidean(a, b)).view(np.uint32)
