@@ -71,6 +71,7 @@ SIGNATURES = {
     "gorse_topk_search_index": (C.c_int32, [_vp, _i64p, C.c_int64, C.c_int32, C.c_int32, _i32p, _f32p, _i32p]),
     "gorse_topk_search_vector": (C.c_int32, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, _i32p, _f32p, _i32p]),
     "gorse_topk_all_pairs": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int32, _i32p, _f32p]),
+    "gorse_topk_set_mask": (C.c_int32, [_vp, _vp]),
     "gorse_topk_synchronize": (C.c_int32, [_vp]),
     "gorse_topk_set_profiling": (C.c_int32, [_vp, C.c_int32]),
     "gorse_topk_get_profile": (C.c_int32, [_vp, C.c_int32, _i64p, _f64p]),
@@ -97,6 +98,7 @@ SIGNATURES = {
     "gorse_hip_test_set_sparse_stripe_rows": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_atomic": (None, [C.c_int32]),
+    "gorse_hip_test_set_sparse_streams": (None, [C.c_int32]),
     "gorse_hip_test_sparse_trace": (C.c_int64, [_vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int64]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
@@ -331,6 +333,12 @@ class TopK:
         dist = np.empty((nq, k), np.float32) if fetch else None
         check(lib().gorse_topk_all_pairs(self.h, q_begin, q_end, k, _p(idx, _i32p), _p(dist, _f32p)))
         return idx, dist
+
+    def set_mask(self, admissible=None):
+        m = None if admissible is None else _arr(admissible, np.uint8)
+        if m is not None and m.size != self.N:
+            raise GorseHipError(ERR_INVALID, "mask must have N entries")
+        check(lib().gorse_topk_set_mask(self.h, None if m is None else m.ctypes.data_as(_vp)))
 
     def resweeps(self):
         n = C.c_int64(0)

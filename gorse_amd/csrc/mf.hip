@@ -183,7 +183,9 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
     if (U <= 0 || I <= 0 || d <= 0) return fail(GORSE_ERR_INVALID, "U, I, d must be positive (got %lld, %lld, %d)",
                                                  (long long)U, (long long)I, d);
     if (U > INT32_MAX || I > INT32_MAX) return fail(GORSE_ERR_INVALID, "U and I must fit int32 (dataset indices are int32)");
-    if (d > 2048) return fail(GORSE_ERR_INVALID, "nFactors %d > 2048 unsupported", d);
+    // the generic kernels stage rows in LDS: bpr_update_kernel<0> 192 bytes per factor (16 groups x 3 rows), the score / rank
+    // kernels less; what must launch decides the limit (64 KB of LDS without opting into more: 341; kept at a round 256)
+    if (d > 256) return fail(GORSE_ERR_INVALID, "nFactors %d > 256 unsupported (the generic BPR update stages 192 B of LDS per factor)", d);
     if (!user_indptr || !user_indices) return fail(GORSE_ERR_INVALID, "user CSR is NULL");
     if ((item_indptr == nullptr) != (item_indices == nullptr))
         return fail(GORSE_ERR_INVALID, "item_indptr and item_indices must both be given or both NULL");

@@ -19,6 +19,8 @@ struct gorse_sparse {
     int32_t logG = 0, ngroups = 0;  // arrangement A: groups of G = 1 << logG consecutive scratch ids
     int32_t logS = 0, naccB = 0;    // arrangement B: S = 1 << logS stripes (scratch id mod S) of naccB rows
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // the stripes of the long queries run next to the ordinary queries (run_queries)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stored rows as CSR with directory entries instead of raw indices (the queries of all_pairs), the tiled posting lists
     DevBuf<int64_t> r_ptr;
     DevBuf<int32_t> r_cid, orig_of, new_of;
@@ -59,6 +61,7 @@ int64_t g_sparse_split = 2048;   // queries with more entries than this are spli
 int g_sparse_stripe_rows = 0;    // rows per stripe of arrangement B are at most this (power of two); 0 = 8192
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
+int g_sparse_two_streams = 1;    // the long queries' stripes on a second stream next to the ordinary queries
 
 int pick_log_group() {
     int l = 11;  // 2048 rows: 8 KB of accumulators + 2 KB of stamps + 1 KB of touched list, 10 waves per CU with KP = 256
@@ -78,7 +81,7 @@ int pick_log_stripes(int64_t N) {
 }
 
 template <int KP>
-int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, hipStream_t s) {
+int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, hipStream_t s) {  // s: the stream of this launch
     auto k1 = sparse::sparse_tile_kernel<KP, true>;
     auto k0 = sparse::sparse_tile_kernel<KP, false>;
     auto kern = atomic ? k1 : k0;
@@ -167,21 +170,29 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     // LDS of a workgroup: ranking buffer + per accumulator 4 B (sum) + 1 B (stamp) + 0.5 B (touched list)
     auto lds_for = [&](int64_t nacc) { return (size_t)2 * kp * 8 + (size_t)nacc * 11 / 2; };
-    auto launch = [&](const TileArgs &x, size_t n, size_t lds) -> int32_t {
+    auto launch = [&](const TileArgs &x, size_t n, size_t lds, hipStream_t st) -> int32_t {
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n, slots));
         switch (kp) {
-            case 256: return launch_tiles<256>(x, grid, lds, atomic, h->stream);
-            case 512: return launch_tiles<512>(x, grid, lds, atomic, h->stream);
-            default: return launch_tiles<1024>(x, grid, lds, atomic, h->stream);
+            case 256: return launch_tiles<256>(x, grid, lds, atomic, st);
+            case 512: return launch_tiles<512>(x, grid, lds, atomic, st);
+            default: return launch_tiles<1024>(x, grid, lds, atomic, st);
         }
     };
     const int tok = h->prof.begin(0, h->stream);
-    if (!workB.empty()) {  // the stripes of the long queries first: they are the longest items of the call
+    if (!workB.empty()) {
+        // The stripes of the long queries on a second stream, next to the ordinary queries: a stripe's workgroup needs 2.5 x
+        // the LDS of a group's, so on their own the stripes leave the CUs at 4 waves (1024 of the chip's 2560 slots busy for
+        // 40 % of the pass, profiles/r02_j_probe_sparse_trace.txt); the ordinary queries fill the rest.
+        hipStream_t st2 = g_sparse_two_streams ? h->stream2 : h->stream;
+        if (st2 != h->stream) {
+            GORSE_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));  // uploads and memsets above
+            GORSE_HIP_CHECK(hipStreamWaitEvent(st2, h->ev_fork, 0));
+        }
         TileArgs b = a;
         b.work = h->workB.p, b.n_work = (int32_t)workB.size(), b.next = h->next.p + 1;
         b.nacc_lds = (int32_t)(ceil_div(h->naccB, 64) * 64);
         b.trace = a.trace ? a.trace + workA.size() : nullptr;
-        GORSE_TRY(launch(b, workB.size(), lds_for(b.nacc_lds)));
+        GORSE_TRY(launch(b, workB.size(), lds_for(b.nacc_lds), st2));
         GORSE_HIP_CHECK(hipGetLastError());
         sparse::MergeArgs m;
         m.split_t = h->split_t.p, m.n_split = (int32_t)split_t.size(), m.nparts = S;
@@ -191,18 +202,20 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
         const unsigned mg = (unsigned)std::min<size_t>(split_t.size(), 4096);
         switch (kp) {
-            case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
-            case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
-            default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, st2>>>(m); break;
+            case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, st2>>>(m); break;
+            default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, st2>>>(m); break;
         }
         GORSE_HIP_CHECK(hipGetLastError());
+        if (st2 != h->stream) GORSE_HIP_CHECK(hipEventRecord(h->ev_join, st2));
     }
     if (!workA.empty()) {
         a.work = h->work.p, a.n_work = (int32_t)workA.size(), a.next = h->next.p;
         a.nacc_lds = 1 << h->logG;
-        GORSE_TRY(launch(a, workA.size(), lds_for(a.nacc_lds)));
+        GORSE_TRY(launch(a, workA.size(), lds_for(a.nacc_lds), h->stream));
         GORSE_HIP_CHECK(hipGetLastError());
     }
+    if (!workB.empty() && g_sparse_two_streams) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     h->prof.end(tok, h->stream);
     unsigned long long st[2] = {0, 0};
     GORSE_HIP_CHECK(hipMemcpyAsync(st, h->stat.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -266,6 +279,9 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         if (h->naccB > 65536) return fail(GORSE_ERR_INVALID, "too many rows per stripe");
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         std::vector<int64_t> &ptr0 = h->r_ptr_host;
         ptr0.resize((size_t)N + 1);
         for (int64_t r = 0; r <= N; r++) ptr0[(size_t)r] = indptr[r] - base;
@@ -328,10 +344,16 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
 extern "C" int32_t gorse_sparse_destroy(gorse_sparse *h) {
     if (!h) return GORSE_OK;
     (void)hipSetDevice(h->device);
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
     }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
     return GORSE_OK;
 }
@@ -457,3 +479,4 @@ extern "C" void gorse_hip_test_set_sparse_tile(int32_t rows) { g_sparse_tile = r
 extern "C" void gorse_hip_test_set_sparse_stripe_rows(int32_t rows) { g_sparse_stripe_rows = rows; }
 extern "C" void gorse_hip_test_set_sparse_split(int64_t entries) { g_sparse_split = entries; }
 extern "C" void gorse_hip_test_set_sparse_atomic(int32_t mode) { g_sparse_atomic = mode; }
+extern "C" void gorse_hip_test_set_sparse_streams(int32_t two) { g_sparse_two_streams = two != 0; }

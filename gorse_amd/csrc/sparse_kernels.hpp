@@ -348,9 +348,10 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_
 // One list at a time, its postings over the lanes (segments longer than kGather).  The first 64 postings of the next SEVEN
 // segments are in flight while one is applied (the compiler keeps loads behind the LDS atomics of the program order, so the
 // look-ahead is spelled out).  Every accumulator reached goes on the touched list (no +0 test: the add returns nothing here).
+// track = false (a stripe of a long query: it reaches most of its rows and is read back densely): no touched list.
 template <bool ATOMIC>
 __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const Visit &v, float *acc, uint16_t *touched, int tcap,
-                                        int lane, GroupState &gs, Trace &tr) {
+                                        int lane, GroupState &gs, Trace &tr, bool track) {
     struct Seg {
         uint32_t sl, el;  // wave-uniform; el == sl: none
         float ql;
@@ -386,7 +387,7 @@ __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const 
             {
                 const bool have = r0.sl + lane < r0.el;
                 if (have) acc_add<ATOMIC>(acc, r0.P.loc, __fmul_rn(r0.ql, r0.P.val));
-                touch(touched, tcap, gs, have, r0.P.loc, lane);
+                if (track) touch(touched, tcap, gs, have, r0.P.loc, lane);
             }
             for (uint32_t p = r0.sl + kBlock; p < r0.el; p += 4 * kBlock) {  // long segments: four loads in flight
                 Posting x[4];
@@ -401,7 +402,7 @@ __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const 
     #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (have[j]) acc_add<ATOMIC>(acc, x[j].loc, __fmul_rn(r0.ql, x[j].val));
-                    touch(touched, tcap, gs, have[j], x[j].loc, lane);
+                    if (track) touch(touched, tcap, gs, have[j], x[j].loc, lane);
                 }
             }
             gs.walked += r0.el - r0.sl;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                     if (!__ballot(len > (uint32_t)kGather))
                         apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, lane, gs, tr);
                     else
-                        apply_one_by_one<ATOMIC>(post, v0, acc, touched, tcap, lane, gs, tr);
+                        apply_one_by_one<ATOMIC>(post, v0, acc, touched, tcap, lane, gs, tr, whole);
                 }
             }
             if (++c == nch) {  // the view is complete: read it back
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         const unsigned long long key = cand ? make_key(ord, a.orig_of[sid]) : 0;
                         push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
                     };
-                    if ((int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
+                    if (!whole || (int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
                         tr.dense_groups++;
                         for (int i = lane; i < nacc; i += kBlock) {
                             const float x = acc[i];

@@ -81,7 +81,8 @@ __global__ void gather_rows_kernel(const float *__restrict__ X, const float *__r
 // Bruteforce selection (bruteforce.go:45-62 / 67-82), one thread per query, literal heaps.
 __global__ void select_kernel(const float *__restrict__ dist, const int64_t *__restrict__ qidx, int64_t nq, int64_t N,
                               int k, int prune0, int32_t *heap_v, float *heap_w, int32_t *__restrict__ out_idx,
-                              float *__restrict__ out_dist, int32_t *__restrict__ out_cnt) {
+                              float *__restrict__ out_dist, int32_t *__restrict__ out_cnt,
+                              const uint8_t *__restrict__ mask) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     const int64_t skip = qidx ? qidx[q] : -1;
@@ -90,7 +91,7 @@ __global__ void select_kernel(const float *__restrict__ dist, const int64_t *__r
     GoHeap<true> mx(hv, hw);
     const float *dq = dist + q * N;
     for (int64_t i = 0; i < N; i++) {
-        if (i == skip) continue;
+        if (i == skip || (mask && !mask[i])) continue;  // a masked row is never pushed: Bruteforce over the admissible rows
         mx.push((int32_t)i, dq[i]);
         if (mx.n > k) mx.pop();
     }
@@ -139,7 +140,8 @@ int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int 
     tok = h->prof.begin(GORSE_PROF_TOPK_RESCORE, h->stream);
     select_kernel<<<dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, h->stream>>>(h->dist.p, qidx_dev, nq, h->N, k, prune0,
                                                                               h->heap_v.p, h->heap_w.p, h->out_idx.p,
-                                                                              h->out_dist.p, h->out_cnt.p);
+                                                                              h->out_dist.p, h->out_cnt.p,
+                                                                              h->has_mask ? h->mask.p : nullptr);
     GORSE_HIP_CHECK(hipGetLastError());
     h->prof.end(tok, h->stream);
     if (idx_out) GORSE_HIP_CHECK(hipMemcpyAsync(idx_out, h->out_idx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
@@ -170,7 +172,9 @@ extern "C" int32_t gorse_topk_create(gorse_topk **out, int32_t device, int64_t N
     *out = nullptr;
     if (N <= 0 || d <= 0 || !X) return fail(GORSE_ERR_INVALID, "N, d must be positive and X non-NULL");
     if (N > INT32_MAX) return fail(GORSE_ERR_INVALID, "N must fit int32");
-    if (d > 4096) return fail(GORSE_ERR_INVALID, "d %d > 4096 unsupported", d);
+    // dist_kernel stages 17 rows of d floats per workgroup in LDS (68 d bytes) and norm2_kernel 16 (64 d): 64 KB of LDS
+    // without opting into more
+    if (d > 960) return fail(GORSE_ERR_INVALID, "d %d > 960 unsupported (the literal scan stages 68 d bytes of LDS)", d);
     if (dtype != GORSE_DTYPE_F32 && dtype != GORSE_DTYPE_BF16) return fail(GORSE_ERR_INVALID, "unknown dtype %d", dtype);
     if (metric < 0 || metric > 3) return fail(GORSE_ERR_INVALID, "unknown metric %d", metric);
     if (metric == GORSE_METRIC_EUCLIDEAN_BF16 && dtype != GORSE_DTYPE_BF16)
@@ -352,6 +356,35 @@ extern "C" int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
     if (n_fallback) *n_fallback = h->n_fallback;
     if (n_tie_resolved) *n_tie_resolved = h->n_tie;
+    return GORSE_OK;
+}
+
+// rscale_m[i] = admissible[i] ? base[i] (or 1 without a base) : NaN -- a NaN score fails every comparison of the sweep
+__global__ void masked_scale_kernel(const uint8_t *__restrict__ mask, const float *__restrict__ base, int64_t n,
+                                    float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = mask[i] ? (base ? base[i] : 1.0f) : __builtin_nanf("");
+}
+
+extern "C" int32_t gorse_topk_set_mask(gorse_topk *h, const uint8_t *admissible) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    if (!admissible) {
+        h->has_mask = false;
+        return GORSE_OK;
+    }
+    GORSE_TRY(h->mask.ensure((size_t)h->N));
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->mask.p, admissible, (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+    h->n_admissible = 0;
+    for (int64_t r = 0; r < h->N; r++) h->n_admissible += admissible[r] != 0;
+    if (h->mfma_ok) {
+        GORSE_TRY(h->rscale_m.ensure((size_t)h->N));
+        const float *base = h->metric == GORSE_METRIC_NEG_DOT ? nullptr : h->rscale.p;
+        masked_scale_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->mask.p, base, h->N, h->rscale_m.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->has_mask = true;
     return GORSE_OK;
 }
 

@@ -45,6 +45,11 @@ struct gorse_topk {
     gorse::DevBuf<float> rp_sdst;
     gorse::DevBuf<unsigned long long> sweep_prof;  // probe: phase counters of the instrumented sweep
     gorse::KernelProfile prof{GORSE_PROF_TOPK_NCLASSES};
+    // gorse_topk_set_mask: rows with mask == 0 take no part in any search (as if they had never been added)
+    gorse::DevBuf<uint8_t> mask;
+    gorse::DevBuf<float> rscale_m;  // the sweep's per-row value (cosine scale / Euclidean bias / 1 for -dot) with NaN for masked rows
+    bool has_mask = false;
+    int64_t n_admissible = 0;
     bool bf16_order = false;  // GORSE_METRIC_EUCLIDEAN_BF16: metric is kept as GORSE_METRIC_EUCLIDEAN, the distance kernels get id 3
     int kernel_metric() const { return bf16_order ? 3 : metric; }
     int64_t n_fallback = 0, n_tie = 0, n_resweep = 0;  // of the last search: path A rows, tie replays, warm starts swept again

@@ -1186,10 +1186,13 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     const bool contiguous = !by_vector && qid_host == nullptr;
     const bool exclude_self = !by_vector;
     const int kth = k + (exclude_self ? 1 : 0);
-    const int64_t admissible = h->N - (exclude_self ? 1 : 0);
+    // with a mask the query's own row may or may not be admissible: the larger count only sends a query whose list comes out
+    // one short (fewer than k admissible rows in all) to path A
+    const int64_t admissible = h->has_mask ? h->n_admissible : h->N - (exclude_self ? 1 : 0);
     const int64_t expect = std::min<int64_t>(k, admissible);
     const bool euclid = h->metric == GORSE_METRIC_EUCLIDEAN;
-    const bool scale = h->metric == GORSE_METRIC_COSINE || euclid;  // a per-candidate value enters the epilogue
+    // a per-candidate value enters the epilogue: cosine scale, Euclidean bias, or -- with a mask -- 1 / NaN
+    const bool scale = h->metric == GORSE_METRIC_COSINE || euclid || h->has_mask;
     const float other = h->metric == GORSE_METRIC_COSINE ? 1.0f : h->max_norm;
     const int64_t mb = std::min(nq, kChunkQ);
     GORSE_TRY(h->cbuf.ensure((size_t)mb * kCap));
@@ -1245,7 +1248,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         SweepParams sp;
         sp.A = h->opA;
         sp.B = Bop;
-        sp.rscale = scale ? h->rscale.p : nullptr;
+        sp.rscale = h->has_mask ? h->rscale_m.p : (scale ? h->rscale.p : nullptr);
         sp.qmargin = h->qmargin.p;
         sp.cbuf = h->cbuf.p;
         sp.ccnt = h->ccnt.p;
@@ -1348,7 +1351,9 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         };
         // stage 2: history sweep + literal heap replay (topk_tie_sort_kernel, topk_tie_replay_kernel) for the flagged queries
         std::vector<int64_t> rest;
-        if (!fb.empty() && g_topk_force_path != 3) {
+        // (with a mask the replay's gap arithmetic -- which counts the rows between two recorded ones -- would count masked
+        // rows too: those queries take the literal scan, which skips masked rows)
+        if (!fb.empty() && g_topk_force_path != 3 && !h->has_mask) {
             std::vector<int32_t> pos;
             std::vector<int64_t> selfs;
             std::vector<uint8_t> f2;

@@ -107,6 +107,7 @@ void read_latent(std::istream &r, std::string &id, std::vector<float> &data) {
         } else if (tag == 0x15) {  // unpacked float
             float f;
             s.read((char *)&f, 4);
+            if (s.gcount() != 4) throw std::runtime_error("unexpected EOF");
             data.push_back(f);
         } else {
             throw std::runtime_error("unknown LatentFactor field");

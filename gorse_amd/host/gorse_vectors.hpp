@@ -83,6 +83,12 @@ struct Searcher {
     // many of them into cnt (nq)
     virtual void search(const std::string &collection, const float *X, int64_t n, int d, int metric, const float *Q,
                         int64_t nq, int k, int32_t *idx, float *dist, int32_t *cnt) = 0;
+    // the same over the rows with admissible[r] != 0 only (hidden vectors, the categories filter), in ONE search; false =
+    // not offered, the caller filters an over-fetched search instead
+    virtual bool search_masked(const std::string &, const float *, int64_t, int, int, const uint8_t *, const float *, int64_t, int,
+                               int32_t *, float *, int32_t *) {
+        return false;
+    }
 };
 
 // One gorse_topk handle per collection, rebuilt lazily after a change (like BruteforceHIP.sync in INTEGRATION.md).
@@ -111,6 +117,23 @@ public:
         // one call for all queries: >= 64 of them run on the MFMA path of the library, fewer on its literal scan
         if (gorse_topk_search_vector(h, Q, nq, k, 0, idx, dist, cnt) != GORSE_OK)
             throw std::runtime_error(std::string("gorse_topk_search_vector: ") + gorse_hip_last_error());
+    }
+    // the filter as a device mask (gorse_topk_set_mask): the sweep never sees an inadmissible row, k stays topK
+    bool search_masked(const std::string &collection, const float *X, int64_t n, int d, int metric, const uint8_t *admissible,
+                       const float *Q, int64_t nq, int k, int32_t *idx, float *dist, int32_t *cnt) override {
+        gorse_topk *&h = handles_[collection];
+        if (!h) {
+            if (gorse_topk_create(&h, device_, n, d, GORSE_DTYPE_F32, metric, X) != GORSE_OK) {
+                handles_.erase(collection);
+                throw std::runtime_error(std::string("gorse_topk_create: ") + gorse_hip_last_error());
+            }
+        }
+        if (gorse_topk_set_mask(h, admissible) != GORSE_OK)
+            throw std::runtime_error(std::string("gorse_topk_set_mask: ") + gorse_hip_last_error());
+        const int32_t rc = gorse_topk_search_vector(h, Q, nq, k, 0, idx, dist, cnt);
+        (void)gorse_topk_set_mask(h, nullptr);
+        if (rc != GORSE_OK) throw std::runtime_error(std::string("gorse_topk_search_vector: ") + gorse_hip_last_error());
+        return true;
     }
 
 private:
@@ -355,8 +378,28 @@ public:
         const int64_t n = (int64_t)c.rows.size();
         if (n == 0) return out;
         const int metric = c.info.Dist == Dot ? GORSE_METRIC_NEG_DOT : (c.info.Dist == Euclidean ? GORSE_METRIC_EUCLIDEAN : GORSE_METRIC_COSINE);
-        std::vector<char> ok((size_t)n);
-        for (int64_t r = 0; r < n; r++) ok[(size_t)r] = admissible(c.rows[(size_t)r], categories);
+        std::vector<uint8_t> ok((size_t)n);
+        bool filtered = false;
+        for (int64_t r = 0; r < n; r++) {
+            ok[(size_t)r] = admissible(c.rows[(size_t)r], categories);
+            filtered = filtered || !ok[(size_t)r];
+        }
+        if (filtered) {  // the filter as a device mask, where the searcher offers it: one search with k = topK
+            const int64_t k1 = std::min<int64_t>(n, topK);
+            std::vector<int32_t> idx1((size_t)(nq * k1), -1), cnt1((size_t)nq, 0);
+            std::vector<float> dist1((size_t)(nq * k1), 0.0f);
+            if (searcher_->search_masked(name, c.data.data(), n, d, metric, ok.data(), queries.data(), nq, (int)k1, idx1.data(),
+                                         dist1.data(), cnt1.data())) {
+                for (int64_t t = 0; t < nq; t++)
+                    for (int e = 0; e < cnt1[(size_t)t]; e++) {
+                        ScoredVector s;
+                        static_cast<Vector &>(s) = c.rows[(size_t)idx1[(size_t)(t * k1 + e)]];
+                        s.Score = -dist1[(size_t)(t * k1 + e)];
+                        out[(size_t)t].push_back(std::move(s));
+                    }
+                return out;
+            }
+        }
         // queries still short of topK admissible vectors are searched again with a 4x larger k
         std::vector<int64_t> todo((size_t)nq);
         for (int64_t t = 0; t < nq; t++) todo[(size_t)t] = t;

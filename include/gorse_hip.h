@@ -223,6 +223,11 @@ int32_t gorse_topk_synchronize(gorse_topk *h);
 #define GORSE_PROF_TOPK_REPLAY 5  /* path B: topk_tie_sort_kernel + topk_tie_replay_kernel (literal heap replay) */
 int32_t gorse_topk_set_profiling(gorse_topk *h, int32_t on);
 int32_t gorse_topk_get_profile(gorse_topk *h, int32_t kernel_class, int64_t *launches, double *total_ms);
+/* admissible[r] == 0 removes row r from every later search -- as if ann.Bruteforce held the admissible rows only (their ids
+ * unchanged): what IsHidden and the categories filter of storage/vectors/xvec.go:386-394 need, evaluated by the caller once
+ * per filter instead of an over-fetch loop around the search.  NULL = all rows (the default).  The mask is applied inside the
+ * candidate sweep (a masked row scores NaN) and in the literal scan. */
+int32_t gorse_topk_set_mask(gorse_topk *h, const uint8_t *admissible /*host, N bytes, or NULL*/);
 /* statistics of the last all_pairs / search call: queries that took the exact fallback path */
 int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int64_t *n_tie_resolved);
 

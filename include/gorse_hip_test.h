@@ -64,6 +64,8 @@ void gorse_hip_test_set_sparse_split(int64_t entries);
  * wave, -1 = the library's choice (ds_add_f32 unless a product of a stored and a query value could fall below 2^-100,
  * where partial sums may be subnormal and the LDS adder's handling of those is not relied upon). */
 void gorse_hip_test_set_sparse_atomic(int32_t mode);
+/* 1 (default) = the stripes of the long queries run on a second stream next to the ordinary queries, 0 = before them. */
+void gorse_hip_test_set_sparse_streams(int32_t two);
 /* probe: with on != 0 the following calls of the handle record what every work item (a query, or one stripe of a long query)
  * did; with out != NULL copies up to cap records of the last call as 10 uint64 each: {start, end (100 MHz ticks), query,
  * stripe + 1 (0 = whole query), entries, chunks taken 64 lists at once, their rounds, segments walked one list at a time,

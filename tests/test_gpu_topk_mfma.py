@@ -262,3 +262,40 @@ def test_warm_started_sweep_returns_the_same_rows(oracle, metric, dtype, d, N, k
         assert np.array_equal(out[v][0], out[WARM_OFF][0]) and np.array_equal(bits(out[v][1]), bits(out[WARM_OFF][1]))
     qs = np.concatenate([np.arange(0, N, 1999), [5, 100, 139]])
     check_rows(oracle, Xe, metric, qs, k, out[WARM_ALWAYS][0][qs], out[WARM_ALWAYS][1][qs])
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("metric", [capi.METRIC_COSINE, capi.METRIC_NEG_DOT, capi.METRIC_EUCLIDEAN])
+def test_admissibility_mask(oracle, metric, path):
+    """gorse_topk_set_mask: rows with mask 0 take no part in a search -- the answer is ann.Bruteforce over the admissible rows
+    alone (ids unchanged), for a mild and for a 1 %-selective mask (what a category filter looks like), duplicates (ties) among
+    the admissible rows included; clearing the mask restores the unfiltered answer."""
+    capi.lib().gorse_hip_test_set_topk_path(path)
+    rng = np.random.default_rng(31 + metric)
+    N, d, k = 6000, 48, 10
+    Xf = rng.standard_normal((N, d)).astype(np.float32) * rng.uniform(0.5, 2.0, (N, 1)).astype(np.float32)
+    Xf[200:210] = Xf[7]
+    t = capi.TopK(Xf, metric)
+    plain = t.all_pairs(k)
+    qv = rng.standard_normal((80, d)).astype(np.float32)
+    for keep in (0.7, 0.01):
+        mask = (rng.random(N) < keep).astype(np.uint8)
+        mask[200:206] = 1
+        mask[7] = 1
+        rows = np.nonzero(mask)[0]
+        sub = np.ascontiguousarray(Xf[rows])
+        t.set_mask(mask)
+        idx, dist, cnt = t.search_vector(qv, k)
+        for r in range(0, 80, 7):
+            ei, ed = oracle.search_vector(sub, metric, qv[r], k)
+            assert cnt[r] == ei.size and np.array_equal(idx[r, :cnt[r]], rows[ei]), (keep, r)
+            assert np.array_equal(bits(dist[r, :cnt[r]]), bits(ed)), (keep, r)
+        qs = rows[::max(1, rows.size // 25)]
+        i2, d2, c2 = t.search_index(qs, k)
+        for r, q in enumerate(qs):  # exclude_self on a masked index: the query row is one of the admissible rows
+            ei, ed = oracle.search_index(sub, metric, int(np.searchsorted(rows, q)), k)
+            assert c2[r] == ei.size and np.array_equal(i2[r, :c2[r]], rows[ei]), (keep, q)
+            assert np.array_equal(bits(d2[r, :c2[r]]), bits(ed)), (keep, q)
+    t.set_mask(None)
+    again = t.all_pairs(k)
+    assert np.array_equal(again[0], plain[0]) and np.array_equal(bits(again[1]), bits(plain[1]))
