@@ -9,6 +9,8 @@ package ann
 import "C"
 
 import (
+	"encoding/binary"
+	"io"
 	"sync"
 	"unsafe"
 
@@ -90,6 +92,9 @@ func (b *BruteforceHIP) SearchIndex(q, k int, prune0 bool) ([]lo.Tuple2[int, flo
 	if b.d == 0 || q < 0 || q >= len(b.data)/b.d {
 		return nil, errors.Errorf("index out of range: %v", q)
 	}
+	if k <= 0 { // the reference's heap of capacity 0 keeps nothing
+		return []lo.Tuple2[int, float32]{}, nil
+	}
 	if err := b.sync(); err != nil {
 		return nil, err
 	}
@@ -106,7 +111,7 @@ func (b *BruteforceHIP) SearchIndex(q, k int, prune0 bool) ([]lo.Tuple2[int, flo
 func (b *BruteforceHIP) SearchVector(q []float32, k int, prune0 bool) []lo.Tuple2[int, float32] {
 	b.mu.Lock()
 	defer b.mu.Unlock()
-	if b.d == 0 || len(q) != b.d || b.sync() != nil {
+	if b.d == 0 || len(q) != b.d || k <= 0 || b.sync() != nil {
 		return nil
 	}
 	idx, dist := make([]int32, k), make([]float32, k)
@@ -116,6 +121,71 @@ func (b *BruteforceHIP) SearchVector(q []float32, k int, prune0 bool) []lo.Tuple
 		return nil
 	}
 	return zip(idx, dist, int(cnt))
+}
+
+// SearchVectors is SearchVector for many queries in one device search (>= 64 queries take the MFMA sweep).  Queries whose
+// length is not the index's dimension get an empty result, like SearchVector.
+func (b *BruteforceHIP) SearchVectors(qs [][]float32, k int, prune0 bool) [][]lo.Tuple2[int, float32] {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	out := make([][]lo.Tuple2[int, float32], len(qs))
+	if b.d == 0 || k <= 0 || len(qs) == 0 || b.sync() != nil {
+		return out
+	}
+	rows := make([]int, 0, len(qs))
+	flat := make([]float32, 0, len(qs)*b.d)
+	for t, q := range qs {
+		if len(q) == b.d {
+			rows = append(rows, t)
+			flat = append(flat, q...)
+		}
+	}
+	if len(rows) == 0 {
+		return out
+	}
+	idx, dist, cnt := make([]int32, len(rows)*k), make([]float32, len(rows)*k), make([]C.int32_t, len(rows))
+	if rc := C.gorse_topk_search_vector(b.h, unsafe.Pointer(&flat[0]), C.int64_t(len(rows)), C.int32_t(k), cbool(prune0),
+		(*C.int32_t)(unsafe.Pointer(&idx[0])), (*C.float)(unsafe.Pointer(&dist[0])), &cnt[0]); rc != 0 {
+		return out
+	}
+	for r, t := range rows {
+		out[t] = zip(idx[r*k:(r+1)*k], dist[r*k:(r+1)*k], int(cnt[r]))
+	}
+	return out
+}
+
+// Marshal writes the vectors (dimension, count, row-major float32, little endian): the exact index has no graph to save.
+func (b *BruteforceHIP) Marshal(w io.Writer) error {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	n := 0
+	if b.d > 0 {
+		n = len(b.data) / b.d
+	}
+	if err := binary.Write(w, binary.LittleEndian, []int64{int64(b.metric), int64(b.d), int64(n)}); err != nil {
+		return errors.WithStack(err)
+	}
+	return errors.WithStack(binary.Write(w, binary.LittleEndian, b.data))
+}
+
+// Unmarshal reads what Marshal wrote; the device index is rebuilt at the next search.
+func (b *BruteforceHIP) Unmarshal(r io.Reader) error {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	var head [3]int64
+	if err := binary.Read(r, binary.LittleEndian, head[:]); err != nil {
+		return errors.WithStack(err)
+	}
+	if head[1] < 0 || head[2] < 0 || (head[1] == 0 && head[2] != 0) {
+		return errors.Errorf("BruteforceHIP: bad header %v", head)
+	}
+	b.metric, b.d = Metric(head[0]), int(head[1])
+	b.data = make([]float32, head[1]*head[2])
+	if err := binary.Read(r, binary.LittleEndian, b.data); err != nil {
+		return errors.WithStack(err)
+	}
+	b.dirty = true
+	return nil
 }
 
 // SearchAll is SearchIndex for every stored vector in one device pass (the item-to-item bulk build): row q of the
@@ -130,6 +200,9 @@ func (b *BruteforceHIP) SearchAll(k int) (idx []int32, dist []float32, err error
 		return nil, nil, err
 	}
 	n := len(b.data) / b.d
+	if n == 0 || k <= 0 {
+		return nil, nil, nil
+	}
 	idx, dist = make([]int32, n*k), make([]float32, n*k)
 	if rc := C.gorse_topk_all_pairs(b.h, 0, C.int64_t(n), C.int32_t(k), (*C.int32_t)(unsafe.Pointer(&idx[0])),
 		(*C.float)(unsafe.Pointer(&dist[0]))); rc != 0 {

@@ -293,12 +293,15 @@ func (db *Hip) QueryVectors(ctx context.Context, name string, q Vector, categori
 	return db.queryDense(c, q.Values, categories, topK)
 }
 
-// queryDense: the exact top-K of the admissible vectors, by searching an over-fetched k' and growing it until topK
-// admissible ones are found or the collection is exhausted.
+// queryDense: the exact top-K of the admissible vectors in ONE search: the filter (hidden vectors, CONTAIN_ALL categories,
+// xvec.go:386-394) goes to the device as a mask (gorse_topk_set_mask), so k stays topK however selective the filter is.
 func (db *Hip) queryDense(c *hipCollection, q []float32, categories []string, topK int) ([]ScoredVector, error) {
 	d, n := c.info.Dimension, len(c.rows)
 	if d == 0 || len(q) != d {
 		return nil, errors.Errorf("query has dimension %d, collection %s has %d", len(q), c.info.Name, d)
+	}
+	if n == 0 || topK <= 0 {
+		return []ScoredVector{}, nil
 	}
 	if c.dense == nil {
 		metric := C.int32_t(C.GORSE_METRIC_COSINE)
@@ -312,23 +315,27 @@ func (db *Hip) queryDense(c *hipCollection, q []float32, categories []string, to
 			return nil, lastError("gorse_topk_create")
 		}
 	}
-	for k := min(n, max(2*topK, topK+32)); ; k = min(n, 4*k) {
-		idx, dist := make([]int32, k), make([]float32, k)
-		var cnt C.int32_t
-		if rc := C.gorse_topk_search_vector(c.dense, unsafe.Pointer(&q[0]), 1, C.int32_t(k), 0, (*C.int32_t)(unsafe.Pointer(&idx[0])),
-			(*C.float)(unsafe.Pointer(&dist[0])), &cnt); rc != 0 {
-			return nil, lastError("gorse_topk_search_vector")
-		}
-		results := make([]ScoredVector, 0, topK)
-		for t := 0; t < int(cnt) && len(results) < topK; t++ {
-			if v := &c.rows[idx[t]]; admissible(v, categories) {
-				results = append(results, ScoredVector{Vector: *v, Score: -dist[t]}) // Dot: a.b; else the negated distance
-			}
-		}
-		if len(results) == topK || k == n {
-			return results, nil
+	ok := make([]uint8, n)
+	for t := range c.rows {
+		if admissible(&c.rows[t], categories) {
+			ok[t] = 1
 		}
 	}
+	if rc := C.gorse_topk_set_mask(c.dense, (*C.uint8_t)(unsafe.Pointer(&ok[0]))); rc != 0 {
+		return nil, lastError("gorse_topk_set_mask")
+	}
+	k := min(n, topK)
+	idx, dist := make([]int32, k), make([]float32, k)
+	var cnt C.int32_t
+	if rc := C.gorse_topk_search_vector(c.dense, unsafe.Pointer(&q[0]), 1, C.int32_t(k), 0, (*C.int32_t)(unsafe.Pointer(&idx[0])),
+		(*C.float)(unsafe.Pointer(&dist[0])), &cnt); rc != 0 {
+		return nil, lastError("gorse_topk_search_vector")
+	}
+	results := make([]ScoredVector, 0, int(cnt))
+	for t := 0; t < int(cnt); t++ {
+		results = append(results, ScoredVector{Vector: c.rows[idx[t]], Score: -dist[t]}) // Dot: a.b; else the negated distance
+	}
+	return results, nil
 }
 
 // querySparse answers all queries in ONE device call; the filter travels as an admissibility mask.
@@ -384,6 +391,9 @@ func (db *Hip) querySparse(c *hipCollection, queries []Vector, categories []stri
 		qidx, qval = append(qidx, 0), append(qval, 0)
 	}
 	nq := len(queries)
+	if nq == 0 || topK <= 0 {
+		return make([][]ScoredVector, nq), nil
+	}
 	idx, score, cnt := make([]int32, nq*topK), make([]float32, nq*topK), make([]int32, nq)
 	if rc := C.gorse_sparse_search(c.sparse, C.int64_t(nq), (*C.int64_t)(unsafe.Pointer(&qptr[0])), (*C.uint32_t)(unsafe.Pointer(&qidx[0])),
 		(*C.float)(unsafe.Pointer(&qval[0])), nil, C.int32_t(topK), (*C.int32_t)(unsafe.Pointer(&idx[0])),
