@@ -62,6 +62,7 @@ int g_sparse_stripe_rows = 0;    // rows per stripe of arrangement B are at most
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 int g_sparse_two_streams = 1;    // the long queries' stripes on a second stream next to the ordinary queries
+int g_sparse_flat = 1;           // segments longer than kGather: flattened batches (1) or one list at a time (0)
 
 int pick_log_group() {
     int l = 11;  // 2048 rows: 8 KB of accumulators + 2 KB of stamps + 1 KB of touched list, 10 waves per CU with KP = 256
@@ -162,6 +163,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
     a.stat = h->stat.p;
     a.trace = nullptr;
+    a.flat = g_sparse_flat;
     const size_t n_items = workA.size() + workB.size();
     if (h->trace_on) {
         GORSE_TRY(h->trace.ensure(n_items));
@@ -460,8 +462,8 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
-// 10 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1 (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
-// one list at a time, groups read back densely, groups read back by re-walking}; returns the number of work items
+// 12 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1 (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
+// one list at a time, groups read back densely, groups read back by re-walking, flattened batches, rows shared inside a batch}; returns the number of work items
 extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out, int64_t cap) {
     if (!h) return -1;
     h->trace_on = on != 0;
@@ -469,7 +471,8 @@ extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint
     const int64_t n = std::min<int64_t>(cap, (int64_t)h->trace_host.size());
     for (int64_t i = 0; i < n; i++) {
         const sparse::Trace &t = h->trace_host[(size_t)i];
-        uint64_t *o = out + i * 10;
+        uint64_t *o = out + i * 12;
+        o[10] = t.batches, o[11] = t.shared_rows;
         o[0] = t.t0, o[1] = t.t1, o[2] = (uint64_t)t.t, o[3] = (uint64_t)(t.part + 1), o[4] = t.entries;
         o[5] = t.fast_chunks, o[6] = t.rounds, o[7] = t.slow_segments, o[8] = t.dense_groups, o[9] = t.sparse_groups;
     }
@@ -480,3 +483,4 @@ extern "C" void gorse_hip_test_set_sparse_stripe_rows(int32_t rows) { g_sparse_s
 extern "C" void gorse_hip_test_set_sparse_split(int64_t entries) { g_sparse_split = entries; }
 extern "C" void gorse_hip_test_set_sparse_atomic(int32_t mode) { g_sparse_atomic = mode; }
 extern "C" void gorse_hip_test_set_sparse_streams(int32_t two) { g_sparse_two_streams = two != 0; }
+extern "C" void gorse_hip_test_set_sparse_flat(int32_t flat) { g_sparse_flat = flat != 0; }

@@ -61,6 +61,7 @@ struct Trace {
     unsigned long long t0, t1;  // s_memrealtime (100 MHz) at its start / end
     int32_t t, part;
     uint32_t entries, fast_chunks, rounds, slow_segments, dense_groups, sparse_groups;
+    uint32_t batches, shared_rows;  // flattened path: batches of 64 postings, rows of a batch that two lists shared
 };
 
 struct TileArgs {
@@ -87,6 +88,7 @@ struct TileArgs {
     int32_t n_work;
     int32_t *next;     // work counter
     int32_t nacc_lds;  // accumulators the launch's LDS holds (G, or naccB rounded up to 64)
+    int32_t flat;      // probe: 0 = segments longer than kGather go one list at a time instead of in flattened batches
     int k;
     int32_t *out_idx;   // nq x k, padded with -1
     float *out_score;   // nq x k, padded with -inf
@@ -411,6 +413,100 @@ __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const 
     }
 }
 
+// Flattened batches (visits with a segment longer than kGather).  The segments of the visit are laid end to end in list order
+// and cut into batches of 64 postings, one per lane: a batch holds the tail of one list, whole lists, and the head of another.
+// Within one list the rows are distinct; two lists of a batch may share a row, and then the earlier list's product has to go
+// first.  A batch that mixes lists stamps its rows (as apply_at_once does); where a lane reads a foreign stamp, the lanes that
+// share that row are found by a ballot and ranked by lane number = list order, and the batch is applied in rank order: round r
+// adds the r-th sharer of every row, all of them to different accumulators.  The LDS executes the rounds in issue order, so
+// every accumulator still receives its products in ascending index order.  (One list at a time the C3-shard item-to-item
+// pass spent 0.27 us per SEGMENT of 4 postings on average -- 3.2e8 of them, profiles/r02_k_probe_sparse_trace.txt.)
+// Assembly is a wave-uniform walk over the lists; kFlatAhead batches are in flight while one is applied.
+template <bool ATOMIC>
+__device__ inline void apply_flattened(const Posting *__restrict__ post, const Visit &v, float *acc, volatile uint8_t *tag,
+                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Trace &tr, bool track) {
+    struct Batch {
+        Posting P;
+        float q;
+        int n;       // postings of the batch (wave-uniform); 0: none left
+        bool mixed;  // more than one list
+    };
+    unsigned long long m = __ballot(v.e > v.s);
+    uint32_t cur_s = 0, cur_e = 0;  // what is left of the list being cut
+    float cur_q = 0.0f;
+    auto fill = [&](Batch &b) {
+        b.n = 0, b.mixed = false, b.q = 0.0f;
+        uint32_t addr = 0;
+        int lists = 0;
+        while (b.n < kBlock) {
+            if (cur_s >= cur_e) {
+                if (!m) break;
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                cur_s = lane_u32(v.s, l), cur_e = lane_u32(v.e, l), cur_q = lane_f32(v.qv, l);
+                tr.slow_segments++;
+            }
+            const uint32_t take = min(cur_e - cur_s, (uint32_t)(kBlock - b.n));
+            const uint32_t at = (uint32_t)(lane - b.n);
+            if (at < take) {
+                addr = cur_s + at;
+                b.q = cur_q;
+            }
+            cur_s += take, b.n += (int)take, lists++;
+        }
+        b.mixed = lists > 1;
+        b.P = Posting{0, 0.0f};
+        if (lane < b.n) b.P = post[addr];
+    };
+    auto apply = [&](const Batch &b) {
+        const bool have = lane < b.n;
+        const int32_t row = b.P.loc;
+        const float term = __fmul_rn(b.q, b.P.val);
+        unsigned long long lost = 0;
+        if (b.mixed) {
+            if (have) tag[row] = (uint8_t)lane;
+            uint32_t stamp = (uint32_t)lane;
+            if (have) stamp = tag[row];
+            lost = __ballot(stamp != (uint32_t)lane);
+        }
+        if (!lost) {
+            if (have) acc_add<ATOMIC>(acc, row, term);
+        } else {
+            int rank = 0, last = 0;
+            while (lost) {
+                const int l = __ffsll((long long)lost) - 1;
+                const int32_t r = __builtin_amdgcn_readlane(row, l);
+                const unsigned long long same = __ballot(have && row == r);
+                if (have && row == r) rank = lanes_below(same, lane);
+                lost &= ~same;
+                last = max(last, __popcll(same) - 1);
+                tr.shared_rows++;
+            }
+            for (int rd = 0; rd <= last; rd++)
+                if (have && rank == rd) acc_add<ATOMIC>(acc, row, term);
+        }
+        if (track) touch(touched, tcap, gs, have, row, lane);
+        gs.walked += (uint32_t)b.n;
+        tr.batches++;
+    };
+    constexpr int kFlatAhead = 6;
+    Batch ring[kFlatAhead];
+#pragma unroll
+    for (int i = 0; i < kFlatAhead - 1; i++) fill(ring[i]);
+    bool more = ring[0].n > 0;
+    while (more) {
+#pragma unroll
+        for (int slot = 0; slot < kFlatAhead; slot++) {
+            if (ring[slot].n == 0) {
+                more = false;
+                break;
+            }
+            fill(ring[(slot + kFlatAhead - 1) % kFlatAhead]);
+            apply(ring[slot]);
+        }
+    }
+}
+
 template <int KP, bool ATOMIC>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
@@ -516,6 +612,8 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 if (__ballot(len > 0)) {
                     if (!__ballot(len > (uint32_t)kGather))
                         apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                    else if (a.flat)
+                        apply_flattened<ATOMIC>(post, v0, acc, tag, touched, tcap, lane, gs, tr, whole);
                     else
                         apply_one_by_one<ATOMIC>(post, v0, acc, touched, tcap, lane, gs, tr, whole);
                 }
