@@ -99,7 +99,6 @@ SIGNATURES = {
     "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_atomic": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_streams": (None, [C.c_int32]),
-    "gorse_hip_test_set_sparse_flat": (None, [C.c_int32]),
     "gorse_hip_test_sparse_trace": (C.c_int64, [_vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int64]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
@@ -490,9 +489,9 @@ class Sparse:
         return a.value, b.value
 
     def trace(self, on=True):
-        """probe: switch the per-work-item records on / off; returns the records of the last call (n x 12 uint64)"""
+        """probe: switch the per-work-item records on / off; returns the records of the last call (n x 16 uint64)"""
         n = lib().gorse_hip_test_sparse_trace(self.h, int(bool(on)), None, 0)
-        out = np.zeros((max(n, 0), 12), np.uint64)
+        out = np.zeros((max(n, 0), 16), np.uint64)
         if n > 0:
             lib().gorse_hip_test_sparse_trace(self.h, int(bool(on)), out.ctypes.data_as(C.POINTER(C.c_uint64)), n)
         return out

@@ -62,7 +62,6 @@ int g_sparse_stripe_rows = 0;    // rows per stripe of arrangement B are at most
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 int g_sparse_two_streams = 1;    // the long queries' stripes on a second stream next to the ordinary queries
-int g_sparse_flat = 1;           // segments longer than kGather: flattened batches (1) or one list at a time (0)
 
 int pick_log_group() {
     int l = 11;  // 2048 rows: 8 KB of accumulators + 2 KB of stamps + 1 KB of touched list, 10 waves per CU with KP = 256
@@ -163,7 +162,6 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
     a.stat = h->stat.p;
     a.trace = nullptr;
-    a.flat = g_sparse_flat;
     const size_t n_items = workA.size() + workB.size();
     if (h->trace_on) {
         GORSE_TRY(h->trace.ensure(n_items));
@@ -288,15 +286,16 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         ptr0.resize((size_t)N + 1);
         for (int64_t r = 0; r <= N; r++) ptr0[(size_t)r] = indptr[r] - base;
         GORSE_TRY(h->r_ptr.alloc((size_t)N + 1));
-        GORSE_TRY(h->r_cid.alloc((size_t)nnz));
-        GORSE_TRY(h->r_val.alloc((size_t)nnz));
+        // + 1 / + 2: the tile kernel's look-ahead loads clamp to element 0 (and 1) of every array instead of branching
+        GORSE_TRY(h->r_cid.alloc((size_t)nnz + 1));
+        GORSE_TRY(h->r_val.alloc((size_t)nnz + 1));
         GORSE_TRY(h->orig_of.alloc((size_t)N));
         GORSE_TRY(h->new_of.alloc((size_t)N));
         GORSE_TRY(h->dims.alloc((size_t)h->Dc));
-        GORSE_TRY(h->offA.alloc((size_t)cellsA + 1));
-        GORSE_TRY(h->offB.alloc((size_t)cellsB + 1));
-        GORSE_TRY(h->postA.alloc((size_t)nnz));
-        GORSE_TRY(h->postB.alloc((size_t)nnz));
+        GORSE_TRY(h->offA.alloc((size_t)cellsA + 2));
+        GORSE_TRY(h->offB.alloc((size_t)cellsB + 2));
+        GORSE_TRY(h->postA.alloc((size_t)nnz + 1));
+        GORSE_TRY(h->postB.alloc((size_t)nnz + 1));
         DevBuf<uint32_t> raw, cursor, sums;
         GORSE_TRY(raw.alloc((size_t)nnz));
         GORSE_TRY(cursor.alloc((size_t)std::max(cellsA, cellsB) + 1));
@@ -399,8 +398,8 @@ extern "C" int32_t gorse_sparse_search(gorse_sparse *h, int64_t nq, const int64_
     for (int64_t t = 0; t <= nq; t++) ptr0[(size_t)t] = q_indptr[t] - base;
     GORSE_TRY(h->q_ptr.ensure((size_t)nq + 1));
     GORSE_TRY(h->q_idx.ensure((size_t)qnnz));
-    GORSE_TRY(h->q_cid.ensure((size_t)qnnz));
-    GORSE_TRY(h->q_val.ensure((size_t)qnnz));
+    GORSE_TRY(h->q_cid.ensure((size_t)qnnz + 1));
+    GORSE_TRY(h->q_val.ensure((size_t)qnnz + 1));
     GORSE_HIP_CHECK(hipMemcpyAsync(h->q_ptr.p, ptr0.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, h->stream));
     if (qnnz > 0) {
         GORSE_HIP_CHECK(hipMemcpyAsync(h->q_idx.p, q_indices + base, (size_t)qnnz * 4, hipMemcpyHostToDevice, h->stream));
@@ -462,7 +461,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
-// 12 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1 (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
+// 16 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1 (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
 // one list at a time, groups read back densely, groups read back by re-walking, flattened batches, rows shared inside a batch}; returns the number of work items
 extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out, int64_t cap) {
     if (!h) return -1;
@@ -471,8 +470,8 @@ extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint
     const int64_t n = std::min<int64_t>(cap, (int64_t)h->trace_host.size());
     for (int64_t i = 0; i < n; i++) {
         const sparse::Trace &t = h->trace_host[(size_t)i];
-        uint64_t *o = out + i * 12;
-        o[10] = t.batches, o[11] = t.shared_rows;
+        uint64_t *o = out + i * 16;
+        o[10] = t.batches, o[11] = t.shared_rows, o[12] = t.ticks_once, o[13] = t.ticks_flat, o[14] = t.ticks_back, o[15] = t.ticks_head;
         o[0] = t.t0, o[1] = t.t1, o[2] = (uint64_t)t.t, o[3] = (uint64_t)(t.part + 1), o[4] = t.entries;
         o[5] = t.fast_chunks, o[6] = t.rounds, o[7] = t.slow_segments, o[8] = t.dense_groups, o[9] = t.sparse_groups;
     }
@@ -483,4 +482,3 @@ extern "C" void gorse_hip_test_set_sparse_stripe_rows(int32_t rows) { g_sparse_s
 extern "C" void gorse_hip_test_set_sparse_split(int64_t entries) { g_sparse_split = entries; }
 extern "C" void gorse_hip_test_set_sparse_atomic(int32_t mode) { g_sparse_atomic = mode; }
 extern "C" void gorse_hip_test_set_sparse_streams(int32_t two) { g_sparse_two_streams = two != 0; }
-extern "C" void gorse_hip_test_set_sparse_flat(int32_t flat) { g_sparse_flat = flat != 0; }

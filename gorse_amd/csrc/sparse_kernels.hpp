@@ -42,6 +42,12 @@
 namespace gorse {
 namespace sparse {
 
+// LDS pointers that carry their address space: a volatile access through a generic pointer compiles to FLAT instructions
+// (the address-space inference leaves volatile accesses alone), and a FLAT access waits for EVERY outstanding global load
+// (s_waitcnt vmcnt(0)) -- which turned the whole look-ahead of the visit pipeline into dead code until round 2's session m.
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) float lds_f32;
+
 constexpr int kBlock = 64;  // one wavefront per workgroup
 constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
 
@@ -62,6 +68,8 @@ struct Trace {
     int32_t t, part;
     uint32_t entries, fast_chunks, rounds, slow_segments, dense_groups, sparse_groups;
     uint32_t batches, shared_rows;  // flattened path: batches of 64 postings, rows of a batch that two lists shared
+    uint32_t ticks_once, ticks_flat, ticks_back, ticks_head;  // 10 ns ticks inside apply_at_once / apply_flattened (or one list at
+                                                              // a time) / the read-backs; from the start to the end of view 7
 };
 
 struct TileArgs {
@@ -88,7 +96,6 @@ struct TileArgs {
     int32_t n_work;
     int32_t *next;     // work counter
     int32_t nacc_lds;  // accumulators the launch's LDS holds (G, or naccB rounded up to 64)
-    int32_t flat;      // probe: 0 = segments longer than kGather go one list at a time instead of in flattened batches
     int k;
     int32_t *out_idx;   // nq x k, padded with -1
     float *out_score;   // nq x k, padded with -inf
@@ -250,7 +257,7 @@ __device__ inline void write_result(const unsigned long long *s_buf, int cnt, in
 template <bool ATOMIC>
 __device__ inline float acc_add_old(float *acc, int32_t i, float term) {
     if (ATOMIC) return __hip_atomic_fetch_add(&acc[i], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    volatile float *a = acc;
+    volatile lds_f32 *a = (volatile lds_f32 *)acc;
     const float old = a[i];
     a[i] = __fadd_rn(old, term);
     return old;
@@ -260,7 +267,7 @@ __device__ inline void acc_add(float *acc, int32_t i, float term) {
     if (ATOMIC) {
         __hip_atomic_fetch_add(&acc[i], term, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-        volatile float *a = acc;
+        volatile lds_f32 *a = (volatile lds_f32 *)acc;
         a[i] = __fadd_rn(a[i], term);
     }
 }
@@ -271,11 +278,14 @@ __device__ inline float acc_take(float *acc, int32_t i) {
 // What a lane holds of one VISIT = (group or stripe, chunk of 64 of the query's indices): its index's directory entry and value,
 // the segment [s, e) of that index's posting list, and the first kGather postings of it.  The three parts are loaded one visit
 // apart (see the pipeline in sparse_tile_kernel), so that no load is waited for.
+// Loaded values are never touched in the stage that loads them (a select on a loaded value is a wait for it): `in` says whether
+// the lane has an entry at all, cid / qv / s / e are raw until the next stage folds `in` into them.
 struct Visit {
+    bool in;  // the lane has an entry of the query in this visit (stage 1), and the index is stored (after stage 2)
     int32_t cid;
     float qv;
-    uint32_t s, e;
-    Posting P[kGather];
+    uint32_t s, e;  // valid where in (after stage 3's fold: s = e = 0 elsewhere)
+    Posting P[kGather];  // P[j] valid for j < e - s
 };
 
 // the group's / stripe's state while it accumulates
@@ -303,7 +313,7 @@ __device__ inline void touch(uint16_t *touched, int tcap, GroupState &gs, bool a
 // Rows whose accumulator was +0 before the add go on the touched list (a sum that returns to zero and is reached again is
 // listed twice; the read-back takes it once).
 template <bool ATOMIC>
-__device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_t *tag, uint16_t *touched, int tcap, int lane,
+__device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8 *tag, uint16_t *touched, int tcap, int lane,
                                      GroupState &gs, Trace &tr) {
     const uint32_t len = v.e - v.s;
     bool pending = len > 0;
@@ -347,72 +357,6 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile uint8_
     gs.walked += wave_sum_u32(len);
 }
 
-// One list at a time, its postings over the lanes (segments longer than kGather).  The first 64 postings of the next SEVEN
-// segments are in flight while one is applied (the compiler keeps loads behind the LDS atomics of the program order, so the
-// look-ahead is spelled out).  Every accumulator reached goes on the touched list (no +0 test: the add returns nothing here).
-// track = false (a stripe of a long query: it reaches most of its rows and is read back densely): no touched list.
-template <bool ATOMIC>
-__device__ inline void apply_one_by_one(const Posting *__restrict__ post, const Visit &v, float *acc, uint16_t *touched, int tcap,
-                                        int lane, GroupState &gs, Trace &tr, bool track) {
-    struct Seg {
-        uint32_t sl, el;  // wave-uniform; el == sl: none
-        float ql;
-        Posting P;
-    };
-    unsigned long long m = __ballot(v.e > v.s);
-    auto next = [&](Seg &x) {
-        x.sl = 0, x.el = 0, x.ql = 0.0f;
-        x.P = Posting{0, 0.0f};
-        if (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            x.sl = lane_u32(v.s, l), x.el = lane_u32(v.e, l), x.ql = lane_f32(v.qv, l);
-            if (x.sl + lane < x.el) x.P = post[x.sl + lane];
-        }
-    };
-    // a ring of kAhead segments whose first 64 postings are in flight; the loop is unrolled over the ring so that the ring
-    // slots are registers
-    constexpr int kAhead = 8;
-    Seg ring[kAhead];
-#pragma unroll
-    for (int i = 0; i < kAhead - 1; i++) next(ring[i]);
-    bool more = ring[0].el > ring[0].sl;
-    while (more) {
-#pragma unroll
-        for (int slot = 0; slot < kAhead; slot++) {
-            Seg &r0 = ring[slot];
-            if (!(r0.el > r0.sl)) {
-                more = false;
-                break;
-            }
-            next(ring[(slot + kAhead - 1) % kAhead]);
-            {
-                const bool have = r0.sl + lane < r0.el;
-                if (have) acc_add<ATOMIC>(acc, r0.P.loc, __fmul_rn(r0.ql, r0.P.val));
-                if (track) touch(touched, tcap, gs, have, r0.P.loc, lane);
-            }
-            for (uint32_t p = r0.sl + kBlock; p < r0.el; p += 4 * kBlock) {  // long segments: four loads in flight
-                Posting x[4];
-                bool have[4];
-    #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t at = p + j * kBlock + lane;
-                    have[j] = at < r0.el;
-                    x[j] = Posting{0, 0.0f};
-                    if (have[j]) x[j] = post[at];
-                }
-    #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (have[j]) acc_add<ATOMIC>(acc, x[j].loc, __fmul_rn(r0.ql, x[j].val));
-                    if (track) touch(touched, tcap, gs, have[j], x[j].loc, lane);
-                }
-            }
-            gs.walked += r0.el - r0.sl;
-            tr.slow_segments++;
-        }
-    }
-}
-
 // Flattened batches (visits with a segment longer than kGather).  The segments of the visit are laid end to end in list order
 // and cut into batches of 64 postings, one per lane: a batch holds the tail of one list, whole lists, and the head of another.
 // Within one list the rows are distinct; two lists of a batch may share a row, and then the earlier list's product has to go
@@ -423,7 +367,7 @@ __device__ inline void apply_one_by_one(const Posting *__restrict__ post, const 
 // pass spent 0.27 us per SEGMENT of 4 postings on average -- 3.2e8 of them, profiles/r02_k_probe_sparse_trace.txt.)
 // Assembly is a wave-uniform walk over the lists; kFlatAhead batches are in flight while one is applied.
 template <bool ATOMIC>
-__device__ inline void apply_flattened(const Posting *__restrict__ post, const Visit &v, float *acc, volatile uint8_t *tag,
+__device__ inline void apply_flattened(const Posting *__restrict__ post, const Visit &v, float *acc, volatile lds_u8 *tag,
                                        uint16_t *touched, int tcap, int lane, GroupState &gs, Trace &tr, bool track) {
     struct Batch {
         Posting P;
@@ -455,8 +399,8 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
             cur_s += take, b.n += (int)take, lists++;
         }
         b.mixed = lists > 1;
-        b.P = Posting{0, 0.0f};
-        if (lane < b.n) b.P = post[addr];
+        b.P = post[addr];  // every fill issues exactly one load (lanes past n read posting 0 and are not applied): the wait for a
+                           // batch is then "all but the kFlatAhead - 1 younger loads" on every path, not "all loads"
     };
     auto apply = [&](const Batch &b) {
         const bool have = lane < b.n;
@@ -479,7 +423,8 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
                 const unsigned long long same = __ballot(have && row == r);
                 if (have && row == r) rank = lanes_below(same, lane);
                 lost &= ~same;
-                last = max(last, __popcll(same) - 1);
+                const int sharers = (int)__popcll(same) - 1;
+                last = sharers > last ? sharers : last;
                 tr.shared_rows++;
             }
             for (int rd = 0; rd <= last; rd++)
@@ -489,10 +434,12 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
         gs.walked += (uint32_t)b.n;
         tr.batches++;
     };
+    // kFlatAhead batches in flight; a slot is refilled right after it was applied (its own load has been waited for, so the
+    // refill never waits for a register that may still be a load's destination)
     constexpr int kFlatAhead = 6;
     Batch ring[kFlatAhead];
 #pragma unroll
-    for (int i = 0; i < kFlatAhead - 1; i++) fill(ring[i]);
+    for (int i = 0; i < kFlatAhead; i++) fill(ring[i]);
     bool more = ring[0].n > 0;
     while (more) {
 #pragma unroll
@@ -501,8 +448,8 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
                 more = false;
                 break;
             }
-            fill(ring[(slot + kFlatAhead - 1) % kFlatAhead]);
             apply(ring[slot]);
+            fill(ring[slot]);
         }
     }
 }
@@ -514,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     const int NL = a.nacc_lds;  // accumulators in LDS, a multiple of 64
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(s_mem);
     float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
-    volatile uint8_t *tag = s_mem + (size_t)CAP * 8 + (size_t)NL * 4;
+    volatile lds_u8 *tag = (volatile lds_u8 *)(s_mem + (size_t)CAP * 8 + (size_t)NL * 4);
     uint16_t *touched = reinterpret_cast<uint16_t *>(s_mem + (size_t)CAP * 8 + (size_t)NL * 5);  // NL / 4 entries
     const int lane = threadIdx.x;
     for (int i = lane; i < NL; i += kBlock) acc[i] = 0.0f;
@@ -548,50 +495,34 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const int64_t nch = (L + kBlock - 1) / kBlock;  // chunks of 64 indices
         const int64_t V = nch * nviews;                 // visits, view-major
         // The pipeline: while visit v is applied, the postings of v + 1, the directory entries of v + 2 and the (index, value)
-        // pairs of v + 3 are in flight.  A query of at most 64 entries has one chunk: its pairs stay in registers.
-        const bool small = nch <= 1;
-        int32_t cid0 = -1;
-        float qv0 = 0.0f;
-        if (small && lane < L) {
-            cid0 = a.q_cid[qs + lane];
-            qv0 = a.q_val[qs + lane];
-        }
+        // pairs of v + 3 are in flight.  (A query of one chunk re-reads its 64 pairs at every visit: two cached loads, and no
+        // branch in the loop that would make the compiler wait for everything in flight.)
         // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (view, chunk) counters
         int64_t c1 = 0, c2 = 0;
         int g2 = whole ? 0 : wk.part;
+        // Every stage issues the SAME loads on every path (clamped addresses, results masked afterwards; the host pads each
+        // array by one element): a load that a branch may skip makes the compiler's wait for any OLDER load "wait for all".
         auto stage1 = [&](int64_t v, Visit &x) {
-            x.cid = -1, x.qv = 0.0f;
-            if (v >= V) return;
-            if (small) {
-                x.cid = cid0, x.qv = qv0;
-                return;
-            }
             const int64_t at = c1 * kBlock + lane;
-            if (at < L) {
-                x.cid = a.q_cid[qs + at];
-                x.qv = a.q_val[qs + at];
-            }
+            x.in = v < V && at < L;
+            x.cid = a.q_cid[qs + (x.in ? at : 0)];
+            x.qv = a.q_val[qs + (x.in ? at : 0)];
             if (++c1 == nch) c1 = 0;
         };
-        auto stage2 = [&](int64_t v, Visit &x) {
-            x.s = 0, x.e = 0;
-            if (v >= V) return;
-            if (x.cid >= 0) {
-                const uint32_t *o = off + (size_t)x.cid * dir_stride + g2;
-                x.s = o[0], x.e = o[1];
-            }
+        auto stage2 = [&](int64_t v, Visit &x) {  // folds stage 1: in &= the index is stored
+            x.in = x.in && x.cid >= 0;
+            const uint32_t *o = off + (x.in ? (size_t)x.cid * dir_stride + g2 : (size_t)0);
+            x.s = o[0], x.e = o[1];
             if (++c2 == nch) {
                 c2 = 0;
                 g2++;
             }
         };
-        auto stage3 = [&](Visit &x) {
+        auto stage3 = [&](Visit &x) {  // folds stage 2: s = e = 0 where the lane has nothing
+            if (!x.in) x.s = 0, x.e = 0;
             const uint32_t len = x.e - x.s;
 #pragma unroll
-            for (int j = 0; j < kGather; j++) {
-                x.P[j] = Posting{0, 0.0f};
-                if ((uint32_t)j < len) x.P[j] = post[x.s + j];
-            }
+            for (int j = 0; j < kGather; j++) x.P[j] = post[x.s + ((uint32_t)j < len ? j : 0)];
         };
         Visit v0, v1, v2, v3;
         stage1(0, v0);
@@ -604,26 +535,38 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         int64_t c = 0;  // chunk of visit v inside its view
         int g = 0;
         for (int64_t v = 0; v < V; v++) {
-            stage1(v + 3, v3);
-            stage2(v + 2, v2);
+            // consumers first: each stage needs what the stage before it loaded during the PREVIOUS visit, so whatever the compiler
+            // waits for here has had a whole visit to arrive
             stage3(v1);
+            stage2(v + 2, v2);
+            stage1(v + 3, v3);
             {   // visit v
                 const uint32_t len = v0.e - v0.s;
                 if (__ballot(len > 0)) {
-                    if (!__ballot(len > (uint32_t)kGather))
+                    const unsigned long long c0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+                    const bool once = !__ballot(len > (uint32_t)kGather);
+                    if (once)
                         apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, lane, gs, tr);
-                    else if (a.flat)
-                        apply_flattened<ATOMIC>(post, v0, acc, tag, touched, tcap, lane, gs, tr, whole);
                     else
-                        apply_one_by_one<ATOMIC>(post, v0, acc, touched, tcap, lane, gs, tr, whole);
+                        apply_flattened<ATOMIC>(post, v0, acc, tag, touched, tcap, lane, gs, tr, whole);
+                    if (a.trace) (once ? tr.ticks_once : tr.ticks_flat) += (uint32_t)(__builtin_amdgcn_s_memrealtime() - c0);
                 }
             }
             if (++c == nch) {  // the view is complete: read it back
+                const unsigned long long c0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
                 if (gs.walked > 0) {
-                    auto consider = [&](bool have, int32_t i, float x) {
+                    // sid = the row's scratch id, og = orig_of[sid], loaded one step ahead of its use (the read-back used to wait
+                    // for this gather inside every step that had a candidate: 43 us per group of 2048 accumulators,
+                    // profiles/r02_k_probe_sparse_trace.txt)
+                    auto sid_of = [&](int32_t i) { return whole ? ((int64_t)g << a.logG) + i : ((int64_t)i << a.logS) + wk.part; };
+                    auto orig_at = [&](bool in, int32_t i) {
+                        const int64_t sid = sid_of(i);
+                        return in && sid < a.N ? a.orig_of[sid] : 0;
+                    };
+                    auto consider = [&](bool have, int32_t i, float x, int32_t og, bool og_loaded) {
                         have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
                         if (!__ballot(have)) return;
-                        const int64_t sid = whole ? ((int64_t)g << a.logG) + i : ((int64_t)i << a.logS) + wk.part;
+                        const int64_t sid = sid_of(i);
                         my_hit += have;
                         have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
                         const uint32_t ord = score_ord(x);
@@ -631,15 +574,29 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         my_neg += have && ord < kZeroOrd;
                         const bool cand = have && ord >= (uint32_t)(thr >> 32);
                         if (!__ballot(cand)) return;
-                        const unsigned long long key = cand ? make_key(ord, a.orig_of[sid]) : 0;
+                        if (!og_loaded) og = cand ? a.orig_of[sid] : 0;
+                        const unsigned long long key = cand ? make_key(ord, og) : 0;
                         push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
                     };
                     if (!whole || (int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
                         tr.dense_groups++;
-                        for (int i = lane; i < nacc; i += kBlock) {
-                            const float x = acc[i];
-                            if (__float_as_uint(x) != 0) acc[i] = 0.0f;
-                            consider(true, i, x);
+                        constexpr int kStep = 4;
+                        int32_t og_next[kStep];
+#pragma unroll
+                        for (int j = 0; j < kStep; j++) og_next[j] = orig_at(j * kBlock + lane < nacc, j * kBlock + lane);
+                        for (int i0 = 0; i0 < nacc; i0 += kStep * kBlock) {
+                            int32_t og[kStep];
+                            float x[kStep];
+#pragma unroll
+                            for (int j = 0; j < kStep; j++) {
+                                const int i = i0 + j * kBlock + lane, in = i0 + (kStep + j) * kBlock + lane;
+                                og[j] = og_next[j];
+                                og_next[j] = orig_at(in < nacc, in);
+                                x[j] = i < nacc ? acc[i] : 0.0f;
+                                if (__float_as_uint(x[j]) != 0) acc[i] = 0.0f;
+                            }
+#pragma unroll
+                            for (int j = 0; j < kStep; j++) consider(i0 + j * kBlock + lane < nacc, i0 + j * kBlock + lane, x[j], og[j], true);
                         }
                     } else {
                         tr.sparse_groups++;
@@ -647,10 +604,15 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                             const bool have = i0 + lane < gs.tcnt;
                             const int i = have ? (int)touched[i0 + lane] : 0;
                             const float x = have ? acc_take(acc, i) : 0.0f;  // an accumulator listed twice: the first taker gets it
-                            consider(have, i, x);
+                            consider(have, i, x, 0, false);  // few candidates once the threshold has risen: the gather is the exception
                         }
                     }
                     walked_q += gs.walked;
+                }
+                if (a.trace) {
+                    const unsigned long long c1 = __builtin_amdgcn_s_memrealtime();
+                    tr.ticks_back += (uint32_t)(c1 - c0);
+                    if (g == 7) tr.ticks_head = (uint32_t)(c1 - tr.t0);
                 }
                 gs = GroupState{0, 0};
                 c = 0;

@@ -66,13 +66,11 @@ void gorse_hip_test_set_sparse_split(int64_t entries);
 void gorse_hip_test_set_sparse_atomic(int32_t mode);
 /* 1 (default) = the stripes of the long queries run on a second stream next to the ordinary queries, 0 = before them. */
 void gorse_hip_test_set_sparse_streams(int32_t two);
-/* 1 (default) = visits with a segment of more than 8 postings are applied as flattened batches of 64 postings, 0 = one list at a
- * time (the round-2 first form, kept for the comparison in profiles/). */
-void gorse_hip_test_set_sparse_flat(int32_t flat);
 /* probe: with on != 0 the following calls of the handle record what every work item (a query, or one stripe of a long query)
- * did; with out != NULL copies up to cap records of the last call as 12 uint64 each: {start, end (100 MHz ticks), query,
+ * did; with out != NULL copies up to cap records of the last call as 16 uint64 each: {start, end (100 MHz ticks), query,
  * stripe + 1 (0 = whole query), entries, chunks taken 64 lists at once, their rounds, segments walked one list at a time,
- * groups read back densely, groups read back by re-walking, flattened batches, rows two lists of a batch shared}.  Returns the number of work items of the last call. */
+ * groups read back densely, groups read back by re-walking, flattened batches, rows two lists of a batch shared,
+ * 10 ns ticks in the 64-lists-at-once path / in the batches / in the read-backs / until the end of the eighth group}.  Returns the number of work items of the last call. */
 int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /*host or NULL*/, int64_t cap);
 /* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
  * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.

@@ -14,7 +14,6 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "c3"
     tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     flat = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    capi.lib().gorse_hip_test_set_sparse_flat(flat)
     data = synth.s_big_shard(rank=0, world=8) if which == "c3" else synth.s_ml1m()
     ptr, idx, val = synth.idf_vectors(data.iptr, data.iidx, data.U)
     capi.lib().gorse_hip_test_set_sparse_tile(tile)
@@ -44,13 +43,17 @@ def main():
             print("%-18s n=%7d  total %.1f ms  entries %.3e  chunks at once %.3e (rounds %.3e)  one-list segments %.3e  dense groups %.3e  re-walked %.3e  batches %.3e  shared rows %.3e"
                   % (name, m.sum(), dur[m].sum() / 1e3, tr[m, 4].sum(), tr[m, 5].sum(), tr[m, 6].sum(), tr[m, 7].sum(), tr[m, 8].sum(), tr[m, 9].sum(),
                      tr[m, 10].sum(), tr[m, 11].sum()))
+    for name, m in (("whole-query items", ~split), ("stripe parts", split)):
+        if m.any():
+            print("%-18s ms inside: 64 lists at once %.1f, batches / one list at a time %.1f, read-backs %.1f; until the end of group 8: %.1f"
+                  % (name, tr[m, 12].sum() / 1e5, tr[m, 13].sum() / 1e5, tr[m, 14].sum() / 1e5, tr[m, 15].sum() / 1e5))
     # a linear model of an item's duration in its counters: microseconds per unit
     cols = [np.ones(len(tr)), tr[:, 4], tr[:, 5], tr[:, 6], tr[:, 7], tr[:, 8], tr[:, 9]] + ([tr[:, 10], tr[:, 11]] if flat else [])
     X = np.stack(cols, axis=1).astype(np.float64)
     coef, *_ = np.linalg.lstsq(X, dur, rcond=None)
     print(("least-squares us per: item %.2f, entry %.4f, chunk at once %.3f, round %.3f, one-list segment %.4f, dense group %.2f, re-walked group %.2f"
            + (", batch %.3f, shared row %.3f" if flat else "")) % tuple(coef))
-    capi.lib().gorse_hip_test_set_sparse_flat(1)
+
     capi.lib().gorse_hip_test_set_sparse_tile(0)
 
 

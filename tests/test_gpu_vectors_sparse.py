@@ -139,7 +139,6 @@ def hooks():
     L.gorse_hip_test_set_sparse_stripe_rows(0)
     L.gorse_hip_test_set_sparse_split(2048)
     L.gorse_hip_test_set_sparse_atomic(-1)
-    L.gorse_hip_test_set_sparse_flat(1)
 
 
 @pytest.mark.parametrize("k", [5, 70, 300])
@@ -200,13 +199,12 @@ def test_tiny_values_take_the_non_atomic_form(oracle):
     assert (np.abs(got[1][np.isfinite(got[1])]) < 2.0 ** -126).any()  # subnormal scores were produced and ranked
 
 
-@pytest.mark.parametrize("flat", [1, 0])
 @pytest.mark.parametrize("atomic", [1, 0])
-def test_lists_that_share_rows_keep_the_index_order(oracle, flat, atomic, hooks):
+def test_lists_that_share_rows_keep_the_index_order(oracle, atomic, hooks):
     """Dense-ish rows with values over 12 orders of magnitude and both signs: every accumulator is reached by most lists of a
     query and its float32 sum depends on the order of the products.  Posting lists of 10 .. 200 postings per group laid into
-    batches of 64 (several lists per batch, shared rows in nearly every batch), and the same one list at a time."""
-    rng = np.random.default_rng(31 + flat)
+    batches of 64 (several lists per batch, shared rows in nearly every batch)."""
+    rng = np.random.default_rng(31)
     rows, dims = 700, 150
     ptr = np.zeros(rows + 1, np.int64)
     idx, val = [], []
@@ -216,7 +214,6 @@ def test_lists_that_share_rows_keep_the_index_order(oracle, flat, atomic, hooks)
         idx.append(have.astype(np.uint32))
         val.append((np.exp(rng.uniform(-14, 14, have.size)) * rng.choice([-1.0, 1.0], have.size)).astype(np.float32))
     idx, val = np.concatenate(idx), np.concatenate(val)
-    hooks.gorse_hip_test_set_sparse_flat(flat)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
     for tile, split in ((256, 0), (2048, 0), (256, 64)):  # groups of 256 / one group / long queries over row stripes
         hooks.gorse_hip_test_set_sparse_tile(tile)
@@ -241,7 +238,6 @@ def test_random_configurations(oracle, hooks):
         hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 2048])))
         hooks.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
         hooks.gorse_hip_test_set_sparse_atomic(int(rng.choice([-1, 0, 1])))
-        hooks.gorse_hip_test_set_sparse_flat(int(rng.integers(0, 4) > 0))
         s = capi.Sparse(ptr, idx, val)
         k = int(rng.choice([1, 2, 7, 64, 65, 300]))
         mask = None
