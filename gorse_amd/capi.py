@@ -95,10 +95,8 @@ SIGNATURES = {
     "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
-    "gorse_hip_test_set_sparse_stripe_rows": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_atomic": (None, [C.c_int32]),
-    "gorse_hip_test_set_sparse_streams": (None, [C.c_int32]),
     "gorse_hip_test_sparse_trace": (C.c_int64, [_vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int64]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),

@@ -546,11 +546,18 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         if (beg >= end) continue;
         float *pu = P + u * d;
         // item rows are gathered TWO samples ahead of the arithmetic (a/b: this sample, a1/b1: the next, a2/b2 in
-        // flight); positions past the run's end re-read the last sample's rows (result unused)
+        // flight), their indices THREE ahead and the hot-row slot of a positive item one ahead; positions past the run's end
+        // re-read the last sample (result unused).  Nothing is used in the iteration that loads it: the counter the waits go
+        // by also counts the atomics, so a wait for a load issued after them is a wait for their acknowledgement from L2 --
+        // once per sample in the first form of this loop (s_waitcnt vmcnt(0) behind the index loads and behind hot.slot[i]).
         float p[NC], a[NC], b[NC], a1[NC], b1[NC], a2[NC], b2[NC];
         const int last = end - 1;
+        auto at = [&](int s) { return s <= last ? s : last; };
+        const int32_t *slot_of = hot.n_hot > 0 ? hot.slot : si;  // without hot rows: any readable word, the value is not used
         int i = si[beg], j = sj[beg];
-        int i1 = si[beg + 1 <= last ? beg + 1 : last], j1 = sj[beg + 1 <= last ? beg + 1 : last];
+        int i1 = si[at(beg + 1)], j1 = sj[at(beg + 1)];
+        int i2 = si[at(beg + 2)], j2 = sj[at(beg + 2)];
+        int slot = slot_of[hot.n_hot > 0 ? i : beg], slot1 = slot_of[hot.n_hot > 0 ? i1 : beg];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
@@ -560,18 +567,15 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j1 * d + 16 * c + lane);
         }
         for (int s = beg; s < end; s++) {
-            const int s2 = s + 2 <= last ? s + 2 : last;
-            const int i2 = si[s2], j2 = sj[s2];
+            const int i3 = si[at(s + 3)], j3 = sj[at(s + 3)];
+            const int slot2 = slot_of[hot.n_hot > 0 ? i2 : beg];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i2 * d + 16 * c + lane);
                 b2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j2 * d + 16 * c + lane);
             }
             float *qi = Q + (int64_t)i * d, *qj = Q + (int64_t)j * d;
-            if (hot.n_hot > 0) {
-                const int slot = hot.slot[i];
-                if (slot >= 0) qi = hot.rep + ((int64_t)slot * kHotReplicas + (group & (kHotReplicas - 1))) * d;
-            }
+            if (hot.n_hot > 0 && slot >= 0) qi = hot.rep + ((int64_t)slot * kHotReplicas + (group & (kHotReplicas - 1))) * d;
             const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
             const float ex = bpr_exp(-diff, exp_mode);
             const float grad = ex / (1.0f + ex);
@@ -590,10 +594,8 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
                 a1[c] = a2[c];
                 b1[c] = b2[c];
             }
-            i = i1;
-            j = j1;
-            i1 = i2;
-            j1 = j2;
+            i = i1, j = j1, i1 = i2, j1 = j2, i2 = i3, j2 = j3;
+            slot = slot1, slot1 = slot2;
         }
 #pragma unroll
         for (int c = 0; c < NC; c++)  // the only writer of this row in the launch

@@ -16,17 +16,14 @@ using gorse::sparse::TileArgs;
 struct gorse_sparse {
     int device = 0;
     int64_t N = 0, nnz = 0, Dc = 0;
-    int32_t logG = 0, ngroups = 0;  // arrangement A: groups of G = 1 << logG consecutive scratch ids
-    int32_t logS = 0, naccB = 0;    // arrangement B: S = 1 << logS stripes (scratch id mod S) of naccB rows
+    int32_t logG = 0, ngroups = 0;  // groups of G = 1 << logG consecutive scratch ids
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // the stripes of the long queries run next to the ordinary queries (run_queries)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // stored rows as CSR with directory entries instead of raw indices (the queries of all_pairs), the tiled posting lists
     DevBuf<int64_t> r_ptr;
     DevBuf<int32_t> r_cid, orig_of, new_of;
     DevBuf<float> r_val;
-    DevBuf<uint32_t> dims, offA, offB;
-    DevBuf<sparse::Posting> postA, postB;
+    DevBuf<uint32_t> dims, off;
+    DevBuf<sparse::Posting> post;
     DevBuf<uint8_t> mask_sid;
     bool has_mask = false;
     int64_t n_admissible = 0;  // rows with mask != 0 (N without a mask)
@@ -37,7 +34,6 @@ struct gorse_sparse {
     DevBuf<int64_t> q_ptr, q_excl;
     DevBuf<uint32_t> q_idx;
     DevBuf<int32_t> q_cid, out_idx, out_cnt, next, split_t, part_cnt;
-    DevBuf<sparse::Work> workB;
     DevBuf<float> q_val, out_score;
     DevBuf<sparse::Work> work;
     DevBuf<unsigned long long> part_keys, stat;
@@ -56,12 +52,10 @@ struct gorse_sparse {
 namespace {
 
 // probes / test hooks (include/gorse_hip_test.h); results never depend on them
-int g_sparse_tile = 0;           // rows per group of arrangement A (power of two, 256 .. 16384); 0 = 2048
-int64_t g_sparse_split = 2048;   // queries with more entries than this are split over the stripes of arrangement B; <= 0 = never
-int g_sparse_stripe_rows = 0;    // rows per stripe of arrangement B are at most this (power of two); 0 = 8192
+int g_sparse_tile = 0;           // rows per group (power of two, 256 .. 16384); 0 = 2048
+int64_t g_sparse_split = 2048;   // queries with more entries than this become one work item per group; <= 0 = never
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
-int g_sparse_two_streams = 1;    // the long queries' stripes on a second stream next to the ordinary queries
 
 int pick_log_group() {
     int l = 11;  // 2048 rows: 8 KB of accumulators + 2 KB of stamps + 1 KB of touched list, 10 waves per CU with KP = 256
@@ -72,14 +66,6 @@ int pick_log_group() {
     }
     return l;
 }
-// stripes of arrangement B: the fewest (a power of two, at least 2) whose row count fits the LDS budget of a stripe
-int pick_log_stripes(int64_t N) {
-    const int64_t most = g_sparse_stripe_rows > 0 ? g_sparse_stripe_rows : 8192;
-    int l = 1;
-    while (ceil_div(N, (int64_t)1 << l) > most && l < 20) l++;
-    return l;
-}
-
 template <int KP>
 int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, hipStream_t s) {  // s: the stream of this launch
     auto k1 = sparse::sparse_tile_kernel<KP, true>;
@@ -109,48 +95,27 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
                     float *score_out, int32_t *cnt_out) {
     const int kp = sparse::pick_kp(k);
     if (!kp) return fail(GORSE_ERR_INVALID, "k = %d: must be in 1..1024", k);
-    if (nq > (INT32_MAX >> (h->logS + 1))) return fail(GORSE_ERR_INVALID, "too many queries in one call");
+    if (nq > INT32_MAX / 2) return fail(GORSE_ERR_INVALID, "too many queries in one call");
     GORSE_TRY(h->out_idx.ensure((size_t)nq * k));
     GORSE_TRY(h->out_score.ensure((size_t)nq * k));
     GORSE_TRY(h->out_cnt.ensure((size_t)nq));
     GORSE_TRY(h->stat.ensure(2));
-    // work items, longest first: a long query as one item per stripe of arrangement B (+ a merge), the others as one item
-    // over arrangement A
-    const int S = 1 << h->logS;
-    std::vector<sparse::Work> workA, workB;
-    std::vector<int32_t> split_t;
-    workA.reserve((size_t)nq);
-    for (int64_t t = 0; t < nq; t++) {
-        const int64_t L = q_len_host[t + 1] - q_len_host[t];
-        if (g_sparse_split > 0 && L > g_sparse_split) {
-            for (int s = 0; s < S; s++) workB.push_back(sparse::Work{(int32_t)t, s, (int32_t)split_t.size()});
-            split_t.push_back((int32_t)t);
-        } else {
-            workA.push_back(sparse::Work{(int32_t)t, -1, 0});
-        }
-    }
-    auto by_length = [&](const sparse::Work &x, const sparse::Work &y) {
-        return q_len_host[x.t + 1] - q_len_host[x.t] > q_len_host[y.t + 1] - q_len_host[y.t];
-    };
-    std::stable_sort(workA.begin(), workA.end(), by_length);
-    std::stable_sort(workB.begin(), workB.end(), by_length);
-    GORSE_TRY(h->next.ensure(2));
-    GORSE_TRY(h->work.ensure(workA.size()));
-    GORSE_TRY(h->workB.ensure(workB.size()));
-    if (!workA.empty())
-        GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, workA.data(), workA.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
-    if (!workB.empty()) {
-        GORSE_HIP_CHECK(hipMemcpyAsync(h->workB.p, workB.data(), workB.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
-        GORSE_TRY(h->split_t.ensure(split_t.size()));
-        GORSE_TRY(h->part_keys.ensure(split_t.size() * (size_t)S * (size_t)kp));
-        GORSE_TRY(h->part_cnt.ensure(split_t.size() * (size_t)S * 2));
-        GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, split_t.data(), split_t.size() * 4, hipMemcpyHostToDevice, h->stream));
-    }
+    GORSE_TRY(h->next.ensure(1));
+    // Work items: a long query as one item per group (+ a merge of the partial rankings), the others as one item each.  Long
+    // queries first, everything longest first: the launch ends with the cheap items.  The partial rankings of the long queries
+    // are bounded (kPartBytes): a call with more long queries than fit takes several launches.
+    const int64_t ng = h->ngroups;
+    std::vector<int32_t> longs, shorts;
+    for (int64_t t = 0; t < nq; t++)
+        (g_sparse_split > 0 && q_len_host[t + 1] - q_len_host[t] > g_sparse_split ? longs : shorts).push_back((int32_t)t);
+    auto by_length = [&](int32_t x, int32_t y) { return q_len_host[x + 1] - q_len_host[x] > q_len_host[y + 1] - q_len_host[y]; };
+    std::stable_sort(longs.begin(), longs.end(), by_length);
+    std::stable_sort(shorts.begin(), shorts.end(), by_length);
+    constexpr size_t kPartBytes = (size_t)2 << 30;
+    const size_t per_launch = std::max<size_t>(1, kPartBytes / ((size_t)ng * kp * 8));
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
-    GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, 2 * sizeof(int32_t), h->stream));
     TileArgs a;
-    a.offA = h->offA.p, a.postA = h->postA.p, a.ngroups = h->ngroups, a.logG = h->logG;
-    a.offB = h->offB.p, a.postB = h->postB.p, a.logS = h->logS, a.naccB = h->naccB;
+    a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG;
     a.N = h->N;
     a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
     a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
@@ -159,63 +124,69 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.n_admissible = h->has_mask ? h->n_admissible : h->N;
     a.k = k;
     a.out_idx = h->out_idx.p, a.out_score = h->out_score.p, a.out_cnt = h->out_cnt.p;
-    a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
     a.stat = h->stat.p;
-    a.trace = nullptr;
-    const size_t n_items = workA.size() + workB.size();
-    if (h->trace_on) {
-        GORSE_TRY(h->trace.ensure(n_items));
-        a.trace = h->trace.p;
-    }
+    a.next = h->next.p;
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     // LDS of a workgroup: ranking buffer + per accumulator 4 B (sum) + 1 B (stamp) + 0.5 B (touched list)
-    auto lds_for = [&](int64_t nacc) { return (size_t)2 * kp * 8 + (size_t)nacc * 11 / 2; };
-    auto launch = [&](const TileArgs &x, size_t n, size_t lds, hipStream_t st) -> int32_t {
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n, slots));
-        switch (kp) {
-            case 256: return launch_tiles<256>(x, grid, lds, atomic, st);
-            case 512: return launch_tiles<512>(x, grid, lds, atomic, st);
-            default: return launch_tiles<1024>(x, grid, lds, atomic, st);
-        }
-    };
+    const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 << h->logG) / 2;
     const int tok = h->prof.begin(0, h->stream);
-    if (!workB.empty()) {
-        // The stripes of the long queries on a second stream, next to the ordinary queries: a stripe's workgroup needs 2.5 x
-        // the LDS of a group's, so on their own the stripes leave the CUs at 4 waves (1024 of the chip's 2560 slots busy for
-        // 40 % of the pass, profiles/r02_j_probe_sparse_trace.txt); the ordinary queries fill the rest.
-        hipStream_t st2 = g_sparse_two_streams ? h->stream2 : h->stream;
-        if (st2 != h->stream) {
-            GORSE_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));  // uploads and memsets above
-            GORSE_HIP_CHECK(hipStreamWaitEvent(st2, h->ev_fork, 0));
+    std::vector<sparse::Work> work;
+    h->trace_host.clear();
+    for (size_t l0 = 0; l0 == 0 || l0 < longs.size(); l0 += per_launch) {
+        const size_t l1 = std::min(longs.size(), l0 + per_launch);
+        work.clear();
+        for (size_t l = l0; l < l1; l++)
+            for (int32_t g = 0; g < h->ngroups; g++) work.push_back(sparse::Work{longs[l], g, (int32_t)(l - l0)});
+        if (l0 == 0)
+            for (int32_t t : shorts) work.push_back(sparse::Work{t, -1, 0});
+        if (work.empty()) break;
+        const size_t n_long = l1 - l0;
+        GORSE_TRY(h->work.ensure(work.size()));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
+        if (n_long > 0) {
+            GORSE_TRY(h->split_t.ensure(n_long));
+            GORSE_TRY(h->part_keys.ensure(n_long * (size_t)ng * (size_t)kp));
+            GORSE_TRY(h->part_cnt.ensure(n_long * (size_t)ng * 2));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, longs.data() + l0, n_long * 4, hipMemcpyHostToDevice, h->stream));
         }
-        TileArgs b = a;
-        b.work = h->workB.p, b.n_work = (int32_t)workB.size(), b.next = h->next.p + 1;
-        b.nacc_lds = (int32_t)(ceil_div(h->naccB, 64) * 64);
-        b.trace = a.trace ? a.trace + workA.size() : nullptr;
-        GORSE_TRY(launch(b, workB.size(), lds_for(b.nacc_lds), st2));
-        GORSE_HIP_CHECK(hipGetLastError());
-        sparse::MergeArgs m;
-        m.split_t = h->split_t.p, m.n_split = (int32_t)split_t.size(), m.nparts = S;
-        m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
-        m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
-        m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
-        m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
-        const unsigned mg = (unsigned)std::min<size_t>(split_t.size(), 4096);
+        GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sizeof(int32_t), h->stream));
+        a.work = h->work.p, a.n_work = (int32_t)work.size();
+        a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
+        a.trace = nullptr;
+        if (h->trace_on) {
+            GORSE_TRY(h->trace.ensure(work.size()));
+            a.trace = h->trace.p;
+        }
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
         switch (kp) {
-            case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, st2>>>(m); break;
-            case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, st2>>>(m); break;
-            default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, st2>>>(m); break;
+            case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;
+            case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, h->stream)); break;
+            default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, h->stream)); break;
         }
         GORSE_HIP_CHECK(hipGetLastError());
-        if (st2 != h->stream) GORSE_HIP_CHECK(hipEventRecord(h->ev_join, st2));
+        if (n_long > 0) {
+            sparse::MergeArgs m;
+            m.split_t = h->split_t.p, m.n_split = (int32_t)n_long, m.nparts = h->ngroups;
+            m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
+            m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
+            m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
+            m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
+            const unsigned mg = (unsigned)std::min<size_t>(n_long, 4096);
+            switch (kp) {
+                case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+                case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+                default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            }
+            GORSE_HIP_CHECK(hipGetLastError());
+        }
+        // the host work list, split_t and the trace buffer are reused by the next launch
+        if (l1 < longs.size() || h->trace_on) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->trace_on) {
+            const size_t at = h->trace_host.size();
+            h->trace_host.resize(at + work.size());
+            GORSE_HIP_CHECK(hipMemcpy(h->trace_host.data() + at, h->trace.p, work.size() * sizeof(sparse::Trace), hipMemcpyDeviceToHost));
+        }
     }
-    if (!workA.empty()) {
-        a.work = h->work.p, a.n_work = (int32_t)workA.size(), a.next = h->next.p;
-        a.nacc_lds = 1 << h->logG;
-        GORSE_TRY(launch(a, workA.size(), lds_for(a.nacc_lds), h->stream));
-        GORSE_HIP_CHECK(hipGetLastError());
-    }
-    if (!workB.empty() && g_sparse_two_streams) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     h->prof.end(tok, h->stream);
     unsigned long long st[2] = {0, 0};
     GORSE_HIP_CHECK(hipMemcpyAsync(st, h->stat.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -224,13 +195,9 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     if (score_out)
         GORSE_HIP_CHECK(hipMemcpyAsync(score_out, h->out_score.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
     if (cnt_out) GORSE_HIP_CHECK(hipMemcpyAsync(cnt_out, h->out_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
-    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from the work lists and `split_t`
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from the work list and `longs`
     h->last_postings = (int64_t)st[0];
     h->last_hits = (int64_t)st[1];
-    if (h->trace_on) {
-        h->trace_host.resize(n_items);
-        GORSE_HIP_CHECK(hipMemcpy(h->trace_host.data(), h->trace.p, n_items * sizeof(sparse::Trace), hipMemcpyDeviceToHost));
-    }
     return GORSE_OK;
 }
 
@@ -269,19 +236,12 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     h->Dc = (int64_t)dims.size();
     h->logG = pick_log_group();
     h->ngroups = (int32_t)ceil_div(N, (int64_t)1 << h->logG);
-    h->logS = pick_log_stripes(N);
-    h->naccB = (int32_t)ceil_div(N, (int64_t)1 << h->logS);
     int32_t rc = [&]() -> int32_t {
-        const int64_t cellsA = h->Dc * h->ngroups, cellsB = h->Dc << h->logS;
-        if (std::max(cellsA, cellsB) >= (int64_t)1 << 33)
-            return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d row groups / %d stripes", (long long)h->Dc,
-                        h->ngroups, 1 << h->logS);
-        if (h->naccB > 65536) return fail(GORSE_ERR_INVALID, "too many rows per stripe");
+        const int64_t cells = h->Dc * h->ngroups;
+        if (cells >= (int64_t)1 << 33)
+            return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d row groups", (long long)h->Dc, h->ngroups);
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-        GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         std::vector<int64_t> &ptr0 = h->r_ptr_host;
         ptr0.resize((size_t)N + 1);
         for (int64_t r = 0; r <= N; r++) ptr0[(size_t)r] = indptr[r] - base;
@@ -292,18 +252,15 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         GORSE_TRY(h->orig_of.alloc((size_t)N));
         GORSE_TRY(h->new_of.alloc((size_t)N));
         GORSE_TRY(h->dims.alloc((size_t)h->Dc));
-        GORSE_TRY(h->offA.alloc((size_t)cellsA + 2));
-        GORSE_TRY(h->offB.alloc((size_t)cellsB + 2));
-        GORSE_TRY(h->postA.alloc((size_t)nnz + 1));
-        GORSE_TRY(h->postB.alloc((size_t)nnz + 1));
+        GORSE_TRY(h->off.alloc((size_t)cells + 2));
+        GORSE_TRY(h->post.alloc((size_t)nnz + 1));
         DevBuf<uint32_t> raw, cursor, sums;
         GORSE_TRY(raw.alloc((size_t)nnz));
-        GORSE_TRY(cursor.alloc((size_t)std::max(cellsA, cellsB) + 1));
+        GORSE_TRY(cursor.alloc((size_t)cells + 1));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->orig_of.p, h->order.orig_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->new_of.p, h->order.new_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->r_ptr.p, ptr0.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, h->stream));
-        GORSE_HIP_CHECK(hipMemsetAsync(h->offA.p, 0, ((size_t)cellsA + 1) * 4, h->stream));
-        GORSE_HIP_CHECK(hipMemsetAsync(h->offB.p, 0, ((size_t)cellsB + 1) * 4, h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->off.p, 0, ((size_t)cells + 2) * 4, h->stream));
         if (nnz > 0) {
             GORSE_HIP_CHECK(hipMemcpyAsync(h->dims.p, dims.data(), dims.size() * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(raw.p, indices + base, (size_t)nnz * 4, hipMemcpyHostToDevice, h->stream));
@@ -311,21 +268,15 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
             const unsigned eg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(nnz, 256)));
             sparse::sparse_translate_kernel<<<dim3(eg), dim3(256), 0, h->stream>>>(raw.p, nnz, h->dims.p, h->Dc, h->r_cid.p);
             const unsigned rg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, ceil_div(N, 4)));
-            // each arrangement: counts per (index, bucket) -> exclusive scan = the directory -> scatter through a cursor copy
+            // counts per (index, group) -> exclusive scan = the directory -> scatter through a cursor copy
             sparse::BuildArgs b;
             b.r_ptr = h->r_ptr.p, b.r_cid = h->r_cid.p, b.r_val = h->r_val.p, b.N = N, b.new_of = h->new_of.p;
-            b.stride = h->ngroups, b.shift = h->logG, b.cnt = h->offA.p, b.post = h->postA.p;
-            sparse::sparse_build_kernel<false, false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
-            GORSE_TRY(scan_exclusive(h->offA.p, cellsA + 1, sums, h->stream));
-            GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->offA.p, ((size_t)cellsA + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
+            b.stride = h->ngroups, b.shift = h->logG, b.cnt = h->off.p, b.post = h->post.p;
+            sparse::sparse_build_kernel<false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
+            GORSE_TRY(scan_exclusive(h->off.p, cells + 1, sums, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->off.p, ((size_t)cells + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
             b.cnt = cursor.p;
-            sparse::sparse_build_kernel<true, false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
-            b.stride = 1 << h->logS, b.shift = h->logS, b.cnt = h->offB.p, b.post = h->postB.p;
-            sparse::sparse_build_kernel<false, true><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
-            GORSE_TRY(scan_exclusive(h->offB.p, cellsB + 1, sums, h->stream));
-            GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->offB.p, ((size_t)cellsB + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
-            b.cnt = cursor.p;
-            sparse::sparse_build_kernel<true, true><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
+            sparse::sparse_build_kernel<true><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
             GORSE_HIP_CHECK(hipGetLastError());
         }
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the temporaries die with this scope
@@ -345,16 +296,10 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
 extern "C" int32_t gorse_sparse_destroy(gorse_sparse *h) {
     if (!h) return GORSE_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream2) {
-        (void)hipStreamSynchronize(h->stream2);
-        (void)hipStreamDestroy(h->stream2);
-    }
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
     }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
     return GORSE_OK;
 }
@@ -461,7 +406,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
-// 16 uint64 {t0, t1 (100 MHz ticks), query, stripe + 1 (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
+// 16 uint64 {t0, t1 (100 MHz ticks), query, group + 1 of a long query (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
 // one list at a time, groups read back densely, groups read back by re-walking, flattened batches, rows shared inside a batch}; returns the number of work items
 extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out, int64_t cap) {
     if (!h) return -1;
@@ -478,7 +423,6 @@ extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint
     return (int64_t)h->trace_host.size();
 }
 extern "C" void gorse_hip_test_set_sparse_tile(int32_t rows) { g_sparse_tile = rows; }
-extern "C" void gorse_hip_test_set_sparse_stripe_rows(int32_t rows) { g_sparse_stripe_rows = rows; }
 extern "C" void gorse_hip_test_set_sparse_split(int64_t entries) { g_sparse_split = entries; }
 extern "C" void gorse_hip_test_set_sparse_atomic(int32_t mode) { g_sparse_atomic = mode; }
-extern "C" void gorse_hip_test_set_sparse_streams(int32_t two) { g_sparse_two_streams = two != 0; }
+

@@ -11,20 +11,19 @@
 //   with ds_add_f32.  A row occurs at most once per posting list, so the lanes of one instruction never collide, and the LDS
 //   executes one wave's instructions in issue order: every accumulator receives its products in ascending index order -- the
 //   float32 merge-order sparse dot of the oracle, bit for bit.
-// * The posting lists exist in two arrangements:
-//     A  sorted by row GROUP (G consecutive scratch ids, G accumulators in LDS): a query of ordinary length visits the groups
-//        one after the other, reading of every posting list the segment that falls into the group;
-//     B  sorted by row STRIPE (scratch id mod S, N / S accumulators in LDS): a LONG query is split into S work items, one per
-//        stripe, each of which walks every posting list of the query once, reading one contiguous segment of it; a merge
-//        kernel joins the S partial rankings.  (As group visits the longest query of the C3 shard took 186 ms on its own:
-//        49 groups x 1,820 chunks of scattered 8-byte reads, profiles/r02_f_probe_sparse_trace.txt.)
+// * The posting lists are sorted by row GROUP (G consecutive scratch ids, G accumulators in LDS): segment (c, g) holds the
+//   postings of index c that fall into group g.  A query of ordinary length is ONE work item that visits the groups one after
+//   the other; a LONG query (more than 2048 entries) is one work item PER GROUP, and a merge kernel joins the partial
+//   rankings.  (As one item the longest query of the C3 shard took 186 ms on its own; round 2's first answer, a second
+//   arrangement by row stripes with 2.5 x the LDS per item, left the chip at 4 waves per CU for 40 % of the pass and spent
+//   its time on the rows that the lists of a stripe share -- profiles/r02_f / r02_n_probe_sparse_trace.txt.)
 // * 64 lists at once: where every list of a chunk contributes at most 8 postings, every lane gathers the postings of ITS
 //   list, the lanes stamp their rows in a byte-per-row tag array and read the stamps back -- a foreign stamp means two lists
 //   share a row and the order of their products matters; rounds of "everybody below the lowest loser, then the loser" keep
 //   that order (see apply_at_once).  Longer segments go one list at a time with their postings over the lanes.
 // * Nothing waits for memory: the (index, value) pairs, directory entries and postings of the next three visits are in flight
 //   while one is applied.
-// * A group / stripe is read back either by a scan of its accumulators (dense) or from the list of accumulators that were +0
+// * A group is read back either by a scan of its accumulators (dense) or from the list of accumulators that were +0
 //   before an add (sparse); both leave the accumulators zero.
 //
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
@@ -52,14 +51,14 @@ constexpr int kBlock = 64;  // one wavefront per workgroup
 constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
 
 struct Posting {
-    int32_t loc;  // accumulator of the row: scratch id mod G (arrangement A) or scratch id / S (arrangement B)
+    int32_t loc;  // accumulator of the row: scratch id mod G
     float val;
 };
 
 struct Work {
     int32_t t;      // query of the call
-    int32_t part;   // -1 = the whole query over arrangement A, else stripe `part` of it over arrangement B
-    int32_t pslot;  // split queries: which block of partial rankings
+    int32_t part;   // -1 = the whole query (all groups), else group `part` of a long query
+    int32_t pslot;  // long queries: which block of partial rankings
 };
 
 // probe (gorse_hip_test_sparse_trace): what one work item did
@@ -73,14 +72,10 @@ struct Trace {
 };
 
 struct TileArgs {
-    // arrangement A: segment (c, g) = postA[offA[c * ngroups + g], offA[c * ngroups + g + 1]), rows g * G + loc
-    const uint32_t *offA;
-    const Posting *postA;
+    // segment (c, g) = post[off[c * ngroups + g], off[c * ngroups + g + 1]), rows g * G + loc
+    const uint32_t *off;
+    const Posting *post;
     int32_t ngroups, logG;
-    // arrangement B: segment (c, s) = postB[offB[c * S + s], offB[c * S + s + 1]), rows loc * S + s
-    const uint32_t *offB;
-    const Posting *postB;
-    int32_t logS, naccB;  // S = 1 << logS stripes of naccB = ceil(N / S) rows
     int64_t N;
     const int32_t *orig_of, *new_of;  // scratch id <-> caller's row
     // queries: CSR rows q_first .. of (q_ptr, q_cid, q_val); q_cid = directory entry of the index or -1 (never stored)
@@ -95,13 +90,12 @@ struct TileArgs {
     const Work *work;
     int32_t n_work;
     int32_t *next;     // work counter
-    int32_t nacc_lds;  // accumulators the launch's LDS holds (G, or naccB rounded up to 64)
     int k;
     int32_t *out_idx;   // nq x k, padded with -1
     float *out_score;   // nq x k, padded with -inf
     int32_t *out_cnt;   // nq
-    unsigned long long *part_keys;  // per (pslot, stripe): KP keys, descending, padded with 0
-    int32_t *part_cnt;              // per (pslot, stripe): rows scoring above / below zero
+    unsigned long long *part_keys;  // per (pslot, group): KP keys, descending, padded with 0
+    int32_t *part_cnt;              // per (pslot, group): rows scoring above / below zero
     unsigned long long *stat;       // [0] += postings walked, [1] += rows with a non-zero score
     Trace *trace;                   // probe: one record per work item, or null
 };
@@ -275,7 +269,7 @@ __device__ inline float acc_take(float *acc, int32_t i) {
     return __hip_atomic_exchange(&acc[i], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// What a lane holds of one VISIT = (group or stripe, chunk of 64 of the query's indices): its index's directory entry and value,
+// What a lane holds of one VISIT = (group, chunk of 64 of the query's indices): its index's directory entry and value,
 // the segment [s, e) of that index's posting list, and the first kGather postings of it.  The three parts are loaded one visit
 // apart (see the pipeline in sparse_tile_kernel), so that no load is waited for.
 // Loaded values are never touched in the stage that loads them (a select on a loaded value is a wait for it): `in` says whether
@@ -288,7 +282,7 @@ struct Visit {
     Posting P[kGather];  // P[j] valid for j < e - s
 };
 
-// the group's / stripe's state while it accumulates
+// the group's state while it accumulates
 struct GroupState {
     uint32_t walked;  // postings applied
     int tcnt;         // entries of the touched list
@@ -368,7 +362,7 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
 // Assembly is a wave-uniform walk over the lists; kFlatAhead batches are in flight while one is applied.
 template <bool ATOMIC>
 __device__ inline void apply_flattened(const Posting *__restrict__ post, const Visit &v, float *acc, volatile lds_u8 *tag,
-                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Trace &tr, bool track) {
+                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Trace &tr) {
     struct Batch {
         Posting P;
         float q;
@@ -430,7 +424,7 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
             for (int rd = 0; rd <= last; rd++)
                 if (have && rank == rd) acc_add<ATOMIC>(acc, row, term);
         }
-        if (track) touch(touched, tcap, gs, have, row, lane);
+        touch(touched, tcap, gs, have, row, lane);
         gs.walked += (uint32_t)b.n;
         tr.batches++;
     };
@@ -458,7 +452,7 @@ template <int KP, bool ATOMIC>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
     extern __shared__ __align__(16) unsigned char s_mem[];
-    const int NL = a.nacc_lds;  // accumulators in LDS, a multiple of 64
+    const int NL = 1 << a.logG;  // accumulators in LDS
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(s_mem);
     float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
     volatile lds_u8 *tag = (volatile lds_u8 *)(s_mem + (size_t)CAP * 8 + (size_t)NL * 4);
@@ -484,13 +478,13 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         unsigned long long walked_q = 0;
         Trace tr{};
         if (a.trace) tr.t0 = __builtin_amdgcn_s_memrealtime();
-        // the view of this item: arrangement A (the groups one after the other) or one stripe of arrangement B
+        // the views of this item: every group, or the one group of this part of a long query
         const bool whole = wk.part < 0;
-        const uint32_t *off = whole ? a.offA : a.offB;
-        const Posting *post = whole ? a.postA : a.postB;
-        const int dir_stride = whole ? a.ngroups : (1 << a.logS);
+        const uint32_t *off = a.off;
+        const Posting *post = a.post;
+        const int dir_stride = a.ngroups;
         const int nviews = whole ? a.ngroups : 1;
-        const int nacc = whole ? (1 << a.logG) : ((a.naccB + kBlock - 1) / kBlock) * kBlock;
+        const int nacc = NL;
         const int tcap = nacc >> 2;
         const int64_t nch = (L + kBlock - 1) / kBlock;  // chunks of 64 indices
         const int64_t V = nch * nviews;                 // visits, view-major
@@ -499,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         // branch in the loop that would make the compiler wait for everything in flight.)
         // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (view, chunk) counters
         int64_t c1 = 0, c2 = 0;
-        int g2 = whole ? 0 : wk.part;
+        int g2 = whole ? 0 : wk.part;  // group of the visit stage 2 is at
         // Every stage issues the SAME loads on every path (clamped addresses, results masked afterwards; the host pads each
         // array by one element): a load that a branch may skip makes the compiler's wait for any OLDER load "wait for all".
         auto stage1 = [&](int64_t v, Visit &x) {
@@ -533,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         stage3(v0);
         GroupState gs{0, 0};
         int64_t c = 0;  // chunk of visit v inside its view
-        int g = 0;
+        int g = whole ? 0 : wk.part;
         for (int64_t v = 0; v < V; v++) {
             // consumers first: each stage needs what the stage before it loaded during the PREVIOUS visit, so whatever the compiler
             // waits for here has had a whole visit to arrive
@@ -548,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                     if (once)
                         apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, lane, gs, tr);
                     else
-                        apply_flattened<ATOMIC>(post, v0, acc, tag, touched, tcap, lane, gs, tr, whole);
+                        apply_flattened<ATOMIC>(post, v0, acc, tag, touched, tcap, lane, gs, tr);
                     if (a.trace) (once ? tr.ticks_once : tr.ticks_flat) += (uint32_t)(__builtin_amdgcn_s_memrealtime() - c0);
                 }
             }
@@ -558,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                     // sid = the row's scratch id, og = orig_of[sid], loaded one step ahead of its use (the read-back used to wait
                     // for this gather inside every step that had a candidate: 43 us per group of 2048 accumulators,
                     // profiles/r02_k_probe_sparse_trace.txt)
-                    auto sid_of = [&](int32_t i) { return whole ? ((int64_t)g << a.logG) + i : ((int64_t)i << a.logS) + wk.part; };
+                    auto sid_of = [&](int32_t i) { return ((int64_t)g << a.logG) + i; };
                     auto orig_at = [&](bool in, int32_t i) {
                         const int64_t sid = sid_of(i);
                         return in && sid < a.N ? a.orig_of[sid] : 0;
@@ -578,7 +572,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         const unsigned long long key = cand ? make_key(ord, og) : 0;
                         push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
                     };
-                    if (!whole || (int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
+                    if ((int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
                         tr.dense_groups++;
                         constexpr int kStep = 4;
                         int32_t og_next[kStep];
@@ -612,7 +606,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 if (a.trace) {
                     const unsigned long long c1 = __builtin_amdgcn_s_memrealtime();
                     tr.ticks_back += (uint32_t)(c1 - c0);
-                    if (g == 7) tr.ticks_head = (uint32_t)(c1 - tr.t0);
+                    if (whole && g == 7) tr.ticks_head = (uint32_t)(c1 - tr.t0);
                 }
                 gs = GroupState{0, 0};
                 c = 0;
@@ -627,7 +621,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
             write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         } else {
-            const size_t part = ((size_t)wk.pslot << a.logS) + wk.part;
+            const size_t part = (size_t)wk.pslot * a.ngroups + wk.part;
             for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
             if (lane == 0) {
                 a.part_cnt[part * 2] = (int32_t)pos;
@@ -647,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     }
 }
 
-// the partial rankings of a split query (one per stripe) -> its result row
+// the partial rankings of a long query (one per group) -> its result row
 struct MergeArgs {
     const int32_t *split_t;  // query of every block of partial rankings
     int32_t n_split, nparts;
@@ -720,22 +714,22 @@ struct BuildArgs {
     const float *r_val;
     int64_t N;
     const int32_t *new_of;  // scratch id of every row
-    int32_t stride;         // directory entries per index: groups (arrangement A) or stripes (B)
-    int32_t shift;          // A: log2 G (bucket = sid >> shift, loc = sid mod G); B: log2 S (bucket = sid mod S, loc = sid >> shift)
-    uint32_t *cnt;  // Dc * stride (+ 1): entries per (index, bucket); the cursor of the scatter pass afterwards
+    int32_t stride;         // directory entries per index = groups
+    int32_t shift;          // log2 G (group = sid >> shift, loc = sid mod G)
+    uint32_t *cnt;  // Dc * stride (+ 1): entries per (index, group); the cursor of the scatter pass afterwards
     Posting *post;
 };
 
-// one wave per stored row; SCATTER = false counts the entries of every (index, bucket), true places them; BY_STRIPE = arrangement B
-template <bool SCATTER, bool BY_STRIPE>
+// one wave per stored row; SCATTER = false counts the entries of every (index, group), true places them
+template <bool SCATTER>
 __global__ __launch_bounds__(256) void sparse_build_kernel(BuildArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t low = ((int64_t)1 << a.shift) - 1;
     for (int64_t r = wave; r < a.N; r += nwaves) {
         const int64_t sid = a.new_of[r];
-        const int32_t bucket = BY_STRIPE ? (int32_t)(sid & low) : (int32_t)(sid >> a.shift);
-        const int32_t loc = BY_STRIPE ? (int32_t)(sid >> a.shift) : (int32_t)(sid & low);
+        const int32_t bucket = (int32_t)(sid >> a.shift);
+        const int32_t loc = (int32_t)(sid & low);
         for (int64_t e = a.r_ptr[r] + lane; e < a.r_ptr[r + 1]; e += 64) {
             uint32_t *c = a.cnt + (size_t)a.r_cid[e] * a.stride + bucket;
             if (SCATTER)

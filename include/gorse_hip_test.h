@@ -51,24 +51,19 @@ int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/
 /* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
-/* rows per group of a handle created AFTERWARDS (arrangement A of the posting lists, csrc/sparse_kernels.hpp): a power of two
+/* rows per group of a handle created AFTERWARDS (the posting lists are cut by row group, csrc/sparse_kernels.hpp): a power of two
  * in 256 .. 16384; 0 = 2048.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);
-/* most rows per stripe of arrangement B of a handle created AFTERWARDS (power of two; 0 = 8192): the number of stripes -- and
- * of work items a long query is split into -- follows from it. */
-void gorse_hip_test_set_sparse_stripe_rows(int32_t rows);
-/* queries with more than `entries` entries are answered by one work item per row stripe and a merge instead of one item
+/* queries with more than `entries` entries are answered by one work item per row group and a merge instead of one item
  * (default 2048; <= 0 = never): lets small test inputs take that path. */
 void gorse_hip_test_set_sparse_split(int64_t entries);
 /* how products reach the LDS accumulators: 1 = ds_add_f32 (no return value, no wait), 0 = load / add / store by the same
  * wave, -1 = the library's choice (ds_add_f32 unless a product of a stored and a query value could fall below 2^-100,
  * where partial sums may be subnormal and the LDS adder's handling of those is not relied upon). */
 void gorse_hip_test_set_sparse_atomic(int32_t mode);
-/* 1 (default) = the stripes of the long queries run on a second stream next to the ordinary queries, 0 = before them. */
-void gorse_hip_test_set_sparse_streams(int32_t two);
-/* probe: with on != 0 the following calls of the handle record what every work item (a query, or one stripe of a long query)
+/* probe: with on != 0 the following calls of the handle record what every work item (a query, or one group of a long query)
  * did; with out != NULL copies up to cap records of the last call as 16 uint64 each: {start, end (100 MHz ticks), query,
- * stripe + 1 (0 = whole query), entries, chunks taken 64 lists at once, their rounds, segments walked one list at a time,
+ * group + 1 of a long query (0 = whole query), entries, chunks taken 64 lists at once, their rounds, segments walked one list at a time,
  * groups read back densely, groups read back by re-walking, flattened batches, rows two lists of a batch shared,
  * 10 ns ticks in the 64-lists-at-once path / in the batches / in the read-backs / until the end of the eighth group}.  Returns the number of work items of the last call. */
 int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /*host or NULL*/, int64_t cap);

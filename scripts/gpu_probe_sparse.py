@@ -10,10 +10,9 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from gorse_amd import capi, synth  # noqa: E402
 
 
-def run(name, ptr, idx, val, k=100, tile=0, split=2048, slots=0, atomic=-1, reps=2, stripe=0):
+def run(name, ptr, idx, val, k=100, tile=0, split=2048, slots=0, atomic=-1, reps=2):
     L = capi.lib()
     L.gorse_hip_test_set_sparse_tile(tile)
-    L.gorse_hip_test_set_sparse_stripe_rows(stripe)
     L.gorse_hip_test_set_sparse_split(split)
     L.gorse_hip_test_set_sparse_slots(slots)
     L.gorse_hip_test_set_sparse_atomic(atomic)
@@ -29,13 +28,12 @@ def run(name, ptr, idx, val, k=100, tile=0, split=2048, slots=0, atomic=-1, reps
     n, ms = s.get_profile()
     per = ms / max(n, 1)
     postings, hits = s.last_stats()
-    print("%-40s N=%8d nnz=%10d k=%d group=%5s stripe<=%5s split>%6d slots=%5s atomic=%2d create %7.3f s  all-pairs %9.3f ms (wall %9.3f)  "
+    print("%-40s N=%8d nnz=%10d k=%d group=%5s split>%6d slots=%5s atomic=%2d create %7.3f s  all-pairs %9.3f ms (wall %9.3f)  "
           "postings %.3e  %.3e postings/s  %8.1f GB/s algorithmic  non-zero pairs/query %.0f"
-          % (name, s.N, int(ptr[-1]), k, tile or "auto", stripe or "auto", split, slots or "max", atomic, t_create, per, wall * 1e3, postings,
+          % (name, s.N, int(ptr[-1]), k, tile or "auto", split, slots or "max", atomic, t_create, per, wall * 1e3, postings,
              postings / (per * 1e-3), postings * 8 / (per * 1e-3) / 1e9, hits / s.N), flush=True)
     s.close()
     L.gorse_hip_test_set_sparse_tile(0)
-    L.gorse_hip_test_set_sparse_stripe_rows(0)
     L.gorse_hip_test_set_sparse_split(2048)
     L.gorse_hip_test_set_sparse_slots(0)
     L.gorse_hip_test_set_sparse_atomic(-1)
@@ -55,8 +53,6 @@ def main():
         run(name + " items user-to-user", *u2u)
         for tile in (1024, 2048, 8192):
             run(name + " users item-to-item", *i2i, tile=tile)
-        for stripe in (2048, 4096, 16384):
-            run(name + " users item-to-item", *i2i, stripe=stripe)
         for split in (256, 1024, 8192):
             run(name + " users item-to-item", *i2i, split=split)
         run(name + " users item-to-item", *i2i, atomic=0)

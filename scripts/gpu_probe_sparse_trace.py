@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU probe: where an all-pairs pass of the sparse top-k spends its time, from the per-work-item records of
 gorse_hip_test_sparse_trace: the span of the launch, how busy the resident waves are over it (tail vs throughput), the longest
-work items, and the cost per class of work (entries, stripe parts, lists-at-once chunks and their rounds, one-list segments)."""
+work items, and the cost per class of work (entries, group parts of long queries, lists-at-once chunks and their rounds, one-list segments)."""
 import sys
 
 import numpy as np
@@ -34,16 +34,16 @@ def main():
     busy = [(np.minimum(t1, edges[i + 1]) - np.maximum(t0, edges[i])).clip(min=0).sum() / (edges[i + 1] - edges[i]) for i in range(20)]
     print("waves busy per 5 %% slice of the span: " + " ".join("%.0f" % b for b in busy))
     order = np.argsort(-dur)[:12]
-    print("longest work items (us, query, stripe+1, entries, chunks at once, rounds, one-list segments, dense groups, re-walked groups, batches, shared rows):")
+    print("longest work items (us, query, group+1, entries, chunks at once, rounds, one-list segments, dense groups, re-walked groups, batches, shared rows):")
     for i in order:
         print("  %9.1f %s" % (dur[i], " ".join(str(int(x)) for x in tr[i, 2:])))
     split = tr[:, 3] > 0
-    for name, m in (("whole-query items", ~split), ("stripe parts", split)):
+    for name, m in (("whole-query items", ~split), ("group parts of long queries", split)):
         if m.any():
             print("%-18s n=%7d  total %.1f ms  entries %.3e  chunks at once %.3e (rounds %.3e)  one-list segments %.3e  dense groups %.3e  re-walked %.3e  batches %.3e  shared rows %.3e"
                   % (name, m.sum(), dur[m].sum() / 1e3, tr[m, 4].sum(), tr[m, 5].sum(), tr[m, 6].sum(), tr[m, 7].sum(), tr[m, 8].sum(), tr[m, 9].sum(),
                      tr[m, 10].sum(), tr[m, 11].sum()))
-    for name, m in (("whole-query items", ~split), ("stripe parts", split)):
+    for name, m in (("whole-query items", ~split), ("group parts of long queries", split)):
         if m.any():
             print("%-18s ms inside: 64 lists at once %.1f, batches / one list at a time %.1f, read-backs %.1f; until the end of group 8: %.1f"
                   % (name, tr[m, 12].sum() / 1e5, tr[m, 13].sum() / 1e5, tr[m, 14].sum() / 1e5, tr[m, 15].sum() / 1e5))

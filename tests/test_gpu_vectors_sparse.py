@@ -136,23 +136,21 @@ def hooks():
     yield L
     L.gorse_hip_test_set_sparse_slots(0)
     L.gorse_hip_test_set_sparse_tile(0)
-    L.gorse_hip_test_set_sparse_stripe_rows(0)
     L.gorse_hip_test_set_sparse_split(2048)
     L.gorse_hip_test_set_sparse_atomic(-1)
 
 
 @pytest.mark.parametrize("k", [5, 70, 300])
-def test_long_queries_are_split_over_the_row_stripes(oracle, k, hooks):
-    """queries with more entries than the threshold (2048 by default, 6 here) are answered by one work item per row stripe
-    (arrangement B of the posting lists: 32 stripes here), each with its own ranking, and a merge: same results, in one call
-    together with unsplit queries (arrangement A: 36 groups of 256 rows), masks, exclusions, negative and cancelling scores"""
+def test_long_queries_are_split_over_the_row_groups(oracle, k, hooks):
+    """queries with more entries than the threshold (2048 by default, 6 here) are answered by one work item per row group
+    (36 groups of 256 rows here), each with its own ranking, and a merge: same results, in one call together with unsplit
+    queries, masks, exclusions, negative and cancelling scores"""
     rng = np.random.default_rng(47)
     ptr, idx, val = random_csr(rng, 9000, 80, 0, 14, neg=True, zipf=True)
     n_long = int((np.diff(ptr) > 6).sum())
     assert n_long > 100 and n_long < 8000
     mask = (rng.random(9000) < 0.8).astype(np.uint8)
     hooks.gorse_hip_test_set_sparse_tile(256)
-    hooks.gorse_hip_test_set_sparse_stripe_rows(512)
     s = capi.Sparse(ptr, idx, val)
     hooks.gorse_hip_test_set_sparse_split(6)
     sample = list(range(0, 9000, 23))
@@ -177,7 +175,6 @@ def test_both_accumulation_forms(oracle, atomic, hooks):
     ptr, idx, val = random_csr(rng, 20000, 300, 1, 40, neg=True, zipf=True)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
     hooks.gorse_hip_test_set_sparse_tile(1024)
-    hooks.gorse_hip_test_set_sparse_stripe_rows(1024)
     hooks.gorse_hip_test_set_sparse_split(200)
     s = capi.Sparse(ptr, idx, val)
     sample = list(range(0, 20000, 397))
@@ -215,9 +212,8 @@ def test_lists_that_share_rows_keep_the_index_order(oracle, atomic, hooks):
         val.append((np.exp(rng.uniform(-14, 14, have.size)) * rng.choice([-1.0, 1.0], have.size)).astype(np.float32))
     idx, val = np.concatenate(idx), np.concatenate(val)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
-    for tile, split in ((256, 0), (2048, 0), (256, 64)):  # groups of 256 / one group / long queries over row stripes
+    for tile, split in ((256, 0), (2048, 0), (256, 64)):  # groups of 256 / one group / long queries as one item per group
         hooks.gorse_hip_test_set_sparse_tile(tile)
-        hooks.gorse_hip_test_set_sparse_stripe_rows(256)
         hooks.gorse_hip_test_set_sparse_split(split)
         s = capi.Sparse(ptr, idx, val)
         got = s.all_pairs(50)
@@ -227,14 +223,13 @@ def test_lists_that_share_rows_keep_the_index_order(oracle, atomic, hooks):
 
 def test_random_configurations(oracle, hooks):
     """thirty random small problems, each with random k, mask, exclusions and random settings of the library's switches
-    (group height, stripe height, split threshold, workgroups per launch, accumulation form): every answer equals the oracle's"""
+    (group height, split threshold, workgroups per launch, accumulation form): every answer equals the oracle's"""
     rng = np.random.default_rng(2027)
     for case in range(30):
         rows, dims = int(rng.integers(1, 400 if case % 3 else 3000)), int(rng.integers(1, 120))
         hi = int(rng.integers(0, min(dims, 30) + 1))
         ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
         hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 256, 512, 2048])))
-        hooks.gorse_hip_test_set_sparse_stripe_rows(int(rng.choice([0, 64, 256])))
         hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 2048])))
         hooks.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
         hooks.gorse_hip_test_set_sparse_atomic(int(rng.choice([-1, 0, 1])))
