@@ -29,6 +29,7 @@ struct gorse_sparse {
     int64_t n_admissible = 0;  // rows with mask != 0 (N without a mask)
     float stored_small = 0.0f;  // smallest non-zero |value| stored
     sparse::RowOrder order;    // host copy: masks arrive in the caller's row order
+    std::vector<double> group_share;  // per group: share of the stored entries that its rows hold
     std::vector<int64_t> r_ptr_host;
     // staging of one call
     DevBuf<int64_t> q_ptr, q_excl;
@@ -106,11 +107,40 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     // are bounded (kPartBytes): a call with more long queries than fit takes several launches.
     const int64_t ng = h->ngroups;
     std::vector<int32_t> longs, shorts;
-    for (int64_t t = 0; t < nq; t++)
-        (g_sparse_split > 0 && q_len_host[t + 1] - q_len_host[t] > g_sparse_split ? longs : shorts).push_back((int32_t)t);
-    auto by_length = [&](int32_t x, int32_t y) { return q_len_host[x + 1] - q_len_host[x] > q_len_host[y + 1] - q_len_host[y]; };
-    std::stable_sort(longs.begin(), longs.end(), by_length);
-    std::stable_sort(shorts.begin(), shorts.end(), by_length);
+    {   // counting sort by length, longest first (stable in t)
+        const int64_t cut = g_sparse_split > 0 ? g_sparse_split : INT64_MAX;
+        std::vector<int32_t> count;
+        int64_t longest_short = 0;
+        for (int64_t t = 0; t < nq; t++) {
+            const int64_t L = q_len_host[t + 1] - q_len_host[t];
+            if (L > cut)
+                longs.push_back((int32_t)t);
+            else
+                longest_short = std::max(longest_short, L);
+        }
+        if (longest_short <= (1 << 22)) {
+            count.assign((size_t)longest_short + 2, 0);
+            for (int64_t t = 0; t < nq; t++) {
+                const int64_t L = q_len_host[t + 1] - q_len_host[t];
+                if (L <= cut) count[(size_t)(longest_short - L) + 1]++;
+            }
+            for (size_t i = 1; i < count.size(); i++) count[i] += count[i - 1];
+            shorts.resize((size_t)nq - longs.size());
+            for (int64_t t = 0; t < nq; t++) {
+                const int64_t L = q_len_host[t + 1] - q_len_host[t];
+                if (L <= cut) shorts[(size_t)count[(size_t)(longest_short - L)]++] = (int32_t)t;
+            }
+        } else {  // never split and very long: a comparison sort
+            for (int64_t t = 0; t < nq; t++)
+                if (q_len_host[t + 1] - q_len_host[t] <= cut) shorts.push_back((int32_t)t);
+            std::stable_sort(shorts.begin(), shorts.end(), [&](int32_t x, int32_t y) {
+                return q_len_host[x + 1] - q_len_host[x] > q_len_host[y + 1] - q_len_host[y];
+            });
+        }
+        std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) {
+            return q_len_host[x + 1] - q_len_host[x] > q_len_host[y + 1] - q_len_host[y];
+        });
+    }
     constexpr size_t kPartBytes = (size_t)2 << 30;
     const size_t per_launch = std::max<size_t>(1, kPartBytes / ((size_t)ng * kp * 8));
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
@@ -135,10 +165,16 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     for (size_t l0 = 0; l0 == 0 || l0 < longs.size(); l0 += per_launch) {
         const size_t l1 = std::min(longs.size(), l0 + per_launch);
         work.clear();
+        // the parts of the long queries by estimated cost (entries of the query x share of the stored entries in the group's
+        // rows), dearest first and at a raised wave priority where one part alone is a sizeable piece of the launch: (longest
+        // query, most popular rows) ran for 60 of the launch's 68 ms (profiles/r02_o_probe_sparse_trace.txt)
         for (size_t l = l0; l < l1; l++)
-            for (int32_t g = 0; g < h->ngroups; g++) work.push_back(sparse::Work{longs[l], g, (int32_t)(l - l0)});
+            for (int32_t g = 0; g < h->ngroups; g++) work.push_back(sparse::Work{longs[l], g, (int32_t)(l - l0), 0});
+        auto cost = [&](const sparse::Work &w) { return (double)(q_len_host[w.t + 1] - q_len_host[w.t]) * h->group_share[(size_t)w.part]; };
+        std::stable_sort(work.begin(), work.end(), [&](const sparse::Work &x, const sparse::Work &y) { return cost(x) > cost(y); });
+        for (sparse::Work &w : work) w.prio = cost(w) >= 4096.0;
         if (l0 == 0)
-            for (int32_t t : shorts) work.push_back(sparse::Work{t, -1, 0});
+            for (int32_t t : shorts) work.push_back(sparse::Work{t, -1, 0, 0});
         if (work.empty()) break;
         const size_t n_long = l1 - l0;
         GORSE_TRY(h->work.ensure(work.size()));
@@ -236,6 +272,11 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     h->Dc = (int64_t)dims.size();
     h->logG = pick_log_group();
     h->ngroups = (int32_t)ceil_div(N, (int64_t)1 << h->logG);
+    h->group_share.assign((size_t)h->ngroups, 0.0);
+    for (int64_t sid = 0; sid < N; sid++) {
+        const int64_t r = h->order.orig_of[(size_t)sid];
+        h->group_share[(size_t)(sid >> h->logG)] += (double)(indptr[r + 1] - indptr[r]) / (double)std::max<int64_t>(nnz, 1);
+    }
     int32_t rc = [&]() -> int32_t {
         const int64_t cells = h->Dc * h->ngroups;
         if (cells >= (int64_t)1 << 33)

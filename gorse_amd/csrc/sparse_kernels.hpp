@@ -17,7 +17,7 @@
 //   rankings.  (As one item the longest query of the C3 shard took 186 ms on its own; round 2's first answer, a second
 //   arrangement by row stripes with 2.5 x the LDS per item, left the chip at 4 waves per CU for 40 % of the pass and spent
 //   its time on the rows that the lists of a stripe share -- profiles/r02_f / r02_n_probe_sparse_trace.txt.)
-// * 64 lists at once: where every list of a chunk contributes at most 8 postings, every lane gathers the postings of ITS
+// * 64 lists at once: where every list of a chunk contributes at most 16 postings, every lane gathers the postings of ITS
 //   list, the lanes stamp their rows in a byte-per-row tag array and read the stamps back -- a foreign stamp means two lists
 //   share a row and the order of their products matters; rounds of "everybody below the lowest loser, then the loser" keep
 //   that order (see apply_at_once).  Longer segments go one list at a time with their postings over the lanes.
@@ -48,7 +48,7 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) float lds_f32;
 
 constexpr int kBlock = 64;  // one wavefront per workgroup
-constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
+constexpr int kGather = 16;  // longest segment the 64-lists-at-once path takes
 
 struct Posting {
     int32_t loc;  // accumulator of the row: scratch id mod G
@@ -59,6 +59,8 @@ struct Work {
     int32_t t;      // query of the call
     int32_t part;   // -1 = the whole query (all groups), else group `part` of a long query
     int32_t pslot;  // long queries: which block of partial rankings
+    int32_t prio;   // != 0: an item that alone is a sizeable part of the launch (a long query in a group of popular rows); its wave
+                    // runs at a raised priority
 };
 
 // probe (gorse_hip_test_sparse_trace): what one work item did
@@ -312,20 +314,31 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
     const uint32_t len = v.e - v.s;
     bool pending = len > 0;
     tr.fast_chunks++;
+    // has[j] = lanes whose list has a j-th posting: the loops below stop at the longest list of the chunk (typically 2 - 4
+    // postings, not kGather), and the postings of the chunk are the popcounts
+    unsigned long long has[kGather];
+    int longest = 0;
+#pragma unroll
+    for (int j = 0; j < kGather; j++) {
+        has[j] = __ballot((uint32_t)j < len);
+        if (has[j]) longest = j + 1;
+        gs.walked += (uint32_t)__popcll(has[j]);
+    }
     for (;;) {
         tr.rounds++;
 #pragma unroll
-        for (int j = 0; j < kGather; j++)
-            if (pending && (uint32_t)j < len) tag[v.P[j].loc] = (uint8_t)lane;
-        uint32_t stamp[kGather];
-#pragma unroll
         for (int j = 0; j < kGather; j++) {
-            stamp[j] = (uint32_t)lane;
-            if (pending && (uint32_t)j < len) stamp[j] = tag[v.P[j].loc];
+            if (j < longest && pending && (uint32_t)j < len) tag[v.P[j].loc] = (uint8_t)lane;
         }
         bool lost = false;
 #pragma unroll
-        for (int j = 0; j < kGather; j++) lost = lost | (stamp[j] != (uint32_t)lane);
+        for (int j = 0; j < kGather; j++) {
+            if (j < longest) {
+                uint32_t stamp = (uint32_t)lane;
+                if (pending && (uint32_t)j < len) stamp = tag[v.P[j].loc];
+                lost = lost | (stamp != (uint32_t)lane);
+            }
+        }
         const unsigned long long ml = __ballot(lost);
         const int lim = ml ? __ffsll((long long)ml) - 1 : 64;
 #pragma unroll
@@ -336,19 +349,17 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
 #pragma unroll
             for (int j = 0; j < kGather; j++) {
                 old[j] = 1.0f;
-                if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, v.P[j].loc, __fmul_rn(v.qv, v.P[j].val));
+                if (j < longest && go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, v.P[j].loc, __fmul_rn(v.qv, v.P[j].val));
             }
 #pragma unroll
             for (int j = 0; j < kGather; j++) {
-                if (!__ballot(go && (uint32_t)j < len)) break;
-                touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, v.P[j].loc, lane);
+                if (j < longest) touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, v.P[j].loc, lane);
             }
         }
         if (!ml) break;
         pending = pending && lane > lim;
         if (!__ballot(pending)) break;
     }
-    gs.walked += wave_sum_u32(len);
 }
 
 // Flattened batches (visits with a segment longer than kGather).  The segments of the visit are laid end to end in list order
@@ -466,6 +477,10 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         w = __builtin_amdgcn_readfirstlane(w);
         if (w >= a.n_work) break;
         const Work wk = a.work[w];
+        if (wk.prio)
+            __builtin_amdgcn_s_setprio(3);
+        else
+            __builtin_amdgcn_s_setprio(0);
         const int64_t t = wk.t, qr = a.q_first + t;
         const int64_t qs = a.q_ptr[qr];
         const int64_t L = a.q_ptr[qr + 1] - qs;
@@ -516,7 +531,8 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             if (!x.in) x.s = 0, x.e = 0;
             const uint32_t len = x.e - x.s;
 #pragma unroll
-            for (int j = 0; j < kGather; j++) x.P[j] = post[x.s + ((uint32_t)j < len ? j : 0)];
+            for (int j = 0; j < kGather; j++)  // (what the loop top waits for is everything in flight anyway: skipping costs nothing)
+                if (__ballot((uint32_t)j < len)) x.P[j] = post[x.s + ((uint32_t)j < len ? j : 0)];
         };
         Visit v0, v1, v2, v3;
         stage1(0, v0);

@@ -44,6 +44,16 @@ def main():
     shapes = []
     if which in ("all", "small"):
         shapes.append(("S-ml1m", synth.s_ml1m()))
+    if which == "c3tiles":  # the switches that matter at scale, on the C3 shard's item-to-item vectors only
+        data = synth.s_big_shard(rank=0, world=8)
+        i2i = synth.idf_vectors(data.iptr, data.iidx, data.U)
+        run("C3/8 users item-to-item", *i2i)
+        for tile in (1024, 4096):
+            run("C3/8 users item-to-item", *i2i, tile=tile)
+        for split in (512, 8192):
+            run("C3/8 users item-to-item", *i2i, split=split)
+        run("C3/8 items user-to-user", *synth.idf_vectors(data.uptr, data.uidx, data.I))
+        return
     if which in ("all", "c3"):
         shapes.append(("S-big shard (C3/8)", synth.s_big_shard(rank=0, world=8)))
     for name, data in shapes:

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round 2, fifteenth device session: long queries as one work item per row group (one arrangement of the posting lists).
+# Round 2, sixteenth device session: long queries as one work item per row group (one arrangement of the posting lists).
 set -u
-TAG=${1:-r02_o}
+TAG=${1:-r02_p}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_vectors_sparse.py tests/test_gpu_vectors_db.py tests/test_gpu_cf_parity.py -q -m gpu -x > "$OUT/${TAG}_pytest.log" 2>&1
+timeout 600 python -m pytest tests/test_gpu_vectors_sparse.py tests/test_gpu_vectors_db.py -q -m gpu -x > "$OUT/${TAG}_pytest.log" 2>&1
 echo "pytest exit $?"; tail -5 "$OUT/${TAG}_pytest.log"
 timeout 300 python scripts/gpu_probe_sparse_trace.py c3 0 1 > "$OUT/${TAG}_probe_sparse_trace.txt" 2>&1
 echo "sparse trace exit $?"; cut -c1-400 "$OUT/${TAG}_probe_sparse_trace.txt"
@@ -17,5 +17,5 @@ for line in open(sys.argv[1]):
     if line.startswith("{"):
         d = json.loads(line); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d.get("cpu_baseline", {}).get("value"))
 PY
-timeout 300 python scripts/gpu_probe_users.py > "$OUT/${TAG}_probe_bpr_users.txt" 2>&1
-echo "bpr probe exit $?"; tail -12 "$OUT/${TAG}_probe_bpr_users.txt" | cut -c1-300
+timeout 300 python scripts/gpu_probe_sparse.py c3tiles > "$OUT/${TAG}_probe_sparse_c3.txt" 2>&1
+echo "sparse probe exit $?"; cut -c1-250 "$OUT/${TAG}_probe_sparse_c3.txt"
