@@ -240,9 +240,10 @@ __device__ __forceinline__ void gram_load_stage(const float *__restrict__ B, con
 
 // G += sum over fb[0..n) of q q^T, sum += column sums; the whole wave walks one row (or one chunk of a row)
 template <int NB>
+// idx0 / idx1: lane l's entries l and 64 + l of the row as loaded by the caller (any value past the row's end)
 __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, const float *__restrict__ zeros,
                                                 const int32_t *__restrict__ fb, int n, int d, int lane,
-                                                GramAcc<NB> &g) {
+                                                GramAcc<NB> &g, int idx0, int idx1) {
 #pragma unroll
     for (int t = 0; t < GramAcc<NB>::NT; t++)
 #pragma unroll
@@ -254,8 +255,8 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
     constexpr int kStagesPerBatch = 64 / (2 * kAlsPairs);
     // index batches: lane l of idx_cur holds entry 64 * batch + l (or -1 past the row's end, which makes the
     // gathers of those entries read zeros); idx_nxt is the batch after it
-    int idx_cur = lane < n ? fb[lane] : -1;
-    int idx_nxt = 64 + lane < n ? fb[64 + lane] : -1;
+    int idx_cur = lane < n ? idx0 : -1;
+    int idx_nxt = 64 + lane < n ? idx1 : -1;
     int loaded = 0;  // stages whose gathers have been issued
     auto issue = [&](float (&fr)[kAlsPairs][NB]) {
         const int sb = loaded % kStagesPerBatch;
@@ -415,14 +416,30 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
     float *ss = sM + 64 * kAlsDP;
     const float one_w = 1 - w;
     const int64_t wave = (int64_t)blockIdx.x * kAlsRowWaves + wv, nwaves = (int64_t)gridDim.x * kAlsRowWaves;
+    // A row starts with three dependent reads (row id -> row pointer -> the first 128 indices) before its first gather can be
+    // issued: ~3 memory latencies in front of ~25 us of work.  They are taken off the path: the next row's id is read at the
+    // top of a row, its pointer after the accumulation, its first indices before the solve -- each is in flight while the
+    // current row computes.  (idx[0] exists even without feedback: DevBuf never allocates less than one element.)
+    auto first_indices = [&](int64_t beg_, int n_, int &i0, int &i1) {
+        i0 = idx[lane < n_ ? beg_ + lane : 0];
+        i1 = idx[64 + lane < n_ ? beg_ + 64 + lane : 0];
+    };
+    int64_t u = 0, beg = 0;
+    int n = 0, idx0 = 0, idx1 = 0;
+    if (wave < n_rows) {
+        u = rows[wave];
+        beg = ptr[u];
+        n = (int)(ptr[u + 1] - beg);
+        first_indices(beg, n, idx0, idx1);
+    }
     for (int64_t t = wave; t < n_rows; t += nwaves) {
-        const int64_t u = rows[t];
-        const int64_t beg = ptr[u];
-        const int n = (int)(ptr[u + 1] - beg);
+        const int64_t u_next = rows[t + nwaves < n_rows ? t + nwaves : t];
         GramAcc<NB> g;
         unsigned long long t0 = 0;
         if (prof) t0 = __builtin_amdgcn_s_memtime();
-        gram_accumulate<NB>(B, zeros, idx + beg, n, d, lane, g);
+        gram_accumulate<NB>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1);
+        const int64_t beg_next = ptr[u_next];
+        const int64_t end_next = ptr[u_next + 1];
         if (prof) {
             // the accumulators are only complete once they are read: touch one so that the stamp waits for the MFMAs
             const unsigned long long t1 = __builtin_amdgcn_s_memtime() + (__float_as_int(g.t[0][0]) & 0);
@@ -452,6 +469,9 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         // MFMAs, and at equal priority the arbiter lets one VALU operation through per 64-cycle MFMA (840 cycles per solve
         // step, profiles/r02_g_probe_als_prof.txt).  At raised priority the chain issues at its own pace and the MFMA stream
         // takes the slots in between -- it needs one issue per 64 cycles.
+        const int n_next = (int)(end_next - beg_next);
+        int idx0_next, idx1_next;
+        first_indices(beg_next, n_next, idx0_next, idx1_next);
         __builtin_amdgcn_s_setprio(3);
         als_solve_row<32 * NB, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         __builtin_amdgcn_s_setprio(0);
@@ -461,6 +481,7 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
             c_rows++;
             c_ent += n;
         }
+        u = u_next, beg = beg_next, n = n_next, idx0 = idx0_next, idx1 = idx1_next;
     }
     if (prof && lane == 0) {
         atomicAdd(prof + 0, c_acc);
@@ -487,7 +508,9 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
     const int64_t stride = (int64_t)d * d + d;
     for (int64_t c = wave; c < n_chunks; c += nwaves) {
         GramAcc<NB> g;
-        gram_accumulate<NB>(B, zeros, idx + chunk_beg[c], chunk_cnt[c], d, lane, g);
+        const int32_t *fb = idx + chunk_beg[c];
+        const int cn = chunk_cnt[c];
+        gram_accumulate<NB>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0]);
         float *dst = partial + c * stride;
         gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
             const int i = ci + 4 * (lane >> 5), j = cj + (lane & 31);

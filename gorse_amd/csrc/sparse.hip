@@ -69,9 +69,8 @@ int pick_log_group() {
 }
 template <int KP>
 int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, hipStream_t s) {  // s: the stream of this launch
-    auto k1 = sparse::sparse_tile_kernel<KP, true>;
-    auto k0 = sparse::sparse_tile_kernel<KP, false>;
-    auto kern = atomic ? k1 : k0;
+    auto kern = a.trace ? (atomic ? sparse::sparse_tile_kernel<KP, true, true> : sparse::sparse_tile_kernel<KP, false, true>)
+                        : (atomic ? sparse::sparse_tile_kernel<KP, true, false> : sparse::sparse_tile_kernel<KP, false, false>);
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), dim3(sparse::kBlock), lds, s>>>(a);
     return GORSE_OK;

@@ -17,7 +17,7 @@
 //   rankings.  (As one item the longest query of the C3 shard took 186 ms on its own; round 2's first answer, a second
 //   arrangement by row stripes with 2.5 x the LDS per item, left the chip at 4 waves per CU for 40 % of the pass and spent
 //   its time on the rows that the lists of a stripe share -- profiles/r02_f / r02_n_probe_sparse_trace.txt.)
-// * 64 lists at once: where every list of a chunk contributes at most 16 postings, every lane gathers the postings of ITS
+// * 64 lists at once: where every list of a chunk contributes at most 8 postings, every lane gathers the postings of ITS
 //   list, the lanes stamp their rows in a byte-per-row tag array and read the stamps back -- a foreign stamp means two lists
 //   share a row and the order of their products matters; rounds of "everybody below the lowest loser, then the loser" keep
 //   that order (see apply_at_once).  Longer segments go one list at a time with their postings over the lanes.
@@ -48,7 +48,7 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) float lds_f32;
 
 constexpr int kBlock = 64;  // one wavefront per workgroup
-constexpr int kGather = 16;  // longest segment the 64-lists-at-once path takes
+constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
 
 struct Posting {
     int32_t loc;  // accumulator of the row: scratch id mod G
@@ -71,6 +71,20 @@ struct Trace {
     uint32_t batches, shared_rows;  // flattened path: batches of 64 postings, rows of a batch that two lists shared
     uint32_t ticks_once, ticks_flat, ticks_back, ticks_head;  // 10 ns ticks inside apply_at_once / apply_flattened (or one list at
                                                               // a time) / the read-backs; from the start to the end of view 7
+};
+
+// The counters exist in the probe's instantiation of the kernel only (TRACE): in the shipped one they would hold sixteen scalar
+// registers of a kernel that already spills them.
+template <bool TRACE>
+struct Tracer {
+    Trace r{};
+    __device__ inline void add(uint32_t Trace::*field, uint32_t by = 1) {
+        if constexpr (TRACE) r.*field += by;
+    }
+    __device__ inline unsigned long long now() const {
+        if constexpr (TRACE) return __builtin_amdgcn_s_memrealtime();
+        return 0;
+    }
 };
 
 struct TileArgs {
@@ -308,36 +322,23 @@ __device__ inline void touch(uint16_t *touched, int tcap, GroupState &gs, bool a
 // and the lanes above lim go round again.  Without sharing: one round.
 // Rows whose accumulator was +0 before the add go on the touched list (a sum that returns to zero and is reached again is
 // listed twice; the read-back takes it once).
-template <bool ATOMIC>
+template <bool ATOMIC, bool TRACE>
 __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8 *tag, uint16_t *touched, int tcap, int lane,
-                                     GroupState &gs, Trace &tr) {
+                                     GroupState &gs, Tracer<TRACE> &tr) {
     const uint32_t len = v.e - v.s;
     bool pending = len > 0;
-    tr.fast_chunks++;
-    // has[j] = lanes whose list has a j-th posting: the loops below stop at the longest list of the chunk (typically 2 - 4
-    // postings, not kGather), and the postings of the chunk are the popcounts
-    unsigned long long has[kGather];
-    int longest = 0;
-#pragma unroll
-    for (int j = 0; j < kGather; j++) {
-        has[j] = __ballot((uint32_t)j < len);
-        if (has[j]) longest = j + 1;
-        gs.walked += (uint32_t)__popcll(has[j]);
-    }
+    tr.add(&Trace::fast_chunks);
     for (;;) {
-        tr.rounds++;
+        tr.add(&Trace::rounds);
 #pragma unroll
-        for (int j = 0; j < kGather; j++) {
-            if (j < longest && pending && (uint32_t)j < len) tag[v.P[j].loc] = (uint8_t)lane;
-        }
+        for (int j = 0; j < kGather; j++)
+            if (pending && (uint32_t)j < len) tag[v.P[j].loc] = (uint8_t)lane;
         bool lost = false;
 #pragma unroll
         for (int j = 0; j < kGather; j++) {
-            if (j < longest) {
-                uint32_t stamp = (uint32_t)lane;
-                if (pending && (uint32_t)j < len) stamp = tag[v.P[j].loc];
-                lost = lost | (stamp != (uint32_t)lane);
-            }
+            uint32_t stamp = (uint32_t)lane;
+            if (pending && (uint32_t)j < len) stamp = tag[v.P[j].loc];
+            lost = lost | (stamp != (uint32_t)lane);
         }
         const unsigned long long ml = __ballot(lost);
         const int lim = ml ? __ffsll((long long)ml) - 1 : 64;
@@ -349,11 +350,14 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
 #pragma unroll
             for (int j = 0; j < kGather; j++) {
                 old[j] = 1.0f;
-                if (j < longest && go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, v.P[j].loc, __fmul_rn(v.qv, v.P[j].val));
+                if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, v.P[j].loc, __fmul_rn(v.qv, v.P[j].val));
             }
 #pragma unroll
             for (int j = 0; j < kGather; j++) {
-                if (j < longest) touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, v.P[j].loc, lane);
+                const unsigned long long m = __ballot(go && (uint32_t)j < len);
+                if (!m) break;
+                gs.walked += (uint32_t)__popcll(m);
+                touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, v.P[j].loc, lane);
             }
         }
         if (!ml) break;
@@ -371,9 +375,9 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
 // every accumulator still receives its products in ascending index order.  (One list at a time the C3-shard item-to-item
 // pass spent 0.27 us per SEGMENT of 4 postings on average -- 3.2e8 of them, profiles/r02_k_probe_sparse_trace.txt.)
 // Assembly is a wave-uniform walk over the lists; kFlatAhead batches are in flight while one is applied.
-template <bool ATOMIC>
+template <bool ATOMIC, bool TRACE>
 __device__ inline void apply_flattened(const Posting *__restrict__ post, const Visit &v, float *acc, volatile lds_u8 *tag,
-                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Trace &tr) {
+                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Tracer<TRACE> &tr) {
     struct Batch {
         Posting P;
         float q;
@@ -393,7 +397,7 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
                 const int l = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 cur_s = lane_u32(v.s, l), cur_e = lane_u32(v.e, l), cur_q = lane_f32(v.qv, l);
-                tr.slow_segments++;
+                tr.add(&Trace::slow_segments);
             }
             const uint32_t take = min(cur_e - cur_s, (uint32_t)(kBlock - b.n));
             const uint32_t at = (uint32_t)(lane - b.n);
@@ -430,14 +434,14 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
                 lost &= ~same;
                 const int sharers = (int)__popcll(same) - 1;
                 last = sharers > last ? sharers : last;
-                tr.shared_rows++;
+                tr.add(&Trace::shared_rows);
             }
             for (int rd = 0; rd <= last; rd++)
                 if (have && rank == rd) acc_add<ATOMIC>(acc, row, term);
         }
         touch(touched, tcap, gs, have, row, lane);
         gs.walked += (uint32_t)b.n;
-        tr.batches++;
+        tr.add(&Trace::batches);
     };
     // kFlatAhead batches in flight; a slot is refilled right after it was applied (its own load has been waited for, so the
     // refill never waits for a register that may still be a load's destination)
@@ -459,7 +463,7 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
     }
 }
 
-template <int KP, bool ATOMIC>
+template <int KP, bool ATOMIC, bool TRACE>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
     extern __shared__ __align__(16) unsigned char s_mem[];
@@ -483,16 +487,16 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             __builtin_amdgcn_s_setprio(0);
         const int64_t t = wk.t, qr = a.q_first + t;
         const int64_t qs = a.q_ptr[qr];
-        const int64_t L = a.q_ptr[qr + 1] - qs;
+        const int L = (int)(a.q_ptr[qr + 1] - qs);  // a query's indices are distinct uint32 and the host caps L below 2^31
         const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? qr : (int64_t)-1);
         const bool ex_in = ex >= 0 && ex < a.N;
-        const int64_t ex_sid = ex_in ? (int64_t)a.new_of[ex] : (int64_t)-1;
+        const int32_t ex_sid = ex_in ? a.new_of[ex] : -1;
         int bcnt = 0;
         unsigned long long thr = 0;
-        long long my_pos = 0, my_neg = 0, my_hit = 0;
+        int my_pos = 0, my_neg = 0, my_hit = 0;  // per lane: at most N / 64 + 1 each
         unsigned long long walked_q = 0;
-        Trace tr{};
-        if (a.trace) tr.t0 = __builtin_amdgcn_s_memrealtime();
+        Tracer<TRACE> tr;
+        if constexpr (TRACE) tr.r.t0 = tr.now();
         // the views of this item: every group, or the one group of this part of a long query
         const bool whole = wk.part < 0;
         const uint32_t *off = a.off;
@@ -501,18 +505,18 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const int nviews = whole ? a.ngroups : 1;
         const int nacc = NL;
         const int tcap = nacc >> 2;
-        const int64_t nch = (L + kBlock - 1) / kBlock;  // chunks of 64 indices
-        const int64_t V = nch * nviews;                 // visits, view-major
+        const int nch = (int)(((int64_t)L + kBlock - 1) / kBlock);  // chunks of 64 indices
+        const int64_t V = (int64_t)nch * nviews;                    // visits, view-major
         // The pipeline: while visit v is applied, the postings of v + 1, the directory entries of v + 2 and the (index, value)
         // pairs of v + 3 are in flight.  (A query of one chunk re-reads its 64 pairs at every visit: two cached loads, and no
         // branch in the loop that would make the compiler wait for everything in flight.)
         // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (view, chunk) counters
-        int64_t c1 = 0, c2 = 0;
+        int c1 = 0, c2 = 0;
         int g2 = whole ? 0 : wk.part;  // group of the visit stage 2 is at
         // Every stage issues the SAME loads on every path (clamped addresses, results masked afterwards; the host pads each
         // array by one element): a load that a branch may skip makes the compiler's wait for any OLDER load "wait for all".
         auto stage1 = [&](int64_t v, Visit &x) {
-            const int64_t at = c1 * kBlock + lane;
+            const int at = c1 * kBlock + lane;
             x.in = v < V && at < L;
             x.cid = a.q_cid[qs + (x.in ? at : 0)];
             x.qv = a.q_val[qs + (x.in ? at : 0)];
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         stage2(1, v1);
         stage3(v0);
         GroupState gs{0, 0};
-        int64_t c = 0;  // chunk of visit v inside its view
+        int c = 0;  // chunk of visit v inside its view
         int g = whole ? 0 : wk.part;
         for (int64_t v = 0; v < V; v++) {
             // consumers first: each stage needs what the stage before it loaded during the PREVIOUS visit, so whatever the compiler
@@ -553,30 +557,30 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             {   // visit v
                 const uint32_t len = v0.e - v0.s;
                 if (__ballot(len > 0)) {
-                    const unsigned long long c0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+                    const unsigned long long c0 = tr.now();
                     const bool once = !__ballot(len > (uint32_t)kGather);
                     if (once)
-                        apply_at_once<ATOMIC>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                        apply_at_once<ATOMIC, TRACE>(v0, acc, tag, touched, tcap, lane, gs, tr);
                     else
-                        apply_flattened<ATOMIC>(post, v0, acc, tag, touched, tcap, lane, gs, tr);
-                    if (a.trace) (once ? tr.ticks_once : tr.ticks_flat) += (uint32_t)(__builtin_amdgcn_s_memrealtime() - c0);
+                        apply_flattened<ATOMIC, TRACE>(post, v0, acc, tag, touched, tcap, lane, gs, tr);
+                    tr.add(once ? &Trace::ticks_once : &Trace::ticks_flat, (uint32_t)(tr.now() - c0));
                 }
             }
             if (++c == nch) {  // the view is complete: read it back
-                const unsigned long long c0 = a.trace ? __builtin_amdgcn_s_memrealtime() : 0;
+                const unsigned long long c0 = tr.now();
                 if (gs.walked > 0) {
                     // sid = the row's scratch id, og = orig_of[sid], loaded one step ahead of its use (the read-back used to wait
                     // for this gather inside every step that had a candidate: 43 us per group of 2048 accumulators,
                     // profiles/r02_k_probe_sparse_trace.txt)
-                    auto sid_of = [&](int32_t i) { return ((int64_t)g << a.logG) + i; };
+                    auto sid_of = [&](int32_t i) { return (int32_t)((g << a.logG) + i); };  // N fits int32
                     auto orig_at = [&](bool in, int32_t i) {
-                        const int64_t sid = sid_of(i);
+                        const int32_t sid = sid_of(i);
                         return in && sid < a.N ? a.orig_of[sid] : 0;
                     };
                     auto consider = [&](bool have, int32_t i, float x, int32_t og, bool og_loaded) {
                         have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
                         if (!__ballot(have)) return;
-                        const int64_t sid = sid_of(i);
+                        const int32_t sid = sid_of(i);
                         my_hit += have;
                         have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
                         const uint32_t ord = score_ord(x);
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
                     };
                     if ((int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
-                        tr.dense_groups++;
+                        tr.add(&Trace::dense_groups);
                         constexpr int kStep = 4;
                         int32_t og_next[kStep];
 #pragma unroll
@@ -609,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                             for (int j = 0; j < kStep; j++) consider(i0 + j * kBlock + lane < nacc, i0 + j * kBlock + lane, x[j], og[j], true);
                         }
                     } else {
-                        tr.sparse_groups++;
+                        tr.add(&Trace::sparse_groups);
                         for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {
                             const bool have = i0 + lane < gs.tcnt;
                             const int i = have ? (int)touched[i0 + lane] : 0;
@@ -619,10 +623,10 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                     }
                     walked_q += gs.walked;
                 }
-                if (a.trace) {
-                    const unsigned long long c1 = __builtin_amdgcn_s_memrealtime();
-                    tr.ticks_back += (uint32_t)(c1 - c0);
-                    if (whole && g == 7) tr.ticks_head = (uint32_t)(c1 - tr.t0);
+                if constexpr (TRACE) {
+                    const unsigned long long c1 = tr.now();
+                    tr.r.ticks_back += (uint32_t)(c1 - c0);
+                    if (whole && g == 7) tr.r.ticks_head = (uint32_t)(c1 - tr.r.t0);
                 }
                 gs = GroupState{0, 0};
                 c = 0;
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             }
             v0 = v1, v1 = v2, v2 = v3;
         }
-        const long long pos = wave_sum(my_pos), neg = wave_sum(my_neg), hit = wave_sum(my_hit);
+        const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);
         finish<KP>(s_buf, bcnt, lane);
         if (whole) {
             const bool ex_counts = ex_in && (!a.mask_sid || a.mask_sid[ex_sid]);
@@ -648,10 +652,12 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             atomicAdd(&a.stat[0], walked_q);
             atomicAdd(&a.stat[1], (unsigned long long)hit);
         }
-        if (a.trace && lane == 0) {
-            tr.t1 = __builtin_amdgcn_s_memrealtime();
-            tr.t = wk.t, tr.part = wk.part, tr.entries = (uint32_t)L;
-            a.trace[w] = tr;
+        if constexpr (TRACE) {
+            if (lane == 0) {
+                tr.r.t1 = tr.now();
+                tr.r.t = wk.t, tr.r.part = wk.part, tr.r.entries = (uint32_t)L;
+                a.trace[w] = tr.r;
+            }
         }
         __syncthreads();  // s_buf is reused by the next work item
     }
