@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 2, seventeenth device session: long queries as one work item per row group (one arrangement of the posting lists).
+# Round 2, eighteenth device session: long queries as one work item per row group (one arrangement of the posting lists).
 set -u
-TAG=${1:-r02_q}
+TAG=${1:-r02_r}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -19,12 +19,3 @@ for line in open(sys.argv[1]):
 PY
 timeout 300 python scripts/gpu_probe_sparse.py c3tiles > "$OUT/${TAG}_probe_sparse_c3.txt" 2>&1
 echo "sparse probe exit $?"; cut -c1-250 "$OUT/${TAG}_probe_sparse_c3.txt"
-timeout 300 python bench.py --workload als --steps 4 --warmup 1 > "$OUT/${TAG}_bench_als.json" 2> "$OUT/${TAG}_bench_als.err"
-echo "bench als exit $?"; python - "$OUT/${TAG}_bench_als.json" <<'PY'
-import json, sys
-for line in open(sys.argv[1]):
-    if line.startswith("{"):
-        d = json.loads(line); print(d["value"], d["ms_per_step"], d["roofline"]["frac"])
-PY
-timeout 300 python -m pytest tests/test_gpu_cf_parity.py tests/test_gpu_baseline_configs.py -q -m gpu -x -k "als" > "$OUT/${TAG}_pytest_als.log" 2>&1
-echo "pytest als exit $?"; tail -3 "$OUT/${TAG}_pytest_als.log"

@@ -137,6 +137,7 @@ def hooks():
     L.gorse_hip_test_set_sparse_slots(0)
     L.gorse_hip_test_set_sparse_tile(0)
     L.gorse_hip_test_set_sparse_split(2048)
+    L.gorse_hip_test_set_sparse_heavy(16384)
     L.gorse_hip_test_set_sparse_atomic(-1)
 
 
@@ -153,6 +154,8 @@ def test_long_queries_are_split_over_the_row_groups(oracle, k, hooks):
     hooks.gorse_hip_test_set_sparse_tile(256)
     s = capi.Sparse(ptr, idx, val)
     hooks.gorse_hip_test_set_sparse_split(6)
+    hooks.gorse_hip_test_set_sparse_heavy(9)  # more than 9 entries: the first four groups in eight parts each (32 rows per part)
+    assert int((np.diff(ptr) > 9).sum()) > 50
     sample = list(range(0, 9000, 23))
     got = s.all_pairs(k)
     check(oracle, ptr, idx, val, k, [x[sample] for x in got], rows_of(ptr, idx, val, sample), sample)
@@ -212,9 +215,11 @@ def test_lists_that_share_rows_keep_the_index_order(oracle, atomic, hooks):
         val.append((np.exp(rng.uniform(-14, 14, have.size)) * rng.choice([-1.0, 1.0], have.size)).astype(np.float32))
     idx, val = np.concatenate(idx), np.concatenate(val)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
-    for tile, split in ((256, 0), (2048, 0), (256, 64)):  # groups of 256 / one group / long queries as one item per group
+    # groups of 256 / one group / long queries as one item per group / ... and the first groups in eight parts each
+    for tile, split, heavy in ((256, 0, 0), (2048, 0, 0), (256, 64, 0), (256, 20, 21), (2048, 20, 21)):
         hooks.gorse_hip_test_set_sparse_tile(tile)
         hooks.gorse_hip_test_set_sparse_split(split)
+        hooks.gorse_hip_test_set_sparse_heavy(heavy)
         s = capi.Sparse(ptr, idx, val)
         got = s.all_pairs(50)
         check(oracle, ptr, idx, val, 50, got, rows_of(ptr, idx, val, range(rows)), list(range(rows)))
@@ -231,6 +236,7 @@ def test_random_configurations(oracle, hooks):
         ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
         hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 256, 512, 2048])))
         hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 2048])))
+        hooks.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 2, 5, 12, 16384])))
         hooks.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 1, 2, 5, 64])))
         hooks.gorse_hip_test_set_sparse_atomic(int(rng.choice([-1, 0, 1])))
         s = capi.Sparse(ptr, idx, val)
