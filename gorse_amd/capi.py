@@ -97,7 +97,6 @@ SIGNATURES = {
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_split": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_heavy": (None, [C.c_int64]),
-    "gorse_hip_test_set_sparse_heavy": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_atomic": (None, [C.c_int32]),
     "gorse_hip_test_sparse_trace": (C.c_int64, [_vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int64]),
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),

@@ -16,7 +16,7 @@ using gorse::sparse::TileArgs;
 struct gorse_sparse {
     int device = 0;
     int64_t N = 0, nnz = 0, Dc = 0;
-    sparse::Layout lay{};           // groups of G = 1 << logG consecutive scratch ids; directory cells per list
+    int32_t logG = 0, ngroups = 0;  // groups of G = 1 << logG consecutive scratch ids
     hipStream_t stream = nullptr;
     // stored rows as CSR with directory entries instead of raw indices (the queries of all_pairs), the tiled posting lists
     DevBuf<int64_t> r_ptr;
@@ -29,12 +29,13 @@ struct gorse_sparse {
     int64_t n_admissible = 0;  // rows with mask != 0 (N without a mask)
     float stored_small = 0.0f;  // smallest non-zero |value| stored
     sparse::RowOrder order;    // host copy: masks arrive in the caller's row order
-    std::vector<double> cell_share;  // per directory cell: share of the stored entries that its rows hold
+    std::vector<double> group_share;  // per group: share of the stored entries that its rows hold
     std::vector<int64_t> r_ptr_host;
     // staging of one call
     DevBuf<int64_t> q_ptr, q_excl;
     DevBuf<uint32_t> q_idx;
-    DevBuf<int32_t> q_cid, out_idx, out_cnt, next, split_t, split_n, part_cnt;
+    DevBuf<int32_t> q_cid, out_idx, out_cnt, next, split_t, part_cnt, heavy_t, heavy_pslot;
+    DevBuf<uint2> dense;  // heavy queries of a launch: n x Dc {present, value bits}
     DevBuf<float> q_val, out_score;
     DevBuf<sparse::Work> work;
     DevBuf<unsigned long long> part_keys, stat;
@@ -55,7 +56,8 @@ namespace {
 // probes / test hooks (include/gorse_hip_test.h); results never depend on them
 int g_sparse_tile = 0;           // rows per group (power of two, 256 .. 16384); 0 = 2048
 int64_t g_sparse_split = 2048;   // queries with more entries than this become one work item per group; <= 0 = never
-int64_t g_sparse_heavy = 16384;  // ... and with more than this, one per directory cell (the fine groups in kFine parts); <= 0 = never
+int64_t g_sparse_heavy = 16384;  // ... and with more than this they are scored row by row against a dense copy (sparse_rows_kernel);
+                                 // <= 0 = never
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 
@@ -101,12 +103,11 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     GORSE_TRY(h->out_score.ensure((size_t)nq * k));
     GORSE_TRY(h->out_cnt.ensure((size_t)nq));
     GORSE_TRY(h->stat.ensure(2));
-    GORSE_TRY(h->next.ensure(1));
+    GORSE_TRY(h->next.ensure(2));
     // Work items: a long query as one item per group (+ a merge of the partial rankings), the others as one item each.  Long
     // queries first, everything longest first: the launch ends with the cheap items.  The partial rankings of the long queries
     // are bounded (kPartBytes): a call with more long queries than fit takes several launches.
-    const sparse::Layout &lay = h->lay;
-    const int64_t ng = lay.stride;  // most partial rankings a long query can have
+    const int64_t ng = h->ngroups;
     std::vector<int32_t> longs, shorts;
     {   // counting sort by length, longest first (stable in t)
         const int64_t cut = g_sparse_split > 0 ? g_sparse_split : INT64_MAX;
@@ -143,10 +144,13 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         });
     }
     constexpr size_t kPartBytes = (size_t)2 << 30;
-    const size_t per_launch = std::max<size_t>(1, kPartBytes / ((size_t)ng * kp * 8));
+    constexpr size_t kDenseBytes = (size_t)1 << 30;
+    const size_t per_launch = std::max<size_t>(
+        1, std::min(kPartBytes / ((size_t)ng * kp * 8), kDenseBytes / ((size_t)std::max<int64_t>(h->Dc, 1) * sizeof(uint2))));
+    auto is_heavy = [&](int32_t t) { return g_sparse_heavy > 0 && q_len_host[t + 1] - q_len_host[t] > g_sparse_heavy; };
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
     TileArgs a;
-    a.off = h->off.p, a.post = h->post.p, a.lay = lay, a.part_stride = lay.stride;
+    a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG;
     a.N = h->N;
     a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
     a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
@@ -159,7 +163,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.next = h->next.p;
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     // LDS of a workgroup: ranking buffer + per accumulator 4 B (sum) + 1 B (stamp) + 0.5 B (touched list)
-    const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 << lay.logG) / 2;
+    const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 << h->logG) / 2;
     const int tok = h->prof.begin(0, h->stream);
     std::vector<sparse::Work> work;
     h->trace_host.clear();
@@ -169,42 +173,57 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         // the parts of the long queries by estimated cost (entries of the query x share of the stored entries in the group's
         // rows), dearest first and at a raised wave priority where one part alone is a sizeable piece of the launch: (longest
         // query, most popular rows) ran for 60 of the launch's 68 ms (profiles/r02_o_probe_sparse_trace.txt)
-        std::vector<int32_t> nparts(l1 - l0);
+        std::vector<int32_t> heavy_t, heavy_pslot;
         for (size_t l = l0; l < l1; l++) {
-            const int32_t t = longs[l], ps = (int32_t)(l - l0);
-            const bool heavy = g_sparse_heavy > 0 && q_len_host[t + 1] - q_len_host[t] > g_sparse_heavy;
-            int32_t pidx = 0;
-            for (int32_t g = 0; g < lay.ngroups; g++) {
-                const int32_t c0 = lay.first_cell(g), nc = lay.cells(g);
-                if (heavy && nc > 1)
-                    for (int32_t c = c0; c < c0 + nc; c++) work.push_back(sparse::Work{t, c, 1, ps, pidx++, 0});
-                else
-                    work.push_back(sparse::Work{t, c0, nc, ps, pidx++, 0});
+            if (is_heavy(longs[l])) {
+                heavy_t.push_back(longs[l]);
+                heavy_pslot.push_back((int32_t)(l - l0));
+                continue;
             }
-            nparts[l - l0] = pidx;
+            for (int32_t g = 0; g < h->ngroups; g++) work.push_back(sparse::Work{longs[l], g, (int32_t)(l - l0), 0});
         }
-        auto cost = [&](const sparse::Work &w) {
-            double share = 0;
-            for (int32_t c = w.cell; c < w.cell + w.ncell; c++) share += h->cell_share[(size_t)c];
-            return (double)(q_len_host[w.t + 1] - q_len_host[w.t]) * share;
-        };
+        auto cost = [&](const sparse::Work &w) { return (double)(q_len_host[w.t + 1] - q_len_host[w.t]) * h->group_share[(size_t)w.part]; };
         std::stable_sort(work.begin(), work.end(), [&](const sparse::Work &x, const sparse::Work &y) { return cost(x) > cost(y); });
         for (sparse::Work &w : work) w.prio = cost(w) >= 4096.0;
         if (l0 == 0)
-            for (int32_t t : shorts) work.push_back(sparse::Work{t, -1, 0, 0, 0, 0});
-        if (work.empty()) break;
+            for (int32_t t : shorts) work.push_back(sparse::Work{t, -1, 0, 0});
+        if (work.empty() && heavy_t.empty()) break;
         const size_t n_long = l1 - l0;
         GORSE_TRY(h->work.ensure(work.size()));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
         if (n_long > 0) {
             GORSE_TRY(h->split_t.ensure(n_long));
-            GORSE_TRY(h->split_n.ensure(n_long));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->split_n.p, nparts.data(), n_long * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_TRY(h->part_keys.ensure(n_long * (size_t)ng * (size_t)kp));
             GORSE_TRY(h->part_cnt.ensure(n_long * (size_t)ng * 2));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, longs.data() + l0, n_long * 4, hipMemcpyHostToDevice, h->stream));
         }
-        GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sizeof(int32_t), h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, 2 * sizeof(int32_t), h->stream));
+        if (!heavy_t.empty()) {  // the heavy queries: dense copies, then every stored row against them
+            const size_t nh = heavy_t.size();
+            GORSE_TRY(h->heavy_t.ensure(nh));
+            GORSE_TRY(h->heavy_pslot.ensure(nh));
+            GORSE_TRY(h->dense.ensure(nh * (size_t)h->Dc + 1));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_t.p, heavy_t.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_pslot.p, heavy_pslot.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->dense.p, 0, (nh * (size_t)h->Dc + 1) * sizeof(uint2), h->stream));
+            sparse::sparse_dense_query_kernel<<<dim3(64, (unsigned)nh), dim3(256), 0, h->stream>>>(qp, qc, qv, q_first, h->heavy_t.p,
+                                                                                                   h->Dc, h->dense.p);
+            sparse::RowsArgs r;
+            r.r_ptr = h->r_ptr.p, r.r_cid = h->r_cid.p, r.r_val = h->r_val.p, r.orig_of = h->orig_of.p;
+            r.N = h->N, r.logG = h->logG, r.ngroups = h->ngroups;
+            r.dense = h->dense.p, r.Dc = h->Dc;
+            r.heavy_t = h->heavy_t.p, r.heavy_pslot = h->heavy_pslot.p, r.n_heavy = (int32_t)nh;
+            r.q_first = q_first, r.exclude = excl_dev, r.exclude_self = exclude_self, r.mask_sid = a.mask_sid;
+            r.k = k, r.next = h->next.p + 1;
+            r.part_keys = h->part_keys.p, r.part_cnt = h->part_cnt.p, r.stat = h->stat.p;
+            const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->ngroups, slots));
+            switch (kp) {
+                case 256: sparse::sparse_rows_kernel<256><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream>>>(r); break;
+                case 512: sparse::sparse_rows_kernel<512><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream>>>(r); break;
+                default: sparse::sparse_rows_kernel<1024><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream>>>(r); break;
+            }
+            GORSE_HIP_CHECK(hipGetLastError());
+        }
         a.work = h->work.p, a.n_work = (int32_t)work.size();
         a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
         a.trace = nullptr;
@@ -212,16 +231,18 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             GORSE_TRY(h->trace.ensure(work.size()));
             a.trace = h->trace.p;
         }
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
-        switch (kp) {
-            case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;
-            case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, h->stream)); break;
-            default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, h->stream)); break;
+        if (!work.empty()) {
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
+            switch (kp) {
+                case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;
+                case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, h->stream)); break;
+                default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, h->stream)); break;
+            }
+            GORSE_HIP_CHECK(hipGetLastError());
         }
-        GORSE_HIP_CHECK(hipGetLastError());
         if (n_long > 0) {
             sparse::MergeArgs m;
-            m.split_t = h->split_t.p, m.split_n = h->split_n.p, m.n_split = (int32_t)n_long, m.part_stride = lay.stride;
+            m.split_t = h->split_t.p, m.n_split = (int32_t)n_long, m.nparts = h->ngroups;
             m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
             m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
             m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
@@ -234,8 +255,8 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             }
             GORSE_HIP_CHECK(hipGetLastError());
         }
-        // the host work list, split_t / split_n and the trace buffer are reused by the next launch
-        if (n_long > 0 || h->trace_on) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // `nparts` dies with this iteration
+        // the host lists (work, heavy_*, split_t) and the trace buffer are reused or die with this iteration
+        if (l1 < longs.size() || h->trace_on || !heavy_t.empty()) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->trace_on) {
             const size_t at = h->trace_host.size();
             h->trace_host.resize(at + work.size());
@@ -289,19 +310,17 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     h->order = sparse::order_rows(N, indptr);
     const std::vector<uint32_t> dims = sparse::distinct_indices(indices + base, nnz);
     h->Dc = (int64_t)dims.size();
-    h->lay.logG = pick_log_group();
-    h->lay.ngroups = (int32_t)ceil_div(N, (int64_t)1 << h->lay.logG);
-    h->lay.nfine = std::min(h->lay.ngroups, 4);  // the 8192 rows with the most entries: 70 % of the postings a query of the C3 shard walks
-    h->lay.stride = h->lay.nfine * sparse::kFine + h->lay.ngroups - h->lay.nfine;
-    h->cell_share.assign((size_t)h->lay.stride, 0.0);
+    h->logG = pick_log_group();
+    h->ngroups = (int32_t)ceil_div(N, (int64_t)1 << h->logG);
+    h->group_share.assign((size_t)h->ngroups, 0.0);
     for (int64_t sid = 0; sid < N; sid++) {
         const int64_t r = h->order.orig_of[(size_t)sid];
-        h->cell_share[(size_t)h->lay.cell_of_row(sid)] += (double)(indptr[r + 1] - indptr[r]) / (double)std::max<int64_t>(nnz, 1);
+        h->group_share[(size_t)(sid >> h->logG)] += (double)(indptr[r + 1] - indptr[r]) / (double)std::max<int64_t>(nnz, 1);
     }
     int32_t rc = [&]() -> int32_t {
-        const int64_t cells = h->Dc * h->lay.stride;
+        const int64_t cells = h->Dc * h->ngroups;
         if (cells >= (int64_t)1 << 33)
-            return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d directory cells", (long long)h->Dc, h->lay.stride);
+            return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d row groups", (long long)h->Dc, h->ngroups);
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         std::vector<int64_t> &ptr0 = h->r_ptr_host;
@@ -333,7 +352,7 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
             // counts per (index, group) -> exclusive scan = the directory -> scatter through a cursor copy
             sparse::BuildArgs b;
             b.r_ptr = h->r_ptr.p, b.r_cid = h->r_cid.p, b.r_val = h->r_val.p, b.N = N, b.new_of = h->new_of.p;
-            b.lay = h->lay, b.cnt = h->off.p, b.post = h->post.p;
+            b.stride = h->ngroups, b.shift = h->logG, b.cnt = h->off.p, b.post = h->post.p;
             sparse::sparse_build_kernel<false><<<dim3(rg), dim3(256), 0, h->stream>>>(b);
             GORSE_TRY(scan_exclusive(h->off.p, cells + 1, sums, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(cursor.p, h->off.p, ((size_t)cells + 1) * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -468,7 +487,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
-// 16 uint64 {t0, t1 (100 MHz ticks), query, first directory cell + 1 of a part of a long query (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
+// 16 uint64 {t0, t1 (100 MHz ticks), query, group + 1 of a long query (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
 // one list at a time, groups read back densely, groups read back by re-walking, flattened batches, rows shared inside a batch}; returns the number of work items
 extern "C" int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out, int64_t cap) {
     if (!h) return -1;

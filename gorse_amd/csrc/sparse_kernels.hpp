@@ -14,10 +14,10 @@
 // * The posting lists are sorted by row GROUP (G consecutive scratch ids, G accumulators in LDS): segment (c, g) holds the
 //   postings of index c that fall into group g.  A query of ordinary length is ONE work item that visits the groups one after
 //   the other; a LONG query (more than 2048 entries) is one work item PER GROUP, and a merge kernel joins the partial
-//   rankings.  The directory of the first groups (the rows most lists reach) is kFine times finer than the groups: a HEAVY
-//   query (more than 16384 entries) takes those groups as kFine parts each, one per sub-range of rows -- as one part, the
-//   longest query of the C3 shard x the 2048 most popular rows ran for 65 of the launch's 68 ms on one wave
-//   (profiles/r02_p_probe_sparse_trace.txt).  (As one item the longest query of the C3 shard took 186 ms on its own; round 2's first answer, a second
+//   rankings.  A HEAVY query (more than 16384 entries) does not walk posting lists at all: it is scattered into a dense vector
+//   over the indices and every stored row is scored against that, one row per lane (sparse_rows_kernel) -- a heavy query reaches
+//   most rows anyway, and its (query, most popular rows) part kept one wave busy for 65 of a launch's 68 ms, every one of its
+//   100,000 lists having postings there (profiles/r02_p / r02_r_probe_sparse_trace.txt).  (As one item the longest query of the C3 shard took 186 ms on its own; round 2's first answer, a second
 //   arrangement by row stripes with 2.5 x the LDS per item, left the chip at 4 waves per CU for 40 % of the pass and spent
 //   its time on the rows that the lists of a stripe share -- profiles/r02_f / r02_n_probe_sparse_trace.txt.)
 // * 64 lists at once: where every list of a chunk contributes at most 8 postings, every lane gathers the postings of ITS
@@ -54,32 +54,16 @@ constexpr int kBlock = 64;  // one wavefront per workgroup
 constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
 
 struct Posting {
-    int32_t loc;  // accumulator of the row: scratch id mod G (also in the cells of a fine group)
+    int32_t loc;  // accumulator of the row: scratch id mod G
     float val;
 };
 
-constexpr int kFine = 8;  // directory cells per group among the first `nfine` groups
-
-// directory cells of a list: kFine per group for the first nfine groups (sub-ranges of G / kFine rows), one per group after
-struct Layout {
-    int32_t logG, ngroups, nfine, stride;  // stride = cells per list = nfine * kFine + ngroups - nfine
-    __host__ __device__ inline int first_cell(int g) const { return g < nfine ? g * kFine : nfine * kFine + (g - nfine); }
-    __host__ __device__ inline int cells(int g) const { return g < nfine ? kFine : 1; }
-    __host__ __device__ inline int group_of_cell(int c) const { return c < nfine * kFine ? c / kFine : nfine + (c - nfine * kFine); }
-    __host__ __device__ inline int cell_of_row(int64_t sid) const {
-        const int g = (int)(sid >> logG);
-        return g < nfine ? (int)(sid >> (logG - 3)) : nfine * kFine + (g - nfine);
-    }
-};
-static_assert(kFine == 8, "cell_of_row shifts by log2 kFine = 3");
-
 struct Work {
     int32_t t;      // query of the call
-    int32_t cell;   // -1 = the whole query (all groups), else the first directory cell of this part of a long query
-    int32_t ncell;  // parts: 1 (one group, or one sub-range of a fine group) or kFine (a whole fine group)
-    int32_t pslot;  // parts: which block of partial rankings
-    int32_t pidx;   // parts: which ranking of the block
-    int32_t prio;   // != 0: an item that alone is a sizeable piece of the launch; its wave runs at a raised priority
+    int32_t part;   // -1 = the whole query (all groups), else group `part` of a long query
+    int32_t pslot;  // long queries: which block of partial rankings
+    int32_t prio;   // != 0: an item that alone is a sizeable part of the launch (a long query in a group of popular rows); its wave
+                    // runs at a raised priority
 };
 
 // probe (gorse_hip_test_sparse_trace): what one work item did
@@ -107,11 +91,10 @@ struct Tracer {
 };
 
 struct TileArgs {
-    // cell (c, x) of the directory = post[off[c * stride + x], off[c * stride + x + 1]); the rows of a posting: group * G + loc
+    // segment (c, g) = post[off[c * ngroups + g], off[c * ngroups + g + 1]), rows g * G + loc
     const uint32_t *off;
     const Posting *post;
-    Layout lay;
-    int32_t part_stride;  // partial rankings per long query (blocks of part_keys / part_cnt)
+    int32_t ngroups, logG;
     int64_t N;
     const int32_t *orig_of, *new_of;  // scratch id <-> caller's row
     // queries: CSR rows q_first .. of (q_ptr, q_cid, q_val); q_cid = directory entry of the index or -1 (never stored)
@@ -487,7 +470,7 @@ template <int KP, bool ATOMIC, bool TRACE>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
     extern __shared__ __align__(16) unsigned char s_mem[];
-    const int NL = 1 << a.lay.logG;  // accumulators in LDS
+    const int NL = 1 << a.logG;  // accumulators in LDS
     unsigned long long *s_buf = reinterpret_cast<unsigned long long *>(s_mem);
     float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
     volatile lds_u8 *tag = (volatile lds_u8 *)(s_mem + (size_t)CAP * 8 + (size_t)NL * 4);
@@ -518,16 +501,13 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         Tracer<TRACE> tr;
         if constexpr (TRACE) tr.r.t0 = tr.now();
         // the views of this item: every group, or the one group of this part of a long query
-        const bool whole = wk.cell < 0;
+        const bool whole = wk.part < 0;
         const uint32_t *off = a.off;
         const Posting *post = a.post;
-        const int dir_stride = a.lay.stride;
-        const int nviews = whole ? a.lay.ngroups : 1;
-        // the accumulators a view reaches: all of the group, or the sub-range of one cell of a fine group
-        const bool sub = !whole && wk.ncell == 1 && wk.cell < a.lay.nfine * kFine;
-        const int acc0 = sub ? (wk.cell % kFine) * (NL / kFine) : 0;
-        const int nacc = sub ? NL / kFine : NL;
-        const int tcap = NL >> 2;
+        const int dir_stride = a.ngroups;
+        const int nviews = whole ? a.ngroups : 1;
+        const int nacc = NL;
+        const int tcap = nacc >> 2;
         const int nch = (int)(((int64_t)L + kBlock - 1) / kBlock);  // chunks of 64 indices
         const int64_t V = (int64_t)nch * nviews;                    // visits, view-major
         // The pipeline: while visit v is applied, the postings of v + 1, the directory entries of v + 2 and the (index, value)
@@ -535,8 +515,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         // branch in the loop that would make the compiler wait for everything in flight.)
         // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (view, chunk) counters
         int c1 = 0, c2 = 0;
-        int g2 = whole ? 0 : a.lay.group_of_cell(wk.cell);  // group of the visit stage 2 is at
-        int cell2 = whole ? 0 : wk.cell, ncell2 = whole ? a.lay.cells(0) : wk.ncell;
+        int g2 = whole ? 0 : wk.part;  // group of the visit stage 2 is at
         // Every stage issues the SAME loads on every path (clamped addresses, results masked afterwards; the host pads each
         // array by one element): a load that a branch may skip makes the compiler's wait for any OLDER load "wait for all".
         auto stage1 = [&](int64_t v, Visit &x) {
@@ -548,13 +527,11 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         };
         auto stage2 = [&](int64_t v, Visit &x) {  // folds stage 1: in &= the index is stored
             x.in = x.in && x.cid >= 0;
-            const uint32_t *o = off + (x.in ? (size_t)x.cid * dir_stride + cell2 : (size_t)0);
-            x.s = o[0], x.e = o[x.in ? ncell2 : 1];
+            const uint32_t *o = off + (x.in ? (size_t)x.cid * dir_stride + g2 : (size_t)0);
+            x.s = o[0], x.e = o[1];
             if (++c2 == nch) {
                 c2 = 0;
                 g2++;
-                cell2 += ncell2;
-                ncell2 = a.lay.cells(g2);
             }
         };
         auto stage3 = [&](Visit &x) {  // folds stage 2: s = e = 0 where the lane has nothing
@@ -573,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         stage3(v0);
         GroupState gs{0, 0};
         int c = 0;  // chunk of visit v inside its view
-        int g = whole ? 0 : a.lay.group_of_cell(wk.cell);
+        int g = whole ? 0 : wk.part;
         for (int64_t v = 0; v < V; v++) {
             // consumers first: each stage needs what the stage before it loaded during the PREVIOUS visit, so whatever the compiler
             // waits for here has had a whole visit to arrive
@@ -598,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                     // sid = the row's scratch id, og = orig_of[sid], loaded one step ahead of its use (the read-back used to wait
                     // for this gather inside every step that had a candidate: 43 us per group of 2048 accumulators,
                     // profiles/r02_k_probe_sparse_trace.txt)
-                    auto sid_of = [&](int32_t i) { return (int32_t)((g << a.lay.logG) + i); };  // N fits int32
+                    auto sid_of = [&](int32_t i) { return (int32_t)((g << a.logG) + i); };  // N fits int32
                     auto orig_at = [&](bool in, int32_t i) {
                         const int32_t sid = sid_of(i);
                         return in && sid < a.N ? a.orig_of[sid] : 0;
@@ -623,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         constexpr int kStep = 4;
                         int32_t og_next[kStep];
 #pragma unroll
-                        for (int j = 0; j < kStep; j++) og_next[j] = orig_at(j * kBlock + lane < nacc, acc0 + j * kBlock + lane);
+                        for (int j = 0; j < kStep; j++) og_next[j] = orig_at(j * kBlock + lane < nacc, j * kBlock + lane);
                         for (int i0 = 0; i0 < nacc; i0 += kStep * kBlock) {
                             int32_t og[kStep];
                             float x[kStep];
@@ -631,13 +608,12 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                             for (int j = 0; j < kStep; j++) {
                                 const int i = i0 + j * kBlock + lane, in = i0 + (kStep + j) * kBlock + lane;
                                 og[j] = og_next[j];
-                                og_next[j] = orig_at(in < nacc, acc0 + in);
-                                x[j] = i < nacc ? acc[acc0 + i] : 0.0f;
-                                if (__float_as_uint(x[j]) != 0) acc[acc0 + i] = 0.0f;
+                                og_next[j] = orig_at(in < nacc, in);
+                                x[j] = i < nacc ? acc[i] : 0.0f;
+                                if (__float_as_uint(x[j]) != 0) acc[i] = 0.0f;
                             }
 #pragma unroll
-                            for (int j = 0; j < kStep; j++)
-                                consider(i0 + j * kBlock + lane < nacc, acc0 + i0 + j * kBlock + lane, x[j], og[j], true);
+                            for (int j = 0; j < kStep; j++) consider(i0 + j * kBlock + lane < nacc, i0 + j * kBlock + lane, x[j], og[j], true);
                         }
                     } else {
                         tr.add(&Trace::sparse_groups);
@@ -668,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
             write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         } else {
-            const size_t part = (size_t)wk.pslot * a.part_stride + wk.pidx;
+            const size_t part = (size_t)wk.pslot * a.ngroups + wk.part;
             for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
             if (lane == 0) {
                 a.part_cnt[part * 2] = (int32_t)pos;
@@ -682,8 +658,138 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         if constexpr (TRACE) {
             if (lane == 0) {
                 tr.r.t1 = tr.now();
-                tr.r.t = wk.t, tr.r.part = wk.cell, tr.r.entries = (uint32_t)L;
+                tr.r.t = wk.t, tr.r.part = wk.part, tr.r.entries = (uint32_t)L;
                 a.trace[w] = tr.r;
+            }
+        }
+        __syncthreads();  // s_buf is reused by the next work item
+    }
+}
+
+// ---- heavy queries: every stored row against the dense query ------------------------------------------------------------
+// The query's (index, value) pairs are scattered into dense[c] = {1, value bits} over the directory entries c (zero = the
+// query does not hold the index).  One lane scores one stored row: its entries in storage order = ascending index, each
+// looked up in the dense vector, the products of the matches added one after the other -- the oracle's merge-order sum, with
+// no accumulator shared between lanes.  A work item = (heavy query, row group): the group's rows 64 at a time, longest rows
+// first, so the lanes of a step have rows of similar length; it leaves a partial ranking like a part of a long query.
+struct RowsArgs {
+    const int64_t *r_ptr;  // stored rows in the caller's order: r_ptr[N + 1], r_cid / r_val
+    const int32_t *r_cid;
+    const float *r_val;
+    const int32_t *orig_of;  // scratch id -> caller's row
+    int64_t N;
+    int32_t logG, ngroups;
+    const uint2 *dense;  // n_heavy x Dc
+    int64_t Dc;
+    const int32_t *heavy_t;      // query of the call
+    const int32_t *heavy_pslot;  // its block of partial rankings
+    int32_t n_heavy;
+    int64_t q_first;
+    const int64_t *exclude;
+    int exclude_self;
+    const uint8_t *mask_sid;
+    int k;
+    int32_t *next;
+    unsigned long long *part_keys;
+    int32_t *part_cnt;
+    unsigned long long *stat;
+};
+
+__global__ void sparse_dense_query_kernel(const int64_t *q_ptr, const int32_t *q_cid, const float *q_val, int64_t q_first,
+                                          const int32_t *heavy_t, int64_t Dc, uint2 *dense) {
+    const int h = blockIdx.y;
+    const int64_t qs = q_ptr[q_first + heavy_t[h]], qe = q_ptr[q_first + heavy_t[h] + 1];
+    for (int64_t e = qs + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < qe; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t c = q_cid[e];
+        if (c >= 0) dense[(size_t)h * Dc + c] = make_uint2(1u, __float_as_uint(q_val[e]));
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
+    constexpr int CAP = 2 * KP;
+    constexpr int kDeep = 16;  // entries of a row in flight per lane
+    __shared__ unsigned long long s_buf[CAP];
+    const int lane = threadIdx.x;
+    const int n_items = a.n_heavy * a.ngroups;
+    for (;;) {
+        int w = 0;
+        if (lane == 0) w = atomicAdd(a.next, 1);
+        w = __builtin_amdgcn_readfirstlane(w);
+        if (w >= n_items) break;
+        const int g = w / a.n_heavy, h = w % a.n_heavy;  // group-major: the queries of a group share its rows in the caches
+        const int64_t t = a.heavy_t[h];
+        const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? a.q_first + t : (int64_t)-1);
+        const uint2 *dense = a.dense + (size_t)h * a.Dc;
+        int bcnt = 0;
+        unsigned long long thr = 0;
+        int my_pos = 0, my_neg = 0, my_hit = 0;
+        unsigned long long matched = 0;
+        const int64_t s0 = (int64_t)g << a.logG;
+        const int64_t s1 = min(s0 + ((int64_t)1 << a.logG), a.N);
+        for (int64_t sb = s0; sb < s1; sb += kBlock) {
+            const int64_t sid = sb + lane;
+            const bool in = sid < s1;
+            const int32_t row = a.orig_of[in ? sid : s0];
+            int64_t e = a.r_ptr[row];
+            const int64_t end = in ? a.r_ptr[row + 1] : e;
+            float acc = 0.0f;
+            int32_t c[kDeep];
+            float v[kDeep];
+            // stage 1 of block 0; then per block: the lookups of this block and the entries of the next are in flight together
+#pragma unroll
+            for (int j = 0; j < kDeep; j++) {
+                const int64_t at = e + j < end ? e + j : 0;  // entry 0 exists (a row with an entry was found) or is padding
+                c[j] = a.r_cid[at], v[j] = a.r_val[at];
+            }
+            while (__ballot(e < end)) {
+                uint2 q[kDeep];
+#pragma unroll
+                for (int j = 0; j < kDeep; j++) q[j] = dense[e + j < end ? c[j] : 0];
+                float vv[kDeep];
+                int32_t cn[kDeep];
+#pragma unroll
+                for (int j = 0; j < kDeep; j++) {
+                    vv[j] = v[j];
+                    const int64_t at = e + kDeep + j < end ? e + kDeep + j : 0;
+                    cn[j] = a.r_cid[at], v[j] = a.r_val[at];
+                }
+#pragma unroll
+                for (int j = 0; j < kDeep; j++) {
+                    const bool hit = e + j < end && q[j].x != 0;
+                    const float sum = __fadd_rn(acc, __fmul_rn(__uint_as_float(q[j].y), vv[j]));
+                    acc = hit ? sum : acc;
+                    matched += hit;
+                    c[j] = cn[j];
+                }
+                e += kDeep;
+            }
+            // rank (the same rules as the read-back of sparse_tile_kernel)
+            bool have = in && (__float_as_uint(acc) << 1) != 0;
+            if (__ballot(have)) {
+                my_hit += have;
+                have = have && (int64_t)row != ex && (!a.mask_sid || a.mask_sid[have ? sid : s0]);
+                const uint32_t ord = score_ord(acc);
+                my_pos += have && ord > kZeroOrd;
+                my_neg += have && ord < kZeroOrd;
+                const bool cand = have && ord >= (uint32_t)(thr >> 32);
+                if (__ballot(cand)) {
+                    const unsigned long long key = cand ? make_key(ord, row) : 0;
+                    push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
+                }
+            }
+        }
+        const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);
+        const long long walked = wave_sum((long long)matched);
+        finish<KP>(s_buf, bcnt, lane);
+        const size_t part = (size_t)a.heavy_pslot[h] * a.ngroups + g;
+        for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
+        if (lane == 0) {
+            a.part_cnt[part * 2] = (int32_t)pos;
+            a.part_cnt[part * 2 + 1] = (int32_t)neg;
+            if (a.stat) {
+                atomicAdd(&a.stat[0], (unsigned long long)walked);
+                atomicAdd(&a.stat[1], (unsigned long long)hit);
             }
         }
         __syncthreads();  // s_buf is reused by the next work item
@@ -693,8 +799,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
 // the partial rankings of a long query (one per group) -> its result row
 struct MergeArgs {
     const int32_t *split_t;  // query of every block of partial rankings
-    const int32_t *split_n;  // rankings in the block
-    int32_t n_split, part_stride;
+    int32_t n_split, nparts;
     const unsigned long long *part_keys;
     const int32_t *part_cnt;
     int64_t q_first, N;
@@ -719,9 +824,8 @@ __global__ __launch_bounds__(kBlock) void sparse_merge_kernel(MergeArgs a) {
         int bcnt = 0;
         unsigned long long thr = 0;
         long long pos = 0, neg = 0;
-        const int nparts = a.split_n[b];
-        for (int s = 0; s < nparts; s++) {
-            const size_t part = (size_t)b * a.part_stride + s;
+        for (int s = 0; s < a.nparts; s++) {
+            const size_t part = (size_t)b * a.nparts + s;
             pos += a.part_cnt[part * 2];
             neg += a.part_cnt[part * 2 + 1];
             for (int i = 0; i < KP; i += kBlock) {
@@ -765,23 +869,24 @@ struct BuildArgs {
     const float *r_val;
     int64_t N;
     const int32_t *new_of;  // scratch id of every row
-    Layout lay;
-    uint32_t *cnt;  // Dc * stride (+ 1): entries per (index, cell); the cursor of the scatter pass afterwards
+    int32_t stride;         // directory entries per index = groups
+    int32_t shift;          // log2 G (group = sid >> shift, loc = sid mod G)
+    uint32_t *cnt;  // Dc * stride (+ 1): entries per (index, group); the cursor of the scatter pass afterwards
     Posting *post;
 };
 
-// one wave per stored row; SCATTER = false counts the entries of every (index, cell), true places them
+// one wave per stored row; SCATTER = false counts the entries of every (index, group), true places them
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void sparse_build_kernel(BuildArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t low = ((int64_t)1 << a.lay.logG) - 1;
+    const int64_t low = ((int64_t)1 << a.shift) - 1;
     for (int64_t r = wave; r < a.N; r += nwaves) {
         const int64_t sid = a.new_of[r];
-        const int32_t bucket = a.lay.cell_of_row(sid);
+        const int32_t bucket = (int32_t)(sid >> a.shift);
         const int32_t loc = (int32_t)(sid & low);
         for (int64_t e = a.r_ptr[r] + lane; e < a.r_ptr[r + 1]; e += 64) {
-            uint32_t *c = a.cnt + (size_t)a.r_cid[e] * a.lay.stride + bucket;
+            uint32_t *c = a.cnt + (size_t)a.r_cid[e] * a.stride + bucket;
             if (SCATTER)
                 a.post[atomicAdd(c, 1u)] = Posting{loc, a.r_val[e]};
             else

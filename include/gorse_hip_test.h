@@ -57,8 +57,8 @@ void gorse_hip_test_set_sparse_tile(int32_t rows);
 /* queries with more than `entries` entries are answered by one work item per row group and a merge instead of one item
  * (default 2048; <= 0 = never): lets small test inputs take that path. */
 void gorse_hip_test_set_sparse_split(int64_t entries);
-/* queries with more than `entries` entries (default 16384; <= 0 = never) additionally take each of the first four row groups as
- * eight parts, one per eighth of the group's rows (the directory is that fine there). */
+/* of those, queries with more than `entries` entries (default 16384; <= 0 = never) do not walk posting lists: every stored row is
+ * scored against a dense copy of the query, one row per lane (sparse_rows_kernel). */
 void gorse_hip_test_set_sparse_heavy(int64_t entries);
 /* how products reach the LDS accumulators: 1 = ds_add_f32 (no return value, no wait), 0 = load / add / store by the same
  * wave, -1 = the library's choice (ds_add_f32 unless a product of a stored and a query value could fall below 2^-100,
@@ -66,7 +66,7 @@ void gorse_hip_test_set_sparse_heavy(int64_t entries);
 void gorse_hip_test_set_sparse_atomic(int32_t mode);
 /* probe: with on != 0 the following calls of the handle record what every work item (a query, or one group of a long query)
  * did; with out != NULL copies up to cap records of the last call as 16 uint64 each: {start, end (100 MHz ticks), query,
- * first directory cell + 1 of a part of a long query (0 = whole query), entries, chunks taken 64 lists at once, their rounds, segments walked one list at a time,
+ * group + 1 of a long query (0 = whole query), entries, chunks taken 64 lists at once, their rounds, segments walked one list at a time,
  * groups read back densely, groups read back by re-walking, flattened batches, rows two lists of a batch shared,
  * 10 ns ticks in the 64-lists-at-once path / in the batches / in the read-backs / until the end of the eighth group}.  Returns the number of work items of the last call. */
 int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /*host or NULL*/, int64_t cap);

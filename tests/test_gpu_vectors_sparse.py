@@ -154,7 +154,7 @@ def test_long_queries_are_split_over_the_row_groups(oracle, k, hooks):
     hooks.gorse_hip_test_set_sparse_tile(256)
     s = capi.Sparse(ptr, idx, val)
     hooks.gorse_hip_test_set_sparse_split(6)
-    hooks.gorse_hip_test_set_sparse_heavy(9)  # more than 9 entries: the first four groups in eight parts each (32 rows per part)
+    hooks.gorse_hip_test_set_sparse_heavy(9)  # more than 9 entries: scored row by row against a dense copy of the query
     assert int((np.diff(ptr) > 9).sum()) > 50
     sample = list(range(0, 9000, 23))
     got = s.all_pairs(k)
@@ -215,8 +215,8 @@ def test_lists_that_share_rows_keep_the_index_order(oracle, atomic, hooks):
         val.append((np.exp(rng.uniform(-14, 14, have.size)) * rng.choice([-1.0, 1.0], have.size)).astype(np.float32))
     idx, val = np.concatenate(idx), np.concatenate(val)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
-    # groups of 256 / one group / long queries as one item per group / ... and the first groups in eight parts each
-    for tile, split, heavy in ((256, 0, 0), (2048, 0, 0), (256, 64, 0), (256, 20, 21), (2048, 20, 21)):
+    # groups of 256 / one group / long queries as one item per group / ... and row by row against the dense query
+    for tile, split, heavy in ((256, 0, 0), (2048, 0, 0), (256, 64, 0), (256, 20, 21), (2048, 1, 1)):
         hooks.gorse_hip_test_set_sparse_tile(tile)
         hooks.gorse_hip_test_set_sparse_split(split)
         hooks.gorse_hip_test_set_sparse_heavy(heavy)
@@ -262,7 +262,7 @@ def test_random_configurations(oracle, hooks):
         s.close()
 
 
-def test_edge_inputs(oracle):
+def test_edge_inputs(oracle, hooks):
     """one stored row without entries; only empty rows; indptr that does not start at 0; an index space with huge gaps; k = 1024;
     an empty query between two others; infinities and a NaN among the values (ordered like the oracle's total order)"""
     s = capi.Sparse(np.array([0, 0], np.int64), np.zeros(0, np.uint32), np.zeros(0, np.float32))
@@ -285,6 +285,14 @@ def test_edge_inputs(oracle):
     got = capi.Sparse(ptr3, idx3, val3).search(np.array([0, 2], np.int64), np.array([1, 2], np.uint32), np.ones(2, np.float32), 5)
     check(oracle, ptr3, idx3, val3, 5, got, [(np.array([1, 2], np.uint32), np.ones(2, np.float32))], [-1])
     assert got[0][0, :3].tolist() == [1, 0, 2]  # NaN (positive sign bit pattern) above +inf above -inf
+    # the same through the row-by-row path of the heavy queries (a query value of 0 x inf, a query index nobody stores)
+    hooks.gorse_hip_test_set_sparse_split(1)
+    hooks.gorse_hip_test_set_sparse_heavy(1)
+    qi4, qv4 = np.array([1, 2, 9], np.uint32), np.array([0, 1, 3], np.float32)
+    got = capi.Sparse(ptr3, idx3, val3).search(np.array([0, 3], np.int64), qi4, qv4, 5)
+    check(oracle, ptr3, idx3, val3, 5, got, [(qi4, qv4)], [-1])
+    s = capi.Sparse(ptr + 5, np.concatenate([np.zeros(5, np.uint32), idx]), np.concatenate([np.zeros(5, np.float32), val]))
+    check(oracle, ptr, idx, val, 1024, s.all_pairs(1024), rows_of(ptr, idx, val, range(300)), list(range(300)))
 
 
 def test_argument_errors():
