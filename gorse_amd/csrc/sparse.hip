@@ -34,7 +34,10 @@ struct gorse_sparse {
     // staging of one call
     DevBuf<int64_t> q_ptr, q_excl;
     DevBuf<uint32_t> q_idx;
-    DevBuf<int32_t> q_cid, out_idx, out_cnt, next, split_t, part_cnt, heavy_t, heavy_pslot;
+    DevBuf<int32_t> q_cid, out_idx, out_cnt, next, split_t, split_n, part_cnt, heavy_t, heavy_pslot, range_start;
+    int32_t n_ranges = 0;  // row ranges of about equal cost for sparse_rows_kernel
+    hipStream_t stream2 = nullptr;  // the heavy queries run next to the others
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf<uint2> dense;  // heavy queries of a launch: n x Dc {present, value bits}
     DevBuf<float> q_val, out_score;
     DevBuf<sparse::Work> work;
@@ -107,7 +110,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     // Work items: a long query as one item per group (+ a merge of the partial rankings), the others as one item each.  Long
     // queries first, everything longest first: the launch ends with the cheap items.  The partial rankings of the long queries
     // are bounded (kPartBytes): a call with more long queries than fit takes several launches.
-    const int64_t ng = h->ngroups;
+    const int64_t ng = std::max(h->ngroups, h->n_ranges);  // most partial rankings of one query
     std::vector<int32_t> longs, shorts;
     {   // counting sort by length, longest first (stable in t)
         const int64_t cut = g_sparse_split > 0 ? g_sparse_split : INT64_MAX;
@@ -150,7 +153,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     auto is_heavy = [&](int32_t t) { return g_sparse_heavy > 0 && q_len_host[t + 1] - q_len_host[t] > g_sparse_heavy; };
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
     TileArgs a;
-    a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG;
+    a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG, a.part_stride = (int32_t)ng;
     a.N = h->N;
     a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
     a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
@@ -173,9 +176,10 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         // the parts of the long queries by estimated cost (entries of the query x share of the stored entries in the group's
         // rows), dearest first and at a raised wave priority where one part alone is a sizeable piece of the launch: (longest
         // query, most popular rows) ran for 60 of the launch's 68 ms (profiles/r02_o_probe_sparse_trace.txt)
-        std::vector<int32_t> heavy_t, heavy_pslot;
+        std::vector<int32_t> heavy_t, heavy_pslot, nparts(l1 - l0, h->ngroups);
         for (size_t l = l0; l < l1; l++) {
             if (is_heavy(longs[l])) {
+                nparts[l - l0] = h->n_ranges;
                 heavy_t.push_back(longs[l]);
                 heavy_pslot.push_back((int32_t)(l - l0));
                 continue;
@@ -193,36 +197,41 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
         if (n_long > 0) {
             GORSE_TRY(h->split_t.ensure(n_long));
+            GORSE_TRY(h->split_n.ensure(n_long));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->split_n.p, nparts.data(), n_long * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_TRY(h->part_keys.ensure(n_long * (size_t)ng * (size_t)kp));
             GORSE_TRY(h->part_cnt.ensure(n_long * (size_t)ng * 2));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, longs.data() + l0, n_long * 4, hipMemcpyHostToDevice, h->stream));
         }
         GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, 2 * sizeof(int32_t), h->stream));
-        if (!heavy_t.empty()) {  // the heavy queries: dense copies, then every stored row against them
+        if (!heavy_t.empty()) {  // the heavy queries: dense copies, then every stored row against them -- next to the others
             const size_t nh = heavy_t.size();
             GORSE_TRY(h->heavy_t.ensure(nh));
             GORSE_TRY(h->heavy_pslot.ensure(nh));
             GORSE_TRY(h->dense.ensure(nh * (size_t)h->Dc + 1));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_t.p, heavy_t.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_pslot.p, heavy_pslot.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
-            GORSE_HIP_CHECK(hipMemsetAsync(h->dense.p, 0, (nh * (size_t)h->Dc + 1) * sizeof(uint2), h->stream));
-            sparse::sparse_dense_query_kernel<<<dim3(64, (unsigned)nh), dim3(256), 0, h->stream>>>(qp, qc, qv, q_first, h->heavy_t.p,
-                                                                                                   h->Dc, h->dense.p);
+            GORSE_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));  // uploads, memsets, the buffers of the previous launch
+            GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->dense.p, 0, (nh * (size_t)h->Dc + 1) * sizeof(uint2), h->stream2));
+            sparse::sparse_dense_query_kernel<<<dim3(64, (unsigned)nh), dim3(256), 0, h->stream2>>>(qp, qc, qv, q_first, h->heavy_t.p,
+                                                                                                    h->Dc, h->dense.p);
             sparse::RowsArgs r;
             r.r_ptr = h->r_ptr.p, r.r_cid = h->r_cid.p, r.r_val = h->r_val.p, r.orig_of = h->orig_of.p;
-            r.N = h->N, r.logG = h->logG, r.ngroups = h->ngroups;
+            r.N = h->N, r.range_start = h->range_start.p, r.n_ranges = h->n_ranges, r.part_stride = (int32_t)ng;
             r.dense = h->dense.p, r.Dc = h->Dc;
             r.heavy_t = h->heavy_t.p, r.heavy_pslot = h->heavy_pslot.p, r.n_heavy = (int32_t)nh;
             r.q_first = q_first, r.exclude = excl_dev, r.exclude_self = exclude_self, r.mask_sid = a.mask_sid;
             r.k = k, r.next = h->next.p + 1;
             r.part_keys = h->part_keys.p, r.part_cnt = h->part_cnt.p, r.stat = h->stat.p;
-            const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->ngroups, slots));
+            const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->n_ranges, slots));
             switch (kp) {
-                case 256: sparse::sparse_rows_kernel<256><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream>>>(r); break;
-                case 512: sparse::sparse_rows_kernel<512><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream>>>(r); break;
-                default: sparse::sparse_rows_kernel<1024><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream>>>(r); break;
+                case 256: sparse::sparse_rows_kernel<256><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
+                case 512: sparse::sparse_rows_kernel<512><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
+                default: sparse::sparse_rows_kernel<1024><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
             }
             GORSE_HIP_CHECK(hipGetLastError());
+            GORSE_HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
         }
         a.work = h->work.p, a.n_work = (int32_t)work.size();
         a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
@@ -240,9 +249,10 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             }
             GORSE_HIP_CHECK(hipGetLastError());
         }
+        if (!heavy_t.empty()) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         if (n_long > 0) {
             sparse::MergeArgs m;
-            m.split_t = h->split_t.p, m.n_split = (int32_t)n_long, m.nparts = h->ngroups;
+            m.split_t = h->split_t.p, m.split_n = h->split_n.p, m.n_split = (int32_t)n_long, m.part_stride = (int32_t)ng;
             m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
             m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
             m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
@@ -255,8 +265,8 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             }
             GORSE_HIP_CHECK(hipGetLastError());
         }
-        // the host lists (work, heavy_*, split_t) and the trace buffer are reused or die with this iteration
-        if (l1 < longs.size() || h->trace_on || !heavy_t.empty()) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        // the host lists (work, heavy_*, nparts, split_t) and the trace buffer are reused or die with this iteration
+        if (n_long > 0 || h->trace_on) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->trace_on) {
             const size_t at = h->trace_host.size();
             h->trace_host.resize(at + work.size());
@@ -323,6 +333,30 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
             return fail(GORSE_ERR_INVALID, "index too large: %lld distinct indices x %d row groups", (long long)h->Dc, h->ngroups);
         GORSE_TRY(h->use());
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        {   // row ranges for the heavy queries: blocks of 64 scratch ids (longest rows first: a block costs its first row's length),
+            // closed when they reach 1 / 128 of the total cost -- or the cost of the first block, whichever is larger
+            std::vector<int32_t> starts{0};
+            auto len_of = [&](int64_t sid) { const int64_t r = h->order.orig_of[(size_t)sid]; return indptr[r + 1] - indptr[r]; };
+            int64_t total = 0;
+            for (int64_t sid = 0; sid < N; sid += 64) total += len_of(sid) + 1;
+            const int64_t target = std::max<int64_t>(len_of(0) + 1, total / 128);
+            int64_t cost = 0;
+            for (int64_t sid = 0; sid < N; sid += 64) {
+                cost += len_of(sid) + 1;
+                if (cost >= target && sid + 64 < N) {
+                    starts.push_back((int32_t)(sid + 64));
+                    cost = 0;
+                }
+            }
+            starts.push_back((int32_t)N);
+            h->n_ranges = (int32_t)starts.size() - 1;
+            GORSE_TRY(h->range_start.alloc(starts.size()));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->range_start.p, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
         std::vector<int64_t> &ptr0 = h->r_ptr_host;
         ptr0.resize((size_t)N + 1);
         for (int64_t r = 0; r <= N; r++) ptr0[(size_t)r] = indptr[r] - base;
@@ -377,10 +411,16 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
 extern "C" int32_t gorse_sparse_destroy(gorse_sparse *h) {
     if (!h) return GORSE_OK;
     (void)hipSetDevice(h->device);
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
     }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
     return GORSE_OK;
 }

@@ -95,6 +95,7 @@ struct TileArgs {
     const uint32_t *off;
     const Posting *post;
     int32_t ngroups, logG;
+    int32_t part_stride;  // partial rankings per block of part_keys / part_cnt
     int64_t N;
     const int32_t *orig_of, *new_of;  // scratch id <-> caller's row
     // queries: CSR rows q_first .. of (q_ptr, q_cid, q_val); q_cid = directory entry of the index or -1 (never stored)
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
             write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         } else {
-            const size_t part = (size_t)wk.pslot * a.ngroups + wk.part;
+            const size_t part = (size_t)wk.pslot * a.part_stride + wk.part;
             for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
             if (lane == 0) {
                 a.part_cnt[part * 2] = (int32_t)pos;
@@ -670,15 +671,19 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
 // The query's (index, value) pairs are scattered into dense[c] = {1, value bits} over the directory entries c (zero = the
 // query does not hold the index).  One lane scores one stored row: its entries in storage order = ascending index, each
 // looked up in the dense vector, the products of the matches added one after the other -- the oracle's merge-order sum, with
-// no accumulator shared between lanes.  A work item = (heavy query, row group): the group's rows 64 at a time, longest rows
-// first, so the lanes of a step have rows of similar length; it leaves a partial ranking like a part of a long query.
+// no accumulator shared between lanes.  A work item = (heavy query, row range): the range's rows 64 at a time, longest rows
+// first, so the lanes of a step have rows of similar length; it leaves a partial ranking like a part of a long query.  The
+// ranges are cut by cost (the longest row of every 64 counts): the 64 longest rows are a range of their own -- as row groups of
+// 2048 the first group was 50 ms on one wave (profiles/r02_s_probe_sparse_c3.txt).
 struct RowsArgs {
     const int64_t *r_ptr;  // stored rows in the caller's order: r_ptr[N + 1], r_cid / r_val
     const int32_t *r_cid;
     const float *r_val;
     const int32_t *orig_of;  // scratch id -> caller's row
     int64_t N;
-    int32_t logG, ngroups;
+    const int32_t *range_start;  // n_ranges + 1 scratch ids (multiples of 64; the last = N): ranges of about equal cost
+    int32_t n_ranges;
+    int32_t part_stride;  // partial rankings per block of part_keys / part_cnt
     const uint2 *dense;  // n_heavy x Dc
     int64_t Dc;
     const int32_t *heavy_t;      // query of the call
@@ -711,13 +716,13 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
     constexpr int kDeep = 16;  // entries of a row in flight per lane
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x;
-    const int n_items = a.n_heavy * a.ngroups;
+    const int n_items = a.n_heavy * a.n_ranges;
     for (;;) {
         int w = 0;
         if (lane == 0) w = atomicAdd(a.next, 1);
         w = __builtin_amdgcn_readfirstlane(w);
         if (w >= n_items) break;
-        const int g = w / a.n_heavy, h = w % a.n_heavy;  // group-major: the queries of a group share its rows in the caches
+        const int g = w / a.n_heavy, h = w % a.n_heavy;  // range-major: the queries of a range share its rows in the caches
         const int64_t t = a.heavy_t[h];
         const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? a.q_first + t : (int64_t)-1);
         const uint2 *dense = a.dense + (size_t)h * a.Dc;
@@ -725,8 +730,7 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
         unsigned long long thr = 0;
         int my_pos = 0, my_neg = 0, my_hit = 0;
         unsigned long long matched = 0;
-        const int64_t s0 = (int64_t)g << a.logG;
-        const int64_t s1 = min(s0 + ((int64_t)1 << a.logG), a.N);
+        const int64_t s0 = a.range_start[g], s1 = a.range_start[g + 1];
         for (int64_t sb = s0; sb < s1; sb += kBlock) {
             const int64_t sid = sb + lane;
             const bool in = sid < s1;
@@ -734,34 +738,37 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
             int64_t e = a.r_ptr[row];
             const int64_t end = in ? a.r_ptr[row + 1] : e;
             float acc = 0.0f;
-            int32_t c[kDeep];
-            float v[kDeep];
-            // stage 1 of block 0; then per block: the lookups of this block and the entries of the next are in flight together
-#pragma unroll
-            for (int j = 0; j < kDeep; j++) {
-                const int64_t at = e + j < end ? e + j : 0;  // entry 0 exists (a row with an entry was found) or is padding
-                c[j] = a.r_cid[at], v[j] = a.r_val[at];
-            }
-            while (__ballot(e < end)) {
-                uint2 q[kDeep];
-#pragma unroll
-                for (int j = 0; j < kDeep; j++) q[j] = dense[e + j < end ? c[j] : 0];
-                float vv[kDeep];
-                int32_t cn[kDeep];
+            // three blocks of kDeep entries in flight per lane: the entries of block b + 2 are loaded while the lookups of block
+            // b + 1 are under way and block b is added up
+            int32_t c1[kDeep], c2[kDeep];
+            float v0[kDeep], v1[kDeep], v2[kDeep];
+            uint2 q0[kDeep], q1[kDeep];
+            auto load_entries = [&](int64_t from, int32_t (&c)[kDeep], float (&v)[kDeep]) {
 #pragma unroll
                 for (int j = 0; j < kDeep; j++) {
-                    vv[j] = v[j];
-                    const int64_t at = e + kDeep + j < end ? e + kDeep + j : 0;
-                    cn[j] = a.r_cid[at], v[j] = a.r_val[at];
+                    const int64_t at = from + j < end ? from + j : 0;  // element 0 exists (the arrays are padded)
+                    c[j] = a.r_cid[at], v[j] = a.r_val[at];
                 }
+            };
+            auto look_up = [&](int64_t from, const int32_t (&c)[kDeep], uint2 (&q)[kDeep]) {
+#pragma unroll
+                for (int j = 0; j < kDeep; j++) q[j] = dense[from + j < end ? c[j] : 0];
+            };
+            load_entries(e, c1, v0);
+            look_up(e, c1, q0);
+            load_entries(e + kDeep, c1, v1);
+            while (__ballot(e < end)) {
+                look_up(e + kDeep, c1, q1);
+                load_entries(e + 2 * kDeep, c2, v2);
 #pragma unroll
                 for (int j = 0; j < kDeep; j++) {
-                    const bool hit = e + j < end && q[j].x != 0;
-                    const float sum = __fadd_rn(acc, __fmul_rn(__uint_as_float(q[j].y), vv[j]));
+                    const bool hit = e + j < end && q0[j].x != 0;
+                    const float sum = __fadd_rn(acc, __fmul_rn(__uint_as_float(q0[j].y), v0[j]));
                     acc = hit ? sum : acc;
                     matched += hit;
-                    c[j] = cn[j];
                 }
+#pragma unroll
+                for (int j = 0; j < kDeep; j++) q0[j] = q1[j], v0[j] = v1[j], v1[j] = v2[j], c1[j] = c2[j];
                 e += kDeep;
             }
             // rank (the same rules as the read-back of sparse_tile_kernel)
@@ -782,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
         const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);
         const long long walked = wave_sum((long long)matched);
         finish<KP>(s_buf, bcnt, lane);
-        const size_t part = (size_t)a.heavy_pslot[h] * a.ngroups + g;
+        const size_t part = (size_t)a.heavy_pslot[h] * a.part_stride + g;
         for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
         if (lane == 0) {
             a.part_cnt[part * 2] = (int32_t)pos;
@@ -799,7 +806,8 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
 // the partial rankings of a long query (one per group) -> its result row
 struct MergeArgs {
     const int32_t *split_t;  // query of every block of partial rankings
-    int32_t n_split, nparts;
+    const int32_t *split_n;  // rankings in the block
+    int32_t n_split, part_stride;
     const unsigned long long *part_keys;
     const int32_t *part_cnt;
     int64_t q_first, N;
@@ -824,8 +832,9 @@ __global__ __launch_bounds__(kBlock) void sparse_merge_kernel(MergeArgs a) {
         int bcnt = 0;
         unsigned long long thr = 0;
         long long pos = 0, neg = 0;
-        for (int s = 0; s < a.nparts; s++) {
-            const size_t part = (size_t)b * a.nparts + s;
+        const int nparts = a.split_n[b];
+        for (int s = 0; s < nparts; s++) {
+            const size_t part = (size_t)b * a.part_stride + s;
             pos += a.part_cnt[part * 2];
             neg += a.part_cnt[part * 2 + 1];
             for (int i = 0; i < KP; i += kBlock) {

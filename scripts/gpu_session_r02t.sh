@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 2, nineteenth device session: long queries as one work item per row group (one arrangement of the posting lists).
+# Round 2, twentieth device session: long queries as one work item per row group (one arrangement of the posting lists).
 set -u
-TAG=${1:-r02_s}
+TAG=${1:-r02_t}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
