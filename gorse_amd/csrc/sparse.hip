@@ -224,7 +224,9 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             r.q_first = q_first, r.exclude = excl_dev, r.exclude_self = exclude_self, r.mask_sid = a.mask_sid;
             r.k = k, r.next = h->next.p + 1;
             r.part_keys = h->part_keys.p, r.part_cnt = h->part_cnt.p, r.stat = h->stat.p;
-            const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->n_ranges, slots));
+            // at most four of its waves per CU: the kernel is bound by its longest row, not by throughput, and at 170 VGPRs a full
+            // grid of it would take the register files from the list walk it runs next to
+            const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->n_ranges, std::min<int64_t>(slots, 1024)));
             switch (kp) {
                 case 256: sparse::sparse_rows_kernel<256><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
                 case 512: sparse::sparse_rows_kernel<512><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;

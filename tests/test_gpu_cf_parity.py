@@ -18,6 +18,17 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+def report_elementwise(label, pairs):
+    """prints, next to whichever bar the test applies, the PLAIN element-wise relative error |got - ref| / |ref| (max and the
+    99.9th percentile over the elements with |ref| > 0): the figure "1e-4 relative" would mean with no floor at all"""
+    for name, got, ref in pairs:
+        got, ref = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+        nz = ref != 0
+        rel = np.abs(got[nz] - ref[nz]) / np.abs(ref[nz])
+        print("%s %s: element-wise relative error max %.2e, 99.9th percentile %.2e; max |error| / max |ref| %.2e"
+              % (label, name, rel.max(), np.quantile(rel, 0.999), np.abs(got - ref).max() / np.abs(ref).max()))
+
+
 def rel_err(a, b):
     """Largest element error relative to max(|reference element|, rms of the reference matrix):
     plain element-wise relative error, except that elements far below the matrix scale are
@@ -124,6 +135,7 @@ def test_bpr_sequential_libm_exp_within_tolerance(oracle, small):
     eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
     mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_SEQUENTIAL)
     gP, gQ = mf.get_factors()
+    report_elementwise("BPR sequential epoch (libm exp)", (("P", gP, eP), ("Q", gQ, eQ)))
     assert rel_err(gP, eP) < 1e-4 and rel_err(gQ, eQ) < 1e-4
 
 
@@ -428,6 +440,7 @@ def test_als_epoch_parity(oracle, small, d, path, als_paths):
     gP, gQ = mf.get_factors()
     assert np.isfinite(gP).all()
     scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    report_elementwise("ALS", (("P", gP, eP), ("Q", gQ, eQ)))
     assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
@@ -456,6 +469,7 @@ def test_als_long_rows_chunked(oracle, d, long_row, chunk, als_paths):
         mf.als_epoch(0.05, 0.015)
     gP, gQ = mf.get_factors()
     scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    report_elementwise("ALS", (("P", gP, eP), ("Q", gQ, eQ)))
     assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
@@ -482,6 +496,7 @@ def test_als_rows_without_feedback(oracle, als_paths):
         mf.als_epoch(0.05, 0.015)
         gP, gQ = mf.get_factors()
         scale = max(np.abs(eP).max(), np.abs(eQ).max())
+        report_elementwise("ALS", (("P", gP, eP), ("Q", gQ, eQ)))
         assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
@@ -546,6 +561,7 @@ def test_als_heavy_rows(oracle, path, als_paths):
     mf.als_epoch(0.05, 0.015)
     gP, gQ = mf.get_factors()
     scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    report_elementwise("ALS", (("P", gP, eP), ("Q", gQ, eQ)))
     assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
