@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libgorse_hip.so")
+LIB_PATH = os.environ.get("GORSE_HIP_LIB") or os.path.join(HERE, "lib", "libgorse_hip.so")  # the override serves probe builds
 
 OK, ERR_INVALID, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE, ERR_RANGE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY = 0, 1, 2

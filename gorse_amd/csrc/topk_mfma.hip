@@ -35,7 +35,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxRB = 4;      // a tile holds RB 32-row MFMA blocks (RB = 2 or 4: 64 or 128 candidate rows per barrier)
-constexpr int kWavesMain = 8;  // waves per workgroup of the main sweep, two per SIMD
+#ifndef GORSE_SWEEP_WAVES
+#define GORSE_SWEEP_WAVES 8
+#endif
+constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the main sweep, two per SIMD (a build-time probe switch)
 // the history sweep serves the few queries with ties: small workgroups (2 waves = 64 * NCB queries) spread them over
 // many CUs instead of a handful of 8-wave workgroups; deep operands keep more waves (the tile prefetch registers of a
 // thread grow as the workgroup shrinks)

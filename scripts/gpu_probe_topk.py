@@ -41,6 +41,12 @@ def main():
         run("C4 S-emb bf16 cosine 256K q", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
         run("C4 S-emb bf16 cosine", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "tiles":  # 128- and 64-row tiles (run once per library build: GORSE_HIP_LIB)
+        for v, label in [(2, "128-row tiles"), (1, "64-row tiles")]:
+            capi.lib().gorse_hip_test_set_topk_variant(v)
+            run("C4 256K q: " + label, Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=2)
+        capi.lib().gorse_hip_test_set_topk_variant(0)
+        return
     if len(sys.argv) > 1 and sys.argv[1] in ("onewarm", "onecold"):  # one configuration, for a kernel trace
         capi.lib().gorse_hip_test_set_topk_variant(0 if sys.argv[1] == "onewarm" else 256)
         run("C4 256K q: " + sys.argv[1], Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)

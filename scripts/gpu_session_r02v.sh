@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 2: the main sweep with four-wave workgroups (two per CU, each with its own tiles and barriers) against eight-wave ones.
+set -u
+TAG=${1:-r02_v}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+timeout 300 python scripts/gpu_probe_topk.py tiles > "$OUT/${TAG}_probe_topk_w8.txt" 2>&1
+echo "w8 exit $?"; cut -c1-260 "$OUT/${TAG}_probe_topk_w8.txt"
+GORSE_HIP_LIB=$ROOT/gorse_amd/lib/libgorse_hip_w4.so timeout 300 python scripts/gpu_probe_topk.py tiles > "$OUT/${TAG}_probe_topk_w4.txt" 2>&1
+echo "w4 exit $?"; cut -c1-260 "$OUT/${TAG}_probe_topk_w4.txt"
+GORSE_HIP_LIB=$ROOT/gorse_amd/lib/libgorse_hip_w4.so timeout 400 python -m pytest tests/test_gpu_topk_mfma.py -q -m gpu -x > "$OUT/${TAG}_pytest_w4.log" 2>&1
+echo "pytest w4 exit $?"; tail -3 "$OUT/${TAG}_pytest_w4.log"
