@@ -15,7 +15,7 @@ struct gorse_topk {
     gorse::DevBuf<float> norm2;   // floats.Dot(x, x) per stored vector
     gorse::DevBuf<float> qbuf, qnorm, dist;
     gorse::DevBuf<int64_t> qidx;
-    gorse::DevBuf<int32_t> out_idx, out_cnt, heap_v;
+    gorse::DevBuf<int32_t> out_idx, out_cnt, heap_v, scan_literal;
     gorse::DevBuf<float> out_dist, heap_w;
     // ---- path B (topk_mfma.hip) ----
     bool mfma_ok = false;          // operands built and the data admits a rigorous error bound

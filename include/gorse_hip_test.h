@@ -48,6 +48,9 @@ int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n /*out*/);
  * kernel ticks, [7] waves, and the candidate path split into [8] count + exchange, [9] appends, [10] compaction
  * check / compaction, with [11] lanes that appended. */
 int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/);
+/* 1 = every query of the literal scan (path A) goes through the one-thread-per-query heap kernel; 0 (default) = the queries whose
+ * k + 1 smallest distances are pairwise distinct are answered by select_fast_kernel (same results). */
+void gorse_hip_test_set_scan_literal(int32_t on);
 /* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);

@@ -12,3 +12,7 @@ GORSE_HIP_LIB=$ROOT/gorse_amd/lib/libgorse_hip_w4.so timeout 300 python scripts/
 echo "w4 exit $?"; cut -c1-260 "$OUT/${TAG}_probe_topk_w4.txt"
 GORSE_HIP_LIB=$ROOT/gorse_amd/lib/libgorse_hip_w4.so timeout 400 python -m pytest tests/test_gpu_topk_mfma.py -q -m gpu -x > "$OUT/${TAG}_pytest_w4.log" 2>&1
 echo "pytest w4 exit $?"; tail -3 "$OUT/${TAG}_pytest_w4.log"
+timeout 300 python -m pytest tests/test_gpu_topk_sgemm.py tests/test_gpu_topk_mfma.py tests/test_gpu_vectors_db.py -q -m gpu -x > "$OUT/${TAG}_pytest_topk.log" 2>&1
+echo "pytest topk exit $?"; tail -3 "$OUT/${TAG}_pytest_topk.log"
+timeout 300 python scripts/gpu_probe_query_latency.py > "$OUT/${TAG}_probe_query_latency.txt" 2>&1
+echo "latency probe exit $?"; cat "$OUT/${TAG}_probe_query_latency.txt"

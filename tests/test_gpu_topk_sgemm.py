@@ -101,6 +101,42 @@ def test_bf16_index(oracle):
             assert np.array_equal(idx[q, :cnt[q]], ei) and np.array_equal(bits(dist[q, :cnt[q]]), bits(ed))
 
 
+def test_fast_selection_equals_the_literal_heaps():
+    """the scan's two selection kernels: select_fast_kernel (queries whose k + 1 smallest distances are pairwise distinct) +
+    the literal heap kernel for the rest, against the literal kernel alone -- indices, distance bits, counts, padding; with
+    ties (small integers), a mask, prune0, NaN / inf vectors, k + 1 > N, and sizes around the 1024-thread stride"""
+    rng = np.random.default_rng(21)
+    L = capi.lib()
+    cases = []
+    for N, d, k in ((5000, 24, 100), (1023, 8, 7), (1025, 8, 300), (40, 5, 64), (3000, 16, 1000)):
+        cases.append((rng.standard_normal((N, d)).astype(np.float32), k, None))
+    Xi = rng.integers(-2, 3, (2500, 6)).astype(np.float32)  # many equal distances
+    cases.append((Xi, 20, None))
+    cases.append((Xi, 20, (rng.random(2500) < 0.3).astype(np.uint8)))
+    Xn = rng.standard_normal((800, 12)).astype(np.float32)
+    Xn[5, 3], Xn[77, 0], Xn[300, 1] = np.nan, np.inf, -np.inf
+    cases.append((Xn, 15, None))
+    try:
+        for X, k, mask in cases:
+            for metric in (capi.METRIC_NEG_DOT, capi.METRIC_EUCLIDEAN, capi.METRIC_COSINE):
+                t = capi.TopK(X, metric)
+                if mask is not None:
+                    t.set_mask(mask)
+                qs = rng.integers(0, X.shape[0], 9)
+                qv = rng.standard_normal((5, X.shape[1])).astype(np.float32)
+                for prune0 in (False, True):
+                    L.gorse_hip_test_set_scan_literal(0)
+                    a = t.search_index(qs, k, prune0) + t.search_vector(qv, k, prune0)
+                    L.gorse_hip_test_set_scan_literal(1)
+                    b = t.search_index(qs, k, prune0) + t.search_vector(qv, k, prune0)
+                    for x, y in zip(a, b):
+                        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                                              y.view(np.uint32) if y.dtype == np.float32 else y), (X.shape, k, metric, prune0)
+                t.close()
+    finally:
+        L.gorse_hip_test_set_scan_literal(0)
+
+
 def test_topk_edge_cases(oracle):
     X = np.arange(12, dtype=np.float32).reshape(4, 3)
     t = capi.TopK(X, capi.METRIC_EUCLIDEAN)
