@@ -45,6 +45,7 @@ constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the mai
 constexpr int sweep_waves(bool hist, int kp) { return !hist ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
 constexpr int kWaves = kWavesMain;
 constexpr int kThreads = kWaves * 64;
+constexpr int64_t kMinSweepQueries = 384;  // fewer queries in a call take the scan (see topk_mfma_usable)
 constexpr int kCap = 512;      // candidate-list capacity per query
 constexpr int kEPL = kCap / 64;
 constexpr int kCompactAt = kCap - 64;   // compact a list once it holds more than this (a block adds <= 32)
@@ -1108,7 +1109,10 @@ namespace gorse {
 bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k) {
     if (!h->mfma_ok || g_topk_force_path == 1) return false;
     if (k + 1 > kMaxKth) return false;
-    return g_topk_force_path >= 2 || nq >= 64;
+    // Below ~400 queries the scan (path A: distances in the reference's order, select_fast_kernel) is faster: ~0.2 ms per query at
+    // N = 1M, against the ~40-100 ms one or two workgroups need to sweep a million rows on their own
+    // (profiles/r02_v_probe_query_latency.txt: 8 queries 1.6 ms on the scan, 64 queries 41 ms and 512 queries 97 ms on the sweep).
+    return g_topk_force_path >= 2 || nq >= kMinSweepQueries;
 }
 
 int32_t topk_mfma_prepare(gorse_topk *h) {
