@@ -301,15 +301,15 @@ def _search_result(type_buf, params_buf, score):
     return {"Type": type_buf.value.decode(), "Params": params, "Score": Score(score[0], score[1], score[2])}
 
 
-def search_mock(n_trials, seed=0):
-    """optimize_test.go's TestTPE search (mock model, NDCG = NFactors + InitMean + InitStdDev) under the random study;
-    returns (study.GetBestValue(), search.Result())"""
+def search_mock(n_trials, seed=0, sampler="tpe"):
+    """optimize_test.go's TestTPE search (mock model, NDCG = NFactors + InitMean + InitStdDev) under the TPE study of the
+    reference's test (or independent random trials); returns (study.GetBestValue(), search.Result())"""
     t, p, sc = _search_out()
     best = C.c_double(0)
     H = host()
-    H.gh_search_mock.argtypes = [C.c_int32, C.c_int64, C.POINTER(C.c_double), C.c_char_p, C.c_int64, C.c_char_p, C.c_int64,
+    H.gh_search_mock.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.c_int64, C.c_char_p, C.c_int64,
                                  C.POINTER(C.c_float)]
-    _ck(H.gh_search_mock(n_trials, seed, C.byref(best), t, len(t), p, len(p), sc))
+    _ck(H.gh_search_mock(n_trials, seed, 0 if sampler == "tpe" else 1, C.byref(best), t, len(t), p, len(p), sc))
     return best.value, _search_result(t, p, sc)
 
 

@@ -45,7 +45,7 @@ constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the mai
 constexpr int sweep_waves(bool hist, int kp) { return !hist ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
 constexpr int kWaves = kWavesMain;
 constexpr int kThreads = kWaves * 64;
-constexpr int64_t kMinSweepQueries = 384;  // fewer queries in a call take the scan (see topk_mfma_usable)
+constexpr int64_t kMinSweepQueries = 768;  // fewer queries in a call take the scan (see topk_mfma_usable)
 constexpr int kCap = 512;      // candidate-list capacity per query
 constexpr int kEPL = kCap / 64;
 constexpr int kCompactAt = kCap - 64;   // compact a list once it holds more than this (a block adds <= 32)
@@ -1109,9 +1109,9 @@ namespace gorse {
 bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k) {
     if (!h->mfma_ok || g_topk_force_path == 1) return false;
     if (k + 1 > kMaxKth) return false;
-    // Below ~400 queries the scan (path A: distances in the reference's order, select_fast_kernel) is faster: ~0.2 ms per query at
-    // N = 1M, against the ~40-100 ms one or two workgroups need to sweep a million rows on their own
-    // (profiles/r02_v_probe_query_latency.txt: 8 queries 1.6 ms on the scan, 64 queries 41 ms and 512 queries 97 ms on the sweep).
+    // Below ~800 queries the scan (path A: distances in the reference's order, select_fast_kernel) is faster: 0.12 ms per query at
+    // N = 1M, against the ~40-100 ms one or two workgroups need to sweep a million rows on their own (profiles/
+    // r02_v / r02_w_probe_query_latency.txt: 64 queries 7.4 ms on the scan, 41 ms on the sweep; 512 queries 96 ms on the sweep).
     return g_topk_force_path >= 2 || nq >= kMinSweepQueries;
 }
 

@@ -31,6 +31,7 @@
 
 #include "../../include/gorse_hip.h"
 #include "../csrc/goheap.hpp"
+#include "tpe.hpp"
 
 namespace gorse {
 
@@ -780,9 +781,8 @@ class ModelSearch {
 };
 
 // A trial that draws every parameter independently: uniform over the choices, log-uniform, uniform over the grid
-// low, low + q, ... <= high.  This is goptuna's random sampling, which its TPE sampler also uses for its start-up trials;
-// the TPE model itself (github.com/c-bata/goptuna v0.9.0, absent from /root/reference) is not restated, and which values
-// Go's generator would draw is unpinned like every math/rand stream.
+// low, low + q, ... <= high.  This is goptuna's random sampling, which its TPE sampler also uses for its start-up trials
+// (TpeTrial below); which values Go's generator would draw is unpinned like every math/rand stream.
 class RandomTrial : public Trial {
    public:
     explicit RandomTrial(util::RandomGenerator &rng) : rng_(rng) {}
@@ -810,17 +810,72 @@ class RandomTrial : public Trial {
     util::RandomGenerator &rng_;
 };
 
-// goptuna.CreateStudy(direction = maximize) + study.Optimize(objective, nTrials) with independent random trials
+// A trial of the TPE sampler (tpe.hpp): every parameter is suggested from the finished trials that have it -- at random for
+// the first ten, then the best of 24 candidates drawn from the Parzen estimator of the better trials.
+class TpeTrial : public Trial {
+   public:
+    TpeTrial(util::RandomGenerator &rng, const std::vector<tpe::Finished> &done) : rng_(rng), done_(done), random_(rng) {}
+    std::string SuggestCategorical(const std::string &name, const std::vector<std::string> &choices) override {
+        if (choices.empty()) throw std::invalid_argument("no choices for " + name);
+        std::vector<double> below, above;
+        tpe::split(done_, name, below, above);
+        int c;
+        if ((int)(below.size() + above.size()) < tpe::kStartupTrials)
+            c = rng_.Intn((int)choices.size());
+        else
+            c = tpe::suggest_categorical(below, above, (int)choices.size(), rng_);
+        Values[name] = (double)c;
+        return choices[(size_t)c];
+    }
+    double SuggestLogFloat(const std::string &name, double low, double high) override {
+        if (!(low > 0) || high < low) throw std::invalid_argument("bad log range for " + name);
+        std::vector<double> below, above;
+        tpe::split(done_, name, below, above);
+        if ((int)(below.size() + above.size()) < tpe::kStartupTrials) return Values[name] = random_.SuggestLogFloat(name, low, high);
+        for (double &x : below) x = std::log(x);
+        for (double &x : above) x = std::log(x);
+        const double v = std::exp(tpe::suggest_numerical(below, above, std::log(low), std::log(high), 0.0, rng_));
+        return Values[name] = std::min(std::max(v, low), high);
+    }
+    double SuggestDiscreteFloat(const std::string &name, double low, double high, double q) override {
+        if (!(q > 0) || high < low) throw std::invalid_argument("bad grid for " + name);
+        std::vector<double> below, above;
+        tpe::split(done_, name, below, above);
+        if ((int)(below.size() + above.size()) < tpe::kStartupTrials) return Values[name] = random_.SuggestDiscreteFloat(name, low, high, q);
+        const double v = tpe::suggest_numerical(below, above, low - 0.5 * q, high + 0.5 * q, q, rng_);
+        return Values[name] = std::min(std::max(v, low), high);
+    }
+    std::map<std::string, double> Values;  // what this trial drew (a categorical parameter: the position of the choice)
+
+   private:
+    util::RandomGenerator &rng_;
+    const std::vector<tpe::Finished> &done_;
+    RandomTrial random_;
+};
+
+// goptuna.CreateStudy(direction = maximize, sampler) + study.Optimize(objective, nTrials): the TPE sampler of
+// master/tasks.go:1297-1300 by default, independent random trials on request (goptuna's default sampler)
 class Study {
    public:
-    explicit Study(int64_t seed = 0) : rng_(seed) {}
+    enum class Sampler { TPE, Random };
+    explicit Study(int64_t seed = 0, Sampler sampler = Sampler::TPE) : rng_(seed), sampler_(sampler) {}
     void Optimize(const std::function<double(Trial &)> &objective, int nTrials, const volatile int32_t *cancel = nullptr) {
         for (int t = 0; t < nTrials; t++) {
             if (cancel && *cancel) throw std::runtime_error("context canceled");  // study.WithContext(ctx)
-            RandomTrial trial(rng_);
-            const double v = objective(trial);
+            double v;
+            std::map<std::string, double> drew;
+            if (sampler_ == Sampler::TPE) {
+                TpeTrial trial(rng_, done_);
+                v = objective(trial);
+                drew = trial.Values;
+            } else {
+                RandomTrial trial(rng_);
+                v = objective(trial);
+                drew = trial.Values;
+            }
             if (values_.empty() || v > best_) best_ = v;
             values_.push_back(v);
+            done_.push_back(tpe::Finished{v, drew});
         }
     }
     double GetBestValue() const {
@@ -828,10 +883,13 @@ class Study {
         return best_;
     }
     const std::vector<double> &Values() const { return values_; }
+    const std::vector<tpe::Finished> &Trials() const { return done_; }
 
    private:
     util::RandomGenerator rng_;
+    Sampler sampler_;
     std::vector<double> values_;
+    std::vector<tpe::Finished> done_;
     double best_ = 0;
 };
 

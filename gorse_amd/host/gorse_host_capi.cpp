@@ -273,13 +273,14 @@ void report(const cf::SearchResult &r, char *type_out, int64_t type_cap, char *p
     score3[0] = r.Score_.NDCG, score3[1] = r.Score_.Precision, score3[2] = r.Score_.Recall;
 }
 }  // namespace
-// TestTPE's search (optimize_test.go:101-126) with the random study; best_value = study.GetBestValue()
-int32_t gh_search_mock(int32_t n_trials, int64_t seed, double *best_value, char *type_out, int64_t type_cap, char *params_out,
-                       int64_t params_cap, float *score3) {
+// TestTPE's search (optimize_test.go:101-126); sampler: 0 = TPE (what the reference's test and master use), 1 = random;
+// best_value = study.GetBestValue()
+int32_t gh_search_mock(int32_t n_trials, int64_t seed, int32_t sampler, double *best_value, char *type_out, int64_t type_cap,
+                       char *params_out, int64_t params_cap, float *score3) {
     return guard([&] {
         cf::ModelSearch search({{"mock", [] { return std::unique_ptr<cf::MatrixFactorization>(new MockForSearch()); }}}, nullptr,
                                nullptr, cf::FitConfig(), false);
-        cf::Study study(seed);
+        cf::Study study(seed, sampler ? cf::Study::Sampler::Random : cf::Study::Sampler::TPE);
         study.Optimize([&](cf::Trial &t) { return search.Objective(t); }, n_trials);
         *best_value = study.GetBestValue();
         report(search.Result(), type_out, type_cap, params_out, params_cap, score3);
@@ -322,6 +323,36 @@ int32_t gh_model_search(void *train, void *val, int32_t n_trials, int64_t seed, 
         report(search.Result(), type_out, type_cap, params_out, params_cap, score3);
         if (counters) counters[0] = search.Resident().uploads, counters[1] = search.Resident().reuses, counters[2] = trials;
     });
+}
+
+// ---- the TPE sampler's pieces (tpe.hpp), for the CPU tests ---------------------------------------------------------------
+// the Parzen estimator of `n` observations on [low, high]: returns the number of components (n + 1), fills weights / mus / sigmas
+int32_t gh_tpe_parzen(const double *obs, int32_t n, double low, double high, double *weights, double *mus, double *sigmas, int32_t cap) {
+    const cf::tpe::ParzenEstimator pe(std::vector<double>(obs, obs + n), low, high);
+    const int32_t m = (int32_t)pe.mus.size();
+    for (int32_t i = 0; i < m && i < cap; i++) weights[i] = pe.weights[(size_t)i], mus[i] = pe.mus[(size_t)i], sigmas[i] = pe.sigmas[(size_t)i];
+    return m;
+}
+int32_t gh_tpe_gamma(int32_t n) { return cf::tpe::default_gamma(n); }
+void gh_tpe_weights(int32_t n, double *out) {
+    const std::vector<double> w = cf::tpe::default_weights(n);
+    for (size_t i = 0; i < w.size(); i++) out[i] = w[i];
+}
+void gh_tpe_log_pdf(const double *samples, int32_t ns, const double *obs, int32_t n, double low, double high, double q, double *out) {
+    const cf::tpe::ParzenEstimator pe(std::vector<double>(obs, obs + n), low, high);
+    const std::vector<double> r = cf::tpe::gmm_log_pdf(std::vector<double>(samples, samples + ns), pe, low, high, q);
+    for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
+}
+// a study over one log-uniform parameter x in [low, high] with the objective -(log x - log target)^2: the values suggested
+void gh_tpe_study_1d(int32_t n_trials, int64_t seed, int32_t sampler, double low, double high, double target, double *suggested) {
+    cf::Study study(seed, sampler ? cf::Study::Sampler::Random : cf::Study::Sampler::TPE);
+    int t = 0;
+    study.Optimize([&](cf::Trial &trial) {
+        const double x = trial.SuggestLogFloat("x", low, high);
+        suggested[t++] = x;
+        const double e = std::log(x) - std::log(target);
+        return -e * e;
+    }, n_trials);
 }
 
 // ---- gob (test hooks of gob.hpp) and the MatrixFactorizationUsers blob --------------------------------------------------

@@ -114,7 +114,7 @@ public:
                 throw std::runtime_error(std::string("gorse_topk_create: ") + gorse_hip_last_error());
             }
         }
-        // one call for all queries: >= 384 of them run on the MFMA path of the library, fewer on its scan
+        // one call for all queries: >= 768 of them run on the MFMA path of the library, fewer on its scan
         if (gorse_topk_search_vector(h, Q, nq, k, 0, idx, dist, cnt) != GORSE_OK)
             throw std::runtime_error(std::string("gorse_topk_search_vector: ") + gorse_hip_last_error());
     }

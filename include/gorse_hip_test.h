@@ -26,7 +26,7 @@ void gorse_hip_test_set_exact_exp(int32_t mode);
  * samples in stream order (single thread; makes a run's order deterministic for the parity test).  Used by
  * scripts/gpu_probe_*.py and the tests; 0 (the default) is the only value the product ever runs with. */
 void gorse_hip_test_set_variant(int32_t variant);
-/* top-k path choice: 0 = automatic (MFMA sweep for >= 384 queries, any of the three metrics, k <= 255), 1 = always the
+/* top-k path choice: 0 = automatic (MFMA sweep for >= 768 queries, any of the three metrics, k <= 255), 1 = always the
  * literal scan (path A), 2 = the MFMA sweep whenever its operands exist.  Both paths return identical results;
  * the hook exists so the parity tests can drive each one. */
 void gorse_hip_test_set_topk_path(int32_t path);

@@ -123,7 +123,7 @@ func (b *BruteforceHIP) SearchVector(q []float32, k int, prune0 bool) []lo.Tuple
 	return zip(idx, dist, int(cnt))
 }
 
-// SearchVectors is SearchVector for many queries in one device search (>= 384 queries take the MFMA sweep).  Queries whose
+// SearchVectors is SearchVector for many queries in one device search (>= 768 queries take the MFMA sweep).  Queries whose
 // length is not the index's dimension get an empty result, like SearchVector.
 func (b *BruteforceHIP) SearchVectors(qs [][]float32, k int, prune0 bool) [][]lo.Tuple2[int, float32] {
 	b.mu.Lock()

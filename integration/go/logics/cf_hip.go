@@ -64,7 +64,7 @@ func (items *MatrixFactorizationItems) Search(v []float32, n int) []cache.Score 
 	})
 }
 
-// SearchBulk answers many users in ONE device search (gorse_topk_search_vector with nq queries: >= 384 of them run on the
+// SearchBulk answers many users in ONE device search (gorse_topk_search_vector with nq queries: >= 768 of them run on the
 // MFMA sweep): what the worker's per-user loop (worker/pipeline.go:403-448) becomes, see worker/pipeline_hip.go.
 func (items *MatrixFactorizationItems) SearchBulk(vs [][]float32, n int) [][]cache.Score {
 	res := items.index.SearchVectors(vs, n, false)
