@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
 int g_als_long_row = 4096;  // rows longer than this are cut into chunks (test hook: gorse_hip_test_set_als_plan)
 int g_als_chunk = 4096;     // feedback entries per chunk of a long row
 int g_als_path = 0;         // 0 auto (Gram form for d <= 64), 1 force the residual sweep, 2 force the Gram form
+int g_als_phased = 0;       // als_row_kernel: the waves of a workgroup accumulate together and solve together (probe: path | 4)
 constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
 constexpr int kAlsWaves = 4;        // waves per workgroup of the chunk kernels
 constexpr int kAlsRowWaves = 8;     // waves per workgroup of als_row_kernel: ONE workgroup per CU (2 waves per SIMD) so that its LDS
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
                                                                  const float *__restrict__ S,
                                                                  const int32_t *__restrict__ rows, int64_t n_rows, int d,
                                                                  float w, float reg, const float *__restrict__ zeros,
-                                                                 unsigned long long *prof) {
+                                                                 unsigned long long *prof, int phased) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // probe only (prof != null): s_memtime ticks per wave in [0] Gram accumulation, [1] M to LDS, [2] solve; [3] rows,
@@ -432,7 +433,16 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         n = (int)(ptr[u + 1] - beg);
         first_indices(beg, n, idx0, idx1);
     }
-    for (int64_t t = wave; t < n_rows; t += nwaves) {
+    // phased: the eight waves of the workgroup accumulate together and solve together (a barrier in between and one after): a
+    // solving wave then never shares its SIMD with a wave that streams 64-cycle fp32 MFMAs.  Every wave runs the same number of
+    // iterations; one without a row of its own (the tail) only keeps the barriers.
+    const int64_t t_end = phased ? (n_rows + nwaves - 1) / nwaves * nwaves : n_rows;
+    for (int64_t t = wave; t < t_end; t += nwaves) {
+        if (t >= n_rows) {
+            __syncthreads();
+            __syncthreads();
+            continue;
+        }
         const int64_t u_next = rows[t + nwaves < n_rows ? t + nwaves : t];
         GramAcc<NB> g;
         unsigned long long t0 = 0;
@@ -472,6 +482,7 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         const int n_next = (int)(end_next - beg_next);
         int idx0_next, idx1_next;
         first_indices(beg_next, n_next, idx0_next, idx1_next);
+        if (phased) __syncthreads();
         __builtin_amdgcn_s_setprio(3);
         als_solve_row<32 * NB, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         __builtin_amdgcn_s_setprio(0);
@@ -481,6 +492,7 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
             c_rows++;
             c_ent += n;
         }
+        if (phased) __syncthreads();
         u = u_next, beg = beg_next, n = n_next, idx0 = idx0_next, idx1 = idx1_next;
     }
     if (prof && lane == 0) {
@@ -622,12 +634,12 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
             als_row_kernel<1><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side));
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased);
         } else {
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
             als_row_kernel<2><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side));
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased);
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }
@@ -773,7 +785,10 @@ extern "C" int32_t gorse_mf_rows_import(gorse_mf *h, int32_t side, int64_t begin
     return GORSE_OK;
 }
 
-extern "C" void gorse_hip_test_set_als_path(int32_t path) { g_als_path = path; }
+extern "C" void gorse_hip_test_set_als_path(int32_t path) {
+    g_als_path = path & 3;
+    g_als_phased = (path & 4) != 0;
+}
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
 extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");

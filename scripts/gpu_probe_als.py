@@ -48,8 +48,9 @@ def run(name, U, I, nnz, d, paths, reps=3):
     capi.lib().gorse_hip_test_set_als_path(0)
 
 
-def prof(name, U, I, nnz, d):
+def prof(name, U, I, nnz, d, path=0):
     """phase counters of als_row_kernel (s_memtime) on one epoch"""
+    capi.lib().gorse_hip_test_set_als_path(path)
     uptr, uidx, iptr, iidx = synth.s_als(U, I, nnz, 45)
     P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 1)
     mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx)
@@ -76,6 +77,12 @@ def prof(name, U, I, nnz, d):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "phased":  # accumulate / solve in lockstep per workgroup (path | 4) against free-running
+        prof("C5 d=64 free-running", 500_000, 100_000, 50_000_000, 64, 0)
+        prof("C5 d=64 phased", 500_000, 100_000, 50_000_000, 64, 4)
+        run("C5 full d=64", 500_000, 100_000, 50_000_000, 64, (0, 4), reps=3)
+        capi.lib().gorse_hip_test_set_als_path(0)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "prof":
         prof("C5 d=64", 500_000, 100_000, 50_000_000, 64)
         prof("C5 shard d=16", 125_000, 100_000, 12_500_000, 16)
