@@ -331,28 +331,33 @@ __device__ __forceinline__ void gram_store_sums(const GramAcc<NB> &g, int d, int
 // cycles per step, latency bound; profiles/r01_n_probe_als_prof.txt.)
 //   FORM: mcol[i] = (1 - w) * G[i][lane] + w * S[i][lane] from the raw Gram in LDS and S in global memory (L1-resident);
 //   !FORM: sM already holds M.
-template <int DMAX, bool FORM>
+//   FULL: d == DMAX is known at compile time -- no bound checks, and the step loop is straight-line code.
+// Every load of the set-up is unconditional (clamped index, value masked afterwards): a load inside `if (i < d && lane < d)`
+// becomes its own exec-masked region that waits for its own LDS round trip -- 64 of them in a row cost 11.7K of the solve's
+// 29K cycles per row (profiles/r02_x_probe_als_phased.txt, which also shows that the sibling wave's MFMAs are NOT what slows
+// the solve: it takes as long when all eight waves of the workgroup solve together).
+template <int DMAX, bool FORM, bool FULL = false>
 __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss,
                                               const float *__restrict__ S, int d, float one_w, float w, float reg,
                                               int lane, unsigned long long *c_load = nullptr) {
     unsigned long long t_in = 0;
     if (c_load) t_in = __builtin_amdgcn_s_memtime();
+    if (FULL) d = DMAX;
     float mcol[DMAX];
     if (FORM) {  // an opaque zero offset per call: keeps the 64 loads of S inside the row loop instead of 64 registers
-        int z;   // hoisted across the whole kernel (they are L1 hits; the registers are needed by the accumulation)
+        int z;   // hoisted across the whole kernel (they are LDS / L1 hits; the registers are needed by the accumulation)
         asm volatile("s_mov_b32 %0, 0" : "=s"(z));
         S += z;
     }
+    const bool lane_in = FULL || lane < d;
+    const int lane_c = FULL ? lane : min(lane, d - 1);
 #pragma unroll
     for (int i0 = 0; i0 < DMAX; i0 += 16) {  // 16 columns' worth of loads in flight at a time (register pressure)
 #pragma unroll
         for (int i = i0; i < i0 + 16; i++) {
-            float m = 0.0f;
-            if (i < d && lane < d) {
-                m = sM[i * kAlsDP + lane];
-                if (FORM) m = one_w * m + w * S[i * d + lane];
-            }
-            mcol[i] = m;
+            float m = sM[i * kAlsDP + lane];  // sM is 64 x kAlsDP and zero past d
+            if (FORM) m = one_w * m + w * S[(FULL ? i : min(i, d - 1)) * d + lane_c];
+            mcol[i] = (FULL || (i < d && lane_in)) ? m : 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -364,32 +369,31 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     // accumulation, profiles/r01_p_probe_als_prof.txt).  Same recurrence, products summed in a different order; agreement
     // with the float64 recurrence 6e-7 of the row's scale on random systems (well inside the 1e-4 bar).
     if (c_load) *c_load += __builtin_amdgcn_s_memtime() + (__float_as_int(mcol[DMAX - 1]) & 0) - t_in;  // probe: columns of M in registers
-    const float p0 = lane < d ? a[lane] : 0.0f;
-    const float sv = lane < d ? ss[lane] : 0.0f;
-    float diag = 0.0f;
-    if (lane < d) {
-        diag = sM[lane * kAlsDP + lane];
-        if (FORM) diag = one_w * diag + w * S[lane * d + lane];
-    }
+    const float p0_raw = a[lane_c], sv_raw = ss[lane_c];
+    float diag = sM[lane_c * kAlsDP + lane_c];
+    if (FORM) diag = one_w * diag + w * S[lane_c * d + lane_c];
+    const float p0 = lane_in ? p0_raw : 0.0f;
+    const float sv = lane_in ? sv_raw : 0.0f;
+    if (!lane_in) diag = 0.0f;
     const float inv = __builtin_amdgcn_rcpf(diag + reg);  // 1 ulp; the parity bar of ALS is 1e-4 relative
     const float base = (sv + p0 * diag) * inv;
     float y = 0.0f;
 #pragma unroll
     for (int f = 0; f < DMAX; f++)
-        if (f < d) y = fmaf(mcol[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f)), y);
+        if (FULL || f < d) y = fmaf(mcol[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f)), y);
     float p = p0;
 #pragma unroll
     for (int f = 0; f < DMAX; f++) {
-        if (f < d) {  // uniform; no break, so that the loop unrolls and mcol[f] is a register
+        if (FULL || f < d) {  // uniform; no break, so that the loop unrolls and mcol[f] is a register
             const float yf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), f));
             const float nf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(base), f)) -
                              yf * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), f));
             const float delta = nf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f));
             y = fmaf(delta, mcol[f], y);
-            if (lane == f) p = nf;
+            p = lane == f ? nf : p;
         }
     }
-    if (lane < d) a[lane] = p;
+    if (lane_in) a[lane] = p;
 }
 
 // A: side being solved, B: the other side, S: d x d Gram of B over rows with feedback
@@ -484,7 +488,10 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         first_indices(beg_next, n_next, idx0_next, idx1_next);
         if (phased) __syncthreads();
         __builtin_amdgcn_s_setprio(3);
-        als_solve_row<32 * NB, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+        if (d == 32 * NB)
+            als_solve_row<32 * NB, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+        else
+            als_solve_row<32 * NB, true, false>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
         if (prof) {
