@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 2: the ALS solve with unconditional set-up loads and straight-line steps.
+# Round 2: the ALS Gram accumulation with three gather stages in flight.
 set -u
-TAG=${1:-r02_y}
+TAG=${1:-r02_z}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
