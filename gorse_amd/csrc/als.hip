@@ -282,23 +282,17 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
                         fr[j][bi], fr[j][bj], g.t[GramAcc<NB>::tile(bi, bj)], 0, 0, 0);
         }
     };
-    // A ring of four stages: the gathers of stages s + 1 .. s + 3 are in flight while the MFMAs of stage s run.  (With one stage
-    // ahead every stage waited out the rest of a gather's latency: ~28K cycles per 100-entry row for 10.7K cycles of MFMAs,
-    // profiles/r02_y_probe_als_prof.txt.)  Stages past the end are all-zero gathers that nobody multiplies: every load stays
-    // unconditional, the MFMAs of a stage that does not exist are skipped.
-    float f0[kAlsPairs][NB], f1[kAlsPairs][NB], f2[kAlsPairs][NB], f3[kAlsPairs][NB];
+    // ping-pong: the gathers of stage s + 1 are in flight while the MFMAs of stage s run.  Stages past the
+    // end are all-zero gathers (at most two per row), which keeps every load unconditional.  (A ring of four stages -- three
+    // in flight -- changed nothing: 35.6K against 33.6K cycles of accumulation per 100-entry row, profiles/r02_z_probe_als_prof.txt;
+    // the accumulation does not wait for its gathers.)
+    float f0[kAlsPairs][NB], f1[kAlsPairs][NB];
     issue(f0);
-    issue(f1);
-    issue(f2);
-    for (int s = 0; s < nstages; s += 4) {
-        issue(f3);
+    for (int s = 0; s < nstages; s += 2) {
+        issue(f1);
         consume(f0);
         issue(f0);
-        if (s + 1 < nstages) consume(f1);
-        issue(f1);
-        if (s + 2 < nstages) consume(f2);
-        issue(f2);
-        if (s + 3 < nstages) consume(f3);
+        consume(f1);
     }
 }
 
