@@ -326,7 +326,9 @@ __device__ inline void touch(uint16_t *touched, int tcap, GroupState &gs, bool a
 // and the lanes above lim go round again.  Without sharing: one round.
 // Rows whose accumulator was +0 before the add go on the touched list (a sum that returns to zero and is reached again is
 // listed twice; the read-back takes it once).
-template <bool ATOMIC, bool TRACE>
+// DEPTH = the longest list of the chunk, rounded up to 2, 4 or kGather: the loops below run over DEPTH postings per lane, and a
+// chunk of the tail groups (a few lists with one or two postings each) pays for 2, not for 8.
+template <bool ATOMIC, bool TRACE, int DEPTH>
 __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8 *tag, uint16_t *touched, int tcap, int lane,
                                      GroupState &gs, Tracer<TRACE> &tr) {
     const uint32_t len = v.e - v.s;
@@ -335,11 +337,11 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
     for (;;) {
         tr.add(&Trace::rounds);
 #pragma unroll
-        for (int j = 0; j < kGather; j++)
+        for (int j = 0; j < DEPTH; j++)
             if (pending && (uint32_t)j < len) tag[v.P[j].loc] = (uint8_t)lane;
         bool lost = false;
 #pragma unroll
-        for (int j = 0; j < kGather; j++) {
+        for (int j = 0; j < DEPTH; j++) {
             uint32_t stamp = (uint32_t)lane;
             if (pending && (uint32_t)j < len) stamp = tag[v.P[j].loc];
             lost = lost | (stamp != (uint32_t)lane);
@@ -350,14 +352,14 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
         for (int pass = 0; pass < 2; pass++) {  // the lanes below lim together, then lane lim alone
             if (pass == 1 && !ml) break;
             const bool go = pending && (pass == 0 ? lane < lim : lane == lim);
-            float old[kGather];
+            float old[DEPTH];
 #pragma unroll
-            for (int j = 0; j < kGather; j++) {
+            for (int j = 0; j < DEPTH; j++) {
                 old[j] = 1.0f;
                 if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, v.P[j].loc, __fmul_rn(v.qv, v.P[j].val));
             }
 #pragma unroll
-            for (int j = 0; j < kGather; j++) {
+            for (int j = 0; j < DEPTH; j++) {
                 const unsigned long long m = __ballot(go && (uint32_t)j < len);
                 if (!m) break;
                 gs.walked += (uint32_t)__popcll(m);
@@ -563,9 +565,14 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 if (__ballot(len > 0)) {
                     const unsigned long long c0 = tr.now();
                     const bool once = !__ballot(len > (uint32_t)kGather);
-                    if (once)
-                        apply_at_once<ATOMIC, TRACE>(v0, acc, tag, touched, tcap, lane, gs, tr);
-                    else
+                    if (once) {
+                        if (!__ballot(len > 2u))
+                            apply_at_once<ATOMIC, TRACE, 2>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                        else if (!__ballot(len > 4u))
+                            apply_at_once<ATOMIC, TRACE, 4>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                        else
+                            apply_at_once<ATOMIC, TRACE, kGather>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                    } else
                         apply_flattened<ATOMIC, TRACE>(post, v0, acc, tag, touched, tcap, lane, gs, tr);
                     tr.add(once ? &Trace::ticks_once : &Trace::ticks_flat, (uint32_t)(tr.now() - c0));
                 }
