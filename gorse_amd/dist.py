@@ -146,8 +146,18 @@ class LibComm:
     def __init__(self, rank, world, device, share, always=False):
         from . import capi
         self.capi = capi
-        uid = capi.Comm.unique_id() if rank == 0 else bytes(capi.COMM_ID_BYTES)
+        # Every rank reaches share() whatever happens on rank 0 (an id of zeros = "rank 0 has none"): a rank that raised before
+        # the exchange would leave the others waiting in it
+        none, err = bytes(capi.COMM_ID_BYTES), None
+        uid = none
+        if rank == 0:
+            try:
+                uid = capi.Comm.unique_id()
+            except Exception as e:  # e.g. librccl.so cannot be loaded
+                err = e
         uid = share(uid)
+        if uid == none:
+            raise err or RuntimeError("rank 0 could not draw an RCCL unique id")
         self.comm = capi.Comm(uid, world, rank, device)
         self.world, self.rank, self.always = world, rank, always
 
