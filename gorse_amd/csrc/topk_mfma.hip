@@ -45,6 +45,17 @@ constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the mai
 constexpr int sweep_waves(bool hist, int kp) { return !hist ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
 constexpr int kWaves = kWavesMain;
 constexpr int kThreads = kWaves * 64;
+// LDS of a sweep workgroup: NBUF tile buffers (+ their row scales and block bounds), five words per query, the candidate path's
+// staging area (VOTE only), the tile counters.  Three buffers where they fit next to the rest in 144 KB (the main sweep up to
+// KP = 8 with 128-row tiles), else two; the history sweep keeps two (its small workgroups share a CU).
+constexpr size_t sweep_tile_bytes(int kp, int rb) { return (size_t)32 * rb * (kp * 32 + 16) + (size_t)32 * rb * 4 + 2 * kMaxRB * 4; }
+constexpr size_t sweep_fixed_bytes(int bq, int wv, bool vote) { return (size_t)5 * bq * 4 + (vote ? (size_t)wv * 64 * 16 * 4 : 0) + 64; }
+constexpr int sweep_bufs(int kp, int rb, int bq, int wv, bool vote, bool hist) {
+    return !hist && 3 * sweep_tile_bytes(kp, rb) + sweep_fixed_bytes(bq, wv, vote) <= (size_t)144 * 1024 ? 3 : 2;
+}
+constexpr size_t sweep_lds_bytes(int kp, int rb, int bq, int wv, bool vote, bool hist) {
+    return sweep_bufs(kp, rb, bq, wv, vote, hist) * sweep_tile_bytes(kp, rb) + sweep_fixed_bytes(bq, wv, vote);
+}
 constexpr int64_t kMinSweepQueries = 768;  // fewer queries in a call take the scan (see topk_mfma_usable)
 constexpr int kCap = 512;      // candidate-list capacity per query
 constexpr int kEPL = kCap / 64;
@@ -204,15 +215,19 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     constexpr int BQ = QW * kWaves;
     constexpr int CHUNKS = kTR * KP * 2;  // 16-byte pieces per tile
     constexpr int CPT = (CHUNKS + kThreads - 1) / kThreads;
+    constexpr int NBUF = sweep_bufs(KP, RB, BQ, kWaves, VOTE, HIST);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_tile = smem;
-    float *s_rs = reinterpret_cast<float *>(smem + 2 * kTR * ROWB);
-    float *s_bmm = s_rs + 2 * kTR;  // per buffer and 32-row block: (min, max) row scale
-    int *s_cnt = reinterpret_cast<int *>(s_bmm + 2 * 2 * kMaxRB);  // 2 per query: the interleaved sub-list lengths
+    float *s_rs = reinterpret_cast<float *>(smem + (size_t)NBUF * kTR * ROWB);
+    float *s_bmm = s_rs + NBUF * kTR;  // per buffer and 32-row block: (min, max) row scale
+    int *s_cnt = reinterpret_cast<int *>(s_bmm + NBUF * 2 * kMaxRB);  // 2 per query: the interleaved sub-list lengths
     float *s_f = reinterpret_cast<float *>(s_cnt + 2 * BQ);
     float *s_mg = s_f + BQ;
     int *s_hc = reinterpret_cast<int *>(s_mg + BQ);
-    float *s_stage = reinterpret_cast<float *>(s_hc + BQ);  // 16 scores per thread: where the candidate path parks a block
+    // tile counters: s_sync[b] = waves that have stored their part of a tile into buffer b (ever), s_sync[NBUF + b] = waves that
+    // have finished reading one
+    int *s_sync = s_hc + BQ;
+    float *s_stage = reinterpret_cast<float *>(s_sync + 16);  // VOTE: 16 scores per thread, where the candidate path parks a block
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t wgq0 = (int64_t)blockIdx.x * BQ;
@@ -224,6 +239,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         s_f[t] = q < p.nq ? (p.f0 ? p.f0[q] : -__builtin_inff()) : __builtin_inff();
         s_mg[t] = q < p.nq ? p.qmargin[q] : 0.0f;
     }
+    if (tid < 2 * NBUF) s_sync[tid] = 0;
     // query operands: resident in registers for the whole sweep
     bf16x8 bfrag[NCB][KP];
 #pragma unroll
@@ -279,11 +295,24 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         }
     };
 
+    // The waves of a workgroup share every tile but do not march in step: a wave that takes the candidate path (~2200 cycles)
+    // used to hold the other seven at the tile's barrier -- 27 % of the sweep (profiles/r02_f_probe_topk_prof.txt).  With NBUF
+    // buffers and two counters per buffer a wave only waits for what it needs: tile t complete in its buffer before it
+    // multiplies it, tile t + 1 - NBUF read by everyone before tile t + 1 overwrites it.
+    auto arrive = [&](int *ctr) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's LDS traffic has completed
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_for = [&](int *ctr, int target) {
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     const int64_t NT = (p.N + stride_rows - 1) / stride_rows;
+    __syncthreads();  // the per-query words and the counters are initialised
     load_tile(0);
     store_tile(0);
+    arrive(&s_sync[0]);
     if (NT > 1) load_tile(1);
-    __syncthreads();
 
     float fth[NCB];
     int cnt[NCB];  // length of this lane's sub-list of its query (mirrored in s_cnt around a compaction)
@@ -293,14 +322,30 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         cnt[cb] = 0;
     }
 
+    int buf = 0, round = 0;  // tile t lives in buffer t % NBUF and is that buffer's (t / NBUF)-th tile
     for (int64_t t = 0; t < NT; t++) {
-        const int buf = (int)(t & 1);
         if (PROF) ts = __builtin_amdgcn_s_memtime();
-        if (t + 1 < NT) store_tile(buf ^ 1);  // rows of tile t+1 (loaded during tile t-1)
+        const int nb = buf + 1 == NBUF ? 0 : buf + 1;
+        if (t + 1 < NT) {  // rows of tile t + 1 (loaded during tile t - 1) into the buffer tile t + 1 - NBUF was read from
+            if (t + 1 >= NBUF) {
+                unsigned long long tw = 0;
+                if (PROF) tw = __builtin_amdgcn_s_memtime();
+                wait_for(&s_sync[NBUF + nb], kWaves * (round + (nb == 0 ? 1 : 0)));  // = kWaves * ((t + 1) / NBUF)
+                if (PROF) c_bar += __builtin_amdgcn_s_memtime() - tw;
+            }
+            store_tile(nb);
+            arrive(&s_sync[nb]);
+        }
         if (t + 2 < NT) load_tile(t + 2);
         if (PROF) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             c_store += now - ts;
+            ts = now;
+        }
+        wait_for(&s_sync[buf], kWaves * (round + 1));
+        if (PROF) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            c_bar += now - ts;
             ts = now;
         }
         const unsigned char *tb = s_tile + (size_t)buf * kTR * ROWB;
@@ -466,8 +511,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
             c_comp += now - ts;
             ts = now;
         }
-        __syncthreads();
-        if (PROF) c_bar += __builtin_amdgcn_s_memtime() - ts;
+        arrive(&s_sync[NBUF + buf]);  // this wave has read tile t
+        buf = nb;
+        if (nb == 0) round++;
     }
     if (PROF && lane == 0) {
         atomicAdd(p.prof + 0, c_store);
@@ -1040,9 +1086,7 @@ template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool VOTE = false>
 int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int WV = sweep_waves(HIST, KP);
     constexpr int BQ = 32 * NCB * WV;
-    constexpr int ROWB = KP * 32 + 16;
-    constexpr int TR = 32 * RB;
-    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4 + (size_t)WV * 64 * 16 * 4;
+    const size_t lds = sweep_lds_bytes(KP, RB, BQ, WV, VOTE, HIST);
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1053,8 +1097,8 @@ int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
 
 template <int RB, bool VOTE>
 int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {
-    constexpr int BQ = 32 * 2 * kWaves, ROWB = 8 * 32 + 16, TR = 32 * RB;
-    const size_t lds = (size_t)2 * TR * ROWB + 2 * TR * 4 + 2 * 2 * kMaxRB * 4 + (size_t)5 * BQ * 4 + (size_t)kWaves * 64 * 16 * 4;
+    constexpr int BQ = 32 * 2 * kWaves;
+    const size_t lds = sweep_lds_bytes(8, RB, BQ, kWaves, VOTE, false);
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, true, false, RB, true, VOTE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     topk_sweep_kernel<8, 2, true, false, RB, true, VOTE><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
