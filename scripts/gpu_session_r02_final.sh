@@ -29,6 +29,7 @@ timeout 500 rocprofv3 --kernel-trace --stats -d "$OUT/prof_${TAG}" -o bench -- p
 DB=$(find "$OUT/prof_${TAG}" -name '*_results.db' | head -1)
 python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_kernel_stats.txt" 2>&1
 head -24 "$OUT/${TAG}_kernel_stats.txt" | cut -c1-170
+if [ "${PMC_BPR:-1}" = "1" ]; then
 for W in ml1m c3; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout 150 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_${TAG}_${W}_$C" -o bench -- python "$ROOT/bench.py" --workload $W --steps 4 --warmup 1 --no-cpu-baseline --no-topk --no-extra \
@@ -40,6 +41,7 @@ for W in ml1m c3; do
       "$(find "$OUT/pmc_${TAG}_${W}_WRITE_SIZE" -name '*_results.db' | head -1)" "$OUT/${TAG}_traffic_${W}.json"
   cat "$OUT/${TAG}_traffic_${W}.json" | head -20
 done
+fi
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
     -d "$OUT/pmc_${TAG}_topk_SQ" -o bench -- python "$ROOT/bench.py" --workload topk --topk-steps 1 --no-cpu-baseline > /dev/null 2> "$OUT/${TAG}_pmc_topk_SQ.err"
 DB=$(find "$OUT/pmc_${TAG}_topk_SQ" -name '*_results.db' | head -1)
