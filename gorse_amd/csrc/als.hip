@@ -351,15 +351,17 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
         asm volatile("s_mov_b32 %0, 0" : "=s"(z));
         S += z;
     }
-    const bool lane_in = FULL || lane < d;
-    const int lane_c = FULL ? lane : min(lane, d - 1);
+    // lanes past d hold nothing (DMAX = 32 leaves half of the wave idle): masked even in the FULL form, where the test is a
+    // compile-time fact for DMAX = 64
+    const bool lane_in = (FULL && DMAX >= 64) || lane < d;
+    const int lane_c = (FULL && DMAX >= 64) ? lane : min(lane, d - 1);
 #pragma unroll
     for (int i0 = 0; i0 < DMAX; i0 += 16) {  // 16 columns' worth of loads in flight at a time (register pressure)
 #pragma unroll
         for (int i = i0; i < i0 + 16; i++) {
             float m = sM[i * kAlsDP + lane];  // sM is 64 x kAlsDP and zero past d
             if (FORM) m = one_w * m + w * S[(FULL ? i : min(i, d - 1)) * d + lane_c];
-            mcol[i] = (FULL || (i < d && lane_in)) ? m : 0.0f;
+            mcol[i] = ((FULL || i < d) && lane_in) ? m : 0.0f;
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -241,14 +241,15 @@ __global__ __launch_bounds__(kSelThreads) void select_fast_kernel(const float *_
 
 constexpr int64_t kDistBudget = (int64_t)1 << 28;  // floats in the distance slab (1 GiB)
 int g_scan_literal_only = 0;  // test hook: every query of the scan through the literal heap kernel
+constexpr int64_t kMinRerouteQueries = (int64_t)1 << 40;  // "enough queries": asks topk_mfma_usable about the index and k only
 
 }  // namespace
 
 namespace gorse {
 
 // queries already on the device in h->qbuf (nq x d, fp32) [+ h->qnorm]; qidx_dev = exclude list or null
-int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int k, int prune0, int32_t *idx_out,
-                     float *dist_out, int32_t *cnt_out) {
+int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, const int64_t *qidx_host, int k, int prune0,
+                        int32_t *idx_out, float *dist_out, int32_t *cnt_out, bool reroute) {
     const int d = h->d;
     GORSE_TRY(h->dist.ensure((size_t)nq * h->N));
     GORSE_TRY(h->heap_v.ensure((size_t)nq * 2 * (k + 1)));
@@ -265,22 +266,60 @@ int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int 
     tok = h->prof.begin(GORSE_PROF_TOPK_RESCORE, h->stream);
     const uint8_t *mask = h->has_mask ? h->mask.p : nullptr;
     int32_t *literal = nullptr;
-    if (!(g_scan_literal_only)) {
+    // The queries the fast selection leaves (ties among the k + 1 smallest distances, NaN): the literal heap kernel is one
+    // thread per query over all N rows -- 3.3 s for a million rows, however few queries there are -- so where the MFMA path
+    // can take them (its history sweep + heap replay answer a tie query in tens of milliseconds) they go there.
+    reroute = reroute && !g_scan_literal_only && topk_mfma_usable(h, kMinRerouteQueries, k);
+    if (!g_scan_literal_only) {
         GORSE_TRY(h->scan_literal.ensure((size_t)nq));
         literal = h->scan_literal.p;
         select_fast_kernel<<<dim3((unsigned)nq), dim3(kSelThreads), 0, h->stream>>>(h->dist.p, qidx_dev, h->N, k, prune0, h->out_idx.p,
                                                                                  h->out_dist.p, h->out_cnt.p, mask, literal);
         GORSE_HIP_CHECK(hipGetLastError());
     }
-    select_kernel<<<dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, h->stream>>>(h->dist.p, qidx_dev, nq, h->N, k, prune0,
-                                                                              h->heap_v.p, h->heap_w.p, h->out_idx.p,
-                                                                              h->out_dist.p, h->out_cnt.p, mask, literal);
-    GORSE_HIP_CHECK(hipGetLastError());
+    if (!reroute) {
+        select_kernel<<<dim3((unsigned)ceil_div(nq, 64)), dim3(64), 0, h->stream>>>(h->dist.p, qidx_dev, nq, h->N, k, prune0,
+                                                                                  h->heap_v.p, h->heap_w.p, h->out_idx.p,
+                                                                                  h->out_dist.p, h->out_cnt.p, mask, literal);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
     h->prof.end(tok, h->stream);
+    std::vector<int32_t> flags;
+    if (reroute) {
+        flags.resize((size_t)nq);
+        GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), literal, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
+    }
     if (idx_out) GORSE_HIP_CHECK(hipMemcpyAsync(idx_out, h->out_idx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
     if (dist_out) GORSE_HIP_CHECK(hipMemcpyAsync(dist_out, h->out_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
     if (cnt_out) GORSE_HIP_CHECK(hipMemcpyAsync(cnt_out, h->out_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, h->stream));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (!reroute) return GORSE_OK;
+    std::vector<int64_t> todo;
+    for (int64_t t = 0; t < nq; t++)
+        if (flags[(size_t)t]) todo.push_back(t);
+    if (todo.empty()) return GORSE_OK;
+    const size_t nf = todo.size();
+    std::vector<int64_t> ids(nf);
+    DevBuf<float> qf;
+    if (qidx_host) {
+        for (size_t r = 0; r < nf; r++) ids[r] = qidx_host[todo[r]];
+    } else {  // their vectors, packed
+        GORSE_TRY(qf.alloc(nf * (size_t)d));
+        for (size_t r = 0; r < nf; r++)
+            GORSE_HIP_CHECK(hipMemcpyAsync(qf.p + r * d, h->qbuf.p + todo[r] * d, (size_t)d * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    std::vector<int32_t> ti(nf * (size_t)k), tc(nf);
+    std::vector<float> td(nf * (size_t)k);
+    const int64_t keep_fallback = h->n_fallback;
+    GORSE_TRY(topk_mfma_search(h, qidx_host ? ids.data() : nullptr, -1, qidx_host ? nullptr : qf.p, (int64_t)nf, k, prune0, ti.data(),
+                               td.data(), tc.data()));
+    h->n_fallback += keep_fallback;
+    for (size_t r = 0; r < nf; r++) {
+        const int64_t t = todo[r];
+        if (idx_out) memcpy(idx_out + t * k, ti.data() + r * k, (size_t)k * 4);
+        if (dist_out) memcpy(dist_out + t * k, td.data() + r * k, (size_t)k * 4);
+        if (cnt_out) cnt_out[t] = tc[r];
+    }
     return GORSE_OK;
 }
 
@@ -383,7 +422,7 @@ extern "C" int32_t gorse_topk_search_index(gorse_topk *h, const int64_t *q, int6
         gather_rows_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->X.p, h->norm2.p, h->qidx.p, h->d, h->qbuf.p,
                                                                          h->qnorm.p);
         GORSE_HIP_CHECK(hipGetLastError());
-        GORSE_TRY(topk_scan_block(h, m, h->qidx.p, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
+        GORSE_TRY(topk_scan_block(h, m, h->qidx.p, q + q0, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
                                dist_out ? dist_out + q0 * k : nullptr, count_out ? count_out + q0 : nullptr));
     }
     return GORSE_OK;
@@ -428,7 +467,7 @@ extern "C" int32_t gorse_topk_search_vector(gorse_topk *h, const void *qv, int64
                                            hipMemcpyHostToDevice, h->stream));
         }
         if (h->metric == GORSE_METRIC_COSINE) GORSE_TRY(topk_compute_norms(h, h->qbuf.p, m, h->qnorm.p));
-        GORSE_TRY(topk_scan_block(h, m, nullptr, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
+        GORSE_TRY(topk_scan_block(h, m, nullptr, nullptr, k, prune0, idx_out ? idx_out + q0 * k : nullptr,
                                dist_out ? dist_out + q0 * k : nullptr, count_out ? count_out + q0 : nullptr));
     }
     return GORSE_OK;
@@ -456,7 +495,7 @@ extern "C" int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t 
         gather_rows_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->X.p, h->norm2.p, h->qidx.p, h->d, h->qbuf.p,
                                                                          h->qnorm.p);
         GORSE_HIP_CHECK(hipGetLastError());
-        GORSE_TRY(topk_scan_block(h, m, h->qidx.p, k, 0, idx_out ? idx_out + q0 * k : nullptr,
+        GORSE_TRY(topk_scan_block(h, m, h->qidx.p, ids.data(), k, 0, idx_out ? idx_out + q0 * k : nullptr,
                                dist_out ? dist_out + q0 * k : nullptr, nullptr));
     }
     return GORSE_OK;

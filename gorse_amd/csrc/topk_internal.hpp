@@ -112,10 +112,12 @@ __device__ __forceinline__ float euclid_any_lds(int metric, const float *a, cons
 
 // topk.hip
 int32_t topk_compute_norms(gorse_topk *h, const float *V, int64_t n, float *out);
-// path A on queries whose fp32 rows sit in h->qbuf (nq x d) [+ h->qnorm]; qidx_dev = exclusion ids or null.
-// Results land in h->out_idx / out_dist / out_cnt and, where given, in the host arrays.
-int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, int k, int prune0, int32_t *idx_out,
-                        float *dist_out, int32_t *cnt_out);
+// path A on queries whose fp32 rows sit in h->qbuf (nq x d) [+ h->qnorm]; qidx_dev = exclusion ids or null (qidx_host: the same
+// ids on the host).  Results land in h->out_idx / out_dist / out_cnt and, where given, in the host arrays.  Queries whose answer
+// depends on the heap's history (ties among the k + 1 smallest distances, NaN) go to the MFMA path's tie replay where that is
+// usable and `reroute` allows it, else to the literal heap kernel.
+int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, const int64_t *qidx_host, int k, int prune0,
+                        int32_t *idx_out, float *dist_out, int32_t *cnt_out, bool reroute = true);
 int64_t topk_scan_block_queries(const gorse_topk *h);
 // topk_mfma.hip
 int32_t topk_mfma_prepare(gorse_topk *h);  // at create: operands, scales, error bound

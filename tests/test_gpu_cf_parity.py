@@ -428,7 +428,7 @@ def als_paths():
 # path 1 = the reference's residual recurrence (als_sweep_kernel), path 2 = the Gram form on the fp32 MFMA
 # (als_row_kernel / als_chunk_kernel + als_long_solve_kernel); 0 = what the product picks
 @pytest.mark.parametrize("path", [0, 1, 2])
-@pytest.mark.parametrize("d", [16, 64, 24, 40, 7])
+@pytest.mark.parametrize("d", [16, 64, 32, 24, 40, 7])
 def test_als_epoch_parity(oracle, small, d, path, als_paths):
     # ALS is deterministic w.r.t. Jobs: <= 1e-4 relative after 3 epochs
     capi.lib().gorse_hip_test_set_als_path(path)
@@ -500,7 +500,7 @@ def test_als_rows_without_feedback(oracle, als_paths):
         assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
-@pytest.mark.parametrize("path,d", [(2, 64), (2, 16), (1, 24), (1, 96)])
+@pytest.mark.parametrize("path,d", [(2, 64), (2, 32), (2, 16), (1, 24), (1, 96)])
 def test_als_row_sharded_equals_the_full_epoch(small, path, d, als_paths):
     # three "ranks" on one GPU, each a handle restricted to its row ranges (gorse_als_set_ranges);
     # after every half-sweep the row blocks travel through device buffers (gorse_mf_rows_export / _import), the way
