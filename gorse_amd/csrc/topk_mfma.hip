@@ -377,13 +377,6 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                     }
             }
             // C layout: lane holds column (= query) lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-            if (p.prio & 4) {  // probe (variant bit 14; wrong results): no epilogue at all -- what the tile loop and its MFMAs cost alone
-                float sink = 0.0f;
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) sink += acc[cb][0] + acc[cb][15];
-                if (sink == 12345.678f) fth[0] = sink;  // keeps the MFMAs alive
-                continue;
-            }
             if (p.prio & 2) __builtin_amdgcn_s_setprio(1);  // probe: the whole epilogue ahead of the sibling's MFMA issue
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
@@ -1327,7 +1320,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.kth = kth;
         sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1, sp.vote = 0;
         // variant bit 11: candidate path at the default priority; bit 13: the whole epilogue at priority 1 (probe)
-        sp.prio = ((g_topk_variant & 2048) ? 0 : 1) | ((g_topk_variant & 8192) ? 2 : 0) | ((g_topk_variant & 16384) ? 4 : 0);
+        sp.prio = ((g_topk_variant & 2048) ? 0 : 1) | ((g_topk_variant & 8192) ? 2 : 0);
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
         // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
         // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members

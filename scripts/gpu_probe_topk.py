@@ -41,15 +41,6 @@ def main():
         run("C4 S-emb bf16 cosine 256K q", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=1)
         run("C4 S-emb bf16 cosine", Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 1_000_000, reps=1)
         return
-    if len(sys.argv) > 1 and sys.argv[1] == "ceiling":  # the tile loop without its epilogue (wrong results): the MFMA loop's own speed
-        for v, label in [(256, "cold start"), (256 | 16384, "cold start, no epilogue (probe)")]:
-            capi.lib().gorse_hip_test_set_topk_variant(v)
-            try:
-                run("C4 256K q: " + label, Xb, capi.METRIC_COSINE, capi.DTYPE_BF16, 100, 0, 262144, reps=2)
-            except Exception as e:  # the stages behind the sweep may reject what a sweep without candidates leaves
-                print("C4 256K q: %s: %r" % (label, e), flush=True)
-        capi.lib().gorse_hip_test_set_topk_variant(0)
-        return
     if len(sys.argv) > 1 and sys.argv[1] == "tiles":  # 128- and 64-row tiles (run once per library build: GORSE_HIP_LIB)
         for v, label in [(2, "128-row tiles"), (1, "64-row tiles")]:
             capi.lib().gorse_hip_test_set_topk_variant(v)
