@@ -312,6 +312,8 @@ def bench_sparse(args, world, rank, local, fence, data=None, steps=None, warmup=
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_posting": 8,
                      "avg_launch_ms": avg_ms, "launches": launches},
     }
+    if world == 1 and N == 200_000 and q1 - q0 == N:  # the C3-shard pass the PMC passes were taken on
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("i2i")
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = sparse_cpu_baseline(ptr, idx, val, k, args.cpu_seconds, sp, q0)
@@ -463,6 +465,8 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
                      "algorithmic_bytes_per_epoch": algo, "avg_launch_ms": per_epoch_ms, "launches": ns,
                      "sweeps_ms_per_epoch": sweep_ms / max(steps, 1), "gram_ms_per_epoch": gram_ms / max(steps, 1)},
     }
+    if world == 1 and sc == 1.0:
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("als")
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = als_cpu_baseline(uptr, uidx, iptr, P0, Q0, w, reg, args.cpu_seconds)
