@@ -286,6 +286,10 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from the work list and `longs`
     h->last_postings = (int64_t)st[0];
     h->last_hits = (int64_t)st[1];
+    // per-call scratch that a handle should not sit on between calls (a collection keeps its handle until it changes)
+    constexpr size_t kKeepBytes = (size_t)256 << 20;
+    if (h->part_keys.n * sizeof(unsigned long long) > kKeepBytes) h->part_keys.release();
+    if (h->dense.n * sizeof(uint2) > kKeepBytes) h->dense.release();
     return GORSE_OK;
 }
 
