@@ -228,6 +228,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             // grid of it would take the register files from the list walk it runs next to
             const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->n_ranges, std::min<int64_t>(slots, 1024)));
             switch (kp) {
+                case 128: sparse::sparse_rows_kernel<128><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
                 case 256: sparse::sparse_rows_kernel<256><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
                 case 512: sparse::sparse_rows_kernel<512><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
                 default: sparse::sparse_rows_kernel<1024><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
@@ -245,6 +246,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         if (!work.empty()) {
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
             switch (kp) {
+                case 128: GORSE_TRY(launch_tiles<128>(a, grid, lds, atomic, h->stream)); break;
                 case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;
                 case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, h->stream)); break;
                 default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, h->stream)); break;
@@ -261,6 +263,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
             const unsigned mg = (unsigned)std::min<size_t>(n_long, 4096);
             switch (kp) {
+                case 128: sparse::sparse_merge_kernel<128><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
                 case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
                 case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
                 default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;

@@ -81,7 +81,7 @@ inline float smallest_magnitude(const float *v, int64_t n) {
 
 // LDS ranking buffer of sparse_tile_kernel: the smallest instantiated KP >= k (0 = k too large)
 inline int pick_kp(int k) {
-    for (int kp = 256; kp <= 1024; kp <<= 1)
+    for (int kp = 128; kp <= 1024; kp <<= 1)  // 128: two more waves per CU than 256 for the k = 100 of the similarity refreshes
         if (k <= kp) return kp;
     return 0;
 }
