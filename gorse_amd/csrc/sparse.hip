@@ -149,7 +149,8 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     constexpr size_t kPartBytes = (size_t)2 << 30;
     constexpr size_t kDenseBytes = (size_t)1 << 30;
     const size_t per_launch = std::max<size_t>(
-        1, std::min(kPartBytes / ((size_t)ng * kp * 8), kDenseBytes / ((size_t)std::max<int64_t>(h->Dc, 1) * sizeof(uint2))));
+        1, std::min({kPartBytes / ((size_t)ng * kp * 8), kDenseBytes / ((size_t)std::max<int64_t>(h->Dc, 1) * sizeof(uint2)),
+                     (size_t)32768}));  // 32768: the heavy queries of a launch are a grid dimension
     auto is_heavy = [&](int32_t t) { return g_sparse_heavy > 0 && q_len_host[t + 1] - q_len_host[t] > g_sparse_heavy; };
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
     TileArgs a;
