@@ -346,18 +346,26 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        {   // row ranges for the heavy queries: blocks of 64 scratch ids (longest rows first: a block costs its first row's length),
-            // closed when they reach 1 / 128 of the total cost -- or the cost of the first block, whichever is larger
-            std::vector<int32_t> starts{0};
+        {   // Row ranges of about equal cost for the heavy queries (sparse_rows_kernel).  Rows come longest first.  A row of more
+            // than 1024 entries is walked by the whole wave, 64 entries per step: cost ~ its length; shorter rows go 64 at a time,
+            // one per lane: a block costs ~ 27 x its first (longest) row's length (16 entries per ~5 us step against 64 entries
+            // per ~0.7 us step).  A range closes when it reaches 1 / 192 of the total -- single long rows become ranges of their own.
             auto len_of = [&](int64_t sid) { const int64_t r = h->order.orig_of[(size_t)sid]; return indptr[r + 1] - indptr[r]; };
-            int64_t total = 0;
-            for (int64_t sid = 0; sid < N; sid += 64) total += len_of(sid) + 1;
-            const int64_t target = std::max<int64_t>(len_of(0) + 1, total / 128);
-            int64_t cost = 0;
-            for (int64_t sid = 0; sid < N; sid += 64) {
-                cost += len_of(sid) + 1;
-                if (cost >= target && sid + 64 < N) {
-                    starts.push_back((int32_t)(sid + 64));
+            constexpr int64_t kLongRow = 1024;  // = sparse_rows_kernel's
+            auto cost_at = [&](int64_t sid, int64_t first) -> double {
+                const int64_t len = len_of(sid);
+                if (len > kLongRow) return (double)len;
+                return (sid - first) % 64 == 0 ? 27.0 * (double)(len + 1) : 0.0;
+            };
+            double total = 0;
+            for (int64_t sid = 0; sid < N; sid++) total += cost_at(sid, 0);
+            const double target = std::max(total / 192.0, 1.0);
+            std::vector<int32_t> starts{0};
+            double cost = 0;
+            for (int64_t sid = 0; sid < N; sid++) {
+                cost += cost_at(sid, starts.back());
+                if (cost >= target && sid + 1 < N) {
+                    starts.push_back((int32_t)(sid + 1));
                     cost = 0;
                 }
             }

@@ -680,15 +680,16 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
 // looked up in the dense vector, the products of the matches added one after the other -- the oracle's merge-order sum, with
 // no accumulator shared between lanes.  A work item = (heavy query, row range): the range's rows 64 at a time, longest rows
 // first, so the lanes of a step have rows of similar length; it leaves a partial ranking like a part of a long query.  The
-// ranges are cut by cost (the longest row of every 64 counts): the 64 longest rows are a range of their own -- as row groups of
-// 2048 the first group was 50 ms on one wave (profiles/r02_s_probe_sparse_c3.txt).
+// ranges are cut by cost; a long row is walked by the whole wave (64 consecutive entries per step, added in entry order) and the
+// longest rows are ranges of their own -- as row groups of 2048 the first group was 50 ms on one wave, and with one lane per row
+// the longest row alone 36 ms (profiles/r02_s_probe_sparse_c3.txt, r02_u_kernel_stats.txt).
 struct RowsArgs {
     const int64_t *r_ptr;  // stored rows in the caller's order: r_ptr[N + 1], r_cid / r_val
     const int32_t *r_cid;
     const float *r_val;
     const int32_t *orig_of;  // scratch id -> caller's row
     int64_t N;
-    const int32_t *range_start;  // n_ranges + 1 scratch ids (multiples of 64; the last = N): ranges of about equal cost
+    const int32_t *range_start;  // n_ranges + 1 scratch ids (the last = N): ranges of about equal cost
     int32_t n_ranges;
     int32_t part_stride;  // partial rankings per block of part_keys / part_cnt
     const uint2 *dense;  // n_heavy x Dc
@@ -721,6 +722,7 @@ template <int KP>
 __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
     constexpr int CAP = 2 * KP;
     constexpr int kDeep = 16;  // entries of a row in flight per lane
+    constexpr int64_t kLongRow = 1024;  // rows with more entries are walked by the whole wave, one row at a time
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x;
     const int n_items = a.n_heavy * a.n_ranges;
@@ -745,6 +747,42 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
             int64_t e = a.r_ptr[row];
             const int64_t end = in ? a.r_ptr[row + 1] : e;
             float acc = 0.0f;
+            // Long rows first, one at a time with the whole wave: 64 consecutive entries per step (coalesced), their products
+            // added in lane order = entry order.  One lane walking a 116,000-entry row 16 entries at a time was the kernel's
+            // critical path (38-47 ms, profiles/r02_u_kernel_stats.txt); rows come longest first, so the long ones are the
+            // first lanes of a block.
+            for (unsigned long long ml = __ballot(end - e > kLongRow); ml; ml &= ml - 1) {
+                const int l = __ffsll((long long)ml) - 1;
+                const int64_t e0 = ((int64_t)__builtin_amdgcn_readlane((int)(e >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)e, l);
+                const int64_t e1 = ((int64_t)__builtin_amdgcn_readlane((int)(end >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)end, l);
+                float sum = 0.0f;  // the same in every lane
+                auto fetch = [&](int64_t base, float &prod) {  // this lane's entry of the step: its product, and whether it counts
+                    const int64_t at = base + lane;
+                    const bool have = at < e1;
+                    const int32_t c = a.r_cid[have ? at : 0];
+                    const float v = a.r_val[have ? at : 0];
+                    const uint2 q = dense[have ? c : 0];
+                    prod = __fmul_rn(__uint_as_float(q.y), v);
+                    return have && q.x != 0;
+                };
+                float p_next;
+                bool hit_next = fetch(e0, p_next);
+                for (int64_t base = e0; base < e1; base += kBlock) {
+                    const float p_cur = p_next;
+                    const bool hit = hit_next;
+                    hit_next = fetch(base + kBlock, p_next);  // in flight while this step is added up
+                    unsigned long long mh = __ballot(hit);
+                    matched += lane == 0 ? (unsigned long long)__popcll(mh) : 0;
+                    for (; mh; mh &= mh - 1) {
+                        const int b = __ffsll((long long)mh) - 1;
+                        sum = __fadd_rn(sum, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_cur), b)));
+                    }
+                }
+                if (lane == l) {
+                    acc = sum;
+                    e = end;  // done: the per-lane walk below skips it
+                }
+            }
             // three blocks of kDeep entries in flight per lane: the entries of block b + 2 are loaded while the lookups of block
             // b + 1 are under way and block b is added up
             int32_t c1[kDeep], c2[kDeep];
