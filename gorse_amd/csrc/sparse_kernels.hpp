@@ -702,7 +702,7 @@ struct RowsArgs {
     int exclude_self;
     const uint8_t *mask_sid;
     int k;
-    int32_t *next;
+    int32_t *next;  // 8 work counters, one per queue
     unsigned long long *part_keys;
     int32_t *part_cnt;
     unsigned long long *stat;
@@ -725,13 +725,21 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
     constexpr int64_t kLongRow = 1024;  // rows with more entries are walked by the whole wave, one row at a time
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x;
-    const int n_items = a.n_heavy * a.n_ranges;
+    // Eight queues, one per XCD (workgroup b has been observed on XCD b % 8; for speed only): queue x holds the heavy queries
+    // x, x + 8, ..., query after query, so that the waves of one XCD look up ONE dense vector (1 MB at the C3 shard) at a time
+    // and its L2 keeps it.  With one queue over all queries the launch's working set was all 64 vectors and the kernel ran at
+    // the rate of the L2 misses: 42 ms whatever the cut of the rows (profiles/r02_ah_kernel_stats_i2i.txt).  A workgroup whose
+    // queue is empty helps the next one.
+    for (int turn = 0; turn < 8; turn++) {
+        const int x = ((int)blockIdx.x + turn) & 7;
+        const int n_mine = (a.n_heavy - x + 7) / 8;  // queries x, x + 8, ...
+        const int n_items = n_mine * a.n_ranges;
     for (;;) {
         int w = 0;
-        if (lane == 0) w = atomicAdd(a.next, 1);
+        if (lane == 0) w = atomicAdd(a.next + x, 1);
         w = __builtin_amdgcn_readfirstlane(w);
         if (w >= n_items) break;
-        const int g = w / a.n_heavy, h = w % a.n_heavy;  // range-major: the queries of a range share its rows in the caches
+        const int g = w % a.n_ranges, h = x + 8 * (w / a.n_ranges);
         const int64_t t = a.heavy_t[h];
         const int64_t ex = a.exclude ? a.exclude[t] : (a.exclude_self ? a.q_first + t : (int64_t)-1);
         const uint2 *dense = a.dense + (size_t)h * a.Dc;
@@ -845,6 +853,7 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
             }
         }
         __syncthreads();  // s_buf is reused by the next work item
+    }
     }
 }
 

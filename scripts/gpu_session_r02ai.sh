@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 2: the heavy-query kernel with long rows walked by the whole wave and ranges cut by that cost.
+# Round 2: the heavy-query kernel with one work queue per XCD (one dense vector per L2 at a time).
 set -u
-TAG=${1:-r02_ah}
+TAG=${1:-r02_ai}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
