@@ -175,6 +175,9 @@ int32_t mf_score_device(gorse_mf *h, const int32_t *us, const int32_t *is, int64
 
 }  // namespace gorse
 
+int g_mf_flat_streams = 0;  // probe: 1 = both streams of a handle created afterwards at the same priority
+extern "C" void gorse_hip_test_set_stream_priorities(int32_t on) { g_mf_flat_streams = on ? 0 : 1; }
+
 extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, int64_t I, int32_t d,
                                    const int64_t *user_indptr, const int32_t *user_indices,
                                    const int64_t *item_indptr, const int32_t *item_indices) {
@@ -208,8 +211,13 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
         for (int64_t r = 0; r < I; r++) h->max_item_row = std::max(h->max_item_row, item_indptr[r + 1] - item_indptr[r]);
     int32_t rc = [&]() -> int32_t {
         GORSE_TRY(h->use());
-        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        // the update stream ahead of the sampler / sort stream: the sampler of the next chunk fills what the update kernel
+        // leaves, not the other way round (probe: gorse_hip_test_set_stream_priorities(0) = equal priorities)
+        int prio_lo = 0, prio_hi = 0;
+        GORSE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // lo = least urgent (largest number)
+        const bool flat = g_mf_flat_streams != 0;
+        GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, flat ? prio_lo : prio_hi));
+        GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         for (int b = 0; b < 2; b++) {
             GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
             GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
