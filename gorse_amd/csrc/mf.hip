@@ -175,7 +175,7 @@ int32_t mf_score_device(gorse_mf *h, const int32_t *us, const int32_t *is, int64
 
 }  // namespace gorse
 
-int g_mf_flat_streams = 0;  // probe: 1 = both streams of a handle created afterwards at the same priority
+int g_mf_flat_streams = 1;  // 1 = both streams of a handle at the same priority; 0 (probe) = the update stream ahead
 extern "C" void gorse_hip_test_set_stream_priorities(int32_t on) { g_mf_flat_streams = on ? 0 : 1; }
 
 extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, int64_t I, int32_t d,
@@ -211,8 +211,9 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
         for (int64_t r = 0; r < I; r++) h->max_item_row = std::max(h->max_item_row, item_indptr[r + 1] - item_indptr[r]);
     int32_t rc = [&]() -> int32_t {
         GORSE_TRY(h->use());
-        // the update stream ahead of the sampler / sort stream: the sampler of the next chunk fills what the update kernel
-        // leaves, not the other way round (probe: gorse_hip_test_set_stream_priorities(0) = equal priorities)
+        // Both streams at the same priority.  Probe (gorse_hip_test_set_stream_priorities(1)): the update stream at the highest
+        // stream priority and the sampler / sort stream at the lowest changes nothing at C2 (0.697 vs 0.702 ms per epoch) and
+        // costs 3 % at the C3 shard (13.24 vs 12.80 ms): profiles/r02_ak_probe_stream_prio.txt.
         int prio_lo = 0, prio_hi = 0;
         GORSE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // lo = least urgent (largest number)
         const bool flat = g_mf_flat_streams != 0;

@@ -51,8 +51,8 @@ int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/
 /* 1 = every query of the literal scan (path A) goes through the one-thread-per-query heap kernel; 0 (default) = the queries whose
  * k + 1 smallest distances are pairwise distinct are answered by select_fast_kernel (same results). */
 void gorse_hip_test_set_scan_literal(int32_t on);
-/* 1 (default) = a gorse_mf handle created afterwards runs its update stream at the device's highest stream priority and its
- * sampler / sort stream at the lowest; 0 = both at the lowest (the round-1 behaviour). */
+/* probe: 1 = a gorse_mf handle created afterwards runs its update stream at the device's highest stream priority and its
+ * sampler / sort stream at the lowest; 0 (default) = both at the same priority (measured no better: r02_ak). */
 void gorse_hip_test_set_stream_priorities(int32_t on);
 /* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */

@@ -26,4 +26,4 @@ for name, mk, d, epochs in (("ml1m", synth.s_ml1m, 64, 40), ("c3/8", lambda: syn
         dt = (time.perf_counter() - t0) / epochs
         print("%-5s d=%3d update stream %s: %.4f ms per epoch (%.3e samples/s)" % (name, d, "ahead" if on else "equal", dt * 1e3, data.n_train / dt), flush=True)
         mf.close()
-L.gorse_hip_test_set_stream_priorities(1)
+L.gorse_hip_test_set_stream_priorities(0)
