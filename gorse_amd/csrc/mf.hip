@@ -214,11 +214,15 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
         // Both streams at the same priority.  Probe (gorse_hip_test_set_stream_priorities(1)): the update stream at the highest
         // stream priority and the sampler / sort stream at the lowest changes nothing at C2 (0.697 vs 0.702 ms per epoch) and
         // costs 3 % at the C3 shard (13.24 vs 12.80 ms): profiles/r02_ak_probe_stream_prio.txt.
-        int prio_lo = 0, prio_hi = 0;
-        GORSE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // lo = least urgent (largest number)
-        const bool flat = g_mf_flat_streams != 0;
-        GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, flat ? prio_lo : prio_hi));
-        GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+        if (g_mf_flat_streams) {
+            GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+            GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+        } else {
+            int prio_lo = 0, prio_hi = 0;
+            GORSE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // lo = least urgent (largest number)
+            GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+            GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+        }
         for (int b = 0; b < 2; b++) {
             GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
             GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
