@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
                                                         const int32_t *__restrict__ idx, const float *__restrict__ S,
                                                         int64_t row_begin, int64_t rows, int d, float w, float reg,
                                                         int pred_cap, int q_cap, float *__restrict__ scratch,
-                                                        int64_t scratch_stride) {
+                                                        int64_t scratch_stride, int min_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sp = smem;                      // d          current row of A
     float *red = sp + ((d + 3) & ~3);      // 12
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
     for (int64_t u = row_begin + blockIdx.x; u < rows; u += gridDim.x) {  // rows = end of the row range
         const int64_t beg = ptr[u];
         const int n = (int)(ptr[u + 1] - beg);
+        if (n < min_n) continue;  // a row of als_wide_kernel's
         const int32_t *fb = idx + beg;
         float *pu = A + u * d;
         for (int e = threadIdx.x; e < d; e += blockDim.x) sp[e] = pu[e];
@@ -176,6 +177,119 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
     }
 }
 
+
+// ---- Gram-form row solve for 64 < nFactors <= 128 ------------------------------------------------------------------------
+// The same substitution as below (M = (1 - w) G + w S per row, one Gauss-Seidel sweep), for factor widths whose M no longer
+// fits one wave's registers as columns.  One 256-thread workgroup per row: G = sum q q^T by fused multiply-adds, thread
+// (ti, tj) owning the 8 x 8 block of rows 8 ti .. and columns 8 tj .. (64 accumulators), the entries staged 16 at a time
+// through LDS with the next batch's gathers in flight; M goes to LDS (128 x 129 floats, zero past d: a padded coordinate
+// solves to 0 and changes nothing), and one wave runs the sweep with two coordinates per lane and the columns read from LDS.
+// Rows with more than `max_n` entries are left to the residual sweep, which walks them with the whole workgroup.
+constexpr int kWideLd = 129, kWideBatch = 16;
+__global__ __launch_bounds__(256) void als_wide_kernel(float *__restrict__ A, const float *__restrict__ B,
+                                                       const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                       const float *__restrict__ S, int64_t row_begin, int64_t row_end, int d,
+                                                       float w, float reg, int max_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sM = smem;                           // 128 x 129
+    float *sq = sM + 128 * kWideLd;             // 16 x 128: one batch of gathered rows
+    float *ss = sq + kWideBatch * 128;          // 128 column sums
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int lr = tid >> 4, lc = (tid & 15) * 8;  // gather: entry lr of the batch, columns lc .. lc + 7
+    const float one_w = 1 - w;
+    for (int64_t u = row_begin + blockIdx.x; u < row_end; u += gridDim.x) {
+        const int64_t beg = ptr[u];
+        const int n = (int)(ptr[u + 1] - beg);
+        if (n > max_n) continue;  // the residual sweep's
+        float acc[8][8], cs[8], g[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            cs[a] = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 8; b++) acc[a][b] = 0.0f;
+        }
+        auto gather = [&](int e0) {
+            const int e = e0 + lr;
+            const float *row = B + (int64_t)idx[beg + (e < n ? e : 0)] * d;  // n == 0: idx[beg] may be another row's, unused
+#pragma unroll
+            for (int i = 0; i < 8; i++) g[i] = (e < n && lc + i < d) ? row[lc + i < d ? lc + i : 0] : 0.0f;
+        };
+        if (n > 0) gather(0);
+        for (int e0 = 0; e0 < n; e0 += kWideBatch) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) sq[lr * 128 + lc + i] = g[i];
+            __syncthreads();
+            if (e0 + kWideBatch < n) gather(e0 + kWideBatch);
+            const int m = n - e0 < kWideBatch ? n - e0 : kWideBatch;
+            for (int e = 0; e < m; e++) {
+                float r[8], c[8];
+#pragma unroll
+                for (int a = 0; a < 8; a++) {
+                    r[a] = sq[e * 128 + 8 * ti + a];
+                    c[a] = sq[e * 128 + 8 * tj + a];
+                }
+#pragma unroll
+                for (int a = 0; a < 8; a++)
+#pragma unroll
+                    for (int b = 0; b < 8; b++) acc[a][b] = fmaf(r[a], c[b], acc[a][b]);
+                if (ti == 0) {
+#pragma unroll
+                    for (int b = 0; b < 8; b++) cs[b] += c[b];
+                }
+            }
+            __syncthreads();  // the batch is consumed: sq may be rewritten
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int i = 8 * ti + a, j = 8 * tj + b;
+                sM[i * kWideLd + j] = (i < d && j < d) ? one_w * acc[a][b] + w * S[i * d + j] : 0.0f;
+            }
+        if (ti == 0) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) ss[8 * tj + b] = 8 * tj + b < d ? cs[b] : 0.0f;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int lane = tid, k0 = lane, k1 = lane + 64;
+            float *a = A + u * d;
+            const float p0_lo = k0 < d ? a[k0] : 0.0f, p0_hi = k1 < d ? a[k1] : 0.0f;
+            const float diag_lo = sM[k0 * kWideLd + k0], diag_hi = sM[k1 * kWideLd + k1];
+            // a padded coordinate (k >= d: zero row and column of M) keeps inv = 0: it solves to 0 whatever reg is
+            const float inv_lo = k0 < d ? __builtin_amdgcn_rcpf(diag_lo + reg) : 0.0f;
+            const float inv_hi = k1 < d ? __builtin_amdgcn_rcpf(diag_hi + reg) : 0.0f;
+            const float base_lo = (ss[k0] + p0_lo * diag_lo) * inv_lo, base_hi = (ss[k1] + p0_hi * diag_hi) * inv_hi;
+            float y_lo = 0.0f, y_hi = 0.0f;
+            auto bcast = [&](float lo, float hi, int f) {  // coordinate f of a two-halves vector, to every lane
+                return f < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), f))
+                              : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), f - 64));
+            };
+#pragma unroll 4
+            for (int f = 0; f < 128; f++) {
+                const float pf = bcast(p0_lo, p0_hi, f);
+                y_lo = fmaf(sM[k0 * kWideLd + f], pf, y_lo);
+                y_hi = fmaf(sM[k1 * kWideLd + f], pf, y_hi);
+            }
+            float p_lo = p0_lo, p_hi = p0_hi;
+#pragma unroll 4
+            for (int f = 0; f < 128; f++) {
+                const float col_lo = sM[k0 * kWideLd + f], col_hi = sM[k1 * kWideLd + f];  // M is symmetric: column f = row f
+                const float nf = bcast(base_lo, base_hi, f) - bcast(y_lo, y_hi, f) * bcast(inv_lo, inv_hi, f);
+                const float delta = nf - bcast(p0_lo, p0_hi, f);
+                y_lo = fmaf(delta, col_lo, y_lo);
+                y_hi = fmaf(delta, col_hi, y_hi);
+                if (f < 64)
+                    p_lo = lane == f ? nf : p_lo;
+                else
+                    p_hi = lane == f - 64 ? nf : p_hi;
+            }
+            if (k0 < d) a[k0] = p_lo;
+            if (k1 < d) a[k1] = p_hi;
+        }
+        __syncthreads();  // sM / ss are rewritten by the next row
+    }
+}
 
 // ---- Gram-form row solve (d <= 64) --------------------------------------------------------------
 // model.go:659-690 keeps a residual per feedback entry and re-walks the row's n entries for every one
@@ -603,6 +717,20 @@ int32_t run_gram(gorse_mf *h, const float *F, const int64_t *ptr, int64_t rows, 
 int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, const int32_t *idx, int64_t row_begin,
                   int64_t row_end, int64_t max_row, float w, float reg) {
     const int d = h->d;
+    // 64 < nFactors <= 128: rows of up to kWideMaxRow entries by the Gram form of als_wide_kernel, the rest by the residual sweep
+    const bool wide = d > 64 && d <= 128 && g_als_path == 0 && row_end > row_begin;
+    constexpr int kWideMaxRow = 4096;
+    if (wide) {
+        const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        const int wblocks = (int)std::min<int64_t>(row_end - row_begin, 256 * 2);
+        const int tokw = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
+        als_wide_kernel<<<dim3(wblocks), dim3(256), wlds, h->stream>>>(A, B, ptr, idx, h->gram.p, row_begin, row_end, d, w, reg,
+                                                                        kWideMaxRow);
+        GORSE_HIP_CHECK(hipGetLastError());
+        h->prof.end(tokw, h->stream);
+        if (max_row <= kWideMaxRow) return GORSE_OK;
+    }
     const size_t fixed = ((size_t)((d + 3) & ~3) + 12 + 2 * (size_t)kGroupsPerBlock * d) * sizeof(float);
     const size_t budget = 64 * 1024;
     if (fixed + 1024 > 150 * 1024) return fail(GORSE_ERR_INVALID, "nFactors %d too large for the ALS kernel", d);
@@ -618,7 +746,8 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
                                         (int)shmem));
     int tok = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
     als_sweep_kernel<<<dim3(blocks), dim3(256), shmem, h->stream>>>(A, B, ptr, idx, h->gram.p, row_begin, row_end, d, w, reg,
-                                                                   pred_cap, q_cap, h->als_scratch.p, stride);
+                                                                   pred_cap, q_cap, h->als_scratch.p, stride,
+                                                                   wide ? kWideMaxRow + 1 : 0);
     GORSE_HIP_CHECK(hipGetLastError());
     h->prof.end(tok, h->stream);
     return GORSE_OK;

@@ -77,6 +77,11 @@ def prof(name, U, I, nnz, d, path=0):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":  # nFactors 128: the residual sweep alone (1) against als_wide_kernel + sweep (0)
+        run("20Kx10Kx1M d=128", 20_000, 10_000, 1_000_000, 128, (1, 0), reps=2)
+        run("C5 shard/4 d=128", 125_000, 100_000, 12_500_000, 128, (1, 0), reps=1)
+        capi.lib().gorse_hip_test_set_als_path(0)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "phased":  # accumulate / solve in lockstep per workgroup (path | 4) against free-running
         prof("C5 d=64 free-running", 500_000, 100_000, 50_000_000, 64, 0)
         prof("C5 d=64 phased", 500_000, 100_000, 50_000_000, 64, 4)

@@ -444,6 +444,43 @@ def test_als_epoch_parity(oracle, small, d, path, als_paths):
     assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
+@pytest.mark.parametrize("d", [65, 96, 128])
+def test_als_wide_factors(oracle, small, d, als_paths):
+    """64 < nFactors <= 128: the product's choice is the Gram form of als_wide_kernel (one workgroup per row) for rows of up to
+    4096 entries and the residual sweep for longer ones; both against the oracle, and against the residual sweep alone"""
+    capi.lib().gorse_hip_test_set_als_path(0)
+    mf, P, Q = make_mf(small, d, std=0.1)
+    eP, eQ = P, Q
+    for _ in range(3):
+        eP, eQ = oracle.als_epoch(eP, eQ, small.uptr, small.uidx, small.iptr, small.iidx, 0.05, 0.015)
+        mf.als_epoch(0.05, 0.015)
+    gP, gQ = mf.get_factors()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+    scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    report_elementwise("ALS wide d=%d" % d, (("P", gP, eP), ("Q", gQ, eQ)))
+    assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
+    capi.lib().gorse_hip_test_set_als_path(1)
+    ref, _, _ = make_mf(small, d, std=0.1)
+    for _ in range(3):
+        ref.als_epoch(0.05, 0.015)
+    rP, rQ = ref.get_factors()
+    assert np.abs(gP - rP).max() < 1e-4 * scale and np.abs(gQ - rQ).max() < 1e-4 * scale
+
+
+def test_als_wide_factors_with_heavy_rows(oracle, als_paths):
+    """rows of more than 4096 entries next to short ones at nFactors = 96: the long ones go through the residual sweep"""
+    capi.lib().gorse_hip_test_set_als_path(0)
+    data = synth.synth_cf(40, 6000, 60000, seed=9, min_len=3, max_frac=0.9, n_neg=10)
+    assert np.diff(data.uptr).max() > 4096 and np.diff(data.uptr).min() < 4096
+    mf, P, Q = make_mf(data, 96, std=0.1)
+    eP, eQ = oracle.als_epoch(P, Q, data.uptr, data.uidx, data.iptr, data.iidx, 0.05, 0.015)
+    mf.als_epoch(0.05, 0.015)
+    gP, gQ = mf.get_factors()
+    scale = max(np.abs(eP).max(), np.abs(eQ).max())
+    report_elementwise("ALS wide, heavy rows", (("P", gP, eP), ("Q", gQ, eQ)))
+    assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
+
+
 def test_als_gram_form_rejects_wide_factors(small, als_paths):
     capi.lib().gorse_hip_test_set_als_path(2)
     mf, _, _ = make_mf(small, 96, std=0.1)
@@ -451,7 +488,7 @@ def test_als_gram_form_rejects_wide_factors(small, als_paths):
         mf.als_epoch(0.05, 0.015)
     assert e.value.code == capi.ERR_INVALID
     capi.lib().gorse_hip_test_set_als_path(0)
-    mf.als_epoch(0.05, 0.015)  # automatic choice: residual sweep for nFactors > 64
+    mf.als_epoch(0.05, 0.015)  # automatic choice: als_wide_kernel + the residual sweep for 64 < nFactors <= 128
 
 
 @pytest.mark.parametrize("long_row,chunk", [(16, 16), (40, 13), (0, 0)])
@@ -500,7 +537,7 @@ def test_als_rows_without_feedback(oracle, als_paths):
         assert np.abs(gP - eP).max() < 1e-4 * scale and np.abs(gQ - eQ).max() < 1e-4 * scale
 
 
-@pytest.mark.parametrize("path,d", [(2, 64), (2, 32), (2, 16), (1, 24), (1, 96)])
+@pytest.mark.parametrize("path,d", [(2, 64), (2, 32), (2, 16), (1, 24), (1, 96), (0, 96)])
 def test_als_row_sharded_equals_the_full_epoch(small, path, d, als_paths):
     # three "ranks" on one GPU, each a handle restricted to its row ranges (gorse_als_set_ranges);
     # after every half-sweep the row blocks travel through device buffers (gorse_mf_rows_export / _import), the way
