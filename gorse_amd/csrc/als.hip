@@ -180,114 +180,179 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
 
 // ---- Gram-form row solve for 64 < nFactors <= 128 ------------------------------------------------------------------------
 // The same substitution as below (M = (1 - w) G + w S per row, one Gauss-Seidel sweep), for factor widths whose M no longer
-// fits one wave's registers as columns.  One 256-thread workgroup per row: G = sum q q^T by fused multiply-adds, thread
-// (ti, tj) owning the 8 x 8 block of rows 8 ti .. and columns 8 tj .. (64 accumulators), the entries staged 16 at a time
-// through LDS with the next batch's gathers in flight; M goes to LDS (128 x 129 floats, zero past d: a padded coordinate
-// solves to 0 and changes nothing), and one wave runs the sweep with two coordinates per lane and the columns read from LDS.
-// Rows with more than `max_n` entries are left to the residual sweep, which walks them with the whole workgroup.
-constexpr int kWideLd = 129, kWideBatch = 16;
+// fits one wave's registers as columns.  One 256-thread workgroup per row (or per chunk of a long row): G = sum q q^T by fused
+// multiply-adds, thread (ti, tj) owning the 8 x 8 block of rows 8 ti .. and columns 8 tj .. (64 accumulators), the entries
+// staged 16 at a time through LDS with the next batch's gathers in flight; M goes to LDS (128 x 129 floats, zero past d: a
+// padded coordinate solves to 0 and changes nothing), and one wave runs the sweep with two coordinates per lane and the
+// columns read from LDS.  A row of more than 4096 entries is cut into chunks (the row plan of the d <= 64 form): every chunk
+// leaves its G and column sums in global memory, als_wide_long_kernel adds them in chunk order and solves.
+constexpr int kWideLd = 129, kWideBatch = 16, kWidePartial = 128 * 128 + 128;  // floats per chunk: G row-major, then the sums
+
+// G and the column sums of entries idx[beg .. beg + n) of B, in this thread's 8 x 8 block / (ti == 0) 8 columns
+__device__ __forceinline__ void wide_accumulate(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
+                                                int d, float *sq, float (&acc)[8][8], float (&cs)[8]) {
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int lr = tid >> 4, lc = (tid & 15) * 8;  // gather: entry lr of the batch, columns lc .. lc + 7
+    float g[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        cs[a] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 8; b++) acc[a][b] = 0.0f;
+    }
+    auto gather = [&](int e0) {
+        const int e = e0 + lr;
+        const float *row = B + (int64_t)idx[beg + (e < n ? e : 0)] * d;
+#pragma unroll
+        for (int i = 0; i < 8; i++) g[i] = (e < n && lc + i < d) ? row[lc + i < d ? lc + i : 0] : 0.0f;
+    };
+    if (n > 0) gather(0);
+    for (int e0 = 0; e0 < n; e0 += kWideBatch) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) sq[lr * 128 + lc + i] = g[i];
+        __syncthreads();
+        if (e0 + kWideBatch < n) gather(e0 + kWideBatch);
+        const int m = n - e0 < kWideBatch ? n - e0 : kWideBatch;
+        for (int e = 0; e < m; e++) {
+            float r[8], c[8];
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                r[a] = sq[e * 128 + 8 * ti + a];
+                c[a] = sq[e * 128 + 8 * tj + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = 0; b < 8; b++) acc[a][b] = fmaf(r[a], c[b], acc[a][b]);
+            if (ti == 0) {
+#pragma unroll
+                for (int b = 0; b < 8; b++) cs[b] += c[b];
+            }
+        }
+        __syncthreads();  // the batch is consumed: sq may be rewritten
+    }
+}
+
+// M = (1 - w) G + w S into LDS, then the sweep of row `a` by the first wave; ends with a barrier (sM / ss are free again)
+__device__ __forceinline__ void wide_solve(float *__restrict__ a, const float *__restrict__ S, int d, float w, float reg,
+                                           float *sM, float *ss, const float (&acc)[8][8], const float (&cs)[8]) {
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const float one_w = 1 - w;
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+            const int i = 8 * ti + x, j = 8 * tj + y;
+            sM[i * kWideLd + j] = (i < d && j < d) ? one_w * acc[x][y] + w * S[i * d + j] : 0.0f;
+        }
+    if (ti == 0) {
+#pragma unroll
+        for (int y = 0; y < 8; y++) ss[8 * tj + y] = 8 * tj + y < d ? cs[y] : 0.0f;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int lane = tid, k0 = lane, k1 = lane + 64;
+        const float p0_lo = k0 < d ? a[k0] : 0.0f, p0_hi = k1 < d ? a[k1] : 0.0f;
+        const float diag_lo = sM[k0 * kWideLd + k0], diag_hi = sM[k1 * kWideLd + k1];
+        // a padded coordinate (k >= d: zero row and column of M) keeps inv = 0: it solves to 0 whatever reg is
+        const float inv_lo = k0 < d ? __builtin_amdgcn_rcpf(diag_lo + reg) : 0.0f;
+        const float inv_hi = k1 < d ? __builtin_amdgcn_rcpf(diag_hi + reg) : 0.0f;
+        const float base_lo = (ss[k0] + p0_lo * diag_lo) * inv_lo, base_hi = (ss[k1] + p0_hi * diag_hi) * inv_hi;
+        float y_lo = 0.0f, y_hi = 0.0f;
+        auto bcast = [&](float lo, float hi, int f) {  // coordinate f of a two-halves vector, to every lane
+            return f < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), f))
+                          : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), f - 64));
+        };
+#pragma unroll 4
+        for (int f = 0; f < 128; f++) {
+            const float pf = bcast(p0_lo, p0_hi, f);
+            y_lo = fmaf(sM[k0 * kWideLd + f], pf, y_lo);
+            y_hi = fmaf(sM[k1 * kWideLd + f], pf, y_hi);
+        }
+        float p_lo = p0_lo, p_hi = p0_hi;
+#pragma unroll 4
+        for (int f = 0; f < 128; f++) {
+            const float col_lo = sM[k0 * kWideLd + f], col_hi = sM[k1 * kWideLd + f];  // M is symmetric: column f = row f
+            const float nf = bcast(base_lo, base_hi, f) - bcast(y_lo, y_hi, f) * bcast(inv_lo, inv_hi, f);
+            const float delta = nf - bcast(p0_lo, p0_hi, f);
+            y_lo = fmaf(delta, col_lo, y_lo);
+            y_hi = fmaf(delta, col_hi, y_hi);
+            if (f < 64)
+                p_lo = lane == f ? nf : p_lo;
+            else
+                p_hi = lane == f - 64 ? nf : p_hi;
+        }
+        if (k0 < d) a[k0] = p_lo;
+        if (k1 < d) a[k1] = p_hi;
+    }
+    __syncthreads();
+}
+
+// CHUNKS = false: the rows of `rows` (n_items of them), accumulated and solved.  CHUNKS = true: the chunks of the long rows
+// (chunk_beg / chunk_cnt, n_items of them), each leaving its G and sums in `partial`.
+template <bool CHUNKS>
 __global__ __launch_bounds__(256) void als_wide_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                        const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-                                                       const float *__restrict__ S, int64_t row_begin, int64_t row_end, int d,
-                                                       float w, float reg, int max_n) {
+                                                       const float *__restrict__ S, const int32_t *__restrict__ rows,
+                                                       const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_cnt,
+                                                       int64_t n_items, int d, float w, float reg, float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sM = smem;                           // 128 x 129
     float *sq = sM + 128 * kWideLd;             // 16 x 128: one batch of gathered rows
     float *ss = sq + kWideBatch * 128;          // 128 column sums
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-    const int lr = tid >> 4, lc = (tid & 15) * 8;  // gather: entry lr of the batch, columns lc .. lc + 7
-    const float one_w = 1 - w;
-    for (int64_t u = row_begin + blockIdx.x; u < row_end; u += gridDim.x) {
-        const int64_t beg = ptr[u];
-        const int n = (int)(ptr[u + 1] - beg);
-        if (n > max_n) continue;  // the residual sweep's
-        float acc[8][8], cs[8], g[8];
+    for (int64_t t = blockIdx.x; t < n_items; t += gridDim.x) {
+        float acc[8][8], cs[8];
+        if (CHUNKS) {
+            wide_accumulate(B, idx, chunk_beg[t], chunk_cnt[t], d, sq, acc, cs);
+            float *dst = partial + t * kWidePartial;
 #pragma unroll
-        for (int a = 0; a < 8; a++) {
-            cs[a] = 0.0f;
+            for (int x = 0; x < 8; x++)
 #pragma unroll
-            for (int b = 0; b < 8; b++) acc[a][b] = 0.0f;
-        }
-        auto gather = [&](int e0) {
-            const int e = e0 + lr;
-            const float *row = B + (int64_t)idx[beg + (e < n ? e : 0)] * d;  // n == 0: idx[beg] may be another row's, unused
+                for (int y = 0; y < 8; y++) dst[(8 * ti + x) * 128 + 8 * tj + y] = acc[x][y];
+            if (ti == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) g[i] = (e < n && lc + i < d) ? row[lc + i < d ? lc + i : 0] : 0.0f;
-        };
-        if (n > 0) gather(0);
-        for (int e0 = 0; e0 < n; e0 += kWideBatch) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) sq[lr * 128 + lc + i] = g[i];
-            __syncthreads();
-            if (e0 + kWideBatch < n) gather(e0 + kWideBatch);
-            const int m = n - e0 < kWideBatch ? n - e0 : kWideBatch;
-            for (int e = 0; e < m; e++) {
-                float r[8], c[8];
-#pragma unroll
-                for (int a = 0; a < 8; a++) {
-                    r[a] = sq[e * 128 + 8 * ti + a];
-                    c[a] = sq[e * 128 + 8 * tj + a];
-                }
-#pragma unroll
-                for (int a = 0; a < 8; a++)
-#pragma unroll
-                    for (int b = 0; b < 8; b++) acc[a][b] = fmaf(r[a], c[b], acc[a][b]);
-                if (ti == 0) {
-#pragma unroll
-                    for (int b = 0; b < 8; b++) cs[b] += c[b];
-                }
+                for (int y = 0; y < 8; y++) dst[128 * 128 + 8 * tj + y] = cs[y];
             }
-            __syncthreads();  // the batch is consumed: sq may be rewritten
+        } else {
+            const int64_t u = rows[t];
+            const int64_t beg = ptr[u];
+            wide_accumulate(B, idx, beg, (int)(ptr[u + 1] - beg), d, sq, acc, cs);
+            wide_solve(A + u * d, S, d, w, reg, sM, ss, acc, cs);
         }
+    }
+}
+
+// the long rows: the partial G / sums of a row's chunks added one after the other (a fixed order: deterministic, and the same
+// whichever process solves the row), then the solve
+__global__ __launch_bounds__(256) void als_wide_long_kernel(float *__restrict__ A, const float *__restrict__ S,
+                                                            const int32_t *__restrict__ rows, const int32_t *__restrict__ first,
+                                                            const int32_t *__restrict__ nch, int64_t n_rows, int d, float w,
+                                                            float reg, const float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sM = smem;
+    float *ss = sM + 128 * kWideLd + kWideBatch * 128;
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    for (int64_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
+        float acc[8][8], cs[8];
 #pragma unroll
-        for (int a = 0; a < 8; a++)
+        for (int x = 0; x < 8; x++) {
+            cs[x] = 0.0f;
 #pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const int i = 8 * ti + a, j = 8 * tj + b;
-                sM[i * kWideLd + j] = (i < d && j < d) ? one_w * acc[a][b] + w * S[i * d + j] : 0.0f;
-            }
-        if (ti == 0) {
-#pragma unroll
-            for (int b = 0; b < 8; b++) ss[8 * tj + b] = 8 * tj + b < d ? cs[b] : 0.0f;
+            for (int y = 0; y < 8; y++) acc[x][y] = 0.0f;
         }
-        __syncthreads();
-        if (tid < 64) {
-            const int lane = tid, k0 = lane, k1 = lane + 64;
-            float *a = A + u * d;
-            const float p0_lo = k0 < d ? a[k0] : 0.0f, p0_hi = k1 < d ? a[k1] : 0.0f;
-            const float diag_lo = sM[k0 * kWideLd + k0], diag_hi = sM[k1 * kWideLd + k1];
-            // a padded coordinate (k >= d: zero row and column of M) keeps inv = 0: it solves to 0 whatever reg is
-            const float inv_lo = k0 < d ? __builtin_amdgcn_rcpf(diag_lo + reg) : 0.0f;
-            const float inv_hi = k1 < d ? __builtin_amdgcn_rcpf(diag_hi + reg) : 0.0f;
-            const float base_lo = (ss[k0] + p0_lo * diag_lo) * inv_lo, base_hi = (ss[k1] + p0_hi * diag_hi) * inv_hi;
-            float y_lo = 0.0f, y_hi = 0.0f;
-            auto bcast = [&](float lo, float hi, int f) {  // coordinate f of a two-halves vector, to every lane
-                return f < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), f))
-                              : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), f - 64));
-            };
-#pragma unroll 4
-            for (int f = 0; f < 128; f++) {
-                const float pf = bcast(p0_lo, p0_hi, f);
-                y_lo = fmaf(sM[k0 * kWideLd + f], pf, y_lo);
-                y_hi = fmaf(sM[k1 * kWideLd + f], pf, y_hi);
+        for (int c = 0; c < nch[t]; c++) {
+            const float *src = partial + (int64_t)(first[t] + c) * kWidePartial;
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+#pragma unroll
+                for (int y = 0; y < 8; y++) acc[x][y] += src[(8 * ti + x) * 128 + 8 * tj + y];
+            if (ti == 0) {
+#pragma unroll
+                for (int y = 0; y < 8; y++) cs[y] += src[128 * 128 + 8 * tj + y];
             }
-            float p_lo = p0_lo, p_hi = p0_hi;
-#pragma unroll 4
-            for (int f = 0; f < 128; f++) {
-                const float col_lo = sM[k0 * kWideLd + f], col_hi = sM[k1 * kWideLd + f];  // M is symmetric: column f = row f
-                const float nf = bcast(base_lo, base_hi, f) - bcast(y_lo, y_hi, f) * bcast(inv_lo, inv_hi, f);
-                const float delta = nf - bcast(p0_lo, p0_hi, f);
-                y_lo = fmaf(delta, col_lo, y_lo);
-                y_hi = fmaf(delta, col_hi, y_hi);
-                if (f < 64)
-                    p_lo = lane == f ? nf : p_lo;
-                else
-                    p_hi = lane == f - 64 ? nf : p_hi;
-            }
-            if (k0 < d) a[k0] = p_lo;
-            if (k1 < d) a[k1] = p_hi;
         }
-        __syncthreads();  // sM / ss are rewritten by the next row
+        wide_solve(A + (int64_t)rows[t] * d, S, d, w, reg, sM, ss, acc, cs);
     }
 }
 
@@ -717,19 +782,31 @@ int32_t run_gram(gorse_mf *h, const float *F, const int64_t *ptr, int64_t rows, 
 int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, const int32_t *idx, int64_t row_begin,
                   int64_t row_end, int64_t max_row, float w, float reg) {
     const int d = h->d;
-    // 64 < nFactors <= 128: rows of up to kWideMaxRow entries by the Gram form of als_wide_kernel, the rest by the residual sweep
-    const bool wide = d > 64 && d <= 128 && g_als_path == 0 && row_end > row_begin;
-    constexpr int kWideMaxRow = 4096;
-    if (wide) {
+    // 64 < nFactors <= 128, the product's choice: the Gram form of als_wide_kernel over the row plan (short rows whole, long rows
+    // by chunks + als_wide_long_kernel); the residual sweep below stays as the forced path 1
+    if (d > 64 && d <= 128 && g_als_path == 0) {
+        gorse_mf::AlsPlan &pl = h->als_plan[A == h->P.p ? 0 : 1];
         const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-        const int wblocks = (int)std::min<int64_t>(row_end - row_begin, 256 * 2);
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         const int tokw = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
-        als_wide_kernel<<<dim3(wblocks), dim3(256), wlds, h->stream>>>(A, B, ptr, idx, h->gram.p, row_begin, row_end, d, w, reg,
-                                                                        kWideMaxRow);
-        GORSE_HIP_CHECK(hipGetLastError());
+        if (pl.n_short > 0) {
+            als_wide_kernel<false><<<dim3((unsigned)std::min<int64_t>(pl.n_short, 512)), dim3(256), wlds, h->stream>>>(
+                A, B, ptr, idx, h->gram.p, pl.short_rows.p, nullptr, nullptr, pl.n_short, d, w, reg, nullptr);
+            GORSE_HIP_CHECK(hipGetLastError());
+        }
+        if (pl.n_long > 0) {
+            GORSE_TRY(h->als_partial.ensure((size_t)pl.n_chunks * kWidePartial));
+            als_wide_kernel<true><<<dim3((unsigned)std::min<int64_t>(pl.n_chunks, 2048)), dim3(256), wlds, h->stream>>>(
+                A, B, ptr, idx, h->gram.p, nullptr, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, w, reg, h->als_partial.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+            als_wide_long_kernel<<<dim3((unsigned)std::min<int64_t>(pl.n_long, 512)), dim3(256), wlds, h->stream>>>(
+                A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+        }
         h->prof.end(tokw, h->stream);
-        if (max_row <= kWideMaxRow) return GORSE_OK;
+        return GORSE_OK;
     }
     const size_t fixed = ((size_t)((d + 3) & ~3) + 12 + 2 * (size_t)kGroupsPerBlock * d) * sizeof(float);
     const size_t budget = 64 * 1024;
@@ -746,8 +823,7 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
                                         (int)shmem));
     int tok = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
     als_sweep_kernel<<<dim3(blocks), dim3(256), shmem, h->stream>>>(A, B, ptr, idx, h->gram.p, row_begin, row_end, d, w, reg,
-                                                                   pred_cap, q_cap, h->als_scratch.p, stride,
-                                                                   wide ? kWideMaxRow + 1 : 0);
+                                                                   pred_cap, q_cap, h->als_scratch.p, stride, 0);
     GORSE_HIP_CHECK(hipGetLastError());
     h->prof.end(tok, h->stream);
     return GORSE_OK;

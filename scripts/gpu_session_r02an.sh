@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2: the Gram form for 64 < nFactors <= 128 (als_wide_kernel).
 set -u
-TAG=${1:-r02_am}
+TAG=${1:-r02_an}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
