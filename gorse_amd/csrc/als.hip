@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void als_wide_long_kernel(float *__restrict__ 
 // the exact solution: tests/test_gpu_cf_parity.py::test_als_*).
 int g_als_long_row = 4096;  // rows longer than this are cut into chunks (test hook: gorse_hip_test_set_als_plan)
 int g_als_chunk = 4096;     // feedback entries per chunk of a long row
-int g_als_path = 0;         // 0 auto (Gram form for d <= 64), 1 force the residual sweep, 2 force the Gram form
+int g_als_path = 0;         // 0 auto (Gram form: MFMA kernels for d <= 64, als_wide_kernel for d <= 128; else the residual
+                            // sweep), 1 force the residual sweep, 2 force the MFMA Gram form (d <= 64)
 int g_als_phased = 0;       // als_row_kernel: the waves of a workgroup accumulate together and solve together (probe: path | 4)
 constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
 constexpr int kAlsWaves = 4;        // waves per workgroup of the chunk kernels

@@ -76,8 +76,8 @@ void gorse_hip_test_set_sparse_atomic(int32_t mode);
  * groups read back densely, groups read back by re-walking, flattened batches, rows two lists of a batch shared,
  * 10 ns ticks in the 64-lists-at-once path / in the batches / in the read-backs / until the end of the eighth group}.  Returns the number of work items of the last call. */
 int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /*host or NULL*/, int64_t cap);
-/* ALS row-solve choice: 0 = automatic (Gram form on the fp32 MFMA for nFactors <= 64, the residual sweep
- * otherwise), 1 = always the residual sweep (the reference's own recurrence), 2 = always the Gram form.
+/* ALS row-solve choice: 0 = automatic (Gram form: on the fp32 MFMA for nFactors <= 64, als_wide_kernel for 65..128; the residual
+ * sweep beyond), 1 = always the residual sweep (the reference's own recurrence), 2 = always the MFMA Gram form (nFactors <= 64).
  * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */
 void gorse_hip_test_set_als_path(int32_t path);
 /* thresholds of the Gram-form row plan, for handles created AFTERWARDS: rows longer than long_row feedbacks
