@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 2, last session: the whole GPU suite and the default bench line on the final library.
 set -u
-TAG=${1:-r02_aj}
+TAG=${1:-r02_ao}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
