@@ -424,3 +424,41 @@ def test_sharded_neighbor_refresh_equals_the_single_process_result(tmp_path, wor
         got = np.load(tmp_path / ("nb%d.npz" % r))
         assert np.array_equal(got["dI"], dI) and np.array_equal(got["dD"].view(np.uint32), dD.view(np.uint32))
         assert (got["dC"] == 22).all()
+
+
+def _libcomm_worker(rank, world, port, out):
+    """every rank must come out of LibComm's constructor -- with a communicator or with an exception -- whatever happens on
+    rank 0: here there is no GPU, so the library either cannot draw an id (rank 0) or cannot create the communicator"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def share(uid):
+        t = torch.tensor(list(uid), dtype=torch.uint8)
+        dist.broadcast(t, src=0)
+        return bytes(t.tolist())
+    outcome = "communicator"
+    try:
+        gdist.LibComm(rank, world, 0, share)
+    except Exception as e:
+        outcome = "raised %s" % type(e).__name__
+    # the agreement step of bench.py's make_comm: reached by every rank
+    ok = torch.tensor([1.0 if outcome == "communicator" else 0.0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    with open(os.path.join(out, "rank%d.txt" % rank), "w") as f:
+        f.write("%s|%g" % (outcome, float(ok.item())))
+    dist.destroy_process_group()
+
+
+def test_library_communicator_setup_never_leaves_a_rank_behind(tmp_path):
+    """bench.py's multi-rank path sets the library's RCCL communicator up behind a torch broadcast of rank 0's id; a rank that
+    failed before the broadcast used to leave the others waiting in it.  Without a GPU every rank fails -- and every rank must
+    reach the agreement step and take the torch.distributed fallback together."""
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_libcomm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() for r in range(world)]
+    assert all(g.startswith("raised") and g.endswith("|0") for g in got), got
