@@ -216,7 +216,7 @@ int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t q_end, int3
                              float *dist_out /*host or NULL*/);
 int32_t gorse_topk_synchronize(gorse_topk *h);
 #define GORSE_PROF_TOPK_SCORE 0   /* path A: dist_kernel (pair-at-a-time scan in the reference's order)      */
-#define GORSE_PROF_TOPK_RESCORE 1 /* path A: select_kernel (literal container/heap selection)                 */
+#define GORSE_PROF_TOPK_RESCORE 1 /* path A: select_fast_kernel (+ the literal container/heap select_kernel)    */
 #define GORSE_PROF_TOPK_SWEEP 2   /* path B: topk_sweep_kernel (bf16 MFMA candidate sweep + threshold filter) */
 #define GORSE_PROF_TOPK_SELECT 3  /* path B: topk_rescore_kernel (exact rescoring + ranking of the lists)     */
 #define GORSE_PROF_TOPK_HIST 4    /* path B: history sweep of the queries with ties in their top k+1           */
