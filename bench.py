@@ -12,6 +12,12 @@ Workloads (BASELINE.json configs):
          N*6040 users), Q replicated, one all-reduce of the item-factor delta per epoch over RCCL.
   c3     C3 shard: 125,000 users x 200,000 items x 12.5M feedbacks per rank, nFactors 128 (at N = 8
          this is exactly the 1M x 200K x 100M configuration).
+  c3full C3 whole on ONE GPU: 1M users x 200K items x 100M feedbacks, nFactors 128 (P = 512 MB + Q = 102 MB: outside the
+         256 MiB Infinity Cache).  The default single-GPU line carries it as "c3".
+  big    north_star's "10M x 1M x 128 synthetic set" on ONE GPU: 10M users x 1M items x ~1.0e9 feedbacks (this repo's
+         choice: 100 per user as in C3), nFactors 128 (P = 5.1 GB).  Builder-run (its JSON is kept under profiles/).
+  ml100k C1 shape (943 x 1682 x 99,057), nFactors 16 -- the reference's own default width (model_test.go:35-45); the
+         default line carries it as "ml100k" and, with nFactors 8, as "ml100k_d8".
   topk   C4 alone: item x item cosine top-100 over 1M x 128 bf16 (the default run appends it as "topk").
   als    C5: eALS 500K x 100K x 50M feedbacks, nFactors 64; rows sharded over the ranks (strong scaling), two
          all-gathers of factor row blocks per epoch.
@@ -42,6 +48,7 @@ from gorse_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
+MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA peak = the fp32 vector rate (MI355X_MICROARCH.md: 157.3 TF spec, 155 measured)
 
 
 def measured_traffic(workload):
@@ -64,8 +71,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, choices=["ml1m", "c3", "ml100k", "topk", "als", "i2i"],
-                    help="default: ml1m (C2) on one GPU -- the line then also carries topk (C4), c3, i2i and als objects; c3 on N > 1")
+    ap.add_argument("--workload", default=None, choices=["ml1m", "c3", "c3full", "big", "ml100k", "topk", "als", "i2i"],
+                    help="default: ml1m (C2) on one GPU -- the line then also carries topk (C4), c3 (whole C3), i2i, als and "
+                         "ml100k objects; the C3 shard per rank + sharded topk on N > 1")
+    ap.add_argument("--factors", type=int, default=0, help="nFactors override of a BPR workload")
+    ap.add_argument("--big-draws", type=int, default=1_250_000_000, help="feedback draws of --workload big (about 80 %% remain distinct)")
+    ap.add_argument("--bpr-chunk", type=int, default=0, help="probe: samples per chunk of the BPR pipeline (0 = the library's choice)")
+    ap.add_argument("--sync-steps", type=int, default=3, help="epochs timed through the synchronous gorse_bpr_epoch (0 = skip)")
     ap.add_argument("--comm", default="lib", choices=["lib", "torch"], help="who owns the RCCL communicator of a multi-rank run")
     ap.add_argument("--no-extra", action="store_true", help="default single-GPU run without the c3 / i2i / als objects")
     ap.add_argument("--i2i-shape", default="c3", choices=["c3", "ml1m", "ml100k"])
@@ -80,21 +92,42 @@ def parse():
     return ap.parse_args()
 
 
-def make_data_desc(workload):
-    return {"ml1m": (64, "S-ml1m 6040x3706x994169 per rank (C2), nFactors=64"),
-            "ml100k": (16, "S-ml100k 943x1682x99057 per rank (C1), nFactors=16"),
-            "c3": (128, "S-big shard 125000x200000x12.5M per rank (C3/8), nFactors=128")}[workload]
+BPR_SHAPES = {"ml1m": (64, "S-ml1m 6040x3706x994169 per rank (C2)"),
+              "ml100k": (16, "S-ml100k 943x1682x99057 per rank (C1)"),
+              "c3": (128, "S-big shard 125000x200000x12.5M per rank (C3/8)"),
+              "c3full": (128, "S-big whole 1000000x200000x100M on one GPU (C3)"),
+              "big": (128, "S-huge 10M users x 1M items (north_star's 10M x 1M x 128 set; ~100 feedbacks per user)")}
 
 
-def make_data(workload, rank):
+def make_data_desc(workload, factors=0):
+    d, desc = BPR_SHAPES[workload]
+    d = factors or d
+    return d, "%s, nFactors=%d" % (desc, d)
+
+
+def make_data(workload, rank, args):
+    d, desc = make_data_desc(workload, args.factors)
     if workload == "ml1m":
         data = synth.synth_cf(6040, 3706, 994169, seed=42 + 1000 * rank, min_len=19, n_neg=99, with_test=False)
-        return data, 64, "S-ml1m 6040x3706x994169 per rank (C2), nFactors=64"
-    if workload == "ml100k":
+    elif workload == "ml100k":
         data = synth.synth_cf(943, 1682, 99057, seed=42 + 1000 * rank, min_len=19, n_neg=99, with_test=False)
-        return data, 16, "S-ml100k 943x1682x99057 per rank (C1), nFactors=16"
-    data = synth.s_big_shard(rank=rank, world=8)
-    return data, 128, "S-big shard 125000x200000x12.5M per rank (C3/8), nFactors=128"
+    elif workload == "c3full":
+        data = synth.s_big_full()
+    elif workload == "big":
+        data = synth.s_huge(N=args.big_draws)
+    else:
+        data = synth.s_big_shard(rank=rank, world=8)
+    return data, d, desc
+
+
+def shard_of(full, rank, world):
+    """rank's user shard of a whole data set as its own CFData with both CSR sides (s_big_full lays the shards end to end)"""
+    lo, hi = rank * full.U // world, (rank + 1) * full.U // world
+    uptr, uidx = gdist.shard_csr(full.uptr, full.uidx, lo, hi)
+    rows = np.repeat(np.arange(hi - lo, dtype=np.int64), np.diff(uptr))
+    iptr, iidx = synth._csr_from_pairs(uidx.astype(np.int64), rows, full.I)
+    z, e = np.zeros(hi - lo + 1, np.int64), np.zeros(0, np.int32)
+    return synth.CFData(hi - lo, full.I, uptr, uidx, iptr, iidx, z, e, z.copy(), e.copy())
 
 
 def cpu_baseline(data, d, lr, reg, seconds):
@@ -451,7 +484,14 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
     own = int(uptr[u1] - uptr[u0]) + int(iptr[i1] - iptr[i0])  # gathered rows of this rank's two half-sweeps
     algo = own * d * 4.0 + 2.0 * ((u1 - u0) + (i1 - i0)) * d * 4  # gathers + factor rows read/written
     per_epoch_ms = (sweep_ms + gram_ms) / max(steps, 1)
-    achieved = algo / (per_epoch_ms * 1e-3) / 1e9 if per_epoch_ms > 0 else 0.0
+    hbm_achieved = algo / (per_epoch_ms * 1e-3) / 1e9 if per_epoch_ms > 0 else 0.0
+    # The Gram form does d times the reference's multiply-adds and does them on the fp32 MFMA: per gathered row the upper
+    # triangle of q q^T in 32 x 32 blocks (3 of 4 blocks at nFactors 64).  That, not the gather traffic (the factor matrices
+    # sit in the Infinity Cache), is the roofline this kernel is measured against; the HBM figure stays next to it.
+    nb = (d + 31) // 32
+    macs_per_row = (nb * (nb + 1) // 2) * 32 * 32
+    flops = 2.0 * own * macs_per_row
+    achieved = flops / (per_epoch_ms * 1e-3) / 1e12 if per_epoch_ms > 0 else 0.0
     out = {
         "metric": "ALS feedback entries/sec (nnz per epoch x epochs / time, whole job, N GPUs)",
         "value": n * steps / dt, "unit": "entries/s", "n_gpus": world, "steps": steps,
@@ -460,8 +500,12 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
         "config": {"workload": "S-als %dx%dx%d (C5%s), nFactors=%d, weight=%g reg=%g" % (U, I, n, "" if sc == 1.0 else " x%g" % sc, d, w, reg),
                    "parallelism": "rows sharded x%d, factors replicated, 2 all-gathers((U+I)*d fp32)/epoch over %s" % (world, comm_label)
                    if world > 1 else "single GPU", "factors_finite": bool(np.isfinite(P).all() and np.isfinite(Q).all())},
-        "roofline": {"bound": "hbm", "kernel": "als_row_kernel + als_chunk_kernel (+ S Gram)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "mfma_f32", "kernel": "als_row_kernel + als_chunk_kernel (+ S Gram)", "achieved": achieved,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                     "algorithmic_flop_per_epoch": flops,
+                     "flop_note": "2 flop x gathered rows of both half-sweeps x %d multiply-adds per row (upper triangle of the "
+                                  "Gram update in 32x32 fp32 MFMA blocks)" % macs_per_row,
+                     "hbm_achieved_gbs": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_epoch": algo, "avg_launch_ms": per_epoch_ms, "launches": ns,
                      "sweeps_ms_per_epoch": sweep_ms / max(steps, 1), "gram_ms_per_epoch": gram_ms / max(steps, 1)},
     }
@@ -500,19 +544,22 @@ def make_comm(args, world, rank, local):
     return gdist.TorchComm(), label
 
 
-def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmup, data=None, with_cpu=True):
+def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmup, data=None, with_cpu=True, factors=0):
     """One BPR leg: a step = one epoch = CountFeedback() samples over this rank's resident shard + the item-factor exchange."""
     if data is None:
-        data, d, desc = make_data(workload, rank)
-    else:
-        d, desc = make_data_desc(workload)
+        data = make_data(workload, rank, args)[0]
+    d, desc = make_data_desc(workload, factors or args.factors)
     lr, reg = 0.05, 0.01
     n_samples = data.n_train
+    t_create = time.perf_counter()
     mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, device=local)
-    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, seed=1)  # same Q on every rank
+    t_create = time.perf_counter() - t_create
+    init = synth.init_factors_big if data.U * d >= 1 << 26 else synth.init_factors
+    P0, Q0 = init(data.U, data.I, d, 0.0, 0.001, seed=1)  # same Q on every rank
     if world > 1:
         P0 = synth.init_factors(data.U, 1, d, 0.0, 0.001, seed=100 + rank)[0]
     mf.set_factors(P0, Q0)
+    del P0, Q0
     engine = gdist.HipEngine(mf, args.mode)
     if world > 1:
         if isinstance(comm, gdist.LibComm):
@@ -550,8 +597,17 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
     c_launches, comm_ms = mf.get_profile(capi.PROF_COMM)
     user_runs = args.mode == capi.BPR_HOGWILD_ATOMIC and mf.bpr_user_runs()
     mf.set_profiling(False)
+    # the same epochs through the SYNCHRONOUS entry point (gorse_bpr_epoch: what a Fit loop that evaluates after every epoch
+    # calls): each call drains both streams, so nothing of epoch e + 1 is prepared under epoch e
+    sync_ms = None
+    if world == 1 and args.sync_steps > 0 and args.mode != capi.BPR_SEQUENTIAL:
+        t0 = time.perf_counter()
+        for s in range(args.sync_steps):
+            mf.bpr_epoch(n_samples, lr, reg, 2024, warmup + steps + s + 1, mode=args.mode)
+        sync_ms = (time.perf_counter() - t0) / args.sync_steps * 1e3
     P, Q = mf.get_factors()
     finite = bool(np.isfinite(P).all() and np.isfinite(Q).all())
+    del P, Q
     mf.close()
     if rank != 0:
         return None
@@ -559,6 +615,7 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
     samples_per_launch = steps * n_samples / max(launches, 1)
     avg_ms = upd_ms / max(launches, 1)
     achieved = samples_per_launch * bytes_per_sample / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    ws_mb = (data.U + data.I) * d * 4 / 1e6
     out = {
         "metric": "BPR positive-samples/sec (whole job, N GPUs)",
         "value": world * n_samples * steps / dt,
@@ -571,21 +628,25 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
                    "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode]
                    + (", user runs (triplets counting-sorted by user, p_u register-resident)" if user_runs else
                       (", one group per sample" if args.mode == capi.BPR_HOGWILD_ATOMIC else "")),
+                   "entry_point": "gorse_bpr_epoch_enqueue x steps, one synchronisation at the end (a Fit between two evaluations)",
+                   "sync_entry_point_ms_per_step": sync_ms,
                    "parallelism": "users sharded x%d, item factors replicated, 1 all-reduce(%.1f MB = I*d fp32)/epoch over %s"
-                   % (world, data.I * d * 4 / 1e6, comm_label) if world > 1 else "single GPU", "factors_finite": finite},
+                   % (world, data.I * d * 4 / 1e6, comm_label) if world > 1 else "single GPU", "factors_finite": finite,
+                   "handle_create_seconds": t_create},
         "roofline": {"bound": "hbm", "kernel": "bpr_update_user_kernel" if user_runs else "bpr_update_kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_sample": bytes_per_sample, "avg_launch_ms": avg_ms,
-                     "launches": launches, "sampler_avg_ms": smp_ms / max(s_launches, 1),
+                     "launches": launches, "samples_per_launch": samples_per_launch,
+                     "sampler_avg_ms": smp_ms / max(s_launches, 1),
                      "user_sort_avg_ms": sort_ms / max(o_launches, 1) if o_launches else 0.0,
-                     "note": "working set %.1f MB" % ((data.U + data.I) * d * 4 / 1e6)},
+                     "note": "working set P + Q = %.1f MB (%s the 256 MiB Infinity Cache)" % (ws_mb, "inside" if ws_mb < 268 else "outside")},
     }
     if world > 1:
         out["exchange"] = {"allreduce_avg_ms": comm_ms / max(c_launches, 1) if c_launches else None, "launches": c_launches,
                            "bytes": data.I * d * 4, "path": comm_label}
-    if args.mode == capi.BPR_HOGWILD_ATOMIC and workload in ("ml1m", "c3"):
-        key = {"ml1m": "ml1m_users" if user_runs else "ml1m", "c3": "c3_users"}[workload]
+    if args.mode == capi.BPR_HOGWILD_ATOMIC and workload in ("ml1m", "c3", "c3full", "big") and not (factors or args.factors):
+        key = {"ml1m": "ml1m_users" if user_runs else "ml1m", "c3": "c3_users", "c3full": "c3full_users", "big": "big_users"}[workload]
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(key)
     if world == 1 and with_cpu and not args.no_cpu_baseline:
         try:
@@ -622,6 +683,8 @@ def main():
     torch.cuda.set_device(local)
     # BASELINE.json quotes the single-GPU number on C2 (S-ml1m) and the 8-GPU number on C3: that is what N = 1 / N > 1 run
     workload = args.workload or ("ml1m" if world == 1 else "c3")
+    if args.bpr_chunk:
+        capi.lib().gorse_hip_test_set_bpr_chunk(args.bpr_chunk)
 
     def fence0():
         torch.cuda.synchronize()
@@ -647,19 +710,31 @@ def main():
         return
 
     comm, comm_label = make_comm(args, world, rank, local)
-    out = bench_bpr(args, workload, world, rank, local, comm, comm_label, args.steps, args.warmup)
+    steps, warmup = args.steps, args.warmup
+    if workload in ("c3full", "big") and args.steps == 20 and args.warmup == 3:  # the defaults are sized for a 0.7 ms epoch
+        steps, warmup = (5, 2) if workload == "c3full" else (3, 1)
+    out = bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmup)
     full_line = args.workload is None and world == 1  # the default single-GPU run carries the other configurations too
-    if workload == "ml1m" and not args.no_topk:  # BASELINE.json's metric has two halves; this is the second one
+    # BASELINE.json's metric has two halves; the second one rides on the C2 line of one GPU and on the C3 line of N > 1
+    # (query rows sharded over the ranks, no collective)
+    if ((workload == "ml1m" and world == 1) or (workload == "c3" and world > 1 and args.workload is None)) and not args.no_topk:
         topk = leg(lambda: bench_topk(args, world, rank, local, fence0), "item x item cosine top-100 pairs/sec")
         if rank == 0:
             out["topk"] = topk
     if full_line and not args.no_extra:
-        big = synth.s_big_shard(rank=0, world=8)
-        out["c3"] = leg(lambda: bench_bpr(args, "c3", 1, 0, local, None, "single GPU", 5, 2, data=big, with_cpu=False),
-                        "BPR positive-samples/sec, one C3 shard")
+        full = synth.s_big_full()
+        out["c3"] = leg(lambda: bench_bpr(args, "c3full", 1, 0, local, None, "single GPU", 5, 2, data=full, with_cpu=False),
+                        "BPR positive-samples/sec, C3 whole on one GPU")
+        big = shard_of(full, 0, 8)
+        del full
         out["i2i"] = leg(lambda: bench_sparse(args, 1, 0, local, fence0, data=big, steps=3, warmup=1), "sparse item x item top-100")
         del big
         out["als"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=3, warmup=1), "ALS feedback entries/sec")
+        # the reference's own hyper-parameters (model/cf/model_test.go:35-45: nFactors 16; 8 is the smallest it searches)
+        out["ml100k"] = leg(lambda: bench_bpr(args, "ml100k", 1, 0, local, None, "single GPU", 20, 3, with_cpu=False),
+                            "BPR positive-samples/sec, S-ml100k nFactors 16")
+        out["ml100k_d8"] = leg(lambda: bench_bpr(args, "ml100k", 1, 0, local, None, "single GPU", 20, 3, with_cpu=False, factors=8),
+                               "BPR positive-samples/sec, S-ml100k nFactors 8")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -104,7 +104,7 @@ SIGNATURES = {
     "gorse_hip_test_set_als_path": (None, [C.c_int32]),
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
     "gorse_hip_test_als_profile": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
-    "gorse_hip_test_item_sort": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, _i32p, _i32p, _i32p]),
+    "gorse_hip_test_set_bpr_chunk": (None, [C.c_int64]),
 }
 
 
@@ -226,13 +226,6 @@ class MF:
         if not (u.size == i.size == j.size):
             raise GorseHipError(ERR_INVALID, "triplet arrays differ in length")
         check(lib().gorse_bpr_apply_triplets(self.h, _p(u, _i32p), _p(i, _i32p), _p(j, _i32p), u.size, lr, reg, mode))
-
-    def test_item_sort(self, u, i, j):
-        u, i, j = _arr(u, np.int32), _arr(i, np.int32), _arr(j, np.int32)
-        su, si, sj = np.empty_like(u), np.empty_like(i), np.empty_like(j)
-        check(lib().gorse_hip_test_item_sort(self.h, _p(u, _i32p), _p(i, _i32p), _p(j, _i32p), u.size, _p(su, _i32p),
-                                             _p(si, _i32p), _p(sj, _i32p)))
-        return su, si, sj
 
     def als_epoch(self, weight, reg, cancel=None):
         cp = _p(cancel, _i32p) if cancel is not None else None

@@ -3,17 +3,16 @@
 // Kernels per chunk of samples:
 //   bpr_sample_kernel      : model.go:449-468 -- one thread per sample draws (u, i, j) from a
 //                            counter-based Philox stream; runs AHEAD on its own stream.
-//   bpr_rank/scan/scatter  : counting sort of the chunk's triplets by positive item i (the order in
-//                            which a Hogwild epoch applies its samples is free: parallel.go:44-68).
-//   bpr_update_runs_kernel : model.go:469-488 -- one 16-lane group walks a block of consecutive
-//                            SORTED samples; the positive item's row q_i stays in registers across a
-//                            run of equal i (sequential SGD on q_i inside the run, ONE atomic flush of
-//                            its delta per run), p_u and q_j are gathered per sample (64-byte contiguous
-//                            segments per load) and updated with fp32 atomics.  Popularity-skewed
-//                            positive items therefore never serialise on one L2 channel.
-//   bpr_update_kernel      : the per-sample form (one group per sample, three rows updated in place):
-//                            the sequential parity schedule, the racy diagnostic, and the round-1
-//                            atomic schedule kept for A/B probes.
+//   scan + scatter         : counting sort of the chunk's triplets by USER (the order in which a Hogwild epoch
+//                            applies its samples is free: parallel.go:44-68); the sampler has already counted the
+//                            runs and ranked every sample inside its run.
+//   bpr_update_user_kernel : model.go:469-488 -- one 16-lane group applies ALL samples of one user: p_u is loaded
+//                            once, updated in registers and stored once; q_i / q_j are gathered ahead (64-byte
+//                            contiguous segments per load) and updated with fp32 atomics, hot positive items through
+//                            replica rows.
+//   bpr_update_kernel      : the per-sample form (one group per sample, three rows updated in place): the
+//                            sequential parity schedule, the racy diagnostic, and the Hogwild schedule of shapes
+//                            with few users or a factor width outside 16/32/64/128.
 // HBM-bound: algorithmic bytes per sample = 6*d*4 (three rows read + three written) + 12 (indices).
 #include <algorithm>
 #include <cstdlib>
@@ -275,25 +274,15 @@ __global__ __launch_bounds__(256) void bpr_fold_kernel(HotRows hot, float *Q, in
     }
 }
 
-// ---- item-run schedule: counting sort by (window, positive item) ---------------------------------
-// The chunk is cut into WINDOWS of `window` consecutive samples (sampler order) and each window is
-// sorted by its positive item.  The update kernel walks the sorted array front to back with a fixed
-// number of resident groups, so what runs concurrently is a slice of ONE window (two at a seam):
-// a popular item gets at most share_i * window updates from one stale view of its row, the same
-// staleness bound the per-sample kernel had from its residency, while inside a window every run of
-// equal items is applied sequentially in registers.  (Sorting the whole chunk by item would apply all
-// of an item's updates of the epoch at once from one stale view: measured divergence on S-ml1m.)
+// ---- counting sort by user ---------------------------------------------------------------------
 constexpr int kScanTile = 2048;  // elements per workgroup of the scan (256 threads x 8)
 
-__device__ __forceinline__ int64_t sort_bucket(int32_t i, int32_t I, int64_t s, int wshift) {
-    const int32_t key = i < 0 ? I : i;  // skipped samples sort behind every item of their window
-    return (s >> wshift) * ((int64_t)I + 1) + key;
-}
-
-__global__ __launch_bounds__(256) void bpr_rank_kernel(const int32_t *__restrict__ is, int64_t n, int32_t I, int wshift,
+// first pass of the counting sort for callers whose sampler did not rank (gorse_bpr_apply_triplets, the stable-rank test hook):
+// rank[s] = arrival rank of sample s among the samples of its key; keys < 0 (skipped samples) count under key K
+__global__ __launch_bounds__(256) void bpr_rank_kernel(const int32_t *__restrict__ key, int64_t n, int32_t K,
                                                        int32_t *__restrict__ bucket, int32_t *__restrict__ rank) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x)
-        rank[s] = atomicAdd(&bucket[sort_bucket(is[s], I, s, wshift)], 1);
+        rank[s] = atomicAdd(&bucket[key[s] < 0 ? K : key[s]], 1);
 }
 
 // exclusive scan of data[0..m) in place, three launches: tile sums, scan of the tile sums, tile rescans
@@ -358,20 +347,6 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(int32_t *__restrict__ d
     }
 }
 
-__global__ __launch_bounds__(256) void bpr_scatter_kernel(const int32_t *__restrict__ us, const int32_t *__restrict__ is,
-                                                          const int32_t *__restrict__ js, int64_t n, int32_t I,
-                                                          int wshift, const int32_t *__restrict__ bucket,
-                                                          const int32_t *__restrict__ rank, int32_t *__restrict__ su,
-                                                          int32_t *__restrict__ si, int32_t *__restrict__ sj) {
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t i = is[s];
-        const int64_t pos = (int64_t)bucket[sort_bucket(i, I, s, wshift)] + rank[s];
-        su[pos] = us[s];
-        si[pos] = i;
-        sj[pos] = js[s];
-    }
-}
-
 
 // scatter by an arbitrary key array (one window): keys < 0 sort behind every real key
 __global__ __launch_bounds__(256) void bpr_scatter_by_kernel(const int32_t *__restrict__ key, const int32_t *__restrict__ us,
@@ -387,129 +362,6 @@ __global__ __launch_bounds__(256) void bpr_scatter_by_kernel(const int32_t *__re
         sj[pos] = js[s];
     }
 }
-
-// ---- item-run update ------------------------------------------------------------------------------
-// A group owns `blk` consecutive positions of the item-sorted triplet arrays at a time.  The indices of
-// one batch are loaded coalesced (lane l holds position base + l) and broadcast inside the 16-lane row.
-template <int NC>
-__global__ __launch_bounds__(kBlock) void bpr_update_runs_kernel(float *P, float *Q, const int32_t *__restrict__ su,
-                                                                 const int32_t *__restrict__ si,
-                                                                 const int32_t *__restrict__ sj, int64_t n, int blk,
-                                                                 int d, float lr, float reg, double *loss,
-                                                                 int variant) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & (kGroup - 1);
-    const int gib = threadIdx.x / kGroup;
-    const int64_t group = (int64_t)blockIdx.x * kGroupsPerBlock + gib;
-    const int64_t ngroups = (int64_t)gridDim.x * kGroupsPerBlock;
-    const int64_t span = blk;                              // consecutive sorted positions per group block
-    const int batches = blk < kGroup ? 1 : blk / kGroup;  // index loads: up to 16 positions at a time
-    const int per = blk < kGroup ? blk : kGroup;
-    const VecShape vs(d);
-    const float nreg = -reg;
-    double my_loss = 0.0;
-    // generic-d path: q_i | q_i at load time | p_u | q_j per group in LDS
-    float *sa = smem + (size_t)gib * 4 * d, *sa0 = sa + d, *sp = sa0 + d, *sb = sp + d;
-    for (int64_t base = group * span; base < n; base += ngroups * span) {
-        int cur = -1;
-        float a[NC > 0 ? NC : 1], a0[NC > 0 ? NC : 1];
-        for (int bt = 0; bt < batches; bt++) {
-            const int64_t pos0 = base + (int64_t)bt * kGroup;
-            if (pos0 >= n) break;
-            const int cntv = n - pos0 < per ? (int)(n - pos0) : per;
-            int mu = -1, mi = -1, mj = -1;
-            if (lane < cntv) {
-                mu = su[pos0 + lane];
-                mi = si[pos0 + lane];
-                mj = sj[pos0 + lane];
-            }
-            for (int t = 0; t < cntv; t++) {
-                const int u = __shfl(mu, t, kGroup), i = __shfl(mi, t, kGroup), j = __shfl(mj, t, kGroup);
-                if ((u | i | j) < 0) continue;
-                float *pu = P + (int64_t)u * d, *qj = Q + (int64_t)j * d;
-                if (i != cur) {
-                    if (cur >= 0 && !(variant & 4)) {  // flush the finished run: Q[cur] += (q - q at load time)
-                        float *qc = Q + (int64_t)cur * d;
-                        if constexpr (NC > 0) {
-#pragma unroll
-                            for (int c = 0; c < NC; c++)
-                                __hip_atomic_fetch_add(qc + 16 * c + lane, a[c] - a0[c], __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            for (int e = lane; e < d; e += kGroup)
-                                __hip_atomic_fetch_add(qc + e, sa[e] - sa0[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                    const float *qi = Q + (int64_t)i * d;
-                    if constexpr (NC > 0) {
-#pragma unroll
-                        for (int c = 0; c < NC; c++) a0[c] = a[c] = load_row<MODE_ATOMIC>(qi + 16 * c + lane, variant);
-                    } else {
-                        for (int e = lane; e < d; e += kGroup) sa0[e] = sa[e] = load_row<MODE_ATOMIC>(qi + e, variant);
-                    }
-                    cur = i;
-                }
-                if constexpr (NC > 0) {
-                    float p[NC], b[NC];
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane, variant);
-                        b[c] = load_row<MODE_ATOMIC>(qj + 16 * c + lane, variant);
-                    }
-                    const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
-                    const float ex = expf(-diff);
-                    const float grad = ex / (1.0f + ex);
-                    if (loss && lane == 0) my_loss += (double)log1pf(ex);
-#pragma unroll
-                    for (int c = 0; c < NC; c++) {
-                        const int e = 16 * c + lane;
-                        float t1 = fmaf(a[c], nreg, p[c] * grad);
-                        float t2 = fmaf(b[c], nreg, p[c] * (-grad));
-                        float t3 = fmaf(p[c], nreg, (a[c] - b[c]) * grad);
-                        a[c] = fmaf(t1, lr, a[c]);
-                        if (!(variant & 8)) __hip_atomic_fetch_add(qj + e, t2 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!(variant & 2)) __hip_atomic_fetch_add(pu + e, t3 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                } else {
-                    for (int e = lane; e < d; e += kGroup) {
-                        sp[e] = load_row<MODE_ATOMIC>(pu + e);
-                        sb[e] = load_row<MODE_ATOMIC>(qj + e);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const float diff = dot512_lds(sp, sa, vs, lane) - dot512_lds(sp, sb, vs, lane);
-                    const float ex = expf(-diff);
-                    const float grad = ex / (1.0f + ex);
-                    if (loss && lane == 0) my_loss += (double)log1pf(ex);
-                    __builtin_amdgcn_wave_barrier();
-                    for (int e = lane; e < d; e += kGroup) {
-                        const float pe = sp[e], ae = sa[e], be = sb[e];
-                        float t1 = fmaf(ae, nreg, pe * grad);
-                        float t2 = fmaf(be, nreg, pe * (-grad));
-                        float t3 = fmaf(pe, nreg, (ae - be) * grad);
-                        sa[e] = fmaf(t1, lr, ae);
-                        __hip_atomic_fetch_add(qj + e, t2 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(pu + e, t3 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-        if (cur >= 0 && !(variant & 4)) {
-            float *qc = Q + (int64_t)cur * d;
-            if constexpr (NC > 0) {
-#pragma unroll
-                for (int c = 0; c < NC; c++)
-                    __hip_atomic_fetch_add(qc + 16 * c + lane, a[c] - a0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                for (int e = lane; e < d; e += kGroup)
-                    __hip_atomic_fetch_add(qc + e, sa[e] - sa0[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
-}
-
 
 // ---- user-run schedule ---------------------------------------------------------------------------
 // The chunk's triplets are counting-sorted by USER (the order in which a Hogwild epoch applies its samples is free:
@@ -617,75 +469,8 @@ int32_t exclusive_scan_i32(int32_t *data, int64_t m, int32_t *tmp, hipStream_t s
     return GORSE_OK;
 }
 
-// log2 of the sort window: the staleness bound of the schedule (see above).  32768 samples matches the
-// residency-bounded window of the per-sample kernel (8192 resident waves x 4 samples).
-int window_shift() {
-    const int ov = (g_variant >> 12) & 31;
-    return ov > 0 ? ov : 15;
-}
-int64_t sort_buckets(const gorse_mf *h, int64_t n) { return ceil_div(n, (int64_t)1 << window_shift()) * (h->I + 1); }
 
-// counting sort of the chunk in `trip` (us | is | js, stride cap) into `sorted` (su | si | sj, stride cap)
-int32_t launch_item_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int64_t n, size_t cap, hipStream_t st) {
-    const int wshift = window_shift();
-    const int64_t m = sort_buckets(h, n);
-    if ((size_t)m > h->bucket.n) return fail(GORSE_ERR_INVALID, "sort bucket array too small");
-    GORSE_HIP_CHECK(hipMemsetAsync(h->bucket.p, 0, (size_t)m * sizeof(int32_t), st));
-    const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
-    bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip + cap, n, (int32_t)h->I, wshift, h->bucket.p,
-                                                                 h->rank.p);
-    GORSE_TRY(exclusive_scan_i32(h->bucket.p, m, h->scan_tmp.p, st));
-    bpr_scatter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, trip + cap, trip + 2 * cap, n, (int32_t)h->I,
-                                                                    wshift, h->bucket.p, h->rank.p, sorted, sorted + cap,
-                                                                    sorted + 2 * cap);
-    GORSE_HIP_CHECK(hipGetLastError());
-    return GORSE_OK;
-}
-
-// Positions per group block and resident workgroups.  Their product (x 16 groups) is the SPAN of sorted
-// positions being applied concurrently: every group sees its positive row only as of its block start, so
-// a popular item receives up to share_i * span updates computed from views that miss each other.  32768
-// (block 4 x 8192 groups) reproduces the bound the per-sample kernel had from residency; measured on
-// S-ml1m (lr 0.05): span 131072 diverges, 32768 matches the sequential oracle's NDCG.
-int run_block() {
-    const int ov = (g_variant >> 8) & 15;
-    return ov > 0 ? 1 << (ov - 1) : 4;
-}
-int64_t run_workgroups() {
-    const int ov = (g_variant >> 20) & 15;
-    return ov > 0 ? (int64_t)1 << ov : 512;
-}
-
-int32_t launch_update_runs(gorse_mf *h, const int32_t *sorted, size_t cap, int64_t n, float lr, float reg, double *loss,
-                           hipStream_t st) {
-    if (n <= 0) return GORSE_OK;
-    const int d = h->d;
-    const int blk = run_block();
-    int64_t blocks = ceil_div(ceil_div(n, (int64_t)blk), kGroupsPerBlock);
-    // every workgroup is resident from the start (2 per CU), so the array is walked front to back
-    const int64_t cap_blocks = run_workgroups();
-    if (blocks > cap_blocks) blocks = cap_blocks;
-    dim3 grid((unsigned)blocks), block(kBlock);
-#define LAUNCH(NC, SH)                                                                                          \
-    bpr_update_runs_kernel<NC><<<grid, block, SH, st>>>(h->P.p, h->Q.p, sorted, sorted + cap, sorted + 2 * cap, n, \
-                                                        blk, d, lr, reg, loss, g_variant)
-    if (d == 16)
-        LAUNCH(1, 0);
-    else if (d == 32)
-        LAUNCH(2, 0);
-    else if (d == 64)
-        LAUNCH(4, 0);
-    else if (d == 128)
-        LAUNCH(8, 0);
-    else
-        LAUNCH(0, (size_t)kGroupsPerBlock * 4 * d * sizeof(float));
-#undef LAUNCH
-    GORSE_HIP_CHECK(hipGetLastError());
-    return GORSE_OK;
-}
-
-
-// counting sort of the chunk by user: `sorted` receives su | si | sj, h->bucket[0..U] the run offsets
+// counting sort of the chunk by user: `sorted` receives su | si | sj, bucket[0..U] the run offsets
 // ranked: the sampler already counted the runs into `bucket` and wrote every sample's rank (launch_sampler with a bucket)
 int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int32_t *bucket, int32_t *rank, int64_t n, size_t cap,
                          hipStream_t st, bool ranked) {
@@ -693,12 +478,12 @@ int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int3
     const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
     if (!ranked) {
         GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)m * sizeof(int32_t), st));
-        // one window (shift 62): key = user, skipped samples (u < 0) get key U
+        // key = user, skipped samples (u < 0) get key U
         // test hook (variant bit 29): one thread ranks the samples in stream order -> every run keeps the stream's order
         if (g_variant & (1 << 29))
-            bpr_rank_kernel<<<dim3(1), dim3(1), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, rank);
+            bpr_rank_kernel<<<dim3(1), dim3(1), 0, st>>>(trip, n, (int32_t)h->U, bucket, rank);
         else
-            bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, n, (int32_t)h->U, 62, bucket, rank);
+            bpr_rank_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, n, (int32_t)h->U, bucket, rank);
     }
     GORSE_TRY(exclusive_scan_i32(bucket, m, h->scan_tmp2.p, st));
     bpr_scatter_by_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(trip, trip, trip + cap, trip + 2 * cap, n,
@@ -830,24 +615,23 @@ int32_t launch_sampler(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base,
     return GORSE_OK;
 }
 
+// Samples per chunk.  The user-run schedule loads p_u once per RUN (a user's samples inside one chunk), so a chunk should hold
+// a few dozen samples per user: 4M samples serve the S-ml1m and C3-shard shapes (<= 125K users); the full C3 set (1M users)
+// takes 32M, the 10M-user set 128M -- 52 bytes of triplet / sort buffers per sample of capacity, 6.7 GB of the 288 at most.
+int64_t g_chunk_override = 0;  // probe: gorse_hip_test_set_bpr_chunk
+int64_t chunk_capacity(const gorse_mf *h) {
+    if (g_chunk_override > 0) return g_chunk_override;
+    const int64_t lo = (int64_t)1 << 22, hi = (int64_t)1 << 27;
+    return std::min(std::max(lo, 32 * h->U), hi);
+}
+
 int32_t ensure_trip(gorse_mf *h, int64_t want) {
-    size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)1 << 22);
+    size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(want, 1), chunk_capacity(h));
     if (cap <= h->trip_cap) return GORSE_OK;
     GORSE_TRY(mf_sync_streams(h));
     for (int b = 0; b < 2; b++) GORSE_TRY(h->trip[b].alloc(cap * 3));
     for (int b = 0; b < 2; b++) GORSE_TRY(h->sorted[b].alloc(cap * 3));
-    GORSE_TRY(h->rank.alloc(cap));
     h->trip_cap = cap;
-    return GORSE_OK;
-}
-
-// counters of the counting sort: one per (window, item) of a full chunk
-int32_t ensure_sort(gorse_mf *h) {
-    const int64_t m = sort_buckets(h, (int64_t)h->trip_cap);
-    if ((size_t)m <= h->bucket.n) return GORSE_OK;
-    GORSE_TRY(mf_sync_streams(h));
-    GORSE_TRY(h->bucket.alloc((size_t)m));
-    GORSE_TRY(h->scan_tmp.alloc((size_t)ceil_div(m, kScanTile)));
     return GORSE_OK;
 }
 
@@ -948,9 +732,7 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
     } else {
         // two-stream pipeline: stream2 samples (and item-sorts) chunk c+1 while stream applies chunk c; the
         // buffer parity runs on across calls so that back-to-back enqueued epochs overlap as well
-        const bool runs = mode == MODE_ATOMIC && (g_variant & 64);
-        const bool uruns = mode == MODE_ATOMIC && !runs && user_runs_enabled() && user_runs_supported(h);
-        if (runs) GORSE_TRY(ensure_sort(h));
+        const bool uruns = mode == MODE_ATOMIC && user_runs_enabled() && user_runs_supported(h);
         if (uruns) GORSE_TRY(ensure_user_sort(h));
         int64_t c = 0;
         for (int64_t s0 = 0; s0 < n_samples; s0 += cap, c++) {
@@ -978,11 +760,6 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
                 GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, h->stream2, true));
                 h->prof.end(tok, h->stream2);
             }
-            if (runs) {
-                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
-                GORSE_TRY(launch_item_sort(h, tb, h->sorted[b].p, m, (size_t)cap, h->stream2));
-                h->prof.end(tok, h->stream2);
-            }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
             if (uruns && !fused) {
@@ -993,8 +770,6 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             tok = h->prof.begin(GORSE_PROF_BPR_UPDATE, h->stream);
             if (uruns)
                 GORSE_TRY(launch_update_users(h, h->sorted[b].p, h->ubucket[b].p, (size_t)cap, lr, reg, g_exp_mode_exact, d_loss, h->stream));
-            else if (runs)
-                GORSE_TRY(launch_update_runs(h, h->sorted[b].p, (size_t)cap, m, lr, reg, d_loss, h->stream));
             else
                 GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, d_loss, h->stream));
             h->prof.end(tok, h->stream);
@@ -1016,35 +791,11 @@ extern "C" void gorse_hip_test_set_exact_exp(int32_t mode) { g_exp_mode_exact = 
 
 extern "C" int32_t gorse_mf_bpr_schedule(gorse_mf *h, int32_t *user_runs) {
     if (!h || !user_runs) return fail(GORSE_ERR_INVALID, "NULL argument");
-    *user_runs = (!(g_variant & 64) && user_runs_enabled() && user_runs_supported(h)) ? 1 : 0;
+    *user_runs = (user_runs_enabled() && user_runs_supported(h)) ? 1 : 0;
     return GORSE_OK;
 }
 extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
-
-// test hook: the counting sort of the item-run schedule on a host-supplied chunk
-extern "C" int32_t gorse_hip_test_item_sort(gorse_mf *h, const int32_t *u, const int32_t *i, const int32_t *j, int64_t n,
-                                            int32_t *su, int32_t *si, int32_t *sj) {
-    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
-    if (n <= 0 || !u || !i || !j || !su || !si || !sj) return fail(GORSE_ERR_INVALID, "bad arguments");
-    for (int64_t s = 0; s < n; s++)
-        if (i[s] >= h->I) return fail(GORSE_ERR_RANGE, "item %d out of range", i[s]);
-    GORSE_TRY(h->use());
-    GORSE_TRY(ensure_trip(h, n));
-    if ((size_t)n > h->trip_cap) return fail(GORSE_ERR_INVALID, "n exceeds one chunk (%zu)", h->trip_cap);
-    GORSE_TRY(mf_sync_streams(h));
-    GORSE_TRY(ensure_sort(h));
-    const size_t cap = h->trip_cap;
-    int32_t *tb = h->trip[0].p, *sb = h->sorted[0].p;
-    GORSE_HIP_CHECK(hipMemcpyAsync(tb, u, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    GORSE_HIP_CHECK(hipMemcpyAsync(tb + cap, i, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    GORSE_HIP_CHECK(hipMemcpyAsync(tb + 2 * cap, j, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-    GORSE_TRY(launch_item_sort(h, tb, sb, n, cap, h->stream));
-    GORSE_HIP_CHECK(hipMemcpyAsync(su, sb, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    GORSE_HIP_CHECK(hipMemcpyAsync(si, sb + cap, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    GORSE_HIP_CHECK(hipMemcpyAsync(sj, sb + 2 * cap, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
-    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-    return GORSE_OK;
-}
+extern "C" void gorse_hip_test_set_bpr_chunk(int64_t samples) { g_chunk_override = samples; }
 
 extern "C" int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
                                    int64_t sample_base, int32_t mode, const volatile int32_t *cancel, double *loss_out) {
@@ -1100,16 +851,11 @@ extern "C" int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u, const
         if (mode == MODE_EXACT) {
             GORSE_TRY(run_sequential(h, tb, tb + cap, tb + 2 * cap, u + s0, i + s0, j + s0, m, lr, reg, g_exp_mode_exact,
                                      nullptr, nullptr));
-        } else if (mode == MODE_ATOMIC && !(g_variant & 64) && user_runs_enabled() && user_runs_supported(h)) {
+        } else if (mode == MODE_ATOMIC && user_runs_enabled() && user_runs_supported(h)) {
             GORSE_TRY(ensure_user_sort(h));
             GORSE_TRY(launch_user_sort(h, tb, h->sorted[0].p, h->ubucket[0].p, h->urank[0].p, m, (size_t)cap, h->stream, false));
             GORSE_TRY(launch_update_users(h, h->sorted[0].p, h->ubucket[0].p, (size_t)cap, lr, reg, g_exp_mode_exact, nullptr,
                                           h->stream));
-            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-        } else if (mode == MODE_ATOMIC && (g_variant & 64)) {
-            GORSE_TRY(ensure_sort(h));
-            GORSE_TRY(launch_item_sort(h, tb, h->sorted[0].p, m, (size_t)cap, h->stream));
-            GORSE_TRY(launch_update_runs(h, h->sorted[0].p, (size_t)cap, m, lr, reg, nullptr, h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         } else {
             GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, nullptr, h->stream));

@@ -6,8 +6,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gorse_hip.h"
@@ -189,5 +191,31 @@ struct Philox {
 constexpr int kMaxDraws = 4096;  // per-sample retry cap (the reference spins forever)
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Host-side one-off passes over a dataset (row sorts, validation, counting) split over the host's cores: a Fit of the
+// 10M x 1M set hands over 1e9 feedback entries, and a single thread spends most of a minute on them.  fn(t, begin, end)
+// works on rows [begin, end); `weight` (may be null) is the CSR row pointer the cut points are balanced by.
+template <typename F>
+inline void parallel_rows(int64_t rows, const int64_t *weight, F fn) {
+    const int64_t work = weight ? weight[rows] - weight[0] : rows;
+    int nt = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 64);
+    if (work < (int64_t)1 << 22 || rows < 2 * nt) nt = 1;
+    if (nt == 1) {
+        fn(0, (int64_t)0, rows);
+        return;
+    }
+    std::vector<int64_t> cut((size_t)nt + 1, rows);
+    cut[0] = 0;
+    for (int t = 1; t < nt; t++) {
+        if (weight)
+            cut[t] = std::lower_bound(weight, weight + rows + 1, weight[0] + work * t / nt) - weight;
+        else
+            cut[t] = rows * t / nt;
+        cut[t] = std::min(std::max(cut[t], cut[t - 1]), rows);
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++) th.emplace_back([&, t] { fn(t, cut[t], cut[t + 1]); });
+    for (auto &x : th) x.join();
+}
 
 }  // namespace gorse

@@ -24,23 +24,33 @@ extern "C" int32_t gorse_hip_device_count(int32_t *n) {
 
 namespace {
 
-// each CSR row sorted ascending, on the host (one-off at create time)
+// each CSR row sorted ascending, on the host (one-off at create time; the rows are cut over the host's cores)
 void sort_rows(const int64_t *ptr, const int32_t *idx, int64_t rows, std::vector<int32_t> &out) {
-    out.assign(idx, idx + ptr[rows]);
-    for (int64_t r = 0; r < rows; r++) {
-        int32_t *b = out.data() + ptr[r], *e = out.data() + ptr[r + 1];
-        // rows are short on average; insertion sort for tiny rows, std::sort otherwise
-        if (e - b > 1) std::sort(b, e);
-    }
+    out.resize((size_t)ptr[rows]);
+    parallel_rows(rows, ptr, [&](int, int64_t r0, int64_t r1) {
+        std::copy(idx + ptr[r0], idx + ptr[r1], out.data() + ptr[r0]);
+        for (int64_t r = r0; r < r1; r++) {
+            int32_t *b = out.data() + ptr[r], *e = out.data() + ptr[r + 1];
+            if (e - b > 1) std::sort(b, e);
+        }
+    });
 }
 
 int32_t validate_csr(const char *name, const int64_t *ptr, const int32_t *idx, int64_t rows, int64_t cols) {
     if (ptr[0] != 0) return fail(GORSE_ERR_INVALID, "%s_indptr[0] != 0", name);
     for (int64_t r = 0; r < rows; r++)
         if (ptr[r + 1] < ptr[r]) return fail(GORSE_ERR_INVALID, "%s_indptr not monotone at row %lld", name, (long long)r);
-    for (int64_t t = 0; t < ptr[rows]; t++)
-        if (idx[t] < 0 || idx[t] >= cols)
-            return fail(GORSE_ERR_INVALID, "%s_indices[%lld] = %d out of range [0,%lld)", name, (long long)t, idx[t],
+    std::vector<int64_t> bad(64, -1);  // first offending entry seen by each worker
+    parallel_rows(rows, ptr, [&](int t, int64_t r0, int64_t r1) {
+        for (int64_t e = ptr[r0]; e < ptr[r1]; e++)
+            if (idx[e] < 0 || idx[e] >= cols) {
+                bad[(size_t)t] = e;
+                return;
+            }
+    });
+    for (int64_t e : bad)
+        if (e >= 0)
+            return fail(GORSE_ERR_INVALID, "%s_indices[%lld] = %d out of range [0,%lld)", name, (long long)e, idx[e],
                         (long long)cols);
     return GORSE_OK;
 }
@@ -259,7 +269,19 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
         }
         {   // hot items: share of the training feedback >= 1/2048, at most 1024 of them (bpr.hip, HotRows)
             std::vector<int64_t> cnt((size_t)I, 0);
-            for (int64_t t = 0; t < h->nnz; t++) cnt[user_indices[t]]++;
+            if (h->nnz < ((int64_t)1 << 26) || I > ((int64_t)1 << 22)) {
+                for (int64_t t = 0; t < h->nnz; t++) cnt[user_indices[t]]++;
+            } else {  // a billion entries: per-worker counters, added up afterwards
+                std::vector<std::vector<int32_t>> part(64);
+                parallel_rows(U, user_indptr, [&](int t, int64_t r0, int64_t r1) {
+                    part[(size_t)t].assign((size_t)I, 0);
+                    int32_t *c = part[(size_t)t].data();
+                    for (int64_t e = user_indptr[r0]; e < user_indptr[r1]; e++) c[user_indices[e]]++;
+                });
+                for (auto &pc : part)
+                    if (!pc.empty())
+                        for (int64_t i = 0; i < I; i++) cnt[(size_t)i] += pc[(size_t)i];
+            }
             const int64_t thr = std::max<int64_t>(2, (h->nnz + 2047) / 2048);
             std::vector<int32_t> hot;
             for (int64_t i = 0; i < I; i++)

@@ -20,14 +20,11 @@ struct gorse_mf {
     // BPR triplet chunk buffers (double-buffered: sampler fills one while the other is applied)
     gorse::DevBuf<int32_t> trip[2];
     size_t trip_cap = 0;  // samples per buffer
-    // item-run schedule (bpr.hip): the chunk's triplets counting-sorted by positive item
+    // user-run schedule (bpr.hip): the chunk's triplets counting-sorted by user
     gorse::DevBuf<int32_t> sorted[2];  // su | si | sj, each trip_cap long
-    gorse::DevBuf<int32_t> rank;       // arrival rank of a sample inside its (item, copy) bucket
-    gorse::DevBuf<int32_t> bucket;     // (I+1) * kSortCopies counters -> exclusive offsets after the scan
-    gorse::DevBuf<int32_t> ubucket[2]; // user-run schedule: U + 2 run offsets per triplet buffer (sorted on stream2)
-    gorse::DevBuf<int32_t> urank[2];   // user-run schedule: arrival rank of a sample inside its user's run, per triplet buffer
-    gorse::DevBuf<int32_t> scan_tmp;   // per-tile sums of the scan
-    gorse::DevBuf<int32_t> scan_tmp2;  // the same for the user sort, which may run on the sampler stream
+    gorse::DevBuf<int32_t> ubucket[2]; // U + 2 run offsets per triplet buffer (sorted on stream2)
+    gorse::DevBuf<int32_t> urank[2];   // arrival rank of a sample inside its user's run, per triplet buffer
+    gorse::DevBuf<int32_t> scan_tmp2;  // per-tile sums of the sort's scan (the sort may run on the sampler stream)
     int64_t chunk_seq = 0;             // chunks enqueued so far: buffer = chunk_seq & 1, across calls
     // hot-row replicas of the Hogwild schedule (bpr.hip): popular items' positive updates land here
     gorse::DevBuf<int32_t> hot_slot, hot_items, hot_done;

@@ -273,7 +273,14 @@ Score BPR::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitCo
     // schedule; Jobs > 1: Hogwild workers -> the atomic Hogwild schedule.
     const int mode = config.Jobs <= 1 ? GORSE_BPR_SEQUENTIAL : GORSE_BPR_HOGWILD_ATOMIC;
     const int64_t n = trainSet.CountFeedback();
+    // Between two evaluations the epochs are only enqueued: the sampler and the counting sort of epoch e + 1 run under the
+    // update kernel of epoch e.  The epoch in front of an evaluation (and every sequential epoch) is the synchronous call,
+    // which also polls the cancel flag.
     return fit_loop("bpr", nEpochs, trainSet, valSet, config, [&](int epoch) {
+        const bool eval_next = epoch % config.Verbose == 0 || epoch == nEpochs;
+        const bool cancelled = config.Cancel && *config.Cancel;
+        if (!eval_next && mode != GORSE_BPR_SEQUENTIAL && !cancelled && !config.OnEpoch)
+            return gorse_bpr_epoch_enqueue(h_, n, lr, reg, seed, (uint64_t)epoch, 0, mode);
         return gorse_bpr_epoch(h_, n, lr, reg, seed, (uint64_t)epoch, 0, mode, config.Cancel, nullptr);
     });
 }

@@ -7,6 +7,9 @@ pairs, one held-out positive per user plus `n_neg` fixed negatives (the NCF test
 dataset/dataset.go:466-490).  All randomness is numpy's PCG64 seeded explicitly, so the
 same arrays are produced here and on the GPU box.
 """
+import os
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+
 import numpy as np
 
 
@@ -159,6 +162,157 @@ def s_ml1m():
 def s_big_shard(rank=0, world=8, U_total=1_000_000, I=200_000, N_total=100_000_000, seed=43):
     """One rank's user shard of S-big (C3): U_total/world users, N_total/world feedbacks, all I items."""
     return synth_cf(U_total // world, I, N_total // world, seed=seed + 1000 * rank, min_len=1, n_neg=99, with_test=False)
+
+
+def _shard_arrays(args):
+    rank, world, U_total, I, N_total, seed = args
+    d = s_big_shard(rank, world, U_total, I, N_total, seed)
+    return d.uptr, d.uidx
+
+
+def _cache_dir():
+    d = os.environ.get("GORSE_SYNTH_CACHE", os.path.join("/tmp", "gorse_synth_cache_%d" % os.getuid()))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def s_big_full(world=8, U_total=1_000_000, I=200_000, N_total=100_000_000, seed=43, cache=True):
+    """S-big whole (BASELINE config C3 on ONE GPU): the `world` user shards of s_big_shard laid end to end -- users
+    [r * U_total / world, (r + 1) * U_total / world) are exactly rank r's shard, so the single-GPU run and the 8-rank run train
+    on the same feedback.  The shards are generated in parallel processes; the result (400 MB) is kept under
+    $GORSE_SYNTH_CACHE (default /tmp) so that bench.py and the tests of one session generate it once.  User-major CSR only."""
+    key = os.path.join(_cache_dir(), "sbig_full_w%d_u%d_i%d_n%d_s%d_np%s.npz" % (world, U_total, I, N_total, seed, np.__version__))
+    if cache and os.path.exists(key):
+        z = np.load(key)
+        uptr, uidx = z["uptr"], z["uidx"]
+    else:
+        jobs = [(r, world, U_total, I, N_total, seed) for r in range(world)]
+        with ProcessPoolExecutor(max_workers=min(world, os.cpu_count() or 1)) as ex:
+            parts = list(ex.map(_shard_arrays, jobs))
+        lens = np.concatenate([np.diff(p[0]) for p in parts])
+        uptr = np.zeros(lens.size + 1, np.int64)
+        np.cumsum(lens, out=uptr[1:])
+        uidx = np.ascontiguousarray(np.concatenate([p[1] for p in parts]))
+        if cache:
+            tmp = key + ".tmp%d.npz" % os.getpid()
+            np.savez(tmp, uptr=uptr, uidx=uidx)
+            os.replace(tmp, key)
+    z = np.zeros(uptr.size, np.int64)
+    e = np.zeros(0, np.int32)
+    return CFData(uptr.size - 1, I, uptr, uidx, None, None, z, e, z.copy(), e.copy())
+
+
+def s_huge(U=10_000_000, I=1_000_000, N=1_250_000_000, seed=46, zipf_s=1.0, threads=None, cache=True):
+    """north_star's "10M x 1M x 128 synthetic set" (BASELINE.json; the feedback count is this repo's choice: 100 per user as
+    in C3).  Too large for synth_cf's exact-count rejection rounds, so: log-normal user activity (min 1), Zipf(1.0) item
+    popularity over a random permutation, every user's items drawn with replacement and de-duplicated -- the count that
+    remains (about 0.8 N: 1.0e9 of the 1.25e9 draws) is what the bench line reports.  Rows come out ascending in the item id (the positive pick of
+    the BPR sampler is uniform over the row, model.go:459, so the stored order does not matter to training).  Users are
+    cut into blocks, one numpy Generator per block (SeedSequence.spawn), blocks on host threads.  User-major CSR only."""
+    z = np.zeros(U + 1, np.int64)
+    e = np.zeros(0, np.int32)
+    key = os.path.join(_cache_dir(), "shuge_u%d_i%d_n%d_s%d_z%g_np%s" % (U, I, N, seed, zipf_s, np.__version__))
+    if cache and os.path.exists(key + "_uidx.npy"):
+        return CFData(U, I, np.load(key + "_uptr.npy"), np.load(key + "_uidx.npy"), None, None, z, e, z.copy(), e.copy())
+    rng = np.random.default_rng(seed)
+    act = rng.lognormal(0.0, 1.0, U)
+    lens = np.maximum(1, np.floor(act / act.sum() * N)).astype(np.int64)
+    w = 1.0 / np.power(np.arange(1, I + 1, dtype=np.float64), zipf_s)
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    perm = rng.permutation(I).astype(np.int64)
+    block = 200_000
+    starts = list(range(0, U, block))
+    seeds = np.random.SeedSequence(seed).spawn(len(starts))
+    if threads is None:
+        try:
+            avail_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
+        except (ValueError, OSError):
+            avail_gb = 16.0
+        threads = int(max(1, min(os.cpu_count() or 1, 32, (avail_gb - 16) // 2)))
+
+    def work(b):
+        u0 = starts[b]
+        u1 = min(U, u0 + block)
+        g = np.random.default_rng(seeds[b])
+        ln = lens[u0:u1]
+        rows = np.repeat(np.arange(u1 - u0, dtype=np.int64), ln)
+        items = perm[np.minimum(np.searchsorted(cdf, g.random(rows.size)), I - 1)]
+        key = np.unique(rows * I + items)  # sorted: by user, then item; duplicates of a (user, item) pair once
+        rows = key // I
+        return np.bincount(rows, minlength=u1 - u0), (key - rows * I).astype(np.int32)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(work, range(len(starts))))
+    cnt = np.concatenate([p[0] for p in parts])
+    uptr = np.zeros(U + 1, np.int64)
+    np.cumsum(cnt, out=uptr[1:])
+    uidx = np.empty(int(uptr[-1]), np.int32)
+    o = 0
+    for _, it in parts:
+        uidx[o:o + it.size] = it
+        o += it.size
+    if cache and U * 1 >= 1_000_000:  # gigabytes: a second bench command of the session (a profiler pass) loads it instead
+        np.save(key + "_uptr.npy", uptr)
+        tmp = key + "_uidx.tmp%d.npy" % os.getpid()
+        np.save(tmp, uidx)
+        os.replace(tmp, key + "_uidx.npy")
+    return CFData(U, I, uptr, uidx, None, None, z, e, z.copy(), e.copy())
+
+
+def hold_out(data, n_users, n_neg, seed):
+    """Leave-one-out over the FIRST n_users users with >= 2 feedbacks (dataset.go:258-285 does it for every user): the last
+    stored feedback becomes the test positive, n_neg items outside the user's feedback the fixed negatives (the NCF test.txt
+    layout, dataset.go:466-490).  Returns a CFData whose training CSR lacks the held-out entries (user-major only)."""
+    rng = np.random.default_rng(seed)
+    lens = np.diff(data.uptr)
+    users = np.nonzero(lens >= 2)[0][:n_users]
+    keep = np.ones(data.uidx.size, bool)
+    last = data.uptr[users + 1] - 1
+    keep[last] = False
+    newlen = lens.copy()
+    newlen[users] -= 1
+    uidx = np.ascontiguousarray(data.uidx[keep])
+    uptr = np.zeros(data.U + 1, np.int64)
+    np.cumsum(newlen, out=uptr[1:])
+    has = np.zeros(data.U, bool)
+    has[users] = True
+    test_ptr = np.zeros(data.U + 1, np.int64)
+    np.cumsum(has, out=test_ptr[1:])
+    test_idx = np.ascontiguousarray(data.uidx[last].astype(np.int32))
+    neg_ptr = np.zeros(data.U + 1, np.int64)
+    np.cumsum(np.where(has, n_neg, 0), out=neg_ptr[1:])
+    neg_idx = np.empty(users.size * n_neg, np.int32)
+    for t, u in enumerate(users):
+        posset = data.uidx[data.uptr[u]:data.uptr[u + 1]]
+        got = np.empty(0, np.int64)
+        while got.size < n_neg:
+            c = rng.integers(0, data.I, size=2 * n_neg)
+            got = np.unique(np.concatenate([got, c[~np.isin(c, posset)]]))
+        neg_idx[t * n_neg:(t + 1) * n_neg] = rng.permutation(got)[:n_neg]
+    return CFData(data.U, data.I, uptr, uidx, None, None, test_ptr, test_idx, neg_ptr, neg_idx)
+
+
+def init_factors_big(U, I, d, mean, std, seed, threads=None):
+    """init_factors for matrices of gigabytes: row blocks on host threads, one Generator per block."""
+    threads = threads or min(os.cpu_count() or 1, 32)
+
+    def fill(n, sd):
+        out = np.empty((n, d), np.float32)
+        blk = 1 << 18
+        starts = list(range(0, n, blk))
+        seeds = np.random.SeedSequence(sd).spawn(len(starts))
+
+        def work(b):
+            r0, r1 = starts[b], min(n, starts[b] + blk)
+            g = np.random.default_rng(seeds[b])
+            g.standard_normal(out=out[r0:r1], dtype=np.float32)
+            out[r0:r1] *= np.float32(std)
+            out[r0:r1] += np.float32(mean)
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(work, range(len(starts))))
+        return out
+    return fill(U, seed), fill(I, seed + 1)
 
 
 def init_factors(U, I, d, mean, std, seed):

@@ -18,10 +18,10 @@
  *     thread-local message).  Where the reference panics (slice length mismatch) or
  *     returns an error (ann.Bruteforce.SearchIndex out of range) the matching code is
  *     returned and nothing is modified;
- *   - one handle = one GPU (one process per GPU; multi-GPU = several processes, each
- *     with its own handle, exchanging the item-factor delta through the
- *     gorse_mf_item_delta_* calls and an all-reduce done by the caller, RCCL in
- *     production);
+ *   - one handle = one GPU.  Multi-GPU = one handle per GPU, in one process (the Go master: one goroutine
+ *     per GPU) or in several; the exchange between the replicas runs INSIDE the library over RCCL
+ *     (gorse_comm_*, gorse_mf_item_allreduce, gorse_mf_rows_allgather below).  The gorse_mf_item_delta_*
+ *     calls remain for a caller that brings its own collective;
  *   - calls on one handle must be serialised by the caller (the Go side holds a mutex,
  *     as logics/vector_writer.go does); different handles are independent;
  *   - long calls poll a caller-supplied cancel flag between kernel launches, the

@@ -18,10 +18,7 @@ extern "C" {
  * which makes device and oracle factors comparable bit for bit. */
 void gorse_hip_test_set_exact_exp(int32_t mode);
 /* probe-only switches of the Hogwild update path (bit 0: plain instead of L1-bypassing loads; bits 1/2/3:
- * skip the writes to P / Q[i] / Q[j]; bit 5: no hot-row replicas = the round-1 kernel; bit 6: the
- * experimental item-run schedule (window-sorted triplets, q_i register-resident across a run), with bits
- * 8..11: 1 + log2 of its run-block length, bits 12..16: log2 of its sort window, bits 20..23: log2 of its
- * resident workgroup count); bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
+ * skip the writes to P / Q[i] / Q[j]; bit 5: no hot-row replicas = the round-1 kernel); bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
  * register-resident over a user's samples), bit 28: force the per-sample schedule, bit 29: the user sort ranks
  * samples in stream order (single thread; makes a run's order deterministic for the parity test).  Used by
  * scripts/gpu_probe_*.py and the tests; 0 (the default) is the only value the product ever runs with. */
@@ -88,12 +85,9 @@ void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk);
  * user half-sweep and then the last item half-sweep, ticks summed over the waves in [0] Gram accumulation (gathers +
  * MFMA), [1] M to LDS, [2] the d-step solve, then [3] rows, [4] feedback entries, [5] kernel ticks, [6] waves, [7] 0. */
 int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16 /*host or NULL*/);
-/* the counting sort by positive item that precedes the item-run update kernel, on a host-supplied
- * chunk (n <= one chunk = 4M samples): su/si/sj receive the triplets in the order the kernel walks them
- * (per window of 32768 consecutive samples: ascending i, skipped samples last). */
-int32_t gorse_hip_test_item_sort(gorse_mf *h, const int32_t *u /*host*/, const int32_t *i /*host*/,
-                                 const int32_t *j /*host*/, int64_t n, int32_t *su /*host*/, int32_t *si /*host*/,
-                                 int32_t *sj /*host*/);
+/* probe: samples per chunk of a gorse_mf handle created AFTERWARDS (0 = the library's choice: 32 x users, clamped to
+ * [4M, 128M]); the user-run schedule applies a chunk at a time. */
+void gorse_hip_test_set_bpr_chunk(int64_t samples);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ import (
 
 // Fit the BPR model on one MI355X.  Everything around the epoch body -- Init draws, evaluation schedule, early stopping,
 // logging, span, the returned Score -- is model.go:408-530 unchanged; the body (sampling + the SGD steps of one epoch,
-// model.go:446-494) is one gorse_bpr_epoch call.
+// model.go:446-494) is one gorse_bpr_epoch / gorse_bpr_epoch_enqueue call.
 func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, config *FitConfig) Score {
 	log.Logger().Info("fit bpr (hip)",
 		zap.Int("train_set_size", trainSet.CountFeedback()),
@@ -51,8 +51,19 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 	defer span.End()
 	for epoch := 1; epoch <= bpr.nEpochs; epoch++ {
 		fitStart := time.Now()
-		rc := C.gorse_bpr_epoch(hm.h, C.int64_t(trainSet.CountFeedback()), C.float(bpr.lr), C.float(bpr.reg),
-			C.uint64_t(seed), C.uint64_t(epoch), 0, mode, hm.cancel, nil)
+		// Between two evaluations the epochs are only ENQUEUED (gorse_bpr_epoch_enqueue): the sampler and the counting sort
+		// of epoch e + 1 then run under the update kernel of epoch e (what bench.py times).  The epoch in front of an
+		// evaluation -- and every epoch of the sequential schedule, which cannot be enqueued -- goes through the
+		// synchronous call, which also polls the cancel flag.
+		evalNext := epoch%config.Verbose == 0 || epoch == bpr.nEpochs
+		var rc C.int32_t
+		if !evalNext && mode != C.GORSE_BPR_SEQUENTIAL && ctx.Err() == nil {
+			rc = C.gorse_bpr_epoch_enqueue(hm.h, C.int64_t(trainSet.CountFeedback()), C.float(bpr.lr), C.float(bpr.reg),
+				C.uint64_t(seed), C.uint64_t(epoch), 0, mode)
+		} else {
+			rc = C.gorse_bpr_epoch(hm.h, C.int64_t(trainSet.CountFeedback()), C.float(bpr.lr), C.float(bpr.reg),
+				C.uint64_t(seed), C.uint64_t(epoch), 0, mode, hm.cancel, nil)
+		}
 		if rc == C.GORSE_ERR_CANCELLED {
 			log.Logger().Info("fit bpr canceled", zap.Int("epoch", epoch), zap.Error(ctx.Err()))
 			hm.pull()

@@ -22,6 +22,7 @@ def main(path):
     try:
         pcols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
         if pcols:
+            print("\n# counters_collection columns: %s" % pcols)
             kn = "kernel_name" if "kernel_name" in pcols else ("name" if "name" in pcols else None)
             cn = "counter_name" if "counter_name" in pcols else None
             vn = "value" if "value" in pcols else ("counter_value" if "counter_value" in pcols else None)

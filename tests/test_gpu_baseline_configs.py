@@ -5,6 +5,8 @@
       of gorse_mf_rank on the DEVICE's factors equal the oracle's, index for index.
   C3  one 125,000-user shard of S-big (200,000 items, 12.5M feedbacks), nFactors 128: one epoch, factors finite, NDCG@10
       of 8192 held-out users within +-0.01 of the sequential oracle's epoch.
+  C3' the whole S-big set (1M x 200K x 100M) on one GPU, nFactors 128: one epoch, NDCG@10 of 8192 held-out users within +-0.01
+      of one sequential oracle epoch over the same set (a committed fixture: 100M sequential steps).
   C5  S-als 500,000 x 100,000 x 50M, nFactors 64: one user half-sweep on the device, 2048 rows spread over the row-length
       range (incl. the longest) <= 1e-4 against orc_als_half_range.
   C4  S-emb 1,000,000 x 128 bf16, cosine, k = 100: 96 query rows of the all-pairs pass equal Bruteforce.SearchIndex restated
@@ -55,40 +57,9 @@ def test_c2_ml1m_d64_user_runs_ndcg_and_rank_lists(oracle):
     assert np.array_equal(rlen, elen) and np.array_equal(rank, erank)
 
 
-def _held_out(data, n_users, n_neg, seed):
-    """the last stored feedback of the first n_users users with >= 2 feedbacks becomes the test positive; n_neg negatives"""
-    rng = np.random.default_rng(seed)
-    lens = np.diff(data.uptr)
-    users = np.nonzero(lens >= 2)[0][:n_users]
-    keep = np.ones(data.uidx.size, bool)
-    last = data.uptr[users + 1] - 1
-    keep[last] = False
-    rows = np.repeat(np.arange(data.U, dtype=np.int64), lens)[keep]
-    uidx = np.ascontiguousarray(data.uidx[keep])
-    uptr = np.zeros(data.U + 1, np.int64)
-    np.cumsum(np.bincount(rows, minlength=data.U), out=uptr[1:])
-    has = np.zeros(data.U, bool)
-    has[users] = True
-    test_ptr = np.zeros(data.U + 1, np.int64)
-    np.cumsum(has, out=test_ptr[1:])
-    test_idx = np.ascontiguousarray(data.uidx[last].astype(np.int32))
-    neg_ptr = np.zeros(data.U + 1, np.int64)
-    np.cumsum(np.where(has, n_neg, 0), out=neg_ptr[1:])
-    neg_idx = np.empty(users.size * n_neg, np.int32)
-    for t, u in enumerate(users):
-        posset = data.uidx[data.uptr[u]:data.uptr[u + 1]]
-        got = np.empty(0, np.int64)
-        while got.size < n_neg:
-            c = rng.integers(0, data.I, size=2 * n_neg)
-            got = np.unique(np.concatenate([got, c[~np.isin(c, posset)]]))
-        neg_idx[t * n_neg:(t + 1) * n_neg] = rng.permutation(got)[:n_neg]
-    out = synth.CFData(data.U, data.I, uptr, uidx, None, None, test_ptr, test_idx, neg_ptr, neg_idx)
-    return out
-
-
 def test_c3_shard_d128_one_epoch_ndcg(oracle):
     full = synth.s_big_shard(rank=0, world=8)
-    data = _held_out(full, 8192, 99, 5)
+    data = synth.hold_out(full, 8192, 99, 5)
     d, lr, reg, seed = 128, 0.05, 0.01, 77
     P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
     mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
@@ -108,6 +79,38 @@ def test_c3_shard_d128_one_epoch_ndcg(oracle):
           % (ref, time.perf_counter() - t0, got, base))
     assert ref > base + 0.02  # one epoch moved the ranking
     assert abs(got - ref) < 0.01
+
+
+def test_c3_full_d128_one_epoch_ndcg(oracle):
+    """C3 WHOLE on one GPU (1M x 200K x 100M, nFactors 128: P and Q outside the Infinity Cache, 32M-sample chunks): one epoch of
+    the default Hogwild schedule, factors finite, NDCG@10 of 8192 held-out users within +-0.01 of ONE SEQUENTIAL ORACLE EPOCH over
+    the same set -- 100M sequential SGD steps, minutes of one host core, so the oracle's number is a committed fixture
+    (tests/golden/c3full_oracle_ndcg.json, written by scripts/gen_golden_c3full_ndcg.py on the CPU from the same seeded
+    generators); the evaluation of the device's factors runs here."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c3full_oracle_ndcg.json")))
+    t0 = time.perf_counter()
+    data = synth.hold_out(synth.s_big_full(), 8192, 99, 5)
+    assert data.n_train == gold["n_train"]  # the same data set the fixture was computed on
+    t_data = time.perf_counter() - t0
+    d, lr, reg, seed = 128, 0.05, 0.01, 77
+    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P0, Q0)
+    assert mf.bpr_user_runs()
+    t0 = time.perf_counter()
+    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_ATOMIC)
+    t_epoch = time.perf_counter() - t0
+    gP, gQ = mf.get_factors()
+    mf.close()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+    got = ndcg(oracle, data, gP, gQ)
+    print("C3 whole NDCG@10 of 8192 held-out users after one epoch: sequential oracle %.4f (fixture; %.0f s of one core), device %.4f "
+          "(epoch %.3f s incl. first-call allocations), untrained %.4f; data set ready in %.0f s"
+          % (gold["ndcg_after_one_epoch"], gold["oracle_epoch_seconds"], got, t_epoch, gold["ndcg_untrained"], t_data))
+    assert gold["ndcg_after_one_epoch"] > gold["ndcg_untrained"] + 0.02
+    assert abs(got - gold["ndcg_after_one_epoch"]) < 0.01
 
 
 def rel_to_scale(got, ref):

@@ -210,35 +210,6 @@ def test_bpr_atomic_no_lost_updates(small):
         assert np.abs(moved - expect).max() < 0.02 * np.abs(expect).max()
 
 
-@pytest.mark.parametrize("n,I", [(1, 5), (17, 3), (5000, 200), (300000, 3706), (1 << 20, 50)])
-def test_item_sort_is_a_sorted_permutation(n, I):
-    """Counting sort in front of the item-run kernel: every window of 32768 consecutive samples comes out
-    as a permutation of itself, ascending in the positive item, skipped samples (negative index) last."""
-    uptr = np.arange(65, dtype=np.int64)  # 64 users with one feedback each
-    mf = capi.MF(64, I, 16, uptr, (np.arange(64) % I).astype(np.int32))
-    rng = np.random.default_rng(n)
-    w = 1.0 / np.arange(1, I + 1)  # Zipf: one very popular item
-    i = rng.choice(I, size=n, p=w / w.sum()).astype(np.int32)
-    u = rng.integers(0, 64, n).astype(np.int32)
-    j = rng.integers(0, I, n).astype(np.int32)
-    skip = rng.random(n) < 0.01
-    u[skip] = -1
-    i[skip] = -1
-    j[skip] = -1
-    su, si, sj = mf.test_item_sort(u, i, j)
-    W = 32768  # the schedule's window: consecutive samples that are sorted together
-
-    def canon(a, b, c):
-        t = np.stack([a, b, c], axis=1)
-        return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
-
-    for w0 in range(0, n, W):
-        sl = slice(w0, min(n, w0 + W))
-        key = np.where(si[sl] < 0, I, si[sl])
-        assert np.all(np.diff(key.astype(np.int64)) >= 0)
-        assert np.array_equal(canon(u[sl], i[sl], j[sl]), canon(su[sl], si[sl], sj[sl]))
-
-
 def test_bpr_atomic_hot_rows_fold_exactly(oracle, small):
     """Every item of `small` is a hot row (share >= 1/2048), so the positive updates of this batch land in
     replica rows and reach Q through the folder / fold kernel: all 40 updates of the repeated item must be
