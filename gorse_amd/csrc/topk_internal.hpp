@@ -23,6 +23,7 @@ struct gorse_topk {
     float err_coef = 0.0f;         // |approx - reference| <= err_coef * |q| * |x| (dot of the operands)
     float max_norm = 0.0f;         // max_i sqrt(norm2[i])
     bool coarse_ok = false;        // cosine with nearly equal norms: block-level scale bound in the sweep
+    float rs_min = 0.0f, rs_max = 0.0f;  // cosine: bounds of the row scales 1 / sqrt(norm2[i]) (the DMA sweeps' block bound)
     gorse::DevBuf<uint16_t> opA_own, opB_own;  // bf16 operand matrices N x KPAD (candidate / query roles)
     const uint16_t *opA = nullptr, *opB = nullptr;  // may alias Xb
     gorse::DevBuf<float> rscale;   // cosine: 1 / sqrt(norm2[i])
@@ -38,7 +39,7 @@ struct gorse_topk {
     gorse::DevBuf<int32_t> rp_pos, rp_ccnt, rp_hcnt;
     gorse::DevBuf<int64_t> rp_self;
     gorse::DevBuf<uint16_t> rp_op;
-    gorse::DevBuf<float> rp_margin;
+    gorse::DevBuf<float> rp_margin, rp_fslice;  // rp_fslice: final threshold of every (row slice, query) of a history sweep
     gorse::DevBuf<uint2> rp_cbuf, rp_hbuf;
     gorse::DevBuf<uint8_t> rp_flag;
     gorse::DevBuf<int32_t> rp_sidx, rp_scount;

@@ -45,16 +45,30 @@ constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the mai
 constexpr int sweep_waves(bool hist, int kp) { return !hist ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
 constexpr int kWaves = kWavesMain;
 constexpr int kThreads = kWaves * 64;
-// LDS of a sweep workgroup: NBUF tile buffers (+ their row scales and block bounds), five words per query, the candidate path's
-// staging area (VOTE only), the tile counters.  Three buffers where they fit next to the rest in 144 KB (the main sweep up to
-// KP = 8 with 128-row tiles), else two; the history sweep keeps two (its small workgroups share a CU).
-constexpr size_t sweep_tile_bytes(int kp, int rb) { return (size_t)32 * rb * (kp * 32 + 16) + (size_t)32 * rb * 4 + 2 * kMaxRB * 4; }
+// Tiles reach LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, no VGPR round trip, no ds_write pass) when
+// the operand depth is a power of two and the sweep is a main sweep: the LDS image of a tile is then lane-linear (unpadded
+// rows), and the 16-byte pieces of a row are XOR-swizzled by the row number on the SOURCE address and again on the read, so
+// that the 16 lanes of a ds_read_b128 group fall on 16 different slots of the 256-byte bank row.  Other depths and the
+// history sweep (small workgroups) stage through registers into rows padded by 16 bytes.
+constexpr bool sweep_dma(int kp, bool hist, int rb, int wv) {
+    return !hist && (kp & (kp - 1)) == 0 && (32 * rb * kp * 2) % (64 * wv) == 0 && (32 * rb) % 64 == 0;
+}
+// LDS of a sweep workgroup: NBUF tile buffers (+ their row scales and, without DMA, block bounds), five words per query, the
+// candidate path's staging area (VOTE only), the tile counters.  DMA: four buffers (tile t is multiplied while t + 1 has landed
+// and t + 2 is in flight; the fourth keeps the waves a tile apart); register staging: three where they fit next to the rest
+// in 144 KB (the main sweep up to KP = 8 with 128-row tiles), else two; the history sweep keeps two (its small workgroups
+// share a CU).
+constexpr size_t sweep_row_bytes(int kp, bool dma) { return (size_t)kp * 32 + (dma ? 0 : 16); }
+constexpr size_t sweep_tile_bytes(int kp, int rb, bool dma) {
+    return (size_t)32 * rb * sweep_row_bytes(kp, dma) + (size_t)32 * rb * 4 + (dma ? 0 : 2 * kMaxRB * 4);
+}
 constexpr size_t sweep_fixed_bytes(int bq, int wv, bool vote) { return (size_t)5 * bq * 4 + (vote ? (size_t)wv * 64 * 16 * 4 : 0) + 64; }
 constexpr int sweep_bufs(int kp, int rb, int bq, int wv, bool vote, bool hist) {
-    return !hist && 3 * sweep_tile_bytes(kp, rb) + sweep_fixed_bytes(bq, wv, vote) <= (size_t)144 * 1024 ? 3 : 2;
+    if (sweep_dma(kp, hist, rb, wv)) return 4 * sweep_tile_bytes(kp, rb, true) + sweep_fixed_bytes(bq, wv, vote) <= (size_t)156 * 1024 ? 4 : 3;
+    return !hist && 3 * sweep_tile_bytes(kp, rb, false) + sweep_fixed_bytes(bq, wv, vote) <= (size_t)144 * 1024 ? 3 : 2;
 }
 constexpr size_t sweep_lds_bytes(int kp, int rb, int bq, int wv, bool vote, bool hist) {
-    return sweep_bufs(kp, rb, bq, wv, vote, hist) * sweep_tile_bytes(kp, rb) + sweep_fixed_bytes(bq, wv, vote);
+    return sweep_bufs(kp, rb, bq, wv, vote, hist) * sweep_tile_bytes(kp, rb, sweep_dma(kp, hist, rb, wv)) + sweep_fixed_bytes(bq, wv, vote);
 }
 constexpr int64_t kMinSweepQueries = 768;  // fewer queries in a call take the scan (see topk_mfma_usable)
 constexpr int kCap = 512;      // candidate-list capacity per query
@@ -64,7 +78,8 @@ constexpr int kOverflowAt = kCap - 128; // a compaction that keeps more than thi
 constexpr int kMaxKth = 256;
 constexpr int kHistCap = 4096;          // history entries per query of the tie-replay sweep (see topk_tie_replay_kernel)
 constexpr int kReplayCap = 8192;        // power of two >= kCap + kHistCap: entries the replay sorts
-constexpr int64_t kReplayChunk = 16384; // flagged queries per history sweep (history buffer = 512 MB)
+constexpr int64_t kReplayChunk = 16384; // flagged queries per history sweep (history buffers = 512 MB per row slice)
+constexpr int kMaxSlices = 8;           // row slices of a history sweep (see topk_tie_sort_kernel)
 constexpr int64_t kChunkQ = (int64_t)1 << 20;
 
 __device__ __forceinline__ uint32_t fkey(float x) {  // order-preserving float -> uint
@@ -106,6 +121,8 @@ struct SweepParams {
     int tile_stride;   // 1, or the pilot's sampling stride over the row tiles
     int prio;          // candidate path at raised wave priority (s_setprio): its VALU chain competes with the sibling wave's
                        // MFMA issue, and the wave that took the path is the one the barrier waits for
+    int nslices;       // HIST: row slices (grid.y); the per-query outputs are then nslices x nq long, slice-major
+    float rs_min, rs_max;  // smallest and largest row scale of the index (coarse bound of the DMA sweeps)
     int vote;          // candidate path: skip a score row when no lane of the wave holds a candidate in it (pays when
                        // candidates are rare, i.e. behind a warm start: one or two of a block's 1024 scores)
 };
@@ -121,19 +138,37 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
     // column (lane < 32), odd slots to its partner (lane >= 32); each appends at its own counter (slot 2 * c + half)
     const int n_lo = s_cnt[2 * ql], n_hi = s_cnt[2 * ql + 1];
     const int n = n_lo + n_hi;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2 before they are re-read
+    // The list is re-read by loads the compiler does not see (one asm statement: the wave's appends drained to L2, eight
+    // L1-bypassing loads, their wait).  A load hipcc can see inside the tile loop makes its wait-count pass put
+    // s_waitcnt vmcnt(0) at the head of every iteration (the load may be pending along the back edge), and that drains the
+    // tiles the LDS-DMA has in flight.  All kCap slots are allocated, so the loads need no predicate; slots past the
+    // sub-lists' lengths are masked below (key 0 = never counted: trial >= 1).
+    static_assert(kEPL == 8, "compact_query loads eight entries per lane");
+    unsigned long long ev[kEPL];
+    {
+        const uint2 *src = qb + lane;
+        asm volatile("s_waitcnt vmcnt(0)\n\t"
+                     "global_load_dwordx2 %0, %8, off sc1\n\t"
+                     "global_load_dwordx2 %1, %8, off offset:512 sc1\n\t"
+                     "global_load_dwordx2 %2, %8, off offset:1024 sc1\n\t"
+                     "global_load_dwordx2 %3, %8, off offset:1536 sc1\n\t"
+                     "global_load_dwordx2 %4, %8, off offset:2048 sc1\n\t"
+                     "global_load_dwordx2 %5, %8, off offset:2560 sc1\n\t"
+                     "global_load_dwordx2 %6, %8, off offset:3072 sc1\n\t"
+                     "global_load_dwordx2 %7, %8, off offset:3584 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(ev[0]), "=&v"(ev[1]), "=&v"(ev[2]), "=&v"(ev[3]), "=&v"(ev[4]), "=&v"(ev[5]), "=&v"(ev[6]), "=&v"(ev[7])
+                     : "v"(src)
+                     : "memory");
+    }
     uint32_t key[kEPL], idx[kEPL];
     bool valid[kEPL];
 #pragma unroll
     for (int j = 0; j < kEPL; j++) {
         const int e = j * 64 + lane;
         valid[j] = (e & 1) ? (e >> 1) < n_hi : (e >> 1) < n_lo;
-        unsigned long long v = 0;  // key 0 = never counted below (trial >= 1)
-        if (valid[j])
-            v = __hip_atomic_load(reinterpret_cast<unsigned long long *>(qb + e), __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
-        key[j] = (uint32_t)v;
-        idx[j] = (uint32_t)(v >> 32);
+        key[j] = valid[j] ? (uint32_t)ev[j] : 0u;
+        idx[j] = (uint32_t)(ev[j] >> 32);
     }
     float newf = -__builtin_inff();
     if (n >= kth) {
@@ -210,7 +245,10 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, n_hits = 0;  // slow path: count + exchange | appends | compaction
     if (PROF) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int KPAD = KP * 16;
-    constexpr int ROWB = KPAD * 2 + 16;  // +16 B: consecutive rows start 4 banks apart, ds_read_b128 conflict-free
+    constexpr bool DMA = sweep_dma(KP, HIST, RB, kWaves);
+    // register staging: +16 B per row, consecutive rows start 4 banks apart, ds_read_b128 conflict-free; DMA: unpadded rows,
+    // the pieces of a row swizzled instead (see piece_swizzle)
+    constexpr int ROWB = (int)sweep_row_bytes(KP, DMA);
     constexpr int QW = 32 * NCB;
     constexpr int BQ = QW * kWaves;
     constexpr int CHUNKS = kTR * KP * 2;  // 16-byte pieces per tile
@@ -219,12 +257,12 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_tile = smem;
     float *s_rs = reinterpret_cast<float *>(smem + (size_t)NBUF * kTR * ROWB);
-    float *s_bmm = s_rs + NBUF * kTR;  // per buffer and 32-row block: (min, max) row scale
-    int *s_cnt = reinterpret_cast<int *>(s_bmm + NBUF * 2 * kMaxRB);  // 2 per query: the interleaved sub-list lengths
+    float *s_bmm = s_rs + NBUF * kTR;  // register staging only: per buffer and 32-row block the (min, max) row scale
+    int *s_cnt = reinterpret_cast<int *>(s_bmm + (DMA ? 0 : NBUF * 2 * kMaxRB));  // 2 per query: the interleaved sub-list lengths
     float *s_f = reinterpret_cast<float *>(s_cnt + 2 * BQ);
     float *s_mg = s_f + BQ;
     int *s_hc = reinterpret_cast<int *>(s_mg + BQ);
-    // tile counters: s_sync[b] = waves that have stored their part of a tile into buffer b (ever), s_sync[NBUF + b] = waves that
+    // tile counters: s_sync[b] = waves whose part of a tile has reached buffer b (ever), s_sync[NBUF + b] = waves that
     // have finished reading one
     int *s_sync = s_hc + BQ;
     float *s_stage = reinterpret_cast<float *>(s_sync + 16);  // VOTE: 16 scores per thread, where the candidate path parks a block
@@ -253,19 +291,33 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
             bfrag[cb][ks] = *reinterpret_cast<bf16x8 *>(&v);
         }
     }
+    // the operands are consumed here once, so that hipcc waits for their loads NOW: a load still pending when the tile loop is
+    // entered costs a wait in every iteration (and that wait drains the LDS-DMA of the tiles in flight)
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int ks = 0; ks < KP; ks++) asm volatile("" : "+v"(bfrag[cb][ks]));
 
-    uint4 pre[CPT];
-    float pre_rs = 0.0f;
     const int64_t stride_rows = (int64_t)p.tile_stride * kTR;  // the pilot samples every tile_stride-th tile
-    auto load_tile = [&](int64_t t) {
-        const int64_t base_row = t * stride_rows;
+    // A history sweep may be cut into row slices (blockIdx.y): every slice sweeps its own tiles from a cold threshold and
+    // keeps its own lists; topk_tie_sort_kernel joins them (see there for why that is a superset of the unsliced history).
+    const int64_t NT_all = (p.N + stride_rows - 1) / stride_rows;
+    const int64_t T0 = NT_all * blockIdx.y / gridDim.y, T1 = NT_all * (blockIdx.y + 1) / gridDim.y;
+    const int64_t NT = T1 - T0;
+    const int64_t qslice = (int64_t)blockIdx.y * p.nq;  // this slice's rows of the per-query output arrays
+
+    // ---- register staging (history sweeps, operand depths that are not a power of two) ----
+    uint4 pre[DMA ? 1 : CPT];
+    float pre_rs = 0.0f;
+    auto load_tile = [&](int64_t tl) {
+        const int64_t base_row = (T0 + tl) * stride_rows;
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
             const int ch = tid + c * kThreads;
             if (ch < CHUNKS) {
                 const int row = ch / (KP * 2), cc = ch % (KP * 2);
                 const int64_t grow = base_row + row;
-                pre[c] = grow < p.N ? reinterpret_cast<const uint4 *>(p.A + grow * KPAD)[cc] : make_uint4(0, 0, 0, 0);
+                pre[DMA ? 0 : c] = grow < p.N ? reinterpret_cast<const uint4 *>(p.A + grow * KPAD)[cc] : make_uint4(0, 0, 0, 0);
             }
         }
         if (SCALE && tid < kTR) pre_rs = base_row + tid < p.N ? p.rscale[base_row + tid] : 0.0f;
@@ -276,7 +328,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
             const int ch = tid + c * kThreads;
             if (ch < CHUNKS) {
                 const int row = ch / (KP * 2), cc = ch % (KP * 2);
-                *reinterpret_cast<uint4 *>(s_tile + (size_t)buf * kTR * ROWB + row * ROWB + cc * 16) = pre[c];
+                *reinterpret_cast<uint4 *>(s_tile + (size_t)buf * kTR * ROWB + row * ROWB + cc * 16) = pre[DMA ? 0 : c];
             }
         }
         if (SCALE && tid < kTR) {
@@ -295,24 +347,109 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         }
     };
 
+    // ---- LDS-DMA ----
+    // Piece c (16 bytes) of row r lives at piece c ^ piece_swizzle(r) of the row's LDS image: the 16 lanes of a ds_read_b128
+    // group read one piece column of 16 different rows, and the XOR spreads them over the 16 slots of the 256-byte bank row.
+    constexpr int PPR = KP * 2;  // pieces per row
+    auto piece_swizzle = [](int row) -> int {
+        if constexpr (PPR >= 16) return row & 15;
+        else if constexpr (PPR == 8) return (row >> 1) & 7;
+        else if constexpr (PPR == 4) return (row >> 2) & 3;
+        else return (row >> 3) & 1;
+    };
+    // A wave-instruction moves 64 pieces: DMA instruction j of wave w covers pieces [(w * DPW + j) * 64, +64) of the tile;
+    // the row scales (one dword per row) follow as instructions of 64 rows each, issued by the first kTR / 64 waves.
+    constexpr int DPW = DMA ? CHUNKS / 64 / kWaves : 0;  // tile instructions per wave (CHUNKS = 64 * KP * RB: a multiple of 64 * kWaves
+                                                         // for every instantiation that takes this path)
+    static_assert(!DMA || (CHUNKS % (64 * kWaves) == 0 && kTR % 64 == 0), "DMA tiling");
+    constexpr int RSW = (DMA && SCALE) ? kTR / 64 : 0;   // waves that also move a scale instruction
+    const int wu = __builtin_amdgcn_readfirstlane(w);    // provably wave-uniform (LDS destinations, branch conditions)
+    // The DMA is issued from inline assembly: the builtin makes hipcc treat every later LDS access of the kernel (the tile
+    // counters, the fragment reads) as dependent on it and put s_waitcnt vmcnt(0) in front -- which drains the very tiles
+    // that are meant to stay in flight.  An asm statement is invisible to that bookkeeping (cdna_hip_programming.md 5.7);
+    // the waits are dma_wait's, by count.  M0 = LDS destination of lane 0; the statement saves and restores it.
+    const unsigned lds_tiles = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_tile;
+    const unsigned lds_rs = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)s_rs;
+    auto dma_tile = [&](int64_t tl, int buf) {
+        if constexpr (DMA) {
+            const int64_t base_row = (T0 + tl) * stride_rows;
+#pragma unroll
+            for (int j = 0; j < DPW; j++) {
+                const int piece = (wu * DPW + j) * 64 + lane;
+                const int row = piece / PPR, cs = piece % PPR;  // LDS position; its content is source piece cs ^ swizzle
+                int64_t grow = base_row + row;
+                if (grow >= p.N) grow = p.N - 1;  // rows past N: any readable address; their scores become NaN below
+                const uint16_t *src = p.A + grow * KPAD + ((cs ^ piece_swizzle(row)) << 3);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_tiles + (unsigned)buf * (kTR * ROWB) + (unsigned)(wu * DPW + j) * 1024u);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+            if (SCALE && wu < RSW) {
+                int64_t grow = base_row + wu * 64 + lane;
+                if (grow >= p.N) grow = p.N - 1;
+                const float *src = p.rscale + grow;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_rs + (unsigned)(buf * kTR + wu * 64) * 4u);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        }
+    };
+    // "everything this wave issued before its last `keep` tiles' DMA instructions has completed": loads (the DMA among them)
+    // retire in order, so once no more than keep * (instructions per tile) operations are outstanding, every older tile of
+    // this wave is in LDS -- whatever stores (the candidate appends) are still on their way.
+    auto dma_wait = [&](int keep) {
+        if constexpr (DMA) {
+            if (keep == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (wu < RSW) {
+                if (keep == 1)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DPW + 1)) : "memory");
+            } else {
+                if (keep == 1)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
+            }
+        }
+    };
+
     // The waves of a workgroup share every tile but do not march in step: a wave that takes the candidate path (~2200 cycles)
     // used to hold the other seven at the tile's barrier -- 27 % of the sweep (profiles/r02_f_probe_topk_prof.txt).  With NBUF
     // buffers and two counters per buffer a wave only waits for what it needs: tile t complete in its buffer before it
-    // multiplies it, tile t + 1 - NBUF read by everyone before tile t + 1 overwrites it.
+    // multiplies it, the tile that buffer held before read by everyone before it is overwritten.
+    // LDS executes a wave's operations in issue order, so a counter increment behind the wave's own LDS traffic needs no
+    // fence (a workgroup-scope release would also drain the DMA in flight: s_waitcnt vmcnt(0)); the compiler is kept from
+    // moving memory operations across by the asm statements' memory clobbers.
     auto arrive = [&](int *ctr) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's LDS traffic has completed
+        if constexpr (DMA)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_reads of the tile have returned
+        else
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's LDS traffic has completed
         if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto wait_for = [&](int *ctr, int target) {
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (DMA)
+            asm volatile("" ::: "memory");
+        else
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    const int64_t NT = (p.N + stride_rows - 1) / stride_rows;
     __syncthreads();  // the per-query words and the counters are initialised
-    load_tile(0);
-    store_tile(0);
-    arrive(&s_sync[0]);
-    if (NT > 1) load_tile(1);
+    if constexpr (DMA) {
+        if (NT > 0) dma_tile(0, 0);
+        if (NT > 1) dma_tile(1, 1);
+    } else {
+        if (NT > 0) {
+            load_tile(0);
+            store_tile(0);
+            arrive(&s_sync[0]);
+        }
+        if (NT > 1) load_tile(1);
+    }
 
     float fth[NCB];
     int cnt[NCB];  // length of this lane's sub-list of its query (mirrored in s_cnt around a compaction)
@@ -321,22 +458,48 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         fth[cb] = s_f[w * QW + cb * 32 + (lane & 31)];
         cnt[cb] = 0;
     }
+    // DMA: the lane's read offsets inside a 32-row block, one per k-step (row & 15 is the same in every block of a tile)
+    unsigned aoff[DMA ? KP : 1];
+    if constexpr (DMA) {
+        const int r = lane & 31;
+#pragma unroll
+        for (int ks = 0; ks < KP; ks++) aoff[ks] = (unsigned)(r * ROWB + (((ks * 2 + (lane >> 5)) ^ piece_swizzle(r)) << 4));
+    }
 
     int buf = 0, round = 0;  // tile t lives in buffer t % NBUF and is that buffer's (t / NBUF)-th tile
     for (int64_t t = 0; t < NT; t++) {
         if (PROF) ts = __builtin_amdgcn_s_memtime();
         const int nb = buf + 1 == NBUF ? 0 : buf + 1;
-        if (t + 1 < NT) {  // rows of tile t + 1 (loaded during tile t - 1) into the buffer tile t + 1 - NBUF was read from
-            if (t + 1 >= NBUF) {
-                unsigned long long tw = 0;
-                if (PROF) tw = __builtin_amdgcn_s_memtime();
-                wait_for(&s_sync[NBUF + nb], kWaves * (round + (nb == 0 ? 1 : 0)));  // = kWaves * ((t + 1) / NBUF)
-                if (PROF) c_bar += __builtin_amdgcn_s_memtime() - tw;
+        if constexpr (DMA) {
+            // tile t + 2 goes into the buffer tile t + 2 - NBUF was read from
+            const int b2 = nb + 1 == NBUF ? 0 : nb + 1;
+            if (t + 2 < NT) {
+                if (t + 2 >= NBUF) {
+                    unsigned long long tw = 0;
+                    if (PROF) tw = __builtin_amdgcn_s_memtime();
+                    wait_for(&s_sync[NBUF + b2], kWaves * (int)((t + 2) / NBUF));
+                    if (PROF) c_bar += __builtin_amdgcn_s_memtime() - tw;
+                }
+                dma_tile(t + 2, b2);
+                dma_wait(2);  // tiles t + 1 and t + 2 may be in flight: tile t has landed
+            } else {
+                dma_wait(0);
             }
-            store_tile(nb);
-            arrive(&s_sync[nb]);
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&s_sync[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (t + 1 < NT) {  // rows of tile t + 1 (loaded during tile t - 1) into the buffer tile t + 1 - NBUF was read from
+                if (t + 1 >= NBUF) {
+                    unsigned long long tw = 0;
+                    if (PROF) tw = __builtin_amdgcn_s_memtime();
+                    wait_for(&s_sync[NBUF + nb], kWaves * (round + (nb == 0 ? 1 : 0)));  // = kWaves * ((t + 1) / NBUF)
+                    if (PROF) c_bar += __builtin_amdgcn_s_memtime() - tw;
+                }
+                store_tile(nb);
+                arrive(&s_sync[nb]);
+            }
+            if (t + 2 < NT) load_tile(t + 2);
         }
-        if (t + 2 < NT) load_tile(t + 2);
         if (PROF) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             c_store += now - ts;
@@ -349,9 +512,10 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
             ts = now;
         }
         const unsigned char *tb = s_tile + (size_t)buf * kTR * ROWB;
-        const int64_t base_row = t * stride_rows;
+        const int64_t base_row = (T0 + t) * stride_rows;
         const int valid = (int)std::min<int64_t>(kTR, p.N - base_row);
-#pragma unroll
+        // not unrolled: four copies of the epilogue and its candidate path cost the C4 instantiation 34 spilled VGPRs
+#pragma unroll 1
         for (int rb = 0; rb < RB; rb++) {
             f32x16 acc[NCB];
 #pragma unroll
@@ -359,6 +523,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[cb][r] = 0.0f;
             const unsigned char *rowp = tb + (rb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+            const unsigned char *blkp = tb + rb * 32 * ROWB;  // DMA: + aoff[ks]
             // candidate fragments: up to 8 k-steps of ds_read_b128 in flight ahead of the MFMAs that use them
             constexpr int PF = KP < 8 ? KP : 8;
 #pragma unroll
@@ -366,7 +531,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                 bf16x8 a[PF];
 #pragma unroll
                 for (int j = 0; j < PF; j++)
-                    if (k0 + j < KP) a[j] = *reinterpret_cast<const bf16x8 *>(rowp + (k0 + j) * 32);
+                    if (k0 + j < KP)
+                        a[j] = DMA ? *reinterpret_cast<const bf16x8 *>(blkp + aoff[DMA ? k0 + j : 0])
+                                   : *reinterpret_cast<const bf16x8 *>(rowp + (k0 + j) * 32);
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead: hipcc otherwise sinks each next to its MFMA
 #pragma unroll
                 for (int j = 0; j < PF; j++)
@@ -411,7 +578,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
 #pragma unroll
                 for (int r = 1; r < 16; r++) m = fmaxf(m, acc[cb][r]);
                 if (coarse) {  // an upper bound of every scaled score of the block: scales are positive
-                    const float mn = s_bmm[(buf * kMaxRB + rb) * 2 + 0], mx = s_bmm[(buf * kMaxRB + rb) * 2 + 1];
+                    // DMA: the extreme scales of ALL rows (coarse is offered only when they lie within 2 % of each other)
+                    const float mn = DMA ? p.rs_min : s_bmm[(buf * kMaxRB + rb) * 2 + 0];
+                    const float mx = DMA ? p.rs_max : s_bmm[(buf * kMaxRB + rb) * 2 + 1];
                     m = m * (m >= 0.0f ? mx : mn);
                 }
                 if (PROF) n_blk++;
@@ -424,7 +593,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                     if (p.prio & 1) __builtin_amdgcn_s_setprio(3);
                     if (coarse) scale_rows();
                     const int ql = w * QW + cb * 32 + (lane & 31);
-                    const int64_t qg = wgq0 + ql;
+                    const int64_t qg = qslice + wgq0 + ql;
                     uint2 *qb = p.cbuf + qg * kCap;
                     const float f = fth[cb];
                     // One pass, one compare per score: every lane appends to ITS OWN sub-list of the query (even /
@@ -485,8 +654,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                             const int l = __builtin_ctzll(need);
                             need &= need - 1;
                             const int qlc = w * QW + cb * 32 + l;
-                            compact_query<HIST>(p.cbuf + (wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg,
-                                                p.cflag + wgq0 + qlc, HIST ? p.hbuf + (wgq0 + qlc) * kHistCap : nullptr, s_hc);
+                            compact_query<HIST>(p.cbuf + (qslice + wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg,
+                                                p.cflag + qslice + wgq0 + qlc,
+                                                HIST ? p.hbuf + (qslice + wgq0 + qlc) * kHistCap : nullptr, s_hc);
                         } while (need);
                         cnt[cb] = s_cnt[2 * ql + (lane >> 5)];
                         fth[cb] = s_f[ql];
@@ -536,8 +706,8 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     __builtin_amdgcn_wave_barrier();
     for (int l = 0; l < QW; l++) {
         const int ql = w * QW + l;
-        const int64_t qg = wgq0 + ql;
-        if (qg >= p.nq) break;
+        if (wgq0 + ql >= p.nq) break;
+        const int64_t qg = qslice + wgq0 + ql;
         if (s_f[ql] == __builtin_inff()) {  // flagged
             if (p.f_out && lane == 0) p.f_out[qg] = -__builtin_inff();
             continue;
@@ -691,7 +861,10 @@ struct ReplayParams {
     const int32_t *ccnt;
     const uint2 *hbuf;
     const int32_t *hcnt;
-    uint8_t *cflag;        // in: flags of the history sweep (non-zero: undecidable); out: 2 = undecided here
+    const float *fslice;   // nslices x nq: the threshold every slice of the history sweep ended with (-inf: none)
+    int nslices;           // cbuf / ccnt / hbuf / hcnt / cflag / fslice hold nslices x nq entries, slice-major
+    int64_t nq;
+    uint8_t *cflag;        // in: flags of the history sweep (non-zero: undecidable); out [0, nq): 2 = undecided here
     int64_t N;
     int d, metric, k, prune0;
     int32_t *out_idx;
@@ -711,22 +884,54 @@ __global__ __launch_bounds__(kBlock) void topk_tie_sort_kernel(ReplayParams p) {
     float *s_dst = smem_f + kReplayCap;                      // kReplayCap
     float *sq = s_dst + kReplayCap;                          // d
     float *sx = sq + d;                                      // kGroupsPerBlock * d
-    int *s_misc = reinterpret_cast<int *>(sx + (size_t)kGroupsPerBlock * d);  // [0] NaN seen
+    int *s_misc = reinterpret_cast<int *>(sx + (size_t)kGroupsPerBlock * d);  // [0] NaN seen, [1] recorded rows kept by the join
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
-    if (p.cflag[t]) return;  // the history sweep could not hold this query: path A
-    const int n1 = p.ccnt[t], n2 = p.hcnt[t], n = n1 + n2;
+    // Join of the row slices.  Slice s swept its rows from a cold threshold, so its list + history hold every row of the slice
+    // whose approximate score reached (K-th best approximate score among the slice's EARLIER rows) - 2 delta -- a superset
+    // of what an unsliced sweep records there, and far too many.  A row of slice s is needed only if its score reaches
+    // F_s = max over the earlier slices u < s of f_u, f_u = the threshold slice u ended with = (a lower bound of the K-th
+    // best approximate score of slice u's rows) - 2 delta: a row below F_s has at least K earlier rows whose approximate
+    // scores exceed its own by more than 2 delta, i.e. K earlier rows that are strictly closer in exact arithmetic, which
+    // is the replay's condition for treating it as one of the unrecorded rows of a gap (see ReplayParams).
+    int *s_n = s_misc + 1;
+    bool flagged = false;
+    for (int sl = 0; sl < p.nslices; sl++) flagged |= p.cflag[(int64_t)sl * p.nq + t] != 0;
+    if (flagged) {  // some slice could not hold this query (overflow): path A
+        if (tid == 0) p.cflag[t] = 1;
+        return;
+    }
     const int64_t self = p.self[t];
     const int64_t row = p.pos[t];
     const float *qrow = p.Qf ? p.Qf + row * d : p.X + self * d;
     for (int e = tid; e < d; e += kBlock) sq[e] = qrow[e];
-    if (tid == 0) s_misc[0] = 0;
+    if (tid == 0) s_misc[0] = 0, s_n[0] = 0;
+    __syncthreads();
+    float fprev = -__builtin_inff();
+    for (int sl = 0; sl < p.nslices; sl++) {
+        const int64_t qs = (int64_t)sl * p.nq + t;
+        const int n1 = p.ccnt[qs], n2 = p.hcnt[qs];
+        const uint2 *cb = p.cbuf + qs * kCap, *hb = p.hbuf + qs * kHistCap;
+        for (int c = tid; c < n1 + n2; c += kBlock) {
+            const uint2 ent = c < n1 ? cb[c] : hb[c - n1];
+            if (fkey_inv(ent.x) >= fprev) {
+                const int at = atomicAdd(s_n, 1);
+                if (at < kReplayCap) s_idx[at] = (int)ent.y;
+            }
+        }
+        fprev = fmaxf(fprev, p.fslice[qs]);
+    }
+    __syncthreads();
+    const int n = s_n[0];
+    if (n > kReplayCap) {  // more recorded rows than the replay sorts: path A
+        if (tid == 0) p.cflag[t] = 1;
+        return;
+    }
     __syncthreads();
     const VecShape vs(d);
     const float qq = p.metric == GORSE_METRIC_COSINE ? p.qn2[row] : 0.0f;
-    const uint2 *cb = p.cbuf + t * kCap, *hb = p.hbuf + t * kHistCap;
     for (int c = gib; c < n; c += kGroupsPerBlock) {  // exact distances, as topk_rescore_kernel
-        const int64_t i = c < n1 ? cb[c].y : hb[c - n1].y;
+        const int64_t i = s_idx[c];
         float *xr = sx + (size_t)gib * d;
         for (int e = lane; e < d; e += kGroup) xr[e] = p.X[i * d + e];
         __builtin_amdgcn_wave_barrier();
@@ -742,7 +947,6 @@ __global__ __launch_bounds__(kBlock) void topk_tie_sort_kernel(ReplayParams p) {
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            s_idx[c] = (int)i;
             s_dst[c] = r;
             if (r != r) s_misc[0] = 1;
         }
@@ -870,7 +1074,7 @@ struct RegHeap {
 
 // stage 2 of the tie path: one WAVE per query replays the reference's heap over the sorted entries (see the comment
 // above ReplayParams); four queries per workgroup, no LDS.
-__global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, int64_t nq) {
+__global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, int64_t nq, int g_replay_literal) {
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= nq) return;
@@ -888,7 +1092,31 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
         mx.push(-1, kInf);
         mx.pop(dv, dw);
     };
+    // T leaves the heap array as it is unless equal weights sit where its push and pop look.  With the heap full (n = k),
+    // push(+inf) climbs from slot n to the root and shifts the path's elements down one level; pop then sends the element
+    // E that came to rest in slot n (the old occupant of slot p1 = parent(n)) back down from the root, and every level
+    // restores its old occupant iff (a) the path's child wins the comparison of the two children -- certain when it is the
+    // LEFT child (container/heap prefers the left on a tie), and when it is the right child only if the old parent is
+    // strictly greater than the left child -- and (b) the old parent is strictly greater than E.  E then stops in p1, whose
+    // remaining child cannot beat it.  A dozen scalar comparisons instead of two sift passes and a snapshot compare
+    // (tests/test_replay_claim_cpu.py checks the criterion against the literal T).
+    auto t_is_identity = [&]() -> bool {
+        const int n = mx.n;
+        if (n < 1) return false;
+        int child = (n - 1) / 2;  // p1
+        const float e = mx.getw(child);
+        if (!(e < kInf)) return false;
+        while (child > 0) {
+            const int parent = (child - 1) / 2;
+            const float wp = mx.getw(parent);
+            if (!(wp > e) || !(wp < kInf)) return false;
+            if ((child & 1) == 0 && !(wp > mx.getw(child - 1))) return false;  // right child: the left sibling must lose
+            child = parent;
+        }
+        return true;
+    };
     auto t_pow = [&](int64_t gap) {
+        if (!(g_replay_literal) && t_is_identity()) return;
         int64_t steps = 0;
         while (steps < gap && steps < 16) {  // fixpoint (the usual case: no equal distances on the path) or pre-period
             const RegHeap<true> snap = mx;
@@ -1090,7 +1318,8 @@ int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE><<<dim3(grid), dim3(WV * 64), lds, h->stream>>>(p);
+    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE>
+        <<<dim3(grid, HIST ? (unsigned)std::max(p.nslices, 1) : 1u), dim3(WV * 64), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -1189,6 +1418,10 @@ int32_t topk_mfma_prepare(gorse_topk *h) {
         float mn2 = std::numeric_limits<float>::infinity();
         for (float v : n2) mn2 = std::min(mn2, v);
         h->coarse_ok = h->metric == GORSE_METRIC_COSINE && mn2 > 0.0f && std::sqrt(mx / mn2) <= 1.02f;
+        if (h->metric == GORSE_METRIC_COSINE && mn2 > 0.0f) {  // bounds of 1 / sqrtf(norm2[i]) as the device rounds it
+            h->rs_min = (1.0f / std::sqrt(mx)) * (1.0f - 1e-6f);
+            h->rs_max = (1.0f / std::sqrt(mn2)) * (1.0f + 1e-6f);
+        }
     }
     h->kp = kp;
     const int kpad = kp * 16;
@@ -1319,6 +1552,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.nq = m;
         sp.kth = kth;
         sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1, sp.vote = 0;
+        sp.nslices = 1;
+        sp.rs_min = h->rs_min, sp.rs_max = h->rs_max;
         // variant bit 11: candidate path at the default priority; bit 13: the whole epilogue at priority 1 (probe)
         sp.prio = ((g_topk_variant & 2048) ? 0 : 1) | ((g_topk_variant & 8192) ? 2 : 0);
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
@@ -1420,19 +1655,28 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 GORSE_TRY(h->rp_self.ensure((size_t)m2));
                 GORSE_TRY(h->rp_op.ensure((size_t)m2 * kpad));
                 GORSE_TRY(h->rp_margin.ensure((size_t)m2));
-                GORSE_TRY(h->rp_cbuf.ensure((size_t)m2 * kCap));
-                GORSE_TRY(h->rp_hbuf.ensure((size_t)m2 * kHistCap));
-                GORSE_TRY(h->rp_ccnt.ensure((size_t)m2));
-                GORSE_TRY(h->rp_hcnt.ensure((size_t)m2));
-                GORSE_TRY(h->rp_flag.ensure((size_t)m2));
+                // Row slices: a history sweep serves few queries (1 % of a chunk), so its workgroups are few, and each would walk
+                // all N rows on its own -- 56 ms for 10,000 queries at C4, three quarters of the tie path.  Cut into slices of
+                // rows, slices x as many workgroups each walk 1 / slices of the rows; topk_tie_sort_kernel joins the slices.
+                // Variant bit 14: eight slices whatever N (lets small test inputs take the path); bit 15: one slice.
+                int nsl = (int)std::min<int64_t>(kMaxSlices, std::max<int64_t>(1, h->N / 32768));
+                if (g_topk_variant & 16384) nsl = kMaxSlices;
+                if (g_topk_variant & 32768) nsl = 1;
+                const size_t sm2 = (size_t)nsl * (size_t)m2;
+                GORSE_TRY(h->rp_cbuf.ensure(sm2 * kCap));
+                GORSE_TRY(h->rp_hbuf.ensure(sm2 * kHistCap));
+                GORSE_TRY(h->rp_ccnt.ensure(sm2));
+                GORSE_TRY(h->rp_hcnt.ensure(sm2));
+                GORSE_TRY(h->rp_flag.ensure(sm2));
+                GORSE_TRY(h->rp_fslice.ensure(sm2));
                 GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_pos.p, pos.data(), (size_t)m2 * 4, hipMemcpyHostToDevice, h->stream));
                 GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_self.p, selfs.data(), (size_t)m2 * 8, hipMemcpyHostToDevice, h->stream));
                 gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, h->rp_pos.p, kpad,
                                                                                  h->rp_op.p, h->rp_margin.p);
                 GORSE_HIP_CHECK(hipGetLastError());
-                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, (size_t)m2, h->stream));
-                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_hcnt.p, 0, (size_t)m2 * 4, h->stream));
-                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, (size_t)m2 * 4, h->stream));
+                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, sm2, h->stream));
+                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_hcnt.p, 0, sm2 * 4, h->stream));
+                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, sm2 * 4, h->stream));
                 SweepParams hp = sp;
                 hp.f0 = nullptr;  // the history sweep records what a threshold that starts at -inf would have kept
                 hp.vote = 0;
@@ -1443,6 +1687,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 hp.cflag = h->rp_flag.p;
                 hp.hbuf = h->rp_hbuf.p;
                 hp.hcnt = h->rp_hcnt.p;
+                hp.f_out = h->rp_fslice.p;
+                hp.nslices = nsl;
                 hp.nq = m2;
                 tok = h->prof.begin(GORSE_PROF_TOPK_HIST, h->stream);
                 GORSE_TRY(dispatch_sweep(h, hp, scale, true));
@@ -1458,6 +1704,9 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 pp.ccnt = h->rp_ccnt.p;
                 pp.hbuf = h->rp_hbuf.p;
                 pp.hcnt = h->rp_hcnt.p;
+                pp.fslice = h->rp_fslice.p;
+                pp.nslices = nsl;
+                pp.nq = m2;
                 pp.cflag = h->rp_flag.p;
                 pp.N = h->N;
                 pp.d = d;
@@ -1479,7 +1728,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 tok = h->prof.begin(GORSE_PROF_TOPK_REPLAY, h->stream);
                 topk_tie_sort_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
                 GORSE_HIP_CHECK(hipGetLastError());
-                topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2);
+                topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2, (g_topk_variant & 65536) ? 1 : 0);
                 GORSE_HIP_CHECK(hipGetLastError());
                 h->prof.end(tok, h->stream);
                 f2.resize((size_t)m2);

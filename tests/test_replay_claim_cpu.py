@@ -177,3 +177,51 @@ def test_t_is_a_short_cycle():
         worst_pre = max(worst_pre, seen[tuple(h.v)])
         worst_per = max(worst_per, t - seen[tuple(h.v)])
     assert worst_pre <= 12 and worst_per <= 32, (worst_pre, worst_per)
+
+
+def t_is_identity(h):
+    """the criterion of t_is_identity in topk_tie_replay_kernel: T = push(+inf), pop leaves the array of a FULL heap as it is"""
+    n = len(h.v)
+    if n < 1:
+        return False
+    child = (n - 1) // 2
+    e = h.w[child]
+    if not e < INF:
+        return False
+    while child > 0:
+        parent = (child - 1) // 2
+        wp = h.w[parent]
+        if not wp > e or not wp < INF:
+            return False
+        if child % 2 == 0 and not wp > h.w[child - 1]:
+            return False
+        child = parent
+    return True
+
+
+def test_identity_criterion_of_T_is_sound():
+    """Whenever the criterion holds, the literal T leaves values and weights where they were; and it is not vacuous: it
+    holds for most heaps without ties, fails for some with ties, and among the failures T really does move elements."""
+    rng = np.random.default_rng(3)
+    held = moved_when_rejected = rejected = 0
+    for trial in range(4000):
+        k = int(rng.integers(1, 40))
+        levels = int(rng.integers(1, 6))  # few distinct weights: many ties
+        h = GoMaxHeap()
+        for i in range(k + int(rng.integers(0, 30))):
+            h.push(i, float(rng.integers(0, levels if trial % 2 else 1000)))
+            if len(h.v) > k:
+                h.pop()
+        if len(h.v) < k:
+            continue
+        v0, w0 = list(h.v), list(h.w)
+        ok = t_is_identity(h)
+        h.push(-1, INF)
+        h.pop()
+        if ok:
+            held += 1
+            assert h.v == v0 and h.w == w0
+        else:
+            rejected += 1
+            moved_when_rejected += h.v != v0
+    assert held > 1000 and rejected > 100 and moved_when_rejected > 20
