@@ -396,25 +396,22 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
             }
         }
     };
-    // "everything this wave issued before its last `keep` tiles' DMA instructions has completed": loads (the DMA among them)
-    // retire in order, so once no more than keep * (instructions per tile) operations are outstanding, every older tile of
-    // this wave is in LDS -- whatever stores (the candidate appends) are still on their way.
+    // "everything this wave issued before the DMA instructions of its last `keep` (0 or 1) tiles has completed": loads (the DMA
+    // among them) retire in order, so once no more than one tile's instructions are outstanding, every older tile of this wave
+    // is in LDS -- whatever stores (the candidate appends) are still on their way.
     auto dma_wait = [&](int keep) {
         if constexpr (DMA) {
-            if (keep == 0) {
+            if (keep == 0)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else if (wu < RSW) {
-                if (keep == 1)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1) : "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DPW + 1)) : "memory");
-            } else {
-                if (keep == 1)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
-            }
+            else if (wu < RSW)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
         }
+    };
+    auto post = [&](int *ctr) {  // DMA: this wave's part of a tile is in LDS (dma_wait came first)
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     // The waves of a workgroup share every tile but do not march in step: a wave that takes the candidate path (~2200 cycles)
@@ -432,7 +429,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto wait_for = [&](int *ctr, int target) {
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        // bounded (a few seconds): a protocol error shows as wrong rows in the parity tests, not as a hung device
+        for (unsigned spins = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && spins < (1u << 26); spins++)
+            __builtin_amdgcn_s_sleep(1);
         if constexpr (DMA)
             asm volatile("" ::: "memory");
         else
@@ -442,6 +441,10 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     if constexpr (DMA) {
         if (NT > 0) dma_tile(0, 0);
         if (NT > 1) dma_tile(1, 1);
+        if (NT > 0) {
+            dma_wait(NT > 1 ? 1 : 0);  // tile 0 has landed (tile 1 may be in flight)
+            post(&s_sync[0]);
+        }
     } else {
         if (NT > 0) {
             load_tile(0);
@@ -471,7 +474,8 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         if (PROF) ts = __builtin_amdgcn_s_memtime();
         const int nb = buf + 1 == NBUF ? 0 : buf + 1;
         if constexpr (DMA) {
-            // tile t + 2 goes into the buffer tile t + 2 - NBUF was read from
+            // tile t + 2 goes into the buffer tile t + 2 - NBUF was read from; tile t + 1 (issued a tile ago) has landed by now
+            // and is announced here, one tile ahead of its use, so that a wave may run a tile ahead of the slowest one
             const int b2 = nb + 1 == NBUF ? 0 : nb + 1;
             if (t + 2 < NT) {
                 if (t + 2 >= NBUF) {
@@ -481,12 +485,11 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                     if (PROF) c_bar += __builtin_amdgcn_s_memtime() - tw;
                 }
                 dma_tile(t + 2, b2);
-                dma_wait(2);  // tiles t + 1 and t + 2 may be in flight: tile t has landed
-            } else {
-                dma_wait(0);
             }
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(&s_sync[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (t + 1 < NT) {
+                dma_wait(t + 2 < NT ? 1 : 0);
+                post(&s_sync[nb]);
+            }
         } else {
             if (t + 1 < NT) {  // rows of tile t + 1 (loaded during tile t - 1) into the buffer tile t + 1 - NBUF was read from
                 if (t + 1 >= NBUF) {
@@ -1553,7 +1556,10 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.kth = kth;
         sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1, sp.vote = 0;
         sp.nslices = 1;
-        sp.rs_min = h->rs_min, sp.rs_max = h->rs_max;
+        // bounds of the per-row value for the DMA sweeps' block test: the cosine scales; without them (a masked -dot index:
+        // the value is 1 or NaN) the bound is the score itself
+        sp.rs_min = h->metric == GORSE_METRIC_COSINE ? h->rs_min : 1.0f;
+        sp.rs_max = h->metric == GORSE_METRIC_COSINE ? h->rs_max : 1.0f;
         // variant bit 11: candidate path at the default priority; bit 13: the whole epilogue at priority 1 (probe)
         sp.prio = ((g_topk_variant & 2048) ? 0 : 1) | ((g_topk_variant & 8192) ? 2 : 0);
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800

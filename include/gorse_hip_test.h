@@ -31,8 +31,10 @@ void gorse_hip_test_set_topk_path(int32_t path);
  * ships with), bit 2 / bit 3 = block-level row-scale bound of the cosine sweep off / on (default: on when all norms
  * are within 2 % of each other), bit 4 = the instrumented twin (see below), bit 5 / bit 6 = compact a candidate list
  * when one of its two sub-lists exceeds 128 / 96 entries (default 224), bit 7 = the candidate path of the C4-shaped
- * sweep votes on each score row wave-wide before touching it (written without a GPU; to be measured).  Results never
- * depend on them. */
+ * sweep votes on each score row wave-wide before touching it (written without a GPU; to be measured), bit 14 = the history
+ * sweep of the tie path in eight row slices whatever the index size (default: one slice per 32768 rows, at most eight),
+ * bit 15 = in one slice, bit 16 = the tie replay applies every T = "push +inf, pop" literally instead of first testing
+ * whether it leaves the heap as it is.  Results never depend on them. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
 /* variant bit 8 (256) switches the warm start of the sweep off (pilot sweep over every 16th row tile -> initial thresholds,
  * verified by the main sweep; csrc/topk_mfma.hip topk_mfma_search), bit 9 (512) switches it on below its size limit of 2^17

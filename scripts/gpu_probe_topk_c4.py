@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""C4 (1M x 128 bf16, cosine, k = 100) on the device: the all-pairs pass with its stage times, a few rows checked against the
+oracle, and the switches of the tie path (row slices of the history sweep, the replay's shortcut).  usage: gpu_probe_topk_c4.py [n_queries]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from gorse_amd import capi, synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def run(t, k, q0, q1, label, reps=2):
+    t.all_pairs(k, q0, q1, fetch=False)
+    t.synchronize()
+    classes = (capi.PROF_TOPK_SWEEP, capi.PROF_TOPK_SELECT, capi.PROF_TOPK_HIST, capi.PROF_TOPK_REPLAY)
+    t.set_profiling(True)
+    before = [t.get_profile(c) for c in classes]  # the counters are cumulative
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        t.all_pairs(k, q0, q1, fetch=False)
+    t.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    stages = [(a[0] - b[0], a[1] - b[1]) for a, b in zip([t.get_profile(c) for c in classes], before)]
+    t.set_profiling(False)
+    n_fb, n_tie = t.last_stats()
+    print("%-34s %8.2f ms per pass | sweep %.2f rescore %.2f history %.2f replay %.2f ms | tie queries %d, to the scan %d"
+          % (label, dt * 1e3, *(ms / max(reps, 1) for _, ms in stages), n_tie, n_fb), flush=True)
+
+
+def main():
+    nq = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    N, d, k = 1_000_000, 128, 100
+    Xb, Xe = synth.s_emb(N, d, 44)
+    t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
+    L = capi.lib()
+    run(t, k, 0, nq, "default")
+    # parity of a few rows (the GPU tests and bench.py check more)
+    o = orc.Oracle()
+    o.set_isa(orc.ISA_AVX512)
+    idx, dist = t.all_pairs(k, 500_000, 500_016)
+    for r in range(16):
+        ei, ed = o.search_index(Xe, orc.METRIC_COSINE, 500_000 + r, k)
+        assert np.array_equal(idx[r], ei) and np.array_equal(dist[r].view(np.uint32), ed.view(np.uint32)), r
+    print("16 rows equal the oracle's", flush=True)
+    for v, label in ((1 << 15, "history sweep in one slice"), (1 << 16, "replay: literal T"), ((1 << 15) | (1 << 16), "one slice + literal T (round 2)"),
+                     (256, "no warm start"), (4, "no block-level scale bound")):
+        L.gorse_hip_test_set_topk_variant(v)
+        run(t, k, 0, nq, label, reps=1)
+    L.gorse_hip_test_set_topk_variant(0)
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,42 @@ def test_tie_replay_long_history(oracle, N, d, k, lo, hi, metric):
         assert c2[r] == ei.size and np.array_equal(i2[r, :c2[r]], ei) and np.array_equal(bits(d2[r, :c2[r]]), bits(ed))
 
 
+V_SLICES8, V_SLICE1, V_REPLAY_LITERAL = 1 << 14, 1 << 15, 1 << 16
+
+
+@pytest.mark.parametrize("variant", [V_SLICES8, V_SLICE1, V_SLICES8 | V_REPLAY_LITERAL, V_SLICE1 | V_REPLAY_LITERAL])
+@pytest.mark.parametrize("metric", [capi.METRIC_NEG_DOT, capi.METRIC_COSINE, capi.METRIC_EUCLIDEAN])
+def test_history_sweep_in_row_slices_and_the_replay_shortcut(oracle, variant, metric):
+    """The tie path's two round-3 changes, each against its plain form and the oracle: the history sweep cut into eight row
+    slices that start cold and are joined by topk_tie_sort_kernel (thresholds of the earlier slices filter the later ones),
+    and the replay's test "T = push +inf, pop leaves this heap as it is" in place of the literal T + snapshot compare.
+    Small-integer vectors: ties everywhere, long gaps of unrecorded rows between the recorded ones."""
+    rng = np.random.default_rng(77 + metric)
+    N, d, k = 24000, 6, 40
+    X = rng.integers(-4, 5, (N, d)).astype(np.float32)
+    if metric == capi.METRIC_COSINE:
+        X[(X == 0).all(1)] = 1.0
+    capi.lib().gorse_hip_test_set_topk_variant(variant)
+    t = capi.TopK(X, metric)
+    qs = rng.choice(N, 256, replace=False)
+    idx, dist, cnt = t.search_index(qs, k)
+    n_scan, n_replay = t.last_stats()
+    for r, q in enumerate(qs):
+        ei, ed = oracle.search_index(X, metric, int(q), k)
+        assert cnt[r] == ei.size and np.array_equal(idx[r, :cnt[r]], ei), (q, n_scan, n_replay)
+        assert np.array_equal(bits(dist[r, :cnt[r]]), bits(ed))
+    assert n_replay > 100, (n_scan, n_replay)  # the replay, not the literal scan, answered them
+    # distinct distances and a few planted ties: the slices' join must keep every row the reference's heap accepted
+    Xf = rng.standard_normal((N, 16)).astype(np.float32)
+    Xf[5000] = Xf[17]
+    Xf[23000] = Xf[17]
+    t2 = capi.TopK(Xf, metric)
+    i2, d2, c2 = t2.search_index(np.arange(0, 1024), 20)
+    for q in (0, 17, 18, 500, 1023):
+        ei, ed = oracle.search_index(Xf, metric, q, 20)
+        assert c2[q] == ei.size and np.array_equal(i2[q, :c2[q]], ei) and np.array_equal(bits(d2[q, :c2[q]]), bits(ed))
+
+
 def test_duplicates_and_overflowing_lists(oracle):
     # 700 copies of one vector: every list holds > kCap - 128 equal scores -> overflow flag -> scan
     rng = np.random.default_rng(5)
