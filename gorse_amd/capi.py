@@ -38,6 +38,9 @@ SIGNATURES = {
     "gorse_mf_get_factors": (C.c_int32, [_vp, _f32p, _f32p]),
     "gorse_mf_score": (C.c_int32, [_vp, _i32p, _i32p, C.c_int64, _f32p]),
     "gorse_mf_rank": (C.c_int32, [_vp, C.c_int64, _i32p, _i64p, _i32p, C.c_int32, _i32p, _i32p]),
+    "gorse_mf_sample_user_negatives": (C.c_int32, [_vp, _i64p, _i32p, C.c_int32, C.c_uint64, _i32p, _i32p]),
+    "gorse_mf_resident_candidates": (C.c_int32, [_vp, _i64p, _i64p]),
+    "gorse_mf_rank_resident": (C.c_int32, [_vp, C.c_int32, _i32p, _i32p, _i32p]),
     "gorse_bpr_epoch": (C.c_int32, [_vp, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
                                     _i32p, _f64p]),
     "gorse_bpr_epoch_enqueue": (C.c_int32, [_vp, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int64,
@@ -201,6 +204,29 @@ class MF:
         check(lib().gorse_mf_rank(self.h, users.size, _p(users, _i32p), _p(cand_indptr, _i64p), _p(cand, _i32p), topk,
                                   _p(rank, _i32p), _p(rlen, _i32p)))
         return rank, rlen
+
+    def sample_user_negatives(self, test_indptr, test_indices, num_candidates, seed=0, fetch=True):
+        """dataset.SampleUserNegatives on the device: (neg U x n padded with -1, len U); the candidate lists of the users with
+        test feedback stay resident for rank_resident"""
+        tp, ti = _arr(test_indptr, np.int64), _arr(test_indices, np.int32)
+        if ti.size == 0:
+            ti = np.zeros(1, np.int32)
+        neg = np.empty((self.U, num_candidates), np.int32) if fetch else None
+        ln = np.empty(self.U, np.int32) if fetch else None
+        check(lib().gorse_mf_sample_user_negatives(self.h, _p(tp, _i64p), _p(ti, _i32p), num_candidates, seed,
+                                                   _p(neg, _i32p) if fetch else None, _p(ln, _i32p) if fetch else None))
+        return neg, ln
+
+    def rank_resident(self, topk):
+        """Rank over the resident candidate lists: (users, rank n_users x topk padded with -1, lengths)"""
+        nu, nc = C.c_int64(0), C.c_int64(0)
+        check(lib().gorse_mf_resident_candidates(self.h, C.byref(nu), C.byref(nc)))
+        users = np.empty(nu.value, np.int32)
+        rank = np.empty((nu.value, topk), np.int32)
+        rlen = np.empty(nu.value, np.int32)
+        if nu.value:
+            check(lib().gorse_mf_rank_resident(self.h, topk, _p(users, _i32p), _p(rank, _i32p), _p(rlen, _i32p)))
+        return users, rank, rlen
 
     def bpr_epoch(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_ATOMIC, want_loss=False,
                   cancel=None):

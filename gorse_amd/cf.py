@@ -144,9 +144,10 @@ class Dataset:
         return self._idf(1, self.CountItems())
 
 
-def datasets_from_synth(data):
+def datasets_from_synth(data, preload_negatives=True):
     """(train, test) Datasets from a gorse_amd.synth.CFData, in the NCF built-in layout
-    (dataset.LoadDataFromBuiltIn, dataset/dataset.go:398-490): shared dictionaries, preloaded negatives."""
+    (dataset.LoadDataFromBuiltIn, dataset/dataset.go:398-490): shared dictionaries, preloaded negatives -- or, with
+    preload_negatives=False, a production split (master/tasks.go:232): Evaluate samples the negatives itself."""
     train = Dataset()
     for u in range(data.U):
         train.AddUser(u)
@@ -157,8 +158,9 @@ def datasets_from_synth(data):
     test = Dataset(share_dicts_with=train)
     trows = np.repeat(np.arange(data.U, dtype=np.int32), np.diff(data.test_ptr))
     test.add_feedback_arrays(trows, data.test_idx)
-    for u in np.nonzero(np.diff(data.neg_ptr) > 0)[0]:
-        test.SetNegatives(int(u), data.neg_idx[data.neg_ptr[u]:data.neg_ptr[u + 1]])
+    if preload_negatives:
+        for u in np.nonzero(np.diff(data.neg_ptr) > 0)[0]:
+            test.SetNegatives(int(u), data.neg_idx[data.neg_ptr[u]:data.neg_ptr[u + 1]])
     return train, test
 
 
@@ -265,6 +267,11 @@ class _Model:
 
     def Name(self):
         return host().gh_model_name(self.p).decode()
+
+    def factors(self):
+        """(P, Q): the model's UserFactor / ItemFactor rows as matrices"""
+        U, I = self.CountUsers(), self.CountItems()
+        return (np.stack([self.GetUserFactor(u) for u in range(U)]), np.stack([self.GetItemFactor(i) for i in range(I)]))
 
     def load_factors(self, P, Q):
         P, Q = np.ascontiguousarray(P, np.float32), np.ascontiguousarray(Q, np.float32)

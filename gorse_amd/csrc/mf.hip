@@ -396,29 +396,46 @@ extern "C" int32_t gorse_mf_rank(gorse_mf *h, int64_t n_users, const int32_t *us
         if (cand[c] < 0 || cand[c] >= h->I) return fail(GORSE_ERR_RANGE, "candidate %d out of range", cand[c]);
     GORSE_TRY(h->use());
     GORSE_TRY(mf_sync_streams(h));
-    // staging layout: cand_ptr | users | cand | pair_u | score | heap_v | heap_w | rank | len
+    // inputs to the device (their own buffer: mf_rank_device carves h->stage for its scratch)
     size_t off = 0;
     auto carve = [&](size_t bytes) {
         size_t o = off;
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    size_t o_ptr = carve((size_t)(n_users + 1) * 8), o_users = carve((size_t)n_users * 4), o_cand = carve((size_t)nc * 4),
-           o_pu = carve((size_t)nc * 4), o_score = carve((size_t)nc * 4), o_hv = carve((size_t)n_users * (topk + 1) * 4),
-           o_hw = carve((size_t)n_users * (topk + 1) * 4), o_rank = carve((size_t)n_users * topk * 4),
-           o_len = carve((size_t)n_users * 4);
+    const size_t o_ptr = carve((size_t)(n_users + 1) * 8), o_users = carve((size_t)n_users * 4), o_cand = carve((size_t)std::max<int64_t>(nc, 1) * 4);
+    GORSE_TRY(h->rank_in.ensure(off));
+    char *base = h->rank_in.p;
+    int64_t *d_ptr = (int64_t *)(base + o_ptr);
+    int32_t *d_users = (int32_t *)(base + o_users), *d_cand = (int32_t *)(base + o_cand);
+    GORSE_HIP_CHECK(hipMemcpyAsync(d_ptr, cand_indptr, (size_t)(n_users + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(d_users, users, (size_t)n_users * 4, hipMemcpyHostToDevice, h->stream));
+    if (nc > 0) GORSE_HIP_CHECK(hipMemcpyAsync(d_cand, cand, (size_t)nc * 4, hipMemcpyHostToDevice, h->stream));
+    GORSE_TRY(mf_rank_device(h, n_users, d_users, d_ptr, d_cand, nc, topk, rank_out, rank_len));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+int32_t gorse::mf_rank_device(gorse_mf *h, int64_t n_users, const int32_t *d_users, const int64_t *d_ptr, const int32_t *d_cand,
+                              int64_t nc, int32_t topk, int32_t *rank_out, int32_t *rank_len) {
+    // scratch layout: pair_u | score | heap_v | heap_w | rank | len
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_pu = carve((size_t)std::max<int64_t>(nc, 1) * 4), o_score = carve((size_t)std::max<int64_t>(nc, 1) * 4),
+                 o_hv = carve((size_t)n_users * (topk + 1) * 4), o_hw = carve((size_t)n_users * (topk + 1) * 4),
+                 o_rank = carve((size_t)n_users * topk * 4), o_len = carve((size_t)n_users * 4);
     GORSE_TRY(h->stage.ensure(off));
     char *base = h->stage.p;
-    int64_t *d_ptr = (int64_t *)(base + o_ptr);
-    int32_t *d_users = (int32_t *)(base + o_users), *d_cand = (int32_t *)(base + o_cand), *d_pu = (int32_t *)(base + o_pu);
+    int32_t *d_pu = (int32_t *)(base + o_pu);
     float *d_score = (float *)(base + o_score);
     int32_t *d_hv = (int32_t *)(base + o_hv);
     float *d_hw = (float *)(base + o_hw);
     int32_t *d_rank = (int32_t *)(base + o_rank), *d_len = (int32_t *)(base + o_len);
-    GORSE_HIP_CHECK(hipMemcpyAsync(d_ptr, cand_indptr, (size_t)(n_users + 1) * 8, hipMemcpyHostToDevice, h->stream));
-    GORSE_HIP_CHECK(hipMemcpyAsync(d_users, users, (size_t)n_users * 4, hipMemcpyHostToDevice, h->stream));
     if (nc > 0) {
-        GORSE_HIP_CHECK(hipMemcpyAsync(d_cand, cand, (size_t)nc * 4, hipMemcpyHostToDevice, h->stream));
         int64_t eb = n_users < 4096 ? n_users : 4096;
         expand_users_kernel<<<dim3((unsigned)eb), dim3(64), 0, h->stream>>>(d_ptr, d_users, n_users, d_pu);
         GORSE_HIP_CHECK(hipGetLastError());
@@ -429,7 +446,6 @@ extern "C" int32_t gorse_mf_rank(gorse_mf *h, int64_t n_users, const int32_t *us
     GORSE_HIP_CHECK(hipGetLastError());
     GORSE_HIP_CHECK(hipMemcpyAsync(rank_out, d_rank, (size_t)n_users * topk * 4, hipMemcpyDeviceToHost, h->stream));
     GORSE_HIP_CHECK(hipMemcpyAsync(rank_len, d_len, (size_t)n_users * 4, hipMemcpyDeviceToHost, h->stream));
-    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     return GORSE_OK;
 }
 

@@ -54,8 +54,14 @@ struct gorse_mf {
     gorse::DevBuf<unsigned long long> als_prof;  // probe: phase counters of als_row_kernel (gorse_hip_test_als_profile)
     gorse::DevBuf<float> als_zeros;    // 64 zero words: where padding lanes of the gathers read
     gorse::DevBuf<float> als_partial;  // n_chunks x (d*d + d) partial Gram matrices + column sums
+    // Evaluate's resident split (eval.hip): the test rows, every user's sampled negatives, and the candidate CSR of the users
+    // with test feedback (user ids ascending, "test items then negatives" per user)
+    gorse::DevBuf<int64_t> ev_tptr, ev_upos, ev_cpos, ev_cptr;
+    gorse::DevBuf<int32_t> ev_tidx, ev_neg, ev_neglen, ev_has, ev_clen, ev_users, ev_cand;
+    int64_t ev_users_n = 0, ev_cand_n = 0;
+    bool ev_valid = false;
     // generic staging
-    gorse::DevBuf<char> stage;
+    gorse::DevBuf<char> stage, rank_in;
     gorse::KernelProfile prof{GORSE_PROF_NCLASSES};
 
     int32_t use() const {
@@ -71,4 +77,8 @@ int32_t mf_sync_streams(gorse_mf *h);
 int32_t mf_delta_export_async(gorse_mf *h, float *dst);        // mf.hip: dst <- Q - Q_sync, enqueued on h->stream
 int32_t mf_delta_import_async(gorse_mf *h, const float *src);  // mf.hip: Q <- Q_sync + src; Q_sync <- Q
 int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, int64_t lo, int64_t hi);
+// mf.hip: Rank + TopKFilter for n_users users over candidate lists ALREADY on the device (nc entries in all); the rank lists go
+// to the host arrays (n_users * topk padded with -1, lengths), enqueued on h->stream -- the caller synchronises
+int32_t mf_rank_device(gorse_mf *h, int64_t n_users, const int32_t *d_users, const int64_t *d_cand_ptr, const int32_t *d_cand,
+                       int64_t nc, int32_t topk, int32_t *rank_out, int32_t *rank_len);
 }

@@ -163,6 +163,7 @@ void MatrixFactorization::create_handle(const dataset::Dataset &trainSet, bool w
         }
         h_ = res->h;
         borrowed_ = true;
+        handle_train_ = (const void *)&trainSet;
         check(gorse_mf_set_factors(h_, UserFactor.data(), ItemFactor.data()));
         return;
     }
@@ -172,6 +173,7 @@ void MatrixFactorization::create_handle(const dataset::Dataset &trainSet, bool w
     if (with_items) flatten(trainSet.GetItemFeedback(), (size_t)trainSet.CountItems(), iptr, iidx);
     check(gorse_mf_create(&h_, device, trainSet.CountUsers(), trainSet.CountItems(), nFactors_, uptr.data(), uidx.data(),
                           with_items ? iptr.data() : nullptr, with_items ? iidx.data() : nullptr));
+    handle_train_ = (const void *)&trainSet;
     check(gorse_mf_set_factors(h_, UserFactor.data(), ItemFactor.data()));
 }
 
@@ -189,6 +191,25 @@ void MatrixFactorization::ensure_resident() {
 std::vector<float> Evaluate(MatrixFactorization &estimator, dataset::Dataset &testSet, dataset::Dataset &trainSet, int topK,
                             int numCandidates, int nJobs, const std::vector<Metric> &scorers) {
     (void)nJobs;  // the device ranks every user at once; sums are taken in user order (== nJobs 1)
+    // a production split has no preloaded negatives: sample them on the device when the handle of this Fit holds trainSet
+    // (the host loop of Dataset::SampleUserNegatives draws the same lists, only user after user)
+    if (!testSet.HasNegatives()) estimator.SampleNegativesOnDevice(testSet, trainSet, numCandidates);
+    if (estimator.HasResidentCandidates(testSet)) {  // every later Evaluate of the Fit: no upload, rank lists only
+        const auto &tf = testSet.GetUserFeedback();
+        std::vector<int32_t> users;
+        auto ranks = estimator.RankResident(users, topK);
+        std::vector<float> sum(scorers.size(), 0.0f);
+        float count = 0;
+        for (size_t t = 0; t < users.size(); t++) {
+            const auto &row = tf[(size_t)users[t]];
+            TargetSet target(row.begin(), row.end());
+            count++;
+            for (size_t m = 0; m < scorers.size(); m++) sum[m] += scorers[m](target, ranks[t]);
+        }
+        const float inv = 1 / count;
+        for (auto &x : sum) x *= inv;
+        return sum;
+    }
     const auto &negatives = testSet.SampleUserNegatives(trainSet, numCandidates);
     const auto &tf = testSet.GetUserFeedback();
     std::vector<int32_t> users;

@@ -51,6 +51,8 @@ namespace util {
 class RandomGenerator {
    public:
     explicit RandomGenerator(int64_t seed = 0) { g_.init((uint64_t)seed, 0, 0); }
+    // a generator on one of the library's counter-based streams (csrc/common.hpp Philox: seed, epoch word, sample word)
+    RandomGenerator(int64_t seed, uint64_t epoch, uint64_t sample) { g_.init((uint64_t)seed, epoch, sample); }
     int32_t Int31n(int32_t n) { return g_.int31n(n); }
     int Intn(int n) { return (int)g_.int31n((int32_t)n); }
     int64_t Int63() { return ((int64_t)g_.int31() << 32) | ((int64_t)g_.int31() << 1) | (g_.int31() & 1); }
@@ -423,23 +425,37 @@ class Dataset {
         if (negatives_.size() < (size_t)CountUsers()) negatives_.resize((size_t)CountUsers());
         negatives_[(size_t)user] = std::move(negs);
     }
-    // SampleUserNegatives (dataset.go:242-253): cached; seed 0 generator
+    // SampleUserNegatives (dataset.go:242-253): cached.  The reference walks the users with ONE generator seeded 0; its
+    // math/rand stream is not reproducible, so user u draws from its own stream (0, "neg", u) instead --
+    // the stream gorse_mf_sample_user_negatives uses on the device, where all users are sampled at once: the host loop
+    // below and the device produce the same lists.
+    static constexpr uint64_t kNegStream = 0x6e6567ull;
+    bool HasNegatives() const {
+        for (auto &n : negatives_)
+            if (!n.empty()) return true;
+        return false;
+    }
     const std::vector<std::vector<int32_t>> &SampleUserNegatives(const Dataset &excludeSet, int numCandidates) {
-        bool any = false;
-        for (auto &n : negatives_) any = any || !n.empty();
-        if (!any) {
-            util::RandomGenerator rng(0);
+        if (!HasNegatives()) {
             negatives_.assign((size_t)CountUsers(), {});
             const auto &mine = GetUserFeedback();
             const auto &other = excludeSet.GetUserFeedback();
             for (int u = 0; u < CountUsers(); u++) {
-                std::set<int32_t> ex(mine[(size_t)u].begin(), mine[(size_t)u].end());
+                std::set<int32_t> ex;
+                if ((size_t)u < mine.size()) ex.insert(mine[(size_t)u].begin(), mine[(size_t)u].end());
                 if ((size_t)u < other.size()) ex.insert(other[(size_t)u].begin(), other[(size_t)u].end());
+                util::RandomGenerator rng(0, kNegStream, (uint64_t)u);
                 negatives_[(size_t)u] = rng.SampleInt32(0, (int32_t)CountItems(), numCandidates, ex);
             }
         }
         if (negatives_.size() < (size_t)CountUsers()) negatives_.resize((size_t)CountUsers());
         return negatives_;
+    }
+    // the device's lists (U x n padded with -1, lengths) become this split's cached negatives
+    void SetSampledNegatives(const std::vector<int32_t> &neg, const std::vector<int32_t> &len, int n) {
+        negatives_.assign((size_t)CountUsers(), {});
+        for (size_t u = 0; u < negatives_.size() && u < len.size(); u++)
+            negatives_[u].assign(neg.begin() + (ptrdiff_t)(u * (size_t)n), neg.begin() + (ptrdiff_t)(u * (size_t)n) + len[u]);
     }
 
    private:
@@ -632,6 +648,36 @@ class MatrixFactorization {
     void Marshal(std::ostream &w) const;
     void Unmarshal(std::istream &r);
 
+    // SampleUserNegatives on the device: possible when the resident handle holds `trainSet` (a Fit in
+    // progress).  Fills testSet's cached negatives and leaves the candidate lists of the users with test feedback resident, so
+    // that every Evaluate of this Fit ranks without an upload (RankResident).
+    bool SampleNegativesOnDevice(dataset::Dataset &testSet, const dataset::Dataset &trainSet, int numCandidates) {
+        if (!h_ || handle_train_ != (const void *)&trainSet || testSet.CountUsers() != trainSet.CountUsers()) return false;
+        const size_t U = (size_t)testSet.CountUsers();
+        const auto &tf = testSet.GetUserFeedback();
+        std::vector<int64_t> tptr(U + 1, 0);
+        for (size_t u = 0; u < U; u++) tptr[u + 1] = tptr[u] + (u < tf.size() ? (int64_t)tf[u].size() : 0);
+        std::vector<int32_t> tidx((size_t)tptr[U] + 1, 0);
+        for (size_t u = 0; u < U && u < tf.size(); u++) std::copy(tf[u].begin(), tf[u].end(), tidx.begin() + tptr[u]);
+        std::vector<int32_t> neg(U * (size_t)numCandidates), len(U);
+        check(gorse_mf_sample_user_negatives(h_, tptr.data(), tidx.data(), numCandidates, 0, neg.data(), len.data()));
+        testSet.SetSampledNegatives(neg, len, numCandidates);
+        resident_eval_ = (const void *)&testSet;
+        return true;
+    }
+    bool HasResidentCandidates(const dataset::Dataset &testSet) const { return h_ && resident_eval_ == (const void *)&testSet; }
+    std::vector<std::vector<int32_t>> RankResident(std::vector<int32_t> &users, int topN) {
+        int64_t nu = 0, nc = 0;
+        check(gorse_mf_resident_candidates(h_, &nu, &nc));
+        users.resize((size_t)nu);
+        std::vector<int32_t> rank((size_t)nu * (size_t)topN), len((size_t)nu);
+        if (nu > 0) check(gorse_mf_rank_resident(h_, topN, users.data(), rank.data(), len.data()));
+        std::vector<std::vector<int32_t>> out((size_t)nu);
+        for (size_t t = 0; t < (size_t)nu; t++)
+            out[t].assign(rank.begin() + (ptrdiff_t)(t * (size_t)topN), rank.begin() + (ptrdiff_t)(t * (size_t)topN) + len[t]);
+        return out;
+    }
+
     // Rank lists for Evaluate: user -> candidates, on the device (evaluator.go:162-169)
     std::vector<std::vector<int32_t>> RankMany(const std::vector<int32_t> &users,
                                                const std::vector<std::vector<int32_t>> &cands, int topN) {
@@ -662,6 +708,7 @@ class MatrixFactorization {
         if (h_ && !borrowed_) gorse_mf_destroy(h_);  // a borrowed handle stays with its ResidentDataset
         h_ = nullptr;
         borrowed_ = false;
+        handle_train_ = resident_eval_ = nullptr;
     }
     util::RandomGenerator &GetRandomGenerator() { return rng_; }
     // the shared evaluate / early-stopping epoch loop of BPR.Fit and ALS.Fit (model.go:432-440, 496-518)
@@ -674,6 +721,8 @@ class MatrixFactorization {
     gorse_mf *h_ = nullptr;
     bool borrowed_ = false;
     int device_ = 0;
+    const void *handle_train_ = nullptr;   // the training set the resident handle was created from (a Fit in progress)
+    const void *resident_eval_ = nullptr;  // the test split whose candidate lists are resident on h_
 };
 
 // Evaluate (evaluator.go:35-72): candidates = test positives ++ negatives; device rank lists; the

@@ -101,6 +101,25 @@ int32_t gorse_mf_score(gorse_mf *h, const int32_t *u /*host*/, const int32_t *it
 int32_t gorse_mf_rank(gorse_mf *h, int64_t n_users, const int32_t *users /*host*/, const int64_t *cand_indptr /*host*/,
                       const int32_t *cand /*host*/, int32_t topk, int32_t *rank_out /*host*/, int32_t *rank_len /*host*/);
 
+/* dataset.SampleUserNegatives on the device (dataset/dataset.go:242-253 through RandomGenerator.SampleInt32,
+ * common/util/random.go:108-132): for EVERY user num_candidates distinct items outside (the user's feedback in the test split
+ * given here, union the user's train feedback the handle holds), in draw order -- or ALL remaining items ascending when no
+ * more than num_candidates are left (random.go:115-121).  User u draws from its own Philox4x32-10 stream keyed by
+ * (seed, "neg", u) through Go's Int31n (the reference's single math/rand stream, seeded 0, is not reproducible: SURVEY.md
+ * 8c); the reference passes seed 0.  neg_out (host or NULL) receives U * num_candidates items padded with -1, neg_len (host
+ * or NULL) the counts.  The call also leaves, resident on the device, the candidate lists Evaluate ranks
+ * (model/cf/evaluator.go:47-53: for each user WITH test feedback, ascending, the test items followed by the negatives):
+ * gorse_mf_rank_resident ranks them without any upload -- the Evaluate between two epochs of a Fit. */
+int32_t gorse_mf_sample_user_negatives(gorse_mf *h, const int64_t *test_indptr /*host, U+1*/,
+                                       const int32_t *test_indices /*host*/, int32_t num_candidates, uint64_t seed,
+                                       int32_t *neg_out /*host or NULL*/, int32_t *neg_len /*host or NULL*/);
+/* how many users have test feedback / how many candidates their lists hold (sizes of gorse_mf_rank_resident's outputs) */
+int32_t gorse_mf_resident_candidates(gorse_mf *h, int64_t *n_users /*out*/, int64_t *n_candidates /*out*/);
+/* gorse_mf_rank over the resident candidate lists: users_out (host or NULL) n_users ids, rank_out n_users * topk padded with
+ * -1, rank_len n_users. */
+int32_t gorse_mf_rank_resident(gorse_mf *h, int32_t topk, int32_t *users_out /*host or NULL*/, int32_t *rank_out /*host*/,
+                               int32_t *rank_len /*host*/);
+
 /* ---- BPR, model/cf/model.go:446-494 ------------------------------------------------------
  * One call = n_samples SGD steps (the reference does CountFeedback() per epoch).
  * Sampling (model.go:449-468) runs on the device from a counter-based Philox4x32-10 stream

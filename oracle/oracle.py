@@ -119,6 +119,8 @@ class Oracle:
         L.orc_bpr_epoch_sampled.restype = C.c_double
         L.orc_bpr_epoch_sampled.argtypes = [_f32p, _f32p, C.c_int64, C.c_int64, C.c_int64, _i64p, _i32p, _i32p,
                                             C.c_uint64, C.c_uint64, C.c_int64, C.c_int64, C.c_float, C.c_float]
+        L.orc_sample_user_negatives.restype = None
+        L.orc_sample_user_negatives.argtypes = [C.c_int64, C.c_int64, _i64p, _i32p, _i64p, _i32p, C.c_int32, C.c_uint64, _i32p, _i32p]
         L.orc_bpr_sample.restype = None
         L.orc_bpr_sample.argtypes = [C.c_int64, C.c_int64, _i64p, _i32p, _i32p, C.c_uint64, C.c_uint64, C.c_int64,
                                      C.c_int64, _i32p, _i32p, _i32p]
@@ -357,6 +359,17 @@ class Oracle:
         self.L.orc_bpr_sample(U, I, pp, pi, ps, seed, epoch, sample_base, n, u.ctypes.data_as(_i32p),
                               i.ctypes.data_as(_i32p), j.ctypes.data_as(_i32p))
         return u, i, j
+
+    def sample_user_negatives(self, U, I, train_ptr, train_idx, test_ptr, test_idx, n, seed=0):
+        """dataset.SampleUserNegatives (dataset.go:242-253): (neg U x n int32 padded with -1, len U)"""
+        train_ptr, p1 = _i64(train_ptr)
+        srt, p2 = _i32(sort_rows(train_ptr, np.asarray(train_idx, np.int32)))
+        test_ptr, p3 = _i64(test_ptr)
+        test_idx, p4 = _i32(test_idx if len(test_idx) else np.zeros(1, np.int32))
+        out = np.zeros((U, n), np.int32)
+        ln = np.zeros(U, np.int32)
+        self.L.orc_sample_user_negatives(U, I, p1, p2, p3, p4, n, seed, out.ctypes.data_as(_i32p), ln.ctypes.data_as(_i32p))
+        return out, ln
 
     # ---- BPR / ALS -------------------------------------------------------
     def bpr_apply_triplets(self, P, Q, u, i, j, lr, reg):

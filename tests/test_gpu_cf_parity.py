@@ -608,3 +608,38 @@ def test_error_paths(small):
     with pytest.raises(capi.GorseHipError) as e:
         mf.bpr_epoch(small.n_train, 0.05, 0.01, 1, 1, cancel=cancel)
     assert e.value.code == capi.ERR_CANCELLED
+
+
+@pytest.mark.parametrize("U,I,n", [(300, 200, 20), (64, 37, 30), (500, 5000, 100), (40, 12, 12)])
+def test_sample_user_negatives_matches_oracle(oracle, U, I, n):
+    """dataset.SampleUserNegatives on the device (eval.hip) against the oracle, integer for integer: rejection branch and the
+    enumerate-when-dense branch (random.go:115-121), users without test feedback, rows with repeated items, a user who has
+    seen everything; and the resident candidate lists rank exactly like an uploaded copy of themselves."""
+    rng = np.random.default_rng(U + I)
+    train = [rng.integers(0, I, int(rng.integers(0, max(2, I // 3)))).astype(np.int32) for _ in range(U)]
+    test = [rng.integers(0, I, int(rng.integers(0, 3))).astype(np.int32) for _ in range(U)]
+    train[3], test[3] = np.arange(I, dtype=np.int32), np.zeros(0, np.int32)
+    test[5] = np.concatenate([train[5][:2], test[5]]).astype(np.int32)
+
+    def csr(rows):
+        ptr = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum([r.size for r in rows], out=ptr[1:])
+        return ptr, np.concatenate(rows).astype(np.int32) if ptr[-1] else np.zeros(0, np.int32)
+    tp, ti = csr(train)
+    sp, si = csr(test)
+    d = 16
+    mf = capi.MF(U, I, d, tp, ti)
+    P, Q = synth.init_factors(U, I, d, 0.0, 0.5, 3)
+    mf.set_factors(P, Q)
+    neg, ln = mf.sample_user_negatives(sp, si, n, seed=0)
+    eneg, eln = oracle.sample_user_negatives(U, I, tp, ti, sp, si, n, seed=0)
+    assert np.array_equal(ln, eln) and np.array_equal(neg, eneg)
+    users, rank, rlen = mf.rank_resident(10)
+    exp_users = np.nonzero(np.diff(sp) > 0)[0].astype(np.int32)
+    assert np.array_equal(users, exp_users)
+    cands = [np.concatenate([test[u], neg[u, :ln[u]]]) for u in exp_users]
+    cptr, cand = csr(cands)
+    r2, l2 = mf.rank(exp_users, cptr, cand, 10)
+    assert np.array_equal(rlen, l2) and np.array_equal(rank, r2)
+    er, el = oracle.mf_rank(P, Q, exp_users, cptr, cand, 10)
+    assert np.array_equal(rlen, el) and np.array_equal(rank, er)

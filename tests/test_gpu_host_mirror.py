@@ -141,6 +141,35 @@ def test_evaluate_equals_oracle(oracle):
     assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
 
 
+def test_fit_of_a_production_split_samples_its_negatives_on_the_device(oracle):
+    """A split without preloaded negatives (master/tasks.go:232: SplitCF, then Evaluate -> SampleUserNegatives): the first
+    Evaluate of the Fit samples every user's negatives on the device (gorse_mf_sample_user_negatives) and the later ones rank
+    the resident candidate lists.  The cached lists equal the oracle's (same per-user streams), the host loop draws the same
+    lists for a model without a resident training set, and the Fit's final score is what the oracle computes from the final
+    factors with those lists."""
+    data = synth.synth_cf(400, 260, 9000, seed=11, min_len=3, n_neg=10)
+    train, test = cf.datasets_from_synth(data, preload_negatives=False)
+    m = cf.NewBPR({"NFactors": 16, "NEpochs": 6, "Lr": 0.05, "InitStdDev": 0.01})
+    score = m.Fit(train, test, cf.NewFitConfig().SetVerbose(2).SetJobs(4))
+    neg, ln = oracle.sample_user_negatives(data.U, data.I, data.uptr, data.uidx, data.test_ptr, data.test_idx, 100, seed=0)
+    for u in range(data.U):
+        assert test.Negatives(u) == neg[u, :ln[u]].tolist(), u
+    # the host loop (a second split object, no Fit in progress): same lists
+    train2, test2 = cf.datasets_from_synth(data, preload_negatives=False)
+    P, Q = m.factors()
+    m2 = cf.NewBPR({"NFactors": 16})
+    m2.load_factors(P, Q)
+    s2 = cf.Evaluate(m2, test2, train2, 10, 100, 1, cf.NDCG, cf.Precision, cf.Recall)
+    for u in range(0, data.U, 7):
+        assert test2.Negatives(u) == neg[u, :ln[u]].tolist(), u
+    neg_ptr = np.zeros(data.U + 1, np.int64)
+    np.cumsum(ln, out=neg_ptr[1:])
+    neg_idx = np.concatenate([neg[u, :ln[u]] for u in range(data.U)]).astype(np.int32)
+    exp = oracle.evaluate(P, Q, data.test_ptr, data.test_idx, neg_ptr, neg_idx, 10)
+    assert np.array_equal(np.asarray(s2, np.float32).view(np.uint32), exp.view(np.uint32))
+    assert np.float32(score.NDCG) == exp[0] and np.float32(score.Precision) == exp[1] and np.float32(score.Recall) == exp[2]
+
+
 def test_bruteforce_index_like_ann_tests(oracle):
     # common/ann/ann.go:21-25 contract; logics/cf_test.go:26-58 golden
     k = KATS["mf_items_search"]
