@@ -531,11 +531,12 @@ extern "C" int32_t gorse_topk_last_stats(gorse_topk *h, int64_t *n_fallback, int
     return GORSE_OK;
 }
 
-// rscale_m[i] = admissible[i] ? base[i] (or 1 without a base) : NaN -- a NaN score fails every comparison of the sweep
-__global__ void masked_scale_kernel(const uint8_t *__restrict__ mask, const float *__restrict__ base, int64_t n,
+// rscale_m[i] = admissible[i] ? base[i] : NaN -- a NaN score fails every comparison of the sweep; the kTopkRowPad entries
+// behind row n - 1 are NaN as well (the sweep's tiles read them for the rows past N)
+__global__ void masked_scale_kernel(const uint8_t *__restrict__ mask, const float *__restrict__ base, int64_t n, int64_t n_padded,
                                     float *__restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = mask[i] ? (base ? base[i] : 1.0f) : __builtin_nanf("");
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_padded; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (i < n && mask[i]) ? base[i] : __builtin_nanf("");
 }
 
 extern "C" int32_t gorse_topk_set_mask(gorse_topk *h, const uint8_t *admissible) {
@@ -550,9 +551,8 @@ extern "C" int32_t gorse_topk_set_mask(gorse_topk *h, const uint8_t *admissible)
     h->n_admissible = 0;
     for (int64_t r = 0; r < h->N; r++) h->n_admissible += admissible[r] != 0;
     if (h->mfma_ok) {
-        GORSE_TRY(h->rscale_m.ensure((size_t)h->N));
-        const float *base = h->metric == GORSE_METRIC_NEG_DOT ? nullptr : h->rscale.p;
-        masked_scale_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->mask.p, base, h->N, h->rscale_m.p);
+        GORSE_TRY(h->rscale_m.ensure((size_t)h->N + gorse::kTopkRowPad));
+        masked_scale_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->mask.p, h->rscale.p, h->N, h->N + gorse::kTopkRowPad, h->rscale_m.p);
         GORSE_HIP_CHECK(hipGetLastError());
     }
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));

@@ -26,7 +26,8 @@ struct gorse_topk {
     float rs_min = 0.0f, rs_max = 0.0f;  // cosine: bounds of the row scales 1 / sqrt(norm2[i]) (the DMA sweeps' block bound)
     gorse::DevBuf<uint16_t> opA_own, opB_own;  // bf16 operand matrices N x KPAD (candidate / query roles)
     const uint16_t *opA = nullptr, *opB = nullptr;  // may alias Xb
-    gorse::DevBuf<float> rscale;   // cosine: 1 / sqrt(norm2[i])
+    gorse::DevBuf<float> rscale;   // the sweep's per-row value: cosine 1 / sqrt(norm2[i]), Euclidean -norm2[i] / 2, -dot 1; N + kTopkRowPad
+                                   // entries, the padding NaN (what the sweep's tiles read for the rows past N)
     gorse::DevBuf<uint16_t> opQ;   // query operands of the current chunk when they are not rows of opB
     gorse::DevBuf<float> qn2, qmargin, qf32;
     gorse::DevBuf<int64_t> qid;
@@ -63,6 +64,7 @@ struct gorse_topk {
 };
 
 namespace gorse {
+constexpr int64_t kTopkRowPad = 256;  // NaN entries behind the last row value: one tile of the sweep reaches at most 127 rows past N
 // floats.Euclidean (squared part) in AVX512 order for rows staged in LDS: floats_avx512.c:374-441
 __device__ __forceinline__ float euclid512_lds(const float *a, const float *b, const VecShape &vs, int lane) {
     float acc = 0.0f;

@@ -54,7 +54,7 @@ constexpr bool sweep_dma(int kp, bool hist, int rb, int wv) {
     return !hist && (kp & (kp - 1)) == 0 && (32 * rb * kp * 2) % (64 * wv) == 0 && (32 * rb) % 64 == 0;
 }
 // LDS of a sweep workgroup: NBUF tile buffers (+ their row scales and, without DMA, block bounds), five words per query, the
-// candidate path's staging area (VOTE only), the tile counters.  DMA: four buffers (tile t is multiplied while t + 1 has landed
+// tile counters.  DMA: four buffers (tile t is multiplied while t + 1 has landed
 // and t + 2 is in flight; the fourth keeps the waves a tile apart); register staging: three where they fit next to the rest
 // in 144 KB (the main sweep up to KP = 8 with 128-row tiles), else two; the history sweep keeps two (its small workgroups
 // share a CU).
@@ -62,13 +62,13 @@ constexpr size_t sweep_row_bytes(int kp, bool dma) { return (size_t)kp * 32 + (d
 constexpr size_t sweep_tile_bytes(int kp, int rb, bool dma) {
     return (size_t)32 * rb * sweep_row_bytes(kp, dma) + (size_t)32 * rb * 4 + (dma ? 0 : 2 * kMaxRB * 4);
 }
-constexpr size_t sweep_fixed_bytes(int bq, int wv, bool vote) { return (size_t)5 * bq * 4 + (vote ? (size_t)wv * 64 * 16 * 4 : 0) + 64; }
-constexpr int sweep_bufs(int kp, int rb, int bq, int wv, bool vote, bool hist) {
-    if (sweep_dma(kp, hist, rb, wv)) return 4 * sweep_tile_bytes(kp, rb, true) + sweep_fixed_bytes(bq, wv, vote) <= (size_t)156 * 1024 ? 4 : 3;
-    return !hist && 3 * sweep_tile_bytes(kp, rb, false) + sweep_fixed_bytes(bq, wv, vote) <= (size_t)144 * 1024 ? 3 : 2;
+constexpr size_t sweep_fixed_bytes(int bq) { return (size_t)5 * bq * 4 + 64; }
+constexpr int sweep_bufs(int kp, int rb, int bq, int wv, bool hist) {
+    if (sweep_dma(kp, hist, rb, wv)) return 4 * sweep_tile_bytes(kp, rb, true) + sweep_fixed_bytes(bq) <= (size_t)156 * 1024 ? 4 : 3;
+    return !hist && 3 * sweep_tile_bytes(kp, rb, false) + sweep_fixed_bytes(bq) <= (size_t)144 * 1024 ? 3 : 2;
 }
-constexpr size_t sweep_lds_bytes(int kp, int rb, int bq, int wv, bool vote, bool hist) {
-    return sweep_bufs(kp, rb, bq, wv, vote, hist) * sweep_tile_bytes(kp, rb, sweep_dma(kp, hist, rb, wv)) + sweep_fixed_bytes(bq, wv, vote);
+constexpr size_t sweep_lds_bytes(int kp, int rb, int bq, int wv, bool hist) {
+    return sweep_bufs(kp, rb, bq, wv, hist) * sweep_tile_bytes(kp, rb, sweep_dma(kp, hist, rb, wv)) + sweep_fixed_bytes(bq);
 }
 constexpr int64_t kMinSweepQueries = 768;  // fewer queries in a call take the scan (see topk_mfma_usable)
 constexpr int kCap = 512;      // candidate-list capacity per query
@@ -100,7 +100,7 @@ inline int topk_rows_per_tile() { return (g_topk_variant & 1) ? 64 : ((g_topk_va
 struct SweepParams {
     const uint16_t *A;     // candidate operands, N x KPAD bf16
     const uint16_t *B;     // query operands, nq x KPAD bf16
-    const float *rscale;   // per-candidate score scale (cosine) or null
+    const float *rscale;   // per-row value of the epilogue (cosine scale, Euclidean bias, 1 for -dot; NaN: row not admissible)
     const float *qmargin;  // per-query 2*delta_q
     uint2 *cbuf;           // nq x kCap (key, index)
     int32_t *ccnt;         // nq
@@ -110,8 +110,7 @@ struct SweepParams {
     int64_t N, nq;
     int kth;
     int compact_at;        // a sub-list longer than this triggers the compaction of its query (<= kCompactAt / 2)
-    int coarse;            // cosine: reject a 32-row block on max(raw score) x (block's extreme row scale) first
-    int bias;              // Euclidean: the per-candidate value (-|x|^2 / 2) is ADDED to the score instead of multiplied
+    int ep;                // EP_SCALE / EP_BIAS / EP_COARSE: what the epilogue does with the per-row values (host side: picks the kernel)
     unsigned long long *prof;  // PROF instantiations: 8 cycle / event counters summed over all waves
     // warm start (see topk_mfma_search): a PILOT sweep walks every tile_stride-th tile with kth = a small j and writes the
     // threshold it ends with to f_out; the main sweep starts from f0 and verifies it (compact_query: a threshold that a later
@@ -119,12 +118,8 @@ struct SweepParams {
     const float *f0;   // nq initial thresholds or null (-inf)
     float *f_out;      // pilot: nq final thresholds; null otherwise
     int tile_stride;   // 1, or the pilot's sampling stride over the row tiles
-    int prio;          // candidate path at raised wave priority (s_setprio): its VALU chain competes with the sibling wave's
-                       // MFMA issue, and the wave that took the path is the one the barrier waits for
     int nslices;       // HIST: row slices (grid.y); the per-query outputs are then nslices x nq long, slice-major
-    float rs_min, rs_max;  // smallest and largest row scale of the index (coarse bound of the DMA sweeps)
-    int vote;          // candidate path: skip a score row when no lane of the wave holds a candidate in it (pays when
-                       // candidates are rare, i.e. behind a warm start: one or two of a block's 1024 scores)
+    float rs_min, rs_max;  // smallest and largest row value of the index (EP_COARSE bound of the DMA sweeps)
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
@@ -229,23 +224,41 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
     }
 }
 
+// What the epilogue does with a block's 32 x 32 raw scores before it compares them with the thresholds:
+constexpr int EP_NONE = 0;    // nothing (-dot without a mask; register-staged sweeps only)
+constexpr int EP_SCALE = 1;   // every score times its row's value (cosine with unequal norms; masked rows: NaN)
+constexpr int EP_BIAS = 2;    // every score plus its row's value (Euclidean: -|x|^2 / 2)
+constexpr int EP_COARSE = 3;  // the block's LARGEST raw score times the extreme row value bounds every scaled score of the block
+                              // (values positive and nearly equal, or all 1): the rows are scaled only when that bound reaches a threshold
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {  // one instruction; fmaxf would canonicalise MFMA results first
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+__device__ __forceinline__ float max2f(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // PROF (probe only): s_memtime stamps around the phases of the tile loop, summed over the waves into p.prof:
-// [0] tile store + prefetch issue, [1] MFMA + epilogues (slow paths included), [2] slow paths alone, [3] barrier wait,
-// [4] row blocks examined, [5] row blocks that took the slow path, [6] whole kernel, [7] waves
-// VOTE (probe only, variant bit 7, never run on a device yet): in the candidate path every one of the 16 score rows is first
-// voted on by the whole wave and skipped when no lane holds a candidate in it (a block that takes the path has one or
-// two candidates among its 1024 scores), instead of running the 16 predicated compare + append bodies.  The appends
-// that do happen are the same, in the same per-lane order, so the lists -- and every result -- are unchanged.
-template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool PROF = false, bool VOTE = false>
+// [0] tile movement (DMA issue / tile store + prefetch issue), [1] MFMA + epilogues (candidate paths included), [2] candidate
+// paths alone, [3] waiting for a tile, [4] row blocks examined, [5] row blocks that took the candidate path, [6] whole kernel,
+// [7] waves, [8] candidate path: set-up + row scaling, [9] appends, [10] compaction check / compaction, [11] candidate paths
+template <int KP, int NCB, int EP, bool HIST, int RB, bool PROF = false>
 __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kernel(SweepParams p) {
     constexpr int kWaves = sweep_waves(HIST, KP);
     constexpr int kThreads = kWaves * 64;
     constexpr int kTR = 32 * RB;
+    constexpr bool SCALE = EP != EP_NONE;  // a per-row value travels with the tile
     unsigned long long c_store = 0, c_comp = 0, c_slow = 0, c_bar = 0, n_blk = 0, n_slow = 0, t_begin = 0, ts = 0;
-    unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, n_hits = 0;  // slow path: count + exchange | appends | compaction
+    unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, n_hits = 0;
     if (PROF) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int KPAD = KP * 16;
     constexpr bool DMA = sweep_dma(KP, HIST, RB, kWaves);
+    static_assert(!DMA || SCALE, "the DMA sweeps mask the rows past N through the row values (NaN padding)");
     // register staging: +16 B per row, consecutive rows start 4 banks apart, ds_read_b128 conflict-free; DMA: unpadded rows,
     // the pieces of a row swizzled instead (see piece_swizzle)
     constexpr int ROWB = (int)sweep_row_bytes(KP, DMA);
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     constexpr int BQ = QW * kWaves;
     constexpr int CHUNKS = kTR * KP * 2;  // 16-byte pieces per tile
     constexpr int CPT = (CHUNKS + kThreads - 1) / kThreads;
-    constexpr int NBUF = sweep_bufs(KP, RB, BQ, kWaves, VOTE, HIST);
+    constexpr int NBUF = sweep_bufs(KP, RB, BQ, kWaves, HIST);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_tile = smem;
     float *s_rs = reinterpret_cast<float *>(smem + (size_t)NBUF * kTR * ROWB);
@@ -265,7 +278,6 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     // tile counters: s_sync[b] = waves whose part of a tile has reached buffer b (ever), s_sync[NBUF + b] = waves that
     // have finished reading one
     int *s_sync = s_hc + BQ;
-    float *s_stage = reinterpret_cast<float *>(s_sync + 16);  // VOTE: 16 scores per thread, where the candidate path parks a block
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t wgq0 = (int64_t)blockIdx.x * BQ;
@@ -358,37 +370,53 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         else return (row >> 3) & 1;
     };
     // A wave-instruction moves 64 pieces: DMA instruction j of wave w covers pieces [(w * DPW + j) * 64, +64) of the tile;
-    // the row scales (one dword per row) follow as instructions of 64 rows each, issued by the first kTR / 64 waves.
-    constexpr int DPW = DMA ? CHUNKS / 64 / kWaves : 0;  // tile instructions per wave (CHUNKS = 64 * KP * RB: a multiple of 64 * kWaves
-                                                         // for every instantiation that takes this path)
+    // the row values (one dword per row) follow as instructions of 64 rows each, issued by the first kTR / 64 waves.
+    constexpr int DPW = DMA ? CHUNKS / 64 / kWaves : 0;  // tile instructions per wave
     static_assert(!DMA || (CHUNKS % (64 * kWaves) == 0 && kTR % 64 == 0), "DMA tiling");
-    constexpr int RSW = (DMA && SCALE) ? kTR / 64 : 0;   // waves that also move a scale instruction
+    constexpr int RSW = DMA ? kTR / 64 : 0;              // waves that also move a row-value instruction
     const int wu = __builtin_amdgcn_readfirstlane(w);    // provably wave-uniform (LDS destinations, branch conditions)
     // The DMA is issued from inline assembly: the builtin makes hipcc treat every later LDS access of the kernel (the tile
     // counters, the fragment reads) as dependent on it and put s_waitcnt vmcnt(0) in front -- which drains the very tiles
     // that are meant to stay in flight.  An asm statement is invisible to that bookkeeping (cdna_hip_programming.md 5.7);
     // the waits are dma_wait's, by count.  M0 = LDS destination of lane 0; the statement saves and restores it.
+    // Addressing: the tile's first byte is a scalar (it advances by one tile per iteration), the lane's place inside the
+    // tile a 32-bit register computed once -- global_load_lds with an SGPR base and a VGPR offset.  The last tile, whose
+    // rows may lie past N, clamps its rows instead (their scores are discarded through the NaN padding of the row values).
     const unsigned lds_tiles = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_tile;
     const unsigned lds_rs = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)s_rs;
+    unsigned dsrc[DMA ? DPW : 1];  // byte offset of this lane's piece of instruction j from the tile's first byte
+    if constexpr (DMA) {
+#pragma unroll
+        for (int j = 0; j < DPW; j++) {
+            const int piece = (wu * DPW + j) * 64 + lane;
+            const int row = piece / PPR, cs = piece % PPR;  // LDS position; its content is source piece cs ^ swizzle
+            dsrc[j] = (unsigned)(row * (KPAD * 2) + ((cs ^ piece_swizzle(row)) << 4));
+        }
+    }
     auto dma_tile = [&](int64_t tl, int buf) {
         if constexpr (DMA) {
             const int64_t base_row = (T0 + tl) * stride_rows;
+            const bool inside = base_row + kTR <= p.N;  // wave-uniform
+            const unsigned char *tile0 = reinterpret_cast<const unsigned char *>(p.A) + base_row * (KPAD * 2);
 #pragma unroll
             for (int j = 0; j < DPW; j++) {
-                const int piece = (wu * DPW + j) * 64 + lane;
-                const int row = piece / PPR, cs = piece % PPR;  // LDS position; its content is source piece cs ^ swizzle
-                int64_t grow = base_row + row;
-                if (grow >= p.N) grow = p.N - 1;  // rows past N: any readable address; their scores become NaN below
-                const uint16_t *src = p.A + grow * KPAD + ((cs ^ piece_swizzle(row)) << 3);
                 const unsigned dst = __builtin_amdgcn_readfirstlane(lds_tiles + (unsigned)buf * (kTR * ROWB) + (unsigned)(wu * DPW + j) * 1024u);
                 unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                if (inside) {
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(dsrc[j]), "s"(tile0), "s"(dst) : "memory");
+                } else {
+                    const int piece = (wu * DPW + j) * 64 + lane;
+                    const int row = piece / PPR, cs = piece % PPR;
+                    int64_t grow = base_row + row;
+                    if (grow >= p.N) grow = p.N - 1;
+                    const uint16_t *src = p.A + grow * KPAD + ((cs ^ piece_swizzle(row)) << 3);
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                }
             }
-            if (SCALE && wu < RSW) {
-                int64_t grow = base_row + wu * 64 + lane;
-                if (grow >= p.N) grow = p.N - 1;
-                const float *src = p.rscale + grow;
+            if (wu < RSW) {  // the row values are padded with NaN past N (topk_mfma_prepare): no clamp
+                const float *src = p.rscale + base_row + wu * 64 + lane;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(lds_rs + (unsigned)(buf * kTR + wu * 64) * 4u);
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -414,7 +442,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    // The waves of a workgroup share every tile but do not march in step: a wave that takes the candidate path (~2200 cycles)
+    // The waves of a workgroup share every tile but do not march in step: a wave that takes the candidate path
     // used to hold the other seven at the tile's barrier -- 27 % of the sweep (profiles/r02_f_probe_topk_prof.txt).  With NBUF
     // buffers and two counters per buffer a wave only waits for what it needs: tile t complete in its buffer before it
     // multiplies it, the tile that buffer held before read by everyone before it is overwritten.
@@ -455,11 +483,14 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
     }
 
     float fth[NCB];
-    int cnt[NCB];  // length of this lane's sub-list of its query (mirrored in s_cnt around a compaction)
+    int cnt[NCB];      // length of this lane's sub-list of its query (mirrored in s_cnt around a compaction)
+    uint2 *mine[NCB];  // the lane's sub-list: slots 2 * c + (lane >> 5) of its query's list (see compact_query)
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
-        fth[cb] = s_f[w * QW + cb * 32 + (lane & 31)];
+        const int ql = w * QW + cb * 32 + (lane & 31);
+        fth[cb] = s_f[ql];
         cnt[cb] = 0;
+        mine[cb] = p.cbuf + (qslice + wgq0 + ql) * kCap + (lane >> 5);
     }
     // DMA: the lane's read offsets inside a 32-row block, one per k-step (row & 15 is the same in every block of a tile)
     unsigned aoff[DMA ? KP : 1];
@@ -516,7 +547,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         }
         const unsigned char *tb = s_tile + (size_t)buf * kTR * ROWB;
         const int64_t base_row = (T0 + t) * stride_rows;
-        const int valid = (int)std::min<int64_t>(kTR, p.N - base_row);
+        // register staging zero-fills the rows past N; their scores are set to NaN below.  The DMA sweeps need nothing: the
+        // row values of those rows are NaN
+        const int valid = DMA ? kTR : (int)std::min<int64_t>(kTR, p.N - base_row);
         // not unrolled: four copies of the epilogue and its candidate path cost the C4 instantiation 34 spilled VGPRs
 #pragma unroll 1
         for (int rb = 0; rb < RB; rb++) {
@@ -546,17 +579,18 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                             acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bfrag[cb][k0 + j], acc[cb], 0, 0, 0);
                     }
             }
-            // C layout: lane holds column (= query) lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-            if (p.prio & 2) __builtin_amdgcn_s_setprio(1);  // probe: the whole epilogue ahead of the sibling's MFMA issue
+            // C layout: lane holds column (= query) lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).
+            // The epilogue shares the SIMD's issue slots with the sibling wave's MFMAs (about five ordinary instructions fit
+            // beside one MFMA: MI355X_MICROARCH.md), so it is counted in instructions: 10 for the maxima of a column block,
+            // 4 for the bound, 2 for the vote.
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
-                const bool coarse = SCALE && p.coarse;
                 auto scale_rows = [&]() {
                     const float4 *r4 = reinterpret_cast<const float4 *>(s_rs + buf * kTR + rb * 32);
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         const float4 s = r4[2 * g + (lane >> 5)];
-                        if (p.bias) {  // q.x - |x|^2 / 2 = (|q|^2 - |q - x|^2) / 2: same order as the distance
+                        if (EP == EP_BIAS) {  // q.x - |x|^2 / 2 = (|q|^2 - |q - x|^2) / 2: same order as the distance
                             acc[cb][4 * g + 0] += s.x;
                             acc[cb][4 * g + 1] += s.y;
                             acc[cb][4 * g + 2] += s.z;
@@ -569,19 +603,22 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                         }
                     }
                 };
-                if (SCALE && !coarse) scale_rows();
-                if (valid < kTR) {  // last tile: rows past N never qualify (NaN fails every >=, fmaxf skips it)
+                if (EP == EP_SCALE || EP == EP_BIAS) scale_rows();
+                if (!DMA && valid < kTR) {  // last tile: rows past N never qualify (NaN fails every >=, the maxima skip it)
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         const int row = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                         if (row >= valid) acc[cb][r] = __builtin_nanf("");
                     }
                 }
-                float m = acc[cb][0];
+                // maxima of the four register quads (rows 8 g + 4 (lane >> 5) + 0..3), then of the block: the candidate path
+                // looks only into the quads whose maximum qualifies
+                float gm[4];
 #pragma unroll
-                for (int r = 1; r < 16; r++) m = fmaxf(m, acc[cb][r]);
-                if (coarse) {  // an upper bound of every scaled score of the block: scales are positive
-                    // DMA: the extreme scales of ALL rows (coarse is offered only when they lie within 2 % of each other)
+                for (int g = 0; g < 4; g++) gm[g] = max2f(max3f(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2]), acc[cb][4 * g + 3]);
+                float m = max2f(max3f(gm[0], gm[1], gm[2]), gm[3]);
+                if (EP == EP_COARSE) {  // an upper bound of every scaled score of the block: the row values are positive
+                    // DMA: the extreme values of ALL rows (offered only when they lie within 2 % of each other)
                     const float mn = DMA ? p.rs_min : s_bmm[(buf * kMaxRB + rb) * 2 + 0];
                     const float mx = DMA ? p.rs_max : s_bmm[(buf * kMaxRB + rb) * 2 + 1];
                     m = m * (m >= 0.0f ? mx : mn);
@@ -593,53 +630,34 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                         tsl = __builtin_amdgcn_s_memtime();
                         n_slow++;
                     }
-                    if (p.prio & 1) __builtin_amdgcn_s_setprio(3);
-                    if (coarse) scale_rows();
-                    const int ql = w * QW + cb * 32 + (lane & 31);
-                    const int64_t qg = qslice + wgq0 + ql;
-                    uint2 *qb = p.cbuf + qg * kCap;
+                    __builtin_amdgcn_s_setprio(3);  // the wave on this path is the one its workgroup waits for
+                    if (EP == EP_COARSE) {
+                        scale_rows();
+#pragma unroll
+                        for (int g = 0; g < 4; g++) gm[g] = max2f(max3f(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2]), acc[cb][4 * g + 3]);
+                    }
                     const float f = fth[cb];
-                    // One pass, one compare per score: every lane appends to ITS OWN sub-list of the query (even /
-                    // odd slots, see compact_query), so no slot exchange between the two lanes of a query and no
-                    // counting pass are needed.  f is +inf for lanes past nq and for flagged queries; rows past N are
-                    // NaN.  (Measured before this form: ~2600 cycles per candidate block, VALU-issue bound next to
-                    // the sibling wave's MFMAs -- profiles/r01_i_probe_topk_prof.txt.)
+                    // Every lane appends to ITS OWN sub-list of the query (even / odd slots, see compact_query), so no slot
+                    // exchange between the two lanes of a query and no counting pass are needed.  f is +inf for lanes past nq
+                    // and for flagged queries; rows past N are NaN.  A block that comes here holds one or two candidates among
+                    // its 1024 scores: a quad is opened only if its maximum qualifies (a NaN maximum never does: the hardware
+                    // maximum skips NaN operands, and a quad of four NaNs holds no candidate).
                     unsigned long long tq = 0;
                     if (PROF) {
                         tq = __builtin_amdgcn_s_memtime();
                         c_s1 += tq - tsl;
                     }
-                    uint2 *mine = qb + (lane >> 5);
-                    if (VOTE) {
-                        // Candidates are rare behind a warm start (one or two of the block's 1024 scores): instead of 16
-                        // predicated compare + append bodies (whose scalar bookkeeping -- ~14 instructions and two or three
-                        // branches per score row -- was 1700 of the path's 2300 cycles, profiles/r02_e_probe_topk_prof.txt),
-                        // every lane builds the bit mask of its passing rows with branch-free VALU code, parks its 16 scores
-                        // in LDS and walks its own mask: the loop runs as often as the busiest lane has candidates.
-                        uint32_t lm = 0;
 #pragma unroll
-                        for (int r = 0; r < 16; r++) lm |= acc[cb][r] >= f ? (1u << r) : 0u;
-                        if (__builtin_amdgcn_ballot_w64(lm != 0) != 0) {  // the block bound can be a false alarm
-                            float *st = s_stage + (size_t)tid * 16;
+                    for (int g = 0; g < 4; g++) {
+                        if (gm[g] >= f) {
 #pragma unroll
-                            for (int g = 0; g < 4; g++)
-                                *reinterpret_cast<float4 *>(st + 4 * g) =
-                                    make_float4(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2], acc[cb][4 * g + 3]);
-                            while (lm) {
-                                const int r = __builtin_ctz(lm);
-                                lm &= lm - 1;
-                                const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                                mine[2 * cnt[cb]] = make_uint2(fkey(st[r]), row);
-                                cnt[cb]++;
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            if (acc[cb][r] >= f) {
-                                const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                                mine[2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
-                                cnt[cb]++;
+                            for (int e = 0; e < 4; e++) {
+                                const int r = 4 * g + e;
+                                if (acc[cb][r] >= f) {
+                                    const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                                    mine[cb][2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
+                                    cnt[cb]++;
+                                }
                             }
                         }
                     }
@@ -651,6 +669,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                     }
                     uint64_t need = __builtin_amdgcn_ballot_w64(cnt[cb] > p.compact_at);
                     if (need) {
+                        const int ql = w * QW + cb * 32 + (lane & 31);
                         s_cnt[2 * ql + (lane >> 5)] = cnt[cb];
                         need = (need | (need >> 32)) & 0xffffffffull;  // either sub-list of a query
                         do {
@@ -664,12 +683,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                         cnt[cb] = s_cnt[2 * ql + (lane >> 5)];
                         fth[cb] = s_f[ql];
                     }
-                    if (p.prio & 1) {
-                        if (p.prio & 2)
-                            __builtin_amdgcn_s_setprio(1);
-                        else
-                            __builtin_amdgcn_s_setprio(0);
-                    }
+                    __builtin_amdgcn_s_setprio(0);
                     if (PROF) {
                         const unsigned long long now = __builtin_amdgcn_s_memtime();
                         c_s3 += now - tq;
@@ -678,7 +692,6 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
                 }
             }
         }
-        if (p.prio & 2) __builtin_amdgcn_s_setprio(0);
         if (PROF) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             c_comp += now - ts;
@@ -1313,69 +1326,73 @@ __global__ void margin_kernel(const float *__restrict__ qn2, int64_t nq, float c
 
 const int kSupportedKP[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
 
-template <int KP, int NCB, bool SCALE, bool HIST, int RB, bool VOTE = false>
+template <int KP, int NCB, int EP, bool HIST, int RB>
 int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int WV = sweep_waves(HIST, KP);
     constexpr int BQ = 32 * NCB * WV;
-    const size_t lds = sweep_lds_bytes(KP, RB, BQ, WV, VOTE, HIST);
+    const size_t lds = sweep_lds_bytes(KP, RB, BQ, WV, HIST);
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE>),
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, EP, HIST, RB, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<KP, NCB, SCALE, HIST, RB, false, VOTE>
+    topk_sweep_kernel<KP, NCB, EP, HIST, RB, false>
         <<<dim3(grid, HIST ? (unsigned)std::max(p.nslices, 1) : 1u), dim3(WV * 64), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 
-template <int RB, bool VOTE>
-int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {
+template <int RB>
+int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {  // the instrumented twin of the C4-shaped sweep (probe only)
     constexpr int BQ = 32 * 2 * kWaves;
-    const size_t lds = sweep_lds_bytes(8, RB, BQ, kWaves, VOTE, false);
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, true, false, RB, true, VOTE>),
+    const size_t lds = sweep_lds_bytes(8, RB, BQ, kWaves, false);
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, EP_COARSE, false, RB, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<8, 2, true, false, RB, true, VOTE><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
+    topk_sweep_kernel<8, 2, EP_COARSE, false, RB, true><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
 
+template <int KP, int NCB, bool HIST, int RB>
+int32_t launch_sweep_ep(gorse_topk *h, const SweepParams &p) {
+    switch (p.ep) {
+        case EP_SCALE: return launch_sweep_one<KP, NCB, EP_SCALE, HIST, RB>(h, p);
+        case EP_BIAS: return launch_sweep_one<KP, NCB, EP_BIAS, HIST, RB>(h, p);
+        case EP_COARSE: return launch_sweep_one<KP, NCB, EP_COARSE, HIST, RB>(h, p);
+    }
+    return fail(GORSE_ERR_INVALID, "unknown epilogue %d", p.ep);
+}
+
 template <int KP, int NCB>
-int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
-    // 128-row tiles (one barrier per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
+int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
+    // 128-row tiles (one tile hand-over per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
     // queries keeps the 64-row form
     const bool wide = !hist && KP <= 8 && topk_rows_per_tile() == 128;
     if constexpr (KP == 8 && NCB == 2) {
-        if ((g_topk_variant & 16) && scale && !hist && p.prof)  // instrumented twin of the C4 sweep (probe only)
-            return p.vote ? (wide ? launch_sweep_prof<4, true>(h, p) : launch_sweep_prof<2, true>(h, p))
-                          : (wide ? launch_sweep_prof<4, false>(h, p) : launch_sweep_prof<2, false>(h, p));
-    }
-    if (p.vote && !hist) {  // behind a warm start: the candidate path for rare candidates
-        if (wide) {
-            if constexpr (KP <= 8)
-                return scale ? launch_sweep_one<KP, NCB, true, false, 4, true>(h, p) : launch_sweep_one<KP, NCB, false, false, 4, true>(h, p);
-        }
-        return scale ? launch_sweep_one<KP, NCB, true, false, 2, true>(h, p) : launch_sweep_one<KP, NCB, false, false, 2, true>(h, p);
+        if ((g_topk_variant & 16) && p.ep == EP_COARSE && !hist && p.prof)
+            return wide ? launch_sweep_prof<4>(h, p) : launch_sweep_prof<2>(h, p);
     }
     if (wide) {
-        if constexpr (KP <= 8)
-            return scale ? launch_sweep_one<KP, NCB, true, false, 4>(h, p) : launch_sweep_one<KP, NCB, false, false, 4>(h, p);
+        if constexpr (KP <= 8) return launch_sweep_ep<KP, NCB, false, 4>(h, p);
     }
-    if (scale) return hist ? launch_sweep_one<KP, NCB, true, true, 2>(h, p) : launch_sweep_one<KP, NCB, true, false, 2>(h, p);
-    return hist ? launch_sweep_one<KP, NCB, false, true, 2>(h, p) : launch_sweep_one<KP, NCB, false, false, 2>(h, p);
+    return hist ? launch_sweep_ep<KP, NCB, true, 2>(h, p) : launch_sweep_ep<KP, NCB, false, 2>(h, p);
 }
 
-int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool scale, bool hist) {
+int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
     switch (h->kp) {
-        case 1: return launch_sweep<1, 2>(h, p, scale, hist);
-        case 2: return launch_sweep<2, 2>(h, p, scale, hist);
-        case 3: return launch_sweep<3, 2>(h, p, scale, hist);
-        case 4: return launch_sweep<4, 2>(h, p, scale, hist);
-        case 6: return launch_sweep<6, 2>(h, p, scale, hist);
-        case 8: return launch_sweep<8, 2>(h, p, scale, hist);
-        case 12: return launch_sweep<12, 1>(h, p, scale, hist);  // 2 column blocks would spill
-        case 16: return launch_sweep<16, 1>(h, p, scale, hist);
-        case 24: return launch_sweep<24, 1>(h, p, scale, hist);
+        case 1: return launch_sweep<1, 2>(h, p, hist);
+        case 2: return launch_sweep<2, 2>(h, p, hist);
+        case 3: return launch_sweep<3, 2>(h, p, hist);
+        case 4: return launch_sweep<4, 2>(h, p, hist);
+        case 6: return launch_sweep<6, 2>(h, p, hist);
+        case 8: return launch_sweep<8, 2>(h, p, hist);
+        case 12: return launch_sweep<12, 1>(h, p, hist);  // 2 column blocks would spill
+        case 16: return launch_sweep<16, 1>(h, p, hist);
+        case 24: return launch_sweep<24, 1>(h, p, hist);
     }
     return fail(GORSE_ERR_INVALID, "unsupported operand depth %d", h->kp);
+}
+
+__global__ void fill_kernel(float *__restrict__ out, int64_t n, float v) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = v;
 }
 
 }  // namespace
@@ -1451,16 +1468,17 @@ int32_t topk_mfma_prepare(gorse_topk *h) {
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }
-    if (h->metric == GORSE_METRIC_EUCLIDEAN) {  // per-candidate bias -|x|^2 / 2 in the slot the cosine scale uses
-        GORSE_TRY(h->rscale.alloc((size_t)N));
+    // the per-row value of the sweep's epilogue: cosine 1 / |x|, Euclidean -|x|^2 / 2 (added), -dot 1; kTopkRowPad NaN entries
+    // behind it -- a tile of the sweep reaches past N, and a NaN value keeps those rows out of every list
+    GORSE_TRY(h->rscale.alloc((size_t)N + kTopkRowPad));
+    if (h->metric == GORSE_METRIC_EUCLIDEAN)
         bias_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->norm2.p, N, h->rscale.p);
-        GORSE_HIP_CHECK(hipGetLastError());
-    }
-    if (h->metric == GORSE_METRIC_COSINE) {
-        GORSE_TRY(h->rscale.alloc((size_t)N));
+    else if (h->metric == GORSE_METRIC_COSINE)
         rscale_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->norm2.p, N, h->rscale.p);
-        GORSE_HIP_CHECK(hipGetLastError());
-    }
+    else
+        fill_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(h->rscale.p, N, 1.0f);
+    fill_kernel<<<dim3(1), dim3(256), 0, h->stream>>>(h->rscale.p + N, kTopkRowPad, __builtin_nanf(""));
+    GORSE_HIP_CHECK(hipGetLastError());
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->mfma_ok = true;
     return GORSE_OK;
@@ -1478,8 +1496,6 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     const int64_t admissible = h->has_mask ? h->n_admissible : h->N - (exclude_self ? 1 : 0);
     const int64_t expect = std::min<int64_t>(k, admissible);
     const bool euclid = h->metric == GORSE_METRIC_EUCLIDEAN;
-    // a per-candidate value enters the epilogue: cosine scale, Euclidean bias, or -- with a mask -- 1 / NaN
-    const bool scale = h->metric == GORSE_METRIC_COSINE || euclid || h->has_mask;
     const float other = h->metric == GORSE_METRIC_COSINE ? 1.0f : h->max_norm;
     const int64_t mb = std::min(nq, kChunkQ);
     GORSE_TRY(h->cbuf.ensure((size_t)mb * kCap));
@@ -1535,15 +1551,19 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         SweepParams sp;
         sp.A = h->opA;
         sp.B = Bop;
-        sp.rscale = h->has_mask ? h->rscale_m.p : (scale ? h->rscale.p : nullptr);
+        sp.rscale = h->has_mask ? h->rscale_m.p : h->rscale.p;
         sp.qmargin = h->qmargin.p;
         sp.cbuf = h->cbuf.p;
         sp.ccnt = h->ccnt.p;
         sp.cflag = h->cflag.p;
         sp.hbuf = nullptr;
         sp.hcnt = nullptr;
-        sp.coarse = euclid ? 0 : ((g_topk_variant & 4) ? 0 : ((g_topk_variant & 8) ? 1 : (h->coarse_ok ? 1 : 0)));
-        sp.bias = euclid ? 1 : 0;
+        // epilogue: Euclidean adds its bias to every score; cosine multiplies every score by the row scale unless the scales
+        // lie within 2 % of each other (then the block's largest raw score times the extreme scale bounds the block and
+        // rows are scaled only behind that test; variant bit 2 / 3: off / on whatever the norms); -dot has the value 1
+        // (NaN for a masked row), which the block test never needs
+        const bool cos_coarse = (g_topk_variant & 4) ? false : ((g_topk_variant & 8) ? true : h->coarse_ok);
+        sp.ep = euclid ? EP_BIAS : (h->metric == GORSE_METRIC_COSINE ? (cos_coarse ? EP_COARSE : EP_SCALE) : EP_COARSE);
         sp.compact_at = (g_topk_variant & 32) ? 128 : ((g_topk_variant & 64) ? 96 : kCompactAt / 2);
         sp.prof = nullptr;
         if (g_topk_variant & 16) {
@@ -1554,14 +1574,12 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.N = h->N;
         sp.nq = m;
         sp.kth = kth;
-        sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1, sp.vote = 0;
+        sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1;
         sp.nslices = 1;
         // bounds of the per-row value for the DMA sweeps' block test: the cosine scales; without them (a masked -dot index:
         // the value is 1 or NaN) the bound is the score itself
         sp.rs_min = h->metric == GORSE_METRIC_COSINE ? h->rs_min : 1.0f;
         sp.rs_max = h->metric == GORSE_METRIC_COSINE ? h->rs_max : 1.0f;
-        // variant bit 11: candidate path at the default priority; bit 13: the whole epilogue at priority 1 (probe)
-        sp.prio = ((g_topk_variant & 2048) ? 0 : 1) | ((g_topk_variant & 8192) ? 2 : 0);
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
         // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
         // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
@@ -1593,16 +1611,15 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 p1.kth = pilot_kth(p2.kth, 16);
                 p1.tile_stride = pilot_stride * 16;
                 p1.f_out = h->f1.p;
-                GORSE_TRY(dispatch_sweep(h, p1, scale, false));
+                GORSE_TRY(dispatch_sweep(h, p1, false));
                 GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
                 p2.f0 = h->f1.p;
             }
-            GORSE_TRY(dispatch_sweep(h, p2, scale, false));
+            GORSE_TRY(dispatch_sweep(h, p2, false));
             GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot's flags say nothing about the query
             sp.f0 = h->f0.p;
-            sp.vote = (g_topk_variant & 4096) ? 1 : 0;  // variant bit 12: lane-mask candidate path (measured slower: r02_f)
         }
-        GORSE_TRY(dispatch_sweep(h, sp, scale, false));
+        GORSE_TRY(dispatch_sweep(h, sp, false));
         // The queries whose warm start failed its verification carry flag 2: topk_rescore_kernel leaves flagged queries alone
         // and stage 2 below (history sweep from -inf + literal replay) answers them together with the tie queries -- a sweep
         // of their own would cost one workgroup a full pass over the rows (48 ms for 86 queries, profiles/r02_h_*).
@@ -1685,7 +1702,6 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, sm2 * 4, h->stream));
                 SweepParams hp = sp;
                 hp.f0 = nullptr;  // the history sweep records what a threshold that starts at -inf would have kept
-                hp.vote = 0;
                 hp.B = h->rp_op.p;
                 hp.qmargin = h->rp_margin.p;
                 hp.cbuf = h->rp_cbuf.p;
@@ -1697,7 +1713,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 hp.nslices = nsl;
                 hp.nq = m2;
                 tok = h->prof.begin(GORSE_PROF_TOPK_HIST, h->stream);
-                GORSE_TRY(dispatch_sweep(h, hp, scale, true));
+                GORSE_TRY(dispatch_sweep(h, hp, true));
                 h->prof.end(tok, h->stream);
                 ReplayParams pp;
                 pp.X = h->X.p;
