@@ -231,17 +231,12 @@ constexpr int EP_BIAS = 2;    // every score plus its row's value (Euclidean: -|
 constexpr int EP_COARSE = 3;  // the block's LARGEST raw score times the extreme row value bounds every scaled score of the block
                               // (values positive and nearly equal, or all 1): the rows are scaled only when that bound reaches a threshold
 
-__device__ __forceinline__ float max3f(float a, float b, float c) {  // one instruction; fmaxf would canonicalise MFMA results first
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-__device__ __forceinline__ float max2f(float a, float b) {
-    float d;
-    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
+// Maxima of MFMA results are taken by instructions the COMPILER emits (fmaxf nests become v_max3_f32): an inline-asm
+// v_max3_f32 reading an accumulator right behind the MFMA that writes it gets no wait states from hipcc (asm statements are
+// not padded: cdna_hip_programming.md 5.7) and reads the registers before the matrix pipe has written them -- measured:
+// maxima too small, blocks with a candidate skipped, 23,000 of a million queries failing the warm start's verification.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
 
 // PROF (probe only): s_memtime stamps around the phases of the tile loop, summed over the waves into p.prof:
 // [0] tile movement (DMA issue / tile store + prefetch issue), [1] MFMA + epilogues (candidate paths included), [2] candidate

@@ -146,6 +146,90 @@ inline std::string decode_string(const std::string &stream) {
     return m.str();
 }
 
+// ---- []float32 at top level (common/ann/hnsw.go:299-303: encoding.WriteGob of every stored vector) -----------------------
+// Two messages: the definition of type 65 as wireType{SliceT: sliceType{CommonType{Name: "[]float32", Id: 65}, Elem: float}},
+// then the value: type id 65, the singleton marker 0, the element count, the elements as gob floats.
+inline std::string encode_f32_slice(const float *v, size_t n) {
+    std::string def;
+    put_int(def, -65);
+    put_uint(def, 2);  // wireType field 1 (SliceT): delta 2 from -1
+    put_uint(def, 1);  //   sliceType field 0 (CommonType)
+    put_uint(def, 1);  //     CommonType field 0 (Name)
+    put_string(def, "[]float32");
+    put_uint(def, 1);  //     CommonType field 1 (Id)
+    put_int(def, 65);
+    put_uint(def, 0);  //     end of CommonType
+    put_uint(def, 1);  //   sliceType field 1 (Elem)
+    put_int(def, tFloat);
+    put_uint(def, 0);  //   end of sliceType
+    put_uint(def, 0);  // end of wireType
+    std::string val;
+    put_int(val, 65);
+    put_uint(val, 0);  // not a struct: singleton marker
+    put_uint(val, n);
+    for (size_t k = 0; k < n; k++) put_float(val, (double)v[k]);
+    return message(def) + message(val);
+}
+inline std::vector<float> decode_f32_slice(const std::string &stream) {
+    Reader r(stream);
+    int64_t id;
+    Reader m = value_message(r, id);
+    if (m.uint() != 0) throw std::runtime_error("gob: expected a non-struct value");
+    const uint64_t n = m.uint();
+    if (n > (uint64_t)(m.end - m.p)) throw std::runtime_error("gob: slice length runs past the end");  // >= 1 byte per element
+    std::vector<float> out((size_t)n);
+    for (auto &x : out) x = (float)m.flt();
+    return out;
+}
+// time.Time at top level travels as a GobEncoder value: the last bytes of the stream are time.Time.MarshalBinary -- version
+// 1: 1 + 8 (seconds since year 1, big endian) + 4 (nanoseconds) + 2 (zone offset in minutes, -1 = UTC) = 15 bytes; version 2
+// adds one byte of offset seconds.  Returns Unix nanoseconds; the zone is dropped (an instant, not a wall clock).
+inline int64_t decode_time_unix_nanos(const std::string &stream) {
+    auto parse = [&](size_t len, uint8_t version, int64_t &out) {
+        if (stream.size() < len + 1) return false;
+        const uint8_t *b = (const uint8_t *)stream.data() + stream.size() - len;
+        if (b[0] != version || b[-1] != len) return false;  // preceded by its byte count
+        uint64_t sec = 0, ns = 0;
+        for (int k = 0; k < 8; k++) sec = (sec << 8) | b[1 + k];
+        for (int k = 0; k < 4; k++) ns = (ns << 8) | b[9 + k];
+        const int64_t unix_sec = (int64_t)sec - 62135596800ll;  // seconds from year 1 to 1970
+        out = unix_sec * 1000000000ll + (int64_t)ns;
+        return true;
+    };
+    int64_t t = 0;
+    if (parse(15, 1, t) || parse(16, 2, t)) return t;
+    throw std::runtime_error("gob: not a time.Time value");
+}
+
+// gob.NewEncoder(buf).Encode(t) for a time.Time in UTC: the definition of type 65 as wireType{GobEncoderT (field 4):
+// gobEncoderType{CommonType{Name: "Time", Id: 65}}}, then type id 65, the singleton marker, the byte count and
+// time.Time.MarshalBinary version 1 (zone offset -1 = UTC).
+inline std::string encode_time_unix_nanos(int64_t t) {
+    std::string def;
+    put_int(def, -65);
+    put_uint(def, 5);  // wireType field 4 (GobEncoderT): delta 5 from -1
+    put_uint(def, 1);  //   gobEncoderType field 0 (CommonType)
+    put_uint(def, 1);  //     CommonType field 0 (Name)
+    put_string(def, "Time");
+    put_uint(def, 1);  //     CommonType field 1 (Id)
+    put_int(def, 65);
+    put_uint(def, 0);  //     end of CommonType
+    put_uint(def, 0);  //   end of gobEncoderType
+    put_uint(def, 0);  // end of wireType
+    int64_t sec = t / 1000000000ll, ns = t % 1000000000ll;
+    if (ns < 0) ns += 1000000000ll, sec -= 1;
+    const uint64_t s1 = (uint64_t)(sec + 62135596800ll);
+    std::string payload(1, (char)1);
+    for (int k = 7; k >= 0; k--) payload.push_back((char)((s1 >> (8 * k)) & 0xFF));
+    for (int k = 3; k >= 0; k--) payload.push_back((char)(((uint64_t)ns >> (8 * k)) & 0xFF));
+    payload += "\xff\xff";
+    std::string val;
+    put_int(val, 65);
+    put_uint(val, 0);
+    put_string(val, payload);
+    return message(def) + message(val);
+}
+
 // ---- model.Params = map[ParamName]any ------------------------------------------------------------------------------
 struct Value {
     enum Kind { Int, Float, Bool, String } kind = Float;

@@ -535,6 +535,51 @@ std::vector<std::string> split_lines(const char *s) {
 vectors::HipDatabase &vdb(void *h) { return *((VdbHandle *)h)->db; }
 }  // namespace
 
+// MatrixFactorizationItems (logics/cf.go:36-128); cb = a search callback (the CPU test-suite's checker) or NULL for the GPU
+void *gh_mfitems_new(int64_t timestamp_unix_nanos, gh_search_cb cb) {
+    std::shared_ptr<vectors::Searcher> s;
+    if (cb) s = std::make_shared<CallbackSearcher>(cb);
+    return new logics::MatrixFactorizationItems(timestamp_unix_nanos, s);
+}
+void gh_mfitems_free(void *m) { delete (logics::MatrixFactorizationItems *)m; }
+void gh_mfitems_add(void *m, const char *id, const float *v, int32_t d) {
+    ((logics::MatrixFactorizationItems *)m)->Add(id, std::vector<float>(v, v + d));
+}
+int64_t gh_mfitems_count(void *m) { return (int64_t)((logics::MatrixFactorizationItems *)m)->Count(); }
+int32_t gh_mfitems_dimension(void *m) { return ((logics::MatrixFactorizationItems *)m)->Dimension(); }
+int64_t gh_mfitems_timestamp(void *m) { return ((logics::MatrixFactorizationItems *)m)->Timestamp(); }
+int64_t gh_mfitems_id(void *m, int64_t i, char *buf, int64_t cap) {
+    return copy_out(((logics::MatrixFactorizationItems *)m)->Id((size_t)i), buf, cap);
+}
+void gh_mfitems_row(void *m, int64_t i, float *out) {
+    auto *x = (logics::MatrixFactorizationItems *)m;
+    std::memcpy(out, x->Row((size_t)i), (size_t)x->Dimension() * sizeof(float));
+}
+int64_t gh_mfitems_marshal(void *m, char *buf, int64_t cap) {
+    return copy_out(((logics::MatrixFactorizationItems *)m)->Marshal(), buf, cap);
+}
+int32_t gh_mfitems_unmarshal(void *m, const char *buf, int64_t n) {
+    return guard([&] { ((logics::MatrixFactorizationItems *)m)->Unmarshal(std::string(buf, (size_t)n)); });
+}
+// Search: ids joined by '\n' into ids_buf (returns the byte count), scores into scores[0..cap_scores); *n_out = results
+int64_t gh_mfitems_search(void *m, const float *v, int32_t d, int32_t n, char *ids_buf, int64_t cap, double *scores,
+                          int32_t cap_scores, int32_t *n_out) {
+    int64_t bytes = -1;
+    const int32_t rc = guard([&] {
+        auto res = ((logics::MatrixFactorizationItems *)m)->Search(std::vector<float>(v, v + d), n);
+        std::string joined;
+        for (size_t t = 0; t < res.size(); t++) {
+            if (t) joined.push_back('\n');
+            joined += res[t].Id;
+            if ((int32_t)t < cap_scores) scores[t] = res[t].Value;
+        }
+        *n_out = (int32_t)res.size();
+        bytes = copy_out(joined, ids_buf, cap);
+    });
+    return rc == 0 ? bytes : -1;
+}
+int64_t gh_gob_f32_slice(const float *v, int32_t n, char *buf, int64_t cap) { return copy_out(gob::encode_f32_slice(v, (size_t)n), buf, cap); }
+
 void *gh_vdb_open(const char *url) {
     void *out = nullptr;
     guard([&] { out = new VdbHandle{vectors::Open(url)}; });

@@ -828,6 +828,157 @@ private:
     std::map<std::string, std::vector<float>> embeddings_;
 };
 
+// MatrixFactorizationItems (logics/cf.go:36-128): item id -> embedding with a nearest-item search by -floats.Dot, and its
+// blob.  The reference keeps an ann.HNSW graph and writes it into the blob (cf.go:81-101 -> hnsw.go:278-337); here the
+// neighbours come from the exact index, so there is no graph to write.  The blob keeps the reference's
+// framing -- WriteGob(time.Time), WriteGob(int dimension), the index, WriteGob(int64 count), one WriteGob(string) per id --
+// and only the index section differs.  Cross-build files:
+//   * Unmarshal READS THE REFERENCE'S INDEX SECTION (HNSW.Marshal: float32 levelFactor, four int64 parameters, int64 count,
+//     one WriteGob([]float32) per vector, count bottom neighbour queues, int64 layers x (int32 count x (int32 key, queue)),
+//     int32 enterPoint; a queue = one bool + WriteSlice of 8-byte (int32, float32) pairs, common/heap/pq.go:128-133) and
+//     keeps the vectors; the graph is skipped.  A master without this library can hand its file to a worker with it.
+//   * Marshal writes an index section that a reference reader REJECTS CLEANLY: where HNSW.Unmarshal expects levelFactor it
+//     finds the bytes "GHIP" (as a float32: 1.4e10, no level factor), then an int64 version (1) in the maxConnection slot,
+//     three int64 zeros, the vector count 1 and an EMPTY gob stream (int32 0) for that "vector" -- encoding.ReadGob returns
+//     gob's EOF, an ordinary error, before anything is allocated.  Behind it: int64 count, int32 dimension, the float32 rows.
+class MatrixFactorizationItems {
+public:
+    explicit MatrixFactorizationItems(int64_t timestampUnixNanos = 0, std::shared_ptr<vectors::Searcher> searcher = nullptr)
+        : timestamp_(timestampUnixNanos), searcher_(std::move(searcher)) {}
+    void Add(const std::string &itemId, const std::vector<float> &v) {
+        if (dimension_ == 0)
+            dimension_ = (int)v.size();
+        else if (dimension_ != (int)v.size())
+            return;  // "dimension mismatch" is logged and the item dropped (cf.go:56-61)
+        items_.push_back(itemId);
+        data_.insert(data_.end(), v.begin(), v.end());
+        if (searcher_) searcher_->invalidate(kCollection);
+    }
+    int64_t Timestamp() const { return timestamp_; }
+    int Dimension() const { return dimension_; }
+    size_t Count() const { return items_.size(); }
+    const std::string &Id(size_t i) const { return items_[i]; }
+    const float *Row(size_t i) const { return data_.data() + i * (size_t)dimension_; }
+    // Search (cf.go:69-79): the n nearest items by -dot, Score = the inner product
+    std::vector<Score> Search(const std::vector<float> &v, int n) {
+        std::vector<Score> out;
+        if (items_.empty() || n <= 0) return out;
+        if ((int)v.size() != dimension_) throw std::invalid_argument("floats: slice lengths do not match");
+        if (!searcher_) searcher_ = std::make_shared<vectors::HipSearcher>();
+        std::vector<int32_t> idx((size_t)n);
+        std::vector<float> dist((size_t)n);
+        int32_t cnt = 0;
+        searcher_->search(kCollection, data_.data(), (int64_t)items_.size(), dimension_, GORSE_METRIC_NEG_DOT, v.data(), 1, n,
+                          idx.data(), dist.data(), &cnt);
+        for (int32_t t = 0; t < cnt; t++) {
+            Score sc;
+            sc.Id = items_[(size_t)idx[(size_t)t]];
+            sc.Value = -(double)dist[(size_t)t];
+            out.push_back(std::move(sc));
+        }
+        return out;
+    }
+    std::string Marshal() const {
+        std::string w;
+        put_gob(w, gob::encode_time_unix_nanos(timestamp_));
+        put_gob(w, gob::encode_int(dimension_));
+        w += "GHIP";               // levelFactor slot
+        put<int64_t>(w, 1);        // maxConnection slot: the version of this section
+        put<int64_t>(w, 0);
+        put<int64_t>(w, 0);
+        put<int64_t>(w, 0);
+        put<int64_t>(w, 1);        // "one vector" ...
+        put<int32_t>(w, 0);        // ... whose gob stream is empty: the reference's reader stops here with an error
+        put<int64_t>(w, (int64_t)items_.size());
+        put<int32_t>(w, dimension_);
+        w.append((const char *)data_.data(), data_.size() * sizeof(float));
+        put_gob(w, gob::encode_int((int64_t)items_.size()));
+        for (const auto &id : items_) put_gob(w, gob::encode_string(id));
+        return w;
+    }
+    void Unmarshal(const std::string &blob) {
+        size_t at = 0;
+        items_.clear();
+        data_.clear();
+        if (searcher_) searcher_->invalidate(kCollection);
+        timestamp_ = gob::decode_time_unix_nanos(bytes(blob, at, get<int32_t>(blob, at)));
+        dimension_ = (int)gob::decode_int(bytes(blob, at, get<int32_t>(blob, at)));
+        int64_t n;
+        if (blob.size() - at >= 4 && blob.compare(at, 4, "GHIP") == 0) {  // this library's index section
+            at += 4;
+            const int64_t version = get<int64_t>(blob, at);
+            if (version != 1) throw std::runtime_error("MatrixFactorizationItems index section version " + std::to_string(version) + " is not supported");
+            at += 3 * 8 + 8 + 4;
+            if (at > blob.size()) throw std::runtime_error("unexpected EOF");
+            n = get<int64_t>(blob, at);
+            const int32_t d = get<int32_t>(blob, at);
+            if (n < 0 || d != dimension_ || (n > 0 && (blob.size() - at) / sizeof(float) / (size_t)std::max(d, 1) < (size_t)n))
+                throw std::runtime_error("unexpected EOF");
+            data_.resize((size_t)n * (size_t)d);
+            std::memcpy(data_.data(), blob.data() + at, data_.size() * sizeof(float));
+            at += data_.size() * sizeof(float);
+        } else {  // the reference's: HNSW.Marshal (hnsw.go:278-337)
+            at += 4 + 4 * 8;  // levelFactor, maxConnection, maxConnection0, ef, efConstruction
+            if (at > blob.size()) throw std::runtime_error("unexpected EOF");
+            n = get<int64_t>(blob, at);
+            if (n < 0) throw std::runtime_error("negative vector count");
+            for (int64_t i = 0; i < n; i++) {
+                const std::vector<float> v = gob::decode_f32_slice(bytes(blob, at, get<int32_t>(blob, at)));
+                if ((int)v.size() != dimension_)
+                    throw std::runtime_error("vector " + std::to_string(i) + " has " + std::to_string(v.size()) + " dimensions");
+                data_.insert(data_.end(), v.begin(), v.end());
+            }
+            for (int64_t i = 0; i < n; i++) skip_queue(blob, at);  // bottom layer
+            const int64_t layers = get<int64_t>(blob, at);
+            for (int64_t l = 0; l < layers; l++) {
+                const int32_t m = get<int32_t>(blob, at);
+                for (int32_t e = 0; e < m; e++) {
+                    (void)get<int32_t>(blob, at);
+                    skip_queue(blob, at);
+                }
+            }
+            (void)get<int32_t>(blob, at);  // enterPoint
+        }
+        const int64_t numItems = gob::decode_int(bytes(blob, at, get<int32_t>(blob, at)));
+        if (numItems != n) throw std::runtime_error("ids and vectors differ in number");
+        for (int64_t i = 0; i < numItems; i++) items_.push_back(gob::decode_string(bytes(blob, at, get<int32_t>(blob, at))));
+    }
+
+private:
+    template <typename T>
+    static void put(std::string &w, T v) { w.append((const char *)&v, sizeof(T)); }
+    static void put_gob(std::string &w, const std::string &stream) {  // encoding.WriteGob: int32 byte count + the stream
+        put<int32_t>(w, (int32_t)stream.size());
+        w += stream;
+    }
+    template <typename T>
+    static T get(const std::string &b, size_t &at) {
+        if (b.size() < at || b.size() - at < sizeof(T)) throw std::runtime_error("unexpected EOF");
+        T v;
+        std::memcpy(&v, b.data() + at, sizeof(T));
+        at += sizeof(T);
+        return v;
+    }
+    static std::string bytes(const std::string &b, size_t &at, int32_t n) {
+        if (n < 0 || b.size() < at || b.size() - at < (size_t)n) throw std::runtime_error("unexpected EOF");
+        std::string out = b.substr(at, (size_t)n);
+        at += (size_t)n;
+        return out;
+    }
+    static void skip_queue(const std::string &b, size_t &at) {  // PriorityQueue.Marshal, pq.go:128-133
+        (void)get<uint8_t>(b, at);
+        const int32_t len = get<int32_t>(b, at);
+        if (len < 0 || b.size() - at < (size_t)len * 8) throw std::runtime_error("unexpected EOF");
+        at += (size_t)len * 8;
+    }
+    static constexpr const char *kCollection = "matrix_factorization_items";
+    int64_t timestamp_ = 0;
+    int dimension_ = 0;
+    std::vector<std::string> items_;
+    std::vector<float> data_;
+    std::shared_ptr<vectors::Searcher> searcher_;
+};
+
 // The publishing step of the master after a fit (master/tasks.go:925-969): the predictable items' factors go into a fresh
 // Dot collection collaborative_filtering_<modelId> (batches of batchSize, Id / IsHidden / Categories from the item table,
 // Timestamp = the model id), the predictable users' factors into the MatrixFactorizationUsers blob the workers download.

@@ -424,6 +424,77 @@ def CollaborativeRecommendBulk(client, collection, embeddings, excludes, cache_s
     return [flat[cuts[t]:cuts[t + 1]] for t in range(Q.shape[0])]
 
 
+class MatrixFactorizationItems:
+    """logics.MatrixFactorizationItems (logics/cf.go:36-128): item id -> embedding, nearest items by -dot on the exact index, and
+    its blob: reads the reference's HNSW-based stream (keeping the vectors and ids) and this library's own versioned framing,
+    writes the latter.  searcher = a search callback (the CPU test-suite) or None for the GPU."""
+
+    def __init__(self, timestamp_unix_nanos=0, searcher=None):
+        H = _host()
+        H.gh_mfitems_new.restype = C.c_void_p
+        H.gh_mfitems_new.argtypes = [C.c_int64, C.c_void_p]
+        for n, r, a in (("gh_mfitems_free", None, [C.c_void_p]), ("gh_mfitems_add", None, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int32]),
+                        ("gh_mfitems_count", C.c_int64, [C.c_void_p]), ("gh_mfitems_dimension", C.c_int32, [C.c_void_p]),
+                        ("gh_mfitems_timestamp", C.c_int64, [C.c_void_p]), ("gh_mfitems_id", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
+                        ("gh_mfitems_row", None, [C.c_void_p, C.c_int64, C.POINTER(C.c_float)]),
+                        ("gh_mfitems_marshal", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+                        ("gh_mfitems_unmarshal", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+                        ("gh_mfitems_search", C.c_int64, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
+                                                          C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32)])):
+            getattr(H, n).restype = r
+            getattr(H, n).argtypes = a
+        self._cb = SEARCH_CB(searcher) if searcher is not None else None
+        self.p = C.c_void_p(H.gh_mfitems_new(int(timestamp_unix_nanos), C.cast(self._cb, C.c_void_p) if self._cb else None))
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            _host().gh_mfitems_free(self.p)
+            self.p = None
+
+    def Add(self, item_id, v):
+        v = np.ascontiguousarray(v, np.float32)
+        _host().gh_mfitems_add(self.p, str(item_id).encode(), v.ctypes.data_as(C.POINTER(C.c_float)), v.size)
+
+    def Count(self):
+        return _host().gh_mfitems_count(self.p)
+
+    def Dimension(self):
+        return _host().gh_mfitems_dimension(self.p)
+
+    def Timestamp(self):
+        return _host().gh_mfitems_timestamp(self.p)
+
+    def Id(self, i):
+        buf = C.create_string_buffer(4096)
+        n = _host().gh_mfitems_id(self.p, i, buf, len(buf))
+        return buf.raw[:n].decode()
+
+    def Row(self, i):
+        out = np.empty(self.Dimension(), np.float32)
+        _host().gh_mfitems_row(self.p, i, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def Marshal(self):
+        n = _host().gh_mfitems_marshal(self.p, None, 0)
+        buf = C.create_string_buffer(max(int(n), 1))
+        _host().gh_mfitems_marshal(self.p, buf, len(buf))
+        return buf.raw[:n]
+
+    def Unmarshal(self, blob):
+        _ck(_host().gh_mfitems_unmarshal(self.p, blob, len(blob)))
+
+    def Search(self, v, n):
+        v = np.ascontiguousarray(v, np.float32)
+        ids = C.create_string_buffer(1 << 16)
+        scores = (C.c_double * max(n, 1))()
+        cnt = C.c_int32(0)
+        nb = _host().gh_mfitems_search(self.p, v.ctypes.data_as(C.POINTER(C.c_float)), v.size, n, ids, len(ids), scores, n, C.byref(cnt))
+        if nb < 0:
+            _ck(-1)
+        names = ids.raw[:nb].decode().split("\n") if cnt.value else []
+        return [(names[t], scores[t]) for t in range(cnt.value)]
+
+
 class MatrixFactorizationUsers:
     """logics.MatrixFactorizationUsers (logics/cf.go:122-179): user id -> embedding, the blob workers download"""
 

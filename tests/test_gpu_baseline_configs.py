@@ -145,6 +145,9 @@ def test_c5_als_user_half_sweep_rows(oracle):
     print("C5 user half-sweep, %d rows (lengths %d..%d): max error / largest |ref| of the row %.2e; element-wise relative %.2e"
           % (rows.size, lens[rows].min(), lens[rows].max(), worst_scale, worst_elem))
     assert worst_scale < 1e-4
+    # the bar as stated in tests/test_gpu_cf_parity.py: |err| <= 1e-4 |ref| + 5e-5 * (largest |ref| of the row)
+    bound = 1e-4 * np.abs(A.astype(np.float64)) + 5e-5 * np.abs(A).max(axis=1, keepdims=True)
+    assert (np.abs(gP[rows].astype(np.float64) - A) <= bound).all()
 
 
 def test_c4_rows_against_the_oracle(oracle):
