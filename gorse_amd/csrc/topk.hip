@@ -28,8 +28,9 @@ __global__ __launch_bounds__(kBlock) void norm2_kernel(const float *__restrict__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & (kGroup - 1), gib = threadIdx.x / kGroup;
     const VecShape vs(d);
+    const int gpb = blockDim.x / kGroup;  // groups per workgroup: 16, fewer when d is large (scan_groups)
     float *sa = smem + (size_t)gib * d;
-    for (int64_t t = (int64_t)blockIdx.x * kGroupsPerBlock + gib; t < n; t += (int64_t)gridDim.x * kGroupsPerBlock) {
+    for (int64_t t = (int64_t)blockIdx.x * gpb + gib; t < n; t += (int64_t)gridDim.x * gpb) {
         for (int e = lane; e < d; e += kGroup) sa[e] = X[t * d + e];
         __builtin_amdgcn_wave_barrier();
         float r = dot512_lds(sa, sa, vs, lane);
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(kBlock) void dist_kernel(const float *__restrict__ 
     for (int e = threadIdx.x; e < d; e += blockDim.x) sq[e] = Qv[q * d + e];
     __syncthreads();
     const float qq = metric == GORSE_METRIC_COSINE ? qnorm2[q] : 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * kGroupsPerBlock + gib; i < N; i += (int64_t)gridDim.x * kGroupsPerBlock) {
+    const int gpb = blockDim.x / kGroup;  // groups per workgroup: 16, fewer when d is large (scan_groups)
+    for (int64_t i = (int64_t)blockIdx.x * gpb + gib; i < N; i += (int64_t)gridDim.x * gpb) {
         for (int e = lane; e < d; e += kGroup) sx[e] = X[i * d + e];
         __builtin_amdgcn_wave_barrier();
         float r;
@@ -239,6 +241,13 @@ __global__ __launch_bounds__(kSelThreads) void select_fast_kernel(const float *_
     }
 }
 
+constexpr int kTopkMaxDim = 16384;
+// 16-lane groups per workgroup of dist_kernel / norm2_kernel: as many as keep (1 + g) rows of d floats inside 144 KB of LDS
+int scan_groups(int d) {
+    int g = kGroupsPerBlock;
+    while (g > 1 && (size_t)(1 + g) * (size_t)d * sizeof(float) > (size_t)144 * 1024) g >>= 1;
+    return g;
+}
 constexpr int64_t kDistBudget = (int64_t)1 << 28;  // floats in the distance slab (1 GiB)
 int g_scan_literal_only = 0;  // test hook: every query of the scan through the literal heap kernel
 constexpr int64_t kMinRerouteQueries = (int64_t)1 << 40;  // "enough queries": asks topk_mfma_usable about the index and k only
@@ -257,10 +266,13 @@ int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, cons
     GORSE_TRY(h->out_idx.ensure((size_t)nq * k));
     GORSE_TRY(h->out_dist.ensure((size_t)nq * k));
     GORSE_TRY(h->out_cnt.ensure((size_t)nq));
-    int64_t bx = std::min<int64_t>(ceil_div(h->N, kGroupsPerBlock), 1024);
+    const int gpb = scan_groups(d);
+    int64_t bx = std::min<int64_t>(ceil_div(h->N, gpb), 1024);
     int tok = h->prof.begin(GORSE_PROF_TOPK_SCORE, h->stream);
-    dist_kernel<<<dim3((unsigned)bx, (unsigned)nq), dim3(kBlock), (size_t)(1 + kGroupsPerBlock) * d * sizeof(float),
-                  h->stream>>>(h->X.p, h->norm2.p, h->qbuf.p, h->qnorm.p, h->N, d, h->kernel_metric(), h->dist.p);
+    const size_t dist_lds = (size_t)(1 + gpb) * d * sizeof(float);
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dist_lds));
+    dist_kernel<<<dim3((unsigned)bx, (unsigned)nq), dim3(gpb * kGroup), dist_lds, h->stream>>>(h->X.p, h->norm2.p, h->qbuf.p, h->qnorm.p,
+                                                                                              h->N, d, h->kernel_metric(), h->dist.p);
     GORSE_HIP_CHECK(hipGetLastError());
     h->prof.end(tok, h->stream);
     tok = h->prof.begin(GORSE_PROF_TOPK_RESCORE, h->stream);
@@ -269,7 +281,9 @@ int32_t topk_scan_block(gorse_topk *h, int64_t nq, const int64_t *qidx_dev, cons
     // The queries the fast selection leaves (ties among the k + 1 smallest distances, NaN): the literal heap kernel is one
     // thread per query over all N rows -- 3.3 s for a million rows, however few queries there are -- so where the MFMA path
     // can take them (its history sweep + heap replay answer a tie query in tens of milliseconds) they go there.
-    reroute = reroute && !g_scan_literal_only && topk_mfma_usable(h, kMinRerouteQueries, k);
+    // (not with a mask: the replay counts the rows between two recorded ones, masked rows included, so the MFMA path sends a
+    // masked tie query back to the literal kernel anyway -- after a full sweep)
+    reroute = reroute && !g_scan_literal_only && !h->has_mask && topk_mfma_usable(h, kMinRerouteQueries, k);
     if (!g_scan_literal_only) {
         GORSE_TRY(h->scan_literal.ensure((size_t)nq));
         literal = h->scan_literal.p;
@@ -329,9 +343,11 @@ int64_t topk_scan_block_queries(const gorse_topk *h) {
 }
 
 int32_t topk_compute_norms(gorse_topk *h, const float *V, int64_t n, float *out) {
-    int64_t bx = std::min<int64_t>(ceil_div(n, kGroupsPerBlock), 4096);
-    norm2_kernel<<<dim3((unsigned)bx), dim3(kBlock), (size_t)kGroupsPerBlock * h->d * sizeof(float), h->stream>>>(V, n, h->d,
-                                                                                                                out);
+    const int gpb = scan_groups(h->d);
+    int64_t bx = std::min<int64_t>(ceil_div(n, gpb), 4096);
+    const size_t lds = (size_t)gpb * h->d * sizeof(float);
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&norm2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    norm2_kernel<<<dim3((unsigned)bx), dim3(gpb * kGroup), lds, h->stream>>>(V, n, h->d, out);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -344,9 +360,10 @@ extern "C" int32_t gorse_topk_create(gorse_topk **out, int32_t device, int64_t N
     *out = nullptr;
     if (N <= 0 || d <= 0 || !X) return fail(GORSE_ERR_INVALID, "N, d must be positive and X non-NULL");
     if (N > INT32_MAX) return fail(GORSE_ERR_INVALID, "N must fit int32");
-    // dist_kernel stages 17 rows of d floats per workgroup in LDS (68 d bytes) and norm2_kernel 16 (64 d): 64 KB of LDS
-    // without opting into more
-    if (d > 960) return fail(GORSE_ERR_INVALID, "d %d > 960 unsupported (the literal scan stages 68 d bytes of LDS)", d);
+    // dist_kernel stages 1 + g rows of d floats per workgroup in LDS, g = 16 groups down to 1 as d grows (scan_groups):
+    // the reference's shipped configuration uses embeddings of 1024 dimensions (config.toml: embedding_dimensions), 1536 and
+    // 3072 are common
+    if (d > kTopkMaxDim) return fail(GORSE_ERR_INVALID, "d %d > %d unsupported (the scan stages two rows of d floats in 160 KB of LDS)", d, kTopkMaxDim);
     if (dtype != GORSE_DTYPE_F32 && dtype != GORSE_DTYPE_BF16) return fail(GORSE_ERR_INVALID, "unknown dtype %d", dtype);
     if (metric < 0 || metric > 3) return fail(GORSE_ERR_INVALID, "unknown metric %d", metric);
     if (metric == GORSE_METRIC_EUCLIDEAN_BF16 && dtype != GORSE_DTYPE_BF16)

@@ -14,8 +14,11 @@ import (
 	"sync"
 	"unsafe"
 
+	"github.com/gorse-io/gorse/common/encoding"
+	"github.com/gorse-io/gorse/common/log"
 	"github.com/pkg/errors"
 	"github.com/samber/lo"
+	"go.uber.org/zap"
 )
 
 // Metric of a BruteforceHIP index (the distance functions the reference passes to ann.NewBruteforce / ann.NewHNSW).
@@ -36,6 +39,16 @@ type BruteforceHIP struct {
 	data   []float32 // row-major, len = n * d
 	h      *C.gorse_topk
 	dirty  bool
+	lastErr error // the device failure behind the last empty answer of SearchVector / SearchVectors, if any
+}
+
+// LastError returns (and clears) the device failure behind the last empty answer.
+func (b *BruteforceHIP) LastError() error {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	err := b.lastErr
+	b.lastErr = nil
+	return err
 }
 
 func NewBruteforceHIP(metric Metric) *BruteforceHIP { return &BruteforceHIP{metric: metric} }
@@ -108,10 +121,17 @@ func (b *BruteforceHIP) SearchIndex(q, k int, prune0 bool) ([]lo.Tuple2[int, flo
 	return zip(idx, dist, int(cnt)), nil
 }
 
+// SearchVector has no error result in ann.Index (ann.go:21-25): a device failure (no GPU, a dimension the library cannot hold)
+// is logged and, like an empty index, answered with no neighbours -- LastError tells the two apart.
 func (b *BruteforceHIP) SearchVector(q []float32, k int, prune0 bool) []lo.Tuple2[int, float32] {
 	b.mu.Lock()
 	defer b.mu.Unlock()
-	if b.d == 0 || len(q) != b.d || k <= 0 || b.sync() != nil {
+	if b.d == 0 || len(q) != b.d || k <= 0 {
+		return nil
+	}
+	if err := b.sync(); err != nil {
+		b.lastErr = err
+		log.Logger().Error("BruteforceHIP: device index unavailable", zap.Error(err))
 		return nil
 	}
 	idx, dist := make([]int32, k), make([]float32, k)
@@ -154,7 +174,16 @@ func (b *BruteforceHIP) SearchVectors(qs [][]float32, k int, prune0 bool) [][]lo
 	return out
 }
 
-// Marshal writes the vectors (dimension, count, row-major float32, little endian): the exact index has no graph to save.
+// The index section of a MatrixFactorizationItems file (logics/cf.go:81-128) in the place of HNSW.Marshal (hnsw.go:278-337).
+// Marshal writes a section a build WITHOUT this library rejects cleanly: where HNSW.Unmarshal expects levelFactor it finds the
+// bytes "GHIP", then an int64 version in the maxConnection slot, three int64 zeros, the vector count 1 and an EMPTY gob stream
+// for that "vector" -- encoding.ReadGob returns gob's EOF there, an ordinary error, before anything is allocated.  Behind it:
+// int64 count, int32 dimension, the float32 rows.  Unmarshal reads that section AND the reference's own (keeping the vectors,
+// skipping the graph), so a master without the library can hand its file to a worker with it.
+// The C++ twin of both directions, with its test on a hand-built reference stream: gorse_amd/host/gorse_vectors.hpp
+// (logics::MatrixFactorizationItems), tests/test_items_blob_cpu.py.
+var hipMagic = [4]byte{'G', 'H', 'I', 'P'}
+
 func (b *BruteforceHIP) Marshal(w io.Writer) error {
 	b.mu.Lock()
 	defer b.mu.Unlock()
@@ -162,30 +191,114 @@ func (b *BruteforceHIP) Marshal(w io.Writer) error {
 	if b.d > 0 {
 		n = len(b.data) / b.d
 	}
-	if err := binary.Write(w, binary.LittleEndian, []int64{int64(b.metric), int64(b.d), int64(n)}); err != nil {
+	head := struct {
+		Magic   [4]byte
+		Version int64
+		Zero    [3]int64
+		One     int64
+		Empty   int32
+		N       int64
+		D       int32
+	}{Magic: hipMagic, Version: 1, One: 1, N: int64(n), D: int32(b.d)}
+	if err := binary.Write(w, binary.LittleEndian, head); err != nil {
 		return errors.WithStack(err)
 	}
 	return errors.WithStack(binary.Write(w, binary.LittleEndian, b.data))
 }
 
-// Unmarshal reads what Marshal wrote; the device index is rebuilt at the next search.
+func skipQueue(r io.Reader) error { // PriorityQueue.Marshal, common/heap/pq.go:128-133: one bool, int32 length, 8-byte elements
+	var head struct {
+		Desc bool
+		Len  int32
+	}
+	if err := binary.Read(r, binary.LittleEndian, &head); err != nil {
+		return err
+	}
+	if head.Len < 0 {
+		return errors.New("negative queue length")
+	}
+	_, err := io.CopyN(io.Discard, r, int64(head.Len)*8)
+	return err
+}
+
 func (b *BruteforceHIP) Unmarshal(r io.Reader) error {
 	b.mu.Lock()
 	defer b.mu.Unlock()
-	var head [3]int64
-	if err := binary.Read(r, binary.LittleEndian, head[:]); err != nil {
+	var first [4]byte
+	if err := binary.Read(r, binary.LittleEndian, &first); err != nil {
 		return errors.WithStack(err)
 	}
-	if head[1] < 0 || head[2] < 0 || (head[1] == 0 && head[2] != 0) {
-		return errors.Errorf("BruteforceHIP: bad header %v", head)
-	}
-	b.metric, b.d = Metric(head[0]), int(head[1])
-	b.data = make([]float32, head[1]*head[2])
-	if err := binary.Read(r, binary.LittleEndian, b.data); err != nil {
+	var params [4]int64
+	if err := binary.Read(r, binary.LittleEndian, &params); err != nil {
 		return errors.WithStack(err)
 	}
+	var n int64
+	if err := binary.Read(r, binary.LittleEndian, &n); err != nil {
+		return errors.WithStack(err)
+	}
+	if first == hipMagic { // this library's section
+		if params[0] != 1 {
+			return errors.Errorf("BruteforceHIP: index section version %d is not supported", params[0])
+		}
+		var rest struct {
+			Empty int32
+			N     int64
+			D     int32
+		}
+		if err := binary.Read(r, binary.LittleEndian, &rest); err != nil {
+			return errors.WithStack(err)
+		}
+		if rest.N < 0 || rest.D < 0 {
+			return errors.Errorf("BruteforceHIP: bad header %v", rest)
+		}
+		b.d, b.data = int(rest.D), make([]float32, rest.N*int64(rest.D))
+		b.dirty = true
+		return errors.WithStack(binary.Read(r, binary.LittleEndian, b.data))
+	}
+	// the reference's section: the vectors, then a graph this index has no use for
+	if n < 0 {
+		return errors.New("negative vector count")
+	}
+	b.d, b.data = 0, b.data[:0]
+	for i := int64(0); i < n; i++ {
+		var v []float32
+		if err := encoding.ReadGob(r, &v); err != nil {
+			return errors.WithStack(err)
+		}
+		if b.d == 0 {
+			b.d = len(v)
+		} else if len(v) != b.d {
+			return errors.Errorf("vector %d has %d dimensions, want %d", i, len(v), b.d)
+		}
+		b.data = append(b.data, v...)
+	}
+	for i := int64(0); i < n; i++ {
+		if err := skipQueue(r); err != nil {
+			return errors.WithStack(err)
+		}
+	}
+	var layers int64
+	if err := binary.Read(r, binary.LittleEndian, &layers); err != nil {
+		return errors.WithStack(err)
+	}
+	for l := int64(0); l < layers; l++ {
+		var m int32
+		if err := binary.Read(r, binary.LittleEndian, &m); err != nil {
+			return errors.WithStack(err)
+		}
+		for e := int32(0); e < m; e++ {
+			var key int32
+			if err := binary.Read(r, binary.LittleEndian, &key); err != nil {
+				return errors.WithStack(err)
+			}
+			if err := skipQueue(r); err != nil {
+				return errors.WithStack(err)
+			}
+		}
+	}
+	var enterPoint int32
 	b.dirty = true
-	return nil
+	return errors.WithStack(binary.Read(r, binary.LittleEndian, &enterPoint))
 }
 
 // SearchAll is SearchIndex for every stored vector in one device pass (the item-to-item bulk build): row q of the
