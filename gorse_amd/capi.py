@@ -51,6 +51,7 @@ SIGNATURES = {
     "gorse_als_epoch": (C.c_int32, [_vp, C.c_float, C.c_float, _i32p]),
     "gorse_als_set_ranges": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "gorse_als_half_epoch": (C.c_int32, [_vp, C.c_int32, C.c_float, C.c_float]),
+    "gorse_als_half_epoch_enqueue": (C.c_int32, [_vp, C.c_int32, C.c_float, C.c_float]),
     "gorse_mf_rows_export": (C.c_int32, [_vp, C.c_int32, C.c_int64, C.c_int64, _vp]),
     "gorse_mf_rows_import": (C.c_int32, [_vp, C.c_int32, C.c_int64, C.c_int64, _vp]),
     "gorse_mf_item_sync_mark": (C.c_int32, [_vp]),
@@ -275,6 +276,9 @@ class MF:
 
     def als_half_epoch(self, side, weight, reg):
         check(lib().gorse_als_half_epoch(self.h, side, weight, reg))
+
+    def als_half_epoch_enqueue(self, side, weight, reg):
+        check(lib().gorse_als_half_epoch_enqueue(self.h, side, weight, reg))
 
     def rows_export(self, side, begin, end, dev_ptr):
         check(lib().gorse_mf_rows_export(self.h, side, begin, end, _vp(dev_ptr)))

@@ -964,6 +964,16 @@ extern "C" int32_t gorse_als_half_epoch(gorse_mf *h, int32_t side, float weight,
     return GORSE_OK;
 }
 
+// the same, only enqueued on the handle's stream: one process driving N handles (integration/go/model/cf/rccl_hip.go) enqueues
+// the half-sweep of every device, then gorse_mf_rows_allgather (stream-ordered), and synchronises once per epoch -- through
+// the synchronous call the N devices would solve their row ranges one after the other
+extern "C" int32_t gorse_als_half_epoch_enqueue(gorse_mf *h, int32_t side, float weight, float reg) {
+    GORSE_TRY(als_check(h));
+    if (side != 0 && side != 1) return fail(GORSE_ERR_INVALID, "side must be 0 (users) or 1 (items)");
+    GORSE_TRY(h->use());
+    return half_epoch(h, side, weight, reg);
+}
+
 extern "C" int32_t gorse_als_set_ranges(gorse_mf *h, int64_t u_begin, int64_t u_end, int64_t i_begin, int64_t i_end) {
     GORSE_TRY(als_check(h));
     if (u_begin < 0 || u_end > h->U || u_begin > u_end || i_begin < 0 || i_end > h->I || i_begin > i_end)

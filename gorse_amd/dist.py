@@ -171,6 +171,51 @@ class LibComm:
         self.comm.close()
 
 
+class LocalComms:
+    """One process, N GPUs -- the Go master's mode (integration/go/model/cf/rccl_hip.go): gorse_comm_create_local gives one
+    communicator per device, and every exchange is ONE library call that receives all N (handle, communicator) pairs and
+    issues their collectives as one RCCL group."""
+
+    def __init__(self, devices):
+        from . import capi
+        self.capi = capi
+        self.comms = capi.Comm.local(devices)
+        self.world = len(self.comms)
+
+    def item_allreduce(self, mfs):
+        self.capi.item_allreduce(mfs, self.comms)
+
+    def rows_allgather(self, mfs, side, row_splits):
+        self.capi.rows_allgather(mfs, self.comms, side, row_splits)
+
+    def close(self):
+        for c in self.comms:
+            c.close()
+
+
+def run_epoch_local(engines, comms, samples, lr, reg, seed, epoch):
+    """hipGroup.bprEpoch of rccl_hip.go: the epoch of EVERY device is enqueued first (nothing waits for a device), then the
+    item factors are summed by one grouped all-reduce over all (handle, communicator) pairs.  engines[r] drives the handle
+    of shard r (its sample stream starts at r << 40), samples[r] = its share of the epoch's samples."""
+    for r, (eng, n) in enumerate(zip(engines, samples)):
+        eng.epoch(n, lr, reg, seed, epoch, r * (1 << 40))
+    comms.item_allreduce([e.mf for e in engines])
+
+
+def run_als_epoch_local(engines, comms, weight, reg):
+    """alsEpochSharded of rccl_hip.go: per half-sweep every device's kernels are enqueued (gorse_als_half_epoch_enqueue -- the
+    synchronous call would make the devices take turns), then one grouped all-gather of the row blocks; one host
+    synchronisation per epoch."""
+    world = len(engines)
+    for side in (0, 1):
+        for eng in engines:
+            eng.mf.als_half_epoch_enqueue(side, weight, reg)
+        rows = engines[0].rows[side]
+        comms.rows_allgather([e.mf for e in engines], side, [shard_range(rows, r, world)[0] for r in range(world)] + [rows])
+    for eng in engines:
+        eng.mf.synchronize()
+
+
 class TorchComm:
     """torch.distributed plumbing (backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' in the CPU tests)."""
 
@@ -259,7 +304,10 @@ class HipAlsEngine:
             self.buf = [torch.zeros(b * mf.d, dtype=torch.float32, device=device) for b in self.block]
 
     def half(self, side, weight, reg):
-        self.mf.als_half_epoch(side, weight, reg)
+        if self.buf is None:  # no torch staging: a single GPU, or the exchange inside the library (stream-ordered): enqueue only
+            self.mf.als_half_epoch_enqueue(side, weight, reg)
+        else:
+            self.mf.als_half_epoch(side, weight, reg)
 
     def export_block(self, side):
         lo, hi = self.range[side]

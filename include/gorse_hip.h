@@ -158,6 +158,10 @@ int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const volatile int
  * :693-738); gorse_als_epoch = half 0 then half 1 on the current ranges. */
 int32_t gorse_als_set_ranges(gorse_mf *h, int64_t u_begin, int64_t u_end, int64_t i_begin, int64_t i_end);
 int32_t gorse_als_half_epoch(gorse_mf *h, int32_t side, float weight, float reg);
+/* Same, but only enqueues the kernels on the handle's stream (gorse_mf_rows_allgather is ordered behind them on that stream;
+ * gorse_mf_synchronize ends the epoch): what a caller driving several handles from one thread uses, so that the devices
+ * solve their row ranges at the same time. */
+int32_t gorse_als_half_epoch_enqueue(gorse_mf *h, int32_t side, float weight, float reg);
 /* factor rows [begin,end) of side 0 (P) / 1 (Q) -> / <- a device buffer owned by the caller */
 int32_t gorse_mf_rows_export(gorse_mf *h, int32_t side, int64_t begin, int64_t end, float *dst /*device*/);
 int32_t gorse_mf_rows_import(gorse_mf *h, int32_t side, int64_t begin, int64_t end, const float *src /*device*/);

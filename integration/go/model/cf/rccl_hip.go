@@ -169,15 +169,22 @@ func alsEpochSharded(handles []*C.gorse_mf, comms []*C.gorse_comm, users, items 
 		return s
 	}
 	for side, rows := range []int{users, items} { // model.go:645-690, then :693-738
+		// enqueued, not run: the synchronous gorse_als_half_epoch would make the N devices solve their row ranges one after
+		// the other from this goroutine; the all-gather below is ordered behind the kernels on every handle's stream
 		for _, h := range handles {
-			if rc := C.gorse_als_half_epoch(h, C.int32_t(side), C.float(weight), C.float(reg)); rc != 0 {
-				return hipError("gorse_als_half_epoch", rc)
+			if rc := C.gorse_als_half_epoch_enqueue(h, C.int32_t(side), C.float(weight), C.float(reg)); rc != 0 {
+				return hipError("gorse_als_half_epoch_enqueue", rc)
 			}
 		}
 		sp := splits(rows)
 		if rc := C.gorse_mf_rows_allgather((**C.gorse_mf)(unsafe.Pointer(&handles[0])), (**C.gorse_comm)(unsafe.Pointer(&comms[0])),
 			C.int32_t(n), C.int32_t(side), &sp[0]); rc != 0 {
 			return hipError("gorse_mf_rows_allgather", rc)
+		}
+	}
+	for _, h := range handles { // one host synchronisation per epoch
+		if rc := C.gorse_mf_synchronize(h); rc != 0 {
+			return hipError("gorse_mf_synchronize", rc)
 		}
 	}
 	return nil

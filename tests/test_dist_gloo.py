@@ -264,6 +264,8 @@ class StandInMF:
         ptr, idx, bptr = (d.uptr, d.uidx, d.iptr) if side == 0 else (d.iptr, d.iidx, d.uptr)
         self.o.als_half_range(self.F[side], self.F[1 - side], ptr, idx, bptr, w, reg, *self.ranges[side])
 
+    als_half_epoch_enqueue = als_half_epoch  # the stand-in has no stream: "enqueue" runs it
+
     def rows_export(self, side, lo, hi, ptr):
         self._view(ptr, (hi - lo) * self.d)[:] = self.F[side][lo:hi].ravel()
 
@@ -346,6 +348,76 @@ def test_hip_engines_over_gloo_with_a_stand_in_handle(tmp_path):
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / ("bP%d.npy" % r)), engines[r][0].P)
         assert np.array_equal(np.load(tmp_path / ("bQ%d.npy" % r)), engines[r][0].Q)
+
+
+# ---- one process, N handles: the Go master's mode (integration/go/model/cf/rccl_hip.go) -----------------------------------------
+class StubLocalComms:
+    """gorse_mf_item_allreduce / gorse_mf_rows_allgather over N stand-in handles of ONE process: what the grouped RCCL calls of
+    csrc/comm.hip leave in the replicas (export kernel -> all-reduce -> import kernel; one broadcast per owner)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.calls = []
+
+    def item_allreduce(self, mfs):
+        assert len(mfs) == self.world
+        self.calls.append("item_allreduce x%d" % len(mfs))
+        total = sum((m.F[1] - m.Qsync) for m in mfs)  # rank order, like the emulation the multi-process test compares with
+        for m in mfs:
+            m.F[1] = (m.Qsync + total).astype(np.float32)
+            m.Qsync = m.F[1].copy()
+
+    def rows_allgather(self, mfs, side, row_splits):
+        assert len(mfs) == self.world and row_splits[0] == 0 and len(row_splits) == self.world + 1
+        self.calls.append("rows_allgather side %d" % side)
+        for r, owner in enumerate(mfs):
+            lo, hi = row_splits[r], row_splits[r + 1]
+            for m in mfs:
+                if m is not owner:
+                    m.F[side][lo:hi] = owner.F[side][lo:hi]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_process_n_handles_call_sequence(world):
+    """run_epoch_local / run_als_epoch_local (the Python twins of hipGroup.bprEpoch / alsEpochSharded): N handles driven from one
+    thread -- every device's epoch enqueued, then ONE grouped exchange -- give exactly what one process per rank gives: the
+    single-process emulation for BPR, the unsharded oracle epoch for ALS."""
+    import types
+    from oracle import oracle as orc
+    data, P, Q = _problem()
+    engines, samples, ref = [], [], []
+    for r in range(world):
+        lo, hi, uptr, uidx, n = _rank_inputs(data, P, r, world)
+        mf = StandInMF(types.SimpleNamespace(uptr=uptr, uidx=uidx), P[lo:hi], Q)
+        mf.item_sync_mark()
+        engines.append(gdist.HipEngine(mf, 0, device="cpu"))
+        samples.append(n)
+        ref.append((OracleEngine(P[lo:hi], Q, uptr, uidx), n))
+    comms = StubLocalComms(world)
+    for ep in range(1, 4):
+        gdist.run_epoch_local(engines, comms, samples, 0.05, 0.01, 11, ep)
+        deltas = []
+        for r, (e, n) in enumerate(ref):
+            e.epoch(n, 0.05, 0.01, 11, ep, r * (1 << 40))
+            deltas.append(e.export_delta())
+        total = sum(deltas[1:], deltas[0])
+        for e, _ in ref:
+            e.import_delta(total.clone())
+    assert comms.calls == ["item_allreduce x%d" % world] * 3  # one grouped call per epoch
+    for r in range(world):
+        assert np.array_equal(engines[r].mf.F[0], ref[r][0].P) and np.array_equal(engines[r].mf.F[1], ref[r][0].Q)
+    # ALS: every handle holds the whole data set and solves its row ranges
+    data, P, Q = _als_problem()
+    aengines = [gdist.HipAlsEngine(StandInMF(data, P, Q), r, world, device="cpu", staging=False) for r in range(world)]
+    comms = StubLocalComms(world)
+    eP, eQ = P, Q
+    o = orc.Oracle()
+    for _ in range(2):
+        gdist.run_als_epoch_local(aengines, comms, 0.05, 0.015)
+        eP, eQ = o.als_epoch(eP, eQ, data.uptr, data.uidx, data.iptr, data.iidx, 0.05, 0.015)
+    assert comms.calls == ["rows_allgather side 0", "rows_allgather side 1"] * 2
+    for e in aengines:
+        assert np.array_equal(e.mf.F[0], eP) and np.array_equal(e.mf.F[1], eQ)
 
 
 # ---- the neighbour refresh (sparse item-to-item / user-to-user, dense top-k) over row shards --------------------------------

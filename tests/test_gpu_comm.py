@@ -83,3 +83,27 @@ def test_run_epoch_through_the_library_communicator(data):
     for x, y in zip(mf.get_factors(), ref_mf.get_factors()):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
     comm.close()
+
+
+def test_one_process_local_communicators_call_sequence(data):
+    """run_epoch_local / run_als_epoch_local (the Go master's order: every device's kernels enqueued, then ONE grouped exchange over
+    all (handle, communicator) pairs of the process) on what a one-GPU box holds of it: a group of one.  The N > 1 arithmetic
+    of the same two functions is covered by tests/test_dist_gloo.py::test_one_process_n_handles_call_sequence."""
+    d = 32
+    comms = gdist.LocalComms([0])
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, data.iptr, data.iidx)
+    P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.1, 4)
+    mf.set_factors(P0, Q0)
+    mf.item_sync_mark()
+    eng = gdist.HipEngine(mf, capi.BPR_HOGWILD_ATOMIC)
+    gdist.run_epoch_local([eng], comms, [data.n_train], 0.05, 0.01, 5, 1)
+    P, Q = mf.get_factors()
+    assert np.isfinite(P).all() and np.isfinite(Q).all() and not np.array_equal(Q, Q0)
+    als = gdist.HipAlsEngine(mf, 0, 1, staging=False)
+    gdist.run_als_epoch_local([als], comms, 0.05, 0.015)  # enqueued half-sweeps + grouped all-gathers, one synchronisation
+    ref_mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, data.iptr, data.iidx)
+    ref_mf.set_factors(P, Q)
+    ref_mf.als_epoch(0.05, 0.015)
+    for x, y in zip(mf.get_factors(), ref_mf.get_factors()):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    comms.close()
