@@ -533,7 +533,11 @@ def make_comm(args, world, rank, local):
                 t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
                 dist.broadcast(t, src=0)
                 return bytes(t.cpu().tolist())
-            lib = gdist.LibComm(rank, world, local, share)
+            def agree(ok):
+                t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return float(t.item()) > 0
+            lib = gdist.LibComm(rank, world, local, share, agree=agree)
         except Exception as e:  # reported in the line; the run goes on over torch.distributed
             why = repr(e)
         ok = torch.tensor([1.0 if lib is not None else 0.0], device="cuda")

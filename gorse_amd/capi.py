@@ -66,6 +66,8 @@ SIGNATURES = {
     "gorse_mf_item_allreduce": (C.c_int32, [C.POINTER(_vp), C.POINTER(_vp), C.c_int32]),
     "gorse_mf_rows_allgather": (C.c_int32, [C.POINTER(_vp), C.POINTER(_vp), C.c_int32, C.c_int32, _i64p]),
     "gorse_comm_allreduce_f32": (C.c_int32, [_vp, _f32p, C.c_int64]),
+    "gorse_comm_allreduce_f32_local": (C.c_int32, [C.POINTER(_vp), C.c_int32, C.POINTER(_f32p), C.c_int64]),
+    "gorse_comm_available": (C.c_int32, []),
     "gorse_mf_synchronize": (C.c_int32, [_vp]),
     "gorse_mf_set_profiling": (C.c_int32, [_vp, C.c_int32]),
     "gorse_mf_get_profile": (C.c_int32, [_vp, C.c_int32, _i64p, _f64p]),
@@ -430,6 +432,22 @@ class Comm:
         a = np.array(values, dtype=np.float32)
         check(lib().gorse_comm_allreduce_f32(self.h, _p(a, _f32p), a.size))
         return a
+
+
+def comm_available():
+    """None when RCCL can be opened in this process, else the reason"""
+    if lib().gorse_comm_available() == 0:
+        return None
+    return lib().gorse_hip_last_error().decode()
+
+
+def allreduce_f32_local(comms, arrays):
+    """gorse_comm_allreduce_f32_local: one array of equal length per communicator of this process, summed in place"""
+    arrs = [np.ascontiguousarray(a, np.float32) for a in arrays]
+    cs = (_vp * len(comms))(*[c.h for c in comms])
+    bs = (_f32p * len(arrs))(*[_p(a, _f32p) for a in arrs])
+    check(lib().gorse_comm_allreduce_f32_local(cs, len(comms), bs, arrs[0].size))
+    return arrs
 
 
 def _pairs(mfs, comms):

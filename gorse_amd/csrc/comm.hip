@@ -30,6 +30,11 @@ struct Rccl {
     std::string why;
 };
 
+std::string &rccl_why() {
+    static std::string why;
+    return why;
+}
+
 Rccl *rccl() {
     static Rccl r;
     static std::once_flag once;
@@ -66,12 +71,15 @@ Rccl *rccl() {
             r.lib = nullptr;
         }
     });
+    if (!r.lib) rccl_why() = r.why;
     return r.lib ? &r : nullptr;
 }
 
 int32_t need_rccl(Rccl **out) {
     *out = rccl();
-    if (!*out) return fail(GORSE_ERR_HIP, "RCCL unavailable: %s", rccl() ? "" : "dlopen(librccl.so.1) failed");
+    if (!*out) {
+        return fail(GORSE_ERR_HIP, "RCCL unavailable: %s", rccl_why().empty() ? "dlopen(librccl.so.1) failed" : rccl_why().c_str());
+    }
     return GORSE_OK;
 }
 
@@ -141,7 +149,14 @@ extern "C" int32_t gorse_comm_create_local(gorse_comm **out, const int32_t *devi
     GORSE_RCCL_CHECK(R, R->CommInitAll(comms.data(), n, devs.data()));
     for (int i = 0; i < n; i++) {
         gorse_comm *c = new (std::nothrow) gorse_comm();
-        if (!c) return fail(GORSE_ERR_NOMEM, "out of host memory");
+        if (!c) {  // nothing half-made is left behind: the wrappers made so far and every communicator go back
+            for (int j = 0; j < i; j++) {
+                delete out[j];
+                out[j] = nullptr;
+            }
+            for (int j = 0; j < n; j++) (void)R->CommDestroy(comms[(size_t)j]);
+            return fail(GORSE_ERR_NOMEM, "out of host memory");
+        }
         c->comm = comms[(size_t)i], c->world = n, c->rank = i, c->device = devices[i];
         out[i] = c;
     }
@@ -193,7 +208,10 @@ extern "C" int32_t gorse_mf_item_allreduce(gorse_mf *const *hs, gorse_comm *cons
     GORSE_RCCL_CHECK(R, R->GroupStart());
     for (int i = 0; i < n; i++) {
         gorse_mf *h = hs[i];
-        GORSE_HIP_CHECK(hipSetDevice(h->device));
+        if (hipError_t he = hipSetDevice(h->device); he != hipSuccess) {
+            (void)R->GroupEnd();  // the group never stays open on this thread
+            return fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(he));
+        }
         ncclResult_t e = R->AllReduce(cs[i]->xbuf.p, cs[i]->xbuf.p, (size_t)h->I * h->d, ncclFloat32, ncclSum, cs[i]->comm, h->stream);
         if (e != ncclSuccess) {
             (void)R->GroupEnd();
@@ -232,7 +250,10 @@ extern "C" int32_t gorse_mf_rows_allgather(gorse_mf *const *hs, gorse_comm *cons
     GORSE_RCCL_CHECK(R, R->GroupStart());
     for (int i = 0; i < n; i++) {
         gorse_mf *h = hs[i];
-        GORSE_HIP_CHECK(hipSetDevice(h->device));
+        if (hipError_t he = hipSetDevice(h->device); he != hipSuccess) {
+            (void)R->GroupEnd();
+            return fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(he));
+        }
         float *base = side == 0 ? h->P.p : h->Q.p;
         for (int r = 0; r < world; r++) {
             const int64_t lo = row_splits[r], cnt = (row_splits[r + 1] - lo) * h->d;
@@ -266,4 +287,46 @@ extern "C" int32_t gorse_comm_allreduce_f32(gorse_comm *c, float *buf, int64_t n
     GORSE_HIP_CHECK(hipStreamSynchronize(nullptr));
     GORSE_HIP_CHECK(hipMemcpy(buf, tmp.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return GORSE_OK;
+}
+
+// The same for ALL ranks of a single process (gorse_comm_create_local): the one-rank call above blocks until every rank has
+// called it, so a process that owns several ranks must issue them as one group.  bufs[i] = rank i's n floats, summed in place.
+extern "C" int32_t gorse_comm_allreduce_f32_local(gorse_comm *const *cs, int32_t n_comms, float *const *bufs, int64_t n) {
+    if (!cs || !bufs || n_comms < 1 || n < 0) return fail(GORSE_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < n_comms; i++)
+        if (!cs[i] || !bufs[i]) return fail(GORSE_ERR_INVALID, "NULL communicator or buffer at %d", i);
+    if (n == 0) return GORSE_OK;
+    Rccl *R;
+    GORSE_TRY(need_rccl(&R));
+    std::vector<DevBuf<float>> tmp((size_t)n_comms);
+    for (int i = 0; i < n_comms; i++) {
+        GORSE_HIP_CHECK(hipSetDevice(cs[i]->device));
+        GORSE_TRY(tmp[(size_t)i].alloc((size_t)n));
+        GORSE_HIP_CHECK(hipMemcpy(tmp[(size_t)i].p, bufs[i], (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    GORSE_RCCL_CHECK(R, R->GroupStart());
+    for (int i = 0; i < n_comms; i++) {
+        ncclResult_t e = hipSetDevice(cs[i]->device) == hipSuccess
+                             ? R->AllReduce(tmp[(size_t)i].p, tmp[(size_t)i].p, (size_t)n, ncclFloat32, ncclSum, cs[i]->comm, nullptr)
+                             : ncclUnhandledCudaError;
+        if (e != ncclSuccess) {
+            (void)R->GroupEnd();
+            return fail(GORSE_ERR_HIP, "ncclAllReduce: %s", R->GetErrorString(e));
+        }
+    }
+    GORSE_RCCL_CHECK(R, R->GroupEnd());
+    for (int i = 0; i < n_comms; i++) {
+        GORSE_HIP_CHECK(hipSetDevice(cs[i]->device));
+        GORSE_HIP_CHECK(hipStreamSynchronize(nullptr));
+        GORSE_HIP_CHECK(hipMemcpy(bufs[i], tmp[(size_t)i].p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    return GORSE_OK;
+}
+
+// can this process open RCCL at all?  Every rank asks BEFORE the ranks meet inside gorse_comm_create (a collective
+// initialisation: a rank that cannot load the library would leave the others waiting there) and the answers are agreed on by
+// whatever carried the unique id.
+extern "C" int32_t gorse_comm_available(void) {
+    Rccl *R;
+    return need_rccl(&R);
 }

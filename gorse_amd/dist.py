@@ -143,9 +143,16 @@ class LibComm:
     id, `share(bytes) -> bytes` ships it to every rank (bench.py: a torch.distributed broadcast).  `always` runs the
     collectives at world 1 too (what the one-GPU box can test of this path)."""
 
-    def __init__(self, rank, world, device, share, always=False):
+    def __init__(self, rank, world, device, share, always=False, agree=None):
+        """agree(ok: bool) -> bool: true iff every rank passed true (bench.py: an all-reduce MIN).  gorse_comm_create is a
+        collective initialisation, so a rank that cannot open RCCL must say so BEFORE the others enter it."""
         from . import capi
         self.capi = capi
+        why = capi.comm_available()
+        if agree is not None and not agree(why is None):
+            raise RuntimeError("RCCL is unavailable on some rank" + (": " + why if why else ""))
+        if agree is None and why is not None:
+            raise RuntimeError("RCCL unavailable: " + why)
         # Every rank reaches share() whatever happens on rank 0 (an id of zeros = "rank 0 has none"): a rank that raised before
         # the exchange would leave the others waiting in it
         none, err = bytes(capi.COMM_ID_BYTES), None

@@ -188,7 +188,8 @@ int32_t gorse_mf_item_delta_import(gorse_mf *h, const float *src /*device*/);
  *                             gorse_mf_item_sync_mark once before the first epoch)
  *   gorse_mf_rows_allgather : after gorse_als_half_epoch(side): rank r's rows [row_splits[r], row_splits[r+1]) of P (side 0)
  *                             or Q (side 1) reach every replica (one broadcast per owner, grouped; (U or I)*d fp32)
- *   gorse_comm_allreduce_f32: n host floats summed over the ranks in place (metric partial sums of a sharded Evaluate) */
+ *   gorse_comm_allreduce_f32: n host floats summed over the ranks in place (metric partial sums of a sharded Evaluate);
+ *                             one process per GPU only -- a process holding several ranks uses gorse_comm_allreduce_f32_local */
 typedef struct gorse_comm gorse_comm;
 #define GORSE_COMM_ID_BYTES 128
 int32_t gorse_comm_unique_id(uint8_t *id /*host, GORSE_COMM_ID_BYTES*/);
@@ -200,6 +201,12 @@ int32_t gorse_mf_item_allreduce(gorse_mf *const *handles, gorse_comm *const *com
 int32_t gorse_mf_rows_allgather(gorse_mf *const *handles, gorse_comm *const *comms, int32_t n, int32_t side,
                                 const int64_t *row_splits /*host, world + 1*/);
 int32_t gorse_comm_allreduce_f32(gorse_comm *c, float *buf /*host, in place*/, int64_t n);
+/* gorse_comm_allreduce_f32 blocks until EVERY rank has called it: a process that owns several ranks
+ * (gorse_comm_create_local) calls this instead, once, with all of them: bufs[i] = rank i's n floats. */
+int32_t gorse_comm_allreduce_f32_local(gorse_comm *const *comms, int32_t n_comms, float *const *bufs /*host, in place*/, int64_t n);
+/* GORSE_OK when RCCL can be opened in this process.  gorse_comm_create is a collective initialisation: every rank checks
+ * this first and the ranks agree on the answers (over whatever carried the unique id) before any of them enters it. */
+int32_t gorse_comm_available(void);
 /* Raw device addresses of the resident factor matrices (row-major U*d, I*d). */
 int32_t gorse_mf_device_ptrs(gorse_mf *h, float **P /*out: device*/, float **Q /*out: device*/);
 

@@ -56,6 +56,9 @@ def test_rows_allgather_and_host_allreduce_world_1(data):
         capi.rows_allgather([mf], [comm], 0, [0, data.U - 1])
     assert e.value.code == capi.ERR_RANGE
     assert comm.allreduce_f32([1.5, -2.0, 3.25]).tolist() == [1.5, -2.0, 3.25]
+    assert capi.comm_available() is None
+    got = capi.allreduce_f32_local(capi.Comm.local([0]), [np.array([0.5, 4.0], np.float32)])  # the one-process form, a group of one
+    assert got[0].tolist() == [0.5, 4.0]
 
 
 def test_run_epoch_through_the_library_communicator(data):
