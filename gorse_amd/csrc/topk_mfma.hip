@@ -39,6 +39,10 @@ constexpr int kMaxRB = 4;      // a tile holds RB 32-row MFMA blocks (RB = 2 or 
 #define GORSE_SWEEP_WAVES 8
 #endif
 constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the main sweep, two per SIMD (a build-time probe switch)
+#ifndef GORSE_SWEEP_NCB
+#define GORSE_SWEEP_NCB 2
+#endif
+constexpr int kNcbMain = GORSE_SWEEP_NCB;  // 32-query column blocks per wave for operand depths up to 8 (probe switch)
 // the history sweep serves the few queries with ties: small workgroups (2 waves = 64 * NCB queries) spread them over
 // many CUs instead of a handful of 8-wave workgroups; deep operands keep more waves (the tile prefetch registers of a
 // thread grow as the workgroup shrinks)
@@ -118,6 +122,8 @@ struct SweepParams {
     const float *f0;   // nq initial thresholds or null (-inf)
     float *f_out;      // pilot: nq final thresholds; null otherwise
     int tile_stride;   // 1, or the pilot's sampling stride over the row tiles
+    int probe;         // timing probes (results are garbage): 1 = every threshold +inf (no block ever qualifies: the sweep's floor),
+                       // 2 = qualifying blocks scale and scan their rows but append nothing
     int nslices;       // HIST: row slices (grid.y); the per-query outputs are then nslices x nq long, slice-major
     float rs_min, rs_max;  // smallest and largest row value of the index (EP_COARSE bound of the DMA sweeps)
 };
@@ -243,7 +249,7 @@ __device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
 // paths alone, [3] waiting for a tile, [4] row blocks examined, [5] row blocks that took the candidate path, [6] whole kernel,
 // [7] waves, [8] candidate path: set-up + row scaling, [9] appends, [10] compaction check / compaction, [11] candidate paths
 template <int KP, int NCB, int EP, bool HIST, int RB, bool PROF = false>
-__global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kernel(SweepParams p) {
+__global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) + 3) / 4 < 2 ? 2 : (sweep_waves(HIST, KP) + 3) / 4) void topk_sweep_kernel(SweepParams p) {
     constexpr int kWaves = sweep_waves(HIST, KP);
     constexpr int kThreads = kWaves * 64;
     constexpr int kTR = 32 * RB;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
         s_cnt[2 * t] = 0;
         s_cnt[2 * t + 1] = 0;
         s_hc[t] = 0;
-        s_f[t] = q < p.nq ? (p.f0 ? p.f0[q] : -__builtin_inff()) : __builtin_inff();
+        s_f[t] = q < p.nq && p.probe != 1 ? (p.f0 ? p.f0[q] : -__builtin_inff()) : __builtin_inff();
         s_mg[t] = q < p.nq ? p.qmargin[q] : 0.0f;
     }
     if (tid < 2 * NBUF) s_sync[tid] = 0;
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), 2) void topk_sweep_kern
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
                                 const int r = 4 * g + e;
-                                if (acc[cb][r] >= f) {
+                                if (acc[cb][r] >= f && p.probe != 2) {
                                     const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
                                     mine[cb][2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
                                     cnt[cb]++;
@@ -1337,11 +1343,11 @@ int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
 
 template <int RB>
 int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {  // the instrumented twin of the C4-shaped sweep (probe only)
-    constexpr int BQ = 32 * 2 * kWaves;
+    constexpr int BQ = 32 * kNcbMain * kWaves;
     const size_t lds = sweep_lds_bytes(8, RB, BQ, kWaves, false);
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, 2, EP_COARSE, false, RB, true>),
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<8, kNcbMain, EP_COARSE, false, RB, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<8, 2, EP_COARSE, false, RB, true><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
+    topk_sweep_kernel<8, kNcbMain, EP_COARSE, false, RB, true><<<dim3((unsigned)ceil_div(p.nq, BQ)), dim3(kThreads), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -1361,7 +1367,7 @@ int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
     // 128-row tiles (one tile hand-over per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
     // queries keeps the 64-row form
     const bool wide = !hist && KP <= 8 && topk_rows_per_tile() == 128;
-    if constexpr (KP == 8 && NCB == 2) {
+    if constexpr (KP == 8 && NCB == kNcbMain) {
         if ((g_topk_variant & 16) && p.ep == EP_COARSE && !hist && p.prof)
             return wide ? launch_sweep_prof<4>(h, p) : launch_sweep_prof<2>(h, p);
     }
@@ -1373,12 +1379,12 @@ int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
 
 int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
     switch (h->kp) {
-        case 1: return launch_sweep<1, 2>(h, p, hist);
-        case 2: return launch_sweep<2, 2>(h, p, hist);
-        case 3: return launch_sweep<3, 2>(h, p, hist);
-        case 4: return launch_sweep<4, 2>(h, p, hist);
-        case 6: return launch_sweep<6, 2>(h, p, hist);
-        case 8: return launch_sweep<8, 2>(h, p, hist);
+        case 1: return launch_sweep<1, kNcbMain>(h, p, hist);
+        case 2: return launch_sweep<2, kNcbMain>(h, p, hist);
+        case 3: return launch_sweep<3, kNcbMain>(h, p, hist);
+        case 4: return launch_sweep<4, kNcbMain>(h, p, hist);
+        case 6: return launch_sweep<6, kNcbMain>(h, p, hist);
+        case 8: return launch_sweep<8, kNcbMain>(h, p, hist);
         case 12: return launch_sweep<12, 1>(h, p, hist);  // 2 column blocks would spill
         case 16: return launch_sweep<16, 1>(h, p, hist);
         case 24: return launch_sweep<24, 1>(h, p, hist);
@@ -1571,6 +1577,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.kth = kth;
         sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1;
         sp.nslices = 1;
+        sp.probe = (g_topk_variant >> 17) & 3;  // variant bits 17 / 18: timing probes of the main sweep (the call then returns garbage)
         // bounds of the per-row value for the DMA sweeps' block test: the cosine scales; without them (a masked -dot index:
         // the value is 1 or NaN) the bound is the score itself
         sp.rs_min = h->metric == GORSE_METRIC_COSINE ? h->rs_min : 1.0f;
@@ -1615,6 +1622,11 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             sp.f0 = h->f0.p;
         }
         GORSE_TRY(dispatch_sweep(h, sp, false));
+        if (sp.probe) {  // timing probe: nothing behind the sweep is meaningful
+            h->prof.end(tok, h->stream);
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+            continue;
+        }
         // The queries whose warm start failed its verification carry flag 2: topk_rescore_kernel leaves flagged queries alone
         // and stage 2 below (history sweep from -inf + literal replay) answers them together with the tie queries -- a sweep
         // of their own would cost one workgroup a full pass over the rows (48 ms for 86 queries, profiles/r02_h_*).

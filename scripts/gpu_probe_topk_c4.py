@@ -30,7 +30,7 @@ def run(t, k, q0, q1, label, reps=2):
 
 
 def main():
-    nq = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    nq = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1_000_000
     N, d, k = 1_000_000, 128, 100
     Xb, Xe = synth.s_emb(N, d, 44)
     t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
@@ -44,6 +44,16 @@ def main():
         ei, ed = o.search_index(Xe, orc.METRIC_COSINE, 500_000 + r, k)
         assert np.array_equal(idx[r], ei) and np.array_equal(dist[r].view(np.uint32), ed.view(np.uint32)), r
     print("16 rows equal the oracle's", flush=True)
+    if "quick" in sys.argv[1:]:
+        return
+    if "floor" in sys.argv[1:]:  # what the sweep costs without its candidate path (results are garbage: timing only)
+        for v, label in ((256, "cold sweep alone"), (256 | (1 << 17), "cold sweep, no block ever qualifies"),
+                         (256 | (1 << 18), "cold sweep, qualifying blocks append nothing"),
+                         (1 << 17, "pilots + main, no block qualifies"), (1 << 18, "pilots + main, nothing appended")):
+            L.gorse_hip_test_set_topk_variant(v)
+            run(t, k, 0, nq, label, reps=1)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
     for v, label in ((1 << 15, "history sweep in one slice"), (1 << 16, "replay: literal T"), ((1 << 15) | (1 << 16), "one slice + literal T (round 2)"),
                      (256, "no warm start"), (4, "no block-level scale bound")):
         L.gorse_hip_test_set_topk_variant(v)
