@@ -383,7 +383,7 @@ class TopK:
         return n.value, ms.value
 
     def sweep_profile(self):
-        out = (C.c_uint64 * 12)()
+        out = (C.c_uint64 * 16)()
         check(lib().gorse_hip_test_get_sweep_profile(self.h, out))
         return [int(x) for x in out]
 

@@ -588,11 +588,11 @@ extern "C" int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n) {
 extern "C" void gorse_hip_test_set_topk_path(int32_t path) { gorse::g_topk_force_path = path; }
 extern "C" void gorse_hip_test_set_topk_variant(int32_t v) { gorse::g_topk_variant = v; }
 // probe: the 8 phase counters of the last instrumented sweep (variant bit 4) of this handle
-extern "C" int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12) {
-    if (!h || !out12) return fail(GORSE_ERR_INVALID, "NULL argument");
-    if (h->sweep_prof.n < 12) return fail(GORSE_ERR_INVALID, "no instrumented sweep has run on this handle");
+extern "C" int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out16) {
+    if (!h || !out16) return fail(GORSE_ERR_INVALID, "NULL argument");
+    if (h->sweep_prof.n < 16) return fail(GORSE_ERR_INVALID, "no instrumented sweep has run on this handle");
     GORSE_TRY(h->use());
-    GORSE_HIP_CHECK(hipMemcpyAsync(out12, h->sweep_prof.p, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(out16, h->sweep_prof.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     return GORSE_OK;
 }

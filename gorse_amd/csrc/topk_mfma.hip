@@ -42,6 +42,15 @@ constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the mai
 #ifndef GORSE_SWEEP_NCB
 #define GORSE_SWEEP_NCB 2
 #endif
+#ifndef GORSE_SWEEP_ORDER
+#define GORSE_SWEEP_ORDER 0
+#endif
+#ifndef GORSE_SWEEP_PIPE
+#define GORSE_SWEEP_PIPE 1
+#endif
+#ifndef GORSE_SWEEP_HALVES
+#define GORSE_SWEEP_HALVES 1
+#endif
 constexpr int kNcbMain = GORSE_SWEEP_NCB;  // 32-query column blocks per wave for operand depths up to 8 (probe switch)
 // the history sweep serves the few queries with ties: small workgroups (2 waves = 64 * NCB queries) spread them over
 // many CUs instead of a handful of 8-wave workgroups; deep operands keep more waves (the tile prefetch registers of a
@@ -115,15 +124,15 @@ struct SweepParams {
     int kth;
     int compact_at;        // a sub-list longer than this triggers the compaction of its query (<= kCompactAt / 2)
     int ep;                // EP_SCALE / EP_BIAS / EP_COARSE: what the epilogue does with the per-row values (host side: picks the kernel)
-    unsigned long long *prof;  // PROF instantiations: 8 cycle / event counters summed over all waves
+    unsigned long long *prof;  // PROF instantiations: 16 cycle / event counters summed over all waves
     // warm start (see topk_mfma_search): a PILOT sweep walks every tile_stride-th tile with kth = a small j and writes the
     // threshold it ends with to f_out; the main sweep starts from f0 and verifies it (compact_query: a threshold that a later
     // K-th-best bound does not reach flags the query 2 = "sweep again from -inf")
     const float *f0;   // nq initial thresholds or null (-inf)
     float *f_out;      // pilot: nq final thresholds; null otherwise
     int tile_stride;   // 1, or the pilot's sampling stride over the row tiles
-    int probe;         // timing probes (results are garbage): 1 = every threshold +inf (no block ever qualifies: the sweep's floor),
-                       // 2 = qualifying blocks scale and scan their rows but append nothing
+    int probe;         // timing probes of the MAIN sweep (results are garbage): 1 = every threshold +inf (no block ever qualifies: the
+                       // sweep's floor), 2 = a qualifying block does nothing, 3 = it tests and counts its candidates without storing them
     int nslices;       // HIST: row slices (grid.y); the per-query outputs are then nslices x nq long, slice-major
     float rs_min, rs_max;  // smallest and largest row value of the index (EP_COARSE bound of the DMA sweeps)
 };
@@ -255,10 +264,12 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     constexpr int kTR = 32 * RB;
     constexpr bool SCALE = EP != EP_NONE;  // a per-row value travels with the tile
     unsigned long long c_store = 0, c_comp = 0, c_slow = 0, c_bar = 0, n_blk = 0, n_slow = 0, t_begin = 0, ts = 0;
+    unsigned long long c_free = 0, c_issue = 0, c_land = 0, c_post = 0;  // the tile top: buffer wait, DMA issue, landing wait, announcement
     unsigned long long c_s1 = 0, c_s2 = 0, c_s3 = 0, n_hits = 0;
     if (PROF) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int KPAD = KP * 16;
     constexpr bool DMA = sweep_dma(KP, HIST, RB, kWaves);
+    constexpr bool PIPE = GORSE_SWEEP_PIPE && KP <= 8 && !HIST;  // row blocks software-pipelined: see the row-block loop
     static_assert(!DMA || SCALE, "the DMA sweeps mask the rows past N through the row values (NaN padding)");
     // register staging: +16 B per row, consecutive rows start 4 banks apart, ds_read_b128 conflict-free; DMA: unpadded rows,
     // the pieces of a row swizzled instead (see piece_swizzle)
@@ -370,12 +381,20 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         else if constexpr (PPR == 4) return (row >> 2) & 3;
         else return (row >> 3) & 1;
     };
-    // A wave-instruction moves 64 pieces: DMA instruction j of wave w covers pieces [(w * DPW + j) * 64, +64) of the tile;
-    // the row values (one dword per row) follow as instructions of 64 rows each, issued by the first kTR / 64 waves.
-    constexpr int DPW = DMA ? CHUNKS / 64 / kWaves : 0;  // tile instructions per wave
-    static_assert(!DMA || (CHUNKS % (64 * kWaves) == 0 && kTR % 64 == 0), "DMA tiling");
-    constexpr int RSW = DMA ? kTR / 64 : 0;              // waves that also move a row-value instruction
+    // A wave-instruction moves 64 pieces.  The two waves that share a SIMD (w and w + kWaves / 2: a workgroup's waves go round
+    // the four SIMDs) take turns: the lower half of the waves moves the even tiles, the upper half the odd ones, so that
+    // while one of the two spends its ~150 cycles per DMA instruction the other has the MFMA pipe to itself -- issued by all
+    // eight at the top of every tile, both waves of every SIMD stood in that phase together (17 % of the sweep,
+    // profiles/r03_l_probe_c4_prof.txt).  DMA instruction j of issuing wave wi covers pieces [(wi * DPW + j) * 64, +64) of
+    // the tile; the row values (one dword per row) follow as instructions of 64 rows each, issued by the first kTR / 64 of them.
+    constexpr int ISS = !DMA ? 1 : (GORSE_SWEEP_HALVES && kWaves >= 4 ? kWaves / 2 : kWaves);  // waves that move one tile
+    constexpr bool HALVES = DMA && ISS < kWaves;
+    constexpr int DPW = DMA ? CHUNKS / 64 / ISS : 0;  // tile instructions per issuing wave
+    static_assert(!DMA || (CHUNKS % (64 * ISS) == 0 && kTR % 64 == 0 && kTR / 64 <= ISS), "DMA tiling");
+    constexpr int RSW = DMA ? kTR / 64 : 0;              // issuing waves that also move a row-value instruction
     const int wu = __builtin_amdgcn_readfirstlane(w);    // provably wave-uniform (LDS destinations, branch conditions)
+    const int wi = wu % ISS, grp = wu / ISS;             // place among the waves that move a tile; which tiles (parity)
+    constexpr int ISS_OR_ALL = DMA ? ISS : kWaves;       // announcements that complete a tile
     // The DMA is issued from inline assembly: the builtin makes hipcc treat every later LDS access of the kernel (the tile
     // counters, the fragment reads) as dependent on it and put s_waitcnt vmcnt(0) in front -- which drains the very tiles
     // that are meant to stay in flight.  An asm statement is invisible to that bookkeeping (cdna_hip_programming.md 5.7);
@@ -389,7 +408,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     if constexpr (DMA) {
 #pragma unroll
         for (int j = 0; j < DPW; j++) {
-            const int piece = (wu * DPW + j) * 64 + lane;
+            const int piece = (wi * DPW + j) * 64 + lane;
             const int row = piece / PPR, cs = piece % PPR;  // LDS position; its content is source piece cs ^ swizzle
             dsrc[j] = (unsigned)(row * (KPAD * 2) + ((cs ^ piece_swizzle(row)) << 4));
         }
@@ -401,13 +420,13 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             const unsigned char *tile0 = reinterpret_cast<const unsigned char *>(p.A) + base_row * (KPAD * 2);
 #pragma unroll
             for (int j = 0; j < DPW; j++) {
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_tiles + (unsigned)buf * (kTR * ROWB) + (unsigned)(wu * DPW + j) * 1024u);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_tiles + (unsigned)buf * (kTR * ROWB) + (unsigned)(wi * DPW + j) * 1024u);
                 unsigned keep;
                 if (inside) {
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(dsrc[j]), "s"(tile0), "s"(dst) : "memory");
                 } else {
-                    const int piece = (wu * DPW + j) * 64 + lane;
+                    const int piece = (wi * DPW + j) * 64 + lane;
                     const int row = piece / PPR, cs = piece % PPR;
                     int64_t grow = base_row + row;
                     if (grow >= p.N) grow = p.N - 1;
@@ -416,9 +435,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
                 }
             }
-            if (wu < RSW) {  // the row values are padded with NaN past N (topk_mfma_prepare): no clamp
-                const float *src = p.rscale + base_row + wu * 64 + lane;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_rs + (unsigned)(buf * kTR + wu * 64) * 4u);
+            if (wi < RSW) {  // the row values are padded with NaN past N (topk_mfma_prepare): no clamp
+                const float *src = p.rscale + base_row + wi * 64 + lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_rs + (unsigned)(buf * kTR + wi * 64) * 4u);
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -432,7 +451,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         if constexpr (DMA) {
             if (keep == 0)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (wu < RSW)
+            else if (wi < RSW)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
@@ -467,7 +486,14 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     __syncthreads();  // the per-query words and the counters are initialised
-    if constexpr (DMA) {
+    if constexpr (HALVES) {
+        if (grp == 0 && NT > 0) {
+            dma_tile(0, 0);
+            dma_wait(0);
+            post(&s_sync[0]);
+        }
+        if (grp == 1 && NT > 1) dma_tile(1, 1);  // announced at the top of tile 0
+    } else if constexpr (DMA) {
         if (NT > 0) dma_tile(0, 0);
         if (NT > 1) dma_tile(1, 1);
         if (NT > 0) {
@@ -483,13 +509,22 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         if (NT > 1) load_tile(1);
     }
 
-    float fth[NCB];
+    // RAWF (EP_COARSE with the index-wide bounds of the row values): the block and quad tests compare RAW maxima with the
+    // threshold divided by the extreme row value, rounded down -- fl(raw * s) >= f with s <= rs_max (f > 0), or s >= rs_min and
+    // raw < 0 (f <= 0), implies raw >= fraw -- so that rows are scaled only inside a quad that holds a candidate
+    constexpr bool RAWF = EP == EP_COARSE && DMA;
+    auto raw_threshold = [&](float f) -> float {
+        const float q = f / (f > 0.0f ? p.rs_max : p.rs_min);
+        return fabsf(q) == __builtin_inff() ? q : q - fabsf(q) * 2.4e-7f;
+    };
+    float fth[NCB], fraw[RAWF ? NCB : 1];
     int cnt[NCB];      // length of this lane's sub-list of its query (mirrored in s_cnt around a compaction)
     uint2 *mine[NCB];  // the lane's sub-list: slots 2 * c + (lane >> 5) of its query's list (see compact_query)
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
         const int ql = w * QW + cb * 32 + (lane & 31);
         fth[cb] = s_f[ql];
+        if (RAWF) fraw[RAWF ? cb : 0] = raw_threshold(fth[cb]);
         cnt[cb] = 0;
         mine[cb] = p.cbuf + (qslice + wgq0 + ql) * kCap + (lane >> 5);
     }
@@ -501,11 +536,52 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         for (int ks = 0; ks < KP; ks++) aoff[ks] = (unsigned)(r * ROWB + (((ks * 2 + (lane >> 5)) ^ piece_swizzle(r)) << 4));
     }
 
+    // the fragments of the row block about to be multiplied (PIPE), read from block-0-relative address `blk` of a tile
+    bf16x8 af[PIPE ? KP : 1];
+    auto frag = [&](const unsigned char *blk, int ks) -> bf16x8 {
+        return DMA ? *reinterpret_cast<const bf16x8 *>(blk + aoff[DMA ? ks : 0])
+                   : *reinterpret_cast<const bf16x8 *>(blk + (lane & 31) * ROWB + (lane >> 5) * 16 + ks * 32);
+    };
     int buf = 0, round = 0;  // tile t lives in buffer t % NBUF and is that buffer's (t / NBUF)-th tile
     for (int64_t t = 0; t < NT; t++) {
         if (PROF) ts = __builtin_amdgcn_s_memtime();
         const int nb = buf + 1 == NBUF ? 0 : buf + 1;
-        if constexpr (DMA) {
+        if constexpr (HALVES) {
+            // This wave's half moves the tiles of its parity: at such a tile's top it issues tile t + 2 (into the buffer tile
+            // t + 2 - NBUF was read from); at the other tiles' tops it waits for what it issued a tile ago -- everything it has
+            // in flight: the appends of the last row blocks ride along, a few hundred cycles now and then -- and announces
+            // tile t + 1, three row blocks ahead of its first use.
+            const int b2 = nb + 1 == NBUF ? 0 : nb + 1;
+            if ((int)(t & 1) == grp) {
+                if (t + 2 < NT) {
+                    if (t + 2 >= NBUF) {
+                        unsigned long long tw = 0;
+                        if (PROF) tw = __builtin_amdgcn_s_memtime();
+                        wait_for(&s_sync[NBUF + b2], kWaves * (int)((t + 2) / NBUF));
+                        if (PROF) {
+                            const unsigned long long now = __builtin_amdgcn_s_memtime();
+                            c_bar += now - tw;
+                            c_free += now - tw;
+                        }
+                    }
+                    unsigned long long ti = 0;
+                    if (PROF) ti = __builtin_amdgcn_s_memtime();
+                    dma_tile(t + 2, b2);
+                    if (PROF) c_issue += __builtin_amdgcn_s_memtime() - ti;
+                }
+            } else if (t + 1 < NT) {
+                unsigned long long ti = 0;
+                if (PROF) ti = __builtin_amdgcn_s_memtime();
+                dma_wait(0);
+                if (PROF) {
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    c_land += now - ti;
+                    ti = now;
+                }
+                post(&s_sync[nb]);
+                if (PROF) c_post += __builtin_amdgcn_s_memtime() - ti;
+            }
+        } else if constexpr (DMA) {
             // tile t + 2 goes into the buffer tile t + 2 - NBUF was read from; tile t + 1 (issued a tile ago) has landed by now
             // and is announced here, one tile ahead of its use, so that a wave may run a tile ahead of the slowest one
             const int b2 = nb + 1 == NBUF ? 0 : nb + 1;
@@ -514,13 +590,28 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                     unsigned long long tw = 0;
                     if (PROF) tw = __builtin_amdgcn_s_memtime();
                     wait_for(&s_sync[NBUF + b2], kWaves * (int)((t + 2) / NBUF));
-                    if (PROF) c_bar += __builtin_amdgcn_s_memtime() - tw;
+                    if (PROF) {
+                        const unsigned long long now = __builtin_amdgcn_s_memtime();
+                        c_bar += now - tw;
+                        c_free += now - tw;
+                    }
                 }
+                unsigned long long ti = 0;
+                if (PROF) ti = __builtin_amdgcn_s_memtime();
                 dma_tile(t + 2, b2);
+                if (PROF) c_issue += __builtin_amdgcn_s_memtime() - ti;
             }
             if (t + 1 < NT) {
+                unsigned long long ti = 0;
+                if (PROF) ti = __builtin_amdgcn_s_memtime();
                 dma_wait(t + 2 < NT ? 1 : 0);
+                if (PROF) {
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    c_land += now - ti;
+                    ti = now;
+                }
                 post(&s_sync[nb]);
+                if (PROF) c_post += __builtin_amdgcn_s_memtime() - ti;
             }
         } else {
             if (t + 1 < NT) {  // rows of tile t + 1 (loaded during tile t - 1) into the buffer tile t + 1 - NBUF was read from
@@ -540,13 +631,18 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             c_store += now - ts;
             ts = now;
         }
-        wait_for(&s_sync[buf], kWaves * (round + 1));
+        // PIPE: tile t has been waited for inside the last row block of tile t - 1 (its first fragments are in registers)
+        if (!PIPE || t == 0) wait_for(&s_sync[buf], ISS_OR_ALL * (round + 1));
         if (PROF) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             c_bar += now - ts;
             ts = now;
         }
         const unsigned char *tb = s_tile + (size_t)buf * kTR * ROWB;
+        if (PIPE && t == 0) {
+#pragma unroll
+            for (int ks = 0; ks < KP; ks++) af[PIPE ? ks : 0] = frag(tb, ks);
+        }
         const int64_t base_row = (T0 + t) * stride_rows;
         // register staging zero-fills the rows past N; their scores are set to NaN below.  The DMA sweeps need nothing: the
         // row values of those rows are NaN
@@ -559,6 +655,46 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[cb][r] = 0.0f;
+            if constexpr (PIPE) {
+                // Software pipeline over row blocks (and across tiles): the fragments of block rb are in registers when its
+                // MFMAs start; each register quad is refilled with the NEXT block's fragment as soon as the last MFMA reading it
+                // is issued, so the LDS round trip runs under the rest of the chain and the epilogue instead of ahead of the
+                // first MFMA.  The next block of the last row block is block 0 of tile t + 1, announced a tile ago.
+                const unsigned char *nx = tb + (rb + 1) * 32 * ROWB;
+                if (rb + 1 == RB) {
+                    nx = tb;  // last tile: a re-read nobody uses
+                    if (t + 1 < NT) {
+                        unsigned long long tw = 0;
+                        if (PROF) tw = __builtin_amdgcn_s_memtime();
+                        wait_for(&s_sync[nb], ISS_OR_ALL * (round + (nb == 0 ? 1 : 0) + 1));
+                        if (PROF) c_bar += __builtin_amdgcn_s_memtime() - tw;
+                        nx = s_tile + (size_t)nb * kTR * ROWB;
+                    }
+                }
+#if GORSE_SWEEP_ORDER == 1
+#pragma unroll
+                for (int cb = 0; cb + 1 < NCB; cb++)
+#pragma unroll
+                    for (int ks = 0; ks < KP; ks++)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfrag[cb][ks], acc[cb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KP; ks++) {
+                    acc[NCB - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfrag[NCB - 1][ks], acc[NCB - 1], 0, 0, 0);
+                    af[ks] = frag(nx, ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
+#pragma unroll
+                for (int ks = 0; ks < KP; ks++) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], bfrag[cb][ks], acc[cb], 0, 0, 0);
+                    af[ks] = frag(nx, ks);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
+            } else {
             const unsigned char *rowp = tb + (rb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
             const unsigned char *blkp = tb + rb * 32 * ROWB;  // DMA: + aoff[ks]
             // candidate fragments: up to 8 k-steps of ds_read_b128 in flight ahead of the MFMAs that use them
@@ -579,6 +715,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                         for (int cb = 0; cb < NCB; cb++)
                             acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bfrag[cb][k0 + j], acc[cb], 0, 0, 0);
                     }
+            }
             }
             // C layout: lane holds column (= query) lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5).
             // The epilogue shares the SIMD's issue slots with the sibling wave's MFMAs (about five ordinary instructions fit
@@ -618,45 +755,60 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
 #pragma unroll
                 for (int g = 0; g < 4; g++) gm[g] = max2f(max3f(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2]), acc[cb][4 * g + 3]);
                 float m = max2f(max3f(gm[0], gm[1], gm[2]), gm[3]);
-                if (EP == EP_COARSE) {  // an upper bound of every scaled score of the block: the row values are positive
-                    // DMA: the extreme values of ALL rows (offered only when they lie within 2 % of each other)
-                    const float mn = DMA ? p.rs_min : s_bmm[(buf * kMaxRB + rb) * 2 + 0];
-                    const float mx = DMA ? p.rs_max : s_bmm[(buf * kMaxRB + rb) * 2 + 1];
+                if (EP == EP_COARSE && !RAWF) {  // an upper bound of every scaled score of the block: the row values are positive
+                    const float mn = s_bmm[(buf * kMaxRB + rb) * 2 + 0];
+                    const float mx = s_bmm[(buf * kMaxRB + rb) * 2 + 1];
                     m = m * (m >= 0.0f ? mx : mn);
                 }
                 if (PROF) n_blk++;
-                if (__builtin_amdgcn_ballot_w64(m >= fth[cb]) != 0) {
+                if (__builtin_amdgcn_ballot_w64(m >= (RAWF ? fraw[RAWF ? cb : 0] : fth[cb])) != 0) {
                     unsigned long long tsl = 0;
                     if (PROF) {
                         tsl = __builtin_amdgcn_s_memtime();
                         n_slow++;
                     }
                     __builtin_amdgcn_s_setprio(3);  // the wave on this path is the one its workgroup waits for
-                    if (EP == EP_COARSE) {
+                    if (EP == EP_COARSE && !RAWF) {
                         scale_rows();
 #pragma unroll
                         for (int g = 0; g < 4; g++) gm[g] = max2f(max3f(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2]), acc[cb][4 * g + 3]);
                     }
+                    float4 rs4[RAWF ? 4 : 1];  // RAWF: the row values of the four quads, in flight while the quads are tested
+                    if (RAWF) {
+                        const float4 *r4 = reinterpret_cast<const float4 *>(s_rs + buf * kTR + rb * 32);
+#pragma unroll
+                        for (int g = 0; g < 4; g++) rs4[RAWF ? g : 0] = r4[2 * g + (lane >> 5)];
+                    }
                     const float f = fth[cb];
+                    const float fq = RAWF ? fraw[RAWF ? cb : 0] : f;  // what a quad's maximum is compared with
                     // Every lane appends to ITS OWN sub-list of the query (even / odd slots, see compact_query), so no slot
                     // exchange between the two lanes of a query and no counting pass are needed.  f is +inf for lanes past nq
                     // and for flagged queries; rows past N are NaN.  A block that comes here holds one or two candidates among
                     // its 1024 scores: a quad is opened only if its maximum qualifies (a NaN maximum never does: the hardware
                     // maximum skips NaN operands, and a quad of four NaNs holds no candidate).
                     unsigned long long tq = 0;
+                    int cnt_was = 0;
                     if (PROF) {
                         tq = __builtin_amdgcn_s_memtime();
                         c_s1 += tq - tsl;
+                        cnt_was = cnt[cb];
                     }
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
-                        if (gm[g] >= f) {
+                        if (gm[g] >= fq && p.probe != 2) {
+                            if (RAWF) {
+                                const float4 sc = rs4[RAWF ? g : 0];
+                                acc[cb][4 * g + 0] *= sc.x;
+                                acc[cb][4 * g + 1] *= sc.y;
+                                acc[cb][4 * g + 2] *= sc.z;
+                                acc[cb][4 * g + 3] *= sc.w;
+                            }
 #pragma unroll
                             for (int e = 0; e < 4; e++) {
                                 const int r = 4 * g + e;
-                                if (acc[cb][r] >= f && p.probe != 2) {
+                                if (acc[cb][r] >= f) {
                                     const uint32_t row = (uint32_t)(base_row + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                                    mine[cb][2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
+                                    if (p.probe != 3) mine[cb][2 * cnt[cb]] = make_uint2(fkey(acc[cb][r]), row);
                                     cnt[cb]++;
                                 }
                             }
@@ -666,7 +818,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                         const unsigned long long now = __builtin_amdgcn_s_memtime();
                         c_s2 += now - tq;
                         tq = now;
-                        n_hits++;
+                        n_hits += __builtin_amdgcn_ballot_w64(cnt[cb] != cnt_was) != 0;  // blocks that did append something
                     }
                     uint64_t need = __builtin_amdgcn_ballot_w64(cnt[cb] > p.compact_at);
                     if (need) {
@@ -683,6 +835,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                         } while (need);
                         cnt[cb] = s_cnt[2 * ql + (lane >> 5)];
                         fth[cb] = s_f[ql];
+                        if (RAWF) fraw[RAWF ? cb : 0] = raw_threshold(fth[cb]);
                     }
                     __builtin_amdgcn_s_setprio(0);
                     if (PROF) {
@@ -715,6 +868,10 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         atomicAdd(p.prof + 9, c_s2);
         atomicAdd(p.prof + 10, c_s3);
         atomicAdd(p.prof + 11, n_hits);
+        atomicAdd(p.prof + 12, c_free);
+        atomicAdd(p.prof + 13, c_issue);
+        atomicAdd(p.prof + 14, c_land);
+        atomicAdd(p.prof + 15, c_post);
     }
     // final threshold + compaction of every list this wave owns
 #pragma unroll
@@ -742,6 +899,8 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
 // ---- exact rescoring + ranking of one query's candidate list ------------------------------------------
 struct RescoreParams {
     const float *X;        // N x d fp32 stored vectors
+    const uint16_t *Xb;    // the same vectors as given in bf16 (a bf16 index), or null: the rows are gathered from here -- half
+                           // the bytes, the same fp32 values once widened
     const float *norm2;    // N
     const float *Qf;       // nq x d fp32 query vectors, or null (queries are stored vectors)
     const float *qn2;      // nq query norms (cosine)
@@ -781,7 +940,21 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     for (int c = gib; c < n; c += kGroupsPerBlock) {
         const int64_t i = cb[c].y;
         float *row = sx + (size_t)gib * d;
-        for (int e = lane; e < d; e += kGroup) row[e] = p.X[i * d + e];
+        if (p.Xb && (d & 7) == 0) {  // 16-byte pieces of the bf16 row, widened into the LDS row
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.Xb + i * d);
+            for (int e = lane; e < d / 8; e += kGroup) {
+                const uint4 v = src[e];
+                float4 *dst = reinterpret_cast<float4 *>(row + 8 * e);
+                dst[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                                     __uint_as_float(v.y & 0xffff0000u));
+                dst[1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
+                                     __uint_as_float(v.w & 0xffff0000u));
+            }
+        } else if (p.Xb) {
+            for (int e = lane; e < d; e += kGroup) row[e] = __uint_as_float((uint32_t)p.Xb[i * d + e] << 16);
+        } else {
+            for (int e = lane; e < d; e += kGroup) row[e] = p.X[i * d + e];
+        }
         __builtin_amdgcn_wave_barrier();
         float r;
         if (p.metric == GORSE_METRIC_EUCLIDEAN || p.metric == kMetricEuclidBf16) {
@@ -800,51 +973,90 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
         }
     }
     __syncthreads();
-    // rank every candidate among the admissible ones; flag ties that reach the top k+1
-    bool bad = false;
-    int my_rank[kCap / kBlock];
+    // Order the admissible candidates by exact distance: a bitonic sort of (order-preserving key of the distance, index) in
+    // LDS -- n = ~240 at C4, where ranking every candidate against every other one was two thirds of this kernel's time.
+    // Equal distances are adjacent afterwards; one inside the top k + 1 hands the query to the tie path, so the order
+    // among equals never shows.  The query itself, a NaN distance and the padding up to the power of two sort last.
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(s_e);
+    int P = 2;
+    while (P < n) P <<= 1;
+    {
+        uint32_t kreg[kCap / kBlock];
+        int ireg[kCap / kBlock];
 #pragma unroll
-    for (int s = 0; s < kCap / kBlock; s++) {
-        const int c = tid + s * kBlock;
-        my_rank[s] = -1;
-        if (c >= n || s_i[c] == self) continue;
-        const float e = s_e[c];
-        if (e != e) {
-            bad = true;
-            continue;
+        for (int s = 0; s < kCap / kBlock; s++) {
+            const int c = tid + s * kBlock;
+            kreg[s] = 0xffffffffu;
+            ireg[s] = -1;
+            if (c < n && s_i[c] != self) {
+                const float e = s_e[c];
+                if (e != e) {
+                    s_misc[1] = 1;
+                } else {
+                    const uint32_t u = __float_as_uint(e);
+                    kreg[s] = e == 0.0f ? 0x80000000u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+                    ireg[s] = s_i[c] | (u == 0x80000000u ? (int)0x80000000 : 0);  // bit 31: the distance is -0
+                }
+            }
         }
-        int rank = 0;
-        bool tie = false;
-        for (int c2 = 0; c2 < n; c2++) {
-            if (c2 == c || s_i[c2] == self) continue;
-            const float e2 = s_e[c2];
-            rank += (e2 < e) || (e2 == e && c2 < c);
-            tie |= (e2 == e);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < kCap / kBlock; s++) {
+            const int c = tid + s * kBlock;
+            if (c < P) {
+                s_key[c] = kreg[s];
+                s_i[c] = ireg[s];
+            }
         }
-        if (tie && rank <= k) bad = true;
-        my_rank[s] = rank;
-        if (rank < k && p.prune0 && !(e > 0)) atomicAdd(&s_misc[0], 1);
     }
-    if (bad) s_misc[1] = 1;
     __syncthreads();
-    int admissible = n;
-    for (int c2 = 0; c2 < n; c2++)
-        if (s_i[c2] == self) admissible--;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int x = tid; x < P / 2; x += kBlock) {
+                const int lo = 2 * x - (x & (stride - 1));  // the x-th pair of this step: (lo, lo + stride)
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = s_key[lo], b = s_key[hi];
+                if ((a > b) == up) {
+                    s_key[lo] = b;
+                    s_key[hi] = a;
+                    const int ia = s_i[lo];
+                    s_i[lo] = s_i[hi];
+                    s_i[hi] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int admissible = 0;  // the keys below the sentinel, counted by everyone (a binary search over the sorted keys)
+    {
+        int lo = 0, hi = P;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_key[mid] != 0xffffffffu) lo = mid + 1;
+            else hi = mid;
+        }
+        admissible = lo;
+    }
     const int top = admissible < k ? admissible : k;
+    // ties that reach the top k + 1; the non-positive distances among the top k (prune0: they are the first ones)
+    for (int r = tid; r <= k && r < admissible; r += kBlock) {
+        const uint32_t a = s_key[r];
+        if ((r > 0 && s_key[r - 1] == a) || (r + 1 < admissible && s_key[r + 1] == a)) s_misc[1] = 1;
+        if (r < k && p.prune0 && a <= 0x80000000u) atomicAdd(&s_misc[0], 1);
+    }
+    __syncthreads();
     if (s_misc[1] || top < p.expect) {  // ties, NaN, or a list that cannot hold the answer: path A
         if (tid == 0) p.cflag[t] = 1;
         return;
     }
-    const int dropped = s_misc[0];  // prune0: the non-positive distances are the smallest, i.e. the first ones
-#pragma unroll
-    for (int s = 0; s < kCap / kBlock; s++) {
-        const int c = tid + s * kBlock;
-        const int rank = my_rank[s];
-        if (rank < 0 || rank >= k) continue;
-        const float e = s_e[c];
-        if (p.prune0 && !(e > 0)) continue;
-        p.out_idx[t * k + rank - dropped] = s_i[c];
-        p.out_dist[t * k + rank - dropped] = e;
+    const int dropped = s_misc[0];
+    for (int r = dropped + tid; r < top; r += kBlock) {
+        const uint32_t a = s_key[r];
+        const int iv = s_i[r];
+        const uint32_t u = iv < 0 ? 0x80000000u : ((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
+        p.out_idx[t * k + r - dropped] = iv & 0x7fffffff;
+        p.out_dist[t * k + r - dropped] = __uint_as_float(u);
     }
     const int cnt = top - dropped;
     for (int r = cnt + tid; r < k; r += kBlock) {
@@ -1565,11 +1777,13 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         // (NaN for a masked row), which the block test never needs
         const bool cos_coarse = (g_topk_variant & 4) ? false : ((g_topk_variant & 8) ? true : h->coarse_ok);
         sp.ep = euclid ? EP_BIAS : (h->metric == GORSE_METRIC_COSINE ? (cos_coarse ? EP_COARSE : EP_SCALE) : EP_COARSE);
-        sp.compact_at = (g_topk_variant & 32) ? 128 : ((g_topk_variant & 64) ? 96 : kCompactAt / 2);
+        // a list is compacted (threshold raised to its K-th best) once a sub-list holds 128: 4.7 ms of the C4 pass less than at
+        // kCompactAt / 2 = 224 (fewer rows accepted late in the sweep; profiles/r03_p_probe_c4_floor.txt)
+        sp.compact_at = (g_topk_variant & 32) ? kCompactAt / 2 : ((g_topk_variant & 64) ? 96 : 128);
         sp.prof = nullptr;
         if (g_topk_variant & 16) {
-            GORSE_TRY(h->sweep_prof.ensure(12));
-            GORSE_HIP_CHECK(hipMemsetAsync(h->sweep_prof.p, 0, 12 * sizeof(unsigned long long), h->stream));
+            GORSE_TRY(h->sweep_prof.ensure(16));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->sweep_prof.p, 0, 16 * sizeof(unsigned long long), h->stream));
             sp.prof = h->sweep_prof.p;
         }
         sp.N = h->N;
@@ -1577,7 +1791,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.kth = kth;
         sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1;
         sp.nslices = 1;
-        sp.probe = (g_topk_variant >> 17) & 3;  // variant bits 17 / 18: timing probes of the main sweep (the call then returns garbage)
+        sp.probe = (g_topk_variant >> 17) & 3;  // variant bits 17-18: timing probes of the main sweep (the call then returns garbage)
         // bounds of the per-row value for the DMA sweeps' block test: the cosine scales; without them (a masked -dot index:
         // the value is 1 or NaN) the bound is the score itself
         sp.rs_min = h->metric == GORSE_METRIC_COSINE ? h->rs_min : 1.0f;
@@ -1608,6 +1822,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             p2.tile_stride = pilot_stride;
             p2.f_out = h->f0.p;
             p2.prof = nullptr;  // the instrumented twin profiles the main sweep only
+            p2.probe = 0;
             if (h->N >= (int64_t)1 << 18 || (g_topk_variant & 512)) {
                 SweepParams p1 = p2;
                 p1.kth = pilot_kth(p2.kth, 16);
@@ -1633,6 +1848,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         h->prof.end(tok, h->stream);
         RescoreParams rp;
         rp.X = h->X.p;
+        rp.Xb = h->dtype == GORSE_DTYPE_BF16 ? h->Xb.p : nullptr;
         rp.norm2 = h->norm2.p;
         rp.Qf = Qf;
         rp.qn2 = qn2;

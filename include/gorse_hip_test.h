@@ -30,23 +30,25 @@ void gorse_hip_test_set_topk_path(int32_t path);
 /* probe switches of the MFMA sweep: bit 0 = 64 candidate rows per LDS tile, bit 1 = 128 (default: what the library
  * ships with), bit 2 / bit 3 = block-level row-scale bound of the cosine sweep off / on (default: on when all norms
  * are within 2 % of each other), bit 4 = the instrumented twin (see below), bit 5 / bit 6 = compact a candidate list
- * when one of its two sub-lists exceeds 128 / 96 entries (default 224), bit 7 = the candidate path of the C4-shaped
- * sweep votes on each score row wave-wide before touching it (written without a GPU; to be measured), bit 14 = the history
+ * when one of its two sub-lists exceeds 224 / 96 entries (default 128), bit 14 = the history
  * sweep of the tie path in eight row slices whatever the index size (default: one slice per 32768 rows, at most eight),
  * bit 15 = in one slice, bit 16 = the tie replay applies every T = "push +inf, pop" literally instead of first testing
- * whether it leaves the heap as it is.  Results never depend on them. */
+ * whether it leaves the heap as it is, bits 17-18 = timing probes of the main sweep (1: no block ever qualifies, 2: a qualifying
+ * block does nothing, 3: it counts its candidates without storing them; the search then returns after the sweep, results
+ * undefined).  Results never depend on the others. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
 /* variant bit 8 (256) switches the warm start of the sweep off (pilot sweep over every 16th row tile -> initial thresholds,
  * verified by the main sweep; csrc/topk_mfma.hip topk_mfma_search), bit 9 (512) switches it on below its size limit of 2^17
  * rows, bit 10 (1024) gives the pilot a kth of 2 so that most warm starts fail their verification.  This returns how many
  * queries of the last search failed it and were swept again from -inf. */
 int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n /*out*/);
-/* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its twelve
+/* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its sixteen
  * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the
  * candidate paths inside [1], [3] barrier wait, then [4] row blocks examined, [5] row blocks with a candidate, [6]
  * kernel ticks, [7] waves, and the candidate path split into [8] count + exchange, [9] appends, [10] compaction
- * check / compaction, with [11] lanes that appended. */
-int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out12 /*host*/);
+ * check / compaction, with [11] candidate-path blocks that appended something; the tile top split into [12] wait for the
+ * buffer, [13] LDS-DMA issue, [14] wait for the previous tile's DMA, [15] its announcement. */
+int32_t gorse_hip_test_get_sweep_profile(gorse_topk *h, uint64_t *out16 /*host*/);
 /* 1 = every query of the literal scan (path A) goes through the one-thread-per-query heap kernel; 0 (default) = the queries whose
  * k + 1 smallest distances are pairwise distinct are answered by select_fast_kernel (same results). */
 void gorse_hip_test_set_scan_literal(int32_t on);

@@ -46,10 +46,24 @@ def main():
     print("16 rows equal the oracle's", flush=True)
     if "quick" in sys.argv[1:]:
         return
+    if "prof" in sys.argv[1:]:  # the instrumented twin of the main sweep: where a wave's cycles go (s_memtime ticks per wave)
+        for v, label in ((16, "warm main sweep"), (16 | 32, "warm main sweep, compaction at 224"), (16 | 64, "warm main sweep, compaction at 96"),
+                         (16 | 256 | (1 << 17), "cold sweep, no block ever qualifies")):
+            L.gorse_hip_test_set_topk_variant(v)
+            run(t, k, 0, nq, label + " (instrumented)", reps=1)
+            c = t.sweep_profile()
+            waves = max(c[7], 1)
+            print("  per wave: total %.0f = tile top %.0f + waits %.0f + row blocks %.0f (candidate path %.0f: scale %.0f append %.0f compact %.0f)"
+                  % (c[6] / waves, c[0] / waves, c[3] / waves, c[1] / waves, c[2] / waves, c[8] / waves, c[9] / waves, c[10] / waves))
+            print("  tile top per wave: buffer wait %.0f, DMA issue %.0f, landing wait %.0f, announcement %.0f" % tuple(x / waves for x in c[12:16]))
+            print("  blocks %d, on the candidate path %d (%.2f %%), of those with an append %d (%.1f %%), waves %d; ticks per block %.1f"
+                  % (c[4], c[5], 100.0 * c[5] / max(c[4], 1), c[11], 100.0 * c[11] / max(c[5], 1), waves, c[1] / max(c[4], 1)), flush=True)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
     if "floor" in sys.argv[1:]:  # what the sweep costs without its candidate path (results are garbage: timing only)
         for v, label in ((256, "cold sweep alone"), (256 | (1 << 17), "cold sweep, no block ever qualifies"),
-                         (256 | (1 << 18), "cold sweep, qualifying blocks append nothing"),
-                         (1 << 17, "pilots + main, no block qualifies"), (1 << 18, "pilots + main, nothing appended")):
+                         (1 << 17, "main: no block qualifies"), (2 << 17, "main: qualifying blocks do nothing"),
+                         (3 << 17, "main: candidates counted, not stored"), (32, "compaction at 224"), (64, "compaction at 96")):
             L.gorse_hip_test_set_topk_variant(v)
             run(t, k, 0, nq, label, reps=1)
         L.gorse_hip_test_set_topk_variant(0)
