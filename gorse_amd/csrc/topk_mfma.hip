@@ -896,6 +896,26 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     }
 }
 
+// A stored vector into the LDS row of a 16-lane group: from the bf16 rows as given when the index is bf16 (half the bytes,
+// the same fp32 values once widened), else from the fp32 rows.
+__device__ __forceinline__ void gather_row(float *row, const float *X, const uint16_t *Xb, int64_t i, int d, int lane) {
+    if (Xb && (d & 7) == 0) {  // 16-byte pieces
+        const uint4 *src = reinterpret_cast<const uint4 *>(Xb + i * d);
+        for (int e = lane; e < d / 8; e += kGroup) {
+            const uint4 v = src[e];
+            float4 *dst = reinterpret_cast<float4 *>(row + 8 * e);
+            dst[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                                 __uint_as_float(v.y & 0xffff0000u));
+            dst[1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
+                                 __uint_as_float(v.w & 0xffff0000u));
+        }
+    } else if (Xb) {
+        for (int e = lane; e < d; e += kGroup) row[e] = __uint_as_float((uint32_t)Xb[i * d + e] << 16);
+    } else {
+        for (int e = lane; e < d; e += kGroup) row[e] = X[i * d + e];
+    }
+}
+
 // ---- exact rescoring + ranking of one query's candidate list ------------------------------------------
 struct RescoreParams {
     const float *X;        // N x d fp32 stored vectors
@@ -940,21 +960,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     for (int c = gib; c < n; c += kGroupsPerBlock) {
         const int64_t i = cb[c].y;
         float *row = sx + (size_t)gib * d;
-        if (p.Xb && (d & 7) == 0) {  // 16-byte pieces of the bf16 row, widened into the LDS row
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.Xb + i * d);
-            for (int e = lane; e < d / 8; e += kGroup) {
-                const uint4 v = src[e];
-                float4 *dst = reinterpret_cast<float4 *>(row + 8 * e);
-                dst[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                                     __uint_as_float(v.y & 0xffff0000u));
-                dst[1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
-                                     __uint_as_float(v.w & 0xffff0000u));
-            }
-        } else if (p.Xb) {
-            for (int e = lane; e < d; e += kGroup) row[e] = __uint_as_float((uint32_t)p.Xb[i * d + e] << 16);
-        } else {
-            for (int e = lane; e < d; e += kGroup) row[e] = p.X[i * d + e];
-        }
+        gather_row(row, p.X, p.Xb, i, d, lane);
         __builtin_amdgcn_wave_barrier();
         float r;
         if (p.metric == GORSE_METRIC_EUCLIDEAN || p.metric == kMetricEuclidBf16) {
@@ -1081,6 +1087,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
 // Queries with a NaN, an overflowed history or an undetected cycle are flagged 2 and go to path A.
 struct ReplayParams {
     const float *X;
+    const uint16_t *Xb;    // bf16 index: the rows as given (see RescoreParams), else null
     const float *norm2;
     const float *Qf;       // by-vector queries: fp32 rows of the chunk (row pos[t]), or null
     const float *qn2;      // query norms of the chunk (row pos[t]), cosine only
@@ -1092,6 +1099,7 @@ struct ReplayParams {
     const int32_t *hcnt;
     const float *fslice;   // nslices x nq: the threshold every slice of the history sweep ended with (-inf: none)
     int nslices;           // cbuf / ccnt / hbuf / hcnt / cflag / fslice hold nslices x nq entries, slice-major
+    unsigned long long *prof;  // probe (variant bit 4): replay counters, see gorse_hip_test_get_sweep_profile; else null
     int64_t nq;
     uint8_t *cflag;        // in: flags of the history sweep (non-zero: undecidable); out [0, nq): 2 = undecided here
     int64_t N;
@@ -1162,7 +1170,7 @@ __global__ __launch_bounds__(kBlock) void topk_tie_sort_kernel(ReplayParams p) {
     for (int c = gib; c < n; c += kGroupsPerBlock) {  // exact distances, as topk_rescore_kernel
         const int64_t i = s_idx[c];
         float *xr = sx + (size_t)gib * d;
-        for (int e = lane; e < d; e += kGroup) xr[e] = p.X[i * d + e];
+        gather_row(xr, p.X, p.Xb, i, d, lane);
         __builtin_amdgcn_wave_barrier();
         float r;
         if (p.metric == GORSE_METRIC_EUCLIDEAN || p.metric == kMetricEuclidBf16) {
@@ -1314,6 +1322,8 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
     const int64_t row = p.pos[t];
     bool undecided = n < 0;
     const float kInf = __builtin_inff();
+    const unsigned long long t_begin = p.prof ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long n_push = 0, n_tpow = 0, n_slow_tpow = 0, n_T = 0;
     RegHeap<true> mx;
     auto apply_T = [&]() {  // a push that goes to the root and is popped at once
         int dv;
@@ -1345,12 +1355,15 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
         return true;
     };
     auto t_pow = [&](int64_t gap) {
+        n_tpow++;
         if (!(g_replay_literal) && t_is_identity()) return;
+        n_slow_tpow++;
         int64_t steps = 0;
         while (steps < gap && steps < 16) {  // fixpoint (the usual case: no equal distances on the path) or pre-period
             const RegHeap<true> snap = mx;
             apply_T();
             steps++;
+            n_T++;
             if (mx.same_values(snap, lane)) return;
         }
         if (steps == gap) return;
@@ -1361,6 +1374,7 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
             apply_T();
             period++;
             steps++;
+            n_T++;
             if (steps == gap) return;
             if (mx.same_values(snap, lane)) {
                 closed = true;
@@ -1407,6 +1421,7 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
                 pend = 0;
                 if (undecided) break;
             }
+            n_push++;
             mx.push((int32_t)i, dd);
             if (mx.n > k) {
                 int dv;
@@ -1421,6 +1436,20 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
         if (gap > 0 && mx.n < k) undecided = true;
         pend += gap;
         if (!undecided && pend > 0) t_pow(pend);
+    }
+    if (p.prof && lane == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_begin;
+        atomicAdd(p.prof + 0, dt);
+        atomicMax(p.prof + 1, dt);
+        atomicAdd(p.prof + 2, (unsigned long long)(n > 0 ? n : 0));
+        atomicAdd(p.prof + 3, 1ull);
+        atomicAdd(p.prof + 4, n_push);
+        atomicAdd(p.prof + 5, n_tpow);
+        atomicAdd(p.prof + 6, n_slow_tpow);
+        atomicAdd(p.prof + 7, n_T);
+        atomicMax(p.prof + 8, n_T);
+        atomicMax(p.prof + 9, (unsigned long long)(n > 0 ? n : 0));
+        atomicAdd(p.prof + 10, undecided ? 1ull : 0ull);
     }
     if (undecided) {
         if (lane == 0) p.cflag[t] = 2;
@@ -1444,6 +1473,298 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
     }
     if (lane == 0) p.out_cnt[row] = cnt;
     for (int e = cnt + lane; e < k; e += 64) {
+        p.out_idx[row * k + e] = -1;
+        p.out_dist[row * k + e] = kInf;
+    }
+}
+
+
+// ---- the same replay with one LANE per query ----------------------------------------------------------------------
+// The replay is scalar work: the wave-per-query kernel above issues ~1.8 M cycles of readlane / writelane traffic per
+// query (18 ms for the 9,934 tie queries of C4, profiles/r03_r_probe_c4_replay.txt).  Here every lane replays its own
+// query and keeps its heap in its own LDS column (slot j of lane q at word j * QPW + q: bank q whatever the slot, so the
+// lanes never conflict, and no lane ever reads another's column: no barriers).  The ancestors of a push and the path of
+// the identity test are known before the first comparison, so their weights are read together -- one LDS round trip
+// instead of one per level; only the pop walks level by level.
+constexpr int kLaneDepth = 8;   // ancestors of slot 256
+constexpr int kLaneLog = 24;    // slots one T can write (<= 9 by its push, <= 9 by its pop)
+template <bool DESC, int stride>
+struct LaneHeap {
+    int *W, *V;  // this lane's column: slot j at [j * stride]
+    int n;
+    __device__ __forceinline__ static bool less(float a, float b) { return DESC ? a > b : a < b; }
+    __device__ __forceinline__ float getw(int j) const { return __int_as_float(W[j * stride]); }
+    __device__ __forceinline__ int getv(int j) const { return V[j * stride]; }
+    // log (probe of change): slot and old value of everything written, when lg != nullptr
+    int *lg;
+    int nlog;
+    __device__ __forceinline__ void set(int j, float wt, int val) {
+        if (lg) {
+            if (nlog < kLaneLog) {
+                lg[(2 * nlog) * stride] = j;
+                lg[(2 * nlog + 1) * stride] = V[j * stride];
+            }
+            nlog++;
+        }
+        W[j * stride] = __float_as_int(wt);
+        V[j * stride] = val;
+    }
+    __device__ __forceinline__ void push(int val, float wt) {  // heap.Push: append, up(n - 1)
+        int j = n++;
+        int anc[kLaneDepth], av[kLaneDepth];
+        float aw[kLaneDepth];
+        int a = j;
+#pragma unroll
+        for (int l = 0; l < kLaneDepth; l++) {
+            const bool ok = a > 0;
+            a = ok ? (a - 1) / 2 : 0;
+            anc[l] = ok ? a : -1;
+            aw[l] = getw(a);
+            av[l] = getv(a);
+        }
+#pragma unroll
+        for (int l = 0; l < kLaneDepth; l++) {
+            if (anc[l] < 0 || !less(wt, aw[l])) break;
+            set(j, aw[l], av[l]);
+            j = anc[l];
+        }
+        set(j, wt, val);
+    }
+    __device__ __forceinline__ void pop(int &val, float &wt) {  // heap.Pop: swap(0, n - 1), down(0, n - 1), take the last
+        val = getv(0);
+        wt = getw(0);
+        const int m = --n;
+        if (m == 0) return;
+        const float wl = getw(m);
+        const int vl = getv(m);
+        int i = 0;
+        for (;;) {
+            const int j1 = 2 * i + 1;
+            if (j1 >= m) break;
+            const bool two = j1 + 1 < m;
+            const int j2 = two ? j1 + 1 : j1;
+            const float w1 = getw(j1), w2 = getw(j2);
+            const int v1 = getv(j1), v2 = getv(j2);
+            int j = j1, vj = v1;
+            float wj = w1;
+            if (two && less(w2, wj)) {
+                j = j2;
+                wj = w2;
+                vj = v2;
+            }
+            if (!less(wj, wl)) break;
+            set(i, wj, vj);
+            i = j;
+        }
+        set(i, wl, vl);
+    }
+};
+
+template <int QPW>  // queries (= active lanes) per workgroup: a constant so that a slot's address is a shift
+__global__ __launch_bounds__(64) void topk_tie_replay_lane_kernel(ReplayParams p, int64_t nq, int slots) {
+    constexpr int qpw = QPW;
+    extern __shared__ int smem_i[];
+    const int lane = threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * qpw + lane;
+    if (lane >= qpw || t >= nq) return;
+    if (p.cflag[t]) return;
+    int *W = smem_i + lane, *V = W + slots * qpw, *LG = V + slots * qpw, *SN = LG + 2 * kLaneLog * qpw;  // SN: a snapshot of V
+    const int n = p.scount[t];
+    const int k = p.k;
+    const int64_t self = p.self[t];
+    const int64_t row = p.pos[t];
+    bool undecided = n < 0;
+    const float kInf = __builtin_inff();
+    const unsigned long long t_begin = p.prof ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long n_push = 0, n_tpow = 0, n_slow_tpow = 0, n_T = 0;
+    LaneHeap<true, QPW> mx;
+    mx.W = W, mx.V = V, mx.n = 0, mx.lg = nullptr, mx.nlog = 0;
+    // topk_tie_replay_kernel's t_is_identity, the path's weights read before the first comparison
+    auto t_is_identity = [&]() -> bool {
+        const int hn = mx.n;
+        if (hn < 1) return false;
+        int child = (hn - 1) / 2;  // p1
+        const float e = mx.getw(child);
+        float wp[kLaneDepth], ws[kLaneDepth];
+        bool has[kLaneDepth], right[kLaneDepth];
+        int c = child;
+#pragma unroll
+        for (int l = 0; l < kLaneDepth; l++) {
+            has[l] = c > 0;
+            const int parent = has[l] ? (c - 1) / 2 : 0;
+            right[l] = has[l] && (c & 1) == 0;
+            wp[l] = mx.getw(parent);
+            ws[l] = mx.getw(right[l] ? c - 1 : 0);
+            c = parent;
+        }
+        if (!(e < kInf)) return false;
+#pragma unroll
+        for (int l = 0; l < kLaneDepth; l++) {
+            if (!has[l]) break;
+            if (!(wp[l] > e) || !(wp[l] < kInf)) return false;
+            if (right[l] && !(wp[l] > ws[l])) return false;
+        }
+        return true;
+    };
+    auto apply_T = [&]() {
+        int dv;
+        float dw;
+        mx.push(-1, kInf);
+        mx.pop(dv, dw);
+    };
+    // T^gap when T is not the identity: literal applications until nothing changes (the change is read off the log of
+    // what T wrote), then topk_tie_replay_kernel's search for the period against a snapshot of the values
+    auto t_pow = [&](int64_t gap) {
+        n_tpow++;
+        if (t_is_identity()) return;
+        n_slow_tpow++;
+        int64_t steps = 0;
+        while (steps < gap && steps < 16) {
+            const int before = mx.n;
+            mx.lg = LG;
+            mx.nlog = 0;
+            apply_T();
+            mx.lg = nullptr;
+            steps++;
+            n_T++;
+            bool same = mx.nlog <= kLaneLog;
+            for (int r = 0; r < mx.nlog && same; r++) {
+                const int sl = LG[(2 * r) * qpw];
+                if (sl < before && V[sl * qpw] != LG[(2 * r + 1) * qpw]) same = false;
+            }
+            if (same) return;
+        }
+        if (steps == gap) return;
+        const int hn = mx.n;
+        for (int sl = 0; sl < hn; sl++) SN[sl * qpw] = V[sl * qpw];  // inside the cycle now (or not: then the query is flagged)
+        int64_t period = 0;
+        bool closed = false;
+        while (period < 64) {
+            apply_T();
+            period++;
+            steps++;
+            n_T++;
+            if (steps == gap) return;
+            bool same = true;
+            for (int sl = 0; sl < hn && same; sl++) same = SN[sl * qpw] == V[sl * qpw];
+            if (same) {
+                closed = true;
+                break;
+            }
+        }
+        if (!closed) {
+            undecided = true;
+            return;
+        }
+        const int64_t rem = (gap - steps) % period;
+        for (int64_t r = 0; r < rem; r++) apply_T();
+    };
+    const int32_t *sidx = p.sidx + t * kReplayCap;
+    const float *sdst = p.sdst + t * kReplayCap;
+    int64_t prev = -1;
+    int64_t pend = 0;
+    // Lanes run in step, so an entry that only counts (strictly worse than a full heap's root: the reference pushes it to the
+    // root and pops it at once) must not cost its lane a turn of the heap work the others do: every lane first walks over
+    // such entries (inner loop), then the lanes that stopped at a real push do it together.
+    float rootw = kInf;  // W[0] of a non-empty heap
+    int e0 = 0;
+    int nxt_i = n > 0 ? sidx[0] : 0;  // one entry ahead (16-byte groups two ahead were slower: profiles/r03_v_*)
+    float nxt_d = n > 0 ? sdst[0] : 0.0f;
+    while (e0 < n && !undecided) {
+        int64_t i = 0;
+        float dd = 0.0f;
+        bool have = false;
+        while (e0 < n) {
+            i = nxt_i;
+            dd = nxt_d;
+            e0++;
+            if (e0 < n) {
+                nxt_i = sidx[e0];
+                nxt_d = sdst[e0];
+            }
+            if (i == self) continue;
+            if (i == prev) {
+                undecided = true;
+                break;
+            }
+            int64_t gap = i - prev - 1;
+            if (self > prev && self < i) gap--;
+            if (gap > 0 && mx.n < k) {
+                undecided = true;
+                break;
+            }
+            pend += gap;
+            prev = i;
+            if (mx.n == k && dd > rootw) {
+                pend++;
+                continue;
+            }
+            have = true;
+            break;
+        }
+        if (!have || undecided) break;
+        if (pend > 0) {
+            t_pow(pend);
+            pend = 0;
+            if (undecided) break;
+        }
+        n_push++;
+        mx.push((int32_t)i, dd);
+        if (mx.n > k) {
+            int dv;
+            float dw;
+            mx.pop(dv, dw);
+        }
+        rootw = mx.getw(0);
+    }
+    if (!undecided) {
+        int64_t gap = p.N - 1 - prev;
+        if (self > prev) gap--;
+        if (gap > 0 && mx.n < k) undecided = true;
+        pend += gap;
+        if (!undecided && pend > 0) t_pow(pend);
+    }
+    if (p.prof) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_begin;
+        atomicAdd(p.prof + 0, dt);
+        atomicMax(p.prof + 1, dt);
+        atomicAdd(p.prof + 2, (unsigned long long)(n > 0 ? n : 0));
+        atomicAdd(p.prof + 3, 1ull);
+        atomicAdd(p.prof + 4, n_push);
+        atomicAdd(p.prof + 5, n_tpow);
+        atomicAdd(p.prof + 6, n_slow_tpow);
+        atomicAdd(p.prof + 7, n_T);
+        atomicMax(p.prof + 8, n_T);
+        atomicMax(p.prof + 9, (unsigned long long)(n > 0 ? n : 0));
+        atomicAdd(p.prof + 10, undecided ? 1ull : 0ull);
+    }
+    if (undecided) {
+        p.cflag[t] = 2;
+        return;
+    }
+    // Reverse(): re-push in array order (pq.go:121-128) -- in place: the min-heap of the first e entries lives in the slots
+    // the max-heap's first e entries have been read from
+    const int hn = mx.n;
+    LaneHeap<false, QPW> mn;
+    mn.W = W, mn.V = V, mn.n = 0, mn.lg = nullptr, mn.nlog = 0;
+    for (int e = 0; e < hn; e++) {
+        const int val = V[e * qpw];
+        const float wt = __int_as_float(W[e * qpw]);
+        mn.push(val, wt);
+    }
+    int cnt = 0;
+    while (mn.n > 0) {
+        int v;
+        float w;
+        mn.pop(v, w);
+        if (!p.prune0 || w > 0) {
+            p.out_idx[row * k + cnt] = v;
+            p.out_dist[row * k + cnt] = w;
+            cnt++;
+        }
+    }
+    p.out_cnt[row] = cnt;
+    for (int e = cnt; e < k; e++) {
         p.out_idx[row * k + e] = -1;
         p.out_dist[row * k + e] = kInf;
     }
@@ -1940,6 +2261,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 h->prof.end(tok, h->stream);
                 ReplayParams pp;
                 pp.X = h->X.p;
+                pp.Xb = h->dtype == GORSE_DTYPE_BF16 ? h->Xb.p : nullptr;
                 pp.norm2 = h->norm2.p;
                 pp.Qf = Qf;
                 pp.qn2 = qn2;
@@ -1951,6 +2273,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 pp.hcnt = h->rp_hcnt.p;
                 pp.fslice = h->rp_fslice.p;
                 pp.nslices = nsl;
+                pp.prof = (g_topk_variant & 16) && h->sweep_prof.n >= 16 ? h->sweep_prof.p : nullptr;  // the sweep's counters are overwritten
+                if (pp.prof) GORSE_HIP_CHECK(hipMemsetAsync(pp.prof, 0, 16 * sizeof(unsigned long long), h->stream));
                 pp.nq = m2;
                 pp.cflag = h->rp_flag.p;
                 pp.N = h->N;
@@ -1973,8 +2297,29 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 tok = h->prof.begin(GORSE_PROF_TOPK_REPLAY, h->stream);
                 topk_tie_sort_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
                 GORSE_HIP_CHECK(hipGetLastError());
-                topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2, (g_topk_variant & 65536) ? 1 : 0);
-                GORSE_HIP_CHECK(hipGetLastError());
+                // one lane per query (variant bit 19: the round-2 kernel, a wave per query)
+                const bool lanes = !(g_topk_variant & (1 << 19)) && !(g_topk_variant & 65536);
+                if (lanes) {
+                    const int slots = k + 1;
+                    int qpw = 64;
+                    while (qpw > 16 && (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4 > (size_t)144 * 1024) qpw >>= 1;
+                    const size_t llds = (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4;
+                    auto launch_lanes = [&](auto tag) -> int32_t {
+                        constexpr int Q = decltype(tag)::value;
+                        GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_tie_replay_lane_kernel<Q>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+                        topk_tie_replay_lane_kernel<Q><<<dim3((unsigned)ceil_div(m2, Q)), dim3(64), llds, h->stream>>>(pp, m2, slots);
+                        GORSE_HIP_CHECK(hipGetLastError());
+                        return GORSE_OK;
+                    };
+                    if (qpw == 64) GORSE_TRY(launch_lanes(std::integral_constant<int, 64>()));
+                    else if (qpw == 32) GORSE_TRY(launch_lanes(std::integral_constant<int, 32>()));
+                    else GORSE_TRY(launch_lanes(std::integral_constant<int, 16>()));
+                }
+                if (!lanes) {
+                    topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2, (g_topk_variant & 65536) ? 1 : 0);
+                    GORSE_HIP_CHECK(hipGetLastError());
+                }
                 h->prof.end(tok, h->stream);
                 f2.resize((size_t)m2);
                 GORSE_HIP_CHECK(hipMemcpyAsync(f2.data(), h->rp_flag.p, (size_t)m2, hipMemcpyDeviceToHost, h->stream));

@@ -33,7 +33,8 @@ void gorse_hip_test_set_topk_path(int32_t path);
  * when one of its two sub-lists exceeds 224 / 96 entries (default 128), bit 14 = the history
  * sweep of the tie path in eight row slices whatever the index size (default: one slice per 32768 rows, at most eight),
  * bit 15 = in one slice, bit 16 = the tie replay applies every T = "push +inf, pop" literally instead of first testing
- * whether it leaves the heap as it is, bits 17-18 = timing probes of the main sweep (1: no block ever qualifies, 2: a qualifying
+ * whether it leaves the heap as it is (and a wave per query), bit 19 = the tie replay with a wave per query for every query
+ * (default: a lane per query), bits 17-18 = timing probes of the main sweep (1: no block ever qualifies, 2: a qualifying
  * block does nothing, 3: it counts its candidates without storing them; the search then returns after the sweep, results
  * undefined).  Results never depend on the others. */
 void gorse_hip_test_set_topk_variant(int32_t variant);

@@ -46,6 +46,15 @@ def main():
     print("16 rows equal the oracle's", flush=True)
     if "quick" in sys.argv[1:]:
         return
+    if "replay" in sys.argv[1:]:  # the tie replay's counters (they overwrite the sweep's)
+        L.gorse_hip_test_set_topk_variant(16)
+        run(t, k, 0, nq, "instrumented", reps=1)
+        c = t.sweep_profile()
+        q = max(c[3], 1)
+        print("  replay: %d queries, ticks per query mean %.0f max %d; entries mean %.0f max %d; pushes %.0f, T^gap calls %.0f of which not the identity %.0f, literal T %.0f (max %d) per query; undecided %d"
+              % (c[3], c[0] / q, c[1], c[2] / q, c[9], c[4] / q, c[5] / q, c[6] / q, c[7] / q, c[8], c[10]), flush=True)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
     if "prof" in sys.argv[1:]:  # the instrumented twin of the main sweep: where a wave's cycles go (s_memtime ticks per wave)
         for v, label in ((16, "warm main sweep"), (16 | 32, "warm main sweep, compaction at 224"), (16 | 64, "warm main sweep, compaction at 96"),
                          (16 | 256 | (1 << 17), "cold sweep, no block ever qualifies")):

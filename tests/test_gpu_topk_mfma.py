@@ -150,15 +150,17 @@ def test_tie_replay_long_history(oracle, N, d, k, lo, hi, metric):
         assert c2[r] == ei.size and np.array_equal(i2[r, :c2[r]], ei) and np.array_equal(bits(d2[r, :c2[r]]), bits(ed))
 
 
-V_SLICES8, V_SLICE1, V_REPLAY_LITERAL = 1 << 14, 1 << 15, 1 << 16
+V_SLICES8, V_SLICE1, V_REPLAY_LITERAL, V_REPLAY_WAVES, V_INSTRUMENTED = 1 << 14, 1 << 15, 1 << 16, 1 << 19, 16
 
 
-@pytest.mark.parametrize("variant", [V_SLICES8, V_SLICE1, V_SLICES8 | V_REPLAY_LITERAL, V_SLICE1 | V_REPLAY_LITERAL])
+@pytest.mark.parametrize("variant", [V_SLICES8, V_SLICE1, V_SLICES8 | V_REPLAY_LITERAL, V_SLICE1 | V_REPLAY_LITERAL, V_SLICES8 | V_REPLAY_WAVES,
+                                     V_SLICES8 | V_INSTRUMENTED])
 @pytest.mark.parametrize("metric", [capi.METRIC_NEG_DOT, capi.METRIC_COSINE, capi.METRIC_EUCLIDEAN])
 def test_history_sweep_in_row_slices_and_the_replay_shortcut(oracle, variant, metric):
     """The tie path's two round-3 changes, each against its plain form and the oracle: the history sweep cut into eight row
     slices that start cold and are joined by topk_tie_sort_kernel (thresholds of the earlier slices filter the later ones),
-    and the replay's test "T = push +inf, pop leaves this heap as it is" in place of the literal T + snapshot compare.
+    and the replay's test "T = push +inf, pop leaves this heap as it is" in place of the literal T + snapshot compare; the
+    replay with one lane per query (default) against the one with a wave per query (V_REPLAY_WAVES).
     Small-integer vectors: ties everywhere, long gaps of unrecorded rows between the recorded ones."""
     rng = np.random.default_rng(77 + metric)
     N, d, k = 24000, 6, 40
@@ -175,6 +177,11 @@ def test_history_sweep_in_row_slices_and_the_replay_shortcut(oracle, variant, me
         assert cnt[r] == ei.size and np.array_equal(idx[r, :cnt[r]], ei), (q, n_scan, n_replay)
         assert np.array_equal(bits(dist[r, :cnt[r]]), bits(ed))
     assert n_replay > 100, (n_scan, n_replay)  # the replay, not the literal scan, answered them
+    if variant & V_INSTRUMENTED:  # the lane-per-query replay and what it passed on to the wave-per-query one
+        c = t.sweep_profile()
+        print("replay (metric %d): %d queries on lanes, %d T^gap calls, %d not the identity, %d literal T (at most %d in one query)"
+              % (metric, c[3], c[5], c[6], c[7], c[8]))
+        assert c[3] >= n_replay
     # distinct distances and a few planted ties: the slices' join must keep every row the reference's heap accepted
     Xf = rng.standard_normal((N, 16)).astype(np.float32)
     Xf[5000] = Xf[17]
