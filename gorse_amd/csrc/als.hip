@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void als_sweep_kernel(float *__restrict__ A, c
 // columns read from LDS.  A row of more than 4096 entries is cut into chunks (the row plan of the d <= 64 form): every chunk
 // leaves its G and column sums in global memory, als_wide_long_kernel adds them in chunk order and solves.
 constexpr int kWideLd = 129, kWideBatch = 16, kWidePartial = 128 * 128 + 128;  // floats per chunk: G row-major, then the sums
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // G and the column sums of entries idx[beg .. beg + n) of B, in this thread's 8 x 8 block / (ti == 0) 8 columns
 __device__ __forceinline__ void wide_accumulate(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
@@ -233,6 +234,9 @@ __device__ __forceinline__ void wide_accumulate(const float *__restrict__ B, con
     }
 }
 
+__device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float reg, const float *sM, const float *ss,
+                                           const float *sy = nullptr);
+
 // M = (1 - w) G + w S into LDS, then the sweep of row `a` by the first wave; ends with a barrier (sM / ss are free again)
 __device__ __forceinline__ void wide_solve(float *__restrict__ a, const float *__restrict__ S, int d, float w, float reg,
                                            float *sM, float *ss, const float (&acc)[8][8], const float (&cs)[8]) {
@@ -250,57 +254,383 @@ __device__ __forceinline__ void wide_solve(float *__restrict__ a, const float *_
         for (int y = 0; y < 8; y++) ss[8 * tj + y] = 8 * tj + y < d ? cs[y] : 0.0f;
     }
     __syncthreads();
+    wide_sweep(a, d, reg, sM, ss);
+}
+
+// the Gauss-Seidel sweep of row `a` over M (LDS, 128 x kWideLd, zero past d) and the column sums ss by the first wave, two
+// coordinates per lane; ends with a barrier (sM / ss are free again)
+// sy != null: y = M p (the row's current factors) has been formed by the whole workgroup (wide_add_S: two partial sums per
+// coordinate, even and odd rows of M, at sy[k] and sy[128 + k]) with p at sy[256 + k]; else this wave forms it here.
+__device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float reg, const float *sM, const float *ss, const float *sy) {
+    const int tid = threadIdx.x;
     if (tid < 64) {
+        // the chain's operations must not queue behind the 64-cycle MFMAs of the other workgroup's wave on this SIMD (as in
+        // als_row_kernel: at equal priority the arbiter lets one of them through per MFMA)
+        __builtin_amdgcn_s_setprio(3);
         const int lane = tid, k0 = lane, k1 = lane + 64;
-        const float p0_lo = k0 < d ? a[k0] : 0.0f, p0_hi = k1 < d ? a[k1] : 0.0f;
+        const float p0_lo = sy ? sy[256 + k0] : (k0 < d ? a[k0] : 0.0f), p0_hi = sy ? sy[256 + k1] : (k1 < d ? a[k1] : 0.0f);
         const float diag_lo = sM[k0 * kWideLd + k0], diag_hi = sM[k1 * kWideLd + k1];
         // a padded coordinate (k >= d: zero row and column of M) keeps inv = 0: it solves to 0 whatever reg is
         const float inv_lo = k0 < d ? __builtin_amdgcn_rcpf(diag_lo + reg) : 0.0f;
         const float inv_hi = k1 < d ? __builtin_amdgcn_rcpf(diag_hi + reg) : 0.0f;
         const float base_lo = (ss[k0] + p0_lo * diag_lo) * inv_lo, base_hi = (ss[k1] + p0_hi * diag_hi) * inv_hi;
         float y_lo = 0.0f, y_hi = 0.0f;
-        auto bcast = [&](float lo, float hi, int f) {  // coordinate f of a two-halves vector, to every lane
-            return f < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), f))
-                          : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), f - 64));
-        };
+        auto lane_of = [](float v, int f) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), f)); };
+        // (the two halves of the coordinates are separate loops: which register a step's scalars come from is then known
+        // at compile time instead of being a uniform branch in every step)
+        if (sy) {
+            y_lo = sy[k0] + sy[128 + k0];
+            y_hi = sy[k1] + sy[128 + k1];
+        } else {
 #pragma unroll 4
-        for (int f = 0; f < 128; f++) {
-            const float pf = bcast(p0_lo, p0_hi, f);
-            y_lo = fmaf(sM[k0 * kWideLd + f], pf, y_lo);
-            y_hi = fmaf(sM[k1 * kWideLd + f], pf, y_hi);
+            for (int f = 0; f < 64; f++) {
+                const float pf = lane_of(p0_lo, f);
+                y_lo = fmaf(sM[k0 * kWideLd + f], pf, y_lo);
+                y_hi = fmaf(sM[k1 * kWideLd + f], pf, y_hi);
+            }
+#pragma unroll 4
+            for (int f = 0; f < 64; f++) {
+                const float pf = lane_of(p0_hi, f);
+                y_lo = fmaf(sM[k0 * kWideLd + 64 + f], pf, y_lo);
+                y_hi = fmaf(sM[k1 * kWideLd + 64 + f], pf, y_hi);
+            }
         }
+        // The sweep is one dependent chain through y; per step it is kept to three operations: every lane forms its own
+        // would-be step delta_k = (base_k - p_k) - y_k inv_k (one fused operation on the chain), lane f's is broadcast
+        // (v_readlane), and y += delta_f M[:, f].  The new coordinate p_f' = base_f - y_f inv_f is formed beside the chain, the
+        // columns of M for the next eight steps are read from LDS while the current eight run.  (profiles/r03_zc: 22.5K
+        // cycles per row = 176 per step with base, y, inv and p0 of coordinate f broadcast separately in every step.)
+        const float g_lo = base_lo - p0_lo, g_hi = base_hi - p0_hi;
         float p_lo = p0_lo, p_hi = p0_hi;
-#pragma unroll 4
-        for (int f = 0; f < 128; f++) {
-            const float col_lo = sM[k0 * kWideLd + f], col_hi = sM[k1 * kWideLd + f];  // M is symmetric: column f = row f
-            const float nf = bcast(base_lo, base_hi, f) - bcast(y_lo, y_hi, f) * bcast(inv_lo, inv_hi, f);
-            const float delta = nf - bcast(p0_lo, p0_hi, f);
-            y_lo = fmaf(delta, col_lo, y_lo);
-            y_hi = fmaf(delta, col_hi, y_hi);
-            if (f < 64)
-                p_lo = lane == f ? nf : p_lo;
-            else
-                p_hi = lane == f - 64 ? nf : p_hi;
-        }
+        auto sweep_half = [&](const int hi) {
+            const float *c0 = sM + k0 * kWideLd + 64 * hi, *c1 = sM + k1 * kWideLd + 64 * hi;
+            float cl[8], ch[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) cl[j] = c0[j], ch[j] = c1[j];
+#pragma unroll 1
+            for (int fb = 0; fb < 64; fb += 8) {
+                float nl[8], nh[8];
+                const int nb = fb + 8 < 64 ? fb + 8 : fb;
+#pragma unroll
+                for (int j = 0; j < 8; j++) nl[j] = c0[nb + j], nh[j] = c1[nb + j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int f = fb + j;
+                    const float yk = hi ? y_hi : y_lo;
+                    const float dk = fmaf(-yk, hi ? inv_hi : inv_lo, hi ? g_hi : g_lo);
+                    const float nf = (hi ? base_hi : base_lo) - yk * (hi ? inv_hi : inv_lo);
+                    const float delta = lane_of(dk, f);
+                    y_lo = fmaf(delta, cl[j], y_lo);
+                    y_hi = fmaf(delta, ch[j], y_hi);
+                    if (hi)
+                        p_hi = lane == f ? nf : p_hi;
+                    else
+                        p_lo = lane == f ? nf : p_lo;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) cl[j] = nl[j], ch[j] = nh[j];
+            }
+        };
+        sweep_half(0);
+        sweep_half(1);
         if (k0 < d) a[k0] = p_lo;
         if (k1 < d) a[k1] = p_hi;
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
 }
 
+
+// ---- G of a wide row on the fp32 MFMA ---------------------------------------------------------------------------------
+// The 128 x 128 Gram matrix is 4 x 4 blocks of 32 x 32; its upper triangle is ten v_mfma_f32_32x32x2_f32 tiles, shared out
+// among the four waves of the workgroup 3 + 3 + 2 + 2 (the diagonal blocks' waves also keep the column sums of their two
+// column blocks).  The gathered rows go through LDS 32 entries at a time -- two buffers inside the region that holds M
+// afterwards, so one barrier per batch: a buffer is rewritten two batches after it was read -- and an MFMA consumes two
+// entries: lane (half, col) supplies q[entry 2 p + half][32 b + col] as the A operand of block b and as the B operand.
+// 192 MFMA cycles per entry pair on the busiest SIMD against ~512 cycles of fused multiply-adds per pair and thread before.
+__device__ __forceinline__ constexpr int wide_tiles(int wv) { return wv < 2 ? 3 : 2; }
+__device__ __forceinline__ constexpr int wide_tile_bi(int wv, int t) { return wv == 0 ? (t == 2 ? 1 : 0) : (wv == 1 ? (t == 2 ? 3 : 2) : wv - 2); }
+__device__ __forceinline__ constexpr int wide_tile_bj(int wv, int t) { return wv == 0 ? (t == 0 ? 0 : 1) : (wv == 1 ? (t == 0 ? 2 : 3) : 2 + t); }
+constexpr int kWideMfmaBatch = 32;
+
+// A thread's share of the gather pipeline: the batch that is consumed next (two entries x eight columns) and the row ids of the
+// batch after it.  It lives across rows: a row's first batch is gathered while the row before it is still being accumulated,
+// formed and swept -- a gather is two dependent reads (entry -> row id -> row), ~10K cycles in front of a 100-entry row's
+// ~12K cycles of MFMA when it starts cold (profiles/r03_zb_probe_als_wide.txt: 44K cycles of accumulation per such row).
+struct WideStage {
+    float g[2][8];
+    int ix[2];
+};
+__device__ __forceinline__ void wide_load_ids(const int32_t *__restrict__ idx, int64_t beg, int n, int e0, int (&ix)[2]) {
+    const int lr = threadIdx.x >> 4;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+        const int e = e0 + lr + 16 * h2;
+        ix[h2] = idx[beg + (e < n ? e : 0)];
+    }
+}
+__device__ __forceinline__ void wide_gather(const float *__restrict__ B, int n, int e0, int d, const int (&ix)[2], float (&g)[2][8]) {
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 8;  // entries lr and lr + 16 of the batch, columns lc .. lc + 7
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+        const int e = e0 + lr + 16 * h2;
+        const float *row = B + (int64_t)ix[h2] * d;
+#pragma unroll
+        for (int i = 0; i < 8; i++) g[h2][i] = (e < n && lc + i < d) ? row[lc + i < d ? lc + i : 0] : 0.0f;
+    }
+}
+// the pipeline's state for a workgroup's first item
+__device__ __forceinline__ void wide_first_batch(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n, int d,
+                                                 WideStage &st) {
+    wide_load_ids(idx, beg, n, 0, st.ix);
+    wide_gather(B, n, 0, d, st.ix, st.g);
+    wide_load_ids(idx, beg, n, kWideMfmaBatch, st.ix);
+}
+
+// G of item (beg, n) into this wave's tiles; on entry st holds the item's first batch and the ids of its second, on exit those of
+// the next item (nbeg, nn)
+template <int W>
+__device__ __forceinline__ void wide_gram_mfma(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
+                                               int64_t nbeg, int nn, int d, float *sbuf, WideStage &st, f32x16 (&tl)[3],
+                                               float (&cs)[2]) {
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int lr = tid >> 4, lc = (tid & 15) * 8;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) tl[t][r] = 0.0f;
+    cs[0] = cs[1] = 0.0f;
+    int ixn[2];  // the next item's first ids: read now, used when this item's last batch is being multiplied
+    wide_load_ids(idx, nbeg, nn, 0, ixn);
+    auto next_item = [&]() {
+        wide_gather(B, nn, 0, d, ixn, st.g);
+        wide_load_ids(idx, nbeg, nn, kWideMfmaBatch, st.ix);
+    };
+    int buf = 0;
+    for (int e0 = 0; e0 < n; e0 += kWideMfmaBatch) {
+        float *sq = sbuf + buf * (kWideMfmaBatch * 128);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {  // (16-byte stores: as dwords the eight-column shares of 16 lanes met in four banks)
+            float4 *dst = reinterpret_cast<float4 *>(sq + (lr + 16 * h2) * 128 + lc);
+            dst[0] = make_float4(st.g[h2][0], st.g[h2][1], st.g[h2][2], st.g[h2][3]);
+            dst[1] = make_float4(st.g[h2][4], st.g[h2][5], st.g[h2][6], st.g[h2][7]);
+        }
+        __syncthreads();
+        if (e0 + kWideMfmaBatch < n) {
+            wide_gather(B, n, e0 + kWideMfmaBatch, d, st.ix, st.g);
+            wide_load_ids(idx, beg, n, e0 + 2 * kWideMfmaBatch, st.ix);
+        } else {
+            next_item();
+        }
+        const int m = n - e0 < kWideMfmaBatch ? n - e0 : kWideMfmaBatch;
+        const int pairs = (m + 1) >> 1;  // (an odd batch end: the second entry of the last pair is a row of zeros)
+        const float *mine = sq + half * 128 + col;
+#pragma unroll 2
+        for (int p = 0; p < pairs; p++) {
+            float fr[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                bool used = false;
+#pragma unroll
+                for (int t = 0; t < wide_tiles(W); t++) used |= wide_tile_bi(W, t) == b || wide_tile_bj(W, t) == b;
+                fr[b] = used ? mine[p * 256 + 32 * b] : 0.0f;
+            }
+#pragma unroll
+            for (int t = 0; t < wide_tiles(W); t++)
+                tl[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[wide_tile_bi(W, t)], fr[wide_tile_bj(W, t)], tl[t], 0, 0, 0);
+            if (W < 2) {
+                cs[0] += fr[2 * W];
+                cs[1] += fr[2 * W + 1];
+            }
+        }
+        buf ^= 1;
+    }
+    if (n <= 0) next_item();
+    __syncthreads();  // the batches are consumed: the region is M's now
+}
+
+// this wave's tiles -> (1 - w) G in LDS (both triangles, zero past d), its column sums -> ss; wide_add_S completes M.  (With the
+// loads of S in here -- 96 of them, each its own 64-bit address -- the kernel needed 300 registers.)
+template <int W>
+__device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const float (&cs)[2], int d, float w, float *sM, float *ss) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const float one_w = 1 - w;
+#pragma unroll
+    for (int t = 0; t < wide_tiles(W); t++) {
+        const int bi = wide_tile_bi(W, t), bj = wide_tile_bj(W, t);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * bj + col;
+            const bool in = i < d && j < d;
+            const float v = tl[t][r];
+            sM[i * kWideLd + j] = in ? one_w * v : 0.0f;
+            if (bi != bj) sM[j * kWideLd + i] = in ? one_w * v : 0.0f;
+        }
+    }
+    if (W < 2) {
+#pragma unroll
+        for (int b2 = 0; b2 < 2; b2++) {
+            const float other = __shfl_xor(cs[b2], 32, 64);
+            const int e = 32 * (2 * W + b2) + col;
+            if (lane < 32) ss[e] = e < d ? cs[b2] + other : 0.0f;
+        }
+    }
+}
+
+// M += w S over the d x d corner, the whole workgroup, S read row by row (the same two roundings per element as
+// (1 - w) G + w S written in one expression: the products are rounded before the sum either way)
+// The thread's 64 elements of w S (rows (tid >> 7) + 2 q of column tid & 127, zero past d) are read once per workgroup and kept
+// in registers: the same S for every row of the half-sweep.
+__device__ __forceinline__ void wide_load_wS(const float *__restrict__ S, int d, float w, float (&ws)[64]) {
+    const int j = threadIdx.x & 127, i0 = threadIdx.x >> 7;
+#pragma unroll
+    for (int q = 0; q < 64; q++) {
+        const int i = i0 + 2 * q;
+        const bool in = i < d && j < d;
+        const float v = S[in ? i * d + j : 0];
+        ws[q] = in ? w * v : 0.0f;
+    }
+}
+// M += w S, and with it the sweep's starting y = M p: the thread that completes the elements M[i][j], i = i0 + 2 q, of column j
+// also sums M[i][j] p_i over them (M is symmetric: that is its part of y_j); p is at sy[256 ..], the two partial sums of
+// coordinate j go to sy[j] (even rows) and sy[128 + j] (odd rows)
+__device__ __forceinline__ void wide_add_S(const float (&ws)[64], float *sM, float *sy) {
+    const int i0 = threadIdx.x >> 7, j = threadIdx.x & 127;
+    float *col = sM + i0 * kWideLd + j;
+    const float *p = sy + 256 + i0;
+    float y = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 64; q++) {
+        const float m = col[2 * q * kWideLd] + ws[q];
+        col[2 * q * kWideLd] = m;
+        y = fmaf(m, p[2 * q], y);
+    }
+    sy[128 * i0 + j] = y;
+}
+
+// this wave's tiles -> the chunk's partial G (row-major 128 x 128, both triangles) and column sums in global memory
+template <int W>
+__device__ __forceinline__ void wide_partial_mfma(const f32x16 (&tl)[3], const float (&cs)[2], float *__restrict__ dst) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int t = 0; t < wide_tiles(W); t++) {
+        const int bi = wide_tile_bi(W, t), bj = wide_tile_bj(W, t);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * bj + col;
+            dst[i * 128 + j] = tl[t][r];
+            if (bi != bj) dst[j * 128 + i] = tl[t][r];
+        }
+    }
+    if (W < 2) {
+#pragma unroll
+        for (int b2 = 0; b2 < 2; b2++) {
+            const float other = __shfl_xor(cs[b2], 32, 64);
+            if (lane < 32) dst[128 * 128 + 32 * (2 * W + b2) + col] = cs[b2] + other;
+        }
+    }
+}
+
+template <int W, bool CHUNKS>
+__device__ __forceinline__ void wide_item_mfma(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
+                                               int64_t nbeg, int nn, int d, WideStage &st, float w, float *sM, float *ss,
+                                               float *__restrict__ dst) {
+    f32x16 tl[3];
+    float cs[2];
+    wide_gram_mfma<W>(B, idx, beg, n, nbeg, nn, d, sM, st, tl, cs);
+    if (CHUNKS)
+        wide_partial_mfma<W>(tl, cs, dst);
+    else
+        wide_form_mfma<W>(tl, cs, d, w, sM, ss);
+}
+
 // CHUNKS = false: the rows of `rows` (n_items of them), accumulated and solved.  CHUNKS = true: the chunks of the long rows
-// (chunk_beg / chunk_cnt, n_items of them), each leaving its G and sums in `partial`.
-template <bool CHUNKS>
-__global__ __launch_bounds__(256) void als_wide_kernel(float *__restrict__ A, const float *__restrict__ B,
+// (chunk_beg / chunk_cnt, n_items of them), each leaving its G and sums in `partial`.  MFMA = false: the round-2 form (G by
+// fused multiply-adds, a thread per 8 x 8 block), kept as the probe's comparison (gorse_hip_test_set_als_path(8)).
+template <bool CHUNKS, bool MFMA>
+__global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                        const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                                                        const float *__restrict__ S, const int32_t *__restrict__ rows,
                                                        const int64_t *__restrict__ chunk_beg, const int32_t *__restrict__ chunk_cnt,
-                                                       int64_t n_items, int d, float w, float reg, float *__restrict__ partial) {
+                                                       int64_t n_items, int d, float w, float reg, float *__restrict__ partial,
+                                                       int probe, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // probe only (prof != null, MFMA rows): s_memtime ticks of the workgroup's first wave in [0] G, [1] M to LDS + S, [2] sweep;
+    // [3] rows, [4] entries, [5] kernel ticks, [6] workgroups
+    unsigned long long c_acc = 0, c_m = 0, c_solve = 0, c_rows = 0, c_ent = 0, t_begin = 0;
+    if (prof) t_begin = __builtin_amdgcn_s_memtime();
     float *sM = smem;                           // 128 x 129
     float *sq = sM + 128 * kWideLd;             // 16 x 128: one batch of gathered rows
     float *ss = sq + kWideBatch * 128;          // 128 column sums
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    if constexpr (MFMA) {
+        auto item = [&](int64_t t, int64_t &u, int64_t &beg, int &n) {
+            u = 0, beg = 0, n = 0;
+            if (t >= n_items) return;
+            if (CHUNKS) {
+                beg = chunk_beg[t];
+                n = chunk_cnt[t];
+            } else {
+                u = rows[t];
+                beg = ptr[u];
+                n = (int)(ptr[u + 1] - beg);
+            }
+        };
+        int64_t u, beg;
+        int n;
+        item(blockIdx.x, u, beg, n);
+        WideStage st;
+        wide_first_batch(B, idx, beg, n, d, st);
+        float ws[CHUNKS ? 1 : 64];
+        if constexpr (!CHUNKS) wide_load_wS(S, d, w, ws);
+        for (int64_t t = blockIdx.x; t < n_items; t += gridDim.x) {
+            int64_t u2, beg2;
+            int n2;
+            item(t + gridDim.x, u2, beg2, n2);
+            float *dst = CHUNKS ? partial + t * kWidePartial : nullptr;
+            // the row's current factors: read now, needed (in LDS) when M is complete
+            const float pa = (!CHUNKS && tid < d) ? A[u * d + tid] : 0.0f;
+            unsigned long long t0 = 0;
+            if (prof) t0 = __builtin_amdgcn_s_memtime();
+            switch (tid >> 6) {  // wave-uniform; every branch meets the same barriers
+            case 0: wide_item_mfma<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+            case 1: wide_item_mfma<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+            case 2: wide_item_mfma<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+            default: wide_item_mfma<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+            }
+            if (!CHUNKS) {
+                if (tid < 128) sq[256 + tid] = pa;  // (the batch region: free in this form of the kernel)
+                __syncthreads();
+                unsigned long long t1 = 0;
+                if (prof) t1 = __builtin_amdgcn_s_memtime();
+                if constexpr (!CHUNKS) {
+                    if (!(probe & 2)) wide_add_S(ws, sM, sq);
+                }
+                __syncthreads();
+                unsigned long long t2 = 0;
+                if (prof) t2 = __builtin_amdgcn_s_memtime();
+                if (!(probe & 1)) wide_sweep(A + u * d, d, reg, sM, ss, sq);
+                if (prof) {
+                    c_acc += t1 - t0;
+                    c_m += t2 - t1;
+                    c_solve += __builtin_amdgcn_s_memtime() - t2;
+                    c_rows++;
+                    c_ent += n;
+                }
+            }
+            u = u2, beg = beg2, n = n2;
+        }
+        if (prof && threadIdx.x == 0) {
+            atomicAdd(prof + 0, c_acc);
+            atomicAdd(prof + 1, c_m);
+            atomicAdd(prof + 2, c_solve);
+            atomicAdd(prof + 3, c_rows);
+            atomicAdd(prof + 4, c_ent);
+            atomicAdd(prof + 5, (unsigned long long)__builtin_amdgcn_s_memtime() - t_begin);
+            atomicAdd(prof + 6, 1ull);
+        }
+        return;
+    }
     for (int64_t t = blockIdx.x; t < n_items; t += gridDim.x) {
         float acc[8][8], cs[8];
         if (CHUNKS) {
@@ -371,6 +701,9 @@ int g_als_long_row = 4096;  // rows longer than this are cut into chunks (test h
 int g_als_chunk = 4096;     // feedback entries per chunk of a long row
 int g_als_path = 0;         // 0 auto (Gram form: MFMA kernels for d <= 64, als_wide_kernel for d <= 128; else the residual
                             // sweep), 1 force the residual sweep, 2 force the MFMA Gram form (d <= 64)
+int g_als_wide_fma = 0;     // als_wide_kernel: G by fused multiply-adds (round 2) instead of the fp32 MFMA (probe: path | 8)
+bool g_als_prof = false;    // probe: 8 counters per side in h->als_prof (gorse_hip_test_als_profile)
+int g_als_wide_probe = 0;   // timing probes of als_wide_kernel (results are garbage): path | 16 = no sweep, path | 32 = S not added
 int g_als_phased = 0;       // als_row_kernel: the waves of a workgroup accumulate together and solve together (probe: path | 4)
 constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
 constexpr int kAlsWaves = 4;        // waves per workgroup of the chunk kernels
@@ -378,7 +711,6 @@ constexpr int kAlsRowWaves = 8;     // waves per workgroup of als_row_kernel: ON
                                     // holds the 8 per-wave M buffers (133 KB) next to one copy of S (16 KB)
 constexpr int kAlsPairs = 8;        // feedback-entry pairs per pipeline stage (16 entries, 4 KB at d = 64)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float wave_sum64(float v) {
     v = group_tree16(v);  // every lane of a 16-lane row holds its row's total
@@ -788,19 +1120,31 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
     if (d > 64 && d <= 128 && g_als_path == 0) {
         gorse_mf::AlsPlan &pl = h->als_plan[A == h->P.p ? 0 : 1];
         const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        const bool mfma = !g_als_wide_fma;
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        unsigned long long *wprof = nullptr;
+        if (g_als_prof) {
+            const int side = A == h->P.p ? 0 : 1;
+            GORSE_TRY(h->als_prof.ensure(16));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->als_prof.p + 8 * side, 0, 8 * sizeof(unsigned long long), h->stream));
+            wprof = h->als_prof.p + 8 * side;
+        }
         const int tokw = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
         if (pl.n_short > 0) {
-            als_wide_kernel<false><<<dim3((unsigned)std::min<int64_t>(pl.n_short, 512)), dim3(256), wlds, h->stream>>>(
-                A, B, ptr, idx, h->gram.p, pl.short_rows.p, nullptr, nullptr, pl.n_short, d, w, reg, nullptr);
+            auto k = mfma ? als_wide_kernel<false, true> : als_wide_kernel<false, false>;
+            k<<<dim3((unsigned)std::min<int64_t>(pl.n_short, 512)), dim3(256), wlds, h->stream>>>(
+                A, B, ptr, idx, h->gram.p, pl.short_rows.p, nullptr, nullptr, pl.n_short, d, w, reg, nullptr, g_als_wide_probe, wprof);
             GORSE_HIP_CHECK(hipGetLastError());
         }
         if (pl.n_long > 0) {
             GORSE_TRY(h->als_partial.ensure((size_t)pl.n_chunks * kWidePartial));
-            als_wide_kernel<true><<<dim3((unsigned)std::min<int64_t>(pl.n_chunks, 2048)), dim3(256), wlds, h->stream>>>(
-                A, B, ptr, idx, h->gram.p, nullptr, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, w, reg, h->als_partial.p);
+            auto k = mfma ? als_wide_kernel<true, true> : als_wide_kernel<true, false>;
+            k<<<dim3((unsigned)std::min<int64_t>(pl.n_chunks, 2048)), dim3(256), wlds, h->stream>>>(
+                A, B, ptr, idx, h->gram.p, nullptr, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, w, reg, h->als_partial.p, 0, nullptr);
             GORSE_HIP_CHECK(hipGetLastError());
             als_wide_long_kernel<<<dim3((unsigned)std::min<int64_t>(pl.n_long, 512)), dim3(256), wlds, h->stream>>>(
                 A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p);
@@ -832,7 +1176,6 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
 
 
 // probe: 8 counters per side in h->als_prof when the hook is on
-bool g_als_prof = false;
 unsigned long long *als_prof_slot(gorse_mf *h, int side) { return g_als_prof && h->als_prof.n >= 16 ? h->als_prof.p + 8 * side : nullptr; }
 
 int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int64_t *ptr, const int32_t *idx, float w,
@@ -908,7 +1251,41 @@ int32_t run_gram_mfma(gorse_mf *h, const float *F, int side) {
     return GORSE_OK;
 }
 
+// the same for 64 < nFactors <= 128: the chunks go through als_wide_kernel's MFMA form (partial G of 128 x 128 + sums per chunk),
+// added in chunk order
+__global__ void als_gram_reduce_wide_kernel(const float *__restrict__ partial, int nparts, int d, float *__restrict__ S) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= d * d) return;
+    const int i = e / d, j = e % d;
+    float acc = 0.0f;
+    for (int c = 0; c < nparts; c++) acc += partial[(int64_t)c * kWidePartial + i * 128 + j];
+    S[e] = acc;
+}
+int32_t run_gram_mfma_wide(gorse_mf *h, const float *F, int side) {
+    const int d = h->d, dd = d * d;
+    gorse_mf::AlsPlan &pl = h->als_plan[side];
+    GORSE_TRY(h->gram.ensure((size_t)dd));
+    int tok = h->prof.begin(GORSE_PROF_ALS_GRAM, h->stream);
+    if (pl.n_gchunks == 0) {
+        GORSE_HIP_CHECK(hipMemsetAsync(h->gram.p, 0, (size_t)dd * sizeof(float), h->stream));
+    } else {
+        GORSE_TRY(h->gram_partial.ensure((size_t)pl.n_gchunks * kWidePartial));
+        const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        als_wide_kernel<true, true><<<dim3((unsigned)std::min<int64_t>(pl.n_gchunks, 2048)), dim3(256), wlds, h->stream>>>(
+            nullptr, F, nullptr, pl.fb_rows.p, nullptr, nullptr, pl.g_beg.p, pl.g_cnt.p, pl.n_gchunks, d, 0.0f, 0.0f, h->gram_partial.p, 0,
+            nullptr);
+        GORSE_HIP_CHECK(hipGetLastError());
+        als_gram_reduce_wide_kernel<<<dim3((unsigned)ceil_div(dd, 256)), dim3(256), 0, h->stream>>>(h->gram_partial.p, (int)pl.n_gchunks,
+                                                                                                   d, h->gram.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    h->prof.end(tok, h->stream);
+    return GORSE_OK;
+}
+
 bool use_gram_form(const gorse_mf *h) { return g_als_path == 2 || (g_als_path == 0 && h->d <= 64); }
+bool use_wide_mfma(const gorse_mf *h) { return g_als_path == 0 && h->d > 64 && h->d <= 128 && !g_als_wide_fma; }
 
 }  // namespace
 
@@ -925,7 +1302,10 @@ int32_t half_epoch(gorse_mf *h, int side, float weight, float reg) {
         GORSE_TRY(run_gram_mfma(h, B, 1 - side));
         GORSE_TRY(run_side_gram(h, side, A, B, ptr, idx, weight, reg));
     } else {
-        GORSE_TRY(run_gram(h, B, side == 0 ? h->iptr.p : h->uptr.p, side == 0 ? h->I : h->U, GORSE_PROF_ALS_GRAM));
+        if (use_wide_mfma(h))
+            GORSE_TRY(run_gram_mfma_wide(h, B, 1 - side));
+        else
+            GORSE_TRY(run_gram(h, B, side == 0 ? h->iptr.p : h->uptr.p, side == 0 ? h->I : h->U, GORSE_PROF_ALS_GRAM));
         GORSE_TRY(run_sweep(h, A, B, ptr, idx, h->als_lo[side], h->als_hi[side],
                             side == 0 ? h->max_user_row : h->max_item_row, weight, reg));
     }
@@ -1015,6 +1395,8 @@ extern "C" int32_t gorse_mf_rows_import(gorse_mf *h, int32_t side, int64_t begin
 extern "C" void gorse_hip_test_set_als_path(int32_t path) {
     g_als_path = path & 3;
     g_als_phased = (path & 4) != 0;
+    g_als_wide_fma = (path & 8) != 0;
+    g_als_wide_probe = (path >> 4) & 3;
 }
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
 extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {
