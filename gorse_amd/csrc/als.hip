@@ -703,6 +703,7 @@ int g_als_path = 0;         // 0 auto (Gram form: MFMA kernels for d <= 64, als_
                             // sweep), 1 force the residual sweep, 2 force the MFMA Gram form (d <= 64)
 int g_als_wide_fma = 0;     // als_wide_kernel: G by fused multiply-adds (round 2) instead of the fp32 MFMA (probe: path | 8)
 bool g_als_prof = false;    // probe: 8 counters per side in h->als_prof (gorse_hip_test_als_profile)
+int g_als_slow_gather = 0;  // als_row_kernel / als_chunk_kernel: the first form of the gather stage whatever the shape (probe: path | 64)
 int g_als_wide_probe = 0;   // timing probes of als_wide_kernel (results are garbage): path | 16 = no sweep, path | 32 = S not added
 int g_als_phased = 0;       // als_row_kernel: the waves of a workgroup accumulate together and solve together (probe: path | 4)
 constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
@@ -751,12 +752,43 @@ __device__ __forceinline__ void gram_load_stage(const float *__restrict__ B, con
     }
 }
 
+// The same stage when d = 32 NB and the matrix (with its zero row `zero_row` behind the last one, mf.hip) spans less than 4 GB
+// and 2^24 rows: the lane's entry comes through the LDS crossbar (ds_bpermute: one instruction instead of two v_readlane, two
+// moves and a select), its address is a 32-bit offset from the scalar base (one v_mad_u32_u24 per load instead of a 64-bit
+// multiply, two 64-bit adds and four selects), and an entry past the row's end is the zero row, not a selected address.  The
+// first form issues ~18 vector instructions per entry pair beside its three MFMAs, and the accumulation ran at 337 cycles per
+// entry against 96 of MFMA (profiles/r03_zh_probe_als_prof.txt).
+// FULL: d = 32 NB; else the lanes of columns past d read the zero row too (one select per load).
+template <int NB, bool FULL>
+__device__ __forceinline__ void gram_load_stage32(const float *__restrict__ B, uint32_t rowbytes, int idx, int first, int lane, int d,
+                                                  int zero_row, float (&fr)[kAlsPairs][NB]) {
+    const int half = lane >> 5, col = lane & 31;
+    const int sel = (first + half) * 4;  // ds_bpermute address of this half's entry of pair 0
+    const uint32_t zero_off = __umul24((uint32_t)zero_row, rowbytes);
+#pragma unroll
+    for (int j = 0; j < kAlsPairs; j++) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 8 * j, idx);
+        const uint32_t off = __umul24(r, rowbytes) + (uint32_t)col * 4u;
+        if (FULL) {
+            const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
+#pragma unroll
+            for (int b = 0; b < NB; b++) fr[j][b] = row[32 * b];  // (the block's 128 bytes: the load's immediate offset)
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const uint32_t o = 32 * b + col < d ? off + 128u * b : zero_off;
+                fr[j][b] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + o);
+            }
+        }
+    }
+}
+
 // G += sum over fb[0..n) of q q^T, sum += column sums; the whole wave walks one row (or one chunk of a row)
-template <int NB>
+template <int NB, int FAST = 0>  // 0: the first form of the stage, 1: 32-bit offsets and d = 32 NB, 2: 32-bit offsets, any d
 // idx0 / idx1: lane l's entries l and 64 + l of the row as loaded by the caller (any value past the row's end)
 __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, const float *__restrict__ zeros,
                                                 const int32_t *__restrict__ fb, int n, int d, int lane,
-                                                GramAcc<NB> &g, int idx0, int idx1) {
+                                                GramAcc<NB> &g, int idx0, int idx1, int zero_row = 0) {
 #pragma unroll
     for (int t = 0; t < GramAcc<NB>::NT; t++)
 #pragma unroll
@@ -768,24 +800,33 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
     constexpr int kStagesPerBatch = 64 / (2 * kAlsPairs);
     // index batches: lane l of idx_cur holds entry 64 * batch + l (or -1 past the row's end, which makes the
     // gathers of those entries read zeros); idx_nxt is the batch after it
-    int idx_cur = lane < n ? idx0 : -1;
-    int idx_nxt = 64 + lane < n ? idx1 : -1;
+    const int past = FAST ? zero_row : -1;  // what an entry past the row's end reads: the zero row / the zeros through a select
+    int idx_cur = lane < n ? idx0 : past;
+    int idx_nxt = 64 + lane < n ? idx1 : past;
     int loaded = 0;  // stages whose gathers have been issued
     auto issue = [&](float (&fr)[kAlsPairs][NB]) {
         const int sb = loaded % kStagesPerBatch;
         if (sb == 0 && loaded > 0) {
             idx_cur = idx_nxt;
             const int64_t nb = (int64_t)(loaded / kStagesPerBatch + 1) * 64 + lane;
-            idx_nxt = nb < n ? fb[nb] : -1;
+            idx_nxt = nb < n ? fb[nb] : past;
         }
-        gram_load_stage<NB>(B, zeros, idx_cur, sb * 2 * kAlsPairs, d, lane, fr);
+        if (FAST)
+            gram_load_stage32<NB, FAST == 1>(B, (uint32_t)d * 4u, idx_cur, sb * 2 * kAlsPairs, lane, d, zero_row, fr);
+        else
+            gram_load_stage<NB>(B, zeros, idx_cur, sb * 2 * kAlsPairs, d, lane, fr);
         loaded++;
     };
     auto consume = [&](const float (&fr)[kAlsPairs][NB]) {
 #pragma unroll
         for (int j = 0; j < kAlsPairs; j++) {
 #pragma unroll
-            for (int b = 0; b < NB; b++) g.sum[b] += fr[j][b];
+            for (int b = 0; b < NB; b++) {
+                if (FAST)  // (kept from being paired into v_pk_add_f32, which costs beside the MFMAs: MI355X_MICROARCH.md)
+                    asm("v_add_f32 %0, %1, %0" : "+v"(g.sum[b]) : "v"(fr[j][b]));
+                else
+                    g.sum[b] += fr[j][b];
+            }
 #pragma unroll
             for (int bi = 0; bi < NB; bi++)
 #pragma unroll
@@ -898,13 +939,17 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     for (int f = 0; f < DMAX; f++)
         if (FULL || f < d) y = fmaf(mcol[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f)), y);
     float p = p0;
+    // Three operations on the chain per step (wide_sweep has the same form): every lane forms its own would-be step
+    // delta_k = (base_k - p_k) - y_k inv_k with one fused operation, lane f's is broadcast, y += delta_f M[:, f]; the new
+    // coordinate base_f - y_f inv_f is formed beside the chain.  (Four broadcasts and two more dependent operations per step
+    // before: 235 cycles per step next to the sibling wave's MFMAs, profiles/r03_zi_probe_als_prof.txt.)
+    const float gk = base - p0;
 #pragma unroll
     for (int f = 0; f < DMAX; f++) {
         if (FULL || f < d) {  // uniform; no break, so that the loop unrolls and mcol[f] is a register
-            const float yf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), f));
-            const float nf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(base), f)) -
-                             yf * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), f));
-            const float delta = nf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f));
+            const float dk = fmaf(-y, inv, gk);
+            const float nf = base - y * inv;
+            const float delta = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), f));
             y = fmaf(delta, mcol[f], y);
             p = lane == f ? nf : p;
         }
@@ -920,7 +965,7 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
                                                                  const float *__restrict__ S,
                                                                  const int32_t *__restrict__ rows, int64_t n_rows, int d,
                                                                  float w, float reg, const float *__restrict__ zeros,
-                                                                 unsigned long long *prof, int phased) {
+                                                                 unsigned long long *prof, int phased, int zero_row) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // probe only (prof != null): s_memtime ticks per wave in [0] Gram accumulation, [1] M to LDS, [2] solve; [3] rows,
@@ -967,7 +1012,12 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         GramAcc<NB> g;
         unsigned long long t0 = 0;
         if (prof) t0 = __builtin_amdgcn_s_memtime();
-        gram_accumulate<NB>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1);
+        if (zero_row >= 0 && d == 32 * NB)
+            gram_accumulate<NB, 1>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+        else if (zero_row >= 0)
+            gram_accumulate<NB, 2>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+        else
+            gram_accumulate<NB, 0>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1);
         const int64_t beg_next = ptr[u_next];
         const int64_t end_next = ptr[u_next + 1];
         if (prof) {
@@ -1037,7 +1087,7 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
                                                                    const int64_t *__restrict__ chunk_beg,
                                                                    const int32_t *__restrict__ chunk_cnt,
                                                                    int64_t n_chunks, int d, float *__restrict__ partial,
-                                                                   const float *__restrict__ zeros) {
+                                                                   const float *__restrict__ zeros, int zero_row) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
     const int64_t stride = (int64_t)d * d + d;
@@ -1045,7 +1095,12 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
         GramAcc<NB> g;
         const int32_t *fb = idx + chunk_beg[c];
         const int cn = chunk_cnt[c];
-        gram_accumulate<NB>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0]);
+        if (zero_row >= 0 && d == 32 * NB)
+            gram_accumulate<NB, 1>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
+        else if (zero_row >= 0)
+            gram_accumulate<NB, 2>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
+        else
+            gram_accumulate<NB, 0>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0]);
         float *dst = partial + c * stride;
         gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
             const int i = ci + 4 * (lane >> 5), j = cj + (lane & 31);
@@ -1178,9 +1233,19 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
 // probe: 8 counters per side in h->als_prof when the hook is on
 unsigned long long *als_prof_slot(gorse_mf *h, int side) { return g_als_prof && h->als_prof.n >= 16 ? h->als_prof.p + 8 * side : nullptr; }
 
+// the row id of the zero row behind matrix F (mf.hip) when the fast gather stage applies: offsets in 32 bits, row ids in 24; else
+// -1 (the first form of the stage)
+int als_zero_row(const gorse_mf *h, const float *F) {
+    const int64_t rows = F == h->P.p ? h->U : h->I;
+    const int d = h->d;
+    if (g_als_slow_gather || rows + 1 >= ((int64_t)1 << 24) || (rows + 1) * d * 4 >= ((int64_t)1 << 32)) return -1;
+    return (int)rows;
+}
+
 int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int64_t *ptr, const int32_t *idx, float w,
                       float reg) {
     const int d = h->d;
+    const int zrow = als_zero_row(h, B);
     gorse_mf::AlsPlan &pl = h->als_plan[side];
     const size_t lds = ((size_t)d * d + (size_t)kAlsRowWaves * (64 * kAlsDP + 64)) * sizeof(float);
     if (g_als_prof) {
@@ -1194,12 +1259,12 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
             als_row_kernel<1><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased);
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased, zrow);
         } else {
             GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)lds));
             als_row_kernel<2><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased);
+                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased, zrow);
         }
         GORSE_HIP_CHECK(hipGetLastError());
     }
@@ -1208,10 +1273,10 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_chunks, kAlsWaves), 2048);
         if (d <= 32)
             als_chunk_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p,
-                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p);
+                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow);
         else
             als_chunk_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p,
-                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p);
+                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow);
         GORSE_HIP_CHECK(hipGetLastError());
         als_long_solve_kernel<<<dim3((unsigned)std::min<int64_t>(pl.n_long, 1024)), dim3(256), 0, h->stream>>>(
             A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p);
@@ -1225,6 +1290,7 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
 // "feedback list", cut into chunks; partial Gram matrices are added in chunk order (deterministic, bitwise symmetric)
 int32_t run_gram_mfma(gorse_mf *h, const float *F, int side) {
     const int d = h->d, dd = d * d;
+    const int zrow = als_zero_row(h, F);
     gorse_mf::AlsPlan &pl = h->als_plan[side];
     GORSE_TRY(h->gram.ensure((size_t)dd));
     int tok = h->prof.begin(GORSE_PROF_ALS_GRAM, h->stream);
@@ -1237,11 +1303,11 @@ int32_t run_gram_mfma(gorse_mf *h, const float *F, int side) {
         if (d <= 32)
             als_chunk_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p,
                                                                                    pl.n_gchunks, d, h->gram_partial.p,
-                                                                                   h->als_zeros.p);
+                                                                                   h->als_zeros.p, zrow);
         else
             als_chunk_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p,
                                                                                    pl.n_gchunks, d, h->gram_partial.p,
-                                                                                   h->als_zeros.p);
+                                                                                   h->als_zeros.p, zrow);
         GORSE_HIP_CHECK(hipGetLastError());
         als_gram_reduce_kernel<<<dim3((unsigned)ceil_div(dd, 256)), dim3(256), 0, h->stream>>>(
             h->gram_partial.p, (int)pl.n_gchunks, dd, h->gram.p, stride);
@@ -1397,6 +1463,7 @@ extern "C" void gorse_hip_test_set_als_path(int32_t path) {
     g_als_phased = (path & 4) != 0;
     g_als_wide_fma = (path & 8) != 0;
     g_als_wide_probe = (path >> 4) & 3;
+    g_als_slow_gather = (path & 64) != 0;
 }
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
 extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {

@@ -237,10 +237,12 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
             GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
         }
-        GORSE_TRY(h->P.alloc((size_t)U * d));
-        GORSE_TRY(h->Q.alloc((size_t)I * d));
-        GORSE_HIP_CHECK(hipMemsetAsync(h->P.p, 0, (size_t)U * d * sizeof(float), h->stream));
-        GORSE_HIP_CHECK(hipMemsetAsync(h->Q.p, 0, (size_t)I * d * sizeof(float), h->stream));
+        // one row more than the matrix has, and it stays zero: the ALS gathers send the entries past a row's end there (row id U
+        // resp. I) instead of selecting an address per load
+        GORSE_TRY(h->P.alloc((size_t)(U + 1) * d));
+        GORSE_TRY(h->Q.alloc((size_t)(I + 1) * d));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->P.p, 0, (size_t)(U + 1) * d * sizeof(float), h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->Q.p, 0, (size_t)(I + 1) * d * sizeof(float), h->stream));
         GORSE_TRY(h->uptr.alloc((size_t)U + 1));
         GORSE_TRY(h->uidx.alloc((size_t)h->nnz));
         GORSE_TRY(h->uidx_sorted.alloc((size_t)h->nnz));
