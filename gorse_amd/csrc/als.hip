@@ -298,7 +298,7 @@ __device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float r
         // The sweep is one dependent chain through y; per step it is kept to three operations: every lane forms its own
         // would-be step delta_k = (base_k - p_k) - y_k inv_k (one fused operation on the chain), lane f's is broadcast
         // (v_readlane), and y += delta_f M[:, f].  The new coordinate p_f' = base_f - y_f inv_f is formed beside the chain, the
-        // columns of M for the next eight steps are read from LDS while the current eight run.  (profiles/r03_zc: 22.5K
+        // columns of M for the next eight steps are read from LDS while the current eight run.  (profiles/r03_zc_probe_als_wide.txt: 22.5K
         // cycles per row = 176 per step with base, y, inv and p0 of coordinate f broadcast separately in every step.)
         const float g_lo = base_lo - p0_lo, g_hi = base_hi - p0_hi;
         float p_lo = p0_lo, p_hi = p0_hi;

@@ -1668,7 +1668,7 @@ __global__ __launch_bounds__(64) void topk_tie_replay_lane_kernel(ReplayParams p
     // such entries (inner loop), then the lanes that stopped at a real push do it together.
     float rootw = kInf;  // W[0] of a non-empty heap
     int e0 = 0;
-    int nxt_i = n > 0 ? sidx[0] : 0;  // one entry ahead (16-byte groups two ahead were slower: profiles/r03_v_*)
+    int nxt_i = n > 0 ? sidx[0] : 0;  // one entry ahead (16-byte groups two ahead were slower: profiles/r03_v_kernel_stats_default.txt)
     float nxt_d = n > 0 ? sdst[0] : 0.0f;
     while (e0 < n && !undecided) {
         int64_t i = 0;
