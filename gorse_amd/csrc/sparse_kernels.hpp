@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include "rank_keys.hpp"
 
 namespace gorse {
 namespace sparse {
@@ -120,31 +121,13 @@ struct TileArgs {
     Trace *trace;                   // probe: one record per work item, or null
 };
 
-constexpr uint32_t kZeroOrd = 0x80000000u;  // ordered bits of +0
-// order-preserving bits of a score: larger float <=> larger unsigned; -0 counts as +0
-__device__ inline uint32_t score_ord(float score) {
-    uint32_t u = __float_as_uint(score);
-    if ((u << 1) == 0) u = 0;
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ inline unsigned long long make_key(uint32_t ord, int32_t row) {
-    return ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)row);
-}
-// results the reference returns (xvec.go:379-446): it ranks every admissible document, cuts to k, drops Score == 0.
-// pos / neg = admissible rows scoring above / below zero, adm = admissible rows; the rest score zero.
-__device__ inline int written(long long pos, long long neg, long long adm, int k) {
-    if (pos >= k) return k;
-    const long long zeros = adm - pos - neg;
-    long long n = pos;
-    if (pos + zeros < k) n += neg < k - pos - zeros ? neg : k - pos - zeros;
-    return (int)n;
-}
-__device__ inline float key_score(unsigned long long key) {
-    uint32_t u = (uint32_t)(key >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
-    return __uint_as_float(u);
-}
-__device__ inline int32_t key_row(unsigned long long key) { return (int32_t)(0xFFFFFFFFu - (uint32_t)key); }
+// the key encodings and the count of returned results: rank_keys.hpp (shared with the host library's CPU test hook)
+using rank::kZeroOrd;
+using rank::key_row;
+using rank::key_score;
+using rank::make_key;
+using rank::score_ord;
+using rank::written;
 
 // bitonic sort of b[0..CAP) into descending order by the 64 lanes of the workgroup; ends with a barrier
 template <int CAP>

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <limits>
 
+#include "rank_keys.hpp"
 #include "topk_internal.hpp"
 
 using namespace gorse;
@@ -95,14 +96,8 @@ constexpr int64_t kReplayChunk = 16384; // flagged queries per history sweep (hi
 constexpr int kMaxSlices = 8;           // row slices of a history sweep (see topk_tie_sort_kernel)
 constexpr int64_t kChunkQ = (int64_t)1 << 20;
 
-__device__ __forceinline__ uint32_t fkey(float x) {  // order-preserving float -> uint
-    uint32_t b = __float_as_uint(x);
-    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(uint32_t k) {
-    uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
-    return __uint_as_float(b);
-}
+using gorse::rank::fkey;      // order-preserving float -> uint of an approximate score, and back (rank_keys.hpp)
+using gorse::rank::fkey_inv;
 __device__ __forceinline__ int lane_rank(uint64_t m) {  // set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
 }
@@ -999,9 +994,8 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
                 if (e != e) {
                     s_misc[1] = 1;
                 } else {
-                    const uint32_t u = __float_as_uint(e);
-                    kreg[s] = e == 0.0f ? 0x80000000u : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
-                    ireg[s] = s_i[c] | (u == 0x80000000u ? (int)0x80000000 : 0);  // bit 31: the distance is -0
+                    kreg[s] = gorse::rank::dist_key(e);
+                    ireg[s] = s_i[c] | (gorse::rank::dist_is_negative_zero(e) ? (int)0x80000000 : 0);  // bit 31: the distance is -0
                 }
             }
         }
@@ -1049,7 +1043,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     for (int r = tid; r <= k && r < admissible; r += kBlock) {
         const uint32_t a = s_key[r];
         if ((r > 0 && s_key[r - 1] == a) || (r + 1 < admissible && s_key[r + 1] == a)) s_misc[1] = 1;
-        if (r < k && p.prune0 && a <= 0x80000000u) atomicAdd(&s_misc[0], 1);
+        if (r < k && p.prune0 && gorse::rank::dist_key_nonpositive(a)) atomicAdd(&s_misc[0], 1);
     }
     __syncthreads();
     if (s_misc[1] || top < p.expect) {  // ties, NaN, or a list that cannot hold the answer: path A
@@ -1060,9 +1054,8 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     for (int r = dropped + tid; r < top; r += kBlock) {
         const uint32_t a = s_key[r];
         const int iv = s_i[r];
-        const uint32_t u = iv < 0 ? 0x80000000u : ((a & 0x80000000u) ? (a & 0x7fffffffu) : ~a);
         p.out_idx[t * k + r - dropped] = iv & 0x7fffffff;
-        p.out_dist[t * k + r - dropped] = __uint_as_float(u);
+        p.out_dist[t * k + r - dropped] = gorse::rank::dist_from_key(a, iv < 0);
     }
     const int cnt = top - dropped;
     for (int r = cnt + tid; r < k; r += kBlock) {

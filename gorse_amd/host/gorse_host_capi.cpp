@@ -6,6 +6,7 @@
 
 #include "gorse_cf.hpp"
 #include "gorse_vectors.hpp"
+#include "../csrc/rank_keys.hpp"
 
 using namespace gorse;
 
@@ -842,4 +843,25 @@ void *gh_publish_cf(void *m, void *h, int64_t model_id, const uint8_t *hidden, i
     return out;
 }
 int32_t gh_mfusers_count(void *u) { return (int32_t)((logics::MatrixFactorizationUsers *)u)->Count(); }
+
+// CPU test hook for the ranking kernels' integer encodings (csrc/rank_keys.hpp, the very header the kernels include):
+// what = 0 fkey, 1 fkey_inv(fkey), 2 dist_key, 3 dist_from_key(dist_key, -0 flag), 4 score_ord, 5 key_score(make_key(score_ord, row))
+// -> out_u32[i]; 6 key_row(make_key(.., row)) with row = i.  Float results come back as their bits.
+void gh_test_rank_key(int32_t what, const float *x, int64_t n, uint32_t *out_u32) {
+    namespace rk = gorse::rank;
+    for (int64_t i = 0; i < n; i++) {
+        switch (what) {
+        case 0: out_u32[i] = rk::fkey(x[i]); break;
+        case 1: out_u32[i] = rk::f2u(rk::fkey_inv(rk::fkey(x[i]))); break;
+        case 2: out_u32[i] = rk::dist_key(x[i]); break;
+        case 3: out_u32[i] = rk::f2u(rk::dist_from_key(rk::dist_key(x[i]), rk::dist_is_negative_zero(x[i]))); break;
+        case 4: out_u32[i] = rk::score_ord(x[i]); break;
+        case 5: out_u32[i] = rk::f2u(rk::key_score(rk::make_key(rk::score_ord(x[i]), (int32_t)i))); break;
+        default: out_u32[i] = (uint32_t)rk::key_row(rk::make_key(rk::score_ord(x[i]), (int32_t)i)); break;
+        }
+    }
+}
+// the 64-bit sparse ranking key itself, and the number of results the reference returns (xvec.go:379-446)
+uint64_t gh_test_sparse_key(float score, int32_t row) { return gorse::rank::make_key(gorse::rank::score_ord(score), row); }
+int32_t gh_test_sparse_written(int64_t pos, int64_t neg, int64_t adm, int32_t k) { return gorse::rank::written(pos, neg, adm, k); }
 }  // extern "C"
