@@ -32,7 +32,8 @@ func (als *ALS) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 		return Score{}
 	}
 	defer hm.close()
-	score := hm.evaluate(valSet, trainSet, config.TopK, config.Candidates, NDCG, Precision, Recall)
+	const evalSeed = 0 // util.NewRandomGenerator(0) of dataset.go:244: the negatives' own stream
+	score := hm.evaluateResident(valSet, trainSet, config.TopK, config.Candidates, evalSeed, NDCG, Precision, Recall)
 	scores := []lo.Tuple2[int, float32]{{A: 0, B: score[0]}}
 	_, span := monitor.Start(ctx, "ALS.Fit", als.nEpochs)
 	defer span.End()
@@ -50,7 +51,7 @@ func (als *ALS) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 		fitTime := time.Since(fitStart)
 		if epoch%config.Verbose == 0 || epoch == als.nEpochs {
 			evalStart := time.Now()
-			score = hm.evaluate(valSet, trainSet, config.TopK, config.Candidates, NDCG, Precision, Recall)
+			score = hm.evaluateResident(valSet, trainSet, config.TopK, config.Candidates, evalSeed, NDCG, Precision, Recall)
 			scores = append(scores, lo.Tuple2[int, float32]{A: epoch, B: score[0]})
 			log.Logger().Info(fmt.Sprintf("fit als %v/%v", epoch, als.nEpochs),
 				zap.String("fit_time", fitTime.String()),

@@ -39,8 +39,9 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 	if config.Jobs <= 1 {
 		mode = C.GORSE_BPR_SEQUENTIAL // parallel.Parallel with one worker runs the samples strictly in order
 	}
+	const evalSeed = 0 // util.NewRandomGenerator(0) of dataset.go:244: the negatives' own stream
 	evalStart := time.Now()
-	score := hm.evaluate(valSet, trainSet, config.TopK, config.Candidates, NDCG, Precision, Recall)
+	score := hm.evaluateResident(valSet, trainSet, config.TopK, config.Candidates, evalSeed, NDCG, Precision, Recall)
 	scores := []lo.Tuple2[int, float32]{{A: 0, B: score[0]}}
 	log.Logger().Debug(fmt.Sprintf("fit bpr %v/%v", 0, bpr.nEpochs),
 		zap.String("eval_time", time.Since(evalStart).String()),
@@ -75,7 +76,7 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 		fitTime := time.Since(fitStart)
 		if epoch%config.Verbose == 0 || epoch == bpr.nEpochs {
 			evalStart = time.Now()
-			score = hm.evaluate(valSet, trainSet, config.TopK, config.Candidates, NDCG, Precision, Recall)
+			score = hm.evaluateResident(valSet, trainSet, config.TopK, config.Candidates, evalSeed, NDCG, Precision, Recall)
 			scores = append(scores, lo.Tuple2[int, float32]{A: epoch, B: score[0]})
 			log.Logger().Info(fmt.Sprintf("fit bpr %v/%v", epoch, bpr.nEpochs),
 				zap.String("fit_time", fitTime.String()),

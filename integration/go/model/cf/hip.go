@@ -57,6 +57,7 @@ func packRows(rows [][]float32, d int) []float32 {
 type hipModel struct {
 	h            *C.gorse_mf
 	flatP, flatQ []float32
+	negativesResident bool // gorse_mf_sample_user_negatives has run on this handle (evaluateResident)
 	cancel       *C.int32_t // C memory: a goroutine sets it when ctx is done, the library polls it between launches
 	stop         chan struct{}
 }
@@ -126,6 +127,46 @@ func (m *hipModel) evaluate(testSet, trainSet dataset.CFSplit, topK, numCandidat
 	if rc := C.gorse_mf_rank(m.h, C.int64_t(len(users)), (*C.int32_t)(unsafe.Pointer(&users[0])), (*C.int64_t)(unsafe.Pointer(&candPtr[0])),
 		(*C.int32_t)(unsafe.Pointer(&cand[0])), C.int32_t(topK), (*C.int32_t)(unsafe.Pointer(&rank[0])), (*C.int32_t)(unsafe.Pointer(&rankLen[0]))); rc != 0 {
 		panic(hipError("gorse_mf_rank", rc))
+	}
+	for t, u := range users {
+		targetSet := mapset.NewSet(testSet.GetUserFeedback()[u]...)
+		rankList := rank[t*topK : t*topK+int(rankLen[t])]
+		for i, metric := range scorers {
+			sum[i] += metric(targetSet, rankList)
+		}
+	}
+	floats.MulConst(sum, 1/float32(len(users)))
+	return sum
+}
+
+// evaluateResident is the same Evaluate with the negatives drawn ON THE DEVICE (gorse_mf_sample_user_negatives: dataset.go:242-253
+// over RandomGenerator.SampleInt32, one Philox stream per test user -- the host's RandomGenerator(seed, epoch, sample) in the C++
+// twin draws the same lists) and the candidate lists left there: the first call of a Fit samples, every later evaluation only ranks
+// (gorse_mf_rank_resident), so nothing but topK ids per user crosses PCIe between two epochs.  The reference caches the negatives in
+// the Dataset the same way (dataset.go:243: drawn once, `if len(d.negatives) == 0`).
+func (m *hipModel) evaluateResident(testSet, trainSet dataset.CFSplit, topK, numCandidates int, seed uint64, scorers ...Metric) []float32 {
+	if !m.negativesResident {
+		indptr, indices := flatten(testSet.GetUserFeedback())
+		if rc := C.gorse_mf_sample_user_negatives(m.h, (*C.int64_t)(unsafe.Pointer(&indptr[0])), (*C.int32_t)(unsafe.Pointer(&indices[0])),
+			C.int32_t(numCandidates), C.uint64_t(seed), nil, nil); rc != 0 {
+			panic(hipError("gorse_mf_sample_user_negatives", rc))
+		}
+		m.negativesResident = true
+	}
+	var nUsers, nCand C.int64_t
+	if rc := C.gorse_mf_resident_candidates(m.h, &nUsers, &nCand); rc != 0 {
+		panic(hipError("gorse_mf_resident_candidates", rc))
+	}
+	sum := make([]float32, len(scorers))
+	if nUsers == 0 {
+		return sum
+	}
+	users := make([]int32, int(nUsers))
+	rank := make([]int32, int(nUsers)*topK)
+	rankLen := make([]int32, int(nUsers))
+	if rc := C.gorse_mf_rank_resident(m.h, C.int32_t(topK), (*C.int32_t)(unsafe.Pointer(&users[0])), (*C.int32_t)(unsafe.Pointer(&rank[0])),
+		(*C.int32_t)(unsafe.Pointer(&rankLen[0]))); rc != 0 {
+		panic(hipError("gorse_mf_rank_resident", rc))
 	}
 	for t, u := range users {
 		targetSet := mapset.NewSet(testSet.GetUserFeedback()[u]...)
