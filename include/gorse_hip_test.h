@@ -80,7 +80,11 @@ void gorse_hip_test_set_sparse_atomic(int32_t mode);
 int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /*host or NULL*/, int64_t cap);
 /* ALS row-solve choice: 0 = automatic (Gram form: on the fp32 MFMA for nFactors <= 64, als_wide_kernel for 65..128; the residual
  * sweep beyond), 1 = always the residual sweep (the reference's own recurrence), 2 = always the MFMA Gram form (nFactors <= 64).
- * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one. */
+ * Both meet the 1e-4 relative bar; the hook lets the parity tests drive each one.  Probe bits on top of the choice: 4 = the
+ * waves of als_row_kernel's workgroup accumulate and solve in lockstep, 8 = als_wide_kernel builds G by fused multiply-adds
+ * (round 2) instead of the fp32 MFMA, 16 / 32 = timing probes of als_wide_kernel (no sweep / S not added: results undefined),
+ * 64 = the first form of the Gram kernels' gather stage whatever the shape (the product takes it for factor matrices of
+ * >= 4 GB or >= 2^24 rows; otherwise 32-bit offsets from a scalar base, see csrc/als.hip gram_load_stage32). */
 void gorse_hip_test_set_als_path(int32_t path);
 /* thresholds of the Gram-form row plan, for handles created AFTERWARDS: rows longer than long_row feedbacks
  * are cut into chunks of `chunk` entries (defaults 4096 / 4096; <= 0 restores a default).  Lets small test

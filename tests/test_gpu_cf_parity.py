@@ -461,8 +461,9 @@ def als_paths():
 
 
 # path 1 = the reference's residual recurrence (als_sweep_kernel), path 2 = the Gram form on the fp32 MFMA
-# (als_row_kernel / als_chunk_kernel + als_long_solve_kernel); 0 = what the product picks
-@pytest.mark.parametrize("path", [0, 1, 2])
+# (als_row_kernel / als_chunk_kernel + als_long_solve_kernel); 0 = what the product picks; 2 | 64 = the Gram form with the
+# first form of its gather stage (what matrices of >= 4 GB or >= 2^24 rows take; the default is the 32-bit-offset stage)
+@pytest.mark.parametrize("path", [0, 1, 2, 2 | 64])
 @pytest.mark.parametrize("d", [16, 64, 32, 24, 40, 7])
 def test_als_epoch_parity(oracle, small, d, path, als_paths):
     # ALS is deterministic w.r.t. Jobs: <= 1e-4 relative after 3 epochs
@@ -481,11 +482,12 @@ def test_als_epoch_parity(oracle, small, d, path, als_paths):
     assert_als_close(gQ, eQ, "Q")
 
 
+@pytest.mark.parametrize("wide_path", [0, 8])
 @pytest.mark.parametrize("d", [65, 96, 128])
-def test_als_wide_factors(oracle, small, d, als_paths):
-    """64 < nFactors <= 128: the product's choice is the Gram form of als_wide_kernel (one workgroup per row) for rows of up to
-    4096 entries and the residual sweep for longer ones; both against the oracle, and against the residual sweep alone"""
-    capi.lib().gorse_hip_test_set_als_path(0)
+def test_als_wide_factors(oracle, small, d, wide_path, als_paths):
+    """64 < nFactors <= 128: the product's choice is the Gram form of als_wide_kernel (one workgroup per row, G on the fp32 MFMA;
+    wide_path 8: by fused multiply-adds, the round-2 form kept as the probe's comparison), long rows by chunks; against the oracle"""
+    capi.lib().gorse_hip_test_set_als_path(wide_path)
     mf, P, Q = make_mf(small, d, std=0.1)
     eP, eQ = P, Q
     for _ in range(3):
