@@ -944,14 +944,17 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     // coordinate base_f - y_f inv_f is formed beside the chain.  (Four broadcasts and two more dependent operations per step
     // before: 235 cycles per step next to the sibling wave's MFMAs, profiles/r03_zi_probe_als_prof.txt.)
     const float gk = base - p0;
+    // (the lane number is made opaque once per row: hipcc otherwise keeps the 64 masks `lane == f` in scalar registers across
+    // the rows of the kernel, spills them into a vector register and reloads two words per step)
+    int lane_here = lane;
+    asm volatile("" : "+v"(lane_here));
 #pragma unroll
     for (int f = 0; f < DMAX; f++) {
         if (FULL || f < d) {  // uniform; no break, so that the loop unrolls and mcol[f] is a register
             const float dk = fmaf(-y, inv, gk);
-            const float nf = base - y * inv;
             const float delta = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), f));
             y = fmaf(delta, mcol[f], y);
-            p = lane == f ? nf : p;
+            p = lane_here == f ? p0 + dk : p;  // p_f' = p_f + delta_f (lane f's own dk IS delta_f)
         }
     }
     if (lane_in) a[lane] = p;
@@ -1056,6 +1059,8 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         __builtin_amdgcn_s_setprio(3);
         if (d == 32 * NB)
             als_solve_row<32 * NB, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+        else if (NB == 1 && d == 16)  // the reference's default nFactors: straight-line too
+            als_solve_row<16, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         else
             als_solve_row<32 * NB, true, false>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         __builtin_amdgcn_s_setprio(0);
