@@ -145,7 +145,8 @@ __device__ __forceinline__ void update_elem(float *pu, float *qi, float *qj, int
 // deep atomic queue, and every gather of that row -- and the retirement of every wave that updated it --
 // waits in it (measured: positive-item atomics redirected away from the rows being read = 2.0x, spread
 // over 8 rows each = 2.7x on S-ml1m; profiles/r01_b_probe_rep.txt).  So the positive-item update of a HOT
-// item (share of the training feedback >= 1/2048, chosen at create time) lands in one of kHotReplicas
+// item (share of the training feedback >= 1/8192, chosen at create time) -- and, in the user-run schedule, the update of a
+// hot item drawn as the NEGATIVE -- lands in one of kHotReplicas
 // private rows picked by the group id, and FOLDER workgroups of the same launch keep draining the
 // replicas into the real rows with one combined atomic per element and pass.  Q stays the only source of
 // truth for every reader; a hot row's update becomes visible one folder pass (tens of microseconds) late,
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
                                                                  const int32_t *__restrict__ sj,
                                                                  const int32_t *__restrict__ off, int32_t U, int d,
                                                                  float lr, float reg, int exp_mode, double *loss,
-                                                                 HotRows hot, int folders) {
+                                                                 HotRows hot, int folders, int neg_replicas) {
     if ((int)blockIdx.x < folders) {
         const int workers = (int)gridDim.x - folders;
         const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         int i1 = si[at(beg + 1)], j1 = sj[at(beg + 1)];
         int i2 = si[at(beg + 2)], j2 = sj[at(beg + 2)];
         int slot = slot_of[hot.n_hot > 0 ? i : beg], slot1 = slot_of[hot.n_hot > 0 ? i1 : beg];
+        int slotj = slot_of[hot.n_hot > 0 ? j : beg], slotj1 = slot_of[hot.n_hot > 0 ? j1 : beg];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         for (int s = beg; s < end; s++) {
             const int i3 = si[at(s + 3)], j3 = sj[at(s + 3)];
             const int slot2 = slot_of[hot.n_hot > 0 ? i2 : beg];
+            const int slotj2 = slot_of[hot.n_hot > 0 ? j2 : beg];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i2 * d + 16 * c + lane);
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             }
             float *qi = Q + (int64_t)i * d, *qj = Q + (int64_t)j * d;
             if (hot.n_hot > 0 && slot >= 0) qi = hot.rep + ((int64_t)slot * kHotReplicas + (group & (kHotReplicas - 1))) * d;
+            if (hot.n_hot > 0 && slotj >= 0 && neg_replicas) qj = hot.rep + ((int64_t)slotj * kHotReplicas + (group & (kHotReplicas - 1))) * d;
             const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
             const float ex = bpr_exp(-diff, exp_mode);
             const float grad = ex / (1.0f + ex);
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             }
             i = i1, j = j1, i1 = i2, j1 = j2, i2 = i3, j2 = j3;
             slot = slot1, slot1 = slot2;
+            slotj = slotj1, slotj1 = slotj2;
         }
 #pragma unroll
         for (int c = 0; c < NC; c++)  // the only writer of this row in the launch
@@ -527,7 +532,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     dim3 grid((unsigned)blocks), block(kBlock);
 #define LAUNCH(NC)                                                                                                     \
     bpr_update_user_kernel<NC><<<grid, block, 0, st>>>(h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket,         \
-                                                       (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders)
+                                                       (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, (g_variant & (1 << 25)) ? 0 : 1)
     if (d == 16)
         LAUNCH(1);
     else if (d == 32)

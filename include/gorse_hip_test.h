@@ -19,7 +19,8 @@ extern "C" {
 void gorse_hip_test_set_exact_exp(int32_t mode);
 /* probe-only switches of the Hogwild update path (bit 0: plain instead of L1-bypassing loads; bits 1/2/3:
  * skip the writes to P / Q[i] / Q[j]; bit 5: no hot-row replicas = the round-1 kernel); bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
- * register-resident over a user's samples), bit 28: force the per-sample schedule, bit 29: the user sort ranks
+ * register-resident over a user's samples), bit 25: the user-run schedule sends only the POSITIVE item's update of a hot item
+ * through the replicas (round 2), bit 28: force the per-sample schedule, bit 29: the user sort ranks
  * samples in stream order (single thread; makes a run's order deterministic for the parity test).  Used by
  * scripts/gpu_probe_*.py and the tests; 0 (the default) is the only value the product ever runs with. */
 void gorse_hip_test_set_variant(int32_t variant);

@@ -17,7 +17,7 @@ L = capi.lib()
 EPOCHS = 8
 PER_SAMPLE, USERS, NO_REPLICAS, SORT_ON_UPDATE_STREAM = 1 << 28, 128, 32, 1 << 27
 variants = [(PER_SAMPLE, "per-sample groups + replicas"), (PER_SAMPLE | NO_REPLICAS, "per-sample groups, no replicas"),
-            (USERS, "user runs, sort under the update"),
+            (USERS, "user runs, sort under the update"), (USERS | (1 << 25), "user runs, negatives NOT through the replicas"),
             (USERS | SORT_ON_UPDATE_STREAM, "user runs, sort between updates"), (USERS | NO_REPLICAS, "user runs, no replicas")]
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 cases = [("ml1m", lambda: synth.s_ml1m(), 64), ("ml100k", lambda: synth.s_ml100k(), 16)]
