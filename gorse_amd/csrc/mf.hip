@@ -269,7 +269,7 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_TRY(als_build_plan(h, 0, user_indptr, U, 0, U));
             GORSE_TRY(als_build_plan(h, 1, item_indptr, I, 0, I));
         }
-        {   // hot items: share of the training feedback >= 1/8192, at most 1024 of them (bpr.hip, HotRows)
+        {   // hot items: share of the training feedback >= 1/8192 (and >= 64 feedbacks), at most 1024 and a quarter of the items (bpr.hip, HotRows)
             std::vector<int64_t> cnt((size_t)I, 0);
             if (h->nnz < ((int64_t)1 << 26) || I > ((int64_t)1 << 22)) {
                 for (int64_t t = 0; t < h->nnz; t++) cnt[user_indices[t]]++;
@@ -284,9 +284,13 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
                     if (!pc.empty())
                         for (int64_t i = 0; i < I; i++) cnt[(size_t)i] += pc[(size_t)i];
             }
-            const int64_t hdiv = 8192;  // (2048 until round 3: with the negatives routed through the replicas too, 8192 is 6 % faster
-            const size_t hcap = 1024;   //  at C2, profiles/r03_zx_probe_bpr_hot.txt; every item hot = too stale: the fit diverges)
-            const int64_t thr = std::max<int64_t>(2, (h->nnz + hdiv - 1) / hdiv);
+            // 1/2048 until round 3: with the negatives routed through the replicas too, 1/8192 is 6 % faster at C2
+            // (profiles/r03_zx_probe_bpr_hot.txt).  A replica's content reaches Q one folder pass late, so the hot items stay a
+            // minority: at least 64 feedbacks, at most a quarter of the items (S-ml100k with two thirds of its items hot lost
+            // 0.011 of NDCG@10 in the per-sample schedule; with every item hot S-ml1m's fit diverges)
+            const int64_t hdiv = 8192;
+            const size_t hcap = (size_t)std::min<int64_t>(1024, std::max<int64_t>(1, I / 4));
+            const int64_t thr = std::max<int64_t>(64, (h->nnz + hdiv - 1) / hdiv);
             std::vector<int32_t> hot;
             for (int64_t i = 0; i < I; i++)
                 if (cnt[i] >= thr) hot.push_back((int32_t)i);
