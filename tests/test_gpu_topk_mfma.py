@@ -193,6 +193,28 @@ def test_history_sweep_in_row_slices_and_the_replay_shortcut(oracle, variant, me
         assert c2[q] == ei.size and np.array_equal(i2[q, :c2[q]], ei) and np.array_equal(bits(d2[q, :c2[q]]), bits(ed))
 
 
+@pytest.mark.parametrize("k", [130, 250])
+def test_tie_replay_with_large_k(oracle, k):
+    """k + 1 > 128 heap slots per query: the lane-per-query replay then takes 32 queries per workgroup instead of 64 (its LDS
+    columns grow with k); small-integer vectors make nearly every query a tie query."""
+    rng = np.random.default_rng(500 + k)
+    N, d = 9000, 6
+    X = rng.integers(-4, 5, (N, d)).astype(np.float32)
+    capi.lib().gorse_hip_test_set_topk_variant(V_SLICES8)
+    try:
+        t = capi.TopK(X, capi.METRIC_NEG_DOT)
+        qs = rng.choice(N, 96, replace=False)
+        idx, dist, cnt = t.search_index(qs, k)
+        n_scan, n_replay = t.last_stats()
+    finally:
+        capi.lib().gorse_hip_test_set_topk_variant(0)
+    for r, q in enumerate(qs):
+        ei, ed = oracle.search_index(X, capi.METRIC_NEG_DOT, int(q), k)
+        assert cnt[r] == ei.size and np.array_equal(idx[r, :cnt[r]], ei), (q, n_scan, n_replay)
+        assert np.array_equal(bits(dist[r, :cnt[r]]), bits(ed))
+    assert n_replay > 50, (n_scan, n_replay)
+
+
 def test_duplicates_and_overflowing_lists(oracle):
     # 700 copies of one vector: every list holds > kCap - 128 equal scores -> overflow flag -> scan
     rng = np.random.default_rng(5)
