@@ -411,7 +411,8 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         int i1 = si[at(beg + 1)], j1 = sj[at(beg + 1)];
         int i2 = si[at(beg + 2)], j2 = sj[at(beg + 2)];
         int slot = slot_of[hot.n_hot > 0 ? i : beg], slot1 = slot_of[hot.n_hot > 0 ? i1 : beg];
-        int slotj = slot_of[hot.n_hot > 0 ? j : beg], slotj1 = slot_of[hot.n_hot > 0 ? j1 : beg];
+        // (not routed: the positive's word again -- in cache -- so that every path issues the same loads from a valid address)
+        int slotj = slot_of[hot.n_hot > 0 ? (neg_replicas ? j : i) : beg], slotj1 = slot_of[hot.n_hot > 0 ? (neg_replicas ? j1 : i1) : beg];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         for (int s = beg; s < end; s++) {
             const int i3 = si[at(s + 3)], j3 = sj[at(s + 3)];
             const int slot2 = slot_of[hot.n_hot > 0 ? i2 : beg];
-            const int slotj2 = slot_of[hot.n_hot > 0 ? j2 : beg];
+            const int slotj2 = slot_of[hot.n_hot > 0 ? (neg_replicas ? j2 : i2) : beg];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i2 * d + 16 * c + lane);
@@ -529,10 +530,13 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
         GORSE_HIP_CHECK(hipMemsetAsync(h->hot_done.p, 0, sizeof(int32_t), st));
     }
     blocks += folders;
+    // the negative's slot look-up is one more gather per sample: only where a draw has a fair chance of meeting a hot item (C2: a
+    // quarter of the items are hot; at the 10M x 1M set one in ten thousand, and the look-up cost 4 % of the epoch)
+    const int neg_rep = !(g_variant & (1 << 25)) && (int64_t)hot.n_hot * 64 >= h->I ? 1 : 0;
     dim3 grid((unsigned)blocks), block(kBlock);
 #define LAUNCH(NC)                                                                                                     \
     bpr_update_user_kernel<NC><<<grid, block, 0, st>>>(h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket,         \
-                                                       (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, (g_variant & (1 << 25)) ? 0 : 1)
+                                                       (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, neg_rep)
     if (d == 16)
         LAUNCH(1);
     else if (d == 32)
