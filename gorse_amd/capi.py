@@ -111,6 +111,9 @@ SIGNATURES = {
     "gorse_hip_test_set_als_plan": (None, [C.c_int32, C.c_int32]),
     "gorse_hip_test_als_profile": (C.c_int32, [_vp, C.c_int32, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_set_bpr_chunk": (None, [C.c_int64]),
+    "gorse_hip_test_bpr_prepare_chunk": (C.c_int32, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
+    "gorse_hip_test_set_bpr_tuning": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gorse_hip_test_set_bpr_cold_window": (None, [C.c_int64]),
 }
 
 
@@ -249,6 +252,15 @@ class MF:
         check(lib().gorse_bpr_sample_triplets(self.h, n, seed, epoch, sample_base, _p(u, _i32p), _p(i, _i32p),
                                               _p(j, _i32p)))
         return u, i, j
+
+    def bpr_prepare_chunk(self, n, seed, epoch, sample_base=0):
+        """test hook: (run offsets U + 2, positives n, negatives n) of the user-run schedule's preparation of one chunk"""
+        off = np.empty(self.U + 2, np.int32)
+        si = np.empty(n, np.int32)
+        sj = np.empty(n, np.int32)
+        check(lib().gorse_hip_test_bpr_prepare_chunk(self.h, n, seed, epoch, sample_base, _p(off, _i32p), _p(si, _i32p),
+                                                     _p(sj, _i32p)))
+        return off, si, sj
 
     def bpr_apply_triplets(self, u, i, j, lr, reg, mode):
         u, i, j = _arr(u, np.int32), _arr(i, np.int32), _arr(j, np.int32)

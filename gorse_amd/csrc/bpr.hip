@@ -87,6 +87,88 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(int32_t U, int32_t I, c
     }
 }
 
+// ---- sampling for the user-run schedule: user first, items by run -----------------------------
+// The same triplets as bpr_sample_kernel (sample s = the Philox stream keyed by (seed, epoch, sample_base + s)), produced in two
+// passes so that what is random about the memory accesses shrinks from ~13 cache lines per sample to ~3:
+//   bpr_sample_user_kernel  : sample s draws its USER only (model.go:452-458; one look at the row pointers) and takes its
+//                             arrival rank in that user's run (the count pass of the counting sort by user);
+//   scan + bpr_scatter_ids  : position of sample s in the user-sorted order -> perm[position] = s (4 bytes scattered per
+//                             sample instead of the whole triplet);
+//   bpr_sample_items_kernel : one 16-lane group per USER walks the user's run: every lane replays the stream of one sample up
+//                             to the user draw (no memory: the first non-empty row drawn IS the user) and draws the positive
+//                             and the negative (model.go:459-468) -- the user's two item rows are read by all samples of the
+//                             run while they sit in the cache -- and writes (i, j) straight to the sorted position.
+// A sample whose negative cannot be found (kMaxDraws rejections: a user holding nearly every item) keeps its place in the run
+// with j = -1; bpr_update_user_kernel skips it.
+__global__ __launch_bounds__(256) void bpr_sample_user_kernel(int32_t U, const int64_t *__restrict__ uptr, uint64_t seed,
+                                                              uint64_t epoch, int64_t sample_base, int64_t n,
+                                                              int32_t *__restrict__ key, int32_t *__restrict__ fail_count,
+                                                              int32_t *__restrict__ bucket, int32_t *__restrict__ rank) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        Philox g;
+        g.init(seed, epoch, (uint64_t)(sample_base + s));
+        int32_t u = -1;
+        for (int t = 0; t < kMaxDraws; t++) {
+            const int32_t cu = g.int31n(U);
+            if (uptr[cu + 1] > uptr[cu]) {
+                u = cu;
+                break;
+            }
+        }
+        if (u < 0) atomicAdd(fail_count, 1);
+        key[s] = u;
+        rank[s] = atomicAdd(&bucket[u < 0 ? U : u], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_scatter_ids_kernel(const int32_t *__restrict__ key, const int32_t *__restrict__ rank,
+                                                              const int32_t *__restrict__ bucket, int64_t n, int32_t U,
+                                                              int32_t *__restrict__ perm) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t k = key[s] < 0 ? U : key[s];
+        perm[(int64_t)bucket[k] + rank[s]] = (int32_t)s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void bpr_sample_items_kernel(int32_t U, int32_t I, const int64_t *__restrict__ uptr,
+                                                                  const int32_t *__restrict__ uidx,
+                                                                  const int32_t *__restrict__ usorted, uint64_t seed,
+                                                                  uint64_t epoch, int64_t sample_base,
+                                                                  const int32_t *__restrict__ off,
+                                                                  const int32_t *__restrict__ perm, int32_t *__restrict__ si,
+                                                                  int32_t *__restrict__ sj, int32_t *__restrict__ fail_count) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int64_t group = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
+    const int64_t ngroups = (int64_t)gridDim.x * kGroupsPerBlock;
+    for (int64_t u = group; u < U; u += ngroups) {
+        const int beg = off[u], end = off[u + 1];
+        if (beg >= end) continue;
+        const int64_t rbeg = uptr[u];
+        const int64_t cnt = uptr[u + 1] - rbeg;
+        for (int t = beg + lane; t < end; t += kGroup) {
+            Philox g;
+            g.init(seed, epoch, (uint64_t)(sample_base + perm[t]));
+            // the user draw again: rows drawn before u were empty (u is the first non-empty one), no look-up needed
+            for (int k = 0; k < kMaxDraws; k++)
+                if (g.int31n(U) == (int32_t)u) break;
+            int32_t pi = uidx[rbeg + g.int31n((int32_t)cnt)], nj = -1;
+            for (int k = 0; k < kMaxDraws; k++) {
+                const int32_t c = g.int31n(I);
+                if (!row_contains(usorted + rbeg, cnt, c)) {
+                    nj = c;
+                    break;
+                }
+            }
+            if (nj < 0) {
+                atomicAdd(fail_count, 1);
+                pi = -1;
+            }
+            si[t] = pi;
+            sj[t] = nj;
+        }
+    }
+}
+
 // ---- memory access flavours ------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ float load_row(const float *p, int variant = 0) {
@@ -161,19 +243,35 @@ struct HotRows {
     float *rep;            // n_hot x kHotReplicas x d, all zero outside an update launch
     int32_t *done;         // worker workgroups that have finished (zeroed before the launch)
     int n_hot;
+    int64_t stride_s, stride_r;  // replica r of slot s starts at rep + s * stride_s + r * stride_r
+    int fold_check;        // folder passes read a replica word before exchanging it (an untouched word costs a load, not an atomic)
+    int fold_sleep;        // s_sleep argument between folder passes
 };
 
+__device__ __forceinline__ void folder_sleep(int n) {
+    for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(8);
+}
 // one folder pass: (slot, element) pairs strided over the folder threads
 __device__ __forceinline__ void fold_pass(const HotRows &hot, float *Q, int d, int64_t tid, int64_t nthreads) {
     const int64_t work = (int64_t)hot.n_hot * d;
     for (int64_t w = tid; w < work; w += nthreads) {
         const int64_t slot = w / d;
         const int e = (int)(w - slot * d);
-        float *r0 = hot.rep + slot * kHotReplicas * d + e;
+        float *r0 = hot.rep + slot * hot.stride_s + e;
         float v[kHotReplicas];
+        if (hot.fold_check) {
 #pragma unroll
-        for (int r = 0; r < kHotReplicas; r++)
-            v[r] = __hip_atomic_exchange(r0 + (int64_t)r * d, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int r = 0; r < kHotReplicas; r++)
+                v[r] = __hip_atomic_load(r0 + r * hot.stride_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int r = 0; r < kHotReplicas; r++)
+                if (v[r] != 0.0f)
+                    v[r] = __hip_atomic_exchange(r0 + r * hot.stride_r, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+            for (int r = 0; r < kHotReplicas; r++)
+                v[r] = __hip_atomic_exchange(r0 + r * hot.stride_r, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         float sum = 0.0f;
 #pragma unroll
         for (int r = 0; r < kHotReplicas; r++) sum += v[r];
@@ -198,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
         for (int pass = 0; pass < (1 << 16); pass++) {
             fold_pass(hot, Q, d, tid, nthreads);
             if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
-            __builtin_amdgcn_s_sleep(8);
+            folder_sleep(hot.fold_sleep);
         }
         return;
     }
@@ -217,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
         float *qiw = qi;  // where the positive item's update lands
         if (MODE == MODE_ATOMIC && hot.n_hot > 0) {
             const int slot = hot.slot[i];
-            if (slot >= 0) qiw = hot.rep + ((int64_t)slot * kHotReplicas + (group & (kHotReplicas - 1))) * d;
+            if (slot >= 0) qiw = hot.rep + (int64_t)slot * hot.stride_s + (int64_t)(group & (kHotReplicas - 1)) * hot.stride_r;
         }
         if constexpr (NC > 0) {
             float p[NC], a[NC], b[NC];
@@ -264,12 +362,12 @@ __global__ __launch_bounds__(256) void bpr_fold_kernel(HotRows hot, float *Q, in
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < work; w += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = w / d;
         const int e = (int)(w - slot * d);
-        float *r0 = hot.rep + slot * kHotReplicas * d + e;
+        float *r0 = hot.rep + slot * hot.stride_s + e;
         float sum = 0.0f;
 #pragma unroll
         for (int r = 0; r < kHotReplicas; r++) {
-            sum += r0[(int64_t)r * d];
-            r0[(int64_t)r * d] = 0.0f;
+            sum += r0[r * hot.stride_r];
+            r0[r * hot.stride_r] = 0.0f;
         }
         if (sum != 0.0f) Q[(int64_t)hot.items[slot] * d + e] += sum;
     }
@@ -372,7 +470,19 @@ __global__ __launch_bounds__(256) void bpr_scatter_by_kernel(const int32_t *__re
 // gathers disappear.  q_i / q_j are gathered one sample ahead of the arithmetic and updated with atomics exactly as
 // in bpr_update_kernel (hot positive items through the replicas).  Users are drawn uniformly (model.go:452-458), so
 // the runs are Poisson(N / U)-sized: balanced without any work splitting.
-template <int NC>
+// Item classes (hot.slot): >= 0 = replica slot of a HOT item, kWarm = fp32 atomics straight onto the row, kCold = an item whose
+// row is touched so rarely (expected touches per `cold window` samples < 1, gorse_mf_create) that the reference's own unlocked
+// load / fma / store (model.go:473-488 under parallel.go:44-81) loses next to nothing: its update is ONE write-through store of
+// fma(t, lr, row) instead of d atomic dwords.  ST selects which side may take that route: ST_NEG the negative, ST_POS the
+// positive, ST_LIVE re-reads the row just before the store instead of adding to the snapshot gathered two samples earlier
+// (diagnostic: a shorter window in which another group's update can be overwritten, one more gather per row).
+constexpr int kWarm = -1, kCold = -2;
+constexpr int ST_NEG = 1, ST_POS = 2, ST_LIVE = 4;
+
+// D8: nFactors = 8 (the width of model_test.go:35-48): lanes 0..7 of the group own the eight elements -- the unfused 8-lane tail of
+// the AVX512 kernels (floats_avx512.c:350-358, VecShape::unfused) -- and lanes 8..15 mirror them (the reduction needs the products
+// replicated there); only lanes 0..7 write.
+template <int NC, int ST, bool D8 = false>
 __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float *Q, const int32_t *__restrict__ si,
                                                                  const int32_t *__restrict__ sj,
                                                                  const int32_t *__restrict__ off, int32_t U, int d,
@@ -384,82 +494,138 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         for (int pass = 0; pass < (1 << 16); pass++) {
             fold_pass(hot, Q, d, tid, nthreads);
             if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
-            __builtin_amdgcn_s_sleep(8);
+            folder_sleep(hot.fold_sleep);
         }
         return;
     }
-    const int lane = threadIdx.x & (kGroup - 1);
+    const int glane = threadIdx.x & (kGroup - 1);
+    const int lane = D8 ? (glane & 7) : glane;   // element owned inside a 16-float chunk
+    const bool writer = !D8 || glane < 8;
+    auto mad = [](float x, float y, float z) { return D8 ? x * y + z : fmaf(x, y, z); };
     const int gib = threadIdx.x / kGroup;
     const int64_t group = (int64_t)((int)blockIdx.x - folders) * kGroupsPerBlock + gib;
     const int64_t ngroups = (int64_t)((int)gridDim.x - folders) * kGroupsPerBlock;
     const float nreg = -reg;
     double my_loss = 0.0;
+    // which class look-ups this launch needs (every path issues the same loads from a valid address: a look-up nobody needs
+    // reads a word that is in cache anyway)
+    const bool look_i = hot.n_hot > 0 || (ST & ST_POS);
+    const bool look_j = (hot.n_hot > 0 && neg_replicas) || (ST & ST_NEG);
+    const int32_t *slot_of = (look_i || look_j) ? hot.slot : si;
+    const int64_t rep_r = (int64_t)(group & (kHotReplicas - 1)) * hot.stride_r;
+    // the items of this group's last two samples: a row one of them wrote is NOT in the snapshot of the current sample (gathered
+    // two samples ago), so its update goes through an atomic whatever its class -- a store would overwrite the group's own work
+    int im1 = -1, jm1 = -1, im2 = -1, jm2 = -1;
     for (int64_t u = group; u < U; u += ngroups) {
         const int beg = off[u], end = off[u + 1];
         if (beg >= end) continue;
         float *pu = P + u * d;
         // item rows are gathered TWO samples ahead of the arithmetic (a/b: this sample, a1/b1: the next, a2/b2 in
-        // flight), their indices THREE ahead and the hot-row slot of a positive item one ahead; positions past the run's end
+        // flight), their indices THREE ahead and the class of an item one ahead; positions past the run's end
         // re-read the last sample (result unused).  Nothing is used in the iteration that loads it: the counter the waits go
         // by also counts the atomics, so a wait for a load issued after them is a wait for their acknowledgement from L2 --
         // once per sample in the first form of this loop (s_waitcnt vmcnt(0) behind the index loads and behind hot.slot[i]).
         float p[NC], a[NC], b[NC], a1[NC], b1[NC], a2[NC], b2[NC];
         const int last = end - 1;
         auto at = [&](int s) { return s <= last ? s : last; };
-        const int32_t *slot_of = hot.n_hot > 0 ? hot.slot : si;  // without hot rows: any readable word, the value is not used
+        auto cl = [](int x) { return x < 0 ? 0 : x; };  // a skipped sample (i = j = -1) gathers row 0, its results are not used
+        auto idx_i = [&](int i_, int j_) { return look_i ? cl(i_) : (look_j ? cl(j_) : beg); };
+        auto idx_j = [&](int i_, int j_) { return look_j ? cl(j_) : (look_i ? cl(i_) : beg); };
         int i = si[beg], j = sj[beg];
         int i1 = si[at(beg + 1)], j1 = sj[at(beg + 1)];
         int i2 = si[at(beg + 2)], j2 = sj[at(beg + 2)];
-        int slot = slot_of[hot.n_hot > 0 ? i : beg], slot1 = slot_of[hot.n_hot > 0 ? i1 : beg];
-        // (not routed: the positive's word again -- in cache -- so that every path issues the same loads from a valid address)
-        int slotj = slot_of[hot.n_hot > 0 ? (neg_replicas ? j : i) : beg], slotj1 = slot_of[hot.n_hot > 0 ? (neg_replicas ? j1 : i1) : beg];
+        int slot = slot_of[idx_i(i, j)], slot1 = slot_of[idx_i(i1, j1)];
+        int slotj = slot_of[idx_j(i, j)], slotj1 = slot_of[idx_j(i1, j1)];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
-            a[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i * d + 16 * c + lane);
-            b[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j * d + 16 * c + lane);
-            a1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i1 * d + 16 * c + lane);
-            b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j1 * d + 16 * c + lane);
+            a[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i) * d + 16 * c + lane);
+            b[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j) * d + 16 * c + lane);
+            a1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i1) * d + 16 * c + lane);
+            b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j1) * d + 16 * c + lane);
         }
         for (int s = beg; s < end; s++) {
             const int i3 = si[at(s + 3)], j3 = sj[at(s + 3)];
-            const int slot2 = slot_of[hot.n_hot > 0 ? i2 : beg];
-            const int slotj2 = slot_of[hot.n_hot > 0 ? (neg_replicas ? j2 : i2) : beg];
+            const int slot2 = slot_of[idx_i(i2, j2)];
+            const int slotj2 = slot_of[idx_j(i2, j2)];
+            float al[NC], bl[NC];
+            if constexpr ((ST & ST_LIVE) != 0) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    al[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i) * d + 16 * c + lane);
+                    bl[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j) * d + 16 * c + lane);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)i2 * d + 16 * c + lane);
-                b2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)j2 * d + 16 * c + lane);
+                a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i2) * d + 16 * c + lane);
+                b2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j2) * d + 16 * c + lane);
             }
-            float *qi = Q + (int64_t)i * d, *qj = Q + (int64_t)j * d;
-            if (hot.n_hot > 0 && slot >= 0) qi = hot.rep + ((int64_t)slot * kHotReplicas + (group & (kHotReplicas - 1))) * d;
-            if (hot.n_hot > 0 && slotj >= 0 && neg_replicas) qj = hot.rep + ((int64_t)slotj * kHotReplicas + (group & (kHotReplicas - 1))) * d;
-            const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
+            const bool valid = j >= 0;  // j < 0: the sampler found no negative for this sample (bpr_sample_items_kernel)
+            float *qi = Q + (int64_t)cl(i) * d, *qj = Q + (int64_t)cl(j) * d;
+            if (hot.n_hot > 0 && slot >= 0) qi = hot.rep + (int64_t)slot * hot.stride_s + rep_r;
+            if (hot.n_hot > 0 && neg_replicas && slotj >= 0) qj = hot.rep + (int64_t)slotj * hot.stride_s + rep_r;
+            bool st_i = false, st_j = false;
+            if constexpr ((ST & (ST_POS | ST_NEG)) != 0) {
+                const bool own_i = i == j || i == im1 || i == jm1 || i == im2 || i == jm2;
+                const bool own_j = i == j || j == im1 || j == jm1 || j == im2 || j == jm2;
+                st_i = (ST & ST_POS) && slot == kCold && !own_i;
+                st_j = (ST & ST_NEG) && slotj == kCold && !own_j;
+            }
+            const float diff = D8 ? group_tree8(p[0] * a[0]) - group_tree8(p[0] * b[0]) : dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
             const float ex = bpr_exp(-diff, exp_mode);
             const float grad = ex / (1.0f + ex);
-            if (loss && lane == 0) my_loss += (double)log1pf(ex);
+            if (loss && glane == 0 && valid) my_loss += (double)log1pf(ex);
+            float t1[NC], t2[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const int e = 16 * c + lane;
-                const float t1 = fmaf(a[c], nreg, p[c] * grad);
-                const float t2 = fmaf(b[c], nreg, p[c] * (-grad));
-                const float t3 = fmaf(p[c], nreg, (a[c] - b[c]) * grad);
-                __hip_atomic_fetch_add(qi + e, t1 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(qj + e, t2 * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                p[c] = fmaf(t3, lr, p[c]);
+                t1[c] = mad(a[c], nreg, p[c] * grad);
+                t2[c] = mad(b[c], nreg, p[c] * (-grad));
+                const float t3 = mad(p[c], nreg, (a[c] - b[c]) * grad);
+                p[c] = valid ? mad(t3, lr, p[c]) : p[c];
+            }
+            if (!valid || !writer) {
+                // nothing to write
+            } else if (st_i) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    __hip_atomic_store(qi + 16 * c + lane, mad(t1[c], lr, (ST & ST_LIVE) ? al[c] : a[c]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    __hip_atomic_fetch_add(qi + 16 * c + lane, t1[c] * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!valid || !writer) {
+            } else if (st_j) {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    __hip_atomic_store(qj + 16 * c + lane, mad(t2[c], lr, (ST & ST_LIVE) ? bl[c] : b[c]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    __hip_atomic_fetch_add(qj + 16 * c + lane, t2[c] * lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
                 a[c] = a1[c];
                 b[c] = b1[c];
                 a1[c] = a2[c];
                 b1[c] = b2[c];
             }
+            im2 = im1, jm2 = jm1, im1 = i, jm1 = j;
             i = i1, j = j1, i1 = i2, j1 = j2, i2 = i3, j2 = j3;
             slot = slot1, slot1 = slot2;
             slotj = slotj1, slotj1 = slotj2;
         }
+        if (writer) {
 #pragma unroll
-        for (int c = 0; c < NC; c++)  // the only writer of this row in the launch
-            __hip_atomic_store(pu + 16 * c + lane, p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int c = 0; c < NC; c++)  // the only writer of this row in the launch
+                __hip_atomic_store(pu + 16 * c + lane, p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
+    if (loss && glane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
     if (folders > 0) {
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -513,7 +679,26 @@ int32_t ensure_user_sort(gorse_mf *h) {
 // user runs need enough users to fill the chip with one 16-lane group each (4096 groups = one wave per SIMD) and a
 // register-resident factor width; otherwise the per-sample schedule is the faster one (S-ml100k: 943 users)
 bool user_runs_supported(const gorse_mf *h) {
-    return (h->d == 16 || h->d == 32 || h->d == 64 || h->d == 128) && (h->U >= 4096 || (g_variant & 128));
+    return (h->d == 8 || h->d == 16 || h->d == 32 || h->d == 64 || h->d == 128) && (h->U >= 4096 || (g_variant & 128));
+}
+
+// probe switches of the hot-row machinery (gorse_hip_test_set_bpr_tuning): replica layout, folder behaviour, store classes
+int g_rep_spread = 0;   // 1: replica r of every slot lives in its own block of n_hot rows (the 8 replicas of an item far apart)
+int g_fold_check = 0;   // 1: folder passes load a replica word before exchanging it
+int g_fold_sleep = 1;   // s_sleep(8) repetitions between folder passes
+constexpr int kDefaultStoreMode = 0;
+int g_store_mode = kDefaultStoreMode;  // ST_* bits of bpr_update_user_kernel
+
+HotRows make_hot(const gorse_mf *h) {
+    HotRows hot{h->hot_slot.p, h->hot_items.p, h->hot_rep.p, h->hot_done.p, 0, 0, 0, g_fold_check, g_fold_sleep};
+    if (g_rep_spread) {
+        hot.stride_s = h->d;
+        hot.stride_r = (int64_t)std::max(h->n_hot, 1) * h->d;
+    } else {
+        hot.stride_s = (int64_t)kHotReplicas * h->d;
+        hot.stride_r = h->d;
+    }
+    return hot;
 }
 
 int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *bucket, size_t cap, float lr, float reg,
@@ -522,7 +707,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     int64_t blocks = ceil_div(h->U, kGroupsPerBlock);
     const int64_t capb = 256 * 16;
     if (blocks > capb) blocks = capb;
-    HotRows hot{h->hot_slot.p, h->hot_items.p, h->hot_rep.p, h->hot_done.p, 0};
+    HotRows hot = make_hot(h);
     int folders = 0;
     if (h->n_hot > 0 && !(g_variant & 32)) {
         hot.n_hot = h->n_hot;
@@ -534,10 +719,24 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     // quarter of the items are hot; at the 10M x 1M set one in ten thousand, and the look-up cost 4 % of the epoch)
     const int neg_rep = !(g_variant & (1 << 25)) && (int64_t)hot.n_hot * 64 >= h->I ? 1 : 0;
     dim3 grid((unsigned)blocks), block(kBlock);
+    // cold items by store only where the handle found any (gorse_mf_create: n_cold) -- the atomics-only instantiation otherwise
+    const int store_mode = h->n_cold > 0 ? g_store_mode : 0;
+#define LAUNCH2(NC, ST)                                                                                                \
+    bpr_update_user_kernel<(NC == 0 ? 1 : NC), ST, NC == 0><<<grid, block, 0, st>>>(                                   \
+        h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket, (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, neg_rep)
 #define LAUNCH(NC)                                                                                                     \
-    bpr_update_user_kernel<NC><<<grid, block, 0, st>>>(h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket,         \
-                                                       (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, neg_rep)
-    if (d == 16)
+    do {                                                                                                               \
+        switch (store_mode) {                                                                                          \
+        case 1: LAUNCH2(NC, 1); break;                                                                                 \
+        case 3: LAUNCH2(NC, 3); break;                                                                                 \
+        case 5: LAUNCH2(NC, 5); break;                                                                                 \
+        case 7: LAUNCH2(NC, 7); break;                                                                                 \
+        default: LAUNCH2(NC, 0); break;                                                                                \
+        }                                                                                                              \
+    } while (0)
+    if (d == 8)
+        LAUNCH(0);
+    else if (d == 16)
         LAUNCH(1);
     else if (d == 32)
         LAUNCH(2);
@@ -545,6 +744,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
         LAUNCH(4);
     else
         LAUNCH(8);
+#undef LAUNCH2
 #undef LAUNCH
     GORSE_HIP_CHECK(hipGetLastError());
     if (folders > 0) {
@@ -565,7 +765,7 @@ int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, co
     int64_t blocks = ceil_div(n, kGroupsPerBlock);
     const int64_t cap = 256 * 16;  // 16 workgroups of 4 waves per CU: grid-stride beyond that
     if (blocks > cap) blocks = cap;
-    HotRows hot{h->hot_slot.p, h->hot_items.p, h->hot_rep.p, h->hot_done.p, 0};
+    HotRows hot = make_hot(h);
     int folders = 0;
     if (MODE == MODE_ATOMIC && h->n_hot > 0 && !(g_variant & 32)) {
         hot.n_hot = h->n_hot;
@@ -620,6 +820,34 @@ int32_t launch_sampler(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base,
     bpr_sample_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
                                                                     h->uidx_sorted.p, seed, epoch, base, n, trip,
                                                                     trip + cap, trip + 2 * cap, h->fail_count.p, bucket, rank);
+    GORSE_HIP_CHECK(hipGetLastError());
+    return GORSE_OK;
+}
+
+// The user-run schedule's preparation of one chunk (see bpr_sample_user_kernel): user draws + ranks, scan of the run counters,
+// sample ids scattered to their sorted positions, item draws by run.  `trip` (3 x cap ints, otherwise the unsorted triplets)
+// holds the keys and the permutation; `sorted` receives si at cap, sj at 2 cap; bucket[0..U] the run offsets.
+int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base, int64_t n, int32_t *trip, int32_t *sorted,
+                             int32_t *bucket, int32_t *rank, size_t cap, hipStream_t st) {
+    if (n <= 0) return GORSE_OK;
+    const int64_t m = h->U + 2;
+    const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
+    int32_t *key = trip, *perm = trip + cap;
+    int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
+    GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)m * sizeof(int32_t), st));
+    bpr_sample_user_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, h->uptr.p, seed, epoch, base, n, key,
+                                                                         h->fail_count.p, bucket, rank);
+    h->prof.end(tok, st);
+    tok = h->prof.begin(GORSE_PROF_BPR_SORT, st);
+    GORSE_TRY(exclusive_scan_i32(bucket, m, h->scan_tmp2.p, st));
+    bpr_scatter_ids_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(key, rank, bucket, n, (int32_t)h->U, perm);
+    h->prof.end(tok, st);
+    tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
+    const int64_t gblocks = std::min<int64_t>(ceil_div(h->U, kGroupsPerBlock), 256 * 16);
+    bpr_sample_items_kernel<<<dim3((unsigned)gblocks), dim3(kBlock), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
+                                                                              h->uidx_sorted.p, seed, epoch, base, bucket, perm,
+                                                                              sorted + cap, sorted + 2 * cap, h->fail_count.p);
+    h->prof.end(tok, st);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -759,18 +987,27 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             // U + 2 counters, scatter) follows on the sampler stream: the whole preparation of chunk c + 1 runs under the
             // update kernel of chunk c.  (Round 1 measured a sort on this stream as slower -- its separate rank pass put
             // 1 M returning atomics next to the update kernel's; that pass is gone.)  Variant bit 27: sort on the update stream.
+            // Variant bit 27: the round-3 preparation (whole triplets sampled per sample, then scattered) with the sort on the
+            // update stream; bit 26: the same with the sort on the sampler stream.
             const bool fused = uruns && !(g_variant & (1 << 29)) && !(g_variant & (1 << 27));
-            int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, h->stream2);
-            GORSE_TRY(launch_sampler(h, seed, epoch, base + s0, m, tb, (size_t)cap, h->stream2, fused ? h->ubucket[b].p : nullptr,
-                                     fused ? h->urank[b].p : nullptr));
-            h->prof.end(tok, h->stream2);
-            if (fused) {
-                tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
-                GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, h->stream2, true));
+            const bool by_run = fused && !(g_variant & (1 << 26));
+            if (by_run) {
+                GORSE_TRY(launch_prepare_users(h, seed, epoch, base + s0, m, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p,
+                                               (size_t)cap, h->stream2));
+            } else {
+                int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, h->stream2);
+                GORSE_TRY(launch_sampler(h, seed, epoch, base + s0, m, tb, (size_t)cap, h->stream2, fused ? h->ubucket[b].p : nullptr,
+                                         fused ? h->urank[b].p : nullptr));
                 h->prof.end(tok, h->stream2);
+                if (fused) {
+                    tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
+                    GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, h->stream2, true));
+                    h->prof.end(tok, h->stream2);
+                }
             }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
+            int tok;
             if (uruns && !fused) {
                 tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream);
                 GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, h->stream, false));
@@ -805,6 +1042,12 @@ extern "C" int32_t gorse_mf_bpr_schedule(gorse_mf *h, int32_t *user_runs) {
 }
 extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
 extern "C" void gorse_hip_test_set_bpr_chunk(int64_t samples) { g_chunk_override = samples; }
+extern "C" void gorse_hip_test_set_bpr_tuning(int32_t store_mode, int32_t rep_spread, int32_t fold_check, int32_t fold_sleep) {
+    g_store_mode = store_mode < 0 ? kDefaultStoreMode : store_mode;
+    g_rep_spread = rep_spread;
+    g_fold_check = fold_check;
+    g_fold_sleep = fold_sleep < 0 ? 1 : fold_sleep;
+}
 
 extern "C" int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
                                    int64_t sample_base, int32_t mode, const volatile int32_t *cancel, double *loss_out) {
@@ -835,6 +1078,25 @@ extern "C" int32_t gorse_bpr_sample_triplets(gorse_mf *h, int64_t n, uint64_t se
         GORSE_HIP_CHECK(hipMemcpyAsync(j + s0, tb + 2 * cap, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     }
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_hip_test_bpr_prepare_chunk(gorse_mf *h, int64_t n, uint64_t seed, uint64_t epoch, int64_t sample_base,
+                                                    int32_t *off /*U + 2*/, int32_t *si /*n*/, int32_t *sj /*n*/) {
+    if (!h || !off || !si || !sj) return fail(GORSE_ERR_INVALID, "NULL argument");
+    GORSE_TRY(h->use());
+    GORSE_TRY(ensure_trip(h, n));
+    if (n < 0 || n > (int64_t)h->trip_cap) return fail(GORSE_ERR_INVALID, "n outside one chunk (%zu samples)", h->trip_cap);
+    if (!user_runs_supported(h)) return fail(GORSE_ERR_INVALID, "this handle does not run the user-run schedule");
+    GORSE_TRY(ensure_user_sort(h));
+    GORSE_TRY(mf_sync_streams(h));
+    const size_t cap = h->trip_cap;
+    GORSE_TRY(launch_prepare_users(h, seed, epoch, sample_base, n, h->trip[0].p, h->sorted[0].p, h->ubucket[0].p, h->urank[0].p, cap,
+                                   h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(off, h->ubucket[0].p, (size_t)(h->U + 2) * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(si, h->sorted[0].p + cap, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipMemcpyAsync(sj, h->sorted[0].p + 2 * cap, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     return GORSE_OK;
 }
 

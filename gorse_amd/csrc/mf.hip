@@ -187,6 +187,9 @@ int32_t mf_score_device(gorse_mf *h, const int32_t *us, const int32_t *is, int64
 
 int g_mf_flat_streams = 1;  // 1 = both streams of a handle at the same priority; 0 (probe) = the update stream ahead
 extern "C" void gorse_hip_test_set_stream_priorities(int32_t on) { g_mf_flat_streams = on ? 0 : 1; }
+constexpr int64_t kDefaultColdWindow = 0;
+int64_t g_mf_cold_window = kDefaultColdWindow;  // items expected to be touched less than once per this many samples are "cold" (0 = none)
+extern "C" void gorse_hip_test_set_bpr_cold_window(int64_t samples) { g_mf_cold_window = samples < 0 ? kDefaultColdWindow : samples; }
 
 extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, int64_t I, int32_t d,
                                    const int64_t *user_indptr, const int32_t *user_indices,
@@ -301,6 +304,18 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
                 std::sort(hot.begin(), hot.end());
             }
             std::vector<int32_t> slot((size_t)I, -1);
+            // cold items (class -2, bpr.hip kCold): a sample touches item i with probability share(i) as its positive and 1 / I as
+            // its negative; where fewer than one touch is expected per `cold window` samples the row's update may be a plain
+            // write-through store (the reference's own unlocked write) instead of d atomic dwords
+            h->n_cold = 0;
+            if (g_mf_cold_window > 0 && h->nnz > 0) {
+                const double w = (double)g_mf_cold_window;
+                for (int64_t i = 0; i < I; i++)
+                    if (((double)cnt[(size_t)i] / (double)h->nnz + 1.0 / (double)I) * w < 1.0) {
+                        slot[(size_t)i] = -2;
+                        h->n_cold++;
+                    }
+            }
             for (size_t k = 0; k < hot.size(); k++) slot[hot[k]] = (int32_t)k;
             h->n_hot = (int)hot.size();
             GORSE_TRY(h->hot_slot.alloc((size_t)I));

@@ -30,6 +30,7 @@ struct gorse_mf {
     gorse::DevBuf<int32_t> hot_slot, hot_items, hot_done;
     gorse::DevBuf<float> hot_rep;
     int n_hot = 0;
+    int64_t n_cold = 0;  // items of class "cold" in hot_slot (-2): updates by write-through store (bpr.hip)
     gorse::DevBuf<int32_t> order;  // sequential mode: samples sorted by dependency level
     gorse::DevBuf<double> loss;
     gorse::DevBuf<int32_t> fail_count;

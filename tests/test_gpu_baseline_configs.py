@@ -9,8 +9,8 @@
       of one sequential oracle epoch over the same set (a committed fixture: 100M sequential steps).
   C5  S-als 500,000 x 100,000 x 50M, nFactors 64: one user half-sweep on the device, 2048 rows spread over the row-length
       range (incl. the longest) <= 1e-4 against orc_als_half_range.
-  C4  S-emb 1,000,000 x 128 bf16, cosine, k = 100: 96 query rows of the all-pairs pass equal Bruteforce.SearchIndex restated
-      (oracle) in indices AND distance bits.
+  C4  S-emb 1,000,000 x 128 bf16, cosine, k = 100: 96 query rows through the scan (path A) and 128 rows of a 1024-query call
+      through the MFMA path (the kernel bench.py times) equal Bruteforce.SearchIndex restated (oracle) in indices AND distance bits.
 
 The element-wise relative error |got - ref| / |ref| is printed next to the bar each ALS comparison uses (`rel_to_scale`:
 error over the largest reference magnitude, the form "1e-4 relative fp32" takes for a matrix whose small elements are
@@ -150,13 +150,45 @@ def test_c5_als_user_half_sweep_rows(oracle):
     assert (np.abs(gP[rows].astype(np.float64) - A) <= bound).all()
 
 
+def _check_c4_rows(oracle, Xe, idx, dist, q0, rows, k):
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+
+    def one(r):
+        ei, ed = oracle.search_index(Xe, orc.METRIC_COSINE, q0 + r, k)
+        return r, ei, ed
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 32)) as ex:  # the oracle runs outside the GIL (ctypes)
+        for r, ei, ed in ex.map(one, rows):
+            assert ei.size == k and np.array_equal(idx[r], ei), "row %d: indices differ" % (q0 + r)
+            assert np.array_equal(dist[r].view(np.uint32), ed.view(np.uint32)), "row %d: distances differ" % (q0 + r)
+
+
 def test_c4_rows_against_the_oracle(oracle):
+    """96 query rows: a call of fewer than 768 queries takes the literal scan (path A, csrc/topk.hip)."""
     Xb, Xe = synth.s_emb(1_000_000, 128, 44)
     k = 100
     t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
     q0, q1 = 500_000, 500_096
     idx, dist = t.all_pairs(k, q0, q1)
-    for r in range(q1 - q0):
-        ei, ed = oracle.search_index(Xe, orc.METRIC_COSINE, q0 + r, k)
-        assert ei.size == k and np.array_equal(idx[r], ei), "row %d: indices differ" % (q0 + r)
-        assert np.array_equal(dist[r].view(np.uint32), ed.view(np.uint32)), "row %d: distances differ" % (q0 + r)
+    _check_c4_rows(oracle, Xe, idx, dist, q0, range(q1 - q0), k)
+
+
+def test_c4_mfma_path_rows_against_the_oracle(oracle):
+    """The kernel bench.py times at C4: a call of 1024 queries against the 1M x 128 bf16 index takes the MFMA path (pilot + main
+    sweep, exact rescoring, tie replay: csrc/topk_mfma.hip) -- asserted through the handle's profile, which must show sweep
+    launches -- and 128 of its rows (every eighth) equal Bruteforce.SearchIndex restated (common/ann/bruteforce.go:39-83) in indices
+    AND distance bits."""
+    Xb, Xe = synth.s_emb(1_000_000, 128, 44)
+    k = 100
+    t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
+    q0, q1 = 500_000, 501_024
+    t.set_profiling(True)
+    idx, dist = t.all_pairs(k, q0, q1)
+    launches, sweep_ms = t.get_profile(capi.PROF_TOPK_SWEEP)
+    scans, _ = t.get_profile(capi.PROF_TOPK_SCORE)
+    n_fb, n_tie = t.last_stats()
+    t.set_profiling(False)
+    print("C4, 1024 queries: %d sweep launches (%.1f ms), %d scan launches, %d queries through the tie replay, %d fell back to the scan"
+          % (launches, sweep_ms, scans, n_tie, n_fb))
+    assert launches >= 1 and n_fb == 0  # the MFMA sweep answered every query
+    _check_c4_rows(oracle, Xe, idx, dist, q0, range(0, q1 - q0, 8), k)

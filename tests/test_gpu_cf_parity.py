@@ -387,7 +387,7 @@ def test_bpr_hogwild_schedules_ndcg_parity(oracle, variant):
     assert abs(got - ref) < 0.01
 
 
-@pytest.mark.parametrize("d", [16, 64, 128])
+@pytest.mark.parametrize("d", [8, 16, 64, 128])
 def test_bpr_user_runs_equal_the_sequential_result_when_items_are_disjoint(oracle, d):
     """The user-run schedule in a case with a unique answer: every item row is touched by ONE sample, users repeat
     a lot, and the test hook ranks the samples in stream order.  Then every p_u sees exactly the sequential history
@@ -425,6 +425,133 @@ def test_bpr_user_runs_equal_the_sequential_result_when_items_are_disjoint(oracl
     touched[i[keep]] = True
     touched[j[keep]] = True
     assert np.array_equal(bits(gQ[~touched]), bits(Q[~touched]))  # nothing else moved
+
+
+@pytest.mark.parametrize("store_mode", [1, 3, 5, 7])
+def test_bpr_user_runs_cold_rows_by_store_are_bit_exact(oracle, store_mode):
+    """The cold-row route of the user-run schedule (csrc/bpr.hip ST_*): an item expected to be touched less than once per cold
+    window gets its update as ONE write-through store of fma(t, lr, row) -- the reference's own unlocked write (model.go:478-488)
+    -- instead of d atomic dwords.  With every item row touched by one sample and ranks in stream order the result is unique:
+    P bit-exact, and the rows that took the store route equal the sequential oracle BIT FOR BIT (one fma, where the atomic
+    route rounds twice).  A row the same group touched within its last two samples falls back to the atomic (its snapshot
+    predates the group's own write): the repeated triplets at the end exercise that."""
+    oracle.set_exp(1)
+    L = capi.lib()
+    L.gorse_hip_test_set_exact_exp(1)
+    d = 64
+    rng = np.random.default_rng(100 + store_mode)
+    U, I, n = 37, 3000, 1400
+    rows = [rng.choice(40, 3, replace=False).astype(np.int32) for _ in range(U)]
+    uptr = np.arange(0, 3 * U + 1, 3, dtype=np.int64)
+    uidx = np.concatenate(rows)
+    items = rng.permutation(np.arange(40, I))[:2 * n].astype(np.int32)  # never among the dataset's items: class "cold"
+    u = rng.integers(0, U, n).astype(np.int32)
+    i, j = items[:n].copy(), items[n:].copy()
+    P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 9)
+    L.gorse_hip_test_set_bpr_cold_window(1024)  # 1 / I < 1 / 1024 <= share of every item of the dataset
+    L.gorse_hip_test_set_bpr_tuning(store_mode, 0, 0, 1)
+    L.gorse_hip_test_set_variant(VARIANT_USER_RUNS | VARIANT_STABLE_RANK)
+    try:
+        mf = capi.MF(U, I, d, uptr, uidx)
+        mf.set_factors(P, Q)
+        mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_HOGWILD_ATOMIC)
+        gP, gQ = mf.get_factors()
+        eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
+        assert np.array_equal(bits(gP), bits(eP))
+        stored = np.zeros(I, bool)
+        if store_mode & 2:
+            stored[i] = True
+        if store_mode & 1:
+            stored[j] = True
+        assert np.array_equal(bits(gQ[stored]), bits(eQ[stored]))
+        assert rel_err(gQ, eQ) < 1e-6
+        # one user, the same two cold rows three samples in a row: the second and third update of a row must not be computed
+        # onto a snapshot that lacks the first (they take the atomic route) -- all three land
+        mf.set_factors(P, Q)
+        a, b = int(items[0]), int(items[1])
+        u2 = np.zeros(3, np.int32)
+        mf.bpr_apply_triplets(u2, np.full(3, a, np.int32), np.full(3, b, np.int32), 1e-4, 0.0, capi.BPR_HOGWILD_ATOMIC)
+        _, gQ2 = mf.get_factors()
+        diff = float(P[0] @ Q[a] - P[0] @ Q[b])
+        step = 1e-4 / (1.0 + np.exp(diff)) * P[0].astype(np.float64)
+        assert np.abs((gQ2[a] - Q[a]) - 3 * step).max() < 0.02 * np.abs(3 * step).max()
+        assert np.abs((gQ2[b] - Q[b]) + 3 * step).max() < 0.02 * np.abs(3 * step).max()
+    finally:
+        L.gorse_hip_test_set_variant(0)
+        L.gorse_hip_test_set_bpr_tuning(-1, 0, 0, 1)
+        L.gorse_hip_test_set_bpr_cold_window(-1)
+
+
+def _sorted_triples(u, i, j):
+    t = np.stack([u, i, j], axis=1)
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+def test_prepared_chunk_holds_the_sampled_triplets(oracle, small):
+    """The user-run schedule prepares a chunk in two passes -- user draws + counting sort of the sample ids, then the item draws
+    run by run (csrc/bpr.hip launch_prepare_users) -- and must produce exactly the triplets of the per-sample sampler
+    (model.go:449-468 through the shared Philox stream; test_sampler_matches_oracle pins that one to the oracle), each in the
+    run of its user."""
+    L = capi.lib()
+    L.gorse_hip_test_set_variant(VARIANT_USER_RUNS)
+    try:
+        U, I = 60, 40
+        lens = np.zeros(U, np.int64)
+        lens[::3] = 5
+        lens[3] = I  # this user holds every item: no negative exists (the reference would spin forever; here the sample is skipped)
+        uptr = np.zeros(U + 1, np.int64)
+        np.cumsum(lens, out=uptr[1:])
+        rng = np.random.default_rng(3)
+        uidx = np.concatenate([rng.permutation(I)[:n] for n in lens if n > 0]).astype(np.int32)
+        ragged = (U, I, uptr, uidx)
+        for (U, I, uptr, uidx) in [(small.U, small.I, small.uptr, small.uidx), ragged]:
+            mf = capi.MF(U, I, 16, uptr, uidx)
+            for (seed, epoch, base, n) in [(1, 0, 0, 20000), (0xDEADBEEFCAFE, 7, 123456789012, 5000)]:
+                off, si, sj = mf.bpr_prepare_chunk(n, seed, epoch, base)
+                gu, gi, gj = mf.bpr_sample_triplets(n, seed, epoch, base)
+                assert off[0] == 0 and off[U + 1] == n and (np.diff(off) >= 0).all()
+                su = np.repeat(np.arange(U + 1, dtype=np.int32), np.diff(off))
+                ok = sj[:off[U]] >= 0  # positions past off[U]: samples whose user draw failed (never written)
+                failed = gu < 0
+                # a sample the per-sample sampler gave up on (-1, -1, -1) is, here, either without a user or a (-1, -1) in its run
+                assert int(failed.sum()) == int((~ok).sum()) + int(n - off[U])
+                assert np.array_equal(_sorted_triples(su[:off[U]][ok], si[:off[U]][ok], sj[:off[U]][ok]),
+                                      _sorted_triples(gu[~failed], gi[~failed], gj[~failed]))
+                assert (si[:off[U]][~ok] == -1).all()
+            mf.close()
+    finally:
+        L.gorse_hip_test_set_variant(0)
+
+
+def test_epoch_with_a_user_holding_every_item_skips_its_samples(oracle):
+    """bpr_update_user_kernel meets (-1, -1) pairs inside a run (no negative found): nothing is written for them, the rest of the
+    run is applied.  Compared with the oracle's Hogwild-free sequential pass over the triplets that exist."""
+    L = capi.lib()
+    U, I, d = 48, 32, 16
+    lens = np.full(U, 4, np.int64)
+    lens[7] = I
+    uptr = np.zeros(U + 1, np.int64)
+    np.cumsum(lens, out=uptr[1:])
+    rng = np.random.default_rng(5)
+    uidx = np.concatenate([rng.permutation(I)[:n] for n in lens]).astype(np.int32)
+    P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 2)
+    L.gorse_hip_test_set_variant(VARIANT_USER_RUNS)
+    try:
+        mf = capi.MF(U, I, d, uptr, uidx)
+        mf.set_factors(P, Q)
+        mf.bpr_epoch(3000, 1e-4, 0.0, 9, 1)
+        gP, gQ = mf.get_factors()
+    finally:
+        L.gorse_hip_test_set_variant(0)
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+    assert np.array_equal(bits(gP[7]), bits(P[7]))  # every sample of user 7 was skipped
+    gu, gi, gj = mf.bpr_sample_triplets(3000, 9, 1)
+    keep = gu >= 0
+    assert (gu[keep] != 7).all() and (~keep).sum() > 0
+    eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, gu[keep], gi[keep], gj[keep], 1e-4, 0.0)
+    # lr small, reg 0: every update is (almost) computed from the initial state, so the order matters little next to the move
+    assert np.abs(gQ - eQ).max() < 2e-2 * np.abs(eQ - Q).max()
+    assert np.abs(gP - eP).max() < 2e-2 * np.abs(eP - P).max()
 
 
 def test_evaluate_on_device_ranks_equals_the_oracle(oracle):
