@@ -61,9 +61,90 @@ def measured_traffic(workload):
         if f is None or w is None:
             return None, None
         return f + w, "profiles/traffic.json[%s]: FETCH_SIZE %.0f MB + WRITE_SIZE %.0f MB per launch; %s" % (
-            workload, f / 1e6, w / 1e6, rec.get("how", ""))
+            workload, f / 1e6, w / 1e6, rec.get("how", ""))  # the source string is prose: compact() moves it to the notes file
     except Exception:
         return None, None
+
+
+# The driver keeps the last 8 KB of stdout: the JSON line carries numbers; everything that is prose (where a traffic figure
+# came from, what a CPU sample was, how a flop count is defined) goes to a notes file keyed by the same path.
+NOTE_KEYS = {"traffic_source", "sample", "flop_note", "note", "entry_point", "parallelism", "kernel", "how"}
+
+
+def compact(obj, notes, path=""):
+    if isinstance(obj, dict):
+        out = {}
+        for k, v in obj.items():
+            here = "%s.%s" % (path, k) if path else k
+            if k in NOTE_KEYS and isinstance(v, str):
+                notes[here] = v
+            else:
+                out[k] = compact(v, notes, here)
+        return out
+    if isinstance(obj, float):
+        return float("%.5g" % obj)
+    return obj
+
+
+def write_notes(notes):
+    for d in (os.path.join(ROOT, "gpurun_out"), "/tmp"):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_notes.json")
+            json.dump(notes, open(path, "w"), indent=1, sort_keys=True)
+            return path
+        except Exception:
+            continue
+    return None
+
+
+class ClockSampler:
+    """Shader clock of the device while a leg runs: a thread reads the current level of pp_dpm_sclk (amdgpu sysfs) every 5 ms.
+    The MFMA-bound sweep follows the clock the box sustains under load (MI355X_MICROARCH.md, DVFS); its roofline fraction is
+    quoted against the spec peak, so the line says what clock the number was measured at.  None when the file is not there."""
+
+    def __init__(self, local):
+        self.path, self.vals, self.stop, self.th = None, [], False, None
+        try:
+            cards = sorted(c for c in os.listdir("/sys/class/drm") if c.startswith("card") and c[4:].isdigit())
+            amd = []
+            for c in cards:
+                f = "/sys/class/drm/%s/device/pp_dpm_sclk" % c
+                if os.path.exists(f):
+                    amd.append(f)
+            if amd:
+                self.path = amd[min(local, len(amd) - 1)]
+        except Exception:
+            self.path = None
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return float(line.split(":")[1].strip().split("M")[0])
+        except Exception:
+            return None
+        return None
+
+    def __enter__(self):
+        if self.path:
+            def loop():
+                while not self.stop:
+                    v = self._read()
+                    if v:
+                        self.vals.append(v)
+                    time.sleep(0.005)
+            self.th = threading.Thread(target=loop, daemon=True)
+            self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        if self.th:
+            self.th.join()
+
+    def ghz(self):
+        return float(np.mean(self.vals)) / 1e3 if self.vals else None
 
 
 def parse():
@@ -239,11 +320,12 @@ def bench_topk(args, world, rank, local, fence):
     t.all_pairs(k, q0, q1, fetch=False)
     fence()
     t.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.topk_steps):
-        t.all_pairs(k, q0, q1, fetch=False)
-    fence()
-    dt = time.perf_counter() - t0
+    with ClockSampler(local) as clk:
+        t0 = time.perf_counter()
+        for _ in range(args.topk_steps):
+            t.all_pairs(k, q0, q1, fetch=False)
+        fence()
+        dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -271,6 +353,7 @@ def bench_topk(args, world, rank, local, fence):
         "roofline": {"bound": "mfma", "kernel": "topk_sweep_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                      "algorithmic_flop_per_pair": 2 * d, "avg_launch_ms": avg_ms, "launches": launches,
+                     "clock_ghz": clk.ghz(),  # mean shader clock over the timed steps (pp_dpm_sclk), None if unreadable
                      "rescore_avg_ms": resc_ms / max(r_launches, 1),
                      "tie_history_sweep_ms_per_step": hist_ms / max(args.topk_steps, 1),
                      "tie_replay_ms_per_step": replay_ms / max(args.topk_steps, 1)},
@@ -485,13 +568,13 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
     algo = own * d * 4.0 + 2.0 * ((u1 - u0) + (i1 - i0)) * d * 4  # gathers + factor rows read/written
     per_epoch_ms = (sweep_ms + gram_ms) / max(steps, 1)
     hbm_achieved = algo / (per_epoch_ms * 1e-3) / 1e9 if per_epoch_ms > 0 else 0.0
-    # The Gram form does d times the reference's multiply-adds and does them on the fp32 MFMA: per gathered row the upper
-    # triangle of q q^T in 32 x 32 blocks (3 of 4 blocks at nFactors 64).  That, not the gather traffic (the factor matrices
-    # sit in the Infinity Cache), is the roofline this kernel is measured against; the HBM figure stays next to it.
-    nb = (d + 31) // 32
-    macs_per_row = (nb * (nb + 1) // 2) * 32 * 32
+    # Primary roofline = SURVEY.md 8(d): the sweep is classed HBM-bound at 2*nnz*d*4 + 2*(U+I)*d*4 algorithmic bytes per epoch.
+    # Secondary (mfma_f32_*): the Gram form this library runs does ~d times the reference recurrence's multiply-adds on the fp32
+    # MFMA; it is priced on the STRICT upper triangle of q q^T (d (d + 1) / 2 multiply-adds per gathered row), not on the three
+    # full 32 x 32 blocks the kernel actually issues at nFactors 64 -- implementation work is not algorithmic work.
+    macs_per_row = d * (d + 1) // 2
     flops = 2.0 * own * macs_per_row
-    achieved = flops / (per_epoch_ms * 1e-3) / 1e12 if per_epoch_ms > 0 else 0.0
+    mfma_achieved = flops / (per_epoch_ms * 1e-3) / 1e12 if per_epoch_ms > 0 else 0.0
     out = {
         "metric": "ALS feedback entries/sec (nnz per epoch x epochs / time, whole job, N GPUs)",
         "value": n * steps / dt, "unit": "entries/s", "n_gpus": world, "steps": steps,
@@ -500,13 +583,13 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
         "config": {"workload": "S-als %dx%dx%d (C5%s), nFactors=%d, weight=%g reg=%g" % (U, I, n, "" if sc == 1.0 else " x%g" % sc, d, w, reg),
                    "parallelism": "rows sharded x%d, factors replicated, 2 all-gathers((U+I)*d fp32)/epoch over %s" % (world, comm_label)
                    if world > 1 else "single GPU", "factors_finite": bool(np.isfinite(P).all() and np.isfinite(Q).all())},
-        "roofline": {"bound": "mfma_f32", "kernel": "als_row_kernel + als_chunk_kernel (+ S Gram)", "achieved": achieved,
-                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                     "algorithmic_flop_per_epoch": flops,
-                     "flop_note": "2 flop x gathered rows of both half-sweeps x %d multiply-adds per row (upper triangle of the "
-                                  "Gram update in 32x32 fp32 MFMA blocks)" % macs_per_row,
-                     "hbm_achieved_gbs": hbm_achieved, "hbm_frac": hbm_achieved / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "als_row_kernel + als_chunk_kernel (+ S Gram)", "achieved": hbm_achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_epoch": algo, "avg_launch_ms": per_epoch_ms, "launches": ns,
+                     "mfma_f32_tflops": mfma_achieved, "mfma_f32_frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS,
+                     "mfma_macs_per_gathered_row": macs_per_row,
+                     "flop_note": "secondary figure: 2 flop x gathered rows of both half-sweeps x d (d + 1) / 2 multiply-adds (strict "
+                                  "upper triangle of the Gram update) against the %.1f TFLOP/s fp32 MFMA peak" % MFMA_F32_PEAK_TFLOPS,
                      "sweeps_ms_per_epoch": sweep_ms / max(steps, 1), "gram_ms_per_epoch": gram_ms / max(steps, 1)},
     }
     if world == 1 and sc == 1.0:

@@ -244,13 +244,8 @@ struct HotRows {
     int32_t *done;         // worker workgroups that have finished (zeroed before the launch)
     int n_hot;
     int64_t stride_s, stride_r;  // replica r of slot s starts at rep + s * stride_s + r * stride_r
-    int fold_check;        // folder passes read a replica word before exchanging it (an untouched word costs a load, not an atomic)
-    int fold_sleep;        // s_sleep argument between folder passes
 };
 
-__device__ __forceinline__ void folder_sleep(int n) {
-    for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(8);
-}
 // one folder pass: (slot, element) pairs strided over the folder threads
 __device__ __forceinline__ void fold_pass(const HotRows &hot, float *Q, int d, int64_t tid, int64_t nthreads) {
     const int64_t work = (int64_t)hot.n_hot * d;
@@ -259,19 +254,9 @@ __device__ __forceinline__ void fold_pass(const HotRows &hot, float *Q, int d, i
         const int e = (int)(w - slot * d);
         float *r0 = hot.rep + slot * hot.stride_s + e;
         float v[kHotReplicas];
-        if (hot.fold_check) {
 #pragma unroll
-            for (int r = 0; r < kHotReplicas; r++)
-                v[r] = __hip_atomic_load(r0 + r * hot.stride_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int r = 0; r < kHotReplicas; r++)
-                if (v[r] != 0.0f)
-                    v[r] = __hip_atomic_exchange(r0 + r * hot.stride_r, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-#pragma unroll
-            for (int r = 0; r < kHotReplicas; r++)
-                v[r] = __hip_atomic_exchange(r0 + r * hot.stride_r, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int r = 0; r < kHotReplicas; r++)
+            v[r] = __hip_atomic_exchange(r0 + r * hot.stride_r, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float sum = 0.0f;
 #pragma unroll
         for (int r = 0; r < kHotReplicas; r++) sum += v[r];
@@ -296,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
         for (int pass = 0; pass < (1 << 16); pass++) {
             fold_pass(hot, Q, d, tid, nthreads);
             if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
-            folder_sleep(hot.fold_sleep);
+            __builtin_amdgcn_s_sleep(8);
         }
         return;
     }
@@ -494,10 +479,13 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         for (int pass = 0; pass < (1 << 16); pass++) {
             fold_pass(hot, Q, d, tid, nthreads);
             if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
-            folder_sleep(hot.fold_sleep);
+            __builtin_amdgcn_s_sleep(8);
         }
         return;
     }
+    // with the store route open for negatives their rows are gathered ONE sample ahead instead of two: what a store can
+    // overwrite is what other groups added between the gather and the store, and that window halves
+    constexpr bool NEG1 = (ST & ST_NEG) != 0;
     const int glane = threadIdx.x & (kGroup - 1);
     const int lane = D8 ? (glane & 7) : glane;   // element owned inside a 16-float chunk
     const bool writer = !D8 || glane < 8;
@@ -542,7 +530,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             a[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i) * d + 16 * c + lane);
             b[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j) * d + 16 * c + lane);
             a1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i1) * d + 16 * c + lane);
-            b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j1) * d + 16 * c + lane);
+            if constexpr (!NEG1) b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j1) * d + 16 * c + lane);
         }
         for (int s = beg; s < end; s++) {
             const int i3 = si[at(s + 3)], j3 = sj[at(s + 3)];
@@ -559,7 +547,10 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i2) * d + 16 * c + lane);
-                b2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j2) * d + 16 * c + lane);
+                if constexpr (NEG1)
+                    b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j1) * d + 16 * c + lane);
+                else
+                    b2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j2) * d + 16 * c + lane);
             }
             const bool valid = j >= 0;  // j < 0: the sampler found no negative for this sample (bpr_sample_items_kernel)
             float *qi = Q + (int64_t)cl(i) * d, *qj = Q + (int64_t)cl(j) * d;
@@ -612,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
                 a[c] = a1[c];
                 b[c] = b1[c];
                 a1[c] = a2[c];
-                b1[c] = b2[c];
+                if constexpr (!NEG1) b1[c] = b2[c];
             }
             im2 = im1, jm2 = jm1, im1 = i, jm1 = j;
             i = i1, j = j1, i1 = i2, j1 = j2, i2 = i3, j2 = j3;
@@ -682,23 +673,13 @@ bool user_runs_supported(const gorse_mf *h) {
     return (h->d == 8 || h->d == 16 || h->d == 32 || h->d == 64 || h->d == 128) && (h->U >= 4096 || (g_variant & 128));
 }
 
-// probe switches of the hot-row machinery (gorse_hip_test_set_bpr_tuning): replica layout, folder behaviour, store classes
-int g_rep_spread = 0;   // 1: replica r of every slot lives in its own block of n_hot rows (the 8 replicas of an item far apart)
-int g_fold_check = 0;   // 1: folder passes load a replica word before exchanging it
-int g_fold_sleep = 1;   // s_sleep(8) repetitions between folder passes
+// which item updates may take the store route (gorse_hip_test_set_bpr_store_mode)
 constexpr int kDefaultStoreMode = 0;
 int g_store_mode = kDefaultStoreMode;  // ST_* bits of bpr_update_user_kernel
 
 HotRows make_hot(const gorse_mf *h) {
-    HotRows hot{h->hot_slot.p, h->hot_items.p, h->hot_rep.p, h->hot_done.p, 0, 0, 0, g_fold_check, g_fold_sleep};
-    if (g_rep_spread) {
-        hot.stride_s = h->d;
-        hot.stride_r = (int64_t)std::max(h->n_hot, 1) * h->d;
-    } else {
-        hot.stride_s = (int64_t)kHotReplicas * h->d;
-        hot.stride_r = h->d;
-    }
-    return hot;
+    // the eight replica rows of a slot lie next to each other (r04_a: 4 KB apart or n_hot rows apart makes no difference)
+    return HotRows{h->hot_slot.p, h->hot_items.p, h->hot_rep.p, h->hot_done.p, 0, (int64_t)kHotReplicas * h->d, h->d};
 }
 
 int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *bucket, size_t cap, float lr, float reg,
@@ -1042,11 +1023,8 @@ extern "C" int32_t gorse_mf_bpr_schedule(gorse_mf *h, int32_t *user_runs) {
 }
 extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
 extern "C" void gorse_hip_test_set_bpr_chunk(int64_t samples) { g_chunk_override = samples; }
-extern "C" void gorse_hip_test_set_bpr_tuning(int32_t store_mode, int32_t rep_spread, int32_t fold_check, int32_t fold_sleep) {
+extern "C" void gorse_hip_test_set_bpr_store_mode(int32_t store_mode) {
     g_store_mode = store_mode < 0 ? kDefaultStoreMode : store_mode;
-    g_rep_spread = rep_spread;
-    g_fold_check = fold_check;
-    g_fold_sleep = fold_sleep < 0 ? 1 : fold_sleep;
 }
 
 extern "C" int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,

@@ -1,5 +1,7 @@
 // gorse_cf.cpp -- implementation of the host mirror (see gorse_cf.hpp).  Numeric work goes through
 // the C ABI only; this file is the C++ twin of what model/cf/bpr_hip.go / als_hip.go would contain.
+#include <chrono>
+
 #include "gorse_cf.hpp"
 
 #include "gob.hpp"
@@ -245,12 +247,20 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
         if (config.Log) config.Log(s);
     };
     const std::vector<Metric> metrics{NDCG, Precision, Recall};
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    // eval_time / fit_time as in the reference's log lines (model.go:432-440, 496-503).  Epochs between two evaluations are
+    // only enqueued (see BPR::Fit), so fit_time is the mean over the epochs since the last evaluation, not the last epoch's.
+    auto t_eval = clk::now();
     auto score = Evaluate(*this, valSet, trainSet, config.TopK, config.Candidates, config.Jobs, metrics);
     std::vector<std::pair<int, float>> scores{{0, score[0]}};
-    log(fmt("fit %s 0/%d NDCG@%d=%g Precision@%d=%g Recall@%d=%g", tag, nEpochs, config.TopK, score[0], config.TopK, score[1],
-            config.TopK, score[2]));
+    log(fmt("fit %s 0/%d eval_time=%.3fms NDCG@%d=%g Precision@%d=%g Recall@%d=%g", tag, nEpochs, ms_since(t_eval), config.TopK,
+            score[0], config.TopK, score[1], config.TopK, score[2]));
+    auto t_fit = clk::now();
+    int fit_epochs = 0;
     for (int epoch = 1; epoch <= nEpochs; epoch++) {
         int32_t rc = run_epoch(epoch);
+        fit_epochs++;
         if (rc == GORSE_ERR_CANCELLED) {  // "fit bpr canceled" -> Score{} (model.go:490-493)
             log(fmt("fit %s canceled epoch=%d", tag, epoch));
             pull_factors();
@@ -259,10 +269,14 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
         }
         check(rc);
         if (epoch % config.Verbose == 0 || epoch == nEpochs) {
+            const double fit_ms = ms_since(t_fit) / fit_epochs;
+            t_eval = clk::now();
             score = Evaluate(*this, valSet, trainSet, config.TopK, config.Candidates, config.Jobs, metrics);
             scores.emplace_back(epoch, score[0]);
-            log(fmt("fit %s %d/%d NDCG@%d=%g Precision@%d=%g Recall@%d=%g", tag, epoch, nEpochs, config.TopK, score[0],
-                    config.TopK, score[1], config.TopK, score[2]));
+            log(fmt("fit %s %d/%d fit_time=%.3fms eval_time=%.3fms NDCG@%d=%g Precision@%d=%g Recall@%d=%g", tag, epoch, nEpochs,
+                    fit_ms, ms_since(t_eval), config.TopK, score[0], config.TopK, score[1], config.TopK, score[2]));
+            t_fit = clk::now();
+            fit_epochs = 0;
             if (config.Patience > 0 && epoch > config.Patience) {
                 // lo.MaxBy with strict > : the FIRST maximum
                 auto best = scores[0];

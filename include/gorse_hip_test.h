@@ -98,13 +98,12 @@ int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16 
 /* probe: samples per chunk of a gorse_mf handle created AFTERWARDS (0 = the library's choice: 32 x users, clamped to
  * [4M, 128M]); the user-run schedule applies a chunk at a time. */
 void gorse_hip_test_set_bpr_chunk(int64_t samples);
-/* probe switches of the user-run BPR update (csrc/bpr.hip).  store_mode: bit 0 = the NEGATIVE item of a sample, when its class is
- * "cold", is updated by one write-through store of fma(t, lr, row) instead of d atomic dwords (the reference's own unlocked
- * write, model.go:478-488), bit 1 = the positive item likewise, bit 2 = the store adds to a row re-read in the same iteration
- * instead of the snapshot gathered two samples earlier; rep_spread: 1 = the eight replica rows of a hot item lie n_hot rows
- * apart instead of next to each other; fold_check: 1 = a folder pass reads a replica word before exchanging it; fold_sleep:
- * s_sleep(8) repetitions between folder passes.  (0, 0, 0, 1) is what the library ships with unless csrc/bpr.hip says otherwise. */
-void gorse_hip_test_set_bpr_tuning(int32_t store_mode, int32_t rep_spread, int32_t fold_check, int32_t fold_sleep);
+/* which item updates of the user-run BPR kernel may take the STORE route (csrc/bpr.hip ST_*): bit 0 = the NEGATIVE item of a
+ * sample, when its class is "cold", is updated by one write-through store of fma(t, lr, row) instead of d atomic dwords (the
+ * reference's own unlocked write, model.go:478-488; its row is then gathered one sample ahead instead of two), bit 1 = the
+ * positive item likewise, bit 2 = the store adds to a row re-read in the same iteration instead of the gathered snapshot;
+ * < 0 = the library's default.  Which items are cold is fixed at gorse_mf_create (gorse_hip_test_set_bpr_cold_window). */
+void gorse_hip_test_set_bpr_store_mode(int32_t store_mode);
 /* test hook: runs the user-run schedule's preparation of ONE chunk (user draws, counting sort of the sample ids by user, item
  * draws by run: csrc/bpr.hip launch_prepare_users) for samples [sample_base, sample_base + n) and returns the run offsets
  * (off[u] .. off[u + 1] = the positions of user u's samples; off[U] .. off[U + 1] = samples whose user draw failed) and the

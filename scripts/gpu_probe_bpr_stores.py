@@ -8,7 +8,7 @@ Q[r][0] / 2^-31 = (#times r was a positive) - (#times r was a negative) - (what 
 from gorse_bpr_sample_triplets.  |expected - got| summed over the cold rows is a lower bound of the updates lost there
 (a lost positive and a lost negative of one row cancel), reported relative to the updates those rows received.
 
-usage: gpu_probe_bpr_stores.py [c2] [c3s] [c3] [tune]      Output -> profiles/rNN_*_probe_bpr_stores.txt"""
+usage: gpu_probe_bpr_stores.py [c2] [c3s] [c3]      Output -> profiles/rNN_*_probe_bpr_stores.txt"""
 import json
 import os
 import sys
@@ -50,9 +50,9 @@ def run_case(name, data, d, epochs, ref_ndcg, variants, n_loss):
     U, I = data.U, data.I
     P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.001, 1)
     share = np.bincount(data.uidx, minlength=I) / float(data.n_train)
-    for label, window, store, spread, check, sleep, extra_variant in variants:
+    for label, window, store, extra_variant in variants:
         L.gorse_hip_test_set_bpr_cold_window(window)
-        L.gorse_hip_test_set_bpr_tuning(store, spread, check, sleep)
+        L.gorse_hip_test_set_bpr_store_mode(store)
         L.gorse_hip_test_set_variant(128 | extra_variant)
         mf = capi.MF(U, I, d, data.uptr, data.uidx)
         cold = (share + 1.0 / I) * window < 1.0 if window > 0 else np.zeros(I, bool)
@@ -88,26 +88,20 @@ def run_case(name, data, d, epochs, ref_ndcg, variants, n_loss):
                                           wall / epochs * 1e3, epochs * data.n_train / wall, ndcg, ref_ndcg, lost), flush=True)
         mf.close()
     L.gorse_hip_test_set_bpr_cold_window(-1)
-    L.gorse_hip_test_set_bpr_tuning(-1, 0, 0, 1)
+    L.gorse_hip_test_set_bpr_store_mode(-1)
     L.gorse_hip_test_set_variant(0)
 
 
 def store_variants(windows):
-    v = [("atomics only", 0, 0, 0, 0, 1, 0)]
+    v = [("atomics only", 0, 0, 0), ("atomics only, round-3 preparation", 0, 0, 1 << 26)]
     for w in windows:
-        v += [("W=%d stores: negatives" % w, w, 1, 0, 0, 1, 0), ("W=%d stores: negatives + positives" % w, w, 3, 0, 0, 1, 0),
-              ("W=%d stores: negatives, live re-read" % w, w, 5, 0, 0, 1, 0), ("W=%d stores: both, live re-read" % w, w, 7, 0, 0, 1, 0)]
-    v += [("stores on every item but the hot ones", 1, 3, 0, 0, 1, 0), ("stores on every item, no replicas", 1, 3, 0, 0, 1, 32)]
+        v += [("W=%d stores: negatives" % w, w, 1, 0), ("W=%d stores: negatives + positives" % w, w, 3, 0),
+              ("W=%d stores: negatives, live re-read" % w, w, 5, 0), ("W=%d stores: both, live re-read" % w, w, 7, 0)]
+    v += [("stores on every item but the hot ones", 1, 3, 0)]
     return v
 
 
-tune_variants = [("atomics only (shipping)", 0, 0, 0, 0, 1, 0), ("replicas spread", 0, 0, 1, 0, 1, 0), ("folder checks before exchanging", 0, 0, 0, 1, 1, 0),
-                 ("folder sleeps 8x", 0, 0, 0, 0, 8, 0), ("folder sleeps 32x", 0, 0, 0, 0, 32, 0), ("spread + check", 0, 0, 1, 1, 1, 0),
-                 ("spread + check + sleep 8x", 0, 0, 1, 1, 8, 0), ("check + sleep 8x", 0, 0, 0, 1, 8, 0), ("check + sleep 32x", 0, 0, 0, 1, 32, 0),
-                 ("no replicas", 0, 0, 0, 0, 1, 32),
-                 ("round-3 preparation (per-sample sampler, triplets scattered)", 0, 0, 0, 0, 1, 1 << 26)]
-
-if "c2" in args or "tune" in args:
+if "c2" in args:
     data = synth.s_ml1m()
     d, epochs = 64, 8
     srt = orc.sort_rows(data.uptr, data.uidx)
@@ -115,10 +109,7 @@ if "c2" in args or "tune" in args:
     for ep in range(epochs):
         o.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, 77, 1 + ep, 0, data.n_train, 0.05, 0.01)
     ref = o.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)[0]
-    if "tune" in args:
-        run_case("c2", data, d, epochs, ref, tune_variants, 0)
-    if "c2" in args:
-        run_case("c2", data, d, epochs, ref, store_variants([4096, 2048]), data.n_train)
+    run_case("c2", data, d, epochs, ref, store_variants([32768, 2048]), data.n_train)
 if "c3s" in args:
     data = synth.hold_out(synth.s_big_shard(rank=0, world=8), 8192, 99, 5)
     d = 128
@@ -128,12 +119,10 @@ if "c3s" in args:
     o.bpr_epoch_sampled(P, Q, data.uptr, data.uidx, srt, 77, 1, 0, data.n_train, 0.05, 0.01)
     ref = o.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)[0]
     print("c3s sequential oracle epoch: %.0f s" % (time.perf_counter() - t0), flush=True)
-    if "tune" in args:
-        run_case("c3s", data, d, 1, ref, tune_variants, 0)
-    run_case("c3s", data, d, 1, ref, store_variants([131072, 32768, 8192]), data.n_train)
+    run_case("c3s", data, d, 1, ref, store_variants([32768]), data.n_train)
 if "c3" in args:
     gold = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "c3full_oracle_ndcg.json")))
     t0 = time.perf_counter()
     data = synth.hold_out(synth.s_big_full(), 8192, 99, 5)
     print("c3 data set ready in %.0f s" % (time.perf_counter() - t0), flush=True)
-    run_case("c3", data, 128, 1, gold["ndcg_after_one_epoch"], store_variants([131072, 32768, 8192]), 32_000_000)
+    run_case("c3", data, 128, 1, gold["ndcg_after_one_epoch"], store_variants([32768, 8192]), 32_000_000)

@@ -449,7 +449,7 @@ def test_bpr_user_runs_cold_rows_by_store_are_bit_exact(oracle, store_mode):
     i, j = items[:n].copy(), items[n:].copy()
     P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 9)
     L.gorse_hip_test_set_bpr_cold_window(1024)  # 1 / I < 1 / 1024 <= share of every item of the dataset
-    L.gorse_hip_test_set_bpr_tuning(store_mode, 0, 0, 1)
+    L.gorse_hip_test_set_bpr_store_mode(store_mode)
     L.gorse_hip_test_set_variant(VARIANT_USER_RUNS | VARIANT_STABLE_RANK)
     try:
         mf = capi.MF(U, I, d, uptr, uidx)
@@ -478,7 +478,7 @@ def test_bpr_user_runs_cold_rows_by_store_are_bit_exact(oracle, store_mode):
         assert np.abs((gQ2[b] - Q[b]) + 3 * step).max() < 0.02 * np.abs(3 * step).max()
     finally:
         L.gorse_hip_test_set_variant(0)
-        L.gorse_hip_test_set_bpr_tuning(-1, 0, 0, 1)
+        L.gorse_hip_test_set_bpr_store_mode(-1)
         L.gorse_hip_test_set_bpr_cold_window(-1)
 
 
