@@ -92,12 +92,12 @@ __global__ __launch_bounds__(256) void bpr_sample_kernel(int32_t U, int32_t I, c
 // passes so that what is random about the memory accesses shrinks from ~13 cache lines per sample to ~3:
 //   bpr_sample_user_kernel  : sample s draws its USER only (model.go:452-458; one look at the row pointers) and takes its
 //                             arrival rank in that user's run (the count pass of the counting sort by user);
-//   scan + bpr_scatter_ids  : position of sample s in the user-sorted order -> perm[position] = s (4 bytes scattered per
-//                             sample instead of the whole triplet);
-//   bpr_sample_items_kernel : one 16-lane group per USER walks the user's run: every lane replays the stream of one sample up
-//                             to the user draw (no memory: the first non-empty row drawn IS the user) and draws the positive
-//                             and the negative (model.go:459-468) -- the user's two item rows are read by all samples of the
-//                             run while they sit in the cache -- and writes (i, j) straight to the sorted position.
+//   scan + bpr_scatter_ids  : position of sample s in the user-sorted order -> perm[position] = s, su[position] = its user
+//                             (8 bytes scattered per sample instead of the whole triplet);
+//   bpr_sample_items_kernel : one thread per SORTED position replays the stream of its sample up to the user draw (no memory:
+//                             the first non-empty row drawn IS the user) and draws the positive and the negative
+//                             (model.go:459-468) -- neighbouring threads hold samples of the same user, whose two item rows are
+//                             read while they sit in the cache -- and writes (i, j) straight to the sorted position.
 // A sample whose negative cannot be found (kMaxDraws rejections: a user holding nearly every item) keeps its place in the run
 // with j = -1; bpr_update_user_kernel skips it.
 __global__ __launch_bounds__(256) void bpr_sample_user_kernel(int32_t U, const int64_t *__restrict__ uptr, uint64_t seed,
@@ -123,49 +123,48 @@ __global__ __launch_bounds__(256) void bpr_sample_user_kernel(int32_t U, const i
 
 __global__ __launch_bounds__(256) void bpr_scatter_ids_kernel(const int32_t *__restrict__ key, const int32_t *__restrict__ rank,
                                                               const int32_t *__restrict__ bucket, int64_t n, int32_t U,
-                                                              int32_t *__restrict__ perm) {
+                                                              int32_t *__restrict__ perm, int32_t *__restrict__ su) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         const int32_t k = key[s] < 0 ? U : key[s];
-        perm[(int64_t)bucket[k] + rank[s]] = (int32_t)s;
+        const int64_t pos = (int64_t)bucket[k] + rank[s];
+        perm[pos] = (int32_t)s;
+        su[pos] = key[s];
     }
 }
 
-__global__ __launch_bounds__(kBlock) void bpr_sample_items_kernel(int32_t U, int32_t I, const int64_t *__restrict__ uptr,
-                                                                  const int32_t *__restrict__ uidx,
-                                                                  const int32_t *__restrict__ usorted, uint64_t seed,
-                                                                  uint64_t epoch, int64_t sample_base,
-                                                                  const int32_t *__restrict__ off,
-                                                                  const int32_t *__restrict__ perm, int32_t *__restrict__ si,
-                                                                  int32_t *__restrict__ sj, int32_t *__restrict__ fail_count) {
-    const int lane = threadIdx.x & (kGroup - 1);
-    const int64_t group = (int64_t)blockIdx.x * kGroupsPerBlock + threadIdx.x / kGroup;
-    const int64_t ngroups = (int64_t)gridDim.x * kGroupsPerBlock;
-    for (int64_t u = group; u < U; u += ngroups) {
-        const int beg = off[u], end = off[u + 1];
-        if (beg >= end) continue;
+__global__ __launch_bounds__(256) void bpr_sample_items_kernel(int32_t U, int32_t I, const int64_t *__restrict__ uptr,
+                                                               const int32_t *__restrict__ uidx,
+                                                               const int32_t *__restrict__ usorted, uint64_t seed,
+                                                               uint64_t epoch, int64_t sample_base, int64_t n,
+                                                               const int32_t *__restrict__ su,
+                                                               const int32_t *__restrict__ perm, int32_t *__restrict__ si,
+                                                               int32_t *__restrict__ sj, int32_t *__restrict__ fail_count) {
+    // one thread per SORTED position: neighbouring threads hold samples of the same user, so the user's row pointers and its
+    // two item rows are shared by the lanes of a wave (and by the waves that follow) while they sit in the cache
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t u = su[t];
+        if (u < 0) continue;  // no user could be drawn: the positions behind the last run, never read
         const int64_t rbeg = uptr[u];
         const int64_t cnt = uptr[u + 1] - rbeg;
-        for (int t = beg + lane; t < end; t += kGroup) {
-            Philox g;
-            g.init(seed, epoch, (uint64_t)(sample_base + perm[t]));
-            // the user draw again: rows drawn before u were empty (u is the first non-empty one), no look-up needed
-            for (int k = 0; k < kMaxDraws; k++)
-                if (g.int31n(U) == (int32_t)u) break;
-            int32_t pi = uidx[rbeg + g.int31n((int32_t)cnt)], nj = -1;
-            for (int k = 0; k < kMaxDraws; k++) {
-                const int32_t c = g.int31n(I);
-                if (!row_contains(usorted + rbeg, cnt, c)) {
-                    nj = c;
-                    break;
-                }
+        Philox g;
+        g.init(seed, epoch, (uint64_t)(sample_base + perm[t]));
+        // the user draw again: rows drawn before u were empty (u is the first non-empty one), no look-up needed
+        for (int k = 0; k < kMaxDraws; k++)
+            if (g.int31n(U) == u) break;
+        int32_t pi = uidx[rbeg + g.int31n((int32_t)cnt)], nj = -1;
+        for (int k = 0; k < kMaxDraws; k++) {
+            const int32_t c = g.int31n(I);
+            if (!row_contains(usorted + rbeg, cnt, c)) {
+                nj = c;
+                break;
             }
-            if (nj < 0) {
-                atomicAdd(fail_count, 1);
-                pi = -1;
-            }
-            si[t] = pi;
-            sj[t] = nj;
         }
+        if (nj < 0) {
+            atomicAdd(fail_count, 1);
+            pi = -1;
+        }
+        si[t] = pi;
+        sj[t] = nj;
     }
 }
 
@@ -356,6 +355,8 @@ __global__ __launch_bounds__(256) void bpr_fold_kernel(HotRows hot, float *Q, in
         }
         if (sum != 0.0f) Q[(int64_t)hot.items[slot] * d + e] += sum;
     }
+    // every worker of the update launch has finished (stream order): the arrival counter goes back to zero for the next launch
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hot.done = 0;
 }
 
 // ---- counting sort by user ---------------------------------------------------------------------
@@ -623,8 +624,36 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
     }
 }
 
+// the whole scan by ONE workgroup, tile after tile (a few thousand counters: two launches and two dependencies fewer)
+__global__ __launch_bounds__(256) void scan_small_kernel(int32_t *__restrict__ data, int64_t m) {
+    __shared__ int32_t lds[4];
+    int32_t carry = 0;
+    for (int64_t t0 = 0; t0 < m; t0 += kScanTile) {
+        const int64_t base = t0 + (int64_t)threadIdx.x * 8;
+        int32_t x[8], v = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            x[e] = base + e < m ? data[base + e] : 0;
+            v += x[e];
+        }
+        int32_t total;
+        int32_t run = carry + block_exclusive_scan_256(v, lds, &total);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (base + e < m) data[base + e] = run;
+            run += x[e];
+        }
+        carry += total;
+    }
+}
+
 int32_t exclusive_scan_i32(int32_t *data, int64_t m, int32_t *tmp, hipStream_t st) {
     const int64_t nt = ceil_div(m, kScanTile);
+    if (nt <= 16) {
+        scan_small_kernel<<<dim3(1), dim3(256), 0, st>>>(data, m);
+        GORSE_HIP_CHECK(hipGetLastError());
+        return GORSE_OK;
+    }
     scan_tile_sums_kernel<<<dim3((unsigned)nt), dim3(256), 0, st>>>(data, m, tmp);
     scan_sums_kernel<<<dim3(1), dim3(256), 0, st>>>(tmp, nt);
     scan_apply_kernel<<<dim3((unsigned)nt), dim3(256), 0, st>>>(data, m, tmp);
@@ -674,7 +703,10 @@ bool user_runs_supported(const gorse_mf *h) {
 }
 
 // which item updates may take the store route (gorse_hip_test_set_bpr_store_mode)
-constexpr int kDefaultStoreMode = 0;
+// ST_NEG: measured at C3 whole (profiles/r04_b_probe_bpr_stores_*.txt): update kernel 89 -> 60 ms per epoch, 4 % of the updates of cold rows
+// overwritten, NDCG@10 0.6100 against 0.6096 with atomics only (sequential oracle 0.6126); the positive side stays atomic -- by store
+// it costs 0.003-0.005 of NDCG for 6 % more speed
+constexpr int kDefaultStoreMode = 1;
 int g_store_mode = kDefaultStoreMode;  // ST_* bits of bpr_update_user_kernel
 
 HotRows make_hot(const gorse_mf *h) {
@@ -692,8 +724,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     int folders = 0;
     if (h->n_hot > 0 && !(g_variant & 32)) {
         hot.n_hot = h->n_hot;
-        folders = kFolderBlocks;
-        GORSE_HIP_CHECK(hipMemsetAsync(h->hot_done.p, 0, sizeof(int32_t), st));
+        folders = kFolderBlocks;  // hot_done is zero: gorse_mf_create, and every fold kernel leaves it so
     }
     blocks += folders;
     // the negative's slot look-up is one more gather per sample: only where a draw has a fair chance of meeting a hot item (C2: a
@@ -750,8 +781,7 @@ int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, co
     int folders = 0;
     if (MODE == MODE_ATOMIC && h->n_hot > 0 && !(g_variant & 32)) {
         hot.n_hot = h->n_hot;
-        folders = kFolderBlocks;
-        GORSE_HIP_CHECK(hipMemsetAsync(h->hot_done.p, 0, sizeof(int32_t), st));
+        folders = kFolderBlocks;  // hot_done is zero: gorse_mf_create, and every fold kernel leaves it so
     }
     blocks += folders;
     dim3 grid((unsigned)blocks), block(kBlock);
@@ -821,13 +851,12 @@ int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t
     h->prof.end(tok, st);
     tok = h->prof.begin(GORSE_PROF_BPR_SORT, st);
     GORSE_TRY(exclusive_scan_i32(bucket, m, h->scan_tmp2.p, st));
-    bpr_scatter_ids_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(key, rank, bucket, n, (int32_t)h->U, perm);
+    bpr_scatter_ids_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(key, rank, bucket, n, (int32_t)h->U, perm, sorted);
     h->prof.end(tok, st);
     tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
-    const int64_t gblocks = std::min<int64_t>(ceil_div(h->U, kGroupsPerBlock), 256 * 16);
-    bpr_sample_items_kernel<<<dim3((unsigned)gblocks), dim3(kBlock), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
-                                                                              h->uidx_sorted.p, seed, epoch, base, bucket, perm,
-                                                                              sorted + cap, sorted + 2 * cap, h->fail_count.p);
+    bpr_sample_items_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
+                                                                          h->uidx_sorted.p, seed, epoch, base, n, sorted, perm,
+                                                                          sorted + cap, sorted + 2 * cap, h->fail_count.p);
     h->prof.end(tok, st);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;

@@ -187,7 +187,9 @@ int32_t mf_score_device(gorse_mf *h, const int32_t *us, const int32_t *is, int64
 
 int g_mf_flat_streams = 1;  // 1 = both streams of a handle at the same priority; 0 (probe) = the update stream ahead
 extern "C" void gorse_hip_test_set_stream_priorities(int32_t on) { g_mf_flat_streams = on ? 0 : 1; }
-constexpr int64_t kDefaultColdWindow = 0;
+// 32768: no item of a catalogue smaller than that is cold (S-ml1m: every update stays an atomic; with 2048 there, a third of
+// the cold rows' updates were overwritten); at C3 98 % of the items are
+constexpr int64_t kDefaultColdWindow = 32768;
 int64_t g_mf_cold_window = kDefaultColdWindow;  // items expected to be touched less than once per this many samples are "cold" (0 = none)
 extern "C" void gorse_hip_test_set_bpr_cold_window(int64_t samples) { g_mf_cold_window = samples < 0 ? kDefaultColdWindow : samples; }
 
@@ -322,6 +324,7 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_TRY(h->hot_items.alloc(hot.size()));
             GORSE_TRY(h->hot_rep.alloc(hot.size() * 8 * (size_t)d));
             GORSE_TRY(h->hot_done.alloc(1));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->hot_done.p, 0, sizeof(int32_t), h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->hot_slot.p, slot.data(), (size_t)I * sizeof(int32_t), hipMemcpyHostToDevice,
                                            h->stream));
             if (!hot.empty())

@@ -48,8 +48,12 @@ extern "C" {
 #define GORSE_ERR_NOMEM (-6)
 
 /* BPR update schedules (gorse_bpr_epoch / gorse_bpr_apply_triplets `mode`) */
-#define GORSE_BPR_HOGWILD_ATOMIC 0 /* all samples of a chunk in flight, item-run privatised + fp32 atomics:  *
-                                    * no lost updates (production schedule, Jobs > 1)                       */
+#define GORSE_BPR_HOGWILD_ATOMIC 0 /* production schedule (Jobs > 1): all samples of a chunk in flight.  User rows   *
+                                    * are updated exactly (one group owns a user's run), item rows by fp32 atomics *
+                                    * (hot items through replica rows) -- except the NEGATIVE item of a sample when *
+                                    * it is a cold item (expected to be touched less than once per 32768 samples):  *
+                                    * that update is the reference's own unlocked load/fma/store (model.go:478-488) *
+                                    * and can overwrite a concurrent update of the same row, as the CPU Hogwild can */
 #define GORSE_BPR_SEQUENTIAL 1     /* dependency-levelled: bit-faithful to the reference with Jobs = 1  */
 #define GORSE_BPR_HOGWILD_RACY 2   /* write-through load/fma/store, lost updates like the CPU Hogwild   */
 
@@ -135,7 +139,7 @@ int32_t gorse_bpr_epoch_enqueue(gorse_mf *h, int64_t n_samples, float lr, float 
                                 int64_t sample_base, int32_t mode);
 /* Which form of the GORSE_BPR_HOGWILD_ATOMIC schedule this handle runs: 1 = user runs (the chunk's triplets are
  * counting-sorted by user and one 16-lane group applies all samples of a user with p_u in registers; chosen when
- * there are >= 4096 users and nFactors is 16/32/64/128), 0 = one group per sample.  Both apply exactly the triplets
+ * there are >= 4096 users and nFactors is 8/16/32/64/128), 0 = one group per sample.  Both apply exactly the triplets
  * gorse_bpr_sample_triplets returns, in a different (Hogwild-legal) order; GORSE_BPR_SCHEDULE=users|samples in the
  * environment overrides the choice. */
 int32_t gorse_mf_bpr_schedule(gorse_mf *h, int32_t *user_runs /*out*/);
@@ -217,10 +221,10 @@ int32_t gorse_mf_device_ptrs(gorse_mf *h, float **P /*out: device*/, float **Q /
 int32_t gorse_mf_synchronize(gorse_mf *h);
 int32_t gorse_mf_set_profiling(gorse_mf *h, int32_t on);
 #define GORSE_PROF_BPR_UPDATE 0
-#define GORSE_PROF_BPR_SAMPLE 1
+#define GORSE_PROF_BPR_SAMPLE 1 /* the sampler kernels (user draws; item draws by run) */
 #define GORSE_PROF_ALS_SWEEP 2
 #define GORSE_PROF_ALS_GRAM 3
-#define GORSE_PROF_BPR_SORT 4 /* counting sort of a chunk's triplets by positive item (rank + scan + scatter) */
+#define GORSE_PROF_BPR_SORT 4 /* counting sort of a chunk's sample ids by USER (scan of the run counters + scatter) */
 #define GORSE_PROF_COMM 5 /* the RCCL collectives of gorse_mf_item_allreduce / gorse_mf_rows_allgather          */
 #define GORSE_PROF_NCLASSES 6
 int32_t gorse_mf_get_profile(gorse_mf *h, int32_t kernel_class, int64_t *launches, double *total_ms);
