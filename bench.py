@@ -101,25 +101,25 @@ def write_notes(notes):
 class ClockSampler:
     """Shader clock of the device while a leg runs: a thread reads the current level of pp_dpm_sclk (amdgpu sysfs) every 5 ms.
     The MFMA-bound sweep follows the clock the box sustains under load (MI355X_MICROARCH.md, DVFS); its roofline fraction is
-    quoted against the spec peak, so the line says what clock the number was measured at.  None when the file is not there."""
+    quoted against the spec peak, so the line says what clock the number was measured at.  A box shows the sysfs nodes of ALL
+    its GPUs whichever one the process may use: every card is sampled and the busiest one (highest mean clock) is reported.
+    None when no such file is readable."""
 
     def __init__(self, local):
-        self.path, self.vals, self.stop, self.th = None, [], False, None
+        self.paths, self.vals, self.stop, self.th = [], [], False, None
         try:
-            cards = sorted(c for c in os.listdir("/sys/class/drm") if c.startswith("card") and c[4:].isdigit())
-            amd = []
-            for c in cards:
+            for c in sorted(os.listdir("/sys/class/drm")):
                 f = "/sys/class/drm/%s/device/pp_dpm_sclk" % c
-                if os.path.exists(f):
-                    amd.append(f)
-            if amd:
-                self.path = amd[min(local, len(amd) - 1)]
+                if c.startswith("card") and c[4:].isdigit() and os.path.exists(f):
+                    self.paths.append(f)
         except Exception:
-            self.path = None
+            self.paths = []
+        self.vals = [[] for _ in self.paths]
 
-    def _read(self):
+    @staticmethod
+    def _read(path):
         try:
-            for line in open(self.path):
+            for line in open(path):
                 if "*" in line:
                     return float(line.split(":")[1].strip().split("M")[0])
         except Exception:
@@ -127,12 +127,13 @@ class ClockSampler:
         return None
 
     def __enter__(self):
-        if self.path:
+        if self.paths:
             def loop():
                 while not self.stop:
-                    v = self._read()
-                    if v:
-                        self.vals.append(v)
+                    for k, f in enumerate(self.paths):
+                        v = self._read(f)
+                        if v:
+                            self.vals[k].append(v)
                     time.sleep(0.005)
             self.th = threading.Thread(target=loop, daemon=True)
             self.th.start()
@@ -144,7 +145,8 @@ class ClockSampler:
             self.th.join()
 
     def ghz(self):
-        return float(np.mean(self.vals)) / 1e3 if self.vals else None
+        means = [float(np.mean(v)) for v in self.vals if v]
+        return max(means) / 1e3 if means else None
 
 
 def parse():
@@ -172,6 +174,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
+
+BIG_DRAWS_DEFAULT_LINE = 250_000_000  # scripts/gen_golden_ndcg.py big and the -m gpu test at that size use the same set
 
 BPR_SHAPES = {"ml1m": (64, "S-ml1m 6040x3706x994169 per rank (C2)"),
               "ml100k": (16, "S-ml100k 943x1682x99057 per rank (C1)"),
@@ -885,6 +889,10 @@ def main():
         out["ml100k_d8"] = leg(lambda: bench_bpr(args, "ml100k", 1, 0, local, None, "single GPU", 20, 3, with_cpu=False, factors=8),
                                "BPR positive-samples/sec, S-ml100k nFactors 8")
         out["fit"] = leg(lambda: bench_fit(args, local), "BPR.Fit wall seconds (S-ml1m, nFactors 8 / 16, 30 epochs)")
+        # north_star's 10M x 1M x 128 set: P = 5.1 GB, far outside every cache.  250M draws (220M distinct feedbacks, 22 per user)
+        # instead of --workload big's 1.25e9 so that the set generates in seconds inside the driver's run; same users, same items
+        out["big"] = leg(lambda: bench_bpr(args, "big", 1, 0, local, None, "single GPU", 3, 1, data=synth.s_huge(N=BIG_DRAWS_DEFAULT_LINE),
+                                           with_cpu=False), "BPR positive-samples/sec, 10M users x 1M items, nFactors 128")
     if rank == 0:
         emit(out)
     if world > 1:

@@ -24,7 +24,7 @@ using namespace gorse;
 
 namespace {
 
-int g_variant = 0;  // probe-only ablation bits (1 plain loads, 2/4/8 skip P/Qi/Qj writes)
+int g_variant = 0;  // schedule switches of the tests and probes (gorse_hip_test_set_variant); nothing of it reaches a kernel
 constexpr int MODE_ATOMIC = GORSE_BPR_HOGWILD_ATOMIC;
 constexpr int MODE_EXACT = GORSE_BPR_SEQUENTIAL;
 constexpr int MODE_RACY = GORSE_BPR_HOGWILD_RACY;
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void bpr_sample_items_kernel(int32_t U, int32_
 
 // ---- memory access flavours ------------------------------------------------------------------
 template <int MODE>
-__device__ __forceinline__ float load_row(const float *p, int variant = 0) {
-    if (MODE == MODE_EXACT || (variant & 1))
+__device__ __forceinline__ float load_row(const float *p) {
+    if (MODE == MODE_EXACT)
         return *p;
     else  // agent-scope load: served by L2 (never stale for written-back data), bypasses the CU's L1
         return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -199,7 +199,7 @@ __device__ __forceinline__ float bpr_exp(float x, int exp_mode) {
 // one element of the three updates of model.go:473-488 (operation order of SURVEY.md A2)
 template <int MODE>
 __device__ __forceinline__ void update_elem(float *pu, float *qi, float *qj, int e, float p, float a, float b, float grad,
-                                            float nreg, float lr, bool fused, bool same_item, int variant = 0) {
+                                            float nreg, float lr, bool fused, bool same_item) {
     float t1 = p * grad;
     t1 = fused ? fmaf(a, nreg, t1) : a * nreg + t1;
     float t2 = p * (-grad);
@@ -215,9 +215,9 @@ __device__ __forceinline__ void update_elem(float *pu, float *qi, float *qj, int
         qj[e] = fused ? fmaf(t2, lr, base) : t2 * lr + base;
         pu[e] = fused ? fmaf(t3, lr, p) : t3 * lr + p;
     } else {
-        if (!(variant & 4)) apply<MODE>(qi + e, a, t1, lr, fused);
-        if (!(variant & 8)) apply<MODE>(qj + e, b, t2, lr, fused);
-        if (!(variant & 2)) apply<MODE>(pu + e, p, t3, lr, fused);
+        apply<MODE>(qi + e, a, t1, lr, fused);
+        apply<MODE>(qj + e, b, t2, lr, fused);
+        apply<MODE>(pu + e, p, t3, lr, fused);
     }
 }
 
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
                                                             const int32_t *__restrict__ js,
                                                             const int32_t *__restrict__ order, int64_t begin,
                                                             int64_t end, int d, float lr, float reg, int exp_mode,
-                                                            double *loss, int variant, HotRows hot, int folders) {
+                                                            double *loss, HotRows hot, int folders) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (MODE == MODE_ATOMIC && (int)blockIdx.x < folders) {
         // folder workgroups: drain the replicas until every worker workgroup has finished.  Nobody waits
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
             float p[NC], a[NC], b[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                p[c] = load_row<MODE>(pu + 16 * c + lane, variant);
-                a[c] = load_row<MODE>(qi + 16 * c + lane, variant);
-                b[c] = load_row<MODE>(qj + 16 * c + lane, variant);
+                p[c] = load_row<MODE>(pu + 16 * c + lane);
+                a[c] = load_row<MODE>(qi + 16 * c + lane);
+                b[c] = load_row<MODE>(qj + 16 * c + lane);
             }
             const float diff = dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
             const float ex = bpr_exp(-diff, exp_mode);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
             if (loss && lane == 0) my_loss += (double)log1pf(ex);
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                update_elem<MODE>(pu, qiw, qj, 16 * c + lane, p[c], a[c], b[c], grad, nreg, lr, true, i == j, variant);
+                update_elem<MODE>(pu, qiw, qj, 16 * c + lane, p[c], a[c], b[c], grad, nreg, lr, true, i == j);
         } else {
             float *sp = smem + (size_t)gib * 3 * d, *sa = sp + d, *sb = sa + d;
             for (int e = lane; e < d; e += kGroup) {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void bpr_scatter_by_kernel(const int32_t *__re
 // fma(t, lr, row) instead of d atomic dwords.  ST selects which side may take that route: ST_NEG the negative, ST_POS the
 // positive, ST_LIVE re-reads the row just before the store instead of adding to the snapshot gathered two samples earlier
 // (diagnostic: a shorter window in which another group's update can be overwritten, one more gather per row).
-constexpr int kWarm = -1, kCold = -2;
+constexpr int kCold = -2;  // (-1 = "warm": fp32 atomics straight onto the row)
 constexpr int ST_NEG = 1, ST_POS = 2, ST_LIVE = 4;
 
 // D8: nFactors = 8 (the width of model_test.go:35-48): lanes 0..7 of the group own the eight elements -- the unfused 8-lane tail of
@@ -733,6 +733,13 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     dim3 grid((unsigned)blocks), block(kBlock);
     // cold items by store only where the handle found any (gorse_mf_create: n_cold) -- the atomics-only instantiation otherwise
     const int store_mode = h->n_cold > 0 ? g_store_mode : 0;
+    // the library ships two forms of the kernel (atomics only; cold negatives by store); the positive-side and re-reading forms of
+    // the ablation (profiles/r04_*_probe_bpr_stores_*.txt) exist in `make probe-lib` builds only
+#ifdef GORSE_PROBE
+#define PROBE_CASES(NC) case 3: LAUNCH2(NC, 3); break; case 5: LAUNCH2(NC, 5); break; case 7: LAUNCH2(NC, 7); break;
+#else
+#define PROBE_CASES(NC)
+#endif
 #define LAUNCH2(NC, ST)                                                                                                \
     bpr_update_user_kernel<(NC == 0 ? 1 : NC), ST, NC == 0><<<grid, block, 0, st>>>(                                   \
         h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket, (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, neg_rep)
@@ -740,9 +747,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     do {                                                                                                               \
         switch (store_mode) {                                                                                          \
         case 1: LAUNCH2(NC, 1); break;                                                                                 \
-        case 3: LAUNCH2(NC, 3); break;                                                                                 \
-        case 5: LAUNCH2(NC, 5); break;                                                                                 \
-        case 7: LAUNCH2(NC, 7); break;                                                                                 \
+        PROBE_CASES(NC)                                                                                                \
         default: LAUNCH2(NC, 0); break;                                                                                \
         }                                                                                                              \
     } while (0)
@@ -758,6 +763,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
         LAUNCH(8);
 #undef LAUNCH2
 #undef LAUNCH
+#undef PROBE_CASES
     GORSE_HIP_CHECK(hipGetLastError());
     if (folders > 0) {
         const int64_t fb = std::min<int64_t>(ceil_div((int64_t)hot.n_hot * d, 256), 512);
@@ -787,7 +793,7 @@ int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, co
     dim3 grid((unsigned)blocks), block(kBlock);
 #define LAUNCH(NC, SH)                                                                                               \
     bpr_update_kernel<NC, MODE><<<grid, block, SH, st>>>(h->P.p, h->Q.p, us, is, js, order, begin, end, d, lr, reg, \
-                                                         exp_mode, loss, g_variant, hot, folders)
+                                                         exp_mode, loss, hot, folders)
     if (d == 16)
         LAUNCH(1, 0);
     else if (d == 32)
@@ -1054,6 +1060,16 @@ extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
 extern "C" void gorse_hip_test_set_bpr_chunk(int64_t samples) { g_chunk_override = samples; }
 extern "C" void gorse_hip_test_set_bpr_store_mode(int32_t store_mode) {
     g_store_mode = store_mode < 0 ? kDefaultStoreMode : store_mode;
+#ifndef GORSE_PROBE
+    if (g_store_mode & ~1) g_store_mode &= 1;  // forms the shipped library does not carry fall back to the nearest one it does
+#endif
+}
+extern "C" int32_t gorse_hip_test_probe_build(void) {
+#ifdef GORSE_PROBE
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,

@@ -75,8 +75,10 @@ int pick_log_group() {
 }
 template <int KP>
 int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, hipStream_t s) {  // s: the stream of this launch
-    auto kern = a.trace ? (atomic ? sparse::sparse_tile_kernel<KP, true, true> : sparse::sparse_tile_kernel<KP, false, true>)
-                        : (atomic ? sparse::sparse_tile_kernel<KP, true, false> : sparse::sparse_tile_kernel<KP, false, false>);
+    auto kern = atomic ? sparse::sparse_tile_kernel<KP, true, false> : sparse::sparse_tile_kernel<KP, false, false>;
+#ifdef GORSE_PROBE  // the trace instantiation exists in `make probe-lib` builds only
+    if (a.trace) kern = atomic ? sparse::sparse_tile_kernel<KP, true, true> : sparse::sparse_tile_kernel<KP, false, true>;
+#endif
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), dim3(sparse::kBlock), lds, s>>>(a);
     return GORSE_OK;
@@ -240,10 +242,12 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         a.work = h->work.p, a.n_work = (int32_t)work.size();
         a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
         a.trace = nullptr;
+#ifdef GORSE_PROBE
         if (h->trace_on) {
             GORSE_TRY(h->trace.ensure(work.size()));
             a.trace = h->trace.p;
         }
+#endif
         if (!work.empty()) {
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
             switch (kp) {

@@ -58,7 +58,7 @@ constexpr int kNcbMain = GORSE_SWEEP_NCB;  // 32-query column blocks per wave fo
 // thread grow as the workgroup shrinks)
 constexpr int sweep_waves(bool hist, int kp) { return !hist ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
 constexpr int kWaves = kWavesMain;
-constexpr int kThreads = kWaves * 64;
+[[maybe_unused]] constexpr int kThreads = kWaves * 64;
 // Tiles reach LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, no VGPR round trip, no ds_write pass) when
 // the operand depth is a power of two and the sweep is a main sweep: the LDS image of a tile is then lane-linear (unpadded
 // rows), and the 16-byte pieces of a row are XOR-swizzled by the row number on the SOURCE address and again on the read, so
@@ -1302,6 +1302,7 @@ struct RegHeap {
     }
 };
 
+#ifdef GORSE_PROBE  // the round-2 replay (a wave per query): kept for `make probe-lib` only, the library ships the lane kernel
 // stage 2 of the tie path: one WAVE per query replays the reference's heap over the sorted entries (see the comment
 // above ReplayParams); four queries per workgroup, no LDS.
 __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, int64_t nq, int g_replay_literal) {
@@ -1470,6 +1471,7 @@ __global__ __launch_bounds__(256) void topk_tie_replay_kernel(ReplayParams p, in
         p.out_dist[row * k + e] = kInf;
     }
 }
+#endif  // GORSE_PROBE
 
 
 // ---- the same replay with one LANE per query ----------------------------------------------------------------------
@@ -1867,6 +1869,7 @@ int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     return GORSE_OK;
 }
 
+#ifdef GORSE_PROBE  // `make probe-lib`: the shipped library carries neither the instrumented twin nor its counters
 template <int RB>
 int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {  // the instrumented twin of the C4-shaped sweep (probe only)
     constexpr int BQ = 32 * kNcbMain * kWaves;
@@ -1877,6 +1880,7 @@ int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {  // the instrum
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
+#endif
 
 template <int KP, int NCB, bool HIST, int RB>
 int32_t launch_sweep_ep(gorse_topk *h, const SweepParams &p) {
@@ -1893,10 +1897,12 @@ int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
     // 128-row tiles (one tile hand-over per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
     // queries keeps the 64-row form
     const bool wide = !hist && KP <= 8 && topk_rows_per_tile() == 128;
+#ifdef GORSE_PROBE
     if constexpr (KP == 8 && NCB == kNcbMain) {
         if ((g_topk_variant & 16) && p.ep == EP_COARSE && !hist && p.prof)
             return wide ? launch_sweep_prof<4>(h, p) : launch_sweep_prof<2>(h, p);
     }
+#endif
     if (wide) {
         if constexpr (KP <= 8) return launch_sweep_ep<KP, NCB, false, 4>(h, p);
     }
@@ -2290,8 +2296,12 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 tok = h->prof.begin(GORSE_PROF_TOPK_REPLAY, h->stream);
                 topk_tie_sort_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
                 GORSE_HIP_CHECK(hipGetLastError());
-                // one lane per query (variant bit 19: the round-2 kernel, a wave per query)
+                // one lane per query (probe build, variant bit 19 / 16: the round-2 kernel, a wave per query)
+#ifdef GORSE_PROBE
                 const bool lanes = !(g_topk_variant & (1 << 19)) && !(g_topk_variant & 65536);
+#else
+                const bool lanes = true;
+#endif
                 if (lanes) {
                     const int slots = k + 1;
                     int qpw = 64;
@@ -2309,10 +2319,12 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                     else if (qpw == 32) GORSE_TRY(launch_lanes(std::integral_constant<int, 32>()));
                     else GORSE_TRY(launch_lanes(std::integral_constant<int, 16>()));
                 }
+#ifdef GORSE_PROBE
                 if (!lanes) {
                     topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2, (g_topk_variant & 65536) ? 1 : 0);
                     GORSE_HIP_CHECK(hipGetLastError());
                 }
+#endif
                 h->prof.end(tok, h->stream);
                 f2.resize((size_t)m2);
                 GORSE_HIP_CHECK(hipMemcpyAsync(f2.data(), h->rp_flag.p, (size_t)m2, hipMemcpyDeviceToHost, h->stream));

@@ -17,8 +17,7 @@ extern "C" {
  * 1 = the float32 FreeBSD/math32 scheme restated in oracle/gorse_oracle.c (orc_exp_restated),
  * which makes device and oracle factors comparable bit for bit. */
 void gorse_hip_test_set_exact_exp(int32_t mode);
-/* probe-only switches of the Hogwild update path (bit 0: plain instead of L1-bypassing loads; bits 1/2/3:
- * skip the writes to P / Q[i] / Q[j]; bit 5: no hot-row replicas = the round-1 kernel); bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
+/* schedule switches of the Hogwild update path (bit 5: no hot-row replicas = the round-1 kernel; bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
  * register-resident over a user's samples), bit 25: the user-run schedule sends only the POSITIVE item's update of a hot item
  * through the replicas (round 2), bit 28: force the per-sample schedule, bit 29: the user sort ranks
  * samples in stream order (single thread; makes a run's order deterministic for the parity test).  Used by
@@ -104,6 +103,10 @@ void gorse_hip_test_set_bpr_chunk(int64_t samples);
  * positive item likewise, bit 2 = the store adds to a row re-read in the same iteration instead of the gathered snapshot;
  * < 0 = the library's default.  Which items are cold is fixed at gorse_mf_create (gorse_hip_test_set_bpr_cold_window). */
 void gorse_hip_test_set_bpr_store_mode(int32_t store_mode);
+/* 1 = this is a `make probe-lib` build (csrc/Makefile, -DGORSE_PROBE): it also carries the instrumented twin of the top-k sweep, the
+ * wave-per-query tie replay, the sparse kernel's trace instantiation and the positive-side / re-reading forms of the BPR store
+ * route.  The library `make all` ships (0) answers the switches that would select those with its own nearest form. */
+int32_t gorse_hip_test_probe_build(void);
 /* test hook: runs the user-run schedule's preparation of ONE chunk (user draws, counting sort of the sample ids by user, item
  * draws by run: csrc/bpr.hip launch_prepare_users) for samples [sample_base, sample_base + n) and returns the run offsets
  * (off[u] .. off[u + 1] = the positions of user u's samples; off[U] .. off[U + 1] = samples whose user draw failed) and the

@@ -2,25 +2,18 @@
 
 // logics/cf.go with the MI355X index.  The reference file changes in THREE lines (INTEGRATION.md, "logics/cf.go"): the field
 // `index *ann.HNSW[[]float32]` becomes `index itemsIndex`, the constructor calls `newItemsIndex()`, and the non-hip build gets
-// the one-function file that returns the HNSW.  Everything else -- Add, Search, Marshal, Unmarshal, the framing of the blob --
+// the one-function file that returns the HNSW (cf_nohip.go); the interface itself sits in the untagged cf_index.go.  Everything else -- Add, Search, Marshal, Unmarshal, the framing of the blob --
 // stays the reference's code; only the index section of the blob differs, and BruteforceHIP.Unmarshal reads both forms
 // (common/ann/bruteforce_hip.go).  Not compiled here: no Go toolchain in the build image.
 package logics
 
 import (
-	"io"
-
 	"github.com/gorse-io/gorse/common/ann"
 	"github.com/samber/lo"
 )
 
-// itemsIndex is what MatrixFactorizationItems needs of its index (the methods logics/cf.go:36-128 calls on ann.HNSW).
-type itemsIndex interface {
-	Add(v []float32) int // the slot of the new vector
-	SearchVector(q []float32, n int, prune0 bool) []lo.Tuple2[int, float32]
-	Marshal(w io.Writer) error
-	Unmarshal(r io.Reader) error
-}
+// itemsIndex (the methods logics/cf.go calls on its index) is declared in cf_index.go, which carries no build tag: the
+// non-hip build uses the type too.
 
 type hipItemsIndex struct{ *ann.BruteforceHIP }
 

@@ -147,6 +147,11 @@ func (m *hipModel) evaluate(testSet, trainSet dataset.CFSplit, topK, numCandidat
 func (m *hipModel) evaluateResident(testSet, trainSet dataset.CFSplit, topK, numCandidates int, seed uint64, scorers ...Metric) []float32 {
 	if !m.negativesResident {
 		indptr, indices := flatten(testSet.GetUserFeedback())
+		if len(indices) == 0 {
+			// a validation split without feedback: the reference's Evaluate then averages over zero users (NaN scores,
+			// evaluator.go:69-70); &indices[0] of an empty slice would panic instead -- hand the library one unused word
+			indices = []int32{0}
+		}
 		if rc := C.gorse_mf_sample_user_negatives(m.h, (*C.int64_t)(unsafe.Pointer(&indptr[0])), (*C.int32_t)(unsafe.Pointer(&indices[0])),
 			C.int32_t(numCandidates), C.uint64_t(seed), nil, nil); rc != 0 {
 			panic(hipError("gorse_mf_sample_user_negatives", rc))

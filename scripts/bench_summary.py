@@ -5,8 +5,8 @@ import sys
 
 
 def show(name, d):
-    if not isinstance(d, dict) or d.get("value") is None:
-        print(name, d)
+    if not isinstance(d, dict) or d.get("value") is None or "ms_per_step" not in d:
+        print(name, json.dumps(d)[:400] if isinstance(d, dict) else d)
         return
     r = d.get("roofline", {})
     extra = ""

@@ -14,7 +14,12 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the positive-side and re-reading forms of the store route live in the probe build only (make -C gorse_amd/csrc probe-lib)
+_probe = os.path.join(ROOT, "gorse_amd", "lib", "libgorse_hip_probe.so")
+if os.path.exists(_probe):
+    os.environ.setdefault("GORSE_HIP_LIB", _probe)
 import numpy as np
 
 from gorse_amd import capi, synth

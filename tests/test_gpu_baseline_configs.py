@@ -85,7 +85,7 @@ def test_c3_full_d128_one_epoch_ndcg(oracle):
     """C3 WHOLE on one GPU (1M x 200K x 100M, nFactors 128: P and Q outside the Infinity Cache, 32M-sample chunks): one epoch of
     the default Hogwild schedule, factors finite, NDCG@10 of 8192 held-out users within +-0.01 of ONE SEQUENTIAL ORACLE EPOCH over
     the same set -- 100M sequential SGD steps, minutes of one host core, so the oracle's number is a committed fixture
-    (tests/golden/c3full_oracle_ndcg.json, written by scripts/gen_golden_c3full_ndcg.py on the CPU from the same seeded
+    (tests/golden/c3full_oracle_ndcg.json, written by scripts/gen_golden_ndcg.py on the CPU from the same seeded
     generators); the evaluation of the device's factors runs here."""
     import json
     import os
@@ -107,6 +107,42 @@ def test_c3_full_d128_one_epoch_ndcg(oracle):
     assert np.isfinite(gP).all() and np.isfinite(gQ).all()
     got = ndcg(oracle, data, gP, gQ)
     print("C3 whole NDCG@10 of 8192 held-out users after one epoch: sequential oracle %.4f (fixture; %.0f s of one core), device %.4f "
+          "(epoch %.3f s incl. first-call allocations), untrained %.4f; data set ready in %.0f s"
+          % (gold["ndcg_after_one_epoch"], gold["oracle_epoch_seconds"], got, t_epoch, gold["ndcg_untrained"], t_data))
+    assert gold["ndcg_after_one_epoch"] > gold["ndcg_untrained"] + 0.02
+    assert abs(got - gold["ndcg_after_one_epoch"]) < 0.01
+
+
+def test_big_10m_users_d128_one_epoch_ndcg(oracle):
+    """north_star's "10M x 1M x 128 synthetic set" (BASELINE.json) on one GPU: 10M users x 1M items, 250M draws = 220M feedbacks
+    (the `big` object of bench.py's default line), nFactors 128 -- P is 5.1 GB, Q 512 MB, nothing of the factors fits a cache,
+    128M-sample chunks.  One epoch of the default Hogwild schedule: factors finite, NDCG@10 of 8192 held-out users within +-0.01
+    of ONE SEQUENTIAL ORACLE EPOCH over the same set (tests/golden/big_oracle_ndcg.json, written by scripts/gen_golden_ndcg.py big
+    on the CPU: 2.2e8 sequential steps)."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "big_oracle_ndcg.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/big_oracle_ndcg.json has not been generated (scripts/gen_golden_ndcg.py big)")
+    gold = json.load(open(path))
+    t0 = time.perf_counter()
+    data = synth.hold_out(synth.s_huge(N=250_000_000), 8192, 99, 5)
+    assert data.n_train == gold["n_train"]  # the same data set the fixture was computed on
+    t_data = time.perf_counter() - t0
+    d, lr, reg, seed = 128, 0.05, 0.01, 77
+    P0, Q0 = synth.init_factors_big(data.U, data.I, d, 0.0, 0.001, 1)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P0, Q0)
+    del P0, Q0
+    assert mf.bpr_user_runs()
+    t0 = time.perf_counter()
+    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_ATOMIC)
+    t_epoch = time.perf_counter() - t0
+    gP, gQ = mf.get_factors()
+    mf.close()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+    got = ndcg(oracle, data, gP, gQ)
+    print("10M x 1M set NDCG@10 of 8192 held-out users after one epoch: sequential oracle %.4f (fixture; %.0f s of one core), device %.4f "
           "(epoch %.3f s incl. first-call allocations), untrained %.4f; data set ready in %.0f s"
           % (gold["ndcg_after_one_epoch"], gold["oracle_epoch_seconds"], got, t_epoch, gold["ndcg_untrained"], t_data))
     assert gold["ndcg_after_one_epoch"] > gold["ndcg_untrained"] + 0.02
