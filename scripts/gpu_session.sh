@@ -74,8 +74,10 @@ for STAGE in "$@"; do
         rm -rf "$OUT/pmc_${TAG}_${W}_SQ" ;;
     probe)
         ARGS=$(echo "${B:-}" | tr '+' ' ')
+        PLIB="$ROOT/gorse_amd/lib/libgorse_hip_probe.so"  # the probe build (make -C gorse_amd/csrc probe-lib) when it exists
+        [ -f "$PLIB" ] && export GORSE_HIP_LIB="$PLIB"
         timeout 900 python "scripts/$A" $ARGS > "$OUT/${TAG}_probe_$(basename "$A" .py)${C:+_$C}.txt" 2>&1
-        echo "probe $A exit $?"; cut -c1-220 "$OUT/${TAG}_probe_$(basename "$A" .py)${C:+_$C}.txt" | tail -40 ;;
+        echo "probe $A exit $?"; unset GORSE_HIP_LIB; cut -c1-220 "$OUT/${TAG}_probe_$(basename "$A" .py)${C:+_$C}.txt" | tail -40 ;;
     smoke)
         timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/${TAG}_smoke.txt" 2>&1
         echo "smoke exit $?"; tail -2 "$OUT/${TAG}_smoke.txt" ;;
