@@ -100,6 +100,7 @@ SIGNATURES = {
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
+    "gorse_hip_test_set_sparse_head": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
     "gorse_hip_test_set_scan_literal": (None, [C.c_int32]),
     "gorse_hip_test_set_stream_priorities": (None, [C.c_int32]),

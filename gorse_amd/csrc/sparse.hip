@@ -63,6 +63,17 @@ int64_t g_sparse_heavy = 16384;  // ... and with more than this they are scored 
                                  // <= 0 = never
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
+int g_sparse_head = -1;          // groups a whole-query item visits one by one (the rest in hashed super-visits); -1 = head_groups_of()
+
+// The head: the leading groups (rows come longest first, so the groups' shares of the stored entries fall) that hold more than
+// their even share of the entries -- there a (query, group) visit meets hundreds of postings and the directly indexed accumulators
+// pay; behind them a visit meets a few dozen and the super-visits of sparse_tile_kernel take several groups at once.
+int head_groups_of(const gorse_sparse *h) {
+    if (g_sparse_head >= 0) return std::min<int>(g_sparse_head, h->ngroups);
+    int n = 0;
+    while (n < h->ngroups && h->group_share[(size_t)n] * h->ngroups > 1.0) n++;
+    return std::max(1, std::min(n, h->ngroups));
+}
 
 int pick_log_group() {
     int l = 11;  // 2048 rows: 8 KB of accumulators + 2 KB of stamps + 1 KB of touched list, 10 waves per CU with KP = 256
@@ -157,6 +168,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
     TileArgs a;
     a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG, a.part_stride = (int32_t)ng;
+    a.head_groups = head_groups_of(h);
     a.N = h->N;
     a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
     a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
@@ -548,6 +560,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 }
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
+extern "C" void gorse_hip_test_set_sparse_head(int32_t groups) { g_sparse_head = groups; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
 // 16 uint64 {t0, t1 (100 MHz ticks), query, group + 1 of a long query (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked
 // one list at a time, groups read back densely, groups read back by re-walking, flattened batches, rows shared inside a batch}; returns the number of work items

@@ -55,9 +55,10 @@ constexpr int kBlock = 64;  // one wavefront per workgroup
 constexpr int kGather = 8;  // longest segment the 64-lists-at-once path takes
 
 struct Posting {
-    int32_t loc;  // accumulator of the row: scratch id mod G
+    int32_t loc;  // the row's scratch id (its accumulator in a directly indexed group: loc & (G - 1))
     float val;
 };
+typedef int32_t __attribute__((may_alias)) lds_key;  // hash keys of the super-visits live in the accumulators' LDS words
 
 struct Work {
     int32_t t;      // query of the call
@@ -96,6 +97,8 @@ struct TileArgs {
     const uint32_t *off;
     const Posting *post;
     int32_t ngroups, logG;
+    int32_t head_groups;  // a whole-query item visits the groups [0, head_groups) one by one with directly indexed accumulators and
+                          // the rest in SUPER-VISITS of several groups with hashed accumulators (see sparse_tile_kernel); = ngroups: never
     int32_t part_stride;  // partial rankings per block of part_keys / part_cnt
     int64_t N;
     const int32_t *orig_of, *new_of;  // scratch id <-> caller's row
@@ -313,7 +316,7 @@ __device__ inline void touch(uint16_t *touched, int tcap, GroupState &gs, bool a
 // chunk of the tail groups (a few lists with one or two postings each) pays for 2, not for 8.
 template <bool ATOMIC, bool TRACE, int DEPTH>
 __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8 *tag, uint16_t *touched, int tcap, int lane,
-                                     GroupState &gs, Tracer<TRACE> &tr) {
+                                     GroupState &gs, Tracer<TRACE> &tr, int lm) {
     const uint32_t len = v.e - v.s;
     bool pending = len > 0;
     tr.add(&Trace::fast_chunks);
@@ -321,12 +324,12 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
         tr.add(&Trace::rounds);
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
-            if (pending && (uint32_t)j < len) tag[v.P[j].loc] = (uint8_t)lane;
+            if (pending && (uint32_t)j < len) tag[(v.P[j].loc & lm)] = (uint8_t)lane;
         bool lost = false;
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
             uint32_t stamp = (uint32_t)lane;
-            if (pending && (uint32_t)j < len) stamp = tag[v.P[j].loc];
+            if (pending && (uint32_t)j < len) stamp = tag[(v.P[j].loc & lm)];
             lost = lost | (stamp != (uint32_t)lane);
         }
         const unsigned long long ml = __ballot(lost);
@@ -339,14 +342,14 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
 #pragma unroll
             for (int j = 0; j < DEPTH; j++) {
                 old[j] = 1.0f;
-                if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, v.P[j].loc, __fmul_rn(v.qv, v.P[j].val));
+                if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, (v.P[j].loc & lm), __fmul_rn(v.qv, v.P[j].val));
             }
 #pragma unroll
             for (int j = 0; j < DEPTH; j++) {
                 const unsigned long long m = __ballot(go && (uint32_t)j < len);
                 if (!m) break;
                 gs.walked += (uint32_t)__popcll(m);
-                touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, v.P[j].loc, lane);
+                touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, (v.P[j].loc & lm), lane);
             }
         }
         if (!ml) break;
@@ -364,9 +367,14 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
 // every accumulator still receives its products in ascending index order.  (One list at a time the C3-shard item-to-item
 // pass spent 0.27 us per SEGMENT of 4 postings on average -- 3.2e8 of them, profiles/r02_k_probe_sparse_trace.txt.)
 // Assembly is a wave-uniform walk over the lists; kFlatAhead batches are in flight while one is applied.
-template <bool ATOMIC, bool TRACE>
+// HASH (the super-visits of the tail groups): the rows of several groups share the workgroup's accumulator words as an open-addressed
+// table -- word h of the first half holds a row's scratch id + 1 (0 = free), word S + h its sum -- so the accumulator of a posting
+// is found by probing (multiplicative hash, linear probing, ds_cmpst) instead of loc & lm; everything after that (stamps, rank
+// rounds, ds_add_f32 in issue order) is the same, and `touched` lists the slots this visit claimed.  The caller guarantees
+// at most S / 2 postings per super-visit, so the table never fills.
+template <bool ATOMIC, bool TRACE, bool HASH = false>
 __device__ inline void apply_flattened(const Posting *__restrict__ post, const Visit &v, float *acc, volatile lds_u8 *tag,
-                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Tracer<TRACE> &tr) {
+                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Tracer<TRACE> &tr, int lm) {
     struct Batch {
         Posting P;
         float q;
@@ -402,7 +410,25 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
     };
     auto apply = [&](const Batch &b) {
         const bool have = lane < b.n;
-        const int32_t row = b.P.loc;
+        int32_t row = b.P.loc & lm;
+        bool claimed = false;
+        float *sums = acc;
+        if constexpr (HASH) {  // lm = S - 1
+            const int S = lm + 1;
+            lds_key *hkey = reinterpret_cast<lds_key *>(acc);
+            sums = acc + S;
+            if (have) {
+                const int32_t key = b.P.loc + 1;
+                uint32_t hs = ((uint32_t)b.P.loc * 2654435761u) >> (__builtin_clz((unsigned)S) + 1);
+                for (;;) {
+                    const int32_t old = atomicCAS(&hkey[hs], 0, key);
+                    claimed = old == 0;
+                    if (old == 0 || old == key) break;
+                    hs = (hs + 1) & (uint32_t)lm;
+                }
+                row = (int32_t)hs;
+            }
+        }
         const float term = __fmul_rn(b.q, b.P.val);
         unsigned long long lost = 0;
         if (b.mixed) {
@@ -412,7 +438,7 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
             lost = __ballot(stamp != (uint32_t)lane);
         }
         if (!lost) {
-            if (have) acc_add<ATOMIC>(acc, row, term);
+            if (have) acc_add<ATOMIC>(sums, row, term);
         } else {
             int rank = 0, last = 0;
             while (lost) {
@@ -426,9 +452,9 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
                 tr.add(&Trace::shared_rows);
             }
             for (int rd = 0; rd <= last; rd++)
-                if (have && rank == rd) acc_add<ATOMIC>(acc, row, term);
+                if (have && rank == rd) acc_add<ATOMIC>(sums, row, term);
         }
-        touch(touched, tcap, gs, have, row, lane);
+        touch(touched, tcap, gs, HASH ? claimed : have, row, lane);
         gs.walked += (uint32_t)b.n;
         tr.add(&Trace::batches);
     };
@@ -491,8 +517,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const uint32_t *off = a.off;
         const Posting *post = a.post;
         const int dir_stride = a.ngroups;
-        const int nviews = whole ? a.ngroups : 1;
+        const int nviews = whole ? a.head_groups : 1;  // a whole-query item: the head groups here, the others in super-visits below
         const int nacc = NL;
+        const int lm = NL - 1;
         const int tcap = nacc >> 2;
         const int nch = (int)(((int64_t)L + kBlock - 1) / kBlock);  // chunks of 64 indices
         const int64_t V = (int64_t)nch * nviews;                    // visits, view-major
@@ -535,6 +562,71 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         stage2(1, v1);
         stage3(v0);
         GroupState gs{0, 0};
+        // one candidate per lane: sid = the row's scratch id, x = its sum; og = orig_of[sid] where the caller has loaded it
+        auto consider = [&](bool have, int32_t sid, float x, int32_t og, bool og_loaded) {
+            have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
+            if (!__ballot(have)) return;
+            my_hit += have;
+            have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
+            const uint32_t ord = score_ord(x);
+            my_pos += have && ord > kZeroOrd;
+            my_neg += have && ord < kZeroOrd;
+            const bool cand = have && ord >= (uint32_t)(thr >> 32);
+            if (!__ballot(cand)) return;
+            if (!og_loaded) og = cand ? a.orig_of[sid] : 0;
+            const unsigned long long key = cand ? make_key(ord, og) : 0;
+            push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
+        };
+        // reads group gg's directly indexed accumulators back (a scan, or the touched list) and leaves them zero
+        auto read_back = [&](int gg) {
+            const unsigned long long c0 = tr.now();
+            if (gs.walked > 0) {
+                // og = orig_of[sid], loaded one step ahead of its use (the read-back used to wait for this gather inside every step
+                // that had a candidate: 43 us per group of 2048 accumulators, profiles/r02_k_probe_sparse_trace.txt)
+                auto sid_of = [&](int32_t i) { return (int32_t)((gg << a.logG) + i); };  // N fits int32
+                auto orig_at = [&](bool in, int32_t i) {
+                    const int32_t sid = sid_of(i);
+                    return in && sid < a.N ? a.orig_of[sid] : 0;
+                };
+                if ((int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
+                    tr.add(&Trace::dense_groups);
+                    constexpr int kStep = 4;
+                    int32_t og_next[kStep];
+#pragma unroll
+                    for (int j = 0; j < kStep; j++) og_next[j] = orig_at(j * kBlock + lane < nacc, j * kBlock + lane);
+                    for (int i0 = 0; i0 < nacc; i0 += kStep * kBlock) {
+                        int32_t og[kStep];
+                        float x[kStep];
+#pragma unroll
+                        for (int j = 0; j < kStep; j++) {
+                            const int i = i0 + j * kBlock + lane, in = i0 + (kStep + j) * kBlock + lane;
+                            og[j] = og_next[j];
+                            og_next[j] = orig_at(in < nacc, in);
+                            x[j] = i < nacc ? acc[i] : 0.0f;
+                            if (__float_as_uint(x[j]) != 0) acc[i] = 0.0f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < kStep; j++)
+                            consider(i0 + j * kBlock + lane < nacc, sid_of(i0 + j * kBlock + lane), x[j], og[j], true);
+                    }
+                } else {
+                    tr.add(&Trace::sparse_groups);
+                    for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {
+                        const bool have = i0 + lane < gs.tcnt;
+                        const int i = have ? (int)touched[i0 + lane] : 0;
+                        const float x = have ? acc_take(acc, i) : 0.0f;  // an accumulator listed twice: the first taker gets it
+                        consider(have, sid_of(i), x, 0, false);  // few candidates once the threshold has risen: the gather is the exception
+                    }
+                }
+                walked_q += gs.walked;
+            }
+            if constexpr (TRACE) {
+                const unsigned long long c1 = tr.now();
+                tr.r.ticks_back += (uint32_t)(c1 - c0);
+                if (whole && gg == 7) tr.r.ticks_head = (uint32_t)(c1 - tr.r.t0);
+            }
+            gs = GroupState{0, 0};
+        };
         int c = 0;  // chunk of visit v inside its view
         int g = whole ? 0 : wk.part;
         for (int64_t v = 0; v < V; v++) {
@@ -550,83 +642,102 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                     const bool once = !__ballot(len > (uint32_t)kGather);
                     if (once) {
                         if (!__ballot(len > 2u))
-                            apply_at_once<ATOMIC, TRACE, 2>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                            apply_at_once<ATOMIC, TRACE, 2>(v0, acc, tag, touched, tcap, lane, gs, tr, lm);
                         else if (!__ballot(len > 4u))
-                            apply_at_once<ATOMIC, TRACE, 4>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                            apply_at_once<ATOMIC, TRACE, 4>(v0, acc, tag, touched, tcap, lane, gs, tr, lm);
                         else
-                            apply_at_once<ATOMIC, TRACE, kGather>(v0, acc, tag, touched, tcap, lane, gs, tr);
+                            apply_at_once<ATOMIC, TRACE, kGather>(v0, acc, tag, touched, tcap, lane, gs, tr, lm);
                     } else
-                        apply_flattened<ATOMIC, TRACE>(post, v0, acc, tag, touched, tcap, lane, gs, tr);
+                        apply_flattened<ATOMIC, TRACE>(post, v0, acc, tag, touched, tcap, lane, gs, tr, lm);
                     tr.add(once ? &Trace::ticks_once : &Trace::ticks_flat, (uint32_t)(tr.now() - c0));
                 }
             }
             if (++c == nch) {  // the view is complete: read it back
-                const unsigned long long c0 = tr.now();
-                if (gs.walked > 0) {
-                    // sid = the row's scratch id, og = orig_of[sid], loaded one step ahead of its use (the read-back used to wait
-                    // for this gather inside every step that had a candidate: 43 us per group of 2048 accumulators,
-                    // profiles/r02_k_probe_sparse_trace.txt)
-                    auto sid_of = [&](int32_t i) { return (int32_t)((g << a.logG) + i); };  // N fits int32
-                    auto orig_at = [&](bool in, int32_t i) {
-                        const int32_t sid = sid_of(i);
-                        return in && sid < a.N ? a.orig_of[sid] : 0;
-                    };
-                    auto consider = [&](bool have, int32_t i, float x, int32_t og, bool og_loaded) {
-                        have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
-                        if (!__ballot(have)) return;
-                        const int32_t sid = sid_of(i);
-                        my_hit += have;
-                        have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
-                        const uint32_t ord = score_ord(x);
-                        my_pos += have && ord > kZeroOrd;
-                        my_neg += have && ord < kZeroOrd;
-                        const bool cand = have && ord >= (uint32_t)(thr >> 32);
-                        if (!__ballot(cand)) return;
-                        if (!og_loaded) og = cand ? a.orig_of[sid] : 0;
-                        const unsigned long long key = cand ? make_key(ord, og) : 0;
-                        push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
-                    };
-                    if ((int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
-                        tr.add(&Trace::dense_groups);
-                        constexpr int kStep = 4;
-                        int32_t og_next[kStep];
-#pragma unroll
-                        for (int j = 0; j < kStep; j++) og_next[j] = orig_at(j * kBlock + lane < nacc, j * kBlock + lane);
-                        for (int i0 = 0; i0 < nacc; i0 += kStep * kBlock) {
-                            int32_t og[kStep];
-                            float x[kStep];
-#pragma unroll
-                            for (int j = 0; j < kStep; j++) {
-                                const int i = i0 + j * kBlock + lane, in = i0 + (kStep + j) * kBlock + lane;
-                                og[j] = og_next[j];
-                                og_next[j] = orig_at(in < nacc, in);
-                                x[j] = i < nacc ? acc[i] : 0.0f;
-                                if (__float_as_uint(x[j]) != 0) acc[i] = 0.0f;
-                            }
-#pragma unroll
-                            for (int j = 0; j < kStep; j++) consider(i0 + j * kBlock + lane < nacc, i0 + j * kBlock + lane, x[j], og[j], true);
-                        }
-                    } else {
-                        tr.add(&Trace::sparse_groups);
-                        for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {
-                            const bool have = i0 + lane < gs.tcnt;
-                            const int i = have ? (int)touched[i0 + lane] : 0;
-                            const float x = have ? acc_take(acc, i) : 0.0f;  // an accumulator listed twice: the first taker gets it
-                            consider(have, i, x, 0, false);  // few candidates once the threshold has risen: the gather is the exception
-                        }
-                    }
-                    walked_q += gs.walked;
-                }
-                if constexpr (TRACE) {
-                    const unsigned long long c1 = tr.now();
-                    tr.r.ticks_back += (uint32_t)(c1 - c0);
-                    if (whole && g == 7) tr.r.ticks_head = (uint32_t)(c1 - tr.r.t0);
-                }
-                gs = GroupState{0, 0};
+                read_back(g);
                 c = 0;
                 g++;
             }
             v0 = v1, v1 = v2, v2 = v3;
+        }
+        // ---- the tail groups of a whole-query item: SUPER-VISITS ------------------------------------------------------------
+        // Behind the head groups a (query, group) visit finds a few dozen postings spread over as many lists, and its fixed cost
+        // (three pipeline stages, stamps, read-back: ~460 instructions) was 70 % of the C3-shard pass (profiles/r02_af_probe_sparse_trace.txt).
+        // Here w consecutive groups are taken at once: the directory gives every list's postings in [g, g + w) as ONE contiguous
+        // segment (off is a prefix array over (list, group)), a count pass sizes w so that at most S / 2 postings -- hence at most
+        // that many distinct rows -- are met, and they are accumulated through apply_flattened<HASH> in an open-addressed table
+        // that lives in the accumulator words.  Chunk after chunk, list after list: every row still receives its products in
+        // ascending index order.  A single group with more postings than that takes the direct accumulators (apply_flattened).
+        if (whole && a.head_groups < a.ngroups) {
+            const int S = nacc >> 1, cap_t = nacc >> 2;
+            lds_key *hkey = reinterpret_cast<lds_key *>(acc);
+            float *hval = acc + S;
+            auto seg_of = [&](int ch, int gg, int ww, Visit &x) {  // the lane's list in chunk ch: its postings in groups [gg, gg + ww)
+                const int at = ch * kBlock + lane;
+                const bool in = at < L;
+                const int32_t cid = a.q_cid[qs + (in ? at : 0)];
+                x.qv = a.q_val[qs + (in ? at : 0)];
+                x.in = in && cid >= 0;
+                const uint32_t *o = off + (x.in ? (size_t)cid * dir_stride + gg : (size_t)0);
+                const uint32_t s0 = o[0], e0 = o[ww];
+                x.s = x.in ? s0 : 0, x.e = x.in ? e0 : 0;
+            };
+            int gg = a.head_groups, ww = 4;
+            while (gg < a.ngroups) {
+                if (ww > a.ngroups - gg) ww = a.ngroups - gg;
+                uint32_t mine = 0;
+                Visit x;
+                for (int ch = 0; ch < nch; ch++) {
+                    seg_of(ch, gg, ww, x);
+                    mine += x.e - x.s;
+                }
+                const uint32_t total = wave_sum_u32(mine);
+                if (total == 0) {
+                    gg += ww;
+                    ww = ww < 64 ? ww * 2 : ww;
+                    continue;
+                }
+                if (total > (uint32_t)cap_t && ww > 1) {  // too many for the table: narrower, in proportion
+                    const int nw = (int)(((unsigned long long)ww * (unsigned)cap_t) / total);
+                    ww = nw < 1 ? 1 : (nw < ww ? nw : ww - 1);
+                    continue;
+                }
+                const unsigned long long c0 = tr.now();
+                if (total > (uint32_t)cap_t) {  // one group, many postings: directly indexed accumulators
+                    for (int ch = 0; ch < nch; ch++) {
+                        if (nch > 1) seg_of(ch, gg, 1, x);
+                        if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE>(post, x, acc, tag, touched, tcap, lane, gs, tr, lm);
+                    }
+                    tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
+                    read_back(gg);
+                    gg += 1;
+                    continue;
+                }
+                for (int ch = 0; ch < nch; ch++) {
+                    if (nch > 1) seg_of(ch, gg, ww, x);
+                    if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE, true>(post, x, acc, tag, touched, tcap, lane, gs, tr, S - 1);
+                }
+                tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
+                const unsigned long long c1 = tr.now();
+                for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {  // the slots this super-visit claimed, each once
+                    const bool have = i0 + lane < gs.tcnt;
+                    const int slot = have ? (int)touched[i0 + lane] : 0;
+                    int32_t sid = 0;
+                    float xsum = 0.0f;
+                    if (have) {
+                        sid = hkey[slot] - 1;
+                        xsum = hval[slot];
+                        hkey[slot] = 0;
+                        hval[slot] = 0.0f;
+                    }
+                    consider(have, sid, xsum, 0, false);
+                }
+                tr.add(&Trace::ticks_back, (uint32_t)(tr.now() - c1));
+                tr.add(&Trace::sparse_groups);
+                walked_q += gs.walked;
+                gs = GroupState{0, 0};
+                gg += ww;
+                if (total * 4 <= (uint32_t)cap_t && ww < 64) ww *= 2;
+            }
         }
         const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);
         finish<KP>(s_buf, bcnt, lane);
@@ -926,11 +1037,10 @@ template <bool SCATTER>
 __global__ __launch_bounds__(256) void sparse_build_kernel(BuildArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t low = ((int64_t)1 << a.shift) - 1;
     for (int64_t r = wave; r < a.N; r += nwaves) {
         const int64_t sid = a.new_of[r];
         const int32_t bucket = (int32_t)(sid >> a.shift);
-        const int32_t loc = (int32_t)(sid & low);
+        const int32_t loc = (int32_t)sid;  // the posting carries the scratch id: a super-visit spans several groups
         for (int64_t e = a.r_ptr[r] + lane; e < a.r_ptr[r + 1]; e += 64) {
             uint32_t *c = a.cnt + (size_t)a.r_cid[e] * a.stride + bucket;
             if (SCATTER)

@@ -59,6 +59,11 @@ void gorse_hip_test_set_stream_priorities(int32_t on);
 /* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
+/* groups that a query of ordinary length visits one by one with directly indexed accumulators; the groups behind them are taken
+ * several at once with hashed accumulators (csrc/sparse_kernels.hpp, super-visits).  -1 (default) = the leading groups that hold
+ * more than their even share of the stored entries; 0 = none (every group through the super-visit loop, which falls back to the
+ * direct accumulators where one group alone has too many postings); a value >= the number of groups = no super-visits. */
+void gorse_hip_test_set_sparse_head(int32_t groups);
 /* rows per group of a handle created AFTERWARDS (the posting lists are cut by row group, csrc/sparse_kernels.hpp): a power of two
  * in 256 .. 16384; 0 = 2048.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);

@@ -135,6 +135,7 @@ def hooks():
     L = capi.lib()
     yield L
     L.gorse_hip_test_set_sparse_slots(0)
+    L.gorse_hip_test_set_sparse_head(-1)
     L.gorse_hip_test_set_sparse_tile(0)
     L.gorse_hip_test_set_sparse_split(2048)
     L.gorse_hip_test_set_sparse_heavy(16384)
@@ -215,8 +216,12 @@ def test_lists_that_share_rows_keep_the_index_order(oracle, atomic, hooks):
         val.append((np.exp(rng.uniform(-14, 14, have.size)) * rng.choice([-1.0, 1.0], have.size)).astype(np.float32))
     idx, val = np.concatenate(idx), np.concatenate(val)
     hooks.gorse_hip_test_set_sparse_atomic(atomic)
-    # groups of 256 / one group / long queries as one item per group / ... and row by row against the dense query
-    for tile, split, heavy in ((256, 0, 0), (2048, 0, 0), (256, 64, 0), (256, 20, 21), (2048, 1, 1)):
+    # groups of 256 / one group / long queries as one item per group / ... and row by row against the dense query; then every
+    # group through the super-visit loop (head 0: the 40 popular rows overflow the hashed table and fall back to the direct
+    # accumulators, the others are hashed) and only the first group visited directly
+    for tile, split, heavy, head in ((256, 0, 0, 1000), (2048, 0, 0, -1), (256, 64, 0, -1), (256, 20, 21, -1), (2048, 1, 1, -1),
+                                     (256, 0, 0, 0), (256, 0, 0, 1), (512, 0, 0, 0)):
+        hooks.gorse_hip_test_set_sparse_head(head)
         hooks.gorse_hip_test_set_sparse_tile(tile)
         hooks.gorse_hip_test_set_sparse_split(split)
         hooks.gorse_hip_test_set_sparse_heavy(heavy)
@@ -234,6 +239,7 @@ def test_random_configurations(oracle, hooks):
         rows, dims = int(rng.integers(1, 400 if case % 3 else 3000)), int(rng.integers(1, 120))
         hi = int(rng.integers(0, min(dims, 30) + 1))
         ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
+        hooks.gorse_hip_test_set_sparse_head(int(rng.choice([-1, 0, 1, 2, 1000])))
         hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([0, 256, 512, 2048])))
         hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 2048])))
         hooks.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 2, 5, 12, 16384])))
