@@ -40,6 +40,7 @@ SIGNATURES = {
     "gorse_mf_rank": (C.c_int32, [_vp, C.c_int64, _i32p, _i64p, _i32p, C.c_int32, _i32p, _i32p]),
     "gorse_mf_sample_user_negatives": (C.c_int32, [_vp, _i64p, _i32p, C.c_int32, C.c_uint64, _i32p, _i32p]),
     "gorse_mf_resident_candidates": (C.c_int32, [_vp, _i64p, _i64p]),
+    "gorse_mf_resident_generation": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_mf_rank_resident": (C.c_int32, [_vp, C.c_int32, _i32p, _i32p, _i32p]),
     "gorse_bpr_epoch": (C.c_int32, [_vp, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_int64, C.c_int32,
                                     _i32p, _f64p]),

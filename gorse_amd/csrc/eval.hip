@@ -165,6 +165,7 @@ extern "C" int32_t gorse_mf_sample_user_negatives(gorse_mf *h, const int64_t *te
     GORSE_HIP_CHECK(hipMemcpyAsync(h->ev_cptr.p + h->ev_users_n, &h->ev_cand_n, 8, hipMemcpyHostToDevice, h->stream));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // upos / cpos are host temporaries
     h->ev_valid = true;
+    h->ev_generation++;  // every sampling replaces the resident lists: a caller that kept the old number knows they are not its own
     return GORSE_OK;
 }
 
@@ -173,6 +174,12 @@ extern "C" int32_t gorse_mf_resident_candidates(gorse_mf *h, int64_t *n_users, i
     if (!h->ev_valid) return fail(GORSE_ERR_INVALID, "no resident candidate lists (gorse_mf_sample_user_negatives first)");
     if (n_users) *n_users = h->ev_users_n;
     if (n_candidates) *n_candidates = h->ev_cand_n;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_mf_resident_generation(gorse_mf *h, uint64_t *generation) {
+    if (!h || !generation) return fail(GORSE_ERR_INVALID, "NULL argument");
+    *generation = h->ev_valid ? h->ev_generation : 0;
     return GORSE_OK;
 }
 

@@ -61,6 +61,7 @@ struct gorse_mf {
     gorse::DevBuf<int32_t> ev_tidx, ev_neg, ev_neglen, ev_has, ev_clen, ev_users, ev_cand;
     int64_t ev_users_n = 0, ev_cand_n = 0;
     bool ev_valid = false;
+    uint64_t ev_generation = 0;  // bumped by every gorse_mf_sample_user_negatives (gorse_mf_resident_generation)
     // generic staging
     gorse::DevBuf<char> stage, rank_in;
     gorse::KernelProfile prof{GORSE_PROF_NCLASSES};

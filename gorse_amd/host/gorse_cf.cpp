@@ -166,6 +166,8 @@ void MatrixFactorization::create_handle(const dataset::Dataset &trainSet, bool w
         h_ = res->h;
         borrowed_ = true;
         handle_train_ = (const void *)&trainSet;
+        resident_eval_ = nullptr;  // a lent handle: whatever lists it holds are not this Fit's
+        resident_gen_ = 0;
         check(gorse_mf_set_factors(h_, UserFactor.data(), ItemFactor.data()));
         return;
     }
@@ -196,7 +198,7 @@ std::vector<float> Evaluate(MatrixFactorization &estimator, dataset::Dataset &te
     // a production split has no preloaded negatives: sample them on the device when the handle of this Fit holds trainSet
     // (the host loop of Dataset::SampleUserNegatives draws the same lists, only user after user)
     if (!testSet.HasNegatives()) estimator.SampleNegativesOnDevice(testSet, trainSet, numCandidates);
-    if (estimator.HasResidentCandidates(testSet)) {  // every later Evaluate of the Fit: no upload, rank lists only
+    if (estimator.HasResidentCandidates(testSet, numCandidates)) {  // every later Evaluate of the Fit: no upload, rank lists only
         const auto &tf = testSet.GetUserFeedback();
         std::vector<int32_t> users;
         auto ranks = estimator.RankResident(users, topK);

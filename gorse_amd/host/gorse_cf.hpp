@@ -663,9 +663,20 @@ class MatrixFactorization {
         check(gorse_mf_sample_user_negatives(h_, tptr.data(), tidx.data(), numCandidates, 0, neg.data(), len.data()));
         testSet.SetSampledNegatives(neg, len, numCandidates);
         resident_eval_ = (const void *)&testSet;
+        resident_candidates_ = numCandidates;
+        resident_feedback_ = (int64_t)testSet.CountFeedback();
+        check(gorse_mf_resident_generation(h_, &resident_gen_));
         return true;
     }
-    bool HasResidentCandidates(const dataset::Dataset &testSet) const { return h_ && resident_eval_ == (const void *)&testSet; }
+    // The lists on the handle are this model's own sampling of THIS split: same object, same size, same candidate count, and no
+    // other sampling on the (possibly lent) handle since -- the handle's generation number still reads what ours returned.
+    bool HasResidentCandidates(const dataset::Dataset &testSet, int numCandidates) const {
+        if (!h_ || resident_eval_ != (const void *)&testSet || resident_candidates_ != numCandidates ||
+            resident_feedback_ != (int64_t)testSet.CountFeedback())
+            return false;
+        uint64_t now = 0;
+        return gorse_mf_resident_generation(h_, &now) == GORSE_OK && now != 0 && now == resident_gen_;
+    }
     std::vector<std::vector<int32_t>> RankResident(std::vector<int32_t> &users, int topN) {
         int64_t nu = 0, nc = 0;
         check(gorse_mf_resident_candidates(h_, &nu, &nc));
@@ -709,6 +720,7 @@ class MatrixFactorization {
         h_ = nullptr;
         borrowed_ = false;
         handle_train_ = resident_eval_ = nullptr;
+        resident_gen_ = 0;
     }
     util::RandomGenerator &GetRandomGenerator() { return rng_; }
     // the shared evaluate / early-stopping epoch loop of BPR.Fit and ALS.Fit (model.go:432-440, 496-518)
@@ -723,6 +735,9 @@ class MatrixFactorization {
     int device_ = 0;
     const void *handle_train_ = nullptr;   // the training set the resident handle was created from (a Fit in progress)
     const void *resident_eval_ = nullptr;  // the test split whose candidate lists are resident on h_
+    uint64_t resident_gen_ = 0;            // ... as of this sampling (gorse_mf_resident_generation), with this many candidates
+    int resident_candidates_ = 0;          //     per user and this many test feedbacks
+    int64_t resident_feedback_ = -1;
 };
 
 // Evaluate (evaluator.go:35-72): candidates = test positives ++ negatives; device rank lists; the

@@ -119,6 +119,10 @@ int32_t gorse_mf_sample_user_negatives(gorse_mf *h, const int64_t *test_indptr /
                                        int32_t *neg_out /*host or NULL*/, int32_t *neg_len /*host or NULL*/);
 /* how many users have test feedback / how many candidates their lists hold (sizes of gorse_mf_rank_resident's outputs) */
 int32_t gorse_mf_resident_candidates(gorse_mf *h, int64_t *n_users /*out*/, int64_t *n_candidates /*out*/);
+/* A number that changes with every gorse_mf_sample_user_negatives on this handle (0 = no lists resident).  A handle may be lent to
+ * several models in turn (host/gorse_cf.hpp ResidentDataset): a model remembers the number its own sampling returned and ranks
+ * the resident lists only while it still reads the same one. */
+int32_t gorse_mf_resident_generation(gorse_mf *h, uint64_t *generation /*out*/);
 /* gorse_mf_rank over the resident candidate lists: users_out (host or NULL) n_users ids, rank_out n_users * topk padded with
  * -1, rank_len n_users. */
 int32_t gorse_mf_rank_resident(gorse_mf *h, int32_t topk, int32_t *users_out /*host or NULL*/, int32_t *rank_out /*host*/,

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # the positive-side and re-reading forms of the store route live in the probe build only (make -C gorse_amd/csrc probe-lib)
 _probe = os.path.join(ROOT, "gorse_amd", "lib", "libgorse_hip_probe.so")
-if os.path.exists(_probe):
+if os.path.exists(_probe) and os.path.getmtime(_probe) >= os.path.getmtime(os.path.join(ROOT, "gorse_amd", "lib", "libgorse_hip.so")):
     os.environ.setdefault("GORSE_HIP_LIB", _probe)
 import numpy as np
 

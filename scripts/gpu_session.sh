@@ -75,7 +75,7 @@ for STAGE in "$@"; do
     probe)
         ARGS=$(echo "${B:-}" | tr '+' ' ')
         PLIB="$ROOT/gorse_amd/lib/libgorse_hip_probe.so"  # the probe build (make -C gorse_amd/csrc probe-lib) when it exists
-        [ -f "$PLIB" ] && export GORSE_HIP_LIB="$PLIB"
+        [ -f "$PLIB" ] && [ "$PLIB" -nt "$ROOT/gorse_amd/lib/libgorse_hip.so" ] && export GORSE_HIP_LIB="$PLIB"  # never a stale one
         timeout 900 python "scripts/$A" $ARGS > "$OUT/${TAG}_probe_$(basename "$A" .py)${C:+_$C}.txt" 2>&1
         echo "probe $A exit $?"; unset GORSE_HIP_LIB; cut -c1-220 "$OUT/${TAG}_probe_$(basename "$A" .py)${C:+_$C}.txt" | tail -40 ;;
     smoke)
