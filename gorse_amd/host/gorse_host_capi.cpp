@@ -559,6 +559,25 @@ void gh_mfitems_row(void *m, int64_t i, float *out) {
 int64_t gh_mfitems_marshal(void *m, char *buf, int64_t cap) {
     return copy_out(((logics::MatrixFactorizationItems *)m)->Marshal(), buf, cap);
 }
+// the blob with the reference's own index section and a device-built graph (MarshalReference); called twice by the ctypes wrapper
+// (size, then content): the bytes of the first call are kept until the second has copied them
+int64_t gh_mfitems_marshal_reference(void *m, char *buf, int64_t cap) {
+    static thread_local std::string kept;
+    static thread_local void *kept_for = nullptr;
+    int64_t out = -1;
+    guard([&] {
+        if (!(buf && kept_for == m)) {
+            kept = ((logics::MatrixFactorizationItems *)m)->MarshalReference();
+            kept_for = m;
+        }
+        out = copy_out(kept, buf, cap);
+        if (buf) {
+            kept.clear();
+            kept_for = nullptr;
+        }
+    });
+    return out;
+}
 int32_t gh_mfitems_unmarshal(void *m, const char *buf, int64_t n) {
     return guard([&] { ((logics::MatrixFactorizationItems *)m)->Unmarshal(std::string(buf, (size_t)n)); });
 }

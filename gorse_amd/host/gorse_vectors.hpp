@@ -896,6 +896,98 @@ public:
         for (const auto &id : items_) put_gob(w, gob::encode_string(id));
         return w;
     }
+    // The blob with its index section in the REFERENCE'S OWN format (HNSW.Marshal, hnsw.go:278-337) and a graph BUILT BY THE DEVICE,
+    // for clusters in which some workers run a build without this library: their HNSW.Unmarshal loads the file and their own
+    // knnSearch (hnsw.go:100-114) walks it.  The graph is what insert (hnsw.go:117-185) aims at, computed exactly instead of
+    // searched for: every vector draws its level floor(-ln(u) * levelFactor) (hnsw.go:137); layer L holds the vectors of level
+    // >= L, and a vector's neighbours in a layer are its nearest vectors OF THAT LAYER by -dot -- maxConnection0 = 96 at the bottom,
+    // maxConnection = 48 above (NewHNSW's parameters, hnsw.go:52-60) -- from one exact all-pairs search per layer on the device
+    // (a million vectors: one MFMA pass instead of a million efConstruction = 100 searches).  Each queue is written ascending in
+    // the distance, which is a valid heap array for heap.PriorityQueue (pq.go:42-48); the enter point is the first vector of the
+    // top layer.  This library's own reader keeps the vectors of such a file and skips the graph, like any reference file.
+    std::string MarshalReference() {
+        constexpr int kM = 48, kM0 = 96, kEfConstruction = 100;
+        const float levelFactor = 1.0f / std::log(48.0f);
+        const int64_t n = (int64_t)items_.size();
+        const int d = dimension_;
+        std::string w;
+        put_gob(w, gob::encode_time_unix_nanos(timestamp_));
+        put_gob(w, gob::encode_int(dimension_));
+        put<float>(w, levelFactor);
+        put<int64_t>(w, kM);
+        put<int64_t>(w, kM0);
+        put<int64_t>(w, 0);  // ef: efSearchValue falls back to efConstruction (hnsw.go:268-273)
+        put<int64_t>(w, kEfConstruction);
+        put<int64_t>(w, n);
+        for (int64_t i = 0; i < n; i++) put_gob(w, gob::encode_f32_slice(Row((size_t)i), (size_t)d));
+        // levels: one splitmix64 stream seeded by the count (the reference's rand.Float32 stream cannot be reproduced: SURVEY 8c)
+        std::vector<int> level((size_t)n, 0);
+        uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        int top = 0;
+        for (int64_t i = 0; i < n; i++) {
+            st += 0x9E3779B97F4A7C15ull;
+            uint64_t z = st;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            const float u = ((float)(z >> 40) + 1.0f) / 16777216.0f;  // (0, 1]
+            level[(size_t)i] = (int)std::floor(-std::log(u) * levelFactor);
+            top = std::max(top, level[(size_t)i]);
+        }
+        if (!searcher_) searcher_ = std::make_shared<vectors::HipSearcher>();
+        // the neighbour queues of one layer: members (ascending ids; empty = every vector), at most cap neighbours each
+        auto write_layer = [&](const std::vector<int32_t> &members, int cap, bool with_keys, const std::string &coll) {
+            const int64_t m = members.empty() ? n : (int64_t)members.size();
+            std::vector<float> sub;
+            const float *X = data_.data();
+            if (!members.empty()) {
+                sub.resize((size_t)m * (size_t)d);
+                for (int64_t t = 0; t < m; t++) std::memcpy(sub.data() + (size_t)t * (size_t)d, Row((size_t)members[(size_t)t]), (size_t)d * sizeof(float));
+                X = sub.data();
+            }
+            const int k = (int)std::min<int64_t>((int64_t)cap + 1, m);  // + 1: the vector itself may be among its own nearest
+            const int64_t block = 65536;
+            std::vector<int32_t> idx((size_t)std::min(block, m) * (size_t)k), cnt((size_t)std::min(block, m));
+            std::vector<float> dist(idx.size());
+            searcher_->invalidate(coll);
+            for (int64_t q0 = 0; q0 < m; q0 += block) {
+                const int64_t nq = std::min(block, m - q0);
+                searcher_->search(coll, X, m, d, GORSE_METRIC_NEG_DOT, X + (size_t)q0 * (size_t)d, nq, k, idx.data(), dist.data(), cnt.data());
+                for (int64_t t = 0; t < nq; t++) {
+                    const int64_t self = q0 + t;
+                    if (with_keys) put<int32_t>(w, members.empty() ? (int32_t)self : members[(size_t)self]);
+                    int32_t len = 0;
+                    for (int32_t j = 0; j < cnt[(size_t)t] && len < cap; j++) len += idx[(size_t)t * (size_t)k + (size_t)j] != (int32_t)self;
+                    put<uint8_t>(w, 0);  // desc = false
+                    put<int32_t>(w, len);
+                    int32_t done = 0;
+                    for (int32_t j = 0; j < cnt[(size_t)t] && done < len; j++) {
+                        const int32_t r = idx[(size_t)t * (size_t)k + (size_t)j];
+                        if (r == (int32_t)self) continue;
+                        put<int32_t>(w, members.empty() ? r : members[(size_t)r]);
+                        put<float>(w, dist[(size_t)t * (size_t)k + (size_t)j]);
+                        done++;
+                    }
+                }
+            }
+            searcher_->invalidate(coll);
+        };
+        if (n > 0) write_layer({}, kM0, false, std::string(kCollection) + "#hnsw0");
+        put<int64_t>(w, (int64_t)top);  // len(upperNeighbors)
+        int32_t enter = 0;
+        for (int L = 1; L <= top; L++) {
+            std::vector<int32_t> members;
+            for (int64_t i = 0; i < n; i++)
+                if (level[(size_t)i] >= L) members.push_back((int32_t)i);
+            put<int32_t>(w, (int32_t)members.size());
+            write_layer(members, kM, true, std::string(kCollection) + "#hnsw" + std::to_string(L));
+            if (L == top) enter = members.front();
+        }
+        put<int32_t>(w, enter);
+        put_gob(w, gob::encode_int(n));
+        for (const auto &id : items_) put_gob(w, gob::encode_string(id));
+        return w;
+    }
     void Unmarshal(const std::string &blob) {
         size_t at = 0;
         items_.clear();

@@ -438,6 +438,7 @@ class MatrixFactorizationItems:
                         ("gh_mfitems_timestamp", C.c_int64, [C.c_void_p]), ("gh_mfitems_id", C.c_int64, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
                         ("gh_mfitems_row", None, [C.c_void_p, C.c_int64, C.POINTER(C.c_float)]),
                         ("gh_mfitems_marshal", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
+                        ("gh_mfitems_marshal_reference", C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
                         ("gh_mfitems_unmarshal", C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
                         ("gh_mfitems_search", C.c_int64, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.c_int32, C.c_char_p, C.c_int64,
                                                           C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_int32)])):
@@ -478,6 +479,16 @@ class MatrixFactorizationItems:
         n = _host().gh_mfitems_marshal(self.p, None, 0)
         buf = C.create_string_buffer(max(int(n), 1))
         _host().gh_mfitems_marshal(self.p, buf, len(buf))
+        return buf.raw[:n]
+
+    def MarshalReference(self):
+        """the blob in the reference's own format (HNSW.Marshal) with a graph built by the device's exact all-pairs search: what a
+        master with this library writes for workers without it (gorse_vectors.hpp MarshalReference)"""
+        n = _host().gh_mfitems_marshal_reference(self.p, None, 0)
+        if n < 0:
+            raise RuntimeError("MarshalReference failed: %s" % _host().gh_last_error().decode("utf-8", "replace"))
+        buf = C.create_string_buffer(max(int(n), 1))
+        _host().gh_mfitems_marshal_reference(self.p, buf, len(buf))
         return buf.raw[:n]
 
     def Unmarshal(self, blob):

@@ -549,3 +549,89 @@ def load_ref():
     if not (_cpu_has("avx512f") and _cpu_has("avx512bw") and _cpu_has("fma") and _cpu_has("avx2")):
         return None
     return Ref(path)
+
+
+# ---- ann.HNSW search restated (test infrastructure, pure Python: small cases only) ---------------------------------------
+def hnsw_parse_index_section(blob, at):
+    """HNSW.Unmarshal (common/ann/hnsw.go:339-418) over the bytes of an index section starting at `at`: returns
+    (params dict, vector gob streams, bottom = list of [(value, weight)], upper = list of {key: [(value, weight)]}, enterPoint,
+    position behind the section).  A queue = PriorityQueue.Marshal (common/heap/pq.go:128-133): bool desc, int32 length,
+    (int32 value, float32 weight) pairs."""
+    import struct
+
+    def queue():
+        nonlocal at
+        desc, ln = struct.unpack_from("<?i", blob, at)
+        at += 5
+        q = [struct.unpack_from("<if", blob, at + 8 * j) for j in range(ln)]
+        at += 8 * ln
+        return desc, q
+    level_factor, m, m0, ef, efc = struct.unpack_from("<fqqqq", blob, at)
+    at += 36
+    (n,) = struct.unpack_from("<q", blob, at)
+    at += 8
+    streams = []
+    for _ in range(n):
+        (ln,) = struct.unpack_from("<i", blob, at)
+        streams.append(blob[at + 4:at + 4 + ln])
+        at += 4 + ln
+    bottom = [queue() for _ in range(n)]
+    (layers,) = struct.unpack_from("<q", blob, at)
+    at += 8
+    upper = []
+    for _ in range(layers):
+        (cnt,) = struct.unpack_from("<i", blob, at)
+        at += 4
+        layer = {}
+        for _ in range(cnt):
+            (key,) = struct.unpack_from("<i", blob, at)
+            at += 4
+            layer[key] = queue()
+        upper.append(layer)
+    (enter,) = struct.unpack_from("<i", blob, at)
+    at += 4
+    params = {"levelFactor": level_factor, "maxConnection": m, "maxConnection0": m0, "ef": ef, "efConstruction": efc}
+    return params, streams, bottom, upper, enter, at
+
+
+def hnsw_knn_search(X, bottom, upper, enter, params, q, k):
+    """HNSW.SearchVector (hnsw.go:88-98) = knnSearch (hnsw.go:100-114) over searchLayer (hnsw.go:187-229) and selectNeighbors
+    (hnsw.go:254-260) with distance = -floats.Dot (logics/cf.go:32-34), on a graph given as parsed queues.  The two heaps of
+    searchLayer are Python heapq's (container/heap's sift rules matter only between EQUAL distances, which a recall check does
+    not depend on).  Returns the ids, nearest first."""
+    import heapq
+
+    def dist(i):
+        return float(-np.dot(X[i].astype(np.float32), q.astype(np.float32)))
+
+    def neighbours(c, layer):
+        return [v for v, _ in (bottom[c][1] if layer == 0 else upper[layer - 1][c][1])]
+
+    def search_layer(enter_points, ef, layer):
+        visited = set(i for _, i in enter_points)
+        cand = list(enter_points)  # min-heap by distance
+        heapq.heapify(cand)
+        w = [(-dd, i) for dd, i in enter_points]  # max-heap by distance
+        heapq.heapify(w)
+        while cand:
+            cq, c = heapq.heappop(cand)
+            if cq > -w[0][0]:
+                break
+            for e in neighbours(c, layer):
+                if e in visited:
+                    continue
+                visited.add(e)
+                eq = dist(e)
+                if eq < -w[0][0] or len(w) < ef:
+                    heapq.heappush(cand, (eq, e))
+                    heapq.heappush(w, (-eq, e))
+                    if len(w) > ef:
+                        heapq.heappop(w)
+        return sorted((-nd, i) for nd, i in w)
+    ef = max(params["ef"], k) if params["ef"] > 0 else max(params["efConstruction"], k)  # efSearchValue, hnsw.go:268-273
+    points = [(dist(enter), enter)]
+    for layer in range(len(upper), 0, -1):
+        w = search_layer(points, 1, layer)
+        points = [w[0]]
+    w = search_layer(points, ef, 0)
+    return [i for _, i in w[:k]]

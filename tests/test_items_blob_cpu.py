@@ -201,3 +201,62 @@ def test_add_search_marshal_from_scratch(oracle):
     m2 = V.MatrixFactorizationItems(searcher=cpu_searcher(oracle))
     m2.Unmarshal(m.Marshal())
     assert m2.Timestamp() == 42 and m2.Search(X[4], 3) == got
+
+
+def _index_section_start(blob):
+    at = 0
+    for _ in range(2):  # timestamp, dimension
+        (ln,) = struct.unpack_from("<i", blob, at)
+        at += 4 + ln
+    return at
+
+
+def test_marshal_reference_writes_a_graph_the_reference_can_walk(oracle):
+    """MarshalReference: the blob in the reference's own format (logics/cf.go:81-101 around HNSW.Marshal, hnsw.go:278-337) with a
+    graph built from exact all-pairs searches -- what a master with this library hands to workers WITHOUT it.  Checked here: the
+    reference's reader walks the whole file; NewHNSW's parameters; every queue is a valid heap array (ascending distances), holds
+    no self loop and at most maxConnection0 / maxConnection entries whose weights are the -dot distances; the layers nest; and the
+    reference's own knnSearch (restated: oracle.hnsw_knn_search) finds the exact nearest items on it.  This library's reader
+    takes the file like any reference file (vectors and ids kept)."""
+    oracle.set_isa(orc.ISA_AVX512)
+    rng = np.random.default_rng(21)
+    n, d = 700, 12
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    ids = ["item-%d" % i for i in range(n)]
+    m = V.MatrixFactorizationItems(timestamp_unix_nanos=1_790_000_000_123_456_789, searcher=cpu_searcher(oracle))
+    for i in range(n):
+        m.Add(ids[i], X[i])
+    blob = m.MarshalReference()
+    assert reference_reader_outcome(blob) == "ok"
+    params, streams, bottom, upper, enter, end = orc.hnsw_parse_index_section(blob, _index_section_start(blob))
+    assert params["maxConnection"] == 48 and params["maxConnection0"] == 96 and params["efConstruction"] == 100 and params["ef"] == 0
+    assert abs(params["levelFactor"] - 1.0 / np.log(48.0)) < 1e-6
+    assert len(streams) == n and streams[5] == gob_f32_slice(X[5])  # the vectors as the reference writes them
+    for i, (desc, q) in enumerate(bottom):
+        assert not desc and 0 < len(q) <= 96 and all(v != i and 0 <= v < n for v, _ in q)
+        w = [x for _, x in q]
+        assert w == sorted(w)
+        ei, ed = oracle.search_vector(X, orc.METRIC_NEG_DOT, X[i], 97)
+        want = [(int(j), float(dd)) for j, dd in zip(ei, ed) if j != i][:96]
+        assert [(v, np.float32(x)) for v, x in q] == [(j, np.float32(dd)) for j, dd in want], i
+    assert len(upper) >= 1 and enter in upper[-1]
+    for L, layer in enumerate(upper):
+        members = set(layer)
+        if L > 0:
+            assert members <= set(upper[L - 1])  # a vector of level >= L + 1 is also in layer L
+        for key, (desc, q) in layer.items():
+            assert not desc and len(q) <= 48 and all(v in members and v != key for v, _ in q)
+            assert [x for _, x in q] == sorted(x for _, x in q)
+    # the reference's search on this graph: the exact answer (nearly every pair is linked at this size)
+    for t in range(40):
+        qv = rng.standard_normal(d).astype(np.float32)
+        got = orc.hnsw_knn_search(X, bottom, upper, enter, params, qv, 5)
+        ei, _ = oracle.search_vector(X, orc.METRIC_NEG_DOT, qv, 5)
+        assert got == [int(j) for j in ei], t
+    m2 = V.MatrixFactorizationItems(searcher=cpu_searcher(oracle))
+    m2.Unmarshal(blob)
+    assert m2.Count() == n and m2.Timestamp() == m.Timestamp()
+    assert all(m2.Id(i) == ids[i] and np.array_equal(m2.Row(i), X[i]) for i in range(0, n, 37))
+    # nothing stored: an empty graph the reference reads as well
+    e = V.MatrixFactorizationItems(searcher=cpu_searcher(oracle))
+    assert reference_reader_outcome(e.MarshalReference()) == "ok"
