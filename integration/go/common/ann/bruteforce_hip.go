@@ -11,10 +11,13 @@ import "C"
 import (
 	"encoding/binary"
 	"io"
+	"math"
+	"math/rand"
 	"sync"
 	"unsafe"
 
 	"github.com/gorse-io/gorse/common/encoding"
+	"github.com/gorse-io/gorse/common/heap"
 	"github.com/gorse-io/gorse/common/log"
 	"github.com/pkg/errors"
 	"github.com/samber/lo"
@@ -206,6 +209,102 @@ func (b *BruteforceHIP) Marshal(w io.Writer) error {
 	return errors.WithStack(binary.Write(w, binary.LittleEndian, b.data))
 }
 
+// MarshalReference writes the index section in the REFERENCE'S OWN format (HNSW.Marshal, hnsw.go:278-337) with a graph built by
+// the device, for clusters in which some workers run a build without this library (set `recommend.collaborative.hip_compat_blob`
+// on the master, see INTEGRATION.md): their HNSW.Unmarshal loads it and their own knnSearch walks it.  Every vector draws its
+// level as insert does (hnsw.go:137); layer L holds the vectors of level >= L; a vector's queue in a layer = its nearest vectors
+// OF THAT LAYER by the index's distance, 96 at the bottom and 48 above (NewHNSW, hnsw.go:52-60), from ONE exact all-pairs search
+// per layer (gorse_topk_all_pairs) instead of one efConstruction search per insertion; queues ascending in the distance = valid
+// heap arrays (heap/pq.go:42-48).  The C++ twin with its tests (recall 1.000 of the reference's search restated, 20,000 x 32):
+// gorse_amd/host/gorse_vectors.hpp MarshalReference, tests/test_items_blob_cpu.py, tests/test_gpu_items_graph.py.
+func (b *BruteforceHIP) MarshalReference(w io.Writer) error {
+	b.mu.Lock()
+	n := 0
+	if b.d > 0 {
+		n = len(b.data) / b.d
+	}
+	data, d := b.data, b.d
+	b.mu.Unlock()
+	const m, m0, efConstruction = 48, 96, 100
+	levelFactor := float32(1.0 / math.Log(48))
+	if err := binary.Write(w, binary.LittleEndian, struct {
+		LevelFactor                float32
+		M, M0, Ef, EfConstruction int64
+		N                          int64
+	}{levelFactor, m, m0, 0, efConstruction, int64(n)}); err != nil {
+		return errors.WithStack(err)
+	}
+	for i := 0; i < n; i++ {
+		if err := encoding.WriteGob(w, data[i*d:(i+1)*d]); err != nil {
+			return errors.WithStack(err)
+		}
+	}
+	level, top := make([]int, n), 0
+	for i := range level {
+		level[i] = int(math.Floor(-math.Log(float64(1-rand.Float32())) * float64(levelFactor)))
+		top = max(top, level[i])
+	}
+	// one layer: the exact nearest `limit` other members of every member, written as PriorityQueue.Marshal does
+	writeLayer := func(members []int32, limit int, withKeys bool) error {
+		sub := NewBruteforceHIP(b.metric)
+		defer sub.Close()
+		for _, i := range members {
+			sub.Add(data[int(i)*d : (int(i)+1)*d])
+		}
+		k := min(limit+1, len(members)) // + 1: the vector itself may be among its own nearest
+		idx, dist, err := sub.SearchAll(k)
+		if err != nil {
+			return err
+		}
+		for t, key := range members {
+			if withKeys {
+				if err := binary.Write(w, binary.LittleEndian, key); err != nil {
+					return errors.WithStack(err)
+				}
+			}
+			elems := make([]heap.Elem[int32, float32], 0, limit)
+			for j := 0; j < k && len(elems) < limit; j++ {
+				if r := idx[t*k+j]; r >= 0 && int(r) != t {
+					elems = append(elems, heap.Elem[int32, float32]{Value: members[r], Weight: dist[t*k+j]})
+				}
+			}
+			if err := binary.Write(w, binary.LittleEndian, false); err != nil {
+				return errors.WithStack(err)
+			}
+			if err := encoding.WriteSlice(w, elems); err != nil {
+				return errors.WithStack(err)
+			}
+		}
+		return nil
+	}
+	all := make([]int32, n)
+	for i := range all {
+		all[i] = int32(i)
+	}
+	if n > 0 {
+		if err := writeLayer(all, m0, false); err != nil {
+			return err
+		}
+	}
+	if err := binary.Write(w, binary.LittleEndian, int64(top)); err != nil {
+		return errors.WithStack(err)
+	}
+	enter := int32(0)
+	for l := 1; l <= top; l++ {
+		members := lo.Filter(all, func(i int32, _ int) bool { return level[i] >= l })
+		if err := binary.Write(w, binary.LittleEndian, int32(len(members))); err != nil {
+			return errors.WithStack(err)
+		}
+		if err := writeLayer(members, m, true); err != nil {
+			return err
+		}
+		if l == top {
+			enter = members[0]
+		}
+	}
+	return errors.WithStack(binary.Write(w, binary.LittleEndian, enter))
+}
+
 func skipQueue(r io.Reader) error { // PriorityQueue.Marshal, common/heap/pq.go:128-133: one bool, int32 length, 8-byte elements
 	var head struct {
 		Desc bool
@@ -248,8 +347,10 @@ func (b *BruteforceHIP) Unmarshal(r io.Reader) error {
 		if err := binary.Read(r, binary.LittleEndian, &rest); err != nil {
 			return errors.WithStack(err)
 		}
-		if rest.N < 0 || rest.D < 0 {
-			return errors.Errorf("BruteforceHIP: bad header %v", rest)
+		// One / Empty are what Marshal wrote (count 1, empty gob stream); N x D must be a size a sane file can hold: a corrupt
+		// header must end in an error, not in a panic of make()
+		if n != 1 || rest.Empty != 0 || rest.N < 0 || rest.D < 0 || rest.D > 1<<16 || rest.N > (1<<33)/int64(max(rest.D, 1)) {
+			return errors.Errorf("BruteforceHIP: bad header (one %d, %+v)", n, rest)
 		}
 		b.d, b.data = int(rest.D), make([]float32, rest.N*int64(rest.D))
 		b.dirty = true
