@@ -314,55 +314,22 @@ __device__ inline void touch(uint16_t *touched, int tcap, GroupState &gs, bool a
 // listed twice; the read-back takes it once).
 // DEPTH = the longest list of the chunk, rounded up to 2, 4 or kGather: the loops below run over DEPTH postings per lane, and a
 // chunk of the tail groups (a few lists with one or two postings each) pays for 2, not for 8.
-// HASH (the super-visits of the tail groups, see apply_flattened): the accumulator of a posting is a slot of the open-addressed
-// table in the accumulator words, found once per posting before the rounds; `touched` lists the slots claimed here.
-template <bool ATOMIC, bool TRACE, int DEPTH, bool HASH = false>
+template <bool ATOMIC, bool TRACE, int DEPTH>
 __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8 *tag, uint16_t *touched, int tcap, int lane,
                                      GroupState &gs, Tracer<TRACE> &tr, int lm) {
     const uint32_t len = v.e - v.s;
     bool pending = len > 0;
     tr.add(&Trace::fast_chunks);
-    int32_t at[DEPTH];  // the accumulator of posting j
-    float *sums = acc;
-    if constexpr (HASH) {  // lm = S - 1
-        const int S = lm + 1;
-        lds_key *hkey = reinterpret_cast<lds_key *>(acc);
-        sums = acc + S;
-        const int shift = __builtin_clz((unsigned)S) + 1;
-#pragma unroll
-        for (int j = 0; j < DEPTH; j++) {
-            at[j] = 0;
-            bool claimed = false;
-            if ((uint32_t)j < len) {
-                const int32_t key = v.P[j].loc + 1;
-                uint32_t hs = ((uint32_t)v.P[j].loc * 2654435761u) >> shift;
-                for (;;) {
-                    const int32_t old = atomicCAS(&hkey[hs], 0, key);
-                    claimed = old == 0;
-                    if (old == 0 || old == key) break;
-                    hs = (hs + 1) & (uint32_t)lm;
-                }
-                at[j] = (int32_t)hs;
-            }
-            const unsigned long long m = __ballot((uint32_t)j < len);
-            if (!m) break;
-            gs.walked += (uint32_t)__popcll(m);
-            touch(touched, tcap, gs, claimed, at[j], lane);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < DEPTH; j++) at[j] = v.P[j].loc & lm;
-    }
     for (;;) {
         tr.add(&Trace::rounds);
 #pragma unroll
         for (int j = 0; j < DEPTH; j++)
-            if (pending && (uint32_t)j < len) tag[at[j]] = (uint8_t)lane;
+            if (pending && (uint32_t)j < len) tag[(v.P[j].loc & lm)] = (uint8_t)lane;
         bool lost = false;
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) {
             uint32_t stamp = (uint32_t)lane;
-            if (pending && (uint32_t)j < len) stamp = tag[at[j]];
+            if (pending && (uint32_t)j < len) stamp = tag[(v.P[j].loc & lm)];
             lost = lost | (stamp != (uint32_t)lane);
         }
         const unsigned long long ml = __ballot(lost);
@@ -371,24 +338,18 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
         for (int pass = 0; pass < 2; pass++) {  // the lanes below lim together, then lane lim alone
             if (pass == 1 && !ml) break;
             const bool go = pending && (pass == 0 ? lane < lim : lane == lim);
-            if constexpr (HASH) {
+            float old[DEPTH];
 #pragma unroll
-                for (int j = 0; j < DEPTH; j++)
-                    if (go && (uint32_t)j < len) acc_add<ATOMIC>(sums, at[j], __fmul_rn(v.qv, v.P[j].val));
-            } else {
-                float old[DEPTH];
+            for (int j = 0; j < DEPTH; j++) {
+                old[j] = 1.0f;
+                if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, (v.P[j].loc & lm), __fmul_rn(v.qv, v.P[j].val));
+            }
 #pragma unroll
-                for (int j = 0; j < DEPTH; j++) {
-                    old[j] = 1.0f;
-                    if (go && (uint32_t)j < len) old[j] = acc_add_old<ATOMIC>(acc, at[j], __fmul_rn(v.qv, v.P[j].val));
-                }
-#pragma unroll
-                for (int j = 0; j < DEPTH; j++) {
-                    const unsigned long long m = __ballot(go && (uint32_t)j < len);
-                    if (!m) break;
-                    gs.walked += (uint32_t)__popcll(m);
-                    touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, at[j], lane);
-                }
+            for (int j = 0; j < DEPTH; j++) {
+                const unsigned long long m = __ballot(go && (uint32_t)j < len);
+                if (!m) break;
+                gs.walked += (uint32_t)__popcll(m);
+                touch(touched, tcap, gs, __float_as_uint(old[j]) == 0, (v.P[j].loc & lm), lane);
             }
         }
         if (!ml) break;
@@ -723,15 +684,13 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             int gg = a.head_groups, ww = 4;
             while (gg < a.ngroups) {
                 if (ww > a.ngroups - gg) ww = a.ngroups - gg;
-                uint32_t mine = 0, longest = 0;
+                uint32_t mine = 0;
                 Visit x;
                 for (int ch = 0; ch < nch; ch++) {
                     seg_of(ch, gg, ww, x);
                     mine += x.e - x.s;
-                    longest = max(longest, x.e - x.s);
                 }
                 const uint32_t total = wave_sum_u32(mine);
-                const unsigned long long deep = __ballot(longest > (uint32_t)kGather);  // a list with more postings than a lane takes at once
                 if (total == 0) {
                     gg += ww;
                     ww = ww < 64 ? ww * 2 : ww;
@@ -755,24 +714,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 }
                 for (int ch = 0; ch < nch; ch++) {
                     if (nch > 1) seg_of(ch, gg, ww, x);
-                    if (!__ballot(x.e > x.s)) continue;
-                    if (deep) {
-                        apply_flattened<ATOMIC, TRACE, true>(post, x, acc, tag, touched, tcap, lane, gs, tr, S - 1);
-                        continue;
-                    }
-                    // every list of the chunk has at most kGather postings in these groups: each lane takes its own list
-                    const uint32_t len = x.e - x.s;
-#pragma unroll
-                    for (int j = 0; j < kGather; j++)
-                        if (__ballot((uint32_t)j < len)) x.P[j] = post[x.s + ((uint32_t)j < len ? j : 0)];
-                    if (!__ballot(len > 2u))
-                        apply_at_once<ATOMIC, TRACE, 2, true>(x, acc, tag, touched, tcap, lane, gs, tr, S - 1);
-                    else if (!__ballot(len > 4u))
-                        apply_at_once<ATOMIC, TRACE, 4, true>(x, acc, tag, touched, tcap, lane, gs, tr, S - 1);
-                    else
-                        apply_at_once<ATOMIC, TRACE, kGather, true>(x, acc, tag, touched, tcap, lane, gs, tr, S - 1);
+                    if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE, true>(post, x, acc, tag, touched, tcap, lane, gs, tr, S - 1);
                 }
-                tr.add(deep ? &Trace::ticks_flat : &Trace::ticks_once, (uint32_t)(tr.now() - c0));
+                tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
                 const unsigned long long c1 = tr.now();
                 for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {  // the slots this super-visit claimed, each once
                     const bool have = i0 + lane < gs.tcnt;
