@@ -86,11 +86,11 @@ def compact(obj, notes, path=""):
     return obj
 
 
-def write_notes(notes):
+def write_notes(notes, tag="default"):
     for d in (os.path.join(ROOT, "gpurun_out"), "/tmp"):
         try:
             os.makedirs(d, exist_ok=True)
-            path = os.path.join(d, "bench_notes.json")
+            path = os.path.join(d, "bench_notes_%s.json" % tag)
             json.dump(notes, open(path, "w"), indent=1, sort_keys=True)
             return path
         except Exception:
@@ -801,7 +801,7 @@ def leg(fn, what):
         return {"metric": what, "value": None, "error": repr(e)}
 
 
-def emit(out):
+def emit(out, tag="default"):
     """ONE JSON line: the headline keys first, then `topk` (the second half of BASELINE.json's metric), then the other
     configurations; prose goes to the notes file (see compact)."""
     head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -816,7 +816,7 @@ def emit(out):
             break
         if isinstance(line.get(k), dict) and "config" in line[k]:
             notes[k + ".config"] = line[k].pop("config")
-    line["notes"] = write_notes(notes)
+    line["notes"] = write_notes(notes, tag)
     print(json.dumps(line, separators=(",", ":")), flush=True)
 
 
@@ -856,7 +856,7 @@ def main():
                 out["warmup"] = 1
                 out["vs_baseline"] = None
         if rank == 0:
-            emit(out)
+            emit(out, workload)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -894,7 +894,7 @@ def main():
         out["big"] = leg(lambda: bench_bpr(args, "big", 1, 0, local, None, "single GPU", 3, 1, data=synth.s_huge(N=BIG_DRAWS_DEFAULT_LINE),
                                            with_cpu=False), "BPR positive-samples/sec, 10M users x 1M items, nFactors 128")
     if rank == 0:
-        emit(out)
+        emit(out, args.workload or ("default" if world == 1 else "default_n%d" % world))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
