@@ -381,45 +381,32 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
         int n;       // postings of the batch (wave-uniform); 0: none left
         bool mixed;  // more than one list
     };
-    // The segments laid end to end: lane l's list covers the positions [start_l, incl_l) of the concatenation (an inclusive scan
-    // of the lengths over the lanes); batch b is the positions [64 b, 64 b + 64), and a position finds its list by a binary search
-    // over the lanes' prefixes (six ds_bpermute steps for all 64 postings at once).  Until round 4 the batch was assembled by a
-    // wave-uniform walk over the lists -- three v_readlane and a dozen scalar operations per list, ~330 cycles for a list that
-    // contributes two postings (profiles/r04_g_probe_sparse_trace.txt: 2.4e8 such segments = 36 s of the pass's 117 s of wave time).
-    const uint32_t len = v.e - v.s;
-    uint32_t incl = len;
-#pragma unroll
-    for (int o = 1; o < kBlock; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)incl, o, kBlock);
-        if (lane >= o) incl += y;
-    }
-    const uint32_t total = lane_u32(incl, kBlock - 1);
-    const uint32_t start = incl - len;
-    uint32_t next_p = 0;  // first position of the next batch to assemble
-    auto bperm = [&](uint32_t val, int from) { return (uint32_t)__builtin_amdgcn_ds_bpermute(from << 2, (int)val); };
+    unsigned long long m = __ballot(v.e > v.s);
+    uint32_t cur_s = 0, cur_e = 0;  // what is left of the list being cut
+    float cur_q = 0.0f;
     auto fill = [&](Batch &b) {
-        const uint32_t p0 = next_p;
-        b.n = p0 < total ? (int)min(total - p0, (uint32_t)kBlock) : 0;
-        next_p += kBlock;
-        const uint32_t p = p0 + (uint32_t)lane;
-        int lo = 0, hi = kBlock - 1;  // the first lane whose inclusive prefix exceeds p
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int mid = (lo + hi) >> 1;
-            const bool above = bperm(incl, mid) > p;
-            hi = above ? mid : hi;
-            lo = above ? lo : mid + 1;
+        b.n = 0, b.mixed = false, b.q = 0.0f;
+        uint32_t addr = 0;
+        int lists = 0;
+        while (b.n < kBlock) {
+            if (cur_s >= cur_e) {
+                if (!m) break;
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                cur_s = lane_u32(v.s, l), cur_e = lane_u32(v.e, l), cur_q = lane_f32(v.qv, l);
+                tr.add(&Trace::slow_segments);
+            }
+            const uint32_t take = min(cur_e - cur_s, (uint32_t)(kBlock - b.n));
+            const uint32_t at = (uint32_t)(lane - b.n);
+            if (at < take) {
+                addr = cur_s + at;
+                b.q = cur_q;
+            }
+            cur_s += take, b.n += (int)take, lists++;
         }
-        const int owner = lo < kBlock ? lo : kBlock - 1;
-        const uint32_t o_start = bperm(start, owner), o_s = bperm(v.s, owner);
-        b.q = __uint_as_float(bperm(__float_as_uint(v.qv), owner));
-        const bool have = lane < b.n;
-        const int first = __builtin_amdgcn_readfirstlane(owner);
-        b.mixed = __ballot(have && owner != first) != 0;
-        if (TRACE) tr.add(&Trace::slow_segments, b.n > 0 ? (uint32_t)(__builtin_amdgcn_readlane(owner, b.n - 1) - first + 1) : 0);
-        b.P = post[have ? o_s + (p - o_start) : 0];  // every fill issues exactly one load (lanes past n read posting 0 and are not
-                                                      // applied): the wait for a batch is then "all but the kFlatAhead - 1 younger
-                                                      // loads" on every path, not "all loads"
+        b.mixed = lists > 1;
+        b.P = post[addr];  // every fill issues exactly one load (lanes past n read posting 0 and are not applied): the wait for a
+                           // batch is then "all but the kFlatAhead - 1 younger loads" on every path, not "all loads"
     };
     auto apply = [&](const Batch &b) {
         const bool have = lane < b.n;
