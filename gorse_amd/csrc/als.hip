@@ -558,6 +558,9 @@ __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A,
     // probe only (prof != null, MFMA rows): s_memtime ticks of the workgroup's first wave in [0] G, [1] M to LDS + S, [2] sweep;
     // [3] rows, [4] entries, [5] kernel ticks, [6] workgroups
     unsigned long long c_acc = 0, c_m = 0, c_solve = 0, c_rows = 0, c_ent = 0, t_begin = 0;
+#ifndef GORSE_PROBE
+    prof = nullptr;  // the phase counters exist in `make probe-lib` builds only: here every `if (prof)` folds away
+#endif
     if (prof) t_begin = __builtin_amdgcn_s_memtime();
     float *sM = smem;                           // 128 x 129
     float *sq = sM + 128 * kWideLd;             // 16 x 128: one batch of gathered rows
@@ -891,6 +894,23 @@ __device__ __forceinline__ void gram_store_sums(const GramAcc<NB> &g, int d, int
 // becomes its own exec-masked region that waits for its own LDS round trip -- 64 of them in a row cost 11.7K of the solve's
 // 29K cycles per row (profiles/r02_x_probe_als_phased.txt, which also shows that the sibling wave's MFMAs are NOT what slows
 // the solve: it takes as long when all eight waves of the workgroup solve together).
+// The d steps of the sweep, unrolled at compile time (the lane a step writes is an immediate of v_writelane_b32).
+template <int F, int DMAX, bool FULL>
+struct SolveSteps {
+    static __device__ __forceinline__ void run(float &y, int &steps, const float (&mcol)[DMAX], float inv, float gk, int d) {
+        if (FULL || F < d) {  // uniform
+            const float dk = fmaf(-y, inv, gk);
+            const int delta = __builtin_amdgcn_readlane(__float_as_int(dk), F);
+            y = fmaf(__int_as_float(delta), mcol[F], y);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(steps) : "s"(delta), "n"(F));
+        }
+        SolveSteps<F + 1, DMAX, FULL>::run(y, steps, mcol, inv, gk, d);
+    }
+};
+template <int DMAX, bool FULL>
+struct SolveSteps<DMAX, DMAX, FULL> {
+    static __device__ __forceinline__ void run(float &, int &, const float (&)[DMAX], float, float, int) {}
+};
 template <int DMAX, bool FORM, bool FULL = false>
 __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss,
                                               const float *__restrict__ S, int d, float one_w, float w, float reg,
@@ -938,25 +958,19 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
 #pragma unroll
     for (int f = 0; f < DMAX; f++)
         if (FULL || f < d) y = fmaf(mcol[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f)), y);
-    float p = p0;
     // Three operations on the chain per step (wide_sweep has the same form): every lane forms its own would-be step
     // delta_k = (base_k - p_k) - y_k inv_k with one fused operation, lane f's is broadcast, y += delta_f M[:, f]; the new
     // coordinate base_f - y_f inv_f is formed beside the chain.  (Four broadcasts and two more dependent operations per step
     // before: 235 cycles per step next to the sibling wave's MFMAs, profiles/r03_zi_probe_als_prof.txt.)
     const float gk = base - p0;
-    // (the lane number is made opaque once per row: hipcc otherwise keeps the 64 masks `lane == f` in scalar registers across
-    // the rows of the kernel, spills them into a vector register and reloads two words per step)
-    int lane_here = lane;
-    asm volatile("" : "+v"(lane_here));
-#pragma unroll
-    for (int f = 0; f < DMAX; f++) {
-        if (FULL || f < d) {  // uniform; no break, so that the loop unrolls and mcol[f] is a register
-            const float dk = fmaf(-y, inv, gk);
-            const float delta = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dk), f));
-            y = fmaf(delta, mcol[f], y);
-            p = lane_here == f ? p0 + dk : p;  // p_f' = p_f + delta_f (lane f's own dk IS delta_f)
-        }
-    }
+    // Lane f's new coordinate is p0_f + delta_f, and delta_f is already in a scalar register (the broadcast of the chain): it is
+    // written into lane f of a vector of steps (v_writelane, one instruction beside the chain) and added to p0 once after the loop.
+    // (Until round 4 every step selected `lane == f ? p0 + dk : p`: hipcc kept the 64 masks in 128 scalar registers, spilled them
+    // into vector registers once per row and reloaded two words per step -- the 64 v_writelane + ~130 v_readlane per row of the
+    // kernel's 416 "SGPR spills".)
+    int steps = 0;
+    SolveSteps<0, DMAX, FULL>::run(y, steps, mcol, inv, gk, d);
+    const float p = p0 + __int_as_float(steps);  // p_f' = p_f + delta_f; lanes past d: 0 + 0
     if (lane_in) a[lane] = p;
 }
 
@@ -974,6 +988,9 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
     // probe only (prof != null): s_memtime ticks per wave in [0] Gram accumulation, [1] M to LDS, [2] solve; [3] rows,
     // [4] feedback entries, [5] kernel ticks, [6] waves
     unsigned long long c_acc = 0, c_m = 0, c_solve = 0, c_rows = 0, c_ent = 0, t_begin = 0, c_load = 0;
+#ifndef GORSE_PROBE
+    prof = nullptr;  // the phase counters exist in `make probe-lib` builds only: here every `if (prof)` folds away
+#endif
     if (prof) t_begin = __builtin_amdgcn_s_memtime();
     // S (d x d, the same for every row of the half-sweep) is copied to LDS once: read from global memory inside the solve, its
     // 64 loads per row queued behind the sibling waves' gathers -- 24.6K of the solve's 40.5K cycles per row

@@ -2122,7 +2122,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         // among the true kth - 1 best, that score is below the kth best of ALL rows unless X >= j -- j is chosen for a
         // tail of ~1e-3 -- and about 16 j rows lie above it.  The main sweep starts there and VERIFIES it (compact_query
         // flags a query whose K-th-best bound does not reach its threshold); those few queries join the tie queries' stage.
-        const int pilot_stride = 16;
+        // (probe: variant bit 20 = every 8th row tile, bit 21 = every 32nd, bit 22 = without the 1/256 pilot in front)
+        const int pilot_stride = (g_topk_variant & (1 << 20)) ? 8 : ((g_topk_variant & (1 << 21)) ? 32 : 16);
         // probe / test switches: bit 8 = no warm start, bit 9 = warm start whatever N, bit 10 = a pilot kth of 2 (thresholds
         // far too high: most queries fail the verification and are swept again)
         const bool warm = !(g_topk_variant & 256) && kth >= 8 && (h->N >= (int64_t)1 << 17 || (g_topk_variant & 512));
@@ -2143,7 +2144,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             p2.f_out = h->f0.p;
             p2.prof = nullptr;  // the instrumented twin profiles the main sweep only
             p2.probe = 0;
-            if (h->N >= (int64_t)1 << 18 || (g_topk_variant & 512)) {
+            if ((h->N >= (int64_t)1 << 18 || (g_topk_variant & 512)) && !(g_topk_variant & (1 << 22))) {
                 SweepParams p1 = p2;
                 p1.kth = pilot_kth(p2.kth, 16);
                 p1.tile_stride = pilot_stride * 16;

@@ -36,7 +36,8 @@ void gorse_hip_test_set_topk_path(int32_t path);
  * whether it leaves the heap as it is (and a wave per query), bit 19 = the tie replay with a wave per query for every query
  * (default: a lane per query), bits 17-18 = timing probes of the main sweep (1: no block ever qualifies, 2: a qualifying
  * block does nothing, 3: it counts its candidates without storing them; the search then returns after the sweep, results
- * undefined).  Results never depend on the others. */
+ * undefined), bits 20-22 = the warm start's pilot sample: every 8th / every 32nd row tile instead of every 16th, and without the
+ * 1/256 pilot in front (scripts/gpu_probe_topk_c4.py pilot).  Results never depend on the others. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
 /* variant bit 8 (256) switches the warm start of the sweep off (pilot sweep over every 16th row tile -> initial thresholds,
  * verified by the main sweep; csrc/topk_mfma.hip topk_mfma_search), bit 9 (512) switches it on below its size limit of 2^17

@@ -69,6 +69,13 @@ def main():
                   % (c[4], c[5], 100.0 * c[5] / max(c[4], 1), c[11], 100.0 * c[11] / max(c[5], 1), waves, c[1] / max(c[4], 1)), flush=True)
         L.gorse_hip_test_set_topk_variant(0)
         return
+    if "pilot" in sys.argv[1:]:  # the warm start: stride of the pilot sample, with and without the 1/256 pilot in front of it
+        for v, label in ((0, "pilots 1/256 + 1/16 (default)"), (1 << 20, "pilots 1/128 + 1/8"), (1 << 21, "pilots 1/512 + 1/32"),
+                         (1 << 22, "pilot 1/16 alone"), ((1 << 21) | (1 << 22), "pilot 1/32 alone"), (256, "no warm start")):
+            L.gorse_hip_test_set_topk_variant(v)
+            run(t, k, 0, nq, label, reps=2)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
     if "floor" in sys.argv[1:]:  # what the sweep costs without its candidate path (results are garbage: timing only)
         for v, label in ((256, "cold sweep alone"), (256 | (1 << 17), "cold sweep, no block ever qualifies"),
                          (1 << 17, "main: no block qualifies"), (2 << 17, "main: qualifying blocks do nothing"),
