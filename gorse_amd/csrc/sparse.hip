@@ -181,7 +181,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.next = h->next.p;
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     // LDS of a workgroup: ranking buffer + per accumulator 4 B (sum) + 1 B (stamp) + 0.5 B (touched list)
-    const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 << h->logG) / 2;
+    const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 << h->logG) / 2 + 64;  // + the batch assembly's board
     const int tok = h->prof.begin(0, h->stream);
     std::vector<sparse::Work> work;
     h->trace_host.clear();
@@ -289,7 +289,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         }
         // the host lists (work, heavy_*, nparts, split_t) and the trace buffer are reused or die with this iteration
         if (n_long > 0 || h->trace_on) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (h->trace_on) {
+        if (h->trace_on && a.trace) {  // (a.trace stays null outside `make probe-lib` builds: nothing was recorded)
             const size_t at = h->trace_host.size();
             h->trace_host.resize(at + work.size());
             GORSE_HIP_CHECK(hipMemcpy(h->trace_host.data() + at, h->trace.p, work.size() * sizeof(sparse::Trace), hipMemcpyDeviceToHost));

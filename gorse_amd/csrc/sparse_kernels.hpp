@@ -374,39 +374,59 @@ __device__ inline void apply_at_once(const Visit &v, float *acc, volatile lds_u8
 // at most S / 2 postings per super-visit, so the table never fills.
 template <bool ATOMIC, bool TRACE, bool HASH = false>
 __device__ inline void apply_flattened(const Posting *__restrict__ post, const Visit &v, float *acc, volatile lds_u8 *tag,
-                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Tracer<TRACE> &tr, int lm) {
+                                       uint16_t *touched, int tcap, int lane, GroupState &gs, Tracer<TRACE> &tr, int lm,
+                                       volatile lds_u8 *board) {
     struct Batch {
         Posting P;
         float q;
         int n;       // postings of the batch (wave-uniform); 0: none left
         bool mixed;  // more than one list
     };
-    unsigned long long m = __ballot(v.e > v.s);
-    uint32_t cur_s = 0, cur_e = 0;  // what is left of the list being cut
-    float cur_q = 0.0f;
+    // The segments laid end to end: lane l's list covers the positions [start_l, incl_l) of the concatenation (an inclusive scan
+    // of the lengths over the lanes, DPP only); batch b is the positions [64 b, 64 b + 64).  A position finds its list without a walk
+    // over the lists and without a dependent chain: every list that STARTS inside the batch's window writes its lane number to
+    // board[start - p0] (64 bytes of LDS), every position reads its byte back, and a prefix maximum over the lanes (DPP) carries the
+    // last start forward; positions in front of the first start belong to the list that continues from the batch before (the first
+    // lane whose prefix exceeds p0: one ballot).  Two LDS round trips per batch (board, then the owner's segment start / value by
+    // ds_bpermute).  Until round 4 the batch was assembled by a wave-uniform walk over the lists -- three v_readlane and a dozen scalar
+    // operations per list, ~330 cycles for a list that contributes two postings (profiles/r04_g_probe_sparse_trace.txt: 2.4e8 such
+    // segments); a binary search over the prefixes (six dependent ds_bpermute) was no faster (profiles/r04_j_*_bsearch.txt).
+    const uint32_t len = v.e - v.s;
+    auto dpp_scan = [&](uint32_t x, auto op) {  // inclusive scan over the 64 lanes; 0 is the identity of op
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));  // row_shr:1
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));  // row_shr:2
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));  // row_shr:4
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));  // row_shr:8
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+        x = op(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+        return x;
+    };
+    const uint32_t incl = dpp_scan(len, [](uint32_t a, uint32_t b) { return a + b; });
+    const uint32_t total = lane_u32(incl, kBlock - 1);
+    const uint32_t start = incl - len;
+    uint32_t next_p = 0;  // first position of the next batch to assemble
+    auto bperm = [&](uint32_t val, uint32_t from) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)val); };
     auto fill = [&](Batch &b) {
-        b.n = 0, b.mixed = false, b.q = 0.0f;
-        uint32_t addr = 0;
-        int lists = 0;
-        while (b.n < kBlock) {
-            if (cur_s >= cur_e) {
-                if (!m) break;
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                cur_s = lane_u32(v.s, l), cur_e = lane_u32(v.e, l), cur_q = lane_f32(v.qv, l);
-                tr.add(&Trace::slow_segments);
-            }
-            const uint32_t take = min(cur_e - cur_s, (uint32_t)(kBlock - b.n));
-            const uint32_t at = (uint32_t)(lane - b.n);
-            if (at < take) {
-                addr = cur_s + at;
-                b.q = cur_q;
-            }
-            cur_s += take, b.n += (int)take, lists++;
-        }
-        b.mixed = lists > 1;
-        b.P = post[addr];  // every fill issues exactly one load (lanes past n read posting 0 and are not applied): the wait for a
-                           // batch is then "all but the kFlatAhead - 1 younger loads" on every path, not "all loads"
+        const uint32_t p0 = next_p;
+        b.n = p0 < total ? (int)min(total - p0, (uint32_t)kBlock) : 0;
+        next_p += kBlock;
+        const uint32_t rel = start - p0;
+        if (len > 0 && rel < (uint32_t)kBlock) board[rel] = (uint8_t)(lane + 1);
+        uint32_t f = board[lane];
+        board[lane] = 0;
+        f = dpp_scan(f, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+        const unsigned long long over = __ballot(incl > p0);  // the list that continues into this window (or starts at p0)
+        const uint32_t carry = over ? (uint32_t)(__ffsll((long long)over) - 1) : 0u;
+        const uint32_t owner = f ? f - 1 : carry;
+        const uint32_t o_start = bperm(start, owner), o_s = bperm(v.s, owner);
+        b.q = __uint_as_float(bperm(__float_as_uint(v.qv), owner));
+        const bool have = lane < b.n;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)owner);
+        b.mixed = __ballot(have && owner != first) != 0;
+        if (TRACE) tr.add(&Trace::slow_segments, b.n > 0 ? (uint32_t)(__builtin_amdgcn_readlane((int)owner, b.n - 1) - (int)first + 1) : 0);
+        b.P = post[have ? o_s + (p0 + (uint32_t)lane - o_start) : 0];  // every fill issues exactly one load (lanes past n read
+                                                                       // posting 0 and are not applied): the wait for a batch is then
+                                                                       // "all but the kFlatAhead - 1 younger loads", not "all loads"
     };
     auto apply = [&](const Batch &b) {
         const bool have = lane < b.n;
@@ -487,7 +507,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     float *acc = reinterpret_cast<float *>(s_mem + (size_t)CAP * 8);
     volatile lds_u8 *tag = (volatile lds_u8 *)(s_mem + (size_t)CAP * 8 + (size_t)NL * 4);
     uint16_t *touched = reinterpret_cast<uint16_t *>(s_mem + (size_t)CAP * 8 + (size_t)NL * 5);  // NL / 4 entries
+    volatile lds_u8 *board = (volatile lds_u8 *)(s_mem + (size_t)CAP * 8 + (size_t)NL * 5 + (size_t)NL / 2);  // 64 bytes (apply_flattened)
     const int lane = threadIdx.x;
+    board[lane] = 0;
     for (int i = lane; i < NL; i += kBlock) acc[i] = 0.0f;
     __syncthreads();
     for (;;) {
@@ -648,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                         else
                             apply_at_once<ATOMIC, TRACE, kGather>(v0, acc, tag, touched, tcap, lane, gs, tr, lm);
                     } else
-                        apply_flattened<ATOMIC, TRACE>(post, v0, acc, tag, touched, tcap, lane, gs, tr, lm);
+                        apply_flattened<ATOMIC, TRACE>(post, v0, acc, tag, touched, tcap, lane, gs, tr, lm, board);
                     tr.add(once ? &Trace::ticks_once : &Trace::ticks_flat, (uint32_t)(tr.now() - c0));
                 }
             }
@@ -705,7 +727,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 if (total > (uint32_t)cap_t) {  // one group, many postings: directly indexed accumulators
                     for (int ch = 0; ch < nch; ch++) {
                         if (nch > 1) seg_of(ch, gg, 1, x);
-                        if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE>(post, x, acc, tag, touched, tcap, lane, gs, tr, lm);
+                        if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE>(post, x, acc, tag, touched, tcap, lane, gs, tr, lm, board);
                     }
                     tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
                     read_back(gg);
@@ -714,7 +736,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 }
                 for (int ch = 0; ch < nch; ch++) {
                     if (nch > 1) seg_of(ch, gg, ww, x);
-                    if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE, true>(post, x, acc, tag, touched, tcap, lane, gs, tr, S - 1);
+                    if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE, true>(post, x, acc, tag, touched, tcap, lane, gs, tr, S - 1, board);
                 }
                 tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
                 const unsigned long long c1 = tr.now();
