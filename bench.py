@@ -791,6 +791,31 @@ def bench_fit(args, local):
     return out
 
 
+def bench_mm(args, local):
+    """floats.MM (common/floats/floats.go:241: C += A B as an l-ascending fmaf chain per element) on the fp32 MFMA, where the
+    reference's CTR models and its tests call it.  2048^3, NN; the kernel time comes from hipEvents around the launch inside
+    gorse_hip_sgemm (the entry point takes host buffers: the copies are not part of the figure; PCIe-inclusive: `host_to_host_ms`)."""
+    n = 2048
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((n, n)).astype(np.float32)
+    b = rng.standard_normal((n, n)).astype(np.float32)
+    c0 = np.zeros((n, n), np.float32)
+    L = capi.lib()
+    capi.sgemm(0, 0, n, n, n, a.ravel(), n, b.ravel(), n, c0.ravel(), n, device=local)  # code objects
+    ms, wall = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        capi.sgemm(0, 0, n, n, n, a.ravel(), n, b.ravel(), n, c0.ravel(), n, device=local)
+        wall.append((time.perf_counter() - t0) * 1e3)
+        ms.append(L.gorse_hip_test_sgemm_last_ms())
+    t = float(np.median(ms))
+    tf = 2.0 * n * n * n / (t * 1e-3) / 1e12
+    return {"metric": "floats.MM TFLOP/s (fp32, 2048^3 NN, bit-equal to the reference's fmaf chain)", "value": tf, "unit": "TFLOP/s",
+            "ms_per_step": t, "steps": 3, "higher_is_better": True, "dtype": "f32", "data": "synthetic", "host_to_host_ms": float(np.median(wall)),
+            "roofline": {"bound": "mfma_f32", "kernel": "sgemm_mfma_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": t, "launches": 3}}
+
+
 def leg(fn, what):
     """a secondary leg of the default line: its failure costs the line that object only"""
     try:
@@ -811,7 +836,7 @@ def emit(out, tag="default"):
     notes = {}
     line = compact(ordered, notes)
     # the driver's tail is 8 KB: if the line is still long, the secondary objects' `config` blocks move to the notes as well
-    for k in ("ml100k_d8", "ml100k", "i2i", "als", "c3", "fit"):
+    for k in ("mm", "ml100k_d8", "ml100k", "i2i", "als", "c3", "fit"):
         if len(json.dumps(line, separators=(",", ":"))) < 7000:
             break
         if isinstance(line.get(k), dict) and "config" in line[k]:
@@ -888,6 +913,7 @@ def main():
                             "BPR positive-samples/sec, S-ml100k nFactors 16")
         out["ml100k_d8"] = leg(lambda: bench_bpr(args, "ml100k", 1, 0, local, None, "single GPU", 20, 3, with_cpu=False, factors=8),
                                "BPR positive-samples/sec, S-ml100k nFactors 8")
+        out["mm"] = leg(lambda: bench_mm(args, local), "floats.MM TFLOP/s")
         out["fit"] = leg(lambda: bench_fit(args, local), "BPR.Fit wall seconds (S-ml1m, nFactors 8 / 16, 30 epochs)")
         # north_star's 10M x 1M x 128 set: P = 5.1 GB, far outside every cache.  250M draws (220M distinct feedbacks, 22 per user)
         # instead of --workload big's 1.25e9 so that the set generates in seconds inside the driver's run; same users, same items

@@ -5,7 +5,10 @@
 // Semantics are the reference's (NOT BLAS beta=0): the NN, TN and TT cases accumulate into C
 // through an l-ascending FMA chain per element (clang contracts `c += a*b` in _mm512_mm), the NT
 // case overwrites C with floats.Dot of two rows in AVX512 lane order.  The f32 chain is exactly
-// what one MFMA f32 accumulator does, so results are bit-identical to the AVX512 build.
+// what one accumulator of v_mfma_f32_32x32x2_f32 does -- checked bit for bit on the device
+// (scripts/probe_mfma_f32_chain.hip, profiles/r04_q_probe_mfma_f32_chain.txt: wide exponent ranges, signed
+// zeros) -- so the three chain cases run on the matrix cores (sgemm_mfma_kernel, round 4) and stay
+// bit-identical to the AVX512 build; sgemm_chain_kernel is the same chain on the vector ALU (tiny shapes).
 #include <algorithm>
 
 #include "cf_device.hpp"
@@ -39,6 +42,97 @@ __global__ __launch_bounds__(TS *TS) void sgemm_chain_kernel(int m, int n, int k
     if (i < m && j < n) c[(int64_t)i * ldc + j] = acc;
 }
 
+// NN / TN / TT on the fp32 MFMA.  A workgroup of four waves owns a 128 x 128 tile of C, a wave a 64 x 64 quarter as 2 x 2 accumulators
+// of 32 x 32; the operands pass through LDS in blocks of 16 l: As[i][l] (row stride 17 words: the 32 lanes of a fragment read 32
+// different banks), Bs[l][j].  One v_mfma_f32_32x32x2_f32 advances every element of an accumulator by TWO steps of its chain
+// (l, then l + 1); an odd last l is one fmaf per element afterwards -- never a padded zero step, which would turn an accumulated
+// -0 into +0.  Rows / columns past m / n are loaded as zeros and not stored.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMmTile = 128, kMmKB = 16, kMmAs = kMmKB + 1;
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ a, int lda,
+                                                         const float *__restrict__ b, int ldb, float *__restrict__ c, int ldc) {
+    __shared__ float As[kMmTile * kMmAs];
+    __shared__ float Bs[kMmKB * kMmTile];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = blockIdx.y * kMmTile, j0 = blockIdx.x * kMmTile;
+    const int wi = 64 * (wv >> 1), wj = 64 * (wv & 1);  // the wave's quarter inside the tile
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; bi++)
+#pragma unroll
+        for (int bj = 0; bj < 2; bj++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = i0 + wi + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = j0 + wj + 32 * bj + (lane & 31);
+                acc[bi][bj][r] = (i < m && j < n) ? c[(int64_t)i * ldc + j] : 0.0f;
+            }
+    const int k2 = k & ~1;  // the l that come in pairs
+    for (int l0 = 0; l0 < k2; l0 += kMmKB) {
+        // global -> LDS: 2048 elements of each operand, 8 per thread
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            int ti, tl;  // element (ti, tl) of the A tile
+            if (TA) {    // a[l * lda + i]: contiguous in i
+                tl = tid >> 4;
+                ti = (tid & 15) * 8 + e;
+            } else {     // a[i * lda + l]: contiguous in l
+                ti = tid >> 1;
+                tl = (tid & 1) * 8 + e;
+            }
+            const int gi = i0 + ti, gl = l0 + tl;
+            float v = 0.0f;
+            if (gi < m && gl < k2) v = TA ? a[(int64_t)gl * lda + gi] : a[(int64_t)gi * lda + gl];
+            As[ti * kMmAs + tl] = v;
+            int ul, uj;  // element (ul, uj) of the B tile
+            if (TB) {    // b[j * ldb + l]: contiguous in l
+                uj = tid >> 1;
+                ul = (tid & 1) * 8 + e;
+            } else {     // b[l * ldb + j]: contiguous in j
+                ul = tid >> 4;
+                uj = (tid & 15) * 8 + e;
+            }
+            const int gj = j0 + uj, hl = l0 + ul;
+            float w = 0.0f;
+            if (gj < n && hl < k2) w = TB ? b[(int64_t)gj * ldb + hl] : b[(int64_t)hl * ldb + gj];
+            Bs[ul * kMmTile + uj] = w;
+        }
+        __syncthreads();
+        const int steps = min(kMmKB, k2 - l0);  // even
+        for (int kk = 0; kk < steps; kk += 2) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int bi = 0; bi < 2; bi++) fa[bi] = As[(wi + 32 * bi + (lane & 31)) * kMmAs + kk + (lane >> 5)];
+#pragma unroll
+            for (int bj = 0; bj < 2; bj++) fb[bj] = Bs[(kk + (lane >> 5)) * kMmTile + wj + 32 * bj + (lane & 31)];
+#pragma unroll
+            for (int bi = 0; bi < 2; bi++)
+#pragma unroll
+                for (int bj = 0; bj < 2; bj++) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi], fb[bj], acc[bi][bj], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const bool odd = (k & 1) != 0;
+#pragma unroll
+    for (int bi = 0; bi < 2; bi++)
+#pragma unroll
+        for (int bj = 0; bj < 2; bj++) {
+            const int j = j0 + wj + 32 * bj + (lane & 31);
+            float bl = 0.0f;
+            if (odd && j < n) bl = TB ? b[(int64_t)j * ldb + (k - 1)] : b[(int64_t)(k - 1) * ldb + j];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int i = i0 + wi + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (i < m && j < n) {
+                    float v = acc[bi][bj][r];
+                    if (odd) v = fmaf(TA ? a[(int64_t)(k - 1) * lda + i] : a[(int64_t)i * lda + (k - 1)], bl, v);
+                    c[(int64_t)i * ldc + j] = v;
+                }
+            }
+        }
+}
+
 // NT: C[i][j] = floats.Dot(A row i, B row j) in AVX512 order; one 16-lane group per element.
 __global__ __launch_bounds__(kBlock) void sgemm_nt_kernel(int m, int n, int k, const float *__restrict__ a, int lda,
                                                           const float *__restrict__ b, int ldb, float *__restrict__ c,
@@ -61,7 +155,13 @@ __global__ __launch_bounds__(kBlock) void sgemm_nt_kernel(int m, int n, int k, c
     }
 }
 
+int g_sgemm_valu = 0;  // test hook: 1 = the vector-ALU chain whatever the shape (gorse_hip_test_set_sgemm_valu)
+double g_sgemm_last_ms = 0.0;  // kernel time of the last call (hipEvents around the launch): gorse_hip_test_sgemm_last_ms
+
 }  // namespace
+
+extern "C" void gorse_hip_test_set_sgemm_valu(int32_t on) { g_sgemm_valu = on; }
+extern "C" double gorse_hip_test_sgemm_last_ms(void) { return g_sgemm_last_ms; }
 
 extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k,
                                    const float *a, int32_t lda, const float *b, int32_t ldb, float *c, int32_t ldc) {
@@ -90,10 +190,22 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
         GORSE_HIP_CHECK(hipMemcpyAsync(db.p, b, nb * 4, hipMemcpyHostToDevice, st));
     }
     GORSE_HIP_CHECK(hipMemcpyAsync(dc.p, c, nc * 4, hipMemcpyHostToDevice, st));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    (void)hipEventCreate(&ev0);
+    (void)hipEventCreate(&ev1);
+    (void)hipEventRecord(ev0, st);
     if (!transA && transB) {
         int64_t blocks = std::min<int64_t>(ceil_div((int64_t)m * n, kGroupsPerBlock), 8192);
         sgemm_nt_kernel<<<dim3((unsigned)blocks), dim3(kBlock), (size_t)kGroupsPerBlock * 2 * std::max(k, 1) * 4, st>>>(
             m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+    } else if (k > 0 && (int64_t)m * n >= 64 * 64 && !g_sgemm_valu) {  // the matrix cores (a tile is 128 x 128: below 64 x 64 the vector ALU form)
+        dim3 grid((unsigned)ceil_div(n, kMmTile), (unsigned)ceil_div(m, kMmTile)), block(256);
+        if (!transA && !transB)
+            sgemm_mfma_kernel<false, false><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+        else if (transA && !transB)
+            sgemm_mfma_kernel<true, false><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+        else
+            sgemm_mfma_kernel<true, true><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
     } else if (k > 0) {
         dim3 grid((unsigned)ceil_div(n, TS), (unsigned)ceil_div(m, TS)), block(TS * TS);
         if (!transA && !transB)
@@ -103,8 +215,15 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
         else
             sgemm_chain_kernel<true, true><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
     }
-    GORSE_HIP_CHECK(hipGetLastError());
-    GORSE_HIP_CHECK(hipMemcpyAsync(c, dc.p, nc * 4, hipMemcpyDeviceToHost, st));
-    GORSE_HIP_CHECK(hipStreamSynchronize(st));
+    const hipError_t launched = hipGetLastError();
+    (void)hipEventRecord(ev1, st);
+    hipError_t rc = launched;
+    if (rc == hipSuccess) rc = hipMemcpyAsync(c, dc.p, nc * 4, hipMemcpyDeviceToHost, st);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    float ms = 0.0f;
+    if (rc == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) g_sgemm_last_ms = ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (rc != hipSuccess) return fail(GORSE_ERR_HIP, "gorse_hip_sgemm: %s", hipGetErrorString(rc));
     return GORSE_OK;
 }

@@ -109,6 +109,11 @@ void gorse_hip_test_set_bpr_chunk(int64_t samples);
  * positive item likewise, bit 2 = the store adds to a row re-read in the same iteration instead of the gathered snapshot;
  * < 0 = the library's default.  Which items are cold is fixed at gorse_mf_create (gorse_hip_test_set_bpr_cold_window). */
 void gorse_hip_test_set_bpr_store_mode(int32_t store_mode);
+/* floats.MM (csrc/sgemm.hip): 1 = the NN / TN / TT chains on the vector ALU whatever the shape (default: on the fp32 MFMA from 64 x 64
+ * results on; both are the same l-ascending fmaf chain, bit for bit).  The second hook returns the kernel time of the last
+ * gorse_hip_sgemm call in milliseconds (hipEvents around the launch, copies excluded): bench.py's `mm` object. */
+void gorse_hip_test_set_sgemm_valu(int32_t on);
+double gorse_hip_test_sgemm_last_ms(void);
 /* 1 = this is a `make probe-lib` build (csrc/Makefile, -DGORSE_PROBE): it also carries the instrumented twin of the top-k sweep, the
  * wave-per-query tie replay, the sparse kernel's trace instantiation and the positive-side / re-reading forms of the BPR store
  * route.  The library `make all` ships (0) answers the switches that would select those with its own nearest form. */

@@ -192,6 +192,46 @@ def test_sgemm_larger_vs_oracle(oracle):
                 assert np.array_equal(bits(got), bits(exp)), (m, n, k, tA, tB)
 
 
+def test_sgemm_on_the_matrix_cores_is_the_same_chain(oracle):
+    """floats.MM's NN / TN / TT cases run on v_mfma_f32_32x32x2_f32 from 64 x 64 results on (csrc/sgemm.hip sgemm_mfma_kernel): every
+    element must still be the l-ascending fmaf chain of _mm512_mm onto C's previous value -- the oracle's, bit for bit, and the
+    vector-ALU kernel's (test hook).  Shapes off the 128-tile and off the 16-step block, k = 1 / 2 / 3 / odd, padded leading
+    dimensions, values over 24 binary orders of magnitude, and a C of signed zeros against all-zero operands (a padded zero step
+    would turn -0 into +0: the kernel never takes one)."""
+    rng = np.random.default_rng(9)
+    L = capi.lib()
+    for (m, n, k) in [(64, 64, 1), (64, 65, 2), (70, 64, 3), (129, 257, 33), (300, 131, 130), (257, 300, 67)]:
+        for tA, tB in ((0, 0), (1, 0), (1, 1)):
+            pad = int(rng.integers(0, 3))
+            ar, ac = ((k, m) if tA else (m, k))
+            br, bc = ((n, k) if tB else (k, n))
+            a = np.ldexp(rng.uniform(-1, 1, (ar, ac + pad)), rng.integers(-12, 12, (ar, ac + pad))).astype(np.float32)
+            b = np.ldexp(rng.uniform(-1, 1, (br, bc + pad)), rng.integers(-12, 12, (br, bc + pad))).astype(np.float32)
+            c0 = rng.standard_normal((m, n + pad)).astype(np.float32)
+            c0[::3, ::5] = -0.0
+            args = (tA, tB, m, n, k, a.ravel(), ac + pad, b.ravel(), bc + pad, c0.ravel(), n + pad)
+            got = capi.sgemm(*args)
+            assert L.gorse_hip_test_sgemm_last_ms() > 0.0
+            exp = oracle.mm(*args)
+            assert np.array_equal(bits(got), bits(exp)), (m, n, k, tA, tB)
+            L.gorse_hip_test_set_sgemm_valu(1)
+            try:
+                valu = capi.sgemm(*args)
+            finally:
+                L.gorse_hip_test_set_sgemm_valu(0)
+            assert np.array_equal(bits(got), bits(valu)), (m, n, k, tA, tB)
+    # signed zeros: C = -0 stays -0 under products that are all +0 or -0 only if no extra step is taken
+    m = n = 64
+    for k in (4, 5):
+        a = np.zeros((m, k), np.float32)
+        b = np.zeros((k, n), np.float32)
+        b[1::2] = -0.0
+        c0 = np.full((m, n), -0.0, np.float32)
+        got = capi.sgemm(0, 0, m, n, k, a.ravel(), k, b.ravel(), n, c0.ravel(), n)
+        exp = oracle.mm(0, 0, m, n, k, a.ravel(), k, b.ravel(), n, c0.ravel(), n)
+        assert np.array_equal(bits(got), bits(exp)), k
+
+
 def test_sgemm_errors():
     with pytest.raises(capi.GorseHipError):
         capi.sgemm(0, 0, 2, 2, 2, np.zeros(4), 1, np.zeros(4), 2, np.zeros(4), 2)  # lda too small
