@@ -42,82 +42,112 @@ __global__ __launch_bounds__(TS *TS) void sgemm_chain_kernel(int m, int n, int k
     if (i < m && j < n) c[(int64_t)i * ldc + j] = acc;
 }
 
-// NN / TN / TT on the fp32 MFMA.  A workgroup of four waves owns a 128 x 128 tile of C, a wave a 64 x 64 quarter as 2 x 2 accumulators
-// of 32 x 32; the operands pass through LDS in blocks of 16 l: As[i][l] (row stride 17 words: the 32 lanes of a fragment read 32
+// NN / TN / TT on the fp32 MFMA.  A workgroup of four waves owns a 128 x 128 (or 64 x 64) tile of C, a wave a quarter of it as 2 x 2
+// (or one) accumulators of 32 x 32; the operands pass through LDS in blocks of 16 l: As[i][l] (row stride 17 words: the 32 lanes of a fragment read 32
 // different banks), Bs[l][j].  One v_mfma_f32_32x32x2_f32 advances every element of an accumulator by TWO steps of its chain
 // (l, then l + 1); an odd last l is one fmaf per element afterwards -- never a padded zero step, which would turn an accumulated
 // -0 into +0.  Rows / columns past m / n are loaded as zeros and not stored.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMmTile = 128, kMmKB = 16, kMmAs = kMmKB + 1;
+constexpr int kMmKB = 16, kMmAs = kMmKB + 1;
 
-template <bool TA, bool TB>
+// W = 2: a 128 x 128 tile per workgroup (2 x 2 accumulators per wave); W = 1: 64 x 64 (one accumulator per wave) for shapes that
+// would otherwise leave most of the 256 CUs without a tile.  The next block's operands are loaded into registers while the
+// current block's MFMAs run (global latency behind the matrix pipe), then stored to LDS between two barriers.
+template <bool TA, bool TB, int W>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ a, int lda,
                                                          const float *__restrict__ b, int ldb, float *__restrict__ c, int ldc) {
-    __shared__ float As[kMmTile * kMmAs];
-    __shared__ float Bs[kMmKB * kMmTile];
+    constexpr int T = 64 * W;       // tile edge
+    constexpr int PT = T * kMmKB / 256;  // elements of each operand tile per thread (8 or 4)
+    __shared__ float As[T * kMmAs];
+    __shared__ float Bs[kMmKB * T];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i0 = blockIdx.y * kMmTile, j0 = blockIdx.x * kMmTile;
-    const int wi = 64 * (wv >> 1), wj = 64 * (wv & 1);  // the wave's quarter inside the tile
-    f32x16 acc[2][2];
+    const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
+    const int wi = 32 * W * (wv >> 1), wj = 32 * W * (wv & 1);  // the wave's quarter inside the tile
+    f32x16 acc[W][W];
 #pragma unroll
-    for (int bi = 0; bi < 2; bi++)
+    for (int bi = 0; bi < W; bi++)
 #pragma unroll
-        for (int bj = 0; bj < 2; bj++)
+        for (int bj = 0; bj < W; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int i = i0 + wi + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = j0 + wj + 32 * bj + (lane & 31);
                 acc[bi][bj][r] = (i < m && j < n) ? c[(int64_t)i * ldc + j] : 0.0f;
             }
     const int k2 = k & ~1;  // the l that come in pairs
-    for (int l0 = 0; l0 < k2; l0 += kMmKB) {
-        // global -> LDS: 2048 elements of each operand, 8 per thread
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            int ti, tl;  // element (ti, tl) of the A tile
-            if (TA) {    // a[l * lda + i]: contiguous in i
-                tl = tid >> 4;
-                ti = (tid & 15) * 8 + e;
-            } else {     // a[i * lda + l]: contiguous in l
-                ti = tid >> 1;
-                tl = (tid & 1) * 8 + e;
-            }
-            const int gi = i0 + ti, gl = l0 + tl;
-            float v = 0.0f;
-            if (gi < m && gl < k2) v = TA ? a[(int64_t)gl * lda + gi] : a[(int64_t)gi * lda + gl];
-            As[ti * kMmAs + tl] = v;
-            int ul, uj;  // element (ul, uj) of the B tile
-            if (TB) {    // b[j * ldb + l]: contiguous in l
-                uj = tid >> 1;
-                ul = (tid & 1) * 8 + e;
-            } else {     // b[l * ldb + j]: contiguous in j
-                ul = tid >> 4;
-                uj = (tid & 15) * 8 + e;
-            }
-            const int gj = j0 + uj, hl = l0 + ul;
-            float w = 0.0f;
-            if (gj < n && hl < k2) w = TB ? b[(int64_t)gj * ldb + hl] : b[(int64_t)hl * ldb + gj];
-            Bs[ul * kMmTile + uj] = w;
+    // element e of this thread in the A tile is (ti, tl), in the B tile (ul, uj): contiguous along the operand's storage order
+    auto a_at = [&](int e, int &ti, int &tl) {
+        const int x = tid * PT + e;
+        if (TA) {  // a[l * lda + i]: contiguous in i
+            tl = x / T;
+            ti = x % T;
+        } else {   // a[i * lda + l]: contiguous in l
+            ti = x / kMmKB;
+            tl = x % kMmKB;
         }
+    };
+    auto b_at = [&](int e, int &ul, int &uj) {
+        const int x = tid * PT + e;
+        if (TB) {  // b[j * ldb + l]: contiguous in l
+            uj = x / kMmKB;
+            ul = x % kMmKB;
+        } else {   // b[l * ldb + j]: contiguous in j
+            ul = x / T;
+            uj = x % T;
+        }
+    };
+    float ra[PT], rb[PT];
+    auto gload = [&](int l0) {
+#pragma unroll
+        for (int e = 0; e < PT; e++) {
+            int ti, tl, ul, uj;
+            a_at(e, ti, tl);
+            b_at(e, ul, uj);
+            const int gi = i0 + ti, gl = l0 + tl, gj = j0 + uj, hl = l0 + ul;
+            ra[e] = (gi < m && gl < k2) ? (TA ? a[(int64_t)gl * lda + gi] : a[(int64_t)gi * lda + gl]) : 0.0f;
+            rb[e] = (gj < n && hl < k2) ? (TB ? b[(int64_t)gj * ldb + hl] : b[(int64_t)hl * ldb + gj]) : 0.0f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < PT; e++) {
+            int ti, tl, ul, uj;
+            a_at(e, ti, tl);
+            b_at(e, ul, uj);
+            As[ti * kMmAs + tl] = ra[e];
+            Bs[ul * T + uj] = rb[e];
+        }
+    };
+    if (k2 > 0) {
+        gload(0);
+        lstore();
         __syncthreads();
+    }
+    for (int l0 = 0; l0 < k2; l0 += kMmKB) {
+        const bool more = l0 + kMmKB < k2;
+        if (more) gload(l0 + kMmKB);
         const int steps = min(kMmKB, k2 - l0);  // even
         for (int kk = 0; kk < steps; kk += 2) {
-            float fa[2], fb[2];
+            float fa[W], fb[W];
 #pragma unroll
-            for (int bi = 0; bi < 2; bi++) fa[bi] = As[(wi + 32 * bi + (lane & 31)) * kMmAs + kk + (lane >> 5)];
+            for (int bi = 0; bi < W; bi++) fa[bi] = As[(wi + 32 * bi + (lane & 31)) * kMmAs + kk + (lane >> 5)];
 #pragma unroll
-            for (int bj = 0; bj < 2; bj++) fb[bj] = Bs[(kk + (lane >> 5)) * kMmTile + wj + 32 * bj + (lane & 31)];
+            for (int bj = 0; bj < W; bj++) fb[bj] = Bs[(kk + (lane >> 5)) * T + wj + 32 * bj + (lane & 31)];
 #pragma unroll
-            for (int bi = 0; bi < 2; bi++)
+            for (int bi = 0; bi < W; bi++)
 #pragma unroll
-                for (int bj = 0; bj < 2; bj++) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi], fb[bj], acc[bi][bj], 0, 0, 0);
+                for (int bj = 0; bj < W; bj++) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi], fb[bj], acc[bi][bj], 0, 0, 0);
         }
         __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
     }
     const bool odd = (k & 1) != 0;
 #pragma unroll
-    for (int bi = 0; bi < 2; bi++)
+    for (int bi = 0; bi < W; bi++)
 #pragma unroll
-        for (int bj = 0; bj < 2; bj++) {
+        for (int bj = 0; bj < W; bj++) {
             const int j = j0 + wj + 32 * bj + (lane & 31);
             float bl = 0.0f;
             if (odd && j < n) bl = TB ? b[(int64_t)j * ldb + (k - 1)] : b[(int64_t)(k - 1) * ldb + j];
@@ -199,13 +229,24 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
         sgemm_nt_kernel<<<dim3((unsigned)blocks), dim3(kBlock), (size_t)kGroupsPerBlock * 2 * std::max(k, 1) * 4, st>>>(
             m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
     } else if (k > 0 && (int64_t)m * n >= 64 * 64 && !g_sgemm_valu) {  // the matrix cores (a tile is 128 x 128: below 64 x 64 the vector ALU form)
-        dim3 grid((unsigned)ceil_div(n, kMmTile), (unsigned)ceil_div(m, kMmTile)), block(256);
+        // 128 x 128 tiles where they give every CU work (>= 512 of them: two per CU), 64 x 64 tiles otherwise
+        const bool big = (int64_t)ceil_div(n, 128) * ceil_div(m, 128) >= 512;
+        const int T = big ? 128 : 64;
+        dim3 grid((unsigned)ceil_div(n, T), (unsigned)ceil_div(m, T)), block(256);
+#define MM(TA_, TB_)                                                                                                   \
+    do {                                                                                                               \
+        if (big)                                                                                                       \
+            sgemm_mfma_kernel<TA_, TB_, 2><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);          \
+        else                                                                                                           \
+            sgemm_mfma_kernel<TA_, TB_, 1><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);          \
+    } while (0)
         if (!transA && !transB)
-            sgemm_mfma_kernel<false, false><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+            MM(false, false);
         else if (transA && !transB)
-            sgemm_mfma_kernel<true, false><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+            MM(true, false);
         else
-            sgemm_mfma_kernel<true, true><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+            MM(true, true);
+#undef MM
     } else if (k > 0) {
         dim3 grid((unsigned)ceil_div(n, TS), (unsigned)ceil_div(m, TS)), block(TS * TS);
         if (!transA && !transB)
