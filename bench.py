@@ -717,7 +717,7 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "samples_per_step_per_gpu": n_samples, "lr": lr, "reg": reg,
                    "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode]
-                   + (", user runs (triplets counting-sorted by user, p_u register-resident)" if user_runs else
+                   + (", user runs (sample ids counting-sorted by user, p_u register-resident, cold negatives by store)" if user_runs else
                       (", one group per sample" if args.mode == capi.BPR_HOGWILD_ATOMIC else "")),
                    "entry_point": "gorse_bpr_epoch_enqueue x steps, one synchronisation at the end (a Fit between two evaluations)",
                    "sync_entry_point_ms_per_step": sync_ms,

@@ -1,18 +1,22 @@
 // bpr.hip -- BPR training step on gfx950.  Reference: model/cf/model.go:446-494.
 //
-// Kernels per chunk of samples:
-//   bpr_sample_kernel      : model.go:449-468 -- one thread per sample draws (u, i, j) from a
-//                            counter-based Philox stream; runs AHEAD on its own stream.
-//   scan + scatter         : counting sort of the chunk's triplets by USER (the order in which a Hogwild epoch
-//                            applies its samples is free: parallel.go:44-68); the sampler has already counted the
-//                            runs and ranked every sample inside its run.
+// Kernels per chunk of samples (the user-run schedule: the production Hogwild form for >= 4096 users and nFactors 8/16/32/64/128):
+//   bpr_sample_user_kernel : model.go:452-458 -- sample s draws its USER from the counter-based Philox stream of sample s and
+//                            takes its rank in that user's run; runs AHEAD on its own stream, like the rest of the preparation.
+//   scan + bpr_scatter_ids : counting sort of the chunk's SAMPLE IDS by user (the order in which a Hogwild epoch applies its
+//                            samples is free: parallel.go:44-68).
+//   bpr_sample_items_kernel: model.go:459-468 -- one thread per sorted position replays its sample's stream and draws the
+//                            positive and the negative; (i, j) are written in sorted order.
 //   bpr_update_user_kernel : model.go:469-488 -- one 16-lane group applies ALL samples of one user: p_u is loaded
 //                            once, updated in registers and stored once; q_i / q_j are gathered ahead (64-byte
-//                            contiguous segments per load) and updated with fp32 atomics, hot positive items through
-//                            replica rows.
+//                            contiguous segments per load) and updated with fp32 atomics (hot items through replica
+//                            rows) -- or, the negative of a COLD item, by one write-through store of fma(t, lr, row).
+// Other schedules:
+//   bpr_sample_kernel      : model.go:449-468 -- one thread per sample draws the whole triplet (the same stream): the
+//                            per-sample and sequential schedules, gorse_bpr_sample_triplets.
 //   bpr_update_kernel      : the per-sample form (one group per sample, three rows updated in place): the
 //                            sequential parity schedule, the racy diagnostic, and the Hogwild schedule of shapes
-//                            with few users or a factor width outside 16/32/64/128.
+//                            with few users or another factor width.
 // HBM-bound: algorithmic bytes per sample = 6*d*4 (three rows read + three written) + 12 (indices).
 #include <algorithm>
 #include <cstdlib>
@@ -999,11 +1003,8 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             int32_t *tb = h->trip[b].p;
             // a never-recorded event is complete: the first two chunks of a handle do not wait
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_consumed[b], 0));
-            // user runs: the sampler ranks its samples inside their users' runs and the rest of the counting sort (scan of
-            // U + 2 counters, scatter) follows on the sampler stream: the whole preparation of chunk c + 1 runs under the
-            // update kernel of chunk c.  (Round 1 measured a sort on this stream as slower -- its separate rank pass put
-            // 1 M returning atomics next to the update kernel's; that pass is gone.)  Variant bit 27: sort on the update stream.
-            // Variant bit 27: the round-3 preparation (whole triplets sampled per sample, then scattered) with the sort on the
+            // user runs: the whole preparation of chunk c + 1 (launch_prepare_users) runs on the sampler stream under the update
+            // kernel of chunk c.  Variant bit 27: the round-3 preparation (whole triplets sampled per sample, then scattered) with the sort on the
             // update stream; bit 26: the same with the sort on the sampler stream.
             const bool fused = uruns && !(g_variant & (1 << 29)) && !(g_variant & (1 << 27));
             const bool by_run = fused && !(g_variant & (1 << 26));

@@ -141,7 +141,7 @@ int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uin
 /* Same, but only enqueues the work on the handle's stream (hogwild modes only). */
 int32_t gorse_bpr_epoch_enqueue(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
                                 int64_t sample_base, int32_t mode);
-/* Which form of the GORSE_BPR_HOGWILD_ATOMIC schedule this handle runs: 1 = user runs (the chunk's triplets are
+/* Which form of the GORSE_BPR_HOGWILD_ATOMIC schedule this handle runs: 1 = user runs (the chunk's samples are
  * counting-sorted by user and one 16-lane group applies all samples of a user with p_u in registers; chosen when
  * there are >= 4096 users and nFactors is 8/16/32/64/128), 0 = one group per sample.  Both apply exactly the triplets
  * gorse_bpr_sample_triplets returns, in a different (Hogwild-legal) order; GORSE_BPR_SCHEDULE=users|samples in the
