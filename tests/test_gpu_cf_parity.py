@@ -526,6 +526,23 @@ def test_prepared_chunk_holds_the_sampled_triplets(oracle, small):
         L.gorse_hip_test_set_variant(0)
 
 
+def test_prepared_chunk_at_a_size_the_product_takes_the_path(oracle):
+    """the same comparison without any test switch: 5000 users (>= 4096: the user-run schedule is the product's choice), a chunk
+    of 300,000 samples drawn from a late stream position, every nFactors the user-run kernel serves"""
+    data = synth.synth_cf(5000, 3000, 120000, seed=17, min_len=2, n_neg=5, with_test=False)
+    for d in (8, 16, 32, 64, 128):
+        mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+        assert mf.bpr_user_runs()
+        n, seed, epoch, base = 300_000, 0x1234_5678_9ABC, 3, (1 << 40) + 12345
+        off, si, sj = mf.bpr_prepare_chunk(n, seed, epoch, base)
+        gu, gi, gj = mf.bpr_sample_triplets(n, seed, epoch, base)
+        assert off[data.U] == n and (gu >= 0).all()
+        su = np.repeat(np.arange(data.U + 1, dtype=np.int32), np.diff(off))
+        assert np.array_equal(_sorted_triples(su[:n], si, sj), _sorted_triples(gu, gi, gj))
+        assert np.array_equal(np.bincount(gu, minlength=data.U), np.diff(off)[:data.U])
+        mf.close()
+
+
 def test_epoch_with_a_user_holding_every_item_skips_its_samples(oracle):
     """bpr_update_user_kernel meets (-1, -1) pairs inside a run (no negative found): nothing is written for them, the rest of the
     run is applied.  Compared with the oracle's Hogwild-free sequential pass over the triplets that exist."""
