@@ -237,7 +237,7 @@ __device__ __forceinline__ void update_elem(float *pu, float *qi, float *qj, int
 // truth for every reader; a hot row's update becomes visible one folder pass (tens of microseconds) late,
 // the same order as the latency of the atomics themselves.  A fold kernel after the launch leaves every
 // replica zero, so nothing outside bpr.hip ever sees them.
-constexpr int kHotReplicas = 8;
+constexpr int kHotReplicas = GORSE_HOT_REPLICAS;
 constexpr int kFolderBlocks = 32;
 
 struct HotRows {
@@ -811,7 +811,6 @@ int32_t launch_update_mode(gorse_mf *h, const int32_t *us, const int32_t *is, co
 #undef LAUNCH
     GORSE_HIP_CHECK(hipGetLastError());
     if (folders > 0) {
-        static_assert(kHotReplicas == 8, "gorse_mf_create sizes hot_rep for 8 replicas");
         const int64_t fb = std::min<int64_t>(ceil_div((int64_t)hot.n_hot * d, 256), 512);
         bpr_fold_kernel<<<dim3((unsigned)fb), dim3(256), 0, st>>>(hot, h->Q.p, d);
         GORSE_HIP_CHECK(hipGetLastError());

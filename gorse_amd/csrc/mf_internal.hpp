@@ -2,6 +2,10 @@
 #pragma once
 #include "cf_device.hpp"
 
+#ifndef GORSE_HOT_REPLICAS
+#define GORSE_HOT_REPLICAS 8  // replica rows per hot item (bpr.hip kHotReplicas; gorse_mf_create sizes hot_rep by it)
+#endif
+
 struct gorse_mf {
     int device = 0;
     int64_t U = 0, I = 0, nnz = 0;
