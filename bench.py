@@ -46,6 +46,13 @@ import torch.distributed as dist  # noqa: E402
 from gorse_amd import capi, synth  # noqa: E402
 from gorse_amd import dist as gdist  # noqa: E402
 
+# Where the few scalars of the run's own bookkeeping (max-over-ranks of a time, agreement flags) live for a collective: the GPU under
+# nccl (= RCCL, what the driver runs); host memory under GORSE_BENCH_BACKEND=gloo -- a FUNCTIONAL check of the N > 1 code path on a box
+# with fewer GPUs than ranks (all ranks then share the visible devices round robin and the exchange goes through host staging:
+# scripts/gpu_session.sh stage `ranks2`; its numbers mean nothing).
+BACKEND = os.environ.get("GORSE_BENCH_BACKEND", "nccl")
+COLL_DEV = "cuda" if BACKEND == "nccl" else "cpu"
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA peak = the fp32 vector rate (MI355X_MICROARCH.md: 157.3 TF spec, 155 measured)
@@ -330,7 +337,7 @@ def bench_topk(args, world, rank, local, fence):
             t.all_pairs(k, q0, q1, fetch=False)
         fence()
         dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEV)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -408,7 +415,7 @@ def bench_sparse(args, world, rank, local, fence, data=None, steps=None, warmup=
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEV)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     launches, ms = sp.get_profile()
@@ -557,7 +564,7 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
     mf.synchronize()
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEV)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -612,22 +619,22 @@ def make_comm(args, world, rank, local):
     set up.  Returns (comm, label)."""
     if world == 1:
         return None, "single GPU"
-    label = "torch.distributed nccl"
-    if args.comm == "lib":
+    label = "torch.distributed " + BACKEND
+    if args.comm == "lib" and BACKEND == "nccl":
         lib, why = None, ""
         try:
             def share(uid):
-                t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+                t = torch.tensor(list(uid), dtype=torch.uint8, device=COLL_DEV)
                 dist.broadcast(t, src=0)
                 return bytes(t.cpu().tolist())
             def agree(ok):
-                t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+                t = torch.tensor([1.0 if ok else 0.0], device=COLL_DEV)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 return float(t.item()) > 0
             lib = gdist.LibComm(rank, world, local, share, agree=agree)
         except Exception as e:  # reported in the line; the run goes on over torch.distributed
             why = repr(e)
-        ok = torch.tensor([1.0 if lib is not None else 0.0], device="cuda")
+        ok = torch.tensor([1.0 if lib is not None else 0.0], device=COLL_DEV)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank takes the same path
         if float(ok.item()) > 0:
             return lib, "gorse_comm (RCCL inside libgorse_hip, collectives on the handle's stream)"
@@ -678,7 +685,7 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
         step(warmup + s + 1)
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEV)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -850,10 +857,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if BACKEND != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if BACKEND == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(BACKEND)
     if args.gpus != world:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)

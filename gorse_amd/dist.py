@@ -232,12 +232,30 @@ class TorchComm:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
 
+    def _staged(self, tensor):
+        """gloo moves host memory: a device tensor goes through a host copy (the functional multi-rank check of bench.py on a box
+        with fewer GPUs than ranks; under nccl = RCCL nothing is staged)"""
+        return self.dist.is_initialized() and self.dist.get_backend() == "gloo" and tensor.is_cuda
+
     def all_reduce_sum(self, tensor):
+        if self._staged(tensor):
+            host = tensor.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM)
+            tensor.copy_(host)
+            return
         self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM)
 
     def all_gather(self, tensor):
         """concatenation over ranks of equal-sized 1-D tensors"""
         import torch
+        if self._staged(tensor):
+            parts = [torch.empty(tensor.numel(), dtype=tensor.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, tensor.cpu())
+            return torch.cat(parts).to(tensor.device)
+        if self.dist.is_initialized() and self.dist.get_backend() == "gloo":
+            parts = [torch.empty_like(tensor) for _ in range(self.world)]
+            self.dist.all_gather(parts, tensor)
+            return torch.cat(parts)
         out = torch.empty(self.world * tensor.numel(), dtype=tensor.dtype, device=tensor.device)
         self.dist.all_gather_into_tensor(out, tensor)
         return out

@@ -11,6 +11,7 @@
 #   pmc:<workload>:<kernel substring>:<key>[:wide]   FETCH_SIZE and WRITE_SIZE passes -> <tag>_traffic.json[key]
 #   sq:<workload>:<kernel substring>                 one SQ pass (MFMA busy, wave cycles, waits) -> <tag>_pmc_SQ_<W>.txt
 #   probe:<script>[:<args with + for spaces>]        python scripts/<script> args -> <tag>_probe_<script>.txt
+#   ranks2[:<workload>]  bench.py as TWO ranks on the one GPU over gloo (functional check of the N > 1 path; numbers meaningless)
 #   smoke                __graft_entry__.smoke()
 set -u
 TAG=$1
@@ -78,6 +79,11 @@ for STAGE in "$@"; do
         [ -f "$PLIB" ] && [ "$PLIB" -nt "$ROOT/gorse_amd/lib/libgorse_hip.so" ] && export GORSE_HIP_LIB="$PLIB"  # never a stale one
         timeout 900 python "scripts/$A" $ARGS > "$OUT/${TAG}_probe_$(basename "$A" .py)${C:+_$C}.txt" 2>&1
         echo "probe $A exit $?"; unset GORSE_HIP_LIB; cut -c1-220 "$OUT/${TAG}_probe_$(basename "$A" .py)${C:+_$C}.txt" | tail -40 ;;
+    ranks2)  # FUNCTIONAL check of bench.py's N > 1 path on a one-GPU box: two ranks share the GPU, gloo carries the exchange
+        W=${A:-c3}
+        GORSE_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+            bench.py --gpus 2 --steps 3 --warmup 1 --topk-n 200000 --topk-steps 1 $(bench_args $W) ${BENCH_EXTRA:-} > "$OUT/${TAG}_bench_ranks2_${W}.json" 2> "$OUT/${TAG}_bench_ranks2_${W}.err"
+        echo "ranks2 $W exit $?"; tail -3 "$OUT/${TAG}_bench_ranks2_${W}.err"; python "$ROOT/scripts/bench_summary.py" "$OUT/${TAG}_bench_ranks2_${W}.json" ;;
     smoke)
         timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/${TAG}_smoke.txt" 2>&1
         echo "smoke exit $?"; tail -2 "$OUT/${TAG}_smoke.txt" ;;
