@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""GPU probe: C2 epochs (update kernel ms, epoch ms) with whatever library GORSE_HIP_LIB names -- used to compare builds of csrc/bpr.hip
+with a different number of replica rows per hot item (-DGORSE_HOT_REPLICAS=16: 0.627 ms either way, round 4)."""
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
