@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "mf_internal.hpp"
+#include <utility>
 
 using namespace gorse;
 
@@ -472,7 +473,7 @@ constexpr int ST_NEG = 1, ST_POS = 2, ST_LIVE = 4;
 // D8: nFactors = 8 (the width of model_test.go:35-48): lanes 0..7 of the group own the eight elements -- the unfused 8-lane tail of
 // the AVX512 kernels (floats_avx512.c:350-358, VecShape::unfused) -- and lanes 8..15 mirror them (the reduction needs the products
 // replicated there); only lanes 0..7 write.
-template <int NC, int ST, bool D8 = false>
+template <int NC, int ST, bool D8 = false, int G = 2, int IA = 3>
 __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float *Q, const int32_t *__restrict__ si,
                                                                  const int32_t *__restrict__ sj,
                                                                  const int32_t *__restrict__ off, int32_t U, int d,
@@ -513,35 +514,42 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         const int beg = off[u], end = off[u + 1];
         if (beg >= end) continue;
         float *pu = P + u * d;
-        // item rows are gathered TWO samples ahead of the arithmetic (a/b: this sample, a1/b1: the next, a2/b2 in
-        // flight), their indices THREE ahead and the class of an item one ahead; positions past the run's end
-        // re-read the last sample (result unused).  Nothing is used in the iteration that loads it: the counter the waits go
-        // by also counts the atomics, so a wait for a load issued after them is a wait for their acknowledgement from L2 --
-        // once per sample in the first form of this loop (s_waitcnt vmcnt(0) behind the index loads and behind hot.slot[i]).
-        float p[NC], a[NC], b[NC], a1[NC], b1[NC], a2[NC], b2[NC];
+        // item rows are gathered G samples ahead of the arithmetic (ra[0] / rb[0]: this sample, ra[k]: sample s + k, the row of sample
+        // s + G in flight), their indices IA ahead and the class of an item G ahead; positions past the run's end re-read the
+        // last sample (result unused).  Nothing is used in the iteration that loads it: the counter the waits go by also counts the
+        // atomics and returns in order, so a wait for a load issued after them is a wait for their acknowledgement from the memory
+        // side.  What a load waits behind is therefore the atomics of min(G, IA - G) iterations ago: with few groups per SIMD
+        // (C2: 6040 groups on 1024 SIMDs) that distance IS the time of an iteration.
+        static_assert(IA > G && G >= 2, "indices ahead of the rows they address");
+        static_assert(ST == 0 || G == 2, "the own-history rule of the store route looks two samples back");
+        constexpr int GB = NEG1 ? 1 : G;  // the negative's gather distance
+        float p[NC], ra[G][NC], rb[GB][NC];
         const int last = end - 1;
         auto at = [&](int s) { return s <= last ? s : last; };
         auto cl = [](int x) { return x < 0 ? 0 : x; };  // a skipped sample (i = j = -1) gathers row 0, its results are not used
         auto idx_i = [&](int i_, int j_) { return look_i ? cl(i_) : (look_j ? cl(j_) : beg); };
         auto idx_j = [&](int i_, int j_) { return look_j ? cl(j_) : (look_i ? cl(i_) : beg); };
-        int i = si[beg], j = sj[beg];
-        int i1 = si[at(beg + 1)], j1 = sj[at(beg + 1)];
-        int i2 = si[at(beg + 2)], j2 = sj[at(beg + 2)];
-        int slot = slot_of[idx_i(i, j)], slot1 = slot_of[idx_i(i1, j1)];
-        int slotj = slot_of[idx_j(i, j)], slotj1 = slot_of[idx_j(i1, j1)];
+        int ii[IA], jj[IA], sli[G], slj[G];
+#pragma unroll
+        for (int k = 0; k < IA; k++) ii[k] = si[at(beg + k)], jj[k] = sj[at(beg + k)];
+#pragma unroll
+        for (int k = 0; k < G; k++) sli[k] = slot_of[idx_i(ii[k], jj[k])], slj[k] = slot_of[idx_j(ii[k], jj[k])];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
-            a[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i) * d + 16 * c + lane);
-            b[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j) * d + 16 * c + lane);
-            a1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i1) * d + 16 * c + lane);
-            if constexpr (!NEG1) b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j1) * d + 16 * c + lane);
+#pragma unroll
+            for (int k = 0; k < G; k++) ra[k][c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(ii[k]) * d + 16 * c + lane);
+#pragma unroll
+            for (int k = 0; k < GB; k++) rb[k][c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(jj[k]) * d + 16 * c + lane);
         }
         for (int s = beg; s < end; s++) {
-            const int i3 = si[at(s + 3)], j3 = sj[at(s + 3)];
-            const int slot2 = slot_of[idx_i(i2, j2)];
-            const int slotj2 = slot_of[idx_j(i2, j2)];
-            float al[NC], bl[NC];
+            const int in_ = si[at(s + IA)], jn_ = sj[at(s + IA)];
+            const int sli_n = slot_of[idx_i(ii[G], jj[G])];
+            const int slj_n = slot_of[idx_j(ii[G], jj[G])];
+            const int i = ii[0], j = jj[0], slot = sli[0], slotj = slj[0];
+            float(&a)[NC] = ra[0];
+            float(&b)[NC] = rb[0];
+            float al[NC], bl[NC], ran[NC], rbn[NC];
             if constexpr ((ST & ST_LIVE) != 0) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
@@ -551,11 +559,8 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             }
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                a2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(i2) * d + 16 * c + lane);
-                if constexpr (NEG1)
-                    b1[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j1) * d + 16 * c + lane);
-                else
-                    b2[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(j2) * d + 16 * c + lane);
+                ran[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(ii[G]) * d + 16 * c + lane);
+                rbn[c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(jj[GB]) * d + 16 * c + lane);
             }
             const bool valid = j >= 0;  // j < 0: the sampler found no negative for this sample (bpr_sample_items_kernel)
             float *qi = Q + (int64_t)cl(i) * d, *qj = Q + (int64_t)cl(j) * d;
@@ -605,15 +610,20 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             }
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                a[c] = a1[c];
-                b[c] = b1[c];
-                a1[c] = a2[c];
-                if constexpr (!NEG1) b1[c] = b2[c];
+#pragma unroll
+                for (int k = 0; k + 1 < G; k++) ra[k][c] = ra[k + 1][c];
+                ra[G - 1][c] = ran[c];
+#pragma unroll
+                for (int k = 0; k + 1 < GB; k++) rb[k][c] = rb[k + 1][c];
+                rb[GB - 1][c] = rbn[c];
             }
             im2 = im1, jm2 = jm1, im1 = i, jm1 = j;
-            i = i1, j = j1, i1 = i2, j1 = j2, i2 = i3, j2 = j3;
-            slot = slot1, slot1 = slot2;
-            slotj = slotj1, slotj1 = slotj2;
+#pragma unroll
+            for (int k = 0; k + 1 < IA; k++) ii[k] = ii[k + 1], jj[k] = jj[k + 1];
+            ii[IA - 1] = in_, jj[IA - 1] = jn_;
+#pragma unroll
+            for (int k = 0; k + 1 < G; k++) sli[k] = sli[k + 1], slj[k] = slj[k + 1];
+            sli[G - 1] = sli_n, slj[G - 1] = slj_n;
         }
         if (writer) {
 #pragma unroll
@@ -627,6 +637,151 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+
+#ifdef GORSE_PROBE
+// ---- PROBE BUILD ONLY (make probe-lib; scripts/gpu_probe_bpr_depth.py, gpu_probe_bpr_c2_limits.py): the user-run kernel without a
+// register rotation (atomics only).  A measured dead end, kept so that the measurement can be repeated:
+// bpr_update_user_kernel keeps its gathered rows in a, a1, a2 and moves them down at the end of every iteration: the move of a2 is
+// a USE of the row loaded in that very iteration, the wait in front of it counts (in order) everything issued since -- and because
+// the atomics sit behind a lane-dependent branch the compiler has to assume they were not issued: `s_waitcnt vmcnt(0)` at the end
+// of every sample.  Here the ring is addressed by a compile-time step index (the loop is unrolled R times, no value ever moves), the
+// atomics are issued unconditionally (a sample past the run's end or without a negative adds 0.0f), the smallest wait in the loop
+// is vmcnt(18): no atomic of the last sample is ever waited for.  Result (profiles/r04_s_probe_bpr_depth.txt, _c2_limits.txt):
+// C2 0.615-0.629 ms against 0.619-0.629, d = 16 0.320 against 0.336, d = 8 0.415 against 0.436, C3 shard 11.5-12.4 against 11.1 --
+// the waits were never what the kernel is bound by.  What is (profiles/r04_s_probe_atomics3.txt): the atomic unit itself, which
+// sustains 318 G dwords/s on a 3704-row table when nothing reads it and 243 G/s when the same rows are also LOADED (as every sample
+// must); on a 30K-row table 302-317 G/s either way.
+template <int N, class F, int... K>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, K...>) {
+    (f(std::integral_constant<int, K>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int NC, bool D8, int R, int D>
+__global__ __launch_bounds__(kBlock) void bpr_update_user_ring_kernel(float *P, float *Q, const int32_t *__restrict__ si,
+                                                                      const int32_t *__restrict__ sj,
+                                                                      const int32_t *__restrict__ off, int32_t U, int d, float lr,
+                                                                      float reg, int exp_mode, double *loss, HotRows hot,
+                                                                      int folders, int neg_replicas) {
+    if ((int)blockIdx.x < folders) {
+        const int workers = (int)gridDim.x - folders;
+        const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
+        for (int pass = 0; pass < (1 << 16); pass++) {
+            fold_pass(hot, Q, d, tid, nthreads);
+            if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        return;
+    }
+    static_assert(D >= 1 && R - D >= 2, "ids D steps ahead of the rows they address, rows at least two steps ahead of their use");
+    constexpr int G = R - D;  // rows and classes are gathered G samples ahead, ids R ahead
+    const int glane = threadIdx.x & (kGroup - 1);
+    const int lane = D8 ? (glane & 7) : glane;
+    auto mad = [](float x, float y, float z) { return D8 ? x * y + z : fmaf(x, y, z); };
+    // gpw groups of a wave work (4 = all; fewer = more waves for the same runs, the other lanes idle), the launch may use smaller
+    // workgroups than kBlock
+    const int gpw = (neg_replicas >> 4) & 7, wave = threadIdx.x >> 6, giw = (threadIdx.x & 63) / kGroup;
+    const int gpb = ((int)blockDim.x >> 6) * gpw;
+    int64_t group = (int64_t)((int)blockIdx.x - folders) * gpb + wave * gpw + giw;
+    const int64_t ngroups = (int64_t)((int)gridDim.x - folders) * gpb;
+    if (giw >= gpw) group = U;  // an idle group: no run
+    const float nreg = -reg;
+    double my_loss = 0.0;
+    const bool look_i = hot.n_hot > 0;
+    const bool look_j = hot.n_hot > 0 && (neg_replicas & 1);
+#ifdef GORSE_PROBE
+    const bool no_atomics = (neg_replicas & 2) != 0;  // probe: what the kernel costs without its item updates
+#else
+    constexpr bool no_atomics = false;
+#endif
+    const int32_t *slot_of = look_i ? hot.slot : si;
+    const int64_t rep_r = (int64_t)(group & (kHotReplicas - 1)) * hot.stride_r;
+    for (int64_t u = group; u < U; u += ngroups) {
+        const int beg = off[u], end = off[u + 1];
+        if (beg >= end) continue;
+        float *pu = P + u * d;
+        const int last = end - 1;
+        auto at = [&](int s) { return s <= last ? s : last; };
+        auto cl = [](int x) { return x < 0 ? 0 : x; };
+        auto idx_i = [&](int i_) { return look_i ? cl(i_) : beg; };
+        auto idx_j = [&](int i_, int j_) { return look_j ? cl(j_) : idx_i(i_); };
+        // ring slot K holds sample beg + m with m % R == K: its item ids, the items' classes, their rows
+        float p[NC], ra[R][NC], rb[R][NC];
+        int ii[R], jj[R], sli[R], slj[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) ii[k] = si[at(beg + k)], jj[k] = sj[at(beg + k)];
+#pragma unroll
+        for (int k = 0; k < G; k++) sli[k] = slot_of[idx_i(ii[k])], slj[k] = slot_of[idx_j(ii[k], jj[k])];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                ra[k][c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(ii[k]) * d + 16 * c + lane);
+                rb[k][c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(jj[k]) * d + 16 * c + lane);
+            }
+        }
+        // nothing pending on entry: what the loop's waits count is then what the loop itself issued (a pending load of the
+        // prologue would be "a few instructions old" at the head of every iteration as far as the compiler can tell)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        for (int s0 = beg; s0 < end; s0 += R) {
+            static_for<R>([&](auto KC) {
+                constexpr int K = decltype(KC)::value, KP = (K + G) % R;
+                const int s = s0 + K;
+                const int i = ii[K], j = jj[K], slot = sli[K], slotj = slj[K];
+                const bool valid = j >= 0 && s < end;  // j < 0: the sampler found no negative (bpr_sample_items_kernel)
+                // sample s + R's ids into the slot this sample leaves; class and rows of sample s + G (its ids were loaded D steps ago)
+                ii[K] = si[at(s + R)], jj[K] = sj[at(s + R)];
+                sli[KP] = slot_of[idx_i(ii[KP])], slj[KP] = slot_of[idx_j(ii[KP], jj[KP])];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    ra[KP][c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(ii[KP]) * d + 16 * c + lane);
+                    rb[KP][c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(jj[KP]) * d + 16 * c + lane);
+                }
+                float(&a)[NC] = ra[K];
+                float(&b)[NC] = rb[K];
+                float *qi = Q + (int64_t)cl(i) * d, *qj = Q + (int64_t)cl(j) * d;
+                if (hot.n_hot > 0 && slot >= 0) qi = hot.rep + (int64_t)slot * hot.stride_s + rep_r;
+                if (look_j && slotj >= 0) qj = hot.rep + (int64_t)slotj * hot.stride_s + rep_r;
+                const float diff =
+                    D8 ? group_tree8(p[0] * a[0]) - group_tree8(p[0] * b[0]) : dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
+                const float ex = bpr_exp(-diff, exp_mode);
+                const float grad = ex / (1.0f + ex);
+                if (loss && glane == 0 && valid) my_loss += (double)log1pf(ex);
+                const float step = valid ? lr : 0.0f;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const float t1 = mad(a[c], nreg, p[c] * grad);
+                    const float t2 = mad(b[c], nreg, p[c] * (-grad));
+                    const float t3 = mad(p[c], nreg, (a[c] - b[c]) * grad);
+                    p[c] = valid ? mad(t3, lr, p[c]) : p[c];
+                    if (no_atomics) continue;
+                    if constexpr (D8) {  // lanes 0..7 carry the positive's row, their mirrors 8..15 the negative's: one instruction
+                        __hip_atomic_fetch_add((glane < 8 ? qi : qj) + lane, (glane < 8 ? t1 : t2) * step, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        __hip_atomic_fetch_add(qi + 16 * c + lane, t1 * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(qj + 16 * c + lane, t2 * step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            });
+        }
+        if (!D8 || glane < 8) {
+#pragma unroll
+            for (int c = 0; c < NC; c++)  // the only writer of this row in the launch
+                __hip_atomic_store(pu + 16 * c + lane, p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (loss && glane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
+    if (folders > 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+#endif  // GORSE_PROBE
 
 // the whole scan by ONE workgroup, tile after tile (a few thousand counters: two launches and two dependencies fewer)
 __global__ __launch_bounds__(256) void scan_small_kernel(int32_t *__restrict__ data, int64_t m) {
@@ -712,6 +867,9 @@ bool user_runs_supported(const gorse_mf *h) {
 // it costs 0.003-0.005 of NDCG for 6 % more speed
 constexpr int kDefaultStoreMode = 1;
 int g_store_mode = kDefaultStoreMode;  // ST_* bits of bpr_update_user_kernel
+int g_user_gpw = 4;                      // probe builds: groups of a wave that work in the ring kernel (4 = all)
+int g_user_block = kBlock;               // probe builds: threads per workgroup of the ring kernel
+int g_user_depth = 0;                  // probe builds: which (G, IA) pipeline of the atomics-only kernel (gorse_hip_test_set_bpr_user_depth)
 
 HotRows make_hot(const gorse_mf *h) {
     // the eight replica rows of a slot lie next to each other (r04_a: 4 KB apart or n_hot rows apart makes no difference)
@@ -735,24 +893,52 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     // quarter of the items are hot; at the 10M x 1M set one in ten thousand, and the look-up cost 4 % of the epoch)
     const int neg_rep = !(g_variant & (1 << 25)) && (int64_t)hot.n_hot * 64 >= h->I ? 1 : 0;
     dim3 grid((unsigned)blocks), block(kBlock);
+#ifdef GORSE_PROBE
+    const int64_t rblocks = std::min<int64_t>(ceil_div(h->U, g_user_block / 64 * g_user_gpw), capb * (kBlock / g_user_block)) + folders;
+    dim3 rgrid((unsigned)rblocks), rblock(g_user_block);
+#endif
     // cold items by store only where the handle found any (gorse_mf_create: n_cold) -- the atomics-only instantiation otherwise
     const int store_mode = h->n_cold > 0 ? g_store_mode : 0;
     // the library ships two forms of the kernel (atomics only; cold negatives by store); the positive-side and re-reading forms of
     // the ablation (profiles/r04_*_probe_bpr_stores_*.txt) exist in `make probe-lib` builds only
 #ifdef GORSE_PROBE
-#define PROBE_CASES(NC) case 3: LAUNCH2(NC, 3); break; case 5: LAUNCH2(NC, 5); break; case 7: LAUNCH2(NC, 7); break;
+#define PROBE_CASES(NC) case 3: LAUNCH2(NC, 3, 2, 3); break; case 5: LAUNCH2(NC, 5, 2, 3); break; case 7: LAUNCH2(NC, 7, 2, 3); break;
+#define PROBE_DEPTHS(NC)                                                                                               \
+    case 1: LAUNCH2(NC, 0, 2, 4); break;                                                                               \
+    case 2: LAUNCH2(NC, 0, 3, 5); break;                                                                               \
+    case 3: LAUNCH2(NC, 0, 3, 6); break;                                                                               \
+    case 4: LAUNCH2(NC, 0, 4, 6); break;                                                                               \
+    case 5: LAUNCH2(NC, 0, 4, 8); break;                                                                               \
+    case 6: LAUNCH2(NC, 0, 6, 9); break;                                                                               \
+    case 10: LAUNCHR(NC, 3, 1); break;                                                                                 \
+    case 11: LAUNCHR(NC, 4, 2); break;                                                                                 \
+    case 12: LAUNCHR(NC, 6, 3); break;                                                                                 \
+    case 13: LAUNCHR(NC, 8, 4); break;                                                                                 \
+    case 14: LAUNCHR(NC, 6, 2); break;
 #else
 #define PROBE_CASES(NC)
+#define PROBE_DEPTHS(NC)
 #endif
-#define LAUNCH2(NC, ST)                                                                                                \
-    bpr_update_user_kernel<(NC == 0 ? 1 : NC), ST, NC == 0><<<grid, block, 0, st>>>(                                   \
+#define LAUNCH2(NC, ST, G, IA)                                                                                         \
+    bpr_update_user_kernel<(NC == 0 ? 1 : NC), ST, NC == 0, G, IA><<<grid, block, 0, st>>>(                            \
         h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket, (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, neg_rep)
+#ifdef GORSE_PROBE
+#define LAUNCHR(NC, R, D)                                                                                              \
+    bpr_update_user_ring_kernel<(NC == 0 ? 1 : NC), NC == 0, R, D><<<rgrid, rblock, 0, st>>>(                          \
+        h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket, (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, \
+        neg_rep | ((g_variant >> 23) & 2) | (g_user_gpw << 4))
+#endif
 #define LAUNCH(NC)                                                                                                     \
     do {                                                                                                               \
         switch (store_mode) {                                                                                          \
-        case 1: LAUNCH2(NC, 1); break;                                                                                 \
+        case 1: LAUNCH2(NC, 1, 2, 3); break;                                                                           \
         PROBE_CASES(NC)                                                                                                \
-        default: LAUNCH2(NC, 0); break;                                                                                \
+        default:                                                                                                       \
+            switch (g_user_depth) {                                                                                    \
+            PROBE_DEPTHS(NC)                                                                                           \
+            default: LAUNCH2(NC, 0, 2, 3); break;                                                                      \
+            }                                                                                                          \
+            break;                                                                                                     \
         }                                                                                                              \
     } while (0)
     if (d == 8)
@@ -766,8 +952,10 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     else
         LAUNCH(8);
 #undef LAUNCH2
+#undef LAUNCHR
 #undef LAUNCH
 #undef PROBE_CASES
+#undef PROBE_DEPTHS
     GORSE_HIP_CHECK(hipGetLastError());
     if (folders > 0) {
         const int64_t fb = std::min<int64_t>(ceil_div((int64_t)hot.n_hot * d, 256), 512);
@@ -1057,6 +1245,11 @@ extern "C" int32_t gorse_mf_bpr_schedule(gorse_mf *h, int32_t *user_runs) {
     return GORSE_OK;
 }
 extern "C" void gorse_hip_test_set_variant(int32_t v) { g_variant = v; }
+extern "C" void gorse_hip_test_set_bpr_user_depth(int32_t v) {
+    g_user_depth = v & 0xff;
+    g_user_block = ((v >> 8) & 0xfff) ? ((v >> 8) & 0xfff) : kBlock;  // bits 8..19: threads per workgroup of the ring kernel (64 / 128 / 256)
+    g_user_gpw = (v >> 20) ? (v >> 20) : 4;                           // bits 20..: working groups per wave (1 / 2 / 4)
+}
 extern "C" void gorse_hip_test_set_bpr_chunk(int64_t samples) { g_chunk_override = samples; }
 extern "C" void gorse_hip_test_set_bpr_store_mode(int32_t store_mode) {
     g_store_mode = store_mode < 0 ? kDefaultStoreMode : store_mode;

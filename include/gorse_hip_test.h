@@ -109,6 +109,11 @@ void gorse_hip_test_set_bpr_chunk(int64_t samples);
  * positive item likewise, bit 2 = the store adds to a row re-read in the same iteration instead of the gathered snapshot;
  * < 0 = the library's default.  Which items are cold is fixed at gorse_mf_create (gorse_hip_test_set_bpr_cold_window). */
 void gorse_hip_test_set_bpr_store_mode(int32_t store_mode);
+/* probe builds (make probe-lib) only: which software pipeline of the atomics-only user-run kernel runs.  Bits 0..7: 0 = the shipped
+ * one, 1..6 = (rows gathered G samples ahead, ids IA ahead) = (2,4) (3,5) (3,6) (4,6) (4,8) (6,9) of the same kernel, 10..14 = the ring
+ * kernel without register rotation (ring size / id lead) = 3/1, 4/2, 6/3, 8/4, 6/2; bits 8..19: threads per workgroup of the ring
+ * kernel (0 = 256); bits 20..: how many of a wave's four 16-lane groups work (0 = 4).  Ignored by the product build. */
+void gorse_hip_test_set_bpr_user_depth(int32_t which);
 /* floats.MM (csrc/sgemm.hip): 1 = the NN / TN / TT chains on the vector ALU whatever the shape (default: on the fp32 MFMA from 64 x 64
  * results on; both are the same l-ascending fmaf chain, bit for bit).  The second hook returns the kernel time of the last
  * gorse_hip_sgemm call in milliseconds (hipEvents around the launch, copies excluded): bench.py's `mm` object. */
