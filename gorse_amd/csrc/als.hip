@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "mf_internal.hpp"
+#include <type_traits>
 
 using namespace gorse;
 
@@ -708,6 +709,8 @@ int g_als_wide_fma = 0;     // als_wide_kernel: G by fused multiply-adds (round 
 bool g_als_prof = false;    // probe: 8 counters per side in h->als_prof (gorse_hip_test_als_profile)
 int g_als_slow_gather = 0;  // als_row_kernel / als_chunk_kernel: the first form of the gather stage whatever the shape (probe: path | 64)
 int g_als_wide_probe = 0;   // timing probes of als_wide_kernel (results are garbage): path | 16 = no sweep, path | 32 = S not added
+int g_als_waves8 = 0;       // als_row_kernel in 16 x 16 tiles: 8 waves per workgroup even where 12 fit (probe: path | 256)
+int g_als_tile32 = 0;       // als_row_kernel / als_chunk_kernel: 32 x 32 MFMA tiles even where d = 16 NB takes 16 x 16 ones (probe: path | 128)
 int g_als_phased = 0;       // als_row_kernel: the waves of a workgroup accumulate together and solve together (probe: path | 4)
 constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
 constexpr int kAlsWaves = 4;        // waves per workgroup of the chunk kernels
@@ -852,6 +855,121 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
     }
 }
 
+// ---- the same accumulation in 16 x 16 tiles (d = 16 NB with the fast gather stage) -------------------------------------------------
+// A 32 x 32 diagonal tile computes both triangles of its block: 3072 multiply-adds per gathered row at d = 64 for the 2080 of the
+// strict triangle.  v_mfma_f32_16x16x4_f32 has the same rate (1024 multiply-adds in 32 cycles) on a quarter of the area: ten tiles
+// cover the upper triangle of 64 x 64 with 2560 multiply-adds per row (six of 48 x 48: 1536 against 3072; three of 32 x 32: 768
+// against 1024; one of 16 x 16: 256 against 1024).  A / B fragment: lane l holds q[entry l >> 4 of the quad][16 b + (l & 15)];
+// D: register r of lane l is element (4 (l >> 4) + r, l & 15).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAlsQuads = 4;  // feedback-entry quads per pipeline stage (16 entries, as kAlsPairs pairs)
+
+template <int NB>
+struct GramAcc16 {
+    static constexpr int NT = NB * (NB + 1) / 2;
+    f32x4 t[NT];    // upper-triangular 16x16 tiles (bi <= bj), row-major over (bi, bj)
+    float sum[NB];  // this lane's share of the column sums
+    __device__ __forceinline__ static constexpr int tile(int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
+};
+
+template <int NB>
+__device__ __forceinline__ void gram_load_stage16(const float *__restrict__ B, uint32_t rowbytes, int idx, int first, int lane,
+                                                  float (&fr)[kAlsQuads][NB]) {
+    const int slot = lane >> 4, col = lane & 15;
+    const int sel = (first + slot) * 4;  // ds_bpermute address of this lane's entry of quad 0
+#pragma unroll
+    for (int j = 0; j < kAlsQuads; j++) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 16 * j, idx);
+        const uint32_t off = __umul24(r, rowbytes) + (uint32_t)col * 4u;
+        const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
+#pragma unroll
+        for (int b = 0; b < NB; b++) fr[j][b] = row[16 * b];  // (the block's 64 bytes: the load's immediate offset)
+    }
+}
+
+// idx0 / idx1, zero_row: as gram_accumulate<NB, 1>
+template <int NB>
+__device__ __forceinline__ void gram_accumulate16(const float *__restrict__ B, const int32_t *__restrict__ fb, int n, int d, int lane,
+                                                  GramAcc16<NB> &g, int idx0, int idx1, int zero_row) {
+#pragma unroll
+    for (int t = 0; t < GramAcc16<NB>::NT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) g.t[t][r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; b++) g.sum[b] = 0.0f;
+    if (n <= 0) return;
+    const int nstages = (n + 4 * kAlsQuads - 1) / (4 * kAlsQuads);
+    constexpr int kStagesPerBatch = 64 / (4 * kAlsQuads);
+    int idx_cur = lane < n ? idx0 : zero_row;
+    int idx_nxt = 64 + lane < n ? idx1 : zero_row;
+    int loaded = 0;
+    auto issue = [&](float (&fr)[kAlsQuads][NB]) {
+        const int sb = loaded % kStagesPerBatch;
+        if (sb == 0 && loaded > 0) {
+            idx_cur = idx_nxt;
+            const int64_t nb = (int64_t)(loaded / kStagesPerBatch + 1) * 64 + lane;
+            idx_nxt = nb < n ? fb[nb] : zero_row;
+        }
+        gram_load_stage16<NB>(B, (uint32_t)d * 4u, idx_cur, sb * 4 * kAlsQuads, lane, fr);
+        loaded++;
+    };
+    // (Skipping the MFMAs of the padding -- a stage and a half of the eight of a 100-entry row -- behind a wave-uniform branch per quad
+    // or per stage cost more than it saved: the branch keeps the next stage's gathers from being issued among the MFMAs.  C5 7.28
+    // and 7.52-7.60 ms against 7.06-7.09 unguarded; profiles/r04_u_probe_als_tiles_skip.txt.)
+    auto consume = [&](const float (&fr)[kAlsQuads][NB]) {
+#pragma unroll
+        for (int j = 0; j < kAlsQuads; j++) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) asm("v_add_f32 %0, %1, %0" : "+v"(g.sum[b]) : "v"(fr[j][b]));
+#pragma unroll
+            for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+                for (int bj = bi; bj < NB; bj++)
+                    g.t[GramAcc16<NB>::tile(bi, bj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        fr[j][bi], fr[j][bj], g.t[GramAcc16<NB>::tile(bi, bj)], 0, 0, 0);
+        }
+    };
+    // ping-pong over pairs of stages; an odd last stage (already gathered into f0) is consumed behind the loop instead of being
+    // paired with sixteen zero rows (C5: 7.24-7.26 against 7.46-7.49 ms in one session, profiles/r04_u_probe_als_tiles_peel.txt)
+    float f0[kAlsQuads][NB], f1[kAlsQuads][NB];
+    issue(f0);
+    int s = 0;
+    for (; s + 2 <= nstages; s += 2) {
+        issue(f1);
+        consume(f0);
+        issue(f0);
+        consume(f1);
+    }
+    if (s < nstages) consume(f0);
+}
+
+// the callback gets the compile-time parts of the coordinates: i = ci + 4 * (lane >> 4), j = cj + (lane & 15)
+template <int NB, typename F>
+__device__ __forceinline__ void gram_foreach16(const GramAcc16<NB> &g, F &&f) {
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+        for (int bj = bi; bj < NB; bj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float v = g.t[GramAcc16<NB>::tile(bi, bj)][r];
+                f(16 * bi + r, 16 * bj, v, false);
+                if (bi != bj) f(16 * bi + r, 16 * bj, v, true);
+            }
+}
+
+// column sums: the four 16-lane rows of the wave hold the four entry slots' shares of column 16 b + (l & 15)
+template <int NB>
+__device__ __forceinline__ void gram_store_sums16(const GramAcc16<NB> &g, int lane, float *dst) {
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        float v = g.sum[b];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 16) dst[16 * b + lane] = v;
+    }
+}
+
 // visit every value of the full symmetric G held as upper-triangular tiles; C layout of the 32x32 MFMA: lane holds
 // column lane & 31, rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).  The callback gets the COMPILE-TIME parts (ci, cj)
 // of the coordinates: i = ci + 4 * (lane >> 5), j = cj + (lane & 31); `mirror` says the value is being handed over a
@@ -911,7 +1029,7 @@ template <int DMAX, bool FULL>
 struct SolveSteps<DMAX, DMAX, FULL> {
     static __device__ __forceinline__ void run(float &, int &, const float (&)[DMAX], float, float, int) {}
 };
-template <int DMAX, bool FORM, bool FULL = false>
+template <int DMAX, bool FORM, bool FULL = false, int DP = kAlsDP>  // DP: row stride of sM
 __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss,
                                               const float *__restrict__ S, int d, float one_w, float w, float reg,
                                               int lane, unsigned long long *c_load = nullptr) {
@@ -928,11 +1046,12 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     // compile-time fact for DMAX = 64
     const bool lane_in = (FULL && DMAX >= 64) || lane < d;
     const int lane_c = (FULL && DMAX >= 64) ? lane : min(lane, d - 1);
+    // packed form: this lane's row of the upper triangle starts at trow (element (k, j) at trow + j)
 #pragma unroll
     for (int i0 = 0; i0 < DMAX; i0 += 16) {  // 16 columns' worth of loads in flight at a time (register pressure)
 #pragma unroll
         for (int i = i0; i < i0 + 16; i++) {
-            float m = sM[i * kAlsDP + lane];  // sM is 64 x kAlsDP and zero past d
+            float m = sM[i * DP + (DP == kAlsDP ? lane : lane_c)];  // (DP = kAlsDP: sM is 64 x kAlsDP and zero past d)
             if (FORM) m = one_w * m + w * S[(FULL ? i : min(i, d - 1)) * d + lane_c];
             mcol[i] = ((FULL || i < d) && lane_in) ? m : 0.0f;
         }
@@ -947,7 +1066,7 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     // with the float64 recurrence 6e-7 of the row's scale on random systems (well inside the 1e-4 bar).
     if (c_load) *c_load += __builtin_amdgcn_s_memtime() + (__float_as_int(mcol[DMAX - 1]) & 0) - t_in;  // probe: columns of M in registers
     const float p0_raw = a[lane_c], sv_raw = ss[lane_c];
-    float diag = sM[lane_c * kAlsDP + lane_c];
+    float diag = sM[lane_c * DP + lane_c];
     if (FORM) diag = one_w * diag + w * S[lane_c * d + lane_c];
     const float p0 = lane_in ? p0_raw : 0.0f;
     const float sv = lane_in ? sv_raw : 0.0f;
@@ -975,8 +1094,10 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
 }
 
 // A: side being solved, B: the other side, S: d x d Gram of B over rows with feedback
-template <int NB>
-__global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void als_row_kernel(float *__restrict__ A, const float *__restrict__ B,
+// T16: NB counts 16-column blocks, d = 16 NB, the Gram is accumulated in 16 x 16 tiles (needs the zero row: zero_row >= 0)
+// WAVES: waves per workgroup (one workgroup per CU).  T16 keeps M in d x (d + 1) words per wave, so narrower factors leave room for more.
+template <int NB, bool T16 = false, int WAVES = kAlsRowWaves>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void als_row_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                                  const int64_t *__restrict__ ptr,
                                                                  const int32_t *__restrict__ idx,
                                                                  const float *__restrict__ S,
@@ -998,10 +1119,11 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
     float *sS = smem;
     for (int e = threadIdx.x; e < d * d; e += blockDim.x) sS[e] = S[e];
     __syncthreads();
-    float *sM = smem + (size_t)d * d + (size_t)wv * (64 * kAlsDP + 64);
-    float *ss = sM + 64 * kAlsDP;
+    constexpr int DP = T16 ? 16 * NB + 1 : kAlsDP, MROWS = T16 ? 16 * NB : 64;
+    float *sM = smem + (size_t)d * d + (size_t)wv * (MROWS * DP + MROWS);
+    float *ss = sM + MROWS * DP;
     const float one_w = 1 - w;
-    const int64_t wave = (int64_t)blockIdx.x * kAlsRowWaves + wv, nwaves = (int64_t)gridDim.x * kAlsRowWaves;
+    const int64_t wave = (int64_t)blockIdx.x * WAVES + wv, nwaves = (int64_t)gridDim.x * WAVES;
     // A row starts with three dependent reads (row id -> row pointer -> the first 128 indices) before its first gather can be
     // issued: ~3 memory latencies in front of ~25 us of work.  They are taken off the path: the next row's id is read at the
     // top of a row, its pointer after the accumulation, its first indices before the solve -- each is in flight while the
@@ -1029,10 +1151,12 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
             continue;
         }
         const int64_t u_next = rows[t + nwaves < n_rows ? t + nwaves : t];
-        GramAcc<NB> g;
+        std::conditional_t<T16, GramAcc16<NB>, GramAcc<NB>> g;
         unsigned long long t0 = 0;
         if (prof) t0 = __builtin_amdgcn_s_memtime();
-        if (zero_row >= 0 && d == 32 * NB)
+        if constexpr (T16)
+            gram_accumulate16<NB>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+        else if (zero_row >= 0 && d == 32 * NB)
             gram_accumulate<NB, 1>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0)
             gram_accumulate<NB, 2>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
@@ -1048,16 +1172,23 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         }
         {   // rows / columns past d are zeros of the padded gathers: stored unconditionally (sM is 64 x kAlsDP), with
             // immediate offsets from two lane-dependent bases
-            float *direct = sM + 4 * (lane >> 5) * kAlsDP + (lane & 31);
-            float *mirror = sM + (lane & 31) * kAlsDP + 4 * (lane >> 5);
-            gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
-                if (mir)
-                    mirror[cj * kAlsDP + ci] = v;
-                else
-                    direct[ci * kAlsDP + cj] = v;
-            });
+            auto put = [&](float *direct, float *mirror) {
+                return [=](int ci, int cj, float v, bool mir) {
+                    if (mir)
+                        mirror[cj * DP + ci] = v;
+                    else
+                        direct[ci * DP + cj] = v;
+                };
+            };
+            if constexpr (T16)
+                gram_foreach16<NB>(g, put(sM + 4 * (lane >> 4) * DP + (lane & 15), sM + (lane & 15) * DP + 4 * (lane >> 4)));
+            else
+                gram_foreach<NB>(g, put(sM + 4 * (lane >> 5) * kAlsDP + (lane & 31), sM + (lane & 31) * kAlsDP + 4 * (lane >> 5)));
         }
-        gram_store_sums<NB>(g, d, lane, ss);
+        if constexpr (T16)
+            gram_store_sums16<NB>(g, lane, ss);
+        else
+            gram_store_sums<NB>(g, d, lane, ss);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (prof) {
@@ -1074,7 +1205,9 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
         first_indices(beg_next, n_next, idx0_next, idx1_next);
         if (phased) __syncthreads();
         __builtin_amdgcn_s_setprio(3);
-        if (d == 32 * NB)
+        if constexpr (T16)
+            als_solve_row<16 * NB, true, true, DP>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+        else if (d == 32 * NB)
             als_solve_row<32 * NB, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         else if (NB == 1 && d == 16)  // the reference's default nFactors: straight-line too
             als_solve_row<16, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
@@ -1103,7 +1236,7 @@ __global__ __launch_bounds__(64 * kAlsRowWaves) __attribute__((amdgpu_waves_per_
 }
 
 // long rows, stage 1: one wave per chunk -> partial[c] = [G (d x d, full) | s (d)]
-template <int NB>
+template <int NB, bool T16 = false>
 __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const float *__restrict__ B,
                                                                    const int32_t *__restrict__ idx,
                                                                    const int64_t *__restrict__ chunk_beg,
@@ -1114,21 +1247,31 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
     const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
     const int64_t stride = (int64_t)d * d + d;
     for (int64_t c = wave; c < n_chunks; c += nwaves) {
-        GramAcc<NB> g;
+        std::conditional_t<T16, GramAcc16<NB>, GramAcc<NB>> g;
         const int32_t *fb = idx + chunk_beg[c];
         const int cn = chunk_cnt[c];
-        if (zero_row >= 0 && d == 32 * NB)
+        if constexpr (T16)
+            gram_accumulate16<NB>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
+        else if (zero_row >= 0 && d == 32 * NB)
             gram_accumulate<NB, 1>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         else if (zero_row >= 0)
             gram_accumulate<NB, 2>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         else
             gram_accumulate<NB, 0>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0]);
         float *dst = partial + c * stride;
-        gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
-            const int i = ci + 4 * (lane >> 5), j = cj + (lane & 31);
-            if (i < d && j < d) dst[mir ? j * d + i : i * d + j] = v;
-        });
-        gram_store_sums<NB>(g, d, lane, dst + (int64_t)d * d);
+        if constexpr (T16) {
+            gram_foreach16<NB>(g, [&](int ci, int cj, float v, bool mir) {
+                const int i = ci + 4 * (lane >> 4), j = cj + (lane & 15);
+                dst[mir ? j * d + i : i * d + j] = v;
+            });
+            gram_store_sums16<NB>(g, lane, dst + (int64_t)d * d);
+        } else {
+            gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
+                const int i = ci + 4 * (lane >> 5), j = cj + (lane & 31);
+                if (i < d && j < d) dst[mir ? j * d + i : i * d + j] = v;
+            });
+            gram_store_sums<NB>(g, d, lane, dst + (int64_t)d * d);
+        }
     }
 }
 
@@ -1264,6 +1407,28 @@ int als_zero_row(const gorse_mf *h, const float *F) {
     return (int)rows;
 }
 
+// 16 x 16 MFMA tiles: d a multiple of 16 and the fast gather stage (its zero row stands in for the entries past a row's end)
+bool als_tiles16(int d, int zrow) { return !g_als_tile32 && zrow >= 0 && d % 16 == 0 && d <= 64; }
+
+void launch_chunks(const float *B, const int32_t *idx, const int64_t *chunk_beg, const int32_t *chunk_cnt, int64_t n_chunks, int d,
+                   float *partial, const float *zeros, int zrow, unsigned grid, hipStream_t st) {
+#define CHUNK_LAUNCH(...) \
+    als_chunk_kernel<__VA_ARGS__><<<dim3(grid), dim3(64 * kAlsWaves), 0, st>>>(B, idx, chunk_beg, chunk_cnt, n_chunks, d, partial, zeros, zrow)
+    if (als_tiles16(d, zrow)) {
+        switch (d / 16) {
+        case 1: CHUNK_LAUNCH(1, true); break;
+        case 2: CHUNK_LAUNCH(2, true); break;
+        case 3: CHUNK_LAUNCH(3, true); break;
+        default: CHUNK_LAUNCH(4, true); break;
+        }
+    } else if (d <= 32) {
+        CHUNK_LAUNCH(1);
+    } else {
+        CHUNK_LAUNCH(2);
+    }
+#undef CHUNK_LAUNCH
+}
+
 int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int64_t *ptr, const int32_t *idx, float w,
                       float reg) {
     const int d = h->d;
@@ -1276,29 +1441,41 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
     }
     int tok = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
     if (pl.n_short > 0) {
-        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_short, kAlsRowWaves), 256);  // one workgroup per CU
-        if (d <= 32) {
-            GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)lds));
-            als_row_kernel<1><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased, zrow);
+#define ROW_LAUNCH(WAVES_, LDS_, ...)                                                                                  \
+    do {                                                                                                               \
+        const unsigned grid_ = (unsigned)std::min<int64_t>(ceil_div(pl.n_short, WAVES_), 256); /* one workgroup per CU */ \
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<__VA_ARGS__, WAVES_>,                         \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                 \
+        als_row_kernel<__VA_ARGS__, WAVES_><<<dim3(grid_), dim3(64 * WAVES_), (LDS_), h->stream>>>(                    \
+            A, B, ptr, idx, h->gram.p, pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), \
+            g_als_phased, zrow);                                                                                       \
+    } while (0)
+        if (als_tiles16(d, zrow)) {
+            // d x (d + 1) + d words of M and sums per wave next to S.  Twelve waves per CU where they fit and pay: d = 16 0.86 -> 0.77 ms,
+            // d = 32 1.30 -> 1.26 (C5 shard / 4); d = 48 is no faster with twelve, and d = 64 (M packed as the block rows of its upper
+            // triangle so that twelve buffers fit) was slower: 3.06 against 2.89 ms (profiles/r04_t_probe_als_tiles*.txt)
+            const int wv16 = (d <= 32 && !g_als_waves8) ? 12 : 8;
+            const size_t lds16 = ((size_t)d * d + (size_t)wv16 * ((size_t)d * (d + 1) + d)) * sizeof(float);
+            switch (d / 16 * 100 + wv16) {
+            case 108: ROW_LAUNCH(8, lds16, 1, true); break;
+            case 112: ROW_LAUNCH(12, lds16, 1, true); break;
+            case 208: ROW_LAUNCH(8, lds16, 2, true); break;
+            case 212: ROW_LAUNCH(12, lds16, 2, true); break;
+            case 308: ROW_LAUNCH(8, lds16, 3, true); break;
+            default: ROW_LAUNCH(8, lds16, 4, true); break;
+            }
+        } else if (d <= 32) {
+            ROW_LAUNCH(kAlsRowWaves, lds, 1, false);
         } else {
-            GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_row_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)lds));
-            als_row_kernel<2><<<dim3(grid), dim3(64 * kAlsRowWaves), lds, h->stream>>>(A, B, ptr, idx, h->gram.p,
-                                                                                   pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), g_als_phased, zrow);
+            ROW_LAUNCH(kAlsRowWaves, lds, 2, false);
         }
+#undef ROW_LAUNCH
         GORSE_HIP_CHECK(hipGetLastError());
     }
     if (pl.n_long > 0) {
         GORSE_TRY(h->als_partial.ensure((size_t)pl.n_chunks * ((size_t)d * d + d)));
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_chunks, kAlsWaves), 2048);
-        if (d <= 32)
-            als_chunk_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p,
-                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow);
-        else
-            als_chunk_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p,
-                                                                                   pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow);
+        launch_chunks(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow, grid, h->stream);
         GORSE_HIP_CHECK(hipGetLastError());
         als_long_solve_kernel<<<dim3((unsigned)std::min<int64_t>(pl.n_long, 1024)), dim3(256), 0, h->stream>>>(
             A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p);
@@ -1322,14 +1499,7 @@ int32_t run_gram_mfma(gorse_mf *h, const float *F, int side) {
         const int64_t stride = (int64_t)dd + d;
         GORSE_TRY(h->gram_partial.ensure((size_t)pl.n_gchunks * stride));
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_gchunks, kAlsWaves), 2048);
-        if (d <= 32)
-            als_chunk_kernel<1><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p,
-                                                                                   pl.n_gchunks, d, h->gram_partial.p,
-                                                                                   h->als_zeros.p, zrow);
-        else
-            als_chunk_kernel<2><<<dim3(grid), dim3(64 * kAlsWaves), 0, h->stream>>>(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p,
-                                                                                   pl.n_gchunks, d, h->gram_partial.p,
-                                                                                   h->als_zeros.p, zrow);
+        launch_chunks(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p, pl.n_gchunks, d, h->gram_partial.p, h->als_zeros.p, zrow, grid, h->stream);
         GORSE_HIP_CHECK(hipGetLastError());
         als_gram_reduce_kernel<<<dim3((unsigned)ceil_div(dd, 256)), dim3(256), 0, h->stream>>>(
             h->gram_partial.p, (int)pl.n_gchunks, dd, h->gram.p, stride);
@@ -1486,6 +1656,8 @@ extern "C" void gorse_hip_test_set_als_path(int32_t path) {
     g_als_wide_fma = (path & 8) != 0;
     g_als_wide_probe = (path >> 4) & 3;
     g_als_slow_gather = (path & 64) != 0;
+    g_als_tile32 = (path & 128) != 0;
+    g_als_waves8 = (path & 256) != 0;
 }
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
 extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {

@@ -40,8 +40,8 @@ def run(name, U, I, nnz, d, paths, reps=3):
                                                       int(np.diff(iptr).max()), bool(np.isfinite(gP).all() and np.isfinite(gQ).all()), gen),
               flush=True)
         del mf
-    if len(res) == 2:
-        (aP, aQ), (bP, bQ) = res.values()
+    if len(res) >= 2:
+        (aP, aQ), (bP, bQ) = list(res.values())[0], list(res.values())[-1]
         scale = max(np.abs(aP).max(), np.abs(aQ).max())
         print("%-26s paths agree to %.2e (P) %.2e (Q) of the factor scale after %d epochs"
               % (name, np.abs(aP - bP).max() / scale, np.abs(aQ - bQ).max() / scale, reps + 1), flush=True)
@@ -88,6 +88,14 @@ def main():
         prof("C5 d=64 free-running", 500_000, 100_000, 50_000_000, 64, 0)
         prof("C5 d=64 phased", 500_000, 100_000, 50_000_000, 64, 4)
         run("C5 full d=64", 500_000, 100_000, 50_000_000, 64, (0, 4), reps=3)
+        capi.lib().gorse_hip_test_set_als_path(0)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "tiles":  # round 4: 16 x 16 MFMA tiles (0; 256: at 8 waves per workgroup) against 32 x 32 (128)
+        for d in (64, 48, 32, 16):
+            run("C5 shard/4 d=%d" % d, 125_000, 100_000, 12_500_000, d, (128, 256, 0), reps=3)
+        run("C5 full d=64", 500_000, 100_000, 50_000_000, 64, (128, 0, 128, 0), reps=5)
+        prof("C5 d=64, 32x32 tiles", 500_000, 100_000, 50_000_000, 64, 128)
+        prof("C5 d=64, 16x16 tiles", 500_000, 100_000, 50_000_000, 64, 0)
         capi.lib().gorse_hip_test_set_als_path(0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "prof":
