@@ -709,6 +709,7 @@ int g_als_wide_fma = 0;     // als_wide_kernel: G by fused multiply-adds (round 
 bool g_als_prof = false;    // probe: 8 counters per side in h->als_prof (gorse_hip_test_als_profile)
 int g_als_slow_gather = 0;  // als_row_kernel / als_chunk_kernel: the first form of the gather stage whatever the shape (probe: path | 64)
 int g_als_wide_probe = 0;   // timing probes of als_wide_kernel (results are garbage): path | 16 = no sweep, path | 32 = S not added
+int g_als_nopair = 0;       // 16 x 16 tiles: every row's sweep on its own (probe: path | 512)
 int g_als_waves8 = 0;       // als_row_kernel in 16 x 16 tiles: 8 waves per workgroup even where 12 fit (probe: path | 256)
 int g_als_tile32 = 0;       // als_row_kernel / als_chunk_kernel: 32 x 32 MFMA tiles even where d = 16 NB takes 16 x 16 ones (probe: path | 128)
 int g_als_phased = 0;       // als_row_kernel: the waves of a workgroup accumulate together and solve together (probe: path | 4)
@@ -1013,30 +1014,57 @@ __device__ __forceinline__ void gram_store_sums(const GramAcc<NB> &g, int d, int
 // 29K cycles per row (profiles/r02_x_probe_als_phased.txt, which also shows that the sibling wave's MFMAs are NOT what slows
 // the solve: it takes as long when all eight waves of the workgroup solve together).
 // The d steps of the sweep, unrolled at compile time (the lane a step writes is an immediate of v_writelane_b32).
+// what a row's sweep needs once its M is formed: column `lane` of M, the running y = M p, 1 / (M_kk + reg), base_k - p_k, p_k, and where
+// the row goes
+template <int DMAX>
+struct SolveState {
+    float mcol[DMAX];
+    float y, inv, gk, p0;
+    float *a;
+    bool lane_in;
+    int steps;  // lane f: the bits of delta_f once step f has run
+};
 template <int F, int DMAX, bool FULL>
 struct SolveSteps {
-    static __device__ __forceinline__ void run(float &y, int &steps, const float (&mcol)[DMAX], float inv, float gk, int d) {
+    static __device__ __forceinline__ void run(SolveState<DMAX> &x, int d) {
         if (FULL || F < d) {  // uniform
-            const float dk = fmaf(-y, inv, gk);
+            const float dk = fmaf(-x.y, x.inv, x.gk);
             const int delta = __builtin_amdgcn_readlane(__float_as_int(dk), F);
-            y = fmaf(__int_as_float(delta), mcol[F], y);
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(steps) : "s"(delta), "n"(F));
+            x.y = fmaf(__int_as_float(delta), x.mcol[F], x.y);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(x.steps) : "s"(delta), "n"(F));
         }
-        SolveSteps<F + 1, DMAX, FULL>::run(y, steps, mcol, inv, gk, d);
+        SolveSteps<F + 1, DMAX, FULL>::run(x, d);
+    }
+    // two rows' sweeps, step by step: each chain is three dependent operations per step and every link waits ~45 cycles next to the
+    // sibling wave's MFMA stream -- two independent chains take the same slots twice as well
+    static __device__ __forceinline__ void run2(SolveState<DMAX> &x, SolveState<DMAX> &z, int d) {
+        if (FULL || F < d) {
+            const float dkx = fmaf(-x.y, x.inv, x.gk);
+            const float dkz = fmaf(-z.y, z.inv, z.gk);
+            const int dx = __builtin_amdgcn_readlane(__float_as_int(dkx), F);
+            const int dz = __builtin_amdgcn_readlane(__float_as_int(dkz), F);
+            x.y = fmaf(__int_as_float(dx), x.mcol[F], x.y);
+            z.y = fmaf(__int_as_float(dz), z.mcol[F], z.y);
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(x.steps) : "s"(dx), "n"(F));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(z.steps) : "s"(dz), "n"(F));
+        }
+        SolveSteps<F + 1, DMAX, FULL>::run2(x, z, d);
     }
 };
 template <int DMAX, bool FULL>
 struct SolveSteps<DMAX, DMAX, FULL> {
-    static __device__ __forceinline__ void run(float &, int &, const float (&)[DMAX], float, float, int) {}
+    static __device__ __forceinline__ void run(SolveState<DMAX> &, int) {}
+    static __device__ __forceinline__ void run2(SolveState<DMAX> &, SolveState<DMAX> &, int) {}
 };
+// everything in front of the chain: the columns of M into registers, the diagonal, y = M p
 template <int DMAX, bool FORM, bool FULL = false, int DP = kAlsDP>  // DP: row stride of sM
-__device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss,
-                                              const float *__restrict__ S, int d, float one_w, float w, float reg,
-                                              int lane, unsigned long long *c_load = nullptr) {
+__device__ __forceinline__ void als_solve_prepare(SolveState<DMAX> &x, float *__restrict__ a, const float *sM, const float *ss,
+                                                  const float *__restrict__ S, int d, float one_w, float w, float reg, int lane,
+                                                  unsigned long long *c_load = nullptr) {
     unsigned long long t_in = 0;
     if (c_load) t_in = __builtin_amdgcn_s_memtime();
     if (FULL) d = DMAX;
-    float mcol[DMAX];
+    float (&mcol)[DMAX] = x.mcol;
     if (FORM) {  // an opaque zero offset per call: keeps the 64 loads of S inside the row loop instead of 64 registers
         int z;   // hoisted across the whole kernel (they are LDS / L1 hits; the registers are needed by the accumulation)
         asm volatile("s_mov_b32 %0, 0" : "=s"(z));
@@ -1046,7 +1074,6 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     // compile-time fact for DMAX = 64
     const bool lane_in = (FULL && DMAX >= 64) || lane < d;
     const int lane_c = (FULL && DMAX >= 64) ? lane : min(lane, d - 1);
-    // packed form: this lane's row of the upper triangle starts at trow (element (k, j) at trow + j)
 #pragma unroll
     for (int i0 = 0; i0 < DMAX; i0 += 16) {  // 16 columns' worth of loads in flight at a time (register pressure)
 #pragma unroll
@@ -1073,24 +1100,43 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
     if (!lane_in) diag = 0.0f;
     const float inv = __builtin_amdgcn_rcpf(diag + reg);  // 1 ulp; the parity bar of ALS is 1e-4 relative
     const float base = (sv + p0 * diag) * inv;
-    float y = 0.0f;
+    // y = M p as four interleaved partial sums: one chain of DMAX dependent operations cost ~45 cycles per link next to the sibling
+    // wave's MFMA stream (a fifth of the solve, profiles/r04_u_probe_als_tiles_peel.txt)
+    float yq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int f = 0; f < DMAX; f++)
-        if (FULL || f < d) y = fmaf(mcol[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f)), y);
+        if (FULL || f < d) yq[f & 3] = fmaf(mcol[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), f)), yq[f & 3]);
+    x.y = (yq[0] + yq[1]) + (yq[2] + yq[3]);
     // Three operations on the chain per step (wide_sweep has the same form): every lane forms its own would-be step
     // delta_k = (base_k - p_k) - y_k inv_k with one fused operation, lane f's is broadcast, y += delta_f M[:, f]; the new
     // coordinate base_f - y_f inv_f is formed beside the chain.  (Four broadcasts and two more dependent operations per step
     // before: 235 cycles per step next to the sibling wave's MFMAs, profiles/r03_zi_probe_als_prof.txt.)
-    const float gk = base - p0;
+    x.inv = inv;
+    x.gk = base - p0;
+    x.p0 = p0;
+    x.a = a;
+    x.lane_in = lane_in;
     // Lane f's new coordinate is p0_f + delta_f, and delta_f is already in a scalar register (the broadcast of the chain): it is
     // written into lane f of a vector of steps (v_writelane, one instruction beside the chain) and added to p0 once after the loop.
     // (Until round 4 every step selected `lane == f ? p0 + dk : p`: hipcc kept the 64 masks in 128 scalar registers, spilled them
     // into vector registers once per row and reloaded two words per step -- the 64 v_writelane + ~130 v_readlane per row of the
     // kernel's 416 "SGPR spills".)
-    int steps = 0;
-    SolveSteps<0, DMAX, FULL>::run(y, steps, mcol, inv, gk, d);
-    const float p = p0 + __int_as_float(steps);  // p_f' = p_f + delta_f; lanes past d: 0 + 0
-    if (lane_in) a[lane] = p;
+    x.steps = 0;
+}
+template <int DMAX>
+__device__ __forceinline__ void als_solve_finish(const SolveState<DMAX> &x, int lane) {
+    const float p = x.p0 + __int_as_float(x.steps);  // p_f' = p_f + delta_f; lanes past d: 0 + 0
+    if (x.lane_in) x.a[lane] = p;
+}
+// one Gauss-Seidel sweep over the d coordinates of row `a` against M (LDS, stride DP) and s (LDS)
+template <int DMAX, bool FORM, bool FULL = false, int DP = kAlsDP>
+__device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float *sM, const float *ss,
+                                              const float *__restrict__ S, int d, float one_w, float w, float reg,
+                                              int lane, unsigned long long *c_load = nullptr) {
+    SolveState<DMAX> x;
+    als_solve_prepare<DMAX, FORM, FULL, DP>(x, a, sM, ss, S, d, one_w, w, reg, lane, c_load);
+    SolveSteps<0, DMAX, FULL>::run(x, FULL ? DMAX : d);
+    als_solve_finish<DMAX>(x, lane);
 }
 
 // A: side being solved, B: the other side, S: d x d Gram of B over rows with feedback
@@ -1143,7 +1189,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     // phased: the eight waves of the workgroup accumulate together and solve together (a barrier in between and one after): a
     // solving wave then never shares its SIMD with a wave that streams 64-cycle fp32 MFMAs.  Every wave runs the same number of
     // iterations; one without a row of its own (the tail) only keeps the barriers.
-    const int64_t t_end = phased ? (n_rows + nwaves - 1) / nwaves * nwaves : n_rows;
+    const int64_t t_end = (phased & 1) ? (n_rows + nwaves - 1) / nwaves * nwaves : n_rows;
+    SolveState<T16 ? 16 * NB : 1> held;  // (16 x 16 tiles) the first row of a pair, waiting for the second
+    bool have_held = false;
     for (int64_t t = wave; t < t_end; t += nwaves) {
         if (t >= n_rows) {
             __syncthreads();
@@ -1203,11 +1251,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         const int n_next = (int)(end_next - beg_next);
         int idx0_next, idx1_next;
         first_indices(beg_next, n_next, idx0_next, idx1_next);
-        if (phased) __syncthreads();
+        if (phased & 1) __syncthreads();
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (T16)
-            als_solve_row<16 * NB, true, true, DP>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
-        else if (d == 32 * NB)
+        if constexpr (T16) {
+            // two rows' sweeps run together: the first row of a pair is taken as far as the chain (its M in registers, the LDS
+            // buffer free for the second row's), the chains of both then advance step by step (SolveSteps::run2)
+            SolveState<16 * NB> cur;
+            als_solve_prepare<16 * NB, true, true, DP>(cur, A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+            if (have_held) {
+                SolveSteps<0, 16 * NB, true>::run2(held, cur, d);
+                als_solve_finish<16 * NB>(held, lane);
+                als_solve_finish<16 * NB>(cur, lane);
+                have_held = false;
+            } else if (!phased && t + nwaves < n_rows) {  // (phased: bit 0 = the lockstep probe, bit 1 = no pairing)
+                held = cur;
+                have_held = true;
+            } else {
+                SolveSteps<0, 16 * NB, true>::run(cur, d);
+                als_solve_finish<16 * NB>(cur, lane);
+            }
+        } else if (d == 32 * NB)
             als_solve_row<32 * NB, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
         else if (NB == 1 && d == 16)  // the reference's default nFactors: straight-line too
             als_solve_row<16, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
@@ -1220,7 +1283,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             c_rows++;
             c_ent += n;
         }
-        if (phased) __syncthreads();
+        if (phased & 1) __syncthreads();
         u = u_next, beg = beg_next, n = n_next, idx0 = idx0_next, idx1 = idx1_next;
     }
     if (prof && lane == 0) {
@@ -1448,7 +1511,7 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                 \
         als_row_kernel<__VA_ARGS__, WAVES_><<<dim3(grid_), dim3(64 * WAVES_), (LDS_), h->stream>>>(                    \
             A, B, ptr, idx, h->gram.p, pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), \
-            g_als_phased, zrow);                                                                                       \
+            g_als_phased | (g_als_nopair << 1), zrow);                                                                 \
     } while (0)
         if (als_tiles16(d, zrow)) {
             // d x (d + 1) + d words of M and sums per wave next to S.  Twelve waves per CU where they fit and pay: d = 16 0.86 -> 0.77 ms,
@@ -1658,6 +1721,7 @@ extern "C" void gorse_hip_test_set_als_path(int32_t path) {
     g_als_slow_gather = (path & 64) != 0;
     g_als_tile32 = (path & 128) != 0;
     g_als_waves8 = (path & 256) != 0;
+    g_als_nopair = (path & 512) != 0;
 }
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
 extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {

@@ -93,7 +93,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "tiles":  # round 4: 16 x 16 MFMA tiles (0; 256: at 8 waves per workgroup) against 32 x 32 (128)
         for d in (64, 48, 32, 16):
             run("C5 shard/4 d=%d" % d, 125_000, 100_000, 12_500_000, d, (128, 256, 0), reps=3)
-        run("C5 full d=64", 500_000, 100_000, 50_000_000, 64, (128, 0, 128, 0), reps=5)
+        run("C5 full d=64", 500_000, 100_000, 50_000_000, 64, (128, 512, 0, 512, 0), reps=8)  # 512: every row's sweep on its own
         prof("C5 d=64, 32x32 tiles", 500_000, 100_000, 50_000_000, 64, 128)
         prof("C5 d=64, 16x16 tiles", 500_000, 100_000, 50_000_000, 64, 0)
         capi.lib().gorse_hip_test_set_als_path(0)
