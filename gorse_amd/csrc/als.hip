@@ -709,6 +709,7 @@ int g_als_wide_fma = 0;     // als_wide_kernel: G by fused multiply-adds (round 
 bool g_als_prof = false;    // probe: 8 counters per side in h->als_prof (gorse_hip_test_als_profile)
 int g_als_slow_gather = 0;  // als_row_kernel / als_chunk_kernel: the first form of the gather stage whatever the shape (probe: path | 64)
 int g_als_wide_probe = 0;   // timing probes of als_wide_kernel (results are garbage): path | 16 = no sweep, path | 32 = S not added
+int g_als_nob3 = 0;         // no bf16 x 3 Gram: d = 32 / 64 take the fp32 16 x 16 tiles (probe: path | 1024)
 int g_als_nopair = 0;       // 16 x 16 tiles: every row's sweep on its own (probe: path | 512)
 int g_als_waves8 = 0;       // als_row_kernel in 16 x 16 tiles: 8 waves per workgroup even where 12 fit (probe: path | 256)
 int g_als_tile32 = 0;       // als_row_kernel / als_chunk_kernel: 32 x 32 MFMA tiles even where d = 16 NB takes 16 x 16 ones (probe: path | 128)
@@ -854,6 +855,110 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
         issue(f0);
         consume(f1);
     }
+}
+
+// ---- the same accumulation on the bf16 MFMA, every fp32 value split three ways (d = 32 NB with the fast gather stage) --------------
+// The fp32 MFMA runs at 1/16 of the bf16 rate.  A float is EXACTLY hi + mid + lo with hi = bf16(x), mid = bf16(x - hi),
+// lo = x - hi - mid (round to nearest even; 8 + 8 + 8 significand bits and a float's exponent range: lo IS a bf16 value;
+// tests/test_als_split_cpu.py), so x y = (hi + mid + lo)(hi' + mid' + lo'); the six products hi hi', hi mid', mid hi', hi lo', lo hi',
+// mid mid' are formed exactly by v_mfma_f32_32x32x16_bf16 and added in fp32; what is dropped (mid lo', lo mid', lo lo') is below
+// 2^-23 of |x y| (|mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|) -- an fp32 product's own rounding is 2^-24.  Six bf16 MFMAs of 16 entries (32 cycles each) per 32 x 32 tile: 36 cycles per gathered row at d = 64
+// against 80 for the fp32 tiles.  Fragment: lane l holds column (l & 31) of the EIGHT entries 8 (l >> 5) .. + 7 of a 16-entry stage
+// (the MFMA's k index), two values per register; the accumulators and their D layout are those of the fp32 32 x 32 form.
+typedef __bf16 als_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 als_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float als_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
+    const als_f32x2 v = {a, b};
+    const als_bf16x2 p = __builtin_convertvector(v, als_bf16x2);
+    return *reinterpret_cast<const uint32_t *>(&p);
+}
+constexpr int kAlsOct = 8;  // entries per lane and stage
+
+template <int NB>
+__device__ __forceinline__ void gram_load_stage_b3(const float *__restrict__ B, uint32_t rowbytes, int idx, int first, int lane,
+                                                   float (&fr)[kAlsOct][NB]) {
+    const int half = lane >> 5, col = lane & 31;
+    const int sel = (first + 8 * half) * 4;  // ds_bpermute address of this lane's first entry of the stage
+#pragma unroll
+    for (int k = 0; k < kAlsOct; k++) {
+        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 4 * k, idx);
+        const uint32_t off = __umul24(r, rowbytes) + (uint32_t)col * 4u;
+        const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
+#pragma unroll
+        for (int b = 0; b < NB; b++) fr[k][b] = row[32 * b];
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void gram_accumulate_b3(const float *__restrict__ B, const int32_t *__restrict__ fb, int n, int d, int lane,
+                                                   GramAcc<NB> &g, int idx0, int idx1, int zero_row) {
+#pragma unroll
+    for (int t = 0; t < GramAcc<NB>::NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) g.t[t][r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; b++) g.sum[b] = 0.0f;
+    if (n <= 0) return;
+    const int nstages = (n + 15) / 16;
+    constexpr int kStagesPerBatch = 4;
+    int idx_cur = lane < n ? idx0 : zero_row;
+    int idx_nxt = 64 + lane < n ? idx1 : zero_row;
+    int loaded = 0;
+    auto issue = [&](float (&fr)[kAlsOct][NB]) {
+        const int sb = loaded % kStagesPerBatch;
+        if (sb == 0 && loaded > 0) {
+            idx_cur = idx_nxt;
+            const int64_t nb = (int64_t)(loaded / kStagesPerBatch + 1) * 64 + lane;
+            idx_nxt = nb < n ? fb[nb] : zero_row;
+        }
+        gram_load_stage_b3<NB>(B, (uint32_t)d * 4u, idx_cur, sb * 16, lane, fr);
+        loaded++;
+    };
+    auto consume = [&](const float (&fr)[kAlsOct][NB]) {
+        als_bf16x8 hi[NB], mid[NB], lo[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+                const float x0 = fr[2 * k2][b], x1 = fr[2 * k2 + 1][b];
+                asm("v_add_f32 %0, %1, %0" : "+v"(g.sum[b]) : "v"(x0));
+                asm("v_add_f32 %0, %1, %0" : "+v"(g.sum[b]) : "v"(x1));
+                // v_cvt_pk_bf16_f32: both values rounded to nearest-even, first in the low half
+                ph[k2] = pack_bf16(x0, x1);
+                const float r0 = x0 - __uint_as_float(ph[k2] << 16), r1 = x1 - __uint_as_float(ph[k2] & 0xffff0000u);
+                pm[k2] = pack_bf16(r0, r1);
+                const float l0 = r0 - __uint_as_float(pm[k2] << 16), l1 = r1 - __uint_as_float(pm[k2] & 0xffff0000u);
+                pl[k2] = pack_bf16(l0, l1);
+            }
+            hi[b] = *reinterpret_cast<als_bf16x8 *>(ph);
+            mid[b] = *reinterpret_cast<als_bf16x8 *>(pm);
+            lo[b] = *reinterpret_cast<als_bf16x8 *>(pl);
+        }
+        // product after product over the tiles (consecutive MFMAs write different accumulators), the small terms first
+#pragma unroll
+        for (int pr = 0; pr < 6; pr++)
+#pragma unroll
+            for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+                for (int bj = bi; bj < NB; bj++) {
+                    f32x16 &acc = g.t[GramAcc<NB>::tile(bi, bj)];
+                    const als_bf16x8 &a = pr == 0 ? mid[bi] : (pr == 2 ? lo[bi] : (pr == 4 ? mid[bi] : hi[bi]));
+                    const als_bf16x8 &c = pr == 0 ? mid[bj] : (pr == 1 ? lo[bj] : (pr == 3 ? mid[bj] : hi[bj]));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, c, acc, 0, 0, 0);
+                }
+    };
+    float f0[kAlsOct][NB], f1[kAlsOct][NB];
+    issue(f0);
+    int s = 0;
+    for (; s + 2 <= nstages; s += 2) {
+        issue(f1);
+        consume(f0);
+        issue(f0);
+        consume(f1);
+    }
+    if (s < nstages) consume(f0);
 }
 
 // ---- the same accumulation in 16 x 16 tiles (d = 16 NB with the fast gather stage) -------------------------------------------------
@@ -1140,9 +1245,10 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
 }
 
 // A: side being solved, B: the other side, S: d x d Gram of B over rows with feedback
-// T16: NB counts 16-column blocks, d = 16 NB, the Gram is accumulated in 16 x 16 tiles (needs the zero row: zero_row >= 0)
-// WAVES: waves per workgroup (one workgroup per CU).  T16 keeps M in d x (d + 1) words per wave, so narrower factors leave room for more.
-template <int NB, bool T16 = false, int WAVES = kAlsRowWaves>
+// MODE 0: fp32 MFMA, 32 x 32 tiles, any d <= 32 NB.  MODE 1: NB counts 16-column blocks, d = 16 NB, fp32 MFMA in 16 x 16 tiles.
+// MODE 2: d = 32 NB, the bf16 MFMA on three-way split values (gram_accumulate_b3).  Modes 1 and 2 need the zero row (zero_row >= 0),
+// keep M in d x (d + 1) words per wave and pair the rows' sweeps.  WAVES: waves per workgroup (one workgroup per CU).
+template <int NB, int MODE = 0, int WAVES = kAlsRowWaves>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void als_row_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                                  const int64_t *__restrict__ ptr,
                                                                  const int32_t *__restrict__ idx,
@@ -1165,7 +1271,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     float *sS = smem;
     for (int e = threadIdx.x; e < d * d; e += blockDim.x) sS[e] = S[e];
     __syncthreads();
-    constexpr int DP = T16 ? 16 * NB + 1 : kAlsDP, MROWS = T16 ? 16 * NB : 64;
+    constexpr bool T16 = MODE == 1;
+    constexpr int DD = MODE == 1 ? 16 * NB : 32 * NB;  // modes 1, 2: d itself
+    constexpr int DP = MODE ? DD + 1 : kAlsDP, MROWS = MODE ? DD : 64;
     float *sM = smem + (size_t)d * d + (size_t)wv * (MROWS * DP + MROWS);
     float *ss = sM + MROWS * DP;
     const float one_w = 1 - w;
@@ -1190,7 +1298,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     // solving wave then never shares its SIMD with a wave that streams 64-cycle fp32 MFMAs.  Every wave runs the same number of
     // iterations; one without a row of its own (the tail) only keeps the barriers.
     const int64_t t_end = (phased & 1) ? (n_rows + nwaves - 1) / nwaves * nwaves : n_rows;
-    SolveState<T16 ? 16 * NB : 1> held;  // (16 x 16 tiles) the first row of a pair, waiting for the second
+    SolveState<MODE ? DD : 1> held;  // (modes 1, 2) the first row of a pair, waiting for the second
     bool have_held = false;
     for (int64_t t = wave; t < t_end; t += nwaves) {
         if (t >= n_rows) {
@@ -1204,6 +1312,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         if (prof) t0 = __builtin_amdgcn_s_memtime();
         if constexpr (T16)
             gram_accumulate16<NB>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+        else if constexpr (MODE == 2)
+            gram_accumulate_b3<NB>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0 && d == 32 * NB)
             gram_accumulate<NB, 1>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0)
@@ -1231,7 +1341,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             if constexpr (T16)
                 gram_foreach16<NB>(g, put(sM + 4 * (lane >> 4) * DP + (lane & 15), sM + (lane & 15) * DP + 4 * (lane >> 4)));
             else
-                gram_foreach<NB>(g, put(sM + 4 * (lane >> 5) * kAlsDP + (lane & 31), sM + (lane & 31) * kAlsDP + 4 * (lane >> 5)));
+                gram_foreach<NB>(g, put(sM + 4 * (lane >> 5) * DP + (lane & 31), sM + (lane & 31) * DP + 4 * (lane >> 5)));
         }
         if constexpr (T16)
             gram_store_sums16<NB>(g, lane, ss);
@@ -1253,22 +1363,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         first_indices(beg_next, n_next, idx0_next, idx1_next);
         if (phased & 1) __syncthreads();
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (T16) {
+        if constexpr (MODE != 0) {
             // two rows' sweeps run together: the first row of a pair is taken as far as the chain (its M in registers, the LDS
             // buffer free for the second row's), the chains of both then advance step by step (SolveSteps::run2)
-            SolveState<16 * NB> cur;
-            als_solve_prepare<16 * NB, true, true, DP>(cur, A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+            SolveState<DD> cur;
+            als_solve_prepare<DD, true, true, DP>(cur, A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
             if (have_held) {
-                SolveSteps<0, 16 * NB, true>::run2(held, cur, d);
-                als_solve_finish<16 * NB>(held, lane);
-                als_solve_finish<16 * NB>(cur, lane);
+                SolveSteps<0, DD, true>::run2(held, cur, d);
+                als_solve_finish<DD>(held, lane);
+                als_solve_finish<DD>(cur, lane);
                 have_held = false;
             } else if (!phased && t + nwaves < n_rows) {  // (phased: bit 0 = the lockstep probe, bit 1 = no pairing)
                 held = cur;
                 have_held = true;
             } else {
-                SolveSteps<0, 16 * NB, true>::run(cur, d);
-                als_solve_finish<16 * NB>(cur, lane);
+                SolveSteps<0, DD, true>::run(cur, d);
+                als_solve_finish<DD>(cur, lane);
             }
         } else if (d == 32 * NB)
             als_solve_row<32 * NB, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
@@ -1299,13 +1409,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
 }
 
 // long rows, stage 1: one wave per chunk -> partial[c] = [G (d x d, full) | s (d)]
-template <int NB, bool T16 = false>
+template <int NB, int MODE = 0>
 __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const float *__restrict__ B,
                                                                    const int32_t *__restrict__ idx,
                                                                    const int64_t *__restrict__ chunk_beg,
                                                                    const int32_t *__restrict__ chunk_cnt,
                                                                    int64_t n_chunks, int d, float *__restrict__ partial,
                                                                    const float *__restrict__ zeros, int zero_row) {
+    constexpr bool T16 = MODE == 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
     const int64_t stride = (int64_t)d * d + d;
@@ -1315,6 +1426,8 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
         const int cn = chunk_cnt[c];
         if constexpr (T16)
             gram_accumulate16<NB>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
+        else if constexpr (MODE == 2)
+            gram_accumulate_b3<NB>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         else if (zero_row >= 0 && d == 32 * NB)
             gram_accumulate<NB, 1>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         else if (zero_row >= 0)
@@ -1470,24 +1583,29 @@ int als_zero_row(const gorse_mf *h, const float *F) {
     return (int)rows;
 }
 
-// 16 x 16 MFMA tiles: d a multiple of 16 and the fast gather stage (its zero row stands in for the entries past a row's end)
-bool als_tiles16(int d, int zrow) { return !g_als_tile32 && zrow >= 0 && d % 16 == 0 && d <= 64; }
+// how the Gram of a row is accumulated (als_row_kernel / als_chunk_kernel MODE): 2 = bf16 MFMA on three-way split values (d = 32 or 64),
+// 1 = fp32 MFMA in 16 x 16 tiles (d = 16, 48), both with the fast gather stage (its zero row stands in for the entries past a row's
+// end); 0 = fp32 MFMA in 32 x 32 tiles, any d <= 64
+int als_gram_mode(int d, int zrow) {
+    if (zrow < 0 || d > 64) return 0;
+    if (!g_als_nob3 && d % 32 == 0) return 2;
+    if (!g_als_tile32 && d % 16 == 0) return 1;
+    return 0;
+}
 
 void launch_chunks(const float *B, const int32_t *idx, const int64_t *chunk_beg, const int32_t *chunk_cnt, int64_t n_chunks, int d,
                    float *partial, const float *zeros, int zrow, unsigned grid, hipStream_t st) {
 #define CHUNK_LAUNCH(...) \
     als_chunk_kernel<__VA_ARGS__><<<dim3(grid), dim3(64 * kAlsWaves), 0, st>>>(B, idx, chunk_beg, chunk_cnt, n_chunks, d, partial, zeros, zrow)
-    if (als_tiles16(d, zrow)) {
-        switch (d / 16) {
-        case 1: CHUNK_LAUNCH(1, true); break;
-        case 2: CHUNK_LAUNCH(2, true); break;
-        case 3: CHUNK_LAUNCH(3, true); break;
-        default: CHUNK_LAUNCH(4, true); break;
-        }
-    } else if (d <= 32) {
-        CHUNK_LAUNCH(1);
-    } else {
-        CHUNK_LAUNCH(2);
+    switch (als_gram_mode(d, zrow) * 10 + (als_gram_mode(d, zrow) == 1 ? d / 16 : (d <= 32 ? 1 : 2))) {
+    case 11: CHUNK_LAUNCH(1, 1); break;
+    case 12: CHUNK_LAUNCH(2, 1); break;
+    case 13: CHUNK_LAUNCH(3, 1); break;
+    case 14: CHUNK_LAUNCH(4, 1); break;
+    case 21: CHUNK_LAUNCH(1, 2); break;
+    case 22: CHUNK_LAUNCH(2, 2); break;
+    case 1: CHUNK_LAUNCH(1, 0); break;
+    default: CHUNK_LAUNCH(2, 0); break;
     }
 #undef CHUNK_LAUNCH
 }
@@ -1513,24 +1631,28 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
             A, B, ptr, idx, h->gram.p, pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), \
             g_als_phased | (g_als_nopair << 1), zrow);                                                                 \
     } while (0)
-        if (als_tiles16(d, zrow)) {
+        const int mode = als_gram_mode(d, zrow);
+        if (mode != 0) {
             // d x (d + 1) + d words of M and sums per wave next to S.  Twelve waves per CU where they fit and pay: d = 16 0.86 -> 0.77 ms,
             // d = 32 1.30 -> 1.26 (C5 shard / 4); d = 48 is no faster with twelve, and d = 64 (M packed as the block rows of its upper
             // triangle so that twelve buffers fit) was slower: 3.06 against 2.89 ms (profiles/r04_t_probe_als_tiles*.txt)
             const int wv16 = (d <= 32 && !g_als_waves8) ? 12 : 8;
             const size_t lds16 = ((size_t)d * d + (size_t)wv16 * ((size_t)d * (d + 1) + d)) * sizeof(float);
-            switch (d / 16 * 100 + wv16) {
-            case 108: ROW_LAUNCH(8, lds16, 1, true); break;
-            case 112: ROW_LAUNCH(12, lds16, 1, true); break;
-            case 208: ROW_LAUNCH(8, lds16, 2, true); break;
-            case 212: ROW_LAUNCH(12, lds16, 2, true); break;
-            case 308: ROW_LAUNCH(8, lds16, 3, true); break;
-            default: ROW_LAUNCH(8, lds16, 4, true); break;
+            switch (mode * 1000 + d / 16 * 100 + wv16) {
+            case 1108: ROW_LAUNCH(8, lds16, 1, 1); break;
+            case 1112: ROW_LAUNCH(12, lds16, 1, 1); break;
+            case 1208: ROW_LAUNCH(8, lds16, 2, 1); break;
+            case 1212: ROW_LAUNCH(12, lds16, 2, 1); break;
+            case 1308: ROW_LAUNCH(8, lds16, 3, 1); break;
+            case 1408: ROW_LAUNCH(8, lds16, 4, 1); break;
+            case 2208: ROW_LAUNCH(8, lds16, 1, 2); break;
+            case 2212: ROW_LAUNCH(12, lds16, 1, 2); break;
+            default: ROW_LAUNCH(8, lds16, 2, 2); break;  // 2408
             }
         } else if (d <= 32) {
-            ROW_LAUNCH(kAlsRowWaves, lds, 1, false);
+            ROW_LAUNCH(kAlsRowWaves, lds, 1, 0);
         } else {
-            ROW_LAUNCH(kAlsRowWaves, lds, 2, false);
+            ROW_LAUNCH(kAlsRowWaves, lds, 2, 0);
         }
 #undef ROW_LAUNCH
         GORSE_HIP_CHECK(hipGetLastError());
@@ -1722,6 +1844,7 @@ extern "C" void gorse_hip_test_set_als_path(int32_t path) {
     g_als_tile32 = (path & 128) != 0;
     g_als_waves8 = (path & 256) != 0;
     g_als_nopair = (path & 512) != 0;
+    g_als_nob3 = (path & 1024) != 0;
 }
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
 extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {

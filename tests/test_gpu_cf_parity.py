@@ -68,7 +68,7 @@ def als_half_fp64(A, B, ptr, idx, bptr, w, reg, rows):
     return A[rows]
 
 
-@pytest.mark.parametrize("d", [16, 64, 128])
+@pytest.mark.parametrize("d", [16, 32, 48, 64, 128])
 def test_als_gram_form_stays_within_twice_the_reference_recurrences_fp64_error(oracle, d, als_paths):
     """One user half-sweep, 300 rows, three answers: float64 (als_half_fp64), the oracle = the reference's own float32
     recurrence, and the device's Gram form.  The Gram form sums in a different order; the bar: its distance from the float64
@@ -92,6 +92,36 @@ def test_als_gram_form_stays_within_twice_the_reference_recurrences_fp64_error(o
     assert err_dev.max() <= 2.0 * err_ref.max() + 2e-6 and np.median(err_dev) <= 2.0 * np.median(err_ref) + 1e-6
     assert_als_close(gP[rows], exact, "device vs float64")
     assert_als_close(oP[rows], exact, "oracle vs float64")
+
+
+@pytest.mark.parametrize("d", [32, 64])
+def test_als_bf16_split_gram_is_as_close_to_float64_as_the_fp32_tiles(oracle, d, als_paths):
+    """nFactors 32 / 64 accumulate the Gram on the bf16 MFMA: every float is EXACTLY hi + mid + lo (three bf16 values: its top 16
+    bits, the top 16 bits of the remainder, the rest) and six of the nine partial products are summed in fp32 -- what is dropped is
+    below 2^-23 of a product, an fp32 multiply's own rounding being 2^-24 (csrc/als.hip gram_accumulate_b3).  Checked here against
+    the same half-sweep on the fp32 MFMA (hook 1024: 16 x 16 tiles; 1024 | 128: 32 x 32 tiles) and against float64: the three
+    device forms differ from each other by less than 2e-6 of a row's scale, and the bf16 form's distance from float64 is within
+    1.5x of the fp32 tiles' (+ 5e-7)."""
+    data = synth.synth_cf(600, 400, 30000, seed=22, min_len=3, n_neg=5)
+    w, reg = 0.05, 0.015
+    rows = np.arange(0, 600)
+    got = {}
+    for path in (0, 1024, 1024 | 128):
+        capi.lib().gorse_hip_test_set_als_path(path)
+        mf, P, Q = make_mf(data, d, std=0.1)
+        mf.als_half_epoch(0, w, reg)
+        got[path] = mf.get_factors()[0]
+        mf.close()
+    exact = als_half_fp64(P, Q, data.uptr, data.uidx, data.iptr, w, reg, rows)
+    scale = np.abs(exact).max(axis=1)
+    err = {path: np.abs(g[rows] - exact).max(axis=1) / scale for path, g in got.items()}
+    between = max((np.abs(got[0] - got[p]).max(axis=1) / scale).max() for p in (1024, 1024 | 128))
+    print("ALS d=%d half-sweep vs float64 (max error / row scale): bf16 x 3 median %.2e max %.2e; fp32 16x16 tiles median %.2e max %.2e; "
+          "fp32 32x32 tiles median %.2e max %.2e; largest difference between the forms %.2e"
+          % (d, np.median(err[0]), err[0].max(), np.median(err[1024]), err[1024].max(), np.median(err[1152]), err[1152].max(), between))
+    assert between < 2e-6
+    assert err[0].max() <= 1.5 * max(err[1024].max(), err[1152].max()) + 5e-7
+    assert np.median(err[0]) <= 1.5 * max(np.median(err[1024]), np.median(err[1152])) + 2e-7
 
 
 def rel_err(a, b):
@@ -610,8 +640,10 @@ def als_paths():
 # path 1 = the reference's residual recurrence (als_sweep_kernel), path 2 = the Gram form on the fp32 MFMA
 # (als_row_kernel / als_chunk_kernel + als_long_solve_kernel); 0 = what the product picks; 2 | 64 = the Gram form with the
 # first form of its gather stage (what matrices of >= 4 GB or >= 2^24 rows take; the default is the 32-bit-offset stage)
-@pytest.mark.parametrize("path", [0, 1, 2, 2 | 64])
-@pytest.mark.parametrize("d", [16, 64, 32, 24, 40, 7])
+# 1024 = the fp32 MFMA in 16 x 16 tiles where the default is the bf16 MFMA over three-way split values (nFactors 32, 64);
+# 1024 | 128 = fp32 32 x 32 tiles everywhere (the form of rounds 1-3)
+@pytest.mark.parametrize("path", [0, 1, 2, 2 | 64, 1024, 1024 | 128])
+@pytest.mark.parametrize("d", [16, 64, 32, 48, 24, 40, 7])
 def test_als_epoch_parity(oracle, small, d, path, als_paths):
     # ALS is deterministic w.r.t. Jobs: <= 1e-4 relative after 3 epochs
     capi.lib().gorse_hip_test_set_als_path(path)
