@@ -600,7 +600,10 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
                      "mfma_f32_tflops": mfma_achieved, "mfma_f32_frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS,
                      "mfma_macs_per_gathered_row": macs_per_row,
                      "flop_note": "secondary figure: 2 flop x gathered rows of both half-sweeps x d (d + 1) / 2 multiply-adds (strict "
-                                  "upper triangle of the Gram update) against the %.1f TFLOP/s fp32 MFMA peak" % MFMA_F32_PEAK_TFLOPS,
+                                  "upper triangle of the Gram update) against the %.1f TFLOP/s fp32 MFMA peak; at nFactors 32 / 64 each "
+                                  "multiply-add is formed as six exact bf16-MFMA partial products of three-way split floats, summed in "
+                                  "fp32 (csrc/als.hip gram_accumulate_b3) -- the figure stays in fp32 multiply-adds" % MFMA_F32_PEAK_TFLOPS,
+                     "gram_products": "bf16x3 split, fp32 accumulate" if d in (32, 64) else "fp32 MFMA",
                      "sweeps_ms_per_epoch": sweep_ms / max(steps, 1), "gram_ms_per_epoch": gram_ms / max(steps, 1)},
     }
     if world == 1 and sc == 1.0:
