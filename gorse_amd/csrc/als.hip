@@ -342,6 +342,24 @@ __device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float r
 }
 
 
+// ---- three bf16 values per float (the bf16-MFMA forms of the Gram: wide_gram_b3 below, gram_accumulate_b3 further down) -----------
+typedef __bf16 als_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 als_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float als_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
+    const als_f32x2 v = {a, b};
+    const als_bf16x2 p = __builtin_convertvector(v, als_bf16x2);
+    return *reinterpret_cast<const uint32_t *>(&p);
+}
+// x = hi + mid + lo exactly (round to nearest even each time); the three are returned as the upper halves of floats
+__device__ __forceinline__ void split_pair_bf16(float x0, float x1, uint32_t &ph, uint32_t &pm, uint32_t &pl) {
+    ph = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
+    pm = pack_bf16(r0, r1);
+    const float l0 = r0 - __uint_as_float(pm << 16), l1 = r1 - __uint_as_float(pm & 0xffff0000u);
+    pl = pack_bf16(l0, l1);
+}
+
 // ---- G of a wide row on the fp32 MFMA ---------------------------------------------------------------------------------
 // The 128 x 128 Gram matrix is 4 x 4 blocks of 32 x 32; its upper triangle is ten v_mfma_f32_32x32x2_f32 tiles, shared out
 // among the four waves of the workgroup 3 + 3 + 2 + 2 (the diagonal blocks' waves also keep the column sums of their two
@@ -450,9 +468,131 @@ __device__ __forceinline__ void wide_gram_mfma(const float *__restrict__ B, cons
     __syncthreads();  // the batches are consumed: the region is M's now
 }
 
+// ---- the same on the bf16 MFMA over three-way split values (gram_accumulate_b3 has the arithmetic) ------------------------------------
+// The split is done ONCE, by the thread that gathers: thread (column c = tid & 127, half eg = tid >> 7) gathers column c of the sixteen
+// entries 16 eg .. 16 eg + 15 of a 32-entry batch (a wave reads 256 consecutive bytes of one row per load), keeps the column's sum,
+// splits its sixteen floats and stores the three planes as bf16, entry-contiguous: plane p, column c, entries 0..31 = 64 bytes at
+// p * 10240 + c * 80 (the 80-byte column stride keeps the 16-byte stores and fragment reads of sixteen neighbouring columns on
+// different banks).  A wave's MFMA fragment -- column 32 b + col, entries 8 half .. 8 half + 7 of a 16-entry group -- is ONE 16-byte
+// read.  Two buffers of 30 KB inside M's region; six MFMAs of 32 cycles per tile and 16 entries against eight of 64 cycles.
+struct WideStageB3 {
+    float g[16];  // column c of the sixteen entries of this thread's half of the batch consumed next
+    int id;       // lane & 15: the row id of that entry of the batch AFTER it
+};
+constexpr int kWideB3Col = 80, kWideB3Plane = 128 * kWideB3Col, kWideB3Buf = 3 * kWideB3Plane;  // bytes
+__device__ __forceinline__ int wide_load_id_b3(const int32_t *__restrict__ idx, int64_t beg, int n, int e0) {
+    const int e = e0 + 16 * (threadIdx.x >> 7) + (threadIdx.x & 15);
+    return idx[beg + (e < n ? e : 0)];
+}
+__device__ __forceinline__ void wide_gather_b3(const float *__restrict__ B, int n, int e0, int d, int id, float (&g)[16]) {
+    const int c = threadIdx.x & 127, eb = e0 + 16 * (threadIdx.x >> 7);
+    const uint32_t coff = (uint32_t)(c < d ? c : 0) * 4u, rowbytes = (uint32_t)d * 4u;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        // the wave's sixteen entries: lanes 0..15 hold their ids.  Through the LDS crossbar and as a 32-bit offset from the scalar
+        // base (the form is only taken for factor matrices below 4 GB and 2^24 rows): as scalars -- v_readlane, a 64-bit multiply
+        // and add per load -- the sixteen addresses cost the kernel its scalar registers (323 spills)
+        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * j, id);
+        // RAW: an entry past the row's end / a column past d holds some other element -- masked where the batch is consumed (a
+        // select here is a use of the load, and the wait for it lands in front of the MFMAs the gather is meant to run under)
+        g[j] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + (__umul24(r, rowbytes) + coff));
+    }
+    (void)eb;
+    (void)n;
+}
+__device__ __forceinline__ void wide_first_batch_b3(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n, int d,
+                                                    WideStageB3 &st) {
+    st.id = wide_load_id_b3(idx, beg, n, 0);
+    wide_gather_b3(B, n, 0, d, st.id, st.g);
+    st.id = wide_load_id_b3(idx, beg, n, kWideMfmaBatch);
+}
+// G of item (beg, n) into this wave's tiles, the column sums into `sums` (128 floats: LDS ss, or the chunk's partial in global
+// memory); on entry st holds the item's first batch and the ids of its second, on exit those of the next item (nbeg, nn)
+template <int W>
+__device__ __forceinline__ void wide_gram_b3(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
+                                             int64_t nbeg, int nn, int d, float *sbuf, float *ss, float *__restrict__ sums,
+                                             WideStageB3 &st, f32x16 (&tl)[3]) {
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int c = tid & 127, eg = tid >> 7;
+    unsigned char *base = reinterpret_cast<unsigned char *>(sbuf);
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) tl[t][r] = 0.0f;
+    float colsum = 0.0f;
+    int idn = wide_load_id_b3(idx, nbeg, nn, 0);  // the next item's first ids: read now, used when this item's last batch is multiplied
+    auto next_item = [&]() {
+        wide_gather_b3(B, nn, 0, d, idn, st.g);
+        st.id = wide_load_id_b3(idx, nbeg, nn, kWideMfmaBatch);
+    };
+    int buf = 0;
+    for (int e0 = 0; e0 < n; e0 += kWideMfmaBatch) {
+        unsigned char *sq = base + buf * kWideB3Buf;
+        {
+            uint32_t ph[8], pm[8], pl[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int e = e0 + 16 * eg + 2 * j;
+                const float x0 = (e < n && c < d) ? st.g[2 * j] : 0.0f, x1 = (e + 1 < n && c < d) ? st.g[2 * j + 1] : 0.0f;
+                colsum += x0;
+                colsum += x1;
+                split_pair_bf16(x0, x1, ph[j], pm[j], pl[j]);
+            }
+            uint4 *dh = reinterpret_cast<uint4 *>(sq + c * kWideB3Col + 32 * eg);
+            uint4 *dm = reinterpret_cast<uint4 *>(sq + kWideB3Plane + c * kWideB3Col + 32 * eg);
+            uint4 *dl = reinterpret_cast<uint4 *>(sq + 2 * kWideB3Plane + c * kWideB3Col + 32 * eg);
+            dh[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            dh[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+            dm[0] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+            dm[1] = make_uint4(pm[4], pm[5], pm[6], pm[7]);
+            dl[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            dl[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+        }
+        __syncthreads();
+        if (e0 + kWideMfmaBatch < n) {
+            wide_gather_b3(B, n, e0 + kWideMfmaBatch, d, st.id, st.g);
+            st.id = wide_load_id_b3(idx, beg, n, e0 + 2 * kWideMfmaBatch);
+        } else {
+            next_item();
+        }
+#pragma unroll
+        for (int gq = 0; gq < 2; gq++) {
+            if (e0 + 16 * gq < n) {  // (a batch's second half past the row's end: sixteen zero rows, skipped by the whole workgroup)
+                als_bf16x8 fh[4], fm[4], fl[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    bool used = false;
+#pragma unroll
+                    for (int t = 0; t < wide_tiles(W); t++) used |= wide_tile_bi(W, t) == b || wide_tile_bj(W, t) == b;
+                    if (used) {
+                        const unsigned char *f = sq + (32 * b + col) * kWideB3Col + 32 * gq + 16 * half;
+                        fh[b] = *reinterpret_cast<const als_bf16x8 *>(f);
+                        fm[b] = *reinterpret_cast<const als_bf16x8 *>(f + kWideB3Plane);
+                        fl[b] = *reinterpret_cast<const als_bf16x8 *>(f + 2 * kWideB3Plane);
+                    }
+                }
+#pragma unroll
+                for (int pr = 0; pr < 6; pr++)
+#pragma unroll
+                    for (int t = 0; t < wide_tiles(W); t++) {
+                        const int bi = wide_tile_bi(W, t), bj = wide_tile_bj(W, t);
+                        const als_bf16x8 &a = pr == 0 ? fm[bi] : (pr == 2 ? fl[bi] : (pr == 4 ? fm[bi] : fh[bi]));
+                        const als_bf16x8 &x = pr == 0 ? fm[bj] : (pr == 1 ? fl[bj] : (pr == 3 ? fm[bj] : fh[bj]));
+                        tl[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, x, tl[t], 0, 0, 0);
+                    }
+            }
+        }
+        buf ^= 1;
+    }
+    if (n <= 0) next_item();
+    if (eg == 1) ss[c] = colsum;  // (ss is not read before the barriers that follow the Gram)
+    __syncthreads();              // the batches are consumed: the region is M's now
+    if (eg == 0) sums[c] = c < d ? colsum + ss[c] : 0.0f;
+}
+
 // this wave's tiles -> (1 - w) G in LDS (both triangles, zero past d), its column sums -> ss; wide_add_S completes M.  (With the
 // loads of S in here -- 96 of them, each its own 64-bit address -- the kernel needed 300 registers.)
-template <int W>
+template <int W, bool SUMS = true>  // SUMS = false: the column sums are already in ss (wide_gram_b3)
 __device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const float (&cs)[2], int d, float w, float *sM, float *ss) {
     const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
     const float one_w = 1 - w;
@@ -468,7 +608,7 @@ __device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const floa
             if (bi != bj) sM[j * kWideLd + i] = in ? one_w * v : 0.0f;
         }
     }
-    if (W < 2) {
+    if (SUMS && W < 2) {
 #pragma unroll
         for (int b2 = 0; b2 < 2; b2++) {
             const float other = __shfl_xor(cs[b2], 32, 64);
@@ -510,7 +650,7 @@ __device__ __forceinline__ void wide_add_S(const float (&ws)[64], float *sM, flo
 }
 
 // this wave's tiles -> the chunk's partial G (row-major 128 x 128, both triangles) and column sums in global memory
-template <int W>
+template <int W, bool SUMS = true>
 __device__ __forceinline__ void wide_partial_mfma(const f32x16 (&tl)[3], const float (&cs)[2], float *__restrict__ dst) {
     const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
 #pragma unroll
@@ -523,7 +663,7 @@ __device__ __forceinline__ void wide_partial_mfma(const f32x16 (&tl)[3], const f
             if (bi != bj) dst[j * 128 + i] = tl[t][r];
         }
     }
-    if (W < 2) {
+    if (SUMS && W < 2) {
 #pragma unroll
         for (int b2 = 0; b2 < 2; b2++) {
             const float other = __shfl_xor(cs[b2], 32, 64);
@@ -545,10 +685,23 @@ __device__ __forceinline__ void wide_item_mfma(const float *__restrict__ B, cons
         wide_form_mfma<W>(tl, cs, d, w, sM, ss);
 }
 
+template <int W, bool CHUNKS>
+__device__ __forceinline__ void wide_item_b3(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
+                                             int64_t nbeg, int nn, int d, WideStageB3 &st, float w, float *sM, float *ss,
+                                             float *__restrict__ dst) {
+    f32x16 tl[3];
+    const float cs[2] = {0.0f, 0.0f};
+    wide_gram_b3<W>(B, idx, beg, n, nbeg, nn, d, sM, ss, CHUNKS ? dst + 128 * 128 : ss, st, tl);
+    if (CHUNKS)
+        wide_partial_mfma<W, false>(tl, cs, dst);
+    else
+        wide_form_mfma<W, false>(tl, cs, d, w, sM, ss);
+}
+
 // CHUNKS = false: the rows of `rows` (n_items of them), accumulated and solved.  CHUNKS = true: the chunks of the long rows
 // (chunk_beg / chunk_cnt, n_items of them), each leaving its G and sums in `partial`.  MFMA = false: the round-2 form (G by
 // fused multiply-adds, a thread per 8 x 8 block), kept as the probe's comparison (gorse_hip_test_set_als_path(8)).
-template <bool CHUNKS, bool MFMA>
+template <bool CHUNKS, int MFMA>  // MFMA: 0 = fused multiply-adds, 1 = fp32 MFMA, 2 = bf16 MFMA over three-way split values
 __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                        const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                                                        const float *__restrict__ S, const int32_t *__restrict__ rows,
@@ -567,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A,
     float *sq = sM + 128 * kWideLd;             // 16 x 128: one batch of gathered rows
     float *ss = sq + kWideBatch * 128;          // 128 column sums
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-    if constexpr (MFMA) {
+    if constexpr (MFMA != 0) {
         auto item = [&](int64_t t, int64_t &u, int64_t &beg, int &n) {
             u = 0, beg = 0, n = 0;
             if (t >= n_items) return;
@@ -583,8 +736,11 @@ __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A,
         int64_t u, beg;
         int n;
         item(blockIdx.x, u, beg, n);
-        WideStage st;
-        wide_first_batch(B, idx, beg, n, d, st);
+        std::conditional_t<MFMA == 2, WideStageB3, WideStage> st;
+        if constexpr (MFMA == 2)
+            wide_first_batch_b3(B, idx, beg, n, d, st);
+        else
+            wide_first_batch(B, idx, beg, n, d, st);
         float ws[CHUNKS ? 1 : 64];
         if constexpr (!CHUNKS) wide_load_wS(S, d, w, ws);
         for (int64_t t = blockIdx.x; t < n_items; t += gridDim.x) {
@@ -596,11 +752,20 @@ __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A,
             const float pa = (!CHUNKS && tid < d) ? A[u * d + tid] : 0.0f;
             unsigned long long t0 = 0;
             if (prof) t0 = __builtin_amdgcn_s_memtime();
-            switch (tid >> 6) {  // wave-uniform; every branch meets the same barriers
-            case 0: wide_item_mfma<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-            case 1: wide_item_mfma<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-            case 2: wide_item_mfma<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-            default: wide_item_mfma<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+            if constexpr (MFMA == 2) {
+                switch (tid >> 6) {  // wave-uniform; every branch meets the same barriers
+                case 0: wide_item_b3<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                case 1: wide_item_b3<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                case 2: wide_item_b3<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                default: wide_item_b3<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                }
+            } else {
+                switch (tid >> 6) {
+                case 0: wide_item_mfma<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                case 1: wide_item_mfma<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                case 2: wide_item_mfma<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                default: wide_item_mfma<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                }
             }
             if (!CHUNKS) {
                 if (tid < 128) sq[256 + tid] = pa;  // (the batch region: free in this form of the kernel)
@@ -865,14 +1030,6 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
 // 2^-23 of |x y| (|mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|) -- an fp32 product's own rounding is 2^-24.  Six bf16 MFMAs of 16 entries (32 cycles each) per 32 x 32 tile: 36 cycles per gathered row at d = 64
 // against 80 for the fp32 tiles.  Fragment: lane l holds column (l & 31) of the EIGHT entries 8 (l >> 5) .. + 7 of a 16-entry stage
 // (the MFMA's k index), two values per register; the accumulators and their D layout are those of the fp32 32 x 32 form.
-typedef __bf16 als_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 als_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float als_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // {bf16(a) in bits 0..15, bf16(b) in bits 16..31}
-    const als_f32x2 v = {a, b};
-    const als_bf16x2 p = __builtin_convertvector(v, als_bf16x2);
-    return *reinterpret_cast<const uint32_t *>(&p);
-}
 constexpr int kAlsOct = 8;  // entries per lane and stage
 
 template <int NB>
@@ -1508,6 +1665,7 @@ int32_t run_gram(gorse_mf *h, const float *F, const int64_t *ptr, int64_t rows, 
     return GORSE_OK;
 }
 
+int als_zero_row(const gorse_mf *h, const float *F);
 int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, const int32_t *idx, int64_t row_begin,
                   int64_t row_end, int64_t max_row, float w, float reg) {
     const int d = h->d;
@@ -1516,11 +1674,14 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
     if (d > 64 && d <= 128 && g_als_path == 0) {
         gorse_mf::AlsPlan &pl = h->als_plan[A == h->P.p ? 0 : 1];
         const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
-        const bool mfma = !g_als_wide_fma;
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        // G by fused multiply-adds / the fp32 MFMA / the bf16 MFMA over split values (32-bit gather offsets: als_zero_row's condition)
+        const int form = g_als_wide_fma ? 0 : ((g_als_nob3 || als_zero_row(h, B) < 0) ? 1 : 2);
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         unsigned long long *wprof = nullptr;
         if (g_als_prof) {
@@ -1531,14 +1692,14 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
         }
         const int tokw = h->prof.begin(GORSE_PROF_ALS_SWEEP, h->stream);
         if (pl.n_short > 0) {
-            auto k = mfma ? als_wide_kernel<false, true> : als_wide_kernel<false, false>;
+            auto k = form == 2 ? als_wide_kernel<false, 2> : (form == 1 ? als_wide_kernel<false, 1> : als_wide_kernel<false, 0>);
             k<<<dim3((unsigned)std::min<int64_t>(pl.n_short, 512)), dim3(256), wlds, h->stream>>>(
                 A, B, ptr, idx, h->gram.p, pl.short_rows.p, nullptr, nullptr, pl.n_short, d, w, reg, nullptr, g_als_wide_probe, wprof);
             GORSE_HIP_CHECK(hipGetLastError());
         }
         if (pl.n_long > 0) {
             GORSE_TRY(h->als_partial.ensure((size_t)pl.n_chunks * kWidePartial));
-            auto k = mfma ? als_wide_kernel<true, true> : als_wide_kernel<true, false>;
+            auto k = form == 2 ? als_wide_kernel<true, 2> : (form == 1 ? als_wide_kernel<true, 1> : als_wide_kernel<true, 0>);
             k<<<dim3((unsigned)std::min<int64_t>(pl.n_chunks, 2048)), dim3(256), wlds, h->stream>>>(
                 A, B, ptr, idx, h->gram.p, nullptr, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, w, reg, h->als_partial.p, 0, nullptr);
             GORSE_HIP_CHECK(hipGetLastError());
@@ -1714,8 +1875,9 @@ int32_t run_gram_mfma_wide(gorse_mf *h, const float *F, int side) {
     } else {
         GORSE_TRY(h->gram_partial.ensure((size_t)pl.n_gchunks * kWidePartial));
         const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
-        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
-        als_wide_kernel<true, true><<<dim3((unsigned)std::min<int64_t>(pl.n_gchunks, 2048)), dim3(256), wlds, h->stream>>>(
+        auto gk = (g_als_nob3 || als_zero_row(h, F) < 0) ? als_wide_kernel<true, 1> : als_wide_kernel<true, 2>;
+        GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+        gk<<<dim3((unsigned)std::min<int64_t>(pl.n_gchunks, 2048)), dim3(256), wlds, h->stream>>>(
             nullptr, F, nullptr, pl.fb_rows.p, nullptr, nullptr, pl.g_beg.p, pl.g_cnt.p, pl.n_gchunks, d, 0.0f, 0.0f, h->gram_partial.p, 0,
             nullptr);
         GORSE_HIP_CHECK(hipGetLastError());

@@ -78,10 +78,12 @@ def prof(name, U, I, nnz, d, path=0):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "wide":  # nFactors 128: als_wide_kernel with G by fused multiply-adds (8, round 2) against the fp32 MFMA (0)
-        run("20Kx10Kx1M d=128", 20_000, 10_000, 1_000_000, 128, (8, 0), reps=2)
-        run("C5 shard/4 d=128", 125_000, 100_000, 12_500_000, 128, (8, 0), reps=2)
-        run("C5 shard/4 d=96", 125_000, 100_000, 12_500_000, 96, (8, 0), reps=2)
-        prof("C5 shard/4 d=128", 125_000, 100_000, 12_500_000, 128)
+        # 8: G by fused multiply-adds (round 2); 1024: the fp32 MFMA (round 3); 0: the bf16 MFMA over three-way split values (round 4)
+        run("20Kx10Kx1M d=128", 20_000, 10_000, 1_000_000, 128, (8, 1024, 0), reps=2)
+        run("C5 shard/4 d=128", 125_000, 100_000, 12_500_000, 128, (8, 1024, 0, 1024, 0), reps=3)
+        run("C5 shard/4 d=96", 125_000, 100_000, 12_500_000, 96, (8, 1024, 0), reps=2)
+        prof("C5 shard/4 d=128, fp32 MFMA", 125_000, 100_000, 12_500_000, 128, 1024)
+        prof("C5 shard/4 d=128, bf16 x 3", 125_000, 100_000, 12_500_000, 128)
         capi.lib().gorse_hip_test_set_als_path(0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "phased":  # accumulate / solve in lockstep per workgroup (path | 4) against free-running

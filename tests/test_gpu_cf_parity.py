@@ -661,7 +661,8 @@ def test_als_epoch_parity(oracle, small, d, path, als_paths):
     assert_als_close(gQ, eQ, "Q")
 
 
-@pytest.mark.parametrize("wide_path", [0, 8])
+# wide_path 0 = the product (G on the bf16 MFMA over three-way split values), 1024 = on the fp32 MFMA (round 3), 8 = by fused multiply-adds (round 2)
+@pytest.mark.parametrize("wide_path", [0, 8, 1024])
 @pytest.mark.parametrize("d", [65, 96, 128])
 def test_als_wide_factors(oracle, small, d, wide_path, als_paths):
     """64 < nFactors <= 128: the product's choice is the Gram form of als_wide_kernel (one workgroup per row, G on the fp32 MFMA;
