@@ -52,115 +52,109 @@ constexpr int kMmKB = 16, kMmAs = kMmKB + 1;
 
 // W = 2: a 128 x 128 tile per workgroup (2 x 2 accumulators per wave); W = 1: 64 x 64 (one accumulator per wave) for shapes that
 // would otherwise leave most of the 256 CUs without a tile.  The next block's operands are loaded into registers while the
-// current block's MFMAs run (global latency behind the matrix pipe), then stored to LDS between two barriers.
+// current block's MFMAs run (global latency behind the matrix pipe) and stored into the OTHER LDS buffer: one barrier per block.
+// The operands are PADDED by gorse_hip_sgemm: m and n are multiples of the tile edge (rows / columns past the caller's are computed
+// and never copied back), and the l range of A and B is ALLOCATED up to a multiple of 16 -- read, never multiplied: the MFMA loop
+// stops at k2.  So the kernel has no edge: a thread's PT elements of an operand block are contiguous in the operand's storage, ONE
+// address per operand and block, the elements at immediate offsets.  (With sixteen separately clamped 64-bit addresses the kernel
+// held 236 registers = two waves per SIMD, the matrix pipe 43 % busy: 61-65 TFLOP/s at 4096^3, profiles/r04_zd_pmc_SQ_mm.txt.)
 template <bool TA, bool TB, int W>
-__global__ __launch_bounds__(256) void sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ a, int lda,
-                                                         const float *__restrict__ b, int ldb, float *__restrict__ c, int ldc) {
+__global__ __launch_bounds__(256, W == 2 ? 4 : 2) void sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ a, int lda,
+                                                                         const float *__restrict__ b, int ldb, float *__restrict__ c,
+                                                                         int ldc) {
     constexpr int T = 64 * W;       // tile edge
     constexpr int PT = T * kMmKB / 256;  // elements of each operand tile per thread (8 or 4)
-    __shared__ float As[T * kMmAs];
-    __shared__ float Bs[kMmKB * T];
+    __shared__ float As[2][T * kMmAs];
+    __shared__ float Bs[2][kMmKB * T];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
     const int wi = 32 * W * (wv >> 1), wj = 32 * W * (wv & 1);  // the wave's quarter inside the tile
+    (void)m, (void)n;
+    uint32_t c_lane = ((uint32_t)(i0 + wi + 4 * (lane >> 5)) * (uint32_t)ldc + (uint32_t)(j0 + wj + (lane & 31))) * 4u;
+    auto c_off = [&](int bi, int bj, int r) {
+        return c_lane + ((uint32_t)(32 * bi + (r & 3) + 8 * (r >> 2)) * (uint32_t)ldc + (uint32_t)(32 * bj)) * 4u;
+    };
     f32x16 acc[W][W];
 #pragma unroll
     for (int bi = 0; bi < W; bi++)
 #pragma unroll
         for (int bj = 0; bj < W; bj++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int i = i0 + wi + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = j0 + wj + 32 * bj + (lane & 31);
-                acc[bi][bj][r] = (i < m && j < n) ? c[(int64_t)i * ldc + j] : 0.0f;
-            }
+            for (int r = 0; r < 16; r++)  // (C spans less than 4 GB: gorse_hip_sgemm -- one 32-bit offset per element from the scalar base)
+                acc[bi][bj][r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(c) + c_off(bi, bj, r));
     const int k2 = k & ~1;  // the l that come in pairs
-    // element e of this thread in the A tile is (ti, tl), in the B tile (ul, uj): contiguous along the operand's storage order
-    auto a_at = [&](int e, int &ti, int &tl) {
-        const int x = tid * PT + e;
-        if (TA) {  // a[l * lda + i]: contiguous in i
-            tl = x / T;
-            ti = x % T;
-        } else {   // a[i * lda + l]: contiguous in l
-            ti = x / kMmKB;
-            tl = x % kMmKB;
-        }
-    };
-    auto b_at = [&](int e, int &ul, int &uj) {
-        const int x = tid * PT + e;
-        if (TB) {  // b[j * ldb + l]: contiguous in l
-            uj = x / kMmKB;
-            ul = x % kMmKB;
-        } else {   // b[l * ldb + j]: contiguous in j
-            ul = x / T;
-            uj = x % T;
-        }
-    };
+    // the thread's first element of the A block is (ati, atl), of the B block (bul, buj); the other PT - 1 follow in storage order
+    const int xa = tid * PT;
+    const int ati = TA ? xa % T : xa / kMmKB, atl = TA ? xa / T : xa % kMmKB;
+    const int buj = TB ? xa / kMmKB : xa % T, bul = TB ? xa % kMmKB : xa / T;
+    const float *pa = TA ? a + (int64_t)atl * lda + (i0 + ati) : a + (int64_t)(i0 + ati) * lda + atl;
+    const float *pb = TB ? b + (int64_t)(j0 + buj) * ldb + bul : b + (int64_t)bul * ldb + (j0 + buj);
+    const int64_t sa = TA ? (int64_t)kMmKB * lda : kMmKB, sb = TB ? kMmKB : (int64_t)kMmKB * ldb;  // one block of l further
     float ra[PT], rb[PT];
-    auto gload = [&](int l0) {
+    auto gload = [&]() {
 #pragma unroll
-        for (int e = 0; e < PT; e++) {
-            int ti, tl, ul, uj;
-            a_at(e, ti, tl);
-            b_at(e, ul, uj);
-            const int gi = i0 + ti, gl = l0 + tl, gj = j0 + uj, hl = l0 + ul;
-            ra[e] = (gi < m && gl < k2) ? (TA ? a[(int64_t)gl * lda + gi] : a[(int64_t)gi * lda + gl]) : 0.0f;
-            rb[e] = (gj < n && hl < k2) ? (TB ? b[(int64_t)gj * ldb + hl] : b[(int64_t)hl * ldb + gj]) : 0.0f;
-        }
+        for (int e = 0; e < PT; e++) ra[e] = pa[e], rb[e] = pb[e];
+        pa += sa, pb += sb;
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {  // As[i][l] (stride kMmAs), Bs[l][j] (stride T)
 #pragma unroll
         for (int e = 0; e < PT; e++) {
-            int ti, tl, ul, uj;
-            a_at(e, ti, tl);
-            b_at(e, ul, uj);
-            As[ti * kMmAs + tl] = ra[e];
-            Bs[ul * T + uj] = rb[e];
+            const int ti = TA ? ati + e : ati, tl = TA ? atl : atl + e;
+            const int uj = TB ? buj : buj + e, ul = TB ? bul + e : bul;
+            As[buf][ti * kMmAs + tl] = ra[e];
+            Bs[buf][ul * T + uj] = rb[e];
         }
     };
     if (k2 > 0) {
-        gload(0);
-        lstore();
+        gload();
+        lstore(0);
         __syncthreads();
     }
+    int buf = 0;
     for (int l0 = 0; l0 < k2; l0 += kMmKB) {
         const bool more = l0 + kMmKB < k2;
-        if (more) gload(l0 + kMmKB);
+        if (more) gload();
         const int steps = min(kMmKB, k2 - l0);  // even
+        const float *as = As[buf], *bs = Bs[buf];
         for (int kk = 0; kk < steps; kk += 2) {
             float fa[W], fb[W];
 #pragma unroll
-            for (int bi = 0; bi < W; bi++) fa[bi] = As[(wi + 32 * bi + (lane & 31)) * kMmAs + kk + (lane >> 5)];
+            for (int bi = 0; bi < W; bi++) fa[bi] = as[(wi + 32 * bi + (lane & 31)) * kMmAs + kk + (lane >> 5)];
 #pragma unroll
-            for (int bj = 0; bj < W; bj++) fb[bj] = Bs[(kk + (lane >> 5)) * T + wj + 32 * bj + (lane & 31)];
+            for (int bj = 0; bj < W; bj++) fb[bj] = bs[(kk + (lane >> 5)) * T + wj + 32 * bj + (lane & 31)];
 #pragma unroll
             for (int bi = 0; bi < W; bi++)
 #pragma unroll
                 for (int bj = 0; bj < W; bj++) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi], fb[bj], acc[bi][bj], 0, 0, 0);
         }
+        if (more) lstore(buf ^ 1);  // (the other buffer: everybody left it before the barrier of the block before)
         __syncthreads();
-        if (more) {
-            lstore();
-            __syncthreads();
-        }
+        buf ^= 1;
     }
-    const bool odd = (k & 1) != 0;
+    // (the lane's offset goes through an opaque move: the 64 element offsets are then formed again here instead of being kept in 64
+    // registers from the loads at the top to these stores -- 162 spilled registers at four waves per SIMD)
+    asm volatile("" : "+v"(c_lane));
 #pragma unroll
     for (int bi = 0; bi < W; bi++)
 #pragma unroll
-        for (int bj = 0; bj < W; bj++) {
-            const int j = j0 + wj + 32 * bj + (lane & 31);
-            float bl = 0.0f;
-            if (odd && j < n) bl = TB ? b[(int64_t)j * ldb + (k - 1)] : b[(int64_t)(k - 1) * ldb + j];
+        for (int bj = 0; bj < W; bj++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int i = i0 + wi + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (i < m && j < n) {
-                    float v = acc[bi][bj][r];
-                    if (odd) v = fmaf(TA ? a[(int64_t)(k - 1) * lda + i] : a[(int64_t)i * lda + (k - 1)], bl, v);
-                    c[(int64_t)i * ldc + j] = v;
-                }
-            }
-        }
+            for (int r = 0; r < 16; r++)
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(c) + c_off(bi, bj, r)) = acc[bi][bj][r];
+}
+
+// an odd last l: one fmaf per element after the pairs -- never a padded zero step in the MFMA loop (it would turn an accumulated -0
+// into +0).  Its own launch: inside the tile kernel its 64 operand loads per thread cost the registers of a fourth wave per SIMD.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_last_step_kernel(int m, int n, int l, const float *__restrict__ a, int lda,
+                                                              const float *__restrict__ b, int ldb, float *__restrict__ c, int ldc) {
+    const int64_t total = (int64_t)m * n;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / n), j = (int)(t % n);
+        const float av = TA ? a[(int64_t)l * lda + i] : a[(int64_t)i * lda + l];
+        const float bv = TB ? b[(int64_t)j * ldb + l] : b[(int64_t)l * ldb + j];
+        c[(int64_t)i * ldc + j] = fmaf(av, bv, c[(int64_t)i * ldc + j]);
+    }
 }
 
 // NT: C[i][j] = floats.Dot(A row i, B row j) in AVX512 order; one 16-lane group per element.
@@ -223,22 +217,47 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);
+    bool mfma_timed = false;  // the MFMA branch records its own pair of events (around the kernel, between its re-layout copies)
     (void)hipEventRecord(ev0, st);
     if (!transA && transB) {
         int64_t blocks = std::min<int64_t>(ceil_div((int64_t)m * n, kGroupsPerBlock), 8192);
         sgemm_nt_kernel<<<dim3((unsigned)blocks), dim3(kBlock), (size_t)kGroupsPerBlock * 2 * std::max(k, 1) * 4, st>>>(
             m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
-    } else if (k > 0 && (int64_t)m * n >= 64 * 64 && !g_sgemm_valu) {  // the matrix cores (a tile is 128 x 128: below 64 x 64 the vector ALU form)
-        // 128 x 128 tiles where they give every CU work (>= 512 of them: two per CU), 64 x 64 tiles otherwise
+    } else if (k > 0 && (int64_t)m * n >= 64 * 64 && (int64_t)(m + 128) * (n + 128) * 4 < ((int64_t)1 << 32) && !g_sgemm_valu) {
+        // the matrix cores (a tile is 128 x 128: below 64 x 64 the vector ALU form; C below 4 GB: the kernel addresses it by 32-bit offsets)
+        // 128 x 128 tiles where they give every CU work (>= 512 of them: two per CU), 64 x 64 tiles otherwise.  The kernel has no edge
+        // handling: the operands are re-laid here with m and n rounded up to the tile and the l range allocated up to a multiple of
+        // 16 (zeros; the rows and columns past the caller's are computed and dropped, the l past k are read and never multiplied).
         const bool big = (int64_t)ceil_div(n, 128) * ceil_div(m, 128) >= 512;
         const int T = big ? 128 : 64;
-        dim3 grid((unsigned)ceil_div(n, T), (unsigned)ceil_div(m, T)), block(256);
+        const int mp = (int)ceil_div(m, T) * T, np = (int)ceil_div(n, T) * T, kp = (int)ceil_div(k, kMmKB) * kMmKB;
+        const int pa_rows = transA ? kp : mp, pa_cols = transA ? mp : kp, pb_rows = transB ? np : kp, pb_cols = transB ? kp : np;
+        // (operands that are whole tiles already are used where they lie)
+        const bool whole = mp == m && np == n && kp == k && (int64_t)m * ldc * 4 < ((int64_t)1 << 32);
+        DevBuf<float> pa, pb, pc;
+        const float *ka = da.p, *kb = db.p;
+        float *kc = dc.p;
+        int klda = lda, kldb = ldb, kldc = ldc;
+        if (!whole) {
+            GORSE_TRY(pa.alloc((size_t)pa_rows * pa_cols));
+            GORSE_TRY(pb.alloc((size_t)pb_rows * pb_cols));
+            GORSE_TRY(pc.alloc((size_t)mp * np));
+            GORSE_HIP_CHECK(hipMemsetAsync(pa.p, 0, (size_t)pa_rows * pa_cols * 4, st));
+            GORSE_HIP_CHECK(hipMemsetAsync(pb.p, 0, (size_t)pb_rows * pb_cols * 4, st));
+            GORSE_HIP_CHECK(hipMemsetAsync(pc.p, 0, (size_t)mp * np * 4, st));
+            GORSE_HIP_CHECK(hipMemcpy2DAsync(pa.p, (size_t)pa_cols * 4, da.p, (size_t)lda * 4, (size_t)a_cols * 4, a_rows, hipMemcpyDeviceToDevice, st));
+            GORSE_HIP_CHECK(hipMemcpy2DAsync(pb.p, (size_t)pb_cols * 4, db.p, (size_t)ldb * 4, (size_t)b_cols * 4, b_rows, hipMemcpyDeviceToDevice, st));
+            GORSE_HIP_CHECK(hipMemcpy2DAsync(pc.p, (size_t)np * 4, dc.p, (size_t)ldc * 4, (size_t)n * 4, m, hipMemcpyDeviceToDevice, st));
+            ka = pa.p, kb = pb.p, kc = pc.p, klda = pa_cols, kldb = pb_cols, kldc = np;
+        }
+        (void)hipEventRecord(ev0, st);  // (the figure of gorse_hip_test_sgemm_last_ms: the kernel alone)
+        dim3 grid((unsigned)(np / T), (unsigned)(mp / T)), block(256);
 #define MM(TA_, TB_)                                                                                                   \
     do {                                                                                                               \
         if (big)                                                                                                       \
-            sgemm_mfma_kernel<TA_, TB_, 2><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);          \
+            sgemm_mfma_kernel<TA_, TB_, 2><<<grid, block, 0, st>>>(mp, np, k, ka, klda, kb, kldb, kc, kldc);          \
         else                                                                                                           \
-            sgemm_mfma_kernel<TA_, TB_, 1><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);          \
+            sgemm_mfma_kernel<TA_, TB_, 1><<<grid, block, 0, st>>>(mp, np, k, ka, klda, kb, kldb, kc, kldc);          \
     } while (0)
         if (!transA && !transB)
             MM(false, false);
@@ -247,6 +266,20 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
         else
             MM(true, true);
 #undef MM
+        if (k & 1) {
+            const unsigned lb = (unsigned)std::min<int64_t>(ceil_div((int64_t)mp * np, 256), 4096);
+            if (!transA && !transB)
+                sgemm_last_step_kernel<false, false><<<dim3(lb), dim3(256), 0, st>>>(mp, np, k - 1, ka, klda, kb, kldb, kc, kldc);
+            else if (transA && !transB)
+                sgemm_last_step_kernel<true, false><<<dim3(lb), dim3(256), 0, st>>>(mp, np, k - 1, ka, klda, kb, kldb, kc, kldc);
+            else
+                sgemm_last_step_kernel<true, true><<<dim3(lb), dim3(256), 0, st>>>(mp, np, k - 1, ka, klda, kb, kldb, kc, kldc);
+        }
+        (void)hipEventRecord(ev1, st);
+        GORSE_HIP_CHECK(hipGetLastError());
+        if (!whole) GORSE_HIP_CHECK(hipMemcpy2DAsync(dc.p, (size_t)ldc * 4, pc.p, (size_t)np * 4, (size_t)n * 4, m, hipMemcpyDeviceToDevice, st));
+        GORSE_HIP_CHECK(hipStreamSynchronize(st));  // pa / pb / pc are released at the end of this scope
+        mfma_timed = true;
     } else if (k > 0) {
         dim3 grid((unsigned)ceil_div(n, TS), (unsigned)ceil_div(m, TS)), block(TS * TS);
         if (!transA && !transB)
@@ -257,7 +290,7 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
             sgemm_chain_kernel<true, true><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
     }
     const hipError_t launched = hipGetLastError();
-    (void)hipEventRecord(ev1, st);
+    if (!mfma_timed) (void)hipEventRecord(ev1, st);
     hipError_t rc = launched;
     if (rc == hipSuccess) rc = hipMemcpyAsync(c, dc.p, nc * 4, hipMemcpyDeviceToHost, st);
     if (rc == hipSuccess) rc = hipStreamSynchronize(st);

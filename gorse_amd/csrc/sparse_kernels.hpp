@@ -97,6 +97,7 @@ struct TileArgs {
     const uint32_t *off;
     const Posting *post;
     int32_t ngroups, logG;
+    int32_t cap_shift;    // the hashed table of a super-visit takes at most (accumulators >> cap_shift) postings (2: half full at most)
     int32_t head_groups;  // a whole-query item visits the groups [0, head_groups) one by one with directly indexed accumulators and
                           // the rest in SUPER-VISITS of several groups with hashed accumulators (see sparse_tile_kernel); = ngroups: never
     int32_t part_stride;  // partial rankings per block of part_keys / part_cnt
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         // that lives in the accumulator words.  Chunk after chunk, list after list: every row still receives its products in
         // ascending index order.  A single group with more postings than that takes the direct accumulators (apply_flattened).
         if (whole && a.head_groups < a.ngroups) {
-            const int S = nacc >> 1, cap_t = nacc >> 2;
+            const int S = nacc >> 1, cap_t = nacc >> a.cap_shift;
             lds_key *hkey = reinterpret_cast<lds_key *>(acc);
             float *hval = acc + S;
             auto seg_of = [&](int ch, int gg, int ww, Visit &x) {  // the lane's list in chunk ch: its postings in groups [gg, gg + ww)

@@ -65,6 +65,9 @@ void gorse_hip_test_set_sparse_slots(int64_t max_slots);
  * more than their even share of the stored entries; 0 = none (every group through the super-visit loop, which falls back to the
  * direct accumulators where one group alone has too many postings); a value >= the number of groups = no super-visits. */
 void gorse_hip_test_set_sparse_head(int32_t groups);
+/* probe: a hashed super-visit of the sparse list walk takes at most (accumulators >> cap_shift) postings into its table of
+ * (accumulators / 2) slots: 2 (default) = half full at most, 3 = a quarter, ...; outside 2..6 = the default. */
+void gorse_hip_test_set_sparse_table(int32_t cap_shift);
 /* rows per group of a handle created AFTERWARDS (the posting lists are cut by row group, csrc/sparse_kernels.hpp): a power of two
  * in 256 .. 16384; 0 = 2048.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);
