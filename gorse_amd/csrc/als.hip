@@ -353,6 +353,8 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {  // {bf16(a) i
 }
 // x = hi + mid + lo exactly (round to nearest even each time); the three are returned as the upper halves of floats
 __device__ __forceinline__ void split_pair_bf16(float x0, float x1, uint32_t &ph, uint32_t &pm, uint32_t &pl) {
+    // (v_dot2c_f32_bf16 with a (-1, 0) / (0, -1) operand would subtract a packed half in one instruction instead of a shift or mask and
+    // a subtraction; as hipcc emits it from __builtin_amdgcn_fdot2_f32_bf16 the results were wrong, and the epoch no faster: r04_zh)
     ph = pack_bf16(x0, x1);
     const float r0 = x0 - __uint_as_float(ph << 16), r1 = x1 - __uint_as_float(ph & 0xffff0000u);
     pm = pack_bf16(r0, r1);
@@ -1082,12 +1084,7 @@ __device__ __forceinline__ void gram_accumulate_b3(const float *__restrict__ B, 
                 const float x0 = fr[2 * k2][b], x1 = fr[2 * k2 + 1][b];
                 asm("v_add_f32 %0, %1, %0" : "+v"(g.sum[b]) : "v"(x0));
                 asm("v_add_f32 %0, %1, %0" : "+v"(g.sum[b]) : "v"(x1));
-                // v_cvt_pk_bf16_f32: both values rounded to nearest-even, first in the low half
-                ph[k2] = pack_bf16(x0, x1);
-                const float r0 = x0 - __uint_as_float(ph[k2] << 16), r1 = x1 - __uint_as_float(ph[k2] & 0xffff0000u);
-                pm[k2] = pack_bf16(r0, r1);
-                const float l0 = r0 - __uint_as_float(pm[k2] << 16), l1 = r1 - __uint_as_float(pm[k2] & 0xffff0000u);
-                pl[k2] = pack_bf16(l0, l1);
+                split_pair_bf16(x0, x1, ph[k2], pm[k2], pl[k2]);  // eleven vector instructions per pair of values
             }
             hi[b] = *reinterpret_cast<als_bf16x8 *>(ph);
             mid[b] = *reinterpret_cast<als_bf16x8 *>(pm);
