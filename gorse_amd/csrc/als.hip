@@ -1589,7 +1589,26 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
         else
             gram_accumulate<NB, 0>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0]);
         float *dst = partial + c * stride;
-        if constexpr (T16) {
+        if constexpr (MODE != 0) {
+            // d is a compile-time fact in these forms: the chunk's base + two lane offsets, every element at an immediate offset
+            // (with an address per element the kernel held 227 registers; four waves per SIMD instead of two, which 128 allow, are
+            // no faster: 0.455 against 0.413 ms per launch at C5, profiles/r04_zi_kernel_stats_als.txt -- the bound stays two)
+            constexpr int DD = MODE == 1 ? 16 * NB : 32 * NB, SH = MODE == 1 ? 4 : 5, MK = (1 << SH) - 1;
+            float *direct = dst + 4 * (lane >> SH) * DD + (lane & MK), *mirror = dst + (lane & MK) * DD + 4 * (lane >> SH);
+            auto put = [&](int ci, int cj, float v, bool mir) {
+                if (mir)
+                    mirror[cj * DD + ci] = v;
+                else
+                    direct[ci * DD + cj] = v;
+            };
+            if constexpr (T16) {
+                gram_foreach16<NB>(g, put);
+                gram_store_sums16<NB>(g, lane, dst + DD * DD);
+            } else {
+                gram_foreach<NB>(g, put);
+                gram_store_sums<NB>(g, DD, lane, dst + DD * DD);
+            }
+        } else if constexpr (T16) {
             gram_foreach16<NB>(g, [&](int ci, int cj, float v, bool mir) {
                 const int i = ci + 4 * (lane >> 4), j = cj + (lane & 15);
                 dst[mir ? j * d + i : i * d + j] = v;
