@@ -9,6 +9,8 @@
 // scheduling; sums are tree-reduced (the reference adds sequentially) => parity within 1e-4
 // relative, as BASELINE.md section 2 states.
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "mf_internal.hpp"
 #include <type_traits>
@@ -1682,6 +1684,7 @@ int32_t run_gram(gorse_mf *h, const float *F, const int64_t *ptr, int64_t rows, 
 }
 
 int als_zero_row(const gorse_mf *h, const float *F);
+bool als_split_products();
 int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, const int32_t *idx, int64_t row_begin,
                   int64_t row_end, int64_t max_row, float w, float reg) {
     const int d = h->d;
@@ -1691,7 +1694,7 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
         gorse_mf::AlsPlan &pl = h->als_plan[A == h->P.p ? 0 : 1];
         const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
         // G by fused multiply-adds / the fp32 MFMA / the bf16 MFMA over split values (32-bit gather offsets: als_zero_row's condition)
-        const int form = g_als_wide_fma ? 0 : ((g_als_nob3 || als_zero_row(h, B) < 0) ? 1 : 2);
+        const int form = g_als_wide_fma ? 0 : ((!als_split_products() || als_zero_row(h, B) < 0) ? 1 : 2);
         GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)als_wide_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
@@ -1763,9 +1766,18 @@ int als_zero_row(const gorse_mf *h, const float *F) {
 // how the Gram of a row is accumulated (als_row_kernel / als_chunk_kernel MODE): 2 = bf16 MFMA on three-way split values (d = 32 or 64),
 // 1 = fp32 MFMA in 16 x 16 tiles (d = 16, 48), both with the fast gather stage (its zero row stands in for the entries past a row's
 // end); 0 = fp32 MFMA in 32 x 32 tiles, any d <= 64
+// The environment variable GORSE_ALS_GRAM = "fp32" keeps every product of the Gram on the fp32 MFMA (read once); the default lets
+// nFactors 32 / 64 and 65..128 form them from three-way split floats on the bf16 MFMA (gram_accumulate_b3).
+bool als_split_products() {
+    static const bool fp32_only = [] {
+        const char *e = getenv("GORSE_ALS_GRAM");
+        return e && !strcmp(e, "fp32");
+    }();
+    return !fp32_only && !g_als_nob3;
+}
 int als_gram_mode(int d, int zrow) {
     if (zrow < 0 || d > 64) return 0;
-    if (!g_als_nob3 && d % 32 == 0) return 2;
+    if (als_split_products() && d % 32 == 0) return 2;
     if (!g_als_tile32 && d % 16 == 0) return 1;
     return 0;
 }
@@ -1891,7 +1903,7 @@ int32_t run_gram_mfma_wide(gorse_mf *h, const float *F, int side) {
     } else {
         GORSE_TRY(h->gram_partial.ensure((size_t)pl.n_gchunks * kWidePartial));
         const size_t wlds = ((size_t)128 * kWideLd + (size_t)kWideBatch * 128 + 128) * sizeof(float);
-        auto gk = (g_als_nob3 || als_zero_row(h, F) < 0) ? als_wide_kernel<true, 1> : als_wide_kernel<true, 2>;
+        auto gk = (!als_split_products() || als_zero_row(h, F) < 0) ? als_wide_kernel<true, 1> : als_wide_kernel<true, 2>;
         GORSE_HIP_CHECK(hipFuncSetAttribute((const void *)gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
         gk<<<dim3((unsigned)std::min<int64_t>(pl.n_gchunks, 2048)), dim3(256), wlds, h->stream>>>(
             nullptr, F, nullptr, pl.fb_rows.p, nullptr, nullptr, pl.g_beg.p, pl.g_cnt.p, pl.n_gchunks, d, 0.0f, 0.0f, h->gram_partial.p, 0,

@@ -156,7 +156,11 @@ int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u /*host*/, const i
 
 /* ---- ALS (eALS), model/cf/model.go:641-738 ------------------------------------------------
  * One call = one epoch: S = sum q q^T over items with feedback, user sweep, S = sum p p^T
- * over users with feedback, item sweep.  Needs item_indptr/item_indices. */
+ * over users with feedback, item sweep.  Needs item_indptr/item_indices.
+ * Arithmetic: fp32 in, fp32 out, every sum in fp32.  For nFactors 32, 64 and 65..128 the PRODUCTS of the per-row Gram matrices are
+ * formed on the bf16 matrix unit from an exact three-way split of each float (hi + mid + lo, all bf16): six exact partial products
+ * per pair, the three smallest (below 2^-23 of the product) dropped -- as close to a float64 evaluation as the fp32 matrix unit is
+ * (DESIGN.md section 4).  GORSE_ALS_GRAM=fp32 in the environment keeps every product on the fp32 unit (about 1.2x the epoch time). */
 int32_t gorse_als_epoch(gorse_mf *h, float weight, float reg, const volatile int32_t *cancel /*host or NULL*/);
 /* Row-sharded ALS (one process per GPU): every process holds the whole dataset and both factor
  * matrices, solves only user rows [u_begin,u_end) and item rows [i_begin,i_end) (rows are independent inside a

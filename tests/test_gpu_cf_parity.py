@@ -5,6 +5,8 @@ scores in the reference's AVX512 operation order); BPR factors under the same (s
 schedule bit-exact with the restated exp and <= 1e-4 relative with libm exp; ALS factors
 <= 1e-4 relative; Hogwild schedules: NDCG@10 within +-0.01 of the sequential oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -122,6 +124,40 @@ def test_als_bf16_split_gram_is_as_close_to_float64_as_the_fp32_tiles(oracle, d,
     assert between < 2e-6
     assert err[0].max() <= 1.5 * max(err[1024].max(), err[1152].max()) + 5e-7
     assert np.median(err[0]) <= 1.5 * max(np.median(err[1024]), np.median(err[1152])) + 2e-7
+
+
+def test_als_gram_env_switch_keeps_the_products_on_the_fp32_unit(als_paths, tmp_path):
+    """GORSE_ALS_GRAM=fp32 (read once, when the library first needs it): a child process with the variable set gets, bit for bit, what
+    this process gets with the test hook that turns the bf16 form off."""
+    import subprocess
+    import sys
+    data = synth.synth_cf(300, 200, 9000, seed=23, min_len=3, n_neg=5)
+    capi.lib().gorse_hip_test_set_als_path(1024)
+    mf, P, Q = make_mf(data, 64, std=0.1)
+    mf.als_epoch(0.05, 0.015)
+    want = np.concatenate([x.ravel() for x in mf.get_factors()])
+    mf.close()
+    capi.lib().gorse_hip_test_set_als_path(0)
+    mf, _, _ = make_mf(data, 64, std=0.1)
+    mf.als_epoch(0.05, 0.015)
+    split = np.concatenate([x.ravel() for x in mf.get_factors()])
+    mf.close()
+    assert not np.array_equal(split.view(np.uint32), want.view(np.uint32))  # (the default IS another arithmetic)
+    np.save(tmp_path / "P.npy", P)
+    np.save(tmp_path / "Q.npy", Q)
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from gorse_amd import capi, synth\n"
+        "d = synth.synth_cf(300, 200, 9000, seed=23, min_len=3, n_neg=5)\n"
+        "mf = capi.MF(d.U, d.I, 64, d.uptr, d.uidx, d.iptr, d.iidx)\n"
+        "mf.set_factors(np.load(%r), np.load(%r))\n"
+        "mf.als_epoch(0.05, 0.015)\n"
+        "np.save(%r, np.concatenate([x.ravel() for x in mf.get_factors()]))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "P.npy"), str(tmp_path / "Q.npy"), str(tmp_path / "out.npy"))
+    env = dict(os.environ, GORSE_ALS_GRAM="fp32")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=300)
+    got = np.load(tmp_path / "out.npy")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def rel_err(a, b):
