@@ -248,6 +248,9 @@ struct HotRows {
     int32_t *done;         // worker workgroups that have finished (zeroed before the launch)
     int n_hot;
     int64_t stride_s, stride_r;  // replica r of slot s starts at rep + s * stride_s + r * stride_r
+#ifdef GORSE_PROBE
+    float *warm_scratch = nullptr;  // timing probe (variant bit 23): the atomics of the items WITHOUT replicas land here instead of on Q (results garbage)
+#endif
 };
 
 // one folder pass: (slot, element) pairs strided over the folder threads
@@ -566,6 +569,10 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             float *qi = Q + (int64_t)cl(i) * d, *qj = Q + (int64_t)cl(j) * d;
             if (hot.n_hot > 0 && slot >= 0) qi = hot.rep + (int64_t)slot * hot.stride_s + rep_r;
             if (hot.n_hot > 0 && neg_replicas && slotj >= 0) qj = hot.rep + (int64_t)slotj * hot.stride_s + rep_r;
+#ifdef GORSE_PROBE
+            if (hot.warm_scratch && !(hot.n_hot > 0 && slot >= 0)) qi = hot.warm_scratch + (int64_t)cl(i) * d;
+            if (hot.warm_scratch && !(hot.n_hot > 0 && neg_replicas && slotj >= 0)) qj = hot.warm_scratch + (int64_t)cl(j) * d;
+#endif
             bool st_i = false, st_j = false;
             if constexpr ((ST & (ST_POS | ST_NEG)) != 0) {
                 const bool own_i = i == j || i == im1 || i == jm1 || i == im2 || i == jm2;
@@ -892,6 +899,13 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     // the negative's slot look-up is one more gather per sample: only where a draw has a fair chance of meeting a hot item (C2: a
     // quarter of the items are hot; at the 10M x 1M set one in ten thousand, and the look-up cost 4 % of the epoch)
     const int neg_rep = !(g_variant & (1 << 25)) && (int64_t)hot.n_hot * 64 >= h->I ? 1 : 0;
+#ifdef GORSE_PROBE
+    if (g_variant & (1 << 23)) {
+        static DevBuf<float> scratch;  // (a probe: never released)
+        if (scratch.n < (size_t)h->I * d) GORSE_TRY(scratch.alloc((size_t)h->I * d));
+        hot.warm_scratch = scratch.p;
+    }
+#endif
     dim3 grid((unsigned)blocks), block(kBlock);
 #ifdef GORSE_PROBE
     const int64_t rblocks = std::min<int64_t>(ceil_div(h->U, g_user_block / 64 * g_user_gpw), capb * (kBlock / g_user_block)) + folders;

@@ -55,6 +55,9 @@ for d in (64, 16, 128):
         run("S-ml1m, ring 3/1, %d of 4 groups of a wave working" % gpw, ml, d, 10 | (256 << 8) | (gpw << 20), 0)
         run("S-ml1m, ring 3/1, %d of 4 groups, NO item updates" % gpw, ml, d, 10 | (256 << 8) | (gpw << 20), NOATOM)
     run("S-ml1m, ring 6/3, 1 of 4 groups", ml, d, 12 | (256 << 8) | (1 << 20), 0)
+WARM_ELSEWHERE = 1 << 23
+for d in (64, 16):
+    run("S-ml1m, shipped kernel, atomics of the items without replicas onto a scratch table (TIMING ONLY)", ml, d, 0, WARM_ELSEWHERE)
 for items in (3706, 200000):
     uni = synth.synth_cf(6040, items, 994169, seed=42, zipf_s=0.0, min_len=19, n_neg=99, with_test=False)
     for gpw in (4, 1):
