@@ -879,7 +879,6 @@ bool g_als_prof = false;    // probe: 8 counters per side in h->als_prof (gorse_
 int g_als_slow_gather = 0;  // als_row_kernel / als_chunk_kernel: the first form of the gather stage whatever the shape (probe: path | 64)
 int g_als_wide_probe = 0;   // timing probes of als_wide_kernel (results are garbage): path | 16 = no sweep, path | 32 = S not added
 int g_als_nob3 = 0;         // no bf16 x 3 Gram: d = 32 / 64 take the fp32 16 x 16 tiles (probe: path | 1024)
-int g_als_nopair = 0;       // 16 x 16 tiles: every row's sweep on its own (probe: path | 512)
 int g_als_waves8 = 0;       // als_row_kernel in 16 x 16 tiles: 8 waves per workgroup even where 12 fit (probe: path | 256)
 int g_als_tile32 = 0;       // als_row_kernel / als_chunk_kernel: 32 x 32 MFMA tiles even where d = 16 NB takes 16 x 16 ones (probe: path | 128)
 int g_als_phased = 0;       // als_row_kernel: the waves of a workgroup accumulate together and solve together (probe: path | 4)
@@ -1051,7 +1050,7 @@ __device__ __forceinline__ void gram_load_stage_b3(const float *__restrict__ B, 
     }
 }
 
-template <int NB>
+template <int NB, bool DEEP = true>  // DEEP: four gather stages in the ring (long runs of stages: the chunk kernel), else two
 __device__ __forceinline__ void gram_accumulate_b3(const float *__restrict__ B, const int32_t *__restrict__ fb, int n, int d, int lane,
                                                    GramAcc<NB> &g, int idx0, int idx1, int zero_row) {
 #pragma unroll
@@ -1105,6 +1104,32 @@ __device__ __forceinline__ void gram_accumulate_b3(const float *__restrict__ B, 
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, c, acc, 0, 0, 0);
                 }
     };
+    // DEEP: three stages in flight, a fourth being consumed (a ring of four buffers, unrolled: nothing moves) -- for the chunk kernel,
+    // whose wave walks 256 stages on end: the S Gram 0.27 -> 0.22 ms and the long rows' share of the sweeps with it (C5 6.1 -> 5.8 ms,
+    // profiles/r04_zo_probe_als_tiles.txt).  The row kernel keeps two: a 100-entry row is seven stages, the ring's prologue and the
+    // three stages issued past the row's end (they gather the zero row) cost what the depth saves, and its registers are full (5.80-5.90
+    // against 5.77-5.78 ms in the same session).
+    if constexpr (DEEP) {
+        float f0[kAlsOct][NB], f1[kAlsOct][NB], f2[kAlsOct][NB], f3[kAlsOct][NB];
+        issue(f0);
+        issue(f1);
+        issue(f2);
+        int s = 0;
+        for (; s + 4 <= nstages; s += 4) {
+            issue(f3);
+            consume(f0);
+            issue(f0);
+            consume(f1);
+            issue(f1);
+            consume(f2);
+            issue(f2);
+            consume(f3);
+        }
+        if (s < nstages) consume(f0);
+        if (s + 1 < nstages) consume(f1);
+        if (s + 2 < nstages) consume(f2);
+        return;
+    } else {
     float f0[kAlsOct][NB], f1[kAlsOct][NB];
     issue(f0);
     int s = 0;
@@ -1115,6 +1140,7 @@ __device__ __forceinline__ void gram_accumulate_b3(const float *__restrict__ B, 
         consume(f1);
     }
     if (s < nstages) consume(f0);
+    }
 }
 
 // ---- the same accumulation in 16 x 16 tiles (d = 16 NB with the fast gather stage) -------------------------------------------------
@@ -1149,8 +1175,8 @@ __device__ __forceinline__ void gram_load_stage16(const float *__restrict__ B, u
     }
 }
 
-// idx0 / idx1, zero_row: as gram_accumulate<NB, 1>
-template <int NB>
+// idx0 / idx1, zero_row: as gram_accumulate<NB, 1>; DEEP: as gram_accumulate_b3
+template <int NB, bool DEEP = false>
 __device__ __forceinline__ void gram_accumulate16(const float *__restrict__ B, const int32_t *__restrict__ fb, int n, int d, int lane,
                                                   GramAcc16<NB> &g, int idx0, int idx1, int zero_row) {
 #pragma unroll
@@ -1193,16 +1219,37 @@ __device__ __forceinline__ void gram_accumulate16(const float *__restrict__ B, c
     };
     // ping-pong over pairs of stages; an odd last stage (already gathered into f0) is consumed behind the loop instead of being
     // paired with sixteen zero rows (C5: 7.24-7.26 against 7.46-7.49 ms in one session, profiles/r04_u_probe_als_tiles_peel.txt)
-    float f0[kAlsQuads][NB], f1[kAlsQuads][NB];
-    issue(f0);
-    int s = 0;
-    for (; s + 2 <= nstages; s += 2) {
-        issue(f1);
-        consume(f0);
+    if constexpr (DEEP) {
+        float f0[kAlsQuads][NB], f1[kAlsQuads][NB], f2[kAlsQuads][NB], f3[kAlsQuads][NB];
         issue(f0);
-        consume(f1);
+        issue(f1);
+        issue(f2);
+        int s = 0;
+        for (; s + 4 <= nstages; s += 4) {
+            issue(f3);
+            consume(f0);
+            issue(f0);
+            consume(f1);
+            issue(f1);
+            consume(f2);
+            issue(f2);
+            consume(f3);
+        }
+        if (s < nstages) consume(f0);
+        if (s + 1 < nstages) consume(f1);
+        if (s + 2 < nstages) consume(f2);
+    } else {
+        float f0[kAlsQuads][NB], f1[kAlsQuads][NB];
+        issue(f0);
+        int s = 0;
+        for (; s + 2 <= nstages; s += 2) {
+            issue(f1);
+            consume(f0);
+            issue(f0);
+            consume(f1);
+        }
+        if (s < nstages) consume(f0);
     }
-    if (s < nstages) consume(f0);
 }
 
 // the callback gets the compile-time parts of the coordinates: i = ci + 4 * (lane >> 4), j = cj + (lane & 15)
@@ -1453,7 +1500,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     // phased: the eight waves of the workgroup accumulate together and solve together (a barrier in between and one after): a
     // solving wave then never shares its SIMD with a wave that streams 64-cycle fp32 MFMAs.  Every wave runs the same number of
     // iterations; one without a row of its own (the tail) only keeps the barriers.
-    const int64_t t_end = (phased & 1) ? (n_rows + nwaves - 1) / nwaves * nwaves : n_rows;
+    const int64_t t_end = phased ? (n_rows + nwaves - 1) / nwaves * nwaves : n_rows;
     SolveState<MODE ? DD : 1> held;  // (modes 1, 2) the first row of a pair, waiting for the second
     bool have_held = false;
     for (int64_t t = wave; t < t_end; t += nwaves) {
@@ -1469,7 +1516,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         if constexpr (T16)
             gram_accumulate16<NB>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if constexpr (MODE == 2)
-            gram_accumulate_b3<NB>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+            gram_accumulate_b3<NB, false>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0 && d == 32 * NB)
             gram_accumulate<NB, 1>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0)
@@ -1517,7 +1564,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         const int n_next = (int)(end_next - beg_next);
         int idx0_next, idx1_next;
         first_indices(beg_next, n_next, idx0_next, idx1_next);
-        if (phased & 1) __syncthreads();
+        if (phased) __syncthreads();
         __builtin_amdgcn_s_setprio(3);
         if constexpr (MODE != 0) {
             // two rows' sweeps run together: the first row of a pair is taken as far as the chain (its M in registers, the LDS
@@ -1529,7 +1576,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 als_solve_finish<DD>(held, lane);
                 als_solve_finish<DD>(cur, lane);
                 have_held = false;
-            } else if (!phased && t + nwaves < n_rows) {  // (phased: bit 0 = the lockstep probe, bit 1 = no pairing)
+            } else if (!phased && t + nwaves < n_rows) {
                 held = cur;
                 have_held = true;
             } else {
@@ -1549,7 +1596,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             c_rows++;
             c_ent += n;
         }
-        if (phased & 1) __syncthreads();
+        if (phased) __syncthreads();
         u = u_next, beg = beg_next, n = n_next, idx0 = idx0_next, idx1 = idx1_next;
     }
     if (prof && lane == 0) {
@@ -1581,7 +1628,7 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
         const int32_t *fb = idx + chunk_beg[c];
         const int cn = chunk_cnt[c];
         if constexpr (T16)
-            gram_accumulate16<NB>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
+            gram_accumulate16<NB, true>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         else if constexpr (MODE == 2)
             gram_accumulate_b3<NB>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         else if (zero_row >= 0 && d == 32 * NB)
@@ -1818,7 +1865,7 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                 \
         als_row_kernel<__VA_ARGS__, WAVES_><<<dim3(grid_), dim3(64 * WAVES_), (LDS_), h->stream>>>(                    \
             A, B, ptr, idx, h->gram.p, pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), \
-            g_als_phased | (g_als_nopair << 1), zrow);                                                                 \
+            g_als_phased, zrow);                                                                                       \
     } while (0)
         const int mode = als_gram_mode(d, zrow);
         if (mode != 0) {
@@ -2033,7 +2080,6 @@ extern "C" void gorse_hip_test_set_als_path(int32_t path) {
     g_als_slow_gather = (path & 64) != 0;
     g_als_tile32 = (path & 128) != 0;
     g_als_waves8 = (path & 256) != 0;
-    g_als_nopair = (path & 512) != 0;
     g_als_nob3 = (path & 1024) != 0;
 }
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
