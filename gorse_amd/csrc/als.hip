@@ -1034,6 +1034,12 @@ __device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, con
 // against 80 for the fp32 tiles.  Fragment: lane l holds column (l & 31) of the EIGHT entries 8 (l >> 5) .. + 7 of a 16-entry stage
 // (the MFMA's k index), two values per register; the accumulators and their D layout are those of the fp32 32 x 32 form.
 constexpr int kAlsOct = 8;  // entries per lane and stage
+#ifndef GORSE_ALS_ROW_DEEP
+#define GORSE_ALS_ROW_DEEP 1
+#endif
+constexpr bool kAlsRowDeep = GORSE_ALS_ROW_DEEP != 0;  // the row kernel's bf16 form: four gather stages and no pairing of sweeps (the registers of
+                                                       // one or the other): C5 5.69-5.71 against 5.78 ms (profiles/r04_zq_ab_row_ring.txt)
+constexpr bool kAlsRowPair = !kAlsRowDeep;
 
 template <int NB>
 __device__ __forceinline__ void gram_load_stage_b3(const float *__restrict__ B, uint32_t rowbytes, int idx, int first, int lane,
@@ -1106,9 +1112,8 @@ __device__ __forceinline__ void gram_accumulate_b3(const float *__restrict__ B, 
     };
     // DEEP: three stages in flight, a fourth being consumed (a ring of four buffers, unrolled: nothing moves) -- for the chunk kernel,
     // whose wave walks 256 stages on end: the S Gram 0.27 -> 0.22 ms and the long rows' share of the sweeps with it (C5 6.1 -> 5.8 ms,
-    // profiles/r04_zo_probe_als_tiles.txt).  The row kernel keeps two: a 100-entry row is seven stages, the ring's prologue and the
-    // three stages issued past the row's end (they gather the zero row) cost what the depth saves, and its registers are full (5.80-5.90
-    // against 5.77-5.78 ms in the same session).
+    // profiles/r04_zo_probe_als_tiles.txt).  In the row kernel (a 100-entry row is seven stages) the deeper ring is worth 1.5 %, and only
+    // in place of the pairing of two rows' sweeps -- with both the registers spill (kAlsRowDeep).
     if constexpr (DEEP) {
         float f0[kAlsOct][NB], f1[kAlsOct][NB], f2[kAlsOct][NB], f3[kAlsOct][NB];
         issue(f0);
@@ -1516,7 +1521,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         if constexpr (T16)
             gram_accumulate16<NB>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if constexpr (MODE == 2)
-            gram_accumulate_b3<NB, false>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+            gram_accumulate_b3<NB, kAlsRowDeep>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0 && d == 32 * NB)
             gram_accumulate<NB, 1>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0)
@@ -1576,7 +1581,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 als_solve_finish<DD>(held, lane);
                 als_solve_finish<DD>(cur, lane);
                 have_held = false;
-            } else if (!phased && t + nwaves < n_rows) {
+            } else if (kAlsRowPair && !phased && t + nwaves < n_rows) {
                 held = cur;
                 have_held = true;
             } else {
