@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         unsigned long long t0 = 0;
         if (prof) t0 = __builtin_amdgcn_s_memtime();
         if constexpr (T16)
-            gram_accumulate16<NB>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+            gram_accumulate16<NB, true>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if constexpr (MODE == 2)
             gram_accumulate_b3<NB, kAlsRowDeep>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else if (zero_row >= 0 && d == 32 * NB)
