@@ -97,8 +97,7 @@ int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /
  * Which MFMA form the Gram of a row takes (csrc/als.hip als_gram_mode; default: nFactors 32 / 64 on the bf16 MFMA over three-way
  * split values, 16 / 48 on the fp32 MFMA in 16 x 16 tiles, anything else or without the fast gather stage fp32 32 x 32 tiles):
  * 1024 = no bf16 form (32 / 64 take the 16 x 16 fp32 tiles), 128 = no 16 x 16 tiles either (1024 | 128: everything in 32 x 32
- * fp32 tiles, the form of rounds 1-3); 256 = eight waves per workgroup where twelve are the default (nFactors <= 32), 512 = every
- * row's sweep on its own instead of two rows' sweeps advancing together. */
+ * fp32 tiles, the form of rounds 1-3); 256 = eight waves per workgroup where twelve are the default (nFactors <= 32). */
 void gorse_hip_test_set_als_path(int32_t path);
 /* thresholds of the Gram-form row plan, for handles created AFTERWARDS: rows longer than long_row feedbacks
  * are cut into chunks of `chunk` entries (defaults 4096 / 4096; <= 0 restores a default).  Lets small test

@@ -93,7 +93,7 @@ def main():
         capi.lib().gorse_hip_test_set_als_path(0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "tiles":  # round 4: 16 x 16 MFMA tiles (0; 256: at 8 waves per workgroup) against 32 x 32 (128)
-        # 128: fp32 32 x 32 tiles; 1024: fp32 16 x 16 tiles where the default is the bf16 x 3 form; 256: 8 waves per workgroup; 512: no pairing
+        # 128 | 1024: fp32 32 x 32 tiles; 1024: fp32 16 x 16 tiles where the default is the bf16 x 3 form; 256: 8 waves per workgroup
         for d in (64, 48, 32, 16):
             run("C5 shard/4 d=%d" % d, 125_000, 100_000, 12_500_000, d, (128 | 1024, 1024, 256, 0), reps=3)
         run("C5 full d=64", 500_000, 100_000, 50_000_000, 64, (128 | 1024, 1024, 0, 1024, 0), reps=8)
