@@ -823,7 +823,8 @@ def bench_mm(args, local):
     return {"metric": "floats.MM TFLOP/s (fp32, 4096^3 NN, bit-equal to the reference's fmaf chain)", "value": tf, "unit": "TFLOP/s",
             "ms_per_step": t, "steps": 3, "higher_is_better": True, "dtype": "f32", "data": "synthetic", "host_to_host_ms": float(np.median(wall)),
             "roofline": {"bound": "mfma_f32", "kernel": "sgemm_mfma_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": t, "launches": 3}}
+                         "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": measured_traffic("mm")[0], "traffic_source": measured_traffic("mm")[1],
+                         "avg_launch_ms": t, "launches": 3}}
 
 
 def leg(fn, what):
