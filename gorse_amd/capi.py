@@ -100,6 +100,7 @@ SIGNATURES = {
     "gorse_hip_test_set_topk_variant": (None, [C.c_int32]),
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
+    "gorse_hip_test_topk_last_symmetric": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_head": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_table": (None, [C.c_int32]),
@@ -389,6 +390,11 @@ class TopK:
         n = C.c_int64(0)
         check(lib().gorse_hip_test_topk_resweeps(self.h, C.byref(n)))
         return n.value
+
+    def last_symmetric(self):
+        s = C.c_int32(0)
+        check(lib().gorse_hip_test_topk_last_symmetric(self.h, C.byref(s)))
+        return bool(s.value)
 
     def synchronize(self):
         check(lib().gorse_topk_synchronize(self.h))

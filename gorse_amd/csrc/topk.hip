@@ -584,6 +584,13 @@ extern "C" int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n) {
     return GORSE_OK;
 }
 
+// probe: did the main sweep of the last search (its last chunk) take the symmetric form (csrc/topk_mfma.hip, SYM)
+extern "C" int32_t gorse_hip_test_topk_last_symmetric(gorse_topk *h, int32_t *sym) {
+    if (!h || !sym) return fail(GORSE_ERR_INVALID, "NULL argument");
+    *sym = h->last_sym ? 1 : 0;
+    return GORSE_OK;
+}
+
 // test hook: 0 = automatic path choice, 1 = path A only (literal scan), 2 = path B whenever its operands exist
 extern "C" void gorse_hip_test_set_topk_path(int32_t path) { gorse::g_topk_force_path = path; }
 extern "C" void gorse_hip_test_set_topk_variant(int32_t v) { gorse::g_topk_variant = v; }

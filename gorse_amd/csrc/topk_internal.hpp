@@ -56,6 +56,12 @@ struct gorse_topk {
     int kernel_metric() const { return bf16_order ? 3 : metric; }
     int64_t n_fallback = 0, n_tie = 0, n_resweep = 0;  // of the last search: path A rows, tie replays, warm starts swept again
     gorse::DevBuf<float> f0, f1;                       // warm-start thresholds of a chunk (topk_mfma_search): pilot, pre-pilot
+    // the symmetric all-pairs sweep (topk_mfma.hip, SYM): per query a foreign candidate list and its counter, the raw-score form
+    // of the thresholds; last_sym: did the last search's (last chunk's) main sweep take the symmetric form
+    gorse::DevBuf<uint2> fbuf;
+    gorse::DevBuf<int32_t> fcnt;
+    gorse::DevBuf<float> f0raw;
+    bool last_sym = false;
     int32_t use() const {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return gorse::fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));

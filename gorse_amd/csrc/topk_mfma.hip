@@ -22,6 +22,7 @@
 
 #include "rank_keys.hpp"
 #include "topk_internal.hpp"
+#include "topk_sym.hpp"
 
 using namespace gorse;
 
@@ -77,15 +78,24 @@ constexpr size_t sweep_tile_bytes(int kp, int rb, bool dma) {
     return (size_t)32 * rb * sweep_row_bytes(kp, dma) + (size_t)32 * rb * 4 + (dma ? 0 : 2 * kMaxRB * 4);
 }
 constexpr size_t sweep_fixed_bytes(int bq) { return (size_t)5 * bq * 4 + 64; }
-constexpr int sweep_bufs(int kp, int rb, int bq, int wv, bool hist) {
-    if (sweep_dma(kp, hist, rb, wv)) return 4 * sweep_tile_bytes(kp, rb, true) + sweep_fixed_bytes(bq) <= (size_t)156 * 1024 ? 4 : 3;
+// SYM (the symmetric all-pairs sweep, see topk_sweep_kernel): per tile buffer the thresholds of the tile's rows AS QUERIES (their
+// value and its raw-score form), per wave a staging area of kStageCap (key, row query | column) entries
+constexpr int kStageCap = 128;      // staged foreign candidates per wave
+constexpr int kStageFlushAt = 64;   // a wave empties its staging area once it holds this many
+constexpr size_t sweep_sym_bytes(int rb, int wv, bool sym) { return sym ? (size_t)2 * 32 * rb * 4 : 0; }  // per tile buffer
+constexpr size_t sweep_stage_bytes(int wv, bool sym) { return sym ? (size_t)wv * kStageCap * 8 : 0; }
+constexpr int sweep_bufs(int kp, int rb, int bq, int wv, bool hist, bool sym = false) {
+    if (sweep_dma(kp, hist, rb, wv))
+        return 4 * (sweep_tile_bytes(kp, rb, true) + sweep_sym_bytes(rb, wv, sym)) + sweep_fixed_bytes(bq) + sweep_stage_bytes(wv, sym) <= (size_t)156 * 1024 ? 4 : 3;
     return !hist && 3 * sweep_tile_bytes(kp, rb, false) + sweep_fixed_bytes(bq) <= (size_t)144 * 1024 ? 3 : 2;
 }
-constexpr size_t sweep_lds_bytes(int kp, int rb, int bq, int wv, bool hist) {
-    return sweep_bufs(kp, rb, bq, wv, hist) * sweep_tile_bytes(kp, rb, sweep_dma(kp, hist, rb, wv)) + sweep_fixed_bytes(bq);
+constexpr size_t sweep_lds_bytes(int kp, int rb, int bq, int wv, bool hist, bool sym = false) {
+    return sweep_bufs(kp, rb, bq, wv, hist, sym) * (sweep_tile_bytes(kp, rb, sweep_dma(kp, hist, rb, wv)) + sweep_sym_bytes(rb, wv, sym)) +
+           sweep_fixed_bytes(bq) + sweep_stage_bytes(wv, sym);
 }
 constexpr int64_t kMinSweepQueries = 768;  // fewer queries in a call take the scan (see topk_mfma_usable)
 constexpr int kCap = 512;      // candidate-list capacity per query
+constexpr int kCapF = 512;     // SYM: capacity of a query's FOREIGN list (candidates other workgroups found for it)
 constexpr int kEPL = kCap / 64;
 constexpr int kCompactAt = kCap - 64;   // compact a list once it holds more than this (a block adds <= 32)
 constexpr int kOverflowAt = kCap - 128; // a compaction that keeps more than this cannot make progress
@@ -130,12 +140,21 @@ struct SweepParams {
                        // sweep's floor), 2 = a qualifying block does nothing, 3 = it tests and counts its candidates without storing them
     int nslices;       // HIST: row slices (grid.y); the per-query outputs are then nslices x nq long, slice-major
     float rs_min, rs_max;  // smallest and largest row value of the index (EP_COARSE bound of the DMA sweeps)
+    // SYM sweeps (the queries are the stored rows sym_q0 .. sym_q0 + nq): see topk_sweep_kernel
+    int64_t sym_q0;        // row of query 0, a multiple of the tile height
+    const float *frow;     // nq thresholds of the rows as queries (the pilot's: frozen for the foreign workgroups)
+    const float *frow_raw; // RAWF: their raw-score form (raw_threshold of frow)
+    uint2 *fbuf;           // nq x kCapF foreign lists
+    int32_t *fcnt;         // nq entries appended to them (may exceed kCapF: the list then overflowed)
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
 // HIST: the entries the new threshold drops are appended to the query's history (hb, counter s_hc[ql]) instead of
 // being forgotten; list + history then hold every vector the reference's heap can have accepted.
-template <bool HIST>
+// SYM: the list holds only the rows of the workgroup's OWN part of the sweep (the rest of the query's candidates are in its
+// foreign list), so a list shorter than kth proves nothing about the threshold either way: it is kept as it is, and the
+// warm start is verified over both lists by topk_rescore_kernel.
+template <bool HIST, bool SYM = false>
 __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s_cnt, float *s_f, const float *s_mg,
                                               uint8_t *flag, uint2 *hb = nullptr, int *s_hc = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -189,6 +208,8 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
             if (c >= kth) prefix = trial;
         }
         newf = fkey_inv(prefix) - s_mg[ql];
+    } else if (SYM) {
+        newf = s_f[ql];
     }
     if (newf < s_f[ql]) {
         // Only a warm-started threshold can be above what the list proves (thresholds derived from the list never fall):
@@ -252,7 +273,19 @@ __device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
 // [0] tile movement (DMA issue / tile store + prefetch issue), [1] MFMA + epilogues (candidate paths included), [2] candidate
 // paths alone, [3] waiting for a tile, [4] row blocks examined, [5] row blocks that took the candidate path, [6] whole kernel,
 // [7] waves, [8] candidate path: set-up + row scaling, [9] appends, [10] compaction check / compaction, [11] candidate paths
-template <int KP, int NCB, int EP, bool HIST, int RB, bool PROF = false>
+//
+// SYM -- the symmetric form of an all-pairs sweep.  When the queries are the stored rows sym_q0 .. sym_q0 + nq themselves, the
+// score of (query c, row r) is also the score of (query r, row c): the workgroup of query block C multiplies only the row tiles
+// that do NOT lie in a later query block (the rows before the query range, the query blocks 0 .. C, the rows behind the range) and,
+// for the tiles of the EARLIER query blocks, reads every 32 x 32 block of scores a second time along its rows: in the MFMA's D
+// layout a lane holds ONE column and sixteen rows, so the second test is sixteen compares against the rows' own thresholds
+// (brought into LDS with the tile).  What passes is a candidate of the ROW's query among the columns: it is staged in LDS per
+// wave and appended -- in batches, by returning atomics on a per-query counter -- to that query's FOREIGN list; foreign
+// thresholds are the pilot's and stay frozen (any threshold that was ever valid is a valid lower bound).  Every (query, row) pair
+// is covered exactly once: by the query's own workgroup when the row's tile is not one it skips, else by the workgroup of the
+// row's block (tests/test_topk_sym_schedule_cpu.py walks the schedule).  Workgroups are issued longest first (block C = grid - 1 -
+// blockIdx.x sweeps C + 1 query blocks): half the MFMA work of the square sweep, and no partial last round.
+template <int KP, int NCB, int EP, bool HIST, int RB, bool PROF = false, bool SYM = false>
 __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) + 3) / 4 < 2 ? 2 : (sweep_waves(HIST, KP) + 3) / 4) void topk_sweep_kernel(SweepParams p) {
     constexpr int kWaves = sweep_waves(HIST, KP);
     constexpr int kThreads = kWaves * 64;
@@ -273,11 +306,14 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     constexpr int BQ = QW * kWaves;
     constexpr int CHUNKS = kTR * KP * 2;  // 16-byte pieces per tile
     constexpr int CPT = (CHUNKS + kThreads - 1) / kThreads;
-    constexpr int NBUF = sweep_bufs(KP, RB, BQ, kWaves, HIST);
+    constexpr int NBUF = sweep_bufs(KP, RB, BQ, kWaves, HIST, SYM);
+    static_assert(!SYM || (DMA && !HIST && !PROF && BQ % kTR == 0 && EP != EP_NONE), "SYM: a DMA main sweep whose query blocks are whole tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *s_tile = smem;
     float *s_rs = reinterpret_cast<float *>(smem + (size_t)NBUF * kTR * ROWB);
-    float *s_bmm = s_rs + NBUF * kTR;  // register staging only: per buffer and 32-row block the (min, max) row scale
+    float *s_fq = s_rs + NBUF * kTR;                // SYM: the thresholds of the tile's rows as queries ...
+    float *s_fqr = s_fq + (SYM ? NBUF * kTR : 0);   // ... and their raw-score form (RAWF)
+    float *s_bmm = s_fqr + (SYM ? NBUF * kTR : 0);  // register staging only: per buffer and 32-row block the (min, max) row scale
     int *s_cnt = reinterpret_cast<int *>(s_bmm + (DMA ? 0 : NBUF * 2 * kMaxRB));  // 2 per query: the interleaved sub-list lengths
     float *s_f = reinterpret_cast<float *>(s_cnt + 2 * BQ);
     float *s_mg = s_f + BQ;
@@ -285,9 +321,11 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     // tile counters: s_sync[b] = waves whose part of a tile has reached buffer b (ever), s_sync[NBUF + b] = waves that
     // have finished reading one
     int *s_sync = s_hc + BQ;
+    uint2 *s_stage = reinterpret_cast<uint2 *>(s_sync + 16);  // SYM: kWaves x kStageCap staged foreign candidates
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t wgq0 = (int64_t)blockIdx.x * BQ;
+    const int cblk = SYM ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;  // SYM: longest workgroups first
+    const int64_t wgq0 = (int64_t)cblk * BQ;
     for (int t = tid; t < BQ; t += kThreads) {
         const int64_t q = wgq0 + t;
         s_cnt[2 * t] = 0;
@@ -322,14 +360,21 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     // keeps its own lists; topk_tie_sort_kernel joins them (see there for why that is a superset of the unsliced history).
     const int64_t NT_all = (p.N + stride_rows - 1) / stride_rows;
     const int64_t T0 = NT_all * blockIdx.y / gridDim.y, T1 = NT_all * (blockIdx.y + 1) / gridDim.y;
-    const int64_t NT = T1 - T0;
+    // SYM (one slice, stride 1): the tiles [skip_lo, skip_lo + skip_n) -- whole tiles of LATER query blocks -- are left to those
+    // blocks' workgroups; the tiles [tr_lo, tr_hi) -- the earlier query blocks -- are read along their rows as well
+    const SymSchedule sched(SYM ? p.sym_q0 : 0, SYM ? p.nq : 0, kTR, BQ, cblk);  // topk_sym.hpp
+    const int64_t NT = SYM ? sched.tiles(NT_all) : T1 - T0;
+    auto tile_index = [&](int64_t tl) -> int64_t {  // the tl-th tile this workgroup multiplies
+        if constexpr (SYM) return sched.tile_index(tl);
+        else return T0 + tl;
+    };
     const int64_t qslice = (int64_t)blockIdx.y * p.nq;  // this slice's rows of the per-query output arrays
 
     // ---- register staging (history sweeps, operand depths that are not a power of two) ----
     uint4 pre[DMA ? 1 : CPT];
     float pre_rs = 0.0f;
     auto load_tile = [&](int64_t tl) {
-        const int64_t base_row = (T0 + tl) * stride_rows;
+        const int64_t base_row = tile_index(tl) * stride_rows;
 #pragma unroll
         for (int c = 0; c < CPT; c++) {
             const int ch = tid + c * kThreads;
@@ -399,6 +444,10 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     // rows may lie past N, clamps its rows instead (their scores are discarded through the NaN padding of the row values).
     const unsigned lds_tiles = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_tile;
     const unsigned lds_rs = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)s_rs;
+    const unsigned lds_fq = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)s_fq;
+    const unsigned lds_fqr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)s_fqr;
+    constexpr bool RAWF_ = EP == EP_COARSE && DMA;  // (RAWF below)
+    constexpr int NXD = SYM ? (RAWF_ ? 2 : 1) : 0;  // SYM: extra row-value DMA instructions per tile of the first RSW issuing waves
     unsigned dsrc[DMA ? DPW : 1];  // byte offset of this lane's piece of instruction j from the tile's first byte
     if constexpr (DMA) {
 #pragma unroll
@@ -410,7 +459,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     }
     auto dma_tile = [&](int64_t tl, int buf) {
         if constexpr (DMA) {
-            const int64_t base_row = (T0 + tl) * stride_rows;
+            const int64_t base_row = tile_index(tl) * stride_rows;
             const bool inside = base_row + kTR <= p.N;  // wave-uniform
             const unsigned char *tile0 = reinterpret_cast<const unsigned char *>(p.A) + base_row * (KPAD * 2);
 #pragma unroll
@@ -436,6 +485,22 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                if constexpr (SYM) {
+                    // the thresholds of the tile's rows as queries (any valid address for a tile outside the query range: its
+                    // values are never looked at)
+                    int64_t qi = base_row - p.sym_q0 + wi * 64 + lane;
+                    qi = qi < 0 ? 0 : (qi >= p.nq ? p.nq - 1 : qi);
+                    const float *s1 = p.frow + qi;
+                    const unsigned d1 = __builtin_amdgcn_readfirstlane(lds_fq + (unsigned)(buf * kTR + wi * 64) * 4u);
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(s1), "s"(d1) : "memory");
+                    if constexpr (RAWF_) {
+                        const float *s2 = p.frow_raw + qi;
+                        const unsigned d2 = __builtin_amdgcn_readfirstlane(lds_fqr + (unsigned)(buf * kTR + wi * 64) * 4u);
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(s2), "s"(d2) : "memory");
+                    }
+                }
             }
         }
     };
@@ -447,7 +512,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             if (keep == 0)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (wi < RSW)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1 + NXD) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
         }
@@ -531,6 +596,41 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         for (int ks = 0; ks < KP; ks++) aoff[ks] = (unsigned)(r * ROWB + (((ks * 2 + (lane >> 5)) ^ piece_swizzle(r)) << 4));
     }
 
+    // SYM: what the column's own row contributes to a score read along the rows (its scale / bias; NaN for a column that must
+    // not emit: a lane past nq, a column whose own tile also holds rows outside the query range -- every workgroup multiplies
+    // that tile itself -- and a masked row)
+    float csv[NCB];
+    int stage_n = 0;  // staged foreign candidates of this wave (wave-uniform)
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        csv[cb] = __builtin_nanf("");
+        if constexpr (SYM) {
+            const int64_t q = wgq0 + w * QW + cb * 32 + (lane & 31);
+            if (SymSchedule::column_emits(p.sym_q0, p.nq, kTR, q)) csv[cb] = p.rscale[p.sym_q0 + q];
+            asm volatile("" : "+v"(csv[cb]));  // consumed now: no load pending when the tile loop is entered
+        }
+    }
+    // the staged entries to their queries' foreign lists: one returning atomic per entry, issued from an asm statement together
+    // with its wait (as compact_query's loads: a memory operation hipcc can see inside the tile loop costs a vmcnt(0) per tile)
+    auto flush_stage = [&]() {
+        if constexpr (SYM) {
+            uint2 *stg = s_stage + w * kStageCap;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int e0 = 0; e0 < stage_n; e0 += 64) {
+                const int e = e0 + lane;
+                const bool on = e < stage_n;
+                const uint2 ent = stg[on ? e : 0];
+                const uint32_t rowq = ent.y & 0xfffffu, col = ent.y >> 20;
+                int32_t *ctr = p.fcnt + rowq;
+                int slot = 0;
+                const int one = 1;
+                if (on)
+                    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(slot) : "v"(ctr), "v"(one) : "memory");
+                if (on && slot < kCapF) p.fbuf[(int64_t)rowq * kCapF + slot] = make_uint2(ent.x, (uint32_t)(p.sym_q0 + wgq0 + col));
+            }
+            stage_n = 0;
+        }
+    };
     // the fragments of the row block about to be multiplied (PIPE), read from block-0-relative address `blk` of a tile
     bf16x8 af[PIPE ? KP : 1];
     auto frag = [&](const unsigned char *blk, int ks) -> bf16x8 {
@@ -638,7 +738,9 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
 #pragma unroll
             for (int ks = 0; ks < KP; ks++) af[PIPE ? ks : 0] = frag(tb, ks);
         }
-        const int64_t base_row = (T0 + t) * stride_rows;
+        const int64_t base_row = tile_index(t) * stride_rows;
+        // SYM: a tile of an earlier query block is read along its rows too (wave-uniform)
+        const bool trans = SYM && sched.transposed(tile_index(t));
         // register staging zero-fills the rows past N; their scores are set to NaN below.  The DMA sweeps need nothing: the
         // row values of those rows are NaN
         const int valid = DMA ? kTR : (int)std::min<int64_t>(kTR, p.N - base_row);
@@ -718,6 +820,58 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             // 4 for the bound, 2 for the vote.
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
+                if constexpr (SYM) {
+                    if (trans) {
+                        // the block read along its rows: score (query = row, candidate = this lane's column) against the ROW's threshold.
+                        // RAWF: raw scores against the rows' raw thresholds, the column's scale only behind that test.
+                        const float4 *t4 = reinterpret_cast<const float4 *>((RAWF ? s_fqr : s_fq) + buf * kTR + rb * 32);
+                        const float cv = csv[cb];
+                        auto col_score = [&](float raw) -> float { return EP == EP_BIAS ? raw + cv : raw * cv; };
+                        // sixteen differences and their maxima by quad (the compiler turns a chain of sixteen compares into a bit mask
+                        // built from v_cndmask / shifts, five instructions per score); a NaN score (a column that must not emit)
+                        // is skipped by the hardware maximum, -0 from a flushed difference only opens the exact test below
+                        float qd[4];
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const float4 th = t4[2 * g + (lane >> 5)];
+                            const float a0 = RAWF ? acc[cb][4 * g + 0] : col_score(acc[cb][4 * g + 0]);
+                            const float a1 = RAWF ? acc[cb][4 * g + 1] : col_score(acc[cb][4 * g + 1]);
+                            const float a2 = RAWF ? acc[cb][4 * g + 2] : col_score(acc[cb][4 * g + 2]);
+                            const float a3 = RAWF ? acc[cb][4 * g + 3] : col_score(acc[cb][4 * g + 3]);
+                            qd[g] = max2f(max3f(a0 - th.x, a1 - th.y, a2 - th.z), a3 - th.w);
+                        }
+                        const float dm = max2f(max3f(qd[0], qd[1], qd[2]), qd[3]);
+                        if (__builtin_amdgcn_ballot_w64(dm >= 0.0f) != 0) {
+                            const float4 *f4 = reinterpret_cast<const float4 *>(s_fq + buf * kTR + rb * 32);
+                            const uint32_t colw = (uint32_t)(w * QW + cb * 32 + (lane & 31)) << 20;  // the column inside the workgroup's block
+                            uint2 *stg = s_stage + w * kStageCap;
+#pragma unroll
+                            for (int g = 0; g < 4; g++) {
+                                if (__builtin_amdgcn_ballot_w64(qd[g] >= 0.0f) == 0) continue;
+                                const float4 fr4 = f4[2 * g + (lane >> 5)];
+                                const float frow[4] = {fr4.x, fr4.y, fr4.z, fr4.w};
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const int r = 4 * g + e;
+                                    const float sc = col_score(acc[cb][r]);  // NaN for a column that must not be emitted (csv)
+                                    const bool pass = sc >= frow[e];
+                                    const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+                                    if (m != 0) {
+                                        const int c = __builtin_popcountll(m);
+                                        const uint32_t rowq = (uint32_t)(base_row - p.sym_q0) + (uint32_t)(rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                                        if (stage_n + c <= kStageCap) {
+                                            if (pass) stg[stage_n + lane_rank(m)] = make_uint2(fkey(sc), rowq | colw);
+                                            stage_n += c;
+                                        } else if (pass) {
+                                            p.cflag[rowq] = 1;  // more hits in one block than the staging area holds: that query takes the tie path
+                                        }
+                                    }
+                                }
+                            }
+                            if (stage_n >= kStageFlushAt) flush_stage();
+                        }
+                    }
+                }
                 auto scale_rows = [&]() {
                     const float4 *r4 = reinterpret_cast<const float4 *>(s_rs + buf * kTR + rb * 32);
 #pragma unroll
@@ -824,7 +978,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                             const int l = __builtin_ctzll(need);
                             need &= need - 1;
                             const int qlc = w * QW + cb * 32 + l;
-                            compact_query<HIST>(p.cbuf + (qslice + wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg,
+                            compact_query<HIST, SYM>(p.cbuf + (qslice + wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg,
                                                 p.cflag + qslice + wgq0 + qlc,
                                                 HIST ? p.hbuf + (qslice + wgq0 + qlc) * kHistCap : nullptr, s_hc);
                         } while (need);
@@ -868,6 +1022,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         atomicAdd(p.prof + 14, c_land);
         atomicAdd(p.prof + 15, c_post);
     }
+    if (SYM && stage_n > 0) flush_stage();
     // final threshold + compaction of every list this wave owns
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) s_cnt[2 * (w * QW + cb * 32 + (lane & 31)) + (lane >> 5)] = cnt[cb];
@@ -881,7 +1036,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             if (p.f_out && lane == 0) p.f_out[qg] = -__builtin_inff();
             continue;
         }
-        compact_query<HIST>(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg,
+        compact_query<HIST, SYM>(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg,
                             HIST ? p.hbuf + qg * kHistCap : nullptr, s_hc);
         if (lane == 0) {
             p.ccnt[qg] = s_cnt[2 * ql] + s_cnt[2 * ql + 1];  // packed by the final compaction: slots 0 .. count-1
@@ -929,31 +1084,56 @@ struct RescoreParams {
     int32_t *out_idx;
     float *out_dist;
     int32_t *out_cnt;
+    // SYM sweeps: the query's foreign list, and what the verification of its warm start needs (see below)
+    const uint2 *fbuf;     // nq x kCapF, or null
+    const int32_t *fcnt;
+    const float *f0;       // the thresholds the main sweep started from
+    const float *qmargin;
+    int kth;
 };
+constexpr int kCapT = kCap + kCapF;  // candidates the rescoring takes per query: its own list + its foreign list
 
 __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int d = p.d;
     float *sq = smem_f;                          // d
     float *sx = sq + d;                          // kGroupsPerBlock * d
-    float *s_e = sx + (size_t)kGroupsPerBlock * d;  // kCap
-    int *s_i = reinterpret_cast<int *>(s_e + kCap);  // kCap
-    int *s_misc = s_i + kCap;                    // [0] nonpositive in top-k, [1] flag
+    float *s_e = sx + (size_t)kGroupsPerBlock * d;  // kCapT
+    int *s_i = reinterpret_cast<int *>(s_e + kCapT);  // kCapT
+    int *s_misc = s_i + kCapT;                   // [0] nonpositive in top-k, [1] flag, [2] SYM: candidates that clear the warm start
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
     const int k = p.k;
     if (p.cflag[t]) return;  // path A fills this row
-    const int n = p.ccnt[t];
+    const int n_own = p.ccnt[t];
+    const int n_for = p.fbuf ? p.fcnt[t] : 0;
+    if (n_for > kCapF) {  // the foreign list overflowed: the tie path sweeps this query on its own
+        if (tid == 0) p.cflag[t] = 1;
+        return;
+    }
+    const int n = n_own + n_for;
+    const uint2 *fb = p.fbuf ? p.fbuf + t * kCapF : nullptr;
     const int64_t self = p.Qf ? -1 : (p.qid ? p.qid[t] : p.q0 + t);
     const float *qrow = p.Qf ? p.Qf + t * d : p.X + self * d;
     for (int e = tid; e < d; e += kBlock) sq[e] = qrow[e];
-    if (tid < 2) s_misc[tid] = 0;
+    if (tid < 3) s_misc[tid] = 0;
     __syncthreads();
     const VecShape vs(d);
     const float qq = p.metric == GORSE_METRIC_COSINE ? p.qn2[t] : 0.0f;
     const uint2 *cb = p.cbuf + t * kCap;
+    // SYM: a warm start that the query's own list could not verify (fewer than kth entries: its workgroup saw only part of the
+    // rows) is verified here over both lists -- the threshold f0 is valid iff (kth-th best approximate score) - margin >= f0, and
+    // with the own threshold still at f0 the two lists hold every row that reaches f0.  (An own list of kth entries and more was
+    // verified by the sweep's last compaction; f0 = -inf needs no proof.)
+    const bool verify = p.fbuf && n_own < p.kth && p.f0[t] > -__builtin_inff();
+    if (verify) {
+        const float f0 = p.f0[t], mg = p.qmargin[t];
+        int c_ok = 0;
+        for (int c = tid; c < n; c += kBlock) c_ok += fkey_inv((c < n_own ? cb[c] : fb[c - n_own]).x) - mg >= f0;
+        if (c_ok) atomicAdd(&s_misc[2], c_ok);
+    }
     for (int c = gib; c < n; c += kGroupsPerBlock) {
-        const int64_t i = cb[c].y;
+        const int64_t i = (c < n_own ? cb[c] : fb[c - n_own]).y;
         float *row = sx + (size_t)gib * d;
         gather_row(row, p.X, p.Xb, i, d, lane);
         __builtin_amdgcn_wave_barrier();
@@ -982,10 +1162,10 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     int P = 2;
     while (P < n) P <<= 1;
     {
-        uint32_t kreg[kCap / kBlock];
-        int ireg[kCap / kBlock];
+        uint32_t kreg[kCapT / kBlock];
+        int ireg[kCapT / kBlock];
 #pragma unroll
-        for (int s = 0; s < kCap / kBlock; s++) {
+        for (int s = 0; s < kCapT / kBlock; s++) {
             const int c = tid + s * kBlock;
             kreg[s] = 0xffffffffu;
             ireg[s] = -1;
@@ -1001,7 +1181,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < kCap / kBlock; s++) {
+        for (int s = 0; s < kCapT / kBlock; s++) {
             const int c = tid + s * kBlock;
             if (c < P) {
                 s_key[c] = kreg[s];
@@ -1046,6 +1226,10 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
         if (r < k && p.prune0 && gorse::rank::dist_key_nonpositive(a)) atomicAdd(&s_misc[0], 1);
     }
     __syncthreads();
+    if (verify && s_misc[2] < p.kth) {  // the warm start was too high: swept again from -inf with the tie queries
+        if (tid == 0) p.cflag[t] = 2;
+        return;
+    }
     if (s_misc[1] || top < p.expect) {  // ties, NaN, or a list that cannot hold the answer: path A
         if (tid == 0) p.cflag[t] = 1;
         return;
@@ -1855,15 +2039,15 @@ __global__ void margin_kernel(const float *__restrict__ qn2, int64_t nq, float c
 
 const int kSupportedKP[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
 
-template <int KP, int NCB, int EP, bool HIST, int RB>
+template <int KP, int NCB, int EP, bool HIST, int RB, bool SYM = false>
 int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int WV = sweep_waves(HIST, KP);
     constexpr int BQ = 32 * NCB * WV;
-    const size_t lds = sweep_lds_bytes(KP, RB, BQ, WV, HIST);
+    const size_t lds = sweep_lds_bytes(KP, RB, BQ, WV, HIST, SYM);
     const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
-    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, EP, HIST, RB, false>),
+    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, EP, HIST, RB, false, SYM>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    topk_sweep_kernel<KP, NCB, EP, HIST, RB, false>
+    topk_sweep_kernel<KP, NCB, EP, HIST, RB, false, SYM>
         <<<dim3(grid, HIST ? (unsigned)std::max(p.nslices, 1) : 1u), dim3(WV * 64), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
@@ -1882,18 +2066,25 @@ int32_t launch_sweep_prof(gorse_topk *h, const SweepParams &p) {  // the instrum
 }
 #endif
 
-template <int KP, int NCB, bool HIST, int RB>
+template <int KP, int NCB, bool HIST, int RB, bool SYM = false>
 int32_t launch_sweep_ep(gorse_topk *h, const SweepParams &p) {
     switch (p.ep) {
-        case EP_SCALE: return launch_sweep_one<KP, NCB, EP_SCALE, HIST, RB>(h, p);
-        case EP_BIAS: return launch_sweep_one<KP, NCB, EP_BIAS, HIST, RB>(h, p);
-        case EP_COARSE: return launch_sweep_one<KP, NCB, EP_COARSE, HIST, RB>(h, p);
+        case EP_SCALE: return launch_sweep_one<KP, NCB, EP_SCALE, HIST, RB, SYM>(h, p);
+        case EP_BIAS: return launch_sweep_one<KP, NCB, EP_BIAS, HIST, RB, SYM>(h, p);
+        case EP_COARSE: return launch_sweep_one<KP, NCB, EP_COARSE, HIST, RB, SYM>(h, p);
     }
     return fail(GORSE_ERR_INVALID, "unknown epilogue %d", p.ep);
 }
 
+// the operand depths whose main sweep has a symmetric form: 128-row DMA tiles, two column blocks per wave
+constexpr bool sweep_sym_kp(int kp) { return kp == 2 || kp == 4 || kp == 8; }
+
 template <int KP, int NCB>
-int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
+int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool hist, bool sym = false) {
+    if constexpr (sweep_sym_kp(KP) && NCB == kNcbMain && sweep_dma(KP, false, 4, kWavesMain)) {
+        if (sym) return launch_sweep_ep<KP, NCB, false, 4, true>(h, p);
+    }
+    if (sym) return fail(GORSE_ERR_INVALID, "no symmetric sweep for operand depth %d", KP);
     // 128-row tiles (one tile hand-over per four MFMA row blocks) where LDS allows; the history sweep of the few flagged
     // queries keeps the 64-row form
     const bool wide = !hist && KP <= 8 && topk_rows_per_tile() == 128;
@@ -1909,19 +2100,39 @@ int32_t launch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
     return hist ? launch_sweep_ep<KP, NCB, true, 2>(h, p) : launch_sweep_ep<KP, NCB, false, 2>(h, p);
 }
 
-int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool hist) {
+int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool hist, bool sym = false) {
     switch (h->kp) {
         case 1: return launch_sweep<1, kNcbMain>(h, p, hist);
-        case 2: return launch_sweep<2, kNcbMain>(h, p, hist);
+        case 2: return launch_sweep<2, kNcbMain>(h, p, hist, sym);
         case 3: return launch_sweep<3, kNcbMain>(h, p, hist);
-        case 4: return launch_sweep<4, kNcbMain>(h, p, hist);
+        case 4: return launch_sweep<4, kNcbMain>(h, p, hist, sym);
         case 6: return launch_sweep<6, kNcbMain>(h, p, hist);
-        case 8: return launch_sweep<8, kNcbMain>(h, p, hist);
+        case 8: return launch_sweep<8, kNcbMain>(h, p, hist, sym);
         case 12: return launch_sweep<12, 1>(h, p, hist);  // 2 column blocks would spill
         case 16: return launch_sweep<16, 1>(h, p, hist);
         case 24: return launch_sweep<24, 1>(h, p, hist);
     }
     return fail(GORSE_ERR_INVALID, "unsupported operand depth %d", h->kp);
+}
+
+// SYM: the pilot's thresholds as the main sweep's foreign side uses them.  A query the pilot could not give a threshold (-inf)
+// would make every column of every block a foreign candidate: it gets +inf instead -- nothing is collected for it, neither by
+// its own workgroup nor by the others -- and the flag that sends it to the tie path's sweep from -inf.  raw = the form the
+// RAWF test compares raw scores with (topk_sweep_kernel's raw_threshold), or null.
+__global__ void sym_thresholds_kernel(float *__restrict__ f0, float *__restrict__ raw, uint8_t *__restrict__ cflag, int64_t n,
+                                      float rs_min, float rs_max) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        float f = f0[t];
+        if (f == -__builtin_inff()) {
+            f = __builtin_inff();
+            f0[t] = f;
+            cflag[t] = 2;
+        }
+        if (raw) {
+            const float q = f / (f > 0.0f ? rs_max : rs_min);
+            raw[t] = fabsf(q) == __builtin_inff() ? q : q - fabsf(q) * 2.4e-7f;
+        }
+    }
 }
 
 __global__ void fill_kernel(float *__restrict__ out, int64_t n, float v) {
@@ -2116,6 +2327,10 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         // the value is 1 or NaN) the bound is the score itself
         sp.rs_min = h->metric == GORSE_METRIC_COSINE ? h->rs_min : 1.0f;
         sp.rs_max = h->metric == GORSE_METRIC_COSINE ? h->rs_max : 1.0f;
+        sp.sym_q0 = 0;
+        sp.frow = sp.frow_raw = nullptr;
+        sp.fbuf = nullptr;
+        sp.fcnt = nullptr;
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
         // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
         // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
@@ -2157,7 +2372,29 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot's flags say nothing about the query
             sp.f0 = h->f0.p;
         }
-        GORSE_TRY(dispatch_sweep(h, sp, false));
+        // The symmetric form (topk_sweep_kernel, SYM): the queries are a contiguous range of the stored rows that starts on a tile
+        // boundary, the sweep is warm-started (a foreign workgroup cannot tighten a threshold: it needs a good one from the start)
+        // and there are at least two query blocks.  Variant bit 23 switches it off (the square sweep: tests, ablation).
+        const int64_t sym_q0 = q_contig_begin + c0;
+        const bool sym = warm && contiguous && !(g_topk_variant & (1 << 23)) && sweep_sym_kp(h->kp) && topk_rows_per_tile() == 128 &&
+                         sym_q0 % 128 == 0 && m >= 2 * 32 * kNcbMain * kWavesMain && sp.probe == 0 && !sp.prof;
+        h->last_sym = sym;
+        if (sym) {
+            GORSE_TRY(h->fbuf.ensure((size_t)mb * kCapF));
+            GORSE_TRY(h->fcnt.ensure((size_t)mb));
+            const bool rawf = sp.ep == EP_COARSE;
+            if (rawf) GORSE_TRY(h->f0raw.ensure((size_t)mb));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->fcnt.p, 0, (size_t)m * 4, h->stream));
+            sym_thresholds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
+                h->f0.p, rawf ? h->f0raw.p : nullptr, h->cflag.p, m, sp.rs_min, sp.rs_max);
+            GORSE_HIP_CHECK(hipGetLastError());
+            sp.sym_q0 = sym_q0;
+            sp.frow = h->f0.p;
+            sp.frow_raw = rawf ? h->f0raw.p : nullptr;
+            sp.fbuf = h->fbuf.p;
+            sp.fcnt = h->fcnt.p;
+        }
+        GORSE_TRY(dispatch_sweep(h, sp, false, sym));
         if (sp.probe) {  // timing probe: nothing behind the sweep is meaningful
             h->prof.end(tok, h->stream);
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -2186,7 +2423,12 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         rp.out_idx = h->res_idx.p;
         rp.out_dist = h->res_dist.p;
         rp.out_cnt = h->res_cnt.p;
-        const size_t lds = ((size_t)(1 + kGroupsPerBlock) * d + 2 * kCap + 4) * 4;
+        rp.fbuf = sym ? h->fbuf.p : nullptr;
+        rp.fcnt = sym ? h->fcnt.p : nullptr;
+        rp.f0 = sym ? h->f0.p : nullptr;
+        rp.qmargin = h->qmargin.p;
+        rp.kth = kth;
+        const size_t lds = ((size_t)(1 + kGroupsPerBlock) * d + 2 * kCapT + 4) * 4;
         tok = h->prof.begin(GORSE_PROF_TOPK_SELECT, h->stream);
         topk_rescore_kernel<<<dim3((unsigned)m), dim3(kBlock), lds, h->stream>>>(rp);
         GORSE_HIP_CHECK(hipGetLastError());

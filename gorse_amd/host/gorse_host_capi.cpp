@@ -7,6 +7,7 @@
 #include "gorse_cf.hpp"
 #include "gorse_vectors.hpp"
 #include "../csrc/rank_keys.hpp"
+#include "../csrc/topk_sym.hpp"
 
 using namespace gorse;
 
@@ -879,6 +880,30 @@ void gh_test_rank_key(int32_t what, const float *x, int64_t n, uint32_t *out_u32
         default: out_u32[i] = (uint32_t)rk::key_row(rk::make_key(rk::score_ord(x[i]), (int32_t)i)); break;
         }
     }
+}
+// CPU test hook for the symmetric all-pairs sweep's tile schedule (csrc/topk_sym.hpp, the very header the kernel includes):
+// cover[q * n + r] += 1 for every (query q, row r) pair the workgroups of an all-pairs sweep over n rows (queries = the rows
+// q0 .. q0 + nq) score -- by a workgroup's own columns (every tile it multiplies) or along the rows of a transposed tile, for the
+// columns that emit.  Returns the number of row tiles all workgroups multiplied.
+int64_t gh_test_topk_sym_cover(int64_t n, int64_t q0, int64_t nq, int32_t tile_rows, int32_t bq, int32_t *cover) {
+    const int64_t all_tiles = (n + tile_rows - 1) / tile_rows;
+    const int64_t blocks = (nq + bq - 1) / bq;
+    int64_t multiplied = 0;
+    for (int64_t blk = 0; blk < blocks; blk++) {
+        const gorse::SymSchedule s(q0, nq, tile_rows, bq, blk);
+        const int64_t nt = s.tiles(all_tiles);
+        multiplied += nt;
+        for (int64_t tl = 0; tl < nt; tl++) {
+            const int64_t tile = s.tile_index(tl);
+            for (int64_t r = tile * tile_rows; r < (tile + 1) * tile_rows && r < n; r++)
+                for (int64_t c = blk * bq; c < (blk + 1) * bq; c++) {
+                    if (c < nq) cover[c * n + r] += 1;  // the column's own list
+                    if (s.transposed(tile) && gorse::SymSchedule::column_emits(q0, nq, tile_rows, c))
+                        cover[(r - q0) * n + (q0 + c)] += 1;  // the row's query, candidate = the column's row
+                }
+        }
+    }
+    return multiplied;
 }
 // the 64-bit sparse ranking key itself, and the number of results the reference returns (xvec.go:379-446)
 uint64_t gh_test_sparse_key(float score, int32_t row) { return gorse::rank::make_key(gorse::rank::score_ord(score), row); }

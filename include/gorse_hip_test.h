@@ -44,6 +44,10 @@ void gorse_hip_test_set_topk_variant(int32_t variant);
  * rows, bit 10 (1024) gives the pilot a kth of 2 so that most warm starts fail their verification.  This returns how many
  * queries of the last search failed it and were swept again from -inf. */
 int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n /*out*/);
+/* variant bit 23 (1 << 23) switches the symmetric form of an all-pairs sweep off (the square sweep of rounds 1-4; the symmetric
+ * form is taken when the queries are a contiguous range of the stored rows that starts on a 128-row boundary, the sweep is
+ * warm-started, and the operands are 32 / 64 / 128 bf16 values deep).  This returns whether the last search's main sweep took it. */
+int32_t gorse_hip_test_topk_last_symmetric(gorse_topk *h, int32_t *sym /*out*/);
 /* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its sixteen
  * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the
  * candidate paths inside [1], [3] barrier wait, then [4] row blocks examined, [5] row blocks with a candidate, [6]

@@ -364,3 +364,75 @@ def test_admissibility_mask(oracle, metric, path):
     t.set_mask(None)
     again = t.all_pairs(k)
     assert np.array_equal(again[0], plain[0]) and np.array_equal(bits(again[1]), bits(plain[1]))
+
+
+SYM_OFF = 1 << 23
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_COSINE, capi.METRIC_NEG_DOT, capi.METRIC_EUCLIDEAN])
+@pytest.mark.parametrize("dtype,d,norms", [(capi.DTYPE_BF16, 128, "unit"), (capi.DTYPE_BF16, 128, "skewed"), (capi.DTYPE_BF16, 64, "skewed"),
+                                           (capi.DTYPE_BF16, 32, "unit"), (capi.DTYPE_F32, 40, "skewed")])
+def test_symmetric_sweep_equals_the_square_sweep(oracle, metric, dtype, d, norms):
+    """An all-pairs search whose queries are a contiguous range of the stored rows takes the symmetric form of the sweep
+    (topk_sweep_kernel<..., SYM>: a workgroup skips the row tiles of later query blocks and reads the tiles of earlier ones along
+    their rows, for those rows' foreign lists).  Rows, distance bits and counts must equal the square sweep's (variant bit 23) for
+    every query range -- all rows, a range that starts and ends inside the index, one that ends inside a tile -- with every
+    epilogue (cosine with equal norms: raw-score thresholds; skewed norms: scaled scores; Euclidean: biased scores), duplicates
+    (ties: the history sweep answers them) and a mask; and equal the oracle's on a sample."""
+    rng = np.random.default_rng(9000 + 10 * d + metric)
+    N, k = 20000 + 77, 30
+    Xf = rng.standard_normal((N, d)).astype(np.float32)
+    if norms == "unit":
+        Xf /= np.linalg.norm(Xf, axis=1, keepdims=True)
+    else:
+        Xf *= rng.uniform(0.4, 2.5, (N, 1)).astype(np.float32)
+    Xf[700:730] = Xf[3]      # duplicates across query blocks
+    Xf[15000] = Xf[3]
+    X = to_bf16(Xf) if dtype == capi.DTYPE_BF16 else Xf
+    Xe = from_bf16(X) if dtype == capi.DTYPE_BF16 else Xf
+    t = capi.TopK(X, metric, dtype=dtype)
+    for (q0, q1) in ((0, N), (1024, N), (0, 12000), (2560, 17011)):
+        capi.lib().gorse_hip_test_set_topk_variant(WARM_ALWAYS | SYM_OFF)
+        i_sq, d_sq = t.all_pairs(k, q0, q1)
+        assert not t.last_symmetric()
+        capi.lib().gorse_hip_test_set_topk_variant(WARM_ALWAYS)
+        i_sy, d_sy = t.all_pairs(k, q0, q1)
+        assert t.last_symmetric(), (q0, q1)
+        n_fb, n_tie = t.last_stats()
+        assert n_fb <= 64, "the symmetric sweep handed %d queries to the scan" % n_fb
+        assert np.array_equal(i_sy, i_sq), (q0, q1, np.argwhere((i_sy != i_sq).any(1))[:5])
+        assert np.array_equal(bits(d_sy), bits(d_sq)), (q0, q1)
+        qs = np.concatenate([np.arange(q0, q1, 1777), [q0, q1 - 1]])
+        qs = np.unique(np.concatenate([qs, [q for q in (3, 700, 729, 15000) if q0 <= q < q1]])).astype(np.int64)
+        check_rows(oracle, Xe, metric, qs, k, i_sy[qs - q0], d_sy[qs - q0])
+    # a query range that does not start on a tile boundary takes the square sweep
+    t.all_pairs(k, 100, 9000)
+    assert not t.last_symmetric()
+    # with a mask: masked rows are nobody's candidates, but they are still queries
+    mask = (rng.random(N) < 0.6).astype(np.uint8)
+    t.set_mask(mask)
+    capi.lib().gorse_hip_test_set_topk_variant(WARM_ALWAYS | SYM_OFF)
+    i_sq, d_sq = t.all_pairs(k)
+    capi.lib().gorse_hip_test_set_topk_variant(WARM_ALWAYS)
+    i_sy, d_sy = t.all_pairs(k)
+    assert t.last_symmetric()
+    assert np.array_equal(i_sy, i_sq) and np.array_equal(bits(d_sy), bits(d_sq))
+    assert mask[i_sy[i_sy >= 0]].all()
+
+
+def test_symmetric_sweep_with_overflowing_foreign_lists(oracle):
+    """900 copies of one vector: every copy is a candidate of every other copy, so the foreign lists of the copies overflow and the
+    staging areas of the workgroups fill inside one block -- those queries are flagged and answered by the tie path; everybody
+    else's rows are untouched."""
+    rng = np.random.default_rng(12)
+    N, d, k = 24000, 64, 20
+    Xf = rng.standard_normal((N, d)).astype(np.float32)
+    Xf[5000:5900] = Xf[17]
+    Xb = to_bf16(Xf)
+    Xe = from_bf16(Xb)
+    t = capi.TopK(Xb, capi.METRIC_NEG_DOT, dtype=capi.DTYPE_BF16)
+    capi.lib().gorse_hip_test_set_topk_variant(WARM_ALWAYS)
+    idx, dist = t.all_pairs(k)
+    assert t.last_symmetric()
+    qs = np.array([0, 17, 18, 4999, 5000, 5450, 5899, 5900, 12345, N - 1])
+    check_rows(oracle, Xe, capi.METRIC_NEG_DOT, qs, k, idx[qs], dist[qs])
