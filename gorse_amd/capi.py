@@ -101,6 +101,9 @@ SIGNATURES = {
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
     "gorse_hip_test_topk_last_symmetric": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
+    "gorse_hip_test_topk_sym_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
+    "gorse_hip_test_topk_get_thresholds": (C.c_int32, [_vp, _f32p, C.c_int64]),
+    "gorse_hip_test_topk_get_pilot_state": (C.c_int32, [_vp, C.POINTER(C.c_uint8), _i32p, C.c_int64]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_head": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_table": (None, [C.c_int32]),
@@ -390,6 +393,21 @@ class TopK:
         n = C.c_int64(0)
         check(lib().gorse_hip_test_topk_resweeps(self.h, C.byref(n)))
         return n.value
+
+    def pilot_state(self, n):
+        f, c = np.empty(n, np.uint8), np.empty(n, np.int32)
+        check(lib().gorse_hip_test_topk_get_pilot_state(self.h, f.ctypes.data_as(C.POINTER(C.c_uint8)), c.ctypes.data_as(_i32p), n))
+        return f, c
+
+    def warm_thresholds(self, n):
+        out = np.empty(n, np.float32)
+        check(lib().gorse_hip_test_topk_get_thresholds(self.h, out.ctypes.data_as(_f32p), n))
+        return out
+
+    def sym_stats(self):
+        out = (C.c_uint64 * 4)()
+        check(lib().gorse_hip_test_topk_sym_stats(self.h, out))
+        return [int(x) for x in out]
 
     def last_symmetric(self):
         s = C.c_int32(0)

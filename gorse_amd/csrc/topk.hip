@@ -591,6 +591,38 @@ extern "C" int32_t gorse_hip_test_topk_last_symmetric(gorse_topk *h, int32_t *sy
     return GORSE_OK;
 }
 
+// probe: the four counters of the last symmetric search: queries the pilot left without a threshold, warm starts the rescoring could
+// not verify, foreign lists that overflowed, hits beyond a wave's staging area
+extern "C" int32_t gorse_hip_test_topk_sym_stats(gorse_topk *h, uint64_t *out4) {
+    if (!h || !out4) return fail(GORSE_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < 4; i++) out4[i] = 0;
+    if (h->sym_stats.n < 4) return GORSE_OK;
+    GORSE_TRY(h->use());
+    GORSE_HIP_CHECK(hipMemcpyAsync(out4, h->sym_stats.p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+// probe: the warm-start thresholds of the last search's last chunk (n of them, as the pilot -- or, for a symmetric sweep,
+// sym_thresholds_kernel -- left them)
+extern "C" int32_t gorse_hip_test_topk_get_thresholds(gorse_topk *h, float *out, int64_t n) {
+    if (!h || !out) return fail(GORSE_ERR_INVALID, "NULL argument");
+    if ((int64_t)h->f0.n < n) return fail(GORSE_ERR_INVALID, "no warm start of that size has run on this handle");
+    GORSE_TRY(h->use());
+    GORSE_HIP_CHECK(hipMemcpyAsync(out, h->f0.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+// probe (variant bit 24): the pilot's per-query flags and list lengths
+extern "C" int32_t gorse_hip_test_topk_get_pilot_state(gorse_topk *h, uint8_t *flags, int32_t *counts, int64_t n) {
+    if (!h || !flags || !counts) return fail(GORSE_ERR_INVALID, "NULL argument");
+    if ((int64_t)h->dbg_flags.size() < n) return fail(GORSE_ERR_INVALID, "no pilot-only search of that size has run on this handle");
+    memcpy(flags, h->dbg_flags.data(), (size_t)n);
+    memcpy(counts, h->dbg_counts.data(), (size_t)n * 4);
+    return GORSE_OK;
+}
+
 // test hook: 0 = automatic path choice, 1 = path A only (literal scan), 2 = path B whenever its operands exist
 extern "C" void gorse_hip_test_set_topk_path(int32_t path) { gorse::g_topk_force_path = path; }
 extern "C" void gorse_hip_test_set_topk_variant(int32_t v) { gorse::g_topk_variant = v; }

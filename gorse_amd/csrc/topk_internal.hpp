@@ -61,7 +61,11 @@ struct gorse_topk {
     gorse::DevBuf<uint2> fbuf;
     gorse::DevBuf<int32_t> fcnt;
     gorse::DevBuf<float> f0raw;
+    gorse::DevBuf<unsigned long long> sym_stats;  // counters of the last symmetric search (gorse_hip_test_topk_sym_stats)
     bool last_sym = false;
+    unsigned long long sym_unset_before = 0;  // sym_stats[0] before the current chunk's pilots
+    std::vector<uint8_t> dbg_flags;   // probe (variant bit 24): the pilot's flags and list lengths of the last chunk
+    std::vector<int32_t> dbg_counts;
     int32_t use() const {
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return gorse::fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));

@@ -83,7 +83,7 @@ constexpr size_t sweep_fixed_bytes(int bq) { return (size_t)5 * bq * 4 + 64; }
 constexpr int kStageCap = 128;      // staged foreign candidates per wave
 constexpr int kStageFlushAt = 64;   // a wave empties its staging area once it holds this many
 constexpr size_t sweep_sym_bytes(int rb, int wv, bool sym) { return sym ? (size_t)2 * 32 * rb * 4 : 0; }  // per tile buffer
-constexpr size_t sweep_stage_bytes(int wv, bool sym) { return sym ? (size_t)wv * kStageCap * 8 : 0; }
+constexpr size_t sweep_stage_bytes(int wv, bool sym) { return sym ? (size_t)wv * kStageCap * 8 + 64 : 0; }  // + 4 x kMaxRB block minima
 constexpr int sweep_bufs(int kp, int rb, int bq, int wv, bool hist, bool sym = false) {
     if (sweep_dma(kp, hist, rb, wv))
         return 4 * (sweep_tile_bytes(kp, rb, true) + sweep_sym_bytes(rb, wv, sym)) + sweep_fixed_bytes(bq) + sweep_stage_bytes(wv, sym) <= (size_t)156 * 1024 ? 4 : 3;
@@ -146,14 +146,19 @@ struct SweepParams {
     const float *frow_raw; // RAWF: their raw-score form (raw_threshold of frow)
     uint2 *fbuf;           // nq x kCapF foreign lists
     int32_t *fcnt;         // nq entries appended to them (may exceed kCapF: the list then overflowed)
+    unsigned long long *sym_stats;  // [0] queries without a pilot threshold, [1] warm starts the rescoring could not verify, [2] foreign
+                                    // lists that overflowed, [3] (query, block) hits beyond a wave's staging area
+    int sym_probe;         // timing probes of the symmetric sweep (results are garbage): 1 = no tile is read along its rows, 2 = the
+                           // block and row tests run but a hit does nothing, 3 = hits are staged but never flushed
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
 // HIST: the entries the new threshold drops are appended to the query's history (hb, counter s_hc[ql]) instead of
 // being forgotten; list + history then hold every vector the reference's heap can have accepted.
 // SYM: the list holds only the rows of the workgroup's OWN part of the sweep (the rest of the query's candidates are in its
-// foreign list), so a list shorter than kth proves nothing about the threshold either way: it is kept as it is, and the
-// warm start is verified over both lists by topk_rescore_kernel.
+// foreign list), so what it proves about the warm start is one-sided: a K-th-best bound that clears the threshold verifies it
+// (the own rows are a subset of all rows) and raises it; one that does not proves nothing -- the warm start is then verified over
+// both lists by topk_rescore_kernel, which learns from the final threshold (f_out) whether the sweep ever raised it.
 template <bool HIST, bool SYM = false>
 __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s_cnt, float *s_f, const float *s_mg,
                                               uint8_t *flag, uint2 *hb = nullptr, int *s_hc = nullptr) {
@@ -208,8 +213,14 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
             if (c >= kth) prefix = trial;
         }
         newf = fkey_inv(prefix) - s_mg[ql];
-    } else if (SYM) {
+    }
+    // SYM: the own list is a PART of the query's candidates, so its K-th best says nothing against the warm start: a bound
+    // below the current threshold (or no bound at all) leaves threshold and list as they are
+    if (SYM && newf <= s_f[ql]) {
         newf = s_f[ql];
+        // nothing will be dropped: the next attempt waits for 64 more entries (s_hc, unused without HIST, holds the list length that
+        // allows it) instead of following every append
+        if (lane == 0) s_hc[ql] = n + 64;
     }
     if (newf < s_f[ql]) {
         // Only a warm-started threshold can be above what the list proves (thresholds derived from the list never fall):
@@ -322,6 +333,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     // have finished reading one
     int *s_sync = s_hc + BQ;
     uint2 *s_stage = reinterpret_cast<uint2 *>(s_sync + 16);  // SYM: kWaves x kStageCap staged foreign candidates
+    float *s_fmin = reinterpret_cast<float *>(s_stage + kWaves * kStageCap);  // SYM: per tile buffer and 32-row block the smallest row threshold
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int cblk = SYM ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;  // SYM: longest workgroups first
@@ -521,6 +533,18 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         asm volatile("" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    // SYM: the waves that moved the rows' thresholds (64 rows each) leave the smallest one of every 32-row block next to them, before
+    // they announce the tile: a block whose largest score stays below it needs no row-by-row test (LDS runs a wave's operations in order)
+    auto landed = [&](int b) {
+        if constexpr (SYM) {
+            if (wi < RSW) {
+                float v = (RAWF_ ? s_fqr : s_fq)[b * kTR + wi * 64 + lane];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+                if ((lane & 31) == 0) s_fmin[b * kMaxRB + wi * 2 + (lane >> 5)] = v;
+            }
+        }
+    };
 
     // The waves of a workgroup share every tile but do not march in step: a wave that takes the candidate path
     // used to hold the other seven at the tile's barrier -- 27 % of the sweep (profiles/r02_f_probe_topk_prof.txt).  With NBUF
@@ -550,6 +574,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         if (grp == 0 && NT > 0) {
             dma_tile(0, 0);
             dma_wait(0);
+            landed(0);
             post(&s_sync[0]);
         }
         if (grp == 1 && NT > 1) dma_tile(1, 1);  // announced at the top of tile 0
@@ -558,6 +583,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         if (NT > 1) dma_tile(1, 1);
         if (NT > 0) {
             dma_wait(NT > 1 ? 1 : 0);  // tile 0 has landed (tile 1 may be in flight)
+            landed(0);
             post(&s_sync[0]);
         }
     } else {
@@ -673,6 +699,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                     c_land += now - ti;
                     ti = now;
                 }
+                landed(nb);
                 post(&s_sync[nb]);
                 if (PROF) c_post += __builtin_amdgcn_s_memtime() - ti;
             }
@@ -705,6 +732,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                     c_land += now - ti;
                     ti = now;
                 }
+                landed(nb);
                 post(&s_sync[nb]);
                 if (PROF) c_post += __builtin_amdgcn_s_memtime() - ti;
             }
@@ -740,7 +768,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         }
         const int64_t base_row = tile_index(t) * stride_rows;
         // SYM: a tile of an earlier query block is read along its rows too (wave-uniform)
-        const bool trans = SYM && sched.transposed(tile_index(t));
+        const bool trans = SYM && sched.transposed(tile_index(t)) && p.sym_probe != 1;
         // register staging zero-fills the rows past N; their scores are set to NaN below.  The DMA sweeps need nothing: the
         // row values of those rows are NaN
         const int valid = DMA ? kTR : (int)std::min<int64_t>(kTR, p.N - base_row);
@@ -827,6 +855,13 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                         const float4 *t4 = reinterpret_cast<const float4 *>((RAWF ? s_fqr : s_fq) + buf * kTR + rb * 32);
                         const float cv = csv[cb];
                         auto col_score = [&](float raw) -> float { return EP == EP_BIAS ? raw + cv : raw * cv; };
+                        // first the block's largest score against the smallest threshold of its 32 rows (landed): most blocks end here
+                        const float fmin_blk = s_fmin[buf * kMaxRB + rb];
+                        float mq[4];
+#pragma unroll
+                        for (int g = 0; g < 4; g++) mq[g] = max2f(max3f(acc[cb][4 * g], acc[cb][4 * g + 1], acc[cb][4 * g + 2]), acc[cb][4 * g + 3]);
+                        const float mraw = max2f(max3f(mq[0], mq[1], mq[2]), mq[3]);
+                        if (__builtin_amdgcn_ballot_w64((RAWF ? mraw : col_score(mraw)) >= fmin_blk) != 0) {
                         // sixteen differences and their maxima by quad (the compiler turns a chain of sixteen compares into a bit mask
                         // built from v_cndmask / shifts, five instructions per score); a NaN score (a column that must not emit)
                         // is skipped by the hardware maximum, -0 from a flushed difference only opens the exact test below
@@ -841,7 +876,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                             qd[g] = max2f(max3f(a0 - th.x, a1 - th.y, a2 - th.z), a3 - th.w);
                         }
                         const float dm = max2f(max3f(qd[0], qd[1], qd[2]), qd[3]);
-                        if (__builtin_amdgcn_ballot_w64(dm >= 0.0f) != 0) {
+                        if (__builtin_amdgcn_ballot_w64(dm >= 0.0f) != 0 && p.sym_probe != 2) {
                             const float4 *f4 = reinterpret_cast<const float4 *>(s_fq + buf * kTR + rb * 32);
                             const uint32_t colw = (uint32_t)(w * QW + cb * 32 + (lane & 31)) << 20;  // the column inside the workgroup's block
                             uint2 *stg = s_stage + w * kStageCap;
@@ -864,11 +899,18 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                                             stage_n += c;
                                         } else if (pass) {
                                             p.cflag[rowq] = 1;  // more hits in one block than the staging area holds: that query takes the tie path
+                                            atomicAdd(p.sym_stats + 3, 1ull);
                                         }
                                     }
                                 }
                             }
-                            if (stage_n >= kStageFlushAt) flush_stage();
+                            if (stage_n >= kStageFlushAt) {
+                                if (p.sym_probe == 3)
+                                    stage_n = 0;
+                                else
+                                    flush_stage();
+                            }
+                        }
                         }
                     }
                 }
@@ -978,6 +1020,10 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                             const int l = __builtin_ctzll(need);
                             need &= need - 1;
                             const int qlc = w * QW + cb * 32 + l;
+                            // (see compact_query; a sub-list holds kCap / 2 entries and a block adds at most 16 to one)
+                            if (SYM && s_cnt[2 * qlc] + s_cnt[2 * qlc + 1] < s_hc[qlc] && s_cnt[2 * qlc] <= kCap / 2 - 32 &&
+                                s_cnt[2 * qlc + 1] <= kCap / 2 - 32)
+                                continue;
                             compact_query<HIST, SYM>(p.cbuf + (qslice + wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg,
                                                 p.cflag + qslice + wgq0 + qlc,
                                                 HIST ? p.hbuf + (qslice + wgq0 + qlc) * kHistCap : nullptr, s_hc);
@@ -1088,6 +1134,8 @@ struct RescoreParams {
     const uint2 *fbuf;     // nq x kCapF, or null
     const int32_t *fcnt;
     const float *f0;       // the thresholds the main sweep started from
+    const float *ffinal;   // the thresholds its workgroups ended with (above f0: raised, hence verified, by the own list)
+    unsigned long long *sym_stats;  // (SweepParams)
     const float *qmargin;
     int kth;
 };
@@ -1097,10 +1145,11 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     const int d = p.d;
     float *sq = smem_f;                          // d
-    float *sx = sq + d;                          // kGroupsPerBlock * d
-    float *s_e = sx + (size_t)kGroupsPerBlock * d;  // kCapT
+    float *sx = sq + d;                          // 2 * kGroupsPerBlock * d
+    float *s_e = sx + (size_t)2 * kGroupsPerBlock * d;  // kCapT
     int *s_i = reinterpret_cast<int *>(s_e + kCapT);  // kCapT
-    int *s_misc = s_i + kCapT;                   // [0] nonpositive in top-k, [1] flag, [2] SYM: candidates that clear the warm start
+    int *s_misc = s_i + kCapT;                   // [0] nonpositive in top-k, [1] flag, [2] SYM: candidates that clear the warm start,
+                                                 // [3], [4] the histogram selection's bin and remainder, [5] survivors of the pruning
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
     const int k = p.k;
@@ -1108,49 +1157,133 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     const int n_own = p.ccnt[t];
     const int n_for = p.fbuf ? p.fcnt[t] : 0;
     if (n_for > kCapF) {  // the foreign list overflowed: the tie path sweeps this query on its own
-        if (tid == 0) p.cflag[t] = 1;
+        if (tid == 0) {
+            p.cflag[t] = 1;
+            atomicAdd(p.sym_stats + 2, 1ull);
+        }
         return;
     }
-    const int n = n_own + n_for;
+    const int n_all = n_own + n_for;
     const uint2 *fb = p.fbuf ? p.fbuf + t * kCapF : nullptr;
     const int64_t self = p.Qf ? -1 : (p.qid ? p.qid[t] : p.q0 + t);
     const float *qrow = p.Qf ? p.Qf + t * d : p.X + self * d;
     for (int e = tid; e < d; e += kBlock) sq[e] = qrow[e];
-    if (tid < 3) s_misc[tid] = 0;
+    if (tid < 6) s_misc[tid] = 0;
     __syncthreads();
     const VecShape vs(d);
     const float qq = p.metric == GORSE_METRIC_COSINE ? p.qn2[t] : 0.0f;
     const uint2 *cb = p.cbuf + t * kCap;
-    // SYM: a warm start that the query's own list could not verify (fewer than kth entries: its workgroup saw only part of the
-    // rows) is verified here over both lists -- the threshold f0 is valid iff (kth-th best approximate score) - margin >= f0, and
-    // with the own threshold still at f0 the two lists hold every row that reaches f0.  (An own list of kth entries and more was
-    // verified by the sweep's last compaction; f0 = -inf needs no proof.)
-    const bool verify = p.fbuf && n_own < p.kth && p.f0[t] > -__builtin_inff();
+    // the candidates into registers: kCapT / kBlock per thread
+    constexpr int EPT = kCapT / kBlock;
+    uint32_t ekey[EPT], eidx[EPT];
+    bool ev[EPT];
+#pragma unroll
+    for (int s = 0; s < EPT; s++) {
+        const int c = tid + s * kBlock;
+        ev[s] = c < n_all;
+        const uint2 ent = ev[s] ? (c < n_own ? cb[c] : fb[c - n_own]) : make_uint2(0u, 0u);
+        ekey[s] = ent.x;
+        eidx[s] = ent.y;
+    }
+    // SYM: a warm start that the query's own list could not verify is verified here over both lists -- the threshold f0 is valid
+    // iff (kth-th best approximate score) - margin >= f0, and with the own threshold still at f0 the two lists hold every row that
+    // reaches f0.  (A final own threshold above f0 was derived from -- and verified by -- the own list; f0 = -inf needs no proof.)
+    const float mg = p.qmargin[t];
+    const bool verify = p.fbuf && p.f0[t] > -__builtin_inff() && !(p.ffinal[t] > p.f0[t]);
     if (verify) {
-        const float f0 = p.f0[t], mg = p.qmargin[t];
+        const float f0 = p.f0[t];
         int c_ok = 0;
-        for (int c = tid; c < n; c += kBlock) c_ok += fkey_inv((c < n_own ? cb[c] : fb[c - n_own]).x) - mg >= f0;
+#pragma unroll
+        for (int s = 0; s < EPT; s++) c_ok += ev[s] && fkey_inv(ekey[s]) - mg >= f0;
         if (c_ok) atomicAdd(&s_misc[2], c_ok);
     }
-    for (int c = gib; c < n; c += kGroupsPerBlock) {
-        const int64_t i = (c < n_own ? cb[c] : fb[c - n_own]).y;
-        float *row = sx + (size_t)gib * d;
-        gather_row(row, p.X, p.Xb, i, d, lane);
+    // Pruning by the approximate scores (round 5): only a row whose approximate score reaches (kth-th best approximate score of the
+    // lists) - margin can be among the kth best in exact arithmetic -- the sweep's own rule, applied once more to what the lists hold
+    // at the end (thresholds frozen for the foreign side, never tightened for a short own part: ~270 entries at C4, ~110 of which
+    // pass) -- so the exact distances, whose gathers are this kernel's time, and the sort are those of the survivors.  The kth-th
+    // largest key's 16 leading bits (a lower bound, as in compact_query) by two 256-bin histograms in LDS.
+    int *s_h = reinterpret_cast<int *>(s_e);  // 256 bins (s_e is written later)
+    float thr = -__builtin_inff();
+    if (n_all >= p.kth && n_all > p.kth + 8) {  // uniform
+        uint32_t prefix = 0;
+        int need = p.kth;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
+            s_h[tid] = 0;  // kBlock == 256 bins
+            __syncthreads();
+            const int sh = pass == 0 ? 24 : 16;
+#pragma unroll
+            for (int s = 0; s < EPT; s++)
+                if (ev[s] && (pass == 0 || (ekey[s] >> 24) == (prefix >> 24))) atomicAdd(&s_h[(ekey[s] >> sh) & 255u], 1);
+            __syncthreads();
+            if (tid < 64) {  // bins in DESCENDING order: position 4 tid + j is bin 255 - (4 tid + j)
+                int c[4], tot = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    c[j] = s_h[255 - (4 * tid + j)];
+                    tot += c[j];
+                }
+                int incl = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (tid >= o) incl += v;
+                }
+                int acc = incl - tot;
+                if (acc < need && incl >= need) {  // exactly one lane
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (acc < need && acc + c[j] >= need) {
+                            s_misc[3] = 255 - (4 * tid + j);
+                            s_misc[4] = need - acc;
+                        }
+                        acc += c[j];
+                    }
+                }
+            }
+            __syncthreads();
+            prefix |= (uint32_t)s_misc[3] << sh;
+            need = s_misc[4];
+            __syncthreads();
+        }
+        thr = fkey_inv(prefix) - mg;
+    } else {
+        __syncthreads();
+    }
+    // the survivors' row ids, packed (any order)
+#pragma unroll
+    for (int s = 0; s < EPT; s++)
+        if (ev[s] && fkey_inv(ekey[s]) >= thr) s_i[atomicAdd(&s_misc[5], 1)] = (int)eidx[s];
+    __syncthreads();
+    const int n = s_misc[5];
+    // exact distances, two candidates per 16-lane group and step (their gathers in flight together: the loop is latency-bound)
+    for (int c0 = gib; c0 < n; c0 += 2 * kGroupsPerBlock) {
+        const int c1 = c0 + kGroupsPerBlock;
+        const bool two = c1 < n;
+        const int64_t i0 = s_i[c0], i1 = s_i[two ? c1 : c0];
+        float *row0 = sx + (size_t)gib * d, *row1 = sx + (size_t)(kGroupsPerBlock + gib) * d;
+        gather_row(row0, p.X, p.Xb, i0, d, lane);
+        gather_row(row1, p.X, p.Xb, i1, d, lane);
         __builtin_amdgcn_wave_barrier();
-        float r;
-        if (p.metric == GORSE_METRIC_EUCLIDEAN || p.metric == kMetricEuclidBf16) {
-            r = euclid_any_lds(p.metric, sq, row, vs, lane);
-        } else {
-            const float ab = dot512_lds(sq, row, vs, lane);
-            if (p.metric == GORSE_METRIC_NEG_DOT)
-                r = -ab;
-            else
-                r = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+        float r[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const float *row = u ? row1 : row0;
+            const int64_t i = u ? i1 : i0;
+            if (p.metric == GORSE_METRIC_EUCLIDEAN || p.metric == kMetricEuclidBf16) {
+                r[u] = euclid_any_lds(p.metric, sq, row, vs, lane);
+            } else {
+                const float ab = dot512_lds(sq, row, vs, lane);
+                if (p.metric == GORSE_METRIC_NEG_DOT)
+                    r[u] = -ab;
+                else
+                    r[u] = 1.0f - ab / (sqrtf(qq) * sqrtf(p.norm2[i]));
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            s_e[c] = r;
-            s_i[c] = (int)i;
+            s_e[c0] = r[0];
+            if (two) s_e[c1] = r[1];
         }
     }
     __syncthreads();
@@ -1227,7 +1360,10 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     }
     __syncthreads();
     if (verify && s_misc[2] < p.kth) {  // the warm start was too high: swept again from -inf with the tie queries
-        if (tid == 0) p.cflag[t] = 2;
+        if (tid == 0) {
+            p.cflag[t] = 2;
+            atomicAdd(p.sym_stats + 1, 1ull);
+        }
         return;
     }
     if (s_misc[1] || top < p.expect) {  // ties, NaN, or a list that cannot hold the answer: path A
@@ -2120,7 +2256,7 @@ int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool hist, bool sym 
 // its own workgroup nor by the others -- and the flag that sends it to the tie path's sweep from -inf.  raw = the form the
 // RAWF test compares raw scores with (topk_sweep_kernel's raw_threshold), or null.
 __global__ void sym_thresholds_kernel(float *__restrict__ f0, float *__restrict__ raw, uint8_t *__restrict__ cflag, int64_t n,
-                                      float rs_min, float rs_max) {
+                                      float rs_min, float rs_max, unsigned long long *__restrict__ stats) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         float f = f0[t];
         if (f == -__builtin_inff()) {
@@ -2133,6 +2269,11 @@ __global__ void sym_thresholds_kernel(float *__restrict__ f0, float *__restrict_
             raw[t] = fabsf(q) == __builtin_inff() ? q : q - fabsf(q) * 2.4e-7f;
         }
     }
+}
+
+__global__ void pilot_unset_count_kernel(const float *__restrict__ f0, int64_t n, unsigned long long *__restrict__ stats) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        if (f0[t] == -__builtin_inff()) atomicAdd(stats + 0, 1ull);
 }
 
 __global__ void fill_kernel(float *__restrict__ out, int64_t n, float v) {
@@ -2257,6 +2398,7 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     h->n_fallback = 0;
     h->n_tie = 0;
     h->n_resweep = 0;
+    h->sym_unset_before = 0;
     std::vector<uint8_t> flags((size_t)mb);
     for (int64_t c0 = 0; c0 < nq; c0 += kChunkQ) {
         const int64_t m = std::min(kChunkQ, nq - c0);
@@ -2331,6 +2473,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         sp.frow = sp.frow_raw = nullptr;
         sp.fbuf = nullptr;
         sp.fcnt = nullptr;
+        sp.sym_stats = nullptr;
+        sp.sym_probe = (g_topk_variant >> 25) & 3;  // variant bits 25-26: timing probes of the symmetric sweep (the call returns garbage)
         // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
         // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
         // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
@@ -2369,6 +2513,15 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 p2.f0 = h->f1.p;
             }
             GORSE_TRY(dispatch_sweep(h, p2, false));
+            if (g_topk_variant & (1 << 24)) {  // probe: stop behind the pilot, keep its flags and list lengths (results are garbage)
+                h->dbg_flags.resize((size_t)m);
+                h->dbg_counts.resize((size_t)m);
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->dbg_flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->dbg_counts.data(), h->ccnt.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+                GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+                h->prof.end(tok, h->stream);
+                return GORSE_OK;
+            }
             GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot's flags say nothing about the query
             sp.f0 = h->f0.p;
         }
@@ -2376,8 +2529,25 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         // boundary, the sweep is warm-started (a foreign workgroup cannot tighten a threshold: it needs a good one from the start)
         // and there are at least two query blocks.  Variant bit 23 switches it off (the square sweep: tests, ablation).
         const int64_t sym_q0 = q_contig_begin + c0;
-        const bool sym = warm && contiguous && !(g_topk_variant & (1 << 23)) && sweep_sym_kp(h->kp) && topk_rows_per_tile() == 128 &&
-                         sym_q0 % 128 == 0 && m >= 2 * 32 * kNcbMain * kWavesMain && sp.probe == 0 && !sp.prof;
+        bool sym = warm && contiguous && !(g_topk_variant & (1 << 23)) && sweep_sym_kp(h->kp) && topk_rows_per_tile() == 128 &&
+                   sym_q0 % 128 == 0 && m >= 2 * 32 * kNcbMain * kWavesMain && sp.probe <= 1 && !sp.prof;
+        if (warm) {
+            GORSE_TRY(h->sym_stats.ensure(4));
+            if (c0 == 0) GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p, 0, 4 * sizeof(unsigned long long), h->stream));
+            pilot_unset_count_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(h->f0.p, m, h->sym_stats.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+        }
+        if (sym) {
+            // A query the pilot left without a threshold costs the symmetric form a sweep of its own (the tie path's), the square form
+            // only a cold start: where the pilot fails for many (rows sorted so that the systematic sample misleads it -- the
+            // Euclidean case of test_warm_started_sweep_returns_the_same_rows), the square sweep is the better one.  One 8-byte read
+            // behind the pilots.
+            unsigned long long unset = 0;
+            GORSE_HIP_CHECK(hipMemcpyAsync(&unset, h->sym_stats.p, sizeof(unset), hipMemcpyDeviceToHost, h->stream));
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+            if ((int64_t)(unset - h->sym_unset_before) * 32 > m) sym = false;
+            h->sym_unset_before = unset;
+        }
         h->last_sym = sym;
         if (sym) {
             GORSE_TRY(h->fbuf.ensure((size_t)mb * kCapF));
@@ -2386,16 +2556,18 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             if (rawf) GORSE_TRY(h->f0raw.ensure((size_t)mb));
             GORSE_HIP_CHECK(hipMemsetAsync(h->fcnt.p, 0, (size_t)m * 4, h->stream));
             sym_thresholds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
-                h->f0.p, rawf ? h->f0raw.p : nullptr, h->cflag.p, m, sp.rs_min, sp.rs_max);
+                h->f0.p, rawf ? h->f0raw.p : nullptr, h->cflag.p, m, sp.rs_min, sp.rs_max, h->sym_stats.p);
             GORSE_HIP_CHECK(hipGetLastError());
             sp.sym_q0 = sym_q0;
             sp.frow = h->f0.p;
             sp.frow_raw = rawf ? h->f0raw.p : nullptr;
             sp.fbuf = h->fbuf.p;
             sp.fcnt = h->fcnt.p;
+            sp.sym_stats = h->sym_stats.p;
+            sp.f_out = h->f1.p;  // the thresholds the workgroups end with: topk_rescore_kernel's verification reads them
         }
         GORSE_TRY(dispatch_sweep(h, sp, false, sym));
-        if (sp.probe) {  // timing probe: nothing behind the sweep is meaningful
+        if (sp.probe || sp.sym_probe) {  // timing probe: nothing behind the sweep is meaningful
             h->prof.end(tok, h->stream);
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
             continue;
@@ -2426,9 +2598,11 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         rp.fbuf = sym ? h->fbuf.p : nullptr;
         rp.fcnt = sym ? h->fcnt.p : nullptr;
         rp.f0 = sym ? h->f0.p : nullptr;
+        rp.ffinal = sym ? h->f1.p : nullptr;
+        rp.sym_stats = sym ? h->sym_stats.p : nullptr;
         rp.qmargin = h->qmargin.p;
         rp.kth = kth;
-        const size_t lds = ((size_t)(1 + kGroupsPerBlock) * d + 2 * kCapT + 4) * 4;
+        const size_t lds = ((size_t)(1 + 2 * kGroupsPerBlock) * d + 2 * kCapT + 8) * 4;
         tok = h->prof.begin(GORSE_PROF_TOPK_SELECT, h->stream);
         topk_rescore_kernel<<<dim3((unsigned)m), dim3(kBlock), lds, h->stream>>>(rp);
         GORSE_HIP_CHECK(hipGetLastError());

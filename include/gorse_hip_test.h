@@ -48,6 +48,13 @@ int32_t gorse_hip_test_topk_resweeps(gorse_topk *h, int64_t *n /*out*/);
  * form is taken when the queries are a contiguous range of the stored rows that starts on a 128-row boundary, the sweep is
  * warm-started, and the operands are 32 / 64 / 128 bf16 values deep).  This returns whether the last search's main sweep took it. */
 int32_t gorse_hip_test_topk_last_symmetric(gorse_topk *h, int32_t *sym /*out*/);
+/* counters of the last symmetric search: [0] queries the pilot left without a threshold (they take the tie path's sweep), [1] warm
+ * starts the rescoring could not verify over both lists, [2] foreign lists that overflowed, [3] hits beyond a wave's staging area */
+int32_t gorse_hip_test_topk_sym_stats(gorse_topk *h, uint64_t *out4 /*host*/);
+/* variant bit 24: the search stops behind the pilot sweep (results undefined); this returns the pilot's flags and list lengths */
+int32_t gorse_hip_test_topk_get_pilot_state(gorse_topk *h, uint8_t *flags /*host*/, int32_t *counts /*host*/, int64_t n);
+/* the warm-start thresholds of the last search's last chunk (the first n queries) */
+int32_t gorse_hip_test_topk_get_thresholds(gorse_topk *h, float *out /*host*/, int64_t n);
 /* variant bit 4 runs an instrumented twin of the C4-shaped sweep (d = 128 bf16, cosine); this returns its sixteen
  * counters summed over all waves: s_memtime ticks in [0] tile store + prefetch issue, [1] MFMA + epilogues, [2] the
  * candidate paths inside [1], [3] barrier wait, then [4] row blocks examined, [5] row blocks with a candidate, [6]

@@ -46,6 +46,53 @@ def main():
     print("16 rows equal the oracle's", flush=True)
     if "quick" in sys.argv[1:]:
         return
+    if "sym" in sys.argv[1:]:  # the symmetric form of the sweep against the square one: stage times, then EVERY row of both passes
+        SYM_OFF = 1 << 23
+        for rep in range(2):
+            for v, label in ((0, "symmetric sweep (default)"), (SYM_OFF, "square sweep (variant bit 23)")):
+                L.gorse_hip_test_set_topk_variant(v)
+                run(t, k, 0, nq, label, reps=2)
+                print("   main sweep symmetric: %s" % t.last_symmetric(), flush=True)
+        L.gorse_hip_test_set_topk_variant(0)
+        i_sy, d_sy = t.all_pairs(k, 0, nq)
+        st = t.last_stats()
+        print("symmetric: tie queries %d, to the scan %d, warm starts swept again %d" % (st[1], st[0], t.resweeps()), flush=True)
+        L.gorse_hip_test_set_topk_variant(SYM_OFF)
+        i_sq, d_sq = t.all_pairs(k, 0, nq)
+        st = t.last_stats()
+        print("square:    tie queries %d, to the scan %d, warm starts swept again %d" % (st[1], st[0], t.resweeps()), flush=True)
+        L.gorse_hip_test_set_topk_variant(0)
+        same_i = np.array_equal(i_sy, i_sq)
+        same_d = np.array_equal(d_sy.view(np.uint32), d_sq.view(np.uint32))
+        print("all %d rows of the two passes equal: indices %s, distance bits %s" % (nq, same_i, same_d), flush=True)
+        if not (same_i and same_d):
+            bad = np.argwhere((i_sy != i_sq).any(1) | (d_sy.view(np.uint32) != d_sq.view(np.uint32)).any(1)).ravel()
+            print("  %d rows differ, first: %s" % (bad.size, bad[:20]), flush=True)
+            for q in bad[:3]:
+                ei, ed = o.search_index(Xe, orc.METRIC_COSINE, int(q), k)
+                print("  row %d: symmetric equals the oracle %s, square equals the oracle %s" % (q, np.array_equal(i_sy[q], ei), np.array_equal(i_sq[q], ei)))
+        # a query range inside the index (what a rank of a sharded refresh runs): symmetric only inside its own square
+        for (a, b) in ((250_112, 500_096), (0, 131_072)):
+            L.gorse_hip_test_set_topk_variant(0)
+            i1, d1 = t.all_pairs(k, a, b)
+            sym = t.last_symmetric()
+            print("   range [%d, %d) symmetric %s: equal to the full pass's rows: %s" % (a, b, sym, np.array_equal(i1, i_sq[a:b]) and
+                  np.array_equal(d1.view(np.uint32), d_sq[a:b].view(np.uint32))), flush=True)
+            run(t, k, a, b, "range [%d, %d) symmetric" % (a, b), reps=2)
+            L.gorse_hip_test_set_topk_variant(SYM_OFF)
+            run(t, k, a, b, "range [%d, %d) square" % (a, b), reps=2)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
+    if "symfloor" in sys.argv[1:]:  # what the parts of the symmetric sweep cost (results are garbage: timing only)
+        run(t, k, 0, nq, "symmetric sweep", reps=2)
+        print("   counters [no pilot threshold, unverified, foreign overflow, staging overflow]: %s" % t.sym_stats(), flush=True)
+        for v, label in ((1 << 25, "no tile read along its rows"), (2 << 25, "block + row tests, a hit does nothing"), (3 << 25, "hits staged, never flushed"),
+                         (1 << 17, "no block qualifies on the column side (own thresholds +inf)"), ((1 << 17) | (1 << 25), "neither side: the symmetric floor"),
+                         ((1 << 23) | (1 << 17), "square sweep, no block qualifies")):
+            L.gorse_hip_test_set_topk_variant(v)
+            run(t, k, 0, nq, label, reps=2)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
     if "replay" in sys.argv[1:]:  # the tie replay's counters (they overwrite the sweep's)
         L.gorse_hip_test_set_topk_variant(16)
         run(t, k, 0, nq, "instrumented", reps=1)
