@@ -886,7 +886,6 @@ constexpr int kAlsDP = 65;          // LDS row stride of the per-wave M matrix
 constexpr int kAlsWaves = 4;        // waves per workgroup of the chunk kernels
 constexpr int kAlsRowWaves = 8;     // waves per workgroup of als_row_kernel: ONE workgroup per CU (2 waves per SIMD) so that its LDS
                                     // holds the 8 per-wave M buffers (133 KB) next to one copy of S (16 KB)
-constexpr int kAlsPairs = 8;        // feedback-entry pairs per pipeline stage (16 entries, 4 KB at d = 64)
 
 
 __device__ __forceinline__ float wave_sum64(float v) {
@@ -906,124 +905,8 @@ struct GramAcc {
     __device__ __forceinline__ static constexpr int tile(int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
 };
 
-// one pipeline stage: kAlsPairs entry pairs of the 64-entry index batch held in `idx` (one entry per lane)
-template <int NB>
-__device__ __forceinline__ void gram_load_stage(const float *__restrict__ B, const float *__restrict__ zeros, int idx,
-                                                int first, int d, int lane, float (&fr)[kAlsPairs][NB]) {
-    const int half = lane >> 5, col = lane & 31;
-#pragma unroll
-    for (int j = 0; j < kAlsPairs; j++) {
-        const int r0 = __builtin_amdgcn_readlane(idx, first + 2 * j);
-        const int r1 = __builtin_amdgcn_readlane(idx, first + 2 * j + 1);
-        const int r = half ? r1 : r0;
-        const float *row = B + (int64_t)r * d;
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const int e = 32 * b + col;
-            // padding lanes and entries past the row's end read a zero word instead: the select is on the
-            // ADDRESS, so every lane issues the load and no branch (with its vmcnt(0)) splits the gathers
-            const float *src = (r >= 0 && e < d) ? row + e : zeros + lane;
-            fr[j][b] = *src;
-        }
-    }
-}
-
-// The same stage when d = 32 NB and the matrix (with its zero row `zero_row` behind the last one, mf.hip) spans less than 4 GB
-// and 2^24 rows: the lane's entry comes through the LDS crossbar (ds_bpermute: one instruction instead of two v_readlane, two
-// moves and a select), its address is a 32-bit offset from the scalar base (one v_mad_u32_u24 per load instead of a 64-bit
-// multiply, two 64-bit adds and four selects), and an entry past the row's end is the zero row, not a selected address.  The
-// first form issues ~18 vector instructions per entry pair beside its three MFMAs, and the accumulation ran at 337 cycles per
-// entry against 96 of MFMA (profiles/r03_zh_probe_als_prof.txt).
-// FULL: d = 32 NB; else the lanes of columns past d read the zero row too (one select per load).
-template <int NB, bool FULL>
-__device__ __forceinline__ void gram_load_stage32(const float *__restrict__ B, uint32_t rowbytes, int idx, int first, int lane, int d,
-                                                  int zero_row, float (&fr)[kAlsPairs][NB]) {
-    const int half = lane >> 5, col = lane & 31;
-    const int sel = (first + half) * 4;  // ds_bpermute address of this half's entry of pair 0
-    const uint32_t zero_off = __umul24((uint32_t)zero_row, rowbytes);
-#pragma unroll
-    for (int j = 0; j < kAlsPairs; j++) {
-        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 8 * j, idx);
-        const uint32_t off = __umul24(r, rowbytes) + (uint32_t)col * 4u;
-        if (FULL) {
-            const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
-#pragma unroll
-            for (int b = 0; b < NB; b++) fr[j][b] = row[32 * b];  // (the block's 128 bytes: the load's immediate offset)
-        } else {
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                const uint32_t o = 32 * b + col < d ? off + 128u * b : zero_off;
-                fr[j][b] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + o);
-            }
-        }
-    }
-}
-
-// G += sum over fb[0..n) of q q^T, sum += column sums; the whole wave walks one row (or one chunk of a row)
-template <int NB, int FAST = 0>  // 0: the first form of the stage, 1: 32-bit offsets and d = 32 NB, 2: 32-bit offsets, any d
-// idx0 / idx1: lane l's entries l and 64 + l of the row as loaded by the caller (any value past the row's end)
-__device__ __forceinline__ void gram_accumulate(const float *__restrict__ B, const float *__restrict__ zeros,
-                                                const int32_t *__restrict__ fb, int n, int d, int lane,
-                                                GramAcc<NB> &g, int idx0, int idx1, int zero_row = 0) {
-#pragma unroll
-    for (int t = 0; t < GramAcc<NB>::NT; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) g.t[t][r] = 0.0f;
-#pragma unroll
-    for (int b = 0; b < NB; b++) g.sum[b] = 0.0f;
-    if (n <= 0) return;
-    const int nstages = (n + 2 * kAlsPairs - 1) / (2 * kAlsPairs);
-    constexpr int kStagesPerBatch = 64 / (2 * kAlsPairs);
-    // index batches: lane l of idx_cur holds entry 64 * batch + l (or -1 past the row's end, which makes the
-    // gathers of those entries read zeros); idx_nxt is the batch after it
-    const int past = FAST ? zero_row : -1;  // what an entry past the row's end reads: the zero row / the zeros through a select
-    int idx_cur = lane < n ? idx0 : past;
-    int idx_nxt = 64 + lane < n ? idx1 : past;
-    int loaded = 0;  // stages whose gathers have been issued
-    auto issue = [&](float (&fr)[kAlsPairs][NB]) {
-        const int sb = loaded % kStagesPerBatch;
-        if (sb == 0 && loaded > 0) {
-            idx_cur = idx_nxt;
-            const int64_t nb = (int64_t)(loaded / kStagesPerBatch + 1) * 64 + lane;
-            idx_nxt = nb < n ? fb[nb] : past;
-        }
-        if (FAST)
-            gram_load_stage32<NB, FAST == 1>(B, (uint32_t)d * 4u, idx_cur, sb * 2 * kAlsPairs, lane, d, zero_row, fr);
-        else
-            gram_load_stage<NB>(B, zeros, idx_cur, sb * 2 * kAlsPairs, d, lane, fr);
-        loaded++;
-    };
-    auto consume = [&](const float (&fr)[kAlsPairs][NB]) {
-#pragma unroll
-        for (int j = 0; j < kAlsPairs; j++) {
-#pragma unroll
-            for (int b = 0; b < NB; b++) {
-                if (FAST)  // (kept from being paired into v_pk_add_f32, which costs beside the MFMAs: MI355X_MICROARCH.md)
-                    asm("v_add_f32 %0, %1, %0" : "+v"(g.sum[b]) : "v"(fr[j][b]));
-                else
-                    g.sum[b] += fr[j][b];
-            }
-#pragma unroll
-            for (int bi = 0; bi < NB; bi++)
-#pragma unroll
-                for (int bj = bi; bj < NB; bj++)
-                    g.t[GramAcc<NB>::tile(bi, bj)] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fr[j][bi], fr[j][bj], g.t[GramAcc<NB>::tile(bi, bj)], 0, 0, 0);
-        }
-    };
-    // ping-pong: the gathers of stage s + 1 are in flight while the MFMAs of stage s run.  Stages past the
-    // end are all-zero gathers (at most two per row), which keeps every load unconditional.  (A ring of four stages -- three
-    // in flight -- changed nothing: 35.6K against 33.6K cycles of accumulation per 100-entry row, profiles/r02_z_probe_als_prof.txt;
-    // the accumulation does not wait for its gathers.)
-    float f0[kAlsPairs][NB], f1[kAlsPairs][NB];
-    issue(f0);
-    for (int s = 0; s < nstages; s += 2) {
-        issue(f1);
-        consume(f0);
-        issue(f0);
-        consume(f1);
-    }
-}
+// (Rounds 1-4 accumulated these tiles on the fp32 MFMA, v_mfma_f32_32x32x2_f32 over gathered entry pairs -- gram_accumulate, three forms of
+// its gather stage; the 16 x 16 tile forms below and the bf16 form replaced it for every shape in round 5.)
 
 // ---- the same accumulation on the bf16 MFMA, every fp32 value split three ways (d = 32 NB with the fast gather stage) --------------
 // The fp32 MFMA runs at 1/16 of the bf16 rate.  A float is EXACTLY hi + mid + lo with hi = bf16(x), mid = bf16(x - hi),
@@ -1165,23 +1048,47 @@ struct GramAcc16 {
     __device__ __forceinline__ static constexpr int tile(int bi, int bj) { return bi * NB - bi * (bi - 1) / 2 + (bj - bi); }
 };
 
-template <int NB>
+// FULL: d = 16 NB; else (round 5: any d <= 16 NB -- the reference's own test width 8 among them) the lanes of the columns past d read word
+// 0 of the zero row (one select per load, on the offset).  O64: the matrix spans 4 GB and more, or 2^24 rows: a 64-bit address per
+// entry instead of the 24 x 24-bit offset.
+template <int NB, bool FULL = true, bool O64 = false>
 __device__ __forceinline__ void gram_load_stage16(const float *__restrict__ B, uint32_t rowbytes, int idx, int first, int lane,
-                                                  float (&fr)[kAlsQuads][NB]) {
+                                                  float (&fr)[kAlsQuads][NB], int d = 16 * NB, int zero_row = 0) {
     const int slot = lane >> 4, col = lane & 15;
     const int sel = (first + slot) * 4;  // ds_bpermute address of this lane's entry of quad 0
+    if constexpr (O64) {
+        const char *zero = reinterpret_cast<const char *>(B) + (uint64_t)(uint32_t)zero_row * rowbytes;
 #pragma unroll
-    for (int j = 0; j < kAlsQuads; j++) {
-        const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 16 * j, idx);
-        const uint32_t off = __umul24(r, rowbytes) + (uint32_t)col * 4u;
-        const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
+        for (int j = 0; j < kAlsQuads; j++) {
+            const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 16 * j, idx);
+            const char *row = reinterpret_cast<const char *>(B) + (uint64_t)r * rowbytes + (uint32_t)col * 4u;
 #pragma unroll
-        for (int b = 0; b < NB; b++) fr[j][b] = row[16 * b];  // (the block's 64 bytes: the load's immediate offset)
+            for (int b = 0; b < NB; b++) fr[j][b] = *reinterpret_cast<const float *>((FULL || 16 * b + col < d) ? row + 64 * b : zero);
+        }
+    } else {
+        const uint32_t zero_off = __umul24((uint32_t)zero_row, rowbytes);
+#pragma unroll
+        for (int j = 0; j < kAlsQuads; j++) {
+            const uint32_t r = (uint32_t)__builtin_amdgcn_ds_bpermute(sel + 16 * j, idx);
+            const uint32_t off = __umul24(r, rowbytes) + (uint32_t)col * 4u;
+            if constexpr (FULL) {
+                const float *row = reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off);
+#pragma unroll
+                for (int b = 0; b < NB; b++) fr[j][b] = row[16 * b];  // (the block's 64 bytes: the load's immediate offset)
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const uint32_t o = 16 * b + col < d ? off + 64u * b : zero_off;
+                    fr[j][b] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + o);
+                }
+            }
+        }
     }
 }
 
-// idx0 / idx1, zero_row: as gram_accumulate<NB, 1>; DEEP: as gram_accumulate_b3
-template <int NB, bool DEEP = false>
+// idx0 / idx1: lane l's entries l and 64 + l of the row as loaded by the caller (any value past the row's end); zero_row: the row id of
+// the zero row behind B (what an entry past the row's end reads); DEEP: as gram_accumulate_b3
+template <int NB, bool DEEP = false, bool FULL = true, bool O64 = false>
 __device__ __forceinline__ void gram_accumulate16(const float *__restrict__ B, const int32_t *__restrict__ fb, int n, int d, int lane,
                                                   GramAcc16<NB> &g, int idx0, int idx1, int zero_row) {
 #pragma unroll
@@ -1203,7 +1110,7 @@ __device__ __forceinline__ void gram_accumulate16(const float *__restrict__ B, c
             const int64_t nb = (int64_t)(loaded / kStagesPerBatch + 1) * 64 + lane;
             idx_nxt = nb < n ? fb[nb] : zero_row;
         }
-        gram_load_stage16<NB>(B, (uint32_t)d * 4u, idx_cur, sb * 4 * kAlsQuads, lane, fr);
+        gram_load_stage16<NB, FULL, O64>(B, (uint32_t)d * 4u, idx_cur, sb * 4 * kAlsQuads, lane, fr, d, zero_row);
         loaded++;
     };
     // (Skipping the MFMAs of the padding -- a stage and a half of the eight of a 100-entry row -- behind a wave-uniform branch per quad
@@ -1274,13 +1181,13 @@ __device__ __forceinline__ void gram_foreach16(const GramAcc16<NB> &g, F &&f) {
 
 // column sums: the four 16-lane rows of the wave hold the four entry slots' shares of column 16 b + (l & 15)
 template <int NB>
-__device__ __forceinline__ void gram_store_sums16(const GramAcc16<NB> &g, int lane, float *dst) {
+__device__ __forceinline__ void gram_store_sums16(const GramAcc16<NB> &g, int lane, float *dst, int d = 16 * NB) {
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         float v = g.sum[b];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (lane < 16) dst[16 * b + lane] = v;
+        if (lane < 16 && 16 * b + lane < d) dst[16 * b + lane] = v;
     }
 }
 
@@ -1370,10 +1277,14 @@ struct SolveSteps<DMAX, DMAX, FULL> {
     static __device__ __forceinline__ void run2(SolveState<DMAX> &, SolveState<DMAX> &, int) {}
 };
 // everything in front of the chain: the columns of M into registers, the diagonal, y = M p
-template <int DMAX, bool FORM, bool FULL = false, int DP = kAlsDP>  // DP: row stride of sM
+// PAD (with FULL): the system is DMAX x DMAX with zeros past dvalid -- M, S (stride DMAX) and the sums are zero there -- so the DMAX
+// steps run as straight-line code and the steps past dvalid change nothing; only the lanes past dvalid are masked (ONE mask: a
+// bound check per column of M kept 2 x DMAX scalar registers alive across the row loop, 392 scalar spills at DMAX = 64).
+template <int DMAX, bool FORM, bool FULL = false, int DP = kAlsDP, bool PAD = false>  // DP: row stride of sM
 __device__ __forceinline__ void als_solve_prepare(SolveState<DMAX> &x, float *__restrict__ a, const float *sM, const float *ss,
                                                   const float *__restrict__ S, int d, float one_w, float w, float reg, int lane,
-                                                  unsigned long long *c_load = nullptr) {
+                                                  unsigned long long *c_load = nullptr, int dvalid = 0) {
+    static_assert(!PAD || FULL, "a padded system is solved with all DMAX steps");
     unsigned long long t_in = 0;
     if (c_load) t_in = __builtin_amdgcn_s_memtime();
     if (FULL) d = DMAX;
@@ -1385,8 +1296,8 @@ __device__ __forceinline__ void als_solve_prepare(SolveState<DMAX> &x, float *__
     }
     // lanes past d hold nothing (DMAX = 32 leaves half of the wave idle): masked even in the FULL form, where the test is a
     // compile-time fact for DMAX = 64
-    const bool lane_in = (FULL && DMAX >= 64) || lane < d;
-    const int lane_c = (FULL && DMAX >= 64) ? lane : min(lane, d - 1);
+    const bool lane_in = PAD ? lane < dvalid : ((FULL && DMAX >= 64) || lane < d);
+    const int lane_c = PAD ? min(lane, dvalid - 1) : ((FULL && DMAX >= 64) ? lane : min(lane, d - 1));
 #pragma unroll
     for (int i0 = 0; i0 < DMAX; i0 += 16) {  // 16 columns' worth of loads in flight at a time (register pressure)
 #pragma unroll
@@ -1411,7 +1322,8 @@ __device__ __forceinline__ void als_solve_prepare(SolveState<DMAX> &x, float *__
     const float p0 = lane_in ? p0_raw : 0.0f;
     const float sv = lane_in ? sv_raw : 0.0f;
     if (!lane_in) diag = 0.0f;
-    const float inv = __builtin_amdgcn_rcpf(diag + reg);  // 1 ulp; the parity bar of ALS is 1e-4 relative
+    float inv = __builtin_amdgcn_rcpf(diag + reg);  // 1 ulp; the parity bar of ALS is 1e-4 relative
+    if (PAD && !lane_in) inv = 0.0f;  // (reg may be 0: the step of a padding coordinate must come out as 0, not 0 / 0)
     const float base = (sv + p0 * diag) * inv;
     // y = M p as four interleaved partial sums: one chain of DMAX dependent operations cost ~45 cycles per link next to the sibling
     // wave's MFMA stream (a fifth of the solve, profiles/r04_u_probe_als_tiles_peel.txt)
@@ -1453,10 +1365,14 @@ __device__ __forceinline__ void als_solve_row(float *__restrict__ a, const float
 }
 
 // A: side being solved, B: the other side, S: d x d Gram of B over rows with feedback
-// MODE 0: fp32 MFMA, 32 x 32 tiles, any d <= 32 NB.  MODE 1: NB counts 16-column blocks, d = 16 NB, fp32 MFMA in 16 x 16 tiles.
-// MODE 2: d = 32 NB, the bf16 MFMA on three-way split values (gram_accumulate_b3).  Modes 1 and 2 need the zero row (zero_row >= 0),
-// keep M in d x (d + 1) words per wave and pair the rows' sweeps.  WAVES: waves per workgroup (one workgroup per CU).
-template <int NB, int MODE = 0, int WAVES = kAlsRowWaves>
+// MODE 1: NB counts 16-column blocks, d = 16 NB, fp32 MFMA in 16 x 16 tiles.  MODE 2: d = 32 NB, the bf16 MFMA on three-way split
+// values (gram_accumulate_b3).  MODE 3 (round 5): ANY d <= 16 NB in 16 x 16 fp32 tiles -- the columns past d are gathered from the
+// zero row, M is 16 NB x (16 NB + 1) with zeros past d, the sweep runs d steps -- which is what the reference's test width 8 and
+// every nFactors that is not a multiple of 16 take.  MODE 4: mode 3 with 64-bit gather addresses (factor matrices of 4 GB and
+// more, or 2^24 rows).  (The 32 x 32 fp32 tile form of rounds 1-4, MODE 0, served those shapes with 124 registers + 175 scalar spills
+// for d = 8; it is gone.)  All modes gather through the zero row behind the matrix (zero_row), keep M per wave in LDS and pair the
+// rows' sweeps.  WAVES: waves per workgroup (one workgroup per CU).
+template <int NB, int MODE = 1, int WAVES = kAlsRowWaves>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES / 4, WAVES / 4))) void als_row_kernel(float *__restrict__ A, const float *__restrict__ B,
                                                                  const int64_t *__restrict__ ptr,
                                                                  const int32_t *__restrict__ idx,
@@ -1477,12 +1393,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     // 64 loads per row queued behind the sibling waves' gathers -- 24.6K of the solve's 40.5K cycles per row
     // (profiles/r02_i_probe_als_prof.txt)
     float *sS = smem;
-    for (int e = threadIdx.x; e < d * d; e += blockDim.x) sS[e] = S[e];
+    if constexpr (MODE == 3 || MODE == 4) {  // S padded to the tiles' 16 NB x 16 NB with zeros (als_solve_prepare, PAD)
+        for (int e = threadIdx.x; e < 16 * NB * 16 * NB; e += blockDim.x) {
+            const int i = e / (16 * NB), j = e % (16 * NB);
+            sS[e] = i < d && j < d ? S[i * d + j] : 0.0f;
+        }
+    } else {
+        for (int e = threadIdx.x; e < d * d; e += blockDim.x) sS[e] = S[e];
+    }
     __syncthreads();
-    constexpr bool T16 = MODE == 1;
-    constexpr int DD = MODE == 1 ? 16 * NB : 32 * NB;  // modes 1, 2: d itself
-    constexpr int DP = MODE ? DD + 1 : kAlsDP, MROWS = MODE ? DD : 64;
-    float *sM = smem + (size_t)d * d + (size_t)wv * (MROWS * DP + MROWS);
+    static_assert(MODE >= 1 && MODE <= 4, "als_row_kernel modes");
+    constexpr bool T16 = MODE != 2;
+    constexpr bool FULLD = MODE == 1 || MODE == 2;       // d is DD itself
+    constexpr int DD = MODE == 2 ? 32 * NB : 16 * NB;    // modes 1, 2: d itself; 3, 4: d rounded up to whole 16-column blocks
+    constexpr int DP = DD + 1, MROWS = DD;
+    float *sM = smem + (size_t)(FULLD ? d * d : DD * DD) + (size_t)wv * (MROWS * DP + MROWS);
     float *ss = sM + MROWS * DP;
     const float one_w = 1 - w;
     const int64_t wave = (int64_t)blockIdx.x * WAVES + wv, nwaves = (int64_t)gridDim.x * WAVES;
@@ -1506,7 +1431,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
     // solving wave then never shares its SIMD with a wave that streams 64-cycle fp32 MFMAs.  Every wave runs the same number of
     // iterations; one without a row of its own (the tail) only keeps the barriers.
     const int64_t t_end = phased ? (n_rows + nwaves - 1) / nwaves * nwaves : n_rows;
-    SolveState<MODE ? DD : 1> held;  // (modes 1, 2) the first row of a pair, waiting for the second
+    SolveState<DD> held;  // the first row of a pair, waiting for the second
     bool have_held = false;
     for (int64_t t = wave; t < t_end; t += nwaves) {
         if (t >= n_rows) {
@@ -1519,15 +1444,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         unsigned long long t0 = 0;
         if (prof) t0 = __builtin_amdgcn_s_memtime();
         if constexpr (T16)
-            gram_accumulate16<NB, true>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
-        else if constexpr (MODE == 2)
-            gram_accumulate_b3<NB, kAlsRowDeep>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
-        else if (zero_row >= 0 && d == 32 * NB)
-            gram_accumulate<NB, 1>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
-        else if (zero_row >= 0)
-            gram_accumulate<NB, 2>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
+            gram_accumulate16<NB, true, FULLD, MODE == 4>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         else
-            gram_accumulate<NB, 0>(B, zeros, idx + beg, n, d, lane, g, idx0, idx1);
+            gram_accumulate_b3<NB, kAlsRowDeep>(B, idx + beg, n, d, lane, g, idx0, idx1, zero_row);
         const int64_t beg_next = ptr[u_next];
         const int64_t end_next = ptr[u_next + 1];
         if (prof) {
@@ -1536,7 +1455,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             c_acc += t1 - t0;
             t0 = t1;
         }
-        {   // rows / columns past d are zeros of the padded gathers: stored unconditionally (sM is 64 x kAlsDP), with
+        {   // rows / columns past d are zeros of the padded gathers: stored unconditionally (sM is DD x DP), with
             // immediate offsets from two lane-dependent bases
             auto put = [&](float *direct, float *mirror) {
                 return [=](int ci, int cj, float v, bool mir) {
@@ -1552,7 +1471,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 gram_foreach<NB>(g, put(sM + 4 * (lane >> 5) * DP + (lane & 31), sM + (lane & 31) * DP + 4 * (lane >> 5)));
         }
         if constexpr (T16)
-            gram_store_sums16<NB>(g, lane, ss);
+            gram_store_sums16<NB>(g, lane, ss);  // (ss holds DD words: the sums of the padding columns are zeros)
         else
             gram_store_sums<NB>(g, d, lane, ss);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1571,11 +1490,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         first_indices(beg_next, n_next, idx0_next, idx1_next);
         if (phased) __syncthreads();
         __builtin_amdgcn_s_setprio(3);
-        if constexpr (MODE != 0) {
+        {
             // two rows' sweeps run together: the first row of a pair is taken as far as the chain (its M in registers, the LDS
             // buffer free for the second row's), the chains of both then advance step by step (SolveSteps::run2)
             SolveState<DD> cur;
-            als_solve_prepare<DD, true, true, DP>(cur, A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+            als_solve_prepare<DD, true, true, DP, !FULLD>(cur, A + u * d, sM, ss, sS, DD, one_w, w, reg, lane, prof ? &c_load : nullptr, d);
             if (have_held) {
                 SolveSteps<0, DD, true>::run2(held, cur, d);
                 als_solve_finish<DD>(held, lane);
@@ -1588,12 +1507,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 SolveSteps<0, DD, true>::run(cur, d);
                 als_solve_finish<DD>(cur, lane);
             }
-        } else if (d == 32 * NB)
-            als_solve_row<32 * NB, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
-        else if (NB == 1 && d == 16)  // the reference's default nFactors: straight-line too
-            als_solve_row<16, true, true>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
-        else
-            als_solve_row<32 * NB, true, false>(A + u * d, sM, ss, sS, d, one_w, w, reg, lane, prof ? &c_load : nullptr);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_wave_barrier();
         if (prof) {
@@ -1617,14 +1531,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
 }
 
 // long rows, stage 1: one wave per chunk -> partial[c] = [G (d x d, full) | s (d)]
-template <int NB, int MODE = 0>
+template <int NB, int MODE = 1>  // (modes: als_row_kernel)
 __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const float *__restrict__ B,
                                                                    const int32_t *__restrict__ idx,
                                                                    const int64_t *__restrict__ chunk_beg,
                                                                    const int32_t *__restrict__ chunk_cnt,
                                                                    int64_t n_chunks, int d, float *__restrict__ partial,
                                                                    const float *__restrict__ zeros, int zero_row) {
-    constexpr bool T16 = MODE == 1;
+    static_assert(MODE >= 1 && MODE <= 4, "als_chunk_kernel modes");
+    constexpr bool T16 = MODE != 2;
+    constexpr bool FULLD = MODE == 1 || MODE == 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
     const int64_t stride = (int64_t)d * d + d;
@@ -1633,17 +1549,11 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
         const int32_t *fb = idx + chunk_beg[c];
         const int cn = chunk_cnt[c];
         if constexpr (T16)
-            gram_accumulate16<NB, true>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
-        else if constexpr (MODE == 2)
-            gram_accumulate_b3<NB>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
-        else if (zero_row >= 0 && d == 32 * NB)
-            gram_accumulate<NB, 1>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
-        else if (zero_row >= 0)
-            gram_accumulate<NB, 2>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
+            gram_accumulate16<NB, true, FULLD, MODE == 4>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         else
-            gram_accumulate<NB, 0>(B, zeros, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0]);
+            gram_accumulate_b3<NB>(B, fb, cn, d, lane, g, fb[lane < cn ? lane : 0], fb[64 + lane < cn ? 64 + lane : 0], zero_row);
         float *dst = partial + c * stride;
-        if constexpr (MODE != 0) {
+        if constexpr (FULLD) {
             // d is a compile-time fact in these forms: the chunk's base + two lane offsets, every element at an immediate offset
             // (with an address per element the kernel held 227 registers; four waves per SIMD instead of two, which 128 allow, are
             // no faster: 0.455 against 0.413 ms per launch at C5, profiles/r04_zi_kernel_stats_als.txt -- the bound stays two)
@@ -1662,32 +1572,32 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
                 gram_foreach<NB>(g, put);
                 gram_store_sums<NB>(g, DD, lane, dst + DD * DD);
             }
-        } else if constexpr (T16) {
+        } else {  // modes 3, 4: d x d of the 16 NB x 16 NB tiles
             gram_foreach16<NB>(g, [&](int ci, int cj, float v, bool mir) {
                 const int i = ci + 4 * (lane >> 4), j = cj + (lane & 15);
-                dst[mir ? j * d + i : i * d + j] = v;
-            });
-            gram_store_sums16<NB>(g, lane, dst + (int64_t)d * d);
-        } else {
-            gram_foreach<NB>(g, [&](int ci, int cj, float v, bool mir) {
-                const int i = ci + 4 * (lane >> 5), j = cj + (lane & 31);
                 if (i < d && j < d) dst[mir ? j * d + i : i * d + j] = v;
             });
-            gram_store_sums<NB>(g, d, lane, dst + (int64_t)d * d);
+            gram_store_sums16<NB>(g, lane, dst + (int64_t)d * d, d);
         }
     }
 }
 
-// long rows, stage 2: one workgroup per row adds the row's partials in chunk order, wave 0 solves
+// long rows, stage 2: one workgroup per row adds the row's partials in chunk order, wave 0 solves.  DMAX = d rounded up to a
+// multiple of 16, FULL: d == DMAX (round 5: the one 64-step form with its bound checks held 300 scalar spills)
+template <int DMAX>
 __global__ __launch_bounds__(256) void als_long_solve_kernel(float *__restrict__ A, const float *__restrict__ S,
                                                              const int32_t *__restrict__ rows,
                                                              const int32_t *__restrict__ first,
                                                              const int32_t *__restrict__ nch, int64_t n_rows, int d,
                                                              float w, float reg, const float *__restrict__ partial) {
-    __shared__ float sM[64 * kAlsDP];
-    __shared__ float ss[64];
+    __shared__ float sM[DMAX * kAlsDP];
+    __shared__ float ss[DMAX];
     const float one_w = 1 - w;
     const int64_t stride = (int64_t)d * d + d;
+    // M and the sums padded with zeros to DMAX (als_solve_prepare, PAD): the words past d are written once
+    for (int e = threadIdx.x; e < DMAX * kAlsDP; e += blockDim.x) sM[e] = 0.0f;
+    if (threadIdx.x < DMAX) ss[threadIdx.x] = 0.0f;
+    __syncthreads();
     for (int64_t t = blockIdx.x; t < n_rows; t += gridDim.x) {
         const float *src = partial + (int64_t)first[t] * stride;
         const int nc = nch[t];
@@ -1710,7 +1620,12 @@ __global__ __launch_bounds__(256) void als_long_solve_kernel(float *__restrict__
                 ss[e - d * d] = acc;
         }
         __syncthreads();
-        if (threadIdx.x < 64) als_solve_row<64, false>(A + (int64_t)rows[t] * d, sM, ss, S, d, one_w, w, reg, threadIdx.x);
+        if (threadIdx.x < 64) {
+            SolveState<DMAX> x;
+            als_solve_prepare<DMAX, false, true, kAlsDP, true>(x, A + (int64_t)rows[t] * d, sM, ss, S, DMAX, one_w, w, reg, threadIdx.x, nullptr, d);
+            SolveSteps<0, DMAX, true>::run(x, DMAX);
+            als_solve_finish<DMAX>(x, threadIdx.x);
+        }
         __syncthreads();
     }
 }
@@ -1806,20 +1721,23 @@ int32_t run_sweep(gorse_mf *h, float *A, const float *B, const int64_t *ptr, con
 // probe: 8 counters per side in h->als_prof when the hook is on
 unsigned long long *als_prof_slot(gorse_mf *h, int side) { return g_als_prof && h->als_prof.n >= 16 ? h->als_prof.p + 8 * side : nullptr; }
 
-// the row id of the zero row behind matrix F (mf.hip) when the fast gather stage applies: offsets in 32 bits, row ids in 24; else
-// -1 (the first form of the stage)
+// the row id of the zero row behind matrix F (mf.hip) when 32-bit gather offsets apply (offsets in 32 bits, row ids in 24); else -1
 int als_zero_row(const gorse_mf *h, const float *F) {
     const int64_t rows = F == h->P.p ? h->U : h->I;
     const int d = h->d;
     if (g_als_slow_gather || rows + 1 >= ((int64_t)1 << 24) || (rows + 1) * d * 4 >= ((int64_t)1 << 32)) return -1;
     return (int)rows;
 }
+// the zero row itself (every factor matrix has one behind its last row: mf.hip)
+int als_pad_row(const gorse_mf *h, const float *F) { return (int)(F == h->P.p ? h->U : h->I); }
 
-// how the Gram of a row is accumulated (als_row_kernel / als_chunk_kernel MODE): 2 = bf16 MFMA on three-way split values (d = 32 or 64),
-// 1 = fp32 MFMA in 16 x 16 tiles (d = 16, 48), both with the fast gather stage (its zero row stands in for the entries past a row's
-// end); 0 = fp32 MFMA in 32 x 32 tiles, any d <= 64
-// The environment variable GORSE_ALS_GRAM = "fp32" keeps every product of the Gram on the fp32 MFMA (read once); the default lets
-// nFactors 32 / 64 and 65..128 form them from three-way split floats on the bf16 MFMA (gram_accumulate_b3).
+// how the Gram of a row is accumulated (als_row_kernel / als_chunk_kernel MODE), d <= 64: 2 = bf16 MFMA on three-way split values
+// (d = 32 or 64), 1 = fp32 MFMA in 16 x 16 tiles (d = 16, 48), 3 = the same tiles for any other d (columns past d from the zero row),
+// 4 = mode 3 with 64-bit gather addresses (als_zero_row < 0: a matrix of 4 GB and more, or the test hook 64).  Hook 128: mode 3 for
+// every d (the generic form against the specialised ones).
+// The environment variable GORSE_ALS_GRAM = "fp32" keeps every product of the Gram on the fp32 MFMA (read ONCE, when the library first
+// needs it -- it cannot be changed per handle afterwards); the default lets nFactors 32 / 64 and 65..128 form them from three-way
+// split floats on the bf16 MFMA (gram_accumulate_b3).
 bool als_split_products() {
     static const bool fp32_only = [] {
         const char *e = getenv("GORSE_ALS_GRAM");
@@ -1828,35 +1746,55 @@ bool als_split_products() {
     return !fp32_only && !g_als_nob3;
 }
 int als_gram_mode(int d, int zrow) {
-    if (zrow < 0 || d > 64) return 0;
+    if (zrow < 0) return 4;
+    if (g_als_tile32) return 3;
     if (als_split_products() && d % 32 == 0) return 2;
-    if (!g_als_tile32 && d % 16 == 0) return 1;
-    return 0;
+    if (d % 16 == 0) return 1;
+    return 3;
 }
 
 void launch_chunks(const float *B, const int32_t *idx, const int64_t *chunk_beg, const int32_t *chunk_cnt, int64_t n_chunks, int d,
-                   float *partial, const float *zeros, int zrow, unsigned grid, hipStream_t st) {
+                   float *partial, const float *zeros, int zrow, int pad_row, unsigned grid, hipStream_t st) {
 #define CHUNK_LAUNCH(...) \
-    als_chunk_kernel<__VA_ARGS__><<<dim3(grid), dim3(64 * kAlsWaves), 0, st>>>(B, idx, chunk_beg, chunk_cnt, n_chunks, d, partial, zeros, zrow)
-    switch (als_gram_mode(d, zrow) * 10 + (als_gram_mode(d, zrow) == 1 ? d / 16 : (d <= 32 ? 1 : 2))) {
+    als_chunk_kernel<__VA_ARGS__><<<dim3(grid), dim3(64 * kAlsWaves), 0, st>>>(B, idx, chunk_beg, chunk_cnt, n_chunks, d, partial, zeros, pad_row)
+    const int mode = als_gram_mode(d, zrow);
+    switch (mode * 10 + (mode == 2 ? d / 32 : (d + 15) / 16)) {
     case 11: CHUNK_LAUNCH(1, 1); break;
     case 12: CHUNK_LAUNCH(2, 1); break;
     case 13: CHUNK_LAUNCH(3, 1); break;
     case 14: CHUNK_LAUNCH(4, 1); break;
     case 21: CHUNK_LAUNCH(1, 2); break;
     case 22: CHUNK_LAUNCH(2, 2); break;
-    case 1: CHUNK_LAUNCH(1, 0); break;
-    default: CHUNK_LAUNCH(2, 0); break;
+    case 31: CHUNK_LAUNCH(1, 3); break;
+    case 32: CHUNK_LAUNCH(2, 3); break;
+    case 33: CHUNK_LAUNCH(3, 3); break;
+    case 34: CHUNK_LAUNCH(4, 3); break;
+    case 41: CHUNK_LAUNCH(1, 4); break;
+    case 42: CHUNK_LAUNCH(2, 4); break;
+    case 43: CHUNK_LAUNCH(3, 4); break;
+    default: CHUNK_LAUNCH(4, 4); break;
     }
 #undef CHUNK_LAUNCH
+}
+
+void launch_long_solve(float *A, const float *S, const int32_t *rows, const int32_t *first, const int32_t *nch, int64_t n_rows, int d,
+                       float w, float reg, const float *partial, hipStream_t st) {
+#define LONG_LAUNCH(DMAX_) \
+    als_long_solve_kernel<DMAX_><<<dim3((unsigned)std::min<int64_t>(n_rows, 1024)), dim3(256), 0, st>>>(A, S, rows, first, nch, n_rows, d, w, reg, partial)
+    switch ((d + 15) / 16) {
+    case 1: LONG_LAUNCH(16); break;
+    case 2: LONG_LAUNCH(32); break;
+    case 3: LONG_LAUNCH(48); break;
+    default: LONG_LAUNCH(64); break;
+    }
+#undef LONG_LAUNCH
 }
 
 int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int64_t *ptr, const int32_t *idx, float w,
                       float reg) {
     const int d = h->d;
-    const int zrow = als_zero_row(h, B);
+    const int zrow = als_zero_row(h, B), pad_row = als_pad_row(h, B);
     gorse_mf::AlsPlan &pl = h->als_plan[side];
-    const size_t lds = ((size_t)d * d + (size_t)kAlsRowWaves * (64 * kAlsDP + 64)) * sizeof(float);
     if (g_als_prof) {
         GORSE_TRY(h->als_prof.ensure(16));
         GORSE_HIP_CHECK(hipMemsetAsync(h->als_prof.p + 8 * side, 0, 8 * sizeof(unsigned long long), h->stream));
@@ -1870,16 +1808,18 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_)));                 \
         als_row_kernel<__VA_ARGS__, WAVES_><<<dim3(grid_), dim3(64 * WAVES_), (LDS_), h->stream>>>(                    \
             A, B, ptr, idx, h->gram.p, pl.short_rows.p, pl.n_short, d, w, reg, h->als_zeros.p, als_prof_slot(h, side), \
-            g_als_phased, zrow);                                                                                       \
+            g_als_phased, pad_row);                                                                                    \
     } while (0)
         const int mode = als_gram_mode(d, zrow);
-        if (mode != 0) {
-            // d x (d + 1) + d words of M and sums per wave next to S.  Twelve waves per CU where they fit and pay: d = 16 0.86 -> 0.77 ms,
-            // d = 32 1.30 -> 1.26 (C5 shard / 4); d = 48 is no faster with twelve, and d = 64 (M packed as the block rows of its upper
-            // triangle so that twelve buffers fit) was slower: 3.06 against 2.89 ms (profiles/r04_t_probe_als_tiles*.txt)
-            const int wv16 = (d <= 32 && !g_als_waves8) ? 12 : 8;
-            const size_t lds16 = ((size_t)d * d + (size_t)wv16 * ((size_t)d * (d + 1) + d)) * sizeof(float);
-            switch (mode * 1000 + d / 16 * 100 + wv16) {
+        {
+            // DD x (DD + 1) + DD words of M and sums per wave next to S (DD = d, or d rounded up to whole 16-column blocks in modes 3, 4).
+            // Twelve waves per CU where they fit and pay: d = 16 0.86 -> 0.77 ms, d = 32 1.30 -> 1.26 (C5 shard / 4); d = 48 is no
+            // faster with twelve, and d = 64 (M packed as the block rows of its upper triangle so that twelve buffers fit) was slower:
+            // 3.06 against 2.89 ms (profiles/r04_t_probe_als_tiles*.txt)
+            const int dd = mode == 2 ? d : (d + 15) / 16 * 16;
+            const int wv16 = (dd <= 32 && !g_als_waves8 && mode != 4) ? 12 : 8;
+            const size_t lds16 = ((size_t)dd * dd + (size_t)wv16 * ((size_t)dd * (dd + 1) + dd)) * sizeof(float);
+            switch (mode * 1000 + (mode == 2 ? d / 32 * 2 : dd / 16) * 100 + wv16) {
             case 1108: ROW_LAUNCH(8, lds16, 1, 1); break;
             case 1112: ROW_LAUNCH(12, lds16, 1, 1); break;
             case 1208: ROW_LAUNCH(8, lds16, 2, 1); break;
@@ -1888,12 +1828,19 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
             case 1408: ROW_LAUNCH(8, lds16, 4, 1); break;
             case 2208: ROW_LAUNCH(8, lds16, 1, 2); break;
             case 2212: ROW_LAUNCH(12, lds16, 1, 2); break;
-            default: ROW_LAUNCH(8, lds16, 2, 2); break;  // 2408
+            case 2408: ROW_LAUNCH(8, lds16, 2, 2); break;
+            case 3108: ROW_LAUNCH(8, lds16, 1, 3); break;
+            case 3112: ROW_LAUNCH(12, lds16, 1, 3); break;
+            case 3208: ROW_LAUNCH(8, lds16, 2, 3); break;
+            case 3212: ROW_LAUNCH(12, lds16, 2, 3); break;
+            case 3308: ROW_LAUNCH(8, lds16, 3, 3); break;
+            case 3408: ROW_LAUNCH(8, lds16, 4, 3); break;
+            case 4108: ROW_LAUNCH(8, lds16, 1, 4); break;
+            case 4208: ROW_LAUNCH(8, lds16, 2, 4); break;
+            case 4308: ROW_LAUNCH(8, lds16, 3, 4); break;
+            case 4408: ROW_LAUNCH(8, lds16, 4, 4); break;
+            default: return fail(GORSE_ERR_INVALID, "no ALS row kernel for nFactors %d (mode %d)", d, mode);
             }
-        } else if (d <= 32) {
-            ROW_LAUNCH(kAlsRowWaves, lds, 1, 0);
-        } else {
-            ROW_LAUNCH(kAlsRowWaves, lds, 2, 0);
         }
 #undef ROW_LAUNCH
         GORSE_HIP_CHECK(hipGetLastError());
@@ -1901,10 +1848,9 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
     if (pl.n_long > 0) {
         GORSE_TRY(h->als_partial.ensure((size_t)pl.n_chunks * ((size_t)d * d + d)));
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_chunks, kAlsWaves), 2048);
-        launch_chunks(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow, grid, h->stream);
+        launch_chunks(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow, pad_row, grid, h->stream);
         GORSE_HIP_CHECK(hipGetLastError());
-        als_long_solve_kernel<<<dim3((unsigned)std::min<int64_t>(pl.n_long, 1024)), dim3(256), 0, h->stream>>>(
-            A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p);
+        launch_long_solve(A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p, h->stream);
         GORSE_HIP_CHECK(hipGetLastError());
     }
     h->prof.end(tok, h->stream);
@@ -1915,7 +1861,7 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
 // "feedback list", cut into chunks; partial Gram matrices are added in chunk order (deterministic, bitwise symmetric)
 int32_t run_gram_mfma(gorse_mf *h, const float *F, int side) {
     const int d = h->d, dd = d * d;
-    const int zrow = als_zero_row(h, F);
+    const int zrow = als_zero_row(h, F), pad_row = als_pad_row(h, F);
     gorse_mf::AlsPlan &pl = h->als_plan[side];
     GORSE_TRY(h->gram.ensure((size_t)dd));
     int tok = h->prof.begin(GORSE_PROF_ALS_GRAM, h->stream);
@@ -1925,7 +1871,7 @@ int32_t run_gram_mfma(gorse_mf *h, const float *F, int side) {
         const int64_t stride = (int64_t)dd + d;
         GORSE_TRY(h->gram_partial.ensure((size_t)pl.n_gchunks * stride));
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_gchunks, kAlsWaves), 2048);
-        launch_chunks(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p, pl.n_gchunks, d, h->gram_partial.p, h->als_zeros.p, zrow, grid, h->stream);
+        launch_chunks(F, pl.fb_rows.p, pl.g_beg.p, pl.g_cnt.p, pl.n_gchunks, d, h->gram_partial.p, h->als_zeros.p, zrow, pad_row, grid, h->stream);
         GORSE_HIP_CHECK(hipGetLastError());
         als_gram_reduce_kernel<<<dim3((unsigned)ceil_div(dd, 256)), dim3(256), 0, h->stream>>>(
             h->gram_partial.p, (int)pl.n_gchunks, dd, h->gram.p, stride);

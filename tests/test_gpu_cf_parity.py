@@ -101,7 +101,7 @@ def test_als_bf16_split_gram_is_as_close_to_float64_as_the_fp32_tiles(oracle, d,
     """nFactors 32 / 64 accumulate the Gram on the bf16 MFMA: every float is EXACTLY hi + mid + lo (three bf16 values: its top 16
     bits, the top 16 bits of the remainder, the rest) and six of the nine partial products are summed in fp32 -- what is dropped is
     below 2^-23 of a product, an fp32 multiply's own rounding being 2^-24 (csrc/als.hip gram_accumulate_b3).  Checked here against
-    the same half-sweep on the fp32 MFMA (hook 1024: 16 x 16 tiles; 1024 | 128: 32 x 32 tiles) and against float64: the three
+    the same half-sweep on the fp32 MFMA (hook 1024: 16 x 16 tiles; 1024 | 128: the generic padded tile form) and against float64: the three
     device forms differ from each other by less than 2e-6 of a row's scale, and the bf16 form's distance from float64 is within
     1.5x of the fp32 tiles' (+ 5e-7)."""
     data = synth.synth_cf(600, 400, 30000, seed=22, min_len=3, n_neg=5)
@@ -119,7 +119,7 @@ def test_als_bf16_split_gram_is_as_close_to_float64_as_the_fp32_tiles(oracle, d,
     err = {path: np.abs(g[rows] - exact).max(axis=1) / scale for path, g in got.items()}
     between = max((np.abs(got[0] - got[p]).max(axis=1) / scale).max() for p in (1024, 1024 | 128))
     print("ALS d=%d half-sweep vs float64 (max error / row scale): bf16 x 3 median %.2e max %.2e; fp32 16x16 tiles median %.2e max %.2e; "
-          "fp32 32x32 tiles median %.2e max %.2e; largest difference between the forms %.2e"
+          "fp32 padded tiles median %.2e max %.2e; largest difference between the forms %.2e"
           % (d, np.median(err[0]), err[0].max(), np.median(err[1024]), err[1024].max(), np.median(err[1152]), err[1152].max(), between))
     assert between < 2e-6
     assert err[0].max() <= 1.5 * max(err[1024].max(), err[1152].max()) + 5e-7
@@ -673,13 +673,14 @@ def als_paths():
     capi.lib().gorse_hip_test_set_als_plan(0, 0)
 
 
-# path 1 = the reference's residual recurrence (als_sweep_kernel), path 2 = the Gram form on the fp32 MFMA
-# (als_row_kernel / als_chunk_kernel + als_long_solve_kernel); 0 = what the product picks; 2 | 64 = the Gram form with the
-# first form of its gather stage (what matrices of >= 4 GB or >= 2^24 rows take; the default is the 32-bit-offset stage)
+# path 1 = the reference's residual recurrence (als_sweep_kernel), path 2 = the Gram form on the matrix cores
+# (als_row_kernel / als_chunk_kernel + als_long_solve_kernel); 0 = what the product picks; 2 | 64 = the Gram form with 64-bit
+# gather addresses (MODE 4: what matrices of >= 4 GB or >= 2^24 rows take; the default is the 32-bit-offset stage)
 # 1024 = the fp32 MFMA in 16 x 16 tiles where the default is the bf16 MFMA over three-way split values (nFactors 32, 64);
-# 1024 | 128 = fp32 32 x 32 tiles everywhere (the form of rounds 1-3)
+# 1024 | 128 = the generic padded 16 x 16 tile form (MODE 3: what every nFactors that is not a multiple of 16 takes) for every width
+# nFactors 8 is the reference's own test width (model/cf/model_test.go:93-104), 16 its default (model.go:583-596)
 @pytest.mark.parametrize("path", [0, 1, 2, 2 | 64, 1024, 1024 | 128])
-@pytest.mark.parametrize("d", [16, 64, 32, 48, 24, 40, 7])
+@pytest.mark.parametrize("d", [16, 64, 32, 48, 24, 40, 7, 8, 56])
 def test_als_epoch_parity(oracle, small, d, path, als_paths):
     # ALS is deterministic w.r.t. Jobs: <= 1e-4 relative after 3 epochs
     capi.lib().gorse_hip_test_set_als_path(path)
@@ -749,11 +750,12 @@ def test_als_gram_form_rejects_wide_factors(small, als_paths):
 
 
 @pytest.mark.parametrize("long_row,chunk", [(16, 16), (40, 13), (0, 0)])
-@pytest.mark.parametrize("d", [16, 64, 33])
-def test_als_long_rows_chunked(oracle, d, long_row, chunk, als_paths):
+@pytest.mark.parametrize("d,path", [(16, 2), (64, 2), (33, 2), (8, 2), (8, 2 | 64), (50, 2 | 64), (64, 2 | 128)])
+def test_als_long_rows_chunked(oracle, d, path, long_row, chunk, als_paths):
     # long-row path of the Gram form: partial Gram matrices per chunk, reduced in chunk order.  Small plan
     # thresholds push most rows of a small input through it; (0, 0) = the default plan on heavy rows
-    capi.lib().gorse_hip_test_set_als_path(2)
+    # (path 2 | 64: 64-bit gather addresses; 2 | 128: the generic padded tile form where d has a specialised one)
+    capi.lib().gorse_hip_test_set_als_path(path)
     capi.lib().gorse_hip_test_set_als_plan(long_row, chunk)
     data = synth.synth_cf(60, 5000, 50000, seed=11, min_len=3, max_frac=0.9, n_neg=10)
     mf, P, Q = make_mf(data, d, std=0.1)
