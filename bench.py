@@ -176,7 +176,9 @@ def parse():
     ap.add_argument("--topk-n", type=int, default=1_000_000)
     ap.add_argument("--topk-steps", type=int, default=2)
     ap.add_argument("--topk-budget", type=float, default=60.0, help="seconds the timed top-k steps may take (see bench_topk)")
-    ap.add_argument("--mode", type=int, default=capi.BPR_HOGWILD_ATOMIC)
+    ap.add_argument("--mode", type=int, default=capi.BPR_HOGWILD_STORES,
+                    help="BPR schedule: 3 = what Fit runs with Jobs > 1 (atomics + the reference's unlocked store for cold negatives), "
+                         "0 = atomics only, 1 = sequential, 2 = racy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -188,7 +190,7 @@ BPR_SHAPES = {"ml1m": (64, "S-ml1m 6040x3706x994169 per rank (C2)"),
               "ml100k": (16, "S-ml100k 943x1682x99057 per rank (C1)"),
               "c3": (128, "S-big shard 125000x200000x12.5M per rank (C3/8)"),
               "c3full": (128, "S-big whole 1000000x200000x100M on one GPU (C3)"),
-              "big": (128, "S-huge 10M users x 1M items (north_star's 10M x 1M x 128 set; ~100 feedbacks per user)")}
+              "big": (128, "S-huge 10M users x 1M items (north_star's 10M x 1M x 128 set)")}
 
 
 def make_data_desc(workload, factors=0):
@@ -238,7 +240,7 @@ def cpu_baseline(data, d, lr, reg, seconds):
     L.orc_bpr_epoch_sampled.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, i64p, i32p, i32p,
                                         ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, ctypes.c_float]
-    P, Q = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 1)
+    P, Q = (synth.init_factors_big if data.U * d >= 1 << 26 else synth.init_factors)(data.U, data.I, d, 0.0, 0.001, 1)
     srt = orc.sort_rows(data.uptr, data.uidx)
     uptr = np.ascontiguousarray(data.uptr, np.int64)
     uidx = np.ascontiguousarray(data.uidx, np.int32)
@@ -347,6 +349,7 @@ def bench_topk(args, world, rank, local, fence):
     p_launches, replay_ms = t.get_profile(capi.PROF_TOPK_REPLAY)
     t.set_profiling(False)
     n_fb, n_tie = t.last_stats()
+    symmetric, sym_stats = t.last_symmetric(), t.sym_stats()
     if rank != 0:
         return None
     pairs_step = (q1 - q0) * (N - 1)
@@ -360,10 +363,15 @@ def bench_topk(args, world, rank, local, fence):
         "higher_is_better": True, "scaling": "strong", "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "S-emb %dx%d bf16, cosine, k=%d (C4), query rows sharded x%d" % (N, d, k, world),
                    "queries_per_step_per_gpu": q1 - q0, "all_query_rows": q1 - q0 == full,
-                   "tie_replayed_queries": n_tie, "scan_fallback_queries": n_fb},
+                   "tie_replayed_queries": n_tie, "scan_fallback_queries": n_fb, "symmetric_sweep": symmetric,
+                   "queries_without_pilot_threshold": sym_stats[0], "foreign_lists_overflowed": sym_stats[2]},
         "roofline": {"bound": "mfma", "kernel": "topk_sweep_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                      "algorithmic_flop_per_pair": 2 * d, "avg_launch_ms": avg_ms, "launches": launches,
+                     "flop_note": "achieved = ALGORITHMIC flops (2 d per scored (query, row) pair, SURVEY 8d) over the sweep launches' time; "
+                                  "the symmetric form of the sweep (csrc/topk_mfma.hip, SYM) issues about half of them on the matrix cores -- "
+                                  "every score of the square block [q0, q1) x [q0, q1) serves both of its queries -- so MFMA-busy counters read "
+                                  "lower than this fraction" if symmetric else "achieved = algorithmic flops (2 d per scored pair) over the sweep launches' time",
                      "clock_ghz": clk.ghz(),  # mean shader clock over the timed steps (pp_dpm_sclk), None if unreadable
                      "rescore_avg_ms": resc_ms / max(r_launches, 1),
                      "tie_history_sweep_ms_per_step": hist_ms / max(args.topk_steps, 1),
@@ -537,15 +545,16 @@ def als_cpu_baseline(uptr, uidx, iptr, P, Q, w, reg, seconds):
                       "half-sweep), hence entries / (2 x time)" % (rows, n, threads, dt, t_gram)}
 
 
-def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
-    """BASELINE config C5: eALS, nFactors 64.  Every rank holds the dataset and both factor matrices and solves its
+def bench_als(args, world, rank, local, fence, steps=None, warmup=None, factors=64, data=None):
+    """BASELINE config C5: eALS, nFactors 64 (factors: another width on the same set -- the default line carries 16, the
+    reference's default nFactors, model.go:583-596).  Every rank holds the dataset and both factor matrices and solves its
     row ranges (gorse_amd.dist.run_als_epoch); a step = one epoch = 2 half-sweeps + 2 all-gathers."""
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     sc = args.als_scale
-    U, I, nnz, d = int(500_000 * sc), int(100_000 * sc), int(50_000_000 * sc), 64
+    U, I, nnz, d = int(500_000 * sc), int(100_000 * sc), int(50_000_000 * sc), factors
     w, reg = 0.001, 0.06
-    uptr, uidx, iptr, iidx = synth.s_als(U, I, nnz, 45)
+    uptr, uidx, iptr, iidx = data if data is not None else synth.s_als(U, I, nnz, 45)
     n = int(uptr[-1])
     mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx, device=local)
     P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.1, seed=1)
@@ -606,9 +615,9 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None):
                      "gram_products": "bf16x3 split, fp32 accumulate" if d in (32, 64) else "fp32 MFMA",
                      "sweeps_ms_per_epoch": sweep_ms / max(steps, 1), "gram_ms_per_epoch": gram_ms / max(steps, 1)},
     }
-    if world == 1 and sc == 1.0:
+    if world == 1 and sc == 1.0 and d == 64:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("als")
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and d == 64:
         try:
             out["cpu_baseline"] = als_cpu_baseline(uptr, uidx, iptr, P0, Q0, w, reg, args.cpu_seconds)
         except Exception as e:
@@ -652,6 +661,8 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
     d, desc = make_data_desc(workload, factors or args.factors)
     lr, reg = 0.05, 0.01
     n_samples = data.n_train
+    if workload in ("big", "c3full"):  # what ran, to the feedback
+        desc += ", %d feedbacks = %.1f per user" % (n_samples, n_samples / data.U)
     t_create = time.perf_counter()
     mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx, device=local)
     t_create = time.perf_counter() - t_create
@@ -696,7 +707,7 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
     s_launches, smp_ms = mf.get_profile(capi.PROF_BPR_SAMPLE)
     o_launches, sort_ms = mf.get_profile(capi.PROF_BPR_SORT)
     c_launches, comm_ms = mf.get_profile(capi.PROF_COMM)
-    user_runs = args.mode == capi.BPR_HOGWILD_ATOMIC and mf.bpr_user_runs()
+    user_runs = args.mode in (capi.BPR_HOGWILD_ATOMIC, capi.BPR_HOGWILD_STORES) and mf.bpr_user_runs()
     mf.set_profiling(False)
     # the same epochs through the SYNCHRONOUS entry point (gorse_bpr_epoch: what a Fit loop that evaluates after every epoch
     # calls): each call drains both streams, so nothing of epoch e + 1 is prepared under epoch e
@@ -726,9 +737,9 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": desc, "samples_per_step_per_gpu": n_samples, "lr": lr, "reg": reg,
-                   "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy"}[args.mode]
+                   "schedule": {0: "hogwild-atomic", 1: "sequential", 2: "hogwild-racy", 3: "hogwild-stores (GORSE_BPR_HOGWILD_STORES: what Fit runs)"}[args.mode]
                    + (", user runs (sample ids counting-sorted by user, p_u register-resident, cold negatives by store)" if user_runs else
-                      (", one group per sample" if args.mode == capi.BPR_HOGWILD_ATOMIC else "")),
+                      (", one group per sample" if args.mode in (capi.BPR_HOGWILD_ATOMIC, capi.BPR_HOGWILD_STORES) else "")),
                    "entry_point": "gorse_bpr_epoch_enqueue x steps, one synchronisation at the end (a Fit between two evaluations)",
                    "sync_entry_point_ms_per_step": sync_ms,
                    "parallelism": "users sharded x%d, item factors replicated, 1 all-reduce(%.1f MB = I*d fp32)/epoch over %s"
@@ -746,12 +757,18 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
     if world > 1:
         out["exchange"] = {"allreduce_avg_ms": comm_ms / max(c_launches, 1) if c_launches else None, "launches": c_launches,
                            "bytes": data.I * d * 4, "path": comm_label}
-    if args.mode == capi.BPR_HOGWILD_ATOMIC and workload in ("ml1m", "c3", "c3full", "big") and not (factors or args.factors):
+    if args.mode in (capi.BPR_HOGWILD_ATOMIC, capi.BPR_HOGWILD_STORES) and workload in ("ml1m", "c3", "c3full", "big") and not (factors or args.factors):
         key = {"ml1m": "ml1m_users" if user_runs else "ml1m", "c3": "c3_users", "c3full": "c3full_users", "big": "big_users"}[workload]
-        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic(key)
+        tr, src = measured_traffic(key)
+        # the recorded figure is the mean over the FULL-size launches (one chunk: 32 samples per user, clamped to [4M, 128M], or the
+        # whole epoch); `traffic` is scaled to the mean launch samples_per_launch describes, the full-size figure rides along
+        full_launch = min(n_samples, min(max(32 * data.U, 4 << 20), 128 << 20))
+        out["roofline"]["traffic_full_launch"], out["roofline"]["full_launch_samples"] = tr, full_launch
+        out["roofline"]["traffic"] = tr * samples_per_launch / full_launch if tr is not None else None
+        out["roofline"]["traffic_source"] = src
     if world == 1 and with_cpu and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(data, d, lr, reg, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(data, d, lr, reg, args.cpu_seconds if with_cpu is True else float(with_cpu))
         except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
@@ -798,6 +815,38 @@ def bench_fit(args, local):
             rec["oracle_seconds"] = time.perf_counter() - t0
         out["d%d" % d] = rec
     out["value"] = out["d8"]["value"]
+    # ALS.Fit at the reference's own shape (model/cf/model_test.go:93-104: ml-1m, nFactors 8, Reg 0.015, Alpha 0.05, 30 epochs; and
+    # the default width 16, model.go:583-596) through the C++ twin of ALS.Fit, same FitConfig; ms per epoch from its own log, NDCG@10
+    # next to the oracle's (the reference's float32 recurrence, 30 epochs from the same kind of init)
+    reg_a, alpha = 0.015, 0.05
+    for d in (8, 16):
+        params = {"NFactors": d, "Reg": reg_a, "Alpha": alpha, "NEpochs": epochs}
+        m = cf.NewALS(dict(params))
+        cfg = cf.NewFitConfig().SetJobs(max(2, os.cpu_count() or 2))
+        m.Fit(train, test, cfg)  # first Fit of a width: code objects, buffers, the row plan
+        m = cf.NewALS(dict(params, RandomState=1))
+        t0 = time.perf_counter()
+        score = m.Fit(train, test, cfg)
+        wall = time.perf_counter() - t0
+        fit_ms = [float(x) for x in re.findall(r"fit_time=([0-9.]+)ms", m.log)]
+        eval_ms = [float(x) for x in re.findall(r"eval_time=([0-9.]+)ms", m.log)]
+        nnz = int(data.uptr[-1])
+        rec = {"value": wall, "epochs_done": m.epochs_done, "fit_ms_per_epoch": float(np.mean(fit_ms)) if fit_ms else None,
+               "entries_per_s": nnz / (float(np.mean(fit_ms)) * 1e-3) if fit_ms else None,
+               "eval_ms": float(np.mean(eval_ms)) if eval_ms else None, "evaluations": len(eval_ms), "ndcg": score.NDCG}
+        if fit_ms:  # 2 nnz d 4 + 2 (U + I) d 4 bytes per epoch
+            algo = 2.0 * nnz * d * 4 + 2.0 * (data.U + data.I) * d * 4
+            rec["hbm_frac"] = algo / (float(np.mean(fit_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            o = orc.Oracle()
+            P, Q = synth.init_factors(data.U, data.I, d, 0.0, 0.1, 3)
+            t0 = time.perf_counter()
+            for ep in range(epochs):
+                P, Q = o.als_epoch(P, Q, data.uptr, data.uidx, data.iptr, data.iidx, alpha, reg_a)
+            rec["oracle_ndcg"] = float(o.evaluate(P, Q, data.test_ptr, data.test_idx, data.neg_ptr, data.neg_idx, 10)[0])
+            rec["oracle_seconds"] = time.perf_counter() - t0
+        out["als_d%d" % d] = rec
     return out
 
 
@@ -821,6 +870,7 @@ def bench_mm(args, local):
     t = float(np.median(ms))
     tf = 2.0 * n * n * n / (t * 1e-3) / 1e12
     return {"metric": "floats.MM TFLOP/s (fp32, 4096^3 NN, bit-equal to the reference's fmaf chain)", "value": tf, "unit": "TFLOP/s",
+            "config": {"workload": "floats.MM 4096 x 4096 x 4096 fp32, NN (common/floats/mm.go:19-49)"},
             "ms_per_step": t, "steps": 3, "higher_is_better": True, "dtype": "f32", "data": "synthetic", "host_to_host_ms": float(np.median(wall)),
             "roofline": {"bound": "mfma_f32", "kernel": "sgemm_mfma_kernel", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": measured_traffic("mm")[0], "traffic_source": measured_traffic("mm")[1],
@@ -847,12 +897,29 @@ def emit(out, tag="default"):
     notes = {}
     line = compact(ordered, notes)
     # the driver's tail is 8 KB: if the line is still long, the secondary objects' `config` blocks move to the notes as well
-    for k in ("mm", "ml100k_d8", "ml100k", "i2i", "als", "c3", "fit"):
+    # the secondary objects first lose what the headline already says about the whole line (one GPU, synthetic data, ...) and
+    # the finer points of their rooflines: moved to the notes, numbers included
+    boiler = ("n_gpus", "warmup", "higher_is_better", "scaling", "vs_baseline", "data")
+    fine = ("algorithmic_bytes_per_sample", "sampler_avg_ms", "user_sort_avg_ms", "algorithmic_flop_per_pair", "mfma_macs_per_gathered_row",
+            "algorithmic_bytes_per_epoch", "sweeps_ms_per_epoch", "gram_ms_per_epoch", "full_launch_samples")
+    for k, v in line.items():
+        if k in ("config", "roofline", "cpu_baseline") or not isinstance(v, dict) or "metric" not in v:
+            continue
+        moved = {b: v.pop(b) for b in boiler if b in v}
+        if isinstance(v.get("roofline"), dict):
+            moved.update({"roofline." + f: v["roofline"].pop(f) for f in fine if f in v["roofline"]})
+        if moved:
+            notes[k + ".moved"] = moved
+    # (what is left of a moved block is its `workload` string: every object says in the line itself what it ran)
+    for k in ("mm", "ml100k_d8", "ml100k", "als_d16", "i2i", "als", "c3", "big", "fit"):
         if len(json.dumps(line, separators=(",", ":"))) < 7000:
             break
-        if isinstance(line.get(k), dict) and "config" in line[k]:
-            notes[k + ".config"] = line[k].pop("config")
-    line["notes"] = write_notes(notes, tag)
+        if isinstance(line.get(k), dict) and isinstance(line[k].get("config"), dict) and len(line[k]["config"]) > 1:
+            notes[k + ".config"] = line[k]["config"]
+            line[k]["config"] = {"workload": line[k]["config"].get("workload")}
+    # the notes of this run lie next to the line's log (gpurun_out/ is scratch); the copy of the round's last run is committed as
+    # profiles/r05_bench_notes_<tag>.json
+    line["notes"] = {"this_run": write_notes(notes, tag), "committed_copy": "profiles/r05_bench_notes_%s.json" % tag}
     print(json.dumps(line, separators=(",", ":")), flush=True)
 
 
@@ -917,13 +984,17 @@ def main():
             out["topk"] = topk
     if full_line and not args.no_extra:
         full = synth.s_big_full()
-        out["c3"] = leg(lambda: bench_bpr(args, "c3full", 1, 0, local, None, "single GPU", 5, 2, data=full, with_cpu=False),
+        out["c3"] = leg(lambda: bench_bpr(args, "c3full", 1, 0, local, None, "single GPU", 5, 2, data=full, with_cpu=5.0),
                         "BPR positive-samples/sec, C3 whole on one GPU")
         big = shard_of(full, 0, 8)
         del full
         out["i2i"] = leg(lambda: bench_sparse(args, 1, 0, local, fence0, data=big, steps=3, warmup=1), "sparse item x item top-100")
         del big
-        out["als"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=3, warmup=1), "ALS feedback entries/sec")
+        s_als = synth.s_als(int(500_000 * args.als_scale), int(100_000 * args.als_scale), int(50_000_000 * args.als_scale), 45)
+        out["als"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=3, warmup=1, data=s_als), "ALS feedback entries/sec")
+        out["als_d16"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=3, warmup=1, factors=16, data=s_als),
+                             "ALS feedback entries/sec, C5's set at the reference's default nFactors 16")
+        del s_als
         # the reference's own hyper-parameters (model/cf/model_test.go:35-45: nFactors 16; 8 is the smallest it searches)
         out["ml100k"] = leg(lambda: bench_bpr(args, "ml100k", 1, 0, local, None, "single GPU", 20, 3, with_cpu=False),
                             "BPR positive-samples/sec, S-ml100k nFactors 16")
@@ -934,7 +1005,7 @@ def main():
         # north_star's 10M x 1M x 128 set: P = 5.1 GB, far outside every cache.  250M draws (220M distinct feedbacks, 22 per user)
         # instead of --workload big's 1.25e9 so that the set generates in seconds inside the driver's run; same users, same items
         out["big"] = leg(lambda: bench_bpr(args, "big", 1, 0, local, None, "single GPU", 3, 1, data=synth.s_huge(N=BIG_DRAWS_DEFAULT_LINE),
-                                           with_cpu=False), "BPR positive-samples/sec, 10M users x 1M items, nFactors 128")
+                                           with_cpu=5.0), "BPR positive-samples/sec, 10M users x 1M items, nFactors 128")
     if rank == 0:
         emit(out, args.workload or ("default" if world == 1 else "default_n%d" % world))
     if world > 1:

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GORSE_HIP_LIB") or os.path.join(HERE, "lib", "libgorse_hip.so")  # the override serves probe builds
 
 OK, ERR_INVALID, ERR_HIP, ERR_CANCELLED, ERR_NO_DEVICE, ERR_RANGE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
-BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY = 0, 1, 2
+BPR_HOGWILD_ATOMIC, BPR_SEQUENTIAL, BPR_HOGWILD_RACY, BPR_HOGWILD_STORES = 0, 1, 2, 3
 DTYPE_F32, DTYPE_BF16 = 0, 1
 METRIC_NEG_DOT, METRIC_EUCLIDEAN, METRIC_COSINE, METRIC_EUCLIDEAN_BF16 = 0, 1, 2, 3
 PROF_BPR_UPDATE, PROF_BPR_SAMPLE, PROF_ALS_SWEEP, PROF_ALS_GRAM, PROF_BPR_SORT, PROF_COMM = 0, 1, 2, 3, 4, 5
@@ -49,6 +49,7 @@ SIGNATURES = {
     "gorse_bpr_sample_triplets": (C.c_int32, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
     "gorse_bpr_apply_triplets": (C.c_int32, [_vp, _i32p, _i32p, _i32p, C.c_int64, C.c_float, C.c_float, C.c_int32]),
     "gorse_mf_bpr_schedule": (C.c_int32, [_vp, _i32p]),
+    "gorse_mf_set_bpr_cold_window": (C.c_int32, [_vp, C.c_int64, _i64p]),
     "gorse_als_epoch": (C.c_int32, [_vp, C.c_float, C.c_float, _i32p]),
     "gorse_als_set_ranges": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     "gorse_als_half_epoch": (C.c_int32, [_vp, C.c_int32, C.c_float, C.c_float]),
@@ -244,6 +245,12 @@ class MF:
         if nu.value:
             check(lib().gorse_mf_rank_resident(self.h, topk, _p(users, _i32p), _p(rank, _i32p), _p(rlen, _i32p)))
         return users, rank, rlen
+
+    def set_bpr_cold_window(self, samples):
+        """the cold window of THIS handle (GORSE_BPR_HOGWILD_STORES); returns the number of cold items"""
+        n = C.c_int64(0)
+        check(lib().gorse_mf_set_bpr_cold_window(self.h, samples, C.byref(n)))
+        return n.value
 
     def bpr_epoch(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_ATOMIC, want_loss=False,
                   cancel=None):

@@ -33,6 +33,7 @@ int g_variant = 0;  // schedule switches of the tests and probes (gorse_hip_test
 constexpr int MODE_ATOMIC = GORSE_BPR_HOGWILD_ATOMIC;
 constexpr int MODE_EXACT = GORSE_BPR_SEQUENTIAL;
 constexpr int MODE_RACY = GORSE_BPR_HOGWILD_RACY;
+constexpr int MODE_STORES = GORSE_BPR_HOGWILD_STORES;  // MODE_ATOMIC with the cold negatives by store (user-run schedule only)
 
 // ---- sampling ------------------------------------------------------------------------------
 __device__ __forceinline__ bool row_contains(const int32_t *__restrict__ row, int64_t n, int32_t x) {
@@ -884,7 +885,7 @@ HotRows make_hot(const gorse_mf *h) {
 }
 
 int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *bucket, size_t cap, float lr, float reg,
-                            int exp_mode, double *loss, hipStream_t st) {
+                            int exp_mode, double *loss, hipStream_t st, bool stores) {
     const int d = h->d;
     int64_t blocks = ceil_div(h->U, kGroupsPerBlock);
     const int64_t capb = 256 * 16;
@@ -911,8 +912,8 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
     const int64_t rblocks = std::min<int64_t>(ceil_div(h->U, g_user_block / 64 * g_user_gpw), capb * (kBlock / g_user_block)) + folders;
     dim3 rgrid((unsigned)rblocks), rblock(g_user_block);
 #endif
-    // cold items by store only where the handle found any (gorse_mf_create: n_cold) -- the atomics-only instantiation otherwise
-    const int store_mode = h->n_cold > 0 ? g_store_mode : 0;
+    // cold items by store only in GORSE_BPR_HOGWILD_STORES and where the handle has any (n_cold) -- the atomics-only instantiation otherwise
+    const int store_mode = stores && h->n_cold > 0 ? g_store_mode : 0;
     // the library ships two forms of the kernel (atomics only; cold negatives by store); the positive-side and re-reading forms of
     // the ablation (profiles/r04_*_probe_bpr_stores_*.txt) exist in `make probe-lib` builds only
 #ifdef GORSE_PROBE
@@ -1157,7 +1158,7 @@ bool user_runs_enabled() { return (g_variant & 128) ? true : ((g_variant & (1 <<
 int g_exp_mode_exact = 0;  // exp flavour of the sequential schedule; tests flip it to 1 for bit parity
 
 int32_t check_mode(int mode) {
-    if (mode != MODE_ATOMIC && mode != MODE_EXACT && mode != MODE_RACY)
+    if (mode != MODE_ATOMIC && mode != MODE_EXACT && mode != MODE_RACY && mode != MODE_STORES)
         return fail(GORSE_ERR_INVALID, "unknown BPR mode %d", mode);
     return GORSE_OK;
 }
@@ -1190,7 +1191,7 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
     } else {
         // two-stream pipeline: stream2 samples (and item-sorts) chunk c+1 while stream applies chunk c; the
         // buffer parity runs on across calls so that back-to-back enqueued epochs overlap as well
-        const bool uruns = mode == MODE_ATOMIC && user_runs_enabled() && user_runs_supported(h);
+        const bool uruns = (mode == MODE_ATOMIC || mode == MODE_STORES) && user_runs_enabled() && user_runs_supported(h);
         if (uruns) GORSE_TRY(ensure_user_sort(h));
         int64_t c = 0;
         for (int64_t s0 = 0; s0 < n_samples; s0 += cap, c++) {
@@ -1233,9 +1234,10 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             }
             tok = h->prof.begin(GORSE_PROF_BPR_UPDATE, h->stream);
             if (uruns)
-                GORSE_TRY(launch_update_users(h, h->sorted[b].p, h->ubucket[b].p, (size_t)cap, lr, reg, g_exp_mode_exact, d_loss, h->stream));
-            else
-                GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, d_loss, h->stream));
+                GORSE_TRY(launch_update_users(h, h->sorted[b].p, h->ubucket[b].p, (size_t)cap, lr, reg, g_exp_mode_exact, d_loss, h->stream,
+                                              mode == MODE_STORES));
+            else  // (the per-sample schedule has no store route: mode 3 is mode 0 there)
+                GORSE_TRY(launch_update(h, mode == MODE_STORES ? MODE_ATOMIC : mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, d_loss, h->stream));
             h->prof.end(tok, h->stream);
             GORSE_HIP_CHECK(hipEventRecord(h->ev_consumed[b], h->stream));
             if (cancel && (c & 7) == 7) GORSE_TRY(mf_sync_streams(h));
@@ -1352,14 +1354,14 @@ extern "C" int32_t gorse_bpr_apply_triplets(gorse_mf *h, const int32_t *u, const
         if (mode == MODE_EXACT) {
             GORSE_TRY(run_sequential(h, tb, tb + cap, tb + 2 * cap, u + s0, i + s0, j + s0, m, lr, reg, g_exp_mode_exact,
                                      nullptr, nullptr));
-        } else if (mode == MODE_ATOMIC && user_runs_enabled() && user_runs_supported(h)) {
+        } else if ((mode == MODE_ATOMIC || mode == MODE_STORES) && user_runs_enabled() && user_runs_supported(h)) {
             GORSE_TRY(ensure_user_sort(h));
             GORSE_TRY(launch_user_sort(h, tb, h->sorted[0].p, h->ubucket[0].p, h->urank[0].p, m, (size_t)cap, h->stream, false));
             GORSE_TRY(launch_update_users(h, h->sorted[0].p, h->ubucket[0].p, (size_t)cap, lr, reg, g_exp_mode_exact, nullptr,
-                                          h->stream));
+                                          h->stream, mode == MODE_STORES));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         } else {
-            GORSE_TRY(launch_update(h, mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, nullptr, h->stream));
+            GORSE_TRY(launch_update(h, mode == MODE_STORES ? MODE_ATOMIC : mode, tb, tb + cap, tb + 2 * cap, nullptr, 0, m, lr, reg, 0, nullptr, h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         }
     }

@@ -193,6 +193,29 @@ constexpr int64_t kDefaultColdWindow = 32768;
 int64_t g_mf_cold_window = kDefaultColdWindow;  // items expected to be touched less than once per this many samples are "cold" (0 = none)
 extern "C" void gorse_hip_test_set_bpr_cold_window(int64_t samples) { g_mf_cold_window = samples < 0 ? kDefaultColdWindow : samples; }
 
+// the cold classes of one handle for another window: warm <-> cold only, the hot slots stay (include/gorse_hip.h)
+extern "C" int32_t gorse_mf_set_bpr_cold_window(gorse_mf *h, int64_t samples, int64_t *n_cold) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (samples < 0) return fail(GORSE_ERR_INVALID, "cold window < 0");
+    GORSE_TRY(h->use());
+    if ((int64_t)h->h_hot_slot.size() != h->I) return fail(GORSE_ERR_INVALID, "this handle has no item classes");
+    GORSE_TRY(mf_sync_streams(h));  // no epoch may be reading the classes
+    h->cold_window = samples;
+    h->n_cold = 0;
+    for (int64_t i = 0; i < h->I; i++) {
+        int32_t &s = h->h_hot_slot[(size_t)i];
+        if (s >= 0) continue;  // hot: replica slot
+        const bool cold = samples > 0 && h->nnz > 0 &&
+                          ((double)h->h_item_count[(size_t)i] / (double)h->nnz + 1.0 / (double)h->I) * (double)samples < 1.0;
+        s = cold ? -2 : -1;
+        h->n_cold += cold;
+    }
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->hot_slot.p, h->h_hot_slot.data(), (size_t)h->I * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (n_cold) *n_cold = h->n_cold;
+    return GORSE_OK;
+}
+
 extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, int64_t I, int32_t d,
                                    const int64_t *user_indptr, const int32_t *user_indices,
                                    const int64_t *item_indptr, const int32_t *item_indices) {
@@ -308,10 +331,14 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             std::vector<int32_t> slot((size_t)I, -1);
             // cold items (class -2, bpr.hip kCold): a sample touches item i with probability share(i) as its positive and 1 / I as
             // its negative; where fewer than one touch is expected per `cold window` samples the row's update may be a plain
-            // write-through store (the reference's own unlocked write) instead of d atomic dwords
+            // write-through store (the reference's own unlocked write) instead of d atomic dwords -- in GORSE_BPR_HOGWILD_STORES
+            // only.  The window is the handle's own (gorse_mf_set_bpr_cold_window re-classifies from the counts kept here).
+            h->h_item_count.resize((size_t)I);
+            for (int64_t i = 0; i < I; i++) h->h_item_count[(size_t)i] = (int32_t)std::min<int64_t>(cnt[(size_t)i], INT32_MAX);
+            h->cold_window = g_mf_cold_window;
             h->n_cold = 0;
-            if (g_mf_cold_window > 0 && h->nnz > 0) {
-                const double w = (double)g_mf_cold_window;
+            if (h->cold_window > 0 && h->nnz > 0) {
+                const double w = (double)h->cold_window;
                 for (int64_t i = 0; i < I; i++)
                     if (((double)cnt[(size_t)i] / (double)h->nnz + 1.0 / (double)I) * w < 1.0) {
                         slot[(size_t)i] = -2;
@@ -319,6 +346,7 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
                     }
             }
             for (size_t k = 0; k < hot.size(); k++) slot[hot[k]] = (int32_t)k;
+            h->h_hot_slot = slot;
             h->n_hot = (int)hot.size();
             GORSE_TRY(h->hot_slot.alloc((size_t)I));
             GORSE_TRY(h->hot_items.alloc(hot.size()));

@@ -1,5 +1,7 @@
 // mf_internal.hpp -- the gorse_mf handle: everything one model keeps resident in HBM.
 #pragma once
+#include <vector>
+
 #include "cf_device.hpp"
 
 #ifndef GORSE_HOT_REPLICAS
@@ -35,6 +37,9 @@ struct gorse_mf {
     gorse::DevBuf<float> hot_rep;
     int n_hot = 0;
     int64_t n_cold = 0;  // items of class "cold" in hot_slot (-2): updates by write-through store (bpr.hip)
+    int64_t cold_window = 0;               // what n_cold was computed for (gorse_mf_set_bpr_cold_window)
+    std::vector<int32_t> h_item_count;     // training feedbacks per item and
+    std::vector<int32_t> h_hot_slot;       // the class of every item (replica slot, -1 warm, -2 cold) as last uploaded: host copies for a re-classification
     gorse::DevBuf<int32_t> order;  // sequential mode: samples sorted by dependency level
     gorse::DevBuf<double> loss;
     gorse::DevBuf<int32_t> fail_count;

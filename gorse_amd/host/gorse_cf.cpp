@@ -308,7 +308,10 @@ Score BPR::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitCo
     const uint64_t seed = (uint64_t)GetRandomGenerator().Int63();
     // Jobs <= 1: parallel.Parallel runs the samples strictly in order (parallel.go:34-43) -> sequential
     // schedule; Jobs > 1: Hogwild workers -> the atomic Hogwild schedule.
-    const int mode = config.Jobs <= 1 ? GORSE_BPR_SEQUENTIAL : GORSE_BPR_HOGWILD_ATOMIC;
+    // Jobs > 1 is the reference's Hogwild: workers write item rows without a lock (model.go:478-488) -- GORSE_BPR_HOGWILD_STORES keeps
+    // that semantics for the cold negatives and atomics everywhere else; GORSE_BPR_HOGWILD_ATOMIC (no lost item update) is the
+    // caller's choice through the C ABI, not Fit's
+    const int mode = config.Jobs <= 1 ? GORSE_BPR_SEQUENTIAL : GORSE_BPR_HOGWILD_STORES;
     const int64_t n = trainSet.CountFeedback();
     // Between two evaluations the epochs are only enqueued: the sampler and the counting sort of epoch e + 1 run under the
     // update kernel of epoch e.  The epoch in front of an evaluation (and every sequential epoch) is the synchronous call,

@@ -48,14 +48,19 @@ extern "C" {
 #define GORSE_ERR_NOMEM (-6)
 
 /* BPR update schedules (gorse_bpr_epoch / gorse_bpr_apply_triplets `mode`) */
-#define GORSE_BPR_HOGWILD_ATOMIC 0 /* production schedule (Jobs > 1): all samples of a chunk in flight.  User rows   *
-                                    * are updated exactly (one group owns a user's run), item rows by fp32 atomics *
-                                    * (hot items through replica rows) -- except the NEGATIVE item of a sample when *
-                                    * it is a cold item (expected to be touched less than once per 32768 samples):  *
-                                    * that update is the reference's own unlocked load/fma/store (model.go:478-488) *
-                                    * and can overwrite a concurrent update of the same row, as the CPU Hogwild can */
+#define GORSE_BPR_HOGWILD_ATOMIC 0 /* Jobs > 1, NO lost item update: all samples of a chunk in flight.  User rows are  *
+                                    * updated exactly (one group owns a user's run), every item row by fp32 atomics     *
+                                    * (hot items through replica rows)                                                   */
 #define GORSE_BPR_SEQUENTIAL 1     /* dependency-levelled: bit-faithful to the reference with Jobs = 1  */
 #define GORSE_BPR_HOGWILD_RACY 2   /* write-through load/fma/store, lost updates like the CPU Hogwild   */
+#define GORSE_BPR_HOGWILD_STORES 3 /* the schedule Fit runs with Jobs > 1 (the reference's own Hogwild semantics):       *
+                                    * GORSE_BPR_HOGWILD_ATOMIC, except that the NEGATIVE item of a sample, when it is a  *
+                                    * COLD item (expected to be touched less than once per cold window of samples, see   *
+                                    * gorse_mf_set_bpr_cold_window; default 32768), is updated by the reference's own    *
+                                    * unlocked load / fma / store (model.go:478-488): such a write can overwrite a       *
+                                    * concurrent update of the same row, as two of the reference's workers can (measured *
+                                    * at C3: 4 % of the cold rows' updates, NDCG@10 unchanged).      *
+                                    * Where the handle has no cold item, or runs the per-sample schedule, it IS mode 0.  */
 
 /* top-k element types and metrics */
 #define GORSE_DTYPE_F32 0
@@ -141,6 +146,11 @@ int32_t gorse_bpr_epoch(gorse_mf *h, int64_t n_samples, float lr, float reg, uin
 /* Same, but only enqueues the work on the handle's stream (hogwild modes only). */
 int32_t gorse_bpr_epoch_enqueue(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t seed, uint64_t epoch,
                                 int64_t sample_base, int32_t mode);
+/* The cold window of THIS handle (GORSE_BPR_HOGWILD_STORES): item i is cold when (its share of the training feedback + 1 / I) x
+ * samples < 1, i.e. when fewer than one touch of its row is expected per `samples` samples in flight.  gorse_mf_create starts
+ * from 32768; 0 = no item is cold (mode 3 is then mode 0); takes effect from the next epoch call.  Returns the number of cold
+ * items through n_cold (may be NULL). */
+int32_t gorse_mf_set_bpr_cold_window(gorse_mf *h, int64_t samples, int64_t *n_cold /*out, may be NULL*/);
 /* Which form of the GORSE_BPR_HOGWILD_ATOMIC schedule this handle runs: 1 = user runs (the chunk's samples are
  * counting-sorted by user and one 16-lane group applies all samples of a user with p_u in registers; chosen when
  * there are >= 4096 users and nFactors is 8/16/32/64/128), 0 = one group per sample.  Both apply exactly the triplets

@@ -35,7 +35,7 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 	defer hm.close()
 	// one sampler stream per Fit, seeded like the reference's worker generators (model.go:420-423)
 	seed := uint64(bpr.GetRandomGenerator().Int63())
-	mode := C.int32_t(C.GORSE_BPR_HOGWILD_ATOMIC)
+	mode := C.int32_t(C.GORSE_BPR_HOGWILD_STORES)
 	if config.Jobs <= 1 {
 		mode = C.GORSE_BPR_SEQUENTIAL // parallel.Parallel with one worker runs the samples strictly in order
 	}

@@ -130,7 +130,7 @@ func (g *hipGroup) bprEpoch(trainSet dataset.CFSplit, lr, reg float32, seed uint
 		n := int64(float64(trainSet.CountFeedback())*float64(with[r])/float64(total) + 0.5)
 		// sample_base r << 40: every shard reads its own stretch of the Philox stream
 		if rc := C.gorse_bpr_epoch_enqueue(h, C.int64_t(n), C.float(lr), C.float(reg), C.uint64_t(seed), C.uint64_t(epoch),
-			C.int64_t(r)<<40, C.GORSE_BPR_HOGWILD_ATOMIC); rc != 0 {
+			C.int64_t(r)<<40, C.GORSE_BPR_HOGWILD_STORES); rc != 0 {
 			return hipError("gorse_bpr_epoch_enqueue", rc)
 		}
 	}

@@ -6,7 +6,7 @@ import sys
 
 def show(name, d):
     if not isinstance(d, dict) or d.get("value") is None or "ms_per_step" not in d:
-        print(name, json.dumps(d)[:400] if isinstance(d, dict) else d)
+        print(name, json.dumps(d)[:3000] if isinstance(d, dict) else d)
         return
     r = d.get("roofline", {})
     extra = ""

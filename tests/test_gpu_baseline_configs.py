@@ -43,7 +43,7 @@ def test_c2_ml1m_d64_user_runs_ndcg_and_rank_lists(oracle):
     mf.set_factors(P0, Q0)
     assert mf.bpr_user_runs()  # the schedule bench.py times at C2
     for ep in range(1, epochs + 1):
-        mf.bpr_epoch(data.n_train, lr, reg, seed, ep, mode=capi.BPR_HOGWILD_ATOMIC)
+        mf.bpr_epoch(data.n_train, lr, reg, seed, ep, mode=capi.BPR_HOGWILD_STORES)
     gP, gQ = mf.get_factors()
     assert np.isfinite(gP).all() and np.isfinite(gQ).all()
     got = ndcg(oracle, data, gP, gQ)
@@ -65,7 +65,7 @@ def test_c3_shard_d128_one_epoch_ndcg(oracle):
     mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
     mf.set_factors(P0, Q0)
     assert mf.bpr_user_runs()
-    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_ATOMIC)
+    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_STORES)
     gP, gQ = mf.get_factors()
     assert np.isfinite(gP).all() and np.isfinite(gQ).all()
     got = ndcg(oracle, data, gP, gQ)
@@ -100,7 +100,7 @@ def test_c3_full_d128_one_epoch_ndcg(oracle):
     mf.set_factors(P0, Q0)
     assert mf.bpr_user_runs()
     t0 = time.perf_counter()
-    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_ATOMIC)
+    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_STORES)
     t_epoch = time.perf_counter() - t0
     gP, gQ = mf.get_factors()
     mf.close()
@@ -136,7 +136,7 @@ def test_big_10m_users_d128_one_epoch_ndcg(oracle):
     del P0, Q0
     assert mf.bpr_user_runs()
     t0 = time.perf_counter()
-    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_ATOMIC)
+    mf.bpr_epoch(data.n_train, lr, reg, seed, 1, mode=capi.BPR_HOGWILD_STORES)
     t_epoch = time.perf_counter() - t0
     gP, gQ = mf.get_factors()
     mf.close()

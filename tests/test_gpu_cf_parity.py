@@ -517,15 +517,23 @@ def test_bpr_user_runs_cold_rows_by_store_are_bit_exact(oracle, store_mode):
     u = rng.integers(0, U, n).astype(np.int32)
     i, j = items[:n].copy(), items[n:].copy()
     P, Q = synth.init_factors(U, I, d, 0.0, 0.1, 9)
-    L.gorse_hip_test_set_bpr_cold_window(1024)  # 1 / I < 1 / 1024 <= share of every item of the dataset
     L.gorse_hip_test_set_bpr_store_mode(store_mode)
     L.gorse_hip_test_set_variant(VARIANT_USER_RUNS | VARIANT_STABLE_RANK)
     try:
         mf = capi.MF(U, I, d, uptr, uidx)
+        assert mf.set_bpr_cold_window(1024) >= I - 40  # THIS handle's window: 1 / I < 1 / 1024 <= share of every item of the dataset
         mf.set_factors(P, Q)
+        # GORSE_BPR_HOGWILD_ATOMIC never takes the store route, whatever the handle's cold classes: every item row by atomics
+        # (two roundings per element where the store route has one: not the oracle's bits)
         mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_HOGWILD_ATOMIC)
-        gP, gQ = mf.get_factors()
+        aP, aQ = mf.get_factors()
         eP, eQ, _ = oracle.bpr_apply_triplets(P, Q, u, i, j, 0.05, 0.01)
+        assert np.array_equal(bits(aP), bits(eP)) and rel_err(aQ, eQ) < 1e-6
+        if store_mode == 1:
+            assert not np.array_equal(bits(aQ[j]), bits(eQ[j]))
+        mf.set_factors(P, Q)
+        mf.bpr_apply_triplets(u, i, j, 0.05, 0.01, capi.BPR_HOGWILD_STORES)
+        gP, gQ = mf.get_factors()
         assert np.array_equal(bits(gP), bits(eP))
         stored = np.zeros(I, bool)
         if store_mode & 2:
@@ -539,7 +547,7 @@ def test_bpr_user_runs_cold_rows_by_store_are_bit_exact(oracle, store_mode):
         mf.set_factors(P, Q)
         a, b = int(items[0]), int(items[1])
         u2 = np.zeros(3, np.int32)
-        mf.bpr_apply_triplets(u2, np.full(3, a, np.int32), np.full(3, b, np.int32), 1e-4, 0.0, capi.BPR_HOGWILD_ATOMIC)
+        mf.bpr_apply_triplets(u2, np.full(3, a, np.int32), np.full(3, b, np.int32), 1e-4, 0.0, capi.BPR_HOGWILD_STORES)
         _, gQ2 = mf.get_factors()
         diff = float(P[0] @ Q[a] - P[0] @ Q[b])
         step = 1e-4 / (1.0 + np.exp(diff)) * P[0].astype(np.float64)
@@ -548,7 +556,6 @@ def test_bpr_user_runs_cold_rows_by_store_are_bit_exact(oracle, store_mode):
     finally:
         L.gorse_hip_test_set_variant(0)
         L.gorse_hip_test_set_bpr_store_mode(-1)
-        L.gorse_hip_test_set_bpr_cold_window(-1)
 
 
 def _sorted_triples(u, i, j):
