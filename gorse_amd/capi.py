@@ -95,6 +95,8 @@ SIGNATURES = {
     "gorse_sparse_last_stats": (C.c_int32, [_vp, _i64p, _i64p]),
     "gorse_hip_sgemm": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f32p, C.c_int32,
                                     _f32p, C.c_int32, _f32p, C.c_int32]),
+    "gorse_hip_sgemm_device": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32,
+                                           _vp, C.c_int32, _vp, C.c_int32]),
     "gorse_hip_test_set_exact_exp": (None, [C.c_int32]),
     "gorse_hip_test_set_variant": (None, [C.c_int32]),
     "gorse_hip_test_set_topk_path": (None, [C.c_int32]),
@@ -595,3 +597,9 @@ def sgemm(transA, transB, m, n, k, a, lda, b, ldb, c, ldc, device=0):
     check(lib().gorse_hip_sgemm(device, int(transA), int(transB), m, n, k, _p(a, _f32p), lda, _p(b, _f32p), ldb,
                                 _p(c, _f32p), ldc))
     return c
+
+
+def sgemm_device(transA, transB, m, n, k, a_ptr, lda, b_ptr, ldb, c_ptr, ldc, device=0):
+    """gorse_hip_sgemm_device: the operands are device addresses (e.g. torch tensors' data_ptr()); C is updated in place"""
+    check(lib().gorse_hip_sgemm_device(device, int(transA), int(transB), m, n, k, C.c_void_p(a_ptr), lda, C.c_void_p(b_ptr), ldb,
+                                       C.c_void_p(c_ptr), ldc))

@@ -187,13 +187,28 @@ double g_sgemm_last_ms = 0.0;  // kernel time of the last call (hipEvents around
 extern "C" void gorse_hip_test_set_sgemm_valu(int32_t on) { g_sgemm_valu = on; }
 extern "C" double gorse_hip_test_sgemm_last_ms(void) { return g_sgemm_last_ms; }
 
-extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k,
-                                   const float *a, int32_t lda, const float *b, int32_t ldb, float *c, int32_t ldc) {
+namespace {
+// the pair of events around the kernel(s) of one call: released on every path out of it
+struct EventPair {
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    EventPair() {
+        (void)hipEventCreate(&ev0);
+        (void)hipEventCreate(&ev1);
+    }
+    EventPair(const EventPair &) = delete;
+    EventPair &operator=(const EventPair &) = delete;
+    ~EventPair() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
+int32_t sgemm_check(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k, const void *a, int32_t lda,
+                    const void *b, int32_t ldb, const void *c, int32_t ldc) {
     if (m < 0 || n < 0 || k < 0) return fail(GORSE_ERR_INVALID, "negative dimension");
     if (m == 0 || n == 0) return GORSE_OK;
     if (!a || !b || !c) return fail(GORSE_ERR_INVALID, "NULL matrix");
-    const int a_rows = transA ? k : m, a_cols = transA ? m : k;
-    const int b_rows = transB ? n : k, b_cols = transB ? k : n;
+    const int a_cols = transA ? m : k, b_cols = transB ? k : n;
     if (lda < a_cols || ldb < b_cols || ldc < n) return fail(GORSE_ERR_INVALID, "leading dimension too small");
     if (k > 8192 && !transA && transB) return fail(GORSE_ERR_INVALID, "k %d > 8192 unsupported in the NT case", k);
     int ndev = 0;
@@ -201,28 +216,19 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
         return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
     if (device < 0 || device >= ndev) return fail(GORSE_ERR_INVALID, "device %d out of range", device);
     GORSE_HIP_CHECK(hipSetDevice(device));
-    const size_t na = (size_t)(a_rows > 0 ? (a_rows - 1) : 0) * lda + a_cols;
-    const size_t nb = (size_t)(b_rows > 0 ? (b_rows - 1) : 0) * ldb + b_cols;
-    const size_t nc = (size_t)(m - 1) * ldc + n;
-    DevBuf<float> da, db, dc;
-    GORSE_TRY(da.alloc(na));
-    GORSE_TRY(db.alloc(nb));
-    GORSE_TRY(dc.alloc(nc));
-    hipStream_t st = nullptr;  // one-shot call: the null stream is fine
-    if (k > 0) {
-        GORSE_HIP_CHECK(hipMemcpyAsync(da.p, a, na * 4, hipMemcpyHostToDevice, st));
-        GORSE_HIP_CHECK(hipMemcpyAsync(db.p, b, nb * 4, hipMemcpyHostToDevice, st));
-    }
-    GORSE_HIP_CHECK(hipMemcpyAsync(dc.p, c, nc * 4, hipMemcpyHostToDevice, st));
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    (void)hipEventCreate(&ev0);
-    (void)hipEventCreate(&ev1);
-    bool mfma_timed = false;  // the MFMA branch records its own pair of events (around the kernel, between its re-layout copies)
-    (void)hipEventRecord(ev0, st);
+    return GORSE_OK;
+}
+
+// C (+)= A B on matrices that lie in device memory; everything is enqueued on st, the events of `ev` bracket the kernel(s)
+int32_t sgemm_on_device(hipStream_t st, EventPair &ev, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k, const float *da,
+                        int32_t lda, const float *db, int32_t ldb, float *dc, int32_t ldc) {
+    const int a_rows = transA ? k : m, a_cols = transA ? m : k;
+    const int b_rows = transB ? n : k, b_cols = transB ? k : n;
+    (void)hipEventRecord(ev.ev0, st);
     if (!transA && transB) {
         int64_t blocks = std::min<int64_t>(ceil_div((int64_t)m * n, kGroupsPerBlock), 8192);
         sgemm_nt_kernel<<<dim3((unsigned)blocks), dim3(kBlock), (size_t)kGroupsPerBlock * 2 * std::max(k, 1) * 4, st>>>(
-            m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+            m, n, k, da, lda, db, ldb, dc, ldc);
     } else if (k > 0 && (int64_t)m * n >= 64 * 64 && (int64_t)(m + 128) * (n + 128) * 4 < ((int64_t)1 << 32) && !g_sgemm_valu) {
         // the matrix cores (a tile is 128 x 128: below 64 x 64 the vector ALU form; C below 4 GB: the kernel addresses it by 32-bit offsets)
         // 128 x 128 tiles where they give every CU work (>= 512 of them: two per CU), 64 x 64 tiles otherwise.  The kernel has no edge
@@ -235,8 +241,8 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
         // (operands that are whole tiles already are used where they lie)
         const bool whole = mp == m && np == n && kp == k && (int64_t)m * ldc * 4 < ((int64_t)1 << 32);
         DevBuf<float> pa, pb, pc;
-        const float *ka = da.p, *kb = db.p;
-        float *kc = dc.p;
+        const float *ka = da, *kb = db;
+        float *kc = dc;
         int klda = lda, kldb = ldb, kldc = ldc;
         if (!whole) {
             GORSE_TRY(pa.alloc((size_t)pa_rows * pa_cols));
@@ -245,12 +251,12 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
             GORSE_HIP_CHECK(hipMemsetAsync(pa.p, 0, (size_t)pa_rows * pa_cols * 4, st));
             GORSE_HIP_CHECK(hipMemsetAsync(pb.p, 0, (size_t)pb_rows * pb_cols * 4, st));
             GORSE_HIP_CHECK(hipMemsetAsync(pc.p, 0, (size_t)mp * np * 4, st));
-            GORSE_HIP_CHECK(hipMemcpy2DAsync(pa.p, (size_t)pa_cols * 4, da.p, (size_t)lda * 4, (size_t)a_cols * 4, a_rows, hipMemcpyDeviceToDevice, st));
-            GORSE_HIP_CHECK(hipMemcpy2DAsync(pb.p, (size_t)pb_cols * 4, db.p, (size_t)ldb * 4, (size_t)b_cols * 4, b_rows, hipMemcpyDeviceToDevice, st));
-            GORSE_HIP_CHECK(hipMemcpy2DAsync(pc.p, (size_t)np * 4, dc.p, (size_t)ldc * 4, (size_t)n * 4, m, hipMemcpyDeviceToDevice, st));
+            GORSE_HIP_CHECK(hipMemcpy2DAsync(pa.p, (size_t)pa_cols * 4, da, (size_t)lda * 4, (size_t)a_cols * 4, a_rows, hipMemcpyDeviceToDevice, st));
+            GORSE_HIP_CHECK(hipMemcpy2DAsync(pb.p, (size_t)pb_cols * 4, db, (size_t)ldb * 4, (size_t)b_cols * 4, b_rows, hipMemcpyDeviceToDevice, st));
+            GORSE_HIP_CHECK(hipMemcpy2DAsync(pc.p, (size_t)np * 4, dc, (size_t)ldc * 4, (size_t)n * 4, m, hipMemcpyDeviceToDevice, st));
             ka = pa.p, kb = pb.p, kc = pc.p, klda = pa_cols, kldb = pb_cols, kldc = np;
         }
-        (void)hipEventRecord(ev0, st);  // (the figure of gorse_hip_test_sgemm_last_ms: the kernel alone)
+        (void)hipEventRecord(ev.ev0, st);  // (the figure of gorse_hip_test_sgemm_last_ms: the kernel alone)
         dim3 grid((unsigned)(np / T), (unsigned)(mp / T)), block(256);
 #define MM(TA_, TB_)                                                                                                   \
     do {                                                                                                               \
@@ -275,29 +281,68 @@ extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t trans
             else
                 sgemm_last_step_kernel<true, true><<<dim3(lb), dim3(256), 0, st>>>(mp, np, k - 1, ka, klda, kb, kldb, kc, kldc);
         }
-        (void)hipEventRecord(ev1, st);
+        (void)hipEventRecord(ev.ev1, st);
         GORSE_HIP_CHECK(hipGetLastError());
-        if (!whole) GORSE_HIP_CHECK(hipMemcpy2DAsync(dc.p, (size_t)ldc * 4, pc.p, (size_t)np * 4, (size_t)n * 4, m, hipMemcpyDeviceToDevice, st));
-        GORSE_HIP_CHECK(hipStreamSynchronize(st));  // pa / pb / pc are released at the end of this scope
-        mfma_timed = true;
+        if (!whole) {
+            GORSE_HIP_CHECK(hipMemcpy2DAsync(dc, (size_t)ldc * 4, pc.p, (size_t)np * 4, (size_t)n * 4, m, hipMemcpyDeviceToDevice, st));
+            GORSE_HIP_CHECK(hipStreamSynchronize(st));  // pa / pb / pc are released at the end of this scope
+        }
+        return GORSE_OK;
     } else if (k > 0) {
         dim3 grid((unsigned)ceil_div(n, TS), (unsigned)ceil_div(m, TS)), block(TS * TS);
         if (!transA && !transB)
-            sgemm_chain_kernel<false, false><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+            sgemm_chain_kernel<false, false><<<grid, block, 0, st>>>(m, n, k, da, lda, db, ldb, dc, ldc);
         else if (transA && !transB)
-            sgemm_chain_kernel<true, false><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+            sgemm_chain_kernel<true, false><<<grid, block, 0, st>>>(m, n, k, da, lda, db, ldb, dc, ldc);
         else
-            sgemm_chain_kernel<true, true><<<grid, block, 0, st>>>(m, n, k, da.p, lda, db.p, ldb, dc.p, ldc);
+            sgemm_chain_kernel<true, true><<<grid, block, 0, st>>>(m, n, k, da, lda, db, ldb, dc, ldc);
     }
-    const hipError_t launched = hipGetLastError();
-    if (!mfma_timed) (void)hipEventRecord(ev1, st);
-    hipError_t rc = launched;
-    if (rc == hipSuccess) rc = hipMemcpyAsync(c, dc.p, nc * 4, hipMemcpyDeviceToHost, st);
-    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    GORSE_HIP_CHECK(hipGetLastError());
+    (void)hipEventRecord(ev.ev1, st);
+    return GORSE_OK;
+}
+}  // namespace
+
+extern "C" int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k,
+                                   const float *a, int32_t lda, const float *b, int32_t ldb, float *c, int32_t ldc) {
+    GORSE_TRY(sgemm_check(device, transA, transB, m, n, k, a, lda, b, ldb, c, ldc));
+    if (m == 0 || n == 0) return GORSE_OK;
+    const int a_rows = transA ? k : m, a_cols = transA ? m : k;
+    const int b_rows = transB ? n : k, b_cols = transB ? k : n;
+    const size_t na = (size_t)(a_rows > 0 ? (a_rows - 1) : 0) * lda + a_cols;
+    const size_t nb = (size_t)(b_rows > 0 ? (b_rows - 1) : 0) * ldb + b_cols;
+    const size_t nc = (size_t)(m - 1) * ldc + n;
+    DevBuf<float> da, db, dc;
+    GORSE_TRY(da.alloc(na));
+    GORSE_TRY(db.alloc(nb));
+    GORSE_TRY(dc.alloc(nc));
+    hipStream_t st = nullptr;  // one-shot call: the null stream is fine
+    if (k > 0) {
+        GORSE_HIP_CHECK(hipMemcpyAsync(da.p, a, na * 4, hipMemcpyHostToDevice, st));
+        GORSE_HIP_CHECK(hipMemcpyAsync(db.p, b, nb * 4, hipMemcpyHostToDevice, st));
+    }
+    GORSE_HIP_CHECK(hipMemcpyAsync(dc.p, c, nc * 4, hipMemcpyHostToDevice, st));
+    EventPair ev;
+    GORSE_TRY(sgemm_on_device(st, ev, transA, transB, m, n, k, da.p, lda, db.p, ldb, dc.p, ldc));
+    GORSE_HIP_CHECK(hipMemcpyAsync(c, dc.p, nc * 4, hipMemcpyDeviceToHost, st));
+    GORSE_HIP_CHECK(hipStreamSynchronize(st));
     float ms = 0.0f;
-    if (rc == hipSuccess && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) g_sgemm_last_ms = ms;
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    if (rc != hipSuccess) return fail(GORSE_ERR_HIP, "gorse_hip_sgemm: %s", hipGetErrorString(rc));
+    if (hipEventElapsedTime(&ms, ev.ev0, ev.ev1) == hipSuccess) g_sgemm_last_ms = ms;
+    return GORSE_OK;
+}
+
+// The same product on matrices that already lie in the memory of `device` (a caller that keeps its operands resident -- the
+// reference's common/nn layers call floats.MM in a loop -- pays no PCIe transfer: 13 ms of them around a 1.2 ms kernel at 4096^3).
+// Synchronous: the result is complete when the call returns.
+extern "C" int32_t gorse_hip_sgemm_device(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k,
+                                          const float *a_dev, int32_t lda, const float *b_dev, int32_t ldb, float *c_dev, int32_t ldc) {
+    GORSE_TRY(sgemm_check(device, transA, transB, m, n, k, a_dev, lda, b_dev, ldb, c_dev, ldc));
+    if (m == 0 || n == 0) return GORSE_OK;
+    hipStream_t st = nullptr;
+    EventPair ev;
+    GORSE_TRY(sgemm_on_device(st, ev, transA, transB, m, n, k, a_dev, lda, b_dev, ldb, c_dev, ldc));
+    GORSE_HIP_CHECK(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev.ev0, ev.ev1) == hipSuccess) g_sgemm_last_ms = ms;
     return GORSE_OK;
 }

@@ -563,13 +563,19 @@ int64_t gh_mfitems_marshal(void *m, char *buf, int64_t cap) {
 // the blob with the reference's own index section and a device-built graph (MarshalReference); called twice by the ctypes wrapper
 // (size, then content): the bytes of the first call are kept until the second has copied them
 int64_t gh_mfitems_marshal_reference(void *m, char *buf, int64_t cap) {
+    // kept for: the object AND the state it was marshalled from (items added between the two calls make a fresh blob)
     static thread_local std::string kept;
     static thread_local void *kept_for = nullptr;
+    static thread_local size_t kept_count = 0;
+    static thread_local int64_t kept_stamp = 0;
     int64_t out = -1;
     guard([&] {
-        if (!(buf && kept_for == m)) {
-            kept = ((logics::MatrixFactorizationItems *)m)->MarshalReference();
+        auto *items = (logics::MatrixFactorizationItems *)m;
+        if (!(buf && kept_for == m && kept_count == items->Count() && kept_stamp == items->Timestamp() && (int64_t)kept.size() <= cap)) {
+            kept = items->MarshalReference();
             kept_for = m;
+            kept_count = items->Count();
+            kept_stamp = items->Timestamp();
         }
         out = copy_out(kept, buf, cap);
         if (buf) {

@@ -900,9 +900,11 @@ public:
     // for clusters in which some workers run a build without this library: their HNSW.Unmarshal loads the file and their own
     // knnSearch (hnsw.go:100-114) walks it.  The graph is what insert (hnsw.go:117-185) aims at, computed exactly instead of
     // searched for: every vector draws its level floor(-ln(u) * levelFactor) (hnsw.go:137); layer L holds the vectors of level
-    // >= L, and a vector's neighbours in a layer are its nearest vectors OF THAT LAYER by -dot -- maxConnection0 = 96 at the bottom,
-    // maxConnection = 48 above (NewHNSW's parameters, hnsw.go:52-60) -- from one exact all-pairs search per layer on the device
-    // (a million vectors: one MFMA pass instead of a million efConstruction = 100 searches).  Each queue is written ascending in
+    // >= L, and a vector's neighbours in a layer are its nearest vectors OF THAT LAYER by -dot plus a few reverse links (write_layer)
+    // -- maxConnection0 = 96 at the bottom, maxConnection = 48 above (NewHNSW's parameters, hnsw.go:52-60) -- from one exact
+    // all-pairs search per layer on the device (a million vectors: one MFMA pass instead of a million efConstruction = 100
+    // searches).  The levels come from one splitmix64 stream seeded by the count: the Go twin (integration/go/common/ann/
+    // bruteforce_hip.go) draws the same stream, so both write the same blob for the same model.  Each queue is written ascending in
     // the distance, which is a valid heap array for heap.PriorityQueue (pq.go:42-48); the enter point is the first vector of the
     // top layer.  This library's own reader keeps the vectors of such a file and skips the graph, like any reference file.
     std::string MarshalReference() {
@@ -935,7 +937,13 @@ public:
             top = std::max(top, level[(size_t)i]);
         }
         if (!searcher_) searcher_ = std::make_shared<vectors::HipSearcher>();
-        // the neighbour queues of one layer: members (ascending ids; empty = every vector), at most cap neighbours each
+        // The neighbour queues of one layer: members (ascending ids; empty = every vector), at most cap neighbours each.
+        // A queue = the vector's nearest cap - cap / 8 other members (exact) + up to cap / 8 REVERSE links: members that list this
+        // vector among their nearest without being listed back, the ones with the fewest incoming links first.  Under -dot on
+        // factors of unequal length every exact list points at the same long vectors, and a short vector that nobody lists could
+        // never be reached by the reference's walk (insert links both ways, hnsw.go:163-183, and so keeps such vectors attached
+        // while their neighbours' queues have room; its shrink keeps the nearest, which here would give the exact list back: a
+        // reverse link is by construction farther than every exact neighbour).  Every queue is written ascending in the distance.
         auto write_layer = [&](const std::vector<int32_t> &members, int cap, bool with_keys, const std::string &coll) {
             const int64_t m = members.empty() ? n : (int64_t)members.size();
             std::vector<float> sub;
@@ -945,32 +953,85 @@ public:
                 for (int64_t t = 0; t < m; t++) std::memcpy(sub.data() + (size_t)t * (size_t)d, Row((size_t)members[(size_t)t]), (size_t)d * sizeof(float));
                 X = sub.data();
             }
-            const int k = (int)std::min<int64_t>((int64_t)cap + 1, m);  // + 1: the vector itself may be among its own nearest
+            const int cap_r = m > (int64_t)cap + 1 ? cap / 8 : 0;  // reverse slots (a layer smaller than a queue links everybody anyway)
+            const int cap_f = cap - cap_r;
+            const int k = (int)std::min<int64_t>((int64_t)cap_f + 1, m);  // + 1: the vector itself may be among its own nearest
             const int64_t block = 65536;
             std::vector<int32_t> idx((size_t)std::min(block, m) * (size_t)k), cnt((size_t)std::min(block, m));
             std::vector<float> dist(idx.size());
+            // forward lists of the whole layer: fwd_i / fwd_d, cap_f slots per member, flen of them used
+            std::vector<int32_t> fwd_i((size_t)m * (size_t)cap_f), flen((size_t)m, 0), indeg((size_t)m, 0);
+            std::vector<float> fwd_d((size_t)m * (size_t)cap_f);
             searcher_->invalidate(coll);
             for (int64_t q0 = 0; q0 < m; q0 += block) {
                 const int64_t nq = std::min(block, m - q0);
                 searcher_->search(coll, X, m, d, GORSE_METRIC_NEG_DOT, X + (size_t)q0 * (size_t)d, nq, k, idx.data(), dist.data(), cnt.data());
                 for (int64_t t = 0; t < nq; t++) {
                     const int64_t self = q0 + t;
-                    if (with_keys) put<int32_t>(w, members.empty() ? (int32_t)self : members[(size_t)self]);
                     int32_t len = 0;
-                    for (int32_t j = 0; j < cnt[(size_t)t] && len < cap; j++) len += idx[(size_t)t * (size_t)k + (size_t)j] != (int32_t)self;
-                    put<uint8_t>(w, 0);  // desc = false
-                    put<int32_t>(w, len);
-                    int32_t done = 0;
-                    for (int32_t j = 0; j < cnt[(size_t)t] && done < len; j++) {
+                    for (int32_t j = 0; j < cnt[(size_t)t] && len < cap_f; j++) {
                         const int32_t r = idx[(size_t)t * (size_t)k + (size_t)j];
                         if (r == (int32_t)self) continue;
-                        put<int32_t>(w, members.empty() ? r : members[(size_t)r]);
-                        put<float>(w, dist[(size_t)t * (size_t)k + (size_t)j]);
-                        done++;
+                        fwd_i[(size_t)self * (size_t)cap_f + (size_t)len] = r;
+                        fwd_d[(size_t)self * (size_t)cap_f + (size_t)len] = dist[(size_t)t * (size_t)k + (size_t)j];
+                        indeg[(size_t)r]++;
+                        len++;
                     }
+                    flen[(size_t)self] = len;
                 }
             }
             searcher_->invalidate(coll);
+            // reverse candidates by target (CSR): r <- t for every forward link t -> r
+            std::vector<int64_t> rptr((size_t)m + 1, 0);
+            std::vector<int32_t> rsrc;
+            std::vector<float> rdst;
+            if (cap_r > 0) {
+                for (int64_t t = 0; t < m; t++)
+                    for (int32_t j = 0; j < flen[(size_t)t]; j++) rptr[(size_t)fwd_i[(size_t)t * (size_t)cap_f + (size_t)j] + 1]++;
+                for (int64_t t = 0; t < m; t++) rptr[(size_t)t + 1] += rptr[(size_t)t];
+                rsrc.resize((size_t)rptr[(size_t)m]);
+                rdst.resize(rsrc.size());
+                std::vector<int64_t> at(rptr.begin(), rptr.end() - 1);
+                for (int64_t t = 0; t < m; t++)
+                    for (int32_t j = 0; j < flen[(size_t)t]; j++) {
+                        const int32_t r = fwd_i[(size_t)t * (size_t)cap_f + (size_t)j];
+                        rsrc[(size_t)at[(size_t)r]] = (int32_t)t;
+                        rdst[(size_t)at[(size_t)r]++] = fwd_d[(size_t)t * (size_t)cap_f + (size_t)j];  // -dot is symmetric, bit for bit
+                    }
+            }
+            std::vector<std::pair<float, int32_t>> q;     // one queue: (distance, member)
+            std::vector<std::pair<int32_t, int64_t>> cand;  // (incoming links of the source, position in rsrc)
+            for (int64_t r = 0; r < m; r++) {
+                q.clear();
+                for (int32_t j = 0; j < flen[(size_t)r]; j++)
+                    q.emplace_back(fwd_d[(size_t)r * (size_t)cap_f + (size_t)j], fwd_i[(size_t)r * (size_t)cap_f + (size_t)j]);
+                if (cap_r > 0) {
+                    cand.clear();
+                    const int32_t *f0 = fwd_i.data() + (size_t)r * (size_t)cap_f;
+                    for (int64_t e = rptr[(size_t)r]; e < rptr[(size_t)r + 1]; e++) {
+                        const int32_t t = rsrc[(size_t)e];
+                        if (std::find(f0, f0 + flen[(size_t)r], t) == f0 + flen[(size_t)r]) cand.emplace_back(indeg[(size_t)t], e);
+                    }
+                    const size_t take = std::min<size_t>((size_t)cap_r, cand.size());
+                    std::partial_sort(cand.begin(), cand.begin() + (std::ptrdiff_t)take, cand.end(), [&](const auto &a, const auto &b) {
+                        if (a.first != b.first) return a.first < b.first;
+                        if (rdst[(size_t)a.second] != rdst[(size_t)b.second]) return rdst[(size_t)a.second] < rdst[(size_t)b.second];
+                        return rsrc[(size_t)a.second] < rsrc[(size_t)b.second];
+                    });
+                    for (size_t c = 0; c < take; c++) {
+                        q.emplace_back(rdst[(size_t)cand[c].second], rsrc[(size_t)cand[c].second]);
+                        indeg[(size_t)rsrc[(size_t)cand[c].second]]++;
+                    }
+                    std::sort(q.begin(), q.end());
+                }
+                if (with_keys) put<int32_t>(w, members.empty() ? (int32_t)r : members[(size_t)r]);
+                put<uint8_t>(w, 0);  // desc = false
+                put<int32_t>(w, (int32_t)q.size());
+                for (const auto &e : q) {
+                    put<int32_t>(w, members.empty() ? e.second : members[(size_t)e.second]);
+                    put<float>(w, e.first);
+                }
+            }
         };
         if (n > 0) write_layer({}, kM0, false, std::string(kCollection) + "#hnsw0");
         put<int64_t>(w, (int64_t)top);  // len(upperNeighbors)

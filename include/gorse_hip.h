@@ -327,6 +327,11 @@ int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, int64_t *hit
 int32_t gorse_hip_sgemm(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k,
                         const float *a /*host*/, int32_t lda, const float *b /*host*/, int32_t ldb, float *c /*host*/,
                         int32_t ldc);
+/* the same product on matrices that already lie in the memory of `device` (a caller that keeps its operands resident pays no
+ * PCIe transfer); synchronous: C is complete when the call returns */
+int32_t gorse_hip_sgemm_device(int32_t device, int32_t transA, int32_t transB, int32_t m, int32_t n, int32_t k,
+                               const float *a /*device*/, int32_t lda, const float *b /*device*/, int32_t ldb, float *c /*device*/,
+                               int32_t ldc);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import (
 	"encoding/binary"
 	"io"
 	"math"
-	"math/rand"
+	"sort"
 	"sync"
 	"unsafe"
 
@@ -213,7 +213,7 @@ func (b *BruteforceHIP) Marshal(w io.Writer) error {
 // the device, for clusters in which some workers run a build without this library (set `recommend.collaborative.hip_compat_blob`
 // on the master, see INTEGRATION.md): their HNSW.Unmarshal loads it and their own knnSearch walks it.  Every vector draws its
 // level as insert does (hnsw.go:137); layer L holds the vectors of level >= L; a vector's queue in a layer = its nearest vectors
-// OF THAT LAYER by the index's distance, 96 at the bottom and 48 above (NewHNSW, hnsw.go:52-60), from ONE exact all-pairs search
+// OF THAT LAYER by the index's distance plus a few reverse links, 96 at the bottom and 48 above (NewHNSW, hnsw.go:52-60), from ONE exact all-pairs search
 // per layer (gorse_topk_all_pairs) instead of one efConstruction search per insertion; queues ascending in the distance = valid
 // heap arrays (heap/pq.go:42-48).  The C++ twin with its tests (recall 1.000 of the reference's search restated, 20,000 x 32):
 // gorse_amd/host/gorse_vectors.hpp MarshalReference, tests/test_items_blob_cpu.py, tests/test_gpu_items_graph.py.
@@ -239,35 +239,91 @@ func (b *BruteforceHIP) MarshalReference(w io.Writer) error {
 			return errors.WithStack(err)
 		}
 	}
+	// levels: ONE splitmix64 stream seeded by the count -- the very stream of the C++ twin (gorse_vectors.hpp MarshalReference), so that
+	// both write the same blob for the same model, and the same model always yields the same blob (math/rand's global stream would not)
 	level, top := make([]int, n), 0
+	st := uint64(0x9E3779B97F4A7C15) ^ uint64(n)
 	for i := range level {
-		level[i] = int(math.Floor(-math.Log(float64(1-rand.Float32())) * float64(levelFactor)))
+		st += 0x9E3779B97F4A7C15
+		z := st
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EB
+		z ^= z >> 31
+		u := (float32(z>>40) + 1) / 16777216 // (0, 1]
+		level[i] = int(math.Floor(float64(-float32(math.Log(float64(u))) * levelFactor)))
 		top = max(top, level[i])
 	}
-	// one layer: the exact nearest `limit` other members of every member, written as PriorityQueue.Marshal does
+	// One layer, written as PriorityQueue.Marshal does.  A queue = the member's nearest limit - limit/8 other members (exact) + up to
+	// limit/8 REVERSE links: members that list it among their nearest without being listed back, those with the fewest incoming links
+	// first.  Under the inner product every exact list points at the same long vectors; a short vector nobody lists could never be
+	// reached by knnSearch (insert links both ways, hnsw.go:163-183; its shrink keeps the nearest, which on exact lists would drop every
+	// reverse link again).  Queues ascending in the distance.
 	writeLayer := func(members []int32, limit int, withKeys bool) error {
 		sub := NewBruteforceHIP(b.metric)
 		defer sub.Close()
 		for _, i := range members {
 			sub.Add(data[int(i)*d : (int(i)+1)*d])
 		}
-		k := min(limit+1, len(members)) // + 1: the vector itself may be among its own nearest
+		m := len(members)
+		capR := 0
+		if m > limit+1 {
+			capR = limit / 8
+		}
+		capF := limit - capR
+		k := min(capF+1, m) // + 1: the vector itself may be among its own nearest
 		idx, dist, err := sub.SearchAll(k)
 		if err != nil {
 			return err
 		}
-		for t, key := range members {
+		fwd := make([][]heap.Elem[int32, float32], m)
+		indeg := make([]int32, m)
+		for t := range members {
+			for j := 0; j < k && len(fwd[t]) < capF; j++ {
+				if r := idx[t*k+j]; r >= 0 && int(r) != t {
+					fwd[t] = append(fwd[t], heap.Elem[int32, float32]{Value: r, Weight: dist[t*k+j]})
+					indeg[r]++
+				}
+			}
+		}
+		rev := make([][]heap.Elem[int32, float32], m) // r <- t for every forward link t -> r
+		if capR > 0 {
+			for t := range members {
+				for _, e := range fwd[t] {
+					rev[e.Value] = append(rev[e.Value], heap.Elem[int32, float32]{Value: int32(t), Weight: e.Weight})
+				}
+			}
+		}
+		for r, key := range members {
+			q := append([]heap.Elem[int32, float32]{}, fwd[r]...)
+			if capR > 0 {
+				cand := lo.Filter(rev[r], func(e heap.Elem[int32, float32], _ int) bool {
+					return !lo.ContainsBy(fwd[r], func(f heap.Elem[int32, float32]) bool { return f.Value == e.Value })
+				})
+				sort.Slice(cand, func(a, b int) bool {
+					if indeg[cand[a].Value] != indeg[cand[b].Value] {
+						return indeg[cand[a].Value] < indeg[cand[b].Value]
+					}
+					if cand[a].Weight != cand[b].Weight {
+						return cand[a].Weight < cand[b].Weight
+					}
+					return cand[a].Value < cand[b].Value
+				})
+				for _, e := range cand[:min(capR, len(cand))] {
+					q = append(q, e)
+					indeg[e.Value]++
+				}
+				sort.Slice(q, func(a, b int) bool {
+					return q[a].Weight < q[b].Weight || (q[a].Weight == q[b].Weight && q[a].Value < q[b].Value)
+				})
+			}
 			if withKeys {
 				if err := binary.Write(w, binary.LittleEndian, key); err != nil {
 					return errors.WithStack(err)
 				}
 			}
-			elems := make([]heap.Elem[int32, float32], 0, limit)
-			for j := 0; j < k && len(elems) < limit; j++ {
-				if r := idx[t*k+j]; r >= 0 && int(r) != t {
-					elems = append(elems, heap.Elem[int32, float32]{Value: members[r], Weight: dist[t*k+j]})
-				}
-			}
+			elems := lo.Map(q, func(e heap.Elem[int32, float32], _ int) heap.Elem[int32, float32] {
+				return heap.Elem[int32, float32]{Value: members[e.Value], Weight: e.Weight}
+			})
 			if err := binary.Write(w, binary.LittleEndian, false); err != nil {
 				return errors.WithStack(err)
 			}

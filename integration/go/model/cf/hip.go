@@ -13,6 +13,7 @@ import "C"
 
 import (
 	"context"
+	"math"
 	"sync/atomic"
 	"unsafe"
 
@@ -146,12 +147,8 @@ func (m *hipModel) evaluate(testSet, trainSet dataset.CFSplit, topK, numCandidat
 // the Dataset the same way (dataset.go:243: drawn once, `if len(d.negatives) == 0`).
 func (m *hipModel) evaluateResident(testSet, trainSet dataset.CFSplit, topK, numCandidates int, seed uint64, scorers ...Metric) []float32 {
 	if !m.negativesResident {
+		// (flatten leaves one unused word in `indices` when the split holds no feedback: &indices[0] exists)
 		indptr, indices := flatten(testSet.GetUserFeedback())
-		if len(indices) == 0 {
-			// a validation split without feedback: the reference's Evaluate then averages over zero users (NaN scores,
-			// evaluator.go:69-70); &indices[0] of an empty slice would panic instead -- hand the library one unused word
-			indices = []int32{0}
-		}
 		if rc := C.gorse_mf_sample_user_negatives(m.h, (*C.int64_t)(unsafe.Pointer(&indptr[0])), (*C.int32_t)(unsafe.Pointer(&indices[0])),
 			C.int32_t(numCandidates), C.uint64_t(seed), nil, nil); rc != 0 {
 			panic(hipError("gorse_mf_sample_user_negatives", rc))
@@ -164,6 +161,12 @@ func (m *hipModel) evaluateResident(testSet, trainSet dataset.CFSplit, topK, num
 	}
 	sum := make([]float32, len(scorers))
 	if nUsers == 0 {
+		// a validation split without feedback: the reference's Evaluate averages over zero users -- floats.MulConst(sum, 1/count)
+		// with count = 0 is 0 * +Inf = NaN (evaluator.go:69-70) -- and so does this twin: early stopping and the log lines of Fit
+		// then see what they see in the reference
+		for i := range sum {
+			sum[i] = float32(math.NaN())
+		}
 		return sum
 	}
 	users := make([]int32, int(nUsers))

@@ -91,7 +91,14 @@ def test_als_gram_form_stays_within_twice_the_reference_recurrences_fp64_error(o
     err_ref = np.abs(oP[rows] - exact).max(axis=1) / np.abs(exact).max(axis=1)
     print("ALS d=%d vs float64, max error / row scale: device Gram form median %.2e max %.2e; reference recurrence (oracle) median %.2e max %.2e"
           % (d, np.median(err_dev), err_dev.max(), np.median(err_ref), err_ref.max()))
-    assert err_dev.max() <= 2.0 * err_ref.max() + 2e-6 and np.median(err_dev) <= 2.0 * np.median(err_ref) + 1e-6
+    if d in (16, 48):
+        # fp32 products (16 x 16 fp32 MFMA tiles): the original bar -- no farther from float64 than the reference's own recurrence, up
+        # to the noise of one half-sweep (measured: 0.8-0.9x of the reference's maximum and median)
+        assert err_dev.max() <= 1.25 * err_ref.max() + 2e-7 and np.median(err_dev) <= 1.25 * np.median(err_ref) + 1e-7
+    else:
+        # bf16 x 3 split products (nFactors 32, 64, 65..128): their own explicit bound -- within twice the reference's distance
+        # (+ 2e-6 of the row scale at the maximum, 1e-6 at the median); at nFactors 128 the device IS farther than the reference
+        assert err_dev.max() <= 2.0 * err_ref.max() + 2e-6 and np.median(err_dev) <= 2.0 * np.median(err_ref) + 1e-6
     assert_als_close(gP[rows], exact, "device vs float64")
     assert_als_close(oP[rows], exact, "oracle vs float64")
 

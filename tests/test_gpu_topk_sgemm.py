@@ -232,6 +232,59 @@ def test_sgemm_on_the_matrix_cores_is_the_same_chain(oracle):
         assert np.array_equal(bits(got), bits(exp)), k
 
 
+def test_sgemm_denormals_on_the_matrix_cores(oracle):
+    """Subnormal operands, products that underflow into the subnormal range and chains that climb out of it again: the fp32 MFMA must
+    treat them as the fmaf chain of the reference does (no flush to zero anywhere), bit for bit against the oracle and the vector-ALU
+    kernel; signed zeros among them."""
+    rng = np.random.default_rng(19)
+    L = capi.lib()
+    m, n, k = 96, 64, 37
+    for case in range(3):
+        a = np.ldexp(rng.uniform(-1, 1, (m, k)), rng.integers(-80, -60, (m, k))).astype(np.float32)  # ~1e-21: products ~1e-42 (subnormal)
+        b = np.ldexp(rng.uniform(-1, 1, (k, n)), rng.integers(-80, -60, (k, n))).astype(np.float32)
+        if case == 1:  # subnormal operands times large ones
+            a = (a * np.float32(1e-20)).astype(np.float32)
+            b = np.ldexp(rng.uniform(-1, 1, (k, n)), rng.integers(0, 30, (k, n))).astype(np.float32)
+        if case == 2:  # a chain that starts subnormal and leaves the range
+            b[k // 2:] = np.ldexp(rng.uniform(-1, 1, (k - k // 2, n)), 40).astype(np.float32)
+        a[::7, ::3] = -0.0
+        c0 = np.zeros((m, n), np.float32)
+        c0[::2] = np.float32(1e-44)  # a subnormal C
+        c0[1::4] = -0.0
+        args = (0, 0, m, n, k, a.ravel(), k, b.ravel(), n, c0.ravel(), n)
+        got = capi.sgemm(*args)
+        exp = oracle.mm(*args)
+        if case == 0:
+            assert (np.abs(exp[exp != 0]) < 1.2e-38).any()  # subnormal results
+        if case == 1:
+            assert (np.abs(a[a != 0]) < 1.2e-38).all()  # subnormal operands
+        assert np.array_equal(bits(got), bits(exp)), case
+        L.gorse_hip_test_set_sgemm_valu(1)
+        try:
+            valu = capi.sgemm(*args)
+        finally:
+            L.gorse_hip_test_set_sgemm_valu(0)
+        assert np.array_equal(bits(got), bits(valu)), case
+
+
+def test_sgemm_device_entry_point_equals_the_host_one():
+    """gorse_hip_sgemm_device: operands resident in device memory (here torch tensors), C updated in place -- the same bits as the
+    host-buffer entry point, on a shape off the tiles and on whole tiles."""
+    import torch
+    rng = np.random.default_rng(5)
+    for (m, n, k), (tA, tB) in (((300, 131, 130), (0, 0)), ((256, 256, 64), (1, 0)), ((64, 65, 3), (1, 1)), ((33, 20, 17), (0, 1))):
+        ar, ac = ((k, m) if tA else (m, k))
+        br, bc = ((n, k) if tB else (k, n))
+        a = rng.standard_normal((ar, ac)).astype(np.float32)
+        b = rng.standard_normal((br, bc)).astype(np.float32)
+        c0 = rng.standard_normal((m, n)).astype(np.float32)
+        want = capi.sgemm(tA, tB, m, n, k, a.ravel(), ac, b.ravel(), bc, c0.ravel(), n)
+        ta, tb, tc = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c0.copy()).cuda()
+        torch.cuda.synchronize()
+        capi.sgemm_device(tA, tB, m, n, k, ta.data_ptr(), ac, tb.data_ptr(), bc, tc.data_ptr(), n)
+        assert np.array_equal(bits(tc.cpu().numpy().ravel()), bits(want)), (m, n, k, tA, tB)
+
+
 def test_sgemm_errors():
     with pytest.raises(capi.GorseHipError):
         capi.sgemm(0, 0, 2, 2, 2, np.zeros(4), 1, np.zeros(4), 2, np.zeros(4), 2)  # lda too small

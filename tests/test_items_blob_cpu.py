@@ -232,13 +232,22 @@ def test_marshal_reference_writes_a_graph_the_reference_can_walk(oracle):
     assert params["maxConnection"] == 48 and params["maxConnection0"] == 96 and params["efConstruction"] == 100 and params["ef"] == 0
     assert abs(params["levelFactor"] - 1.0 / np.log(48.0)) < 1e-6
     assert len(streams) == n and streams[5] == gob_f32_slice(X[5])  # the vectors as the reference writes them
+    indeg = np.zeros(n, np.int64)
     for i, (desc, q) in enumerate(bottom):
-        assert not desc and 0 < len(q) <= 96 and all(v != i and 0 <= v < n for v, _ in q)
+        # a queue = the 84 nearest others (exact) + at most 12 reverse links, ascending, every weight the pair's own -dot distance
+        assert not desc and 84 <= len(q) <= 96 and all(v != i and 0 <= v < n for v, _ in q) and len({v for v, _ in q}) == len(q)
         w = [x for _, x in q]
         assert w == sorted(w)
-        ei, ed = oracle.search_vector(X, orc.METRIC_NEG_DOT, X[i], 97)
-        want = [(int(j), float(dd)) for j, dd in zip(ei, ed) if j != i][:96]
-        assert [(v, np.float32(x)) for v, x in q] == [(j, np.float32(dd)) for j, dd in want], i
+        ei, ed = oracle.search_vector(X, orc.METRIC_NEG_DOT, X[i], 85)
+        want = [(int(j), np.float32(dd)) for j, dd in zip(ei, ed) if j != i][:84]
+        have = {v: np.float32(x) for v, x in q}
+        assert all(have.get(j) == dd for j, dd in want), i
+        exact = dict(want)
+        for v, x in q:
+            if v not in exact:  # a reverse link: i is among v's nearest, and the weight is the same distance
+                assert np.float32(x) == np.float32(-np.dot(X[i].astype(np.float64), X[v].astype(np.float64))) or abs(x + float(X[i] @ X[v])) < 1e-5
+            indeg[v] += 1
+    assert (indeg > 0).all()  # every vector can be reached
     assert len(upper) >= 1 and enter in upper[-1]
     for L, layer in enumerate(upper):
         members = set(layer)
