@@ -477,12 +477,21 @@ constexpr int ST_NEG = 1, ST_POS = 2, ST_LIVE = 4;
 // D8: nFactors = 8 (the width of model_test.go:35-48): lanes 0..7 of the group own the eight elements -- the unfused 8-lane tail of
 // the AVX512 kernels (floats_avx512.c:350-358, VecShape::unfused) -- and lanes 8..15 mirror them (the reduction needs the products
 // replicated there); only lanes 0..7 write.
-template <int NC, int ST, bool D8 = false, int G = 2, int IA = 3>
+// SEG (round 5, nFactors <= 32; `make probe-lib` builds only -- a measured dead end, kept so that the measurement can be repeated): a
+// user's run is cut into `segs` consecutive segments, each taken by its own group: every segment starts from the row as it stood
+// before the launch and adds its own change to it with atomics at the end.  With 6040 users (S-ml1m) a group per user leaves the chip
+// at 1.5 waves per SIMD walking ~165 dependent samples each; the segments are the reference's own race -- two of its workers that drew
+// the same user both update p_u from what they read (model.go:449-488) -- made regular.  Result (profiles/r05_k_probe_gpu_probe_bpr_
+// segments.txt: S-ml1m, 30 epochs, three seeds): 3 segments take 5 % off the epoch (0.456 -> 0.432 ms at nFactors 8, 0.350 -> 0.332 at
+// 16, nothing at 32) for 0.001-0.003 of NDCG@10 -- the epoch is not the per-user chain but the chunk's preparation running beside
+// it -- and with 4 / 8 segments a fit DIVERGED (NaN) in two of 18 runs: a heavy user's segments each apply the whole run's
+// regularisation shrink to the same starting row, and the summed changes overshoot (n_u lr reg > 1 for 2000 feedbacks).
+template <int NC, int ST, bool D8 = false, int G = 2, int IA = 3, bool SEG = false>
 __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float *Q, const int32_t *__restrict__ si,
                                                                  const int32_t *__restrict__ sj,
                                                                  const int32_t *__restrict__ off, int32_t U, int d,
                                                                  float lr, float reg, int exp_mode, double *loss,
-                                                                 HotRows hot, int folders, int neg_replicas) {
+                                                                 HotRows hot, int folders, int neg_replicas, int segs = 1) {
     if ((int)blockIdx.x < folders) {
         const int workers = (int)gridDim.x - folders;
         const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
@@ -514,8 +523,15 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
     // the items of this group's last two samples: a row one of them wrote is NOT in the snapshot of the current sample (gathered
     // two samples ago), so its update goes through an atomic whatever its class -- a store would overwrite the group's own work
     int im1 = -1, jm1 = -1, im2 = -1, jm2 = -1;
-    for (int64_t u = group; u < U; u += ngroups) {
-        const int beg = off[u], end = off[u + 1];
+    const int64_t runs = SEG ? (int64_t)U * segs : (int64_t)U;
+    for (int64_t run = group; run < runs; run += ngroups) {
+        const int64_t u = SEG ? run / segs : run;
+        int beg = off[u], end = off[u + 1];
+        if constexpr (SEG) {  // segment run - u * segs of the user's run
+            const int64_t len = end - beg, sg = run - u * segs;
+            end = beg + (int)(len * (sg + 1) / segs);
+            beg = beg + (int)(len * sg / segs);
+        }
         if (beg >= end) continue;
         float *pu = P + u * d;
         // item rows are gathered G samples ahead of the arithmetic (ra[0] / rb[0]: this sample, ra[k]: sample s + k, the row of sample
@@ -538,9 +554,11 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         for (int k = 0; k < IA; k++) ii[k] = si[at(beg + k)], jj[k] = sj[at(beg + k)];
 #pragma unroll
         for (int k = 0; k < G; k++) sli[k] = slot_of[idx_i(ii[k], jj[k])], slj[k] = slot_of[idx_j(ii[k], jj[k])];
+        float p_in[SEG ? NC : 1];  // SEG: the row as this segment found it
 #pragma unroll
         for (int c = 0; c < NC; c++) {
             p[c] = load_row<MODE_ATOMIC>(pu + 16 * c + lane);
+            if (SEG) p_in[SEG ? c : 0] = p[c];
 #pragma unroll
             for (int k = 0; k < G; k++) ra[k][c] = load_row<MODE_ATOMIC>(Q + (int64_t)cl(ii[k]) * d + 16 * c + lane);
 #pragma unroll
@@ -635,8 +653,12 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         }
         if (writer) {
 #pragma unroll
-            for (int c = 0; c < NC; c++)  // the only writer of this row in the launch
-                __hip_atomic_store(pu + 16 * c + lane, p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int c = 0; c < NC; c++) {
+                if (SEG)  // one of `segs` writers of this row: its own change, added
+                    __hip_atomic_fetch_add(pu + 16 * c + lane, p[c] - p_in[SEG ? c : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else  // the only writer of this row in the launch
+                    __hip_atomic_store(pu + 16 * c + lane, p[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (loss && glane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
@@ -875,6 +897,19 @@ bool user_runs_supported(const gorse_mf *h) {
 // it costs 0.003-0.005 of NDCG for 6 % more speed
 constexpr int kDefaultStoreMode = 1;
 int g_store_mode = kDefaultStoreMode;  // ST_* bits of bpr_update_user_kernel
+#ifdef GORSE_PROBE
+constexpr bool kProbeBuild = true;
+#else
+constexpr bool kProbeBuild = false;
+#endif
+int g_user_segments = 0;               // segments per user run of the SEG form (gorse_hip_test_set_bpr_user_segments): 0 = the library's choice
+// segments per user run: the probe build's hook, nFactors <= 32
+int user_segments(const gorse_mf *h) {
+#ifdef GORSE_PROBE
+    if (h->d <= 32 && g_user_segments > 0) return std::min(g_user_segments, 8);
+#endif
+    return 1;  // the shipped library runs one group per user run (see bpr_update_user_kernel, SEG)
+}
 int g_user_gpw = 4;                      // probe builds: groups of a wave that work in the ring kernel (4 = all)
 int g_user_block = kBlock;               // probe builds: threads per workgroup of the ring kernel
 int g_user_depth = 0;                  // probe builds: which (G, IA) pipeline of the atomics-only kernel (gorse_hip_test_set_bpr_user_depth)
@@ -887,7 +922,8 @@ HotRows make_hot(const gorse_mf *h) {
 int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *bucket, size_t cap, float lr, float reg,
                             int exp_mode, double *loss, hipStream_t st, bool stores) {
     const int d = h->d;
-    int64_t blocks = ceil_div(h->U, kGroupsPerBlock);
+    const int segs = user_segments(h);
+    int64_t blocks = ceil_div(h->U * segs, kGroupsPerBlock);
     const int64_t capb = 256 * 16;
     if (blocks > capb) blocks = capb;
     HotRows hot = make_hot(h);
@@ -935,8 +971,18 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
 #define PROBE_DEPTHS(NC)
 #endif
 #define LAUNCH2(NC, ST, G, IA)                                                                                         \
-    bpr_update_user_kernel<(NC == 0 ? 1 : NC), ST, NC == 0, G, IA><<<grid, block, 0, st>>>(                            \
-        h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket, (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, neg_rep)
+    do {                                                                                                               \
+        if constexpr (NC <= 2 && G == 2 && IA == 3 && kProbeBuild) {                                                   \
+            if (segs > 1) {                                                                                            \
+                bpr_update_user_kernel<(NC == 0 ? 1 : NC), ST, NC == 0, G, IA, true><<<grid, block, 0, st>>>(          \
+                    h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket, (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, \
+                    neg_rep, segs);                                                                                    \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        bpr_update_user_kernel<(NC == 0 ? 1 : NC), ST, NC == 0, G, IA><<<grid, block, 0, st>>>(                        \
+            h->P.p, h->Q.p, sorted + cap, sorted + 2 * cap, bucket, (int32_t)h->U, d, lr, reg, exp_mode, loss, hot, folders, neg_rep); \
+    } while (0)
 #ifdef GORSE_PROBE
 #define LAUNCHR(NC, R, D)                                                                                              \
     bpr_update_user_ring_kernel<(NC == 0 ? 1 : NC), NC == 0, R, D><<<rgrid, rblock, 0, st>>>(                          \
@@ -1267,6 +1313,7 @@ extern "C" void gorse_hip_test_set_bpr_user_depth(int32_t v) {
     g_user_gpw = (v >> 20) ? (v >> 20) : 4;                           // bits 20..: working groups per wave (1 / 2 / 4)
 }
 extern "C" void gorse_hip_test_set_bpr_chunk(int64_t samples) { g_chunk_override = samples; }
+extern "C" void gorse_hip_test_set_bpr_user_segments(int32_t segments) { g_user_segments = segments < 0 ? 0 : segments; }
 extern "C" void gorse_hip_test_set_bpr_store_mode(int32_t store_mode) {
     g_store_mode = store_mode < 0 ? kDefaultStoreMode : store_mode;
 #ifndef GORSE_PROBE

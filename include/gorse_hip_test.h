@@ -127,6 +127,12 @@ void gorse_hip_test_set_bpr_chunk(int64_t samples);
  * positive item likewise, bit 2 = the store adds to a row re-read in the same iteration instead of the gathered snapshot;
  * < 0 = the library's default.  Which items are cold is fixed at gorse_mf_create (gorse_hip_test_set_bpr_cold_window). */
 void gorse_hip_test_set_bpr_store_mode(int32_t store_mode);
+/* `make probe-lib` builds only (a measured dead end, csrc/bpr.hip SEG): n = 2..8 segments per user run of the user-run schedule at
+ * nFactors <= 32; 0 / 1 = the plain form.  The shipped library ignores it. */
+void gorse_hip_test_set_bpr_user_segments(int32_t segments);
+/* `make probe-lib` builds only (a measured dead end, csrc/bpr.hip SEG): n = 2..8 segments per user run of the user-run schedule at
+ * nFactors <= 32; 0 / 1 = the plain form.  The shipped library ignores it. */
+void gorse_hip_test_set_bpr_user_segments(int32_t segments);
 /* probe builds (make probe-lib) only: which software pipeline of the atomics-only user-run kernel runs.  Bits 0..7: 0 = the shipped
  * one, 1..6 = (rows gathered G samples ahead, ids IA ahead) = (2,4) (3,5) (3,6) (4,6) (4,8) (6,9) of the same kernel, 10..14 = the ring
  * kernel without register rotation (ring size / id lead) = 3/1, 4/2, 6/3, 8/4, 6/2; bits 8..19: threads per workgroup of the ring
