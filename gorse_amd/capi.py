@@ -123,6 +123,7 @@ SIGNATURES = {
     "gorse_hip_test_set_bpr_chunk": (None, [C.c_int64]),
     "gorse_hip_test_bpr_prepare_chunk": (C.c_int32, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
     "gorse_hip_test_set_bpr_store_mode": (None, [C.c_int32]),
+    "gorse_hip_test_set_prep_cu_stride": (None, [C.c_int32]),
     "gorse_hip_test_set_bpr_user_segments": (None, [C.c_int32]),
     "gorse_hip_test_set_bpr_user_segments": (None, [C.c_int32]),
     "gorse_hip_test_set_bpr_user_depth": (None, [C.c_int32]),

@@ -187,6 +187,8 @@ int32_t mf_score_device(gorse_mf *h, const int32_t *us, const int32_t *is, int64
 
 int g_mf_flat_streams = 1;  // 1 = both streams of a handle at the same priority; 0 (probe) = the update stream ahead
 extern "C" void gorse_hip_test_set_stream_priorities(int32_t on) { g_mf_flat_streams = on ? 0 : 1; }
+int g_mf_prep_cu_stride = 0;  // probe: > 1 = the preparation stream of a handle created afterwards runs on every n-th CU only
+extern "C" void gorse_hip_test_set_prep_cu_stride(int32_t n) { g_mf_prep_cu_stride = n; }
 // 32768: no item of a catalogue smaller than that is cold (S-ml1m: every update stays an atomic; with 2048 there, a third of
 // the cold rows' updates were overwritten); at C3 98 % of the items are
 constexpr int64_t kDefaultColdWindow = 32768;
@@ -252,7 +254,16 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
         // Both streams at the same priority.  Probe (gorse_hip_test_set_stream_priorities(1)): the update stream at the highest
         // stream priority and the sampler / sort stream at the lowest changes nothing at C2 (0.697 vs 0.702 ms per epoch) and
         // costs 3 % at the C3 shard (13.24 vs 12.80 ms): profiles/r02_ak_probe_stream_prio.txt.
-        if (g_mf_flat_streams) {
+        if (g_mf_prep_cu_stride > 1) {
+            // probe: the preparation stream on every n-th CU only (hipExtStreamCreateWithCUMask): the chunk's preparation then
+            // disturbs the update kernel it runs beside on 1 / n of the chip (gorse_hip_test_set_prep_cu_stride)
+            int ncu = 256;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int c = 0; c < ncu; c += g_mf_prep_cu_stride) mask[(size_t)c / 32] |= 1u << (c % 32);
+            GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+            GORSE_HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
+        } else if (g_mf_flat_streams) {
             GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
             GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         } else {

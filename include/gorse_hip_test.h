@@ -68,6 +68,9 @@ void gorse_hip_test_set_scan_literal(int32_t on);
 /* probe: 1 = a gorse_mf handle created afterwards runs its update stream at the device's highest stream priority and its
  * sampler / sort stream at the lowest; 0 (default) = both at the same priority (measured no better: r02_ak). */
 void gorse_hip_test_set_stream_priorities(int32_t on);
+/* probe: n > 1 = the sampler / sort stream of a gorse_mf handle created afterwards is confined to every n-th CU
+ * (hipExtStreamCreateWithCUMask); 0 / 1 = the whole chip (default). */
+void gorse_hip_test_set_prep_cu_stride(int32_t n);
 /* sparse top-k (csrc/sparse*.h*).  Results never depend on any of these.
  * slots: at most this many single-wave workgroups per launch of sparse_tile_kernel (0 = the library's 16 per CU). */
 void gorse_hip_test_set_sparse_slots(int64_t max_slots);
