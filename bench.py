@@ -313,7 +313,7 @@ def bench_topk(args, world, rank, local, fence):
     N, d, k = args.topk_n, 128, 100
     Xb, Xe = synth.s_emb(N, d, 44)
     t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16, device=local)
-    q0, q1 = rank * N // world, (rank + 1) * N // world
+    q0, q1 = gdist.shard_range(N, rank, world, align=128)  # tile-aligned shards: every rank's pass can take the symmetric sweep
     t.all_pairs(k, q0, min(q1, q0 + 8192), fetch=False)  # warm-up: allocations, code objects
     fence()
     # keep the default run bounded: if a 16K-query pass predicts more than --topk-budget seconds for the timed

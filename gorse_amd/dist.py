@@ -13,11 +13,16 @@ same function over gloo with world_size 2).
 import numpy as np
 
 
-def shard_range(n_rows, rank, world):
-    """Contiguous row range [lo, hi) owned by `rank` (remainder rows go to the first ranks)."""
+def shard_range(n_rows, rank, world, align=1):
+    """Contiguous row range [lo, hi) owned by `rank` (remainder rows go to the first ranks).  With `align` the inner
+    boundaries are rounded down to a multiple of it (the symmetric form of the dense all-pairs sweep needs the first
+    query row on a tile boundary: gorse_amd/csrc/topk_mfma.hip, 128 rows)."""
     base, rem = divmod(int(n_rows), int(world))
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+
+    def edge(r):
+        at = r * base + min(r, rem)
+        return at if r == world or align <= 1 else at // align * align
+    return edge(rank), edge(rank + 1)
 
 
 def samples_for_rank(n_total, users_with_feedback_local, users_with_feedback_total):
@@ -100,12 +105,14 @@ def refresh_neighbors_sharded(engine, comm, k, gather=True):
     engine.n_rows, engine.neighbors(lo, hi, k) -> (idx int32 (hi-lo) x k, score float32, cnt int32)."""
     world = comm.world if comm is not None else 1
     rank = comm.rank if comm is not None else 0
-    lo, hi = shard_range(engine.n_rows, rank, world)
+    align = getattr(engine, "shard_align", 1)
+    lo, hi = shard_range(engine.n_rows, rank, world, align)
     idx, score, cnt = engine.neighbors(lo, hi, k)
     if world == 1 or not gather:
         return idx, score, cnt
     import torch
-    b = block_rows(engine.n_rows, world)
+    spans = [shard_range(engine.n_rows, r, world, align) for r in range(world)]
+    b = max(h - l for l, h in spans)
     dev = getattr(engine, "device", "cpu")
 
     def padded(a, fill, width):
@@ -115,7 +122,6 @@ def refresh_neighbors_sharded(engine, comm, k, gather=True):
     g_idx = comm.all_gather(padded(idx, -1, k)).cpu().numpy().reshape(world, b, k)
     g_score = comm.all_gather(padded(score, -np.inf, k)).cpu().numpy().reshape(world, b, k)
     g_cnt = comm.all_gather(padded(cnt, 0, 1)).cpu().numpy().reshape(world, b)
-    spans = [shard_range(engine.n_rows, r, world) for r in range(world)]
     return (np.concatenate([g_idx[r, :h - l] for r, (l, h) in enumerate(spans)]),
             np.concatenate([g_score[r, :h - l] for r, (l, h) in enumerate(spans)]),
             np.concatenate([g_cnt[r, :h - l] for r, (l, h) in enumerate(spans)]))
@@ -126,6 +132,8 @@ class HipNeighborsEngine:
 
     def __init__(self, index, device="cuda", fetch=True):
         self.index, self.device, self.n_rows, self.fetch = index, device, index.N, fetch
+        # a dense index: shards start on a tile boundary, so that every rank's pass can take the symmetric form of the sweep
+        self.shard_align = 128 if hasattr(index, "last_symmetric") else 1
 
     def neighbors(self, lo, hi, k):
         if not self.fetch:  # results stay in HBM (bench.py's timed region); nothing to gather

@@ -77,6 +77,9 @@ def test_shard_range_partitions_rows():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+            tiled = [gdist.shard_range(n, r, w, align=128) for r in range(w)]
+            assert tiled[0][0] == 0 and tiled[-1][1] == n and all(a[1] == b[0] for a, b in zip(tiled, tiled[1:]))
+            assert all(l % 128 == 0 for l, _ in tiled) and all(abs(a[0] - b[0]) < 128 for a, b in zip(tiled, spans))
 
 
 def test_two_rank_bpr_matches_single_process_emulation(tmp_path):
