@@ -411,6 +411,12 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
         const uint32_t p0 = next_p;
         b.n = p0 < total ? (int)min(total - p0, (uint32_t)kBlock) : 0;
         next_p += kBlock;
+        if (p0 >= total) {  // nothing left: the slot's one load all the same (see below), none of the assembly
+            b.mixed = false;
+            b.q = 0.0f;
+            b.P = post[0];
+            return;
+        }
         const uint32_t rel = start - p0;
         if (len > 0 && rel < (uint32_t)kBlock) board[rel] = (uint8_t)(lane + 1);
         uint32_t f = board[lane];
@@ -481,6 +487,14 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
     };
     // kFlatAhead batches in flight; a slot is refilled right after it was applied (its own load has been waited for, so the
     // refill never waits for a register that may still be a load's destination)
+    if (total <= (uint32_t)(2 * kBlock)) {  // one or two batches (most calls of the tail windows): no ring
+        Batch b0, b1;
+        fill(b0);
+        fill(b1);
+        apply(b0);
+        if (b1.n > 0) apply(b1);
+        return;
+    }
     constexpr int kFlatAhead = 6;
     Batch ring[kFlatAhead];
 #pragma unroll
@@ -685,81 +699,138 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         // ---- the tail groups of a whole-query item: SUPER-VISITS ------------------------------------------------------------
         // Behind the head groups a (query, group) visit finds a few dozen postings spread over as many lists, and its fixed cost
         // (three pipeline stages, stamps, read-back: ~460 instructions) was 70 % of the C3-shard pass (profiles/r02_af_probe_sparse_trace.txt).
-        // Here w consecutive groups are taken at once: the directory gives every list's postings in [g, g + w) as ONE contiguous
-        // segment (off is a prefix array over (list, group)), a count pass sizes w so that at most S / 2 postings -- hence at most
-        // that many distinct rows -- are met, and they are accumulated through apply_flattened<HASH> in an open-addressed table
+        // Here several consecutive groups are taken at once -- a WINDOW: the directory gives every list's postings in [gb, ge) as ONE
+        // contiguous segment (off is a prefix array over (list, group)); the windows are cut so that at most S / 2 postings -- hence at
+        // most that many distinct rows -- are met, and they are accumulated through apply_flattened<HASH> in an open-addressed table
         // that lives in the accumulator words.  Chunk after chunk, list after list: every row still receives its products in
         // ascending index order.  A single group with more postings than that takes the direct accumulators (apply_flattened).
+        // Round 5: the windows are PLANNED, 63 groups at a time, before any of them is visited -- lane i sums the directory entries
+        // off[c][g0 + i] over the lists of the query (one coalesced 256-byte read per list, eight in flight), the differences of
+        // neighbouring lanes are the postings the query meets per group, and a scalar greedy pass cuts the windows (lane j of `plan`
+        // = window j).  Until then every window was sized by its own count pass (two dependent loads per chunk, then three more per
+        // chunk to apply it: ~5 exposed round trips per (window, chunk)); with the plan known the visits run through the same kind of
+        // software pipeline as the head groups: index / value pairs two visits ahead, directory entries one visit ahead.
         if (whole && a.head_groups < a.ngroups) {
-            const int S = nacc >> 1, cap_t = nacc >> a.cap_shift;
+            const int S = nacc >> 1;
+            const uint32_t cap_t = (uint32_t)(nacc >> a.cap_shift);
             lds_key *hkey = reinterpret_cast<lds_key *>(acc);
             float *hval = acc + S;
-            auto seg_of = [&](int ch, int gg, int ww, Visit &x) {  // the lane's list in chunk ch: its postings in groups [gg, gg + ww)
-                const int at = ch * kBlock + lane;
-                const bool in = at < L;
-                const int32_t cid = a.q_cid[qs + (in ? at : 0)];
-                x.qv = a.q_val[qs + (in ? at : 0)];
-                x.in = in && cid >= 0;
-                const uint32_t *o = off + (x.in ? (size_t)cid * dir_stride + gg : (size_t)0);
-                const uint32_t s0 = o[0], e0 = o[ww];
-                x.s = x.in ? s0 : 0, x.e = x.in ? e0 : 0;
-            };
-            int gg = a.head_groups, ww = 4;
-            while (gg < a.ngroups) {
-                if (ww > a.ngroups - gg) ww = a.ngroups - gg;
-                uint32_t mine = 0;
-                Visit x;
+            for (int g0 = a.head_groups; g0 < a.ngroups; g0 += kBlock - 1) {
+                const int gcount = a.ngroups - g0 < kBlock - 1 ? a.ngroups - g0 : kBlock - 1;  // groups g0 .. g0 + gcount - 1
+                // -- the plan
+                const int gi = g0 + (lane < gcount ? lane : gcount);
+                uint32_t psum = 0;  // sum over the lists of off[c][gi], modulo 2^32 (the differences are what is used)
                 for (int ch = 0; ch < nch; ch++) {
-                    seg_of(ch, gg, ww, x);
-                    mine += x.e - x.s;
-                }
-                const uint32_t total = wave_sum_u32(mine);
-                if (total == 0) {
-                    gg += ww;
-                    ww = ww < 64 ? ww * 2 : ww;
-                    continue;
-                }
-                if (total > (uint32_t)cap_t && ww > 1) {  // too many for the table: narrower, in proportion
-                    const int nw = (int)(((unsigned long long)ww * (unsigned)cap_t) / total);
-                    ww = nw < 1 ? 1 : (nw < ww ? nw : ww - 1);
-                    continue;
-                }
-                const unsigned long long c0 = tr.now();
-                if (total > (uint32_t)cap_t) {  // one group, many postings: directly indexed accumulators
-                    for (int ch = 0; ch < nch; ch++) {
-                        if (nch > 1) seg_of(ch, gg, 1, x);
-                        if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE>(post, x, acc, tag, touched, tcap, lane, gs, tr, lm, board);
+                    const int at = ch * kBlock + lane;
+                    int32_t cid = a.q_cid[qs + (at < L ? at : 0)];
+                    if (at >= L) cid = -1;
+                    const int nl = L - ch * kBlock < kBlock ? L - ch * kBlock : kBlock;
+                    for (int j0 = 0; j0 < nl; j0 += 8) {
+                        uint32_t tv[8];
+                        int32_t cj[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            cj[u] = __builtin_amdgcn_readlane(cid, j0 + u);
+                            tv[u] = off[(size_t)(cj[u] < 0 ? 0 : cj[u]) * dir_stride + gi];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) psum += cj[u] < 0 ? 0u : tv[u];
                     }
-                    tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
-                    read_back(gg);
-                    gg += 1;
-                    continue;
                 }
-                for (int ch = 0; ch < nch; ch++) {
-                    if (nch > 1) seg_of(ch, gg, ww, x);
-                    if (__ballot(x.e > x.s)) apply_flattened<ATOMIC, TRACE, true>(post, x, acc, tag, touched, tcap, lane, gs, tr, S - 1, board);
-                }
-                tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
-                const unsigned long long c1 = tr.now();
-                for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {  // the slots this super-visit claimed, each once
-                    const bool have = i0 + lane < gs.tcnt;
-                    const int slot = have ? (int)touched[i0 + lane] : 0;
-                    int32_t sid = 0;
-                    float xsum = 0.0f;
-                    if (have) {
-                        sid = hkey[slot] - 1;
-                        xsum = hval[slot];
-                        hkey[slot] = 0;
-                        hval[slot] = 0.0f;
+                const uint32_t pnext = (uint32_t)__builtin_amdgcn_ds_bpermute((lane < kBlock - 1 ? lane + 1 : lane) << 2, (int)psum);
+                const uint32_t tot = lane < gcount ? pnext - psum : 0u;  // postings of the query in group g0 + lane
+                uint32_t plan = 0;  // lane j: window j = begin | end << 8 (relative to g0) | direct << 16
+                int nwin = 0;
+                {
+                    int wb = 0;
+                    uint32_t sum = 0;
+                    auto emit = [&](int b, int e, uint32_t direct) {
+                        if (lane == nwin) plan = (uint32_t)b | ((uint32_t)e << 8) | (direct << 16);
+                        nwin++;
+                    };
+                    for (int i = 0; i < gcount; i++) {
+                        const uint32_t ti = lane_u32(tot, i);
+                        if (ti > cap_t) {  // more than the table takes: the group on its own, directly indexed accumulators
+                            if (sum > 0) emit(wb, i, 0);
+                            emit(i, i + 1, 1);
+                            wb = i + 1, sum = 0;
+                        } else if (sum + ti > cap_t) {
+                            emit(wb, i, 0);
+                            wb = i, sum = ti;
+                        } else
+                            sum += ti;
                     }
-                    consider(have, sid, xsum, 0, false);
+                    if (sum > 0) emit(wb, gcount, 0);
                 }
-                tr.add(&Trace::ticks_back, (uint32_t)(tr.now() - c1));
-                tr.add(&Trace::sparse_groups);
-                walked_q += gs.walked;
-                gs = GroupState{0, 0};
-                gg += ww;
-                if (total * 4 <= (uint32_t)cap_t && ww < 64) ww *= 2;
+                // -- the visits: window-major, chunk after chunk
+                const int64_t Vb = (int64_t)nwin * nch;
+                int t1 = 0, t2 = 0, j2 = 0;
+                auto tstage1 = [&](int64_t v, Visit &x) {
+                    const int at = t1 * kBlock + lane;
+                    x.in = v < Vb && at < L;
+                    x.cid = a.q_cid[qs + (x.in ? at : 0)];
+                    x.qv = a.q_val[qs + (x.in ? at : 0)];
+                    if (++t1 == nch) t1 = 0;
+                };
+                auto tstage2 = [&](Visit &x) {  // folds stage 1; the window of the visit from the plan
+                    x.in = x.in && x.cid >= 0;
+                    const uint32_t w = lane_u32(plan, j2 < kBlock ? j2 : kBlock - 1);
+                    const size_t base = x.in ? (size_t)x.cid * dir_stride + g0 : (size_t)0;
+                    x.s = off[base + (x.in ? (w & 255u) : 0u)];
+                    x.e = off[base + (x.in ? ((w >> 8) & 255u) : 0u)];
+                    if (++t2 == nch) {
+                        t2 = 0;
+                        j2++;
+                    }
+                };
+                Visit x0, x1, x2;
+                tstage1(0, x0);
+                tstage1(1, x1);
+                tstage2(x0);
+                int tc = 0, jw = 0;
+                for (int64_t v = 0; v < Vb; v++) {
+                    tstage2(x1);
+                    tstage1(v + 2, x2);
+                    if (!x0.in) x0.s = 0, x0.e = 0;
+                    const uint32_t w = lane_u32(plan, jw);
+                    const bool direct = (w >> 16) != 0;
+                    const int gg = g0 + (int)(w & 255u);
+                    if (__ballot(x0.e > x0.s)) {
+                        const unsigned long long c0 = tr.now();
+                        if (direct)
+                            apply_flattened<ATOMIC, TRACE>(post, x0, acc, tag, touched, tcap, lane, gs, tr, lm, board);
+                        else
+                            apply_flattened<ATOMIC, TRACE, true>(post, x0, acc, tag, touched, tcap, lane, gs, tr, S - 1, board);
+                        tr.add(&Trace::ticks_flat, (uint32_t)(tr.now() - c0));
+                    }
+                    if (++tc == nch) {  // the window is complete: read it back
+                        tc = 0;
+                        jw++;
+                        if (direct)
+                            read_back(gg);
+                        else {
+                            const unsigned long long c1 = tr.now();
+                            for (int i0 = 0; i0 < gs.tcnt; i0 += kBlock) {  // the slots this super-visit claimed, each once
+                                const bool have = i0 + lane < gs.tcnt;
+                                const int slot = have ? (int)touched[i0 + lane] : 0;
+                                int32_t sid = 0;
+                                float xsum = 0.0f;
+                                if (have) {
+                                    sid = hkey[slot] - 1;
+                                    xsum = hval[slot];
+                                    hkey[slot] = 0;
+                                    hval[slot] = 0.0f;
+                                }
+                                consider(have, sid, xsum, 0, false);
+                            }
+                            tr.add(&Trace::ticks_back, (uint32_t)(tr.now() - c1));
+                            tr.add(&Trace::sparse_groups);
+                            walked_q += gs.walked;
+                            gs = GroupState{0, 0};
+                        }
+                    }
+                    x0 = x1, x1 = x2;
+                }
             }
         }
         const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);

@@ -47,6 +47,12 @@ def main():
         if m.any():
             print("%-18s ms inside: 64 lists at once %.1f, batches / one list at a time %.1f, read-backs %.1f; until the end of group 8: %.1f"
                   % (name, tr[m, 12].sum() / 1e5, tr[m, 13].sum() / 1e5, tr[m, 14].sum() / 1e5, tr[m, 15].sum() / 1e5))
+    whole_e = tr[:, 4]
+    for lo, hi in ((0, 64), (64, 256), (256, 1024), (1024, 1 << 30)):
+        m = ~split & (whole_e > lo) & (whole_e <= hi)
+        if m.any():
+            print("whole-query items with %5d < entries <= %-10d n=%7d  total %9.1f ms  mean %8.1f us  of it batches %.1f ms, read-backs %.1f ms, until the end of group 8 %.1f ms"
+                  % (lo, hi, m.sum(), dur[m].sum() / 1e3, dur[m].mean(), tr[m, 13].sum() / 1e5, tr[m, 14].sum() / 1e5, tr[m, 15].sum() / 1e5))
     # a linear model of an item's duration in its counters: microseconds per unit
     cols = [np.ones(len(tr)), tr[:, 4], tr[:, 5], tr[:, 6], tr[:, 7], tr[:, 8], tr[:, 9]] + ([tr[:, 10], tr[:, 11]] if flat else [])
     X = np.stack(cols, axis=1).astype(np.float64)
