@@ -10,6 +10,7 @@
 #   stats[:<workload>]   rocprofv3 --kernel-trace --stats of the same command (no CPU baseline) -> <tag>_kernel_stats_<W>.txt
 #   pmc:<workload>:<kernel substring>:<key>[:wide]   FETCH_SIZE and WRITE_SIZE passes -> <tag>_traffic.json[key]
 #   sq:<workload>:<kernel substring>                 one SQ pass (MFMA busy, wave cycles, waits) -> <tag>_pmc_SQ_<W>.txt
+#   pmcx:<workload>:<kernel substring>:<counters joined by +>[:<name>]   one pass of any counters -> <tag>_pmcx_<W>[_<name>].txt
 #   probe:<script>[:<args with + for spaces>]        python scripts/<script> args -> <tag>_probe_<script>.txt
 #   ranks2[:<workload>]  bench.py as TWO ranks on the one GPU over gloo (functional check of the N > 1 path; numbers meaningless)
 #   smoke                __graft_entry__.smoke()
@@ -73,6 +74,14 @@ for STAGE in "$@"; do
         python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmc_SQ_${W}.txt" 2>&1
         grep -h "$B" "$OUT/${TAG}_pmc_SQ_${W}.txt" | cut -c1-60,91-170 | head -12
         rm -rf "$OUT/pmc_${TAG}_${W}_SQ" ;;
+    pmcx)  # pmcx:<workload>:<kernel substring>:<counters joined by +>[:<name>]   any counter set in one pass -> <tag>_pmcx_<W>[_name].txt
+        W=$A
+        CNTS=$(echo "$C" | tr '+' ' ')
+        ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $CNTS -d "$OUT/pmcx_${TAG}_${W}" -o bench -- python "$ROOT/bench.py" $(bench_args $W) --no-cpu-baseline --topk-steps 1 ${BENCH_EXTRA:-} > /dev/null 2> "$OUT/${TAG}_pmcx_${W}${D:+_$D}.err" )
+        DB=$(find "$OUT/pmcx_${TAG}_${W}" -name '*_results.db' | head -1)
+        python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmcx_${W}${D:+_$D}.txt" 2>&1
+        grep -h "$B" "$OUT/${TAG}_pmcx_${W}${D:+_$D}.txt" | cut -c1-60,91-200 | head -12
+        rm -rf "$OUT/pmcx_${TAG}_${W}" ;;
     probe)
         ARGS=$(echo "${B:-}" | tr '+' ' ')
         PLIB="$ROOT/gorse_amd/lib/libgorse_hip_probe.so"  # the probe build (make -C gorse_amd/csrc probe-lib) when it exists
