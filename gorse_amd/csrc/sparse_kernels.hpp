@@ -560,8 +560,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const int tcap = nacc >> 2;
         const int nch = (int)(((int64_t)L + kBlock - 1) / kBlock);  // chunks of 64 indices
         const int64_t V = (int64_t)nch * nviews;                    // visits, view-major
-        // The pipeline: while visit v is applied, the postings of v + 1, the directory entries of v + 2 and the (index, value)
-        // pairs of v + 3 are in flight.  (A query of one chunk re-reads its 64 pairs at every visit: two cached loads, and no
+        // The pipeline: while visit v is applied, the postings of v + 1, the directory entries of v + 2 and v + 3 and the (index,
+        // value) pairs of v + 4 and v + 5 are in flight (round 5: one visit deeper each -- a visit of a tail group applies a few dozen
+        // postings in less time than a load takes, and the registers are there since the tail left this loop).  (A query of one chunk re-reads its 64 pairs at every visit: two cached loads, and no
         // branch in the loop that would make the compiler wait for everything in flight.)
         // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (view, chunk) counters
         int c1 = 0, c2 = 0;
@@ -587,16 +588,21 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         auto stage3 = [&](Visit &x) {  // folds stage 2: s = e = 0 where the lane has nothing
             if (!x.in) x.s = 0, x.e = 0;
             const uint32_t len = x.e - x.s;
+            const bool once = !__ballot(len > (uint32_t)kGather);  // a visit with a longer segment takes the flattened path, which loads
+                                                                   // its postings itself: eight gathers of 64 lines each for nothing
 #pragma unroll
             for (int j = 0; j < kGather; j++)  // (what the loop top waits for is everything in flight anyway: skipping costs nothing)
-                if (__ballot((uint32_t)j < len)) x.P[j] = post[x.s + ((uint32_t)j < len ? j : 0)];
+                if (once && __ballot((uint32_t)j < len)) x.P[j] = post[x.s + ((uint32_t)j < len ? j : 0)];
         };
-        Visit v0, v1, v2, v3;
+        Visit v0, v1, v2, v3, v4, v5;
         stage1(0, v0);
         stage1(1, v1);
         stage1(2, v2);
+        stage1(3, v3);
+        stage1(4, v4);
         stage2(0, v0);
         stage2(1, v1);
+        stage2(2, v2);
         stage3(v0);
         GroupState gs{0, 0};
         // one candidate per lane: sid = the row's scratch id, x = its sum; og = orig_of[sid] where the caller has loaded it
@@ -670,8 +676,8 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             // consumers first: each stage needs what the stage before it loaded during the PREVIOUS visit, so whatever the compiler
             // waits for here has had a whole visit to arrive
             stage3(v1);
-            stage2(v + 2, v2);
-            stage1(v + 3, v3);
+            stage2(v + 3, v3);
+            stage1(v + 5, v5);
             {   // visit v
                 const uint32_t len = v0.e - v0.s;
                 if (__ballot(len > 0)) {
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 c = 0;
                 g++;
             }
-            v0 = v1, v1 = v2, v2 = v3;
+            v0 = v1, v1 = v2, v2 = v3, v3 = v4, v4 = v5;
         }
         // ---- the tail groups of a whole-query item: SUPER-VISITS ------------------------------------------------------------
         // Behind the head groups a (query, group) visit finds a few dozen postings spread over as many lists, and its fixed cost
