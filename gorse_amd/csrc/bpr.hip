@@ -174,6 +174,197 @@ __global__ __launch_bounds__(256) void bpr_sample_items_kernel(int32_t U, int32_
     }
 }
 
+// ---- the preparation by user BINS (round 5) ---------------------------------------------------
+// What the three kernels above put on the memory side per sample -- one returning atomic on the user's counter and two 4-byte stores
+// to random places of the sorted order, every 64-byte line of which is written in sixteen pieces by workgroups of different XCDs --
+// is what the update kernel, which runs beside the preparation of the next chunk, is bound by (its item-row atomics).  The binned form
+// sorts in two levels so that no global atomic and no lone store is left per sample:
+//   bpr_bin_count_kernel   : a workgroup draws the users of one TILE of samples (as bpr_sample_user_kernel does), stores the keys and
+//                            counts them per BIN (a range of 2^shift user ids) in LDS and writes its row of the tile x bin matrix;
+//   bpr_bin_offsets_kernel : the matrix's columns -> prefix over the tiles, and the bins' totals;
+//   bpr_bin_scatter_kernel : scans the bin totals (every workgroup for itself: < 8192 bins), adds its row of the matrix = its tile's
+//                            place in every bin, and writes (sample id, user) there -- runs of a tile's samples of one bin, written
+//                            by ONE workgroup, merge in its L2;
+//   bpr_bin_sort_kernel    : a workgroup per bin counts the bin's samples per user in LDS, scans, writes the run offsets of its users
+//                            (bucket[] as the update kernel reads it) and places (sample id, user) at the sorted positions -- stores
+//                            inside the bin's own window;
+//   bpr_sample_items_kernel: unchanged.
+// The order of the samples inside a run is the order of arrival as before (no order is promised: the runs are multisets).
+constexpr int kBinThreads = 512;     // workgroup of the count / scatter kernels
+constexpr int kMaxBins = 8192;       // bins of a chunk at most (LDS: one counter each)
+constexpr int kMaxBinShift = 11;     // user ids per bin at most 2^11 (LDS of the sort kernel: two counters each)
+
+template <int NW>
+__device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t *lds /* NW + 1 */, int32_t *total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[wid] = x;
+    __syncthreads();
+    int32_t base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const int32_t t = lds[w];
+        if (w < wid) base += t;
+        all += t;
+    }
+    if (total) *total = all;
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ __launch_bounds__(kBinThreads) void bpr_bin_count_kernel(int32_t U, const int64_t *__restrict__ uptr, uint64_t seed,
+                                                                    uint64_t epoch, int64_t sample_base, int64_t n, int64_t tile,
+                                                                    int shift, int nbins, int32_t *__restrict__ key,
+                                                                    int32_t *__restrict__ fail_count,
+                                                                    int32_t *__restrict__ H) {
+    __shared__ int32_t hist[kMaxBins];
+    for (int b = threadIdx.x; b < nbins; b += kBinThreads) hist[b] = 0;
+    __syncthreads();
+    const int64_t s0 = (int64_t)blockIdx.x * tile, s1 = s0 + tile < n ? s0 + tile : n;
+    for (int64_t s = s0 + threadIdx.x; s < s1; s += kBinThreads) {
+        Philox g;
+        g.init(seed, epoch, (uint64_t)(sample_base + s));
+        int32_t u = -1;
+        for (int t = 0; t < kMaxDraws; t++) {
+            const int32_t cu = g.int31n(U);
+            if (uptr[cu + 1] > uptr[cu]) {
+                u = cu;
+                break;
+            }
+        }
+        if (u < 0) atomicAdd(fail_count, 1);
+        key[s] = u;
+        atomicAdd(&hist[(u < 0 ? U : u) >> shift], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += kBinThreads) H[(int64_t)blockIdx.x * nbins + b] = hist[b];
+}
+
+// H[t][b] = tile t's count of bin b -> the exclusive prefix over the tiles, in place; bin_count[b] = the bin's total.  (The first form
+// of the binned preparation reserved a tile's share of a bin with a returning atomic on the bin's cursor: a few hundred tiles on
+// one address take ~0.4 us each, one after the other -- 88 us at S-ml1m, the whole gain.  r05_zd_bpr_serial_*.txt)
+constexpr int kOffWaves = 16;
+__global__ __launch_bounds__(kOffWaves * 64) void bpr_bin_offsets_kernel(int32_t *__restrict__ H, int tiles, int nbins,
+                                                                         int32_t *__restrict__ bin_count) {
+    __shared__ int32_t seg[kOffWaves][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    const int per = (tiles + kOffWaves - 1) / kOffWaves, t0 = w * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    int32_t sum = 0;
+    if (b < nbins)
+        for (int t = t0; t < t1; t++) sum += H[(int64_t)t * nbins + b];
+    seg[w][lane] = sum;
+    __syncthreads();
+    int32_t run = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kOffWaves; k++) {
+        const int32_t v = seg[k][lane];
+        if (k < w) run += v;
+        total += v;
+    }
+    if (b < nbins) {
+        for (int t = t0; t < t1; t++) {
+            const int32_t v = H[(int64_t)t * nbins + b];
+            H[(int64_t)t * nbins + b] = run;
+            run += v;
+        }
+        if (w == 0) bin_count[b] = total;
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void bpr_bin_scatter_kernel(int32_t U, const int32_t *__restrict__ key, int64_t n, int64_t tile,
+                                                                      int shift, int nbins, const int32_t *__restrict__ bin_count,
+                                                                      const int32_t *__restrict__ H, int32_t *__restrict__ bin_start,
+                                                                      int32_t *__restrict__ bs, int32_t *__restrict__ bu) {
+    __shared__ int32_t cur[kMaxBins];  // where this tile's next sample of a bin goes
+    __shared__ int32_t wsum[kBinThreads / 64 + 1];
+    constexpr int PER = kMaxBins / kBinThreads;  // bins per thread of the scan
+    {
+        // exclusive scan of the chunk's bin counts (every workgroup its own: < 8192 words); a bin's start + the counts of the tiles
+        // in front of this one = this tile's place in the bin
+        int32_t c[PER], v = 0;
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const int b = threadIdx.x * PER + e;
+            c[e] = b < nbins ? bin_count[b] : 0;
+            v += c[e];
+        }
+        int32_t run = block_exclusive_scan<kBinThreads / 64>(v, wsum, nullptr);
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const int b = threadIdx.x * PER + e;
+            if (blockIdx.x == 0 && b <= nbins) bin_start[b] = run;  // bin_start[nbins] = n (nbins < kMaxBins)
+            if (b < nbins) cur[b] = run + H[(int64_t)blockIdx.x * nbins + b];
+            run += c[e];
+        }
+    }
+    __syncthreads();
+    const int64_t s0 = (int64_t)blockIdx.x * tile, s1 = s0 + tile < n ? s0 + tile : n;
+    for (int64_t s = s0 + threadIdx.x; s < s1; s += kBinThreads) {
+        const int32_t u = key[s];
+        const int32_t pos = atomicAdd(&cur[(u < 0 ? U : u) >> shift], 1);
+        bs[pos] = (int32_t)(s);
+        bu[pos] = u;
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_bin_sort_kernel(int32_t U, int shift, int nbins, const int32_t *__restrict__ bin_start,
+                                                           const int32_t *__restrict__ bs, const int32_t *__restrict__ bu,
+                                                           int32_t *__restrict__ bucket, int32_t *__restrict__ perm,
+                                                           int32_t *__restrict__ su) {
+    __shared__ int32_t cnt[1 << kMaxBinShift];
+    __shared__ int32_t wsum[5];
+    const int ub = 1 << shift;
+    for (int b = blockIdx.x; b < nbins; b += gridDim.x) {
+        const int32_t ulo = b << shift;  // keys ulo .. ulo + ub - 1 (key U = the samples without a user, sorted last)
+        const int32_t b0 = bin_start[b], b1 = bin_start[b + 1];
+        for (int k = threadIdx.x; k < ub; k += 256) cnt[k] = 0;
+        __syncthreads();
+        for (int32_t e = b0 + threadIdx.x; e < b1; e += 256) {
+            const int32_t u = bu[e];
+            atomicAdd(&cnt[(u < 0 ? U : u) - ulo], 1);
+        }
+        __syncthreads();
+        // exclusive scan of cnt[0 .. ub): eight counters per thread and round
+        int32_t carry = 0;
+        for (int k0 = 0; k0 < ub; k0 += 2048) {
+            int32_t c[8], v = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int k = k0 + threadIdx.x * 8 + e;
+                c[e] = k < ub ? cnt[k] : 0;
+                v += c[e];
+            }
+            int32_t total;
+            int32_t run = carry + block_exclusive_scan<4>(v, wsum, &total);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int k = k0 + threadIdx.x * 8 + e;
+                if (k < ub) {
+                    cnt[k] = run;
+                    if (ulo + k <= U) bucket[ulo + k] = b0 + run;
+                    if (ulo + k == U) bucket[U + 1] = b1;
+                }
+                run += c[e];
+            }
+            carry += total;
+        }
+        __syncthreads();
+        for (int32_t e = b0 + threadIdx.x; e < b1; e += 256) {
+            const int32_t u = bu[e];
+            const int32_t p = b0 + atomicAdd(&cnt[(u < 0 ? U : u) - ulo], 1);
+            perm[p] = bs[e];
+            su[p] = u;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- memory access flavours ------------------------------------------------------------------
 template <int MODE>
 __device__ __forceinline__ float load_row(const float *p) {
@@ -875,9 +1066,14 @@ int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int3
 }
 int32_t ensure_user_sort(gorse_mf *h) {
     const int64_t m = h->U + 2;
-    if ((size_t)m <= h->ubucket[0].n && h->scan_tmp2.n >= (size_t)ceil_div(m, kScanTile) && h->urank[0].n >= h->trip_cap)
+    // the tile x bin matrix of the binned preparation: prep_bins gives a chunk at most max(512, cap / 65536) tiles and min(kMaxBins - 1, U + 1) bins
+    const size_t mat = (size_t)std::max<int64_t>(512, ceil_div((int64_t)h->trip_cap, 65536)) * (size_t)std::min<int64_t>(kMaxBins - 1, h->U + 1);
+    if ((size_t)m <= h->ubucket[0].n && h->scan_tmp2.n >= (size_t)ceil_div(m, kScanTile) && h->urank[0].n >= h->trip_cap &&
+        h->ubins.n >= (size_t)2 * kMaxBins && h->ubinmat.n >= mat)
         return GORSE_OK;
     GORSE_TRY(mf_sync_streams(h));
+    if (h->ubins.n < (size_t)2 * kMaxBins) GORSE_TRY(h->ubins.alloc((size_t)2 * kMaxBins));
+    if (h->ubinmat.n < mat) GORSE_TRY(h->ubinmat.alloc(mat));
     for (int b = 0; b < 2; b++) {
         GORSE_TRY(h->ubucket[b].alloc((size_t)m));
         GORSE_TRY(h->urank[b].alloc(h->trip_cap));  // per buffer: the sampler of chunk c + 1 ranks while chunk c is applied
@@ -1096,11 +1292,55 @@ int32_t launch_sampler(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base,
 // The user-run schedule's preparation of one chunk (see bpr_sample_user_kernel): user draws + ranks, scan of the run counters,
 // sample ids scattered to their sorted positions, item draws by run.  `trip` (3 x cap ints, otherwise the unsorted triplets)
 // holds the keys and the permutation; `sorted` receives si at cap, sj at 2 cap; bucket[0..U] the run offsets.
+// bins of the binned preparation for a chunk of n samples: user ids per bin 2^shift, (U >> shift) + 1 bins (key U = no user)
+struct PrepBins {
+    int shift, nbins;
+    int64_t tile;  // samples per workgroup of the count / scatter kernels
+    bool ok;       // false: more user ids per bin than the sort kernel's LDS holds (U > 16M) -> the preparation without bins
+};
+PrepBins prep_bins(int64_t U, int64_t n) {
+    PrepBins b;
+    const int64_t target = std::min<int64_t>(std::max<int64_t>(n / 4096, 512), kMaxBins - 1);
+    b.shift = 0;
+    while ((U >> b.shift) + 1 > target) b.shift++;
+    b.nbins = (int)((U >> b.shift) + 1);
+    int64_t t = 4096;
+    while (t < 65536 && t * 512 < n) t *= 2;
+    b.tile = t;
+    b.ok = b.shift <= kMaxBinShift;
+    return b;
+}
+
 int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base, int64_t n, int32_t *trip, int32_t *sorted,
                              int32_t *bucket, int32_t *rank, size_t cap, hipStream_t st) {
     if (n <= 0) return GORSE_OK;
     const int64_t m = h->U + 2;
     const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
+    const PrepBins pb = prep_bins(h->U, n);
+    if (pb.ok && !(g_variant & (1 << 21))) {  // variant bit 21 (probes, tests): the preparation without bins
+        int32_t *key = trip, *bs = trip + cap, *bu = trip + 2 * cap, *perm = rank;
+        int32_t *bin_count = h->ubins.p, *bin_start = h->ubins.p + kMaxBins, *H = h->ubinmat.p;
+        const unsigned tiles = (unsigned)ceil_div(n, pb.tile);
+        if ((size_t)tiles * pb.nbins > h->ubinmat.n) return fail(GORSE_ERR_INVALID, "tile x bin matrix smaller than %u x %d", tiles, pb.nbins);
+        int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
+        bpr_bin_count_kernel<<<dim3(tiles), dim3(kBinThreads), 0, st>>>((int32_t)h->U, h->uptr.p, seed, epoch, base, n, pb.tile, pb.shift,
+                                                                        pb.nbins, key, h->fail_count.p, H);
+        h->prof.end(tok, st);
+        tok = h->prof.begin(GORSE_PROF_BPR_SORT, st);
+        bpr_bin_offsets_kernel<<<dim3((unsigned)ceil_div(pb.nbins, 64)), dim3(kOffWaves * 64), 0, st>>>(H, (int)tiles, pb.nbins, bin_count);
+        bpr_bin_scatter_kernel<<<dim3(tiles), dim3(kBinThreads), 0, st>>>((int32_t)h->U, key, n, pb.tile, pb.shift, pb.nbins, bin_count,
+                                                                          H, bin_start, bs, bu);
+        bpr_bin_sort_kernel<<<dim3((unsigned)pb.nbins), dim3(256), 0, st>>>((int32_t)h->U, pb.shift, pb.nbins, bin_start, bs, bu, bucket,
+                                                                            perm, sorted);
+        h->prof.end(tok, st);
+        tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
+        bpr_sample_items_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
+                                                                              h->uidx_sorted.p, seed, epoch, base, n, sorted, perm,
+                                                                              sorted + cap, sorted + 2 * cap, h->fail_count.p);
+        h->prof.end(tok, st);
+        GORSE_HIP_CHECK(hipGetLastError());
+        return GORSE_OK;
+    }
     int32_t *key = trip, *perm = trip + cap;
     int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
     GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)m * sizeof(int32_t), st));
@@ -1249,8 +1489,10 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
                 return fail(GORSE_ERR_CANCELLED, "cancelled");
             }
             int32_t *tb = h->trip[b].p;
+            // variant bit 22 (probes): the preparation on the update stream, so that a kernel timeline shows every kernel alone
+            const hipStream_t prep = (g_variant & (1 << 22)) ? h->stream : h->stream2;
             // a never-recorded event is complete: the first two chunks of a handle do not wait
-            GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_consumed[b], 0));
+            GORSE_HIP_CHECK(hipStreamWaitEvent(prep, h->ev_consumed[b], 0));
             // user runs: the whole preparation of chunk c + 1 (launch_prepare_users) runs on the sampler stream under the update
             // kernel of chunk c.  Variant bit 27: the round-3 preparation (whole triplets sampled per sample, then scattered) with the sort on the
             // update stream; bit 26: the same with the sort on the sampler stream.
@@ -1258,19 +1500,19 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             const bool by_run = fused && !(g_variant & (1 << 26));
             if (by_run) {
                 GORSE_TRY(launch_prepare_users(h, seed, epoch, base + s0, m, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p,
-                                               (size_t)cap, h->stream2));
+                                               (size_t)cap, prep));
             } else {
-                int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, h->stream2);
-                GORSE_TRY(launch_sampler(h, seed, epoch, base + s0, m, tb, (size_t)cap, h->stream2, fused ? h->ubucket[b].p : nullptr,
+                int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, prep);
+                GORSE_TRY(launch_sampler(h, seed, epoch, base + s0, m, tb, (size_t)cap, prep, fused ? h->ubucket[b].p : nullptr,
                                          fused ? h->urank[b].p : nullptr));
-                h->prof.end(tok, h->stream2);
+                h->prof.end(tok, prep);
                 if (fused) {
-                    tok = h->prof.begin(GORSE_PROF_BPR_SORT, h->stream2);
-                    GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, h->stream2, true));
-                    h->prof.end(tok, h->stream2);
+                    tok = h->prof.begin(GORSE_PROF_BPR_SORT, prep);
+                    GORSE_TRY(launch_user_sort(h, tb, h->sorted[b].p, h->ubucket[b].p, h->urank[b].p, m, (size_t)cap, prep, true));
+                    h->prof.end(tok, prep);
                 }
             }
-            GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], h->stream2));
+            GORSE_HIP_CHECK(hipEventRecord(h->ev_sampled[b], prep));
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_sampled[b], 0));
             int tok;
             if (uruns && !fused) {

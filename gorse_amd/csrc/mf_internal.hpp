@@ -31,6 +31,8 @@ struct gorse_mf {
     gorse::DevBuf<int32_t> ubucket[2]; // U + 2 run offsets per triplet buffer (sorted on stream2)
     gorse::DevBuf<int32_t> urank[2];   // arrival rank of a sample inside its user's run, per triplet buffer
     gorse::DevBuf<int32_t> scan_tmp2;  // per-tile sums of the sort's scan (the sort may run on the sampler stream)
+    gorse::DevBuf<int32_t> ubins;      // binned preparation: bin totals, bin starts at kMaxBins (preparations are serial: one copy)
+    gorse::DevBuf<int32_t> ubinmat;    // binned preparation: the tile x bin count matrix
     int64_t chunk_seq = 0;             // chunks enqueued so far: buffer = chunk_seq & 1, across calls
     // hot-row replicas of the Hogwild schedule (bpr.hip): popular items' positive updates land here
     gorse::DevBuf<int32_t> hot_slot, hot_items, hot_done;

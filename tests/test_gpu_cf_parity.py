@@ -623,6 +623,35 @@ def test_prepared_chunk_at_a_size_the_product_takes_the_path(oracle):
         mf.close()
 
 
+def test_prepared_chunk_binned_and_unbinned_on_many_users(oracle):
+    """The binned preparation (csrc/bpr.hip, bpr_bin_count / _scatter / _sort kernels: bins of 2^shift user ids, here 1024 ids per bin
+    and several tiles) and the preparation without bins (variant bit 21) hold the same runs: the triplets of the per-sample sampler,
+    each in the run of its user; users without feedback (every third id) never own a run."""
+    L = capi.lib()
+    U, I = 300_000, 2000
+    lens = np.full(U, 3, np.int64)
+    lens[::3] = 0
+    uptr = np.zeros(U + 1, np.int64)
+    np.cumsum(lens, out=uptr[1:])
+    rng = np.random.default_rng(11)
+    uidx = (rng.integers(0, I - 3, int(uptr[-1]) // 3)[:, None] + np.arange(3)).astype(np.int32).reshape(-1)  # three distinct items per row
+    mf = capi.MF(U, I, 16, uptr, uidx)
+    try:
+        n, seed, epoch, base = 1_500_000, 77, 2, 999
+        gu, gi, gj = mf.bpr_sample_triplets(n, seed, epoch, base)
+        assert (gu >= 0).all() and (lens[gu] > 0).all()
+        want = _sorted_triples(gu, gi, gj)
+        for variant in (0, 1 << 21):
+            L.gorse_hip_test_set_variant(variant)
+            off, si, sj = mf.bpr_prepare_chunk(n, seed, epoch, base)
+            assert off[0] == 0 and off[U] == n and off[U + 1] == n and (np.diff(off) >= 0).all()
+            su = np.repeat(np.arange(U + 1, dtype=np.int32), np.diff(off))
+            assert np.array_equal(_sorted_triples(su[:n], si, sj), want), variant
+    finally:
+        L.gorse_hip_test_set_variant(0)
+        mf.close()
+
+
 def test_epoch_with_a_user_holding_every_item_skips_its_samples(oracle):
     """bpr_update_user_kernel meets (-1, -1) pairs inside a run (no negative found): nothing is written for them, the rest of the
     run is applied.  Compared with the oracle's Hogwild-free sequential pass over the triplets that exist."""
