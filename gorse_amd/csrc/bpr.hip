@@ -129,31 +129,46 @@ __global__ __launch_bounds__(256) void bpr_sample_user_kernel(int32_t U, const i
 
 __global__ __launch_bounds__(256) void bpr_scatter_ids_kernel(const int32_t *__restrict__ key, const int32_t *__restrict__ rank,
                                                               const int32_t *__restrict__ bucket, int64_t n, int32_t U,
-                                                              int32_t *__restrict__ perm, int32_t *__restrict__ su) {
+                                                              int2 *__restrict__ pairs) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) {
         const int32_t k = key[s] < 0 ? U : key[s];
         const int64_t pos = (int64_t)bucket[k] + rank[s];
-        perm[pos] = (int32_t)s;
-        su[pos] = key[s];
+        pairs[pos] = make_int2((int32_t)s, key[s]);  // (sample id, user) at the sorted position: one 8-byte store
     }
+}
+
+// the item draws of one sample from the start of its stream (model.go:452-468): the path of a sample whose first negative candidate
+// was one of the user's own items -- the batch in bpr_sample_items_kernel only carries the first candidate
+__device__ __forceinline__ int32_t draw_negative_again(int32_t U, int32_t I, const int32_t *__restrict__ row, int64_t cnt, int32_t u,
+                                                    uint64_t seed, uint64_t epoch, uint64_t sample) {
+    Philox g;
+    g.init(seed, epoch, sample);
+    for (int k = 0; k < kMaxDraws; k++)
+        if (g.int31n(U) == u) break;
+    (void)g.int31n((int32_t)cnt);  // the positive's draw
+    for (int k = 0; k < kMaxDraws; k++) {
+        const int32_t c = g.int31n(I);
+        if (!row_contains(row, cnt, c)) return c;
+    }
+    return -1;
 }
 
 __global__ __launch_bounds__(256) void bpr_sample_items_kernel(int32_t U, int32_t I, const int64_t *__restrict__ uptr,
                                                                const int32_t *__restrict__ uidx,
                                                                const int32_t *__restrict__ usorted, uint64_t seed,
                                                                uint64_t epoch, int64_t sample_base, int64_t n,
-                                                               const int32_t *__restrict__ su,
-                                                               const int32_t *__restrict__ perm, int32_t *__restrict__ si,
+                                                               const int2 *__restrict__ pairs, int32_t *__restrict__ si,
                                                                int32_t *__restrict__ sj, int32_t *__restrict__ fail_count) {
     // one thread per SORTED position: neighbouring threads hold samples of the same user, so the user's row pointers and its
     // two item rows are shared by the lanes of a wave (and by the waves that follow) while they sit in the cache
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t u = su[t];
+        const int2 pr = pairs[t];  // (sample id, user)
+        const int32_t u = pr.y;
         if (u < 0) continue;  // no user could be drawn: the positions behind the last run, never read
         const int64_t rbeg = uptr[u];
         const int64_t cnt = uptr[u + 1] - rbeg;
         Philox g;
-        g.init(seed, epoch, (uint64_t)(sample_base + perm[t]));
+        g.init(seed, epoch, (uint64_t)(sample_base + pr.x));
         // the user draw again: rows drawn before u were empty (u is the first non-empty one), no look-up needed
         for (int k = 0; k < kMaxDraws; k++)
             if (g.int31n(U) == u) break;
@@ -171,6 +186,86 @@ __global__ __launch_bounds__(256) void bpr_sample_items_kernel(int32_t U, int32_
         }
         si[t] = pi;
         sj[t] = nj;
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_sample_items_batch_kernel(int32_t U, int32_t I, const int64_t *__restrict__ uptr,
+                                                               const int32_t *__restrict__ uidx,
+                                                               const int32_t *__restrict__ usorted, uint64_t seed,
+                                                               uint64_t epoch, int64_t sample_base, int64_t n,
+                                                               const int2 *__restrict__ pairs, int32_t *__restrict__ si,
+                                                               int32_t *__restrict__ sj, int32_t *__restrict__ fail_count) {
+    // bpr_sample_items_kernel with four positions per thread, in lock step: a sample is a chain of ~12 dependent loads (row pointers, the
+    // positive, the binary search of the negative candidate in the sorted row); where the rows do not sit in the L2 (C3 shard: 12.5M
+    // feedbacks) four chains per thread take 100 -> 81 us per 4M samples; where they do (S-ml1m) the one-sample kernel is the
+    // faster one (37 against 47 us per million: more steps per wave, the redo of the samples whose first candidate is rejected).
+    // The search is the same lower bound, one step of all four per round.
+    constexpr int B = 4;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t tb = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tb < n; tb += B * nthreads) {
+        int32_t u[B], sid[B];
+#pragma unroll
+        for (int e = 0; e < B; e++) {
+            const int64_t t = tb + e * nthreads;
+            const int2 pr = t < n ? pairs[t] : make_int2(0, -1);  // (sample id, user)
+            u[e] = pr.y;  // u < 0: no user could be drawn (the positions behind the last run, never read)
+            sid[e] = pr.x;
+        }
+        int64_t rbeg[B];
+        int32_t cnt[B];
+#pragma unroll
+        for (int e = 0; e < B; e++) {
+            const int32_t uu = u[e] < 0 ? 0 : u[e];
+            rbeg[e] = uptr[uu];
+            cnt[e] = (int32_t)(uptr[uu + 1] - rbeg[e]);
+            if (u[e] < 0 || cnt[e] <= 0) cnt[e] = 0;
+        }
+        int32_t pi[B], c[B];
+#pragma unroll
+        for (int e = 0; e < B; e++) {
+            Philox g;
+            g.init(seed, epoch, (uint64_t)(sample_base + sid[e]));
+            // the user draw again: rows drawn before u were empty (u is the first non-empty one), no look-up needed
+            for (int k = 0; k < kMaxDraws; k++)
+                if (cnt[e] == 0 || g.int31n(U) == u[e]) break;
+            const int32_t r = g.int31n(cnt[e] > 0 ? cnt[e] : 1);
+            c[e] = g.int31n(I);
+            pi[e] = cnt[e] > 0 ? uidx[rbeg[e] + r] : -1;
+        }
+        int32_t lo[B], len[B];
+#pragma unroll
+        for (int e = 0; e < B; e++) lo[e] = 0, len[e] = cnt[e];
+        while ((len[0] | len[1] | len[2] | len[3]) != 0) {  // (lengths are >= 0)
+            int32_t v[B];
+#pragma unroll
+            for (int e = 0; e < B; e++) v[e] = len[e] > 0 ? usorted[rbeg[e] + lo[e] + (len[e] >> 1)] : 0;
+#pragma unroll
+            for (int e = 0; e < B; e++) {
+                if (len[e] > 0) {
+                    const int32_t half = len[e] >> 1;
+                    if (v[e] < c[e]) {
+                        lo[e] += half + 1;
+                        len[e] -= half + 1;
+                    } else {
+                        len[e] = half;
+                    }
+                }
+            }
+        }
+        int32_t at[B];
+#pragma unroll
+        for (int e = 0; e < B; e++) at[e] = lo[e] < cnt[e] ? usorted[rbeg[e] + lo[e]] : -1;
+#pragma unroll
+        for (int e = 0; e < B; e++) {
+            const int64_t t = tb + e * nthreads;
+            if (t >= n || u[e] < 0) continue;
+            int32_t nj = c[e];
+            if (at[e] == c[e])  // the candidate is one of the user's items: the rest of the draws, one at a time
+                nj = draw_negative_again(U, I, usorted + rbeg[e], cnt[e], u[e], seed, epoch, (uint64_t)(sample_base + sid[e]));
+            if (nj < 0) atomicAdd(fail_count, 1);
+            si[t] = nj < 0 ? -1 : pi[e];
+            sj[t] = nj;
+        }
     }
 }
 
@@ -192,6 +287,7 @@ __global__ __launch_bounds__(256) void bpr_sample_items_kernel(int32_t U, int32_
 // The order of the samples inside a run is the order of arrival as before (no order is promised: the runs are multisets).
 constexpr int kBinThreads = 512;     // workgroup of the count / scatter kernels
 constexpr int kMaxBins = 8192;       // bins of a chunk at most (LDS: one counter each)
+constexpr int kBinBatch = 8;         // samples of a thread whose loads are in flight together (scatter / sort kernels)
 constexpr int kMaxBinShift = 11;     // user ids per bin at most 2^11 (LDS of the sort kernel: two counters each)
 
 template <int NW>
@@ -217,6 +313,19 @@ __device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t *lds 
     return base + x - v;
 }
 
+// the user draw of a sample whose FIRST draw met a user without feedback: the stream again from its start (model.go:452-458)
+__device__ __forceinline__ int32_t draw_user_again(int32_t U, const int64_t *__restrict__ uptr, uint64_t seed, uint64_t epoch,
+                                                uint64_t sample, int32_t *__restrict__ fail_count) {
+    Philox g;
+    g.init(seed, epoch, sample);
+    for (int t = 0; t < kMaxDraws; t++) {
+        const int32_t cu = g.int31n(U);
+        if (uptr[cu + 1] > uptr[cu]) return cu;
+    }
+    atomicAdd(fail_count, 1);
+    return -1;
+}
+
 __global__ __launch_bounds__(kBinThreads) void bpr_bin_count_kernel(int32_t U, const int64_t *__restrict__ uptr, uint64_t seed,
                                                                     uint64_t epoch, int64_t sample_base, int64_t n, int64_t tile,
                                                                     int shift, int nbins, int32_t *__restrict__ key,
@@ -226,20 +335,31 @@ __global__ __launch_bounds__(kBinThreads) void bpr_bin_count_kernel(int32_t U, c
     for (int b = threadIdx.x; b < nbins; b += kBinThreads) hist[b] = 0;
     __syncthreads();
     const int64_t s0 = (int64_t)blockIdx.x * tile, s1 = s0 + tile < n ? s0 + tile : n;
-    for (int64_t s = s0 + threadIdx.x; s < s1; s += kBinThreads) {
-        Philox g;
-        g.init(seed, epoch, (uint64_t)(sample_base + s));
-        int32_t u = -1;
-        for (int t = 0; t < kMaxDraws; t++) {
-            const int32_t cu = g.int31n(U);
-            if (uptr[cu + 1] > uptr[cu]) {
-                u = cu;
-                break;
+    // four samples per thread at a time: their first user draws' row pointers are in flight together (the draw that finds an
+    // empty row -- rare -- goes on alone, same stream, same order of draws)
+    constexpr int B = 4;
+    for (int64_t sb = s0 + threadIdx.x; sb < s1; sb += B * kBinThreads) {
+        int32_t cu[B];
+        int64_t r0[B], r1[B];
+#pragma unroll
+        for (int e = 0; e < B; e++) {
+            const int64_t s = sb + (int64_t)e * kBinThreads;
+            Philox g;
+            g.init(seed, epoch, (uint64_t)(sample_base + (s < s1 ? s : s0)));
+            cu[e] = g.int31n(U);
+            r0[e] = uptr[cu[e]];
+            r1[e] = uptr[cu[e] + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < B; e++) {
+            const int64_t s = sb + (int64_t)e * kBinThreads;
+            if (s < s1) {
+                int32_t u = r1[e] > r0[e] ? cu[e] : -1;
+                if (u < 0) u = draw_user_again(U, uptr, seed, epoch, (uint64_t)(sample_base + s), fail_count);
+                key[s] = u;
+                atomicAdd(&hist[(u < 0 ? U : u) >> shift], 1);
             }
         }
-        if (u < 0) atomicAdd(fail_count, 1);
-        key[s] = u;
-        atomicAdd(&hist[(u < 0 ? U : u) >> shift], 1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < nbins; b += kBinThreads) H[(int64_t)blockIdx.x * nbins + b] = hist[b];
@@ -280,7 +400,7 @@ __global__ __launch_bounds__(kOffWaves * 64) void bpr_bin_offsets_kernel(int32_t
 __global__ __launch_bounds__(kBinThreads) void bpr_bin_scatter_kernel(int32_t U, const int32_t *__restrict__ key, int64_t n, int64_t tile,
                                                                       int shift, int nbins, const int32_t *__restrict__ bin_count,
                                                                       const int32_t *__restrict__ H, int32_t *__restrict__ bin_start,
-                                                                      int32_t *__restrict__ bs, int32_t *__restrict__ bu) {
+                                                                      int2 *__restrict__ bp) {
     __shared__ int32_t cur[kMaxBins];  // where this tile's next sample of a bin goes
     __shared__ int32_t wsum[kBinThreads / 64 + 1];
     constexpr int PER = kMaxBins / kBinThreads;  // bins per thread of the scan
@@ -304,19 +424,29 @@ __global__ __launch_bounds__(kBinThreads) void bpr_bin_scatter_kernel(int32_t U,
         }
     }
     __syncthreads();
+    // (eight keys per thread in flight: one load per iteration made the loop a chain of memory latencies -- 96 -> us per 4M samples)
     const int64_t s0 = (int64_t)blockIdx.x * tile, s1 = s0 + tile < n ? s0 + tile : n;
-    for (int64_t s = s0 + threadIdx.x; s < s1; s += kBinThreads) {
-        const int32_t u = key[s];
-        const int32_t pos = atomicAdd(&cur[(u < 0 ? U : u) >> shift], 1);
-        bs[pos] = (int32_t)(s);
-        bu[pos] = u;
+    for (int64_t sb = s0 + threadIdx.x; sb < s1; sb += kBinBatch * kBinThreads) {
+        int32_t u[kBinBatch];
+#pragma unroll
+        for (int e = 0; e < kBinBatch; e++) {
+            const int64_t s = sb + (int64_t)e * kBinThreads;
+            u[e] = s < s1 ? key[s] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < kBinBatch; e++) {
+            const int64_t s = sb + (int64_t)e * kBinThreads;
+            if (s < s1) {
+                const int32_t pos = atomicAdd(&cur[(u[e] < 0 ? U : u[e]) >> shift], 1);
+                bp[pos] = make_int2((int32_t)s, u[e]);  // (sample id, user): one 8-byte store
+            }
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void bpr_bin_sort_kernel(int32_t U, int shift, int nbins, const int32_t *__restrict__ bin_start,
-                                                           const int32_t *__restrict__ bs, const int32_t *__restrict__ bu,
-                                                           int32_t *__restrict__ bucket, int32_t *__restrict__ perm,
-                                                           int32_t *__restrict__ su) {
+                                                           const int2 *__restrict__ bp, int32_t *__restrict__ bucket,
+                                                           int2 *__restrict__ pairs) {
     __shared__ int32_t cnt[1 << kMaxBinShift];
     __shared__ int32_t wsum[5];
     const int ub = 1 << shift;
@@ -325,9 +455,13 @@ __global__ __launch_bounds__(256) void bpr_bin_sort_kernel(int32_t U, int shift,
         const int32_t b0 = bin_start[b], b1 = bin_start[b + 1];
         for (int k = threadIdx.x; k < ub; k += 256) cnt[k] = 0;
         __syncthreads();
-        for (int32_t e = b0 + threadIdx.x; e < b1; e += 256) {
-            const int32_t u = bu[e];
-            atomicAdd(&cnt[(u < 0 ? U : u) - ulo], 1);
+        for (int32_t eb = b0 + threadIdx.x; eb < b1; eb += kBinBatch * 256) {
+            int32_t u[kBinBatch];
+#pragma unroll
+            for (int e = 0; e < kBinBatch; e++) u[e] = eb + e * 256 < b1 ? bp[eb + e * 256].y : 0;
+#pragma unroll
+            for (int e = 0; e < kBinBatch; e++)
+                if (eb + e * 256 < b1) atomicAdd(&cnt[(u[e] < 0 ? U : u[e]) - ulo], 1);
         }
         __syncthreads();
         // exclusive scan of cnt[0 .. ub): eight counters per thread and round
@@ -355,11 +489,17 @@ __global__ __launch_bounds__(256) void bpr_bin_sort_kernel(int32_t U, int shift,
             carry += total;
         }
         __syncthreads();
-        for (int32_t e = b0 + threadIdx.x; e < b1; e += 256) {
-            const int32_t u = bu[e];
-            const int32_t p = b0 + atomicAdd(&cnt[(u < 0 ? U : u) - ulo], 1);
-            perm[p] = bs[e];
-            su[p] = u;
+        for (int32_t eb = b0 + threadIdx.x; eb < b1; eb += kBinBatch * 256) {
+            int2 pr[kBinBatch];
+#pragma unroll
+            for (int e = 0; e < kBinBatch; e++) pr[e] = eb + e * 256 < b1 ? bp[eb + e * 256] : make_int2(0, 0);
+#pragma unroll
+            for (int e = 0; e < kBinBatch; e++) {
+                if (eb + e * 256 < b1) {
+                    const int32_t p = b0 + atomicAdd(&cnt[(pr[e].y < 0 ? U : pr[e].y) - ulo], 1);
+                    pairs[p] = pr[e];
+                }
+            }
         }
         __syncthreads();
     }
@@ -1068,7 +1208,7 @@ int32_t ensure_user_sort(gorse_mf *h) {
     const int64_t m = h->U + 2;
     // the tile x bin matrix of the binned preparation: prep_bins gives a chunk at most max(512, cap / 65536) tiles and min(kMaxBins - 1, U + 1) bins
     const size_t mat = (size_t)std::max<int64_t>(512, ceil_div((int64_t)h->trip_cap, 65536)) * (size_t)std::min<int64_t>(kMaxBins - 1, h->U + 1);
-    if ((size_t)m <= h->ubucket[0].n && h->scan_tmp2.n >= (size_t)ceil_div(m, kScanTile) && h->urank[0].n >= h->trip_cap &&
+    if ((size_t)m <= h->ubucket[0].n && h->scan_tmp2.n >= (size_t)ceil_div(m, kScanTile) && h->urank[0].n >= 2 * h->trip_cap &&
         h->ubins.n >= (size_t)2 * kMaxBins && h->ubinmat.n >= mat)
         return GORSE_OK;
     GORSE_TRY(mf_sync_streams(h));
@@ -1076,7 +1216,9 @@ int32_t ensure_user_sort(gorse_mf *h) {
     if (h->ubinmat.n < mat) GORSE_TRY(h->ubinmat.alloc(mat));
     for (int b = 0; b < 2; b++) {
         GORSE_TRY(h->ubucket[b].alloc((size_t)m));
-        GORSE_TRY(h->urank[b].alloc(h->trip_cap));  // per buffer: the sampler of chunk c + 1 ranks while chunk c is applied
+        // per buffer (the sampler of chunk c + 1 ranks while chunk c is applied); twice the chunk: the binned preparation's (sample id,
+        // user) pairs in sorted order
+        GORSE_TRY(h->urank[b].alloc(2 * h->trip_cap));
     }
     if (h->scan_tmp2.n < (size_t)ceil_div(m, kScanTile)) GORSE_TRY(h->scan_tmp2.alloc((size_t)ceil_div(m, kScanTile)));
     return GORSE_OK;
@@ -1291,7 +1433,8 @@ int32_t launch_sampler(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base,
 
 // The user-run schedule's preparation of one chunk (see bpr_sample_user_kernel): user draws + ranks, scan of the run counters,
 // sample ids scattered to their sorted positions, item draws by run.  `trip` (3 x cap ints, otherwise the unsorted triplets)
-// holds the keys and the permutation; `sorted` receives si at cap, sj at 2 cap; bucket[0..U] the run offsets.
+// holds the keys and (sample id, user) pairs; `rank` (2 x cap) the ranks or the sorted pairs; `sorted` receives si at cap, sj at
+// 2 cap; bucket[0..U + 1] the run offsets.
 // bins of the binned preparation for a chunk of n samples: user ids per bin 2^shift, (U >> shift) + 1 bins (key U = no user)
 struct PrepBins {
     int shift, nbins;
@@ -1317,8 +1460,20 @@ int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t
     const int64_t m = h->U + 2;
     const int64_t blocks = std::min<int64_t>(ceil_div(n, 256), 256 * 8);
     const PrepBins pb = prep_bins(h->U, n);
+    // the item draws: four positions per thread where the users' rows cannot all sit in the L2s (see bpr_sample_items_batch_kernel)
+    auto launch_items = [&](const int2 *pairs) {
+        if (h->uidx.n > ((size_t)8 << 20))
+            bpr_sample_items_batch_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
+                                                                                        h->uidx_sorted.p, seed, epoch, base, n, pairs,
+                                                                                        sorted + cap, sorted + 2 * cap, h->fail_count.p);
+        else
+            bpr_sample_items_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
+                                                                                  h->uidx_sorted.p, seed, epoch, base, n, pairs,
+                                                                                  sorted + cap, sorted + 2 * cap, h->fail_count.p);
+    };
     if (pb.ok && !(g_variant & (1 << 21))) {  // variant bit 21 (probes, tests): the preparation without bins
-        int32_t *key = trip, *bs = trip + cap, *bu = trip + 2 * cap, *perm = rank;
+        int32_t *key = trip;
+        int2 *bp = reinterpret_cast<int2 *>(trip + cap), *pairs = reinterpret_cast<int2 *>(rank);  // (rank: 2 x cap words, ensure_user_sort)
         int32_t *bin_count = h->ubins.p, *bin_start = h->ubins.p + kMaxBins, *H = h->ubinmat.p;
         const unsigned tiles = (unsigned)ceil_div(n, pb.tile);
         if ((size_t)tiles * pb.nbins > h->ubinmat.n) return fail(GORSE_ERR_INVALID, "tile x bin matrix smaller than %u x %d", tiles, pb.nbins);
@@ -1329,19 +1484,17 @@ int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t
         tok = h->prof.begin(GORSE_PROF_BPR_SORT, st);
         bpr_bin_offsets_kernel<<<dim3((unsigned)ceil_div(pb.nbins, 64)), dim3(kOffWaves * 64), 0, st>>>(H, (int)tiles, pb.nbins, bin_count);
         bpr_bin_scatter_kernel<<<dim3(tiles), dim3(kBinThreads), 0, st>>>((int32_t)h->U, key, n, pb.tile, pb.shift, pb.nbins, bin_count,
-                                                                          H, bin_start, bs, bu);
-        bpr_bin_sort_kernel<<<dim3((unsigned)pb.nbins), dim3(256), 0, st>>>((int32_t)h->U, pb.shift, pb.nbins, bin_start, bs, bu, bucket,
-                                                                            perm, sorted);
+                                                                          H, bin_start, bp);
+        bpr_bin_sort_kernel<<<dim3((unsigned)pb.nbins), dim3(256), 0, st>>>((int32_t)h->U, pb.shift, pb.nbins, bin_start, bp, bucket, pairs);
         h->prof.end(tok, st);
         tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
-        bpr_sample_items_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
-                                                                              h->uidx_sorted.p, seed, epoch, base, n, sorted, perm,
-                                                                              sorted + cap, sorted + 2 * cap, h->fail_count.p);
+        launch_items(pairs);
         h->prof.end(tok, st);
         GORSE_HIP_CHECK(hipGetLastError());
         return GORSE_OK;
     }
-    int32_t *key = trip, *perm = trip + cap;
+    int32_t *key = trip;
+    int2 *pairs = reinterpret_cast<int2 *>(trip + cap);
     int tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
     GORSE_HIP_CHECK(hipMemsetAsync(bucket, 0, (size_t)m * sizeof(int32_t), st));
     bpr_sample_user_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, h->uptr.p, seed, epoch, base, n, key,
@@ -1349,12 +1502,10 @@ int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t
     h->prof.end(tok, st);
     tok = h->prof.begin(GORSE_PROF_BPR_SORT, st);
     GORSE_TRY(exclusive_scan_i32(bucket, m, h->scan_tmp2.p, st));
-    bpr_scatter_ids_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(key, rank, bucket, n, (int32_t)h->U, perm, sorted);
+    bpr_scatter_ids_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(key, rank, bucket, n, (int32_t)h->U, pairs);
     h->prof.end(tok, st);
     tok = h->prof.begin(GORSE_PROF_BPR_SAMPLE, st);
-    bpr_sample_items_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((int32_t)h->U, (int32_t)h->I, h->uptr.p, h->uidx.p,
-                                                                          h->uidx_sorted.p, seed, epoch, base, n, sorted, perm,
-                                                                          sorted + cap, sorted + 2 * cap, h->fail_count.p);
+    launch_items(pairs);
     h->prof.end(tok, st);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
@@ -1372,6 +1523,7 @@ int64_t chunk_capacity(const gorse_mf *h) {
 
 int32_t ensure_trip(gorse_mf *h, int64_t want) {
     size_t cap = (size_t)std::min<int64_t>(std::max<int64_t>(want, 1), chunk_capacity(h));
+    cap = (cap + 1) & ~(size_t)1;  // even: trip + cap is read as (sample id, user) pairs of 8 bytes
     if (cap <= h->trip_cap) return GORSE_OK;
     GORSE_TRY(mf_sync_streams(h));
     for (int b = 0; b < 2; b++) GORSE_TRY(h->trip[b].alloc(cap * 3));
