@@ -577,13 +577,28 @@ struct HotRows {
     const int32_t *slot;   // I entries: replica slot of an item, or -1
     const int32_t *items;  // n_hot entries: item of a slot
     float *rep;            // n_hot x kHotReplicas x d, all zero outside an update launch
-    int32_t *done;         // worker workgroups that have finished (zeroed before the launch)
+    int32_t *done;         // worker workgroups that have finished, counted in kDoneStripes words (zeroed before the launch)
     int n_hot;
     int64_t stride_s, stride_r;  // replica r of slot s starts at rep + s * stride_s + r * stride_r
 #ifdef GORSE_PROBE
     float *warm_scratch = nullptr;  // timing probe (variant bit 23): the atomics of the items WITHOUT replicas land here instead of on Q (results garbage)
 #endif
 };
+
+// The arrival counter of the worker workgroups, in kDoneStripes words 256 bytes apart: one 64-byte line serves 88 M atomics/s
+// (scripts/probe_atomics4.hip), and the per-sample kernel's 4096 workgroups, which all finish within a few microseconds of each other,
+// queued 46 us on a single word at the end of every launch (S-ml100k: a third of the kernel).
+constexpr int kDoneStripes = GORSE_HOT_DONE_STRIPES, kDoneStride = GORSE_HOT_DONE_STRIDE;
+__device__ __forceinline__ void worker_done(const HotRows &hot) {
+    __hip_atomic_fetch_add(hot.done + (blockIdx.x & (kDoneStripes - 1)) * kDoneStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool workers_done(const HotRows &hot, int workers) {  // (called by whole waves)
+    const int lane = threadIdx.x & 63;
+    int v = lane < kDoneStripes ? __hip_atomic_load(hot.done + lane * kDoneStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v >= workers;
+}
 
 // one folder pass: (slot, element) pairs strided over the folder threads
 __device__ __forceinline__ void fold_pass(const HotRows &hot, float *Q, int d, int64_t tid, int64_t nthreads) {
@@ -619,7 +634,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
         const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
         for (int pass = 0; pass < (1 << 16); pass++) {
             fold_pass(hot, Q, d, tid, nthreads);
-            if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
+            if (workers_done(hot, workers)) break;
             __builtin_amdgcn_s_sleep(8);
         }
         return;
@@ -676,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_kernel(float *P, float *Q, 
     if (loss && lane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
     if (MODE == MODE_ATOMIC && folders > 0) {
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) worker_done(hot);
     }
 }
 
@@ -696,7 +711,7 @@ __global__ __launch_bounds__(256) void bpr_fold_kernel(HotRows hot, float *Q, in
         if (sum != 0.0f) Q[(int64_t)hot.items[slot] * d + e] += sum;
     }
     // every worker of the update launch has finished (stream order): the arrival counter goes back to zero for the next launch
-    if (blockIdx.x == 0 && threadIdx.x == 0) *hot.done = 0;
+    if (blockIdx.x == 0 && threadIdx.x < kDoneStripes) hot.done[threadIdx.x * kDoneStride] = 0;
 }
 
 // ---- counting sort by user ---------------------------------------------------------------------
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
         const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
         for (int pass = 0; pass < (1 << 16); pass++) {
             fold_pass(hot, Q, d, tid, nthreads);
-            if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
+            if (workers_done(hot, workers)) break;
             __builtin_amdgcn_s_sleep(8);
         }
         return;
@@ -995,7 +1010,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
     if (loss && glane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
     if (folders > 0) {
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) worker_done(hot);
     }
 }
 
@@ -1032,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_ring_kernel(float *P, 
         const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)folders * blockDim.x;
         for (int pass = 0; pass < (1 << 16); pass++) {
             fold_pass(hot, Q, d, tid, nthreads);
-            if (__hip_atomic_load(hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= workers) break;
+            if (workers_done(hot, workers)) break;
             __builtin_amdgcn_s_sleep(8);
         }
         return;
@@ -1139,7 +1154,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_ring_kernel(float *P, 
     if (loss && glane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
     if (folders > 0) {
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(hot.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) worker_done(hot);
     }
 }
 #endif  // GORSE_PROBE

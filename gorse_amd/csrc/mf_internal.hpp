@@ -5,6 +5,8 @@
 #include "cf_device.hpp"
 
 #ifndef GORSE_HOT_REPLICAS
+#define GORSE_HOT_DONE_STRIPES 32  // words of the workers' arrival counter (bpr.hip worker_done), GORSE_HOT_DONE_STRIDE words apart
+#define GORSE_HOT_DONE_STRIDE 64
 #define GORSE_HOT_REPLICAS 8  // replica rows per hot item (bpr.hip kHotReplicas; gorse_mf_create sizes hot_rep by it)
 #endif
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BPR epochs with the preparation ON THE UPDATE STREAM (variant bit 22) next to the production schedule (preparation of chunk c + 1
 under the update of chunk c), for a kernel timeline under rocprofv3: the serial runs show every kernel's duration alone.
-usage: gpu_probe_bpr_serial.py <shape: ml1m | c3s> <serial | overlapped | both> <nFactors> [<nFactors> ...]"""
+usage: gpu_probe_bpr_serial.py <shape: ml1m | ml100k | c3s> <serial | overlapped | both> <nFactors> [<nFactors> ...]"""
 import os
 import sys
 import time
@@ -12,8 +12,8 @@ from gorse_amd import capi, synth  # noqa: E402
 shape = sys.argv[1] if len(sys.argv) > 1 else "ml1m"
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 widths = [int(x) for x in sys.argv[3:]] or [16]
-data = synth.s_ml1m() if shape == "ml1m" else synth.s_big_shard()
-epochs = 8 if shape == "ml1m" else 3
+data = synth.s_ml1m() if shape == "ml1m" else (synth.s_ml100k() if shape == "ml100k" else synth.s_big_shard())
+epochs = 3 if shape == "c3s" else 8
 for d in widths:
     P0, Q0 = synth.init_factors(data.U, data.I, d, 0.0, 0.001, 3)
     for variant, name in ((0, "overlapped"), (1 << 22, "serial")):
