@@ -361,7 +361,7 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             h->n_hot = (int)hot.size();
             GORSE_TRY(h->hot_slot.alloc((size_t)I));
             GORSE_TRY(h->hot_items.alloc(hot.size()));
-            GORSE_TRY(h->hot_rep.alloc(hot.size() * GORSE_HOT_REPLICAS * (size_t)d));
+            GORSE_TRY(h->hot_rep.alloc(hot.size() * GORSE_HOT_REPLICAS_ALLOC * (size_t)d));
             GORSE_TRY(h->hot_done.alloc((size_t)GORSE_HOT_DONE_STRIPES * GORSE_HOT_DONE_STRIDE));  // (bpr.hip worker_done)
             GORSE_HIP_CHECK(hipMemsetAsync(h->hot_done.p, 0, (size_t)GORSE_HOT_DONE_STRIPES * GORSE_HOT_DONE_STRIDE * sizeof(int32_t), h->stream));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->hot_slot.p, slot.data(), (size_t)I * sizeof(int32_t), hipMemcpyHostToDevice,
@@ -369,7 +369,7 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             if (!hot.empty())
                 GORSE_HIP_CHECK(hipMemcpyAsync(h->hot_items.p, hot.data(), hot.size() * sizeof(int32_t),
                                                hipMemcpyHostToDevice, h->stream));
-            GORSE_HIP_CHECK(hipMemsetAsync(h->hot_rep.p, 0, std::max<size_t>(1, hot.size() * GORSE_HOT_REPLICAS * (size_t)d) * sizeof(float),
+            GORSE_HIP_CHECK(hipMemsetAsync(h->hot_rep.p, 0, std::max<size_t>(1, hot.size() * GORSE_HOT_REPLICAS_ALLOC * (size_t)d) * sizeof(float),
                                            h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // slot / hot are host temporaries
         }

@@ -4,11 +4,12 @@
 
 #include "cf_device.hpp"
 
-#ifndef GORSE_HOT_REPLICAS
 #define GORSE_HOT_DONE_STRIPES 32  // words of the workers' arrival counter (bpr.hip worker_done), GORSE_HOT_DONE_STRIDE words apart
 #define GORSE_HOT_DONE_STRIDE 64
-#define GORSE_HOT_REPLICAS 8  // replica rows per hot item (bpr.hip kHotReplicas; gorse_mf_create sizes hot_rep by it)
+#ifndef GORSE_HOT_REPLICAS
+#define GORSE_HOT_REPLICAS 8  // replica rows per hot item (bpr.hip kHotReplicas); A/B builds of bpr.hip: make ab AB_FLAGS=-DGORSE_HOT_REPLICAS=16
 #endif
+#define GORSE_HOT_REPLICAS_ALLOC 32  // replica rows ALLOCATED per hot item by gorse_mf_create (>= every build's GORSE_HOT_REPLICAS)
 
 struct gorse_mf {
     int device = 0;
