@@ -870,8 +870,8 @@ __global__ __launch_bounds__(256) void als_wide_long_kernel(float *__restrict__ 
 // consumes two entries.  Same mathematics, different summation order than the reference: parity is
 // the 1e-4 relative bar of BASELINE.md (the reference's own fp32 residual recurrence is no closer to
 // the exact solution: tests/test_gpu_cf_parity.py::test_als_*).
-int g_als_long_row = 4096;  // rows longer than this are cut into chunks (test hook: gorse_hip_test_set_als_plan)
-int g_als_chunk = 4096;     // feedback entries per chunk of a long row
+int g_als_long_row = 0;  // rows longer than this are cut into chunks; 0 = by the side's size (als_build_plan); test hook: gorse_hip_test_set_als_plan
+int g_als_chunk = 0;     // feedback entries per chunk of a long row; 0 = the threshold
 int g_als_path = 0;         // 0 auto (Gram form: MFMA kernels for d <= 64, als_wide_kernel for d <= 128; else the residual
                             // sweep), 1 force the residual sweep, 2 force the MFMA Gram form (d <= 64)
 int g_als_wide_fma = 0;     // als_wide_kernel: G by fused multiply-adds (round 2) instead of the fp32 MFMA (probe: path | 8)
@@ -2046,8 +2046,8 @@ extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint6
 }
 // takes effect for handles created afterwards (the row plan is built in gorse_mf_create)
 extern "C" void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk) {
-    g_als_long_row = long_row > 0 ? long_row : 4096;
-    g_als_chunk = chunk > 0 ? chunk : 4096;
+    g_als_long_row = long_row > 0 ? long_row : 0;  // 0: chosen per side by als_build_plan
+    g_als_chunk = chunk > 0 ? chunk : 0;
 }
 
 namespace gorse {
@@ -2060,9 +2060,23 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, 
     }
     std::vector<int32_t> shorts, lrows, lfirst, lnch, crow, ccnt;
     std::vector<int64_t> cbeg;
+    // A short row is ONE wave's work from its first entry to its solve, so the longest short row is the row kernel's critical path:
+    // 4096 entries are 70-90 us of one wave, which a side of 50M entries never notices and a side of 1M entries (S-ml1m: the
+    // reference's own test shape) waits for with the chip empty -- its epoch at nFactors 8 takes 0.196 ms with the threshold at 4096,
+    // 0.125 at 1024, 0.095 at 256 (profiles/r05_zq_probe_als_plan.txt).  The threshold therefore follows the side's size: the even
+    // share of one of ~4096 wave slots, as a power of two between 256 (512 from nFactors 64 on: a chunk's partial Gram is d x d
+    // floats) and 4096.  It is taken from the WHOLE side, not from the range [lo, hi): every rank of a sharded sweep cuts the same rows
+    // the same way (the sharded epoch stays bit-equal to the unsharded one).
+    int64_t long_row = g_als_long_row, chunk_len = g_als_chunk;
+    if (long_row <= 0) {
+        const int64_t share = (ptr[rows] - ptr[0]) / 4096, floor_ = h->d >= 64 ? 512 : 256;
+        long_row = floor_;
+        while (long_row < 4096 && long_row < share) long_row *= 2;
+    }
+    if (chunk_len <= 0) chunk_len = long_row;
     for (int64_t r = lo; r < hi; r++) {  // the rows this handle solves; the Gram list below covers ALL rows
         const int64_t n = ptr[r + 1] - ptr[r];
-        if (n <= g_als_long_row) {
+        if (n <= long_row) {
             shorts.push_back((int32_t)r);
             continue;
         }
@@ -2070,7 +2084,7 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, 
         lfirst.push_back((int32_t)crow.size());
         // at most 256 chunks per row (the long-row solver adds a row's partials one after the other): very long
         // rows get proportionally longer chunks, in multiples of one pipeline stage (16 entries)
-        const int64_t chunk = std::max<int64_t>(g_als_chunk, (ceil_div(n, 256) + 15) / 16 * 16);
+        const int64_t chunk = std::max<int64_t>(chunk_len, (ceil_div(n, 256) + 15) / 16 * 16);
         int nc = 0;
         for (int64_t b = 0; b < n; b += chunk, nc++) {
             crow.push_back((int32_t)r);
