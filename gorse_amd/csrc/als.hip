@@ -872,6 +872,7 @@ __global__ __launch_bounds__(256) void als_wide_long_kernel(float *__restrict__ 
 // the exact solution: tests/test_gpu_cf_parity.py::test_als_*).
 int g_als_long_row = 0;  // rows longer than this are cut into chunks; 0 = by the side's size (als_build_plan); test hook: gorse_hip_test_set_als_plan
 int g_als_chunk = 0;     // feedback entries per chunk of a long row; 0 = the threshold
+bool g_als_solve_adds = false;  // tests (path | 2048): no als_partial_reduce_kernel in front of the long-row solve
 int g_als_path = 0;         // 0 auto (Gram form: MFMA kernels for d <= 64, als_wide_kernel for d <= 128; else the residual
                             // sweep), 1 force the residual sweep, 2 force the MFMA Gram form (d <= 64)
 int g_als_wide_fma = 0;     // als_wide_kernel: G by fused multiply-adds (round 2) instead of the fp32 MFMA (probe: path | 8)
@@ -1537,14 +1538,18 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
                                                                    const int64_t *__restrict__ chunk_beg,
                                                                    const int32_t *__restrict__ chunk_cnt,
                                                                    int64_t n_chunks, int d, float *__restrict__ partial,
-                                                                   const float *__restrict__ zeros, int zero_row) {
+                                                                   const float *__restrict__ zeros, int zero_row,
+                                                                   const int32_t *__restrict__ order) {
     static_assert(MODE >= 1 && MODE <= 4, "als_chunk_kernel modes");
     constexpr bool T16 = MODE != 2;
     constexpr bool FULLD = MODE == 1 || MODE == 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * kAlsWaves + wv, nwaves = (int64_t)gridDim.x * kAlsWaves;
     const int64_t stride = (int64_t)d * d + d;
-    for (int64_t c = wave; c < n_chunks; c += nwaves) {
+    // `order` (may be null): the chunks longest first.  A wave takes the chunks wave, wave + nwaves, ... of that list: the 16K-entry
+    // chunks of the most popular rows (a row has at most 256 chunks) start first instead of wherever their rows' numbers put them
+    for (int64_t ci = wave; ci < n_chunks; ci += nwaves) {
+        const int64_t c = order ? order[ci] : ci;
         std::conditional_t<T16, GramAcc16<NB>, GramAcc<NB>> g;
         const int32_t *fb = idx + chunk_beg[c];
         const int cn = chunk_cnt[c];
@@ -1754,9 +1759,9 @@ int als_gram_mode(int d, int zrow) {
 }
 
 void launch_chunks(const float *B, const int32_t *idx, const int64_t *chunk_beg, const int32_t *chunk_cnt, int64_t n_chunks, int d,
-                   float *partial, const float *zeros, int zrow, int pad_row, unsigned grid, hipStream_t st) {
+                   float *partial, const float *zeros, int zrow, int pad_row, unsigned grid, hipStream_t st, const int32_t *order = nullptr) {
 #define CHUNK_LAUNCH(...) \
-    als_chunk_kernel<__VA_ARGS__><<<dim3(grid), dim3(64 * kAlsWaves), 0, st>>>(B, idx, chunk_beg, chunk_cnt, n_chunks, d, partial, zeros, pad_row)
+    als_chunk_kernel<__VA_ARGS__><<<dim3(grid), dim3(64 * kAlsWaves), 0, st>>>(B, idx, chunk_beg, chunk_cnt, n_chunks, d, partial, zeros, pad_row, order)
     const int mode = als_gram_mode(d, zrow);
     switch (mode * 10 + (mode == 2 ? d / 32 : (d + 15) / 16)) {
     case 11: CHUNK_LAUNCH(1, 1); break;
@@ -1775,6 +1780,42 @@ void launch_chunks(const float *B, const int32_t *idx, const int64_t *chunk_beg,
     default: CHUNK_LAUNCH(4, 4); break;
     }
 #undef CHUNK_LAUNCH
+}
+
+// long rows, stage 1 1/2: the partials of a row added up by ONE THREAD PER ELEMENT, for rows with many chunks.  als_long_solve_kernel
+// sums a row's partials with the 256 threads of its one workgroup, seventeen elements per thread one after the other, four loads in
+// flight each: the most popular row of C5's item side (256 partials of 16.6 KB) was 0.52 ms of a 5.6 ms epoch, the rest of the chip
+// waiting for that workgroup.  Here every element of every long row has its own thread (the row's 256 partials = 64 dependent steps,
+// once), the solve then reads ONE partial per row.  The same four chains by chunk number mod 4 and the same (a0 + a1) + (a2 + a3) as
+// in als_long_solve_kernel, which then adds 0 to the result: the row's solution is the same in every bit.
+__global__ __launch_bounds__(256) void als_partial_reduce_kernel(const float *__restrict__ partial, const int32_t *__restrict__ first,
+                                                                 const int32_t *__restrict__ nch, int64_t n_rows, int stride,
+                                                                 float *__restrict__ out) {
+    const int nb = (stride + 255) / 256;
+    for (int64_t b = blockIdx.x; b < n_rows * nb; b += gridDim.x) {
+        const int64_t t = b / nb;
+        const int e = (int)(b - t * nb) * 256 + threadIdx.x;
+        if (e >= stride) continue;
+        const float *src = partial + (int64_t)first[t] * stride + e;
+        const int nc = nch[t];
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int c = 0;
+        for (; c + 15 < nc; c += 16) {  // sixteen loads in flight; every chain still adds its chunks in order
+            float x[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = src[(int64_t)(c + j) * stride];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) a0 += x[j], a1 += x[j + 1], a2 += x[j + 2], a3 += x[j + 3];
+        }
+        for (; c + 3 < nc; c += 4) {
+            a0 += src[(int64_t)c * stride];
+            a1 += src[(int64_t)(c + 1) * stride];
+            a2 += src[(int64_t)(c + 2) * stride];
+            a3 += src[(int64_t)(c + 3) * stride];
+        }
+        for (; c < nc; c++) a0 += src[(int64_t)c * stride];
+        out[t * stride + e] = (a0 + a1) + (a2 + a3);
+    }
 }
 
 void launch_long_solve(float *A, const float *S, const int32_t *rows, const int32_t *first, const int32_t *nch, int64_t n_rows, int d,
@@ -1848,9 +1889,20 @@ int32_t run_side_gram(gorse_mf *h, int side, float *A, const float *B, const int
     if (pl.n_long > 0) {
         GORSE_TRY(h->als_partial.ensure((size_t)pl.n_chunks * ((size_t)d * d + d)));
         const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(pl.n_chunks, kAlsWaves), 2048);
-        launch_chunks(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow, pad_row, grid, h->stream);
+        launch_chunks(B, idx, pl.chunk_beg.p, pl.chunk_cnt.p, pl.n_chunks, d, h->als_partial.p, h->als_zeros.p, zrow, pad_row, grid, h->stream,
+                      pl.chunk_order.p);
         GORSE_HIP_CHECK(hipGetLastError());
-        launch_long_solve(A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p, h->stream);
+        if (pl.max_nch > 8 && !g_als_solve_adds) {  // (path | 2048: the solve kernel adds the partials itself whatever their number -- tests)
+            const int stride = d * d + d;
+            GORSE_TRY(h->als_reduced.ensure((size_t)pl.n_long * stride));
+            const int64_t blocks = std::min<int64_t>(pl.n_long * ceil_div(stride, 256), (int64_t)1 << 20);
+            als_partial_reduce_kernel<<<dim3((unsigned)blocks), dim3(256), 0, h->stream>>>(h->als_partial.p, pl.long_first.p, pl.long_nch.p,
+                                                                                        pl.n_long, stride, h->als_reduced.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+            launch_long_solve(A, h->gram.p, pl.long_rows.p, pl.long_ident.p, pl.long_one.p, pl.n_long, d, w, reg, h->als_reduced.p, h->stream);
+        } else {
+            launch_long_solve(A, h->gram.p, pl.long_rows.p, pl.long_first.p, pl.long_nch.p, pl.n_long, d, w, reg, h->als_partial.p, h->stream);
+        }
         GORSE_HIP_CHECK(hipGetLastError());
     }
     h->prof.end(tok, h->stream);
@@ -2032,6 +2084,7 @@ extern "C" void gorse_hip_test_set_als_path(int32_t path) {
     g_als_tile32 = (path & 128) != 0;
     g_als_waves8 = (path & 256) != 0;
     g_als_nob3 = (path & 1024) != 0;
+    g_als_solve_adds = (path & 2048) != 0;
 }
 // probe: phase counters of als_row_kernel for the last half-sweep of each side (16 values: users, items)
 extern "C" int32_t gorse_hip_test_als_profile(gorse_mf *h, int32_t enable, uint64_t *out16) {
@@ -2082,8 +2135,9 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, 
         }
         lrows.push_back((int32_t)r);
         lfirst.push_back((int32_t)crow.size());
-        // at most 256 chunks per row (the long-row solver adds a row's partials one after the other): very long
-        // rows get proportionally longer chunks, in multiples of one pipeline stage (16 entries)
+        // at most 256 chunks per row: very long rows get proportionally longer chunks, in multiples of one pipeline stage (16 entries).
+        // (1024 chunks per row, so that the 4.1M-entry row of C5's item side comes in chunks of 4096 entries like everybody else's
+        // instead of 16K: measured, no change -- the chunk kernel runs at the row kernel's rate per entry, not at its longest chunk's.)
         const int64_t chunk = std::max<int64_t>(chunk_len, (ceil_div(n, 256) + 15) / 16 * 16);
         int nc = 0;
         for (int64_t b = 0; b < n; b += chunk, nc++) {
@@ -2119,8 +2173,22 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, 
     GORSE_TRY(up32(pl.long_rows, lrows));
     GORSE_TRY(up32(pl.long_first, lfirst));
     GORSE_TRY(up32(pl.long_nch, lnch));
+    {   // the row list of a solve that reads ONE (already added up) partial per row: als_partial_reduce_kernel
+        std::vector<int32_t> ident(lrows.size()), one(lrows.size(), 1);
+        for (size_t k = 0; k < ident.size(); k++) ident[k] = (int32_t)k;
+        GORSE_TRY(up32(pl.long_ident, ident));
+        GORSE_TRY(up32(pl.long_one, one));
+        pl.max_nch = 0;
+        for (int32_t v : lnch) pl.max_nch = std::max(pl.max_nch, v);
+    }
     GORSE_TRY(up32(pl.chunk_row, crow));
     GORSE_TRY(up32(pl.chunk_cnt, ccnt));
+    {   // the chunks longest first (als_chunk_kernel's `order`)
+        std::vector<int32_t> order(ccnt.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = (int32_t)k;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return ccnt[a] > ccnt[b]; });
+        GORSE_TRY(up32(pl.chunk_order, order));
+    }
     GORSE_TRY(up32(pl.fb_rows, fbr));
     GORSE_TRY(up32(pl.g_cnt, gcnt));
     GORSE_TRY(pl.g_beg.alloc(gbeg.size()));

@@ -57,8 +57,11 @@ struct gorse_mf {
     struct AlsPlan {
         gorse::DevBuf<int32_t> short_rows;               // n_short row ids
         gorse::DevBuf<int32_t> chunk_row, chunk_cnt;     // n_chunks
+        gorse::DevBuf<int32_t> chunk_order;              // n_chunks: the chunks longest first
         gorse::DevBuf<int64_t> chunk_beg;                // n_chunks: offset into the side's indices
         gorse::DevBuf<int32_t> long_rows, long_first, long_nch;  // n_long
+        gorse::DevBuf<int32_t> long_ident, long_one;             // n_long: 0, 1, 2, ... and 1, 1, 1, ... (the solve after als_partial_reduce_kernel)
+        int32_t max_nch = 0;                                     // most chunks of one row
         // rows with feedback (the rows S = sum x x^T runs over, model.go:645-658), cut into Gram chunks
         gorse::DevBuf<int32_t> fb_rows, g_cnt;
         gorse::DevBuf<int64_t> g_beg;
@@ -69,6 +72,7 @@ struct gorse_mf {
     gorse::DevBuf<unsigned long long> als_prof;  // probe: phase counters of als_row_kernel (gorse_hip_test_als_profile)
     gorse::DevBuf<float> als_zeros;    // 64 zero words: where padding lanes of the gathers read
     gorse::DevBuf<float> als_partial;  // n_chunks x (d*d + d) partial Gram matrices + column sums
+    gorse::DevBuf<float> als_reduced;  // n_long x (d*d + d): a long row's partials added up (als_partial_reduce_kernel)
     // Evaluate's resident split (eval.hip): the test rows, every user's sampled negatives, and the candidate CSR of the users
     // with test feedback (user ids ascending, "test items then negatives" per user)
     gorse::DevBuf<int64_t> ev_tptr, ev_upos, ev_cpos, ev_cptr;

@@ -792,6 +792,24 @@ def test_als_gram_form_rejects_wide_factors(small, als_paths):
     mf.als_epoch(0.05, 0.015)  # automatic choice: als_wide_kernel + the residual sweep for 64 < nFactors <= 128
 
 
+@pytest.mark.parametrize("d", [8, 16, 50, 64])
+def test_als_long_row_partials_added_per_element_equal_the_solve_kernels_own_sum(oracle, d, als_paths):
+    """A long row's partial Gram matrices are added up by als_partial_reduce_kernel (a thread per element, rows with more than eight
+    chunks) before als_long_solve_kernel reads ONE partial per row; with path | 2048 the solve kernel adds them itself, as it did
+    before.  Same chains, same order: the factors are equal in every bit (here: rows of up to 225 chunks)."""
+    data = synth.synth_cf(60, 5000, 50000, seed=11, min_len=3, max_frac=0.9, n_neg=10)
+    out = []
+    for path in (2, 2 | 2048):
+        capi.lib().gorse_hip_test_set_als_path(path)
+        capi.lib().gorse_hip_test_set_als_plan(48, 20)
+        mf, P, Q = make_mf(data, d, std=0.1)
+        for _ in range(2):
+            mf.als_epoch(0.05, 0.015)
+        out.append(mf.get_factors())
+        mf.close()
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and np.array_equal(bits(out[0][1]), bits(out[1][1]))
+
+
 @pytest.mark.parametrize("long_row,chunk", [(16, 16), (40, 13), (0, 0)])
 @pytest.mark.parametrize("d,path", [(16, 2), (64, 2), (33, 2), (8, 2), (8, 2 | 64), (50, 2 | 64), (64, 2 | 128)])
 def test_als_long_rows_chunked(oracle, d, path, long_row, chunk, als_paths):
