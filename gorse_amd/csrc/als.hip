@@ -63,7 +63,15 @@ __global__ void als_gram_reduce_kernel(const float *__restrict__ partial, int np
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= dd) return;
     float s = 0.0f;
-    for (int g = 0; g < nparts; g++) s += partial[(size_t)g * stride + e];  // fixed order: deterministic
+    int g = 0;
+    for (; g + 15 < nparts; g += 16) {  // sixteen loads in flight, added in the same fixed order (one load at a time: 128 us for C5's 489 partials)
+        float x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = partial[(size_t)(g + j) * stride + e];
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += x[j];
+    }
+    for (; g < nparts; g++) s += partial[(size_t)g * stride + e];  // fixed order: deterministic
     S[e] = s;
 }
 
