@@ -20,7 +20,9 @@ void gorse_hip_test_set_exact_exp(int32_t mode);
 /* schedule switches of the Hogwild update path (bit 5: no hot-row replicas = the round-1 kernel; bit 7: force the user-run schedule (triplets counting-sorted by user, p_u
  * register-resident over a user's samples), bit 25: the user-run schedule sends only the POSITIVE item's update of a hot item
  * through the replicas (round 2), bit 28: force the per-sample schedule, bit 29: the user sort ranks
- * samples in stream order (single thread; makes a run's order deterministic for the parity test).  Used by
+ * samples in stream order (single thread; makes a run's order deterministic for the parity test), bit 21: the user-run
+ * schedule's chunk preparation WITHOUT user bins (round 4's form: a returning atomic per sample on its user's run counter),
+ * bit 22: the chunk preparation on the update stream instead of beside it (kernel timelines: every kernel alone).  Used by
  * scripts/gpu_probe_*.py and the tests; 0 (the default) is the only value the product ever runs with. */
 void gorse_hip_test_set_variant(int32_t variant);
 /* top-k path choice: 0 = automatic (MFMA sweep for >= 768 queries, any of the three metrics, k <= 255), 1 = always the
@@ -111,11 +113,14 @@ int64_t gorse_hip_test_sparse_trace(gorse_sparse *h, int32_t on, uint64_t *out /
  * Which MFMA form the Gram of a row takes (csrc/als.hip als_gram_mode; default: nFactors 32 / 64 on the bf16 MFMA over three-way
  * split values, 16 / 48 on the fp32 MFMA in 16 x 16 tiles, anything else or without the fast gather stage fp32 32 x 32 tiles):
  * 1024 = no bf16 form (32 / 64 take the 16 x 16 fp32 tiles), 128 = no 16 x 16 tiles either (1024 | 128: everything in 32 x 32
- * fp32 tiles, the form of rounds 1-3); 256 = eight waves per workgroup where twelve are the default (nFactors <= 32). */
+ * fp32 tiles, the form of rounds 1-3); 256 = eight waves per workgroup where twelve are the default (nFactors <= 32);
+ * 2048 = als_long_solve_kernel adds a long row's partial Gram matrices itself however many there are (default: rows of more
+ * than eight chunks go through als_partial_reduce_kernel first; the two are equal in every bit). */
 void gorse_hip_test_set_als_path(int32_t path);
 /* thresholds of the Gram-form row plan, for handles created AFTERWARDS: rows longer than long_row feedbacks
- * are cut into chunks of `chunk` entries (defaults 4096 / 4096; <= 0 restores a default).  Lets small test
- * inputs exercise the long-row path. */
+ * are cut into chunks of `chunk` entries; <= 0 restores the library's choice (round 5: by the side's size -- the even
+ * share of one of ~4096 wave slots, a power of two between 256 (512 from nFactors 64 on) and 4096; chunk = the
+ * threshold).  Lets small test inputs exercise the long-row path. */
 void gorse_hip_test_set_als_plan(int32_t long_row, int32_t chunk);
 /* probe: enable != 0 makes als_row_kernel stamp its phases with s_memtime; out16 (may be NULL) receives, for the last
  * user half-sweep and then the last item half-sweep, ticks summed over the waves in [0] Gram accumulation (gathers +
