@@ -2,6 +2,9 @@
 // Reference: model/cf/model.go:118-203 (BaseMatrixFactorization), evaluator.go:162-169 (Rank),
 // common/heap/filter.go:23-59 (TopKFilter).
 #include <algorithm>
+#include <mutex>
+#include <chrono>
+#include <cstdlib>
 
 #include "goheap.hpp"
 #include "mf_internal.hpp"
@@ -31,7 +34,7 @@ void sort_rows(const int64_t *ptr, const int32_t *idx, int64_t rows, std::vector
         std::copy(idx + ptr[r0], idx + ptr[r1], out.data() + ptr[r0]);
         for (int64_t r = r0; r < r1; r++) {
             int32_t *b = out.data() + ptr[r], *e = out.data() + ptr[r + 1];
-            if (e - b > 1) std::sort(b, e);
+            if (e - b > 1 && !std::is_sorted(b, e)) std::sort(b, e);
         }
     });
 }
@@ -218,6 +221,32 @@ extern "C" int32_t gorse_mf_set_bpr_cold_window(gorse_mf *h, int64_t samples, in
     return GORSE_OK;
 }
 
+// The two streams and four events of a handle are kept for the next handle on the same device when a handle is destroyed: creating and
+// destroying them costs ~4 ms each on this runtime -- 8 of the 45 ms of a whole BPR.Fit at the reference's own test shape, where every Fit
+// makes its own handle.  Only the default kind (two non-blocking streams of one priority); at most four sets per device wait here.
+namespace {
+struct StreamSet {
+    hipStream_t s = nullptr, s2 = nullptr;
+    hipEvent_t sampled[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+};
+std::mutex g_stream_pool_mu;
+std::vector<StreamSet> g_stream_pool[64];  // by device
+}  // namespace
+
+// GORSE_MF_TRACE=1: the phases of gorse_mf_create / gorse_mf_destroy in milliseconds on stderr (where a short Fit's time goes)
+namespace {
+struct CreateTrace {
+    bool on = getenv("GORSE_MF_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gorse_mf] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
 extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, int64_t I, int32_t d,
                                    const int64_t *user_indptr, const int32_t *user_indices,
                                    const int64_t *item_indptr, const int32_t *item_indices) {
@@ -232,8 +261,10 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
     if (!user_indptr || !user_indices) return fail(GORSE_ERR_INVALID, "user CSR is NULL");
     if ((item_indptr == nullptr) != (item_indices == nullptr))
         return fail(GORSE_ERR_INVALID, "item_indptr and item_indices must both be given or both NULL");
+    CreateTrace trace;
     GORSE_TRY(validate_csr("user", user_indptr, user_indices, U, I));
     if (item_indptr) GORSE_TRY(validate_csr("item", item_indptr, item_indices, I, U));
+    trace.mark("create: validate");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(GORSE_ERR_NO_DEVICE, "no HIP device visible (libgorse_hip needs an MI355X / gfx950)");
@@ -264,8 +295,21 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
             GORSE_HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
         } else if (g_mf_flat_streams) {
-            GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-            GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            {
+                std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+                auto &pool = g_stream_pool[device & 63];
+                if (!pool.empty()) {  // (its streams are idle and its events complete: gorse_mf_destroy synchronised them)
+                    const StreamSet ss = pool.back();
+                    pool.pop_back();
+                    h->stream = ss.s, h->stream2 = ss.s2;
+                    for (int b = 0; b < 2; b++) h->ev_sampled[b] = ss.sampled[b], h->ev_consumed[b] = ss.consumed[b];
+                }
+            }
+            h->pooled_streams = true;
+            if (!h->stream) {
+                GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+                GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+            }
         } else {
             int prio_lo = 0, prio_hi = 0;
             GORSE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // lo = least urgent (largest number)
@@ -273,9 +317,10 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         }
         for (int b = 0; b < 2; b++) {
-            GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
-            GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
+            if (!h->ev_sampled[b]) GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
+            if (!h->ev_consumed[b]) GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
         }
+        trace.mark("create: streams, events");
         // one row more than the matrix has, and it stays zero: the ALS gathers send the entries past a row's end there (row id U
         // resp. I) instead of selecting an address per load
         GORSE_TRY(h->P.alloc((size_t)(U + 1) * d));
@@ -289,8 +334,10 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
                                        h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->uidx.p, user_indices, (size_t)h->nnz * sizeof(int32_t), hipMemcpyHostToDevice,
                                        h->stream));
+        trace.mark("create: P, Q, user CSR");
         std::vector<int32_t> sorted;
         sort_rows(user_indptr, user_indices, U, sorted);
+        trace.mark("create: sort_rows");
         GORSE_HIP_CHECK(hipMemcpyAsync(h->uidx_sorted.p, sorted.data(), (size_t)h->nnz * sizeof(int32_t),
                                        hipMemcpyHostToDevice, h->stream));
         if (h->has_item_csr) {
@@ -308,6 +355,7 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_TRY(als_build_plan(h, 0, user_indptr, U, 0, U));
             GORSE_TRY(als_build_plan(h, 1, item_indptr, I, 0, I));
         }
+        trace.mark("create: item CSR, ALS plan");
         {   // hot items: share of the training feedback >= 1/8192 (and >= 64 feedbacks), at most 1024 and a quarter of the items (bpr.hip, HotRows)
             std::vector<int64_t> cnt((size_t)I, 0);
             if (h->nnz < ((int64_t)1 << 26) || I > ((int64_t)1 << 22)) {
@@ -373,6 +421,7 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
                                            h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // slot / hot are host temporaries
         }
+        trace.mark("create: item classes");
         GORSE_TRY(h->loss.alloc(1));
         GORSE_TRY(h->fail_count.alloc(1));
         GORSE_HIP_CHECK(hipMemsetAsync(h->fail_count.p, 0, sizeof(int32_t), h->stream));
@@ -385,22 +434,43 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
         last_error() = keep;
         return rc;
     }
+    trace.mark("create: last sync");
     *out = h;
     return GORSE_OK;
 }
 
 extern "C" int32_t gorse_mf_destroy(gorse_mf *h) {
     if (!h) return GORSE_OK;
+    CreateTrace trace;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-    for (int b = 0; b < 2; b++) {
-        if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
-        if (h->ev_consumed[b]) (void)hipEventDestroy(h->ev_consumed[b]);
+    bool ok = true;
+    if (h->stream) ok = hipStreamSynchronize(h->stream) == hipSuccess && ok;
+    if (h->stream2) ok = hipStreamSynchronize(h->stream2) == hipSuccess && ok;
+    bool kept = false;
+    if (ok && h->pooled_streams && h->stream && h->stream2 && h->ev_sampled[0] && h->ev_sampled[1] && h->ev_consumed[0] &&
+        h->ev_consumed[1]) {  // a complete, healthy set: it waits for the next handle of this device
+        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
+        auto &pool = g_stream_pool[h->device & 63];
+        if (pool.size() < 4) {
+            StreamSet ss;
+            ss.s = h->stream, ss.s2 = h->stream2;
+            for (int b = 0; b < 2; b++) ss.sampled[b] = h->ev_sampled[b], ss.consumed[b] = h->ev_consumed[b];
+            pool.push_back(ss);
+            kept = true;
+        }
     }
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (!kept) {
+        for (int b = 0; b < 2; b++) {
+            if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
+            if (h->ev_consumed[b]) (void)hipEventDestroy(h->ev_consumed[b]);
+        }
+        trace.mark("destroy: sync, events");
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    }
+    trace.mark("destroy: streams");
     delete h;
+    trace.mark("destroy: buffers");
     return GORSE_OK;
 }
 

@@ -260,6 +260,7 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
             score[0], config.TopK, score[1], config.TopK, score[2]));
     auto t_fit = clk::now();
     int fit_epochs = 0;
+    epochs_done_ = 0;
     for (int epoch = 1; epoch <= nEpochs; epoch++) {
         int32_t rc = run_epoch(epoch);
         fit_epochs++;
@@ -290,20 +291,30 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
                 }
             }
         }
+        epochs_done_ = epoch;  // (where the progress hook fires: a cancelled epoch and the epoch an early stop breaks at do not count)
         if (config.OnEpoch) config.OnEpoch(epoch);
     }
+    const auto t_pull = clk::now();
     pull_factors();  // the reference's [][]float32 rows, before Marshal / GetUserFactor are used
     if (borrowed_) release();  // a lent handle goes back: the next Fit overwrites its factors (Predict re-uploads ours)
+    log(fmt("fit %s teardown pull=%.3fms", tag, ms_since(t_pull)));
     log(fmt("fit %s complete NDCG@%d=%g", tag, config.TopK, score[0]));
     return Score{score[0], score[1], score[2]};
 }
 
 Score BPR::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitConfig &config) {
     // Init (model.go:532-540): users first, then items
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
     GetRandomGenerator().NormalMatrix(trainSet.CountUsers(), nFactors_, initMean, initStdDev, UserFactor);
     GetRandomGenerator().NormalMatrix(trainSet.CountItems(), nFactors_, initMean, initStdDev, ItemFactor);
+    const auto t1 = clk::now();
     Init(trainSet);
+    const auto t2 = clk::now();
     create_handle(trainSet, false, config.Device, config.Resident);
+    // (not a line of the reference's log: where a Fit's time goes outside its epochs and evaluations)
+    if (config.Log) config.Log(fmt("fit bpr setup draws=%.3fms init=%.3fms handle=%.3fms", ms(t0, t1), ms(t1, t2), ms(t2, clk::now())));
     // per-Fit sampler seed, as rng[i] = NewRandomGenerator(bpr.GetRandomGenerator().Int63()) (model.go:420-423)
     const uint64_t seed = (uint64_t)GetRandomGenerator().Int63();
     // Jobs <= 1: parallel.Parallel runs the samples strictly in order (parallel.go:34-43) -> sequential
@@ -319,17 +330,25 @@ Score BPR::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitCo
     return fit_loop("bpr", nEpochs, trainSet, valSet, config, [&](int epoch) {
         const bool eval_next = epoch % config.Verbose == 0 || epoch == nEpochs;
         const bool cancelled = config.Cancel && *config.Cancel;
-        if (!eval_next && mode != GORSE_BPR_SEQUENTIAL && !cancelled && !config.OnEpoch)
+        // (OnEpoch = the reference's span.Add(1), a progress count: it fires when the epoch has been ISSUED, as in the Go twin,
+        // integration/go/model/cf/bpr_hip.go:93 -- until round 5 a hook forced the synchronous entry point for every epoch here)
+        if (!eval_next && mode != GORSE_BPR_SEQUENTIAL && !cancelled)
             return gorse_bpr_epoch_enqueue(h_, n, lr, reg, seed, (uint64_t)epoch, 0, mode);
         return gorse_bpr_epoch(h_, n, lr, reg, seed, (uint64_t)epoch, 0, mode, config.Cancel, nullptr);
     });
 }
 
 Score ALS::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitConfig &config) {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
     GetRandomGenerator().NormalMatrix(trainSet.CountUsers(), nFactors_, initMean, initStdDev, UserFactor);
     GetRandomGenerator().NormalMatrix(trainSet.CountItems(), nFactors_, initMean, initStdDev, ItemFactor);
+    const auto t1 = clk::now();
     Init(trainSet);
+    const auto t2 = clk::now();
     create_handle(trainSet, true, config.Device, config.Resident);
+    if (config.Log) config.Log(fmt("fit als setup draws=%.3fms init=%.3fms handle=%.3fms", ms(t0, t1), ms(t1, t2), ms(t2, clk::now())));
     return fit_loop("als", nEpochs, trainSet, valSet, config,
                     [&](int) { return gorse_als_epoch(h_, weight, reg, config.Cancel); });
 }

@@ -610,6 +610,7 @@ class MatrixFactorization {
     const float *GetUserFactor(int32_t u) const { return UserFactor.data() + (size_t)u * (size_t)nFactors_; }
     const float *GetItemFactor(int32_t i) const { return ItemFactor.data() + (size_t)i * (size_t)nFactors_; }
     int NFactors() const { return nFactors_; }
+    int EpochsDone() const { return epochs_done_; }  // epochs the last Fit ran (early stopping / cancellation: fewer than NEpochs)
     // Predict (model.go:182-193): unknown ids -> 0 (+ warning)
     float Predict(const std::string &userId, const std::string &itemId) {
         int32_t u = UserIndex ? UserIndex->Id(userId) : -1, i = ItemIndex ? ItemIndex->Id(itemId) : -1;
@@ -732,6 +733,7 @@ class MatrixFactorization {
     util::RandomGenerator rng_{0};
     gorse_mf *h_ = nullptr;
     bool borrowed_ = false;
+    int epochs_done_ = 0;  // fit_loop
     int device_ = 0;
     const void *handle_train_ = nullptr;   // the training set the resident handle was created from (a Fit in progress)
     const void *resident_eval_ = nullptr;  // the test split whose candidate lists are resident on h_

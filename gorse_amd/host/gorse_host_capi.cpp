@@ -147,13 +147,12 @@ int32_t gh_model_fit(void *m, void *train, void *val, int32_t jobs, int32_t verb
     return guard([&] {
         cf::FitConfig c;
         c.Jobs = jobs, c.Verbose = verbose, c.Candidates = candidates, c.TopK = topk, c.Patience = patience, c.Cancel = cancel;
-        int done = 0;
         std::string logs;
-        c.OnEpoch = [&](int) { done++; };
+        // (the count of epochs comes from the model: EpochsDone)
         c.Log = [&](const std::string &s) { logs += s + "\n"; };
         cf::Score s = ((cf::MatrixFactorization *)m)->Fit(*(dataset::Dataset *)train, *(dataset::Dataset *)val, c);
         score3[0] = s.NDCG, score3[1] = s.Precision, score3[2] = s.Recall;
-        if (epochs_done) *epochs_done = done;
+        if (epochs_done) *epochs_done = ((cf::MatrixFactorization *)m)->EpochsDone();
         if (log_out && log_cap > 0) {
             size_t n = std::min<size_t>((size_t)log_cap - 1, logs.size());
             memcpy(log_out, logs.data(), n);
