@@ -2,7 +2,6 @@
 // Reference: model/cf/model.go:118-203 (BaseMatrixFactorization), evaluator.go:162-169 (Rank),
 // common/heap/filter.go:23-59 (TopKFilter).
 #include <algorithm>
-#include <mutex>
 #include <chrono>
 #include <cstdlib>
 
@@ -221,18 +220,6 @@ extern "C" int32_t gorse_mf_set_bpr_cold_window(gorse_mf *h, int64_t samples, in
     return GORSE_OK;
 }
 
-// The two streams and four events of a handle are kept for the next handle on the same device when a handle is destroyed: creating and
-// destroying them costs ~4 ms each on this runtime -- 8 of the 45 ms of a whole BPR.Fit at the reference's own test shape, where every Fit
-// makes its own handle.  Only the default kind (two non-blocking streams of one priority); at most four sets per device wait here.
-namespace {
-struct StreamSet {
-    hipStream_t s = nullptr, s2 = nullptr;
-    hipEvent_t sampled[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
-};
-std::mutex g_stream_pool_mu;
-std::vector<StreamSet> g_stream_pool[64];  // by device
-}  // namespace
-
 // GORSE_MF_TRACE=1: the phases of gorse_mf_create / gorse_mf_destroy in milliseconds on stderr (where a short Fit's time goes)
 namespace {
 struct CreateTrace {
@@ -295,21 +282,13 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
             GORSE_HIP_CHECK(hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()));
         } else if (g_mf_flat_streams) {
-            {
-                std::lock_guard<std::mutex> lock(g_stream_pool_mu);
-                auto &pool = g_stream_pool[device & 63];
-                if (!pool.empty()) {  // (its streams are idle and its events complete: gorse_mf_destroy synchronised them)
-                    const StreamSet ss = pool.back();
-                    pool.pop_back();
-                    h->stream = ss.s, h->stream2 = ss.s2;
-                    for (int b = 0; b < 2; b++) h->ev_sampled[b] = ss.sampled[b], h->ev_consumed[b] = ss.consumed[b];
-                }
-            }
-            h->pooled_streams = true;
-            if (!h->stream) {
-                GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-                GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-            }
+            // (Round 5 kept the streams and events of a destroyed handle for the next one -- creating and destroying them costs ~8 ms
+            // per handle, a third of a whole BPR.Fit at the reference's own test shape.  Reverted: the idle streams keep hardware queues,
+            // the runtime has four per process, and the two streams of the NEXT handle -- the sparse index's list walk and its
+            // heavy-query kernel in the same bench process -- then shared one and ran one after the other: 36.9 -> 43.7 ms,
+            // profiles/r05_zy_*.)
+            GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+            GORSE_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
         } else {
             int prio_lo = 0, prio_hi = 0;
             GORSE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // lo = least urgent (largest number)
@@ -317,8 +296,8 @@ extern "C" int32_t gorse_mf_create(gorse_mf **out, int32_t device, int64_t U, in
             GORSE_HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         }
         for (int b = 0; b < 2; b++) {
-            if (!h->ev_sampled[b]) GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
-            if (!h->ev_consumed[b]) GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
+            GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_sampled[b], hipEventDisableTiming));
+            GORSE_HIP_CHECK(hipEventCreateWithFlags(&h->ev_consumed[b], hipEventDisableTiming));
         }
         trace.mark("create: streams, events");
         // one row more than the matrix has, and it stays zero: the ALS gathers send the entries past a row's end there (row id U
@@ -443,31 +422,15 @@ extern "C" int32_t gorse_mf_destroy(gorse_mf *h) {
     if (!h) return GORSE_OK;
     CreateTrace trace;
     (void)hipSetDevice(h->device);
-    bool ok = true;
-    if (h->stream) ok = hipStreamSynchronize(h->stream) == hipSuccess && ok;
-    if (h->stream2) ok = hipStreamSynchronize(h->stream2) == hipSuccess && ok;
-    bool kept = false;
-    if (ok && h->pooled_streams && h->stream && h->stream2 && h->ev_sampled[0] && h->ev_sampled[1] && h->ev_consumed[0] &&
-        h->ev_consumed[1]) {  // a complete, healthy set: it waits for the next handle of this device
-        std::lock_guard<std::mutex> lock(g_stream_pool_mu);
-        auto &pool = g_stream_pool[h->device & 63];
-        if (pool.size() < 4) {
-            StreamSet ss;
-            ss.s = h->stream, ss.s2 = h->stream2;
-            for (int b = 0; b < 2; b++) ss.sampled[b] = h->ev_sampled[b], ss.consumed[b] = h->ev_consumed[b];
-            pool.push_back(ss);
-            kept = true;
-        }
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (int b = 0; b < 2; b++) {
+        if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
+        if (h->ev_consumed[b]) (void)hipEventDestroy(h->ev_consumed[b]);
     }
-    if (!kept) {
-        for (int b = 0; b < 2; b++) {
-            if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
-            if (h->ev_consumed[b]) (void)hipEventDestroy(h->ev_consumed[b]);
-        }
-        trace.mark("destroy: sync, events");
-        if (h->stream) (void)hipStreamDestroy(h->stream);
-        if (h->stream2) (void)hipStreamDestroy(h->stream2);
-    }
+    trace.mark("destroy: sync, events");
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     trace.mark("destroy: streams");
     delete h;
     trace.mark("destroy: buffers");

@@ -19,7 +19,6 @@ struct gorse_mf {
     bool has_item_csr = false;
     hipStream_t stream = nullptr;   // update kernels, copies
     hipStream_t stream2 = nullptr;  // sampler running ahead of the update kernels
-    bool pooled_streams = false;    // the default kind of streams: gorse_mf_destroy may keep them for the next handle (mf.hip)
     hipEvent_t ev_sampled[2] = {nullptr, nullptr};
     hipEvent_t ev_consumed[2] = {nullptr, nullptr};
     // factors, row-major, row stride d (rows 16-byte aligned whenever d % 4 == 0)
