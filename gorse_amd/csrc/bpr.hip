@@ -1528,7 +1528,7 @@ int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t
 
 // Samples per chunk.  The user-run schedule loads p_u once per RUN (a user's samples inside one chunk), so a chunk should hold
 // a few dozen samples per user: 4M samples serve the S-ml1m and C3-shard shapes (<= 125K users); the full C3 set (1M users)
-// takes 32M, the 10M-user set 128M -- 52 bytes of triplet / sort buffers per sample of capacity, 6.7 GB of the 288 at most.
+// takes 32M, the 10M-user set 128M -- 64 bytes of triplet / pair / sort buffers per sample of capacity, 8.2 GB of the 288 at most.
 int64_t g_chunk_override = 0;  // probe: gorse_hip_test_set_bpr_chunk
 int64_t chunk_capacity(const gorse_mf *h) {
     if (g_chunk_override > 0) return g_chunk_override;
