@@ -36,6 +36,13 @@ import sys
 import threading
 import time
 
+# Every handle runs two streams side by side (update / preparation of the next chunk; list walk / heavy-query kernel), and the HIP
+# runtime multiplexes a process's streams onto FOUR hardware queues per device unless told otherwise; a rank of an N > 1 run also
+# holds torch's and RCCL's streams, and two streams on one queue run one after the other ("Streams and hardware
+# queues"; profiles/r05_zzc: two ranks sharing one GPU 55.5 -> 50.6 ms per step with eight, the single-process legs unchanged).
+# Must be in the environment before the runtime initialises: hence here, before anything imports it.  The caller's value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
