@@ -521,7 +521,8 @@ struct ResidentDataset {
 struct FitConfig {
     int Jobs = 1, Verbose = 10, Candidates = 100, TopK = 10, Patience = 0;
     const volatile int32_t *Cancel = nullptr;        // ctx.Done()
-    std::function<void(int)> OnEpoch;                 // span.Add(1)
+    std::function<void(int)> OnEpoch;                 // span.Add(1): a progress count -- fires when the epoch has been ISSUED (the epochs between two
+                                                      // evaluations are only enqueued; every epoch is done before an evaluation and before Fit returns)
     std::function<void(const std::string &)> Log;     // zap logger lines ("fit bpr e/E ...")
     int Device = 0;
     // a dataset kept on the device across Fit calls (the trials of a ModelSearch, the fit periods of the
