@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "bpr_bins.hpp"
 #include "mf_internal.hpp"
 #include <utility>
 
@@ -286,9 +287,7 @@ __global__ __launch_bounds__(256) void bpr_sample_items_batch_kernel(int32_t U, 
 //   bpr_sample_items_kernel: unchanged.
 // The order of the samples inside a run is the order of arrival as before (no order is promised: the runs are multisets).
 constexpr int kBinThreads = 512;     // workgroup of the count / scatter kernels
-constexpr int kMaxBins = 8192;       // bins of a chunk at most (LDS: one counter each)
 constexpr int kBinBatch = 8;         // samples of a thread whose loads are in flight together (scatter / sort kernels)
-constexpr int kMaxBinShift = 11;     // user ids per bin at most 2^11 (LDS of the sort kernel: two counters each)
 
 template <int NW>
 __device__ __forceinline__ int32_t block_exclusive_scan(int32_t v, int32_t *lds /* NW + 1 */, int32_t *total) {
@@ -1222,7 +1221,7 @@ int32_t launch_user_sort(gorse_mf *h, const int32_t *trip, int32_t *sorted, int3
 int32_t ensure_user_sort(gorse_mf *h) {
     const int64_t m = h->U + 2;
     // the tile x bin matrix of the binned preparation: prep_bins gives a chunk at most max(512, cap / 65536) tiles and min(kMaxBins - 1, U + 1) bins
-    const size_t mat = (size_t)std::max<int64_t>(512, ceil_div((int64_t)h->trip_cap, 65536)) * (size_t)std::min<int64_t>(kMaxBins - 1, h->U + 1);
+    const size_t mat = prep_matrix_words(h->U, (int64_t)h->trip_cap);
     if ((size_t)m <= h->ubucket[0].n && h->scan_tmp2.n >= (size_t)ceil_div(m, kScanTile) && h->urank[0].n >= 2 * h->trip_cap &&
         h->ubins.n >= (size_t)2 * kMaxBins && h->ubinmat.n >= mat)
         return GORSE_OK;
@@ -1450,25 +1449,7 @@ int32_t launch_sampler(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base,
 // sample ids scattered to their sorted positions, item draws by run.  `trip` (3 x cap ints, otherwise the unsorted triplets)
 // holds the keys and (sample id, user) pairs; `rank` (2 x cap) the ranks or the sorted pairs; `sorted` receives si at cap, sj at
 // 2 cap; bucket[0..U + 1] the run offsets.
-// bins of the binned preparation for a chunk of n samples: user ids per bin 2^shift, (U >> shift) + 1 bins (key U = no user)
-struct PrepBins {
-    int shift, nbins;
-    int64_t tile;  // samples per workgroup of the count / scatter kernels
-    bool ok;       // false: more user ids per bin than the sort kernel's LDS holds (U > 16M) -> the preparation without bins
-};
-PrepBins prep_bins(int64_t U, int64_t n) {
-    PrepBins b;
-    const int64_t target = std::min<int64_t>(std::max<int64_t>(n / 4096, 512), kMaxBins - 1);
-    b.shift = 0;
-    while ((U >> b.shift) + 1 > target) b.shift++;
-    b.nbins = (int)((U >> b.shift) + 1);
-    int64_t t = 4096;
-    while (t < 65536 && t * 512 < n) t *= 2;
-    b.tile = t;
-    b.ok = b.shift <= kMaxBinShift;
-    return b;
-}
-
+// (PrepBins / prep_bins: csrc/bpr_bins.hpp, shared with the CPU cover test)
 int32_t launch_prepare_users(gorse_mf *h, uint64_t seed, uint64_t epoch, int64_t base, int64_t n, int32_t *trip, int32_t *sorted,
                              int32_t *bucket, int32_t *rank, size_t cap, hipStream_t st) {
     if (n <= 0) return GORSE_OK;

@@ -7,6 +7,7 @@
 #include "gorse_cf.hpp"
 #include "gorse_vectors.hpp"
 #include "../csrc/rank_keys.hpp"
+#include "../csrc/bpr_bins.hpp"
 #include "../csrc/topk_sym.hpp"
 
 using namespace gorse;
@@ -909,6 +910,22 @@ int64_t gh_test_topk_sym_cover(int64_t n, int64_t q0, int64_t nq, int32_t tile_r
         }
     }
     return multiplied;
+}
+// CPU test hooks for the BPR chunk preparation by user bins (csrc/bpr_bins.hpp, the very header the launch code includes):
+// the geometry of a chunk -> out[0..4] = shift, bins, tile, tiles, ok; the words of the tile x bin matrix a handle allocates;
+// and the four passes restated on the CPU over given user keys -> run offsets bucket[U + 2] and the (sample id, user) pairs in run order.
+void gh_test_bpr_bins_geometry(int64_t U, int64_t n, int64_t *out5) {
+    const gorse::PrepBins pb = gorse::prep_bins(U, n);
+    out5[0] = pb.shift, out5[1] = pb.nbins, out5[2] = pb.tile, out5[3] = (n + pb.tile - 1) / pb.tile, out5[4] = pb.ok ? 1 : 0;
+}
+int64_t gh_test_bpr_bins_matrix_words(int64_t U, int64_t cap) { return (int64_t)gorse::prep_matrix_words(U, cap); }
+int32_t gh_test_bpr_bins_emulate(int64_t U, const int32_t *key, int64_t n, int32_t *bucket, int32_t *pair_s, int32_t *pair_u) {
+    std::vector<int32_t> b, ps, pu;
+    if (!gorse::prep_bins_emulate(U, key, n, b, ps, pu)) return 0;
+    std::copy(b.begin(), b.end(), bucket);
+    std::copy(ps.begin(), ps.end(), pair_s);
+    std::copy(pu.begin(), pu.end(), pair_u);
+    return 1;
 }
 // the 64-bit sparse ranking key itself, and the number of results the reference returns (xvec.go:379-446)
 uint64_t gh_test_sparse_key(float score, int32_t row) { return gorse::rank::make_key(gorse::rank::score_ord(score), row); }
