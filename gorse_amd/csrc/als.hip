@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "als_plan.hpp"
 #include "mf_internal.hpp"
 #include <type_traits>
 
@@ -2121,19 +2122,9 @@ int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, 
     }
     std::vector<int32_t> shorts, lrows, lfirst, lnch, crow, ccnt;
     std::vector<int64_t> cbeg;
-    // A short row is ONE wave's work from its first entry to its solve, so the longest short row is the row kernel's critical path:
-    // 4096 entries are 70-90 us of one wave, which a side of 50M entries never notices and a side of 1M entries (S-ml1m: the
-    // reference's own test shape) waits for with the chip empty -- its epoch at nFactors 8 takes 0.196 ms with the threshold at 4096,
-    // 0.125 at 1024, 0.095 at 256 (profiles/r05_zq_probe_als_plan.txt).  The threshold therefore follows the side's size: the even
-    // share of one of ~4096 wave slots, as a power of two between 256 (512 from nFactors 64 on: a chunk's partial Gram is d x d
-    // floats) and 4096.  It is taken from the WHOLE side, not from the range [lo, hi): every rank of a sharded sweep cuts the same rows
-    // the same way (the sharded epoch stays bit-equal to the unsharded one).
+    // the threshold follows the side's size (csrc/als_plan.hpp, shared with the CPU test), taken from the WHOLE side, not from [lo, hi)
     int64_t long_row = g_als_long_row, chunk_len = g_als_chunk;
-    if (long_row <= 0) {
-        const int64_t share = (ptr[rows] - ptr[0]) / 4096, floor_ = h->d >= 64 ? 512 : 256;
-        long_row = floor_;
-        while (long_row < 4096 && long_row < share) long_row *= 2;
-    }
+    if (long_row <= 0) long_row = als_long_row_threshold(ptr[rows] - ptr[0], h->d);
     if (chunk_len <= 0) chunk_len = long_row;
     for (int64_t r = lo; r < hi; r++) {  // the rows this handle solves; the Gram list below covers ALL rows
         const int64_t n = ptr[r + 1] - ptr[r];

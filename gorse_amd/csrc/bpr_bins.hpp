@@ -1,5 +1,5 @@
 // bpr_bins.hpp -- the geometry of the BPR chunk preparation by user bins (csrc/bpr.hip: bpr_bin_count / _offsets / _scatter / _sort
-// kernels), shared by the launch code and by the CPU cover test (host library hook gh_test_bpr_bins_*, tests/test_bpr_bins_cpu.py).
+// kernels), shared by the launch code and by the CPU cover test (host library hook gh_test_bpr_bins_*, tests/test_launch_geometry_cpu.py).
 // Pure host C++: no device code, no HIP types.  Reference semantics of what is being grouped: model/cf/model.go:449-468 (the samples
 // of an epoch, users drawn uniformly); the order in which a Hogwild epoch applies them is free (common/parallel/parallel.go:44-68).
 #pragma once
@@ -22,7 +22,7 @@ inline PrepBins prep_bins(int64_t U, int64_t n) {
     PrepBins b;
     int64_t target = std::min<int64_t>(std::max<int64_t>(n / 4096, 512), kMaxBins - 1);
     // (a small chunk of a handle with millions of users -- the tail of an epoch -- takes as many bins as the sort kernel's LDS asks for,
-    // not the few its samples would: found by tests/test_bpr_bins_cpu.py, which met shift 15 at 10M users and a one-sample chunk)
+    // not the few its samples would: found by tests/test_launch_geometry_cpu.py, which met shift 15 at 10M users and a one-sample chunk)
     const int64_t need = (U >> kMaxBinShift) + 1;
     if (need <= kMaxBins - 1) target = std::max(target, need);
     b.shift = 0;

@@ -7,6 +7,7 @@
 #include "gorse_cf.hpp"
 #include "gorse_vectors.hpp"
 #include "../csrc/rank_keys.hpp"
+#include "../csrc/als_plan.hpp"
 #include "../csrc/bpr_bins.hpp"
 #include "../csrc/topk_sym.hpp"
 
@@ -927,6 +928,8 @@ int32_t gh_test_bpr_bins_emulate(int64_t U, const int32_t *key, int64_t n, int32
     std::copy(pu.begin(), pu.end(), pair_u);
     return 1;
 }
+// the ALS row plan's long-row threshold for a side of `side_entries` feedbacks (csrc/als_plan.hpp, the header als_build_plan includes)
+int64_t gh_test_als_long_row(int64_t side_entries, int32_t d) { return gorse::als_long_row_threshold(side_entries, d); }
 // the 64-bit sparse ranking key itself, and the number of results the reference returns (xvec.go:379-446)
 uint64_t gh_test_sparse_key(float score, int32_t row) { return gorse::rank::make_key(gorse::rank::score_ord(score), row); }
 int32_t gh_test_sparse_written(int64_t pos, int64_t neg, int64_t adm, int32_t k) { return gorse::rank::written(pos, neg, adm, k); }

@@ -60,3 +60,21 @@ def test_the_four_passes_group_every_sample_by_its_user(U, n, empty_every):
     assert np.array_equal(np.sort(ps), np.arange(n)) and np.array_equal(pu, key[ps])         # a permutation, each with its own key
     run_of = np.repeat(np.arange(U + 1), np.diff(bucket))
     assert np.array_equal(run_of, np.where(pu < 0, U, pu))                                   # every pair inside the run of its user
+
+
+def test_als_long_row_threshold_follows_the_side():
+    """csrc/als_plan.hpp (included by als_build_plan): a power of two in [256 (512 from nFactors 64 on), 4096], non-decreasing in the
+    side's size, 4096 for the sides of C5 (50M entries) and 256 / 512 for S-ml1m's (model/cf/model_test.go:93-104: the shape of
+    TestCCD_MovieLens)."""
+    L = C.CDLL(cf.HOST_LIB)
+    L.gh_test_als_long_row.restype = C.c_int64
+    L.gh_test_als_long_row.argtypes = [C.c_int64, C.c_int32]
+    for d in (8, 16, 48, 64, 128):
+        floor = 512 if d >= 64 else 256
+        prev = 0
+        for entries in [0, 1, 1000, 994_169, 1 << 20, 3_000_000, 10_000_000, 16_777_216, 50_000_000, 1_000_000_000]:
+            t = L.gh_test_als_long_row(entries, d)
+            assert floor <= t <= 4096 and t & (t - 1) == 0 and t >= prev
+            assert t == floor or t // 2 < entries / 4096 or t == 4096
+            prev = t
+        assert L.gh_test_als_long_row(994_169, d) == floor and L.gh_test_als_long_row(50_000_000, d) == 4096
