@@ -65,17 +65,25 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA peak = the fp32 vector rate (MI355X_MICROARCH.md: 157.3 TF spec, 155 measured)
 
 
+TRAFFIC_ROUND = "r06"  # a PMC record is reported only if its session is of THIS round (the kernels it measured are the ones timed)
+
+
 def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the last committed PMC passes (profiles/traffic.json, written
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json, written
     by scripts/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this very command).
-    bench.py cannot collect counters on itself; it reports the recorded figure and says where it came from."""
+    bench.py cannot collect counters on itself; it reports the recorded figure and says where it came from -- and REFUSES
+    (traffic: null) a record whose session is not of the current round: a figure measured on an earlier round's kernels says
+    nothing about the ones this run timed."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[workload]
         f, w = rec.get("fetch_bytes_per_launch"), rec.get("write_bytes_per_launch")
         if f is None or w is None:
             return None, None
+        if not str(rec.get("session", "")).startswith(TRAFFIC_ROUND):
+            return None, "profiles/traffic.json[%s] is a record of session %r, not of round %s: not reported" % (
+                workload, rec.get("session", "?"), TRAFFIC_ROUND)
         return f + w, "profiles/traffic.json[%s]: FETCH_SIZE %.0f MB + WRITE_SIZE %.0f MB per launch; %s" % (
-            workload, f / 1e6, w / 1e6, rec.get("how", ""))  # the source string is prose: compact() moves it to the notes file
+            workload, f / 1e6, w / 1e6, "session %s; %s" % (rec.get("session", "?"), rec.get("how", "")))  # prose: compact() moves it to the notes file
     except Exception:
         return None, None
 
@@ -761,12 +769,27 @@ def bench_bpr(args, workload, world, rank, local, comm, comm_label, steps, warmu
                      "user_sort_avg_ms": sort_ms / max(o_launches, 1) if o_launches else 0.0,
                      "note": "working set P + Q = %.1f MB (%s the 256 MiB Infinity Cache)" % (ws_mb, "inside" if ws_mb < 268 else "outside")},
     }
+    if user_runs and ws_mb < 32.0 and avg_ms > 0:
+        # The working set (P + Q) never leaves the L2s (4 MB x 8 XCDs) / the Infinity Cache: "fraction of HBM peak" describes nothing
+        # physical here.  What the launch IS bound by: every item update is d fp32 atomics performed memory-side (at the L2 / fabric),
+        # two item rows per sample, against the rate the unit gives under THIS access mix -- a table of this many rows that is also
+        # gathered two samples ahead: scripts/probe_atomics3.hip, profiles/r04_s_probe_atomics3.txt: 243 G dword/s (318 G when nothing
+        # reads the rows; DESIGN.md section 4 "Why C2 stays").  The nominal HBM figure stays next to it (`frac`).
+        atomic_dw = samples_per_launch * 2 * d
+        a_rate = atomic_dw / (avg_ms * 1e-3) / 1e9
+        out["roofline"]["bound_measured"] = "l2_atomic"
+        out["roofline"]["l2_atomic"] = {"achieved": a_rate, "peak": 243.0, "unit": "G atomic dwords/s", "frac": a_rate / 243.0,
+                                        "atomic_dwords_per_sample": 2 * d,
+                                        "note": "peak = fp32 atomic adds/s the memory side sustains on a 3,704-row table whose rows are also "
+                                                "gathered two iterations ahead (scripts/probe_atomics3.hip, profiles/r04_s_probe_atomics3.txt); "
+                                                "318 G/s when nothing reads the rows"}
     if world > 1:
         out["exchange"] = {"allreduce_avg_ms": comm_ms / max(c_launches, 1) if c_launches else None, "launches": c_launches,
                            "bytes": data.I * d * 4, "path": comm_label}
     if args.mode in (capi.BPR_HOGWILD_ATOMIC, capi.BPR_HOGWILD_STORES) and workload in ("ml1m", "c3", "c3full", "big") and not (factors or args.factors):
         key = {"ml1m": "ml1m_users" if user_runs else "ml1m", "c3": "c3_users", "c3full": "c3full_users", "big": "big_users"}[workload]
         tr, src = measured_traffic(key)
+        out["roofline"]["traffic_session_round"] = TRAFFIC_ROUND if tr is not None else None
         # the recorded figure is the mean over the FULL-size launches (one chunk: 32 samples per user, clamped to [4M, 128M], or the
         # whole epoch); `traffic` is scaled to the mean launch samples_per_launch describes, the full-size figure rides along
         full_launch = min(n_samples, min(max(32 * data.U, 4 << 20), 128 << 20))
@@ -925,8 +948,8 @@ def emit(out, tag="default"):
             notes[k + ".config"] = line[k]["config"]
             line[k]["config"] = {"workload": line[k]["config"].get("workload")}
     # the notes of this run lie next to the line's log (gpurun_out/ is scratch); the copy of the round's last run is committed as
-    # profiles/r05_bench_notes_<tag>.json
-    line["notes"] = {"this_run": write_notes(notes, tag), "committed_copy": "profiles/r05_bench_notes_%s.json" % tag}
+    # profiles/r06_bench_notes_<tag>.json
+    line["notes"] = {"this_run": write_notes(notes, tag), "committed_copy": "profiles/r06_bench_notes_%s.json" % tag}
     print(json.dumps(line, separators=(",", ":")), flush=True)
 
 

@@ -71,6 +71,8 @@ SIGNATURES = {
     "gorse_comm_allreduce_f32_local": (C.c_int32, [C.POINTER(_vp), C.c_int32, C.POINTER(_f32p), C.c_int64]),
     "gorse_comm_available": (C.c_int32, []),
     "gorse_mf_synchronize": (C.c_int32, [_vp]),
+    "gorse_mf_epoch_throttle": (C.c_int32, [_vp, C.c_int32, _i32p]),
+    "gorse_mf_epoch_times": (C.c_int32, [_vp, _i64p, C.POINTER(C.c_double), _i64p, C.c_int32]),
     "gorse_mf_set_profiling": (C.c_int32, [_vp, C.c_int32]),
     "gorse_mf_get_profile": (C.c_int32, [_vp, C.c_int32, _i64p, _f64p]),
     "gorse_mf_reset_profile": (C.c_int32, [_vp]),
@@ -107,6 +109,8 @@ SIGNATURES = {
     "gorse_hip_test_topk_sym_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "gorse_hip_test_topk_get_thresholds": (C.c_int32, [_vp, _f32p, C.c_int64]),
     "gorse_hip_test_topk_get_pilot_state": (C.c_int32, [_vp, C.POINTER(C.c_uint8), _i32p, C.c_int64]),
+    "gorse_hip_test_topk_get_flags": (C.c_int32, [_vp, C.POINTER(C.c_uint8), C.c_int64]),
+    "gorse_hip_test_topk_get_foreign_counts": (C.c_int32, [_vp, _i32p, C.c_int64]),
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_head": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_table": (None, [C.c_int32]),
@@ -124,7 +128,6 @@ SIGNATURES = {
     "gorse_hip_test_bpr_prepare_chunk": (C.c_int32, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_int64, _i32p, _i32p, _i32p]),
     "gorse_hip_test_set_bpr_store_mode": (None, [C.c_int32]),
     "gorse_hip_test_set_prep_cu_stride": (None, [C.c_int32]),
-    "gorse_hip_test_set_bpr_user_segments": (None, [C.c_int32]),
     "gorse_hip_test_set_bpr_user_segments": (None, [C.c_int32]),
     "gorse_hip_test_set_bpr_user_depth": (None, [C.c_int32]),
     "gorse_hip_test_probe_build": (C.c_int32, []),
@@ -257,7 +260,7 @@ class MF:
         check(lib().gorse_mf_set_bpr_cold_window(self.h, samples, C.byref(n)))
         return n.value
 
-    def bpr_epoch(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_ATOMIC, want_loss=False,
+    def bpr_epoch(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_STORES, want_loss=False,
                   cancel=None):
         loss = C.c_double(0)
         cp = _p(cancel, _i32p) if cancel is not None else None
@@ -265,7 +268,7 @@ class MF:
                                     C.byref(loss) if want_loss else None))
         return loss.value
 
-    def bpr_epoch_enqueue(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_ATOMIC):
+    def bpr_epoch_enqueue(self, n_samples, lr, reg, seed, epoch, sample_base=0, mode=BPR_HOGWILD_STORES):
         check(lib().gorse_bpr_epoch_enqueue(self.h, n_samples, lr, reg, seed, epoch, sample_base, mode))
 
     def bpr_sample_triplets(self, n, seed, epoch, sample_base=0):
@@ -336,6 +339,16 @@ class MF:
 
     def synchronize(self):
         check(lib().gorse_mf_synchronize(self.h))
+
+    def epoch_throttle(self, max_in_flight, cancel=None):
+        """blocks until at most max_in_flight enqueued epochs are unfinished; raises GorseHipError(ERR_CANCELLED) when *cancel is set"""
+        check(lib().gorse_mf_epoch_throttle(self.h, max_in_flight, _p(cancel, _i32p) if cancel is not None else None))
+
+    def epoch_times(self, reset=False):
+        """(finished epochs, their device milliseconds, epochs still in flight) since the last reset"""
+        n, ms, fl = C.c_int64(0), C.c_double(0), C.c_int64(0)
+        check(lib().gorse_mf_epoch_times(self.h, C.byref(n), C.byref(ms), C.byref(fl), int(bool(reset))))
+        return n.value, ms.value, fl.value
 
     def set_profiling(self, on):
         check(lib().gorse_mf_set_profiling(self.h, int(bool(on))))
@@ -415,6 +428,18 @@ class TopK:
         out = np.empty(n, np.float32)
         check(lib().gorse_hip_test_topk_get_thresholds(self.h, out.ctypes.data_as(_f32p), n))
         return out
+
+    def last_flags(self, n):
+        """per-query flags of the last MFMA search's last chunk behind the rescoring (non-zero: the query took the tie path)"""
+        f = np.empty(n, np.uint8)
+        check(lib().gorse_hip_test_topk_get_flags(self.h, f.ctypes.data_as(C.POINTER(C.c_uint8)), n))
+        return f
+
+    def foreign_counts(self, n):
+        """entries appended to each query's foreign list by the last symmetric sweep (> 512: the list overflowed)"""
+        c = np.empty(n, np.int32)
+        check(lib().gorse_hip_test_topk_get_foreign_counts(self.h, c.ctypes.data_as(_i32p), n))
+        return c
 
     def sym_stats(self):
         out = (C.c_uint64 * 4)()

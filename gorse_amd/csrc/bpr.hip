@@ -1608,6 +1608,7 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
         return GORSE_OK;
     }
     GORSE_TRY(ensure_trip(h, n_samples));
+    GORSE_TRY(mf_epoch_begin(h));  // epoch pacing: the (begin, end) pair gorse_mf_epoch_throttle / _times read (csrc/mf.hip)
     double *d_loss = loss_out ? h->loss.p : nullptr;
     if (d_loss) GORSE_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), h->stream));
     const int64_t cap = (int64_t)h->trip_cap;
@@ -1679,10 +1680,12 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
             if (cancel && (c & 7) == 7) GORSE_TRY(mf_sync_streams(h));
         }
     }
+    GORSE_TRY(mf_epoch_end(h));
     if (sync || loss_out) {
         if (loss_out)
             GORSE_HIP_CHECK(hipMemcpyAsync(loss_out, h->loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         GORSE_TRY(mf_sync_streams(h));
+        GORSE_TRY(mf_epoch_harvest(h, true));  // every epoch issued so far is done: their device times are read now
     }
     return GORSE_OK;
 }

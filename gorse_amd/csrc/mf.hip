@@ -6,6 +6,8 @@
 #include <cstdlib>
 
 #include "goheap.hpp"
+#include <time.h>
+
 #include "mf_internal.hpp"
 
 using namespace gorse;
@@ -160,6 +162,58 @@ namespace gorse {
 int32_t mf_sync_streams(gorse_mf *h) {
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream2));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+// ---- epoch pacing ---------------------------------------------------------------------------------------------------------
+// A Fit that enqueues its epochs between two evaluations (gorse_bpr_epoch_enqueue) neither knows how long an epoch took on the
+// device -- the reference logs that as fit_time (model.go:496-503) -- nor sees a cancelled context before its next synchronous
+// call (the reference checks per sample, model.go:449).  Every epoch is therefore bracketed by a (begin, end) event pair on the update
+// stream: begin = the stream reaches the epoch (= the end of the previous epoch's last update kernel when epochs follow each other),
+// end = its last update kernel is done.  gorse_mf_epoch_throttle waits on them with the cancel flag in hand, gorse_mf_epoch_times
+// adds up their spans.
+int32_t mf_epoch_begin(gorse_mf *h) {
+    if (!h->ep_events) {
+        for (int i = 0; i < gorse_mf::kEpochRing; i++) {
+            GORSE_HIP_CHECK(hipEventCreate(&h->ev_ep_begin[i]));
+            GORSE_HIP_CHECK(hipEventCreate(&h->ev_ep_end[i]));
+        }
+        h->ep_events = true;
+    }
+    if (h->ep_seq - h->ep_done >= (uint64_t)gorse_mf::kEpochRing) {  // the slot about to be reused was never read
+        GORSE_TRY(mf_epoch_harvest(h, false));
+        while (h->ep_seq - h->ep_done >= (uint64_t)gorse_mf::kEpochRing) {
+            h->ep_done++;
+            h->ep_untimed++;
+        }
+    }
+    GORSE_HIP_CHECK(hipEventRecord(h->ev_ep_begin[h->ep_seq % gorse_mf::kEpochRing], h->stream));
+    return GORSE_OK;
+}
+int32_t mf_epoch_end(gorse_mf *h) {
+    GORSE_HIP_CHECK(hipEventRecord(h->ev_ep_end[h->ep_seq % gorse_mf::kEpochRing], h->stream));
+    h->ep_seq++;
+    return GORSE_OK;
+}
+int32_t mf_epoch_harvest(gorse_mf *h, bool wait) {
+    while (h->ep_done < h->ep_seq) {
+        const int slot = (int)(h->ep_done % gorse_mf::kEpochRing);
+        if (wait) {
+            GORSE_HIP_CHECK(hipEventSynchronize(h->ev_ep_end[slot]));
+        } else {
+            const hipError_t q = hipEventQuery(h->ev_ep_end[slot]);
+            if (q == hipErrorNotReady) {
+                (void)hipGetLastError();
+                break;
+            }
+            GORSE_HIP_CHECK(q);
+        }
+        float ms = 0.0f;
+        GORSE_HIP_CHECK(hipEventElapsedTime(&ms, h->ev_ep_begin[slot], h->ev_ep_end[slot]));
+        h->ep_ms += ms;
+        h->ep_timed++;
+        h->ep_done++;
+    }
     return GORSE_OK;
 }
 
@@ -428,6 +482,11 @@ extern "C" int32_t gorse_mf_destroy(gorse_mf *h) {
         if (h->ev_sampled[b]) (void)hipEventDestroy(h->ev_sampled[b]);
         if (h->ev_consumed[b]) (void)hipEventDestroy(h->ev_consumed[b]);
     }
+    if (h->ep_events)
+        for (int i = 0; i < gorse_mf::kEpochRing; i++) {
+            (void)hipEventDestroy(h->ev_ep_begin[i]);
+            (void)hipEventDestroy(h->ev_ep_end[i]);
+        }
     trace.mark("destroy: sync, events");
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -617,6 +676,37 @@ extern "C" int32_t gorse_mf_synchronize(gorse_mf *h) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
     GORSE_TRY(h->use());
     return mf_sync_streams(h);
+}
+extern "C" int32_t gorse_mf_epoch_throttle(gorse_mf *h, int32_t max_in_flight, const volatile int32_t *cancel) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (max_in_flight < 0) return fail(GORSE_ERR_INVALID, "max_in_flight < 0");
+    GORSE_TRY(h->use());
+    // the epochs are finished in order: wait for the oldest until no more than max_in_flight are left, the cancel flag in hand
+    for (;;) {
+        GORSE_TRY(mf_epoch_harvest(h, false));
+        if (h->ep_seq - h->ep_done <= (uint64_t)max_in_flight) return GORSE_OK;
+        if (cancel && *cancel) return fail(GORSE_ERR_CANCELLED, "cancelled");
+        if (!cancel) {  // nobody to listen for: block on the oldest epoch
+            GORSE_HIP_CHECK(hipEventSynchronize(h->ev_ep_end[h->ep_done % gorse_mf::kEpochRing]));
+        } else {
+            struct timespec ts = {0, 20000};  // 20 us between two looks at the event and the flag
+            nanosleep(&ts, nullptr);
+        }
+    }
+}
+extern "C" int32_t gorse_mf_epoch_times(gorse_mf *h, int64_t *epochs, double *total_ms, int64_t *in_flight, int32_t reset) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    GORSE_TRY(h->use());
+    GORSE_TRY(mf_epoch_harvest(h, false));
+    if (epochs) *epochs = h->ep_timed;
+    if (total_ms) *total_ms = h->ep_ms;
+    if (in_flight) *in_flight = (int64_t)(h->ep_seq - h->ep_done);
+    if (reset) {
+        h->ep_ms = 0.0;
+        h->ep_timed = 0;
+        h->ep_untimed = 0;
+    }
+    return GORSE_OK;
 }
 extern "C" int32_t gorse_mf_set_profiling(gorse_mf *h, int32_t on) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");

@@ -9,7 +9,14 @@
 #ifndef GORSE_HOT_REPLICAS
 #define GORSE_HOT_REPLICAS 8  // replica rows per hot item (bpr.hip kHotReplicas); A/B builds of bpr.hip: make ab AB_FLAGS=-DGORSE_HOT_REPLICAS=16
 #endif
-#define GORSE_HOT_REPLICAS_ALLOC 32  // replica rows ALLOCATED per hot item by gorse_mf_create (>= every build's GORSE_HOT_REPLICAS)
+// replica rows ALLOCATED (and cleared) per hot item by gorse_mf_create: exactly what the kernels use.  An A/B build of bpr.hip alone with
+// more replicas (make ab AB_SRC=bpr AB_FLAGS=-DGORSE_HOT_REPLICAS=16) needs mf.hip to allocate as many: build the library with
+// -DGORSE_HOT_REPLICAS_ALLOC=32 for such a session (round 5 always allocated 32: up to 16 MB of allocation + memset per handle at
+// nFactors 128, in the very Fit whose handle creation the same round had shortened)
+#ifndef GORSE_HOT_REPLICAS_ALLOC
+#define GORSE_HOT_REPLICAS_ALLOC GORSE_HOT_REPLICAS
+#endif
+static_assert(GORSE_HOT_REPLICAS_ALLOC >= GORSE_HOT_REPLICAS, "gorse_mf_create must allocate every replica row the kernels use");
 
 struct gorse_mf {
     int device = 0;
@@ -21,6 +28,15 @@ struct gorse_mf {
     hipStream_t stream2 = nullptr;  // sampler running ahead of the update kernels
     hipEvent_t ev_sampled[2] = {nullptr, nullptr};
     hipEvent_t ev_consumed[2] = {nullptr, nullptr};
+    // epoch pacing (gorse_mf_epoch_throttle / gorse_mf_epoch_times): a ring of (begin, end) event pairs, one per BPR epoch, recorded
+    // on the update stream; created with the first epoch.  ep_seq = epochs issued, ep_done = epochs whose events have been read.
+    static constexpr int kEpochRing = 16;
+    hipEvent_t ev_ep_begin[kEpochRing] = {}, ev_ep_end[kEpochRing] = {};
+    bool ep_events = false;
+    uint64_t ep_seq = 0, ep_done = 0;
+    double ep_ms = 0.0;     // device milliseconds of the epochs read so far (since the last reset)
+    int64_t ep_timed = 0;   // how many epochs that sum covers
+    int64_t ep_untimed = 0; // epochs whose events were overwritten before anybody read them (more than kEpochRing in flight)
     // factors, row-major, row stride d (rows 16-byte aligned whenever d % 4 == 0)
     gorse::DevBuf<float> P, Q, Qsync;
     // dataset.CFSplit user->items (stored order + row-sorted copy) and item->users
@@ -94,6 +110,10 @@ struct gorse_mf {
 namespace gorse {
 // implemented in bpr.hip / als.hip, used across files
 int32_t mf_sync_streams(gorse_mf *h);
+// epoch pacing: mark the begin / end of one epoch on the update stream; read the finished ones (wait = block for all of them)
+int32_t mf_epoch_begin(gorse_mf *h);
+int32_t mf_epoch_end(gorse_mf *h);
+int32_t mf_epoch_harvest(gorse_mf *h, bool wait);
 int32_t mf_delta_export_async(gorse_mf *h, float *dst);        // mf.hip: dst <- Q - Q_sync, enqueued on h->stream
 int32_t mf_delta_import_async(gorse_mf *h, const float *src);  // mf.hip: Q <- Q_sync + src; Q_sync <- Q
 int32_t als_build_plan(gorse_mf *h, int side, const int64_t *ptr, int64_t rows, int64_t lo, int64_t hi);

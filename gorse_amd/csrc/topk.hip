@@ -614,6 +614,25 @@ extern "C" int32_t gorse_hip_test_topk_get_thresholds(gorse_topk *h, float *out,
     return GORSE_OK;
 }
 
+// test hook: the per-query flags of the last MFMA search's last chunk as the host read them behind the rescoring (non-zero = the
+// query went on to the tie path: ties among its k + 1 best, a warm start that could not be verified, no pilot threshold, a list
+// that overflowed), and -- after a symmetric sweep -- how many entries the other workgroups appended to every query's foreign list
+// (more than the list's 512 slots = it overflowed)
+extern "C" int32_t gorse_hip_test_topk_get_flags(gorse_topk *h, uint8_t *flags, int64_t n) {
+    if (!h || !flags) return fail(GORSE_ERR_INVALID, "NULL argument");
+    if ((int64_t)h->host_flags.size() < n) return fail(GORSE_ERR_INVALID, "no MFMA search of that size has run on this handle");
+    memcpy(flags, h->host_flags.data(), (size_t)n);
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_hip_test_topk_get_foreign_counts(gorse_topk *h, int32_t *counts, int64_t n) {
+    if (!h || !counts) return fail(GORSE_ERR_INVALID, "NULL argument");
+    if ((int64_t)h->fcnt.n < n) return fail(GORSE_ERR_INVALID, "no symmetric sweep of that size has run on this handle");
+    GORSE_TRY(h->use());
+    GORSE_HIP_CHECK(hipMemcpyAsync(counts, h->fcnt.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
 // probe (variant bit 24): the pilot's per-query flags and list lengths
 extern "C" int32_t gorse_hip_test_topk_get_pilot_state(gorse_topk *h, uint8_t *flags, int32_t *counts, int64_t n) {
     if (!h || !flags || !counts) return fail(GORSE_ERR_INVALID, "NULL argument");

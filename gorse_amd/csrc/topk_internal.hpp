@@ -63,7 +63,8 @@ struct gorse_topk {
     gorse::DevBuf<float> f0raw;
     gorse::DevBuf<unsigned long long> sym_stats;  // counters of the last symmetric search (gorse_hip_test_topk_sym_stats)
     bool last_sym = false;
-    unsigned long long sym_unset_before = 0;  // sym_stats[0] before the current chunk's pilots
+    std::vector<uint8_t> host_flags;  // the last chunk's per-query flags as the host read them behind the rescoring (non-zero: the
+                                      // query left the sweep + rescoring undecided and went on to the tie path; gorse_hip_test_topk_get_flags)
     std::vector<uint8_t> dbg_flags;   // probe (variant bit 24): the pilot's flags and list lengths of the last chunk
     std::vector<int32_t> dbg_counts;
     int32_t use() const {

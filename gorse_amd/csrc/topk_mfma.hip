@@ -2273,7 +2273,10 @@ __global__ void sym_thresholds_kernel(float *__restrict__ f0, float *__restrict_
 
 __global__ void pilot_unset_count_kernel(const float *__restrict__ f0, int64_t n, unsigned long long *__restrict__ stats) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
-        if (f0[t] == -__builtin_inff()) atomicAdd(stats + 0, 1ull);
+        if (f0[t] == -__builtin_inff()) {
+            atomicAdd(stats + 0, 1ull);  // the search's total
+            atomicAdd(stats + 4, 1ull);  // this chunk's
+        }
 }
 
 __global__ void fill_kernel(float *__restrict__ out, int64_t n, float v) {
@@ -2398,8 +2401,8 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     h->n_fallback = 0;
     h->n_tie = 0;
     h->n_resweep = 0;
-    h->sym_unset_before = 0;
-    std::vector<uint8_t> flags((size_t)mb);
+    std::vector<uint8_t> &flags = h->host_flags;  // kept in the handle: gorse_hip_test_topk_get_flags
+    flags.assign((size_t)mb, 0);
     for (int64_t c0 = 0; c0 < nq; c0 += kChunkQ) {
         const int64_t m = std::min(kChunkQ, nq - c0);
         const uint16_t *Bop;
@@ -2532,8 +2535,12 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
         bool sym = warm && contiguous && !(g_topk_variant & (1 << 23)) && sweep_sym_kp(h->kp) && topk_rows_per_tile() == 128 &&
                    sym_q0 % 128 == 0 && m >= 2 * 32 * kNcbMain * kWavesMain && sp.probe <= 1 && !sp.prof;
         if (warm) {
-            GORSE_TRY(h->sym_stats.ensure(4));
-            if (c0 == 0) GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p, 0, 4 * sizeof(unsigned long long), h->stream));
+            // sym_stats[0..3]: the counters of the whole search (every chunk adds to them); [4]: THIS chunk's queries without a pilot
+            // threshold -- cleared per chunk, so that a chunk that was not eligible for the symmetric form leaves nothing behind for the
+            // next one's decision (round 5 took a difference against a host copy that only symmetric chunks updated)
+            GORSE_TRY(h->sym_stats.ensure(8));
+            if (c0 == 0) GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p, 0, 8 * sizeof(unsigned long long), h->stream));
+            else GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p + 4, 0, sizeof(unsigned long long), h->stream));
             pilot_unset_count_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(h->f0.p, m, h->sym_stats.p);
             GORSE_HIP_CHECK(hipGetLastError());
         }
@@ -2543,10 +2550,9 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
             // Euclidean case of test_warm_started_sweep_returns_the_same_rows), the square sweep is the better one.  One 8-byte read
             // behind the pilots.
             unsigned long long unset = 0;
-            GORSE_HIP_CHECK(hipMemcpyAsync(&unset, h->sym_stats.p, sizeof(unset), hipMemcpyDeviceToHost, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(&unset, h->sym_stats.p + 4, sizeof(unset), hipMemcpyDeviceToHost, h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-            if ((int64_t)(unset - h->sym_unset_before) * 32 > m) sym = false;
-            h->sym_unset_before = unset;
+            if ((int64_t)unset * 32 > m) sym = false;
         }
         h->last_sym = sym;
         if (sym) {

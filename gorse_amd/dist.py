@@ -15,13 +15,16 @@ import numpy as np
 
 def shard_range(n_rows, rank, world, align=1):
     """Contiguous row range [lo, hi) owned by `rank` (remainder rows go to the first ranks).  With `align` the inner
-    boundaries are rounded down to a multiple of it (the symmetric form of the dense all-pairs sweep needs the first
-    query row on a tile boundary: gorse_amd/csrc/topk_mfma.hip, 128 rows)."""
+    boundaries are rounded to the NEAREST multiple of it (the symmetric form of the dense all-pairs sweep needs the first
+    query row on a tile boundary: gorse_amd/csrc/topk_mfma.hip, 128 rows) -- but only where a shard is much larger than the
+    alignment (n_rows / world >= 8 * align): rounding the boundaries of small shards empties some and doubles others (200 rows
+    over 4 ranks at 128: (0,0) (0,0) (0,128) (128,200)), and a search of that size takes the scan anyway, which needs no alignment."""
     base, rem = divmod(int(n_rows), int(world))
+    aligned = align > 1 and base >= 8 * align
 
     def edge(r):
         at = r * base + min(r, rem)
-        return at if r == world or align <= 1 else at // align * align
+        return at if r == world or r == 0 or not aligned else (at + align // 2) // align * align
     return edge(rank), edge(rank + 1)
 
 

@@ -252,7 +252,9 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
     // eval_time / fit_time as in the reference's log lines (model.go:432-440, 496-503).  Epochs between two evaluations are
-    // only enqueued (see BPR::Fit), so fit_time is the mean over the epochs since the last evaluation, not the last epoch's.
+    // only enqueued (see BPR::Fit), so fit_time is the mean over the epochs since the last evaluation, not the last epoch's --
+    // and, where the library timed the epochs on the device (gorse_mf_epoch_times: hipEvents on the update stream, BPR), the mean of
+    // THEIR device times: what an enqueueing host measures with its own clock is when it issued an epoch, not how long it ran.
     auto t_eval = clk::now();
     auto score = Evaluate(*this, valSet, trainSet, config.TopK, config.Candidates, config.Jobs, metrics);
     std::vector<std::pair<int, float>> scores{{0, score[0]}};
@@ -261,6 +263,7 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
     auto t_fit = clk::now();
     int fit_epochs = 0;
     epochs_done_ = 0;
+    if (h_) (void)gorse_mf_epoch_times(h_, nullptr, nullptr, nullptr, 1);  // epochs of an earlier Fit on a lent handle do not count
     for (int epoch = 1; epoch <= nEpochs; epoch++) {
         int32_t rc = run_epoch(epoch);
         fit_epochs++;
@@ -272,7 +275,12 @@ Score MatrixFactorization::fit_loop(const char *tag, int nEpochs, dataset::Datas
         }
         check(rc);
         if (epoch % config.Verbose == 0 || epoch == nEpochs) {
-            const double fit_ms = ms_since(t_fit) / fit_epochs;
+            double fit_ms = ms_since(t_fit) / fit_epochs;
+            {
+                int64_t timed = 0;
+                double dev_ms = 0;
+                if (h_ && gorse_mf_epoch_times(h_, &timed, &dev_ms, nullptr, 1) == GORSE_OK && timed == fit_epochs) fit_ms = dev_ms / timed;
+            }
             t_eval = clk::now();
             score = Evaluate(*this, valSet, trainSet, config.TopK, config.Candidates, config.Jobs, metrics);
             scores.emplace_back(epoch, score[0]);
@@ -332,8 +340,16 @@ Score BPR::Fit(dataset::Dataset &trainSet, dataset::Dataset &valSet, const FitCo
         const bool cancelled = config.Cancel && *config.Cancel;
         // (OnEpoch = the reference's span.Add(1), a progress count: it fires when the epoch has been ISSUED, as in the Go twin,
         // integration/go/model/cf/bpr_hip.go:93 -- until round 5 a hook forced the synchronous entry point for every epoch here)
-        if (!eval_next && mode != GORSE_BPR_SEQUENTIAL && !cancelled)
+        if (!eval_next && mode != GORSE_BPR_SEQUENTIAL && !cancelled) {
+            // at most two epochs in flight: the preparation of epoch e + 1 still runs under the update of epoch e, and a cancelled
+            // context is seen within two epochs (the wait looks at the flag every 20 us) instead of at the next evaluation
+            const int32_t rc = gorse_mf_epoch_throttle(h_, kEnqueueDepth, config.Cancel);
+            if (rc != GORSE_OK) {
+                if (rc == GORSE_ERR_CANCELLED) (void)gorse_mf_synchronize(h_);  // drain what is in flight: the factors are pulled next
+                return rc;
+            }
             return gorse_bpr_epoch_enqueue(h_, n, lr, reg, seed, (uint64_t)epoch, 0, mode);
+        }
         return gorse_bpr_epoch(h_, n, lr, reg, seed, (uint64_t)epoch, 0, mode, config.Cancel, nullptr);
     });
 }

@@ -533,6 +533,9 @@ struct FitConfig {
     FitConfig &SetPatience(int p) { Patience = p; return *this; }
 };
 inline FitConfig NewFitConfig() { return FitConfig(); }
+// epochs a Fit keeps in flight between two evaluations (BPR::Fit, gorse_mf_epoch_throttle): two -- one running, one whose preparation
+// runs under it -- so that a cancelled context is seen within two epochs; the reference checks per sample (model.go:449)
+constexpr int kEnqueueDepth = 2;
 
 using TargetSet = std::set<int32_t>;
 using Metric = float (*)(const TargetSet &, const std::vector<int32_t> &);

@@ -933,4 +933,14 @@ int64_t gh_test_als_long_row(int64_t side_entries, int32_t d) { return gorse::al
 // the 64-bit sparse ranking key itself, and the number of results the reference returns (xvec.go:379-446)
 uint64_t gh_test_sparse_key(float score, int32_t row) { return gorse::rank::make_key(gorse::rank::score_ord(score), row); }
 int32_t gh_test_sparse_written(int64_t pos, int64_t neg, int64_t adm, int32_t k) { return gorse::rank::written(pos, neg, adm, k); }
+// the HNSW levels MarshalReference gives the n vectors of a model (gorse_vectors.hpp ReferenceLevels: the arithmetic both twins share)
+// and the levelFactor it writes, as its bits
+uint32_t gh_test_hnsw_levels(int64_t n, int32_t *level) {
+    const std::vector<int> lv = logics::MatrixFactorizationItems::ReferenceLevels(n);
+    for (int64_t i = 0; i < n; i++) level[i] = lv[(size_t)i];
+    const float f = logics::MatrixFactorizationItems::ReferenceLevelFactor();
+    uint32_t bits;
+    memcpy(&bits, &f, 4);
+    return bits;
+}
 }  // extern "C"

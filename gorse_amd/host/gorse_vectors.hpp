@@ -907,9 +907,36 @@ public:
     // bruteforce_hip.go) draws the same stream, so both write the same blob for the same model.  Each queue is written ascending in
     // the distance, which is a valid heap array for heap.PriorityQueue (pq.go:42-48); the enter point is the first vector of the
     // top layer.  This library's own reader keeps the vectors of such a file and skips the graph, like any reference file.
+    // The level of every vector of a MarshalReference stream: hnsw.go:137 (floor(-log(u) * levelFactor)) on ONE splitmix64 stream seeded
+    // by the count.  Both twins use the SAME arithmetic, step for step -- the logarithm in double, rounded to float, times the float
+    // factor, floored in double; levelFactor = float(1 / log(48.0)) in double -- because a float logf and a rounded double log can
+    // differ by one ulp, and a product that straddles an integer would then give the Go twin (integration/go/common/ann/
+    // bruteforce_hip.go: float32(math.Log(float64(u)))) and this one different levels, hence different blobs.
+    // tests/test_items_blob_cpu.py compares the stream with a numpy restatement for a million draws.
+    static float ReferenceLevelFactor() { return (float)(1.0 / std::log(48.0)); }
+    static std::vector<int> ReferenceLevels(int64_t n, int *top_out = nullptr) {
+        const float levelFactor = ReferenceLevelFactor();
+        std::vector<int> level((size_t)std::max<int64_t>(n, 0), 0);
+        uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        int top = 0;
+        for (int64_t i = 0; i < n; i++) {
+            st += 0x9E3779B97F4A7C15ull;
+            uint64_t z = st;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            const float u = ((float)(z >> 40) + 1.0f) / 16777216.0f;  // (0, 1]
+            const float lg = (float)std::log((double)u);
+            const float prod = -lg * levelFactor;  // one float multiplication, as the Go twin's
+            level[(size_t)i] = (int)std::floor((double)prod);
+            top = std::max(top, level[(size_t)i]);
+        }
+        if (top_out) *top_out = top;
+        return level;
+    }
     std::string MarshalReference() {
         constexpr int kM = 48, kM0 = 96, kEfConstruction = 100;
-        const float levelFactor = 1.0f / std::log(48.0f);
+        const float levelFactor = ReferenceLevelFactor();
         const int64_t n = (int64_t)items_.size();
         const int d = dimension_;
         std::string w;
@@ -923,19 +950,8 @@ public:
         put<int64_t>(w, n);
         for (int64_t i = 0; i < n; i++) put_gob(w, gob::encode_f32_slice(Row((size_t)i), (size_t)d));
         // levels: one splitmix64 stream seeded by the count (the reference's rand.Float32 stream cannot be reproduced: SURVEY 8c)
-        std::vector<int> level((size_t)n, 0);
-        uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
         int top = 0;
-        for (int64_t i = 0; i < n; i++) {
-            st += 0x9E3779B97F4A7C15ull;
-            uint64_t z = st;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-            z ^= z >> 31;
-            const float u = ((float)(z >> 40) + 1.0f) / 16777216.0f;  // (0, 1]
-            level[(size_t)i] = (int)std::floor(-std::log(u) * levelFactor);
-            top = std::max(top, level[(size_t)i]);
-        }
+        const std::vector<int> level = ReferenceLevels(n, &top);
         if (!searcher_) searcher_ = std::make_shared<vectors::HipSearcher>();
         // The neighbour queues of one layer: members (ascending ids; empty = every vector), at most cap neighbours each.
         // A queue = the vector's nearest cap - cap / 8 other members (exact) + up to cap / 8 REVERSE links: members that list this

@@ -237,6 +237,20 @@ int32_t gorse_mf_device_ptrs(gorse_mf *h, float **P /*out: device*/, float **Q /
  * launch of the dominant kernels with hipEvents on the stream they run on and accumulates
  * (count, milliseconds) per kernel class; bench.py reads these for the roofline line. */
 int32_t gorse_mf_synchronize(gorse_mf *h);
+/* Epoch pacing for a Fit loop that ENQUEUES its epochs between two evaluations (gorse_bpr_epoch_enqueue).  Replaces two things the
+ * reference's loop has for free (model/cf/model.go:446-503): it checks ctx per sample (:449), and it logs the epoch's duration as
+ * fit_time (:496-503).
+ *   gorse_mf_epoch_throttle: returns once at most max_in_flight of the epochs issued so far are unfinished on the device (0 = all
+ *     done), looking at *cancel (host, may be NULL) every ~20 us while it waits: GORSE_ERR_CANCELLED as soon as the flag is set (the
+ *     caller then drains with gorse_mf_synchronize, at most max_in_flight + 1 epochs).  A Fit that calls it with 2 in front of every
+ *     enqueued epoch still has the next epoch's preparation running under the current update kernel, and sees a cancel within
+ *     two epochs instead of within Verbose.
+ *   gorse_mf_epoch_times: the DEVICE time of the BPR epochs that have finished since the last reset -- per epoch from the moment the
+ *     update stream reaches it (= the end of the previous epoch's last update kernel when epochs follow each other) to the end of its
+ *     own last update kernel: hipEvents on the handle's stream, no host clock -- and how many epochs are still in flight. */
+int32_t gorse_mf_epoch_throttle(gorse_mf *h, int32_t max_in_flight, const volatile int32_t *cancel /*host or NULL*/);
+int32_t gorse_mf_epoch_times(gorse_mf *h, int64_t *epochs /*out*/, double *total_ms /*out*/, int64_t *in_flight /*out, may be NULL*/,
+                             int32_t reset);
 int32_t gorse_mf_set_profiling(gorse_mf *h, int32_t on);
 #define GORSE_PROF_BPR_UPDATE 0
 #define GORSE_PROF_BPR_SAMPLE 1 /* the sampler kernels (user draws; item draws by run) */

@@ -53,6 +53,12 @@ int32_t gorse_hip_test_topk_last_symmetric(gorse_topk *h, int32_t *sym /*out*/);
 /* counters of the last symmetric search: [0] queries the pilot left without a threshold (they take the tie path's sweep), [1] warm
  * starts the rescoring could not verify over both lists, [2] foreign lists that overflowed, [3] hits beyond a wave's staging area */
 int32_t gorse_hip_test_topk_sym_stats(gorse_topk *h, uint64_t *out4 /*host*/);
+/* the per-query flags of the last MFMA search's last chunk (the first n queries) as the host read them behind the rescoring: non-zero =
+ * the query left sweep + rescoring undecided and went on to the tie path (ties among its k + 1 best exact distances, a warm start
+ * that could not be verified, no pilot threshold, an overflowing list) */
+int32_t gorse_hip_test_topk_get_flags(gorse_topk *h, uint8_t *flags /*host*/, int64_t n);
+/* after a symmetric sweep: the entries other workgroups appended to each query's foreign list (more than 512 = the list overflowed) */
+int32_t gorse_hip_test_topk_get_foreign_counts(gorse_topk *h, int32_t *counts /*host*/, int64_t n);
 /* variant bit 24: the search stops behind the pilot sweep (results undefined); this returns the pilot's flags and list lengths */
 int32_t gorse_hip_test_topk_get_pilot_state(gorse_topk *h, uint8_t *flags /*host*/, int32_t *counts /*host*/, int64_t n);
 /* the warm-start thresholds of the last search's last chunk (the first n queries) */
@@ -135,9 +141,6 @@ void gorse_hip_test_set_bpr_chunk(int64_t samples);
  * positive item likewise, bit 2 = the store adds to a row re-read in the same iteration instead of the gathered snapshot;
  * < 0 = the library's default.  Which items are cold is fixed at gorse_mf_create (gorse_hip_test_set_bpr_cold_window). */
 void gorse_hip_test_set_bpr_store_mode(int32_t store_mode);
-/* `make probe-lib` builds only (a measured dead end, csrc/bpr.hip SEG): n = 2..8 segments per user run of the user-run schedule at
- * nFactors <= 32; 0 / 1 = the plain form.  The shipped library ignores it. */
-void gorse_hip_test_set_bpr_user_segments(int32_t segments);
 /* `make probe-lib` builds only (a measured dead end, csrc/bpr.hip SEG): n = 2..8 segments per user run of the user-run schedule at
  * nFactors <= 32; 0 / 1 = the plain form.  The shipped library ignores it. */
 void gorse_hip_test_set_bpr_user_segments(int32_t segments);

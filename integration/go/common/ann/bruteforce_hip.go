@@ -240,7 +240,10 @@ func (b *BruteforceHIP) MarshalReference(w io.Writer) error {
 		}
 	}
 	// levels: ONE splitmix64 stream seeded by the count -- the very stream of the C++ twin (gorse_vectors.hpp MarshalReference), so that
-	// both write the same blob for the same model, and the same model always yields the same blob (math/rand's global stream would not)
+	// both write the same blob for the same model, and the same model always yields the same blob (math/rand's global stream would not).
+	// The arithmetic is the twin's, step for step (ReferenceLevels): log in float64, rounded to float32, ONE float32 multiplication by
+	// levelFactor = float32(1 / math.Log(48)), floor in float64 -- a float32 logf on one side would differ by an ulp now and then, and a
+	// product that straddles an integer would change a level and with it the blob (tests/test_items_blob_cpu.py pins the stream).
 	level, top := make([]int, n), 0
 	st := uint64(0x9E3779B97F4A7C15) ^ uint64(n)
 	for i := range level {

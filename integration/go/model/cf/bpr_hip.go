@@ -50,8 +50,13 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 		zap.Float32(fmt.Sprintf("Recall@%v", config.TopK), score[2]))
 	_, span := monitor.Start(ctx, "BPR.Fit", bpr.nEpochs)
 	defer span.End()
+	// enqueueDepth: epochs kept in flight between two evaluations (one running, one whose preparation runs under it).  The reference
+	// checks ctx per sample (model.go:449); gorse_mf_epoch_throttle waits with the cancel flag in hand, so a cancelled context ends
+	// the Fit within two epochs instead of at the next evaluation.  (host/gorse_cf.hpp kEnqueueDepth: the C++ twin, tested there.)
+	const enqueueDepth = 2
+	C.gorse_mf_epoch_times(hm.h, nil, nil, nil, 1) // a lent handle's earlier epochs do not count
+	fitStart, fitEpochs := time.Now(), 0
 	for epoch := 1; epoch <= bpr.nEpochs; epoch++ {
-		fitStart := time.Now()
 		// Between two evaluations the epochs are only ENQUEUED (gorse_bpr_epoch_enqueue): the sampler and the counting sort
 		// of epoch e + 1 then run under the update kernel of epoch e (what bench.py times).  The epoch in front of an
 		// evaluation -- and every epoch of the sequential schedule, which cannot be enqueued -- goes through the
@@ -59,12 +64,17 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 		evalNext := epoch%config.Verbose == 0 || epoch == bpr.nEpochs
 		var rc C.int32_t
 		if !evalNext && mode != C.GORSE_BPR_SEQUENTIAL && ctx.Err() == nil {
-			rc = C.gorse_bpr_epoch_enqueue(hm.h, C.int64_t(trainSet.CountFeedback()), C.float(bpr.lr), C.float(bpr.reg),
-				C.uint64_t(seed), C.uint64_t(epoch), 0, mode)
+			if rc = C.gorse_mf_epoch_throttle(hm.h, enqueueDepth, hm.cancel); rc == 0 {
+				rc = C.gorse_bpr_epoch_enqueue(hm.h, C.int64_t(trainSet.CountFeedback()), C.float(bpr.lr), C.float(bpr.reg),
+					C.uint64_t(seed), C.uint64_t(epoch), 0, mode)
+			} else if rc == C.GORSE_ERR_CANCELLED {
+				C.gorse_mf_synchronize(hm.h) // drain the (at most enqueueDepth) epochs in flight before the factors are pulled
+			}
 		} else {
 			rc = C.gorse_bpr_epoch(hm.h, C.int64_t(trainSet.CountFeedback()), C.float(bpr.lr), C.float(bpr.reg),
 				C.uint64_t(seed), C.uint64_t(epoch), 0, mode, hm.cancel, nil)
 		}
+		fitEpochs++
 		if rc == C.GORSE_ERR_CANCELLED {
 			log.Logger().Info("fit bpr canceled", zap.Int("epoch", epoch), zap.Error(ctx.Err()))
 			hm.pull()
@@ -73,8 +83,16 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 			log.Logger().Error("fit bpr", zap.Error(hipError("gorse_bpr_epoch", rc)))
 			return Score{}
 		}
-		fitTime := time.Since(fitStart)
 		if epoch%config.Verbose == 0 || epoch == bpr.nEpochs {
+			// fit_time (model.go:496-503, what dashboards read): the mean DEVICE time of the epochs since the last evaluation
+			// (hipEvents on the handle's update stream, gorse_mf_epoch_times) -- the host's clock around an enqueue measures the
+			// enqueue.  Falls back to the host's mean over the period when the library timed another number of epochs.
+			fitTime := time.Since(fitStart) / time.Duration(fitEpochs)
+			var timed C.int64_t
+			var devMs C.double
+			if C.gorse_mf_epoch_times(hm.h, &timed, &devMs, nil, 1) == 0 && int(timed) == fitEpochs {
+				fitTime = time.Duration(float64(devMs) / float64(timed) * float64(time.Millisecond))
+			}
 			evalStart = time.Now()
 			score = hm.evaluateResident(valSet, trainSet, config.TopK, config.Candidates, evalSeed, NDCG, Precision, Recall)
 			scores = append(scores, lo.Tuple2[int, float32]{A: epoch, B: score[0]})
@@ -89,6 +107,7 @@ func (bpr *BPR) Fit(ctx context.Context, trainSet, valSet dataset.CFSplit, confi
 					zap.Int("best_epoch", best.A), zap.Float32("best_NDCG", best.B), zap.Int("patience", config.Patience))
 				break
 			}
+			fitStart, fitEpochs = time.Now(), 0
 		}
 		span.Add(1)
 	}

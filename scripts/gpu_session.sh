@@ -63,7 +63,7 @@ for STAGE in "$@"; do
             DB=$(find "$OUT/pmc_${TAG}_${W}_$CNT" -name '*_results.db' | head -1)
             python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmc_${W}_$CNT.txt" 2>&1
         done
-        python "$ROOT/scripts/pmc_traffic.py" "$C" "$B" "$(find "$OUT/pmc_${TAG}_${W}_FETCH_SIZE" -name '*_results.db' | head -1)" \
+        GORSE_PMC_SESSION="${PMC_SESSION:-$TAG}" python "$ROOT/scripts/pmc_traffic.py" "$C" "$B" "$(find "$OUT/pmc_${TAG}_${W}_FETCH_SIZE" -name '*_results.db' | head -1)" \
             "$(find "$OUT/pmc_${TAG}_${W}_WRITE_SIZE" -name '*_results.db' | head -1)" "$OUT/${TAG}_traffic.json" ${D:-narrow}
         rm -rf "$OUT"/pmc_${TAG}_${W}_* ;;
     sq)

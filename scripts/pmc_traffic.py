@@ -12,6 +12,7 @@ usage: pmc_traffic.py <workload> <kernel substring> <fetch_results.db> <write_re
   wide   = the kernel streams with 16-byte-per-lane loads: FETCH_SIZE x 2 (the guide's gfx950 correction), raw value kept
   narrow = dword gathers / fp32 atomics (default): the guide lists that width as uncalibrated, the raw value is reported"""
 import json
+import os
 import sqlite3
 import sys
 
@@ -50,6 +51,7 @@ def main():
     fetch = None if f is None else f * 1024.0 * (2.0 if wide else 1.0)
     rec[workload] = {
         "kernel": ksub,
+        "session": os.environ.get("GORSE_PMC_SESSION", ""),  # bench.py reports a record only if this names the current round
         "fetch_bytes_per_launch": fetch,
         "fetch_bytes_raw": None if f is None else f * 1024.0,
         "write_bytes_per_launch": None if w is None else w * 1024.0,

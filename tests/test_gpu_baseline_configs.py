@@ -9,8 +9,12 @@
       of one sequential oracle epoch over the same set (a committed fixture: 100M sequential steps).
   C5  S-als 500,000 x 100,000 x 50M, nFactors 64: one user half-sweep on the device, 2048 rows spread over the row-length
       range (incl. the longest) <= 1e-4 against orc_als_half_range.
-  C4  S-emb 1,000,000 x 128 bf16, cosine, k = 100: 96 query rows through the scan (path A) and 128 rows of a 1024-query call
-      through the MFMA path (the kernel bench.py times) equal Bruteforce.SearchIndex restated (oracle) in indices AND distance bits.
+      (user half-sweep; round 6: the ITEM half-sweep too -- the long rows' chunk plan and partial reduce at full size).
+  C4  S-emb 1,000,000 x 128 bf16, cosine, k = 100: 96 query rows through the scan (path A), 128 rows of a 1024-query call through the
+      SQUARE MFMA sweep, 128 rows of a tile-aligned 1024-query call through the SYMMETRIC sweep, and (round 6) THE PASS bench.py
+      times -- all_pairs over all 1,000,000 query rows, symmetric form -- with >= 256 rows (first / last query block, tie-replayed rows,
+      rows without a pilot threshold, rows whose foreign list overflowed) equal to Bruteforce.SearchIndex restated (oracle) in
+      indices AND distance bits.
 
 The element-wise relative error |got - ref| / |ref| is printed next to the bar each ALS comparison uses (`rel_to_scale`:
 error over the largest reference magnitude, the form "1e-4 relative fp32" takes for a matrix whose small elements are
@@ -209,11 +213,12 @@ def test_c4_rows_against_the_oracle(oracle):
     _check_c4_rows(oracle, Xe, idx, dist, q0, range(q1 - q0), k)
 
 
-def test_c4_mfma_path_rows_against_the_oracle(oracle):
-    """The kernel bench.py times at C4: a call of 1024 queries against the 1M x 128 bf16 index takes the MFMA path (pilot + main
-    sweep, exact rescoring, tie replay: csrc/topk_mfma.hip) -- asserted through the handle's profile, which must show sweep
-    launches -- and 128 of its rows (every eighth) equal Bruteforce.SearchIndex restated (common/ann/bruteforce.go:39-83) in indices
-    AND distance bits."""
+def test_c4_square_sweep_rows_against_the_oracle(oracle):
+    """The SQUARE form of the MFMA sweep at C4's size: a call of 1024 queries that does NOT start on a 128-row boundary (500,000 mod
+    128 = 32) takes the square sweep (pilot + main sweep, exact rescoring, tie replay: csrc/topk_mfma.hip) -- asserted through the
+    handle's profile, which must show sweep launches, and `last_symmetric()`, which must be false -- and 128 of its rows (every eighth)
+    equal Bruteforce.SearchIndex restated (common/ann/bruteforce.go:39-83) in indices AND distance bits.  (Until round 5 this was "the
+    kernel bench.py times at C4"; since the symmetric form exists, that one is test_c4_full_symmetric_pass_rows_against_the_oracle.)"""
     Xb, Xe = synth.s_emb(1_000_000, 128, 44)
     k = 100
     t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
@@ -224,7 +229,103 @@ def test_c4_mfma_path_rows_against_the_oracle(oracle):
     scans, _ = t.get_profile(capi.PROF_TOPK_SCORE)
     n_fb, n_tie = t.last_stats()
     t.set_profiling(False)
-    print("C4, 1024 queries: %d sweep launches (%.1f ms), %d scan launches, %d queries through the tie replay, %d fell back to the scan"
-          % (launches, sweep_ms, scans, n_tie, n_fb))
+    print("C4, 1024 queries from row 500,000: %d sweep launches (%.1f ms), %d scan launches, %d queries through the tie replay, %d fell "
+          "back to the scan" % (launches, sweep_ms, scans, n_tie, n_fb))
     assert launches >= 1 and n_fb == 0  # the MFMA sweep answered every query
+    assert not t.last_symmetric()
     _check_c4_rows(oracle, Xe, idx, dist, q0, range(0, q1 - q0, 8), k)
+
+
+def test_c4_symmetric_sweep_of_a_tile_aligned_range_against_the_oracle(oracle):
+    """The same 1024-query call started on a 128-row boundary (499,968) takes the SYMMETRIC sweep: 128 rows against the oracle."""
+    Xb, Xe = synth.s_emb(1_000_000, 128, 44)
+    k = 100
+    t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
+    q0 = 500_000 // 128 * 128
+    q1 = q0 + 1024
+    idx, dist = t.all_pairs(k, q0, q1)
+    n_fb, n_tie = t.last_stats()
+    assert t.last_symmetric() and n_fb == 0
+    _check_c4_rows(oracle, Xe, idx, dist, q0, range(0, q1 - q0, 8), k)
+
+
+def test_c4_full_symmetric_pass_rows_against_the_oracle(oracle):
+    """THE pass bench.py times at C4 (its `topk` object): all_pairs(k = 100, 0, 1,000,000) over S-emb 1M x 128 bf16, cosine -- one chunk of
+    a million queries through the symmetric sweep (topk_sweep_kernel<8, 2, EP_COARSE, false, 4, false, SYM = true>), the rescoring over own +
+    foreign lists, the tie path -- with the results fetched.  Asserted: the symmetric form ran, no query fell back to the scan, and
+    >= 256 rows equal Bruteforce.SearchIndex restated (common/ann/bruteforce.go:39-83) in indices AND distance bits.  The sample is drawn
+    from what the pass itself reports: rows of the FIRST query block (every neighbour they have in a later block reached them through a
+    foreign list) and of the LAST one (no foreign list at all), rows the tie path answered, rows the pilot left without a threshold, rows
+    whose foreign list overflowed, and rows spread over the whole range."""
+    N, k = 1_000_000, 100
+    Xb, Xe = synth.s_emb(N, 128, 44)
+    t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16)
+    t0 = time.perf_counter()
+    idx, dist = t.all_pairs(k, 0, N)
+    t_pass = time.perf_counter() - t0
+    n_fb, n_tie = t.last_stats()
+    stats = t.sym_stats()
+    assert t.last_symmetric()
+    assert n_fb == 0  # scan_fallback == 0
+    flags = t.last_flags(N)            # non-zero: the query went on to the tie path
+    thr = t.warm_thresholds(N)         # +inf: the pilot left the query without a threshold (sym_thresholds_kernel)
+    fcnt = t.foreign_counts(N)         # > 512: the foreign list overflowed
+    tie_rows = np.flatnonzero(flags)
+    unset_rows = np.flatnonzero(np.isposinf(thr))
+    over_rows = np.flatnonzero(fcnt > 512)
+    print("C4 full symmetric pass (first call, incl. allocations + the fetch of 800 MB): %.2f s; %d queries through the tie path (%d replayed), "
+          "%d without a pilot threshold (sym_stats %d), %d foreign lists overflowed (sym_stats %d), %d hits beyond a staging area; "
+          "foreign list length mean %.1f max %d" % (t_pass, tie_rows.size, n_tie, unset_rows.size, stats[0], over_rows.size, stats[2],
+                                                     stats[3], float(fcnt.mean()), int(fcnt.max())))
+    assert tie_rows.size == n_tie  # every flagged query was answered by the replay (none left for the scan)
+    # (the rescoring counts an overflowed foreign list only for a query nothing else had flagged before: <=)
+    assert unset_rows.size == stats[0] and stats[2] <= over_rows.size
+    assert (flags[unset_rows] != 0).all() and (flags[over_rows] != 0).all()  # both kinds take the tie path
+    # neighbours in a LATER block exist for the rows of the first block (their answers came through foreign lists)
+    first = np.arange(0, 512, 16)
+    assert (idx[first] >= 512).any(axis=1).all() and (fcnt[first] > 0).all()
+    assert (fcnt[N - 64:] == 0).all()  # nobody sweeps behind the last query block's last tile
+    rng = np.random.default_rng(7)
+    pick = lambda rows, n: rows if rows.size <= n else rng.choice(rows, n, replace=False)
+    sample = np.unique(np.concatenate([
+        first, np.arange(N - 512, N, 16),                      # first and last query block
+        pick(tie_rows, 64), pick(unset_rows, 32), pick(over_rows, 48),
+        np.arange(1000, N, N // 96)]))                         # spread over the range
+    assert sample.size >= 256
+    _check_c4_rows(oracle, Xe, idx, dist, 0, sample.tolist(), k)
+    print("C4 full symmetric pass: %d rows equal the oracle in indices and distance bits (%d of them answered by the tie path, %d without "
+          "a pilot threshold, %d with an overflowed foreign list)" % (sample.size, int(np.isin(sample, tie_rows).sum()),
+                                                                      int(np.isin(sample, unset_rows).sum()), int(np.isin(sample, over_rows).sum())))
+
+
+def test_c5_als_item_half_sweep_rows(oracle):
+    """C5's ITEM half-sweep at full size (model/cf/model.go:693-738): the side with the 100K+-entry rows, i.e. the chunk plan
+    (als_chunk_kernel over 4096-entry chunks), als_partial_reduce_kernel and als_long_solve_kernel at the size bench.py runs them.
+    2048 item rows spread over the row-length range incl. the eight longest against orc_als_half_range on the same inputs."""
+    U, I, d, w, reg = 500_000, 100_000, 64, 0.001, 0.06
+    uptr, uidx, iptr, iidx = synth.s_als(U, I, 50_000_000, 45)
+    P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.1, seed=1)
+    mf = capi.MF(U, I, d, uptr, uidx, iptr, iidx)
+    mf.set_factors(P0, Q0)
+    mf.als_half_epoch(1, w, reg)  # every item row against P0
+    gP, gQ = mf.get_factors()
+    assert np.array_equal(gP.view(np.uint32), P0.view(np.uint32))
+    assert np.isfinite(gQ).all()
+    lens = np.diff(iptr)
+    by_len = np.argsort(lens, kind="stable")
+    rows = np.unique(np.concatenate([by_len[np.linspace(0, I - 1, 2040).astype(np.int64)], by_len[-8:]]))
+    A = np.ascontiguousarray(Q0[rows])  # the sampled rows as one compact problem: one Gram pass of the oracle for all of them
+    sub_ptr = np.zeros(rows.size + 1, np.int64)
+    np.cumsum(lens[rows], out=sub_ptr[1:])
+    sub_idx = np.concatenate([iidx[iptr[r]:iptr[r + 1]] for r in rows])
+    # the oracle's half-sweep solves rows of its first argument against the second with the CSR given: items against P0
+    oracle.als_half_range(A, P0, sub_ptr, sub_idx, uptr, w, reg, 0, rows.size)
+    worst_scale = max(rel_to_scale(gQ[r:r + 1], A[t:t + 1]) for t, r in enumerate(rows))
+    worst_elem = elementwise_rel(gQ[rows], A)
+    n_long = int((lens[rows] > 4096).sum())
+    print("C5 item half-sweep, %d rows (lengths %d..%d, %d of them cut into chunks): max error / largest |ref| of the row %.2e; "
+          "element-wise relative %.2e" % (rows.size, lens[rows].min(), lens[rows].max(), n_long, worst_scale, worst_elem))
+    assert n_long >= 8 and lens[rows].max() > 100_000  # the chunk plan + partial reduce are on the path
+    assert worst_scale < 1e-4
+    bound = 1e-4 * np.abs(A.astype(np.float64)) + 5e-5 * np.abs(A).max(axis=1, keepdims=True)
+    assert (np.abs(gQ[rows].astype(np.float64) - A) <= bound).all()

@@ -996,3 +996,42 @@ def test_sample_user_negatives_matches_oracle(oracle, U, I, n):
     assert np.array_equal(rlen, l2) and np.array_equal(rank, r2)
     er, el = oracle.mf_rank(P, Q, exp_users, cptr, cand, 10)
     assert np.array_equal(rlen, el) and np.array_equal(rank, er)
+
+
+def test_epoch_throttle_and_device_epoch_times():
+    """gorse_mf_epoch_throttle / gorse_mf_epoch_times (include/gorse_hip.h): a loop that enqueues epochs behind throttle(2) never has
+    more than three in flight, the device times of the finished epochs add up to about the update kernels' own, and a raised
+    cancel flag ends the wait with GORSE_ERR_CANCELLED."""
+    data = synth.s_ml1m()
+    d = 32
+    P, Q = synth.init_factors(data.U, data.I, d, 0.0, 0.01, 1)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P, Q)
+    mf.bpr_epoch(data.n_train, 0.05, 0.01, 3, 1)  # buffers, code objects
+    mf.epoch_times(reset=True)
+    mf.set_profiling(True)
+    mf.reset_profile()
+    worst = 0
+    for ep in range(2, 14):
+        mf.epoch_throttle(2)
+        worst = max(worst, mf.epoch_times()[2])
+        mf.bpr_epoch_enqueue(data.n_train, 0.05, 0.01, 3, ep)
+    assert worst <= 2
+    mf.epoch_throttle(0)
+    n, ms, flying = mf.epoch_times()
+    launches, upd_ms = mf.get_profile(capi.PROF_BPR_UPDATE)
+    mf.set_profiling(False)
+    print("12 enqueued epochs: device time %.3f ms per epoch (update kernels alone %.3f ms)" % (ms / n, upd_ms / launches))
+    assert n == 12 and flying == 0
+    assert upd_ms / launches * 0.95 <= ms / n <= upd_ms / launches * 2.0 + 0.2
+    # a cancelled wait
+    cancel = np.ones(1, np.int32)
+    for ep in range(14, 20):
+        mf.bpr_epoch_enqueue(data.n_train, 0.05, 0.01, 3, ep)
+    with pytest.raises(capi.GorseHipError) as e:
+        mf.epoch_throttle(0, cancel=cancel)
+    assert e.value.code == capi.ERR_CANCELLED
+    mf.synchronize()
+    mf.epoch_throttle(0, cancel=cancel)  # nothing in flight: nothing to cancel
+    gP, gQ = mf.get_factors()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()

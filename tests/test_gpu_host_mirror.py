@@ -189,3 +189,50 @@ def test_bruteforce_index_like_ann_tests(oracle):
     for q in (0, 17, 299):
         ei, ed = oracle.search_index(X, orc.METRIC_EUCLIDEAN, q, 10)
         assert b.SearchIndex(q, 10, False) == [(int(a), float(c)) for a, c in zip(ei, ed)]
+
+
+def test_cancel_during_enqueued_epochs_is_seen_within_two_epochs():
+    """BPR.Fit with Verbose larger than the epoch count only ENQUEUES its epochs; the reference checks ctx per sample
+    (model/cf/model.go:449).  The twin keeps at most two epochs in flight (gorse_mf_epoch_throttle, kEnqueueDepth) and looks at
+    the cancel flag while it waits: a flag raised in the middle of 4000 epochs ends the Fit within milliseconds, with Score{}."""
+    import threading
+    import time
+    data = synth.s_ml1m()
+    train, test = cf.datasets_from_synth(data)
+    n_epochs = 4000  # ~0.3 ms each on the device: 1.2 s if nobody cancels
+    m = cf.NewBPR({"NFactors": 16, "NEpochs": n_epochs, "Lr": 0.05})
+    cfg = cf.NewFitConfig().SetJobs(4).SetVerbose(100000)
+    cfg.cancel = np.zeros(1, np.int32)
+    out = {}
+
+    def run():
+        out["score"] = m.Fit(train, test, cfg)
+        out["t_end"] = time.perf_counter()
+    th = threading.Thread(target=run)
+    t0 = time.perf_counter()
+    th.start()
+    time.sleep(0.35)  # setup (~25 ms) + the first evaluation + a few hundred epochs
+    t_cancel = time.perf_counter()
+    cfg.cancel[0] = 1
+    th.join()
+    s = out["score"]
+    print("cancel raised %.0f ms into the Fit; Fit returned %.1f ms later with %d of %d epochs done"
+          % ((t_cancel - t0) * 1e3, (out["t_end"] - t_cancel) * 1e3, m.epochs_done, n_epochs))
+    assert (s.NDCG, s.Precision, s.Recall) == (0.0, 0.0, 0.0) and "canceled" in m.log
+    assert 0 < m.epochs_done < n_epochs
+    assert out["t_end"] - t_cancel < 0.25  # two epochs in flight + the pull of the factors, not the remaining thousands
+
+
+def test_fit_time_is_the_epochs_device_time():
+    """fit_time of the twin's log (model.go:496-503) = the mean DEVICE time of the epochs since the last evaluation
+    (gorse_mf_epoch_times), not the time the host took to enqueue them: it agrees with the update kernels' own profile."""
+    import re
+    data = synth.s_ml1m()
+    train, test = cf.datasets_from_synth(data)
+    m = cf.NewBPR({"NFactors": 16, "NEpochs": 20, "Lr": 0.05})
+    m.Fit(train, test, cf.NewFitConfig().SetJobs(4).SetVerbose(10))
+    m = cf.NewBPR({"NFactors": 16, "NEpochs": 20, "Lr": 0.05})
+    m.Fit(train, test, cf.NewFitConfig().SetJobs(4).SetVerbose(10))
+    fit_ms = [float(x) for x in re.findall(r"fit_time=([0-9.]+)ms", m.log)]
+    print("fit_time per epoch of the two evaluation periods: %s ms" % fit_ms)
+    assert len(fit_ms) == 2 and all(0.1 < x < 2.0 for x in fit_ms)  # ~0.3 ms on an idle MI355X; an enqueue takes ~0.05

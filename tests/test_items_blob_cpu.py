@@ -269,3 +269,36 @@ def test_marshal_reference_writes_a_graph_the_reference_can_walk(oracle):
     # nothing stored: an empty graph the reference reads as well
     e = V.MatrixFactorizationItems(searcher=cpu_searcher(oracle))
     assert reference_reader_outcome(e.MarshalReference()) == "ok"
+
+
+def test_reference_levels_follow_the_arithmetic_the_go_twin_writes():
+    """The level stream of MarshalReference (hnsw.go:137 on a splitmix64 stream): the C++ twin's draws equal a numpy restatement of the
+    Go twin's expression -- int(math.Floor(float64(-float32(math.Log(float64(u))) * levelFactor))), levelFactor = float32(1 /
+    math.Log(48)) -- for a million vectors, including the draws whose product lies within a few ulps of an integer (where a float
+    logf on one side would flip a level)."""
+    import ctypes as C
+
+    from gorse_amd import cf
+    H = cf.host()
+    H.gh_test_hnsw_levels.restype = C.c_uint32
+    H.gh_test_hnsw_levels.argtypes = [C.c_int64, C.c_void_p]
+    for n in (1, 1000, 1_000_000):
+        got = np.empty(n, np.int32)
+        bits = H.gh_test_hnsw_levels(n, got.ctypes.data)
+        factor = np.float32(1.0 / np.log(np.float64(48.0)))
+        assert bits == int(factor.view(np.uint32))
+        M = (1 << 64) - 1
+        st = (0x9E3779B97F4A7C15 ^ n) & M
+        z = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(st))  # wraps modulo 2^64
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        u = ((z >> np.uint64(40)).astype(np.float32) + np.float32(1.0)) / np.float32(16777216.0)
+        lg = np.log(u.astype(np.float64)).astype(np.float32)
+        want = np.floor((-lg * factor).astype(np.float64)).astype(np.int32)
+        assert np.array_equal(got, want)
+        if n == 1_000_000:
+            prod = (-lg * factor).astype(np.float64)
+            near = np.abs(prod - np.round(prod)) < 1e-5  # the draws a one-ulp difference of the logarithm could flip
+            print("levels of %d vectors: top %d, %d draws within 1e-5 of an integer" % (n, got.max(), int(near.sum())))
+            assert got.max() >= 3 and (got == 0).mean() > 0.97
