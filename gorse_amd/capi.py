@@ -104,6 +104,15 @@ SIGNATURES = {
     "gorse_hip_test_set_topk_path": (None, [C.c_int32]),
     "gorse_hip_test_set_topk_variant": (None, [C.c_int32]),
     "gorse_hip_test_get_sweep_profile": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
+    "gorse_topk_tri_begin": (C.c_int32, [_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "gorse_topk_tri_slice": (C.c_int32, [_vp, C.c_int32, _i64p, _i64p, _i64p]),
+    "gorse_topk_tri_thresholds_get": (C.c_int32, [_vp, C.c_int64, C.c_int64, _vp]),
+    "gorse_topk_tri_thresholds_put": (C.c_int32, [_vp, C.c_int64, C.c_int64, _vp]),
+    "gorse_topk_tri_sweep": (C.c_int32, [_vp]),
+    "gorse_topk_tri_pack": (C.c_int32, [_vp, C.c_int32, _i64p, _i64p]),
+    "gorse_topk_tri_pack_read": (C.c_int32, [_vp, _vp, _vp]),
+    "gorse_topk_tri_unpack": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int64, _vp, C.c_int64]),
+    "gorse_topk_tri_finish": (C.c_int32, [_vp, _i32p, _f32p]),
     "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
     "gorse_hip_test_topk_last_symmetric": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
     "gorse_hip_test_topk_sym_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
@@ -408,6 +417,52 @@ class TopK:
         check(lib().gorse_topk_all_pairs(self.h, q_begin, q_end, k, _p(idx, _i32p), _p(dist, _f32p)))
         return idx, dist
 
+    # ---- the triangle-sharded all-pairs search (include/gorse_hip.h, gorse_topk_tri_*): host-memory forms of the messages ----
+    def tri_begin(self, k, rank, world, q_begin=0, q_end=None):
+        q_end = self.N if q_end is None else q_end
+        self._tri = (k, q_end - q_begin)
+        check(lib().gorse_topk_tri_begin(self.h, q_begin, q_end, k, rank, world))
+
+    def tri_slice(self, rank):
+        """(lo, hi, owned): the queries whose pilots `rank` runs, and how many queries it owns"""
+        lo, hi, ow = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().gorse_topk_tri_slice(self.h, rank, C.byref(lo), C.byref(hi), C.byref(ow)))
+        return lo.value, hi.value, ow.value
+
+    def tri_thresholds_get(self, lo, hi):
+        out = np.empty(hi - lo, np.float32)
+        check(lib().gorse_topk_tri_thresholds_get(self.h, lo, hi, out.ctypes.data_as(_vp)))
+        return out
+
+    def tri_thresholds_put(self, lo, hi, thr):
+        thr = _arr(thr, np.float32)
+        assert thr.size == hi - lo
+        check(lib().gorse_topk_tri_thresholds_put(self.h, lo, hi, thr.ctypes.data_as(_vp)))
+
+    def tri_sweep(self):
+        check(lib().gorse_topk_tri_sweep(self.h))
+
+    def tri_pack(self, dest):
+        """the message for `dest`: (counts int32 per query dest owns, entries uint64 = (key, row) pairs end to end)"""
+        nc, ne = C.c_int64(0), C.c_int64(0)
+        check(lib().gorse_topk_tri_pack(self.h, dest, C.byref(nc), C.byref(ne)))
+        counts, entries = np.empty(nc.value, np.int32), np.empty(ne.value, np.uint64)
+        check(lib().gorse_topk_tri_pack_read(self.h, counts.ctypes.data_as(_vp), entries.ctypes.data_as(_vp)))
+        return counts, entries
+
+    def tri_unpack(self, src, counts, entries):
+        counts, entries = _arr(counts, np.int32), _arr(entries, np.uint64)
+        check(lib().gorse_topk_tri_unpack(self.h, src, counts.ctypes.data_as(_vp), counts.size, entries.ctypes.data_as(_vp), entries.size))
+
+    def tri_finish(self, idx=None, dist=None, fetch=True):
+        """rescoring + tie path of the queries this rank owns; with fetch their rows are written into idx / dist (nq x k, allocated
+        here when not given: the rows of other ranks' queries are then -1 / +inf)"""
+        k, nq = self._tri
+        if fetch and idx is None:
+            idx, dist = np.full((nq, k), -1, np.int32), np.full((nq, k), np.inf, np.float32)
+        check(lib().gorse_topk_tri_finish(self.h, _p(idx, _i32p) if fetch else None, _p(dist, _f32p) if fetch else None))
+        return idx, dist
+
     def set_mask(self, admissible=None):
         m = None if admissible is None else _arr(admissible, np.uint8)
         if m is not None and m.size != self.N:
@@ -566,6 +621,52 @@ class Sparse:
             self.h = None
 
     __del__ = close
+
+    # ---- the triangle-sharded all-pairs search (include/gorse_hip.h, gorse_topk_tri_*): host-memory forms of the messages ----
+    def tri_begin(self, k, rank, world, q_begin=0, q_end=None):
+        q_end = self.N if q_end is None else q_end
+        self._tri = (k, q_end - q_begin)
+        check(lib().gorse_topk_tri_begin(self.h, q_begin, q_end, k, rank, world))
+
+    def tri_slice(self, rank):
+        """(lo, hi, owned): the queries whose pilots `rank` runs, and how many queries it owns"""
+        lo, hi, ow = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().gorse_topk_tri_slice(self.h, rank, C.byref(lo), C.byref(hi), C.byref(ow)))
+        return lo.value, hi.value, ow.value
+
+    def tri_thresholds_get(self, lo, hi):
+        out = np.empty(hi - lo, np.float32)
+        check(lib().gorse_topk_tri_thresholds_get(self.h, lo, hi, out.ctypes.data_as(_vp)))
+        return out
+
+    def tri_thresholds_put(self, lo, hi, thr):
+        thr = _arr(thr, np.float32)
+        assert thr.size == hi - lo
+        check(lib().gorse_topk_tri_thresholds_put(self.h, lo, hi, thr.ctypes.data_as(_vp)))
+
+    def tri_sweep(self):
+        check(lib().gorse_topk_tri_sweep(self.h))
+
+    def tri_pack(self, dest):
+        """the message for `dest`: (counts int32 per query dest owns, entries uint64 = (key, row) pairs end to end)"""
+        nc, ne = C.c_int64(0), C.c_int64(0)
+        check(lib().gorse_topk_tri_pack(self.h, dest, C.byref(nc), C.byref(ne)))
+        counts, entries = np.empty(nc.value, np.int32), np.empty(ne.value, np.uint64)
+        check(lib().gorse_topk_tri_pack_read(self.h, counts.ctypes.data_as(_vp), entries.ctypes.data_as(_vp)))
+        return counts, entries
+
+    def tri_unpack(self, src, counts, entries):
+        counts, entries = _arr(counts, np.int32), _arr(entries, np.uint64)
+        check(lib().gorse_topk_tri_unpack(self.h, src, counts.ctypes.data_as(_vp), counts.size, entries.ctypes.data_as(_vp), entries.size))
+
+    def tri_finish(self, idx=None, dist=None, fetch=True):
+        """rescoring + tie path of the queries this rank owns; with fetch their rows are written into idx / dist (nq x k, allocated
+        here when not given: the rows of other ranks' queries are then -1 / +inf)"""
+        k, nq = self._tri
+        if fetch and idx is None:
+            idx, dist = np.full((nq, k), -1, np.int32), np.full((nq, k), np.inf, np.float32)
+        check(lib().gorse_topk_tri_finish(self.h, _p(idx, _i32p) if fetch else None, _p(dist, _f32p) if fetch else None))
+        return idx, dist
 
     def set_mask(self, admissible=None):
         m = None if admissible is None else _arr(admissible, np.uint8)

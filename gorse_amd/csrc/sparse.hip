@@ -120,7 +120,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     GORSE_TRY(h->out_score.ensure((size_t)nq * k));
     GORSE_TRY(h->out_cnt.ensure((size_t)nq));
     GORSE_TRY(h->stat.ensure(2));
-    GORSE_TRY(h->next.ensure(16));
+    GORSE_TRY(h->next.ensure(sparse::kQueueWords));
     // Work items: a long query as one item per group (+ a merge of the partial rankings), the others as one item each.  Long
     // queries first, everything longest first: the launch ends with the cheap items.  The partial rankings of the long queries
     // are bounded (kPartBytes): a call with more long queries than fit takes several launches.
@@ -220,7 +220,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             GORSE_TRY(h->part_cnt.ensure(n_long * (size_t)ng * 2));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, longs.data() + l0, n_long * 4, hipMemcpyHostToDevice, h->stream));
         }
-        GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, 16 * sizeof(int32_t), h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sparse::kQueueWords * sizeof(int32_t), h->stream));
         if (!heavy_t.empty()) {  // the heavy queries: dense copies, then every stored row against them -- next to the others
             const size_t nh = heavy_t.size();
             GORSE_TRY(h->heavy_t.ensure(nh));

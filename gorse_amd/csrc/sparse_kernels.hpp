@@ -114,7 +114,7 @@ struct TileArgs {
     int64_t n_admissible;     // number of admissible rows (N without a mask)
     const Work *work;
     int32_t n_work;
-    int32_t *next;     // work counter
+    int32_t *next;     // work counters: kQueueStripes of them from word kQueueBase on, kQueueStride words apart (sparse_tile_kernel)
     int k;
     int32_t *out_idx;   // nq x k, padded with -1
     float *out_score;   // nq x k, padded with -inf
@@ -513,6 +513,14 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
     }
 }
 
+#ifndef GORSE_SPARSE_QUEUE_STRIPES
+#define GORSE_SPARSE_QUEUE_STRIPES 32  // A/B: 1 = one counter for every wave (rounds 1-5)
+#endif
+constexpr int kQueueStripes = GORSE_SPARSE_QUEUE_STRIPES;  // a power of two
+constexpr int kQueueStride = 64;   // words between two stripes' counters: 256 bytes
+constexpr int kQueueBase = 64;     // words 0 .. 15 of the buffer: the heavy-query kernel's eight queues (RowsArgs::next = next + 8)
+constexpr int kQueueWords = kQueueBase + kQueueStripes * kQueueStride;
+
 template <int KP, bool ATOMIC, bool TRACE>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
@@ -527,11 +535,20 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     board[lane] = 0;
     for (int i = lane; i < NL; i += kBlock) acc[i] = 0.0f;
     __syncthreads();
+    // The work list is taken through kQueueStripes counters, each on a 256-byte line of its own: stripe s hands out the items
+    // s, s + kQueueStripes, ... (the list is sorted dearest first, so every stripe is too).  A wave starts on its workgroup's
+    // stripe and moves on when a stripe runs dry; a dry stripe stays dry, so kQueueStripes dry ones in a row end the wave.  One
+    // counter for all waves is one memory line serving 88 M returning atomics per second (scripts/probe_atomics4.hip).
+    int qstripe = (int)(blockIdx.x & (kQueueStripes - 1)), qdry = 0;
     for (;;) {
         int w = 0;
-        if (lane == 0) w = atomicAdd(a.next, 1);
-        w = __builtin_amdgcn_readfirstlane(w);
-        if (w >= a.n_work) break;
+        if (lane == 0) w = atomicAdd(a.next + kQueueBase + qstripe * kQueueStride, 1);
+        w = __builtin_amdgcn_readfirstlane(w) * kQueueStripes + qstripe;
+        if (w >= a.n_work) {
+            if (++qdry == kQueueStripes) break;
+            qstripe = (qstripe + 1) & (kQueueStripes - 1);
+            continue;
+        }
         const Work wk = a.work[w];
         if (wk.prio)
             __builtin_amdgcn_s_setprio(3);

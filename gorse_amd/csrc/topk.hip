@@ -415,6 +415,7 @@ extern "C" int32_t gorse_topk_destroy(gorse_topk *h) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
     }
+    topk_mfma_release(h);
     delete h;
     return GORSE_OK;
 }

@@ -5,6 +5,10 @@
 
 #define GORSE_PROF_TOPK_NCLASSES 6
 
+namespace gorse {
+struct TopkChunkState;  // topk_mfma.hip: what the stages of one chunk of an MFMA search share
+}
+
 struct gorse_topk {
     int device = 0;
     int64_t N = 0;
@@ -63,6 +67,14 @@ struct gorse_topk {
     gorse::DevBuf<float> f0raw;
     gorse::DevBuf<unsigned long long> sym_stats;  // counters of the last symmetric search (gorse_hip_test_topk_sym_stats)
     bool last_sym = false;
+    // the state of the search in progress (topk_mfma.hip): its stages run back to back in topk_mfma_search, call by call in the
+    // triangle-sharded search (gorse_topk_tri_*), whose message buffers follow
+    gorse::TopkChunkState *cstate = nullptr;
+    gorse::TopkChunkState *chunk_state();
+    gorse::DevBuf<int32_t> tri_counts, tri_in_counts;
+    gorse::DevBuf<long long> tri_offsets;
+    gorse::DevBuf<uint2> tri_entries, tri_in_entries;
+    int64_t tri_packed_counts = 0, tri_packed_entries = 0;
     std::vector<uint8_t> host_flags;  // the last chunk's per-query flags as the host read them behind the rescoring (non-zero: the
                                       // query left the sweep + rescoring undecided and went on to the tie path; gorse_hip_test_topk_get_flags)
     std::vector<uint8_t> dbg_flags;   // probe (variant bit 24): the pilot's flags and list lengths of the last chunk
@@ -140,6 +152,7 @@ int32_t topk_mfma_prepare(gorse_topk *h);  // at create: operands, scales, error
 int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev,
                          int64_t nq, int k, int prune0, int32_t *idx_out, float *dist_out, int32_t *cnt_out);
 bool topk_mfma_usable(const gorse_topk *h, int64_t nq, int k);
+void topk_mfma_release(gorse_topk *h);  // at destroy: the search state
 extern int g_topk_variant;     // probe switches of the sweep (tile rows, coarse scale test)
 extern int g_topk_force_path;  // 0 auto, 1 path A only, 2 path B whenever it is usable, 3 = 2 without the tie replay
 }  // namespace gorse

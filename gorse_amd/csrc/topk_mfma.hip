@@ -53,6 +53,9 @@ constexpr int kWavesMain = GORSE_SWEEP_WAVES;  // waves per workgroup of the mai
 #ifndef GORSE_SWEEP_HALVES
 #define GORSE_SWEEP_HALVES 1
 #endif
+#ifndef GORSE_SWEEP_YOUNG_PRIO
+#define GORSE_SWEEP_YOUNG_PRIO 0  // A/B switch: 1 = the second-dispatched half of a workgroup's waves runs the tile loop at s_setprio 1
+#endif
 constexpr int kNcbMain = GORSE_SWEEP_NCB;  // 32-query column blocks per wave for operand depths up to 8 (probe switch)
 // the history sweep serves the few queries with ties: small workgroups (2 waves = 64 * NCB queries) spread them over
 // many CUs instead of a handful of 8-wave workgroups; deep operands keep more waves (the tile prefetch registers of a
@@ -150,6 +153,10 @@ struct SweepParams {
                                     // lists that overflowed, [3] (query, block) hits beyond a wave's staging area
     int sym_probe;         // timing probes of the symmetric sweep (results are garbage): 1 = no tile is read along its rows, 2 = the
                            // block and row tests run but a hit does nothing, 3 = hits are staged but never flushed
+    // SYM, triangle sharding over GPUs (gorse_topk_tri_*): this launch sweeps the query blocks C with C % sym_world == sym_rank only --
+    // their own lists, and what they find for the rows of EVERY earlier block (foreign lists of queries other ranks own included);
+    // 0 of 1 = the whole triangle
+    int sym_rank, sym_world;
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     float *s_fmin = reinterpret_cast<float *>(s_stage + kWaves * kStageCap);  // SYM: per tile buffer and 32-row block the smallest row threshold
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int cblk = SYM ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;  // SYM: longest workgroups first
+    // SYM: longest workgroups first; of a triangle shard the blocks sym_rank, sym_rank + sym_world, ... (the grid holds exactly those)
+    const int cblk = SYM ? p.sym_rank + p.sym_world * (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int64_t wgq0 = (int64_t)cblk * BQ;
     for (int t = tid; t < BQ; t += kThreads) {
         const int64_t q = wgq0 + t;
@@ -663,6 +671,16 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         return DMA ? *reinterpret_cast<const bf16x8 *>(blk + aoff[DMA ? ks : 0])
                    : *reinterpret_cast<const bf16x8 *>(blk + (lane & 31) * ROWB + (lane >> 5) * 16 + ks * 32);
     };
+    // MI355X_MICROARCH.md "Two waves per SIMD", item 4: of the two waves that share a SIMD the younger one (w >= kWaves / 2) loses the
+    // issue arbitration on every segment; a static priority for that half is the A/B switch GORSE_SWEEP_YOUNG_PRIO
+    const bool young = GORSE_SWEEP_YOUNG_PRIO && !HIST && wu >= kWaves / 2;
+    auto base_prio = [&]() {
+        if (young)
+            __builtin_amdgcn_s_setprio(1);
+        else
+            __builtin_amdgcn_s_setprio(0);
+    };
+    if (GORSE_SWEEP_YOUNG_PRIO) base_prio();
     int buf = 0, round = 0;  // tile t lives in buffer t % NBUF and is that buffer's (t / NBUF)-th tile
     for (int64_t t = 0; t < NT; t++) {
         if (PROF) ts = __builtin_amdgcn_s_memtime();
@@ -1032,7 +1050,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                         fth[cb] = s_f[ql];
                         if (RAWF) fraw[RAWF ? cb : 0] = raw_threshold(fth[cb]);
                     }
-                    __builtin_amdgcn_s_setprio(0);
+                    base_prio();
                     if (PROF) {
                         const unsigned long long now = __builtin_amdgcn_s_memtime();
                         c_s3 += now - tq;
@@ -1138,6 +1156,7 @@ struct RescoreParams {
     unsigned long long *sym_stats;  // (SweepParams)
     const float *qmargin;
     int kth;
+    int tri_rank, tri_world, tri_bq;  // triangle sharding: only the queries of the blocks this rank owns (t / tri_bq % tri_world == tri_rank)
 };
 constexpr int kCapT = kCap + kCapF;  // candidates the rescoring takes per query: its own list + its foreign list
 
@@ -1153,6 +1172,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
     const int k = p.k;
+    if (p.tri_world > 1 && (int)((t / p.tri_bq) % p.tri_world) != p.tri_rank) return;  // another rank's query
     if (p.cflag[t]) return;  // path A fills this row
     const int n_own = p.ccnt[t];
     const int n_for = p.fbuf ? p.fcnt[t] : 0;
@@ -2180,7 +2200,11 @@ int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     constexpr int WV = sweep_waves(HIST, KP);
     constexpr int BQ = 32 * NCB * WV;
     const size_t lds = sweep_lds_bytes(KP, RB, BQ, WV, HIST, SYM);
-    const unsigned grid = (unsigned)ceil_div(p.nq, BQ);
+    unsigned grid = (unsigned)ceil_div(p.nq, BQ);
+    if (SYM && p.sym_world > 1) {  // the blocks of this triangle shard
+        if ((int64_t)grid <= p.sym_rank) return GORSE_OK;
+        grid = (unsigned)ceil_div((int64_t)grid - p.sym_rank, p.sym_world);
+    }
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, EP, HIST, RB, false, SYM>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     topk_sweep_kernel<KP, NCB, EP, HIST, RB, false, SYM>
@@ -2372,20 +2396,66 @@ int32_t topk_mfma_prepare(gorse_topk *h) {
     return GORSE_OK;
 }
 
-int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev,
-                         int64_t nq, int k, int prune0, int32_t *idx_out, float *dist_out, int32_t *cnt_out) {
+}  // namespace gorse
+
+namespace {
+constexpr int kSymBQ = 32 * kNcbMain * kWavesMain;  // queries per workgroup (= query block) of the main sweep: the unit of a triangle shard
+
+// What the stages of one chunk of a search share.  topk_mfma_search runs them back to back; the triangle-sharded search
+// (gorse_topk_tri_*) keeps the state in the handle between its calls: the pilots over THIS rank's slice of the queries, then -- once
+// every rank's thresholds have arrived -- the main sweep over this rank's query blocks, then -- once the foreign lists have been
+// exchanged -- rescoring and tie path for the queries this rank owns.
+}  // namespace
+namespace gorse {
+struct TopkChunkState {
+    int64_t nq = 0, m = 0, c0 = 0, q_contig_begin = -1, mb = 0;
+    const int64_t *qid_host = nullptr;
+    const float *qv_dev = nullptr;
+    bool by_vector = false, contiguous = false, euclid = false, warm = false, sym = false;
+    int k = 0, kth = 0, prune0 = 0, pilot_stride = 16;
+    int64_t expect = 0;
+    float other = 0.0f;
+    const uint16_t *Bop = nullptr;
+    const float *qn2 = nullptr, *Qf = nullptr;
+    SweepParams sp;
+    int tri_rank = 0, tri_world = 1;
+    int tri_stage = 0;  // gorse_topk_tri_*: 0 none, 1 begun (pilots of the own slice done), 2 swept, 3 finished
+    int64_t tri_lo = 0, tri_hi = 0;  // the slice of the queries whose pilots this rank ran
+};
+}  // namespace gorse
+namespace {
+using ChunkState = gorse::TopkChunkState;
+
+// the per-query arrays of a sweep restricted to the queries [lo, lo + n) (a pilot over one rank's slice)
+SweepParams slice_params(const SweepParams &sp, int64_t lo, int64_t n, int kpad) {
+    SweepParams p = sp;
+    p.B = sp.B + lo * (int64_t)kpad;
+    p.qmargin = sp.qmargin + lo;
+    p.cbuf = sp.cbuf + lo * kCap;
+    p.ccnt = sp.ccnt + lo;
+    p.cflag = sp.cflag + lo;
+    if (sp.f0) p.f0 = sp.f0 + lo;
+    p.nq = n;
+    return p;
+}
+
+int32_t search_setup(gorse_topk *h, ChunkState &cs, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev, int64_t nq,
+                     int k, int prune0) {
     const int d = h->d, kpad = h->kp * 16;
-    const bool by_vector = qv_dev != nullptr;
-    const bool contiguous = !by_vector && qid_host == nullptr;
-    const bool exclude_self = !by_vector;
-    const int kth = k + (exclude_self ? 1 : 0);
+    cs = ChunkState();
+    cs.nq = nq, cs.qid_host = qid_host, cs.q_contig_begin = q_contig_begin, cs.qv_dev = qv_dev, cs.k = k, cs.prune0 = prune0;
+    cs.by_vector = qv_dev != nullptr;
+    cs.contiguous = !cs.by_vector && qid_host == nullptr;
+    const bool exclude_self = !cs.by_vector;
+    cs.kth = k + (exclude_self ? 1 : 0);
     // with a mask the query's own row may or may not be admissible: the larger count only sends a query whose list comes out
     // one short (fewer than k admissible rows in all) to path A
     const int64_t admissible = h->has_mask ? h->n_admissible : h->N - (exclude_self ? 1 : 0);
-    const int64_t expect = std::min<int64_t>(k, admissible);
-    const bool euclid = h->metric == GORSE_METRIC_EUCLIDEAN;
-    const float other = h->metric == GORSE_METRIC_COSINE ? 1.0f : h->max_norm;
+    cs.expect = std::min<int64_t>(k, admissible);
+    cs.euclid = h->metric == GORSE_METRIC_EUCLIDEAN;
+    cs.other = h->metric == GORSE_METRIC_COSINE ? 1.0f : h->max_norm;
     const int64_t mb = std::min(nq, kChunkQ);
+    cs.mb = mb;
     GORSE_TRY(h->cbuf.ensure((size_t)mb * kCap));
     GORSE_TRY(h->ccnt.ensure((size_t)mb));
     GORSE_TRY(h->cflag.ensure((size_t)mb));
@@ -2393,129 +2463,457 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
     GORSE_TRY(h->res_idx.ensure((size_t)mb * k));
     GORSE_TRY(h->res_dist.ensure((size_t)mb * k));
     GORSE_TRY(h->res_cnt.ensure((size_t)mb));
-    if (!contiguous) {
+    if (!cs.contiguous) {
         GORSE_TRY(h->opQ.ensure((size_t)mb * kpad));
         GORSE_TRY(h->qn2.ensure((size_t)mb));
     }
     if (qid_host) GORSE_TRY(h->qid.ensure((size_t)mb));
+    (void)d;
     h->n_fallback = 0;
     h->n_tie = 0;
     h->n_resweep = 0;
-    std::vector<uint8_t> &flags = h->host_flags;  // kept in the handle: gorse_hip_test_topk_get_flags
-    flags.assign((size_t)mb, 0);
+    h->host_flags.assign((size_t)mb, 0);  // kept in the handle: gorse_hip_test_topk_get_flags
+    return GORSE_OK;
+}
+
+// stage A: the chunk's query operands, margins and the main sweep's parameters (cs.sp); decides whether the sweep is warm-started
+int32_t chunk_prepare(gorse_topk *h, ChunkState &cs) {
+    const uint16_t *Bop;
+    const float *qn2;
+    const float *Qf = nullptr;
+    const int64_t m = cs.m, c0 = cs.c0, q_contig_begin = cs.q_contig_begin;
+    const int64_t *qid_host = cs.qid_host;
+    const float *qv_dev = cs.qv_dev;
+    const int d = h->d, kpad = h->kp * 16, kth = cs.kth;
+    const bool contiguous = cs.contiguous, euclid = cs.euclid;
+    const float other = cs.other;
+    if (contiguous) {
+        Bop = h->opB + (q_contig_begin + c0) * kpad;
+        qn2 = h->norm2.p + q_contig_begin + c0;
+    } else if (qid_host) {
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->qid.p, qid_host + c0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
+        gather_queries_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->opB, h->norm2.p, h->qid.p, m, kpad,
+                                                                            h->opQ.p, h->qn2.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        Bop = h->opQ.p;
+        qn2 = h->qn2.p;
+    } else {
+        Qf = qv_dev + c0 * d;
+        if (h->dtype == GORSE_DTYPE_BF16)
+            pad_bf16_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(nullptr, Qf, m, d, kpad, h->opQ.p);
+        else
+            split_f32_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(Qf, m, d, kpad, 1, h->opQ.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        GORSE_TRY(topk_compute_norms(h, Qf, m, h->qn2.p));
+        Bop = h->opQ.p;
+        qn2 = h->qn2.p;
+    }
+    if (euclid)
+        margin_euclid_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
+            qn2, m, h->err_coef, h->max_norm, (float)(d * 5.9604645e-8), h->qmargin.p);
+    else
+        margin_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
+            qn2, m, h->err_coef, other, h->qmargin.p);
+    GORSE_HIP_CHECK(hipGetLastError());
+    GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
+    SweepParams &sp = cs.sp;
+    sp.A = h->opA;
+    sp.B = Bop;
+    sp.rscale = h->has_mask ? h->rscale_m.p : h->rscale.p;
+    sp.qmargin = h->qmargin.p;
+    sp.cbuf = h->cbuf.p;
+    sp.ccnt = h->ccnt.p;
+    sp.cflag = h->cflag.p;
+    sp.hbuf = nullptr;
+    sp.hcnt = nullptr;
+    // epilogue: Euclidean adds its bias to every score; cosine multiplies every score by the row scale unless the scales
+    // lie within 2 % of each other (then the block's largest raw score times the extreme scale bounds the block and
+    // rows are scaled only behind that test; variant bit 2 / 3: off / on whatever the norms); -dot has the value 1
+    // (NaN for a masked row), which the block test never needs
+    const bool cos_coarse = (g_topk_variant & 4) ? false : ((g_topk_variant & 8) ? true : h->coarse_ok);
+    sp.ep = euclid ? EP_BIAS : (h->metric == GORSE_METRIC_COSINE ? (cos_coarse ? EP_COARSE : EP_SCALE) : EP_COARSE);
+    // a list is compacted (threshold raised to its K-th best) once a sub-list holds 128: 4.7 ms of the C4 pass less than at
+    // kCompactAt / 2 = 224 (fewer rows accepted late in the sweep; profiles/r03_p_probe_c4_floor.txt)
+    sp.compact_at = (g_topk_variant & 32) ? kCompactAt / 2 : ((g_topk_variant & 64) ? 96 : 128);
+    sp.prof = nullptr;
+    if (g_topk_variant & 16) {
+        GORSE_TRY(h->sweep_prof.ensure(16));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->sweep_prof.p, 0, 16 * sizeof(unsigned long long), h->stream));
+        sp.prof = h->sweep_prof.p;
+    }
+    sp.N = h->N;
+    sp.nq = m;
+    sp.kth = kth;
+    sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1;
+    sp.nslices = 1;
+    sp.probe = (g_topk_variant >> 17) & 3;  // variant bits 17-18: timing probes of the main sweep (the call then returns garbage)
+    // bounds of the per-row value for the DMA sweeps' block test: the cosine scales; without them (a masked -dot index:
+    // the value is 1 or NaN) the bound is the score itself
+    sp.rs_min = h->metric == GORSE_METRIC_COSINE ? h->rs_min : 1.0f;
+    sp.rs_max = h->metric == GORSE_METRIC_COSINE ? h->rs_max : 1.0f;
+    sp.sym_q0 = 0;
+    sp.frow = sp.frow_raw = nullptr;
+    sp.fbuf = nullptr;
+    sp.fcnt = nullptr;
+    sp.sym_stats = nullptr;
+    sp.sym_rank = 0, sp.sym_world = 1;
+    sp.sym_probe = (g_topk_variant >> 25) & 3;  // variant bits 25-26: timing probes of the symmetric sweep (the call returns garbage)
+    // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
+    // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
+    // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
+    // among the true kth - 1 best, that score is below the kth best of ALL rows unless X >= j -- j is chosen for a
+    // tail of ~1e-3 -- and about 16 j rows lie above it.  The main sweep starts there and VERIFIES it (compact_query
+    // flags a query whose K-th-best bound does not reach its threshold); those few queries join the tie queries' stage.
+    // (probe: variant bit 20 = every 8th row tile, bit 21 = every 32nd, bit 22 = without the 1/256 pilot in front)
+    cs.pilot_stride = (g_topk_variant & (1 << 20)) ? 8 : ((g_topk_variant & (1 << 21)) ? 32 : 16);
+    // probe / test switches: bit 8 = no warm start, bit 9 = warm start whatever N, bit 10 = a pilot kth of 2 (thresholds
+    // far too high: most queries fail the verification and are swept again)
+    cs.warm = !(g_topk_variant & 256) && kth >= 8 && (h->N >= (int64_t)1 << 17 || (g_topk_variant & 512));
+    cs.Bop = Bop, cs.qn2 = qn2, cs.Qf = Qf;
+    return GORSE_OK;
+}
+
+// stage B: the pilot sweeps (see chunk_prepare's comment on the warm start) over the queries [lo, hi) of the chunk: their thresholds
+// land in h->f0[lo .. hi)
+int32_t chunk_pilots(gorse_topk *h, ChunkState &cs, int64_t lo, int64_t hi) {
+    if (hi <= lo) return GORSE_OK;
+    // two pilots: the 1/16 sample's own sweep would start cold (and a cold start accepts ~1500 rows per query however
+    // few rows there are: every block of its 1/16 of the tiles would take the slow epilogue), so a 1/256 sample --
+    // a subset of the 1/16 sample -- proposes ITS thresholds first, by the same rule
+    auto pilot_kth = [](int of, int ratio) {
+        const double lam = (double)(of - 1) / ratio;
+        return (int)std::ceil(lam + 3.3 * std::sqrt(lam) + 1.5);
+    };
+    SweepParams p2 = slice_params(cs.sp, lo, hi - lo, h->kp * 16);
+    p2.kth = (g_topk_variant & 1024) ? 2 : pilot_kth(cs.kth, cs.pilot_stride);
+    p2.tile_stride = cs.pilot_stride;
+    p2.f_out = h->f0.p + lo;
+    p2.prof = nullptr;  // the instrumented twin profiles the main sweep only
+    p2.probe = 0;
+    if ((h->N >= (int64_t)1 << 18 || (g_topk_variant & 512)) && !(g_topk_variant & (1 << 22))) {
+        SweepParams p1 = p2;
+        p1.kth = pilot_kth(p2.kth, 16);
+        p1.tile_stride = cs.pilot_stride * 16;
+        p1.f_out = h->f1.p + lo;
+        GORSE_TRY(dispatch_sweep(h, p1, false));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p + lo, 0, (size_t)(hi - lo), h->stream));
+        p2.f0 = h->f1.p + lo;
+    }
+    GORSE_TRY(dispatch_sweep(h, p2, false));
+    GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p + lo, 0, (size_t)(hi - lo), h->stream));  // a pilot's flags say nothing about the query
+    return GORSE_OK;
+}
+
+// stage C: the main sweep -- symmetric where the call allows it (cs.sym says which form ran)
+int32_t chunk_main(gorse_topk *h, ChunkState &cs) {
+    const int64_t m = cs.m;
+    SweepParams &sp = cs.sp;
+    if (cs.warm) sp.f0 = h->f0.p;
+    // The symmetric form (topk_sweep_kernel, SYM): the queries are a contiguous range of the stored rows that starts on a tile
+    // boundary, the sweep is warm-started (a foreign workgroup cannot tighten a threshold: it needs a good one from the start)
+    // and there are at least two query blocks.  Variant bit 23 switches it off (the square sweep: tests, ablation).
+    const int64_t sym_q0 = cs.q_contig_begin + cs.c0;
+    bool sym = cs.warm && cs.contiguous && !(g_topk_variant & (1 << 23)) && sweep_sym_kp(h->kp) && topk_rows_per_tile() == 128 &&
+               sym_q0 % 128 == 0 && m >= 2 * 32 * kNcbMain * kWavesMain && sp.probe <= 1 && !sp.prof;
+    if (cs.warm) {
+        // sym_stats[0..3]: the counters of the whole search (every chunk adds to them); [4]: THIS chunk's queries without a pilot
+        // threshold -- cleared per chunk, so that a chunk that was not eligible for the symmetric form leaves nothing behind for the
+        // next one's decision (round 5 took a difference against a host copy that only symmetric chunks updated)
+        GORSE_TRY(h->sym_stats.ensure(8));
+        if (cs.c0 == 0) GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p, 0, 8 * sizeof(unsigned long long), h->stream));
+        else GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p + 4, 0, sizeof(unsigned long long), h->stream));
+        pilot_unset_count_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(h->f0.p, m, h->sym_stats.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+    }
+    if (sym && cs.tri_world == 1) {
+        // A query the pilot left without a threshold costs the symmetric form a sweep of its own (the tie path's), the square form
+        // only a cold start: where the pilot fails for many (rows sorted so that the systematic sample misleads it -- the
+        // Euclidean case of test_warm_started_sweep_returns_the_same_rows), the square sweep is the better one.  One 8-byte read
+        // behind the pilots.
+        unsigned long long unset = 0;
+        GORSE_HIP_CHECK(hipMemcpyAsync(&unset, h->sym_stats.p + 4, sizeof(unset), hipMemcpyDeviceToHost, h->stream));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if ((int64_t)unset * 32 > m && cs.tri_world == 1) sym = false;
+    }
+    h->last_sym = sym;
+    if (sym) {
+        GORSE_TRY(h->fbuf.ensure((size_t)cs.mb * kCapF));
+        GORSE_TRY(h->fcnt.ensure((size_t)cs.mb));
+        const bool rawf = sp.ep == EP_COARSE;
+        if (rawf) GORSE_TRY(h->f0raw.ensure((size_t)cs.mb));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->fcnt.p, 0, (size_t)m * 4, h->stream));
+        sym_thresholds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
+            h->f0.p, rawf ? h->f0raw.p : nullptr, h->cflag.p, m, sp.rs_min, sp.rs_max, h->sym_stats.p);
+        GORSE_HIP_CHECK(hipGetLastError());
+        sp.sym_q0 = sym_q0;
+        sp.frow = h->f0.p;
+        sp.frow_raw = rawf ? h->f0raw.p : nullptr;
+        sp.fbuf = h->fbuf.p;
+        sp.fcnt = h->fcnt.p;
+        sp.sym_stats = h->sym_stats.p;
+        sp.f_out = h->f1.p;  // the thresholds the workgroups end with: topk_rescore_kernel's verification reads them
+        sp.sym_rank = cs.tri_rank, sp.sym_world = cs.tri_world;
+    }
+    GORSE_TRY(dispatch_sweep(h, sp, false, sym));
+    cs.sym = sym;
+    return GORSE_OK;
+}
+
+// stage D: exact rescoring of the lists, the tie path for what that leaves undecided, the literal scan for what THAT leaves; the
+// chunk's rows end up in h->res_idx / res_dist / res_cnt (a triangle shard: the rows of the queries this rank owns)
+int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
+    const int64_t m = cs.m, c0 = cs.c0, q_contig_begin = cs.q_contig_begin;
+    const int64_t *qid_host = cs.qid_host;
+    const int d = h->d, kpad = h->kp * 16, k = cs.k, kth = cs.kth, prune0 = cs.prune0;
+    const int64_t expect = cs.expect;
+    const bool by_vector = cs.by_vector, sym = cs.sym;
+    const uint16_t *Bop = cs.Bop;
+    const float *qn2 = cs.qn2, *Qf = cs.Qf;
+    const SweepParams &sp = cs.sp;
+    std::vector<uint8_t> &flags = h->host_flags;
+    int tok;
+    RescoreParams rp;
+    rp.X = h->X.p;
+    rp.Xb = h->dtype == GORSE_DTYPE_BF16 ? h->Xb.p : nullptr;
+    rp.norm2 = h->norm2.p;
+    rp.Qf = Qf;
+    rp.qn2 = qn2;
+    rp.qid = qid_host ? h->qid.p : nullptr;
+    rp.q0 = q_contig_begin + c0;
+    rp.tri_rank = cs.tri_rank, rp.tri_world = cs.tri_world, rp.tri_bq = kSymBQ;
+    rp.cbuf = h->cbuf.p;
+    rp.ccnt = h->ccnt.p;
+    rp.cflag = h->cflag.p;
+    rp.d = d;
+    rp.metric = h->kernel_metric();
+    rp.k = k;
+    rp.prune0 = prune0;
+    rp.expect = expect;
+    rp.out_idx = h->res_idx.p;
+    rp.out_dist = h->res_dist.p;
+    rp.out_cnt = h->res_cnt.p;
+    rp.fbuf = sym ? h->fbuf.p : nullptr;
+    rp.fcnt = sym ? h->fcnt.p : nullptr;
+    rp.f0 = sym ? h->f0.p : nullptr;
+    rp.ffinal = sym ? h->f1.p : nullptr;
+    rp.sym_stats = sym ? h->sym_stats.p : nullptr;
+    rp.qmargin = h->qmargin.p;
+    rp.kth = kth;
+    const size_t lds = ((size_t)(1 + 2 * kGroupsPerBlock) * d + 2 * kCapT + 8) * 4;
+    tok = h->prof.begin(GORSE_PROF_TOPK_SELECT, h->stream);
+    topk_rescore_kernel<<<dim3((unsigned)m), dim3(kBlock), lds, h->stream>>>(rp);
+    GORSE_HIP_CHECK(hipGetLastError());
+    h->prof.end(tok, h->stream);
+    GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<int64_t> fb;  // queries the sweep + rescoring could not decide (ties in the top k+1, NaN, overflow)
+    for (int64_t t = 0; t < m; t++) {
+        if (cs.tri_world > 1 && (int)((t / kSymBQ) % cs.tri_world) != cs.tri_rank) {
+            flags[t] = 0;  // another rank's query: its flags (a staging overflow seen here) have travelled to its owner
+            continue;
+        }
+        if (flags[t]) {
+            fb.push_back(t);
+            h->n_resweep += flags[t] == 2;
+        }
+    }
+    auto stored_id = [&](int64_t t) -> int64_t {
+        return by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
+    };
+    // stage 2: history sweep + literal heap replay (topk_tie_sort_kernel, topk_tie_replay_kernel) for the flagged queries
+    std::vector<int64_t> rest;
+    // (with a mask the replay's gap arithmetic -- which counts the rows between two recorded ones -- would count masked
+    // rows too: those queries take the literal scan, which skips masked rows)
+    if (!fb.empty() && g_topk_force_path != 3 && !h->has_mask) {
+        std::vector<int32_t> pos;
+        std::vector<int64_t> selfs;
+        std::vector<uint8_t> f2;
+        for (size_t f0 = 0; f0 < fb.size(); f0 += (size_t)kReplayChunk) {
+            const int64_t m2 = std::min<int64_t>(kReplayChunk, (int64_t)(fb.size() - f0));
+            pos.resize((size_t)m2);
+            selfs.resize((size_t)m2);
+            for (int64_t r = 0; r < m2; r++) {
+                pos[r] = (int32_t)fb[f0 + r];
+                selfs[r] = stored_id(fb[f0 + r]);
+            }
+            GORSE_TRY(h->rp_pos.ensure((size_t)m2));
+            GORSE_TRY(h->rp_self.ensure((size_t)m2));
+            GORSE_TRY(h->rp_op.ensure((size_t)m2 * kpad));
+            GORSE_TRY(h->rp_margin.ensure((size_t)m2));
+            // Row slices: a history sweep serves few queries (1 % of a chunk), so its workgroups are few, and each would walk
+            // all N rows on its own -- 56 ms for 10,000 queries at C4, three quarters of the tie path.  Cut into slices of
+            // rows, slices x as many workgroups each walk 1 / slices of the rows; topk_tie_sort_kernel joins the slices.
+            // Variant bit 14: eight slices whatever N (lets small test inputs take the path); bit 15: one slice.
+            int nsl = (int)std::min<int64_t>(kMaxSlices, std::max<int64_t>(1, h->N / 32768));
+            if (g_topk_variant & 16384) nsl = kMaxSlices;
+            if (g_topk_variant & 32768) nsl = 1;
+            const size_t sm2 = (size_t)nsl * (size_t)m2;
+            GORSE_TRY(h->rp_cbuf.ensure(sm2 * kCap));
+            GORSE_TRY(h->rp_hbuf.ensure(sm2 * kHistCap));
+            GORSE_TRY(h->rp_ccnt.ensure(sm2));
+            GORSE_TRY(h->rp_hcnt.ensure(sm2));
+            GORSE_TRY(h->rp_flag.ensure(sm2));
+            GORSE_TRY(h->rp_fslice.ensure(sm2));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_pos.p, pos.data(), (size_t)m2 * 4, hipMemcpyHostToDevice, h->stream));
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_self.p, selfs.data(), (size_t)m2 * 8, hipMemcpyHostToDevice, h->stream));
+            gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, h->rp_pos.p, kpad,
+                                                                             h->rp_op.p, h->rp_margin.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+            GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, sm2, h->stream));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->rp_hcnt.p, 0, sm2 * 4, h->stream));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, sm2 * 4, h->stream));
+            SweepParams hp = sp;
+            hp.f0 = nullptr;  // the history sweep records what a threshold that starts at -inf would have kept
+            hp.B = h->rp_op.p;
+            hp.qmargin = h->rp_margin.p;
+            hp.cbuf = h->rp_cbuf.p;
+            hp.ccnt = h->rp_ccnt.p;
+            hp.cflag = h->rp_flag.p;
+            hp.hbuf = h->rp_hbuf.p;
+            hp.hcnt = h->rp_hcnt.p;
+            hp.f_out = h->rp_fslice.p;
+            hp.nslices = nsl;
+            hp.nq = m2;
+            tok = h->prof.begin(GORSE_PROF_TOPK_HIST, h->stream);
+            GORSE_TRY(dispatch_sweep(h, hp, true));
+            h->prof.end(tok, h->stream);
+            ReplayParams pp;
+            pp.X = h->X.p;
+            pp.Xb = h->dtype == GORSE_DTYPE_BF16 ? h->Xb.p : nullptr;
+            pp.norm2 = h->norm2.p;
+            pp.Qf = Qf;
+            pp.qn2 = qn2;
+            pp.self = h->rp_self.p;
+            pp.pos = h->rp_pos.p;
+            pp.cbuf = h->rp_cbuf.p;
+            pp.ccnt = h->rp_ccnt.p;
+            pp.hbuf = h->rp_hbuf.p;
+            pp.hcnt = h->rp_hcnt.p;
+            pp.fslice = h->rp_fslice.p;
+            pp.nslices = nsl;
+            pp.prof = (g_topk_variant & 16) && h->sweep_prof.n >= 16 ? h->sweep_prof.p : nullptr;  // the sweep's counters are overwritten
+            if (pp.prof) GORSE_HIP_CHECK(hipMemsetAsync(pp.prof, 0, 16 * sizeof(unsigned long long), h->stream));
+            pp.nq = m2;
+            pp.cflag = h->rp_flag.p;
+            pp.N = h->N;
+            pp.d = d;
+            pp.metric = h->kernel_metric();
+            pp.k = k;
+            pp.prune0 = prune0;
+            pp.out_idx = h->res_idx.p;
+            pp.out_dist = h->res_dist.p;
+            pp.out_cnt = h->res_cnt.p;
+            GORSE_TRY(h->rp_sidx.ensure((size_t)m2 * kReplayCap));
+            GORSE_TRY(h->rp_sdst.ensure((size_t)m2 * kReplayCap));
+            GORSE_TRY(h->rp_scount.ensure((size_t)m2));
+            pp.sidx = h->rp_sidx.p;
+            pp.sdst = h->rp_sdst.p;
+            pp.scount = h->rp_scount.p;
+            const size_t rlds = ((size_t)2 * kReplayCap + (size_t)(1 + kGroupsPerBlock) * d + 4) * 4;
+            GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_tie_sort_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+            tok = h->prof.begin(GORSE_PROF_TOPK_REPLAY, h->stream);
+            topk_tie_sort_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
+            GORSE_HIP_CHECK(hipGetLastError());
+            // one lane per query (probe build, variant bit 19 / 16: the round-2 kernel, a wave per query)
+#ifdef GORSE_PROBE
+            const bool lanes = !(g_topk_variant & (1 << 19)) && !(g_topk_variant & 65536);
+#else
+            const bool lanes = true;
+#endif
+            if (lanes) {
+                const int slots = k + 1;
+                int qpw = 64;
+                while (qpw > 16 && (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4 > (size_t)144 * 1024) qpw >>= 1;
+                const size_t llds = (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4;
+                auto launch_lanes = [&](auto tag) -> int32_t {
+                    constexpr int Q = decltype(tag)::value;
+                    GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_tie_replay_lane_kernel<Q>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+                    topk_tie_replay_lane_kernel<Q><<<dim3((unsigned)ceil_div(m2, Q)), dim3(64), llds, h->stream>>>(pp, m2, slots);
+                    GORSE_HIP_CHECK(hipGetLastError());
+                    return GORSE_OK;
+                };
+                if (qpw == 64) GORSE_TRY(launch_lanes(std::integral_constant<int, 64>()));
+                else if (qpw == 32) GORSE_TRY(launch_lanes(std::integral_constant<int, 32>()));
+                else GORSE_TRY(launch_lanes(std::integral_constant<int, 16>()));
+            }
+#ifdef GORSE_PROBE
+            if (!lanes) {
+                topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2, (g_topk_variant & 65536) ? 1 : 0);
+                GORSE_HIP_CHECK(hipGetLastError());
+            }
+#endif
+            h->prof.end(tok, h->stream);
+            f2.resize((size_t)m2);
+            GORSE_HIP_CHECK(hipMemcpyAsync(f2.data(), h->rp_flag.p, (size_t)m2, hipMemcpyDeviceToHost, h->stream));
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+            for (int64_t r = 0; r < m2; r++) {
+                if (f2[r])
+                    rest.push_back(fb[f0 + r]);
+                else
+                    h->n_tie++;
+            }
+        }
+    } else {
+        rest = fb;
+    }
+    // stage 3: whatever is left replays the reference literally over all N vectors (path A); its rows go into
+    // the chunk's device result arrays like everybody else's
+    if (!rest.empty()) {
+        h->n_fallback += (int64_t)rest.size();
+        const int64_t bq = topk_scan_block_queries(h);
+        std::vector<int64_t> ids((size_t)std::min<int64_t>(bq, (int64_t)rest.size()));
+        std::vector<int32_t> ti((size_t)ids.size() * k), tc(ids.size());
+        std::vector<float> td((size_t)ids.size() * k);
+        GORSE_TRY(h->qbuf.ensure(ids.size() * (size_t)d));
+        GORSE_TRY(h->qnorm.ensure(ids.size()));
+        GORSE_TRY(h->qidx.ensure(ids.size()));
+        for (size_t f0 = 0; f0 < rest.size(); f0 += (size_t)bq) {
+            const int64_t fm = std::min<int64_t>(bq, (int64_t)(rest.size() - f0));
+            for (int64_t r = 0; r < fm; r++) {
+                const int64_t t = rest[f0 + r];
+                ids[r] = stored_id(t);
+                const float *src = by_vector ? Qf + t * d : h->X.p + ids[r] * d;
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->qbuf.p + r * d, src, (size_t)d * 4, hipMemcpyDeviceToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->qnorm.p + r, qn2 + t, 4, hipMemcpyDeviceToDevice, h->stream));
+            }
+            const int64_t *excl = nullptr;
+            if (!by_vector) {
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->qidx.p, ids.data(), (size_t)fm * 8, hipMemcpyHostToDevice, h->stream));
+                excl = h->qidx.p;
+            }
+            GORSE_TRY(topk_scan_block(h, fm, excl, by_vector ? nullptr : ids.data(), k, prune0, ti.data(), td.data(), tc.data(),
+                                      /*reroute=*/false));  // these queries come FROM the replay: the literal kernel ends it
+            for (int64_t r = 0; r < fm; r++) {
+                const int64_t t = rest[f0 + r];
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_idx.p + t * k, ti.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_dist.p + t * k, td.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->res_cnt.p + t, tc.data() + r, 4, hipMemcpyHostToDevice, h->stream));
+            }
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        }
+    }
+    return GORSE_OK;
+}
+
+}  // namespace
+
+namespace gorse {
+
+int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_contig_begin, const float *qv_dev,
+                         int64_t nq, int k, int prune0, int32_t *idx_out, float *dist_out, int32_t *cnt_out) {
+    ChunkState &cs = *h->chunk_state();
+    GORSE_TRY(search_setup(h, cs, qid_host, q_contig_begin, qv_dev, nq, k, prune0));
     for (int64_t c0 = 0; c0 < nq; c0 += kChunkQ) {
         const int64_t m = std::min(kChunkQ, nq - c0);
-        const uint16_t *Bop;
-        const float *qn2;
-        const float *Qf = nullptr;
-        if (contiguous) {
-            Bop = h->opB + (q_contig_begin + c0) * kpad;
-            qn2 = h->norm2.p + q_contig_begin + c0;
-        } else if (qid_host) {
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->qid.p, qid_host + c0, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));
-            gather_queries_kernel<<<dim3((unsigned)m), dim3(64), 0, h->stream>>>(h->opB, h->norm2.p, h->qid.p, m, kpad,
-                                                                                h->opQ.p, h->qn2.p);
-            GORSE_HIP_CHECK(hipGetLastError());
-            Bop = h->opQ.p;
-            qn2 = h->qn2.p;
-        } else {
-            Qf = qv_dev + c0 * d;
-            if (h->dtype == GORSE_DTYPE_BF16)
-                pad_bf16_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(nullptr, Qf, m, d, kpad, h->opQ.p);
-            else
-                split_f32_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>(Qf, m, d, kpad, 1, h->opQ.p);
-            GORSE_HIP_CHECK(hipGetLastError());
-            GORSE_TRY(topk_compute_norms(h, Qf, m, h->qn2.p));
-            Bop = h->opQ.p;
-            qn2 = h->qn2.p;
-        }
-        if (euclid)
-            margin_euclid_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
-                qn2, m, h->err_coef, h->max_norm, (float)(d * 5.9604645e-8), h->qmargin.p);
-        else
-            margin_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
-                qn2, m, h->err_coef, other, h->qmargin.p);
-        GORSE_HIP_CHECK(hipGetLastError());
-        GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
-        SweepParams sp;
-        sp.A = h->opA;
-        sp.B = Bop;
-        sp.rscale = h->has_mask ? h->rscale_m.p : h->rscale.p;
-        sp.qmargin = h->qmargin.p;
-        sp.cbuf = h->cbuf.p;
-        sp.ccnt = h->ccnt.p;
-        sp.cflag = h->cflag.p;
-        sp.hbuf = nullptr;
-        sp.hcnt = nullptr;
-        // epilogue: Euclidean adds its bias to every score; cosine multiplies every score by the row scale unless the scales
-        // lie within 2 % of each other (then the block's largest raw score times the extreme scale bounds the block and
-        // rows are scaled only behind that test; variant bit 2 / 3: off / on whatever the norms); -dot has the value 1
-        // (NaN for a masked row), which the block test never needs
-        const bool cos_coarse = (g_topk_variant & 4) ? false : ((g_topk_variant & 8) ? true : h->coarse_ok);
-        sp.ep = euclid ? EP_BIAS : (h->metric == GORSE_METRIC_COSINE ? (cos_coarse ? EP_COARSE : EP_SCALE) : EP_COARSE);
-        // a list is compacted (threshold raised to its K-th best) once a sub-list holds 128: 4.7 ms of the C4 pass less than at
-        // kCompactAt / 2 = 224 (fewer rows accepted late in the sweep; profiles/r03_p_probe_c4_floor.txt)
-        sp.compact_at = (g_topk_variant & 32) ? kCompactAt / 2 : ((g_topk_variant & 64) ? 96 : 128);
-        sp.prof = nullptr;
-        if (g_topk_variant & 16) {
-            GORSE_TRY(h->sweep_prof.ensure(16));
-            GORSE_HIP_CHECK(hipMemsetAsync(h->sweep_prof.p, 0, 16 * sizeof(unsigned long long), h->stream));
-            sp.prof = h->sweep_prof.p;
-        }
-        sp.N = h->N;
-        sp.nq = m;
-        sp.kth = kth;
-        sp.f0 = nullptr, sp.f_out = nullptr, sp.tile_stride = 1;
-        sp.nslices = 1;
-        sp.probe = (g_topk_variant >> 17) & 3;  // variant bits 17-18: timing probes of the main sweep (the call then returns garbage)
-        // bounds of the per-row value for the DMA sweeps' block test: the cosine scales; without them (a masked -dot index:
-        // the value is 1 or NaN) the bound is the score itself
-        sp.rs_min = h->metric == GORSE_METRIC_COSINE ? h->rs_min : 1.0f;
-        sp.rs_max = h->metric == GORSE_METRIC_COSINE ? h->rs_max : 1.0f;
-        sp.sym_q0 = 0;
-        sp.frow = sp.frow_raw = nullptr;
-        sp.fbuf = nullptr;
-        sp.fcnt = nullptr;
-        sp.sym_stats = nullptr;
-        sp.sym_probe = (g_topk_variant >> 25) & 3;  // variant bits 25-26: timing probes of the symmetric sweep (the call returns garbage)
-        // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
-        // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
-        // with kth_pilot = j yields the j-th best score of a 1/16 sample: with X ~ Binomial(kth - 1, 1/16) sample members
-        // among the true kth - 1 best, that score is below the kth best of ALL rows unless X >= j -- j is chosen for a
-        // tail of ~1e-3 -- and about 16 j rows lie above it.  The main sweep starts there and VERIFIES it (compact_query
-        // flags a query whose K-th-best bound does not reach its threshold); those few queries join the tie queries' stage.
-        // (probe: variant bit 20 = every 8th row tile, bit 21 = every 32nd, bit 22 = without the 1/256 pilot in front)
-        const int pilot_stride = (g_topk_variant & (1 << 20)) ? 8 : ((g_topk_variant & (1 << 21)) ? 32 : 16);
-        // probe / test switches: bit 8 = no warm start, bit 9 = warm start whatever N, bit 10 = a pilot kth of 2 (thresholds
-        // far too high: most queries fail the verification and are swept again)
-        const bool warm = !(g_topk_variant & 256) && kth >= 8 && (h->N >= (int64_t)1 << 17 || (g_topk_variant & 512));
+        cs.c0 = c0, cs.m = m;
+        GORSE_TRY(chunk_prepare(h, cs));
         int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
-        if (warm) {
-            // two pilots: the 1/16 sample's own sweep would start cold (and a cold start accepts ~1500 rows per query however
-            // few rows there are: every block of its 1/16 of the tiles would take the slow epilogue), so a 1/256 sample --
-            // a subset of the 1/16 sample -- proposes ITS thresholds first, by the same rule
-            auto pilot_kth = [](int of, int ratio) {
-                const double lam = (double)(of - 1) / ratio;
-                return (int)std::ceil(lam + 3.3 * std::sqrt(lam) + 1.5);
-            };
-            GORSE_TRY(h->f0.ensure((size_t)mb));
-            GORSE_TRY(h->f1.ensure((size_t)mb));
-            SweepParams p2 = sp;
-            p2.kth = (g_topk_variant & 1024) ? 2 : pilot_kth(kth, pilot_stride);
-            p2.tile_stride = pilot_stride;
-            p2.f_out = h->f0.p;
-            p2.prof = nullptr;  // the instrumented twin profiles the main sweep only
-            p2.probe = 0;
-            if ((h->N >= (int64_t)1 << 18 || (g_topk_variant & 512)) && !(g_topk_variant & (1 << 22))) {
-                SweepParams p1 = p2;
-                p1.kth = pilot_kth(p2.kth, 16);
-                p1.tile_stride = pilot_stride * 16;
-                p1.f_out = h->f1.p;
-                GORSE_TRY(dispatch_sweep(h, p1, false));
-                GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));
-                p2.f0 = h->f1.p;
-            }
-            GORSE_TRY(dispatch_sweep(h, p2, false));
+        if (cs.warm) {
+            GORSE_TRY(h->f0.ensure((size_t)cs.mb));
+            GORSE_TRY(h->f1.ensure((size_t)cs.mb));
+            GORSE_TRY(chunk_pilots(h, cs, 0, m));
             if (g_topk_variant & (1 << 24)) {  // probe: stop behind the pilot, keep its flags and list lengths (results are garbage)
                 h->dbg_flags.resize((size_t)m);
                 h->dbg_counts.resize((size_t)m);
@@ -2525,279 +2923,19 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
                 h->prof.end(tok, h->stream);
                 return GORSE_OK;
             }
-            GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p, 0, (size_t)m, h->stream));  // a pilot's flags say nothing about the query
-            sp.f0 = h->f0.p;
         }
-        // The symmetric form (topk_sweep_kernel, SYM): the queries are a contiguous range of the stored rows that starts on a tile
-        // boundary, the sweep is warm-started (a foreign workgroup cannot tighten a threshold: it needs a good one from the start)
-        // and there are at least two query blocks.  Variant bit 23 switches it off (the square sweep: tests, ablation).
-        const int64_t sym_q0 = q_contig_begin + c0;
-        bool sym = warm && contiguous && !(g_topk_variant & (1 << 23)) && sweep_sym_kp(h->kp) && topk_rows_per_tile() == 128 &&
-                   sym_q0 % 128 == 0 && m >= 2 * 32 * kNcbMain * kWavesMain && sp.probe <= 1 && !sp.prof;
-        if (warm) {
-            // sym_stats[0..3]: the counters of the whole search (every chunk adds to them); [4]: THIS chunk's queries without a pilot
-            // threshold -- cleared per chunk, so that a chunk that was not eligible for the symmetric form leaves nothing behind for the
-            // next one's decision (round 5 took a difference against a host copy that only symmetric chunks updated)
-            GORSE_TRY(h->sym_stats.ensure(8));
-            if (c0 == 0) GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p, 0, 8 * sizeof(unsigned long long), h->stream));
-            else GORSE_HIP_CHECK(hipMemsetAsync(h->sym_stats.p + 4, 0, sizeof(unsigned long long), h->stream));
-            pilot_unset_count_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(h->f0.p, m, h->sym_stats.p);
-            GORSE_HIP_CHECK(hipGetLastError());
-        }
-        if (sym) {
-            // A query the pilot left without a threshold costs the symmetric form a sweep of its own (the tie path's), the square form
-            // only a cold start: where the pilot fails for many (rows sorted so that the systematic sample misleads it -- the
-            // Euclidean case of test_warm_started_sweep_returns_the_same_rows), the square sweep is the better one.  One 8-byte read
-            // behind the pilots.
-            unsigned long long unset = 0;
-            GORSE_HIP_CHECK(hipMemcpyAsync(&unset, h->sym_stats.p + 4, sizeof(unset), hipMemcpyDeviceToHost, h->stream));
-            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-            if ((int64_t)unset * 32 > m) sym = false;
-        }
-        h->last_sym = sym;
-        if (sym) {
-            GORSE_TRY(h->fbuf.ensure((size_t)mb * kCapF));
-            GORSE_TRY(h->fcnt.ensure((size_t)mb));
-            const bool rawf = sp.ep == EP_COARSE;
-            if (rawf) GORSE_TRY(h->f0raw.ensure((size_t)mb));
-            GORSE_HIP_CHECK(hipMemsetAsync(h->fcnt.p, 0, (size_t)m * 4, h->stream));
-            sym_thresholds_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(m, 256), 1024)), dim3(256), 0, h->stream>>>(
-                h->f0.p, rawf ? h->f0raw.p : nullptr, h->cflag.p, m, sp.rs_min, sp.rs_max, h->sym_stats.p);
-            GORSE_HIP_CHECK(hipGetLastError());
-            sp.sym_q0 = sym_q0;
-            sp.frow = h->f0.p;
-            sp.frow_raw = rawf ? h->f0raw.p : nullptr;
-            sp.fbuf = h->fbuf.p;
-            sp.fcnt = h->fcnt.p;
-            sp.sym_stats = h->sym_stats.p;
-            sp.f_out = h->f1.p;  // the thresholds the workgroups end with: topk_rescore_kernel's verification reads them
-        }
-        GORSE_TRY(dispatch_sweep(h, sp, false, sym));
-        if (sp.probe || sp.sym_probe) {  // timing probe: nothing behind the sweep is meaningful
+        GORSE_TRY(chunk_main(h, cs));
+        h->last_sym = cs.sym;
+        if (cs.sp.probe || cs.sp.sym_probe) {  // timing probe: nothing behind the sweep is meaningful
             h->prof.end(tok, h->stream);
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
             continue;
         }
         // The queries whose warm start failed its verification carry flag 2: topk_rescore_kernel leaves flagged queries alone
-        // and stage 2 below (history sweep from -inf + literal replay) answers them together with the tie queries -- a sweep
+        // and stage 2 of chunk_finish (history sweep from -inf + literal replay) answers them together with the tie queries -- a sweep
         // of their own would cost one workgroup a full pass over the rows (48 ms for 86 queries, profiles/r02_h_*).
         h->prof.end(tok, h->stream);
-        RescoreParams rp;
-        rp.X = h->X.p;
-        rp.Xb = h->dtype == GORSE_DTYPE_BF16 ? h->Xb.p : nullptr;
-        rp.norm2 = h->norm2.p;
-        rp.Qf = Qf;
-        rp.qn2 = qn2;
-        rp.qid = qid_host ? h->qid.p : nullptr;
-        rp.q0 = q_contig_begin + c0;
-        rp.cbuf = h->cbuf.p;
-        rp.ccnt = h->ccnt.p;
-        rp.cflag = h->cflag.p;
-        rp.d = d;
-        rp.metric = h->kernel_metric();
-        rp.k = k;
-        rp.prune0 = prune0;
-        rp.expect = expect;
-        rp.out_idx = h->res_idx.p;
-        rp.out_dist = h->res_dist.p;
-        rp.out_cnt = h->res_cnt.p;
-        rp.fbuf = sym ? h->fbuf.p : nullptr;
-        rp.fcnt = sym ? h->fcnt.p : nullptr;
-        rp.f0 = sym ? h->f0.p : nullptr;
-        rp.ffinal = sym ? h->f1.p : nullptr;
-        rp.sym_stats = sym ? h->sym_stats.p : nullptr;
-        rp.qmargin = h->qmargin.p;
-        rp.kth = kth;
-        const size_t lds = ((size_t)(1 + 2 * kGroupsPerBlock) * d + 2 * kCapT + 8) * 4;
-        tok = h->prof.begin(GORSE_PROF_TOPK_SELECT, h->stream);
-        topk_rescore_kernel<<<dim3((unsigned)m), dim3(kBlock), lds, h->stream>>>(rp);
-        GORSE_HIP_CHECK(hipGetLastError());
-        h->prof.end(tok, h->stream);
-        GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
-        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-        std::vector<int64_t> fb;  // queries the sweep + rescoring could not decide (ties in the top k+1, NaN, overflow)
-        for (int64_t t = 0; t < m; t++)
-            if (flags[t]) {
-                fb.push_back(t);
-                h->n_resweep += flags[t] == 2;
-            }
-        auto stored_id = [&](int64_t t) -> int64_t {
-            return by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
-        };
-        // stage 2: history sweep + literal heap replay (topk_tie_sort_kernel, topk_tie_replay_kernel) for the flagged queries
-        std::vector<int64_t> rest;
-        // (with a mask the replay's gap arithmetic -- which counts the rows between two recorded ones -- would count masked
-        // rows too: those queries take the literal scan, which skips masked rows)
-        if (!fb.empty() && g_topk_force_path != 3 && !h->has_mask) {
-            std::vector<int32_t> pos;
-            std::vector<int64_t> selfs;
-            std::vector<uint8_t> f2;
-            for (size_t f0 = 0; f0 < fb.size(); f0 += (size_t)kReplayChunk) {
-                const int64_t m2 = std::min<int64_t>(kReplayChunk, (int64_t)(fb.size() - f0));
-                pos.resize((size_t)m2);
-                selfs.resize((size_t)m2);
-                for (int64_t r = 0; r < m2; r++) {
-                    pos[r] = (int32_t)fb[f0 + r];
-                    selfs[r] = stored_id(fb[f0 + r]);
-                }
-                GORSE_TRY(h->rp_pos.ensure((size_t)m2));
-                GORSE_TRY(h->rp_self.ensure((size_t)m2));
-                GORSE_TRY(h->rp_op.ensure((size_t)m2 * kpad));
-                GORSE_TRY(h->rp_margin.ensure((size_t)m2));
-                // Row slices: a history sweep serves few queries (1 % of a chunk), so its workgroups are few, and each would walk
-                // all N rows on its own -- 56 ms for 10,000 queries at C4, three quarters of the tie path.  Cut into slices of
-                // rows, slices x as many workgroups each walk 1 / slices of the rows; topk_tie_sort_kernel joins the slices.
-                // Variant bit 14: eight slices whatever N (lets small test inputs take the path); bit 15: one slice.
-                int nsl = (int)std::min<int64_t>(kMaxSlices, std::max<int64_t>(1, h->N / 32768));
-                if (g_topk_variant & 16384) nsl = kMaxSlices;
-                if (g_topk_variant & 32768) nsl = 1;
-                const size_t sm2 = (size_t)nsl * (size_t)m2;
-                GORSE_TRY(h->rp_cbuf.ensure(sm2 * kCap));
-                GORSE_TRY(h->rp_hbuf.ensure(sm2 * kHistCap));
-                GORSE_TRY(h->rp_ccnt.ensure(sm2));
-                GORSE_TRY(h->rp_hcnt.ensure(sm2));
-                GORSE_TRY(h->rp_flag.ensure(sm2));
-                GORSE_TRY(h->rp_fslice.ensure(sm2));
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_pos.p, pos.data(), (size_t)m2 * 4, hipMemcpyHostToDevice, h->stream));
-                GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_self.p, selfs.data(), (size_t)m2 * 8, hipMemcpyHostToDevice, h->stream));
-                gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, h->rp_pos.p, kpad,
-                                                                                 h->rp_op.p, h->rp_margin.p);
-                GORSE_HIP_CHECK(hipGetLastError());
-                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, sm2, h->stream));
-                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_hcnt.p, 0, sm2 * 4, h->stream));
-                GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, sm2 * 4, h->stream));
-                SweepParams hp = sp;
-                hp.f0 = nullptr;  // the history sweep records what a threshold that starts at -inf would have kept
-                hp.B = h->rp_op.p;
-                hp.qmargin = h->rp_margin.p;
-                hp.cbuf = h->rp_cbuf.p;
-                hp.ccnt = h->rp_ccnt.p;
-                hp.cflag = h->rp_flag.p;
-                hp.hbuf = h->rp_hbuf.p;
-                hp.hcnt = h->rp_hcnt.p;
-                hp.f_out = h->rp_fslice.p;
-                hp.nslices = nsl;
-                hp.nq = m2;
-                tok = h->prof.begin(GORSE_PROF_TOPK_HIST, h->stream);
-                GORSE_TRY(dispatch_sweep(h, hp, true));
-                h->prof.end(tok, h->stream);
-                ReplayParams pp;
-                pp.X = h->X.p;
-                pp.Xb = h->dtype == GORSE_DTYPE_BF16 ? h->Xb.p : nullptr;
-                pp.norm2 = h->norm2.p;
-                pp.Qf = Qf;
-                pp.qn2 = qn2;
-                pp.self = h->rp_self.p;
-                pp.pos = h->rp_pos.p;
-                pp.cbuf = h->rp_cbuf.p;
-                pp.ccnt = h->rp_ccnt.p;
-                pp.hbuf = h->rp_hbuf.p;
-                pp.hcnt = h->rp_hcnt.p;
-                pp.fslice = h->rp_fslice.p;
-                pp.nslices = nsl;
-                pp.prof = (g_topk_variant & 16) && h->sweep_prof.n >= 16 ? h->sweep_prof.p : nullptr;  // the sweep's counters are overwritten
-                if (pp.prof) GORSE_HIP_CHECK(hipMemsetAsync(pp.prof, 0, 16 * sizeof(unsigned long long), h->stream));
-                pp.nq = m2;
-                pp.cflag = h->rp_flag.p;
-                pp.N = h->N;
-                pp.d = d;
-                pp.metric = h->kernel_metric();
-                pp.k = k;
-                pp.prune0 = prune0;
-                pp.out_idx = h->res_idx.p;
-                pp.out_dist = h->res_dist.p;
-                pp.out_cnt = h->res_cnt.p;
-                GORSE_TRY(h->rp_sidx.ensure((size_t)m2 * kReplayCap));
-                GORSE_TRY(h->rp_sdst.ensure((size_t)m2 * kReplayCap));
-                GORSE_TRY(h->rp_scount.ensure((size_t)m2));
-                pp.sidx = h->rp_sidx.p;
-                pp.sdst = h->rp_sdst.p;
-                pp.scount = h->rp_scount.p;
-                const size_t rlds = ((size_t)2 * kReplayCap + (size_t)(1 + kGroupsPerBlock) * d + 4) * 4;
-                GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_tie_sort_kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-                tok = h->prof.begin(GORSE_PROF_TOPK_REPLAY, h->stream);
-                topk_tie_sort_kernel<<<dim3((unsigned)m2), dim3(kBlock), rlds, h->stream>>>(pp);
-                GORSE_HIP_CHECK(hipGetLastError());
-                // one lane per query (probe build, variant bit 19 / 16: the round-2 kernel, a wave per query)
-#ifdef GORSE_PROBE
-                const bool lanes = !(g_topk_variant & (1 << 19)) && !(g_topk_variant & 65536);
-#else
-                const bool lanes = true;
-#endif
-                if (lanes) {
-                    const int slots = k + 1;
-                    int qpw = 64;
-                    while (qpw > 16 && (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4 > (size_t)144 * 1024) qpw >>= 1;
-                    const size_t llds = (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4;
-                    auto launch_lanes = [&](auto tag) -> int32_t {
-                        constexpr int Q = decltype(tag)::value;
-                        GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_tie_replay_lane_kernel<Q>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
-                        topk_tie_replay_lane_kernel<Q><<<dim3((unsigned)ceil_div(m2, Q)), dim3(64), llds, h->stream>>>(pp, m2, slots);
-                        GORSE_HIP_CHECK(hipGetLastError());
-                        return GORSE_OK;
-                    };
-                    if (qpw == 64) GORSE_TRY(launch_lanes(std::integral_constant<int, 64>()));
-                    else if (qpw == 32) GORSE_TRY(launch_lanes(std::integral_constant<int, 32>()));
-                    else GORSE_TRY(launch_lanes(std::integral_constant<int, 16>()));
-                }
-#ifdef GORSE_PROBE
-                if (!lanes) {
-                    topk_tie_replay_kernel<<<dim3((unsigned)ceil_div(m2, 4)), dim3(256), 0, h->stream>>>(pp, m2, (g_topk_variant & 65536) ? 1 : 0);
-                    GORSE_HIP_CHECK(hipGetLastError());
-                }
-#endif
-                h->prof.end(tok, h->stream);
-                f2.resize((size_t)m2);
-                GORSE_HIP_CHECK(hipMemcpyAsync(f2.data(), h->rp_flag.p, (size_t)m2, hipMemcpyDeviceToHost, h->stream));
-                GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-                for (int64_t r = 0; r < m2; r++) {
-                    if (f2[r])
-                        rest.push_back(fb[f0 + r]);
-                    else
-                        h->n_tie++;
-                }
-            }
-        } else {
-            rest = fb;
-        }
-        // stage 3: whatever is left replays the reference literally over all N vectors (path A); its rows go into
-        // the chunk's device result arrays like everybody else's
-        if (!rest.empty()) {
-            h->n_fallback += (int64_t)rest.size();
-            const int64_t bq = topk_scan_block_queries(h);
-            std::vector<int64_t> ids((size_t)std::min<int64_t>(bq, (int64_t)rest.size()));
-            std::vector<int32_t> ti((size_t)ids.size() * k), tc(ids.size());
-            std::vector<float> td((size_t)ids.size() * k);
-            GORSE_TRY(h->qbuf.ensure(ids.size() * (size_t)d));
-            GORSE_TRY(h->qnorm.ensure(ids.size()));
-            GORSE_TRY(h->qidx.ensure(ids.size()));
-            for (size_t f0 = 0; f0 < rest.size(); f0 += (size_t)bq) {
-                const int64_t fm = std::min<int64_t>(bq, (int64_t)(rest.size() - f0));
-                for (int64_t r = 0; r < fm; r++) {
-                    const int64_t t = rest[f0 + r];
-                    ids[r] = stored_id(t);
-                    const float *src = by_vector ? Qf + t * d : h->X.p + ids[r] * d;
-                    GORSE_HIP_CHECK(hipMemcpyAsync(h->qbuf.p + r * d, src, (size_t)d * 4, hipMemcpyDeviceToDevice, h->stream));
-                    GORSE_HIP_CHECK(hipMemcpyAsync(h->qnorm.p + r, qn2 + t, 4, hipMemcpyDeviceToDevice, h->stream));
-                }
-                const int64_t *excl = nullptr;
-                if (!by_vector) {
-                    GORSE_HIP_CHECK(hipMemcpyAsync(h->qidx.p, ids.data(), (size_t)fm * 8, hipMemcpyHostToDevice, h->stream));
-                    excl = h->qidx.p;
-                }
-                GORSE_TRY(topk_scan_block(h, fm, excl, by_vector ? nullptr : ids.data(), k, prune0, ti.data(), td.data(), tc.data(),
-                                          /*reroute=*/false));  // these queries come FROM the replay: the literal kernel ends it
-                for (int64_t r = 0; r < fm; r++) {
-                    const int64_t t = rest[f0 + r];
-                    GORSE_HIP_CHECK(hipMemcpyAsync(h->res_idx.p + t * k, ti.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
-                    GORSE_HIP_CHECK(hipMemcpyAsync(h->res_dist.p + t * k, td.data() + r * k, (size_t)k * 4, hipMemcpyHostToDevice, h->stream));
-                    GORSE_HIP_CHECK(hipMemcpyAsync(h->res_cnt.p + t, tc.data() + r, 4, hipMemcpyHostToDevice, h->stream));
-                }
-                GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-            }
-        }
+        GORSE_TRY(chunk_finish(h, cs));
         if (idx_out)
             GORSE_HIP_CHECK(hipMemcpyAsync(idx_out + c0 * k, h->res_idx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, h->stream));
         if (dist_out)
@@ -2810,3 +2948,279 @@ int32_t topk_mfma_search(gorse_topk *h, const int64_t *qid_host, int64_t q_conti
 }
 
 }  // namespace gorse
+
+// ---- triangle-sharded all-pairs search (top-k row) --------------------------------------------
+// Query-row sharding gives a rank the saving of the symmetric sweep on its own diagonal square only (1 / world^2 of the matrix).
+// Here the TRIANGLE is sharded: rank r sweeps the query blocks C with C % world == r -- each block's own lists, and what it finds
+// for the rows of every earlier block as queries, whoever owns them -- so the union over the ranks is exactly the single-rank
+// symmetric sweep, every score still serving both of its queries.  The pilots are sharded by contiguous slices of the queries
+// (their thresholds are all-gathered: 4 bytes per query); after the sweep a rank holds partial foreign lists of queries the
+// OTHER ranks own, which travel to the owners (pack -> all-to-all -> unpack: ~130 entries of 8 bytes per query in all); rescoring
+// and tie path then run on the owner.  The exchange itself is the caller's (gorse_amd/dist.py: torch.distributed, or host memory when
+// the ranks are emulated on one device); every buffer that crosses the boundary may be host or device memory.
+namespace {
+__device__ __forceinline__ int64_t tri_query_of(int64_t i, int rank, int world) {  // the i-th query a rank owns
+    return ((i / kSymBQ) * world + rank) * (int64_t)kSymBQ + i % kSymBQ;
+}
+__global__ void tri_pack_counts_kernel(const int32_t *__restrict__ fcnt, const uint8_t *__restrict__ cflag, int64_t n_owned, int dest,
+                                       int world, int32_t *__restrict__ counts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_owned; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = tri_query_of(i, dest, world);
+        const int32_t c = fcnt[t];
+        // -1 = "this part of the list is useless": a staging overflow here (flag 1; flag 2 = no pilot threshold is known to every
+        // rank) or more entries than a list holds -- the owner then sends the query down the tie path
+        counts[i] = (cflag[t] == 1 || c > kCapF) ? -1 : c;
+    }
+}
+// exclusive prefix of max(counts, 0) by ONE workgroup (n <= a million words: two passes over a few megabytes)
+__global__ __launch_bounds__(1024) void tri_scan_kernel(const int32_t *__restrict__ counts, int64_t n, int64_t *__restrict__ offsets) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024, a = tid * per, b = a + per < n ? a + per : n;
+    long long s = 0;
+    for (int64_t i = a; i < b; i++) s += counts[i] > 0 ? counts[i] : 0;
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        offsets[n] = run;
+    }
+    __syncthreads();
+    long long run = part[tid];
+    for (int64_t i = a; i < b; i++) {
+        offsets[i] = run;
+        run += counts[i] > 0 ? counts[i] : 0;
+    }
+}
+__global__ void tri_pack_entries_kernel(const uint2 *__restrict__ fbuf, const int32_t *__restrict__ counts, const int64_t *__restrict__ offsets,
+                                        int64_t n_owned, int dest, int world, uint2 *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_owned; i += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int c = counts[i];
+        const uint2 *src = fbuf + tri_query_of(i, dest, world) * kCapF;
+        uint2 *dst = out + offsets[i];
+        for (int e = lane; e < c; e += 64) dst[e] = src[e];
+    }
+}
+__global__ void tri_unpack_kernel(uint2 *__restrict__ fbuf, int32_t *__restrict__ fcnt, const int32_t *__restrict__ counts,
+                                  const int64_t *__restrict__ offsets, const uint2 *__restrict__ entries, int64_t n_owned, int rank, int world) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n_owned; i += (int64_t)gridDim.x * (blockDim.x >> 6)) {
+        const int64_t t = tri_query_of(i, rank, world);
+        const int c = counts[i];
+        const int base = fcnt[t];  // (every lane reads it before lane 0 writes: a wave runs in step)
+        if (c < 0) {
+            if (lane == 0) fcnt[t] = kCapF + 1;  // overflowed on the sender's side: topk_rescore_kernel flags the query
+            continue;
+        }
+        const uint2 *src = entries + offsets[i];
+        uint2 *dst = fbuf + t * kCapF;
+        for (int e = lane; e < c; e += 64)
+            if (base + e < kCapF) dst[base + e] = src[e];
+        if (lane == 0) fcnt[t] = base + c;  // may pass kCapF: the list overflowed at its owner
+    }
+}
+
+struct TriGeom {
+    int64_t nq, nblk;
+    int world;
+    int64_t blocks_of(int r) const { return nblk > r ? (nblk - r + world - 1) / world : 0; }
+    int64_t owned(int r) const {  // queries rank r owns: whole blocks, but for the globally last one
+        const int64_t nb = blocks_of(r);
+        if (nb == 0) return 0;
+        const int64_t last = r + (nb - 1) * world;  // its last block
+        return (nb - 1) * kSymBQ + std::min<int64_t>(kSymBQ, nq - last * kSymBQ);
+    }
+    void slice(int r, int64_t *lo, int64_t *hi) const {  // the queries whose pilots rank r runs: whole blocks, even split
+        *lo = std::min(nq, nblk * r / world * kSymBQ);
+        *hi = std::min(nq, nblk * (r + 1) / world * kSymBQ);
+    }
+};
+TriGeom tri_geom(const ChunkState &cs) { return TriGeom{cs.m, ceil_div(cs.m, kSymBQ), cs.tri_world}; }
+
+int32_t tri_state(gorse_topk *h, int stage_min, ChunkState **out) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    ChunkState *cs = h->cstate;
+    if (!cs || cs->tri_stage < stage_min) return fail(GORSE_ERR_INVALID, "gorse_topk_tri_*: called out of order (stage %d, needs %d)", cs ? cs->tri_stage : 0, stage_min);
+    GORSE_TRY(h->use());
+    *out = cs;
+    return GORSE_OK;
+}
+}  // namespace
+
+gorse::TopkChunkState *gorse_topk::chunk_state() {
+    if (!cstate) cstate = new gorse::TopkChunkState();
+    return cstate;
+}
+namespace gorse {
+void topk_mfma_release(gorse_topk *h) {
+    delete h->cstate;
+    h->cstate = nullptr;
+}
+}  // namespace gorse
+
+extern "C" int32_t gorse_topk_tri_begin(gorse_topk *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t rank, int32_t world) {
+    if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    if (q_begin < 0 || q_end > h->N || q_begin >= q_end || k <= 0) return fail(GORSE_ERR_RANGE, "bad query range");
+    if (world < 1 || rank < 0 || rank >= world) return fail(GORSE_ERR_INVALID, "rank %d of %d", rank, world);
+    const int64_t nq = q_end - q_begin;
+    GORSE_TRY(h->use());
+    // what the symmetric sweep needs (chunk_main): a warm-started MFMA search over one chunk that starts on a tile boundary
+    const bool ok = topk_mfma_usable(h, nq, k) && nq <= kChunkQ && sweep_sym_kp(h->kp) && topk_rows_per_tile() == 128 && q_begin % 128 == 0 &&
+                    nq >= 2 * kSymBQ && k + 1 >= 8 && h->N >= (int64_t)1 << 17 && !(g_topk_variant & ((1 << 23) | 256));
+    if (!ok)
+        return fail(GORSE_ERR_INVALID, "this search has no symmetric form (operand depth, a range that does not start on a 128-row boundary, fewer than "
+                                       "%d queries or more than %lld, an index of fewer than 2^17 rows): shard its query rows instead", 2 * kSymBQ, (long long)kChunkQ);
+    ChunkState &cs = *h->chunk_state();
+    GORSE_TRY(search_setup(h, cs, nullptr, q_begin, nullptr, nq, k, 0));
+    cs.c0 = 0, cs.m = nq, cs.tri_rank = rank, cs.tri_world = world;
+    GORSE_TRY(chunk_prepare(h, cs));
+    if (!cs.warm) return fail(GORSE_ERR_INVALID, "the sweep of this search is not warm-started");
+    GORSE_TRY(h->f0.ensure((size_t)cs.mb));
+    GORSE_TRY(h->f1.ensure((size_t)cs.mb));
+    tri_geom(cs).slice(rank, &cs.tri_lo, &cs.tri_hi);
+    const int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
+    GORSE_TRY(chunk_pilots(h, cs, cs.tri_lo, cs.tri_hi));
+    h->prof.end(tok, h->stream);
+    cs.tri_stage = 1;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_tri_slice(gorse_topk *h, int32_t rank, int64_t *lo, int64_t *hi, int64_t *owned) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 1, &cs));
+    if (rank < 0 || rank >= cs->tri_world) return fail(GORSE_ERR_INVALID, "rank %d of %d", rank, cs->tri_world);
+    int64_t a, b;
+    tri_geom(*cs).slice(rank, &a, &b);
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+    if (owned) *owned = tri_geom(*cs).owned(rank);
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_tri_thresholds_get(gorse_topk *h, int64_t lo, int64_t hi, float *dst) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 1, &cs));
+    if (lo < 0 || hi > cs->m || lo > hi || !dst) return fail(GORSE_ERR_RANGE, "bad slice");
+    GORSE_HIP_CHECK(hipMemcpyAsync(dst, h->f0.p + lo, (size_t)(hi - lo) * 4, hipMemcpyDefault, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+extern "C" int32_t gorse_topk_tri_thresholds_put(gorse_topk *h, int64_t lo, int64_t hi, const float *src) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 1, &cs));
+    if (lo < 0 || hi > cs->m || lo > hi || !src) return fail(GORSE_ERR_RANGE, "bad slice");
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->f0.p + lo, src, (size_t)(hi - lo) * 4, hipMemcpyDefault, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the source may be reused
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_tri_sweep(gorse_topk *h) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 1, &cs));
+    const int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
+    GORSE_TRY(chunk_main(h, *cs));
+    h->prof.end(tok, h->stream);
+    if (!cs->sym) return fail(GORSE_ERR_INVALID, "the main sweep did not take the symmetric form");
+    cs->tri_stage = 2;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_tri_pack(gorse_topk *h, int32_t dest, int64_t *n_counts, int64_t *n_entries) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 2, &cs));
+    if (dest < 0 || dest >= cs->tri_world || dest == cs->tri_rank) return fail(GORSE_ERR_INVALID, "bad destination rank %d", dest);
+    const int64_t n = tri_geom(*cs).owned(dest);
+    GORSE_TRY(h->tri_counts.ensure((size_t)std::max<int64_t>(n, 1)));
+    GORSE_TRY(h->tri_offsets.ensure((size_t)n + 1));
+    long long total = 0;
+    if (n > 0) {
+        tri_pack_counts_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 2048)), dim3(256), 0, h->stream>>>(
+            h->fcnt.p, h->cflag.p, n, dest, cs->tri_world, h->tri_counts.p);
+        tri_scan_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(h->tri_counts.p, n, reinterpret_cast<int64_t *>(h->tri_offsets.p));
+        GORSE_HIP_CHECK(hipGetLastError());
+        GORSE_HIP_CHECK(hipMemcpyAsync(&total, h->tri_offsets.p + n, 8, hipMemcpyDeviceToHost, h->stream));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        GORSE_TRY(h->tri_entries.ensure((size_t)std::max<long long>(total, 1)));
+        if (total > 0) {
+            tri_pack_entries_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), 8192)), dim3(256), 0, h->stream>>>(
+                h->fbuf.p, h->tri_counts.p, reinterpret_cast<const int64_t *>(h->tri_offsets.p), n, dest, cs->tri_world, h->tri_entries.p);
+            GORSE_HIP_CHECK(hipGetLastError());
+        }
+    }
+    h->tri_packed_counts = n, h->tri_packed_entries = total;
+    if (n_counts) *n_counts = n;
+    if (n_entries) *n_entries = total;
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_tri_pack_read(gorse_topk *h, int32_t *counts, uint64_t *entries) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 2, &cs));
+    if (counts && h->tri_packed_counts > 0)
+        GORSE_HIP_CHECK(hipMemcpyAsync(counts, h->tri_counts.p, (size_t)h->tri_packed_counts * 4, hipMemcpyDefault, h->stream));
+    if (entries && h->tri_packed_entries > 0)
+        GORSE_HIP_CHECK(hipMemcpyAsync(entries, h->tri_entries.p, (size_t)h->tri_packed_entries * 8, hipMemcpyDefault, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_tri_unpack(gorse_topk *h, int32_t src, const int32_t *counts, int64_t n_counts, const uint64_t *entries,
+                                         int64_t n_entries) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 2, &cs));
+    if (src < 0 || src >= cs->tri_world || src == cs->tri_rank) return fail(GORSE_ERR_INVALID, "bad source rank %d", src);
+    const int64_t n = tri_geom(*cs).owned(cs->tri_rank);
+    if (n_counts != n) return fail(GORSE_ERR_INVALID, "rank %d owns %lld queries, the message holds %lld", cs->tri_rank, (long long)n, (long long)n_counts);
+    if (n == 0) return GORSE_OK;
+    if (!counts || (n_entries > 0 && !entries) || n_entries < 0) return fail(GORSE_ERR_INVALID, "NULL message");
+    GORSE_TRY(h->tri_in_counts.ensure((size_t)n));
+    GORSE_TRY(h->tri_offsets.ensure((size_t)n + 1));
+    GORSE_TRY(h->tri_in_entries.ensure((size_t)std::max<int64_t>(n_entries, 1)));
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->tri_in_counts.p, counts, (size_t)n * 4, hipMemcpyDefault, h->stream));
+    if (n_entries > 0) GORSE_HIP_CHECK(hipMemcpyAsync(h->tri_in_entries.p, entries, (size_t)n_entries * 8, hipMemcpyDefault, h->stream));
+    tri_scan_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(h->tri_in_counts.p, n, reinterpret_cast<int64_t *>(h->tri_offsets.p));
+    long long total = 0;
+    GORSE_HIP_CHECK(hipMemcpyAsync(&total, h->tri_offsets.p + n, 8, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (total != n_entries) return fail(GORSE_ERR_INVALID, "the message's counts add up to %lld entries, it holds %lld", total, (long long)n_entries);
+    tri_unpack_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), 8192)), dim3(256), 0, h->stream>>>(
+        h->fbuf.p, h->fcnt.p, h->tri_in_counts.p, reinterpret_cast<const int64_t *>(h->tri_offsets.p), h->tri_in_entries.p, n, cs->tri_rank, cs->tri_world);
+    GORSE_HIP_CHECK(hipGetLastError());
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the caller's buffers may be reused
+    return GORSE_OK;
+}
+
+extern "C" int32_t gorse_topk_tri_finish(gorse_topk *h, int32_t *idx_out, float *dist_out) {
+    ChunkState *cs;
+    GORSE_TRY(tri_state(h, 2, &cs));
+    GORSE_TRY(chunk_finish(h, *cs));
+    // the rows of the queries this rank owns into the caller's nq x k arrays (the others are left alone): one strided copy for
+    // the whole blocks, one for a partial last block
+    const TriGeom g = tri_geom(*cs);
+    const int k = cs->k, W = cs->tri_world, r = cs->tri_rank;
+    const int64_t nb = g.blocks_of(r);
+    if (nb > 0 && (idx_out || dist_out)) {
+        const int64_t last = r + (nb - 1) * W;
+        const bool partial = (last + 1) * kSymBQ > g.nq;
+        const int64_t full = partial ? nb - 1 : nb;
+        const size_t width = (size_t)kSymBQ * k * 4, pitch = width * W, first = (size_t)r * kSymBQ * k;
+        if (full > 0) {
+            if (idx_out) GORSE_HIP_CHECK(hipMemcpy2DAsync(idx_out + first, pitch, h->res_idx.p + first, pitch, width, (size_t)full, hipMemcpyDeviceToHost, h->stream));
+            if (dist_out) GORSE_HIP_CHECK(hipMemcpy2DAsync(dist_out + first, pitch, h->res_dist.p + first, pitch, width, (size_t)full, hipMemcpyDeviceToHost, h->stream));
+        }
+        if (partial) {
+            const size_t at = (size_t)last * kSymBQ * k, bytes = (size_t)(g.nq - last * kSymBQ) * k * 4;
+            if (idx_out) GORSE_HIP_CHECK(hipMemcpyAsync(idx_out + at, h->res_idx.p + at, bytes, hipMemcpyDeviceToHost, h->stream));
+            if (dist_out) GORSE_HIP_CHECK(hipMemcpyAsync(dist_out + at, h->res_dist.p + at, bytes, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+    cs->tri_stage = 3;
+    return GORSE_OK;
+}

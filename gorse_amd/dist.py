@@ -130,6 +130,134 @@ def refresh_neighbors_sharded(engine, comm, k, gather=True):
             np.concatenate([g_cnt[r, :h - l] for r, (l, h) in enumerate(spans)]))
 
 
+def tri_owned_rows(n_rows, rank, world, block=512):
+    """Rows (of an all-pairs search over n_rows stored rows) whose results rank `rank` of a TRIANGLE-sharded search ends up
+    holding: the query blocks (512 rows: a workgroup of the symmetric sweep) rank, rank + world, ..."""
+    blocks = np.arange(rank, -(-n_rows // block), world, dtype=np.int64)
+    rows = (blocks[:, None] * block + np.arange(block, dtype=np.int64)[None, :]).ravel()
+    return rows[rows < n_rows]
+
+
+def refresh_neighbors_triangle(engine, comm, k, gather=True):
+    """The dense all-pairs refresh with the TRIANGLE of the symmetric sweep sharded over the ranks (include/gorse_hip.h,
+    gorse_topk_tri_*): rank r sweeps the query blocks r, r + world, ... -- their own candidate lists and what
+    they find for the rows of every earlier block -- so that the ranks together do exactly the single-rank symmetric sweep, where
+    refresh_neighbors_sharded (query rows split) keeps the symmetric saving on each rank's diagonal square only.  Two exchanges:
+    an all-gather of the pilot thresholds (4 bytes per query) in front of the main sweep, an all-to-all of the foreign candidate
+    lists (~130 entries of 8 bytes per query in all) behind it; rescoring and tie path run on a query's owner.
+    engine: begin(k, rank, world), slice(r) -> (lo, hi, owned), thresholds() -> own slice, put_thresholds(lo, hi, a), sweep(),
+    pack(dest) -> (counts, entries), unpack(src, counts, entries), finish() -> (idx, dist) with this rank's rows filled in.
+    comm: all_gather_var(array) -> list per rank, all_to_all_var(list per dest) -> list per source (TorchComm), or None.
+    Returns (idx, dist) of all n_rows rows when gather (every rank), else this rank's arrays (foreign rows -1 / +inf)."""
+    world = comm.world if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    engine.begin(k, rank, world)
+    if world > 1:
+        parts = comm.all_gather_var(engine.thresholds())
+        for r, a in enumerate(parts):
+            if r != rank:
+                lo, hi, _ = engine.slice(r)
+                engine.put_thresholds(lo, hi, a)
+    engine.sweep()
+    if world > 1:
+        empty = (np.zeros(0, np.int32), np.zeros(0, np.uint64))
+        out = [engine.pack(d) if d != rank else empty for d in range(world)]
+        counts_in = comm.all_to_all_var([c for c, _ in out])
+        entries_in = comm.all_to_all_var([e.view(np.int64) for _, e in out])
+        for s_ in range(world):
+            if s_ != rank:
+                engine.unpack(s_, counts_in[s_], entries_in[s_].view(np.uint64))
+    idx, dist = engine.finish()
+    if world == 1 or not gather or idx is None:
+        return idx, dist
+    own = tri_owned_rows(engine.n_rows, rank, world)
+    g_idx = comm.all_gather_var(np.ascontiguousarray(idx[own]).ravel())
+    g_dist = comm.all_gather_var(np.ascontiguousarray(dist[own]).ravel())
+    for r in range(world):
+        rows = tri_owned_rows(engine.n_rows, r, world)
+        idx[rows] = g_idx[r].reshape(rows.size, k)
+        dist[rows] = g_dist[r].reshape(rows.size, k)
+    return idx, dist
+
+
+def refresh_neighbors_triangle_local(engines, k, timings=None):
+    """The same search with all `world` ranks in THIS process, one engine (handle) per rank -- N devices of one node driven by one
+    process (the Go master's mode), or N handles on ONE device: the emulation the single-GPU box can run, every exchange through
+    host memory.  The protocol is refresh_neighbors_triangle's, stage by stage over all ranks.  timings (a dict): per rank the
+    seconds of its stages [pilots, sweep, pack, unpack, finish], measured around calls that end synchronised."""
+    import time
+    world = len(engines)
+    tm = [[0.0] * 5 for _ in range(world)]
+
+    def timed(r, stage, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        engines[r].synchronize()
+        tm[r][stage] += time.perf_counter() - t0
+        return out
+    for r, e in enumerate(engines):
+        timed(r, 0, lambda: e.begin(k, r, world))
+    thr = [e.thresholds() for e in engines]
+    for r, e in enumerate(engines):
+        for s_ in range(world):
+            if s_ != r:
+                lo, hi, _ = e.slice(s_)
+                e.put_thresholds(lo, hi, thr[s_])
+    for r, e in enumerate(engines):
+        timed(r, 1, e.sweep)
+    msgs = {}
+    for r, e in enumerate(engines):
+        for d in range(world):
+            if d != r:
+                msgs[(r, d)] = timed(r, 2, lambda: e.pack(d))
+    for (src, d), (c, ent) in msgs.items():
+        timed(d, 3, lambda: engines[d].unpack(src, c, ent))
+    idx = dist = None
+    for r, e in enumerate(engines):
+        idx, dist = timed(r, 4, lambda: e.finish(idx, dist))  # every rank writes its own rows into the same arrays
+    if timings is not None:
+        timings["per_rank_seconds"] = tm
+        timings["message_bytes"] = {"%d->%d" % kd: int(c.nbytes + ent.nbytes) for kd, (c, ent) in msgs.items()}
+    return idx, dist
+
+
+class HipTriEngine:
+    """A gorse_topk handle (capi.TopK) as the engine of refresh_neighbors_triangle: messages as host numpy arrays."""
+
+    def __init__(self, index, fetch=True):
+        self.index, self.n_rows, self.fetch = index, index.N, fetch
+        self.rank = 0
+
+    def begin(self, k, rank, world):
+        self.rank = rank
+        self.index.tri_begin(k, rank, world)
+
+    def slice(self, r):
+        return self.index.tri_slice(r)
+
+    def thresholds(self):
+        lo, hi, _ = self.index.tri_slice(self.rank)
+        return self.index.tri_thresholds_get(lo, hi)
+
+    def put_thresholds(self, lo, hi, a):
+        self.index.tri_thresholds_put(lo, hi, a)
+
+    def sweep(self):
+        self.index.tri_sweep()
+
+    def pack(self, dest):
+        return self.index.tri_pack(dest)
+
+    def unpack(self, src, counts, entries):
+        self.index.tri_unpack(src, counts, entries)
+
+    def finish(self, idx=None, dist=None):
+        return self.index.tri_finish(idx, dist, fetch=self.fetch)
+
+    def synchronize(self):
+        self.index.synchronize()
+
+
 class HipNeighborsEngine:
     """A gorse_sparse (capi.Sparse) or gorse_topk (capi.TopK) handle as the engine of refresh_neighbors_sharded."""
 
@@ -274,6 +402,59 @@ class TorchComm:
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
+
+    def _xdev(self):
+        """where a message of host arrays travels: the GPU under nccl (= RCCL), host memory under gloo"""
+        import torch
+        return torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def all_gather_var(self, a):
+        """all-gather of 1-D numpy arrays of one dtype whose lengths differ by rank -> the list of every rank's array"""
+        import torch
+        a = np.ascontiguousarray(a)
+        if self.world == 1:
+            return [a]
+        dev = self._xdev()
+        n = torch.tensor([a.size], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n)
+        sizes = [int(x.item()) for x in sizes]
+        width = max(max(sizes), 1)
+        mine = torch.zeros(width, dtype=torch.from_numpy(a[:0]).dtype, device=dev)
+        mine[:a.size] = torch.from_numpy(a).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return [p[:sizes[r]].cpu().numpy() for r, p in enumerate(parts)]
+
+    def all_to_all_var(self, out):
+        """out[d] = the 1-D numpy array (one dtype for all) this rank sends to rank d -> the list of what every rank sent here.
+        Sizes first (an all-gather of the size row), then one point-to-point pair per (source, destination) -- send / recv exist
+        under both RCCL and gloo."""
+        import torch
+        if self.world == 1:
+            return [np.ascontiguousarray(out[0])]
+        dev = self._xdev()
+        out = [np.ascontiguousarray(o) for o in out]
+        row = torch.tensor([o.size for o in out], dtype=torch.int64, device=dev)
+        rows = [torch.zeros_like(row) for _ in range(self.world)]
+        self.dist.all_gather(rows, row)
+        sizes_in = [int(rows[s_][self.rank].item()) for s_ in range(self.world)]
+        tdt = torch.from_numpy(out[0][:0]).dtype
+        recv = [torch.empty(max(sizes_in[s_], 0), dtype=tdt, device=dev) for s_ in range(self.world)]
+        send = [torch.from_numpy(o).to(dev) for o in out]
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            if out[peer].size:
+                ops.append(self.dist.P2POp(self.dist.isend, send[peer], peer))
+            if sizes_in[peer]:
+                ops.append(self.dist.P2POp(self.dist.irecv, recv[peer], peer))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        recv[self.rank] = send[self.rank]
+        return [r_.cpu().numpy() for r_ in recv]
 
 
 class HipEngine:

@@ -280,6 +280,36 @@ int32_t gorse_topk_search_vector(gorse_topk *h, const void *qv /*host*/, int64_t
  * Results stay on the device unless host pointers are given (either may be NULL). */
 int32_t gorse_topk_all_pairs(gorse_topk *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t *idx_out /*host or NULL*/,
                              float *dist_out /*host or NULL*/);
+/* ---- triangle-sharded all-pairs search over W GPUs (top-k row) -----------------------------------------------------
+ * gorse_topk_all_pairs over the stored rows [q_begin, q_end) takes the SYMMETRIC form of the sweep: every score of the square block
+ * serves both of its queries.  Sharding the QUERY ROWS over W ranks keeps that saving on each rank's diagonal square only; these
+ * calls shard the TRIANGLE instead -- rank r sweeps the query blocks (512 queries) C with C % W == r -- so the W ranks together do
+ * exactly the single-rank sweep.  One handle per rank, every rank holds the whole index; the calls of one search, in order:
+ *   gorse_topk_tri_begin            the search's buffers + the PILOT sweeps of this rank's slice of the queries (slice r of W, whole
+ *                                   blocks); GORSE_ERR_INVALID when the search has no symmetric form (shard its query rows then)
+ *   gorse_topk_tri_slice            which queries a rank's pilots cover, how many queries it owns (arithmetic: any rank can be asked)
+ *   gorse_topk_tri_thresholds_get / _put   the pilot thresholds of a slice out of / into the handle: an ALL-GATHER of 4 bytes per
+ *                                   query, every rank must hold all of them before ...
+ *   gorse_topk_tri_sweep            ... the main sweep of this rank's blocks: own lists, and foreign lists for EVERY earlier block's rows
+ *   gorse_topk_tri_pack(dest) / _pack_read   the foreign lists this rank holds for the queries `dest` owns, as one message: a count per
+ *                                   owned query (-1: the sender's part overflowed), then the (key, row) entries end to end
+ *   gorse_topk_tri_unpack(src, ...) a message from `src` appended to this rank's own queries' foreign lists: an ALL-TO-ALL of ~130
+ *                                   entries x 8 bytes per query in all
+ *   gorse_topk_tri_finish           exact rescoring + tie path for the queries this rank owns; their rows are written into the
+ *                                   caller's nq x k arrays (the other rows are left alone; NULL = results stay on the device)
+ * The exchange itself is the caller's (integration/go/common/ann/bruteforce_hip.go: RCCL; gorse_amd/dist.py: torch.distributed,
+ * or host memory when the ranks are emulated on one device): every buffer that crosses this boundary may be HOST OR DEVICE memory.
+ * Results are those of gorse_topk_all_pairs, row for row, bit for bit (tests/test_gpu_topk_tri.py). */
+int32_t gorse_topk_tri_begin(gorse_topk *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t rank, int32_t world);
+int32_t gorse_topk_tri_slice(gorse_topk *h, int32_t rank, int64_t *lo /*out*/, int64_t *hi /*out*/, int64_t *owned /*out*/);
+int32_t gorse_topk_tri_thresholds_get(gorse_topk *h, int64_t lo, int64_t hi, float *dst /*host or device*/);
+int32_t gorse_topk_tri_thresholds_put(gorse_topk *h, int64_t lo, int64_t hi, const float *src /*host or device*/);
+int32_t gorse_topk_tri_sweep(gorse_topk *h);
+int32_t gorse_topk_tri_pack(gorse_topk *h, int32_t dest, int64_t *n_counts /*out*/, int64_t *n_entries /*out*/);
+int32_t gorse_topk_tri_pack_read(gorse_topk *h, int32_t *counts /*host or device, n_counts*/, uint64_t *entries /*host or device, n_entries*/);
+int32_t gorse_topk_tri_unpack(gorse_topk *h, int32_t src, const int32_t *counts, int64_t n_counts, const uint64_t *entries,
+                              int64_t n_entries);
+int32_t gorse_topk_tri_finish(gorse_topk *h, int32_t *idx_out /*host nq x k or NULL*/, float *dist_out /*host nq x k or NULL*/);
 int32_t gorse_topk_synchronize(gorse_topk *h);
 #define GORSE_PROF_TOPK_SCORE 0   /* path A: dist_kernel (pair-at-a-time scan in the reference's order)      */
 #define GORSE_PROF_TOPK_RESCORE 1 /* path A: select_fast_kernel (+ the literal container/heap select_kernel)    */

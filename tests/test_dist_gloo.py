@@ -542,3 +542,125 @@ def test_library_communicator_setup_never_leaves_a_rank_behind(tmp_path):
     mp.spawn(_libcomm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() for r in range(world)]
     assert all(g.startswith("raised") and g.endswith("|0") for g in got), got
+
+
+# ---- the triangle-sharded dense all-pairs search: protocol + exchange over gloo with a stand-in engine ---------------------------
+class NumpyTriEngine:
+    """Stands in for a gorse_topk handle behind gorse_amd.dist.refresh_neighbors_triangle (what HipTriEngine drives on a GPU: include/
+    gorse_hip.h gorse_topk_tri_*): exact -dot scores in numpy, the SAME ownership, slices and messages -- rank r runs the pilots of its
+    slice (threshold = k-th best over every 4th row: a lower bound of the true k-th best), sweeps the query blocks r, r + world, ...
+    (own lists: rows of the blocks up to its own; foreign lists: for the rows of every EARLIER block, its columns that reach the row's
+    threshold), packs per destination a count per owned query + (key, row) entries, and ranks own + foreign candidates at the end."""
+    BLOCK = 512
+
+    def __init__(self, X):
+        self.X, self.n_rows = X.astype(np.float64), X.shape[0]
+        self.S = -(self.X @ self.X.T)  # distances: -dot
+        np.fill_diagonal(self.S, np.inf)
+
+    def _blocks(self, r):
+        return list(range(r, -(-self.n_rows // self.BLOCK), self.world))
+
+    def _rows_of(self, c):
+        return np.arange(c * self.BLOCK, min((c + 1) * self.BLOCK, self.n_rows))
+
+    def begin(self, k, rank, world):
+        self.k, self.rank, self.world = k, rank, world
+        self.thr = np.full(self.n_rows, np.nan)
+        lo, hi, _ = self.slice(rank)
+        sample = np.arange(0, self.n_rows, 4)
+        for q in range(lo, hi):
+            self.thr[q] = np.sort(self.S[q, sample])[k]  # (k + 1)-th smallest of a sample: >= the true k-th smallest distance
+        self.own, self.foreign = {}, {q: [] for q in range(self.n_rows)}
+
+    def slice(self, r):
+        nblk = -(-self.n_rows // self.BLOCK)
+        lo, hi = nblk * r // self.world * self.BLOCK, nblk * (r + 1) // self.world * self.BLOCK
+        owned = sum(self._rows_of(c).size for c in self._blocks(r))
+        return min(lo, self.n_rows), min(hi, self.n_rows), owned
+
+    def thresholds(self):
+        lo, hi, _ = self.slice(self.rank)
+        return self.thr[lo:hi].astype(np.float64)
+
+    def put_thresholds(self, lo, hi, a):
+        self.thr[lo:hi] = a
+
+    def sweep(self):
+        assert not np.isnan(self.thr).any()  # every rank's slice has arrived
+        for c in self._blocks(self.rank):
+            cols = self._rows_of(c)
+            upto = min((c + 1) * self.BLOCK, self.n_rows)
+            for q in cols:  # own lists: the rows of the blocks 0 .. c
+                r = np.flatnonzero(self.S[q, :upto] <= self.thr[q])
+                self.own[q] = list(zip(self.S[q, r].tolist(), r.tolist()))
+            for r in range(c * self.BLOCK):  # the earlier blocks' rows as queries: candidates among this block's columns
+                hit = cols[self.S[r, cols] <= self.thr[r]]
+                self.foreign[r].extend(zip(self.S[r, hit].tolist(), hit.tolist()))
+
+    def _owned(self, r):
+        return np.concatenate([self._rows_of(c) for c in self._blocks(r)]) if self._blocks(r) else np.zeros(0, np.int64)
+
+    def pack(self, dest):
+        qs = self._owned(dest)
+        counts = np.array([len(self.foreign[q]) for q in qs], np.int32)
+        ent = [np.float32(d_).view(np.uint32).astype(np.uint64) << np.uint64(32) | np.uint64(i) for q in qs for d_, i in self.foreign[q]]
+        return counts, np.array(ent, np.uint64)
+
+    def unpack(self, src, counts, entries):
+        qs, at = self._owned(self.rank), 0
+        assert counts.size == qs.size and int(counts.sum()) == entries.size
+        for q, c in zip(qs, counts):
+            for e in entries[at:at + c]:
+                self.foreign[q].append((float(np.uint32(e >> np.uint64(32)).view(np.float32)), int(e & np.uint64(0xffffffff))))
+            at += c
+
+    def finish(self, idx=None, dist=None):
+        if idx is None:
+            idx, dist = np.full((self.n_rows, self.k), -1, np.int32), np.full((self.n_rows, self.k), np.inf, np.float32)
+        for q in self._owned(self.rank):
+            cand = sorted(set((np.float32(d_), i) for d_, i in self.own[q] + self.foreign[q]))[:self.k]
+            idx[q], dist[q] = [i for _, i in cand], [d_ for d_, _ in cand]
+        return idx, dist
+
+    def synchronize(self):
+        pass
+
+
+def _tri_problem():
+    rng = np.random.default_rng(17)
+    return rng.standard_normal((1300, 12)).astype(np.float32), 7  # three blocks, the last one partial
+
+
+def _tri_worker(rank, world, port, out):
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    X, k = _tri_problem()
+    idx, dst = gdist.refresh_neighbors_triangle(NumpyTriEngine(X), gdist.TorchComm(), k)
+    np.save(os.path.join(out, "ti%d.npy" % rank), idx)
+    np.save(os.path.join(out, "td%d.npy" % rank), dst)
+    dist.destroy_process_group()
+
+
+def test_triangle_sharded_search_protocol_over_gloo(tmp_path):
+    """refresh_neighbors_triangle over a world of 2 and 3 (gloo): thresholds all-gathered, foreign lists through the all-to-all of
+    variable-size messages, every rank ends with ALL rows, equal to the brute force; and the one-process form
+    (refresh_neighbors_triangle_local: what emulates the ranks on one GPU) gives the same rows."""
+    X, k = _tri_problem()
+    S = -(X.astype(np.float64) @ X.astype(np.float64).T)
+    np.fill_diagonal(S, np.inf)
+    want = np.argsort(S, axis=1, kind="stable")[:, :k]
+    for world in (2, 3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_tri_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+        for r in range(world):
+            assert np.array_equal(np.load(tmp_path / ("ti%d.npy" % r)), want), (world, r)
+        tm = {}
+        idx, _ = gdist.refresh_neighbors_triangle_local([NumpyTriEngine(X) for _ in range(world)], k, timings=tm)
+        assert np.array_equal(idx, want) and len(tm["message_bytes"]) == world * (world - 1)
+    # ownership arithmetic: the ranks' rows partition the index, block by block
+    for world in (1, 2, 3, 8):
+        rows = np.concatenate([gdist.tri_owned_rows(1300, r, world) for r in range(world)])
+        assert np.array_equal(np.sort(rows), np.arange(1300))

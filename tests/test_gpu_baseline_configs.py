@@ -162,6 +162,28 @@ def elementwise_rel(got, ref):
     return float((np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30)).max())
 
 
+def _als_rows_fp64(A, B, ptr, idx, bptr, w, reg, rows):
+    """the reference's half-sweep recurrence (model.go:659-690 / 707-738) for the given rows in float64, S in float64 too"""
+    has = np.diff(bptr) > 0
+    B64 = B.astype(np.float64)
+    S = B64[has].T @ B64[has]
+    out = np.empty((len(rows), A.shape[1]), np.float64)
+    for t, u in enumerate(rows):
+        Bu = B64[idx[ptr[u]:ptr[u + 1]]]
+        pu = A[u].astype(np.float64)
+        pred = Bu @ pu
+        for f in range(A.shape[1]):
+            q = Bu[:, f]
+            res = pred - pu[f] * q
+            a = ((1 - (1 - w) * res) * q).sum()
+            c = ((1 - w) * q * q).sum()
+            b = w * (pu @ S[:, f] - pu[f] * S[f, f])
+            pu[f] = (a - b) / (c + w * S[f, f] + reg)
+            pred = res + pu[f] * q
+        out[t] = pu
+    return out
+
+
 def test_c5_als_user_half_sweep_rows(oracle):
     U, I, d, w, reg = 500_000, 100_000, 64, 0.001, 0.06
     uptr, uidx, iptr, iidx = synth.s_als(U, I, 50_000_000, 45)
@@ -182,12 +204,20 @@ def test_c5_als_user_half_sweep_rows(oracle):
     oracle.als_half_range(A, Q0, sub_ptr, sub_idx, iptr, w, reg, 0, rows.size)
     worst_scale = max(rel_to_scale(gP[r:r + 1], A[t:t + 1]) for t, r in enumerate(rows))
     worst_elem = elementwise_rel(gP[rows], A)
-    print("C5 user half-sweep, %d rows (lengths %d..%d): max error / largest |ref| of the row %.2e; element-wise relative %.2e"
-          % (rows.size, lens[rows].min(), lens[rows].max(), worst_scale, worst_elem))
+    # round 6: the same recurrence in float64 as the arbiter between the two float32 answers (see the item-side test below)
+    X = _als_rows_fp64(P0, Q0, uptr, uidx, iptr, w, reg, rows)
+    sc = np.abs(X).max(axis=1, keepdims=True)
+    e_dev, e_orc = np.abs(gP[rows] - X), np.abs(A - X)
+    print("C5 user half-sweep, %d rows (lengths %d..%d): device against oracle: max error / largest |ref| of the row %.2e, element-wise "
+          "relative %.2e; against float64 (max error / row scale, element-wise relative): device %.2e, %.2e; oracle %.2e, %.2e"
+          % (rows.size, lens[rows].min(), lens[rows].max(), worst_scale, worst_elem, float((e_dev / sc).max()), elementwise_rel(gP[rows], X),
+             float((e_orc / sc).max()), elementwise_rel(A, X)))
     assert worst_scale < 1e-4
     # the bar as stated in tests/test_gpu_cf_parity.py: |err| <= 1e-4 |ref| + 5e-5 * (largest |ref| of the row)
     bound = 1e-4 * np.abs(A.astype(np.float64)) + 5e-5 * np.abs(A).max(axis=1, keepdims=True)
     assert (np.abs(gP[rows].astype(np.float64) - A) <= bound).all()
+    # and the device is nowhere farther from the exact recurrence than the reference's own float32 arithmetic is (+ 2e-6 of the row scale)
+    assert ((e_dev / sc).max(axis=1) <= (e_orc / sc).max(axis=1) + 2e-6).all()
 
 
 def _check_c4_rows(oracle, Xe, idx, dist, q0, rows, k):
@@ -301,7 +331,18 @@ def test_c4_full_symmetric_pass_rows_against_the_oracle(oracle):
 def test_c5_als_item_half_sweep_rows(oracle):
     """C5's ITEM half-sweep at full size (model/cf/model.go:693-738): the side with the 100K+-entry rows, i.e. the chunk plan
     (als_chunk_kernel over 4096-entry chunks), als_partial_reduce_kernel and als_long_solve_kernel at the size bench.py runs them.
-    2048 item rows spread over the row-length range incl. the eight longest against orc_als_half_range on the same inputs."""
+    2048 item rows spread over the row-length range incl. the eight longest (4.1M entries), three answers: the device's, the oracle's
+    (= the reference's own float32 arithmetic: S summed over 500,000 users one after the other in float32, model.go:695-706, the
+    residual recurrence summed over a row's entries one after the other) and the same recurrence in float64.
+
+    What round 6's first run of this test found (profiles/r06_b_probe_gpu_probe_als_c5_items.txt): at this size the REFERENCE's float32
+    sums are what drifts -- its answer is 1.9e-4 of the row scale away from float64 already on short rows (S over 500K sequential
+    float32 additions), 4.6e-3 on the 4.1M-entry row -- while the device's Gram form (partial sums per 4096-entry chunk, added
+    pairwise) stays within 5e-6 of float64 on every row.  "Within 1e-4 of the reference" therefore cannot hold where the reference is
+    farther than that from its own exact value; the bars, in order:
+      1. device vs float64: the stated ALS bar |err| <= 1e-4 |ref| + 5e-5 rowmax|ref| -- and in fact < 2e-5 of the row scale;
+      2. the device is nowhere farther from float64 than the oracle is (+ 2e-6);
+      3. device vs oracle: within the stated bar PLUS the oracle's own distance from float64, row by row (triangle inequality)."""
     U, I, d, w, reg = 500_000, 100_000, 64, 0.001, 0.06
     uptr, uidx, iptr, iidx = synth.s_als(U, I, 50_000_000, 45)
     P0, Q0 = synth.init_factors(U, I, d, 0.0, 0.1, seed=1)
@@ -320,12 +361,17 @@ def test_c5_als_item_half_sweep_rows(oracle):
     sub_idx = np.concatenate([iidx[iptr[r]:iptr[r + 1]] for r in rows])
     # the oracle's half-sweep solves rows of its first argument against the second with the CSR given: items against P0
     oracle.als_half_range(A, P0, sub_ptr, sub_idx, uptr, w, reg, 0, rows.size)
-    worst_scale = max(rel_to_scale(gQ[r:r + 1], A[t:t + 1]) for t, r in enumerate(rows))
-    worst_elem = elementwise_rel(gQ[rows], A)
+    X = _als_rows_fp64(Q0, P0, iptr, iidx, uptr, w, reg, rows)
+    scale = np.abs(X).max(axis=1, keepdims=True)
+    e_dev = np.abs(gQ[rows] - X)
+    e_orc = np.abs(A - X)
     n_long = int((lens[rows] > 4096).sum())
-    print("C5 item half-sweep, %d rows (lengths %d..%d, %d of them cut into chunks): max error / largest |ref| of the row %.2e; "
-          "element-wise relative %.2e" % (rows.size, lens[rows].min(), lens[rows].max(), n_long, worst_scale, worst_elem))
+    print("C5 item half-sweep, %d rows (lengths %d..%d, %d of them cut into chunks): max error / row scale against float64: device %.2e, "
+          "oracle (the reference's float32 sums) %.2e; device against oracle %.2e (element-wise relative %.2e)"
+          % (rows.size, lens[rows].min(), lens[rows].max(), n_long, float((e_dev / scale).max()), float((e_orc / scale).max()),
+             float((np.abs(gQ[rows] - A.astype(np.float64)) / scale).max()), elementwise_rel(gQ[rows], A)))
     assert n_long >= 8 and lens[rows].max() > 100_000  # the chunk plan + partial reduce are on the path
-    assert worst_scale < 1e-4
-    bound = 1e-4 * np.abs(A.astype(np.float64)) + 5e-5 * np.abs(A).max(axis=1, keepdims=True)
-    assert (np.abs(gQ[rows].astype(np.float64) - A) <= bound).all()
+    bar = 1e-4 * np.abs(X) + 5e-5 * scale
+    assert (e_dev <= bar).all() and float((e_dev / scale).max()) < 2e-5                      # 1.
+    assert ((e_dev / scale).max(axis=1) <= (e_orc / scale).max(axis=1) + 2e-6).all()         # 2.
+    assert (np.abs(gQ[rows] - A.astype(np.float64)) <= bar + e_orc.max(axis=1, keepdims=True)).all()  # 3.
