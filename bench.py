@@ -191,6 +191,11 @@ def parse():
     ap.add_argument("--topk-n", type=int, default=1_000_000)
     ap.add_argument("--topk-steps", type=int, default=2)
     ap.add_argument("--topk-budget", type=float, default=60.0, help="seconds the timed top-k steps may take (see bench_topk)")
+    ap.add_argument("--topk-shard", default="auto", choices=["auto", "rows", "tri"],
+                    help="how the C4 pass is split over N > 1 ranks: tri = the TRIANGLE of the symmetric sweep (rank r takes the query blocks "
+                         "r, r + N, ...; thresholds all-gathered, foreign candidate lists all-to-all: gorse_topk_tri_*), rows = contiguous "
+                         "query-row shards (no exchange; the symmetric saving on each rank's diagonal square only); auto = tri up to 4 "
+                         "ranks, rows beyond (DESIGN.md section 5: measured per-rank passes 125 / 74 / 67 ms against 130 / 86 / 57)")
     ap.add_argument("--mode", type=int, default=capi.BPR_HOGWILD_STORES,
                     help="BPR schedule: 3 = what Fit runs with Jobs > 1 (atomics + the reference's unlocked store for cold negatives), "
                          "0 = atomics only, 1 = sequential, 2 = racy")
@@ -322,38 +327,61 @@ def topk_cpu_baseline(Xe, k, seconds, idx_gpu, dist_gpu, q_begin):
 
 
 def bench_topk(args, world, rank, local, fence):
-    """BASELINE config C4: item-to-item cosine top-100 over N x 128 bf16 embeddings; query rows sharded over ranks,
-    X replicated, no collective.  A step = one all-pairs pass over this rank's query shard; the
-    N x k indices + distances stay in HBM (timed region: embeddings resident -> results resident)."""
+    """BASELINE config C4: item-to-item cosine top-100 over N x 128 bf16 embeddings, X replicated.  Over N > 1 ranks either the
+    TRIANGLE of the symmetric sweep is sharded (--topk-shard tri; the default up to 4 ranks: rank r sweeps the query blocks r, r + N,
+    ..., the pilot thresholds are all-gathered and the foreign candidate lists exchanged all-to-all inside the timed region) or the
+    query rows (rows: no collective).  A step = one all-pairs pass (this rank's share of it); the N x k indices +
+    distances stay in HBM (timed region: embeddings resident -> results resident)."""
     N, d, k = args.topk_n, 128, 100
     Xb, Xe = synth.s_emb(N, d, 44)
     t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16, device=local)
-    q0, q1 = gdist.shard_range(N, rank, world, align=128)  # tile-aligned shards: every rank's pass can take the symmetric sweep
-    t.all_pairs(k, q0, min(q1, q0 + 8192), fetch=False)  # warm-up: allocations, code objects
-    fence()
-    # keep the default run bounded: if a 16K-query pass predicts more than --topk-budget seconds for the timed
-    # steps, time a prefix of the query rows instead (all N stored vectors are still scanned per query; the
-    # pairs/s figure is over the rows actually processed and config.queries_per_step_per_gpu says how many)
-    probe_q = min(q1 - q0, 16384)
-    t0 = time.perf_counter()
-    t.all_pairs(k, q0, q0 + probe_q, fetch=False)
-    fence()
-    per_query = (time.perf_counter() - t0) / probe_q
-    full = q1 - q0
-    if per_query * full * args.topk_steps > args.topk_budget:
-        q1 = q0 + max(probe_q, int(args.topk_budget / args.topk_steps / per_query) // 8192 * 8192)
-        q1 = min(q1, q0 + full)
-    # one untimed pass over exactly the timed query range: the tie path sizes its buffers by the number of queries with
-    # ties (1 % of them), so a short warm-up leaves allocations inside the first timed step
-    t.all_pairs(k, q0, q1, fetch=False)
-    fence()
-    t.set_profiling(True)
-    with ClockSampler(local) as clk:
-        t0 = time.perf_counter()
-        for _ in range(args.topk_steps):
-            t.all_pairs(k, q0, q1, fetch=False)
+    tri = world > 1 and N >= 1 << 17 and (args.topk_shard == "tri" or (args.topk_shard == "auto" and world <= 4))
+    if tri:
+        # the triangle of the symmetric sweep sharded over the ranks: every rank's step covers ALL N query rows' share of the work
+        # (its query blocks r, r + world, ...), the exchanges (thresholds, foreign lists) are inside the timed region
+        eng = gdist.HipTriEngine(t, fetch=False, device="cuda" if BACKEND == "nccl" else "cpu")
+        tcomm = gdist.TorchComm()
+        gdist.refresh_neighbors_triangle(eng, tcomm, k, gather=False)  # allocations, code objects
+        gdist.refresh_neighbors_triangle(eng, tcomm, k, gather=False)
         fence()
-        dt = time.perf_counter() - t0
+        t.set_profiling(True)
+        with ClockSampler(local) as clk:
+            t0 = time.perf_counter()
+            for _ in range(args.topk_steps):
+                gdist.refresh_neighbors_triangle(eng, tcomm, k, gather=False)
+            fence()
+            dt = time.perf_counter() - t0
+        q0, q1 = 0, N
+        full = N
+        own_queries = t.tri_slice(rank)[2]
+    else:
+        q0, q1 = gdist.shard_range(N, rank, world, align=128)  # tile-aligned shards: every rank's pass can take the symmetric sweep
+        t.all_pairs(k, q0, min(q1, q0 + 8192), fetch=False)  # warm-up: allocations, code objects
+        fence()
+        # keep the default run bounded: if a 16K-query pass predicts more than --topk-budget seconds for the timed
+        # steps, time a prefix of the query rows instead (all N stored vectors are still scanned per query; the
+        # pairs/s figure is over the rows actually processed and config.queries_per_step_per_gpu says how many)
+        probe_q = min(q1 - q0, 16384)
+        t0 = time.perf_counter()
+        t.all_pairs(k, q0, q0 + probe_q, fetch=False)
+        fence()
+        per_query = (time.perf_counter() - t0) / probe_q
+        full = q1 - q0
+        if per_query * full * args.topk_steps > args.topk_budget:
+            q1 = q0 + max(probe_q, int(args.topk_budget / args.topk_steps / per_query) // 8192 * 8192)
+            q1 = min(q1, q0 + full)
+        # one untimed pass over exactly the timed query range: the tie path sizes its buffers by the number of queries with
+        # ties (1 % of them), so a short warm-up leaves allocations inside the first timed step
+        t.all_pairs(k, q0, q1, fetch=False)
+        fence()
+        t.set_profiling(True)
+        with ClockSampler(local) as clk:
+            t0 = time.perf_counter()
+            for _ in range(args.topk_steps):
+                t.all_pairs(k, q0, q1, fetch=False)
+            fence()
+            dt = time.perf_counter() - t0
+        own_queries = q1 - q0
     tt = torch.tensor([dt], dtype=torch.float64, device=COLL_DEV)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -367,8 +395,9 @@ def bench_topk(args, world, rank, local, fence):
     symmetric, sym_stats = t.last_symmetric(), t.sym_stats()
     if rank != 0:
         return None
-    pairs_step = (q1 - q0) * (N - 1)
-    flops_launch = 2.0 * d * (q1 - q0) * N * args.topk_steps / max(launches, 1)  # 2*d flop per scored pair
+    # rows sharded: every rank answers its q1 - q0 query rows; triangle: the ranks TOGETHER answer all N (a rank owns own_queries of them)
+    pairs_step = (q1 - q0) * (N - 1) / (world if tri else 1)
+    flops_launch = 2.0 * d * (q1 - q0) / (world if tri else 1) * N * args.topk_steps / max(launches, 1)  # 2*d flop per scored pair
     avg_ms = sweep_ms / max(launches, 1)
     achieved = flops_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     out = {
@@ -376,8 +405,9 @@ def bench_topk(args, world, rank, local, fence):
         "value": world * pairs_step * args.topk_steps / dt, "unit": "pairs/s",
         "n_gpus": world, "steps": args.topk_steps, "ms_per_step": dt / args.topk_steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "S-emb %dx%d bf16, cosine, k=%d (C4), query rows sharded x%d" % (N, d, k, world),
-                   "queries_per_step_per_gpu": q1 - q0, "all_query_rows": q1 - q0 == full,
+        "config": {"workload": "S-emb %dx%d bf16, cosine, k=%d (C4), %s x%d" % (N, d, k, "the triangle of the symmetric sweep sharded" if tri else "query rows sharded", world),
+                   "sharding": "triangle" if tri else "rows",
+                   "queries_per_step_per_gpu": own_queries, "all_query_rows": q1 - q0 == full,
                    "tie_replayed_queries": n_tie, "scan_fallback_queries": n_fb, "symmetric_sweep": symmetric,
                    "queries_without_pilot_threshold": sym_stats[0], "foreign_lists_overflowed": sym_stats[2]},
         "roofline": {"bound": "mfma", "kernel": "topk_sweep_kernel", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
@@ -394,7 +424,7 @@ def bench_topk(args, world, rank, local, fence):
     }
     if N == 1_000_000 and q1 - q0 == N:
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = measured_traffic("topk")
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not tri:
         try:
             m = min(q1 - q0, 65536)
             idx, dst = t.all_pairs(k, q0, q0 + m)

@@ -442,17 +442,37 @@ class TopK:
     def tri_sweep(self):
         check(lib().gorse_topk_tri_sweep(self.h))
 
-    def tri_pack(self, dest):
-        """the message for `dest`: (counts int32 per query dest owns, entries uint64 = (key, row) pairs end to end)"""
+    def tri_pack_device(self, dest):
+        """builds the message for `dest` in the handle's device buffers; returns (number of counts, number of entries)"""
         nc, ne = C.c_int64(0), C.c_int64(0)
         check(lib().gorse_topk_tri_pack(self.h, dest, C.byref(nc), C.byref(ne)))
-        counts, entries = np.empty(nc.value, np.int32), np.empty(ne.value, np.uint64)
+        return nc.value, ne.value
+
+    def tri_pack_fetch(self, nc, ne):
+        counts, entries = np.empty(nc, np.int32), np.empty(ne, np.uint64)
         check(lib().gorse_topk_tri_pack_read(self.h, counts.ctypes.data_as(_vp), entries.ctypes.data_as(_vp)))
         return counts, entries
+
+    def tri_pack(self, dest):
+        """the message for `dest`: (counts int32 per query dest owns, entries uint64 = (key, row) pairs end to end)"""
+        return self.tri_pack_fetch(*self.tri_pack_device(dest))
 
     def tri_unpack(self, src, counts, entries):
         counts, entries = _arr(counts, np.int32), _arr(entries, np.uint64)
         check(lib().gorse_topk_tri_unpack(self.h, src, counts.ctypes.data_as(_vp), counts.size, entries.ctypes.data_as(_vp), entries.size))
+
+    # device-pointer forms (the messages stay on the GPU: torch tensors' data_ptr(); gorse_amd.dist.HipTriEngine(device="cuda"))
+    def tri_thresholds_get_ptr(self, lo, hi, ptr):
+        check(lib().gorse_topk_tri_thresholds_get(self.h, lo, hi, _vp(ptr)))
+
+    def tri_thresholds_put_ptr(self, lo, hi, ptr):
+        check(lib().gorse_topk_tri_thresholds_put(self.h, lo, hi, _vp(ptr)))
+
+    def tri_pack_read_ptr(self, counts_ptr, entries_ptr):
+        check(lib().gorse_topk_tri_pack_read(self.h, _vp(counts_ptr), _vp(entries_ptr)))
+
+    def tri_unpack_ptr(self, src, counts_ptr, n_counts, entries_ptr, n_entries):
+        check(lib().gorse_topk_tri_unpack(self.h, src, _vp(counts_ptr), n_counts, _vp(entries_ptr), n_entries))
 
     def tri_finish(self, idx=None, dist=None, fetch=True):
         """rescoring + tie path of the queries this rank owns; with fetch their rows are written into idx / dist (nq x k, allocated
@@ -647,17 +667,37 @@ class Sparse:
     def tri_sweep(self):
         check(lib().gorse_topk_tri_sweep(self.h))
 
-    def tri_pack(self, dest):
-        """the message for `dest`: (counts int32 per query dest owns, entries uint64 = (key, row) pairs end to end)"""
+    def tri_pack_device(self, dest):
+        """builds the message for `dest` in the handle's device buffers; returns (number of counts, number of entries)"""
         nc, ne = C.c_int64(0), C.c_int64(0)
         check(lib().gorse_topk_tri_pack(self.h, dest, C.byref(nc), C.byref(ne)))
-        counts, entries = np.empty(nc.value, np.int32), np.empty(ne.value, np.uint64)
+        return nc.value, ne.value
+
+    def tri_pack_fetch(self, nc, ne):
+        counts, entries = np.empty(nc, np.int32), np.empty(ne, np.uint64)
         check(lib().gorse_topk_tri_pack_read(self.h, counts.ctypes.data_as(_vp), entries.ctypes.data_as(_vp)))
         return counts, entries
+
+    def tri_pack(self, dest):
+        """the message for `dest`: (counts int32 per query dest owns, entries uint64 = (key, row) pairs end to end)"""
+        return self.tri_pack_fetch(*self.tri_pack_device(dest))
 
     def tri_unpack(self, src, counts, entries):
         counts, entries = _arr(counts, np.int32), _arr(entries, np.uint64)
         check(lib().gorse_topk_tri_unpack(self.h, src, counts.ctypes.data_as(_vp), counts.size, entries.ctypes.data_as(_vp), entries.size))
+
+    # device-pointer forms (the messages stay on the GPU: torch tensors' data_ptr(); gorse_amd.dist.HipTriEngine(device="cuda"))
+    def tri_thresholds_get_ptr(self, lo, hi, ptr):
+        check(lib().gorse_topk_tri_thresholds_get(self.h, lo, hi, _vp(ptr)))
+
+    def tri_thresholds_put_ptr(self, lo, hi, ptr):
+        check(lib().gorse_topk_tri_thresholds_put(self.h, lo, hi, _vp(ptr)))
+
+    def tri_pack_read_ptr(self, counts_ptr, entries_ptr):
+        check(lib().gorse_topk_tri_pack_read(self.h, _vp(counts_ptr), _vp(entries_ptr)))
+
+    def tri_unpack_ptr(self, src, counts_ptr, n_counts, entries_ptr, n_entries):
+        check(lib().gorse_topk_tri_unpack(self.h, src, _vp(counts_ptr), n_counts, _vp(entries_ptr), n_entries))
 
     def tri_finish(self, idx=None, dist=None, fetch=True):
         """rescoring + tie path of the queries this rank owns; with fetch their rows are written into idx / dist (nq x k, allocated

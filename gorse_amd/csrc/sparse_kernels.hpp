@@ -513,8 +513,13 @@ __device__ inline void apply_flattened(const Posting *__restrict__ post, const V
     }
 }
 
+// Measured (profiles/r06_d_ab_sparse_queue.txt, both builds in one session, twice): ONE counter 36.64-36.69 ms per C3-shard pass, 32 stripes
+// 38.66-38.71 ms.  The head of the queue on one memory line is not what the pass waits for -- 3e5 items in 36 ms are 8 M returning
+// atomics per second against the 88 M a line serves, and a wave meets the counter ~70 times per launch -- while the stripes cost the
+// dearest-first order its meaning at the END of the launch: a wave drains its home stripe and then walks the others one by one,
+// so the last, cheap items of 32 lists are found late.  The single counter stays; the switch is kept for the record.
 #ifndef GORSE_SPARSE_QUEUE_STRIPES
-#define GORSE_SPARSE_QUEUE_STRIPES 32  // A/B: 1 = one counter for every wave (rounds 1-5)
+#define GORSE_SPARSE_QUEUE_STRIPES 1  // make ab AB=q32 AB_SRC=sparse AB_FLAGS=-DGORSE_SPARSE_QUEUE_STRIPES=32
 #endif
 constexpr int kQueueStripes = GORSE_SPARSE_QUEUE_STRIPES;  // a power of two
 constexpr int kQueueStride = 64;   // words between two stripes' counters: 256 bytes
@@ -535,10 +540,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     board[lane] = 0;
     for (int i = lane; i < NL; i += kBlock) acc[i] = 0.0f;
     __syncthreads();
-    // The work list is taken through kQueueStripes counters, each on a 256-byte line of its own: stripe s hands out the items
-    // s, s + kQueueStripes, ... (the list is sorted dearest first, so every stripe is too).  A wave starts on its workgroup's
-    // stripe and moves on when a stripe runs dry; a dry stripe stays dry, so kQueueStripes dry ones in a row end the wave.  One
-    // counter for all waves is one memory line serving 88 M returning atomics per second (scripts/probe_atomics4.hip).
+    // The work list is taken through kQueueStripes counters (1 in the shipped build: see above), each on a 256-byte line of its own:
+    // stripe s hands out the items s, s + kQueueStripes, ... (the list is sorted dearest first, so every stripe is too).  A wave starts
+    // on its workgroup's stripe and moves on when a stripe runs dry; a dry stripe stays dry, so kQueueStripes dry ones in a row end it.
     int qstripe = (int)(blockIdx.x & (kQueueStripes - 1)), qdry = 0;
     for (;;) {
         int w = 0;

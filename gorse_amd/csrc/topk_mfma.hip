@@ -107,6 +107,7 @@ constexpr int kHistCap = 4096;          // history entries per query of the tie-
 constexpr int kReplayCap = 8192;        // power of two >= kCap + kHistCap: entries the replay sorts
 constexpr int64_t kReplayChunk = 16384; // flagged queries per history sweep (history buffers = 512 MB per row slice)
 constexpr int kMaxSlices = 8;           // row slices of a history sweep (see topk_tie_sort_kernel)
+constexpr int kMaxSlicesFew = 32;       // ... of one that serves few queries (chunk_finish)
 constexpr int64_t kChunkQ = (int64_t)1 << 20;
 
 using gorse::rank::fkey;      // order-preserving float -> uint of an approximate score, and back (rank_keys.hpp)
@@ -2267,7 +2268,11 @@ int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool hist, bool sym 
         case 3: return launch_sweep<3, kNcbMain>(h, p, hist);
         case 4: return launch_sweep<4, kNcbMain>(h, p, hist, sym);
         case 6: return launch_sweep<6, kNcbMain>(h, p, hist);
-        case 8: return launch_sweep<8, kNcbMain>(h, p, hist, sym);
+        case 8:
+            // variant bit 27 (probe): the history sweep of the tie path with ONE column block per wave -- 64 queries per two-wave
+            // workgroup instead of 128: twice the workgroups, each with half the acceptances of a cold start
+            if (hist && (g_topk_variant & (1 << 27))) return launch_sweep<8, 1>(h, p, true);
+            return launch_sweep<8, kNcbMain>(h, p, hist, sym);
         case 12: return launch_sweep<12, 1>(h, p, hist);  // 2 column blocks would spill
         case 16: return launch_sweep<16, 1>(h, p, hist);
         case 24: return launch_sweep<24, 1>(h, p, hist);
@@ -2745,6 +2750,15 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
             // rows, slices x as many workgroups each walk 1 / slices of the rows; topk_tie_sort_kernel joins the slices.
             // Variant bit 14: eight slices whatever N (lets small test inputs take the path); bit 15: one slice.
             int nsl = (int)std::min<int64_t>(kMaxSlices, std::max<int64_t>(1, h->N / 32768));
+            // Few flagged queries -- a rank of a sharded search holds 1 / world of them, and the history sweep's time does not
+            // shrink with their number: every workgroup (128 queries) walks its slice of the rows whatever else runs -- take more,
+            // shorter slices until the launch has ~512 workgroups (at most kMaxSlicesFew, slices of at least 16384 rows).  A full
+            // single-GPU C4 pass (10,136 queries: 80 x 8 workgroups) keeps its eight: sixteen were measured there, 9.2 + 14.0 ms
+            // against 11.4 + 11.4 (every slice starts cold, the join and the replay pay for it).
+            {
+                const int64_t wgs = ceil_div(m2, (int64_t)64 * kNcbMain);
+                while (nsl >= kMaxSlices && nsl < kMaxSlicesFew && wgs * nsl < 512 && h->N / (2 * (int64_t)nsl) >= 16384) nsl *= 2;
+            }
             if (g_topk_variant & 16384) nsl = kMaxSlices;
             if (g_topk_variant & 32768) nsl = 1;
             const size_t sm2 = (size_t)nsl * (size_t)m2;
@@ -2825,6 +2839,11 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
                 const int slots = k + 1;
                 int qpw = 64;
                 while (qpw > 16 && (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4 > (size_t)144 * 1024) qpw >>= 1;
+                // The lanes of a wave replay their queries in step: a wave takes as long as its lanes' branches laid end to end, and
+                // the launch as long as its slowest wave, however few queries there are (1,250 queries of one rank of eight: 11.9 ms,
+                // the 10,136 of a whole C4 pass: 11.5).  Fewer queries per wave while the launch has fewer waves than the chip has CUs
+                // (variant bit 28: 64 whatever the size).
+                while (qpw > 16 && !(g_topk_variant & (1 << 28)) && ceil_div(m2, (int64_t)qpw) < 256) qpw >>= 1;
                 const size_t llds = (size_t)(3 * slots + 2 * kLaneLog) * qpw * 4;
                 auto launch_lanes = [&](auto tag) -> int32_t {
                     constexpr int Q = decltype(tag)::value;

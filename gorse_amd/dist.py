@@ -146,7 +146,8 @@ def refresh_neighbors_triangle(engine, comm, k, gather=True):
     an all-gather of the pilot thresholds (4 bytes per query) in front of the main sweep, an all-to-all of the foreign candidate
     lists (~130 entries of 8 bytes per query in all) behind it; rescoring and tie path run on a query's owner.
     engine: begin(k, rank, world), slice(r) -> (lo, hi, owned), thresholds() -> own slice, put_thresholds(lo, hi, a), sweep(),
-    pack(dest) -> (counts, entries), unpack(src, counts, entries), finish() -> (idx, dist) with this rank's rows filled in.
+    pack(dest) -> (counts int32, entries as int64 words), unpack(src, counts, entries), finish() -> (idx, dist) with this rank's
+    rows filled in.  Thresholds and messages are numpy arrays or torch tensors (HipTriEngine(device="cuda"): they never leave the GPU).
     comm: all_gather_var(array) -> list per rank, all_to_all_var(list per dest) -> list per source (TorchComm), or None.
     Returns (idx, dist) of all n_rows rows when gather (every rank), else this rank's arrays (foreign rows -1 / +inf)."""
     world = comm.world if comm is not None else 1
@@ -160,13 +161,14 @@ def refresh_neighbors_triangle(engine, comm, k, gather=True):
                 engine.put_thresholds(lo, hi, a)
     engine.sweep()
     if world > 1:
-        empty = (np.zeros(0, np.int32), np.zeros(0, np.uint64))
-        out = [engine.pack(d) if d != rank else empty for d in range(world)]
-        counts_in = comm.all_to_all_var([c for c, _ in out])
-        entries_in = comm.all_to_all_var([e.view(np.int64) for _, e in out])
+        out = [engine.pack(d) if d != rank else None for d in range(world)]
+        like = next(o for o in out if o is not None)
+        out[rank] = (like[0][:0], like[1][:0])
+        counts_in = comm.all_to_all_var([c for c, _ in out])    # int32 per owned query
+        entries_in = comm.all_to_all_var([e for _, e in out])   # (key, row) pairs as 64-bit words (int64: what torch moves)
         for s_ in range(world):
             if s_ != rank:
-                engine.unpack(s_, counts_in[s_], entries_in[s_].view(np.uint64))
+                engine.unpack(s_, counts_in[s_], entries_in[s_])
     idx, dist = engine.finish()
     if world == 1 or not gather or idx is None:
         return idx, dist
@@ -184,10 +186,11 @@ def refresh_neighbors_triangle_local(engines, k, timings=None):
     """The same search with all `world` ranks in THIS process, one engine (handle) per rank -- N devices of one node driven by one
     process (the Go master's mode), or N handles on ONE device: the emulation the single-GPU box can run, every exchange through
     host memory.  The protocol is refresh_neighbors_triangle's, stage by stage over all ranks.  timings (a dict): per rank the
-    seconds of its stages [pilots, sweep, pack, unpack, finish], measured around calls that end synchronised."""
+    seconds of its stages [pilots, sweep, pack (kernels), unpack (host -> device copy + kernel), finish, message device -> host],
+    measured around calls that end synchronised; the last one and the copy inside unpack stand in for the transfers over xGMI."""
     import time
     world = len(engines)
-    tm = [[0.0] * 5 for _ in range(world)]
+    tm = [[0.0] * 6 for _ in range(world)]
 
     def timed(r, stage, fn):
         t0 = time.perf_counter()
@@ -209,7 +212,11 @@ def refresh_neighbors_triangle_local(engines, k, timings=None):
     for r, e in enumerate(engines):
         for d in range(world):
             if d != r:
-                msgs[(r, d)] = timed(r, 2, lambda: e.pack(d))
+                if hasattr(e, "pack_device"):
+                    sizes = timed(r, 2, lambda: e.pack_device(d))
+                    msgs[(r, d)] = timed(r, 5, lambda: e.pack_fetch(*sizes))
+                else:
+                    msgs[(r, d)] = timed(r, 2, lambda: e.pack(d))
     for (src, d), (c, ent) in msgs.items():
         timed(d, 3, lambda: engines[d].unpack(src, c, ent))
     idx = dist = None
@@ -222,11 +229,17 @@ def refresh_neighbors_triangle_local(engines, k, timings=None):
 
 
 class HipTriEngine:
-    """A gorse_topk handle (capi.TopK) as the engine of refresh_neighbors_triangle: messages as host numpy arrays."""
+    """A gorse_topk handle (capi.TopK) as the engine of refresh_neighbors_triangle.  device = "cpu": thresholds and messages as host
+    numpy arrays (the one-GPU emulation, gloo); device = "cuda": as torch CUDA tensors filled and read by the library through their
+    device pointers -- under RCCL the foreign lists go GPU to GPU."""
 
-    def __init__(self, index, fetch=True):
-        self.index, self.n_rows, self.fetch = index, index.N, fetch
+    def __init__(self, index, fetch=True, device="cpu"):
+        self.index, self.n_rows, self.fetch, self.device = index, index.N, fetch, device
         self.rank = 0
+        self.torch = None
+        if device != "cpu":
+            import torch
+            self.torch = torch
 
     def begin(self, k, rank, world):
         self.rank = rank
@@ -237,19 +250,45 @@ class HipTriEngine:
 
     def thresholds(self):
         lo, hi, _ = self.index.tri_slice(self.rank)
-        return self.index.tri_thresholds_get(lo, hi)
+        if self.torch is None:
+            return self.index.tri_thresholds_get(lo, hi)
+        t = self.torch.empty(hi - lo, dtype=self.torch.float32, device=self.device)
+        self.index.tri_thresholds_get_ptr(lo, hi, t.data_ptr())
+        return t
 
     def put_thresholds(self, lo, hi, a):
-        self.index.tri_thresholds_put(lo, hi, a)
+        if self.torch is None or not self.torch.is_tensor(a):
+            return self.index.tri_thresholds_put(lo, hi, a)
+        a = a.to(self.device).contiguous()
+        self.torch.cuda.synchronize()  # the collective that filled it ran on torch's stream
+        self.index.tri_thresholds_put_ptr(lo, hi, a.data_ptr())
 
     def sweep(self):
         self.index.tri_sweep()
 
     def pack(self, dest):
-        return self.index.tri_pack(dest)
+        if self.torch is None:
+            c, e = self.index.tri_pack(dest)
+            return c, e.view(np.int64)
+        nc, ne = self.index.tri_pack_device(dest)
+        c = self.torch.empty(nc, dtype=self.torch.int32, device=self.device)
+        e = self.torch.empty(ne, dtype=self.torch.int64, device=self.device)
+        self.index.tri_pack_read_ptr(c.data_ptr(), e.data_ptr())
+        return c, e
+
+    def pack_device(self, dest):
+        return self.index.tri_pack_device(dest)
+
+    def pack_fetch(self, nc, ne):
+        c, e = self.index.tri_pack_fetch(nc, ne)
+        return c, e.view(np.int64)
 
     def unpack(self, src, counts, entries):
-        self.index.tri_unpack(src, counts, entries)
+        if self.torch is None or not self.torch.is_tensor(counts):
+            return self.index.tri_unpack(src, counts, np.asarray(entries).view(np.uint64))
+        counts, entries = counts.to(self.device).contiguous(), entries.to(self.device).contiguous()
+        self.torch.cuda.synchronize()
+        self.index.tri_unpack_ptr(src, counts.data_ptr(), counts.numel(), entries.data_ptr(), entries.numel())
 
     def finish(self, idx=None, dist=None):
         return self.index.tri_finish(idx, dist, fetch=self.fetch)
@@ -409,44 +448,45 @@ class TorchComm:
         return torch.device("cuda", torch.cuda.current_device()) if self.dist.get_backend() == "nccl" else torch.device("cpu")
 
     def all_gather_var(self, a):
-        """all-gather of 1-D numpy arrays of one dtype whose lengths differ by rank -> the list of every rank's array"""
+        """all-gather of 1-D arrays of one dtype whose lengths differ by rank -> the list of every rank's array.  numpy in, numpy
+        out; a torch tensor in (a CUDA tensor under RCCL: nothing touches the host), torch tensors out."""
         import torch
-        a = np.ascontiguousarray(a)
+        as_torch = torch.is_tensor(a)
         if self.world == 1:
             return [a]
         dev = self._xdev()
-        n = torch.tensor([a.size], dtype=torch.int64, device=dev)
+        t = (a if as_torch else torch.from_numpy(np.ascontiguousarray(a))).to(dev)
+        n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
         sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
         self.dist.all_gather(sizes, n)
         sizes = [int(x.item()) for x in sizes]
-        width = max(max(sizes), 1)
-        mine = torch.zeros(width, dtype=torch.from_numpy(a[:0]).dtype, device=dev)
-        mine[:a.size] = torch.from_numpy(a).to(dev)
+        mine = torch.zeros(max(max(sizes), 1), dtype=t.dtype, device=dev)
+        mine[:t.numel()] = t
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(parts, mine)
-        return [p[:sizes[r]].cpu().numpy() for r, p in enumerate(parts)]
+        parts = [p[:sizes[r]] for r, p in enumerate(parts)]
+        return [p.to(a.device) for p in parts] if as_torch else [p.cpu().numpy() for p in parts]
 
     def all_to_all_var(self, out):
-        """out[d] = the 1-D numpy array (one dtype for all) this rank sends to rank d -> the list of what every rank sent here.
-        Sizes first (an all-gather of the size row), then one point-to-point pair per (source, destination) -- send / recv exist
-        under both RCCL and gloo."""
+        """out[d] = the 1-D array (one dtype for all; numpy or torch) this rank sends to rank d -> the list of what every rank sent
+        here.  Sizes first (an all-gather of the size row), then one point-to-point pair per (source, destination) -- send / recv
+        exist under both RCCL and gloo; under RCCL the payloads stay in device memory."""
         import torch
+        as_torch = torch.is_tensor(out[0])
         if self.world == 1:
-            return [np.ascontiguousarray(out[0])]
+            return [out[0]]
         dev = self._xdev()
-        out = [np.ascontiguousarray(o) for o in out]
-        row = torch.tensor([o.size for o in out], dtype=torch.int64, device=dev)
+        send = [(o if as_torch else torch.from_numpy(np.ascontiguousarray(o))).to(dev).contiguous() for o in out]
+        row = torch.tensor([o.numel() for o in send], dtype=torch.int64, device=dev)
         rows = [torch.zeros_like(row) for _ in range(self.world)]
         self.dist.all_gather(rows, row)
         sizes_in = [int(rows[s_][self.rank].item()) for s_ in range(self.world)]
-        tdt = torch.from_numpy(out[0][:0]).dtype
-        recv = [torch.empty(max(sizes_in[s_], 0), dtype=tdt, device=dev) for s_ in range(self.world)]
-        send = [torch.from_numpy(o).to(dev) for o in out]
+        recv = [torch.empty(sizes_in[s_], dtype=send[0].dtype, device=dev) for s_ in range(self.world)]
         ops = []
         for peer in range(self.world):
             if peer == self.rank:
                 continue
-            if out[peer].size:
+            if send[peer].numel():
                 ops.append(self.dist.P2POp(self.dist.isend, send[peer], peer))
             if sizes_in[peer]:
                 ops.append(self.dist.P2POp(self.dist.irecv, recv[peer], peer))
@@ -454,7 +494,7 @@ class TorchComm:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
         recv[self.rank] = send[self.rank]
-        return [r_.cpu().numpy() for r_ in recv]
+        return [r_.to(out[0].device) for r_ in recv] if as_torch else [r_.cpu().numpy() for r_ in recv]
 
 
 class HipEngine:

@@ -116,6 +116,20 @@ def main():
                   % (c[4], c[5], 100.0 * c[5] / max(c[4], 1), c[11], 100.0 * c[11] / max(c[5], 1), waves, c[1] / max(c[4], 1)), flush=True)
         L.gorse_hip_test_set_topk_variant(0)
         return
+    if "lanes" in sys.argv[1:]:  # the tie replay: queries per wave chosen by the launch's size (default) against always 64 (variant bit 28)
+        for v, label in ((0, "queries per replay wave by launch size"), (1 << 28, "64 queries per replay wave"),
+                         (0, "by launch size again"), (1 << 28, "64 again")):
+            L.gorse_hip_test_set_topk_variant(v)
+            run(t, k, 0, nq, label, reps=2)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
+    if "hist" in sys.argv[1:]:  # the tie path's history sweep: workgroups of 64 queries (variant bit 27) against 128, 8 / 1 row slices
+        for v, label in ((0, "default (128 queries per history workgroup, 8 slices)"), (1 << 27, "64 queries per history workgroup"),
+                         (0, "default again"), (1 << 27, "64 queries again")):
+            L.gorse_hip_test_set_topk_variant(v)
+            run(t, k, 0, nq, label, reps=2)
+        L.gorse_hip_test_set_topk_variant(0)
+        return
     if "pilot" in sys.argv[1:]:  # the warm start: stride of the pilot sample, with and without the 1/256 pilot in front of it
         for v, label in ((0, "pilots 1/256 + 1/16 (default)"), (1 << 20, "pilots 1/128 + 1/8"), (1 << 21, "pilots 1/512 + 1/32"),
                          (1 << 22, "pilot 1/16 alone"), ((1 << 21) | (1 << 22), "pilot 1/32 alone"), (256, "no warm start")):

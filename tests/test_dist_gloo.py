@@ -605,9 +605,10 @@ class NumpyTriEngine:
         qs = self._owned(dest)
         counts = np.array([len(self.foreign[q]) for q in qs], np.int32)
         ent = [np.float32(d_).view(np.uint32).astype(np.uint64) << np.uint64(32) | np.uint64(i) for q in qs for d_, i in self.foreign[q]]
-        return counts, np.array(ent, np.uint64)
+        return counts, np.array(ent, np.uint64).view(np.int64)  # the entries travel as 64-bit words
 
     def unpack(self, src, counts, entries):
+        entries = np.asarray(entries).view(np.uint64)
         qs, at = self._owned(self.rank), 0
         assert counts.size == qs.size and int(counts.sum()) == entries.size
         for q, c in zip(qs, counts):
