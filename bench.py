@@ -648,7 +648,8 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None, factors=
         "config": {"workload": "S-als %dx%dx%d (C5%s), nFactors=%d, weight=%g reg=%g" % (U, I, n, "" if sc == 1.0 else " x%g" % sc, d, w, reg),
                    "parallelism": "rows sharded x%d, factors replicated, 2 all-gathers((U+I)*d fp32)/epoch over %s" % (world, comm_label)
                    if world > 1 else "single GPU", "factors_finite": bool(np.isfinite(P).all() and np.isfinite(Q).all())},
-        "roofline": {"bound": "hbm", "kernel": "als_row_kernel + als_chunk_kernel (+ S Gram)", "achieved": hbm_achieved,
+        "roofline": {"bound": "hbm", "kernel": ("als_wide_kernel + als_gram_partial_kernel" if d > 64 else "als_row_kernel + als_chunk_kernel") + " (+ S Gram)",
+                     "achieved": hbm_achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_epoch": algo, "avg_launch_ms": per_epoch_ms, "launches": ns,
                      "mfma_f32_tflops": mfma_achieved, "mfma_f32_frac": mfma_achieved / MFMA_F32_PEAK_TFLOPS,
@@ -657,7 +658,7 @@ def bench_als(args, world, rank, local, fence, steps=None, warmup=None, factors=
                                   "upper triangle of the Gram update) against the %.1f TFLOP/s fp32 MFMA peak; at nFactors 32 / 64 each "
                                   "multiply-add is formed as six exact bf16-MFMA partial products of three-way split floats, summed in "
                                   "fp32 (csrc/als.hip gram_accumulate_b3) -- the figure stays in fp32 multiply-adds" % MFMA_F32_PEAK_TFLOPS,
-                     "gram_products": "bf16x3 split, fp32 accumulate" if d in (32, 64) else "fp32 MFMA",
+                     "gram_products": "bf16x3 split, fp32 accumulate" if d in (32, 64) or d > 64 else "fp32 MFMA",
                      "sweeps_ms_per_epoch": sweep_ms / max(steps, 1), "gram_ms_per_epoch": gram_ms / max(steps, 1)},
     }
     if world == 1 and sc == 1.0 and d == 64:
@@ -863,6 +864,13 @@ def bench_fit(args, local):
         rec = {"value": wall, "epochs_done": m.epochs_done, "fit_ms_per_epoch": float(np.mean(fit_ms)) if fit_ms else None,
                "samples_per_s": data.n_train / (float(np.mean(fit_ms)) * 1e-3) if fit_ms else None,
                "eval_ms": float(np.mean(eval_ms)) if eval_ms else None, "evaluations": len(eval_ms), "ndcg": score.NDCG}
+        if fit_ms:  # SURVEY 8(d) bytes per sample over the epoch's DEVICE time (fit_time of the twin's log = gorse_mf_epoch_times)
+            ep_s = float(np.mean(fit_ms)) * 1e-3
+            gbs = data.n_train * (6 * d * 4 + 12) / ep_s / 1e9
+            rec["roofline"] = {"bound": "hbm", "kernel": "bpr_update_user_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ep_s * 1e3,
+                               "l2_atomic": {"achieved": data.n_train * 2 * d / ep_s / 1e9, "peak": 243.0, "unit": "G atomic dwords/s",
+                                             "frac": data.n_train * 2 * d / ep_s / 1e9 / 243.0}}
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             o = orc.Oracle()
@@ -897,6 +905,8 @@ def bench_fit(args, local):
         if fit_ms:  # 2 nnz d 4 + 2 (U + I) d 4 bytes per epoch
             algo = 2.0 * nnz * d * 4 + 2.0 * (data.U + data.I) * d * 4
             rec["hbm_frac"] = algo / (float(np.mean(fit_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            rec["roofline"] = {"bound": "hbm", "kernel": "als_row_kernel", "achieved": rec["hbm_frac"] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": rec["hbm_frac"], "traffic": None, "avg_launch_ms": float(np.mean(fit_ms))}
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             o = orc.Oracle()
@@ -971,12 +981,17 @@ def emit(out, tag="default"):
         if moved:
             notes[k + ".moved"] = moved
     # (what is left of a moved block is its `workload` string: every object says in the line itself what it ran)
-    for k in ("mm", "ml100k_d8", "ml100k", "als_d16", "i2i", "als", "c3", "big", "fit"):
+    for k in ("mm", "ml100k_d8", "ml100k", "als_d128", "als_d16", "i2i", "als", "c3", "big", "fit"):
         if len(json.dumps(line, separators=(",", ":"))) < 7000:
             break
         if isinstance(line.get(k), dict) and isinstance(line[k].get("config"), dict) and len(line[k]["config"]) > 1:
             notes[k + ".config"] = line[k]["config"]
             line[k]["config"] = {"workload": line[k]["config"].get("workload")}
+    # last resort for the 8 KB tail: the rooflines of the `fit` records (derived from their fit_ms_per_epoch) move to the notes too
+    if len(json.dumps(line, separators=(",", ":"))) >= 7700 and isinstance(line.get("fit"), dict):
+        for k, v in line["fit"].items():
+            if isinstance(v, dict) and "roofline" in v:
+                notes["fit.%s.roofline" % k] = v.pop("roofline")
     # the notes of this run lie next to the line's log (gpurun_out/ is scratch); the copy of the round's last run is committed as
     # profiles/r06_bench_notes_<tag>.json
     line["notes"] = {"this_run": write_notes(notes, tag), "committed_copy": "profiles/r06_bench_notes_%s.json" % tag}
@@ -1054,6 +1069,9 @@ def main():
         out["als"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=3, warmup=1, data=s_als), "ALS feedback entries/sec")
         out["als_d16"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=3, warmup=1, factors=16, data=s_als),
                              "ALS feedback entries/sec, C5's set at the reference's default nFactors 16")
+        # 65 <= nFactors <= 128 take another set of kernels (als_wide_kernel: M in LDS, a workgroup per row): C5's set at the widest
+        out["als_d128"] = leg(lambda: bench_als(args, 1, 0, local, fence0, steps=2, warmup=1, factors=128, data=s_als),
+                              "ALS feedback entries/sec, C5's set at nFactors 128")
         del s_als
         # the reference's own hyper-parameters (model/cf/model_test.go:35-45: nFactors 16; 8 is the smallest it searches)
         out["ml100k"] = leg(lambda: bench_bpr(args, "ml100k", 1, 0, local, None, "single GPU", 20, 3, with_cpu=False),
