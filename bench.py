@@ -867,10 +867,9 @@ def bench_fit(args, local):
         if fit_ms:  # SURVEY 8(d) bytes per sample over the epoch's DEVICE time (fit_time of the twin's log = gorse_mf_epoch_times)
             ep_s = float(np.mean(fit_ms)) * 1e-3
             gbs = data.n_train * (6 * d * 4 + 12) / ep_s / 1e9
-            rec["roofline"] = {"bound": "hbm", "kernel": "bpr_update_user_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ep_s * 1e3,
-                               "l2_atomic": {"achieved": data.n_train * 2 * d / ep_s / 1e9, "peak": 243.0, "unit": "G atomic dwords/s",
-                                             "frac": data.n_train * 2 * d / ep_s / 1e9 / 243.0}}
+            rec["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                               "l2_atomic_frac": data.n_train * 2 * d / ep_s / 1e9 / 243.0}  # of the 243 G atomic dwords/s (see the headline)
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             o = orc.Oracle()
@@ -905,8 +904,8 @@ def bench_fit(args, local):
         if fit_ms:  # 2 nnz d 4 + 2 (U + I) d 4 bytes per epoch
             algo = 2.0 * nnz * d * 4 + 2.0 * (data.U + data.I) * d * 4
             rec["hbm_frac"] = algo / (float(np.mean(fit_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS
-            rec["roofline"] = {"bound": "hbm", "kernel": "als_row_kernel", "achieved": rec["hbm_frac"] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": rec["hbm_frac"], "traffic": None, "avg_launch_ms": float(np.mean(fit_ms))}
+            rec["roofline"] = {"bound": "hbm", "achieved": rec["hbm_frac"] * HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": rec["hbm_frac"], "traffic": None}  # (avg_launch_ms = fit_ms_per_epoch)
         if not args.no_cpu_baseline:
             from oracle import oracle as orc
             o = orc.Oracle()
@@ -971,13 +970,30 @@ def emit(out, tag="default"):
     # the finer points of their rooflines: moved to the notes, numbers included
     boiler = ("n_gpus", "warmup", "higher_is_better", "scaling", "vs_baseline", "data")
     fine = ("algorithmic_bytes_per_sample", "sampler_avg_ms", "user_sort_avg_ms", "algorithmic_flop_per_pair", "mfma_macs_per_gathered_row",
-            "algorithmic_bytes_per_epoch", "sweeps_ms_per_epoch", "gram_ms_per_epoch", "full_launch_samples")
+            "algorithmic_bytes_per_epoch", "sweeps_ms_per_epoch", "gram_ms_per_epoch", "full_launch_samples", "traffic_full_launch",
+            "traffic_session_round")
+    if isinstance(line.get("roofline"), dict):  # the headline keeps its figures but for the bookkeeping of the traffic record
+        notes["roofline.moved"] = {f: line["roofline"].pop(f) for f in ("full_launch_samples", "traffic_full_launch", "traffic_session_round")
+                                   if f in line["roofline"]}
+    if isinstance(line.get("fit"), dict):  # per Fit record: what follows from the figures that stay, or describes the check beside them
+        for k, v in line["fit"].items():
+            if isinstance(v, dict):
+                moved = {f: v.pop(f) for f in ("epochs_done", "evaluations", "oracle_seconds", "samples_per_s", "entries_per_s", "hbm_frac") if f in v}
+                if moved:
+                    notes["fit.%s.moved" % k] = moved
+    # what a secondary object's roofline keeps in the line itself (the contract's keys + the stage times of the top-k pass); the rest
+    # -- launch counts, samples per launch, clock, secondary rates -- rides in the notes, numbers included
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "mfma_f32_frac", "rescore_avg_ms",
+            "tie_history_sweep_ms_per_step", "tie_replay_ms_per_step", "bound_measured", "l2_atomic")
     for k, v in line.items():
         if k in ("config", "roofline", "cpu_baseline") or not isinstance(v, dict) or "metric" not in v:
             continue
         moved = {b: v.pop(b) for b in boiler if b in v}
+        if isinstance(v.get("metric"), str) and " (" in v["metric"]:  # the parenthetical of a secondary metric's name: to the notes
+            moved["metric"] = v["metric"]
+            v["metric"] = v["metric"].split(" (")[0]
         if isinstance(v.get("roofline"), dict):
-            moved.update({"roofline." + f: v["roofline"].pop(f) for f in fine if f in v["roofline"]})
+            moved.update({"roofline." + f: v["roofline"].pop(f) for f in list(v["roofline"]) if f in fine or f not in keep})
         if moved:
             notes[k + ".moved"] = moved
     # (what is left of a moved block is its `workload` string: every object says in the line itself what it ran)
@@ -988,7 +1004,7 @@ def emit(out, tag="default"):
             notes[k + ".config"] = line[k]["config"]
             line[k]["config"] = {"workload": line[k]["config"].get("workload")}
     # last resort for the 8 KB tail: the rooflines of the `fit` records (derived from their fit_ms_per_epoch) move to the notes too
-    if len(json.dumps(line, separators=(",", ":"))) >= 7700 and isinstance(line.get("fit"), dict):
+    if len(json.dumps(line, separators=(",", ":"))) >= 7900 and isinstance(line.get("fit"), dict):
         for k, v in line["fit"].items():
             if isinstance(v, dict) and "roofline" in v:
                 notes["fit.%s.roofline" % k] = v.pop("roofline")
