@@ -621,8 +621,10 @@ extern "C" int32_t gorse_hip_test_topk_get_thresholds(gorse_topk *h, float *out,
 // (more than the list's 512 slots = it overflowed)
 extern "C" int32_t gorse_hip_test_topk_get_flags(gorse_topk *h, uint8_t *flags, int64_t n) {
     if (!h || !flags) return fail(GORSE_ERR_INVALID, "NULL argument");
-    if ((int64_t)h->host_flags.size() < n) return fail(GORSE_ERR_INVALID, "no MFMA search of that size has run on this handle");
-    memcpy(flags, h->host_flags.data(), (size_t)n);
+    if ((int64_t)h->cflag.n < n) return fail(GORSE_ERR_INVALID, "no MFMA search of that size has run on this handle");
+    GORSE_TRY(h->use());  // the flag bytes stay on the device behind the rescoring: the tie path lists them there (flag_compact_kernel)
+    GORSE_HIP_CHECK(hipMemcpyAsync(flags, h->cflag.p, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     return GORSE_OK;
 }
 extern "C" int32_t gorse_hip_test_topk_get_foreign_counts(gorse_topk *h, int32_t *counts, int64_t n) {

@@ -41,7 +41,9 @@ struct gorse_topk {
     gorse::DevBuf<int32_t> res_idx, res_cnt;
     gorse::DevBuf<float> res_dist;
     // tie replay (history sweep of the flagged queries + topk_tie_sort_kernel + topk_tie_replay_kernel)
-    gorse::DevBuf<int32_t> rp_pos, rp_ccnt, rp_hcnt;
+    gorse::DevBuf<int32_t> rp_pos, rp_ccnt, rp_hcnt, fl_pos;  // fl_*: the chunk's flagged queries, listed on the device (flag_compact_kernel)
+    gorse::DevBuf<int64_t> fl_self;
+    gorse::DevBuf<long long> fl_cnt;
     gorse::DevBuf<int64_t> rp_self;
     gorse::DevBuf<uint16_t> rp_op;
     gorse::DevBuf<float> rp_margin, rp_fslice;  // rp_fslice: final threshold of every (row slice, query) of a history sweep
@@ -75,8 +77,6 @@ struct gorse_topk {
     gorse::DevBuf<long long> tri_offsets;
     gorse::DevBuf<uint2> tri_entries, tri_in_entries;
     int64_t tri_packed_counts = 0, tri_packed_entries = 0;
-    std::vector<uint8_t> host_flags;  // the last chunk's per-query flags as the host read them behind the rescoring (non-zero: the
-                                      // query left the sweep + rescoring undecided and went on to the tie path; gorse_hip_test_topk_get_flags)
     std::vector<uint8_t> dbg_flags;   // probe (variant bit 24): the pilot's flags and list lengths of the last chunk
     std::vector<int32_t> dbg_counts;
     int32_t use() const {

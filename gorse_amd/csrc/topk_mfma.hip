@@ -2308,6 +2308,46 @@ __global__ void pilot_unset_count_kernel(const float *__restrict__ f0, int64_t n
         }
 }
 
+// The flagged queries of a chunk, listed in ascending order by ONE workgroup (a megabyte of flag bytes: two passes of a few
+// microseconds): pos[] their positions in the chunk, self[] the stored ids the tie path excludes (-1: a query vector), cnt[0] how
+// many, cnt[1] how many of them carry flag 2 (a warm start that could not be verified).  Of a triangle shard only the queries this
+// rank owns count.
+__global__ __launch_bounds__(1024) void flag_compact_kernel(const uint8_t *__restrict__ cflag, int64_t m, int tri_rank, int tri_world, int bq,
+                                                            int64_t q0, const int64_t *__restrict__ qid, int by_vector,
+                                                            int32_t *__restrict__ pos, int64_t *__restrict__ self, long long *__restrict__ cnt) {
+    __shared__ int part[1024], part2[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = ((m + 1023) / 1024 + 15) & ~(int64_t)15, a = std::min<int64_t>(m, tid * per), b = std::min<int64_t>(m, a + per);
+    auto mine = [&](int64_t t) { return tri_world <= 1 || (int)((t / bq) % tri_world) == tri_rank; };
+    int c1 = 0, c2 = 0;
+    for (int64_t t = a; t < b; t++) {
+        const uint8_t f = cflag[t];
+        if (f && mine(t)) c1++, c2 += f == 2;
+    }
+    part[tid] = c1;
+    part2[tid] = c2;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, run2 = 0;
+        for (int i = 0; i < 1024; i++) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+            run2 += part2[i];
+        }
+        cnt[0] = run;
+        cnt[1] = run2;
+    }
+    __syncthreads();
+    int at = part[tid];
+    for (int64_t t = a; t < b; t++)
+        if (cflag[t] && mine(t)) {
+            pos[at] = (int32_t)t;
+            self[at] = by_vector ? -1 : (qid ? qid[t] : q0 + t);
+            at++;
+        }
+}
+
 __global__ void fill_kernel(float *__restrict__ out, int64_t n, float v) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) out[t] = v;
 }
@@ -2477,7 +2517,6 @@ int32_t search_setup(gorse_topk *h, ChunkState &cs, const int64_t *qid_host, int
     h->n_fallback = 0;
     h->n_tie = 0;
     h->n_resweep = 0;
-    h->host_flags.assign((size_t)mb, 0);  // kept in the handle: gorse_hip_test_topk_get_flags
     return GORSE_OK;
 }
 
@@ -2675,7 +2714,6 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
     const uint16_t *Bop = cs.Bop;
     const float *qn2 = cs.qn2, *Qf = cs.Qf;
     const SweepParams &sp = cs.sp;
-    std::vector<uint8_t> &flags = h->host_flags;
     int tok;
     RescoreParams rp;
     rp.X = h->X.p;
@@ -2709,19 +2747,29 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
     topk_rescore_kernel<<<dim3((unsigned)m), dim3(kBlock), lds, h->stream>>>(rp);
     GORSE_HIP_CHECK(hipGetLastError());
     h->prof.end(tok, h->stream);
-    GORSE_HIP_CHECK(hipMemcpyAsync(flags.data(), h->cflag.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    // The queries the sweep + rescoring could not decide (ties in the top k + 1, NaN, overflow; of a triangle shard: among the queries
+    // this rank owns -- a foreign query's flag, a staging overflow seen here, has travelled to its owner) are listed ON THE DEVICE,
+    // in ascending order, with the stored ids the replay excludes: the host reads two words.  (Rounds 1-5 copied the chunk's flag
+    // bytes out and walked them: 0.63 ms between the rescoring and the tie path of a C4 pass, profiles/r06_i_timeline_topk_c4_before.txt.)
+    GORSE_TRY(h->fl_pos.ensure((size_t)cs.mb));
+    GORSE_TRY(h->fl_self.ensure((size_t)cs.mb));
+    GORSE_TRY(h->fl_cnt.ensure(2));
+    flag_compact_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(h->cflag.p, m, cs.tri_rank, cs.tri_world, kSymBQ,
+                                                              by_vector ? (int64_t)-1 : q_contig_begin + c0, qid_host ? h->qid.p : nullptr,
+                                                              by_vector ? 1 : 0, h->fl_pos.p, h->fl_self.p, h->fl_cnt.p);
+    GORSE_HIP_CHECK(hipGetLastError());
+    long long fl[2] = {0, 0};
+    GORSE_HIP_CHECK(hipMemcpyAsync(fl, h->fl_cnt.p, sizeof(fl), hipMemcpyDeviceToHost, h->stream));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-    std::vector<int64_t> fb;  // queries the sweep + rescoring could not decide (ties in the top k+1, NaN, overflow)
-    for (int64_t t = 0; t < m; t++) {
-        if (cs.tri_world > 1 && (int)((t / kSymBQ) % cs.tri_world) != cs.tri_rank) {
-            flags[t] = 0;  // another rank's query: its flags (a staging overflow seen here) have travelled to its owner
-            continue;
-        }
-        if (flags[t]) {
-            fb.push_back(t);
-            h->n_resweep += flags[t] == 2;
-        }
-    }
+    const int64_t n_flagged = fl[0];
+    h->n_resweep += fl[1];
+    auto fetch_pos = [&](int64_t at, int64_t n, std::vector<int64_t> &out) -> int32_t {  // flagged positions [at, at + n) to the host
+        std::vector<int32_t> tmp((size_t)n);
+        GORSE_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->fl_pos.p + at, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        for (int32_t v : tmp) out.push_back(v);
+        return GORSE_OK;
+    };
     auto stored_id = [&](int64_t t) -> int64_t {
         return by_vector ? -1 : (qid_host ? qid_host[c0 + t] : q_contig_begin + c0 + t);
     };
@@ -2729,20 +2777,12 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
     std::vector<int64_t> rest;
     // (with a mask the replay's gap arithmetic -- which counts the rows between two recorded ones -- would count masked
     // rows too: those queries take the literal scan, which skips masked rows)
-    if (!fb.empty() && g_topk_force_path != 3 && !h->has_mask) {
-        std::vector<int32_t> pos;
-        std::vector<int64_t> selfs;
+    if (n_flagged > 0 && g_topk_force_path != 3 && !h->has_mask) {
         std::vector<uint8_t> f2;
-        for (size_t f0 = 0; f0 < fb.size(); f0 += (size_t)kReplayChunk) {
-            const int64_t m2 = std::min<int64_t>(kReplayChunk, (int64_t)(fb.size() - f0));
-            pos.resize((size_t)m2);
-            selfs.resize((size_t)m2);
-            for (int64_t r = 0; r < m2; r++) {
-                pos[r] = (int32_t)fb[f0 + r];
-                selfs[r] = stored_id(fb[f0 + r]);
-            }
-            GORSE_TRY(h->rp_pos.ensure((size_t)m2));
-            GORSE_TRY(h->rp_self.ensure((size_t)m2));
+        for (int64_t f0 = 0; f0 < n_flagged; f0 += kReplayChunk) {
+            const int64_t m2 = std::min<int64_t>(kReplayChunk, n_flagged - f0);
+            const int32_t *pos_dev = h->fl_pos.p + f0;
+            const int64_t *self_dev = h->fl_self.p + f0;
             GORSE_TRY(h->rp_op.ensure((size_t)m2 * kpad));
             GORSE_TRY(h->rp_margin.ensure((size_t)m2));
             // Row slices: a history sweep serves few queries (1 % of a chunk), so its workgroups are few, and each would walk
@@ -2768,9 +2808,7 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
             GORSE_TRY(h->rp_hcnt.ensure(sm2));
             GORSE_TRY(h->rp_flag.ensure(sm2));
             GORSE_TRY(h->rp_fslice.ensure(sm2));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_pos.p, pos.data(), (size_t)m2 * 4, hipMemcpyHostToDevice, h->stream));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->rp_self.p, selfs.data(), (size_t)m2 * 8, hipMemcpyHostToDevice, h->stream));
-            gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, h->rp_pos.p, kpad,
+            gather_pos_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(Bop, h->qmargin.p, pos_dev, kpad,
                                                                              h->rp_op.p, h->rp_margin.p);
             GORSE_HIP_CHECK(hipGetLastError());
             GORSE_HIP_CHECK(hipMemsetAsync(h->rp_flag.p, 0, sm2, h->stream));
@@ -2797,8 +2835,8 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
             pp.norm2 = h->norm2.p;
             pp.Qf = Qf;
             pp.qn2 = qn2;
-            pp.self = h->rp_self.p;
-            pp.pos = h->rp_pos.p;
+            pp.self = self_dev;
+            pp.pos = pos_dev;
             pp.cbuf = h->rp_cbuf.p;
             pp.ccnt = h->rp_ccnt.p;
             pp.hbuf = h->rp_hbuf.p;
@@ -2867,15 +2905,18 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
             f2.resize((size_t)m2);
             GORSE_HIP_CHECK(hipMemcpyAsync(f2.data(), h->rp_flag.p, (size_t)m2, hipMemcpyDeviceToHost, h->stream));
             GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-            for (int64_t r = 0; r < m2; r++) {
-                if (f2[r])
-                    rest.push_back(fb[f0 + r]);
-                else
-                    h->n_tie++;
+            int64_t undecided = 0;
+            for (int64_t r = 0; r < m2; r++) undecided += f2[r] != 0;
+            h->n_tie += m2 - undecided;
+            if (undecided > 0) {  // rare: their positions come to the host now
+                std::vector<int64_t> at;
+                GORSE_TRY(fetch_pos(f0, m2, at));
+                for (int64_t r = 0; r < m2; r++)
+                    if (f2[r]) rest.push_back(at[(size_t)r]);
             }
         }
-    } else {
-        rest = fb;
+    } else if (n_flagged > 0) {
+        GORSE_TRY(fetch_pos(0, n_flagged, rest));
     }
     // stage 3: whatever is left replays the reference literally over all N vectors (path A); its rows go into
     // the chunk's device result arrays like everybody else's
