@@ -58,27 +58,48 @@ constexpr int kMmKB = 16, kMmAs = kMmKB + 1;
 // stops at k2.  So the kernel has no edge: a thread's PT elements of an operand block are contiguous in the operand's storage, ONE
 // address per operand and block, the elements at immediate offsets.  (With sixteen separately clamped 64-bit addresses the kernel
 // held 236 registers = two waves per SIMD, the matrix pipe 43 % busy: 61-65 TFLOP/s at 4096^3, profiles/r04_zd_pmc_SQ_mm.txt.)
+// Round 6, measured and not kept (profiles/r06_k_ab_mm_pipelined.txt, r06_l_ab_mm_eight_waves.txt, r06_m_pmc_SQ_mm.txt; every form bit-equal):
+//   * the fragment reads of step s + 1 issued before the MFMAs of step s (unrolled block, the LDS round trip hidden inside the wave):
+//     needs a second fragment set = 168 registers = three workgroups per CU -- 96.7 TFLOP/s against 112.6 at 4096^3;
+//   * eight waves per workgroup (64 x 32 of the tile each, 54 registers, eight waves per SIMD), four or three workgroups per CU:
+//     112.3-112.6 against 113.6 -- the kernel is not short of ready waves either.
+// What the counters say about the shipped form at 4096^3: SQ_VALU_MFMA_BUSY_CYCLES 2^31 = 64 cycles x every MFMA; GRBM_GUI_ACTIVE / 8 XCDs
+// / 1.199 ms = 2.05 GHz -- the clock the chip sustains under this load (MI355X_MICROARCH.md, DVFS), not the 2.4 GHz the 157.3 TFLOP/s
+// peak is quoted at -- and the matrix pipe is busy in 0.85 of those cycles: 114.6 TFLOP/s is 0.73 of the nominal peak and 0.85 of the
+// 134.6 TFLOP/s this clock allows.  126 TFLOP/s (0.80 nominal) would need the pipe 0.94 busy at 2.05 GHz.  The one inefficiency the
+// counters show on the critical path: SQ_LDS_BANK_CONFLICT 2^25 cycles (5 % of a CU's time) from the two-way conflicts of the A tile's
+// stores (two threads hold the two halves of a row of 16 l, rows 17 words apart: 17 a = 17 b + 8 mod 64 at a - b = 8).
+#ifndef GORSE_MM_WAVES
+#define GORSE_MM_WAVES 4  // waves per workgroup of the 128 x 128 tile form: 4 (a 64 x 64 quarter each) or 8 (half a quarter: 64 x 32)
+#endif
+#ifndef GORSE_MM_WGS8
+#define GORSE_MM_WGS8 4   // workgroups per CU the eight-wave form is compiled for (4: 64 registers per wave; 3: 85)
+#endif
+constexpr int mm_waves(int w) { return w == 2 ? GORSE_MM_WAVES : 4; }
 template <bool TA, bool TB, int W>
-__global__ __launch_bounds__(256, W == 2 ? 4 : 2) void sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ a, int lda,
+__global__ __launch_bounds__(64 * mm_waves(W), W == 2 ? (mm_waves(W) == 8 ? GORSE_MM_WGS8 : 4) : 2) void sgemm_mfma_kernel(int m, int n, int k, const float *__restrict__ a, int lda,
                                                                          const float *__restrict__ b, int ldb, float *__restrict__ c,
                                                                          int ldc) {
     constexpr int T = 64 * W;       // tile edge
-    constexpr int PT = T * kMmKB / 256;  // elements of each operand tile per thread (8 or 4)
+    constexpr int NWV = mm_waves(W), NT = 64 * NWV;
+    constexpr int CW = NWV == 8 ? W / 2 : W;  // 32-column blocks per wave (eight waves: each takes half of a quarter's columns)
+    constexpr int PT = T * kMmKB / NT;  // elements of each operand tile per thread (8 or 4)
     __shared__ float As[2][T * kMmAs];
     __shared__ float Bs[2][kMmKB * T];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
-    const int wi = 32 * W * (wv >> 1), wj = 32 * W * (wv & 1);  // the wave's quarter inside the tile
+    const int qv = NWV == 8 ? wv >> 1 : wv;  // the wave's quarter inside the tile, and (eight waves) its half of the quarter's columns
+    const int wi = 32 * W * (qv >> 1), wj = 32 * W * (qv & 1) + (NWV == 8 ? 32 * CW * (wv & 1) : 0);
     (void)m, (void)n;
     uint32_t c_lane = ((uint32_t)(i0 + wi + 4 * (lane >> 5)) * (uint32_t)ldc + (uint32_t)(j0 + wj + (lane & 31))) * 4u;
     auto c_off = [&](int bi, int bj, int r) {
         return c_lane + ((uint32_t)(32 * bi + (r & 3) + 8 * (r >> 2)) * (uint32_t)ldc + (uint32_t)(32 * bj)) * 4u;
     };
-    f32x16 acc[W][W];
+    f32x16 acc[W][CW];
 #pragma unroll
     for (int bi = 0; bi < W; bi++)
 #pragma unroll
-        for (int bj = 0; bj < W; bj++)
+        for (int bj = 0; bj < CW; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++)  // (C spans less than 4 GB: gorse_hip_sgemm -- one 32-bit offset per element from the scalar base)
                 acc[bi][bj][r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(c) + c_off(bi, bj, r));
@@ -117,15 +138,15 @@ __global__ __launch_bounds__(256, W == 2 ? 4 : 2) void sgemm_mfma_kernel(int m, 
         const int steps = min(kMmKB, k2 - l0);  // even
         const float *as = As[buf], *bs = Bs[buf];
         for (int kk = 0; kk < steps; kk += 2) {
-            float fa[W], fb[W];
+            float fa[W], fb[CW];
 #pragma unroll
             for (int bi = 0; bi < W; bi++) fa[bi] = as[(wi + 32 * bi + (lane & 31)) * kMmAs + kk + (lane >> 5)];
 #pragma unroll
-            for (int bj = 0; bj < W; bj++) fb[bj] = bs[(kk + (lane >> 5)) * T + wj + 32 * bj + (lane & 31)];
+            for (int bj = 0; bj < CW; bj++) fb[bj] = bs[(kk + (lane >> 5)) * T + wj + 32 * bj + (lane & 31)];
 #pragma unroll
             for (int bi = 0; bi < W; bi++)
 #pragma unroll
-                for (int bj = 0; bj < W; bj++) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi], fb[bj], acc[bi][bj], 0, 0, 0);
+                for (int bj = 0; bj < CW; bj++) acc[bi][bj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[bi], fb[bj], acc[bi][bj], 0, 0, 0);
         }
         if (more) lstore(buf ^ 1);  // (the other buffer: everybody left it before the barrier of the block before)
         __syncthreads();
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(256, W == 2 ? 4 : 2) void sgemm_mfma_kernel(int m, 
 #pragma unroll
     for (int bi = 0; bi < W; bi++)
 #pragma unroll
-        for (int bj = 0; bj < W; bj++)
+        for (int bj = 0; bj < CW; bj++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(c) + c_off(bi, bj, r)) = acc[bi][bj][r];
@@ -261,7 +282,7 @@ int32_t sgemm_on_device(hipStream_t st, EventPair &ev, int32_t transA, int32_t t
 #define MM(TA_, TB_)                                                                                                   \
     do {                                                                                                               \
         if (big)                                                                                                       \
-            sgemm_mfma_kernel<TA_, TB_, 2><<<grid, block, 0, st>>>(mp, np, k, ka, klda, kb, kldb, kc, kldc);          \
+            sgemm_mfma_kernel<TA_, TB_, 2><<<grid, dim3(64 * mm_waves(2)), 0, st>>>(mp, np, k, ka, klda, kb, kldb, kc, kldc); \
         else                                                                                                           \
             sgemm_mfma_kernel<TA_, TB_, 1><<<grid, block, 0, st>>>(mp, np, k, ka, klda, kb, kldb, kc, kldc);          \
     } while (0)

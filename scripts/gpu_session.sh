@@ -11,6 +11,7 @@
 #   pmc:<workload>:<kernel substring>:<key>[:wide]   FETCH_SIZE and WRITE_SIZE passes -> <tag>_traffic.json[key]
 #   sq:<workload>:<kernel substring>                 one SQ pass (MFMA busy, wave cycles, waits) -> <tag>_pmc_SQ_<W>.txt
 #   pmcx:<workload>:<kernel substring>:<counters joined by +>[:<name>]   one pass of any counters -> <tag>_pmcx_<W>[_<name>].txt
+#   mmpmc / mmsq         floats.MM 4096^3 (scripts/gpu_mm_once.py) under the two traffic passes / one SQ pass
 #   probe:<script>[:<args with + for spaces>]        python scripts/<script> args -> <tag>_probe_<script>.txt
 #   ranks2[:<workload>]  bench.py as TWO ranks on the one GPU over gloo (functional check of the N > 1 path; numbers meaningless)
 #   smoke                __graft_entry__.smoke()
@@ -82,6 +83,20 @@ for STAGE in "$@"; do
         python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmcx_${W}${D:+_$D}.txt" 2>&1
         grep -h "$B" "$OUT/${TAG}_pmcx_${W}${D:+_$D}.txt" | cut -c1-60,91-200 | head -12
         rm -rf "$OUT/pmcx_${TAG}_${W}" ;;
+    mmpmc)  # floats.MM 4096^3 (scripts/gpu_mm_once.py): the FETCH_SIZE / WRITE_SIZE passes -> <tag>_traffic.json[mm]
+        for CNT in FETCH_SIZE WRITE_SIZE; do
+            ( cd /tmp && PYTHONPATH=$ROOT timeout 600 rocprofv3 --kernel-trace --pmc $CNT -d "$OUT/pmc_${TAG}_mm_$CNT" -o bench -- python "$ROOT/scripts/gpu_mm_once.py" > /dev/null 2> "$OUT/${TAG}_pmc_mm_$CNT.err" )
+        done
+        GORSE_PMC_SESSION="${PMC_SESSION:-$TAG}" python "$ROOT/scripts/pmc_traffic.py" mm sgemm_mfma "$(find "$OUT/pmc_${TAG}_mm_FETCH_SIZE" -name '*_results.db' | head -1)" \
+            "$(find "$OUT/pmc_${TAG}_mm_WRITE_SIZE" -name '*_results.db' | head -1)" "$OUT/${TAG}_traffic.json" wide
+        rm -rf "$OUT"/pmc_${TAG}_mm_* ;;
+    mmsq)   # the same command under one SQ pass: matrix-pipe busy cycles, wave cycles, waits, the clock (GRBM_GUI_ACTIVE / time)
+        ( cd /tmp && PYTHONPATH=$ROOT timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+            -d "$OUT/pmc_${TAG}_mm_SQ" -o bench -- python "$ROOT/scripts/gpu_mm_once.py" > "$OUT/${TAG}_pmc_SQ_mm.out" 2> "$OUT/${TAG}_pmc_SQ_mm.err" )
+        DB=$(find "$OUT/pmc_${TAG}_mm_SQ" -name '*_results.db' | head -1)
+        python "$ROOT/scripts/rocpd_summary.py" "$DB" > "$OUT/${TAG}_pmc_SQ_mm.txt" 2>&1
+        grep -h "sgemm_mfma" "$OUT/${TAG}_pmc_SQ_mm.txt" | cut -c1-60,91-170 | head -12; cat "$OUT/${TAG}_pmc_SQ_mm.out" | tail -3
+        rm -rf "$OUT/pmc_${TAG}_mm_SQ" ;;
     probe)
         ARGS=$(echo "${B:-}" | tr '+' ' ')
         PLIB="$ROOT/gorse_amd/lib/libgorse_hip_probe.so"  # the probe build (make -C gorse_amd/csrc probe-lib) when it exists
