@@ -66,9 +66,9 @@ constexpr int kMmKB = 16, kMmAs = kMmKB + 1;
 // What the counters say about the shipped form at 4096^3: SQ_VALU_MFMA_BUSY_CYCLES 2^31 = 64 cycles x every MFMA; GRBM_GUI_ACTIVE / 8 XCDs
 // / 1.199 ms = 2.05 GHz -- the clock the chip sustains under this load (MI355X_MICROARCH.md, DVFS), not the 2.4 GHz the 157.3 TFLOP/s
 // peak is quoted at -- and the matrix pipe is busy in 0.85 of those cycles: 114.6 TFLOP/s is 0.73 of the nominal peak and 0.85 of the
-// 134.6 TFLOP/s this clock allows.  126 TFLOP/s (0.80 nominal) would need the pipe 0.94 busy at 2.05 GHz.  The one inefficiency the
-// counters show on the critical path: SQ_LDS_BANK_CONFLICT 2^25 cycles (5 % of a CU's time) from the two-way conflicts of the A tile's
-// stores (two threads hold the two halves of a row of 16 l, rows 17 words apart: 17 a = 17 b + 8 mod 64 at a - b = 8).
+// 134.6 TFLOP/s this clock allows.  126 TFLOP/s (0.80 nominal) would need the pipe 0.94 busy at 2.05 GHz.  SQ_LDS_BANK_CONFLICT reads
+// 2^25 cycles (5 % of a CU's time); a conflict-free assignment of the A tile's stores (the two halves of a row of 16 l to lanes whose
+// rows never differ by 8) changed neither that counter nor the time (114.9 against 114.4, r06_n_ab_mm_astore.txt): not kept.
 #ifndef GORSE_MM_WAVES
 #define GORSE_MM_WAVES 4  // waves per workgroup of the 128 x 128 tile form: 4 (a 64 x 64 quarter each) or 8 (half a quarter: 64 x 32)
 #endif
