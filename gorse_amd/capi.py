@@ -113,6 +113,7 @@ SIGNATURES = {
     "gorse_topk_tri_pack_read": (C.c_int32, [_vp, _vp, _vp]),
     "gorse_topk_tri_unpack": (C.c_int32, [_vp, C.c_int32, _vp, C.c_int64, _vp, C.c_int64]),
     "gorse_topk_tri_finish": (C.c_int32, [_vp, _i32p, _f32p]),
+    "gorse_topk_tri_all_pairs_local": (C.c_int32, [C.POINTER(_vp), C.c_int32, C.c_int64, C.c_int64, C.c_int32, _i32p, _f32p]),
     "gorse_hip_test_topk_resweeps": (C.c_int32, [_vp, _i64p]),
     "gorse_hip_test_topk_last_symmetric": (C.c_int32, [_vp, C.POINTER(C.c_int32)]),
     "gorse_hip_test_topk_sym_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
@@ -546,6 +547,17 @@ class TopK:
         a, b = C.c_int64(0), C.c_int64(0)
         check(lib().gorse_topk_last_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+def topk_tri_all_pairs_local(handles, k, q_begin=0, q_end=None, fetch=True):
+    """gorse_topk_tri_all_pairs_local: the triangle-sharded all-pairs search over the TopK handles of ONE process (handles[r] = rank r)"""
+    q_end = handles[0].N if q_end is None else q_end
+    nq = q_end - q_begin
+    hs = (_vp * len(handles))(*[h.h for h in handles])
+    idx = np.empty((nq, k), np.int32) if fetch else None
+    dist = np.empty((nq, k), np.float32) if fetch else None
+    check(lib().gorse_topk_tri_all_pairs_local(hs, len(handles), q_begin, q_end, k, _p(idx, _i32p), _p(dist, _f32p)))
+    return idx, dist
 
 
 class Comm:

@@ -3284,3 +3284,40 @@ extern "C" int32_t gorse_topk_tri_finish(gorse_topk *h, int32_t *idx_out, float 
     cs->tri_stage = 3;
     return GORSE_OK;
 }
+
+// One process, N handles (one per GPU -- or N on one device: the emulation the tests run): the whole triangle-sharded search in one
+// call, the two exchanges as device-to-device copies between the handles (hipMemcpyDefault: peer-to-peer over xGMI where the devices
+// can reach each other, staged otherwise).  What a Go master that owns all GPUs of a node calls (integration/go/common/ann/
+// bruteforce_hip.go SearchAllSharded); one process per GPU drives gorse_topk_tri_* itself and moves the messages over its own transport.
+extern "C" int32_t gorse_topk_tri_all_pairs_local(gorse_topk **hs, int32_t n, int64_t q_begin, int64_t q_end, int32_t k, int32_t *idx_out,
+                                                  float *dist_out) {
+    if (!hs || n < 1) return fail(GORSE_ERR_INVALID, "no handles");
+    for (int r = 0; r < n; r++)
+        if (!hs[r]) return fail(GORSE_ERR_INVALID, "handle %d is NULL", r);
+    for (int r = 0; r < n; r++) GORSE_TRY(gorse_topk_tri_begin(hs[r], q_begin, q_end, k, r, n));  // every rank's pilots are enqueued ...
+    for (int r = 0; r < n; r++) {                                                                // ... before anybody waits for them
+        GORSE_TRY(hs[r]->use());
+        GORSE_HIP_CHECK(hipStreamSynchronize(hs[r]->stream));
+    }
+    for (int r = 0; r < n; r++)  // all-gather of the thresholds: every rank fetches the other ranks' slices from where they lie
+        for (int s = 0; s < n; s++) {
+            if (s == r) continue;
+            int64_t lo = 0, hi = 0;
+            GORSE_TRY(gorse_topk_tri_slice(hs[s], s, &lo, &hi, nullptr));
+            if (hi > lo) GORSE_TRY(gorse_topk_tri_thresholds_put(hs[r], lo, hi, hs[s]->f0.p + lo));
+        }
+    for (int r = 0; r < n; r++) GORSE_TRY(gorse_topk_tri_sweep(hs[r]));  // enqueued on every device, then awaited
+    for (int r = 0; r < n; r++) {
+        GORSE_TRY(hs[r]->use());
+        GORSE_HIP_CHECK(hipStreamSynchronize(hs[r]->stream));
+    }
+    for (int src = 0; src < n; src++)  // all-to-all of the foreign lists
+        for (int dst = 0; dst < n; dst++) {
+            if (dst == src) continue;
+            int64_t nc = 0, ne = 0;
+            GORSE_TRY(gorse_topk_tri_pack(hs[src], dst, &nc, &ne));
+            if (nc > 0) GORSE_TRY(gorse_topk_tri_unpack(hs[dst], src, hs[src]->tri_counts.p, nc, reinterpret_cast<const uint64_t *>(hs[src]->tri_entries.p), ne));
+        }
+    for (int r = 0; r < n; r++) GORSE_TRY(gorse_topk_tri_finish(hs[r], idx_out, dist_out));  // every rank writes the rows it owns
+    return GORSE_OK;
+}

@@ -310,6 +310,11 @@ int32_t gorse_topk_tri_pack_read(gorse_topk *h, int32_t *counts /*host or device
 int32_t gorse_topk_tri_unpack(gorse_topk *h, int32_t src, const int32_t *counts, int64_t n_counts, const uint64_t *entries,
                               int64_t n_entries);
 int32_t gorse_topk_tri_finish(gorse_topk *h, int32_t *idx_out /*host nq x k or NULL*/, float *dist_out /*host nq x k or NULL*/);
+/* ONE process that holds all n handles (one per GPU of a node -- the Go master's mode -- or n on one device: the emulation the tests
+ * run): the whole sequence above in one call, both exchanges as device-to-device copies between the handles.  hs[r] is rank r; every
+ * handle holds the same index.  idx_out / dist_out: all nq x k rows (every rank writes the rows it owns), or NULL. */
+int32_t gorse_topk_tri_all_pairs_local(gorse_topk **hs, int32_t n, int64_t q_begin, int64_t q_end, int32_t k, int32_t *idx_out /*host or NULL*/,
+                                       float *dist_out /*host or NULL*/);
 int32_t gorse_topk_synchronize(gorse_topk *h);
 #define GORSE_PROF_TOPK_SCORE 0   /* path A: dist_kernel (pair-at-a-time scan in the reference's order)      */
 #define GORSE_PROF_TOPK_RESCORE 1 /* path A: select_fast_kernel (+ the literal container/heap select_kernel)    */

@@ -49,6 +49,10 @@ def test_triangle_shards_equal_the_single_rank_pass(oracle, metric, dtype, d):
         assert np.array_equal(idx, ref_i), "world %d: indices differ in %d rows" % (world, int((idx != ref_i).any(axis=1).sum()))
         assert np.array_equal(bits(dist), bits(ref_d)), "world %d: distance bits differ" % world
         assert all(h.last_symmetric() for h in handles[:world])
+    # the one-call form for a process that holds every rank's handle (gorse_topk_tri_all_pairs_local: what the Go master calls)
+    for world in (2, 4):
+        li, ld = capi.topk_tri_all_pairs_local(handles[:world], k)
+        assert np.array_equal(li, ref_i) and np.array_equal(bits(ld), bits(ref_d)), "one-call form, world %d" % world
     # a sample against the oracle itself (the single-rank pass is checked against it elsewhere: tests/test_gpu_topk_mfma.py)
     o_metric = {capi.METRIC_COSINE: orc.METRIC_COSINE, capi.METRIC_NEG_DOT: orc.METRIC_NEG_DOT, capi.METRIC_EUCLIDEAN: orc.METRIC_EUCLIDEAN}[metric]
     Xo = X if dtype == capi.DTYPE_F32 else Xe
