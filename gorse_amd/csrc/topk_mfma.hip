@@ -3211,6 +3211,7 @@ extern "C" int32_t gorse_topk_tri_pack(gorse_topk *h, int32_t dest, int64_t *n_c
             tri_pack_entries_kernel<<<dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), 8192)), dim3(256), 0, h->stream>>>(
                 h->fbuf.p, h->tri_counts.p, reinterpret_cast<const int64_t *>(h->tri_offsets.p), n, dest, cs->tri_world, h->tri_entries.p);
             GORSE_HIP_CHECK(hipGetLastError());
+            GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // the message is complete when this returns: another handle's stream may read it
         }
     }
     h->tri_packed_counts = n, h->tri_packed_entries = total;
