@@ -194,8 +194,8 @@ def parse():
     ap.add_argument("--topk-shard", default="auto", choices=["auto", "rows", "tri"],
                     help="how the C4 pass is split over N > 1 ranks: tri = the TRIANGLE of the symmetric sweep (rank r takes the query blocks "
                          "r, r + N, ...; thresholds all-gathered, foreign candidate lists all-to-all: gorse_topk_tri_*), rows = contiguous "
-                         "query-row shards (no exchange; the symmetric saving on each rank's diagonal square only); auto = tri up to 4 "
-                         "ranks, rows beyond (DESIGN.md section 5: measured per-rank passes 125 / 74 / 67 ms against 130 / 86 / 57)")
+                         "query-row shards (no exchange; the symmetric saving on each rank's diagonal square only); auto = tri "
+                         "(DESIGN.md section 5: measured per-rank passes 122 / 71 / 46 ms at 2 / 4 / 8 ranks against 130 / 86 / 57)")
     ap.add_argument("--mode", type=int, default=capi.BPR_HOGWILD_STORES,
                     help="BPR schedule: 3 = what Fit runs with Jobs > 1 (atomics + the reference's unlocked store for cold negatives), "
                          "0 = atomics only, 1 = sequential, 2 = racy")
@@ -328,14 +328,14 @@ def topk_cpu_baseline(Xe, k, seconds, idx_gpu, dist_gpu, q_begin):
 
 def bench_topk(args, world, rank, local, fence):
     """BASELINE config C4: item-to-item cosine top-100 over N x 128 bf16 embeddings, X replicated.  Over N > 1 ranks either the
-    TRIANGLE of the symmetric sweep is sharded (--topk-shard tri; the default up to 4 ranks: rank r sweeps the query blocks r, r + N,
+    TRIANGLE of the symmetric sweep is sharded (--topk-shard tri, the default: rank r sweeps the query blocks r, r + N,
     ..., the pilot thresholds are all-gathered and the foreign candidate lists exchanged all-to-all inside the timed region) or the
     query rows (rows: no collective).  A step = one all-pairs pass (this rank's share of it); the N x k indices +
     distances stay in HBM (timed region: embeddings resident -> results resident)."""
     N, d, k = args.topk_n, 128, 100
     Xb, Xe = synth.s_emb(N, d, 44)
     t = capi.TopK(Xb, capi.METRIC_COSINE, dtype=capi.DTYPE_BF16, device=local)
-    tri = world > 1 and N >= 1 << 17 and (args.topk_shard == "tri" or (args.topk_shard == "auto" and world <= 4))
+    tri = world > 1 and N >= 1 << 17 and args.topk_shard in ("tri", "auto")
     if tri:
         # the triangle of the symmetric sweep sharded over the ranks: every rank's step covers ALL N query rows' share of the work
         # (its query blocks r, r + world, ...), the exchanges (thresholds, foreign lists) are inside the timed region

@@ -158,6 +158,7 @@ struct SweepParams {
     // their own lists, and what they find for the rows of EVERY earlier block (foreign lists of queries other ranks own included);
     // 0 of 1 = the whole triangle
     int sym_rank, sym_world;
+    int sym_slices;  // SYM: row slices per query block (grid.y; 1 = the whole block's tiles in one workgroup)
 };
 
 // One wave raises the filter threshold of local query ql and compacts its list.
@@ -384,9 +385,13 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
     // SYM (one slice, stride 1): the tiles [skip_lo, skip_lo + skip_n) -- whole tiles of LATER query blocks -- are left to those
     // blocks' workgroups; the tiles [tr_lo, tr_hi) -- the earlier query blocks -- are read along their rows as well
     const SymSchedule sched(SYM ? p.sym_q0 : 0, SYM ? p.nq : 0, kTR, BQ, cblk);  // topk_sym.hpp
-    const int64_t NT = SYM ? sched.tiles(NT_all) : T1 - T0;
+    // SYM with row slices (gridDim.y > 1: the long blocks of a triangle shard): slice y takes an even share of the tiles the block
+    // multiplies, with its own candidate lists (qslice below), the foreign side unchanged
+    const int64_t NTs = SYM ? sched.tiles(NT_all) : 0;
+    const int64_t S0 = SYM ? NTs * blockIdx.y / gridDim.y : 0, S1 = SYM ? NTs * (blockIdx.y + 1) / gridDim.y : 0;
+    const int64_t NT = SYM ? S1 - S0 : T1 - T0;
     auto tile_index = [&](int64_t tl) -> int64_t {  // the tl-th tile this workgroup multiplies
-        if constexpr (SYM) return sched.tile_index(tl);
+        if constexpr (SYM) return sched.tile_index(S0 + tl);
         else return T0 + tl;
     };
     const int64_t qslice = (int64_t)blockIdx.y * p.nq;  // this slice's rows of the per-query output arrays
@@ -1158,7 +1163,10 @@ struct RescoreParams {
     const float *qmargin;
     int kth;
     int tri_rank, tri_world, tri_bq;  // triangle sharding: only the queries of the blocks this rank owns (t / tri_bq % tri_world == tri_rank)
+    int own_slices;                   // SYM sweeps cut into row slices: own lists / counters / flags / final thresholds per slice ...
+    int64_t own_stride;               // ... own_stride queries apart (slice-major)
 };
+constexpr int kMaxOwnSlices = 4;
 constexpr int kCapT = kCap + kCapF;  // candidates the rescoring takes per query: its own list + its foreign list
 
 __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
@@ -1174,11 +1182,28 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     const int tid = threadIdx.x, lane = tid & (kGroup - 1), gib = tid / kGroup;
     const int k = p.k;
     if (p.tri_world > 1 && (int)((t / p.tri_bq) % p.tri_world) != p.tri_rank) return;  // another rank's query
-    if (p.cflag[t]) return;  // path A fills this row
-    const int n_own = p.ccnt[t];
+    // SYM with row slices (a triangle shard whose long blocks are cut over several workgroups: topk_sweep_kernel, sym_slices): the
+    // query has one own list, counter, flag and final threshold PER SLICE, slice-major like a history sweep's
+    const int nsl = p.own_slices > 1 ? p.own_slices : 1;
+    {
+        uint8_t f = p.cflag[t];
+        for (int sl = 1; sl < nsl; sl++) {
+            const uint8_t g = p.cflag[(int64_t)sl * p.own_stride + t];
+            f = f ? f : g;
+        }
+        if (f) {  // path A / the tie path fills this row (a flag of a later slice moves to where the host's list is made from)
+            if (tid == 0 && !p.cflag[t]) p.cflag[t] = f;
+            return;
+        }
+    }
+    int n_own_at[kMaxOwnSlices + 1];
+    n_own_at[0] = 0;
+#pragma unroll
+    for (int sl = 0; sl < kMaxOwnSlices; sl++) n_own_at[sl + 1] = n_own_at[sl] + (sl < nsl ? p.ccnt[(int64_t)sl * p.own_stride + t] : 0);
+    const int n_own = n_own_at[kMaxOwnSlices];
     const int n_for = p.fbuf ? p.fcnt[t] : 0;
-    if (n_for > kCapF) {  // the foreign list overflowed: the tie path sweeps this query on its own
-        if (tid == 0) {
+    if (n_for > kCapF || n_own + (n_for > 0 ? n_for : 0) > kCapT) {  // the foreign list overflowed (or, sliced, the lists together exceed
+        if (tid == 0) {                                                // what this kernel ranks): the tie path sweeps this query on its own
             p.cflag[t] = 1;
             atomicAdd(p.sym_stats + 2, 1ull);
         }
@@ -1202,7 +1227,17 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     for (int s = 0; s < EPT; s++) {
         const int c = tid + s * kBlock;
         ev[s] = c < n_all;
-        const uint2 ent = ev[s] ? (c < n_own ? cb[c] : fb[c - n_own]) : make_uint2(0u, 0u);
+        uint2 ent = make_uint2(0u, 0u);
+        if (ev[s]) {
+            if (c >= n_own) {
+                ent = fb[c - n_own];
+            } else {
+                int sl = 0;
+#pragma unroll
+                for (int u = 1; u < kMaxOwnSlices; u++) sl += c >= n_own_at[u] ? 1 : 0;
+                ent = cb[(int64_t)sl * p.own_stride * kCap + (c - n_own_at[sl])];
+            }
+        }
         ekey[s] = ent.x;
         eidx[s] = ent.y;
     }
@@ -1210,7 +1245,10 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(RescoreParams p) {
     // iff (kth-th best approximate score) - margin >= f0, and with the own threshold still at f0 the two lists hold every row that
     // reaches f0.  (A final own threshold above f0 was derived from -- and verified by -- the own list; f0 = -inf needs no proof.)
     const float mg = p.qmargin[t];
-    const bool verify = p.fbuf && p.f0[t] > -__builtin_inff() && !(p.ffinal[t] > p.f0[t]);
+    // (sliced: a slice that raised its threshold above f0 proved f0 over its own rows, a subset of all rows: that verifies it)
+    float ffin = p.fbuf ? p.ffinal[t] : 0.0f;
+    for (int sl = 1; sl < nsl && p.fbuf; sl++) ffin = fmaxf(ffin, p.ffinal[(int64_t)sl * p.own_stride + t]);
+    const bool verify = p.fbuf && p.f0[t] > -__builtin_inff() && !(ffin > p.f0[t]);
     if (verify) {
         const float f0 = p.f0[t];
         int c_ok = 0;
@@ -2209,7 +2247,7 @@ int32_t launch_sweep_one(gorse_topk *h, const SweepParams &p) {
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&topk_sweep_kernel<KP, NCB, EP, HIST, RB, false, SYM>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     topk_sweep_kernel<KP, NCB, EP, HIST, RB, false, SYM>
-        <<<dim3(grid, HIST ? (unsigned)std::max(p.nslices, 1) : 1u), dim3(WV * 64), lds, h->stream>>>(p);
+        <<<dim3(grid, HIST ? (unsigned)std::max(p.nslices, 1) : (SYM ? (unsigned)std::max(p.sym_slices, 1) : 1u)), dim3(WV * 64), lds, h->stream>>>(p);
     GORSE_HIP_CHECK(hipGetLastError());
     return GORSE_OK;
 }
@@ -2464,6 +2502,7 @@ struct TopkChunkState {
     const float *qn2 = nullptr, *Qf = nullptr;
     SweepParams sp;
     int tri_rank = 0, tri_world = 1;
+    int sym_slices = 1;  // row slices per query block of the symmetric main sweep (a triangle shard with few, long workgroups)
     int tri_stage = 0;  // gorse_topk_tri_*: 0 none, 1 begun (pilots of the own slice done), 2 swept, 3 finished
     int64_t tri_lo = 0, tri_hi = 0;  // the slice of the queries whose pilots this rank ran
 };
@@ -2600,7 +2639,7 @@ int32_t chunk_prepare(gorse_topk *h, ChunkState &cs) {
     sp.fbuf = nullptr;
     sp.fcnt = nullptr;
     sp.sym_stats = nullptr;
-    sp.sym_rank = 0, sp.sym_world = 1;
+    sp.sym_rank = 0, sp.sym_world = 1, sp.sym_slices = 1;
     sp.sym_probe = (g_topk_variant >> 25) & 3;  // variant bits 25-26: timing probes of the symmetric sweep (the call returns garbage)
     // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
     // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
@@ -2697,6 +2736,9 @@ int32_t chunk_main(gorse_topk *h, ChunkState &cs) {
         sp.sym_stats = h->sym_stats.p;
         sp.f_out = h->f1.p;  // the thresholds the workgroups end with: topk_rescore_kernel's verification reads them
         sp.sym_rank = cs.tri_rank, sp.sym_world = cs.tri_world;
+        sp.sym_slices = cs.sym_slices;
+        if (cs.sym_slices > 1)  // (slice 0's flags were cleared by chunk_prepare and may carry sym_thresholds_kernel's 2)
+            GORSE_HIP_CHECK(hipMemsetAsync(h->cflag.p + cs.mb, 0, (size_t)(cs.sym_slices - 1) * cs.mb, h->stream));
     }
     GORSE_TRY(dispatch_sweep(h, sp, false, sym));
     cs.sym = sym;
@@ -2724,6 +2766,7 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
     rp.qid = qid_host ? h->qid.p : nullptr;
     rp.q0 = q_contig_begin + c0;
     rp.tri_rank = cs.tri_rank, rp.tri_world = cs.tri_world, rp.tri_bq = kSymBQ;
+    rp.own_slices = sym ? cs.sym_slices : 1, rp.own_stride = cs.mb;
     rp.cbuf = h->cbuf.p;
     rp.ccnt = h->ccnt.p;
     rp.cflag = h->cflag.p;
@@ -3139,10 +3182,28 @@ extern "C" int32_t gorse_topk_tri_begin(gorse_topk *h, int64_t q_begin, int64_t 
     ChunkState &cs = *h->chunk_state();
     GORSE_TRY(search_setup(h, cs, nullptr, q_begin, nullptr, nq, k, 0));
     cs.c0 = 0, cs.m = nq, cs.tri_rank = rank, cs.tri_world = world;
+    // A launch is as long as its longest workgroup, and the longest block of the triangle sweeps every row with its 512 queries on ONE
+    // CU: 40 ms at C4, whatever the number of ranks (a rank of eight holds 244 workgroups for 256 CUs: its main sweep took those 40 ms
+    // where its share of the work is 19).  Few, long workgroups are therefore cut by ROWS: slice y of a block takes an even share of
+    // its tiles, with own lists of its own (slice-major, like a history sweep's: topk_rescore_kernel takes them together); 1, 2 or 4
+    // slices, the fewest that give the launch ~768 workgroups.  (Variant bits 29-30 force 1 / 2 / 4: tests, ablation.)
+    {
+        const int64_t blocks = tri_geom(cs).blocks_of(rank);
+        int S = 1;
+        while (S < kMaxOwnSlices && blocks * S < 768) S *= 2;
+        const int forced = (g_topk_variant >> 29) & 3;
+        if (forced) S = forced == 1 ? 1 : (forced == 2 ? 2 : 4);
+        cs.sym_slices = world > 1 || forced ? S : 1;
+        if (cs.sym_slices > 1) {
+            GORSE_TRY(h->cbuf.ensure((size_t)cs.sym_slices * cs.mb * kCap));
+            GORSE_TRY(h->ccnt.ensure((size_t)cs.sym_slices * cs.mb));
+            GORSE_TRY(h->cflag.ensure((size_t)cs.sym_slices * cs.mb));
+        }
+    }
     GORSE_TRY(chunk_prepare(h, cs));
     if (!cs.warm) return fail(GORSE_ERR_INVALID, "the sweep of this search is not warm-started");
     GORSE_TRY(h->f0.ensure((size_t)cs.mb));
-    GORSE_TRY(h->f1.ensure((size_t)cs.mb));
+    GORSE_TRY(h->f1.ensure((size_t)cs.sym_slices * cs.mb));
     tri_geom(cs).slice(rank, &cs.tri_lo, &cs.tri_hi);
     const int tok = h->prof.begin(GORSE_PROF_TOPK_SWEEP, h->stream);
     GORSE_TRY(chunk_pilots(h, cs, cs.tri_lo, cs.tri_hi));

@@ -41,6 +41,9 @@ void gorse_hip_test_set_topk_path(int32_t path);
  * undefined), bits 20-22 = the warm start's pilot sample: every 8th / every 32nd row tile instead of every 16th, and without the
  * 1/256 pilot in front (scripts/gpu_probe_topk_c4.py pilot).  Results never depend on the others. */
 void gorse_hip_test_set_topk_variant(int32_t variant);
+/* (round 6) bit 27 = the tie path's history sweep with 64 instead of 128 queries per workgroup, bit 28 = the tie replay with 64 queries
+ * per wave whatever the launch's size, bits 29-30 = the row slices per query block of a triangle-sharded sweep (gorse_topk_tri_*):
+ * 1 = one, 2 = two, 3 = four (0: by the launch's size).  Results never depend on them. */
 /* variant bit 8 (256) switches the warm start of the sweep off (pilot sweep over every 16th row tile -> initial thresholds,
  * verified by the main sweep; csrc/topk_mfma.hip topk_mfma_search), bit 9 (512) switches it on below its size limit of 2^17
  * rows, bit 10 (1024) gives the pilot a kth of 2 so that most warm starts fail their verification.  This returns how many

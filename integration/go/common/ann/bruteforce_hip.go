@@ -488,7 +488,7 @@ func (b *BruteforceHIP) SearchAll(k int) (idx []int32, dist []float32, err error
 // all-pairs sweep sharded over them (include/gorse_hip.h, gorse_topk_tri_*: device r takes the query blocks r, r + len(devices), ...; the
 // pilot thresholds and the foreign candidate lists move between the devices inside the one library call).  Rows, distances and their
 // order are SearchAll's, bit for bit (tests/test_gpu_topk_tri.py).  Measured per device, the devices emulated on one MI355X at a million
-// 128-dimensional vectors: 125 / 75 / 64 ms at 2 / 4 / 8 devices against 223 ms on one; a search that has no symmetric form (fewer than
+// 128-dimensional vectors: 122 / 71 / 46 ms at 2 / 4 / 8 devices against 222 ms on one; a search that has no symmetric form (fewer than
 // 2^17 vectors, more than 128 bf16 / 42 fp32 dimensions) returns an error: fall back to SearchAll or to contiguous shards of SearchIndex.
 func (b *BruteforceHIP) SearchAllSharded(k int, devices []int) (idx []int32, dist []float32, err error) {
 	b.mu.Lock()

@@ -16,7 +16,7 @@ def show(name, d):
         extra += " cpu %.3g %s" % (d["cpu_baseline"]["value"], d["cpu_baseline"]["unit"])
     print("%-10s %.4g %s  %.3f ms/step  %s frac %.3f (kernel %.3f ms x %s)%s" % (
         name, d["value"], d["unit"], d["ms_per_step"], r.get("bound"), r.get("frac", float("nan")), r.get("avg_launch_ms", float("nan")),
-        r.get("launches"), extra))
+        r.get("launches", "-") if r.get("launches") is not None else "-", extra))
 
 
 for line in open(sys.argv[1]):

@@ -49,6 +49,15 @@ def test_triangle_shards_equal_the_single_rank_pass(oracle, metric, dtype, d):
         assert np.array_equal(idx, ref_i), "world %d: indices differ in %d rows" % (world, int((idx != ref_i).any(axis=1).sum()))
         assert np.array_equal(bits(dist), bits(ref_d)), "world %d: distance bits differ" % world
         assert all(h.last_symmetric() for h in handles[:world])
+    # the long blocks cut by rows (own lists per slice; chosen by the launch's size -- at this size never): forced to 2 and 4 slices
+    L = capi.lib()
+    try:
+        for forced, world in ((2, 1), (3, 2), (2, 3)):
+            L.gorse_hip_test_set_topk_variant(forced << 29)
+            idx, dist, _ = run_world(handles, k, world)
+            assert np.array_equal(idx, ref_i) and np.array_equal(bits(dist), bits(ref_d)), "slices forced (%d), world %d" % (forced, world)
+    finally:
+        L.gorse_hip_test_set_topk_variant(0)
     # the one-call form for a process that holds every rank's handle (gorse_topk_tri_all_pairs_local: what the Go master calls)
     for world in (2, 4):
         li, ld = capi.topk_tri_all_pairs_local(handles[:world], k)
