@@ -191,6 +191,7 @@ def parse():
     ap.add_argument("--topk-n", type=int, default=1_000_000)
     ap.add_argument("--topk-steps", type=int, default=2)
     ap.add_argument("--topk-budget", type=float, default=60.0, help="seconds the timed top-k steps may take (see bench_topk)")
+    ap.add_argument("--topk-watchdog", type=float, default=240.0, help="N > 1: seconds the sharded top-k leg may take before the line is emitted without it")
     ap.add_argument("--topk-shard", default="auto", choices=["auto", "rows", "tri"],
                     help="how the C4 pass is split over N > 1 ranks: tri = the TRIANGLE of the symmetric sweep (rank r takes the query blocks "
                          "r, r + N, ...; thresholds all-gathered, foreign candidate lists all-to-all: gorse_topk_tri_*), rows = contiguous "
@@ -1070,7 +1071,23 @@ def main():
     # BASELINE.json's metric has two halves; the second one rides on the C2 line of one GPU and on the C3 line of N > 1
     # (query rows sharded over the ranks, no collective)
     if ((workload == "ml1m" and world == 1) or (workload == "c3" and world > 1 and args.workload is None)) and not args.no_topk:
+        # N > 1: the top-k leg's exchanges (the triangle shard's all-gather and all-to-all over RCCL) have run on emulated ranks and over
+        # gloo only -- no multi-GPU node was ever available to the builder.  A collective that never completes must not cost the line
+        # its BPR half: a watchdog on every rank emits the line WITHOUT the leg (rank 0) and leaves, should the leg not return in time.
+        dog = None
+        if world > 1:
+            def bark():
+                if rank == 0:
+                    out["topk"] = {"metric": "item x item cosine top-100 pairs/sec", "value": None,
+                                   "error": "the sharded top-k leg did not return within %d s (watchdog); --topk-shard rows has no exchange" % args.topk_watchdog}
+                    emit(out, args.workload or "default_n%d" % world)
+                os._exit(0)
+            dog = threading.Timer(args.topk_watchdog, bark)
+            dog.daemon = True
+            dog.start()
         topk = leg(lambda: bench_topk(args, world, rank, local, fence0), "item x item cosine top-100 pairs/sec")
+        if dog is not None:
+            dog.cancel()
         if rank == 0:
             out["topk"] = topk
     if full_line and not args.no_extra:
