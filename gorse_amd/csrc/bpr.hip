@@ -831,6 +831,9 @@ constexpr int ST_NEG = 1, ST_POS = 2, ST_LIVE = 4;
 // 16, nothing at 32) for 0.001-0.003 of NDCG@10 -- the epoch is not the per-user chain but the chunk's preparation running beside
 // it -- and with 4 / 8 segments a fit DIVERGED (NaN) in two of 18 runs: a heavy user's segments each apply the whole run's
 // regularisation shrink to the same starting row, and the summed changes overshoot (n_u lr reg > 1 for 2000 feedbacks).
+#ifndef GORSE_BPR_D8_PAIRS
+#define GORSE_BPR_D8_PAIRS 1  // A/B: 0 = nFactors 8 with lanes 8..15 of a group mirroring lanes 0..7 (rounds 4-5)
+#endif
 template <int NC, int ST, bool D8 = false, int G = 2, int IA = 3, bool SEG = false>
 __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float *Q, const int32_t *__restrict__ si,
                                                                  const int32_t *__restrict__ sj,
@@ -852,11 +855,15 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
     constexpr bool NEG1 = (ST & ST_NEG) != 0;
     const int glane = threadIdx.x & (kGroup - 1);
     const int lane = D8 ? (glane & 7) : glane;   // element owned inside a 16-float chunk
-    const bool writer = !D8 || glane < 8;
+    // D8 (round 6): the two halves of a 16-lane group take a user run EACH (eight lanes own a row of eight: until round 5 lanes 8..15
+    // mirrored lanes 0..7 and only wrote nothing) -- eight runs per wave instead of four
+    constexpr int SUBS = D8 && GORSE_BPR_D8_PAIRS ? 2 : 1;
+    const bool writer = !D8 || SUBS == 2 || glane < 8;
     auto mad = [](float x, float y, float z) { return D8 ? x * y + z : fmaf(x, y, z); };
+    auto tree8 = [](float v) { return SUBS == 2 ? group_tree8_halves(v) : group_tree8(v); };
     const int gib = threadIdx.x / kGroup;
-    const int64_t group = (int64_t)((int)blockIdx.x - folders) * kGroupsPerBlock + gib;
-    const int64_t ngroups = (int64_t)((int)gridDim.x - folders) * kGroupsPerBlock;
+    const int64_t group = ((int64_t)((int)blockIdx.x - folders) * kGroupsPerBlock + gib) * SUBS + (SUBS == 2 ? glane >> 3 : 0);
+    const int64_t ngroups = (int64_t)((int)gridDim.x - folders) * kGroupsPerBlock * SUBS;
     const float nreg = -reg;
     double my_loss = 0.0;
     // which class look-ups this launch needs (every path issues the same loads from a valid address: a look-up nobody needs
@@ -944,10 +951,10 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
                 st_i = (ST & ST_POS) && slot == kCold && !own_i;
                 st_j = (ST & ST_NEG) && slotj == kCold && !own_j;
             }
-            const float diff = D8 ? group_tree8(p[0] * a[0]) - group_tree8(p[0] * b[0]) : dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
+            const float diff = D8 ? tree8(p[0] * a[0]) - tree8(p[0] * b[0]) : dot512_regs<NC>(p, a) - dot512_regs<NC>(p, b);
             const float ex = bpr_exp(-diff, exp_mode);
             const float grad = ex / (1.0f + ex);
-            if (loss && glane == 0 && valid) my_loss += (double)log1pf(ex);
+            if (loss && (SUBS == 2 ? (glane & 7) == 0 : glane == 0) && valid) my_loss += (double)log1pf(ex);
             float t1[NC], t2[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) {
@@ -1006,7 +1013,7 @@ __global__ __launch_bounds__(kBlock) void bpr_update_user_kernel(float *P, float
             }
         }
     }
-    if (loss && glane == 0 && my_loss != 0.0) atomicAdd(loss, my_loss);
+    if (loss && (SUBS == 2 ? (glane & 7) == 0 : glane == 0) && my_loss != 0.0) atomicAdd(loss, my_loss);
     if (folders > 0) {
         __syncthreads();
         if (threadIdx.x == 0) worker_done(hot);
@@ -1275,7 +1282,7 @@ int32_t launch_update_users(gorse_mf *h, const int32_t *sorted, const int32_t *b
                             int exp_mode, double *loss, hipStream_t st, bool stores) {
     const int d = h->d;
     const int segs = user_segments(h);
-    int64_t blocks = ceil_div(h->U * segs, kGroupsPerBlock);
+    int64_t blocks = ceil_div(h->U * segs, (int64_t)kGroupsPerBlock * (d == 8 && GORSE_BPR_D8_PAIRS ? 2 : 1));  // nFactors 8: two runs per group
     const int64_t capb = 256 * 16;
     if (blocks > capb) blocks = capb;
     HotRows hot = make_hot(h);

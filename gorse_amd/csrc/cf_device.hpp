@@ -40,6 +40,21 @@ __device__ __forceinline__ float group_tree8(float v) {
     return v;
 }
 
+// The same 8 -> 1 tree inside each aligned group of EIGHT lanes (no mirror: the two halves of a 16-lane row hold different data): the
+// partner of lane l is l ^ 4, then l ^ 2, then l ^ 1 -- the pairs the rotations above add, and since an addition's operands commute bit
+// for bit every lane of the eight ends with group_tree8's total.  l ^ 4 by two DPP moves (quad_perm [3,2,1,0]: l ^ 3, then
+// row_half_mirror: 7 - l = l ^ 7), l ^ 2 and l ^ 1 by one quad_perm each.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group_tree8_halves(float v) {
+    v = v + dpp_move<0x141>(dpp_move<0x1B>(v));
+    v = v + dpp_move<0x4E>(v);
+    v = v + dpp_move<0xB1>(v);
+    return v;
+}
+
 // Vector-length bookkeeping of the AVX512 kernels: full 16-chunks, optional 8-tail, scalar tail.
 struct VecShape {
     int d, nfull, has8, tail0;  // tail0 = first scalar-tail element
