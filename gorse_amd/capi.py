@@ -124,6 +124,7 @@ SIGNATURES = {
     "gorse_hip_test_set_sparse_slots": (None, [C.c_int64]),
     "gorse_hip_test_set_sparse_head": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_table": (None, [C.c_int32]),
+    "gorse_hip_test_set_sparse_probe": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
     "gorse_hip_test_set_scan_literal": (None, [C.c_int32]),
     "gorse_hip_test_set_stream_priorities": (None, [C.c_int32]),

@@ -63,6 +63,7 @@ int64_t g_sparse_heavy = 16384;  // ... and with more than this they are scored 
                                  // <= 0 = never
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
+int g_sparse_tri_probe = 0;      // timing probe: whole-query items stop at their own group (gorse_hip_test_set_sparse_probe)
 int g_sparse_cap_shift = 2;      // postings a super-visit's table takes: accumulators >> this (gorse_hip_test_set_sparse_table)
 int g_sparse_head = -1;          // groups a whole-query item visits one by one (the rest in hashed super-visits); -1 = head_groups_of()
 
@@ -171,6 +172,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG, a.part_stride = (int32_t)ng;
     a.head_groups = head_groups_of(h);
     a.cap_shift = g_sparse_cap_shift;
+    a.tri_probe = g_sparse_tri_probe;
     a.N = h->N;
     a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
     a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
@@ -563,6 +565,7 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 extern "C" void gorse_hip_test_set_sparse_head(int32_t groups) { g_sparse_head = groups; }
+extern "C" void gorse_hip_test_set_sparse_probe(int32_t probe) { g_sparse_tri_probe = probe; }
 extern "C" void gorse_hip_test_set_sparse_table(int32_t cap_shift) { g_sparse_cap_shift = cap_shift >= 2 && cap_shift <= 6 ? cap_shift : 2; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
 // 16 uint64 {t0, t1 (100 MHz ticks), query, group + 1 of a long query (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked

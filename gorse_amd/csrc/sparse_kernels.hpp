@@ -97,6 +97,8 @@ struct TileArgs {
     const uint32_t *off;
     const Posting *post;
     int32_t ngroups, logG;
+    int32_t tri_probe;    // timing probe (results are garbage): a whole-query item visits only the groups up to its own row's -- what a
+                          // symmetric walk of the whole-query items would leave of the list walk (gorse_hip_test_set_sparse_probe)
     int32_t cap_shift;    // the hashed table of a super-visit takes at most (accumulators >> cap_shift) postings (2: half full at most)
     int32_t head_groups;  // a whole-query item visits the groups [0, head_groups) one by one with directly indexed accumulators and
                           // the rest in SUPER-VISITS of several groups with hashed accumulators (see sparse_tile_kernel); = ngroups: never
@@ -575,7 +577,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const uint32_t *off = a.off;
         const Posting *post = a.post;
         const int dir_stride = a.ngroups;
-        const int nviews = whole ? a.head_groups : 1;  // a whole-query item: the head groups here, the others in super-visits below
+        // (timing probe: the groups up to the query's own)
+        const int glim = whole && a.tri_probe && qr < a.N ? (a.new_of[qr] >> a.logG) + 1 : a.ngroups;
+        const int nviews = whole ? (a.head_groups < glim ? a.head_groups : glim) : 1;  // a whole-query item: the head groups here, the others in super-visits below
         const int nacc = NL;
         const int lm = NL - 1;
         const int tcap = nacc >> 2;
@@ -737,13 +741,13 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         // = window j).  Until then every window was sized by its own count pass (two dependent loads per chunk, then three more per
         // chunk to apply it: ~5 exposed round trips per (window, chunk)); with the plan known the visits run through the same kind of
         // software pipeline as the head groups: index / value pairs two visits ahead, directory entries one visit ahead.
-        if (whole && a.head_groups < a.ngroups) {
+        if (whole && a.head_groups < glim) {
             const int S = nacc >> 1;
             const uint32_t cap_t = (uint32_t)(nacc >> a.cap_shift);
             lds_key *hkey = reinterpret_cast<lds_key *>(acc);
             float *hval = acc + S;
-            for (int g0 = a.head_groups; g0 < a.ngroups; g0 += kBlock - 1) {
-                const int gcount = a.ngroups - g0 < kBlock - 1 ? a.ngroups - g0 : kBlock - 1;  // groups g0 .. g0 + gcount - 1
+            for (int g0 = a.head_groups; g0 < glim; g0 += kBlock - 1) {
+                const int gcount = glim - g0 < kBlock - 1 ? glim - g0 : kBlock - 1;  // groups g0 .. g0 + gcount - 1
                 // -- the plan
                 const int gi = g0 + (lane < gcount ? lane : gcount);
                 uint32_t psum = 0;  // sum over the lists of off[c][gi], modulo 2^32 (the differences are what is used)

@@ -93,6 +93,9 @@ void gorse_hip_test_set_sparse_head(int32_t groups);
 /* probe: a hashed super-visit of the sparse list walk takes at most (accumulators >> cap_shift) postings into its table of
  * (accumulators / 2) slots: 2 (default) = half full at most, 3 = a quarter, ...; outside 2..6 = the default. */
 void gorse_hip_test_set_sparse_table(int32_t cap_shift);
+/* timing probe (results are garbage): 1 = a whole-query item of the sparse list walk visits only the row groups up to its own row's --
+ * the postings a symmetric walk of the whole-query items would still meet (sparse).  0 = off (default). */
+void gorse_hip_test_set_sparse_probe(int32_t probe);
 /* rows per group of a handle created AFTERWARDS (the posting lists are cut by row group, csrc/sparse_kernels.hpp): a power of two
  * in 256 .. 16384; 0 = 2048.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);
