@@ -125,6 +125,8 @@ SIGNATURES = {
     "gorse_hip_test_set_sparse_head": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_table": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_probe": (None, [C.c_int32]),
+    "gorse_hip_test_set_sparse_sym": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gorse_hip_test_sparse_sym_stats": (None, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
     "gorse_hip_test_set_scan_literal": (None, [C.c_int32]),
     "gorse_hip_test_set_stream_priorities": (None, [C.c_int32]),
@@ -763,6 +765,12 @@ class Sparse:
         a, b = C.c_int64(0), C.c_int64(0)
         check(lib().gorse_sparse_last_stats(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def sym_stats(self):
+        """the last call: (ran in symmetric form, rows redone after a foreign list overflowed, foreign entries ranked, longest foreign list)"""
+        out = (C.c_int64 * 4)()
+        lib().gorse_hip_test_sparse_sym_stats(self.h, out)
+        return tuple(int(x) for x in out)
 
     def trace(self, on=True):
         """probe: switch the per-work-item records on / off; returns the records of the last call (n x 16 uint64)"""

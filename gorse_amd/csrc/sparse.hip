@@ -42,6 +42,20 @@ struct gorse_sparse {
     DevBuf<float> q_val, out_score;
     DevBuf<sparse::Work> work;
     DevBuf<unsigned long long> part_keys, stat;
+    // the symmetric form of an all-pairs pass (sparse::SymArgs)
+    DevBuf<unsigned long long> sym_tp, sym_flist, sym_own;
+    DevBuf<uint32_t> sym_neg, sym_fcnt;
+    DevBuf<int32_t> sym_redo;
+    // The work plan of the last all-pairs call (the queries are the stored rows, which never change): the host's sorts and the
+    // uploads of a 200,000-row pass were ~1.5 ms of its 36 (r06_y2: kernels 26.5 ms, pass 28.9).  `valid`: the host lists below are
+    // the plan of (q_first, nq, split, heavy); `on_device`: work / split_* / heavy_* on the device still hold it.
+    struct Plan {
+        bool valid = false, on_device = false;
+        int64_t q_first = -1, nq = -1, split = 0, heavy = 0;
+        std::vector<int32_t> longs, shorts, heavy_t, heavy_pslot, nparts;
+        std::vector<sparse::Work> work;
+    } plan;
+    int64_t last_sym[4] = {0, 0, 0, 0};  // the last call: ran symmetric, rows redone, foreign entries ranked, longest foreign list
     DevBuf<sparse::Trace> trace;  // probe (gorse_hip_test_sparse_trace)
     std::vector<sparse::Trace> trace_host;
     bool trace_on = false;
@@ -63,6 +77,8 @@ int64_t g_sparse_heavy = 16384;  // ... and with more than this they are scored 
                                  // <= 0 = never
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
+int g_sparse_sym = -1;            // an eligible all-pairs pass walks its whole-query pairs once (SymArgs): -1 / 1 = yes, 0 = never
+int g_sparse_sym_caps[3] = {0, 0, 0};  // foreign list capacities of the three tiers (0 = the defaults): tests overflow them on purpose
 int g_sparse_tri_probe = 0;      // timing probe: whole-query items stop at their own group (gorse_hip_test_set_sparse_probe)
 int g_sparse_cap_shift = 2;      // postings a super-visit's table takes: accumulators >> this (gorse_hip_test_set_sparse_table)
 int g_sparse_head = -1;          // groups a whole-query item visits one by one (the rest in hashed super-visits); -1 = head_groups_of()
@@ -87,10 +103,11 @@ int pick_log_group() {
     return l;
 }
 template <int KP>
-int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, hipStream_t s) {  // s: the stream of this launch
+int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, bool sym, hipStream_t s) {  // s: the stream of this launch
     auto kern = atomic ? sparse::sparse_tile_kernel<KP, true, false> : sparse::sparse_tile_kernel<KP, false, false>;
+    if (sym) kern = atomic ? sparse::sparse_tile_kernel<KP, true, false, true> : sparse::sparse_tile_kernel<KP, false, false, true>;
 #ifdef GORSE_PROBE  // the trace instantiation exists in `make probe-lib` builds only
-    if (a.trace) kern = atomic ? sparse::sparse_tile_kernel<KP, true, true> : sparse::sparse_tile_kernel<KP, false, true>;
+    if (a.trace && !sym) kern = atomic ? sparse::sparse_tile_kernel<KP, true, true> : sparse::sparse_tile_kernel<KP, false, true>;
 #endif
     GORSE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<dim3(grid), dim3(sparse::kBlock), lds, s>>>(a);
@@ -120,14 +137,19 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     GORSE_TRY(h->out_idx.ensure((size_t)nq * k));
     GORSE_TRY(h->out_score.ensure((size_t)nq * k));
     GORSE_TRY(h->out_cnt.ensure((size_t)nq));
-    GORSE_TRY(h->stat.ensure(2));
+    GORSE_TRY(h->stat.ensure(4));
     GORSE_TRY(h->next.ensure(sparse::kQueueWords));
     // Work items: a long query as one item per group (+ a merge of the partial rankings), the others as one item each.  Long
     // queries first, everything longest first: the launch ends with the cheap items.  The partial rankings of the long queries
     // are bounded (kPartBytes): a call with more long queries than fit takes several launches.
     const int64_t ng = std::max(h->ngroups, h->n_ranges);  // most partial rankings of one query
-    std::vector<int32_t> longs, shorts;
-    {   // counting sort by length, longest first (stable in t)
+    gorse_sparse::Plan &plan = h->plan;
+    const bool plan_hit = qp == h->r_ptr.p && plan.valid && plan.q_first == q_first && plan.nq == nq && plan.split == g_sparse_split &&
+                          plan.heavy == g_sparse_heavy;
+    if (!plan_hit) plan.valid = plan.on_device = false;
+    std::vector<int32_t> &longs = plan.longs, &shorts = plan.shorts;
+    if (!plan_hit) {   // counting sort by length, longest first (stable in t)
+        longs.clear(), shorts.clear();
         const int64_t cut = g_sparse_split > 0 ? g_sparse_split : INT64_MAX;
         std::vector<int32_t> count;
         int64_t longest_short = 0;
@@ -167,8 +189,47 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         1, std::min({kPartBytes / ((size_t)ng * kp * 8), kDenseBytes / ((size_t)std::max<int64_t>(h->Dc, 1) * sizeof(uint2)),
                      (size_t)32768}));  // 32768: the heavy queries of a launch are a grid dimension
     auto is_heavy = [&](int32_t t) { return g_sparse_heavy > 0 && q_len_host[t + 1] - q_len_host[t] > g_sparse_heavy; };
-    GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 2 * sizeof(unsigned long long), h->stream));
+    GORSE_HIP_CHECK(hipMemsetAsync(h->stat.p, 0, 4 * sizeof(unsigned long long), h->stream));
     TileArgs a;
+    // The symmetric form: every stored row is a query and leaves out only itself; the long / heavy rows are the first scratch ids
+    // (rows are numbered longest first and a query's length is its row's).
+    bool sym = g_sparse_sym != 0 && qp == h->r_ptr.p && q_first == 0 && nq == h->N && exclude_self && !excl_dev && !h->has_mask &&
+               !h->trace_on && !shorts.empty() && longs.size() < (size_t)h->N;
+    for (size_t l = 0; sym && l < longs.size(); l++) sym = h->order.new_of[(size_t)longs[l]] < (int64_t)longs.size();
+    a.sym = sparse::SymArgs{};
+    if (sym) {
+        sparse::SymArgs &y = a.sym;
+        const int64_t N = h->N;
+        // Foreign list capacities.  A row's bound is published by its own item; what arrives before that is appended unfiltered, and
+        // that is the rows at the head of the work list while the launch fills (up to a launch's waves deliver to them at once).
+        y.first = (int32_t)longs.size();
+        y.t1 = (int32_t)std::min<int64_t>(N, 16384), y.t2 = (int32_t)std::min<int64_t>(N, 65536);
+        const int32_t most = (int32_t)std::min<int64_t>(N, 1 << 20);  // a list never holds more than N - 1 entries
+        y.c1 = std::min(most, g_sparse_sym_caps[0] > 0 ? g_sparse_sym_caps[0] : 8192);
+        y.c2 = std::min(most, g_sparse_sym_caps[1] > 0 ? g_sparse_sym_caps[1] : 1024);
+        y.c3 = std::min(most, g_sparse_sym_caps[2] > 0 ? g_sparse_sym_caps[2] : (N > ((int64_t)1 << 21) ? 64 : 256));
+        const size_t cells = (size_t)y.t1 * y.c1 + (size_t)(y.t2 - y.t1) * y.c2 + (size_t)(N - y.t2) * y.c3;
+        GORSE_TRY(h->sym_tp.ensure((size_t)N));
+        GORSE_TRY(h->sym_neg.ensure((size_t)N));
+        GORSE_TRY(h->sym_fcnt.ensure((size_t)N));
+        GORSE_TRY(h->sym_flist.ensure(cells));
+        GORSE_TRY(h->sym_own.ensure((size_t)N * kp));
+        GORSE_TRY(h->sym_redo.ensure((size_t)N + 1));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->sym_tp.p, 0, (size_t)N * 8, h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->sym_neg.p, 0, (size_t)N * 4, h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->sym_fcnt.p, 0, (size_t)N * 4, h->stream));
+        GORSE_HIP_CHECK(hipMemsetAsync(h->sym_redo.p, 0, 4, h->stream));
+        {   // the heads of the first lists, which their rows' items read while they fill (sym_tighten): one strided clear.  The first
+            // four row groups: behind them a row's own walk reaches its first read-back in well under a millisecond.
+            y.tl = std::min<int32_t>(y.t1, 8192);
+            const size_t look = (size_t)std::min<int32_t>(y.c1, sparse::kSymLook);
+            if (look == (size_t)y.c1)
+                GORSE_HIP_CHECK(hipMemsetAsync(h->sym_flist.p, 0, (size_t)y.tl * y.c1 * 8, h->stream));
+            else
+                GORSE_HIP_CHECK(hipMemset2DAsync(h->sym_flist.p, (size_t)y.c1 * 8, 0, look * 8, (size_t)y.tl, h->stream));
+        }
+        y.tp = h->sym_tp.p, y.neg = h->sym_neg.p, y.fcnt = h->sym_fcnt.p, y.flist = h->sym_flist.p, y.own = h->sym_own.p;
+    }
     a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG, a.part_stride = (int32_t)ng;
     a.head_groups = head_groups_of(h);
     a.cap_shift = g_sparse_cap_shift;
@@ -186,41 +247,60 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     const int64_t slots = g_sparse_max_slots > 0 ? g_sparse_max_slots : 256 * 16;
     // LDS of a workgroup: ranking buffer + per accumulator 4 B (sum) + 1 B (stamp) + 0.5 B (touched list)
     const size_t lds = (size_t)2 * kp * 8 + ((size_t)11 << h->logG) / 2 + 64;  // + the batch assembly's board
+    auto launch_work = [&](size_t n_items, bool symmetric) -> int32_t {  // a.work / a.n_work are set
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)n_items, slots));
+        switch (kp) {
+            case 128: GORSE_TRY(launch_tiles<128>(a, grid, lds, atomic, symmetric, h->stream)); break;
+            case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, symmetric, h->stream)); break;
+            case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, symmetric, h->stream)); break;
+            default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, symmetric, h->stream)); break;
+        }
+        GORSE_HIP_CHECK(hipGetLastError());
+        return GORSE_OK;
+    };
     const int tok = h->prof.begin(0, h->stream);
-    std::vector<sparse::Work> work;
+    std::vector<sparse::Work> &work = plan.work;
+    std::vector<int32_t> &heavy_t = plan.heavy_t, &heavy_pslot = plan.heavy_pslot, &nparts = plan.nparts;
+    const bool one_launch = longs.size() <= per_launch;  // (a plan is kept across calls only then)
     h->trace_host.clear();
     for (size_t l0 = 0; l0 == 0 || l0 < longs.size(); l0 += per_launch) {
         const size_t l1 = std::min(longs.size(), l0 + per_launch);
-        work.clear();
-        // the parts of the long queries by estimated cost (entries of the query x share of the stored entries in the group's
-        // rows), dearest first and at a raised wave priority where one part alone is a sizeable piece of the launch: (longest
-        // query, most popular rows) ran for 60 of the launch's 68 ms (profiles/r02_o_probe_sparse_trace.txt)
-        std::vector<int32_t> heavy_t, heavy_pslot, nparts(l1 - l0, h->ngroups);
-        for (size_t l = l0; l < l1; l++) {
-            if (is_heavy(longs[l])) {
-                nparts[l - l0] = h->n_ranges;
-                heavy_t.push_back(longs[l]);
-                heavy_pslot.push_back((int32_t)(l - l0));
-                continue;
+        if (!(plan_hit && one_launch)) {
+            work.clear(), heavy_t.clear(), heavy_pslot.clear();
+            // the parts of the long queries by estimated cost (entries of the query x share of the stored entries in the group's
+            // rows), dearest first and at a raised wave priority where one part alone is a sizeable piece of the launch: (longest
+            // query, most popular rows) ran for 60 of the launch's 68 ms (profiles/r02_o_probe_sparse_trace.txt)
+            nparts.assign(l1 - l0, h->ngroups);
+            for (size_t l = l0; l < l1; l++) {
+                if (is_heavy(longs[l])) {
+                    nparts[l - l0] = h->n_ranges;
+                    heavy_t.push_back(longs[l]);
+                    heavy_pslot.push_back((int32_t)(l - l0));
+                    continue;
+                }
+                for (int32_t g = 0; g < h->ngroups; g++) work.push_back(sparse::Work{longs[l], g, (int32_t)(l - l0), 0});
             }
-            for (int32_t g = 0; g < h->ngroups; g++) work.push_back(sparse::Work{longs[l], g, (int32_t)(l - l0), 0});
+            auto cost = [&](const sparse::Work &w) { return (double)(q_len_host[w.t + 1] - q_len_host[w.t]) * h->group_share[(size_t)w.part]; };
+            std::stable_sort(work.begin(), work.end(), [&](const sparse::Work &x, const sparse::Work &y) { return cost(x) > cost(y); });
+            for (sparse::Work &w : work) w.prio = cost(w) >= 4096.0;
+            if (l0 == 0)
+                for (int32_t t : shorts) work.push_back(sparse::Work{t, -1, 0, 0});
         }
-        auto cost = [&](const sparse::Work &w) { return (double)(q_len_host[w.t + 1] - q_len_host[w.t]) * h->group_share[(size_t)w.part]; };
-        std::stable_sort(work.begin(), work.end(), [&](const sparse::Work &x, const sparse::Work &y) { return cost(x) > cost(y); });
-        for (sparse::Work &w : work) w.prio = cost(w) >= 4096.0;
-        if (l0 == 0)
-            for (int32_t t : shorts) work.push_back(sparse::Work{t, -1, 0, 0});
         if (work.empty() && heavy_t.empty()) break;
         const size_t n_long = l1 - l0;
+        const bool upload = !(plan_hit && one_launch && plan.on_device);
         GORSE_TRY(h->work.ensure(work.size()));
-        GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
+        if (upload)
+            GORSE_HIP_CHECK(hipMemcpyAsync(h->work.p, work.data(), work.size() * sizeof(sparse::Work), hipMemcpyHostToDevice, h->stream));
         if (n_long > 0) {
             GORSE_TRY(h->split_t.ensure(n_long));
             GORSE_TRY(h->split_n.ensure(n_long));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->split_n.p, nparts.data(), n_long * 4, hipMemcpyHostToDevice, h->stream));
             GORSE_TRY(h->part_keys.ensure(n_long * (size_t)ng * (size_t)kp));
             GORSE_TRY(h->part_cnt.ensure(n_long * (size_t)ng * 2));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, longs.data() + l0, n_long * 4, hipMemcpyHostToDevice, h->stream));
+            if (upload) {
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->split_n.p, nparts.data(), n_long * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->split_t.p, longs.data() + l0, n_long * 4, hipMemcpyHostToDevice, h->stream));
+            }
         }
         GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sparse::kQueueWords * sizeof(int32_t), h->stream));
         if (!heavy_t.empty()) {  // the heavy queries: dense copies, then every stored row against them -- next to the others
@@ -228,8 +308,10 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             GORSE_TRY(h->heavy_t.ensure(nh));
             GORSE_TRY(h->heavy_pslot.ensure(nh));
             GORSE_TRY(h->dense.ensure(nh * (size_t)h->Dc + 1));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_t.p, heavy_t.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
-            GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_pslot.p, heavy_pslot.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
+            if (upload) {
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_t.p, heavy_t.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
+                GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_pslot.p, heavy_pslot.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
+            }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));  // uploads, memsets, the buffers of the previous launch
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
             GORSE_HIP_CHECK(hipMemsetAsync(h->dense.p, 0, (nh * (size_t)h->Dc + 1) * sizeof(uint2), h->stream2));
@@ -264,16 +346,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             a.trace = h->trace.p;
         }
 #endif
-        if (!work.empty()) {
-            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)work.size(), slots));
-            switch (kp) {
-                case 128: GORSE_TRY(launch_tiles<128>(a, grid, lds, atomic, h->stream)); break;
-                case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, h->stream)); break;
-                case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, h->stream)); break;
-                default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, h->stream)); break;
-            }
-            GORSE_HIP_CHECK(hipGetLastError());
-        }
+        if (!work.empty()) GORSE_TRY(launch_work(work.size(), sym));
         if (!heavy_t.empty()) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         if (n_long > 0) {
             sparse::MergeArgs m;
@@ -291,16 +364,53 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             }
             GORSE_HIP_CHECK(hipGetLastError());
         }
-        // the host lists (work, heavy_*, nparts, split_t) and the trace buffer are reused or die with this iteration
-        if (n_long > 0 || h->trace_on) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        // the host lists (work, heavy_*, nparts, split_t) and the trace buffer are reused by the next iteration
+        if ((n_long > 0 && !one_launch) || h->trace_on) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->trace_on && a.trace) {  // (a.trace stays null outside `make probe-lib` builds: nothing was recorded)
             const size_t at = h->trace_host.size();
             h->trace_host.resize(at + work.size());
             GORSE_HIP_CHECK(hipMemcpy(h->trace_host.data() + at, h->trace.p, work.size() * sizeof(sparse::Trace), hipMemcpyDeviceToHost));
         }
     }
+    int32_t n_redo = 0;
+    bool redo_overwrote = false;
+    if (sym) {  // own keys + foreign lists -> the whole-query rows
+        sparse::SymMergeArgs m;
+        m.sym = a.sym, m.N = h->N, m.new_of = h->new_of.p, m.k = k;
+        m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
+        m.redo = h->sym_redo.p, m.stat = h->stat.p;
+        const unsigned mg = (unsigned)std::min<int64_t>(h->N, 256 * 32);
+        switch (kp) {
+            case 128: sparse::sparse_sym_merge_kernel<128><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            case 256: sparse::sparse_sym_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            case 512: sparse::sparse_sym_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            default: sparse::sparse_sym_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+        }
+        GORSE_HIP_CHECK(hipGetLastError());
+        GORSE_HIP_CHECK(hipMemcpyAsync(&n_redo, h->sym_redo.p, 4, hipMemcpyDeviceToHost, h->stream));
+        GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (n_redo > 0) {  // rows whose foreign list overflowed: the unsymmetric walk, as whole-query items
+            std::vector<int32_t> rows((size_t)n_redo);
+            GORSE_HIP_CHECK(hipMemcpy(rows.data(), h->sym_redo.p + 1, (size_t)n_redo * 4, hipMemcpyDeviceToHost));
+            std::sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) {
+                const int64_t lx = q_len_host[x + 1] - q_len_host[x], ly = q_len_host[y + 1] - q_len_host[y];
+                return lx != ly ? lx > ly : x < y;
+            });
+            std::vector<sparse::Work> again;
+            for (int32_t t : rows) again.push_back(sparse::Work{t, -1, 0, 0});
+            redo_overwrote = true;  // (the device's work list is no longer the plan's)
+            GORSE_HIP_CHECK(hipMemcpy(h->work.p, again.data(), again.size() * sizeof(sparse::Work), hipMemcpyHostToDevice));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sparse::kQueueWords * sizeof(int32_t), h->stream));
+            a.work = h->work.p, a.n_work = (int32_t)again.size();
+            a.trace = nullptr;
+            GORSE_TRY(launch_work(again.size(), false));
+        }
+    }
     h->prof.end(tok, h->stream);
-    unsigned long long st[2] = {0, 0};
+    plan.valid = plan.on_device = qp == h->r_ptr.p && one_launch;
+    if (redo_overwrote) plan.on_device = false;
+    plan.q_first = q_first, plan.nq = nq, plan.split = g_sparse_split, plan.heavy = g_sparse_heavy;
+    unsigned long long st[4] = {0, 0, 0, 0};
     GORSE_HIP_CHECK(hipMemcpyAsync(st, h->stat.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     if (idx_out)
         GORSE_HIP_CHECK(hipMemcpyAsync(idx_out, h->out_idx.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, h->stream));
@@ -310,6 +420,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));  // also covers the uploads from the work list and `longs`
     h->last_postings = (int64_t)st[0];
     h->last_hits = (int64_t)st[1];
+    h->last_sym[0] = sym, h->last_sym[1] = n_redo, h->last_sym[2] = (int64_t)st[2], h->last_sym[3] = (int64_t)st[3];
     // per-call scratch that a handle should not sit on between calls (a collection keeps its handle until it changes)
     constexpr size_t kKeepBytes = (size_t)256 << 20;
     if (h->part_keys.n * sizeof(unsigned long long) > kKeepBytes) h->part_keys.release();
@@ -566,6 +677,13 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 extern "C" void gorse_hip_test_set_sparse_head(int32_t groups) { g_sparse_head = groups; }
 extern "C" void gorse_hip_test_set_sparse_probe(int32_t probe) { g_sparse_tri_probe = probe; }
+extern "C" void gorse_hip_test_set_sparse_sym(int32_t mode, int32_t c1, int32_t c2, int32_t c3) {
+    g_sparse_sym = mode;
+    g_sparse_sym_caps[0] = c1, g_sparse_sym_caps[1] = c2, g_sparse_sym_caps[2] = c3;
+}
+extern "C" void gorse_hip_test_sparse_sym_stats(const gorse_sparse *h, int64_t out[4]) {
+    for (int i = 0; i < 4; i++) out[i] = h ? h->last_sym[i] : 0;
+}
 extern "C" void gorse_hip_test_set_sparse_table(int32_t cap_shift) { g_sparse_cap_shift = cap_shift >= 2 && cap_shift <= 6 ? cap_shift : 2; }
 // probe: per-work-item records of the NEXT calls of this handle (on != 0), or the records of the last call: up to cap rows of
 // 16 uint64 {t0, t1 (100 MHz ticks), query, group + 1 of a long query (0 = the whole query), entries, chunks taken 64 lists at once, their rounds, segments walked

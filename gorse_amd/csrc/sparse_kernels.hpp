@@ -92,6 +92,56 @@ struct Tracer {
     }
 };
 
+// The SYMMETRIC form of an all-pairs pass (round 6; every stored row is a query, nothing masked or excluded but the row itself).
+// score(q, r) and score(r, q) are the same products added in the same order, so a pair of whole-query rows is walked ONCE, by the
+// shorter one: rows are numbered longest first, a whole-query item q visits the groups up to its own and keeps the rows r with
+// sid(r) < sid(q) for its own ranking -- and DELIVERS the score to r's ranking when r is a whole-query row too (sid(r) >= first;
+// the long / heavy queries in front of them walk everything themselves, as before):
+//   * tp[sid] = { low word: a lower bound of the ord of r's k-th key, published by r's own item whenever its threshold moves and
+//     exactly at its end; high word: positive scores delivered to r, counted while the deliverer saw fewer than k -- written()
+//     needs min(pos, k) only -- plus r's own count at its end }, neg[sid]: negative scores delivered, always counted;
+//   * a delivered score whose ord is >= the published bound is appended to r's FOREIGN LIST (fcnt[sid] hands out the slots; the
+//     work list runs longest first, so r's bound is usually final before the shorter rows reach it -- on the C3 shard nothing a
+//     final bound lets through exists at all, what is appended arrived while r was still in flight with no bound yet; the lists
+//     of the first rows are therefore the long ones: three tiers of capacity);
+//   * r's item leaves its own sorted keys in own[t * KP ..) instead of a result; sparse_sym_merge_kernel ranks own + foreign
+//     (keys are distinct: one total order) and writes the row; a row whose foreign list overflowed goes on the redo list and takes
+//     the unsymmetric walk in a second launch.
+constexpr int kSymLook = 1024;  // entries at the head of the foreign list of a row in front of SymArgs::tl that the row's own item may read for a bound (sym_tighten)
+struct SymArgs {
+    int32_t first;             // the first scratch id that receives (= number of long / heavy rows)
+    int32_t t1, t2;            // foreign list capacities: c1 for sid < t1, c2 for sid < t2, c3 behind
+    int32_t tl;                // <= t1: the rows in front of it tighten their bound from their foreign list's head (sym_tighten)
+    int32_t c1, c2, c3;
+    unsigned long long *tp;    // N
+    uint32_t *neg, *fcnt;      // N each
+    unsigned long long *flist; // see sym_list_at
+    unsigned long long *own;   // N x KP, by query
+};
+// A stale value only costs work (a weaker bound lets more through, a lower count adds once more): both words only ever grow.
+#ifndef GORSE_SPARSE_SYM_PLAIN_LOAD
+#define GORSE_SPARSE_SYM_PLAIN_LOAD 0
+#endif
+__device__ inline unsigned long long sym_load_tp(const unsigned long long *p) {
+#if GORSE_SPARSE_SYM_PLAIN_LOAD
+    return *reinterpret_cast<const volatile unsigned long long *>(p);
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ inline int64_t sym_list_at(const SymArgs &y, int32_t sid, uint32_t &cap) {
+    if (sid < y.t1) {
+        cap = (uint32_t)y.c1;
+        return (int64_t)sid * y.c1;
+    }
+    if (sid < y.t2) {
+        cap = (uint32_t)y.c2;
+        return (int64_t)y.t1 * y.c1 + (int64_t)(sid - y.t1) * y.c2;
+    }
+    cap = (uint32_t)y.c3;
+    return (int64_t)y.t1 * y.c1 + (int64_t)(y.t2 - y.t1) * y.c2 + (int64_t)(sid - y.t2) * y.c3;
+}
+
 struct TileArgs {
     // segment (c, g) = post[off[c * ngroups + g], off[c * ngroups + g + 1]), rows g * G + loc
     const uint32_t *off;
@@ -125,6 +175,7 @@ struct TileArgs {
     int32_t *part_cnt;              // per (pslot, group): rows scoring above / below zero
     unsigned long long *stat;       // [0] += postings walked, [1] += rows with a non-zero score
     Trace *trace;                   // probe: one record per work item, or null
+    SymArgs sym;                    // the SYM instantiation's whole-query items (see SymArgs)
 };
 
 // the key encodings and the count of returned results: rank_keys.hpp (shared with the host library's CPU test hook)
@@ -528,7 +579,7 @@ constexpr int kQueueStride = 64;   // words between two stripes' counters: 256 b
 constexpr int kQueueBase = 64;     // words 0 .. 15 of the buffer: the heavy-query kernel's eight queues (RowsArgs::next = next + 8)
 constexpr int kQueueWords = kQueueBase + kQueueStripes * kQueueStride;
 
-template <int KP, bool ATOMIC, bool TRACE>
+template <int KP, bool ATOMIC, bool TRACE, bool SYM = false>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
     constexpr int CAP = 2 * KP;
     extern __shared__ __align__(16) unsigned char s_mem[];
@@ -577,8 +628,11 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const uint32_t *off = a.off;
         const Posting *post = a.post;
         const int dir_stride = a.ngroups;
-        // (timing probe: the groups up to the query's own)
-        const int glim = whole && a.tri_probe && qr < a.N ? (a.new_of[qr] >> a.logG) + 1 : a.ngroups;
+        // SYM: a whole-query item takes the rows in front of its own (and the timing probe stops there too)
+        const bool symw = SYM && whole;
+        const int32_t sid_q = symw || (whole && a.tri_probe && qr < a.N) ? a.new_of[qr] : 0;
+        const int glim = symw || (whole && a.tri_probe && qr < a.N) ? (sid_q >> a.logG) + 1 : a.ngroups;
+        uint32_t pub = 0;  // SYM: the bound this item has published for its row
         const int nviews = whole ? (a.head_groups < glim ? a.head_groups : glim) : 1;  // a whole-query item: the head groups here, the others in super-visits below
         const int nacc = NL;
         const int lm = NL - 1;
@@ -635,15 +689,44 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
             if (!__ballot(have)) return;
             my_hit += have;
-            have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
+            if (symw)
+                have = have && sid < sid_q;
+            else
+                have = have && sid != ex_sid && (!a.mask_sid || a.mask_sid[have ? sid : 0]);
             const uint32_t ord = score_ord(x);
             my_pos += have && ord > kZeroOrd;
             my_neg += have && ord < kZeroOrd;
+            if constexpr (SYM) {
+                const bool dl = symw && have && sid >= a.sym.first;
+                if (__ballot(dl)) {  // the other row's side of the pair
+                    const int32_t rs = dl ? sid : a.sym.first;
+                    const unsigned long long tp = sym_load_tp(&a.sym.tp[rs]);
+                    // a bound above zero says the row holds k positive scores already: its counts no longer matter (written())
+                    const bool counts = dl && (uint32_t)tp <= kZeroOrd;
+                    if (counts && ord > kZeroOrd && (uint32_t)(tp >> 32) < (uint32_t)a.k)
+                        __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(&a.sym.tp[rs]) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (counts && ord < kZeroOrd) __hip_atomic_fetch_add(&a.sym.neg[rs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (dl && ord >= (uint32_t)tp) {
+                        const uint32_t slot = __hip_atomic_fetch_add(&a.sym.fcnt[rs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        uint32_t cap;
+                        const int64_t at = sym_list_at(a.sym, rs, cap);
+                        if (slot < cap)
+                            __hip_atomic_store(&a.sym.flist[at + slot], make_key(ord, (int32_t)qr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
             const bool cand = have && ord >= (uint32_t)(thr >> 32);
             if (!__ballot(cand)) return;
             if (!og_loaded) og = cand ? a.orig_of[sid] : 0;
             const unsigned long long key = cand ? make_key(ord, og) : 0;
             push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
+            if constexpr (SYM) {
+                if (symw && (uint32_t)(thr >> 32) > pub) {  // the ranking's threshold moved: a better bound for whoever delivers here
+                    pub = (uint32_t)(thr >> 32);
+                    if (lane == 0)
+                        __hip_atomic_store(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]), pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         };
         // reads group gg's directly indexed accumulators back (a scan, or the touched list) and leaves them zero
         auto read_back = [&](int gg) {
@@ -695,6 +778,50 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             }
             gs = GroupState{0, 0};
         };
+        // SYM: a bound from what has been DELIVERED to this row so far.  A row of the first groups publishes nothing of its own until
+        // its first read-back, which for the longest whole-query rows is milliseconds away (2000 lists over the rows that hold half of
+        // all entries) -- and half the launch delivers to it meanwhile, unfiltered (20,000 entries in one list, r06_x).  Between two
+        // visits the item looks at its foreign list: any k delivered scores bound the k-th key from below, so the k-th largest ord of
+        // the entries that arrived since the last look is published (if higher).  Only the zeroed head of the list is read (kSymLook
+        // entries, cleared by the host before the pass for the rows in front of SymArgs::tl): a slot handed out but not yet written
+        // reads as 0.
+        uint32_t seen = 0;
+        auto sym_tighten = [&]() {
+            if (sid_q >= a.sym.tl || seen >= (uint32_t)kSymLook) return;
+            uint32_t fc = 0;
+            if (lane == 0) fc = __hip_atomic_load(&a.sym.fcnt[sid_q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)fc);
+            uint32_t cap;
+            const int64_t at = sym_list_at(a.sym, sid_q, cap);
+            if (fc > cap) fc = cap;
+            if (fc > (uint32_t)kSymLook) fc = (uint32_t)kSymLook;
+            // (a window of R entries per lane: 4 keeps the kernel at the 3 waves per SIMD + one wave of sparse_rows_kernel beside them)
+            constexpr int R = KP <= 256 ? 4 : 16;
+            constexpr uint32_t kWindow = (uint32_t)(R * kBlock);
+            const uint32_t need = (uint32_t)a.k + ((uint32_t)a.k >> 1) > 256u ? (uint32_t)a.k + ((uint32_t)a.k >> 1) : 256u;
+            if (fc < seen + (need < kWindow ? need : kWindow)) return;
+            const uint32_t n = fc - seen < kWindow ? fc - seen : kWindow;
+            uint32_t o[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const uint32_t i = (uint32_t)(j * kBlock + lane);
+                const unsigned long long key = i < n ? __hip_atomic_load(&a.sym.flist[at + seen + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                o[j] = (uint32_t)(key >> 32);
+            }
+            seen += n;
+            uint32_t kth = 0;
+            for (int b = 31; b >= 0; --b) {
+                const uint32_t trial = kth | (1u << b);
+                int cge = 0;
+#pragma unroll
+                for (int j = 0; j < R; j++) cge += __popcll(__ballot(o[j] >= trial));
+                if (cge >= a.k) kth = trial;
+            }
+            if (kth > pub) {
+                pub = kth;
+                if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]), pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
         int c = 0;  // chunk of visit v inside its view
         int g = whole ? 0 : wk.part;
         for (int64_t v = 0; v < V; v++) {
@@ -724,6 +851,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 read_back(g);
                 c = 0;
                 g++;
+            }
+            if constexpr (SYM) {
+                if (symw) sym_tighten();
             }
             v0 = v1, v1 = v2, v2 = v3, v3 = v4, v4 = v5;
         }
@@ -866,7 +996,16 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         }
         const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);
         finish<KP>(s_buf, bcnt, lane);
-        if (whole) {
+        if (symw) {  // the row's own half: its sorted keys, its counts, and the exact bound its own walk gives
+            for (int i = lane; i < KP; i += kBlock) a.sym.own[(size_t)t * KP + i] = bcnt > 0 ? s_buf[i] : 0;
+            if (lane == 0) {
+                const uint32_t kth = bcnt >= a.k ? (uint32_t)(s_buf[a.k - 1] >> 32) : 0u;
+                if (kth > pub)
+                    __hip_atomic_store(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]), kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pos) __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]) + 1, (uint32_t)pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (neg) __hip_atomic_fetch_add(&a.sym.neg[sid_q], (uint32_t)neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (whole) {
             const bool ex_counts = ex_in && (!a.mask_sid || a.mask_sid[ex_sid]);
             const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
             write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
@@ -1120,6 +1259,66 @@ __global__ __launch_bounds__(kBlock) void sparse_merge_kernel(MergeArgs a) {
         const bool ex_in = ex >= 0 && ex < a.N;
         const bool ex_counts = ex_in && (!a.mask_sid || a.mask_sid[a.new_of[ex_in ? ex : 0]]);
         const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
+        write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
+        __syncthreads();
+    }
+}
+
+// SYM: own keys + foreign list -> the result row of every whole-query row (see SymArgs)
+struct SymMergeArgs {
+    SymArgs sym;
+    int64_t N;
+    const int32_t *new_of;
+    int k;
+    int32_t *out_idx;
+    float *out_score;
+    int32_t *out_cnt;
+    int32_t *redo;                // [0] = rows on the list, [1 ..] = the rows (queries) whose foreign list overflowed
+    unsigned long long *stat;     // [2] += foreign entries ranked, [3] = max over the rows (atomicMax)
+};
+
+template <int KP>
+__global__ __launch_bounds__(kBlock) void sparse_sym_merge_kernel(SymMergeArgs a) {
+    constexpr int CAP = 2 * KP;
+    __shared__ unsigned long long s_buf[CAP];
+    const int lane = threadIdx.x;
+    for (int64_t t = blockIdx.x; t < a.N; t += gridDim.x) {
+        const int32_t sid = a.new_of[t];
+        if (sid < a.sym.first) continue;  // a long / heavy row: its own kernels wrote it
+        uint32_t cap;
+        const int64_t at = sym_list_at(a.sym, sid, cap);
+        const uint32_t fc = a.sym.fcnt[sid];
+        if (lane == 0 && fc) {
+            atomicAdd(&a.stat[2], (unsigned long long)fc);
+            atomicMax(&a.stat[3], (unsigned long long)fc);
+        }
+        if (fc > cap) {
+            if (lane == 0) a.redo[1 + atomicAdd(&a.redo[0], 1)] = (int32_t)t;
+            continue;
+        }
+        const unsigned long long tp = a.sym.tp[sid];
+        const int cnt = written((long long)(tp >> 32), (long long)a.sym.neg[sid], a.N - 1, a.k);
+        const unsigned long long *own = a.sym.own + (size_t)t * KP;
+        if (fc == 0) {  // nothing delivered that counts: the own keys are the row, already in order
+            for (int i = lane; i < a.k; i += kBlock) {
+                const unsigned long long key = i < cnt ? own[i] : 0;
+                a.out_idx[t * a.k + i] = i < cnt ? key_row(key) : -1;
+                a.out_score[t * a.k + i] = i < cnt ? key_score(key) : __uint_as_float(0xff800000u);
+            }
+            if (lane == 0) a.out_cnt[t] = cnt;
+            continue;
+        }
+        int bcnt = 0;
+        unsigned long long thr = 0;
+        for (int i = 0; i < KP; i += kBlock) {
+            const unsigned long long key = own[i + lane];
+            push<KP>(s_buf, a.k, bcnt, thr, key, key > thr, lane);
+        }
+        for (uint32_t i = 0; i < fc; i += kBlock) {
+            const unsigned long long key = i + lane < fc ? a.sym.flist[at + i + lane] : 0;
+            push<KP>(s_buf, a.k, bcnt, thr, key, key > thr, lane);
+        }
+        finish<KP>(s_buf, bcnt, lane);
         write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         __syncthreads();
     }

@@ -358,7 +358,10 @@ int32_t gorse_sparse_search(gorse_sparse *h, int64_t nq, const int64_t *q_indptr
                             const int64_t *exclude /*host or NULL*/, int32_t k, int32_t *idx_out /*host*/,
                             float *score_out /*host*/, int32_t *count_out /*host*/);
 /* every stored row q in [q_begin, q_end) as a query (the item-to-item / user-to-user refresh): exclude_self != 0
- * treats row q as absent from its own ranking.  Host pointers may be NULL (results stay on the device). */
+ * treats row q as absent from its own ranking.  Host pointers may be NULL (results stay on the device).
+ * A call over ALL rows with exclude_self and no mask walks every pair of ordinary rows once and delivers the score to both
+ * rankings (the same products in the same order: the same bits; csrc/sparse_kernels.hpp, SymArgs) -- results identical to
+ * any other way of asking, ~2 KB of device scratch per row.  The handle keeps the work plan of its last all-pairs call. */
 int32_t gorse_sparse_all_pairs(gorse_sparse *h, int64_t q_begin, int64_t q_end, int32_t k, int32_t exclude_self,
                                int32_t *idx_out /*host or NULL*/, float *score_out /*host or NULL*/,
                                int32_t *count_out /*host or NULL*/);

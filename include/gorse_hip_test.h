@@ -96,6 +96,13 @@ void gorse_hip_test_set_sparse_table(int32_t cap_shift);
 /* timing probe (results are garbage): 1 = a whole-query item of the sparse list walk visits only the row groups up to its own row's --
  * the postings a symmetric walk of the whole-query items would still meet (sparse).  0 = off (default). */
 void gorse_hip_test_set_sparse_probe(int32_t probe);
+/* The symmetric form of gorse_sparse_all_pairs over all rows (csrc/sparse_kernels.hpp, SymArgs): mode 0 = never (the walk every other
+ * call takes), -1 / 1 = when the call is eligible (default).  c1 / c2 / c3 > 0 replace the capacities of the three tiers of foreign lists
+ * (tests overflow them on purpose: the rows then take the unsymmetric walk in a second launch); 0 = the defaults.  Results never differ. */
+void gorse_hip_test_set_sparse_sym(int32_t mode, int32_t c1, int32_t c2, int32_t c3);
+/* the last call of the handle: out[0] = it ran in symmetric form, [1] = rows redone after an overflow, [2] = foreign entries ranked,
+ * [3] = the longest foreign list */
+void gorse_hip_test_sparse_sym_stats(const gorse_sparse *h, int64_t out[4]);
 /* rows per group of a handle created AFTERWARDS (the posting lists are cut by row group, csrc/sparse_kernels.hpp): a power of two
  * in 256 .. 16384; 0 = 2048.  A workgroup holds a group's accumulators: 5.5 bytes of LDS per row. */
 void gorse_hip_test_set_sparse_tile(int32_t rows);

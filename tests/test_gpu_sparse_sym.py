@@ -1,0 +1,149 @@
+"""GPU parity: the SYMMETRIC form of the sparse all-pairs pass (csrc/sparse_kernels.hpp, SymArgs; round 6).  When every stored row is a
+query and leaves out only itself, a pair of whole-query rows is walked once, by the shorter row, and the score is delivered to the other
+row's ranking (published bounds, foreign lists, a merge, and the unsymmetric walk again for a row whose list overflowed).  Rows, score
+bits, counts and padding must equal the unsymmetric walk's -- which tests/test_gpu_vectors_sparse.py holds against the oracle -- and the
+oracle's (storage/vectors/xvec.go:379-446 through oracle/)."""
+import numpy as np
+import pytest
+
+from gorse_amd import capi, synth
+from sparse_cases import check_against_oracle as check, random_csr, rows_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def hooks():
+    L = capi.lib()
+    yield L
+    L.gorse_hip_test_set_sparse_sym(-1, 0, 0, 0)
+    L.gorse_hip_test_set_sparse_slots(0)
+    L.gorse_hip_test_set_sparse_head(-1)
+    L.gorse_hip_test_set_sparse_tile(0)
+    L.gorse_hip_test_set_sparse_split(2048)
+    L.gorse_hip_test_set_sparse_heavy(16384)
+    L.gorse_hip_test_set_sparse_atomic(-1)
+
+
+def _bits(x):
+    return x.view(np.uint32) if x.dtype == np.float32 else x
+
+
+def _same(x, y):
+    for a, b in zip(x, y):
+        assert np.array_equal(_bits(a), _bits(b))
+
+
+def _both(hooks, s, k, caps=(0, 0, 0)):
+    """(unsymmetric, symmetric) results of all_pairs(k) and the symmetric call's statistics"""
+    hooks.gorse_hip_test_set_sparse_sym(0, 0, 0, 0)
+    plain = s.all_pairs(k)
+    assert s.sym_stats()[0] == 0
+    hooks.gorse_hip_test_set_sparse_sym(1, *caps)
+    sym = s.all_pairs(k)
+    st = s.sym_stats()
+    hooks.gorse_hip_test_set_sparse_sym(-1, 0, 0, 0)
+    return plain, sym, st
+
+
+@pytest.mark.parametrize("k", [1, 7, 100, 130, 300, 1024])
+@pytest.mark.parametrize("shape", ["signed_zipf", "positive", "short_rows"])
+def test_symmetric_pass_equals_the_unsymmetric_one(oracle, hooks, shape, k):
+    rng = np.random.default_rng(600 + k)
+    if shape == "signed_zipf":  # long and heavy rows in front (their own kernels), negative and cancelling scores
+        ptr, idx, val = random_csr(rng, 5000, 90, 0, 14, neg=True, zipf=True)
+        hooks.gorse_hip_test_set_sparse_tile(256)
+        hooks.gorse_hip_test_set_sparse_split(6)
+        hooks.gorse_hip_test_set_sparse_heavy(9)
+    elif shape == "positive":  # the shape of the IDF collections: everything positive, most pairs share something
+        ptr, idx, val = random_csr(rng, 3000, 300, 1, 40, zipf=True)
+        hooks.gorse_hip_test_set_sparse_tile(512)
+    else:  # most rows have fewer than k partners: no bound is ever published, everything delivered is appended
+        ptr, idx, val = random_csr(rng, 4000, 6000, 0, 4)
+    s = capi.Sparse(ptr, idx, val)
+    plain, sym, st = _both(hooks, s, k)
+    assert st[0] == 1
+    _same(plain, sym)
+    sample = list(range(0, ptr.size - 1, 97))
+    check(oracle, ptr, idx, val, k, [x[sample] for x in sym], rows_of(ptr, idx, val, sample), sample)
+    s.close()
+
+
+def test_overflowing_foreign_lists_send_rows_through_the_unsymmetric_walk(oracle, hooks):
+    rng = np.random.default_rng(77)
+    ptr, idx, val = random_csr(rng, 6000, 200, 0, 12, neg=True, zipf=True)
+    hooks.gorse_hip_test_set_sparse_tile(256)
+    hooks.gorse_hip_test_set_sparse_split(10)
+    s = capi.Sparse(ptr, idx, val)
+    for caps in ((1, 1, 1), (3, 2, 1), (64, 8, 2)):
+        plain, sym, st = _both(hooks, s, 20, caps)
+        assert st[0] == 1 and st[1] > 0, st  # rows were redone
+        assert st[3] > caps[2]
+        _same(plain, sym)
+    sample = list(range(0, 6000, 61))
+    check(oracle, ptr, idx, val, 20, [x[sample] for x in sym], rows_of(ptr, idx, val, sample), sample)
+    s.close()
+
+
+def test_equal_rows_and_equal_scores(oracle, hooks):
+    """blocks of identical rows: equal lengths (the order of the scratch ids decides who walks a pair) and equal scores (ascending row
+    among them, whether a key came from the own walk or was delivered)"""
+    rng = np.random.default_rng(5)
+    base_ptr, base_idx, base_val = random_csr(rng, 40, 30, 1, 8)
+    reps = rng.integers(0, 40, 1500)
+    ptr = [0]
+    idx, val = [], []
+    for r in reps:
+        idx.append(base_idx[base_ptr[r]:base_ptr[r + 1]])
+        val.append(base_val[base_ptr[r]:base_ptr[r + 1]])
+        ptr.append(ptr[-1] + idx[-1].size)
+    ptr, idx, val = np.array(ptr, np.int64), np.concatenate(idx), np.concatenate(val)
+    hooks.gorse_hip_test_set_sparse_tile(256)
+    s = capi.Sparse(ptr, idx, val)
+    for k in (5, 64, 200):
+        plain, sym, st = _both(hooks, s, k)
+        assert st[0] == 1
+        _same(plain, sym)
+        check(oracle, ptr, idx, val, k, [x[:200] for x in sym], rows_of(ptr, idx, val, range(200)), list(range(200)))
+    s.close()
+
+
+def test_calls_that_are_not_all_pairs_keep_the_unsymmetric_walk(hooks):
+    rng = np.random.default_rng(9)
+    ptr, idx, val = random_csr(rng, 800, 100, 0, 10)
+    s = capi.Sparse(ptr, idx, val)
+    s.all_pairs(5)
+    assert s.sym_stats()[0] == 1
+    s.all_pairs(5, 0, 799)
+    assert s.sym_stats()[0] == 0
+    s.all_pairs(5, exclude_self=False)
+    assert s.sym_stats()[0] == 0
+    s.set_mask((rng.random(800) < 0.5).astype(np.uint8))
+    s.all_pairs(5)
+    assert s.sym_stats()[0] == 0
+    s.set_mask(None)
+    qp, qi, qv = random_csr(rng, 800, 100, 0, 10)
+    s.search(qp, qi, qv, 5)
+    assert s.sym_stats()[0] == 0
+    s.close()
+
+
+def test_idf_collection_of_a_synthetic_shard(oracle, hooks):
+    """the writer's own shape (logics/vector_writer.go:192-209: IDF weights over the users of an item), default switches: both forms,
+    the statistics of the symmetric one (fewer postings walked, no row redone), a sample against the oracle"""
+    data = synth.s_ml1m()
+    ptr, idx, val = synth.idf_vectors(data.iptr, data.iidx, data.U)
+    s = capi.Sparse(ptr, idx, val)
+    hooks.gorse_hip_test_set_sparse_sym(0, 0, 0, 0)
+    plain = s.all_pairs(100)
+    walked_plain = s.last_stats()[0]
+    hooks.gorse_hip_test_set_sparse_sym(1, 0, 0, 0)
+    sym = s.all_pairs(100)
+    walked_sym = s.last_stats()[0]
+    st = s.sym_stats()
+    assert st[0] == 1 and st[1] == 0
+    assert walked_sym < walked_plain
+    _same(plain, sym)
+    sample = list(range(0, ptr.size - 1, max(1, (ptr.size - 1) // 64)))
+    check(oracle, ptr, idx, val, 100, [x[sample] for x in sym], rows_of(ptr, idx, val, sample), sample)
+    s.close()

@@ -19,10 +19,18 @@ def test_all_pairs_equals_oracle(oracle):
     for k in (7, 64, 100):
         got = s.all_pairs(k)
         check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(600)), list(range(600)))
-    # statistics of the last call: multiply-adds = posting-list lengths summed over the queries' indices
+    # statistics of the last call: postings walked = posting-list lengths summed over the queries' indices in the unsymmetric walk
+    # (the symmetric form of an all-pairs pass, tests/test_gpu_sparse_sym.py, walks fewer)
     lens = np.bincount(idx, minlength=400)
     postings, hits = s.last_stats()
-    assert postings == int(lens[idx].sum())
+    assert s.sym_stats()[0] == 1 and postings <= int(lens[idx].sum())  # (one row group here: the same)
+    capi.lib().gorse_hip_test_set_sparse_sym(0, 0, 0, 0)
+    try:
+        _same(got, s.all_pairs(100))
+        postings, hits = s.last_stats()
+        assert postings == int(lens[idx].sum())
+    finally:
+        capi.lib().gorse_hip_test_set_sparse_sym(-1, 0, 0, 0)
     got = s.all_pairs(5, q_begin=590, q_end=597, exclude_self=False)
     check(oracle, ptr, idx, val, 5, got, rows_of(ptr, idx, val, range(590, 597)), [-1] * 7)
 
