@@ -126,6 +126,7 @@ SIGNATURES = {
     "gorse_hip_test_set_sparse_table": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_probe": (None, [C.c_int32]),
     "gorse_hip_test_set_sparse_sym": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gorse_hip_test_set_sparse_front": (None, [C.c_int32]),
     "gorse_hip_test_sparse_sym_stats": (None, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gorse_hip_test_set_sparse_tile": (None, [C.c_int32]),
     "gorse_hip_test_set_scan_literal": (None, [C.c_int32]),

@@ -16,6 +16,7 @@ using gorse::sparse::TileArgs;
 struct gorse_sparse {
     int device = 0;
     int64_t N = 0, nnz = 0, Dc = 0;
+    int64_t Np = 0;  // scratch ids: N + the phantom ids behind the front (sparse_host.hpp, RowOrder)
     int32_t logG = 0, ngroups = 0;  // groups of G = 1 << logG consecutive scratch ids
     hipStream_t stream = nullptr;
     // stored rows as CSR with directory entries instead of raw indices (the queries of all_pairs), the tiled posting lists
@@ -79,6 +80,8 @@ int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for t
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
 int g_sparse_sym = -1;            // an eligible all-pairs pass walks its whole-query pairs once (SymArgs): -1 / 1 = yes, 0 = never
 int g_sparse_sym_caps[3] = {0, 0, 0};  // foreign list capacities of the three tiers (0 = the defaults): tests overflow them on purpose
+int64_t g_sparse_rows_wgs = 1024;  // most workgroups of sparse_rows_kernel (probe: bits 8.. of gorse_hip_test_set_sparse_probe x 256)
+int g_sparse_front = 1;           // handles created afterwards give the rows longer than the split threshold a row group of their own (RowOrder)
 int g_sparse_tri_probe = 0;      // timing probe: whole-query items stop at their own group (gorse_hip_test_set_sparse_probe)
 int g_sparse_cap_shift = 2;      // postings a super-visit's table takes: accumulators >> this (gorse_hip_test_set_sparse_table)
 int g_sparse_head = -1;          // groups a whole-query item visits one by one (the rest in hashed super-visits); -1 = head_groups_of()
@@ -195,14 +198,14 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     // (rows are numbered longest first and a query's length is its row's).
     bool sym = g_sparse_sym != 0 && qp == h->r_ptr.p && q_first == 0 && nq == h->N && exclude_self && !excl_dev && !h->has_mask &&
                !h->trace_on && !shorts.empty() && longs.size() < (size_t)h->N;
-    for (size_t l = 0; sym && l < longs.size(); l++) sym = h->order.new_of[(size_t)longs[l]] < (int64_t)longs.size();
+    for (size_t l = 0; sym && l < longs.size(); l++) sym = h->order.rank_of(h->order.new_of[(size_t)longs[l]]) < (int64_t)longs.size();
     a.sym = sparse::SymArgs{};
     if (sym) {
         sparse::SymArgs &y = a.sym;
-        const int64_t N = h->N;
+        const int64_t N = h->Np;  // (per scratch id)
         // Foreign list capacities.  A row's bound is published by its own item; what arrives before that is appended unfiltered, and
         // that is the rows at the head of the work list while the launch fills (up to a launch's waves deliver to them at once).
-        y.first = (int32_t)longs.size();
+        y.first = (int32_t)h->order.sid_of_rank((int64_t)longs.size());
         y.t1 = (int32_t)std::min<int64_t>(N, 16384), y.t2 = (int32_t)std::min<int64_t>(N, 65536);
         const int32_t most = (int32_t)std::min<int64_t>(N, 1 << 20);  // a list never holds more than N - 1 entries
         y.c1 = std::min(most, g_sparse_sym_caps[0] > 0 ? g_sparse_sym_caps[0] : 8192);
@@ -234,7 +237,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     a.head_groups = head_groups_of(h);
     a.cap_shift = g_sparse_cap_shift;
     a.tri_probe = g_sparse_tri_probe;
-    a.N = h->N;
+    a.N = h->N, a.Np = h->Np;
     a.orig_of = h->orig_of.p, a.new_of = h->new_of.p;
     a.q_ptr = qp, a.q_cid = qc, a.q_val = qv, a.q_first = q_first;
     a.exclude = excl_dev, a.exclude_self = exclude_self;
@@ -327,7 +330,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             r.part_keys = h->part_keys.p, r.part_cnt = h->part_cnt.p, r.stat = h->stat.p;
             // at most four of its waves per CU: the kernel is bound by its longest row, not by throughput, and at 170 VGPRs a full
             // grid of it would take the register files from the list walk it runs next to
-            const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->n_ranges, std::min<int64_t>(slots, 1024)));
+            const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->n_ranges, std::min<int64_t>(slots, g_sparse_rows_wgs)));
             switch (kp) {
                 case 128: sparse::sparse_rows_kernel<128><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
                 case 256: sparse::sparse_rows_kernel<256><<<dim3(rgrid), dim3(sparse::kBlock), 0, h->stream2>>>(r); break;
@@ -458,14 +461,20 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     h->device = device;
     h->N = N;
     h->nnz = nnz;
-    h->order = sparse::order_rows(N, indptr);
+    h->logG = pick_log_group();
+    h->order = sparse::order_rows(N, indptr, g_sparse_front ? g_sparse_split : 0, (int64_t)1 << h->logG);
+    const int64_t Np = h->Np = h->order.Np;
+    if (Np > INT32_MAX) {
+        delete h;
+        return fail(GORSE_ERR_INVALID, "N must fit int32");
+    }
     const std::vector<uint32_t> dims = sparse::distinct_indices(indices + base, nnz);
     h->Dc = (int64_t)dims.size();
-    h->logG = pick_log_group();
-    h->ngroups = (int32_t)ceil_div(N, (int64_t)1 << h->logG);
+    h->ngroups = (int32_t)ceil_div(Np, (int64_t)1 << h->logG);
     h->group_share.assign((size_t)h->ngroups, 0.0);
-    for (int64_t sid = 0; sid < N; sid++) {
+    for (int64_t sid = 0; sid < Np; sid++) {
         const int64_t r = h->order.orig_of[(size_t)sid];
+        if (r < 0) continue;
         h->group_share[(size_t)(sid >> h->logG)] += (double)(indptr[r + 1] - indptr[r]) / (double)std::max<int64_t>(nnz, 1);
     }
     int32_t rc = [&]() -> int32_t {
@@ -481,7 +490,7 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
             // than 1024 entries is walked by the whole wave, 64 entries per step: cost ~ its length; shorter rows go 64 at a time,
             // one per lane: a block costs ~ 27 x its first (longest) row's length (16 entries per ~5 us step against 64 entries
             // per ~0.7 us step).  A range closes when it reaches 1 / 192 of the total -- single long rows become ranges of their own.
-            auto len_of = [&](int64_t sid) { const int64_t r = h->order.orig_of[(size_t)sid]; return indptr[r + 1] - indptr[r]; };
+            auto len_of = [&](int64_t sid) { const int64_t r = h->order.orig_of[(size_t)sid]; return r < 0 ? (int64_t)0 : indptr[r + 1] - indptr[r]; };
             constexpr int64_t kLongRow = 1024;  // = sparse_rows_kernel's
             auto cost_at = [&](int64_t sid, int64_t first) -> double {
                 const int64_t len = len_of(sid);
@@ -489,18 +498,18 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
                 return (sid - first) % 64 == 0 ? 27.0 * (double)(len + 1) : 0.0;
             };
             double total = 0;
-            for (int64_t sid = 0; sid < N; sid++) total += cost_at(sid, 0);
+            for (int64_t sid = 0; sid < Np; sid++) total += cost_at(sid, 0);
             const double target = std::max(total / 192.0, 1.0);
             std::vector<int32_t> starts{0};
             double cost = 0;
-            for (int64_t sid = 0; sid < N; sid++) {
+            for (int64_t sid = 0; sid < Np; sid++) {
                 cost += cost_at(sid, starts.back());
-                if (cost >= target && sid + 1 < N) {
+                if (cost >= target && sid + 1 < Np) {
                     starts.push_back((int32_t)(sid + 1));
                     cost = 0;
                 }
             }
-            starts.push_back((int32_t)N);
+            starts.push_back((int32_t)Np);
             h->n_ranges = (int32_t)starts.size() - 1;
             GORSE_TRY(h->range_start.alloc(starts.size()));
             GORSE_HIP_CHECK(hipMemcpyAsync(h->range_start.p, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, h->stream));
@@ -513,7 +522,7 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         // + 1 / + 2: the tile kernel's look-ahead loads clamp to element 0 (and 1) of every array instead of branching
         GORSE_TRY(h->r_cid.alloc((size_t)nnz + 1));
         GORSE_TRY(h->r_val.alloc((size_t)nnz + 1));
-        GORSE_TRY(h->orig_of.alloc((size_t)N));
+        GORSE_TRY(h->orig_of.alloc((size_t)Np));
         GORSE_TRY(h->new_of.alloc((size_t)N));
         GORSE_TRY(h->dims.alloc((size_t)h->Dc));
         GORSE_TRY(h->off.alloc((size_t)cells + 2));
@@ -521,7 +530,7 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
         DevBuf<uint32_t> raw, cursor, sums;
         GORSE_TRY(raw.alloc((size_t)nnz));
         GORSE_TRY(cursor.alloc((size_t)cells + 1));
-        GORSE_HIP_CHECK(hipMemcpyAsync(h->orig_of.p, h->order.orig_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
+        GORSE_HIP_CHECK(hipMemcpyAsync(h->orig_of.p, h->order.orig_of.data(), (size_t)Np * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->new_of.p, h->order.new_of.data(), (size_t)N * 4, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemcpyAsync(h->r_ptr.p, ptr0.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice, h->stream));
         GORSE_HIP_CHECK(hipMemsetAsync(h->off.p, 0, ((size_t)cells + 2) * 4, h->stream));
@@ -581,14 +590,15 @@ extern "C" int32_t gorse_sparse_set_mask(gorse_sparse *h, const uint8_t *admissi
         h->has_mask = false;
         return GORSE_OK;
     }
-    std::vector<uint8_t> by_sid((size_t)h->N);
+    std::vector<uint8_t> by_sid((size_t)h->Np);
     h->n_admissible = 0;
-    for (int64_t s = 0; s < h->N; s++) {
-        by_sid[(size_t)s] = admissible[h->order.orig_of[(size_t)s]] != 0;
+    for (int64_t s = 0; s < h->Np; s++) {
+        const int64_t r = h->order.orig_of[(size_t)s];
+        by_sid[(size_t)s] = r >= 0 && admissible[r] != 0;
         h->n_admissible += by_sid[(size_t)s];
     }
-    GORSE_TRY(h->mask_sid.ensure((size_t)h->N));
-    GORSE_HIP_CHECK(hipMemcpyAsync(h->mask_sid.p, by_sid.data(), (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+    GORSE_TRY(h->mask_sid.ensure((size_t)h->Np));
+    GORSE_HIP_CHECK(hipMemcpyAsync(h->mask_sid.p, by_sid.data(), (size_t)h->Np, hipMemcpyHostToDevice, h->stream));
     GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->has_mask = true;
     return GORSE_OK;
@@ -676,7 +686,11 @@ extern "C" int32_t gorse_sparse_last_stats(gorse_sparse *h, int64_t *postings, i
 
 extern "C" void gorse_hip_test_set_sparse_slots(int64_t max_slots) { g_sparse_max_slots = max_slots; }
 extern "C" void gorse_hip_test_set_sparse_head(int32_t groups) { g_sparse_head = groups; }
-extern "C" void gorse_hip_test_set_sparse_probe(int32_t probe) { g_sparse_tri_probe = probe; }
+extern "C" void gorse_hip_test_set_sparse_probe(int32_t probe) {
+    g_sparse_tri_probe = probe & 0xff;
+    g_sparse_rows_wgs = (probe >> 8) > 0 ? (int64_t)(probe >> 8) * 256 : 1024;
+}
+extern "C" void gorse_hip_test_set_sparse_front(int32_t on) { g_sparse_front = on; }
 extern "C" void gorse_hip_test_set_sparse_sym(int32_t mode, int32_t c1, int32_t c2, int32_t c3) {
     g_sparse_sym = mode;
     g_sparse_sym_caps[0] = c1, g_sparse_sym_caps[1] = c2, g_sparse_sym_caps[2] = c3;

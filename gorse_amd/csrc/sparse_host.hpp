@@ -29,19 +29,37 @@ inline std::string validate_csr(int64_t rows, const int64_t *indptr, const uint3
 // Scratch numbering of the stored rows: longest row first (ties by row).  Rows with many entries are the ones most queries
 // reach; numbering them first puts them into the first tiles (sparse_kernels.hpp), whose accumulators are then dense.
 // Results, masks and exclusions keep the caller's row ids (orig_of translates back).
+// Round 6: the FRONT.  The rows longer than `front_cut` (the ones a pass answers as long / heavy queries) get a row group of their
+// own when there are fewer of them than a group holds: `pad` phantom ids follow them (orig_of = -1: no entries, never a query,
+// never a result), so that the next row starts group 1.  The symmetric all-pairs pass then lets the front DELIVER its scores and
+// every other row leaves group 0 out of its walk (sparse_kernels.hpp, FrontArgs).
 struct RowOrder {
     std::vector<int32_t> new_of;   // caller's row -> scratch id
-    std::vector<int32_t> orig_of;  // scratch id -> caller's row
+    std::vector<int32_t> orig_of;  // scratch id -> caller's row, or -1 (a phantom id)
+    int64_t Np = 0;                // scratch ids: N + pad
+    int32_t n_front = 0, pad = 0;  // pad > 0: ids [0, n_front) are the front, [n_front, n_front + pad) phantoms
+    int64_t rank_of(int64_t sid) const { return sid < n_front ? sid : sid - pad; }       // position in the longest-first order
+    int64_t sid_of_rank(int64_t rank) const { return rank < n_front ? rank : rank + pad; }
 };
-inline RowOrder order_rows(int64_t N, const int64_t *indptr) {
+inline RowOrder order_rows(int64_t N, const int64_t *indptr, int64_t front_cut = 0, int64_t group = 0) {
     RowOrder o;
-    o.orig_of.resize((size_t)N);
+    std::vector<int32_t> by_len((size_t)N);
     o.new_of.resize((size_t)N);
-    std::iota(o.orig_of.begin(), o.orig_of.end(), 0);
-    std::stable_sort(o.orig_of.begin(), o.orig_of.end(), [&](int32_t a, int32_t b) {
+    std::iota(by_len.begin(), by_len.end(), 0);
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int32_t a, int32_t b) {
         return indptr[a + 1] - indptr[a] > indptr[b + 1] - indptr[b];
     });
-    for (int64_t t = 0; t < N; t++) o.new_of[(size_t)o.orig_of[(size_t)t]] = (int32_t)t;
+    int64_t n_front = 0;
+    if (front_cut > 0 && group > 0)
+        while (n_front < N && indptr[by_len[(size_t)n_front] + 1] - indptr[by_len[(size_t)n_front]] > front_cut) n_front++;
+    if (n_front > 0 && n_front < group && n_front < N) o.n_front = (int32_t)n_front, o.pad = (int32_t)(group - n_front);
+    o.Np = N + o.pad;
+    o.orig_of.assign((size_t)o.Np, -1);
+    for (int64_t t = 0; t < N; t++) {
+        const int64_t sid = o.sid_of_rank(t);
+        o.orig_of[(size_t)sid] = by_len[(size_t)t];
+        o.new_of[(size_t)by_len[(size_t)t]] = (int32_t)sid;
+    }
     return o;
 }
 

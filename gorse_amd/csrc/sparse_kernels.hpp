@@ -153,8 +153,8 @@ struct TileArgs {
     int32_t head_groups;  // a whole-query item visits the groups [0, head_groups) one by one with directly indexed accumulators and
                           // the rest in SUPER-VISITS of several groups with hashed accumulators (see sparse_tile_kernel); = ngroups: never
     int32_t part_stride;  // partial rankings per block of part_keys / part_cnt
-    int64_t N;
-    const int32_t *orig_of, *new_of;  // scratch id <-> caller's row
+    int64_t N, Np;                    // stored rows; scratch ids (N + the phantom ids behind the front: sparse_host.hpp)
+    const int32_t *orig_of, *new_of;  // scratch id <-> caller's row (orig_of = -1: a phantom id)
     // queries: CSR rows q_first .. of (q_ptr, q_cid, q_val); q_cid = directory entry of the index or -1 (never stored)
     const int64_t *q_ptr;
     const int32_t *q_cid;
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 auto sid_of = [&](int32_t i) { return (int32_t)((gg << a.logG) + i); };  // N fits int32
                 auto orig_at = [&](bool in, int32_t i) {
                     const int32_t sid = sid_of(i);
-                    return in && sid < a.N ? a.orig_of[sid] : 0;
+                    return in && sid < a.Np ? a.orig_of[sid] : 0;
                 };
                 if ((int64_t)gs.walked * 4 >= nacc || gs.tcnt > tcap) {
                     tr.add(&Trace::dense_groups);
@@ -1109,9 +1109,10 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
         for (int64_t sb = s0; sb < s1; sb += kBlock) {
             const int64_t sid = sb + lane;
             const bool in = sid < s1;
-            const int32_t row = a.orig_of[in ? sid : s0];
+            const int32_t row_or_none = a.orig_of[in ? sid : s0];  // (-1: a phantom id behind the front, an empty row)
+            const int32_t row = row_or_none < 0 ? 0 : row_or_none;
             int64_t e = a.r_ptr[row];
-            const int64_t end = in ? a.r_ptr[row + 1] : e;
+            const int64_t end = in && row_or_none >= 0 ? a.r_ptr[row + 1] : e;
             float acc = 0.0f;
             // Long rows first, one at a time with the whole wave: 64 consecutive entries per step (coalesced), their products
             // added in lane order = entry order.  One lane walking a 116,000-entry row 16 entries at a time was the kernel's

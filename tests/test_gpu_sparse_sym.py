@@ -17,6 +17,7 @@ def hooks():
     L = capi.lib()
     yield L
     L.gorse_hip_test_set_sparse_sym(-1, 0, 0, 0)
+    L.gorse_hip_test_set_sparse_front(1)
     L.gorse_hip_test_set_sparse_slots(0)
     L.gorse_hip_test_set_sparse_head(-1)
     L.gorse_hip_test_set_sparse_tile(0)
@@ -146,4 +147,43 @@ def test_idf_collection_of_a_synthetic_shard(oracle, hooks):
     _same(plain, sym)
     sample = list(range(0, ptr.size - 1, max(1, (ptr.size - 1) // 64)))
     check(oracle, ptr, idx, val, 100, [x[sample] for x in sym], rows_of(ptr, idx, val, sample), sample)
+    s.close()
+
+
+@pytest.mark.parametrize("k", [3, 100, 300])
+@pytest.mark.parametrize("split", [38, 33, 20])
+def test_front_group_of_the_long_rows(oracle, hooks, split, k):
+    """The rows longer than the split threshold at creation get a row group of their own (phantom scratch ids behind them) when they are
+    fewer than a group holds (split 38: ~150 of 3000 rows, 33: ~500, 20: more than the 512 of a group -> plain numbering): every kind of
+    call -- all pairs in both forms, a query range, searches with masks and exclusions -- against the plain numbering and the oracle."""
+    rng = np.random.default_rng(800 + split)
+    ptr, idx, val = random_csr(rng, 3000, 300, 1, 40, neg=(split == 33), zipf=True)
+    n_long = int((np.diff(ptr) > split).sum())
+    assert (n_long < 512) == (split != 20) and n_long > 0
+    hooks.gorse_hip_test_set_sparse_tile(512)
+    hooks.gorse_hip_test_set_sparse_split(split)
+    hooks.gorse_hip_test_set_sparse_heavy(39)  # the longest rows: the dense-vector kernel
+    hooks.gorse_hip_test_set_sparse_front(0)
+    plain_index = capi.Sparse(ptr, idx, val)
+    hooks.gorse_hip_test_set_sparse_front(1)
+    s = capi.Sparse(ptr, idx, val)
+    ref, sym, st = _both(hooks, plain_index, k)
+    unsym2, sym2, st2 = _both(hooks, s, k)
+    assert st[0] == 1 and st2[0] == 1
+    _same(ref, sym)
+    _same(ref, unsym2)
+    _same(ref, sym2)
+    sample = list(range(0, 3000, 41))
+    check(oracle, ptr, idx, val, k, [x[sample] for x in sym2], rows_of(ptr, idx, val, sample), sample)
+    _same(plain_index.all_pairs(k, 100, 900, exclude_self=False), s.all_pairs(k, 100, 900, exclude_self=False))
+    mask = (rng.random(3000) < 0.7).astype(np.uint8)
+    qp, qi, qv = random_csr(rng, 40, 320, 0, 60, neg=True)
+    excl = rng.integers(-1, 3000, 40).astype(np.int64)
+    for index in (plain_index, s):
+        index.set_mask(mask)
+    got = s.search(qp, qi, qv, k, exclude=excl)
+    _same(plain_index.search(qp, qi, qv, k, exclude=excl), got)
+    check(oracle, ptr, idx, val, k, got, rows_of(qp, qi, qv, range(40)), list(excl), mask)
+    _same(plain_index.all_pairs(k), s.all_pairs(k))
+    plain_index.close()
     s.close()
