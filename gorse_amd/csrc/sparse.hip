@@ -46,6 +46,7 @@ struct gorse_sparse {
     // the symmetric form of an all-pairs pass (sparse::SymArgs)
     DevBuf<unsigned long long> sym_tp, sym_flist, sym_own;
     DevBuf<uint32_t> sym_neg, sym_fcnt;
+    DevBuf<float> sym_fm, sym_fmt;  // the front's score matrix and its transpose (SymArgs)
     DevBuf<int32_t> sym_redo;
     // The work plan of the last all-pairs call (the queries are the stored rows, which never change): the host's sorts and the
     // uploads of a 200,000-row pass were ~1.5 ms of its 36 (r06_y2: kernels 26.5 ms, pass 28.9).  `valid`: the host lists below are
@@ -78,7 +79,8 @@ int64_t g_sparse_heavy = 16384;  // ... and with more than this they are scored 
                                  // <= 0 = never
 int g_sparse_atomic = -1;        // -1 = ds_add_f32 unless the values call for the load/add/store form, 0 / 1 = force
 int64_t g_sparse_max_slots = 0;  // workgroups per launch (0 = 16 per CU)
-int g_sparse_sym = -1;            // an eligible all-pairs pass walks its whole-query pairs once (SymArgs): -1 / 1 = yes, 0 = never
+int g_sparse_sym = -1;            // an eligible all-pairs pass walks its whole-query pairs once (SymArgs): -1 / 1 = yes, 0 = never,
+                                  // 2 = yes, but the front (the long rows in a group of their own) does not deliver
 int g_sparse_sym_caps[3] = {0, 0, 0};  // foreign list capacities of the three tiers (0 = the defaults): tests overflow them on purpose
 int64_t g_sparse_rows_wgs = 1024;  // most workgroups of sparse_rows_kernel (probe: bits 8.. of gorse_hip_test_set_sparse_probe x 256)
 int g_sparse_front = 1;           // handles created afterwards give the rows longer than the split threshold a row group of their own (RowOrder)
@@ -108,7 +110,8 @@ int pick_log_group() {
 template <int KP>
 int32_t launch_tiles(const TileArgs &a, unsigned grid, size_t lds, bool atomic, bool sym, hipStream_t s) {  // s: the stream of this launch
     auto kern = atomic ? sparse::sparse_tile_kernel<KP, true, false> : sparse::sparse_tile_kernel<KP, false, false>;
-    if (sym) kern = atomic ? sparse::sparse_tile_kernel<KP, true, false, true> : sparse::sparse_tile_kernel<KP, false, false, true>;
+    if (sym) kern = atomic ? sparse::sparse_tile_kernel<KP, true, false, 1> : sparse::sparse_tile_kernel<KP, false, false, 1>;
+    if (sym && a.sym.front) kern = atomic ? sparse::sparse_tile_kernel<KP, true, false, 2> : sparse::sparse_tile_kernel<KP, false, false, 2>;
 #ifdef GORSE_PROBE  // the trace instantiation exists in `make probe-lib` builds only
     if (a.trace && !sym) kern = atomic ? sparse::sparse_tile_kernel<KP, true, true> : sparse::sparse_tile_kernel<KP, false, true>;
 #endif
@@ -231,6 +234,17 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             else
                 GORSE_HIP_CHECK(hipMemset2DAsync(h->sym_flist.p, (size_t)y.c1 * 8, 0, look * 8, (size_t)y.tl, h->stream));
         }
+        // The front delivers when the long / heavy rows of this call are exactly the rows that got group 0 to themselves at creation.
+        y.front = 0;
+        if (g_sparse_sym != 2 && h->order.pad > 0 && (int64_t)longs.size() == h->order.n_front) {
+            y.front = h->order.n_front;
+            y.fw = (y.front + 63) / 64 * 64;
+            y.Ns = N - y.first;
+            GORSE_TRY(h->sym_fm.ensure((size_t)y.front * (size_t)y.Ns));
+            GORSE_TRY(h->sym_fmt.ensure((size_t)y.Ns * (size_t)y.fw));
+            GORSE_HIP_CHECK(hipMemsetAsync(h->sym_fm.p, 0, (size_t)y.front * (size_t)y.Ns * 4, h->stream));
+            y.fm = h->sym_fm.p, y.fmt = h->sym_fmt.p;
+        }
         y.tp = h->sym_tp.p, y.neg = h->sym_neg.p, y.fcnt = h->sym_fcnt.p, y.flist = h->sym_flist.p, y.own = h->sym_own.p;
     }
     a.off = h->off.p, a.post = h->post.p, a.ngroups = h->ngroups, a.logG = h->logG, a.part_stride = (int32_t)ng;
@@ -328,6 +342,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             r.q_first = q_first, r.exclude = excl_dev, r.exclude_self = exclude_self, r.mask_sid = a.mask_sid;
             r.k = k, r.next = h->next.p + 8;
             r.part_keys = h->part_keys.p, r.part_cnt = h->part_cnt.p, r.stat = h->stat.p;
+            r.fm = sym && a.sym.front ? a.sym.fm : nullptr, r.Ns = a.sym.Ns, r.first = a.sym.first, r.new_of = h->new_of.p;
             // at most four of its waves per CU: the kernel is bound by its longest row, not by throughput, and at 170 VGPRs a full
             // grid of it would take the register files from the list walk it runs next to
             const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)nh * h->n_ranges, std::min<int64_t>(slots, g_sparse_rows_wgs)));
@@ -379,7 +394,11 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     bool redo_overwrote = false;
     if (sym) {  // own keys + foreign lists -> the whole-query rows
         sparse::SymMergeArgs m;
-        m.sym = a.sym, m.N = h->N, m.new_of = h->new_of.p, m.k = k;
+        m.sym = a.sym, m.N = h->N, m.new_of = h->new_of.p, m.orig_of = h->orig_of.p, m.k = k;
+        if (a.sym.front) {
+            sparse::sparse_front_transpose_kernel<<<dim3((unsigned)ceil_div(a.sym.Ns, (int64_t)64), (unsigned)(a.sym.fw / 64)), dim3(256), 0, h->stream>>>(a.sym);
+            GORSE_HIP_CHECK(hipGetLastError());
+        }
         m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
         m.redo = h->sym_redo.p, m.stat = h->stat.p;
         const unsigned mg = (unsigned)std::min<int64_t>(h->N, 256 * 32);

@@ -117,6 +117,16 @@ struct SymArgs {
     uint32_t *neg, *fcnt;      // N each
     unsigned long long *flist; // see sym_list_at
     unsigned long long *own;   // N x KP, by query
+    // The FRONT (the long / heavy rows in a row group of their own, scratch ids [0, front); first = the group's size): the rows behind
+    // it leave group 0 out of their walk, and the front's own kernels -- which score every row anyway -- leave score(front row, r) in
+    // fm[slot][sid(r) - first], slot = the front row's scratch id.  No bound filters these: the front IS most rows' best candidates.
+    // A row's item starts with a bound from the column as far as it is written (the front's items come first in the work list);
+    // sparse_front_transpose_kernel turns the matrix and the merge ranks own + foreign + front.  0 = no front.
+    int32_t front;
+    int32_t fw;                // slots per row of fmt: front rounded up to 64
+    int64_t Ns;                // rows behind the front: Np - first
+    float *fm;                 // front x Ns
+    float *fmt;                // Ns x fw
 };
 // A stale value only costs work (a weaker bound lets more through, a lower count adds once more): both words only ever grow.
 #ifndef GORSE_SPARSE_SYM_PLAIN_LOAD
@@ -283,14 +293,22 @@ __device__ inline void push(unsigned long long *s_buf, int k, int &bcnt, unsigne
     }
 }
 
-// sorts what the buffer holds (padding with 0) -- positive scores first, then the negative ones; all lanes together
+// sorts what the buffer holds (padding with 0) -- positive scores first, then the negative ones; all lanes together.
+// Round 6: only the smallest power of two that holds the keys is sorted (the rest is padding) -- every work item ends here, and most
+// hold far fewer keys than the buffer takes (a 256-entry sort is 36 passes of 4 steps, a 64-entry one 21 of 1).
 template <int KP>
 __device__ inline void finish(unsigned long long *s_buf, int bcnt, int lane) {
     constexpr int CAP = 2 * KP;
     __syncthreads();
     for (int i = bcnt + lane; i < CAP; i += kBlock) s_buf[i] = 0;
     __syncthreads();
-    if (bcnt > 0) sort_desc<CAP>(s_buf, lane);
+    if (bcnt <= 0) return;
+    if (bcnt <= kBlock)
+        sort_desc<kBlock>(s_buf, lane);
+    else if (bcnt <= CAP / 2)
+        sort_desc<(CAP / 2 > kBlock ? CAP / 2 : kBlock)>(s_buf, lane);
+    else
+        sort_desc<CAP>(s_buf, lane);
 }
 
 // result row t from the sorted buffer: cnt entries, the rest padded
@@ -579,8 +597,39 @@ constexpr int kQueueStride = 64;   // words between two stripes' counters: 256 b
 constexpr int kQueueBase = 64;     // words 0 .. 15 of the buffer: the heavy-query kernel's eight queues (RowsArgs::next = next + 8)
 constexpr int kQueueWords = kQueueBase + kQueueStripes * kQueueStride;
 
-template <int KP, bool ATOMIC, bool TRACE, bool SYM = false>
+// the k-th largest of the wave's 64 R values (0 = fewer than k of them are non-zero): bit by bit, one ballot per value and bit
+template <int R>
+__device__ inline uint32_t kth_largest_ord(const uint32_t (&o)[R], int k) {
+    uint32_t kth = 0;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t trial = kth | (1u << b);
+        int cge = 0;
+#pragma unroll
+        for (int j = 0; j < R; j++) cge += __popcll(__ballot(o[j] >= trial));
+        if (cge >= k) kth = trial;
+    }
+    return kth;
+}
+
+// the k-th largest ord among the first 256 scores of a column of the front's matrix (SymArgs::fm), 0 = fewer than k are there.
+// Not inlined: the list walk's registers are a budget (three of its waves + one of sparse_rows_kernel per SIMD).
+__device__ __attribute__((noinline)) uint32_t front_bound(const float *col, int64_t Ns, int front, int k, int lane) {
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = j * kBlock + lane;
+        const float x = slot < front ? __hip_atomic_load(&col[(size_t)slot * Ns], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        o[j] = (__float_as_uint(x) << 1) != 0 ? score_ord(x) : 0u;
+    }
+    return kth_largest_ord<4>(o, k);
+}
+
+// SYMMODE: 0 = the unsymmetric walk, 1 = the symmetric form (SymArgs), 2 = the symmetric form with a delivering front.  Two
+// instantiations rather than one with a switch: the bound of an item comes from its foreign list (sym_tighten) in one and from the
+// front's column (front_bound) in the other, and either alone keeps the kernel at 112 registers.
+template <int KP, bool ATOMIC, bool TRACE, int SYMMODE = 0>
 __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
+    constexpr bool SYM = SYMMODE != 0, FRONT = SYMMODE == 2;
     constexpr int CAP = 2 * KP;
     extern __shared__ __align__(16) unsigned char s_mem[];
     const int NL = 1 << a.logG;  // accumulators in LDS
@@ -630,10 +679,26 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         const int dir_stride = a.ngroups;
         // SYM: a whole-query item takes the rows in front of its own (and the timing probe stops there too)
         const bool symw = SYM && whole;
-        const int32_t sid_q = symw || (whole && a.tri_probe && qr < a.N) ? a.new_of[qr] : 0;
+        const int32_t sid_q = SYM || (whole && a.tri_probe && qr < a.N) ? a.new_of[qr] : 0;
         const int glim = symw || (whole && a.tri_probe && qr < a.N) ? (sid_q >> a.logG) + 1 : a.ngroups;
+        const int gfirst = FRONT && symw ? 1 : 0;  // SYM with a front: group 0 is the front's, which delivers (SymArgs)
         uint32_t pub = 0;  // SYM: the bound this item has published for its row
-        const int nviews = whole ? (a.head_groups < glim ? a.head_groups : glim) : 1;  // a whole-query item: the head groups here, the others in super-visits below
+        // (a part of a front row: where its scores go, indexed by the other row's scratch id)
+        float *fm_row = FRONT && !whole ? a.sym.fm + ((size_t)sid_q * a.sym.Ns - a.sym.first) : nullptr;
+        if constexpr (FRONT) {
+            // the front's column of this row, as far as it is written (a score is stored once, whole; what is missing reads as the
+            // cleared 0): the k-th largest ord among the scores of the 64 R longest rows opens the item's threshold and is published
+            if (symw) {
+                const uint32_t kth = front_bound(a.sym.fm + (sid_q - a.sym.first), a.sym.Ns, a.sym.front, a.k, lane);
+                if (kth > 0) {
+                    pub = kth;
+                    thr = ((unsigned long long)kth << 32) - 1;
+                    if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]), pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the item's first loads stay behind this: the block's registers are free again)
+        const int nviews = whole ? (a.head_groups < glim ? a.head_groups : glim) - gfirst : 1;  // a whole-query item: the head groups here, the others in super-visits below
         const int nacc = NL;
         const int lm = NL - 1;
         const int tcap = nacc >> 2;
@@ -645,7 +710,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         // branch in the loop that would make the compiler wait for everything in flight.)
         // stage 1 and stage 2 are each called for v = 0, 1, 2, ... in turn: they keep their own (view, chunk) counters
         int c1 = 0, c2 = 0;
-        int g2 = whole ? 0 : wk.part;  // group of the visit stage 2 is at
+        int g2 = whole ? gfirst : wk.part;  // group of the visit stage 2 is at
         // Every stage issues the SAME loads on every path (clamped addresses, results masked afterwards; the host pads each
         // array by one element): a load that a branch may skip makes the compiler's wait for any OLDER load "wait for all".
         auto stage1 = [&](int64_t v, Visit &x) {
@@ -689,6 +754,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             have = have && (__float_as_uint(x) << 1) != 0;  // a zero score is dropped by the reference's wrapper
             if (!__ballot(have)) return;
             my_hit += have;
+            if constexpr (FRONT) {  // a part of a front row: the score is the other row's candidate too
+                if (fm_row && have && sid >= a.sym.first) fm_row[sid] = x;
+            }
             if (symw)
                 have = have && sid < sid_q;
             else
@@ -809,21 +877,14 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 o[j] = (uint32_t)(key >> 32);
             }
             seen += n;
-            uint32_t kth = 0;
-            for (int b = 31; b >= 0; --b) {
-                const uint32_t trial = kth | (1u << b);
-                int cge = 0;
-#pragma unroll
-                for (int j = 0; j < R; j++) cge += __popcll(__ballot(o[j] >= trial));
-                if (cge >= a.k) kth = trial;
-            }
+            const uint32_t kth = kth_largest_ord<R>(o, a.k);
             if (kth > pub) {
                 pub = kth;
                 if (lane == 0) __hip_atomic_store(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]), pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
         int c = 0;  // chunk of visit v inside its view
-        int g = whole ? 0 : wk.part;
+        int g = whole ? gfirst : wk.part;
         for (int64_t v = 0; v < V; v++) {
             // consumers first: each stage needs what the stage before it loaded during the PREVIOUS visit, so whatever the compiler
             // waits for here has had a whole visit to arrive
@@ -852,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
                 c = 0;
                 g++;
             }
-            if constexpr (SYM) {
+            if constexpr (SYM && !FRONT) {
                 if (symw) sym_tighten();
             }
             v0 = v1, v1 = v2, v2 = v3, v3 = v4, v4 = v5;
@@ -1064,6 +1125,11 @@ struct RowsArgs {
     unsigned long long *part_keys;
     int32_t *part_cnt;
     unsigned long long *stat;
+    // the symmetric pass's front (SymArgs): non-zero scores of the rows from `first` on go to fm[slot of the query][sid - first]; null = off
+    float *fm;
+    int64_t Ns;
+    int32_t first;
+    const int32_t *new_of;
 };
 
 __global__ void sparse_dense_query_kernel(const int64_t *q_ptr, const int32_t *q_cid, const float *q_val, int64_t q_first,
@@ -1185,6 +1251,7 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
             }
             // rank (the same rules as the read-back of sparse_tile_kernel)
             bool have = in && (__float_as_uint(acc) << 1) != 0;
+            if (a.fm && have && sid >= a.first) a.fm[(size_t)a.new_of[a.q_first + t] * a.Ns + (sid - a.first)] = acc;
             if (__ballot(have)) {
                 my_hit += have;
                 have = have && (int64_t)row != ex && (!a.mask_sid || a.mask_sid[have ? sid : s0]);
@@ -1269,7 +1336,7 @@ __global__ __launch_bounds__(kBlock) void sparse_merge_kernel(MergeArgs a) {
 struct SymMergeArgs {
     SymArgs sym;
     int64_t N;
-    const int32_t *new_of;
+    const int32_t *new_of, *orig_of;
     int k;
     int32_t *out_idx;
     float *out_score;
@@ -1277,6 +1344,18 @@ struct SymMergeArgs {
     int32_t *redo;                // [0] = rows on the list, [1 ..] = the rows (queries) whose foreign list overflowed
     unsigned long long *stat;     // [2] += foreign entries ranked, [3] = max over the rows (atomicMax)
 };
+
+// fm (front x Ns) -> fmt (Ns x fw): 64 x 64 tiles through LDS, slots past the front read as 0
+__global__ __launch_bounds__(256) void sparse_front_transpose_kernel(SymArgs y) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int s0 = (int)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) tile[j][tx] = s0 + j < y.front && r0 + tx < y.Ns ? y.fm[(size_t)(s0 + j) * y.Ns + r0 + tx] : 0.0f;
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4)
+        if (r0 + j < y.Ns) y.fmt[(size_t)(r0 + j) * y.fw + s0 + tx] = tile[tx][j];
+}
 
 template <int KP>
 __global__ __launch_bounds__(kBlock) void sparse_sym_merge_kernel(SymMergeArgs a) {
@@ -1298,9 +1377,11 @@ __global__ __launch_bounds__(kBlock) void sparse_sym_merge_kernel(SymMergeArgs a
             continue;
         }
         const unsigned long long tp = a.sym.tp[sid];
-        const int cnt = written((long long)(tp >> 32), (long long)a.sym.neg[sid], a.N - 1, a.k);
+        long long pos = (long long)(tp >> 32), neg = (long long)a.sym.neg[sid];
+        const float *frow = a.sym.front ? a.sym.fmt + (size_t)(sid - a.sym.first) * a.sym.fw : nullptr;
         const unsigned long long *own = a.sym.own + (size_t)t * KP;
-        if (fc == 0) {  // nothing delivered that counts: the own keys are the row, already in order
+        if (fc == 0 && !frow) {  // nothing delivered that counts: the own keys are the row, already in order
+            const int cnt = written(pos, neg, a.N - 1, a.k);
             for (int i = lane; i < a.k; i += kBlock) {
                 const unsigned long long key = i < cnt ? own[i] : 0;
                 a.out_idx[t * a.k + i] = i < cnt ? key_row(key) : -1;
@@ -1319,8 +1400,29 @@ __global__ __launch_bounds__(kBlock) void sparse_sym_merge_kernel(SymMergeArgs a
             const unsigned long long key = i + lane < fc ? a.sym.flist[at + i + lane] : 0;
             push<KP>(s_buf, a.k, bcnt, thr, key, key > thr, lane);
         }
+        if (frow) {  // the front's scores: all of them count, and what the row's published bound lets through is ranked (the bound
+                     // holds for every candidate of the row)
+            const uint32_t bound = (uint32_t)tp;
+            int fp = 0, fn = 0;
+            for (int i = 0; i < a.sym.fw; i += kBlock) {
+                const float x = frow[i + lane];
+                fp += x > 0.0f, fn += x < 0.0f;
+                const uint32_t ord = score_ord(x);
+                const bool cand = (__float_as_uint(x) << 1) != 0 && ord >= bound && ord >= (uint32_t)(thr >> 32);
+                if (!__ballot(cand)) continue;
+                const unsigned long long key = cand ? make_key(ord, a.orig_of[i + lane]) : 0;
+                push<KP>(s_buf, a.k, bcnt, thr, key, cand && key > thr, lane);
+            }
+            pos += wave_sum((long long)fp), neg += wave_sum((long long)fn);
+        }
+        if (bcnt > KP) {  // (at least k keys: cut to them before the sort -- half the buffer sorts in a third of the time)
+            __syncthreads();
+            for (int i = bcnt + lane; i < CAP; i += kBlock) s_buf[i] = 0;
+            __syncthreads();
+            cut_to_k<KP>(s_buf, a.k, bcnt, thr, lane);
+        }
         finish<KP>(s_buf, bcnt, lane);
-        write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
+        write_result(s_buf, written(pos, neg, a.N - 1, a.k), a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         __syncthreads();
     }
 }

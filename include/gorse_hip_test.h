@@ -97,7 +97,7 @@ void gorse_hip_test_set_sparse_table(int32_t cap_shift);
  * the postings a symmetric walk of the whole-query items would still meet (sparse).  0 = off (default). */
 void gorse_hip_test_set_sparse_probe(int32_t probe);
 /* The symmetric form of gorse_sparse_all_pairs over all rows (csrc/sparse_kernels.hpp, SymArgs): mode 0 = never (the walk every other
- * call takes), -1 / 1 = when the call is eligible (default).  c1 / c2 / c3 > 0 replace the capacities of the three tiers of foreign lists
+ * call takes), -1 / 1 = when the call is eligible (default), 2 = likewise, but the front (gorse_hip_test_set_sparse_front) does not deliver.  c1 / c2 / c3 > 0 replace the capacities of the three tiers of foreign lists
  * (tests overflow them on purpose: the rows then take the unsymmetric walk in a second launch); 0 = the defaults.  Results never differ. */
 void gorse_hip_test_set_sparse_sym(int32_t mode, int32_t c1, int32_t c2, int32_t c3);
 /* handles created AFTERWARDS: 1 (default) = the rows longer than the split threshold in force at creation get a row group of their own

@@ -16,7 +16,16 @@ L = capi.lib()
 N, k = ptr.size - 1, 100
 caps = [int(x) for x in sys.argv[1:4]] if len(sys.argv) >= 4 else [0, 0, 0]
 res = {}
-for mode, label in ((0, "unsymmetric"), (1, "symmetric"), (0, "unsymmetric again"), (1, "symmetric again")):
+if len(sys.argv) == 2:  # `<mode> [+ 256 x (workgroups of the heavy-query kernel / 256)]`: that form alone, for a timeline
+    L.gorse_hip_test_set_sparse_sym(int(sys.argv[1]) & 0xff, 0, 0, 0)
+    L.gorse_hip_test_set_sparse_probe(int(sys.argv[1]) & ~0xff)
+    for _ in range(4):
+        sp.all_pairs(k, 0, N, fetch=False)
+    sp.synchronize()
+    print(sp.sym_stats(), sp.last_stats())
+    sys.exit(0)
+for mode, label in ((0, "unsymmetric"), (1, "symmetric"), (2, "symmetric, no front"), (0, "unsymmetric again"), (1, "symmetric again"),
+                    (2, "symmetric, no front again")):
     L.gorse_hip_test_set_sparse_sym(mode, *caps)
     out = sp.all_pairs(k, 0, N)
     res[mode] = out
@@ -30,7 +39,7 @@ for mode, label in ((0, "unsymmetric"), (1, "symmetric"), (0, "unsymmetric again
           % (label, dt * 1e3, postings, sp.sym_stats()), flush=True)
 L.gorse_hip_test_set_sparse_sym(-1, 0, 0, 0)
 same = [bool(np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b))
-        for a, b in zip(res[0], res[1])]
+        for other in (1, 2) for a, b in zip(res[0], res[other])]
 print("rows, score bits, counts equal over all %d rows: %s" % (N, same), flush=True)
 if not all(same):
     bad = np.nonzero((res[0][0] != res[1][0]).any(axis=1) | (res[0][2] != res[1][2]))[0]

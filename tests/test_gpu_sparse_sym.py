@@ -172,7 +172,14 @@ def test_front_group_of_the_long_rows(oracle, hooks, split, k):
     assert st[0] == 1 and st2[0] == 1
     _same(ref, sym)
     _same(ref, unsym2)
-    _same(ref, sym2)
+    _same(ref, sym2)  # (fewer long rows than a group holds: the front delivered)
+    hooks.gorse_hip_test_set_sparse_sym(2, 0, 0, 0)  # the front does not deliver
+    _same(ref, s.all_pairs(k))
+    assert s.sym_stats()[0] == 1
+    hooks.gorse_hip_test_set_sparse_sym(1, 1, 1, 1)  # every foreign list overflows
+    _same(ref, s.all_pairs(k))
+    assert s.sym_stats()[1] > 0
+    hooks.gorse_hip_test_set_sparse_sym(-1, 0, 0, 0)
     sample = list(range(0, 3000, 41))
     check(oracle, ptr, idx, val, k, [x[sample] for x in sym2], rows_of(ptr, idx, val, sample), sample)
     _same(plain_index.all_pairs(k, 100, 900, exclude_self=False), s.all_pairs(k, 100, 900, exclude_self=False))
