@@ -458,8 +458,9 @@ def bench_sparse(args, world, rank, local, fence, data=None, steps=None, warmup=
     q0, q1 = gdist.shard_range(N, rank, world)
     eng = gdist.HipNeighborsEngine(sp, fetch=False)
     comm = gdist.TorchComm() if world > 1 else None
-    sp.all_pairs(k, q0, min(q1, q0 + 4096), fetch=False)  # warm-up: scratch allocation, code objects
-    for _ in range(max(warmup - 1, 0)):
+    # warm-up steps are whole steps (the pass the timed region repeats): scratch allocation, code objects, and the work plan the
+    # handle keeps for its all-pairs pass (csrc/sparse.hip, gorse_sparse::Plan)
+    for _ in range(max(warmup, 1)):
         gdist.refresh_neighbors_sharded(eng, comm, k, gather=False)
     fence()
     sp.set_profiling(True)

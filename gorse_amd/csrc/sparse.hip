@@ -225,18 +225,11 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         GORSE_HIP_CHECK(hipMemsetAsync(h->sym_neg.p, 0, (size_t)N * 4, h->stream));
         GORSE_HIP_CHECK(hipMemsetAsync(h->sym_fcnt.p, 0, (size_t)N * 4, h->stream));
         GORSE_HIP_CHECK(hipMemsetAsync(h->sym_redo.p, 0, 4, h->stream));
-        {   // the heads of the first lists, which their rows' items read while they fill (sym_tighten): one strided clear.  The first
-            // four row groups: behind them a row's own walk reaches its first read-back in well under a millisecond.
-            y.tl = std::min<int32_t>(y.t1, 8192);
-            const size_t look = (size_t)std::min<int32_t>(y.c1, sparse::kSymLook);
-            if (look == (size_t)y.c1)
-                GORSE_HIP_CHECK(hipMemsetAsync(h->sym_flist.p, 0, (size_t)y.tl * y.c1 * 8, h->stream));
-            else
-                GORSE_HIP_CHECK(hipMemset2DAsync(h->sym_flist.p, (size_t)y.c1 * 8, 0, look * 8, (size_t)y.tl, h->stream));
-        }
         // The front delivers when the long / heavy rows of this call are exactly the rows that got group 0 to themselves at creation.
         y.front = 0;
-        if (g_sparse_sym != 2 && h->order.pad > 0 && (int64_t)longs.size() == h->order.n_front) {
+        constexpr size_t kFrontBytes = (size_t)16 << 30;  // the score matrix and its transpose: beyond this the front keeps its scores
+        if (g_sparse_sym != 2 && h->order.pad > 0 && (int64_t)longs.size() == h->order.n_front &&
+            (size_t)h->order.n_front * (size_t)(N - y.first) * 8 <= kFrontBytes) {
             y.front = h->order.n_front;
             y.fw = (y.front + 63) / 64 * 64;
             y.Ns = N - y.first;
@@ -244,6 +237,17 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             GORSE_TRY(h->sym_fmt.ensure((size_t)y.Ns * (size_t)y.fw));
             GORSE_HIP_CHECK(hipMemsetAsync(h->sym_fm.p, 0, (size_t)y.front * (size_t)y.Ns * 4, h->stream));
             y.fm = h->sym_fm.p, y.fmt = h->sym_fmt.p;
+        }
+        y.tl = 0;
+        if (!y.front) {   // the heads of the first lists, which their rows' items read while they fill (sym_tighten): one strided clear.  The first
+            // four row groups: behind them a row's own walk reaches its first read-back in well under a millisecond.  (With a front
+            // that delivers, an item's bound comes from the front's column instead: nothing to clear.)
+            y.tl = std::min<int32_t>(y.t1, 8192);
+            const size_t look = (size_t)std::min<int32_t>(y.c1, sparse::kSymLook);
+            if (look == (size_t)y.c1)
+                GORSE_HIP_CHECK(hipMemsetAsync(h->sym_flist.p, 0, (size_t)y.tl * y.c1 * 8, h->stream));
+            else
+                GORSE_HIP_CHECK(hipMemset2DAsync(h->sym_flist.p, (size_t)y.c1 * 8, 0, look * 8, (size_t)y.tl, h->stream));
         }
         y.tp = h->sym_tp.p, y.neg = h->sym_neg.p, y.fcnt = h->sym_fcnt.p, y.flist = h->sym_flist.p, y.own = h->sym_own.p;
     }

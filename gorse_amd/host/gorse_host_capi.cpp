@@ -7,6 +7,7 @@
 #include "gorse_cf.hpp"
 #include "gorse_vectors.hpp"
 #include "../csrc/rank_keys.hpp"
+#include "../csrc/sparse_host.hpp"
 #include "../csrc/als_plan.hpp"
 #include "../csrc/bpr_bins.hpp"
 #include "../csrc/topk_sym.hpp"
@@ -933,6 +934,16 @@ int64_t gh_test_als_long_row(int64_t side_entries, int32_t d) { return gorse::al
 // the 64-bit sparse ranking key itself, and the number of results the reference returns (xvec.go:379-446)
 uint64_t gh_test_sparse_key(float score, int32_t row) { return gorse::rank::make_key(gorse::rank::score_ord(score), row); }
 int32_t gh_test_sparse_written(int64_t pos, int64_t neg, int64_t adm, int32_t k) { return gorse::rank::written(pos, neg, adm, k); }
+// the scratch numbering of a sparse index's rows (csrc/sparse_host.hpp, the header gorse_sparse_create includes): longest first, the
+// rows longer than front_cut in a row group of their own with phantom ids behind them.  new_of: n, orig_of: n + group entries at most;
+// out3 = {scratch ids, front rows, phantom ids}
+void gh_test_sparse_row_order(int64_t n, const int64_t *indptr, int64_t front_cut, int64_t group, int32_t *new_of, int32_t *orig_of,
+                              int64_t *out3) {
+    const gorse::sparse::RowOrder o = gorse::sparse::order_rows(n, indptr, front_cut, group);
+    for (int64_t r = 0; r < n; r++) new_of[r] = o.new_of[(size_t)r];
+    for (int64_t s = 0; s < o.Np; s++) orig_of[s] = o.orig_of[(size_t)s];
+    out3[0] = o.Np, out3[1] = o.n_front, out3[2] = o.pad;
+}
 // the HNSW levels MarshalReference gives the n vectors of a model (gorse_vectors.hpp ReferenceLevels: the arithmetic both twins share)
 // and the levelFactor it writes, as its bits
 uint32_t gh_test_hnsw_levels(int64_t n, int32_t *level) {
