@@ -199,7 +199,9 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     TileArgs a;
     // The symmetric form: every stored row is a query and leaves out only itself; the long / heavy rows are the first scratch ids
     // (rows are numbered longest first and a query's length is its row's).
-    bool sym = g_sparse_sym != 0 && qp == h->r_ptr.p && q_first == 0 && nq == h->N && exclude_self && !excl_dev && !h->has_mask &&
+    // (a collection of one row group has nothing to leave out: S-ml100k's 1682 items 0.82 ms unsymmetric, 0.92 symmetric,
+    // profiles/r06_zg_probe_gpu_probe_sparse_shapes.txt -- the symmetric form is the default from two groups on)
+    bool sym = g_sparse_sym != 0 && (g_sparse_sym > 0 || h->ngroups >= 2) && qp == h->r_ptr.p && q_first == 0 && nq == h->N && exclude_self && !excl_dev && !h->has_mask &&
                !h->trace_on && !shorts.empty() && longs.size() < (size_t)h->N;
     for (size_t l = 0; sym && l < longs.size(); l++) sym = h->order.rank_of(h->order.new_of[(size_t)longs[l]]) < (int64_t)longs.size();
     a.sym = sparse::SymArgs{};
@@ -275,6 +277,23 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             case 256: GORSE_TRY(launch_tiles<256>(a, grid, lds, atomic, symmetric, h->stream)); break;
             case 512: GORSE_TRY(launch_tiles<512>(a, grid, lds, atomic, symmetric, h->stream)); break;
             default: GORSE_TRY(launch_tiles<1024>(a, grid, lds, atomic, symmetric, h->stream)); break;
+        }
+        GORSE_HIP_CHECK(hipGetLastError());
+        return GORSE_OK;
+    };
+    auto launch_merge = [&](size_t n_long) -> int32_t {  // split_t / split_n / part_* of n_long queries -> their result rows
+        sparse::MergeArgs m;
+        m.split_t = h->split_t.p, m.split_n = h->split_n.p, m.n_split = (int32_t)n_long, m.part_stride = (int32_t)ng;
+        m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
+        m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
+        m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
+        m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
+        const unsigned mg = (unsigned)std::min<size_t>(n_long, 4096);
+        switch (kp) {
+            case 128: sparse::sparse_merge_kernel<128><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
+            default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
         }
         GORSE_HIP_CHECK(hipGetLastError());
         return GORSE_OK;
@@ -370,22 +389,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
 #endif
         if (!work.empty()) GORSE_TRY(launch_work(work.size(), sym));
         if (!heavy_t.empty()) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-        if (n_long > 0) {
-            sparse::MergeArgs m;
-            m.split_t = h->split_t.p, m.split_n = h->split_n.p, m.n_split = (int32_t)n_long, m.part_stride = (int32_t)ng;
-            m.part_keys = h->part_keys.p, m.part_cnt = h->part_cnt.p;
-            m.q_first = q_first, m.N = h->N, m.exclude = excl_dev, m.exclude_self = exclude_self;
-            m.mask_sid = a.mask_sid, m.new_of = h->new_of.p, m.n_admissible = a.n_admissible, m.k = k;
-            m.out_idx = a.out_idx, m.out_score = a.out_score, m.out_cnt = a.out_cnt;
-            const unsigned mg = (unsigned)std::min<size_t>(n_long, 4096);
-            switch (kp) {
-                case 128: sparse::sparse_merge_kernel<128><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
-                case 256: sparse::sparse_merge_kernel<256><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
-                case 512: sparse::sparse_merge_kernel<512><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
-                default: sparse::sparse_merge_kernel<1024><<<dim3(mg), dim3(sparse::kBlock), 0, h->stream>>>(m); break;
-            }
-            GORSE_HIP_CHECK(hipGetLastError());
-        }
+        if (n_long > 0) GORSE_TRY(launch_merge(n_long));
         // the host lists (work, heavy_*, nparts, split_t) and the trace buffer are reused by the next iteration
         if ((n_long > 0 && !one_launch) || h->trace_on) GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->trace_on && a.trace) {  // (a.trace stays null outside `make probe-lib` builds: nothing was recorded)
@@ -415,21 +419,42 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         GORSE_HIP_CHECK(hipGetLastError());
         GORSE_HIP_CHECK(hipMemcpyAsync(&n_redo, h->sym_redo.p, 4, hipMemcpyDeviceToHost, h->stream));
         GORSE_HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (n_redo > 0) {  // rows whose foreign list overflowed: the unsymmetric walk, as whole-query items
+        if (n_redo > 0) {
+            // Rows whose foreign list overflowed take the unsymmetric walk -- as LONG queries do: one work item per row group and a
+            // merge.  (As whole-query items, 100 rows of the C3 shard's users were 100 waves for 26 ms behind a 430 ms pass,
+            // profiles/r06_zh_timeline_sparse_users.txt; the first k rows behind the front never see k candidates of their own, so
+            // nothing bounds what is delivered to them.)  More rows than the partial rankings hold: whole-query items.
             std::vector<int32_t> rows((size_t)n_redo);
             GORSE_HIP_CHECK(hipMemcpy(rows.data(), h->sym_redo.p + 1, (size_t)n_redo * 4, hipMemcpyDeviceToHost));
             std::sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) {
                 const int64_t lx = q_len_host[x + 1] - q_len_host[x], ly = q_len_host[y + 1] - q_len_host[y];
                 return lx != ly ? lx > ly : x < y;
             });
+            const bool as_parts = (size_t)n_redo <= per_launch && g_sparse_split > 0;
             std::vector<sparse::Work> again;
-            for (int32_t t : rows) again.push_back(sparse::Work{t, -1, 0, 0});
+            if (as_parts) {
+                for (size_t j = 0; j < rows.size(); j++)
+                    for (int32_t g = 0; g < h->ngroups; g++) again.push_back(sparse::Work{rows[j], g, (int32_t)j, 0});
+                auto cost = [&](const sparse::Work &w) { return (double)(q_len_host[w.t + 1] - q_len_host[w.t]) * h->group_share[(size_t)w.part]; };
+                std::stable_sort(again.begin(), again.end(), [&](const sparse::Work &x, const sparse::Work &y) { return cost(x) > cost(y); });
+                const std::vector<int32_t> n_parts(rows.size(), h->ngroups);
+                GORSE_TRY(h->split_t.ensure(rows.size()));
+                GORSE_TRY(h->split_n.ensure(rows.size()));
+                GORSE_TRY(h->part_keys.ensure(rows.size() * (size_t)ng * (size_t)kp));
+                GORSE_TRY(h->part_cnt.ensure(rows.size() * (size_t)ng * 2));
+                GORSE_HIP_CHECK(hipMemcpy(h->split_t.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+                GORSE_HIP_CHECK(hipMemcpy(h->split_n.p, n_parts.data(), rows.size() * 4, hipMemcpyHostToDevice));
+                a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
+            } else
+                for (int32_t t : rows) again.push_back(sparse::Work{t, -1, 0, 0});
             redo_overwrote = true;  // (the device's work list is no longer the plan's)
+            GORSE_TRY(h->work.ensure(again.size()));
             GORSE_HIP_CHECK(hipMemcpy(h->work.p, again.data(), again.size() * sizeof(sparse::Work), hipMemcpyHostToDevice));
             GORSE_HIP_CHECK(hipMemsetAsync(h->next.p, 0, sparse::kQueueWords * sizeof(int32_t), h->stream));
             a.work = h->work.p, a.n_work = (int32_t)again.size();
             a.trace = nullptr;
             GORSE_TRY(launch_work(again.size(), false));
+            if (as_parts) GORSE_TRY(launch_merge(rows.size()));
         }
     }
     h->prof.end(tok, h->stream);

@@ -114,6 +114,11 @@ def test_calls_that_are_not_all_pairs_keep_the_unsymmetric_walk(hooks):
     ptr, idx, val = random_csr(rng, 800, 100, 0, 10)
     s = capi.Sparse(ptr, idx, val)
     s.all_pairs(5)
+    assert s.sym_stats()[0] == 0  # one row group: nothing to leave out, the default keeps the unsymmetric walk
+    hooks.gorse_hip_test_set_sparse_tile(256)
+    s.close()
+    s = capi.Sparse(ptr, idx, val)
+    s.all_pairs(5)
     assert s.sym_stats()[0] == 1
     s.all_pairs(5, 0, 799)
     assert s.sym_stats()[0] == 0

@@ -16,16 +16,17 @@ def test_all_pairs_equals_oracle(oracle):
     rng = np.random.default_rng(100)
     ptr, idx, val = random_csr(rng, 600, 400, 0, 30)
     s = capi.Sparse(ptr, idx, val)
-    for k in (7, 64, 100):
-        got = s.all_pairs(k)
-        check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(600)), list(range(600)))
-    # statistics of the last call: postings walked = posting-list lengths summed over the queries' indices in the unsymmetric walk
-    # (the symmetric form of an all-pairs pass, tests/test_gpu_sparse_sym.py, walks fewer)
-    lens = np.bincount(idx, minlength=400)
-    postings, hits = s.last_stats()
-    assert s.sym_stats()[0] == 1 and postings <= int(lens[idx].sum())  # (one row group here: the same)
-    capi.lib().gorse_hip_test_set_sparse_sym(0, 0, 0, 0)
+    capi.lib().gorse_hip_test_set_sparse_sym(1, 0, 0, 0)  # (one row group: the default would keep the unsymmetric walk)
     try:
+        for k in (7, 64, 100):
+            got = s.all_pairs(k)
+            check(oracle, ptr, idx, val, k, got, rows_of(ptr, idx, val, range(600)), list(range(600)))
+        # statistics of the last call: postings walked = posting-list lengths summed over the queries' indices in the unsymmetric
+        # walk (the symmetric form of an all-pairs pass, tests/test_gpu_sparse_sym.py, walks fewer where there is a group to leave out)
+        lens = np.bincount(idx, minlength=400)
+        postings, hits = s.last_stats()
+        assert s.sym_stats()[0] == 1 and postings <= int(lens[idx].sum())
+        capi.lib().gorse_hip_test_set_sparse_sym(0, 0, 0, 0)
         _same(got, s.all_pairs(100))
         postings, hits = s.last_stats()
         assert postings == int(lens[idx].sum())
