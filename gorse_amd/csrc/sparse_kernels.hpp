@@ -29,6 +29,9 @@
 // * A group is read back either by a scan of its accumulators (dense) or from the list of accumulators that were +0
 //   before an add (sparse); both leave the accumulators zero.
 //
+// Round 6: an all-pairs pass over all rows takes the SYMMETRIC form -- a pair of rows is walked once and the score delivered to the
+// other row's ranking; the long rows form a front that delivers to everybody (SymArgs below).
+//
 // Ranking: 64-bit keys (order-preserving score bits, ~row) are distinct, so "the k largest keys, descending" is one
 // well-defined answer whatever order the lanes append in.  Keys above the running threshold go to an LDS buffer of 2*KP
 // entries; when it overflows, the k-th largest key is found by bisection on the key bits (the keys sit in registers, one

@@ -93,8 +93,10 @@ void gorse_hip_test_set_sparse_head(int32_t groups);
 /* probe: a hashed super-visit of the sparse list walk takes at most (accumulators >> cap_shift) postings into its table of
  * (accumulators / 2) slots: 2 (default) = half full at most, 3 = a quarter, ...; outside 2..6 = the default. */
 void gorse_hip_test_set_sparse_table(int32_t cap_shift);
-/* timing probe (results are garbage): 1 = a whole-query item of the sparse list walk visits only the row groups up to its own row's --
- * the postings a symmetric walk of the whole-query items would still meet (sparse).  0 = off (default). */
+/* timing probe (results are garbage): low byte 1 = a whole-query item of the UNSYMMETRIC sparse list walk visits only the row groups up to
+ * its own row's -- the postings a symmetric walk of the whole-query items would still meet (sparse); 0 = off
+ * (default).  Bits 8..: most workgroups of the dense-vector kernel of the heavy queries, in units of 256 (0 = 1024, the default; results
+ * unaffected). */
 void gorse_hip_test_set_sparse_probe(int32_t probe);
 /* The symmetric form of gorse_sparse_all_pairs over all rows (csrc/sparse_kernels.hpp, SymArgs): mode 0 = never (the walk every other
  * call takes), -1 / 1 = when the call is eligible (default), 2 = likewise, but the front (gorse_hip_test_set_sparse_front) does not deliver.  c1 / c2 / c3 > 0 replace the capacities of the three tiers of foreign lists
