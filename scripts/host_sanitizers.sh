@@ -10,7 +10,7 @@ cp "$LIB" /tmp/libgorse_host_orig.so
     -o "$LIB" gorse_cf.cpp gorse_host_capi.cpp -L../lib -lgorse_hip -Wl,-rpath,"$ROOT/gorse_amd/lib" ) || { cp /tmp/libgorse_host_orig.so "$LIB"; exit 1; }
 cd "$ROOT"
 LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 \
-    timeout 1500 python -m pytest tests/test_host_mirror_cpu.py tests/test_vectors_db_cpu.py tests/test_metrics_cpu.py tests/test_items_blob_cpu.py \
+    timeout 1500 python -m pytest tests/test_host_mirror_cpu.py tests/test_vectors_db_cpu.py tests/test_metrics_cpu.py tests/test_items_blob_cpu.py tests/test_rank_keys_cpu.py tests/test_sparse_row_order_cpu.py \
     -q -s > /tmp/host_sanitizers.log 2>&1
 cp /tmp/libgorse_host_orig.so "$LIB"
 echo "sanitizer reports: $(grep -c 'runtime error\|AddressSanitizer' /tmp/host_sanitizers.log)"
