@@ -17,6 +17,7 @@ struct gorse_sparse {
     int device = 0;
     int64_t N = 0, nnz = 0, Dc = 0;
     int64_t Np = 0;  // scratch ids: N + the phantom ids behind the front (sparse_host.hpp, RowOrder)
+    int64_t front_cut = 0;  // the rows longer than this are the front (0 = no front); the split threshold of a symmetric pass
     int32_t logG = 0, ngroups = 0;  // groups of G = 1 << logG consecutive scratch ids
     hipStream_t stream = nullptr;
     // stored rows as CSR with directory entries instead of raw indices (the queries of all_pairs), the tiled posting lists
@@ -83,7 +84,8 @@ int g_sparse_sym = -1;            // an eligible all-pairs pass walks its whole-
                                   // 2 = yes, but the front (the long rows in a group of their own) does not deliver
 int g_sparse_sym_caps[3] = {0, 0, 0};  // foreign list capacities of the three tiers (0 = the defaults): tests overflow them on purpose
 int64_t g_sparse_rows_wgs = 1024;  // most workgroups of sparse_rows_kernel (probe: bits 8.. of gorse_hip_test_set_sparse_probe x 256)
-int g_sparse_front = 1;           // handles created afterwards give the rows longer than the split threshold a row group of their own (RowOrder)
+int g_sparse_front = 1;           // handles created afterwards give their longest rows a row group of their own (RowOrder): 0 = no, 1 = the rows
+                                  // longer than 1 .. 2 x the split threshold (gorse_sparse_create), > 1 = the rows longer than this
 int g_sparse_tri_probe = 0;      // timing probe: whole-query items stop at their own group (gorse_hip_test_set_sparse_probe)
 int g_sparse_cap_shift = 2;      // postings a super-visit's table takes: accumulators >> this (gorse_hip_test_set_sparse_table)
 int g_sparse_head = -1;          // groups a whole-query item visits one by one (the rest in hashed super-visits); -1 = head_groups_of()
@@ -150,13 +152,19 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     // are bounded (kPartBytes): a call with more long queries than fit takes several launches.
     const int64_t ng = std::max(h->ngroups, h->n_ranges);  // most partial rankings of one query
     gorse_sparse::Plan &plan = h->plan;
-    const bool plan_hit = qp == h->r_ptr.p && plan.valid && plan.q_first == q_first && plan.nq == nq && plan.split == g_sparse_split &&
+    // The split threshold of this call.  A symmetric pass's whole-query items stop at their own row group, so a long row as ONE item is
+    // no tail there; one work item per group is what costs (the C3 shard pass: 24.3 ms with the rows longer than 2048 split, 21.9 with
+    // those longer than 4096, profiles/r06_zo_probe_gpu_probe_sparse_knobs.txt): such a pass splits the front's rows only.
+    const bool sym_call = g_sparse_sym != 0 && (g_sparse_sym > 0 || h->ngroups >= 2) && qp == h->r_ptr.p && q_first == 0 && nq == h->N &&
+                          exclude_self && !excl_dev && !h->has_mask && !h->trace_on;
+    const int64_t split_used = sym_call && h->front_cut > 0 && h->order.pad > 0 ? h->front_cut : g_sparse_split;
+    const bool plan_hit = qp == h->r_ptr.p && plan.valid && plan.q_first == q_first && plan.nq == nq && plan.split == split_used &&
                           plan.heavy == g_sparse_heavy;
     if (!plan_hit) plan.valid = plan.on_device = false;
     std::vector<int32_t> &longs = plan.longs, &shorts = plan.shorts;
     if (!plan_hit) {   // counting sort by length, longest first (stable in t)
         longs.clear(), shorts.clear();
-        const int64_t cut = g_sparse_split > 0 ? g_sparse_split : INT64_MAX;
+        const int64_t cut = split_used > 0 ? split_used : INT64_MAX;
         std::vector<int32_t> count;
         int64_t longest_short = 0;
         for (int64_t t = 0; t < nq; t++) {
@@ -201,8 +209,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     // (rows are numbered longest first and a query's length is its row's).
     // (a collection of one row group has nothing to leave out: S-ml100k's 1682 items 0.82 ms unsymmetric, 0.92 symmetric,
     // profiles/r06_zg_probe_gpu_probe_sparse_shapes.txt -- the symmetric form is the default from two groups on)
-    bool sym = g_sparse_sym != 0 && (g_sparse_sym > 0 || h->ngroups >= 2) && qp == h->r_ptr.p && q_first == 0 && nq == h->N && exclude_self && !excl_dev && !h->has_mask &&
-               !h->trace_on && !shorts.empty() && longs.size() < (size_t)h->N;
+    bool sym = sym_call && !shorts.empty() && longs.size() < (size_t)h->N;
     for (size_t l = 0; sym && l < longs.size(); l++) sym = h->order.rank_of(h->order.new_of[(size_t)longs[l]]) < (int64_t)longs.size();
     a.sym = sparse::SymArgs{};
     if (sym) {
@@ -230,7 +237,8 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
         // The front delivers when the long / heavy rows of this call are exactly the rows that got group 0 to themselves at creation.
         y.front = 0;
         constexpr size_t kFrontBytes = (size_t)16 << 30;  // the score matrix and its transpose: beyond this the front keeps its scores
-        if (g_sparse_sym != 2 && h->order.pad > 0 && (int64_t)longs.size() == h->order.n_front &&
+        // (... and fewer front rows than 2.5 k give front_bound too little to bound an item by: the foreign lists would fill)
+        if (g_sparse_sym != 2 && h->order.pad > 0 && (int64_t)longs.size() == h->order.n_front && 2 * (int64_t)h->order.n_front >= 5 * (int64_t)k &&
             (size_t)h->order.n_front * (size_t)(N - y.first) * 8 <= kFrontBytes) {
             y.front = h->order.n_front;
             y.fw = (y.front + 63) / 64 * 64;
@@ -460,7 +468,7 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
     h->prof.end(tok, h->stream);
     plan.valid = plan.on_device = qp == h->r_ptr.p && one_launch;
     if (redo_overwrote) plan.on_device = false;
-    plan.q_first = q_first, plan.nq = nq, plan.split = g_sparse_split, plan.heavy = g_sparse_heavy;
+    plan.q_first = q_first, plan.nq = nq, plan.split = split_used, plan.heavy = g_sparse_heavy;
     unsigned long long st[4] = {0, 0, 0, 0};
     GORSE_HIP_CHECK(hipMemcpyAsync(st, h->stat.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     if (idx_out)
@@ -510,7 +518,28 @@ extern "C" int32_t gorse_sparse_create(gorse_sparse **out, int32_t device, int64
     h->N = N;
     h->nnz = nnz;
     h->logG = pick_log_group();
-    h->order = sparse::order_rows(N, indptr, g_sparse_front ? g_sparse_split : 0, (int64_t)1 << h->logG);
+    {   // The front: the rows longer than `front_cut` -- the largest of split x {2, 1.75, 1.5, 1.25, 1} that leaves at least 300 of them
+        // (three times the hundred neighbours the reference keeps per item, config.go: front_bound wants a few k scores), or the
+        // value of the test hook.
+        int64_t cut = 0;
+        if (g_sparse_front > 1)
+            cut = g_sparse_front;
+        else if (g_sparse_front == 1 && g_sparse_split > 0) {
+            std::vector<int64_t> lens((size_t)N);
+            for (int64_t r = 0; r < N; r++) lens[(size_t)r] = indptr[r + 1] - indptr[r];
+            const size_t want = (size_t)std::min<int64_t>(300, N);
+            std::nth_element(lens.begin(), lens.begin() + (want - 1), lens.end(), std::greater<int64_t>());
+            const int64_t len300 = lens[want - 1];  // at least 300 rows are this long or longer
+            cut = g_sparse_split;
+            for (int q = 8; q > 4; q--)
+                if (g_sparse_split * q / 4 < len300) {
+                    cut = g_sparse_split * q / 4;
+                    break;
+                }
+        }
+        h->front_cut = cut;
+        h->order = sparse::order_rows(N, indptr, cut, (int64_t)1 << h->logG);
+    }
     const int64_t Np = h->Np = h->order.Np;
     if (Np > INT32_MAX) {
         delete h;
@@ -738,7 +767,7 @@ extern "C" void gorse_hip_test_set_sparse_probe(int32_t probe) {
     g_sparse_tri_probe = probe & 0xff;
     g_sparse_rows_wgs = (probe >> 8) > 0 ? (int64_t)(probe >> 8) * 256 : 1024;
 }
-extern "C" void gorse_hip_test_set_sparse_front(int32_t on) { g_sparse_front = on; }
+extern "C" void gorse_hip_test_set_sparse_front(int32_t front) { g_sparse_front = front; }
 extern "C" void gorse_hip_test_set_sparse_sym(int32_t mode, int32_t c1, int32_t c2, int32_t c3) {
     g_sparse_sym = mode;
     g_sparse_sym_caps[0] = c1, g_sparse_sym_caps[1] = c2, g_sparse_sym_caps[2] = c3;

@@ -701,7 +701,9 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // (the item's first loads stay behind this: the block's registers are free again)
-        const int nviews = whole ? (a.head_groups < glim ? a.head_groups : glim) - gfirst : 1;  // a whole-query item: the head groups here, the others in super-visits below
+        // a whole-query item: the head groups [gfirst, ghead) here, the others in super-visits below
+        const int ghead = a.head_groups < gfirst ? gfirst : (a.head_groups < glim ? a.head_groups : glim);
+        const int nviews = whole ? ghead - gfirst : 1;
         const int nacc = NL;
         const int lm = NL - 1;
         const int tcap = nacc >> 2;
@@ -935,12 +937,12 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         // = window j).  Until then every window was sized by its own count pass (two dependent loads per chunk, then three more per
         // chunk to apply it: ~5 exposed round trips per (window, chunk)); with the plan known the visits run through the same kind of
         // software pipeline as the head groups: index / value pairs two visits ahead, directory entries one visit ahead.
-        if (whole && a.head_groups < glim) {
+        if (whole && ghead < glim) {
             const int S = nacc >> 1;
             const uint32_t cap_t = (uint32_t)(nacc >> a.cap_shift);
             lds_key *hkey = reinterpret_cast<lds_key *>(acc);
             float *hval = acc + S;
-            for (int g0 = a.head_groups; g0 < glim; g0 += kBlock - 1) {
+            for (int g0 = ghead; g0 < glim; g0 += kBlock - 1) {
                 const int gcount = glim - g0 < kBlock - 1 ? glim - g0 : kBlock - 1;  // groups g0 .. g0 + gcount - 1
                 // -- the plan
                 const int gi = g0 + (lane < gcount ? lane : gcount);

@@ -102,9 +102,11 @@ void gorse_hip_test_set_sparse_probe(int32_t probe);
  * call takes), -1 / 1 = when the call is eligible (default), 2 = likewise, but the front (gorse_hip_test_set_sparse_front) does not deliver.  c1 / c2 / c3 > 0 replace the capacities of the three tiers of foreign lists
  * (tests overflow them on purpose: the rows then take the unsymmetric walk in a second launch); 0 = the defaults.  Results never differ. */
 void gorse_hip_test_set_sparse_sym(int32_t mode, int32_t c1, int32_t c2, int32_t c3);
-/* handles created AFTERWARDS: 1 (default) = the rows longer than the split threshold in force at creation get a row group of their own
- * when they are fewer than a group holds (phantom scratch ids behind them: csrc/sparse_host.hpp, RowOrder), 0 = plain longest-first numbering. */
-void gorse_hip_test_set_sparse_front(int32_t on);
+/* handles created AFTERWARDS: the FRONT = the longest rows in a row group of their own when they are fewer than a group holds (phantom
+ * scratch ids behind them: csrc/sparse_host.hpp, RowOrder).  1 (default) = the rows longer than 1 .. 2 x the split threshold in force at
+ * creation (the largest multiple that leaves 300 rows: gorse_sparse_create), > 1 = the rows longer than this, 0 = plain longest-first
+ * numbering.  A symmetric all-pairs pass splits exactly the front's rows into per-group work items. */
+void gorse_hip_test_set_sparse_front(int32_t front);
 /* the last call of the handle: out[0] = it ran in symmetric form, [1] = rows redone after an overflow, [2] = foreign entries ranked,
  * [3] = the longest foreign list */
 void gorse_hip_test_sparse_sym_stats(const gorse_sparse *h, int64_t out[4]);

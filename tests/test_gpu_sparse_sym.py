@@ -199,3 +199,28 @@ def test_front_group_of_the_long_rows(oracle, hooks, split, k):
     _same(plain_index.all_pairs(k), s.all_pairs(k))
     plain_index.close()
     s.close()
+
+
+@pytest.mark.parametrize("k", [5, 100])
+@pytest.mark.parametrize("head", [-1, 0, 1, 1000])
+def test_front_cut_above_the_split_threshold(oracle, hooks, head, k):
+    """The front's rows are the ones longer than a cut of their own (here 36 of at most 40 entries, the split threshold of every other call
+    20): a symmetric pass splits only them into per-group work items, the rows between the two thresholds walk as single items.  With 0, 1 and
+    all head groups (the groups a whole-query item visits one by one; the super-visits behind them must start behind the front too)."""
+    rng = np.random.default_rng(900)
+    ptr, idx, val = random_csr(rng, 4000, 300, 1, 40, zipf=True)
+    assert 100 < int((np.diff(ptr) > 36).sum()) < 512
+    hooks.gorse_hip_test_set_sparse_tile(512)
+    hooks.gorse_hip_test_set_sparse_split(20)
+    hooks.gorse_hip_test_set_sparse_heavy(39)
+    hooks.gorse_hip_test_set_sparse_head(head)
+    hooks.gorse_hip_test_set_sparse_front(36)
+    s = capi.Sparse(ptr, idx, val)
+    plain, sym, st = _both(hooks, s, k)
+    assert st[0] == 1
+    _same(plain, sym)
+    sample = list(range(0, 4000, 53))
+    check(oracle, ptr, idx, val, k, [x[sample] for x in sym], rows_of(ptr, idx, val, sample), sample)
+    got = s.all_pairs(k, 17, 3000)  # a range: the unsymmetric walk with its own split threshold, on the front's numbering
+    check(oracle, ptr, idx, val, k, [x[:60] for x in got], rows_of(ptr, idx, val, range(17, 77)), list(range(17, 77)))
+    s.close()
