@@ -38,7 +38,7 @@ def run(split, heavy, tile, head=-1, slots=0, rows_wgs=0):
         sp.all_pairs(k, 0, N, fetch=False)
     sp.synchronize()
     dt = (time.perf_counter() - t0) / 5
-    print("split %5d (front %4d rows) heavy %6d (%3d rows) tile %5d head %2d slots %5d rows-kernel wgs %5d: %7.2f ms  postings %.3e  sym %s  equal %s"
+    print("split %5d (> split: %4d rows) heavy %6d (%3d rows) tile %5d head %2d slots %5d rows-kernel wgs %5d: %7.2f ms  postings %.3e  sym %s  equal %s"
           % (split, int((lens > split).sum()), heavy, int((lens > heavy).sum()), tile or 2048, head, slots or 4096, rows_wgs * 256 or 1024,
              dt * 1e3, sp.last_stats()[0], sp.sym_stats(), same), flush=True)
     sp.close()
@@ -46,7 +46,11 @@ def run(split, heavy, tile, head=-1, slots=0, rows_wgs=0):
 
 
 ok = run(2048, 16384, 0)
-if len(sys.argv) > 1 and sys.argv[1] == "split":
+if len(sys.argv) > 1 and sys.argv[1] == "balance":  # list walk against dense-vector kernel at the default front
+    for heavy, wgs in itertools.product((16384, 20480, 24576, 32768), (0, 8, 16)):
+        ok &= run(2048, heavy, 0, rows_wgs=wgs)
+    ok &= run(2048, 16384, 0)
+elif len(sys.argv) > 1 and sys.argv[1] == "split":
     for split in (2560, 3072, 3584, 4096, 5120, 6144, 8192, 12288, 16384):
         ok &= run(split, 16384, 0)
     for split, heavy in ((4096, 12288), (4096, 24576), (6144, 12288), (6144, 24576), (3072, 12288), (3072, 24576)):
