@@ -224,3 +224,40 @@ def test_front_cut_above_the_split_threshold(oracle, hooks, head, k):
     got = s.all_pairs(k, 17, 3000)  # a range: the unsymmetric walk with its own split threshold, on the front's numbering
     check(oracle, ptr, idx, val, k, [x[:60] for x in got], rows_of(ptr, idx, val, range(17, 77)), list(range(17, 77)))
     s.close()
+
+
+def test_random_configurations_of_the_symmetric_pass(oracle, hooks):
+    """Thirty random small collections (empty rows, equal rows, signed values, fewer rows than k, one row group or dozens) under random settings
+    of every switch the pass has (rows per group, split / heavy thresholds, the front's cut, head groups, workgroups, accumulation form, foreign
+    list capacities, with and without the front's delivery): the symmetric pass equals the unsymmetric one everywhere and the oracle on a sample."""
+    rng = np.random.default_rng(4242)
+    for case in range(30):
+        rows, dims = int(rng.integers(2, 2000)), int(rng.integers(1, 200))
+        hi = int(rng.integers(0, min(dims, 40) + 1))
+        ptr, idx, val = random_csr(rng, rows, dims, 0, hi, neg=bool(rng.integers(0, 2)), zipf=bool(rng.integers(0, 2)))
+        if case % 5 == 0:  # blocks of identical rows
+            keep = rng.integers(0, rows, rows)
+            lens = np.diff(ptr)[keep]
+            idx = np.concatenate([idx[ptr[r]:ptr[r + 1]] for r in keep]) if lens.sum() else idx[:0]
+            val = np.concatenate([val[ptr[r]:ptr[r + 1]] for r in keep]) if lens.sum() else val[:0]
+            ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        hooks.gorse_hip_test_set_sparse_tile(int(rng.choice([256, 512, 2048])))
+        hooks.gorse_hip_test_set_sparse_split(int(rng.choice([0, 1, 3, 8, 20, 2048])))
+        hooks.gorse_hip_test_set_sparse_heavy(int(rng.choice([0, 2, 12, 30, 16384])))
+        hooks.gorse_hip_test_set_sparse_head(int(rng.choice([-1, 0, 1, 2, 1000])))
+        hooks.gorse_hip_test_set_sparse_slots(int(rng.choice([0, 3, 64])))
+        hooks.gorse_hip_test_set_sparse_atomic(int(rng.choice([-1, 0, 1])))
+        hooks.gorse_hip_test_set_sparse_front(int(rng.choice([0, 1, 1, 5, 15, 30])))
+        s = capi.Sparse(ptr, idx, val)
+        k = int(rng.choice([1, 2, 7, 64, 100, 129, 300, 1024]))
+        caps = (0, 0, 0) if rng.random() < 0.6 else tuple(int(x) for x in rng.choice([1, 4, 64], 3))
+        hooks.gorse_hip_test_set_sparse_sym(0, 0, 0, 0)
+        plain = s.all_pairs(k)
+        hooks.gorse_hip_test_set_sparse_sym(int(rng.choice([1, 1, 2])), *caps)
+        sym = s.all_pairs(k)
+        hooks.gorse_hip_test_set_sparse_sym(-1, 0, 0, 0)
+        for a, b in zip(plain, sym):
+            assert np.array_equal(_bits(a), _bits(b)), case
+        sample = sorted(set(int(x) for x in rng.integers(0, rows, 12)))
+        check(oracle, ptr, idx, val, k, [x[sample] for x in sym], rows_of(ptr, idx, val, sample), sample)
+        s.close()
