@@ -184,7 +184,7 @@ struct TileArgs {
     int32_t *out_idx;   // nq x k, padded with -1
     float *out_score;   // nq x k, padded with -inf
     int32_t *out_cnt;   // nq
-    unsigned long long *part_keys;  // per (pslot, group): KP keys, descending, padded with 0
+    unsigned long long *part_keys;  // per (pslot, group): the best KP keys of the part in any order, padded with 0
     int32_t *part_cnt;              // per (pslot, group): rows scoring above / below zero
     unsigned long long *stat;       // [0] += postings walked, [1] += rows with a non-zero score
     Trace *trace;                   // probe: one record per work item, or null
@@ -1061,11 +1061,19 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             }
         }
         const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);
-        finish<KP>(s_buf, bcnt, lane);
-        if (symw) {  // the row's own half: its sorted keys, its counts, and the exact bound its own walk gives
-            for (int i = lane; i < KP; i += kBlock) a.sym.own[(size_t)t * KP + i] = bcnt > 0 ? s_buf[i] : 0;
+        if (symw || !whole) {
+            // The keys go to a merge, which takes them in any order: no sort, only the best KP of the buffer -- a cut where it holds
+            // more, and for a symmetric item wherever it holds k: the cut's threshold is the exact bound its own walk gives.
+            __syncthreads();
+            for (int i = bcnt + lane; i < CAP; i += kBlock) s_buf[i] = 0;
+            __syncthreads();
+            if (bcnt > KP || (symw && bcnt >= a.k)) cut_to_k<KP>(s_buf, a.k, bcnt, thr, lane);
+        } else
+            finish<KP>(s_buf, bcnt, lane);
+        if (symw) {  // the row's own half: its keys, its counts, and the exact bound of its own walk
+            for (int i = lane; i < KP; i += kBlock) a.sym.own[(size_t)t * KP + i] = i < bcnt ? s_buf[i] : 0;
             if (lane == 0) {
-                const uint32_t kth = bcnt >= a.k ? (uint32_t)(s_buf[a.k - 1] >> 32) : 0u;
+                const uint32_t kth = bcnt >= a.k ? (uint32_t)((thr + 1) >> 32) : 0u;
                 if (kth > pub)
                     __hip_atomic_store(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]), kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pos) __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(&a.sym.tp[sid_q]) + 1, (uint32_t)pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1077,7 +1085,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         } else {
             const size_t part = (size_t)wk.pslot * a.part_stride + wk.part;
-            for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = bcnt > 0 ? s_buf[i] : 0;
+            for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = i < bcnt ? s_buf[i] : 0;
             if (lane == 0) {
                 a.part_cnt[part * 2] = (int32_t)pos;
                 a.part_cnt[part * 2 + 1] = (int32_t)neg;
@@ -1385,16 +1393,6 @@ __global__ __launch_bounds__(kBlock) void sparse_sym_merge_kernel(SymMergeArgs a
         long long pos = (long long)(tp >> 32), neg = (long long)a.sym.neg[sid];
         const float *frow = a.sym.front ? a.sym.fmt + (size_t)(sid - a.sym.first) * a.sym.fw : nullptr;
         const unsigned long long *own = a.sym.own + (size_t)t * KP;
-        if (fc == 0 && !frow) {  // nothing delivered that counts: the own keys are the row, already in order
-            const int cnt = written(pos, neg, a.N - 1, a.k);
-            for (int i = lane; i < a.k; i += kBlock) {
-                const unsigned long long key = i < cnt ? own[i] : 0;
-                a.out_idx[t * a.k + i] = i < cnt ? key_row(key) : -1;
-                a.out_score[t * a.k + i] = i < cnt ? key_score(key) : __uint_as_float(0xff800000u);
-            }
-            if (lane == 0) a.out_cnt[t] = cnt;
-            continue;
-        }
         int bcnt = 0;
         unsigned long long thr = 0;
         for (int i = 0; i < KP; i += kBlock) {
