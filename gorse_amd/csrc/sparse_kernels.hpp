@@ -325,6 +325,41 @@ __device__ inline void write_result(const unsigned long long *s_buf, int cnt, in
     if (lane == 0) out_cnt[t] = cnt;
 }
 
+// Result row t from the UNSORTED buffer (bcnt distinct keys, cnt of them returned).  Up to 256 keys: no sort -- a key's place in the
+// row is the number of keys above it; every lane counts that for its (at most four) keys against the whole buffer, one broadcast
+// read per key, no barrier.  (A 128-key bitonic sort is 28 passes of reads, writes and a barrier, with every wave of a CU on the
+// LDS at once: the symmetric pass's merge went 1.02 -> 0.68 ms.)  More keys: the sort.  All lanes together.
+template <int KP>
+__device__ inline void write_ranked(unsigned long long *s_buf, int bcnt, int cnt, int k, int64_t t, int32_t *out_idx, float *out_score,
+                                    int32_t *out_cnt, int lane) {
+    if (bcnt > 256) {
+        finish<KP>(s_buf, bcnt, lane);
+        write_result(s_buf, cnt, k, t, out_idx, out_score, out_cnt, lane);
+        return;
+    }
+    __syncthreads();
+    unsigned long long mine[4];
+    int above[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) mine[j] = j * kBlock + lane < bcnt ? s_buf[j * kBlock + lane] : ~0ull;
+    for (int i = 0; i < bcnt; i++) {
+        const unsigned long long other = s_buf[i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) above[j] += other > mine[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j * kBlock + lane < bcnt && above[j] < cnt) {
+            out_idx[t * k + above[j]] = key_row(mine[j]);
+            out_score[t * k + above[j]] = key_score(mine[j]);
+        }
+    for (int i = (cnt < bcnt ? cnt : bcnt) + lane; i < k; i += kBlock) {
+        out_idx[t * k + i] = -1;
+        out_score[t * k + i] = __uint_as_float(0xff800000u);
+    }
+    if (lane == 0) out_cnt[t] = cnt;
+}
+
 // ATOMIC: ds_add_rtn_f32 / ds_add_f32.  !ATOMIC: load / add / store by the same wave, for inputs whose partial sums may be
 // subnormal (the LDS adder's handling of those is not relied upon); same order, same bits, slower.
 // acc_add_old returns the accumulator's value BEFORE the add (exactly +0 = the row had not been reached, or its sum is back
@@ -1061,15 +1096,14 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
             }
         }
         const long long pos = wave_sum((long long)my_pos), neg = wave_sum((long long)my_neg), hit = wave_sum((long long)my_hit);
-        if (symw || !whole) {
-            // The keys go to a merge, which takes them in any order: no sort, only the best KP of the buffer -- a cut where it holds
-            // more, and for a symmetric item wherever it holds k: the cut's threshold is the exact bound its own walk gives.
+        {   // No sort here.  Keys that go to a merge are taken in any order, a result row is written by counting (write_ranked): what
+            // is needed is the best KP of the buffer -- a cut where it holds more, and for a symmetric item wherever it holds k: the
+            // cut's threshold is the exact bound its own walk gives.
             __syncthreads();
             for (int i = bcnt + lane; i < CAP; i += kBlock) s_buf[i] = 0;
             __syncthreads();
             if (bcnt > KP || (symw && bcnt >= a.k)) cut_to_k<KP>(s_buf, a.k, bcnt, thr, lane);
-        } else
-            finish<KP>(s_buf, bcnt, lane);
+        }
         if (symw) {  // the row's own half: its keys, its counts, and the exact bound of its own walk
             for (int i = lane; i < KP; i += kBlock) a.sym.own[(size_t)t * KP + i] = i < bcnt ? s_buf[i] : 0;
             if (lane == 0) {
@@ -1082,7 +1116,7 @@ __global__ __launch_bounds__(kBlock) void sparse_tile_kernel(TileArgs a) {
         } else if (whole) {
             const bool ex_counts = ex_in && (!a.mask_sid || a.mask_sid[ex_sid]);
             const int cnt = written(pos, neg, a.n_admissible - (ex_counts ? 1 : 0), a.k);
-            write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
+            write_ranked<KP>(s_buf, bcnt, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         } else {
             const size_t part = (size_t)wk.pslot * a.part_stride + wk.part;
             for (int i = lane; i < KP; i += kBlock) a.part_keys[part * KP + i] = i < bcnt ? s_buf[i] : 0;
@@ -1425,35 +1459,7 @@ __global__ __launch_bounds__(kBlock) void sparse_sym_merge_kernel(SymMergeArgs a
             cut_to_k<KP>(s_buf, a.k, bcnt, thr, lane);
         }
         const int cnt = written(pos, neg, a.N - 1, a.k);
-        if (bcnt <= 256) {
-            // No sort: the keys are distinct, so a key's place in the row is the number of keys above it -- every lane counts that for
-            // its (at most four) keys against the whole buffer, one broadcast read per key, no barrier.  (The 128-key bitonic sort
-            // was 28 passes of reads, writes and a barrier with 32 waves of a CU on the LDS at once: 1.0 of the pass's 21.9 ms.)
-            __syncthreads();
-            unsigned long long mine[4];
-            int above[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 4; j++) mine[j] = j * kBlock + lane < bcnt ? s_buf[j * kBlock + lane] : ~0ull;
-            for (int i = 0; i < bcnt; i++) {
-                const unsigned long long other = s_buf[i];
-#pragma unroll
-                for (int j = 0; j < 4; j++) above[j] += other > mine[j];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (j * kBlock + lane < bcnt && above[j] < cnt) {
-                    a.out_idx[t * a.k + above[j]] = key_row(mine[j]);
-                    a.out_score[t * a.k + above[j]] = key_score(mine[j]);
-                }
-            for (int i = (cnt < bcnt ? cnt : bcnt) + lane; i < a.k; i += kBlock) {
-                a.out_idx[t * a.k + i] = -1;
-                a.out_score[t * a.k + i] = __uint_as_float(0xff800000u);
-            }
-            if (lane == 0) a.out_cnt[t] = cnt;
-        } else {
-            finish<KP>(s_buf, bcnt, lane);
-            write_result(s_buf, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
-        }
+        write_ranked<KP>(s_buf, bcnt, cnt, a.k, t, a.out_idx, a.out_score, a.out_cnt, lane);
         __syncthreads();
     }
 }
