@@ -1194,6 +1194,7 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
     constexpr int CAP = 2 * KP;
     constexpr int kDeep = 16;  // entries of a row in flight per lane
     constexpr int64_t kLongRow = 1024;  // rows with more entries are walked by the whole wave, one row at a time
+    constexpr int kDenseStep = 16;      // ... and a step of 64 entries with more matches than this adds all 64 lanes (see below)
     __shared__ unsigned long long s_buf[CAP];
     const int lane = threadIdx.x;
     // Eight queues, one per XCD (workgroup b has been observed on XCD b % 8; for speed only): queue x holds the heavy queries
@@ -1253,10 +1254,20 @@ __global__ __launch_bounds__(kBlock) void sparse_rows_kernel(RowsArgs a) {
                     hit_next = fetch(base + kBlock, p_next);  // in flight while this step is added up
                     unsigned long long mh = __ballot(hit);
                     matched += lane == 0 ? (unsigned long long)__popcll(mh) : 0;
-                    for (; mh; mh &= mh - 1) {
-                        const int b = __ffsll((long long)mh) - 1;
-                        sum = __fadd_rn(sum, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_cur), b)));
-                    }
+                    if (__popcll(mh) > kDenseStep) {
+                        // Many matches in the step: all 64 lanes in lane order with -0 where there is no match -- x + (-0) is x for
+                        // every x, so the sum is the matches' sum in entry order, bit for bit -- two instructions per lane (a read of
+                        // a fixed lane, an add) instead of the eight of the loop below per match (find the bit, read that lane, add,
+                        // clear the bit, branch): a wave alone on its SIMD issues one instruction every four cycles, and this loop
+                        // was the kernel's largest share of them (r06_zy2_pmc_SQ_i2i.txt: 40 % of its cycles issuing).
+                        const int pz = hit ? __float_as_int(p_cur) : (int)0x80000000;
+#pragma unroll
+                        for (int b = 0; b < kBlock; b++) sum = __fadd_rn(sum, __int_as_float(__builtin_amdgcn_readlane(pz, b)));
+                    } else
+                        for (; mh; mh &= mh - 1) {
+                            const int b = __ffsll((long long)mh) - 1;
+                            sum = __fadd_rn(sum, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_cur), b)));
+                        }
                 }
                 if (lane == l) {
                     acc = sum;
