@@ -361,6 +361,23 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
                 GORSE_HIP_CHECK(hipMemcpyAsync(h->heavy_pslot.p, heavy_pslot.data(), nh * 4, hipMemcpyHostToDevice, h->stream));
             }
             GORSE_HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));  // uploads, memsets, the buffers of the previous launch
+        }
+        // The list walk is enqueued BEFORE the dense-vector kernel's chain (which waits for the fork event only): it then holds its
+        // waves when the other kernel arrives.  In the other order -- decided by a race of tens of microseconds until round 6 -- the
+        // dense-vector kernel takes its slots first and the pass is 1-3 ms longer (profiles/r06_zz3_timeline_sparse_front.txt: list walk
+        // 18.7 ms with the dense-vector kernel 18.0 beside it, against 20.4 with 13.9).
+        a.work = h->work.p, a.n_work = (int32_t)work.size();
+        a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
+        a.trace = nullptr;
+#ifdef GORSE_PROBE
+        if (h->trace_on) {
+            GORSE_TRY(h->trace.ensure(work.size()));
+            a.trace = h->trace.p;
+        }
+#endif
+        if (!work.empty()) GORSE_TRY(launch_work(work.size(), sym));
+        if (!heavy_t.empty()) {
+            const size_t nh = heavy_t.size();
             GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
             GORSE_HIP_CHECK(hipMemsetAsync(h->dense.p, 0, (nh * (size_t)h->Dc + 1) * sizeof(uint2), h->stream2));
             sparse::sparse_dense_query_kernel<<<dim3(64, (unsigned)nh), dim3(256), 0, h->stream2>>>(qp, qc, qv, q_first, h->heavy_t.p,
@@ -386,16 +403,6 @@ int32_t run_queries(gorse_sparse *h, const int64_t *qp, const int32_t *qc, const
             GORSE_HIP_CHECK(hipGetLastError());
             GORSE_HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
         }
-        a.work = h->work.p, a.n_work = (int32_t)work.size();
-        a.part_keys = h->part_keys.p, a.part_cnt = h->part_cnt.p;
-        a.trace = nullptr;
-#ifdef GORSE_PROBE
-        if (h->trace_on) {
-            GORSE_TRY(h->trace.ensure(work.size()));
-            a.trace = h->trace.p;
-        }
-#endif
-        if (!work.empty()) GORSE_TRY(launch_work(work.size(), sym));
         if (!heavy_t.empty()) GORSE_HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
         if (n_long > 0) GORSE_TRY(launch_merge(n_long));
         // the host lists (work, heavy_*, nparts, split_t) and the trace buffer are reused by the next iteration
