@@ -47,7 +47,7 @@ def run(split, heavy, tile, head=-1, slots=0, rows_wgs=0):
 
 ok = run(2048, 16384, 0)
 if len(sys.argv) > 1 and sys.argv[1] == "balance":  # list walk against dense-vector kernel at the default front
-    for heavy, wgs in itertools.product((16384, 20480, 24576, 32768), (0, 8, 16)):
+    for heavy, wgs in itertools.product((8192, 10240, 12288, 16384, 20480, 24576), (0, 8)):
         ok &= run(2048, heavy, 0, rows_wgs=wgs)
     ok &= run(2048, 16384, 0)
 elif len(sys.argv) > 1 and sys.argv[1] == "split":
