@@ -45,6 +45,9 @@ def run(split, heavy, tile, head=-1, slots=0, rows_wgs=0):
     return same
 
 
+if len(sys.argv) > 3 and sys.argv[1] == "one":  # one configuration (split, heavy), for a kernel timeline
+    run(int(sys.argv[2]), int(sys.argv[3]), 0)
+    sys.exit(0)
 ok = run(2048, 16384, 0)
 if len(sys.argv) > 1 and sys.argv[1] == "balance":  # list walk against dense-vector kernel at the default front
     for heavy, wgs in itertools.product((8192, 10240, 12288, 16384, 20480, 24576), (0, 8)):
