@@ -46,8 +46,10 @@ __global__ __launch_bounds__(256) void als_gram_partial_kernel(const float *__re
             const float *x = smem + r * d;
 #pragma unroll
             for (int e = 0; e < MAXE; e++) {
-                int idx = threadIdx.x + e * 256;
-                if (idx < dd) acc[e] += x[idx / d] * x[idx % d];
+                // (an element past d * d accumulates element d * d - 1 and is never stored: a bound check here is 64 masks that
+                // hipcc keeps in scalar registers across the row loop -- 65 spills)
+                const int idx = threadIdx.x + e * 256 < dd ? threadIdx.x + e * 256 : dd - 1;
+                acc[e] += x[idx / d] * x[idx % d];
             }
         }
         __syncthreads();
@@ -254,12 +256,16 @@ __device__ __forceinline__ void wide_solve(float *__restrict__ a, const float *_
                                            float *sM, float *ss, const float (&acc)[8][8], const float (&cs)[8]) {
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const float one_w = 1 - w;
+    // (the 64 bound checks below are invariant across the callers' row loops; with d as written hipcc keeps their masks in scalar
+    // registers over the loop -- 86 / 100 spills in als_wide_long_kernel / als_wide_kernel<false, 0>: an opaque copy of d forms them here)
+    int dq = d;
+    asm volatile("" : "+s"(dq));
 #pragma unroll
     for (int x = 0; x < 8; x++)
 #pragma unroll
         for (int y = 0; y < 8; y++) {
             const int i = 8 * ti + x, j = 8 * tj + y;
-            sM[i * kWideLd + j] = (i < d && j < d) ? one_w * acc[x][y] + w * S[i * d + j] : 0.0f;
+            sM[i * kWideLd + j] = (i < dq && j < dq) ? one_w * acc[x][y] + w * S[i * d + j] : 0.0f;
         }
     if (ti == 0) {
 #pragma unroll
@@ -615,10 +621,12 @@ __device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const floa
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * bj + col;
-            const bool in = i < d && j < d;
-            const float v = tl[t][r];
-            sM[i * kWideLd + j] = in ? one_w * v : 0.0f;
-            if (bi != bj) sM[j * kWideLd + i] = in ? one_w * v : 0.0f;
+            // No `i < d && j < d` select: the gathers zero every column past d (wide_gather, wide_gram_b3), so the rows and columns of G
+            // past d ARE zero.  The 160 selects' masks are invariant across the row loop: hipcc kept them in scalar registers over it
+            // (311 / 335 spills into vector lanes in als_wide_kernel<false, 2 / 1>).
+            const float v = one_w * tl[t][r];
+            sM[i * kWideLd + j] = v;
+            if (bi != bj) sM[j * kWideLd + i] = v;
         }
     }
     if (SUMS && W < 2) {
@@ -626,9 +634,10 @@ __device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const floa
         for (int b2 = 0; b2 < 2; b2++) {
             const float other = __shfl_xor(cs[b2], 32, 64);
             const int e = 32 * (2 * W + b2) + col;
-            if (lane < 32) ss[e] = e < d ? cs[b2] + other : 0.0f;
+            if (lane < 32) ss[e] = cs[b2] + other;  // (a column past d: a sum of zeros)
         }
     }
+    (void)d;
 }
 
 // M += w S over the d x d corner, the whole workgroup, S read row by row (the same two roundings per element as
@@ -1587,9 +1596,13 @@ __global__ __launch_bounds__(64 * kAlsWaves, 2) void als_chunk_kernel(const floa
                 gram_store_sums<NB>(g, DD, lane, dst + DD * DD);
             }
         } else {  // modes 3, 4: d x d of the 16 NB x 16 NB tiles
+            // (an opaque copy of d: the stores' bound checks are invariant across the chunk loop, and with d as written their masks
+            // stay in scalar registers over the accumulation -- 34 / 38 spills at NB = 4)
+            int dq = d;
+            asm volatile("" : "+s"(dq));
             gram_foreach16<NB>(g, [&](int ci, int cj, float v, bool mir) {
                 const int i = ci + 4 * (lane >> 4), j = cj + (lane & 15);
-                if (i < d && j < d) dst[mir ? j * d + i : i * d + j] = v;
+                if (i < dq && j < dq) dst[mir ? j * d + i : i * d + j] = v;
             });
             gram_store_sums16<NB>(g, lane, dst + (int64_t)d * d, d);
         }

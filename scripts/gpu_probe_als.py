@@ -86,6 +86,11 @@ def main():
         prof("C5 shard/4 d=128, bf16 x 3", 125_000, 100_000, 12_500_000, 128)
         capi.lib().gorse_hip_test_set_als_path(0)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "spills":  # round 6: the kernels that lost their scalar spills (A/B against the build before)
+        run("C5 full d=128", 500_000, 100_000, 50_000_000, 128, (0,), reps=3)
+        run("C5 shard/4 d=96", 125_000, 100_000, 12_500_000, 96, (0,), reps=3)
+        run("C5 shard/4 d=56", 125_000, 100_000, 12_500_000, 56, (0,), reps=3)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "phased":  # accumulate / solve in lockstep per workgroup (path | 4) against free-running
         prof("C5 d=64 free-running", 500_000, 100_000, 50_000_000, 64, 0)
         prof("C5 d=64 phased", 500_000, 100_000, 50_000_000, 64, 4)
