@@ -277,7 +277,7 @@ __device__ __forceinline__ void wide_solve(float *__restrict__ a, const float *_
 
 // the Gauss-Seidel sweep of row `a` over M (LDS, 128 x kWideLd, zero past d) and the column sums ss by the first wave, two
 // coordinates per lane; ends with a barrier (sM / ss are free again)
-// sy != null: y = M p (the row's current factors) has been formed by the whole workgroup (wide_add_S: two partial sums per
+// sy != null: y = M p (the row's current factors) has been formed by the whole workgroup (wide_form_y: two partial sums per
 // coordinate, even and odd rows of M, at sy[k] and sy[128 + k]) with p at sy[256 + k]; else this wave forms it here.
 __device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float reg, const float *sM, const float *ss, const float *sy) {
     const int tid = threadIdx.x;
@@ -318,8 +318,11 @@ __device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float r
         // (v_readlane), and y += delta_f M[:, f].  The new coordinate p_f' = base_f - y_f inv_f is formed beside the chain, the
         // columns of M for the next eight steps are read from LDS while the current eight run.  (profiles/r03_zc_probe_als_wide.txt: 22.5K
         // cycles per row = 176 per step with base, y, inv and p0 of coordinate f broadcast separately in every step.)
+        // (Round 6: the new coordinate is no longer formed in every step -- a multiply, a subtraction, a compare and a select beside
+        // the chain's three operations.  A lane keeps y as it stands at ITS OWN step, one compare and one select per step; every lane
+        // has exactly one step per half, so p' = base - y inv is formed once behind the half, the same two roundings.)
         const float g_lo = base_lo - p0_lo, g_hi = base_hi - p0_hi;
-        float p_lo = p0_lo, p_hi = p0_hi;
+        float ys_lo = 0.0f, ys_hi = 0.0f;
         auto sweep_half = [&](const int hi) {
             const float *c0 = sM + k0 * kWideLd + 64 * hi, *c1 = sM + k1 * kWideLd + 64 * hi;
             float cl[8], ch[8];
@@ -336,14 +339,13 @@ __device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float r
                     const int f = fb + j;
                     const float yk = hi ? y_hi : y_lo;
                     const float dk = fmaf(-yk, hi ? inv_hi : inv_lo, hi ? g_hi : g_lo);
-                    const float nf = (hi ? base_hi : base_lo) - yk * (hi ? inv_hi : inv_lo);
                     const float delta = lane_of(dk, f);
                     y_lo = fmaf(delta, cl[j], y_lo);
                     y_hi = fmaf(delta, ch[j], y_hi);
                     if (hi)
-                        p_hi = lane == f ? nf : p_hi;
+                        ys_hi = lane == f ? yk : ys_hi;
                     else
-                        p_lo = lane == f ? nf : p_lo;
+                        ys_lo = lane == f ? yk : ys_lo;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) cl[j] = nl[j], ch[j] = nh[j];
@@ -351,6 +353,7 @@ __device__ __forceinline__ void wide_sweep(float *__restrict__ a, int d, float r
         };
         sweep_half(0);
         sweep_half(1);
+        const float p_lo = base_lo - ys_lo * inv_lo, p_hi = base_hi - ys_hi * inv_hi;
         if (k0 < d) a[k0] = p_lo;
         if (k1 < d) a[k1] = p_hi;
         __builtin_amdgcn_s_setprio(0);
@@ -609,12 +612,18 @@ __device__ __forceinline__ void wide_gram_b3(const float *__restrict__ B, const 
     if (eg == 0) sums[c] = c < d ? colsum + ss[c] : 0.0f;
 }
 
-// this wave's tiles -> (1 - w) G in LDS (both triangles, zero past d), its column sums -> ss; wide_add_S completes M.  (With the
-// loads of S in here -- 96 of them, each its own 64-bit address -- the kernel needed 300 registers.)
+// this wave's tiles -> M = (1 - w) G + w S in LDS (both triangles, zero past d), its column sums -> ss.  w S comes from the wave's
+// registers in the layout of its tiles (wide_load_wS_tiles: read once per workgroup, the same S for every row of the half-sweep), so M
+// is complete when it is written: the separate pass that added w S to every element in LDS (64 reads and 64 writes per thread and
+// row, 27 % of a 100-entry row's time in the phase counters of round 4) is gone, the elements are the same in every bit -- the
+// two products are rounded before the sum either way.  (With the loads of S in here -- 96 of them, each its own 64-bit address --
+// the kernel needed 300 registers.)
 template <int W, bool SUMS = true>  // SUMS = false: the column sums are already in ss (wide_gram_b3)
-__device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const float (&cs)[2], int d, float w, float *sM, float *ss) {
+__device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const float (&cs)[2], int d, float w, float *sM, float *ss,
+                                               const float (&ws)[64]) {
     const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
     const float one_w = 1 - w;
+    int o = 0;
 #pragma unroll
     for (int t = 0; t < wide_tiles(W); t++) {
         const int bi = wide_tile_bi(W, t), bj = wide_tile_bj(W, t);
@@ -622,12 +631,13 @@ __device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const floa
         for (int r = 0; r < 16; r++) {
             const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * bj + col;
             // No `i < d && j < d` select: the gathers zero every column past d (wide_gather, wide_gram_b3), so the rows and columns of G
-            // past d ARE zero.  The 160 selects' masks are invariant across the row loop: hipcc kept them in scalar registers over it
-            // (311 / 335 spills into vector lanes in als_wide_kernel<false, 2 / 1>).
+            // past d ARE zero, and so are those of w S as loaded.  The 160 selects' masks are invariant across the row loop: hipcc kept
+            // them in scalar registers over it (311 / 335 spills into vector lanes in als_wide_kernel<false, 2 / 1>).
             const float v = one_w * tl[t][r];
-            sM[i * kWideLd + j] = v;
-            if (bi != bj) sM[j * kWideLd + i] = v;
+            sM[i * kWideLd + j] = v + ws[o + r];
+            if (bi != bj) sM[j * kWideLd + i] = v + ws[o + 16 + r];
         }
+        o += bi != bj ? 32 : 16;
     }
     if (SUMS && W < 2) {
 #pragma unroll
@@ -640,34 +650,42 @@ __device__ __forceinline__ void wide_form_mfma(const f32x16 (&tl)[3], const floa
     (void)d;
 }
 
-// M += w S over the d x d corner, the whole workgroup, S read row by row (the same two roundings per element as
-// (1 - w) G + w S written in one expression: the products are rounded before the sum either way)
-// The thread's 64 elements of w S (rows (tid >> 7) + 2 q of column tid & 127, zero past d) are read once per workgroup and kept
-// in registers: the same S for every row of the half-sweep.
-__device__ __forceinline__ void wide_load_wS(const float *__restrict__ S, int d, float w, float (&ws)[64]) {
-    const int j = threadIdx.x & 127, i0 = threadIdx.x >> 7;
+// w S in the layout of wave W's tiles (wide_form_mfma): element r of tile t, and behind it -- for a tile off the diagonal -- the
+// mirrored element S[j][i] (S is symmetric as the wide Gram kernels leave it; read anyway: any S gives the M of the formula);
+// zero past d.  64 registers in every wave: a diagonal tile takes 16, the others 32.
+template <int W>
+__device__ __forceinline__ void wide_load_wS_tiles(const float *__restrict__ S, int d, float w, float (&ws)[64]) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    int o = 0;
 #pragma unroll
-    for (int q = 0; q < 64; q++) {
-        const int i = i0 + 2 * q;
-        const bool in = i < d && j < d;
-        const float v = S[in ? i * d + j : 0];
-        ws[q] = in ? w * v : 0.0f;
+    for (int t = 0; t < wide_tiles(W); t++) {
+        const int bi = wide_tile_bi(W, t), bj = wide_tile_bj(W, t);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * half, j = 32 * bj + col;
+            const bool in = i < d && j < d;
+            const float v = S[in ? i * d + j : 0];
+            ws[o + r] = in ? w * v : 0.0f;
+            if (bi != bj) {
+                const float vm = S[in ? j * d + i : 0];
+                ws[o + 16 + r] = in ? w * vm : 0.0f;
+            }
+        }
+        o += bi != bj ? 32 : 16;
     }
+#pragma unroll
+    for (int q = o; q < 64; q++) ws[q] = 0.0f;
 }
-// M += w S, and with it the sweep's starting y = M p: the thread that completes the elements M[i][j], i = i0 + 2 q, of column j
-// also sums M[i][j] p_i over them (M is symmetric: that is its part of y_j); p is at sy[256 ..], the two partial sums of
-// coordinate j go to sy[j] (even rows) and sy[128 + j] (odd rows)
-__device__ __forceinline__ void wide_add_S(const float (&ws)[64], float *sM, float *sy) {
+// the sweep's starting y = M p over the complete M: thread (i0 = tid >> 7, j = tid & 127) sums M[i][j] p_i over the rows i = i0 + 2 q
+// of column j (M is symmetric: that is its part of y_j); p is at sy[256 ..], the two partial sums of coordinate j go to sy[j] (even
+// rows) and sy[128 + j] (odd rows) -- the sums and their order are those of the pass that also added w S (rounds 3-5)
+__device__ __forceinline__ void wide_form_y(const float *sM, float *sy) {
     const int i0 = threadIdx.x >> 7, j = threadIdx.x & 127;
-    float *col = sM + i0 * kWideLd + j;
+    const float *col = sM + i0 * kWideLd + j;
     const float *p = sy + 256 + i0;
     float y = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 64; q++) {
-        const float m = col[2 * q * kWideLd] + ws[q];
-        col[2 * q * kWideLd] = m;
-        y = fmaf(m, p[2 * q], y);
-    }
+    for (int q = 0; q < 64; q++) y = fmaf(col[2 * q * kWideLd], p[2 * q], y);
     sy[128 * i0 + j] = y;
 }
 
@@ -697,27 +715,27 @@ __device__ __forceinline__ void wide_partial_mfma(const f32x16 (&tl)[3], const f
 template <int W, bool CHUNKS>
 __device__ __forceinline__ void wide_item_mfma(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
                                                int64_t nbeg, int nn, int d, WideStage &st, float w, float *sM, float *ss,
-                                               float *__restrict__ dst) {
+                                               float *__restrict__ dst, const float (&ws)[64]) {
     f32x16 tl[3];
     float cs[2];
     wide_gram_mfma<W>(B, idx, beg, n, nbeg, nn, d, sM, st, tl, cs);
     if (CHUNKS)
         wide_partial_mfma<W>(tl, cs, dst);
     else
-        wide_form_mfma<W>(tl, cs, d, w, sM, ss);
+        wide_form_mfma<W>(tl, cs, d, w, sM, ss, ws);
 }
 
 template <int W, bool CHUNKS>
 __device__ __forceinline__ void wide_item_b3(const float *__restrict__ B, const int32_t *__restrict__ idx, int64_t beg, int n,
                                              int64_t nbeg, int nn, int d, WideStageB3 &st, float w, float *sM, float *ss,
-                                             float *__restrict__ dst) {
+                                             float *__restrict__ dst, const float (&ws)[64]) {
     f32x16 tl[3];
     const float cs[2] = {0.0f, 0.0f};
     wide_gram_b3<W>(B, idx, beg, n, nbeg, nn, d, sM, ss, CHUNKS ? dst + 128 * 128 : ss, st, tl);
     if (CHUNKS)
         wide_partial_mfma<W, false>(tl, cs, dst);
     else
-        wide_form_mfma<W, false>(tl, cs, d, w, sM, ss);
+        wide_form_mfma<W, false>(tl, cs, d, w, sM, ss, ws);
 }
 
 // CHUNKS = false: the rows of `rows` (n_items of them), accumulated and solved.  CHUNKS = true: the chunks of the long rows
@@ -763,8 +781,15 @@ __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A,
             wide_first_batch_b3(B, idx, beg, n, d, st);
         else
             wide_first_batch(B, idx, beg, n, d, st);
-        float ws[CHUNKS ? 1 : 64];
-        if constexpr (!CHUNKS) wide_load_wS(S, d, w, ws);
+        float ws[64];  // (CHUNKS: never read, folds away)
+        if constexpr (!CHUNKS) {
+            switch (tid >> 6) {
+            case 0: wide_load_wS_tiles<0>(S, d, w, ws); break;
+            case 1: wide_load_wS_tiles<1>(S, d, w, ws); break;
+            case 2: wide_load_wS_tiles<2>(S, d, w, ws); break;
+            default: wide_load_wS_tiles<3>(S, d, w, ws); break;
+            }
+        }
         for (int64_t t = blockIdx.x; t < n_items; t += gridDim.x) {
             int64_t u2, beg2;
             int n2;
@@ -776,17 +801,17 @@ __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A,
             if (prof) t0 = __builtin_amdgcn_s_memtime();
             if constexpr (MFMA == 2) {
                 switch (tid >> 6) {  // wave-uniform; every branch meets the same barriers
-                case 0: wide_item_b3<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-                case 1: wide_item_b3<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-                case 2: wide_item_b3<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-                default: wide_item_b3<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                case 0: wide_item_b3<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
+                case 1: wide_item_b3<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
+                case 2: wide_item_b3<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
+                default: wide_item_b3<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
                 }
             } else {
                 switch (tid >> 6) {
-                case 0: wide_item_mfma<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-                case 1: wide_item_mfma<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-                case 2: wide_item_mfma<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
-                default: wide_item_mfma<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst); break;
+                case 0: wide_item_mfma<0, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
+                case 1: wide_item_mfma<1, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
+                case 2: wide_item_mfma<2, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
+                default: wide_item_mfma<3, CHUNKS>(B, idx, beg, n, beg2, n2, d, st, w, sM, ss, dst, ws); break;
                 }
             }
             if (!CHUNKS) {
@@ -795,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void als_wide_kernel(float *__restrict__ A,
                 unsigned long long t1 = 0;
                 if (prof) t1 = __builtin_amdgcn_s_memtime();
                 if constexpr (!CHUNKS) {
-                    if (!(probe & 2)) wide_add_S(ws, sM, sq);
+                    if (!(probe & 2)) wide_form_y(sM, sq);
                 }
                 __syncthreads();
                 unsigned long long t2 = 0;

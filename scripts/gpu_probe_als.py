@@ -34,6 +34,8 @@ def run(name, U, I, nnz, d, paths, reps=3):
         ng, gram = mf.get_profile(capi.PROF_ALS_GRAM)
         gP, gQ = mf.get_factors()
         res[path] = (gP, gQ)
+        import zlib
+        print("%-26s path %d factors crc32 P %08x Q %08x" % (name, path, zlib.crc32(gP.tobytes()), zlib.crc32(gQ.tobytes())), flush=True)
         algo = 2.0 * n * d * 4 + 2.0 * (U + I) * d * 4
         print("%-26s path %d U=%7d I=%7d nnz=%9d d=%3d epoch %9.3f ms (sweeps %9.3f ms, S-gram %7.3f ms) algorithmic %6.1f GB/s "
               "max item row %d finite=%s gen %.1fs" % (name, path, U, I, n, d, dt * 1e3, sweep / reps, gram / reps, algo / dt / 1e9,
