@@ -1609,13 +1609,14 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
     if (n_samples < 0) return fail(GORSE_ERR_INVALID, "n_samples < 0");
     GORSE_TRY(check_mode(mode));
+    const bool chained = h->ep_chain;  // the previous epoch was the last thing issued on this handle (mf_internal.hpp: ep_begin_prev)
     GORSE_TRY(h->use());
     if (n_samples == 0) {
         if (loss_out) *loss_out = 0;
         return GORSE_OK;
     }
     GORSE_TRY(ensure_trip(h, n_samples));
-    GORSE_TRY(mf_epoch_begin(h));  // epoch pacing: the (begin, end) pair gorse_mf_epoch_throttle / _times read (csrc/mf.hip)
+    GORSE_TRY(mf_epoch_begin(h, chained));  // epoch pacing: the (begin, end) pair gorse_mf_epoch_throttle / _times read (csrc/mf.hip)
     double *d_loss = loss_out ? h->loss.p : nullptr;
     if (d_loss) GORSE_HIP_CHECK(hipMemsetAsync(d_loss, 0, sizeof(double), h->stream));
     const int64_t cap = (int64_t)h->trip_cap;
@@ -1688,6 +1689,7 @@ int32_t epoch_impl(gorse_mf *h, int64_t n_samples, float lr, float reg, uint64_t
         }
     }
     GORSE_TRY(mf_epoch_end(h));
+    h->ep_chain = true;
     if (sync || loss_out) {
         if (loss_out)
             GORSE_HIP_CHECK(hipMemcpyAsync(loss_out, h->loss.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));

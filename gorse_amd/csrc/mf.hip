@@ -172,7 +172,7 @@ int32_t mf_sync_streams(gorse_mf *h) {
 // stream: begin = the stream reaches the epoch (= the end of the previous epoch's last update kernel when epochs follow each other),
 // end = its last update kernel is done.  gorse_mf_epoch_throttle waits on them with the cancel flag in hand, gorse_mf_epoch_times
 // adds up their spans.
-int32_t mf_epoch_begin(gorse_mf *h) {
+int32_t mf_epoch_begin(gorse_mf *h, bool chained) {
     if (!h->ep_events) {
         for (int i = 0; i < gorse_mf::kEpochRing; i++) {
             GORSE_HIP_CHECK(hipEventCreate(&h->ev_ep_begin[i]));
@@ -180,14 +180,29 @@ int32_t mf_epoch_begin(gorse_mf *h) {
         }
         h->ep_events = true;
     }
-    if (h->ep_seq - h->ep_done >= (uint64_t)gorse_mf::kEpochRing) {  // the slot about to be reused was never read
+    // (one slot of margin: an epoch's begin may be the END event of the slot before it, which must outlive the epoch's own harvest)
+    if (h->ep_seq - h->ep_done >= (uint64_t)gorse_mf::kEpochRing - 1) {  // the slot about to be reused was never read
         GORSE_TRY(mf_epoch_harvest(h, false));
-        while (h->ep_seq - h->ep_done >= (uint64_t)gorse_mf::kEpochRing) {
+        while (h->ep_seq - h->ep_done >= (uint64_t)gorse_mf::kEpochRing - 1) {
             h->ep_done++;
             h->ep_untimed++;
         }
     }
-    GORSE_HIP_CHECK(hipEventRecord(h->ev_ep_begin[h->ep_seq % gorse_mf::kEpochRing], h->stream));
+    const int slot = (int)(h->ep_seq % gorse_mf::kEpochRing);
+    // chained (gorse_mf::ep_begin_prev): the previous epoch was the last thing issued on this handle and has not ended yet -- the update
+    // stream reaches this epoch when that one ends
+    bool from_prev = false;
+    if (chained && h->ep_seq > 0) {
+        const hipError_t q = hipEventQuery(h->ev_ep_end[(h->ep_seq - 1) % gorse_mf::kEpochRing]);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            from_prev = true;
+        } else {
+            GORSE_HIP_CHECK(q);
+        }
+    }
+    h->ep_begin_prev[slot] = from_prev;
+    if (!from_prev) GORSE_HIP_CHECK(hipEventRecord(h->ev_ep_begin[slot], h->stream));
     return GORSE_OK;
 }
 int32_t mf_epoch_end(gorse_mf *h) {
@@ -209,7 +224,8 @@ int32_t mf_epoch_harvest(gorse_mf *h, bool wait) {
             GORSE_HIP_CHECK(q);
         }
         float ms = 0.0f;
-        GORSE_HIP_CHECK(hipEventElapsedTime(&ms, h->ev_ep_begin[slot], h->ev_ep_end[slot]));
+        const hipEvent_t begin = h->ep_begin_prev[slot] ? h->ev_ep_end[(slot + gorse_mf::kEpochRing - 1) % gorse_mf::kEpochRing] : h->ev_ep_begin[slot];
+        GORSE_HIP_CHECK(hipEventElapsedTime(&ms, begin, h->ev_ep_end[slot]));
         h->ep_ms += ms;
         h->ep_timed++;
         h->ep_done++;
@@ -680,7 +696,9 @@ extern "C" int32_t gorse_mf_synchronize(gorse_mf *h) {
 extern "C" int32_t gorse_mf_epoch_throttle(gorse_mf *h, int32_t max_in_flight, const volatile int32_t *cancel) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
     if (max_in_flight < 0) return fail(GORSE_ERR_INVALID, "max_in_flight < 0");
+    const bool chain = h->ep_chain;  // (this call issues nothing on the handle's streams: two epochs around it still follow each other)
     GORSE_TRY(h->use());
+    h->ep_chain = chain;
     // the epochs are finished in order: wait for the oldest until no more than max_in_flight are left, the cancel flag in hand
     for (;;) {
         GORSE_TRY(mf_epoch_harvest(h, false));
@@ -696,7 +714,9 @@ extern "C" int32_t gorse_mf_epoch_throttle(gorse_mf *h, int32_t max_in_flight, c
 }
 extern "C" int32_t gorse_mf_epoch_times(gorse_mf *h, int64_t *epochs, double *total_ms, int64_t *in_flight, int32_t reset) {
     if (!h) return fail(GORSE_ERR_INVALID, "handle is NULL");
+    const bool chain = h->ep_chain;
     GORSE_TRY(h->use());
+    h->ep_chain = chain;
     GORSE_TRY(mf_epoch_harvest(h, false));
     if (epochs) *epochs = h->ep_timed;
     if (total_ms) *total_ms = h->ep_ms;

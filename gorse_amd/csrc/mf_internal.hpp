@@ -33,6 +33,11 @@ struct gorse_mf {
     static constexpr int kEpochRing = 16;
     hipEvent_t ev_ep_begin[kEpochRing] = {}, ev_ep_end[kEpochRing] = {};
     bool ep_events = false;
+    // An epoch that is enqueued while the one before it is still in flight, with nothing else issued on the handle in between (ep_chain:
+    // set by the epoch, cleared by every other entry point through use()), begins where that one ended: its begin IS the previous slot's
+    // end event (ep_begin_prev) and no event of its own is recorded -- one barrier packet less in front of its update kernel.
+    bool ep_begin_prev[kEpochRing] = {};
+    mutable bool ep_chain = false;
     uint64_t ep_seq = 0, ep_done = 0;
     double ep_ms = 0.0;     // device milliseconds of the epochs read so far (since the last reset)
     int64_t ep_timed = 0;   // how many epochs that sum covers
@@ -101,6 +106,7 @@ struct gorse_mf {
     gorse::KernelProfile prof{GORSE_PROF_NCLASSES};
 
     int32_t use() const {
+        ep_chain = false;  // (an entry point that issues nothing restores it: gorse_mf_epoch_throttle / _times)
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return gorse::fail(GORSE_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
         return GORSE_OK;
@@ -111,7 +117,7 @@ namespace gorse {
 // implemented in bpr.hip / als.hip, used across files
 int32_t mf_sync_streams(gorse_mf *h);
 // epoch pacing: mark the begin / end of one epoch on the update stream; read the finished ones (wait = block for all of them)
-int32_t mf_epoch_begin(gorse_mf *h);
+int32_t mf_epoch_begin(gorse_mf *h, bool chained);
 int32_t mf_epoch_end(gorse_mf *h);
 int32_t mf_epoch_harvest(gorse_mf *h, bool wait);
 int32_t mf_delta_export_async(gorse_mf *h, float *dst);        // mf.hip: dst <- Q - Q_sync, enqueued on h->stream

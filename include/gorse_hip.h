@@ -246,8 +246,10 @@ int32_t gorse_mf_synchronize(gorse_mf *h);
  *     enqueued epoch still has the next epoch's preparation running under the current update kernel, and sees a cancel within
  *     two epochs instead of within Verbose.
  *   gorse_mf_epoch_times: the DEVICE time of the BPR epochs that have finished since the last reset -- per epoch from the moment the
- *     update stream reaches it (= the end of the previous epoch's last update kernel when epochs follow each other) to the end of its
- *     own last update kernel: hipEvents on the handle's stream, no host clock -- and how many epochs are still in flight. */
+ *     update stream reaches it (= the end of the previous epoch's last update kernel when epochs follow each other: an epoch enqueued
+ *     while its predecessor is in flight takes that one's end event as its begin, so the times of back-to-back epochs add up to the
+ *     stream's time) to the end of its own last update kernel: hipEvents on the handle's stream, no host clock -- and how many epochs
+ *     are still in flight. */
 int32_t gorse_mf_epoch_throttle(gorse_mf *h, int32_t max_in_flight, const volatile int32_t *cancel /*host or NULL*/);
 int32_t gorse_mf_epoch_times(gorse_mf *h, int64_t *epochs /*out*/, double *total_ms /*out*/, int64_t *in_flight /*out, may be NULL*/,
                              int32_t reset);

@@ -1001,6 +1001,59 @@ def test_sample_user_negatives_matches_oracle(oracle, U, I, n):
     assert np.array_equal(rlen, el) and np.array_equal(rank, er)
 
 
+def test_epochs_that_follow_each_other_begin_where_the_one_before_ended():
+    """Epoch pacing, round 6 (csrc/mf.hip, mf_epoch_begin): an epoch enqueued while the one before it is still in flight -- nothing else
+    issued on the handle in between -- takes that one's end event as its begin (one barrier packet less in front of its update
+    kernel), so the device times of back-to-back epochs tile the stream's time: their sum is the wall time of the batch.  Any other
+    entry point between two epochs breaks the chain (gorse_mf::use clears it; the epoch before has ended by then anyway when the call
+    is a synchronous one): the next epoch records a begin of its own, and no epoch's span swallows the other call's time."""
+    import time
+    data = synth.s_ml1m()
+    d = 16
+    P, Q = synth.init_factors(data.U, data.I, d, 0.0, 0.01, 1)
+    mf = capi.MF(data.U, data.I, d, data.uptr, data.uidx)
+    mf.set_factors(P, Q)
+    mf.bpr_epoch(data.n_train, 0.05, 0.01, 3, 1)  # buffers, code objects
+    mf.synchronize()
+    mf.epoch_times(reset=True)
+    n_ep = 12
+    t0 = time.perf_counter()
+    for ep in range(2, 2 + n_ep):
+        mf.bpr_epoch_enqueue(data.n_train, 0.05, 0.01, 3, ep)
+    mf.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    n, ms, flying = mf.epoch_times(reset=True)
+    print("%d enqueued epochs: device time %.3f ms, wall %.3f ms" % (n, ms, wall))
+    assert n == n_ep and flying == 0
+    assert 0.85 * wall <= ms <= 1.02 * wall  # (the first epoch's begin is its own: the stream was idle)
+    # throttled as a Fit loop does it (gorse_mf_epoch_throttle issues nothing: the chain holds through it)
+    t0 = time.perf_counter()
+    for ep in range(20, 20 + n_ep):
+        mf.epoch_throttle(2)
+        mf.bpr_epoch_enqueue(data.n_train, 0.05, 0.01, 3, ep)
+    mf.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    n, ms, flying = mf.epoch_times(reset=True)
+    print("%d epochs behind throttle(2): device time %.3f ms, wall %.3f ms" % (n, ms, wall))
+    assert n == n_ep and 0.85 * wall <= ms <= 1.02 * wall
+    per_epoch = ms / n_ep
+    # other calls between two epochs: their time is in neither epoch's span
+    us = np.arange(4096, dtype=np.int32) % data.U
+    its = np.arange(4096, dtype=np.int32) % data.I
+    mf.bpr_epoch_enqueue(data.n_train, 0.05, 0.01, 3, 40)
+    t0 = time.perf_counter()
+    for _ in range(64):
+        mf.score(us, its)
+    other = (time.perf_counter() - t0) * 1e3
+    mf.bpr_epoch_enqueue(data.n_train, 0.05, 0.01, 3, 41)
+    mf.synchronize()
+    n, ms, flying = mf.epoch_times(reset=True)
+    print("two epochs around %.2f ms of scoring calls: device time %.3f ms (%.3f per epoch before)" % (other, ms, per_epoch))
+    assert n == 2 and ms <= 2 * per_epoch * 1.5 + 0.1
+    gP, gQ = mf.get_factors()
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+
+
 def test_epoch_throttle_and_device_epoch_times():
     """gorse_mf_epoch_throttle / gorse_mf_epoch_times (include/gorse_hip.h): a loop that enqueues epochs behind throttle(2) never has
     more than three in flight, the device times of the finished epochs add up to about the update kernels' own, and a raised
