@@ -47,6 +47,7 @@ struct gorse_topk {
     gorse::DevBuf<int64_t> rp_self;
     gorse::DevBuf<uint16_t> rp_op;
     gorse::DevBuf<float> rp_margin, rp_fslice;  // rp_fslice: final threshold of every (row slice, query) of a history sweep
+    gorse::DevBuf<float> rp_fwarm;              // starting threshold of every (row slice, query) of a history sweep (tie_warm_kernel)
     gorse::DevBuf<uint2> rp_cbuf, rp_hbuf;
     gorse::DevBuf<uint8_t> rp_flag;
     gorse::DevBuf<int32_t> rp_sidx, rp_scount;

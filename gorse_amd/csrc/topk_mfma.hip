@@ -60,16 +60,24 @@ constexpr int kNcbMain = GORSE_SWEEP_NCB;  // 32-query column blocks per wave fo
 // the history sweep serves the few queries with ties: small workgroups (2 waves = 64 * NCB queries) spread them over
 // many CUs instead of a handful of 8-wave workgroups; deep operands keep more waves (the tile prefetch registers of a
 // thread grow as the workgroup shrinks)
-constexpr int sweep_waves(bool hist, int kp) { return !hist ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
+// Round 6 (GORSE_HIST_DMA): at the power-of-two depths that have LDS-DMA tiles the history sweep takes the main sweep's form instead --
+// eight waves, 512 queries per workgroup, 64-row DMA tiles: the two-wave workgroups staged their tiles through registers and ran
+// the matrix pipe at 0.22 PFLOP/s (C4: 11.7 ms for 10,136 queries against 9.5 ms; profiles/r06_zzk_probe_topk_c4_hist_dma_warm.txt).
+// The other depths keep the two-wave form.
+#ifndef GORSE_HIST_DMA
+#define GORSE_HIST_DMA 1
+#endif
+constexpr bool sweep_hist_dma(int kp) { return GORSE_HIST_DMA && (kp == 2 || kp == 4 || kp == 8); }
+constexpr int sweep_waves(bool hist, int kp) { return !hist || sweep_hist_dma(kp) ? kWavesMain : (kp <= 8 ? 2 : (kp <= 12 ? 4 : 8)); }
 constexpr int kWaves = kWavesMain;
 [[maybe_unused]] constexpr int kThreads = kWaves * 64;
 // Tiles reach LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave-instruction, no VGPR round trip, no ds_write pass) when
 // the operand depth is a power of two and the sweep is a main sweep: the LDS image of a tile is then lane-linear (unpadded
 // rows), and the 16-byte pieces of a row are XOR-swizzled by the row number on the SOURCE address and again on the read, so
-// that the 16 lanes of a ds_read_b128 group fall on 16 different slots of the 256-byte bank row.  Other depths and the
-// history sweep (small workgroups) stage through registers into rows padded by 16 bytes.
+// that the 16 lanes of a ds_read_b128 group fall on 16 different slots of the 256-byte bank row.  Other depths (and their
+// history sweeps' small workgroups) stage through registers into rows padded by 16 bytes.
 constexpr bool sweep_dma(int kp, bool hist, int rb, int wv) {
-    return !hist && (kp & (kp - 1)) == 0 && (32 * rb * kp * 2) % (64 * wv) == 0 && (32 * rb) % 64 == 0;
+    return (!hist || sweep_hist_dma(kp)) && (kp & (kp - 1)) == 0 && (32 * rb * kp * 2) % (64 * wv) == 0 && (32 * rb) % 64 == 0;
 }
 // LDS of a sweep workgroup: NBUF tile buffers (+ their row scales and, without DMA, block bounds), five words per query, the
 // tile counters.  DMA: four buffers (tile t is multiplied while t + 1 has landed
@@ -143,6 +151,9 @@ struct SweepParams {
     int probe;         // timing probes of the MAIN sweep (results are garbage): 1 = every threshold +inf (no block ever qualifies: the
                        // sweep's floor), 2 = a qualifying block does nothing, 3 = it tests and counts its candidates without storing them
     int nslices;       // HIST: row slices (grid.y); the per-query outputs are then nslices x nq long, slice-major
+    const float *fwarm;  // HIST: nslices x nq starting thresholds of the slices (tie_warm_kernel: each a valid lower bound of the K-th
+                         // best score among the rows IN FRONT of the slice, so nothing the reference's heap can have accepted is
+                         // missed; -inf = cold), or null: every slice starts cold.  Trusted: a compaction never flags them.
     float rs_min, rs_max;  // smallest and largest row value of the index (EP_COARSE bound of the DMA sweeps)
     // SYM sweeps (the queries are the stored rows sym_q0 .. sym_q0 + nq): see topk_sweep_kernel
     int64_t sym_q0;        // row of query 0, a multiple of the tile height
@@ -170,7 +181,7 @@ struct SweepParams {
 // both lists by topk_rescore_kernel, which learns from the final threshold (f_out) whether the sweep ever raised it.
 template <bool HIST, bool SYM = false>
 __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s_cnt, float *s_f, const float *s_mg,
-                                              uint8_t *flag, uint2 *hb = nullptr, int *s_hc = nullptr) {
+                                              uint8_t *flag, uint2 *hb = nullptr, int *s_hc = nullptr, bool trust = false) {
     const int lane = threadIdx.x & 63;
     // the list is two interleaved sub-lists: even slots belong to the lane holding rows 0-3, 8-11, ... of the query's
     // column (lane < 32), odd slots to its partner (lane >= 32); each appends at its own counter (slot 2 * c + half)
@@ -231,6 +242,9 @@ __device__ __forceinline__ void compact_query(uint2 *qb, int ql, int kth, int *s
         // allows it) instead of following every append
         if (lane == 0) s_hc[ql] = n + 64;
     }
+    // trust (a history slice started from tie_warm_kernel's bound): the starting threshold is a proven lower bound of the K-th best
+    // score of the rows in front of the slice -- the slice's own rows need not prove it again, and it never falls
+    if (trust && newf < s_f[ql]) newf = s_f[ql];
     if (newf < s_f[ql]) {
         // Only a warm-started threshold can be above what the list proves (thresholds derived from the list never fall):
         // the K-th best of everything above it is not known to clear it by the margin, so rows may have been dropped
@@ -353,7 +367,8 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
         s_cnt[2 * t] = 0;
         s_cnt[2 * t + 1] = 0;
         s_hc[t] = 0;
-        s_f[t] = q < p.nq && p.probe != 1 ? (p.f0 ? p.f0[q] : -__builtin_inff()) : __builtin_inff();
+        s_f[t] = q < p.nq && p.probe != 1 ? (p.f0 ? p.f0[q] : (HIST && p.fwarm ? p.fwarm[(int64_t)blockIdx.y * p.nq + q] : -__builtin_inff()))
+                                            : __builtin_inff();
         s_mg[t] = q < p.nq ? p.qmargin[q] : 0.0f;
     }
     if (tid < 2 * NBUF) s_sync[tid] = 0;
@@ -1050,7 +1065,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
                                 continue;
                             compact_query<HIST, SYM>(p.cbuf + (qslice + wgq0 + qlc) * kCap, qlc, p.kth, s_cnt, s_f, s_mg,
                                                 p.cflag + qslice + wgq0 + qlc,
-                                                HIST ? p.hbuf + (qslice + wgq0 + qlc) * kHistCap : nullptr, s_hc);
+                                                HIST ? p.hbuf + (qslice + wgq0 + qlc) * kHistCap : nullptr, s_hc, HIST && p.fwarm != nullptr);
                         } while (need);
                         cnt[cb] = s_cnt[2 * ql + (lane >> 5)];
                         fth[cb] = s_f[ql];
@@ -1107,7 +1122,7 @@ __global__ __launch_bounds__(64 * sweep_waves(HIST, KP), (sweep_waves(HIST, KP) 
             continue;
         }
         compact_query<HIST, SYM>(p.cbuf + qg * kCap, ql, p.kth, s_cnt, s_f, s_mg, p.cflag + qg,
-                            HIST ? p.hbuf + qg * kHistCap : nullptr, s_hc);
+                            HIST ? p.hbuf + qg * kHistCap : nullptr, s_hc, HIST && p.fwarm != nullptr);
         if (lane == 0) {
             p.ccnt[qg] = s_cnt[2 * ql] + s_cnt[2 * ql + 1];  // packed by the final compaction: slots 0 .. count-1
             if (HIST) p.hcnt[qg] = s_hc[ql];
@@ -2318,6 +2333,91 @@ int32_t dispatch_sweep(gorse_topk *h, const SweepParams &p, bool hist, bool sym 
     return fail(GORSE_ERR_INVALID, "unsupported operand depth %d", h->kp);
 }
 
+// The history sweep's row slices need not start cold (round 6).  A slice that starts at row r_s may drop every row whose approximate
+// score stays below (K-th best approximate score among ANY set of rows in front of r_s) - 2 delta: at least K earlier rows are then
+// strictly closer in exact arithmetic, and the reference's heap pushed such a row to its root and popped it at once (ReplayParams).
+// The main sweep's lists of a flagged query -- its own list and, after a symmetric sweep, its foreign list: ~270 distinct rows with
+// their approximate scores, whatever became of the query's thresholds -- are such a set: one wave per flagged query takes the list
+// entries in front of every slice and, where there are at least kth of them, leaves a lower bound of their kth-th best score minus
+// the query's margin as the slice's starting threshold (the bound as compact_query forms it: the 16 leading key bits).  Slice 0 and
+// the slices with fewer than kth list entries in front of them start cold (-inf).  At C4: ~270 entries per query, so from the fourth
+// slice of eight on a slice records the few dozen rows that reach its bound instead of the ~710 a cold start accepts.
+struct WarmParams {
+    const int32_t *pos;  // row of the flagged query in the chunk's arrays
+    int64_t m2, N;
+    int nsl, tile_rows, kth;
+    const uint2 *cbuf;  // the main sweep's own lists (own_slices of them per query, own_stride queries apart) ...
+    const int32_t *ccnt;
+    int own_slices;
+    int64_t own_stride;
+    const uint2 *fbuf;  // ... and foreign lists (or null)
+    const int32_t *fcnt;
+    const float *margin;  // m2: the flagged queries' 2 delta (gather_pos_kernel)
+    float *fwarm;         // nsl x m2, slice-major
+};
+__global__ __launch_bounds__(64) void tie_warm_kernel(WarmParams p) {
+    const int64_t t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t q = p.pos[t];
+    constexpr int EPL = kCapT / 64;  // at most kCapT entries are looked at: any subset of the lists is a valid set
+    int n_at[kMaxOwnSlices + 2];
+    n_at[0] = 0;
+#pragma unroll
+    for (int sl = 0; sl < kMaxOwnSlices; sl++) {
+        int c = sl < p.own_slices ? p.ccnt[(int64_t)sl * p.own_stride + q] : 0;
+        c = c < 0 ? 0 : (c > kCap ? kCap : c);
+        n_at[sl + 1] = n_at[sl] + c;
+    }
+    int nf = p.fbuf ? p.fcnt[q] : 0;
+    nf = nf < 0 ? 0 : (nf > kCapF ? kCapF : nf);
+    const int n_own = n_at[kMaxOwnSlices];
+    const int n_all = n_own + nf < kCapT ? n_own + nf : kCapT;
+    uint32_t key[EPL];
+    int64_t row[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; j++) {
+        const int c = j * 64 + lane;
+        uint2 ent = make_uint2(0u, 0u);
+        if (c < n_all) {
+            if (c >= n_own) {
+                ent = p.fbuf[q * kCapF + (c - n_own)];
+            } else {
+                int sl = 0;
+#pragma unroll
+                for (int u = 1; u < kMaxOwnSlices; u++) sl += c >= n_at[u] ? 1 : 0;
+                ent = p.cbuf[((int64_t)sl * p.own_stride + q) * kCap + (c - n_at[sl])];
+            }
+        }
+        key[j] = c < n_all ? ent.x : 0u;
+        row[j] = c < n_all ? (int64_t)ent.y : p.N;
+    }
+    const float mg = p.margin[t];
+    const int64_t nt_all = (p.N + p.tile_rows - 1) / p.tile_rows;
+    for (int s = 0; s < p.nsl; s++) {
+        const int64_t r_s = (nt_all * s / p.nsl) * p.tile_rows;  // topk_sweep_kernel: the slice's first tile T0 = NT_all * y / slices
+        uint32_t k_in[EPL];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            k_in[j] = row[j] < r_s ? key[j] : 0u;  // key 0: never counted (trial >= 2^16)
+            cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(k_in[j] != 0u));
+        }
+        float f = -__builtin_inff();
+        if (s > 0 && cnt >= p.kth) {
+            uint32_t prefix = 0;
+            for (int b = 31; b >= 16; --b) {
+                const uint32_t trial = prefix | (1u << b);
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) c += __builtin_popcountll(__builtin_amdgcn_ballot_w64(k_in[j] >= trial));
+                if (c >= p.kth) prefix = trial;
+            }
+            f = fkey_inv(prefix) - mg;
+        }
+        if (lane == 0) p.fwarm[(int64_t)s * p.m2 + t] = f;
+    }
+}
+
 // SYM: the pilot's thresholds as the main sweep's foreign side uses them.  A query the pilot could not give a threshold (-inf)
 // would make every column of every block a foreign candidate: it gets +inf instead -- nothing is collected for it, neither by
 // its own workgroup nor by the others -- and the flag that sends it to the tie path's sweep from -inf.  raw = the form the
@@ -2651,6 +2751,7 @@ int32_t chunk_prepare(gorse_topk *h, ChunkState &cs) {
     sp.fcnt = nullptr;
     sp.sym_stats = nullptr;
     sp.sym_rank = 0, sp.sym_world = 1, sp.sym_slices = 1;
+    sp.fwarm = nullptr;
     sp.sym_probe = (g_topk_variant >> 25) & 3;  // variant bits 25-26: timing probes of the symmetric sweep (the call returns garbage)
     // Warm start.  A streaming threshold that begins at -inf accepts ~kth * ln(N / kth) * (its lag) rows per query (1800
     // at C4) and every accepted row costs its 32 x 32 block the slow epilogue.  A pilot sweep over every 16th row tile
@@ -2850,6 +2951,9 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
             // single-GPU C4 pass (10,136 queries: 80 x 8 workgroups) keeps its eight: sixteen were measured there, 9.2 + 14.0 ms
             // against 11.4 + 11.4 (every slice starts cold, the join and the replay pay for it).
             {
+                // (counted in 128-query units whatever the history workgroup holds -- 512 queries in the eight-wave DMA form of round 6:
+                // with that form's true count the rule would take 32 slices at C4's 10,136 queries, measured 228.3 ms per pass against
+                // 220.2 with eight, 224.3 with sixteen: profiles/r06_zzl_probe_topk_c4_hist_slices.txt)
                 const int64_t wgs = ceil_div(m2, (int64_t)64 * kNcbMain);
                 while (nsl >= kMaxSlices && nsl < kMaxSlicesFew && wgs * nsl < 512 && h->N / (2 * (int64_t)nsl) >= 16384) nsl *= 2;
             }
@@ -2870,6 +2974,23 @@ int32_t chunk_finish(gorse_topk *h, ChunkState &cs) {
             GORSE_HIP_CHECK(hipMemsetAsync(h->rp_ccnt.p, 0, sm2 * 4, h->stream));
             SweepParams hp = sp;
             hp.f0 = nullptr;  // the history sweep records what a threshold that starts at -inf would have kept
+            hp.fwarm = nullptr;
+            // ... or, slice by slice, what a threshold that starts at a bound the main sweep's lists prove would have kept
+            // (tie_warm_kernel; variant bit 11: every slice cold, the form of rounds 2-5)
+            if (nsl > 1 && !(g_topk_variant & 2048)) {
+                GORSE_TRY(h->rp_fwarm.ensure(sm2));
+                WarmParams wp;
+                wp.pos = pos_dev, wp.m2 = m2, wp.N = h->N, wp.nsl = nsl, wp.tile_rows = 64 /* the history sweep's tiles: launch_sweep */,
+                wp.kth = kth;
+                wp.cbuf = h->cbuf.p, wp.ccnt = h->ccnt.p;
+                wp.own_slices = sym ? std::max(1, cs.sym_slices) : 1, wp.own_stride = cs.mb;
+                wp.fbuf = sym ? h->fbuf.p : nullptr, wp.fcnt = sym ? h->fcnt.p : nullptr;
+                wp.margin = h->rp_margin.p;
+                wp.fwarm = h->rp_fwarm.p;
+                tie_warm_kernel<<<dim3((unsigned)m2), dim3(64), 0, h->stream>>>(wp);
+                GORSE_HIP_CHECK(hipGetLastError());
+                hp.fwarm = h->rp_fwarm.p;
+            }
             hp.B = h->rp_op.p;
             hp.qmargin = h->rp_margin.p;
             hp.cbuf = h->rp_cbuf.p;

@@ -123,6 +123,24 @@ def main():
             run(t, k, 0, nq, label, reps=2)
         L.gorse_hip_test_set_topk_variant(0)
         return
+    if "warm" in sys.argv[1:]:  # round 6: the history sweep's slices started from the bounds the main sweep's lists prove (default) against cold (bit 11)
+        COLD = 1 << 11
+        for rep in range(2):
+            for v, label in ((0, "history slices warm (default)"), (COLD, "history slices cold (bit 11)")):
+                L.gorse_hip_test_set_topk_variant(v)
+                run(t, k, 0, nq, label, reps=2)
+        L.gorse_hip_test_set_topk_variant(0)
+        i_a, d_a = t.all_pairs(k, 0, nq)
+        st_a = t.last_stats()
+        L.gorse_hip_test_set_topk_variant(COLD)
+        i_b, d_b = t.all_pairs(k, 0, nq)
+        st_b = t.last_stats()
+        L.gorse_hip_test_set_topk_variant(0)
+        same = np.array_equal(i_a, i_b) and np.array_equal(d_a.view(np.uint32), d_b.view(np.uint32))
+        print("warm: tie queries %d, to the scan %d; cold: %d, %d" % (st_a[1], st_a[0], st_b[1], st_b[0]), flush=True)
+        print("all %d rows with warm-started history slices equal the cold form's: %s" % (nq, same), flush=True)
+        assert same
+        return
     if "hist" in sys.argv[1:]:  # the tie path's history sweep: workgroups of 64 queries (variant bit 27) against 128, 8 / 1 row slices
         for v, label in ((0, "default (128 queries per history workgroup, 8 slices)"), (1 << 27, "64 queries per history workgroup"),
                          (0, "default again"), (1 << 27, "64 queries again")):
