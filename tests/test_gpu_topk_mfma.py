@@ -193,6 +193,44 @@ def test_history_sweep_in_row_slices_and_the_replay_shortcut(oracle, variant, me
         assert c2[q] == ei.size and np.array_equal(i2[q, :c2[q]], ei) and np.array_equal(bits(d2[q, :c2[q]]), bits(ed))
 
 
+V_COLD_SLICES = 1 << 11
+
+
+@pytest.mark.parametrize("metric", [capi.METRIC_COSINE, capi.METRIC_NEG_DOT, capi.METRIC_EUCLIDEAN])
+def test_history_slices_started_from_the_main_sweeps_lists(oracle, metric):
+    """Round 6 (csrc/topk_mfma.hip: tie_warm_kernel, GORSE_HIST_DMA).  A bf16 index of d = 128 (eight k-steps: the history sweep takes the
+    main sweep's eight-wave LDS-DMA form) with planted duplicates, eight row slices forced on a small index: every slice but the first
+    starts from the bound the main sweep's list entries in front of it prove (default) -- against the slices that start cold (variant
+    bit 11), every row of the two forms compared, and a sample of tie rows and plain rows against the oracle."""
+    rng = np.random.default_rng(4100 + metric)
+    N, d, k, nq = 24000, 128, 30, 2048
+    Xf = rng.standard_normal((N, d)).astype(np.float32)
+    if metric == capi.METRIC_COSINE:
+        Xf /= np.sqrt((Xf * Xf).sum(1))[:, None]
+    # duplicates of rows that many queries hold in their top k: ties inside the top k + 1, at the boundary, and late in the index
+    for src, dst in ((3, 9000), (3, 23990), (40, 12000), (40, 12001), (700, 23000), (1500, 100), (1999, 15000), (5, 6), (2047, 23999)):
+        Xf[dst] = Xf[src]
+    Xf[1000:1016] = Xf[1000]  # sixteen equal rows: their own queries tie among themselves
+    X = to_bf16(Xf)
+    Xe = from_bf16(X)
+    out = {}
+    for v in (V_SLICES8, V_SLICES8 | V_COLD_SLICES):
+        capi.lib().gorse_hip_test_set_topk_variant(v | 512)  # (bit 9: the warm-started main sweep on an index this small)
+        t = capi.TopK(X, metric, dtype=capi.DTYPE_BF16)
+        idx, dist, cnt = t.search_index(np.arange(nq), k)
+        out[v] = (idx.copy(), dist.copy(), cnt.copy(), t.last_stats())
+        del t
+    capi.lib().gorse_hip_test_set_topk_variant(0)
+    (i_w, d_w, c_w, st_w), (i_c, d_c, c_c, st_c) = out[V_SLICES8], out[V_SLICES8 | V_COLD_SLICES]
+    print("metric %d: tie replays warm %d cold %d, to the scan %d / %d" % (metric, st_w[1], st_c[1], st_w[0], st_c[0]))
+    assert st_w[1] >= 16 and st_c[1] == st_w[1]  # the replay answered the tie queries in both forms
+    assert np.array_equal(c_w, c_c) and np.array_equal(i_w, i_c) and np.array_equal(bits(d_w), bits(d_c))
+    for q in (0, 3, 5, 6, 40, 100, 700, 1000, 1007, 1015, 1500, 1999, 2047, 1234, 77):
+        ei, ed = oracle.search_index(Xe, metric, q, k)
+        assert c_w[q] == ei.size and np.array_equal(i_w[q, :c_w[q]], ei), q
+        assert np.array_equal(bits(d_w[q, :c_w[q]]), bits(ed)), q
+
+
 @pytest.mark.parametrize("k", [130, 250])
 def test_tie_replay_with_large_k(oracle, k):
     """k + 1 > 128 heap slots per query: the lane-per-query replay then takes 32 queries per workgroup instead of 64 (its LDS
