@@ -1025,7 +1025,7 @@ def test_epochs_that_follow_each_other_begin_where_the_one_before_ended():
     n, ms, flying = mf.epoch_times(reset=True)
     print("%d enqueued epochs: device time %.3f ms, wall %.3f ms" % (n, ms, wall))
     assert n == n_ep and flying == 0
-    assert 0.85 * wall <= ms <= 1.02 * wall  # (the first epoch's begin is its own: the stream was idle)
+    assert 0.7 * wall <= ms <= 1.05 * wall  # (the first epoch's begin is its own: the stream was idle; 0.99 measured -- slack for a host hiccup)
     # throttled as a Fit loop does it (gorse_mf_epoch_throttle issues nothing: the chain holds through it)
     t0 = time.perf_counter()
     for ep in range(20, 20 + n_ep):
@@ -1035,7 +1035,7 @@ def test_epochs_that_follow_each_other_begin_where_the_one_before_ended():
     wall = (time.perf_counter() - t0) * 1e3
     n, ms, flying = mf.epoch_times(reset=True)
     print("%d epochs behind throttle(2): device time %.3f ms, wall %.3f ms" % (n, ms, wall))
-    assert n == n_ep and 0.85 * wall <= ms <= 1.02 * wall
+    assert n == n_ep and 0.7 * wall <= ms <= 1.05 * wall
     per_epoch = ms / n_ep
     # other calls between two epochs: their time is in neither epoch's span
     us = np.arange(4096, dtype=np.int32) % data.U
